@@ -1,0 +1,34 @@
+"""Loader for oracle/_ref/libezref.so (the reference's own interp sources, built by
+oracle/build_ref.sh).  TEST INFRASTRUCTURE ONLY.
+
+The library keeps a few FST file-I/O symbols undefined (grid-from-file code that the hot
+path never reaches), so it must be opened with lazy binding; ctypes forces RTLD_NOW, hence
+the explicit dlopen through libc.
+"""
+import ctypes, os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SO = os.path.join(_HERE, "..", "oracle", "_ref", "libezref.so")
+_lib = None
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+def ref():
+    global _lib
+    if _lib is None:
+        libc = ctypes.CDLL(None)
+        libc.dlopen.restype = ctypes.c_void_p
+        libc.dlopen.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        h = libc.dlopen(os.path.abspath(REF_SO).encode(), os.RTLD_LAZY | os.RTLD_LOCAL)
+        if not h:
+            raise OSError("cannot dlopen " + REF_SO)
+        _lib = ctypes.CDLL(REF_SO, handle=h)
+    return _lib
+
+def fptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+def iptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
