@@ -4,7 +4,8 @@
  * Restatement of the grid-descriptor codecs
  *   CIGAXG  (reference: src/base/igaxg.f90:5-143)   integer descriptors -> real
  *   CXGAIG  (reference: src/base/xgaig.f90:4-195)   real descriptors -> integer
- * for the grid types the hot path uses ('L', 'E', 'A', 'B', 'G').
+ * for the grid types the hot path uses ('L', 'E', 'A', 'B', 'G', and old-style 'N'/'S' as
+ * needed by the polar-wind helper grids of ez_calcnpolarwind.c:86-91).
  *
  * Why this file exists twice in the build: igaxg.f90 / xgaig.f90 `use app`, a module
  * of the un-vendored App submodule (empty in /root/reference), so those two files are
@@ -24,6 +25,17 @@ void orc_cigaxg(char grtyp, float *xg1, float *xg2, float *xg3, float *xg4,
                 int ig1, int ig2, int ig3, int ig4)
 {
     switch (grtyp) {
+    case 'N': case 'S':                           /* igaxg.f90:53-58 : "ancien style" only */
+        if (ig4 < 32768) {
+            *xg1 = (float)ig2 * 0.1f;
+            *xg2 = (float)ig1 * 0.1f;
+            *xg3 = (float)ig4 * 100.f;
+            *xg4 = (float)ig3 * 0.01f;
+        } else {
+            fprintf(stderr, "orc_cigaxg: new-style N/S descriptors not restated\n");
+            *xg1 = *xg2 = *xg3 = *xg4 = 0.f;
+        }
+        break;
     case 'A': case 'B': case 'G':                 /* igaxg.f90:87-91 */
         *xg1 = (float)ig1; *xg2 = (float)ig2; *xg3 = 0.f; *xg4 = 0.f;
         break;
@@ -60,6 +72,15 @@ void orc_cxgaig(char grtyp, int *ig1, int *ig2, int *ig3, int *ig4,
                 float xg1, float xg2, float xg3, float xg4)
 {
     switch (grtyp) {
+    case 'N': case 'S':                           /* xgaig.f90:57-66 : the in-range ("old style") branch */
+        *ig1 = nint_f(xg2 * 10.f);
+        *ig2 = nint_f(xg1 * 10.f);
+        *ig3 = nint_f(xg4 * 100.f);
+        *ig4 = nint_f(xg3 * 0.01f);
+        while (*ig3 < 0) *ig3 += 36000;
+        if (*ig1 < 0 || *ig2 < 0 || *ig1 > 2047 || *ig2 > 2047 || *ig4 > 32000)
+            fprintf(stderr, "orc_cxgaig: N/S descriptor outside the old-style range is not restated\n");
+        break;
     case 'A': case 'B': case 'G':                 /* xgaig.f90:98-104 : truncation */
         *ig1 = (int)xg1; *ig2 = (int)xg2; *ig3 = 0; *ig4 = 0;
         break;

@@ -1,0 +1,70 @@
+"""Shared grid/field case definitions for the parity tests (deterministic, libm-free inputs)."""
+import numpy as np
+
+
+def splitmix64(seed, n):
+    """splitmix64 stream -> uint64[n] (SURVEY.md section 8d generator)."""
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) + (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def hash_uniform(seed, n):
+    """float32 uniform in [0,1) from the top 24 bits."""
+    return ((splitmix64(seed, n) >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)).astype(np.float32)
+
+
+def tri(t):
+    """triangle wave in [0,1], period 1 (piecewise-polynomial, no libm)."""
+    t = t - np.floor(t)
+    return (1.0 - np.abs(2.0 * t - 1.0)).astype(np.float32)
+
+
+def synth_field(ni, nj, seed, base=250.0, amp=60.0, noise=1e-3):
+    """Smooth 'temperature-like' field + small hash noise, float32 [nj, ni] flattened (i fastest)."""
+    i = np.arange(ni, dtype=np.float32)[None, :] / np.float32(ni)
+    j = np.arange(nj, dtype=np.float32)[:, None] / np.float32(nj)
+    smooth = tri(i * 2 + 0.13) * tri(j + 0.31) + 0.25 * tri(i * 5 + j * 3)
+    z = np.float32(base) + np.float32(amp) * smooth.astype(np.float32)
+    z = z * (np.float32(1.0) + np.float32(noise) * (hash_uniform(seed, ni * nj).reshape(nj, ni) - np.float32(0.5)))
+    return np.ascontiguousarray(z.astype(np.float32).reshape(-1))
+
+
+def synth_wind(ni, nj, seed):
+    i = np.arange(ni, dtype=np.float32)[None, :] / np.float32(ni)
+    j = np.arange(nj, dtype=np.float32)[:, None] / np.float32(nj)
+    u = 30.0 * (tri(i * 3 + j) - 0.5) * 2 + 2.0 * (hash_uniform(seed, ni * nj).reshape(nj, ni) - 0.5)
+    v = 30.0 * (tri(i + j * 2 + 0.4) - 0.5) * 2 + 2.0 * (hash_uniform(seed + 7, ni * nj).reshape(nj, ni) - 0.5)
+    return (np.ascontiguousarray(u.astype(np.float32).reshape(-1)),
+            np.ascontiguousarray(v.astype(np.float32).reshape(-1)))
+
+
+def ze_axes(ni, nj):
+    """Z-on-E axes of a global GEM-like grid: column ni duplicates column 1."""
+    ax = (np.arange(ni, dtype=np.float64) * 360.0 / (ni - 1)).astype(np.float32)
+    ay = (-90.0 + (np.arange(nj, dtype=np.float64) + 0.5) * 180.0 / nj).astype(np.float32)
+    return ax, ay
+
+
+E_IG = (1210, 1600, 57600, 54401)   # cxgaig('E', 31, -90, -20, -20)
+
+# name -> dict(src=(ni,nj,grtyp,ig,grref,axes_fn), dst=(ni,nj,grtyp,ig))
+def scalar_cases():
+    cases = {}
+    cases["G_to_L"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(90, 46, "L", (400, 400, 0, 0)))
+    cases["G_to_L_odd"] = dict(src=(50, 26, "G", (0, 0, 0, 0), " ", None), dst=(72, 37, "L", (500, 500, 0, 0)))
+    # L global, ni*dlon = 360 -> extension 2 (cfg1 shape): lat0=-89.55 dlat=.9 ; 40x200 -> use 9 deg
+    cases["Lglobal_to_L"] = dict(src=(40, 20, "L", (900, 900, 450, 0), " ", None), dst=(80, 40, "L", (450, 450, 0, 0)))
+    # L with duplicated last column -> extension 1
+    cases["Lrepeat_to_L"] = dict(src=(41, 21, "L", (900, 900, 0, 0), " ", None), dst=(60, 31, "L", (600, 600, 0, 0)))
+    # L regional -> extension 0, points outside -> DEHORS / extrapolation
+    cases["Lregional_to_L"] = dict(src=(30, 20, "L", (200, 200, 11000, 20000), " ", None), dst=(40, 30, "L", (200, 200, 10400, 19000)))
+    cases["A_to_L"] = dict(src=(48, 24, "A", (0, 0, 0, 0), " ", None), dst=(60, 31, "L", (600, 600, 0, 0)))
+    cases["B_to_L"] = dict(src=(49, 25, "B", (0, 0, 0, 0), " ", None), dst=(60, 31, "L", (600, 600, 0, 0)))
+    cases["ZE_to_L"] = dict(src=(65, 32, "Z", E_IG, "E", ze_axes), dst=(80, 41, "L", (450, 450, 0, 0)))
+    cases["G_to_G"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(96, 48, "G", (0, 0, 0, 0)))
+    cases["L_to_G"] = dict(src=(40, 20, "L", (900, 900, 450, 0), " ", None), dst=(64, 32, "G", (0, 0, 0, 0)))
+    return cases

@@ -1,0 +1,76 @@
+"""Generates tests/golden/ez_golden.npz from the reference's own code (oracle/_ref/libezref.so,
+built by oracle/build_ref.sh from /root/reference).  Runs only in the build container.
+Fixtures are DATA: for every case of tests/ezcases.py the reference's outputs (zout per degree and
+polar_correction setting, target lat/lon, located x/y, Gaussian latitudes, wind outputs).
+Inputs are regenerated from tests/ezcases.py (deterministic, libm-free).
+
+    python tests/golden/make_golden.py
+"""
+import ctypes, os, sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, ".."))
+from reflib import ref, fptr          # noqa: E402
+import ezcases as ec                  # noqa: E402
+
+DEG = {0: b"nearest", 1: b"linear", 3: b"cubic"}
+
+
+def define(L, spec):
+    ni, nj, grtyp, ig, grref, axes = spec
+    if grtyp == "Z":
+        ax, ay = axes(ni, nj)
+        return L.c_ezgdef_fmem(ni, nj, grtyp.encode(), grref.encode(), ig[0], ig[1], ig[2], ig[3], fptr(ax), fptr(ay))
+    return L.c_ezqkdef(ni, nj, grtyp.encode(), ig[0], ig[1], ig[2], ig[3], 0)
+
+
+def case_inputs(name, case):
+    ni, nj = case["src"][:2]
+    zin = ec.synth_field(ni, nj, seed=11)
+    uu, vv = ec.synth_wind(ni, nj, seed=21)
+    if case["src"][2] in ("Z", "B") or name == "Lrepeat_to_L":
+        for a in (zin, uu, vv):
+            a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+    return zin, uu, vv
+
+
+def main():
+    L = ref()
+    out = {}
+    for nj in (8, 32, 200, 2200):
+        gd = L.c_ezqkdef(2 * nj, nj, b"G", 0, 0, 0, 0, 0)
+        ax = np.zeros(2 * nj, np.float32); ay = np.zeros(nj, np.float32)
+        L.c_gdgaxes(gd, fptr(ax), fptr(ay))
+        out[f"gausslat_{nj}"] = ay
+    for name, case in sorted(ec.scalar_cases().items()):
+        gdin = define(L, case["src"]); gdout = define(L, case["dst"] + (" ", None))
+        L.c_ezdefset(gdout, gdin)
+        no, mo = case["dst"][:2]
+        zin, uu, vv = case_inputs(name, case)
+        for degree in (0, 1, 3):
+            for polar in (1, 0):
+                L.c_ezsetopt(b"interp_degree", DEG[degree])
+                L.c_ezsetopt(b"polar_correction", b"yes" if polar else b"no")
+                z = np.zeros(no * mo, np.float32)
+                rc = L.c_ezsint(fptr(z), fptr(zin))
+                out[f"{name}/z_d{degree}_p{polar}"] = z
+                out[f"{name}/rc_d{degree}_p{polar}"] = np.int32(rc)
+                if name != "G_to_G" and name != "L_to_G":
+                    u = np.zeros(no * mo, np.float32); v = np.zeros(no * mo, np.float32)
+                    rc = L.c_ezuvint(fptr(u), fptr(v), fptr(uu), fptr(vv))
+                    out[f"{name}/u_d{degree}_p{polar}"] = u
+                    out[f"{name}/v_d{degree}_p{polar}"] = v
+        lat = np.zeros(no * mo, np.float32); lon = np.zeros(no * mo, np.float32)
+        L.c_gdll(gdout, fptr(lat), fptr(lon))
+        x = np.zeros(no * mo, np.float32); y = np.zeros(no * mo, np.float32)
+        lon2 = lon.copy()
+        L.c_gdxyfll(gdin, fptr(x), fptr(y), fptr(lat), fptr(lon2), no * mo)
+        out[f"{name}/lat"] = lat; out[f"{name}/lon"] = lon; out[f"{name}/x"] = x; out[f"{name}/y"] = y
+    L.c_ezsetopt(b"interp_degree", b"cubic"); L.c_ezsetopt(b"polar_correction", b"yes")
+    np.savez_compressed(os.path.join(HERE, "ez_golden.npz"), **out)
+    print("wrote", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+"""CPU oracle vs the committed golden vectors (tests/golden/ez_golden.npz, produced from the
+reference's own code by tests/golden/make_golden.py).  Bit-exact.  Needs no reference build."""
+import ctypes, os
+import numpy as np
+import pytest
+
+import oraclelib as ol
+import ezcases as ec
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "ez_golden.npz"))
+CASES = ec.scalar_cases()
+
+
+def orc_define(spec):
+    ni, nj, grtyp, ig, grref, axes = spec
+    if grtyp == "Z":
+        ax, ay = axes(ni, nj)
+        return ol.grid_define(ni, nj, grtyp, ig, grref, ax, ay)
+    return ol.grid_define(ni, nj, grtyp, ig)
+
+
+def case_inputs(name, case):
+    ni, nj = case["src"][:2]
+    zin = ec.synth_field(ni, nj, seed=11)
+    uu, vv = ec.synth_wind(ni, nj, seed=21)
+    if case["src"][2] in ("Z", "B") or name == "Lrepeat_to_L":
+        for a in (zin, uu, vv):
+            a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+    return zin, uu, vv
+
+
+@pytest.mark.parametrize("nj", [8, 32, 200, 2200])
+def test_gauss_lat_golden(nj):
+    mine = np.zeros(nj, np.float32)
+    ol.oracle().orc_gauss_lat(ol.fptr(mine), nj)
+    assert np.array_equal(mine.view(np.uint32), GOLD[f"gausslat_{nj}"].view(np.uint32))
+    if nj == 2200:   # SURVEY.md section 8c item 1 probe anchors
+        assert abs(mine[0] - (-89.9374390)) < 1e-6 and abs(mine[1] - (-89.8559875)) < 1e-6
+        assert abs(mine[1099] - (-0.0409012)) < 1e-6 and abs(mine[2199] - 89.9374390) < 1e-6
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_scalar_golden(name):
+    O = ol.oracle()
+    case = CASES[name]
+    no, mo = case["dst"][:2]
+    zin, uu, vv = case_inputs(name, case)
+    gi = orc_define(case["src"]); go = orc_define(case["dst"] + (" ", None))
+    gs = O.orc_defset(go, gi)
+    for degree in (0, 1, 3):
+        for polar in (1, 0):
+            opts = ol.default_opts(degre_interp=degree, polar_correction=polar)
+            z = np.zeros(no * mo, np.float32)
+            rc = O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(z), ol.fptr(zin))
+            assert rc == int(GOLD[f"{name}/rc_d{degree}_p{polar}"])
+            assert np.array_equal(z.view(np.uint32), GOLD[f"{name}/z_d{degree}_p{polar}"].view(np.uint32)), (name, degree, polar)
+    assert np.array_equal(ol.np_from(go.contents.lat, no * mo), GOLD[f"{name}/lat"])
+    assert np.array_equal(ol.np_from(go.contents.lon, no * mo), GOLD[f"{name}/lon"])
+    x = np.zeros(no * mo, np.float32); y = np.zeros(no * mo, np.float32)
+    lon2 = GOLD[f"{name}/lon"].copy()
+    O.orc_gdxyfll(gi, ol.fptr(x), ol.fptr(y), ol.fptr(GOLD[f"{name}/lat"].copy()), ol.fptr(lon2), no * mo)
+    assert np.array_equal(x.view(np.uint32), GOLD[f"{name}/x"].view(np.uint32))
+    assert np.array_equal(y.view(np.uint32), GOLD[f"{name}/y"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", [n for n in sorted(CASES) if n not in ("G_to_G", "L_to_G")])
+def test_vector_golden(name):
+    O = ol.oracle()
+    case = CASES[name]
+    no, mo = case["dst"][:2]
+    zin, uu, vv = case_inputs(name, case)
+    gi = orc_define(case["src"]); go = orc_define(case["dst"] + (" ", None))
+    gs = O.orc_defset(go, gi)
+    for degree in (0, 1, 3):
+        for polar in (1, 0):
+            opts = ol.default_opts(degre_interp=degree, polar_correction=polar)
+            u = np.zeros(no * mo, np.float32); v = np.zeros(no * mo, np.float32)
+            O.orc_ezuvint(gs, ctypes.byref(opts), ol.fptr(u), ol.fptr(v), ol.fptr(uu), ol.fptr(vv))
+            assert np.array_equal(u.view(np.uint32), GOLD[f"{name}/u_d{degree}_p{polar}"].view(np.uint32)), (name, degree, polar)
+            assert np.array_equal(v.view(np.uint32), GOLD[f"{name}/v_d{degree}_p{polar}"].view(np.uint32)), (name, degree, polar)
