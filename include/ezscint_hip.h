@@ -1,0 +1,84 @@
+/*
+ * ezscint_hip.h -- C ABI of the MI355X-native EZ interpolator (librmn_ez_hip.so).
+ *
+ * Drop-in for the EZSCINT entry points of librmn on the c_ezdefset / c_ezsint / c_ezuvint /
+ * c_gdxysint path: same names, argument meaning, ownership and return codes as the reference
+ * header src/PUBLIC_INCLUDES/rmn/ezscint.h (line numbers cited per function).  Every c_foo has
+ * its Fortran twin foo_ (scalars by reference, hidden trailing string lengths), as in the
+ * reference (rpnmacros.h:21 f77name).
+ *
+ * Additive entry points (not in the reference, never change the above): *_dev variants taking
+ * DEVICE pointers, batched / fused pipeline calls, and stream selection.  See INTEGRATION.md.
+ */
+#ifndef EZSCINT_HIP_H
+#define EZSCINT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- grid definition / set selection (host only) --------------------------------------- */
+int32_t c_ezqkdef(int32_t ni, int32_t nj, char *grtyp, int32_t ig1, int32_t ig2, int32_t ig3, int32_t ig4, int32_t iunit);          /* ezscint.h:66 ; src/interp/ezqkdef.c:25 */
+int32_t c_ezgdef_fmem(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t ig1, int32_t ig2, int32_t ig3, int32_t ig4,
+                      float *ax, float *ay);                                                                                         /* ezscint.h:28 ; ezgdef_fmem.c:37 (ax/ay are copied) */
+int32_t c_ezdefset(int32_t gdout, int32_t gdin);                                                                                     /* ezscint.h:11 ; ezdefset.c:38 ; returns 1 */
+int32_t c_gdrls(int32_t gdin);                                                                                                       /* ezscint.h:75 ; gdrls.c:34 */
+int32_t c_ezgetgdin(void);                                                                                                           /* ezscint.h:186 */
+int32_t c_ezgetgdout(void);                                                                                                          /* ezscint.h:187 */
+int32_t c_ezgprm(int32_t gdid, char *grtyp, int32_t *ni, int32_t *nj, int32_t *ig1, int32_t *ig2, int32_t *ig3, int32_t *ig4);       /* ezscint.h:51 */
+int32_t c_ezgxprm(int32_t gdid, int32_t *ni, int32_t *nj, char *grtyp, int32_t *ig1, int32_t *ig2, int32_t *ig3, int32_t *ig4,
+                  char *grref, int32_t *ig1ref, int32_t *ig2ref, int32_t *ig3ref, int32_t *ig4ref);                                  /* ezscint.h:57 */
+int32_t c_gdgaxes(int32_t gdid, float *ax, float *ay);                                                                               /* ezscint.h:96 */
+int32_t c_gdll(int32_t gdid, float *lat, float *lon);                                                                                /* ezscint.h:62 */
+int32_t c_gdxyfll(int32_t gdid, float *x, float *y, float *lat, float *lon, int32_t n);                                              /* ezscint.h:138 ; gdxyfll.c:141 */
+
+/* ---- options (thread-local, string keyed; src/interp/ezsetopt.c:59-215) ------------------ */
+int32_t c_ezsetopt(char *option, char *value);                                                                                       /* ezscint.h:78 ; 0 ok / -1 */
+int32_t c_ezgetopt(char *option, char *value);                                                                                       /* ezscint.h:35 */
+int32_t c_ezsetval(char *option, float fvalue);                                                                                      /* ezscint.h:81 */
+int32_t c_ezsetival(char *option, int32_t ivalue);                                                                                   /* ezscint.h:84 */
+int32_t c_ezgetval(char *option, float *fvalue);                                                                                     /* ezscint.h:38 */
+int32_t c_ezgetival(char *option, int32_t *ivalue);                                                                                  /* ezscint.h:41 */
+
+/* ---- interpolation, HOST pointers (reference semantics) ---------------------------------- */
+int32_t c_ezsint(float *zout, float *zin);                                                                                           /* ezscint.h:87 ; ezsint.c:38 ; 0 ok, 1 same grid, 2 extrapolated, -1 error */
+int32_t c_ezuvint(float *uuout, float *vvout, float *uuin, float *vvin);                                                             /* ezscint.h:90 ; ezuvint.c:32 */
+int32_t c_gdxysint(float *zout, float *zin, int32_t gdin, float *x, float *y, int32_t npts);                                         /* src/interp/gdxysint.h:4 ; gdxysint.c:30 */
+int32_t c_gdxysval(int32_t gdin, float *zout, float *zin, float *x, float *y, int32_t n);                                            /* ezscint.h:120 ; gdxysval.c:50 */
+
+/* ---- Fortran twins (f77name(x) = x_) ------------------------------------------------------ */
+int32_t ezqkdef_(int32_t *ni, int32_t *nj, char *grtyp, int32_t *ig1, int32_t *ig2, int32_t *ig3, int32_t *ig4, int32_t *iunit, int32_t lengrtyp);
+int32_t ezgdef_fmem_(int32_t *ni, int32_t *nj, char *grtyp, char *grref, int32_t *ig1, int32_t *ig2, int32_t *ig3, int32_t *ig4,
+                     float *ax, float *ay, int32_t lengrtyp, int32_t lengrref);
+int32_t ezdefset_(int32_t *gdout, int32_t *gdin);
+int32_t ezsetopt_(char *option, char *value, int32_t lenoption, int32_t lenvalue);
+int32_t ezsint_(float *zout, float *zin);
+int32_t ezuvint_(float *uuout, float *vvout, float *uuin, float *vvin);
+int32_t gdxysint_(float *zout, float *zin, int32_t *gdin, float *x, float *y, int32_t *npts);
+int32_t gdxysval_(int32_t *gdin, float *zout, float *zin, float *x, float *y, int32_t *n);
+int32_t gdxyfll_(int32_t *gdid, float *x, float *y, float *lat, float *lon, int32_t *n);
+int32_t gdll_(int32_t *gdid, float *lat, float *lon);
+int32_t gdrls_(int32_t *gdin);
+
+/* ---- additive: device-resident entry points ----------------------------------------------- */
+/* All pointers are DEVICE pointers on the current HIP device; work is enqueued on the stream set by
+ * ezhip_use_stream (default: the null stream) and NOT synchronised. */
+void    ezhip_use_stream(void *hip_stream);
+int32_t c_ezsint_dev(float *d_zout, const float *d_zin);
+int32_t c_ezuvint_dev(float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin);
+int32_t c_gdxysint_dev(float *d_zout, const float *d_zin, int32_t gdin, const float *d_x, const float *d_y, int32_t npts);
+int32_t c_gdxyfll_dev(int32_t gdid, float *d_x, float *d_y, const float *d_lat, const float *d_lon, int32_t n);
+/* nfields independent fields on the current grid set; field f at d_zin + f*ni_in*nj_in, d_zout + f*ni_out*nj_out */
+int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields);
+/* forces plan construction for the current set / options (what the reference does lazily in its first call) */
+int32_t ezhip_prepare_set(void);
+/* which kernel family the current set uses: 1 = separable (k_sep), 2 = per-point (k_pts) */
+int32_t ezhip_set_mode(void);
+/* 1 when a HIP device is usable */
+int32_t ezhip_available(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1568 @@
+/*
+ * ez_host.c -- C host front-end of the MI355X-native EZ interpolator (librmn_ez_hip.so).
+ *
+ * Mirrors the reference's EZSCINT front-end (src/interp/ez*.c, gd*.c): a global grid table, per
+ * (gdout, gdin) grid sets, thread-local "current set" and options, string-keyed option setters,
+ * and the c_ezsint / c_ezuvint / c_gdxysint entry points with the reference's names, argument
+ * meaning and return codes (include/ezscint_hip.h cites the reference line of each).
+ *
+ * What is different by design: the O(npts) loops run on the GPU through the HIP shim
+ * (ezhip_shim.h).  The host only does O(ni + nj) setup: grid descriptors, Gaussian latitudes,
+ * Newton coefficient tables, and -- for rectilinear source/target pairs -- the per-column /
+ * per-row tap tables of the separable kernel.  There is NO CPU fallback for the interpolation
+ * itself: without a usable HIP device the interpolation entry points fail loudly (-1).
+ *
+ * Scope: grid types L, A, B, G (global), E, Z on L / E.  Other types are rejected (-1).
+ */
+#include <ctype.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ezhip_shim.h"
+#include "../../include/ezscint_hip.h"
+
+/* ------------------------------------------------------------------------------------------ */
+/* types                                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+enum { DEG_NEAREST = 0, DEG_LINEAR = 1, DEG_CUBIC = 3 };
+enum { XT_MAXIMUM = 4, XT_MINIMUM = 5, XT_VALUE = 6, XT_ABORT = 13 };
+
+typedef struct {            /* src/interp/ez_def.h:225-243, defaults src/interp/ez_statics.c:17 */
+    int degre_interp, degre_extrap, use_1subgrid, valeur_1subgrid, verbose, polar_correction;
+    int wgt_num, msg_pt_tol, cld_interp_alg;
+    float msg_gridpt_dist, msg_dist_thresh, valeur_extrap;
+} ezh_opts;
+
+typedef struct {            /* one compiled separable plan: device tables + the descriptor */
+    int built;
+    ezhip_sep_plan p;
+    void *dev[12];          /* owned device allocations */
+} ezh_sepplan;
+
+typedef struct ezh_set {
+    int gdin, gdout;
+    struct ezh_set *next;
+    int extrap;             /* ez_defzones: 1 = EZ_EXTRAP (DEHORS zone), 0 = EZ_NO_EXTRAP (polar zones) */
+    int have_dehors;        /* EZ_EXTRAP and at least one target point lies outside */
+    int sep_capable;        /* geometry allows the separable kernel */
+    float *x1d, *y1d;       /* host: located x per target column, y per target row (separable) */
+    float ypole_n, ypole_s;
+    ezh_sepplan sep[3][2];  /* [degree index][vector_mode] */
+    float *d_x, *d_y;       /* per-point located coordinates (generic mode) */
+    float *d_scratch;       /* float[8]: fill value + keys, pole values */
+    float *d_prow;          /* 2 * ni_src synthetic polar wind rows (vector mode), u then v: [u_n, u_s, v_n, v_s] */
+    float *d_stage_in, *d_stage_out, *d_stage_in2, *d_stage_out2;   /* host-pointer ABI staging */
+} ezh_set;
+
+typedef struct {
+    int used, refcount;
+    char grtyp, grref;
+    int ni, nj, ig[4], igref[4];
+    float xg[4], xgref[4];
+    int i1, i2, j1, j2, extension;
+    float *ax, *ay, *ncx, *ncy;            /* host */
+    float *d_ax, *d_ay, *d_ncx, *d_ncy;    /* device mirrors */
+    /* this grid as a TARGET: its lat/lon.  Separable grids keep 1-D arrays. */
+    int coords_ready, separable;
+    float *lat1d, *lon1d, *lat2d, *lon2d;
+    float *d_lat, *d_lon; int d_coords_valid;
+    ezh_set *sets;                          /* sets having this grid as gdout */
+} ezh_grid;
+
+static ezh_grid *G = NULL;
+static int nG = 0, capG = 0;
+static pthread_mutex_t g_mtx = PTHREAD_MUTEX_INITIALIZER;
+
+static __thread int cur_gdin = -1, cur_gdout = -1;
+static __thread ezh_opts O = {DEG_CUBIC, XT_MAXIMUM, 0, -1, 0, 1, 16, 0, 4, 0.5f, 3.0f, 0.0f};
+
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* descriptor codecs: CIGAXG / CXGAIG (src/base/igaxg.f90:51-135, src/base/xgaig.f90:57-192)     */
+/* ------------------------------------------------------------------------------------------ */
+static void h_cigaxg(char t, float *x1, float *x2, float *x3, float *x4, int i1, int i2, int i3, int i4)
+{
+    *x1 = *x2 = *x3 = *x4 = 0.f;
+    if (t == 'A' || t == 'B' || t == 'G') { *x1 = (float)i1; *x2 = (float)i2; }
+    else if (t == 'L') {
+        *x1 = (float)i3 * 0.01f - 90.f; *x2 = (float)i4 * 0.01f;
+        *x3 = (float)i1 * 0.01f;        *x4 = (float)i2 * 0.01f;
+    } else if (t == 'E') {
+        int b = i3 & 3, l3 = i3 >> 2, l1 = (i1 << 2) | b;
+        b = i4 & 3;
+        int l4 = i4 >> 2, l2 = (i2 << 2) | b;
+        if (l2 > 3600) l2 -= 7201;
+        *x1 = (float)(((double)l1 - 3600.0) / 40.0);
+        if (l3 < 3559) l3 += 16384;
+        *x2 = (float)(((double)l3 - 3600.0) / 40.0);
+        *x3 = (float)((double)l2 / 40.0);
+        *x4 = (float)((double)l4 / 40.0);
+    } else if ((t == 'N' || t == 'S') && i4 < 32768) {
+        *x1 = (float)i2 * 0.1f; *x2 = (float)i1 * 0.1f; *x3 = (float)i4 * 100.f; *x4 = (float)i3 * 0.01f;
+    }
+}
+
+static int nintf_(float v) { return (int)lroundf(v); }
+
+static void h_cxgaig(char t, int *i1, int *i2, int *i3, int *i4, float x1, float x2, float x3, float x4)
+{
+    *i1 = *i2 = *i3 = *i4 = 0;
+    if (t == 'A' || t == 'B' || t == 'G') { *i1 = (int)x1; *i2 = (int)x2; }
+    else if (t == 'L') {
+        *i1 = nintf_(x3 * 100.f); *i2 = nintf_(x4 * 100.f);
+        *i3 = nintf_((90.f + x1) * 100.f); *i4 = nintf_(x2 * 100.f);
+        while (*i4 < 0) *i4 += 36000;
+    } else if (t == 'N' || t == 'S') {
+        *i1 = nintf_(x2 * 10.f); *i2 = nintf_(x1 * 10.f); *i3 = nintf_(x4 * 100.f); *i4 = nintf_(x3 * 0.01f);
+        while (*i3 < 0) *i3 += 36000;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Gaussian latitudes: ez_glat.inc:26-67 -> DGAUSS (dgauss.F:90-131) -> ORDLEG (ordleg.F:50-86)   */
+/* all REAL arithmetic with the float libm, as the reference                                    */
+/* ------------------------------------------------------------------------------------------ */
+static float legendre_norm(float coa, int ir)
+{
+    float theta = acosf(coa), c1 = sqrtf(2.f), fn = 0.f, fn2 = 0.f;
+    for (int n = 1; n <= ir; n++) {
+        fn = (float)n; fn2 = 2.f * fn;
+        float q = fn2 * fn2;
+        c1 = c1 * sqrtf(1.0f - 1.0f / q);
+    }
+    float ang = fn * theta, s1 = 0.0f, c4 = 1.0f, a = -1.0f, b = 0.0f;
+    for (int kk = 1; kk <= ir + 1; kk += 2) {
+        int k = kk - 1;
+        if (k == ir) c4 = 0.5f * c4;
+        s1 = s1 + c4 * cosf(ang);
+        a = a + 2.0f; b = b + 1.0f;
+        ang = theta * (fn - (float)k - 2.0f);
+        c4 = (a * (fn - b + 1.0f) / (b * (fn2 - a))) * c4;
+    }
+    return s1 * c1;
+}
+
+static void h_gauss_lat(float *lat, int nj)
+{
+    const float pie = 3.1415926535898f, rdtodg = 57.295779513082f, tol = 1.0e-6f;
+    float *rt = (float *)calloc((size_t)nj + 2, sizeof(float));
+    float normn = sqrtf(2.0f / (2.0f * (float)nj + 1.0f)), normnm = sqrtf(2.0f / (2.0f * (float)nj - 1.0f));
+    int half = nj / 2;
+    for (int i = 1; i <= half; i++) {
+        float t = (float)(4 * i - 1) * pie / (float)(4 * nj + 2);
+        rt[i] = cosf(t + 1.0f / (8.0f * (float)(nj * nj) * tanf(t)));
+    }
+    for (int i = 1; i <= half; i++) {
+        float delta;
+        do {
+            float pn = normn * legendre_norm(rt[i], nj);
+            float pnm = normnm * legendre_norm(rt[i], nj - 1);
+            float rdpdx = (rt[i] * rt[i] - 1.0f) / ((float)nj * (rt[i] * pn - pnm));
+            delta = -pn * rdpdx;
+            rt[i] = rt[i] + delta;
+        } while (fabsf(delta) > tol);
+        rt[nj + 1 - i] = -rt[i];
+    }
+    if (nj % 2) rt[half + 1] = 0.0f;
+    /* ez_glat: reverse to south->north, then degrees */
+    for (int j = 1; j <= nj; j++) lat[j - 1] = 90.f - rdtodg * acosf(rt[nj + 1 - j]);
+    free(rt);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Newton coefficient tables: ez_nwtncof.inc:20-178                                             */
+/* ------------------------------------------------------------------------------------------ */
+static void recip6(float *c, int ld, float a, float b, float cc, float d)
+{
+    c[0] = 1.f / (b - a); c[ld] = 1.f / (cc - a); c[2 * ld] = 1.f / (cc - b);
+    c[3 * ld] = 1.f / (d - a); c[4 * ld] = 1.f / (d - b); c[5 * ld] = 1.f / (d - cc);
+}
+
+static int h_nwtncof(ezh_grid *g)
+{
+    int ni = g->ni, nj = g->nj, ext = g->extension;
+    const float *ax = g->ax, *ay = g->ay;
+    for (int i = 0; i + 1 < ni; i++) if (ax[i + 1] <= ax[i]) { fprintf(stderr, "ez_nwtncof: x axis must be strictly increasing\n"); exit(13); }
+    for (int j = 0; j + 1 < nj; j++) if (ay[j + 1] <= ay[j]) { fprintf(stderr, "ez_nwtncof: y axis must be strictly increasing\n"); exit(13); }
+    g->ncx = (float *)malloc(sizeof(float) * 6 * ni);
+    g->ncy = (float *)malloc(sizeof(float) * 6 * nj);
+    for (int k = 0; k < 6 * ni; k++) g->ncx[k] = 1.0f;
+    for (int k = 0; k < 6 * nj; k++) g->ncy[k] = 1.0f;
+    for (int i = 1; i + 2 < ni; i++) recip6(&g->ncx[i], ni, ax[i - 1], ax[i], ax[i + 1], ax[i + 2]);
+    for (int j = 1; j + 2 < nj; j++) recip6(&g->ncy[j], nj, ay[j - 1], ay[j], ay[j + 1], ay[j + 2]);
+    if (ext == 1) {
+        recip6(&g->ncx[0], ni, ax[0] - (ax[ni - 1] - ax[ni - 2]), ax[0], ax[1], ax[2]);
+        recip6(&g->ncx[ni - 2], ni, ax[ni - 3], ax[ni - 2], ax[ni - 1], ax[ni - 1] + (ax[1] - ax[0]));
+    } else if (ext == 2) {
+        recip6(&g->ncx[0], ni, ax[0] - (360.0f - ax[ni - 1]), ax[0], ax[1], ax[2]);
+        recip6(&g->ncx[ni - 2], ni, ax[ni - 3], ax[ni - 2], ax[ni - 1], ax[0] + 360.0f);
+        recip6(&g->ncx[ni - 1], ni, ax[ni - 2], ax[ni - 1], ax[0] + 360.0f, ax[1] + 360.0f);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ez_xpncof.c:48-226 : i1,i2,j1,j2 and the longitude "extension"                               */
+/* ------------------------------------------------------------------------------------------ */
+static void h_xpncof(ezh_grid *g)
+{
+    int ni = g->ni, nj = g->nj;
+    g->i1 = 1; g->i2 = ni; g->j1 = 1; g->j2 = nj; g->extension = 0;
+    if (g->grtyp == 'A' || g->grtyp == 'G') g->extension = 2;
+    else if (g->grtyp == 'B') g->extension = 1;
+    else if (g->grtyp == 'L') {
+        float lat0, lon0, dlat, dlon;
+        h_cigaxg('L', &lat0, &lon0, &dlat, &dlon, g->ig[0], g->ig[1], g->ig[2], g->ig[3]);
+        if ((double)(lat0 - dlat) > (-90.0 + 0.01 * (double)dlat)) return;
+        float lastlat = lat0 + (float)(nj - 1) * dlat;
+        if ((double)(lastlat + dlat) < (90.0 - 0.01 * (double)dlat)) return;
+        if (lon0 < 0.0) lon0 += 360.0;
+        float lastlon = lon0 + (dlon * (float)(ni - 1));
+        if ((double)(lastlon - lon0) > (360 - 0.01 * (double)dlon)) { g->extension = 1; return; }
+        float extra = lastlon + dlon;
+        if ((double)(extra - lon0) > (360.0 - (double)dlon * 0.01)) g->extension = 2;
+    } else if (g->grtyp == 'Z' && g->grref == 'E') {
+        g->extension = ((g->ax[ni - 1] - g->ax[0]) < 359.0) ? 0 : 1;
+    } else if (g->grtyp == 'Z' && g->grref == 'L') {
+        const float *ax = g->ax, *ay = g->ay;
+        float dlat = ay[1] - ay[0];
+        if ((double)(ay[0] - dlat) > (-90.0 + 0.01 * (double)dlat)) return;
+        dlat = ay[nj - 1] - ay[nj - 2];
+        if ((double)(ay[nj - 1] + dlat) < (90.0 - 0.01 * (double)dlat)) return;
+        float dlon = ax[ni - 1] - ax[ni - 2];
+        if ((double)(ax[ni - 1] - ax[0]) > (360.0 - 0.01 * (double)dlon)) g->extension = 1;
+        else if ((double)((ax[ni - 1] + dlon) - ax[0]) > (360.0 - 0.01 * (double)dlon)) g->extension = 2;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* rotated-frame helpers: ez_crot.inc, ez_lac.inc, ez_cal.inc, mxm.F90, ez_gfxyfll.c, ez_gfllfxy.c */
+/* ------------------------------------------------------------------------------------------ */
+static void h_lac(float *xyz, const float *lon, const float *lat, int n)
+{
+    float dar = acosf(-1.0f) / 180.0f;
+    for (int i = 0; i < n; i++) {
+        float cd = cosf(dar * lat[i]);
+        xyz[3 * i] = cd * cosf(dar * lon[i]); xyz[3 * i + 1] = cd * sinf(dar * lon[i]); xyz[3 * i + 2] = sinf(dar * lat[i]);
+    }
+}
+static void h_cal(float *lon, float *lat, const float *xyz, int n)
+{
+    float rad = 180.f / acosf(-1.00f);
+    for (int i = 0; i < n; i++) {
+        lat[i] = asinf(fmaxf(-1.00f, fminf(1.0f, xyz[3 * i + 2]))) * rad;
+        lon[i] = atan2f(xyz[3 * i + 1], xyz[3 * i]) * rad;
+        lon[i] = fmodf(lon[i], 360.0f);
+        if (lon[i] < 0.0f) lon[i] = lon[i] + 360.0f;
+    }
+}
+static void h_crot(float *r, float *ri, float lon1, float lat1, float lon2, float lat2)
+{
+    float p[3], q[3];
+    h_lac(p, &lon1, &lat1, 1); h_lac(q, &lon2, &lat2, 1);
+    float a = (p[0] * q[0]) + (p[1] * q[1]) + (p[2] * q[2]);
+    float t1 = (p[1] * q[2]) - (q[1] * p[2]), t2 = (q[0] * p[2]) - (p[0] * q[2]), t3 = (p[0] * q[1]) - (q[0] * p[1]);
+    float b = sqrtf(t1 * t1 + t2 * t2 + t3 * t3);
+    float c = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    float e1 = ((a * p[0]) - q[0]) / b, e2 = ((a * p[1]) - q[1]) / b, e3 = ((a * p[2]) - q[2]) / b;
+    float d = sqrtf(e1 * e1 + e2 * e2 + e3 * e3);
+    /* Fortran r(i,j) -> r[(j-1)*3 + i-1] */
+    r[0] = -p[0] / c; r[3] = -p[1] / c; r[6] = -p[2] / c;
+    r[1] = e1 / d;    r[4] = e2 / d;    r[7] = e3 / d;
+    r[2] = t1 / b;    r[5] = t2 / b;    r[8] = t3 / b;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) ri[j * 3 + i] = r[i * 3 + j];
+}
+static void h_mxm3(const float *a, const float *b, float *c, int n)
+{
+    for (int j = 0; j < n; j++) for (int i = 0; i < 3; i++) {
+        float s = 0.0f;
+        for (int k = 0; k < 3; k++) s = s + a[k * 3 + i] * b[3 * j + k];
+        c[3 * j + i] = s;
+    }
+}
+/* true -> rotated (forward = 1, ez_gfxyfll) or rotated -> true (forward = 0, ez_gfllfxy) */
+static void h_rotate(float *lon_o, float *lat_o, const float *lon, const float *lat, int n, const float *xg4, int forward)
+{
+    float r[9], ri[9];
+    float *cart = (float *)malloc(sizeof(float) * 3 * (size_t)n), *rot = (float *)malloc(sizeof(float) * 3 * (size_t)n);
+    h_crot(r, ri, xg4[1], xg4[0], xg4[3], xg4[2]);
+    h_lac(cart, lon, lat, n);
+    h_mxm3(forward ? r : ri, cart, rot, n);
+    h_cal(lon_o, lat_o, rot, n);
+    free(cart); free(rot);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* host locate (exact restatement; used for the 1-D tables and for c_gdxyfll)                    */
+/* ez_ll2rgd.inc:22-166, ez_ll2igd.inc:22-86, ez_llll2gd.inc:22-53, ez_cherche.inc:53-69          */
+/* ------------------------------------------------------------------------------------------ */
+static int h_cherche(float v, const float *tab, int n)
+{
+    int lo = 1, hi = n, mid = (int)((float)(lo + hi) * 0.5f);
+    while (mid != lo) {
+        if (v <= tab[mid - 1]) hi = mid; else lo = mid;
+        mid = (int)((float)(lo + hi) * 0.5f);
+    }
+    return mid;
+}
+static void h_llll2gd(float *x, float *y, const float *lat, float *lon, int n, float lat0, float lon0, float dlat, float dlon, float lonref)
+{
+    if (lonref == -180.0f) { for (int i = 0; i < n; i++) if (lon[i] > 180.0f) lon[i] = lon[i] - 360.0f; }
+    else { for (int i = 0; i < n; i++) if (lon[i] < 0.0f) lon[i] = lon[i] + 360.0f; }
+    for (int i = 0; i < n; i++) { x[i] = (lon[i] - lon0) / dlon + 1.0f; y[i] = (lat[i] - lat0) / dlat + 1.0f; }
+}
+/* lon[] is modified in place exactly where the reference modifies it */
+static int h_locate(const ezh_grid *g, float *x, float *y, const float *lat, float *lon, int n)
+{
+    int ni = g->ni, nj = g->nj;
+    float lat0, lon0, dlat, dlon;
+    switch (g->grtyp) {
+    case 'A':
+        dlon = 360.0f / (float)ni; lon0 = 0.0f; dlat = 180.0f / (float)nj; lat0 = -90.0f + dlat * 0.5f;
+        for (int i = 0; i < n; i++) if (lon[i] < 0.0f) lon[i] = lon[i] + 360.0f;
+        h_llll2gd(x, y, lat, lon, n, lat0, lon0, dlat, dlon, 0.0f);
+        return 0;
+    case 'B':
+        dlon = 360.0f / (float)(ni - 1); lon0 = 0.0f; dlat = 180.0f / (float)(nj - 1); lat0 = -90.0f;
+        for (int i = 0; i < n; i++) if (lon[i] < 0.0f) lon[i] = lon[i] + 360.0f;
+        h_llll2gd(x, y, lat, lon, n, lat0, lon0, dlat, dlon, 0.0f);
+        return 0;
+    case 'L':
+        h_cigaxg('L', &lat0, &lon0, &dlat, &dlon, g->ig[0], g->ig[1], g->ig[2], g->ig[3]);
+        for (int i = 0; i < n; i++) {
+            if (lon[i] < lon0) lon[i] = lon[i] + 360.0f;
+            if (lon[i] > (lon0 + (float)ni * dlon)) lon[i] = lon[i] - 360.0f;
+        }
+        h_llll2gd(x, y, lat, lon, n, lat0, lon0, dlat, dlon, 0.0f);
+        return 0;
+    case 'E': {
+        float *la = (float *)malloc(sizeof(float) * (size_t)n), *lo = (float *)malloc(sizeof(float) * (size_t)n);
+        h_rotate(lo, la, lon, lat, n, g->xg, 1);
+        dlon = 360.0f / (float)(ni - 1); lon0 = 0.0f; dlat = 180.0f / (float)nj; lat0 = -90.f + 0.5f * dlat;
+        h_llll2gd(x, y, la, lo, n, lat0, lon0, dlat, dlon, 0.0f);
+        free(la); free(lo);
+        return 0;
+    }
+    case 'G': case 'Z':
+        if (g->grref == 'L') {
+            h_cigaxg('L', &lat0, &lon0, &dlat, &dlon, g->igref[0], g->igref[1], g->igref[2], g->igref[3]);
+            h_llll2gd(x, y, lat, lon, n, lat0, lon0, dlat, dlon, (g->ax[0] < 0.0f) ? -180.0f : 0.0f);
+            for (int i = 0; i < n; i++) { x[i] = x[i] - 1.0f; y[i] = y[i] - 1.0f; }
+        } else {
+            h_rotate(x, y, lon, lat, n, g->xgref, 1);
+        }
+        for (int i = 0; i < n; i++) {
+            int ix = h_cherche(x[i], g->ax, ni), iy = h_cherche(y[i], g->ay, nj);
+            if (ix >= ni) ix = ni - 1;
+            if (iy >= nj) iy = nj - 1;
+            x[i] = (float)ix + (x[i] - g->ax[ix - 1]) / (g->ax[ix] - g->ax[ix - 1]);
+            y[i] = (float)iy + (y[i] - g->ay[iy - 1]) / (g->ay[iy] - g->ay[iy - 1]);
+        }
+        return 0;
+    }
+    return -1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* grid table                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+static int grid_ok(int gd) { return gd >= 0 && gd < nG && G[gd].used; }
+
+static int type_supported(char t, char ref, int ig1, int ig2)
+{
+    if (t == 'L' || t == 'E') return 1;
+    if (t == 'A' || t == 'B' || t == 'G') return ig1 == 0 && ig2 == 0;   /* hemispheric / inverted: out of scope */
+    if (t == 'Z') return ref == 'L' || ref == 'E';
+    return 0;
+}
+
+static int find_grid(int ni, int nj, char t, char ref, const int *ig, const float *ax, const float *ay)
+{
+    for (int k = 0; k < nG; k++) {
+        ezh_grid *g = &G[k];
+        if (!g->used || g->ni != ni || g->nj != nj || g->grtyp != t) continue;
+        if (memcmp(g->ig, ig, sizeof(int) * 4)) continue;
+        if (t == 'Z') {
+            if (g->grref != ref) continue;
+            if (memcmp(g->ax, ax, sizeof(float) * ni) || memcmp(g->ay, ay, sizeof(float) * nj)) continue;
+        }
+        return k;
+    }
+    return -1;
+}
+
+int32_t c_ezgdef_fmem(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t ig1, int32_t ig2, int32_t ig3, int32_t ig4, float *ax, float *ay)
+{
+    char t = grtyp[0], ref = grref ? grref[0] : ' ';
+    if (!type_supported(t, ref, ig1, ig2)) {
+        fprintf(stderr, "<c_ezgdef_fmem> grid type '%c' (ref '%c') is outside the MI355X hot-path scope\n", t, ref);
+        return -1;
+    }
+    int ig[4] = {ig1, ig2, ig3, ig4};
+    pthread_mutex_lock(&g_mtx);
+    int gd = find_grid(ni, nj, t, ref, ig, ax, ay);
+    if (gd >= 0) { G[gd].refcount++; pthread_mutex_unlock(&g_mtx); return gd; }
+    for (gd = 0; gd < nG; gd++) if (!G[gd].used) break;
+    if (gd == nG) {
+        if (nG == capG) { capG = capG ? 2 * capG : 64; G = (ezh_grid *)realloc(G, sizeof(ezh_grid) * capG); }
+        nG++;
+    }
+    ezh_grid *g = &G[gd];
+    memset(g, 0, sizeof(*g));
+    g->used = 1; g->refcount = 1; g->grtyp = t; g->grref = (t == 'Z') ? ref : 0;
+    g->ni = ni; g->nj = nj; memcpy(g->ig, ig, sizeof(ig));
+    switch (t) {                                            /* c_ezdefxg, ez_defxg.c:28-170 */
+    case 'A': case 'G':
+        g->xg[3] = (float)(360. / ni); g->xg[1] = 0.0f; g->xg[2] = (float)(180. / nj); g->xg[0] = (float)(-90. + 0.5 * (double)g->xg[2]);
+        break;
+    case 'B':
+        g->xg[3] = (float)(360. / (ni - 1)); g->xg[1] = 0.0f; g->xg[2] = (float)(180. / (nj - 1)); g->xg[0] = -90.f;
+        break;
+    case 'L': case 'E':
+        h_cigaxg(t, &g->xg[0], &g->xg[1], &g->xg[2], &g->xg[3], ig1, ig2, ig3, ig4);
+        break;
+    }
+    if (t == 'Z') {                                         /* c_ezdefaxes, ez_defaxes.c:43-54 */
+        memcpy(g->igref, ig, sizeof(ig));
+        h_cigaxg(ref, &g->xgref[0], &g->xgref[1], &g->xgref[2], &g->xgref[3], ig1, ig2, ig3, ig4);
+        g->ax = (float *)malloc(sizeof(float) * ni); memcpy(g->ax, ax, sizeof(float) * ni);
+        g->ay = (float *)malloc(sizeof(float) * nj); memcpy(g->ay, ay, sizeof(float) * nj);
+    } else if (t == 'G') {                                  /* ez_defaxes.c:65-91 */
+        g->grref = 'L';
+        g->xgref[0] = 0.0f; g->xgref[1] = 0.0f; g->xgref[2] = 1.0f; g->xgref[3] = 1.0f;
+        h_cxgaig('L', &g->igref[0], &g->igref[1], &g->igref[2], &g->igref[3], 0.0f, 0.0f, 1.0f, 1.0f);
+        g->ax = (float *)malloc(sizeof(float) * ni);
+        float dlon = (float)(360. / (float)ni);
+        for (int i = 0; i < ni; i++) g->ax[i] = (float)i * dlon;
+        g->ay = (float *)malloc(sizeof(float) * nj);
+        h_gauss_lat(g->ay, nj);
+    }
+    h_xpncof(g);
+    if (t == 'Z' || t == 'G') h_nwtncof(g);
+    pthread_mutex_unlock(&g_mtx);
+    if (O.verbose > 0) printf("Gdid = %02d  grtyp '%c' ni %d nj %d ig %d %d %d %d\n", gd, t, ni, nj, ig1, ig2, ig3, ig4);
+    return gd;
+}
+
+int32_t c_ezqkdef(int32_t ni, int32_t nj, char *grtyp, int32_t ig1, int32_t ig2, int32_t ig3, int32_t ig4, int32_t iunit)
+{
+    (void)iunit;
+    char t = grtyp[0];
+    if (t == '#' || t == 'Y' || t == 'Z' || t == 'U' || t == ' ') {
+        fprintf(stderr, "<c_ezqkdef> grid descriptors read from an FST file are outside the MI355X hot-path scope; use c_ezgdef_fmem\n");
+        return -1;
+    }
+    char ref[2] = " ";
+    return c_ezgdef_fmem(ni, nj, grtyp, ref, ig1, ig2, ig3, ig4, NULL, NULL);
+}
+
+static void free_sepplan(ezh_sepplan *sp)
+{
+    for (int k = 0; k < 12; k++) { ezhip_free(sp->dev[k]); sp->dev[k] = NULL; }
+    sp->built = 0;
+}
+static void free_set(ezh_set *s)
+{
+    for (int d = 0; d < 3; d++) for (int v = 0; v < 2; v++) free_sepplan(&s->sep[d][v]);
+    free(s->x1d); free(s->y1d);
+    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow);
+    ezhip_free(s->d_stage_in); ezhip_free(s->d_stage_out); ezhip_free(s->d_stage_in2); ezhip_free(s->d_stage_out2);
+    free(s);
+}
+
+int32_t c_gdrls(int32_t gd)          /* gdrls.c:34-77: refcount, free at zero */
+{
+    pthread_mutex_lock(&g_mtx);
+    if (!grid_ok(gd)) { pthread_mutex_unlock(&g_mtx); return -1; }
+    ezh_grid *g = &G[gd];
+    if (g->refcount > 0) g->refcount--;
+    if (g->refcount == 0) {
+        for (ezh_set *s = g->sets; s;) { ezh_set *n = s->next; free_set(s); s = n; }
+        for (int k = 0; k < nG; k++) {                     /* sets of other targets that use this grid as source */
+            if (!G[k].used || k == gd) continue;
+            ezh_set **pp = &G[k].sets;
+            while (*pp) { if ((*pp)->gdin == gd) { ezh_set *d = *pp; *pp = d->next; free_set(d); } else pp = &(*pp)->next; }
+        }
+        free(g->ax); free(g->ay); free(g->ncx); free(g->ncy);
+        free(g->lat1d); free(g->lon1d); free(g->lat2d); free(g->lon2d);
+        ezhip_free(g->d_ax); ezhip_free(g->d_ay); ezhip_free(g->d_ncx); ezhip_free(g->d_ncy);
+        ezhip_free(g->d_lat); ezhip_free(g->d_lon);
+        memset(g, 0, sizeof(*g));
+        if (cur_gdin == gd) cur_gdin = -1;
+        if (cur_gdout == gd) cur_gdout = -1;
+    }
+    pthread_mutex_unlock(&g_mtx);
+    return 0;
+}
+
+static ezh_set *find_set(int gdout, int gdin, int create)
+{
+    ezh_grid *go = &G[gdout];
+    for (ezh_set *s = go->sets; s; s = s->next) if (s->gdin == gdin) return s;
+    if (!create) return NULL;
+    ezh_set *s = (ezh_set *)calloc(1, sizeof(ezh_set));
+    s->gdin = gdin; s->gdout = gdout;
+    s->next = go->sets; go->sets = s;
+    return s;
+}
+
+int32_t c_ezdefset(int32_t gdout, int32_t gdin)     /* ezdefset.c:38-171 */
+{
+    if (!grid_ok(gdout) || !grid_ok(gdin)) { fprintf(stderr, "<c_ezdefset> invalid grid id\n"); return -1; }
+    pthread_mutex_lock(&g_mtx);
+    find_set(gdout, gdin, 1);
+    pthread_mutex_unlock(&g_mtx);
+    cur_gdin = gdin; cur_gdout = gdout;
+    return 1;
+}
+int32_t c_ezgetgdin(void) { return cur_gdin; }
+int32_t c_ezgetgdout(void) { return cur_gdout; }
+
+int32_t c_ezgprm(int32_t gd, char *grtyp, int32_t *ni, int32_t *nj, int32_t *ig1, int32_t *ig2, int32_t *ig3, int32_t *ig4)
+{
+    if (!grid_ok(gd)) return -1;
+    ezh_grid *g = &G[gd];
+    grtyp[0] = g->grtyp; *ni = g->ni; *nj = g->nj; *ig1 = g->ig[0]; *ig2 = g->ig[1]; *ig3 = g->ig[2]; *ig4 = g->ig[3];
+    return 0;
+}
+int32_t c_ezgxprm(int32_t gd, int32_t *ni, int32_t *nj, char *grtyp, int32_t *ig1, int32_t *ig2, int32_t *ig3, int32_t *ig4,
+                  char *grref, int32_t *ig1ref, int32_t *ig2ref, int32_t *ig3ref, int32_t *ig4ref)
+{
+    if (!grid_ok(gd)) return -1;
+    ezh_grid *g = &G[gd];
+    grtyp[0] = g->grtyp; grtyp[1] = 0; *ni = g->ni; *nj = g->nj;
+    *ig1 = g->ig[0]; *ig2 = g->ig[1]; *ig3 = g->ig[2]; *ig4 = g->ig[3];
+    if (g->grtyp == 'Z' || g->grtyp == 'G') {
+        grref[0] = g->grref; grref[1] = 0;
+        *ig1ref = g->igref[0]; *ig2ref = g->igref[1]; *ig3ref = g->igref[2]; *ig4ref = g->igref[3];
+    } else { grref[0] = ' '; grref[1] = 0; *ig1ref = *ig2ref = *ig3ref = *ig4ref = -1; }
+    return 0;
+}
+int32_t c_gdgaxes(int32_t gd, float *ax, float *ay)
+{
+    if (!grid_ok(gd) || !G[gd].ax) return -1;
+    memcpy(ax, G[gd].ax, sizeof(float) * G[gd].ni); memcpy(ay, G[gd].ay, sizeof(float) * G[gd].nj);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* options: ezsetopt.c:59-215, ezgetopt.c, ezsetval.c:86-166                                    */
+/* ------------------------------------------------------------------------------------------ */
+static void lower32(char *dst, const char *src)
+{
+    memset(dst, 0, 32);
+    strncpy(dst, src, 31);
+    for (char *p = dst; *p; p++) *p = (char)tolower((int)*p);
+}
+static int deg_of(const char *v)
+{
+    if (!strcmp(v, "nearest")) return 0;
+    if (!strcmp(v, "linear")) return 1;
+    if (!strcmp(v, "cubic")) return 3;
+    return -1;
+}
+int32_t c_ezsetopt(char *option, char *value)
+{
+    char o[32], v[32];
+    lower32(o, option); lower32(v, value);
+    static const char *oa[][2] = {{"correction_polaire", "polar_correction"}, {"degre_interp", "interp_degree"},
+                                  {"degre_extrap", "extrap_degree"}, {"use_1sousgrille", "use_1subgrid"}};
+    static const char *va[][2] = {{"oui", "yes"}, {"ouiouioui", "yesyesyes"}, {"non", "no"}, {"voisin", "nearest"}, {"lineair", "linear"},
+                                  {"lineaire", "linear"}, {"cubique", "cubic"}, {"neutre", "neutral"}, {"valeur", "value"}};
+    for (unsigned k = 0; k < sizeof(oa) / sizeof(oa[0]); k++) if (!strcmp(o, oa[k][0])) strcpy(o, oa[k][1]);
+    for (unsigned k = 0; k < sizeof(va) / sizeof(va[0]); k++) if (!strcmp(v, va[k][0])) strcpy(v, va[k][1]);
+    int ook = 0, vok = 0;
+    if (!strcmp(o, "use_1subgrid")) { ook = 1; vok = 1; if (!strcmp(v, "yes")) O.use_1subgrid = 1; else if (!strcmp(v, "no")) O.use_1subgrid = 0; else vok = 0; }
+    if (!strcmp(o, "verbose")) { ook = 1; vok = 1; if (!strcmp(v, "yes")) O.verbose = 1; else if (!strcmp(v, "yesyesyes")) O.verbose = 2; else if (!strcmp(v, "no")) O.verbose = 0; else vok = 0; }
+    if (!strcmp(o, "polar_correction")) { ook = 1; vok = 1; if (!strcmp(v, "yes")) O.polar_correction = 1; else if (!strcmp(v, "no")) O.polar_correction = 0; else vok = 0; }
+    if (!strcmp(o, "interp_degree")) {
+        ook = 1; vok = 1;
+        int d = deg_of(v);
+        if (d >= 0) O.degre_interp = d;
+        else if (!strcmp(v, "average")) O.degre_interp = 4;
+        else if (!strcmp(v, "sph_average")) O.degre_interp = 5;
+        else vok = 0;
+    }
+    if (!strcmp(o, "extrap_degree")) {
+        ook = 1; vok = 1;
+        int d = deg_of(v);
+        if (!strcmp(v, "neutral")) O.degre_extrap = O.degre_interp;
+        else if (d >= 0) O.degre_extrap = d;
+        else if (!strcmp(v, "maximum")) O.degre_extrap = XT_MAXIMUM;
+        else if (!strcmp(v, "minimum")) O.degre_extrap = XT_MINIMUM;
+        else if (!strcmp(v, "value")) O.degre_extrap = XT_VALUE;
+        else if (!strcmp(v, "abort")) O.degre_extrap = XT_ABORT;
+        else vok = 0;
+    }
+    if (!strcmp(o, "cloud_interp_alg")) {
+        if (!strcmp(v, "linear")) { ook = vok = 1; O.cld_interp_alg = 1; }
+        if (!strcmp(v, "distance")) { ook = vok = 1; O.cld_interp_alg = 4; }
+    }
+    if (ook + vok != 2) {
+        if (!ook) fprintf(stderr, "ezsetopt : option not recognized : %s\n", option);
+        if (!vok) fprintf(stderr, "ezsetopt : value not recognized : %s\n", value);
+        return -1;
+    }
+    return 0;
+}
+int32_t c_ezgetopt(char *option, char *value)
+{
+    char o[32];
+    lower32(o, option);
+    static const char *dn[] = {"nearest", "linear", "?", "cubic"};
+    if (!strcmp(o, "verbose")) strcpy(value, O.verbose == 1 ? "yes" : O.verbose == 2 ? "yesyesyes" : "no");
+    if (!strcmp(o, "use_1subgrid")) strcpy(value, O.use_1subgrid == 1 ? "yes" : "no");
+    if (!strcmp(o, "polar_correction")) strcpy(value, O.polar_correction == 1 ? "yes" : "no");
+    if (!strcmp(o, "interp_degree")) strcpy(value, (O.degre_interp == 0 || O.degre_interp == 1 || O.degre_interp == 3) ? dn[O.degre_interp] : "error");
+    if (!strcmp(o, "degre_interp")) strcpy(value, O.degre_interp == 0 ? "voisin" : O.degre_interp == 1 ? "lineaire" : O.degre_interp == 3 ? "cubique" : "erreur");
+    if (!strcmp(o, "extrap_degree")) {
+        switch (O.degre_extrap) {
+        case 0: case 1: case 3: strcpy(value, dn[O.degre_extrap]); break;
+        case XT_MAXIMUM: strcpy(value, "maximum"); break;
+        case XT_MINIMUM: strcpy(value, "minimum"); break;
+        case XT_VALUE: strcpy(value, "value"); break;
+        case XT_ABORT: strcpy(value, "abort"); break;
+        default: strcpy(value, "error");
+        }
+    }
+    if (!strcmp(o, "cloud_interp_alg")) strcpy(value, O.cld_interp_alg == 1 ? "linear" : "distance");
+    return 0;
+}
+int32_t c_ezsetval(char *option, float fvalue)
+{
+    char o[32];
+    lower32(o, option);
+    if (!strcmp(o, "extrap_value")) O.valeur_extrap = fvalue;
+    if (!strcmp(o, "missing_gridpt_distance")) O.msg_gridpt_dist = fvalue;
+    if (!strcmp(o, "missing_distance_threshold")) O.msg_dist_thresh = fvalue;
+    return 0;
+}
+int32_t c_ezsetival(char *option, int32_t ivalue)
+{
+    char o[32];
+    lower32(o, option);
+    if (!strcmp(o, "weight_number")) O.wgt_num = ivalue;
+    if (!strcmp(o, "missing_points_tolerance")) O.msg_pt_tol = ivalue;
+    if (!strcmp(o, "subgridid")) O.valeur_1subgrid = ivalue;
+    return 0;
+}
+int32_t c_ezgetval(char *option, float *fvalue)
+{
+    char o[32];
+    lower32(o, option);
+    if (!strcmp(o, "extrap_value")) *fvalue = O.valeur_extrap;
+    if (!strcmp(o, "missing_gridpt_distance")) *fvalue = O.msg_gridpt_dist;
+    if (!strcmp(o, "missing_distance_threshold")) *fvalue = O.msg_dist_thresh;
+    return 0;
+}
+int32_t c_ezgetival(char *option, int32_t *ivalue)
+{
+    char o[32];
+    lower32(o, option);
+    if (!strcmp(o, "weight_number")) *ivalue = O.wgt_num;
+    if (!strcmp(o, "missing_points_tolerance")) *ivalue = O.msg_pt_tol;
+    if (!strcmp(o, "subgridid")) *ivalue = O.valeur_1subgrid;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* target coordinates: ez_calclatlon.c:30-284 (GRLL grll.f:57-64, c_llfgr ez_llfgr.c:25-33)       */
+/* ------------------------------------------------------------------------------------------ */
+static void ensure_coords(ezh_grid *g)
+{
+    if (g->coords_ready) return;
+    int ni = g->ni, nj = g->nj;
+    g->separable = !(g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E'));
+    g->lat1d = (float *)malloc(sizeof(float) * nj);
+    g->lon1d = (float *)malloc(sizeof(float) * ni);
+    if (g->grtyp == 'L' || g->grtyp == 'A' || g->grtyp == 'B') {
+        for (int j = 0; j < nj; j++) g->lat1d[j] = g->xg[0] + (float)j * g->xg[2];
+        for (int i = 0; i < ni; i++) g->lon1d[i] = fmodf(g->xg[1] + (float)i * g->xg[3], 360.0f);
+    } else if (g->grtyp == 'E') {
+        float dlon = (float)(360. / (ni - 1)), dlat = (float)(180. / nj);
+        float lat00 = (float)(-90. + 0.5 * (double)dlat);
+        for (int j = 0; j < nj; j++) g->lat1d[j] = lat00 + (float)j * dlat;
+        for (int i = 0; i < ni; i++) g->lon1d[i] = fmodf(0.0f + (float)i * dlon, 360.0f);
+    } else {   /* G, Z */
+        for (int j = 0; j < nj; j++) g->lat1d[j] = g->ay[j];
+        for (int i = 0; i < ni; i++) g->lon1d[i] = g->ax[i];
+        if (g->grref == 'L') {
+            for (int j = 0; j < nj; j++) {
+                float y = (float)((double)g->lat1d[j] + 1.0);
+                g->lat1d[j] = (float)((double)g->xgref[0] + (double)g->xgref[2] * ((double)y - 1.0));
+            }
+            for (int i = 0; i < ni; i++) {
+                float x = (float)((double)g->lon1d[i] + 1.0);
+                float lo = (float)((double)g->xgref[1] + (double)g->xgref[3] * ((double)x - 1.0));
+                g->lon1d[i] = (float)fmod(fmod((double)lo, 360.0) + 360.0, 360.0);
+            }
+        }
+    }
+    if (!g->separable) {   /* rotated grids: full 2-D true lat/lon through ez_gfllfxy */
+        size_t n = (size_t)ni * nj;
+        float *rlat = (float *)malloc(sizeof(float) * n), *rlon = (float *)malloc(sizeof(float) * n);
+        for (int j = 0; j < nj; j++) for (int i = 0; i < ni; i++) { rlat[(size_t)j * ni + i] = g->lat1d[j]; rlon[(size_t)j * ni + i] = g->lon1d[i]; }
+        g->lat2d = (float *)malloc(sizeof(float) * n); g->lon2d = (float *)malloc(sizeof(float) * n);
+        h_rotate(g->lon2d, g->lat2d, rlon, rlat, (int)n, g->grtyp == 'E' ? g->xg : g->xgref, 0);
+        free(rlat); free(rlon);
+    }
+    g->coords_ready = 1;
+}
+
+int32_t c_gdll(int32_t gd, float *lat, float *lon)
+{
+    if (!grid_ok(gd)) return -1;
+    ezh_grid *g = &G[gd];
+    ensure_coords(g);
+    size_t n = (size_t)g->ni * g->nj;
+    if (g->separable) {
+        for (int j = 0; j < g->nj; j++) for (int i = 0; i < g->ni; i++) { lat[(size_t)j * g->ni + i] = g->lat1d[j]; lon[(size_t)j * g->ni + i] = g->lon1d[i]; }
+    } else { memcpy(lat, g->lat2d, sizeof(float) * n); memcpy(lon, g->lon2d, sizeof(float) * n); }
+    return 0;
+}
+
+/* c_gdxyfll / c_gdxyfll_orig, gdxyfll.c:90-139: regular sources work on a copy of lon, G/Z sources
+ * modify the caller's lon in place. */
+int32_t c_gdxyfll(int32_t gd, float *x, float *y, float *lat, float *lon, int32_t n)
+{
+    if (!grid_ok(gd)) return -1;
+    ezh_grid *g = &G[gd];
+    if (g->grtyp == 'G' || g->grtyp == 'Z') return h_locate(g, x, y, lat, lon, n);
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    memcpy(tmp, lon, sizeof(float) * (size_t)n);
+    int rc = h_locate(g, x, y, lat, tmp, n);
+    free(tmp);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* device mirrors                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+static void *upload(const void *h, size_t nbytes)
+{
+    void *d = ezhip_malloc(nbytes);
+    if (d && ezhip_h2d(d, h, nbytes)) { ezhip_free(d); return NULL; }
+    return d;
+}
+static int need_device(const char *who)
+{
+    if (ezhip_runtime_ok()) return 0;
+    fprintf(stderr, "<%s> no usable HIP device: the MI355X interpolation path has no CPU fallback\n", who);
+    return -1;
+}
+static int ensure_grid_dev(ezh_grid *g)
+{
+    if (g->ax && !g->d_ax) {
+        g->d_ax = (float *)upload(g->ax, sizeof(float) * g->ni);
+        g->d_ay = (float *)upload(g->ay, sizeof(float) * g->nj);
+        g->d_ncx = (float *)upload(g->ncx, sizeof(float) * 6 * g->ni);
+        g->d_ncy = (float *)upload(g->ncy, sizeof(float) * 6 * g->nj);
+        ezhip_sync();
+        if (!g->d_ax || !g->d_ay || !g->d_ncx || !g->d_ncy) return -1;
+    }
+    return 0;
+}
+static int ensure_coords_dev(ezh_grid *g)
+{
+    ensure_coords(g);
+    if (g->d_coords_valid) return 0;
+    ezhip_free(g->d_lat); ezhip_free(g->d_lon);
+    if (g->separable) {
+        g->d_lat = (float *)upload(g->lat1d, sizeof(float) * g->nj);
+        g->d_lon = (float *)upload(g->lon1d, sizeof(float) * g->ni);
+    } else {
+        size_t n = (size_t)g->ni * g->nj;
+        g->d_lat = (float *)upload(g->lat2d, sizeof(float) * n);
+        g->d_lon = (float *)upload(g->lon2d, sizeof(float) * n);
+    }
+    ezhip_sync();
+    g->d_coords_valid = (g->d_lat && g->d_lon);
+    return g->d_coords_valid ? 0 : -1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* set analysis: zones (ez_defzones.c:25-113) and kernel-family choice                           */
+/* ------------------------------------------------------------------------------------------ */
+static int src_is_separable(const ezh_grid *g)
+{   /* x depends on lon only and y on lat only: everything but the rotated frames */
+    return !(g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E'));
+}
+static int src_irregular(const ezh_grid *g) { return g->grtyp == 'G' || g->grtyp == 'Z'; }
+
+static int set_extrap(const ezh_grid *gi)
+{
+    if (gi->grtyp == 'L') return gi->extension == 0;
+    if (gi->grtyp == 'Z' && (gi->grref == 'E' || gi->grref == 'L'))
+        return 358.0 > (gi->ax[gi->ni - 1] - gi->ax[0]);
+    return 0;
+}
+
+static void pole_y(const ezh_grid *gi, float *yn, float *ys)
+{   /* ez_defzone_polenord.c:46-53, ez_defzone_polesud.c:46-54 */
+    if (gi->grtyp == 'Z' && gi->grref == 'E') { *yn = (float)(gi->nj + 0.5); *ys = 0.5f; return; }
+    float x, lat, lon;
+    lat = 90.0f; lon = 0.0f; c_gdxyfll((int)(gi - G), &x, yn, &lat, &lon, 1);
+    lat = -90.0f; lon = 0.0f; c_gdxyfll((int)(gi - G), &x, ys, &lat, &lon, 1);
+}
+
+static void analyse_set(ezh_set *s)
+{
+    ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
+    ensure_coords(go);
+    s->extrap = set_extrap(gi);
+    pole_y(gi, &s->ypole_n, &s->ypole_s);
+    s->sep_capable = go->separable && src_is_separable(gi);
+    if (s->sep_capable && !s->x1d) {
+        /* 1-D locate with the exact host code; the reference's in-place edits of the target's cached
+         * longitudes land in lon1d, exactly as they would in its 2-D cache */
+        int ni = go->ni, nj = go->nj, n = imax(ni, nj);
+        float *lat = (float *)malloc(sizeof(float) * n), *lon = (float *)malloc(sizeof(float) * n);
+        float *x = (float *)malloc(sizeof(float) * n), *y = (float *)malloc(sizeof(float) * n);
+        for (int k = 0; k < n; k++) { lat[k] = go->lat1d[k < nj ? k : nj - 1]; lon[k] = go->lon1d[k < ni ? k : ni - 1]; }
+        h_locate(gi, x, y, lat, lon, n);
+        s->x1d = (float *)malloc(sizeof(float) * ni); memcpy(s->x1d, x, sizeof(float) * ni);
+        s->y1d = (float *)malloc(sizeof(float) * nj); memcpy(s->y1d, y, sizeof(float) * nj);
+        if (memcmp(go->lon1d, lon, sizeof(float) * ni)) { memcpy(go->lon1d, lon, sizeof(float) * ni); go->d_coords_valid = 0; }
+        free(lat); free(lon); free(x); free(y);
+        s->have_dehors = 0;
+        if (s->extrap) {
+            for (int i = 0; i < ni && !s->have_dehors; i++) { int ix = (int)((double)s->x1d[i] + 0.5); if (ix < 1 || ix > gi->ni) s->have_dehors = 1; }
+            for (int j = 0; j < nj && !s->have_dehors; j++) { int iy = (int)((double)s->y1d[j] + 0.5); if (iy < 1 || iy > gi->nj) s->have_dehors = 1; }
+        }
+    }
+}
+
+/* 1 = separable kernel, 2 = per-point kernel */
+static int choose_mode(const ezh_set *s, int degree, int polar)
+{
+    const ezh_grid *gi = &G[s->gdin];
+    if (!s->sep_capable) return 2;
+    if (getenv("EZHIP_FORCE_PTS")) return 2;
+    /* ez_irgdint_3_nw rounds every intermediate to REAL (ez_irgdint_3_nw.inc:32): not a linear
+     * functional of the stencil, keep it on the point-exact kernel */
+    if (src_irregular(gi) && gi->extension == 0 && degree == DEG_CUBIC) return 2;
+    /* out-of-grid points re-interpolated with another degree (ez_corrval.c:98-110): point kernel */
+    if (polar && s->extrap && s->have_dehors && O.degre_extrap < XT_MAXIMUM) return 2;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* separable plan construction                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+static double fa_(double a1, double a2, double a3, double a4, double x, double x1, double x2, double x3)
+{ return a1 + (x - x1) * (a2 + (x - x2) * (a3 + a4 * (x - x3))); }
+static double fa2_(double c1, double a1, double a2) { return c1 * (a2 - a1); }
+static double fa3_(double c1, double c2, double c3, double a1, double a2, double a3) { return c2 * (c3 * (a3 - a2) - c1 * (a2 - a1)); }
+static double fa4_(double c1, double c2, double c3, double c4, double c5, double c6, double a1, double a2, double a3, double a4)
+{ return c4 * (c5 * (c6 * (a4 - a3) - c3 * (a3 - a2)) - c2 * (c3 * (a3 - a2) - c1 * (a2 - a1))); }
+
+/* weights of the Newton-form 1-D cubic (ez_irgdint_3_w.inc:86-89): the functional applied to unit vectors */
+static void newton_weights(double w[4], const double c[6], double x, double x1, double x2, double x3)
+{
+    for (int k = 0; k < 4; k++) {
+        double z[4] = {0, 0, 0, 0};
+        z[k] = 1.0;
+        double a2 = fa2_(c[0], z[0], z[1]);
+        double a3 = fa3_(c[0], c[1], c[2], z[0], z[1], z[2]);
+        double a4 = fa4_(c[0], c[1], c[2], c[3], c[4], c[5], z[0], z[1], z[2], z[3]);
+        w[k] = fa_(z[0], a2, a3, a4, x, x1, x2, x3);
+    }
+}
+/* weights of cubic8.cdk:1-3 (uniform spacing; REAL literals) */
+static double cubic8(double z1, double z2, double z3, double z4, double dx)
+{
+    const double c6 = (double)0.1666666666666f, c3 = (double)0.3333333333333f;
+    return ((((z4 - z1) * c6 + 0.5 * (z2 - z3)) * dx + 0.5 * (z1 + z3) - z2) * dx + z3 - c6 * z4 - 0.5 * z2 - c3 * z1) * dx + z2;
+}
+static void cubic_weights(double w[4], double dx)
+{
+    for (int k = 0; k < 4; k++) { double z[4] = {0, 0, 0, 0}; z[k] = 1.0; w[k] = cubic8(z[0], z[1], z[2], z[3], dx); }
+}
+
+/* seam columns of ez_irgdint_3_w.inc:100-156 / _wnnc: 1-based indices and float abscissae */
+static void irr_cols(const float *ax, int ni, int wrap, int i, int ip2_wrap1, int idx[4], float xs[4])
+{
+#define AX(k) ax[(k) - 1]
+    idx[0] = i - 1; idx[1] = i; idx[2] = i + 1; idx[3] = i + 2;
+    if (wrap == 1 && (i <= 1 || i >= (ni - wrap))) {
+        if (i == 1) { idx[0] = ni - 1; idx[2] = 2; idx[3] = 3; xs[0] = AX(ni - 1) - 360.0f; xs[1] = AX(1); xs[2] = AX(2); xs[3] = AX(3); }
+        if (i == (ni - 1)) { idx[0] = ni - 2; idx[2] = ni; idx[3] = ip2_wrap1; xs[0] = AX(ni - 2); xs[1] = AX(ni - 1); xs[2] = AX(ni); xs[3] = AX(2) + 360.0f; }
+    } else if (wrap == 2 && (i <= 1 || i > (ni - wrap))) {
+        if (i == 1) { idx[0] = ni; idx[2] = 2; idx[3] = 3; xs[0] = AX(ni) - 360.0f; xs[1] = AX(1); xs[2] = AX(2); xs[3] = AX(3); }
+        if (i == (ni - 1)) { idx[0] = ni - 2; idx[2] = ni; idx[3] = 1; xs[0] = AX(ni - 2); xs[1] = AX(ni - 1); xs[2] = AX(ni); xs[3] = AX(1) + 360.0f; }
+        if (i == ni) { idx[0] = ni - 1; idx[2] = 1; idx[3] = 2; xs[0] = AX(ni - 1); xs[1] = AX(ni); xs[2] = AX(1) + 360.0f; xs[3] = AX(2) + 360.0f; }
+    } else {
+        xs[0] = AX(idx[0]); xs[1] = AX(i); xs[2] = AX(idx[2]); xs[3] = AX(idx[3]);
+    }
+#undef AX
+}
+/* seam columns of ez_rgdint_3_w.inc:72-90 */
+static void reg_cols(int ni, int wrap, int *i, int idx[4])
+{
+    int limite = ni + 2 - wrap;
+    int im1 = (limite + *i - 1) % limite, ip1 = (limite + *i + 1) % limite, ip2 = (limite + *i + 2) % limite;
+    if (im1 == 0) im1 = ni;
+    if (*i == 0) *i = ni;
+    if (ip1 == 0) ip1 = ni;
+    if (ip2 == 0) ip2 = ni;
+    if (wrap == 1) { if (ip2 == ni) ip2 = 2; if (im1 == ni) im1 = ni - 1; }
+    idx[0] = im1; idx[1] = *i; idx[2] = ip1; idx[3] = ip2;
+}
+
+/* column taps (1-based idx -> stored 0-based) for the MAIN kernel of the dispatch table gdinterp.c:133-309 */
+static void col_taps_main(const ezh_grid *g, int degree, float px, int idx[4], double w[4])
+{
+    int ni = g->ni, wrap = g->extension, irr = src_irregular(g);
+    idx[0] = idx[1] = idx[2] = idx[3] = 1; w[0] = w[1] = w[2] = w[3] = 0.0;
+    if (degree == DEG_NEAREST) { idx[0] = imin(ni, imax(1, nintf_(px))); return; }           /* ez_rgdint_0.inc */
+    if (degree == DEG_LINEAR) {
+        if (!irr) {
+            if (wrap == 2) {                                                                  /* ez_rgdint_1_w.inc */
+                int limite = ni + 2 - wrap, i = imin(ni - 2 + wrap, imax(1, (int)px)), ip1 = i + 1;
+                if (i == (ni - 2 + wrap)) ip1 = (limite + i + 1) % limite;
+                idx[0] = i; idx[1] = ip1; w[0] = (double)(px - (float)i);
+            } else {                                                                          /* ez_rgdint_1_nw.inc */
+                int i = imin(ni - 1, imax(1, (int)px));
+                idx[0] = i; idx[1] = i + 1; w[0] = (double)(px - (float)i);
+            }
+        } else if (wrap == 0) {                                                               /* ez_irgdint_1_nw.inc */
+            int i = imin(ni - 1, imax(1, (int)px));
+            double x1 = g->ax[i - 1], x2 = g->ax[i];
+            double x = (double)g->ax[i - 1] + (x2 - x1) * (double)(px - (float)i);
+            idx[0] = i; idx[1] = i + 1; w[0] = (x - x1) / (x2 - x1);
+        } else {                                                                              /* ez_irgdint_1_w.inc */
+            int limite = ni + 2 - wrap, i = imin(ni - 2 + wrap, imax(1, (int)px)), ip1 = i + 1;
+            double x1 = g->ax[i - 1], x2 = 0.0;
+            if (ip1 <= ni) x2 = g->ax[ip1 - 1];
+            if (i == (ni - 2 + wrap)) { ip1 = (limite + i + 1) % limite; x2 = (double)(g->ax[1] + g->ax[ni - 1]); }
+            double x = x1 + (x2 - x1) * (double)(px - (float)i);
+            idx[0] = i; idx[1] = ip1; w[0] = (x - x1) / (x2 - x1);
+        }
+        return;
+    }
+    if (!irr) {
+        if (wrap == 0) {                                                                      /* ez_rgdint_3_nw.inc */
+            int i = imin(ni - 2, imax(2, (int)px));
+            idx[0] = i - 1; idx[1] = i; idx[2] = i + 1; idx[3] = i + 2;
+            cubic_weights(w, (double)(px - (float)i));
+        } else {                                                                              /* ez_rgdint_3_w.inc */
+            int i = imin(ni - 2 + wrap, imax(1, imax(2 - wrap, (int)px)));
+            reg_cols(ni, wrap, &i, idx);
+            cubic_weights(w, (double)(px - (float)i));
+        }
+        return;
+    }
+    /* ez_irgdint_3_w.inc (wrap > 0; wrap == 0 never reaches the separable kernel) */
+    int i = imin(ni - 2 + wrap, imax(1, imax(2 - wrap, (int)px)));
+    float xs[4];
+    irr_cols(g->ax, ni, wrap, i, 2, idx, xs);
+    double x = (double)(xs[1] + (xs[2] - xs[1]) * (px - (float)i));
+    double c[6];
+    for (int k = 0; k < 6; k++) c[k] = (double)g->ncx[k * ni + (i - 1)];
+    newton_weights(w, c, x, (double)xs[0], (double)xs[1], (double)xs[2]);
+}
+
+/* column taps for the polar STRIP kernels (ez_corrval_aunord.c:60-104) */
+static void col_taps_strip(const ezh_grid *g, int degree, float px, int idx[4], double w[4])
+{
+    int ni = g->ni, wrap = g->extension;
+    idx[0] = idx[1] = idx[2] = idx[3] = 1; w[0] = w[1] = w[2] = w[3] = 0.0;
+    if (degree == DEG_NEAREST) { idx[0] = imin(ni, imax(1, nintf_(px))); return; }
+    if (degree == DEG_LINEAR) {                                                               /* ez_rgdint_1_w on the strip */
+        int limite = ni + 2 - wrap, i = imin(ni - 2 + wrap, imax(1, (int)px)), ip1 = i + 1;
+        if (wrap > 0 && i == (ni - 2 + wrap)) ip1 = (limite + i + 1) % limite;
+        idx[0] = i; idx[1] = ip1; w[0] = (double)(px - (float)i);
+        return;
+    }
+    int i = imin(ni - 2 + wrap, imax(1, imax(2 - wrap, (int)px)));
+    if (g->grtyp == 'Z' || g->grtyp == 'E' || g->grtyp == 'G') {                             /* ez_irgdint_3_wnnc.inc */
+        float xs[4];
+        irr_cols(g->ax, ni, wrap, i, 1, idx, xs);
+        double x1 = xs[0], x2 = xs[1], x3 = xs[2], x4 = xs[3];
+        double x = x2 + (x3 - x2) * (double)(px - (float)i);
+        double c[6] = {1.0 / (x2 - x1), 1.0 / (x3 - x1), 1.0 / (x3 - x2), 1.0 / (x4 - x1), 1.0 / (x4 - x2), 1.0 / (x4 - x3)};
+        newton_weights(w, c, x, x1, x2, x3);
+    } else {                                                                                  /* ez_rgdint_3_wnnc.inc */
+        if ((wrap > 0 && i <= 1) || i >= (ni - 1)) reg_cols(ni, wrap, &i, idx);
+        else { idx[0] = i - 1; idx[1] = i; idx[2] = i + 1; idx[3] = i + 2; }
+        cubic_weights(w, (double)(px - (float)i));
+    }
+}
+
+/* row taps of the MAIN kernel: base row (1-based j of the first tap) and weights */
+static void row_taps_main(const ezh_grid *g, int degree, float py, int *jfirst, double w[4])
+{
+    int nj = g->nj, j1 = g->j1, j2 = g->j2, wrap = g->extension, irr = src_irregular(g);
+    w[0] = w[1] = w[2] = w[3] = 0.0;
+    if (degree == DEG_NEAREST) { *jfirst = imin(j2, imax(j1, nintf_(py))); return; }
+    if (degree == DEG_LINEAR) {
+        if (!irr) { int j = imin(j2 - 1, imax(j1, (int)py)); *jfirst = j; w[0] = (double)(py - (float)j); return; }
+        int j;
+        if (wrap == 0) j = imin(nj - 1, imax(1, (int)py));
+        else { j = imin(j2 - 1, imax(j1 + 1, (int)py)); if (j < 0) j = j - 1; }
+        float a = g->ay[j - 1], b = g->ay[j];
+        double y = (double)(a + (b - a) * (py - (float)j));
+        *jfirst = j; w[0] = (y - (double)a) / (double)(b - a);
+        return;
+    }
+    int j = imin(j2 - 2, imax(j1 + 1, (int)py));
+    *jfirst = j - 1;
+    if (!irr) { cubic_weights(w, (double)(py - (float)j)); return; }
+    const float *ay = g->ay;
+    double y = (double)(ay[j - 1] + (ay[j] - ay[j - 1]) * (py - (float)j));
+    double c[6];
+    for (int k = 0; k < 6; k++) c[k] = (double)g->ncy[k * nj + (j - 1)];
+    newton_weights(w, c, y, (double)ay[j - 2], (double)ay[j - 1], (double)ay[j]);
+}
+
+/* one polar-strip row: ez_corrval_aunord.c:41-111 (north = 1), ez_corrval_ausud.c:55-126 (north = 0) */
+static void strip_row(const ezh_grid *g, int degree, float py, int north, ezhip_special_row *sr)
+{
+    int j1 = g->j1, j2 = g->j2;
+    int j1s = north ? j2 - 2 : j1 - 1, j2s = j1s + 3;
+    int rows[4] = {0, 0, 0, 0}, ntap;
+    sr->kind = 0; sr->w[0] = sr->w[1] = sr->w[2] = sr->w[3] = 0.0;
+    if (degree == DEG_CUBIC) {
+        int j = imin(j2s - 2, imax(j1s + 1, (int)py));
+        ntap = 4;
+        for (int k = 0; k < 4; k++) rows[k] = j - 1 + k;
+        if (g->grtyp == 'Z' || g->grtyp == 'E' || g->grtyp == 'G') {
+            float ay4[4];
+            if (north) {
+                if (g->ay[j2 - 1] == 90.0) { ay4[0] = g->ay[j2 - 4]; ay4[1] = g->ay[j2 - 3]; ay4[2] = g->ay[j2 - 2]; ay4[3] = g->ay[j2 - 1]; }
+                else { ay4[0] = g->ay[j2 - 3]; ay4[1] = g->ay[j2 - 2]; ay4[2] = g->ay[j2 - 1]; ay4[3] = 90.0f; }
+            } else {
+                if (g->ay[j1 - 1] == -90.0) { ay4[0] = g->ay[0]; ay4[1] = g->ay[1]; ay4[2] = g->ay[2]; ay4[3] = g->ay[3]; }
+                else { ay4[0] = -90.0f; ay4[1] = g->ay[0]; ay4[2] = g->ay[1]; ay4[3] = g->ay[2]; }
+            }
+            const float *b = ay4 - j1s;
+            double y = (double)(b[j] + (b[j + 1] - b[j]) * (py - (float)j));
+            double y1 = b[j - 1], y2 = b[j], y3 = b[j + 1], y4 = b[j + 2];
+            double c[6] = {1.0 / (y2 - y1), 1.0 / (y3 - y1), 1.0 / (y3 - y2), 1.0 / (y4 - y1), 1.0 / (y4 - y2), 1.0 / (y4 - y3)};
+            newton_weights(sr->w, c, y, y1, y2, y3);
+        } else cubic_weights(sr->w, (double)(py - (float)j));
+    } else if (north) {
+        float ty = (float)((double)py - (1.0 * (j2 - 3)));
+        int off = j2 - 3;
+        if (degree == DEG_LINEAR) { int j = imin(3, imax(1, (int)ty)); ntap = 2; rows[0] = j + off; rows[1] = j + 1 + off; sr->w[0] = (double)(ty - (float)j); }
+        else { int j = imin(4, imax(1, nintf_(ty))); ntap = 1; rows[0] = j + off; }
+    } else {
+        if (degree == DEG_LINEAR) { int j = imin(j2s - 1, imax(j1s, (int)py)); ntap = 2; rows[0] = j; rows[1] = j + 1; sr->w[0] = (double)(py - (float)j); }
+        else { int j = imin(j2s, imax(j1s, nintf_(py))); ntap = 1; rows[0] = j; }
+    }
+    for (int k = 0; k < 4; k++) {
+        int r = k < ntap ? rows[k] : rows[0];
+        sr->tap[k] = r > j2 ? EZ_ROW_POLE_N : r < j1 ? EZ_ROW_POLE_S : r - j1;
+    }
+}
+
+static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
+{
+    int di = degree == DEG_CUBIC ? 2 : degree;
+    ezh_sepplan *sp = &s->sep[di][vector_mode];
+    /* plans depend on polar_correction: bit 1 of built records the setting they were built for */
+    if (sp->built == 1 + polar) return 0;
+    free_sepplan(sp);
+    ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
+    int nic = go->ni, njr = go->nj;
+    int *cidx = (int *)malloc(sizeof(int) * 4 * nic), *cidx_s = (int *)malloc(sizeof(int) * 4 * nic);
+    double *cw = (double *)malloc(sizeof(double) * 4 * nic), *cw_s = (double *)malloc(sizeof(double) * 4 * nic);
+    unsigned char *cflag = (unsigned char *)calloc(nic, 1), *rflag = (unsigned char *)calloc(njr, 1);
+    int *rbase = (int *)malloc(sizeof(int) * njr);
+    double *rw = (double *)malloc(sizeof(double) * 4 * njr);
+    ezhip_special_row *special = (ezhip_special_row *)calloc((size_t)njr + 1, sizeof(ezhip_special_row));
+    int nspecial = 0;
+    for (int c = 0; c < nic; c++) {
+        int idx[4]; double w[4];
+        col_taps_main(gi, degree, s->x1d[c], idx, w);
+        for (int k = 0; k < 4; k++) { cidx[k * nic + c] = idx[k] - 1; cw[k * nic + c] = w[k]; }
+        col_taps_strip(gi, degree, s->x1d[c], idx, w);
+        for (int k = 0; k < 4; k++) { cidx_s[k * nic + c] = idx[k] - 1; cw_s[k * nic + c] = w[k]; }
+        if (polar && s->extrap) { int ix = (int)((double)s->x1d[c] + 0.5); if (ix < 1 || ix > gi->ni) cflag[c] = EZF_DEHORS; }
+    }
+    for (int r = 0; r < njr; r++) {
+        float py = s->y1d[r];
+        int jf; double w[4];
+        row_taps_main(gi, degree, py, &jf, w);
+        rbase[r] = jf - gi->j1;
+        for (int k = 0; k < 4; k++) rw[k * njr + r] = w[k];
+        if (!polar) continue;
+        ezhip_special_row *sr = &special[nspecial];
+        sr->row = r;
+        if (s->extrap) {                                          /* ez_defzone_dehors.c:63-74 */
+            int iy = (int)((double)py + 0.5);
+            if (iy < 1 || iy > gi->nj) { sr->kind = 3; rflag[r] = 1; nspecial++; }
+            continue;
+        }
+        int au_n = (int)py > (gi->j2 - 2), au_s = (int)py < (gi->j1 + 1);
+        int po_n = fabs((double)(py - s->ypole_n)) < 1.0e-3, po_s = fabs((double)(py - s->ypole_s)) < 1.0e-3;
+        if (vector_mode) { po_n = po_s = 0; }
+        if (po_s) sr->kind = 2;
+        else if (po_n) sr->kind = 1;
+        else if (au_s) strip_row(gi, degree, py, 0, sr);
+        else if (au_n) strip_row(gi, degree, py, 1, sr);
+        else continue;
+        rflag[r] = 1; nspecial++;
+    }
+    ezhip_sep_plan *p = &sp->p;
+    memset(p, 0, sizeof(*p));
+    p->degree = degree; p->ni_src = gi->ni; p->nj_src = gi->nj; p->ni_dst = nic; p->nj_dst = njr;
+    p->cidx = (const int *)(sp->dev[0] = upload(cidx, sizeof(int) * 4 * nic));
+    p->cw = (const double *)(sp->dev[1] = upload(cw, sizeof(double) * 4 * nic));
+    p->cidx_s = (const int *)(sp->dev[2] = upload(cidx_s, sizeof(int) * 4 * nic));
+    p->cw_s = (const double *)(sp->dev[3] = upload(cw_s, sizeof(double) * 4 * nic));
+    p->cflag = (const unsigned char *)(sp->dev[4] = upload(cflag, nic));
+    p->rbase = (const int *)(sp->dev[5] = upload(rbase, sizeof(int) * njr));
+    p->rw = (const double *)(sp->dev[6] = upload(rw, sizeof(double) * 4 * njr));
+    p->rflag = (const unsigned char *)(sp->dev[7] = upload(rflag, njr));
+    p->special = (const ezhip_special_row *)(sp->dev[8] = upload(special, sizeof(ezhip_special_row) * (nspecial + 1)));
+    p->n_special = nspecial;
+    p->pole_weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
+    p->vector_mode = vector_mode;
+    ezhip_sync();
+    int ok = 1;
+    for (int k = 0; k < 9; k++) ok &= (sp->dev[k] != NULL);
+    free(cidx); free(cidx_s); free(cw); free(cw_s); free(cflag); free(rflag); free(rbase); free(rw); free(special);
+    if (!ok) { free_sepplan(sp); return -1; }
+    sp->built = 1 + polar;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* per-point plan                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+static void fill_locate_plan(const ezh_grid *gi, ezhip_locate_plan *lp)
+{
+    memset(lp, 0, sizeof(*lp));
+    lp->ni = gi->ni; lp->nj = gi->nj;
+    float r[9], ri[9];
+    switch (gi->grtyp) {
+    case 'A': lp->kind = 0; lp->dlon = 360.0f / (float)gi->ni; lp->lon0 = 0.0f; lp->dlat = 180.0f / (float)gi->nj; lp->lat0 = -90.0f + lp->dlat * 0.5f; lp->lon_fix = 2; break;
+    case 'B': lp->kind = 0; lp->dlon = 360.0f / (float)(gi->ni - 1); lp->lon0 = 0.0f; lp->dlat = 180.0f / (float)(gi->nj - 1); lp->lat0 = -90.0f; lp->lon_fix = 2; break;
+    case 'L': lp->kind = 0; h_cigaxg('L', &lp->lat0, &lp->lon0, &lp->dlat, &lp->dlon, gi->ig[0], gi->ig[1], gi->ig[2], gi->ig[3]); lp->lon_fix = 1; break;
+    case 'E':
+        lp->kind = 3; lp->dlon = 360.0f / (float)(gi->ni - 1); lp->lon0 = 0.0f; lp->dlat = 180.0f / (float)gi->nj; lp->lat0 = -90.f + 0.5f * lp->dlat;
+        h_crot(r, ri, gi->xg[1], gi->xg[0], gi->xg[3], gi->xg[2]); memcpy(lp->r, r, sizeof(r));
+        break;
+    default:
+        lp->ax = gi->d_ax; lp->ay = gi->d_ay;
+        if (gi->grref == 'L') {
+            lp->kind = 1;
+            h_cigaxg('L', &lp->lat0, &lp->lon0, &lp->dlat, &lp->dlon, gi->igref[0], gi->igref[1], gi->igref[2], gi->igref[3]);
+            lp->lonref = (gi->ax[0] < 0.0f) ? -180.0f : 0.0f;
+        } else {
+            lp->kind = 2;
+            h_crot(r, ri, gi->xgref[1], gi->xgref[0], gi->xgref[3], gi->xgref[2]); memcpy(lp->r, r, sizeof(r));
+        }
+    }
+}
+
+static int ensure_points(ezh_set *s)
+{
+    if (s->d_x) return 0;
+    ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
+    if (ensure_grid_dev(gi) || ensure_coords_dev(go)) return -1;
+    size_t n = (size_t)go->ni * go->nj;
+    s->d_x = (float *)ezhip_malloc(sizeof(float) * n);
+    s->d_y = (float *)ezhip_malloc(sizeof(float) * n);
+    if (!s->d_x || !s->d_y) return -1;
+    ezhip_locate_plan lp;
+    fill_locate_plan(gi, &lp);
+    return ezhip_locate(&lp, s->d_x, s->d_y, go->d_lat, go->d_lon, go->ni, go->nj, go->separable);
+}
+
+static void fill_pts_plan(const ezh_set *s, const ezh_grid *gi, ezhip_pts_plan *pp, int degree, int zones, int vector_mode)
+{
+    memset(pp, 0, sizeof(*pp));
+    pp->degree = degree; pp->irregular = src_irregular(gi);
+    pp->ni = gi->ni; pp->nj = gi->nj; pp->i1 = gi->i1; pp->i2 = gi->i2; pp->j1 = gi->j1; pp->j2 = gi->j2; pp->wrap = gi->extension;
+    pp->ax = gi->d_ax; pp->ay = gi->d_ay; pp->ncx = gi->d_ncx; pp->ncy = gi->d_ncy;
+    pp->zones = zones; pp->degre_extrap = O.degre_extrap; pp->vector_mode = vector_mode;
+    pp->pole_weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
+    if (s) { pp->ypole_n = s->ypole_n; pp->ypole_s = s->ypole_s; }
+    if (gi->ay && gi->nj >= 4) {
+        int j1 = gi->j1, j2 = gi->j2;
+        const float *ay = gi->ay;
+        if (ay[j2 - 1] == 90.0) { pp->ay4_n[0] = ay[j2 - 4]; pp->ay4_n[1] = ay[j2 - 3]; pp->ay4_n[2] = ay[j2 - 2]; pp->ay4_n[3] = ay[j2 - 1]; }
+        else { pp->ay4_n[0] = ay[j2 - 3]; pp->ay4_n[1] = ay[j2 - 2]; pp->ay4_n[2] = ay[j2 - 1]; pp->ay4_n[3] = 90.0f; }
+        if (ay[j1 - 1] == -90.0) { pp->ay4_s[0] = ay[0]; pp->ay4_s[1] = ay[1]; pp->ay4_s[2] = ay[2]; pp->ay4_s[3] = ay[3]; }
+        else { pp->ay4_s[0] = -90.0f; pp->ay4_s[1] = ay[0]; pp->ay4_s[2] = ay[1]; pp->ay4_s[3] = ay[2]; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* scalar interpolation on device pointers                                                       */
+/* ------------------------------------------------------------------------------------------ */
+static ezh_set *current_set(const char *who)
+{
+    if (cur_gdin < 0 || cur_gdout < 0 || !grid_ok(cur_gdin) || !grid_ok(cur_gdout)) {
+        fprintf(stderr, "<%s> Source or target grid undefined! Aborting...\n", who);
+        return NULL;
+    }
+    pthread_mutex_lock(&g_mtx);
+    ezh_set *s = find_set(cur_gdout, cur_gdin, 1);
+    if (!s->x1d && !s->d_x) analyse_set(s);
+    pthread_mutex_unlock(&g_mtx);
+    return s;
+}
+
+static int ensure_scratch(ezh_set *s)
+{
+    if (!s->d_scratch) s->d_scratch = (float *)ezhip_malloc(sizeof(float) * 8);
+    return s->d_scratch ? 0 : -1;
+}
+
+/* one field, device pointers; vector_mode: 0 scalar, 1 = u/v component with synthetic pole rows
+ * (prow_n / prow_s device pointers, may be NULL when polar correction is off) */
+static int run_field(ezh_set *s, float *d_zout, const float *d_zin, int vector_mode, const float *prow_n, const float *prow_s)
+{
+    ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
+    int degree = O.degre_interp, polar = O.polar_correction == 1;
+    if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) {
+        fprintf(stderr, "<ezsint> interp_degree %d (average modes) is outside the MI355X hot-path scope\n", degree);
+        return -1;
+    }
+    int ierc = 0;
+    if (ensure_scratch(s)) return -1;
+    float *d_fill = s->d_scratch, *d_poles = s->d_scratch + 4;
+    int mode = choose_mode(s, degree, polar);
+    int need_fill = 0;
+    if (polar && s->extrap) {
+        int dehors = s->sep_capable ? s->have_dehors : 1;   /* unknown without a pass over x,y: assume present */
+        if (dehors) {
+            if (s->sep_capable) ierc = 2;
+            if (O.degre_extrap == XT_ABORT && s->sep_capable) {
+                fprintf(stderr, "<ez_corrval> There are points on the destination grid that lie outside the source grid\n");
+                return -1;
+            }
+            need_fill = (O.degre_extrap >= XT_MAXIMUM) || vector_mode;
+        }
+    }
+    if (need_fill && ezhip_fill_value(d_fill, d_zin, (size_t)gi->ni * gi->nj, O.degre_extrap, O.valeur_extrap, vector_mode)) return -1;
+    if (mode == 1) {
+        if (build_sep_plan(s, degree, vector_mode, polar)) return -1;
+        int di = degree == DEG_CUBIC ? 2 : degree;
+        ezhip_sep_plan p = s->sep[di][vector_mode].p;
+        p.fill = d_fill;
+        if (p.pole_weighted) { if (ensure_grid_dev(gi)) return -1; p.ax = gi->d_ax; }
+        p.pole_row_n = prow_n; p.pole_row_s = prow_s;
+        if (ezhip_interp_sep(&p, d_zout, d_zin)) return -1;
+        return ierc;
+    }
+    if (ensure_points(s)) return -1;
+    ezhip_pts_plan pp;
+    int zones = !polar ? 0 : (s->extrap ? 2 : 1);
+    fill_pts_plan(s, gi, &pp, degree, zones, vector_mode);
+    pp.fill = d_fill; pp.polevals = d_poles;
+    pp.pole_row_n = prow_n; pp.pole_row_s = prow_s;
+    if (zones == 1 && !vector_mode && ezhip_polevals(d_poles, d_zin, gi->ni, gi->nj, pp.pole_weighted, gi->d_ax)) return -1;
+    if (zones == 2 && !s->sep_capable) {
+        /* The reference returns 2 only when the DEHORS zone is non-empty; on the per-point path that
+         * needs a reduction over x,y which is done once and cached in have_dehors by ezhip_prepare. */
+        if (s->have_dehors) ierc = 2;
+    }
+    if (ezhip_interp_pts(&pp, d_zout, d_zin, s->d_x, s->d_y, go->ni * go->nj)) return -1;
+    return ierc;
+}
+
+void ezhip_use_stream(void *hip_stream) { ezhip_set_stream(hip_stream); }
+int32_t ezhip_available(void) { return ezhip_runtime_ok(); }
+
+int32_t c_ezsint_dev(float *d_zout, const float *d_zin)
+{
+    ezh_set *s = current_set("c_ezsint");
+    if (!s) return -1;
+    if (need_device("c_ezsint")) return -1;
+    if (s->gdin == s->gdout) { ezhip_d2d(d_zout, d_zin, sizeof(float) * (size_t)G[s->gdin].ni * G[s->gdin].nj); return 1; }
+    return run_field(s, d_zout, d_zin, 0, NULL, NULL);
+}
+
+int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields)
+{
+    ezh_set *s = current_set("c_ezsint_batch");
+    if (!s) return -1;
+    if (need_device("c_ezsint_batch")) return -1;
+    size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
+    int rc = 0;
+    for (int f = 0; f < nfields; f++) {
+        int r = (s->gdin == s->gdout) ? (ezhip_d2d(d_zout + f * nout, d_zin + f * nin, sizeof(float) * nin), 1)
+                                      : run_field(s, d_zout + f * nout, d_zin + f * nin, 0, NULL, NULL);
+        if (r < 0) return r;
+        if (r > rc) rc = r;
+    }
+    return rc;
+}
+
+int32_t ezhip_prepare_set(void)
+{
+    ezh_set *s = current_set("ezhip_prepare_set");
+    if (!s) return -1;
+    if (need_device("ezhip_prepare_set")) return -1;
+    int degree = O.degre_interp, polar = O.polar_correction == 1;
+    if (choose_mode(s, degree, polar) == 1) return build_sep_plan(s, degree, 0, polar);
+    if (ensure_points(s)) return -1;
+    if (s->extrap && !s->sep_capable && !s->have_dehors) {
+        /* classify once on the host (first-call work, like ez_defzones) */
+        ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
+        size_t n = (size_t)go->ni * go->nj;
+        float *x = (float *)malloc(sizeof(float) * n), *y = (float *)malloc(sizeof(float) * n);
+        ezhip_d2h(x, s->d_x, sizeof(float) * n); ezhip_d2h(y, s->d_y, sizeof(float) * n); ezhip_sync();
+        for (size_t k = 0; k < n; k++) {
+            int ix = (int)((double)x[k] + 0.5), iy = (int)((double)y[k] + 0.5);
+            if (ix < 1 || iy < 1 || ix > gi->ni || iy > gi->nj) { s->have_dehors = 1; break; }
+        }
+        free(x); free(y);
+    }
+    return 0;
+}
+
+int32_t ezhip_set_mode(void)
+{
+    ezh_set *s = current_set("ezhip_set_mode");
+    if (!s) return -1;
+    return choose_mode(s, O.degre_interp, O.polar_correction == 1);
+}
+
+/* host-pointer ABI: stage through device buffers owned by the set */
+static int stage(float **d, size_t n) { if (!*d) *d = (float *)ezhip_malloc(sizeof(float) * n); return *d ? 0 : -1; }
+
+int32_t c_ezsint(float *zout, float *zin)               /* ezsint.c:38-135 */
+{
+    ezh_set *s = current_set("c_ezsint");
+    if (!s) return -1;
+    size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
+    if (s->gdin == s->gdout) { memcpy(zout, zin, sizeof(float) * nin); return 1; }
+    if (need_device("c_ezsint")) return -1;
+    if (stage(&s->d_stage_in, nin) || stage(&s->d_stage_out, nout)) return -1;
+    if (ezhip_prepare_set()) return -1;
+    if (ezhip_h2d(s->d_stage_in, zin, sizeof(float) * nin)) return -1;
+    int rc = run_field(s, s->d_stage_out, s->d_stage_in, 0, NULL, NULL);
+    if (rc < 0) return rc;
+    if (ezhip_d2h(zout, s->d_stage_out, sizeof(float) * nout) || ezhip_sync()) return -1;
+    return rc;
+}
+
+/* c_gdxysint / c_gdxysval (gdxysint.c:30-54, gdxysval.c:50-123): caller-supplied x,y, no polar correction */
+int32_t c_gdxysint_dev(float *d_zout, const float *d_zin, int32_t gdin, const float *d_x, const float *d_y, int32_t npts)
+{
+    if (!grid_ok(gdin)) return -1;
+    if (need_device("c_gdxysint")) return -1;
+    ezh_grid *gi = &G[gdin];
+    int degree = O.degre_interp;
+    if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return -1;
+    if (ensure_grid_dev(gi)) return -1;
+    ezhip_pts_plan pp;
+    fill_pts_plan(NULL, gi, &pp, degree, 0, 0);
+    return ezhip_interp_pts(&pp, d_zout, d_zin, d_x, d_y, npts) ? -1 : 0;
+}
+int32_t c_gdxysint(float *zout, float *zin, int32_t gdin, float *x, float *y, int32_t npts)
+{
+    if (!grid_ok(gdin)) return -1;
+    if (need_device("c_gdxysint")) return -1;
+    size_t nin = (size_t)G[gdin].ni * G[gdin].nj;
+    float *d_in = (float *)upload(zin, sizeof(float) * nin), *d_x = (float *)upload(x, sizeof(float) * (size_t)npts);
+    float *d_y = (float *)upload(y, sizeof(float) * (size_t)npts), *d_out = (float *)ezhip_malloc(sizeof(float) * (size_t)npts);
+    int rc = (d_in && d_x && d_y && d_out) ? c_gdxysint_dev(d_out, d_in, gdin, d_x, d_y, npts) : -1;
+    if (rc == 0 && (ezhip_d2h(zout, d_out, sizeof(float) * (size_t)npts) || ezhip_sync())) rc = -1;
+    ezhip_sync();
+    ezhip_free(d_in); ezhip_free(d_x); ezhip_free(d_y); ezhip_free(d_out);
+    return rc;
+}
+int32_t c_gdxysval(int32_t gdin, float *zout, float *zin, float *x, float *y, int32_t n) { return c_gdxysint(zout, zin, gdin, x, y, n); }
+
+int32_t c_gdxyfll_dev(int32_t gd, float *d_x, float *d_y, const float *d_lat, const float *d_lon, int32_t n)
+{
+    if (!grid_ok(gd)) return -1;
+    if (need_device("c_gdxyfll")) return -1;
+    ezh_grid *g = &G[gd];
+    if (ensure_grid_dev(g)) return -1;
+    ezhip_locate_plan lp;
+    fill_locate_plan(g, &lp);
+    return ezhip_locate(&lp, d_x, d_y, d_lat, d_lon, n, 1, 0) ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* vector interpolation: c_ezuvint_orig, ezuvint.c:51-94                                         */
+/* ------------------------------------------------------------------------------------------ */
+static const float RDTODG = 57.295779513082f, DGTORD = 1.7453292519943e-2f;
+
+static void h_llwfgdw(float *z1, float *z2, const float *xlon, int n, char t, float xg4)
+{   /* ez_llwfgdw.inc:22-170 (N, S, and the lat-lon family) */
+    for (int i = 0; i < n; i++) {
+        float uu = z1[i], vv = z2[i], spd = sqrtf(uu * uu + vv * vv), dir;
+        if (spd == 0.0f) dir = 0.0f;
+        else if (t == 'N') dir = (uu == 0.0f) ? ((vv >= 0.0f) ? xlon[i] + xg4 - 90.0f : xlon[i] + xg4 + 90.0f) : xlon[i] + xg4 - RDTODG * atan2f(vv, uu);
+        else if (t == 'S') dir = (uu == 0.0f) ? ((vv >= 0.0f) ? 90.0f - xlon[i] + xg4 : 270.0f - xlon[i] + xg4) : 180.0f - xlon[i] + xg4 - RDTODG * atan2f(vv, uu);
+        else dir = (uu == 0.0f) ? ((vv >= 0.0f) ? 180.0f : 0.0f) : 270.0f - RDTODG * atan2f(vv, uu);
+        dir = fmodf(fmodf(dir, 360.0f) + 360.0f, 360.0f);
+        z1[i] = spd; z2[i] = dir;
+    }
+}
+static void h_gdwfllw(float *z1, float *z2, const float *xlon, int n, char t, float xg4)
+{   /* ez_gdwfllw.inc:23-137 */
+    for (int i = 0; i < n; i++) {
+        float psi = t == 'N' ? xlon[i] + xg4 - z2[i] : t == 'S' ? 180.0f - xlon[i] + xg4 - z2[i] : 270.0f - z2[i];
+        float u = cosf(psi * DGTORD) * z1[i], v = sinf(psi * DGTORD) * z1[i];
+        z1[i] = u; z2[i] = v;
+    }
+}
+static float h_poleval(const float *z, int ni, const ezh_grid *g)
+{   /* ez_calcpoleval.inc:21-48 (host: used on O(ni) synthetic wind rows only) */
+    float p = 0.0f;
+    if (g->grtyp == 'Z' && g->grref == 'E') {
+        for (int i = 0; i + 1 < ni; i++) p = p + z[i] * (g->ax[i + 1] - g->ax[i]);
+        if ((g->ax[ni - 1] - g->ax[0]) != 0.0f) p = p / (g->ax[ni - 1] - g->ax[0]);
+        return p;
+    }
+    for (int i = 0; i < ni; i++) p = p + z[i];
+    return p / (1.0f * (float)ni);
+}
+/* lat/lon of one source row: c_gdllfxy_orig, gdllfxy.c:245-390 */
+static void h_row_latlon(const ezh_grid *g, float *lat, float *lon, int row1 /* 1-based */)
+{
+    int ni = g->ni;
+    float y = (float)(1.0 * row1);
+    for (int i = 0; i < ni; i++) {
+        float x = (float)(1.0 * (i + 1));
+        if (g->grtyp == 'A' || g->grtyp == 'B' || g->grtyp == 'L') {
+            lat[i] = (float)(((double)y - 1.0) * (double)g->xg[2] + (double)g->xg[0]);
+            lon[i] = (float)(((double)x - 1.0) * (double)g->xg[3] + (double)g->xg[1]);
+            lon[i] = (float)fmod((double)(lon[i] + 360.0), 360.0);
+        } else if (g->grtyp == 'E') {
+            float dlat = (float)(180.0 / g->nj), dlon = (float)(360.0 / (g->ni - 1));
+            float swlat = (float)(-90.0 + 0.5 * (double)dlat);
+            lon[i] = (float)(((double)x - 1.0) * (double)dlon + 0.0);
+            lat[i] = (float)(((double)y - 1.0) * (double)dlat + (double)swlat);
+        } else {
+            int ix = imin(imax((int)x - 1, 0), g->ni - 2), iy = imin(imax((int)y - 1, 0), g->j2 - 2);
+            float dx = g->ax[ix + 1] - g->ax[ix], dy = g->ay[iy + 1] - g->ay[iy];
+            float tx = (float)((double)g->ax[ix] + (((double)x - 1.0 - ix) * (double)dx));
+            float ty = (float)((double)g->ay[iy] + (((double)y - 1.0 - iy) * (double)dy));
+            if (g->grref == 'L') {
+                lat[i] = ty * g->xgref[2] + g->xgref[0];
+                lon[i] = tx * g->xgref[3] + g->xgref[1];
+                lon[i] = (float)fmod((double)(lon[i] + 360.0), 360.0);
+            } else { lat[i] = ty; lon[i] = tx; }   /* rotated-frame coordinates; converted below */
+        }
+    }
+    if (g->grtyp == 'E') { float *a = (float *)malloc(sizeof(float) * ni), *b = (float *)malloc(sizeof(float) * ni); memcpy(a, lon, sizeof(float) * ni); memcpy(b, lat, sizeof(float) * ni); h_rotate(lon, lat, a, b, ni, g->xg, 0); free(a); free(b); }
+    if (g->grtyp == 'Z' && g->grref == 'E') { float *a = (float *)malloc(sizeof(float) * ni), *b = (float *)malloc(sizeof(float) * ni); memcpy(a, lon, sizeof(float) * ni); memcpy(b, lat, sizeof(float) * ni); h_rotate(lon, lat, a, b, ni, g->xgref, 0); free(a); free(b); }
+}
+
+/* ez_calcnpolarwind.c:28-138 / ez_calcspolarwind.c: synthetic pole row of (u,v) from the last/first source row */
+static void h_polar_wind(const ezh_grid *g, float *pu, float *pv, const float *urow, const float *vrow, int north)
+{
+    int ni = g->ni;
+    float *plat = (float *)malloc(sizeof(float) * ni), *plon = (float *)malloc(sizeof(float) * ni);
+    float *spd = (float *)malloc(sizeof(float) * ni), *wd = (float *)malloc(sizeof(float) * ni);
+    h_row_latlon(g, plat, plon, north ? g->nj : 1);
+    if (g->grtyp == 'Z' && g->grref == 'E') {
+        float *a = (float *)malloc(sizeof(float) * ni), *b = (float *)malloc(sizeof(float) * ni);
+        memcpy(a, plon, sizeof(float) * ni); memcpy(b, plat, sizeof(float) * ni);
+        h_rotate(plon, plat, a, b, ni, g->xgref, 1);
+        free(a); free(b);
+    }
+    memcpy(spd, urow, sizeof(float) * ni); memcpy(wd, vrow, sizeof(float) * ni);
+    h_llwfgdw(spd, wd, plon, ni, 'A', 0.f);
+    char hs = north ? 'N' : 'S';
+    int i1, i2, i3, i4; float x1, x2, x3, x4;
+    h_cxgaig(hs, &i1, &i2, &i3, &i4, 0.0f, 0.0f, 1000.0f, 0.0f);
+    h_cigaxg(hs, &x1, &x2, &x3, &x4, i1, i2, i3, i4);
+    memcpy(pu, spd, sizeof(float) * ni); memcpy(pv, wd, sizeof(float) * ni);
+    h_gdwfllw(pu, pv, plon, ni, hs, x4);
+    float s0 = h_poleval(pu, ni, g), w0 = h_poleval(pv, ni, g), zero = 0.0f;
+    h_llwfgdw(&s0, &w0, &zero, 1, hs, x4);
+    spd[0] = s0; wd[0] = w0;
+    for (int i = 1; i < ni; i++) { wd[i] = north ? wd[0] + plon[i] : wd[0] - plon[i]; spd[i] = spd[0]; }
+    wd[0] = wd[0] + plon[0];
+    memcpy(pu, spd, sizeof(float) * ni); memcpy(pv, wd, sizeof(float) * ni);
+    h_gdwfllw(pu, pv, plon, ni, 'A', 0.f);
+    free(plat); free(plon); free(spd); free(wd);
+}
+
+int32_t c_ezuvint_dev(float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin)
+{
+    ezh_set *s = current_set("c_ezuvint");
+    if (!s) return -1;
+    if (need_device("c_ezuvint")) return -1;
+    ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
+    if (go->grtyp == 'E' || (go->grtyp == 'Z' && go->grref == 'E') || go->grtyp == 'Z') {
+        fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp);
+        return -1;
+    }
+    int ni = gi->ni, nj = gi->nj, polar = O.polar_correction == 1;
+    const float *pun = NULL, *pus = NULL, *pvn = NULL, *pvs = NULL;
+    if (polar && !s->extrap) {
+        /* synthetic polar wind rows: O(ni) work on two source rows, done on the host with the exact
+         * reference arithmetic (ez_calcnpolarwind.c) and sent back as four ni-float rows */
+        if (!s->d_prow) s->d_prow = (float *)ezhip_malloc(sizeof(float) * 4 * (size_t)ni);
+        if (!s->d_prow) return -1;
+        float *rows = (float *)malloc(sizeof(float) * 8 * (size_t)ni);
+        float *un = rows, *vn = rows + ni, *us = rows + 2 * ni, *vs = rows + 3 * ni, *out = rows + 4 * ni;
+        ezhip_d2h(un, d_uuin + (size_t)(nj - 1) * ni, sizeof(float) * ni); ezhip_d2h(vn, d_vvin + (size_t)(nj - 1) * ni, sizeof(float) * ni);
+        ezhip_d2h(us, d_uuin, sizeof(float) * ni); ezhip_d2h(vs, d_vvin, sizeof(float) * ni);
+        if (ezhip_sync()) { free(rows); return -1; }
+        h_polar_wind(gi, out, out + 2 * ni, un, vn, 1);          /* out: [u_n, u_s, v_n, v_s] */
+        h_polar_wind(gi, out + ni, out + 3 * ni, us, vs, 0);
+        ezhip_h2d(s->d_prow, out, sizeof(float) * 4 * (size_t)ni);
+        if (ezhip_sync()) { free(rows); return -1; }
+        free(rows);
+        pun = s->d_prow; pus = s->d_prow + ni; pvn = s->d_prow + 2 * ni; pvs = s->d_prow + 3 * ni;
+    }
+    int r1 = run_field(s, d_uuout, d_uuin, 1, pun, pus);
+    if (r1 < 0) return r1;
+    int r2 = run_field(s, d_vvout, d_vvin, 1, pvn, pvs);
+    if (r2 < 0) return r2;
+    if (ensure_coords_dev(go)) return -1;
+    ezhip_wind_plan wp;
+    memset(&wp, 0, sizeof(wp));
+    wp.separable = go->separable;
+    wp.src_rotated = (gi->grtyp == 'E' || (gi->grtyp == 'Z' && gi->grref == 'E'));
+    if (wp.src_rotated) { const float *xg = gi->grtyp == 'E' ? gi->xg : gi->xgref; h_crot(wp.r, wp.ri, xg[1], xg[0], xg[3], xg[2]); }
+    else if (gi->grtyp == 'Z' && gi->grref != 'L') return -1;
+    if (ezhip_wind_rotate(&wp, d_uuout, d_vvout, go->d_lat, go->d_lon, go->ni, go->nj)) return -1;
+    return (r1 == 2 || r2 == 2) ? 2 : 0;
+}
+
+int32_t c_ezuvint(float *uuout, float *vvout, float *uuin, float *vvin)
+{
+    ezh_set *s = current_set("c_ezuvint");
+    if (!s) return -1;
+    if (need_device("c_ezuvint")) return -1;
+    size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
+    if (stage(&s->d_stage_in, nin) || stage(&s->d_stage_out, nout) || stage(&s->d_stage_in2, nin) || stage(&s->d_stage_out2, nout)) return -1;
+    if (ezhip_h2d(s->d_stage_in, uuin, sizeof(float) * nin) || ezhip_h2d(s->d_stage_in2, vvin, sizeof(float) * nin)) return -1;
+    int rc = c_ezuvint_dev(s->d_stage_out, s->d_stage_out2, s->d_stage_in, s->d_stage_in2);
+    if (rc < 0) return rc;
+    if (ezhip_d2h(uuout, s->d_stage_out, sizeof(float) * nout) || ezhip_d2h(vvout, s->d_stage_out2, sizeof(float) * nout) || ezhip_sync()) return -1;
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Fortran twins (rpnmacros.h:21 f77name; scalars by reference; hidden string lengths last)       */
+/* ------------------------------------------------------------------------------------------ */
+int32_t ezqkdef_(int32_t *ni, int32_t *nj, char *grtyp, int32_t *ig1, int32_t *ig2, int32_t *ig3, int32_t *ig4, int32_t *iunit, int32_t l)
+{ (void)l; char t[2] = {grtyp[0], 0}; return c_ezqkdef(*ni, *nj, t, *ig1, *ig2, *ig3, *ig4, *iunit); }
+int32_t ezgdef_fmem_(int32_t *ni, int32_t *nj, char *grtyp, char *grref, int32_t *ig1, int32_t *ig2, int32_t *ig3, int32_t *ig4, float *ax, float *ay, int32_t l1, int32_t l2)
+{ (void)l1; (void)l2; char t[2] = {grtyp[0], 0}, r[2] = {grref[0], 0}; return c_ezgdef_fmem(*ni, *nj, t, r, *ig1, *ig2, *ig3, *ig4, ax, ay); }
+int32_t ezdefset_(int32_t *gdout, int32_t *gdin) { return c_ezdefset(*gdout, *gdin); }
+static void ftn2c(char *dst, const char *src, int len)
+{
+    int n = len < 31 ? len : 31;
+    memset(dst, 0, 32); memcpy(dst, src, (size_t)n);
+    while (n > 0 && (dst[n - 1] == ' ' || dst[n - 1] == 0)) dst[--n] = 0;
+}
+int32_t ezsetopt_(char *option, char *value, int32_t lo, int32_t lv)
+{ char o[32], v[32]; ftn2c(o, option, lo); ftn2c(v, value, lv); return c_ezsetopt(o, v); }
+int32_t ezsint_(float *zout, float *zin) { return c_ezsint(zout, zin); }
+int32_t ezuvint_(float *uo, float *vo, float *ui, float *vi) { return c_ezuvint(uo, vo, ui, vi); }
+int32_t gdxysint_(float *zout, float *zin, int32_t *gdin, float *x, float *y, int32_t *npts) { return c_gdxysint(zout, zin, *gdin, x, y, *npts); }
+int32_t gdxysval_(int32_t *gdin, float *zout, float *zin, float *x, float *y, int32_t *n) { return c_gdxysval(*gdin, zout, zin, x, y, *n); }
+int32_t gdxyfll_(int32_t *gd, float *x, float *y, float *lat, float *lon, int32_t *n) { return c_gdxyfll(*gd, x, y, lat, lon, *n); }
+int32_t gdll_(int32_t *gd, float *lat, float *lon) { return c_gdll(*gd, lat, lon); }
+int32_t gdrls_(int32_t *gd) { return c_gdrls(*gd); }

@@ -1,0 +1,774 @@
+/*
+ * ez_kernels.hip -- hand-written HIP kernels (gfx950 / MI355X) for librmn's EZ interpolation
+ * hot path, plus the thin C-ABI shim the C host front-end calls (ezhip_shim.h).
+ *
+ * Kernels:
+ *   k_sep<DEG>      separable ("rectilinear on rectilinear") interpolation: per-column / per-row
+ *                   tap tables, rolling 4-row register window, fused polar special rows.
+ *                   Replaces the do n=1,npts loops of ez_irgdint_3_w / ez_rgdint_3_w / ez_(i)rgdint_1_(n)w /
+ *                   ez_rgdint_0 (reference src/interp/*.inc) when x depends on the target column
+ *                   only and y on the target row only -- the BASELINE cfg1/2/4/5 shape.
+ *   k_pts           generic per-point interpolation at arbitrary (x,y): point-by-point restatement
+ *                   of the 11 leaf kernels + zone handling (ez_defzones.c, ez_corrval*.c).
+ *   k_locate        lat/lon -> source index space (ez_ll2rgd.inc, ez_ll2igd.inc, ez_cherche.inc,
+ *                   ez_gfxyfll.c).
+ *   k_wind_rotate   c_gdwdfuv + c_gduvfwd fused (ez_llwfgdw.inc, ez_gdwfllw.inc, ez_llwfgfw.c).
+ *   k_polevals / k_minmax / k_fill   small reductions (ez_calcpoleval.inc, ez_aminmax.inc).
+ *
+ * No MFMA: there is no dense contraction on this path; the bound is HBM.
+ * Wavefront = 64 lanes throughout.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "ezhip_shim.h"
+
+/* Everything that restates reference arithmetic must not be contracted into FMAs; the separable
+ * kernel uses explicit fma() where fusion is intended. */
+#pragma clang fp contract(off)
+
+/* ===================================================================================== */
+/* runtime plumbing                                                                         */
+/* ===================================================================================== */
+static thread_local hipStream_t g_stream = nullptr;
+static thread_local char g_err[256] = "";
+
+static int set_err(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return 0;
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return -1;
+}
+
+extern "C" int ezhip_runtime_ok(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n > 0;
+}
+extern "C" const char *ezhip_last_error(void) { return g_err; }
+extern "C" void *ezhip_malloc(size_t nbytes)
+{
+    void *p = nullptr;
+    if (set_err(hipMalloc(&p, nbytes ? nbytes : 4), "hipMalloc")) return nullptr;
+    return p;
+}
+extern "C" void ezhip_free(void *d) { if (d) (void)hipFree(d); }
+extern "C" int ezhip_h2d(void *d, const void *h, size_t n) { return set_err(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, g_stream), "h2d"); }
+extern "C" int ezhip_d2h(void *h, const void *d, size_t n) { return set_err(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream), "d2h"); }
+extern "C" int ezhip_d2d(void *dst, const void *src, size_t n) { return set_err(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, g_stream), "d2d"); }
+extern "C" int ezhip_memset(void *d, int v, size_t n) { return set_err(hipMemsetAsync(d, v, n, g_stream), "memset"); }
+extern "C" int ezhip_sync(void) { return set_err(hipStreamSynchronize(g_stream), "sync"); }
+extern "C" void ezhip_set_stream(void *s) { g_stream = (hipStream_t)s; }
+extern "C" void *ezhip_get_stream(void) { return (void *)g_stream; }
+extern "C" void *ezhip_host_alloc(size_t n)
+{
+    void *p = nullptr;
+    if (set_err(hipHostMalloc(&p, n ? n : 4, hipHostMallocDefault), "hipHostMalloc")) return nullptr;
+    return p;
+}
+extern "C" void ezhip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+#define LAUNCH_CHECK(what) set_err(hipGetLastError(), what)
+
+/* ===================================================================================== */
+/* block reduction helpers (wave = 64)                                                      */
+/* ===================================================================================== */
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+/* sum over a 256-thread block; result valid in every thread */
+__device__ double block_sum_256(double v, double *lds4)
+{
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds4[w] = v;
+    __syncthreads();
+    return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+/* ez_calcpoleval (src/interp/ez_calcpoleval.inc:21-48) as a block reduction.  The reference sums
+ * sequentially in REAL; a parallel sum cannot reproduce that order, so it is accumulated in double
+ * (deterministic tree) and rounded once: |diff| <= ~ni * 2^-24 relative, far inside 1e-5. */
+__device__ float block_poleval(const float *zrow, int ni, int weighted, const float *ax, double *lds4)
+{
+    double s = 0.0;
+    if (weighted) {
+        for (int i = threadIdx.x; i < ni - 1; i += 256) s += (double)(zrow[i] * (ax[i + 1] - ax[i]));
+        s = block_sum_256(s, lds4);
+        float span = ax[ni - 1] - ax[0];
+        float p = (float)s;
+        if (span != 0.0f) p = p / span;
+        return p;
+    }
+    for (int i = threadIdx.x; i < ni; i += 256) s += (double)zrow[i];
+    s = block_sum_256(s, lds4);
+    return (float)s / (1.0f * (float)ni);
+}
+
+/* ===================================================================================== */
+/* k_sep : separable interpolation                                                          */
+/* ===================================================================================== */
+#define SEP_BLOCK 256
+
+struct ColTaps { int i0, i1, i2, i3; double w0, w1, w2, w3; };
+
+__device__ __forceinline__ ColTaps load_col(const int *cidx, const double *cw, int ni_dst, int c)
+{
+    ColTaps t;
+    t.i0 = cidx[c]; t.i1 = cidx[ni_dst + c]; t.i2 = cidx[2 * ni_dst + c]; t.i3 = cidx[3 * ni_dst + c];
+    t.w0 = cw[c]; t.w1 = cw[ni_dst + c]; t.w2 = cw[2 * ni_dst + c]; t.w3 = cw[3 * ni_dst + c];
+    return t;
+}
+
+/* x-direction pass on one source row */
+template <int DEG>
+__device__ __forceinline__ double xpass(const float *__restrict__ zrow, const ColTaps &t)
+{
+    if (DEG == 0) return (double)zrow[t.i0];
+    if (DEG == 1) {   /* zlin8.cdk: z1 + (z2 - z1) * dx, exactly as the reference evaluates it */
+        double z1 = (double)zrow[t.i0], z2 = (double)zrow[t.i1];
+        return z1 + (z2 - z1) * t.w0;
+    }
+    double z0 = (double)zrow[t.i0], z1 = (double)zrow[t.i1], z2 = (double)zrow[t.i2], z3 = (double)zrow[t.i3];
+    return fma(t.w3, z3, fma(t.w2, z2, fma(t.w1, z1, t.w0 * z0)));
+}
+
+template <int DEG>
+__global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__restrict__ zout,
+                                                   const float *__restrict__ zin, int rows_per_block, int nblk_main)
+{
+    __shared__ double lds4[4];
+    const int c = blockIdx.x * SEP_BLOCK + threadIdx.x;
+    const bool cvalid = c < p.ni_dst;
+    const int cc = cvalid ? c : p.ni_dst - 1;
+    const int nis = p.ni_src;
+    const float fillv = p.fill ? *p.fill : 0.0f;
+
+    if ((int)blockIdx.y < nblk_main) {
+        const ColTaps t = load_col(p.cidx, p.cw, p.ni_dst, cc);
+        const bool cdehors = p.cflag[cc] != 0;
+        const int r0 = blockIdx.y * rows_per_block;
+        const int r1 = min(r0 + rows_per_block, p.nj_dst);
+        double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        int cur = -(1 << 28);
+        for (int r = r0; r < r1; r++) {
+            if (p.rflag[r]) continue;                       /* uniform: row handled as special */
+            const int jb = p.rbase[r];                      /* uniform -> scalar loads */
+            double val;
+            if (DEG == 0) {
+                val = xpass<0>(zin + (size_t)jb * nis, t);
+            } else if (DEG == 1) {
+                int d = jb - cur;
+                if (d != 0) {
+                    if (d == 1) { t0 = t1; t1 = xpass<1>(zin + (size_t)(jb + 1) * nis, t); }
+                    else { t0 = xpass<1>(zin + (size_t)jb * nis, t); t1 = xpass<1>(zin + (size_t)(jb + 1) * nis, t); }
+                    cur = jb;
+                }
+                val = t0 + (t1 - t0) * p.rw[r];
+            } else {
+                int d = jb - cur;
+                if (d != 0) {
+                    const float *zr = zin + (size_t)jb * nis;
+                    if (d == 1) { t0 = t1; t1 = t2; t2 = t3; t3 = xpass<3>(zr + 3 * (size_t)nis, t); }
+                    else if (d == 2) { t0 = t2; t1 = t3; t2 = xpass<3>(zr + 2 * (size_t)nis, t); t3 = xpass<3>(zr + 3 * (size_t)nis, t); }
+                    else if (d == 3) { t0 = t3; t1 = xpass<3>(zr + (size_t)nis, t); t2 = xpass<3>(zr + 2 * (size_t)nis, t); t3 = xpass<3>(zr + 3 * (size_t)nis, t); }
+                    else { t0 = xpass<3>(zr, t); t1 = xpass<3>(zr + (size_t)nis, t); t2 = xpass<3>(zr + 2 * (size_t)nis, t); t3 = xpass<3>(zr + 3 * (size_t)nis, t); }
+                    cur = jb;
+                }
+                const double w0 = p.rw[r], w1 = p.rw[p.nj_dst + r], w2 = p.rw[2 * p.nj_dst + r], w3 = p.rw[3 * p.nj_dst + r];
+                val = fma(w3, t3, fma(w2, t2, fma(w1, t1, w0 * t0)));
+            }
+            if (cvalid) zout[(size_t)r * p.ni_dst + c] = cdehors ? fillv : (float)val;
+        }
+        return;
+    }
+
+    /* ---- special rows: polar strips, pole rows, fully-outside rows ------------------------- */
+    const ezhip_special_row sr = p.special[blockIdx.y - nblk_main];
+    float outv;
+    if (sr.kind == 3) {
+        outv = fillv;
+    } else {
+        bool need_n = (sr.kind == 1), need_s = (sr.kind == 2);
+        if (sr.kind == 0)
+            for (int k = 0; k < 4; k++) { need_n |= (sr.tap[k] == EZ_ROW_POLE_N); need_s |= (sr.tap[k] == EZ_ROW_POLE_S); }
+        float pole_n = 0.f, pole_s = 0.f;
+        if (!p.vector_mode) {
+            if (need_n) pole_n = block_poleval(zin + (size_t)(p.nj_src - 1) * nis, nis, p.pole_weighted, p.ax, lds4);
+            if (need_s) pole_s = block_poleval(zin, nis, p.pole_weighted, p.ax, lds4);
+        }
+        if (sr.kind == 1) outv = pole_n;
+        else if (sr.kind == 2) outv = pole_s;
+        else {
+            const ColTaps t = load_col(p.cidx_s, p.cw_s, p.ni_dst, cc);
+            double tv[4];
+            const int ntap = (DEG == 3) ? 4 : (DEG == 1 ? 2 : 1);
+            for (int k = 0; k < ntap; k++) {
+                int row = sr.tap[k];
+                if (row >= 0) tv[k] = xpass<DEG>(zin + (size_t)row * nis, t);
+                else if (p.vector_mode) tv[k] = xpass<DEG>(row == EZ_ROW_POLE_N ? p.pole_row_n : p.pole_row_s, t);
+                else tv[k] = (double)(row == EZ_ROW_POLE_N ? pole_n : pole_s);   /* constant row interpolates to itself */
+            }
+            double val;
+            if (DEG == 0) val = tv[0];
+            else if (DEG == 1) val = tv[0] + (tv[1] - tv[0]) * sr.w[0];
+            else val = fma(sr.w[3], tv[3], fma(sr.w[2], tv[2], fma(sr.w[1], tv[1], sr.w[0] * tv[0])));
+            outv = (float)val;
+        }
+    }
+    if (cvalid) zout[(size_t)sr.row * p.ni_dst + c] = outv;
+}
+
+extern "C" int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin)
+{
+    const int rows_per_block = 16;
+    int nblk_main = (plan->nj_dst + rows_per_block - 1) / rows_per_block;
+    dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, nblk_main + plan->n_special);
+    dim3 block(SEP_BLOCK);
+    switch (plan->degree) {
+    case 0: hipLaunchKernelGGL(k_sep<0>, grid, block, 0, g_stream, *plan, d_zout, d_zin, rows_per_block, nblk_main); break;
+    case 1: hipLaunchKernelGGL(k_sep<1>, grid, block, 0, g_stream, *plan, d_zout, d_zin, rows_per_block, nblk_main); break;
+    case 3: hipLaunchKernelGGL(k_sep<3>, grid, block, 0, g_stream, *plan, d_zout, d_zin, rows_per_block, nblk_main); break;
+    default: snprintf(g_err, sizeof(g_err), "ezhip_interp_sep: bad degree %d", plan->degree); return -1;
+    }
+    return LAUNCH_CHECK("k_sep");
+}
+
+/* ===================================================================================== */
+/* k_pts : generic per-point interpolation (restates the reference leaf kernels)            */
+/* ===================================================================================== */
+
+/* Source-field accessor with synthetic pole rows above j2 / below j1 (the 4-row strips of
+ * ez_fillnpole.inc / ez_fillspole.inc without materialising them). */
+struct FieldAcc {
+    const float *z; int ni, j1, j2;
+    float pole_n, pole_s;
+    const float *prow_n, *prow_s;       /* vector mode: per-column pole rows */
+    __device__ __forceinline__ float operator()(int i, int j) const
+    {
+        if (j > j2) return prow_n ? prow_n[i - 1] : pole_n;
+        if (j < j1) return prow_s ? prow_s[i - 1] : pole_s;
+        return z[(size_t)(j - j1) * ni + (i - 1)];
+    }
+};
+
+__device__ __forceinline__ double d_zlin(double a, double b, double t) { return a + (b - a) * t; }
+__device__ __forceinline__ double d_cubic(double z1, double z2, double z3, double z4, double dx)
+{   /* cubic8.cdk: the two literals are default-REAL constants */
+    const double c6 = (double)0.1666666666666f, c3 = (double)0.3333333333333f;
+    return ((((z4 - z1) * c6 + 0.5 * (z2 - z3)) * dx + 0.5 * (z1 + z3) - z2) * dx + z3 - c6 * z4 - 0.5 * z2 - c3 * z1) * dx + z2;
+}
+__device__ __forceinline__ double d_fa(double a1, double a2, double a3, double a4, double x, double x1, double x2, double x3)
+{ return a1 + (x - x1) * (a2 + (x - x2) * (a3 + a4 * (x - x3))); }
+__device__ __forceinline__ double d_fa2(double c1, double a1, double a2) { return c1 * (a2 - a1); }
+__device__ __forceinline__ double d_fa3(double c1, double c2, double c3, double a1, double a2, double a3)
+{ return c2 * (c3 * (a3 - a2) - c1 * (a2 - a1)); }
+__device__ __forceinline__ double d_fa4(double c1, double c2, double c3, double c4, double c5, double c6, double a1, double a2, double a3, double a4)
+{ return c4 * (c5 * (c6 * (a4 - a3) - c3 * (a3 - a2)) - c2 * (c3 * (a3 - a2) - c1 * (a2 - a1))); }
+
+__device__ __forceinline__ int d_nint(float v) { return (int)lroundf(v); }
+
+/* ez_rgdint_0.inc:20-35 */
+template <class A> __device__ float p_rgdint_0(const A &Z, float px, float py, int ni, int j1, int j2)
+{
+    int i = min(ni, max(1, d_nint(px)));
+    int j = min(j2, max(j1, d_nint(py)));
+    return Z(i, j);
+}
+/* ez_rgdint_1_nw.inc:20-44 */
+template <class A> __device__ float p_rgdint_1_nw(const A &Z, float px, float py, int ni, int j1, int j2)
+{
+    int i = min(ni - 1, max(1, (int)px));
+    int j = min(j2 - 1, max(j1, (int)py));
+    double dx = (double)(px - (float)i), dy = (double)(py - (float)j);
+    double y2 = d_zlin((double)Z(i, j), (double)Z(i + 1, j), dx);
+    double y3 = d_zlin((double)Z(i, j + 1), (double)Z(i + 1, j + 1), dx);
+    return (float)d_zlin(y2, y3, dy);
+}
+/* ez_rgdint_1_w.inc:20-51 */
+template <class A> __device__ float p_rgdint_1_w(const A &Z, float px, float py, int ni, int j1, int j2, int wrap)
+{
+    int limite = ni + 2 - wrap;
+    int i = min(ni - 2 + wrap, max(1, (int)px));
+    int j = min(j2 - 1, max(j1, (int)py));
+    int ip1 = i + 1;
+    if (wrap > 0 && (i == (ni - 2 + wrap))) ip1 = (limite + i + 1) % limite;
+    double dx = (double)(px - (float)i), dy = (double)(py - (float)j);
+    double y2 = d_zlin((double)Z(i, j), (double)Z(ip1, j), dx);
+    double y3 = d_zlin((double)Z(i, j + 1), (double)Z(ip1, j + 1), dx);
+    return (float)d_zlin(y2, y3, dy);
+}
+template <class A> __device__ __forceinline__ float cubic_rows(const A &Z, int im1, int i, int ip1, int ip2, int j, double dx, double dy)
+{
+    double y1 = d_cubic((double)Z(im1, j - 1), (double)Z(i, j - 1), (double)Z(ip1, j - 1), (double)Z(ip2, j - 1), dx);
+    double y2 = d_cubic((double)Z(im1, j), (double)Z(i, j), (double)Z(ip1, j), (double)Z(ip2, j), dx);
+    double y3 = d_cubic((double)Z(im1, j + 1), (double)Z(i, j + 1), (double)Z(ip1, j + 1), (double)Z(ip2, j + 1), dx);
+    double y4 = d_cubic((double)Z(im1, j + 2), (double)Z(i, j + 2), (double)Z(ip1, j + 2), (double)Z(ip2, j + 2), dx);
+    return (float)d_cubic(y1, y2, y3, y4, dy);
+}
+/* ez_rgdint_3_nw.inc:20-77 */
+template <class A> __device__ float p_rgdint_3_nw(const A &Z, float px, float py, int ni, int j1, int j2)
+{
+    int i = min(ni - 2, max(2, (int)px));
+    int j = min(j2 - 2, max(j1 + 1, (int)py));
+    return cubic_rows(Z, i - 1, i, i + 1, i + 2, j, (double)(px - (float)i), (double)(py - (float)j));
+}
+__device__ __forceinline__ void wrap_cols_regular(int ni, int wrap, int limite, int &i, int &im1, int &ip1, int &ip2)
+{   /* ez_rgdint_3_w.inc:72-90 (literal, including the wrap==1 remaps) */
+    im1 = (limite + i - 1) % limite; ip1 = (limite + i + 1) % limite; ip2 = (limite + i + 2) % limite;
+    if (im1 == 0) im1 = ni;
+    if (i == 0) i = ni;
+    if (ip1 == 0) ip1 = ni;
+    if (ip2 == 0) ip2 = ni;
+    if (wrap == 1) { if (ip2 == ni) ip2 = 2; if (im1 == ni) im1 = ni - 1; }
+}
+/* ez_rgdint_3_w.inc:20-108 (nnc = 0), ez_rgdint_3_wnnc.inc:20-107 (nnc = 1) */
+template <class A> __device__ float p_rgdint_3_w(const A &Z, float px, float py, int ni, int j1, int j2, int wrap, int nnc)
+{
+    int limite = ni + 2 - wrap;
+    int i = min(ni - 2 + wrap, max(1, max(2 - wrap, (int)px)));
+    int j = min(j2 - 2, max(j1 + 1, (int)py));
+    int im1, ip1, ip2;
+    bool seam = nnc ? ((wrap > 0 && i <= 1) || i >= (ni - 1)) : (wrap > 0);
+    if (seam) wrap_cols_regular(ni, wrap, limite, i, im1, ip1, ip2);
+    else { im1 = i - 1; ip1 = i + 1; ip2 = i + 2; }
+    return cubic_rows(Z, im1, i, ip1, ip2, j, (double)(px - (float)i), (double)(py - (float)j));
+}
+/* ez_irgdint_1_nw.inc:20-50 */
+template <class A> __device__ float p_irgdint_1_nw(const A &Z, float px, float py, const float *ax, const float *ay, int ni, int nj)
+{
+    int i = min(ni - 1, max(1, (int)px));
+    int j = min(nj - 1, max(1, (int)py));
+    double x1 = ax[i - 1], x2 = ax[i];
+    double x = (double)ax[i - 1] + (x2 - x1) * (double)(px - (float)i);
+    double y = (double)(ay[j - 1] + (ay[j] - ay[j - 1]) * (py - (float)j));
+    double dx = (x - x1) / (x2 - x1);
+    double dy = (y - (double)ay[j - 1]) / (double)(ay[j] - ay[j - 1]);
+    double y1 = d_zlin((double)Z(i, j), (double)Z(i + 1, j), dx);
+    double y2 = d_zlin((double)Z(i, j + 1), (double)Z(i + 1, j + 1), dx);
+    return (float)d_zlin(y1, y2, dy);
+}
+/* ez_irgdint_1_w.inc:20-64 (ay indexed from j1) */
+template <class A> __device__ float p_irgdint_1_w(const A &Z, float px, float py, const float *ax, const float *ay, int ni, int j1, int j2, int wrap)
+{
+    int limite = ni + 2 - wrap;
+    int i = min(ni - 2 + wrap, max(1, (int)px));
+    int j = min(j2 - 1, max(j1 + 1, (int)py));
+    if (j < 0) j = j - 1;
+    int ip1 = i + 1;
+    double x1 = ax[i - 1], x2 = 0.0;
+    if (ip1 <= ni) x2 = ax[ip1 - 1];
+    if (wrap > 0 && (i == (ni - 2 + wrap))) { ip1 = (limite + i + 1) % limite; x2 = (double)(ax[1] + ax[ni - 1]); }
+    float ayj = ay[j - j1], ayj1 = ay[j + 1 - j1];
+    double x = x1 + (x2 - x1) * (double)(px - (float)i);
+    double y = (double)(ayj + (ayj1 - ayj) * (py - (float)j));
+    double dx = (x - x1) / (x2 - x1);
+    double dy = (y - (double)ayj) / (double)(ayj1 - ayj);
+    double y1 = d_zlin((double)Z(i, j), (double)Z(ip1, j), dx);
+    double y2 = d_zlin((double)Z(i, j + 1), (double)Z(ip1, j + 1), dx);
+    return (float)d_zlin(y1, y2, dy);
+}
+/* ez_irgdint_3_nw.inc:20-168: the statement functions are REAL there (results rounded to float) */
+template <class A> __device__ float p_irgdint_3_nw(const A &Z, float px, float py, const float *ax, const float *ay,
+                                                   const float *cx, const float *cy, int i1, int i2, int j1, int j2)
+{
+    const int ni = i2 - i1 + 1, nnj = j2 - j1 + 1;
+#define RF(e) ((double)(float)(e))
+    int i = min(i2 - 2, max(i1 + 1, (int)px));
+    int j = min(j2 - 2, max(j1 + 1, (int)py));
+    const float *a = ax - i1, *b = ay - j1;
+    double x = (double)(a[i] + (a[i + 1] - a[i]) * (px - (float)i));
+    double y = (double)(b[j] + (b[j + 1] - b[j]) * (py - (float)j));
+    double x1 = a[i - 1], x2 = a[i], x3 = a[i + 1];
+    double y1 = b[j - 1], y2 = b[j], y3 = b[j + 1];
+    double c1 = cx[i - i1], c2 = cx[ni + i - i1], c3 = cx[2 * ni + i - i1], c4 = cx[3 * ni + i - i1], c5 = cx[4 * ni + i - i1], c6 = cx[5 * ni + i - i1];
+    double bb[4];
+    for (int r = 0; r < 4; r++) {
+        int jj = j - 1 + r;
+        double z1 = Z(i - 1, jj), z2 = Z(i, jj), z3 = Z(i + 1, jj), z4 = Z(i + 2, jj);
+        double a2 = RF(d_fa2(c1, z1, z2));
+        double a3 = RF(d_fa3(c1, c2, c3, z1, z2, z3));
+        double a4 = RF(d_fa4(c1, c2, c3, c4, c5, c6, z1, z2, z3, z4));
+        bb[r] = RF(d_fa(z1, a2, a3, a4, x, x1, x2, x3));
+    }
+    double d1 = cy[j - j1], d2 = cy[nnj + j - j1], d3 = cy[2 * nnj + j - j1], d4 = cy[3 * nnj + j - j1], d5 = cy[4 * nnj + j - j1], d6 = cy[5 * nnj + j - j1];
+    double b12 = RF(d_fa2(d1, bb[0], bb[1]));
+    double b13 = RF(d_fa3(d1, d2, d3, bb[0], bb[1], bb[2]));
+    double b14 = RF(d_fa4(d1, d2, d3, d4, d5, d6, bb[0], bb[1], bb[2], bb[3]));
+    return (float)d_fa(bb[0], b12, b13, b14, y, y1, y2, y3);
+#undef RF
+}
+/* seam logic of ez_irgdint_3_w.inc:100-156 / ez_irgdint_3_wnnc.inc:100-156 */
+__device__ __forceinline__ void irr_cols(const float *ax, int ni, int wrap, int i, int ip2_wrap1,
+                                         int &im1, int &ip1, int &ip2, float &x1, float &x2, float &x3, float &x4)
+{
+#define AX(k) ax[(k) - 1]
+    im1 = i - 1; ip1 = i + 1; ip2 = i + 2;
+    x1 = x2 = x3 = x4 = 0.f;
+    if (wrap == 1 && (i <= 1 || i >= (ni - wrap))) {
+        if (i == 1) { im1 = ni - 1; ip1 = 2; ip2 = 3; x1 = AX(ni - 1) - 360.0f; x2 = AX(1); x3 = AX(2); x4 = AX(3); }
+        if (i == (ni - 1)) { im1 = ni - 2; ip1 = ni; ip2 = ip2_wrap1; x1 = AX(ni - 2); x2 = AX(ni - 1); x3 = AX(ni); x4 = AX(2) + 360.0f; }
+    } else if (wrap == 2 && (i <= 1 || i > (ni - wrap))) {
+        if (i == 1) { im1 = ni; ip1 = 2; ip2 = 3; x1 = AX(ni) - 360.0f; x2 = AX(1); x3 = AX(2); x4 = AX(3); }
+        if (i == (ni - 1)) { im1 = ni - 2; ip1 = ni; ip2 = 1; x1 = AX(ni - 2); x2 = AX(ni - 1); x3 = AX(ni); x4 = AX(1) + 360.0f; }
+        if (i == ni) { im1 = ni - 1; ip1 = 1; ip2 = 2; x1 = AX(ni - 1); x2 = AX(ni); x3 = AX(1) + 360.0f; x4 = AX(2) + 360.0f; }
+    } else {
+        x1 = AX(im1); x2 = AX(i); x3 = AX(ip1); x4 = AX(ip2);
+    }
+#undef AX
+}
+/* ez_irgdint_3_w.inc:20-235 */
+template <class A> __device__ float p_irgdint_3_w(const A &Z, float px, float py, const float *ax, const float *ay,
+                                                  const float *cx, const float *cy, int ni, int j1, int j2, int wrap)
+{
+    const int nnj = j2 - j1 + 1;
+    int i = min(ni - 2 + wrap, max(1, max(2 - wrap, (int)px)));
+    int j = min(j2 - 2, max(j1 + 1, (int)py));
+    int im1, ip1, ip2; float x1, x2, x3, x4;
+    irr_cols(ax, ni, wrap, i, 2, im1, ip1, ip2, x1, x2, x3, x4);
+    const float *b = ay - j1;
+    double x = (double)(x2 + (x3 - x2) * (px - (float)i));
+    double y = (double)(b[j] + (b[j + 1] - b[j]) * (py - (float)j));
+    float y1 = b[j - 1], y2 = b[j], y3 = b[j + 1];
+    double c1 = cx[i - 1], c2 = cx[ni + i - 1], c3 = cx[2 * ni + i - 1], c4 = cx[3 * ni + i - 1], c5 = cx[4 * ni + i - 1], c6 = cx[5 * ni + i - 1];
+    double bb[4];
+    for (int r = 0; r < 4; r++) {
+        int jj = j - 1 + r;
+        double z1 = Z(im1, jj), z2 = Z(i, jj), z3 = Z(ip1, jj), z4 = Z(ip2, jj);
+        double a2 = d_fa2(c1, z1, z2);
+        double a3 = d_fa3(c1, c2, c3, z1, z2, z3);
+        double a4 = d_fa4(c1, c2, c3, c4, c5, c6, z1, z2, z3, z4);
+        bb[r] = d_fa(z1, a2, a3, a4, x, (double)x1, (double)x2, (double)x3);
+    }
+    double d1 = cy[j - j1], d2 = cy[nnj + j - j1], d3 = cy[2 * nnj + j - j1], d4 = cy[3 * nnj + j - j1], d5 = cy[4 * nnj + j - j1], d6 = cy[5 * nnj + j - j1];
+    double b12 = d_fa2(d1, bb[0], bb[1]);
+    double b13 = d_fa3(d1, d2, d3, bb[0], bb[1], bb[2]);
+    double b14 = d_fa4(d1, d2, d3, d4, d5, d6, bb[0], bb[1], bb[2], bb[3]);
+    return (float)d_fa(bb[0], b12, b13, b14, y, (double)y1, (double)y2, (double)y3);
+}
+/* ez_irgdint_3_wnnc.inc:20-246 (ay: 4-entry strip latitudes indexed from j1) */
+template <class A> __device__ float p_irgdint_3_wnnc(const A &Z, float px, float py, const float *ax, const float *ay4,
+                                                     int ni, int j1, int j2, int wrap)
+{
+    int i = min(ni - 2 + wrap, max(1, max(2 - wrap, (int)px)));
+    int j = min(j2 - 2, max(j1 + 1, (int)py));
+    int im1, ip1, ip2; float fx1, fx2, fx3, fx4;
+    irr_cols(ax, ni, wrap, i, 1, im1, ip1, ip2, fx1, fx2, fx3, fx4);
+    double x1 = fx1, x2 = fx2, x3 = fx3, x4 = fx4;
+    const float *b = ay4 - j1;
+    double x = x2 + (x3 - x2) * (double)(px - (float)i);
+    double y = (double)(b[j] + (b[j + 1] - b[j]) * (py - (float)j));
+    double c1 = 1.0 / (x2 - x1), c2 = 1.0 / (x3 - x1), c3 = 1.0 / (x3 - x2);
+    double c4 = 1.0 / (x4 - x1), c5 = 1.0 / (x4 - x2), c6 = 1.0 / (x4 - x3);
+    double y1 = b[j - 1], y2 = b[j], y3 = b[j + 1], y4 = b[j + 2];
+    double bb[4];
+    for (int r = 0; r < 4; r++) {
+        int jj = j - 1 + r;
+        double z1 = Z(im1, jj), z2 = Z(i, jj), z3 = Z(ip1, jj), z4 = Z(ip2, jj);
+        double a2 = d_fa2(c1, z1, z2);
+        double a3 = d_fa3(c1, c2, c3, z1, z2, z3);
+        double a4 = d_fa4(c1, c2, c3, c4, c5, c6, z1, z2, z3, z4);
+        bb[r] = d_fa(z1, a2, a3, a4, x, x1, x2, x3);
+    }
+    double d1 = 1.0 / (y2 - y1), d2 = 1.0 / (y3 - y1), d3 = 1.0 / (y3 - y2);
+    double d4 = 1.0 / (y4 - y1), d5 = 1.0 / (y4 - y2), d6 = 1.0 / (y4 - y3);
+    double b12 = d_fa2(d1, bb[0], bb[1]);
+    double b13 = d_fa3(d1, d2, d3, bb[0], bb[1], bb[2]);
+    double b14 = d_fa4(d1, d2, d3, d4, d5, d6, bb[0], bb[1], bb[2], bb[3]);
+    return (float)d_fa(bb[0], b12, b13, b14, y, y1, y2, y3);
+}
+
+/* c_gdinterp dispatch (src/interp/gdinterp.c:133-309) for one point */
+template <class A>
+__device__ float gdinterp_point(const ezhip_pts_plan &p, const A &Z, int degree, float px, float py)
+{
+    if (p.irregular) {
+        switch (degree) {
+        case 0: return p_rgdint_0(Z, px, py, p.ni, p.j1, p.j2);
+        case 1: return p.wrap == 0 ? p_irgdint_1_nw(Z, px, py, p.ax, p.ay, p.ni, p.nj)
+                                   : p_irgdint_1_w(Z, px, py, p.ax, p.ay, p.ni, p.j1, p.j2, p.wrap);
+        default: return p.wrap == 0 ? p_irgdint_3_nw(Z, px, py, p.ax, p.ay, p.ncx, p.ncy, p.i1, p.i2, p.j1, p.j2)
+                                    : p_irgdint_3_w(Z, px, py, p.ax, p.ay, p.ncx, p.ncy, p.ni, p.j1, p.j2, p.wrap);
+        }
+    }
+    switch (degree) {
+    case 0: return p_rgdint_0(Z, px, py, p.ni, p.j1, p.j2);
+    case 1: return p.wrap == 2 ? p_rgdint_1_w(Z, px, py, p.ni, p.j1, p.j2, p.wrap)
+                               : p_rgdint_1_nw(Z, px, py, p.ni, p.j1, p.j2);
+    default: return p.wrap == 0 ? p_rgdint_3_nw(Z, px, py, p.ni, p.j1, p.j2)
+                                : p_rgdint_3_w(Z, px, py, p.ni, p.j1, p.j2, p.wrap, 0);
+    }
+}
+
+/* polar strip interpolation of one point: ez_corrval_aunord.c:28-117 / ez_corrval_ausud.c:30-137 */
+template <class A>
+__device__ float strip_point(const ezhip_pts_plan &p, const A &Z, int north, float px, float py)
+{
+    const int j1s = north ? p.j2 - 2 : p.j1 - 1, j2s = j1s + 3;
+    if (p.degree == 3) {
+        if (p.irregular) return p_irgdint_3_wnnc(Z, px, py, p.ax, north ? p.ay4_n : p.ay4_s, p.ni, j1s, j2s, p.wrap);
+        return p_rgdint_3_w(Z, px, py, p.ni, j1s, j2s, p.wrap, 1);
+    }
+    if (north) {
+        /* ty = y - (j2 - 3): strip rows renumbered 1..4.  FieldAcc rows are absolute, so evaluate with
+         * absolute row bounds j2-2 .. j2+1 and shift the fractional coordinate back. */
+        float ty = (float)((double)py - (1.0 * (p.j2 - 3)));
+        /* rows 1..4 of the strip == absolute rows j2-2..j2+1: remap through an offset accessor */
+        struct Off { const A &Z; int off; __device__ float operator()(int i, int j) const { return Z(i, j + off); } } ZO{Z, p.j2 - 3};
+        if (p.degree == 1) return p_rgdint_1_w(ZO, px, ty, p.ni, 1, 4, p.wrap);
+        return p_rgdint_0(ZO, px, ty, p.ni, 1, 4);
+    }
+    if (p.degree == 1) return p_rgdint_1_w(Z, px, py, p.ni, j1s, j2s, p.wrap);
+    return p_rgdint_0(Z, px, py, p.ni, j1s, j2s);
+}
+
+__global__ __launch_bounds__(256) void k_pts(ezhip_pts_plan p, float *__restrict__ zout, const float *__restrict__ zin,
+                                             const float *__restrict__ xs, const float *__restrict__ ys, int npts)
+{
+    int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= npts) return;
+    const float px = xs[n], py = ys[n];
+    FieldAcc Z;
+    Z.z = zin; Z.ni = p.ni; Z.j1 = p.j1; Z.j2 = p.j2;
+    Z.pole_n = 0.f; Z.pole_s = 0.f; Z.prow_n = nullptr; Z.prow_s = nullptr;
+    float out;
+    if (p.zones == 2) {                                   /* EZ_EXTRAP: ez_defzone_dehors.c:63-74 */
+        int ix = (int)((double)px + 0.5), iy = (int)((double)py + 0.5);
+        bool dehors = ix < 1 || iy < 1 || ix > p.ni || iy > p.nj;
+        if (!dehors) out = gdinterp_point(p, Z, p.degree, px, py);
+        else if (p.degre_extrap >= 4) out = *p.fill;
+        else out = gdinterp_point(p, Z, p.degre_extrap, px, py);
+    } else if (p.zones == 1) {                            /* EZ_NO_EXTRAP */
+        bool au_n = (int)py > (p.j2 - 2);                 /* ez_defzone_nord.c:41-49 */
+        bool au_s = (int)py < (p.j1 + 1);                 /* ez_defzone_sud.c:42-50 */
+        bool po_n = fabs((double)(py - p.ypole_n)) < 1.0e-3;
+        bool po_s = fabs((double)(py - p.ypole_s)) < 1.0e-3;
+        if (p.vector_mode) {
+            Z.prow_n = p.pole_row_n; Z.prow_s = p.pole_row_s;
+            /* ez_corrvec.c:24-48: strips only (pole zones re-run the same strips) */
+            if (au_s) out = strip_point(p, Z, 0, px, py);
+            else if (au_n) out = strip_point(p, Z, 1, px, py);
+            else out = gdinterp_point(p, Z, p.degree, px, py);
+        } else {
+            Z.pole_n = p.polevals[0]; Z.pole_s = p.polevals[1];
+            /* ez_corrval.c:121-145 applies AU_NORD, AU_SUD, POLE_NORD, POLE_SUD in that order: last writer wins */
+            if (po_s) out = Z.pole_s;
+            else if (po_n) out = Z.pole_n;
+            else if (au_s) out = strip_point(p, Z, 0, px, py);
+            else if (au_n) out = strip_point(p, Z, 1, px, py);
+            else out = gdinterp_point(p, Z, p.degree, px, py);
+        }
+    } else {
+        out = gdinterp_point(p, Z, p.degree, px, py);
+    }
+    zout[n] = out;
+}
+
+extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin,
+                                const float *d_x, const float *d_y, int npts)
+{
+    if (npts <= 0) return 0;
+    hipLaunchKernelGGL(k_pts, dim3((npts + 255) / 256), dim3(256), 0, g_stream, *plan, d_zout, d_zin, d_x, d_y, npts);
+    return LAUNCH_CHECK("k_pts");
+}
+
+/* ===================================================================================== */
+/* small reductions                                                                         */
+/* ===================================================================================== */
+__global__ __launch_bounds__(256) void k_polevals(float *out2, const float *zin, int ni, int nj, int weighted, const float *ax)
+{
+    __shared__ double lds4[4];
+    const float *row = blockIdx.x == 0 ? zin + (size_t)(nj - 1) * ni : zin;
+    float v = block_poleval(row, ni, weighted, ax, lds4);
+    if (threadIdx.x == 0) out2[blockIdx.x] = v;
+}
+extern "C" int ezhip_polevals(float *d_out2, const float *d_zin, int ni, int nj, int weighted, const float *d_ax)
+{
+    hipLaunchKernelGGL(k_polevals, dim3(2), dim3(256), 0, g_stream, d_out2, d_zin, ni, nj, weighted, d_ax);
+    return LAUNCH_CHECK("k_polevals");
+}
+
+/* float min/max through order-preserving unsigned keys (no NaN handling: the reference has none) */
+__device__ __forceinline__ unsigned f2key(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__global__ __launch_bounds__(256) void k_minmax(unsigned *keys2, const float *z, size_t n)
+{
+    unsigned kmin = 0xffffffffu, kmax = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned k = f2key(z[i]);
+        kmin = min(kmin, k); kmax = max(kmax, k);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (unsigned)__shfl_down((int)kmin, off, 64));
+        kmax = max(kmax, (unsigned)__shfl_down((int)kmax, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&keys2[0], kmin); atomicMax(&keys2[1], kmax); }
+}
+/* ez_corrval.c:60-87 fill value from min/max */
+__global__ void k_fill(float *fill, const unsigned *keys2, int degre_extrap, float valeur, int vector_mode)
+{
+    float vmin = key2f(keys2[0]), vmax = key2f(keys2[1]);
+    float f = 0.0f;
+    if (!vector_mode) {
+        if (degre_extrap == 4) f = (float)((double)vmax + 0.05 * (double)(vmax - vmin));
+        else if (degre_extrap == 5) f = (float)((double)vmin - 0.05 * (double)(vmax - vmin));
+        else if (degre_extrap == 6) f = valeur;
+    }
+    *fill = f;
+}
+extern "C" int ezhip_fill_value(float *d_fill, const float *d_zin, size_t n, int degre_extrap, float valeur, int vector_mode)
+{
+    /* d_fill points at float[4]: [0] = fill, [2..3] reused as the two uint keys */
+    unsigned *keys = (unsigned *)(d_fill + 2);
+    unsigned init[2] = {0xffffffffu, 0u};
+    if (set_err(hipMemcpyAsync(keys, init, sizeof(init), hipMemcpyHostToDevice, g_stream), "fill init")) return -1;
+    if (!vector_mode && (degre_extrap == 4 || degre_extrap == 5)) {
+        int nb = (int)((n + 255) / 256); if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(256), 0, g_stream, keys, d_zin, n);
+    }
+    hipLaunchKernelGGL(k_fill, dim3(1), dim3(1), 0, g_stream, d_fill, keys, degre_extrap, valeur, vector_mode);
+    return LAUNCH_CHECK("k_fill");
+}
+
+/* ===================================================================================== */
+/* k_locate                                                                                 */
+/* ===================================================================================== */
+__device__ __forceinline__ int d_cherche(float val, const float *tab, int n)
+{   /* ez_cherche.inc:53-69 */
+    int debut = 1, fin = n;
+    int milieu = (int)((float)(debut + fin) * 0.5f);
+    while (milieu != debut) {
+        if (val <= tab[milieu - 1]) fin = milieu; else debut = milieu;
+        milieu = (int)((float)(debut + fin) * 0.5f);
+    }
+    return milieu;
+}
+
+/* true (lon,lat) -> rotated (lon,lat): ez_lac.inc + mxm + ez_cal.inc with matrix r */
+__device__ __forceinline__ void d_rotate(const float *r, float lon, float lat, float &lon_o, float &lat_o)
+{
+    const float dar = (float)(3.14159274101257324 / 180.0);     /* acos(-1.)/180. evaluated in REAL */
+    float cosdar = cosf(dar * lat);
+    float c0 = cosdar * cosf(dar * lon), c1 = cosdar * sinf(dar * lon), c2 = sinf(dar * lat);
+    float q[3];
+    for (int i = 0; i < 3; i++) { float s = 0.0f; s = s + r[i] * c0; s = s + r[3 + i] * c1; s = s + r[6 + i] * c2; q[i] = s; }
+    const float rad = (float)(180.0 / 3.14159274101257324);
+    lat_o = asinf(fmaxf(-1.00f, fminf(1.0f, q[2]))) * rad;
+    float lo = atan2f(q[1], q[0]) * rad;
+    lo = fmodf(lo, 360.0f);
+    if (lo < 0.0f) lo = lo + 360.0f;
+    lon_o = lo;
+}
+
+__global__ __launch_bounds__(256) void k_locate(ezhip_locate_plan p, float *__restrict__ xo, float *__restrict__ yo,
+                                                const float *__restrict__ lats, const float *__restrict__ lons,
+                                                int ni_dst, int nj_dst, int separable)
+{
+    size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t npts = (size_t)ni_dst * nj_dst;
+    if (n >= npts) return;
+    float lat, lon;
+    if (separable) { lat = lats[n / ni_dst]; lon = lons[n % ni_dst]; }
+    else { lat = lats[n]; lon = lons[n]; }
+    float px, py;
+    if (p.kind == 0 || p.kind == 3) {
+        if (p.kind == 3) { float lo, la; d_rotate(p.r, lon, lat, lo, la); lon = lo; lat = la; }
+        if (p.lon_fix == 1) {                               /* ez_ll2rgd.inc:137-145 */
+            if (lon < p.lon0) lon = lon + 360.0f;
+            if (lon > (p.lon0 + (float)p.ni * p.dlon)) lon = lon - 360.0f;
+        } else if (p.lon_fix == 2) {
+            if (lon < 0.0f) lon = lon + 360.0f;
+        }
+        if (lon < 0.0f) lon = lon + 360.0f;                 /* ez_llll2gd.inc:40-45 (lonref 0) */
+        px = (lon - p.lon0) / p.dlon + 1.0f;
+        py = (lat - p.lat0) / p.dlat + 1.0f;
+    } else {
+        if (p.kind == 1) {                                  /* ez_ll2igd.inc:55-66 */
+            if (p.lonref == -180.0f) { if (lon > 180.0f) lon = lon - 360.0f; }
+            else { if (lon < 0.0f) lon = lon + 360.0f; }
+            px = (lon - p.lon0) / p.dlon + 1.0f;
+            py = (lat - p.lat0) / p.dlat + 1.0f;
+            px = px - 1.0f; py = py - 1.0f;
+        } else {                                            /* ez_ll2igd.inc:69-72 */
+            d_rotate(p.r, lon, lat, px, py);
+        }
+        int indx = d_cherche(px, p.ax, p.ni);               /* ez_ll2igd.inc:74-85 */
+        int indy = d_cherche(py, p.ay, p.nj);
+        if (indx >= p.ni) indx = p.ni - 1;
+        if (indy >= p.nj) indy = p.nj - 1;
+        px = (float)indx + (px - p.ax[indx - 1]) / (p.ax[indx] - p.ax[indx - 1]);
+        py = (float)indy + (py - p.ay[indy - 1]) / (p.ay[indy] - p.ay[indy - 1]);
+    }
+    xo[n] = px; yo[n] = py;
+}
+
+extern "C" int ezhip_locate(const ezhip_locate_plan *plan, float *d_x, float *d_y,
+                            const float *d_lat, const float *d_lon, int ni_dst, int nj_dst, int separable)
+{
+    size_t npts = (size_t)ni_dst * nj_dst;
+    if (!npts) return 0;
+    hipLaunchKernelGGL(k_locate, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, g_stream, *plan, d_x, d_y, d_lat, d_lon, ni_dst, nj_dst, separable);
+    return LAUNCH_CHECK("k_locate");
+}
+
+/* ===================================================================================== */
+/* k_wind_rotate                                                                            */
+/* ===================================================================================== */
+__global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *__restrict__ uu, float *__restrict__ vv,
+                                                     const float *__restrict__ lats, const float *__restrict__ lons,
+                                                     int ni_dst, int nj_dst)
+{
+    const float RDTODG = 57.295779513082f, DGTORD = 1.7453292519943e-2f;
+    size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t npts = (size_t)ni_dst * nj_dst;
+    if (n >= npts) return;
+    float lat, lon;
+    if (p.separable) { lat = lats[n / ni_dst]; lon = lons[n % ni_dst]; }
+    else { lat = lats[n]; lon = lons[n]; }
+    float u = uu[n], v = vv[n];
+    if (p.src_rotated) {                                    /* c_ezllwfgfw, ez_llwfgfw.c:38-73 */
+        float lon_r, lat_r;
+        d_rotate(p.r, lon, lat, lon_r, lat_r);
+        const double dar = (double)(float)(3.14159274101257324 / 180.0);
+        double a = sin(dar * (double)lon_r), b = cos(dar * (double)lon_r);
+        double c = sin(dar * (double)lat_r), d = cos(dar * (double)lat_r);
+        float x0 = (float)(-((double)u * a) - ((double)v * b * c));     /* ez_uvacart.inc */
+        float x1 = (float)(((double)u * b) - ((double)v * a * c));
+        float x2 = (float)((double)v * d);
+        float q[3];
+        for (int i = 0; i < 3; i++) { float s = 0.0f; s = s + p.ri[i] * x0; s = s + p.ri[3 + i] * x1; s = s + p.ri[6 + i] * x2; q[i] = s; }
+        double aa = cos(dar * (double)lon), bb = sin(dar * (double)lon);   /* ez_cartauv.inc at TRUE lon/lat */
+        double ee = cos(dar * (double)lat), ff = sin(dar * (double)lat);
+        u = (float)(((double)q[1] * aa) - ((double)q[0] * bb));
+        double cc = ((double)q[0] * aa) + ((double)q[1] * bb);
+        double dd = sqrt(cc * cc + (double)(q[2] * q[2]));
+        double sg = ((double)q[2] * ee) - (cc * ff);
+        v = (float)(sg >= 0.0 ? fabs(dd) : -fabs(dd));
+    }
+    /* ez_llwfgdw.inc:108-127 ('L'/A/B/G): components -> speed, direction */
+    float spd = sqrtf(u * u + v * v), dir;
+    if (spd == 0.0f) dir = 0.0f;
+    else if (u == 0.0f) dir = (v >= 0.0f) ? 180.0f : 0.0f;
+    else dir = 270.0f - RDTODG * atan2f(v, u);
+    dir = fmodf(fmodf(dir, 360.0f) + 360.0f, 360.0f);
+    /* ez_gdwfllw.inc:118-129 ('L'/A/B/G): speed, direction -> target components */
+    float psi = 270.0f - dir;
+    uu[n] = cosf(psi * DGTORD) * spd;
+    vv[n] = sinf(psi * DGTORD) * spd;
+}
+
+extern "C" int ezhip_wind_rotate(const ezhip_wind_plan *plan, float *d_uu, float *d_vv,
+                                 const float *d_lat, const float *d_lon, int ni_dst, int nj_dst)
+{
+    size_t npts = (size_t)ni_dst * nj_dst;
+    if (!npts) return 0;
+    hipLaunchKernelGGL(k_wind_rotate, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, g_stream, *plan, d_uu, d_vv, d_lat, d_lon, ni_dst, nj_dst);
+    return LAUNCH_CHECK("k_wind_rotate");
+}

@@ -1,0 +1,137 @@
+/*
+ * ezhip_shim.h -- internal boundary between the C host front-end (ez_host.c, pack_host.c) and the
+ * HIP translation units (ez_kernels.hip, pack_kernels.hip).  Plain C types only.
+ *
+ * The host front-end never includes a HIP header: device memory, streams and kernel launches are
+ * reached exclusively through these functions ("thin HIP C-ABI shim", BASELINE.json north_star).
+ */
+#ifndef EZHIP_SHIM_H
+#define EZHIP_SHIM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime plumbing ---------------------------------------------------------------- */
+int    ezhip_runtime_ok(void);                       /* 1 if a HIP device is usable, else 0 */
+const char *ezhip_last_error(void);
+void  *ezhip_malloc(size_t nbytes);                  /* NULL on failure */
+void   ezhip_free(void *d);
+int    ezhip_h2d(void *d, const void *h, size_t nbytes);     /* async on the current stream */
+int    ezhip_d2h(void *h, const void *d, size_t nbytes);     /* async on the current stream */
+int    ezhip_d2d(void *dst, const void *src, size_t nbytes);
+int    ezhip_memset(void *d, int v, size_t nbytes);
+int    ezhip_sync(void);                             /* synchronise the current stream */
+void   ezhip_set_stream(void *hip_stream);           /* thread-local; NULL = default stream */
+void  *ezhip_get_stream(void);
+void  *ezhip_host_alloc(size_t nbytes);              /* pinned host staging */
+void   ezhip_host_free(void *p);
+
+/* ---- interpolation plans --------------------------------------------------------------- */
+
+/* row/column flags of the separable plan */
+enum {
+    EZF_MAIN   = 0,
+    EZF_DEHORS = 1          /* column or row lies outside the source grid: write the fill value */
+};
+
+/* A "special" target row: every tap names a source row (>= 0) or a synthetic pole row. */
+enum { EZ_ROW_POLE_N = -1, EZ_ROW_POLE_S = -2 };
+
+typedef struct {
+    int    row;             /* target row (0-based) */
+    int    kind;            /* 0 = strip interpolation, 1 = whole row := north pole value,
+                               2 = whole row := south pole value, 3 = whole row := fill value */
+    int    tap[4];          /* source rows / EZ_ROW_POLE_* */
+    double w[4];            /* cubic: 4 weights; linear: w[0] = dy; nearest: unused */
+} ezhip_special_row;
+
+/*
+ * Separable plan ("mode A"): source and target are both rectilinear in lat/lon, so the located
+ * x depends only on the target column and y only on the target row.  All arrays are DEVICE
+ * pointers, SoA with leading dimension ni_dst (columns) or nj_dst (rows).
+ */
+typedef struct {
+    int degree;                       /* 0 nearest, 1 linear, 3 cubic */
+    int ni_src, nj_src, ni_dst, nj_dst;
+    const int    *cidx;               /* [4][ni_dst] 0-based source column of each tap */
+    const double *cw;                 /* [4][ni_dst] cubic weights | linear: cw[0][] = dx */
+    const int    *cidx_s;             /* same, for the polar-strip kernels (wnnc / regular forms) */
+    const double *cw_s;
+    const unsigned char *cflag;       /* [ni_dst] EZF_* */
+    const int    *rbase;              /* [nj_dst] 0-based first source row of the taps */
+    const double *rw;                 /* [4][nj_dst] cubic weights | linear: rw[0][] = dy */
+    const unsigned char *rflag;       /* [nj_dst] 0 = main row, 1 = handled as a special row */
+    const ezhip_special_row *special; /* [n_special] */
+    int n_special;
+    int pole_weighted;                /* 1: Z-on-E trapezoid pole value (needs ax) */
+    const float *ax;                  /* device source x axis (pole_weighted only) */
+    int vector_mode;                  /* 1: strip pole rows come from pole_rows_n/s instead of a scalar */
+    const float *pole_row_n, *pole_row_s;   /* [ni_src] synthetic polar wind rows (vector mode) */
+    const float *fill;                /* device scalar written to DEHORS points (may be NULL) */
+} ezhip_sep_plan;
+
+int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin);
+
+/*
+ * Generic per-point plan ("mode B"): arbitrary located coordinates.  Restates the reference's
+ * leaf kernel for the grid kind / degree / wrap, point by point, including zone handling.
+ */
+typedef struct {
+    int degree;                       /* 0, 1, 3 */
+    int irregular;                    /* 1: Z/#/G source (ax, ay, ncx, ncy tables), 0: regular */
+    int ni, nj, i1, i2, j1, j2, wrap; /* source geometry, 1-based bounds as in the reference */
+    const float *ax, *ay, *ncx, *ncy; /* device; NULL for regular sources */
+    /* zone handling (0 = none: c_gdxysint semantics) */
+    int zones;                        /* 0 none, 1 EZ_NO_EXTRAP (polar zones), 2 EZ_EXTRAP (DEHORS) */
+    int degre_extrap;                 /* used when zones == 2 */
+    float ypole_n, ypole_s;
+    float ay4_n[4], ay4_s[4];         /* strip latitudes (irregular cubic) */
+    int pole_weighted;
+    int vector_mode;
+    const float *pole_row_n, *pole_row_s;
+    const float *fill;                /* device scalar */
+    const float *polevals;            /* device float[2] = {north, south}; computed by ezhip_polevals */
+} ezhip_pts_plan;
+
+int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin,
+                     const float *d_x, const float *d_y, int npts);
+
+/* pole values {north, south} of a source field -> device float[2] */
+int ezhip_polevals(float *d_out2, const float *d_zin, int ni, int nj, int weighted, const float *d_ax);
+/* min / max of a field -> device float[2]; then fill = f(min,max) on device */
+int ezhip_fill_value(float *d_fill, const float *d_zin, size_t n, int degre_extrap, float valeur, int vector_mode);
+
+/* ---- locate ------------------------------------------------------------------------------ */
+typedef struct {
+    int kind;                         /* 0: regular lat-lon (llll2gd), 1: irregular axes on 'L' ref (G, Z/L),
+                                         2: irregular axes on rotated 'E' ref (Z/E), 3: regular rotated 'E' */
+    int ni, nj;
+    float lat0, lon0, dlat, dlon;     /* kind 0/3: llll2gd parameters; kind 1: reference-grid decode */
+    float lonref;                     /* kind 1: 0 or -180 */
+    int   lon_fix;                    /* kind 0: 1 = 'L' wrap fix (lon0, ni*dlon), 2 = "<0 -> +360" */
+    float r[9];                       /* kind 2/3: rotation matrix (Fortran order) */
+    const float *ax, *ay;             /* device axes (kind 1/2) */
+} ezhip_locate_plan;
+
+/* separable target: lat1d[nj_dst], lon1d[ni_dst] (device); full target: lat2d/lon2d [npts] */
+int ezhip_locate(const ezhip_locate_plan *plan, float *d_x, float *d_y,
+                 const float *d_lat, const float *d_lon, int ni_dst, int nj_dst, int separable);
+
+/* ---- winds ------------------------------------------------------------------------------- */
+typedef struct {
+    int src_rotated;                  /* 1: source is E / Z-on-E: rotate through ri */
+    float r[9], ri[9];
+    int separable;                    /* target lat/lon given as 1-D arrays */
+} ezhip_wind_plan;
+
+/* in place on (uu, vv): source-grid components -> target ('L'-like) grid components */
+int ezhip_wind_rotate(const ezhip_wind_plan *plan, float *d_uu, float *d_vv,
+                      const float *d_lat, const float *d_lon, int ni_dst, int nj_dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

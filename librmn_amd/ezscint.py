@@ -1,0 +1,163 @@
+"""Python mirror of librmn's EZSCINT C interface (src/PUBLIC_INCLUDES/rmn/ezscint.h) bound to
+librmn_ez_hip.so.  Host-pointer calls take numpy float32 arrays; ``*_dev`` calls take torch CUDA
+(ROCm) tensors or raw device pointers and enqueue on the given / current stream."""
+import ctypes
+import numpy as np
+
+from .lib import load_library
+
+_F = ctypes.POINTER(ctypes.c_float)
+_configured = False
+
+
+def _lib():
+    global _configured
+    L = load_library()
+    if not _configured:
+        i32, vp, cp = ctypes.c_int32, ctypes.c_void_p, ctypes.c_char_p
+        L.c_ezqkdef.argtypes = [i32, i32, cp, i32, i32, i32, i32, i32]
+        L.c_ezgdef_fmem.argtypes = [i32, i32, cp, cp, i32, i32, i32, i32, vp, vp]
+        L.c_ezdefset.argtypes = [i32, i32]
+        L.c_ezsetopt.argtypes = [cp, cp]
+        L.c_ezgetopt.argtypes = [cp, cp]
+        L.c_ezsetval.argtypes = [cp, ctypes.c_float]
+        L.c_ezsetival.argtypes = [cp, i32]
+        L.c_ezsint.argtypes = [vp, vp]
+        L.c_ezuvint.argtypes = [vp, vp, vp, vp]
+        L.c_gdxysint.argtypes = [vp, vp, i32, vp, vp, i32]
+        L.c_gdxysval.argtypes = [i32, vp, vp, vp, vp, i32]
+        L.c_gdxyfll.argtypes = [i32, vp, vp, vp, vp, i32]
+        L.c_gdll.argtypes = [i32, vp, vp]
+        L.c_gdgaxes.argtypes = [i32, vp, vp]
+        L.c_gdrls.argtypes = [i32]
+        L.ezhip_use_stream.argtypes = [vp]
+        L.ezhip_use_stream.restype = None
+        L.c_ezsint_dev.argtypes = [vp, vp]
+        L.c_ezuvint_dev.argtypes = [vp, vp, vp, vp]
+        L.c_gdxysint_dev.argtypes = [vp, vp, i32, vp, vp, i32]
+        L.c_gdxyfll_dev.argtypes = [i32, vp, vp, vp, vp, i32]
+        L.c_ezsint_batch_dev.argtypes = [vp, vp, i32]
+        _configured = True
+    return L
+
+
+def _np(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data
+
+
+def _dptr(t):
+    """device pointer of a torch tensor (or pass an int through)"""
+    if isinstance(t, int):
+        return t
+    assert t.is_cuda and t.is_contiguous() and t.dtype.is_floating_point and t.element_size() == 4
+    return t.data_ptr()
+
+
+def available():
+    return bool(_lib().ezhip_available())
+
+
+def ezqkdef(ni, nj, grtyp, ig1, ig2, ig3, ig4, iunit=0):
+    return _lib().c_ezqkdef(ni, nj, grtyp.encode(), ig1, ig2, ig3, ig4, iunit)
+
+
+def ezgdef_fmem(ni, nj, grtyp, grref, ig1, ig2, ig3, ig4, ax, ay):
+    ax, pax = _np(ax); ay, pay = _np(ay)
+    return _lib().c_ezgdef_fmem(ni, nj, grtyp.encode(), grref.encode(), ig1, ig2, ig3, ig4, pax, pay)
+
+
+def ezdefset(gdout, gdin):
+    return _lib().c_ezdefset(gdout, gdin)
+
+
+def ezsetopt(option, value):
+    return _lib().c_ezsetopt(option.encode(), value.encode())
+
+
+def ezgetopt(option):
+    buf = ctypes.create_string_buffer(64)
+    _lib().c_ezgetopt(option.encode(), buf)
+    return buf.value.decode()
+
+
+def ezsetval(option, value):
+    return _lib().c_ezsetval(option.encode(), float(value))
+
+
+def gdrls(gdid):
+    return _lib().c_gdrls(gdid)
+
+
+def gdgaxes(gdid, ni, nj):
+    ax = np.zeros(ni, np.float32); ay = np.zeros(nj, np.float32)
+    rc = _lib().c_gdgaxes(gdid, ax.ctypes.data, ay.ctypes.data)
+    return rc, ax, ay
+
+
+def gdll(gdid, npts):
+    lat = np.zeros(npts, np.float32); lon = np.zeros(npts, np.float32)
+    rc = _lib().c_gdll(gdid, lat.ctypes.data, lon.ctypes.data)
+    return rc, lat, lon
+
+
+def gdxyfll(gdid, lat, lon):
+    lat, plat = _np(lat); lon = np.array(lon, dtype=np.float32, copy=True)
+    x = np.zeros(lat.size, np.float32); y = np.zeros(lat.size, np.float32)
+    rc = _lib().c_gdxyfll(gdid, x.ctypes.data, y.ctypes.data, plat, lon.ctypes.data, lat.size)
+    return rc, x, y
+
+
+def ezsint(zin, nout):
+    """host-pointer c_ezsint: returns (rc, zout)"""
+    zin, pin = _np(zin)
+    zout = np.zeros(nout, np.float32)
+    rc = _lib().c_ezsint(zout.ctypes.data, pin)
+    return rc, zout
+
+
+def ezuvint(uuin, vvin, nout):
+    uuin, pu = _np(uuin); vvin, pv = _np(vvin)
+    uo = np.zeros(nout, np.float32); vo = np.zeros(nout, np.float32)
+    rc = _lib().c_ezuvint(uo.ctypes.data, vo.ctypes.data, pu, pv)
+    return rc, uo, vo
+
+
+def gdxysint(zin, gdin, x, y):
+    zin, pin = _np(zin); x, px = _np(x); y, py = _np(y)
+    zout = np.zeros(x.size, np.float32)
+    rc = _lib().c_gdxysint(zout.ctypes.data, pin, gdin, px, py, x.size)
+    return rc, zout
+
+
+def use_stream(stream_handle):
+    """hipStream_t as an integer (torch: torch.cuda.current_stream().cuda_stream); 0/None = null stream"""
+    _lib().ezhip_use_stream(ctypes.c_void_p(stream_handle or 0))
+
+
+def ezsint_dev(zout, zin):
+    return _lib().c_ezsint_dev(_dptr(zout), _dptr(zin))
+
+
+def ezsint_batch_dev(zout, zin, nfields):
+    return _lib().c_ezsint_batch_dev(_dptr(zout), _dptr(zin), nfields)
+
+
+def ezuvint_dev(uuout, vvout, uuin, vvin):
+    return _lib().c_ezuvint_dev(_dptr(uuout), _dptr(vvout), _dptr(uuin), _dptr(vvin))
+
+
+def gdxysint_dev(zout, zin, gdin, x, y, npts):
+    return _lib().c_gdxysint_dev(_dptr(zout), _dptr(zin), gdin, _dptr(x), _dptr(y), npts)
+
+
+def gdxyfll_dev(gdid, x, y, lat, lon, n):
+    return _lib().c_gdxyfll_dev(gdid, _dptr(x), _dptr(y), _dptr(lat), _dptr(lon), n)
+
+
+def prepare_set():
+    return _lib().ezhip_prepare_set()
+
+
+def set_mode():
+    return _lib().ezhip_set_mode()
