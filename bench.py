@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native EZ interpolation hot path.
+
+Workload (BASELINE.json configs[1] / configs[3]): c_ezsint bicubic, 4400x2200 global Gaussian 'G'
+-> 7200x3601 0.05-degree lat-lon 'L', default options (cubic, polar_correction=yes), synthetic
+"temperature-like" fields (tests/ezcases.py generator, libm-free).  One STEP = one pass of the hot
+path over one batch of FIELDS_PER_STEP distinct device-resident source fields per GPU (fields shard
+by record across ranks, no data-path collective: weak scaling; 8 GPUs x 32 fields = the 256-field
+batch of configs[3]).  Inputs are resident in HBM when the timed region starts.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline     -- k_sep<3>: algorithmic bytes per launch (4*ni_s*nj_s + 4*npts_out =
+                  142.43 MB) / average launch duration, HIP events on the launch stream
+  cpu_baseline -- the reference's own c_ezsint (oracle/_ref/libezref.so, 1 thread) or, if that
+                  build is absent, the oracle port, on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np   # noqa: E402
+
+NI_S, NJ_S, NI_D, NJ_D = 4400, 2200, 7200, 3601
+L_IG = (5, 5, 0, 0)                       # 'L' lat0=-90 lon0=0 dlat=dlon=0.05
+NPTS_OUT = NI_D * NJ_D
+ALGO_BYTES = 4 * NI_S * NJ_S + 4 * NPTS_OUT   # 142,428,800 B per field
+HBM_PEAK_GBPS = 8000.0                        # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(sample_fields=4):
+    """reference c_ezsint steady state (x,y cached), 1 thread, on `sample_fields` fields"""
+    import ezcases as ec
+    zin = ec.synth_field(NI_S, NJ_S, seed=2)
+    zout = np.zeros(NPTS_OUT, np.float32)
+    try:
+        from reflib import ref, have_ref, fptr
+        if have_ref():
+            L = ref()
+            gdin = L.c_ezqkdef(NI_S, NJ_S, b"G", 0, 0, 0, 0, 0)
+            gdout = L.c_ezqkdef(NI_D, NJ_D, b"L", L_IG[0], L_IG[1], L_IG[2], L_IG[3], 0)
+            L.c_ezdefset(gdout, gdin)
+            t0 = time.perf_counter()
+            L.c_ezsint(fptr(zout), fptr(zin))              # first call: lat/lon + locate + zones
+            first = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for _ in range(sample_fields):
+                L.c_ezsint(fptr(zout), fptr(zin))
+            dt = (time.perf_counter() - t0) / sample_fields
+            return {"value": NPTS_OUT / dt / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "reference",
+                    "sample": f"{sample_fields} fields cfg2 steady-state c_ezsint ({dt:.3f} s/field), "
+                              f"first call incl. locate {first:.2f} s, oracle/_ref/libezref.so"}
+    except Exception as e:   # noqa: BLE001
+        sys.stderr.write(f"cpu_baseline: reference build unusable ({e}); timing the oracle port\n")
+    import oraclelib as ol
+    O = ol.oracle()
+    gi = ol.grid_define(NI_S, NJ_S, "G"); go = ol.grid_define(NI_D, NJ_D, "L", L_IG)
+    gs = O.orc_defset(go, gi)
+    opts = ol.default_opts()
+    O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(zout), ol.fptr(zin))
+    t0 = time.perf_counter()
+    for _ in range(sample_fields):
+        O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(zout), ol.fptr(zin))
+    dt = (time.perf_counter() - t0) / sample_fields
+    return {"value": NPTS_OUT / dt / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_fields} fields cfg2 steady-state orc_ezsint ({dt:.3f} s/field)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--fields-per-step", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from librmn_amd import ezscint as ez
+    import ezcases as ec
+
+    F = args.fields_per_step
+    gdin = ez.ezqkdef(NI_S, NJ_S, "G", 0, 0, 0, 0)
+    gdout = ez.ezqkdef(NI_D, NJ_D, "L", *L_IG)
+    assert ez.ezdefset(gdout, gdin) == 1
+    stream = torch.cuda.current_stream()
+    ez.use_stream(stream.cuda_stream)
+    assert ez.prepare_set() == 0 and ez.set_mode() == 1
+
+    # F distinct synthetic source fields, resident in HBM (seed per global field index)
+    base = torch.from_numpy(ec.synth_field(NI_S, NJ_S, seed=1000 + rank * F)).cuda()
+    d_in = torch.empty((F, NI_S * NJ_S), dtype=torch.float32, device="cuda")
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1234 + rank)
+    for f in range(F):
+        d_in[f] = base * (1.0 + 1e-3 * (torch.rand(NI_S * NJ_S, device="cuda", generator=gen) - 0.5)) + 0.01 * f
+    d_out = torch.empty((F, NPTS_OUT), dtype=torch.float32, device="cuda")
+
+    def step():
+        rc = ez.ezsint_batch_dev(d_out, d_in, F)
+        assert rc == 0, rc
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev_ms = ev0.elapsed_time(ev1)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    launches = args.steps * F
+    kern_us = ev_ms * 1e3 / launches              # average k_sep<3> launch-to-launch duration on the stream
+    achieved = ALGO_BYTES / (kern_us * 1e-6) / 1e9
+    if rank == 0:
+        total_pts = float(NPTS_OUT) * F * args.steps * world
+        out = {
+            "metric": "interp Mpoints/s + pack GB/s, 4400x2200->7200x3601 bicubic, 1/2/4/8 GPU",
+            "value": total_pts / elapsed / 1e6,
+            "unit": "Mpoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "cfg2/cfg4: c_ezsint bicubic G 4400x2200 -> L 7200x3601, polar_correction=yes, "
+                                   f"{F} device-resident fields per step per GPU (sharded by record, no collective)",
+                       "fields_per_step_per_gpu": F, "points_per_field": NPTS_OUT},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_sep<3>", "avg_launch_us": kern_us, "algorithmic_bytes_per_launch": ALGO_BYTES},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

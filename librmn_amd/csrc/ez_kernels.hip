@@ -6,7 +6,7 @@
  *   k_sep<DEG>      separable ("rectilinear on rectilinear") interpolation: per-column / per-row
  *                   tap tables, rolling 4-row register window, fused polar special rows.
  *                   Replaces the do n=1,npts loops of ez_irgdint_3_w / ez_rgdint_3_w / ez_(i)rgdint_1_(n)w /
- *                   ez_rgdint_0 (reference src/interp/*.inc) when x depends on the target column
+ *                   ez_rgdint_0 (reference src/interp, the .inc leaf kernels) when x depends on the target column
  *                   only and y on the target row only -- the BASELINE cfg1/2/4/5 shape.
  *   k_pts           generic per-point interpolation at arbitrary (x,y): point-by-point restatement
  *                   of the 11 leaf kernels + zone handling (ez_defzones.c, ez_corrval*.c).
@@ -92,23 +92,39 @@ __device__ double block_sum_256(double v, double *lds4)
     return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
-/* ez_calcpoleval (src/interp/ez_calcpoleval.inc:21-48) as a block reduction.  The reference sums
- * sequentially in REAL; a parallel sum cannot reproduce that order, so it is accumulated in double
- * (deterministic tree) and rounded once: |diff| <= ~ni * 2^-24 relative, far inside 1e-5. */
-__device__ float block_poleval(const float *zrow, int ni, int weighted, const float *ax, double *lds4)
+/* ez_calcpoleval (src/interp/ez_calcpoleval.inc:21-48).  The reference accumulates the row
+ * SEQUENTIALLY in REAL; any tree order changes the low bits (measured 2.9e-6 relative at ni = 4400),
+ * so the sum is kept sequential: the block stages the row through LDS in 1024-element chunks (the
+ * Z-on-E variant stages the REAL products z(i)*(ax(i+1)-ax(i))) and lane 0 adds them in index order.
+ * ~4 cycles per dependent v_add_f32: ~8 us for ni = 4400, hidden because the special blocks that
+ * need it are dispatched first and run beside the main blocks.  Result valid in every thread. */
+#define POLE_CHUNK 1024
+__device__ float block_poleval(const float *zrow, int ni, int weighted, const float *ax, float *lds /* POLE_CHUNK + 1 */)
 {
-    double s = 0.0;
-    if (weighted) {
-        for (int i = threadIdx.x; i < ni - 1; i += 256) s += (double)(zrow[i] * (ax[i + 1] - ax[i]));
-        s = block_sum_256(s, lds4);
-        float span = ax[ni - 1] - ax[0];
-        float p = (float)s;
-        if (span != 0.0f) p = p / span;
-        return p;
+    const int n = weighted ? ni - 1 : ni;
+    float s = 0.0f;
+    for (int base = 0; base < n; base += POLE_CHUNK) {
+        const int m = min(POLE_CHUNK, n - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < m; k += blockDim.x) {
+            int i = base + k;
+            lds[k] = weighted ? zrow[i] * (ax[i + 1] - ax[i]) : zrow[i];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll 8
+            for (int k = 0; k < m; k++) s = s + lds[k];
+        }
     }
-    for (int i = threadIdx.x; i < ni; i += 256) s += (double)zrow[i];
-    s = block_sum_256(s, lds4);
-    return (float)s / (1.0f * (float)ni);
+    if (threadIdx.x == 0) {
+        if (weighted) { float span = ax[ni - 1] - ax[0]; if (span != 0.0f) s = s / span; }
+        else s = s / (1.0f * (float)ni);
+        lds[POLE_CHUNK] = s;
+    }
+    __syncthreads();
+    s = lds[POLE_CHUNK];
+    __syncthreads();
+    return s;
 }
 
 /* ===================================================================================== */
@@ -143,17 +159,20 @@ template <int DEG>
 __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__restrict__ zout,
                                                    const float *__restrict__ zin, int rows_per_block, int nblk_main)
 {
-    __shared__ double lds4[4];
+    __shared__ float lds_pole[POLE_CHUNK + 1];
     const int c = blockIdx.x * SEP_BLOCK + threadIdx.x;
     const bool cvalid = c < p.ni_dst;
     const int cc = cvalid ? c : p.ni_dst - 1;
     const int nis = p.ni_src;
     const float fillv = p.fill ? *p.fill : 0.0f;
 
-    if ((int)blockIdx.y < nblk_main) {
+    /* special rows occupy the FIRST blockIdx.y values: their sequential pole sums start early and
+     * overlap the main blocks */
+    if ((int)blockIdx.y >= p.n_special) {
+        const int by = blockIdx.y - p.n_special;
         const ColTaps t = load_col(p.cidx, p.cw, p.ni_dst, cc);
         const bool cdehors = p.cflag[cc] != 0;
-        const int r0 = blockIdx.y * rows_per_block;
+        const int r0 = by * rows_per_block;
         const int r1 = min(r0 + rows_per_block, p.nj_dst);
         double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         int cur = -(1 << 28);
@@ -190,7 +209,7 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
     }
 
     /* ---- special rows: polar strips, pole rows, fully-outside rows ------------------------- */
-    const ezhip_special_row sr = p.special[blockIdx.y - nblk_main];
+    const ezhip_special_row sr = p.special[blockIdx.y];
     float outv;
     if (sr.kind == 3) {
         outv = fillv;
@@ -200,8 +219,8 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
             for (int k = 0; k < 4; k++) { need_n |= (sr.tap[k] == EZ_ROW_POLE_N); need_s |= (sr.tap[k] == EZ_ROW_POLE_S); }
         float pole_n = 0.f, pole_s = 0.f;
         if (!p.vector_mode) {
-            if (need_n) pole_n = block_poleval(zin + (size_t)(p.nj_src - 1) * nis, nis, p.pole_weighted, p.ax, lds4);
-            if (need_s) pole_s = block_poleval(zin, nis, p.pole_weighted, p.ax, lds4);
+            if (need_n) pole_n = block_poleval(zin + (size_t)(p.nj_src - 1) * nis, nis, p.pole_weighted, p.ax, lds_pole);
+            if (need_s) pole_s = block_poleval(zin, nis, p.pole_weighted, p.ax, lds_pole);
         }
         if (sr.kind == 1) outv = pole_n;
         else if (sr.kind == 2) outv = pole_s;
@@ -583,7 +602,7 @@ extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const
 /* ===================================================================================== */
 __global__ __launch_bounds__(256) void k_polevals(float *out2, const float *zin, int ni, int nj, int weighted, const float *ax)
 {
-    __shared__ double lds4[4];
+    __shared__ float lds4[POLE_CHUNK + 1];
     const float *row = blockIdx.x == 0 ? zin + (size_t)(nj - 1) * ni : zin;
     float v = block_poleval(row, ni, weighted, ax, lds4);
     if (threadIdx.x == 0) out2[blockIdx.x] = v;

@@ -21,6 +21,24 @@ def build_library(force=False):
     return _SO
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, requested by
+    torch as plain "libamdhip64.so").  If this library bound the system copy and torch later loaded
+    its bundled one, the process would hold TWO HIP runtimes: streams and device pointers could not
+    be shared and the second runtime to initialise sees no device.  Pre-loading torch's copy (when
+    torch is installed) makes both resolve to one runtime, whatever the import order.  Pure C
+    callers without torch simply get the system runtime through the library's RUNPATH."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.submodule_search_locations:
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:   # noqa: BLE001 -- best effort; the system runtime is the fallback
+        pass
+
+
 def load_library():
     """Returns the ctypes handle of librmn_ez_hip.so; raises (loudly) when it has not been built."""
     global _lib
@@ -28,5 +46,6 @@ def load_library():
         if not os.path.exists(_SO):
             raise OSError(f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback for the MI355X hot path)")
+        _share_torch_hip_runtime()
         _lib = ctypes.CDLL(_SO)
     return _lib

@@ -190,6 +190,6 @@ def test_full_size_cfg2_properties():
     err = relerr(got, want)
     assert err.max() <= RTOL, float(err.max())
     sub = np.ix_(rows, cols)
-    assert relerr(got.reshape(mo, no)[sub], want.reshape(mo, no)[sub]).max() <= 2e-7
+    assert relerr(got.reshape(mo, no)[sub], want.reshape(mo, no)[sub]).max() <= 2e-7   # <= 1 ulp incl. pole rows and seams
     frac_exact = np.count_nonzero(got == want) / got.size
     assert frac_exact > 0.999, frac_exact
