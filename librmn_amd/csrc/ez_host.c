@@ -39,7 +39,7 @@ typedef struct {            /* src/interp/ez_def.h:225-243, defaults src/interp/
 typedef struct {            /* one compiled separable plan: device tables + the descriptor */
     int built;
     ezhip_sep_plan p;
-    void *dev[12];          /* owned device allocations */
+    void *dev[16];          /* owned device allocations */
 } ezh_sepplan;
 
 typedef struct ezh_set {
@@ -463,7 +463,7 @@ int32_t c_ezqkdef(int32_t ni, int32_t nj, char *grtyp, int32_t ig1, int32_t ig2,
 
 static void free_sepplan(ezh_sepplan *sp)
 {
-    for (int k = 0; k < 12; k++) { ezhip_free(sp->dev[k]); sp->dev[k] = NULL; }
+    for (int k = 0; k < 16; k++) { ezhip_free(sp->dev[k]); sp->dev[k] = NULL; }
     sp->built = 0;
 }
 static void free_set(ezh_set *s)
@@ -1109,6 +1109,35 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
         else continue;
         rflag[r] = 1; nspecial++;
     }
+    /* LDS staging geometry of k_sep: per column-block the contiguous (modulo ni) source column window,
+     * per row-block the source row window.  A block whose taps do not fit falls back to gathers. */
+    const int ntap = degree == DEG_CUBIC ? 4 : (degree == DEG_LINEAR ? 2 : 1);
+    int nbx = (nic + EZHIP_SEP_COLS - 1) / EZHIP_SEP_COLS, nby = (njr + EZHIP_SEP_ROWS - 1) / EZHIP_SEP_ROWS;
+    int *coff = (int *)calloc((size_t)4 * nic, sizeof(int));
+    int *blk_base = (int *)malloc(sizeof(int) * nbx), *blk_w = (int *)malloc(sizeof(int) * nbx);
+    int *brow_s0 = (int *)malloc(sizeof(int) * nby), *brow_n = (int *)malloc(sizeof(int) * nby);
+    for (int bx = 0; bx < nbx; bx++) {
+        int c0 = bx * EZHIP_SEP_COLS, c1 = imin(c0 + EZHIP_SEP_COLS, nic);
+        int base = cidx[c0], maxoff = 0;
+        for (int c = c0; c < c1; c++)
+            for (int k = 0; k < ntap; k++) {
+                int off = (cidx[k * nic + c] - base + gi->ni) % gi->ni;
+                coff[k * nic + c] = off;
+                if (off > maxoff) maxoff = off;
+            }
+        if (maxoff + 1 > EZHIP_SEP_WMAX || maxoff + 1 > gi->ni) { blk_base[bx] = -1; blk_w[bx] = 0; }
+        else { blk_base[bx] = base; blk_w[bx] = maxoff + 1; }
+    }
+    for (int by = 0; by < nby; by++) {
+        int r0 = by * EZHIP_SEP_ROWS, r1 = imin(r0 + EZHIP_SEP_ROWS, njr), lo = 1 << 30, hi = -1;
+        for (int r = r0; r < r1; r++) {
+            if (rflag[r]) continue;
+            if (rbase[r] < lo) lo = rbase[r];
+            if (rbase[r] + ntap > hi) hi = rbase[r] + ntap;
+        }
+        if (hi < 0 || hi - lo > EZHIP_SEP_RMAX) { brow_s0[by] = 0; brow_n[by] = 0; }
+        else { brow_s0[by] = lo; brow_n[by] = hi - lo; }
+    }
     ezhip_sep_plan *p = &sp->p;
     memset(p, 0, sizeof(*p));
     p->degree = degree; p->ni_src = gi->ni; p->nj_src = gi->nj; p->ni_dst = nic; p->nj_dst = njr;
@@ -1121,12 +1150,18 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
     p->rw = (const double *)(sp->dev[6] = upload(rw, sizeof(double) * 4 * njr));
     p->rflag = (const unsigned char *)(sp->dev[7] = upload(rflag, njr));
     p->special = (const ezhip_special_row *)(sp->dev[8] = upload(special, sizeof(ezhip_special_row) * (nspecial + 1)));
+    p->coff = (const int *)(sp->dev[9] = upload(coff, sizeof(int) * 4 * nic));
+    p->blk_base = (const int *)(sp->dev[10] = upload(blk_base, sizeof(int) * nbx));
+    p->blk_w = (const int *)(sp->dev[11] = upload(blk_w, sizeof(int) * nbx));
+    p->brow_s0 = (const int *)(sp->dev[12] = upload(brow_s0, sizeof(int) * nby));
+    p->brow_n = (const int *)(sp->dev[13] = upload(brow_n, sizeof(int) * nby));
     p->n_special = nspecial;
     p->pole_weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
     p->vector_mode = vector_mode;
     ezhip_sync();
     int ok = 1;
-    for (int k = 0; k < 9; k++) ok &= (sp->dev[k] != NULL);
+    for (int k = 0; k < 14; k++) ok &= (sp->dev[k] != NULL);
+    free(coff); free(blk_base); free(blk_w); free(brow_s0); free(brow_n);
     free(cidx); free(cidx_s); free(cw); free(cw_s); free(cflag); free(rflag); free(rbase); free(rw); free(special);
     if (!ok) { free_sepplan(sp); return -1; }
     sp->built = 1 + polar;

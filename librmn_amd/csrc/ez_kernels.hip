@@ -99,7 +99,7 @@ __device__ double block_sum_256(double v, double *lds4)
  * ~4 cycles per dependent v_add_f32: ~8 us for ni = 4400, hidden because the special blocks that
  * need it are dispatched first and run beside the main blocks.  Result valid in every thread. */
 #define POLE_CHUNK 1024
-__device__ float block_poleval(const float *zrow, int ni, int weighted, const float *ax, float *lds /* POLE_CHUNK + 1 */)
+__device__ float block_poleval(const float *zrow, int ni, int weighted, const float *ax, float *lds /* >= POLE_CHUNK + 1 floats */)
 {
     const int n = weighted ? ni - 1 : ni;
     float s = 0.0f;
@@ -142,9 +142,9 @@ __device__ __forceinline__ ColTaps load_col(const int *cidx, const double *cw, i
     return t;
 }
 
-/* x-direction pass on one source row */
-template <int DEG>
-__device__ __forceinline__ double xpass(const float *__restrict__ zrow, const ColTaps &t)
+/* x-direction pass on one source row (global memory or an LDS patch row; indices are relative to zrow) */
+template <int DEG, class T>
+__device__ __forceinline__ double xpass(const T *__restrict__ zrow, const ColTaps &t)
 {
     if (DEG == 0) return (double)zrow[t.i0];
     if (DEG == 1) {   /* zlin8.cdk: z1 + (z2 - z1) * dx, exactly as the reference evaluates it */
@@ -155,11 +155,49 @@ __device__ __forceinline__ double xpass(const float *__restrict__ zrow, const Co
     return fma(t.w3, z3, fma(t.w2, z2, fma(t.w1, z1, t.w0 * z0)));
 }
 
+/* The main-row loop: rolling window of x-pass results over the source rows; `rowptr(s)` yields the
+ * base pointer of source row s (global memory, or the block's LDS patch). */
+template <int DEG, class RowPtr>
+__device__ __forceinline__ void sep_rows(const ezhip_sep_plan &p, const ColTaps &t, RowPtr rowptr, int r0, int r1,
+                                         float *__restrict__ zout, int c, bool cvalid, bool cdehors, float fillv)
+{
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    int cur = -(1 << 28);
+    for (int r = r0; r < r1; r++) {
+        if (p.rflag[r]) continue;                       /* uniform: row handled as special */
+        const int jb = p.rbase[r];                      /* uniform -> scalar loads */
+        double val;
+        if (DEG == 0) {
+            val = xpass<0>(rowptr(jb), t);
+        } else if (DEG == 1) {
+            int d = jb - cur;
+            if (d != 0) {
+                if (d == 1) { t0 = t1; t1 = xpass<1>(rowptr(jb + 1), t); }
+                else { t0 = xpass<1>(rowptr(jb), t); t1 = xpass<1>(rowptr(jb + 1), t); }
+                cur = jb;
+            }
+            val = t0 + (t1 - t0) * p.rw[r];
+        } else {
+            int d = jb - cur;
+            if (d != 0) {
+                if (d == 1) { t0 = t1; t1 = t2; t2 = t3; t3 = xpass<3>(rowptr(jb + 3), t); }
+                else if (d == 2) { t0 = t2; t1 = t3; t2 = xpass<3>(rowptr(jb + 2), t); t3 = xpass<3>(rowptr(jb + 3), t); }
+                else if (d == 3) { t0 = t3; t1 = xpass<3>(rowptr(jb + 1), t); t2 = xpass<3>(rowptr(jb + 2), t); t3 = xpass<3>(rowptr(jb + 3), t); }
+                else { t0 = xpass<3>(rowptr(jb), t); t1 = xpass<3>(rowptr(jb + 1), t); t2 = xpass<3>(rowptr(jb + 2), t); t3 = xpass<3>(rowptr(jb + 3), t); }
+                cur = jb;
+            }
+            const double w0 = p.rw[r], w1 = p.rw[p.nj_dst + r], w2 = p.rw[2 * p.nj_dst + r], w3 = p.rw[3 * p.nj_dst + r];
+            val = fma(w3, t3, fma(w2, t2, fma(w1, t1, w0 * t0)));
+        }
+        if (cvalid) zout[(size_t)r * p.ni_dst + c] = cdehors ? fillv : (float)val;
+    }
+}
+
 template <int DEG>
 __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__restrict__ zout,
-                                                   const float *__restrict__ zin, int rows_per_block, int nblk_main)
+                                                   const float *__restrict__ zin)
 {
-    __shared__ float lds_pole[POLE_CHUNK + 1];
+    __shared__ float patch[EZHIP_SEP_RMAX * EZHIP_SEP_WMAX];   /* also the pole-sum staging buffer */
     const int c = blockIdx.x * SEP_BLOCK + threadIdx.x;
     const bool cvalid = c < p.ni_dst;
     const int cc = cvalid ? c : p.ni_dst - 1;
@@ -170,40 +208,30 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
      * overlap the main blocks */
     if ((int)blockIdx.y >= p.n_special) {
         const int by = blockIdx.y - p.n_special;
-        const ColTaps t = load_col(p.cidx, p.cw, p.ni_dst, cc);
         const bool cdehors = p.cflag[cc] != 0;
-        const int r0 = by * rows_per_block;
-        const int r1 = min(r0 + rows_per_block, p.nj_dst);
-        double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-        int cur = -(1 << 28);
-        for (int r = r0; r < r1; r++) {
-            if (p.rflag[r]) continue;                       /* uniform: row handled as special */
-            const int jb = p.rbase[r];                      /* uniform -> scalar loads */
-            double val;
-            if (DEG == 0) {
-                val = xpass<0>(zin + (size_t)jb * nis, t);
-            } else if (DEG == 1) {
-                int d = jb - cur;
-                if (d != 0) {
-                    if (d == 1) { t0 = t1; t1 = xpass<1>(zin + (size_t)(jb + 1) * nis, t); }
-                    else { t0 = xpass<1>(zin + (size_t)jb * nis, t); t1 = xpass<1>(zin + (size_t)(jb + 1) * nis, t); }
-                    cur = jb;
+        const int r0 = by * EZHIP_SEP_ROWS;
+        const int r1 = min(r0 + EZHIP_SEP_ROWS, p.nj_dst);
+        const int base = p.blk_base[blockIdx.x], W = p.blk_w[blockIdx.x];
+        const int s0 = p.brow_s0[by], nrows = p.brow_n[by];
+        if (base >= 0 && nrows > 0) {
+            /* stage the source patch [s0, s0+nrows) x [base, base+W) (columns modulo ni_src: the
+             * longitude seam is unrolled) with coalesced loads, all issued before the first use */
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            for (int row = wv; row < nrows; row += SEP_BLOCK / 64) {
+                const float *zr = zin + (size_t)(s0 + row) * nis;
+                for (int u = lane; u < W; u += 64) {
+                    int col = base + u;
+                    if (col >= nis) col -= nis;
+                    patch[row * EZHIP_SEP_WMAX + u] = zr[col];
                 }
-                val = t0 + (t1 - t0) * p.rw[r];
-            } else {
-                int d = jb - cur;
-                if (d != 0) {
-                    const float *zr = zin + (size_t)jb * nis;
-                    if (d == 1) { t0 = t1; t1 = t2; t2 = t3; t3 = xpass<3>(zr + 3 * (size_t)nis, t); }
-                    else if (d == 2) { t0 = t2; t1 = t3; t2 = xpass<3>(zr + 2 * (size_t)nis, t); t3 = xpass<3>(zr + 3 * (size_t)nis, t); }
-                    else if (d == 3) { t0 = t3; t1 = xpass<3>(zr + (size_t)nis, t); t2 = xpass<3>(zr + 2 * (size_t)nis, t); t3 = xpass<3>(zr + 3 * (size_t)nis, t); }
-                    else { t0 = xpass<3>(zr, t); t1 = xpass<3>(zr + (size_t)nis, t); t2 = xpass<3>(zr + 2 * (size_t)nis, t); t3 = xpass<3>(zr + 3 * (size_t)nis, t); }
-                    cur = jb;
-                }
-                const double w0 = p.rw[r], w1 = p.rw[p.nj_dst + r], w2 = p.rw[2 * p.nj_dst + r], w3 = p.rw[3 * p.nj_dst + r];
-                val = fma(w3, t3, fma(w2, t2, fma(w1, t1, w0 * t0)));
             }
-            if (cvalid) zout[(size_t)r * p.ni_dst + c] = cdehors ? fillv : (float)val;
+            ColTaps t = load_col(p.coff, p.cw, p.ni_dst, cc);
+            __syncthreads();
+            sep_rows<DEG>(p, t, [&](int s) { return patch + (s - s0) * EZHIP_SEP_WMAX; }, r0, r1, zout, c, cvalid, cdehors, fillv);
+        } else {
+            /* patch does not fit (strong down-sampling, or non-contiguous literal seam columns): gather */
+            const ColTaps t = load_col(p.cidx, p.cw, p.ni_dst, cc);
+            sep_rows<DEG>(p, t, [&](int s) { return zin + (size_t)s * nis; }, r0, r1, zout, c, cvalid, cdehors, fillv);
         }
         return;
     }
@@ -219,8 +247,8 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
             for (int k = 0; k < 4; k++) { need_n |= (sr.tap[k] == EZ_ROW_POLE_N); need_s |= (sr.tap[k] == EZ_ROW_POLE_S); }
         float pole_n = 0.f, pole_s = 0.f;
         if (!p.vector_mode) {
-            if (need_n) pole_n = block_poleval(zin + (size_t)(p.nj_src - 1) * nis, nis, p.pole_weighted, p.ax, lds_pole);
-            if (need_s) pole_s = block_poleval(zin, nis, p.pole_weighted, p.ax, lds_pole);
+            if (need_n) pole_n = block_poleval(zin + (size_t)(p.nj_src - 1) * nis, nis, p.pole_weighted, p.ax, patch);
+            if (need_s) pole_s = block_poleval(zin, nis, p.pole_weighted, p.ax, patch);
         }
         if (sr.kind == 1) outv = pole_n;
         else if (sr.kind == 2) outv = pole_s;
@@ -246,14 +274,13 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
 
 extern "C" int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin)
 {
-    const int rows_per_block = 16;
-    int nblk_main = (plan->nj_dst + rows_per_block - 1) / rows_per_block;
+    int nblk_main = (plan->nj_dst + EZHIP_SEP_ROWS - 1) / EZHIP_SEP_ROWS;
     dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, nblk_main + plan->n_special);
     dim3 block(SEP_BLOCK);
     switch (plan->degree) {
-    case 0: hipLaunchKernelGGL(k_sep<0>, grid, block, 0, g_stream, *plan, d_zout, d_zin, rows_per_block, nblk_main); break;
-    case 1: hipLaunchKernelGGL(k_sep<1>, grid, block, 0, g_stream, *plan, d_zout, d_zin, rows_per_block, nblk_main); break;
-    case 3: hipLaunchKernelGGL(k_sep<3>, grid, block, 0, g_stream, *plan, d_zout, d_zin, rows_per_block, nblk_main); break;
+    case 0: hipLaunchKernelGGL(k_sep<0>, grid, block, 0, g_stream, *plan, d_zout, d_zin); break;
+    case 1: hipLaunchKernelGGL(k_sep<1>, grid, block, 0, g_stream, *plan, d_zout, d_zin); break;
+    case 3: hipLaunchKernelGGL(k_sep<3>, grid, block, 0, g_stream, *plan, d_zout, d_zin); break;
     default: snprintf(g_err, sizeof(g_err), "ezhip_interp_sep: bad degree %d", plan->degree); return -1;
     }
     return LAUNCH_CHECK("k_sep");

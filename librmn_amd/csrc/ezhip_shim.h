@@ -53,10 +53,21 @@ typedef struct {
  * x depends only on the target column and y only on the target row.  All arrays are DEVICE
  * pointers, SoA with leading dimension ni_dst (columns) or nj_dst (rows).
  */
+/* k_sep geometry shared by the plan builder (host) and the kernel */
+#define EZHIP_SEP_COLS 256            /* target columns per block = threads per block */
+#define EZHIP_SEP_ROWS 16             /* target rows per block */
+#define EZHIP_SEP_WMAX 272            /* max staged source columns per block (>= 256 + stencil) */
+#define EZHIP_SEP_RMAX 20             /* max staged source rows per block (>= 16 + stencil) */
+
 typedef struct {
     int degree;                       /* 0 nearest, 1 linear, 3 cubic */
     int ni_src, nj_src, ni_dst, nj_dst;
     const int    *cidx;               /* [4][ni_dst] 0-based source column of each tap */
+    const int    *coff;               /* [4][ni_dst] the same taps as offsets into the block's staged patch */
+    const int    *blk_base;           /* [nblk_x] first staged source column of the block, -1: patch not usable */
+    const int    *blk_w;              /* [nblk_x] staged width (<= EZHIP_SEP_WMAX) */
+    const int    *brow_s0;            /* [nblk_y] first staged source row of the row-block */
+    const int    *brow_n;             /* [nblk_y] staged rows (<= EZHIP_SEP_RMAX), 0: not usable */
     const double *cw;                 /* [4][ni_dst] cubic weights | linear: cw[0][] = dx */
     const int    *cidx_s;             /* same, for the polar-strip kernels (wnnc / regular forms) */
     const double *cw_s;

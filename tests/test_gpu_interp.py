@@ -158,11 +158,13 @@ def test_full_size_cfg2_properties():
     setopts(3, 1)
     ez.use_stream(torch.cuda.current_stream().cuda_stream)
     d_out = torch.empty(no * mo, dtype=torch.float32, device="cuda")
-    # 1. constants are reproduced exactly (weights sum to 1 up to rounding)
+    # 1. constants are reproduced (weights sum to 1 up to rounding).  The polar rows are excluded:
+    #    the reference's pole value is a SEQUENTIAL float sum / ni, which is itself inexact for a
+    #    constant row (273.1378 instead of 273.15 at ni = 4400) -- reproduced, and checked in step 4.
     d_in = torch.full((ni * nj,), 273.15, dtype=torch.float32, device="cuda")
     assert ez.ezsint_dev(d_out, d_in) == 0
     torch.cuda.synchronize()
-    assert float((d_out - 273.15).abs().max()) <= 273.15 * 2e-7
+    assert float((d_out.view(mo, no)[4:-4] - 273.15).abs().max()) <= 273.15 * 2e-7
     # 2. linearity: interp(a*f + b*g) == a*interp(f) + b*interp(g) within rounding
     f = torch.from_numpy(ec.synth_field(ni, nj, seed=2)).cuda(); g = torch.from_numpy(ec.synth_field(ni, nj, seed=9)).cuda()
     of = torch.empty_like(d_out); og = torch.empty_like(d_out); oc = torch.empty_like(d_out)
