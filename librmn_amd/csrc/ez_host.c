@@ -1125,7 +1125,10 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
                 coff[k * nic + c] = off;
                 if (off > maxoff) maxoff = off;
             }
-        if (maxoff + 1 > EZHIP_SEP_WMAX || maxoff + 1 > gi->ni) { blk_base[bx] = -1; blk_w[bx] = 0; }
+        int consecutive = 1;      /* the staged kernel reads taps at patch columns off0, off0+1, .. */
+        for (int c = c0; c < c1 && consecutive; c++)
+            for (int k = 1; k < ntap; k++) if (coff[k * nic + c] != coff[c] + k) { consecutive = 0; break; }
+        if (!consecutive || maxoff + 1 > EZHIP_SEP_WMAX || maxoff + 1 > gi->ni) { blk_base[bx] = -1; blk_w[bx] = 0; }
         else { blk_base[bx] = base; blk_w[bx] = maxoff + 1; }
     }
     for (int by = 0; by < nby; by++) {
@@ -1138,9 +1141,36 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
         if (hi < 0 || hi - lo > EZHIP_SEP_RMAX) { brow_s0[by] = 0; brow_n[by] = 0; }
         else { brow_s0[by] = lo; brow_n[by] = hi - lo; }
     }
+    ezhip_rowinfo *rinfo = (ezhip_rowinfo *)calloc((size_t)nby * EZHIP_SEP_ROWS, sizeof(ezhip_rowinfo));
+    for (int by = 0; by < nby; by++)
+        for (int k = 0; k < EZHIP_SEP_ROWS; k++) {
+            int r = by * EZHIP_SEP_ROWS + k;
+            ezhip_rowinfo *q = &rinfo[r];
+            if (r >= njr || rflag[r]) { q->flag = 1; continue; }
+            q->jb = rbase[r] - brow_s0[by];
+            for (int w = 0; w < 4; w++) q->w[w] = rw[w * njr + r];
+        }
     ezhip_sep_plan *p = &sp->p;
     memset(p, 0, sizeof(*p));
     p->degree = degree; p->ni_src = gi->ni; p->nj_src = gi->nj; p->ni_dst = nic; p->nj_dst = njr;
+    {   /* LDS geometry: row stride = widest staged block, rows = tallest staged row-block; the buffer also
+         * serves the sequential pole sums of the special blocks (1025 floats) */
+        int wmax = 1, nmax = 1;
+        for (int bx = 0; bx < nbx; bx++) if (blk_w[bx] > wmax) wmax = blk_w[bx];
+        for (int by = 0; by < nby; by++) if (brow_n[by] > nmax) nmax = brow_n[by];
+        p->wstride = wmax; p->patch_elems = wmax * nmax;
+        if (p->patch_elems < 1032) p->patch_elems = 1032;
+        p->nblk_y = nby;
+        /* row-blocks streamed per thread block: 1 (measured best on gfx950; > 1 selects the experimental
+         * register-staged software pipeline, see k_sep) */
+        int rb = 1;
+        if (getenv("EZHIP_SEP_RB")) rb = atoi(getenv("EZHIP_SEP_RB"));
+        if (rb > 8) rb = 8;
+        if (rb < 1) rb = 1;
+        p->rb_per_block = rb;
+    }
+    p->rowinfo = (const ezhip_rowinfo *)(sp->dev[14] = upload(rinfo, sizeof(ezhip_rowinfo) * (size_t)nby * EZHIP_SEP_ROWS));
+    free(rinfo);
     p->cidx = (const int *)(sp->dev[0] = upload(cidx, sizeof(int) * 4 * nic));
     p->cw = (const double *)(sp->dev[1] = upload(cw, sizeof(double) * 4 * nic));
     p->cidx_s = (const int *)(sp->dev[2] = upload(cidx_s, sizeof(int) * 4 * nic));
@@ -1160,7 +1190,7 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
     p->vector_mode = vector_mode;
     ezhip_sync();
     int ok = 1;
-    for (int k = 0; k < 14; k++) ok &= (sp->dev[k] != NULL);
+    for (int k = 0; k < 15; k++) ok &= (sp->dev[k] != NULL);
     free(coff); free(blk_base); free(blk_w); free(brow_s0); free(brow_n);
     free(cidx); free(cidx_s); free(cw); free(cw_s); free(cflag); free(rflag); free(rbase); free(rw); free(special);
     if (!ok) { free_sepplan(sp); return -1; }

@@ -155,17 +155,22 @@ __device__ __forceinline__ double xpass(const T *__restrict__ zrow, const ColTap
     return fma(t.w3, z3, fma(t.w2, z2, fma(t.w1, z1, t.w0 * z0)));
 }
 
+/* per-row metadata of one row-block, staged in LDS once (a per-row chain of dependent global /
+ * scalar loads measured ~1000 cycles per row and made the first version latency-bound) */
+struct RowInfo { int rbase[EZHIP_SEP_ROWS]; int rflag[EZHIP_SEP_ROWS]; double rw[4][EZHIP_SEP_ROWS]; };
+
 /* The main-row loop: rolling window of x-pass results over the source rows; `rowptr(s)` yields the
  * base pointer of source row s (global memory, or the block's LDS patch). */
 template <int DEG, class RowPtr>
-__device__ __forceinline__ void sep_rows(const ezhip_sep_plan &p, const ColTaps &t, RowPtr rowptr, int r0, int r1,
+__device__ __forceinline__ void sep_rows(const ezhip_sep_plan &p, const RowInfo &ri, const ColTaps &t, RowPtr rowptr, int r0, int r1,
                                          float *__restrict__ zout, int c, bool cvalid, bool cdehors, float fillv)
 {
     double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     int cur = -(1 << 28);
-    for (int r = r0; r < r1; r++) {
-        if (p.rflag[r]) continue;                       /* uniform: row handled as special */
-        const int jb = p.rbase[r];                      /* uniform -> scalar loads */
+    for (int k = 0; k < r1 - r0; k++) {
+        if (ri.rflag[k]) continue;                      /* uniform: row handled as special */
+        const int r = r0 + k;
+        const int jb = ri.rbase[k];
         double val;
         if (DEG == 0) {
             val = xpass<0>(rowptr(jb), t);
@@ -176,7 +181,7 @@ __device__ __forceinline__ void sep_rows(const ezhip_sep_plan &p, const ColTaps 
                 else { t0 = xpass<1>(rowptr(jb), t); t1 = xpass<1>(rowptr(jb + 1), t); }
                 cur = jb;
             }
-            val = t0 + (t1 - t0) * p.rw[r];
+            val = t0 + (t1 - t0) * ri.rw[0][k];
         } else {
             int d = jb - cur;
             if (d != 0) {
@@ -186,18 +191,149 @@ __device__ __forceinline__ void sep_rows(const ezhip_sep_plan &p, const ColTaps 
                 else { t0 = xpass<3>(rowptr(jb), t); t1 = xpass<3>(rowptr(jb + 1), t); t2 = xpass<3>(rowptr(jb + 2), t); t3 = xpass<3>(rowptr(jb + 3), t); }
                 cur = jb;
             }
-            const double w0 = p.rw[r], w1 = p.rw[p.nj_dst + r], w2 = p.rw[2 * p.nj_dst + r], w3 = p.rw[3 * p.nj_dst + r];
-            val = fma(w3, t3, fma(w2, t2, fma(w1, t1, w0 * t0)));
+            val = fma(ri.rw[3][k], t3, fma(ri.rw[2][k], t2, fma(ri.rw[1][k], t1, ri.rw[0][k] * t0)));
         }
         if (cvalid) zout[(size_t)r * p.ni_dst + c] = cdehors ? fillv : (float)val;
     }
 }
 
+/* x-direction pass on one LDS patch row with four CONSECUTIVE taps */
 template <int DEG>
+__device__ __forceinline__ double xrow(const float *pr, const double (&cw)[4])
+{
+    if (DEG == 0) return (double)pr[0];
+    if (DEG == 1) { double z1 = (double)pr[0], z2 = (double)pr[1]; return z1 + (z2 - z1) * cw[0]; }
+    return fma(cw[3], (double)pr[3], fma(cw[2], (double)pr[2], fma(cw[1], (double)pr[1], cw[0] * (double)pr[0])));
+}
+
+/* Staged fast path of one (column-block, row-block): the source patch is in LDS and the four taps of
+ * every column are consecutive patch columns.  Lean by construction -- three earlier versions were
+ * bound by (1) dependent global loads per row, (2) ~46 VALU per row, (3) ~40 serialized scalar-cache
+ * round trips per wave (13 us wave lifetime for 145 VALU instructions):
+ *   - lane k (< 16) of every wave loads the metadata {jb, flag, w[4]} of row k ONCE (one coalesced
+ *     vector load); each statically unrolled row then broadcasts it with v_readlane into SGPRs:
+ *     no memory instruction and no wait in the row loop, control flow on jb is scalar, the weights
+ *     feed v_fma_f64 as scalar operands;
+ *   - one VGPR address per new source row, taps at immediate offsets. */
+__device__ __forceinline__ double readlane_f64(double v, int k)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+
+#define SEP_RIT ((EZHIP_SEP_RMAX + 3) / 4)     /* staged rows per wave (4 waves) */
+#define SEP_QCH ((EZHIP_SEP_WMAX + 63) / 64)   /* 64-column chunks per staged row */
+
+/* Register image of one row-block's patch while its global loads are in flight (software
+ * pipeline: the loads of row-block i+1 are issued BEFORE row-block i is computed and stored, and
+ * committed to the other LDS buffer afterwards).  Measured motivation: staging alone costs 19 us
+ * and the stores alone 19 us per field; un-overlapped (load -> barrier -> compute -> store per
+ * block) they add up to 34-44 us whatever the instruction count. */
+struct PatchRegs { float v[SEP_RIT][SEP_QCH]; ezhip_rowinfo ri; };
+
+__device__ __forceinline__ void patch_issue(PatchRegs &pr, const ezhip_sep_plan &p, const float *__restrict__ zin,
+                                            int by, const unsigned (&coloff)[SEP_QCH], int W, int lane, int wv)
+{
+    const int s0 = p.brow_s0[by], n = p.brow_n[by];
+#pragma unroll
+    for (int it = 0; it < SEP_RIT; it++) {
+        const int row = it * 4 + wv;
+        if (row < n) {                                           /* wave-uniform */
+            const float *zr = zin + (size_t)(s0 + row) * p.ni_src;
+#pragma unroll
+            for (int q = 0; q < SEP_QCH; q++)
+                if (lane + 64 * q < W) pr.v[it][q] = zr[coloff[q]];
+        }
+    }
+    pr.ri = p.rowinfo[(size_t)by * EZHIP_SEP_ROWS + (threadIdx.x & (EZHIP_SEP_ROWS - 1))];
+}
+
+__device__ __forceinline__ void patch_commit(const PatchRegs &pr, float *buf, int n, int W, int wstride, int lane, int wv)
+{
+#pragma unroll
+    for (int it = 0; it < SEP_RIT; it++) {
+        const int row = it * 4 + wv;
+        if (row < n) {
+            float *dst = buf + row * wstride + lane;
+#pragma unroll
+            for (int q = 0; q < SEP_QCH; q++)
+                if (lane + 64 * q < W) dst[64 * q] = pr.v[it][q];
+        }
+    }
+}
+
+/* 16 statically unrolled target rows of one row-block from the LDS patch (taps = consecutive patch
+ * columns).  Row metadata sits in lane k of `ri` and is broadcast with v_readlane: no memory
+ * instruction or wait inside the row loop, scalar control flow, scalar weight operands. */
+template <int DEG>
+__device__ __forceinline__ void sep_rows_staged(const ezhip_sep_plan &p, const ezhip_rowinfo &mine, const float *patch, int wstride,
+                                                int off0, const double (&cw)[4], int r0,
+                                                float *__restrict__ zout, int c, bool cvalid, bool cdehors, float fillv)
+{
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    int cur = -(1 << 28);
+    const float *pcol = patch + off0;
+    float *orow = zout + (size_t)r0 * p.ni_dst + c;
+#define XP(row) xrow<DEG>(pcol + (row) * wstride, cw)
+#pragma unroll
+    for (int k = 0; k < EZHIP_SEP_ROWS; k++, orow += p.ni_dst) {
+        if (__builtin_amdgcn_readlane(mine.flag, k)) continue;   /* scalar: special row, or past the last row */
+        const int jb = __builtin_amdgcn_readlane(mine.jb, k);     /* patch-relative first source row */
+        double val;
+        if (DEG == 0) {
+            val = XP(jb);
+        } else if (DEG == 1) {
+            const int d = jb - cur;
+            if (d != 0) {
+                if (d == 1) { t0 = t1; t1 = XP(jb + 1); }
+                else { t0 = XP(jb); t1 = XP(jb + 1); }
+                cur = jb;
+            }
+            val = t0 + (t1 - t0) * readlane_f64(mine.w[0], k);
+        } else {
+            const int d = jb - cur;
+            if (d != 0) {
+                if (d == 1) { t0 = t1; t1 = t2; t2 = t3; t3 = XP(jb + 3); }
+                else if (d == 2) { t0 = t2; t1 = t3; t2 = XP(jb + 2); t3 = XP(jb + 3); }
+                else if (d == 3) { t0 = t3; t1 = XP(jb + 1); t2 = XP(jb + 2); t3 = XP(jb + 3); }
+                else { t0 = XP(jb); t1 = XP(jb + 1); t2 = XP(jb + 2); t3 = XP(jb + 3); }
+                cur = jb;
+            }
+            val = fma(readlane_f64(mine.w[3], k), t3, fma(readlane_f64(mine.w[2], k), t2,
+                  fma(readlane_f64(mine.w[1], k), t1, readlane_f64(mine.w[0], k) * t0)));
+        }
+        if (cvalid) *orow = cdehors ? fillv : (float)val;
+    }
+#undef XP
+}
+
+/* gather fallback for one row-block (patch not usable: strong down-sampling, non-consecutive literal
+ * seam taps, or more source rows than the patch holds) */
+template <int DEG>
+__device__ void sep_rowblock_gather(const ezhip_sep_plan &p, RowInfo &ri, float *__restrict__ zout, const float *__restrict__ zin,
+                                    int by, int cc, int c, bool cvalid, bool cdehors, float fillv)
+{
+    const int r0 = by * EZHIP_SEP_ROWS, r1 = min(r0 + EZHIP_SEP_ROWS, p.nj_dst);
+    __syncthreads();
+    if (threadIdx.x < EZHIP_SEP_ROWS) {
+        const int k = threadIdx.x, r = r0 + k;
+        const bool ok = r < r1;
+        ri.rflag[k] = ok ? p.rflag[r] : 1;
+        ri.rbase[k] = ok ? p.rbase[r] : 0;
+        for (int q = 0; q < 4; q++) ri.rw[q][k] = ok ? p.rw[q * p.nj_dst + r] : 0.0;
+    }
+    const ColTaps t = load_col(p.cidx, p.cw, p.ni_dst, cc);
+    __syncthreads();
+    const int nis = p.ni_src;
+    sep_rows<DEG>(p, ri, t, [&](int s) { return zin + (size_t)s * nis; }, r0, r1, zout, c, cvalid, cdehors, fillv);
+}
+
+template <int DEG, bool PIPE>
 __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__restrict__ zout,
                                                    const float *__restrict__ zin)
 {
-    __shared__ float patch[EZHIP_SEP_RMAX * EZHIP_SEP_WMAX];   /* also the pole-sum staging buffer */
+    extern __shared__ float smem[];        /* 2 patch buffers of p.patch_elems floats; also the pole-sum buffer */
+    __shared__ RowInfo ri_lds;             /* gather fallback only */
     const int c = blockIdx.x * SEP_BLOCK + threadIdx.x;
     const bool cvalid = c < p.ni_dst;
     const int cc = cvalid ? c : p.ni_dst - 1;
@@ -207,36 +343,62 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
     /* special rows occupy the FIRST blockIdx.y values: their sequential pole sums start early and
      * overlap the main blocks */
     if ((int)blockIdx.y >= p.n_special) {
-        const int by = blockIdx.y - p.n_special;
+        const int gy = blockIdx.y - p.n_special;
+        const int by0 = gy * p.rb_per_block, by1 = min(by0 + p.rb_per_block, p.nblk_y);
         const bool cdehors = p.cflag[cc] != 0;
-        const int r0 = by * EZHIP_SEP_ROWS;
-        const int r1 = min(r0 + EZHIP_SEP_ROWS, p.nj_dst);
         const int base = p.blk_base[blockIdx.x], W = p.blk_w[blockIdx.x];
-        const int s0 = p.brow_s0[by], nrows = p.brow_n[by];
-        if (base >= 0 && nrows > 0) {
-            /* stage the source patch [s0, s0+nrows) x [base, base+W) (columns modulo ni_src: the
-             * longitude seam is unrolled) with coalesced loads, all issued before the first use */
-            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-            for (int row = wv; row < nrows; row += SEP_BLOCK / 64) {
-                const float *zr = zin + (size_t)(s0 + row) * nis;
-                for (int u = lane; u < W; u += 64) {
-                    int col = base + u;
-                    if (col >= nis) col -= nis;
-                    patch[row * EZHIP_SEP_WMAX + u] = zr[col];
-                }
+        if (base < 0) {
+            for (int by = by0; by < by1; by++) sep_rowblock_gather<DEG>(p, ri_lds, zout, zin, by, cc, c, cvalid, cdehors, fillv);
+            return;
+        }
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        unsigned coloff[SEP_QCH];
+#pragma unroll
+        for (int q = 0; q < SEP_QCH; q++) {          /* source column of patch column lane + 64 q (seam unrolled) */
+            int col = base + lane + 64 * q;
+            if (col >= nis) col -= nis;
+            coloff[q] = (unsigned)col;
+        }
+        const int off0 = p.coff[cc];
+        const double cw[4] = {p.cw[cc], p.cw[p.ni_dst + cc], p.cw[2 * p.ni_dst + cc], p.cw[3 * p.ni_dst + cc]};
+        if (!PIPE) {
+            /* one row-block per thread block: stage (all loads issued up-front), barrier, compute + store.
+             * No vector load is issued after a store, so no wave ever waits on a store acknowledgement. */
+            const int by = by0, s0 = p.brow_s0[by], n = p.brow_n[by];
+            if (n <= 0) { sep_rowblock_gather<DEG>(p, ri_lds, zout, zin, by, cc, c, cvalid, cdehors, fillv); return; }
+            for (int row = wv; row < n; row += SEP_BLOCK / 64) {
+                const float *zr = zin + (size_t)(s0 + row) * nis;      /* uniform base */
+                float *prow = smem + row * p.wstride + lane;
+#pragma unroll
+                for (int q = 0; q < SEP_QCH; q++)
+                    if (lane + 64 * q < W) prow[64 * q] = zr[coloff[q]];
             }
-            ColTaps t = load_col(p.coff, p.cw, p.ni_dst, cc);
+            const ezhip_rowinfo mine = p.rowinfo[(size_t)by * EZHIP_SEP_ROWS + (threadIdx.x & (EZHIP_SEP_ROWS - 1))];
             __syncthreads();
-            sep_rows<DEG>(p, t, [&](int s) { return patch + (s - s0) * EZHIP_SEP_WMAX; }, r0, r1, zout, c, cvalid, cdehors, fillv);
-        } else {
-            /* patch does not fit (strong down-sampling, or non-contiguous literal seam columns): gather */
-            const ColTaps t = load_col(p.cidx, p.cw, p.ni_dst, cc);
-            sep_rows<DEG>(p, t, [&](int s) { return zin + (size_t)s * nis; }, r0, r1, zout, c, cvalid, cdehors, fillv);
+            sep_rows_staged<DEG>(p, mine, smem, p.wstride, off0, cw, by * EZHIP_SEP_ROWS, zout, c, cvalid, cdehors, fillv);
+            return;
+        }
+        /* experimental software pipeline over rb_per_block row-blocks (EZHIP_SEP_RB > 1): register-staged
+         * prefetch of the next patch.  Measured slower on gfx950 (137 VGPRs -> 3 waves/SIMD, and the
+         * in-order vmcnt makes the prefetch wait behind the previous row-block's stores). */
+        PatchRegs pr;
+        patch_issue(pr, p, zin, by0, coloff, W, lane, wv);
+        int buf = 0;
+        for (int by = by0; by < by1; by++, buf ^= 1) {
+            float *patch = smem + buf * p.patch_elems;
+            const int n = p.brow_n[by];
+            patch_commit(pr, patch, n, W, p.wstride, lane, wv);       /* waits for this row-block's loads */
+            const ezhip_rowinfo mine = pr.ri;
+            __syncthreads();                                          /* patch[buf] complete; patch[buf^1] free again */
+            if (by + 1 < by1) patch_issue(pr, p, zin, by + 1, coloff, W, lane, wv);   /* in flight during the compute below */
+            if (n > 0) sep_rows_staged<DEG>(p, mine, patch, p.wstride, off0, cw, by * EZHIP_SEP_ROWS, zout, c, cvalid, cdehors, fillv);
+            else sep_rowblock_gather<DEG>(p, ri_lds, zout, zin, by, cc, c, cvalid, cdehors, fillv);
         }
         return;
     }
 
     /* ---- special rows: polar strips, pole rows, fully-outside rows ------------------------- */
+    float *patch = smem;
     const ezhip_special_row sr = p.special[blockIdx.y];
     float outv;
     if (sr.kind == 3) {
@@ -274,13 +436,17 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
 
 extern "C" int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin)
 {
-    int nblk_main = (plan->nj_dst + EZHIP_SEP_ROWS - 1) / EZHIP_SEP_ROWS;
-    dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, nblk_main + plan->n_special);
+    int nmain = (plan->nblk_y + plan->rb_per_block - 1) / plan->rb_per_block;
+    dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, nmain + plan->n_special);
     dim3 block(SEP_BLOCK);
+    const bool pipe = plan->rb_per_block > 1;
+    size_t lds = sizeof(float) * (pipe ? 2 : 1) * (size_t)plan->patch_elems;
+#define LAUNCH_SEP(D) do { if (pipe) hipLaunchKernelGGL((k_sep<D, true>), grid, block, lds, g_stream, *plan, d_zout, d_zin); \
+                           else hipLaunchKernelGGL((k_sep<D, false>), grid, block, lds, g_stream, *plan, d_zout, d_zin); } while (0)
     switch (plan->degree) {
-    case 0: hipLaunchKernelGGL(k_sep<0>, grid, block, 0, g_stream, *plan, d_zout, d_zin); break;
-    case 1: hipLaunchKernelGGL(k_sep<1>, grid, block, 0, g_stream, *plan, d_zout, d_zin); break;
-    case 3: hipLaunchKernelGGL(k_sep<3>, grid, block, 0, g_stream, *plan, d_zout, d_zin); break;
+    case 0: LAUNCH_SEP(0); break;
+    case 1: LAUNCH_SEP(1); break;
+    case 3: LAUNCH_SEP(3); break;
     default: snprintf(g_err, sizeof(g_err), "ezhip_interp_sep: bad degree %d", plan->degree); return -1;
     }
     return LAUNCH_CHECK("k_sep");

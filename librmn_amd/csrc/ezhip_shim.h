@@ -59,9 +59,21 @@ typedef struct {
 #define EZHIP_SEP_WMAX 272            /* max staged source columns per block (>= 256 + stencil) */
 #define EZHIP_SEP_RMAX 20             /* max staged source rows per block (>= 16 + stencil) */
 
+/* per target row, AoS so that one row is two scalar loads; padded to a multiple of EZHIP_SEP_ROWS rows */
+typedef struct {
+    int    jb;              /* first source row of the taps, RELATIVE to the row-block's staged patch */
+    int    flag;            /* != 0: not a main row (special row, or padding past the last row) */
+    int    pad0, pad1;
+    double w[4];            /* cubic: y weights; linear: w[0] = dy */
+} ezhip_rowinfo;
+
 typedef struct {
     int degree;                       /* 0 nearest, 1 linear, 3 cubic */
     int ni_src, nj_src, ni_dst, nj_dst;
+    const ezhip_rowinfo *rowinfo;     /* [nblk_y * EZHIP_SEP_ROWS] */
+    int nblk_y;                       /* row-blocks of EZHIP_SEP_ROWS target rows */
+    int rb_per_block;                 /* consecutive row-blocks streamed by one thread block (software pipeline) */
+    int wstride, patch_elems;         /* LDS patch row stride and size (floats) of ONE of the two buffers */
     const int    *cidx;               /* [4][ni_dst] 0-based source column of each tap */
     const int    *coff;               /* [4][ni_dst] the same taps as offsets into the block's staged patch */
     const int    *blk_base;           /* [nblk_x] first staged source column of the block, -1: patch not usable */
