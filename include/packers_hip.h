@@ -1,0 +1,58 @@
+/*
+ * packers_hip.h -- C ABI of the MI355X-native field packers (librmn_ez_hip.so).
+ *
+ * Drop-in for librmn's compact_float / compact_integer / c_float_packer / armn_compress entry points
+ * (same names, argument meaning, return values; reference lines cited per function).  Host-pointer
+ * calls stage through device memory; the additive *_dev entry points take DEVICE pointers and enqueue
+ * on the stream selected with ezhip_use_stream (ezscint_hip.h).
+ *
+ * Not implemented on the GPU path in this round and rejected loudly (NULL / -1): tokens wider than
+ * 32 bits, and armn_compress UNCOMPRESS (SURVEY.md section 8f "next" rows).
+ */
+#ifndef PACKERS_HIP_H
+#define PACKERS_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* include/armn_compress.h:30-41 ; src/packers/compact.tmplc:37-431.  opCode 1 = FLOAT_PACK, 2 = FLOAT_UNPACK.
+ * packedTokenBitSize > 64 means (slot width << 6) | significant bits, as c_fstecr passes it (fstd98.c:1170).
+ * missingTag must be non-NULL (the reference dereferences it unconditionally). */
+void *compact_float(void *unpackedArrayOfFloat, void *packedHeader, void *packedArrayOfInt, const int elementCount,
+                    const int packedTokenBitSize, const int offset, const int stride, const int opCode,
+                    const int hasMissing, const void *const missingTag);
+
+/* src/packers/packers.h:6 ; src/packers/compact_integer.c:325-570.  opCode 1/3 = pack unsigned/signed,
+ * 2/4 = unpack.  Returns bitSizeOfPackedToken (or 0). */
+int compact_integer(void *unpackedArrayOfInt, void *packedHeader, void *packedArrayOfInt, int elementCount,
+                    int bitSizeOfPackedToken, int off_set, int stride, int opCode);
+
+/* src/packers/packers.h:11 ; src/packers/float_packer.c:258-283, 212-243, 289-319 */
+int32_t c_float_packer(float *source, int32_t nbits, int32_t *header, int32_t *stream, int32_t npts);
+int32_t c_float_unpacker(float *dest, int32_t *header, int32_t *stream, int32_t npts, int32_t *nbits);
+void    c_float_packer_params(int32_t *header_size, int32_t *stream_size, int32_t *p1, int32_t *p2, int32_t npts);
+
+/* include/armn_compress.h:17 ; src/compresseur/c_zfstlib.c:67-203.  op_code 1 = COMPRESS (in place on the
+ * 16-bit-slot token words produced by compact_float), returns the compressed byte count or -1. */
+int  armn_compress(unsigned char *fld, int ni, int nj, int nk, int nbits, int op_code);
+void c_armn_compress_setlevel(int level);       /* src/compresseur/c_zfstlib.c:1325 ; BEST = 1, FAST = 0 */
+int  c_armn_compress_getlevel(void);
+void c_armn_compress_setswap(int swapState);
+
+/* ---- additive: device-resident entry points -------------------------------------------------- */
+void *compact_float_dev(void *d_unpacked, void *d_header, void *d_packed, int elementCount, int packedTokenBitSize,
+                        int offset, int stride, int opCode, int hasMissing, const void *missingTag_host, int header_style);
+int   compact_integer_dev(void *d_unpacked, void *d_header, void *d_packed, int elementCount,
+                          int bitSizeOfPackedToken, int off_set, int stride, int opCode);
+/* out-of-place: d_words = ni*nj 16-bit-slot tokens (two per word), d_z >= (ni*nj/2 + 16) words.  Returns zlng or -1. */
+int   armn_compress_dev(void *d_z, const void *d_words, int ni, int nj, int nbits);
+/* fused cfg5 pipeline step: quantise + pack to 16-bit slots + compress one field that is already on the device
+ * (fstd98.c:1170-1172).  d_record receives [4 header words][stream]; returns zlng (>0), or -1 when the
+ * field is not compressible (d_record then holds the plain 16-bit-slot pack). */
+int   ezhip_pack16_compress_dev(void *d_record, const float *d_field, int ni, int nj, int nbits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

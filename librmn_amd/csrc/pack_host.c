@@ -1,0 +1,398 @@
+/*
+ * pack_host.c -- C host front-end of the MI355X-native field packers (librmn_ez_hip.so): librmn's
+ * compact_float / compact_integer / c_float_packer / armn_compress entry points (include/packers_hip.h)
+ * over the HIP kernels of pack_kernels.hip.  Host-pointer calls stage through device memory; there is
+ * NO CPU fallback (calls fail loudly without a HIP device).
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ezhip_shim.h"
+#include "packhip_shim.h"
+#include "../../include/packers_hip.h"
+
+static int need_device(const char *who)
+{
+    if (ezhip_runtime_ok()) return 0;
+    fprintf(stderr, "<%s> no usable HIP device: the MI355X packer path has no CPU fallback\n", who);
+    return -1;
+}
+static unsigned key_of(float f) { unsigned u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+static float float_of(unsigned k) { unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &u, 4); return f; }
+
+/* small per-thread device scratch: stats (4 u32) + cf params */
+static __thread void *t_scratch = NULL;
+static void *scratch(void)
+{
+    if (!t_scratch) t_scratch = ezhip_malloc(256);
+    return t_scratch;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* compact_float                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+static void split_token_size(int arg, int *bs, int *eff)
+{   /* compact.tmplc:121-129 */
+    if (arg > 64) { *eff = arg >> 6; *bs = arg & 0x3F; } else { *bs = arg; *eff = arg; }
+}
+
+void *compact_float_dev(void *d_unpacked, void *d_header, void *d_packed, int elementCount, int packedTokenBitSize,
+                        int offset, int stride, int opCode, int hasMissing, const void *missingTag, int header_style)
+{
+    if (need_device("compact_float")) return NULL;
+    if (packedTokenBitSize == 0) return NULL;
+    if (packedTokenBitSize == 1 && hasMissing) return NULL;
+    int bs, eff;
+    split_token_size(packedTokenBitSize, &bs, &eff);
+    if (eff > 32 || bs > 32) { fprintf(stderr, "<compact_float> tokens wider than 32 bits are not supported on the MI355X path\n"); return NULL; }
+    float tag = *(const float *)missingTag;
+    unsigned *d_stats = (unsigned *)scratch();
+    if (!d_stats) return NULL;
+    packhip_cf_params *d_pp = (packhip_cf_params *)((char *)d_stats + 64);
+    if (opCode == 1) {
+        unsigned n = (unsigned)elementCount;
+        if (header_style == 2 && n > 268435455u) { fprintf(stderr, "<compact_float> element count overflow in xxpack header\n"); return NULL; }
+        if (packhip_stats(d_stats, d_unpacked, n, stride, 0, hasMissing, tag)) return NULL;
+        if (packhip_cf_header(d_pp, (unsigned *)d_header, d_stats, n, bs, header_style, hasMissing)) return NULL;
+        if (packhip_cf_pack((unsigned *)d_packed, (const float *)d_unpacked, n, eff, offset, stride, d_pp, hasMissing, tag)) return NULL;
+        return d_packed;
+    }
+    if (opCode == 2) {
+        unsigned hdr[4];
+        if (ezhip_d2h(hdr, d_header, sizeof(hdr)) || ezhip_sync()) return NULL;
+        unsigned marker = hdr[0] >> 20, counter = hdr[0] & 0xFFFFF;
+        unsigned rangeExpo = hdr[1] >> 16, minExpo = (hdr[1] >> 4) & 0xFFF, minSign = hdr[1] & 0xF;
+        unsigned minMantisa32 = hdr[2], bitSize = (hdr[3] >> 8) & 0xFF, emptySpace = hdr[3] & 0xFF;
+        unsigned intCount = (marker == 0x7ff || marker == 0x7ef) ? (unsigned)elementCount : (emptySpace << 20 | counter);
+        int tokenSize = (int)bitSize;
+        if (tokenSize > 32 || tokenSize < 1) return NULL;
+        unsigned missingToken = (tokenSize != 32) ? ~(0xFFFFFFFFu << tokenSize) : ~0u;
+        unsigned rangeExponent = rangeExpo - 4096 + 127 + tokenSize;
+        double mulFactor = ldexp(1.0, (int)(rangeExponent - 127 - tokenSize)), minF = 0;
+        if (!(minMantisa32 == 0 || minExpo < 849)) {
+            unsigned u = (minSign & 1) << 31 | ((minExpo + 127 - 1024 + 48) & 0xFF) << 23 | ((minMantisa32 >> 8) & 0x7fffff);
+            float f; memcpy(&f, &u, 4); minF = f;
+        }
+        if (packhip_cf_unpack((float *)d_unpacked, (const unsigned *)d_packed, intCount, tokenSize, offset, stride, minF, mulFactor, missingToken, hasMissing, tag)) return NULL;
+        return d_unpacked;
+    }
+    fprintf(stderr, "<compact_float> opCode (%d) is not defined\n", opCode);
+    return NULL;
+}
+
+void *compact_float(void *unpackedArrayOfFloat, void *packedHeader, void *packedArrayOfInt, const int elementCount,
+                    const int packedTokenBitSize, const int offset, const int stride, const int opCode,
+                    const int hasMissing, const void *const missingTag)
+{
+    if (need_device("compact_float")) return NULL;
+    if (packedTokenBitSize == 0) return NULL;
+    int bs, eff;
+    split_token_size(packedTokenBitSize, &bs, &eff);
+    if (eff > 32) { fprintf(stderr, "<compact_float> tokens wider than 32 bits are not supported on the MI355X path\n"); return NULL; }
+    unsigned *hdr = (unsigned *)packedHeader, *out = (unsigned *)packedArrayOfInt;
+    size_t n = (size_t)elementCount, nfl = n ? (n - 1) * (size_t)stride + 1 : 0;
+    size_t span_words = ((size_t)offset + n * (size_t)eff + 31) / 32;      /* words the stream touches, from the stream base */
+    /* header style (compact.tmplc:159-168): the stream may START INSIDE the header (style 1); mirror that
+     * aliasing on the device by staging one contiguous image [header | stream] */
+    int style = ((&hdr[3] == out && offset == 24) || (&hdr[0] == out && offset == 120)) ? 1 : 2;
+    size_t lead = (style == 1) ? (size_t)(out - hdr) : 4;       /* words between header start and stream base */
+    float *d_a = (float *)ezhip_malloc(sizeof(float) * (nfl ? nfl : 1));
+    unsigned *d_img = (unsigned *)ezhip_malloc(4 * (lead + span_words + 8));
+    void *ret = NULL;
+    if (!d_a || !d_img) goto done;
+    unsigned *d_hdr = d_img, *d_out = d_img + lead;
+    if (opCode == 1) {
+        if (ezhip_h2d(d_a, unpackedArrayOfFloat, sizeof(float) * nfl)) goto done;
+        if (ezhip_h2d(d_out, out, 4 * span_words)) goto done;      /* neighbouring bits of the first / last word survive */
+        if (style == 1 && lead) { if (ezhip_h2d(d_hdr, hdr, 4 * lead)) goto done; }
+        if (!compact_float_dev(d_a, d_hdr, d_out, elementCount, packedTokenBitSize, offset, stride, 1, hasMissing, missingTag, style)) goto done;
+        if (style == 1) { size_t tot = lead + span_words; if (tot < 4) tot = 4; if (ezhip_d2h(hdr, d_hdr, 4 * tot)) goto done; }
+        else { if (ezhip_d2h(hdr, d_hdr, 16) || ezhip_d2h(out, d_out, 4 * span_words)) goto done; }
+        if (ezhip_sync()) goto done;
+        ret = packedArrayOfInt;
+    } else if (opCode == 2) {
+        if (ezhip_h2d(d_hdr, hdr, 16) || ezhip_h2d(d_out, out, 4 * span_words)) goto done;
+        if (nfl && stride != 1 && ezhip_h2d(d_a, unpackedArrayOfFloat, sizeof(float) * nfl)) goto done;   /* keep the gaps */
+        if (!compact_float_dev(d_a, d_hdr, d_out, elementCount, packedTokenBitSize, offset, stride, 2, hasMissing, missingTag, style)) goto done;
+        if (ezhip_d2h(unpackedArrayOfFloat, d_a, sizeof(float) * nfl) || ezhip_sync()) goto done;
+        ret = unpackedArrayOfFloat;
+    } else fprintf(stderr, "<compact_float> opCode (%d) is not defined\n", opCode);
+done:
+    ezhip_sync();
+    ezhip_free(d_a); ezhip_free(d_img);
+    return ret;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* compact_integer                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+static int bitlen32(unsigned v) { int n = 0; while (v) { v >>= 1; n++; } return n; }
+
+typedef struct { int E, shift, with_header, is_signed; unsigned minv, positiveMask, hdr[4]; } ci_plan;
+
+/* everything compact_integer decides before the token loop (compact_integer.c:396-530) */
+static int ci_prepare_pack(ci_plan *pl, const void *d_unpacked, int has_header, size_t n, int bitSize, int stride, int opCode)
+{
+    unsigned *d_stats = (unsigned *)scratch();
+    if (!d_stats) return -1;
+    unsigned st[4] = {0, 0, 0, 0};
+    memset(pl, 0, sizeof(*pl));
+    pl->with_header = has_header; pl->is_signed = (opCode == 3);
+    if (has_header || bitSize == -1) {
+        if (packhip_stats(d_stats, d_unpacked, n, stride, opCode == 1 ? 1 : 2, 0, 0.f)) return -1;
+        if (ezhip_d2h(st, d_stats, sizeof(st)) || ezhip_sync()) return -1;
+    }
+    if (has_header) {                                                     /* constructHeader :186-231 */
+        unsigned maxRange;
+        if (opCode == 1) { maxRange = st[1] - st[0]; pl->minv = st[0]; pl->hdr[2] = st[0]; pl->hdr[3] = st[1]; }
+        else {
+            int mn = (int)(st[0] ^ 0x80000000u), mx = (int)(st[1] ^ 0x80000000u);
+            maxRange = (mx > 0 && mn < 0) ? (unsigned)mx + (unsigned)(-mn) : (unsigned)(mx - mn);
+            pl->minv = (unsigned)mn; pl->hdr[2] = (unsigned)mn; pl->hdr[3] = (unsigned)mx;
+        }
+        int bitRequired = bitlen32(maxRange);
+        if (bitSize == -1) bitSize = bitRequired;
+        else while ((bitRequired - bitSize) > 0) { pl->shift++; bitRequired--; }
+        pl->hdr[0] = 0xFD000000u | ((unsigned)pl->shift << 6) | (unsigned)bitSize;
+        pl->hdr[1] = (unsigned)n;
+    } else if (bitSize == -1) {                                           /* :446-489 */
+        unsigned maxSpan;
+        if (opCode == 3) { int mn = (int)(st[0] ^ 0x80000000u), mx = (int)(st[1] ^ 0x80000000u); maxSpan = (unsigned)((abs(mn) > mx) ? abs(mn) : mx); }
+        else maxSpan = st[2];
+        bitSize = bitlen32(maxSpan) + (opCode == 3 ? 1 : 0);
+    }
+    pl->E = bitSize;
+    if (bitSize >= 1 && bitSize <= 32) pl->positiveMask = (opCode < 3) ? 0 : (1u << (bitSize - 1));
+    return 0;
+}
+
+int compact_integer_dev(void *d_unpacked, void *d_header, void *d_packed, int elementCount,
+                        int bitSizeOfPackedToken, int off_set, int stride, int opCode)
+{
+    if (need_device("compact_integer")) return 0;
+    if (bitSizeOfPackedToken == 0) return 0;
+    size_t n = (size_t)elementCount;
+    if (opCode == 1 || opCode == 3) {
+        ci_plan pl;
+        if (ci_prepare_pack(&pl, d_unpacked, d_header != NULL, n, bitSizeOfPackedToken, stride, opCode)) return 0;
+        if (d_header && (ezhip_h2d(d_header, pl.hdr, 16) || ezhip_sync())) return 0;
+        if (pl.E < 1 || pl.E > 32) return pl.E;
+        if (packhip_ci_pack((unsigned *)d_packed, d_unpacked, n, pl.E, off_set, stride, pl.with_header, pl.is_signed, pl.minv, pl.shift, pl.positiveMask)) return 0;
+        return pl.E;
+    }
+    if (opCode == 2 || opCode == 4) {
+        int tokenSize = bitSizeOfPackedToken, shift = 0; unsigned minv = 0;
+        if (d_header != NULL) {
+            unsigned hdr[4];
+            if (ezhip_d2h(hdr, d_header, sizeof(hdr)) || ezhip_sync()) return 0;
+            tokenSize = hdr[0] & 0x3F; shift = (hdr[0] >> 6) & 0x3F; n = hdr[1]; minv = hdr[2];
+        }
+        if (tokenSize < 1 || tokenSize > 32) { fprintf(stderr, "<compact_integer> token size %d not supported on the MI355X path\n", tokenSize); return 0; }
+        unsigned negMask = (opCode < 3) ? 0 : (unsigned)(-(int)(1u << (bitSizeOfPackedToken - 1)));
+        if (packhip_ci_unpack(d_unpacked, (const unsigned *)d_packed, n, tokenSize, off_set, stride, d_header != NULL, minv, shift, negMask)) return 0;
+        return bitSizeOfPackedToken;
+    }
+    fprintf(stderr, "<compact_integer> opCode (%d) is not defined\n", opCode);
+    return 0;
+}
+
+int compact_integer(void *unpackedArrayOfInt, void *packedHeader, void *packedArrayOfInt, int elementCount,
+                    int bitSizeOfPackedToken, int off_set, int stride, int opCode)
+{
+    if (need_device("compact_integer")) return 0;
+    if (bitSizeOfPackedToken == 0) return 0;
+    size_t n = (size_t)elementCount;
+    int rc = 0;
+    unsigned *d_a = NULL, *d_out = NULL;
+    if (opCode == 1 || opCode == 3) {
+        size_t nin = n ? (n - 1) * (size_t)stride + 1 : 0;
+        d_a = (unsigned *)ezhip_malloc(4 * (nin ? nin : 1));
+        if (!d_a || ezhip_h2d(d_a, unpackedArrayOfInt, 4 * nin)) goto done;
+        ci_plan pl;
+        if (ci_prepare_pack(&pl, d_a, packedHeader != NULL, n, bitSizeOfPackedToken, stride, opCode)) goto done;
+        if (packedHeader) memcpy(packedHeader, pl.hdr, 16);
+        rc = pl.E;
+        if (pl.E < 1 || pl.E > 32) goto done;
+        size_t words = ((size_t)off_set + n * (size_t)pl.E + 31) / 32;
+        d_out = (unsigned *)ezhip_malloc(4 * (words + 4));
+        rc = 0;
+        if (!d_out || ezhip_h2d(d_out, packedArrayOfInt, 4 * words)) goto done;     /* first/last word neighbours survive */
+        if (packhip_ci_pack(d_out, d_a, n, pl.E, off_set, stride, pl.with_header, pl.is_signed, pl.minv, pl.shift, pl.positiveMask)) goto done;
+        if (ezhip_d2h(packedArrayOfInt, d_out, 4 * words) || ezhip_sync()) goto done;
+        rc = pl.E;
+    } else if (opCode == 2 || opCode == 4) {
+        int tokenSize = bitSizeOfPackedToken, shift = 0; unsigned minv = 0;
+        if (packedHeader) { unsigned *h = (unsigned *)packedHeader; tokenSize = h[0] & 0x3F; shift = (h[0] >> 6) & 0x3F; n = h[1]; minv = h[2]; }
+        if (tokenSize < 1 || tokenSize > 32) { fprintf(stderr, "<compact_integer> token size %d not supported on the MI355X path\n", tokenSize); goto done; }
+        size_t nin = n ? (n - 1) * (size_t)stride + 1 : 0, words = ((size_t)off_set + n * (size_t)tokenSize + 31) / 32;
+        d_a = (unsigned *)ezhip_malloc(4 * (nin ? nin : 1)); d_out = (unsigned *)ezhip_malloc(4 * (words + 4));
+        if (!d_a || !d_out || ezhip_h2d(d_out, packedArrayOfInt, 4 * words)) goto done;
+        if (stride != 1 && ezhip_h2d(d_a, unpackedArrayOfInt, 4 * nin)) goto done;
+        unsigned negMask = (opCode < 3) ? 0 : (unsigned)(-(int)(1u << (bitSizeOfPackedToken - 1)));
+        if (packhip_ci_unpack(d_a, d_out, n, tokenSize, off_set, stride, packedHeader != NULL, minv, shift, negMask)) goto done;
+        if (ezhip_d2h(unpackedArrayOfInt, d_a, 4 * nin) || ezhip_sync()) goto done;
+        rc = bitSizeOfPackedToken;
+    } else fprintf(stderr, "<compact_integer> opCode (%d) is not defined\n", opCode);
+done:
+    ezhip_sync();
+    ezhip_free(d_a); ezhip_free(d_out);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* c_float_packer / c_float_unpacker                                                            */
+/* ------------------------------------------------------------------------------------------ */
+static int aligned_mantissa(int src, int maxExp)
+{
+    int mantis = (1 << 23) | (0x7FFFFF & src);
+    int e = (src >> 23) & 0xFF, shift = maxExp - e;
+    if (shift > 31) shift = 31;
+    mantis = mantis >> shift;
+    if (src >> 31) mantis = -mantis;
+    return mantis;
+}
+
+int32_t c_float_packer(float *source, int32_t nbits, int32_t *header, int32_t *stream, int32_t npts)
+{
+    if (nbits > 16 || nbits < 1) { fprintf(stderr, "<c_float_packer> nbits must be > 0 and <= 16 ,nbits = %d\n", nbits); return -1; }
+    if (need_device("c_float_packer")) return -1;
+    header[2] = npts;
+    header[0] = (int32_t)(0xEFFu << 20);
+    header[0] = header[0] | ((nbits - 1) << 16);
+    float *d_src = (float *)ezhip_malloc(4 * (size_t)(npts > 0 ? npts : 1));
+    int *d_stream = (int *)ezhip_malloc(4 * (size_t)((npts + 1) / 2 + 1));
+    unsigned *d_stats = (unsigned *)scratch();
+    int rc = -1;
+    if (!d_src || !d_stream || !d_stats) goto done;
+    unsigned st[4];
+    if (ezhip_h2d(d_src, source, 4 * (size_t)npts)) goto done;
+    if (packhip_stats(d_stats, d_src, (size_t)npts, 1, 0, 0, 0.f)) goto done;
+    if (ezhip_d2h(st, d_stats, sizeof(st)) || ezhip_sync()) goto done;
+    {   /* float_packer_1, float_packer.c:128-202: header arithmetic on the min / max values */
+        float fminf_ = float_of(st[0]), fmaxf_ = float_of(st[1]);
+        int fmin_i, fmax_i;
+        memcpy(&fmin_i, &fminf_, 4); memcpy(&fmax_i, &fmaxf_, 4);
+        int MaxExp = (fmax_i >> 23) & 0xFF, Exp = (fmin_i >> 23) & 0xFF;
+        MaxExp = MaxExp > Exp ? MaxExp : Exp;
+        int Maximum = aligned_mantissa(fmax_i, MaxExp);
+        if (((fmax_i >> 23) & 0xFF) < 1) Maximum = 0;
+        int Minimum = aligned_mantissa(fmin_i, MaxExp);
+        if (((fmin_i >> 23) & 0xFF) < 1) Minimum = 0;
+        Maximum = Maximum - Minimum;
+        int Shift2 = 0, Round = 1, Mask = ~(-1 << nbits);
+        while (Maximum > Mask) { Maximum = Maximum >> 1; Round = Round << 1; Shift2++; }
+        Round = Round >> 1;
+        header[1] = Minimum;
+        header[0] = header[0] | ((MaxExp & 0xFF) << 8) | (Shift2 & 0xFF);
+        if (packhip_fp_pack(d_stream, d_src, npts, MaxExp, Minimum, Round, Shift2, Mask)) goto done;
+    }
+    if (ezhip_d2h(stream, d_stream, 4 * (size_t)((npts + 1) / 2)) || ezhip_sync()) goto done;
+    rc = 0;
+done:
+    ezhip_sync();
+    ezhip_free(d_src); ezhip_free(d_stream);
+    (void)key_of;
+    return rc;
+}
+
+int32_t c_float_unpacker(float *dest, int32_t *header, int32_t *stream, int32_t npts, int32_t *nbits)
+{
+    *nbits = ((header[0] >> 16) & 0xF) + 1;
+    if (0xEFF != ((header[0] >> 20) & 0xFFF)) { fprintf(stderr, "<c_float_unpacker> Invalid header\n"); return -1; }
+    if (npts != header[2]) { fprintf(stderr, "<c_float_unpacker> Inconsistent number of points (header/request mismatch)\n"); return -1; }
+    if (need_device("c_float_unpacker")) return -1;
+    float *d_dest = (float *)ezhip_malloc(4 * (size_t)(npts > 0 ? npts : 1));
+    int *d_stream = (int *)ezhip_malloc(4 * (size_t)((npts + 1) / 2 + 1));
+    int rc = -1;
+    if (!d_dest || !d_stream) goto done;
+    if (ezhip_h2d(d_stream, stream, 4 * (size_t)((npts + 1) / 2))) goto done;
+    if (packhip_fp_unpack(d_dest, d_stream, npts, (header[0] >> 8) & 0xFF, header[1], header[0] & 0xFF)) goto done;
+    if (ezhip_d2h(dest, d_dest, 4 * (size_t)npts) || ezhip_sync()) goto done;
+    rc = 0;
+done:
+    ezhip_sync();
+    ezhip_free(d_dest); ezhip_free(d_stream);
+    return rc;
+}
+
+void c_float_packer_params(int32_t *header_size, int32_t *stream_size, int32_t *p1, int32_t *p2, int32_t npts)
+{   /* float_packer.c:289-319 */
+    *header_size = 3 * (int32_t)sizeof(int32_t);
+    *stream_size = ((npts + 1) / 2) * (int32_t)sizeof(int32_t);
+    *p1 = 0; *p2 = 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* armn_compress                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+static int g_level = -1, g_swap = 1;
+void c_armn_compress_setlevel(int level) { g_level = level; }
+int  c_armn_compress_getlevel(void) { return g_level; }
+void c_armn_compress_setswap(int swapState) { g_swap = swapState; }
+
+int armn_compress_dev(void *d_z, const void *d_words, int ni, int nj, int nbits)
+{
+    if (need_device("armn_compress")) return -1;
+    if (nbits > 16 || ni == 1 || nj == 1) { fprintf(stderr, "<armn_compress> Cannot compress if nbits>16 or ni=1 or nj=1. Returning original field\n"); return -1; }
+    if (g_level == -1) g_level = 1;                                   /* BEST, c_zfstlib.c:92-97 */
+    int minimum = (g_level == 0) || ni < 16 || nj < 16 || nbits <= 4; /* :132 */
+    size_t n = (size_t)ni * nj;
+    void *d_work = ezhip_malloc(packhip_armn_work_bytes(ni, nj));
+    if (!d_work) return -1;
+    unsigned long long bits = 0;
+    /* the raw stream can exceed the source size for incompressible fields: the caller's buffer holds
+     * n/2 + 16 words, the bound checked below uses the exact bit count from the scan */
+    size_t z_words = n / 2 + 16;
+    int rc = packhip_armn_encode((unsigned *)d_z, z_words, (const unsigned *)d_words, ni, nj, nbits, minimum, d_work, &bits);
+    ezhip_free(d_work);
+    if (rc) return -1;
+    long long zlng = 1 + 4 * (1 + (long long)((bits + 32) / 32));
+    long long lng_origin = 1 + (long long)n * 2;
+    if (zlng >= lng_origin) return -1;
+    return (int)zlng;
+}
+
+int armn_compress(unsigned char *fld, int ni, int nj, int nk, int nbits, int op_code)
+{
+    (void)nk;
+    if (op_code == 2) {
+        fprintf(stderr, "<armn_compress> UNCOMPRESS is not part of the MI355X hot path (SURVEY 8f next row)\n");
+        return -1;
+    }
+    if (op_code != 1) return 0;
+    if (need_device("armn_compress")) return -1;
+    if (nbits > 16 || ni == 1 || nj == 1) { fprintf(stderr, "<armn_compress> Cannot compress if nbits>16 or ni=1 or nj=1. Returning original field\n"); return -1; }
+    size_t n = (size_t)ni * nj, words = (n + 1) / 2;
+    unsigned *d_in = (unsigned *)ezhip_malloc(4 * (words + 2)), *d_z = (unsigned *)ezhip_malloc(4 * (n / 2 + 32));
+    int zlng = -1;
+    if (!d_in || !d_z) goto done;
+    if (ezhip_h2d(d_in, fld, 4 * words)) goto done;
+    zlng = armn_compress_dev(d_z, d_in, ni, nj, nbits);
+    if (zlng > 0) {
+        /* the reference copies zlng bytes; its last byte comes from an unwritten malloc'ed word (undefined):
+         * here it is the zero byte of the zero-initialised stream */
+        if (ezhip_d2h(fld, d_z, (size_t)zlng) || ezhip_sync()) zlng = -1;
+    }
+done:
+    ezhip_sync();
+    ezhip_free(d_in); ezhip_free(d_z);
+    return zlng;
+}
+
+/* fused cfg5 step on device data (fstd98.c:1170-1172): compact_float(16-bit slots, style 2) + armn_compress */
+int ezhip_pack16_compress_dev(void *d_record, const float *d_field, int ni, int nj, int nbits)
+{
+    float tag = 0.f;
+    unsigned *rec = (unsigned *)d_record;
+    size_t n = (size_t)ni * nj;
+    if (!compact_float_dev((void *)d_field, rec, rec + 4, (int)n, nbits + 64 * (nbits > 16 ? nbits : 16), 0, 1, 1, 0, &tag, 2)) return -1;
+    unsigned *d_z = (unsigned *)ezhip_malloc(4 * (n / 2 + 32));
+    if (!d_z) return -1;
+    int zlng = armn_compress_dev(d_z, rec + 4, ni, nj, nbits);
+    if (zlng > 0 && ezhip_d2d(rec + 4, d_z, (size_t)zlng)) zlng = -1;
+    ezhip_sync();
+    ezhip_free(d_z);
+    return zlng;
+}

@@ -1,0 +1,533 @@
+/*
+ * pack_kernels.hip -- HIP kernels (gfx950) for librmn's field packers: compact_float, compact_integer,
+ * c_float_packer and armn_compress (COMPRESS), plus their C-ABI launchers (packhip_*).
+ *
+ * All streams are MSB-first token streams in host-endian uint32 words (include/bitPacking.h `stuff`).
+ * Mapping to the GPU: a token stream with a FIXED token width is embarrassingly parallel once every
+ * thread owns whole 32-bit output words (no atomics); the variable-width armn_compress stream is
+ * sized by an exclusive scan of per-tile bit lengths and then emitted independently per tile into a
+ * zeroed buffer with atomicOr (tiles share boundary words).  Integer / bit work only: HBM bound.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "packhip_shim.h"
+
+#pragma clang fp contract(off)
+
+extern "C" void *ezhip_get_stream(void);
+#define STREAM ((hipStream_t)ezhip_get_stream())
+static int chk(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return -1; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* reductions                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ unsigned f2key(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+/* stats[0] = min key, stats[1] = max key, stats[2] = OR of raw words (compact_integer auto width) */
+template <int KIND>   /* 0: float keys, 1: uint32, 2: int32 (biased) */
+__global__ __launch_bounds__(256) void k_stats(unsigned *stats, const unsigned *a, size_t n, int stride, int has_missing, float tag)
+{
+    unsigned kmin = 0xffffffffu, kmax = 0u, kor = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned raw = a[i * stride], k;
+        if (KIND == 0) { float f = __uint_as_float(raw); if (has_missing && f == tag) continue; k = f2key(f); }
+        else if (KIND == 1) k = raw;
+        else k = raw ^ 0x80000000u;
+        kmin = min(kmin, k); kmax = max(kmax, k); kor |= raw;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (unsigned)__shfl_down((int)kmin, off, 64));
+        kmax = max(kmax, (unsigned)__shfl_down((int)kmax, off, 64));
+        kor |= (unsigned)__shfl_down((int)kor, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&stats[0], kmin); atomicMax(&stats[1], kmax); atomicOr(&stats[2], kor); }
+}
+
+extern "C" int packhip_stats(unsigned *d_stats, const void *d_a, size_t n, int stride, int kind, int has_missing, float tag)
+{
+    unsigned init[4] = {0xffffffffu, 0u, 0u, 0u};
+    if (hipMemcpyAsync(d_stats, init, sizeof(init), hipMemcpyHostToDevice, STREAM) != hipSuccess) return -1;
+    int nb = (int)((n + 255) / 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
+    if (kind == 0) hipLaunchKernelGGL(k_stats<0>, dim3(nb), dim3(256), 0, STREAM, d_stats, (const unsigned *)d_a, n, stride, has_missing, tag);
+    else if (kind == 1) hipLaunchKernelGGL(k_stats<1>, dim3(nb), dim3(256), 0, STREAM, d_stats, (const unsigned *)d_a, n, stride, 0, 0.f);
+    else hipLaunchKernelGGL(k_stats<2>, dim3(nb), dim3(256), 0, STREAM, d_stats, (const unsigned *)d_a, n, stride, 0, 0.f);
+    return chk("k_stats");
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* compact_float: header (compact.tmplc:210-290) on one lane, then the token stream               */
+/* ------------------------------------------------------------------------------------------ */
+__global__ void k_cf_header(packhip_cf_params *pp, unsigned *hdr, const unsigned *stats, unsigned n, int bs, int style, int has_missing)
+{
+    double minF = (double)key2f(stats[0]), maxF = (double)key2f(stats[1]);
+    unsigned missingToken = (bs != 32) ? ~(0xFFFFFFFFu << bs) : ~0u;
+    int too_large = (maxF > 1.0e+38) || (minF < -1.0e+38);
+    unsigned long long range = (unsigned long long)__double_as_longlong((maxF - minF) * 2);
+    unsigned long long minbits = (unsigned long long)__double_as_longlong(minF);
+    range &= 0xFFF0000000000000ull;
+    double ranged = __longlong_as_double((long long)range);
+    unsigned tempInt = (ranged == 0) ? 0 : (unsigned)(long long)((maxF - minF) * ldexp(1.0, bs) / ranged);
+    if (tempInt == missingToken && has_missing) range += 0x0010000000000000ull;
+    int rexpo = (int)((range >> 52) & 0x7FF);
+    int tempExpo = (ranged == 0) ? 0 : (rexpo - 1023);
+    unsigned scaledExpOfMinFloat = (unsigned)((int)((minbits >> 52) & 0x7FF) - 1023 + 1024 - 48);
+    unsigned scaledExpOfRange = (unsigned)(tempExpo - bs);
+    unsigned signOfMinFloat = (minF < 0) ? 1 : 0;
+    if (minF == 0.0) scaledExpOfMinFloat &= 0x00000111;
+    unsigned headerType = (style == 1) ? (has_missing == 1 ? 0x7ef : 0x7ff) : (has_missing == 1 ? 0xfef : 0xfff);
+    hdr[0] = headerType << 20 | ((n << 12) >> 12);
+    hdr[1] = ((scaledExpOfRange + 4096) << 16) | ((scaledExpOfMinFloat << 4) | signOfMinFloat);
+    if (minF == 0.0) hdr[2] = 0;
+    else hdr[2] = 0x80000000u | ((unsigned)((minbits >> 32) & 0xFFFFF) << 11) | ((unsigned)((minbits >> 29) & 0x7) << 8);
+    unsigned w3 = (unsigned)bs << 8 | ((n << 4) >> 24);
+    hdr[3] = w3;       /* style 1 (offset 24): the stream then overwrites the low byte, as in the reference */
+    pp->hdr3 = w3;
+    pp->minF = minF;
+    pp->mulFactor = ldexp(1.0, bs) / ldexp(1.0, tempExpo);
+    pp->missingToken = missingToken;
+    pp->too_large = too_large;
+}
+
+__device__ __forceinline__ unsigned cf_token(const float *a, size_t i, int stride, const packhip_cf_params &p, int has_missing, float tag)
+{
+    float x = a[i * stride];
+    if (has_missing == 1 && x == tag) return p.missingToken;
+    return (unsigned)(long long)(((double)x - p.minF) * p.mulFactor);
+}
+
+/* generic fixed-width stream: one thread per output word; TOK(t) yields token t (already masked to E bits
+ * when it has to be).  Bits before `offset` in the first word and after the last token in the last word
+ * are preserved (compact.tmplc:292-300, :329-332). */
+template <class TokFn>
+__device__ __forceinline__ void emit_word(unsigned *out, size_t w, size_t n, int E, int offset, TokFn TOK)
+{
+    const long long first_bit = (long long)w * 32, end_bit = (long long)offset + (long long)n * E;
+    long long t0 = (first_bit - offset) / E;
+    if (first_bit < offset) t0 = 0;
+    unsigned word = 0, written = 0;           /* written: mask of bits this stream owns in the word */
+    for (long long t = t0; t < (long long)n; t++) {
+        long long tb = (long long)offset + t * E;            /* first stream bit of token t */
+        if (tb >= first_bit + 32) break;
+        unsigned long long tok = (unsigned long long)TOK((size_t)t) & (E == 32 ? 0xFFFFFFFFull : ((1ull << E) - 1));
+        long long sh = (first_bit + 32) - (tb + E);          /* left shift that aligns the token's LSB in this word */
+        unsigned piece, mask;
+        unsigned long long full = (E == 32) ? 0xFFFFFFFFull : ((1ull << E) - 1);
+        if (sh >= 0) { piece = (unsigned)(tok << sh); mask = (unsigned)(full << sh); }
+        else { piece = (unsigned)(tok >> (-sh)); mask = (unsigned)(full >> (-sh)); }
+        word |= piece; written |= mask;
+    }
+    (void)end_bit;
+    if (written != 0xFFFFFFFFu) word |= out[w] & ~written;   /* partial first / last word: keep the neighbours */
+    out[w] = word;
+}
+
+__global__ __launch_bounds__(256) void k_cf_pack(unsigned *out, const float *a, size_t n, int E, int offset, int stride,
+                                                 const packhip_cf_params *pp, int has_missing, float tag, size_t w0, size_t nwords)
+{
+    size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nwords) return;
+    const packhip_cf_params p = *pp;
+    emit_word(out, w0 + k, n, E, offset, [&](size_t t) { return cf_token(a, t, stride, p, has_missing, tag); });
+}
+
+/* fast path: 16-bit slots, offset 0, stride 1: 8 floats -> 4 words per thread (16 B in / 8 B out per token pair) */
+__global__ __launch_bounds__(256) void k_cf_pack16(uint4 *out, const float4 *a, size_t n8, const packhip_cf_params *pp)
+{
+    size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n8) return;
+    const double minF = pp->minF, mul = pp->mulFactor;
+    float4 x = a[2 * k], y = a[2 * k + 1];
+#define TK(v) ((unsigned)(long long)(((double)(v) - minF) * mul) & 0xFFFFu)
+    uint4 o;
+    o.x = TK(x.x) << 16 | TK(x.y); o.y = TK(x.z) << 16 | TK(x.w);
+    o.z = TK(y.x) << 16 | TK(y.y); o.w = TK(y.z) << 16 | TK(y.w);
+#undef TK
+    out[k] = o;
+}
+
+extern "C" int packhip_cf_header(packhip_cf_params *d_pp, unsigned *d_hdr, const unsigned *d_stats, unsigned n, int bs, int style, int has_missing)
+{
+    hipLaunchKernelGGL(k_cf_header, dim3(1), dim3(1), 0, STREAM, d_pp, d_hdr, d_stats, n, bs, style, has_missing);
+    return chk("k_cf_header");
+}
+
+extern "C" int packhip_cf_pack(unsigned *d_out, const float *d_a, size_t n, int E, int offset, int stride,
+                               const packhip_cf_params *d_pp, int has_missing, float tag)
+{
+    if (n == 0) return 0;
+    size_t w0 = (size_t)offset / 32, w1 = ((size_t)offset + n * (size_t)E + 31) / 32;
+    if (E == 16 && offset == 0 && stride == 1 && !has_missing && ((uintptr_t)d_a % 16 == 0) && ((uintptr_t)d_out % 16 == 0)) {
+        size_t n8 = n / 8;
+        if (n8) hipLaunchKernelGGL(k_cf_pack16, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, STREAM, (uint4 *)d_out, (const float4 *)d_a, n8, d_pp);
+        size_t done_words = n8 * 4;
+        if (done_words < w1)    /* tail words through the generic kernel */
+            hipLaunchKernelGGL(k_cf_pack, dim3((unsigned)((w1 - done_words + 255) / 256)), dim3(256), 0, STREAM, d_out, d_a, n, E, offset, stride, d_pp, 0, tag, done_words, w1 - done_words);
+        return chk("k_cf_pack16");
+    }
+    hipLaunchKernelGGL(k_cf_pack, dim3((unsigned)((w1 - w0 + 255) / 256)), dim3(256), 0, STREAM, d_out, d_a, n, E, offset, stride, d_pp, has_missing, tag, w0, w1 - w0);
+    return chk("k_cf_pack");
+}
+
+/* token t of a fixed-width stream */
+__device__ __forceinline__ unsigned read_token(const unsigned *in, size_t t, int E, int offset)
+{
+    unsigned long long bit = (unsigned long long)offset + (unsigned long long)t * E;
+    size_t w = (size_t)(bit >> 5);
+    int sh = (int)(bit & 31);
+    unsigned long long two = ((unsigned long long)in[w] << 32) | (sh + E > 32 ? in[w + 1] : 0u);
+    return (unsigned)((two << sh) >> (64 - E));
+}
+
+/* FLOAT_UNPACK, compact.tmplc:336-425 */
+__global__ __launch_bounds__(256) void k_cf_unpack(float *a, const unsigned *in, size_t n, int tokenSize, int offset, int stride,
+                                                   double minF, double mulFactor, unsigned missingToken, int has_missing, float tag)
+{
+    size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    int sig = tokenSize > 32 ? 32 : tokenSize;
+    unsigned tok = read_token(in, t, sig, offset);       /* tokenSize > 32 is not produced by the packer */
+    float v;
+    if (has_missing == 1 && tok == missingToken) v = tag;
+    else if (tok == 0) v = (float)minF;
+    else v = (float)((tok * mulFactor) * 1.0000000000001 + minF);
+    a[t * stride] = v;
+}
+extern "C" int packhip_cf_unpack(float *d_a, const unsigned *d_in, size_t n, int tokenSize, int offset, int stride,
+                                 double minF, double mulFactor, unsigned missingToken, int has_missing, float tag)
+{
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_cf_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM, d_a, d_in, n, tokenSize, offset, stride, minF, mulFactor, missingToken, has_missing, tag);
+    return chk("k_cf_unpack");
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* compact_integer (compact_integer.c:69-170, 245-303)                                           */
+/* ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_ci_pack(unsigned *out, const unsigned *a, size_t n, int E, int offset, int stride,
+                                                 int with_header, int is_signed, unsigned minv, int shift, unsigned positiveMask, size_t w0, size_t nwords)
+{
+    size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nwords) return;
+    emit_word(out, w0 + k, n, E, offset, [&](size_t t) {
+        unsigned x = a[t * stride];
+        if (!with_header) return x + positiveMask;
+        if (is_signed) return (unsigned)(((int)x - (int)minv) >> shift);
+        return (x - minv) >> shift;
+    });
+}
+extern "C" int packhip_ci_pack(unsigned *d_out, const void *d_a, size_t n, int E, int offset, int stride,
+                               int with_header, int is_signed, unsigned minv, int shift, unsigned positiveMask)
+{
+    if (!n) return 0;
+    size_t w0 = (size_t)offset / 32, w1 = ((size_t)offset + n * (size_t)E + 31) / 32;
+    hipLaunchKernelGGL(k_ci_pack, dim3((unsigned)((w1 - w0 + 255) / 256)), dim3(256), 0, STREAM, d_out, (const unsigned *)d_a, n, E, offset, stride, with_header, is_signed, minv, shift, positiveMask, w0, w1 - w0);
+    return chk("k_ci_pack");
+}
+__global__ __launch_bounds__(256) void k_ci_unpack(unsigned *a, const unsigned *in, size_t n, int E, int offset, int stride,
+                                                   int with_header, unsigned minv, int shift, unsigned negMask)
+{
+    size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    unsigned tok = read_token(in, t, E > 32 ? 32 : E, offset);
+    a[t * stride] = with_header ? (tok << shift) + minv : tok + negMask;
+}
+extern "C" int packhip_ci_unpack(void *d_a, const unsigned *d_in, size_t n, int E, int offset, int stride, int with_header, unsigned minv, int shift, unsigned negMask)
+{
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_ci_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM, (unsigned *)d_a, d_in, n, E, offset, stride, with_header, minv, shift, negMask);
+    return chk("k_ci_unpack");
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* c_float_packer (float_packer.c:128-202): two 16-bit tokens per word                           */
+/* ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ int aligned_mantissa(int src, int maxExp)
+{
+    int mantis = (1 << 23) | (0x7FFFFF & src);
+    int e = (src >> 23) & 0xFF;
+    int shift = maxExp - e;
+    if (shift > 31) shift = 31;
+    mantis = mantis >> shift;
+    if (src >> 31) mantis = -mantis;
+    return mantis;
+}
+__global__ __launch_bounds__(256) void k_fp_pack(unsigned *stream, const int *src, int npts, int MaxExp, int Minimum, int Round, int Shift2, int Mask)
+{
+    int w = blockIdx.x * 256 + threadIdx.x;
+    if (2 * w >= npts) return;
+    unsigned word = 0;
+    for (int h = 0; h < 2; h++) {
+        int k = 2 * w + h;
+        unsigned tok = 0;
+        if (k < npts) {
+            int m = aligned_mantissa(src[k], MaxExp);
+            m = m - Minimum; m = m + Round; m = m >> Shift2;
+            if (m > Mask) m = Mask;
+            tok = (unsigned)m & 0xFFFFu;
+        }
+        word = (word << 16) | tok;
+    }
+    stream[w] = word;
+}
+extern "C" int packhip_fp_pack(int *d_stream, const float *d_src, int npts, int MaxExp, int Minimum, int Round, int Shift2, int Mask)
+{
+    if (npts <= 0) return 0;
+    int nw = (npts + 1) / 2;
+    hipLaunchKernelGGL(k_fp_pack, dim3((nw + 255) / 256), dim3(256), 0, STREAM, (unsigned *)d_stream, (const int *)d_src, npts, MaxExp, Minimum, Round, Shift2, Mask);
+    return chk("k_fp_pack");
+}
+/* float_unpacker_1 (float_packer.c:40-113) */
+__global__ __launch_bounds__(256) void k_fp_unpack(float *dest, const unsigned *stream, int npts, int maxExp, int minimum, int shift2)
+{
+    int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= npts) return;
+    if (maxExp == 0) { dest[k] = 0.0f; return; }
+    unsigned word = stream[k >> 1];
+    int mantis = (int)((k & 1) ? (word & 0xFFFF) : (word >> 16));
+    mantis = mantis << shift2;
+    mantis = mantis + minimum;
+    int sgn = (mantis >> 31) & 1;
+    if (sgn) mantis = -mantis;
+    if (mantis > 0xFFFFFF) mantis = 0xFFFFFF;
+    int ti = (mantis & 0x7FFFFF) | (maxExp << 23);
+    ti = ti | (sgn << 31);
+    if (mantis & (1 << 23)) dest[k] = __int_as_float(ti);
+    else {
+        int t2 = maxExp << 23;
+        t2 = t2 | (sgn << 31);
+        t2 = t2 & (~((mantis << 8) >> 31));
+        dest[k] = __int_as_float(ti) - __int_as_float(t2);
+    }
+}
+extern "C" int packhip_fp_unpack(float *d_dest, const int *d_stream, int npts, int maxExp, int minimum, int shift2)
+{
+    if (npts <= 0) return 0;
+    hipLaunchKernelGGL(k_fp_unpack, dim3((npts + 255) / 256), dim3(256), 0, STREAM, d_dest, (const unsigned *)d_stream, npts, maxExp, minimum, shift2);
+    return chk("k_fp_unpack");
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* armn_compress COMPRESS (c_zfstlib.c:469-588 MINIMUM, :646-789 PARALLELOGRAM)                   */
+/* ------------------------------------------------------------------------------------------ */
+/* token k of the packed-word layout: two 16-bit tokens per word, first in the high half (the reference
+ * gets the same ushort array by swapping halves on little-endian hosts, c_zfstlib.c:119-126) */
+__device__ __forceinline__ int tokat(const unsigned *w, size_t k) { unsigned x = w[k >> 1]; return (int)((k & 1) ? (x & 0xFFFFu) : (x >> 16)); }
+
+__device__ __forceinline__ int bitlen(unsigned v) { return v ? 32 - __clz((int)v) : 0; }
+
+/* OR `nbits` bits of `tok` into a zeroed MSB-first stream at absolute bit position `pos` */
+__device__ __forceinline__ void put_bits(unsigned *z, unsigned long long pos, unsigned tok, int nbits)
+{
+    size_t w = (size_t)(pos >> 5);
+    int sh = (int)(pos & 31);
+    unsigned long long v = (unsigned long long)(tok & (nbits == 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1))) << (64 - nbits - sh);
+    unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    if (hi) atomicOr(&z[w], hi);
+    if (lo) atomicOr(&z[w + 1], lo);
+}
+
+struct Tile { int i0, j0, m, n; };   /* 0-based origin and extent of a tile */
+__device__ __forceinline__ Tile tile_of(long long t, int ni, int nj, int istep, int origin, int ntx)
+{
+    Tile T;
+    int ty = (int)(t / ntx), tx = (int)(t % ntx);
+    T.i0 = origin + tx * istep; T.j0 = origin + ty * istep;
+    T.m = min(istep, ni - T.i0); T.n = min(istep, nj - T.j0);
+    return T;
+}
+__device__ __forceinline__ int lorenzo(const unsigned *w, int ni, int i, int j)
+{   /* d(i,j) = u(i,j) - (u(i,j-1) + u(i-1,j) - u(i-1,j-1)), from ORIGINAL values (:691-696) */
+    size_t k = (size_t)ni * j + i;
+    return tokat(w, k) - (tokat(w, k - ni) + tokat(w, k - 1) - tokat(w, k - 1 - ni));
+}
+
+/* pass A: per-tile nbits_needed (uint8) + global flag "some |d| > 65535" (parallelogram only) */
+template <int PARA>
+__global__ __launch_bounds__(256) void k_armn_tiles(unsigned char *nb, unsigned *gt16, const unsigned *w, int ni, int nj, int istep, int ntx, long long ntiles)
+{
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    Tile T = tile_of(t, ni, nj, istep, PARA ? 1 : 0, ntx);
+    unsigned need;
+    if (PARA) {
+        int mx = 0;
+        for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) { int d = abs(lorenzo(w, ni, T.i0 + m, T.j0 + n)); mx = max(mx, d); }
+        if (mx > 65535) atomicOr(gt16, 1u);
+        need = (unsigned)bitlen((unsigned)mx);
+    } else {
+        int lo = 65536, hi = -1;
+        for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) { int v = tokat(w, (size_t)ni * (T.j0 + n) + T.i0 + m); lo = min(lo, v); hi = max(hi, v); }
+        need = (unsigned)bitlen((unsigned)(hi - lo));
+    }
+    if (need == 16) need = 15;
+    nb[t] = (unsigned char)need;
+}
+
+__device__ __forceinline__ unsigned tile_bits(int PARA, unsigned need, int cnt, int container, int nbits)
+{
+    if (PARA) return (unsigned)container + (need == 0 ? 0u : (unsigned)cnt * (need == 15 ? 17u : need + 1u));
+    if (need == 0) return 4u + (unsigned)nbits;
+    if (need == 15) return 4u + 16u * (unsigned)cnt;
+    return 4u + (unsigned)nbits + need * (unsigned)cnt;
+}
+
+#define SCAN_TPB 256
+#define SCAN_ITEMS 8      /* tiles per thread */
+/* pass B: per-block total of tile bit lengths */
+template <int PARA>
+__global__ __launch_bounds__(SCAN_TPB) void k_armn_blocksum(unsigned long long *bsum, const unsigned char *nb, const unsigned *gt16,
+                                                            int ni, int nj, int istep, int ntx, long long ntiles, int nbits)
+{
+    __shared__ unsigned long long sh[SCAN_TPB / 64];
+    const int container = (PARA && nbits >= 15 && *gt16) ? 5 : 4;
+    long long base = ((long long)blockIdx.x * SCAN_TPB + threadIdx.x) * SCAN_ITEMS;
+    unsigned long long s = 0;
+    for (int q = 0; q < SCAN_ITEMS; q++) {
+        long long t = base + q;
+        if (t < ntiles) { Tile T = tile_of(t, ni, nj, istep, PARA ? 1 : 0, ntx); s += tile_bits(PARA, nb[t], T.m * T.n, container, nbits); }
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+/* pass S: exclusive scan of the block totals (single block, sequential chunks; nblocks is small) */
+__global__ __launch_bounds__(256) void k_armn_scan(unsigned long long *bsum, int nblocks, unsigned long long *total)
+{
+    __shared__ unsigned long long sh[256];
+    unsigned long long carry = 0;
+    for (int base = 0; base < nblocks; base += 256) {
+        int i = base + threadIdx.x;
+        unsigned long long v = i < nblocks ? bsum[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            unsigned long long add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nblocks) bsum[i] = carry + sh[threadIdx.x] - v;
+        carry += sh[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+/* pass C: emission.  Each thread rescans its SCAN_ITEMS tiles from the block base and ORs them in. */
+template <int PARA>
+__global__ __launch_bounds__(SCAN_TPB) void k_armn_emit(unsigned *z, const unsigned long long *bsum, const unsigned char *nb, const unsigned *gt16,
+                                                        const unsigned *w, int ni, int nj, int istep, int ntx, long long ntiles, int nbits,
+                                                        unsigned long long body_start)
+{
+    __shared__ unsigned long long sh[SCAN_TPB];
+    const int container = (PARA && nbits >= 15 && *gt16) ? 5 : 4;
+    long long base = ((long long)blockIdx.x * SCAN_TPB + threadIdx.x) * SCAN_ITEMS;
+    unsigned bits[SCAN_ITEMS];
+    unsigned long long mine = 0;
+    for (int q = 0; q < SCAN_ITEMS; q++) {
+        long long t = base + q;
+        bits[q] = 0;
+        if (t < ntiles) { Tile T = tile_of(t, ni, nj, istep, PARA ? 1 : 0, ntx); bits[q] = tile_bits(PARA, nb[t], T.m * T.n, container, nbits); }
+        mine += bits[q];
+    }
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < SCAN_TPB; off <<= 1) {
+        unsigned long long add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    unsigned long long pos = body_start + bsum[blockIdx.x] + sh[threadIdx.x] - mine;
+    for (int q = 0; q < SCAN_ITEMS; q++) {
+        long long t = base + q;
+        if (t >= ntiles) break;
+        Tile T = tile_of(t, ni, nj, istep, PARA ? 1 : 0, ntx);
+        unsigned need = nb[t];
+        unsigned long long p = pos;
+        if (PARA) {
+            put_bits(z, p, need, container); p += container;
+            if (need) {
+                int width = need == 15 ? 17 : (int)need + 1;
+                for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) { put_bits(z, p, (unsigned)lorenzo(w, ni, T.i0 + m, T.j0 + n), width); p += width; }
+            }
+        } else {
+            int lo = 65536;
+            for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) lo = min(lo, tokat(w, (size_t)ni * (T.j0 + n) + T.i0 + m));
+            put_bits(z, p, need, 4); p += 4;
+            if (need != 15) { put_bits(z, p, (unsigned)lo, nbits); p += nbits; }
+            if (need) {
+                int width = need == 15 ? 16 : (int)need;
+                for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) {
+                    int v = tokat(w, (size_t)ni * (T.j0 + n) + T.i0 + m);
+                    put_bits(z, p, (unsigned)(need == 15 ? v : v - lo), width); p += width;
+                }
+            }
+        }
+        pos += bits[q];
+    }
+}
+/* parallelogram prefix: 3-bit container, row 1, column 1 (:712-721) */
+__global__ __launch_bounds__(256) void k_armn_prefix(unsigned *z, const unsigned *w, const unsigned *gt16, int ni, int nj, int nbits, unsigned header)
+{
+    int t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) { z[0] = header; put_bits(z, 32, (nbits >= 15 && *gt16) ? 5u : 4u, 3); }
+    if (t < ni) put_bits(z, 32 + 3 + (unsigned long long)t * nbits, (unsigned)tokat(w, t), nbits);
+    else if (t < ni + nj - 1) { int j = t - ni + 1; put_bits(z, 32 + 3 + (unsigned long long)t * nbits, (unsigned)tokat(w, (size_t)ni * j), nbits); }
+}
+
+/* d_work: nb[ntiles] bytes, then (8-aligned) bsum[nblocks+1] u64, gt16 u32.  Returns total stream bits
+ * (from the start of word 1, terminator excluded) through *h_bits after synchronising. */
+extern "C" int packhip_armn_encode(unsigned *d_z, size_t z_words, const unsigned *d_words, int ni, int nj, int nbits, int minimum_method,
+                                   void *d_work, unsigned long long *h_bits)
+{
+    const int istep = minimum_method ? 5 : 3, origin = minimum_method ? 0 : 1;
+    const int ntx = (ni - origin + istep - 1) / istep, nty = (nj - origin + istep - 1) / istep;
+    const long long ntiles = (long long)ntx * nty;
+    const int per_block = SCAN_TPB * SCAN_ITEMS;
+    const int nblocks = (int)((ntiles + per_block - 1) / per_block);
+    unsigned char *nb = (unsigned char *)d_work;
+    unsigned long long *bsum = (unsigned long long *)((char *)d_work + (((size_t)ntiles + 15) & ~(size_t)15));
+    unsigned long long *total = bsum + nblocks;
+    unsigned *gt16 = (unsigned *)(total + 1);
+    hipStream_t st = STREAM;
+    if (hipMemsetAsync(d_z, 0, z_words * 4, st) != hipSuccess) return -1;
+    if (hipMemsetAsync(gt16, 0, 4, st) != hipSuccess) return -1;
+    const unsigned tb = (unsigned)((ntiles + 255) / 256);
+    unsigned long long body_start;
+    if (minimum_method) {
+        unsigned header = 3u | 0u << 4 | 5u << 7 | ((unsigned)nbits & 31u) << 10 | 1u << 15;
+        hipLaunchKernelGGL(k_armn_tiles<0>, dim3(tb), dim3(256), 0, st, nb, gt16, d_words, ni, nj, istep, ntx, ntiles);
+        hipLaunchKernelGGL(k_armn_blocksum<0>, dim3(nblocks), dim3(SCAN_TPB), 0, st, bsum, nb, gt16, ni, nj, istep, ntx, ntiles, nbits);
+        hipLaunchKernelGGL(k_armn_scan, dim3(1), dim3(256), 0, st, bsum, nblocks, total);
+        if (hipMemcpyAsync(d_z, &header, 4, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        body_start = 32;
+        hipLaunchKernelGGL(k_armn_emit<0>, dim3(nblocks), dim3(SCAN_TPB), 0, st, d_z, bsum, nb, gt16, d_words, ni, nj, istep, ntx, ntiles, nbits, body_start);
+    } else {
+        unsigned header = 4u | 1u << 4 | 3u << 7 | ((unsigned)nbits & 31u) << 10 | 1u << 15;
+        hipLaunchKernelGGL(k_armn_tiles<1>, dim3(tb), dim3(256), 0, st, nb, gt16, d_words, ni, nj, istep, ntx, ntiles);
+        hipLaunchKernelGGL(k_armn_blocksum<1>, dim3(nblocks), dim3(SCAN_TPB), 0, st, bsum, nb, gt16, ni, nj, istep, ntx, ntiles, nbits);
+        hipLaunchKernelGGL(k_armn_scan, dim3(1), dim3(256), 0, st, bsum, nblocks, total);
+        hipLaunchKernelGGL(k_armn_prefix, dim3((ni + nj + 255) / 256), dim3(256), 0, st, d_z, d_words, gt16, ni, nj, nbits, header);
+        body_start = 32 + 3 + (unsigned long long)(ni + nj - 1) * nbits;
+        hipLaunchKernelGGL(k_armn_emit<1>, dim3(nblocks), dim3(SCAN_TPB), 0, st, d_z, bsum, nb, gt16, d_words, ni, nj, istep, ntx, ntiles, nbits, body_start);
+    }
+    if (chk("armn_encode")) return -1;
+    unsigned long long tot = 0;
+    if (hipMemcpyAsync(&tot, total, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    *h_bits = body_start - 32 + tot;
+    return 0;
+}
+extern "C" size_t packhip_armn_work_bytes(int ni, int nj)
+{
+    long long ntiles = ((long long)(ni + 2) / 3 + 1) * ((long long)(nj + 2) / 3 + 1);
+    return (size_t)ntiles + 64 + 8 * ((size_t)(ntiles / (SCAN_TPB * SCAN_ITEMS)) + 8) + 64;
+}

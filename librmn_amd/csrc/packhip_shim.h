@@ -1,0 +1,33 @@
+/* packhip_shim.h -- internal boundary between pack_host.c (C) and pack_kernels.hip.  Plain C types. */
+#ifndef PACKHIP_SHIM_H
+#define PACKHIP_SHIM_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct {
+    double minF, mulFactor;
+    unsigned missingToken, hdr3;
+    int too_large, pad;
+} packhip_cf_params;
+
+/* stats[0..2] = min key, max key, OR; kind 0 float keys, 1 uint32, 2 int32 (biased by 0x80000000) */
+int packhip_stats(unsigned *d_stats, const void *d_a, size_t n, int stride, int kind, int has_missing, float tag);
+int packhip_cf_header(packhip_cf_params *d_pp, unsigned *d_hdr, const unsigned *d_stats, unsigned n, int bs, int style, int has_missing);
+int packhip_cf_pack(unsigned *d_out, const float *d_a, size_t n, int E, int offset, int stride,
+                    const packhip_cf_params *d_pp, int has_missing, float tag);
+int packhip_cf_unpack(float *d_a, const unsigned *d_in, size_t n, int tokenSize, int offset, int stride,
+                      double minF, double mulFactor, unsigned missingToken, int has_missing, float tag);
+int packhip_ci_pack(unsigned *d_out, const void *d_a, size_t n, int E, int offset, int stride,
+                    int with_header, int is_signed, unsigned minv, int shift, unsigned positiveMask);
+int packhip_ci_unpack(void *d_a, const unsigned *d_in, size_t n, int E, int offset, int stride, int with_header, unsigned minv, int shift, unsigned negMask);
+int packhip_fp_pack(int *d_stream, const float *d_src, int npts, int MaxExp, int Minimum, int Round, int Shift2, int Mask);
+int packhip_fp_unpack(float *d_dest, const int *d_stream, int npts, int maxExp, int minimum, int shift2);
+int packhip_armn_encode(unsigned *d_z, size_t z_words, const unsigned *d_words, int ni, int nj, int nbits, int minimum_method,
+                        void *d_work, unsigned long long *h_bits);
+size_t packhip_armn_work_bytes(int ni, int nj);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,112 @@
+"""Python mirror of librmn's packer C interface (src/packers/packers.h, include/armn_compress.h) bound to
+librmn_ez_hip.so.  Host calls take numpy arrays (uint32 word buffers for packed data)."""
+import ctypes
+import numpy as np
+
+from .lib import load_library
+
+FLOAT_PACK, FLOAT_UNPACK = 1, 2
+_configured = False
+
+
+def _lib():
+    global _configured
+    L = load_library()
+    if not _configured:
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        L.compact_float.restype = vp
+        L.compact_float.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.compact_integer.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci]
+        L.c_float_packer.argtypes = [vp, ci, vp, vp, ci]
+        L.c_float_unpacker.argtypes = [vp, vp, vp, ci, vp]
+        L.armn_compress.argtypes = [vp, ci, ci, ci, ci, ci]
+        L.c_armn_compress_setlevel.argtypes = [ci]
+        L.compact_float_dev.restype = vp
+        L.compact_float_dev.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci]
+        L.compact_integer_dev.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci]
+        L.armn_compress_dev.argtypes = [vp, vp, ci, ci, ci]
+        L.ezhip_pack16_compress_dev.argtypes = [vp, vp, ci, ci, ci]
+        _configured = True
+    return L
+
+
+def stream_words(n, bits, offset=0):
+    return (offset + n * bits + 31) // 32
+
+
+def compact_float_pack(a, nbits_arg, offset=0, stride=1, has_missing=0, tag=0.0, style1=False, prefill=0):
+    """returns the uint32 image [4 header words | stream] (style 2) or the style-1 image where the stream
+    starts at bit 24 of header word 3 (pass style1=True; offset is then forced to 24)"""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    n = (a.size + stride - 1) // stride
+    eff = (nbits_arg >> 6) if nbits_arg > 64 else nbits_arg
+    tagv = np.array([tag], np.float32)
+    if style1:
+        buf = np.full(3 + stream_words(n, eff, 24) + 1, prefill, np.uint32)
+        r = _lib().compact_float(a.ctypes.data, buf.ctypes.data, buf[3:].ctypes.data, n, nbits_arg, 24, stride, FLOAT_PACK, has_missing, tagv.ctypes.data)
+    else:
+        buf = np.full(4 + stream_words(n, eff, offset) + 1, prefill, np.uint32)
+        r = _lib().compact_float(a.ctypes.data, buf.ctypes.data, buf[4:].ctypes.data, n, nbits_arg, offset, stride, FLOAT_PACK, has_missing, tagv.ctypes.data)
+    return (None if not r else buf)
+
+
+def compact_float_unpack(buf, n, nbits_arg, offset=0, stride=1, has_missing=0, tag=0.0):
+    out = np.zeros(n * stride, np.float32)
+    tagv = np.array([tag], np.float32)
+    r = _lib().compact_float(out.ctypes.data, buf.ctypes.data, buf[4:].ctypes.data, n, nbits_arg, offset, stride, FLOAT_UNPACK, has_missing, tagv.ctypes.data)
+    return None if not r else out
+
+
+def compact_integer_pack(a, nbits, op, header=False, offset=0, stride=1, prefill=0):
+    a = np.ascontiguousarray(a)
+    n = (a.size + stride - 1) // stride
+    nb = 32 if nbits == -1 else nbits
+    out = np.full(stream_words(n, nb, offset) + 1, prefill, np.uint32)
+    hdr = np.zeros(4, np.uint32)
+    rc = _lib().compact_integer(a.ctypes.data, hdr.ctypes.data if header else None, out.ctypes.data, n, nbits, offset, stride, op)
+    return rc, hdr, out
+
+
+def compact_integer_unpack(out, n, nbits, op, hdr=None, offset=0, stride=1, dtype=np.uint32):
+    a = np.zeros(n * stride, dtype)
+    rc = _lib().compact_integer(a.ctypes.data, hdr.ctypes.data if hdr is not None else None, out.ctypes.data, n, nbits, offset, stride, op)
+    return rc, a
+
+
+def float_packer(a, nbits):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    hdr = np.zeros(3, np.int32); stream = np.zeros((a.size + 1) // 2, np.int32)
+    rc = _lib().c_float_packer(a.ctypes.data, nbits, hdr.ctypes.data, stream.ctypes.data, a.size)
+    return rc, hdr, stream
+
+
+def float_unpacker(hdr, stream, n):
+    out = np.zeros(n, np.float32); nb = ctypes.c_int(0)
+    rc = _lib().c_float_unpacker(out.ctypes.data, hdr.ctypes.data, stream.ctypes.data, n, ctypes.byref(nb))
+    return rc, out, nb.value
+
+
+def armn_compress(words, ni, nj, nbits):
+    """in place on a uint32 word buffer (two 16-bit tokens per word); returns zlng or -1"""
+    return _lib().armn_compress(words.ctypes.data, ni, nj, 1, nbits, 1)
+
+
+def armn_setlevel(level):
+    _lib().c_armn_compress_setlevel(level)
+
+
+def _dptr(t):
+    return t if isinstance(t, int) else t.data_ptr()
+
+
+def compact_float_pack_dev(d_field, d_header, d_stream, n, nbits_arg, offset=0, stride=1, style=2):
+    tagv = np.array([0.0], np.float32)
+    return _lib().compact_float_dev(_dptr(d_field), _dptr(d_header), _dptr(d_stream), n, nbits_arg, offset, stride, FLOAT_PACK, 0, tagv.ctypes.data, style)
+
+
+def armn_compress_dev(d_z, d_words, ni, nj, nbits):
+    return _lib().armn_compress_dev(_dptr(d_z), _dptr(d_words), ni, nj, nbits)
+
+
+def pack16_compress_dev(d_record, d_field, ni, nj, nbits):
+    return _lib().ezhip_pack16_compress_dev(_dptr(d_record), _dptr(d_field), ni, nj, nbits)

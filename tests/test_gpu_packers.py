@@ -1,0 +1,141 @@
+"""GPU parity tests of the packers: HIP path (through the C ABI) vs the CPU oracle, BIT-EXACT
+(every packed word, header words, return values)."""
+import ctypes
+import numpy as np
+import pytest
+
+import oraclelib as ol
+import packcases as pc
+import test_oracle_packers as top
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+from librmn_amd import packers as pk   # noqa: E402
+
+
+@pytest.mark.parametrize("nbits_arg", [1, 4, 8, 12, 15, 16, 17, 24, 31, 32, 16 + 64 * 16, 12 + 64 * 16])
+@pytest.mark.parametrize("n,stride,offset", [(1, 1, 0), (2, 1, 0), (31, 1, 0), (33, 2, 5), (1000, 1, 0), (1000, 3, 37), (7200 * 17, 1, 0), (7200 * 17 + 5, 1, 0)])
+def test_compact_float_pack_bit_exact(nbits_arg, n, stride, offset):
+    a = pc.float_field(n * stride, seed=nbits_arg + n)
+    want = top.pack_float(a, nbits_arg, offset=offset, stride=stride, prefill=0xDEADBEEF)
+    got = pk.compact_float_pack(a, nbits_arg, offset=offset, stride=stride, prefill=0xDEADBEEF)
+    assert got is not None
+    m = got.size
+    assert np.array_equal(got[:m], want[:m]), (np.nonzero(got[:m] != want[:m])[0][:5], [hex(int(x)) for x in got[:6]], [hex(int(x)) for x in want[:6]])
+
+
+def test_compact_float_style1_and_missing_and_zero_min():
+    a = np.array([0.0, 1.0, 2.0, 3.0, 3.5], np.float32)
+    want = top.pack_float(a, 4, style2=False)
+    got = pk.compact_float_pack(a, 4, style1=True)
+    assert np.array_equal(got[:5], want[:5])
+    b = pc.float_field(5000, seed=1); b[[3, 50, 4999]] = -999.0
+    want = top.pack_float(b, 12, has_missing=1, tag=-999.0)
+    got = pk.compact_float_pack(b, 12, has_missing=1, tag=-999.0)
+    assert np.array_equal(got[:got.size - 1], want[:got.size - 1])
+    c = np.full(100, 7.25, np.float32)                              # zero range
+    assert np.array_equal(pk.compact_float_pack(c, 16)[:54], top.pack_float(c, 16)[:54])
+
+
+@pytest.mark.parametrize("nbits", [4, 12, 16, 24])
+def test_compact_float_unpack_bit_exact(nbits):
+    n = 10007
+    a = pc.float_field(n, seed=nbits)
+    buf = top.pack_float(a, nbits)
+    want = np.zeros(n, np.float32); tagv = np.array([0.0], np.float32)
+    top.O().orc_compact_float(want.ctypes.data, buf[:4].ctypes.data, buf[4:].ctypes.data, n, nbits, 0, 1, 2, 0, tagv.ctypes.data)
+    got = pk.compact_float_unpack(buf, n, nbits)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("nbits", [1, 2, 4, 8, 12, 15, 16, 17, 24, 31, 32, -1])
+@pytest.mark.parametrize("op,header,stride,offset", [(1, False, 1, 0), (3, False, 1, 0), (1, True, 1, 0), (3, True, 2, 0), (1, False, 3, 37), (3, False, 1, 5)])
+def test_compact_integer_bit_exact(nbits, op, header, stride, offset):
+    if nbits == 32 and offset:
+        pytest.skip("undefined in the reference")
+    n = 3001
+    rng = np.random.default_rng(abs(nbits) * 11 + op)
+    width = 20 if nbits == -1 else nbits
+    a = rng.integers(0, 2 ** min(width, 32), n * stride, dtype=np.uint64).astype(np.uint32)
+    if op == 3:
+        a = (a.astype(np.int64) - 2 ** (width - 1)).astype(np.int32)
+    rc_w, hdr_w, out_w = top.pack_int(a, nbits, op, header, offset, stride, prefill=0x5A5A5A5A)
+    rc_g, hdr_g, out_g = pk.compact_integer_pack(a, nbits, op, header, offset, stride, prefill=0x5A5A5A5A)
+    assert rc_g == rc_w
+    words = (offset + n * rc_w + 31) // 32
+    assert np.array_equal(out_g[:words], out_w[:words])
+    if header:
+        assert np.array_equal(hdr_g, hdr_w)
+    # unpack through the HIP path
+    rc, back = pk.compact_integer_unpack(out_g, n, rc_w if nbits == -1 else nbits, op + 1, hdr_g if header else None, offset, stride, a.dtype)
+    if header and (int(hdr_w[0]) >> 6) & 0x3F:
+        sh = (int(hdr_w[0]) >> 6) & 0x3F
+        ref = a[::stride].astype(np.int64); mn = ref.min()
+        assert np.array_equal(back[::stride].astype(np.int64), ((ref - mn) >> sh << sh) + mn)
+    else:
+        assert np.array_equal(back[::stride], a[::stride])
+
+
+@pytest.mark.parametrize("nbits", [1, 5, 12, 14, 16])
+def test_float_packer_bit_exact(nbits):
+    for n in (1, 2, 1001, 100000):
+        a = (np.arange(n, dtype=np.float64) * 1.234 - 1123.123).astype(np.float32)
+        hdr_w = np.zeros(3, np.int32); st_w = np.zeros((n + 1) // 2, np.int32)
+        assert top.O().orc_float_packer(a.ctypes.data, nbits, hdr_w.ctypes.data, st_w.ctypes.data, n) == 0
+        rc, hdr_g, st_g = pk.float_packer(a, nbits)
+        assert rc == 0 and np.array_equal(hdr_g, hdr_w) and np.array_equal(st_g, st_w)
+        rc, back, nb = pk.float_unpacker(hdr_g, st_g, n)
+        want = np.zeros(n, np.float32); nbw = ctypes.c_int(0)
+        top.O().orc_float_unpacker(want.ctypes.data, hdr_w.ctypes.data, st_w.ctypes.data, n, ctypes.byref(nbw))
+        assert rc == 0 and nb == nbits and np.array_equal(back.view(np.uint32), want.view(np.uint32))
+
+
+ARMN = [(16, 16), (17, 19), (64, 48), (7200, 17), (15, 40), (40, 9), (1000, 777)]
+
+
+@pytest.mark.parametrize("ni,nj", ARMN)
+@pytest.mark.parametrize("kind", ["smooth", "noisy", "constant", "bigdiff"])
+@pytest.mark.parametrize("nbits", [16, 12, 4])
+def test_armn_compress_bit_exact(ni, nj, kind, nbits):
+    tok = pc.token_field(ni, nj, nbits, kind, seed=ni * 3 + nj)
+    words = pc.tokens_to_words(tok)
+    bw = np.zeros(words.size + 8, np.uint32); bw[:words.size] = words
+    bg = bw.copy()
+    zw = top.O().orc_armn_compress(bw.ctypes.data, ni, nj, 1, nbits, 1)
+    zg = pk.armn_compress(bg, ni, nj, nbits)
+    assert zg == zw, (zg, zw)
+    if zw > 0:
+        nfull = (zw - 1) // 4                 # the zlng-th byte is undefined in the reference
+        assert np.array_equal(bg[:nfull], bw[:nfull]), np.nonzero(bg[:nfull] != bw[:nfull])[0][:5]
+        back = np.zeros(ni * nj, np.uint16)   # and the reference's decoder (restated) recovers the tokens
+        assert top.O().orc_armn_decode(back.ctypes.data, bg.ctypes.data, ni, nj) == 0
+        assert np.array_equal(back, tok)
+    else:
+        assert np.array_equal(bg[:words.size], words)             # rejected: buffer untouched
+
+
+def test_cfg5_pipeline_full_size_device_resident():
+    """interp -> compact_float(16-bit slots) -> armn_compress on one full-size field, all on the device;
+    compared with the oracle chain on the same interpolated field (bit-exact record)."""
+    from librmn_amd import ezscint as ez
+    import ezcases as ec
+    ni, nj, no, mo = 4400, 2200, 7200, 3601
+    gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(no, mo, "L", 5, 5, 0, 0)
+    ez.ezdefset(gdout, gdin)
+    ez.ezsetopt("interp_degree", "cubic"); ez.ezsetopt("polar_correction", "yes")
+    ez.use_stream(0)
+    f = torch.from_numpy(ec.synth_field(ni, nj, seed=2)).cuda()
+    z = torch.empty(no * mo, dtype=torch.float32, device="cuda")
+    assert ez.ezsint_dev(z, f) == 0
+    n = no * mo
+    rec = torch.zeros(4 + n // 2 + 64, dtype=torch.int32, device="cuda")
+    zlng = pk.pack16_compress_dev(rec, z, no, mo, 16)
+    torch.cuda.synchronize()
+    zh = z.cpu().numpy()
+    want = top.pack_float(zh, 16 + 64 * 16)
+    zw = top.O().orc_armn_compress(want[4:].ctypes.data, no, mo, 1, 16, 1)
+    assert zlng == zw and zw > 0
+    got = rec.cpu().numpy().view(np.uint32)
+    nfull = 4 + (zw - 1) // 4
+    assert np.array_equal(got[:nfull], want[:nfull])
+    assert zw < 0.5 * n * 2                                  # a smooth field compresses
