@@ -348,7 +348,9 @@ int armn_compress_dev(void *d_z, const void *d_words, int ni, int nj, int nbits)
     int rc = packhip_armn_encode((unsigned *)d_z, z_words, (const unsigned *)d_words, ni, nj, nbits, minimum, d_work, &bits);
     ezhip_free(d_work);
     if (rc) return -1;
-    long long zlng = 1 + 4 * (1 + (long long)((bits + 32) / 32));
+    /* a word is flushed only when a later token crosses its end (stuff macro), the two 16-bit terminator
+     * tokens flush every word that holds stream bits: words = ceil(bits / 32) */
+    long long zlng = 1 + 4 * (1 + (long long)((bits + 31) / 32));
     long long lng_origin = 1 + (long long)n * 2;
     if (zlng >= lng_origin) return -1;
     return (int)zlng;

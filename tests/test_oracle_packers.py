@@ -188,7 +188,7 @@ def test_armn_encode_decode_round_trip(ni, nj, kind, nbits):
         # header + 3-bit container + first row/col + one container-width zero per 3x3 tile + 32 terminator bits
         tiles = ((ni - 1 + 2) // 3) * ((nj - 1 + 2) // 3)
         bits = 3 + (ni + nj - 1) * nbits + tiles * 4
-        assert zlng == 1 + 4 * (1 + (bits + 32) // 32)
+        assert zlng == 1 + 4 * (1 + (bits + 31) // 32)
     if kind == "bigdiff" and nbits >= 15 and not minimum:
         assert (int(z[1]) >> 29) == 5                            # 5-bit containers once a |diff| exceeds 65535
 
