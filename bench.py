@@ -139,6 +139,26 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
+    # ---- second timed region: the packers on the interpolated fields (device-resident) ------------------
+    from librmn_amd import packers as pk
+    npk = min(F, 8)
+    rec = torch.zeros((npk, 4 + NPTS_OUT // 2 + 64), dtype=torch.int32, device="cuda")
+    def pack_step():
+        for f in range(npk):
+            assert pk.compact_float_pack_dev(d_out[f], rec[f], rec[f][4:], NPTS_OUT, 16 + 64 * 16) != 0
+    pack_step(); torch.cuda.synchronize()
+    pe0 = torch.cuda.Event(enable_timing=True); pe1 = torch.cuda.Event(enable_timing=True)
+    pe0.record(stream)
+    for _ in range(3):
+        pack_step()
+    pe1.record(stream); torch.cuda.synchronize()
+    pack_us = pe0.elapsed_time(pe1) * 1e3 / (3 * npk)
+    # fused cfg5 step: compact_float(16-bit slots) + armn_compress per field (returns zlng: one sync per field)
+    t1 = time.perf_counter()
+    zl = [pk.pack16_compress_dev(rec[f], d_out[f], NI_D, NJ_D, 16) for f in range(npk)]
+    torch.cuda.synchronize()
+    comp_us = (time.perf_counter() - t1) * 1e6 / npk
+
     launches = args.steps * F
     kern_us = ev_ms * 1e3 / launches              # average k_sep<3> launch-to-launch duration on the stream
     achieved = ALGO_BYTES / (kern_us * 1e-6) / 1e9
@@ -163,6 +183,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": "k_sep<3>", "avg_launch_us": kern_us, "algorithmic_bytes_per_launch": ALGO_BYTES},
+            "pack": {"compact_float_16bit_GBps": 4.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9, "us_per_field": pack_us,
+                     "algorithmic_GBps_6B_per_elem": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9,
+                     "frac_of_hbm_peak": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                     "pack16_plus_armn_compress_us_per_field": comp_us, "zlng_bytes": int(zl[0]),
+                     "compression_ratio": float(zl[0]) / (2.0 * NPTS_OUT), "unit": "GB/s of float input"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

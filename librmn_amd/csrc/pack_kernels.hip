@@ -47,14 +47,24 @@ __global__ __launch_bounds__(256) void k_stats(unsigned *stats, const unsigned *
         kmax = max(kmax, (unsigned)__shfl_down((int)kmax, off, 64));
         kor |= (unsigned)__shfl_down((int)kor, off, 64);
     }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&stats[0], kmin); atomicMax(&stats[1], kmax); atomicOr(&stats[2], kor); }
+    /* one atomic triple per BLOCK: per-wave atomics on three shared words cost 570 us on a 26 M element field */
+    __shared__ unsigned sh[3][4];
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = kmin; sh[1][threadIdx.x >> 6] = kmax; sh[2][threadIdx.x >> 6] = kor; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&stats[0], min(min(sh[0][0], sh[0][1]), min(sh[0][2], sh[0][3])));
+        atomicMax(&stats[1], max(max(sh[1][0], sh[1][1]), max(sh[1][2], sh[1][3])));
+        atomicOr(&stats[2], sh[2][0] | sh[2][1] | sh[2][2] | sh[2][3]);
+    }
 }
 
 extern "C" int packhip_stats(unsigned *d_stats, const void *d_a, size_t n, int stride, int kind, int has_missing, float tag)
 {
-    unsigned init[4] = {0xffffffffu, 0u, 0u, 0u};
-    if (hipMemcpyAsync(d_stats, init, sizeof(init), hipMemcpyHostToDevice, STREAM) != hipSuccess) return -1;
-    int nb = (int)((n + 255) / 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
+    /* {min key, max key, or, pad} = {0xffffffff, 0, 0, 0} with two memsets (a pageable H2D copy would
+     * serialise the host with the stream) */
+    if (hipMemsetAsync(d_stats, 0, 16, STREAM) != hipSuccess) return -1;
+    if (hipMemsetAsync(d_stats, 0xFF, 4, STREAM) != hipSuccess) return -1;
+    int nb = (int)((n + 255) / 256); if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;
     if (kind == 0) hipLaunchKernelGGL(k_stats<0>, dim3(nb), dim3(256), 0, STREAM, d_stats, (const unsigned *)d_a, n, stride, has_missing, tag);
     else if (kind == 1) hipLaunchKernelGGL(k_stats<1>, dim3(nb), dim3(256), 0, STREAM, d_stats, (const unsigned *)d_a, n, stride, 0, 0.f);
     else hipLaunchKernelGGL(k_stats<2>, dim3(nb), dim3(256), 0, STREAM, d_stats, (const unsigned *)d_a, n, stride, 0, 0.f);
@@ -420,7 +430,28 @@ __global__ __launch_bounds__(256) void k_armn_scan(unsigned long long *bsum, int
     }
     if (threadIdx.x == 0) *total = carry;
 }
-/* pass C: emission.  Each thread rescans its SCAN_ITEMS tiles from the block base and ORs them in. */
+/* MSB-first bit writer over a zeroed stream: a thread owns a CONTIGUOUS bit range, so only its first and
+ * last (partial) words can be shared with neighbours and need atomicOr; interior words are plain stores.
+ * (One atomicOr per token cost 1.2 ms per 26 M-token field.) */
+struct BitOut {
+    unsigned *z; size_t w; unsigned cw; int used; bool first_shared;
+    __device__ __forceinline__ void init(unsigned *zz, unsigned long long pos) { z = zz; w = (size_t)(pos >> 5); used = (int)(pos & 31); cw = 0; first_shared = used != 0; }
+    __device__ __forceinline__ void flush_full() { if (first_shared) { atomicOr(&z[w], cw); first_shared = false; } else z[w] = cw; w++; cw = 0; used = 0; }
+    __device__ __forceinline__ void put(unsigned tok, int nbits)
+    {
+        tok &= (nbits == 32) ? 0xFFFFFFFFu : ((1u << nbits) - 1);
+        while (nbits > 0) {
+            int take = min(nbits, 32 - used);
+            unsigned piece = (take == 32) ? tok : ((tok >> (nbits - take)) & ((1u << take) - 1));
+            cw |= piece << (32 - used - take);
+            used += take; nbits -= take;
+            if (used == 32) flush_full();
+        }
+    }
+    __device__ __forceinline__ void finish() { if (used > 0 && cw) atomicOr(&z[w], cw); }
+};
+
+/* pass C: emission.  Each thread rescans its SCAN_ITEMS consecutive tiles from the block base and writes them. */
 template <int PARA>
 __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit(unsigned *z, const unsigned long long *bsum, const unsigned char *nb, const unsigned *gt16,
                                                         const unsigned *w, int ni, int nj, int istep, int ntx, long long ntiles, int nbits,
@@ -429,13 +460,10 @@ __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit(unsigned *z, const unsig
     __shared__ unsigned long long sh[SCAN_TPB];
     const int container = (PARA && nbits >= 15 && *gt16) ? 5 : 4;
     long long base = ((long long)blockIdx.x * SCAN_TPB + threadIdx.x) * SCAN_ITEMS;
-    unsigned bits[SCAN_ITEMS];
     unsigned long long mine = 0;
     for (int q = 0; q < SCAN_ITEMS; q++) {
         long long t = base + q;
-        bits[q] = 0;
-        if (t < ntiles) { Tile T = tile_of(t, ni, nj, istep, PARA ? 1 : 0, ntx); bits[q] = tile_bits(PARA, nb[t], T.m * T.n, container, nbits); }
-        mine += bits[q];
+        if (t < ntiles) { Tile T = tile_of(t, ni, nj, istep, PARA ? 1 : 0, ntx); mine += tile_bits(PARA, nb[t], T.m * T.n, container, nbits); }
     }
     sh[threadIdx.x] = mine;
     __syncthreads();
@@ -445,34 +473,35 @@ __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit(unsigned *z, const unsig
         sh[threadIdx.x] += add;
         __syncthreads();
     }
-    unsigned long long pos = body_start + bsum[blockIdx.x] + sh[threadIdx.x] - mine;
+    if (base >= ntiles) return;
+    BitOut bo;
+    bo.init(z, body_start + bsum[blockIdx.x] + sh[threadIdx.x] - mine);
     for (int q = 0; q < SCAN_ITEMS; q++) {
         long long t = base + q;
         if (t >= ntiles) break;
         Tile T = tile_of(t, ni, nj, istep, PARA ? 1 : 0, ntx);
         unsigned need = nb[t];
-        unsigned long long p = pos;
         if (PARA) {
-            put_bits(z, p, need, container); p += container;
+            bo.put(need, container);
             if (need) {
                 int width = need == 15 ? 17 : (int)need + 1;
-                for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) { put_bits(z, p, (unsigned)lorenzo(w, ni, T.i0 + m, T.j0 + n), width); p += width; }
+                for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) bo.put((unsigned)lorenzo(w, ni, T.i0 + m, T.j0 + n), width);
             }
         } else {
             int lo = 65536;
             for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) lo = min(lo, tokat(w, (size_t)ni * (T.j0 + n) + T.i0 + m));
-            put_bits(z, p, need, 4); p += 4;
-            if (need != 15) { put_bits(z, p, (unsigned)lo, nbits); p += nbits; }
+            bo.put(need, 4);
+            if (need != 15) bo.put((unsigned)lo, nbits);
             if (need) {
                 int width = need == 15 ? 16 : (int)need;
                 for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) {
                     int v = tokat(w, (size_t)ni * (T.j0 + n) + T.i0 + m);
-                    put_bits(z, p, (unsigned)(need == 15 ? v : v - lo), width); p += width;
+                    bo.put((unsigned)(need == 15 ? v : v - lo), width);
                 }
             }
         }
-        pos += bits[q];
     }
+    bo.finish();
 }
 /* parallelogram prefix: 3-bit container, row 1, column 1 (:712-721) */
 __global__ __launch_bounds__(256) void k_armn_prefix(unsigned *z, const unsigned *w, const unsigned *gt16, int ni, int nj, int nbits, unsigned header)
@@ -482,6 +511,8 @@ __global__ __launch_bounds__(256) void k_armn_prefix(unsigned *z, const unsigned
     if (t < ni) put_bits(z, 32 + 3 + (unsigned long long)t * nbits, (unsigned)tokat(w, t), nbits);
     else if (t < ni + nj - 1) { int j = t - ni + 1; put_bits(z, 32 + 3 + (unsigned long long)t * nbits, (unsigned)tokat(w, (size_t)ni * j), nbits); }
 }
+
+__global__ void k_set_word(unsigned *z, unsigned v) { z[0] = v; }
 
 /* d_work: nb[ntiles] bytes, then (8-aligned) bsum[nblocks+1] u64, gt16 u32.  Returns total stream bits
  * (from the start of word 1, terminator excluded) through *h_bits after synchronising. */
@@ -507,7 +538,7 @@ extern "C" int packhip_armn_encode(unsigned *d_z, size_t z_words, const unsigned
         hipLaunchKernelGGL(k_armn_tiles<0>, dim3(tb), dim3(256), 0, st, nb, gt16, d_words, ni, nj, istep, ntx, ntiles);
         hipLaunchKernelGGL(k_armn_blocksum<0>, dim3(nblocks), dim3(SCAN_TPB), 0, st, bsum, nb, gt16, ni, nj, istep, ntx, ntiles, nbits);
         hipLaunchKernelGGL(k_armn_scan, dim3(1), dim3(256), 0, st, bsum, nblocks, total);
-        if (hipMemcpyAsync(d_z, &header, 4, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, d_z, header);
         body_start = 32;
         hipLaunchKernelGGL(k_armn_emit<0>, dim3(nblocks), dim3(SCAN_TPB), 0, st, d_z, bsum, nb, gt16, d_words, ni, nj, istep, ntx, ntiles, nbits, body_start);
     } else {
