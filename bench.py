@@ -94,9 +94,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from librmn_amd import ezscint as ez
+    from librmn_amd import sharding as sh
     import ezcases as ec
 
     F = args.fields_per_step
+    my_fields = sh.fields_of_rank(F * world, rank, world)      # record sharding: field f -> rank f mod world
     gdin = ez.ezqkdef(NI_S, NJ_S, "G", 0, 0, 0, 0)
     gdout = ez.ezqkdef(NI_D, NJ_D, "L", *L_IG)
     assert ez.ezdefset(gdout, gdin) == 1
@@ -105,11 +107,11 @@ def main():
     assert ez.prepare_set() == 0 and ez.set_mode() == 1
 
     # F distinct synthetic source fields, resident in HBM (seed per global field index)
-    base = torch.from_numpy(ec.synth_field(NI_S, NJ_S, seed=1000 + rank * F)).cuda()
+    base = torch.from_numpy(ec.synth_field(NI_S, NJ_S, seed=1000 + my_fields[0])).cuda()
     d_in = torch.empty((F, NI_S * NJ_S), dtype=torch.float32, device="cuda")
     gen = torch.Generator(device="cuda"); gen.manual_seed(1234 + rank)
     for f in range(F):
-        d_in[f] = base * (1.0 + 1e-3 * (torch.rand(NI_S * NJ_S, device="cuda", generator=gen) - 0.5)) + 0.01 * f
+        d_in[f] = base * (1.0 + 1e-3 * (torch.rand(NI_S * NJ_S, device="cuda", generator=gen) - 0.5)) + 0.01 * my_fields[f]
     d_out = torch.empty((F, NPTS_OUT), dtype=torch.float32, device="cuda")
 
     def step():
@@ -134,10 +136,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ev_ms = ev0.elapsed_time(ev1)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    elapsed = sh.max_over_ranks(elapsed, device="cuda")        # the batch takes as long as its slowest rank
 
     # ---- second timed region: the packers on the interpolated fields (device-resident) ------------------
     from librmn_amd import packers as pk

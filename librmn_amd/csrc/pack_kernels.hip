@@ -35,13 +35,24 @@ template <int KIND>   /* 0: float keys, 1: uint32, 2: int32 (biased) */
 __global__ __launch_bounds__(256) void k_stats(unsigned *stats, const unsigned *a, size_t n, int stride, int has_missing, float tag)
 {
     unsigned kmin = 0xffffffffu, kmax = 0u, kor = 0u;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        unsigned raw = a[i * stride], k;
-        if (KIND == 0) { float f = __uint_as_float(raw); if (has_missing && f == tag) continue; k = f2key(f); }
-        else if (KIND == 1) k = raw;
-        else k = raw ^ 0x80000000u;
-        kmin = min(kmin, k); kmax = max(kmax, k); kor |= raw;
+#define STAT1(raw_) do { unsigned raw = (raw_), k; bool skip = false;                                              \
+        if (KIND == 0) { float f = __uint_as_float(raw); skip = has_missing && f == tag; k = f2key(f); }            \
+        else if (KIND == 1) k = raw; else k = raw ^ 0x80000000u;                                                   \
+        if (!skip) { kmin = min(kmin, k); kmax = max(kmax, k); kor |= raw; } } while (0)
+    size_t i0 = 0;
+    if (stride == 1 && ((uintptr_t)a & 15) == 0) {          /* 16 B per lane, two loads in flight */
+        const uint4 *a4 = (const uint4 *)a;
+        size_t n4 = n / 4, step = (size_t)gridDim.x * 256;
+        size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+        for (; i + step < n4; i += 2 * step) {
+            uint4 u = a4[i], v = a4[i + step];
+            STAT1(u.x); STAT1(u.y); STAT1(u.z); STAT1(u.w); STAT1(v.x); STAT1(v.y); STAT1(v.z); STAT1(v.w);
+        }
+        for (; i < n4; i += step) { uint4 u = a4[i]; STAT1(u.x); STAT1(u.y); STAT1(u.z); STAT1(u.w); }
+        i0 = n4 * 4;
     }
+    for (size_t i = i0 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) STAT1(a[i * stride]);
+#undef STAT1
     for (int off = 32; off > 0; off >>= 1) {
         kmin = min(kmin, (unsigned)__shfl_down((int)kmin, off, 64));
         kmax = max(kmax, (unsigned)__shfl_down((int)kmax, off, 64));
