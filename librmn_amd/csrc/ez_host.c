@@ -39,7 +39,7 @@ typedef struct {            /* src/interp/ez_def.h:225-243, defaults src/interp/
 typedef struct {            /* one compiled separable plan: device tables + the descriptor */
     int built;
     ezhip_sep_plan p;
-    void *dev[16];          /* owned device allocations */
+    void *dev[24];          /* owned device allocations */
 } ezh_sepplan;
 
 typedef struct ezh_set {
@@ -463,7 +463,7 @@ int32_t c_ezqkdef(int32_t ni, int32_t nj, char *grtyp, int32_t ig1, int32_t ig2,
 
 static void free_sepplan(ezh_sepplan *sp)
 {
-    for (int k = 0; k < 16; k++) { ezhip_free(sp->dev[k]); sp->dev[k] = NULL; }
+    for (int k = 0; k < 24; k++) { ezhip_free(sp->dev[k]); sp->dev[k] = NULL; }
     sp->built = 0;
 }
 static void free_set(ezh_set *s)
@@ -1061,6 +1061,72 @@ static void strip_row(const ezh_grid *g, int degree, float py, int north, ezhip_
     }
 }
 
+/* Row-streaming geometry of k_sep_stream: segments of target rows per 256-column strip, sized so that every
+ * thread block is co-resident (<= CUs x EZHIP_ST_BLOCKS_PER_CU blocks) and carries about the same cost. */
+static void build_stream_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, const ezh_grid *gi, int nic, int njr, int nbx, int ntap,
+                                  const int *blk_base, const int *blk_w, const int *rbase, const double *rw,
+                                  const unsigned char *rflag, const ezhip_special_row *special, int nspecial, int vector_mode)
+{
+    p->nseg = 0;
+    /* opt-in (EZHIP_SEP_STREAM=1): on MI355X round 1 the streaming variant is correct but slower than the tile
+     * kernel (56 vs 41 us nearest, polar off): 4 compute waves per block leave it latency-bound per row
+     * (profiles/r01_stream_experiments.txt) */
+    if (!getenv("EZHIP_SEP_STREAM") || atoi(getenv("EZHIP_SEP_STREAM")) == 0) return;
+    int wmax = 1, prev = -1;
+    for (int bx = 0; bx < nbx; bx++) { if (blk_base[bx] < 0) return; if (blk_w[bx] > wmax) wmax = blk_w[bx]; }
+    int nch = (wmax + 63) / 64;
+    if (nch > 5) return;
+    for (int r = 0; r < njr; r++) { if (rflag[r]) continue; if (rbase[r] < prev) return; prev = rbase[r]; }   /* rows must stream forward */
+    int nseg = (256 * EZHIP_ST_BLOCKS_PER_CU) / nbx;
+    if (nseg > njr / 24) nseg = njr / 24;
+    if (getenv("EZHIP_SEP_NSEG")) nseg = atoi(getenv("EZHIP_SEP_NSEG"));
+    if (nseg < 1) return;
+    /* cost model: a main row costs 1, a special row ~6 (gathers), a block that must form a sequential pole sum
+     * pays ~35 rows of time up-front */
+    double *cost = (double *)malloc(sizeof(double) * njr), total = 0.0;
+    int is = 0;
+    for (int r = 0; r < njr; r++) {
+        cost[r] = 1.0;
+        if (rflag[r]) { cost[r] = 6.0; while (is < nspecial && special[is].row < r) is++; if (is < nspecial && special[is].row == r && special[is].kind != 3 && !vector_mode) cost[r] += 35.0 / 3.0; }
+        total += cost[r];
+    }
+    int *seg_r0 = (int *)calloc((size_t)nseg + 1, sizeof(int)), *seg_s0 = (int *)calloc(nseg, sizeof(int)), *seg_sn = (int *)calloc(nseg, sizeof(int));
+    int *seg_sp0 = (int *)calloc((size_t)nseg + 1, sizeof(int));
+    double acc = 0.0; int sidx = 1;
+    for (int r = 0; r < njr && sidx < nseg; r++) { acc += cost[r]; if (acc >= total * sidx / nseg) seg_r0[sidx++] = r + 1; }
+    while (sidx <= nseg) seg_r0[sidx++] = njr;
+    seg_r0[nseg] = njr;
+    ezhip_rowinfo *ris = (ezhip_rowinfo *)calloc((size_t)njr + 1, sizeof(ezhip_rowinfo));
+    int rows_max = 1; is = 0;
+    for (int sg = 0; sg < nseg; sg++) {
+        int a = seg_r0[sg], b = seg_r0[sg + 1], lo = 1 << 30, hi = -1;
+        if (b - a > rows_max) rows_max = b - a;
+        for (int r = a; r < b; r++) { if (rflag[r]) continue; if (rbase[r] < lo) lo = rbase[r]; if (rbase[r] + ntap > hi) hi = rbase[r] + ntap; }
+        if (hi < 0) { lo = 0; hi = 0; }
+        seg_s0[sg] = lo; seg_sn[sg] = hi - lo;
+        for (int r = a; r < b; r++) {
+            ezhip_rowinfo *q = &ris[r];
+            if (rflag[r]) { q->flag = 1; continue; }
+            q->jb = rbase[r] - lo;
+            for (int w = 0; w < 4; w++) q->w[w] = rw[w * njr + r];
+        }
+        while (is < nspecial && special[is].row < a) is++;
+        seg_sp0[sg] = is;
+    }
+    seg_sp0[nseg] = nspecial;
+    for (int sg = nseg - 1; sg >= 0; sg--) if (seg_sp0[sg] > seg_sp0[sg + 1]) seg_sp0[sg] = seg_sp0[sg + 1];
+    p->seg_r0 = (const int *)(sp->dev[16] = upload(seg_r0, sizeof(int) * ((size_t)nseg + 1)));
+    p->seg_s0 = (const int *)(sp->dev[17] = upload(seg_s0, sizeof(int) * nseg));
+    p->seg_sn = (const int *)(sp->dev[18] = upload(seg_sn, sizeof(int) * nseg));
+    p->seg_sp0 = (const int *)(sp->dev[19] = upload(seg_sp0, sizeof(int) * ((size_t)nseg + 1)));
+    p->rowinfo_seg = (const ezhip_rowinfo *)(sp->dev[20] = upload(ris, sizeof(ezhip_rowinfo) * ((size_t)njr + 1)));
+    p->seg_rows_max = rows_max; p->nch = nch;
+    p->debug_flags = getenv("EZHIP_DEBUG") ? atoi(getenv("EZHIP_DEBUG")) : 0;
+    if (sp->dev[16] && sp->dev[17] && sp->dev[18] && sp->dev[19] && sp->dev[20]) p->nseg = nseg;
+    free(cost); free(seg_r0); free(seg_s0); free(seg_sn); free(seg_sp0); free(ris);
+    (void)gi; (void)nic;
+}
+
 static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
 {
     int di = degree == DEG_CUBIC ? 2 : degree;
@@ -1186,6 +1252,7 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
     p->brow_s0 = (const int *)(sp->dev[12] = upload(brow_s0, sizeof(int) * nby));
     p->brow_n = (const int *)(sp->dev[13] = upload(brow_n, sizeof(int) * nby));
     p->n_special = nspecial;
+    build_stream_geometry(sp, p, gi, nic, njr, nbx, ntap, blk_base, blk_w, rbase, rw, rflag, special, nspecial, vector_mode);
     p->pole_weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
     p->vector_mode = vector_mode;
     ezhip_sync();

@@ -434,8 +434,255 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
     if (cvalid) zout[(size_t)sr.row * p.ni_dst + c] = outv;
 }
 
+/* ===================================================================================== */
+/* k_sep_stream : row-streaming separable interpolation                                     */
+/* ===================================================================================== */
+/* Why: measured on MI355X (profiles/r01_ubench.txt) the tile kernel's patch staging (18 us, 1.9x read
+ * amplification from halo rows / line granularity) and its stores (19 us) ADD instead of overlapping,
+ * and any vector load issued after a store waits for that store's acknowledgement (in-order vmcnt).
+ * Here one thread block owns a 256-column strip x a long segment of target rows:
+ *   - wave 4 (loader) streams every source row of the strip ONCE into an LDS ring with LDS-DMA
+ *     (global_load_lds_dword: no VGPRs, completion tracked by its own vmcnt), EZHIP_ST_DEPTH rows in flight;
+ *   - waves 0-3 (compute) only read LDS and store to global memory: they never wait on vmcnt;
+ *   - hand-off through two kinds of LDS words: `loaded` (rows landed) and per-wave `needed` (lowest
+ *     source row a compute wave still reads), polled with s_sleep.
+ * All blocks are co-resident (grid <= CUs x EZHIP_ST_BLOCKS_PER_CU), equal work per block. */
+#define ST_THREADS 320
+#define ST_DEPTH (60 / NCH > 20 ? 20 : 60 / NCH)   /* source rows in flight per loader wave (vmcnt <= 63) */
+
+
+template <int DEG, int NCH>
+__global__ __launch_bounds__(ST_THREADS) void k_sep_stream(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict__ zin)
+{
+    extern __shared__ float smem[];
+    constexpr int WSTR = 64 * NCH;                              /* ring row stride (floats) */
+    float *ring = smem;                                         /* [EZHIP_ST_NSLOT][WSTR] */
+    ezhip_rowinfo *rinfo = (ezhip_rowinfo *)(ring + EZHIP_ST_NSLOT * WSTR);   /* [seg_rows_max] */
+    float *scratch = (float *)(rinfo + p.seg_rows_max);                       /* POLE_CHUNK + 1 floats (pole sums) */
+    /* hand-off words live in their own LDS objects so that the compiler never orders them behind the ring's DMA */
+    __shared__ int sync[8];                                                    /* [0] loaded, [1..4] needed, [5] pole ready */
+    __shared__ float poles[2];                                                 /* [0] north, [1] south */
+    /* NB: hand-off words are accessed with workgroup-scope relaxed atomics (ds_read/ds_write).  `volatile`
+     * LDS accesses are lowered to flat_load/flat_store ... sc0 sc1, which go down the vector-memory pipe
+     * behind the stores (measured: 1100 cycles per row). */
+#define SYNC_LD(i) __hip_atomic_load(&sync[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define SYNC_ST(i, v) __hip_atomic_store(&sync[i], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+    const int seg = blockIdx.y, nis = p.ni_src;
+    const int r0 = p.seg_r0[seg], r1 = p.seg_r0[seg + 1];
+    const int s_first = p.seg_s0[seg], s_count = p.seg_sn[seg];
+    const int sp0 = p.seg_sp0[seg], sp1 = p.seg_sp0[seg + 1];
+    const int base = p.blk_base[blockIdx.x];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float fillv = p.fill ? *p.fill : 0.0f;
+
+    if (threadIdx.x < 8) sync[threadIdx.x] = 0;
+    /* stage this segment's row metadata (all threads; before any store is issued) */
+    {
+        const int nwords = (r1 - r0) * (int)(sizeof(ezhip_rowinfo) / 4);
+        const int *src = (const int *)(p.rowinfo_seg + r0);
+        int *dst = (int *)rinfo;
+        for (int k = threadIdx.x; k < nwords; k += ST_THREADS) dst[k] = src[k];
+    }
+    __syncthreads();
+
+    if (wave == 4) {
+        /* ---------------- loader wave ---------------- */
+        if (sp1 > sp0 && !p.vector_mode) {
+            /* the segment owns polar special rows: sequential REAL pole sums first (ez_calcpoleval order) */
+            bool need_n = false, need_s = false;
+            for (int q = sp0; q < sp1; q++) {
+                const ezhip_special_row sr = p.special[q];
+                need_n |= (sr.kind == 1); need_s |= (sr.kind == 2);
+                if (sr.kind == 0) for (int k = 0; k < 4; k++) { need_n |= (sr.tap[k] == EZ_ROW_POLE_N); need_s |= (sr.tap[k] == EZ_ROW_POLE_S); }
+            }
+            for (int which = 0; which < 2; which++) {
+                if (!(which == 0 ? need_n : need_s)) continue;
+                const float *zrow = which == 0 ? zin + (size_t)(p.nj_src - 1) * nis : zin;
+                const int n = p.pole_weighted ? nis - 1 : nis;
+                float acc = 0.0f;
+                for (int b0 = 0; b0 < n; b0 += POLE_CHUNK) {
+                    const int m = min(POLE_CHUNK, n - b0);
+                    for (int k = lane; k < m; k += 64) { int i = b0 + k; scratch[k] = p.pole_weighted ? zrow[i] * (p.ax[i + 1] - p.ax[i]) : zrow[i]; }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) {
+#pragma unroll 8
+                        for (int k = 0; k < m; k++) acc = acc + scratch[k];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (lane == 0) {
+                    if (p.pole_weighted) { float span = p.ax[nis - 1] - p.ax[0]; if (span != 0.0f) acc = acc / span; }
+                    else acc = acc / (1.0f * (float)nis);
+                    poles[which] = acc;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) SYNC_ST(5, 1);
+        }
+        unsigned coloff[NCH];
+#pragma unroll
+        for (int q = 0; q < NCH; q++) {          /* source column of ring column lane + 64 q (seam unrolled, tail clamped) */
+            int u = min(lane + 64 * q, p.blk_w[blockIdx.x] - 1);
+            int col = base + u;
+            if (col >= nis) col -= nis;
+            coloff[q] = (unsigned)col;
+        }
+        int free_below = (p.debug_flags & 2) ? (1 << 30) : 0;
+        for (int s = 0; s < s_count; s++) {
+            /* slot s % NSLOT still holds row s - NSLOT: wait until no compute wave needs it */
+            if (s - EZHIP_ST_NSLOT >= free_below) {          /* re-read the consumers' progress only when the cached value blocks */
+                while (true) {
+                    free_below = min(min(SYNC_LD(1), SYNC_LD(2)), min(SYNC_LD(3), SYNC_LD(4)));
+                    if (s - EZHIP_ST_NSLOT < free_below) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            const float *zr = zin + (size_t)(s_first + s) * nis;
+            float *slot = ring + (s % EZHIP_ST_NSLOT) * WSTR;
+#pragma unroll
+            for (int q = 0; q < NCH; q++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(zr + coloff[q]),
+                                                 (__attribute__((address_space(3))) void *)(slot + 64 * q), 4, 0, 0);
+            if (s >= ST_DEPTH) {
+                /* rows 0 .. s-ST_DEPTH have landed once at most NCH*ST_DEPTH younger loads remain */
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH * ST_DEPTH) : "memory");
+                if (lane == 0) SYNC_ST(0, s - ST_DEPTH + 1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) SYNC_ST(0, s_count);
+    } else {
+        /* ---------------- compute waves ---------------- */
+        const int c = blockIdx.x * SEP_BLOCK + threadIdx.x;
+        const bool cvalid0 = c < p.ni_dst;
+        const int cc = cvalid0 ? c : p.ni_dst - 1;
+        const bool cdehors = p.cflag[cc] != 0;
+        const int off0 = p.coff[cc];
+        const double cw[4] = {p.cw[cc], p.cw[p.ni_dst + cc], p.cw[2 * p.ni_dst + cc], p.cw[3 * p.ni_dst + cc]};
+        double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        int cur = -(1 << 28), have = (p.debug_flags & 2) ? (1 << 30) : 0;
+        double dbg_acc = 0;
+        const bool cvalid = cvalid0 && !(p.debug_flags & 1);
+        float *orow = zout + (size_t)r0 * p.ni_dst + c;
+        const float *pcol = ring + off0;
+        const int ntap = DEG == 3 ? 4 : (DEG == 1 ? 2 : 1);
+#define XS(row) xrow<DEG>(pcol + ((row) % EZHIP_ST_NSLOT) * WSTR, cw)
+        /* Row metadata: lane l of the wave holds row g0 + l of the current 64-row group (ONE LDS read per 64 rows);
+         * each row then broadcasts it with v_readlane.  A per-row dependent LDS read (metadata, then the ring)
+         * measured ~1100 cycles per row at 4 compute waves per SIMD: the row loop must not chain LDS round trips. */
+        const int nrows = r1 - r0;
+        for (int g0 = 0; g0 < nrows; g0 += 64) {
+            const ezhip_rowinfo mine = rinfo[min(g0 + lane, nrows - 1)];
+            const int kmax = min(64, nrows - g0);
+            for (int k = 0; k < kmax; k++, orow += p.ni_dst) {
+                if (__builtin_amdgcn_readlane(mine.flag, k)) continue;
+                const int jb = __builtin_amdgcn_readlane(mine.jb, k);   /* relative to s_first */
+                if (jb != cur) {
+                    if (lane == 0) SYNC_ST(1 + wave, jb);            /* rows below jb are free for the loader */
+                    const int need = jb + ntap;
+                    if (have < need) {
+                        while ((have = SYNC_LD(0)) < need) __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                double val;
+                if (DEG == 0) { val = XS(jb); cur = jb; }
+                else if (DEG == 1) {
+                    const int d = jb - cur;
+                    if (d != 0) {
+                        if (d == 1) { t0 = t1; t1 = XS(jb + 1); }
+                        else { t0 = XS(jb); t1 = XS(jb + 1); }
+                        cur = jb;
+                    }
+                    val = t0 + (t1 - t0) * readlane_f64(mine.w[0], k);
+                } else {
+                    const int d = jb - cur;
+                    if (d != 0) {
+                        if (d == 1) { t0 = t1; t1 = t2; t2 = t3; t3 = XS(jb + 3); }
+                        else if (d == 2) { t0 = t2; t1 = t3; t2 = XS(jb + 2); t3 = XS(jb + 3); }
+                        else if (d == 3) { t0 = t3; t1 = XS(jb + 1); t2 = XS(jb + 2); t3 = XS(jb + 3); }
+                        else { t0 = XS(jb); t1 = XS(jb + 1); t2 = XS(jb + 2); t3 = XS(jb + 3); }
+                        cur = jb;
+                    }
+                    val = fma(readlane_f64(mine.w[3], k), t3, fma(readlane_f64(mine.w[2], k), t2,
+                          fma(readlane_f64(mine.w[1], k), t1, readlane_f64(mine.w[0], k) * t0)));
+                }
+                if (cvalid) *orow = cdehors ? fillv : (float)val;
+                else dbg_acc += val;
+            }
+        }
+        if (dbg_acc == 1.2345e300 && cvalid0) zout[c] = 0.f;   /* keeps the arithmetic alive in the no-store debug mode */
+#undef XS
+        if (lane == 0) SYNC_ST(1 + wave, 1 << 30);               /* nothing needed any more */
+
+        /* special rows of this segment (polar strips / pole rows / outside rows): gathers from global memory */
+        if (sp1 > sp0) {
+            float pole_n = 0.f, pole_s = 0.f;
+            bool have_poles = false;
+            for (int q = sp0; q < sp1; q++) {
+                const ezhip_special_row sr = p.special[q];
+                float outv;
+                if (sr.kind == 3) outv = fillv;
+                else {
+                    if (!p.vector_mode && !have_poles) {
+                        while (SYNC_LD(5) == 0) __builtin_amdgcn_s_sleep(4);
+                        pole_n = poles[0]; pole_s = poles[1]; have_poles = true;
+                    }
+                    if (sr.kind == 1) outv = pole_n;
+                    else if (sr.kind == 2) outv = pole_s;
+                    else {
+                        const ColTaps t = load_col(p.cidx_s, p.cw_s, p.ni_dst, cc);
+                        double tv[4];
+                        for (int k = 0; k < ntap; k++) {
+                            int row = sr.tap[k];
+                            if (row >= 0) tv[k] = xpass<DEG>(zin + (size_t)row * nis, t);
+                            else if (p.vector_mode) tv[k] = xpass<DEG>(row == EZ_ROW_POLE_N ? p.pole_row_n : p.pole_row_s, t);
+                            else tv[k] = (double)(row == EZ_ROW_POLE_N ? pole_n : pole_s);
+                        }
+                        double val;
+                        if (DEG == 0) val = tv[0];
+                        else if (DEG == 1) val = tv[0] + (tv[1] - tv[0]) * sr.w[0];
+                        else val = fma(sr.w[3], tv[3], fma(sr.w[2], tv[2], fma(sr.w[1], tv[1], sr.w[0] * tv[0])));
+                        outv = (float)val;
+                    }
+                }
+                if (cvalid) zout[(size_t)sr.row * p.ni_dst + c] = outv;
+            }
+        }
+    }
+}
+
+static size_t stream_lds_bytes(const ezhip_sep_plan *plan)
+{
+    return sizeof(float) * (size_t)EZHIP_ST_NSLOT * 64 * plan->nch + sizeof(ezhip_rowinfo) * (size_t)plan->seg_rows_max
+           + sizeof(float) * (POLE_CHUNK + 1);
+}
+
+template <int DEG>
+static int launch_stream(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin)
+{
+    dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, plan->nseg), block(ST_THREADS);
+    size_t lds = stream_lds_bytes(plan);
+    switch (plan->nch) {
+    case 1: hipLaunchKernelGGL((k_sep_stream<DEG, 1>), grid, block, lds, g_stream, *plan, d_zout, d_zin); break;
+    case 2: hipLaunchKernelGGL((k_sep_stream<DEG, 2>), grid, block, lds, g_stream, *plan, d_zout, d_zin); break;
+    case 3: hipLaunchKernelGGL((k_sep_stream<DEG, 3>), grid, block, lds, g_stream, *plan, d_zout, d_zin); break;
+    case 4: hipLaunchKernelGGL((k_sep_stream<DEG, 4>), grid, block, lds, g_stream, *plan, d_zout, d_zin); break;
+    default: hipLaunchKernelGGL((k_sep_stream<DEG, 5>), grid, block, lds, g_stream, *plan, d_zout, d_zin); break;
+    }
+    return LAUNCH_CHECK("k_sep_stream");
+}
+
 extern "C" int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin)
 {
+    if (plan->nseg > 0) {
+        switch (plan->degree) {
+        case 0: return launch_stream<0>(plan, d_zout, d_zin);
+        case 1: return launch_stream<1>(plan, d_zout, d_zin);
+        case 3: return launch_stream<3>(plan, d_zout, d_zin);
+        }
+    }
     int nmain = (plan->nblk_y + plan->rb_per_block - 1) / plan->rb_per_block;
     dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, nmain + plan->n_special);
     dim3 block(SEP_BLOCK);

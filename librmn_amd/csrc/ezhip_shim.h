@@ -94,9 +94,21 @@ typedef struct {
     int vector_mode;                  /* 1: strip pole rows come from pole_rows_n/s instead of a scalar */
     const float *pole_row_n, *pole_row_s;   /* [ni_src] synthetic polar wind rows (vector mode) */
     const float *fill;                /* device scalar written to DEHORS points (may be NULL) */
+    /* ---- row-streaming variant (k_sep_stream): one thread block = one 256-column strip x one segment of
+     * target rows; a loader wave streams the strip's source rows ONCE through an LDS ring (LDS-DMA) while
+     * four compute waves consume them.  nseg == 0: variant not usable for this plan. */
+    int nseg, nch;                    /* segments per strip; 64-column chunks per staged source row */
+    const int *seg_r0;                /* [nseg + 1] target-row boundaries */
+    const int *seg_s0, *seg_sn;       /* [nseg] first source row / number of source rows streamed */
+    const int *seg_sp0;               /* [nseg + 1] range of special rows (indices into special[]) owned by the segment */
+    const ezhip_rowinfo *rowinfo_seg; /* [nj_dst] like rowinfo, jb relative to the SEGMENT's first streamed row */
+    int seg_rows_max;                 /* max target rows of a segment (LDS sizing) */
+    int debug_flags;                  /* development only (EZHIP_DEBUG): bit 0 = suppress the main stores, bit 1 = no loader waits */
 } ezhip_sep_plan;
 
 int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin);
+#define EZHIP_ST_NSLOT 32            /* LDS ring slots (source rows) of k_sep_stream */
+#define EZHIP_ST_BLOCKS_PER_CU 4
 
 /*
  * Generic per-point plan ("mode B"): arbitrary located coordinates.  Restates the reference's

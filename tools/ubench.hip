@@ -114,6 +114,38 @@ __global__ __launch_bounds__(512) void k_spec(float *out, const float *in)
         __syncthreads();
     }
 }
+// loader-only: one wave per block streams `nrows` source rows of a 164-column strip through an LDS ring
+template <int MODE, int DEPTH>   // MODE 0: LDS-DMA dword ; 1: global_load dword -> regs -> ds_write ; 2: LDS-DMA but 4 loader waves
+__global__ __launch_bounds__(320) void k_loader(float *out, const float *in, int nrows_per_block)
+{
+    __shared__ float ring[40 * 192];
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int base = (int)(blockIdx.x * 156.4f);
+    int s_first = blockIdx.y * nrows_per_block;
+    if (MODE != 2 && wave != 4) return;
+    unsigned coloff[3];
+    for (int q = 0; q < 3; q++) { int col = base + min(lane + 64 * q, 163); if (col >= NIS) col -= NIS; coloff[q] = col; }
+    int step = (MODE == 2) ? 5 : 1, start = (MODE == 2) ? wave : 0;
+    float acc = 0;
+    for (int s = start; s < nrows_per_block; s += step) {
+        if (s_first + s >= NJS) break;
+        const float *zr = in + (size_t)(s_first + s) * NIS;
+        float *slot = ring + (s % 40) * 192;
+        if (MODE == 1) {
+            float v0 = zr[coloff[0]], v1 = zr[coloff[1]], v2 = zr[coloff[2]];
+            slot[lane] = v0; slot[lane + 64] = v1; slot[lane + 128] = v2;
+        } else {
+            for (int q = 0; q < 3; q++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(zr + coloff[q]),
+                                                 (__attribute__((address_space(3))) void *)(slot + 64 * q), 4, 0, 0);
+            if (s / step >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * DEPTH) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    acc = ring[lane];
+    if (acc == 12345.f) out[lane] = acc;
+}
 template <class F> float timeit(F f, int reps = 20)
 {
     f(); CHECK(hipDeviceSynchronize());
@@ -145,5 +177,10 @@ int main()
     printf("specialized K=8         : %7.2f us\n", timeit([&] { hipLaunchKernelGGL(k_spec<8>, dim3(29, 29), dim3(512), 0, 0, OUTB, INB); }));
     printf("specialized K=2         : %7.2f us\n", timeit([&] { hipLaunchKernelGGL(k_spec<2>, dim3(29, 113), dim3(512), 0, 0, OUTB, INB); }));
     printf("specialized K=16        : %7.2f us\n", timeit([&] { hipLaunchKernelGGL(k_spec<16>, dim3(29, 15), dim3(512), 0, 0, OUTB, INB); }));
+    printf("loader-only DMA depth20 : %7.2f us\n", timeit([&] { hipLaunchKernelGGL((k_loader<0, 20>), dim3(29, 35), dim3(320), 0, 0, OUTB, INB, 63); }));
+    printf("loader-only DMA depth8  : %7.2f us\n", timeit([&] { hipLaunchKernelGGL((k_loader<0, 8>), dim3(29, 35), dim3(320), 0, 0, OUTB, INB, 63); }));
+    printf("loader-only regs        : %7.2f us\n", timeit([&] { hipLaunchKernelGGL((k_loader<1, 8>), dim3(29, 35), dim3(320), 0, 0, OUTB, INB, 63); }));
+    printf("loader 5 waves DMA d12  : %7.2f us\n", timeit([&] { hipLaunchKernelGGL((k_loader<2, 12>), dim3(29, 35), dim3(320), 0, 0, OUTB, INB, 63); }));
+    printf("loader-only DMA 29x140  : %7.2f us\n", timeit([&] { hipLaunchKernelGGL((k_loader<0, 20>), dim3(29, 140), dim3(320), 0, 0, OUTB, INB, 16); }));
     return 0;
 }
