@@ -1216,6 +1216,17 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
             q->jb = rbase[r] - brow_s0[by];
             for (int w = 0; w < 4; w++) q->w[w] = rw[w * njr + r];
         }
+    /* pad0 = 1 on every row of a row-block that the straight-line kernel body can take: 16 main rows, each
+     * advancing the source window by 0 or 1, and the whole window inside the staged patch */
+    for (int by = 0; by < nby; by++) {
+        int ok = brow_n[by] > 0 && !getenv("EZHIP_SEP_NOSIMPLE");
+        for (int k = 0; k < EZHIP_SEP_ROWS && ok; k++) {
+            int r = by * EZHIP_SEP_ROWS + k;
+            if (r >= njr || rflag[r]) { ok = 0; break; }
+            if (k > 0) { int d = rbase[r] - rbase[r - 1]; if (d < 0 || d > 1) ok = 0; }
+        }
+        for (int k = 0; k < EZHIP_SEP_ROWS; k++) rinfo[by * EZHIP_SEP_ROWS + k].pad0 = ok;
+    }
     ezhip_sep_plan *p = &sp->p;
     memset(p, 0, sizeof(*p));
     p->degree = degree; p->ni_src = gi->ni; p->nj_src = gi->nj; p->ni_dst = nic; p->nj_dst = njr;
@@ -1224,15 +1235,16 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
         int wmax = 1, nmax = 1;
         for (int bx = 0; bx < nbx; bx++) if (blk_w[bx] > wmax) wmax = blk_w[bx];
         for (int by = 0; by < nby; by++) if (brow_n[by] > nmax) nmax = brow_n[by];
-        p->wstride = wmax; p->patch_elems = wmax * nmax;
-        if (p->patch_elems < 1032) p->patch_elems = 1032;
-        p->nblk_y = nby;
-        /* row-blocks streamed per thread block: 1 (measured best on gfx950; > 1 selects the experimental
-         * register-staged software pipeline, see k_sep) */
-        int rb = 1;
+        /* row-blocks per thread block: 2 for bicubic (LDS-DMA software pipeline: the next patch is in flight while
+         * the current one is computed and stored; measured 64 -> 57-59 us at cfg2), 1 otherwise (no gain measured) */
+        int rb = (degree == DEG_CUBIC) ? 2 : 1;
         if (getenv("EZHIP_SEP_RB")) rb = atoi(getenv("EZHIP_SEP_RB"));
         if (rb > 8) rb = 8;
         if (rb < 1) rb = 1;
+        if (rb > 1) wmax = 64 * ((wmax + 63) / 64);      /* LDS-DMA pipeline: rows are staged in whole 64-float chunks */
+        p->wstride = wmax; p->patch_elems = wmax * nmax;
+        if (p->patch_elems < 1032) p->patch_elems = 1032;
+        p->nblk_y = nby;
         p->rb_per_block = rb;
     }
     p->rowinfo = (const ezhip_rowinfo *)(sp->dev[14] = upload(rinfo, sizeof(ezhip_rowinfo) * (size_t)nby * EZHIP_SEP_ROWS));

@@ -221,6 +221,20 @@ __device__ __forceinline__ double readlane_f64(double v, int k)
     return __hiloint2double(hi, lo);
 }
 
+/* LDS-DMA of one dword per lane, issued through inline asm ON PURPOSE: for the builtin the compiler tracks the
+ * LDS destination and conservatively inserts `s_waitcnt vmcnt(0)` in front of later ds_reads that may alias it
+ * (it cannot tell the two patch buffers apart), which serialises the software pipeline and drains the stores.
+ * Completion is ordered by the hand-placed vmcnt waits + the workgroup barrier instead.
+ * LDS address of lane l = lds_byte_addr + 4 l ; global address = base + voff_bytes(l).  m0 is written without a
+ * clobber (it is a reserved register for inline asm); nothing else in these kernels uses m0. */
+__device__ __forceinline__ void lds_dma_dword(const float *base_uniform, unsigned voff_bytes, unsigned lds_byte_addr)
+{
+    const char *addr = (const char *)base_uniform + voff_bytes;        /* per-lane 64-bit address */
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                 :: "v"(addr), "s"(__builtin_amdgcn_readfirstlane((int)lds_byte_addr)) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; }
+
 #define SEP_RIT ((EZHIP_SEP_RMAX + 3) / 4)     /* staged rows per wave (4 waves) */
 #define SEP_QCH ((EZHIP_SEP_WMAX + 63) / 64)   /* 64-column chunks per staged row */
 
@@ -307,6 +321,45 @@ __device__ __forceinline__ void sep_rows_staged(const ezhip_sep_plan &p, const e
 #undef XP
 }
 
+/* Straight-line variant of sep_rows_staged for the common row-block: no flagged row and every row advances
+ * the source window by 0 or 1 (any up-sampling target).  The window shift is a SELECT on a scalar condition
+ * and the newest source row is x-passed for every target row (16 x-passes instead of ~14), so the 16 unrolled
+ * rows contain no branch: the compiler hoists all LDS reads and overlaps the rows (the branchy version chains
+ * one LDS round trip per row; measured ~700-1000 cycles per row). */
+template <int DEG>
+__device__ __forceinline__ void sep_rows_simple(const ezhip_sep_plan &p, const ezhip_rowinfo &mine, const float *patch, int wstride,
+                                                int off0, const double (&cw)[4], int r0,
+                                                float *__restrict__ zout, int c, bool cvalid, bool cdehors, float fillv)
+{
+    const float *pcol = patch + off0;
+    float *orow = zout + (size_t)r0 * p.ni_dst + c;
+    const int jb0 = __builtin_amdgcn_readlane(mine.jb, 0);
+#define XP(row) xrow<DEG>(pcol + (row) * wstride, cw)
+    double t0, t1, t2, t3;
+    if (DEG == 3) { t0 = XP(jb0); t1 = XP(jb0 + 1); t2 = XP(jb0 + 2); t3 = XP(jb0 + 3); }
+    else { t0 = XP(jb0); t1 = XP(jb0 + 1); t2 = t3 = 0.0; }
+    int prev = jb0;
+#pragma unroll
+    for (int k = 0; k < EZHIP_SEP_ROWS; k++, orow += p.ni_dst) {
+        const int jb = __builtin_amdgcn_readlane(mine.jb, k);
+        const bool adv = jb != prev;                       /* scalar; jb - prev is 0 or 1 by construction */
+        prev = jb;
+        double val;
+        if (DEG == 1) {
+            const double tn = XP(jb + 1);
+            t0 = adv ? t1 : t0; t1 = adv ? tn : t1;
+            val = t0 + (t1 - t0) * readlane_f64(mine.w[0], k);
+        } else {
+            const double tn = XP(jb + 3);
+            t0 = adv ? t1 : t0; t1 = adv ? t2 : t1; t2 = adv ? t3 : t2; t3 = adv ? tn : t3;
+            val = fma(readlane_f64(mine.w[3], k), t3, fma(readlane_f64(mine.w[2], k), t2,
+                  fma(readlane_f64(mine.w[1], k), t1, readlane_f64(mine.w[0], k) * t0)));
+        }
+        if (cvalid) *orow = cdehors ? fillv : (float)val;
+    }
+#undef XP
+}
+
 /* gather fallback for one row-block (patch not usable: strong down-sampling, non-consecutive literal
  * seam taps, or more source rows than the patch holds) */
 template <int DEG>
@@ -375,24 +428,67 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
             }
             const ezhip_rowinfo mine = p.rowinfo[(size_t)by * EZHIP_SEP_ROWS + (threadIdx.x & (EZHIP_SEP_ROWS - 1))];
             __syncthreads();
-            sep_rows_staged<DEG>(p, mine, smem, p.wstride, off0, cw, by * EZHIP_SEP_ROWS, zout, c, cvalid, cdehors, fillv);
+            if (DEG != 0 && mine.pad0)      /* pad0 (uniform across lanes): row-block qualifies for the straight-line body */
+                sep_rows_simple<DEG>(p, mine, smem, p.wstride, off0, cw, by * EZHIP_SEP_ROWS, zout, c, cvalid, cdehors, fillv);
+            else
+                sep_rows_staged<DEG>(p, mine, smem, p.wstride, off0, cw, by * EZHIP_SEP_ROWS, zout, c, cvalid, cdehors, fillv);
             return;
         }
-        /* experimental software pipeline over rb_per_block row-blocks (EZHIP_SEP_RB > 1): register-staged
-         * prefetch of the next patch.  Measured slower on gfx950 (137 VGPRs -> 3 waves/SIMD, and the
-         * in-order vmcnt makes the prefetch wait behind the previous row-block's stores). */
-        PatchRegs pr;
-        patch_issue(pr, p, zin, by0, coloff, W, lane, wv);
-        int buf = 0;
-        for (int by = by0; by < by1; by++, buf ^= 1) {
-            float *patch = smem + buf * p.patch_elems;
+        /* Software pipeline over rb_per_block consecutive row-blocks with LDS-DMA (global_load_lds: no VGPR
+         * staging) and two patch buffers.  Why: with one row-block per thread block, all blocks of a launch run
+         * their staging phase, then their compute phase, in near lockstep (only ~3 rounds of blocks per CU), so the
+         * HBM time and the fp64 VALU time ADD (nearest 41 us, bicubic 60 us).  Here the DMA of row-block i+1 is in
+         * flight while row-block i is computed and stored.  vmcnt is in-order and shared by loads and stores: the
+         * wait for DMA(i+1) is `vmcnt(16)`, i.e. "all but the 16 youngest" = the 16 stores of row-block i, which are
+         * therefore never waited for.  That needs exactly 16 store instructions per wave: guaranteed for row-blocks
+         * marked simple (pad0) by storing unconditionally (out-of-range lanes duplicate the last column's value). */
+        const int wstr = p.wstride;      /* = 64 * nch: DMA chunks are 64 floats */
+        unsigned coloff_c[SEP_QCH];
+#pragma unroll
+        for (int q = 0; q < SEP_QCH; q++) {
+            int col = base + min(lane + 64 * q, W - 1);
+            if (col >= nis) col -= nis;
+            coloff_c[q] = (unsigned)col;
+        }
+        float *bufA = smem, *bufB = smem + p.patch_elems;
+        float *riA = smem + 2 * p.patch_elems, *riB = riA + 192;      /* row metadata of a row-block: 16 x 48 B = 192 dwords */
+        auto dma_issue = [&](int by, float *dst, float *ridst) {
+            const int s0 = p.brow_s0[by], n = p.brow_n[by];
+            for (int row = wv; row < n; row += SEP_BLOCK / 64) {
+                const float *zr = zin + (size_t)(s0 + row) * nis;
+                float *prow = dst + row * wstr;
+#pragma unroll
+                for (int q = 0; q < SEP_QCH; q++)
+                    if (64 * q < W)        /* wave-uniform: whole 64-float chunk (tail lanes re-load the last valid column) */
+                        lds_dma_dword(zr, coloff_c[q] * 4u, lds_addr_of(prow + 64 * q));
+            }
+            if (wv == 3) {               /* the row metadata rides the same DMA (no register load inside the loop) */
+                const float *src = (const float *)(p.rowinfo + (size_t)by * EZHIP_SEP_ROWS);
+#pragma unroll
+                for (int q = 0; q < 3; q++) lds_dma_dword(src, (unsigned)(lane + 64 * q) * 4u, lds_addr_of(ridst + 64 * q));
+            }
+        };
+        dma_issue(by0, bufA, riA);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int c_st = cc;             /* unconditional stores: lanes past the last column rewrite column ni_dst-1 */
+        for (int by = by0; by < by1; by++) {
+            const bool odd = (by - by0) & 1;
+            float *cur = odd ? bufB : bufA, *nxt = odd ? bufA : bufB;
+            const ezhip_rowinfo mine = ((const ezhip_rowinfo *)(odd ? riB : riA))[threadIdx.x & (EZHIP_SEP_ROWS - 1)];
             const int n = p.brow_n[by];
-            patch_commit(pr, patch, n, W, p.wstride, lane, wv);       /* waits for this row-block's loads */
-            const ezhip_rowinfo mine = pr.ri;
-            __syncthreads();                                          /* patch[buf] complete; patch[buf^1] free again */
-            if (by + 1 < by1) patch_issue(pr, p, zin, by + 1, coloff, W, lane, wv);   /* in flight during the compute below */
-            if (n > 0) sep_rows_staged<DEG>(p, mine, patch, p.wstride, off0, cw, by * EZHIP_SEP_ROWS, zout, c, cvalid, cdehors, fillv);
-            else sep_rowblock_gather<DEG>(p, ri_lds, zout, zin, by, cc, c, cvalid, cdehors, fillv);
+            const bool more = by + 1 < by1;
+            if (more) dma_issue(by + 1, nxt, odd ? riA : riB);
+            const bool simple = DEG != 0 && __builtin_amdgcn_readfirstlane(mine.pad0) != 0;
+            if (n > 0 && simple) {
+                sep_rows_simple<DEG>(p, mine, cur, wstr, off0, cw, by * EZHIP_SEP_ROWS, zout, c_st, true, cdehors, fillv);
+                if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     /* DMA(by+1) landed; the 16 stores stay in flight */
+            } else {
+                if (n > 0) sep_rows_staged<DEG>(p, mine, cur, wstr, off0, cw, by * EZHIP_SEP_ROWS, zout, c, cvalid, cdehors, fillv);
+                else sep_rowblock_gather<DEG>(p, ri_lds, zout, zin, by, cc, c, cvalid, cdehors, fillv);
+                if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();             /* everyone's DMA landed, everyone finished reading `cur` */
         }
         return;
     }
@@ -687,7 +783,7 @@ extern "C" int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const
     dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, nmain + plan->n_special);
     dim3 block(SEP_BLOCK);
     const bool pipe = plan->rb_per_block > 1;
-    size_t lds = sizeof(float) * (pipe ? 2 : 1) * (size_t)plan->patch_elems;
+    size_t lds = sizeof(float) * ((pipe ? 2 : 1) * (size_t)plan->patch_elems + (pipe ? 2 * 192 : 0));
 #define LAUNCH_SEP(D) do { if (pipe) hipLaunchKernelGGL((k_sep<D, true>), grid, block, lds, g_stream, *plan, d_zout, d_zin); \
                            else hipLaunchKernelGGL((k_sep<D, false>), grid, block, lds, g_stream, *plan, d_zout, d_zin); } while (0)
     switch (plan->degree) {
