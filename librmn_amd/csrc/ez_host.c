@@ -53,6 +53,7 @@ typedef struct ezh_set {
     ezh_sepplan sep[3][2];  /* [degree index][vector_mode] */
     float *d_x, *d_y;       /* per-point located coordinates (generic mode) */
     float *d_scratch;       /* float[8]: fill value + keys, pole values */
+    float *d_poles_batch; int poles_cap;   /* pole values of a c_ezsint_batch_dev batch (2 per field) */
     float *d_prow;          /* 2 * ni_src synthetic polar wind rows (vector mode), u then v: [u_n, u_s, v_n, v_s] */
     float *d_stage_in, *d_stage_out, *d_stage_in2, *d_stage_out2;   /* host-pointer ABI staging */
 } ezh_set;
@@ -470,7 +471,7 @@ static void free_set(ezh_set *s)
 {
     for (int d = 0; d < 3; d++) for (int v = 0; v < 2; v++) free_sepplan(&s->sep[d][v]);
     free(s->x1d); free(s->y1d);
-    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow);
+    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch);
     ezhip_free(s->d_stage_in); ezhip_free(s->d_stage_out); ezhip_free(s->d_stage_in2); ezhip_free(s->d_stage_out2);
     free(s);
 }
@@ -1127,6 +1128,71 @@ static void build_stream_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, const ezh_
     (void)gi; (void)nic;
 }
 
+/* k_sepx geometry: valid row-blocks, their staging steps (first-of-segment / continuing), ring slots.
+ * Leaves p->x_nseg == 0 when the plan does not qualify (then k_sep runs). */
+static void build_sepx_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, int degree, int nbx, int nby, int njr,
+                                const int *blk_base, const int *brow_s0, const int *brow_n,
+                                const int *rbase, const double *rw, const unsigned char *rflag)
+{
+    p->x_nseg = 0;
+    p->debug_flags = getenv("EZHIP_DEBUG") ? atoi(getenv("EZHIP_DEBUG")) : 0;
+    if (degree == DEG_NEAREST || getenv("EZHIP_NO_SEPX")) return;
+    for (int bx = 0; bx < nbx; bx++) if (blk_base[bx] < 0) return;
+    int *vb = (int *)malloc(sizeof(int) * (nby + 1)), nvb = 0, tr = 4, ok = 1;
+    for (int by = 0; by < nby && ok; by++) {
+        int r0 = by * EZHIP_SEP_ROWS, r1 = imin(r0 + EZHIP_SEP_ROWS, njr), nmain = 0;
+        for (int r = r0; r < r1; r++) nmain += !rflag[r];
+        if (!nmain) continue;
+        if (brow_n[by] <= 0) { ok = 0; break; }          /* source window taller than the patch: k_sep's gather path */
+        if (brow_n[by] > tr) tr = brow_n[by];
+        vb[nvb++] = by;
+    }
+    if (!ok || nvb == 0 || tr > 32 || njr >= (1 << 26)) { free(vb); return; }
+    int mirror = getenv("EZHIP_SEPX_MIRROR") ? atoi(getenv("EZHIP_SEPX_MIRROR")) : 0;
+    ezhip_xstep *first = (ezhip_xstep *)calloc(nvb, sizeof(ezhip_xstep)), *cont = (ezhip_xstep *)calloc(nvb, sizeof(ezhip_xstep));
+    ezhip_xrows *xr = (ezhip_xrows *)calloc((size_t)nvb, sizeof(ezhip_xrows));
+    int prows = 1;
+    for (int i = 0; i < nvb; i++) {
+        int by = vb[i], a = brow_s0[by], b = a + brow_n[by];
+        first[i].s0 = a; first[i].n = b - a; first[i].slot0 = a % tr; first[i].by = by;
+        cont[i] = first[i];
+        if (i > 0) {       /* rows already in the ring: the previous window [pa, pb) */
+            int pa = brow_s0[vb[i - 1]], pb = pa + brow_n[vb[i - 1]];
+            if (a >= pa && b >= pb && a <= pb) { cont[i].s0 = pb; cont[i].n = b - pb; }
+            else if (a <= pa && b <= pb && b >= pa) { cont[i].s0 = a; cont[i].n = pa - a; }
+            cont[i].slot0 = cont[i].s0 % tr;
+        }
+        if (first[i].n > prows) prows = first[i].n;
+        /* target rows: a row that is not a main row re-stores the nearest main row of the same row-block */
+        int r0 = by * EZHIP_SEP_ROWS, lastmain = -1;
+        for (int k = 0; k < EZHIP_SEP_ROWS; k++) { int r = r0 + k; if (r < njr && !rflag[r]) { lastmain = r; break; } }
+        for (int k = 0; k < EZHIP_SEP_ROWS; k++) {
+            int r = r0 + k;
+            if (r < njr && !rflag[r]) lastmain = r;
+            xr[i].pk[k] = (lastmain << 5) | (rbase[lastmain] % tr);
+            for (int w = 0; w < 4; w++) xr[i].w[k][w] = rw[w * njr + lastmain];
+        }
+    }
+    size_t lds = ezhip_sepx_lds_bytes(tr, mirror, prows, p->wstride);
+    int cap = ezhip_sepx_capacity(degree, mirror, lds);
+    if (cap <= 0) cap = 768;
+    int nseg = cap / nbx;
+    if (nseg < 1) nseg = 1;
+    int rb = (nvb + nseg - 1) / nseg;
+    if (getenv("EZHIP_SEPX_RB")) rb = atoi(getenv("EZHIP_SEPX_RB"));
+    if (rb < 1) rb = 1;
+    p->x_rb = rb; p->x_nseg = (nvb + rb - 1) / rb; p->x_nvb = nvb;
+    p->x_tr = tr; p->x_prows = prows; p->x_mirror = mirror;
+    if (getenv("EZHIP_VERBOSE"))
+        fprintf(stderr, "k_sepx plan: degree %d, %d column blocks x %d segments of %d row-blocks (%d valid), ring %d rows, patch %d rows x %d, LDS %zu B, capacity %d blocks\n",
+                degree, nbx, p->x_nseg, rb, nvb, tr, prows, p->wstride, lds, cap);
+    p->x_first = (const ezhip_xstep *)(sp->dev[21] = upload(first, sizeof(ezhip_xstep) * nvb));
+    p->x_cont = (const ezhip_xstep *)(sp->dev[22] = upload(cont, sizeof(ezhip_xstep) * nvb));
+    p->x_rows = (const ezhip_xrows *)(sp->dev[23] = upload(xr, sizeof(ezhip_xrows) * (size_t)nvb));
+    if (!sp->dev[21] || !sp->dev[22] || !sp->dev[23]) p->x_nseg = 0;
+    free(first); free(cont); free(xr); free(vb);
+}
+
 static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
 {
     int di = degree == DEG_CUBIC ? 2 : degree;
@@ -1241,7 +1307,7 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
         if (getenv("EZHIP_SEP_RB")) rb = atoi(getenv("EZHIP_SEP_RB"));
         if (rb > 8) rb = 8;
         if (rb < 1) rb = 1;
-        if (rb > 1) wmax = 64 * ((wmax + 63) / 64);      /* LDS-DMA pipeline: rows are staged in whole 64-float chunks */
+        wmax = 64 * ((wmax + 63) / 64);      /* LDS-DMA (k_sep pipeline, k_sepx): rows are staged in whole 64-float chunks */
         p->wstride = wmax; p->patch_elems = wmax * nmax;
         if (p->patch_elems < 1032) p->patch_elems = 1032;
         p->nblk_y = nby;
@@ -1264,6 +1330,11 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
     p->brow_s0 = (const int *)(sp->dev[12] = upload(brow_s0, sizeof(int) * nby));
     p->brow_n = (const int *)(sp->dev[13] = upload(brow_n, sizeof(int) * nby));
     p->n_special = nspecial;
+    for (int k = 0; k < nspecial && !vector_mode; k++) {
+        if (special[k].kind == 1 || special[k].kind == 2) p->need_poles = 1;
+        if (special[k].kind == 0) for (int q = 0; q < 4; q++) if (special[k].tap[q] < 0) p->need_poles = 1;
+    }
+    build_sepx_geometry(sp, p, degree, nbx, nby, njr, blk_base, brow_s0, brow_n, rbase, rw, rflag);
     build_stream_geometry(sp, p, gi, nic, njr, nbx, ntap, blk_base, blk_w, rbase, rw, rflag, special, nspecial, vector_mode);
     p->pole_weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
     p->vector_mode = vector_mode;
@@ -1363,7 +1434,14 @@ static int ensure_scratch(ezh_set *s)
 
 /* one field, device pointers; vector_mode: 0 scalar, 1 = u/v component with synthetic pole rows
  * (prow_n / prow_s device pointers, may be NULL when polar correction is off) */
+static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector_mode, const float *prow_n, const float *prow_s, const float *d_poles_pre);
 static int run_field(ezh_set *s, float *d_zout, const float *d_zin, int vector_mode, const float *prow_n, const float *prow_s)
+{
+    return run_field_p(s, d_zout, d_zin, vector_mode, prow_n, prow_s, NULL);
+}
+
+/* d_poles_pre: device float[2] pole values of this field already computed (batch entry point), or NULL */
+static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector_mode, const float *prow_n, const float *prow_s, const float *d_poles_pre)
 {
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     int degree = O.degre_interp, polar = O.polar_correction == 1;
@@ -1395,6 +1473,8 @@ static int run_field(ezh_set *s, float *d_zout, const float *d_zin, int vector_m
         p.fill = d_fill;
         if (p.pole_weighted) { if (ensure_grid_dev(gi)) return -1; p.ax = gi->d_ax; }
         p.pole_row_n = prow_n; p.pole_row_s = prow_s;
+        p.polevals = d_poles_pre ? d_poles_pre : d_poles;
+        if (p.need_poles && !d_poles_pre && ezhip_polevals(d_poles, d_zin, gi->ni, gi->nj, p.pole_weighted, p.ax)) return -1;
         if (ezhip_interp_sep(&p, d_zout, d_zin)) return -1;
         return ierc;
     }
@@ -1402,9 +1482,9 @@ static int run_field(ezh_set *s, float *d_zout, const float *d_zin, int vector_m
     ezhip_pts_plan pp;
     int zones = !polar ? 0 : (s->extrap ? 2 : 1);
     fill_pts_plan(s, gi, &pp, degree, zones, vector_mode);
-    pp.fill = d_fill; pp.polevals = d_poles;
+    pp.fill = d_fill; pp.polevals = d_poles_pre ? d_poles_pre : d_poles;
     pp.pole_row_n = prow_n; pp.pole_row_s = prow_s;
-    if (zones == 1 && !vector_mode && ezhip_polevals(d_poles, d_zin, gi->ni, gi->nj, pp.pole_weighted, gi->d_ax)) return -1;
+    if (zones == 1 && !vector_mode && !d_poles_pre && ezhip_polevals(d_poles, d_zin, gi->ni, gi->nj, pp.pole_weighted, gi->d_ax)) return -1;
     if (zones == 2 && !s->sep_capable) {
         /* The reference returns 2 only when the DEHORS zone is non-empty; on the per-point path that
          * needs a reduction over x,y which is done once and cached in have_dehors by ezhip_prepare. */
@@ -1433,9 +1513,23 @@ int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields)
     if (need_device("c_ezsint_batch")) return -1;
     size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
     int rc = 0;
+    /* the pole values (a sequential REAL sum per pole row, ~10 us of one lane) of ALL fields in one launch */
+    float *d_poles_all = NULL;
+    if (s->gdin != s->gdout && O.polar_correction == 1 && !s->extrap && nfields > 1) {
+        ezh_grid *gi = &G[s->gdin];
+        if (nfields > s->poles_cap) {
+            ezhip_sync(); ezhip_free(s->d_poles_batch);
+            s->d_poles_batch = (float *)ezhip_malloc(sizeof(float) * 2 * (size_t)nfields);
+            s->poles_cap = s->d_poles_batch ? nfields : 0;
+        }
+        int weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
+        if (weighted && ensure_grid_dev(gi)) return -1;
+        if (s->d_poles_batch && ezhip_polevals_batch(s->d_poles_batch, d_zin, nin, nfields, gi->ni, gi->nj, weighted, gi->d_ax) == 0)
+            d_poles_all = s->d_poles_batch;
+    }
     for (int f = 0; f < nfields; f++) {
         int r = (s->gdin == s->gdout) ? (ezhip_d2d(d_zout + f * nout, d_zin + f * nin, sizeof(float) * nin), 1)
-                                      : run_field(s, d_zout + f * nout, d_zin + f * nin, 0, NULL, NULL);
+                                      : run_field_p(s, d_zout + f * nout, d_zin + f * nin, 0, NULL, NULL, d_poles_all ? d_poles_all + 2 * f : NULL);
         if (r < 0) return r;
         if (r > rc) rc = r;
     }

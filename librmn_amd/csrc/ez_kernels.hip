@@ -99,21 +99,32 @@ __device__ double block_sum_256(double v, double *lds4)
  * ~4 cycles per dependent v_add_f32: ~8 us for ni = 4400, hidden because the special blocks that
  * need it are dispatched first and run beside the main blocks.  Result valid in every thread. */
 #define POLE_CHUNK 1024
-__device__ float block_poleval(const float *zrow, int ni, int weighted, const float *ax, float *lds /* >= POLE_CHUNK + 1 floats */)
+__device__ float block_poleval(const float *zrow, int ni, int weighted, const float *ax, float *lds /* 16-byte aligned, >= POLE_CHUNK + 4 floats */)
 {
     const int n = weighted ? ni - 1 : ni;
     float s = 0.0f;
     for (int base = 0; base < n; base += POLE_CHUNK) {
         const int m = min(POLE_CHUNK, n - base);
         __syncthreads();
-        for (int k = threadIdx.x; k < m; k += blockDim.x) {
+        for (int k = threadIdx.x; k < POLE_CHUNK; k += blockDim.x) {
             int i = base + k;
-            lds[k] = weighted ? zrow[i] * (ax[i + 1] - ax[i]) : zrow[i];
+            lds[k] = k >= m ? 0.0f : (weighted ? zrow[i] * (ax[i + 1] - ax[i]) : zrow[i]);
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-#pragma unroll 8
-            for (int k = 0; k < m; k++) s = s + lds[k];
+            /* the reference's sum is a sequential REAL accumulation: one lane, 64 elements (16 x ds_read_b128) in
+             * flight per dependent-add burst; the per-element LDS round trip of the scalar loop cost 20 us per row */
+            const float4 *l4 = (const float4 *)lds;
+            const int m4 = m >> 2;
+            int q = 0;
+            for (; q + 16 <= m4; q += 16) {
+                float4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) v[u] = l4[q + u];
+#pragma unroll
+                for (int u = 0; u < 16; u++) { s = s + v[u].x; s = s + v[u].y; s = s + v[u].z; s = s + v[u].w; }
+            }
+            for (int k = 4 * q; k < m; k++) s = s + lds[k];
         }
     }
     if (threadIdx.x == 0) {
@@ -381,6 +392,49 @@ __device__ void sep_rowblock_gather(const ezhip_sep_plan &p, RowInfo &ri, float 
     sep_rows<DEG>(p, ri, t, [&](int s) { return zin + (size_t)s * nis; }, r0, r1, zout, c, cvalid, cdehors, fillv);
 }
 
+/* special target rows of one column block: polar strips, pole rows, fully-outside rows (blockIdx.y indexes
+ * p.special).  `patch` is LDS scratch of at least POLE_CHUNK + 1 floats. */
+template <int DEG>
+__device__ void sep_special(const ezhip_sep_plan &p, float *__restrict__ zout, const float *__restrict__ zin, float *patch,
+                            int c, int cc, bool cvalid, float fillv)
+{
+    const int nis = p.ni_src;
+    /* ---- special rows: polar strips, pole rows, fully-outside rows ------------------------- */
+    const ezhip_special_row sr = p.special[blockIdx.y];
+    float outv;
+    if (sr.kind == 3) {
+        outv = fillv;
+    } else {
+        bool need_n = (sr.kind == 1), need_s = (sr.kind == 2);
+        if (sr.kind == 0)
+            for (int k = 0; k < 4; k++) { need_n |= (sr.tap[k] == EZ_ROW_POLE_N); need_s |= (sr.tap[k] == EZ_ROW_POLE_S); }
+        float pole_n = 0.f, pole_s = 0.f;
+        if (!p.vector_mode) {       /* pole values: precomputed once per field by k_polevals (a sequential REAL sum: ~10 us) */
+            if (need_n) pole_n = p.polevals[0];
+            if (need_s) pole_s = p.polevals[1];
+        }
+        if (sr.kind == 1) outv = pole_n;
+        else if (sr.kind == 2) outv = pole_s;
+        else {
+            const ColTaps t = load_col(p.cidx_s, p.cw_s, p.ni_dst, cc);
+            double tv[4];
+            const int ntap = (DEG == 3) ? 4 : (DEG == 1 ? 2 : 1);
+            for (int k = 0; k < ntap; k++) {
+                int row = sr.tap[k];
+                if (row >= 0) tv[k] = xpass<DEG>(zin + (size_t)row * nis, t);
+                else if (p.vector_mode) tv[k] = xpass<DEG>(row == EZ_ROW_POLE_N ? p.pole_row_n : p.pole_row_s, t);
+                else tv[k] = (double)(row == EZ_ROW_POLE_N ? pole_n : pole_s);   /* constant row interpolates to itself */
+            }
+            double val;
+            if (DEG == 0) val = tv[0];
+            else if (DEG == 1) val = tv[0] + (tv[1] - tv[0]) * sr.w[0];
+            else val = fma(sr.w[3], tv[3], fma(sr.w[2], tv[2], fma(sr.w[1], tv[1], sr.w[0] * tv[0])));
+            outv = (float)val;
+        }
+    }
+    if (cvalid) zout[(size_t)sr.row * p.ni_dst + c] = outv;
+}
+
 template <int DEG, bool PIPE>
 __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__restrict__ zout,
                                                    const float *__restrict__ zin)
@@ -493,41 +547,228 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
         return;
     }
 
-    /* ---- special rows: polar strips, pole rows, fully-outside rows ------------------------- */
-    float *patch = smem;
-    const ezhip_special_row sr = p.special[blockIdx.y];
-    float outv;
-    if (sr.kind == 3) {
-        outv = fillv;
-    } else {
-        bool need_n = (sr.kind == 1), need_s = (sr.kind == 2);
-        if (sr.kind == 0)
-            for (int k = 0; k < 4; k++) { need_n |= (sr.tap[k] == EZ_ROW_POLE_N); need_s |= (sr.tap[k] == EZ_ROW_POLE_S); }
-        float pole_n = 0.f, pole_s = 0.f;
-        if (!p.vector_mode) {
-            if (need_n) pole_n = block_poleval(zin + (size_t)(p.nj_src - 1) * nis, nis, p.pole_weighted, p.ax, patch);
-            if (need_s) pole_s = block_poleval(zin, nis, p.pole_weighted, p.ax, patch);
+    sep_special<DEG>(p, zout, zin, smem, c, cc, cvalid, fillv);
+}
+
+/* ===================================================================================== */
+/* k_sepx : separable interpolation, x-pass results in a per-thread LDS ring                 */
+/* ===================================================================================== */
+/* Why (measured on MI355X, profiles/r01_*): k_sep keeps a rolling 4-row window of x-pass results in registers;
+ * shifting it costs 8 v_cndmask per target row, the row weights 8 v_readlane, the newest source row is x-passed
+ * once per TARGET row, and every row-block re-stages its 3 halo rows: ~33 VALU instructions per point = 26 us of
+ * pure VALU time per cfg2 field next to 34 us of memory time.  Here
+ *   - a thread block owns a 256-column strip x x_rb consecutive row-blocks; each source row of the strip is
+ *     staged (LDS-DMA, one patch buffer) and x-interpolated exactly once per thread block;
+ *   - the fp64 x-pass result of source row s goes to T[s mod x_tr][thread] in LDS: a per-thread, dynamically
+ *     indexable extension of the register file (no barrier: a thread only reads what it wrote);
+ *   - the y-pass of a target row reads its 4 taps from T at a row-uniform slot and multiplies by weights held in
+ *     SGPRs (scalar loads from the constant address space): 4 fma + cvt + store per point, no select, no readlane;
+ *   - per row-block: wait DMA(i) -> barrier -> x-pass of the NEW rows -> barrier -> issue DMA(i+1) -> y-pass + 16
+ *     stores.  vmcnt is in-order: `vmcnt(16)` = "everything but my 16 youngest stores", so the DMA wait never waits
+ *     for a store acknowledgement.  Exactly 16 unconditional stores per wave and row-block: rows that are not main
+ *     rows (special rows, padding) re-store a neighbouring main row (x_rowinfo.flag = target row to write), columns
+ *     past the last one re-store the last column.
+ * The arithmetic is the one of k_sep (same fma chains), so results are bit-identical to it. */
+#define CONSTP(T, ptr) ((const __attribute__((address_space(4))) T *)(ptr))
+#define SEPX_G 2                                   /* source rows per x-pass group */
+#define SEPX_YG 2                                  /* target rows per y-pass load/compute group (4: SGPR spills) */
+
+template <int DEG, bool MIRROR>
+__global__ __launch_bounds__(SEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict__ zin)
+{
+    extern __shared__ double smem_x[];
+    const int c = blockIdx.x * SEP_BLOCK + threadIdx.x;
+    const int cc = min(c, p.ni_dst - 1);
+    const float fillv = p.fill ? *p.fill : 0.0f;
+    if ((int)blockIdx.y < p.n_special) { sep_special<DEG>(p, zout, zin, (float *)smem_x, c, cc, c < p.ni_dst, fillv); return; }
+    const int seg = blockIdx.y - p.n_special;
+    const int i0 = seg * p.x_rb, i1 = min(i0 + p.x_rb, p.x_nvb);
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nis = p.ni_src, nid = p.ni_dst, trows = p.x_tr, wstr = p.wstride;
+    const bool cdehors = p.cflag[cc] != 0;
+    const int base = p.blk_base[blockIdx.x], W = p.blk_w[blockIdx.x];
+    double *T = smem_x + threadIdx.x;                                           /* T[slot * 256] */
+    float *patch = (float *)(smem_x + (size_t)(trows + (MIRROR ? 3 : 0)) * SEP_BLOCK);
+    unsigned coloff[SEP_QCH];
+#pragma unroll
+    for (int q = 0; q < SEP_QCH; q++) {          /* source column of patch column lane + 64 q (seam unrolled; tail lanes clamp) */
+        int col = base + min(lane + 64 * q, W - 1);
+        if (col >= nis) col -= nis;
+        coloff[q] = (unsigned)col * 4u;
+    }
+    const float *pcol = patch + p.coff[cc];
+    const double cw[4] = {p.cw[cc], p.cw[nid + cc], p.cw[2 * nid + cc], p.cw[3 * nid + cc]};
+    const int dbg = p.debug_flags;          /* development knock-outs (EZHIP_DEBUG): 1 no stores, 4 no DMA, 8 no x-pass, 16 no y-pass */
+    auto dma_issue = [&](const ezhip_xstep &st) {
+        if (dbg & 4) return;
+        for (int row = wv; row < st.n; row += SEP_BLOCK / 64) {
+            const float *zr = zin + (size_t)(st.s0 + row) * nis;
+            float *prow = patch + row * wstr;
+#pragma unroll
+            for (int q = 0; q < SEP_QCH; q++)
+                if (64 * q < W) lds_dma_dword(zr, coloff[q], lds_addr_of(prow + 64 * q));
         }
-        if (sr.kind == 1) outv = pole_n;
-        else if (sr.kind == 2) outv = pole_s;
-        else {
-            const ColTaps t = load_col(p.cidx_s, p.cw_s, p.ni_dst, cc);
-            double tv[4];
-            const int ntap = (DEG == 3) ? 4 : (DEG == 1 ? 2 : 1);
-            for (int k = 0; k < ntap; k++) {
-                int row = sr.tap[k];
-                if (row >= 0) tv[k] = xpass<DEG>(zin + (size_t)row * nis, t);
-                else if (p.vector_mode) tv[k] = xpass<DEG>(row == EZ_ROW_POLE_N ? p.pole_row_n : p.pole_row_s, t);
-                else tv[k] = (double)(row == EZ_ROW_POLE_N ? pole_n : pole_s);   /* constant row interpolates to itself */
+    };
+    auto load_step = [](const ezhip_xstep *tab, int i) {       /* four scalar loads (constant address space) */
+        const auto *q = CONSTP(int, tab) + 4 * i;
+        ezhip_xstep s; s.s0 = q[0]; s.n = q[1]; s.slot0 = q[2]; s.by = q[3];
+        return s;
+    };
+    const bool any_dehors = __syncthreads_or(cdehors) != 0;       /* block-uniform: the fill-value select only where needed */
+    ezhip_xstep st = load_step(p.x_first, i0);
+    dma_issue(st);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int i = i0; i < i1; i++) {
+        __syncthreads();                                   /* every wave's share of DMA(i) has landed */
+        const auto *xr = CONSTP(ezhip_xrows, p.x_rows) + i;
+        int pk[EZHIP_SEP_ROWS];                            /* 16 scalars: target row << 5 | ring slot of the first tap */
+#pragma unroll
+        for (int k = 0; k < EZHIP_SEP_ROWS; k++) pk[k] = xr->pk[k];
+        /* ---- x-pass of the new source rows -> ring, SEPX_G rows per group, software-pipelined by hand: the 4 taps of
+         * a row are four ds_read_b32 issued through inline asm (left to the compiler they become two ds_read2_b32, which
+         * cost 8 LDS cycles per wave each on gfx950 against ~2 for ds_read_b32: tools/irate), the reads of group g+1 are
+         * issued before group g is computed, and the wait is lgkmcnt(4 G): LDS returns in order, so "all but the youngest
+         * 4 G" covers group g (outstanding scalar loads only make the wait stricter). */
+        if (!(dbg & 8) && st.n > 0) {
+            const unsigned pbase = lds_addr_of(pcol);
+            const int ng = (st.n + SEPX_G - 1) / SEPX_G;
+            float xa[SEPX_G][4], xb[SEPX_G][4];
+            auto xissue = [&](int g, float (&x)[SEPX_G][4]) {
+#pragma unroll
+                for (int q = 0; q < SEPX_G; q++) {
+                    const int srow = min(g * SEPX_G + q, st.n - 1);          /* scalar; a short last group recomputes its last row */
+                    const unsigned addr = pbase + (unsigned)(srow * wstr) * 4u;
+                    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:8\n\tds_read_b32 %3, %4 offset:12"
+                                 : "=&v"(x[q][0]), "=&v"(x[q][1]), "=&v"(x[q][2]), "=&v"(x[q][3]) : "v"(addr) : "memory");
+                }
+            };
+            auto xcomp = [&](int g, float (&x)[SEPX_G][4], bool last) {
+                static_assert(SEPX_G == 2, "the wait below names 2 x 4 registers");
+                if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[0][3]),
+                                                                  "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[1][2]), "+v"(x[1][3]) :: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[0][3]),
+                                                            "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[1][2]), "+v"(x[1][3]) :: "memory");
+#pragma unroll
+                for (int q = 0; q < SEPX_G; q++) {
+                    const int srow = min(g * SEPX_G + q, st.n - 1);
+                    int sl = st.slot0 + srow;
+                    if (sl >= trows) sl -= trows;
+                    double t;
+                    if (DEG == 1) { const double z1 = (double)x[q][0], z2 = (double)x[q][1]; t = z1 + (z2 - z1) * cw[0]; }
+                    else t = fma(cw[3], (double)x[q][3], fma(cw[2], (double)x[q][2], fma(cw[1], (double)x[q][1], cw[0] * (double)x[q][0])));
+                    T[sl * SEP_BLOCK] = t;
+                    if (MIRROR) T[(sl < 3 ? sl + trows : sl) * SEP_BLOCK] = t;
+                }
+            };
+            xissue(0, xa);
+#pragma unroll
+            for (int g = 0; g < (EZHIP_SEP_RMAX + SEPX_G - 1) / SEPX_G; g += 2) {
+                if (g < ng) {
+                    if (g + 1 < ng) xissue(g + 1, xb);
+                    xcomp(g, xa, g + 1 >= ng);
+                }
+                if (g + 1 < ng) {
+                    if (g + 2 < ng) xissue(g + 2, xa);
+                    xcomp(g + 1, xb, g + 2 >= ng);
+                }
             }
-            double val;
-            if (DEG == 0) val = tv[0];
-            else if (DEG == 1) val = tv[0] + (tv[1] - tv[0]) * sr.w[0];
-            else val = fma(sr.w[3], tv[3], fma(sr.w[2], tv[2], fma(sr.w[1], tv[1], sr.w[0] * tv[0])));
-            outv = (float)val;
+        }
+        __syncthreads();                                   /* the patch is free again */
+        ezhip_xstep nst = st;
+        if (i + 1 < i1) { nst = load_step(p.x_cont, i + 1); dma_issue(nst); }
+        /* ---- y-pass: 16 target rows from the ring, in groups of SEPX_YG rows.  The loads of group g+1 (ring
+         * taps: LDS; weights: scalar loads) are issued before group g is computed; sched_barrier keeps that order
+         * (left alone, the scheduler emits load -> wait -> compute row by row: one SMEM + one LDS round trip per row) */
+        struct YGroup { double t[SEPX_YG][4]; double w[SEPX_YG][4]; };
+        auto yload = [&](int g, YGroup &x) {
+#pragma unroll
+            for (int r = 0; r < SEPX_YG; r++) {
+                const int k = g * SEPX_YG + r, sl = pk[k] & 31;
+#pragma unroll
+                for (int j = 0; j < 4; j++) x.w[r][j] = xr->w[k][j];
+                if (MIRROR) {
+                    const double *tp = T + sl * SEP_BLOCK;
+                    x.t[r][0] = tp[0]; x.t[r][1] = tp[SEP_BLOCK];
+                    if (DEG == 3) { x.t[r][2] = tp[2 * SEP_BLOCK]; x.t[r][3] = tp[3 * SEP_BLOCK]; }
+                } else {
+                    int s1 = sl + 1; if (s1 >= trows) s1 -= trows;
+                    x.t[r][0] = T[sl * SEP_BLOCK]; x.t[r][1] = T[s1 * SEP_BLOCK];
+                    if (DEG == 3) {
+                        int s2 = s1 + 1; if (s2 >= trows) s2 -= trows;
+                        int s3 = s2 + 1; if (s3 >= trows) s3 -= trows;
+                        x.t[r][2] = T[s2 * SEP_BLOCK]; x.t[r][3] = T[s3 * SEP_BLOCK];
+                    }
+                }
+            }
+        };
+        auto ycomp = [&](int g, const YGroup &x, const bool any_dehors) {
+#pragma unroll
+            for (int r = 0; r < SEPX_YG; r++) {
+                const int orow = pk[g * SEPX_YG + r] >> 5;
+                double val;
+                if (DEG == 1) val = x.t[r][0] + (x.t[r][1] - x.t[r][0]) * x.w[r][0];
+                else val = fma(x.w[r][3], x.t[r][3], fma(x.w[r][2], x.t[r][2], fma(x.w[r][1], x.t[r][1], x.w[r][0] * x.t[r][0])));
+                if (!(dbg & 1)) zout[(size_t)orow * nid + cc] = (any_dehors && cdehors) ? fillv : (float)val;
+            }
+        };
+        YGroup ya, yb;
+        if (!(dbg & 16)) {
+        yload(0, ya);
+#pragma unroll
+        for (int g = 0; g < EZHIP_SEP_ROWS / SEPX_YG; g += 2) {
+            yload(g + 1, yb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (any_dehors) ycomp(g, ya, true); else ycomp(g, ya, false);
+            if (g + 2 < EZHIP_SEP_ROWS / SEPX_YG) yload(g + 2, ya);
+            __builtin_amdgcn_sched_barrier(0);
+            if (any_dehors) ycomp(g + 1, yb, true); else ycomp(g + 1, yb, false);
+        }
+        }
+        st = nst;
+        if (dbg & 17) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (i + 1 < i1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     /* DMA(i+1) landed; the 16 stores stay in flight */
+    }
+}
+
+extern "C" size_t ezhip_sepx_lds_bytes(int x_tr, int x_mirror, int x_prows, int wstride)
+{
+    size_t b = sizeof(double) * (size_t)(x_tr + (x_mirror ? 3 : 0)) * SEP_BLOCK + sizeof(float) * (size_t)x_prows * wstride;
+    const size_t pole = sizeof(float) * (POLE_CHUNK + 1);
+    return b < pole ? pole : b;
+}
+
+extern "C" int ezhip_sepx_capacity(int degree, int mirror, size_t lds_bytes)
+{
+    int dev = 0, ncu = 0, nb = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    hipError_t e;
+    if (degree == 1) e = mirror ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<1, true>, SEP_BLOCK, lds_bytes)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<1, false>, SEP_BLOCK, lds_bytes);
+    else e = mirror ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<3, true>, SEP_BLOCK, lds_bytes)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<3, false>, SEP_BLOCK, lds_bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return nb * ncu;
+}
+
+template <int DEG>
+static int launch_sepx(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin)
+{
+    dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, plan->x_nseg + plan->n_special), block(SEP_BLOCK);
+    size_t lds = ezhip_sepx_lds_bytes(plan->x_tr, plan->x_mirror, plan->x_prows, plan->wstride);
+    if (lds > 64 * 1024) {
+        static thread_local bool raised[2][2];
+        bool &r = raised[DEG == 3][plan->x_mirror != 0];
+        if (!r) {
+            hipError_t e = plan->x_mirror ? hipFuncSetAttribute((const void *)k_sepx<DEG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                                          : hipFuncSetAttribute((const void *)k_sepx<DEG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return set_err(e, "k_sepx LDS size");
+            r = true;
         }
     }
-    if (cvalid) zout[(size_t)sr.row * p.ni_dst + c] = outv;
+    if (plan->x_mirror) hipLaunchKernelGGL((k_sepx<DEG, true>), grid, block, lds, g_stream, *plan, d_zout, d_zin);
+    else hipLaunchKernelGGL((k_sepx<DEG, false>), grid, block, lds, g_stream, *plan, d_zout, d_zin);
+    return LAUNCH_CHECK("k_sepx");
 }
 
 /* ===================================================================================== */
@@ -778,6 +1019,10 @@ extern "C" int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const
         case 1: return launch_stream<1>(plan, d_zout, d_zin);
         case 3: return launch_stream<3>(plan, d_zout, d_zin);
         }
+    }
+    if (plan->x_nseg > 0) {
+        if (plan->degree == 1) return launch_sepx<1>(plan, d_zout, d_zin);
+        if (plan->degree == 3) return launch_sepx<3>(plan, d_zout, d_zin);
     }
     int nmain = (plan->nblk_y + plan->rb_per_block - 1) / plan->rb_per_block;
     dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, nmain + plan->n_special);
@@ -1136,17 +1381,23 @@ extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const
 /* ===================================================================================== */
 /* small reductions                                                                         */
 /* ===================================================================================== */
-__global__ __launch_bounds__(256) void k_polevals(float *out2, const float *zin, int ni, int nj, int weighted, const float *ax)
+__global__ __launch_bounds__(256) void k_polevals(float *out2, const float *zin, size_t field_stride, int ni, int nj, int weighted, const float *ax)
 {
-    __shared__ float lds4[POLE_CHUNK + 1];
+    __shared__ __attribute__((aligned(16))) float lds4[POLE_CHUNK + 4];
+    zin += blockIdx.y * field_stride;
     const float *row = blockIdx.x == 0 ? zin + (size_t)(nj - 1) * ni : zin;
     float v = block_poleval(row, ni, weighted, ax, lds4);
-    if (threadIdx.x == 0) out2[blockIdx.x] = v;
+    if (threadIdx.x == 0) out2[2 * blockIdx.y + blockIdx.x] = v;
+}
+/* d_out[2 f] = north, d_out[2 f + 1] = south pole value of field f (fields field_stride floats apart) */
+extern "C" int ezhip_polevals_batch(float *d_out, const float *d_zin, size_t field_stride, int nfields, int ni, int nj, int weighted, const float *d_ax)
+{
+    hipLaunchKernelGGL(k_polevals, dim3(2, nfields), dim3(256), 0, g_stream, d_out, d_zin, field_stride, ni, nj, weighted, d_ax);
+    return LAUNCH_CHECK("k_polevals");
 }
 extern "C" int ezhip_polevals(float *d_out2, const float *d_zin, int ni, int nj, int weighted, const float *d_ax)
 {
-    hipLaunchKernelGGL(k_polevals, dim3(2), dim3(256), 0, g_stream, d_out2, d_zin, ni, nj, weighted, d_ax);
-    return LAUNCH_CHECK("k_polevals");
+    return ezhip_polevals_batch(d_out2, d_zin, 0, 1, ni, nj, weighted, d_ax);
 }
 
 /* float min/max through order-preserving unsigned keys (no NaN handling: the reference has none) */

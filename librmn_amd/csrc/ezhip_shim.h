@@ -67,6 +67,12 @@ typedef struct {
     double w[4];            /* cubic: y weights; linear: w[0] = dy */
 } ezhip_rowinfo;
 
+/* one staging step of k_sepx: source rows [s0, s0 + n) are new to the ring, the first lands in slot0 */
+typedef struct { int s0, n, slot0, by; } ezhip_xstep;
+/* the 16 target rows of a row-block, laid out for scalar loads: pk = (target row to store << 5) | ring slot of the
+ * first tap (ring <= 32 rows); a row that is not a main row repeats a neighbouring main row */
+typedef struct { int pk[EZHIP_SEP_ROWS]; double w[EZHIP_SEP_ROWS][4]; } ezhip_xrows;
+
 typedef struct {
     int degree;                       /* 0 nearest, 1 linear, 3 cubic */
     int ni_src, nj_src, ni_dst, nj_dst;
@@ -94,6 +100,8 @@ typedef struct {
     int vector_mode;                  /* 1: strip pole rows come from pole_rows_n/s instead of a scalar */
     const float *pole_row_n, *pole_row_s;   /* [ni_src] synthetic polar wind rows (vector mode) */
     const float *fill;                /* device scalar written to DEHORS points (may be NULL) */
+    const float *polevals;            /* device float[2] = {north, south} pole values of THIS field (ezhip_polevals); scalar mode */
+    int need_poles;                   /* some special row uses a scalar pole value */
     /* ---- row-streaming variant (k_sep_stream): one thread block = one 256-column strip x one segment of
      * target rows; a loader wave streams the strip's source rows ONCE through an LDS ring (LDS-DMA) while
      * four compute waves consume them.  nseg == 0: variant not usable for this plan. */
@@ -104,9 +112,20 @@ typedef struct {
     const ezhip_rowinfo *rowinfo_seg; /* [nj_dst] like rowinfo, jb relative to the SEGMENT's first streamed row */
     int seg_rows_max;                 /* max target rows of a segment (LDS sizing) */
     int debug_flags;                  /* development only (EZHIP_DEBUG): bit 0 = suppress the main stores, bit 1 = no loader waits */
+    /* ---- k_sepx (linear / cubic default when x_nseg > 0): one thread block = one 256-column strip x x_rb
+     * consecutive row-blocks.  Every source row of the strip is staged (LDS-DMA) and x-interpolated ONCE per
+     * thread block; the x-pass results live in a per-thread LDS ring of x_tr source rows (fp64), the y-pass
+     * reads its four taps from the ring at a row-uniform slot. */
+    int x_nseg, x_rb, x_nvb;          /* segments per strip, row-blocks per segment, valid row-blocks */
+    int x_tr, x_prows, x_mirror;      /* ring rows, patch rows, 1: ring has 3 mirror rows (taps never wrap) */
+    const ezhip_xstep *x_first, *x_cont;   /* [x_nvb] staging step of a row-block when it starts a segment / continues one */
+    const ezhip_xrows *x_rows;        /* [x_nvb] per row-block: ring slot / target row / y weights of its 16 rows */
 } ezhip_sep_plan;
 
 int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin);
+/* co-resident k_sepx thread blocks on the current device for a given dynamic LDS size (0: unknown) */
+int ezhip_sepx_capacity(int degree, int mirror, size_t lds_bytes);
+size_t ezhip_sepx_lds_bytes(int x_tr, int x_mirror, int x_prows, int wstride);
 #define EZHIP_ST_NSLOT 32            /* LDS ring slots (source rows) of k_sep_stream */
 #define EZHIP_ST_BLOCKS_PER_CU 4
 
@@ -136,6 +155,7 @@ int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const float *d_z
 
 /* pole values {north, south} of a source field -> device float[2] */
 int ezhip_polevals(float *d_out2, const float *d_zin, int ni, int nj, int weighted, const float *d_ax);
+int ezhip_polevals_batch(float *d_out, const float *d_zin, size_t field_stride, int nfields, int ni, int nj, int weighted, const float *d_ax);
 /* min / max of a field -> device float[2]; then fill = f(min,max) on device */
 int ezhip_fill_value(float *d_fill, const float *d_zin, size_t n, int degre_extrap, float valeur, int vector_mode);
 

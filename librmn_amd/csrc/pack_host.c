@@ -22,11 +22,11 @@ static int need_device(const char *who)
 static unsigned key_of(float f) { unsigned u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 static float float_of(unsigned k) { unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &u, 4); return f; }
 
-/* small per-thread device scratch: stats (4 u32) + cf params */
+/* small per-thread device scratch: stats (4 u32) + cf params at +64 B + the reduction partials */
 static __thread void *t_scratch = NULL;
 static void *scratch(void)
 {
-    if (!t_scratch) t_scratch = ezhip_malloc(256);
+    if (!t_scratch) t_scratch = ezhip_malloc(4 * PACKHIP_STATS_WORDS);
     return t_scratch;
 }
 

@@ -12,6 +12,10 @@ typedef struct {
     int too_large, pad;
 } packhip_cf_params;
 
+/* device scratch layout of the reductions: result words, then one {min,max,or} triple per block */
+#define PACKHIP_STATS_PARTIALS 256
+#define PACKHIP_STATS_MAXBLK 2048
+#define PACKHIP_STATS_WORDS (PACKHIP_STATS_PARTIALS + 3 * PACKHIP_STATS_MAXBLK)
 /* stats[0..2] = min key, max key, OR; kind 0 float keys, 1 uint32, 2 int32 (biased by 0x80000000) */
 int packhip_stats(unsigned *d_stats, const void *d_a, size_t n, int stride, int kind, int has_missing, float tag);
 int packhip_cf_header(packhip_cf_params *d_pp, unsigned *d_hdr, const unsigned *d_stats, unsigned n, int bs, int style, int has_missing);

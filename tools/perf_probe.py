@@ -28,7 +28,7 @@ def timeit(fn, reps=5):
 
 DEGS = sys.argv[1].split(",") if len(sys.argv) > 1 else ("cubic", "linear", "nearest")
 for deg in DEGS:
-    for polar in (("yes",) if len(sys.argv) > 1 else ("yes", "no")):
+    for polar in (tuple(os.environ.get("PROBE_POLAR", "yes").split(",")) if len(sys.argv) > 1 else ("yes", "no")):
         ez.ezsetopt("interp_degree", deg); ez.ezsetopt("polar_correction", polar)
         ez.prepare_set()
         us = timeit(lambda: ez.ezsint_batch_dev(d_out, d_in, F))
