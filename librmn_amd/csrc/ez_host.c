@@ -1130,7 +1130,7 @@ static void build_stream_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, const ezh_
 
 /* k_sepx geometry: valid row-blocks, their staging steps (first-of-segment / continuing), ring slots.
  * Leaves p->x_nseg == 0 when the plan does not qualify (then k_sep runs). */
-static void build_sepx_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, int degree, int nbx, int nby, int njr,
+static void build_sepx_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, int degree, int nbx, int nby, int nic, int njr,
                                 const int *blk_base, const int *brow_s0, const int *brow_n,
                                 const int *rbase, const double *rw, const unsigned char *rflag)
 {
@@ -1147,7 +1147,7 @@ static void build_sepx_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, int degree, 
         if (brow_n[by] > tr) tr = brow_n[by];
         vb[nvb++] = by;
     }
-    if (!ok || nvb == 0 || tr > 32 || njr >= (1 << 26)) { free(vb); return; }
+    if (!ok || nvb == 0 || (size_t)njr * (size_t)nic >= ((size_t)1 << 31)) { free(vb); return; }
     int mirror = getenv("EZHIP_SEPX_MIRROR") ? atoi(getenv("EZHIP_SEPX_MIRROR")) : 0;
     ezhip_xstep *first = (ezhip_xstep *)calloc(nvb, sizeof(ezhip_xstep)), *cont = (ezhip_xstep *)calloc(nvb, sizeof(ezhip_xstep));
     ezhip_xrows *xr = (ezhip_xrows *)calloc((size_t)nvb, sizeof(ezhip_xrows));
@@ -1169,8 +1169,12 @@ static void build_sepx_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, int degree, 
         for (int k = 0; k < EZHIP_SEP_ROWS; k++) {
             int r = r0 + k;
             if (r < njr && !rflag[r]) lastmain = r;
-            xr[i].pk[k] = (lastmain << 5) | (rbase[lastmain] % tr);
-            for (int w = 0; w < 4; w++) xr[i].w[k][w] = rw[w * njr + lastmain];
+            ezhip_xrow *q = &xr[i].r[k];
+            for (int w = 0; w < 4; w++) {
+                q->w[w] = rw[w * njr + lastmain];
+                q->t_off[w] = ((rbase[lastmain] + w) % tr) * (int)(EZHIP_SEP_COLS * sizeof(double));
+            }
+            q->o_off = (unsigned)((size_t)lastmain * (size_t)nic);
         }
     }
     size_t lds = ezhip_sepx_lds_bytes(tr, mirror, prows, p->wstride);
@@ -1334,7 +1338,7 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
         if (special[k].kind == 1 || special[k].kind == 2) p->need_poles = 1;
         if (special[k].kind == 0) for (int q = 0; q < 4; q++) if (special[k].tap[q] < 0) p->need_poles = 1;
     }
-    build_sepx_geometry(sp, p, degree, nbx, nby, njr, blk_base, brow_s0, brow_n, rbase, rw, rflag);
+    build_sepx_geometry(sp, p, degree, nbx, nby, nic, njr, blk_base, brow_s0, brow_n, rbase, rw, rflag);
     build_stream_geometry(sp, p, gi, nic, njr, nbx, ntap, blk_base, blk_w, rbase, rw, rflag, special, nspecial, vector_mode);
     p->pole_weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
     p->vector_mode = vector_mode;

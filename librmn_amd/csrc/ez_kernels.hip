@@ -551,30 +551,93 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
 }
 
 /* ===================================================================================== */
-/* k_sepx : separable interpolation, x-pass results in a per-thread LDS ring                 */
+/* k_sepx : separable interpolation, x-pass results in an LDS ring, y-pass with per-lane rows */
 /* ===================================================================================== */
 /* Why (measured on MI355X, profiles/r01_*): k_sep keeps a rolling 4-row window of x-pass results in registers;
- * shifting it costs 8 v_cndmask per target row, the row weights 8 v_readlane, the newest source row is x-passed
- * once per TARGET row, and every row-block re-stages its 3 halo rows: ~33 VALU instructions per point = 26 us of
- * pure VALU time per cfg2 field next to 34 us of memory time.  Here
- *   - a thread block owns a 256-column strip x x_rb consecutive row-blocks; each source row of the strip is
- *     staged (LDS-DMA, one patch buffer) and x-interpolated exactly once per thread block;
- *   - the fp64 x-pass result of source row s goes to T[s mod x_tr][thread] in LDS: a per-thread, dynamically
- *     indexable extension of the register file (no barrier: a thread only reads what it wrote);
- *   - the y-pass of a target row reads its 4 taps from T at a row-uniform slot and multiplies by weights held in
- *     SGPRs (scalar loads from the constant address space): 4 fma + cvt + store per point, no select, no readlane;
+ * shifting it costs 8 v_cndmask per target row, the row-uniform y weights 8 v_readlane (or one scalar load and one
+ * lgkmcnt(0) per row), the newest source row is x-passed once per TARGET row and every row-block re-stages its halo
+ * rows: ~33 VALU + ~25 SALU instructions per point, 4 waves per SIMD -> issue-bound, 26 us of VALU next to 34 us of
+ * memory time per cfg2 field.  Here
+ *   - a thread block owns a 256-column strip x x_rb consecutive row-blocks; each source row of the strip is staged
+ *     (LDS-DMA, one patch buffer) and x-interpolated exactly once per thread block;
+ *   - x-pass: thread = target column (x weights are per-thread constants); the fp64 result of source row s goes to
+ *     the ring T[s mod x_tr][column] in LDS;
+ *   - y-pass: lane = (target row, column): a wave covers 2 target rows x 32 columns per instruction, so the y weights,
+ *     the four ring-tap addresses and the store offset of a row are PER-LANE registers, loaded once per row-block
+ *     from a 64-byte row record that rides the DMA; the 8 column groups of a row pair are immediate offsets.  Per 64
+ *     points: 4 ds_read_b64 + 4 fp64 ops + cvt + store, no scalar work at all;
  *   - per row-block: wait DMA(i) -> barrier -> x-pass of the NEW rows -> barrier -> issue DMA(i+1) -> y-pass + 16
- *     stores.  vmcnt is in-order: `vmcnt(16)` = "everything but my 16 youngest stores", so the DMA wait never waits
- *     for a store acknowledgement.  Exactly 16 unconditional stores per wave and row-block: rows that are not main
- *     rows (special rows, padding) re-store a neighbouring main row (x_rowinfo.flag = target row to write), columns
- *     past the last one re-store the last column.
+ *     stores per wave.  vmcnt is in-order: `vmcnt(16)` = "everything but my 16 youngest stores", so the DMA wait never
+ *     waits for a store acknowledgement.  Rows that are not main rows (special rows, padding) re-store a neighbouring
+ *     main row (the record names the row to write).
  * The arithmetic is the one of k_sep (same fma chains), so results are bit-identical to it. */
 #define CONSTP(T, ptr) ((const __attribute__((address_space(4))) T *)(ptr))
-#define SEPX_G 2                                   /* source rows per x-pass group */
-#define SEPX_YG 2                                  /* target rows per y-pass load/compute group (4: SGPR spills) */
+#define SEPX_REC_DW (EZHIP_SEP_ROWS * 16)          /* dwords of one row-block's records */
 
-template <int DEG, bool MIRROR>
-__global__ __launch_bounds__(SEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict__ zin)
+/* y-pass of one wave and one row-block: 2 row pairs x 8 column groups of 32.  `myrec` = this lane's row record of
+ * the first pair (the second pair is 8 records further), `tcol` = ring base of the lane's column in group 0.
+ * SLOW adds what few blocks need: the DEHORS fill select, the column bound of the last strip, the debug knock-out. */
+template <int DEG, bool SLOW>
+__device__ __forceinline__ void sepx_ypass(const float *myrec, const double *tcol, float *zcol, float fillv, unsigned dmask,
+                                           int l32, int ncol_valid, bool nostore)
+{
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const float4 *r4 = (const float4 *)(myrec + h * 8 * 16);
+        const float4 ra = r4[0], rb = r4[1], rc = r4[2];      /* w[0..3] | tap byte offsets */
+        const unsigned o_off = (unsigned)__float_as_int(myrec[h * 8 * 16 + 12]);
+        const double w0 = __hiloint2double(__float_as_int(ra.y), __float_as_int(ra.x));
+        const double w1 = __hiloint2double(__float_as_int(ra.w), __float_as_int(ra.z));
+        const double w2 = __hiloint2double(__float_as_int(rb.y), __float_as_int(rb.x));
+        const double w3 = __hiloint2double(__float_as_int(rb.w), __float_as_int(rb.z));
+        const char *tb = (const char *)tcol;
+        const double *tp0 = (const double *)(tb + __float_as_int(rc.x)), *tp1 = (const double *)(tb + __float_as_int(rc.y));
+        const double *tp2 = (const double *)(tb + __float_as_int(rc.z)), *tp3 = (const double *)(tb + __float_as_int(rc.w));
+        float *orow = zcol + o_off;                /* element offset of the target row */
+        double t[8][4];
+        if (SLOW) {
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                t[g][0] = tp0[32 * g]; t[g][1] = tp1[32 * g];
+                if (DEG == 3) { t[g][2] = tp2[32 * g]; t[g][3] = tp3[32 * g]; }
+            }
+        } else {
+            /* the ring taps as 32 (16) single ds_read_b64 through inline asm: the compiler pairs them into ds_read2_b64,
+             * which costs 8.1 LDS cycles per wave on gfx950 against 2 x 2.2 for two ds_read_b64 (tools/irate).  One wait
+             * for the row pair; LDS reads of the other waves cover it. */
+            const unsigned a0 = lds_addr_of(tp0), a1 = lds_addr_of(tp1), a2 = lds_addr_of(tp2), a3 = lds_addr_of(tp3);
+#define RD8(A, J) asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:256\n\tds_read_b64 %2, %8 offset:512\n\tds_read_b64 %3, %8 offset:768\n\t" \
+                               "ds_read_b64 %4, %8 offset:1024\n\tds_read_b64 %5, %8 offset:1280\n\tds_read_b64 %6, %8 offset:1536\n\tds_read_b64 %7, %8 offset:1792" \
+                               : "=&v"(t[0][J]), "=&v"(t[1][J]), "=&v"(t[2][J]), "=&v"(t[3][J]), "=&v"(t[4][J]), "=&v"(t[5][J]), "=&v"(t[6][J]), "=&v"(t[7][J]) \
+                               : "v"(A) : "memory")
+            RD8(a0, 0); RD8(a1, 1);
+            if (DEG == 3) { RD8(a2, 2); RD8(a3, 3); }
+#undef RD8
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            /* tie the values to the wait so that no consumer is scheduled above it */
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                if (DEG == 3) asm volatile("" : "+v"(t[g][0]), "+v"(t[g][1]), "+v"(t[g][2]), "+v"(t[g][3]));
+                else asm volatile("" : "+v"(t[g][0]), "+v"(t[g][1]));
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            double val;
+            if (DEG == 1) val = t[g][0] + (t[g][1] - t[g][0]) * w0;
+            else val = fma(w3, t[g][3], fma(w2, t[g][2], fma(w1, t[g][1], w0 * t[g][0])));
+            float out = (float)val;
+            if (SLOW) {
+                out = (dmask >> g) & 1 ? fillv : out;
+                if (!nostore && l32 + 32 * g < ncol_valid) orow[32 * g] = out;
+            } else orow[32 * g] = out;
+        }
+    }
+}
+
+template <int DEG>
+__global__ __launch_bounds__(SEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict__ zin)
 {
     extern __shared__ double smem_x[];
     const int c = blockIdx.x * SEP_BLOCK + threadIdx.x;
@@ -585,10 +648,11 @@ __global__ __launch_bounds__(SEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 4)
     const int i0 = seg * p.x_rb, i1 = min(i0 + p.x_rb, p.x_nvb);
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nis = p.ni_src, nid = p.ni_dst, trows = p.x_tr, wstr = p.wstride;
-    const bool cdehors = p.cflag[cc] != 0;
     const int base = p.blk_base[blockIdx.x], W = p.blk_w[blockIdx.x];
-    double *T = smem_x + threadIdx.x;                                           /* T[slot * 256] */
-    float *patch = (float *)(smem_x + (size_t)(trows + (MIRROR ? 3 : 0)) * SEP_BLOCK);
+    double *T = smem_x;                                                         /* T[slot][256 columns] */
+    float *rec = (float *)(smem_x + (size_t)trows * SEP_BLOCK);                /* 2 x 16 row records of 64 B */
+    float *patch = rec + 2 * SEPX_REC_DW;
+    const int dbg = p.debug_flags;          /* development knock-outs (EZHIP_DEBUG): 1 no stores, 4 no DMA, 8 no x-pass, 16 no y-pass */
     unsigned coloff[SEP_QCH];
 #pragma unroll
     for (int q = 0; q < SEP_QCH; q++) {          /* source column of patch column lane + 64 q (seam unrolled; tail lanes clamp) */
@@ -596,10 +660,31 @@ __global__ __launch_bounds__(SEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 4)
         if (col >= nis) col -= nis;
         coloff[q] = (unsigned)col * 4u;
     }
-    const float *pcol = patch + p.coff[cc];
+    const unsigned pbase = lds_addr_of(patch + p.coff[cc]);
     const double cw[4] = {p.cw[cc], p.cw[nid + cc], p.cw[2 * nid + cc], p.cw[3 * nid + cc]};
-    const int dbg = p.debug_flags;          /* development knock-outs (EZHIP_DEBUG): 1 no stores, 4 no DMA, 8 no x-pass, 16 no y-pass */
-    auto dma_issue = [&](const ezhip_xstep &st) {
+    /* y-pass lane geometry: row r of the pair, column l32 + 32 g of the strip */
+    const int l32 = lane & 31, rsub = lane >> 5;
+    const int ncol_valid = min(SEP_BLOCK, nid - (int)blockIdx.x * SEP_BLOCK);   /* < 256 only in the last column block */
+    const bool full = ncol_valid == SEP_BLOCK;
+    /* DEHORS columns (extrapolation targets): bit g of dmask = column l32 + 32 g takes the fill value */
+    unsigned dmask = 0;
+    {
+        __shared__ unsigned char cf[SEP_BLOCK];
+        cf[threadIdx.x] = p.cflag[cc];
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 8; g++) dmask |= (cf[l32 + 32 * g] != 0 ? 1u : 0u) << g;
+    }
+    const bool any_dehors = __syncthreads_or(dmask != 0) != 0;
+    const bool slow = any_dehors || !full || (dbg & 1);      /* block-uniform: predicated y-pass */
+    float *zcol = zout + (size_t)blockIdx.x * SEP_BLOCK + l32;                 /* + row offset (record) + 32 g */
+
+    auto load_step = [](const ezhip_xstep *tab, int i) {       /* four scalar loads (constant address space) */
+        const auto *q = CONSTP(int, tab) + 4 * i;
+        ezhip_xstep s; s.s0 = q[0]; s.n = q[1]; s.slot0 = q[2]; s.by = q[3];
+        return s;
+    };
+    auto dma_issue = [&](const ezhip_xstep &st, int i) {
         if (dbg & 4) return;
         for (int row = wv; row < st.n; row += SEP_BLOCK / 64) {
             const float *zr = zin + (size_t)(st.s0 + row) * nis;
@@ -608,131 +693,61 @@ __global__ __launch_bounds__(SEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 4)
             for (int q = 0; q < SEP_QCH; q++)
                 if (64 * q < W) lds_dma_dword(zr, coloff[q], lds_addr_of(prow + 64 * q));
         }
+        /* the 16 row records of row-block i: 256 dwords, one 64-dword chunk per wave */
+        lds_dma_dword((const float *)(p.x_rows + i), (unsigned)(threadIdx.x * 4), lds_addr_of(rec + (i & 1) * SEPX_REC_DW + wv * 64));
     };
-    auto load_step = [](const ezhip_xstep *tab, int i) {       /* four scalar loads (constant address space) */
-        const auto *q = CONSTP(int, tab) + 4 * i;
-        ezhip_xstep s; s.s0 = q[0]; s.n = q[1]; s.slot0 = q[2]; s.by = q[3];
-        return s;
-    };
-    const bool any_dehors = __syncthreads_or(cdehors) != 0;       /* block-uniform: the fill-value select only where needed */
     ezhip_xstep st = load_step(p.x_first, i0);
-    dma_issue(st);
+    dma_issue(st, i0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int i = i0; i < i1; i++) {
-        __syncthreads();                                   /* every wave's share of DMA(i) has landed */
-        const auto *xr = CONSTP(ezhip_xrows, p.x_rows) + i;
-        int pk[EZHIP_SEP_ROWS];                            /* 16 scalars: target row << 5 | ring slot of the first tap */
-#pragma unroll
-        for (int k = 0; k < EZHIP_SEP_ROWS; k++) pk[k] = xr->pk[k];
-        /* ---- x-pass of the new source rows -> ring, SEPX_G rows per group, software-pipelined by hand: the 4 taps of
-         * a row are four ds_read_b32 issued through inline asm (left to the compiler they become two ds_read2_b32, which
-         * cost 8 LDS cycles per wave each on gfx950 against ~2 for ds_read_b32: tools/irate), the reads of group g+1 are
-         * issued before group g is computed, and the wait is lgkmcnt(4 G): LDS returns in order, so "all but the youngest
-         * 4 G" covers group g (outstanding scalar loads only make the wait stricter). */
-        if (!(dbg & 8) && st.n > 0) {
-            const unsigned pbase = lds_addr_of(pcol);
-            const int ng = (st.n + SEPX_G - 1) / SEPX_G;
-            float xa[SEPX_G][4], xb[SEPX_G][4];
-            auto xissue = [&](int g, float (&x)[SEPX_G][4]) {
-#pragma unroll
-                for (int q = 0; q < SEPX_G; q++) {
-                    const int srow = min(g * SEPX_G + q, st.n - 1);          /* scalar; a short last group recomputes its last row */
-                    const unsigned addr = pbase + (unsigned)(srow * wstr) * 4u;
-                    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:8\n\tds_read_b32 %3, %4 offset:12"
-                                 : "=&v"(x[q][0]), "=&v"(x[q][1]), "=&v"(x[q][2]), "=&v"(x[q][3]) : "v"(addr) : "memory");
-                }
-            };
-            auto xcomp = [&](int g, float (&x)[SEPX_G][4], bool last) {
-                static_assert(SEPX_G == 2, "the wait below names 2 x 4 registers");
-                if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[0][3]),
-                                                                  "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[1][2]), "+v"(x[1][3]) :: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[0][3]),
-                                                            "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[1][2]), "+v"(x[1][3]) :: "memory");
-#pragma unroll
-                for (int q = 0; q < SEPX_G; q++) {
-                    const int srow = min(g * SEPX_G + q, st.n - 1);
-                    int sl = st.slot0 + srow;
-                    if (sl >= trows) sl -= trows;
-                    double t;
-                    if (DEG == 1) { const double z1 = (double)x[q][0], z2 = (double)x[q][1]; t = z1 + (z2 - z1) * cw[0]; }
-                    else t = fma(cw[3], (double)x[q][3], fma(cw[2], (double)x[q][2], fma(cw[1], (double)x[q][1], cw[0] * (double)x[q][0])));
-                    T[sl * SEP_BLOCK] = t;
-                    if (MIRROR) T[(sl < 3 ? sl + trows : sl) * SEP_BLOCK] = t;
-                }
-            };
-            xissue(0, xa);
-#pragma unroll
-            for (int g = 0; g < (EZHIP_SEP_RMAX + SEPX_G - 1) / SEPX_G; g += 2) {
-                if (g < ng) {
-                    if (g + 1 < ng) xissue(g + 1, xb);
-                    xcomp(g, xa, g + 1 >= ng);
-                }
-                if (g + 1 < ng) {
-                    if (g + 2 < ng) xissue(g + 2, xa);
-                    xcomp(g + 1, xb, g + 2 >= ng);
-                }
-            }
-        }
-        __syncthreads();                                   /* the patch is free again */
-        ezhip_xstep nst = st;
-        if (i + 1 < i1) { nst = load_step(p.x_cont, i + 1); dma_issue(nst); }
-        /* ---- y-pass: 16 target rows from the ring, in groups of SEPX_YG rows.  The loads of group g+1 (ring
-         * taps: LDS; weights: scalar loads) are issued before group g is computed; sched_barrier keeps that order
-         * (left alone, the scheduler emits load -> wait -> compute row by row: one SMEM + one LDS round trip per row) */
-        struct YGroup { double t[SEPX_YG][4]; double w[SEPX_YG][4]; };
-        auto yload = [&](int g, YGroup &x) {
-#pragma unroll
-            for (int r = 0; r < SEPX_YG; r++) {
-                const int k = g * SEPX_YG + r, sl = pk[k] & 31;
-#pragma unroll
-                for (int j = 0; j < 4; j++) x.w[r][j] = xr->w[k][j];
-                if (MIRROR) {
-                    const double *tp = T + sl * SEP_BLOCK;
-                    x.t[r][0] = tp[0]; x.t[r][1] = tp[SEP_BLOCK];
-                    if (DEG == 3) { x.t[r][2] = tp[2 * SEP_BLOCK]; x.t[r][3] = tp[3 * SEP_BLOCK]; }
+        __syncthreads();                                   /* DMA(i) landed in every wave; everyone left y-pass(i-1) */
+        /* ---- x-pass of the new source rows -> ring.  Two rows per iteration; the 4 taps of a row are four
+         * ds_read_b32 through inline asm (the compiler pairs them into ds_read2_b32: 8 LDS cycles per wave each on
+         * gfx950 against ~2 for ds_read_b32, tools/irate) */
+        if (!(dbg & 8)) {
+            int slot = st.slot0;
+            for (int s = 0; s < st.n; s += 2) {
+                const unsigned a0 = pbase + (unsigned)(s * wstr) * 4u;
+                const unsigned a1 = a0 + (s + 1 < st.n ? (unsigned)wstr * 4u : 0u);      /* odd count: the last row twice */
+                float x0, x1, x2, x3, y0, y1, y2, y3;
+                asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:4\n\tds_read_b32 %2, %8 offset:8\n\tds_read_b32 %3, %8 offset:12\n\t"
+                             "ds_read_b32 %4, %9\n\tds_read_b32 %5, %9 offset:4\n\tds_read_b32 %6, %9 offset:8\n\tds_read_b32 %7, %9 offset:12\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
+                             : "v"(a0), "v"(a1) : "memory");
+                double t0, t1;
+                if (DEG == 1) {
+                    const double p1 = (double)x0, p2 = (double)x1, q1 = (double)y0, q2 = (double)y1;
+                    t0 = p1 + (p2 - p1) * cw[0]; t1 = q1 + (q2 - q1) * cw[0];
                 } else {
-                    int s1 = sl + 1; if (s1 >= trows) s1 -= trows;
-                    x.t[r][0] = T[sl * SEP_BLOCK]; x.t[r][1] = T[s1 * SEP_BLOCK];
-                    if (DEG == 3) {
-                        int s2 = s1 + 1; if (s2 >= trows) s2 -= trows;
-                        int s3 = s2 + 1; if (s3 >= trows) s3 -= trows;
-                        x.t[r][2] = T[s2 * SEP_BLOCK]; x.t[r][3] = T[s3 * SEP_BLOCK];
-                    }
+                    t0 = fma(cw[3], (double)x3, fma(cw[2], (double)x2, fma(cw[1], (double)x1, cw[0] * (double)x0)));
+                    t1 = fma(cw[3], (double)y3, fma(cw[2], (double)y2, fma(cw[1], (double)y1, cw[0] * (double)y0)));
                 }
+                int slot1 = slot + 1; if (slot1 >= trows) slot1 -= trows;
+                T[slot * SEP_BLOCK + threadIdx.x] = t0;
+                if (s + 1 < st.n) T[slot1 * SEP_BLOCK + threadIdx.x] = t1;
+                slot = slot1 + 1; if (slot >= trows) slot -= trows;
             }
-        };
-        auto ycomp = [&](int g, const YGroup &x, const bool any_dehors) {
-#pragma unroll
-            for (int r = 0; r < SEPX_YG; r++) {
-                const int orow = pk[g * SEPX_YG + r] >> 5;
-                double val;
-                if (DEG == 1) val = x.t[r][0] + (x.t[r][1] - x.t[r][0]) * x.w[r][0];
-                else val = fma(x.w[r][3], x.t[r][3], fma(x.w[r][2], x.t[r][2], fma(x.w[r][1], x.t[r][1], x.w[r][0] * x.t[r][0])));
-                if (!(dbg & 1)) zout[(size_t)orow * nid + cc] = (any_dehors && cdehors) ? fillv : (float)val;
-            }
-        };
-        YGroup ya, yb;
-        if (!(dbg & 16)) {
-        yload(0, ya);
-#pragma unroll
-        for (int g = 0; g < EZHIP_SEP_ROWS / SEPX_YG; g += 2) {
-            yload(g + 1, yb);
-            __builtin_amdgcn_sched_barrier(0);
-            if (any_dehors) ycomp(g, ya, true); else ycomp(g, ya, false);
-            if (g + 2 < EZHIP_SEP_ROWS / SEPX_YG) yload(g + 2, ya);
-            __builtin_amdgcn_sched_barrier(0);
-            if (any_dehors) ycomp(g + 1, yb, true); else ycomp(g + 1, yb, false);
         }
+        __syncthreads();                                   /* the patch is free again; the ring holds window i for all columns */
+        ezhip_xstep nst = st;
+        if (i + 1 < i1) { nst = load_step(p.x_cont, i + 1); dma_issue(nst, i + 1); }
+        /* ---- y-pass: wave wv owns target rows {2 wv, 2 wv + 1} and {8 + 2 wv, 9 + 2 wv} of the row-block */
+        if (!(dbg & 16)) {
+            const float *myrec = rec + (i & 1) * SEPX_REC_DW + (2 * wv + rsub) * 16;
+            if (slow) sepx_ypass<DEG, true>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, (dbg & 1) != 0);
+            else sepx_ypass<DEG, false>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, false);
         }
         st = nst;
-        if (dbg & 17) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((dbg & 16) || slow) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (i + 1 < i1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     /* DMA(i+1) landed; the 16 stores stay in flight */
     }
 }
 
 extern "C" size_t ezhip_sepx_lds_bytes(int x_tr, int x_mirror, int x_prows, int wstride)
 {
-    size_t b = sizeof(double) * (size_t)(x_tr + (x_mirror ? 3 : 0)) * SEP_BLOCK + sizeof(float) * (size_t)x_prows * wstride;
+    (void)x_mirror;
+    size_t b = sizeof(double) * (size_t)x_tr * SEP_BLOCK + sizeof(float) * (2 * SEPX_REC_DW + (size_t)x_prows * wstride);
     const size_t pole = sizeof(float) * (POLE_CHUNK + 1);
     return b < pole ? pole : b;
 }
@@ -742,11 +757,9 @@ extern "C" int ezhip_sepx_capacity(int degree, int mirror, size_t lds_bytes)
     int dev = 0, ncu = 0, nb = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    hipError_t e;
-    if (degree == 1) e = mirror ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<1, true>, SEP_BLOCK, lds_bytes)
-                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<1, false>, SEP_BLOCK, lds_bytes);
-    else e = mirror ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<3, true>, SEP_BLOCK, lds_bytes)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<3, false>, SEP_BLOCK, lds_bytes);
+    (void)mirror;
+    hipError_t e = degree == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<1>, SEP_BLOCK, lds_bytes)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<3>, SEP_BLOCK, lds_bytes);
     if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
     return nb * ncu;
 }
@@ -757,17 +770,14 @@ static int launch_sepx(const ezhip_sep_plan *plan, float *d_zout, const float *d
     dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, plan->x_nseg + plan->n_special), block(SEP_BLOCK);
     size_t lds = ezhip_sepx_lds_bytes(plan->x_tr, plan->x_mirror, plan->x_prows, plan->wstride);
     if (lds > 64 * 1024) {
-        static thread_local bool raised[2][2];
-        bool &r = raised[DEG == 3][plan->x_mirror != 0];
-        if (!r) {
-            hipError_t e = plan->x_mirror ? hipFuncSetAttribute((const void *)k_sepx<DEG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                                          : hipFuncSetAttribute((const void *)k_sepx<DEG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        static thread_local bool raised[2];
+        if (!raised[DEG == 3]) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_sepx<DEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return set_err(e, "k_sepx LDS size");
-            r = true;
+            raised[DEG == 3] = true;
         }
     }
-    if (plan->x_mirror) hipLaunchKernelGGL((k_sepx<DEG, true>), grid, block, lds, g_stream, *plan, d_zout, d_zin);
-    else hipLaunchKernelGGL((k_sepx<DEG, false>), grid, block, lds, g_stream, *plan, d_zout, d_zin);
+    hipLaunchKernelGGL((k_sepx<DEG>), grid, block, lds, g_stream, *plan, d_zout, d_zin);
     return LAUNCH_CHECK("k_sepx");
 }
 

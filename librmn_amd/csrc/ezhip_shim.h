@@ -69,9 +69,11 @@ typedef struct {
 
 /* one staging step of k_sepx: source rows [s0, s0 + n) are new to the ring, the first lands in slot0 */
 typedef struct { int s0, n, slot0, by; } ezhip_xstep;
-/* the 16 target rows of a row-block, laid out for scalar loads: pk = (target row to store << 5) | ring slot of the
- * first tap (ring <= 32 rows); a row that is not a main row repeats a neighbouring main row */
-typedef struct { int pk[EZHIP_SEP_ROWS]; double w[EZHIP_SEP_ROWS][4]; } ezhip_xrows;
+/* the 16 target rows of a row-block as 64-byte records (they ride the LDS-DMA; one lane of the y-pass reads the
+ * record of ITS row): y weights, byte offsets of the 4 taps in the ring (wrap resolved on the host), element offset
+ * of the target row to store (a row that is not a main row repeats a neighbouring main row) */
+typedef struct { double w[4]; int t_off[4]; unsigned o_off; int pad[3]; } ezhip_xrow;
+typedef struct { ezhip_xrow r[EZHIP_SEP_ROWS]; } ezhip_xrows;
 
 typedef struct {
     int degree;                       /* 0 nearest, 1 linear, 3 cubic */
@@ -119,7 +121,7 @@ typedef struct {
     int x_nseg, x_rb, x_nvb;          /* segments per strip, row-blocks per segment, valid row-blocks */
     int x_tr, x_prows, x_mirror;      /* ring rows, patch rows, 1: ring has 3 mirror rows (taps never wrap) */
     const ezhip_xstep *x_first, *x_cont;   /* [x_nvb] staging step of a row-block when it starts a segment / continues one */
-    const ezhip_xrows *x_rows;        /* [x_nvb] per row-block: ring slot / target row / y weights of its 16 rows */
+    const ezhip_xrows *x_rows;        /* [x_nvb] per row-block: the records of its 16 rows */
 } ezhip_sep_plan;
 
 int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin);

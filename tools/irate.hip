@@ -45,9 +45,18 @@ __global__ __launch_bounds__(1024) void k_rate(unsigned long long *out, const fl
                 if (KIND == 17) asm volatile("v_lshl_add_u32 %0, %1, 11, %0" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
                 if (KIND == 18) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b));
                 if (KIND == 19) asm volatile("v_mov_b64 %0, %1" : "=v"(a[i]) : "v"(b));
+                if (KIND == 20) asm volatile("ds_read2_b64 %0, %1 offset1:32" : "=v"(*(__attribute__((ext_vector_type(2))) double *)&a[i & 6]) : "v"(u[i]));
+                if (KIND == 21) asm volatile("ds_read2_b64 %0, %1 offset1:33" : "=v"(*(__attribute__((ext_vector_type(2))) double *)&a[i & 6]) : "v"(u[i]));
+                if (KIND == 22) asm volatile("ds_read2_b64 %0, %1 offset1:1" : "=v"(*(__attribute__((ext_vector_type(2))) double *)&a[i & 6]) : "v"(u[i] & ~15u));
+                if (KIND == 23) asm volatile("ds_read_b32 %0, %1" : "=v"(f[i]) : "v"(u[i] >> 1));            /* lane stride 4 B */
+                if (KIND == 24) asm volatile("ds_read_b32 %0, %1" : "=v"(f[i]) : "v"((u[i] * 5 >> 4) & ~3u)); /* ~0.61 dword per lane (x-pass pattern) */
+                if (KIND == 25) asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(a[i]) : "v"((u[i] * 5 >> 4) & ~3u));
+                if (KIND == 26) asm volatile("ds_write_b32 %0, %1" :: "v"(u[i] >> 1), "v"(f[i]));
+                if (KIND == 27) asm volatile("ds_write_b128 %0, %1" :: "v"(u[i] * 2), "v"(*(__attribute__((ext_vector_type(2))) double *)&a[i & 6]));
+                if (KIND == 28) asm volatile("global_store_dword %0, %1, off" :: "v"(q[i] ), "v"(f[i]));
             }
         }
-        if (KIND >= 10 && KIND <= 15) asm volatile("s_waitcnt lgkmcnt(0)");
+        if (KIND >= 10 && KIND != 16 && KIND != 17 && KIND != 18 && KIND != 19 && KIND != 28) asm volatile("s_waitcnt lgkmcnt(0)");
     }
     asm volatile("s_waitcnt lgkmcnt(0)");
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -105,5 +114,13 @@ int main()
     run<13>("ds_read2_b32", d_out, d_in, 0);
     run<14>("ds_write_b64", d_out, d_in, 0);
     run<15>("ds_read_b128", d_out, d_in, 0);
+    run<20>("ds_read2_b64 o1:32", d_out, d_in, 0);
+    run<21>("ds_read2_b64 o1:33", d_out, d_in, 0);
+    run<22>("ds_read2_b64 o1:1", d_out, d_in, 0);
+    run<23>("ds_read_b32 stride4", d_out, d_in, 0);
+    run<24>("ds_read_b32 xpass", d_out, d_in, 0);
+    run<25>("ds_read2_b32 xpass", d_out, d_in, 0);
+    run<26>("ds_write_b32 stride4", d_out, d_in, 0);
+    run<27>("ds_write_b128", d_out, d_in, 0);
     return 0;
 }
