@@ -9,8 +9,9 @@ by record across ranks, no data-path collective: weak scaling; 8 GPUs x 32 field
 batch of configs[3]).  Inputs are resident in HBM when the timed region starts.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     -- k_sep<3>: algorithmic bytes per launch (4*ni_s*nj_s + 4*npts_out =
-                  142.43 MB) / average launch duration, HIP events on the launch stream
+  roofline     -- k_sepx<3,16>: one launch interpolates the step's whole batch (blockIdx.z = field), so
+                  algorithmic bytes per launch = fields x (4*ni_s*nj_s + 4*npts_out = 142.43 MB)
+                  / average launch duration, HIP events on the launch stream
   cpu_baseline -- the reference's own c_ezsint (oracle/_ref/libezref.so, 1 thread) or, if that
                   build is absent, the oracle port, on a bounded sample of the same workload.
 """
@@ -158,9 +159,9 @@ def main():
     torch.cuda.synchronize()
     comp_us = (time.perf_counter() - t1) * 1e6 / npk
 
-    launches = args.steps * F
-    kern_us = ev_ms * 1e3 / launches              # average k_sep<3> launch-to-launch duration on the stream
-    achieved = ALGO_BYTES / (kern_us * 1e-6) / 1e9
+    # one k_sepx launch per step covers the F fields of the batch (+ one k_polevals launch: the pole sums)
+    kern_us = ev_ms * 1e3 / args.steps            # average launch-to-launch duration on the stream
+    achieved = F * ALGO_BYTES / (kern_us * 1e-6) / 1e9
     if rank == 0:
         total_pts = float(NPTS_OUT) * F * args.steps * world
         out = {
@@ -181,7 +182,8 @@ def main():
                        "fields_per_step_per_gpu": F, "points_per_field": NPTS_OUT},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "k_sep<3>", "avg_launch_us": kern_us, "algorithmic_bytes_per_launch": ALGO_BYTES},
+                         "kernel": "k_sepx<3, 16>", "avg_launch_us": kern_us, "fields_per_launch": F,
+                         "us_per_field": kern_us / F, "algorithmic_bytes_per_launch": F * ALGO_BYTES},
             "pack": {"compact_float_16bit_GBps": 4.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9, "us_per_field": pack_us,
                      "algorithmic_GBps_6B_per_elem": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9,
                      "frac_of_hbm_peak": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,

@@ -1062,114 +1062,55 @@ static void strip_row(const ezh_grid *g, int degree, float py, int north, ezhip_
     }
 }
 
-/* Row-streaming geometry of k_sep_stream: segments of target rows per 256-column strip, sized so that every
- * thread block is co-resident (<= CUs x EZHIP_ST_BLOCKS_PER_CU blocks) and carries about the same cost. */
-static void build_stream_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, const ezh_grid *gi, int nic, int njr, int nbx, int ntap,
-                                  const int *blk_base, const int *blk_w, const int *rbase, const double *rw,
-                                  const unsigned char *rflag, const ezhip_special_row *special, int nspecial, int vector_mode)
-{
-    p->nseg = 0;
-    /* opt-in (EZHIP_SEP_STREAM=1): on MI355X round 1 the streaming variant is correct but slower than the tile
-     * kernel (56 vs 41 us nearest, polar off): 4 compute waves per block leave it latency-bound per row
-     * (profiles/r01_stream_experiments.txt) */
-    if (!getenv("EZHIP_SEP_STREAM") || atoi(getenv("EZHIP_SEP_STREAM")) == 0) return;
-    int wmax = 1, prev = -1;
-    for (int bx = 0; bx < nbx; bx++) { if (blk_base[bx] < 0) return; if (blk_w[bx] > wmax) wmax = blk_w[bx]; }
-    int nch = (wmax + 63) / 64;
-    if (nch > 5) return;
-    for (int r = 0; r < njr; r++) { if (rflag[r]) continue; if (rbase[r] < prev) return; prev = rbase[r]; }   /* rows must stream forward */
-    int nseg = (256 * EZHIP_ST_BLOCKS_PER_CU) / nbx;
-    if (nseg > njr / 24) nseg = njr / 24;
-    if (getenv("EZHIP_SEP_NSEG")) nseg = atoi(getenv("EZHIP_SEP_NSEG"));
-    if (nseg < 1) return;
-    /* cost model: a main row costs 1, a special row ~6 (gathers), a block that must form a sequential pole sum
-     * pays ~35 rows of time up-front */
-    double *cost = (double *)malloc(sizeof(double) * njr), total = 0.0;
-    int is = 0;
-    for (int r = 0; r < njr; r++) {
-        cost[r] = 1.0;
-        if (rflag[r]) { cost[r] = 6.0; while (is < nspecial && special[is].row < r) is++; if (is < nspecial && special[is].row == r && special[is].kind != 3 && !vector_mode) cost[r] += 35.0 / 3.0; }
-        total += cost[r];
-    }
-    int *seg_r0 = (int *)calloc((size_t)nseg + 1, sizeof(int)), *seg_s0 = (int *)calloc(nseg, sizeof(int)), *seg_sn = (int *)calloc(nseg, sizeof(int));
-    int *seg_sp0 = (int *)calloc((size_t)nseg + 1, sizeof(int));
-    double acc = 0.0; int sidx = 1;
-    for (int r = 0; r < njr && sidx < nseg; r++) { acc += cost[r]; if (acc >= total * sidx / nseg) seg_r0[sidx++] = r + 1; }
-    while (sidx <= nseg) seg_r0[sidx++] = njr;
-    seg_r0[nseg] = njr;
-    ezhip_rowinfo *ris = (ezhip_rowinfo *)calloc((size_t)njr + 1, sizeof(ezhip_rowinfo));
-    int rows_max = 1; is = 0;
-    for (int sg = 0; sg < nseg; sg++) {
-        int a = seg_r0[sg], b = seg_r0[sg + 1], lo = 1 << 30, hi = -1;
-        if (b - a > rows_max) rows_max = b - a;
-        for (int r = a; r < b; r++) { if (rflag[r]) continue; if (rbase[r] < lo) lo = rbase[r]; if (rbase[r] + ntap > hi) hi = rbase[r] + ntap; }
-        if (hi < 0) { lo = 0; hi = 0; }
-        seg_s0[sg] = lo; seg_sn[sg] = hi - lo;
-        for (int r = a; r < b; r++) {
-            ezhip_rowinfo *q = &ris[r];
-            if (rflag[r]) { q->flag = 1; continue; }
-            q->jb = rbase[r] - lo;
-            for (int w = 0; w < 4; w++) q->w[w] = rw[w * njr + r];
-        }
-        while (is < nspecial && special[is].row < a) is++;
-        seg_sp0[sg] = is;
-    }
-    seg_sp0[nseg] = nspecial;
-    for (int sg = nseg - 1; sg >= 0; sg--) if (seg_sp0[sg] > seg_sp0[sg + 1]) seg_sp0[sg] = seg_sp0[sg + 1];
-    p->seg_r0 = (const int *)(sp->dev[16] = upload(seg_r0, sizeof(int) * ((size_t)nseg + 1)));
-    p->seg_s0 = (const int *)(sp->dev[17] = upload(seg_s0, sizeof(int) * nseg));
-    p->seg_sn = (const int *)(sp->dev[18] = upload(seg_sn, sizeof(int) * nseg));
-    p->seg_sp0 = (const int *)(sp->dev[19] = upload(seg_sp0, sizeof(int) * ((size_t)nseg + 1)));
-    p->rowinfo_seg = (const ezhip_rowinfo *)(sp->dev[20] = upload(ris, sizeof(ezhip_rowinfo) * ((size_t)njr + 1)));
-    p->seg_rows_max = rows_max; p->nch = nch;
-    p->debug_flags = getenv("EZHIP_DEBUG") ? atoi(getenv("EZHIP_DEBUG")) : 0;
-    if (sp->dev[16] && sp->dev[17] && sp->dev[18] && sp->dev[19] && sp->dev[20]) p->nseg = nseg;
-    free(cost); free(seg_r0); free(seg_s0); free(seg_sn); free(seg_sp0); free(ris);
-    (void)gi; (void)nic;
-}
-
 /* k_sepx geometry: valid row-blocks, their staging steps (first-of-segment / continuing), ring slots.
  * Leaves p->x_nseg == 0 when the plan does not qualify (then k_sep runs). */
-static void build_sepx_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, int degree, int nbx, int nby, int nic, int njr,
-                                const int *blk_base, const int *brow_s0, const int *brow_n,
-                                const int *rbase, const double *rw, const unsigned char *rflag)
+static void build_sepx_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, int degree, int ntap, int nbx, int nic, int njr,
+                                const int *blk_base, const int *rbase, const double *rw, const unsigned char *rflag)
 {
     p->x_nseg = 0;
     p->debug_flags = getenv("EZHIP_DEBUG") ? atoi(getenv("EZHIP_DEBUG")) : 0;
-    if (degree == DEG_NEAREST || getenv("EZHIP_NO_SEPX")) return;
     for (int bx = 0; bx < nbx; bx++) if (blk_base[bx] < 0) return;
-    int *vb = (int *)malloc(sizeof(int) * (nby + 1)), nvb = 0, tr = 4, ok = 1;
+    if ((size_t)njr * (size_t)nic >= ((size_t)1 << 31)) return;
+    /* target rows per step (row-block of k_sepx): 8 -> smaller ring and patch, more thread blocks per CU */
+    int xr_rows = getenv("EZHIP_SEPX_ROWS") ? atoi(getenv("EZHIP_SEPX_ROWS")) : 16;
+    if (xr_rows != 8) xr_rows = 16;
+    int nby = (njr + xr_rows - 1) / xr_rows;
+    int *vb = (int *)malloc(sizeof(int) * (nby + 1)), *wa = (int *)malloc(sizeof(int) * (nby + 1)), *wn = (int *)malloc(sizeof(int) * (nby + 1));
+    int nvb = 0, tr = 4, ok = 1;
     for (int by = 0; by < nby && ok; by++) {
-        int r0 = by * EZHIP_SEP_ROWS, r1 = imin(r0 + EZHIP_SEP_ROWS, njr), nmain = 0;
-        for (int r = r0; r < r1; r++) nmain += !rflag[r];
-        if (!nmain) continue;
-        if (brow_n[by] <= 0) { ok = 0; break; }          /* source window taller than the patch: k_sep's gather path */
-        if (brow_n[by] > tr) tr = brow_n[by];
-        vb[nvb++] = by;
+        int r0 = by * xr_rows, r1 = imin(r0 + xr_rows, njr), lo = 1 << 30, hi = -1;
+        for (int r = r0; r < r1; r++) {
+            if (rflag[r]) continue;
+            if (rbase[r] < lo) lo = rbase[r];
+            if (rbase[r] + ntap > hi) hi = rbase[r] + ntap;
+        }
+        if (hi < 0) continue;                                /* no main row */
+        if (hi - lo > EZHIP_SEP_RMAX) { ok = 0; break; }     /* source window taller than the patch: k_sep's gather path */
+        if (hi - lo > tr) tr = hi - lo;
+        wa[nvb] = lo; wn[nvb] = hi - lo; vb[nvb++] = by;
     }
-    if (!ok || nvb == 0 || (size_t)njr * (size_t)nic >= ((size_t)1 << 31)) { free(vb); return; }
-    int mirror = getenv("EZHIP_SEPX_MIRROR") ? atoi(getenv("EZHIP_SEPX_MIRROR")) : 0;
+    if (!ok || nvb == 0) { free(vb); free(wa); free(wn); return; }
     ezhip_xstep *first = (ezhip_xstep *)calloc(nvb, sizeof(ezhip_xstep)), *cont = (ezhip_xstep *)calloc(nvb, sizeof(ezhip_xstep));
-    ezhip_xrows *xr = (ezhip_xrows *)calloc((size_t)nvb, sizeof(ezhip_xrows));
+    ezhip_xrow *xr = (ezhip_xrow *)calloc((size_t)nvb * xr_rows, sizeof(ezhip_xrow));
     int prows = 1;
     for (int i = 0; i < nvb; i++) {
-        int by = vb[i], a = brow_s0[by], b = a + brow_n[by];
+        int by = vb[i], a = wa[i], b = a + wn[i];
         first[i].s0 = a; first[i].n = b - a; first[i].slot0 = a % tr; first[i].by = by;
         cont[i] = first[i];
         if (i > 0) {       /* rows already in the ring: the previous window [pa, pb) */
-            int pa = brow_s0[vb[i - 1]], pb = pa + brow_n[vb[i - 1]];
+            int pa = wa[i - 1], pb = pa + wn[i - 1];
             if (a >= pa && b >= pb && a <= pb) { cont[i].s0 = pb; cont[i].n = b - pb; }
             else if (a <= pa && b <= pb && b >= pa) { cont[i].s0 = a; cont[i].n = pa - a; }
             cont[i].slot0 = cont[i].s0 % tr;
         }
         if (first[i].n > prows) prows = first[i].n;
         /* target rows: a row that is not a main row re-stores the nearest main row of the same row-block */
-        int r0 = by * EZHIP_SEP_ROWS, lastmain = -1;
-        for (int k = 0; k < EZHIP_SEP_ROWS; k++) { int r = r0 + k; if (r < njr && !rflag[r]) { lastmain = r; break; } }
-        for (int k = 0; k < EZHIP_SEP_ROWS; k++) {
+        int r0 = by * xr_rows, lastmain = -1;
+        for (int k = 0; k < xr_rows; k++) { int r = r0 + k; if (r < njr && !rflag[r]) { lastmain = r; break; } }
+        for (int k = 0; k < xr_rows; k++) {
             int r = r0 + k;
             if (r < njr && !rflag[r]) lastmain = r;
-            ezhip_xrow *q = &xr[i].r[k];
+            ezhip_xrow *q = &xr[(size_t)i * xr_rows + k];
             for (int w = 0; w < 4; w++) {
                 q->w[w] = rw[w * njr + lastmain];
                 q->t_off[w] = ((rbase[lastmain] + w) % tr) * (int)(EZHIP_SEP_COLS * sizeof(double));
@@ -1177,8 +1118,8 @@ static void build_sepx_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, int degree, 
             q->o_off = (unsigned)((size_t)lastmain * (size_t)nic);
         }
     }
-    size_t lds = ezhip_sepx_lds_bytes(tr, mirror, prows, p->wstride);
-    int cap = ezhip_sepx_capacity(degree, mirror, lds);
+    size_t lds = ezhip_sepx_lds_bytes(tr, xr_rows, prows, p->wstride);
+    int cap = ezhip_sepx_capacity(degree, xr_rows, lds);
     if (cap <= 0) cap = 768;
     int nseg = cap / nbx;
     if (nseg < 1) nseg = 1;
@@ -1186,15 +1127,15 @@ static void build_sepx_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, int degree, 
     if (getenv("EZHIP_SEPX_RB")) rb = atoi(getenv("EZHIP_SEPX_RB"));
     if (rb < 1) rb = 1;
     p->x_rb = rb; p->x_nseg = (nvb + rb - 1) / rb; p->x_nvb = nvb;
-    p->x_tr = tr; p->x_prows = prows; p->x_mirror = mirror;
+    p->x_tr = tr; p->x_prows = prows; p->x_rows_per_step = xr_rows;
     if (getenv("EZHIP_VERBOSE"))
-        fprintf(stderr, "k_sepx plan: degree %d, %d column blocks x %d segments of %d row-blocks (%d valid), ring %d rows, patch %d rows x %d, LDS %zu B, capacity %d blocks\n",
-                degree, nbx, p->x_nseg, rb, nvb, tr, prows, p->wstride, lds, cap);
+        fprintf(stderr, "k_sepx plan: degree %d, %d column blocks x %d segments of %d steps of %d rows (%d valid), ring %d rows, patch %d rows x %d, LDS %zu B, capacity %d blocks\n",
+                degree, nbx, p->x_nseg, rb, xr_rows, nvb, tr, prows, p->wstride, lds, cap);
     p->x_first = (const ezhip_xstep *)(sp->dev[21] = upload(first, sizeof(ezhip_xstep) * nvb));
     p->x_cont = (const ezhip_xstep *)(sp->dev[22] = upload(cont, sizeof(ezhip_xstep) * nvb));
-    p->x_rows = (const ezhip_xrows *)(sp->dev[23] = upload(xr, sizeof(ezhip_xrows) * (size_t)nvb));
+    p->x_rows = (const ezhip_xrow *)(sp->dev[23] = upload(xr, sizeof(ezhip_xrow) * (size_t)nvb * xr_rows));
     if (!sp->dev[21] || !sp->dev[22] || !sp->dev[23]) p->x_nseg = 0;
-    free(first); free(cont); free(xr); free(vb);
+    free(first); free(cont); free(xr); free(vb); free(wa); free(wn);
 }
 
 static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
@@ -1305,17 +1246,10 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
         int wmax = 1, nmax = 1;
         for (int bx = 0; bx < nbx; bx++) if (blk_w[bx] > wmax) wmax = blk_w[bx];
         for (int by = 0; by < nby; by++) if (brow_n[by] > nmax) nmax = brow_n[by];
-        /* row-blocks per thread block: 2 for bicubic (LDS-DMA software pipeline: the next patch is in flight while
-         * the current one is computed and stored; measured 64 -> 57-59 us at cfg2), 1 otherwise (no gain measured) */
-        int rb = (degree == DEG_CUBIC) ? 2 : 1;
-        if (getenv("EZHIP_SEP_RB")) rb = atoi(getenv("EZHIP_SEP_RB"));
-        if (rb > 8) rb = 8;
-        if (rb < 1) rb = 1;
-        wmax = 64 * ((wmax + 63) / 64);      /* LDS-DMA (k_sep pipeline, k_sepx): rows are staged in whole 64-float chunks */
+        wmax = 64 * ((wmax + 63) / 64);      /* k_sepx stages rows with LDS-DMA in whole 64-float chunks */
         p->wstride = wmax; p->patch_elems = wmax * nmax;
         if (p->patch_elems < 1032) p->patch_elems = 1032;
         p->nblk_y = nby;
-        p->rb_per_block = rb;
     }
     p->rowinfo = (const ezhip_rowinfo *)(sp->dev[14] = upload(rinfo, sizeof(ezhip_rowinfo) * (size_t)nby * EZHIP_SEP_ROWS));
     free(rinfo);
@@ -1338,8 +1272,7 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
         if (special[k].kind == 1 || special[k].kind == 2) p->need_poles = 1;
         if (special[k].kind == 0) for (int q = 0; q < 4; q++) if (special[k].tap[q] < 0) p->need_poles = 1;
     }
-    build_sepx_geometry(sp, p, degree, nbx, nby, nic, njr, blk_base, brow_s0, brow_n, rbase, rw, rflag);
-    build_stream_geometry(sp, p, gi, nic, njr, nbx, ntap, blk_base, blk_w, rbase, rw, rflag, special, nspecial, vector_mode);
+    build_sepx_geometry(sp, p, degree, ntap, nbx, nic, njr, blk_base, rbase, rw, rflag);
     p->pole_weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
     p->vector_mode = vector_mode;
     ezhip_sync();
@@ -1478,6 +1411,7 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
         if (p.pole_weighted) { if (ensure_grid_dev(gi)) return -1; p.ax = gi->d_ax; }
         p.pole_row_n = prow_n; p.pole_row_s = prow_s;
         p.polevals = d_poles_pre ? d_poles_pre : d_poles;
+        if (getenv("EZHIP_NO_SEPX")) p.x_nseg = 0;       /* tests: force the fallback tile kernel k_sep */
         if (p.need_poles && !d_poles_pre && ezhip_polevals(d_poles, d_zin, gi->ni, gi->nj, p.pole_weighted, p.ax)) return -1;
         if (ezhip_interp_sep(&p, d_zout, d_zin)) return -1;
         return ierc;
@@ -1530,6 +1464,22 @@ int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields)
         if (weighted && ensure_grid_dev(gi)) return -1;
         if (s->d_poles_batch && ezhip_polevals_batch(s->d_poles_batch, d_zin, nin, nfields, gi->ni, gi->nj, weighted, gi->d_ax) == 0)
             d_poles_all = s->d_poles_batch;
+    }
+    /* separable plan without extrapolation fill: ALL fields in one k_sepx launch (blockIdx.z = field) */
+    if (s->gdin != s->gdout && nfields > 1 && nfields <= 65535 && !(O.polar_correction == 1 && s->extrap) &&
+        (O.degre_interp == DEG_NEAREST || O.degre_interp == DEG_LINEAR || O.degre_interp == DEG_CUBIC) &&
+        choose_mode(s, O.degre_interp, O.polar_correction == 1) == 1 && !getenv("EZHIP_NO_BATCH_LAUNCH") && !getenv("EZHIP_NO_SEPX")) {
+        int degree = O.degre_interp, polar = O.polar_correction == 1;
+        if (ensure_scratch(s) || build_sep_plan(s, degree, 0, polar)) return -1;
+        ezhip_sep_plan p = s->sep[degree == DEG_CUBIC ? 2 : degree][0].p;
+        if (p.x_nseg > 0 && (!p.need_poles || d_poles_all)) {
+            ezh_grid *gi = &G[s->gdin];
+            p.fill = s->d_scratch;
+            if (p.pole_weighted) { if (ensure_grid_dev(gi)) return -1; p.ax = gi->d_ax; }
+            p.polevals = d_poles_all;
+            p.batch_fields = nfields; p.batch_in_stride = nin; p.batch_out_stride = nout;
+            return ezhip_interp_sep(&p, d_zout, d_zin) ? -1 : 0;
+        }
     }
     for (int f = 0; f < nfields; f++) {
         int r = (s->gdin == s->gdout) ? (ezhip_d2d(d_zout + f * nout, d_zin + f * nin, sizeof(float) * nin), 1)

@@ -246,46 +246,7 @@ __device__ __forceinline__ void lds_dma_dword(const float *base_uniform, unsigne
 }
 __device__ __forceinline__ unsigned lds_addr_of(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; }
 
-#define SEP_RIT ((EZHIP_SEP_RMAX + 3) / 4)     /* staged rows per wave (4 waves) */
 #define SEP_QCH ((EZHIP_SEP_WMAX + 63) / 64)   /* 64-column chunks per staged row */
-
-/* Register image of one row-block's patch while its global loads are in flight (software
- * pipeline: the loads of row-block i+1 are issued BEFORE row-block i is computed and stored, and
- * committed to the other LDS buffer afterwards).  Measured motivation: staging alone costs 19 us
- * and the stores alone 19 us per field; un-overlapped (load -> barrier -> compute -> store per
- * block) they add up to 34-44 us whatever the instruction count. */
-struct PatchRegs { float v[SEP_RIT][SEP_QCH]; ezhip_rowinfo ri; };
-
-__device__ __forceinline__ void patch_issue(PatchRegs &pr, const ezhip_sep_plan &p, const float *__restrict__ zin,
-                                            int by, const unsigned (&coloff)[SEP_QCH], int W, int lane, int wv)
-{
-    const int s0 = p.brow_s0[by], n = p.brow_n[by];
-#pragma unroll
-    for (int it = 0; it < SEP_RIT; it++) {
-        const int row = it * 4 + wv;
-        if (row < n) {                                           /* wave-uniform */
-            const float *zr = zin + (size_t)(s0 + row) * p.ni_src;
-#pragma unroll
-            for (int q = 0; q < SEP_QCH; q++)
-                if (lane + 64 * q < W) pr.v[it][q] = zr[coloff[q]];
-        }
-    }
-    pr.ri = p.rowinfo[(size_t)by * EZHIP_SEP_ROWS + (threadIdx.x & (EZHIP_SEP_ROWS - 1))];
-}
-
-__device__ __forceinline__ void patch_commit(const PatchRegs &pr, float *buf, int n, int W, int wstride, int lane, int wv)
-{
-#pragma unroll
-    for (int it = 0; it < SEP_RIT; it++) {
-        const int row = it * 4 + wv;
-        if (row < n) {
-            float *dst = buf + row * wstride + lane;
-#pragma unroll
-            for (int q = 0; q < SEP_QCH; q++)
-                if (lane + 64 * q < W) dst[64 * q] = pr.v[it][q];
-        }
-    }
-}
 
 /* 16 statically unrolled target rows of one row-block from the LDS patch (taps = consecutive patch
  * columns).  Row metadata sits in lane k of `ri` and is broadcast with v_readlane: no memory
@@ -435,11 +396,15 @@ __device__ void sep_special(const ezhip_sep_plan &p, float *__restrict__ zout, c
     if (cvalid) zout[(size_t)sr.row * p.ni_dst + c] = outv;
 }
 
-template <int DEG, bool PIPE>
+/* k_sep: the tile kernel, one (256-column block, 16-row block) per thread block: stage the source patch, barrier,
+ * compute + store.  It is the FALLBACK of k_sepx (below) for plans that one cannot take -- column blocks whose taps
+ * are not consecutive (literal seam remaps: gathers), source windows taller than the patch (strong down-sampling) --
+ * and was the round-1 default before k_sepx (53.5 us per cfg2 bicubic field against 35). */
+template <int DEG>
 __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__restrict__ zout,
                                                    const float *__restrict__ zin)
 {
-    extern __shared__ float smem[];        /* 2 patch buffers of p.patch_elems floats; also the pole-sum buffer */
+    extern __shared__ float smem[];        /* the patch: p.patch_elems floats */
     __shared__ RowInfo ri_lds;             /* gather fallback only */
     const int c = blockIdx.x * SEP_BLOCK + threadIdx.x;
     const bool cvalid = c < p.ni_dst;
@@ -447,17 +412,13 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
     const int nis = p.ni_src;
     const float fillv = p.fill ? *p.fill : 0.0f;
 
-    /* special rows occupy the FIRST blockIdx.y values: their sequential pole sums start early and
-     * overlap the main blocks */
+    /* special rows occupy the FIRST blockIdx.y values */
     if ((int)blockIdx.y >= p.n_special) {
-        const int gy = blockIdx.y - p.n_special;
-        const int by0 = gy * p.rb_per_block, by1 = min(by0 + p.rb_per_block, p.nblk_y);
+        const int by = blockIdx.y - p.n_special;
         const bool cdehors = p.cflag[cc] != 0;
         const int base = p.blk_base[blockIdx.x], W = p.blk_w[blockIdx.x];
-        if (base < 0) {
-            for (int by = by0; by < by1; by++) sep_rowblock_gather<DEG>(p, ri_lds, zout, zin, by, cc, c, cvalid, cdehors, fillv);
-            return;
-        }
+        const int s0 = p.brow_s0[by], n = p.brow_n[by];
+        if (base < 0 || n <= 0) { sep_rowblock_gather<DEG>(p, ri_lds, zout, zin, by, cc, c, cvalid, cdehors, fillv); return; }
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         unsigned coloff[SEP_QCH];
 #pragma unroll
@@ -468,85 +429,22 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
         }
         const int off0 = p.coff[cc];
         const double cw[4] = {p.cw[cc], p.cw[p.ni_dst + cc], p.cw[2 * p.ni_dst + cc], p.cw[3 * p.ni_dst + cc]};
-        if (!PIPE) {
-            /* one row-block per thread block: stage (all loads issued up-front), barrier, compute + store.
-             * No vector load is issued after a store, so no wave ever waits on a store acknowledgement. */
-            const int by = by0, s0 = p.brow_s0[by], n = p.brow_n[by];
-            if (n <= 0) { sep_rowblock_gather<DEG>(p, ri_lds, zout, zin, by, cc, c, cvalid, cdehors, fillv); return; }
-            for (int row = wv; row < n; row += SEP_BLOCK / 64) {
-                const float *zr = zin + (size_t)(s0 + row) * nis;      /* uniform base */
-                float *prow = smem + row * p.wstride + lane;
+        /* all loads issued up-front: no vector load is issued after a store, so no wave waits on a store acknowledgement */
+        for (int row = wv; row < n; row += SEP_BLOCK / 64) {
+            const float *zr = zin + (size_t)(s0 + row) * nis;      /* uniform base */
+            float *prow = smem + row * p.wstride + lane;
 #pragma unroll
-                for (int q = 0; q < SEP_QCH; q++)
-                    if (lane + 64 * q < W) prow[64 * q] = zr[coloff[q]];
-            }
-            const ezhip_rowinfo mine = p.rowinfo[(size_t)by * EZHIP_SEP_ROWS + (threadIdx.x & (EZHIP_SEP_ROWS - 1))];
-            __syncthreads();
-            if (DEG != 0 && mine.pad0)      /* pad0 (uniform across lanes): row-block qualifies for the straight-line body */
-                sep_rows_simple<DEG>(p, mine, smem, p.wstride, off0, cw, by * EZHIP_SEP_ROWS, zout, c, cvalid, cdehors, fillv);
-            else
-                sep_rows_staged<DEG>(p, mine, smem, p.wstride, off0, cw, by * EZHIP_SEP_ROWS, zout, c, cvalid, cdehors, fillv);
-            return;
+            for (int q = 0; q < SEP_QCH; q++)
+                if (lane + 64 * q < W) prow[64 * q] = zr[coloff[q]];
         }
-        /* Software pipeline over rb_per_block consecutive row-blocks with LDS-DMA (global_load_lds: no VGPR
-         * staging) and two patch buffers.  Why: with one row-block per thread block, all blocks of a launch run
-         * their staging phase, then their compute phase, in near lockstep (only ~3 rounds of blocks per CU), so the
-         * HBM time and the fp64 VALU time ADD (nearest 41 us, bicubic 60 us).  Here the DMA of row-block i+1 is in
-         * flight while row-block i is computed and stored.  vmcnt is in-order and shared by loads and stores: the
-         * wait for DMA(i+1) is `vmcnt(16)`, i.e. "all but the 16 youngest" = the 16 stores of row-block i, which are
-         * therefore never waited for.  That needs exactly 16 store instructions per wave: guaranteed for row-blocks
-         * marked simple (pad0) by storing unconditionally (out-of-range lanes duplicate the last column's value). */
-        const int wstr = p.wstride;      /* = 64 * nch: DMA chunks are 64 floats */
-        unsigned coloff_c[SEP_QCH];
-#pragma unroll
-        for (int q = 0; q < SEP_QCH; q++) {
-            int col = base + min(lane + 64 * q, W - 1);
-            if (col >= nis) col -= nis;
-            coloff_c[q] = (unsigned)col;
-        }
-        float *bufA = smem, *bufB = smem + p.patch_elems;
-        float *riA = smem + 2 * p.patch_elems, *riB = riA + 192;      /* row metadata of a row-block: 16 x 48 B = 192 dwords */
-        auto dma_issue = [&](int by, float *dst, float *ridst) {
-            const int s0 = p.brow_s0[by], n = p.brow_n[by];
-            for (int row = wv; row < n; row += SEP_BLOCK / 64) {
-                const float *zr = zin + (size_t)(s0 + row) * nis;
-                float *prow = dst + row * wstr;
-#pragma unroll
-                for (int q = 0; q < SEP_QCH; q++)
-                    if (64 * q < W)        /* wave-uniform: whole 64-float chunk (tail lanes re-load the last valid column) */
-                        lds_dma_dword(zr, coloff_c[q] * 4u, lds_addr_of(prow + 64 * q));
-            }
-            if (wv == 3) {               /* the row metadata rides the same DMA (no register load inside the loop) */
-                const float *src = (const float *)(p.rowinfo + (size_t)by * EZHIP_SEP_ROWS);
-#pragma unroll
-                for (int q = 0; q < 3; q++) lds_dma_dword(src, (unsigned)(lane + 64 * q) * 4u, lds_addr_of(ridst + 64 * q));
-            }
-        };
-        dma_issue(by0, bufA, riA);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const ezhip_rowinfo mine = p.rowinfo[(size_t)by * EZHIP_SEP_ROWS + (threadIdx.x & (EZHIP_SEP_ROWS - 1))];
         __syncthreads();
-        const int c_st = cc;             /* unconditional stores: lanes past the last column rewrite column ni_dst-1 */
-        for (int by = by0; by < by1; by++) {
-            const bool odd = (by - by0) & 1;
-            float *cur = odd ? bufB : bufA, *nxt = odd ? bufA : bufB;
-            const ezhip_rowinfo mine = ((const ezhip_rowinfo *)(odd ? riB : riA))[threadIdx.x & (EZHIP_SEP_ROWS - 1)];
-            const int n = p.brow_n[by];
-            const bool more = by + 1 < by1;
-            if (more) dma_issue(by + 1, nxt, odd ? riA : riB);
-            const bool simple = DEG != 0 && __builtin_amdgcn_readfirstlane(mine.pad0) != 0;
-            if (n > 0 && simple) {
-                sep_rows_simple<DEG>(p, mine, cur, wstr, off0, cw, by * EZHIP_SEP_ROWS, zout, c_st, true, cdehors, fillv);
-                if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     /* DMA(by+1) landed; the 16 stores stay in flight */
-            } else {
-                if (n > 0) sep_rows_staged<DEG>(p, mine, cur, wstr, off0, cw, by * EZHIP_SEP_ROWS, zout, c, cvalid, cdehors, fillv);
-                else sep_rowblock_gather<DEG>(p, ri_lds, zout, zin, by, cc, c, cvalid, cdehors, fillv);
-                if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();             /* everyone's DMA landed, everyone finished reading `cur` */
-        }
+        if (DEG != 0 && mine.pad0)      /* pad0 (uniform across lanes): row-block qualifies for the straight-line body */
+            sep_rows_simple<DEG>(p, mine, smem, p.wstride, off0, cw, by * EZHIP_SEP_ROWS, zout, c, cvalid, cdehors, fillv);
+        else
+            sep_rows_staged<DEG>(p, mine, smem, p.wstride, off0, cw, by * EZHIP_SEP_ROWS, zout, c, cvalid, cdehors, fillv);
         return;
     }
-
     sep_special<DEG>(p, zout, zin, smem, c, cc, cvalid, fillv);
 }
 
@@ -572,17 +470,16 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
  *     main row (the record names the row to write).
  * The arithmetic is the one of k_sep (same fma chains), so results are bit-identical to it. */
 #define CONSTP(T, ptr) ((const __attribute__((address_space(4))) T *)(ptr))
-#define SEPX_REC_DW (EZHIP_SEP_ROWS * 16)          /* dwords of one row-block's records */
 
 /* y-pass of one wave and one row-block: 2 row pairs x 8 column groups of 32.  `myrec` = this lane's row record of
  * the first pair (the second pair is 8 records further), `tcol` = ring base of the lane's column in group 0.
  * SLOW adds what few blocks need: the DEHORS fill select, the column bound of the last strip, the debug knock-out. */
-template <int DEG, bool SLOW>
+template <int DEG, int XR, bool SLOW>
 __device__ __forceinline__ void sepx_ypass(const float *myrec, const double *tcol, float *zcol, float fillv, unsigned dmask,
                                            int l32, int ncol_valid, bool nostore)
 {
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < XR / 8; h++) {
         const float4 *r4 = (const float4 *)(myrec + h * 8 * 16);
         const float4 ra = r4[0], rb = r4[1], rc = r4[2];      /* w[0..3] | tap byte offsets */
         const unsigned o_off = (unsigned)__float_as_int(myrec[h * 8 * 16 + 12]);
@@ -598,7 +495,8 @@ __device__ __forceinline__ void sepx_ypass(const float *myrec, const double *tco
         if (SLOW) {
 #pragma unroll
             for (int g = 0; g < 8; g++) {
-                t[g][0] = tp0[32 * g]; t[g][1] = tp1[32 * g];
+                t[g][0] = tp0[32 * g];
+                if (DEG >= 1) t[g][1] = tp1[32 * g];
                 if (DEG == 3) { t[g][2] = tp2[32 * g]; t[g][3] = tp3[32 * g]; }
             }
         } else {
@@ -610,7 +508,8 @@ __device__ __forceinline__ void sepx_ypass(const float *myrec, const double *tco
                                "ds_read_b64 %4, %8 offset:1024\n\tds_read_b64 %5, %8 offset:1280\n\tds_read_b64 %6, %8 offset:1536\n\tds_read_b64 %7, %8 offset:1792" \
                                : "=&v"(t[0][J]), "=&v"(t[1][J]), "=&v"(t[2][J]), "=&v"(t[3][J]), "=&v"(t[4][J]), "=&v"(t[5][J]), "=&v"(t[6][J]), "=&v"(t[7][J]) \
                                : "v"(A) : "memory")
-            RD8(a0, 0); RD8(a1, 1);
+            RD8(a0, 0);
+            if (DEG >= 1) RD8(a1, 1);
             if (DEG == 3) { RD8(a2, 2); RD8(a3, 3); }
 #undef RD8
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -618,13 +517,15 @@ __device__ __forceinline__ void sepx_ypass(const float *myrec, const double *tco
 #pragma unroll
             for (int g = 0; g < 8; g++) {
                 if (DEG == 3) asm volatile("" : "+v"(t[g][0]), "+v"(t[g][1]), "+v"(t[g][2]), "+v"(t[g][3]));
-                else asm volatile("" : "+v"(t[g][0]), "+v"(t[g][1]));
+                else if (DEG == 1) asm volatile("" : "+v"(t[g][0]), "+v"(t[g][1]));
+                else asm volatile("" : "+v"(t[g][0]));
             }
         }
 #pragma unroll
         for (int g = 0; g < 8; g++) {
             double val;
-            if (DEG == 1) val = t[g][0] + (t[g][1] - t[g][0]) * w0;
+            if (DEG == 0) val = t[g][0];
+            else if (DEG == 1) val = t[g][0] + (t[g][1] - t[g][0]) * w0;
             else val = fma(w3, t[g][3], fma(w2, t[g][2], fma(w1, t[g][1], w0 * t[g][0])));
             float out = (float)val;
             if (SLOW) {
@@ -635,14 +536,17 @@ __device__ __forceinline__ void sepx_ypass(const float *myrec, const double *tco
     }
 }
 
-template <int DEG>
-__global__ __launch_bounds__(SEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 4)))
+template <int DEG, int XR>
+__global__ __launch_bounds__(SEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 6)))
 void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict__ zin)
 {
     extern __shared__ double smem_x[];
     const int c = blockIdx.x * SEP_BLOCK + threadIdx.x;
     const int cc = min(c, p.ni_dst - 1);
     const float fillv = p.fill ? *p.fill : 0.0f;
+    /* blockIdx.z = field of a batch launch (c_ezsint_batch_dev): no ramp-up / drain gap between fields */
+    zin += blockIdx.z * p.batch_in_stride; zout += blockIdx.z * p.batch_out_stride;
+    if (p.polevals) p.polevals += 2 * blockIdx.z;
     if ((int)blockIdx.y < p.n_special) { sep_special<DEG>(p, zout, zin, (float *)smem_x, c, cc, c < p.ni_dst, fillv); return; }
     const int seg = blockIdx.y - p.n_special;
     const int i0 = seg * p.x_rb, i1 = min(i0 + p.x_rb, p.x_nvb);
@@ -650,7 +554,8 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
     const int nis = p.ni_src, nid = p.ni_dst, trows = p.x_tr, wstr = p.wstride;
     const int base = p.blk_base[blockIdx.x], W = p.blk_w[blockIdx.x];
     double *T = smem_x;                                                         /* T[slot][256 columns] */
-    float *rec = (float *)(smem_x + (size_t)trows * SEP_BLOCK);                /* 2 x 16 row records of 64 B */
+    constexpr int SEPX_REC_DW = XR * 16;                                        /* dwords of one step's row records */
+    float *rec = (float *)(smem_x + (size_t)trows * SEP_BLOCK);                /* 2 x XR row records of 64 B */
     float *patch = rec + 2 * SEPX_REC_DW;
     const int dbg = p.debug_flags;          /* development knock-outs (EZHIP_DEBUG): 1 no stores, 4 no DMA, 8 no x-pass, 16 no y-pass */
     unsigned coloff[SEP_QCH];
@@ -660,7 +565,7 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
         if (col >= nis) col -= nis;
         coloff[q] = (unsigned)col * 4u;
     }
-    const unsigned pbase = lds_addr_of(patch + p.coff[cc]);
+    const float *pcol = patch + p.coff[cc];
     const double cw[4] = {p.cw[cc], p.cw[nid + cc], p.cw[2 * nid + cc], p.cw[3 * nid + cc]};
     /* y-pass lane geometry: row r of the pair, column l32 + 32 g of the strip */
     const int l32 = lane & 31, rsub = lane >> 5;
@@ -693,36 +598,21 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
             for (int q = 0; q < SEP_QCH; q++)
                 if (64 * q < W) lds_dma_dword(zr, coloff[q], lds_addr_of(prow + 64 * q));
         }
-        /* the 16 row records of row-block i: 256 dwords, one 64-dword chunk per wave */
-        lds_dma_dword((const float *)(p.x_rows + i), (unsigned)(threadIdx.x * 4), lds_addr_of(rec + (i & 1) * SEPX_REC_DW + wv * 64));
+        /* the XR row records of step i: 16 XR dwords, one 64-dword chunk per wave */
+        if (wv * 64 < SEPX_REC_DW)
+            lds_dma_dword((const float *)(p.x_rows + (size_t)i * XR), (unsigned)(threadIdx.x * 4), lds_addr_of(rec + (i & 1) * SEPX_REC_DW + wv * 64));
     };
     ezhip_xstep st = load_step(p.x_first, i0);
     dma_issue(st, i0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int i = i0; i < i1; i++) {
         __syncthreads();                                   /* DMA(i) landed in every wave; everyone left y-pass(i-1) */
-        /* ---- x-pass of the new source rows -> ring.  Two rows per iteration; the 4 taps of a row are four
-         * ds_read_b32 through inline asm (the compiler pairs them into ds_read2_b32: 8 LDS cycles per wave each on
-         * gfx950 against ~2 for ds_read_b32, tools/irate) */
+        /* ---- x-pass of the new source rows -> ring, two rows per iteration (an odd count repeats the last row) */
         if (!(dbg & 8)) {
             int slot = st.slot0;
             for (int s = 0; s < st.n; s += 2) {
-                const unsigned a0 = pbase + (unsigned)(s * wstr) * 4u;
-                const unsigned a1 = a0 + (s + 1 < st.n ? (unsigned)wstr * 4u : 0u);      /* odd count: the last row twice */
-                float x0, x1, x2, x3, y0, y1, y2, y3;
-                asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:4\n\tds_read_b32 %2, %8 offset:8\n\tds_read_b32 %3, %8 offset:12\n\t"
-                             "ds_read_b32 %4, %9\n\tds_read_b32 %5, %9 offset:4\n\tds_read_b32 %6, %9 offset:8\n\tds_read_b32 %7, %9 offset:12\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
-                             : "v"(a0), "v"(a1) : "memory");
-                double t0, t1;
-                if (DEG == 1) {
-                    const double p1 = (double)x0, p2 = (double)x1, q1 = (double)y0, q2 = (double)y1;
-                    t0 = p1 + (p2 - p1) * cw[0]; t1 = q1 + (q2 - q1) * cw[0];
-                } else {
-                    t0 = fma(cw[3], (double)x3, fma(cw[2], (double)x2, fma(cw[1], (double)x1, cw[0] * (double)x0)));
-                    t1 = fma(cw[3], (double)y3, fma(cw[2], (double)y2, fma(cw[1], (double)y1, cw[0] * (double)y0)));
-                }
+                const float *r0 = pcol + s * wstr, *r1 = r0 + (s + 1 < st.n ? wstr : 0);
+                const double t0 = xrow<DEG>(r0, cw), t1 = xrow<DEG>(r1, cw);
                 int slot1 = slot + 1; if (slot1 >= trows) slot1 -= trows;
                 T[slot * SEP_BLOCK + threadIdx.x] = t0;
                 if (s + 1 < st.n) T[slot1 * SEP_BLOCK + threadIdx.x] = t1;
@@ -735,316 +625,68 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
         /* ---- y-pass: wave wv owns target rows {2 wv, 2 wv + 1} and {8 + 2 wv, 9 + 2 wv} of the row-block */
         if (!(dbg & 16)) {
             const float *myrec = rec + (i & 1) * SEPX_REC_DW + (2 * wv + rsub) * 16;
-            if (slow) sepx_ypass<DEG, true>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, (dbg & 1) != 0);
-            else sepx_ypass<DEG, false>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, false);
+            if (slow) sepx_ypass<DEG, XR, true>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, (dbg & 1) != 0);
+            else sepx_ypass<DEG, XR, false>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, false);
         }
         st = nst;
         if ((dbg & 16) || slow) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (i + 1 < i1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     /* DMA(i+1) landed; the 16 stores stay in flight */
+        else if (i + 1 < i1) {                              /* DMA(i+1) landed; the XR stores of this step stay in flight */
+            if (XR == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
     }
 }
 
-extern "C" size_t ezhip_sepx_lds_bytes(int x_tr, int x_mirror, int x_prows, int wstride)
+extern "C" size_t ezhip_sepx_lds_bytes(int x_tr, int rows_per_step, int x_prows, int wstride)
 {
-    (void)x_mirror;
-    size_t b = sizeof(double) * (size_t)x_tr * SEP_BLOCK + sizeof(float) * (2 * SEPX_REC_DW + (size_t)x_prows * wstride);
+    size_t b = sizeof(double) * (size_t)x_tr * SEP_BLOCK + sizeof(float) * (2 * 16 * (size_t)rows_per_step + (size_t)x_prows * wstride);
     const size_t pole = sizeof(float) * (POLE_CHUNK + 1);
     return b < pole ? pole : b;
 }
 
-extern "C" int ezhip_sepx_capacity(int degree, int mirror, size_t lds_bytes)
+#define SEPX_DISPATCH(DEGV, XRV, EXPR) do { \
+        if ((DEGV) == 0 && (XRV) == 8) { constexpr int D = 0, X = 8; EXPR; } \
+        else if ((DEGV) == 0) { constexpr int D = 0, X = 16; EXPR; } \
+        else if ((DEGV) == 1 && (XRV) == 8) { constexpr int D = 1, X = 8; EXPR; } \
+        else if ((DEGV) == 1) { constexpr int D = 1, X = 16; EXPR; } \
+        else if ((XRV) == 8) { constexpr int D = 3, X = 8; EXPR; } \
+        else { constexpr int D = 3, X = 16; EXPR; } } while (0)
+
+extern "C" int ezhip_sepx_capacity(int degree, int rows_per_step, size_t lds_bytes)
 {
     int dev = 0, ncu = 0, nb = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    (void)mirror;
-    hipError_t e = degree == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<1>, SEP_BLOCK, lds_bytes)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<3>, SEP_BLOCK, lds_bytes);
+    hipError_t e = hipSuccess;
+    SEPX_DISPATCH(degree, rows_per_step, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<D, X>, SEP_BLOCK, lds_bytes));
     if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
     return nb * ncu;
 }
 
-template <int DEG>
 static int launch_sepx(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin)
 {
-    dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, plan->x_nseg + plan->n_special), block(SEP_BLOCK);
-    size_t lds = ezhip_sepx_lds_bytes(plan->x_tr, plan->x_mirror, plan->x_prows, plan->wstride);
-    if (lds > 64 * 1024) {
-        static thread_local bool raised[2];
-        if (!raised[DEG == 3]) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_sepx<DEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return set_err(e, "k_sepx LDS size");
-            raised[DEG == 3] = true;
-        }
+    dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, plan->x_nseg + plan->n_special, plan->batch_fields > 1 ? plan->batch_fields : 1), block(SEP_BLOCK);
+    size_t lds = ezhip_sepx_lds_bytes(plan->x_tr, plan->x_rows_per_step, plan->x_prows, plan->wstride);
+    if (lds > 64 * 1024) {        /* tall windows on wide strips: raise the per-kernel dynamic LDS limit */
+        hipError_t e = hipSuccess;
+        SEPX_DISPATCH(plan->degree, plan->x_rows_per_step,
+                      e = hipFuncSetAttribute((const void *)k_sepx<D, X>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (e != hipSuccess) return set_err(e, "k_sepx LDS size");
     }
-    hipLaunchKernelGGL((k_sepx<DEG>), grid, block, lds, g_stream, *plan, d_zout, d_zin);
+    SEPX_DISPATCH(plan->degree, plan->x_rows_per_step, hipLaunchKernelGGL((k_sepx<D, X>), grid, block, lds, g_stream, *plan, d_zout, d_zin));
     return LAUNCH_CHECK("k_sepx");
-}
-
-/* ===================================================================================== */
-/* k_sep_stream : row-streaming separable interpolation                                     */
-/* ===================================================================================== */
-/* Why: measured on MI355X (profiles/r01_ubench.txt) the tile kernel's patch staging (18 us, 1.9x read
- * amplification from halo rows / line granularity) and its stores (19 us) ADD instead of overlapping,
- * and any vector load issued after a store waits for that store's acknowledgement (in-order vmcnt).
- * Here one thread block owns a 256-column strip x a long segment of target rows:
- *   - wave 4 (loader) streams every source row of the strip ONCE into an LDS ring with LDS-DMA
- *     (global_load_lds_dword: no VGPRs, completion tracked by its own vmcnt), EZHIP_ST_DEPTH rows in flight;
- *   - waves 0-3 (compute) only read LDS and store to global memory: they never wait on vmcnt;
- *   - hand-off through two kinds of LDS words: `loaded` (rows landed) and per-wave `needed` (lowest
- *     source row a compute wave still reads), polled with s_sleep.
- * All blocks are co-resident (grid <= CUs x EZHIP_ST_BLOCKS_PER_CU), equal work per block. */
-#define ST_THREADS 320
-#define ST_DEPTH (60 / NCH > 20 ? 20 : 60 / NCH)   /* source rows in flight per loader wave (vmcnt <= 63) */
-
-
-template <int DEG, int NCH>
-__global__ __launch_bounds__(ST_THREADS) void k_sep_stream(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict__ zin)
-{
-    extern __shared__ float smem[];
-    constexpr int WSTR = 64 * NCH;                              /* ring row stride (floats) */
-    float *ring = smem;                                         /* [EZHIP_ST_NSLOT][WSTR] */
-    ezhip_rowinfo *rinfo = (ezhip_rowinfo *)(ring + EZHIP_ST_NSLOT * WSTR);   /* [seg_rows_max] */
-    float *scratch = (float *)(rinfo + p.seg_rows_max);                       /* POLE_CHUNK + 1 floats (pole sums) */
-    /* hand-off words live in their own LDS objects so that the compiler never orders them behind the ring's DMA */
-    __shared__ int sync[8];                                                    /* [0] loaded, [1..4] needed, [5] pole ready */
-    __shared__ float poles[2];                                                 /* [0] north, [1] south */
-    /* NB: hand-off words are accessed with workgroup-scope relaxed atomics (ds_read/ds_write).  `volatile`
-     * LDS accesses are lowered to flat_load/flat_store ... sc0 sc1, which go down the vector-memory pipe
-     * behind the stores (measured: 1100 cycles per row). */
-#define SYNC_LD(i) __hip_atomic_load(&sync[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define SYNC_ST(i, v) __hip_atomic_store(&sync[i], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-
-    const int seg = blockIdx.y, nis = p.ni_src;
-    const int r0 = p.seg_r0[seg], r1 = p.seg_r0[seg + 1];
-    const int s_first = p.seg_s0[seg], s_count = p.seg_sn[seg];
-    const int sp0 = p.seg_sp0[seg], sp1 = p.seg_sp0[seg + 1];
-    const int base = p.blk_base[blockIdx.x];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float fillv = p.fill ? *p.fill : 0.0f;
-
-    if (threadIdx.x < 8) sync[threadIdx.x] = 0;
-    /* stage this segment's row metadata (all threads; before any store is issued) */
-    {
-        const int nwords = (r1 - r0) * (int)(sizeof(ezhip_rowinfo) / 4);
-        const int *src = (const int *)(p.rowinfo_seg + r0);
-        int *dst = (int *)rinfo;
-        for (int k = threadIdx.x; k < nwords; k += ST_THREADS) dst[k] = src[k];
-    }
-    __syncthreads();
-
-    if (wave == 4) {
-        /* ---------------- loader wave ---------------- */
-        if (sp1 > sp0 && !p.vector_mode) {
-            /* the segment owns polar special rows: sequential REAL pole sums first (ez_calcpoleval order) */
-            bool need_n = false, need_s = false;
-            for (int q = sp0; q < sp1; q++) {
-                const ezhip_special_row sr = p.special[q];
-                need_n |= (sr.kind == 1); need_s |= (sr.kind == 2);
-                if (sr.kind == 0) for (int k = 0; k < 4; k++) { need_n |= (sr.tap[k] == EZ_ROW_POLE_N); need_s |= (sr.tap[k] == EZ_ROW_POLE_S); }
-            }
-            for (int which = 0; which < 2; which++) {
-                if (!(which == 0 ? need_n : need_s)) continue;
-                const float *zrow = which == 0 ? zin + (size_t)(p.nj_src - 1) * nis : zin;
-                const int n = p.pole_weighted ? nis - 1 : nis;
-                float acc = 0.0f;
-                for (int b0 = 0; b0 < n; b0 += POLE_CHUNK) {
-                    const int m = min(POLE_CHUNK, n - b0);
-                    for (int k = lane; k < m; k += 64) { int i = b0 + k; scratch[k] = p.pole_weighted ? zrow[i] * (p.ax[i + 1] - p.ax[i]) : zrow[i]; }
-                    __builtin_amdgcn_wave_barrier();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) {
-#pragma unroll 8
-                        for (int k = 0; k < m; k++) acc = acc + scratch[k];
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (lane == 0) {
-                    if (p.pole_weighted) { float span = p.ax[nis - 1] - p.ax[0]; if (span != 0.0f) acc = acc / span; }
-                    else acc = acc / (1.0f * (float)nis);
-                    poles[which] = acc;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) SYNC_ST(5, 1);
-        }
-        unsigned coloff[NCH];
-#pragma unroll
-        for (int q = 0; q < NCH; q++) {          /* source column of ring column lane + 64 q (seam unrolled, tail clamped) */
-            int u = min(lane + 64 * q, p.blk_w[blockIdx.x] - 1);
-            int col = base + u;
-            if (col >= nis) col -= nis;
-            coloff[q] = (unsigned)col;
-        }
-        int free_below = (p.debug_flags & 2) ? (1 << 30) : 0;
-        for (int s = 0; s < s_count; s++) {
-            /* slot s % NSLOT still holds row s - NSLOT: wait until no compute wave needs it */
-            if (s - EZHIP_ST_NSLOT >= free_below) {          /* re-read the consumers' progress only when the cached value blocks */
-                while (true) {
-                    free_below = min(min(SYNC_LD(1), SYNC_LD(2)), min(SYNC_LD(3), SYNC_LD(4)));
-                    if (s - EZHIP_ST_NSLOT < free_below) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-            const float *zr = zin + (size_t)(s_first + s) * nis;
-            float *slot = ring + (s % EZHIP_ST_NSLOT) * WSTR;
-#pragma unroll
-            for (int q = 0; q < NCH; q++)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(zr + coloff[q]),
-                                                 (__attribute__((address_space(3))) void *)(slot + 64 * q), 4, 0, 0);
-            if (s >= ST_DEPTH) {
-                /* rows 0 .. s-ST_DEPTH have landed once at most NCH*ST_DEPTH younger loads remain */
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH * ST_DEPTH) : "memory");
-                if (lane == 0) SYNC_ST(0, s - ST_DEPTH + 1);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) SYNC_ST(0, s_count);
-    } else {
-        /* ---------------- compute waves ---------------- */
-        const int c = blockIdx.x * SEP_BLOCK + threadIdx.x;
-        const bool cvalid0 = c < p.ni_dst;
-        const int cc = cvalid0 ? c : p.ni_dst - 1;
-        const bool cdehors = p.cflag[cc] != 0;
-        const int off0 = p.coff[cc];
-        const double cw[4] = {p.cw[cc], p.cw[p.ni_dst + cc], p.cw[2 * p.ni_dst + cc], p.cw[3 * p.ni_dst + cc]};
-        double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-        int cur = -(1 << 28), have = (p.debug_flags & 2) ? (1 << 30) : 0;
-        double dbg_acc = 0;
-        const bool cvalid = cvalid0 && !(p.debug_flags & 1);
-        float *orow = zout + (size_t)r0 * p.ni_dst + c;
-        const float *pcol = ring + off0;
-        const int ntap = DEG == 3 ? 4 : (DEG == 1 ? 2 : 1);
-#define XS(row) xrow<DEG>(pcol + ((row) % EZHIP_ST_NSLOT) * WSTR, cw)
-        /* Row metadata: lane l of the wave holds row g0 + l of the current 64-row group (ONE LDS read per 64 rows);
-         * each row then broadcasts it with v_readlane.  A per-row dependent LDS read (metadata, then the ring)
-         * measured ~1100 cycles per row at 4 compute waves per SIMD: the row loop must not chain LDS round trips. */
-        const int nrows = r1 - r0;
-        for (int g0 = 0; g0 < nrows; g0 += 64) {
-            const ezhip_rowinfo mine = rinfo[min(g0 + lane, nrows - 1)];
-            const int kmax = min(64, nrows - g0);
-            for (int k = 0; k < kmax; k++, orow += p.ni_dst) {
-                if (__builtin_amdgcn_readlane(mine.flag, k)) continue;
-                const int jb = __builtin_amdgcn_readlane(mine.jb, k);   /* relative to s_first */
-                if (jb != cur) {
-                    if (lane == 0) SYNC_ST(1 + wave, jb);            /* rows below jb are free for the loader */
-                    const int need = jb + ntap;
-                    if (have < need) {
-                        while ((have = SYNC_LD(0)) < need) __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-                double val;
-                if (DEG == 0) { val = XS(jb); cur = jb; }
-                else if (DEG == 1) {
-                    const int d = jb - cur;
-                    if (d != 0) {
-                        if (d == 1) { t0 = t1; t1 = XS(jb + 1); }
-                        else { t0 = XS(jb); t1 = XS(jb + 1); }
-                        cur = jb;
-                    }
-                    val = t0 + (t1 - t0) * readlane_f64(mine.w[0], k);
-                } else {
-                    const int d = jb - cur;
-                    if (d != 0) {
-                        if (d == 1) { t0 = t1; t1 = t2; t2 = t3; t3 = XS(jb + 3); }
-                        else if (d == 2) { t0 = t2; t1 = t3; t2 = XS(jb + 2); t3 = XS(jb + 3); }
-                        else if (d == 3) { t0 = t3; t1 = XS(jb + 1); t2 = XS(jb + 2); t3 = XS(jb + 3); }
-                        else { t0 = XS(jb); t1 = XS(jb + 1); t2 = XS(jb + 2); t3 = XS(jb + 3); }
-                        cur = jb;
-                    }
-                    val = fma(readlane_f64(mine.w[3], k), t3, fma(readlane_f64(mine.w[2], k), t2,
-                          fma(readlane_f64(mine.w[1], k), t1, readlane_f64(mine.w[0], k) * t0)));
-                }
-                if (cvalid) *orow = cdehors ? fillv : (float)val;
-                else dbg_acc += val;
-            }
-        }
-        if (dbg_acc == 1.2345e300 && cvalid0) zout[c] = 0.f;   /* keeps the arithmetic alive in the no-store debug mode */
-#undef XS
-        if (lane == 0) SYNC_ST(1 + wave, 1 << 30);               /* nothing needed any more */
-
-        /* special rows of this segment (polar strips / pole rows / outside rows): gathers from global memory */
-        if (sp1 > sp0) {
-            float pole_n = 0.f, pole_s = 0.f;
-            bool have_poles = false;
-            for (int q = sp0; q < sp1; q++) {
-                const ezhip_special_row sr = p.special[q];
-                float outv;
-                if (sr.kind == 3) outv = fillv;
-                else {
-                    if (!p.vector_mode && !have_poles) {
-                        while (SYNC_LD(5) == 0) __builtin_amdgcn_s_sleep(4);
-                        pole_n = poles[0]; pole_s = poles[1]; have_poles = true;
-                    }
-                    if (sr.kind == 1) outv = pole_n;
-                    else if (sr.kind == 2) outv = pole_s;
-                    else {
-                        const ColTaps t = load_col(p.cidx_s, p.cw_s, p.ni_dst, cc);
-                        double tv[4];
-                        for (int k = 0; k < ntap; k++) {
-                            int row = sr.tap[k];
-                            if (row >= 0) tv[k] = xpass<DEG>(zin + (size_t)row * nis, t);
-                            else if (p.vector_mode) tv[k] = xpass<DEG>(row == EZ_ROW_POLE_N ? p.pole_row_n : p.pole_row_s, t);
-                            else tv[k] = (double)(row == EZ_ROW_POLE_N ? pole_n : pole_s);
-                        }
-                        double val;
-                        if (DEG == 0) val = tv[0];
-                        else if (DEG == 1) val = tv[0] + (tv[1] - tv[0]) * sr.w[0];
-                        else val = fma(sr.w[3], tv[3], fma(sr.w[2], tv[2], fma(sr.w[1], tv[1], sr.w[0] * tv[0])));
-                        outv = (float)val;
-                    }
-                }
-                if (cvalid) zout[(size_t)sr.row * p.ni_dst + c] = outv;
-            }
-        }
-    }
-}
-
-static size_t stream_lds_bytes(const ezhip_sep_plan *plan)
-{
-    return sizeof(float) * (size_t)EZHIP_ST_NSLOT * 64 * plan->nch + sizeof(ezhip_rowinfo) * (size_t)plan->seg_rows_max
-           + sizeof(float) * (POLE_CHUNK + 1);
-}
-
-template <int DEG>
-static int launch_stream(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin)
-{
-    dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, plan->nseg), block(ST_THREADS);
-    size_t lds = stream_lds_bytes(plan);
-    switch (plan->nch) {
-    case 1: hipLaunchKernelGGL((k_sep_stream<DEG, 1>), grid, block, lds, g_stream, *plan, d_zout, d_zin); break;
-    case 2: hipLaunchKernelGGL((k_sep_stream<DEG, 2>), grid, block, lds, g_stream, *plan, d_zout, d_zin); break;
-    case 3: hipLaunchKernelGGL((k_sep_stream<DEG, 3>), grid, block, lds, g_stream, *plan, d_zout, d_zin); break;
-    case 4: hipLaunchKernelGGL((k_sep_stream<DEG, 4>), grid, block, lds, g_stream, *plan, d_zout, d_zin); break;
-    default: hipLaunchKernelGGL((k_sep_stream<DEG, 5>), grid, block, lds, g_stream, *plan, d_zout, d_zin); break;
-    }
-    return LAUNCH_CHECK("k_sep_stream");
 }
 
 extern "C" int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin)
 {
-    if (plan->nseg > 0) {
-        switch (plan->degree) {
-        case 0: return launch_stream<0>(plan, d_zout, d_zin);
-        case 1: return launch_stream<1>(plan, d_zout, d_zin);
-        case 3: return launch_stream<3>(plan, d_zout, d_zin);
-        }
-    }
-    if (plan->x_nseg > 0) {
-        if (plan->degree == 1) return launch_sepx<1>(plan, d_zout, d_zin);
-        if (plan->degree == 3) return launch_sepx<3>(plan, d_zout, d_zin);
-    }
-    int nmain = (plan->nblk_y + plan->rb_per_block - 1) / plan->rb_per_block;
-    dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, nmain + plan->n_special);
+    if (plan->x_nseg > 0) return launch_sepx(plan, d_zout, d_zin);
+    /* fallback tile kernel: plans k_sepx cannot take (gather column blocks, source windows taller than the patch) */
+    dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, plan->nblk_y + plan->n_special);
     dim3 block(SEP_BLOCK);
-    const bool pipe = plan->rb_per_block > 1;
-    size_t lds = sizeof(float) * ((pipe ? 2 : 1) * (size_t)plan->patch_elems + (pipe ? 2 * 192 : 0));
-#define LAUNCH_SEP(D) do { if (pipe) hipLaunchKernelGGL((k_sep<D, true>), grid, block, lds, g_stream, *plan, d_zout, d_zin); \
-                           else hipLaunchKernelGGL((k_sep<D, false>), grid, block, lds, g_stream, *plan, d_zout, d_zin); } while (0)
+    size_t lds = sizeof(float) * (size_t)plan->patch_elems;
     switch (plan->degree) {
-    case 0: LAUNCH_SEP(0); break;
-    case 1: LAUNCH_SEP(1); break;
-    case 3: LAUNCH_SEP(3); break;
+    case 0: hipLaunchKernelGGL(k_sep<0>, grid, block, lds, g_stream, *plan, d_zout, d_zin); break;
+    case 1: hipLaunchKernelGGL(k_sep<1>, grid, block, lds, g_stream, *plan, d_zout, d_zin); break;
+    case 3: hipLaunchKernelGGL(k_sep<3>, grid, block, lds, g_stream, *plan, d_zout, d_zin); break;
     default: snprintf(g_err, sizeof(g_err), "ezhip_interp_sep: bad degree %d", plan->degree); return -1;
     }
     return LAUNCH_CHECK("k_sep");

@@ -73,14 +73,12 @@ typedef struct { int s0, n, slot0, by; } ezhip_xstep;
  * record of ITS row): y weights, byte offsets of the 4 taps in the ring (wrap resolved on the host), element offset
  * of the target row to store (a row that is not a main row repeats a neighbouring main row) */
 typedef struct { double w[4]; int t_off[4]; unsigned o_off; int pad[3]; } ezhip_xrow;
-typedef struct { ezhip_xrow r[EZHIP_SEP_ROWS]; } ezhip_xrows;
 
 typedef struct {
     int degree;                       /* 0 nearest, 1 linear, 3 cubic */
     int ni_src, nj_src, ni_dst, nj_dst;
     const ezhip_rowinfo *rowinfo;     /* [nblk_y * EZHIP_SEP_ROWS] */
     int nblk_y;                       /* row-blocks of EZHIP_SEP_ROWS target rows */
-    int rb_per_block;                 /* consecutive row-blocks streamed by one thread block (software pipeline) */
     int wstride, patch_elems;         /* LDS patch row stride and size (floats) of ONE of the two buffers */
     const int    *cidx;               /* [4][ni_dst] 0-based source column of each tap */
     const int    *coff;               /* [4][ni_dst] the same taps as offsets into the block's staged patch */
@@ -104,32 +102,23 @@ typedef struct {
     const float *fill;                /* device scalar written to DEHORS points (may be NULL) */
     const float *polevals;            /* device float[2] = {north, south} pole values of THIS field (ezhip_polevals); scalar mode */
     int need_poles;                   /* some special row uses a scalar pole value */
-    /* ---- row-streaming variant (k_sep_stream): one thread block = one 256-column strip x one segment of
-     * target rows; a loader wave streams the strip's source rows ONCE through an LDS ring (LDS-DMA) while
-     * four compute waves consume them.  nseg == 0: variant not usable for this plan. */
-    int nseg, nch;                    /* segments per strip; 64-column chunks per staged source row */
-    const int *seg_r0;                /* [nseg + 1] target-row boundaries */
-    const int *seg_s0, *seg_sn;       /* [nseg] first source row / number of source rows streamed */
-    const int *seg_sp0;               /* [nseg + 1] range of special rows (indices into special[]) owned by the segment */
-    const ezhip_rowinfo *rowinfo_seg; /* [nj_dst] like rowinfo, jb relative to the SEGMENT's first streamed row */
-    int seg_rows_max;                 /* max target rows of a segment (LDS sizing) */
-    int debug_flags;                  /* development only (EZHIP_DEBUG): bit 0 = suppress the main stores, bit 1 = no loader waits */
+    int debug_flags;                  /* development only (EZHIP_DEBUG knock-outs of k_sepx): 1 no stores, 4 no DMA, 8 no x-pass, 16 no y-pass */
     /* ---- k_sepx (linear / cubic default when x_nseg > 0): one thread block = one 256-column strip x x_rb
      * consecutive row-blocks.  Every source row of the strip is staged (LDS-DMA) and x-interpolated ONCE per
      * thread block; the x-pass results live in a per-thread LDS ring of x_tr source rows (fp64), the y-pass
      * reads its four taps from the ring at a row-uniform slot. */
     int x_nseg, x_rb, x_nvb;          /* segments per strip, row-blocks per segment, valid row-blocks */
-    int x_tr, x_prows, x_mirror;      /* ring rows, patch rows, 1: ring has 3 mirror rows (taps never wrap) */
+    int x_tr, x_prows, x_rows_per_step;   /* ring rows, patch rows, target rows per step (8 or 16) */
+    int batch_fields;                 /* > 1: one launch covers this many fields (blockIdx.z), strides below, polevals[2 f] */
+    size_t batch_in_stride, batch_out_stride;   /* floats between consecutive fields */
     const ezhip_xstep *x_first, *x_cont;   /* [x_nvb] staging step of a row-block when it starts a segment / continues one */
-    const ezhip_xrows *x_rows;        /* [x_nvb] per row-block: the records of its 16 rows */
+    const ezhip_xrow *x_rows;         /* [x_nvb * x_rows_per_step] row records */
 } ezhip_sep_plan;
 
 int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin);
 /* co-resident k_sepx thread blocks on the current device for a given dynamic LDS size (0: unknown) */
-int ezhip_sepx_capacity(int degree, int mirror, size_t lds_bytes);
-size_t ezhip_sepx_lds_bytes(int x_tr, int x_mirror, int x_prows, int wstride);
-#define EZHIP_ST_NSLOT 32            /* LDS ring slots (source rows) of k_sep_stream */
-#define EZHIP_ST_BLOCKS_PER_CU 4
+int ezhip_sepx_capacity(int degree, int rows_per_step, size_t lds_bytes);
+size_t ezhip_sepx_lds_bytes(int x_tr, int rows_per_step, int x_prows, int wstride);
 
 /*
  * Generic per-point plan ("mode B"): arbitrary located coordinates.  Restates the reference's

@@ -55,15 +55,18 @@ def _reset_opts():
     yield
     setopts(3, 1)
     os.environ.pop("EZHIP_FORCE_PTS", None)
+    os.environ.pop("EZHIP_NO_SEPX", None)
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-@pytest.mark.parametrize("force_pts", [0, 1])
+@pytest.mark.parametrize("force_pts", [0, 1, 2])      # 0: default (k_sepx where separable), 1: per-point k_pts, 2: fallback tile kernel k_sep
 def test_ezsint_vs_golden(name, force_pts):
     """host-pointer c_ezsint, both kernel families, all degrees, polar correction on/off"""
     case = CASES[name]
-    if force_pts:
+    if force_pts == 1:
         os.environ["EZHIP_FORCE_PTS"] = "1"
+    if force_pts == 2:
+        os.environ["EZHIP_NO_SEPX"] = "1"
     gdin = hip_define(case["src"]); gdout = hip_define(case["dst"] + (" ", None))
     assert gdin >= 0 and gdout >= 0
     assert ez.ezdefset(gdout, gdin) == 1
@@ -195,3 +198,33 @@ def test_full_size_cfg2_properties():
     assert relerr(got.reshape(mo, no)[sub], want.reshape(mo, no)[sub]).max() <= 2e-7   # <= 1 ulp incl. pole rows and seams
     frac_exact = np.count_nonzero(got == want) / got.size
     assert frac_exact > 0.999, frac_exact
+
+
+@pytest.mark.parametrize("degree", [0, 1, 3])
+@pytest.mark.parametrize("polar", [0, 1])
+def test_batch_launch_equals_field_by_field(degree, polar):
+    """c_ezsint_batch_dev (one k_sepx launch for all fields, blockIdx.z = field, pole values of the
+    whole batch from one k_polevals launch) == c_ezsint_dev field by field, bit for bit."""
+    ni, nj, no, mo = 360, 181, 500, 251
+    gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(no, mo, "L", 72, 72, 0, 0)   # 0.72 deg global target
+    ez.ezdefset(gdout, gdin)
+    setopts(degree, polar)
+    ez.use_stream(torch.cuda.current_stream().cuda_stream)
+    F = 5
+    d_in = torch.stack([torch.from_numpy(ec.synth_field(ni, nj, seed=40 + f)) for f in range(F)]).cuda().contiguous()
+    d_b = torch.full((F, no * mo), -1.0, dtype=torch.float32, device="cuda")
+    d_s = torch.full((F, no * mo), -2.0, dtype=torch.float32, device="cuda")
+    assert ez.ezsint_batch_dev(d_b, d_in, F) == 0
+    for f in range(F):
+        assert ez.ezsint_dev(d_s[f], d_in[f]) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(d_b, d_s)
+    # and against the oracle for one field of the batch
+    O = ol.oracle()
+    gi = ol.grid_define(ni, nj, "G"); go = ol.grid_define(no, mo, "L", (72, 72, 0, 0))
+    gs = O.orc_defset(go, gi)
+    opts = ol.default_opts(); opts.degre_interp = degree; opts.polar_correction = polar
+    want = np.zeros(no * mo, np.float32)
+    zin = d_in[3].cpu().numpy()
+    O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(want), ol.fptr(zin))
+    assert relerr(d_b[3].cpu().numpy(), want).max() <= RTOL
