@@ -162,6 +162,14 @@ def main():
     # one k_sepx launch per step covers the F fields of the batch (+ one k_polevals launch: the pole sums)
     kern_us = ev_ms * 1e3 / args.steps            # average launch-to-launch duration on the stream
     achieved = F * ALGO_BYTES / (kern_us * 1e-6) / 1e9
+    # HBM/fabric traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (FETCH_SIZE x2 on gfx950,
+    # WRITE_SIZE exact: MI355X_MICROARCH.md); the per-field figure measured by tools/pmc_traffic.sh is kept in profiles/
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            traffic = json.load(fh)["traffic_MB_per_field"] * 1e6 * F
+    except Exception:   # noqa: BLE001
+        pass
     if rank == 0:
         total_pts = float(NPTS_OUT) * F * args.steps * world
         out = {
@@ -181,7 +189,7 @@ def main():
                                    f"{F} device-resident fields per step per GPU (sharded by record, no collective)",
                        "fields_per_step_per_gpu": F, "points_per_field": NPTS_OUT},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "k_sepx<3, 16>", "avg_launch_us": kern_us, "fields_per_launch": F,
                          "us_per_field": kern_us / F, "algorithmic_bytes_per_launch": F * ALGO_BYTES},
             "pack": {"compact_float_16bit_GBps": 4.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9, "us_per_field": pack_us,

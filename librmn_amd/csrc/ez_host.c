@@ -1248,7 +1248,6 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
         for (int by = 0; by < nby; by++) if (brow_n[by] > nmax) nmax = brow_n[by];
         wmax = 64 * ((wmax + 63) / 64);      /* k_sepx stages rows with LDS-DMA in whole 64-float chunks */
         p->wstride = wmax; p->patch_elems = wmax * nmax;
-        if (p->patch_elems < 1032) p->patch_elems = 1032;
         p->nblk_y = nby;
     }
     p->rowinfo = (const ezhip_rowinfo *)(sp->dev[14] = upload(rinfo, sizeof(ezhip_rowinfo) * (size_t)nby * EZHIP_SEP_ROWS));

@@ -98,7 +98,7 @@ __device__ double block_sum_256(double v, double *lds4)
  * Z-on-E variant stages the REAL products z(i)*(ax(i+1)-ax(i))) and lane 0 adds them in index order.
  * ~4 cycles per dependent v_add_f32: ~8 us for ni = 4400, hidden because the special blocks that
  * need it are dispatched first and run beside the main blocks.  Result valid in every thread. */
-#define POLE_CHUNK 1024
+#define POLE_CHUNK 8192          /* floats staged per pass: a whole source row up to ni = 8192 (one load latency) */
 __device__ float block_poleval(const float *zrow, int ni, int weighted, const float *ax, float *lds /* 16-byte aligned, >= POLE_CHUNK + 4 floats */)
 {
     const int n = weighted ? ni - 1 : ni;
@@ -106,9 +106,9 @@ __device__ float block_poleval(const float *zrow, int ni, int weighted, const fl
     for (int base = 0; base < n; base += POLE_CHUNK) {
         const int m = min(POLE_CHUNK, n - base);
         __syncthreads();
-        for (int k = threadIdx.x; k < POLE_CHUNK; k += blockDim.x) {
+        for (int k = threadIdx.x; k < m; k += blockDim.x) {
             int i = base + k;
-            lds[k] = k >= m ? 0.0f : (weighted ? zrow[i] * (ax[i + 1] - ax[i]) : zrow[i]);
+            lds[k] = weighted ? zrow[i] * (ax[i + 1] - ax[i]) : zrow[i];
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -354,14 +354,14 @@ __device__ void sep_rowblock_gather(const ezhip_sep_plan &p, RowInfo &ri, float 
 }
 
 /* special target rows of one column block: polar strips, pole rows, fully-outside rows (blockIdx.y indexes
- * p.special).  `patch` is LDS scratch of at least POLE_CHUNK + 1 floats. */
+ * p.special).  Pole values come precomputed (p.polevals). */
 template <int DEG>
-__device__ void sep_special(const ezhip_sep_plan &p, float *__restrict__ zout, const float *__restrict__ zin, float *patch,
+__device__ void sep_special(const ezhip_sep_plan &p, float *__restrict__ zout, const float *__restrict__ zin, int ispecial,
                             int c, int cc, bool cvalid, float fillv)
 {
     const int nis = p.ni_src;
     /* ---- special rows: polar strips, pole rows, fully-outside rows ------------------------- */
-    const ezhip_special_row sr = p.special[blockIdx.y];
+    const ezhip_special_row sr = p.special[ispecial];
     float outv;
     if (sr.kind == 3) {
         outv = fillv;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
             sep_rows_staged<DEG>(p, mine, smem, p.wstride, off0, cw, by * EZHIP_SEP_ROWS, zout, c, cvalid, cdehors, fillv);
         return;
     }
-    sep_special<DEG>(p, zout, zin, smem, c, cc, cvalid, fillv);
+    sep_special<DEG>(p, zout, zin, blockIdx.y, c, cc, cvalid, fillv);
 }
 
 /* ===================================================================================== */
@@ -541,18 +541,31 @@ __global__ __launch_bounds__(SEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 6)
 void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict__ zin)
 {
     extern __shared__ double smem_x[];
-    const int c = blockIdx.x * SEP_BLOCK + threadIdx.x;
+    /* XCD-aware work mapping.  Thread blocks are dealt round-robin to the 8 XCDs in linear launch order, and every
+     * XCD has its own L2.  Here XCD k takes the k-th CONTIGUOUS eighth of the (field, segment, strip) space, so the
+     * strips that share source columns (35 of 192 staged floats) and the segments that share halo rows run on the
+     * same L2: measured fabric reads 56 -> (see profiles) MB per cfg2 field. */
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned nx = gridDim.x, nxy = gridDim.x * gridDim.y, total = nxy * gridDim.z;
+        const unsigned L = bx + nx * by + nxy * bz, full = total & ~7u;
+        if (L < full) {
+            const unsigned w = (L & 7u) * (full >> 3) + (L >> 3);
+            bz = w / nxy; const unsigned r = w - bz * nxy; by = r / nx; bx = r - by * nx;
+        }
+    }
+    const int c = bx * SEP_BLOCK + threadIdx.x;
     const int cc = min(c, p.ni_dst - 1);
     const float fillv = p.fill ? *p.fill : 0.0f;
-    /* blockIdx.z = field of a batch launch (c_ezsint_batch_dev): no ramp-up / drain gap between fields */
-    zin += blockIdx.z * p.batch_in_stride; zout += blockIdx.z * p.batch_out_stride;
-    if (p.polevals) p.polevals += 2 * blockIdx.z;
-    if ((int)blockIdx.y < p.n_special) { sep_special<DEG>(p, zout, zin, (float *)smem_x, c, cc, c < p.ni_dst, fillv); return; }
-    const int seg = blockIdx.y - p.n_special;
+    /* bz = field of a batch launch (c_ezsint_batch_dev): no ramp-up / drain gap between fields */
+    zin += bz * p.batch_in_stride; zout += bz * p.batch_out_stride;
+    if (p.polevals) p.polevals += 2 * bz;
+    if (by < p.n_special) { sep_special<DEG>(p, zout, zin, by, c, cc, c < p.ni_dst, fillv); return; }
+    const int seg = by - p.n_special;
     const int i0 = seg * p.x_rb, i1 = min(i0 + p.x_rb, p.x_nvb);
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nis = p.ni_src, nid = p.ni_dst, trows = p.x_tr, wstr = p.wstride;
-    const int base = p.blk_base[blockIdx.x], W = p.blk_w[blockIdx.x];
+    const int base = p.blk_base[bx], W = p.blk_w[bx];
     double *T = smem_x;                                                         /* T[slot][256 columns] */
     constexpr int SEPX_REC_DW = XR * 16;                                        /* dwords of one step's row records */
     float *rec = (float *)(smem_x + (size_t)trows * SEP_BLOCK);                /* 2 x XR row records of 64 B */
@@ -569,7 +582,7 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
     const double cw[4] = {p.cw[cc], p.cw[nid + cc], p.cw[2 * nid + cc], p.cw[3 * nid + cc]};
     /* y-pass lane geometry: row r of the pair, column l32 + 32 g of the strip */
     const int l32 = lane & 31, rsub = lane >> 5;
-    const int ncol_valid = min(SEP_BLOCK, nid - (int)blockIdx.x * SEP_BLOCK);   /* < 256 only in the last column block */
+    const int ncol_valid = min(SEP_BLOCK, nid - bx * SEP_BLOCK);   /* < 256 only in the last column block */
     const bool full = ncol_valid == SEP_BLOCK;
     /* DEHORS columns (extrapolation targets): bit g of dmask = column l32 + 32 g takes the fill value */
     unsigned dmask = 0;
@@ -582,7 +595,7 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
     }
     const bool any_dehors = __syncthreads_or(dmask != 0) != 0;
     const bool slow = any_dehors || !full || (dbg & 1);      /* block-uniform: predicated y-pass */
-    float *zcol = zout + (size_t)blockIdx.x * SEP_BLOCK + l32;                 /* + row offset (record) + 32 g */
+    float *zcol = zout + (size_t)bx * SEP_BLOCK + l32;                 /* + row offset (record) + 32 g */
 
     auto load_step = [](const ezhip_xstep *tab, int i) {       /* four scalar loads (constant address space) */
         const auto *q = CONSTP(int, tab) + 4 * i;
@@ -639,8 +652,8 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
 extern "C" size_t ezhip_sepx_lds_bytes(int x_tr, int rows_per_step, int x_prows, int wstride)
 {
     size_t b = sizeof(double) * (size_t)x_tr * SEP_BLOCK + sizeof(float) * (2 * 16 * (size_t)rows_per_step + (size_t)x_prows * wstride);
-    const size_t pole = sizeof(float) * (POLE_CHUNK + 1);
-    return b < pole ? pole : b;
+    if (getenv("EZHIP_SEPX_PAD")) b += (size_t)atoi(getenv("EZHIP_SEPX_PAD"));      /* development: occupancy experiments */
+    return b;
 }
 
 #define SEPX_DISPATCH(DEGV, XRV, EXPR) do { \
