@@ -76,8 +76,10 @@ def cpu_baseline(sample_fields=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # defaults: a step is ~1 ms, and the first ~10 launches after an idle period run at ramping clocks (measured
+    # 1.13 ms per step over steps 3-5, 1.00 ms over steps 11-60): warm up well past that, then time 50 steps
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--fields-per-step", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -51,6 +51,9 @@ int   armn_compress_dev(void *d_z, const void *d_words, int ni, int nj, int nbit
  * (fstd98.c:1170-1172).  d_record receives [4 header words][stream]; returns zlng (>0), or -1 when the
  * field is not compressible (d_record then holds the plain 16-bit-slot pack). */
 int   ezhip_pack16_compress_dev(void *d_record, const float *d_field, int ni, int nj, int nbits);
+/* frees the calling thread's grow-only device workspaces (staged operands of the host-pointer entry points,
+ * the compressed stream, the armn_compress scan storage); they are re-created on the next call */
+void  ezhip_pack_release(void);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,26 @@ static float float_of(unsigned k) { unsigned u = (k & 0x80000000u) ? (k & 0x7fff
 
 /* small per-thread device scratch: stats (4 u32) + cf params at +64 B + the reduction partials */
 static __thread void *t_scratch = NULL;
+/* per-thread grow-only device workspaces (slot 0/1: staged operands of the host-pointer entry points and the
+ * compressed stream, slot 2: armn_compress scan storage): hipMalloc + hipFree per call cost more than the kernels
+ * (a 52 MB hipMalloc/hipFree pair is ~0.4 ms and hipFree synchronises the device) */
+static __thread struct { void *p; size_t cap; } t_ws[3];
+static void *ws(int slot, size_t bytes)
+{
+    if (t_ws[slot].cap < bytes) {
+        if (t_ws[slot].p) { ezhip_sync(); ezhip_free(t_ws[slot].p); }
+        size_t cap = bytes + bytes / 4 + 256;
+        t_ws[slot].p = ezhip_malloc(cap);
+        t_ws[slot].cap = t_ws[slot].p ? cap : 0;
+    }
+    return t_ws[slot].p;
+}
+void ezhip_pack_release(void)
+{
+    ezhip_sync();
+    for (int k = 0; k < 3; k++) { ezhip_free(t_ws[k].p); t_ws[k].p = NULL; t_ws[k].cap = 0; }
+}
+
 static void *scratch(void)
 {
     if (!t_scratch) t_scratch = ezhip_malloc(4 * PACKHIP_STATS_WORDS);
@@ -98,8 +118,8 @@ void *compact_float(void *unpackedArrayOfFloat, void *packedHeader, void *packed
      * aliasing on the device by staging one contiguous image [header | stream] */
     int style = ((&hdr[3] == out && offset == 24) || (&hdr[0] == out && offset == 120)) ? 1 : 2;
     size_t lead = (style == 1) ? (size_t)(out - hdr) : 4;       /* words between header start and stream base */
-    float *d_a = (float *)ezhip_malloc(sizeof(float) * (nfl ? nfl : 1));
-    unsigned *d_img = (unsigned *)ezhip_malloc(4 * (lead + span_words + 8));
+    float *d_a = (float *)ws(0, sizeof(float) * (nfl ? nfl : 1));
+    unsigned *d_img = (unsigned *)ws(1, 4 * (lead + span_words + 8));
     void *ret = NULL;
     if (!d_a || !d_img) goto done;
     unsigned *d_hdr = d_img, *d_out = d_img + lead;
@@ -121,7 +141,6 @@ void *compact_float(void *unpackedArrayOfFloat, void *packedHeader, void *packed
     } else fprintf(stderr, "<compact_float> opCode (%d) is not defined\n", opCode);
 done:
     ezhip_sync();
-    ezhip_free(d_a); ezhip_free(d_img);
     return ret;
 }
 
@@ -208,7 +227,7 @@ int compact_integer(void *unpackedArrayOfInt, void *packedHeader, void *packedAr
     unsigned *d_a = NULL, *d_out = NULL;
     if (opCode == 1 || opCode == 3) {
         size_t nin = n ? (n - 1) * (size_t)stride + 1 : 0;
-        d_a = (unsigned *)ezhip_malloc(4 * (nin ? nin : 1));
+        d_a = (unsigned *)ws(0, 4 * (nin ? nin : 1));
         if (!d_a || ezhip_h2d(d_a, unpackedArrayOfInt, 4 * nin)) goto done;
         ci_plan pl;
         if (ci_prepare_pack(&pl, d_a, packedHeader != NULL, n, bitSizeOfPackedToken, stride, opCode)) goto done;
@@ -216,7 +235,7 @@ int compact_integer(void *unpackedArrayOfInt, void *packedHeader, void *packedAr
         rc = pl.E;
         if (pl.E < 1 || pl.E > 32) goto done;
         size_t words = ((size_t)off_set + n * (size_t)pl.E + 31) / 32;
-        d_out = (unsigned *)ezhip_malloc(4 * (words + 4));
+        d_out = (unsigned *)ws(1, 4 * (words + 4));
         rc = 0;
         if (!d_out || ezhip_h2d(d_out, packedArrayOfInt, 4 * words)) goto done;     /* first/last word neighbours survive */
         if (packhip_ci_pack(d_out, d_a, n, pl.E, off_set, stride, pl.with_header, pl.is_signed, pl.minv, pl.shift, pl.positiveMask)) goto done;
@@ -227,7 +246,7 @@ int compact_integer(void *unpackedArrayOfInt, void *packedHeader, void *packedAr
         if (packedHeader) { unsigned *h = (unsigned *)packedHeader; tokenSize = h[0] & 0x3F; shift = (h[0] >> 6) & 0x3F; n = h[1]; minv = h[2]; }
         if (tokenSize < 1 || tokenSize > 32) { fprintf(stderr, "<compact_integer> token size %d not supported on the MI355X path\n", tokenSize); goto done; }
         size_t nin = n ? (n - 1) * (size_t)stride + 1 : 0, words = ((size_t)off_set + n * (size_t)tokenSize + 31) / 32;
-        d_a = (unsigned *)ezhip_malloc(4 * (nin ? nin : 1)); d_out = (unsigned *)ezhip_malloc(4 * (words + 4));
+        d_a = (unsigned *)ws(0, 4 * (nin ? nin : 1)); d_out = (unsigned *)ws(1, 4 * (words + 4));
         if (!d_a || !d_out || ezhip_h2d(d_out, packedArrayOfInt, 4 * words)) goto done;
         if (stride != 1 && ezhip_h2d(d_a, unpackedArrayOfInt, 4 * nin)) goto done;
         unsigned negMask = (opCode < 3) ? 0 : (unsigned)(-(int)(1u << (bitSizeOfPackedToken - 1)));
@@ -237,7 +256,6 @@ int compact_integer(void *unpackedArrayOfInt, void *packedHeader, void *packedAr
     } else fprintf(stderr, "<compact_integer> opCode (%d) is not defined\n", opCode);
 done:
     ezhip_sync();
-    ezhip_free(d_a); ezhip_free(d_out);
     return rc;
 }
 
@@ -261,8 +279,8 @@ int32_t c_float_packer(float *source, int32_t nbits, int32_t *header, int32_t *s
     header[2] = npts;
     header[0] = (int32_t)(0xEFFu << 20);
     header[0] = header[0] | ((nbits - 1) << 16);
-    float *d_src = (float *)ezhip_malloc(4 * (size_t)(npts > 0 ? npts : 1));
-    int *d_stream = (int *)ezhip_malloc(4 * (size_t)((npts + 1) / 2 + 1));
+    float *d_src = (float *)ws(0, 4 * (size_t)(npts > 0 ? npts : 1));
+    int *d_stream = (int *)ws(1, 4 * (size_t)((npts + 1) / 2 + 1));
     unsigned *d_stats = (unsigned *)scratch();
     int rc = -1;
     if (!d_src || !d_stream || !d_stats) goto done;
@@ -292,7 +310,6 @@ int32_t c_float_packer(float *source, int32_t nbits, int32_t *header, int32_t *s
     rc = 0;
 done:
     ezhip_sync();
-    ezhip_free(d_src); ezhip_free(d_stream);
     (void)key_of;
     return rc;
 }
@@ -303,8 +320,8 @@ int32_t c_float_unpacker(float *dest, int32_t *header, int32_t *stream, int32_t 
     if (0xEFF != ((header[0] >> 20) & 0xFFF)) { fprintf(stderr, "<c_float_unpacker> Invalid header\n"); return -1; }
     if (npts != header[2]) { fprintf(stderr, "<c_float_unpacker> Inconsistent number of points (header/request mismatch)\n"); return -1; }
     if (need_device("c_float_unpacker")) return -1;
-    float *d_dest = (float *)ezhip_malloc(4 * (size_t)(npts > 0 ? npts : 1));
-    int *d_stream = (int *)ezhip_malloc(4 * (size_t)((npts + 1) / 2 + 1));
+    float *d_dest = (float *)ws(0, 4 * (size_t)(npts > 0 ? npts : 1));
+    int *d_stream = (int *)ws(1, 4 * (size_t)((npts + 1) / 2 + 1));
     int rc = -1;
     if (!d_dest || !d_stream) goto done;
     if (ezhip_h2d(d_stream, stream, 4 * (size_t)((npts + 1) / 2))) goto done;
@@ -313,7 +330,6 @@ int32_t c_float_unpacker(float *dest, int32_t *header, int32_t *stream, int32_t 
     rc = 0;
 done:
     ezhip_sync();
-    ezhip_free(d_dest); ezhip_free(d_stream);
     return rc;
 }
 
@@ -339,14 +355,13 @@ int armn_compress_dev(void *d_z, const void *d_words, int ni, int nj, int nbits)
     if (g_level == -1) g_level = 1;                                   /* BEST, c_zfstlib.c:92-97 */
     int minimum = (g_level == 0) || ni < 16 || nj < 16 || nbits <= 4; /* :132 */
     size_t n = (size_t)ni * nj;
-    void *d_work = ezhip_malloc(packhip_armn_work_bytes(ni, nj));
+    void *d_work = ws(2, packhip_armn_work_bytes(ni, nj));
     if (!d_work) return -1;
     unsigned long long bits = 0;
     /* the raw stream can exceed the source size for incompressible fields: the caller's buffer holds
      * n/2 + 16 words, the bound checked below uses the exact bit count from the scan */
     size_t z_words = n / 2 + 16;
     int rc = packhip_armn_encode((unsigned *)d_z, z_words, (const unsigned *)d_words, ni, nj, nbits, minimum, d_work, &bits);
-    ezhip_free(d_work);
     if (rc) return -1;
     /* a word is flushed only when a later token crosses its end (stuff macro), the two 16-bit terminator
      * tokens flush every word that holds stream bits: words = ceil(bits / 32) */
@@ -367,7 +382,7 @@ int armn_compress(unsigned char *fld, int ni, int nj, int nk, int nbits, int op_
     if (need_device("armn_compress")) return -1;
     if (nbits > 16 || ni == 1 || nj == 1) { fprintf(stderr, "<armn_compress> Cannot compress if nbits>16 or ni=1 or nj=1. Returning original field\n"); return -1; }
     size_t n = (size_t)ni * nj, words = (n + 1) / 2;
-    unsigned *d_in = (unsigned *)ezhip_malloc(4 * (words + 2)), *d_z = (unsigned *)ezhip_malloc(4 * (n / 2 + 32));
+    unsigned *d_in = (unsigned *)ws(0, 4 * (words + 2)), *d_z = (unsigned *)ws(1, 4 * (n / 2 + 32));
     int zlng = -1;
     if (!d_in || !d_z) goto done;
     if (ezhip_h2d(d_in, fld, 4 * words)) goto done;
@@ -379,7 +394,6 @@ int armn_compress(unsigned char *fld, int ni, int nj, int nk, int nbits, int op_
     }
 done:
     ezhip_sync();
-    ezhip_free(d_in); ezhip_free(d_z);
     return zlng;
 }
 
@@ -390,11 +404,10 @@ int ezhip_pack16_compress_dev(void *d_record, const float *d_field, int ni, int 
     unsigned *rec = (unsigned *)d_record;
     size_t n = (size_t)ni * nj;
     if (!compact_float_dev((void *)d_field, rec, rec + 4, (int)n, nbits + 64 * (nbits > 16 ? nbits : 16), 0, 1, 1, 0, &tag, 2)) return -1;
-    unsigned *d_z = (unsigned *)ezhip_malloc(4 * (n / 2 + 32));
+    unsigned *d_z = (unsigned *)ws(1, 4 * (n / 2 + 32));
     if (!d_z) return -1;
     int zlng = armn_compress_dev(d_z, rec + 4, ni, nj, nbits);
     if (zlng > 0 && ezhip_d2d(rec + 4, d_z, (size_t)zlng)) zlng = -1;
     ezhip_sync();
-    ezhip_free(d_z);
     return zlng;
 }

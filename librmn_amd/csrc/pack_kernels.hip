@@ -464,12 +464,18 @@ __global__ __launch_bounds__(256) void k_armn_scan(unsigned long long *bsum, int
     if (threadIdx.x == 0) *total = carry;
 }
 /* MSB-first bit writer over a zeroed stream: a thread owns a CONTIGUOUS bit range, so only its first and
- * last (partial) words can be shared with neighbours and need atomicOr; interior words are plain stores.
- * (One atomicOr per token cost 1.2 ms per 26 M-token field.) */
-struct BitOut {
-    unsigned *z; size_t w; unsigned cw; int used; bool first_shared;
-    __device__ __forceinline__ void init(unsigned *zz, unsigned long long pos) { z = zz; w = (size_t)(pos >> 5); used = (int)(pos & 31); cw = 0; first_shared = used != 0; }
-    __device__ __forceinline__ void flush_full() { if (first_shared) { atomicOr(&z[w], cw); first_shared = false; } else z[w] = cw; w++; cw = 0; used = 0; }
+ * last (partial) words can be shared with neighbours and need an atomic OR; interior words are plain stores.
+ * (One atomicOr per token cost 1.2 ms per 26 M-token field.)  The stream is either global memory or the
+ * thread block's LDS staging buffer. */
+template <class P, int SCOPE>     /* P: `unsigned *` (global stream) or an LDS pointer (staging buffer) */
+struct BitOutT {
+    P z; size_t w; unsigned cw; int used; bool first_shared;
+    __device__ __forceinline__ void init(P zz, unsigned long long pos) { z = zz; w = (size_t)(pos >> 5); used = (int)(pos & 31); cw = 0; first_shared = used != 0; }
+    __device__ __forceinline__ void flush_full()
+    {
+        if (first_shared) { (void)__hip_atomic_fetch_or(&z[w], cw, __ATOMIC_RELAXED, SCOPE); first_shared = false; } else z[w] = cw;
+        w++; cw = 0; used = 0;
+    }
     __device__ __forceinline__ void put(unsigned tok, int nbits)
     {
         tok &= (nbits == 32) ? 0xFFFFFFFFu : ((1u << nbits) - 1);
@@ -481,16 +487,24 @@ struct BitOut {
             if (used == 32) flush_full();
         }
     }
-    __device__ __forceinline__ void finish() { if (used > 0 && cw) atomicOr(&z[w], cw); }
+    __device__ __forceinline__ void finish() { if (used > 0 && cw) (void)__hip_atomic_fetch_or(&z[w], cw, __ATOMIC_RELAXED, SCOPE); }
 };
+typedef __attribute__((address_space(3))) unsigned *lds_uptr;
 
-/* pass C: emission.  Each thread rescans its SCAN_ITEMS consecutive tiles from the block base and writes them. */
+/* pass C: emission.  Each thread rescans its SCAN_ITEMS consecutive tiles from the block base and writes them.
+ * A thread's bit range is contiguous but the 64 lanes of a wave write ~80 B apart: straight to global memory that is
+ * ~40 cache lines per store instruction (255 us per cfg5 field).  So the block's whole bit range (<= EMIT_LDS_WORDS
+ * words) is assembled in LDS, word-aligned with the global stream, and copied out with coalesced stores; only the
+ * block's first and last words are shared with the neighbouring blocks (atomicOr into the zeroed stream).  Blocks whose
+ * range does not fit (MINIMUM method with wide tokens) write directly. */
+#define EMIT_LDS_WORDS 12288
 template <int PARA>
 __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit(unsigned *z, const unsigned long long *bsum, const unsigned char *nb, const unsigned *gt16,
                                                         const unsigned *w, int ni, int nj, int istep, int ntx, long long ntiles, int nbits,
                                                         unsigned long long body_start)
 {
     __shared__ unsigned long long sh[SCAN_TPB];
+    __shared__ unsigned stage[EMIT_LDS_WORDS];
     const int container = (PARA && nbits >= 15 && *gt16) ? 5 : 4;
     long long base = ((long long)blockIdx.x * SCAN_TPB + threadIdx.x) * SCAN_ITEMS;
     unsigned long long mine = 0;
@@ -506,35 +520,62 @@ __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit(unsigned *z, const unsig
         sh[threadIdx.x] += add;
         __syncthreads();
     }
-    if (base >= ntiles) return;
-    BitOut bo;
-    bo.init(z, body_start + bsum[blockIdx.x] + sh[threadIdx.x] - mine);
-    for (int q = 0; q < SCAN_ITEMS; q++) {
-        long long t = base + q;
-        if (t >= ntiles) break;
-        Tile T = tile_of(t, ni, nj, istep, PARA ? 1 : 0, ntx);
-        unsigned need = nb[t];
-        if (PARA) {
-            bo.put(need, container);
-            if (need) {
-                int width = need == 15 ? 17 : (int)need + 1;
-                for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) bo.put((unsigned)lorenzo(w, ni, T.i0 + m, T.j0 + n), width);
-            }
-        } else {
-            int lo = 65536;
-            for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) lo = min(lo, tokat(w, (size_t)ni * (T.j0 + n) + T.i0 + m));
-            bo.put(need, 4);
-            if (need != 15) bo.put((unsigned)lo, nbits);
-            if (need) {
-                int width = need == 15 ? 16 : (int)need;
-                for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) {
-                    int v = tokat(w, (size_t)ni * (T.j0 + n) + T.i0 + m);
-                    bo.put((unsigned)(need == 15 ? v : v - lo), width);
+    const unsigned long long blk_pos = body_start + bsum[blockIdx.x], blk_bits = sh[SCAN_TPB - 1];
+    const size_t w0 = (size_t)(blk_pos >> 5);                                   /* first global word of the block */
+    const size_t nw = (size_t)((blk_pos + blk_bits + 31) >> 5) - w0;           /* words the block touches */
+    const bool staged = nw <= EMIT_LDS_WORDS;                                   /* block-uniform */
+    if (staged) {
+        for (size_t k = threadIdx.x; k < nw; k += SCAN_TPB) stage[k] = 0;
+        __syncthreads();
+    }
+    if (base < ntiles) {
+        const unsigned long long mypos = blk_pos + sh[threadIdx.x] - mine;
+        auto emit_tiles = [&](auto &bo) {
+            for (int q = 0; q < SCAN_ITEMS; q++) {
+                long long t = base + q;
+                if (t >= ntiles) break;
+                Tile T = tile_of(t, ni, nj, istep, PARA ? 1 : 0, ntx);
+                unsigned need = nb[t];
+                if (PARA) {
+                    bo.put(need, container);
+                    if (need) {
+                        int width = need == 15 ? 17 : (int)need + 1;
+                        for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) bo.put((unsigned)lorenzo(w, ni, T.i0 + m, T.j0 + n), width);
+                    }
+                } else {
+                    int lo = 65536;
+                    for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) lo = min(lo, tokat(w, (size_t)ni * (T.j0 + n) + T.i0 + m));
+                    bo.put(need, 4);
+                    if (need != 15) bo.put((unsigned)lo, nbits);
+                    if (need) {
+                        int width = need == 15 ? 16 : (int)need;
+                        for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) {
+                            int v = tokat(w, (size_t)ni * (T.j0 + n) + T.i0 + m);
+                            bo.put((unsigned)(need == 15 ? v : v - lo), width);
+                        }
+                    }
                 }
             }
+            bo.finish();
+        };
+        if (staged) {
+            BitOutT<lds_uptr, __HIP_MEMORY_SCOPE_WORKGROUP> bo;
+            bo.init((lds_uptr)stage, mypos - ((unsigned long long)w0 << 5));
+            emit_tiles(bo);
+        } else {
+            BitOutT<unsigned *, __HIP_MEMORY_SCOPE_AGENT> bo;
+            bo.init(z, mypos);
+            emit_tiles(bo);
         }
     }
-    bo.finish();
+    if (staged) {
+        __syncthreads();
+        for (size_t k = threadIdx.x; k < nw; k += SCAN_TPB) {
+            const unsigned v = stage[k];
+            if (k == 0 || k == nw - 1) { if (v) atomicOr(&z[w0 + k], v); }     /* shared with the neighbouring blocks */
+            else z[w0 + k] = v;
+        }
+    }
 }
 /* parallelogram prefix: 3-bit container, row 1, column 1 (:712-721) */
 __global__ __launch_bounds__(256) void k_armn_prefix(unsigned *z, const unsigned *w, const unsigned *gt16, int ni, int nj, int nbits, unsigned header)
