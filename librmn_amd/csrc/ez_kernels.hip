@@ -620,16 +620,26 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int i = i0; i < i1; i++) {
         __syncthreads();                                   /* DMA(i) landed in every wave; everyone left y-pass(i-1) */
-        /* ---- x-pass of the new source rows -> ring, two rows per iteration (an odd count repeats the last row) */
+        /* ---- x-pass of the new source rows -> ring: chunks of four rows (16 LDS reads in flight per wait), then
+         * chunks of two; an odd count repeats the last row */
         if (!(dbg & 8)) {
-            int slot = st.slot0;
-            for (int s = 0; s < st.n; s += 2) {
+            int slot = st.slot0, s = 0;
+            auto next_slot = [&](int sl) { sl++; return sl >= trows ? sl - trows : sl; };
+            for (; s + 4 <= st.n; s += 4) {
+                const float *r0 = pcol + s * wstr;
+                const double t0 = xrow<DEG>(r0, cw), t1 = xrow<DEG>(r0 + wstr, cw), t2 = xrow<DEG>(r0 + 2 * wstr, cw), t3 = xrow<DEG>(r0 + 3 * wstr, cw);
+                const int s1 = next_slot(slot), s2 = next_slot(s1), s3 = next_slot(s2);
+                T[slot * SEP_BLOCK + threadIdx.x] = t0; T[s1 * SEP_BLOCK + threadIdx.x] = t1;
+                T[s2 * SEP_BLOCK + threadIdx.x] = t2; T[s3 * SEP_BLOCK + threadIdx.x] = t3;
+                slot = next_slot(s3);
+            }
+            for (; s < st.n; s += 2) {
                 const float *r0 = pcol + s * wstr, *r1 = r0 + (s + 1 < st.n ? wstr : 0);
                 const double t0 = xrow<DEG>(r0, cw), t1 = xrow<DEG>(r1, cw);
-                int slot1 = slot + 1; if (slot1 >= trows) slot1 -= trows;
+                const int s1 = next_slot(slot);
                 T[slot * SEP_BLOCK + threadIdx.x] = t0;
-                if (s + 1 < st.n) T[slot1 * SEP_BLOCK + threadIdx.x] = t1;
-                slot = slot1 + 1; if (slot >= trows) slot -= trows;
+                if (s + 1 < st.n) T[s1 * SEP_BLOCK + threadIdx.x] = t1;
+                slot = next_slot(s1);
             }
         }
         __syncthreads();                                   /* the patch is free again; the ring holds window i for all columns */

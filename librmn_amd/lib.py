@@ -4,7 +4,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "librmn_ez_hip.so")
+_SO = os.environ.get("EZHIP_LIBRARY") or os.path.join(_HERE, "librmn_ez_hip.so")   # EZHIP_LIBRARY: development builds
 _lib = None
 
 

@@ -16,8 +16,10 @@ d_in = torch.stack([base + 0.01 * f for f in range(F)]).contiguous()
 d_out = torch.empty((F, NI_D * NJ_D), dtype=torch.float32, device="cuda")
 
 
-def timeit(fn, reps=5):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, reps=40):
+    for _ in range(10):          # past the clock ramp of the first launches
+        fn()
+    torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(reps):
