@@ -76,10 +76,11 @@ def cpu_baseline(sample_fields=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: a step is ~1 ms, and the first ~10 launches after an idle period run at ramping clocks (measured
-    # 1.13 ms per step over steps 3-5, 1.00 ms over steps 11-60): warm up well past that, then time 50 steps
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    # defaults: a step is ~1 ms.  After an idle period the launch durations run 0.92, 0.95, 1.08, 1.18, 1.13, 1.06 ... ms
+    # and settle at 0.92-0.94 ms only after ~40 launches (power management; profiles/r01_launch_series.txt): warm up
+    # past that, then time 60 steps
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--fields-per-step", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

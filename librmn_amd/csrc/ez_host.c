@@ -1368,6 +1368,31 @@ static int ensure_scratch(ezh_set *s)
     return s->d_scratch ? 0 : -1;
 }
 
+/* in-kernel pole values of k_sepx: per host thread a ring of 4 {values, flags} buffers (consecutive launches of one
+ * thread are stream-ordered; the ring only guards a thread that switches streams between calls) and a launch epoch */
+static __thread struct { float *vals; unsigned *flags; int cap; unsigned epoch; } t_pole;
+static int pole_ring(int nfields, ezhip_sep_plan *p)
+{
+    int nb = ((2 * nfields + 7) / 8) * 8;
+    if (t_pole.cap < nb) {
+        ezhip_sync();
+        ezhip_free(t_pole.vals);
+        size_t bytes = (size_t)4 * nb * (sizeof(float) + sizeof(unsigned));
+        t_pole.vals = (float *)ezhip_malloc(bytes);
+        if (!t_pole.vals) { t_pole.cap = 0; return -1; }
+        if (ezhip_memset(t_pole.vals, 0, bytes) || ezhip_sync()) return -1;
+        t_pole.flags = (unsigned *)(t_pole.vals + (size_t)4 * nb);
+        t_pole.cap = nb; t_pole.epoch = 0;
+    }
+    t_pole.epoch++;
+    if (t_pole.epoch == 0) t_pole.epoch = 1;
+    int slot = (int)(t_pole.epoch & 3);
+    p->pole_blocks = nb; p->pole_epoch = t_pole.epoch;
+    p->pole_vals = t_pole.vals + (size_t)slot * t_pole.cap;
+    p->pole_flags = t_pole.flags + (size_t)slot * t_pole.cap;
+    return 0;
+}
+
 /* one field, device pointers; vector_mode: 0 scalar, 1 = u/v component with synthetic pole rows
  * (prow_n / prow_s device pointers, may be NULL when polar correction is off) */
 static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector_mode, const float *prow_n, const float *prow_s, const float *d_poles_pre);
@@ -1411,7 +1436,10 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
         p.pole_row_n = prow_n; p.pole_row_s = prow_s;
         p.polevals = d_poles_pre ? d_poles_pre : d_poles;
         if (getenv("EZHIP_NO_SEPX")) p.x_nseg = 0;       /* tests: force the fallback tile kernel k_sep */
-        if (p.need_poles && !d_poles_pre && ezhip_polevals(d_poles, d_zin, gi->ni, gi->nj, p.pole_weighted, p.ax)) return -1;
+        if (p.need_poles && !d_poles_pre) {
+            if (p.x_nseg > 0 && !getenv("EZHIP_POLES_PRELAUNCH")) { if (pole_ring(1, &p)) return -1; }    /* k_sepx sums the pole rows itself */
+            else if (ezhip_polevals(d_poles, d_zin, gi->ni, gi->nj, p.pole_weighted, p.ax)) return -1;
+        }
         if (ezhip_interp_sep(&p, d_zout, d_zin)) return -1;
         return ierc;
     }
@@ -1450,7 +1478,24 @@ int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields)
     if (need_device("c_ezsint_batch")) return -1;
     size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
     int rc = 0;
-    /* the pole values (a sequential REAL sum per pole row, ~10 us of one lane) of ALL fields in one launch */
+    /* separable plan without extrapolation fill: ALL fields in one k_sepx launch (no ramp-up / drain gap between
+     * fields; the pole rows are summed by producer blocks of the same launch) */
+    if (s->gdin != s->gdout && nfields > 1 && !(O.polar_correction == 1 && s->extrap) &&
+        (O.degre_interp == DEG_NEAREST || O.degre_interp == DEG_LINEAR || O.degre_interp == DEG_CUBIC) &&
+        choose_mode(s, O.degre_interp, O.polar_correction == 1) == 1 && !getenv("EZHIP_NO_BATCH_LAUNCH") && !getenv("EZHIP_NO_SEPX")) {
+        int degree = O.degre_interp, polar = O.polar_correction == 1;
+        if (ensure_scratch(s) || build_sep_plan(s, degree, 0, polar)) return -1;
+        ezhip_sep_plan p = s->sep[degree == DEG_CUBIC ? 2 : degree][0].p;
+        if (p.x_nseg > 0) {
+            ezh_grid *gi = &G[s->gdin];
+            p.fill = s->d_scratch;
+            if (p.pole_weighted) { if (ensure_grid_dev(gi)) return -1; p.ax = gi->d_ax; }
+            if (p.need_poles && pole_ring(nfields, &p)) return -1;
+            p.batch_fields = nfields; p.batch_in_stride = nin; p.batch_out_stride = nout;
+            return ezhip_interp_sep(&p, d_zout, d_zin) ? -1 : 0;
+        }
+    }
+    /* field by field; the pole values (a sequential REAL sum per pole row) of ALL fields from one k_polevals launch */
     float *d_poles_all = NULL;
     if (s->gdin != s->gdout && O.polar_correction == 1 && !s->extrap && nfields > 1) {
         ezh_grid *gi = &G[s->gdin];
@@ -1463,22 +1508,6 @@ int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields)
         if (weighted && ensure_grid_dev(gi)) return -1;
         if (s->d_poles_batch && ezhip_polevals_batch(s->d_poles_batch, d_zin, nin, nfields, gi->ni, gi->nj, weighted, gi->d_ax) == 0)
             d_poles_all = s->d_poles_batch;
-    }
-    /* separable plan without extrapolation fill: ALL fields in one k_sepx launch (blockIdx.z = field) */
-    if (s->gdin != s->gdout && nfields > 1 && nfields <= 65535 && !(O.polar_correction == 1 && s->extrap) &&
-        (O.degre_interp == DEG_NEAREST || O.degre_interp == DEG_LINEAR || O.degre_interp == DEG_CUBIC) &&
-        choose_mode(s, O.degre_interp, O.polar_correction == 1) == 1 && !getenv("EZHIP_NO_BATCH_LAUNCH") && !getenv("EZHIP_NO_SEPX")) {
-        int degree = O.degre_interp, polar = O.polar_correction == 1;
-        if (ensure_scratch(s) || build_sep_plan(s, degree, 0, polar)) return -1;
-        ezhip_sep_plan p = s->sep[degree == DEG_CUBIC ? 2 : degree][0].p;
-        if (p.x_nseg > 0 && (!p.need_poles || d_poles_all)) {
-            ezh_grid *gi = &G[s->gdin];
-            p.fill = s->d_scratch;
-            if (p.pole_weighted) { if (ensure_grid_dev(gi)) return -1; p.ax = gi->d_ax; }
-            p.polevals = d_poles_all;
-            p.batch_fields = nfields; p.batch_in_stride = nin; p.batch_out_stride = nout;
-            return ezhip_interp_sep(&p, d_zout, d_zin) ? -1 : 0;
-        }
     }
     for (int f = 0; f < nfields; f++) {
         int r = (s->gdin == s->gdout) ? (ezhip_d2d(d_zout + f * nout, d_zin + f * nin, sizeof(float) * nin), 1)

@@ -98,13 +98,14 @@ __device__ double block_sum_256(double v, double *lds4)
  * Z-on-E variant stages the REAL products z(i)*(ax(i+1)-ax(i))) and lane 0 adds them in index order.
  * ~4 cycles per dependent v_add_f32: ~8 us for ni = 4400, hidden because the special blocks that
  * need it are dispatched first and run beside the main blocks.  Result valid in every thread. */
-#define POLE_CHUNK 8192          /* floats staged per pass: a whole source row up to ni = 8192 (one load latency) */
-__device__ float block_poleval(const float *zrow, int ni, int weighted, const float *ax, float *lds /* 16-byte aligned, >= POLE_CHUNK + 4 floats */)
+#define POLE_CHUNK 8192          /* floats staged per pass by k_polevals: a whole source row up to ni = 8192 (one load latency) */
+/* lds: 16-byte aligned, chunk + 4 floats; chunk a multiple of 4 */
+__device__ float block_poleval(const float *zrow, int ni, int weighted, const float *ax, float *lds, const int chunk)
 {
     const int n = weighted ? ni - 1 : ni;
     float s = 0.0f;
-    for (int base = 0; base < n; base += POLE_CHUNK) {
-        const int m = min(POLE_CHUNK, n - base);
+    for (int base = 0; base < n; base += chunk) {
+        const int m = min(chunk, n - base);
         __syncthreads();
         for (int k = threadIdx.x; k < m; k += blockDim.x) {
             int i = base + k;
@@ -130,10 +131,10 @@ __device__ float block_poleval(const float *zrow, int ni, int weighted, const fl
     if (threadIdx.x == 0) {
         if (weighted) { float span = ax[ni - 1] - ax[0]; if (span != 0.0f) s = s / span; }
         else s = s / (1.0f * (float)ni);
-        lds[POLE_CHUNK] = s;
+        lds[chunk] = s;
     }
     __syncthreads();
-    s = lds[POLE_CHUNK];
+    s = lds[chunk];
     __syncthreads();
     return s;
 }
@@ -371,8 +372,8 @@ __device__ void sep_special(const ezhip_sep_plan &p, float *__restrict__ zout, c
             for (int k = 0; k < 4; k++) { need_n |= (sr.tap[k] == EZ_ROW_POLE_N); need_s |= (sr.tap[k] == EZ_ROW_POLE_S); }
         float pole_n = 0.f, pole_s = 0.f;
         if (!p.vector_mode) {       /* pole values: precomputed once per field by k_polevals (a sequential REAL sum: ~10 us) */
-            if (need_n) pole_n = p.polevals[0];
-            if (need_s) pole_s = p.polevals[1];
+            if (need_n) pole_n = __hip_atomic_load(&p.polevals[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (need_s) pole_s = __hip_atomic_load(&p.polevals[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (sr.kind == 1) outv = pole_n;
         else if (sr.kind == 2) outv = pole_s;
@@ -545,23 +546,64 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
      * XCD has its own L2.  Here XCD k takes the k-th CONTIGUOUS eighth of the (field, segment, strip) space, so the
      * strips that share source columns (35 of 192 staged floats) and the segments that share halo rows run on the
      * same L2: measured fabric reads 56 -> (see profiles) MB per cfg2 field. */
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    {
-        const unsigned nx = gridDim.x, nxy = gridDim.x * gridDim.y, total = nxy * gridDim.z;
-        const unsigned L = bx + nx * by + nxy * bz, full = total & ~7u;
-        if (L < full) {
-            const unsigned w = (L & 7u) * (full >> 3) + (L >> 3);
-            bz = w / nxy; const unsigned r = w - bz * nxy; by = r / nx; bx = r - by * nx;
+    /* 1-D launch: [pole_blocks producers][work items].  pole_blocks is a multiple of 8, so a work item's XCD is
+     * (its index & 7) as well. */
+    const unsigned L = blockIdx.x, P = p.pole_blocks;
+    if (L < P) {
+        /* producer of one pole value (ez_calcpoleval: a SEQUENTIAL REAL sum, ~20 us on one lane): dispatched first,
+         * published with a release store of the launch epoch; the special-row blocks of the field (last in its
+         * work order) acquire it.  Replaces a separate k_polevals launch (3 % of a cfg2 batch). */
+        const unsigned f = L >> 1, which = L & 1;
+        if ((int)f >= (p.batch_fields > 1 ? p.batch_fields : 1)) return;
+        const float *zf = zin + f * p.batch_in_stride;
+        const float *row = which == 0 ? zf + (size_t)(p.nj_src - 1) * p.ni_src : zf;
+        const int chunk = (int)((p.x_lds_bytes / sizeof(float) - 4) & ~(size_t)3);
+        const float v = block_poleval(row, p.ni_src, p.pole_weighted, p.ax, (float *)smem_x, chunk);
+        if (threadIdx.x == 0) {
+            p.pole_vals[L] = v;
+            __hip_atomic_store(&p.pole_flags[L], p.pole_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
+        return;
+    }
+    int bx, by, bz;
+    {
+        const unsigned nx = p.x_nbx, nxy = nx * (unsigned)(p.x_nseg + p.n_special);
+        const unsigned total = nxy * (unsigned)(p.batch_fields > 1 ? p.batch_fields : 1);
+        const unsigned M = L - P, full = total & ~7u;
+        const unsigned w = M < full ? (M & 7u) * (full >> 3) + (M >> 3) : M;
+        bz = w / nxy; const unsigned r = w - bz * nxy; by = r / nx; bx = r - by * nx;
     }
     const int c = bx * SEP_BLOCK + threadIdx.x;
     const int cc = min(c, p.ni_dst - 1);
     const float fillv = p.fill ? *p.fill : 0.0f;
     /* bz = field of a batch launch (c_ezsint_batch_dev): no ramp-up / drain gap between fields */
     zin += bz * p.batch_in_stride; zout += bz * p.batch_out_stride;
-    if (p.polevals) p.polevals += 2 * bz;
-    if (by < p.n_special) { sep_special<DEG>(p, zout, zin, by, c, cc, c < p.ni_dst, fillv); return; }
-    const int seg = by - p.n_special;
+    /* special rows sit in the MIDDLE of the field's work order: their gathers are latency-bound (tens of us per block),
+     * so they must overlap main blocks (last in the order they became an exposed tail: +6 us per field), and by then
+     * the pole producers have long finished */
+    const int sp0 = p.x_nseg >> 1;
+    if (by >= sp0 && by < sp0 + p.n_special) {
+        if (P) {
+            p.polevals = p.pole_vals + 2 * bz;
+            if (p.need_poles) {
+                /* RELAXED agent-scope loads (sc1: served by the coherence point, never by a stale L1/L2 line), not
+                 * acquire: on the 8-XCD part an agent-scope acquire is `buffer_inv sc1`, which drops the XCD's
+                 * non-local L2 lines -- 232 special-row blocks per field doing that cost +6 us per field.  The flag
+                 * load, the branch on it and the (equally cache-bypassing) value loads in sep_special issue in order. */
+                for (int k = 0; k < 2; k++) {
+                    int spins = 0;
+                    while (__hip_atomic_load(&p.pole_flags[2 * bz + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.pole_epoch) {
+                        __builtin_amdgcn_s_sleep(32);
+                        if (++spins > (1 << 22)) break;  /* seconds: never in a healthy launch; do not hang the device */
+                    }
+                }
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            }
+        } else if (p.polevals) p.polevals += 2 * bz;
+        sep_special<DEG>(p, zout, zin, by - sp0, c, cc, c < p.ni_dst, fillv);
+        return;
+    }
+    const int seg = by < sp0 ? by : by - p.n_special;
     const int i0 = seg * p.x_rb, i1 = min(i0 + p.x_rb, p.x_nvb);
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nis = p.ni_src, nid = p.ni_dst, trows = p.x_tr, wstr = p.wstride;
@@ -687,8 +729,16 @@ extern "C" int ezhip_sepx_capacity(int degree, int rows_per_step, size_t lds_byt
 
 static int launch_sepx(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin)
 {
-    dim3 grid((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK, plan->x_nseg + plan->n_special, plan->batch_fields > 1 ? plan->batch_fields : 1), block(SEP_BLOCK);
+    ezhip_sep_plan pl = *plan;
+    plan = &pl;
+    const size_t nf = plan->batch_fields > 1 ? plan->batch_fields : 1;
+    pl.x_nbx = (plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK;
+    const size_t nblocks = (size_t)pl.pole_blocks + (size_t)pl.x_nbx * (size_t)(plan->x_nseg + plan->n_special) * nf;
+    if (nblocks >= ((size_t)1 << 31)) { snprintf(g_err, sizeof(g_err), "k_sepx: batch too large for one launch"); return -1; }
+    dim3 grid((unsigned)nblocks), block(SEP_BLOCK);
     size_t lds = ezhip_sepx_lds_bytes(plan->x_tr, plan->x_rows_per_step, plan->x_prows, plan->wstride);
+    if (pl.pole_blocks && lds < 4 * 1028) lds = 4 * 1028;          /* the pole producers stage >= 1024 floats per pass */
+    pl.x_lds_bytes = lds;
     if (lds > 64 * 1024) {        /* tall windows on wide strips: raise the per-kernel dynamic LDS limit */
         hipError_t e = hipSuccess;
         SEPX_DISPATCH(plan->degree, plan->x_rows_per_step,
@@ -1061,7 +1111,7 @@ __global__ __launch_bounds__(256) void k_polevals(float *out2, const float *zin,
     __shared__ __attribute__((aligned(16))) float lds4[POLE_CHUNK + 4];
     zin += blockIdx.y * field_stride;
     const float *row = blockIdx.x == 0 ? zin + (size_t)(nj - 1) * ni : zin;
-    float v = block_poleval(row, ni, weighted, ax, lds4);
+    float v = block_poleval(row, ni, weighted, ax, lds4, POLE_CHUNK);
     if (threadIdx.x == 0) out2[2 * blockIdx.y + blockIdx.x] = v;
 }
 /* d_out[2 f] = north, d_out[2 f + 1] = south pole value of field f (fields field_stride floats apart) */

@@ -109,7 +109,12 @@ typedef struct {
      * reads its four taps from the ring at a row-uniform slot. */
     int x_nseg, x_rb, x_nvb;          /* segments per strip, row-blocks per segment, valid row-blocks */
     int x_tr, x_prows, x_rows_per_step;   /* ring rows, patch rows, target rows per step (8 or 16) */
-    int batch_fields;                 /* > 1: one launch covers this many fields (blockIdx.z), strides below, polevals[2 f] */
+    int batch_fields;                 /* > 1: one launch covers this many fields, strides below, polevals[2 f] */
+    /* in-kernel pole values (k_sepx): pole_blocks = 2 * fields rounded up to a multiple of 8 producer blocks (0: pole
+     * values come precomputed in `polevals`), published in pole_vals[2 f + {0 north, 1 south}] with pole_flags[] = epoch */
+    int pole_blocks; unsigned pole_epoch;
+    float *pole_vals; unsigned *pole_flags;
+    int x_nbx; size_t x_lds_bytes;    /* set by the launcher: column strips, dynamic LDS bytes */
     size_t batch_in_stride, batch_out_stride;   /* floats between consecutive fields */
     const ezhip_xstep *x_first, *x_cont;   /* [x_nvb] staging step of a row-block when it starts a segment / continues one */
     const ezhip_xrow *x_rows;         /* [x_nvb * x_rows_per_step] row records */
