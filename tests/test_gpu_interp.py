@@ -228,3 +228,70 @@ def test_batch_launch_equals_field_by_field(degree, polar):
     zin = d_in[3].cpu().numpy()
     O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(want), ol.fptr(zin))
     assert relerr(d_b[3].cpu().numpy(), want).max() <= RTOL
+
+
+def _zl_axes(ni, nj, lon0, lon1, lat0, lat1, seed):
+    """irregular (stretched) lat-lon axes for a 'Z' grid on an 'L' reference"""
+    u = ec.hash_uniform(seed, ni + nj).astype(np.float64)
+    fx = np.cumsum(1.0 + 0.6 * (u[:ni] - 0.5)); fx = (fx - fx[0]) / (fx[-1] - fx[0])
+    fy = np.cumsum(1.0 + 0.6 * (u[ni:] - 0.5)); fy = (fy - fy[0]) / (fy[-1] - fy[0])
+    return (lon0 + (lon1 - lon0) * fx).astype(np.float32), (lat0 + (lat1 - lat0) * fy).astype(np.float32)
+
+
+# (name, source (ni, nj, grtyp, ig, grref, axes), target (...)) -- shapes the small golden cases do not reach:
+# several 256-column strips with a partial last one, many 16-row blocks, ring wrap over many steps, strips that
+# cross the longitude seam, up- and down-sampling, irregular source and target axes, regional sources (DEHORS fill)
+SEPX_SHAPES = [
+    ("G_up",        (360, 180, "G", (0, 0, 0, 0)),                 (777, 391, "L", (46, 46, 0, 0))),          # 1.64 / 2.2 x up-sampling, global
+    ("G_down",      (720, 360, "G", (0, 0, 0, 0)),                 (300, 151, "L", (120, 120, 0, 0))),        # 2.4 x down-sampling
+    ("L_up_offset", (400, 201, "L", (90, 90, 0, 0)),               (1030, 520, "L", (30, 30, 1200, 5000))),   # target window 12S..168N?? clipped by the L definition
+    ("Zregional",   (300, 200, "Z", (100, 100, 0, 0), "L", lambda ni, nj: _zl_axes(ni, nj, 200.0, 300.0, 10.0, 70.0, 5)),
+                    (600, 330, "L", (20, 20, 9500, 19000))),                                                   # regional Z source: DEHORS columns and rows
+    ("Zglobal_tgt", (360, 180, "G", (0, 0, 0, 0)),
+                    (500, 300, "Z", (100, 100, 0, 0), "L", lambda ni, nj: _zl_axes(ni, nj, 0.0, 359.0, -88.0, 88.0, 6))),   # irregular target axes
+]
+
+
+@pytest.mark.parametrize("shape", SEPX_SHAPES, ids=[s[0] for s in SEPX_SHAPES])
+@pytest.mark.parametrize("batch", [1, 3])
+def test_sepx_shapes_vs_oracle(shape, batch):
+    """k_sepx (default separable kernel) on mid-size shapes against the CPU oracle, all degrees, polar on/off,
+    single-field and batch launches; nearest and bilinear bit-exact, bicubic <= 1e-5 relative."""
+    name, src, dst = shape
+
+    def define(spec, hip):
+        ni, nj, grtyp, ig = spec[:4]
+        grref = spec[4] if len(spec) > 4 else " "
+        axes = spec[5](ni, nj) if len(spec) > 5 else (None, None)
+        if hip:
+            if grtyp == "Z":
+                return ez.ezgdef_fmem(ni, nj, grtyp, grref, ig[0], ig[1], ig[2], ig[3], axes[0], axes[1])
+            return ez.ezqkdef(ni, nj, grtyp, ig[0], ig[1], ig[2], ig[3])
+        return ol.grid_define(ni, nj, grtyp, ig, grref, axes[0], axes[1])
+
+    gdin, gdout = define(src, True), define(dst, True)
+    assert gdin >= 0 and gdout >= 0
+    assert ez.ezdefset(gdout, gdin) == 1
+    O = ol.oracle()
+    gs = O.orc_defset(define(dst, False), define(src, False))
+    ni, nj = src[:2]; no, mo = dst[:2]
+    ez.use_stream(torch.cuda.current_stream().cuda_stream)
+    fields = [ec.synth_field(ni, nj, seed=70 + f) for f in range(batch)]
+    d_in = torch.stack([torch.from_numpy(f) for f in fields]).cuda().contiguous()
+    for degree in (0, 1, 3):
+        for polar in (1, 0):
+            setopts(degree, polar)
+            mode = ez.set_mode()         # 1 separable (k_sepx); 2 per point (e.g. ez_irgdint_3_nw: regional irregular cubic)
+            d_out = torch.full((batch, no * mo), -7.0, dtype=torch.float32, device="cuda")
+            rc = ez.ezsint_batch_dev(d_out, d_in, batch) if batch > 1 else ez.ezsint_dev(d_out[0], d_in[0])
+            assert rc in (0, 2)
+            torch.cuda.synchronize()
+            got = d_out.cpu().numpy()
+            opts = ol.default_opts(); opts.degre_interp = degree; opts.polar_correction = polar
+            for f in range(batch):
+                want = np.zeros(no * mo, np.float32)
+                O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(want), ol.fptr(fields[f]))
+                err = relerr(got[f], want)
+                assert err.max() <= RTOL, (name, degree, polar, mode, f, float(err.max()), int(np.argmax(err)))
+                if degree in (0, 1) and not polar:
+                    assert np.array_equal(got[f].view(np.uint32), want.view(np.uint32)), (name, degree, polar, f)
