@@ -74,8 +74,8 @@ void *compact_float_dev(void *d_unpacked, void *d_header, void *d_packed, int el
     if (opCode == 1) {
         unsigned n = (unsigned)elementCount;
         if (header_style == 2 && n > 268435455u) { fprintf(stderr, "<compact_float> element count overflow in xxpack header\n"); return NULL; }
-        if (packhip_stats(d_stats, d_unpacked, n, stride, 0, hasMissing, tag)) return NULL;
-        if (packhip_cf_header(d_pp, (unsigned *)d_header, d_stats, n, bs, header_style, hasMissing)) return NULL;
+        int npart = packhip_stats_partials(d_stats, d_unpacked, n, stride, 0, hasMissing, tag);
+        if (npart < 0 || packhip_cf_header(d_pp, (unsigned *)d_header, d_stats, npart, n, bs, header_style, hasMissing)) return NULL;
         if (packhip_cf_pack((unsigned *)d_packed, (const float *)d_unpacked, n, eff, offset, stride, d_pp, hasMissing, tag)) return NULL;
         return d_packed;
     }

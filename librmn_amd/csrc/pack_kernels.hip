@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "packhip_shim.h"
 
 #pragma clang fp contract(off)
@@ -40,13 +41,14 @@ __global__ __launch_bounds__(256) void k_stats(unsigned *stats, const unsigned *
         else if (KIND == 1) k = raw; else k = raw ^ 0x80000000u;                                                   \
         if (!skip) { kmin = min(kmin, k); kmax = max(kmax, k); kor |= raw; } } while (0)
     size_t i0 = 0;
-    if (stride == 1 && ((uintptr_t)a & 15) == 0) {          /* 16 B per lane, two loads in flight */
+    if (stride == 1 && ((uintptr_t)a & 15) == 0) {          /* 16 B per lane, four loads in flight */
         const uint4 *a4 = (const uint4 *)a;
         size_t n4 = n / 4, step = (size_t)gridDim.x * 256;
         size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-        for (; i + step < n4; i += 2 * step) {
-            uint4 u = a4[i], v = a4[i + step];
+        for (; i + 3 * step < n4; i += 4 * step) {
+            uint4 u = a4[i], v = a4[i + step], x = a4[i + 2 * step], y = a4[i + 3 * step];
             STAT1(u.x); STAT1(u.y); STAT1(u.z); STAT1(u.w); STAT1(v.x); STAT1(v.y); STAT1(v.z); STAT1(v.w);
+            STAT1(x.x); STAT1(x.y); STAT1(x.z); STAT1(x.w); STAT1(y.x); STAT1(y.y); STAT1(y.z); STAT1(y.w);
         }
         for (; i < n4; i += step) { uint4 u = a4[i]; STAT1(u.x); STAT1(u.y); STAT1(u.z); STAT1(u.w); }
         i0 = n4 * 4;
@@ -72,7 +74,8 @@ __global__ __launch_bounds__(256) void k_stats(unsigned *stats, const unsigned *
     }
 }
 
-__global__ __launch_bounds__(256) void k_stats_final(unsigned *stats, int nb)
+/* reduction of the per-block partial triples by one block of 256 threads; result in stats[0..2] */
+__device__ __forceinline__ void stats_reduce_partials(unsigned *stats, int nb)
 {
     unsigned kmin = 0xffffffffu, kmax = 0u, kor = 0u;
     const unsigned *p = stats + PACKHIP_STATS_PARTIALS;
@@ -91,24 +94,36 @@ __global__ __launch_bounds__(256) void k_stats_final(unsigned *stats, int nb)
         stats[2] = sh[2][0] | sh[2][1] | sh[2][2] | sh[2][3];
         stats[3] = 0;
     }
+    __syncthreads();
 }
+__global__ __launch_bounds__(256) void k_stats_final(unsigned *stats, int nb) { stats_reduce_partials(stats, nb); }
 
 /* d_stats: PACKHIP_STATS_WORDS u32 of device scratch; result in d_stats[0..2] */
-extern "C" int packhip_stats(unsigned *d_stats, const void *d_a, size_t n, int stride, int kind, int has_missing, float tag)
+static int stats_blocks(size_t n) { int nb = (int)((n + 4095) / 4096); if (nb > PACKHIP_STATS_MAXBLK) nb = PACKHIP_STATS_MAXBLK; return nb < 1 ? 1 : nb; }
+/* per-block partials only; returns the number of partials (the consumer reduces them: k_cf_header) or -1 */
+extern "C" int packhip_stats_partials(unsigned *d_stats, const void *d_a, size_t n, int stride, int kind, int has_missing, float tag)
 {
-    int nb = (int)((n + 2047) / 2048); if (nb > PACKHIP_STATS_MAXBLK) nb = PACKHIP_STATS_MAXBLK; if (nb < 1) nb = 1;
+    int nb = stats_blocks(n);
     if (kind == 0) hipLaunchKernelGGL(k_stats<0>, dim3(nb), dim3(256), 0, STREAM, d_stats, (const unsigned *)d_a, n, stride, has_missing, tag);
     else if (kind == 1) hipLaunchKernelGGL(k_stats<1>, dim3(nb), dim3(256), 0, STREAM, d_stats, (const unsigned *)d_a, n, stride, 0, 0.f);
     else hipLaunchKernelGGL(k_stats<2>, dim3(nb), dim3(256), 0, STREAM, d_stats, (const unsigned *)d_a, n, stride, 0, 0.f);
+    return chk("k_stats") ? -1 : nb;
+}
+extern "C" int packhip_stats(unsigned *d_stats, const void *d_a, size_t n, int stride, int kind, int has_missing, float tag)
+{
+    int nb = packhip_stats_partials(d_stats, d_a, n, stride, kind, has_missing, tag);
+    if (nb < 0) return -1;
     hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(256), 0, STREAM, d_stats, nb);
-    return chk("k_stats");
+    return chk("k_stats_final");
 }
 
 /* ------------------------------------------------------------------------------------------ */
 /* compact_float: header (compact.tmplc:210-290) on one lane, then the token stream               */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void k_cf_header(packhip_cf_params *pp, unsigned *hdr, const unsigned *stats, unsigned n, int bs, int style, int has_missing)
+__global__ __launch_bounds__(256) void k_cf_header(packhip_cf_params *pp, unsigned *hdr, unsigned *stats, int npartials, unsigned n, int bs, int style, int has_missing)
 {
+    if (npartials > 0) stats_reduce_partials(stats, npartials);     /* fused final reduction of k_stats (one launch less) */
+    if (threadIdx.x != 0) return;
     double minF = (double)key2f(stats[0]), maxF = (double)key2f(stats[1]);
     unsigned missingToken = (bs != 32) ? ~(0xFFFFFFFFu << bs) : ~0u;
     int too_large = (maxF > 1.0e+38) || (minF < -1.0e+38);
@@ -195,9 +210,9 @@ __global__ __launch_bounds__(256) void k_cf_pack16(uint4 *out, const float4 *a, 
     out[k] = o;
 }
 
-extern "C" int packhip_cf_header(packhip_cf_params *d_pp, unsigned *d_hdr, const unsigned *d_stats, unsigned n, int bs, int style, int has_missing)
+extern "C" int packhip_cf_header(packhip_cf_params *d_pp, unsigned *d_hdr, unsigned *d_stats, int npartials, unsigned n, int bs, int style, int has_missing)
 {
-    hipLaunchKernelGGL(k_cf_header, dim3(1), dim3(1), 0, STREAM, d_pp, d_hdr, d_stats, n, bs, style, has_missing);
+    hipLaunchKernelGGL(k_cf_header, dim3(1), dim3(256), 0, STREAM, d_pp, d_hdr, d_stats, npartials, n, bs, style, has_missing);
     return chk("k_cf_header");
 }
 
@@ -577,6 +592,86 @@ __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit(unsigned *z, const unsig
         }
     }
 }
+/* pass C for the PARALLELOGRAM method, one LANE PER TOKEN.  The per-thread sequential writer above spends ~80
+ * instructions per token (Lorenzo difference, variable-width put loop) with every lane walking its own 72 tokens.
+ * Here phase 0 turns the per-thread scan into per-tile bit offsets (LDS), then every lane takes one token slot
+ * (tile, row, column), computes difference, width and absolute bit position in closed form and ORs its bits into the
+ * block's LDS image of the stream (ds_or_b32, at most two words); the image is copied out with coalesced stores. */
+#define TOK_LDS_WORDS 10240        /* >= 2048 tiles x (5 + 9 x 17) bits + alignment */
+__global__ __launch_bounds__(SCAN_TPB) void k_armn_emit_tok(unsigned *z, const unsigned long long *bsum, const unsigned char *nb, const unsigned *gt16,
+                                                            const unsigned *w, int ni, int nj, int ntx, long long ntiles, int nbits,
+                                                            unsigned long long body_start)
+{
+    __shared__ unsigned long long sh[SCAN_TPB];
+    __shared__ unsigned stage[TOK_LDS_WORDS];
+    __shared__ unsigned tmeta[SCAN_TPB * SCAN_ITEMS];      /* bit offset of the tile in the block (28 bits) | need << 28 */
+    const int container = (nbits >= 15 && *gt16) ? 5 : 4;
+    const long long tbase = (long long)blockIdx.x * SCAN_TPB * SCAN_ITEMS;
+    const long long base = tbase + (long long)threadIdx.x * SCAN_ITEMS;
+    unsigned long long mine = 0;
+    unsigned lbits[SCAN_ITEMS];
+    for (int q = 0; q < SCAN_ITEMS; q++) {
+        long long t = base + q;
+        lbits[q] = 0;
+        if (t < ntiles) { Tile T = tile_of(t, ni, nj, 3, 1, ntx); lbits[q] = tile_bits(1, nb[t], T.m * T.n, container, nbits); }
+        mine += lbits[q];
+    }
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < SCAN_TPB; off <<= 1) {
+        unsigned long long add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    const unsigned long long blk_pos = body_start + bsum[blockIdx.x], blk_bits = sh[SCAN_TPB - 1];
+    const size_t w0 = (size_t)(blk_pos >> 5);
+    const size_t nw = (size_t)((blk_pos + blk_bits + 31) >> 5) - w0;           /* <= TOK_LDS_WORDS by construction */
+    {
+        unsigned off = (unsigned)(blk_pos & 31) + (unsigned)(sh[threadIdx.x] - mine);
+        for (int q = 0; q < SCAN_ITEMS; q++) {
+            long long t = base + q;
+            tmeta[threadIdx.x * SCAN_ITEMS + q] = off | ((t < ntiles ? (unsigned)nb[t] : 0u) << 28);
+            off += lbits[q];
+        }
+    }
+    for (size_t k = threadIdx.x; k < nw; k += SCAN_TPB) stage[k] = 0;
+    __syncthreads();
+    const int ntl = (int)min((long long)(SCAN_TPB * SCAN_ITEMS), ntiles - tbase);
+    for (int s = threadIdx.x; s < ntl * 9; s += SCAN_TPB) {
+        const int tl = s / 9, pos = s - 9 * tl;
+        const unsigned meta = tmeta[tl], need = meta >> 28;
+        unsigned bitpos = meta & 0x0FFFFFFFu;
+        unsigned val; int width;
+        if (pos == 0) {                      /* the tile's container field, then (below) its first token */
+            const unsigned wi = bitpos >> 5; const int sh_ = (int)(bitpos & 31);
+            const unsigned long long v = (unsigned long long)need << (64 - container - sh_);
+            if ((unsigned)(v >> 32)) atomicOr(&stage[wi], (unsigned)(v >> 32));
+            if ((unsigned)v) atomicOr(&stage[wi + 1], (unsigned)v);
+        }
+        if (!need) continue;
+        const unsigned t = (unsigned)(tbase + tl);
+        const unsigned ty = t / (unsigned)ntx, tx = t - ty * (unsigned)ntx;
+        const int i0 = 1 + (int)tx * 3, j0 = 1 + (int)ty * 3;
+        const int tm = min(3, ni - i0), tn = min(3, nj - j0);
+        const int n_ = pos / 3, m_ = pos - 3 * n_;
+        if (m_ >= tm || n_ >= tn) continue;
+        width = need == 15 ? 17 : (int)need + 1;
+        val = (unsigned)lorenzo(w, ni, i0 + m_, j0 + n_) & ((1u << width) - 1);
+        bitpos += (unsigned)container + (unsigned)(n_ * tm + m_) * (unsigned)width;
+        const unsigned wi = bitpos >> 5; const int sh_ = (int)(bitpos & 31);
+        const unsigned long long v = (unsigned long long)val << (64 - width - sh_);
+        if ((unsigned)(v >> 32)) atomicOr(&stage[wi], (unsigned)(v >> 32));
+        if ((unsigned)v) atomicOr(&stage[wi + 1], (unsigned)v);
+    }
+    __syncthreads();
+    for (size_t k = threadIdx.x; k < nw; k += SCAN_TPB) {
+        const unsigned v = stage[k];
+        if (k == 0 || k == nw - 1) { if (v) atomicOr(&z[w0 + k], v); }     /* shared with the neighbouring blocks */
+        else z[w0 + k] = v;
+    }
+}
+
 /* parallelogram prefix: 3-bit container, row 1, column 1 (:712-721) */
 __global__ __launch_bounds__(256) void k_armn_prefix(unsigned *z, const unsigned *w, const unsigned *gt16, int ni, int nj, int nbits, unsigned header)
 {
@@ -622,7 +717,10 @@ extern "C" int packhip_armn_encode(unsigned *d_z, size_t z_words, const unsigned
         hipLaunchKernelGGL(k_armn_scan, dim3(1), dim3(256), 0, st, bsum, nblocks, total);
         hipLaunchKernelGGL(k_armn_prefix, dim3((ni + nj + 255) / 256), dim3(256), 0, st, d_z, d_words, gt16, ni, nj, nbits, header);
         body_start = 32 + 3 + (unsigned long long)(ni + nj - 1) * nbits;
-        hipLaunchKernelGGL(k_armn_emit<1>, dim3(nblocks), dim3(SCAN_TPB), 0, st, d_z, bsum, nb, gt16, d_words, ni, nj, istep, ntx, ntiles, nbits, body_start);
+        if (getenv("EZHIP_ARMN_SEQ_EMIT"))     /* development: the per-thread sequential writer */
+            hipLaunchKernelGGL(k_armn_emit<1>, dim3(nblocks), dim3(SCAN_TPB), 0, st, d_z, bsum, nb, gt16, d_words, ni, nj, istep, ntx, ntiles, nbits, body_start);
+        else
+            hipLaunchKernelGGL(k_armn_emit_tok, dim3(nblocks), dim3(SCAN_TPB), 0, st, d_z, bsum, nb, gt16, d_words, ni, nj, ntx, ntiles, nbits, body_start);
     }
     if (chk("armn_encode")) return -1;
     unsigned long long tot = 0;

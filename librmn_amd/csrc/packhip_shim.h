@@ -18,7 +18,9 @@ typedef struct {
 #define PACKHIP_STATS_WORDS (PACKHIP_STATS_PARTIALS + 3 * PACKHIP_STATS_MAXBLK)
 /* stats[0..2] = min key, max key, OR; kind 0 float keys, 1 uint32, 2 int32 (biased by 0x80000000) */
 int packhip_stats(unsigned *d_stats, const void *d_a, size_t n, int stride, int kind, int has_missing, float tag);
-int packhip_cf_header(packhip_cf_params *d_pp, unsigned *d_hdr, const unsigned *d_stats, unsigned n, int bs, int style, int has_missing);
+/* per-block partials only (returns their count, -1 on error); packhip_cf_header(npartials > 0) reduces them itself */
+int packhip_stats_partials(unsigned *d_stats, const void *d_a, size_t n, int stride, int kind, int has_missing, float tag);
+int packhip_cf_header(packhip_cf_params *d_pp, unsigned *d_hdr, unsigned *d_stats, int npartials, unsigned n, int bs, int style, int has_missing);
 int packhip_cf_pack(unsigned *d_out, const float *d_a, size_t n, int E, int offset, int stride,
                     const packhip_cf_params *d_pp, int has_missing, float tag);
 int packhip_cf_unpack(float *d_a, const unsigned *d_in, size_t n, int tokenSize, int offset, int stride,
