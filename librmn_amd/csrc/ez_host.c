@@ -1436,8 +1436,18 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
         p.pole_row_n = prow_n; p.pole_row_s = prow_s;
         p.polevals = d_poles_pre ? d_poles_pre : d_poles;
         if (getenv("EZHIP_NO_SEPX")) p.x_nseg = 0;       /* tests: force the fallback tile kernel k_sep */
+        if (p.x_nseg > 0 && !getenv("EZHIP_SEPX_RB")) {
+            /* a lone field: about half the row-blocks per thread block of the batch setting (the special-row blocks
+             * and the ramp-up / drain of the launch are not hidden by other fields; measured at cfg2, polar on:
+             * 50.5 us with 9 row-blocks per block, 42.2 with 5, 44.6 with 3) */
+            int rb = (p.x_rb + 1) / 2 + (p.x_rb > 4);
+            if (rb < 1) rb = 1;
+            p.x_rb = rb; p.x_nseg = (p.x_nvb + rb - 1) / rb;
+        }
         if (p.need_poles && !d_poles_pre) {
-            if (p.x_nseg > 0 && !getenv("EZHIP_POLES_PRELAUNCH")) { if (pole_ring(1, &p)) return -1; }    /* k_sepx sums the pole rows itself */
+            /* a lone field: k_polevals first.  (The in-kernel producers of the batch launch would make the field's
+             * special-row blocks, co-resident from t = 0, spin for the ~25 us of the pole sums: 50 us instead of 42.) */
+            if (p.x_nseg > 0 && getenv("EZHIP_POLES_INKERNEL")) { if (pole_ring(1, &p)) return -1; }
             else if (ezhip_polevals(d_poles, d_zin, gi->ni, gi->nj, p.pole_weighted, p.ax)) return -1;
         }
         if (ezhip_interp_sep(&p, d_zout, d_zin)) return -1;
@@ -1471,6 +1481,16 @@ int32_t c_ezsint_dev(float *d_zout, const float *d_zin)
     return run_field(s, d_zout, d_zin, 0, NULL, NULL);
 }
 
+static int ensure_batch_poles(ezh_set *s, int nfields)
+{
+    if (nfields > s->poles_cap) {
+        ezhip_sync(); ezhip_free(s->d_poles_batch);
+        s->d_poles_batch = (float *)ezhip_malloc(sizeof(float) * 2 * (size_t)nfields);
+        s->poles_cap = s->d_poles_batch ? nfields : 0;
+    }
+    return s->d_poles_batch ? 0 : -1;
+}
+
 int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields)
 {
     ezh_set *s = current_set("c_ezsint_batch");
@@ -1490,7 +1510,14 @@ int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields)
             ezh_grid *gi = &G[s->gdin];
             p.fill = s->d_scratch;
             if (p.pole_weighted) { if (ensure_grid_dev(gi)) return -1; p.ax = gi->d_ax; }
-            if (p.need_poles && pole_ring(nfields, &p)) return -1;
+            if (p.need_poles) {
+                if (nfields >= 4) { if (pole_ring(nfields, &p)) return -1; }      /* producer blocks of the same launch */
+                else {                                                              /* tiny batch: k_polevals first (see run_field_p) */
+                    if (ensure_batch_poles(s, nfields)) return -1;
+                    if (ezhip_polevals_batch(s->d_poles_batch, d_zin, nin, nfields, gi->ni, gi->nj, p.pole_weighted, p.ax)) return -1;
+                    p.polevals = s->d_poles_batch;
+                }
+            }
             p.batch_fields = nfields; p.batch_in_stride = nin; p.batch_out_stride = nout;
             return ezhip_interp_sep(&p, d_zout, d_zin) ? -1 : 0;
         }
@@ -1499,11 +1526,7 @@ int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields)
     float *d_poles_all = NULL;
     if (s->gdin != s->gdout && O.polar_correction == 1 && !s->extrap && nfields > 1) {
         ezh_grid *gi = &G[s->gdin];
-        if (nfields > s->poles_cap) {
-            ezhip_sync(); ezhip_free(s->d_poles_batch);
-            s->d_poles_batch = (float *)ezhip_malloc(sizeof(float) * 2 * (size_t)nfields);
-            s->poles_cap = s->d_poles_batch ? nfields : 0;
-        }
+        if (ensure_batch_poles(s, nfields)) return -1;
         int weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
         if (weighted && ensure_grid_dev(gi)) return -1;
         if (s->d_poles_batch && ezhip_polevals_batch(s->d_poles_batch, d_zin, nin, nfields, gi->ni, gi->nj, weighted, gi->d_ax) == 0)

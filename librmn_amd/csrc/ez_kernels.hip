@@ -3,11 +3,14 @@
  * hot path, plus the thin C-ABI shim the C host front-end calls (ezhip_shim.h).
  *
  * Kernels:
- *   k_sep<DEG>      separable ("rectilinear on rectilinear") interpolation: per-column / per-row
- *                   tap tables, rolling 4-row register window, fused polar special rows.
+ *   k_sepx<DEG,XR>  separable ("rectilinear on rectilinear") interpolation, the default: one thread block = one
+ *                   256-column strip x several 16-row blocks; source rows staged once by LDS-DMA, x-pass results in
+ *                   an fp64 LDS ring, y-pass with per-lane row records; all fields of a batch in one launch.
  *                   Replaces the do n=1,npts loops of ez_irgdint_3_w / ez_rgdint_3_w / ez_(i)rgdint_1_(n)w /
  *                   ez_rgdint_0 (reference src/interp, the .inc leaf kernels) when x depends on the target column
  *                   only and y on the target row only -- the BASELINE cfg1/2/4/5 shape.
+ *   k_sep<DEG>      the same arithmetic as a (256 x 16) tile kernel with a rolling register window and a gather
+ *                   path: fallback for plans k_sepx cannot take.
  *   k_pts           generic per-point interpolation at arbitrary (x,y): point-by-point restatement
  *                   of the 11 leaf kernels + zone handling (ez_defzones.c, ez_corrval*.c).
  *   k_locate        lat/lon -> source index space (ez_ll2rgd.inc, ez_ll2igd.inc, ez_cherche.inc,
