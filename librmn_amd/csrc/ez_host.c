@@ -70,6 +70,7 @@ typedef struct {
     int coords_ready, separable;
     float *lat1d, *lon1d, *lat2d, *lon2d;
     float *d_lat, *d_lon; int d_coords_valid;
+    float *d_plon2; float xg4_pole[2];     /* this grid as a wind SOURCE: longitudes of its last / first row, PS-frame xg4 (N, S) */
     ezh_set *sets;                          /* sets having this grid as gdout */
 } ezh_grid;
 
@@ -492,7 +493,7 @@ int32_t c_gdrls(int32_t gd)          /* gdrls.c:34-77: refcount, free at zero */
         free(g->ax); free(g->ay); free(g->ncx); free(g->ncy);
         free(g->lat1d); free(g->lon1d); free(g->lat2d); free(g->lon2d);
         ezhip_free(g->d_ax); ezhip_free(g->d_ay); ezhip_free(g->d_ncx); ezhip_free(g->d_ncy);
-        ezhip_free(g->d_lat); ezhip_free(g->d_lon);
+        ezhip_free(g->d_lat); ezhip_free(g->d_lon); ezhip_free(g->d_plon2); g->d_plon2 = NULL;
         memset(g, 0, sizeof(*g));
         if (cur_gdin == gd) cur_gdin = -1;
         if (cur_gdout == gd) cur_gdout = -1;
@@ -1697,6 +1698,19 @@ static void h_row_latlon(const ezh_grid *g, float *lat, float *lon, int row1 /* 
     if (g->grtyp == 'Z' && g->grref == 'E') { float *a = (float *)malloc(sizeof(float) * ni), *b = (float *)malloc(sizeof(float) * ni); memcpy(a, lon, sizeof(float) * ni); memcpy(b, lat, sizeof(float) * ni); h_rotate(lon, lat, a, b, ni, g->xgref, 0); free(a); free(b); }
 }
 
+/* longitudes of the last (north) / first source row as ez_calcnpolarwind sees them (for Z-on-E: rotated frame) */
+static void polar_row_lon(const ezh_grid *g, float *plon, float *tmp_lat, int north)
+{
+    int ni = g->ni;
+    h_row_latlon(g, tmp_lat, plon, north ? g->nj : 1);
+    if (g->grtyp == 'Z' && g->grref == 'E') {
+        float *a = (float *)malloc(sizeof(float) * ni), *b = (float *)malloc(sizeof(float) * ni);
+        memcpy(a, plon, sizeof(float) * ni); memcpy(b, tmp_lat, sizeof(float) * ni);
+        h_rotate(plon, tmp_lat, a, b, ni, g->xgref, 1);
+        free(a); free(b);
+    }
+}
+
 /* ez_calcnpolarwind.c:28-138 / ez_calcspolarwind.c: synthetic pole row of (u,v) from the last/first source row */
 static void h_polar_wind(const ezh_grid *g, float *pu, float *pv, const float *urow, const float *vrow, int north)
 {
@@ -1741,20 +1755,37 @@ int32_t c_ezuvint_dev(float *d_uuout, float *d_vvout, const float *d_uuin, const
     int ni = gi->ni, nj = gi->nj, polar = O.polar_correction == 1;
     const float *pun = NULL, *pus = NULL, *pvn = NULL, *pvs = NULL;
     if (polar && !s->extrap) {
-        /* synthetic polar wind rows: O(ni) work on two source rows, done on the host with the exact
-         * reference arithmetic (ez_calcnpolarwind.c) and sent back as four ni-float rows */
+        /* synthetic polar wind rows (ez_calcnpolarwind.c): one small kernel, no host round trip.  The row longitudes
+         * and the polar-stereographic xg4 depend on the grid only: computed once on the host. */
         if (!s->d_prow) s->d_prow = (float *)ezhip_malloc(sizeof(float) * 4 * (size_t)ni);
         if (!s->d_prow) return -1;
-        float *rows = (float *)malloc(sizeof(float) * 8 * (size_t)ni);
-        float *un = rows, *vn = rows + ni, *us = rows + 2 * ni, *vs = rows + 3 * ni, *out = rows + 4 * ni;
-        ezhip_d2h(un, d_uuin + (size_t)(nj - 1) * ni, sizeof(float) * ni); ezhip_d2h(vn, d_vvin + (size_t)(nj - 1) * ni, sizeof(float) * ni);
-        ezhip_d2h(us, d_uuin, sizeof(float) * ni); ezhip_d2h(vs, d_vvin, sizeof(float) * ni);
-        if (ezhip_sync()) { free(rows); return -1; }
-        h_polar_wind(gi, out, out + 2 * ni, un, vn, 1);          /* out: [u_n, u_s, v_n, v_s] */
-        h_polar_wind(gi, out + ni, out + 3 * ni, us, vs, 0);
-        ezhip_h2d(s->d_prow, out, sizeof(float) * 4 * (size_t)ni);
-        if (ezhip_sync()) { free(rows); return -1; }
-        free(rows);
+        if (!gi->d_plon2) {
+            float *pl = (float *)malloc(sizeof(float) * 3 * (size_t)ni);
+            polar_row_lon(gi, pl, pl + 2 * ni, 1); polar_row_lon(gi, pl + ni, pl + 2 * ni, 0);
+            gi->d_plon2 = (float *)upload(pl, sizeof(float) * 2 * (size_t)ni);
+            free(pl);
+            for (int k = 0; k < 2; k++) {
+                int i1, i2, i3, i4; float x1, x2, x3, x4;
+                h_cxgaig(k == 0 ? 'N' : 'S', &i1, &i2, &i3, &i4, 0.0f, 0.0f, 1000.0f, 0.0f);
+                h_cigaxg(k == 0 ? 'N' : 'S', &x1, &x2, &x3, &x4, i1, i2, i3, i4);
+                gi->xg4_pole[k] = x4;
+            }
+            if (!gi->d_plon2) return -1;
+        }
+        int weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
+        if (weighted && ensure_grid_dev(gi)) return -1;
+        if (getenv("EZHIP_POLAR_WIND_HOST")) {       /* development / tests: the host restatement with the host libm */
+            float *rows = (float *)malloc(sizeof(float) * 8 * (size_t)ni);
+            float *un = rows, *vn = rows + ni, *us = rows + 2 * ni, *vs = rows + 3 * ni, *out = rows + 4 * ni;
+            ezhip_d2h(un, d_uuin + (size_t)(nj - 1) * ni, sizeof(float) * ni); ezhip_d2h(vn, d_vvin + (size_t)(nj - 1) * ni, sizeof(float) * ni);
+            ezhip_d2h(us, d_uuin, sizeof(float) * ni); ezhip_d2h(vs, d_vvin, sizeof(float) * ni);
+            if (ezhip_sync()) { free(rows); return -1; }
+            h_polar_wind(gi, out, out + 2 * ni, un, vn, 1);          /* out: [u_n, u_s, v_n, v_s] */
+            h_polar_wind(gi, out + ni, out + 3 * ni, us, vs, 0);
+            ezhip_h2d(s->d_prow, out, sizeof(float) * 4 * (size_t)ni);
+            if (ezhip_sync()) { free(rows); return -1; }
+            free(rows);
+        } else if (ezhip_polar_wind(s->d_prow, d_uuin, d_vvin, gi->d_plon2, ni, nj, gi->xg4_pole[0], gi->xg4_pole[1], weighted, gi->d_ax)) return -1;
         pun = s->d_prow; pus = s->d_prow + ni; pvn = s->d_prow + 2 * ni; pvs = s->d_prow + 3 * ni;
     }
     int r1 = run_field(s, d_uuout, d_uuin, 1, pun, pus);

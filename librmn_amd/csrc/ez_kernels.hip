@@ -769,6 +769,68 @@ extern "C" int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const
 }
 
 /* ===================================================================================== */
+/* k_polar_wind : synthetic polar wind rows (vector mode)                                     */
+/* ===================================================================================== */
+/* ez_calcnpolarwind.c:28-138 / ez_calcspolarwind.c on the device: from the last / first source row of (u,v) to a row of
+ * pole winds, through speed/direction, a polar-stereographic frame (ez_llwfgdw / ez_gdwfllw 'N' / 'S' with xg4 from
+ * cxgaig/cigaxg), the (sequential REAL) pole value of each component, and back.  blockIdx.x: 0 north, 1 south;
+ * blockIdx.y: field pair.  One block of 256 threads per row; `plon` = longitudes of the source row (host, once per
+ * grid).  out = [u_n, u_s, v_n, v_s] (ni each).  Device sinf/cosf/atan2f: <= 2 ulp from the host libm the reference
+ * uses (the tolerance of the vector path is 1e-5 relative). */
+__device__ __forceinline__ void d_llwfgdw1(float &z1, float &z2, float xlon, char t, float xg4)
+{
+    const float RDTODG = 57.295779513082f;
+    float uu = z1, vv = z2, spd = sqrtf(uu * uu + vv * vv), dir;
+    if (spd == 0.0f) dir = 0.0f;
+    else if (t == 'N') dir = (uu == 0.0f) ? ((vv >= 0.0f) ? xlon + xg4 - 90.0f : xlon + xg4 + 90.0f) : xlon + xg4 - RDTODG * atan2f(vv, uu);
+    else if (t == 'S') dir = (uu == 0.0f) ? ((vv >= 0.0f) ? 90.0f - xlon + xg4 : 270.0f - xlon + xg4) : 180.0f - xlon + xg4 - RDTODG * atan2f(vv, uu);
+    else dir = (uu == 0.0f) ? ((vv >= 0.0f) ? 180.0f : 0.0f) : 270.0f - RDTODG * atan2f(vv, uu);
+    dir = fmodf(fmodf(dir, 360.0f) + 360.0f, 360.0f);
+    z1 = spd; z2 = dir;
+}
+__device__ __forceinline__ void d_gdwfllw1(float &z1, float &z2, float xlon, char t, float xg4)
+{
+    const float DGTORD = 1.7453292519943e-2f;
+    float psi = t == 'N' ? xlon + xg4 - z2 : t == 'S' ? 180.0f - xlon + xg4 - z2 : 270.0f - z2;
+    float u = cosf(psi * DGTORD) * z1, v = sinf(psi * DGTORD) * z1;
+    z1 = u; z2 = v;
+}
+__global__ __launch_bounds__(256) void k_polar_wind(float *out, const float *uu, const float *vv, const float *plon2 /* [north row | south row] */,
+                                                    int ni, int nj, float xg4_n, float xg4_s, int weighted, const float *ax)
+{
+    __shared__ __attribute__((aligned(16))) float lds[POLE_CHUNK + 4];
+    const int north = blockIdx.x == 0;
+    const char hs = north ? 'N' : 'S';
+    const float xg4 = north ? xg4_n : xg4_s;
+    const float *urow = uu + (north ? (size_t)(nj - 1) * ni : 0), *vrow = vv + (north ? (size_t)(nj - 1) * ni : 0);
+    const float *plon = plon2 + (north ? 0 : ni);
+    float *pu = out + (north ? 0 : ni), *pv = out + 2 * (size_t)ni + (north ? 0 : ni);
+    for (int i = threadIdx.x; i < ni; i += 256) {          /* speed / direction on the lat-lon frame, then polar-stereographic components */
+        float a = urow[i], b = vrow[i];
+        d_llwfgdw1(a, b, plon[i], 'A', 0.f);
+        d_gdwfllw1(a, b, plon[i], hs, xg4);
+        pu[i] = a; pv[i] = b;
+    }
+    __threadfence_block();
+    __syncthreads();
+    float s0 = block_poleval(pu, ni, weighted, ax, lds, POLE_CHUNK);
+    float w0 = block_poleval(pv, ni, weighted, ax, lds, POLE_CHUNK);
+    d_llwfgdw1(s0, w0, 0.0f, hs, xg4);
+    __syncthreads();
+    for (int i = threadIdx.x; i < ni; i += 256) {
+        float spd = s0, wd = (i == 0 || north) ? w0 + plon[i] : w0 - plon[i];
+        d_gdwfllw1(spd, wd, plon[i], 'A', 0.f);
+        pu[i] = spd; pv[i] = wd;
+    }
+}
+extern "C" int ezhip_polar_wind(float *d_out4, const float *d_uu, const float *d_vv, const float *d_plon2, int ni, int nj,
+                                float xg4_n, float xg4_s, int weighted, const float *d_ax)
+{
+    hipLaunchKernelGGL(k_polar_wind, dim3(2), dim3(256), 0, g_stream, d_out4, d_uu, d_vv, d_plon2, ni, nj, xg4_n, xg4_s, weighted, d_ax);
+    return LAUNCH_CHECK("k_polar_wind");
+}
+
+/* ===================================================================================== */
 /* k_pts : generic per-point interpolation (restates the reference leaf kernels)            */
 /* ===================================================================================== */
 
@@ -784,6 +846,14 @@ struct FieldAcc {
         if (j < j1) return prow_s ? prow_s[i - 1] : pole_s;
         return z[(size_t)(j - j1) * ni + (i - 1)];
     }
+};
+
+/* Main-zone accessor: the leaf kernels clamp j to [j1, j2], so no pole row can be touched and the 16 gathers of a
+ * point are unconditional (with FieldAcc every gather sits behind two row tests and the loads of a point serialise:
+ * k_pts 392 us per 8 M cfg3 points). */
+struct PlainAcc {
+    const float *z; int ni, j1;
+    __device__ __forceinline__ float operator()(int i, int j) const { return z[(size_t)(j - j1) * ni + (i - 1)]; }
 };
 
 __device__ __forceinline__ double d_zlin(double a, double b, double t) { return a + (b - a) * t; }
@@ -803,14 +873,14 @@ __device__ __forceinline__ double d_fa4(double c1, double c2, double c3, double 
 __device__ __forceinline__ int d_nint(float v) { return (int)lroundf(v); }
 
 /* ez_rgdint_0.inc:20-35 */
-template <class A> __device__ float p_rgdint_0(const A &Z, float px, float py, int ni, int j1, int j2)
+template <class A> __device__ __forceinline__ float p_rgdint_0(const A &Z, float px, float py, int ni, int j1, int j2)
 {
     int i = min(ni, max(1, d_nint(px)));
     int j = min(j2, max(j1, d_nint(py)));
     return Z(i, j);
 }
 /* ez_rgdint_1_nw.inc:20-44 */
-template <class A> __device__ float p_rgdint_1_nw(const A &Z, float px, float py, int ni, int j1, int j2)
+template <class A> __device__ __forceinline__ float p_rgdint_1_nw(const A &Z, float px, float py, int ni, int j1, int j2)
 {
     int i = min(ni - 1, max(1, (int)px));
     int j = min(j2 - 1, max(j1, (int)py));
@@ -820,7 +890,7 @@ template <class A> __device__ float p_rgdint_1_nw(const A &Z, float px, float py
     return (float)d_zlin(y2, y3, dy);
 }
 /* ez_rgdint_1_w.inc:20-51 */
-template <class A> __device__ float p_rgdint_1_w(const A &Z, float px, float py, int ni, int j1, int j2, int wrap)
+template <class A> __device__ __forceinline__ float p_rgdint_1_w(const A &Z, float px, float py, int ni, int j1, int j2, int wrap)
 {
     int limite = ni + 2 - wrap;
     int i = min(ni - 2 + wrap, max(1, (int)px));
@@ -841,7 +911,7 @@ template <class A> __device__ __forceinline__ float cubic_rows(const A &Z, int i
     return (float)d_cubic(y1, y2, y3, y4, dy);
 }
 /* ez_rgdint_3_nw.inc:20-77 */
-template <class A> __device__ float p_rgdint_3_nw(const A &Z, float px, float py, int ni, int j1, int j2)
+template <class A> __device__ __forceinline__ float p_rgdint_3_nw(const A &Z, float px, float py, int ni, int j1, int j2)
 {
     int i = min(ni - 2, max(2, (int)px));
     int j = min(j2 - 2, max(j1 + 1, (int)py));
@@ -857,7 +927,7 @@ __device__ __forceinline__ void wrap_cols_regular(int ni, int wrap, int limite, 
     if (wrap == 1) { if (ip2 == ni) ip2 = 2; if (im1 == ni) im1 = ni - 1; }
 }
 /* ez_rgdint_3_w.inc:20-108 (nnc = 0), ez_rgdint_3_wnnc.inc:20-107 (nnc = 1) */
-template <class A> __device__ float p_rgdint_3_w(const A &Z, float px, float py, int ni, int j1, int j2, int wrap, int nnc)
+template <class A> __device__ __forceinline__ float p_rgdint_3_w(const A &Z, float px, float py, int ni, int j1, int j2, int wrap, int nnc)
 {
     int limite = ni + 2 - wrap;
     int i = min(ni - 2 + wrap, max(1, max(2 - wrap, (int)px)));
@@ -869,7 +939,7 @@ template <class A> __device__ float p_rgdint_3_w(const A &Z, float px, float py,
     return cubic_rows(Z, im1, i, ip1, ip2, j, (double)(px - (float)i), (double)(py - (float)j));
 }
 /* ez_irgdint_1_nw.inc:20-50 */
-template <class A> __device__ float p_irgdint_1_nw(const A &Z, float px, float py, const float *ax, const float *ay, int ni, int nj)
+template <class A> __device__ __forceinline__ float p_irgdint_1_nw(const A &Z, float px, float py, const float *ax, const float *ay, int ni, int nj)
 {
     int i = min(ni - 1, max(1, (int)px));
     int j = min(nj - 1, max(1, (int)py));
@@ -883,7 +953,7 @@ template <class A> __device__ float p_irgdint_1_nw(const A &Z, float px, float p
     return (float)d_zlin(y1, y2, dy);
 }
 /* ez_irgdint_1_w.inc:20-64 (ay indexed from j1) */
-template <class A> __device__ float p_irgdint_1_w(const A &Z, float px, float py, const float *ax, const float *ay, int ni, int j1, int j2, int wrap)
+template <class A> __device__ __forceinline__ float p_irgdint_1_w(const A &Z, float px, float py, const float *ax, const float *ay, int ni, int j1, int j2, int wrap)
 {
     int limite = ni + 2 - wrap;
     int i = min(ni - 2 + wrap, max(1, (int)px));
@@ -903,7 +973,7 @@ template <class A> __device__ float p_irgdint_1_w(const A &Z, float px, float py
     return (float)d_zlin(y1, y2, dy);
 }
 /* ez_irgdint_3_nw.inc:20-168: the statement functions are REAL there (results rounded to float) */
-template <class A> __device__ float p_irgdint_3_nw(const A &Z, float px, float py, const float *ax, const float *ay,
+template <class A> __device__ __forceinline__ float p_irgdint_3_nw(const A &Z, float px, float py, const float *ax, const float *ay,
                                                    const float *cx, const float *cy, int i1, int i2, int j1, int j2)
 {
     const int ni = i2 - i1 + 1, nnj = j2 - j1 + 1;
@@ -952,7 +1022,7 @@ __device__ __forceinline__ void irr_cols(const float *ax, int ni, int wrap, int 
 #undef AX
 }
 /* ez_irgdint_3_w.inc:20-235 */
-template <class A> __device__ float p_irgdint_3_w(const A &Z, float px, float py, const float *ax, const float *ay,
+template <class A> __device__ __forceinline__ float p_irgdint_3_w(const A &Z, float px, float py, const float *ax, const float *ay,
                                                   const float *cx, const float *cy, int ni, int j1, int j2, int wrap)
 {
     const int nnj = j2 - j1 + 1;
@@ -981,7 +1051,7 @@ template <class A> __device__ float p_irgdint_3_w(const A &Z, float px, float py
     return (float)d_fa(bb[0], b12, b13, b14, y, (double)y1, (double)y2, (double)y3);
 }
 /* ez_irgdint_3_wnnc.inc:20-246 (ay: 4-entry strip latitudes indexed from j1) */
-template <class A> __device__ float p_irgdint_3_wnnc(const A &Z, float px, float py, const float *ax, const float *ay4,
+template <class A> __device__ __forceinline__ float p_irgdint_3_wnnc(const A &Z, float px, float py, const float *ax, const float *ay4,
                                                      int ni, int j1, int j2, int wrap)
 {
     int i = min(ni - 2 + wrap, max(1, max(2 - wrap, (int)px)));
@@ -1014,7 +1084,7 @@ template <class A> __device__ float p_irgdint_3_wnnc(const A &Z, float px, float
 
 /* c_gdinterp dispatch (src/interp/gdinterp.c:133-309) for one point */
 template <class A>
-__device__ float gdinterp_point(const ezhip_pts_plan &p, const A &Z, int degree, float px, float py)
+__device__ __noinline__ float gdinterp_point(const ezhip_pts_plan &p, const A &Z, int degree, float px, float py)
 {
     if (p.irregular) {
         switch (degree) {
@@ -1036,7 +1106,7 @@ __device__ float gdinterp_point(const ezhip_pts_plan &p, const A &Z, int degree,
 
 /* polar strip interpolation of one point: ez_corrval_aunord.c:28-117 / ez_corrval_ausud.c:30-137 */
 template <class A>
-__device__ float strip_point(const ezhip_pts_plan &p, const A &Z, int north, float px, float py)
+__device__ __noinline__ float strip_point(const ezhip_pts_plan &p, const A &Z, int north, float px, float py)
 {
     const int j1s = north ? p.j2 - 2 : p.j1 - 1, j2s = j1s + 3;
     if (p.degree == 3) {
@@ -1056,54 +1126,136 @@ __device__ float strip_point(const ezhip_pts_plan &p, const A &Z, int north, flo
     return p_rgdint_0(Z, px, py, p.ni, j1s, j2s);
 }
 
+/* The leaf kernel of the launch as a compile-time choice (gdinterp.c:133-309 dispatch, uniform per launch):
+ * one inlined leaf per k_pts instantiation instead of a call into a function that holds all nine (that version
+ * needed 224 B of scratch per lane and 102 VGPRs).  The rare paths -- polar strips, re-interpolated
+ * extrapolation -- stay out of line. */
+enum { PK_RGD0 = 0, PK_RGD1_NW, PK_RGD1_W, PK_RGD3_NW, PK_RGD3_W, PK_IRGD1_NW, PK_IRGD1_W, PK_IRGD3_NW, PK_IRGD3_W, PK_COUNT };
+template <int KIND, class A>
+__device__ __forceinline__ float leaf_point(const ezhip_pts_plan &p, const A &Z, float px, float py)
+{
+    if (KIND == PK_RGD0) return p_rgdint_0(Z, px, py, p.ni, p.j1, p.j2);
+    if (KIND == PK_RGD1_NW) return p_rgdint_1_nw(Z, px, py, p.ni, p.j1, p.j2);
+    if (KIND == PK_RGD1_W) return p_rgdint_1_w(Z, px, py, p.ni, p.j1, p.j2, p.wrap);
+    if (KIND == PK_RGD3_NW) return p_rgdint_3_nw(Z, px, py, p.ni, p.j1, p.j2);
+    if (KIND == PK_RGD3_W) return p_rgdint_3_w(Z, px, py, p.ni, p.j1, p.j2, p.wrap, 0);
+    if (KIND == PK_IRGD1_NW) return p_irgdint_1_nw(Z, px, py, p.ax, p.ay, p.ni, p.nj);
+    if (KIND == PK_IRGD1_W) return p_irgdint_1_w(Z, px, py, p.ax, p.ay, p.ni, p.j1, p.j2, p.wrap);
+    if (KIND == PK_IRGD3_NW) return p_irgdint_3_nw(Z, px, py, p.ax, p.ay, p.ncx, p.ncy, p.i1, p.i2, p.j1, p.j2);
+    return p_irgdint_3_w(Z, px, py, p.ax, p.ay, p.ncx, p.ncy, p.ni, p.j1, p.j2, p.wrap);
+}
+static int pts_kind(const ezhip_pts_plan *p)
+{
+    if (p->degree == 0) return PK_RGD0;
+    if (p->irregular) return p->degree == 1 ? (p->wrap == 0 ? PK_IRGD1_NW : PK_IRGD1_W) : (p->wrap == 0 ? PK_IRGD3_NW : PK_IRGD3_W);
+    return p->degree == 1 ? (p->wrap == 2 ? PK_RGD1_W : PK_RGD1_NW) : (p->wrap == 0 ? PK_RGD3_NW : PK_RGD3_W);
+}
+
+/* zone of a point (ez_defzones.c:25-113 and the order ez_corrval.c:121-145 / ez_corrvec.c:24-48 apply them in) */
+enum { PZ_NORMAL = 0, PZ_FILL, PZ_REINTERP, PZ_STRIP_S, PZ_STRIP_N, PZ_POLE_S, PZ_POLE_N };
+__device__ __forceinline__ int pts_zone(int zones, int ni, int nj, int j1, int j2, float ypole_n, float ypole_s, int vector_mode,
+                                        int degre_extrap, float px, float py)
+{
+    if (zones == 2) {                                     /* EZ_EXTRAP: ez_defzone_dehors.c:63-74 */
+        int ix = (int)((double)px + 0.5), iy = (int)((double)py + 0.5);
+        bool dehors = ix < 1 || iy < 1 || ix > ni || iy > nj;
+        return !dehors ? PZ_NORMAL : (degre_extrap >= 4 ? PZ_FILL : PZ_REINTERP);
+    }
+    if (zones == 1) {                                     /* EZ_NO_EXTRAP */
+        bool au_n = (int)py > (j2 - 2);                   /* ez_defzone_nord.c:41-49 */
+        bool au_s = (int)py < (j1 + 1);                   /* ez_defzone_sud.c:42-50 */
+        if (!vector_mode) {                               /* AU_NORD, AU_SUD, POLE_NORD, POLE_SUD in that order: last writer wins */
+            if (fabs((double)(py - ypole_s)) < 1.0e-3) return PZ_POLE_S;
+            if (fabs((double)(py - ypole_n)) < 1.0e-3) return PZ_POLE_N;
+        }
+        return au_s ? PZ_STRIP_S : (au_n ? PZ_STRIP_N : PZ_NORMAL);
+    }
+    return PZ_NORMAL;
+}
+
+/* Main kernel: ONE inlined leaf, plan members straight from the kernel-argument segment (global loads, no scratch:
+ * the version that also called the out-of-line strip / re-interpolation code kept the plan in scratch and reached its
+ * tables through 100 flat loads).  Points of the polar strips and re-interpolated extrapolation points are left to
+ * k_pts_special. */
+template <int KIND>
 __global__ __launch_bounds__(256) void k_pts(ezhip_pts_plan p, float *__restrict__ zout, const float *__restrict__ zin,
-                                             const float *__restrict__ xs, const float *__restrict__ ys, int npts)
+                                             const float *__restrict__ xs, const float *__restrict__ ys, int npts,
+                                             int *__restrict__ special_list, unsigned *__restrict__ special_count)
 {
     int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= npts) return;
     const float px = xs[n], py = ys[n];
-    FieldAcc Z;
-    Z.z = zin; Z.ni = p.ni; Z.j1 = p.j1; Z.j2 = p.j2;
-    Z.pole_n = 0.f; Z.pole_s = 0.f; Z.prow_n = nullptr; Z.prow_s = nullptr;
-    float out;
-    if (p.zones == 2) {                                   /* EZ_EXTRAP: ez_defzone_dehors.c:63-74 */
-        int ix = (int)((double)px + 0.5), iy = (int)((double)py + 0.5);
-        bool dehors = ix < 1 || iy < 1 || ix > p.ni || iy > p.nj;
-        if (!dehors) out = gdinterp_point(p, Z, p.degree, px, py);
-        else if (p.degre_extrap >= 4) out = *p.fill;
-        else out = gdinterp_point(p, Z, p.degre_extrap, px, py);
-    } else if (p.zones == 1) {                            /* EZ_NO_EXTRAP */
-        bool au_n = (int)py > (p.j2 - 2);                 /* ez_defzone_nord.c:41-49 */
-        bool au_s = (int)py < (p.j1 + 1);                 /* ez_defzone_sud.c:42-50 */
-        bool po_n = fabs((double)(py - p.ypole_n)) < 1.0e-3;
-        bool po_s = fabs((double)(py - p.ypole_s)) < 1.0e-3;
-        if (p.vector_mode) {
-            Z.prow_n = p.pole_row_n; Z.prow_s = p.pole_row_s;
-            /* ez_corrvec.c:24-48: strips only (pole zones re-run the same strips) */
-            if (au_s) out = strip_point(p, Z, 0, px, py);
-            else if (au_n) out = strip_point(p, Z, 1, px, py);
-            else out = gdinterp_point(p, Z, p.degree, px, py);
-        } else {
-            Z.pole_n = p.polevals[0]; Z.pole_s = p.polevals[1];
-            /* ez_corrval.c:121-145 applies AU_NORD, AU_SUD, POLE_NORD, POLE_SUD in that order: last writer wins */
-            if (po_s) out = Z.pole_s;
-            else if (po_n) out = Z.pole_n;
-            else if (au_s) out = strip_point(p, Z, 0, px, py);
-            else if (au_n) out = strip_point(p, Z, 1, px, py);
-            else out = gdinterp_point(p, Z, p.degree, px, py);
-        }
-    } else {
-        out = gdinterp_point(p, Z, p.degree, px, py);
+    const PlainAcc ZP{zin, p.ni, p.j1};
+    const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
+    if (zone == PZ_NORMAL) zout[n] = leaf_point<KIND>(p, ZP, px, py);
+    else if (zone == PZ_FILL) zout[n] = *p.fill;
+    else if (zone == PZ_POLE_S) zout[n] = p.polevals[1];
+    else if (zone == PZ_POLE_N) zout[n] = p.polevals[0];
+    /* strip / re-interpolated points: appended to the launch's list, one atomic per wave that has any */
+    const bool sp = zone == PZ_REINTERP || zone == PZ_STRIP_S || zone == PZ_STRIP_N;
+    const unsigned long long m = __ballot(sp);
+    if (sp) {
+        const int lane = (int)__lane_id(), leader = __ffsll((long long)m) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(special_count, (unsigned)__popcll(m));
+        base = (unsigned)__shfl((int)base, leader, 64);
+        special_list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = n;
     }
-    zout[n] = out;
 }
+
+/* Special points only (a fraction of a percent of a global target): polar strips on the virtual 4-row strip,
+ * extrapolation points re-interpolated with degre_extrap. */
+__global__ __launch_bounds__(256) void k_pts_special(ezhip_pts_plan p, float *__restrict__ zout, const float *__restrict__ zin,
+                                                     const float *__restrict__ xs, const float *__restrict__ ys,
+                                                     const int *__restrict__ special_list, const unsigned *__restrict__ special_count,
+                                                     unsigned *__restrict__ next_count)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;          /* the other counter of the pair: the next launch's */
+    const unsigned cnt = *special_count;
+    for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+        const int n = special_list[k];
+        const float px = xs[n], py = ys[n];
+        const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
+        FieldAcc Z;
+        Z.z = zin; Z.ni = p.ni; Z.j1 = p.j1; Z.j2 = p.j2;
+        Z.pole_n = 0.f; Z.pole_s = 0.f; Z.prow_n = nullptr; Z.prow_s = nullptr;
+        if (zone == PZ_REINTERP) { zout[n] = gdinterp_point(p, Z, p.degre_extrap, px, py); continue; }
+        if (p.vector_mode) { Z.prow_n = p.pole_row_n; Z.prow_s = p.pole_row_s; }
+        else { Z.pole_n = p.polevals[0]; Z.pole_s = p.polevals[1]; }
+        zout[n] = strip_point(p, Z, zone == PZ_STRIP_N, px, py);
+    }
+}
+
+/* per host thread: the list of special point indices of a launch and a PAIR of counters (the special kernel of
+ * launch e consumes counter e & 1 and zeroes the other one for launch e + 1: no memset between launches) */
+static thread_local struct { int *list; unsigned *count; size_t cap; unsigned epoch; } t_spec;
 
 extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin,
                                 const float *d_x, const float *d_y, int npts)
 {
     if (npts <= 0) return 0;
-    hipLaunchKernelGGL(k_pts, dim3((npts + 255) / 256), dim3(256), 0, g_stream, *plan, d_zout, d_zin, d_x, d_y, npts);
-    return LAUNCH_CHECK("k_pts");
+    const dim3 grid((npts + 255) / 256), block(256);
+    if (t_spec.cap < (size_t)npts) {
+        (void)hipStreamSynchronize(g_stream);
+        if (t_spec.list) (void)hipFree(t_spec.list);
+        t_spec.list = nullptr; t_spec.cap = 0;
+        if (hipMalloc((void **)&t_spec.list, sizeof(int) * (size_t)npts + 64) != hipSuccess) return set_err(hipGetLastError(), "k_pts special list");
+        t_spec.count = (unsigned *)(t_spec.list + npts);
+        if (hipMemsetAsync(t_spec.count, 0, 64, g_stream) != hipSuccess) return -1;
+        t_spec.cap = (size_t)npts; t_spec.epoch = 0;
+    }
+    unsigned *cnt = t_spec.count + (t_spec.epoch & 1), *cnt_next = t_spec.count + ((t_spec.epoch + 1) & 1);
+    t_spec.epoch++;
+#define PTS_CASE(K) case K: hipLaunchKernelGGL(k_pts<K>, grid, block, 0, g_stream, *plan, d_zout, d_zin, d_x, d_y, npts, t_spec.list, cnt); break
+    switch (pts_kind(plan)) {
+    PTS_CASE(PK_RGD0); PTS_CASE(PK_RGD1_NW); PTS_CASE(PK_RGD1_W); PTS_CASE(PK_RGD3_NW); PTS_CASE(PK_RGD3_W);
+    PTS_CASE(PK_IRGD1_NW); PTS_CASE(PK_IRGD1_W); PTS_CASE(PK_IRGD3_NW); PTS_CASE(PK_IRGD3_W);
+    }
+#undef PTS_CASE
+    if (LAUNCH_CHECK("k_pts")) return -1;
+    /* always launched (it also re-arms the counter pair); a grid-stride loop over the few listed points */
+    hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan, d_zout, d_zin, d_x, d_y, t_spec.list, cnt, cnt_next);
+    return LAUNCH_CHECK("k_pts_special");
 }
 
 /* ===================================================================================== */

@@ -178,6 +178,11 @@ typedef struct {
     int separable;                    /* target lat/lon given as 1-D arrays */
 } ezhip_wind_plan;
 
+/* synthetic polar wind rows of a source (u,v) pair: d_out4 = [u_n, u_s, v_n, v_s], ni floats each; d_plon2 = longitudes of
+ * the last and the first source row */
+int ezhip_polar_wind(float *d_out4, const float *d_uu, const float *d_vv, const float *d_plon2, int ni, int nj,
+                     float xg4_n, float xg4_s, int weighted, const float *d_ax);
+
 /* in place on (uu, vv): source-grid components -> target ('L'-like) grid components */
 int ezhip_wind_rotate(const ezhip_wind_plan *plan, float *d_uu, float *d_vv,
                       const float *d_lat, const float *d_lon, int ni_dst, int nj_dst);
