@@ -156,6 +156,22 @@ def main():
         pack_step()
     pe1.record(stream); torch.cuda.synchronize()
     pack_us = pe0.elapsed_time(pe1) * 1e3 / (3 * npk)
+    # fused front half of cfg5: the batch interpolation with compact_float's min/max pass folded into k_sepx, then header +
+    # token kernel per field (ezhip_ezsint_pack16_batch_dev): the pack cost of a field = fused step - plain step
+    rs = 4 + NPTS_OUT // 2 + 64
+    recs = torch.zeros((F, rs), dtype=torch.int32, device="cuda")
+    def fused_step():
+        assert pk.ezsint_pack16_batch_dev(recs, rs, d_out, d_in, F, NPTS_OUT, 16) == 0
+    for _ in range(3):
+        fused_step()
+    torch.cuda.synchronize()
+    fe0 = torch.cuda.Event(enable_timing=True); fe1 = torch.cuda.Event(enable_timing=True)
+    nfused = max(3, min(20, args.steps))
+    fe0.record(stream)
+    for _ in range(nfused):
+        fused_step()
+    fe1.record(stream); torch.cuda.synchronize()
+    fused_us = fe0.elapsed_time(fe1) * 1e3 / (nfused * F)          # interp + pack16 per field
     # fused cfg5 step: compact_float(16-bit slots) + armn_compress per field (returns zlng: one sync per field)
     t1 = time.perf_counter()
     zl = [pk.pack16_compress_dev(rec[f], d_out[f], NI_D, NJ_D, 16) for f in range(npk)]
@@ -198,6 +214,9 @@ def main():
             "pack": {"compact_float_16bit_GBps": 4.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9, "us_per_field": pack_us,
                      "algorithmic_GBps_6B_per_elem": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9,
                      "frac_of_hbm_peak": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                     "fused_interp_pack16_us_per_field": fused_us,
+                     "fused_pack16_cost_us_per_field": fused_us - ev_ms * 1e3 / (args.steps * F),
+                     "fused_compact_float_16bit_GBps": 4.0 * NPTS_OUT / (max(fused_us - ev_ms * 1e3 / (args.steps * F), 1e-3) * 1e-6) / 1e9,
                      "pack16_plus_armn_compress_us_per_field": comp_us, "zlng_bytes": int(zl[0]),
                      "compression_ratio": float(zl[0]) / (2.0 * NPTS_OUT), "unit": "GB/s of float input"},
         }

@@ -71,6 +71,11 @@ int32_t c_gdxysint_dev(float *d_zout, const float *d_zin, int32_t gdin, const fl
 int32_t c_gdxyfll_dev(int32_t gdid, float *d_x, float *d_y, const float *d_lat, const float *d_lon, int32_t n);
 /* nfields independent fields on the current grid set; field f at d_zin + f*ni_in*nj_in, d_zout + f*ni_out*nj_out */
 int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields);
+/* the same launch additionally leaves, per field, {min key, max key, 0} triples (order-preserving uint32 keys of the floats)
+ * of every thread block's output at d_partials[f * stride_words + 3 k], k < *partials_per_field -- compact_float's
+ * min/max pass fused into the interpolation.  -2: the plan has no single-launch path (use c_ezsint_batch_dev). */
+int32_t ezhip_ezsint_batch_minmax_dev(float *d_zout, const float *d_zin, int32_t nfields, uint32_t *d_partials,
+                                      int64_t stride_words, int32_t *partials_per_field);
 /* forces plan construction for the current set / options (what the reference does lazily in its first call) */
 int32_t ezhip_prepare_set(void);
 /* which kernel family the current set uses: 1 = separable (k_sep), 2 = per-point (k_pts) */

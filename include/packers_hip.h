@@ -51,6 +51,12 @@ int   armn_compress_dev(void *d_z, const void *d_words, int ni, int nj, int nbit
  * (fstd98.c:1170-1172).  d_record receives [4 header words][stream]; returns zlng (>0), or -1 when the
  * field is not compressible (d_record then holds the plain 16-bit-slot pack). */
 int   ezhip_pack16_compress_dev(void *d_record, const float *d_field, int ni, int nj, int nbits);
+/* fused front half of the cfg5 pipeline: c_ezsint_batch_dev on the current grid set + compact_float(nbits + 64*max(16,nbits),
+ * header style 2: fstd98.c:1170) of every output field, on the calling thread's stream, no synchronisation.  The min/max
+ * pass of compact_float is fused into the interpolation kernel.  d_records: nfields records of record_stride_words
+ * words, [4 header words][stream]; d_zout keeps the interpolated fields.  Returns the c_ezsint code (0 / 2) or -1. */
+int32_t ezhip_ezsint_pack16_batch_dev(void *d_records, int64_t record_stride_words, float *d_zout, const float *d_zin,
+                                      int32_t nfields, int32_t npts_out, int32_t nbits);
 /* frees the calling thread's grow-only device workspaces (staged operands of the host-pointer entry points,
  * the compressed stream, the armn_compress scan storage); they are re-created on the next call */
 void  ezhip_pack_release(void);

@@ -1072,9 +1072,7 @@ static void build_sepx_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, int degree, 
     p->debug_flags = getenv("EZHIP_DEBUG") ? atoi(getenv("EZHIP_DEBUG")) : 0;
     for (int bx = 0; bx < nbx; bx++) if (blk_base[bx] < 0) return;
     if ((size_t)njr * (size_t)nic >= ((size_t)1 << 31)) return;
-    /* target rows per step (row-block of k_sepx): 8 -> smaller ring and patch, more thread blocks per CU */
-    int xr_rows = getenv("EZHIP_SEPX_ROWS") ? atoi(getenv("EZHIP_SEPX_ROWS")) : 16;
-    if (xr_rows != 8) xr_rows = 16;
+    const int xr_rows = EZHIP_SEP_ROWS;          /* target rows per step (row-block of k_sepx) */
     int nby = (njr + xr_rows - 1) / xr_rows;
     int *vb = (int *)malloc(sizeof(int) * (nby + 1)), *wa = (int *)malloc(sizeof(int) * (nby + 1)), *wn = (int *)malloc(sizeof(int) * (nby + 1));
     int nvb = 0, tr = 4, ok = 1;
@@ -1492,7 +1490,10 @@ static int ensure_batch_poles(ezh_set *s, int nfields)
     return s->d_poles_batch ? 0 : -1;
 }
 
-int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields)
+/* stat_partials != NULL: the launch also leaves, per field, {min key, max key, 0} triples of every thread block's
+ * output at stat_partials[f * stat_stride + 3 k], k < *partials_per_field (compact_float's min/max pass fused into the
+ * interpolation); only the single-launch k_sepx path can do that: returns -2 when it does not apply */
+static int32_t batch_impl(float *d_zout, const float *d_zin, int32_t nfields, unsigned *stat_partials, size_t stat_stride, int32_t *partials_per_field)
 {
     ezh_set *s = current_set("c_ezsint_batch");
     if (!s) return -1;
@@ -1501,7 +1502,7 @@ int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields)
     int rc = 0;
     /* separable plan without extrapolation fill: ALL fields in one k_sepx launch (no ramp-up / drain gap between
      * fields; the pole rows are summed by producer blocks of the same launch) */
-    if (s->gdin != s->gdout && nfields > 1 && !(O.polar_correction == 1 && s->extrap) &&
+    if (s->gdin != s->gdout && (nfields > 1 || stat_partials) && !(O.polar_correction == 1 && s->extrap) &&
         (O.degre_interp == DEG_NEAREST || O.degre_interp == DEG_LINEAR || O.degre_interp == DEG_CUBIC) &&
         choose_mode(s, O.degre_interp, O.polar_correction == 1) == 1 && !getenv("EZHIP_NO_BATCH_LAUNCH") && !getenv("EZHIP_NO_SEPX")) {
         int degree = O.degre_interp, polar = O.polar_correction == 1;
@@ -1520,9 +1521,16 @@ int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields)
                 }
             }
             p.batch_fields = nfields; p.batch_in_stride = nin; p.batch_out_stride = nout;
+            if (stat_partials) {
+                int nbx = (p.ni_dst + EZHIP_SEP_COLS - 1) / EZHIP_SEP_COLS, npf = nbx * (p.x_nseg + p.n_special);
+                if ((size_t)3 * npf > stat_stride) return -2;
+                p.stat_partials = stat_partials; p.stat_stride = stat_stride;
+                if (partials_per_field) *partials_per_field = npf;
+            }
             return ezhip_interp_sep(&p, d_zout, d_zin) ? -1 : 0;
         }
     }
+    if (stat_partials) return -2;
     /* field by field; the pole values (a sequential REAL sum per pole row) of ALL fields from one k_polevals launch */
     float *d_poles_all = NULL;
     if (s->gdin != s->gdout && O.polar_correction == 1 && !s->extrap && nfields > 1) {
@@ -1540,6 +1548,17 @@ int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields)
         if (r > rc) rc = r;
     }
     return rc;
+}
+
+int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields)
+{
+    return batch_impl(d_zout, d_zin, nfields, NULL, 0, NULL);
+}
+
+int32_t ezhip_ezsint_batch_minmax_dev(float *d_zout, const float *d_zin, int32_t nfields, uint32_t *d_partials, int64_t stride_words, int32_t *partials_per_field)
+{
+    if (!d_partials || stride_words <= 0) return -1;
+    return batch_impl(d_zout, d_zin, nfields, d_partials, (size_t)stride_words, partials_per_field);
 }
 
 int32_t ezhip_prepare_set(void)

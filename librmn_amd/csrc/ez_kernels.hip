@@ -142,6 +142,10 @@ __device__ float block_poleval(const float *zrow, int ni, int weighted, const fl
     return s;
 }
 
+/* order-preserving float <-> uint32 keys (min / max by integer compare) */
+__device__ __forceinline__ unsigned f2key(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
 /* ===================================================================================== */
 /* k_sep : separable interpolation                                                          */
 /* ===================================================================================== */
@@ -360,8 +364,8 @@ __device__ void sep_rowblock_gather(const ezhip_sep_plan &p, RowInfo &ri, float 
 /* special target rows of one column block: polar strips, pole rows, fully-outside rows (blockIdx.y indexes
  * p.special).  Pole values come precomputed (p.polevals). */
 template <int DEG>
-__device__ void sep_special(const ezhip_sep_plan &p, float *__restrict__ zout, const float *__restrict__ zin, int ispecial,
-                            int c, int cc, bool cvalid, float fillv)
+__device__ float sep_special(const ezhip_sep_plan &p, float *__restrict__ zout, const float *__restrict__ zin, int ispecial,
+                             int c, int cc, bool cvalid, float fillv)
 {
     const int nis = p.ni_src;
     /* ---- special rows: polar strips, pole rows, fully-outside rows ------------------------- */
@@ -398,6 +402,7 @@ __device__ void sep_special(const ezhip_sep_plan &p, float *__restrict__ zout, c
         }
     }
     if (cvalid) zout[(size_t)sr.row * p.ni_dst + c] = outv;
+    return outv;       /* lanes past the last column carry the value of the last column */
 }
 
 /* k_sep: the tile kernel, one (256-column block, 16-row block) per thread block: stage the source patch, barrier,
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
             sep_rows_staged<DEG>(p, mine, smem, p.wstride, off0, cw, by * EZHIP_SEP_ROWS, zout, c, cvalid, cdehors, fillv);
         return;
     }
-    sep_special<DEG>(p, zout, zin, blockIdx.y, c, cc, cvalid, fillv);
+    (void)sep_special<DEG>(p, zout, zin, blockIdx.y, c, cc, cvalid, fillv);
 }
 
 /* ===================================================================================== */
@@ -478,9 +483,9 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
 /* y-pass of one wave and one row-block: 2 row pairs x 8 column groups of 32.  `myrec` = this lane's row record of
  * the first pair (the second pair is 8 records further), `tcol` = ring base of the lane's column in group 0.
  * SLOW adds what few blocks need: the DEHORS fill select, the column bound of the last strip, the debug knock-out. */
-template <int DEG, int XR, bool SLOW>
+template <int DEG, int XR, bool SLOW, bool STATS>
 __device__ __forceinline__ void sepx_ypass(const float *myrec, const double *tcol, float *zcol, float fillv, unsigned dmask,
-                                           int l32, int ncol_valid, bool nostore)
+                                           int l32, int ncol_valid, bool nostore, float &vmin, float &vmax)
 {
 #pragma unroll
     for (int h = 0; h < XR / 8; h++) {
@@ -534,13 +539,31 @@ __device__ __forceinline__ void sepx_ypass(const float *myrec, const double *tco
             float out = (float)val;
             if (SLOW) {
                 out = (dmask >> g) & 1 ? fillv : out;
-                if (!nostore && l32 + 32 * g < ncol_valid) orow[32 * g] = out;
-            } else orow[32 * g] = out;
+                if (!nostore && l32 + 32 * g < ncol_valid) { orow[32 * g] = out; if (STATS) { vmin = fminf(vmin, out); vmax = fmaxf(vmax, out); } }
+            } else { orow[32 * g] = out; if (STATS) { vmin = fminf(vmin, out); vmax = fmaxf(vmax, out); } }
         }
     }
 }
 
-template <int DEG, int XR>
+/* {min key, max key, 0} of the values a thread block stored -> triple `slot` of the field's partials (the layout
+ * k_cf_header reduces: compact_float's min/max pass fused into the interpolation, STATS instantiation only) */
+__device__ __forceinline__ void block_minmax_partial(float vmin, float vmax, unsigned *triple)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        vmin = fminf(vmin, __shfl_down(vmin, off, 64));
+        vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+    }
+    __shared__ float shm[2][SEP_BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) { shm[0][threadIdx.x >> 6] = vmin; shm[1][threadIdx.x >> 6] = vmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = fminf(fminf(shm[0][0], shm[0][1]), fminf(shm[0][2], shm[0][3]));
+        float b = fmaxf(fmaxf(shm[1][0], shm[1][1]), fmaxf(shm[1][2], shm[1][3]));
+        triple[0] = f2key(a); triple[1] = f2key(b); triple[2] = 0u;
+    }
+}
+
+template <int DEG, int XR, bool STATS>
 __global__ __launch_bounds__(SEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 6)))
 void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict__ zin)
 {
@@ -603,7 +626,8 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
             }
         } else if (p.polevals) p.polevals += 2 * bz;
-        sep_special<DEG>(p, zout, zin, by - sp0, c, cc, c < p.ni_dst, fillv);
+        const float sv = sep_special<DEG>(p, zout, zin, by - sp0, c, cc, c < p.ni_dst, fillv);
+        if (STATS) block_minmax_partial(sv, sv, p.stat_partials + (size_t)bz * p.stat_stride + 3 * (size_t)(by * p.x_nbx + bx));
         return;
     }
     const int seg = by < sp0 ? by : by - p.n_special;
@@ -660,6 +684,7 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
         if (wv * 64 < SEPX_REC_DW)
             lds_dma_dword((const float *)(p.x_rows + (size_t)i * XR), (unsigned)(threadIdx.x * 4), lds_addr_of(rec + (i & 1) * SEPX_REC_DW + wv * 64));
     };
+    float vmin = INFINITY, vmax = -INFINITY;                 /* STATS: extrema of the values this lane stores */
     ezhip_xstep st = load_step(p.x_first, i0);
     dma_issue(st, i0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -693,8 +718,8 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
         /* ---- y-pass: wave wv owns target rows {2 wv, 2 wv + 1} and {8 + 2 wv, 9 + 2 wv} of the row-block */
         if (!(dbg & 16)) {
             const float *myrec = rec + (i & 1) * SEPX_REC_DW + (2 * wv + rsub) * 16;
-            if (slow) sepx_ypass<DEG, XR, true>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, (dbg & 1) != 0);
-            else sepx_ypass<DEG, XR, false>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, false);
+            if (slow) sepx_ypass<DEG, XR, true, STATS>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, (dbg & 1) != 0, vmin, vmax);
+            else sepx_ypass<DEG, XR, false, STATS>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, false, vmin, vmax);
         }
         st = nst;
         if ((dbg & 16) || slow) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -702,6 +727,7 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
             if (XR == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
     }
+    if (STATS) block_minmax_partial(vmin, vmax, p.stat_partials + (size_t)bz * p.stat_stride + 3 * (size_t)(by * p.x_nbx + bx));
 }
 
 extern "C" size_t ezhip_sepx_lds_bytes(int x_tr, int rows_per_step, int x_prows, int wstride)
@@ -711,13 +737,14 @@ extern "C" size_t ezhip_sepx_lds_bytes(int x_tr, int rows_per_step, int x_prows,
     return b;
 }
 
-#define SEPX_DISPATCH(DEGV, XRV, EXPR) do { \
-        if ((DEGV) == 0 && (XRV) == 8) { constexpr int D = 0, X = 8; EXPR; } \
-        else if ((DEGV) == 0) { constexpr int D = 0, X = 16; EXPR; } \
-        else if ((DEGV) == 1 && (XRV) == 8) { constexpr int D = 1, X = 8; EXPR; } \
-        else if ((DEGV) == 1) { constexpr int D = 1, X = 16; EXPR; } \
-        else if ((XRV) == 8) { constexpr int D = 3, X = 8; EXPR; } \
-        else { constexpr int D = 3, X = 16; EXPR; } } while (0)
+/* rows per step: 16 (8 was measured too: smaller ring and patch, 4 blocks per CU, twice the barriers -- no gain) */
+#define SEPX_DISPATCH(DEGV, STATSV, EXPR) do { \
+        if ((DEGV) == 0 && !(STATSV)) { constexpr int D = 0, X = 16; constexpr bool S = false; EXPR; } \
+        else if ((DEGV) == 1 && !(STATSV)) { constexpr int D = 1, X = 16; constexpr bool S = false; EXPR; } \
+        else if (!(STATSV)) { constexpr int D = 3, X = 16; constexpr bool S = false; EXPR; } \
+        else if ((DEGV) == 0) { constexpr int D = 0, X = 16; constexpr bool S = true; EXPR; } \
+        else if ((DEGV) == 1) { constexpr int D = 1, X = 16; constexpr bool S = true; EXPR; } \
+        else { constexpr int D = 3, X = 16; constexpr bool S = true; EXPR; } } while (0)
 
 extern "C" int ezhip_sepx_capacity(int degree, int rows_per_step, size_t lds_bytes)
 {
@@ -725,7 +752,8 @@ extern "C" int ezhip_sepx_capacity(int degree, int rows_per_step, size_t lds_byt
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     hipError_t e = hipSuccess;
-    SEPX_DISPATCH(degree, rows_per_step, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<D, X>, SEP_BLOCK, lds_bytes));
+    (void)rows_per_step;
+    SEPX_DISPATCH(degree, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<D, X, S>, SEP_BLOCK, lds_bytes));
     if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
     return nb * ncu;
 }
@@ -744,11 +772,11 @@ static int launch_sepx(const ezhip_sep_plan *plan, float *d_zout, const float *d
     pl.x_lds_bytes = lds;
     if (lds > 64 * 1024) {        /* tall windows on wide strips: raise the per-kernel dynamic LDS limit */
         hipError_t e = hipSuccess;
-        SEPX_DISPATCH(plan->degree, plan->x_rows_per_step,
-                      e = hipFuncSetAttribute((const void *)k_sepx<D, X>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SEPX_DISPATCH(plan->degree, plan->stat_partials != nullptr,
+                      e = hipFuncSetAttribute((const void *)k_sepx<D, X, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (e != hipSuccess) return set_err(e, "k_sepx LDS size");
     }
-    SEPX_DISPATCH(plan->degree, plan->x_rows_per_step, hipLaunchKernelGGL((k_sepx<D, X>), grid, block, lds, g_stream, *plan, d_zout, d_zin));
+    SEPX_DISPATCH(plan->degree, plan->stat_partials != nullptr, hipLaunchKernelGGL((k_sepx<D, X, S>), grid, block, lds, g_stream, *plan, d_zout, d_zin));
     return LAUNCH_CHECK("k_sepx");
 }
 
@@ -1281,8 +1309,6 @@ extern "C" int ezhip_polevals(float *d_out2, const float *d_zin, int ni, int nj,
 }
 
 /* float min/max through order-preserving unsigned keys (no NaN handling: the reference has none) */
-__device__ __forceinline__ unsigned f2key(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
-__device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
 __global__ __launch_bounds__(256) void k_minmax(unsigned *keys2, const float *z, size_t n)
 {

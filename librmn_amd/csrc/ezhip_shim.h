@@ -115,6 +115,9 @@ typedef struct {
     int pole_blocks; unsigned pole_epoch;
     float *pole_vals; unsigned *pole_flags;
     int x_nbx; size_t x_lds_bytes;    /* set by the launcher: column strips, dynamic LDS bytes */
+    /* fused compact_float min/max (k_sepx<.., STATS>): every thread block writes {min key, max key, 0} of the values it
+     * stored to stat_partials[field * stat_stride + 3 * (work item in field)]; NULL: not requested */
+    unsigned *stat_partials; size_t stat_stride;
     size_t batch_in_stride, batch_out_stride;   /* floats between consecutive fields */
     const ezhip_xstep *x_first, *x_cont;   /* [x_nvb] staging step of a row-block when it starts a segment / continues one */
     const ezhip_xrow *x_rows;         /* [x_nvb * x_rows_per_step] row records */

@@ -27,7 +27,7 @@ static __thread void *t_scratch = NULL;
 /* per-thread grow-only device workspaces (slot 0/1: staged operands of the host-pointer entry points and the
  * compressed stream, slot 2: armn_compress scan storage): hipMalloc + hipFree per call cost more than the kernels
  * (a 52 MB hipMalloc/hipFree pair is ~0.4 ms and hipFree synchronises the device) */
-static __thread struct { void *p; size_t cap; } t_ws[3];
+static __thread struct { void *p; size_t cap; } t_ws[4];
 static void *ws(int slot, size_t bytes)
 {
     if (t_ws[slot].cap < bytes) {
@@ -41,7 +41,7 @@ static void *ws(int slot, size_t bytes)
 void ezhip_pack_release(void)
 {
     ezhip_sync();
-    for (int k = 0; k < 3; k++) { ezhip_free(t_ws[k].p); t_ws[k].p = NULL; t_ws[k].cap = 0; }
+    for (int k = 0; k < 4; k++) { ezhip_free(t_ws[k].p); t_ws[k].p = NULL; t_ws[k].cap = 0; }
 }
 
 static void *scratch(void)
@@ -410,4 +410,43 @@ int ezhip_pack16_compress_dev(void *d_record, const float *d_field, int ni, int 
     if (zlng > 0 && ezhip_d2d(rec + 4, d_z, (size_t)zlng)) zlng = -1;
     ezhip_sync();
     return zlng;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* fused cfg5 front half: interpolate a batch and pack every output field to 16-bit slots         */
+/* ------------------------------------------------------------------------------------------ */
+int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields);
+int32_t ezhip_ezsint_batch_minmax_dev(float *d_zout, const float *d_zin, int32_t nfields, uint32_t *d_partials, int64_t stride_words, int32_t *partials_per_field);
+
+/* c_ezsint_batch_dev + compact_float(nbits + 64*max(16,nbits), style 2) of every output field (fstd98.c:1170), all on
+ * the calling thread's stream, no synchronisation.  The min/max pass of compact_float comes out of the interpolation
+ * kernel itself (every k_sepx thread block leaves the extrema of what it stored; the header kernel reduces them), so
+ * packing a field costs the token kernel only.  d_records: nfields records of record_stride_words words,
+ * [4 header words][stream].  Returns the c_ezsint_batch_dev code (0 / 2) or -1. */
+int32_t ezhip_ezsint_pack16_batch_dev(void *d_records, int64_t record_stride_words, float *d_zout, const float *d_zin,
+                                      int32_t nfields, int32_t npts_out, int32_t nbits)
+{
+    if (need_device("ezhip_ezsint_pack16_batch_dev")) return -1;
+    if (nfields < 1 || npts_out < 1 || nbits < 1 || nbits > 32) return -1;
+    const int bs = nbits, eff = nbits > 16 ? nbits : 16;
+    const size_t stride = PACKHIP_STATS_PARTIALS + 3 * (size_t)8192;          /* words per field: result area + up to 8192 triples */
+    unsigned *d_stats_all = (unsigned *)ws(3, (4 * stride + sizeof(packhip_cf_params)) * (size_t)nfields + 64);
+    if (!d_stats_all) return -1;
+    packhip_cf_params *d_pp = (packhip_cf_params *)(d_stats_all + stride * (size_t)nfields);      /* one per field */
+    int32_t npf = 0;
+    int32_t rc = ezhip_ezsint_batch_minmax_dev(d_zout, d_zin, nfields, d_stats_all + PACKHIP_STATS_PARTIALS, (int64_t)stride, &npf);
+    int fused = rc >= 0;
+    if (rc == -2) rc = c_ezsint_batch_dev(d_zout, d_zin, nfields);             /* plan without the single-launch path: plain pipeline */
+    if (rc < 0) return -1;
+    float tag = 0.f;
+    if (fused && packhip_cf_header_batch(d_pp, (unsigned *)d_records, (size_t)record_stride_words, d_stats_all, stride,
+                                         npf, (unsigned)npts_out, bs, 2, 0, nfields)) return -1;       /* all headers in one launch */
+    for (int f = 0; f < nfields; f++) {
+        unsigned *rec = (unsigned *)d_records + (size_t)f * (size_t)record_stride_words;
+        float *field = d_zout + (size_t)f * (size_t)npts_out;
+        if (fused) {
+            if (packhip_cf_pack(rec + 4, field, (size_t)npts_out, eff, 0, 1, d_pp + f, 0, tag)) return -1;
+        } else if (!compact_float_dev(field, rec, rec + 4, npts_out, nbits + 64 * eff, 0, 1, 1, 0, &tag, 2)) return -1;
+    }
+    return rc;
 }

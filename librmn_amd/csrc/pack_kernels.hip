@@ -41,7 +41,9 @@ __global__ __launch_bounds__(256) void k_stats(unsigned *stats, const unsigned *
         else if (KIND == 1) k = raw; else k = raw ^ 0x80000000u;                                                   \
         if (!skip) { kmin = min(kmin, k); kmax = max(kmax, k); kor |= raw; } } while (0)
     size_t i0 = 0;
-    if (stride == 1 && ((uintptr_t)a & 15) == 0) {          /* 16 B per lane, four loads in flight */
+    /* 16 B per lane, four loads in flight; normally ONE pass per block (grid = n / 4096: the many-short-blocks shape
+     * of k_cf_pack16 streams at 6.9 TB/s where a 2048-block grid-stride loop reached 3.9) */
+    if (stride == 1 && ((uintptr_t)a & 15) == 0) {
         const uint4 *a4 = (const uint4 *)a;
         size_t n4 = n / 4, step = (size_t)gridDim.x * 256;
         size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -120,8 +122,11 @@ extern "C" int packhip_stats(unsigned *d_stats, const void *d_a, size_t n, int s
 /* ------------------------------------------------------------------------------------------ */
 /* compact_float: header (compact.tmplc:210-290) on one lane, then the token stream               */
 /* ------------------------------------------------------------------------------------------ */
-__global__ __launch_bounds__(256) void k_cf_header(packhip_cf_params *pp, unsigned *hdr, unsigned *stats, int npartials, unsigned n, int bs, int style, int has_missing)
+/* one thread block per field: blockIdx.x selects {params, header, stats} through the strides (all 0 for a single field) */
+__global__ __launch_bounds__(256) void k_cf_header(packhip_cf_params *pp, unsigned *hdr, unsigned *stats, int npartials, unsigned n, int bs, int style, int has_missing,
+                                                   size_t hdr_stride_words, size_t stats_stride_words)
 {
+    pp += blockIdx.x; hdr += blockIdx.x * hdr_stride_words; stats += blockIdx.x * stats_stride_words;
     if (npartials > 0) stats_reduce_partials(stats, npartials);     /* fused final reduction of k_stats (one launch less) */
     if (threadIdx.x != 0) return;
     double minF = (double)key2f(stats[0]), maxF = (double)key2f(stats[1]);
@@ -212,7 +217,14 @@ __global__ __launch_bounds__(256) void k_cf_pack16(uint4 *out, const float4 *a, 
 
 extern "C" int packhip_cf_header(packhip_cf_params *d_pp, unsigned *d_hdr, unsigned *d_stats, int npartials, unsigned n, int bs, int style, int has_missing)
 {
-    hipLaunchKernelGGL(k_cf_header, dim3(1), dim3(256), 0, STREAM, d_pp, d_hdr, d_stats, npartials, n, bs, style, has_missing);
+    hipLaunchKernelGGL(k_cf_header, dim3(1), dim3(256), 0, STREAM, d_pp, d_hdr, d_stats, npartials, n, bs, style, has_missing, (size_t)0, (size_t)0);
+    return chk("k_cf_header");
+}
+/* nfields headers in one launch: field f uses d_pp[f], d_hdr + f * hdr_stride_words, d_stats + f * stats_stride_words */
+extern "C" int packhip_cf_header_batch(packhip_cf_params *d_pp, unsigned *d_hdr, size_t hdr_stride_words, unsigned *d_stats, size_t stats_stride_words,
+                                       int npartials, unsigned n, int bs, int style, int has_missing, int nfields)
+{
+    hipLaunchKernelGGL(k_cf_header, dim3(nfields), dim3(256), 0, STREAM, d_pp, d_hdr, d_stats, npartials, n, bs, style, has_missing, hdr_stride_words, stats_stride_words);
     return chk("k_cf_header");
 }
 

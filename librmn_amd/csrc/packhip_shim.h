@@ -14,13 +14,15 @@ typedef struct {
 
 /* device scratch layout of the reductions: result words, then one {min,max,or} triple per block */
 #define PACKHIP_STATS_PARTIALS 256
-#define PACKHIP_STATS_MAXBLK 2048
+#define PACKHIP_STATS_MAXBLK 16384          /* one block per 4096 elements up to 67 M elements, then blocks loop */
 #define PACKHIP_STATS_WORDS (PACKHIP_STATS_PARTIALS + 3 * PACKHIP_STATS_MAXBLK)
 /* stats[0..2] = min key, max key, OR; kind 0 float keys, 1 uint32, 2 int32 (biased by 0x80000000) */
 int packhip_stats(unsigned *d_stats, const void *d_a, size_t n, int stride, int kind, int has_missing, float tag);
 /* per-block partials only (returns their count, -1 on error); packhip_cf_header(npartials > 0) reduces them itself */
 int packhip_stats_partials(unsigned *d_stats, const void *d_a, size_t n, int stride, int kind, int has_missing, float tag);
 int packhip_cf_header(packhip_cf_params *d_pp, unsigned *d_hdr, unsigned *d_stats, int npartials, unsigned n, int bs, int style, int has_missing);
+int packhip_cf_header_batch(packhip_cf_params *d_pp, unsigned *d_hdr, size_t hdr_stride_words, unsigned *d_stats, size_t stats_stride_words,
+                            int npartials, unsigned n, int bs, int style, int has_missing, int nfields);
 int packhip_cf_pack(unsigned *d_out, const float *d_a, size_t n, int E, int offset, int stride,
                     const packhip_cf_params *d_pp, int has_missing, float tag);
 int packhip_cf_unpack(float *d_a, const unsigned *d_in, size_t n, int tokenSize, int offset, int stride,

@@ -26,6 +26,8 @@ def _lib():
         L.compact_integer_dev.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci]
         L.armn_compress_dev.argtypes = [vp, vp, ci, ci, ci]
         L.ezhip_pack16_compress_dev.argtypes = [vp, vp, ci, ci, ci]
+        L.ezhip_ezsint_pack16_batch_dev.argtypes = [vp, ctypes.c_int64, vp, vp, ci, ci, ci]
+        L.ezhip_pack_release.restype = None
         _configured = True
     return L
 
@@ -110,3 +112,12 @@ def armn_compress_dev(d_z, d_words, ni, nj, nbits):
 
 def pack16_compress_dev(d_record, d_field, ni, nj, nbits):
     return _lib().ezhip_pack16_compress_dev(_dptr(d_record), _dptr(d_field), ni, nj, nbits)
+
+
+def ezsint_pack16_batch_dev(d_records, record_stride_words, d_zout, d_zin, nfields, npts_out, nbits):
+    """fused c_ezsint_batch_dev + compact_float 16-bit-slot pack of every output field (min/max from the interpolation kernel)"""
+    return _lib().ezhip_ezsint_pack16_batch_dev(_dptr(d_records), record_stride_words, _dptr(d_zout), _dptr(d_zin), nfields, npts_out, nbits)
+
+
+def pack_release():
+    _lib().ezhip_pack_release()

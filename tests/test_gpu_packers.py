@@ -139,3 +139,37 @@ def test_cfg5_pipeline_full_size_device_resident():
     nfull = 4 + (zw - 1) // 4
     assert np.array_equal(got[:nfull], want[:nfull])
     assert zw < 0.5 * n * 2                                  # a smooth field compresses
+
+
+@pytest.mark.parametrize("degree", ["cubic", "nearest"])
+def test_fused_interp_pack16_equals_separate_steps(degree):
+    """ezhip_ezsint_pack16_batch_dev (compact_float's min/max pass fused into the interpolation kernel) leaves the same
+    fields and bit-identical records as c_ezsint_batch_dev followed by compact_float_dev per field; and the records
+    equal the CPU oracle's compact_float of the interpolated field."""
+    import torch
+    from librmn_amd import ezscint as ez
+    import ezcases as ec
+    ni, nj, no, mo, F, nbits = 360, 181, 520, 261, 3, 16
+    gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(no, mo, "L", 69, 69, 0, 0)
+    assert ez.ezdefset(gdout, gdin) == 1
+    assert ez.ezsetopt("interp_degree", degree) == 0 and ez.ezsetopt("polar_correction", "yes") == 0
+    ez.use_stream(torch.cuda.current_stream().cuda_stream)
+    d_in = torch.stack([torch.from_numpy(ec.synth_field(ni, nj, seed=90 + f)) for f in range(F)]).cuda().contiguous()
+    n = no * mo
+    rs = 4 + (n + 1) // 2 + 8
+    out_a = torch.empty((F, n), dtype=torch.float32, device="cuda"); out_b = torch.empty_like(out_a)
+    rec_a = torch.zeros((F, rs), dtype=torch.int32, device="cuda"); rec_b = torch.zeros_like(rec_a)
+    assert pk.ezsint_pack16_batch_dev(rec_a, rs, out_a, d_in, F, n, nbits) == 0
+    assert ez.ezsint_batch_dev(out_b, d_in, F) == 0
+    for f in range(F):
+        assert pk.compact_float_pack_dev(out_b[f], rec_b[f], rec_b[f][4:], n, nbits + 64 * 16) != 0
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    assert torch.equal(rec_a, rec_b)
+    # against the oracle packer on the GPU-interpolated field
+    z = out_a[1].cpu().numpy()
+    want = top.pack_float(z, nbits + 64 * 16)
+    got = rec_a[1].cpu().numpy().view(np.uint32)
+    m = 4 + (n + 1) // 2
+    assert np.array_equal(got[:m], want[:m])
+    assert ez.ezsetopt("interp_degree", "cubic") == 0
