@@ -449,7 +449,7 @@ __device__ __forceinline__ unsigned tile_bits(int PARA, unsigned need, int cnt, 
 }
 
 #define SCAN_TPB 256
-#define SCAN_ITEMS 8      /* tiles per thread */
+#define SCAN_ITEMS 4      /* tiles per thread (1024 tiles per block: the emit kernel's LDS image stays at 20 KB, 5 blocks per CU) */
 /* pass B: per-block total of tile bit lengths */
 template <int PARA>
 __global__ __launch_bounds__(SCAN_TPB) void k_armn_blocksum(unsigned long long *bsum, const unsigned char *nb, const unsigned *gt16,
@@ -524,7 +524,7 @@ typedef __attribute__((address_space(3))) unsigned *lds_uptr;
  * words) is assembled in LDS, word-aligned with the global stream, and copied out with coalesced stores; only the
  * block's first and last words are shared with the neighbouring blocks (atomicOr into the zeroed stream).  Blocks whose
  * range does not fit (MINIMUM method with wide tokens) write directly. */
-#define EMIT_LDS_WORDS 12288
+#define EMIT_LDS_WORDS 6144
 template <int PARA>
 __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit(unsigned *z, const unsigned long long *bsum, const unsigned char *nb, const unsigned *gt16,
                                                         const unsigned *w, int ni, int nj, int istep, int ntx, long long ntiles, int nbits,
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit(unsigned *z, const unsig
  * Here phase 0 turns the per-thread scan into per-tile bit offsets (LDS), then every lane takes one token slot
  * (tile, row, column), computes difference, width and absolute bit position in closed form and ORs its bits into the
  * block's LDS image of the stream (ds_or_b32, at most two words); the image is copied out with coalesced stores. */
-#define TOK_LDS_WORDS 10240        /* >= 2048 tiles x (5 + 9 x 17) bits + alignment */
+#define TOK_LDS_WORDS (SCAN_TPB * SCAN_ITEMS * 5 + 64)        /* >= tiles per block x (5 + 9 x 17) bits / 32 + alignment */
 __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit_tok(unsigned *z, const unsigned long long *bsum, const unsigned char *nb, const unsigned *gt16,
                                                             const unsigned *w, int ni, int nj, int ntx, long long ntiles, int nbits,
                                                             unsigned long long body_start)
@@ -617,6 +617,7 @@ __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit_tok(unsigned *z, const u
     __shared__ unsigned long long sh[SCAN_TPB];
     __shared__ unsigned stage[TOK_LDS_WORDS];
     __shared__ unsigned tmeta[SCAN_TPB * SCAN_ITEMS];      /* bit offset of the tile in the block (28 bits) | need << 28 */
+    __shared__ unsigned tcoord[SCAN_TPB * SCAN_ITEMS];     /* tile column | tile row << 16 (the launcher checks ntx, nty < 65536) */
     const int container = (nbits >= 15 && *gt16) ? 5 : 4;
     const long long tbase = (long long)blockIdx.x * SCAN_TPB * SCAN_ITEMS;
     const long long base = tbase + (long long)threadIdx.x * SCAN_ITEMS;
@@ -641,10 +642,13 @@ __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit_tok(unsigned *z, const u
     const size_t nw = (size_t)((blk_pos + blk_bits + 31) >> 5) - w0;           /* <= TOK_LDS_WORDS by construction */
     {
         unsigned off = (unsigned)(blk_pos & 31) + (unsigned)(sh[threadIdx.x] - mine);
+        unsigned ty = (unsigned)(base / ntx), tx = (unsigned)(base - (long long)ty * ntx);      /* one division per thread, not per token */
         for (int q = 0; q < SCAN_ITEMS; q++) {
             long long t = base + q;
             tmeta[threadIdx.x * SCAN_ITEMS + q] = off | ((t < ntiles ? (unsigned)nb[t] : 0u) << 28);
+            tcoord[threadIdx.x * SCAN_ITEMS + q] = tx | (ty << 16);
             off += lbits[q];
+            if (++tx == (unsigned)ntx) { tx = 0; ty++; }
         }
     }
     for (size_t k = threadIdx.x; k < nw; k += SCAN_TPB) stage[k] = 0;
@@ -662,9 +666,8 @@ __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit_tok(unsigned *z, const u
             if ((unsigned)v) atomicOr(&stage[wi + 1], (unsigned)v);
         }
         if (!need) continue;
-        const unsigned t = (unsigned)(tbase + tl);
-        const unsigned ty = t / (unsigned)ntx, tx = t - ty * (unsigned)ntx;
-        const int i0 = 1 + (int)tx * 3, j0 = 1 + (int)ty * 3;
+        const unsigned tc = tcoord[tl];
+        const int i0 = 1 + (int)(tc & 0xFFFFu) * 3, j0 = 1 + (int)(tc >> 16) * 3;
         const int tm = min(3, ni - i0), tn = min(3, nj - j0);
         const int n_ = pos / 3, m_ = pos - 3 * n_;
         if (m_ >= tm || n_ >= tn) continue;
@@ -729,7 +732,7 @@ extern "C" int packhip_armn_encode(unsigned *d_z, size_t z_words, const unsigned
         hipLaunchKernelGGL(k_armn_scan, dim3(1), dim3(256), 0, st, bsum, nblocks, total);
         hipLaunchKernelGGL(k_armn_prefix, dim3((ni + nj + 255) / 256), dim3(256), 0, st, d_z, d_words, gt16, ni, nj, nbits, header);
         body_start = 32 + 3 + (unsigned long long)(ni + nj - 1) * nbits;
-        if (getenv("EZHIP_ARMN_SEQ_EMIT"))     /* development: the per-thread sequential writer */
+        if (getenv("EZHIP_ARMN_SEQ_EMIT") || ntx >= 65536 || nty >= 65536)     /* development / huge fields: the per-thread sequential writer */
             hipLaunchKernelGGL(k_armn_emit<1>, dim3(nblocks), dim3(SCAN_TPB), 0, st, d_z, bsum, nb, gt16, d_words, ni, nj, istep, ntx, ntiles, nbits, body_start);
         else
             hipLaunchKernelGGL(k_armn_emit_tok, dim3(nblocks), dim3(SCAN_TPB), 0, st, d_z, bsum, nb, gt16, d_words, ni, nj, ntx, ntiles, nbits, body_start);
