@@ -70,6 +70,7 @@ typedef struct {
     int coords_ready, separable;
     float *lat1d, *lon1d, *lat2d, *lon2d;
     float *d_lat, *d_lon; int d_coords_valid;
+    double *d_windtrig;                    /* this grid as a separable wind TARGET: {cos,sin}(lon) per column, then {cos,sin}(lat) per row */
     float *d_plon2; float xg4_pole[2];     /* this grid as a wind SOURCE: longitudes of its last / first row, PS-frame xg4 (N, S) */
     ezh_set *sets;                          /* sets having this grid as gdout */
 } ezh_grid;
@@ -493,7 +494,7 @@ int32_t c_gdrls(int32_t gd)          /* gdrls.c:34-77: refcount, free at zero */
         free(g->ax); free(g->ay); free(g->ncx); free(g->ncy);
         free(g->lat1d); free(g->lon1d); free(g->lat2d); free(g->lon2d);
         ezhip_free(g->d_ax); ezhip_free(g->d_ay); ezhip_free(g->d_ncx); ezhip_free(g->d_ncy);
-        ezhip_free(g->d_lat); ezhip_free(g->d_lon); ezhip_free(g->d_plon2); g->d_plon2 = NULL;
+        ezhip_free(g->d_lat); ezhip_free(g->d_lon); ezhip_free(g->d_plon2); g->d_plon2 = NULL; ezhip_free(g->d_windtrig); g->d_windtrig = NULL;
         memset(g, 0, sizeof(*g));
         if (cur_gdin == gd) cur_gdin = -1;
         if (cur_gdout == gd) cur_gdout = -1;
@@ -1818,6 +1819,14 @@ int32_t c_ezuvint_dev(float *d_uuout, float *d_vvout, const float *d_uuin, const
     wp.src_rotated = (gi->grtyp == 'E' || (gi->grtyp == 'Z' && gi->grref == 'E'));
     if (wp.src_rotated) { const float *xg = gi->grtyp == 'E' ? gi->xg : gi->xgref; h_crot(wp.r, wp.ri, xg[1], xg[0], xg[3], xg[2]); }
     else if (gi->grtyp == 'Z' && gi->grref != 'L') return -1;
+    if (wp.src_rotated && wp.separable) {
+        if (!go->d_windtrig) {
+            go->d_windtrig = (double *)ezhip_malloc(sizeof(double) * 2 * ((size_t)go->ni + go->nj));
+            if (!go->d_windtrig) return -1;
+            if (ezhip_wind_trig_tables(go->d_windtrig, go->d_windtrig + 2 * (size_t)go->ni, go->d_lat, go->d_lon, go->ni, go->nj)) return -1;
+        }
+        wp.lon_trig = go->d_windtrig; wp.lat_trig = go->d_windtrig + 2 * (size_t)go->ni;
+    }
     if (ezhip_wind_rotate(&wp, d_uuout, d_vvout, go->d_lat, go->d_lon, go->ni, go->nj)) return -1;
     return (r1 == 2 || r2 == 2) ? 2 : 0;
 }

@@ -1433,6 +1433,22 @@ extern "C" int ezhip_locate(const ezhip_locate_plan *plan, float *d_x, float *d_
 /* ===================================================================================== */
 /* k_wind_rotate                                                                            */
 /* ===================================================================================== */
+/* {cos, sin}(dar * angle) in fp64 for the n angles of a separable target's longitudes (or latitudes): the same expressions
+ * k_wind_rotate evaluates per point, once per column / row */
+__global__ __launch_bounds__(256) void k_wind_trig(double *tab, const float *ang, int n)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double dar = (double)(float)(3.14159274101257324 / 180.0);
+    tab[2 * i] = cos(dar * (double)ang[i]); tab[2 * i + 1] = sin(dar * (double)ang[i]);
+}
+extern "C" int ezhip_wind_trig_tables(double *d_lon_trig, double *d_lat_trig, const float *d_lat, const float *d_lon, int ni, int nj)
+{
+    hipLaunchKernelGGL(k_wind_trig, dim3((ni + 255) / 256), dim3(256), 0, g_stream, d_lon_trig, d_lon, ni);
+    hipLaunchKernelGGL(k_wind_trig, dim3((nj + 255) / 256), dim3(256), 0, g_stream, d_lat_trig, d_lat, nj);
+    return LAUNCH_CHECK("k_wind_trig");
+}
+
 __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *__restrict__ uu, float *__restrict__ vv,
                                                      const float *__restrict__ lats, const float *__restrict__ lons,
                                                      int ni_dst, int nj_dst)
@@ -1449,15 +1465,22 @@ __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *_
         float lon_r, lat_r;
         d_rotate(p.r, lon, lat, lon_r, lat_r);
         const double dar = (double)(float)(3.14159274101257324 / 180.0);
-        double a = sin(dar * (double)lon_r), b = cos(dar * (double)lon_r);
-        double c = sin(dar * (double)lat_r), d = cos(dar * (double)lat_r);
+        double a, b, c, d;
+        sincos(dar * (double)lon_r, &a, &b);
+        sincos(dar * (double)lat_r, &c, &d);
         float x0 = (float)(-((double)u * a) - ((double)v * b * c));     /* ez_uvacart.inc */
         float x1 = (float)(((double)u * b) - ((double)v * a * c));
         float x2 = (float)((double)v * d);
         float q[3];
         for (int i = 0; i < 3; i++) { float s = 0.0f; s = s + p.ri[i] * x0; s = s + p.ri[3 + i] * x1; s = s + p.ri[6 + i] * x2; q[i] = s; }
-        double aa = cos(dar * (double)lon), bb = sin(dar * (double)lon);   /* ez_cartauv.inc at TRUE lon/lat */
-        double ee = cos(dar * (double)lat), ff = sin(dar * (double)lat);
+        double aa, bb, ee, ff;                                             /* ez_cartauv.inc at TRUE lon/lat */
+        if (p.separable && p.lon_trig) {     /* separable target: cos/sin of a column's longitude / a row's latitude from tables */
+            const size_t jr = n / ni_dst, ic = n - jr * ni_dst;
+            aa = p.lon_trig[2 * ic]; bb = p.lon_trig[2 * ic + 1]; ee = p.lat_trig[2 * jr]; ff = p.lat_trig[2 * jr + 1];
+        } else {
+            aa = cos(dar * (double)lon); bb = sin(dar * (double)lon);
+            ee = cos(dar * (double)lat); ff = sin(dar * (double)lat);
+        }
         u = (float)(((double)q[1] * aa) - ((double)q[0] * bb));
         double cc = ((double)q[0] * aa) + ((double)q[1] * bb);
         double dd = sqrt(cc * cc + (double)(q[2] * q[2]));

@@ -179,7 +179,9 @@ typedef struct {
     int src_rotated;                  /* 1: source is E / Z-on-E: rotate through ri */
     float r[9], ri[9];
     int separable;                    /* target lat/lon given as 1-D arrays */
+    const double *lon_trig, *lat_trig;   /* separable + rotated source: {cos, sin} per target column / row (ezhip_wind_trig_tables), or NULL */
 } ezhip_wind_plan;
+int ezhip_wind_trig_tables(double *d_lon_trig, double *d_lat_trig, const float *d_lat, const float *d_lon, int ni, int nj);
 
 /* synthetic polar wind rows of a source (u,v) pair: d_out4 = [u_n, u_s, v_n, v_s], ni floats each; d_plon2 = longitudes of
  * the last and the first source row */
