@@ -44,6 +44,7 @@ int32_t c_ezgetival(char *option, int32_t *ivalue);                             
 /* ---- interpolation, HOST pointers (reference semantics) ---------------------------------- */
 int32_t c_ezsint(float *zout, float *zin);                                                                                           /* ezscint.h:87 ; ezsint.c:38 ; 0 ok, 1 same grid, 2 extrapolated, -1 error */
 int32_t c_ezuvint(float *uuout, float *vvout, float *uuin, float *vvin);                                                             /* ezscint.h:90 ; ezuvint.c:32 */
+int32_t c_ezwdint(float *spdout, float *dirout, float *uuin, float *vvin);                                                           /* ezscint.h:93 ; ezwdint.c:37,62 : wind speed / direction on the target grid */
 int32_t c_gdxysint(float *zout, float *zin, int32_t gdin, float *x, float *y, int32_t npts);                                         /* src/interp/gdxysint.h:4 ; gdxysint.c:30 */
 int32_t c_gdxysval(int32_t gdin, float *zout, float *zin, float *x, float *y, int32_t n);                                            /* ezscint.h:120 ; gdxysval.c:50 */
 
@@ -55,6 +56,7 @@ int32_t ezdefset_(int32_t *gdout, int32_t *gdin);
 int32_t ezsetopt_(char *option, char *value, int32_t lenoption, int32_t lenvalue);
 int32_t ezsint_(float *zout, float *zin);
 int32_t ezuvint_(float *uuout, float *vvout, float *uuin, float *vvin);
+int32_t ezwdint_(float *spdout, float *dirout, float *uuin, float *vvin);                    /* ezwdint.c:28 */
 int32_t gdxysint_(float *zout, float *zin, int32_t *gdin, float *x, float *y, int32_t *npts);
 int32_t gdxysval_(int32_t *gdin, float *zout, float *zin, float *x, float *y, int32_t *n);
 int32_t gdxyfll_(int32_t *gdid, float *x, float *y, float *lat, float *lon, int32_t *n);
@@ -67,6 +69,7 @@ int32_t gdrls_(int32_t *gdin);
 void    ezhip_use_stream(void *hip_stream);
 int32_t c_ezsint_dev(float *d_zout, const float *d_zin);
 int32_t c_ezuvint_dev(float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin);
+int32_t c_ezwdint_dev(float *d_spdout, float *d_dirout, const float *d_uuin, const float *d_vvin);
 int32_t c_gdxysint_dev(float *d_zout, const float *d_zin, int32_t gdin, const float *d_x, const float *d_y, int32_t npts);
 int32_t c_gdxyfll_dev(int32_t gdid, float *d_x, float *d_y, const float *d_lat, const float *d_lon, int32_t n);
 /* nfields independent fields on the current grid set; field f at d_zin + f*ni_in*nj_in, d_zout + f*ni_out*nj_out */

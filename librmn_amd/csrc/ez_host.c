@@ -1762,9 +1762,10 @@ static void h_polar_wind(const ezh_grid *g, float *pu, float *pv, const float *u
     free(plat); free(plon); free(spd); free(wd);
 }
 
-int32_t c_ezuvint_dev(float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin)
+/* wd_only: c_ezwdint_orig (ezwdint.c:62-113) = the same path stopped after c_gdwdfuv */
+static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin, int wd_only)
 {
-    ezh_set *s = current_set("c_ezuvint");
+    ezh_set *s = current_set(wd_only ? "c_ezwdint" : "c_ezuvint");
     if (!s) return -1;
     if (need_device("c_ezuvint")) return -1;
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
@@ -1816,6 +1817,7 @@ int32_t c_ezuvint_dev(float *d_uuout, float *d_vvout, const float *d_uuin, const
     ezhip_wind_plan wp;
     memset(&wp, 0, sizeof(wp));
     wp.separable = go->separable;
+    wp.wd_only = wd_only;
     wp.src_rotated = (gi->grtyp == 'E' || (gi->grtyp == 'Z' && gi->grref == 'E'));
     if (wp.src_rotated) { const float *xg = gi->grtyp == 'E' ? gi->xg : gi->xgref; h_crot(wp.r, wp.ri, xg[1], xg[0], xg[3], xg[2]); }
     else if (gi->grtyp == 'Z' && gi->grref != 'L') return -1;
@@ -1831,19 +1833,24 @@ int32_t c_ezuvint_dev(float *d_uuout, float *d_vvout, const float *d_uuin, const
     return (r1 == 2 || r2 == 2) ? 2 : 0;
 }
 
-int32_t c_ezuvint(float *uuout, float *vvout, float *uuin, float *vvin)
+int32_t c_ezuvint_dev(float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin) { return uvint_impl(d_uuout, d_vvout, d_uuin, d_vvin, 0); }
+int32_t c_ezwdint_dev(float *d_spdout, float *d_dirout, const float *d_uuin, const float *d_vvin) { return uvint_impl(d_spdout, d_dirout, d_uuin, d_vvin, 1); }
+
+static int32_t uvint_host(float *uuout, float *vvout, float *uuin, float *vvin, int wd_only)
 {
-    ezh_set *s = current_set("c_ezuvint");
+    ezh_set *s = current_set(wd_only ? "c_ezwdint" : "c_ezuvint");
     if (!s) return -1;
-    if (need_device("c_ezuvint")) return -1;
+    if (need_device(wd_only ? "c_ezwdint" : "c_ezuvint")) return -1;
     size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
     if (stage(&s->d_stage_in, nin) || stage(&s->d_stage_out, nout) || stage(&s->d_stage_in2, nin) || stage(&s->d_stage_out2, nout)) return -1;
     if (ezhip_h2d(s->d_stage_in, uuin, sizeof(float) * nin) || ezhip_h2d(s->d_stage_in2, vvin, sizeof(float) * nin)) return -1;
-    int rc = c_ezuvint_dev(s->d_stage_out, s->d_stage_out2, s->d_stage_in, s->d_stage_in2);
+    int rc = uvint_impl(s->d_stage_out, s->d_stage_out2, s->d_stage_in, s->d_stage_in2, wd_only);
     if (rc < 0) return rc;
     if (ezhip_d2h(uuout, s->d_stage_out, sizeof(float) * nout) || ezhip_d2h(vvout, s->d_stage_out2, sizeof(float) * nout) || ezhip_sync()) return -1;
     return rc;
 }
+int32_t c_ezuvint(float *uuout, float *vvout, float *uuin, float *vvin) { return uvint_host(uuout, vvout, uuin, vvin, 0); }
+int32_t c_ezwdint(float *spdout, float *dirout, float *uuin, float *vvin) { return uvint_host(spdout, dirout, uuin, vvin, 1); }
 
 /* ------------------------------------------------------------------------------------------ */
 /* Fortran twins (rpnmacros.h:21 f77name; scalars by reference; hidden string lengths last)       */
@@ -1863,6 +1870,7 @@ int32_t ezsetopt_(char *option, char *value, int32_t lo, int32_t lv)
 { char o[32], v[32]; ftn2c(o, option, lo); ftn2c(v, value, lv); return c_ezsetopt(o, v); }
 int32_t ezsint_(float *zout, float *zin) { return c_ezsint(zout, zin); }
 int32_t ezuvint_(float *uo, float *vo, float *ui, float *vi) { return c_ezuvint(uo, vo, ui, vi); }
+int32_t ezwdint_(float *so, float *dout, float *ui, float *vi) { return c_ezwdint(so, dout, ui, vi); }
 int32_t gdxysint_(float *zout, float *zin, int32_t *gdin, float *x, float *y, int32_t *npts) { return c_gdxysint(zout, zin, *gdin, x, y, *npts); }
 int32_t gdxysval_(int32_t *gdin, float *zout, float *zin, float *x, float *y, int32_t *n) { return c_gdxysval(*gdin, zout, zin, x, y, *n); }
 int32_t gdxyfll_(int32_t *gd, float *x, float *y, float *lat, float *lon, int32_t *n) { return c_gdxyfll(*gd, x, y, lat, lon, *n); }

@@ -1493,6 +1493,7 @@ __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *_
     else if (u == 0.0f) dir = (v >= 0.0f) ? 180.0f : 0.0f;
     else dir = 270.0f - RDTODG * atan2f(v, u);
     dir = fmodf(fmodf(dir, 360.0f) + 360.0f, 360.0f);
+    if (p.wd_only) { uu[n] = spd; vv[n] = dir; return; }      /* c_ezwdint: speed / direction are the result */
     /* ez_gdwfllw.inc:118-129 ('L'/A/B/G): speed, direction -> target components */
     float psi = 270.0f - dir;
     uu[n] = cosf(psi * DGTORD) * spd;

@@ -179,6 +179,7 @@ typedef struct {
     int src_rotated;                  /* 1: source is E / Z-on-E: rotate through ri */
     float r[9], ri[9];
     int separable;                    /* target lat/lon given as 1-D arrays */
+    int wd_only;                      /* 1: stop after c_gdwdfuv (c_ezwdint): uu := speed, vv := direction */
     const double *lon_trig, *lat_trig;   /* separable + rotated source: {cos, sin} per target column / row (ezhip_wind_trig_tables), or NULL */
 } ezhip_wind_plan;
 int ezhip_wind_trig_tables(double *d_lon_trig, double *d_lat_trig, const float *d_lat, const float *d_lon, int ni, int nj);

@@ -24,6 +24,8 @@ def _lib():
         L.c_ezsetival.argtypes = [cp, i32]
         L.c_ezsint.argtypes = [vp, vp]
         L.c_ezuvint.argtypes = [vp, vp, vp, vp]
+        L.c_ezwdint.argtypes = [vp, vp, vp, vp]
+        L.c_ezwdint_dev.argtypes = [vp, vp, vp, vp]
         L.c_gdxysint.argtypes = [vp, vp, i32, vp, vp, i32]
         L.c_gdxysval.argtypes = [i32, vp, vp, vp, vp, i32]
         L.c_gdxyfll.argtypes = [i32, vp, vp, vp, vp, i32]
@@ -123,6 +125,14 @@ def ezuvint(uuin, vvin, nout):
     return rc, uo, vo
 
 
+def ezwdint(uuin, vvin, nout):
+    """c_ezwdint: interpolated winds as (speed, meteorological direction) on the target grid"""
+    uuin, pu = _np(uuin); vvin, pv = _np(vvin)
+    so = np.zeros(nout, np.float32); do = np.zeros(nout, np.float32)
+    rc = _lib().c_ezwdint(so.ctypes.data, do.ctypes.data, pu, pv)
+    return rc, so, do
+
+
 def gdxysint(zin, gdin, x, y):
     zin, pin = _np(zin); x, px = _np(x); y, py = _np(y)
     zout = np.zeros(x.size, np.float32)
@@ -145,6 +155,10 @@ def ezsint_batch_dev(zout, zin, nfields):
 
 def ezuvint_dev(uuout, vvout, uuin, vvin):
     return _lib().c_ezuvint_dev(_dptr(uuout), _dptr(vvout), _dptr(uuin), _dptr(vvin))
+
+
+def ezwdint_dev(spdout, dirout, uuin, vvin):
+    return _lib().c_ezwdint_dev(_dptr(spdout), _dptr(dirout), _dptr(uuin), _dptr(vvin))
 
 
 def gdxysint_dev(zout, zin, gdin, x, y, npts):

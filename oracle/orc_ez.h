@@ -96,6 +96,7 @@ int orc_ezsint(orc_gridset *gs, const orc_opts *o, float *zout, const float *zin
 /* c_ezuvint_orig (src/interp/ezuvint.c:51-94) */
 int orc_ezuvint(orc_gridset *gs, const orc_opts *o, float *uuout, float *vvout,
                 const float *uuin, const float *vvin);
+int orc_ezwdint(orc_gridset *gs, const orc_opts *o, float *uuout, float *vvout, const float *uuin, const float *vvin);
 
 /* wind conversions (src/interp/gdwdfuv.c, gduvfwd.c) exposed for tests */
 int orc_gdwdfuv(orc_grid *g, float *spd, float *dir, const float *uu, const float *vv,

@@ -403,3 +403,31 @@ int orc_ezuvint(orc_gridset *gs, const orc_opts *o, float *uuout, float *vvout,
     free(spd); free(dir);
     return rc < 0 ? rc : ierc;
 }
+
+/* c_ezwdint_orig, ezwdint.c:62-113: the vector interpolation of c_ezuvint_orig, but the result is left as wind
+ * speed (uuout) and meteorological direction (vvout) on the target grid: c_gdwdfuv only, no c_gduvfwd. */
+int orc_ezwdint(orc_gridset *gs, const orc_opts *o, float *uuout, float *vvout,
+                const float *uuin, const float *vvin)
+{
+    orc_grid *gi = gs->gdin, *go = gs->gdout;
+    int npts = go->ni * go->nj;
+    orc_calclatlon(go);
+    orc_opts ov = *o;
+    ov.vecteur = 1;
+    int ierc = 0;
+    int ierc1 = orc_ezsint(gs, &ov, uuout, uuin);
+    int ierc2 = orc_ezsint(gs, &ov, vvout, vvin);
+    if (ierc1 == 2 || ierc2 == 2) ierc = 2;
+    if (o->polar_correction == 1) {                              /* ez_corrvec.c:24-48 */
+        orc_defzones(gs);
+        if (gs->zones[ORC_Z_AU_NORD].npts > 0) corrvec_strip(gs, o->degre_interp, uuout, vvout, uuin, vvin, 1);
+        if (gs->zones[ORC_Z_AU_SUD].npts > 0) corrvec_strip(gs, o->degre_interp, uuout, vvout, uuin, vvin, 0);
+        if (gs->zones[ORC_Z_POLE_NORD].npts > 0) corrvec_strip(gs, o->degre_interp, uuout, vvout, uuin, vvin, 1);
+        if (gs->zones[ORC_Z_POLE_SUD].npts > 0) corrvec_strip(gs, o->degre_interp, uuout, vvout, uuin, vvin, 0);
+    }
+    float *spd = (float *)malloc(sizeof(float) * npts), *dir = (float *)malloc(sizeof(float) * npts);
+    int rc = orc_gdwdfuv(gi, spd, dir, uuout, vvout, go->lat, go->lon, npts);
+    memcpy(uuout, spd, sizeof(float) * npts); memcpy(vvout, dir, sizeof(float) * npts);
+    free(spd); free(dir);
+    return rc < 0 ? rc : ierc;
+}

@@ -61,6 +61,11 @@ def main():
                     rc = L.c_ezuvint(fptr(u), fptr(v), fptr(uu), fptr(vv))
                     out[f"{name}/u_d{degree}_p{polar}"] = u
                     out[f"{name}/v_d{degree}_p{polar}"] = v
+                    if degree == 3:          # c_ezwdint: speed / direction on the target grid
+                        sp = np.zeros(no * mo, np.float32); wd = np.zeros(no * mo, np.float32)
+                        rc = L.c_ezwdint(fptr(sp), fptr(wd), fptr(uu), fptr(vv))
+                        out[f"{name}/spd_d{degree}_p{polar}"] = sp
+                        out[f"{name}/dir_d{degree}_p{polar}"] = wd
         lat = np.zeros(no * mo, np.float32); lon = np.zeros(no * mo, np.float32)
         L.c_gdll(gdout, fptr(lat), fptr(lon))
         x = np.zeros(no * mo, np.float32); y = np.zeros(no * mo, np.float32)

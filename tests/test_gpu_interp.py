@@ -114,6 +114,26 @@ def test_ezuvint_vs_golden(name):
                 assert eu.max() <= tol and ev.max() <= tol, (name, degree, polar, float(eu.max()), float(ev.max()))
 
 
+@pytest.mark.parametrize("name", [n for n in sorted(CASES) if n not in ("G_to_G", "L_to_G")])
+def test_ezwdint_vs_golden(name):
+    """c_ezwdint (speed / direction on the target grid), bicubic, polar correction on / off, against the reference's
+    own outputs (golden fixture).  Direction is compared modulo 360 and only where the wind is not calm."""
+    case = CASES[name]
+    gdin = hip_define(case["src"]); gdout = hip_define(case["dst"] + (" ", None))
+    assert ez.ezdefset(gdout, gdin) == 1
+    no, mo = case["dst"][:2]
+    _, uu, vv = case_inputs(name, case)
+    for polar in (1, 0):
+        setopts(3, polar)
+        rc, spd, wd = ez.ezwdint(uu, vv, no * mo)
+        assert rc in (0, 2)
+        ws, wdir = GOLD[f"{name}/spd_d3_p{polar}"], GOLD[f"{name}/dir_d3_p{polar}"]
+        assert relerr(spd, ws).max() <= 5e-5, (name, polar, float(relerr(spd, ws).max()))
+        dd = np.abs(((wd.astype(np.float64) - wdir.astype(np.float64)) + 180.0) % 360.0 - 180.0)
+        moving = ws > 1e-3 * ws.max()
+        assert dd[moving].max() <= 2e-2, (name, polar, float(dd[moving].max()))      # degrees
+
+
 def test_gdxysint_matches_oracle_bit_exact():
     """c_gdxysint at arbitrary x,y: every leaf kernel restated operation by operation -> bit-exact"""
     O = ol.oracle()

@@ -78,3 +78,20 @@ def test_vector_golden(name):
             O.orc_ezuvint(gs, ctypes.byref(opts), ol.fptr(u), ol.fptr(v), ol.fptr(uu), ol.fptr(vv))
             assert np.array_equal(u.view(np.uint32), GOLD[f"{name}/u_d{degree}_p{polar}"].view(np.uint32)), (name, degree, polar)
             assert np.array_equal(v.view(np.uint32), GOLD[f"{name}/v_d{degree}_p{polar}"].view(np.uint32)), (name, degree, polar)
+
+
+@pytest.mark.parametrize("name", [n for n in sorted(CASES) if n not in ("G_to_G", "L_to_G")])
+def test_wdint_golden(name):
+    """orc_ezwdint (speed / direction) against the reference's c_ezwdint outputs in the fixture, bit-exact"""
+    O = ol.oracle()
+    case = CASES[name]
+    gi = define(case["src"]); go = define(case["dst"] + (" ", None))
+    gs = O.orc_defset(go, gi)
+    no, mo = case["dst"][:2]
+    _, uu, vv = case_inputs(name, case)
+    for polar in (1, 0):
+        opts = ol.default_opts(degre_interp=3, polar_correction=polar)
+        s = np.zeros(no * mo, np.float32); d = np.zeros(no * mo, np.float32)
+        O.orc_ezwdint(gs, ctypes.byref(opts), ol.fptr(s), ol.fptr(d), ol.fptr(uu), ol.fptr(vv))
+        assert np.array_equal(s.view(np.uint32), GOLD[f"{name}/spd_d3_p{polar}"].view(np.uint32)), (name, polar)
+        assert np.array_equal(d.view(np.uint32), GOLD[f"{name}/dir_d3_p{polar}"].view(np.uint32)), (name, polar)

@@ -214,3 +214,31 @@ def test_ezuvint(name, degree, polar):
     assert np.array_equal(uo.view(np.uint32), ur.view(np.uint32)), f"u: {np.count_nonzero(uo != ur)} differ, max {np.abs(uo - ur).max()}"
     assert np.array_equal(vo.view(np.uint32), vr.view(np.uint32)), f"v: {np.count_nonzero(vo != vr)} differ, max {np.abs(vo - vr).max()}"
     ref_setopts(L, 3, 1)
+
+
+@pytest.mark.parametrize("name", ["G_to_L", "Lglobal_to_L", "ZE_to_L", "B_to_L", "Lregional_to_L"])
+@pytest.mark.parametrize("degree", [1, 3])
+@pytest.mark.parametrize("polar", [1, 0])
+def test_ezwdint(name, degree, polar):
+    """c_ezwdint (ezwdint.c:62-113): interpolated winds as speed / direction on the target grid"""
+    L = ref(); O = ol.oracle()
+    case = CASES[name]
+    gdin = ref_define(L, case["src"]); gdout = ref_define(L, case["dst"] + (" ", None))
+    ref_setopts(L, degree, polar)
+    L.c_ezdefset(gdout, gdin)
+    ni, nj = case["src"][:2]; no, mo = case["dst"][:2]
+    uu, vv = ec.synth_wind(ni, nj, seed=22)
+    if case["src"][2] in ("Z", "B"):
+        for a in (uu, vv):
+            a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+    ur = np.zeros(no * mo, np.float32); vr = np.zeros(no * mo, np.float32)
+    rc_r = L.c_ezwdint(fptr(ur), fptr(vr), fptr(uu), fptr(vv))
+    gi = orc_define(case["src"]); go = orc_define(case["dst"] + (" ", None))
+    gs = O.orc_defset(go, gi)
+    uo = np.zeros(no * mo, np.float32); vo = np.zeros(no * mo, np.float32)
+    opts = ol.default_opts(degre_interp=degree, polar_correction=polar)
+    rc_o = O.orc_ezwdint(gs, ctypes.byref(opts), fptr(uo), fptr(vo), fptr(uu), fptr(vv))
+    assert rc_o == rc_r
+    assert np.array_equal(uo.view(np.uint32), ur.view(np.uint32)), f"speed: {np.count_nonzero(uo != ur)} differ, max {np.abs(uo - ur).max()}"
+    assert np.array_equal(vo.view(np.uint32), vr.view(np.uint32)), f"direction: {np.count_nonzero(vo != vr)} differ, max {np.abs(vo - vr).max()}"
+    ref_setopts(L, 3, 1)
