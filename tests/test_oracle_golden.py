@@ -85,7 +85,7 @@ def test_wdint_golden(name):
     """orc_ezwdint (speed / direction) against the reference's c_ezwdint outputs in the fixture, bit-exact"""
     O = ol.oracle()
     case = CASES[name]
-    gi = define(case["src"]); go = define(case["dst"] + (" ", None))
+    gi = orc_define(case["src"]); go = orc_define(case["dst"] + (" ", None))
     gs = O.orc_defset(go, gi)
     no, mo = case["dst"][:2]
     _, uu, vv = case_inputs(name, case)
