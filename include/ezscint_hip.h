@@ -47,6 +47,9 @@ int32_t c_ezuvint(float *uuout, float *vvout, float *uuin, float *vvin);        
 int32_t c_ezwdint(float *spdout, float *dirout, float *uuin, float *vvin);                                                           /* ezscint.h:93 ; ezwdint.c:37,62 : wind speed / direction on the target grid */
 int32_t c_gdxysint(float *zout, float *zin, int32_t gdin, float *x, float *y, int32_t npts);                                         /* src/interp/gdxysint.h:4 ; gdxysint.c:30 */
 int32_t c_gdxysval(int32_t gdin, float *zout, float *zin, float *x, float *y, int32_t n);                                            /* ezscint.h:120 ; gdxysval.c:50 */
+int32_t c_gdllsval(int32_t gdid, float *zout, float *zin, float *lat, float *lon, int32_t n);                                        /* ezscint.h:108 ; gdllsval.c:33 : locate + c_gdxysval */
+int32_t c_gdxyvval(int32_t gdin, float *uuout, float *vvout, float *uuin, float *vvin, float *x, float *y, int32_t n);               /* ezscint.h:126 ; gdxyvval.c:89 : two scalar interpolations */
+int32_t c_gdllvval(int32_t gdid, float *uuout, float *vvout, float *uuin, float *vvin, float *lat, float *lon, int32_t n);           /* ezscint.h:111 ; gdllvval.c:34 */
 
 /* ---- Fortran twins (f77name(x) = x_) ------------------------------------------------------ */
 int32_t ezqkdef_(int32_t *ni, int32_t *nj, char *grtyp, int32_t *ig1, int32_t *ig2, int32_t *ig3, int32_t *ig4, int32_t *iunit, int32_t lengrtyp);
@@ -57,6 +60,9 @@ int32_t ezsetopt_(char *option, char *value, int32_t lenoption, int32_t lenvalue
 int32_t ezsint_(float *zout, float *zin);
 int32_t ezuvint_(float *uuout, float *vvout, float *uuin, float *vvin);
 int32_t ezwdint_(float *spdout, float *dirout, float *uuin, float *vvin);                    /* ezwdint.c:28 */
+int32_t gdllsval_(int32_t *gdid, float *zout, float *zin, float *lat, float *lon, int32_t *n);
+int32_t gdxyvval_(int32_t *gdin, float *uuout, float *vvout, float *uuin, float *vvin, float *x, float *y, int32_t *n);
+int32_t gdllvval_(int32_t *gdid, float *uuout, float *vvout, float *uuin, float *vvin, float *lat, float *lon, int32_t *n);
 int32_t gdxysint_(float *zout, float *zin, int32_t *gdin, float *x, float *y, int32_t *npts);
 int32_t gdxysval_(int32_t *gdin, float *zout, float *zin, float *x, float *y, int32_t *n);
 int32_t gdxyfll_(int32_t *gdid, float *x, float *y, float *lat, float *lon, int32_t *n);

@@ -1639,6 +1639,35 @@ int32_t c_gdxysint(float *zout, float *zin, int32_t gdin, float *x, float *y, in
 }
 int32_t c_gdxysval(int32_t gdin, float *zout, float *zin, float *x, float *y, int32_t n) { return c_gdxysint(zout, zin, gdin, x, y, n); }
 
+/* interpolation at caller-supplied lat/lon points: locate (c_gdxyfll_orig) then c_gdxysval; gdllsval.c:33-55 returns 0 */
+int32_t c_gdllsval(int32_t gdid, float *zout, float *zin, float *lat, float *lon, int32_t n)
+{
+    if (!grid_ok(gdid) || n < 0) return -1;
+    float *x = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1)), *y = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    int rc = c_gdxyfll(gdid, x, y, lat, lon, n);
+    if (rc >= 0) rc = c_gdxysval(gdid, zout, zin, x, y, n);
+    free(x); free(y);
+    return rc < 0 ? rc : 0;
+}
+/* vector values at x,y: two scalar interpolations, no rotation (gdxyvval.c:89-102) */
+int32_t c_gdxyvval(int32_t gdin, float *uuout, float *vvout, float *uuin, float *vvin, float *x, float *y, int32_t n)
+{
+    int rc = c_gdxysint(uuout, uuin, gdin, x, y, n);
+    if (rc < 0) return rc;
+    rc = c_gdxysint(vvout, vvin, gdin, x, y, n);
+    return rc < 0 ? rc : 0;
+}
+/* gdllvval.c:34-57: locate, then c_gdxyvval */
+int32_t c_gdllvval(int32_t gdid, float *uuout, float *vvout, float *uuin, float *vvin, float *lat, float *lon, int32_t n)
+{
+    if (!grid_ok(gdid) || n < 0) return -1;
+    float *x = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1)), *y = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    int rc = c_gdxyfll(gdid, x, y, lat, lon, n);
+    if (rc >= 0) rc = c_gdxyvval(gdid, uuout, vvout, uuin, vvin, x, y, n);
+    free(x); free(y);
+    return rc < 0 ? rc : 0;
+}
+
 int32_t c_gdxyfll_dev(int32_t gd, float *d_x, float *d_y, const float *d_lat, const float *d_lon, int32_t n)
 {
     if (!grid_ok(gd)) return -1;
@@ -1874,5 +1903,8 @@ int32_t ezwdint_(float *so, float *dout, float *ui, float *vi) { return c_ezwdin
 int32_t gdxysint_(float *zout, float *zin, int32_t *gdin, float *x, float *y, int32_t *npts) { return c_gdxysint(zout, zin, *gdin, x, y, *npts); }
 int32_t gdxysval_(int32_t *gdin, float *zout, float *zin, float *x, float *y, int32_t *n) { return c_gdxysval(*gdin, zout, zin, x, y, *n); }
 int32_t gdxyfll_(int32_t *gd, float *x, float *y, float *lat, float *lon, int32_t *n) { return c_gdxyfll(*gd, x, y, lat, lon, *n); }
+int32_t gdllsval_(int32_t *gd, float *zout, float *zin, float *lat, float *lon, int32_t *n) { return c_gdllsval(*gd, zout, zin, lat, lon, *n); }
+int32_t gdxyvval_(int32_t *gd, float *uo, float *vo, float *ui, float *vi, float *x, float *y, int32_t *n) { return c_gdxyvval(*gd, uo, vo, ui, vi, x, y, *n); }
+int32_t gdllvval_(int32_t *gd, float *uo, float *vo, float *ui, float *vi, float *lat, float *lon, int32_t *n) { return c_gdllvval(*gd, uo, vo, ui, vi, lat, lon, *n); }
 int32_t gdll_(int32_t *gd, float *lat, float *lon) { return c_gdll(*gd, lat, lon); }
 int32_t gdrls_(int32_t *gd) { return c_gdrls(*gd); }

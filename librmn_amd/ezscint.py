@@ -140,6 +140,25 @@ def gdxysint(zin, gdin, x, y):
     return rc, zout
 
 
+def gdllsval(gdid, zin, lat, lon):
+    """c_gdllsval: interpolation at lat/lon points (locate + c_gdxysval)"""
+    zin, pin = _np(zin); lat, pla = _np(lat); lon, plo = _np(lon)
+    zout = np.zeros(lat.size, np.float32)
+    L = _lib()
+    L.c_gdllsval.argtypes = [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_int32]
+    rc = L.c_gdllsval(gdid, zout.ctypes.data, pin, pla, plo, lat.size)
+    return rc, zout
+
+
+def gdllvval(gdid, uuin, vvin, lat, lon):
+    uuin, pu = _np(uuin); vvin, pv = _np(vvin); lat, pla = _np(lat); lon, plo = _np(lon)
+    uo = np.zeros(lat.size, np.float32); vo = np.zeros(lat.size, np.float32)
+    L = _lib()
+    L.c_gdllvval.argtypes = [ctypes.c_int32] + [ctypes.c_void_p] * 6 + [ctypes.c_int32]
+    rc = L.c_gdllvval(gdid, uo.ctypes.data, vo.ctypes.data, pu, pv, pla, plo, lat.size)
+    return rc, uo, vo
+
+
 def use_stream(stream_handle):
     """hipStream_t as an integer (torch: torch.cuda.current_stream().cuda_stream); 0/None = null stream"""
     _lib().ezhip_use_stream(ctypes.c_void_p(stream_handle or 0))

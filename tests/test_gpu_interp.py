@@ -156,6 +156,36 @@ def test_gdxysint_matches_oracle_bit_exact():
             assert np.array_equal(z.view(np.uint32), want.view(np.uint32)), (name, degree, int(np.count_nonzero(z != want)))
 
 
+def test_gdllsval_gdllvval_match_oracle_bit_exact():
+    """c_gdllsval / c_gdllvval = locate (c_gdxyfll) + c_gdxysval / 2 x c_gdxysint at caller-supplied lat/lon points"""
+    O = ol.oracle()
+    rng = np.random.default_rng(11)
+    for name in ("G_to_L", "Lglobal_to_L", "Lregional_to_L"):
+        case = CASES[name]
+        ni, nj = case["src"][:2]
+        gdin = hip_define(case["src"])
+        spec = case["src"]
+        gi = ol.grid_define(ni, nj, spec[2], spec[3], spec[4], *(spec[5](ni, nj) if spec[5] else (None, None)))
+        zin, uu, vv = case_inputs(name, case)
+        n = 3000
+        lat = rng.uniform(-89.0, 89.0, n).astype(np.float32); lon = rng.uniform(0.0, 359.9, n).astype(np.float32)
+        x = np.zeros(n, np.float32); y = np.zeros(n, np.float32)
+        O.orc_gdxyfll(gi, ol.fptr(x), ol.fptr(y), ol.fptr(lat.copy()), ol.fptr(lon.copy()), n)
+        for degree in (1, 3):
+            setopts(degree, 1)
+            rc, z = ez.gdllsval(gdin, zin, lat.copy(), lon.copy())
+            assert rc == 0
+            want = np.zeros(n, np.float32)
+            O.orc_gdinterp(gi, degree, ol.fptr(want), ol.fptr(zin), ol.fptr(x), ol.fptr(y), n)
+            assert np.array_equal(z.view(np.uint32), want.view(np.uint32)), (name, degree)
+            rc, u, v = ez.gdllvval(gdin, uu, vv, lat.copy(), lon.copy())
+            assert rc == 0
+            wu = np.zeros(n, np.float32); wv = np.zeros(n, np.float32)
+            O.orc_gdinterp(gi, degree, ol.fptr(wu), ol.fptr(uu), ol.fptr(x), ol.fptr(y), n)
+            O.orc_gdinterp(gi, degree, ol.fptr(wv), ol.fptr(vv), ol.fptr(x), ol.fptr(y), n)
+            assert np.array_equal(u.view(np.uint32), wu.view(np.uint32)) and np.array_equal(v.view(np.uint32), wv.view(np.uint32)), (name, degree)
+
+
 def test_device_locate_matches_host_locate():
     """k_locate vs the exact host locate for non-rotated sources: bit-exact x,y"""
     for name in ("G_to_L", "Lglobal_to_L", "Lregional_to_L", "A_to_L", "B_to_L"):

@@ -242,3 +242,27 @@ def test_ezwdint(name, degree, polar):
     assert np.array_equal(uo.view(np.uint32), ur.view(np.uint32)), f"speed: {np.count_nonzero(uo != ur)} differ, max {np.abs(uo - ur).max()}"
     assert np.array_equal(vo.view(np.uint32), vr.view(np.uint32)), f"direction: {np.count_nonzero(vo != vr)} differ, max {np.abs(vo - vr).max()}"
     ref_setopts(L, 3, 1)
+
+
+@pytest.mark.parametrize("name", ["G_to_L", "Lglobal_to_L", "Lregional_to_L", "B_to_L"])
+@pytest.mark.parametrize("degree", [0, 1, 3])
+def test_gdllsval_is_locate_plus_gdinterp(name, degree):
+    """c_gdllsval (gdllsval.c:33-55) == c_gdxyfll_orig + c_gdxysval: the composition the product implements"""
+    L = ref(); O = ol.oracle()
+    case = CASES[name]
+    gdin = ref_define(L, case["src"])
+    ref_setopts(L, degree, 1)
+    ni, nj = case["src"][:2]
+    zin = ec.synth_field(ni, nj, seed=11)
+    rng = np.random.default_rng(5)
+    n = 2000
+    lat = rng.uniform(-89.0, 89.0, n).astype(np.float32); lon = rng.uniform(0.0, 359.9, n).astype(np.float32)
+    zr = np.zeros(n, np.float32)
+    assert L.c_gdllsval(gdin, fptr(zr), fptr(zin), fptr(lat.copy()), fptr(lon.copy()), n) == 0
+    gi = orc_define(case["src"])
+    x = np.zeros(n, np.float32); y = np.zeros(n, np.float32)
+    O.orc_gdxyfll(gi, fptr(x), fptr(y), fptr(lat.copy()), fptr(lon.copy()), n)
+    zo = np.zeros(n, np.float32)
+    O.orc_gdinterp(gi, degree, fptr(zo), fptr(zin), fptr(x), fptr(y), n)
+    assert np.array_equal(zo.view(np.uint32), zr.view(np.uint32)), int(np.count_nonzero(zo != zr))
+    ref_setopts(L, 3, 1)
