@@ -73,6 +73,48 @@ def cpu_baseline(sample_fields=4):
             "sample": f"{sample_fields} fields cfg2 steady-state orc_ezsint ({dt:.3f} s/field)"}
 
 
+def extras(ez, torch, stream, d_out, d_in):
+    """secondary measurements next to the headline (never part of `value`): one field per launch, the host-pointer
+    ABI, and BASELINE configs[2] (c_ezuvint, Z-on-E 2560x1280 -> L 4000x2000).  Best effort: {} on any failure."""
+    import ezcases as ec
+    ex = {}
+    try:
+        def ev_time(fn, reps):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                fn()
+            e1.record(stream); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / reps
+        ex["single_field_launch_us"] = ev_time(lambda: ez.ezsint_dev(d_out[0], d_in[0]), 40)
+        zin_h = np.ascontiguousarray(d_in[0].cpu().numpy()); zout_h = np.zeros(NPTS_OUT, np.float32)     # pageable, touched
+        cez = ez._lib().c_ezsint
+        cez(zout_h.ctypes.data, zin_h.ctypes.data)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            cez(zout_h.ctypes.data, zin_h.ctypes.data)
+        ex["host_pointer_abi_ms_per_field"] = (time.perf_counter() - t0) / 3 * 1e3
+        ni, nj, no, mo = 2560, 1280, 4000, 2000
+        ax, ay = ec.ze_axes(ni, nj)
+        g_in = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay); g_out = ez.ezqkdef(no, mo, "L", 9, 9, 0, 0)
+        assert ez.ezdefset(g_out, g_in) == 1
+        uu, vv = ec.synth_wind(ni, nj, seed=3)
+        for a in (uu, vv):
+            a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+        d_u = torch.from_numpy(uu).cuda(); d_v = torch.from_numpy(vv).cuda()
+        o_u = torch.empty(no * mo, dtype=torch.float32, device="cuda"); o_v = torch.empty_like(o_u)
+        us = ev_time(lambda: ez.ezuvint_dev(o_u, o_v, d_u, d_v), 20)
+        ex["cfg3_uvint"] = {"workload": "c_ezuvint_dev bicubic, Z-on-E 2560x1280 -> L 4000x2000, polar_correction=yes",
+                            "us_per_pair": us, "Mpoint_pairs_per_s": no * mo / us,
+                            "algorithmic_GBps": (2 * 4 * ni * nj + 2 * 4 * no * mo) / us / 1e3}
+    except Exception as e:   # noqa: BLE001
+        ex["error"] = repr(e)
+    return ex
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +262,8 @@ def main():
                      "pack16_plus_armn_compress_us_per_field": comp_us, "zlng_bytes": int(zl[0]),
                      "compression_ratio": float(zl[0]) / (2.0 * NPTS_OUT), "unit": "GB/s of float input"},
         }
+        if world == 1:
+            out["extras"] = extras(ez, torch, stream, d_out, d_in)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
