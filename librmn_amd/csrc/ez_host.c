@@ -1436,18 +1436,21 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
         p.pole_row_n = prow_n; p.pole_row_s = prow_s;
         p.polevals = d_poles_pre ? d_poles_pre : d_poles;
         if (getenv("EZHIP_NO_SEPX")) p.x_nseg = 0;       /* tests: force the fallback tile kernel k_sep */
-        if (p.x_nseg > 0 && !getenv("EZHIP_SEPX_RB")) {
-            /* a lone field: about half the row-blocks per thread block of the batch setting (the special-row blocks
-             * and the ramp-up / drain of the launch are not hidden by other fields; measured at cfg2, polar on:
-             * 50.5 us with 9 row-blocks per block, 42.2 with 5, 44.6 with 3) */
-            int rb = (p.x_rb + 1) / 2 + (p.x_rb > 4);
-            if (rb < 1) rb = 1;
-            p.x_rb = rb; p.x_nseg = (p.x_nvb + rb - 1) / rb;
+        if (p.x_nseg > 0) {
+            /* a lone field: the special rows go last in the work order (mid-order they hold slots while the pole
+             * producers of the same launch run) */
+            p.special_last = 1;
+            if (p.need_poles && !getenv("EZHIP_SINGLE_RB")) {     /* measured at cfg2, polar on: 44.3 us with 9 row-blocks per thread block, 39.7 with 6 */
+                int rb = (2 * p.x_rb + 1) / 3;
+                if (rb >= 1) { p.x_rb = rb; p.x_nseg = (p.x_nvb + rb - 1) / rb; }
+            }
+            if (getenv("EZHIP_SINGLE_RB")) { int rb = atoi(getenv("EZHIP_SINGLE_RB")); if (rb >= 1) { p.x_rb = rb; p.x_nseg = (p.x_nvb + rb - 1) / rb; } }
         }
         if (p.need_poles && !d_poles_pre) {
-            /* a lone field: k_polevals first.  (The in-kernel producers of the batch launch would make the field's
-             * special-row blocks, co-resident from t = 0, spin for the ~25 us of the pole sums: 50 us instead of 42.) */
-            if (p.x_nseg > 0 && getenv("EZHIP_POLES_INKERNEL")) { if (pole_ring(1, &p)) return -1; }
+            /* k_sepx sums the pole rows itself (producer blocks at the head of the launch): 43 us per lone cfg2 field
+             * with the halved row-blocks per thread block above, against 57 us with a k_polevals launch (29 us, serial)
+             * in front; the fallback kernel needs the separate launch */
+            if (p.x_nseg > 0 && !getenv("EZHIP_POLES_PRELAUNCH")) { if (pole_ring(1, &p)) return -1; }
             else if (ezhip_polevals(d_poles, d_zin, gi->ni, gi->nj, p.pole_weighted, p.ax)) return -1;
         }
         if (ezhip_interp_sep(&p, d_zout, d_zin)) return -1;

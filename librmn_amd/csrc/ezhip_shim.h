@@ -113,6 +113,7 @@ typedef struct {
     /* in-kernel pole values (k_sepx): pole_blocks = 2 * fields rounded up to a multiple of 8 producer blocks (0: pole
      * values come precomputed in `polevals`), published in pole_vals[2 f + {0 north, 1 south}] with pole_flags[] = epoch */
     int pole_blocks; unsigned pole_epoch;
+    int special_last;                 /* 1: special rows at the end of the field's work order (single-field launch) */
     float *pole_vals; unsigned *pole_flags;
     int x_nbx; size_t x_lds_bytes;    /* set by the launcher: column strips, dynamic LDS bytes */
     /* fused compact_float min/max (k_sepx<.., STATS>): every thread block writes {min key, max key, 0} of the values it
