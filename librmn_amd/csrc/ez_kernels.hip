@@ -540,7 +540,10 @@ __device__ __forceinline__ void sepx_ypass(const float *myrec, const double *tco
             if (SLOW) {
                 out = (dmask >> g) & 1 ? fillv : out;
                 if (!nostore && l32 + 32 * g < ncol_valid) { orow[32 * g] = out; if (STATS) { vmin = fminf(vmin, out); vmax = fmaxf(vmax, out); } }
-            } else { orow[32 * g] = out; if (STATS) { vmin = fminf(vmin, out); vmax = fmaxf(vmax, out); } }
+            } else {
+                __builtin_nontemporal_store(out, &orow[32 * g]);      /* streaming output (`nt`): -0.7 us per cfg2 field */
+                if (STATS) { vmin = fminf(vmin, out); vmax = fmaxf(vmax, out); }
+            }
         }
     }
 }
