@@ -361,7 +361,7 @@ __device__ void sep_rowblock_gather(const ezhip_sep_plan &p, RowInfo &ri, float 
     sep_rows<DEG>(p, ri, t, [&](int s) { return zin + (size_t)s * nis; }, r0, r1, zout, c, cvalid, cdehors, fillv);
 }
 
-/* special target rows of one column block: polar strips, pole rows, fully-outside rows (blockIdx.y indexes
+/* special target rows of one column block: polar strips, pole rows, fully-outside rows (`ispecial` indexes
  * p.special).  Pole values come precomputed (p.polevals). */
 template <int DEG>
 __device__ float sep_special(const ezhip_sep_plan &p, float *__restrict__ zout, const float *__restrict__ zin, int ispecial,
@@ -805,7 +805,7 @@ extern "C" int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const
 /* ez_calcnpolarwind.c:28-138 / ez_calcspolarwind.c on the device: from the last / first source row of (u,v) to a row of
  * pole winds, through speed/direction, a polar-stereographic frame (ez_llwfgdw / ez_gdwfllw 'N' / 'S' with xg4 from
  * cxgaig/cigaxg), the (sequential REAL) pole value of each component, and back.  blockIdx.x: 0 north, 1 south;
- * blockIdx.y: field pair.  One block of 256 threads per row; `plon` = longitudes of the source row (host, once per
+ * One block of 256 threads per row; `plon` = longitudes of the source row (host, once per
  * grid).  out = [u_n, u_s, v_n, v_s] (ni each).  Device sinf/cosf/atan2f: <= 2 ulp from the host libm the reference
  * uses (the tolerance of the vector path is 1e-5 relative). */
 __device__ __forceinline__ void d_llwfgdw1(float &z1, float &z2, float xlon, char t, float xg4)
