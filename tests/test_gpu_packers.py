@@ -142,14 +142,15 @@ def test_cfg5_pipeline_full_size_device_resident():
 
 
 @pytest.mark.parametrize("degree", ["cubic", "nearest"])
-def test_fused_interp_pack16_equals_separate_steps(degree):
+@pytest.mark.parametrize("F", [1, 3, 5])        # 1: lone field; 3: pre-launched pole values; 5: pole sums inside the launch
+def test_fused_interp_pack16_equals_separate_steps(degree, F):
     """ezhip_ezsint_pack16_batch_dev (compact_float's min/max pass fused into the interpolation kernel) leaves the same
     fields and bit-identical records as c_ezsint_batch_dev followed by compact_float_dev per field; and the records
     equal the CPU oracle's compact_float of the interpolated field."""
     import torch
     from librmn_amd import ezscint as ez
     import ezcases as ec
-    ni, nj, no, mo, F, nbits = 360, 181, 520, 261, 3, 16
+    ni, nj, no, mo, nbits = 360, 181, 520, 261, 16
     gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(no, mo, "L", 69, 69, 0, 0)
     assert ez.ezdefset(gdout, gdin) == 1
     assert ez.ezsetopt("interp_degree", degree) == 0 and ez.ezsetopt("polar_correction", "yes") == 0
@@ -167,9 +168,9 @@ def test_fused_interp_pack16_equals_separate_steps(degree):
     assert torch.equal(out_a, out_b)
     assert torch.equal(rec_a, rec_b)
     # against the oracle packer on the GPU-interpolated field
-    z = out_a[1].cpu().numpy()
+    z = out_a[F - 1].cpu().numpy()
     want = top.pack_float(z, nbits + 64 * 16)
-    got = rec_a[1].cpu().numpy().view(np.uint32)
+    got = rec_a[F - 1].cpu().numpy().view(np.uint32)
     m = 4 + (n + 1) // 2
     assert np.array_equal(got[:m], want[:m])
     assert ez.ezsetopt("interp_degree", "cubic") == 0
