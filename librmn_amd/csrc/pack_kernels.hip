@@ -427,8 +427,25 @@ __global__ __launch_bounds__(256) void k_armn_tiles(unsigned char *nb, unsigned 
     Tile T = tile_of(t, ni, nj, istep, PARA ? 1 : 0, ntx);
     unsigned need;
     if (PARA) {
+        /* the 3 x 3 differences need a 4 x 4 patch of tokens (one row above, one column left): all 16 loads are issued
+         * before any is used (with run-time loop bounds the 36 loads of the 9 Lorenzo stencils chained one memory round
+         * trip per token: 51 -> 24 us per cfg5 field); clipped tiles repeat an edge token and mask the result */
+        int u[4][4];
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int jj = T.j0 - 1 + min(n, T.n), ii = T.i0 - 1 + min(m, T.m);
+                u[n][m] = tokat(w, (size_t)ni * jj + ii);
+            }
         int mx = 0;
-        for (int n = 0; n < T.n; n++) for (int m = 0; m < T.m; m++) { int d = abs(lorenzo(w, ni, T.i0 + m, T.j0 + n)); mx = max(mx, d); }
+#pragma unroll
+        for (int n = 1; n < 4; n++)
+#pragma unroll
+            for (int m = 1; m < 4; m++) {
+                const int d = abs(u[n][m] - (u[n - 1][m] + u[n][m - 1] - u[n - 1][m - 1]));
+                if (n <= T.n && m <= T.m) mx = max(mx, d);
+            }
         if (mx > 65535) atomicOr(gt16, 1u);
         need = (unsigned)bitlen((unsigned)mx);
     } else {
@@ -622,12 +639,20 @@ __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit_tok(unsigned *z, const u
     const long long tbase = (long long)blockIdx.x * SCAN_TPB * SCAN_ITEMS;
     const long long base = tbase + (long long)threadIdx.x * SCAN_ITEMS;
     unsigned long long mine = 0;
-    unsigned lbits[SCAN_ITEMS];
-    for (int q = 0; q < SCAN_ITEMS; q++) {
-        long long t = base + q;
-        lbits[q] = 0;
-        if (t < ntiles) { Tile T = tile_of(t, ni, nj, 3, 1, ntx); lbits[q] = tile_bits(1, nb[t], T.m * T.n, container, nbits); }
-        mine += lbits[q];
+    unsigned lbits[SCAN_ITEMS], tcs[SCAN_ITEMS], needs[SCAN_ITEMS];
+    {   /* one 32-bit division per thread (ntiles < 2^31, checked by the launcher), then (tile column, tile row) by increments */
+        unsigned ty = (unsigned)base / (unsigned)ntx, tx = (unsigned)base - ty * (unsigned)ntx;
+        for (int q = 0; q < SCAN_ITEMS; q++) {
+            const long long t = base + q;
+            lbits[q] = 0; needs[q] = 0; tcs[q] = tx | (ty << 16);
+            if (t < ntiles) {
+                const int tm = min(3, ni - 1 - (int)tx * 3), tn = min(3, nj - 1 - (int)ty * 3);
+                needs[q] = nb[t];
+                lbits[q] = tile_bits(1, needs[q], tm * tn, container, nbits);
+            }
+            mine += lbits[q];
+            if (++tx == (unsigned)ntx) { tx = 0; ty++; }
+        }
     }
     sh[threadIdx.x] = mine;
     __syncthreads();
@@ -642,42 +667,60 @@ __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit_tok(unsigned *z, const u
     const size_t nw = (size_t)((blk_pos + blk_bits + 31) >> 5) - w0;           /* <= TOK_LDS_WORDS by construction */
     {
         unsigned off = (unsigned)(blk_pos & 31) + (unsigned)(sh[threadIdx.x] - mine);
-        unsigned ty = (unsigned)(base / ntx), tx = (unsigned)(base - (long long)ty * ntx);      /* one division per thread, not per token */
         for (int q = 0; q < SCAN_ITEMS; q++) {
-            long long t = base + q;
-            tmeta[threadIdx.x * SCAN_ITEMS + q] = off | ((t < ntiles ? (unsigned)nb[t] : 0u) << 28);
-            tcoord[threadIdx.x * SCAN_ITEMS + q] = tx | (ty << 16);
+            tmeta[threadIdx.x * SCAN_ITEMS + q] = off | (needs[q] << 28);
+            tcoord[threadIdx.x * SCAN_ITEMS + q] = tcs[q];
             off += lbits[q];
-            if (++tx == (unsigned)ntx) { tx = 0; ty++; }
         }
     }
     for (size_t k = threadIdx.x; k < nw; k += SCAN_TPB) stage[k] = 0;
     __syncthreads();
     const int ntl = (int)min((long long)(SCAN_TPB * SCAN_ITEMS), ntiles - tbase);
-    for (int s = threadIdx.x; s < ntl * 9; s += SCAN_TPB) {
-        const int tl = s / 9, pos = s - 9 * tl;
-        const unsigned meta = tmeta[tl], need = meta >> 28;
-        unsigned bitpos = meta & 0x0FFFFFFFu;
-        unsigned val; int width;
-        if (pos == 0) {                      /* the tile's container field, then (below) its first token */
-            const unsigned wi = bitpos >> 5; const int sh_ = (int)(bitpos & 31);
-            const unsigned long long v = (unsigned long long)need << (64 - container - sh_);
-            if ((unsigned)(v >> 32)) atomicOr(&stage[wi], (unsigned)(v >> 32));
-            if ((unsigned)v) atomicOr(&stage[wi + 1], (unsigned)v);
-        }
-        if (!need) continue;
-        const unsigned tc = tcoord[tl];
-        const int i0 = 1 + (int)(tc & 0xFFFFu) * 3, j0 = 1 + (int)(tc >> 16) * 3;
-        const int tm = min(3, ni - i0), tn = min(3, nj - j0);
-        const int n_ = pos / 3, m_ = pos - 3 * n_;
-        if (m_ >= tm || n_ >= tn) continue;
-        width = need == 15 ? 17 : (int)need + 1;
-        val = (unsigned)lorenzo(w, ni, i0 + m_, j0 + n_) & ((1u << width) - 1);
-        bitpos += (unsigned)container + (unsigned)(n_ * tm + m_) * (unsigned)width;
+    /* Four token slots per lane and iteration, 32-bit token indices (the launcher checks ni * nj < 2^31) and 16-bit
+     * loads: token k of the two-per-word layout (first token in the HIGH half) is the little-endian halfword k ^ 1. */
+    auto or_bits = [&](unsigned bitpos, unsigned val, int width) {
         const unsigned wi = bitpos >> 5; const int sh_ = (int)(bitpos & 31);
         const unsigned long long v = (unsigned long long)val << (64 - width - sh_);
         if ((unsigned)(v >> 32)) atomicOr(&stage[wi], (unsigned)(v >> 32));
         if ((unsigned)v) atomicOr(&stage[wi + 1], (unsigned)v);
+    };
+    const unsigned short *w16 = (const unsigned short *)w;
+    const int nslots = ntl * 9;
+    for (int s0 = threadIdx.x; s0 < nslots; s0 += 4 * SCAN_TPB) {
+        unsigned meta[4]; int idx[4], tm[4]; bool live[4];
+        unsigned kk[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int s = s0 + q * SCAN_TPB;
+            const unsigned sc = (unsigned)min(s, nslots - 1);
+            const unsigned tl = (sc * 7282u) >> 16;                  /* sc / 9 for sc < 2^14 (at most 9216 slots per block) */
+            const unsigned pos = sc - 9u * tl;
+            const unsigned n_ = (pos * 11u) >> 5, m_ = pos - 3u * n_;    /* pos / 3, pos % 3 for pos < 9 */
+            meta[q] = tmeta[tl];
+            const unsigned tc = tcoord[tl];
+            const int i0 = 1 + (int)(tc & 0xFFFFu) * 3, j0 = 1 + (int)(tc >> 16) * 3;
+            tm[q] = min(3, ni - i0);
+            const int tn = min(3, nj - j0);
+            live[q] = s < nslots && (meta[q] >> 28) != 0 && (int)m_ < tm[q] && (int)n_ < tn;
+            idx[q] = (int)(n_ * (unsigned)tm[q] + m_);
+            kk[q] = (unsigned)ni * (unsigned)(j0 + min((int)n_, tn - 1)) + (unsigned)(i0 + min((int)m_, tm[q] - 1));    /* clamped: always a valid token */
+            if (s < nslots && pos == 0) or_bits(meta[q] & 0x0FFFFFFFu, meta[q] >> 28, container);    /* the tile's container field */
+        }
+        int u00[4], u01[4], u10[4], u11[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned k = kk[q], kn = k - (unsigned)ni;
+            u11[q] = w16[k ^ 1u]; u10[q] = w16[(k - 1u) ^ 1u]; u01[q] = w16[kn ^ 1u]; u00[q] = w16[(kn - 1u) ^ 1u];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (!live[q]) continue;
+            const unsigned need = meta[q] >> 28;
+            const int width = need == 15 ? 17 : (int)need + 1;
+            const int d = u11[q] - (u01[q] + u10[q] - u00[q]);
+            or_bits((meta[q] & 0x0FFFFFFFu) + (unsigned)container + (unsigned)idx[q] * (unsigned)width,
+                    (unsigned)d & ((1u << width) - 1), width);
+        }
     }
     __syncthreads();
     for (size_t k = threadIdx.x; k < nw; k += SCAN_TPB) {
@@ -732,7 +775,7 @@ extern "C" int packhip_armn_encode(unsigned *d_z, size_t z_words, const unsigned
         hipLaunchKernelGGL(k_armn_scan, dim3(1), dim3(256), 0, st, bsum, nblocks, total);
         hipLaunchKernelGGL(k_armn_prefix, dim3((ni + nj + 255) / 256), dim3(256), 0, st, d_z, d_words, gt16, ni, nj, nbits, header);
         body_start = 32 + 3 + (unsigned long long)(ni + nj - 1) * nbits;
-        if (getenv("EZHIP_ARMN_SEQ_EMIT") || ntx >= 65536 || nty >= 65536)     /* development / huge fields: the per-thread sequential writer */
+        if (getenv("EZHIP_ARMN_SEQ_EMIT") || ntx >= 65536 || nty >= 65536 || (long long)ni * nj >= (1ll << 31))     /* development / huge fields: the per-thread sequential writer */
             hipLaunchKernelGGL(k_armn_emit<1>, dim3(nblocks), dim3(SCAN_TPB), 0, st, d_z, bsum, nb, gt16, d_words, ni, nj, istep, ntx, ntiles, nbits, body_start);
         else
             hipLaunchKernelGGL(k_armn_emit_tok, dim3(nblocks), dim3(SCAN_TPB), 0, st, d_z, bsum, nb, gt16, d_words, ni, nj, ntx, ntiles, nbits, body_start);
