@@ -223,7 +223,20 @@ def main():
     torch.cuda.synchronize()
     comp_us = (time.perf_counter() - t1) * 1e6 / npk
 
-    # one k_sepx launch per step covers the F fields of the batch (+ one k_polevals launch: the pole sums)
+    # the whole cfg5 pipeline on the batch: interpolation + 16-bit pack (fused min/max) + armn_compress of every field,
+    # one synchronisation per batch (ezhip_ezsint_pack16_batch_dev + ezhip_pack16_compress_batch_dev(prepacked))
+    def pipeline_step():
+        assert pk.ezsint_pack16_batch_dev(recs, rs, d_out, d_in, F, NPTS_OUT, 16) == 0
+        rc_, zl_ = pk.pack16_compress_batch_dev(recs, rs, None, 0, F, NI_D, NJ_D, 16, prepacked=1)
+        assert rc_ == 0
+        return zl_
+    pipeline_step()
+    t2 = time.perf_counter()
+    npipe = 3
+    for _ in range(npipe):
+        zl_batch = pipeline_step()
+    pipe_us = (time.perf_counter() - t2) * 1e6 / (npipe * F)
+    # one k_sepx launch per step covers the F fields of the batch (the pole sums run inside the same launch)
     kern_us = ev_ms * 1e3 / args.steps            # average launch-to-launch duration on the stream
     achieved = F * ALGO_BYTES / (kern_us * 1e-6) / 1e9
     # HBM/fabric traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (FETCH_SIZE x2 on gfx950,
@@ -262,7 +275,10 @@ def main():
                      "fused_interp_pack16_us_per_field": fused_us,
                      "fused_pack16_cost_us_per_field": fused_us - ev_ms * 1e3 / (args.steps * F),
                      "fused_compact_float_16bit_GBps": 4.0 * NPTS_OUT / (max(fused_us - ev_ms * 1e3 / (args.steps * F), 1e-3) * 1e-6) / 1e9,
-                     "pack16_plus_armn_compress_us_per_field": comp_us, "zlng_bytes": int(zl[0]),
+                     "pack16_plus_armn_compress_us_per_field": comp_us,
+                     "cfg5_pipeline_us_per_field": pipe_us,       # interp + pack16 + armn_compress, batch of F, one sync
+                     "cfg5_pipeline_fields_per_s": 1e6 / pipe_us,
+                     "zlng_bytes": int(zl[0]),
                      "compression_ratio": float(zl[0]) / (2.0 * NPTS_OUT), "unit": "GB/s of float input"},
         }
         if world == 1:

@@ -57,6 +57,11 @@ int   ezhip_pack16_compress_dev(void *d_record, const float *d_field, int ni, in
  * words, [4 header words][stream]; d_zout keeps the interpolated fields.  Returns the c_ezsint code (0 / 2) or -1. */
 int32_t ezhip_ezsint_pack16_batch_dev(void *d_records, int64_t record_stride_words, float *d_zout, const float *d_zin,
                                       int32_t nfields, int32_t npts_out, int32_t nbits);
+/* cfg5 back half for a batch: compact_float(16-bit slots, unless prepacked) + armn_compress of nfields device-resident
+ * fields, asynchronous per field, ONE synchronisation at the end.  zlng_out[f] (host) = compressed byte count of record f
+ * or -1 (not compressible: the record keeps the plain 16-bit pack). */
+int32_t ezhip_pack16_compress_batch_dev(void *d_records, int64_t record_stride_words, const float *d_fields, int64_t field_stride,
+                                        int32_t nfields, int32_t ni, int32_t nj, int32_t nbits, int32_t prepacked, int32_t *zlng_out);
 /* frees the calling thread's grow-only device workspaces (staged operands of the host-pointer entry points,
  * the compressed stream, the armn_compress scan storage); they are re-created on the next call */
 void  ezhip_pack_release(void);

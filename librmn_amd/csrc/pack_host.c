@@ -450,3 +450,31 @@ int32_t ezhip_ezsint_pack16_batch_dev(void *d_records, int64_t record_stride_wor
     }
     return rc;
 }
+
+/* cfg5 back half for a batch: compact_float(16-bit slots) + armn_compress of nfields device-resident fields with ONE
+ * synchronisation at the end (ezhip_pack16_compress_dev returns zlng per call: one sync per field, ~25 % of its time).
+ * prepacked != 0: the records already hold the 16-bit-slot pack (ezhip_ezsint_pack16_batch_dev).  zlng_out[f] = byte
+ * count of record f's compressed stream, or -1 (not compressible: the record keeps the plain pack). */
+int32_t ezhip_pack16_compress_batch_dev(void *d_records, int64_t record_stride_words, const float *d_fields, int64_t field_stride,
+                                        int32_t nfields, int32_t ni, int32_t nj, int32_t nbits, int32_t prepacked, int32_t *zlng_out)
+{
+    if (need_device("ezhip_pack16_compress_batch_dev")) return -1;
+    if (nfields < 1 || nbits > 16 || ni == 1 || nj == 1) return -1;
+    if (g_level == -1) g_level = 1;
+    const int minimum = (g_level == 0) || ni < 16 || nj < 16 || nbits <= 4;
+    const size_t n = (size_t)ni * nj;
+    unsigned *d_z = (unsigned *)ws(1, 4 * (n / 2 + 32));
+    void *d_work = ws(2, packhip_armn_work_bytes(ni, nj));
+    int *d_zlng = (int *)ws(0, sizeof(int) * (size_t)nfields + 64);
+    if (!d_z || !d_work || !d_zlng) return -1;
+    float tag = 0.f;
+    for (int f = 0; f < nfields; f++) {
+        unsigned *rec = (unsigned *)d_records + (size_t)f * (size_t)record_stride_words;
+        if (!prepacked && !compact_float_dev((void *)(d_fields + (size_t)f * (size_t)field_stride), rec, rec + 4, (int)n,
+                                             nbits + 64 * 16, 0, 1, 1, 0, &tag, 2)) return -1;
+        if (packhip_armn_encode(d_z, n / 2 + 16, rec + 4, ni, nj, nbits, minimum, d_work, NULL)) return -1;
+        if (packhip_armn_commit(rec + 4, d_z, d_work, ni, nj, nbits, minimum, d_zlng + f)) return -1;
+    }
+    if (ezhip_d2h(zlng_out, d_zlng, sizeof(int) * (size_t)nfields) || ezhip_sync()) return -1;
+    return 0;
+}

@@ -781,11 +781,39 @@ extern "C" int packhip_armn_encode(unsigned *d_z, size_t z_words, const unsigned
             hipLaunchKernelGGL(k_armn_emit_tok, dim3(nblocks), dim3(SCAN_TPB), 0, st, d_z, bsum, nb, gt16, d_words, ni, nj, ntx, ntiles, nbits, body_start);
     }
     if (chk("armn_encode")) return -1;
+    if (!h_bits) return 0;                       /* asynchronous use: packhip_armn_commit reads the total on the device */
     unsigned long long tot = 0;
     if (hipMemcpyAsync(&tot, total, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
     *h_bits = body_start - 32 + tot;
     return 0;
+}
+
+/* Device-side epilogue of an asynchronous encode: zlng = 1 + 4 (1 + ceil(bits / 32)) from the scan total still in
+ * d_work (c_zfstlib.c:160-179); when the stream is shorter than the plain 16-bit record (zlng < 1 + 2 n) its zlng bytes
+ * replace the tokens at `dst` and *d_zlng = zlng, else dst keeps the plain pack and *d_zlng = -1. */
+__global__ __launch_bounds__(256) void k_armn_commit(unsigned *dst, const unsigned *z, const unsigned long long *total, unsigned long long body_bits,
+                                                     unsigned long long n, int *d_zlng)
+{
+    const unsigned long long bits = body_bits + *total;
+    const long long zlng = 1 + 4 * (1 + (long long)((bits + 31) / 32));
+    const bool ok = zlng < (long long)(1 + 2 * n);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d_zlng = ok ? (int)zlng : -1;
+    if (!ok) return;
+    const size_t nwords = (size_t)((zlng + 3) / 4);
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < nwords; k += (size_t)gridDim.x * 256) dst[k] = z[k];
+}
+extern "C" int packhip_armn_commit(unsigned *d_dst, const unsigned *d_z, void *d_work, int ni, int nj, int nbits, int minimum_method, int *d_zlng)
+{
+    const int istep = minimum_method ? 5 : 3, origin = minimum_method ? 0 : 1;
+    const int ntx = (ni - origin + istep - 1) / istep, nty = (nj - origin + istep - 1) / istep;
+    const long long ntiles = (long long)ntx * nty;
+    const int nblocks = (int)((ntiles + SCAN_TPB * SCAN_ITEMS - 1) / (SCAN_TPB * SCAN_ITEMS));
+    unsigned long long *bsum = (unsigned long long *)((char *)d_work + (((size_t)ntiles + 15) & ~(size_t)15));
+    const unsigned long long *total = bsum + nblocks;
+    const unsigned long long body_bits = minimum_method ? 0ull : 3ull + (unsigned long long)(ni + nj - 1) * nbits;
+    hipLaunchKernelGGL(k_armn_commit, dim3(2048), dim3(256), 0, STREAM, d_dst, d_z, total, body_bits, (unsigned long long)ni * nj, d_zlng);
+    return chk("k_armn_commit");
 }
 extern "C" size_t packhip_armn_work_bytes(int ni, int nj)
 {

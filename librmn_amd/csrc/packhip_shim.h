@@ -35,6 +35,8 @@ int packhip_fp_unpack(float *d_dest, const int *d_stream, int npts, int maxExp, 
 int packhip_armn_encode(unsigned *d_z, size_t z_words, const unsigned *d_words, int ni, int nj, int nbits, int minimum_method,
                         void *d_work, unsigned long long *h_bits);
 size_t packhip_armn_work_bytes(int ni, int nj);
+/* after packhip_armn_encode(..., h_bits = NULL): zlng on the device, stream committed to d_dst when compressible */
+int packhip_armn_commit(unsigned *d_dst, const unsigned *d_z, void *d_work, int ni, int nj, int nbits, int minimum_method, int *d_zlng);
 #ifdef __cplusplus
 }
 #endif

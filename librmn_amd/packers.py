@@ -28,6 +28,7 @@ def _lib():
         L.ezhip_pack16_compress_dev.argtypes = [vp, vp, ci, ci, ci]
         L.ezhip_ezsint_pack16_batch_dev.argtypes = [vp, ctypes.c_int64, vp, vp, ci, ci, ci]
         L.ezhip_pack_release.restype = None
+        L.ezhip_pack16_compress_batch_dev.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, ci, ci, ci, ci, ci, vp]
         _configured = True
     return L
 
@@ -121,3 +122,11 @@ def ezsint_pack16_batch_dev(d_records, record_stride_words, d_zout, d_zin, nfiel
 
 def pack_release():
     _lib().ezhip_pack_release()
+
+
+def pack16_compress_batch_dev(d_records, record_stride_words, d_fields, field_stride, nfields, ni, nj, nbits, prepacked=0):
+    """compact_float(16-bit slots, unless prepacked) + armn_compress of a batch; one synchronisation; returns (rc, zlng[nfields])"""
+    zl = np.zeros(nfields, np.int32)
+    rc = _lib().ezhip_pack16_compress_batch_dev(_dptr(d_records), record_stride_words, _dptr(d_fields) if d_fields is not None else None,
+                                                field_stride, nfields, ni, nj, nbits, prepacked, zl.ctypes.data)
+    return rc, zl

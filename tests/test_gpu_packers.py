@@ -174,3 +174,27 @@ def test_fused_interp_pack16_equals_separate_steps(degree, F):
     m = 4 + (n + 1) // 2
     assert np.array_equal(got[:m], want[:m])
     assert ez.ezsetopt("interp_degree", "cubic") == 0
+
+
+def test_pack16_compress_batch_equals_field_by_field():
+    """ezhip_pack16_compress_batch_dev (asynchronous per field, zlng and the commit on the device, one sync) ==
+    ezhip_pack16_compress_dev field by field: same zlng, same first zlng - 1 bytes; one incompressible field keeps
+    its plain pack and reports -1"""
+    import torch
+    ni, nj, F, nbits = 300, 170, 4, 16
+    n = ni * nj
+    fields = [pc.float_field(n, seed=300 + f) for f in range(F)]
+    fields[2] = (np.frombuffer(np.random.default_rng(3).bytes(4 * n), dtype=np.uint32) % 60000).astype(np.float32)   # noise: not compressible
+    d_f = torch.stack([torch.from_numpy(a) for a in fields]).cuda().contiguous()
+    rs = 4 + (n + 1) // 2 + 40
+    rec_a = torch.zeros((F, rs), dtype=torch.int32, device="cuda"); rec_b = torch.zeros_like(rec_a)
+    rc, zl = pk.pack16_compress_batch_dev(rec_a, rs, d_f, n, F, ni, nj, nbits)
+    assert rc == 0
+    zb = [pk.pack16_compress_dev(rec_b[f], d_f[f], ni, nj, nbits) for f in range(F)]
+    torch.cuda.synchronize()
+    assert list(zl) == zb, (list(zl), zb)
+    assert zl[2] == -1 and all(z > 0 for k, z in enumerate(zl) if k != 2)
+    a = rec_a.cpu().numpy().view(np.uint8).reshape(F, -1); b = rec_b.cpu().numpy().view(np.uint8).reshape(F, -1)
+    for f in range(F):
+        m = 16 + (int(zl[f]) - 1 if zl[f] > 0 else 2 * n)          # header + stream bytes that are defined
+        assert np.array_equal(a[f, :m], b[f, :m]), f
