@@ -66,6 +66,7 @@ typedef struct {
     int i1, i2, j1, j2, extension;
     float *ax, *ay, *ncx, *ncy;            /* host */
     float *d_ax, *d_ay, *d_ncx, *d_ncy;    /* device mirrors */
+    float *d_ncx8, *d_ncy8;                /* Newton coefficients laid out [index][8] for the per-point kernel */
     /* this grid as a TARGET: its lat/lon.  Separable grids keep 1-D arrays. */
     int coords_ready, separable;
     float *lat1d, *lon1d, *lat2d, *lon2d;
@@ -493,7 +494,7 @@ int32_t c_gdrls(int32_t gd)          /* gdrls.c:34-77: refcount, free at zero */
         }
         free(g->ax); free(g->ay); free(g->ncx); free(g->ncy);
         free(g->lat1d); free(g->lon1d); free(g->lat2d); free(g->lon2d);
-        ezhip_free(g->d_ax); ezhip_free(g->d_ay); ezhip_free(g->d_ncx); ezhip_free(g->d_ncy);
+        ezhip_free(g->d_ax); ezhip_free(g->d_ay); ezhip_free(g->d_ncx); ezhip_free(g->d_ncy); ezhip_free(g->d_ncx8); ezhip_free(g->d_ncy8);
         ezhip_free(g->d_lat); ezhip_free(g->d_lon); ezhip_free(g->d_plon2); g->d_plon2 = NULL; ezhip_free(g->d_windtrig); g->d_windtrig = NULL;
         memset(g, 0, sizeof(*g));
         if (cur_gdin == gd) cur_gdin = -1;
@@ -765,8 +766,18 @@ static int ensure_grid_dev(ezh_grid *g)
         g->d_ay = (float *)upload(g->ay, sizeof(float) * g->nj);
         g->d_ncx = (float *)upload(g->ncx, sizeof(float) * 6 * g->ni);
         g->d_ncy = (float *)upload(g->ncy, sizeof(float) * 6 * g->nj);
+        {
+            float *t8 = (float *)calloc((size_t)8 * (g->ni > g->nj ? g->ni : g->nj), sizeof(float));
+            for (int i = 0; i < g->ni; i++) for (int k = 0; k < 6; k++) t8[8 * i + k] = g->ncx[k * g->ni + i];
+            g->d_ncx8 = (float *)upload(t8, sizeof(float) * 8 * g->ni);
+            ezhip_sync();
+            for (int j = 0; j < g->nj; j++) for (int k = 0; k < 6; k++) t8[8 * j + k] = g->ncy[k * g->nj + j];
+            g->d_ncy8 = (float *)upload(t8, sizeof(float) * 8 * g->nj);
+            ezhip_sync();
+            free(t8);
+        }
         ezhip_sync();
-        if (!g->d_ax || !g->d_ay || !g->d_ncx || !g->d_ncy) return -1;
+        if (!g->d_ax || !g->d_ay || !g->d_ncx || !g->d_ncy || !g->d_ncx8 || !g->d_ncy8) return -1;
     }
     return 0;
 }
@@ -1333,6 +1344,7 @@ static void fill_pts_plan(const ezh_set *s, const ezh_grid *gi, ezhip_pts_plan *
     pp->degree = degree; pp->irregular = src_irregular(gi);
     pp->ni = gi->ni; pp->nj = gi->nj; pp->i1 = gi->i1; pp->i2 = gi->i2; pp->j1 = gi->j1; pp->j2 = gi->j2; pp->wrap = gi->extension;
     pp->ax = gi->d_ax; pp->ay = gi->d_ay; pp->ncx = gi->d_ncx; pp->ncy = gi->d_ncy;
+    pp->ncx8 = gi->d_ncx8; pp->ncy8 = gi->d_ncy8;
     pp->zones = zones; pp->degre_extrap = O.degre_extrap; pp->vector_mode = vector_mode;
     pp->pole_weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
     if (s) { pp->ypole_n = s->ypole_n; pp->ypole_s = s->ypole_s; }

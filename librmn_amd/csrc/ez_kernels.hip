@@ -882,10 +882,27 @@ struct FieldAcc {
 /* Main-zone accessor: the leaf kernels clamp j to [j1, j2], so no pole row can be touched and the 16 gathers of a
  * point are unconditional (with FieldAcc every gather sits behind two row tests and the loads of a point serialise:
  * k_pts 392 us per 8 M cfg3 points). */
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      /* 16-byte load at 4-byte alignment (global_load_dwordx4) */
 struct PlainAcc {
     const float *z; int ni, j1;
     __device__ __forceinline__ float operator()(int i, int j) const { return z[(size_t)(j - j1) * ni + (i - 1)]; }
 };
+/* the four taps of one stencil row: ONE 16-byte load when the columns are consecutive (everywhere but at the longitude
+ * seam) -- a gather instruction costs the same for 4 or 16 bytes per lane, and the 16 dword gathers of a bicubic point
+ * were most of k_pts' time */
+template <class A>
+__device__ __forceinline__ void row_taps(const A &Z, int im1, int i, int ip1, int ip2, int jj, double &z1, double &z2, double &z3, double &z4)
+{
+    z1 = Z(im1, jj); z2 = Z(i, jj); z3 = Z(ip1, jj); z4 = Z(ip2, jj);
+}
+template <>
+__device__ __forceinline__ void row_taps<PlainAcc>(const PlainAcc &Z, int im1, int i, int ip1, int ip2, int jj, double &z1, double &z2, double &z3, double &z4)
+{
+    if (i == im1 + 1 && ip1 == i + 1 && ip2 == i + 2) {
+        const f4u v = *(const f4u *)(Z.z + (size_t)(jj - Z.j1) * Z.ni + (im1 - 1));
+        z1 = v.x; z2 = v.y; z3 = v.z; z4 = v.w;
+    } else { z1 = Z(im1, jj); z2 = Z(i, jj); z3 = Z(ip1, jj); z4 = Z(ip2, jj); }
+}
 
 __device__ __forceinline__ double d_zlin(double a, double b, double t) { return a + (b - a) * t; }
 __device__ __forceinline__ double d_cubic(double z1, double z2, double z3, double z4, double dx)
@@ -935,10 +952,15 @@ template <class A> __device__ __forceinline__ float p_rgdint_1_w(const A &Z, flo
 }
 template <class A> __device__ __forceinline__ float cubic_rows(const A &Z, int im1, int i, int ip1, int ip2, int j, double dx, double dy)
 {
-    double y1 = d_cubic((double)Z(im1, j - 1), (double)Z(i, j - 1), (double)Z(ip1, j - 1), (double)Z(ip2, j - 1), dx);
-    double y2 = d_cubic((double)Z(im1, j), (double)Z(i, j), (double)Z(ip1, j), (double)Z(ip2, j), dx);
-    double y3 = d_cubic((double)Z(im1, j + 1), (double)Z(i, j + 1), (double)Z(ip1, j + 1), (double)Z(ip2, j + 1), dx);
-    double y4 = d_cubic((double)Z(im1, j + 2), (double)Z(i, j + 2), (double)Z(ip1, j + 2), (double)Z(ip2, j + 2), dx);
+    double a[4], b[4], c[4], d[4];
+    row_taps(Z, im1, i, ip1, ip2, j - 1, a[0], a[1], a[2], a[3]);
+    row_taps(Z, im1, i, ip1, ip2, j, b[0], b[1], b[2], b[3]);
+    row_taps(Z, im1, i, ip1, ip2, j + 1, c[0], c[1], c[2], c[3]);
+    row_taps(Z, im1, i, ip1, ip2, j + 2, d[0], d[1], d[2], d[3]);
+    double y1 = d_cubic(a[0], a[1], a[2], a[3], dx);
+    double y2 = d_cubic(b[0], b[1], b[2], b[3], dx);
+    double y3 = d_cubic(c[0], c[1], c[2], c[3], dx);
+    double y4 = d_cubic(d[0], d[1], d[2], d[3], dx);
     return (float)d_cubic(y1, y2, y3, y4, dy);
 }
 /* ez_rgdint_3_nw.inc:20-77 */
@@ -1004,7 +1026,11 @@ template <class A> __device__ __forceinline__ float p_irgdint_1_w(const A &Z, fl
     return (float)d_zlin(y1, y2, dy);
 }
 /* ez_irgdint_3_nw.inc:20-168: the statement functions are REAL there (results rounded to float) */
-template <class A> __device__ __forceinline__ float p_irgdint_3_nw(const A &Z, float px, float py, const float *ax, const float *ay,
+/* Newton coefficient tables: the reference's layout is cx(ni,6) (6 strided loads per point); the main kernel reads a
+ * device copy laid out [index][8] (two aligned 16-byte loads) */
+template <bool AOS> __device__ __forceinline__ double coef(const float *c, int k, int idx, int n) { return AOS ? (double)c[idx * 8 + k] : (double)c[k * n + idx]; }
+
+template <class A, bool AOS = false> __device__ __forceinline__ float p_irgdint_3_nw(const A &Z, float px, float py, const float *ax, const float *ay,
                                                    const float *cx, const float *cy, int i1, int i2, int j1, int j2)
 {
     const int ni = i2 - i1 + 1, nnj = j2 - j1 + 1;
@@ -1016,17 +1042,18 @@ template <class A> __device__ __forceinline__ float p_irgdint_3_nw(const A &Z, f
     double y = (double)(b[j] + (b[j + 1] - b[j]) * (py - (float)j));
     double x1 = a[i - 1], x2 = a[i], x3 = a[i + 1];
     double y1 = b[j - 1], y2 = b[j], y3 = b[j + 1];
-    double c1 = cx[i - i1], c2 = cx[ni + i - i1], c3 = cx[2 * ni + i - i1], c4 = cx[3 * ni + i - i1], c5 = cx[4 * ni + i - i1], c6 = cx[5 * ni + i - i1];
+    double c1 = coef<AOS>(cx, 0, i - i1, ni), c2 = coef<AOS>(cx, 1, i - i1, ni), c3 = coef<AOS>(cx, 2, i - i1, ni), c4 = coef<AOS>(cx, 3, i - i1, ni), c5 = coef<AOS>(cx, 4, i - i1, ni), c6 = coef<AOS>(cx, 5, i - i1, ni);
     double bb[4];
     for (int r = 0; r < 4; r++) {
         int jj = j - 1 + r;
-        double z1 = Z(i - 1, jj), z2 = Z(i, jj), z3 = Z(i + 1, jj), z4 = Z(i + 2, jj);
+        double z1, z2, z3, z4;
+        row_taps(Z, i - 1, i, i + 1, i + 2, jj, z1, z2, z3, z4);
         double a2 = RF(d_fa2(c1, z1, z2));
         double a3 = RF(d_fa3(c1, c2, c3, z1, z2, z3));
         double a4 = RF(d_fa4(c1, c2, c3, c4, c5, c6, z1, z2, z3, z4));
         bb[r] = RF(d_fa(z1, a2, a3, a4, x, x1, x2, x3));
     }
-    double d1 = cy[j - j1], d2 = cy[nnj + j - j1], d3 = cy[2 * nnj + j - j1], d4 = cy[3 * nnj + j - j1], d5 = cy[4 * nnj + j - j1], d6 = cy[5 * nnj + j - j1];
+    double d1 = coef<AOS>(cy, 0, j - j1, nnj), d2 = coef<AOS>(cy, 1, j - j1, nnj), d3 = coef<AOS>(cy, 2, j - j1, nnj), d4 = coef<AOS>(cy, 3, j - j1, nnj), d5 = coef<AOS>(cy, 4, j - j1, nnj), d6 = coef<AOS>(cy, 5, j - j1, nnj);
     double b12 = RF(d_fa2(d1, bb[0], bb[1]));
     double b13 = RF(d_fa3(d1, d2, d3, bb[0], bb[1], bb[2]));
     double b14 = RF(d_fa4(d1, d2, d3, d4, d5, d6, bb[0], bb[1], bb[2], bb[3]));
@@ -1053,7 +1080,7 @@ __device__ __forceinline__ void irr_cols(const float *ax, int ni, int wrap, int 
 #undef AX
 }
 /* ez_irgdint_3_w.inc:20-235 */
-template <class A> __device__ __forceinline__ float p_irgdint_3_w(const A &Z, float px, float py, const float *ax, const float *ay,
+template <class A, bool AOS = false> __device__ __forceinline__ float p_irgdint_3_w(const A &Z, float px, float py, const float *ax, const float *ay,
                                                   const float *cx, const float *cy, int ni, int j1, int j2, int wrap)
 {
     const int nnj = j2 - j1 + 1;
@@ -1065,17 +1092,18 @@ template <class A> __device__ __forceinline__ float p_irgdint_3_w(const A &Z, fl
     double x = (double)(x2 + (x3 - x2) * (px - (float)i));
     double y = (double)(b[j] + (b[j + 1] - b[j]) * (py - (float)j));
     float y1 = b[j - 1], y2 = b[j], y3 = b[j + 1];
-    double c1 = cx[i - 1], c2 = cx[ni + i - 1], c3 = cx[2 * ni + i - 1], c4 = cx[3 * ni + i - 1], c5 = cx[4 * ni + i - 1], c6 = cx[5 * ni + i - 1];
+    double c1 = coef<AOS>(cx, 0, i - 1, ni), c2 = coef<AOS>(cx, 1, i - 1, ni), c3 = coef<AOS>(cx, 2, i - 1, ni), c4 = coef<AOS>(cx, 3, i - 1, ni), c5 = coef<AOS>(cx, 4, i - 1, ni), c6 = coef<AOS>(cx, 5, i - 1, ni);
     double bb[4];
     for (int r = 0; r < 4; r++) {
         int jj = j - 1 + r;
-        double z1 = Z(im1, jj), z2 = Z(i, jj), z3 = Z(ip1, jj), z4 = Z(ip2, jj);
+        double z1, z2, z3, z4;
+        row_taps(Z, im1, i, ip1, ip2, jj, z1, z2, z3, z4);
         double a2 = d_fa2(c1, z1, z2);
         double a3 = d_fa3(c1, c2, c3, z1, z2, z3);
         double a4 = d_fa4(c1, c2, c3, c4, c5, c6, z1, z2, z3, z4);
         bb[r] = d_fa(z1, a2, a3, a4, x, (double)x1, (double)x2, (double)x3);
     }
-    double d1 = cy[j - j1], d2 = cy[nnj + j - j1], d3 = cy[2 * nnj + j - j1], d4 = cy[3 * nnj + j - j1], d5 = cy[4 * nnj + j - j1], d6 = cy[5 * nnj + j - j1];
+    double d1 = coef<AOS>(cy, 0, j - j1, nnj), d2 = coef<AOS>(cy, 1, j - j1, nnj), d3 = coef<AOS>(cy, 2, j - j1, nnj), d4 = coef<AOS>(cy, 3, j - j1, nnj), d5 = coef<AOS>(cy, 4, j - j1, nnj), d6 = coef<AOS>(cy, 5, j - j1, nnj);
     double b12 = d_fa2(d1, bb[0], bb[1]);
     double b13 = d_fa3(d1, d2, d3, bb[0], bb[1], bb[2]);
     double b14 = d_fa4(d1, d2, d3, d4, d5, d6, bb[0], bb[1], bb[2], bb[3]);
@@ -1099,7 +1127,8 @@ template <class A> __device__ __forceinline__ float p_irgdint_3_wnnc(const A &Z,
     double bb[4];
     for (int r = 0; r < 4; r++) {
         int jj = j - 1 + r;
-        double z1 = Z(im1, jj), z2 = Z(i, jj), z3 = Z(ip1, jj), z4 = Z(ip2, jj);
+        double z1, z2, z3, z4;
+        row_taps(Z, im1, i, ip1, ip2, jj, z1, z2, z3, z4);
         double a2 = d_fa2(c1, z1, z2);
         double a3 = d_fa3(c1, c2, c3, z1, z2, z3);
         double a4 = d_fa4(c1, c2, c3, c4, c5, c6, z1, z2, z3, z4);
@@ -1172,8 +1201,8 @@ __device__ __forceinline__ float leaf_point(const ezhip_pts_plan &p, const A &Z,
     if (KIND == PK_RGD3_W) return p_rgdint_3_w(Z, px, py, p.ni, p.j1, p.j2, p.wrap, 0);
     if (KIND == PK_IRGD1_NW) return p_irgdint_1_nw(Z, px, py, p.ax, p.ay, p.ni, p.nj);
     if (KIND == PK_IRGD1_W) return p_irgdint_1_w(Z, px, py, p.ax, p.ay, p.ni, p.j1, p.j2, p.wrap);
-    if (KIND == PK_IRGD3_NW) return p_irgdint_3_nw(Z, px, py, p.ax, p.ay, p.ncx, p.ncy, p.i1, p.i2, p.j1, p.j2);
-    return p_irgdint_3_w(Z, px, py, p.ax, p.ay, p.ncx, p.ncy, p.ni, p.j1, p.j2, p.wrap);
+    if (KIND == PK_IRGD3_NW) return p_irgdint_3_nw<A, true>(Z, px, py, p.ax, p.ay, p.ncx8, p.ncy8, p.i1, p.i2, p.j1, p.j2);
+    return p_irgdint_3_w<A, true>(Z, px, py, p.ax, p.ay, p.ncx8, p.ncy8, p.ni, p.j1, p.j2, p.wrap);
 }
 static int pts_kind(const ezhip_pts_plan *p)
 {

@@ -138,6 +138,7 @@ typedef struct {
     int irregular;                    /* 1: Z/#/G source (ax, ay, ncx, ncy tables), 0: regular */
     int ni, nj, i1, i2, j1, j2, wrap; /* source geometry, 1-based bounds as in the reference */
     const float *ax, *ay, *ncx, *ncy; /* device; NULL for regular sources */
+    const float *ncx8, *ncy8;         /* the same coefficients laid out [index][8] (6 used): two 16-byte loads per point */
     /* zone handling (0 = none: c_gdxysint semantics) */
     int zones;                        /* 0 none, 1 EZ_NO_EXTRAP (polar zones), 2 EZ_EXTRAP (DEHORS) */
     int degre_extrap;                 /* used when zones == 2 */
