@@ -1465,6 +1465,7 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
             if (p.x_nseg > 0 && !getenv("EZHIP_POLES_PRELAUNCH")) { if (pole_ring(1, &p)) return -1; }
             else if (ezhip_polevals(d_poles, d_zin, gi->ni, gi->nj, p.pole_weighted, p.ax)) return -1;
         }
+        if (vector_mode && ezhip_side_join()) return -1;      /* the special rows of this launch read the polar wind rows */
         if (ezhip_interp_sep(&p, d_zout, d_zin)) return -1;
         return ierc;
     }
@@ -1850,13 +1851,20 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
             ezhip_h2d(s->d_prow, out, sizeof(float) * 4 * (size_t)ni);
             if (ezhip_sync()) { free(rows); return -1; }
             free(rows);
-        } else if (ezhip_polar_wind(s->d_prow, d_uuin, d_vvin, gi->d_plon2, ni, nj, gi->xg4_pole[0], gi->xg4_pole[1], weighted, gi->d_ax)) return -1;
+        } else {
+            /* on the side stream: only the special points (k_pts_special, or the special rows of the separable kernel) read
+             * these rows, the main kernels of both components overlap the 44 us of sequential pole sums */
+            if (ezhip_side_begin()) return -1;
+            int prc = ezhip_polar_wind(s->d_prow, d_uuin, d_vvin, gi->d_plon2, ni, nj, gi->xg4_pole[0], gi->xg4_pole[1], weighted, gi->d_ax);
+            if (ezhip_side_end() || prc) return -1;
+        }
         pun = s->d_prow; pus = s->d_prow + ni; pvn = s->d_prow + 2 * ni; pvs = s->d_prow + 3 * ni;
     }
     int r1 = run_field(s, d_uuout, d_uuin, 1, pun, pus);
     if (r1 < 0) return r1;
     int r2 = run_field(s, d_vvout, d_vvin, 1, pvn, pvs);
     if (r2 < 0) return r2;
+    if (ezhip_side_join()) return -1;                        /* nothing may outlive the call on the side stream */
     if (ensure_coords_dev(go)) return -1;
     ezhip_wind_plan wp;
     memset(&wp, 0, sizeof(wp));

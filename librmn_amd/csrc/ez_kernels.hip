@@ -65,6 +65,39 @@ extern "C" int ezhip_memset(void *d, int v, size_t n) { return set_err(hipMemset
 extern "C" int ezhip_sync(void) { return set_err(hipStreamSynchronize(g_stream), "sync"); }
 extern "C" void ezhip_set_stream(void *s) { g_stream = (hipStream_t)s; }
 extern "C" void *ezhip_get_stream(void) { return (void *)g_stream; }
+
+/* A small kernel that only LATER work depends on (the polar wind rows: 44 us on two CUs) runs on a per-thread side
+ * stream, forked from and joined back into the caller's stream with events:
+ *   ezhip_side_begin()  side stream waits for everything queued on the caller's stream; launches now go to the side stream
+ *   ezhip_side_end()    launches go to the caller's stream again
+ *   ezhip_side_join()   the caller's stream waits for the side stream's work (no-op when nothing is pending) */
+static thread_local hipStream_t t_side = nullptr, t_main_saved = nullptr;
+static thread_local hipEvent_t t_ev_fork = nullptr, t_ev_join = nullptr;
+static thread_local bool t_side_pending = false;
+extern "C" int ezhip_side_begin(void)
+{
+    if (!t_side) {
+        if (hipStreamCreateWithFlags(&t_side, hipStreamNonBlocking) != hipSuccess) return set_err(hipGetLastError(), "side stream");
+        if (hipEventCreateWithFlags(&t_ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t_ev_join, hipEventDisableTiming) != hipSuccess)
+            return set_err(hipGetLastError(), "side events");
+    }
+    if (hipEventRecord(t_ev_fork, g_stream) != hipSuccess || hipStreamWaitEvent(t_side, t_ev_fork, 0) != hipSuccess) return set_err(hipGetLastError(), "fork");
+    t_main_saved = g_stream; g_stream = t_side;
+    return 0;
+}
+extern "C" int ezhip_side_end(void)
+{
+    hipError_t e = hipEventRecord(t_ev_join, t_side);
+    g_stream = t_main_saved;
+    t_side_pending = true;
+    return e == hipSuccess ? 0 : set_err(e, "side end");
+}
+extern "C" int ezhip_side_join(void)
+{
+    if (!t_side_pending) return 0;
+    t_side_pending = false;
+    return set_err(hipStreamWaitEvent(g_stream, t_ev_join, 0), "join");
+}
 extern "C" void *ezhip_host_alloc(size_t n)
 {
     void *p = nullptr;
@@ -1313,6 +1346,7 @@ extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const
     }
 #undef PTS_CASE
     if (LAUNCH_CHECK("k_pts")) return -1;
+    if (ezhip_side_join()) return -1;       /* the special points read the polar wind rows a side stream may still be producing */
     /* always launched (it also re-arms the counter pair); a grid-stride loop over the few listed points */
     hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan, d_zout, d_zin, d_x, d_y, t_spec.list, cnt, cnt_next);
     return LAUNCH_CHECK("k_pts_special");

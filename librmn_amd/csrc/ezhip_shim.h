@@ -188,6 +188,10 @@ int ezhip_wind_trig_tables(double *d_lon_trig, double *d_lat_trig, const float *
 
 /* synthetic polar wind rows of a source (u,v) pair: d_out4 = [u_n, u_s, v_n, v_s], ni floats each; d_plon2 = longitudes of
  * the last and the first source row */
+/* fork / join of a per-thread side stream (see ez_kernels.hip) */
+int ezhip_side_begin(void);
+int ezhip_side_end(void);
+int ezhip_side_join(void);
 int ezhip_polar_wind(float *d_out4, const float *d_uu, const float *d_vv, const float *d_plon2, int ni, int nj,
                      float xg4_n, float xg4_s, int weighted, const float *d_ax);
 
