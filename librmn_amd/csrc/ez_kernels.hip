@@ -285,6 +285,13 @@ __device__ __forceinline__ void lds_dma_dword(const float *base_uniform, unsigne
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
                  :: "v"(addr), "s"(__builtin_amdgcn_readfirstlane((int)lds_byte_addr)) : "memory");
 }
+/* the 16-byte form (gfx950): lane l brings 16 bytes to lds_byte_addr + 16 l */
+__device__ __forceinline__ void lds_dma_dwordx4(const float *base_uniform, unsigned voff_bytes, unsigned lds_byte_addr)
+{
+    const char *addr = (const char *)base_uniform + voff_bytes;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(addr), "s"(__builtin_amdgcn_readfirstlane((int)lds_byte_addr)) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr_of(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; }
 
 #define SEP_QCH ((EZHIP_SEP_WMAX + 63) / 64)   /* 64-column chunks per staged row */
@@ -683,6 +690,11 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
         if (col >= nis) col -= nis;
         coloff[q] = (unsigned)col * 4u;
     }
+    /* 16-byte DMA: lane l fetches patch columns 4 l .. 4 l + 3; usable when the window does not wrap at the seam, the
+     * row holds it in at most 64 lanes and the last lane stays inside the source row */
+    const int x4lanes = (W + 3) >> 2;
+    const bool x4ok = !(dbg & 128) && base + 4 * x4lanes <= nis && x4lanes <= 64 && 4 * x4lanes <= wstr;
+    const unsigned x4off = (unsigned)(base + 4 * min(lane, x4lanes - 1)) * 4u;
     const float *pcol = patch + p.coff[cc];
     const double cw[4] = {p.cw[cc], p.cw[nid + cc], p.cw[2 * nid + cc], p.cw[3 * nid + cc]};
     /* y-pass lane geometry: row r of the pair, column l32 + 32 g of the strip */
@@ -712,9 +724,13 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
         for (int row = wv; row < st.n; row += SEP_BLOCK / 64) {
             const float *zr = zin + (size_t)(st.s0 + row) * nis;
             float *prow = patch + row * wstr;
+            if (x4ok) {          /* one 16-byte DMA per lane covers the whole patch row (no seam inside the window) */
+                if (lane < x4lanes) lds_dma_dwordx4(zr, x4off, lds_addr_of(prow));
+            } else {
 #pragma unroll
-            for (int q = 0; q < SEP_QCH; q++)
-                if (64 * q < W) lds_dma_dword(zr, coloff[q], lds_addr_of(prow + 64 * q));
+                for (int q = 0; q < SEP_QCH; q++)
+                    if (64 * q < W) lds_dma_dword(zr, coloff[q], lds_addr_of(prow + 64 * q));
+            }
         }
         /* the XR row records of step i: 16 XR dwords, one 64-dword chunk per wave */
         if (wv * 64 < SEPX_REC_DW)
