@@ -1374,11 +1374,17 @@ static ezh_set *current_set(const char *who)
     return s;
 }
 
+/* fill value + pole values of the field being interpolated: per host THREAD (two threads may interpolate different
+ * fields on the same grid set at the same time, each on its own stream) */
+static __thread float *t_scratch8 = NULL;
 static int ensure_scratch(ezh_set *s)
 {
-    if (!s->d_scratch) s->d_scratch = (float *)ezhip_malloc(sizeof(float) * 8);
-    return s->d_scratch ? 0 : -1;
+    (void)s;
+    if (!t_scratch8) t_scratch8 = (float *)ezhip_malloc(sizeof(float) * 8);
+    return t_scratch8 ? 0 : -1;
 }
+/* lazily built per-set state (plans, located points, device mirrors) is built under this lock */
+static pthread_mutex_t g_plan_mtx = PTHREAD_MUTEX_INITIALIZER;
 
 /* in-kernel pole values of k_sepx: per host thread a ring of 4 {values, flags} buffers (consecutive launches of one
  * thread are stream-ordered; the ring only guards a thread that switches streams between calls) and a launch epoch */
@@ -1424,8 +1430,10 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
     }
     int ierc = 0;
     if (ensure_scratch(s)) return -1;
-    float *d_fill = s->d_scratch, *d_poles = s->d_scratch + 4;
-    int mode = choose_mode(s, degree, polar);
+    float *d_fill = t_scratch8, *d_poles = t_scratch8 + 4;
+    pthread_mutex_lock(&g_plan_mtx);
+    int mode = choose_mode(s, degree, polar);          /* may analyse the set (first use) */
+    pthread_mutex_unlock(&g_plan_mtx);
     int need_fill = 0;
     if (polar && s->extrap) {
         int dehors = s->sep_capable ? s->have_dehors : 1;   /* unknown without a pass over x,y: assume present */
@@ -1440,11 +1448,15 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
     }
     if (need_fill && ezhip_fill_value(d_fill, d_zin, (size_t)gi->ni * gi->nj, O.degre_extrap, O.valeur_extrap, vector_mode)) return -1;
     if (mode == 1) {
-        if (build_sep_plan(s, degree, vector_mode, polar)) return -1;
+        pthread_mutex_lock(&g_plan_mtx);
+        int brc = build_sep_plan(s, degree, vector_mode, polar);
         int di = degree == DEG_CUBIC ? 2 : degree;
         ezhip_sep_plan p = s->sep[di][vector_mode].p;
+        if (!brc && p.pole_weighted) brc = ensure_grid_dev(gi);
+        pthread_mutex_unlock(&g_plan_mtx);
+        if (brc) return -1;
         p.fill = d_fill;
-        if (p.pole_weighted) { if (ensure_grid_dev(gi)) return -1; p.ax = gi->d_ax; }
+        if (p.pole_weighted) p.ax = gi->d_ax;
         p.pole_row_n = prow_n; p.pole_row_s = prow_s;
         p.polevals = d_poles_pre ? d_poles_pre : d_poles;
         if (getenv("EZHIP_NO_SEPX")) p.x_nseg = 0;       /* tests: force the fallback tile kernel k_sep */
@@ -1469,10 +1481,13 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
         if (ezhip_interp_sep(&p, d_zout, d_zin)) return -1;
         return ierc;
     }
-    if (ensure_points(s)) return -1;
     ezhip_pts_plan pp;
     int zones = !polar ? 0 : (s->extrap ? 2 : 1);
-    fill_pts_plan(s, gi, &pp, degree, zones, vector_mode);
+    pthread_mutex_lock(&g_plan_mtx);
+    int erc = ensure_points(s);
+    if (!erc) fill_pts_plan(s, gi, &pp, degree, zones, vector_mode);
+    pthread_mutex_unlock(&g_plan_mtx);
+    if (erc) return -1;
     pp.fill = d_fill; pp.polevals = d_poles_pre ? d_poles_pre : d_poles;
     pp.pole_row_n = prow_n; pp.pole_row_s = prow_s;
     if (zones == 1 && !vector_mode && !d_poles_pre && ezhip_polevals(d_poles, d_zin, gi->ni, gi->nj, pp.pole_weighted, gi->d_ax)) return -1;
@@ -1523,11 +1538,15 @@ static int32_t batch_impl(float *d_zout, const float *d_zin, int32_t nfields, un
         (O.degre_interp == DEG_NEAREST || O.degre_interp == DEG_LINEAR || O.degre_interp == DEG_CUBIC) &&
         choose_mode(s, O.degre_interp, O.polar_correction == 1) == 1 && !getenv("EZHIP_NO_BATCH_LAUNCH") && !getenv("EZHIP_NO_SEPX")) {
         int degree = O.degre_interp, polar = O.polar_correction == 1;
-        if (ensure_scratch(s) || build_sep_plan(s, degree, 0, polar)) return -1;
+        if (ensure_scratch(s)) return -1;
+        pthread_mutex_lock(&g_plan_mtx);
+        int brc = build_sep_plan(s, degree, 0, polar);
         ezhip_sep_plan p = s->sep[degree == DEG_CUBIC ? 2 : degree][0].p;
+        pthread_mutex_unlock(&g_plan_mtx);
+        if (brc) return -1;
         if (p.x_nseg > 0) {
             ezh_grid *gi = &G[s->gdin];
-            p.fill = s->d_scratch;
+            p.fill = t_scratch8;
             if (p.pole_weighted) { if (ensure_grid_dev(gi)) return -1; p.ax = gi->d_ax; }
             if (p.need_poles) {
                 if (nfields >= 4) { if (pole_ring(nfields, &p)) return -1; }      /* producer blocks of the same launch */

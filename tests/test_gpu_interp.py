@@ -345,3 +345,46 @@ def test_sepx_shapes_vs_oracle(shape, batch):
                 assert err.max() <= RTOL, (name, degree, polar, mode, f, float(err.max()), int(np.argmax(err)))
                 if degree in (0, 1) and not polar:
                     assert np.array_equal(got[f].view(np.uint32), want.view(np.uint32)), (name, degree, polar, f)
+
+
+def test_two_host_threads_share_a_grid_set():
+    """the reference's threading contract: grids defined once, then every thread calls c_ezdefset + c_ezsint
+    on its own.  Two host threads, each with its own HIP stream, interpolate different fields on the SAME set
+    concurrently, first use (plan build) included; every result is checked against the oracle."""
+    import threading
+    ni, nj, no, mo = 360, 181, 777, 391
+    gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(no, mo, "L", 47, 47, 0, 0)
+    O = ol.oracle()
+    gs = O.orc_defset(ol.grid_define(no, mo, "L", (47, 47, 0, 0)), ol.grid_define(ni, nj, "G"))
+    setopts(3, 1)
+    res, errs = {}, []
+
+    def work(tid):
+        try:
+            st = torch.cuda.Stream()
+            assert ez.ezdefset(gdout, gdin) == 1            # thread-local current set and options
+            setopts(3, 1)
+            ez.use_stream(st.cuda_stream)
+            outs = []
+            with torch.cuda.stream(st):
+                for k in range(5):
+                    f = ec.synth_field(ni, nj, seed=500 + 10 * tid + k)
+                    d_in = torch.from_numpy(f).cuda()
+                    d_out = torch.empty(no * mo, dtype=torch.float32, device="cuda")
+                    assert ez.ezsint_dev(d_out, d_in) == 0
+                    outs.append((f, d_out))
+                st.synchronize()
+            res[tid] = outs
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+    opts = ol.default_opts()
+    for tid in res:
+        for f, d_out in res[tid]:
+            want = np.zeros(no * mo, np.float32)
+            O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(want), ol.fptr(f))
+            assert relerr(d_out.cpu().numpy(), want).max() <= RTOL, tid
+    ez.use_stream(torch.cuda.current_stream().cuda_stream)
