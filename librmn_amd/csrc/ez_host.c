@@ -1894,11 +1894,18 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
     else if (gi->grtyp == 'Z' && gi->grref != 'L') return -1;
     if (wp.src_rotated && wp.separable) {
         if (!go->d_windtrig) {
-            go->d_windtrig = (double *)ezhip_malloc(sizeof(double) * 2 * ((size_t)go->ni + go->nj));
+            size_t nt = 2 * ((size_t)go->ni + go->nj);               /* doubles, then the same count of floats */
+            go->d_windtrig = (double *)ezhip_malloc(sizeof(double) * nt + sizeof(float) * nt);
             if (!go->d_windtrig) return -1;
-            if (ezhip_wind_trig_tables(go->d_windtrig, go->d_windtrig + 2 * (size_t)go->ni, go->d_lat, go->d_lon, go->ni, go->nj)) return -1;
+            float *tf = (float *)(go->d_windtrig + nt);
+            if (ezhip_wind_trig_tables(go->d_windtrig, go->d_windtrig + 2 * (size_t)go->ni, tf, tf + 2 * (size_t)go->ni,
+                                       go->d_lat, go->d_lon, go->ni, go->nj)) return -1;
         }
         wp.lon_trig = go->d_windtrig; wp.lat_trig = go->d_windtrig + 2 * (size_t)go->ni;
+        {
+            const float *tf = (const float *)(go->d_windtrig + 2 * ((size_t)go->ni + go->nj));
+            wp.lon_trigf = tf; wp.lat_trigf = tf + 2 * (size_t)go->ni;
+        }
     }
     if (ezhip_wind_rotate(&wp, d_uuout, d_vvout, go->d_lat, go->d_lon, go->ni, go->nj)) return -1;
     return (r1 == 2 || r2 == 2) ? 2 : 0;

@@ -1446,11 +1446,17 @@ __device__ __forceinline__ int d_cherche(float val, const float *tab, int n)
 }
 
 /* true (lon,lat) -> rotated (lon,lat): ez_lac.inc + mxm + ez_cal.inc with matrix r */
+/* (lon, lat) -> the rotated frame, from the REAL cos / sin of the two angles (ez_lac + mxm + ez_cal) */
+__device__ __forceinline__ void d_rotate_cs(const float *r, float coslat, float sinlat, float coslon, float sinlon, float &lon_o, float &lat_o);
 __device__ __forceinline__ void d_rotate(const float *r, float lon, float lat, float &lon_o, float &lat_o)
 {
     const float dar = (float)(3.14159274101257324 / 180.0);     /* acos(-1.)/180. evaluated in REAL */
-    float cosdar = cosf(dar * lat);
-    float c0 = cosdar * cosf(dar * lon), c1 = cosdar * sinf(dar * lon), c2 = sinf(dar * lat);
+    d_rotate_cs(r, cosf(dar * lat), sinf(dar * lat), cosf(dar * lon), sinf(dar * lon), lon_o, lat_o);
+}
+__device__ __forceinline__ void d_rotate_cs(const float *r, float coslat, float sinlat, float coslon, float sinlon, float &lon_o, float &lat_o)
+{
+    float cosdar = coslat;
+    float c0 = cosdar * coslon, c1 = cosdar * sinlon, c2 = sinlat;
     float q[3];
     for (int i = 0; i < 3; i++) { float s = 0.0f; s = s + r[i] * c0; s = s + r[3 + i] * c1; s = s + r[6 + i] * c2; q[i] = s; }
     const float rad = (float)(180.0 / 3.14159274101257324);
@@ -1517,17 +1523,20 @@ extern "C" int ezhip_locate(const ezhip_locate_plan *plan, float *d_x, float *d_
 /* ===================================================================================== */
 /* {cos, sin}(dar * angle) in fp64 for the n angles of a separable target's longitudes (or latitudes): the same expressions
  * k_wind_rotate evaluates per point, once per column / row */
-__global__ __launch_bounds__(256) void k_wind_trig(double *tab, const float *ang, int n)
+__global__ __launch_bounds__(256) void k_wind_trig(double *tab, float *tabf, const float *ang, int n)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double dar = (double)(float)(3.14159274101257324 / 180.0);
     tab[2 * i] = cos(dar * (double)ang[i]); tab[2 * i + 1] = sin(dar * (double)ang[i]);
+    const float darf = (float)(3.14159274101257324 / 180.0);        /* the REAL pair d_rotate uses */
+    tabf[2 * i] = cosf(darf * ang[i]); tabf[2 * i + 1] = sinf(darf * ang[i]);
 }
-extern "C" int ezhip_wind_trig_tables(double *d_lon_trig, double *d_lat_trig, const float *d_lat, const float *d_lon, int ni, int nj)
+extern "C" int ezhip_wind_trig_tables(double *d_lon_trig, double *d_lat_trig, float *d_lon_trigf, float *d_lat_trigf,
+                                      const float *d_lat, const float *d_lon, int ni, int nj)
 {
-    hipLaunchKernelGGL(k_wind_trig, dim3((ni + 255) / 256), dim3(256), 0, g_stream, d_lon_trig, d_lon, ni);
-    hipLaunchKernelGGL(k_wind_trig, dim3((nj + 255) / 256), dim3(256), 0, g_stream, d_lat_trig, d_lat, nj);
+    hipLaunchKernelGGL(k_wind_trig, dim3((ni + 255) / 256), dim3(256), 0, g_stream, d_lon_trig, d_lon_trigf, d_lon, ni);
+    hipLaunchKernelGGL(k_wind_trig, dim3((nj + 255) / 256), dim3(256), 0, g_stream, d_lat_trig, d_lat_trigf, d_lat, nj);
     return LAUNCH_CHECK("k_wind_trig");
 }
 
@@ -1545,7 +1554,10 @@ __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *_
     float u = uu[n], v = vv[n];
     if (p.src_rotated) {                                    /* c_ezllwfgfw, ez_llwfgfw.c:38-73 */
         float lon_r, lat_r;
-        d_rotate(p.r, lon, lat, lon_r, lat_r);
+        if (p.separable && p.lon_trigf) {       /* REAL cos / sin of the column's longitude and the row's latitude from tables */
+            const size_t jr = n / ni_dst, ic = n - jr * ni_dst;
+            d_rotate_cs(p.r, p.lat_trigf[2 * jr], p.lat_trigf[2 * jr + 1], p.lon_trigf[2 * ic], p.lon_trigf[2 * ic + 1], lon_r, lat_r);
+        } else d_rotate(p.r, lon, lat, lon_r, lat_r);
         const double dar = (double)(float)(3.14159274101257324 / 180.0);
         double a, b, c, d;
         sincos(dar * (double)lon_r, &a, &b);

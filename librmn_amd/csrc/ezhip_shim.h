@@ -183,8 +183,10 @@ typedef struct {
     int separable;                    /* target lat/lon given as 1-D arrays */
     int wd_only;                      /* 1: stop after c_gdwdfuv (c_ezwdint): uu := speed, vv := direction */
     const double *lon_trig, *lat_trig;   /* separable + rotated source: {cos, sin} per target column / row (ezhip_wind_trig_tables), or NULL */
+    const float *lon_trigf, *lat_trigf;  /* the REAL {cos, sin} pairs of the same angles (rotation into the source frame) */
 } ezhip_wind_plan;
-int ezhip_wind_trig_tables(double *d_lon_trig, double *d_lat_trig, const float *d_lat, const float *d_lon, int ni, int nj);
+int ezhip_wind_trig_tables(double *d_lon_trig, double *d_lat_trig, float *d_lon_trigf, float *d_lat_trigf,
+                           const float *d_lat, const float *d_lon, int ni, int nj);
 
 /* synthetic polar wind rows of a source (u,v) pair: d_out4 = [u_n, u_s, v_n, v_s], ni floats each; d_plon2 = longitudes of
  * the last and the first source row */
