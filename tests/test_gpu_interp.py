@@ -388,3 +388,54 @@ def test_two_host_threads_share_a_grid_set():
             O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(want), ol.fptr(f))
             assert relerr(d_out.cpu().numpy(), want).max() <= RTOL, tid
     ez.use_stream(torch.cuda.current_stream().cuda_stream)
+
+
+FULL = os.path.join(os.path.dirname(__file__), "golden", "cfg2_full_golden.npz")
+
+
+def _bit_hash(t):
+    u = t.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    x = 0
+    for part in torch.chunk(t.view(torch.int32), 64):
+        x ^= int(np.bitwise_xor.reduce(part.cpu().numpy().view(np.uint32)))
+    return int(u.sum().item()) & 0xFFFFFFFF, x
+
+
+@pytest.mark.parametrize("fname", ["probe", "synth"])
+def test_full_size_cfg2_against_reference_run(fname):
+    """BASELINE cfg2 at FULL size against the reference's own run of it (tests/golden/make_cfg2_full.py):
+    sampled rows/columns (both pole rows, the rows next to them, the seam columns), the float64 sum of
+    all 25.9 M points and -- where the HIP path is bit-exact (nearest, linear; polar correction off) --
+    a bit hash of the whole output.  'probe' is the survey's drv2 field."""
+    G = np.load(FULL)
+    ni, nj, no, mo = 4400, 2200, 7200, 3601
+    if fname == "probe":
+        zin = (np.float32(280) + (np.float32(20) * G["probe_sin"])[None, :] * G["probe_cos"][:, None]).astype(np.float32)
+    else:
+        zin = ec.synth_field(ni, nj, seed=2)
+    gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(no, mo, "L", 5, 5, 0, 0)
+    assert ez.ezdefset(gdout, gdin) == 1
+    ez.use_stream(torch.cuda.current_stream().cuda_stream)
+    d_in = torch.from_numpy(np.ascontiguousarray(zin).ravel()).cuda()
+    d_out = torch.empty(no * mo, dtype=torch.float32, device="cuda")
+    rows = torch.from_numpy(G["rows"]).cuda(); cols = torch.from_numpy(G["cols"]).cuda()
+    for degree in (3, 1, 0):
+        for polar in (1, 0):
+            setopts(degree, polar)
+            assert ez.ezsint_dev(d_out, d_in) == 0
+            torch.cuda.synchronize()
+            key = f"{fname}/d{degree}_p{polar}"
+            o2 = d_out.view(mo, no)
+            for got, want in ((o2[rows].cpu().numpy(), G[key + "/rows"]), (o2[:, cols].cpu().numpy(), G[key + "/cols"])):
+                assert relerr(got, want).max() <= RTOL, (key, float(relerr(got, want).max()))
+                if degree in (0, 1) and not polar:
+                    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), key
+            s = float(d_out.double().sum().item())
+            assert abs(s - float(G[key + "/sum"])) <= 1e-8 * abs(s), (key, s, float(G[key + "/sum"]))
+            if degree in (0, 1) and not polar:
+                assert _bit_hash(d_out) == tuple(int(v) for v in G[key + "/hash"]), key
+    if fname == "probe":        # the survey's printed anchors of this exact run
+        setopts(3, 1)
+        ez.ezsint_dev(d_out, d_in); torch.cuda.synchronize()
+        f = d_out.cpu().numpy()
+        assert "%.8e %.3f %.3f %.3f" % (f.astype(np.float64).sum(), f[0], f[f.size // 2], f[-1]) == "7.26056487e+09 281.818 276.863 278.271"

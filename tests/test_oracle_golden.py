@@ -95,3 +95,29 @@ def test_wdint_golden(name):
         O.orc_ezwdint(gs, ctypes.byref(opts), ol.fptr(s), ol.fptr(d), ol.fptr(uu), ol.fptr(vv))
         assert np.array_equal(s.view(np.uint32), GOLD[f"{name}/spd_d3_p{polar}"].view(np.uint32)), (name, polar)
         assert np.array_equal(d.view(np.uint32), GOLD[f"{name}/dir_d3_p{polar}"].view(np.uint32)), (name, polar)
+
+
+def test_full_size_cfg2_golden():
+    """the oracle at BASELINE cfg2's full size against the reference's own run of it
+    (tests/golden/make_cfg2_full.py): sampled rows/columns, float64 sum and whole-field bit hash,
+    bit-exact; plus the survey's printed anchors of the same run."""
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg2_full_golden.npz"))
+    ni, nj, no, mo = 4400, 2200, 7200, 3601
+    zin = np.ascontiguousarray((np.float32(280) + (np.float32(20) * G["probe_sin"])[None, :] * G["probe_cos"][:, None]).astype(np.float32))
+    O = ol.oracle()
+    gi = ol.grid_define(ni, nj, "G"); go = ol.grid_define(no, mo, "L", (5, 5, 0, 0))
+    gs = O.orc_defset(go, gi)
+    z = np.zeros((mo, no), np.float32)
+    for degree, polar in ((3, 1), (1, 0), (0, 0)):
+        opts = ol.default_opts(degre_interp=degree, polar_correction=polar)
+        assert O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(z), ol.fptr(zin)) == 0
+        key = f"probe/d{degree}_p{polar}"
+        assert np.array_equal(z[G["rows"]].view(np.uint32), G[key + "/rows"].view(np.uint32)), key
+        assert np.array_equal(z[:, G["cols"]].view(np.uint32), G[key + "/cols"].view(np.uint32)), key
+        assert float(z.astype(np.float64).sum()) == float(G[key + "/sum"]), key
+        if not polar:
+            u = z.ravel().view(np.uint32)
+            assert (int(u.astype(np.uint64).sum()) & 0xFFFFFFFF, int(np.bitwise_xor.reduce(u))) == tuple(int(v) for v in G[key + "/hash"]), key
+        if degree == 3:
+            f = z.ravel()
+            assert "%.8e %.3f %.3f %.3f" % (f.astype(np.float64).sum(), f[0], f[f.size // 2], f[-1]) == "7.26056487e+09 281.818 276.863 278.271"
