@@ -34,7 +34,9 @@ int32_t c_float_unpacker(float *dest, int32_t *header, int32_t *stream, int32_t 
 void    c_float_packer_params(int32_t *header_size, int32_t *stream_size, int32_t *p1, int32_t *p2, int32_t npts);
 
 /* include/armn_compress.h:17 ; src/compresseur/c_zfstlib.c:67-203.  op_code 1 = COMPRESS (in place on the
- * 16-bit-slot token words produced by compact_float), returns the compressed byte count or -1. */
+ * 16-bit-slot token words produced by compact_float), returns the compressed byte count or -1.
+ * op_code 2 = UNCOMPRESS (:181-200, in place: (1 + ni*nj/2) words of tokens come back), returns ni*nj*2.
+ * Streams of the deactivated SAMPLE predictor (c_fstunzip_sample) are refused (-1). */
 int  armn_compress(unsigned char *fld, int ni, int nj, int nk, int nbits, int op_code);
 void c_armn_compress_setlevel(int level);       /* src/compresseur/c_zfstlib.c:1325 ; BEST = 1, FAST = 0 */
 int  c_armn_compress_getlevel(void);
@@ -47,6 +49,16 @@ int   compact_integer_dev(void *d_unpacked, void *d_header, void *d_packed, int 
                           int bitSizeOfPackedToken, int off_set, int stride, int opCode);
 /* out-of-place: d_words = ni*nj 16-bit-slot tokens (two per word), d_z >= (ni*nj/2 + 16) words.  Returns zlng or -1. */
 int   armn_compress_dev(void *d_z, const void *d_words, int ni, int nj, int nbits);
+/* UNCOMPRESS out of place on device data: d_z holds a stream with room for z_words words (reads never go past it),
+ * d_words receives (1 + ni*nj/2) words of 16-bit-slot tokens.  Returns ni*nj*2, or -1 (unknown header / broken stream).
+ * The batch form decodes nfields streams (z_stride_words apart) concurrently, one workgroup per stream for the
+ * serial part (the chain of tile headers), all CUs for the rest; one synchronisation at the end. */
+int   armn_uncompress_dev(void *d_words, const void *d_z, int64_t z_words, int ni, int nj, int nbits);
+int32_t ezhip_armn_uncompress_batch_dev(void *d_words, int64_t out_stride_words, const void *d_z, int64_t z_stride_words, int64_t z_words,
+                                        int ni, int nj, int nbits, int32_t nfields);
+/* read side of ezhip_pack16_compress_dev (fstd98.c:2285-2290): record [4 header words][armn stream if compressed != 0,
+ * else plain 16-bit slots] -> ni*nj floats at d_field.  Returns 0 or -1. */
+int   ezhip_uncompress_unpack16_dev(float *d_field, const void *d_record, int ni, int nj, int nbits, int compressed);
 /* fused cfg5 pipeline step: quantise + pack to 16-bit slots + compress one field that is already on the device
  * (fstd98.c:1170-1172).  d_record receives [4 header words][stream]; returns zlng (>0), or -1 when the
  * field is not compressible (d_record then holds the plain 16-bit-slot pack). */

@@ -371,12 +371,50 @@ int armn_compress_dev(void *d_z, const void *d_words, int ni, int nj, int nbits)
     return (int)zlng;
 }
 
+/* UNCOMPRESS on device data (c_zfstlib.c:181-200): nfields streams, z_stride_words apart, each with room for z_words
+ * words -> (1 + ni*nj/2) words of 16-bit tokens each, out_stride_words apart.  Returns ni*nj*2 like the reference. */
+int32_t ezhip_armn_uncompress_batch_dev(void *d_words, int64_t out_stride_words, const void *d_z, int64_t z_stride_words, int64_t z_words,
+                                        int ni, int nj, int nbits, int32_t nfields)
+{
+    if (nbits > 16 || ni == 1 || nj == 1) return 1 + ni * nj * nbits / 8;          /* :182-184: nothing is touched */
+    if (need_device("armn_compress")) return -1;
+    if (nfields < 1) return ni * nj * 2;
+    size_t per = (packhip_armn_dec_work_bytes(ni, nj, (size_t)z_words) + 255) & ~(size_t)255;
+    char *d_work = (char *)ws(2, per * (size_t)nfields + 4 * (size_t)nfields + 256);
+    if (!d_work) return -1;
+    int *d_status = (int *)(d_work + per * (size_t)nfields);
+    if (packhip_armn_decode((unsigned *)d_words, (size_t)out_stride_words, (const unsigned *)d_z, (size_t)z_stride_words, (size_t)z_words,
+                            ni, nj, nfields, g_swap == 1, d_work, per, d_status)) return -1;
+    int st[64], rc = ni * nj * 2;
+    for (int f0 = 0; f0 < nfields; f0 += 64) {
+        int c = nfields - f0 < 64 ? nfields - f0 : 64;
+        if (ezhip_d2h(st, d_status + f0, sizeof(int) * (size_t)c) || ezhip_sync()) return -1;
+        for (int k = 0; k < c; k++)
+            if (st[k]) { fprintf(stderr, "<armn_compress> UNCOMPRESS: field %d: %s\n", f0 + k, st[k] == -1 ? "Unknown compression algorithm" : "broken stream"); rc = -1; }
+    }
+    return rc;
+}
+int armn_uncompress_dev(void *d_words, const void *d_z, int64_t z_words, int ni, int nj, int nbits)
+{
+    return ezhip_armn_uncompress_batch_dev(d_words, 0, d_z, 0, z_words, ni, nj, nbits, 1);
+}
+
 int armn_compress(unsigned char *fld, int ni, int nj, int nk, int nbits, int op_code)
 {
     (void)nk;
     if (op_code == 2) {
-        fprintf(stderr, "<armn_compress> UNCOMPRESS is not part of the MI355X hot path (SURVEY 8f next row)\n");
-        return -1;
+        if (nbits > 16 || ni == 1 || nj == 1) return 1 + ni * nj * nk * nbits / 8;
+        if (need_device("armn_compress")) return -1;
+        /* the stream is shorter than the plain record it replaced; the reference writes (1 + ni*nj/2) words back (:189) */
+        size_t words = 1 + (size_t)ni * nj / 2;
+        unsigned *d_zc = (unsigned *)ws(0, 4 * (words + 2)), *d_tok = (unsigned *)ws(1, 4 * (words + 2));
+        int rc = -1;
+        if (d_zc && d_tok && !ezhip_h2d(d_zc, fld, 4 * words)) {
+            rc = armn_uncompress_dev(d_tok, d_zc, (int64_t)words, ni, nj, nbits);
+            if (rc > 0 && (ezhip_d2h(fld, d_tok, 4 * words) || ezhip_sync())) rc = -1;
+        }
+        ezhip_sync();
+        return rc;
     }
     if (op_code != 1) return 0;
     if (need_device("armn_compress")) return -1;
@@ -410,6 +448,24 @@ int ezhip_pack16_compress_dev(void *d_record, const float *d_field, int ni, int 
     if (zlng > 0 && ezhip_d2d(rec + 4, d_z, (size_t)zlng)) zlng = -1;
     ezhip_sync();
     return zlng;
+}
+
+/* read side of ezhip_pack16_compress_dev (fstd98.c:2285-2290): a record of 4 header words + armn stream (compressed != 0) or
+ * plain 16-bit slots -> floats.  The record is left untouched. */
+int ezhip_uncompress_unpack16_dev(float *d_field, const void *d_record, int ni, int nj, int nbits, int compressed)
+{
+    float tag = 0.f;
+    const unsigned *rec = (const unsigned *)d_record;
+    size_t n = (size_t)ni * nj, words = 1 + n / 2;
+    const unsigned *tok = rec + 4;
+    if (compressed) {
+        unsigned *d_tok = (unsigned *)ws(1, 4 * (words + 2));
+        if (!d_tok) return -1;
+        if (armn_uncompress_dev(d_tok, rec + 4, (int64_t)words, ni, nj, nbits) < 0) return -1;
+        tok = d_tok;
+    }
+    if (!compact_float_dev(d_field, (void *)rec, (void *)tok, (int)n, nbits + 64 * (nbits > 16 ? nbits : 16), 0, 1, 2, 0, &tag, 2)) return -1;
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */

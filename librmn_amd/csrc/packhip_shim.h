@@ -37,6 +37,10 @@ int packhip_armn_encode(unsigned *d_z, size_t z_words, const unsigned *d_words, 
 size_t packhip_armn_work_bytes(int ni, int nj);
 /* after packhip_armn_encode(..., h_bits = NULL): zlng on the device, stream committed to d_dst when compressible */
 int packhip_armn_commit(unsigned *d_dst, const unsigned *d_z, void *d_work, int ni, int nj, int nbits, int minimum_method, int *d_zlng);
+/* armn_compress UNCOMPRESS (unpack_kernels.hip): nfields streams of z_words capacity each -> (1 + ni*nj/2) token words each */
+size_t packhip_armn_dec_work_bytes(int ni, int nj, size_t z_words);
+int packhip_armn_decode(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
+                        int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,440 @@
+/* unpack_kernels.hip -- armn_compress UNCOMPRESS on gfx950.
+ *
+ * Reference: c_armn_compress op UNCOMPRESS (src/compresseur/c_zfstlib.c:181-200), c_fstunzip (:261-292),
+ * unpackTokensMinimum (:592-643), unpackTokensParallelogram (:792-872).
+ *
+ * The stream is a chain: tile t+1's header sits C + n_t x width(header_t) bits after tile t's, so a tile's
+ * position is known only once every earlier header has been read (~100 clk per tile for one lane: 0.25 s for the
+ * 2.9 M tiles of a cfg2 field, the speed of the CPU decoder).  The chain is resolved in three kernels:
+ *
+ *   k_armn_dec_spec   speculation, all CUs: the stream is cut into windows of DW = 2048 bits.  A tile is at most `ext`
+ *                     bits long, so the chain enters a window at one of its first `ext` bit positions; for EVERY such
+ *                     entry one lane walks the window (as if a tile header started there, interior point count)
+ *                     and records where the walk leaves the window and how many tiles it saw: tab[window][entry].
+ *   k_armn_dec_hop    one workgroup per FIELD, one lane: follows the true chain window by window with one LDS
+ *                     lookup per window (tables and stream are staged through LDS in batches).  Windows in
+ *                     which the point count changes (the last tile of a row of tiles, the last row) are walked
+ *                     tile by tile instead.  Writes each window's true entry and first tile index.
+ *   k_armn_dec_emit   all CUs, one lane per window: walks its window from the true entry -> bit position of every tile.
+ *
+ * then
+ *   k_armn_dec_tiles  one thread per tile: reads its tokens.  MINIMUM: value = minimum + token, final.
+ *                     PARALLELOGRAM: the sign-extended Lorenzo difference mod 2^16.
+ *   k_armn_dec_rows / k_armn_dec_colsum / k_armn_dec_cols   the inverse Lorenzo recurrence
+ *                     u(i,j) = d(i,j) + u(i-1,j) + u(i,j-1) - u(i-1,j-1) is a 2-D prefix sum of d once the first row
+ *                     and column are written as differences; the reference stores 16-bit results, and so
+ *                     the whole sum is carried mod 2^16 (a ring homomorphism: same bits).
+ *
+ * Fields of a batch are decoded concurrently (grid dimension), the serial hop kernel one field per CU.
+ * Output: two 16-bit tokens per word, first in the high half (the reference's half-word swap on little-endian
+ * hosts, :191-198), or natural ushort order when c_armn_compress_setswap(0).                               */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "packhip_shim.h"
+
+extern "C" void *ezhip_get_stream(void);
+#define STREAM ((hipStream_t)ezhip_get_stream())
+
+#define DW        2048                  /* bits per window */
+#define DWW       (DW / 32)
+#define DEXT      416                   /* table entries per window: >= the longest tile (MINIMUM: 4 + 25 x 16 bits) */
+#define DTAIL     16                    /* stream words staged past a window (>= DEXT + 32 bits) */
+#define HOP_TPB   256
+#define HOP_LDS   (96 * 1024)
+
+struct DecGeom {
+    int method, istep, origin, nbits, C;    /* C: width of a tile header */
+    int ntx, nty, mlast, hlast;
+    int n_int, ext;                          /* points of an interior tile; bits of the longest tile */
+    long long ntiles;
+    unsigned body;                           /* bit position of the first tile header (bit 0 = MSB of z[1]) */
+};
+
+__device__ __forceinline__ bool dec_geom(DecGeom &g, const unsigned *z, int ni, int nj)
+{
+    const unsigned h = z[0];
+    g.method = h & 15; g.istep = (h >> 7) & 7; g.nbits = (h >> 10) & 31;
+    /* the encoder names PARALLELOGRAM with step 3 and MINIMUM with step 5, nothing else (:132, :157) */
+    if (g.method == 4 && g.istep == 3) {
+        g.origin = 1; g.C = (int)(z[1] >> 29); g.body = 3u + (unsigned)(ni + nj - 1) * (unsigned)g.nbits;
+        if (g.C != 4 && g.C != 5) return false;
+        g.n_int = 9; g.ext = g.C + 9 * (g.C == 5 ? 32 : 17);
+    } else if (g.method == 3 && g.istep == 5) {
+        g.origin = 0; g.C = 4; g.body = 0;
+        g.n_int = 25; g.ext = 4 + 25 * 16;
+    } else return false;
+    g.ntx = (ni - g.origin + g.istep - 1) / g.istep; g.nty = (nj - g.origin + g.istep - 1) / g.istep;
+    g.mlast = ni - g.origin - (g.ntx - 1) * g.istep; g.hlast = nj - g.origin - (g.nty - 1) * g.istep;
+    g.ntiles = (long long)g.ntx * g.nty;
+    return true;
+}
+
+/* bits of tile `hdr` with n points: the distance to the next header */
+__device__ __forceinline__ int dec_step(const DecGeom &g, unsigned hdr, int n)
+{
+    if (g.method == 4) return g.C + (hdr == 0 ? 0 : n * ((hdr == 15 || hdr == 16) ? 17 : (int)hdr + 1));     /* :826-858 */
+    return hdr == 0 ? 4 + g.nbits : (hdr >= 15 ? 4 + n * 16 : 4 + g.nbits + n * (int)hdr);                    /* :610-638 */
+}
+
+/* nb <= 32 bits at bit position p of an MSB-first word stream */
+template <class P>
+__device__ __forceinline__ unsigned getbits(P s, unsigned p, int nb)
+{
+    if (nb == 0) return 0;
+    const unsigned long long v = (unsigned long long)s[p >> 5] << 32 | s[(p >> 5) + 1];
+    return (unsigned)(v >> (64 - nb - (int)(p & 31))) & (nb == 32 ? 0xFFFFFFFFu : (1u << nb) - 1u);
+}
+__device__ __forceinline__ unsigned gword(const unsigned *z1, size_t w, size_t nwords) { return w < nwords ? z1[w] : 0u; }
+__device__ __forceinline__ unsigned getbits_g(const unsigned *z1, size_t nwords, unsigned p, int nb)
+{
+    if (nb == 0) return 0;
+    const unsigned long long v = (unsigned long long)gword(z1, p >> 5, nwords) << 32 | gword(z1, (p >> 5) + 1, nwords);
+    return (unsigned)(v >> (64 - nb - (int)(p & 31))) & (nb == 32 ? 0xFFFFFFFFu : (1u << nb) - 1u);
+}
+
+/* points of tile t and the number of consecutive tiles from t (t included) that have the same point count */
+__device__ __forceinline__ void dec_run(const DecGeom &g, long long t, int &n, long long &run)
+{
+    const int y = (int)(t / g.ntx), x = (int)(t % g.ntx);
+    const int h = (y == g.nty - 1) ? g.hlast : g.istep, m = (x == g.ntx - 1) ? g.mlast : g.istep;
+    n = m * h;
+    if (g.mlast != g.istep) run = (x < g.ntx - 1) ? (g.ntx - 1 - x) : 1;
+    else if (y == g.nty - 1 || g.hlast == g.istep) run = g.ntiles - t;
+    else run = (long long)(g.nty - 1 - y) * g.ntx - x;
+}
+
+/* tab[window][entry] = (bits past the window's end where the walk from `entry` lands) | tiles seen << 16 */
+__global__ __launch_bounds__(256) void k_armn_dec_spec(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
+                                                       unsigned *tab_all, size_t tab_stride, int nwin)
+{
+    __shared__ unsigned s[DWW + DTAIL];
+    const int f = blockIdx.y, win = blockIdx.x, tid = threadIdx.x;
+    const unsigned *z = z_all + (size_t)f * z_stride;
+    DecGeom g;
+    if (!dec_geom(g, z, ni, nj)) return;
+    const size_t nwords = z_words - 1;
+    unsigned mine = 0;
+    if (tid < DWW + DTAIL) { mine = gword(z + 1, (size_t)win * DWW + tid, nwords); s[tid] = mine; }
+    const int nonzero = __syncthreads_or(mine != 0);
+    unsigned *tab = tab_all + (size_t)f * tab_stride + (size_t)win * DEXT;
+    const unsigned step0 = (unsigned)dec_step(g, 0, g.n_int);
+    for (int e = tid; e < g.ext; e += 256) {
+        unsigned p = (unsigned)e, cnt = 0;
+        if (!nonzero) { cnt = (DW - p + step0 - 1) / step0; p += cnt * step0; }     /* zero words (past the end of the stream): every header reads 0 */
+        while (p < DW) { p += (unsigned)dec_step(g, getbits(s, p, g.C), g.n_int); cnt++; }
+        tab[e] = (p - DW) | cnt << 16;
+    }
+}
+
+__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+
+/* 32-bit twin of dec_run for the serial walker (tile counts are < 2^31, checked by the host) */
+__device__ __forceinline__ void dec_run32(const DecGeom &g, unsigned t, int &n, unsigned &run)
+{
+    const unsigned y = t / (unsigned)g.ntx, x = t - y * (unsigned)g.ntx;
+    const int h = ((int)y == g.nty - 1) ? g.hlast : g.istep, m = ((int)x == g.ntx - 1) ? g.mlast : g.istep;
+    n = m * h;
+    if (g.mlast != g.istep) run = ((int)x < g.ntx - 1) ? (unsigned)(g.ntx - 1) - x : 1u;
+    else if ((int)y == g.nty - 1 || g.hlast == g.istep) run = (unsigned)g.ntiles - t;
+    else run = (unsigned)(g.nty - 1 - (int)y) * (unsigned)g.ntx - x;
+}
+
+/* went[2 w] = entry bit of window w (0xFFFFFFFF: the chain has no tile header in it), went[2 w + 1] = its first tile.
+ * The walk runs on wave 0 with every value forced wave-uniform (readfirstlane), i.e. on the scalar unit: one lane of
+ * vector code costs ~10 clk per dependent instruction, scalar code about half of that and its branches are free. */
+__global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
+                                                          const unsigned *tab_all, size_t tab_stride, unsigned *went_all, size_t went_stride,
+                                                          int nwin, int *status, int dbg)
+{
+    extern __shared__ unsigned lds[];
+    __shared__ unsigned s_pos, s_done, s_t;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const unsigned *z = z_all + (size_t)f * z_stride;
+    DecGeom g;
+    if (!dec_geom(g, z, ni, nj)) { if (tid == 0) status[f] = -1; return; }
+    const unsigned *z1 = z + 1;
+    const size_t nwords = z_words - 1;
+    const unsigned *tab = tab_all + (size_t)f * tab_stride;
+    unsigned *went = went_all + (size_t)f * went_stride;
+    const int ext = (int)uni((unsigned)g.ext), C = (int)uni((unsigned)g.C), n_int = g.n_int;
+    const unsigned ntiles = uni((unsigned)g.ntiles);
+    const int nb = (HOP_LDS / 4 - DTAIL) / (ext + DWW + 2);            /* windows per staged batch */
+    unsigned *tabs = lds, *strm = lds + (size_t)nb * ext, *wl = strm + (size_t)nb * DWW + DTAIL;
+    if (tid == 0) { s_pos = g.body; s_t = 0; s_done = 0; }
+    __syncthreads();
+    for (;;) {
+        const unsigned pos0 = s_pos;
+        const int b0 = (int)(pos0 / DW);
+        if (s_done || b0 >= nwin) break;
+        const int nbw = min(nb, nwin - b0);
+        /* staging: 16 independent loads in flight per thread (a lone workgroup is latency-bound) */
+        for (int e = tid; e < ext; e += HOP_TPB) {
+            int w0 = 0;
+            for (; w0 + 16 <= nbw; w0 += 16) {
+                unsigned r[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) r[k] = tab[(size_t)(b0 + w0 + k) * DEXT + e];
+#pragma unroll
+                for (int k = 0; k < 16; k++) tabs[(w0 + k) * ext + e] = r[k];
+            }
+            for (; w0 < nbw; w0++) tabs[w0 * ext + e] = tab[(size_t)(b0 + w0) * DEXT + e];
+        }
+        {
+            const int total = nbw * DWW + DTAIL;
+            int k0 = 0;
+            for (; k0 + 16 * HOP_TPB <= total; k0 += 16 * HOP_TPB) {
+                unsigned r[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) r[k] = gword(z1, (size_t)b0 * DWW + k0 + k * HOP_TPB + tid, nwords);
+#pragma unroll
+                for (int k = 0; k < 16; k++) strm[k0 + k * HOP_TPB + tid] = r[k];
+            }
+            for (int k = k0 + tid; k < total; k += HOP_TPB) strm[k] = gword(z1, (size_t)b0 * DWW + k, nwords);
+        }
+        for (int k = tid; k < 2 * nbw; k += HOP_TPB) wl[k] = 0xFFFFFFFFu;
+        __syncthreads();
+        if (dbg & 1) { if (tid == 0) { s_pos = (unsigned)(b0 + nbw) * DW; } __syncthreads(); continue; }
+        if (tid < 64) {
+            unsigned pos = uni(pos0), t = uni(s_t), run;
+            int n;
+            dec_run32(g, t, n, run);
+            n = (int)uni((unsigned)n); run = uni(run);
+            const unsigned wend = (unsigned)(b0 + nbw);
+            while (t < ntiles) {
+                const unsigned w = pos / DW;
+                if (w >= wend) break;
+                const unsigned e = pos - w * DW, wr = w - (unsigned)b0;
+                wl[2 * wr] = e; wl[2 * wr + 1] = t;
+                if (e < (unsigned)ext && n == n_int) {
+                    const unsigned v = uni(tabs[wr * (unsigned)ext + e]), cnt = v >> 16;
+                    if (cnt <= run) {
+                        pos = (w + 1) * DW + (v & 0xFFFFu); t += cnt; run -= cnt;
+                        if (run == 0 && t < ntiles) { dec_run32(g, t, n, run); n = (int)uni((unsigned)n); run = uni(run); }
+                        continue;
+                    }
+                }
+                const unsigned end = (w + 1) * DW;                       /* the point count changes in this window: tile by tile */
+                while (pos < end && t < ntiles) {
+                    const unsigned q = pos - (unsigned)b0 * DW;
+                    const unsigned long long v = (unsigned long long)uni(strm[q >> 5]) << 32 | uni(strm[(q >> 5) + 1]);
+                    const unsigned hdr = (unsigned)(v >> (64 - C - (int)(q & 31))) & ((1u << C) - 1u);
+                    pos += (unsigned)dec_step(g, hdr, n);
+                    t++;
+                    if (--run == 0 && t < ntiles) { dec_run32(g, t, n, run); n = (int)uni((unsigned)n); run = uni(run); }
+                }
+            }
+            if (tid == 0) { s_pos = pos; s_t = t; if (t >= ntiles) s_done = 1; }
+        }
+        __syncthreads();
+        for (int k = tid; k < 2 * nbw; k += HOP_TPB) went[2 * (size_t)b0 + k] = wl[k];
+    }
+    if (tid == 0) status[f] = s_done ? 0 : -2;
+}
+
+__global__ __launch_bounds__(256) void k_armn_dec_emit(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
+                                                       const unsigned *went_all, size_t went_stride, unsigned *tilepos_all, size_t tp_stride, int nwin)
+{
+    const int f = blockIdx.y;
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nwin) return;
+    const unsigned *z = z_all + (size_t)f * z_stride;
+    DecGeom g;
+    if (!dec_geom(g, z, ni, nj)) return;
+    const unsigned e = went_all[(size_t)f * went_stride + 2 * (size_t)w];
+    if (e == 0xFFFFFFFFu) return;
+    long long t = went_all[(size_t)f * went_stride + 2 * (size_t)w + 1];
+    unsigned *tilepos = tilepos_all + (size_t)f * tp_stride;
+    const size_t nwords = z_words - 1;
+    unsigned pos = (unsigned)w * DW + e;
+    const unsigned end = (unsigned)(w + 1) * DW;
+    int x = (int)(t % g.ntx), y = (int)(t / g.ntx);
+    while (pos < end && t < g.ntiles) {
+        tilepos[t] = pos;
+        const int n = ((x == g.ntx - 1) ? g.mlast : g.istep) * ((y == g.nty - 1) ? g.hlast : g.istep);
+        pos += (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), n);
+        t++;
+        if (++x == g.ntx) { x = 0; y++; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* token k of the output goes to half-word k^1 when the stream is swapped (high half first)      */
+__device__ __forceinline__ size_t out_slot(size_t k, int swap) { return swap ? (k ^ 1) : k; }
+
+__global__ __launch_bounds__(256) void k_armn_dec_tiles(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
+                                                        const unsigned *tilepos_all, size_t tp_stride,
+                                                        unsigned short *d16_all, size_t d_stride,           /* PARALLELOGRAM differences */
+                                                        unsigned short *out_all, size_t out_stride, int swap, /* MINIMUM: final tokens (half-words) */
+                                                        long long max_tiles)
+{
+    const int f = blockIdx.y;
+    const unsigned *z = z_all + (size_t)f * z_stride;
+    DecGeom g;
+    if (!dec_geom(g, z, ni, nj)) return;
+    const unsigned *z1 = z + 1;
+    const size_t nwords = z_words - 1;
+    unsigned short *d16 = d16_all + (size_t)f * d_stride, *out = out_all + (size_t)f * out_stride;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g.method == 4 && t < ni + nj - 1) {
+        /* row 1 and column 1 as differences (:808-816): the 2-D prefix sum then reproduces them */
+        const int k = (int)t;
+        const unsigned u = getbits_g(z1, nwords, 3u + (unsigned)k * g.nbits, g.nbits);
+        if (k == 0) d16[0] = (unsigned short)u;
+        else if (k < ni) d16[k] = (unsigned short)(u - getbits_g(z1, nwords, 3u + (unsigned)(k - 1) * g.nbits, g.nbits));
+        else {
+            const int j = k - ni + 1;
+            const unsigned prev = getbits_g(z1, nwords, 3u + (unsigned)(j == 1 ? 0 : k - 1) * g.nbits, g.nbits);
+            d16[(size_t)ni * j] = (unsigned short)(u - prev);
+        }
+    }
+    if (t >= g.ntiles || t >= max_tiles) return;
+    const int ty = (int)(t / g.ntx), tx = (int)(t % g.ntx);
+    const int i0 = g.origin + tx * g.istep, j0 = g.origin + ty * g.istep;
+    const int m = min(g.istep, ni - i0), nn = min(g.istep, nj - j0);
+    unsigned pos = tilepos_all[(size_t)f * tp_stride + t];
+    const unsigned hdr = getbits_g(z1, nwords, pos, g.C);
+    pos += g.C;
+    if (g.method == 4) {
+        const int w = hdr == 0 ? 0 : ((hdr == 15 || hdr == 16) ? 17 : (int)hdr + 1);
+        for (int b = 0; b < nn; b++)
+            for (int a = 0; a < m; a++) {
+                int v = 0;
+                if (w) { const unsigned tok = getbits_g(z1, nwords, pos, w); pos += w; v = (int)(tok << (32 - w)) >> (32 - w); }
+                d16[(size_t)ni * (j0 + b) + i0 + a] = (unsigned short)v;
+            }
+    } else {
+        unsigned lo = 0;
+        if (hdr < 15) { lo = getbits_g(z1, nwords, pos, g.nbits); pos += g.nbits; }
+        const int w = hdr == 0 ? 0 : (hdr >= 15 ? 16 : (int)hdr);
+        for (int b = 0; b < nn; b++)
+            for (int a = 0; a < m; a++) {
+                unsigned v = lo;
+                if (w) { v += getbits_g(z1, nwords, pos, w); pos += w; }
+                out[out_slot((size_t)ni * (j0 + b) + i0 + a, swap)] = (unsigned short)v;
+            }
+    }
+}
+
+/* inclusive scan of every row, in place, mod 2^16.  One block per row, 2048-element segments through LDS. */
+__global__ __launch_bounds__(256) void k_armn_dec_rows(const unsigned *z_all, size_t z_stride, unsigned short *d16_all, size_t d_stride, int ni, int nj)
+{
+    const int f = blockIdx.y;
+    if ((z_all[(size_t)f * z_stride] & 15) != 4) return;
+    unsigned short *row = d16_all + (size_t)f * d_stride + (size_t)ni * blockIdx.x;
+    __shared__ unsigned short seg[2048];
+    __shared__ unsigned wtot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned carry = 0;
+    for (int s0 = 0; s0 < ni; s0 += 2048) {
+        const int len = min(2048, ni - s0);
+        for (int k = tid; k < len; k += 256) seg[k] = row[s0 + k];
+        __syncthreads();
+        unsigned v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int idx = tid * 8 + k; sum += (idx < len) ? seg[idx] : 0u; v[k] = sum; }
+        unsigned incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        unsigned off = carry + incl - sum, tot = 0;
+        for (int k = 0; k < 4; k++) { if (k < wv) off += wtot[k]; tot += wtot[k]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int idx = tid * 8 + k; if (idx < len) seg[idx] = (unsigned short)(off + v[k]); }
+        carry += tot;
+        __syncthreads();
+        for (int k = tid; k < len; k += 256) row[s0 + k] = seg[k];
+        __syncthreads();
+    }
+}
+
+/* column totals of each band of `band` rows -> part[band index][ni] */
+__global__ __launch_bounds__(256) void k_armn_dec_colsum(const unsigned *z_all, size_t z_stride, const unsigned short *d16_all, size_t d_stride,
+                                                         unsigned short *part_all, size_t part_stride, int ni, int nj, int band)
+{
+    const int f = blockIdx.z;
+    if ((z_all[(size_t)f * z_stride] & 15) != 4) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ni) return;
+    const unsigned short *d = d16_all + (size_t)f * d_stride;
+    const int j0 = blockIdx.y * band, j1 = min(nj, j0 + band);
+    unsigned s = 0;
+    for (int j = j0; j < j1; j++) s += d[(size_t)ni * j + i];
+    part_all[(size_t)f * part_stride + (size_t)blockIdx.y * ni + i] = (unsigned short)s;
+}
+
+/* running column sums inside each band, offset by the bands above: the final tokens */
+__global__ __launch_bounds__(256) void k_armn_dec_cols(const unsigned *z_all, size_t z_stride, const unsigned short *d16_all, size_t d_stride,
+                                                       const unsigned short *part_all, size_t part_stride,
+                                                       unsigned short *out_all, size_t out_stride, int swap, int ni, int nj, int band)
+{
+    const int f = blockIdx.z;
+    if ((z_all[(size_t)f * z_stride] & 15) != 4) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ni) return;
+    const unsigned short *d = d16_all + (size_t)f * d_stride, *part = part_all + (size_t)f * part_stride;
+    unsigned short *out = out_all + (size_t)f * out_stride;
+    unsigned s = 0;
+    for (int b = 0; b < (int)blockIdx.y; b++) s += part[(size_t)b * ni + i];
+    const int j0 = blockIdx.y * band, j1 = min(nj, j0 + band);
+    for (int j = j0; j < j1; j++) {
+        const size_t k = (size_t)ni * j + i;
+        s += d[k];
+        out[out_slot(k, swap)] = (unsigned short)s;
+    }
+}
+
+#define DEC_BANDS 32
+static size_t dec_max_tiles(int ni, int nj) { return ((size_t)(ni + 2) / 3 + 1) * ((size_t)(nj + 2) / 3 + 1); }   /* tile step >= 3 */
+static size_t dec_nwin(size_t z_words) { return (z_words * 32 + DW - 1) / DW + 1; }
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+extern "C" size_t packhip_armn_dec_work_bytes(int ni, int nj, size_t z_words)
+{
+    const size_t n = (size_t)ni * nj, nwin = dec_nwin(z_words);
+    return al256(4 * dec_max_tiles(ni, nj)) + al256(2 * (n + 8)) + al256(2 * (size_t)DEC_BANDS * ni) + al256(4 * nwin * DEXT) + al256(8 * nwin) + 256;
+}
+
+/* d_out: (1 + ni*nj/2) words per field, zero-filled first (the odd trailing half-word).  d_status: one int per field
+ * (0 ok, -1 unknown header, -2 broken chain).  Everything is asynchronous on the current stream. */
+extern "C" int packhip_armn_decode(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
+                                   int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status)
+{
+    static int attr_done = 0;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)k_armn_dec_hop, hipFuncAttributeMaxDynamicSharedMemorySize, HOP_LDS) != hipSuccess) return -1;
+        attr_done = 1;
+    }
+    hipStream_t st = STREAM;
+    const size_t n = (size_t)ni * nj;
+    if ((unsigned long long)z_words * 32 + 4 * DW >= (1ull << 32)) { fprintf(stderr, "<armn_compress> UNCOMPRESS: stream too large for 32-bit bit positions\n"); return -1; }
+    const long long max_tiles = (long long)dec_max_tiles(ni, nj);
+    if (max_tiles >= (1ll << 31)) { fprintf(stderr, "<armn_compress> UNCOMPRESS: field too large\n"); return -1; }
+    const int nwin = (int)dec_nwin(z_words);
+    char *wk = (char *)d_work;
+    unsigned *tilepos = (unsigned *)wk;                     wk += al256(4 * (size_t)max_tiles);
+    unsigned short *d16 = (unsigned short *)wk;             wk += al256(2 * (n + 8));
+    unsigned short *part = (unsigned short *)wk;            wk += al256(2 * (size_t)DEC_BANDS * ni);
+    unsigned *tab = (unsigned *)wk;                         wk += al256(4 * (size_t)nwin * DEXT);
+    unsigned *went = (unsigned *)wk;
+    const size_t ws4 = work_stride_bytes / 4, ws2 = work_stride_bytes / 2;
+    for (int f = 0; f < nfields; f++) {
+        if (hipMemsetAsync(d_out + (size_t)f * out_stride_words, 0, 4 * (1 + n / 2), st) != hipSuccess) return -1;
+        if (hipMemsetAsync((char *)went + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
+    }
+    hipLaunchKernelGGL(k_armn_dec_spec, dim3(nwin, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, tab, ws4, nwin);
+    hipLaunchKernelGGL(k_armn_dec_hop, dim3(nfields), dim3(HOP_TPB), HOP_LDS, st, d_z, z_stride_words, z_words, ni, nj, tab, ws4, went, ws4, nwin, d_status, getenv("EZHIP_DEC_DEBUG") ? atoi(getenv("EZHIP_DEC_DEBUG")) : 0);
+    hipLaunchKernelGGL(k_armn_dec_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, went, ws4, tilepos, ws4, nwin);
+    const long long grid_tiles = max_tiles > (long long)(ni + nj) ? max_tiles : (long long)(ni + nj);
+    hipLaunchKernelGGL(k_armn_dec_tiles, dim3((unsigned)((grid_tiles + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj,
+                       tilepos, ws4, d16, ws2, (unsigned short *)d_out, out_stride_words * 2, swap, max_tiles);
+    hipLaunchKernelGGL(k_armn_dec_rows, dim3(nj, nfields), dim3(256), 0, st, d_z, z_stride_words, d16, ws2, ni, nj);
+    const int band = (nj + DEC_BANDS - 1) / DEC_BANDS;
+    const int nbands = (nj + band - 1) / band;
+    hipLaunchKernelGGL(k_armn_dec_colsum, dim3((ni + 255) / 256, nbands, nfields), dim3(256), 0, st, d_z, z_stride_words, d16, ws2, part, ws2, ni, nj, band);
+    hipLaunchKernelGGL(k_armn_dec_cols, dim3((ni + 255) / 256, nbands, nfields), dim3(256), 0, st, d_z, z_stride_words, d16, ws2, part, ws2,
+                       (unsigned short *)d_out, out_stride_words * 2, swap, ni, nj, band);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fprintf(stderr, "<armn_compress> UNCOMPRESS launch failed: %s\n", hipGetErrorString(e)); return -1; }
+    return 0;
+}

@@ -28,6 +28,10 @@ def _lib():
         L.ezhip_pack16_compress_dev.argtypes = [vp, vp, ci, ci, ci]
         L.ezhip_ezsint_pack16_batch_dev.argtypes = [vp, ctypes.c_int64, vp, vp, ci, ci, ci]
         L.ezhip_pack_release.restype = None
+        L.c_armn_compress_setswap.argtypes = [ci]
+        L.armn_uncompress_dev.argtypes = [vp, vp, ctypes.c_int64, ci, ci, ci]
+        L.ezhip_armn_uncompress_batch_dev.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, ci, ci, ci, ci]
+        L.ezhip_uncompress_unpack16_dev.argtypes = [vp, vp, ci, ci, ci, ci]
         L.ezhip_pack16_compress_batch_dev.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, ci, ci, ci, ci, ci, vp]
         _configured = True
     return L
@@ -94,8 +98,17 @@ def armn_compress(words, ni, nj, nbits):
     return _lib().armn_compress(words.ctypes.data, ni, nj, 1, nbits, 1)
 
 
+def armn_uncompress(buf, ni, nj, nbits):
+    """in place on a uint32 buffer of at least 1 + ni*nj/2 words holding an armn stream; returns ni*nj*2 or -1"""
+    return _lib().armn_compress(buf.ctypes.data, ni, nj, 1, nbits, 2)
+
+
 def armn_setlevel(level):
     _lib().c_armn_compress_setlevel(level)
+
+
+def armn_setswap(state):
+    _lib().c_armn_compress_setswap(state)
 
 
 def _dptr(t):
@@ -109,6 +122,18 @@ def compact_float_pack_dev(d_field, d_header, d_stream, n, nbits_arg, offset=0, 
 
 def armn_compress_dev(d_z, d_words, ni, nj, nbits):
     return _lib().armn_compress_dev(_dptr(d_z), _dptr(d_words), ni, nj, nbits)
+
+
+def armn_uncompress_dev(d_words, d_z, z_words, ni, nj, nbits):
+    return _lib().armn_uncompress_dev(_dptr(d_words), _dptr(d_z), z_words, ni, nj, nbits)
+
+
+def armn_uncompress_batch_dev(d_words, out_stride_words, d_z, z_stride_words, z_words, ni, nj, nbits, nfields):
+    return _lib().ezhip_armn_uncompress_batch_dev(_dptr(d_words), out_stride_words, _dptr(d_z), z_stride_words, z_words, ni, nj, nbits, nfields)
+
+
+def uncompress_unpack16_dev(d_field, d_record, ni, nj, nbits, compressed):
+    return _lib().ezhip_uncompress_unpack16_dev(_dptr(d_field), _dptr(d_record), ni, nj, nbits, int(compressed))
 
 
 def pack16_compress_dev(d_record, d_field, ni, nj, nbits):

@@ -198,3 +198,105 @@ def test_pack16_compress_batch_equals_field_by_field():
     for f in range(F):
         m = 16 + (int(zl[f]) - 1 if zl[f] > 0 else 2 * n)          # header + stream bytes that are defined
         assert np.array_equal(a[f, :m], b[f, :m]), f
+
+
+# ---------------------------------------------------------------------------------------------
+# armn_compress UNCOMPRESS: the HIP decoder against the restated reference decoder
+# ---------------------------------------------------------------------------------------------
+DEC_SHAPES = ARMN + [(100, 31), (31, 100), (19, 16), (16, 19), (256, 256), (4000, 50), (50, 4000), (18, 18), (3001, 301)]
+
+
+def _oracle_stream(tok, ni, nj, nbits, level):
+    O = top.O()
+    O.orc_armn_compress_setlevel(level)
+    z = np.zeros(ni * nj + 64, np.uint32)
+    zlng = O.orc_armn_encode(z.ctypes.data, tok.ctypes.data, ni, nj, nbits)
+    O.orc_armn_compress_setlevel(-1)
+    return z, zlng
+
+
+@pytest.mark.parametrize("ni,nj", DEC_SHAPES)
+@pytest.mark.parametrize("kind", ["smooth", "noisy", "constant", "bigdiff"])
+@pytest.mark.parametrize("nbits,level", [(16, 1), (12, 1), (4, 1), (16, 0), (9, 0)])
+def test_armn_uncompress_matches_oracle_decoder(ni, nj, kind, nbits, level):
+    """streams written by the oracle's encoder (PARALLELOGRAM at level BEST, MINIMUM at FAST / small / <= 4 bits),
+    compressible or not, decoded by the HIP path == the restated reference decoder == the original tokens"""
+    tok = pc.token_field(ni, nj, nbits, kind, seed=ni * 7 + nj)
+    z, zlng = _oracle_stream(tok, ni, nj, nbits, level)
+    zwords = (zlng - 1) // 4 + 1
+    want = np.zeros(ni * nj, np.uint16)
+    assert top.O().orc_armn_decode(want.ctypes.data, z.ctypes.data, ni, nj) == 0
+    assert np.array_equal(want, tok)
+    d_z = torch.from_numpy(z[:zwords].view(np.int32).copy()).cuda()
+    d_out = torch.full((1 + ni * nj // 2 + 4,), -1, dtype=torch.int32, device="cuda")
+    assert pk.armn_uncompress_dev(d_out, d_z, zwords, ni, nj, nbits) == ni * nj * 2
+    got = d_out.cpu().numpy().view(np.uint32)
+    words = pc.tokens_to_words(tok)
+    assert np.array_equal(got[:words.size], words), np.nonzero(got[:words.size] != words)[0][:5]
+    assert np.all(got[1 + ni * nj // 2:] == 0xFFFFFFFF)            # nothing written past the (1 + n/2) words
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+def test_armn_uncompress_host_in_place_round_trip(swap):
+    ni, nj, nbits = 301, 200, 16
+    tok = pc.token_field(ni, nj, nbits, "smooth", seed=5)
+    words = pc.tokens_to_words(tok)
+    buf = np.zeros(1 + ni * nj // 2 + 2, np.uint32); buf[:words.size] = words
+    zlng = pk.armn_compress(buf, ni, nj, nbits)
+    assert 0 < zlng < ni * nj * 2
+    buf[(zlng + 3) // 4:] = 0xDEADBEEF                              # whatever followed the stream in the record
+    pk.armn_setswap(swap)
+    try:
+        assert pk.armn_uncompress(buf, ni, nj, nbits) == ni * nj * 2
+    finally:
+        pk.armn_setswap(1)
+    if swap:
+        assert np.array_equal(buf[:words.size], words)
+    else:                                                            # fstluk's integer path (fstd98.c:2326-2330): natural ushort order
+        assert np.array_equal(buf.view(np.uint16)[:ni * nj], tok)
+    # the refusals of the reference (c_zfstlib.c:182-184): nothing touched, the odd byte count returned
+    assert pk.armn_uncompress(buf, ni, nj, 17) == 1 + ni * nj * 17 // 8
+    assert pk.armn_uncompress(buf, 1, nj, 16) == 1 + nj * 16 // 8
+
+
+def test_armn_uncompress_rejects_unknown_header():
+    ni, nj = 64, 48
+    z = np.zeros(ni * nj, np.uint32); z[0] = 2 | 3 << 7 | 16 << 10         # SAMPLE predictor (deactivated since 2006)
+    d_z = torch.from_numpy(z.view(np.int32)).cuda()
+    d_out = torch.zeros(1 + ni * nj // 2, dtype=torch.int32, device="cuda")
+    assert pk.armn_uncompress_dev(d_out, d_z, z.size, ni, nj, 16) == -1
+
+
+def test_armn_uncompress_batch_and_full_size_record():
+    """cfg5 read path at full size: 3 different records (one of them plain: not compressible) written by the HIP
+    write path, decoded as a batch -> the original 16-bit tokens; then record -> floats == compact_float unpack"""
+    import ezcases as ec
+    no, mo, F = 7200, 3601, 3
+    n = no * mo
+    stride = 4 + n // 2 + 64
+    fields = np.stack([ec.synth_field(no, mo, seed=31), ec.synth_field(no, mo, seed=32, noise=0.5),
+                       ec.synth_field(no, mo, seed=33, base=1.0, amp=0.5, noise=1e-5)]).reshape(F, n)
+    d_f = torch.from_numpy(fields).cuda()
+    recs = torch.zeros(F * stride, dtype=torch.int32, device="cuda")
+    plain = torch.zeros(F * stride, dtype=torch.int32, device="cuda")
+    for f in range(F):                                                  # plain 16-bit-slot packs (header + tokens)
+        assert pk.compact_float_pack_dev(d_f[f], plain[f * stride:], plain[f * stride + 4:], n, 16 + 64 * 16)
+    rc, zl = pk.pack16_compress_batch_dev(recs, stride, d_f, n, F, no, mo, 16)
+    assert rc == 0 and (zl > 0).sum() >= 2
+    toks = torch.full((F, 1 + n // 2), -1, dtype=torch.int32, device="cuda")
+    comp = [f for f in range(F) if zl[f] > 0]
+    # batch decode of the compressed ones (contiguous selection: decode all, compare the compressed)
+    assert pk.armn_uncompress_batch_dev(toks, 1 + n // 2, recs[4:], stride, stride - 4, no, mo, 16, F) in (n * 2, -1)
+    torch.cuda.synchronize()
+    P = plain.view(F, stride)
+    for f in comp:
+        assert torch.equal(toks[f, :n // 2], P[f, 4:4 + n // 2]), f
+    out = torch.empty(n, dtype=torch.float32, device="cuda"); ref = torch.empty(n, dtype=torch.float32, device="cuda")
+    tagv = np.array([0.0], np.float32)
+    for f in range(F):
+        assert pk.uncompress_unpack16_dev(out, recs[f * stride:], no, mo, 16, zl[f] > 0) == 0
+        assert pk._lib().compact_float_dev(ref.data_ptr(), plain[f * stride:].data_ptr(), plain[f * stride + 4:].data_ptr(), n, 16 + 64 * 16, 0, 1, 2, 0, tagv.ctypes.data, 2)
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), f
+        rng = float(d_f[f].max() - d_f[f].min())                     # tokens truncate to 2^ceil(log2(range)) / 65536
+        assert float((out - d_f[f]).abs().max()) <= 2.0 ** np.ceil(np.log2(rng)) / 65536 * 1.01
