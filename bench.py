@@ -135,7 +135,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the MI355X hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):      # BENCH_FORCE_DIST: exercise the RCCL path with one rank
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
