@@ -219,7 +219,7 @@ orc_grid *orc_grid_define(int ni, int nj, char grtyp, char grref,
     case 'A': case 'B': case 'G':
         if (ig1 != 0 || ig2 != 0) { fprintf(stderr, "orc_grid_define: hemispheric/inverted grids out of scope\n"); free(g); return NULL; }
         break;
-    case 'L': case 'E': case 'Z': break;
+    case 'L': case 'E': case 'Z': case 'N': case 'S': break;
     default: fprintf(stderr, "orc_grid_define: grid type '%c' out of scope\n", grtyp); free(g); return NULL;
     }
     /* c_ezdefxg */
@@ -233,6 +233,7 @@ orc_grid *orc_grid_define(int ni, int nj, char grtyp, char grref,
         g->xg[2] = (float)(180. / (nj - 1)); g->xg[0] = -90.f;
         break;
     case 'E': case 'L':                                         /* ez_defxg.c:111-147 */
+    case 'N': case 'S':                                         /* ez_defxg.c:150-160: xg = (pi, pj, d60, dgrw) */
         orc_cigaxg(grtyp, &g->xg[0], &g->xg[1], &g->xg[2], &g->xg[3], ig1, ig2, ig3, ig4);
         break;
     }
@@ -282,6 +283,42 @@ static void grll(float *lat, float *lon, int ni, int nj, float xla0, float xlo0,
     }
 }
 
+/* LLFXY, src/base/llfxy.F:21-40: all REAL arithmetic (RDTODG from pi.cdk) */
+static void llfxy(float *dlat, float *dlon, float x, float y, float d60, float dgrw, int nhem)
+{
+    const float rdtodg = 57.295779513082f;
+    float re = 1.866025f * 6.371E+6f / d60;
+    float re2 = re * re;
+    *dlat = 90.f; *dlon = 0.f;
+    if (!(x == 0.f && y == 0.f)) {
+        if (x == 0.f) *dlon = copysignf(90.f, y);
+        if (x != 0.f) *dlon = atanf(y / x) * rdtodg;
+        if (x < 0.f) *dlon = *dlon + copysignf(180.f, y);
+        *dlon = *dlon - dgrw;
+        if (*dlon > +180.f) *dlon = *dlon - 360.f;
+        if (*dlon < -180.f) *dlon = *dlon + 360.f;
+        float r2 = x * x + y * y;
+        *dlat = (re2 - r2) / (re2 + r2);
+        *dlat = asinf(*dlat) * rdtodg;
+    }
+    if (nhem == 2) *dlat = -*dlat;
+    if (nhem == 2) *dlon = -*dlon;
+}
+/* GRPS, src/base/grps.f:43-58 */
+static void grps(float *xlat, float *xlon, int ni, int nj, float pi, float pj, float d60, float dgrw, int hem)
+{
+    for (int j = 1; j <= nj; j++) {
+        float y = (float)j - pj;
+        for (int i = 1; i <= ni; i++) {
+            float xla, xlo;
+            llfxy(&xla, &xlo, (float)i - pi, y, d60, dgrw, hem);
+            xlat[(j - 1) * ni + (i - 1)] = xla;
+            if (xlo < 0) xlo = xlo + 360.f;
+            xlon[(j - 1) * ni + (i - 1)] = xlo;
+        }
+    }
+}
+
 int orc_calclatlon(orc_grid *g)
 {
     if (g->lat) return 0;
@@ -304,6 +341,9 @@ int orc_calclatlon(orc_grid *g)
         free(latp); free(lonp);
         break;
     }
+    case 'N': case 'S':                                         /* :83-97 -> GRPS (src/base/grps.f:43-58) */
+        grps(g->lat, g->lon, ni, nj, g->xg[0], g->xg[1], g->xg[2], g->xg[3], g->grtyp == 'N' ? 1 : 2);
+        break;
     case 'Z': case 'G':                                         /* :169-226 */
         for (int j = 0; j < nj; j++)
             for (int i = 0; i < ni; i++) { g->lat[j * ni + i] = g->ay[j]; g->lon[j * ni + i] = g->ax[i]; }
@@ -382,6 +422,30 @@ static void ll2igd(float *px, float *py, const float *xlat, float *xlon, int npt
 }
 
 /* ez_ll2rgd, src/interp/ez_ll2rgd.inc:22-166 (A, B, L, E branches; mutates xlon) */
+/* ez_vxyfll, src/interp/ez_vxyfll.inc:20-99.  dgtord is REAL: `dgtord*(dlon+dgrw)` and `dgtord*dlat` are REAL products
+ * widened on assignment; in the SUD branch rlon is already double when it meets dgtord. */
+static void vxyfll(float *x, float *y, const float *dlat, const float *dlon, int npts, float d60, float dgrw, float pi, float pj, int nhem)
+{
+    const float dgtord = 1.7453292519943e-2f;
+    double re = 1.866025 * 6.371e+6 / (double)d60;
+    for (int i = 0; i < npts; i++) {
+        double rlon, rlat;
+        if (nhem == 1) {
+            rlon = (double)(float)(dgtord * (float)(dlon[i] + dgrw));
+            rlat = (double)(float)(dgtord * dlat[i]);
+        } else {
+            rlon = (double)dlon[i];
+            if (rlon > 180.0) rlon = rlon - 360.0;
+            rlon = (double)dgtord * (-rlon + (double)dgrw);
+            rlat = (double)(float)(dgtord * (-dlat[i]));
+        }
+        double sinlat = sin(rlat);
+        double r = re * sqrt((1.0 - sinlat) / (1.0 + sinlat));
+        x[i] = (float)(r * cos(rlon) + (double)pi);
+        y[i] = (float)(r * sin(rlon) + (double)pj);
+    }
+}
+
 static int ll2rgd(float *px, float *py, const float *xlat, float *xlon, int npts, const orc_grid *g)
 {
     int ni = g->ni, nj = g->nj;
@@ -407,6 +471,12 @@ static int ll2rgd(float *px, float *py, const float *xlat, float *xlon, int npts
         }
         llll2gd(px, py, xlat, xlon, npts, xlat0, xlon0, dellat, dellon, 0.0f);
         return 0;
+    case 'N': case 'S': {                                       /* ez_ll2rgd.inc:43-55 */
+        float pi, pj, d60, dgrw;
+        orc_cigaxg(g->grtyp, &pi, &pj, &d60, &dgrw, g->ig[0], g->ig[1], g->ig[2], g->ig[3]);
+        vxyfll(px, py, xlat, xlon, npts, d60, dgrw, pi, pj, g->grtyp == 'N' ? 1 : 2);
+        return 0;
+    }
     case 'E': {                                                 /* ez_ll2ergd.inc:37-48 */
         float xlat1, xlon1, xlat2, xlon2;
         orc_cigaxg('E', &xlat1, &xlon1, &xlat2, &xlon2, g->ig[0], g->ig[1], g->ig[2], g->ig[3]);
@@ -426,7 +496,7 @@ static int ll2rgd(float *px, float *py, const float *xlat, float *xlon, int npts
 int orc_gdxyfll(const orc_grid *g, float *x, float *y, const float *lat, float *lon, int n)
 {
     switch (g->grtyp) {
-    case 'A': case 'B': case 'E': case 'L': {
+    case 'A': case 'B': case 'E': case 'L': case 'N': case 'S': {
         float *tmplons = (float *)malloc(sizeof(float) * n);
         memcpy(tmplons, lon, sizeof(float) * n);
         int rc = ll2rgd(x, y, lat, tmplons, n, g);
@@ -810,7 +880,7 @@ int orc_calcxy(orc_gridset *gs)   /* src/interp/ez_calcxy.c:28-137 */
     gs->y = (float *)malloc(sizeof(float) * npts);
     int rc;
     switch (gi->grtyp) {   /* note: operates on the target grid's cached lon IN PLACE */
-    case 'A': case 'B': case 'E': case 'L': rc = ll2rgd(gs->x, gs->y, go->lat, go->lon, npts, gi); break;
+    case 'A': case 'B': case 'E': case 'L': case 'N': case 'S': rc = ll2rgd(gs->x, gs->y, go->lat, go->lon, npts, gi); break;
     case 'Z': case 'G': ll2igd(gs->x, gs->y, go->lat, go->lon, npts, gi); rc = 0; break;
     default: rc = -1;
     }
@@ -848,6 +918,7 @@ int orc_defzones(orc_gridset *gs)   /* src/interp/ez_defzones.c:25-113 */
     int npts = go->ni * go->nj;
     int extrap = 0;
     switch (gi->grtyp) {
+    case 'N': case 'S': extrap = 1; break;                        /* :46-50 */
     case 'L':
         extrap = (gi->extension == 0);
         /* falls through into the Z case in the reference; grref is 0 for 'L' so nothing happens */

@@ -50,6 +50,9 @@ def ze_axes(ni, nj):
 
 
 E_IG = (1210, 1600, 57600, 54401)   # cxgaig('E', 31, -90, -20, -20)
+N_IG = (455, 505, 2100, 1000)       # cxgaig('N', 50.5, 45.5, 100000, 21)
+S_IG = (600, 400, 10000, 1500)      # cxgaig('S', 40, 60, 150000, 100)
+N2_IG = (255, 305, 800, 1200)       # cxgaig('N', 30.5, 25.5, 120000, 8)
 
 # name -> dict(src=(ni,nj,grtyp,ig,grref,axes_fn), dst=(ni,nj,grtyp,ig))
 def scalar_cases():
@@ -67,4 +70,10 @@ def scalar_cases():
     cases["ZE_to_L"] = dict(src=(65, 32, "Z", E_IG, "E", ze_axes), dst=(80, 41, "L", (450, 450, 0, 0)))
     cases["G_to_G"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(96, 48, "G", (0, 0, 0, 0)))
     cases["L_to_G"] = dict(src=(40, 20, "L", (900, 900, 450, 0), " ", None), dst=(64, 32, "G", (0, 0, 0, 0)))
+    # polar stereographic grids: N_IG = cxgaig('N', pi=50.5, pj=45.5, d60=100 km, dgrw=21), S_IG = cxgaig('S', 40, 60, 150 km, 100)
+    cases["N_to_L"] = dict(src=(101, 91, "N", N_IG, " ", None), dst=(60, 40, "L", (100, 100, 12000, 20000)))      # partly outside the source: extrapolation
+    cases["L_to_N"] = dict(src=(360, 180, "L", (100, 100, 50, 0), " ", None), dst=(101, 91, "N", N_IG))
+    cases["S_to_L"] = dict(src=(81, 121, "S", S_IG, " ", None), dst=(90, 30, "L", (100, 100, 100, 0)))
+    cases["G_to_S"] = dict(src=(128, 64, "G", (0, 0, 0, 0), " ", None), dst=(81, 121, "S", S_IG))
+    cases["N_to_N"] = dict(src=(101, 91, "N", N_IG, " ", None), dst=(60, 50, "N", N2_IG))
     return cases
