@@ -12,7 +12,7 @@
  * per-row tap tables of the separable kernel.  There is NO CPU fallback for the interpolation
  * itself: without a usable HIP device the interpolation entry points fail loudly (-1).
  *
- * Scope: grid types L, A, B, G (global), E, Z on L / E.  Other types are rejected (-1).
+ * Scope: grid types L, A, B, G (global), E, Z on L / E, polar-stereographic N / S.  Other types are rejected (-1).
  */
 #include <ctype.h>
 #include <math.h>
@@ -321,6 +321,61 @@ static void h_llll2gd(float *x, float *y, const float *lat, float *lon, int n, f
     for (int i = 0; i < n; i++) { x[i] = (lon[i] - lon0) / dlon + 1.0f; y[i] = (lat[i] - lat0) / dlat + 1.0f; }
 }
 /* lon[] is modified in place exactly where the reference modifies it */
+/* polar-stereographic grids: LLFXY (src/base/llfxy.F:21-40, REAL arithmetic), GRPS (src/base/grps.f:43-58),
+ * ez_vxyfll (src/interp/ez_vxyfll.inc:20-99; dgtord is REAL, so `dgtord*(dlon+dgrw)` is a REAL product widened on
+ * assignment, while the SUD branch multiplies in double) */
+static void h_llfxy(float *dlat, float *dlon, float x, float y, float d60, float dgrw, int nhem)
+{
+    const float rdtodg = 57.295779513082f;
+    float re = 1.866025f * 6.371E+6f / d60, re2 = re * re;
+    *dlat = 90.f; *dlon = 0.f;
+    if (!(x == 0.f && y == 0.f)) {
+        if (x == 0.f) *dlon = copysignf(90.f, y);
+        if (x != 0.f) *dlon = atanf(y / x) * rdtodg;
+        if (x < 0.f) *dlon = *dlon + copysignf(180.f, y);
+        *dlon = *dlon - dgrw;
+        if (*dlon > +180.f) *dlon = *dlon - 360.f;
+        if (*dlon < -180.f) *dlon = *dlon + 360.f;
+        float r2 = x * x + y * y;
+        *dlat = (re2 - r2) / (re2 + r2);
+        *dlat = asinf(*dlat) * rdtodg;
+    }
+    if (nhem == 2) { *dlat = -*dlat; *dlon = -*dlon; }
+}
+static void h_grps(float *xlat, float *xlon, int ni, int nj, float pi, float pj, float d60, float dgrw, int hem)
+{
+    for (int j = 1; j <= nj; j++) {
+        float y = (float)j - pj;
+        for (int i = 1; i <= ni; i++) {
+            float xla, xlo;
+            h_llfxy(&xla, &xlo, (float)i - pi, y, d60, dgrw, hem);
+            if (xlo < 0) xlo = xlo + 360.f;
+            xlat[(size_t)(j - 1) * ni + (i - 1)] = xla; xlon[(size_t)(j - 1) * ni + (i - 1)] = xlo;
+        }
+    }
+}
+static void h_vxyfll(float *x, float *y, const float *dlat, const float *dlon, int npts, float d60, float dgrw, float pi, float pj, int nhem)
+{
+    const float dgtord = 1.7453292519943e-2f;
+    double re = 1.866025 * 6.371e+6 / (double)d60;
+    for (int i = 0; i < npts; i++) {
+        double rlon, rlat;
+        if (nhem == 1) {
+            rlon = (double)(float)(dgtord * (float)(dlon[i] + dgrw));
+            rlat = (double)(float)(dgtord * dlat[i]);
+        } else {
+            rlon = (double)dlon[i];
+            if (rlon > 180.0) rlon = rlon - 360.0;
+            rlon = (double)dgtord * (-rlon + (double)dgrw);
+            rlat = (double)(float)(dgtord * (-dlat[i]));
+        }
+        double sinlat = sin(rlat);
+        double r = re * sqrt((1.0 - sinlat) / (1.0 + sinlat));
+        x[i] = (float)(r * cos(rlon) + (double)pi);
+        y[i] = (float)(r * sin(rlon) + (double)pj);
+    }
+}
+
 static int h_locate(const ezh_grid *g, float *x, float *y, const float *lat, float *lon, int n)
 {
     int ni = g->ni, nj = g->nj;
@@ -343,6 +398,9 @@ static int h_locate(const ezh_grid *g, float *x, float *y, const float *lat, flo
             if (lon[i] > (lon0 + (float)ni * dlon)) lon[i] = lon[i] - 360.0f;
         }
         h_llll2gd(x, y, lat, lon, n, lat0, lon0, dlat, dlon, 0.0f);
+        return 0;
+    case 'N': case 'S':                                     /* ez_ll2rgd.inc:43-55 */
+        h_vxyfll(x, y, lat, lon, n, g->xg[2], g->xg[3], g->xg[0], g->xg[1], g->grtyp == 'N' ? 1 : 2);
         return 0;
     case 'E': {
         float *la = (float *)malloc(sizeof(float) * (size_t)n), *lo = (float *)malloc(sizeof(float) * (size_t)n);
@@ -379,7 +437,7 @@ static int grid_ok(int gd) { return gd >= 0 && gd < nG && G[gd].used; }
 
 static int type_supported(char t, char ref, int ig1, int ig2)
 {
-    if (t == 'L' || t == 'E') return 1;
+    if (t == 'L' || t == 'E' || t == 'N' || t == 'S') return 1;
     if (t == 'A' || t == 'B' || t == 'G') return ig1 == 0 && ig2 == 0;   /* hemispheric / inverted: out of scope */
     if (t == 'Z') return ref == 'L' || ref == 'E';
     return 0;
@@ -428,6 +486,7 @@ int32_t c_ezgdef_fmem(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t 
         g->xg[3] = (float)(360. / (ni - 1)); g->xg[1] = 0.0f; g->xg[2] = (float)(180. / (nj - 1)); g->xg[0] = -90.f;
         break;
     case 'L': case 'E':
+    case 'N': case 'S':                                     /* ez_defxg.c:150-160: xg = (pi, pj, d60, dgrw) */
         h_cigaxg(t, &g->xg[0], &g->xg[1], &g->xg[2], &g->xg[3], ig1, ig2, ig3, ig4);
         break;
     }
@@ -681,9 +740,16 @@ static void ensure_coords(ezh_grid *g)
 {
     if (g->coords_ready) return;
     int ni = g->ni, nj = g->nj;
-    g->separable = !(g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E'));
-    g->lat1d = (float *)malloc(sizeof(float) * nj);
-    g->lon1d = (float *)malloc(sizeof(float) * ni);
+    g->separable = !(g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E') || g->grtyp == 'N' || g->grtyp == 'S');
+    g->lat1d = (float *)calloc((size_t)nj, sizeof(float));
+    g->lon1d = (float *)calloc((size_t)ni, sizeof(float));
+    if (g->grtyp == 'N' || g->grtyp == 'S') {              /* ez_calclatlon.c:83-97 */
+        size_t n = (size_t)ni * nj;
+        g->lat2d = (float *)malloc(sizeof(float) * n); g->lon2d = (float *)malloc(sizeof(float) * n);
+        h_grps(g->lat2d, g->lon2d, ni, nj, g->xg[0], g->xg[1], g->xg[2], g->xg[3], g->grtyp == 'N' ? 1 : 2);
+        g->coords_ready = 1;
+        return;
+    }
     if (g->grtyp == 'L' || g->grtyp == 'A' || g->grtyp == 'B') {
         for (int j = 0; j < nj; j++) g->lat1d[j] = g->xg[0] + (float)j * g->xg[2];
         for (int i = 0; i < ni; i++) g->lon1d[i] = fmodf(g->xg[1] + (float)i * g->xg[3], 360.0f);
@@ -804,12 +870,13 @@ static int ensure_coords_dev(ezh_grid *g)
 /* ------------------------------------------------------------------------------------------ */
 static int src_is_separable(const ezh_grid *g)
 {   /* x depends on lon only and y on lat only: everything but the rotated frames */
-    return !(g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E'));
+    return !(g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E') || g->grtyp == 'N' || g->grtyp == 'S');
 }
 static int src_irregular(const ezh_grid *g) { return g->grtyp == 'G' || g->grtyp == 'Z'; }
 
 static int set_extrap(const ezh_grid *gi)
 {
+    if (gi->grtyp == 'N' || gi->grtyp == 'S') return 1;       /* ez_defzones.c:46-50 */
     if (gi->grtyp == 'L') return gi->extension == 0;
     if (gi->grtyp == 'Z' && (gi->grref == 'E' || gi->grref == 'L'))
         return 358.0 > (gi->ax[gi->ni - 1] - gi->ax[0]);
@@ -1307,6 +1374,9 @@ static void fill_locate_plan(const ezh_grid *gi, ezhip_locate_plan *lp)
     case 'A': lp->kind = 0; lp->dlon = 360.0f / (float)gi->ni; lp->lon0 = 0.0f; lp->dlat = 180.0f / (float)gi->nj; lp->lat0 = -90.0f + lp->dlat * 0.5f; lp->lon_fix = 2; break;
     case 'B': lp->kind = 0; lp->dlon = 360.0f / (float)(gi->ni - 1); lp->lon0 = 0.0f; lp->dlat = 180.0f / (float)(gi->nj - 1); lp->lat0 = -90.0f; lp->lon_fix = 2; break;
     case 'L': lp->kind = 0; h_cigaxg('L', &lp->lat0, &lp->lon0, &lp->dlat, &lp->dlon, gi->ig[0], gi->ig[1], gi->ig[2], gi->ig[3]); lp->lon_fix = 1; break;
+    case 'N': case 'S':                                     /* kind 4: ez_vxyfll with (pi, pj, d60, dgrw) in (lat0, lon0, dlat, dlon), hemisphere in lon_fix */
+        lp->kind = 4; lp->lat0 = gi->xg[0]; lp->lon0 = gi->xg[1]; lp->dlat = gi->xg[2]; lp->dlon = gi->xg[3]; lp->lon_fix = gi->grtyp == 'N' ? 1 : 2;
+        break;
     case 'E':
         lp->kind = 3; lp->dlon = 360.0f / (float)(gi->ni - 1); lp->lon0 = 0.0f; lp->dlat = 180.0f / (float)gi->nj; lp->lat0 = -90.f + 0.5f * lp->dlat;
         h_crot(r, ri, gi->xg[1], gi->xg[0], gi->xg[3], gi->xg[2]); memcpy(lp->r, r, sizeof(r));
@@ -1890,6 +1960,8 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
     wp.separable = go->separable;
     wp.wd_only = wd_only;
     wp.src_rotated = (gi->grtyp == 'E' || (gi->grtyp == 'Z' && gi->grref == 'E'));
+    if (gi->grtyp == 'N' || gi->grtyp == 'S') { wp.src_ps = gi->grtyp == 'N' ? 1 : 2; wp.src_xg4 = gi->xg[3]; }
+    if (go->grtyp == 'N' || go->grtyp == 'S') { wp.dst_ps = go->grtyp == 'N' ? 1 : 2; wp.dst_xg4 = go->xg[3]; }
     if (wp.src_rotated) { const float *xg = gi->grtyp == 'E' ? gi->xg : gi->xgref; h_crot(wp.r, wp.ri, xg[1], xg[0], xg[3], xg[2]); }
     else if (gi->grtyp == 'Z' && gi->grref != 'L') return -1;
     if (wp.src_rotated && wp.separable) {

@@ -1478,7 +1478,25 @@ __global__ __launch_bounds__(256) void k_locate(ezhip_locate_plan p, float *__re
     if (separable) { lat = lats[n / ni_dst]; lon = lons[n % ni_dst]; }
     else { lat = lats[n]; lon = lons[n]; }
     float px, py;
-    if (p.kind == 0 || p.kind == 3) {
+    if (p.kind == 4) {                                      /* ez_vxyfll.inc:32-58: REAL dgtord products, the rest in double */
+        const float dgtord = 1.7453292519943e-2f;
+        const float pi = p.lat0, pj = p.lon0, d60 = p.dlat, dgrw = p.dlon;
+        const double re = 1.866025 * 6.371e+6 / (double)d60;
+        double rlon, rlat;
+        if (p.lon_fix == 1) {
+            rlon = (double)(float)(dgtord * (float)(lon + dgrw));
+            rlat = (double)(float)(dgtord * lat);
+        } else {
+            rlon = (double)lon;
+            if (rlon > 180.0) rlon = rlon - 360.0;
+            rlon = (double)dgtord * (-rlon + (double)dgrw);
+            rlat = (double)(float)(dgtord * (-lat));
+        }
+        const double sinlat = sin(rlat);
+        const double r = re * sqrt((1.0 - sinlat) / (1.0 + sinlat));
+        px = (float)(r * cos(rlon) + (double)pi);
+        py = (float)(r * sin(rlon) + (double)pj);
+    } else if (p.kind == 0 || p.kind == 3) {
         if (p.kind == 3) { float lo, la; d_rotate(p.r, lon, lat, lo, la); lon = lo; lat = la; }
         if (p.lon_fix == 1) {                               /* ez_ll2rgd.inc:137-145 */
             if (lon < p.lon0) lon = lon + 360.0f;
@@ -1581,15 +1599,17 @@ __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *_
         double sg = ((double)q[2] * ee) - (cc * ff);
         v = (float)(sg >= 0.0 ? fabs(dd) : -fabs(dd));
     }
-    /* ez_llwfgdw.inc:108-127 ('L'/A/B/G): components -> speed, direction */
+    /* components -> speed, direction: ez_llwfgdw.inc:91-114 ('N'), :117-140 ('S'), :143-165 ('L'/A/B/G) */
     float spd = sqrtf(u * u + v * v), dir;
     if (spd == 0.0f) dir = 0.0f;
+    else if (p.src_ps == 1) dir = (u == 0.0f) ? ((v >= 0.0f) ? lon + p.src_xg4 - 90.0f : lon + p.src_xg4 + 90.0f) : lon + p.src_xg4 - RDTODG * atan2f(v, u);
+    else if (p.src_ps == 2) dir = (u == 0.0f) ? ((v >= 0.0f) ? 90.0f - lon + p.src_xg4 : 270.0f - lon + p.src_xg4) : 180.0f - lon + p.src_xg4 - RDTODG * atan2f(v, u);
     else if (u == 0.0f) dir = (v >= 0.0f) ? 180.0f : 0.0f;
     else dir = 270.0f - RDTODG * atan2f(v, u);
     dir = fmodf(fmodf(dir, 360.0f) + 360.0f, 360.0f);
     if (p.wd_only) { uu[n] = spd; vv[n] = dir; return; }      /* c_ezwdint: speed / direction are the result */
-    /* ez_gdwfllw.inc:118-129 ('L'/A/B/G): speed, direction -> target components */
-    float psi = 270.0f - dir;
+    /* speed, direction -> target components: ez_gdwfllw.inc:93-105 ('N'), :108-121 ('S'), :123-134 ('L'/A/B/G) */
+    float psi = p.dst_ps == 1 ? lon + p.dst_xg4 - dir : p.dst_ps == 2 ? 180.0f - lon + p.dst_xg4 - dir : 270.0f - dir;
     uu[n] = cosf(psi * DGTORD) * spd;
     vv[n] = sinf(psi * DGTORD) * spd;
 }

@@ -163,7 +163,8 @@ int ezhip_fill_value(float *d_fill, const float *d_zin, size_t n, int degre_extr
 /* ---- locate ------------------------------------------------------------------------------ */
 typedef struct {
     int kind;                         /* 0: regular lat-lon (llll2gd), 1: irregular axes on 'L' ref (G, Z/L),
-                                         2: irregular axes on rotated 'E' ref (Z/E), 3: regular rotated 'E' */
+                                         2: irregular axes on rotated 'E' ref (Z/E), 3: regular rotated 'E',
+                                         4: polar stereographic N / S: (lat0, lon0, dlat, dlon) = (pi, pj, d60, dgrw), lon_fix = hemisphere */
     int ni, nj;
     float lat0, lon0, dlat, dlon;     /* kind 0/3: llll2gd parameters; kind 1: reference-grid decode */
     float lonref;                     /* kind 1: 0 or -180 */
@@ -182,6 +183,8 @@ typedef struct {
     float r[9], ri[9];
     int separable;                    /* target lat/lon given as 1-D arrays */
     int wd_only;                      /* 1: stop after c_gdwdfuv (c_ezwdint): uu := speed, vv := direction */
+    int src_ps, dst_ps;               /* 0, or 1 = 'N' / 2 = 'S': polar-stereographic source / target (ez_llwfgdw.inc:91-140, ez_gdwfllw.inc:93-121) */
+    float src_xg4, dst_xg4;           /* their dgrw */
     const double *lon_trig, *lat_trig;   /* separable + rotated source: {cos, sin} per target column / row (ezhip_wind_trig_tables), or NULL */
     const float *lon_trigf, *lat_trigf;  /* the REAL {cos, sin} pairs of the same angles (rotation into the source frame) */
 } ezhip_wind_plan;

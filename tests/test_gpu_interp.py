@@ -439,3 +439,34 @@ def test_full_size_cfg2_against_reference_run(fname):
         ez.ezsint_dev(d_out, d_in); torch.cuda.synchronize()
         f = d_out.cpu().numpy()
         assert "%.8e %.3f %.3f %.3f" % (f.astype(np.float64).sum(), f[0], f[f.size // 2], f[-1]) == "7.26056487e+09 281.818 276.863 278.271"
+
+
+PS_CASES = ["N_to_L", "L_to_N", "S_to_L", "G_to_S", "N_to_N"]
+
+
+@pytest.mark.parametrize("name", PS_CASES)
+def test_polar_stereographic_coordinates_and_locate(name):
+    """N / S grids: c_gdll of the target (GRPS, host) and c_gdxyfll on the source (ez_vxyfll, host)
+    bit-exact against the reference's values; the device locate (double sin/cos/sqrt of the device library) within 1 ulp"""
+    case = CASES[name]
+    gdin = hip_define(case["src"]); gdout = hip_define(case["dst"] + (" ", None))
+    no, mo = case["dst"][:2]
+    rc, lat, lon = ez.gdll(gdout, no * mo)
+    assert rc == 0
+    assert np.array_equal(lat, GOLD[f"{name}/lat"])           # value equality: an 'L' target's first longitude is -0.0 in the reference
+    assert np.array_equal(lon, GOLD[f"{name}/lon"])
+    if case["dst"][2] in ("N", "S"):
+        assert np.array_equal(lat.view(np.uint32), GOLD[f"{name}/lat"].view(np.uint32))
+        assert np.array_equal(lon.view(np.uint32), GOLD[f"{name}/lon"].view(np.uint32))
+    rc, x, y = ez.gdxyfll(gdin, lat.copy(), lon.copy())
+    assert rc == 0
+    if case["src"][2] in ("N", "S"):
+        assert np.array_equal(x.view(np.uint32), GOLD[f"{name}/x"].view(np.uint32))
+        assert np.array_equal(y.view(np.uint32), GOLD[f"{name}/y"].view(np.uint32))
+    d_lat = torch.from_numpy(lat).cuda(); d_lon = torch.from_numpy(lon).cuda()
+    d_x = torch.empty(no * mo, dtype=torch.float32, device="cuda"); d_y = torch.empty_like(d_x)
+    ez.use_stream(0)
+    assert ez.gdxyfll_dev(gdin, d_x, d_y, d_lat, d_lon, no * mo) == 0
+    torch.cuda.synchronize()
+    for got, want in ((d_x.cpu().numpy(), GOLD[f"{name}/x"]), (d_y.cpu().numpy(), GOLD[f"{name}/y"])):
+        assert np.abs(got.astype(np.float64) - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), name

@@ -79,7 +79,8 @@ def test_grid_table_semantics():
     a = ez.ezqkdef(30, 15, "L", 100, 100, 0, 0)
     b = ez.ezqkdef(30, 15, "L", 100, 100, 0, 0)
     assert a == b and a >= 0                       # identical definitions dedupe (ez_identifygrid.c)
-    assert ez.ezqkdef(30, 15, "N", 1, 1, 1, 1) == -1       # polar-stereographic: out of scope, rejected loudly
+    assert ez.ezqkdef(30, 15, "N", 455, 505, 2100, 1000) >= 0  # polar-stereographic: supported
+    assert ez.ezqkdef(30, 15, "!", 1, 1, 1, 1) == -1       # Lambert: out of scope, rejected loudly
     assert ez.ezqkdef(30, 15, "G", 1, 0, 0, 0) == -1       # hemispheric: out of scope
     assert ez.ezdefset(a, 9999) == -1
 
