@@ -12,7 +12,7 @@
  * per-row tap tables of the separable kernel.  There is NO CPU fallback for the interpolation
  * itself: without a usable HIP device the interpolation entry points fail loudly (-1).
  *
- * Scope: grid types L, A, B, G (global), E, Z on L / E, polar-stereographic N / S.  Other types are rejected (-1).
+ * Scope: grid types L, A, B, G (global), E, Z on L / E, polar-stereographic N / S, and 'Y' point clouds on 'L' as TARGETS.  Other types are rejected (-1).
  */
 #include <ctype.h>
 #include <math.h>
@@ -440,6 +440,7 @@ static int type_supported(char t, char ref, int ig1, int ig2)
     if (t == 'L' || t == 'E' || t == 'N' || t == 'S') return 1;
     if (t == 'A' || t == 'B' || t == 'G') return ig1 == 0 && ig2 == 0;   /* hemispheric / inverted: out of scope */
     if (t == 'Z') return ref == 'L' || ref == 'E';
+    if (t == 'Y') return ref == 'L';                                      /* as a target; c_ezdefset refuses it as a source */
     return 0;
 }
 
@@ -452,6 +453,10 @@ static int find_grid(int ni, int nj, char t, char ref, const int *ig, const floa
         if (t == 'Z') {
             if (g->grref != ref) continue;
             if (memcmp(g->ax, ax, sizeof(float) * ni) || memcmp(g->ay, ay, sizeof(float) * nj)) continue;
+        }
+        if (t == 'Y') {
+            if (g->grref != ref) continue;
+            if (memcmp(g->ax, ax, sizeof(float) * (size_t)ni * nj) || memcmp(g->ay, ay, sizeof(float) * (size_t)ni * nj)) continue;
         }
         return k;
     }
@@ -476,7 +481,7 @@ int32_t c_ezgdef_fmem(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t 
     }
     ezh_grid *g = &G[gd];
     memset(g, 0, sizeof(*g));
-    g->used = 1; g->refcount = 1; g->grtyp = t; g->grref = (t == 'Z') ? ref : 0;
+    g->used = 1; g->refcount = 1; g->grtyp = t; g->grref = (t == 'Z' || t == 'Y') ? ref : 0;
     g->ni = ni; g->nj = nj; memcpy(g->ig, ig, sizeof(ig));
     switch (t) {                                            /* c_ezdefxg, ez_defxg.c:28-170 */
     case 'A': case 'G':
@@ -495,6 +500,10 @@ int32_t c_ezgdef_fmem(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t 
         h_cigaxg(ref, &g->xgref[0], &g->xgref[1], &g->xgref[2], &g->xgref[3], ig1, ig2, ig3, ig4);
         g->ax = (float *)malloc(sizeof(float) * ni); memcpy(g->ax, ax, sizeof(float) * ni);
         g->ay = (float *)malloc(sizeof(float) * nj); memcpy(g->ay, ay, sizeof(float) * nj);
+    } else if (t == 'Y') {                                  /* ez_defaxes.c:58-65: ax = lon, ay = lat of every point */
+        size_t n = (size_t)ni * nj;
+        g->ax = (float *)malloc(sizeof(float) * n); memcpy(g->ax, ax, sizeof(float) * n);
+        g->ay = (float *)malloc(sizeof(float) * n); memcpy(g->ay, ay, sizeof(float) * n);
     } else if (t == 'G') {                                  /* ez_defaxes.c:65-91 */
         g->grref = 'L';
         g->xgref[0] = 0.0f; g->xgref[1] = 0.0f; g->xgref[2] = 1.0f; g->xgref[3] = 1.0f;
@@ -577,6 +586,10 @@ static ezh_set *find_set(int gdout, int gdin, int create)
 int32_t c_ezdefset(int32_t gdout, int32_t gdin)     /* ezdefset.c:38-171 */
 {
     if (!grid_ok(gdout) || !grid_ok(gdin)) { fprintf(stderr, "<c_ezdefset> invalid grid id\n"); return -1; }
+    if (G[gdin].grtyp == 'Y') {       /* the reference interpolates FROM a cloud with its cloud_interp_alg (gdinterp.c:207-230): not on this path */
+        fprintf(stderr, "<c_ezdefset> a 'Y' cloud as SOURCE grid is outside the MI355X hot-path scope\n");
+        return -1;
+    }
     pthread_mutex_lock(&g_mtx);
     find_set(gdout, gdin, 1);
     pthread_mutex_unlock(&g_mtx);
@@ -609,7 +622,9 @@ int32_t c_ezgxprm(int32_t gd, int32_t *ni, int32_t *nj, char *grtyp, int32_t *ig
 int32_t c_gdgaxes(int32_t gd, float *ax, float *ay)
 {
     if (!grid_ok(gd) || !G[gd].ax) return -1;
-    memcpy(ax, G[gd].ax, sizeof(float) * G[gd].ni); memcpy(ay, G[gd].ay, sizeof(float) * G[gd].nj);
+    size_t nx = G[gd].ni, ny = G[gd].nj;
+    if (G[gd].grtyp == 'Y') nx = ny = (size_t)G[gd].ni * G[gd].nj;        /* gdgaxes.c:40-45 */
+    memcpy(ax, G[gd].ax, sizeof(float) * nx); memcpy(ay, G[gd].ay, sizeof(float) * ny);
     return 0;
 }
 
@@ -740,9 +755,16 @@ static void ensure_coords(ezh_grid *g)
 {
     if (g->coords_ready) return;
     int ni = g->ni, nj = g->nj;
-    g->separable = !(g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E') || g->grtyp == 'N' || g->grtyp == 'S');
+    g->separable = !(g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E') || g->grtyp == 'N' || g->grtyp == 'S' || g->grtyp == 'Y');
     g->lat1d = (float *)calloc((size_t)nj, sizeof(float));
     g->lon1d = (float *)calloc((size_t)ni, sizeof(float));
+    if (g->grtyp == 'Y') {                                  /* ez_calclatlon.c:127-143 */
+        size_t n = (size_t)ni * nj;
+        g->lat2d = (float *)malloc(sizeof(float) * n); g->lon2d = (float *)malloc(sizeof(float) * n);
+        memcpy(g->lon2d, g->ax, sizeof(float) * n); memcpy(g->lat2d, g->ay, sizeof(float) * n);
+        g->coords_ready = 1;
+        return;
+    }
     if (g->grtyp == 'N' || g->grtyp == 'S') {              /* ez_calclatlon.c:83-97 */
         size_t n = (size_t)ni * nj;
         g->lat2d = (float *)malloc(sizeof(float) * n); g->lon2d = (float *)malloc(sizeof(float) * n);

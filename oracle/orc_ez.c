@@ -220,6 +220,7 @@ orc_grid *orc_grid_define(int ni, int nj, char grtyp, char grref,
         if (ig1 != 0 || ig2 != 0) { fprintf(stderr, "orc_grid_define: hemispheric/inverted grids out of scope\n"); free(g); return NULL; }
         break;
     case 'L': case 'E': case 'Z': case 'N': case 'S': break;
+    case 'Y': if (grref != 'L') { fprintf(stderr, "orc_grid_define: 'Y' grids on '%c' out of scope\n", grref); free(g); return NULL; } break;   /* target only */
     default: fprintf(stderr, "orc_grid_define: grid type '%c' out of scope\n", grtyp); free(g); return NULL;
     }
     /* c_ezdefxg */
@@ -242,6 +243,11 @@ orc_grid *orc_grid_define(int ni, int nj, char grtyp, char grref,
         orc_cigaxg(grref, &g->xgref[0], &g->xgref[1], &g->xgref[2], &g->xgref[3], ig1, ig2, ig3, ig4);
         g->ax = (float *)malloc(sizeof(float) * ni); memcpy(g->ax, ax, sizeof(float) * ni);
         g->ay = (float *)malloc(sizeof(float) * nj); memcpy(g->ay, ay, sizeof(float) * nj);
+    }
+    if (grtyp == 'Y') {                                         /* ez_defaxes.c:58-65: ax = lon, ay = lat of every point */
+        size_t n = (size_t)ni * nj;
+        g->ax = (float *)malloc(sizeof(float) * n); memcpy(g->ax, ax, sizeof(float) * n);
+        g->ay = (float *)malloc(sizeof(float) * n); memcpy(g->ay, ay, sizeof(float) * n);
     }
     if (grtyp == 'G') {                                         /* ez_defaxes.c:65-91 */
         g->grref = 'L';
@@ -341,6 +347,9 @@ int orc_calclatlon(orc_grid *g)
         free(latp); free(lonp);
         break;
     }
+    case 'Y':                                                   /* :127-143, grref 'L' */
+        memcpy(g->lon, g->ax, sizeof(float) * npts); memcpy(g->lat, g->ay, sizeof(float) * npts);
+        break;
     case 'N': case 'S':                                         /* :83-97 -> GRPS (src/base/grps.f:43-58) */
         grps(g->lat, g->lon, ni, nj, g->xg[0], g->xg[1], g->xg[2], g->xg[3], g->grtyp == 'N' ? 1 : 2);
         break;

@@ -49,6 +49,15 @@ def ze_axes(ni, nj):
     return ax, ay
 
 
+def cloud_axes(ni, nj):
+    """'Y' grid: ni*nj scattered points, ax = longitudes, ay = latitudes (hash-generated, libm-free)"""
+    n = ni * nj
+    lon = (hash_uniform(77, n).astype(np.float64) * 360.0).astype(np.float32)
+    lat = (hash_uniform(78, n).astype(np.float64) * 178.0 - 89.0).astype(np.float32)
+    lat[:4] = np.float32([90.0, -90.0, 89.97, -89.97]); lon[4] = np.float32(0.0); lon[5] = np.float32(359.99)
+    return lon, lat
+
+
 E_IG = (1210, 1600, 57600, 54401)   # cxgaig('E', 31, -90, -20, -20)
 N_IG = (455, 505, 2100, 1000)       # cxgaig('N', 50.5, 45.5, 100000, 21)
 S_IG = (600, 400, 10000, 1500)      # cxgaig('S', 40, 60, 150000, 100)
@@ -75,5 +84,13 @@ def scalar_cases():
     cases["L_to_N"] = dict(src=(360, 180, "L", (100, 100, 50, 0), " ", None), dst=(101, 91, "N", N_IG))
     cases["S_to_L"] = dict(src=(81, 121, "S", S_IG, " ", None), dst=(90, 30, "L", (100, 100, 100, 0)))
     cases["G_to_S"] = dict(src=(128, 64, "G", (0, 0, 0, 0), " ", None), dst=(81, 121, "S", S_IG))
+    # 'Y' target: a cloud of points (incl. both poles and the seam)
+    cases["G_to_Y"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(37, 11, "Y", (0, 0, 0, 0)), dst_ref="L", dst_axes=cloud_axes)
+    cases["ZE_to_Y"] = dict(src=(65, 32, "Z", E_IG, "E", ze_axes), dst=(37, 11, "Y", (0, 0, 0, 0)), dst_ref="L", dst_axes=cloud_axes)
     cases["N_to_N"] = dict(src=(101, 91, "N", N_IG, " ", None), dst=(60, 50, "N", N2_IG))
     return cases
+
+
+def dst_spec(case):
+    """target grid spec in the 6-tuple form of the source: (ni, nj, grtyp, ig, grref, axes_fn)"""
+    return case["dst"] + (case.get("dst_ref", " "), case.get("dst_axes"))

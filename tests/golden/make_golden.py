@@ -19,7 +19,7 @@ DEG = {0: b"nearest", 1: b"linear", 3: b"cubic"}
 
 def define(L, spec):
     ni, nj, grtyp, ig, grref, axes = spec
-    if grtyp == "Z":
+    if grtyp in ("Z", "Y"):
         ax, ay = axes(ni, nj)
         return L.c_ezgdef_fmem(ni, nj, grtyp.encode(), grref.encode(), ig[0], ig[1], ig[2], ig[3], fptr(ax), fptr(ay))
     return L.c_ezqkdef(ni, nj, grtyp.encode(), ig[0], ig[1], ig[2], ig[3], 0)
@@ -44,7 +44,7 @@ def main():
         L.c_gdgaxes(gd, fptr(ax), fptr(ay))
         out[f"gausslat_{nj}"] = ay
     for name, case in sorted(ec.scalar_cases().items()):
-        gdin = define(L, case["src"]); gdout = define(L, case["dst"] + (" ", None))
+        gdin = define(L, case["src"]); gdout = define(L, ec.dst_spec(case))
         L.c_ezdefset(gdout, gdin)
         no, mo = case["dst"][:2]
         zin, uu, vv = case_inputs(name, case)

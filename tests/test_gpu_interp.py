@@ -23,7 +23,7 @@ RTOL = 1e-5
 
 def hip_define(spec):
     ni, nj, grtyp, ig, grref, axes = spec
-    if grtyp == "Z":
+    if grtyp in ("Z", "Y"):
         ax, ay = axes(ni, nj)
         return ez.ezgdef_fmem(ni, nj, grtyp, grref, ig[0], ig[1], ig[2], ig[3], ax, ay)
     return ez.ezqkdef(ni, nj, grtyp, ig[0], ig[1], ig[2], ig[3])
@@ -67,7 +67,7 @@ def test_ezsint_vs_golden(name, force_pts):
         os.environ["EZHIP_FORCE_PTS"] = "1"
     if force_pts == 2:
         os.environ["EZHIP_NO_SEPX"] = "1"
-    gdin = hip_define(case["src"]); gdout = hip_define(case["dst"] + (" ", None))
+    gdin = hip_define(case["src"]); gdout = hip_define(ec.dst_spec(case))
     assert gdin >= 0 and gdout >= 0
     assert ez.ezdefset(gdout, gdin) == 1
     no, mo = case["dst"][:2]
@@ -94,7 +94,7 @@ def test_ezsint_vs_golden(name, force_pts):
 @pytest.mark.parametrize("name", [n for n in sorted(CASES) if n not in ("G_to_G", "L_to_G")])
 def test_ezuvint_vs_golden(name):
     case = CASES[name]
-    gdin = hip_define(case["src"]); gdout = hip_define(case["dst"] + (" ", None))
+    gdin = hip_define(case["src"]); gdout = hip_define(ec.dst_spec(case))
     ez.ezdefset(gdout, gdin)
     no, mo = case["dst"][:2]
     _, uu, vv = case_inputs(name, case)
@@ -119,7 +119,7 @@ def test_ezwdint_vs_golden(name):
     """c_ezwdint (speed / direction on the target grid), bicubic, polar correction on / off, against the reference's
     own outputs (golden fixture).  Direction is compared modulo 360 and only where the wind is not calm."""
     case = CASES[name]
-    gdin = hip_define(case["src"]); gdout = hip_define(case["dst"] + (" ", None))
+    gdin = hip_define(case["src"]); gdout = hip_define(ec.dst_spec(case))
     assert ez.ezdefset(gdout, gdin) == 1
     no, mo = case["dst"][:2]
     _, uu, vv = case_inputs(name, case)
@@ -314,7 +314,7 @@ def test_sepx_shapes_vs_oracle(shape, batch):
         grref = spec[4] if len(spec) > 4 else " "
         axes = spec[5](ni, nj) if len(spec) > 5 else (None, None)
         if hip:
-            if grtyp == "Z":
+            if grtyp in ("Z", "Y"):
                 return ez.ezgdef_fmem(ni, nj, grtyp, grref, ig[0], ig[1], ig[2], ig[3], axes[0], axes[1])
             return ez.ezqkdef(ni, nj, grtyp, ig[0], ig[1], ig[2], ig[3])
         return ol.grid_define(ni, nj, grtyp, ig, grref, axes[0], axes[1])
@@ -449,7 +449,7 @@ def test_polar_stereographic_coordinates_and_locate(name):
     """N / S grids: c_gdll of the target (GRPS, host) and c_gdxyfll on the source (ez_vxyfll, host)
     bit-exact against the reference's values; the device locate (double sin/cos/sqrt of the device library) within 1 ulp"""
     case = CASES[name]
-    gdin = hip_define(case["src"]); gdout = hip_define(case["dst"] + (" ", None))
+    gdin = hip_define(case["src"]); gdout = hip_define(ec.dst_spec(case))
     no, mo = case["dst"][:2]
     rc, lat, lon = ez.gdll(gdout, no * mo)
     assert rc == 0

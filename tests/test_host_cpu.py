@@ -49,7 +49,7 @@ def test_gaussian_latitudes_match_reference_golden():
 
 def _define(spec):
     ni, nj, grtyp, ig, grref, axes = spec
-    if grtyp == "Z":
+    if grtyp in ("Z", "Y"):
         ax, ay = axes(ni, nj)
         return ez.ezgdef_fmem(ni, nj, grtyp, grref, ig[0], ig[1], ig[2], ig[3], ax, ay)
     return ez.ezqkdef(ni, nj, grtyp, ig[0], ig[1], ig[2], ig[3])
@@ -58,7 +58,7 @@ def _define(spec):
 @pytest.mark.parametrize("name", sorted(ec.scalar_cases()))
 def test_gdll_and_host_locate_match_reference_golden(name):
     case = ec.scalar_cases()[name]
-    gdin = _define(case["src"]); gdout = _define(case["dst"] + (" ", None))
+    gdin = _define(case["src"]); gdout = _define(ec.dst_spec(case))
     no, mo = case["dst"][:2]
     rc, lat, lon = ez.gdll(gdout, no * mo)
     assert rc == 0

@@ -13,7 +13,7 @@ CASES = ec.scalar_cases()
 
 def orc_define(spec):
     ni, nj, grtyp, ig, grref, axes = spec
-    if grtyp == "Z":
+    if grtyp in ("Z", "Y"):
         ax, ay = axes(ni, nj)
         return ol.grid_define(ni, nj, grtyp, ig, grref, ax, ay)
     return ol.grid_define(ni, nj, grtyp, ig)
@@ -45,7 +45,7 @@ def test_scalar_golden(name):
     case = CASES[name]
     no, mo = case["dst"][:2]
     zin, uu, vv = case_inputs(name, case)
-    gi = orc_define(case["src"]); go = orc_define(case["dst"] + (" ", None))
+    gi = orc_define(case["src"]); go = orc_define(ec.dst_spec(case))
     gs = O.orc_defset(go, gi)
     for degree in (0, 1, 3):
         for polar in (1, 0):
@@ -69,7 +69,7 @@ def test_vector_golden(name):
     case = CASES[name]
     no, mo = case["dst"][:2]
     zin, uu, vv = case_inputs(name, case)
-    gi = orc_define(case["src"]); go = orc_define(case["dst"] + (" ", None))
+    gi = orc_define(case["src"]); go = orc_define(ec.dst_spec(case))
     gs = O.orc_defset(go, gi)
     for degree in (0, 1, 3):
         for polar in (1, 0):
@@ -85,7 +85,7 @@ def test_wdint_golden(name):
     """orc_ezwdint (speed / direction) against the reference's c_ezwdint outputs in the fixture, bit-exact"""
     O = ol.oracle()
     case = CASES[name]
-    gi = orc_define(case["src"]); go = orc_define(case["dst"] + (" ", None))
+    gi = orc_define(case["src"]); go = orc_define(ec.dst_spec(case))
     gs = O.orc_defset(go, gi)
     no, mo = case["dst"][:2]
     _, uu, vv = case_inputs(name, case)

@@ -17,7 +17,7 @@ EXTRAP = {0: b"nearest", 1: b"linear", 3: b"cubic", 4: b"maximum", 5: b"minimum"
 
 def ref_define(L, spec):
     ni, nj, grtyp, ig, grref, axes = spec
-    if grtyp == "Z":
+    if grtyp in ("Z", "Y"):
         ax, ay = axes(ni, nj)
         return L.c_ezgdef_fmem(ni, nj, grtyp.encode(), grref.encode(), ig[0], ig[1], ig[2], ig[3], fptr(ax), fptr(ay))
     return L.c_ezqkdef(ni, nj, grtyp.encode(), ig[0], ig[1], ig[2], ig[3], 0)
@@ -25,7 +25,7 @@ def ref_define(L, spec):
 
 def orc_define(spec):
     ni, nj, grtyp, ig, grref, axes = spec
-    if grtyp == "Z":
+    if grtyp in ("Z", "Y"):
         ax, ay = axes(ni, nj)
         return ol.grid_define(ni, nj, grtyp, ig, grref, ax, ay)
     return ol.grid_define(ni, nj, grtyp, ig)
@@ -67,7 +67,7 @@ CASES = ec.scalar_cases()
 def test_ezsint(name, degree, polar):
     L = ref(); O = ol.oracle()
     case = CASES[name]
-    gdin = ref_define(L, case["src"]); gdout = ref_define(L, {"dst": None} and (case["dst"] + (" ", None)))
+    gdin = ref_define(L, case["src"]); gdout = ref_define(L, ec.dst_spec(case))
     ref_setopts(L, degree, polar)
     assert L.c_ezdefset(gdout, gdin) == 1
     ni, nj = case["src"][0], case["src"][1]
@@ -78,7 +78,7 @@ def test_ezsint(name, degree, polar):
     zr = np.full(no * mo, -999.0, np.float32)
     rc_r = L.c_ezsint(fptr(zr), fptr(zin))
 
-    gi = orc_define(case["src"]); go = orc_define(case["dst"] + (" ", None))
+    gi = orc_define(case["src"]); go = orc_define(ec.dst_spec(case))
     gs = O.orc_defset(go, gi)
     zo = np.full(no * mo, -999.0, np.float32)
     opts = ol.default_opts(degre_interp=degree, polar_correction=polar)
@@ -97,14 +97,14 @@ def test_ezsint(name, degree, polar):
 def test_ezsint_extrapolation(extrap):
     L = ref(); O = ol.oracle()
     case = CASES["Lregional_to_L"]
-    gdin = ref_define(L, case["src"]); gdout = ref_define(L, case["dst"] + (" ", None))
+    gdin = ref_define(L, case["src"]); gdout = ref_define(L, ec.dst_spec(case))
     ref_setopts(L, 3, 1, extrap, 123.5)
     L.c_ezdefset(gdout, gdin)
     ni, nj = case["src"][:2]; no, mo = case["dst"][:2]
     zin = ec.synth_field(ni, nj, seed=5)
     zr = np.zeros(no * mo, np.float32)
     rc_r = L.c_ezsint(fptr(zr), fptr(zin))
-    gi = orc_define(case["src"]); go = orc_define(case["dst"] + (" ", None))
+    gi = orc_define(case["src"]); go = orc_define(ec.dst_spec(case))
     gs = O.orc_defset(go, gi)
     zo = np.zeros(no * mo, np.float32)
     opts = ol.default_opts(degre_extrap=extrap, valeur_extrap=123.5)
@@ -195,7 +195,7 @@ def test_leaf_kernels_irregular(wrap):
 def test_ezuvint(name, degree, polar):
     L = ref(); O = ol.oracle()
     case = CASES[name]
-    gdin = ref_define(L, case["src"]); gdout = ref_define(L, case["dst"] + (" ", None))
+    gdin = ref_define(L, case["src"]); gdout = ref_define(L, ec.dst_spec(case))
     ref_setopts(L, degree, polar)
     L.c_ezdefset(gdout, gdin)
     ni, nj = case["src"][:2]; no, mo = case["dst"][:2]
@@ -205,7 +205,7 @@ def test_ezuvint(name, degree, polar):
             a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
     ur = np.zeros(no * mo, np.float32); vr = np.zeros(no * mo, np.float32)
     rc_r = L.c_ezuvint(fptr(ur), fptr(vr), fptr(uu), fptr(vv))
-    gi = orc_define(case["src"]); go = orc_define(case["dst"] + (" ", None))
+    gi = orc_define(case["src"]); go = orc_define(ec.dst_spec(case))
     gs = O.orc_defset(go, gi)
     uo = np.zeros(no * mo, np.float32); vo = np.zeros(no * mo, np.float32)
     opts = ol.default_opts(degre_interp=degree, polar_correction=polar)
@@ -223,7 +223,7 @@ def test_ezwdint(name, degree, polar):
     """c_ezwdint (ezwdint.c:62-113): interpolated winds as speed / direction on the target grid"""
     L = ref(); O = ol.oracle()
     case = CASES[name]
-    gdin = ref_define(L, case["src"]); gdout = ref_define(L, case["dst"] + (" ", None))
+    gdin = ref_define(L, case["src"]); gdout = ref_define(L, ec.dst_spec(case))
     ref_setopts(L, degree, polar)
     L.c_ezdefset(gdout, gdin)
     ni, nj = case["src"][:2]; no, mo = case["dst"][:2]
@@ -233,7 +233,7 @@ def test_ezwdint(name, degree, polar):
             a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
     ur = np.zeros(no * mo, np.float32); vr = np.zeros(no * mo, np.float32)
     rc_r = L.c_ezwdint(fptr(ur), fptr(vr), fptr(uu), fptr(vv))
-    gi = orc_define(case["src"]); go = orc_define(case["dst"] + (" ", None))
+    gi = orc_define(case["src"]); go = orc_define(ec.dst_spec(case))
     gs = O.orc_defset(go, gi)
     uo = np.zeros(no * mo, np.float32); vo = np.zeros(no * mo, np.float32)
     opts = ol.default_opts(degre_interp=degree, polar_correction=polar)
