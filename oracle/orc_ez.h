@@ -104,6 +104,21 @@ int orc_gdwdfuv(orc_grid *g, float *spd, float *dir, const float *uu, const floa
 int orc_gduvfwd(orc_grid *g, float *uu, float *vv, const float *spd, const float *dir,
                 const float *lat, const float *lon, int npts);
 
+/* Yin-Yang 'U' source grids (oracle/orc_yy.c): c_ezgdef_supergrid + c_ezgdef_yymask, c_ezyysint / c_ezyyuvint towards one
+ * ordinary target grid */
+typedef struct {
+    orc_grid *sub[2], *mask[2];
+    int ni, nj;
+    orc_grid *planned_for;            /* target grid of the cached plan (the reference caches it in the grid set) */
+    float *mask_out;                  /* 1.0: the point is served by Yang */
+    int count[2];
+    float *x[2], *y[2], *lat[2], *lon[2];
+    float *full_lat, *full_lon;
+} orc_supergrid;
+orc_supergrid *orc_supergrid_define(orc_grid *yin, orc_grid *yan);
+int orc_ezyysint(orc_supergrid *sg, orc_grid *gdout, const orc_opts *o, float *zout, const float *zin);
+int orc_ezyyuvint(orc_supergrid *sg, orc_grid *gdout, const orc_opts *o, float *uuout, float *vvout, const float *uuin, const float *vvin);
+
 #ifdef __cplusplus
 }
 #endif

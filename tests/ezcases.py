@@ -94,3 +94,30 @@ def scalar_cases():
 def dst_spec(case):
     """target grid spec in the 6-tuple form of the source: (ni, nj, grtyp, ig, grref, axes_fn)"""
     return case["dst"] + (case.get("dst_ref", " "), case.get("dst_axes"))
+
+
+# Yin-Yang 'U' grid (SURVEY 8f row 3): two Z-on-E subgrids of the same shape.  Yin's frame is the geographic one
+# shifted (centre 0N 180E, equator on the equator); Yang's centre is 0N 0E and its equator runs through the poles.
+YIN_IG = (900, 0, 43200, 43200)     # cxgaig('E', 0, 180, 0, 270)
+YAN_IG = (900, 900, 14400, 0)       # cxgaig('E', 0, 0, 90, 0)
+
+
+def yy_axes(ni, nj):
+    """3-degree Yin-Yang subgrid axes: longitudes 36..324, latitudes -54..54 (overlap of 3 points beyond 45..315 / -45..45)"""
+    ax = (36.0 + 3.0 * np.arange(ni, dtype=np.float64)).astype(np.float32)
+    ay = (-54.0 + 3.0 * np.arange(nj, dtype=np.float64)).astype(np.float32)
+    return ax, ay
+
+
+YY_NI, YY_NJ = 97, 37
+
+
+def yy_targets():
+    return {"L": (72, 37, "L", (500, 500, 0, 0)), "G": (48, 24, "G", (0, 0, 0, 0)), "N": (41, 35, "N", (205, 175, 4000, 1000))}
+
+
+def yy_fields():
+    """scalar field and wind pair on the U grid: [Yin; Yang] concatenated, as the reference expects them"""
+    z = np.concatenate([synth_field(YY_NI, YY_NJ, seed=3), synth_field(YY_NI, YY_NJ, seed=4)])
+    (u0, v0), (u1, v1) = synth_wind(YY_NI, YY_NJ, seed=5), synth_wind(YY_NI, YY_NJ, seed=6)
+    return z, np.concatenate([u0, u1]), np.concatenate([v0, v1])

@@ -266,3 +266,36 @@ def test_gdllsval_is_locate_plus_gdinterp(name, degree):
     O.orc_gdinterp(gi, degree, fptr(zo), fptr(zin), fptr(x), fptr(y), n)
     assert np.array_equal(zo.view(np.uint32), zr.view(np.uint32)), int(np.count_nonzero(zo != zr))
     ref_setopts(L, 3, 1)
+
+
+@pytest.mark.parametrize("tname", sorted(ec.yy_targets()))
+def test_yinyang_source(tname):
+    """Yin-Yang 'U' source (c_ezgdef_supergrid of two Z-on-E subgrids) -> L / G / N target: c_ezsint and c_ezuvint of the
+    reference (c_ezyysint / c_ezyyuvint) == the oracle's restatement, bit for bit, every degree"""
+    L = ref()
+    ni, nj = ec.YY_NI, ec.YY_NJ
+    ax, ay = ec.yy_axes(ni, nj)
+    gy = L.c_ezgdef_fmem(ni, nj, b"Z", b"E", *ec.YIN_IG, fptr(ax), fptr(ay))
+    ga = L.c_ezgdef_fmem(ni, nj, b"Z", b"E", *ec.YAN_IG, fptr(ax), fptr(ay))
+    ids = np.array([gy, ga], np.int32)
+    gu = L.c_ezgdef_supergrid(ni, 2 * nj, b"U", b"F", 1, 2, iptr(ids))
+    no, mo, gt, ig = ec.yy_targets()[tname]
+    go = L.c_ezqkdef(no, mo, gt.encode(), *ig, 0)
+    assert gu >= 0 and go >= 0 and L.c_ezdefset(go, gu) == 1
+    O = ol.oracle()
+    sg = O.orc_supergrid_define(ol.grid_define(ni, nj, "Z", ec.YIN_IG, "E", ax, ay), ol.grid_define(ni, nj, "Z", ec.YAN_IG, "E", ax, ay))
+    ogo = ol.grid_define(no, mo, gt, ig)
+    z, uu, vv = ec.yy_fields()
+    for degree in (3, 1, 0):
+        ref_setopts(L, degree, 1)
+        want = np.zeros(no * mo, np.float32); got = np.zeros(no * mo, np.float32)
+        assert L.c_ezsint(fptr(want), fptr(z)) == 0
+        opts = ol.default_opts(degre_interp=degree)
+        assert O.orc_ezyysint(sg, ogo, ctypes.byref(opts), fptr(got), fptr(z)) == 0
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (tname, degree)
+        wu = np.zeros(no * mo, np.float32); wv = np.zeros(no * mo, np.float32); gu_ = np.zeros(no * mo, np.float32); gv = np.zeros(no * mo, np.float32)
+        assert L.c_ezuvint(fptr(wu), fptr(wv), fptr(uu), fptr(vv)) == 0
+        assert O.orc_ezyyuvint(sg, ogo, ctypes.byref(opts), fptr(gu_), fptr(gv), fptr(uu), fptr(vv)) == 0
+        assert np.array_equal(gu_.view(np.uint32), wu.view(np.uint32)), (tname, degree)
+        assert np.array_equal(gv.view(np.uint32), wv.view(np.uint32)), (tname, degree)
+    ref_setopts(L, 3, 1)
