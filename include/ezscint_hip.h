@@ -22,6 +22,9 @@ extern "C" {
 int32_t c_ezqkdef(int32_t ni, int32_t nj, char *grtyp, int32_t ig1, int32_t ig2, int32_t ig3, int32_t ig4, int32_t iunit);          /* ezscint.h:66 ; src/interp/ezqkdef.c:25 */
 int32_t c_ezgdef_fmem(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t ig1, int32_t ig2, int32_t ig3, int32_t ig4,
                       float *ax, float *ay);                                                                                         /* ezscint.h:28 ; ezgdef_fmem.c:37 (ax/ay are copied) */
+/* Yin-Yang 'U' grid made of two Z-on-E subgrids (ni x nj/2 each), as a SOURCE grid of c_ezsint / c_ezuvint towards one ordinary
+ * target (c_ezyysint / c_ezyyuvint); fields are [Yin; Yang] concatenated.  ezscint.h:32 ; ezgdef_supergrid.c:40 */
+int32_t c_ezgdef_supergrid(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t vercode, int32_t nsubgrids, int32_t *subgrid);
 int32_t c_ezdefset(int32_t gdout, int32_t gdin);                                                                                     /* ezscint.h:11 ; ezdefset.c:38 ; returns 1 */
 int32_t c_gdrls(int32_t gdin);                                                                                                       /* ezscint.h:75 ; gdrls.c:34 */
 int32_t c_ezgetgdin(void);                                                                                                           /* ezscint.h:186 */
@@ -56,6 +59,7 @@ int32_t ezqkdef_(int32_t *ni, int32_t *nj, char *grtyp, int32_t *ig1, int32_t *i
 int32_t ezgdef_fmem_(int32_t *ni, int32_t *nj, char *grtyp, char *grref, int32_t *ig1, int32_t *ig2, int32_t *ig3, int32_t *ig4,
                      float *ax, float *ay, int32_t lengrtyp, int32_t lengrref);
 int32_t ezdefset_(int32_t *gdout, int32_t *gdin);
+int32_t ezgdef_supergrid_(int32_t *ni, int32_t *nj, char *grtyp, char *grref, int32_t *vercode, int32_t *nsubgrids, int32_t *subgrid, int32_t lengrtyp, int32_t lengrref);   /* ezscint.h:31 */
 int32_t ezsetopt_(char *option, char *value, int32_t lenoption, int32_t lenvalue);
 int32_t ezsint_(float *zout, float *zin);
 int32_t ezuvint_(float *uuout, float *vvout, float *uuin, float *vvin);

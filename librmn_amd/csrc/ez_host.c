@@ -56,6 +56,10 @@ typedef struct ezh_set {
     float *d_poles_batch; int poles_cap;   /* pole values of a c_ezsint_batch_dev batch (2 per field) */
     float *d_prow;          /* 2 * ni_src synthetic polar wind rows (vector mode), u then v: [u_n, u_s, v_n, v_s] */
     float *d_stage_in, *d_stage_out, *d_stage_in2, *d_stage_out2;   /* host-pointer ABI staging */
+    /* Yin-Yang 'U' source (c_ezyy_calcxy, ezyy_calcxy.c): per subgrid the list of target points it serves */
+    int yy_ready, yy_count[2];
+    float *d_yy_x[2], *d_yy_y[2], *d_yy_lat[2], *d_yy_lon[2], *d_yy_tmp[4];
+    int *d_yy_idx[2];
 } ezh_set;
 
 typedef struct {
@@ -74,6 +78,7 @@ typedef struct {
     double *d_windtrig;                    /* this grid as a separable wind TARGET: {cos,sin}(lon) per column, then {cos,sin}(lat) per row */
     float *d_plon2; float xg4_pole[2];     /* this grid as a wind SOURCE: longitudes of its last / first row, PS-frame xg4 (N, S) */
     ezh_set *sets;                          /* sets having this grid as gdout */
+    int nsub, sub[2], maskgrid[2];          /* 'U' (Yin-Yang): the two Z-on-E subgrids and their core ("mask") grids */
 } ezh_grid;
 
 static ezh_grid *G = NULL;
@@ -544,6 +549,8 @@ static void free_set(ezh_set *s)
     free(s->x1d); free(s->y1d);
     ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch);
     ezhip_free(s->d_stage_in); ezhip_free(s->d_stage_out); ezhip_free(s->d_stage_in2); ezhip_free(s->d_stage_out2);
+    for (int k = 0; k < 2; k++) { ezhip_free(s->d_yy_x[k]); ezhip_free(s->d_yy_y[k]); ezhip_free(s->d_yy_lat[k]); ezhip_free(s->d_yy_lon[k]); ezhip_free(s->d_yy_idx[k]); }
+    for (int k = 0; k < 4; k++) ezhip_free(s->d_yy_tmp[k]);
     free(s);
 }
 
@@ -586,6 +593,10 @@ static ezh_set *find_set(int gdout, int gdin, int create)
 int32_t c_ezdefset(int32_t gdout, int32_t gdin)     /* ezdefset.c:38-171 */
 {
     if (!grid_ok(gdout) || !grid_ok(gdin)) { fprintf(stderr, "<c_ezdefset> invalid grid id\n"); return -1; }
+    if (G[gdout].grtyp == 'U') {
+        fprintf(stderr, "<c_ezdefset> a Yin-Yang 'U' grid as TARGET is outside the MI355X hot-path scope (interpolate to its two subgrids)\n");
+        return -1;
+    }
     if (G[gdin].grtyp == 'Y') {       /* the reference interpolates FROM a cloud with its cloud_interp_alg (gdinterp.c:207-230): not on this path */
         fprintf(stderr, "<c_ezdefset> a 'Y' cloud as SOURCE grid is outside the MI355X hot-path scope\n");
         return -1;
@@ -1461,7 +1472,7 @@ static ezh_set *current_set(const char *who)
     }
     pthread_mutex_lock(&g_mtx);
     ezh_set *s = find_set(cur_gdout, cur_gdin, 1);
-    if (!s->x1d && !s->d_x) analyse_set(s);
+    if (!s->x1d && !s->d_x && G[cur_gdin].grtyp != 'U') analyse_set(s);
     pthread_mutex_unlock(&g_mtx);
     return s;
 }
@@ -1595,11 +1606,16 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
 void ezhip_use_stream(void *hip_stream) { ezhip_set_stream(hip_stream); }
 int32_t ezhip_available(void) { return ezhip_runtime_ok(); }
 
+static int yy_plan(ezh_set *s);
+static int32_t yy_sint(ezh_set *s, float *d_zout, const float *d_zin);
+static int32_t yy_uvint(ezh_set *s, float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin, int wd_only);
+
 int32_t c_ezsint_dev(float *d_zout, const float *d_zin)
 {
     ezh_set *s = current_set("c_ezsint");
     if (!s) return -1;
     if (need_device("c_ezsint")) return -1;
+    if (G[s->gdin].grtyp == 'U') return yy_sint(s, d_zout, d_zin);
     if (s->gdin == s->gdout) { ezhip_d2d(d_zout, d_zin, sizeof(float) * (size_t)G[s->gdin].ni * G[s->gdin].nj); return 1; }
     return run_field(s, d_zout, d_zin, 0, NULL, NULL);
 }
@@ -1624,6 +1640,11 @@ static int32_t batch_impl(float *d_zout, const float *d_zin, int32_t nfields, un
     if (need_device("c_ezsint_batch")) return -1;
     size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
     int rc = 0;
+    if (G[s->gdin].grtyp == 'U') {                              /* Yin-Yang source: field by field */
+        if (stat_partials) return -1;
+        for (int f = 0; f < nfields; f++) { int r = yy_sint(s, d_zout + f * nout, d_zin + f * nin); if (r < 0) return r; if (r > rc) rc = r; }
+        return rc;
+    }
     /* separable plan without extrapolation fill: ALL fields in one k_sepx launch (no ramp-up / drain gap between
      * fields; the pole rows are summed by producer blocks of the same launch) */
     if (s->gdin != s->gdout && (nfields > 1 || stat_partials) && !(O.polar_correction == 1 && s->extrap) &&
@@ -1694,6 +1715,7 @@ int32_t ezhip_prepare_set(void)
     ezh_set *s = current_set("ezhip_prepare_set");
     if (!s) return -1;
     if (need_device("ezhip_prepare_set")) return -1;
+    if (G[s->gdin].grtyp == 'U') return yy_plan(s);
     int degree = O.degre_interp, polar = O.polar_correction == 1;
     if (choose_mode(s, degree, polar) == 1) return build_sep_plan(s, degree, 0, polar);
     if (ensure_points(s)) return -1;
@@ -1716,6 +1738,7 @@ int32_t ezhip_set_mode(void)
 {
     ezh_set *s = current_set("ezhip_set_mode");
     if (!s) return -1;
+    if (G[s->gdin].grtyp == 'U') return 2;
     return choose_mode(s, O.degre_interp, O.polar_correction == 1);
 }
 
@@ -1730,9 +1753,9 @@ int32_t c_ezsint(float *zout, float *zin)               /* ezsint.c:38-135 */
     if (s->gdin == s->gdout) { memcpy(zout, zin, sizeof(float) * nin); return 1; }
     if (need_device("c_ezsint")) return -1;
     if (stage(&s->d_stage_in, nin) || stage(&s->d_stage_out, nout)) return -1;
-    if (ezhip_prepare_set()) return -1;
+    if (G[s->gdin].grtyp != 'U' && ezhip_prepare_set()) return -1;
     if (ezhip_h2d(s->d_stage_in, zin, sizeof(float) * nin)) return -1;
-    int rc = run_field(s, s->d_stage_out, s->d_stage_in, 0, NULL, NULL);
+    int rc = G[s->gdin].grtyp == 'U' ? yy_sint(s, s->d_stage_out, s->d_stage_in) : run_field(s, s->d_stage_out, s->d_stage_in, 0, NULL, NULL);
     if (rc < 0) return rc;
     if (ezhip_d2h(zout, s->d_stage_out, sizeof(float) * nout) || ezhip_sync()) return -1;
     return rc;
@@ -1924,6 +1947,7 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
     ezh_set *s = current_set(wd_only ? "c_ezwdint" : "c_ezuvint");
     if (!s) return -1;
     if (need_device("c_ezuvint")) return -1;
+    if (G[s->gdin].grtyp == 'U') return yy_uvint(s, d_uuout, d_vvout, d_uuin, d_vvin, wd_only);
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     if (go->grtyp == 'E' || (go->grtyp == 'Z' && go->grref == 'E') || go->grtyp == 'Z') {
         fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp);
@@ -2027,11 +2051,175 @@ int32_t c_ezwdint(float *spdout, float *dirout, float *uuin, float *vvin) { retu
 /* ------------------------------------------------------------------------------------------ */
 /* Fortran twins (rpnmacros.h:21 f77name; scalars by reference; hidden string lengths last)       */
 /* ------------------------------------------------------------------------------------------ */
+/* Yin-Yang 'U' source grids: c_ezgdef_supergrid (ezgdef_supergrid.c:40-150), c_ezgdef_yymask       */
+/* (ezgdef_yymask.c:25-52), c_ezyymint (ezyymint.c:27-95), c_ezyy_calcxy (ezyy_calcxy.c:25-179),     */
+/* c_ezyysint (ezyysint.c:27-170), c_ezyyuvint (ezyyuvint.c:29-215) -- towards ONE ordinary target   */
+/* ------------------------------------------------------------------------------------------ */
+static int yy_maskgrid(const ezh_grid *sub)
+{   /* the part of a subgrid with 45 <= ax <= 315 and -45 <= ay <= 45, as a grid of its own */
+    int k = 0, i0 = 0, j0 = 0;
+    for (int i = 0; i < sub->ni; i++) if (sub->ax[i] >= 45.0 && sub->ax[i] <= 315.0) { k++; if (k == 1) i0 = i; }
+    int yni = k;
+    k = 0;
+    for (int j = 0; j < sub->nj; j++) if (sub->ay[j] >= -45.0 && sub->ay[j] <= 45.0) { k++; if (k == 1) j0 = j; }
+    int ynj = k;
+    char t[2] = {sub->grtyp, 0}, r[2] = {sub->grref, 0};
+    float *ax = (float *)malloc(sizeof(float) * (size_t)(yni > 0 ? yni : 1)), *ay = (float *)malloc(sizeof(float) * (size_t)(ynj > 0 ? ynj : 1));
+    memcpy(ax, &sub->ax[i0], sizeof(float) * (size_t)yni); memcpy(ay, &sub->ay[j0], sizeof(float) * (size_t)ynj);
+    int gd = c_ezgdef_fmem(yni, ynj, t, r, sub->igref[0], sub->igref[1], sub->igref[2], sub->igref[3], ax, ay);
+    free(ax); free(ay);
+    return gd;
+}
+
+int32_t c_ezgdef_supergrid(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t vercode, int32_t nsubgrids, int32_t *subgrid)
+{
+    (void)grref;
+    if (nsubgrids <= 1) { fprintf(stderr, "<c_ezgdef_supergrid> nsubgrids given is less than 2! Aborting...\n"); return -1; }
+    if (vercode != 1) { fprintf(stderr, "<c_ezgdef_supergrid> invalid vercode! Aborting...\n"); return -1; }
+    if (nsubgrids != 2 || grtyp[0] != 'U' || !grid_ok(subgrid[0]) || !grid_ok(subgrid[1])) {
+        fprintf(stderr, "<c_ezgdef_supergrid> only 'U' grids made of two defined subgrids are in the MI355X hot-path scope\n"); return -1;
+    }
+    for (int k = 0; k < 2; k++) {
+        const ezh_grid *sg = &G[subgrid[k]];
+        if (sg->grtyp != 'Z' || sg->grref != 'E' || sg->ni != ni || 2 * sg->nj != nj) {
+            fprintf(stderr, "<c_ezgdef_supergrid> the subgrids of a 'U' grid must be Z-on-E grids of ni x nj/2 points\n"); return -1;
+        }
+    }
+    int m0 = yy_maskgrid(&G[subgrid[0]]), m1 = yy_maskgrid(&G[subgrid[1]]);
+    if (m0 < 0 || m1 < 0) return -1;
+    pthread_mutex_lock(&g_mtx);
+    int gd;
+    for (gd = 0; gd < nG; gd++) if (G[gd].used && G[gd].grtyp == 'U' && G[gd].sub[0] == subgrid[0] && G[gd].sub[1] == subgrid[1]) { G[gd].refcount++; pthread_mutex_unlock(&g_mtx); return gd; }
+    for (gd = 0; gd < nG; gd++) if (!G[gd].used) break;
+    if (gd == nG) {
+        if (nG == capG) { capG = capG ? 2 * capG : 64; G = (ezh_grid *)realloc(G, sizeof(ezh_grid) * capG); }
+        nG++;
+    }
+    ezh_grid *g = &G[gd];
+    memset(g, 0, sizeof(*g));
+    g->used = 1; g->refcount = 1; g->grtyp = 'U'; g->grref = 'F';
+    g->ni = ni; g->nj = nj; memcpy(g->ig, G[subgrid[0]].ig, sizeof(g->ig));
+    g->igref[0] = vercode;
+    g->nsub = 2; g->sub[0] = subgrid[0]; g->sub[1] = subgrid[1]; g->maskgrid[0] = m0; g->maskgrid[1] = m1;
+    pthread_mutex_unlock(&g_mtx);
+    return gd;
+}
+
+/* c_ezyymint + c_ezyy_calcxy for a single target grid: host, once per set (first-call work like ez_calcxy) */
+static int yy_plan(ezh_set *s)
+{
+    if (s->yy_ready) return 0;
+    ezh_grid *gu = &G[s->gdin], *go = &G[s->gdout];
+    const int n = go->ni * go->nj;
+    float *lat = (float *)malloc(sizeof(float) * (size_t)n), *lon = (float *)malloc(sizeof(float) * (size_t)n);
+    float *x = (float *)malloc(sizeof(float) * (size_t)n), *y = (float *)malloc(sizeof(float) * (size_t)n);
+    float *tl = (float *)malloc(sizeof(float) * (size_t)n);
+    int *idx = (int *)malloc(sizeof(int) * (size_t)n);
+    unsigned char *yang = (unsigned char *)malloc((size_t)n);
+    int rc = -1;
+    if (c_gdll(s->gdout, lat, lon)) goto done;
+    {   /* the mask: a point outside the Yin core grid (zone DEHORS of the nearest-neighbour interpolation with extrapolation
+         * value 1 that ezyymint.c:44-66 runs) is served by Yang */
+        const ezh_grid *mg = &G[gu->maskgrid[0]];
+        memcpy(tl, lon, sizeof(float) * (size_t)n);
+        if (h_locate(mg, x, y, lat, tl, n)) goto done;
+        for (int k = 0; k < n; k++) {
+            int ix = (int)((double)x[k] + 0.5), iy = (int)((double)y[k] + 0.5);
+            yang[k] = (ix < 1 || iy < 1 || ix > mg->ni || iy > mg->nj);
+        }
+    }
+    for (int sub = 0; sub < 2; sub++) {
+        int c = 0;
+        for (int k = 0; k < n; k++) if (yang[k] == sub) { idx[c] = k; x[c] = lat[k]; y[c] = lon[k]; c++; }      /* x, y: the list's lat, lon */
+        s->yy_count[sub] = c;
+        float *lx = (float *)malloc(sizeof(float) * (size_t)(c + 1)), *ly = (float *)malloc(sizeof(float) * (size_t)(c + 1));
+        h_locate(&G[gu->sub[sub]], lx, ly, x, y, c);                     /* c_gdxyfll_orig on the list */
+        s->d_yy_idx[sub] = (int *)upload(idx, sizeof(int) * (size_t)(c + 1));
+        s->d_yy_lat[sub] = (float *)upload(x, sizeof(float) * (size_t)(c + 1));
+        s->d_yy_lon[sub] = (float *)upload(y, sizeof(float) * (size_t)(c + 1));
+        s->d_yy_x[sub] = (float *)upload(lx, sizeof(float) * (size_t)(c + 1));
+        s->d_yy_y[sub] = (float *)upload(ly, sizeof(float) * (size_t)(c + 1));
+        ezhip_sync();
+        free(lx); free(ly);
+        if (!s->d_yy_idx[sub] || !s->d_yy_lat[sub] || !s->d_yy_lon[sub] || !s->d_yy_x[sub] || !s->d_yy_y[sub]) goto done;
+    }
+    for (int k = 0; k < 4; k++) { s->d_yy_tmp[k] = (float *)ezhip_malloc(sizeof(float) * (size_t)(n + 1)); if (!s->d_yy_tmp[k]) goto done; }
+    s->yy_ready = 1;
+    rc = 0;
+done:
+    free(lat); free(lon); free(x); free(y); free(tl); free(idx); free(yang);
+    return rc;
+}
+
+/* the degenerate cases of ezyysint.c:88-97: the target IS one of the subgrids */
+static int yy_same_subgrid(const ezh_set *s) { const ezh_grid *gu = &G[s->gdin]; return s->gdout == gu->sub[0] ? 0 : s->gdout == gu->sub[1] ? 1 : -1; }
+
+static int32_t yy_sint(ezh_set *s, float *d_zout, const float *d_zin)
+{
+    ezh_grid *gu = &G[s->gdin], *go = &G[s->gdout];
+    const size_t nsub = (size_t)G[gu->sub[0]].ni * G[gu->sub[0]].nj;
+    int same = yy_same_subgrid(s);
+    if (same >= 0) { ezhip_d2d(d_zout, d_zin + same * nsub, sizeof(float) * nsub); return 1; }
+    int degree = O.degre_interp;
+    if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return -1;
+    if (yy_plan(s)) return -1;
+    (void)go;
+    for (int sub = 0; sub < 2; sub++) {                      /* c_gdxysval on each subgrid (no polar correction), then the merge */
+        ezh_grid *gs = &G[gu->sub[sub]];
+        if (ensure_grid_dev(gs)) return -1;
+        ezhip_pts_plan pp;
+        fill_pts_plan(NULL, gs, &pp, degree, 0, 0);
+        if (ezhip_interp_pts(&pp, s->d_yy_tmp[0], d_zin + sub * nsub, s->d_yy_x[sub], s->d_yy_y[sub], s->yy_count[sub])) return -1;
+        if (ezhip_scatter(d_zout, s->d_yy_tmp[0], s->d_yy_idx[sub], s->yy_count[sub])) return -1;
+    }
+    return 0;
+}
+
+static int32_t yy_uvint(ezh_set *s, float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin, int wd_only)
+{
+    ezh_grid *gu = &G[s->gdin], *go = &G[s->gdout];
+    const size_t nsub = (size_t)G[gu->sub[0]].ni * G[gu->sub[0]].nj;
+    if (yy_same_subgrid(s) >= 0 || wd_only) {
+        fprintf(stderr, "<c_ezuvint> this Yin-Yang case (target = a subgrid, or c_ezwdint) is outside the MI355X hot-path scope\n");
+        return -1;
+    }
+    if (go->grtyp == 'E' || go->grtyp == 'Z') { fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp); return -1; }
+    int degree = O.degre_interp;
+    if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return -1;
+    if (yy_plan(s) || ensure_coords_dev(go)) return -1;
+    for (int sub = 0; sub < 2; sub++) {
+        /* c_gdxyvval + c_gdwdfuv of the subgrid on its list (ezyyuvint.c:177-180), speed / direction merged into the outputs */
+        ezh_grid *gs = &G[gu->sub[sub]];
+        if (ensure_grid_dev(gs)) return -1;
+        ezhip_pts_plan pp;
+        fill_pts_plan(NULL, gs, &pp, degree, 0, 0);
+        const int c = s->yy_count[sub];
+        if (ezhip_interp_pts(&pp, s->d_yy_tmp[0], d_uuin + sub * nsub, s->d_yy_x[sub], s->d_yy_y[sub], c)) return -1;
+        if (ezhip_interp_pts(&pp, s->d_yy_tmp[1], d_vvin + sub * nsub, s->d_yy_x[sub], s->d_yy_y[sub], c)) return -1;
+        ezhip_wind_plan wp;
+        memset(&wp, 0, sizeof(wp));
+        wp.wd_only = 1; wp.src_rotated = 1;
+        h_crot(wp.r, wp.ri, gs->xgref[1], gs->xgref[0], gs->xgref[3], gs->xgref[2]);
+        if (c && ezhip_wind_rotate(&wp, s->d_yy_tmp[0], s->d_yy_tmp[1], s->d_yy_lat[sub], s->d_yy_lon[sub], c, 1)) return -1;
+        if (ezhip_scatter(d_uuout, s->d_yy_tmp[0], s->d_yy_idx[sub], c) || ezhip_scatter(d_vvout, s->d_yy_tmp[1], s->d_yy_idx[sub], c)) return -1;
+    }
+    /* ONE c_gduvfwd on the target with its own lat/lon (ezyyuvint.c:201) */
+    ezhip_wind_plan wp;
+    memset(&wp, 0, sizeof(wp));
+    wp.separable = go->separable; wp.wd_in = 1;
+    if (go->grtyp == 'N' || go->grtyp == 'S') { wp.dst_ps = go->grtyp == 'N' ? 1 : 2; wp.dst_xg4 = go->xg[3]; }
+    if (ezhip_wind_rotate(&wp, d_uuout, d_vvout, go->d_lat, go->d_lon, go->ni, go->nj)) return -1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 int32_t ezqkdef_(int32_t *ni, int32_t *nj, char *grtyp, int32_t *ig1, int32_t *ig2, int32_t *ig3, int32_t *ig4, int32_t *iunit, int32_t l)
 { (void)l; char t[2] = {grtyp[0], 0}; return c_ezqkdef(*ni, *nj, t, *ig1, *ig2, *ig3, *ig4, *iunit); }
 int32_t ezgdef_fmem_(int32_t *ni, int32_t *nj, char *grtyp, char *grref, int32_t *ig1, int32_t *ig2, int32_t *ig3, int32_t *ig4, float *ax, float *ay, int32_t l1, int32_t l2)
 { (void)l1; (void)l2; char t[2] = {grtyp[0], 0}, r[2] = {grref[0], 0}; return c_ezgdef_fmem(*ni, *nj, t, r, *ig1, *ig2, *ig3, *ig4, ax, ay); }
 int32_t ezdefset_(int32_t *gdout, int32_t *gdin) { return c_ezdefset(*gdout, *gdin); }
+int32_t ezgdef_supergrid_(int32_t *ni, int32_t *nj, char *grtyp, char *grref, int32_t *vercode, int32_t *nsubgrids, int32_t *subgrid, int32_t l1, int32_t l2)
+{ (void)l1; (void)l2; char t[2] = {grtyp[0], 0}, r[2] = {grref[0], 0}; return c_ezgdef_supergrid(*ni, *nj, t, r, *vercode, *nsubgrids, subgrid); }
 static void ftn2c(char *dst, const char *src, int len)
 {
     int n = len < 31 ? len : 31;

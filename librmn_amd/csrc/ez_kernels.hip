@@ -1570,6 +1570,13 @@ __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *_
     if (p.separable) { lat = lats[n / ni_dst]; lon = lons[n % ni_dst]; }
     else { lat = lats[n]; lon = lons[n]; }
     float u = uu[n], v = vv[n];
+    if (p.wd_in) {                                          /* speed / direction given: c_gduvfwd only */
+        const float spd_ = u, dir_ = v;
+        float psi_ = p.dst_ps == 1 ? lon + p.dst_xg4 - dir_ : p.dst_ps == 2 ? 180.0f - lon + p.dst_xg4 - dir_ : 270.0f - dir_;
+        uu[n] = cosf(psi_ * DGTORD) * spd_;
+        vv[n] = sinf(psi_ * DGTORD) * spd_;
+        return;
+    }
     if (p.src_rotated) {                                    /* c_ezllwfgfw, ez_llwfgfw.c:38-73 */
         float lon_r, lat_r;
         if (p.separable && p.lon_trigf) {       /* REAL cos / sin of the column's longitude and the row's latitude from tables */
@@ -1612,6 +1619,18 @@ __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *_
     float psi = p.dst_ps == 1 ? lon + p.dst_xg4 - dir : p.dst_ps == 2 ? 180.0f - lon + p.dst_xg4 - dir : 270.0f - dir;
     uu[n] = cosf(psi * DGTORD) * spd;
     vv[n] = sinf(psi * DGTORD) * spd;
+}
+
+__global__ __launch_bounds__(256) void k_scatter(float *__restrict__ dst, const float *__restrict__ src, const int *__restrict__ idx, int n)
+{
+    int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) dst[idx[k]] = src[k];
+}
+extern "C" int ezhip_scatter(float *d_dst, const float *d_src, const int *d_idx, int n)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, d_dst, d_src, d_idx, n);
+    return LAUNCH_CHECK("k_scatter");
 }
 
 extern "C" int ezhip_wind_rotate(const ezhip_wind_plan *plan, float *d_uu, float *d_vv,

@@ -154,6 +154,8 @@ typedef struct {
 int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin,
                      const float *d_x, const float *d_y, int npts);
 
+/* d_dst[d_idx[k]] = d_src[k] (the merge of the Yin and Yang point lists) */
+int ezhip_scatter(float *d_dst, const float *d_src, const int *d_idx, int n);
 /* pole values {north, south} of a source field -> device float[2] */
 int ezhip_polevals(float *d_out2, const float *d_zin, int ni, int nj, int weighted, const float *d_ax);
 int ezhip_polevals_batch(float *d_out, const float *d_zin, size_t field_stride, int nfields, int ni, int nj, int weighted, const float *d_ax);
@@ -183,6 +185,7 @@ typedef struct {
     float r[9], ri[9];
     int separable;                    /* target lat/lon given as 1-D arrays */
     int wd_only;                      /* 1: stop after c_gdwdfuv (c_ezwdint): uu := speed, vv := direction */
+    int wd_in;                        /* 1: uu / vv already hold speed / direction: only c_gduvfwd on the target (Yin-Yang merge) */
     int src_ps, dst_ps;               /* 0, or 1 = 'N' / 2 = 'S': polar-stereographic source / target (ez_llwfgdw.inc:91-140, ez_gdwfllw.inc:93-121) */
     float src_xg4, dst_xg4;           /* their dgrw */
     const double *lon_trig, *lat_trig;   /* separable + rotated source: {cos, sin} per target column / row (ezhip_wind_trig_tables), or NULL */

@@ -18,6 +18,7 @@ def _lib():
         L.c_ezqkdef.argtypes = [i32, i32, cp, i32, i32, i32, i32, i32]
         L.c_ezgdef_fmem.argtypes = [i32, i32, cp, cp, i32, i32, i32, i32, vp, vp]
         L.c_ezdefset.argtypes = [i32, i32]
+        L.c_ezgdef_supergrid.argtypes = [i32, i32, cp, cp, i32, i32, vp]
         L.c_ezsetopt.argtypes = [cp, cp]
         L.c_ezgetopt.argtypes = [cp, cp]
         L.c_ezsetval.argtypes = [cp, ctypes.c_float]
@@ -67,6 +68,11 @@ def ezqkdef(ni, nj, grtyp, ig1, ig2, ig3, ig4, iunit=0):
 def ezgdef_fmem(ni, nj, grtyp, grref, ig1, ig2, ig3, ig4, ax, ay):
     ax, pax = _np(ax); ay, pay = _np(ay)
     return _lib().c_ezgdef_fmem(ni, nj, grtyp.encode(), grref.encode(), ig1, ig2, ig3, ig4, pax, pay)
+
+
+def ezgdef_supergrid(ni, nj, grtyp, grref, vercode, subgrids):
+    ids = np.asarray(subgrids, dtype=np.int32)
+    return _lib().c_ezgdef_supergrid(ni, nj, grtyp.encode(), grref.encode(), vercode, ids.size, ids.ctypes.data)
 
 
 def ezdefset(gdout, gdin):

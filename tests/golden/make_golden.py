@@ -72,6 +72,22 @@ def main():
         lon2 = lon.copy()
         L.c_gdxyfll(gdin, fptr(x), fptr(y), fptr(lat), fptr(lon2), no * mo)
         out[f"{name}/lat"] = lat; out[f"{name}/lon"] = lon; out[f"{name}/x"] = x; out[f"{name}/y"] = y
+    # Yin-Yang 'U' source -> L / G / N targets (c_ezyysint / c_ezyyuvint)
+    yni, ynj = ec.YY_NI, ec.YY_NJ
+    yax, yay = ec.yy_axes(yni, ynj)
+    gy = L.c_ezgdef_fmem(yni, ynj, b"Z", b"E", *ec.YIN_IG, fptr(yax), fptr(yay))
+    ga = L.c_ezgdef_fmem(yni, ynj, b"Z", b"E", *ec.YAN_IG, fptr(yax), fptr(yay))
+    ids = np.array([gy, ga], np.int32)
+    gu = L.c_ezgdef_supergrid(yni, 2 * ynj, b"U", b"F", 1, 2, ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    z, uu, vv = ec.yy_fields()
+    for tname, (no, mo, gt, ig) in ec.yy_targets().items():
+        go = L.c_ezqkdef(no, mo, gt.encode(), *ig, 0)
+        assert L.c_ezdefset(go, gu) == 1
+        for degree in (0, 1, 3):
+            L.c_ezsetopt(b"interp_degree", DEG[degree]); L.c_ezsetopt(b"polar_correction", b"yes")
+            zo = np.zeros(no * mo, np.float32); uo = np.zeros(no * mo, np.float32); vo = np.zeros(no * mo, np.float32)
+            assert L.c_ezsint(fptr(zo), fptr(z)) == 0 and L.c_ezuvint(fptr(uo), fptr(vo), fptr(uu), fptr(vv)) == 0
+            out[f"YY_to_{tname}/z_d{degree}"] = zo; out[f"YY_to_{tname}/u_d{degree}"] = uo; out[f"YY_to_{tname}/v_d{degree}"] = vo
     L.c_ezsetopt(b"interp_degree", b"cubic"); L.c_ezsetopt(b"polar_correction", b"yes")
     np.savez_compressed(os.path.join(HERE, "ez_golden.npz"), **out)
     print("wrote", len(out), "arrays")

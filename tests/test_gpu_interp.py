@@ -470,3 +470,40 @@ def test_polar_stereographic_coordinates_and_locate(name):
     torch.cuda.synchronize()
     for got, want in ((d_x.cpu().numpy(), GOLD[f"{name}/x"]), (d_y.cpu().numpy(), GOLD[f"{name}/y"])):
         assert np.abs(got.astype(np.float64) - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), name
+
+
+@pytest.mark.parametrize("tname", sorted(ec.yy_targets()))
+def test_yinyang_source_vs_golden(tname):
+    """Yin-Yang 'U' source (two Z-on-E subgrids, c_ezgdef_supergrid) -> L / G / N target through c_ezsint / c_ezuvint:
+    mask and point lists on the host (bit-exact locate), per-point kernel per subgrid, merge on the device.
+    Scalars are bit-exact (the per-point kernel restates the leaf kernels); winds within 1e-5 (device trig)."""
+    ni, nj = ec.YY_NI, ec.YY_NJ
+    ax, ay = ec.yy_axes(ni, nj)
+    gy = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.YIN_IG, ax, ay); ga = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.YAN_IG, ax, ay)
+    gu = ez.ezgdef_supergrid(ni, 2 * nj, "U", "F", 1, [gy, ga])
+    no, mo, gt, ig = ec.yy_targets()[tname]
+    go = ez.ezqkdef(no, mo, gt, *ig)
+    assert gu >= 0 and go >= 0 and ez.ezdefset(go, gu) == 1
+    assert ez.ezgdef_supergrid(ni, 2 * nj, "U", "F", 1, [gy, ga]) == gu          # identical definitions dedupe
+    z, uu, vv = ec.yy_fields()
+    for degree in (0, 1, 3):
+        setopts(degree, 1)
+        rc, got = ez.ezsint(z, no * mo)
+        assert rc == 0
+        want = GOLD[f"YY_to_{tname}/z_d{degree}"]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (tname, degree, float(relerr(got, want).max()))
+        rc, gu_, gv = ez.ezuvint(uu, vv, no * mo)
+        assert rc == 0
+        wu = GOLD[f"YY_to_{tname}/u_d{degree}"]; wv = GOLD[f"YY_to_{tname}/v_d{degree}"]
+        spd = np.sqrt(wu.astype(np.float64) ** 2 + wv.astype(np.float64) ** 2)
+        tol = RTOL * np.maximum(spd, spd.max() * 1e-3)
+        assert np.all(np.abs(gu_ - wu) <= tol) and np.all(np.abs(gv - wv) <= tol), (tname, degree)
+    # device-resident call and a batch of 2 fields
+    d_in = torch.from_numpy(np.stack([z, z[::-1].copy()])).cuda(); d_out = torch.empty((2, no * mo), dtype=torch.float32, device="cuda")
+    setopts(3, 1)
+    ez.use_stream(0)
+    assert ez.ezsint_batch_dev(d_out, d_in, 2) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out[0].cpu().numpy().view(np.uint32), GOLD[f"YY_to_{tname}/z_d3"].view(np.uint32))
+    # a U grid is a source only
+    assert ez.ezdefset(gu, go) == -1

@@ -121,3 +121,22 @@ def test_full_size_cfg2_golden():
         if degree == 3:
             f = z.ravel()
             assert "%.8e %.3f %.3f %.3f" % (f.astype(np.float64).sum(), f[0], f[f.size // 2], f[-1]) == "7.26056487e+09 281.818 276.863 278.271"
+
+
+@pytest.mark.parametrize("tname", sorted(ec.yy_targets()))
+def test_yinyang_golden(tname):
+    """Yin-Yang 'U' source -> L / G / N: the oracle's c_ezyysint / c_ezyyuvint restatement against the reference's outputs"""
+    O = ol.oracle()
+    ni, nj = ec.YY_NI, ec.YY_NJ
+    ax, ay = ec.yy_axes(ni, nj)
+    sg = O.orc_supergrid_define(ol.grid_define(ni, nj, "Z", ec.YIN_IG, "E", ax, ay), ol.grid_define(ni, nj, "Z", ec.YAN_IG, "E", ax, ay))
+    no, mo, gt, ig = ec.yy_targets()[tname]
+    go = ol.grid_define(no, mo, gt, ig)
+    z, uu, vv = ec.yy_fields()
+    for degree in (0, 1, 3):
+        opts = ol.default_opts(degre_interp=degree)
+        zo = np.zeros(no * mo, np.float32); uo = np.zeros(no * mo, np.float32); vo = np.zeros(no * mo, np.float32)
+        assert O.orc_ezyysint(sg, go, ctypes.byref(opts), ol.fptr(zo), ol.fptr(z)) == 0
+        assert O.orc_ezyyuvint(sg, go, ctypes.byref(opts), ol.fptr(uo), ol.fptr(vo), ol.fptr(uu), ol.fptr(vv)) == 0
+        for got, key in ((zo, "z"), (uo, "u"), (vo, "v")):
+            assert np.array_equal(got.view(np.uint32), GOLD[f"YY_to_{tname}/{key}_d{degree}"].view(np.uint32)), (tname, key, degree)
