@@ -96,6 +96,24 @@ int32_t ezhip_set_mode(void);
 /* 1 when a HIP device is usable */
 int32_t ezhip_available(void);
 
+/* ---- masked interpolation (src/interp/ez_mask.c) ------------------------------------------- */
+int c_gdsetmask(int gdid, int *mask);                                                                   /* ezscint.h:146 ; ez_mask.c:67 */
+int c_gdgetmask(int gdid, int *mask);                                                                   /* ezscint.h:149 ; ez_mask.c:89 */
+int c_ezsint_m(float *zout, float *zin);                                                                /* ezscint.h:152 ; "not implemented" in the reference too */
+int c_ezuvint_m(float *uuout, float *vvout, float *uuin, float *vvin);                                  /* ezscint.h:155 */
+int c_ezsint_mdm(float *zout, int *mask_out, float *zin, int *mask_in);                                 /* ezscint.h:158 ; ez_mask.c:127 */
+int c_ezuvint_mdm(float *uuout, float *vvout, int *mask_out, float *uuin, float *vvin, int *mask_in);   /* ezscint.h:161 ; ez_mask.c:155 */
+int c_ezsint_mask(int *mask_out, int *mask_in);                                                         /* ezscint.h:164 ; ez_mask.c:184 */
+int c_ezget_mask_zones(int *mask_out, int *mask_in);                                                    /* ez_mask.c:231 */
+int gdsetmask_(int *gdid, int *mask); int gdgetmask_(int *gdid, int *mask);                             /* Fortran twins, ezscint.h:145-163 */
+int ezsint_mdm_(float *zout, int *mask_out, float *zin, int *mask_in);
+int ezuvint_mdm_(float *uuout, float *vvout, int *mask_out, float *uuin, float *vvin, int *mask_in);
+int ezsint_mask_(int *mask_out, int *mask_in); int ezget_mask_zones_(int *mask_out, int *mask_in);
+int c_ezsint_mask_dev(int *d_mask_out, const int *d_mask_in);                                           /* additive: device pointers */
+int c_ezget_mask_zones_dev(int *d_mask_out, const int *d_mask_in);
+int c_ezsint_mdm_dev(float *d_zout, int *d_mask_out, const float *d_zin, const int *d_mask_in);
+int c_ezuvint_mdm_dev(float *d_uuout, float *d_vvout, int *d_mask_out, const float *d_uuin, const float *d_vvin, const int *d_mask_in);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,7 @@ typedef struct {
     double *d_windtrig;                    /* this grid as a separable wind TARGET: {cos,sin}(lon) per column, then {cos,sin}(lat) per row */
     float *d_plon2; float xg4_pole[2];     /* this grid as a wind SOURCE: longitudes of its last / first row, PS-frame xg4 (N, S) */
     ezh_set *sets;                          /* sets having this grid as gdout */
+    int *mask;                              /* c_gdsetmask */
     int nsub, sub[2], maskgrid[2];          /* 'U' (Yin-Yang): the two Z-on-E subgrids and their core ("mask") grids */
 } ezh_grid;
 
@@ -568,7 +569,7 @@ int32_t c_gdrls(int32_t gd)          /* gdrls.c:34-77: refcount, free at zero */
             while (*pp) { if ((*pp)->gdin == gd) { ezh_set *d = *pp; *pp = d->next; free_set(d); } else pp = &(*pp)->next; }
         }
         free(g->ax); free(g->ay); free(g->ncx); free(g->ncy);
-        free(g->lat1d); free(g->lon1d); free(g->lat2d); free(g->lon2d);
+        free(g->lat1d); free(g->lon1d); free(g->lat2d); free(g->lon2d); free(g->mask);
         ezhip_free(g->d_ax); ezhip_free(g->d_ay); ezhip_free(g->d_ncx); ezhip_free(g->d_ncy); ezhip_free(g->d_ncx8); ezhip_free(g->d_ncy8);
         ezhip_free(g->d_lat); ezhip_free(g->d_lon); ezhip_free(g->d_plon2); g->d_plon2 = NULL; ezhip_free(g->d_windtrig); g->d_windtrig = NULL;
         memset(g, 0, sizeof(*g));
@@ -2051,6 +2052,107 @@ int32_t c_ezwdint(float *spdout, float *dirout, float *uuin, float *vvin) { retu
 /* ------------------------------------------------------------------------------------------ */
 /* Fortran twins (rpnmacros.h:21 f77name; scalars by reference; hidden string lengths last)       */
 /* ------------------------------------------------------------------------------------------ */
+/* masks: src/interp/ez_mask.c                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+int c_gdsetmask(int gdid, int *mask)                       /* :67-87 */
+{
+    if (!grid_ok(gdid)) return -1;
+    ezh_grid *g = &G[gdid];
+    if (g->nsub > 0) { fprintf(stderr, "<gdsetmask> This operation is not supported for 'U' grids.\n"); return -1; }
+    size_t n = (size_t)g->ni * g->nj;
+    free(g->mask);
+    g->mask = (int *)malloc(sizeof(int) * n);
+    memcpy(g->mask, mask, sizeof(int) * n);
+    return 0;
+}
+int c_gdgetmask(int gdid, int *mask)                       /* :89-113 */
+{
+    if (!grid_ok(gdid)) return -1;
+    ezh_grid *g = &G[gdid];
+    if (g->nsub > 0) { fprintf(stderr, "<gdgetmask> This operation is not supported for 'U' grids.\n"); return -1; }
+    if (!g->mask) return -1;
+    memcpy(mask, g->mask, sizeof(int) * (size_t)g->ni * g->nj);
+    return 0;
+}
+static ezh_set *mask_set(const char *who)
+{
+    ezh_set *s = current_set(who);
+    if (!s) return NULL;
+    if (G[s->gdin].nsub > 0 || G[s->gdout].nsub > 0) { fprintf(stderr, "<%s> This operation is not supported for 'U' grids.\n", who); return NULL; }
+    if (need_device(who)) return NULL;
+    if (ensure_points(s)) return NULL;                      /* the per-point x, y of the set (the reference reads its cached gset x, y) */
+    return s;
+}
+static int mask_dev(const char *who, int *d_mask_out, const int *d_mask_in, int mode)
+{
+    ezh_set *s = mask_set(who);
+    if (!s) return -1;
+    ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
+    return ezhip_mask(d_mask_out, s->d_x, s->d_y, d_mask_in, gi->ni, gi->nj, go->ni, go->nj, mode, mode == 0 && O.cld_interp_alg == 1) ? -1 : 0;
+}
+int c_ezsint_mask_dev(int *d_mask_out, const int *d_mask_in) { return mask_dev("ezsint_mask", d_mask_out, d_mask_in, 0); }           /* :184-227 */
+int c_ezget_mask_zones_dev(int *d_mask_out, const int *d_mask_in) { return mask_dev("ezget_mask_zones", d_mask_out, d_mask_in, 1); } /* :231-264 */
+static int mask_host(const char *who, int *mask_out, int *mask_in, int mode)
+{
+    ezh_set *s = mask_set(who);
+    if (!s) return -1;
+    size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
+    int *d_in = (int *)upload(mask_in, sizeof(int) * nin), *d_out = (int *)ezhip_malloc(sizeof(int) * nout);
+    int rc = (d_in && d_out) ? mask_dev(who, d_out, d_in, mode) : -1;
+    if (rc == 0 && (ezhip_d2h(mask_out, d_out, sizeof(int) * nout) || ezhip_sync())) rc = -1;
+    ezhip_sync();
+    ezhip_free(d_in); ezhip_free(d_out);
+    return rc;
+}
+int c_ezsint_mask(int *mask_out, int *mask_in) { return mask_host("ezsint_mask", mask_out, mask_in, 0); }
+int c_ezget_mask_zones(int *mask_out, int *mask_in) { return mask_host("ezget_mask_zones", mask_out, mask_in, 1); }
+int c_ezsint_m(float *zout, float *zin) { (void)zout; (void)zin; fprintf(stderr, "<ezsint_m> This operation is currently not implemented.\n"); return 0; }   /* :115-118 */
+int c_ezuvint_m(float *uuout, float *vvout, float *uuin, float *vvin) { (void)uuout; (void)vvout; (void)uuin; (void)vvin; fprintf(stderr, "<ezuvint_m> This operation is currently not implemented.\n"); return 0; }
+
+/* c_ezsint_mdm (:127-153): c_ezsint, c_ezsint_mask, then lorenzo_mask_fill method 2 (masked points <- the field's minimum) */
+int c_ezsint_mdm_dev(float *d_zout, int *d_mask_out, const float *d_zin, const int *d_mask_in)
+{
+    ezh_set *s = mask_set("ezsint_mdm");
+    if (!s) return -1;
+    size_t nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
+    if (c_ezsint_dev(d_zout, d_zin) < 0) return -1;
+    if (c_ezsint_mask_dev(d_mask_out, d_mask_in)) return -1;
+    if (ensure_scratch(s)) return -1;
+    return ezhip_mask_fill_min(d_zout, d_mask_out, nout, (unsigned *)(t_scratch8 + 6)) ? -1 : 0;
+}
+int c_ezuvint_mdm_dev(float *d_uuout, float *d_vvout, int *d_mask_out, const float *d_uuin, const float *d_vvin, const int *d_mask_in)   /* :155-181 */
+{
+    ezh_set *s = mask_set("ezuvint_mdm");
+    if (!s) return -1;
+    size_t nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
+    if (c_ezsint_mask_dev(d_mask_out, d_mask_in)) return -1;
+    if (c_ezuvint_dev(d_uuout, d_vvout, d_uuin, d_vvin) < 0) return -1;
+    if (ensure_scratch(s)) return -1;
+    if (ezhip_mask_fill_min(d_uuout, d_mask_out, nout, (unsigned *)(t_scratch8 + 6))) return -1;
+    return ezhip_mask_fill_min(d_vvout, d_mask_out, nout, (unsigned *)(t_scratch8 + 6)) ? -1 : 0;
+}
+static int mdm_host(float *o1, float *o2, int *mask_out, float *i1, float *i2, int *mask_in)
+{
+    ezh_set *s = mask_set(o2 ? "ezuvint_mdm" : "ezsint_mdm");
+    if (!s) return -1;
+    size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
+    float *d_i1 = (float *)upload(i1, sizeof(float) * nin), *d_i2 = o2 ? (float *)upload(i2, sizeof(float) * nin) : NULL;
+    float *d_o1 = (float *)ezhip_malloc(sizeof(float) * nout), *d_o2 = o2 ? (float *)ezhip_malloc(sizeof(float) * nout) : NULL;
+    int *d_mi = (int *)upload(mask_in, sizeof(int) * nin), *d_mo = (int *)ezhip_malloc(sizeof(int) * nout);
+    int rc = -1;
+    if (d_i1 && d_o1 && d_mi && d_mo && (!o2 || (d_i2 && d_o2))) {
+        rc = o2 ? c_ezuvint_mdm_dev(d_o1, d_o2, d_mo, d_i1, d_i2, d_mi) : c_ezsint_mdm_dev(d_o1, d_mo, d_i1, d_mi);
+        if (rc == 0 && (ezhip_d2h(o1, d_o1, sizeof(float) * nout) || (o2 && ezhip_d2h(o2, d_o2, sizeof(float) * nout)) ||
+                        ezhip_d2h(mask_out, d_mo, sizeof(int) * nout) || ezhip_sync())) rc = -1;
+    }
+    ezhip_sync();
+    ezhip_free(d_i1); ezhip_free(d_i2); ezhip_free(d_o1); ezhip_free(d_o2); ezhip_free(d_mi); ezhip_free(d_mo);
+    return rc;
+}
+int c_ezsint_mdm(float *zout, int *mask_out, float *zin, int *mask_in) { return mdm_host(zout, NULL, mask_out, zin, NULL, mask_in); }
+int c_ezuvint_mdm(float *uuout, float *vvout, int *mask_out, float *uuin, float *vvin, int *mask_in) { return mdm_host(uuout, vvout, mask_out, uuin, vvin, mask_in); }
+
+/* ------------------------------------------------------------------------------------------ */
 /* Yin-Yang 'U' source grids: c_ezgdef_supergrid (ezgdef_supergrid.c:40-150), c_ezgdef_yymask       */
 /* (ezgdef_yymask.c:25-52), c_ezyymint (ezyymint.c:27-95), c_ezyy_calcxy (ezyy_calcxy.c:25-179),     */
 /* c_ezyysint (ezyysint.c:27-170), c_ezyyuvint (ezyyuvint.c:29-215) -- towards ONE ordinary target   */
@@ -2218,6 +2320,12 @@ int32_t ezqkdef_(int32_t *ni, int32_t *nj, char *grtyp, int32_t *ig1, int32_t *i
 int32_t ezgdef_fmem_(int32_t *ni, int32_t *nj, char *grtyp, char *grref, int32_t *ig1, int32_t *ig2, int32_t *ig3, int32_t *ig4, float *ax, float *ay, int32_t l1, int32_t l2)
 { (void)l1; (void)l2; char t[2] = {grtyp[0], 0}, r[2] = {grref[0], 0}; return c_ezgdef_fmem(*ni, *nj, t, r, *ig1, *ig2, *ig3, *ig4, ax, ay); }
 int32_t ezdefset_(int32_t *gdout, int32_t *gdin) { return c_ezdefset(*gdout, *gdin); }
+int gdsetmask_(int *gdid, int *mask) { return c_gdsetmask(*gdid, mask); }
+int gdgetmask_(int *gdid, int *mask) { return c_gdgetmask(*gdid, mask); }
+int ezsint_mdm_(float *zout, int *mask_out, float *zin, int *mask_in) { return c_ezsint_mdm(zout, mask_out, zin, mask_in); }
+int ezuvint_mdm_(float *uuout, float *vvout, int *mask_out, float *uuin, float *vvin, int *mask_in) { return c_ezuvint_mdm(uuout, vvout, mask_out, uuin, vvin, mask_in); }
+int ezsint_mask_(int *mask_out, int *mask_in) { return c_ezsint_mask(mask_out, mask_in); }
+int ezget_mask_zones_(int *mask_out, int *mask_in) { return c_ezget_mask_zones(mask_out, mask_in); }
 int32_t ezgdef_supergrid_(int32_t *ni, int32_t *nj, char *grtyp, char *grref, int32_t *vercode, int32_t *nsubgrids, int32_t *subgrid, int32_t l1, int32_t l2)
 { (void)l1; (void)l2; char t[2] = {grtyp[0], 0}, r[2] = {grref[0], 0}; return c_ezgdef_supergrid(*ni, *nj, t, r, *vercode, *nsubgrids, subgrid); }
 static void ftn2c(char *dst, const char *src, int len)

@@ -1621,6 +1621,68 @@ __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *_
     vv[n] = sinf(psi * DGTORD) * spd;
 }
 
+/* ===================================================================================== */
+/* masks: qqq_ezsint_mask / qqq_ezget_mask_zones (ezget_mask_zones.inc), lorenzo_mask_fill method 2  */
+/* ===================================================================================== */
+/* mask_in(i1, j1), 1-based, with the Fortran's linear addressing (no bounds in the reference: an address past the
+ * array is clamped to it here) */
+__device__ __forceinline__ int mask_at(const int *m, int ni, int nj, int i1, int j1)
+{
+    long long k = (long long)(j1 - 1) * ni + (i1 - 1), n = (long long)ni * nj;
+    k = k < 0 ? 0 : (k >= n ? n - 1 : k);
+    return m[k];
+}
+/* mode 0: c_ezsint_mask (cloud_linear: the second pass of ezget_mask_zones.inc:91-103, which only reads the point's own
+ * first-pass value); mode 1: c_ezget_mask_zones */
+__global__ __launch_bounds__(256) void k_mask(int *__restrict__ mask_out, const float *__restrict__ x, const float *__restrict__ y,
+                                              const int *__restrict__ mask_in, int ni_in, int nj_in, int ni_out, int nj_out, int mode, int cloud_linear)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= (size_t)ni_out * nj_out) return;
+    const float xv = x[k], yv = y[k];
+    const int ix = (int)xv, iy = (int)yv;
+    const bool outside = ix < 1 || ix > ni_in || iy < 1 || iy > nj_in;
+    if (mode == 1) {
+        if (outside) { mask_out[k] = 7; return; }
+        int nmissing = 0;
+        for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) nmissing += mask_at(mask_in, ni_in, nj_in, ix + a, iy + b) == 0;
+        mask_out[k] = 4 - nmissing;
+        return;
+    }
+    int v = 1;
+    if (outside) v = 0;
+    else if (mask_at(mask_in, ni_in, nj_in, (int)lroundf(xv), (int)lroundf(yv)) == 0) v = 0;
+    if (cloud_linear && v == 1) {
+        const int j = (int)(k / ni_out), i = (int)(k - (size_t)j * ni_out);
+        if (i < ni_out - 1 && j < nj_out - 1 &&
+            (mask_at(mask_in, ni_in, nj_in, ix + 1, iy) == 0 || mask_at(mask_in, ni_in, nj_in, ix, iy + 1) == 0 || mask_at(mask_in, ni_in, nj_in, ix + 1, iy + 1) == 0)) v = 0;
+    }
+    mask_out[k] = v;
+}
+extern "C" int ezhip_mask(int *d_mask_out, const float *d_x, const float *d_y, const int *d_mask_in, int ni_in, int nj_in, int ni_out, int nj_out, int mode, int cloud_linear)
+{
+    size_t n = (size_t)ni_out * nj_out;
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, d_mask_out, d_x, d_y, d_mask_in, ni_in, nj_in, ni_out, nj_out, mode, cloud_linear);
+    return LAUNCH_CHECK("k_mask");
+}
+__global__ __launch_bounds__(256) void k_mask_fill(float *__restrict__ fld, const int *__restrict__ mask, const unsigned *keys2, size_t n)
+{
+    const float rmin = key2f(keys2[0]);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) if (mask[i] == 0) fld[i] = rmin;
+}
+/* lorenzo_mask_fill(fld, mask, ni, nj, 2): masked points take minval(fld).  d_keys2: two words of device scratch */
+extern "C" int ezhip_mask_fill_min(float *d_fld, const int *d_mask, size_t n, unsigned *d_keys2)
+{
+    if (!n) return 0;
+    unsigned init[2] = {0xffffffffu, 0u};
+    if (set_err(hipMemcpyAsync(d_keys2, init, sizeof(init), hipMemcpyHostToDevice, g_stream), "mask fill init")) return -1;
+    int nb = (int)((n + 255) / 256); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(256), 0, g_stream, d_keys2, d_fld, n);
+    hipLaunchKernelGGL(k_mask_fill, dim3(nb), dim3(256), 0, g_stream, d_fld, d_mask, d_keys2, n);
+    return LAUNCH_CHECK("k_mask_fill");
+}
+
 __global__ __launch_bounds__(256) void k_scatter(float *__restrict__ dst, const float *__restrict__ src, const int *__restrict__ idx, int n)
 {
     int k = blockIdx.x * 256 + threadIdx.x;

@@ -154,6 +154,9 @@ typedef struct {
 int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin,
                      const float *d_x, const float *d_y, int npts);
 
+/* masks (ez_mask.c): mode 0 = c_ezsint_mask, 1 = c_ezget_mask_zones; x, y = located coordinates of every target point */
+int ezhip_mask(int *d_mask_out, const float *d_x, const float *d_y, const int *d_mask_in, int ni_in, int nj_in, int ni_out, int nj_out, int mode, int cloud_linear);
+int ezhip_mask_fill_min(float *d_fld, const int *d_mask, size_t n, unsigned *d_keys2);
 /* d_dst[d_idx[k]] = d_src[k] (the merge of the Yin and Yang point lists) */
 int ezhip_scatter(float *d_dst, const float *d_src, const int *d_idx, int n);
 /* pole values {north, south} of a source field -> device float[2] */

@@ -24,6 +24,9 @@ def _lib():
         L.c_ezsetval.argtypes = [cp, ctypes.c_float]
         L.c_ezsetival.argtypes = [cp, i32]
         L.c_ezsint.argtypes = [vp, vp]
+        L.c_gdsetmask.argtypes = [i32, vp]; L.c_gdgetmask.argtypes = [i32, vp]
+        L.c_ezsint_mask.argtypes = [vp, vp]; L.c_ezget_mask_zones.argtypes = [vp, vp]
+        L.c_ezsint_mdm.argtypes = [vp, vp, vp, vp]; L.c_ezuvint_mdm.argtypes = [vp, vp, vp, vp, vp, vp]
         L.c_ezuvint.argtypes = [vp, vp, vp, vp]
         L.c_ezwdint.argtypes = [vp, vp, vp, vp]
         L.c_ezwdint_dev.argtypes = [vp, vp, vp, vp]
@@ -200,3 +203,35 @@ def prepare_set():
 
 def set_mode():
     return _lib().ezhip_set_mode()
+
+
+def gdsetmask(gdid, mask):
+    m = np.ascontiguousarray(mask, dtype=np.int32)
+    return _lib().c_gdsetmask(gdid, m.ctypes.data)
+
+
+def gdgetmask(gdid, n):
+    m = np.zeros(n, np.int32)
+    return _lib().c_gdgetmask(gdid, m.ctypes.data), m
+
+
+def ezsint_mask(mask_in, nout):
+    mi = np.ascontiguousarray(mask_in, dtype=np.int32); mo = np.zeros(nout, np.int32)
+    return _lib().c_ezsint_mask(mo.ctypes.data, mi.ctypes.data), mo
+
+
+def ezget_mask_zones(mask_in, nout):
+    mi = np.ascontiguousarray(mask_in, dtype=np.int32); mo = np.zeros(nout, np.int32)
+    return _lib().c_ezget_mask_zones(mo.ctypes.data, mi.ctypes.data), mo
+
+
+def ezsint_mdm(zin, mask_in, nout):
+    zin, pin = _np(zin); mi = np.ascontiguousarray(mask_in, dtype=np.int32)
+    zo = np.zeros(nout, np.float32); mo = np.zeros(nout, np.int32)
+    return _lib().c_ezsint_mdm(zo.ctypes.data, mo.ctypes.data, pin, mi.ctypes.data), zo, mo
+
+
+def ezuvint_mdm(uuin, vvin, mask_in, nout):
+    uuin, pu = _np(uuin); vvin, pv = _np(vvin); mi = np.ascontiguousarray(mask_in, dtype=np.int32)
+    uo = np.zeros(nout, np.float32); vo = np.zeros(nout, np.float32); mo = np.zeros(nout, np.int32)
+    return _lib().c_ezuvint_mdm(uo.ctypes.data, vo.ctypes.data, mo.ctypes.data, pu, pv, mi.ctypes.data), uo, vo, mo

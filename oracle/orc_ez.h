@@ -104,6 +104,11 @@ int orc_gdwdfuv(orc_grid *g, float *spd, float *dir, const float *uu, const floa
 int orc_gduvfwd(orc_grid *g, float *uu, float *vv, const float *spd, const float *dir,
                 const float *lat, const float *lon, int npts);
 
+/* masked interpolation helpers (oracle/orc_mask.c; src/interp/ez_mask.c) */
+int orc_ezsint_mask(orc_gridset *gs, int cloud_linear, int *mask_out, const int *mask_in);
+int orc_ezget_mask_zones(orc_gridset *gs, int *mask_zones, const int *mask_in);
+void orc_mask_fill2(float *fld, const int *mask, int n);
+
 /* Yin-Yang 'U' source grids (oracle/orc_yy.c): c_ezgdef_supergrid + c_ezgdef_yymask, c_ezyysint / c_ezyyuvint towards one
  * ordinary target grid */
 typedef struct {

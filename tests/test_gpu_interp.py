@@ -507,3 +507,53 @@ def test_yinyang_source_vs_golden(tname):
     assert np.array_equal(d_out[0].cpu().numpy().view(np.uint32), GOLD[f"YY_to_{tname}/z_d3"].view(np.uint32))
     # a U grid is a source only
     assert ez.ezdefset(gu, go) == -1
+
+
+def _mask_field(ni, nj, seed):
+    h = ec.hash_uniform(seed, ((ni + 1) // 2) * ((nj + 1) // 2)).reshape((nj + 1) // 2, (ni + 1) // 2)
+    m = (np.repeat(np.repeat(h, 2, axis=0), 2, axis=1)[:nj, :ni] > 0.25).astype(np.int32)
+    return np.ascontiguousarray(m.reshape(-1))
+
+
+@pytest.mark.parametrize("name", ["Lregional_to_L", "G_to_L", "N_to_L", "L_to_N", "G_to_Y"])
+@pytest.mark.parametrize("alg", ["linear", "distance"])
+def test_masks_match_oracle(name, alg):
+    """c_ezsint_mask / c_ezget_mask_zones / c_ezsint_mdm / c_gdsetmask (ez_mask.c) on the device against the oracle
+    (itself pinned against the reference build): integer masks identical, the filled field bit-exact"""
+    case = CASES[name]
+    ni, nj = case["src"][:2]; no, mo = case["dst"][:2]
+    gdin = hip_define(case["src"]); gdout = hip_define(ec.dst_spec(case))
+    assert ez.ezdefset(gdout, gdin) == 1
+    setopts(1, 1)
+    assert ez.ezsetopt("cloud_interp_alg", alg) == 0
+    zin, _, _ = case_inputs(name, case)
+    mask_in = _mask_field(ni, nj, seed=ni + nj)
+    try:
+        rc, zo, mo_ = ez.ezsint_mdm(zin, mask_in, no * mo)
+        assert rc == 0
+        rc, mz = ez.ezget_mask_zones(mask_in, no * mo)
+        assert rc == 0
+        rc, m2 = ez.ezsint_mask(mask_in, no * mo)
+        assert rc == 0 and np.array_equal(m2, mo_)
+    finally:
+        ez.ezsetopt("cloud_interp_alg", "distance")
+    O = ol.oracle()
+    O.orc_ezsint_mask.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    O.orc_ezget_mask_zones.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    O.orc_mask_fill2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    import test_oracle_golden as tog
+    gi = tog.orc_define(case["src"]); go = tog.orc_define(ec.dst_spec(case))
+    gs = O.orc_defset(go, gi)
+    opts = ol.default_opts(degre_interp=1)
+    want = np.zeros(no * mo, np.float32); wm = np.zeros(no * mo, np.int32); wz = np.zeros(no * mo, np.int32)
+    O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(want), ol.fptr(zin))
+    O.orc_ezsint_mask(ctypes.cast(gs, ctypes.c_void_p), int(alg == "linear"), wm.ctypes.data, mask_in.ctypes.data)
+    O.orc_mask_fill2(want.ctypes.data, wm.ctypes.data, no * mo)
+    O.orc_ezget_mask_zones(ctypes.cast(gs, ctypes.c_void_p), wz.ctypes.data, mask_in.ctypes.data)
+    assert np.array_equal(mo_, wm), (name, alg, int((mo_ != wm).sum()))
+    assert np.array_equal(mz, wz), (name, alg)
+    assert np.array_equal(zo.view(np.uint32), want.view(np.uint32)), (name, alg)
+    # the grid-attached mask is just stored and returned
+    assert ez.gdsetmask(gdin, mask_in) == 0
+    rc, back = ez.gdgetmask(gdin, ni * nj)
+    assert rc == 0 and np.array_equal(back, mask_in)
