@@ -96,6 +96,16 @@ int32_t ezhip_set_mode(void);
 /* 1 when a HIP device is usable */
 int32_t ezhip_available(void);
 
+/* ---- wind conversions on their own, subgrid queries, small definitions ------------------------ */
+int32_t c_gdwdfuv(int32_t gdid, float *spd_out, float *wd_out, float *uuin, float *vvin, float *latin, float *lonin, int32_t npts);          /* ezscint.h:132 ; gdwdfuv.c:29 */
+int32_t c_gduvfwd(int32_t gdid, float *uugdout, float *vvgdout, float *uullin, float *vvllin, float *latin, float *lonin, int32_t npts);     /* ezscint.h:129 ; gduvfwd.c:29 ; E / Z targets refused */
+int32_t c_gdwdfuv_dev(int32_t gdid, float *d_spd, float *d_wd, const float *d_uu, const float *d_vv, const float *d_lat, const float *d_lon, int32_t npts);
+int32_t c_gduvfwd_dev(int32_t gdid, float *d_uu, float *d_vv, const float *d_spd, const float *d_wd, const float *d_lat, const float *d_lon, int32_t npts);
+int32_t c_gdxyzfll(int32_t gdid, float *x, float *y, float *lat, float *lon, int32_t n);     /* ezscint.h:141 ; gdxyzfll.c:33 (host) */
+int32_t c_ezgdef_fll(int32_t ni, int32_t nj, float *lat, float *lon);                       /* ezscint.h:24 ; ezgdef_fll.c:36 ('Y' on 'L') */
+int32_t c_ezget_nsubgrids(int32_t gdid);                                                    /* ezscint.h:169 */
+int32_t c_ezget_subgridids(int32_t gdid, int32_t *subgrid);                                 /* ezscint.h:172 */
+
 /* ---- masked interpolation (src/interp/ez_mask.c) ------------------------------------------- */
 int c_gdsetmask(int gdid, int *mask);                                                                   /* ezscint.h:146 ; ez_mask.c:67 */
 int c_gdgetmask(int gdid, int *mask);                                                                   /* ezscint.h:149 ; ez_mask.c:89 */

@@ -2052,6 +2052,97 @@ int32_t c_ezwdint(float *spdout, float *dirout, float *uuin, float *vvin) { retu
 /* ------------------------------------------------------------------------------------------ */
 /* Fortran twins (rpnmacros.h:21 f77name; scalars by reference; hidden string lengths last)       */
 /* ------------------------------------------------------------------------------------------ */
+/* small public entry points around the same kernels                                            */
+/* ------------------------------------------------------------------------------------------ */
+int32_t c_ezget_nsubgrids(int32_t gdid) { if (!grid_ok(gdid)) return -1; return G[gdid].nsub ? G[gdid].nsub : 1; }           /* ezget_nsubgrids.c:25-33 */
+int32_t c_ezget_subgridids(int32_t gdid, int32_t *subgrid)                                                                    /* ezget_subgridids.c:25-37 */
+{
+    if (!grid_ok(gdid)) return -1;
+    if (G[gdid].nsub == 0) { *subgrid = gdid; return 1; }
+    for (int k = 0; k < G[gdid].nsub; k++) subgrid[k] = G[gdid].sub[k];
+    return G[gdid].nsub;
+}
+int32_t c_ezgdef_fll(int32_t ni, int32_t nj, float *lat, float *lon)                                                          /* ezgdef_fll.c:36-51 */
+{
+    int ig1, ig2, ig3, ig4;
+    h_cxgaig('L', &ig1, &ig2, &ig3, &ig4, 0.0f, 0.0f, 1.0f, 1.0f);
+    char t[2] = "Y", r[2] = "L";
+    return c_ezgdef_fmem(ni, nj, t, r, ig1, ig2, ig3, ig4, lon, lat);
+}
+/* c_gdxyzfll (gdxyzfll.c:33-80): like c_gdxyfll for the regular types; 'Z' grids: coordinates on the reference grid
+ * (ABSOLU: the search in the axes is skipped) */
+int32_t c_gdxyzfll(int32_t gdid, float *x, float *y, float *lat, float *lon, int32_t n)
+{
+    if (!grid_ok(gdid)) return -1;
+    ezh_grid *g = &G[gdid];
+    switch (g->grtyp) {
+    case 'A': case 'B': case 'E': case 'G': case 'L': case 'N': case 'S': c_gdxyfll(gdid, x, y, lat, lon, n); break;
+    case 'Y': fprintf(stderr, "<gdxyzfll>: This operation is not supported for 'Y' grids\n"); break;
+    case 'Z':
+        if (g->grref == 'L') {
+            float lat0, lon0, dlat, dlon;
+            h_cigaxg('L', &lat0, &lon0, &dlat, &dlon, g->igref[0], g->igref[1], g->igref[2], g->igref[3]);
+            h_llll2gd(x, y, lat, lon, n, lat0, lon0, dlat, dlon, (g->ax[0] < 0.0f) ? -180.0f : 0.0f);
+            for (int i = 0; i < n; i++) { x[i] = x[i] - 1.0f; y[i] = y[i] - 1.0f; }
+        } else h_rotate(x, y, lon, lat, n, g->xgref, 1);
+        break;
+    default: break;
+    }
+    return 0;
+}
+
+/* c_gdwdfuv (gdwdfuv.c:29-110): grid components at (lat, lon) -> speed, direction; c_gduvfwd (gduvfwd.c:29-96): back */
+static int wind_conv_dev(int32_t gdid, float *d_a, float *d_b, const float *d_lat, const float *d_lon, int32_t npts, int to_wd)
+{
+    if (!grid_ok(gdid)) return -1;
+    if (need_device(to_wd ? "c_gdwdfuv" : "c_gduvfwd")) return -1;
+    ezh_grid *g = &G[gdid];
+    if (g->nsub > 0 || g->grtyp == 'Y') { fprintf(stderr, "<%s> '%c' grids are outside the MI355X hot-path scope here\n", to_wd ? "c_gdwdfuv" : "c_gduvfwd", g->grtyp); return -1; }
+    int rotated = g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E');
+    ezhip_wind_plan wp;
+    memset(&wp, 0, sizeof(wp));
+    if (to_wd) {
+        wp.wd_only = 1; wp.src_rotated = rotated;
+        if (rotated) { const float *xg = g->grtyp == 'E' ? g->xg : g->xgref; h_crot(wp.r, wp.ri, xg[1], xg[0], xg[3], xg[2]); }
+        if (g->grtyp == 'N' || g->grtyp == 'S') { wp.src_ps = g->grtyp == 'N' ? 1 : 2; wp.src_xg4 = g->xg[3]; }
+    } else {
+        if (rotated || g->grtyp == 'Z') { fprintf(stderr, "<c_gduvfwd> '%c' target grids are outside the MI355X hot-path scope for winds\n", g->grtyp); return -1; }
+        wp.wd_in = 1;
+        if (g->grtyp == 'N' || g->grtyp == 'S') { wp.dst_ps = g->grtyp == 'N' ? 1 : 2; wp.dst_xg4 = g->xg[3]; }
+    }
+    if (npts <= 0) return 0;
+    return ezhip_wind_rotate(&wp, d_a, d_b, d_lat, d_lon, npts, 1) ? -1 : 0;
+}
+int32_t c_gdwdfuv_dev(int32_t gdid, float *d_spd, float *d_wd, const float *d_uu, const float *d_vv, const float *d_lat, const float *d_lon, int32_t npts)
+{
+    if (npts > 0 && (d_spd != d_uu) && ezhip_d2d(d_spd, d_uu, sizeof(float) * (size_t)npts)) return -1;
+    if (npts > 0 && (d_wd != d_vv) && ezhip_d2d(d_wd, d_vv, sizeof(float) * (size_t)npts)) return -1;
+    return wind_conv_dev(gdid, d_spd, d_wd, d_lat, d_lon, npts, 1);
+}
+int32_t c_gduvfwd_dev(int32_t gdid, float *d_uu, float *d_vv, const float *d_spd, const float *d_wd, const float *d_lat, const float *d_lon, int32_t npts)
+{
+    if (npts > 0 && (d_uu != d_spd) && ezhip_d2d(d_uu, d_spd, sizeof(float) * (size_t)npts)) return -1;
+    if (npts > 0 && (d_vv != d_wd) && ezhip_d2d(d_vv, d_wd, sizeof(float) * (size_t)npts)) return -1;
+    return wind_conv_dev(gdid, d_uu, d_vv, d_lat, d_lon, npts, 0);
+}
+static int32_t wind_conv_host(int32_t gdid, float *o1, float *o2, float *i1, float *i2, float *lat, float *lon, int32_t npts, int to_wd)
+{
+    if (!grid_ok(gdid)) return -1;
+    if (need_device(to_wd ? "c_gdwdfuv" : "c_gduvfwd")) return -1;
+    size_t nb = sizeof(float) * (size_t)(npts > 0 ? npts : 1);
+    float *d1 = (float *)upload(i1, nb), *d2 = (float *)upload(i2, nb), *dla = (float *)upload(lat, nb), *dlo = (float *)upload(lon, nb);
+    int rc = (d1 && d2 && dla && dlo) ? wind_conv_dev(gdid, d1, d2, dla, dlo, npts, to_wd) : -1;
+    if (rc == 0 && (ezhip_d2h(o1, d1, sizeof(float) * (size_t)npts) || ezhip_d2h(o2, d2, sizeof(float) * (size_t)npts) || ezhip_sync())) rc = -1;
+    ezhip_sync();
+    ezhip_free(d1); ezhip_free(d2); ezhip_free(dla); ezhip_free(dlo);
+    return rc;
+}
+int32_t c_gdwdfuv(int32_t gdid, float *spd_out, float *wd_out, float *uuin, float *vvin, float *latin, float *lonin, int32_t npts)
+{ return wind_conv_host(gdid, spd_out, wd_out, uuin, vvin, latin, lonin, npts, 1); }
+int32_t c_gduvfwd(int32_t gdid, float *uugdout, float *vvgdout, float *uullin, float *vvllin, float *latin, float *lonin, int32_t npts)
+{ return wind_conv_host(gdid, uugdout, vvgdout, uullin, vvllin, latin, lonin, npts, 0); }
+
+/* ------------------------------------------------------------------------------------------ */
 /* masks: src/interp/ez_mask.c                                                                  */
 /* ------------------------------------------------------------------------------------------ */
 int c_gdsetmask(int gdid, int *mask)                       /* :67-87 */

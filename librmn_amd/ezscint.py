@@ -24,6 +24,9 @@ def _lib():
         L.c_ezsetval.argtypes = [cp, ctypes.c_float]
         L.c_ezsetival.argtypes = [cp, i32]
         L.c_ezsint.argtypes = [vp, vp]
+        L.c_gdwdfuv.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32]; L.c_gduvfwd.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32]
+        L.c_gdxyzfll.argtypes = [i32, vp, vp, vp, vp, i32]; L.c_ezgdef_fll.argtypes = [i32, i32, vp, vp]
+        L.c_ezget_nsubgrids.argtypes = [i32]; L.c_ezget_subgridids.argtypes = [i32, vp]
         L.c_gdsetmask.argtypes = [i32, vp]; L.c_gdgetmask.argtypes = [i32, vp]
         L.c_ezsint_mask.argtypes = [vp, vp]; L.c_ezget_mask_zones.argtypes = [vp, vp]
         L.c_ezsint_mdm.argtypes = [vp, vp, vp, vp]; L.c_ezuvint_mdm.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -235,3 +238,41 @@ def ezuvint_mdm(uuin, vvin, mask_in, nout):
     uuin, pu = _np(uuin); vvin, pv = _np(vvin); mi = np.ascontiguousarray(mask_in, dtype=np.int32)
     uo = np.zeros(nout, np.float32); vo = np.zeros(nout, np.float32); mo = np.zeros(nout, np.int32)
     return _lib().c_ezuvint_mdm(uo.ctypes.data, vo.ctypes.data, mo.ctypes.data, pu, pv, mi.ctypes.data), uo, vo, mo
+
+
+def gdwdfuv(gdid, uu, vv, lat, lon):
+    """grid components at (lat, lon) -> (speed, direction)"""
+    a = [np.ascontiguousarray(v, dtype=np.float32) for v in (uu, vv, lat, lon)]
+    spd = np.zeros_like(a[0]); wd = np.zeros_like(a[0])
+    rc = _lib().c_gdwdfuv(gdid, spd.ctypes.data, wd.ctypes.data, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, a[0].size)
+    return rc, spd, wd
+
+
+def gduvfwd(gdid, spd, wd, lat, lon):
+    """(speed, direction) at (lat, lon) -> grid components"""
+    a = [np.ascontiguousarray(v, dtype=np.float32) for v in (spd, wd, lat, lon)]
+    uu = np.zeros_like(a[0]); vv = np.zeros_like(a[0])
+    rc = _lib().c_gduvfwd(gdid, uu.ctypes.data, vv.ctypes.data, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, a[0].size)
+    return rc, uu, vv
+
+
+def gdxyzfll(gdid, lat, lon):
+    lat = np.ascontiguousarray(lat, dtype=np.float32); lon = np.array(lon, dtype=np.float32, copy=True)
+    x = np.zeros_like(lat); y = np.zeros_like(lat)
+    rc = _lib().c_gdxyzfll(gdid, x.ctypes.data, y.ctypes.data, lat.ctypes.data, lon.ctypes.data, lat.size)
+    return rc, x, y
+
+
+def ezgdef_fll(ni, nj, lat, lon):
+    lat = np.ascontiguousarray(lat, dtype=np.float32); lon = np.ascontiguousarray(lon, dtype=np.float32)
+    return _lib().c_ezgdef_fll(ni, nj, lat.ctypes.data, lon.ctypes.data)
+
+
+def ezget_nsubgrids(gdid):
+    return _lib().c_ezget_nsubgrids(gdid)
+
+
+def ezget_subgridids(gdid):
+    ids = np.zeros(4, np.int32)
+    n = _lib().c_ezget_subgridids(gdid, ids.ctypes.data)
+    return n, ids[:max(n, 0)]

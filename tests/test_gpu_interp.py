@@ -557,3 +557,35 @@ def test_masks_match_oracle(name, alg):
     assert ez.gdsetmask(gdin, mask_in) == 0
     rc, back = ez.gdgetmask(gdin, ni * nj)
     assert rc == 0 and np.array_equal(back, mask_in)
+
+
+@pytest.mark.parametrize("kind", ["L", "N", "S", "ZE", "G"])
+def test_gdwdfuv_gduvfwd_match_oracle(kind):
+    """c_gdwdfuv / c_gduvfwd on their own (scattered points) against the oracle (pinned against the reference build):
+    non-rotated grids are the reference's REAL arithmetic with the device's float trig (<= 1e-5), rotated sources idem"""
+    import test_oracle_golden as tog
+    spec = {"L": (40, 20, "L", (900, 900, 450, 0), " ", None), "N": (101, 91, "N", ec.N_IG, " ", None), "S": (81, 121, "S", ec.S_IG, " ", None),
+            "ZE": (65, 32, "Z", ec.E_IG, "E", ec.ze_axes), "G": (64, 32, "G", (0, 0, 0, 0), " ", None)}[kind]
+    g = hip_define(spec); og = tog.orc_define(spec)
+    O = ol.oracle()
+    n = 777
+    lat = (ec.hash_uniform(15, n).astype(np.float64) * 170.0 - 85.0).astype(np.float32)
+    lon = (ec.hash_uniform(16, n).astype(np.float64) * 360.0).astype(np.float32)
+    uu = ((ec.hash_uniform(17, n) - 0.5) * 60).astype(np.float32); vv = ((ec.hash_uniform(18, n) - 0.5) * 60).astype(np.float32)
+    uu[:3] = 0.0; vv[1] = 0.0
+    ws = np.zeros(n, np.float32); wd = np.zeros(n, np.float32)
+    O.orc_gdwdfuv(og, ol.fptr(ws), ol.fptr(wd), ol.fptr(uu), ol.fptr(vv), ol.fptr(lat), ol.fptr(lon), n)
+    rc, gs, gd = ez.gdwdfuv(g, uu, vv, lat, lon)
+    assert rc == 0
+    assert np.all(np.abs(gs - ws) <= 1e-5 * np.maximum(ws, 1e-3))
+    ddir = np.abs(((gd - wd + 180.0) % 360.0) - 180.0)
+    assert np.all(ddir[ws > 1e-3] <= 2e-3), float(ddir.max())           # degrees: 1e-5 of a full turn
+    if kind != "ZE":
+        wu = np.zeros(n, np.float32); wv = np.zeros(n, np.float32)
+        O.orc_gduvfwd(og, ol.fptr(wu), ol.fptr(wv), ol.fptr(ws), ol.fptr(wd), ol.fptr(lat), ol.fptr(lon), n)
+        rc, gu, gv = ez.gduvfwd(g, ws, wd, lat, lon)
+        assert rc == 0
+        tol = 1e-5 * np.maximum(ws, 1e-3) + 1e-6
+        assert np.all(np.abs(gu - wu) <= tol) and np.all(np.abs(gv - wv) <= tol)
+    else:
+        assert ez.gduvfwd(g, ws, wd, lat, lon)[0] == -1                # rotated targets: refused

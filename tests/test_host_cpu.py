@@ -105,3 +105,39 @@ def test_compute_fails_loudly_without_gpu():
     ez.ezdefset(gdout, gdin)
     rc, z = ez.ezsint(np.zeros(64 * 32, np.float32), 90 * 46)
     assert rc == -1                                 # no CPU fallback
+
+
+def test_subgrid_queries_and_fll():
+    """c_ezget_nsubgrids / c_ezget_subgridids (ezget_nsubgrids.c, ezget_subgridids.c), c_ezgdef_fll == 'Y' on 'L' (ezgdef_fll.c)"""
+    ax, ay = ec.yy_axes(ec.YY_NI, ec.YY_NJ)
+    gy = ez.ezgdef_fmem(ec.YY_NI, ec.YY_NJ, "Z", "E", *ec.YIN_IG, ax, ay); ga = ez.ezgdef_fmem(ec.YY_NI, ec.YY_NJ, "Z", "E", *ec.YAN_IG, ax, ay)
+    gu = ez.ezgdef_supergrid(ec.YY_NI, 2 * ec.YY_NJ, "U", "F", 1, [gy, ga])
+    assert ez.ezget_nsubgrids(gu) == 2 and ez.ezget_nsubgrids(gy) == 1
+    n, ids = ez.ezget_subgridids(gu)
+    assert n == 2 and list(ids) == [gy, ga]
+    n, ids = ez.ezget_subgridids(gy)
+    assert n == 1 and list(ids) == [gy]
+    lon, lat = ec.cloud_axes(37, 11)
+    g1 = ez.ezgdef_fll(37, 11, lat, lon)
+    assert g1 >= 0 and g1 == ez.ezgdef_fmem(37, 11, "Y", "L", 100, 100, 9000, 0, lon, lat)      # cxgaig('L', 0, 0, 1, 1)
+
+
+def test_gdxyzfll_vs_reference():
+    """c_gdxyzfll (host only): regular types == c_gdxyfll, 'Z' grids in reference-grid coordinates -- against the reference build"""
+    import reflib as rl
+    if not rl.have_ref():
+        pytest.skip("oracle/_ref/libezref.so not built")
+    L = rl.ref()
+    n = 500
+    lat = (ec.hash_uniform(5, n).astype(np.float64) * 170.0 - 85.0).astype(np.float32)
+    lon = (ec.hash_uniform(6, n).astype(np.float64) * 360.0).astype(np.float32)
+    ax, ay = ec.ze_axes(65, 32)
+    specs = [(lambda: ez.ezgdef_fmem(65, 32, "Z", "E", *ec.E_IG, ax, ay), lambda: L.c_ezgdef_fmem(65, 32, b"Z", b"E", *ec.E_IG, rl.fptr(ax), rl.fptr(ay))),
+             (lambda: ez.ezqkdef(101, 91, "N", *ec.N_IG), lambda: L.c_ezqkdef(101, 91, b"N", *ec.N_IG, 0)),
+             (lambda: ez.ezqkdef(40, 20, "L", 900, 900, 450, 0), lambda: L.c_ezqkdef(40, 20, b"L", 900, 900, 450, 0, 0))]
+    for mine, theirs in specs:
+        g = mine(); gr = theirs()
+        rc, x, y = ez.gdxyzfll(g, lat, lon)
+        xr = np.zeros(n, np.float32); yr = np.zeros(n, np.float32); lo2 = lon.copy()
+        L.c_gdxyzfll(gr, rl.fptr(xr), rl.fptr(yr), rl.fptr(lat.copy()), rl.fptr(lo2), n)
+        assert rc == 0 and np.array_equal(x.view(np.uint32), xr.view(np.uint32)) and np.array_equal(y.view(np.uint32), yr.view(np.uint32))

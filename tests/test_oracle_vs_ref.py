@@ -347,3 +347,26 @@ def test_masks(name, alg):
     if zmin_ok:
         assert np.array_equal(got.view(np.uint32), zo.view(np.uint32)), (name, alg)
     assert 0 < gm.sum() < gm.size and defined.sum() > 0.5 * defined.size
+
+
+@pytest.mark.parametrize("kind", ["L", "N", "S", "ZE", "G"])
+def test_gdwdfuv_gduvfwd_direct(kind):
+    """c_gdwdfuv / c_gduvfwd called on their own at scattered points == the oracle's restatements (bit-exact)"""
+    L = ref(); O = ol.oracle()
+    spec = {"L": (40, 20, "L", (900, 900, 450, 0), " ", None), "N": (101, 91, "N", ec.N_IG, " ", None), "S": (81, 121, "S", ec.S_IG, " ", None),
+            "ZE": (65, 32, "Z", ec.E_IG, "E", ec.ze_axes), "G": (64, 32, "G", (0, 0, 0, 0), " ", None)}[kind]
+    g = ref_define(L, spec); og = orc_define(spec)
+    n = 777
+    lat = (ec.hash_uniform(15, n).astype(np.float64) * 170.0 - 85.0).astype(np.float32)
+    lon = (ec.hash_uniform(16, n).astype(np.float64) * 360.0).astype(np.float32)
+    uu = ((ec.hash_uniform(17, n) - 0.5) * 60).astype(np.float32); vv = ((ec.hash_uniform(18, n) - 0.5) * 60).astype(np.float32)
+    uu[:3] = 0.0; vv[1] = 0.0
+    rs = np.zeros(n, np.float32); rd = np.zeros(n, np.float32); os_ = np.zeros(n, np.float32); od = np.zeros(n, np.float32)
+    L.c_gdwdfuv(g, fptr(rs), fptr(rd), fptr(uu), fptr(vv), fptr(lat), fptr(lon), n)
+    O.orc_gdwdfuv(og, fptr(os_), fptr(od), fptr(uu), fptr(vv), fptr(lat), fptr(lon), n)
+    assert np.array_equal(os_.view(np.uint32), rs.view(np.uint32)) and np.array_equal(od.view(np.uint32), rd.view(np.uint32))
+    if kind != "ZE":
+        ru = np.zeros(n, np.float32); rv = np.zeros(n, np.float32); ou = np.zeros(n, np.float32); ov = np.zeros(n, np.float32)
+        L.c_gduvfwd(g, fptr(ru), fptr(rv), fptr(rs), fptr(rd), fptr(lat), fptr(lon), n)
+        O.orc_gduvfwd(og, fptr(ou), fptr(ov), fptr(rs), fptr(rd), fptr(lat), fptr(lon), n)
+        assert np.array_equal(ou.view(np.uint32), ru.view(np.uint32)) and np.array_equal(ov.view(np.uint32), rv.view(np.uint32))
