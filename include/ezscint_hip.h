@@ -101,6 +101,9 @@ int32_t c_gdwdfuv(int32_t gdid, float *spd_out, float *wd_out, float *uuin, floa
 int32_t c_gduvfwd(int32_t gdid, float *uugdout, float *vvgdout, float *uullin, float *vvllin, float *latin, float *lonin, int32_t npts);     /* ezscint.h:129 ; gduvfwd.c:29 ; E / Z targets refused */
 int32_t c_gdwdfuv_dev(int32_t gdid, float *d_spd, float *d_wd, const float *d_uu, const float *d_vv, const float *d_lat, const float *d_lon, int32_t npts);
 int32_t c_gduvfwd_dev(int32_t gdid, float *d_uu, float *d_vv, const float *d_spd, const float *d_wd, const float *d_lat, const float *d_lon, int32_t npts);
+int32_t c_gdllfxy(int32_t gdid, float *lat, float *lon, float *x, float *y, int32_t n);      /* ezscint.h:102 ; gdllfxy.c:92 (host) */
+int32_t c_gdxywdval(int32_t gdin, float *uuout, float *vvout, float *uuin, float *vvin, float *x, float *y, int32_t n);       /* gdxywdval.c:38 */
+int32_t c_gdllwdval(int32_t gdid, float *uuout, float *vvout, float *uuin, float *vvin, float *lat, float *lon, int32_t n);   /* gdllwdval.c:36 */
 int32_t c_gdxyzfll(int32_t gdid, float *x, float *y, float *lat, float *lon, int32_t n);     /* ezscint.h:141 ; gdxyzfll.c:33 (host) */
 int32_t c_ezgdef_fll(int32_t ni, int32_t nj, float *lat, float *lon);                       /* ezscint.h:24 ; ezgdef_fll.c:36 ('Y' on 'L') */
 int32_t c_ezget_nsubgrids(int32_t gdid);                                                    /* ezscint.h:169 */

@@ -2091,6 +2091,110 @@ int32_t c_gdxyzfll(int32_t gdid, float *x, float *y, float *lat, float *lon, int
     return 0;
 }
 
+int32_t c_gdwdfuv(int32_t gdid, float *spd_out, float *wd_out, float *uuin, float *vvin, float *latin, float *lonin, int32_t npts);
+/* ez_vllfxy (ez_vllfxy.inc:24-98): polar-stereographic x, y -> lat, lon, in double */
+static void h_vllfxy(float *dlat, float *dlon, const float *x, const float *y, int n, float d60, float dgrw, float pi, float pj, int nhem)
+{
+    const float rdtodg = 57.295779513082f;
+    double re = 1.866025 * 6.371e+6 / (double)d60, re2 = re * re;
+    double rlat = 0.0, rlon = 0.0;                       /* the Fortran keeps them across iterations (x1 = y1 = 0 sets both) */
+    for (int i = 0; i < n; i++) {
+        double x1 = (double)(float)(x[i] - pi), y1 = (double)(float)(y[i] - pj);
+        if (x1 == 0. && y1 == 0.) { rlat = 90.0; rlon = 0.0; }
+        if (x1 == 0.0) rlon = copysign(90.0, y1);
+        if (x1 != 0.0) rlon = atan(y1 / x1) * (double)rdtodg;
+        if (x1 < 0.0) rlon = rlon + copysign(180.0, y1);
+        rlon = rlon - (double)dgrw;
+        if (rlon < 0.0) rlon = rlon + 3.6e2;
+        double r2 = x1 * x1 + y1 * y1;
+        rlat = (re2 - r2) / (re2 + r2);
+        rlat = fmax(-1.0, fmin(rlat, 1.0));
+        rlat = asin(rlat) * (double)rdtodg;
+        if (nhem == 2) { rlat = -rlat; rlon = -rlon; if (rlon < 0.0) rlon = rlon + 360.0; }
+        dlat[i] = (float)rlat; dlon[i] = (float)rlon;
+    }
+}
+/* c_gdllfxy_new (gdllfxy.c:92-260), host only: grid coordinates -> lat, lon */
+static int gdllfxy_one(const ezh_grid *g, float *lat, float *lon, const float *x, const float *y, int n)
+{
+    switch (g->grtyp) {
+    case 'A': case 'B': case 'L':
+        for (int i = 0; i < n; i++) {
+            lat[i] = (float)(((double)y[i] - 1.0) * (double)g->xg[2] + (double)g->xg[0]);
+            lon[i] = (float)(((double)x[i] - 1.0) * (double)g->xg[3] + (double)g->xg[1]);
+            lon[i] = (float)fmod((double)lon[i] + 360.0, 360.0);
+        }
+        return 0;
+    case 'E': {
+        float *tx = (float *)malloc(sizeof(float) * (size_t)(n + 1)), *ty = (float *)malloc(sizeof(float) * (size_t)(n + 1));
+        float dlat = (float)(180.0 / g->nj), dlon = (float)(360.0 / (g->ni - 1));
+        float swlat = (float)(-90.0 + 0.5 * (double)dlat), swlon = 0.0f;
+        for (int i = 0; i < n; i++) { tx[i] = (float)(((double)x[i] - 1.0) * (double)dlon + (double)swlon); ty[i] = (float)(((double)y[i] - 1.0) * (double)dlat + (double)swlat); }
+        h_rotate(lon, lat, tx, ty, n, g->xg, 0);
+        free(tx); free(ty);
+        return 0;
+    }
+    case 'N': case 'S':
+        h_vllfxy(lat, lon, x, y, n, g->xg[2], g->xg[3], g->xg[0], g->xg[1], g->grtyp == 'N' ? 1 : 2);
+        for (int i = 0; i < n; i++) lon[i] = (float)fmod((double)lon[i] + 360.0, 360.0);
+        return 0;
+    case 'Y': fprintf(stderr, "<gdllfxy>: This operation is not supported for 'Y' grids\n"); return 0;
+    case 'Z': case 'G': {
+        float *tx = (float *)malloc(sizeof(float) * (size_t)(n + 1)), *ty = (float *)malloc(sizeof(float) * (size_t)(n + 1));
+        for (int i = 0; i < n; i++) {
+            int indx = (int)x[i] - 1, indy = (int)y[i] - 1;
+            indx = indx < 0 ? 0 : indx; indy = indy < 0 ? 0 : indy;
+            indx = indx > g->ni - 2 ? g->ni - 2 : indx; indy = indy > g->j2 - 2 ? g->j2 - 2 : indy;
+            float delxx = g->ax[indx + 1] - g->ax[indx];
+            tx[i] = (float)((double)g->ax[indx] + (((double)x[i] - 1.0 - indx) * (double)delxx));
+            float delyy = g->ay[indy + 1] - g->ay[indy];
+            ty[i] = (float)((double)g->ay[indy] + (((double)y[i] - 1.0 - indy) * (double)delyy));
+        }
+        if (g->grref == 'E') h_rotate(lon, lat, tx, ty, n, g->xgref, 0);
+        else for (int i = 0; i < n; i++) {
+            lat[i] = ty[i] * g->xgref[2] + g->xgref[0];                                       /* float arithmetic in the C source (:244-245) */
+            lon[i] = tx[i] * g->xgref[3] + g->xgref[1];
+            lon[i] = (float)fmod((double)lon[i] + 360.0, 360.0);
+        }
+        free(tx); free(ty);
+        return 0;
+    }
+    }
+    return -1;
+}
+int32_t c_gdllfxy(int32_t gdid, float *lat, float *lon, float *x, float *y, int32_t n)
+{
+    if (!grid_ok(gdid)) return -1;
+    ezh_grid *g = &G[gdid];
+    if (g->nsub > 0) { fprintf(stderr, "<gdllfxy> 'U' grids are outside the MI355X hot-path scope here\n"); return -1; }
+    return gdllfxy_one(g, lat, lon, x, y, n);
+}
+/* c_gdxywdval (gdxywdval.c:38-110) / c_gdllwdval (gdllwdval.c:36-100): interpolated winds at points as speed / direction */
+int32_t c_gdxywdval(int32_t gdin, float *uuout, float *vvout, float *uuin, float *vvin, float *x, float *y, int32_t n)
+{
+    if (!grid_ok(gdin) || n < 0) return -1;
+    if (G[gdin].nsub > 0) { fprintf(stderr, "<gdxywdval> 'U' grids are outside the MI355X hot-path scope here\n"); return -1; }
+    size_t nb = sizeof(float) * (size_t)(n > 0 ? n : 1);
+    float *tlat = (float *)malloc(nb), *tlon = (float *)malloc(nb), *tu = (float *)malloc(nb), *tv = (float *)malloc(nb);
+    int rc = c_gdxyvval(gdin, tu, tv, uuin, vvin, x, y, n);
+    if (rc >= 0) rc = c_gdllfxy(gdin, tlat, tlon, x, y, n);
+    if (rc >= 0) rc = c_gdwdfuv(gdin, uuout, vvout, tu, tv, tlat, tlon, n);
+    free(tlat); free(tlon); free(tu); free(tv);
+    return rc < 0 ? -1 : 0;
+}
+int32_t c_gdllwdval(int32_t gdid, float *uuout, float *vvout, float *uuin, float *vvin, float *lat, float *lon, int32_t n)
+{
+    if (!grid_ok(gdid) || n < 0) return -1;
+    if (G[gdid].nsub > 0) { fprintf(stderr, "<gdllwdval> 'U' grids are outside the MI355X hot-path scope here\n"); return -1; }
+    if (c_gdllvval(gdid, uuout, vvout, uuin, vvin, lat, lon, n) < 0) return -1;           /* gdllwdval.c:79-80 */
+    size_t nb = sizeof(float) * (size_t)(n > 0 ? n : 1);
+    float *s = (float *)malloc(nb), *d = (float *)malloc(nb);
+    int rc = c_gdwdfuv(gdid, s, d, uuout, vvout, lat, lon, n);
+    if (rc >= 0) { memcpy(uuout, s, sizeof(float) * (size_t)n); memcpy(vvout, d, sizeof(float) * (size_t)n); }
+    free(s); free(d);
+    return rc < 0 ? -1 : 0;
+}
+
 /* c_gdwdfuv (gdwdfuv.c:29-110): grid components at (lat, lon) -> speed, direction; c_gduvfwd (gduvfwd.c:29-96): back */
 static int wind_conv_dev(int32_t gdid, float *d_a, float *d_b, const float *d_lat, const float *d_lon, int32_t npts, int to_wd)
 {

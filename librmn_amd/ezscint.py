@@ -25,6 +25,7 @@ def _lib():
         L.c_ezsetival.argtypes = [cp, i32]
         L.c_ezsint.argtypes = [vp, vp]
         L.c_gdwdfuv.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32]; L.c_gduvfwd.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32]
+        L.c_gdllfxy.argtypes = [i32, vp, vp, vp, vp, i32]; L.c_gdxywdval.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32]; L.c_gdllwdval.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32]
         L.c_gdxyzfll.argtypes = [i32, vp, vp, vp, vp, i32]; L.c_ezgdef_fll.argtypes = [i32, i32, vp, vp]
         L.c_ezget_nsubgrids.argtypes = [i32]; L.c_ezget_subgridids.argtypes = [i32, vp]
         L.c_gdsetmask.argtypes = [i32, vp]; L.c_gdgetmask.argtypes = [i32, vp]
@@ -276,3 +277,24 @@ def ezget_subgridids(gdid):
     ids = np.zeros(4, np.int32)
     n = _lib().c_ezget_subgridids(gdid, ids.ctypes.data)
     return n, ids[:max(n, 0)]
+
+
+def gdllfxy(gdid, x, y):
+    x = np.ascontiguousarray(x, dtype=np.float32); y = np.ascontiguousarray(y, dtype=np.float32)
+    lat = np.zeros_like(x); lon = np.zeros_like(x)
+    rc = _lib().c_gdllfxy(gdid, lat.ctypes.data, lon.ctypes.data, x.ctypes.data, y.ctypes.data, x.size)
+    return rc, lat, lon
+
+
+def gdxywdval(gdid, uuin, vvin, x, y):
+    a = [np.ascontiguousarray(v, dtype=np.float32) for v in (uuin, vvin, x, y)]
+    s = np.zeros_like(a[2]); d = np.zeros_like(a[2])
+    rc = _lib().c_gdxywdval(gdid, s.ctypes.data, d.ctypes.data, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, a[2].size)
+    return rc, s, d
+
+
+def gdllwdval(gdid, uuin, vvin, lat, lon):
+    a = [np.ascontiguousarray(v, dtype=np.float32) for v in (uuin, vvin, lat, lon)]
+    s = np.zeros_like(a[2]); d = np.zeros_like(a[2])
+    rc = _lib().c_gdllwdval(gdid, s.ctypes.data, d.ctypes.data, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, a[2].size)
+    return rc, s, d

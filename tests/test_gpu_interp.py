@@ -589,3 +589,33 @@ def test_gdwdfuv_gduvfwd_match_oracle(kind):
         assert np.all(np.abs(gu - wu) <= tol) and np.all(np.abs(gv - wv) <= tol)
     else:
         assert ez.gduvfwd(g, ws, wd, lat, lon)[0] == -1                # rotated targets: refused
+
+
+@pytest.mark.parametrize("kind", ["L", "N", "ZE", "G"])
+def test_gdxywdval_gdllwdval_match_oracle(kind):
+    """c_gdxywdval = c_gdxyvval + c_gdllfxy + c_gdwdfuv, c_gdllwdval = c_gdllvval + c_gdwdfuv (gdxywdval.c:38, gdllwdval.c:36)"""
+    import test_oracle_golden as tog
+    spec = {"L": (40, 20, "L", (900, 900, 450, 0), " ", None), "N": (101, 91, "N", ec.N_IG, " ", None),
+            "ZE": (65, 32, "Z", ec.E_IG, "E", ec.ze_axes), "G": (64, 32, "G", (0, 0, 0, 0), " ", None)}[kind]
+    ni, nj = spec[:2]
+    g = hip_define(spec); og = tog.orc_define(spec)
+    O = ol.oracle()
+    n = 500
+    x = (ec.hash_uniform(35, n).astype(np.float64) * (ni - 3.0) + 2.0).astype(np.float32)
+    y = (ec.hash_uniform(36, n).astype(np.float64) * (nj - 3.0) + 2.0).astype(np.float32)
+    uu, vv = ec.synth_wind(ni, nj, seed=9)
+    if spec[2] == "Z":
+        for a in (uu, vv):
+            a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+    setopts(3, 1)
+    rc, lat, lon = ez.gdllfxy(g, x, y)
+    assert rc == 0
+    iu = np.zeros(n, np.float32); iv = np.zeros(n, np.float32); ws = np.zeros(n, np.float32); wd = np.zeros(n, np.float32)
+    O.orc_gdinterp(og, 3, ol.fptr(iu), ol.fptr(uu), ol.fptr(x), ol.fptr(y), n)
+    O.orc_gdinterp(og, 3, ol.fptr(iv), ol.fptr(vv), ol.fptr(x), ol.fptr(y), n)
+    O.orc_gdwdfuv(og, ol.fptr(ws), ol.fptr(wd), ol.fptr(iu), ol.fptr(iv), ol.fptr(lat), ol.fptr(lon), n)
+    for rc, gs, gd in (ez.gdxywdval(g, uu, vv, x, y), ez.gdllwdval(g, uu, vv, lat, lon)):
+        assert rc == 0
+        assert np.all(np.abs(gs - ws) <= 2e-5 * np.maximum(ws, 1e-2)), float(np.abs(gs - ws).max())
+        ddir = np.abs(((gd - wd + 180.0) % 360.0) - 180.0)
+        assert np.all(ddir[ws > 1e-2] <= 5e-3), float(ddir.max())

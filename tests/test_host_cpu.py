@@ -141,3 +141,33 @@ def test_gdxyzfll_vs_reference():
         xr = np.zeros(n, np.float32); yr = np.zeros(n, np.float32); lo2 = lon.copy()
         L.c_gdxyzfll(gr, rl.fptr(xr), rl.fptr(yr), rl.fptr(lat.copy()), rl.fptr(lo2), n)
         assert rc == 0 and np.array_equal(x.view(np.uint32), xr.view(np.uint32)) and np.array_equal(y.view(np.uint32), yr.view(np.uint32))
+
+
+def test_gdllfxy_vs_reference():
+    """c_gdllfxy (host only), every supported grid type, against the reference build: bit-exact"""
+    import reflib as rl
+    if not rl.have_ref():
+        pytest.skip("oracle/_ref/libezref.so not built")
+    L = rl.ref()
+    n = 600
+    ax, ay = ec.ze_axes(65, 32)
+    specs = {"ZE": (65, 32, lambda: ez.ezgdef_fmem(65, 32, "Z", "E", *ec.E_IG, ax, ay), lambda: L.c_ezgdef_fmem(65, 32, b"Z", b"E", *ec.E_IG, rl.fptr(ax), rl.fptr(ay))),
+             "N": (101, 91, lambda: ez.ezqkdef(101, 91, "N", *ec.N_IG), lambda: L.c_ezqkdef(101, 91, b"N", *ec.N_IG, 0)),
+             "S": (81, 121, lambda: ez.ezqkdef(81, 121, "S", *ec.S_IG), lambda: L.c_ezqkdef(81, 121, b"S", *ec.S_IG, 0)),
+             "L": (40, 20, lambda: ez.ezqkdef(40, 20, "L", 900, 900, 450, 0), lambda: L.c_ezqkdef(40, 20, b"L", 900, 900, 450, 0, 0)),
+             "A": (48, 24, lambda: ez.ezqkdef(48, 24, "A", 0, 0, 0, 0), lambda: L.c_ezqkdef(48, 24, b"A", 0, 0, 0, 0, 0)),
+             "B": (49, 25, lambda: ez.ezqkdef(49, 25, "B", 0, 0, 0, 0), lambda: L.c_ezqkdef(49, 25, b"B", 0, 0, 0, 0, 0)),
+             "G": (64, 32, lambda: ez.ezqkdef(64, 32, "G", 0, 0, 0, 0), lambda: L.c_ezqkdef(64, 32, b"G", 0, 0, 0, 0, 0)),
+             "E": (41, 20, lambda: ez.ezqkdef(41, 20, "E", *ec.E_IG), lambda: L.c_ezqkdef(41, 20, b"E", *ec.E_IG, 0))}
+    for name, (ni, nj, mine, theirs) in specs.items():
+        x = (ec.hash_uniform(25, n).astype(np.float64) * (ni + 1.0) - 0.5).astype(np.float32)
+        y = (ec.hash_uniform(26, n).astype(np.float64) * (nj + 1.0) - 0.5).astype(np.float32)
+        x[0] = 1.0; y[0] = 1.0; x[1] = float(ni); y[1] = float(nj)
+        if name == "N":
+            x[2] = ec.N_IG[1] * 0.1; y[2] = ec.N_IG[0] * 0.1      # the pole itself (pi, pj)
+        g = mine(); gr = theirs()
+        rc, lat, lon = ez.gdllfxy(g, x, y)
+        latr = np.zeros(n, np.float32); lonr = np.zeros(n, np.float32)
+        L.c_gdllfxy(gr, rl.fptr(latr), rl.fptr(lonr), rl.fptr(x.copy()), rl.fptr(y.copy()), n)
+        assert rc == 0 and np.array_equal(lat.view(np.uint32), latr.view(np.uint32)), (name, int((lat != latr).sum()))
+        assert np.array_equal(lon.view(np.uint32), lonr.view(np.uint32)), (name, int((lon != lonr).sum()))
