@@ -36,11 +36,11 @@
 extern "C" void *ezhip_get_stream(void);
 #define STREAM ((hipStream_t)ezhip_get_stream())
 
-#define DW        2048                  /* bits per window */
+#define DW        1024                  /* bits per window (measured: 512 -> 40 ms, 1024 -> 24 ms, 2048 -> 27 ms, 4096 worse, before the 8-window table) */
 #define DWW       (DW / 32)
 #define DEXT      416                   /* table entries per window: >= the longest tile (MINIMUM: 4 + 25 x 16 bits) */
 #define DTAIL     16                    /* stream words staged past a window (>= DEXT + 32 bits) */
-#define HOP_TPB   256
+#define HOP_TPB   1024
 #define HOP_LDS   (96 * 1024)
 
 struct DecGeom {
@@ -127,6 +127,28 @@ __global__ __launch_bounds__(256) void k_armn_dec_spec(const unsigned *z_all, si
     }
 }
 
+/* tab8[w][e]: the same pair after EIGHT windows starting at window w (exit offset into window w + 8, tiles seen);
+ * tiles = 0xFFFF marks "not usable" (the table would run past the last window or the count does not fit) */
+__global__ __launch_bounds__(256) void k_armn_dec_compose(const unsigned *z_all, size_t z_stride, int ni, int nj,
+                                                          const unsigned *tab_all, unsigned *tab8_all, size_t tab_stride, int nwin)
+{
+    const int f = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
+    DecGeom g;
+    if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj)) return;
+    const unsigned *tab = tab_all + (size_t)f * tab_stride;
+    unsigned *tab8 = tab8_all + (size_t)f * tab_stride + (size_t)w * DEXT;
+    for (int e0 = tid; e0 < g.ext; e0 += 256) {
+        unsigned e = (unsigned)e0, cnt = 0;
+        bool ok = w + 8 <= nwin;
+        for (int k = 0; k < 8 && ok; k++) {
+            const unsigned v = tab[(size_t)(w + k) * DEXT + e];
+            cnt += v >> 16; e = v & 0xFFFFu;
+            if (e >= (unsigned)g.ext || cnt >= 0xFFFFu) ok = false;
+        }
+        tab8[e0] = ok ? (e | cnt << 16) : 0xFFFF0000u;
+    }
+}
+
 __device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
 /* 32-bit twin of dec_run for the serial walker (tile counts are < 2^31, checked by the host) */
@@ -144,7 +166,8 @@ __device__ __forceinline__ void dec_run32(const DecGeom &g, unsigned t, int &n, 
  * The walk runs on wave 0 with every value forced wave-uniform (readfirstlane), i.e. on the scalar unit: one lane of
  * vector code costs ~10 clk per dependent instruction, scalar code about half of that and its branches are free. */
 __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
-                                                          const unsigned *tab_all, size_t tab_stride, unsigned *went_all, size_t went_stride,
+                                                          const unsigned *tab_all, const unsigned *tab8_all, size_t tab_stride,
+                                                          unsigned *went_all, unsigned *went8_all, size_t went_stride,
                                                           int nwin, int *status, int dbg)
 {
     extern __shared__ unsigned lds[];
@@ -155,12 +178,13 @@ __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all,
     if (!dec_geom(g, z, ni, nj)) { if (tid == 0) status[f] = -1; return; }
     const unsigned *z1 = z + 1;
     const size_t nwords = z_words - 1;
-    const unsigned *tab = tab_all + (size_t)f * tab_stride;
-    unsigned *went = went_all + (size_t)f * went_stride;
+    const unsigned *tab = tab_all + (size_t)f * tab_stride, *tab8 = tab8_all + (size_t)f * tab_stride;
+    unsigned *went = went_all + (size_t)f * went_stride, *went8 = went8_all + (size_t)f * went_stride;
     const int ext = (int)uni((unsigned)g.ext), C = (int)uni((unsigned)g.C), n_int = g.n_int;
     const unsigned ntiles = uni((unsigned)g.ntiles);
-    const int nb = (HOP_LDS / 4 - DTAIL) / (ext + DWW + 2);            /* windows per staged batch */
-    unsigned *tabs = lds, *strm = lds + (size_t)nb * ext, *wl = strm + (size_t)nb * DWW + DTAIL;
+    const int ext4 = (ext + 3) & ~3, cpr = ext4 >> 2;                  /* LDS row stride (words), 16-byte chunks per row */
+    const int nb = (HOP_LDS / 4 - DTAIL) / (2 * ext4 + DWW + 4);       /* windows per staged batch */
+    unsigned *tabs = lds, *tabs8 = lds + (size_t)nb * ext4, *strm = tabs8 + (size_t)nb * ext4, *wl = strm + (size_t)nb * DWW + DTAIL, *wl8 = wl + 2 * nb;
     if (tid == 0) { s_pos = g.body; s_t = 0; s_done = 0; }
     __syncthreads();
     for (;;) {
@@ -168,31 +192,38 @@ __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all,
         const int b0 = (int)(pos0 / DW);
         if (s_done || b0 >= nwin) break;
         const int nbw = min(nb, nwin - b0);
-        /* staging: 16 independent loads in flight per thread (a lone workgroup is latency-bound) */
-        for (int e = tid; e < ext; e += HOP_TPB) {
-            int w0 = 0;
-            for (; w0 + 16 <= nbw; w0 += 16) {
-                unsigned r[16];
+        /* staging: a lone workgroup is latency-bound (bytes in flight / latency), so every thread issues up to 16
+         * independent 16-byte loads before the first store: lane = 16-byte chunk of a row, 8 rows per pass, 8 passes */
+        for (int row0 = 0; row0 < nbw; row0 += 8 * 8) {
+            uint4 r[8], r8[8];
+            const int ch = tid & 127, rl = tid >> 7;
 #pragma unroll
-                for (int k = 0; k < 16; k++) r[k] = tab[(size_t)(b0 + w0 + k) * DEXT + e];
-#pragma unroll
-                for (int k = 0; k < 16; k++) tabs[(w0 + k) * ext + e] = r[k];
+            for (int k = 0; k < 8; k++) {
+                const int row = min(row0 + 8 * k + rl, nbw - 1), chc = min(ch, cpr - 1);      /* unconditional (clamped): the loads must all be in flight together */
+                r[k] = *(const uint4 *)(tab + (size_t)(b0 + row) * DEXT + 4 * chc);
+                r8[k] = *(const uint4 *)(tab8 + (size_t)(b0 + row) * DEXT + 4 * chc);
             }
-            for (; w0 < nbw; w0++) tabs[w0 * ext + e] = tab[(size_t)(b0 + w0) * DEXT + e];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int row = row0 + 8 * k + rl;
+                if (ch < cpr && row < nbw) { *(uint4 *)(tabs + (size_t)row * ext4 + 4 * ch) = r[k]; *(uint4 *)(tabs8 + (size_t)row * ext4 + 4 * ch) = r8[k]; }
+            }
         }
-        {
+        {   /* stream words of the batch (+ tail): clamped unconditional loads, zero past the end of the stream */
             const int total = nbw * DWW + DTAIL;
-            int k0 = 0;
-            for (; k0 + 16 * HOP_TPB <= total; k0 += 16 * HOP_TPB) {
-                unsigned r[16];
+            for (int k0 = 0; k0 < total; k0 += 4 * HOP_TPB) {
+                unsigned r[4];
 #pragma unroll
-                for (int k = 0; k < 16; k++) r[k] = gword(z1, (size_t)b0 * DWW + k0 + k * HOP_TPB + tid, nwords);
+                for (int k = 0; k < 4; k++) {
+                    const size_t w = (size_t)b0 * DWW + (size_t)min(k0 + k * HOP_TPB + tid, total - 1);
+                    const unsigned v = z1[w < nwords ? w : nwords - 1];
+                    r[k] = w < nwords ? v : 0u;
+                }
 #pragma unroll
-                for (int k = 0; k < 16; k++) strm[k0 + k * HOP_TPB + tid] = r[k];
+                for (int k = 0; k < 4; k++) if (k0 + k * HOP_TPB + tid < total) strm[k0 + k * HOP_TPB + tid] = r[k];
             }
-            for (int k = k0 + tid; k < total; k += HOP_TPB) strm[k] = gword(z1, (size_t)b0 * DWW + k, nwords);
         }
-        for (int k = tid; k < 2 * nbw; k += HOP_TPB) wl[k] = 0xFFFFFFFFu;
+        for (int k = tid; k < 2 * nbw; k += HOP_TPB) { wl[k] = 0xFFFFFFFFu; wl8[k] = 0xFFFFFFFFu; }
         __syncthreads();
         if (dbg & 1) { if (tid == 0) { s_pos = (unsigned)(b0 + nbw) * DW; } __syncthreads(); continue; }
         if (tid < 64) {
@@ -207,7 +238,16 @@ __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all,
                 const unsigned e = pos - w * DW, wr = w - (unsigned)b0;
                 wl[2 * wr] = e; wl[2 * wr + 1] = t;
                 if (e < (unsigned)ext && n == n_int) {
-                    const unsigned v = uni(tabs[wr * (unsigned)ext + e]), cnt = v >> 16;
+                    if (wr + 8 <= (unsigned)nbw) {                       /* eight windows at once when no point-count change lies within */
+                        const unsigned v8 = uni(tabs8[wr * (unsigned)ext4 + e]), cnt8 = v8 >> 16;
+                        if (cnt8 != 0xFFFFu && cnt8 <= run) {
+                            wl8[2 * wr] = e; wl8[2 * wr + 1] = t;
+                            pos = (w + 8) * DW + (v8 & 0xFFFFu); t += cnt8; run -= cnt8;
+                            if (run == 0 && t < ntiles) { dec_run32(g, t, n, run); n = (int)uni((unsigned)n); run = uni(run); }
+                            continue;
+                        }
+                    }
+                    const unsigned v = uni(tabs[wr * (unsigned)ext4 + e]), cnt = v >> 16;
                     if (cnt <= run) {
                         pos = (w + 1) * DW + (v & 0xFFFFu); t += cnt; run -= cnt;
                         if (run == 0 && t < ntiles) { dec_run32(g, t, n, run); n = (int)uni((unsigned)n); run = uni(run); }
@@ -227,9 +267,30 @@ __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all,
             if (tid == 0) { s_pos = pos; s_t = t; if (t >= ntiles) s_done = 1; }
         }
         __syncthreads();
-        for (int k = tid; k < 2 * nbw; k += HOP_TPB) went[2 * (size_t)b0 + k] = wl[k];
+        for (int k = tid; k < 2 * nbw; k += HOP_TPB) { went[2 * (size_t)b0 + k] = wl[k]; went8[2 * (size_t)b0 + k] = wl8[k]; }
     }
     if (tid == 0) status[f] = s_done ? 0 : -2;
+}
+
+/* the seven windows an eight-window hop jumped over: their entries follow from the one-window table */
+__global__ __launch_bounds__(256) void k_armn_dec_expand8(const unsigned *z_all, size_t z_stride, int ni, int nj, const unsigned *tab_all, size_t tab_stride,
+                                                          unsigned *went_all, const unsigned *went8_all, size_t went_stride, int nwin)
+{
+    const int f = blockIdx.y;
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nwin) return;
+    DecGeom g;
+    if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj)) return;
+    const unsigned *went8 = went8_all + (size_t)f * went_stride, *tab = tab_all + (size_t)f * tab_stride;
+    unsigned *went = went_all + (size_t)f * went_stride;
+    unsigned e = went8[2 * (size_t)w];
+    if (e == 0xFFFFFFFFu) return;
+    unsigned t = went8[2 * (size_t)w + 1];
+    for (int k = 0; k < 8 && w + k < nwin; k++) {
+        went[2 * (size_t)(w + k)] = e; went[2 * (size_t)(w + k) + 1] = t;
+        const unsigned v = tab[(size_t)(w + k) * DEXT + e];
+        t += v >> 16; e = v & 0xFFFFu;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_armn_dec_emit(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
@@ -392,7 +453,7 @@ static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" size_t packhip_armn_dec_work_bytes(int ni, int nj, size_t z_words)
 {
     const size_t n = (size_t)ni * nj, nwin = dec_nwin(z_words);
-    return al256(4 * dec_max_tiles(ni, nj)) + al256(2 * (n + 8)) + al256(2 * (size_t)DEC_BANDS * ni) + al256(4 * nwin * DEXT) + al256(8 * nwin) + 256;
+    return al256(4 * dec_max_tiles(ni, nj)) + al256(2 * (n + 8)) + al256(2 * (size_t)DEC_BANDS * ni) + 2 * al256(4 * nwin * DEXT) + 2 * al256(8 * nwin) + 256;
 }
 
 /* d_out: (1 + ni*nj/2) words per field, zero-filled first (the odd trailing half-word).  d_status: one int per field
@@ -416,14 +477,19 @@ extern "C" int packhip_armn_decode(unsigned *d_out, size_t out_stride_words, con
     unsigned short *d16 = (unsigned short *)wk;             wk += al256(2 * (n + 8));
     unsigned short *part = (unsigned short *)wk;            wk += al256(2 * (size_t)DEC_BANDS * ni);
     unsigned *tab = (unsigned *)wk;                         wk += al256(4 * (size_t)nwin * DEXT);
-    unsigned *went = (unsigned *)wk;
+    unsigned *tab8 = (unsigned *)wk;                        wk += al256(4 * (size_t)nwin * DEXT);
+    unsigned *went = (unsigned *)wk;                        wk += al256(8 * (size_t)nwin);
+    unsigned *went8 = (unsigned *)wk;
     const size_t ws4 = work_stride_bytes / 4, ws2 = work_stride_bytes / 2;
     for (int f = 0; f < nfields; f++) {
         if (hipMemsetAsync(d_out + (size_t)f * out_stride_words, 0, 4 * (1 + n / 2), st) != hipSuccess) return -1;
         if (hipMemsetAsync((char *)went + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
+        if (hipMemsetAsync((char *)went8 + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
     }
     hipLaunchKernelGGL(k_armn_dec_spec, dim3(nwin, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, tab, ws4, nwin);
-    hipLaunchKernelGGL(k_armn_dec_hop, dim3(nfields), dim3(HOP_TPB), HOP_LDS, st, d_z, z_stride_words, z_words, ni, nj, tab, ws4, went, ws4, nwin, d_status, getenv("EZHIP_DEC_DEBUG") ? atoi(getenv("EZHIP_DEC_DEBUG")) : 0);
+    hipLaunchKernelGGL(k_armn_dec_compose, dim3(nwin, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, tab8, ws4, nwin);
+    hipLaunchKernelGGL(k_armn_dec_hop, dim3(nfields), dim3(HOP_TPB), HOP_LDS, st, d_z, z_stride_words, z_words, ni, nj, tab, tab8, ws4, went, went8, ws4, nwin, d_status, getenv("EZHIP_DEC_DEBUG") ? atoi(getenv("EZHIP_DEC_DEBUG")) : 0);
+    hipLaunchKernelGGL(k_armn_dec_expand8, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, ws4, went, went8, ws4, nwin);
     hipLaunchKernelGGL(k_armn_dec_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, went, ws4, tilepos, ws4, nwin);
     const long long grid_tiles = max_tiles > (long long)(ni + nj) ? max_tiles : (long long)(ni + nj);
     hipLaunchKernelGGL(k_armn_dec_tiles, dim3((unsigned)((grid_tiles + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj,
