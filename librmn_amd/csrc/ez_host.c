@@ -594,10 +594,6 @@ static ezh_set *find_set(int gdout, int gdin, int create)
 int32_t c_ezdefset(int32_t gdout, int32_t gdin)     /* ezdefset.c:38-171 */
 {
     if (!grid_ok(gdout) || !grid_ok(gdin)) { fprintf(stderr, "<c_ezdefset> invalid grid id\n"); return -1; }
-    if (G[gdout].grtyp == 'U') {
-        fprintf(stderr, "<c_ezdefset> a Yin-Yang 'U' grid as TARGET is outside the MI355X hot-path scope (interpolate to its two subgrids)\n");
-        return -1;
-    }
     if (G[gdin].grtyp == 'Y') {       /* the reference interpolates FROM a cloud with its cloud_interp_alg (gdinterp.c:207-230): not on this path */
         fprintf(stderr, "<c_ezdefset> a 'Y' cloud as SOURCE grid is outside the MI355X hot-path scope\n");
         return -1;
@@ -822,6 +818,11 @@ int32_t c_gdll(int32_t gd, float *lat, float *lon)
 {
     if (!grid_ok(gd)) return -1;
     ezh_grid *g = &G[gd];
+    if (g->nsub > 0) {                                     /* gdll.c:46-70: Yin then Yang */
+        size_t nsub = (size_t)G[g->sub[0]].ni * G[g->sub[0]].nj;
+        if (c_gdll(g->sub[0], lat, lon)) return -1;
+        return c_gdll(g->sub[1], lat + nsub, lon + nsub);
+    }
     ensure_coords(g);
     size_t n = (size_t)g->ni * g->nj;
     if (g->separable) {
@@ -1473,7 +1474,7 @@ static ezh_set *current_set(const char *who)
     }
     pthread_mutex_lock(&g_mtx);
     ezh_set *s = find_set(cur_gdout, cur_gdin, 1);
-    if (!s->x1d && !s->d_x && G[cur_gdin].grtyp != 'U') analyse_set(s);
+    if (!s->x1d && !s->d_x && G[cur_gdin].grtyp != 'U' && G[cur_gdout].grtyp != 'U') analyse_set(s);
     pthread_mutex_unlock(&g_mtx);
     return s;
 }
@@ -1609,6 +1610,7 @@ int32_t ezhip_available(void) { return ezhip_runtime_ok(); }
 
 static int yy_plan(ezh_set *s);
 static int32_t yy_sint(ezh_set *s, float *d_zout, const float *d_zin);
+static int32_t yy_sint_to_u(ezh_set *s, float *d_zout, const float *d_zin);
 static int32_t yy_uvint(ezh_set *s, float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin, int wd_only);
 
 int32_t c_ezsint_dev(float *d_zout, const float *d_zin)
@@ -1616,6 +1618,7 @@ int32_t c_ezsint_dev(float *d_zout, const float *d_zin)
     ezh_set *s = current_set("c_ezsint");
     if (!s) return -1;
     if (need_device("c_ezsint")) return -1;
+    if (G[s->gdout].grtyp == 'U') return yy_sint_to_u(s, d_zout, d_zin);
     if (G[s->gdin].grtyp == 'U') return yy_sint(s, d_zout, d_zin);
     if (s->gdin == s->gdout) { ezhip_d2d(d_zout, d_zin, sizeof(float) * (size_t)G[s->gdin].ni * G[s->gdin].nj); return 1; }
     return run_field(s, d_zout, d_zin, 0, NULL, NULL);
@@ -1641,9 +1644,13 @@ static int32_t batch_impl(float *d_zout, const float *d_zin, int32_t nfields, un
     if (need_device("c_ezsint_batch")) return -1;
     size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
     int rc = 0;
-    if (G[s->gdin].grtyp == 'U') {                              /* Yin-Yang source: field by field */
+    if (G[s->gdin].grtyp == 'U' || G[s->gdout].grtyp == 'U') {  /* Yin-Yang source or target: field by field */
         if (stat_partials) return -1;
-        for (int f = 0; f < nfields; f++) { int r = yy_sint(s, d_zout + f * nout, d_zin + f * nin); if (r < 0) return r; if (r > rc) rc = r; }
+        for (int f = 0; f < nfields; f++) {
+            int r = G[s->gdout].grtyp == 'U' ? yy_sint_to_u(s, d_zout + f * nout, d_zin + f * nin) : yy_sint(s, d_zout + f * nout, d_zin + f * nin);
+            if (r < 0) return r;
+            if (r > rc) rc = r;
+        }
         return rc;
     }
     /* separable plan without extrapolation fill: ALL fields in one k_sepx launch (no ramp-up / drain gap between
@@ -1716,6 +1723,7 @@ int32_t ezhip_prepare_set(void)
     ezh_set *s = current_set("ezhip_prepare_set");
     if (!s) return -1;
     if (need_device("ezhip_prepare_set")) return -1;
+    if (G[s->gdout].grtyp == 'U') return 0;
     if (G[s->gdin].grtyp == 'U') return yy_plan(s);
     int degree = O.degre_interp, polar = O.polar_correction == 1;
     if (choose_mode(s, degree, polar) == 1) return build_sep_plan(s, degree, 0, polar);
@@ -1739,7 +1747,7 @@ int32_t ezhip_set_mode(void)
 {
     ezh_set *s = current_set("ezhip_set_mode");
     if (!s) return -1;
-    if (G[s->gdin].grtyp == 'U') return 2;
+    if (G[s->gdin].grtyp == 'U' || G[s->gdout].grtyp == 'U') return 2;
     return choose_mode(s, O.degre_interp, O.polar_correction == 1);
 }
 
@@ -1754,9 +1762,11 @@ int32_t c_ezsint(float *zout, float *zin)               /* ezsint.c:38-135 */
     if (s->gdin == s->gdout) { memcpy(zout, zin, sizeof(float) * nin); return 1; }
     if (need_device("c_ezsint")) return -1;
     if (stage(&s->d_stage_in, nin) || stage(&s->d_stage_out, nout)) return -1;
-    if (G[s->gdin].grtyp != 'U' && ezhip_prepare_set()) return -1;
+    int yy = G[s->gdin].grtyp == 'U' || G[s->gdout].grtyp == 'U';
+    if (!yy && ezhip_prepare_set()) return -1;
     if (ezhip_h2d(s->d_stage_in, zin, sizeof(float) * nin)) return -1;
-    int rc = G[s->gdin].grtyp == 'U' ? yy_sint(s, s->d_stage_out, s->d_stage_in) : run_field(s, s->d_stage_out, s->d_stage_in, 0, NULL, NULL);
+    int rc = G[s->gdout].grtyp == 'U' ? yy_sint_to_u(s, s->d_stage_out, s->d_stage_in)
+           : G[s->gdin].grtyp == 'U' ? yy_sint(s, s->d_stage_out, s->d_stage_in) : run_field(s, s->d_stage_out, s->d_stage_in, 0, NULL, NULL);
     if (rc < 0) return rc;
     if (ezhip_d2h(zout, s->d_stage_out, sizeof(float) * nout) || ezhip_sync()) return -1;
     return rc;
@@ -1948,6 +1958,7 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
     ezh_set *s = current_set(wd_only ? "c_ezwdint" : "c_ezuvint");
     if (!s) return -1;
     if (need_device("c_ezuvint")) return -1;
+    if (G[s->gdout].grtyp == 'U') { fprintf(stderr, "<c_ezuvint> winds towards a Yin-Yang 'U' grid (rotated subgrids) are outside the MI355X hot-path scope\n"); return -1; }
     if (G[s->gdin].grtyp == 'U') return yy_uvint(s, d_uuout, d_vvout, d_uuin, d_vvin, wd_only);
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     if (go->grtyp == 'E' || (go->grtyp == 'Z' && go->grref == 'E') || go->grtyp == 'Z') {
@@ -2470,6 +2481,24 @@ static int32_t yy_sint(ezh_set *s, float *d_zout, const float *d_zin)
         if (ezhip_scatter(d_zout, s->d_yy_tmp[0], s->d_yy_idx[sub], s->yy_count[sub])) return -1;
     }
     return 0;
+}
+
+/* target = a 'U' grid (ezyysint.c:79-86 for an ordinary source, :162-230 for a 'U' source): its two subgrids are two
+ * ordinary Z-on-E targets, each with its own grid set (and, for a 'U' source, its own mask and point lists) */
+static int32_t yy_sint_to_u(ezh_set *s, float *d_zout, const float *d_zin)
+{
+    const ezh_grid *gu = &G[s->gdout];
+    const size_t nsub = (size_t)G[gu->sub[0]].ni * G[gu->sub[0]].nj;
+    const int save_in = cur_gdin, save_out = cur_gdout, gdin = s->gdin, sub0 = gu->sub[0], sub1 = gu->sub[1];
+    int rc = 0;
+    for (int k = 0; k < 2; k++) {
+        cur_gdin = gdin; cur_gdout = k ? sub1 : sub0;
+        int r = c_ezsint_dev(d_zout + k * nsub, d_zin);
+        if (r < 0) { rc = r; break; }
+        if (r == 2) rc = 2;
+    }
+    cur_gdin = save_in; cur_gdout = save_out;
+    return rc;
 }
 
 static int32_t yy_uvint(ezh_set *s, float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin, int wd_only)

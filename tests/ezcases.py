@@ -121,3 +121,13 @@ def yy_fields():
     z = np.concatenate([synth_field(YY_NI, YY_NJ, seed=3), synth_field(YY_NI, YY_NJ, seed=4)])
     (u0, v0), (u1, v1) = synth_wind(YY_NI, YY_NJ, seed=5), synth_wind(YY_NI, YY_NJ, seed=6)
     return z, np.concatenate([u0, u1]), np.concatenate([v0, v1])
+
+
+YYT_NI, YYT_NJ = 117, 45
+
+
+def yyt_axes(ni, nj):
+    """a second Yin-Yang grid (2.5 degrees, same frames) used as a TARGET: longitudes 35..325, latitudes -55..55"""
+    ax = (35.0 + 2.5 * np.arange(ni, dtype=np.float64)).astype(np.float32)
+    ay = (-55.0 + 2.5 * np.arange(nj, dtype=np.float64)).astype(np.float32)
+    return ax, ay

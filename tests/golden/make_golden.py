@@ -88,6 +88,22 @@ def main():
             zo = np.zeros(no * mo, np.float32); uo = np.zeros(no * mo, np.float32); vo = np.zeros(no * mo, np.float32)
             assert L.c_ezsint(fptr(zo), fptr(z)) == 0 and L.c_ezuvint(fptr(uo), fptr(vo), fptr(uu), fptr(vv)) == 0
             out[f"YY_to_{tname}/z_d{degree}"] = zo; out[f"YY_to_{tname}/u_d{degree}"] = uo; out[f"YY_to_{tname}/v_d{degree}"] = vo
+    # Yin-Yang TARGET: from an ordinary grid (two plain interpolations) and from another Yin-Yang grid (2.5-degree subgrids)
+    tni, tnj = ec.YYT_NI, ec.YYT_NJ
+    tax, tay = ec.yyt_axes(tni, tnj)
+    ty = L.c_ezgdef_fmem(tni, tnj, b"Z", b"E", *ec.YIN_IG, fptr(tax), fptr(tay))
+    ta = L.c_ezgdef_fmem(tni, tnj, b"Z", b"E", *ec.YAN_IG, fptr(tax), fptr(tay))
+    tids = np.array([ty, ta], np.int32)
+    tu = L.c_ezgdef_supergrid(tni, 2 * tnj, b"U", b"F", 1, 2, tids.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    gsrc = L.c_ezqkdef(64, 32, b"G", 0, 0, 0, 0, 0)
+    zg = ec.synth_field(64, 32, seed=11)
+    for degree in (0, 1, 3):
+        L.c_ezsetopt(b"interp_degree", DEG[degree]); L.c_ezsetopt(b"polar_correction", b"yes")
+        zo = np.zeros(2 * tni * tnj, np.float32)
+        assert L.c_ezdefset(tu, gsrc) == 1 and L.c_ezsint(fptr(zo), fptr(zg)) >= 0
+        out[f"G_to_YY/z_d{degree}"] = zo.copy()
+        assert L.c_ezdefset(tu, gu) == 1 and L.c_ezsint(fptr(zo), fptr(z)) >= 0
+        out[f"YY_to_YY/z_d{degree}"] = zo.copy()
     L.c_ezsetopt(b"interp_degree", b"cubic"); L.c_ezsetopt(b"polar_correction", b"yes")
     np.savez_compressed(os.path.join(HERE, "ez_golden.npz"), **out)
     print("wrote", len(out), "arrays")

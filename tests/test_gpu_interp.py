@@ -505,8 +505,40 @@ def test_yinyang_source_vs_golden(tname):
     assert ez.ezsint_batch_dev(d_out, d_in, 2) == 0
     torch.cuda.synchronize()
     assert np.array_equal(d_out[0].cpu().numpy().view(np.uint32), GOLD[f"YY_to_{tname}/z_d3"].view(np.uint32))
-    # a U grid is a source only
-    assert ez.ezdefset(gu, go) == -1
+
+
+def test_yinyang_target_vs_golden():
+    """a Yin-Yang 'U' TARGET (ezyysint.c:79-86, :162-230): from an ordinary grid = two plain interpolations to its Z-on-E
+    subgrids; from another 'U' grid = per target subgrid its own mask and point lists.  Scalars against the reference's
+    outputs; winds towards the rotated subgrids are refused."""
+    ni, nj = ec.YY_NI, ec.YY_NJ
+    ax, ay = ec.yy_axes(ni, nj)
+    gy = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.YIN_IG, ax, ay); ga = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.YAN_IG, ax, ay)
+    gu = ez.ezgdef_supergrid(ni, 2 * nj, "U", "F", 1, [gy, ga])
+    tni, tnj = ec.YYT_NI, ec.YYT_NJ
+    tax, tay = ec.yyt_axes(tni, tnj)
+    ty = ez.ezgdef_fmem(tni, tnj, "Z", "E", *ec.YIN_IG, tax, tay); ta = ez.ezgdef_fmem(tni, tnj, "Z", "E", *ec.YAN_IG, tax, tay)
+    tu = ez.ezgdef_supergrid(tni, 2 * tnj, "U", "F", 1, [ty, ta])
+    gsrc = ez.ezqkdef(64, 32, "G", 0, 0, 0, 0)
+    zg = ec.synth_field(64, 32, seed=11)
+    z, uu, vv = ec.yy_fields()
+    nout = 2 * tni * tnj
+    for degree in (0, 1, 3):
+        setopts(degree, 1)
+        assert ez.ezdefset(tu, gsrc) == 1
+        rc, got = ez.ezsint(zg, nout)
+        want = GOLD[f"G_to_YY/z_d{degree}"]
+        assert rc >= 0 and relerr(got, want).max() <= RTOL, (degree, float(relerr(got, want).max()))
+        assert ez.ezdefset(tu, gu) == 1
+        rc, got = ez.ezsint(z, nout)
+        want = GOLD[f"YY_to_YY/z_d{degree}"]
+        assert rc >= 0
+        if degree == 0:      # a nearest-neighbour pick may flip at a cell edge (device trig in the rotated locate of the G source case only)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert relerr(got, want).max() <= RTOL, (degree, float(relerr(got, want).max()))
+    rc, lat, lon = ez.gdll(tu, nout)
+    assert rc == 0 and lat.size == nout
+    assert ez.ezuvint(uu, vv, nout)[0] == -1
 
 
 def _mask_field(ni, nj, seed):

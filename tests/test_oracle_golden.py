@@ -140,3 +140,29 @@ def test_yinyang_golden(tname):
         assert O.orc_ezyyuvint(sg, go, ctypes.byref(opts), ol.fptr(uo), ol.fptr(vo), ol.fptr(uu), ol.fptr(vv)) == 0
         for got, key in ((zo, "z"), (uo, "u"), (vo, "v")):
             assert np.array_equal(got.view(np.uint32), GOLD[f"YY_to_{tname}/{key}_d{degree}"].view(np.uint32)), (tname, key, degree)
+
+
+def test_yinyang_target_golden():
+    """a Yin-Yang TARGET is its two Z-on-E subgrids taken one after the other (ezyysint.c:79-86, :162-230): the oracle's
+    composition against the reference's outputs, bit for bit"""
+    O = ol.oracle()
+    ni, nj = ec.YY_NI, ec.YY_NJ
+    ax, ay = ec.yy_axes(ni, nj)
+    tni, tnj = ec.YYT_NI, ec.YYT_NJ
+    tax, tay = ec.yyt_axes(tni, tnj)
+    z, _, _ = ec.yy_fields()
+    zg = ec.synth_field(64, 32, seed=11)
+    nsub = tni * tnj
+    for degree in (0, 1, 3):
+        opts = ol.default_opts(degre_interp=degree)
+        got_g = np.zeros(2 * nsub, np.float32); got_y = np.zeros(2 * nsub, np.float32)
+        for k, ig in enumerate((ec.YIN_IG, ec.YAN_IG)):
+            tgt = ol.grid_define(tni, tnj, "Z", ig, "E", tax, tay)
+            gs = O.orc_defset(tgt, ol.grid_define(64, 32, "G"))
+            part = np.zeros(nsub, np.float32)
+            O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(part), ol.fptr(zg)); got_g[k * nsub:(k + 1) * nsub] = part
+            sg = O.orc_supergrid_define(ol.grid_define(ni, nj, "Z", ec.YIN_IG, "E", ax, ay), ol.grid_define(ni, nj, "Z", ec.YAN_IG, "E", ax, ay))
+            tgt2 = ol.grid_define(tni, tnj, "Z", ig, "E", tax, tay)
+            O.orc_ezyysint(sg, tgt2, ctypes.byref(opts), ol.fptr(part), ol.fptr(z)); got_y[k * nsub:(k + 1) * nsub] = part
+        assert np.array_equal(got_g.view(np.uint32), GOLD[f"G_to_YY/z_d{degree}"].view(np.uint32)), degree
+        assert np.array_equal(got_y.view(np.uint32), GOLD[f"YY_to_YY/z_d{degree}"].view(np.uint32)), degree
