@@ -17,6 +17,7 @@
 #include <ctype.h>
 #include <math.h>
 #include <pthread.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -436,6 +437,28 @@ static int h_locate(const ezh_grid *g, float *x, float *y, const float *lat, flo
     return -1;
 }
 
+/* h_locate over many points: slices on host threads (the point loops are independent; first-call work such as the
+ * Yin-Yang point lists locates 3 x 25.9 M points) */
+typedef struct { const ezh_grid *g; float *x, *y; const float *lat; float *lon; int n, rc; } locate_job;
+static void *locate_worker(void *p) { locate_job *j = (locate_job *)p; j->rc = h_locate(j->g, j->x, j->y, j->lat, j->lon, j->n); return NULL; }
+static int h_locate_mt(const ezh_grid *g, float *x, float *y, const float *lat, float *lon, int n)
+{
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    int nt = (int)(ncpu > 32 ? 32 : ncpu);
+    if (n < 400000 || nt < 2) return h_locate(g, x, y, lat, lon, n);
+    pthread_t th[32]; locate_job job[32];
+    int per = (n + nt - 1) / nt, used = 0, rc = 0;
+    for (int t = 0; t < nt; t++) {
+        int o = t * per, c = n - o < per ? n - o : per;
+        if (c <= 0) break;
+        job[t] = (locate_job){g, x + o, y + o, lat + o, lon + o, c, 0};
+        if (pthread_create(&th[t], NULL, locate_worker, &job[t])) { job[t].rc = h_locate(g, x + o, y + o, lat + o, lon + o, c); th[t] = 0; }
+        used = t + 1;
+    }
+    for (int t = 0; t < used; t++) { if (th[t]) pthread_join(th[t], NULL); if (job[t].rc) rc = job[t].rc; }
+    return rc;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* grid table                                                                                   */
 /* ------------------------------------------------------------------------------------------ */
@@ -837,10 +860,10 @@ int32_t c_gdxyfll(int32_t gd, float *x, float *y, float *lat, float *lon, int32_
 {
     if (!grid_ok(gd)) return -1;
     ezh_grid *g = &G[gd];
-    if (g->grtyp == 'G' || g->grtyp == 'Z') return h_locate(g, x, y, lat, lon, n);
+    if (g->grtyp == 'G' || g->grtyp == 'Z') return h_locate_mt(g, x, y, lat, lon, n);
     float *tmp = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
     memcpy(tmp, lon, sizeof(float) * (size_t)n);
-    int rc = h_locate(g, x, y, lat, tmp, n);
+    int rc = h_locate_mt(g, x, y, lat, tmp, n);
     free(tmp);
     return rc;
 }
@@ -2430,7 +2453,7 @@ static int yy_plan(ezh_set *s)
          * value 1 that ezyymint.c:44-66 runs) is served by Yang */
         const ezh_grid *mg = &G[gu->maskgrid[0]];
         memcpy(tl, lon, sizeof(float) * (size_t)n);
-        if (h_locate(mg, x, y, lat, tl, n)) goto done;
+        if (h_locate_mt(mg, x, y, lat, tl, n)) goto done;
         for (int k = 0; k < n; k++) {
             int ix = (int)((double)x[k] + 0.5), iy = (int)((double)y[k] + 0.5);
             yang[k] = (ix < 1 || iy < 1 || ix > mg->ni || iy > mg->nj);
@@ -2441,7 +2464,7 @@ static int yy_plan(ezh_set *s)
         for (int k = 0; k < n; k++) if (yang[k] == sub) { idx[c] = k; x[c] = lat[k]; y[c] = lon[k]; c++; }      /* x, y: the list's lat, lon */
         s->yy_count[sub] = c;
         float *lx = (float *)malloc(sizeof(float) * (size_t)(c + 1)), *ly = (float *)malloc(sizeof(float) * (size_t)(c + 1));
-        h_locate(&G[gu->sub[sub]], lx, ly, x, y, c);                     /* c_gdxyfll_orig on the list */
+        h_locate_mt(&G[gu->sub[sub]], lx, ly, x, y, c);                  /* c_gdxyfll_orig on the list */
         s->d_yy_idx[sub] = (int *)upload(idx, sizeof(int) * (size_t)(c + 1));
         s->d_yy_lat[sub] = (float *)upload(x, sizeof(float) * (size_t)(c + 1));
         s->d_yy_lon[sub] = (float *)upload(y, sizeof(float) * (size_t)(c + 1));
