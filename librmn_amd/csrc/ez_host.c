@@ -2309,8 +2309,10 @@ static ezh_set *mask_set(const char *who)
     if (!s) return NULL;
     if (G[s->gdin].nsub > 0 || G[s->gdout].nsub > 0) { fprintf(stderr, "<%s> This operation is not supported for 'U' grids.\n", who); return NULL; }
     if (need_device(who)) return NULL;
-    if (ensure_points(s)) return NULL;                      /* the per-point x, y of the set (the reference reads its cached gset x, y) */
-    return s;
+    pthread_mutex_lock(&g_plan_mtx);
+    int rc = ensure_points(s);                              /* the per-point x, y of the set (the reference reads its cached gset x, y) */
+    pthread_mutex_unlock(&g_plan_mtx);
+    return rc ? NULL : s;
 }
 static int mask_dev(const char *who, int *d_mask_out, const int *d_mask_in, int mode)
 {
@@ -2437,9 +2439,17 @@ int32_t c_ezgdef_supergrid(int32_t ni, int32_t nj, char *grtyp, char *grref, int
 }
 
 /* c_ezyymint + c_ezyy_calcxy for a single target grid: host, once per set (first-call work like ez_calcxy) */
+static int yy_plan_locked(ezh_set *s);
 static int yy_plan(ezh_set *s)
 {
     if (s->yy_ready) return 0;
+    pthread_mutex_lock(&g_plan_mtx);                        /* lazily built per-set state: one builder at a time */
+    int rc = s->yy_ready ? 0 : yy_plan_locked(s);
+    pthread_mutex_unlock(&g_plan_mtx);
+    return rc;
+}
+static int yy_plan_locked(ezh_set *s)
+{
     ezh_grid *gu = &G[s->gdin], *go = &G[s->gdout];
     const int n = go->ni * go->nj;
     float *lat = (float *)malloc(sizeof(float) * (size_t)n), *lon = (float *)malloc(sizeof(float) * (size_t)n);
