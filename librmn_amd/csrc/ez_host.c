@@ -2510,8 +2510,8 @@ static int32_t yy_sint(ezh_set *s, float *d_zout, const float *d_zin)
         if (ensure_grid_dev(gs)) return -1;
         ezhip_pts_plan pp;
         fill_pts_plan(NULL, gs, &pp, degree, 0, 0);
-        if (ezhip_interp_pts(&pp, s->d_yy_tmp[0], d_zin + sub * nsub, s->d_yy_x[sub], s->d_yy_y[sub], s->yy_count[sub])) return -1;
-        if (ezhip_scatter(d_zout, s->d_yy_tmp[0], s->d_yy_idx[sub], s->yy_count[sub])) return -1;
+        pp.out_idx = s->d_yy_idx[sub];                       /* each point writes its own target position: the merge */
+        if (ezhip_interp_pts(&pp, d_zout, d_zin + sub * nsub, s->d_yy_x[sub], s->d_yy_y[sub], s->yy_count[sub])) return -1;
     }
     return 0;
 }

@@ -1294,12 +1294,13 @@ __global__ __launch_bounds__(256) void k_pts(ezhip_pts_plan p, float *__restrict
     int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= npts) return;
     const float px = xs[n], py = ys[n];
+    const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;        /* Yin-Yang point lists write straight to their target positions */
     const PlainAcc ZP{zin, p.ni, p.j1};
     const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
-    if (zone == PZ_NORMAL) zout[n] = leaf_point<KIND>(p, ZP, px, py);
-    else if (zone == PZ_FILL) zout[n] = *p.fill;
-    else if (zone == PZ_POLE_S) zout[n] = p.polevals[1];
-    else if (zone == PZ_POLE_N) zout[n] = p.polevals[0];
+    if (zone == PZ_NORMAL) zout[o] = leaf_point<KIND>(p, ZP, px, py);
+    else if (zone == PZ_FILL) zout[o] = *p.fill;
+    else if (zone == PZ_POLE_S) zout[o] = p.polevals[1];
+    else if (zone == PZ_POLE_N) zout[o] = p.polevals[0];
     /* strip / re-interpolated points: appended to the launch's list, one atomic per wave that has any */
     const bool sp = zone == PZ_REINTERP || zone == PZ_STRIP_S || zone == PZ_STRIP_N;
     const unsigned long long m = __ballot(sp);
@@ -1324,14 +1325,15 @@ __global__ __launch_bounds__(256) void k_pts_special(ezhip_pts_plan p, float *__
     for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
         const int n = special_list[k];
         const float px = xs[n], py = ys[n];
+        const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;
         const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
         FieldAcc Z;
         Z.z = zin; Z.ni = p.ni; Z.j1 = p.j1; Z.j2 = p.j2;
         Z.pole_n = 0.f; Z.pole_s = 0.f; Z.prow_n = nullptr; Z.prow_s = nullptr;
-        if (zone == PZ_REINTERP) { zout[n] = gdinterp_point(p, Z, p.degre_extrap, px, py); continue; }
+        if (zone == PZ_REINTERP) { zout[o] = gdinterp_point(p, Z, p.degre_extrap, px, py); continue; }
         if (p.vector_mode) { Z.prow_n = p.pole_row_n; Z.prow_s = p.pole_row_s; }
         else { Z.pole_n = p.polevals[0]; Z.pole_s = p.polevals[1]; }
-        zout[n] = strip_point(p, Z, zone == PZ_STRIP_N, px, py);
+        zout[o] = strip_point(p, Z, zone == PZ_STRIP_N, px, py);
     }
 }
 

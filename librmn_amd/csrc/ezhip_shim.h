@@ -149,6 +149,7 @@ typedef struct {
     const float *pole_row_n, *pole_row_s;
     const float *fill;                /* device scalar */
     const float *polevals;            /* device float[2] = {north, south}; computed by ezhip_polevals */
+    const int *out_idx;               /* NULL, or target position of point n (Yin-Yang lists: no temporary + scatter pass) */
 } ezhip_pts_plan;
 
 int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin,
