@@ -1628,6 +1628,40 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
     return ierc;
 }
 
+/* both components of a wind pair on the per-point path in ONE pass (k_pts2); returns -2 when the set is not on that path */
+static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui, const float *d_vi,
+                        const float *pun, const float *pus, const float *pvn, const float *pvs)
+{
+    ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
+    int degree = O.degre_interp, polar = O.polar_correction == 1;
+    if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return -2;
+    if (getenv("EZHIP_NO_PTS2")) return -2;
+    pthread_mutex_lock(&g_plan_mtx);
+    int mode = choose_mode(s, degree, polar);
+    pthread_mutex_unlock(&g_plan_mtx);
+    if (mode != 2) return -2;
+    if (ensure_scratch(s)) return -1;
+    float *d_fill = t_scratch8, *d_poles = t_scratch8 + 4;
+    int ierc = 0;
+    if (polar && s->extrap) {
+        if (O.degre_extrap == XT_ABORT && s->sep_capable && s->have_dehors) return -2;          /* let the per-field path report it */
+        if (ezhip_fill_value(d_fill, d_ui, (size_t)gi->ni * gi->nj, O.degre_extrap, O.valeur_extrap, 1)) return -1;
+    }
+    ezhip_pts_plan pu, pv;
+    int zones = !polar ? 0 : (s->extrap ? 2 : 1);
+    pthread_mutex_lock(&g_plan_mtx);
+    int erc = ensure_points(s);
+    if (!erc) fill_pts_plan(s, gi, &pu, degree, zones, 1);
+    pthread_mutex_unlock(&g_plan_mtx);
+    if (erc) return -1;
+    pu.fill = d_fill; pu.polevals = d_poles;
+    pv = pu;
+    pu.pole_row_n = pun; pu.pole_row_s = pus; pv.pole_row_n = pvn; pv.pole_row_s = pvs;
+    if (zones == 2 && (s->sep_capable ? s->have_dehors : s->have_dehors)) ierc = 2;
+    if (ezhip_interp_pts2(&pu, &pv, d_uo, d_vo, d_ui, d_vi, s->d_x, s->d_y, go->ni * go->nj)) return -1;
+    return ierc;
+}
+
 void ezhip_use_stream(void *hip_stream) { ezhip_set_stream(hip_stream); }
 int32_t ezhip_available(void) { return ezhip_runtime_ok(); }
 
@@ -2030,10 +2064,14 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
         }
         pun = s->d_prow; pus = s->d_prow + ni; pvn = s->d_prow + 2 * ni; pvs = s->d_prow + 3 * ni;
     }
-    int r1 = run_field(s, d_uuout, d_uuin, 1, pun, pus);
-    if (r1 < 0) return r1;
-    int r2 = run_field(s, d_vvout, d_vvin, 1, pvn, pvs);
-    if (r2 < 0) return r2;
+    int r1 = run_pair_pts(s, d_uuout, d_vvout, d_uuin, d_vvin, pun, pus, pvn, pvs), r2 = r1;
+    if (r1 == -1) return -1;
+    if (r1 == -2) {                                          /* separable set: one launch per component */
+        r1 = run_field(s, d_uuout, d_uuin, 1, pun, pus);
+        if (r1 < 0) return r1;
+        r2 = run_field(s, d_vvout, d_vvin, 1, pvn, pvs);
+        if (r2 < 0) return r2;
+    }
     if (ezhip_side_join()) return -1;                        /* nothing may outlive the call on the side stream */
     if (ensure_coords_dev(go)) return -1;
     ezhip_wind_plan wp;
@@ -2041,6 +2079,7 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
     wp.separable = go->separable;
     wp.wd_only = wd_only;
     wp.src_rotated = (gi->grtyp == 'E' || (gi->grtyp == 'Z' && gi->grref == 'E'));
+    wp.fast_trig = getenv("EZHIP_WIND_FAST_TRIG") != NULL;
     if (gi->grtyp == 'N' || gi->grtyp == 'S') { wp.src_ps = gi->grtyp == 'N' ? 1 : 2; wp.src_xg4 = gi->xg[3]; }
     if (go->grtyp == 'N' || go->grtyp == 'S') { wp.dst_ps = go->grtyp == 'N' ? 1 : 2; wp.dst_xg4 = go->xg[3]; }
     if (wp.src_rotated) { const float *xg = gi->grtyp == 'E' ? gi->xg : gi->xgref; h_crot(wp.r, wp.ri, xg[1], xg[0], xg[3], xg[2]); }

@@ -1313,6 +1313,33 @@ __global__ __launch_bounds__(256) void k_pts(ezhip_pts_plan p, float *__restrict
     }
 }
 
+/* The two components of a wind pair in one pass (c_ezuvint on the per-point path): x, y, zone test, indices and weights are
+ * shared (the leaf is inlined twice and the compiler merges everything that does not depend on the field). */
+template <int KIND>
+__global__ __launch_bounds__(256) void k_pts2(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+                                              const float *__restrict__ zin1, const float *__restrict__ zin2,
+                                              const float *__restrict__ xs, const float *__restrict__ ys, int npts,
+                                              int *__restrict__ special_list, unsigned *__restrict__ special_count)
+{
+    int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= npts) return;
+    const float px = xs[n], py = ys[n];
+    const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;
+    const PlainAcc Z1{zin1, p.ni, p.j1}, Z2{zin2, p.ni, p.j1};
+    const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
+    if (zone == PZ_NORMAL) { zout1[o] = leaf_point<KIND>(p, Z1, px, py); zout2[o] = leaf_point<KIND>(p, Z2, px, py); }
+    else if (zone == PZ_FILL) { const float f = *p.fill; zout1[o] = f; zout2[o] = f; }
+    const bool sp = zone == PZ_REINTERP || zone == PZ_STRIP_S || zone == PZ_STRIP_N;
+    const unsigned long long m = __ballot(sp);
+    if (sp) {
+        const int lane = (int)__lane_id(), leader = __ffsll((long long)m) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(special_count, (unsigned)__popcll(m));
+        base = (unsigned)__shfl((int)base, leader, 64);
+        special_list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = n;
+    }
+}
+
 /* Special points only (a fraction of a percent of a global target): polar strips on the virtual 4-row strip,
  * extrapolation points re-interpolated with degre_extrap. */
 __global__ __launch_bounds__(256) void k_pts_special(ezhip_pts_plan p, float *__restrict__ zout, const float *__restrict__ zin,
@@ -1367,6 +1394,37 @@ extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const
     if (ezhip_side_join()) return -1;       /* the special points read the polar wind rows a side stream may still be producing */
     /* always launched (it also re-arms the counter pair); a grid-stride loop over the few listed points */
     hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan, d_zout, d_zin, d_x, d_y, t_spec.list, cnt, cnt_next);
+    return LAUNCH_CHECK("k_pts_special");
+}
+
+/* vector pair: plan_u / plan_v differ only in their polar wind rows (read by the special points) */
+extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_plan *plan_v, float *d_out_u, float *d_out_v,
+                                 const float *d_in_u, const float *d_in_v, const float *d_x, const float *d_y, int npts)
+{
+    if (npts <= 0) return 0;
+    const dim3 grid((npts + 255) / 256), block(256);
+    if (t_spec.cap < (size_t)npts) {
+        (void)hipStreamSynchronize(g_stream);
+        if (t_spec.list) (void)hipFree(t_spec.list);
+        t_spec.list = nullptr; t_spec.cap = 0;
+        if (hipMalloc((void **)&t_spec.list, sizeof(int) * (size_t)npts + 64) != hipSuccess) return set_err(hipGetLastError(), "k_pts special list");
+        t_spec.count = (unsigned *)(t_spec.list + npts);
+        if (hipMemsetAsync(t_spec.count, 0, 64, g_stream) != hipSuccess) return -1;
+        t_spec.cap = (size_t)npts; t_spec.epoch = 0;
+    }
+    unsigned *cnt = t_spec.count + (t_spec.epoch & 1), *cnt_next = t_spec.count + ((t_spec.epoch + 1) & 1);
+    t_spec.epoch++;
+#define PTS2_CASE(K) case K: hipLaunchKernelGGL(k_pts2<K>, grid, block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, t_spec.list, cnt); break
+    switch (pts_kind(plan_u)) {
+    PTS2_CASE(PK_RGD0); PTS2_CASE(PK_RGD1_NW); PTS2_CASE(PK_RGD1_W); PTS2_CASE(PK_RGD3_NW); PTS2_CASE(PK_RGD3_W);
+    PTS2_CASE(PK_IRGD1_NW); PTS2_CASE(PK_IRGD1_W); PTS2_CASE(PK_IRGD3_NW); PTS2_CASE(PK_IRGD3_W);
+    }
+#undef PTS2_CASE
+    if (LAUNCH_CHECK("k_pts2")) return -1;
+    if (ezhip_side_join()) return -1;
+    /* the same list serves both components; both launches re-arm the same counter of the pair */
+    hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan_u, d_out_u, d_in_u, d_x, d_y, t_spec.list, cnt, cnt_next);
+    hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan_v, d_out_v, d_in_v, d_x, d_y, t_spec.list, cnt, cnt_next);
     return LAUNCH_CHECK("k_pts_special");
 }
 
@@ -1587,8 +1645,14 @@ __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *_
         } else d_rotate(p.r, lon, lat, lon_r, lat_r);
         const double dar = (double)(float)(3.14159274101257324 / 180.0);
         double a, b, c, d;
-        sincos(dar * (double)lon_r, &a, &b);
-        sincos(dar * (double)lat_r, &c, &d);
+        if (p.fast_trig) {      /* REAL sine / cosine of the rotated coordinates (1e-7 relative, the tolerance is 1e-5): 4x fewer fp64 operations */
+            float af, bf, cf, df;
+            sincosf((float)dar * lon_r, &af, &bf); sincosf((float)dar * lat_r, &cf, &df);
+            a = af; b = bf; c = cf; d = df;
+        } else {
+            sincos(dar * (double)lon_r, &a, &b);
+            sincos(dar * (double)lat_r, &c, &d);
+        }
         float x0 = (float)(-((double)u * a) - ((double)v * b * c));     /* ez_uvacart.inc */
         float x1 = (float)(((double)u * b) - ((double)v * a * c));
         float x2 = (float)((double)v * d);

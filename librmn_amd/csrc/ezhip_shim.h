@@ -158,6 +158,8 @@ int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const float *d_z
 /* masks (ez_mask.c): mode 0 = c_ezsint_mask, 1 = c_ezget_mask_zones; x, y = located coordinates of every target point */
 int ezhip_mask(int *d_mask_out, const float *d_x, const float *d_y, const int *d_mask_in, int ni_in, int nj_in, int ni_out, int nj_out, int mode, int cloud_linear);
 int ezhip_mask_fill_min(float *d_fld, const int *d_mask, size_t n, unsigned *d_keys2);
+int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_plan *plan_v, float *d_out_u, float *d_out_v,
+                      const float *d_in_u, const float *d_in_v, const float *d_x, const float *d_y, int npts);
 /* d_dst[d_idx[k]] = d_src[k] (the merge of the Yin and Yang point lists) */
 int ezhip_scatter(float *d_dst, const float *d_src, const int *d_idx, int n);
 /* pole values {north, south} of a source field -> device float[2] */
@@ -189,6 +191,7 @@ typedef struct {
     float r[9], ri[9];
     int separable;                    /* target lat/lon given as 1-D arrays */
     int wd_only;                      /* 1: stop after c_gdwdfuv (c_ezwdint): uu := speed, vv := direction */
+    int fast_trig;                    /* 1: REAL instead of REAL*8 sine / cosine of the rotated coordinates (development switch EZHIP_WIND_FAST_TRIG) */
     int wd_in;                        /* 1: uu / vv already hold speed / direction: only c_gduvfwd on the target (Yin-Yang merge) */
     int src_ps, dst_ps;               /* 0, or 1 = 'N' / 2 = 'S': polar-stereographic source / target (ez_llwfgdw.inc:91-140, ez_gdwfllw.inc:93-121) */
     float src_xg4, dst_xg4;           /* their dgrw */
