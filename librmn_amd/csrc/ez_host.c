@@ -2592,8 +2592,7 @@ static int32_t yy_uvint(ezh_set *s, float *d_uuout, float *d_vvout, const float 
         ezhip_pts_plan pp;
         fill_pts_plan(NULL, gs, &pp, degree, 0, 0);
         const int c = s->yy_count[sub];
-        if (ezhip_interp_pts(&pp, s->d_yy_tmp[0], d_uuin + sub * nsub, s->d_yy_x[sub], s->d_yy_y[sub], c)) return -1;
-        if (ezhip_interp_pts(&pp, s->d_yy_tmp[1], d_vvin + sub * nsub, s->d_yy_x[sub], s->d_yy_y[sub], c)) return -1;
+        if (ezhip_interp_pts2(&pp, &pp, s->d_yy_tmp[0], s->d_yy_tmp[1], d_uuin + sub * nsub, d_vvin + sub * nsub, s->d_yy_x[sub], s->d_yy_y[sub], c)) return -1;
         ezhip_wind_plan wp;
         memset(&wp, 0, sizeof(wp));
         wp.wd_only = 1; wp.src_rotated = 1;
