@@ -339,7 +339,7 @@ def test_masks(name, alg):
     # the Fortran reads mask_in(ix+1, iy+1) / mask_in(nint(x), nint(y)) without bounds: where that address lies past the end
     # of the array the reference's answer is whatever follows it in memory -- those points are left out
     x = ol.np_from(gs.contents.x, no * mo); y = ol.np_from(gs.contents.y, no * mo)
-    defined = (np.floor(y) + 1 <= nj) & (np.rint(y) <= nj)
+    defined = (np.floor(y) * ni + np.floor(x) < ni * nj) & ((np.rint(y) - 1) * ni + np.rint(x) - 1 < ni * nj)      # linear (column-major) address inside the array
     assert np.array_equal(gm[defined], mo_[defined]), (name, alg, int((gm != mo_)[defined].sum()))
     assert np.array_equal(gz[defined], mz[defined]), (name, alg, int((gz != mz)[defined].sum()))
     same_mask = gm == mo_
