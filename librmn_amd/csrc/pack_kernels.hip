@@ -738,6 +738,23 @@ __global__ __launch_bounds__(SCAN_TPB) void k_armn_emit_tok(unsigned *z, const u
     }
 }
 
+/* the words that two emit blocks (or the last block and the terminator) share start at zero; every other word of the stream
+ * is stored whole by exactly one block */
+__global__ __launch_bounds__(256) void k_armn_zero_bounds(unsigned *z, size_t z_words, const unsigned long long *bsum, int nblocks,
+                                                          const unsigned long long *total, unsigned long long body_start)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblocks) return;
+    const unsigned long long pos = body_start + bsum[b], end = body_start + (b + 1 < nblocks ? bsum[b + 1] : *total);
+    if (end > pos) {
+        const size_t w0 = (size_t)(pos >> 5), w1 = (size_t)((end + 31) >> 5) - 1;
+        if (w0 < z_words) z[w0] = 0u;
+        if (w1 < z_words) z[w1] = 0u;
+    }
+    if (b == nblocks - 1)                                     /* the two 16-bit terminator tokens and the byte after zlng */
+        for (size_t w = (size_t)(end >> 5); w < (size_t)(end >> 5) + 3 && w < z_words; w++) z[w] = 0u;
+}
+
 /* parallelogram prefix: 3-bit container, row 1, column 1 (:712-721) */
 __global__ __launch_bounds__(256) void k_armn_prefix(unsigned *z, const unsigned *w, const unsigned *gt16, int ni, int nj, int nbits, unsigned header)
 {
@@ -764,7 +781,11 @@ extern "C" int packhip_armn_encode(unsigned *d_z, size_t z_words, const unsigned
     unsigned long long *total = bsum + nblocks;
     unsigned *gt16 = (unsigned *)(total + 1);
     hipStream_t st = STREAM;
-    if (hipMemsetAsync(d_z, 0, z_words * 4, st) != hipSuccess) return -1;
+    /* the stream is assembled with plain stores except for the words that blocks share: only those have to start at zero.
+     * The lane-per-token emitter of the PARALLELOGRAM method gets them zeroed by k_armn_zero_bounds once the scan is known
+     * (52 MB of memset per cfg5 field otherwise); the other emitters OR every token into a fully zeroed buffer. */
+    const bool tok_emit = !minimum_method && !(getenv("EZHIP_ARMN_SEQ_EMIT") || ntx >= 65536 || nty >= 65536 || (long long)ni * nj >= (1ll << 31));
+    if (!tok_emit && hipMemsetAsync(d_z, 0, z_words * 4, st) != hipSuccess) return -1;
     if (hipMemsetAsync(gt16, 0, 4, st) != hipSuccess) return -1;
     const unsigned tb = (unsigned)((ntiles + 255) / 256);
     unsigned long long body_start;
@@ -781,8 +802,13 @@ extern "C" int packhip_armn_encode(unsigned *d_z, size_t z_words, const unsigned
         hipLaunchKernelGGL(k_armn_tiles<1>, dim3(tb), dim3(256), 0, st, nb, gt16, d_words, ni, nj, istep, ntx, ntiles);
         hipLaunchKernelGGL(k_armn_blocksum<1>, dim3(nblocks), dim3(SCAN_TPB), 0, st, bsum, nb, gt16, ni, nj, istep, ntx, ntiles, nbits);
         hipLaunchKernelGGL(k_armn_scan, dim3(1), dim3(1024), 0, st, bsum, nblocks, total);
-        hipLaunchKernelGGL(k_armn_prefix, dim3((ni + nj + 255) / 256), dim3(256), 0, st, d_z, d_words, gt16, ni, nj, nbits, header);
         body_start = 32 + 3 + (unsigned long long)(ni + nj - 1) * nbits;
+        if (tok_emit) {
+            const size_t head_words = (size_t)(body_start >> 5) + 2;
+            if (hipMemsetAsync(d_z, 0, 4 * (head_words < z_words ? head_words : z_words), st) != hipSuccess) return -1;
+            hipLaunchKernelGGL(k_armn_zero_bounds, dim3((nblocks + 255) / 256), dim3(256), 0, st, d_z, z_words, bsum, nblocks, total, body_start);
+        }
+        hipLaunchKernelGGL(k_armn_prefix, dim3((ni + nj + 255) / 256), dim3(256), 0, st, d_z, d_words, gt16, ni, nj, nbits, header);
         if (getenv("EZHIP_ARMN_SEQ_EMIT") || ntx >= 65536 || nty >= 65536 || (long long)ni * nj >= (1ll << 31))     /* development / huge fields: the per-thread sequential writer */
             hipLaunchKernelGGL(k_armn_emit<1>, dim3(nblocks), dim3(SCAN_TPB), 0, st, d_z, bsum, nb, gt16, d_words, ni, nj, istep, ntx, ntiles, nbits, body_start);
         else
