@@ -224,8 +224,13 @@ static void h_xpncof(ezh_grid *g)
 {
     int ni = g->ni, nj = g->nj;
     g->i1 = 1; g->i2 = ni; g->j1 = 1; g->j2 = nj; g->extension = 0;
-    if (g->grtyp == 'A' || g->grtyp == 'G') g->extension = 2;
-    else if (g->grtyp == 'B') g->extension = 1;
+    if (g->grtyp == 'A' || g->grtyp == 'G') {              /* ez_xpncof.c:107-145: hemispheres are expanded into (j1:j2) */
+        g->extension = 2;
+        if (g->ig[0] == 1) { g->j1 = -nj + 1; g->j2 = nj; } else if (g->ig[0] == 2) { g->j1 = 1; g->j2 = 2 * nj; }
+    } else if (g->grtyp == 'B') {
+        g->extension = 1;
+        if (g->ig[0] == 1) { g->j1 = -nj + 2; g->j2 = nj; } else if (g->ig[0] == 2) { g->j1 = 1; g->j2 = 2 * nj - 1; }
+    }
     else if (g->grtyp == 'L') {
         float lat0, lon0, dlat, dlon;
         h_cigaxg('L', &lat0, &lon0, &dlat, &dlon, g->ig[0], g->ig[1], g->ig[2], g->ig[3]);
@@ -389,12 +394,18 @@ static int h_locate(const ezh_grid *g, float *x, float *y, const float *lat, flo
     float lat0, lon0, dlat, dlon;
     switch (g->grtyp) {
     case 'A':
-        dlon = 360.0f / (float)ni; lon0 = 0.0f; dlat = 180.0f / (float)nj; lat0 = -90.0f + dlat * 0.5f;
+        dlon = 360.0f / (float)ni; lon0 = 0.0f;
+        if (g->ig[0] == 1) { dlat = 90.0f / (float)nj; lat0 = dlat * 0.5f; }
+        else if (g->ig[0] == 2) { dlat = 90.0f / (float)nj; lat0 = -90.0f + dlat * 0.5f; }
+        else { dlat = 180.0f / (float)nj; lat0 = -90.0f + dlat * 0.5f; }
         for (int i = 0; i < n; i++) if (lon[i] < 0.0f) lon[i] = lon[i] + 360.0f;
         h_llll2gd(x, y, lat, lon, n, lat0, lon0, dlat, dlon, 0.0f);
         return 0;
     case 'B':
-        dlon = 360.0f / (float)(ni - 1); lon0 = 0.0f; dlat = 180.0f / (float)(nj - 1); lat0 = -90.0f;
+        dlon = 360.0f / (float)(ni - 1); lon0 = 0.0f;
+        if (g->ig[0] == 1) { dlat = 90.0f / (float)(nj - 1); lat0 = 0.0f; }
+        else if (g->ig[0] == 2) { dlat = 90.0f / (float)(nj - 1); lat0 = -90.0f; }
+        else { dlat = 180.0f / (float)(nj - 1); lat0 = -90.0f; }
         for (int i = 0; i < n; i++) if (lon[i] < 0.0f) lon[i] = lon[i] + 360.0f;
         h_llll2gd(x, y, lat, lon, n, lat0, lon0, dlat, dlon, 0.0f);
         return 0;
@@ -467,7 +478,8 @@ static int grid_ok(int gd) { return gd >= 0 && gd < nG && G[gd].used; }
 static int type_supported(char t, char ref, int ig1, int ig2)
 {
     if (t == 'L' || t == 'E' || t == 'N' || t == 'S') return 1;
-    if (t == 'A' || t == 'B' || t == 'G') return ig1 == 0 && ig2 == 0;   /* hemispheric / inverted: out of scope */
+    if (t == 'A' || t == 'B') return ig1 >= 0 && ig1 <= 2 && ig2 == 0;   /* hemispheric: scalars only; y-inverted: out of scope */
+    if (t == 'G') return ig1 == 0 && ig2 == 0;
     if (t == 'Z') return ref == 'L' || ref == 'E';
     if (t == 'Y') return ref == 'L';                                      /* as a target; c_ezdefset refuses it as a source */
     return 0;
@@ -513,11 +525,17 @@ int32_t c_ezgdef_fmem(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t 
     g->used = 1; g->refcount = 1; g->grtyp = t; g->grref = (t == 'Z' || t == 'Y') ? ref : 0;
     g->ni = ni; g->nj = nj; memcpy(g->ig, ig, sizeof(ig));
     switch (t) {                                            /* c_ezdefxg, ez_defxg.c:28-170 */
-    case 'A': case 'G':
-        g->xg[3] = (float)(360. / ni); g->xg[1] = 0.0f; g->xg[2] = (float)(180. / nj); g->xg[0] = (float)(-90. + 0.5 * (double)g->xg[2]);
+    case 'A': case 'G':                                     /* ez_defxg.c:39-62 */
+        g->xg[3] = (float)(360. / ni); g->xg[1] = 0.0f;
+        if (ig1 == 0) { g->xg[2] = (float)(180. / nj); g->xg[0] = (float)(-90. + 0.5 * (double)g->xg[2]); }
+        else if (ig1 == 1) { g->xg[2] = (float)(90. / nj); g->xg[0] = (float)(0.5 * (double)g->xg[2]); }
+        else { g->xg[2] = (float)(90. / nj); g->xg[0] = (float)(-90. + 0.5 * (double)g->xg[2]); }
         break;
-    case 'B':
-        g->xg[3] = (float)(360. / (ni - 1)); g->xg[1] = 0.0f; g->xg[2] = (float)(180. / (nj - 1)); g->xg[0] = -90.f;
+    case 'B':                                               /* ez_defxg.c:77-103 */
+        g->xg[3] = (float)(360. / (ni - 1)); g->xg[1] = 0.0f;
+        if (ig1 == 0) { g->xg[2] = (float)(180. / (nj - 1)); g->xg[0] = -90.f; }
+        else if (ig1 == 1) { g->xg[2] = (float)(90. / (nj - 1)); g->xg[0] = 0.f; }
+        else { g->xg[2] = (float)(90. / (nj - 1)); g->xg[0] = -90.f; }
         break;
     case 'L': case 'E':
     case 'N': case 'S':                                     /* ez_defxg.c:150-160: xg = (pi, pj, d60, dgrw) */
@@ -931,6 +949,7 @@ static int src_is_separable(const ezh_grid *g)
     return !(g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E') || g->grtyp == 'N' || g->grtyp == 'S');
 }
 static int src_irregular(const ezh_grid *g) { return g->grtyp == 'G' || g->grtyp == 'Z'; }
+static int src_hemi(const ezh_grid *g) { return (g->grtyp == 'A' || g->grtyp == 'B') && g->ig[0] != 0; }
 
 static int set_extrap(const ezh_grid *gi)
 {
@@ -982,6 +1001,7 @@ static int choose_mode(const ezh_set *s, int degree, int polar)
     const ezh_grid *gi = &G[s->gdin];
     if (!s->sep_capable) return 2;
     if (getenv("EZHIP_FORCE_PTS")) return 2;
+    if (src_hemi(gi)) return 2;                            /* rows j1..j2 of the expanded field: the per-point kernel indexes them natively */
     /* ez_irgdint_3_nw rounds every intermediate to REAL (ez_irgdint_3_nw.inc:32): not a linear
      * functional of the stencil, keep it on the point-exact kernel */
     if (src_irregular(gi) && gi->extension == 0 && degree == DEG_CUBIC) return 2;
@@ -1429,8 +1449,16 @@ static void fill_locate_plan(const ezh_grid *gi, ezhip_locate_plan *lp)
     lp->ni = gi->ni; lp->nj = gi->nj;
     float r[9], ri[9];
     switch (gi->grtyp) {
-    case 'A': lp->kind = 0; lp->dlon = 360.0f / (float)gi->ni; lp->lon0 = 0.0f; lp->dlat = 180.0f / (float)gi->nj; lp->lat0 = -90.0f + lp->dlat * 0.5f; lp->lon_fix = 2; break;
-    case 'B': lp->kind = 0; lp->dlon = 360.0f / (float)(gi->ni - 1); lp->lon0 = 0.0f; lp->dlat = 180.0f / (float)(gi->nj - 1); lp->lat0 = -90.0f; lp->lon_fix = 2; break;
+    case 'A': lp->kind = 0; lp->dlon = 360.0f / (float)gi->ni; lp->lon0 = 0.0f; lp->lon_fix = 2;
+        if (gi->ig[0] == 1) { lp->dlat = 90.0f / (float)gi->nj; lp->lat0 = lp->dlat * 0.5f; }
+        else if (gi->ig[0] == 2) { lp->dlat = 90.0f / (float)gi->nj; lp->lat0 = -90.0f + lp->dlat * 0.5f; }
+        else { lp->dlat = 180.0f / (float)gi->nj; lp->lat0 = -90.0f + lp->dlat * 0.5f; }
+        break;
+    case 'B': lp->kind = 0; lp->dlon = 360.0f / (float)(gi->ni - 1); lp->lon0 = 0.0f; lp->lon_fix = 2;
+        if (gi->ig[0] == 1) { lp->dlat = 90.0f / (float)(gi->nj - 1); lp->lat0 = 0.0f; }
+        else if (gi->ig[0] == 2) { lp->dlat = 90.0f / (float)(gi->nj - 1); lp->lat0 = -90.0f; }
+        else { lp->dlat = 180.0f / (float)(gi->nj - 1); lp->lat0 = -90.0f; }
+        break;
     case 'L': lp->kind = 0; h_cigaxg('L', &lp->lat0, &lp->lon0, &lp->dlat, &lp->dlon, gi->ig[0], gi->ig[1], gi->ig[2], gi->ig[3]); lp->lon_fix = 1; break;
     case 'N': case 'S':                                     /* kind 4: ez_vxyfll with (pi, pj, d60, dgrw) in (lat0, lon0, dlat, dlon), hemisphere in lon_fix */
         lp->kind = 4; lp->lat0 = gi->xg[0]; lp->lon0 = gi->xg[1]; lp->dlat = gi->xg[2]; lp->dlon = gi->xg[3]; lp->lon_fix = gi->grtyp == 'N' ? 1 : 2;
@@ -1541,6 +1569,16 @@ static int pole_ring(int nfields, ezhip_sep_plan *p)
 
 /* one field, device pointers; vector_mode: 0 scalar, 1 = u/v component with synthetic pole rows
  * (prow_n / prow_s device pointers, may be NULL when polar correction is off) */
+/* per host thread: the expansion of a hemispheric source field (ez_xpnsrcgd) */
+static __thread struct { float *p; size_t cap; } t_xpn;
+static const float *hemi_expand(const ezh_grid *gi, const float *d_zin)
+{
+    size_t n = (size_t)gi->ni * (size_t)(gi->j2 - gi->j1 + 1);
+    if (t_xpn.cap < n) { if (t_xpn.p) { ezhip_sync(); ezhip_free(t_xpn.p); } t_xpn.p = (float *)ezhip_malloc(sizeof(float) * n); t_xpn.cap = t_xpn.p ? n : 0; }
+    if (!t_xpn.p) return NULL;
+    if (ezhip_hemi_expand(t_xpn.p, d_zin, gi->ni, gi->nj, gi->j1, gi->j2, gi->ig[0], gi->grtyp == 'B', 1)) return NULL;
+    return t_xpn.p;
+}
 static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector_mode, const float *prow_n, const float *prow_s, const float *d_poles_pre);
 static int run_field(ezh_set *s, float *d_zout, const float *d_zin, int vector_mode, const float *prow_n, const float *prow_s)
 {
@@ -1618,7 +1656,15 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
     if (erc) return -1;
     pp.fill = d_fill; pp.polevals = d_poles_pre ? d_poles_pre : d_poles;
     pp.pole_row_n = prow_n; pp.pole_row_s = prow_s;
-    if (zones == 1 && !vector_mode && !d_poles_pre && ezhip_polevals(d_poles, d_zin, gi->ni, gi->nj, pp.pole_weighted, gi->d_ax)) return -1;
+    int nj_rows = gi->nj;
+    if (src_hemi(gi)) {                                     /* ezsint.c:108-113: the field mirrored into the other hemisphere, rows j1..j2 */
+        if (vector_mode) { fprintf(stderr, "<c_ezuvint> hemispheric source grids are outside the MI355X hot-path scope for winds\n"); return -1; }
+        d_zin = hemi_expand(gi, d_zin);
+        if (!d_zin) return -1;
+        nj_rows = gi->j2 - gi->j1 + 1;
+        d_poles_pre = NULL; pp.polevals = d_poles;          /* pole values of the EXPANDED field */
+    }
+    if (zones == 1 && !vector_mode && !d_poles_pre && ezhip_polevals(d_poles, d_zin, gi->ni, nj_rows, pp.pole_weighted, gi->d_ax)) return -1;
     if (zones == 2 && !s->sep_capable) {
         /* The reference returns 2 only when the DEHORS zone is non-empty; on the per-point path that
          * needs a reduction over x,y which is done once and cached in have_dehors by ezhip_prepare. */
@@ -1840,6 +1886,7 @@ int32_t c_gdxysint_dev(float *d_zout, const float *d_zin, int32_t gdin, const fl
     if (ensure_grid_dev(gi)) return -1;
     ezhip_pts_plan pp;
     fill_pts_plan(NULL, gi, &pp, degree, 0, 0);
+    if (src_hemi(gi)) { d_zin = hemi_expand(gi, d_zin); if (!d_zin) return -1; }      /* gdxysint.c:44-47 */
     return ezhip_interp_pts(&pp, d_zout, d_zin, d_x, d_y, npts) ? -1 : 0;
 }
 int32_t c_gdxysint(float *zout, float *zin, int32_t gdin, float *x, float *y, int32_t npts)
@@ -2018,6 +2065,7 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
     if (G[s->gdout].grtyp == 'U') { fprintf(stderr, "<c_ezuvint> winds towards a Yin-Yang 'U' grid (rotated subgrids) are outside the MI355X hot-path scope\n"); return -1; }
     if (G[s->gdin].grtyp == 'U') return yy_uvint(s, d_uuout, d_vvout, d_uuin, d_vvin, wd_only);
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
+    if (src_hemi(gi)) { fprintf(stderr, "<c_ezuvint> hemispheric source grids are outside the MI355X hot-path scope for winds\n"); return -1; }
     if (go->grtyp == 'E' || (go->grtyp == 'Z' && go->grref == 'E') || go->grtyp == 'Z') {
         fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp);
         return -1;

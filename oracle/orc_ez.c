@@ -179,8 +179,12 @@ static void xpncof(orc_grid *g)
         extra_lon = last_lon + dlon;
         if ((double)(extra_lon - first_lon) > (360.0 - (double)dlon * 0.01)) g->extension = 2;
         break;
-    case 'A': case 'G': g->extension = 2; break;                /* :107-125 */
-    case 'B': g->extension = 1; break;                          /* :127-145 */
+    case 'A': case 'G': g->extension = 2;                       /* :107-125 */
+        if (g->ig[0] == 1) { g->j1 = -nj + 1; g->j2 = nj; } else if (g->ig[0] == 2) { g->j1 = 1; g->j2 = 2 * nj; }
+        break;
+    case 'B': g->extension = 1;                                 /* :127-145 */
+        if (g->ig[0] == 1) { g->j1 = -nj + 2; g->j2 = nj; } else if (g->ig[0] == 2) { g->j1 = 1; g->j2 = 2 * nj - 1; }
+        break;
     case 'E': break;                                            /* :152-155 extension untouched (0) */
     case 'Z':
         if (g->grref == 'E') {                                  /* :161-171 */
@@ -216,8 +220,11 @@ orc_grid *orc_grid_define(int ni, int nj, char grtyp, char grref,
     g->grtyp = grtyp; g->grref = grref; g->ni = ni; g->nj = nj;
     g->ig[0] = ig1; g->ig[1] = ig2; g->ig[2] = ig3; g->ig[3] = ig4;
     switch (grtyp) {
-    case 'A': case 'B': case 'G':
-        if (ig1 != 0 || ig2 != 0) { fprintf(stderr, "orc_grid_define: hemispheric/inverted grids out of scope\n"); free(g); return NULL; }
+    case 'A': case 'B':
+        if (ig1 < 0 || ig1 > 2 || ig2 != 0) { fprintf(stderr, "orc_grid_define: inverted grids out of scope\n"); free(g); return NULL; }
+        break;
+    case 'G':
+        if (ig1 != 0 || ig2 != 0) { fprintf(stderr, "orc_grid_define: hemispheric/inverted 'G' grids out of scope\n"); free(g); return NULL; }
         break;
     case 'L': case 'E': case 'Z': case 'N': case 'S': break;
     case 'Y': if (grref != 'L') { fprintf(stderr, "orc_grid_define: 'Y' grids on '%c' out of scope\n", grref); free(g); return NULL; } break;   /* target only */
@@ -225,13 +232,17 @@ orc_grid *orc_grid_define(int ni, int nj, char grtyp, char grref,
     }
     /* c_ezdefxg */
     switch (grtyp) {
-    case 'A': case 'G':                                         /* ez_defxg.c:39-49, double -> float */
+    case 'A': case 'G':                                         /* ez_defxg.c:39-62, double -> float */
         g->xg[3] = (float)(360. / ni); g->xg[1] = 0.0f;
-        g->xg[2] = (float)(180. / nj); g->xg[0] = (float)(-90. + 0.5 * (double)g->xg[2]);
+        if (ig1 == 0) { g->xg[2] = (float)(180. / nj); g->xg[0] = (float)(-90. + 0.5 * (double)g->xg[2]); }
+        else if (ig1 == 1) { g->xg[2] = (float)(90. / nj); g->xg[0] = (float)(0.5 * (double)g->xg[2]); }
+        else { g->xg[2] = (float)(90. / nj); g->xg[0] = (float)(-90. + 0.5 * (double)g->xg[2]); }
         break;
-    case 'B':                                                   /* ez_defxg.c:77-85 */
+    case 'B':                                                   /* ez_defxg.c:77-103 */
         g->xg[3] = (float)(360. / (ni - 1)); g->xg[1] = 0.0f;
-        g->xg[2] = (float)(180. / (nj - 1)); g->xg[0] = -90.f;
+        if (ig1 == 0) { g->xg[2] = (float)(180. / (nj - 1)); g->xg[0] = -90.f; }
+        else if (ig1 == 1) { g->xg[2] = (float)(90. / (nj - 1)); g->xg[0] = 0.f; }
+        else { g->xg[2] = (float)(90. / (nj - 1)); g->xg[0] = -90.f; }
         break;
     case 'E': case 'L':                                         /* ez_defxg.c:111-147 */
     case 'N': case 'S':                                         /* ez_defxg.c:150-160: xg = (pi, pj, d60, dgrw) */
@@ -462,13 +473,17 @@ static int ll2rgd(float *px, float *py, const float *xlat, float *xlon, int npts
     switch (g->grtyp) {
     case 'A':                                                   /* :58-78 */
         dellon = 360.0f / (float)ni; xlon0 = 0.0f;
-        dellat = 180.0f / (float)nj; xlat0 = -90.0f + dellat * 0.5f;
+        if (g->ig[0] == 1) { dellat = 90.0f / (float)nj; xlat0 = dellat * 0.5f; }
+        else if (g->ig[0] == 2) { dellat = 90.0f / (float)nj; xlat0 = -90.0f + dellat * 0.5f; }
+        else { dellat = 180.0f / (float)nj; xlat0 = -90.0f + dellat * 0.5f; }
         for (int i = 0; i < npts; i++) if (xlon[i] < 0.0f) xlon[i] = xlon[i] + 360.0f;
         llll2gd(px, py, xlat, xlon, npts, xlat0, xlon0, dellat, dellon, 0.0f);
         return 0;
     case 'B':                                                   /* :80-100 */
         dellon = 360.0f / (float)(ni - 1); xlon0 = 0.0f;
-        dellat = 180.0f / (float)(nj - 1); xlat0 = -90.0f;
+        if (g->ig[0] == 1) { dellat = 90.0f / (float)(nj - 1); xlat0 = 0.0f; }
+        else if (g->ig[0] == 2) { dellat = 90.0f / (float)(nj - 1); xlat0 = -90.0f; }
+        else { dellat = 180.0f / (float)(nj - 1); xlat0 = -90.0f; }
         for (int i = 0; i < npts; i++) if (xlon[i] < 0.0f) xlon[i] = xlon[i] + 360.0f;
         llll2gd(px, py, xlat, xlon, npts, xlat0, xlon0, dellat, dellon, 0.0f);
         return 0;
@@ -987,7 +1002,7 @@ static void corrval_aunord(orc_gridset *gs, int degree, float *zout, const float
     float *temp = (float *)malloc(sizeof(float) * 4 * ni), *vals = (float *)malloc(sizeof(float) * npts);
     float poleval = calcpoleval(&zin[(size_t)(nj - 1) * ni], ni, g->ax, g->grtyp, g->grref);
     /* ez_fillnpole.inc:26-34: rows j2-2, j2-1, j2, then the pole row */
-    for (int r = 0; r < 3; r++) memcpy(&temp[r * ni], &zin[(size_t)(g->j2 - 3 + r) * ni], sizeof(float) * ni);
+    for (int r = 0; r < 3; r++) memcpy(&temp[r * ni], &zin[(size_t)(g->j2 - 2 + r - g->j1) * ni], sizeof(float) * ni);   /* z(ni, j1:j2) */
     for (int i = 0; i < ni; i++) temp[3 * ni + i] = poleval;
     if (degree == ORC_CUBIC) {
         if (g->grtyp == 'Z' || g->grtyp == 'E' || g->grtyp == 'G') {
@@ -1086,10 +1101,36 @@ static int corrval(orc_gridset *gs, const orc_opts *o, float *zout, const float 
 }
 
 /* c_ezsint_orig, src/interp/ezsint.c:75-135 */
+/* ez_xpnsrcgd -> ez_xpngdag2 / ez_xpngdb2 (ez_xpngdag2.inc:20-60, ez_xpngdb2.inc:20-60): a hemispheric field mirrored
+ * into the other hemisphere; zout(ni, j1:j2), row (j - j1) of the C array */
+void orc_xpnsrcgd(const orc_grid *g, float *zout, const float *zi, int symetrie)
+{
+    const int ni = g->ni, nj = g->nj, j1 = g->j1;
+    const float sign = symetrie == 0 ? -1.0f : 1.0f;
+#define ZO(i, j) zout[(size_t)((j) - j1) * ni + (i)]
+#define ZI(i, j) zi[(size_t)((j) - 1) * ni + (i)]
+    for (int j = 1; j <= nj; j++) for (int i = 0; i < ni; i++) ZO(i, j) = ZI(i, j);
+    if (g->grtyp == 'B') {
+        if (g->ig[0] == 1) { for (int j = 2; j <= nj; j++) for (int i = 0; i < ni; i++) ZO(i, 2 - j) = sign * ZI(i, j); }
+        else { for (int j = 2; j <= nj; j++) for (int i = 0; i < ni; i++) ZO(i, nj + j - 1) = sign * ZI(i, nj - j + 1); }
+    } else {
+        if (g->ig[0] == 1) { for (int j = 1; j <= nj; j++) for (int i = 0; i < ni; i++) ZO(i, -j + 1) = sign * ZI(i, j); }
+        else { for (int j = 1; j <= nj; j++) for (int i = 0; i < ni; i++) ZO(i, nj + j) = sign * ZI(i, nj - j + 1); }
+    }
+#undef ZO
+#undef ZI
+}
+
 int orc_ezsint(orc_gridset *gs, const orc_opts *o, float *zout, const float *zin)
 {
     orc_grid *gi = gs->gdin, *go = gs->gdout;
     if (gi == go) { memcpy(zout, zin, sizeof(float) * gi->ni * gi->nj); return 1; }
+    float *xz = NULL;
+    if ((gi->grtyp == 'A' || gi->grtyp == 'B') && gi->ig[0] != 0) {      /* ezsint.c:108-113 -> ez_xpnsrcgd */
+        xz = (float *)malloc(sizeof(float) * 2 * (size_t)gi->ni * gi->nj);
+        orc_xpnsrcgd(gi, xz, zin, o->vecteur == 2 ? 0 : 1);
+        zin = xz;
+    }
     orc_calclatlon(go);
     orc_calcxy(gs);
     orc_gdinterp(gi, o->degre_interp, zout, zin, gs->x, gs->y, go->ni * go->nj);
@@ -1098,5 +1139,6 @@ int orc_ezsint(orc_gridset *gs, const orc_opts *o, float *zout, const float *zin
         orc_defzones(gs);
         ierc = corrval(gs, o, zout, zin);
     }
+    free(xz);
     return ierc;
 }

@@ -91,6 +91,8 @@ void orc_gridset_free(orc_gridset *gs);
 int orc_calcxy(orc_gridset *gs);
 /* ez_defzones (src/interp/ez_defzones.c:25-113) */
 int orc_defzones(orc_gridset *gs);
+/* ez_xpnsrcgd (src/interp/ez_xpnsrcgd.c:28-52): hemispheric A / B source -> its global expansion zout(ni, j1:j2) */
+void orc_xpnsrcgd(const orc_grid *g, float *zout, const float *zi, int symetrie);
 /* c_ezsint_orig (src/interp/ezsint.c:75-135) */
 int orc_ezsint(orc_gridset *gs, const orc_opts *o, float *zout, const float *zin);
 /* c_ezuvint_orig (src/interp/ezuvint.c:51-94) */

@@ -131,3 +131,15 @@ def yyt_axes(ni, nj):
     ax = (35.0 + 2.5 * np.arange(ni, dtype=np.float64)).astype(np.float32)
     ay = (-55.0 + 2.5 * np.arange(nj, dtype=np.float64)).astype(np.float32)
     return ax, ay
+
+
+def hemi_cases():
+    """hemispheric A / B grids (ig1 = 1 north, 2 south): scalar interpolation only"""
+    c = {}
+    c["Anord_to_L"] = dict(src=(48, 12, "A", (1, 0, 0, 0), " ", None), dst=(60, 31, "L", (600, 600, 0, 0)))
+    c["Asud_to_L"] = dict(src=(48, 12, "A", (2, 0, 0, 0), " ", None), dst=(60, 31, "L", (600, 600, 0, 0)))
+    c["Bnord_to_L"] = dict(src=(49, 13, "B", (1, 0, 0, 0), " ", None), dst=(60, 31, "L", (600, 600, 0, 0)))
+    c["Bsud_to_L"] = dict(src=(49, 13, "B", (2, 0, 0, 0), " ", None), dst=(60, 31, "L", (600, 600, 0, 0)))
+    c["L_to_Anord"] = dict(src=(40, 20, "L", (900, 900, 450, 0), " ", None), dst=(48, 12, "A", (1, 0, 0, 0)))
+    c["G_to_Bsud"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(49, 13, "B", (2, 0, 0, 0)))
+    return c

@@ -88,6 +88,23 @@ def main():
             zo = np.zeros(no * mo, np.float32); uo = np.zeros(no * mo, np.float32); vo = np.zeros(no * mo, np.float32)
             assert L.c_ezsint(fptr(zo), fptr(z)) == 0 and L.c_ezuvint(fptr(uo), fptr(vo), fptr(uu), fptr(vv)) == 0
             out[f"YY_to_{tname}/z_d{degree}"] = zo; out[f"YY_to_{tname}/u_d{degree}"] = uo; out[f"YY_to_{tname}/v_d{degree}"] = vo
+    # hemispheric A / B grids: scalars only
+    for name, case in sorted(ec.hemi_cases().items()):
+        ni, nj = case["src"][:2]; no, mo = case["dst"][:2]
+        gdin = define(L, case["src"]); gdout = define(L, ec.dst_spec(case))
+        assert L.c_ezdefset(gdout, gdin) == 1
+        zin = ec.synth_field(ni, nj, seed=11)
+        if case["src"][2] == "B":
+            z2 = zin.reshape(nj, ni); z2[:, -1] = z2[:, 0]; zin = np.ascontiguousarray(z2.reshape(-1))
+        for degree in (0, 1, 3):
+            for polar in (1, 0):
+                L.c_ezsetopt(b"interp_degree", DEG[degree]); L.c_ezsetopt(b"polar_correction", b"yes" if polar else b"no")
+                zo = np.zeros(no * mo, np.float32)
+                rc = L.c_ezsint(fptr(zo), fptr(zin))
+                out[f"{name}/z_d{degree}_p{polar}"] = zo; out[f"{name}/rc_d{degree}_p{polar}"] = np.int32(rc)
+        lat = np.zeros(no * mo, np.float32); lon = np.zeros(no * mo, np.float32)
+        L.c_gdll(gdout, fptr(lat), fptr(lon))
+        out[f"{name}/lat"] = lat; out[f"{name}/lon"] = lon
     # Yin-Yang TARGET: from an ordinary grid (two plain interpolations) and from another Yin-Yang grid (2.5-degree subgrids)
     tni, tnj = ec.YYT_NI, ec.YYT_NJ
     tax, tay = ec.yyt_axes(tni, tnj)

@@ -651,3 +651,34 @@ def test_gdxywdval_gdllwdval_match_oracle(kind):
         assert np.all(np.abs(gs - ws) <= 2e-5 * np.maximum(ws, 1e-2)), float(np.abs(gs - ws).max())
         ddir = np.abs(((gd - wd + 180.0) % 360.0) - 180.0)
         assert np.all(ddir[ws > 1e-2] <= 5e-3), float(ddir.max())
+
+
+HEMI = ec.hemi_cases()
+
+
+@pytest.mark.parametrize("name", sorted(HEMI))
+def test_hemispheric_scalar_vs_golden(name):
+    """hemispheric A / B grids (ig1 = 1, 2): the source field is mirrored into the other hemisphere on the device (k_hemi_expand,
+    ez_xpnsrcgd) and the per-point kernel indexes rows j1..j2 like the reference's leaf kernels -> bit-exact; targets: coordinates"""
+    case = HEMI[name]
+    ni, nj = case["src"][:2]; no, mo = case["dst"][:2]
+    gdin = hip_define(case["src"]); gdout = hip_define(ec.dst_spec(case))
+    assert gdin >= 0 and gdout >= 0 and ez.ezdefset(gdout, gdin) == 1
+    zin = ec.synth_field(ni, nj, seed=11)
+    if case["src"][2] == "B":
+        z2 = zin.reshape(nj, ni); z2[:, -1] = z2[:, 0]; zin = np.ascontiguousarray(z2.reshape(-1))
+    hemi_src = case["src"][2] in ("A", "B") and case["src"][3][0] != 0
+    for degree in (0, 1, 3):
+        for polar in (1, 0):
+            setopts(degree, polar)
+            rc, z = ez.ezsint(zin, no * mo)
+            want = GOLD[f"{name}/z_d{degree}_p{polar}"]
+            assert rc == int(GOLD[f"{name}/rc_d{degree}_p{polar}"]), (name, degree, polar)
+            assert relerr(z, want).max() <= RTOL, (name, degree, polar, float(relerr(z, want).max()))
+            if hemi_src and not polar:
+                assert np.array_equal(z.view(np.uint32), want.view(np.uint32)), (name, degree, polar)
+    rc, lat, lon = ez.gdll(gdout, no * mo)
+    assert rc == 0 and np.array_equal(lat, GOLD[f"{name}/lat"]) and np.array_equal(lon, GOLD[f"{name}/lon"])
+    if hemi_src:
+        uu, vv = ec.synth_wind(ni, nj, seed=3)
+        assert ez.ezuvint(uu, vv, no * mo)[0] == -1          # winds from a hemispheric source: refused

@@ -370,3 +370,34 @@ def test_gdwdfuv_gduvfwd_direct(kind):
         L.c_gduvfwd(g, fptr(ru), fptr(rv), fptr(rs), fptr(rd), fptr(lat), fptr(lon), n)
         O.orc_gduvfwd(og, fptr(ou), fptr(ov), fptr(rs), fptr(rd), fptr(lat), fptr(lon), n)
         assert np.array_equal(ou.view(np.uint32), ru.view(np.uint32)) and np.array_equal(ov.view(np.uint32), rv.view(np.uint32))
+
+
+HEMI = ec.hemi_cases()
+
+
+@pytest.mark.parametrize("name", sorted(HEMI))
+def test_hemispheric_scalar(name):
+    """hemispheric A / B sources (expanded into the other hemisphere, ez_xpnsrcgd) and targets: c_ezsint, c_gdll, x / y"""
+    L = ref(); O = ol.oracle()
+    case = HEMI[name]
+    ni, nj = case["src"][:2]; no, mo = case["dst"][:2]
+    gdin = ref_define(L, case["src"]); gdout = ref_define(L, ec.dst_spec(case))
+    gi = orc_define(case["src"]); go = orc_define(ec.dst_spec(case))
+    gs = O.orc_defset(go, gi)
+    zin = ec.synth_field(ni, nj, seed=11)
+    if case["src"][2] == "B":
+        z2 = zin.reshape(nj, ni); z2[:, -1] = z2[:, 0]; zin = np.ascontiguousarray(z2.reshape(-1))
+    assert L.c_ezdefset(gdout, gdin) == 1
+    for degree in (0, 1, 3):
+        for polar in (1, 0):
+            ref_setopts(L, degree, polar)
+            zr = np.full(no * mo, -999.0, np.float32); zo = np.full(no * mo, -999.0, np.float32)
+            rc_r = L.c_ezsint(fptr(zr), fptr(zin))
+            opts = ol.default_opts(degre_interp=degree, polar_correction=polar)
+            rc_o = O.orc_ezsint(gs, ctypes.byref(opts), fptr(zo), fptr(zin))
+            assert rc_o == rc_r, (name, degree, polar)
+            assert np.array_equal(zo.view(np.uint32), zr.view(np.uint32)), (name, degree, polar, int((zo != zr).sum()))
+    lat = np.zeros(no * mo, np.float32); lon = np.zeros(no * mo, np.float32)
+    L.c_gdll(gdout, fptr(lat), fptr(lon))
+    assert np.array_equal(ol.np_from(go.contents.lat, no * mo), lat)
+    ref_setopts(L, 3, 1)
