@@ -478,8 +478,8 @@ static int grid_ok(int gd) { return gd >= 0 && gd < nG && G[gd].used; }
 static int type_supported(char t, char ref, int ig1, int ig2)
 {
     if (t == 'L' || t == 'E' || t == 'N' || t == 'S') return 1;
-    if (t == 'A' || t == 'B') return ig1 >= 0 && ig1 <= 2 && ig2 == 0;   /* hemispheric: scalars only; y-inverted: out of scope */
-    if (t == 'G') return ig1 == 0 && ig2 == 0;
+    if (t == 'A' || t == 'B') return ig1 >= 0 && ig1 <= 2 && ig2 >= 0 && ig2 <= 1;   /* hemispheric / y-inverted: scalars only */
+    if (t == 'G') return ig1 == 0 && ig2 >= 0 && ig2 <= 1;
     if (t == 'Z') return ref == 'L' || ref == 'E';
     if (t == 'Y') return ref == 'L';                                      /* as a target; c_ezdefset refuses it as a source */
     return 0;
@@ -800,6 +800,7 @@ int32_t c_ezgetival(char *option, int32_t *ivalue)
 /* ------------------------------------------------------------------------------------------ */
 /* target coordinates: ez_calclatlon.c:30-284 (GRLL grll.f:57-64, c_llfgr ez_llfgr.c:25-33)       */
 /* ------------------------------------------------------------------------------------------ */
+static int grid_yinv(const ezh_grid *g);
 static void ensure_coords(ezh_grid *g)
 {
     if (g->coords_ready) return;
@@ -844,6 +845,8 @@ static void ensure_coords(ezh_grid *g)
             }
         }
     }
+    if (grid_yinv(g))                                      /* ez_calclatlon.c:268-279: PERMUT of the latitudes */
+        for (int j = 0; j < nj / 2; j++) { float t = g->lat1d[j]; g->lat1d[j] = g->lat1d[nj - 1 - j]; g->lat1d[nj - 1 - j] = t; }
     if (!g->separable) {   /* rotated grids: full 2-D true lat/lon through ez_gfllfxy */
         size_t n = (size_t)ni * nj;
         float *rlat = (float *)malloc(sizeof(float) * n), *rlon = (float *)malloc(sizeof(float) * n);
@@ -950,6 +953,7 @@ static int src_is_separable(const ezh_grid *g)
 }
 static int src_irregular(const ezh_grid *g) { return g->grtyp == 'G' || g->grtyp == 'Z'; }
 static int src_hemi(const ezh_grid *g) { return (g->grtyp == 'A' || g->grtyp == 'B') && g->ig[0] != 0; }
+static int grid_yinv(const ezh_grid *g) { return (g->grtyp == 'A' || g->grtyp == 'B' || g->grtyp == 'G') && g->ig[1] == 1; }      /* axe_y_inverse, ez_defxg.c:68-72 */
 
 static int set_extrap(const ezh_grid *gi)
 {
@@ -1002,6 +1006,7 @@ static int choose_mode(const ezh_set *s, int degree, int polar)
     if (!s->sep_capable) return 2;
     if (getenv("EZHIP_FORCE_PTS")) return 2;
     if (src_hemi(gi)) return 2;                            /* rows j1..j2 of the expanded field: the per-point kernel indexes them natively */
+    if (grid_yinv(&G[s->gdout])) return 2;                 /* target rows run north to south */
     /* ez_irgdint_3_nw rounds every intermediate to REAL (ez_irgdint_3_nw.inc:32): not a linear
      * functional of the stencil, keep it on the point-exact kernel */
     if (src_irregular(gi) && gi->extension == 0 && degree == DEG_CUBIC) return 2;
@@ -1576,7 +1581,7 @@ static const float *hemi_expand(const ezh_grid *gi, const float *d_zin)
     size_t n = (size_t)gi->ni * (size_t)(gi->j2 - gi->j1 + 1);
     if (t_xpn.cap < n) { if (t_xpn.p) { ezhip_sync(); ezhip_free(t_xpn.p); } t_xpn.p = (float *)ezhip_malloc(sizeof(float) * n); t_xpn.cap = t_xpn.p ? n : 0; }
     if (!t_xpn.p) return NULL;
-    if (ezhip_hemi_expand(t_xpn.p, d_zin, gi->ni, gi->nj, gi->j1, gi->j2, gi->ig[0], gi->grtyp == 'B', 1)) return NULL;
+    if (ezhip_hemi_expand(t_xpn.p, d_zin, gi->ni, gi->nj, gi->j1, gi->j2, src_hemi(gi) ? gi->ig[0] : 0, gi->grtyp == 'B', 1, grid_yinv(gi))) return NULL;
     return t_xpn.p;
 }
 static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector_mode, const float *prow_n, const float *prow_s, const float *d_poles_pre);
@@ -1597,6 +1602,14 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
     int ierc = 0;
     if (ensure_scratch(s)) return -1;
     float *d_fill = t_scratch8, *d_poles = t_scratch8 + 4;
+    if (grid_yinv(gi)) {
+        if (vector_mode) { fprintf(stderr, "<c_ezuvint> y-inverted source grids are outside the MI355X hot-path scope for winds\n"); return -1; }
+        if (!src_hemi(gi)) {                               /* ezsint.c:100-106: the rows in reverse order (PERMUT); a hemisphere is flipped while it is expanded */
+            d_zin = hemi_expand(gi, d_zin);
+            if (!d_zin) return -1;
+            d_poles_pre = NULL;
+        }
+    }
     pthread_mutex_lock(&g_plan_mtx);
     int mode = choose_mode(s, degree, polar);          /* may analyse the set (first use) */
     pthread_mutex_unlock(&g_plan_mtx);
@@ -1681,7 +1694,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     int degree = O.degre_interp, polar = O.polar_correction == 1;
     if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return -2;
-    if (getenv("EZHIP_NO_PTS2")) return -2;
+    if (getenv("EZHIP_NO_PTS2") || src_hemi(gi) || grid_yinv(gi)) return -2;
     pthread_mutex_lock(&g_plan_mtx);
     int mode = choose_mode(s, degree, polar);
     pthread_mutex_unlock(&g_plan_mtx);
@@ -1758,7 +1771,7 @@ static int32_t batch_impl(float *d_zout, const float *d_zin, int32_t nfields, un
     }
     /* separable plan without extrapolation fill: ALL fields in one k_sepx launch (no ramp-up / drain gap between
      * fields; the pole rows are summed by producer blocks of the same launch) */
-    if (s->gdin != s->gdout && (nfields > 1 || stat_partials) && !(O.polar_correction == 1 && s->extrap) &&
+    if (s->gdin != s->gdout && (nfields > 1 || stat_partials) && !(O.polar_correction == 1 && s->extrap) && !grid_yinv(&G[s->gdin]) &&
         (O.degre_interp == DEG_NEAREST || O.degre_interp == DEG_LINEAR || O.degre_interp == DEG_CUBIC) &&
         choose_mode(s, O.degre_interp, O.polar_correction == 1) == 1 && !getenv("EZHIP_NO_BATCH_LAUNCH") && !getenv("EZHIP_NO_SEPX")) {
         int degree = O.degre_interp, polar = O.polar_correction == 1;
@@ -1886,7 +1899,7 @@ int32_t c_gdxysint_dev(float *d_zout, const float *d_zin, int32_t gdin, const fl
     if (ensure_grid_dev(gi)) return -1;
     ezhip_pts_plan pp;
     fill_pts_plan(NULL, gi, &pp, degree, 0, 0);
-    if (src_hemi(gi)) { d_zin = hemi_expand(gi, d_zin); if (!d_zin) return -1; }      /* gdxysint.c:44-47 */
+    if (src_hemi(gi) || grid_yinv(gi)) { d_zin = hemi_expand(gi, d_zin); if (!d_zin) return -1; }      /* gdxysint.c:35-47 */
     return ezhip_interp_pts(&pp, d_zout, d_zin, d_x, d_y, npts) ? -1 : 0;
 }
 int32_t c_gdxysint(float *zout, float *zin, int32_t gdin, float *x, float *y, int32_t npts)
@@ -2065,7 +2078,7 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
     if (G[s->gdout].grtyp == 'U') { fprintf(stderr, "<c_ezuvint> winds towards a Yin-Yang 'U' grid (rotated subgrids) are outside the MI355X hot-path scope\n"); return -1; }
     if (G[s->gdin].grtyp == 'U') return yy_uvint(s, d_uuout, d_vvout, d_uuin, d_vvin, wd_only);
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
-    if (src_hemi(gi)) { fprintf(stderr, "<c_ezuvint> hemispheric source grids are outside the MI355X hot-path scope for winds\n"); return -1; }
+    if (src_hemi(gi) || grid_yinv(gi)) { fprintf(stderr, "<c_ezuvint> hemispheric / y-inverted source grids are outside the MI355X hot-path scope for winds\n"); return -1; }
     if (go->grtyp == 'E' || (go->grtyp == 'Z' && go->grref == 'E') || go->grtyp == 'Z') {
         fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp);
         return -1;

@@ -1750,7 +1750,7 @@ extern "C" int ezhip_mask_fill_min(float *d_fld, const int *d_mask, size_t n, un
 }
 
 /* ez_xpngdag2.inc / ez_xpngdb2.inc: row jo (j1..j2) of the expansion <- source row (1..nj), mirrored rows times sign */
-__global__ __launch_bounds__(256) void k_hemi_expand(float *__restrict__ dst, const float *__restrict__ src, int ni, int nj, int j1, int j2, int hem, int is_b, float sign)
+__global__ __launch_bounds__(256) void k_hemi_expand(float *__restrict__ dst, const float *__restrict__ src, int ni, int nj, int j1, int j2, int hem, int is_b, float sign, int yinv)
 {
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t n = (size_t)ni * (size_t)(j2 - j1 + 1);
@@ -1760,12 +1760,13 @@ __global__ __launch_bounds__(256) void k_hemi_expand(float *__restrict__ dst, co
     if (jo >= 1 && jo <= nj) js = jo;
     else if (hem == 1) { js = is_b ? 2 - jo : 1 - jo; sg = sign; }          /* NORD: zout(i, 2-j) / zout(i, -j+1) = sign * zi(i, j) */
     else { js = is_b ? 2 * nj - jo : 2 * nj + 1 - jo; sg = sign; }          /* SUD:  zout(i, nj+j-1) / zout(i, nj+j) = sign * zi(i, nj-j+1) */
+    if (yinv) js = nj + 1 - js;                               /* the source rows were reversed first (PERMUT) */
     dst[k] = sg * src[(size_t)(js - 1) * ni + i];
 }
-extern "C" int ezhip_hemi_expand(float *d_dst, const float *d_src, int ni, int nj, int j1, int j2, int hem, int is_b, int symetrie)
+extern "C" int ezhip_hemi_expand(float *d_dst, const float *d_src, int ni, int nj, int j1, int j2, int hem, int is_b, int symetrie, int yinv)
 {
     const size_t n = (size_t)ni * (size_t)(j2 - j1 + 1);
-    hipLaunchKernelGGL(k_hemi_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, d_dst, d_src, ni, nj, j1, j2, hem, is_b, symetrie == 0 ? -1.0f : 1.0f);
+    hipLaunchKernelGGL(k_hemi_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, d_dst, d_src, ni, nj, j1, j2, hem, is_b, symetrie == 0 ? -1.0f : 1.0f, yinv);
     return LAUNCH_CHECK("k_hemi_expand");
 }
 

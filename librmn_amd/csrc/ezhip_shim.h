@@ -161,7 +161,7 @@ int ezhip_mask_fill_min(float *d_fld, const int *d_mask, size_t n, unsigned *d_k
 int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_plan *plan_v, float *d_out_u, float *d_out_v,
                       const float *d_in_u, const float *d_in_v, const float *d_x, const float *d_y, int npts);
 /* ez_xpngdag2 / ez_xpngdb2: hemispheric field (ni x nj) -> rows j1..j2 of its global expansion, mirrored rows times +-1 */
-int ezhip_hemi_expand(float *d_dst, const float *d_src, int ni, int nj, int j1, int j2, int hem, int is_b, int symetrie);
+int ezhip_hemi_expand(float *d_dst, const float *d_src, int ni, int nj, int j1, int j2, int hem, int is_b, int symetrie, int yinv);   /* hem 0: copy; yinv: source rows in reverse order first (PERMUT) */
 /* d_dst[d_idx[k]] = d_src[k] (the merge of the Yin and Yang point lists) */
 int ezhip_scatter(float *d_dst, const float *d_src, const int *d_idx, int n);
 /* pole values {north, south} of a source field -> device float[2] */

@@ -221,10 +221,10 @@ orc_grid *orc_grid_define(int ni, int nj, char grtyp, char grref,
     g->ig[0] = ig1; g->ig[1] = ig2; g->ig[2] = ig3; g->ig[3] = ig4;
     switch (grtyp) {
     case 'A': case 'B':
-        if (ig1 < 0 || ig1 > 2 || ig2 != 0) { fprintf(stderr, "orc_grid_define: inverted grids out of scope\n"); free(g); return NULL; }
+        if (ig1 < 0 || ig1 > 2 || ig2 < 0 || ig2 > 1) { fprintf(stderr, "orc_grid_define: bad ig1 / ig2\n"); free(g); return NULL; }
         break;
     case 'G':
-        if (ig1 != 0 || ig2 != 0) { fprintf(stderr, "orc_grid_define: hemispheric/inverted 'G' grids out of scope\n"); free(g); return NULL; }
+        if (ig1 != 0 || ig2 < 0 || ig2 > 1) { fprintf(stderr, "orc_grid_define: hemispheric 'G' grids out of scope\n"); free(g); return NULL; }
         break;
     case 'L': case 'E': case 'Z': case 'N': case 'S': break;
     case 'Y': if (grref != 'L') { fprintf(stderr, "orc_grid_define: 'Y' grids on '%c' out of scope\n", grref); free(g); return NULL; } break;   /* target only */
@@ -298,6 +298,13 @@ static void grll(float *lat, float *lon, int ni, int nj, float xla0, float xlo0,
             lon[(j - 1) * ni + i - 1] = fmodf(xlo0 + (float)(i - 1) * dlo0, 360.0f);
         }
     }
+}
+
+/* PERMUT, src/base/permut.f:30-46: the rows of z(ni, nj) in reverse order */
+void orc_permut(float *z, int ni, int nj)
+{
+    for (int j = 0; j < nj / 2; j++)
+        for (int i = 0; i < ni; i++) { float t = z[(size_t)(nj - 1 - j) * ni + i]; z[(size_t)(nj - 1 - j) * ni + i] = z[(size_t)j * ni + i]; z[(size_t)j * ni + i] = t; }
 }
 
 /* LLFXY, src/base/llfxy.F:21-40: all REAL arithmetic (RDTODG from pi.cdk) */
@@ -385,6 +392,7 @@ int orc_calclatlon(orc_grid *g)
         break;
     default: return -1;
     }
+    if ((g->grtyp == 'A' || g->grtyp == 'B' || g->grtyp == 'G') && g->ig[1] == 1) orc_permut(g->lat, ni, nj);      /* :268-279 */
     return 0;
 }
 
@@ -1125,7 +1133,13 @@ int orc_ezsint(orc_gridset *gs, const orc_opts *o, float *zout, const float *zin
 {
     orc_grid *gi = gs->gdin, *go = gs->gdout;
     if (gi == go) { memcpy(zout, zin, sizeof(float) * gi->ni * gi->nj); return 1; }
-    float *xz = NULL;
+    float *xz = NULL, *pz = NULL;
+    if ((gi->grtyp == 'A' || gi->grtyp == 'B' || gi->grtyp == 'G') && gi->ig[1] == 1) {      /* ezsint.c:100-106: axe_y_inverse */
+        pz = (float *)malloc(sizeof(float) * (size_t)gi->ni * gi->nj);
+        memcpy(pz, zin, sizeof(float) * (size_t)gi->ni * gi->nj);
+        orc_permut(pz, gi->ni, gi->nj);
+        zin = pz;
+    }
     if ((gi->grtyp == 'A' || gi->grtyp == 'B') && gi->ig[0] != 0) {      /* ezsint.c:108-113 -> ez_xpnsrcgd */
         xz = (float *)malloc(sizeof(float) * 2 * (size_t)gi->ni * gi->nj);
         orc_xpnsrcgd(gi, xz, zin, o->vecteur == 2 ? 0 : 1);
@@ -1139,6 +1153,6 @@ int orc_ezsint(orc_gridset *gs, const orc_opts *o, float *zout, const float *zin
         orc_defzones(gs);
         ierc = corrval(gs, o, zout, zin);
     }
-    free(xz);
+    free(xz); free(pz);
     return ierc;
 }

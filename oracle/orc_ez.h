@@ -91,6 +91,7 @@ void orc_gridset_free(orc_gridset *gs);
 int orc_calcxy(orc_gridset *gs);
 /* ez_defzones (src/interp/ez_defzones.c:25-113) */
 int orc_defzones(orc_gridset *gs);
+void orc_permut(float *z, int ni, int nj);      /* src/base/permut.f */
 /* ez_xpnsrcgd (src/interp/ez_xpnsrcgd.c:28-52): hemispheric A / B source -> its global expansion zout(ni, j1:j2) */
 void orc_xpnsrcgd(const orc_grid *g, float *zout, const float *zi, int symetrie);
 /* c_ezsint_orig (src/interp/ezsint.c:75-135) */

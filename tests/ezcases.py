@@ -142,4 +142,10 @@ def hemi_cases():
     c["Bsud_to_L"] = dict(src=(49, 13, "B", (2, 0, 0, 0), " ", None), dst=(60, 31, "L", (600, 600, 0, 0)))
     c["L_to_Anord"] = dict(src=(40, 20, "L", (900, 900, 450, 0), " ", None), dst=(48, 12, "A", (1, 0, 0, 0)))
     c["G_to_Bsud"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(49, 13, "B", (2, 0, 0, 0)))
+    # y-inverted grids (ig2 = 1): the rows run from north to south
+    c["Ainv_to_L"] = dict(src=(48, 24, "A", (0, 1, 0, 0), " ", None), dst=(60, 31, "L", (600, 600, 0, 0)))
+    c["Ginv_to_L"] = dict(src=(64, 32, "G", (0, 1, 0, 0), " ", None), dst=(60, 31, "L", (600, 600, 0, 0)))
+    c["AnordInv_to_L"] = dict(src=(48, 12, "A", (1, 1, 0, 0), " ", None), dst=(60, 31, "L", (600, 600, 0, 0)))
+    c["L_to_Binv"] = dict(src=(40, 20, "L", (900, 900, 450, 0), " ", None), dst=(49, 25, "B", (0, 1, 0, 0)))
+    c["G_to_Ginv"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(48, 24, "G", (0, 1, 0, 0)))
     return c
