@@ -105,6 +105,8 @@ int32_t c_gdllfxy(int32_t gdid, float *lat, float *lon, float *x, float *y, int3
 int32_t c_gdxywdval(int32_t gdin, float *uuout, float *vvout, float *uuin, float *vvin, float *x, float *y, int32_t n);       /* gdxywdval.c:38 */
 int32_t c_gdllwdval(int32_t gdid, float *uuout, float *vvout, float *uuin, float *vvin, float *lat, float *lon, int32_t n);   /* gdllwdval.c:36 */
 int32_t c_gdxyzfll(int32_t gdid, float *x, float *y, float *lat, float *lon, int32_t n);     /* ezscint.h:141 ; gdxyzfll.c:33 (host) */
+int32_t c_ezgdef(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t ig1, int32_t ig2, int32_t ig3, int32_t ig4, float *ax, float *ay);   /* ezscint.h:15 ; ezgdef.c:42 (memory form only) */
+int32_t c_gdxpncf(int32_t gdin, int32_t *i1, int32_t *i2, int32_t *j1, int32_t *j2);        /* ezscint.h:117 ; gdxpncf.c:33 */
 int32_t c_ezgdef_fll(int32_t ni, int32_t nj, float *lat, float *lon);                       /* ezscint.h:24 ; ezgdef_fll.c:36 ('Y' on 'L') */
 int32_t c_ezget_nsubgrids(int32_t gdid);                                                    /* ezscint.h:169 */
 int32_t c_ezget_subgridids(int32_t gdid, int32_t *subgrid);                                 /* ezscint.h:172 */

@@ -2188,6 +2188,23 @@ int32_t c_ezwdint(float *spdout, float *dirout, float *uuin, float *vvin) { retu
 /* ------------------------------------------------------------------------------------------ */
 /* small public entry points around the same kernels                                            */
 /* ------------------------------------------------------------------------------------------ */
+/* c_ezgdef (ezgdef.c:42-95): the memory form is c_ezgdef_fmem; grids described by an FST file are out of scope */
+int32_t c_ezgdef(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t ig1, int32_t ig2, int32_t ig3, int32_t ig4, float *ax, float *ay)
+{
+    if (grtyp[0] == '#') { fprintf(stderr, "The '#' grid type is not supported with ezgdef.\nPlease use ezgdef_ffile or ezgdef_fmem\n"); return -1; }
+    if ((grtyp[0] == 'Y' || grtyp[0] == 'Z') && grref && (!strcmp(grref, "FILE") || !strcmp(grref, "file"))) {
+        fprintf(stderr, "<c_ezgdef> grid descriptors read from an FST file are outside the MI355X hot-path scope; use c_ezgdef_fmem\n");
+        return -1;
+    }
+    return c_ezgdef_fmem(ni, nj, grtyp, grref, ig1, ig2, ig3, ig4, ax, ay);
+}
+int32_t c_gdxpncf(int32_t gdin, int32_t *i1, int32_t *i2, int32_t *j1, int32_t *j2)                                           /* gdxpncf.c:33-50 */
+{
+    if (!grid_ok(gdin)) return -1;
+    if (G[gdin].nsub > 0) { fprintf(stderr, "<gdxpncf> This operation is not supported for 'U' grids.\n"); return -1; }
+    *i1 = G[gdin].i1; *i2 = G[gdin].i2; *j1 = G[gdin].j1; *j2 = G[gdin].j2;
+    return 0;
+}
 int32_t c_ezget_nsubgrids(int32_t gdid) { if (!grid_ok(gdid)) return -1; return G[gdid].nsub ? G[gdid].nsub : 1; }           /* ezget_nsubgrids.c:25-33 */
 int32_t c_ezget_subgridids(int32_t gdid, int32_t *subgrid)                                                                    /* ezget_subgridids.c:25-37 */
 {
