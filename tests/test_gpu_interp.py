@@ -682,3 +682,49 @@ def test_hemispheric_scalar_vs_golden(name):
     if hemi_src:
         uu, vv = ec.synth_wind(ni, nj, seed=3)
         assert ez.ezuvint(uu, vv, no * mo)[0] == -1          # winds from a hemispheric source: refused
+
+
+@pytest.mark.parametrize("name", ["Anord_to_L", "Bsud_to_L", "Ainv_to_L", "AnordInv_to_L"])
+def test_gdxysint_hemispheric_and_inverted_sources(name):
+    """c_gdxysint on a hemispheric / y-inverted source (gdxysint.c:35-47: PERMUT, ez_xpnsrcgd, then the leaf kernel on rows j1..j2)
+    against the oracle's c_gdinterp on the field it permutes / expands itself: bit-exact; and a batch call of the same set"""
+    case = HEMI[name]
+    ni, nj = case["src"][:2]
+    gdin = hip_define(case["src"])
+    import test_oracle_golden as tog
+    gi = tog.orc_define(case["src"])
+    O = ol.oracle()
+    O.orc_xpnsrcgd.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    O.orc_permut.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    zin = ec.synth_field(ni, nj, seed=13)
+    if case["src"][2] == "B":
+        z2 = zin.reshape(nj, ni); z2[:, -1] = z2[:, 0]; zin = np.ascontiguousarray(z2.reshape(-1))
+    hem, yinv = case["src"][3][0], case["src"][3][1]
+    src = zin.copy()
+    if yinv:
+        O.orc_permut(src.ctypes.data, ni, nj)
+    j1, j2 = gi.contents.j1, gi.contents.j2
+    if hem:
+        ex = np.zeros(ni * (j2 - j1 + 1), np.float32)
+        O.orc_xpnsrcgd(ctypes.cast(gi, ctypes.c_void_p), ex.ctypes.data, src.ctypes.data, 1)
+        src = ex
+    n = 400
+    x = (ec.hash_uniform(45, n).astype(np.float64) * (ni - 1.0) + 1.0).astype(np.float32)
+    y = (ec.hash_uniform(46, n).astype(np.float64) * (j2 - j1 - 3.0) + (j1 + 1.5)).astype(np.float32)
+    for degree in (0, 1, 3):
+        setopts(degree, 1)
+        rc, z = ez.gdxysint(zin, gdin, x, y)
+        want = np.zeros(n, np.float32)
+        O.orc_gdinterp(gi, degree, ol.fptr(want), ol.fptr(src), ol.fptr(x), ol.fptr(y), n)
+        assert rc == 0 and np.array_equal(z.view(np.uint32), want.view(np.uint32)), (name, degree, float(relerr(z, want).max()))
+    # the batch entry point on such a set loops over the fields
+    no, mo = case["dst"][:2]
+    gdout = hip_define(ec.dst_spec(case))
+    assert ez.ezdefset(gdout, gdin) == 1
+    setopts(3, 1)
+    d_in = torch.from_numpy(np.stack([zin, zin[::-1].copy()])).cuda(); d_out = torch.empty((2, no * mo), dtype=torch.float32, device="cuda")
+    ez.use_stream(0)
+    assert ez.ezsint_batch_dev(d_out, d_in, 2) == 0
+    torch.cuda.synchronize()
+    rc, single = ez.ezsint(zin, no * mo)
+    assert np.array_equal(d_out[0].cpu().numpy().view(np.uint32), single.view(np.uint32))
