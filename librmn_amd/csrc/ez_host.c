@@ -2075,11 +2075,25 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
     ezh_set *s = current_set(wd_only ? "c_ezwdint" : "c_ezuvint");
     if (!s) return -1;
     if (need_device("c_ezuvint")) return -1;
-    if (G[s->gdout].grtyp == 'U') { fprintf(stderr, "<c_ezuvint> winds towards a Yin-Yang 'U' grid (rotated subgrids) are outside the MI355X hot-path scope\n"); return -1; }
+    if (G[s->gdout].grtyp == 'U') {                        /* ezyyuvint.c:88-106 / :216-300: the two Z-on-E subgrids one after the other */
+        const ezh_grid *gu = &G[s->gdout];
+        const size_t nsub = (size_t)G[gu->sub[0]].ni * G[gu->sub[0]].nj;
+        const int save_in = cur_gdin, save_out = cur_gdout, gdin_ = s->gdin, sub0 = gu->sub[0], sub1 = gu->sub[1];
+        int rc = 0;
+        for (int k = 0; k < 2; k++) {
+            cur_gdin = gdin_; cur_gdout = k ? sub1 : sub0;
+            int r = uvint_impl(d_uuout + k * nsub, d_vvout + k * nsub, d_uuin, d_vvin, wd_only);
+            if (r < 0) { rc = r; break; }
+            if (r == 2) rc = 2;
+        }
+        cur_gdin = save_in; cur_gdout = save_out;
+        return rc;
+    }
     if (G[s->gdin].grtyp == 'U') return yy_uvint(s, d_uuout, d_vvout, d_uuin, d_vvin, wd_only);
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     if (src_hemi(gi) || grid_yinv(gi)) { fprintf(stderr, "<c_ezuvint> hemispheric / y-inverted source grids are outside the MI355X hot-path scope for winds\n"); return -1; }
-    if (go->grtyp == 'E' || (go->grtyp == 'Z' && go->grref == 'E') || go->grtyp == 'Z') {
+    if (go->grtyp == 'E' || (go->grtyp == 'Z' && go->grref != 'E')) {
+        /* regular 'E' targets: the reference reads uninitialised memory; Z-on-L targets: it converts twice (missing break) */
         fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp);
         return -1;
     }
@@ -2143,6 +2157,7 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
     wp.fast_trig = getenv("EZHIP_WIND_FAST_TRIG") != NULL;
     if (gi->grtyp == 'N' || gi->grtyp == 'S') { wp.src_ps = gi->grtyp == 'N' ? 1 : 2; wp.src_xg4 = gi->xg[3]; }
     if (go->grtyp == 'N' || go->grtyp == 'S') { wp.dst_ps = go->grtyp == 'N' ? 1 : 2; wp.dst_xg4 = go->xg[3]; }
+    if (go->grtyp == 'Z' && go->grref == 'E') { float ri_[9]; wp.dst_rotated = 1; h_crot(wp.r_dst, ri_, go->xgref[1], go->xgref[0], go->xgref[3], go->xgref[2]); }
     if (wp.src_rotated) { const float *xg = gi->grtyp == 'E' ? gi->xg : gi->xgref; h_crot(wp.r, wp.ri, xg[1], xg[0], xg[3], xg[2]); }
     else if (gi->grtyp == 'Z' && gi->grref != 'L') return -1;
     if (wp.src_rotated && wp.separable) {
@@ -2361,8 +2376,9 @@ static int wind_conv_dev(int32_t gdid, float *d_a, float *d_b, const float *d_la
         if (rotated) { const float *xg = g->grtyp == 'E' ? g->xg : g->xgref; h_crot(wp.r, wp.ri, xg[1], xg[0], xg[3], xg[2]); }
         if (g->grtyp == 'N' || g->grtyp == 'S') { wp.src_ps = g->grtyp == 'N' ? 1 : 2; wp.src_xg4 = g->xg[3]; }
     } else {
-        if (rotated || g->grtyp == 'Z') { fprintf(stderr, "<c_gduvfwd> '%c' target grids are outside the MI355X hot-path scope for winds\n", g->grtyp); return -1; }
+        if (g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref != 'E')) { fprintf(stderr, "<c_gduvfwd> '%c' target grids are outside the MI355X hot-path scope for winds\n", g->grtyp); return -1; }
         wp.wd_in = 1;
+        if (rotated) { float ri_[9]; wp.dst_rotated = 1; h_crot(wp.r_dst, ri_, g->xgref[1], g->xgref[0], g->xgref[3], g->xgref[2]); }
         if (g->grtyp == 'N' || g->grtyp == 'S') { wp.dst_ps = g->grtyp == 'N' ? 1 : 2; wp.dst_xg4 = g->xg[3]; }
     }
     if (npts <= 0) return 0;
@@ -2659,7 +2675,7 @@ static int32_t yy_uvint(ezh_set *s, float *d_uuout, float *d_vvout, const float 
         fprintf(stderr, "<c_ezuvint> this Yin-Yang case (target = a subgrid, or c_ezwdint) is outside the MI355X hot-path scope\n");
         return -1;
     }
-    if (go->grtyp == 'E' || go->grtyp == 'Z') { fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp); return -1; }
+    if (go->grtyp == 'E' || (go->grtyp == 'Z' && go->grref != 'E')) { fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp); return -1; }
     int degree = O.degre_interp;
     if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return -1;
     if (yy_plan(s) || ensure_coords_dev(go)) return -1;
@@ -2683,6 +2699,7 @@ static int32_t yy_uvint(ezh_set *s, float *d_uuout, float *d_vvout, const float 
     memset(&wp, 0, sizeof(wp));
     wp.separable = go->separable; wp.wd_in = 1;
     if (go->grtyp == 'N' || go->grtyp == 'S') { wp.dst_ps = go->grtyp == 'N' ? 1 : 2; wp.dst_xg4 = go->xg[3]; }
+    if (go->grtyp == 'Z' && go->grref == 'E') { float ri_[9]; wp.dst_rotated = 1; h_crot(wp.r_dst, ri_, go->xgref[1], go->xgref[0], go->xgref[3], go->xgref[2]); }
     if (ezhip_wind_rotate(&wp, d_uuout, d_vvout, go->d_lat, go->d_lon, go->ni, go->nj)) return -1;
     return 0;
 }

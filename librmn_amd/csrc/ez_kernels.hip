@@ -1618,6 +1618,29 @@ extern "C" int ezhip_wind_trig_tables(double *d_lon_trig, double *d_lat_trig, fl
     return LAUNCH_CHECK("k_wind_trig");
 }
 
+/* c_ezgfwfllw after its ez_gdwfllw 'L' step: true components (u, v) at true (lon, lat) -> components on the rotated target grid:
+ * ez_uvacart at the TRUE coordinates, mxm with r, ez_cartauv at the ROTATED coordinates (ez_gfxyfll of the true ones) */
+__device__ __forceinline__ void d_to_rotated_target(const float *r, float lon, float lat, float &u, float &v)
+{
+    const double dar = (double)(float)(3.14159274101257324 / 180.0);
+    double a, b, c, d;
+    sincos(dar * (double)lon, &a, &b);
+    sincos(dar * (double)lat, &c, &d);
+    const float x0 = (float)(-((double)u * a) - ((double)v * b * c));
+    const float x1 = (float)(((double)u * b) - ((double)v * a * c));
+    const float x2 = (float)((double)v * d);
+    float q[3];
+    for (int i = 0; i < 3; i++) { float s = 0.0f; s = s + r[i] * x0; s = s + r[3 + i] * x1; s = s + r[6 + i] * x2; q[i] = s; }
+    float lon_r, lat_r;
+    d_rotate(r, lon, lat, lon_r, lat_r);
+    const double aa = cos(dar * (double)lon_r), bb = sin(dar * (double)lon_r), ee = cos(dar * (double)lat_r), ff = sin(dar * (double)lat_r);
+    u = (float)(((double)q[1] * aa) - ((double)q[0] * bb));
+    const double cc = ((double)q[0] * aa) + ((double)q[1] * bb);
+    const double dd = sqrt(cc * cc + (double)(q[2] * q[2]));
+    const double sg = ((double)q[2] * ee) - (cc * ff);
+    v = (float)(sg >= 0.0 ? fabs(dd) : -fabs(dd));
+}
+
 __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *__restrict__ uu, float *__restrict__ vv,
                                                      const float *__restrict__ lats, const float *__restrict__ lons,
                                                      int ni_dst, int nj_dst)
@@ -1633,8 +1656,9 @@ __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *_
     if (p.wd_in) {                                          /* speed / direction given: c_gduvfwd only */
         const float spd_ = u, dir_ = v;
         float psi_ = p.dst_ps == 1 ? lon + p.dst_xg4 - dir_ : p.dst_ps == 2 ? 180.0f - lon + p.dst_xg4 - dir_ : 270.0f - dir_;
-        uu[n] = cosf(psi_ * DGTORD) * spd_;
-        vv[n] = sinf(psi_ * DGTORD) * spd_;
+        float uo = cosf(psi_ * DGTORD) * spd_, vo = sinf(psi_ * DGTORD) * spd_;
+        if (p.dst_rotated) d_to_rotated_target(p.r_dst, lon, lat, uo, vo);
+        uu[n] = uo; vv[n] = vo;
         return;
     }
     if (p.src_rotated) {                                    /* c_ezllwfgfw, ez_llwfgfw.c:38-73 */
@@ -1683,8 +1707,9 @@ __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *_
     if (p.wd_only) { uu[n] = spd; vv[n] = dir; return; }      /* c_ezwdint: speed / direction are the result */
     /* speed, direction -> target components: ez_gdwfllw.inc:93-105 ('N'), :108-121 ('S'), :123-134 ('L'/A/B/G) */
     float psi = p.dst_ps == 1 ? lon + p.dst_xg4 - dir : p.dst_ps == 2 ? 180.0f - lon + p.dst_xg4 - dir : 270.0f - dir;
-    uu[n] = cosf(psi * DGTORD) * spd;
-    vv[n] = sinf(psi * DGTORD) * spd;
+    float uo = cosf(psi * DGTORD) * spd, vo = sinf(psi * DGTORD) * spd;
+    if (p.dst_rotated) d_to_rotated_target(p.r_dst, lon, lat, uo, vo);      /* Z-on-E target: c_ezgfwfllw */
+    uu[n] = uo; vv[n] = vo;
 }
 
 /* ===================================================================================== */

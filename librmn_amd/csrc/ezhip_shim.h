@@ -197,6 +197,7 @@ typedef struct {
     int wd_in;                        /* 1: uu / vv already hold speed / direction: only c_gduvfwd on the target (Yin-Yang merge) */
     int src_ps, dst_ps;               /* 0, or 1 = 'N' / 2 = 'S': polar-stereographic source / target (ez_llwfgdw.inc:91-140, ez_gdwfllw.inc:93-121) */
     float src_xg4, dst_xg4;           /* their dgrw */
+    int dst_rotated; float r_dst[9];  /* Z-on-E TARGET: c_ezgfwfllw (ez_gfwfllw.c:38-79) with its rotation matrix r */
     const double *lon_trig, *lat_trig;   /* separable + rotated source: {cos, sin} per target column / row (ezhip_wind_trig_tables), or NULL */
     const float *lon_trigf, *lat_trigf;  /* the REAL {cos, sin} pairs of the same angles (rotation into the source frame) */
 } ezhip_wind_plan;

@@ -178,6 +178,38 @@ static void llwfgfw(float *uu, float *vv, const float *latin, const float *lonin
     free(xyz); free(uvcart);
 }
 
+/* c_ezgfwfllw, src/interp/ez_gfwfllw.c:38-79: (speed, direction) at true lat/lon -> components on the rotated grid:
+ * ez_gdwfllw 'L', ez_uvacart at TRUE lon/lat, mxm with r, ez_cartauv at ROTATED lon/lat */
+static void gfwfllw(float *uu, float *vv, const float *latin, const float *lonin,
+                    const float *latgf, const float *longf, int n, int ig1, int ig2, int ig3, int ig4)
+{
+    float r[9], ri[9], xlat1, xlon1, xlat2, xlon2;
+    float *xyz = (float *)malloc(sizeof(float) * 3 * n), *uvcart = (float *)malloc(sizeof(float) * 3 * n);
+    orc_cigaxg('E', &xlat1, &xlon1, &xlat2, &xlon2, ig1, ig2, ig3, ig4);
+    crot(r, ri, xlon1, xlat1, xlon2, xlat2);
+    gdwfllw(uu, vv, lonin, n, 'L', 0, 0, 0, 0);
+    const double dar = (double)(acosf(-1.f) / 180.f);
+    for (int k = 0; k < n; k++) {                                /* ez_uvacart at TRUE lon/lat */
+        double a = sin(dar * (double)lonin[k]), b = cos(dar * (double)lonin[k]);
+        double c = sin(dar * (double)latin[k]), d = cos(dar * (double)latin[k]);
+        xyz[3 * k + 0] = (float)(-((double)uu[k] * a) - ((double)vv[k] * b * c));
+        xyz[3 * k + 1] = (float)(((double)uu[k] * b) - ((double)vv[k] * a * c));
+        xyz[3 * k + 2] = (float)((double)vv[k] * d);
+    }
+    mxm3(r, xyz, uvcart, n);
+    for (int k = 0; k < n; k++) {                                /* ez_cartauv at ROTATED lon/lat */
+        double a = cos(dar * (double)longf[k]), b = sin(dar * (double)longf[k]);
+        double e = cos(dar * (double)latgf[k]), f = sin(dar * (double)latgf[k]);
+        float c1 = uvcart[3 * k + 0], c2 = uvcart[3 * k + 1], c3 = uvcart[3 * k + 2];
+        uu[k] = (float)(((double)c2 * a) - ((double)c1 * b));
+        double c = ((double)c1 * a) + ((double)c2 * b);
+        double d = sqrt(c * c + (double)(c3 * c3));
+        double s = ((double)c3 * e) - (c * f);
+        vv[k] = (float)(s >= 0.0 ? fabs(d) : -fabs(d));
+    }
+    free(xyz); free(uvcart);
+}
+
 /* c_gdwdfuv_orig, src/interp/gdwdfuv.c:29-100 */
 int orc_gdwdfuv(orc_grid *g, float *spd, float *dir, const float *uu, const float *vv,
                 const float *lat, const float *lon, int npts)
@@ -204,12 +236,18 @@ int orc_gdwdfuv(orc_grid *g, float *spd, float *dir, const float *uu, const floa
 int orc_gduvfwd(orc_grid *g, float *uu, float *vv, const float *spd, const float *dir,
                 const float *lat, const float *lon, int npts)
 {
-    (void)lat;
     memcpy(uu, spd, sizeof(float) * npts);
     memcpy(vv, dir, sizeof(float) * npts);
-    if (g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E')) {
-        fprintf(stderr, "orc_gduvfwd: rotated target grids are out of scope\n");
+    if (g->grtyp == 'E') {
+        fprintf(stderr, "orc_gduvfwd: regular 'E' target grids are out of scope (the reference reads uninitialised memory there)\n");
         return -1;
+    }
+    if (g->grtyp == 'Z' && g->grref == 'E') {                   /* :62-80: ez_gfxyfll + c_ezgfwfllw, then return */
+        float *lat_rot = (float *)malloc(sizeof(float) * npts), *lon_rot = (float *)malloc(sizeof(float) * npts);
+        orc_gfxyfll(lon_rot, lat_rot, lon, lat, npts, g->xgref[0], g->xgref[1], g->xgref[2], g->xgref[3]);
+        gfwfllw(uu, vv, lat, lon, lat_rot, lon_rot, npts, g->igref[0], g->igref[1], g->igref[2], g->igref[3]);
+        free(lat_rot); free(lon_rot);
+        return 0;
     }
     if (g->grtyp == 'Z') gdwfllw(uu, vv, lon, npts, g->grref, g->igref[0], g->igref[1], g->igref[2], g->igref[3]);
     gdwfllw(uu, vv, lon, npts, g->grtyp, g->ig[0], g->ig[1], g->ig[2], g->ig[3]);

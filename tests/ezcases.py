@@ -84,6 +84,9 @@ def scalar_cases():
     cases["L_to_N"] = dict(src=(360, 180, "L", (100, 100, 50, 0), " ", None), dst=(101, 91, "N", N_IG))
     cases["S_to_L"] = dict(src=(81, 121, "S", S_IG, " ", None), dst=(90, 30, "L", (100, 100, 100, 0)))
     cases["G_to_S"] = dict(src=(128, 64, "G", (0, 0, 0, 0), " ", None), dst=(81, 121, "S", S_IG))
+    # rotated Z-on-E TARGET (winds: c_ezgfwfllw)
+    cases["L_to_ZE"] = dict(src=(40, 20, "L", (900, 900, 450, 0), " ", None), dst=(65, 32, "Z", E_IG), dst_ref="E", dst_axes=ze_axes)
+    cases["G_to_ZE"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(33, 16, "Z", E_IG), dst_ref="E", dst_axes=ze_axes)
     # 'Y' target: a cloud of points (incl. both poles and the seam)
     cases["G_to_Y"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(37, 11, "Y", (0, 0, 0, 0)), dst_ref="L", dst_axes=cloud_axes)
     cases["ZE_to_Y"] = dict(src=(65, 32, "Z", E_IG, "E", ze_axes), dst=(37, 11, "Y", (0, 0, 0, 0)), dst_ref="L", dst_axes=cloud_axes)

@@ -117,10 +117,16 @@ def main():
     for degree in (0, 1, 3):
         L.c_ezsetopt(b"interp_degree", DEG[degree]); L.c_ezsetopt(b"polar_correction", b"yes")
         zo = np.zeros(2 * tni * tnj, np.float32)
+        uo = np.zeros(2 * tni * tnj, np.float32); vo = np.zeros(2 * tni * tnj, np.float32)
+        ug, vg = ec.synth_wind(64, 32, seed=21)
         assert L.c_ezdefset(tu, gsrc) == 1 and L.c_ezsint(fptr(zo), fptr(zg)) >= 0
         out[f"G_to_YY/z_d{degree}"] = zo.copy()
+        assert L.c_ezuvint(fptr(uo), fptr(vo), fptr(ug), fptr(vg)) >= 0
+        out[f"G_to_YY/u_d{degree}"] = uo.copy(); out[f"G_to_YY/v_d{degree}"] = vo.copy()
         assert L.c_ezdefset(tu, gu) == 1 and L.c_ezsint(fptr(zo), fptr(z)) >= 0
         out[f"YY_to_YY/z_d{degree}"] = zo.copy()
+        assert L.c_ezuvint(fptr(uo), fptr(vo), fptr(uu), fptr(vv)) >= 0
+        out[f"YY_to_YY/u_d{degree}"] = uo.copy(); out[f"YY_to_YY/v_d{degree}"] = vo.copy()
     L.c_ezsetopt(b"interp_degree", b"cubic"); L.c_ezsetopt(b"polar_correction", b"yes")
     np.savez_compressed(os.path.join(HERE, "ez_golden.npz"), **out)
     print("wrote", len(out), "arrays")

@@ -538,7 +538,17 @@ def test_yinyang_target_vs_golden():
         assert relerr(got, want).max() <= RTOL, (degree, float(relerr(got, want).max()))
     rc, lat, lon = ez.gdll(tu, nout)
     assert rc == 0 and lat.size == nout
-    assert ez.ezuvint(uu, vv, nout)[0] == -1
+    # winds towards the 'U' grid: c_ezgfwfllw on each rotated subgrid (ezyyuvint.c), from the G grid and from the other 'U' grid
+    ug, vg = ec.synth_wind(64, 32, seed=21)
+    for degree in (1, 3):
+        setopts(degree, 1)
+        for src, a, b, key in ((gsrc, ug, vg, "G_to_YY"), (gu, uu, vv, "YY_to_YY")):
+            assert ez.ezdefset(tu, src) == 1
+            rc, gu_, gv_ = ez.ezuvint(a, b, nout)
+            wu = GOLD[f"{key}/u_d{degree}"]; wv = GOLD[f"{key}/v_d{degree}"]
+            spd = np.sqrt(wu.astype(np.float64) ** 2 + wv.astype(np.float64) ** 2)
+            tol = RTOL * np.maximum(spd, spd.max() * 1e-3)
+            assert rc >= 0 and np.all(np.abs(gu_ - wu) <= tol) and np.all(np.abs(gv_ - wv) <= tol), (key, degree)
 
 
 def _mask_field(ni, nj, seed):
@@ -612,15 +622,12 @@ def test_gdwdfuv_gduvfwd_match_oracle(kind):
     assert np.all(np.abs(gs - ws) <= 1e-5 * np.maximum(ws, 1e-3))
     ddir = np.abs(((gd - wd + 180.0) % 360.0) - 180.0)
     assert np.all(ddir[ws > 1e-3] <= 2e-3), float(ddir.max())           # degrees: 1e-5 of a full turn
-    if kind != "ZE":
-        wu = np.zeros(n, np.float32); wv = np.zeros(n, np.float32)
-        O.orc_gduvfwd(og, ol.fptr(wu), ol.fptr(wv), ol.fptr(ws), ol.fptr(wd), ol.fptr(lat), ol.fptr(lon), n)
-        rc, gu, gv = ez.gduvfwd(g, ws, wd, lat, lon)
-        assert rc == 0
-        tol = 1e-5 * np.maximum(ws, 1e-3) + 1e-6
-        assert np.all(np.abs(gu - wu) <= tol) and np.all(np.abs(gv - wv) <= tol)
-    else:
-        assert ez.gduvfwd(g, ws, wd, lat, lon)[0] == -1                # rotated targets: refused
+    wu = np.zeros(n, np.float32); wv = np.zeros(n, np.float32)
+    O.orc_gduvfwd(og, ol.fptr(wu), ol.fptr(wv), ol.fptr(ws), ol.fptr(wd), ol.fptr(lat), ol.fptr(lon), n)
+    rc, gu, gv = ez.gduvfwd(g, ws, wd, lat, lon)                      # 'ZE': c_ezgfwfllw towards the rotated frame
+    assert rc == 0
+    tol = 1e-5 * np.maximum(ws, 1e-3) + 1e-6
+    assert np.all(np.abs(gu - wu) <= tol) and np.all(np.abs(gv - wv) <= tol)
 
 
 @pytest.mark.parametrize("kind", ["L", "N", "ZE", "G"])

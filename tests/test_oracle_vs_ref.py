@@ -365,7 +365,7 @@ def test_gdwdfuv_gduvfwd_direct(kind):
     L.c_gdwdfuv(g, fptr(rs), fptr(rd), fptr(uu), fptr(vv), fptr(lat), fptr(lon), n)
     O.orc_gdwdfuv(og, fptr(os_), fptr(od), fptr(uu), fptr(vv), fptr(lat), fptr(lon), n)
     assert np.array_equal(os_.view(np.uint32), rs.view(np.uint32)) and np.array_equal(od.view(np.uint32), rd.view(np.uint32))
-    if kind != "ZE":
+    if True:                                                         # 'ZE' included: c_ezgfwfllw
         ru = np.zeros(n, np.float32); rv = np.zeros(n, np.float32); ou = np.zeros(n, np.float32); ov = np.zeros(n, np.float32)
         L.c_gduvfwd(g, fptr(ru), fptr(rv), fptr(rs), fptr(rd), fptr(lat), fptr(lon), n)
         O.orc_gduvfwd(og, fptr(ou), fptr(ov), fptr(rs), fptr(rd), fptr(lat), fptr(lon), n)
