@@ -2671,8 +2671,8 @@ static int32_t yy_uvint(ezh_set *s, float *d_uuout, float *d_vvout, const float 
 {
     ezh_grid *gu = &G[s->gdin], *go = &G[s->gdout];
     const size_t nsub = (size_t)G[gu->sub[0]].ni * G[gu->sub[0]].nj;
-    if (yy_same_subgrid(s) >= 0 || wd_only) {
-        fprintf(stderr, "<c_ezuvint> this Yin-Yang case (target = a subgrid, or c_ezwdint) is outside the MI355X hot-path scope\n");
+    if (yy_same_subgrid(s) >= 0) {
+        fprintf(stderr, "<c_ezuvint> this Yin-Yang case (target = one of the subgrids) is outside the MI355X hot-path scope\n");
         return -1;
     }
     if (go->grtyp == 'E' || (go->grtyp == 'Z' && go->grref != 'E')) { fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp); return -1; }
@@ -2694,6 +2694,7 @@ static int32_t yy_uvint(ezh_set *s, float *d_uuout, float *d_vvout, const float 
         if (c && ezhip_wind_rotate(&wp, s->d_yy_tmp[0], s->d_yy_tmp[1], s->d_yy_lat[sub], s->d_yy_lon[sub], c, 1)) return -1;
         if (ezhip_scatter(d_uuout, s->d_yy_tmp[0], s->d_yy_idx[sub], c) || ezhip_scatter(d_vvout, s->d_yy_tmp[1], s->d_yy_idx[sub], c)) return -1;
     }
+    if (wd_only) return 0;                                   /* c_ezyywdint (ezyywdint.c:157-205): the merged speed / direction are the result */
     /* ONE c_gduvfwd on the target with its own lat/lon (ezyyuvint.c:201) */
     ezhip_wind_plan wp;
     memset(&wp, 0, sizeof(wp));

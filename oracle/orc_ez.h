@@ -126,6 +126,7 @@ typedef struct {
 orc_supergrid *orc_supergrid_define(orc_grid *yin, orc_grid *yan);
 int orc_ezyysint(orc_supergrid *sg, orc_grid *gdout, const orc_opts *o, float *zout, const float *zin);
 int orc_ezyyuvint(orc_supergrid *sg, orc_grid *gdout, const orc_opts *o, float *uuout, float *vvout, const float *uuin, const float *vvin);
+int orc_ezyywdint(orc_supergrid *sg, orc_grid *gdout, const orc_opts *o, float *spdout, float *dirout, const float *uuin, const float *vvin);
 
 #ifdef __cplusplus
 }

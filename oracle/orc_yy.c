@@ -93,7 +93,7 @@ int orc_ezyysint(orc_supergrid *sg, orc_grid *gdout, const orc_opts *o, float *z
 
 /* c_ezyyuvint, yyin == 1 && yyout == 0 (ezyyuvint.c:164-215): c_gdxyvval + c_gdwdfuv per subgrid on its list, merge of
  * speed / direction, then ONE c_gduvfwd on the target with its full lat/lon */
-int orc_ezyyuvint(orc_supergrid *sg, orc_grid *gdout, const orc_opts *o, float *uuout, float *vvout, const float *uuin, const float *vvin)
+static int yy_uv(orc_supergrid *sg, orc_grid *gdout, const orc_opts *o, float *uuout, float *vvout, const float *uuin, const float *vvin, int wd_only)
 {
     yy_plan(sg, gdout, o);
     int npts = gdout->ni * gdout->nj;
@@ -111,8 +111,14 @@ int orc_ezyyuvint(orc_supergrid *sg, orc_grid *gdout, const orc_opts *o, float *
     float *fs = (float *)malloc(sizeof(float) * npts), *fd = (float *)malloc(sizeof(float) * npts);
     yy_merge(sg, npts, fs, spd[0], spd[1]);
     yy_merge(sg, npts, fd, dir[0], dir[1]);
-    orc_gduvfwd(gdout, uuout, vvout, fs, fd, sg->full_lat, sg->full_lon, npts);
+    if (wd_only) { memcpy(uuout, fs, sizeof(float) * npts); memcpy(vvout, fd, sizeof(float) * npts); }      /* c_ezyywdint (ezyywdint.c:157-205): speed / direction are the result */
+    else orc_gduvfwd(gdout, uuout, vvout, fs, fd, sg->full_lat, sg->full_lon, npts);
     for (int s = 0; s < 2; s++) { free(spd[s]); free(dir[s]); }
     free(fs); free(fd);
     return 0;
 }
+
+int orc_ezyyuvint(orc_supergrid *sg, orc_grid *gdout, const orc_opts *o, float *uuout, float *vvout, const float *uuin, const float *vvin)
+{ return yy_uv(sg, gdout, o, uuout, vvout, uuin, vvin, 0); }
+int orc_ezyywdint(orc_supergrid *sg, orc_grid *gdout, const orc_opts *o, float *spdout, float *dirout, const float *uuin, const float *vvin)
+{ return yy_uv(sg, gdout, o, spdout, dirout, uuin, vvin, 1); }

@@ -88,6 +88,10 @@ def main():
             zo = np.zeros(no * mo, np.float32); uo = np.zeros(no * mo, np.float32); vo = np.zeros(no * mo, np.float32)
             assert L.c_ezsint(fptr(zo), fptr(z)) == 0 and L.c_ezuvint(fptr(uo), fptr(vo), fptr(uu), fptr(vv)) == 0
             out[f"YY_to_{tname}/z_d{degree}"] = zo; out[f"YY_to_{tname}/u_d{degree}"] = uo; out[f"YY_to_{tname}/v_d{degree}"] = vo
+            if degree == 3:
+                so = np.zeros(no * mo, np.float32); do_ = np.zeros(no * mo, np.float32)
+                assert L.c_ezwdint(fptr(so), fptr(do_), fptr(uu), fptr(vv)) == 0
+                out[f"YY_to_{tname}/spd_d3"] = so; out[f"YY_to_{tname}/dir_d3"] = do_
     # hemispheric A / B grids: scalars only
     for name, case in sorted(ec.hemi_cases().items()):
         ni, nj = case["src"][:2]; no, mo = case["dst"][:2]

@@ -58,6 +58,7 @@ def oracle():
         L.orc_supergrid_define.argtypes = [ctypes.POINTER(OrcGrid), ctypes.POINTER(OrcGrid)]
         L.orc_ezyysint.argtypes = [ctypes.c_void_p, ctypes.POINTER(OrcGrid), ctypes.c_void_p, c_float_p, c_float_p]
         L.orc_ezyyuvint.argtypes = [ctypes.c_void_p, ctypes.POINTER(OrcGrid), ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p]
+        L.orc_ezyywdint.argtypes = L.orc_ezyyuvint.argtypes
         L.orc_cigaxg.argtypes = [ctypes.c_char] + [c_float_p] * 4 + [ctypes.c_int] * 4
         L.orc_cxgaig.argtypes = [ctypes.c_char] + [c_int_p] * 4 + [ctypes.c_float] * 4
         _lib = L

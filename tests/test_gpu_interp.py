@@ -498,6 +498,13 @@ def test_yinyang_source_vs_golden(tname):
         spd = np.sqrt(wu.astype(np.float64) ** 2 + wv.astype(np.float64) ** 2)
         tol = RTOL * np.maximum(spd, spd.max() * 1e-3)
         assert np.all(np.abs(gu_ - wu) <= tol) and np.all(np.abs(gv - wv) <= tol), (tname, degree)
+    # c_ezwdint from the 'U' source (c_ezyywdint): the merged speed / direction
+    setopts(3, 1)
+    rc, gs, gd = ez.ezwdint(uu, vv, no * mo)
+    ws = GOLD[f"YY_to_{tname}/spd_d3"]; wd = GOLD[f"YY_to_{tname}/dir_d3"]
+    assert rc == 0 and np.all(np.abs(gs - ws) <= RTOL * np.maximum(ws, ws.max() * 1e-3))
+    ddir = np.abs(((gd - wd + 180.0) % 360.0) - 180.0)
+    assert np.all(ddir[ws > 1e-2] <= 5e-3), float(ddir.max())
     # device-resident call and a batch of 2 fields
     d_in = torch.from_numpy(np.stack([z, z[::-1].copy()])).cuda(); d_out = torch.empty((2, no * mo), dtype=torch.float32, device="cuda")
     setopts(3, 1)

@@ -298,6 +298,9 @@ def test_yinyang_source(tname):
         assert O.orc_ezyyuvint(sg, ogo, ctypes.byref(opts), fptr(gu_), fptr(gv), fptr(uu), fptr(vv)) == 0
         assert np.array_equal(gu_.view(np.uint32), wu.view(np.uint32)), (tname, degree)
         assert np.array_equal(gv.view(np.uint32), wv.view(np.uint32)), (tname, degree)
+        assert L.c_ezwdint(fptr(wu), fptr(wv), fptr(uu), fptr(vv)) == 0              # c_ezyywdint: speed / direction
+        assert O.orc_ezyywdint(sg, ogo, ctypes.byref(opts), fptr(gu_), fptr(gv), fptr(uu), fptr(vv)) == 0
+        assert np.array_equal(gu_.view(np.uint32), wu.view(np.uint32)) and np.array_equal(gv.view(np.uint32), wv.view(np.uint32)), (tname, degree)
     ref_setopts(L, 3, 1)
 
 
