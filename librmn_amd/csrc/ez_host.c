@@ -2634,6 +2634,18 @@ static int32_t yy_sint(ezh_set *s, float *d_zout, const float *d_zin)
     const size_t nsub = (size_t)G[gu->sub[0]].ni * G[gu->sub[0]].nj;
     int same = yy_same_subgrid(s);
     if (same >= 0) { ezhip_d2d(d_zout, d_zin + same * nsub, sizeof(float) * nsub); return 1; }
+    if (O.use_1subgrid == 1) {                               /* ezyysint.c:99-123: the caller picks ONE subgrid as the source */
+        if (O.valeur_1subgrid != gu->sub[0] && O.valeur_1subgrid != gu->sub[1]) {
+            fprintf(stderr, "<c_ezyysint> define src subgridid in ezsetival(subgridid)! Aborting...\n");
+            return -1;
+        }
+        const int k = O.valeur_1subgrid == gu->sub[1];
+        const int save_in = cur_gdin, save_out = cur_gdout, gdout_ = s->gdout, sub_ = gu->sub[k];
+        cur_gdin = sub_; cur_gdout = gdout_;
+        int r = ezhip_prepare_set() ? -1 : c_ezsint_dev(d_zout, d_zin + k * nsub);     /* prepare: the set's out-of-grid classification (return code 2) */
+        cur_gdin = save_in; cur_gdout = save_out;
+        return r;
+    }
     int degree = O.degre_interp;
     if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return -1;
     if (yy_plan(s)) return -1;

@@ -24,6 +24,7 @@ def _lib():
         L.c_ezsetval.argtypes = [cp, ctypes.c_float]
         L.c_ezsetival.argtypes = [cp, i32]
         L.c_ezsint.argtypes = [vp, vp]
+        L.c_ezsetival.argtypes = [cp, i32]; L.c_ezgetival.argtypes = [cp, vp]
         L.c_gdwdfuv.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32]; L.c_gduvfwd.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32]
         L.c_gdllfxy.argtypes = [i32, vp, vp, vp, vp, i32]; L.c_gdxywdval.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32]; L.c_gdllwdval.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32]
         L.c_gdxyzfll.argtypes = [i32, vp, vp, vp, vp, i32]; L.c_ezgdef_fll.argtypes = [i32, i32, vp, vp]
@@ -298,3 +299,13 @@ def gdllwdval(gdid, uuin, vvin, lat, lon):
     s = np.zeros_like(a[2]); d = np.zeros_like(a[2])
     rc = _lib().c_gdllwdval(gdid, s.ctypes.data, d.ctypes.data, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, a[2].size)
     return rc, s, d
+
+
+def ezsetival(option, value):
+    return _lib().c_ezsetival(option.encode(), int(value))
+
+
+def ezgetival(option):
+    v = ctypes.c_int32(0)
+    rc = _lib().c_ezgetival(option.encode(), ctypes.byref(v))
+    return rc, v.value

@@ -505,6 +505,17 @@ def test_yinyang_source_vs_golden(tname):
     assert rc == 0 and np.all(np.abs(gs - ws) <= RTOL * np.maximum(ws, ws.max() * 1e-3))
     ddir = np.abs(((gd - wd + 180.0) % 360.0) - 180.0)
     assert np.all(ddir[ws > 1e-2] <= 5e-3), float(ddir.max())
+    # use_1subgrid: the caller names ONE subgrid as the source (ezyysint.c:99-123) == a plain interpolation from that subgrid
+    if tname == "L":
+        assert ez.ezsetopt("use_1subgrid", "yes") == 0 and ez.ezsetival("subgridid", ga) == 0
+        try:
+            rc1, got1 = ez.ezsint(z, no * mo)
+        finally:
+            ez.ezsetopt("use_1subgrid", "no")
+        assert ez.ezdefset(go, ga) == 1
+        rc2, want1 = ez.ezsint(z[ni * nj:], no * mo)
+        assert rc1 == rc2 and np.array_equal(got1.view(np.uint32), want1.view(np.uint32))
+        assert ez.ezdefset(go, gu) == 1
     # device-resident call and a batch of 2 fields
     d_in = torch.from_numpy(np.stack([z, z[::-1].copy()])).cuda(); d_out = torch.empty((2, no * mo), dtype=torch.float32, device="cuda")
     setopts(3, 1)
