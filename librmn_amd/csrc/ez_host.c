@@ -2092,8 +2092,7 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
     if (G[s->gdin].grtyp == 'U') return yy_uvint(s, d_uuout, d_vvout, d_uuin, d_vvin, wd_only);
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     if (src_hemi(gi) || grid_yinv(gi)) { fprintf(stderr, "<c_ezuvint> hemispheric / y-inverted source grids are outside the MI355X hot-path scope for winds\n"); return -1; }
-    if (go->grtyp == 'E' || (go->grtyp == 'Z' && go->grref != 'E')) {
-        /* regular 'E' targets: the reference reads uninitialised memory; Z-on-L targets: it converts twice (missing break) */
+    if (go->grtyp == 'E') {                                 /* regular 'E' targets: the reference reads uninitialised memory */
         fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp);
         return -1;
     }
@@ -2376,7 +2375,7 @@ static int wind_conv_dev(int32_t gdid, float *d_a, float *d_b, const float *d_la
         if (rotated) { const float *xg = g->grtyp == 'E' ? g->xg : g->xgref; h_crot(wp.r, wp.ri, xg[1], xg[0], xg[3], xg[2]); }
         if (g->grtyp == 'N' || g->grtyp == 'S') { wp.src_ps = g->grtyp == 'N' ? 1 : 2; wp.src_xg4 = g->xg[3]; }
     } else {
-        if (g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref != 'E')) { fprintf(stderr, "<c_gduvfwd> '%c' target grids are outside the MI355X hot-path scope for winds\n", g->grtyp); return -1; }
+        if (g->grtyp == 'E') { fprintf(stderr, "<c_gduvfwd> '%c' target grids are outside the MI355X hot-path scope for winds\n", g->grtyp); return -1; }
         wp.wd_in = 1;
         if (rotated) { float ri_[9]; wp.dst_rotated = 1; h_crot(wp.r_dst, ri_, g->xgref[1], g->xgref[0], g->xgref[3], g->xgref[2]); }
         if (g->grtyp == 'N' || g->grtyp == 'S') { wp.dst_ps = g->grtyp == 'N' ? 1 : 2; wp.dst_xg4 = g->xg[3]; }
@@ -2687,7 +2686,7 @@ static int32_t yy_uvint(ezh_set *s, float *d_uuout, float *d_vvout, const float 
         fprintf(stderr, "<c_ezuvint> this Yin-Yang case (target = one of the subgrids) is outside the MI355X hot-path scope\n");
         return -1;
     }
-    if (go->grtyp == 'E' || (go->grtyp == 'Z' && go->grref != 'E')) { fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp); return -1; }
+    if (go->grtyp == 'E') { fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp); return -1; }
     int degree = O.degre_interp;
     if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return -1;
     if (yy_plan(s) || ensure_coords_dev(go)) return -1;

@@ -140,7 +140,8 @@ static void gdwfllw(float *z1, float *z2, const float *xlon, int n, char grtyp, 
         float psi;
         if (grtyp == 'N') psi = xlon[i] + xg4 - z2[i];
         else if (grtyp == 'S') psi = 180.0f - xlon[i] + xg4 - z2[i];
-        else psi = 270.0f - z2[i];
+        else if (grtyp == 'A' || grtyp == 'B' || grtyp == 'G' || grtyp == 'L') psi = 270.0f - z2[i];
+        else continue;                                                /* any other type (e.g. 'Z'): left as it is (:123-134) */
         float u = cosf(psi * DGTORD) * z1[i];
         float v = sinf(psi * DGTORD) * z1[i];
         z1[i] = u; z2[i] = v;
@@ -231,8 +232,8 @@ int orc_gdwdfuv(orc_grid *g, float *spd, float *dir, const float *uu, const floa
     return 0;
 }
 
-/* c_gduvfwd_orig, src/interp/gduvfwd.c:29-96 (non-rotated targets; Z targets hit the missing
- * `break` at :81-92 and are converted twice -- reproduced) */
+/* c_gduvfwd_orig, src/interp/gduvfwd.c:29-96; a Z target falls through the missing `break` at :81-92 into a second
+ * ez_gdwfllw call with grtyp 'Z', which converts nothing */
 int orc_gduvfwd(orc_grid *g, float *uu, float *vv, const float *spd, const float *dir,
                 const float *lat, const float *lon, int npts)
 {
@@ -249,7 +250,7 @@ int orc_gduvfwd(orc_grid *g, float *uu, float *vv, const float *spd, const float
         free(lat_rot); free(lon_rot);
         return 0;
     }
-    if (g->grtyp == 'Z') gdwfllw(uu, vv, lon, npts, g->grref, g->igref[0], g->igref[1], g->igref[2], g->igref[3]);
+    if (g->grtyp == 'Z' || g->grtyp == 'Y') gdwfllw(uu, vv, lon, npts, g->grref, g->igref[0], g->igref[1], g->igref[2], g->igref[3]);      /* :58-61, :81-87 */
     gdwfllw(uu, vv, lon, npts, g->grtyp, g->ig[0], g->ig[1], g->ig[2], g->ig[3]);
     return 0;
 }

@@ -58,6 +58,13 @@ def cloud_axes(ni, nj):
     return lon, lat
 
 
+def zl_axes(ni, nj):
+    """Z-on-L axes (reference grid cxgaig('L', 0, 0, 1, 1)): longitudes 0..351 step 9 stretched a little, latitudes -90..90"""
+    ax = (np.arange(ni, dtype=np.float64) * (360.0 / ni) + 0.3 * tri(np.arange(ni) / ni).astype(np.float64)).astype(np.float32)
+    ay = (-90.0 + np.arange(nj, dtype=np.float64) * (180.0 / (nj - 1))).astype(np.float32)
+    return ax, ay
+
+
 E_IG = (1210, 1600, 57600, 54401)   # cxgaig('E', 31, -90, -20, -20)
 N_IG = (455, 505, 2100, 1000)       # cxgaig('N', 50.5, 45.5, 100000, 21)
 S_IG = (600, 400, 10000, 1500)      # cxgaig('S', 40, 60, 150000, 100)
@@ -87,6 +94,8 @@ def scalar_cases():
     # rotated Z-on-E TARGET (winds: c_ezgfwfllw)
     cases["L_to_ZE"] = dict(src=(40, 20, "L", (900, 900, 450, 0), " ", None), dst=(65, 32, "Z", E_IG), dst_ref="E", dst_axes=ze_axes)
     cases["G_to_ZE"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(33, 16, "Z", E_IG), dst_ref="E", dst_axes=ze_axes)
+    # Z-on-L TARGET (irregular lat-lon axes)
+    cases["G_to_ZL"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(40, 21, "Z", (100, 100, 9000, 0)), dst_ref="L", dst_axes=zl_axes)
     # 'Y' target: a cloud of points (incl. both poles and the seam)
     cases["G_to_Y"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(37, 11, "Y", (0, 0, 0, 0)), dst_ref="L", dst_axes=cloud_axes)
     cases["ZE_to_Y"] = dict(src=(65, 32, "Z", E_IG, "E", ze_axes), dst=(37, 11, "Y", (0, 0, 0, 0)), dst_ref="L", dst_axes=cloud_axes)
