@@ -58,6 +58,13 @@ def cloud_axes(ni, nj):
     return lon, lat
 
 
+def zereg_axes(ni, nj):
+    """regional Z-on-E axes (rotated frame): longitudes 150..200, latitudes -20..20, slightly stretched"""
+    ax = (150.0 + np.arange(ni, dtype=np.float64) * (50.0 / (ni - 1)) + 0.2 * tri(np.arange(ni) / ni).astype(np.float64)).astype(np.float32)
+    ay = (-20.0 + np.arange(nj, dtype=np.float64) * (40.0 / (nj - 1))).astype(np.float32)
+    return ax, ay
+
+
 def zl_axes(ni, nj):
     """Z-on-L axes (reference grid cxgaig('L', 0, 0, 1, 1)): longitudes 0..351 step 9 stretched a little, latitudes -90..90"""
     ax = (np.arange(ni, dtype=np.float64) * (360.0 / ni) + 0.3 * tri(np.arange(ni) / ni).astype(np.float64)).astype(np.float32)
@@ -94,6 +101,9 @@ def scalar_cases():
     # rotated Z-on-E TARGET (winds: c_ezgfwfllw)
     cases["L_to_ZE"] = dict(src=(40, 20, "L", (900, 900, 450, 0), " ", None), dst=(65, 32, "Z", E_IG), dst_ref="E", dst_axes=ze_axes)
     cases["G_to_ZE"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(33, 16, "Z", E_IG), dst_ref="E", dst_axes=ze_axes)
+    # Z-on-L SOURCE (global, irregular lat-lon axes) and a regional rotated Z-on-E SOURCE (a LAM grid: points outside -> extrapolation)
+    cases["ZL_to_L"] = dict(src=(40, 21, "Z", (100, 100, 9000, 0), "L", zl_axes), dst=(60, 31, "L", (600, 600, 0, 0)))
+    cases["ZEreg_to_L"] = dict(src=(51, 41, "Z", E_IG, "E", zereg_axes), dst=(50, 40, "L", (100, 100, 9000, 24000)))
     # Z-on-L TARGET (irregular lat-lon axes)
     cases["G_to_ZL"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(40, 21, "Z", (100, 100, 9000, 0)), dst_ref="L", dst_axes=zl_axes)
     # 'Y' target: a cloud of points (incl. both poles and the seam)
