@@ -773,3 +773,39 @@ def test_gdxysint_hemispheric_and_inverted_sources(name):
     torch.cuda.synchronize()
     rc, single = ez.ezsint(zin, no * mo)
     assert np.array_equal(d_out[0].cpu().numpy().view(np.uint32), single.view(np.uint32))
+
+
+EXTRAP_NAMES = {0: "nearest", 1: "linear", 3: "cubic", 4: "maximum", 5: "minimum", 6: "value"}
+
+
+@pytest.mark.parametrize("name", ["Lregional_to_L", "N_to_L", "ZEreg_to_L"])
+@pytest.mark.parametrize("extrap", [0, 1, 3, 4, 5, 6])
+def test_extrapolation_degrees_match_oracle(name, extrap):
+    """extrap_degree (ez_corrval.c:60-110) for points outside a regional source: fill with max / min / value, or
+    re-interpolation with another degree -- HIP path against the oracle (pinned against the reference for these modes)"""
+    import test_oracle_golden as tog
+    case = CASES[name]
+    ni, nj = case["src"][:2]; no, mo = case["dst"][:2]
+    gdin = hip_define(case["src"]); gdout = hip_define(ec.dst_spec(case))
+    assert ez.ezdefset(gdout, gdin) == 1
+    zin, _, _ = case_inputs(name, case)
+    O = ol.oracle()
+    gi = tog.orc_define(case["src"]); go = tog.orc_define(ec.dst_spec(case))
+    gs = O.orc_defset(go, gi)
+    for degree in (1, 3):
+        setopts(degree, 1, EXTRAP_NAMES[extrap])
+        assert ez.ezsetval("extrap_value", 123.5) == 0
+        try:
+            rc, z = ez.ezsint(zin, no * mo)
+        finally:
+            ez.ezsetopt("extrap_degree", "maximum")
+        opts = ol.default_opts(degre_interp=degree, degre_extrap=extrap, valeur_extrap=123.5)
+        want = np.zeros(no * mo, np.float32)
+        rc_o = O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(want), ol.fptr(zin))
+        assert rc == rc_o == 2, (name, extrap, degree, rc, rc_o)
+        err = relerr(z, want)
+        if name == "ZEreg_to_L":       # rotated locate: device trig (see test_ezsint_vs_golden)
+            lim = 5e-3 if extrap in (1, 3) else 5e-4        # re-interpolated points are polynomial extrapolations far outside the grid
+            assert np.count_nonzero(err > RTOL) <= z.size // 20 and err.max() <= lim, (name, extrap, degree, float(err.max()))
+        else:
+            assert err.max() <= RTOL, (name, extrap, degree, float(err.max()))
