@@ -93,10 +93,11 @@ def test_ezsint(name, degree, polar):
         f"{name} deg={degree} polar={polar}: {np.count_nonzero(zo != zr)} differ, max {np.abs(zo - zr).max()}"
 
 
+@pytest.mark.parametrize("name", ["Lregional_to_L", "N_to_L", "ZEreg_to_L"])
 @pytest.mark.parametrize("extrap", [0, 1, 3, 4, 5, 6])
-def test_ezsint_extrapolation(extrap):
+def test_ezsint_extrapolation(extrap, name):
     L = ref(); O = ol.oracle()
-    case = CASES["Lregional_to_L"]
+    case = CASES[name]
     gdin = ref_define(L, case["src"]); gdout = ref_define(L, ec.dst_spec(case))
     ref_setopts(L, 3, 1, extrap, 123.5)
     L.c_ezdefset(gdout, gdin)
