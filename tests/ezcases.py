@@ -171,3 +171,13 @@ def hemi_cases():
     c["L_to_Binv"] = dict(src=(40, 20, "L", (900, 900, 450, 0), " ", None), dst=(49, 25, "B", (0, 1, 0, 0)))
     c["G_to_Ginv"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(48, 24, "G", (0, 1, 0, 0)))
     return c
+
+
+def e_cases():
+    """regular rotated 'E' grids.  As a SOURCE only without polar correction: the reference dereferences a NULL ay there
+    (SURVEY appendix D.1); as a scalar TARGET without restriction."""
+    c = {}
+    c["E_to_L"] = dict(src=(41, 20, "E", E_IG, " ", None), dst=(60, 31, "L", (600, 600, 0, 0)), polar=(0,))
+    c["L_to_E"] = dict(src=(40, 20, "L", (900, 900, 450, 0), " ", None), dst=(41, 20, "E", E_IG), polar=(1, 0))
+    c["G_to_E"] = dict(src=(64, 32, "G", (0, 0, 0, 0), " ", None), dst=(33, 16, "E", E_IG), polar=(1, 0))
+    return c

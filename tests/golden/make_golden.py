@@ -92,6 +92,20 @@ def main():
                 so = np.zeros(no * mo, np.float32); do_ = np.zeros(no * mo, np.float32)
                 assert L.c_ezwdint(fptr(so), fptr(do_), fptr(uu), fptr(vv)) == 0
                 out[f"YY_to_{tname}/spd_d3"] = so; out[f"YY_to_{tname}/dir_d3"] = do_
+    # regular rotated 'E' grids
+    for name, case in sorted(ec.e_cases().items()):
+        ni, nj = case["src"][:2]; no, mo = case["dst"][:2]
+        gdin = define(L, case["src"]); gdout = define(L, ec.dst_spec(case))
+        assert L.c_ezdefset(gdout, gdin) == 1
+        zin = ec.synth_field(ni, nj, seed=11)
+        if case["src"][2] == "E":
+            z2 = zin.reshape(nj, ni); z2[:, -1] = z2[:, 0]; zin = np.ascontiguousarray(z2.reshape(-1))
+        for degree in (0, 1, 3):
+            for polar in case["polar"]:
+                L.c_ezsetopt(b"interp_degree", DEG[degree]); L.c_ezsetopt(b"polar_correction", b"yes" if polar else b"no")
+                zo = np.zeros(no * mo, np.float32)
+                rc = L.c_ezsint(fptr(zo), fptr(zin))
+                out[f"{name}/z_d{degree}_p{polar}"] = zo; out[f"{name}/rc_d{degree}_p{polar}"] = np.int32(rc)
     # hemispheric A / B grids: scalars only
     for name, case in sorted(ec.hemi_cases().items()):
         ni, nj = case["src"][:2]; no, mo = case["dst"][:2]

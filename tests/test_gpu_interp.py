@@ -809,3 +809,30 @@ def test_extrapolation_degrees_match_oracle(name, extrap):
             assert np.count_nonzero(err > RTOL) <= z.size // 20 and err.max() <= lim, (name, extrap, degree, float(err.max()))
         else:
             assert err.max() <= RTOL, (name, extrap, degree, float(err.max()))
+
+
+ECASES = ec.e_cases()
+
+
+@pytest.mark.parametrize("name", sorted(ECASES))
+def test_regular_E_grids_vs_golden(name):
+    """regular rotated 'E' grids: as a source (k_locate kind 3; polar correction off, the only setting the reference survives,
+    SURVEY D.1) and as a scalar target (2-D coordinates through ez_gfllfxy on the host)"""
+    case = ECASES[name]
+    ni, nj = case["src"][:2]; no, mo = case["dst"][:2]
+    gdin = hip_define(case["src"]); gdout = hip_define(ec.dst_spec(case))
+    assert gdin >= 0 and gdout >= 0 and ez.ezdefset(gdout, gdin) == 1
+    zin = ec.synth_field(ni, nj, seed=11)
+    if case["src"][2] == "E":
+        z2 = zin.reshape(nj, ni); z2[:, -1] = z2[:, 0]; zin = np.ascontiguousarray(z2.reshape(-1))
+    for degree in (0, 1, 3):
+        for polar in case["polar"]:
+            setopts(degree, polar)
+            rc, z = ez.ezsint(zin, no * mo)
+            want = GOLD[f"{name}/z_d{degree}_p{polar}"]
+            assert rc == int(GOLD[f"{name}/rc_d{degree}_p{polar}"])
+            err = relerr(z, want)
+            if degree == 0:            # a nearest-neighbour pick may flip at a cell edge (device trig in the rotated frame)
+                assert np.count_nonzero(err > RTOL) <= max(4, z.size // 500), (name, polar)
+            else:
+                assert err.max() <= RTOL, (name, degree, polar, float(err.max()))

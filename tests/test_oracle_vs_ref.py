@@ -405,3 +405,30 @@ def test_hemispheric_scalar(name):
     L.c_gdll(gdout, fptr(lat), fptr(lon))
     assert np.array_equal(ol.np_from(go.contents.lat, no * mo), lat)
     ref_setopts(L, 3, 1)
+
+
+ECASES = ec.e_cases()
+
+
+@pytest.mark.parametrize("name", sorted(ECASES))
+def test_regular_E_grids(name):
+    """regular rotated 'E' grids as source (polar correction off: the reference crashes with it on) and as scalar target"""
+    L = ref(); O = ol.oracle()
+    case = ECASES[name]
+    ni, nj = case["src"][:2]; no, mo = case["dst"][:2]
+    gdin = ref_define(L, case["src"]); gdout = ref_define(L, ec.dst_spec(case))
+    gi = orc_define(case["src"]); go = orc_define(ec.dst_spec(case))
+    gs = O.orc_defset(go, gi)
+    zin = ec.synth_field(ni, nj, seed=11)
+    if case["src"][2] == "E":
+        z2 = zin.reshape(nj, ni); z2[:, -1] = z2[:, 0]; zin = np.ascontiguousarray(z2.reshape(-1))
+    assert L.c_ezdefset(gdout, gdin) == 1
+    for degree in (0, 1, 3):
+        for polar in case["polar"]:
+            ref_setopts(L, degree, polar)
+            zr = np.full(no * mo, -999.0, np.float32); zo = np.full(no * mo, -999.0, np.float32)
+            rc_r = L.c_ezsint(fptr(zr), fptr(zin))
+            opts = ol.default_opts(degre_interp=degree, polar_correction=polar)
+            rc_o = O.orc_ezsint(gs, ctypes.byref(opts), fptr(zo), fptr(zin))
+            assert rc_o == rc_r and np.array_equal(zo.view(np.uint32), zr.view(np.uint32)), (name, degree, polar, int((zo != zr).sum()))
+    ref_setopts(L, 3, 1)
