@@ -171,3 +171,23 @@ def test_gdllfxy_vs_reference():
         L.c_gdllfxy(gr, rl.fptr(latr), rl.fptr(lonr), rl.fptr(x.copy()), rl.fptr(y.copy()), n)
         assert rc == 0 and np.array_equal(lat.view(np.uint32), latr.view(np.uint32)), (name, int((lat != latr).sum()))
         assert np.array_equal(lon.view(np.uint32), lonr.view(np.uint32)), (name, int((lon != lonr).sum()))
+
+
+def test_fortran_twins_by_reference_and_hidden_lengths():
+    """the Fortran-ABI twins (f77name(x) = x_): scalars by reference, blank-padded strings with hidden trailing lengths"""
+    import ctypes
+    L = ez._lib()
+    i = lambda v: ctypes.byref(ctypes.c_int32(v))
+    g1 = L.ezqkdef_(i(40), i(20), b"L   ", i(900), i(900), i(450), i(0), i(0), 4)
+    assert g1 == ez.ezqkdef(40, 20, "L", 900, 900, 450, 0)                      # same grid: deduplicated
+    ax, ay = ec.ze_axes(65, 32)
+    g2 = L.ezgdef_fmem_(i(65), i(32), b"Z", b"E", i(ec.E_IG[0]), i(ec.E_IG[1]), i(ec.E_IG[2]), i(ec.E_IG[3]), ctypes.c_void_p(ax.ctypes.data), ctypes.c_void_p(ay.ctypes.data), 1, 1)
+    assert g2 == ez.ezgdef_fmem(65, 32, "Z", "E", *ec.E_IG, ax, ay)
+    assert L.ezdefset_(i(g1), i(g2)) == 1
+    assert L.ezsetopt_(b"INTERP_DEGREE   ", b"LINEAR  ", 16, 8) == 0            # upper case, blank padded
+    assert ez.ezgetopt("interp_degree") == "linear"
+    assert L.ezsetopt_(b"interp_degree", b"cubic", 13, 5) == 0
+    lat = np.zeros(800, np.float32); lon = np.zeros(800, np.float32)
+    assert L.gdll_(i(g1), ctypes.c_void_p(lat.ctypes.data), ctypes.c_void_p(lon.ctypes.data)) == 0 and abs(float(lat[0]) + 85.5) < 1e-4
+    ids = np.array([g2, g2], np.int32)
+    assert L.ezgdef_supergrid_(i(65), i(64), b"U", b"F", i(1), i(2), ctypes.c_void_p(ids.ctypes.data), 1, 1) >= 0
