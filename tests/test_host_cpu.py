@@ -191,3 +191,17 @@ def test_fortran_twins_by_reference_and_hidden_lengths():
     assert L.gdll_(i(g1), ctypes.c_void_p(lat.ctypes.data), ctypes.c_void_p(lon.ctypes.data)) == 0 and abs(float(lat[0]) + 85.5) < 1e-4
     ids = np.array([g2, g2], np.int32)
     assert L.ezgdef_supergrid_(i(65), i(64), b"U", b"F", i(1), i(2), ctypes.c_void_p(ids.ctypes.data), 1, 1) >= 0
+
+
+def test_threaded_host_locate_equals_serial():
+    """c_gdxyfll slices large point sets over host threads (>= 400 k points): same bits as the serial path"""
+    ax, ay = ec.ze_axes(65, 32)
+    g = ez.ezgdef_fmem(65, 32, "Z", "E", *ec.E_IG, ax, ay)
+    n = 900_001
+    lat = (ec.hash_uniform(55, n).astype(np.float64) * 178.0 - 89.0).astype(np.float32)
+    lon = (ec.hash_uniform(56, n).astype(np.float64) * 360.0).astype(np.float32)
+    rc, x, y = ez.gdxyfll(g, lat, lon)
+    assert rc == 0
+    for a, b in ((0, 300_000), (300_000, 600_000), (600_000, n)):
+        rc, xs, ys = ez.gdxyfll(g, lat[a:b], lon[a:b])
+        assert rc == 0 and np.array_equal(xs.view(np.uint32), x[a:b].view(np.uint32)) and np.array_equal(ys.view(np.uint32), y[a:b].view(np.uint32))
