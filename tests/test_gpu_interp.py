@@ -836,3 +836,29 @@ def test_regular_E_grids_vs_golden(name):
                 assert np.count_nonzero(err > RTOL) <= max(4, z.size // 500), (name, polar)
             else:
                 assert err.max() <= RTOL, (name, degree, polar, float(err.max()))
+
+
+def test_yinyang_source_medium_size_vs_oracle():
+    """a 0.5-degree Yin-Yang pair -> 0.25-degree global lat-lon (1 M points: the threaded first-call locate, both point lists,
+    the direct-to-target writes): scalars bit-exact against the oracle, which is pinned against the reference at small size"""
+    ni, nj = 577, 205
+    dx = 270.0 / (ni - 37)
+    ax = (45.0 - 18 * dx + dx * np.arange(ni, dtype=np.float64)).astype(np.float32)
+    dy = 90.0 / (nj - 25)
+    ay = (-45.0 - 12 * dy + dy * np.arange(nj, dtype=np.float64)).astype(np.float32)
+    gy = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.YIN_IG, ax, ay); ga = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.YAN_IG, ax, ay)
+    gu = ez.ezgdef_supergrid(ni, 2 * nj, "U", "F", 1, [gy, ga])
+    no, mo = 1440, 721
+    go = ez.ezqkdef(no, mo, "L", 25, 25, 0, 0)
+    assert ez.ezdefset(go, gu) == 1
+    z = np.concatenate([ec.synth_field(ni, nj, seed=3), ec.synth_field(ni, nj, seed=4)])
+    O = ol.oracle()
+    sg = O.orc_supergrid_define(ol.grid_define(ni, nj, "Z", ec.YIN_IG, "E", ax, ay), ol.grid_define(ni, nj, "Z", ec.YAN_IG, "E", ax, ay))
+    ogo = ol.grid_define(no, mo, "L", (25, 25, 0, 0))
+    for degree in (3, 1):
+        setopts(degree, 1)
+        rc, got = ez.ezsint(z, no * mo)
+        opts = ol.default_opts(degre_interp=degree)
+        want = np.zeros(no * mo, np.float32)
+        assert O.orc_ezyysint(sg, ogo, ctypes.byref(opts), ol.fptr(want), ol.fptr(z)) == 0
+        assert rc == 0 and np.array_equal(got.view(np.uint32), want.view(np.uint32)), (degree, int((got != want).sum()))
