@@ -1463,7 +1463,15 @@ __global__ __launch_bounds__(256) void k_minmax(unsigned *keys2, const float *z,
         kmin = min(kmin, (unsigned)__shfl_down((int)kmin, off, 64));
         kmax = max(kmax, (unsigned)__shfl_down((int)kmax, off, 64));
     }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&keys2[0], kmin); atomicMax(&keys2[1], kmax); }
+    /* one atomic pair per BLOCK (same-address device atomics cost ~23 ns each: one pair per wave of a 2048-block grid was
+     * 190 us of serialised atomics for a 26 M-point field) */
+    __shared__ unsigned smin[4], smax[4];
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = kmin; smax[threadIdx.x >> 6] = kmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&keys2[0], min(min(smin[0], smin[1]), min(smin[2], smin[3])));
+        atomicMax(&keys2[1], max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+    }
 }
 /* ez_corrval.c:60-87 fill value from min/max */
 __global__ void k_fill(float *fill, const unsigned *keys2, int degre_extrap, float valeur, int vector_mode)
@@ -1484,7 +1492,7 @@ extern "C" int ezhip_fill_value(float *d_fill, const float *d_zin, size_t n, int
     unsigned init[2] = {0xffffffffu, 0u};
     if (set_err(hipMemcpyAsync(keys, init, sizeof(init), hipMemcpyHostToDevice, g_stream), "fill init")) return -1;
     if (!vector_mode && (degre_extrap == 4 || degre_extrap == 5)) {
-        int nb = (int)((n + 255) / 256); if (nb > 2048) nb = 2048;
+        int nb = (int)((n + 255) / 256); if (nb > 512) nb = 512;
         hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(256), 0, g_stream, keys, d_zin, n);
     }
     hipLaunchKernelGGL(k_fill, dim3(1), dim3(1), 0, g_stream, d_fill, keys, degre_extrap, valeur, vector_mode);
@@ -1769,7 +1777,7 @@ extern "C" int ezhip_mask_fill_min(float *d_fld, const int *d_mask, size_t n, un
     unsigned init[2] = {0xffffffffu, 0u};
     if (set_err(hipMemcpyAsync(d_keys2, init, sizeof(init), hipMemcpyHostToDevice, g_stream), "mask fill init")) return -1;
     int nb = (int)((n + 255) / 256); if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(256), 0, g_stream, d_keys2, d_fld, n);
+    hipLaunchKernelGGL(k_minmax, dim3(nb > 512 ? 512 : nb), dim3(256), 0, g_stream, d_keys2, d_fld, n);
     hipLaunchKernelGGL(k_mask_fill, dim3(nb), dim3(256), 0, g_stream, d_fld, d_mask, d_keys2, n);
     return LAUNCH_CHECK("k_mask_fill");
 }
