@@ -73,6 +73,35 @@ def cpu_baseline(sample_fields=4):
             "sample": f"{sample_fields} fields cfg2 steady-state orc_ezsint ({dt:.3f} s/field)"}
 
 
+def check_outputs(ez, torch, d_out, d_in, check_f):
+    """the timed launch's outputs, after the timed loop: field `check_f` (input = the fixture's 'synth' field) against the
+    reference's own full-size run (sampled rows / columns within 1e-5 relative, float64 sum), and the first / last field of
+    the batch against a single-field c_ezsint_dev call, bit for bit.  Returns a dict for the JSON line."""
+    res = {"ok": False}
+    try:
+        G = np.load(os.path.join(ROOT, "tests", "golden", "cfg2_full_golden.npz"))
+        o2 = d_out[check_f].view(NJ_D, NI_D)
+        rows = torch.from_numpy(G["rows"]).cuda(); cols = torch.from_numpy(G["cols"]).cuda()
+        worst = 0.0
+        for got, want in ((o2[rows].cpu().numpy(), G["synth/d3_p1/rows"]), (o2[:, cols].cpu().numpy(), G["synth/d3_p1/cols"])):
+            scale = np.maximum(np.abs(want), np.abs(want).max() * 1e-3)
+            worst = max(worst, float((np.abs(got.astype(np.float64) - want) / scale).max()))
+        s = float(d_out[check_f].double().sum().item())
+        sum_rel = abs(s - float(G["synth/d3_p1/sum"])) / abs(s)
+        one = torch.empty(NPTS_OUT, dtype=torch.float32, device="cuda")
+        same = True
+        for f in (0, d_out.shape[0] - 1):
+            assert ez.ezsint_dev(one, d_in[f]) == 0
+            torch.cuda.synchronize()
+            same = same and bool(torch.equal(one, d_out[f]))
+        res = {"ok": bool(worst <= 1e-5 and sum_rel <= 1e-8 and same), "field": check_f,
+               "max_rel_err_vs_reference_run": worst, "sum_rel_diff": sum_rel, "batch_equals_single_calls_bitwise": same,
+               "against": "tests/golden/cfg2_full_golden.npz (reference c_ezsint, sampled rows/cols + sum) and c_ezsint_dev"}
+    except Exception as e:   # noqa: BLE001
+        res["error"] = repr(e)
+    return res
+
+
 def extras(ez, torch, stream, d_out, d_in):
     """secondary measurements next to the headline (never part of `value`): one field per launch, the host-pointer
     ABI, and BASELINE configs[2] (c_ezuvint, Z-on-E 2560x1280 -> L 4000x2000).  Best effort: {} on any failure."""
@@ -161,6 +190,11 @@ def main():
     gen = torch.Generator(device="cuda"); gen.manual_seed(1234 + rank)
     for f in range(F):
         d_in[f] = base * (1.0 + 1e-3 * (torch.rand(NI_S * NJ_S, device="cuda", generator=gen) - 0.5)) + 0.01 * my_fields[f]
+    # one field of rank 0's batch is the reference fixture's input (tests/golden/cfg2_full_golden.npz, 'synth'): after the
+    # timed loop its output is compared with the reference's own full-size run (`checked` in the JSON line)
+    CHECK_F = F // 2
+    if rank == 0:
+        d_in[CHECK_F] = torch.from_numpy(ec.synth_field(NI_S, NJ_S, seed=2)).cuda()
     d_out = torch.empty((F, NPTS_OUT), dtype=torch.float32, device="cuda")
 
     def step():
@@ -189,6 +223,7 @@ def main():
     torch.cuda.synchronize()
     ev_ms = ev0.elapsed_time(ev1)
     elapsed = sh.max_over_ranks(elapsed, device="cuda")        # the batch takes as long as its slowest rank
+    checked = check_outputs(ez, torch, d_out, d_in, CHECK_F) if rank == 0 else None
 
     # ---- second timed region: the packers on the interpolated fields (device-resident) ------------------
     from librmn_amd import packers as pk
@@ -265,6 +300,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "checked": bool(checked and checked.get("ok")),
+            "check": checked,
             "config": {"workload": "cfg2/cfg4: c_ezsint bicubic G 4400x2200 -> L 7200x3601, polar_correction=yes, "
                                    f"{F} device-resident fields per step per GPU (sharded by record, no collective)",
                        "fields_per_step_per_gpu": F, "points_per_field": NPTS_OUT, "prewarm_steps": prewarm},

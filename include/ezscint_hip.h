@@ -93,6 +93,8 @@ int32_t ezhip_ezsint_batch_minmax_dev(float *d_zout, const float *d_zin, int32_t
 int32_t ezhip_prepare_set(void);
 /* which kernel family the current set uses: 1 = separable (k_sep), 2 = per-point (k_pts) */
 int32_t ezhip_set_mode(void);
+/* copies the current set's located x,y (the reference's gridset cache, ez_calcxy.c:56-134) to device arrays of ni_out*nj_out floats */
+int32_t ezhip_set_xy_dev(float *d_x, float *d_y);
 /* 1 when a HIP device is usable */
 int32_t ezhip_available(void);
 

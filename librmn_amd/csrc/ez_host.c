@@ -1485,18 +1485,61 @@ static void fill_locate_plan(const ezh_grid *gi, ezhip_locate_plan *lp)
     }
 }
 
+/* x,y of every target point of a set on the per-point path (the gridset cache of ez_calcxy.c:28-137), device resident.
+ * Rotated sources ('E', Z-on-'E': ez_gfxyfll.c:38-57 -- REAL trig through libm) are located ONCE per set by the exact
+ * host code (h_locate_mt, bit-exact against the reference: tests/test_host_cpu.py) and uploaded: the device's
+ * sinf/cosf/asinf/atan2f differ from glibc in the last ulp, which moved x,y by ~1e-6 of a cell and flipped
+ * nearest-neighbour picks.  EZHIP_DEVICE_LOCATE=1 keeps the device locate (k_locate kinds 2/3) for experiments.
+ * The same first-call pass classifies the DEHORS zone (ez_defzone_dehors.c:63-74): have_dehors decides rc = 2 and
+ * extrap_degree = abort on every entry point. */
 static int ensure_points(ezh_set *s)
 {
     if (s->d_x) return 0;
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
-    if (ensure_grid_dev(gi) || ensure_coords_dev(go)) return -1;
     size_t n = (size_t)go->ni * go->nj;
-    s->d_x = (float *)ezhip_malloc(sizeof(float) * n);
-    s->d_y = (float *)ezhip_malloc(sizeof(float) * n);
-    if (!s->d_x || !s->d_y) return -1;
-    ezhip_locate_plan lp;
-    fill_locate_plan(gi, &lp);
-    return ezhip_locate(&lp, s->d_x, s->d_y, go->d_lat, go->d_lon, go->ni, go->nj, go->separable);
+    int rotated = gi->grtyp == 'E' || (gi->grtyp == 'Z' && gi->grref == 'E');
+    int host_locate = rotated && !getenv("EZHIP_DEVICE_LOCATE");
+    float *hx = NULL, *hy = NULL;
+    if (ensure_grid_dev(gi)) return -1;
+    float *dx = (float *)ezhip_malloc(sizeof(float) * n), *dy = (float *)ezhip_malloc(sizeof(float) * n);
+    if (!dx || !dy) { ezhip_free(dx); ezhip_free(dy); return -1; }
+    int rc = 0;
+    if (host_locate) {
+        ensure_coords(go);
+        hx = (float *)malloc(sizeof(float) * n); hy = (float *)malloc(sizeof(float) * n);
+        float *lat = (float *)malloc(sizeof(float) * n), *lon = (float *)malloc(sizeof(float) * n);
+        if (!hx || !hy || !lat || !lon) rc = -1;
+        else {
+            if (go->separable) {
+                for (int j = 0; j < go->nj; j++) for (int i = 0; i < go->ni; i++) { lat[(size_t)j * go->ni + i] = go->lat1d[j]; lon[(size_t)j * go->ni + i] = go->lon1d[i]; }
+            } else { memcpy(lat, go->lat2d, sizeof(float) * n); memcpy(lon, go->lon2d, sizeof(float) * n); }
+            rc = h_locate_mt(gi, hx, hy, lat, lon, (int)n);
+            if (!rc) rc = ezhip_h2d(dx, hx, sizeof(float) * n) || ezhip_h2d(dy, hy, sizeof(float) * n) || ezhip_sync();
+        }
+        free(lat); free(lon);
+    } else {
+        if (ensure_coords_dev(go)) rc = -1;
+        else {
+            ezhip_locate_plan lp;
+            fill_locate_plan(gi, &lp);
+            rc = ezhip_locate(&lp, dx, dy, go->d_lat, go->d_lon, go->ni, go->nj, go->separable);
+        }
+    }
+    if (!rc && s->extrap && !s->sep_capable) {
+        if (!hx) {
+            hx = (float *)malloc(sizeof(float) * n); hy = (float *)malloc(sizeof(float) * n);
+            if (!hx || !hy || ezhip_d2h(hx, dx, sizeof(float) * n) || ezhip_d2h(hy, dy, sizeof(float) * n) || ezhip_sync()) rc = -1;
+        }
+        s->have_dehors = 0;
+        for (size_t k = 0; k < n && !rc; k++) {
+            int ix = (int)((double)hx[k] + 0.5), iy = (int)((double)hy[k] + 0.5);
+            if (ix < 1 || iy < 1 || ix > gi->ni || iy > gi->nj) { s->have_dehors = 1; break; }
+        }
+    }
+    free(hx); free(hy);
+    if (rc) { ezhip_free(dx); ezhip_free(dy); return -1; }
+    s->d_y = dy; s->d_x = dx;
+    return 0;
 }
 
 static void fill_pts_plan(const ezh_set *s, const ezh_grid *gi, ezhip_pts_plan *pp, int degree, int zones, int vector_mode)
@@ -1614,16 +1657,20 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
     int mode = choose_mode(s, degree, polar);          /* may analyse the set (first use) */
     pthread_mutex_unlock(&g_plan_mtx);
     int need_fill = 0;
-    if (polar && s->extrap) {
-        int dehors = s->sep_capable ? s->have_dehors : 1;   /* unknown without a pass over x,y: assume present */
-        if (dehors) {
-            if (s->sep_capable) ierc = 2;
-            if (O.degre_extrap == XT_ABORT && s->sep_capable) {
-                fprintf(stderr, "<ez_corrval> There are points on the destination grid that lie outside the source grid\n");
-                return -1;
-            }
-            need_fill = (O.degre_extrap >= XT_MAXIMUM) || vector_mode;
+    if (mode != 1) {                                    /* per-point path: x,y (and with them the DEHORS classification) first */
+        pthread_mutex_lock(&g_plan_mtx);
+        int erc0 = ensure_points(s);
+        pthread_mutex_unlock(&g_plan_mtx);
+        if (erc0) return -1;
+    }
+    if (polar && s->extrap && s->have_dehors) {         /* ez_corrval.c:54-60 */
+        ierc = 2;
+        if (O.degre_extrap == XT_ABORT) {
+            fprintf(stderr, "<ez_corrval> There are points on the destination grid that lie outside the source grid\n");
+            fprintf(stderr, "<ez_corrval> aborting at your request!\n\n\n");
+            return -1;
         }
+        need_fill = (O.degre_extrap >= XT_MAXIMUM) || vector_mode;
     }
     if (need_fill && ezhip_fill_value(d_fill, d_zin, (size_t)gi->ni * gi->nj, O.degre_extrap, O.valeur_extrap, vector_mode)) return -1;
     if (mode == 1) {
@@ -1678,11 +1725,6 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
         d_poles_pre = NULL; pp.polevals = d_poles;          /* pole values of the EXPANDED field */
     }
     if (zones == 1 && !vector_mode && !d_poles_pre && ezhip_polevals(d_poles, d_zin, gi->ni, nj_rows, pp.pole_weighted, gi->d_ax)) return -1;
-    if (zones == 2 && !s->sep_capable) {
-        /* The reference returns 2 only when the DEHORS zone is non-empty; on the per-point path that
-         * needs a reduction over x,y which is done once and cached in have_dehors by ezhip_prepare. */
-        if (s->have_dehors) ierc = 2;
-    }
     if (ezhip_interp_pts(&pp, d_zout, d_zin, s->d_x, s->d_y, go->ni * go->nj)) return -1;
     return ierc;
 }
@@ -1702,10 +1744,6 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
     if (ensure_scratch(s)) return -1;
     float *d_fill = t_scratch8, *d_poles = t_scratch8 + 4;
     int ierc = 0;
-    if (polar && s->extrap) {
-        if (O.degre_extrap == XT_ABORT && s->sep_capable && s->have_dehors) return -2;          /* let the per-field path report it */
-        if (ezhip_fill_value(d_fill, d_ui, (size_t)gi->ni * gi->nj, O.degre_extrap, O.valeur_extrap, 1)) return -1;
-    }
     ezhip_pts_plan pu, pv;
     int zones = !polar ? 0 : (s->extrap ? 2 : 1);
     pthread_mutex_lock(&g_plan_mtx);
@@ -1713,10 +1751,14 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
     if (!erc) fill_pts_plan(s, gi, &pu, degree, zones, 1);
     pthread_mutex_unlock(&g_plan_mtx);
     if (erc) return -1;
+    if (polar && s->extrap && s->have_dehors) {
+        if (O.degre_extrap == XT_ABORT) return -2;          /* let the per-field path report it (ez_corrval.c:56-60) */
+        if (ezhip_fill_value(d_fill, d_ui, (size_t)gi->ni * gi->nj, O.degre_extrap, O.valeur_extrap, 1)) return -1;
+    }
     pu.fill = d_fill; pu.polevals = d_poles;
     pv = pu;
     pu.pole_row_n = pun; pu.pole_row_s = pus; pv.pole_row_n = pvn; pv.pole_row_s = pvs;
-    if (zones == 2 && (s->sep_capable ? s->have_dehors : s->have_dehors)) ierc = 2;
+    if (zones == 2 && s->have_dehors) ierc = 2;
     if (ezhip_interp_pts2(&pu, &pv, d_uo, d_vo, d_ui, d_vi, s->d_x, s->d_y, go->ni * go->nj)) return -1;
     return ierc;
 }
@@ -1843,19 +1885,26 @@ int32_t ezhip_prepare_set(void)
     if (G[s->gdin].grtyp == 'U') return yy_plan(s);
     int degree = O.degre_interp, polar = O.polar_correction == 1;
     if (choose_mode(s, degree, polar) == 1) return build_sep_plan(s, degree, 0, polar);
-    if (ensure_points(s)) return -1;
-    if (s->extrap && !s->sep_capable && !s->have_dehors) {
-        /* classify once on the host (first-call work, like ez_defzones) */
-        ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
-        size_t n = (size_t)go->ni * go->nj;
-        float *x = (float *)malloc(sizeof(float) * n), *y = (float *)malloc(sizeof(float) * n);
-        ezhip_d2h(x, s->d_x, sizeof(float) * n); ezhip_d2h(y, s->d_y, sizeof(float) * n); ezhip_sync();
-        for (size_t k = 0; k < n; k++) {
-            int ix = (int)((double)x[k] + 0.5), iy = (int)((double)y[k] + 0.5);
-            if (ix < 1 || iy < 1 || ix > gi->ni || iy > gi->nj) { s->have_dehors = 1; break; }
-        }
-        free(x); free(y);
-    }
+    pthread_mutex_lock(&g_plan_mtx);
+    int erc = ensure_points(s);                     /* locates and classifies the DEHORS zone (first-call work, like ez_defzones) */
+    pthread_mutex_unlock(&g_plan_mtx);
+    return erc ? -1 : 0;
+}
+
+/* the located x,y of the current set (the reference's gridset cache gset.x / gset.y, ez_calcxy.c:56-134), copied to
+ * caller-owned device arrays of ni_out*nj_out floats: lets a test compare the locate on its own */
+int32_t ezhip_set_xy_dev(float *d_x, float *d_y)
+{
+    ezh_set *s = current_set("ezhip_set_xy_dev");
+    if (!s) return -1;
+    if (need_device("ezhip_set_xy_dev")) return -1;
+    if (G[s->gdin].grtyp == 'U' || G[s->gdout].grtyp == 'U') return -1;
+    pthread_mutex_lock(&g_plan_mtx);
+    int erc = ensure_points(s);
+    pthread_mutex_unlock(&g_plan_mtx);
+    if (erc) return -1;
+    size_t n = (size_t)G[s->gdout].ni * G[s->gdout].nj;
+    if (ezhip_d2d(d_x, s->d_x, sizeof(float) * n) || ezhip_d2d(d_y, s->d_y, sizeof(float) * n)) return -1;
     return 0;
 }
 

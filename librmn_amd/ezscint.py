@@ -210,6 +210,12 @@ def set_mode():
     return _lib().ezhip_set_mode()
 
 
+def set_xy_dev(x, y):
+    L = _lib()
+    L.ezhip_set_xy_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    return L.ezhip_set_xy_dev(_dptr(x), _dptr(y))
+
+
 def gdsetmask(gdid, mask):
     m = np.ascontiguousarray(mask, dtype=np.int32)
     return _lib().c_gdsetmask(gdid, m.ctypes.data)

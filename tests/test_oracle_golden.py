@@ -166,3 +166,53 @@ def test_yinyang_target_golden():
             O.orc_ezyysint(sg, tgt2, ctypes.byref(opts), ol.fptr(part), ol.fptr(z)); got_y[k * nsub:(k + 1) * nsub] = part
         assert np.array_equal(got_g.view(np.uint32), GOLD[f"G_to_YY/z_d{degree}"].view(np.uint32)), degree
         assert np.array_equal(got_y.view(np.uint32), GOLD[f"YY_to_YY/z_d{degree}"].view(np.uint32)), degree
+
+
+def _bit_hash(z):
+    u = np.ascontiguousarray(z).reshape(-1).view(np.uint32)
+    return (int(u.astype(np.uint64).sum()) & 0xFFFFFFFF, int(np.bitwise_xor.reduce(u)))
+
+
+def test_cfg1_exact_size_golden():
+    """BASELINE cfg1 at its exact size ('L' 400x200 -> 'L' 800x400): the oracle equals the reference's own run
+    (tests/golden/make_cfg1_full.py) bit for bit, all degrees, polar correction on / off"""
+    G1 = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg1_full_golden.npz"))
+    O = ol.oracle()
+    gi = ol.grid_define(400, 200, "L", (90, 90, 45, 0)); go = ol.grid_define(800, 400, "L", (45, 45, 0, 0))
+    gs = O.orc_defset(go, gi)
+    zin = ec.synth_field(400, 200, seed=1)
+    for degree in (1, 3, 0):
+        for polar in (1, 0):
+            opts = ol.default_opts(degre_interp=degree, polar_correction=polar)
+            z = np.zeros(800 * 400, np.float32)
+            rc = O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(z), ol.fptr(zin))
+            key = f"d{degree}_p{polar}"
+            assert rc == int(G1[key + "/rc"])
+            assert _bit_hash(z) == tuple(int(v) for v in G1[key + "/hash"]), key
+            if degree == 1:
+                assert np.array_equal(z.view(np.uint32), G1[key + "/z"].reshape(-1).view(np.uint32)), key
+
+
+def test_cfg3_full_size_golden():
+    """BASELINE cfg3 at full size (Z-on-E 2560x1280 -> L 4000x2000): located x,y, c_ezsint and c_ezuvint of the oracle
+    equal the reference's own run (tests/golden/make_cfg3_full.py) bit for bit over all 8 M points (bicubic with polar
+    correction, nearest without)"""
+    G3 = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg3_full_golden.npz"))
+    O = ol.oracle()
+    ni, nj, no, mo = 2560, 1280, 4000, 2000
+    ax, ay = ec.ze_axes(ni, nj)
+    gi = ol.grid_define(ni, nj, "Z", ec.E_IG, "E", ax, ay); go = ol.grid_define(no, mo, "L", (9, 9, 0, 0))
+    gs = O.orc_defset(go, gi)
+    uu, vv = ec.synth_wind(ni, nj, seed=3)
+    for a in (uu, vv):
+        a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+    u = np.zeros(no * mo, np.float32); v = np.zeros(no * mo, np.float32); z = np.zeros(no * mo, np.float32)
+    for degree, polar in ((3, 1), (0, 0)):
+        opts = ol.default_opts(degre_interp=degree, polar_correction=polar)
+        assert O.orc_ezuvint(gs, ctypes.byref(opts), ol.fptr(u), ol.fptr(v), ol.fptr(uu), ol.fptr(vv)) >= 0
+        assert O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(z), ol.fptr(uu)) >= 0
+        key = f"d{degree}_p{polar}"
+        for nm, a in (("u", u), ("v", v), ("z", z)):
+            assert _bit_hash(a) == tuple(int(t) for t in G3[f"{key}/{nm}/hash"]), (key, nm)
+    assert _bit_hash(ol.np_from(gs.contents.x, no * mo)) == tuple(int(t) for t in G3["x/hash"])
+    assert _bit_hash(ol.np_from(gs.contents.y, no * mo)) == tuple(int(t) for t in G3["y/hash"])
