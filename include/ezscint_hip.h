@@ -89,6 +89,12 @@ int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields);
  * min/max pass fused into the interpolation.  -2: the plan has no single-launch path (use c_ezsint_batch_dev). */
 int32_t ezhip_ezsint_batch_minmax_dev(float *d_zout, const float *d_zin, int32_t nfields, uint32_t *d_partials,
                                       int64_t stride_words, int32_t *partials_per_field);
+/* the two interpolation passes of the fused cfg5 pipeline (packers_hip.h: ezhip_ezsint_pack16_compress_batch_dev): A stores
+ * nothing and leaves only the min/max partials; B stores compact_float's 16-bit tokens (two per word, first in the high half)
+ * quantised with the {double minF, double mulFactor} found at d_params + f * param_stride_bytes.  -2: not on the k_sepx path */
+int32_t ezhip_ezsint_batch_minmax_only_dev(const float *d_zin, int32_t nfields, uint32_t *d_partials, int64_t stride_words, int32_t *partials_per_field);
+int32_t ezhip_ezsint_batch_tokens_dev(uint32_t *d_tokens, int64_t token_stride_words, const float *d_zin, int32_t nfields,
+                                      const void *d_params, int64_t param_stride_bytes);
 /* forces plan construction for the current set / options (what the reference does lazily in its first call) */
 int32_t ezhip_prepare_set(void);
 /* which kernel family the current set uses: 1 = separable (k_sep), 2 = per-point (k_pts) */

@@ -6,8 +6,7 @@
  * calls stage through device memory; the additive *_dev entry points take DEVICE pointers and enqueue
  * on the stream selected with ezhip_use_stream (ezscint_hip.h).
  *
- * Not implemented on the GPU path in this round and rejected loudly (NULL / -1): tokens wider than
- * 32 bits, and armn_compress UNCOMPRESS (SURVEY.md section 8f "next" rows).
+ * Rejected loudly (NULL / -1): tokens wider than 32 bits, streams of the deactivated SAMPLE predictor.
  */
 #ifndef PACKERS_HIP_H
 #define PACKERS_HIP_H
@@ -47,7 +46,8 @@ void *compact_float_dev(void *d_unpacked, void *d_header, void *d_packed, int el
                         int offset, int stride, int opCode, int hasMissing, const void *missingTag_host, int header_style);
 int   compact_integer_dev(void *d_unpacked, void *d_header, void *d_packed, int elementCount,
                           int bitSizeOfPackedToken, int off_set, int stride, int opCode);
-/* out-of-place: d_words = ni*nj 16-bit-slot tokens (two per word), d_z >= (ni*nj/2 + 16) words.  Returns zlng or -1. */
+/* out-of-place: d_words = ni*nj 16-bit-slot tokens (two per word), d_z >= (ni*nj/2 + 16) words: no store ever goes past that
+ * capacity, also for fields that turn out not to be compressible.  Returns zlng or -1. */
 int   armn_compress_dev(void *d_z, const void *d_words, int ni, int nj, int nbits);
 /* UNCOMPRESS out of place on device data: d_z holds a stream with room for z_words words (reads never go past it),
  * d_words receives (1 + ni*nj/2) words of 16-bit-slot tokens.  Returns ni*nj*2, or -1 (unknown header / broken stream).
@@ -74,6 +74,14 @@ int32_t ezhip_ezsint_pack16_batch_dev(void *d_records, int64_t record_stride_wor
  * or -1 (not compressible: the record keeps the plain 16-bit pack). */
 int32_t ezhip_pack16_compress_batch_dev(void *d_records, int64_t record_stride_words, const float *d_fields, int64_t field_stride,
                                         int32_t nfields, int32_t ni, int32_t nj, int32_t nbits, int32_t prepacked, int32_t *zlng_out);
+/* The whole cfg5 pipeline on a batch, fused: c_ezsint on the current grid set -> compact_float(nbits + 64*16, style 2) ->
+ * armn_compress of nfields device-resident SOURCE fields (fstd98.c:1170-1172) without ever storing the interpolated floats:
+ * the interpolation runs twice (min/max only, then straight to 16-bit tokens), the one-pass encoder writes every stream in
+ * place.  d_records: nfields records of record_stride_words (>= 4 + ni_out*nj_out/2 + 16) words, [4 header words][stream];
+ * zlng_out[f] (host) = byte count of the stream or -1 (not compressible: plain 16-bit pack).  One synchronisation at the end.
+ * Returns 0, -1 on error, -2 when the grid set / shape is outside the fused path (use the two calls above instead). */
+int32_t ezhip_ezsint_pack16_compress_batch_dev(void *d_records, int64_t record_stride_words, const float *d_zin, int32_t nfields,
+                                               int32_t ni_out, int32_t nj_out, int32_t nbits, int32_t *zlng_out);
 /* frees the calling thread's grow-only device workspaces (staged operands of the host-pointer entry points,
  * the compressed stream, the armn_compress scan storage); they are re-created on the next call */
 void  ezhip_pack_release(void);

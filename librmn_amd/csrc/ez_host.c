@@ -1795,7 +1795,15 @@ static int ensure_batch_poles(ezh_set *s, int nfields)
 /* stat_partials != NULL: the launch also leaves, per field, {min key, max key, 0} triples of every thread block's
  * output at stat_partials[f * stat_stride + 3 k], k < *partials_per_field (compact_float's min/max pass fused into the
  * interpolation); only the single-launch k_sepx path can do that: returns -2 when it does not apply */
+typedef struct { int mode; const void *qparams; size_t qstride, out_stride_words; } batch_out;      /* ezhip_sep_plan.out_mode and friends */
+static int32_t batch_impl_o(float *d_zout, const float *d_zin, int32_t nfields, unsigned *stat_partials, size_t stat_stride, int32_t *partials_per_field, const batch_out *bo);
 static int32_t batch_impl(float *d_zout, const float *d_zin, int32_t nfields, unsigned *stat_partials, size_t stat_stride, int32_t *partials_per_field)
+{
+    return batch_impl_o(d_zout, d_zin, nfields, stat_partials, stat_stride, partials_per_field, NULL);
+}
+/* bo != NULL: the launch leaves min/max partials only (mode 2) or 16-bit tokens (mode 3) instead of float fields; only the
+ * single-launch k_sepx path can do that: returns -2 when it does not apply */
+static int32_t batch_impl_o(float *d_zout, const float *d_zin, int32_t nfields, unsigned *stat_partials, size_t stat_stride, int32_t *partials_per_field, const batch_out *bo)
 {
     ezh_set *s = current_set("c_ezsint_batch");
     if (!s) return -1;
@@ -1803,6 +1811,7 @@ static int32_t batch_impl(float *d_zout, const float *d_zin, int32_t nfields, un
     size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
     int rc = 0;
     if (G[s->gdin].grtyp == 'U' || G[s->gdout].grtyp == 'U') {  /* Yin-Yang source or target: field by field */
+        if (bo) return -2;
         if (stat_partials) return -1;
         for (int f = 0; f < nfields; f++) {
             int r = G[s->gdout].grtyp == 'U' ? yy_sint_to_u(s, d_zout + f * nout, d_zin + f * nin) : yy_sint(s, d_zout + f * nout, d_zin + f * nin);
@@ -1813,7 +1822,7 @@ static int32_t batch_impl(float *d_zout, const float *d_zin, int32_t nfields, un
     }
     /* separable plan without extrapolation fill: ALL fields in one k_sepx launch (no ramp-up / drain gap between
      * fields; the pole rows are summed by producer blocks of the same launch) */
-    if (s->gdin != s->gdout && (nfields > 1 || stat_partials) && !(O.polar_correction == 1 && s->extrap) && !grid_yinv(&G[s->gdin]) &&
+    if (s->gdin != s->gdout && (nfields > 1 || stat_partials || bo) && !(O.polar_correction == 1 && s->extrap) && !grid_yinv(&G[s->gdin]) &&
         (O.degre_interp == DEG_NEAREST || O.degre_interp == DEG_LINEAR || O.degre_interp == DEG_CUBIC) &&
         choose_mode(s, O.degre_interp, O.polar_correction == 1) == 1 && !getenv("EZHIP_NO_BATCH_LAUNCH") && !getenv("EZHIP_NO_SEPX")) {
         int degree = O.degre_interp, polar = O.polar_correction == 1;
@@ -1836,6 +1845,11 @@ static int32_t batch_impl(float *d_zout, const float *d_zin, int32_t nfields, un
                 }
             }
             p.batch_fields = nfields; p.batch_in_stride = nin; p.batch_out_stride = nout;
+            if (bo) {
+                if (bo->mode == 3 && (p.ni_dst & 1)) return -2;               /* a token word holds two columns of one row */
+                p.out_mode = bo->mode; p.quant_params = bo->qparams; p.quant_stride = bo->qstride;
+                if (bo->mode == 3) p.batch_out_stride = bo->out_stride_words;
+            }
             if (stat_partials) {
                 int nbx = (p.ni_dst + EZHIP_SEP_COLS - 1) / EZHIP_SEP_COLS, npf = nbx * (p.x_nseg + p.n_special);
                 if ((size_t)3 * npf > stat_stride) return -2;
@@ -1845,7 +1859,7 @@ static int32_t batch_impl(float *d_zout, const float *d_zin, int32_t nfields, un
             return ezhip_interp_sep(&p, d_zout, d_zin) ? -1 : 0;
         }
     }
-    if (stat_partials) return -2;
+    if (stat_partials || bo) return -2;
     /* field by field; the pole values (a sequential REAL sum per pole row) of ALL fields from one k_polevals launch */
     float *d_poles_all = NULL;
     if (s->gdin != s->gdout && O.polar_correction == 1 && !s->extrap && nfields > 1) {
@@ -1874,6 +1888,24 @@ int32_t ezhip_ezsint_batch_minmax_dev(float *d_zout, const float *d_zin, int32_t
 {
     if (!d_partials || stride_words <= 0) return -1;
     return batch_impl(d_zout, d_zin, nfields, d_partials, (size_t)stride_words, partials_per_field);
+}
+
+/* cfg5 pipeline, pass A: interpolate nfields fields WITHOUT storing them; only the {min key, max key, 0} triples of every
+ * thread block (compact_float's min/max pass, compact.tmplc:173-204) are left in d_partials.  -2: plan not on the k_sepx path */
+int32_t ezhip_ezsint_batch_minmax_only_dev(const float *d_zin, int32_t nfields, uint32_t *d_partials, int64_t stride_words, int32_t *partials_per_field)
+{
+    if (!d_partials || stride_words <= 0) return -1;
+    batch_out bo = {2, NULL, 0, 0};
+    return batch_impl_o(NULL, d_zin, nfields, d_partials, (size_t)stride_words, partials_per_field, &bo);
+}
+/* cfg5 pipeline, pass B: interpolate again and leave compact_float's 16-bit tokens of every value (two per word, first in the
+ * high half: the layout armn_compress consumes), quantised with the {minF, mulFactor} at d_params + f * param_stride_bytes */
+int32_t ezhip_ezsint_batch_tokens_dev(uint32_t *d_tokens, int64_t token_stride_words, const float *d_zin, int32_t nfields,
+                                      const void *d_params, int64_t param_stride_bytes)
+{
+    if (!d_tokens || !d_params) return -1;
+    batch_out bo = {3, d_params, (size_t)param_stride_bytes, (size_t)token_stride_words};
+    return batch_impl_o((float *)d_tokens, d_zin, nfields, NULL, 0, NULL, &bo);
 }
 
 int32_t ezhip_prepare_set(void)

@@ -401,11 +401,18 @@ __device__ void sep_rowblock_gather(const ezhip_sep_plan &p, RowInfo &ri, float 
     sep_rows<DEG>(p, ri, t, [&](int s) { return zin + (size_t)s * nis; }, r0, r1, zout, c, cvalid, cdehors, fillv);
 }
 
+/* token output of k_sepx (out_mode 3): compact_float's quantisation parameters of the field, its token array */
+struct QuantP { double minF, mul; unsigned short *tok16; unsigned colbase; };
+__device__ __forceinline__ unsigned quant16(float v, const QuantP &q)
+{   /* compact.tmplc:285-300: (int64)((double(a) - min) * mulFactor); a >= min, so the unsigned conversion truncates identically */
+    return __double2uint_rz(((double)v - q.minF) * q.mul) & 0xFFFFu;
+}
+
 /* special target rows of one column block: polar strips, pole rows, fully-outside rows (`ispecial` indexes
  * p.special).  Pole values come precomputed (p.polevals). */
-template <int DEG>
+template <int DEG, int OUT = 0>
 __device__ float sep_special(const ezhip_sep_plan &p, float *__restrict__ zout, const float *__restrict__ zin, int ispecial,
-                             int c, int cc, bool cvalid, float fillv)
+                             int c, int cc, bool cvalid, float fillv, const QuantP &qp = QuantP())
 {
     const int nis = p.ni_src;
     /* ---- special rows: polar strips, pole rows, fully-outside rows ------------------------- */
@@ -441,7 +448,10 @@ __device__ float sep_special(const ezhip_sep_plan &p, float *__restrict__ zout, 
             outv = (float)val;
         }
     }
-    if (cvalid) zout[(size_t)sr.row * p.ni_dst + c] = outv;
+    if (cvalid) {
+        if (OUT == 3) qp.tok16[((unsigned)sr.row * (unsigned)p.ni_dst + (unsigned)c) ^ 1u] = (unsigned short)quant16(outv, qp);
+        else if (OUT != 2) zout[(size_t)sr.row * p.ni_dst + c] = outv;
+    }
     return outv;       /* lanes past the last column carry the value of the last column */
 }
 
@@ -523,10 +533,13 @@ __global__ __launch_bounds__(SEP_BLOCK) void k_sep(ezhip_sep_plan p, float *__re
 /* y-pass of one wave and one row-block: 2 row pairs x 8 column groups of 32.  `myrec` = this lane's row record of
  * the first pair (the second pair is 8 records further), `tcol` = ring base of the lane's column in group 0.
  * SLOW adds what few blocks need: the DEHORS fill select, the column bound of the last strip, the debug knock-out. */
-template <int DEG, int XR, bool SLOW, bool STATS>
+/* OUT (what the launch leaves behind, ezhip_sep_plan.out_mode): 0 floats, 1 floats + min/max partials, 2 min/max partials
+ * only (nothing stored), 3 compact_float's 16-bit tokens */
+template <int DEG, int XR, bool SLOW, int OUT>
 __device__ __forceinline__ void sepx_ypass(const float *myrec, const double *tcol, float *zcol, float fillv, unsigned dmask,
-                                           int l32, int ncol_valid, bool nostore, float &vmin, float &vmax)
+                                           int l32, int ncol_valid, bool nostore, float &vmin, float &vmax, const QuantP &qp)
 {
+    constexpr bool STATS = OUT == 1 || OUT == 2;
 #pragma unroll
     for (int h = 0; h < XR / 8; h++) {
         const float4 *r4 = (const float4 *)(myrec + h * 8 * 16);
@@ -579,11 +592,66 @@ __device__ __forceinline__ void sepx_ypass(const float *myrec, const double *tco
             float out = (float)val;
             if (SLOW) {
                 out = (dmask >> g) & 1 ? fillv : out;
-                if (!nostore && l32 + 32 * g < ncol_valid) { orow[32 * g] = out; if (STATS) { vmin = fminf(vmin, out); vmax = fmaxf(vmax, out); } }
+                if (!nostore && l32 + 32 * g < ncol_valid) {
+                    if (OUT == 3) qp.tok16[(o_off + qp.colbase + 32u * g) ^ 1u] = (unsigned short)quant16(out, qp);    /* token k = halfword k ^ 1 */
+                    else if (OUT != 2) orow[32 * g] = out;
+                    if (STATS) { vmin = fminf(vmin, out); vmax = fmaxf(vmax, out); }
+                }
             } else {
-                __builtin_nontemporal_store(out, &orow[32 * g]);      /* streaming output (`nt`): -0.7 us per cfg2 field */
+                if (OUT != 2) __builtin_nontemporal_store(out, &orow[32 * g]);      /* streaming output (`nt`): -0.7 us per cfg2 field */
                 if (STATS) { vmin = fminf(vmin, out); vmax = fmaxf(vmax, out); }
             }
+        }
+    }
+}
+
+/* y-pass of the token instantiation (OUT = 3), full strips without DEHORS columns: lane l32 owns the column PAIRS
+ * (2 l32, 2 l32 + 1) + 64 g, g < 4, so the two 16-bit tokens of a stream word sit in one lane: per row pair 16
+ * ds_read_b128 (the LDS cycles of the 32 ds_read_b64 of the float form) and 4 dword stores of 128 contiguous bytes per
+ * row.  Same fma chains, same float rounding, then compact_float's quantisation (compact.tmplc:285-300). */
+typedef double d2_t __attribute__((ext_vector_type(2)));
+template <int DEG, int XR>
+__device__ __forceinline__ void sepx_ypass_q(const float *myrec, const double *tcol2, unsigned *zw, const QuantP &qp)
+{
+#pragma unroll
+    for (int h = 0; h < XR / 8; h++) {
+        const float4 *r4 = (const float4 *)(myrec + h * 8 * 16);
+        const float4 ra = r4[0], rb = r4[1], rc = r4[2];
+        const unsigned o_off = (unsigned)__float_as_int(myrec[h * 8 * 16 + 12]);
+        const double w0 = __hiloint2double(__float_as_int(ra.y), __float_as_int(ra.x));
+        const double w1 = __hiloint2double(__float_as_int(ra.w), __float_as_int(ra.z));
+        const double w2 = __hiloint2double(__float_as_int(rb.y), __float_as_int(rb.x));
+        const double w3 = __hiloint2double(__float_as_int(rb.w), __float_as_int(rb.z));
+        const char *tb = (const char *)tcol2;
+        const unsigned a0 = lds_addr_of(tb + __float_as_int(rc.x)), a1 = lds_addr_of(tb + __float_as_int(rc.y));
+        const unsigned a2 = lds_addr_of(tb + __float_as_int(rc.z)), a3 = lds_addr_of(tb + __float_as_int(rc.w));
+        d2_t t[4][4];
+#define RD4(A, J) asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:512\n\tds_read_b128 %2, %4 offset:1024\n\tds_read_b128 %3, %4 offset:1536" \
+                               : "=&v"(t[0][J]), "=&v"(t[1][J]), "=&v"(t[2][J]), "=&v"(t[3][J]) : "v"(A) : "memory")
+        RD4(a0, 0);
+        if (DEG >= 1) RD4(a1, 1);
+        if (DEG == 3) { RD4(a2, 2); RD4(a3, 3); }
+#undef RD4
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            if (DEG == 3) asm volatile("" : "+v"(t[g][0]), "+v"(t[g][1]), "+v"(t[g][2]), "+v"(t[g][3]));
+            else if (DEG == 1) asm volatile("" : "+v"(t[g][0]), "+v"(t[g][1]));
+            else asm volatile("" : "+v"(t[g][0]));
+        }
+        unsigned *orow = zw + (o_off >> 1);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            unsigned tk[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                double val;
+                if (DEG == 0) val = t[g][0][e];
+                else if (DEG == 1) val = t[g][0][e] + (t[g][1][e] - t[g][0][e]) * w0;
+                else val = fma(w3, t[g][3][e], fma(w2, t[g][2][e], fma(w1, t[g][1][e], w0 * t[g][0][e])));
+                tk[e] = quant16((float)val, qp);
+            }
+            __builtin_nontemporal_store(tk[0] << 16 | tk[1], &orow[32 * g]);
         }
     }
 }
@@ -606,11 +674,12 @@ __device__ __forceinline__ void block_minmax_partial(float vmin, float vmax, uns
     }
 }
 
-template <int DEG, int XR, bool STATS>
+template <int DEG, int XR, int OUT>
 __global__ __launch_bounds__(SEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 6)))
 void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict__ zin)
 {
-    extern __shared__ double smem_x[];
+    extern __shared__ __attribute__((aligned(16))) double smem_x[];
+    constexpr bool STATS = OUT == 1 || OUT == 2;
     /* XCD-aware work mapping.  Thread blocks are dealt round-robin to the 8 XCDs in linear launch order, and every
      * XCD has its own L2.  Here XCD k takes the k-th CONTIGUOUS eighth of the (field, segment, strip) space, so the
      * strips that share source columns (35 of 192 staged floats) and the segments that share halo rows run on the
@@ -646,7 +715,12 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
     const int cc = min(c, p.ni_dst - 1);
     const float fillv = p.fill ? *p.fill : 0.0f;
     /* bz = field of a batch launch (c_ezsint_batch_dev): no ramp-up / drain gap between fields */
-    zin += bz * p.batch_in_stride; zout += bz * p.batch_out_stride;
+    zin += bz * p.batch_in_stride; zout += bz * p.batch_out_stride;        /* OUT = 3: zout is the token array, its stride in words */
+    QuantP qp; qp.minF = 0.0; qp.mul = 0.0; qp.tok16 = (unsigned short *)zout; qp.colbase = 0;
+    if (OUT == 3) {
+        const double *pp = (const double *)((const char *)p.quant_params + (size_t)bz * p.quant_stride);     /* packhip_cf_params: minF, mulFactor first */
+        qp.minF = pp[0]; qp.mul = pp[1];
+    }
     /* special rows sit in the MIDDLE of the field's work order: their gathers are latency-bound (tens of us per block),
      * so they must overlap main blocks (last in the order they became an exposed tail: +6 us per field), and by then
      * the pole producers have long finished */
@@ -669,7 +743,7 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
             }
         } else if (p.polevals) p.polevals += 2 * bz;
-        const float sv = sep_special<DEG>(p, zout, zin, by - sp0, c, cc, c < p.ni_dst, fillv);
+        const float sv = sep_special<DEG, OUT>(p, zout, zin, by - sp0, c, cc, c < p.ni_dst, fillv, qp);
         if (STATS) block_minmax_partial(sv, sv, p.stat_partials + (size_t)bz * p.stat_stride + 3 * (size_t)(by * p.x_nbx + bx));
         return;
     }
@@ -713,6 +787,7 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
     const bool any_dehors = __syncthreads_or(dmask != 0) != 0;
     const bool slow = any_dehors || !full || (dbg & 1);      /* block-uniform: predicated y-pass */
     float *zcol = zout + (size_t)bx * SEP_BLOCK + l32;                 /* + row offset (record) + 32 g */
+    qp.colbase = (unsigned)(bx * SEP_BLOCK + l32);
 
     auto load_step = [](const ezhip_xstep *tab, int i) {       /* four scalar loads (constant address space) */
         const auto *q = CONSTP(int, tab) + 4 * i;
@@ -770,13 +845,15 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
         /* ---- y-pass: wave wv owns target rows {2 wv, 2 wv + 1} and {8 + 2 wv, 9 + 2 wv} of the row-block */
         if (!(dbg & 16)) {
             const float *myrec = rec + (i & 1) * SEPX_REC_DW + (2 * wv + rsub) * 16;
-            if (slow) sepx_ypass<DEG, XR, true, STATS>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, (dbg & 1) != 0, vmin, vmax);
-            else sepx_ypass<DEG, XR, false, STATS>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, false, vmin, vmax);
+            if (slow) sepx_ypass<DEG, XR, true, OUT>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, (dbg & 1) != 0, vmin, vmax, qp);
+            else if (OUT == 3) sepx_ypass_q<DEG, XR>(myrec, T + 2 * l32, (unsigned *)zout + (size_t)bx * (SEP_BLOCK / 2) + l32, qp);
+            else sepx_ypass<DEG, XR, false, OUT>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, false, vmin, vmax, qp);
         }
         st = nst;
-        if ((dbg & 16) || slow) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (i + 1 < i1) {                              /* DMA(i+1) landed; the XR stores of this step stay in flight */
-            if (XR == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if ((dbg & 16) || slow || OUT == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* OUT = 2 stores nothing: only DMA(i+1) is outstanding */
+        else if (i + 1 < i1) {                              /* DMA(i+1) landed; the stores of this step stay in flight */
+            if (OUT == 3) { if (XR == 16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else if (XR == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
     }
     if (STATS) block_minmax_partial(vmin, vmax, p.stat_partials + (size_t)bz * p.stat_stride + 3 * (size_t)(by * p.x_nbx + bx));
@@ -790,13 +867,14 @@ extern "C" size_t ezhip_sepx_lds_bytes(int x_tr, int rows_per_step, int x_prows,
 }
 
 /* rows per step: 16 (8 was measured too: smaller ring and patch, 4 blocks per CU, twice the barriers -- no gain) */
-#define SEPX_DISPATCH(DEGV, STATSV, EXPR) do { \
-        if ((DEGV) == 0 && !(STATSV)) { constexpr int D = 0, X = 16; constexpr bool S = false; EXPR; } \
-        else if ((DEGV) == 1 && !(STATSV)) { constexpr int D = 1, X = 16; constexpr bool S = false; EXPR; } \
-        else if (!(STATSV)) { constexpr int D = 3, X = 16; constexpr bool S = false; EXPR; } \
-        else if ((DEGV) == 0) { constexpr int D = 0, X = 16; constexpr bool S = true; EXPR; } \
-        else if ((DEGV) == 1) { constexpr int D = 1, X = 16; constexpr bool S = true; EXPR; } \
-        else { constexpr int D = 3, X = 16; constexpr bool S = true; EXPR; } } while (0)
+#define SEPX_DISPATCH(DEGV, OUTV, EXPR) do { \
+        constexpr int X = 16; \
+        const int o_ = (OUTV); \
+        if ((DEGV) == 0) { constexpr int D = 0; if (o_ == 0) { constexpr int S = 0; EXPR; } else if (o_ == 1) { constexpr int S = 1; EXPR; } else if (o_ == 2) { constexpr int S = 2; EXPR; } else { constexpr int S = 3; EXPR; } } \
+        else if ((DEGV) == 1) { constexpr int D = 1; if (o_ == 0) { constexpr int S = 0; EXPR; } else if (o_ == 1) { constexpr int S = 1; EXPR; } else if (o_ == 2) { constexpr int S = 2; EXPR; } else { constexpr int S = 3; EXPR; } } \
+        else { constexpr int D = 3; if (o_ == 0) { constexpr int S = 0; EXPR; } else if (o_ == 1) { constexpr int S = 1; EXPR; } else if (o_ == 2) { constexpr int S = 2; EXPR; } else { constexpr int S = 3; EXPR; } } } while (0)
+/* OUT of a plan: 1 when min/max partials are requested next to the float field */
+static int plan_out(const ezhip_sep_plan *p) { return p->out_mode ? p->out_mode : (p->stat_partials ? 1 : 0); }
 
 extern "C" int ezhip_sepx_capacity(int degree, int rows_per_step, size_t lds_bytes)
 {
@@ -805,7 +883,7 @@ extern "C" int ezhip_sepx_capacity(int degree, int rows_per_step, size_t lds_byt
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     hipError_t e = hipSuccess;
     (void)rows_per_step;
-    SEPX_DISPATCH(degree, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<D, X, S>, SEP_BLOCK, lds_bytes));
+    SEPX_DISPATCH(degree, 0, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sepx<D, X, S>, SEP_BLOCK, lds_bytes));
     if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
     return nb * ncu;
 }
@@ -824,11 +902,12 @@ static int launch_sepx(const ezhip_sep_plan *plan, float *d_zout, const float *d
     pl.x_lds_bytes = lds;
     if (lds > 64 * 1024) {        /* tall windows on wide strips: raise the per-kernel dynamic LDS limit */
         hipError_t e = hipSuccess;
-        SEPX_DISPATCH(plan->degree, plan->stat_partials != nullptr,
+        SEPX_DISPATCH(plan->degree, plan_out(plan),
                       e = hipFuncSetAttribute((const void *)k_sepx<D, X, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (e != hipSuccess) return set_err(e, "k_sepx LDS size");
     }
-    SEPX_DISPATCH(plan->degree, plan->stat_partials != nullptr, hipLaunchKernelGGL((k_sepx<D, X, S>), grid, block, lds, g_stream, *plan, d_zout, d_zin));
+    if (plan_out(plan) == 3 && (plan->ni_dst & 1)) { snprintf(g_err, sizeof(g_err), "k_sepx: token output needs an even ni_dst"); return -1; }
+    SEPX_DISPATCH(plan->degree, plan_out(plan), hipLaunchKernelGGL((k_sepx<D, X, S>), grid, block, lds, g_stream, *plan, d_zout, d_zin));
     return LAUNCH_CHECK("k_sepx");
 }
 

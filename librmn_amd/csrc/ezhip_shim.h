@@ -119,6 +119,11 @@ typedef struct {
     /* fused compact_float min/max (k_sepx<.., STATS>): every thread block writes {min key, max key, 0} of the values it
      * stored to stat_partials[field * stat_stride + 3 * (work item in field)]; NULL: not requested */
     unsigned *stat_partials; size_t stat_stride;
+    /* what a launch leaves behind (k_sepx only): 0 float fields in zout; 2 nothing but the min/max partials (compact_float's
+     * first pass over values that are never stored: the cfg5 pipeline); 3 compact_float's 16-bit tokens of the values,
+     * two per 32-bit word, first in the high half (zout is then the token array, batch_out_stride in WORDS; ni_dst even),
+     * quantised with the {minF, mulFactor} of quant_params[field] (packhip_cf_params, quant_stride bytes apart) */
+    int out_mode; const void *quant_params; size_t quant_stride;
     size_t batch_in_stride, batch_out_stride;   /* floats between consecutive fields */
     const ezhip_xstep *x_first, *x_cont;   /* [x_nvb] staging step of a row-block when it starts a segment / continues one */
     const ezhip_xrow *x_rows;         /* [x_nvb * x_rows_per_step] row records */

@@ -27,7 +27,7 @@ static __thread void *t_scratch = NULL;
 /* per-thread grow-only device workspaces (slot 0/1: staged operands of the host-pointer entry points and the
  * compressed stream, slot 2: armn_compress scan storage): hipMalloc + hipFree per call cost more than the kernels
  * (a 52 MB hipMalloc/hipFree pair is ~0.4 ms and hipFree synchronises the device) */
-static __thread struct { void *p; size_t cap; } t_ws[4];
+static __thread struct { void *p; size_t cap; } t_ws[6];
 static void *ws(int slot, size_t bytes)
 {
     if (t_ws[slot].cap < bytes) {
@@ -41,7 +41,7 @@ static void *ws(int slot, size_t bytes)
 void ezhip_pack_release(void)
 {
     ezhip_sync();
-    for (int k = 0; k < 4; k++) { ezhip_free(t_ws[k].p); t_ws[k].p = NULL; t_ws[k].cap = 0; }
+    for (int k = 0; k < 6; k++) { ezhip_free(t_ws[k].p); t_ws[k].p = NULL; t_ws[k].cap = 0; }
 }
 
 static void *scratch(void)
@@ -348,6 +348,25 @@ void c_armn_compress_setlevel(int level) { g_level = level; }
 int  c_armn_compress_getlevel(void) { return g_level; }
 void c_armn_compress_setswap(int swapState) { g_swap = swapState; }
 
+/* one field through the one-pass encoder (k_armn_enc1); the rare field with a |difference| > 65535 runs twice (zlng -2 ->
+ * container 5, c_zfstlib.c:701-711).  Returns zlng, -1 (not compressible / error) or -3 (shape outside the encoder's limits). */
+static int armn_encode1_sync(unsigned *d_z, size_t z_cap_words, const unsigned *d_words, int ni, int nj, int nbits)
+{
+    size_t wb = packhip_armn_enc1_work_bytes(ni, nj, nbits, 1);
+    if (!wb || getenv("EZHIP_ARMN_MULTIPASS")) return -3;
+    char *d_work = (char *)ws(2, wb + 64);
+    if (!d_work) return -1;
+    int *d_zl = (int *)(d_work + ((wb + 15) & ~(size_t)15));
+    int zl = -1;
+    for (int container = 4; container <= 5; container++) {
+        int rc = packhip_armn_encode1(d_z, 0, z_cap_words, d_words, 0, ni, nj, nbits, 1, g_swap == 1, container, d_work, d_zl);
+        if (rc == 1) return -3;
+        if (rc || ezhip_d2h(&zl, d_zl, sizeof(int)) || ezhip_sync()) return -1;
+        if (zl != -2) break;
+    }
+    return zl;
+}
+
 int armn_compress_dev(void *d_z, const void *d_words, int ni, int nj, int nbits)
 {
     if (need_device("armn_compress")) return -1;
@@ -355,19 +374,35 @@ int armn_compress_dev(void *d_z, const void *d_words, int ni, int nj, int nbits)
     if (g_level == -1) g_level = 1;                                   /* BEST, c_zfstlib.c:92-97 */
     int minimum = (g_level == 0) || ni < 16 || nj < 16 || nbits <= 4; /* :132 */
     size_t n = (size_t)ni * nj;
-    void *d_work = ws(2, packhip_armn_work_bytes(ni, nj));
-    if (!d_work) return -1;
-    unsigned long long bits = 0;
-    /* the raw stream can exceed the source size for incompressible fields: the caller's buffer holds
-     * n/2 + 16 words, the bound checked below uses the exact bit count from the scan */
+    /* the raw stream can exceed the source size for incompressible fields: the caller's buffer holds n/2 + 16 words; the
+     * one-pass encoder drops every store at or beyond that capacity (the byte count then says "not compressible") */
     size_t z_words = n / 2 + 16;
-    int rc = packhip_armn_encode((unsigned *)d_z, z_words, (const unsigned *)d_words, ni, nj, nbits, minimum, d_work, &bits);
+    if (!minimum) {
+        int zl = armn_encode1_sync((unsigned *)d_z, z_words, (const unsigned *)d_words, ni, nj, nbits);
+        if (zl != -3) return zl < 0 ? -1 : zl;
+    }
+    /* MINIMUM method (level FAST, small fields, nbits <= 4) and shapes outside the one-pass limits: the multi-kernel encoder.
+     * Its emitters do not bound their stores: it works in a scratch stream with 25 % slack and only a compressible result
+     * (which fits the caller's buffer by definition) is copied out. */
+    void *d_work = ws(2, packhip_armn_work_bytes(ni, nj));
+    size_t zs_words = n / 2 + n / 8 + 64;
+    unsigned *d_zs = (unsigned *)ws(3, 4 * zs_words + 4 * ((n + 1) / 2 + 4));
+    if (!d_work || !d_zs) return -1;
+    const unsigned *d_tok = (const unsigned *)d_words;
+    if (g_swap != 1) {                                                /* c_zfstlib.c:119-126: without the swap the ushort array is the raw memory order */
+        unsigned *d_sw = d_zs + zs_words;
+        if (packhip_swap_halves(d_sw, d_tok, (n + 1) / 2)) return -1;
+        d_tok = d_sw;
+    }
+    unsigned long long bits = 0;
+    int rc = packhip_armn_encode(d_zs, zs_words, d_tok, ni, nj, nbits, minimum, d_work, &bits);
     if (rc) return -1;
     /* a word is flushed only when a later token crosses its end (stuff macro), the two 16-bit terminator
      * tokens flush every word that holds stream bits: words = ceil(bits / 32) */
     long long zlng = 1 + 4 * (1 + (long long)((bits + 31) / 32));
     long long lng_origin = 1 + (long long)n * 2;
     if (zlng >= lng_origin) return -1;
+    if (ezhip_d2d(d_z, d_zs, (size_t)((zlng + 3) / 4) * 4) || ezhip_sync()) return -1;
     return (int)zlng;
 }
 
@@ -511,6 +546,25 @@ int32_t ezhip_ezsint_pack16_batch_dev(void *d_records, int64_t record_stride_wor
  * synchronisation at the end (ezhip_pack16_compress_dev returns zlng per call: one sync per field, ~25 % of its time).
  * prepacked != 0: the records already hold the 16-bit-slot pack (ezhip_ezsint_pack16_batch_dev).  zlng_out[f] = byte
  * count of record f's compressed stream, or -1 (not compressible: the record keeps the plain pack). */
+/* fields whose one-pass encode asked for the 5-bit container (zlng -2): re-run them one by one, synchronously */
+static int redo_wide_fields(unsigned *d_records, size_t record_stride_words, const unsigned *d_tok, size_t tok_stride_words, int in_place,
+                            int32_t nfields, int ni, int nj, int nbits, int32_t *zlng_out)
+{
+    const size_t n = (size_t)ni * nj;
+    for (int f = 0; f < nfields; f++) {
+        if (zlng_out[f] != -2) continue;
+        unsigned *rec = d_records + (size_t)f * record_stride_words;
+        const unsigned *tok = in_place ? rec + 4 : d_tok + (size_t)f * tok_stride_words;
+        unsigned *d_z = (unsigned *)ws(4, 4 * (n / 2 + 32));          /* its own slot: slot 1 may hold the batch's tokens */
+        if (!d_z) return -1;
+        int zl = armn_compress_dev(d_z, tok, ni, nj, nbits);
+        if (zl > 0) { if (ezhip_d2d(rec + 4, d_z, (size_t)zl) || ezhip_sync()) return -1; }
+        else if (!in_place && (ezhip_d2d(rec + 4, tok, 4 * ((n + 1) / 2)) || ezhip_sync())) return -1;
+        zlng_out[f] = zl;
+    }
+    return 0;
+}
+
 int32_t ezhip_pack16_compress_batch_dev(void *d_records, int64_t record_stride_words, const float *d_fields, int64_t field_stride,
                                         int32_t nfields, int32_t ni, int32_t nj, int32_t nbits, int32_t prepacked, int32_t *zlng_out)
 {
@@ -519,8 +573,9 @@ int32_t ezhip_pack16_compress_batch_dev(void *d_records, int64_t record_stride_w
     if (g_level == -1) g_level = 1;
     const int minimum = (g_level == 0) || ni < 16 || nj < 16 || nbits <= 4;
     const size_t n = (size_t)ni * nj;
-    unsigned *d_z = (unsigned *)ws(1, 4 * (n / 2 + 32));
-    void *d_work = ws(2, packhip_armn_work_bytes(ni, nj));
+    unsigned *d_z = (unsigned *)ws(1, 4 * (n / 2 + n / 8 + 64));
+    const size_t wb1 = minimum || getenv("EZHIP_ARMN_MULTIPASS") ? 0 : packhip_armn_enc1_work_bytes(ni, nj, nbits, 1);
+    void *d_work = ws(2, wb1 ? wb1 : packhip_armn_work_bytes(ni, nj));
     int *d_zlng = (int *)ws(0, sizeof(int) * (size_t)nfields + 64);
     if (!d_z || !d_work || !d_zlng) return -1;
     float tag = 0.f;
@@ -528,9 +583,66 @@ int32_t ezhip_pack16_compress_batch_dev(void *d_records, int64_t record_stride_w
         unsigned *rec = (unsigned *)d_records + (size_t)f * (size_t)record_stride_words;
         if (!prepacked && !compact_float_dev((void *)(d_fields + (size_t)f * (size_t)field_stride), rec, rec + 4, (int)n,
                                              nbits + 64 * 16, 0, 1, 1, 0, &tag, 2)) return -1;
-        if (packhip_armn_encode(d_z, n / 2 + 16, rec + 4, ni, nj, nbits, minimum, d_work, NULL)) return -1;
-        if (packhip_armn_commit(rec + 4, d_z, d_work, ni, nj, nbits, minimum, d_zlng + f)) return -1;
+        if (wb1) {
+            /* the tokens sit where the stream has to go: encode into the scratch stream, then the stream's words (zlng > 0 only) back */
+            if (packhip_armn_encode1(d_z, 0, n / 2 + 16, rec + 4, 0, ni, nj, nbits, 1, g_swap == 1, 4, d_work, d_zlng + f)) return -1;
+            if (packhip_cond_copy(rec + 4, 0, d_z, 0, 0, d_zlng + f, 1, 0)) return -1;
+        } else {
+            if (g_swap != 1) { fprintf(stderr, "<armn_compress> swap state 0 is not supported by the batched MINIMUM path\n"); return -1; }
+            if (packhip_armn_encode(d_z, n / 2 + n / 8 + 64, rec + 4, ni, nj, nbits, minimum, d_work, NULL)) return -1;
+            if (packhip_armn_commit(rec + 4, d_z, d_work, ni, nj, nbits, minimum, d_zlng + f)) return -1;
+        }
     }
     if (ezhip_d2h(zlng_out, d_zlng, sizeof(int) * (size_t)nfields) || ezhip_sync()) return -1;
-    return 0;
+    return redo_wide_fields((unsigned *)d_records, (size_t)record_stride_words, NULL, 0, 1, nfields, ni, nj, nbits, zlng_out);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* the whole cfg5 pipeline on a batch, fused (round 2)                                            */
+/* ------------------------------------------------------------------------------------------ */
+int32_t ezhip_ezsint_batch_minmax_only_dev(const float *d_zin, int32_t nfields, uint32_t *d_partials, int64_t stride_words, int32_t *partials_per_field);
+int32_t ezhip_ezsint_batch_tokens_dev(uint32_t *d_tokens, int64_t token_stride_words, const float *d_zin, int32_t nfields,
+                                      const void *d_params, int64_t param_stride_bytes);
+
+/* c_ezsint (current grid set) -> compact_float(nbits + 64*16, header style 2) -> armn_compress of nfields device-resident source
+ * fields (fstd98.c:1170-1172), without ever storing the interpolated floats:
+ *   A  k_sepx<.., min/max only>: the values are computed and reduced, nothing is stored (reads the sources)
+ *   H  one header launch: min/max -> compact_float header words of every record + quantisation parameters
+ *   B  k_sepx<.., tokens>: the same values again -> 16-bit tokens (reads the sources, writes 2 bytes per point)
+ *   E  k_armn_enc1: tokens -> streams, written in place in the records (one launch for the batch)
+ *   F  fields that are not compressible get the plain 16-bit pack (conditional copy, one launch)
+ * One synchronisation at the end (zlng_out).  Returns the c_ezsint code (0), -1 on error, or -2 when the grid set is not on the
+ * single-launch k_sepx path / the shape is outside the one-pass encoder (use the unfused entry points then). */
+int32_t ezhip_ezsint_pack16_compress_batch_dev(void *d_records, int64_t record_stride_words, const float *d_zin, int32_t nfields,
+                                               int32_t ni_out, int32_t nj_out, int32_t nbits, int32_t *zlng_out)
+{
+    if (need_device("ezhip_ezsint_pack16_compress_batch_dev")) return -1;
+    if (nfields < 1 || nbits < 5 || nbits > 16 || ni_out < 16 || nj_out < 16 || (ni_out & 1)) return -2;
+    if (g_level == -1) g_level = 1;
+    if (g_level == 0 || g_swap != 1) return -2;
+    const size_t n = (size_t)ni_out * nj_out;
+    const size_t wb = packhip_armn_enc1_work_bytes(ni_out, nj_out, nbits, nfields);
+    if (!wb) return -2;
+    const size_t tok_stride = (n + 1) / 2 + 4;                                  /* words per field */
+    const size_t stride = PACKHIP_STATS_PARTIALS + 3 * (size_t)8192;
+    unsigned *d_stats_all = (unsigned *)ws(3, (4 * stride + sizeof(packhip_cf_params)) * (size_t)nfields + 64);
+    unsigned *d_tok = (unsigned *)ws(1, 4 * tok_stride * (size_t)nfields);
+    char *d_work = (char *)ws(2, wb + 64);
+    int *d_zlng = (int *)ws(0, sizeof(int) * (size_t)nfields + 64);
+    if (!d_stats_all || !d_tok || !d_work || !d_zlng) return -1;
+    packhip_cf_params *d_pp = (packhip_cf_params *)(d_stats_all + stride * (size_t)nfields);
+    int32_t npf = 0;
+    int32_t rc = ezhip_ezsint_batch_minmax_only_dev(d_zin, nfields, d_stats_all + PACKHIP_STATS_PARTIALS, (int64_t)stride, &npf);
+    if (rc < 0) return rc;                                                        /* -2: not on the single-launch path */
+    if (packhip_cf_header_batch(d_pp, (unsigned *)d_records, (size_t)record_stride_words, d_stats_all, stride,
+                                npf, (unsigned)n, nbits, 2, 0, nfields)) return -1;
+    int32_t rc2 = ezhip_ezsint_batch_tokens_dev(d_tok, (int64_t)tok_stride, d_zin, nfields, d_pp, (int64_t)sizeof(packhip_cf_params));
+    if (rc2 < 0) return -1;
+    const size_t z_cap = (size_t)record_stride_words - 4 < n / 2 + 16 ? (size_t)record_stride_words - 4 : n / 2 + 16;
+    if (packhip_armn_encode1((unsigned *)d_records + 4, (size_t)record_stride_words, z_cap, d_tok, tok_stride,
+                             ni_out, nj_out, nbits, nfields, 1, 4, d_work, d_zlng)) return -1;
+    if (packhip_cond_copy((unsigned *)d_records + 4, (size_t)record_stride_words, d_tok, tok_stride, (n + 1) / 2, d_zlng, nfields, 1)) return -1;
+    if (ezhip_d2h(zlng_out, d_zlng, sizeof(int) * (size_t)nfields) || ezhip_sync()) return -1;
+    if (redo_wide_fields((unsigned *)d_records, (size_t)record_stride_words, d_tok, tok_stride, 0, nfields, ni_out, nj_out, nbits, zlng_out)) return -1;
+    return rc;
 }

@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "packhip_shim.h"
 
 #pragma clang fp contract(off)
@@ -849,6 +850,380 @@ extern "C" int packhip_armn_commit(unsigned *d_dst, const unsigned *d_z, void *d
     hipLaunchKernelGGL(k_armn_commit, dim3(2048), dim3(256), 0, STREAM, d_dst, d_z, total, body_bits, (unsigned long long)ni * nj, d_zlng);
     return chk("k_armn_commit");
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* armn_compress COMPRESS, PARALLELOGRAM method, ONE PASS (round 2)                              */
+/* ------------------------------------------------------------------------------------------ */
+/* The multi-kernel encoder above reads the 16-bit tokens three times (tile widths, block sums, emission), writes the
+ * per-tile widths, scans them in two more launches and assembles the stream in a scratch buffer that a last kernel
+ * copies to its place: six dependent launches, ~7.5 x the algorithmic bytes of a cfg5 field.  Here one launch does it:
+ *   - a thread block owns a CHUNK of consecutive tiles of the stream order (a segment of one row of 3 x 3 tiles, or a few
+ *     whole tile rows of a narrow field); chunks are handed out through a ticket counter, so chunk c only ever waits
+ *     for chunks that are already running (no assumption about the dispatch order);
+ *   - the 4 x (3 T + 1) tokens the chunk needs are staged in LDS once (coalesced word loads); a thread computes the nine
+ *     Lorenzo differences of each of its tiles (kept in registers), the tile's width and bit count;
+ *   - block scan -> tile bit offsets inside the chunk and the chunk's bit count, published as the chunk's AGGREGATE;
+ *     the chunk's absolute position comes from a decoupled look-back over the status words of the earlier chunks
+ *     (8-byte {state, value} granules, agent-scope relaxed stores / loads);
+ *   - every thread writes its tiles into the chunk's LDS image of the stream (bit 0 = chunk start; only a tile's first
+ *     and last words are shared with its neighbours: ds_or, the words in between are plain stores) WHILE wave 0's
+ *     look-back result is still on its way; the image is then shifted to its absolute bit position and copied out with
+ *     coalesced stores, straight into the caller's record;
+ *   - the one word two consecutive chunks share is written by the LATER chunk: a chunk publishes the bits of its
+ *     incomplete last word (`tail` granule) and ORs its predecessor's into its own first word;
+ *   - the chunk that finishes last computes zlng (c_zfstlib.c:160-179).  The width of the per-tile width field (4 bits, 5
+ *     when some |difference| > 65535, :701-711) is a whole-field property: the pass assumes 4, raises a flag otherwise,
+ *     and the host re-runs such a field with 5 (zlng = -2 marks it; never seen on smooth fields).
+ * Bit-exact against the restated reference encoder (tests/test_gpu_packers.py, tools/fuzz_armn.py). */
+#define ENC_TPB 256
+#define ENC_TPT 4                       /* tiles per thread: up to 1024 tiles per chunk */
+#define ENC_MAX_PATCH_WORDS 6400        /* LDS words of the token patch / stream image (25 KB: 6 blocks per CU) */
+struct enc1_args {
+    unsigned *z; size_t z_stride, z_cap;                /* stream: per-field stride and capacity, in words */
+    const unsigned *tok; size_t tok_stride;             /* token words (two 16-bit tokens per word) */
+    int ni, nj, nbits, ntx, nty;
+    int nseg, seg_tiles, rows_per_chunk;                /* nseg > 1: chunk = segment of one tile row; else rows_per_chunk tile rows */
+    int nchunks, npre, row_words, container, nfields;
+    unsigned long long *status, *tail;                  /* [nfields][nchunks] look-back / shared-word granules (zeroed) */
+    unsigned *ctl;                                      /* [0] ticket, [1 + 2 f] finished chunks, [2 + 2 f] gt16 flag (zeroed) */
+    unsigned long long *total;                          /* [nfields] stream bits of the tiles (set by the last chunk) */
+    int *zlng;                                          /* [nfields] result: byte count, -1 not compressible, -2 re-run with container 5 */
+};
+#define ST_AGG (1ull << 62)
+#define ST_PFX (2ull << 62)
+#define ST_VAL(x) ((x) & 0x3FFFFFFFFFFFFFFFull)
+__device__ __forceinline__ unsigned long long ld_granule(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_granule(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+/* word w (>= 1) of the stream prefix: 3-bit container, row 1, column 1 (c_zfstlib.c:712-721); bits at or beyond body_start are zero */
+template <bool SWAPPED>
+__device__ __forceinline__ unsigned enc1_prefix_word(const unsigned *tok, int ni, int nj, int nbits, int container, unsigned long long w)
+{
+    const unsigned short *t16 = (const unsigned short *)tok;
+    const long long P0 = (long long)(w - 1) * 32;            /* first prefix bit of the word (prefix bit 0 = stream bit 32) */
+    const long long ntok = (long long)ni + nj - 1;
+    unsigned word = 0;
+    if (P0 < 3) word |= (unsigned)container << 29;            /* only w == 1 */
+    long long q = P0 <= 3 ? 0 : (P0 - 3) / nbits;
+    for (; q < ntok; q++) {
+        const long long tb = 3 + q * nbits;                   /* first bit of token q */
+        if (tb >= P0 + 32) break;
+        const size_t k = q < ni ? (size_t)q : (size_t)ni * (size_t)(q - ni + 1);
+        const unsigned long long v = (unsigned long long)t16[k ^ (SWAPPED ? 1u : 0u)] & ((1ull << nbits) - 1);
+        const long long sh = (P0 + 32) - (tb + nbits);
+        word |= sh >= 0 ? (unsigned)(v << sh) : (unsigned)(v >> (-sh));
+    }
+    return word;
+}
+
+template <bool SWAPPED>
+__global__ __launch_bounds__(ENC_TPB) void k_armn_enc1(enc1_args a)
+{
+    extern __shared__ unsigned lds[];                      /* token patch, then (aliased) the chunk's stream image */
+    __shared__ unsigned s_ticket, s_wsum[ENC_TPT][ENC_TPB / 64], s_gt;
+    __shared__ unsigned long long s_start;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_ticket = atomicAdd(&a.ctl[0], 1u); s_gt = 0; }
+    __syncthreads();
+    const unsigned per_field = (unsigned)(a.npre + a.nchunks);
+    const unsigned f = s_ticket / per_field, r = s_ticket - f * per_field;
+    if ((int)f >= a.nfields) return;
+    unsigned *z = a.z + (size_t)f * a.z_stride;
+    const unsigned *tok = a.tok + (size_t)f * a.tok_stride;
+    const int ni = a.ni, nj = a.nj, nbits = a.nbits, container = a.container;
+    const unsigned long long body_start = 32ull + 3ull + (unsigned long long)(ni + nj - 1) * (unsigned long long)nbits;
+    const unsigned swz = SWAPPED ? 1u : 0u;
+    if ((int)r < a.npre) {
+        /* prefix block: the stream words that lie wholly inside the prefix, one owner thread per word; word 0 = _fstzip header */
+        const unsigned long long wend = body_start >> 5;      /* first word chunk 0 takes part in */
+        for (unsigned long long w = (unsigned long long)r * (ENC_TPB * 4) + tid, k = 0; k < 4; k++, w += ENC_TPB) {
+            if (w == 0) { if (a.z_cap > 0) z[0] = 4u | 1u << 4 | 3u << 7 | ((unsigned)nbits & 31u) << 10 | 1u << 15; }
+            else if (w < wend && w < a.z_cap) z[w] = enc1_prefix_word<SWAPPED>(tok, ni, nj, nbits, container, w);
+        }
+        return;
+    }
+    const int c = (int)r - a.npre;
+    /* ---- chunk geometry ------------------------------------------------------------------------------------- */
+    int ty0, nrow_t, tx0, nt_x;
+    if (a.nseg > 1) { ty0 = c / a.nseg; nrow_t = 1; tx0 = (c - ty0 * a.nseg) * a.seg_tiles; nt_x = min(a.seg_tiles, a.ntx - tx0); }
+    else { ty0 = c * a.rows_per_chunk; nrow_t = min(a.rows_per_chunk, a.nty - ty0); tx0 = 0; nt_x = a.ntx; }
+    const int ntl = nt_x * nrow_t;                          /* tiles of the chunk (<= ENC_TPB * ENC_TPT) */
+    const int col_lo = 3 * tx0, col_hi = min(ni, 3 * (tx0 + nt_x) + 1);
+    const int prow_n = min(nj, 3 * (ty0 + nrow_t) + 1) - 3 * ty0;
+    const int rw = a.row_words;
+    /* ---- stage the tokens: patch row pr = field row 3 ty0 + pr, columns [col_lo, col_hi) ---------------------- */
+    for (int pr = 0; pr < prow_n; pr++) {
+        const unsigned k_lo = (unsigned)(3 * ty0 + pr) * (unsigned)ni + (unsigned)col_lo, k_hi = k_lo + (unsigned)(col_hi - col_lo);
+        const unsigned w_lo = k_lo >> 1, nw = ((k_hi - 1) >> 1) - w_lo + 1;
+        for (unsigned w = tid; w < nw; w += ENC_TPB) lds[pr * rw + w] = tok[w_lo + w];
+    }
+    __syncthreads();
+    /* ---- per tile: differences, width, bit count -------------------------------------------------------------- */
+    const unsigned short *p16 = (const unsigned short *)lds;
+    int dif[ENC_TPT][9];
+    unsigned bits[ENC_TPT], meta[ENC_TPT];                  /* meta: need | tm << 8 | tn << 12 */
+    bool gt = false;
+#pragma unroll
+    for (int q = 0; q < ENC_TPT; q++) {
+        const int tl = tid + ENC_TPB * q;
+        bits[q] = 0; meta[q] = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) dif[q][k] = 0;
+        if (tl < ntl) {
+            int trow = 0, tcx = tl;
+            if (nrow_t > 1) { trow = tl / nt_x; tcx = tl - trow * nt_x; }
+            const int tm = min(3, ni - (1 + 3 * (tx0 + tcx))), tn = min(3, nj - (1 + 3 * (ty0 + trow)));
+            int u[4][4];
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                const int pr = 3 * trow + min(n, tn);
+                const unsigned par = ((unsigned)(3 * ty0 + pr) * (unsigned)ni + (unsigned)col_lo) & 1u;
+                const unsigned short *prow = p16 + (size_t)pr * rw * 2;
+#pragma unroll
+                for (int m = 0; m < 4; m++) u[n][m] = prow[((unsigned)(3 * tcx + min(m, tm)) + par) ^ swz];
+            }
+            int mx = 0;
+#pragma unroll
+            for (int n = 1; n < 4; n++)
+#pragma unroll
+                for (int m = 1; m < 4; m++) {
+                    const int d = u[n][m] - (u[n - 1][m] + u[n][m - 1] - u[n - 1][m - 1]);
+                    dif[q][(n - 1) * 3 + (m - 1)] = d;
+                    if (n <= tn && m <= tm) mx = max(mx, abs(d));
+                }
+            if (mx > 65535) gt = true;
+            unsigned need = (unsigned)bitlen((unsigned)mx);
+            if (need == 16) need = 15;
+            bits[q] = tile_bits(1, need, tm * tn, container, nbits);
+            meta[q] = need | (unsigned)tm << 8 | (unsigned)tn << 12;
+        }
+    }
+    if (gt && nbits >= 15) s_gt = 1;                        /* benign race: every writer stores 1 */
+    /* ---- block scan, layer by layer (layer q = tiles [256 q, 256 q + 255]) ------------------------------------ */
+    unsigned incl[ENC_TPT];
+#pragma unroll
+    for (int q = 0; q < ENC_TPT; q++) {
+        unsigned v = bits[q];
+        for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(v, off, 64); if (lane >= off) v += o; }
+        incl[q] = v;
+        if (lane == 63) s_wsum[q][wave] = v;
+    }
+    __syncthreads();                                        /* also: every thread is done reading the token patch */
+    unsigned excl[ENC_TPT], agg = 0;
+#pragma unroll
+    for (int q = 0; q < ENC_TPT; q++) {
+        unsigned before = agg;
+        for (int w = 0; w < ENC_TPB / 64; w++) { if (w < wave) before += s_wsum[q][w]; agg += s_wsum[q][w]; }
+        excl[q] = before + incl[q] - bits[q];
+    }
+    unsigned long long *status = a.status + (size_t)f * a.nchunks;
+    if (tid == 0) st_granule(&status[c], (c == 0 ? ST_PFX : ST_AGG) | (unsigned long long)agg);      /* chunk 0: its aggregate IS its inclusive prefix */
+    /* ---- stream image of the chunk in LDS (bit 0 = first bit of the chunk) ------------------------------------- */
+    const unsigned img_words = ((agg + 31) >> 5) + 2;
+    for (unsigned w = tid; w < img_words; w += ENC_TPB) lds[w] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < ENC_TPT; q++) {
+        if (tid + ENC_TPB * q >= ntl) continue;
+        const unsigned need = meta[q] & 0xFF; const int tm = (int)(meta[q] >> 8) & 0xF, tn = (int)(meta[q] >> 12) & 0xF;
+        unsigned wi = excl[q] >> 5; int fill = (int)(excl[q] & 31);
+        unsigned long long acc = 0; bool first = true;
+        auto put = [&](unsigned val, int width) {
+            acc |= (unsigned long long)val << (64 - fill - width);
+            fill += width;
+            if (fill >= 32) {
+                const unsigned word = (unsigned)(acc >> 32);
+                if (first) { atomicOr(&lds[wi], word); first = false; } else lds[wi] = word;
+                wi++; acc <<= 32; fill -= 32;
+            }
+        };
+        put(need, container);
+        if (need) {
+            const int width = need == 15 ? 17 : (int)need + 1;
+            const unsigned mask = (1u << width) - 1;
+#pragma unroll
+            for (int n = 0; n < 3; n++)
+#pragma unroll
+                for (int m = 0; m < 3; m++)
+                    if (n < tn && m < tm) put((unsigned)dif[q][n * 3 + m] & mask, width);
+        }
+        if (fill > 0) atomicOr(&lds[wi], (unsigned)(acc >> 32));
+    }
+    /* ---- look-back (wave 0): exclusive prefix of the chunk aggregates ------------------------------------------ */
+    if (wave == 0) {
+        unsigned long long excl_chunks = 0;
+        if (c > 0) {
+            int basei = c - 1;
+            for (;;) {
+                const int idx = basei - lane;
+                unsigned long long st = idx >= 0 ? ld_granule(&status[idx]) : ST_PFX;
+                unsigned long long pm = __ballot((st >> 62) == 2), vm = __ballot((st >> 62) != 0);
+                bool ready;
+                if (pm) { const int firstp = __builtin_ctzll(pm); const unsigned long long needm = firstp == 63 ? ~0ull : ((2ull << firstp) - 1); ready = (vm & needm) == needm; }
+                else ready = vm == ~0ull;
+                if (!ready) { __builtin_amdgcn_s_sleep(8); continue; }
+                const int firstp = pm ? __builtin_ctzll(pm) : 63;
+                unsigned long long v = lane <= firstp ? ST_VAL(st) : 0ull;
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                excl_chunks += v;
+                if (pm) break;
+                basei -= 64;
+            }
+            if (lane == 0) st_granule(&status[c], ST_PFX | (excl_chunks + agg));
+        }
+        if (lane == 0) s_start = body_start + excl_chunks;
+    }
+    __syncthreads();
+    /* ---- copy out: image shifted to its absolute bit position -------------------------------------------------- */
+    const unsigned long long S = s_start;
+    const unsigned sh = (unsigned)(S & 31);
+    const unsigned long long gw0 = S >> 5;
+    const unsigned nwout = (sh + agg + 31) >> 5;             /* stream words the chunk touches */
+    const bool last_chunk = c == a.nchunks - 1;
+    const bool tail_open = ((sh + agg) & 31) != 0 && !last_chunk;      /* the last word is completed by the next chunk */
+    auto outword = [&](unsigned k) -> unsigned {
+        const unsigned lo = lds[k];
+        if (sh == 0) return lo;
+        const unsigned hi = k ? lds[k - 1] : 0u;
+        return (hi << (32 - sh)) | (lo >> sh);
+    };
+    const unsigned nstore = nwout - (tail_open ? 1u : 0u);   /* words [0, nstore) are completed by this chunk (word 0 with the carry) */
+    for (unsigned k = 1 + tid; k < nstore; k += ENC_TPB) if (gw0 + k < a.z_cap) z[gw0 + k] = outword(k);
+    if (tid == 0) {
+        unsigned long long *tail = a.tail + (size_t)f * a.nchunks;
+        auto carry_in = [&]() -> unsigned {
+            if (sh == 0) return 0u;
+            if (c == 0) return enc1_prefix_word<SWAPPED>(tok, ni, nj, nbits, container, gw0);
+            unsigned long long t;
+            while (((t = ld_granule(&tail[c - 1])) >> 62) == 0) __builtin_amdgcn_s_sleep(8);
+            return (unsigned)t;
+        };
+        unsigned v0 = outword(0);
+        if (tail_open && nwout == 1) {                       /* the whole chunk lies inside one word: pass it on with the carry */
+            st_granule(&tail[c], ST_PFX | (unsigned long long)(v0 | carry_in()));
+        } else {
+            if (tail_open) st_granule(&tail[c], ST_PFX | (unsigned long long)outword(nwout - 1));
+            v0 |= carry_in();
+            if (gw0 < a.z_cap) z[gw0] = v0;
+        }
+        if (last_chunk) {                                    /* the word after the last one: the byte zlng points at (undefined in the reference) */
+            if (gw0 + nwout < a.z_cap) z[gw0 + nwout] = 0u;
+            st_granule(&a.total[f], S + agg - 32);           /* stream bits from the start of word 1, terminator excluded */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        unsigned dep = 0;
+        if (s_gt) dep = atomicOr(&a.ctl[2 + 2 * f], 1u) & 0u;            /* returned: ordered before the count below */
+        const unsigned done = atomicAdd(&a.ctl[1 + 2 * f], 1u + dep);
+        if (done == (unsigned)a.nchunks - 1) {               /* every chunk of the field is through: zlng (c_zfstlib.c:160-179) */
+            const unsigned long long bits_total = ld_granule(&a.total[f]);
+            const unsigned gtf = __hip_atomic_load(&a.ctl[2 + 2 * f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long zl = 1 + 4 * (1 + (long long)((bits_total + 31) / 32));
+            const long long lng_origin = 1 + 2 * (long long)ni * nj;
+            a.zlng[f] = (gtf && container == 4) ? -2 : (zl >= lng_origin ? -1 : (int)zl);
+        }
+    }
+}
+
+/* geometry of the one-pass encoder for a field shape; returns 0 when the shape is outside its limits (-> multi-kernel path) */
+static int enc1_geometry(enc1_args *a, int ni, int nj, int nbits)
+{
+    if (ni < 16 || nj < 16 || nbits <= 4 || nbits > 16) return 0;
+    if ((long long)ni * nj >= (1ll << 31)) return 0;
+    a->ni = ni; a->nj = nj; a->nbits = nbits;
+    a->ntx = (ni - 1 + 2) / 3; a->nty = (nj - 1 + 2) / 3;
+    const int maxt = ENC_TPB * ENC_TPT;
+    if (a->ntx > maxt) {
+        a->nseg = (a->ntx + maxt - 1) / maxt; a->seg_tiles = (a->ntx + a->nseg - 1) / a->nseg; a->rows_per_chunk = 1;
+        a->nchunks = a->nseg * a->nty;
+        a->row_words = (3 * a->seg_tiles + 1 + 2) / 2 + 1;
+    } else {
+        a->nseg = 1; a->seg_tiles = a->ntx;
+        a->row_words = (ni + 2) / 2 + 1;
+        int R = maxt / a->ntx;
+        const int rmax = (ENC_MAX_PATCH_WORDS / a->row_words - 1) / 3;
+        if (R > rmax) R = rmax;
+        if (R < 1) return 0;
+        a->rows_per_chunk = R;
+        a->nchunks = (a->nty + R - 1) / R;
+    }
+    const unsigned long long body_start = 32ull + 3ull + (unsigned long long)(ni + nj - 1) * (unsigned long long)nbits;
+    a->npre = (int)(((body_start >> 5) + ENC_TPB * 4 - 1) / (ENC_TPB * 4));
+    if (a->npre < 1) a->npre = 1;
+    return 1;
+}
+static size_t enc1_lds_bytes(const enc1_args *a)
+{
+    const size_t prow = (size_t)(a->nseg > 1 ? 4 : 3 * a->rows_per_chunk + 1);
+    size_t patch = prow * (size_t)a->row_words;
+    /* image: tiles x (5 + 9 x 18) bits worst case */
+    size_t tiles = (size_t)(a->nseg > 1 ? a->seg_tiles : a->ntx * a->rows_per_chunk);
+    size_t img = (tiles * 167 + 31) / 32 + 4;
+    return 4 * (patch > img ? patch : img);
+}
+/* control / granule storage of one launch over nfields fields (device scratch, zeroed by the launcher) */
+extern "C" size_t packhip_armn_enc1_work_bytes(int ni, int nj, int nbits, int nfields)
+{
+    enc1_args a;
+    if (!enc1_geometry(&a, ni, nj, nbits)) return 0;
+    return 16 * (size_t)a.nchunks * nfields + 8 * (size_t)nfields + 4 * (1 + 2 * (size_t)nfields) + 4 * (size_t)nfields + 64;
+}
+/* One-pass PARALLELOGRAM encode of nfields token fields (asynchronous).  d_zlng[f] receives the byte count, -1 (not
+ * compressible: the stream may be truncated at z_cap words) or -2 (re-run the field with container = 5).
+ * Returns 1 when the shape is outside the one-pass limits (nothing launched), -1 on error. */
+extern "C" int packhip_armn_encode1(unsigned *d_z, size_t z_stride_words, size_t z_cap_words, const unsigned *d_tok, size_t tok_stride_words,
+                                    int ni, int nj, int nbits, int nfields, int swapped, int container, void *d_work, int *d_zlng)
+{
+    enc1_args a;
+    memset(&a, 0, sizeof(a));
+    if (!enc1_geometry(&a, ni, nj, nbits)) return 1;
+    const size_t lds = enc1_lds_bytes(&a);
+    if (lds > 64 * 1024) return 1;
+    a.z = d_z; a.z_stride = z_stride_words; a.z_cap = z_cap_words; a.tok = d_tok; a.tok_stride = tok_stride_words;
+    a.container = container; a.nfields = nfields; a.zlng = d_zlng;
+    char *w = (char *)d_work;
+    a.status = (unsigned long long *)w; w += 8 * (size_t)a.nchunks * nfields;
+    a.tail = (unsigned long long *)w; w += 8 * (size_t)a.nchunks * nfields;
+    a.total = (unsigned long long *)w; w += 8 * (size_t)nfields;
+    a.ctl = (unsigned *)w; w += 4 * (1 + 2 * (size_t)nfields);
+    hipStream_t st = STREAM;
+    if (hipMemsetAsync(d_work, 0, (size_t)(w - (char *)d_work), st) != hipSuccess) return -1;
+    const size_t nblocks = (size_t)(a.npre + a.nchunks) * (size_t)nfields;
+    if (nblocks >= (1ull << 31)) return 1;
+    if (swapped) hipLaunchKernelGGL(k_armn_enc1<true>, dim3((unsigned)nblocks), dim3(ENC_TPB), lds, st, a);
+    else hipLaunchKernelGGL(k_armn_enc1<false>, dim3((unsigned)nblocks), dim3(ENC_TPB), lds, st, a);
+    return chk("k_armn_enc1") ? -1 : 0;
+}
+
+/* conditional copies behind an asynchronous encode, all fields in one launch (blockIdx.y = field):
+ * mode 0: zlng[f] > 0  -> the stream's ceil(zlng / 4) words (commit of a stream assembled in scratch);
+ * mode 1: zlng[f] == -1 -> nwords token words (a field that is not compressible keeps the plain 16-bit pack) */
+__global__ __launch_bounds__(256) void k_cond_copy(unsigned *dst, size_t dst_stride, const unsigned *src, size_t src_stride, size_t nwords, const int *zlng, int mode)
+{
+    const int f = blockIdx.y, zl = zlng[f];
+    size_t n;
+    if (mode == 0) { if (zl <= 0) return; n = (size_t)(zl + 3) / 4; } else { if (zl != -1) return; n = nwords; }
+    dst += (size_t)f * dst_stride; src += (size_t)f * src_stride;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) dst[k] = src[k];
+}
+extern "C" int packhip_cond_copy(unsigned *d_dst, size_t dst_stride, const unsigned *d_src, size_t src_stride, size_t nwords, const int *d_zlng, int nfields, int mode)
+{
+    hipLaunchKernelGGL(k_cond_copy, dim3(1024, nfields), dim3(256), 0, STREAM, d_dst, dst_stride, d_src, src_stride, nwords, d_zlng, mode);
+    return chk("k_cond_copy");
+}
+/* exchange the 16-bit halves of every word (c_armn_compress_setswap(0) on the multi-kernel path) */
+__global__ __launch_bounds__(256) void k_swap_halves(unsigned *dst, const unsigned *src, size_t n)
+{
+    size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) { unsigned v = src[k]; dst[k] = v << 16 | v >> 16; }
+}
+extern "C" int packhip_swap_halves(unsigned *d_dst, const unsigned *d_src, size_t nwords)
+{
+    if (!nwords) return 0;
+    hipLaunchKernelGGL(k_swap_halves, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, STREAM, d_dst, d_src, nwords);
+    return chk("k_swap_halves");
+}
+
 extern "C" size_t packhip_armn_work_bytes(int ni, int nj)
 {
     long long ntiles = ((long long)(ni + 2) / 3 + 1) * ((long long)(nj + 2) / 3 + 1);

@@ -37,6 +37,14 @@ int packhip_armn_encode(unsigned *d_z, size_t z_words, const unsigned *d_words, 
 size_t packhip_armn_work_bytes(int ni, int nj);
 /* after packhip_armn_encode(..., h_bits = NULL): zlng on the device, stream committed to d_dst when compressible */
 int packhip_armn_commit(unsigned *d_dst, const unsigned *d_z, void *d_work, int ni, int nj, int nbits, int minimum_method, int *d_zlng);
+/* one-pass PARALLELOGRAM encoder (k_armn_enc1): scratch bytes for nfields fields (0: shape outside its limits) */
+size_t packhip_armn_enc1_work_bytes(int ni, int nj, int nbits, int nfields);
+/* asynchronous; d_zlng[f] = byte count, -1 (not compressible) or -2 (re-run that field with container 5).  Returns 0, 1 when the
+ * shape is outside the one-pass limits (nothing launched: use packhip_armn_encode), -1 on error */
+int packhip_armn_encode1(unsigned *d_z, size_t z_stride_words, size_t z_cap_words, const unsigned *d_tok, size_t tok_stride_words,
+                         int ni, int nj, int nbits, int nfields, int swapped, int container, void *d_work, int *d_zlng);
+int packhip_cond_copy(unsigned *d_dst, size_t dst_stride, const unsigned *d_src, size_t src_stride, size_t nwords, const int *d_zlng, int nfields, int mode);
+int packhip_swap_halves(unsigned *d_dst, const unsigned *d_src, size_t nwords);
 /* armn_compress UNCOMPRESS (unpack_kernels.hip): nfields streams of z_words capacity each -> (1 + ni*nj/2) token words each */
 size_t packhip_armn_dec_work_bytes(int ni, int nj, size_t z_words);
 int packhip_armn_decode(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,

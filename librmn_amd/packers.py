@@ -155,3 +155,13 @@ def pack16_compress_batch_dev(d_records, record_stride_words, d_fields, field_st
     rc = _lib().ezhip_pack16_compress_batch_dev(_dptr(d_records), record_stride_words, _dptr(d_fields) if d_fields is not None else None,
                                                 field_stride, nfields, ni, nj, nbits, prepacked, zl.ctypes.data)
     return rc, zl
+
+
+def ezsint_pack16_compress_batch_dev(d_records, record_stride_words, d_zin, nfields, ni_out, nj_out, nbits):
+    """the fused cfg5 pipeline (interpolation twice: min/max only, then tokens; one-pass armn encoder writing in place);
+    returns (rc, zlng[nfields])"""
+    L = _lib()
+    L.ezhip_ezsint_pack16_compress_batch_dev.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    zl = np.zeros(nfields, np.int32)
+    rc = L.ezhip_ezsint_pack16_compress_batch_dev(_dptr(d_records), record_stride_words, _dptr(d_zin), nfields, ni_out, nj_out, nbits, zl.ctypes.data)
+    return rc, zl

@@ -300,3 +300,138 @@ def test_armn_uncompress_batch_and_full_size_record():
         assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), f
         rng = float(d_f[f].max() - d_f[f].min())                     # tokens truncate to 2^ceil(log2(range)) / 65536
         assert float((out - d_f[f]).abs().max()) <= 2.0 ** np.ceil(np.log2(rng)) / 65536 * 1.01
+
+
+# ---------------------------------------------------------------------------------------------
+# round 2: one-pass encoder (k_armn_enc1), fused cfg5 pipeline, capacity bound, swap state
+# ---------------------------------------------------------------------------------------------
+ENC1_SHAPES = [(16, 16), (17, 16), (18, 33), (100, 31), (31, 100), (3073, 19), (3075, 22), (3100, 16), (6200, 20), (9300, 17), (2048, 64), (257, 513)]
+
+
+@pytest.mark.parametrize("ni,nj", ENC1_SHAPES)
+@pytest.mark.parametrize("kind", ["smooth", "noisy", "bigdiff"])
+@pytest.mark.parametrize("nbits", [16, 15, 9, 5])
+def test_armn_one_pass_encoder_chunk_geometries(ni, nj, kind, nbits):
+    """shapes that exercise every chunk geometry of k_armn_enc1: several tile rows per chunk (narrow fields), exactly one,
+    two / three / four segments per tile row, clipped last tiles in both directions, chunks shorter than one stream word;
+    'bigdiff' at 15-16 bits takes the 5-bit container re-run (c_zfstlib.c:701-711).  Bit-exact against the oracle encoder."""
+    tok = pc.token_field(ni, nj, nbits, kind, seed=ni + 7 * nj)
+    words = pc.tokens_to_words(tok)
+    n = ni * nj
+    d_w = torch.from_numpy(words.view(np.int32)).cuda()
+    cap = n // 2 + 16
+    guard = 64
+    d_z = torch.full((cap + guard,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    zg = pk.armn_compress_dev(d_z, d_w, ni, nj, nbits)
+    torch.cuda.synchronize()
+    z = np.zeros(n + 64, np.uint32)
+    zw = top.O().orc_armn_encode(z.ctypes.data, tok.ctypes.data, ni, nj, nbits)
+    if zw >= 1 + 2 * n:
+        zw = -1
+    assert zg == zw, (zg, zw)
+    got = d_z.cpu().numpy().view(np.uint32)
+    assert np.all(got[cap:] == 0x5A5A5A5A)                          # no store beyond the documented capacity, compressible or not
+    if zw > 0:
+        nfull = (zw - 1) // 4
+        assert np.array_equal(got[:nfull], z[:nfull]), np.nonzero(got[:nfull] != z[:nfull])[0][:5]
+
+
+def test_armn_compress_swap_state_zero():
+    """c_armn_compress_setswap(0) (fstd98.c:1209-1211): COMPRESS then reads the 16-bit halves in memory order
+    (c_zfstlib.c:119-126 skipped); compress -> uncompress under the same state is the identity on the words"""
+    ni, nj, nbits = 301, 200, 16
+    tok = pc.token_field(ni, nj, nbits, "smooth", seed=5)
+    words = pc.tokens_to_words(tok)
+    raw = words.view(np.uint16)[:ni * nj].copy()                    # what the reference's ushort pointer sees without the swap
+    z = np.zeros(ni * nj + 64, np.uint32)
+    zw = top.O().orc_armn_encode(z.ctypes.data, raw.ctypes.data, ni, nj, nbits)
+    buf = np.zeros(1 + ni * nj // 2 + 2, np.uint32); buf[:words.size] = words
+    pk.armn_setswap(0)
+    try:
+        zg = pk.armn_compress(buf, ni, nj, nbits)
+        assert zg == zw and zw > 0
+        assert np.array_equal(buf[:(zw - 1) // 4], z[:(zw - 1) // 4])
+        assert pk.armn_uncompress(buf, ni, nj, nbits) == ni * nj * 2
+        assert np.array_equal(buf[:words.size], words)
+        pk.armn_setlevel(0)                                          # MINIMUM method (multi-kernel path) under the same state
+        try:
+            buf2 = np.zeros(1 + ni * nj // 2 + 2, np.uint32); buf2[:words.size] = words
+            z2 = pk.armn_compress(buf2, ni, nj, nbits)
+            assert z2 > 0 and pk.armn_uncompress(buf2, ni, nj, nbits) == ni * nj * 2
+            assert np.array_equal(buf2[:words.size], words)
+        finally:
+            pk.armn_setlevel(1)
+    finally:
+        pk.armn_setswap(1)
+
+
+@pytest.mark.parametrize("degree", ["cubic", "linear", "nearest"])
+@pytest.mark.parametrize("F", [1, 2, 5])
+def test_fused_cfg5_pipeline_equals_unfused(degree, F):
+    """ezhip_ezsint_pack16_compress_batch_dev (interpolation twice -- min/max only, then straight to 16-bit tokens --, one-pass
+    encoder writing in place) leaves the records and byte counts of the unfused chain c_ezsint_batch_dev -> compact_float ->
+    armn_compress, bit for bit; one source field is pure noise (its interpolation is barely / not compressible)"""
+    from librmn_amd import ezscint as ez
+    import ezcases as ec
+    ni, nj, no, mo, nbits = 360, 181, 520, 261, 16
+    gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(no, mo, "L", 69, 69, 0, 0)
+    assert ez.ezdefset(gdout, gdin) == 1
+    assert ez.ezsetopt("interp_degree", degree) == 0 and ez.ezsetopt("polar_correction", "yes") == 0
+    ez.use_stream(torch.cuda.current_stream().cuda_stream)
+    srcs = [ec.synth_field(ni, nj, seed=190 + f) for f in range(F)]
+    if F > 1:
+        srcs[1] = (ec.hash_uniform(5, ni * nj) * np.float32(1000.0)).astype(np.float32)
+    d_in = torch.stack([torch.from_numpy(a) for a in srcs]).cuda().contiguous()
+    n = no * mo
+    rs = 4 + n // 2 + 16
+    rec_a = torch.full((F, rs), 0x11111111, dtype=torch.int32, device="cuda"); rec_b = torch.zeros_like(rec_a)
+    rc, zl_a = pk.ezsint_pack16_compress_batch_dev(rec_a, rs, d_in, F, no, mo, nbits)
+    assert rc == 0, rc
+    out = torch.empty((F, n), dtype=torch.float32, device="cuda")
+    assert pk.ezsint_pack16_batch_dev(rec_b, rs, out, d_in, F, n, nbits) == 0
+    rc, zl_b = pk.pack16_compress_batch_dev(rec_b, rs, None, 0, F, no, mo, nbits, prepacked=1)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert list(zl_a) == list(zl_b), (list(zl_a), list(zl_b))
+    a = rec_a.cpu().numpy().view(np.uint8).reshape(F, -1); b = rec_b.cpu().numpy().view(np.uint8).reshape(F, -1)
+    for f in range(F):
+        m = 16 + (int(zl_a[f]) - 1 if zl_a[f] > 0 else 2 * n)
+        assert np.array_equal(a[f, :m], b[f, :m]), (f, int(zl_a[f]), np.nonzero(a[f, :m] != b[f, :m])[0][:5])
+    # and against the CPU oracle chain on the GPU-interpolated field 0
+    z = out[0].cpu().numpy()
+    want = top.pack_float(z, nbits + 64 * 16)
+    zw = top.O().orc_armn_compress(want[4:].ctypes.data, no, mo, 1, nbits, 1)
+    assert zw == zl_a[0]
+    if zw > 0:
+        got = rec_a[0].cpu().numpy().view(np.uint32)
+        assert np.array_equal(got[:4 + (zw - 1) // 4], want[:4 + (zw - 1) // 4])
+    assert ez.ezsetopt("interp_degree", "cubic") == 0
+
+
+def test_fused_cfg5_pipeline_full_size():
+    """the fused pipeline on full-size cfg5 fields (G 4400x2200 -> L 7200x3601 bicubic, 16 bits): records and byte counts equal
+    the single-field chain (c_ezsint_dev -> ezhip_pack16_compress_dev), which test_cfg5_pipeline_full_size_device_resident
+    pins against the oracle"""
+    from librmn_amd import ezscint as ez
+    import ezcases as ec
+    ni, nj, no, mo = 4400, 2200, 7200, 3601
+    gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(no, mo, "L", 5, 5, 0, 0)
+    assert ez.ezdefset(gdout, gdin) == 1
+    ez.ezsetopt("interp_degree", "cubic"); ez.ezsetopt("polar_correction", "yes")
+    ez.use_stream(torch.cuda.current_stream().cuda_stream)
+    F = 3
+    d_in = torch.stack([torch.from_numpy(ec.synth_field(ni, nj, seed=2 + 11 * f)) for f in range(F)]).cuda().contiguous()
+    n = no * mo
+    rs = 4 + n // 2 + 16
+    rec = torch.zeros((F, rs), dtype=torch.int32, device="cuda")
+    rc, zl = pk.ezsint_pack16_compress_batch_dev(rec, rs, d_in, F, no, mo, 16)
+    assert rc == 0 and all(z > 0 for z in zl), (rc, list(zl))
+    z = torch.empty(n, dtype=torch.float32, device="cuda")
+    one = torch.zeros(4 + n // 2 + 64, dtype=torch.int32, device="cuda")
+    for f in (0, F - 1):
+        assert ez.ezsint_dev(z, d_in[f]) == 0
+        zs = pk.pack16_compress_dev(one, z, no, mo, 16)
+        torch.cuda.synchronize()
+        assert zs == zl[f], (f, zs, int(zl[f]))
+        m = 4 + (zs - 1) // 4
+        assert torch.equal(one[:m], rec[f][:m]), f
