@@ -359,15 +359,19 @@ static int armn_encode1_sync(unsigned *d_z, size_t z_cap_words, const unsigned *
     int *d_zl = (int *)(d_work + ((wb + 15) & ~(size_t)15));
     int zl = -1;
     for (int container = 4; container <= 5; container++) {
+        if (ezhip_memset(d_zl, 0xFD, sizeof(int))) return -1;          /* "unfinished": the kernel's bounded waits gave up (see k_armn_enc1) */
         int rc = packhip_armn_encode1(d_z, 0, z_cap_words, d_words, 0, ni, nj, nbits, 1, g_swap == 1, container, d_work, d_zl);
         if (rc == 1) return -3;
         if (rc || ezhip_d2h(&zl, d_zl, sizeof(int)) || ezhip_sync()) return -1;
         if (zl != -2) break;
     }
+    if (zl < -2) { fprintf(stderr, "<armn_compress> one-pass encoder gave up waiting on the launch order; using the multi-kernel encoder\n"); return -3; }
     return zl;
 }
 
-int armn_compress_dev(void *d_z, const void *d_words, int ni, int nj, int nbits)
+static int armn_compress_dev_ex(void *d_z, const void *d_words, int ni, int nj, int nbits, int allow_onepass);
+int armn_compress_dev(void *d_z, const void *d_words, int ni, int nj, int nbits) { return armn_compress_dev_ex(d_z, d_words, ni, nj, nbits, 1); }
+static int armn_compress_dev_ex(void *d_z, const void *d_words, int ni, int nj, int nbits, int allow_onepass)
 {
     if (need_device("armn_compress")) return -1;
     if (nbits > 16 || ni == 1 || nj == 1) { fprintf(stderr, "<armn_compress> Cannot compress if nbits>16 or ni=1 or nj=1. Returning original field\n"); return -1; }
@@ -377,7 +381,7 @@ int armn_compress_dev(void *d_z, const void *d_words, int ni, int nj, int nbits)
     /* the raw stream can exceed the source size for incompressible fields: the caller's buffer holds n/2 + 16 words; the
      * one-pass encoder drops every store at or beyond that capacity (the byte count then says "not compressible") */
     size_t z_words = n / 2 + 16;
-    if (!minimum) {
+    if (!minimum && allow_onepass) {
         int zl = armn_encode1_sync((unsigned *)d_z, z_words, (const unsigned *)d_words, ni, nj, nbits);
         if (zl != -3) return zl < 0 ? -1 : zl;
     }
@@ -546,18 +550,19 @@ int32_t ezhip_ezsint_pack16_batch_dev(void *d_records, int64_t record_stride_wor
  * synchronisation at the end (ezhip_pack16_compress_dev returns zlng per call: one sync per field, ~25 % of its time).
  * prepacked != 0: the records already hold the 16-bit-slot pack (ezhip_ezsint_pack16_batch_dev).  zlng_out[f] = byte
  * count of record f's compressed stream, or -1 (not compressible: the record keeps the plain pack). */
-/* fields whose one-pass encode asked for the 5-bit container (zlng -2): re-run them one by one, synchronously */
+/* fields whose one-pass encode asked for the 5-bit container (zlng -2) or did not finish (< -2): re-run them one by one, synchronously */
 static int redo_wide_fields(unsigned *d_records, size_t record_stride_words, const unsigned *d_tok, size_t tok_stride_words, int in_place,
                             int32_t nfields, int ni, int nj, int nbits, int32_t *zlng_out)
 {
     const size_t n = (size_t)ni * nj;
     for (int f = 0; f < nfields; f++) {
-        if (zlng_out[f] != -2) continue;
+        if (zlng_out[f] >= -1) continue;                              /* -2: 5-bit container needed; < -2: the one-pass launch gave up */
+        const int onepass = zlng_out[f] == -2;
         unsigned *rec = d_records + (size_t)f * record_stride_words;
         const unsigned *tok = in_place ? rec + 4 : d_tok + (size_t)f * tok_stride_words;
         unsigned *d_z = (unsigned *)ws(4, 4 * (n / 2 + 32));          /* its own slot: slot 1 may hold the batch's tokens */
         if (!d_z) return -1;
-        int zl = armn_compress_dev(d_z, tok, ni, nj, nbits);
+        int zl = armn_compress_dev_ex(d_z, tok, ni, nj, nbits, onepass);
         if (zl > 0) { if (ezhip_d2d(rec + 4, d_z, (size_t)zl) || ezhip_sync()) return -1; }
         else if (!in_place && (ezhip_d2d(rec + 4, tok, 4 * ((n + 1) / 2)) || ezhip_sync())) return -1;
         zlng_out[f] = zl;
@@ -579,6 +584,7 @@ int32_t ezhip_pack16_compress_batch_dev(void *d_records, int64_t record_stride_w
     int *d_zlng = (int *)ws(0, sizeof(int) * (size_t)nfields + 64);
     if (!d_z || !d_work || !d_zlng) return -1;
     float tag = 0.f;
+    if (ezhip_memset(d_zlng, 0xFD, sizeof(int) * (size_t)nfields)) return -1;       /* "unfinished" until a kernel says otherwise */
     for (int f = 0; f < nfields; f++) {
         unsigned *rec = (unsigned *)d_records + (size_t)f * (size_t)record_stride_words;
         if (!prepacked && !compact_float_dev((void *)(d_fields + (size_t)f * (size_t)field_stride), rec, rec + 4, (int)n,
@@ -639,6 +645,7 @@ int32_t ezhip_ezsint_pack16_compress_batch_dev(void *d_records, int64_t record_s
     int32_t rc2 = ezhip_ezsint_batch_tokens_dev(d_tok, (int64_t)tok_stride, d_zin, nfields, d_pp, (int64_t)sizeof(packhip_cf_params));
     if (rc2 < 0) return -1;
     const size_t z_cap = (size_t)record_stride_words - 4 < n / 2 + 16 ? (size_t)record_stride_words - 4 : n / 2 + 16;
+    if (ezhip_memset(d_zlng, 0xFD, sizeof(int) * (size_t)nfields)) return -1;       /* "unfinished" until the encoder says otherwise */
     if (packhip_armn_encode1((unsigned *)d_records + 4, (size_t)record_stride_words, z_cap, d_tok, tok_stride,
                              ni_out, nj_out, nbits, nfields, 1, 4, d_work, d_zlng)) return -1;
     if (packhip_cond_copy((unsigned *)d_records + 4, (size_t)record_stride_words, d_tok, tok_stride, (n + 1) / 2, d_zlng, nfields, 1)) return -1;

@@ -885,13 +885,17 @@ struct enc1_args {
     int nseg, seg_tiles, rows_per_chunk;                /* nseg > 1: chunk = segment of one tile row; else rows_per_chunk tile rows */
     int nchunks, npre, row_words, container, nfields;
     unsigned long long *status, *tail;                  /* [nfields][nchunks] look-back / shared-word granules (zeroed) */
-    unsigned *ctl;                                      /* [0] ticket, [1 + 2 f] finished chunks, [2 + 2 f] gt16 flag (zeroed) */
-    unsigned long long *total;                          /* [nfields] stream bits of the tiles (set by the last chunk) */
+    unsigned *ctl;                                      /* [0] abort flag (zeroed) */
+    size_t tok_words;                                   /* words of one field's token array ((ni nj + 1) / 2): bound of the 16-byte staging loads */
+    int vec;                                            /* 1: token arrays are 16-byte aligned (base and stride): stage with 16-byte loads */
+    unsigned long long *prof;                           /* development (EZHIP_ENC_DEBUG & 16): per-phase clock sums of thread 0 of every chunk block */
+    int debug;                                          /* development knock-outs (EZHIP_ENC_DEBUG): 1 no emission, 2 no copy-out, 4 no staging, 8 no look-back wait */
     int *zlng;                                          /* [nfields] result: byte count, -1 not compressible, -2 re-run with container 5 */
 };
 #define ST_AGG (1ull << 62)
 #define ST_PFX (2ull << 62)
-#define ST_VAL(x) ((x) & 0x3FFFFFFFFFFFFFFFull)
+#define ST_GT  (1ull << 61)          /* a |difference| > 65535 in this chunk (AGG) / in this or an earlier chunk (PFX) */
+#define ST_VAL(x) ((x) & 0x1FFFFFFFFFFFFFFFull)
 __device__ __forceinline__ unsigned long long ld_granule(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_granule(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -916,81 +920,151 @@ __device__ __forceinline__ unsigned enc1_prefix_word(const unsigned *tok, int ni
     return word;
 }
 
+struct EncChunk { int f, c, ty0, nrow_t, tx0, nt_x, ntl, col_lo, prow_n; };
+__device__ __forceinline__ EncChunk enc1_chunk(const enc1_args &a, unsigned g)
+{
+    EncChunk k;
+    const unsigned cc_ = g / (unsigned)a.nfields;              /* chunks INTERLEAVED over the fields: the blocks in flight cover few chunks of each chain */
+    k.f = (int)(g - cc_ * (unsigned)a.nfields); k.c = (int)cc_;
+    if (a.nseg > 1) { k.ty0 = k.c / a.nseg; k.nrow_t = 1; k.tx0 = (k.c - k.ty0 * a.nseg) * a.seg_tiles; k.nt_x = min(a.seg_tiles, a.ntx - k.tx0); }
+    else { k.ty0 = k.c * a.rows_per_chunk; k.nrow_t = min(a.rows_per_chunk, a.nty - k.ty0); k.tx0 = 0; k.nt_x = a.ntx; }
+    k.ntl = k.nt_x * k.nrow_t;
+    k.col_lo = 3 * k.tx0;
+    k.prow_n = min(a.nj, 3 * (k.ty0 + k.nrow_t) + 1) - 3 * k.ty0;
+    return k;
+}
+
+#define ENC_WK 1                        /* look-back: granules per lane and window */
+#define ENC_NLD 7                       /* 16-byte pieces a lane stages up front: rows of up to 448 pieces (chunks of up to 1024 tiles) */
 template <bool SWAPPED>
-__global__ __launch_bounds__(ENC_TPB) void k_armn_enc1(enc1_args a)
+__global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_armn_enc1(enc1_args a)
 {
     extern __shared__ unsigned lds[];                      /* token patch, then (aliased) the chunk's stream image */
-    __shared__ unsigned s_ticket, s_wsum[ENC_TPT][ENC_TPB / 64], s_gt;
+    __shared__ unsigned s_wsum[ENC_TPT][ENC_TPB / 64], s_gt, s_abort, s_gt_all;
     __shared__ unsigned long long s_start;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { s_ticket = atomicAdd(&a.ctl[0], 1u); s_gt = 0; }
-    __syncthreads();
-    const unsigned per_field = (unsigned)(a.npre + a.nchunks);
-    const unsigned f = s_ticket / per_field, r = s_ticket - f * per_field;
-    if ((int)f >= a.nfields) return;
-    unsigned *z = a.z + (size_t)f * a.z_stride;
-    const unsigned *tok = a.tok + (size_t)f * a.tok_stride;
-    const int ni = a.ni, nj = a.nj, nbits = a.nbits, container = a.container;
+    const int ni = a.ni, nj = a.nj, nbits = a.nbits, container = a.container, rw = a.row_words;
     const unsigned long long body_start = 32ull + 3ull + (unsigned long long)(ni + nj - 1) * (unsigned long long)nbits;
-    const unsigned swz = SWAPPED ? 1u : 0u;
-    if ((int)r < a.npre) {
-        /* prefix block: the stream words that lie wholly inside the prefix, one owner thread per word; word 0 = _fstzip header */
+    /* The chain order is the LAUNCH order of the thread blocks: block npre_all + g works on chunk g of the field-interleaved
+     * chunk order and waits only for chunks of lower g.  What was measured instead (32 full-size cfg5 fields, 115 200 chunks):
+     *   - a ticket counter (order = arrival order, independent of the dispatch order): one returning atomic per block on ONE
+     *     word saturates at ~88 per us (MI355X_MICROARCH.md, `dequeue`): 2.16 ms;
+     *   - persistent blocks with static ownership (block b takes chunks b, b + G, ...), tokens of the next chunk prefetched:
+     *     the resident blocks march in lock-step generations, each as slow as its slowest member: 2.6 ms;
+     *   - persistent blocks pulling from 64 work queues: the queues drift apart and chunks wait for predecessors that
+     *     nobody has started: 2.75 ms;
+     *   - this form: 1.3 ms.  Thread blocks are dispatched in index order on every XCD, so the lowest unfinished chunk is always
+     *     resident or next in line.  Should that ever not hold, every wait below is BOUNDED: a block that gives up raises the
+     *     abort flag, all others leave, and the host falls back to the multi-kernel encoder. */
+    const unsigned npre_all = (unsigned)a.npre * (unsigned)a.nfields;
+    if (blockIdx.x < npre_all) {
+        /* prefix block: the stream words that lie wholly inside the prefix (c_zfstlib.c:712-721), one owner thread per word; word 0 = _fstzip header */
+        const unsigned fz = blockIdx.x / (unsigned)a.npre, r = blockIdx.x - fz * (unsigned)a.npre;
+        unsigned *zf = a.z + (size_t)fz * a.z_stride;
         const unsigned long long wend = body_start >> 5;      /* first word chunk 0 takes part in */
         for (unsigned long long w = (unsigned long long)r * (ENC_TPB * 4) + tid, k = 0; k < 4; k++, w += ENC_TPB) {
-            if (w == 0) { if (a.z_cap > 0) z[0] = 4u | 1u << 4 | 3u << 7 | ((unsigned)nbits & 31u) << 10 | 1u << 15; }
-            else if (w < wend && w < a.z_cap) z[w] = enc1_prefix_word<SWAPPED>(tok, ni, nj, nbits, container, w);
+            if (w == 0) { if (a.z_cap > 0) zf[0] = 4u | 1u << 4 | 3u << 7 | ((unsigned)nbits & 31u) << 10 | 1u << 15; }
+            else if (w < wend && w < a.z_cap) zf[w] = enc1_prefix_word<SWAPPED>(a.tok + (size_t)fz * a.tok_stride, ni, nj, nbits, container, w);
         }
         return;
     }
-    const int c = (int)r - a.npre;
-    /* ---- chunk geometry ------------------------------------------------------------------------------------- */
-    int ty0, nrow_t, tx0, nt_x;
-    if (a.nseg > 1) { ty0 = c / a.nseg; nrow_t = 1; tx0 = (c - ty0 * a.nseg) * a.seg_tiles; nt_x = min(a.seg_tiles, a.ntx - tx0); }
-    else { ty0 = c * a.rows_per_chunk; nrow_t = min(a.rows_per_chunk, a.nty - ty0); tx0 = 0; nt_x = a.ntx; }
-    const int ntl = nt_x * nrow_t;                          /* tiles of the chunk (<= ENC_TPB * ENC_TPT) */
-    const int col_lo = 3 * tx0, col_hi = min(ni, 3 * (tx0 + nt_x) + 1);
-    const int prow_n = min(nj, 3 * (ty0 + nrow_t) + 1) - 3 * ty0;
-    const int rw = a.row_words;
-    /* ---- stage the tokens: patch row pr = field row 3 ty0 + pr, columns [col_lo, col_hi) ---------------------- */
-    for (int pr = 0; pr < prow_n; pr++) {
-        const unsigned k_lo = (unsigned)(3 * ty0 + pr) * (unsigned)ni + (unsigned)col_lo, k_hi = k_lo + (unsigned)(col_hi - col_lo);
-        const unsigned w_lo = k_lo >> 1, nw = ((k_hi - 1) >> 1) - w_lo + 1;
-        for (unsigned w = tid; w < nw; w += ENC_TPB) lds[pr * rw + w] = tok[w_lo + w];
+    const EncChunk ck = enc1_chunk(a, blockIdx.x - npre_all);
+    const int f = ck.f, c = ck.c, ty0 = ck.ty0, nrow_t = ck.nrow_t, tx0 = ck.tx0, nt_x = ck.nt_x, ntl = ck.ntl, col_lo = ck.col_lo;
+    unsigned *z = a.z + (size_t)f * a.z_stride;
+    const unsigned *tok = a.tok + (size_t)f * a.tok_stride;
+    unsigned long long tstamp[7]; int nst = 0;
+#define STAMP() do { if (a.prof && tid == 0) tstamp[nst] = __builtin_readcyclecounter(); nst++; } while (0)
+    STAMP();
+    if (tid == 0) { s_gt = 0; s_abort = 0; }
+    /* ---- stage the tokens: LDS row pr holds the words [wbase(pr), wbase(pr) + rw) of the field, wbase = first word of the row's
+     * tokens rounded down to 4 words; every thread issues ALL its 16-byte loads before the first wait (a dword per lane and a
+     * wait per loop iteration kept 8 KB in flight per CU: 1 TB/s); rotated to token order when the first token of a word sits in
+     * the high half (c_zfstlib.c:119-126) ---- */
+    {
+        const int rv = rw >> 2, nitems = ck.prow_n * rv;
+        uint4 *lds4 = (uint4 *)lds;
+        auto rot = [](uint4 &x) {
+            x.x = __builtin_amdgcn_alignbit(x.x, x.x, 16); x.y = __builtin_amdgcn_alignbit(x.y, x.y, 16);
+            x.z = __builtin_amdgcn_alignbit(x.z, x.z, 16); x.w = __builtin_amdgcn_alignbit(x.w, x.w, 16);
+        };
+        const int wv_u = __builtin_amdgcn_readfirstlane(wave);
+        const size_t wb_u = (size_t)((((unsigned)(3 * ty0 + wv_u) * (unsigned)ni + (unsigned)col_lo) >> 1) & ~3u);      /* first staged word of patch row `wave` */
+        const size_t wb_last = (size_t)((((unsigned)(3 * ty0 + ck.prow_n - 1) * (unsigned)ni + (unsigned)col_lo) >> 1) & ~3u);   /* the chunk's last row: the one nearest the array's end */
+        if (nrow_t == 1 && rv <= 64 * ENC_NLD && wb_last + 4u * (unsigned)rv <= a.tok_words) {        /* block-uniform */
+            /* the common shape (one tile row per chunk): wave w stages patch row w; the row base is wave-uniform, a lane's pieces are
+             * 1 KB apart.  (Deriving row and column of every 16-byte piece from a flat index cost 780 instructions per wave.) */
+            if (wv_u < ck.prow_n) {
+                const uint4 *src = (const uint4 *)(tok + wb_u) + lane;
+                uint4 *dst = lds4 + wv_u * rv + lane;
+                uint4 val[ENC_NLD];
+#pragma unroll
+                for (int u = 0; u < ENC_NLD; u++) if (lane + 64 * u < rv) val[u] = src[64 * u];
+#pragma unroll
+                for (int u = 0; u < ENC_NLD; u++) if (lane + 64 * u < rv) { if (SWAPPED) rot(val[u]); dst[64 * u] = val[u]; }
+            }
+        } else {
+            /* chunks of several tile rows (narrow fields) and the last rows of the token array: piece by piece, bounds checked */
+            for (int idx = tid; idx < nitems; idx += ENC_TPB) {
+                const int pr = idx / rv, v = idx - pr * rv;
+                const size_t gw = (size_t)((((unsigned)(3 * ty0 + pr) * (unsigned)ni + (unsigned)col_lo) >> 1) & ~3u) + 4u * (unsigned)v;
+                uint4 x = make_uint4(0u, 0u, 0u, 0u);
+                if (gw + 3 < a.tok_words) x = *(const uint4 *)(tok + gw);
+                else { if (gw < a.tok_words) x.x = tok[gw]; if (gw + 1 < a.tok_words) x.y = tok[gw + 1]; if (gw + 2 < a.tok_words) x.z = tok[gw + 2]; }
+                if (SWAPPED) rot(x);
+                lds4[idx] = x;
+            }
+        }
     }
     __syncthreads();
-    /* ---- per tile: differences, width, bit count -------------------------------------------------------------- */
+    STAMP();
+    if (a.debug & 32) { if (tid == 0 && (c == a.nchunks - 1 || lds[0] == 0x12345u)) a.zlng[f] = 1000; return; }      /* development: staging only */
+    /* ---- per tile: differences (kept in registers), width, bit count ------------------------------------------- */
     const unsigned short *p16 = (const unsigned short *)lds;
-    int dif[ENC_TPT][9];
+    unsigned long long dpk[ENC_TPT][3];                     /* the 3 differences of a tile row, 18 bits each at bits 0 / 21 / 42 (36 plain registers cost two waves per SIMD) */
     unsigned bits[ENC_TPT], meta[ENC_TPT];                  /* meta: need | tm << 8 | tn << 12 */
     bool gt = false;
+    /* halfword offset of patch row n of the chunk's FIRST tile row (block-uniform): row base + token offset inside the row's first 4 staged words */
+    unsigned rowoff[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) rowoff[n] = (unsigned)n * (unsigned)rw * 2u + (((unsigned)(3 * ty0 + n) * (unsigned)ni + (unsigned)col_lo) & 7u);
 #pragma unroll
     for (int q = 0; q < ENC_TPT; q++) {
         const int tl = tid + ENC_TPB * q;
         bits[q] = 0; meta[q] = 0;
-#pragma unroll
-        for (int k = 0; k < 9; k++) dif[q][k] = 0;
+        dpk[q][0] = dpk[q][1] = dpk[q][2] = 0ull;
         if (tl < ntl) {
             int trow = 0, tcx = tl;
             if (nrow_t > 1) { trow = tl / nt_x; tcx = tl - trow * nt_x; }
             const int tm = min(3, ni - (1 + 3 * (tx0 + tcx))), tn = min(3, nj - (1 + 3 * (ty0 + trow)));
-            int u[4][4];
+            /* the 4 x 4 token patch, unclamped: a clipped tile reads tokens that are not its own (inside the LDS allocation) and
+             * masks them below; four row bases, the columns are immediate offsets.  Horizontal differences first: 12 + 9 subtractions */
+            int h[4][3];
 #pragma unroll
             for (int n = 0; n < 4; n++) {
-                const int pr = 3 * trow + min(n, tn);
-                const unsigned par = ((unsigned)(3 * ty0 + pr) * (unsigned)ni + (unsigned)col_lo) & 1u;
-                const unsigned short *prow = p16 + (size_t)pr * rw * 2;
-#pragma unroll
-                for (int m = 0; m < 4; m++) u[n][m] = prow[((unsigned)(3 * tcx + min(m, tm)) + par) ^ swz];
+                const unsigned short *prow = p16 + 3 * tcx + (nrow_t > 1 ? (unsigned)(3 * trow + n) * (unsigned)rw * 2u + (((unsigned)(3 * (ty0 + trow) + n) * (unsigned)ni + (unsigned)col_lo) & 7u) : rowoff[n]);
+                const int u0 = prow[0], u1 = prow[1], u2 = prow[2], u3 = prow[3];
+                h[n][0] = u1 - u0; h[n][1] = u2 - u1; h[n][2] = u3 - u2;
             }
-            int mx = 0;
+            int d[3][3];
 #pragma unroll
-            for (int n = 1; n < 4; n++)
+            for (int n = 0; n < 3; n++)
 #pragma unroll
-                for (int m = 1; m < 4; m++) {
-                    const int d = u[n][m] - (u[n - 1][m] + u[n][m - 1] - u[n - 1][m - 1]);
-                    dif[q][(n - 1) * 3 + (m - 1)] = d;
-                    if (n <= tn && m <= tm) mx = max(mx, abs(d));
-                }
+                for (int m = 0; m < 3; m++) d[n][m] = h[n + 1][m] - h[n][m];        /* u11 - (u01 + u10 - u00), c_zfstlib.c:691-696 */
+            if (tm < 3 || tn < 3) {                          /* the last tile column / row of the field */
+#pragma unroll
+                for (int n = 0; n < 3; n++)
+#pragma unroll
+                    for (int m = 0; m < 3; m++) if (n >= tn || m >= tm) d[n][m] = 0;
+            }
+            int hi = max(max(d[0][0], d[0][1]), d[0][2]), lo = min(min(d[0][0], d[0][1]), d[0][2]);
+#pragma unroll
+            for (int n = 1; n < 3; n++) { hi = max(max(hi, d[n][0]), max(d[n][1], d[n][2])); lo = min(min(lo, d[n][0]), min(d[n][1], d[n][2])); }
+            const int mx = max(hi, -lo);
+#pragma unroll
+            for (int n = 0; n < 3; n++) {
+                const unsigned a0 = (unsigned)d[n][0] & 0x3FFFFu, a1 = (unsigned)d[n][1] & 0x3FFFFu, a2 = (unsigned)d[n][2] & 0x3FFFFu;
+                dpk[q][n] = (unsigned long long)(a0 | a1 << 21) | (unsigned long long)(a1 >> 11 | a2 << 10) << 32;
+            }
             if (mx > 65535) gt = true;
             unsigned need = (unsigned)bitlen((unsigned)mx);
             if (need == 16) need = 15;
@@ -998,15 +1072,16 @@ __global__ __launch_bounds__(ENC_TPB) void k_armn_enc1(enc1_args a)
             meta[q] = need | (unsigned)tm << 8 | (unsigned)tn << 12;
         }
     }
-    if (gt && nbits >= 15) s_gt = 1;                        /* benign race: every writer stores 1 */
+    if (gt) s_gt = 1;                                       /* benign race: every writer stores 1 */
     /* ---- block scan, layer by layer (layer q = tiles [256 q, 256 q + 255]) ------------------------------------ */
+    /* ONE wave scan for the four layers: their bit counts (<= 171 per tile, <= 10 944 per wave) ride in the 16-bit fields of a 64-bit value */
     unsigned incl[ENC_TPT];
+    {
+        static_assert(ENC_TPT == 4, "the packed scan holds four layers");
+        unsigned long long v = (unsigned long long)bits[0] | (unsigned long long)bits[1] << 16 | (unsigned long long)bits[2] << 32 | (unsigned long long)bits[3] << 48;
+        for (int off = 1; off < 64; off <<= 1) { const unsigned long long o = __shfl_up(v, off, 64); if (lane >= off) v += o; }
 #pragma unroll
-    for (int q = 0; q < ENC_TPT; q++) {
-        unsigned v = bits[q];
-        for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(v, off, 64); if (lane >= off) v += o; }
-        incl[q] = v;
-        if (lane == 63) s_wsum[q][wave] = v;
+        for (int q = 0; q < ENC_TPT; q++) { incl[q] = (unsigned)(v >> (16 * q)) & 0xFFFFu; if (lane == 63) s_wsum[q][wave] = incl[q]; }
     }
     __syncthreads();                                        /* also: every thread is done reading the token patch */
     unsigned excl[ENC_TPT], agg = 0;
@@ -1017,114 +1092,189 @@ __global__ __launch_bounds__(ENC_TPB) void k_armn_enc1(enc1_args a)
         excl[q] = before + incl[q] - bits[q];
     }
     unsigned long long *status = a.status + (size_t)f * a.nchunks;
-    if (tid == 0) st_granule(&status[c], (c == 0 ? ST_PFX : ST_AGG) | (unsigned long long)agg);      /* chunk 0: its aggregate IS its inclusive prefix */
-    /* ---- stream image of the chunk in LDS (bit 0 = first bit of the chunk) ------------------------------------- */
-    const unsigned img_words = ((agg + 31) >> 5) + 2;
-    for (unsigned w = tid; w < img_words; w += ENC_TPB) lds[w] = 0;
+    if (tid == 0) st_granule(&status[c], (c == 0 ? ST_PFX : ST_AGG) | (s_gt ? ST_GT : 0ull) | (unsigned long long)agg);      /* chunk 0: its aggregate IS its inclusive prefix */
+    STAMP();
+    /* ---- stream image of the chunk in LDS (bit 0 = first bit of the chunk), over the token patch ---------------- */
+    unsigned *img = lds;
+    const unsigned img_words = ((agg + 31) >> 5) + 4;
+    for (unsigned w = tid; w < img_words; w += ENC_TPB) img[w] = 0;
     __syncthreads();
+    /* a thread writes its tiles MSB first through a 64-bit accumulator; only a tile's first and last words are shared with
+     * the neighbouring tiles (ds_or), the words in between are plain stores.  (Three unconditional ds_or per tile row, branch
+     * free, were slower: the same-word and same-bank conflicts of adjacent tiles cost more than the branches.) */
 #pragma unroll
     for (int q = 0; q < ENC_TPT; q++) {
-        if (tid + ENC_TPB * q >= ntl) continue;
+        if (tid + ENC_TPB * q >= ntl || (a.debug & 1)) continue;
         const unsigned need = meta[q] & 0xFF; const int tm = (int)(meta[q] >> 8) & 0xF, tn = (int)(meta[q] >> 12) & 0xF;
         unsigned wi = excl[q] >> 5; int fill = (int)(excl[q] & 31);
         unsigned long long acc = 0; bool first = true;
-        auto put = [&](unsigned val, int width) {
-            acc |= (unsigned long long)val << (64 - fill - width);
-            fill += width;
-            if (fill >= 32) {
-                const unsigned word = (unsigned)(acc >> 32);
-                if (first) { atomicOr(&lds[wi], word); first = false; } else lds[wi] = word;
-                wi++; acc <<= 32; fill -= 32;
-            }
+        /* the (up to) three tokens of a tile row are ONE value of at most 3 x 18 = 54 bits (the first row carries the tile's width field
+         * in front: <= 59); it goes through a 96-bit window (acc + the row): at most two words are completed per row */
+        const int width = need == 0 ? 0 : (need == 15 ? 17 : (int)need + 1);
+        const unsigned mask = (1u << width) - 1;
+        const int rowlen = tm * width;
+        auto flush = [&]() {
+            const unsigned word = (unsigned)(acc >> 32);
+            if (first) { atomicOr(&img[wi], word); first = false; } else img[wi] = word;
+            wi++; acc <<= 32; fill -= 32;
         };
-        put(need, container);
-        if (need) {
-            const int width = need == 15 ? 17 : (int)need + 1;
-            const unsigned mask = (1u << width) - 1;
 #pragma unroll
-            for (int n = 0; n < 3; n++)
+        for (int n = 0; n < 3; n++) {
+            if (n >= tn || (n > 0 && need == 0)) break;
+            unsigned long long v = 0;
 #pragma unroll
-                for (int m = 0; m < 3; m++)
-                    if (n < tn && m < tm) put((unsigned)dif[q][n * 3 + m] & mask, width);
+            for (int m = 0; m < 3; m++) if (m < tm) v = (v << width) | (unsigned long long)((unsigned)(dpk[q][n] >> (21 * m)) & mask);
+            int L = rowlen;
+            if (n == 0) { v |= (unsigned long long)need << rowlen; L += container; }
+            /* fill < 32 pending bits in acc's top; append L <= 59 bits: first the part that fits the 64-bit accumulator */
+            const int room = 64 - fill;
+            if (L <= room) { acc |= L == 64 ? v : v << (room - L); fill += L; }
+            else { acc |= v >> (L - room); fill = 64; flush(); flush(); acc = v << (64 - (L - room)); fill = L - room; continue; }
+            if (fill >= 32) flush();
+            if (fill >= 32) flush();
         }
-        if (fill > 0) atomicOr(&lds[wi], (unsigned)(acc >> 32));
+        if (fill > 0) atomicOr(&img[wi], (unsigned)(acc >> 32));
     }
-    /* ---- look-back (wave 0): exclusive prefix of the chunk aggregates ------------------------------------------ */
+    __syncthreads();                                        /* the image is complete */
+    STAMP();
+    /* ---- the last 32 bits of the stream up to the END of this chunk (position independent): the next chunk takes the bits of
+     * the word it shares with this one from here, long before this chunk knows where it starts ------------------------- */
+    unsigned long long *tail = a.tail + (size_t)f * a.nchunks;
+    auto prefix_tail = [&]() -> unsigned {
+        const unsigned long long P = body_start - 32; const unsigned s_ = (unsigned)(P & 31);
+        const unsigned wa = enc1_prefix_word<SWAPPED>(tok, ni, nj, nbits, container, P >> 5);
+        return s_ ? (wa << s_) | (enc1_prefix_word<SWAPPED>(tok, ni, nj, nbits, container, (P >> 5) + 1) >> (32 - s_)) : wa;
+    };
+    auto wait_tail = [&](int idx, unsigned long long t) -> unsigned {       /* cumulative tail of chunk idx (t: an earlier load of it) */
+        int spins = 0;
+        while ((t >> 62) == 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 19) || ((spins & 63) == 0 && __hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(&a.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 1; break;
+            }
+            t = ld_granule(&tail[idx]);
+        }
+        return (unsigned)t;
+    };
+    /* ---- wave 0: publish the tail, then look back for the exclusive prefix of the chunk aggregates ------------------ */
     if (wave == 0) {
-        unsigned long long excl_chunks = 0;
-        if (c > 0) {
-            int basei = c - 1;
+        unsigned long long tprev = (lane == 0 && c > 0) ? ld_granule(&tail[c - 1]) : 0ull;      /* needed for the shared word below: ask early */
+        if (lane == 0) {
+            unsigned tl32;
+            if (agg >= 32) { const unsigned e = agg & 31, w = agg >> 5; tl32 = e ? (img[w - 1] << e) | (img[w] >> (32 - e)) : img[w - 1]; }
+            else {                                               /* a chunk shorter than a word (tiny fields): chained */
+                const unsigned tp = c > 0 ? wait_tail(c - 1, tprev) : prefix_tail();
+                tl32 = (tp << agg) | (img[0] >> (32 - agg));
+                tprev = ST_PFX | tp;
+            }
+            st_granule(&tail[c], ST_PFX | (unsigned long long)tl32);
+        }
+        unsigned long long excl_chunks = 0, gt_before = 0;
+        bool gave_up = false;
+        if (c > 0 && !(a.debug & 8)) {
+            /* windows of 256 predecessors (4 per lane, nearest first) */
+            int basei = c - 1, spins = 0;
             for (;;) {
-                const int idx = basei - lane;
-                unsigned long long st = idx >= 0 ? ld_granule(&status[idx]) : ST_PFX;
-                unsigned long long pm = __ballot((st >> 62) == 2), vm = __ballot((st >> 62) != 0);
-                bool ready;
-                if (pm) { const int firstp = __builtin_ctzll(pm); const unsigned long long needm = firstp == 63 ? ~0ull : ((2ull << firstp) - 1); ready = (vm & needm) == needm; }
-                else ready = vm == ~0ull;
-                if (!ready) { __builtin_amdgcn_s_sleep(8); continue; }
+                if (a.prof && lane == 0) atomicAdd(&a.prof[6], 1ull);            /* development: look-back windows read */
+                unsigned long long st[ENC_WK];
+#pragma unroll
+                for (int k = 0; k < ENC_WK; k++) { const int idx = basei - (lane * ENC_WK + k); st[k] = idx >= 0 ? ld_granule(&status[idx]) : ST_PFX; }
+                int kp = ENC_WK;
+#pragma unroll
+                for (int k = ENC_WK - 1; k >= 0; k--) if ((st[k] >> 62) == 2) kp = k;
+                bool lane_ok = true;
+#pragma unroll
+                for (int k = 0; k < ENC_WK; k++) if (k <= kp && (st[k] >> 62) == 0) lane_ok = false;
+                const unsigned long long pm = __ballot(kp < ENC_WK), okm = __ballot(lane_ok);
                 const int firstp = pm ? __builtin_ctzll(pm) : 63;
-                unsigned long long v = lane <= firstp ? ST_VAL(st) : 0ull;
+                const unsigned long long needm = firstp == 63 ? ~0ull : ((2ull << firstp) - 1);
+                if ((okm & needm) != needm) {
+                    /* not there yet: ONE lane polls the ONE nearest granule that is missing, with a pause, then the window is read again */
+                    const int bad_lane = __builtin_ctzll(~okm & needm);
+                    int kbad = 0;
+#pragma unroll
+                    for (int k = ENC_WK - 1; k >= 0; k--) if ((st[k] >> 62) == 0) kbad = k;
+                    const int bad_idx = __shfl(basei - (lane * ENC_WK + kbad), bad_lane, 64);
+                    if (lane == 0) {
+                        while ((ld_granule(&status[bad_idx]) >> 62) == 0) {
+                            if (a.prof) atomicAdd(&a.prof[7], 1ull);               /* development: polls of a missing granule */
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > (1 << 19) || ((spins & 63) == 0 && __hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { gave_up = true; break; }
+                        }
+                    }
+                    gave_up = __shfl((int)gave_up, 0, 64) != 0;
+                    if (gave_up) break;
+                    continue;
+                }
+                unsigned long long v = 0; bool gg = false;
+                if (!pm || lane <= firstp) {
+#pragma unroll
+                    for (int k = 0; k < ENC_WK; k++) if (k <= kp) { v += ST_VAL(st[k]); gg = gg || (st[k] & ST_GT) != 0; }
+                }
                 for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
                 excl_chunks += v;
+                gt_before |= __ballot(gg);
                 if (pm) break;
-                basei -= 64;
+                basei -= 64 * ENC_WK;
             }
-            if (lane == 0) st_granule(&status[c], ST_PFX | (excl_chunks + agg));
+            if (lane == 0 && !gave_up) st_granule(&status[c], ST_PFX | ((gt_before || s_gt) ? ST_GT : 0ull) | (excl_chunks + agg));
         }
-        if (lane == 0) s_start = body_start + excl_chunks;
+        if (lane == 0) {
+            const unsigned long long S = body_start + excl_chunks;
+            s_start = S;
+            s_gt_all = (gt_before || s_gt) ? 1u : 0u;
+            if (gave_up) { s_abort = 1; __hip_atomic_store(&a.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            else {
+                /* the stream word this chunk shares with the earlier ones: the bits in front of S come from their tail (the prefix's for chunk 0) */
+                const unsigned sh = (unsigned)(S & 31);
+                if (sh && (((sh + agg) >> 5) >= 1 || c == a.nchunks - 1)) {         /* the word is completed here (else a later chunk stores it) */
+                    const unsigned tp = c > 0 ? wait_tail(c - 1, tprev) : prefix_tail();
+                    const unsigned v0 = (img[0] >> sh) | ((tp & ((1u << sh) - 1u)) << (32 - sh));
+                    if ((S >> 5) < a.z_cap) z[S >> 5] = v0;
+                }
+            }
+        }
     }
     __syncthreads();
+    STAMP();
+    if (s_abort) return;
     /* ---- copy out: image shifted to its absolute bit position -------------------------------------------------- */
     const unsigned long long S = s_start;
     const unsigned sh = (unsigned)(S & 31);
     const unsigned long long gw0 = S >> 5;
     const unsigned nwout = (sh + agg + 31) >> 5;             /* stream words the chunk touches */
     const bool last_chunk = c == a.nchunks - 1;
-    const bool tail_open = ((sh + agg) & 31) != 0 && !last_chunk;      /* the last word is completed by the next chunk */
-    auto outword = [&](unsigned k) -> unsigned {
-        const unsigned lo = lds[k];
-        if (sh == 0) return lo;
-        const unsigned hi = k ? lds[k - 1] : 0u;
-        return (hi << (32 - sh)) | (lo >> sh);
-    };
-    const unsigned nstore = nwout - (tail_open ? 1u : 0u);   /* words [0, nstore) are completed by this chunk (word 0 with the carry) */
-    for (unsigned k = 1 + tid; k < nstore; k += ENC_TPB) if (gw0 + k < a.z_cap) z[gw0 + k] = outword(k);
-    if (tid == 0) {
-        unsigned long long *tail = a.tail + (size_t)f * a.nchunks;
-        auto carry_in = [&]() -> unsigned {
-            if (sh == 0) return 0u;
-            if (c == 0) return enc1_prefix_word<SWAPPED>(tok, ni, nj, nbits, container, gw0);
-            unsigned long long t;
-            while (((t = ld_granule(&tail[c - 1])) >> 62) == 0) __builtin_amdgcn_s_sleep(8);
-            return (unsigned)t;
-        };
-        unsigned v0 = outword(0);
-        if (tail_open && nwout == 1) {                       /* the whole chunk lies inside one word: pass it on with the carry */
-            st_granule(&tail[c], ST_PFX | (unsigned long long)(v0 | carry_in()));
-        } else {
-            if (tail_open) st_granule(&tail[c], ST_PFX | (unsigned long long)outword(nwout - 1));
-            v0 |= carry_in();
-            if (gw0 < a.z_cap) z[gw0] = v0;
+    const bool tail_open = ((sh + agg) & 31) != 0 && !last_chunk;      /* the last word is completed (and stored) by a later chunk */
+    const unsigned nstore = nwout - (tail_open ? 1u : 0u);   /* words [0, nstore) are completed by this chunk */
+    if (!(a.debug & 2))
+        for (unsigned k = (sh ? 1u : 0u) + tid; k < nstore; k += ENC_TPB) {        /* word 0 with bits of earlier chunks: stored above */
+            const unsigned lo = img[k];
+            const unsigned v = sh == 0 ? lo : ((k ? img[k - 1] : 0u) << (32 - sh)) | (lo >> sh);
+            if (gw0 + k < a.z_cap) z[gw0 + k] = v;
         }
-        if (last_chunk) {                                    /* the word after the last one: the byte zlng points at (undefined in the reference) */
-            if (gw0 + nwout < a.z_cap) z[gw0 + nwout] = 0u;
-            st_granule(&a.total[f], S + agg - 32);           /* stream bits from the start of word 1, terminator excluded */
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        unsigned dep = 0;
-        if (s_gt) dep = atomicOr(&a.ctl[2 + 2 * f], 1u) & 0u;            /* returned: ordered before the count below */
-        const unsigned done = atomicAdd(&a.ctl[1 + 2 * f], 1u + dep);
-        if (done == (unsigned)a.nchunks - 1) {               /* every chunk of the field is through: zlng (c_zfstlib.c:160-179) */
-            const unsigned long long bits_total = ld_granule(&a.total[f]);
-            const unsigned gtf = __hip_atomic_load(&a.ctl[2 + 2 * f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const long long zl = 1 + 4 * (1 + (long long)((bits_total + 31) / 32));
-            const long long lng_origin = 1 + 2 * (long long)ni * nj;
-            a.zlng[f] = (gtf && container == 4) ? -2 : (zl >= lng_origin ? -1 : (int)zl);
-        }
+    if (tid == 0 && last_chunk) {
+        if (gw0 + nwout < a.z_cap) z[gw0 + nwout] = 0u;       /* the word after the last one: the byte zlng points at (undefined in the reference) */
+        const unsigned long long bits_total = S + agg - 32;  /* stream bits from the start of word 1, terminator excluded (c_zfstlib.c:160-179) */
+        const long long zl = 1 + 4 * (1 + (long long)((bits_total + 31) / 32));
+        const long long lng_origin = 1 + 2 * (long long)ni * nj;
+        a.zlng[f] = (s_gt_all && container == 4 && nbits >= 15) ? -2 : (zl >= lng_origin ? -1 : (int)zl);
     }
+    STAMP();
+    if (a.prof && tid == 0) {       /* [0] chunks, [1..5] cycles of: staging, tiles + scan, emission, look-back wait, copy-out */
+        atomicAdd(&a.prof[0], 1ull);
+        for (int k = 1; k < 6; k++) atomicAdd(&a.prof[k], tstamp[k] - tstamp[k - 1]);
+    }
+#undef STAMP
 }
 
+static unsigned long long *g_enc1_prof = nullptr;
+/* development: phase clock sums of the last profiled launch (EZHIP_ENC_DEBUG & 16) -> out[8] */
+extern "C" int packhip_armn_enc1_profile(unsigned long long *out8)
+{
+    if (!g_enc1_prof) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpy(out8, g_enc1_prof, 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
 /* geometry of the one-pass encoder for a field shape; returns 0 when the shape is outside its limits (-> multi-kernel path) */
 static int enc1_geometry(enc1_args *a, int ni, int nj, int nbits)
 {
@@ -1136,10 +1286,10 @@ static int enc1_geometry(enc1_args *a, int ni, int nj, int nbits)
     if (a->ntx > maxt) {
         a->nseg = (a->ntx + maxt - 1) / maxt; a->seg_tiles = (a->ntx + a->nseg - 1) / a->nseg; a->rows_per_chunk = 1;
         a->nchunks = a->nseg * a->nty;
-        a->row_words = (3 * a->seg_tiles + 1 + 2) / 2 + 1;
+        a->row_words = (((3 * a->seg_tiles + 1 + 2) / 2 + 1 + 3) + 3) & ~3;      /* + up to 3 words in front (16-byte aligned start), multiple of 4 */
     } else {
         a->nseg = 1; a->seg_tiles = a->ntx;
-        a->row_words = (ni + 2) / 2 + 1;
+        a->row_words = (((ni + 2) / 2 + 1 + 3) + 3) & ~3;
         int R = maxt / a->ntx;
         const int rmax = (ENC_MAX_PATCH_WORDS / a->row_words - 1) / 3;
         if (R > rmax) R = rmax;
@@ -1152,13 +1302,17 @@ static int enc1_geometry(enc1_args *a, int ni, int nj, int nbits)
     if (a->npre < 1) a->npre = 1;
     return 1;
 }
-static size_t enc1_lds_bytes(const enc1_args *a)
+static size_t enc1_patch_words(const enc1_args *a)
 {
     const size_t prow = (size_t)(a->nseg > 1 ? 4 : 3 * a->rows_per_chunk + 1);
-    size_t patch = prow * (size_t)a->row_words;
-    /* image: tiles x (5 + 9 x 18) bits worst case */
+    return (prow * (size_t)a->row_words + 3) & ~(size_t)3;
+}
+static size_t enc1_lds_bytes(const enc1_args *a)
+{
+    /* the larger of the token patch and the image (tiles x (5 + 9 x 18) bits worst case): the image overwrites the patch */
     size_t tiles = (size_t)(a->nseg > 1 ? a->seg_tiles : a->ntx * a->rows_per_chunk);
-    size_t img = (tiles * 167 + 31) / 32 + 4;
+    size_t img = (tiles * 167 + 31) / 32 + 8;
+    size_t patch = enc1_patch_words(a);
     return 4 * (patch > img ? patch : img);
 }
 /* control / granule storage of one launch over nfields fields (device scratch, zeroed by the launcher) */
@@ -1166,7 +1320,7 @@ extern "C" size_t packhip_armn_enc1_work_bytes(int ni, int nj, int nbits, int nf
 {
     enc1_args a;
     if (!enc1_geometry(&a, ni, nj, nbits)) return 0;
-    return 16 * (size_t)a.nchunks * nfields + 8 * (size_t)nfields + 4 * (1 + 2 * (size_t)nfields) + 4 * (size_t)nfields + 64;
+    return 16 * (size_t)a.nchunks * nfields + 16 + 64 + 64;
 }
 /* One-pass PARALLELOGRAM encode of nfields token fields (asynchronous).  d_zlng[f] receives the byte count, -1 (not
  * compressible: the stream may be truncated at z_cap words) or -2 (re-run the field with container = 5).
@@ -1181,11 +1335,16 @@ extern "C" int packhip_armn_encode1(unsigned *d_z, size_t z_stride_words, size_t
     if (lds > 64 * 1024) return 1;
     a.z = d_z; a.z_stride = z_stride_words; a.z_cap = z_cap_words; a.tok = d_tok; a.tok_stride = tok_stride_words;
     a.container = container; a.nfields = nfields; a.zlng = d_zlng;
+    a.debug = getenv("EZHIP_ENC_DEBUG") ? atoi(getenv("EZHIP_ENC_DEBUG")) : 0;
+    a.tok_words = ((size_t)ni * nj + 1) / 2;
+    if (((uintptr_t)d_tok % 16 != 0) || (tok_stride_words % 4 != 0 && nfields > 1)) return 1;      /* the LDS-DMA staging moves aligned 16-byte pieces */
+    a.vec = 1;
     char *w = (char *)d_work;
     a.status = (unsigned long long *)w; w += 8 * (size_t)a.nchunks * nfields;
     a.tail = (unsigned long long *)w; w += 8 * (size_t)a.nchunks * nfields;
-    a.total = (unsigned long long *)w; w += 8 * (size_t)nfields;
-    a.ctl = (unsigned *)w; w += 4 * (1 + 2 * (size_t)nfields);
+    a.ctl = (unsigned *)w; w += 16;
+    a.prof = (a.debug & 16) ? (unsigned long long *)w : nullptr; w += 64;
+    g_enc1_prof = (a.debug & 16) ? (unsigned long long *)(w - 64) : nullptr;
     hipStream_t st = STREAM;
     if (hipMemsetAsync(d_work, 0, (size_t)(w - (char *)d_work), st) != hipSuccess) return -1;
     const size_t nblocks = (size_t)(a.npre + a.nchunks) * (size_t)nfields;
