@@ -97,10 +97,14 @@ int32_t ezhip_ezsint_batch_tokens_dev(uint32_t *d_tokens, int64_t token_stride_w
                                       const void *d_params, int64_t param_stride_bytes);
 /* forces plan construction for the current set / options (what the reference does lazily in its first call) */
 int32_t ezhip_prepare_set(void);
-/* which kernel family the current set uses: 1 = separable (k_sep), 2 = per-point (k_pts) */
+/* which kernel family the current set uses: 1 = separable (k_sepx, or its fallback k_sep), 2 = per-point (k_pts) */
 int32_t ezhip_set_mode(void);
 /* copies the current set's located x,y (the reference's gridset cache, ez_calcxy.c:56-134) to device arrays of ni_out*nj_out floats */
 int32_t ezhip_set_xy_dev(float *d_x, float *d_y);
+/* Asynchronous (*_dev) calls cannot report what a kernel finds out while it runs.  The one such condition -- k_sepx's bounded wait for
+ * the pole values computed inside the same launch gave up: the polar rows of that call are NaN -- sets a sticky error word that the
+ * next entry point (and the synchronising host-pointer calls, before they return) report as -1; this call reads and clears it. */
+int32_t ezhip_device_error(void);
 /* 1 when a HIP device is usable */
 int32_t ezhip_available(void);
 

@@ -27,6 +27,16 @@ void *compact_float(void *unpackedArrayOfFloat, void *packedHeader, void *packed
 int compact_integer(void *unpackedArrayOfInt, void *packedHeader, void *packedArrayOfInt, int elementCount,
                     int bitSizeOfPackedToken, int off_set, int stride, int opCode);
 
+/* src/packers/compact.c:28-32 (compact.tmplc with FLOAT_TYPE double): unpackedArrayOfFloat and missingTag point to doubles */
+void *compact_double(void *unpackedArrayOfFloat, void *packedHeader, void *packedArrayOfInt, const int elementCount,
+                     const int packedTokenBitSize, const int offset, const int stride, const int opCode,
+                     const int hasMissing, const void *const missingTag);
+/* src/packers/compact_integer.c:592 (opCode 5 = pack, 6 = unpack unsigned short) and :830 (opCode 9 = pack, 10 = unpack unsigned char) */
+int compact_short(void *unpackedArrayOfShort, void *packedHeader, void *packedArrayOfInt, int elementCount,
+                  int bitSizeOfPackedToken, int off_set, int stride, int opCode);
+int compact_char(void *unpackedArrayOfBytes, void *packedHeader, void *packedArrayOfInt, int elementCount,
+                 int bitSizeOfPackedToken, int off_set, int stride, int opCode);
+
 /* src/packers/packers.h:11 ; src/packers/float_packer.c:258-283, 212-243, 289-319 */
 int32_t c_float_packer(float *source, int32_t nbits, int32_t *header, int32_t *stream, int32_t npts);
 int32_t c_float_unpacker(float *dest, int32_t *header, int32_t *stream, int32_t npts, int32_t *nbits);

@@ -18,6 +18,7 @@
 #include <math.h>
 #include <pthread.h>
 #include <unistd.h>
+#include <sys/mman.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -56,7 +57,6 @@ typedef struct ezh_set {
     float *d_scratch;       /* float[8]: fill value + keys, pole values */
     float *d_poles_batch; int poles_cap;   /* pole values of a c_ezsint_batch_dev batch (2 per field) */
     float *d_prow;          /* 2 * ni_src synthetic polar wind rows (vector mode), u then v: [u_n, u_s, v_n, v_s] */
-    float *d_stage_in, *d_stage_out, *d_stage_in2, *d_stage_out2;   /* host-pointer ABI staging */
     /* Yin-Yang 'U' source (c_ezyy_calcxy, ezyy_calcxy.c): per subgrid the list of target points it serves */
     int yy_ready, yy_count[2];
     float *d_yy_x[2], *d_yy_y[2], *d_yy_lat[2], *d_yy_lon[2], *d_yy_tmp[4];
@@ -83,8 +83,31 @@ typedef struct {
     int nsub, sub[2], maskgrid[2];          /* 'U' (Yin-Yang): the two Z-on-E subgrids and their core ("mask") grids */
 } ezh_grid;
 
+/* The grid table never moves: one lazily backed virtual reservation of the reference's capacity (1024 chunks of 128 grids,
+ * gd_key2rowcol.h:24-27).  A thread that interpolates holds &G[gd] while another thread defines grids (the reference has
+ * chunked tables for the same reason, ez_statics.c:6-10); a table grown by realloc() moved under them. */
+#define EZH_MAX_GRIDS (1024 * 128)
 static ezh_grid *G = NULL;
-static int nG = 0, capG = 0;
+static int nG = 0;
+static int grid_table_init(void)
+{
+    if (G) return 0;
+    void *p = mmap(NULL, sizeof(ezh_grid) * (size_t)EZH_MAX_GRIDS, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) { fprintf(stderr, "<ezscint> cannot reserve the grid table\n"); return -1; }
+    G = (ezh_grid *)p;
+    return 0;
+}
+/* a new slot (under g_mtx): the first released slot, else the next one; -1 when the table is full */
+static int grid_slot(void)
+{
+    if (grid_table_init()) return -1;
+    int gd;
+    for (gd = 0; gd < nG; gd++) if (!G[gd].used) return gd;
+    if (nG >= EZH_MAX_GRIDS) { fprintf(stderr, "<ezscint> grid table full (%d grids)\n", EZH_MAX_GRIDS); return -1; }
+    memset(&G[nG], 0, sizeof(ezh_grid));
+    __atomic_store_n(&nG, nG + 1, __ATOMIC_RELEASE);        /* readers (grid_ok) take no lock: entries never move, `used` is set last */
+    return gd;
+}
 static pthread_mutex_t g_mtx = PTHREAD_MUTEX_INITIALIZER;
 
 static __thread int cur_gdin = -1, cur_gdout = -1;
@@ -473,7 +496,7 @@ static int h_locate_mt(const ezh_grid *g, float *x, float *y, const float *lat, 
 /* ------------------------------------------------------------------------------------------ */
 /* grid table                                                                                   */
 /* ------------------------------------------------------------------------------------------ */
-static int grid_ok(int gd) { return gd >= 0 && gd < nG && G[gd].used; }
+static int grid_ok(int gd) { return gd >= 0 && gd < __atomic_load_n(&nG, __ATOMIC_ACQUIRE) && __atomic_load_n(&G[gd].used, __ATOMIC_ACQUIRE); }
 
 static int type_supported(char t, char ref, int ig1, int ig2)
 {
@@ -515,11 +538,8 @@ int32_t c_ezgdef_fmem(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t 
     pthread_mutex_lock(&g_mtx);
     int gd = find_grid(ni, nj, t, ref, ig, ax, ay);
     if (gd >= 0) { G[gd].refcount++; pthread_mutex_unlock(&g_mtx); return gd; }
-    for (gd = 0; gd < nG; gd++) if (!G[gd].used) break;
-    if (gd == nG) {
-        if (nG == capG) { capG = capG ? 2 * capG : 64; G = (ezh_grid *)realloc(G, sizeof(ezh_grid) * capG); }
-        nG++;
-    }
+    gd = grid_slot();
+    if (gd < 0) { pthread_mutex_unlock(&g_mtx); return -1; }
     ezh_grid *g = &G[gd];
     memset(g, 0, sizeof(*g));
     g->used = 1; g->refcount = 1; g->grtyp = t; g->grref = (t == 'Z' || t == 'Y') ? ref : 0;
@@ -590,7 +610,6 @@ static void free_set(ezh_set *s)
     for (int d = 0; d < 3; d++) for (int v = 0; v < 2; v++) free_sepplan(&s->sep[d][v]);
     free(s->x1d); free(s->y1d);
     ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch);
-    ezhip_free(s->d_stage_in); ezhip_free(s->d_stage_out); ezhip_free(s->d_stage_in2); ezhip_free(s->d_stage_out2);
     for (int k = 0; k < 2; k++) { ezhip_free(s->d_yy_x[k]); ezhip_free(s->d_yy_y[k]); ezhip_free(s->d_yy_lat[k]); ezhip_free(s->d_yy_lon[k]); ezhip_free(s->d_yy_idx[k]); }
     for (int k = 0; k < 4; k++) ezhip_free(s->d_yy_tmp[k]);
     free(s);
@@ -897,6 +916,15 @@ static void *upload(const void *h, size_t nbytes)
     void *d = ezhip_malloc(nbytes);
     if (d && ezhip_h2d(d, h, nbytes)) { ezhip_free(d); return NULL; }
     return d;
+}
+/* a kernel of an earlier (asynchronous) call gave up -- today only k_sepx's bounded wait for the in-launch pole sums: the outputs
+ * of that call carry NaN polar rows.  Sticky until reported: entry points report it on entry, the synchronising host-pointer
+ * calls also before they return. */
+static int device_error(const char *who)
+{
+    if (!ezhip_device_error()) return 0;
+    fprintf(stderr, "<%s> a device kernel of this or an earlier call gave up waiting for its pole values: polar rows are NaN\n", who);
+    return -1;
 }
 static int need_device(const char *who)
 {
@@ -1775,7 +1803,7 @@ int32_t c_ezsint_dev(float *d_zout, const float *d_zin)
 {
     ezh_set *s = current_set("c_ezsint");
     if (!s) return -1;
-    if (need_device("c_ezsint")) return -1;
+    if (need_device("c_ezsint") || device_error("c_ezsint")) return -1;
     if (G[s->gdout].grtyp == 'U') return yy_sint_to_u(s, d_zout, d_zin);
     if (G[s->gdin].grtyp == 'U') return yy_sint(s, d_zout, d_zin);
     if (s->gdin == s->gdout) { ezhip_d2d(d_zout, d_zin, sizeof(float) * (size_t)G[s->gdin].ni * G[s->gdin].nj); return 1; }
@@ -1807,7 +1835,7 @@ static int32_t batch_impl_o(float *d_zout, const float *d_zin, int32_t nfields, 
 {
     ezh_set *s = current_set("c_ezsint_batch");
     if (!s) return -1;
-    if (need_device("c_ezsint_batch")) return -1;
+    if (need_device("c_ezsint_batch") || device_error("c_ezsint_batch")) return -1;
     size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
     int rc = 0;
     if (G[s->gdin].grtyp == 'U' || G[s->gdout].grtyp == 'U') {  /* Yin-Yang source or target: field by field */
@@ -1948,8 +1976,19 @@ int32_t ezhip_set_mode(void)
     return choose_mode(s, O.degre_interp, O.polar_correction == 1);
 }
 
-/* host-pointer ABI: stage through device buffers owned by the set */
-static int stage(float **d, size_t n) { if (!*d) *d = (float *)ezhip_malloc(sizeof(float) * n); return *d ? 0 : -1; }
+/* host-pointer ABI: stage through device buffers owned by the calling THREAD (grow-only, like t_scratch8 and the packers'
+ * workspaces): two host threads may run c_ezsint / c_ezuvint on the same grid pair at the same time, each on its own stream
+ * (buffers owned by the set were overwritten by the other thread, and allocated without a lock) */
+static __thread struct { float *p; size_t cap; } t_stage[4];
+static float *stage(int slot, size_t n)
+{
+    if (t_stage[slot].cap < n) {
+        if (t_stage[slot].p) { ezhip_sync(); ezhip_free(t_stage[slot].p); }
+        t_stage[slot].p = (float *)ezhip_malloc(sizeof(float) * n);
+        t_stage[slot].cap = t_stage[slot].p ? n : 0;
+    }
+    return t_stage[slot].p;
+}
 
 int32_t c_ezsint(float *zout, float *zin)               /* ezsint.c:38-135 */
 {
@@ -1958,14 +1997,16 @@ int32_t c_ezsint(float *zout, float *zin)               /* ezsint.c:38-135 */
     size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
     if (s->gdin == s->gdout) { memcpy(zout, zin, sizeof(float) * nin); return 1; }
     if (need_device("c_ezsint")) return -1;
-    if (stage(&s->d_stage_in, nin) || stage(&s->d_stage_out, nout)) return -1;
+    float *d_in = stage(0, nin), *d_out = stage(1, nout);
+    if (!d_in || !d_out) return -1;
     int yy = G[s->gdin].grtyp == 'U' || G[s->gdout].grtyp == 'U';
     if (!yy && ezhip_prepare_set()) return -1;
-    if (ezhip_h2d(s->d_stage_in, zin, sizeof(float) * nin)) return -1;
-    int rc = G[s->gdout].grtyp == 'U' ? yy_sint_to_u(s, s->d_stage_out, s->d_stage_in)
-           : G[s->gdin].grtyp == 'U' ? yy_sint(s, s->d_stage_out, s->d_stage_in) : run_field(s, s->d_stage_out, s->d_stage_in, 0, NULL, NULL);
+    if (ezhip_h2d(d_in, zin, sizeof(float) * nin)) return -1;
+    int rc = G[s->gdout].grtyp == 'U' ? yy_sint_to_u(s, d_out, d_in)
+           : G[s->gdin].grtyp == 'U' ? yy_sint(s, d_out, d_in) : run_field(s, d_out, d_in, 0, NULL, NULL);
     if (rc < 0) return rc;
-    if (ezhip_d2h(zout, s->d_stage_out, sizeof(float) * nout) || ezhip_sync()) return -1;
+    if (ezhip_d2h(zout, d_out, sizeof(float) * nout) || ezhip_sync()) return -1;
+    if (device_error("c_ezsint")) return -1;
     return rc;
 }
 
@@ -1983,17 +2024,20 @@ int32_t c_gdxysint_dev(float *d_zout, const float *d_zin, int32_t gdin, const fl
     if (src_hemi(gi) || grid_yinv(gi)) { d_zin = hemi_expand(gi, d_zin); if (!d_zin) return -1; }      /* gdxysint.c:35-47 */
     return ezhip_interp_pts(&pp, d_zout, d_zin, d_x, d_y, npts) ? -1 : 0;
 }
+static float *stage(int slot, size_t n);
 int32_t c_gdxysint(float *zout, float *zin, int32_t gdin, float *x, float *y, int32_t npts)
 {
     if (!grid_ok(gdin)) return -1;
     if (need_device("c_gdxysint")) return -1;
-    size_t nin = (size_t)G[gdin].ni * G[gdin].nj;
-    float *d_in = (float *)upload(zin, sizeof(float) * nin), *d_x = (float *)upload(x, sizeof(float) * (size_t)npts);
-    float *d_y = (float *)upload(y, sizeof(float) * (size_t)npts), *d_out = (float *)ezhip_malloc(sizeof(float) * (size_t)npts);
-    int rc = (d_in && d_x && d_y && d_out) ? c_gdxysint_dev(d_out, d_in, gdin, d_x, d_y, npts) : -1;
-    if (rc == 0 && (ezhip_d2h(zout, d_out, sizeof(float) * (size_t)npts) || ezhip_sync())) rc = -1;
-    ezhip_sync();
-    ezhip_free(d_in); ezhip_free(d_x); ezhip_free(d_y); ezhip_free(d_out);
+    if (npts <= 0) return 0;
+    /* the calling thread's grow-only staging buffers (four hipMalloc / hipFree pairs per call cost more than the copies) */
+    size_t nin = (size_t)G[gdin].ni * G[gdin].nj, np = (size_t)npts;
+    float *d_in = stage(0, nin), *d_out = stage(1, np), *d_xy = stage(2, 2 * np);
+    if (!d_in || !d_out || !d_xy) return -1;
+    if (ezhip_h2d(d_in, zin, sizeof(float) * nin) || ezhip_h2d(d_xy, x, sizeof(float) * np) || ezhip_h2d(d_xy + np, y, sizeof(float) * np)) return -1;
+    int rc = c_gdxysint_dev(d_out, d_in, gdin, d_xy, d_xy + np, npts);
+    if (rc == 0 && ezhip_d2h(zout, d_out, sizeof(float) * np)) rc = -1;
+    if (ezhip_sync()) rc = -1;
     return rc;
 }
 int32_t c_gdxysval(int32_t gdin, float *zout, float *zin, float *x, float *y, int32_t n) { return c_gdxysint(zout, zin, gdin, x, y, n); }
@@ -2155,7 +2199,7 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
 {
     ezh_set *s = current_set(wd_only ? "c_ezwdint" : "c_ezuvint");
     if (!s) return -1;
-    if (need_device("c_ezuvint")) return -1;
+    if (need_device("c_ezuvint") || device_error("c_ezuvint")) return -1;
     if (G[s->gdout].grtyp == 'U') {                        /* ezyyuvint.c:88-106 / :216-300: the two Z-on-E subgrids one after the other */
         const ezh_grid *gu = &G[s->gdout];
         const size_t nsub = (size_t)G[gu->sub[0]].ni * G[gu->sub[0]].nj;
@@ -2268,11 +2312,12 @@ static int32_t uvint_host(float *uuout, float *vvout, float *uuin, float *vvin, 
     if (!s) return -1;
     if (need_device(wd_only ? "c_ezwdint" : "c_ezuvint")) return -1;
     size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
-    if (stage(&s->d_stage_in, nin) || stage(&s->d_stage_out, nout) || stage(&s->d_stage_in2, nin) || stage(&s->d_stage_out2, nout)) return -1;
-    if (ezhip_h2d(s->d_stage_in, uuin, sizeof(float) * nin) || ezhip_h2d(s->d_stage_in2, vvin, sizeof(float) * nin)) return -1;
-    int rc = uvint_impl(s->d_stage_out, s->d_stage_out2, s->d_stage_in, s->d_stage_in2, wd_only);
+    float *d_in = stage(0, nin), *d_out = stage(1, nout), *d_in2 = stage(2, nin), *d_out2 = stage(3, nout);
+    if (!d_in || !d_out || !d_in2 || !d_out2) return -1;
+    if (ezhip_h2d(d_in, uuin, sizeof(float) * nin) || ezhip_h2d(d_in2, vvin, sizeof(float) * nin)) return -1;
+    int rc = uvint_impl(d_out, d_out2, d_in, d_in2, wd_only);
     if (rc < 0) return rc;
-    if (ezhip_d2h(uuout, s->d_stage_out, sizeof(float) * nout) || ezhip_d2h(vvout, s->d_stage_out2, sizeof(float) * nout) || ezhip_sync()) return -1;
+    if (ezhip_d2h(uuout, d_out, sizeof(float) * nout) || ezhip_d2h(vvout, d_out2, sizeof(float) * nout) || ezhip_sync()) return -1;
     return rc;
 }
 int32_t c_ezuvint(float *uuout, float *vvout, float *uuin, float *vvin) { return uvint_host(uuout, vvout, uuin, vvin, 0); }
@@ -2636,11 +2681,8 @@ int32_t c_ezgdef_supergrid(int32_t ni, int32_t nj, char *grtyp, char *grref, int
     pthread_mutex_lock(&g_mtx);
     int gd;
     for (gd = 0; gd < nG; gd++) if (G[gd].used && G[gd].grtyp == 'U' && G[gd].sub[0] == subgrid[0] && G[gd].sub[1] == subgrid[1]) { G[gd].refcount++; pthread_mutex_unlock(&g_mtx); return gd; }
-    for (gd = 0; gd < nG; gd++) if (!G[gd].used) break;
-    if (gd == nG) {
-        if (nG == capG) { capG = capG ? 2 * capG : 64; G = (ezh_grid *)realloc(G, sizeof(ezh_grid) * capG); }
-        nG++;
-    }
+    gd = grid_slot();
+    if (gd < 0) { pthread_mutex_unlock(&g_mtx); return -1; }
     ezh_grid *g = &G[gd];
     memset(g, 0, sizeof(*g));
     g->used = 1; g->refcount = 1; g->grtyp = 'U'; g->grref = 'F';

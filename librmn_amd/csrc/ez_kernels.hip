@@ -108,6 +108,30 @@ extern "C" void ezhip_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 #define LAUNCH_CHECK(what) set_err(hipGetLastError(), what)
 
+/* Device-side error word: one int in pinned host memory that a kernel sets (system-scope store) when it has to give up --
+ * today only k_sepx's bounded wait for the in-launch pole sums.  Sticky: ezhip_device_error() reports and clears it; the
+ * entry points check it at entry and, where they synchronise anyway, before they return. */
+static int *g_dev_err = nullptr;
+static int *dev_err_word(void)
+{
+    static int *volatile word = nullptr;
+    if (!word) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        memset(p, 0, 64);
+        int *expect = nullptr;
+        if (!__atomic_compare_exchange_n((int **)&word, &expect, (int *)p, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) (void)hipHostFree(p);
+    }
+    g_dev_err = word;
+    return word;
+}
+extern "C" int ezhip_device_error(void)
+{
+    int *w = dev_err_word();
+    if (!w) return 0;
+    return __atomic_exchange_n(w, 0, __ATOMIC_ACQ_REL);
+}
+
 /* ===================================================================================== */
 /* block reduction helpers (wave = 64)                                                      */
 /* ===================================================================================== */
@@ -426,8 +450,8 @@ __device__ float sep_special(const ezhip_sep_plan &p, float *__restrict__ zout, 
             for (int k = 0; k < 4; k++) { need_n |= (sr.tap[k] == EZ_ROW_POLE_N); need_s |= (sr.tap[k] == EZ_ROW_POLE_S); }
         float pole_n = 0.f, pole_s = 0.f;
         if (!p.vector_mode) {       /* pole values: precomputed once per field by k_polevals (a sequential REAL sum: ~10 us) */
-            if (need_n) pole_n = __hip_atomic_load(&p.polevals[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (need_s) pole_s = __hip_atomic_load(&p.polevals[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (need_n) pole_n = p.pole_timeout ? __builtin_nanf("") : __hip_atomic_load(&p.polevals[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (need_s) pole_s = p.pole_timeout ? __builtin_nanf("") : __hip_atomic_load(&p.polevals[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (sr.kind == 1) outv = pole_n;
         else if (sr.kind == 2) outv = pole_s;
@@ -737,7 +761,12 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
                     int spins = 0;
                     while (__hip_atomic_load(&p.pole_flags[2 * bz + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.pole_epoch) {
                         __builtin_amdgcn_s_sleep(32);
-                        if (++spins > (1 << 22)) break;  /* seconds: never in a healthy launch; do not hang the device */
+                        if (++spins > (1 << 22)) {       /* seconds: never in a healthy launch.  Do not hang the device, and do not go on with
+                                                            whatever the slot holds: the polar rows become NaN and the host learns of it */
+                            p.pole_timeout = 1;
+                            if (p.err_word && threadIdx.x == 0) __hip_atomic_store(p.err_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            break;
+                        }
                     }
                 }
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -892,6 +921,9 @@ static int launch_sepx(const ezhip_sep_plan *plan, float *d_zout, const float *d
 {
     ezhip_sep_plan pl = *plan;
     plan = &pl;
+    pl.err_word = pl.pole_blocks ? dev_err_word() : nullptr;
+    pl.pole_timeout = getenv("EZHIP_TEST_POLE_TIMEOUT") ? 1 : 0;        /* tests: behave as if the wait had timed out */
+    if (pl.pole_timeout && pl.err_word) __atomic_store_n(pl.err_word, 1, __ATOMIC_RELEASE);
     const size_t nf = plan->batch_fields > 1 ? plan->batch_fields : 1;
     pl.x_nbx = (plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK;
     const size_t nblocks = (size_t)pl.pole_blocks + (size_t)pl.x_nbx * (size_t)(plan->x_nseg + plan->n_special) * nf;

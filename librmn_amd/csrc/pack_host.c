@@ -144,6 +144,70 @@ done:
     return ret;
 }
 
+/* compact_double (compact.c:28-32: compact.tmplc on REAL*8 arrays; c_fstecr's packer for 64-bit IEEE fields, fstd98.c:826).
+ * Same header and stream as compact_float; the extrema, the quantisation and the unpacked values are doubles.  The missing-value
+ * tag is read through a double pointer and narrowed to float, as the reference does (compact.tmplc:106). */
+void *compact_double(void *unpackedArrayOfFloat, void *packedHeader, void *packedArrayOfInt, const int elementCount,
+                     const int packedTokenBitSize, const int offset, const int stride, const int opCode,
+                     const int hasMissing, const void *const missingTag)
+{
+    if (need_device("compact_double")) return NULL;
+    if (packedTokenBitSize == 0) return NULL;
+    if (packedTokenBitSize == 1 && hasMissing) return NULL;
+    int bs, eff;
+    split_token_size(packedTokenBitSize, &bs, &eff);
+    if (eff > 32 || bs > 32) { fprintf(stderr, "<compact_double> tokens wider than 32 bits are not supported on the MI355X path\n"); return NULL; }
+    const float tag = (float)*(const double *)missingTag;
+    unsigned *hdr = (unsigned *)packedHeader, *out = (unsigned *)packedArrayOfInt;
+    size_t n = (size_t)elementCount, nfl = n ? (n - 1) * (size_t)stride + 1 : 0;
+    size_t span_words = ((size_t)offset + n * (size_t)eff + 31) / 32;
+    int style = ((&hdr[3] == out && offset == 24) || (&hdr[0] == out && offset == 120)) ? 1 : 2;
+    size_t lead = (style == 1) ? (size_t)(out - hdr) : 4;
+    double *d_a = (double *)ws(0, sizeof(double) * (nfl ? nfl : 1));
+    unsigned *d_img = (unsigned *)ws(1, 4 * (lead + span_words + 8));
+    char *d_sc = (char *)ws(4, sizeof(packhip_cf_params) + 64 + sizeof(double) * 2048);
+    void *ret = NULL;
+    if (!d_a || !d_img || !d_sc) goto done;
+    packhip_cf_params *d_pp = (packhip_cf_params *)d_sc;
+    double *d_partials = (double *)(d_sc + ((sizeof(packhip_cf_params) + 63) & ~(size_t)63));
+    unsigned *d_hdr = d_img, *d_out = d_img + lead;
+    if (opCode == 1) {
+        if (style == 2 && n > 268435455u) { fprintf(stderr, "<compact_double> element count overflow in xxpack header\n"); goto done; }
+        if (ezhip_h2d(d_a, unpackedArrayOfFloat, sizeof(double) * nfl)) goto done;
+        if (ezhip_h2d(d_out, out, 4 * span_words)) goto done;
+        if (style == 1 && lead) { if (ezhip_h2d(d_hdr, hdr, 4 * lead)) goto done; }
+        if (packhip_cf_pack_f64(d_out, d_hdr, d_pp, d_partials, d_a, n, bs, eff, offset, stride, style, hasMissing, tag)) goto done;
+        if (style == 1) { size_t tot = lead + span_words; if (tot < 4) tot = 4; if (ezhip_d2h(hdr, d_hdr, 4 * tot)) goto done; }
+        else { if (ezhip_d2h(hdr, d_hdr, 16) || ezhip_d2h(out, d_out, 4 * span_words)) goto done; }
+        if (ezhip_sync()) goto done;
+        ret = packedArrayOfInt;
+    } else if (opCode == 2) {
+        unsigned marker = hdr[0] >> 20, counter = hdr[0] & 0xFFFFF;
+        unsigned rangeExpo = hdr[1] >> 16, minExpo = (hdr[1] >> 4) & 0xFFF, minSign = hdr[1] & 0xF;
+        unsigned minMantisa32 = hdr[2], bitSize = (hdr[3] >> 8) & 0xFF, emptySpace = hdr[3] & 0xFF;
+        unsigned intCount = (marker == 0x7ff || marker == 0x7ef) ? (unsigned)elementCount : (emptySpace << 20 | counter);
+        int tokenSize = (int)bitSize;
+        if (tokenSize > 32 || tokenSize < 1) goto done;
+        unsigned missingToken = (tokenSize != 32) ? ~(0xFFFFFFFFu << tokenSize) : ~0u;
+        unsigned rangeExponent = rangeExpo - 4096 + 127 + tokenSize;
+        double mulFactor = ldexp(1.0, (int)(rangeExponent - 127 - tokenSize)), minF = 0;
+        if (!(minMantisa32 == 0 || minExpo < 849)) {         /* compact.tmplc:374-381: the minimum comes back as a REAL*4 */
+            unsigned u = (minSign & 1) << 31 | ((minExpo + 127 - 1024 + 48) & 0xFF) << 23 | ((minMantisa32 >> 8) & 0x7fffff);
+            float f; memcpy(&f, &u, 4); minF = f;
+        }
+        size_t nfl2 = intCount ? ((size_t)intCount - 1) * (size_t)stride + 1 : 0, span2 = ((size_t)offset + (size_t)intCount * (size_t)tokenSize + 31) / 32;
+        d_a = (double *)ws(0, sizeof(double) * (nfl2 ? nfl2 : 1)); d_img = (unsigned *)ws(1, 4 * (span2 + 8));
+        if (!d_a || !d_img || ezhip_h2d(d_img, out, 4 * span2)) goto done;
+        if (nfl2 && stride != 1 && ezhip_h2d(d_a, unpackedArrayOfFloat, sizeof(double) * nfl2)) goto done;   /* keep the gaps */
+        if (packhip_cf_unpack_f64(d_a, d_img, intCount, tokenSize, offset, stride, minF, mulFactor, missingToken, hasMissing, tag)) goto done;
+        if (ezhip_d2h(unpackedArrayOfFloat, d_a, sizeof(double) * nfl2) || ezhip_sync()) goto done;
+        ret = unpackedArrayOfFloat;
+    } else fprintf(stderr, "<compact_double> opCode (%d) is not defined\n", opCode);
+done:
+    ezhip_sync();
+    return ret;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* compact_integer                                                                              */
 /* ------------------------------------------------------------------------------------------ */
@@ -257,6 +321,63 @@ int compact_integer(void *unpackedArrayOfInt, void *packedHeader, void *packedAr
 done:
     ezhip_sync();
     return rc;
+}
+
+/* compact_short (compact_integer.c:592-826, opCode 5 pack / 6 unpack) and compact_char (:830-1060, opCode 9 / 10): compact_integer's
+ * unsigned forms on arrays of unsigned short / unsigned char (c_fstecr / c_fstluk use them for datyp 2 / 4 fields held in 16- / 8-bit
+ * arrays, fstd98.c:1214-1290, :2312-2322).  The elements are widened to a dense uint32 array on the device and go through the
+ * compact_integer kernels; unpacked values are truncated to the element width like the reference's store does. */
+static int compact_narrow(const char *who, int elem_bytes, int op_pack, int op_unpack, void *unpacked, void *packedHeader, void *packedArrayOfInt,
+                          int elementCount, int bitSizeOfPackedToken, int off_set, int stride, int opCode)
+{
+    if (need_device(who)) return 0;
+    if (bitSizeOfPackedToken == 0) return 0;
+    size_t n = (size_t)elementCount;
+    int rc = 0;
+    if (opCode == op_pack) {
+        size_t nin = n ? (n - 1) * (size_t)stride + 1 : 0;
+        void *d_src = ws(4, (size_t)elem_bytes * (nin ? nin : 1) + 16);
+        unsigned *d_a = (unsigned *)ws(0, 4 * (n ? n : 1));
+        if (!d_src || !d_a || ezhip_h2d(d_src, unpacked, (size_t)elem_bytes * nin) || packhip_widen(d_a, d_src, n, stride, elem_bytes)) goto done;
+        ci_plan pl;
+        if (ci_prepare_pack(&pl, d_a, packedHeader != NULL, n, bitSizeOfPackedToken, 1, 1)) goto done;
+        if (packedHeader) memcpy(packedHeader, pl.hdr, 16);
+        rc = pl.E;
+        if (pl.E < 1 || pl.E > 32) goto done;
+        size_t words = ((size_t)off_set + n * (size_t)pl.E + 31) / 32;
+        unsigned *d_out = (unsigned *)ws(1, 4 * (words + 4));
+        rc = 0;
+        if (!d_out || ezhip_h2d(d_out, packedArrayOfInt, 4 * words)) goto done;     /* first/last word neighbours survive */
+        if (packhip_ci_pack(d_out, d_a, n, pl.E, off_set, 1, pl.with_header, 0, pl.minv, pl.shift, 0)) goto done;
+        if (ezhip_d2h(packedArrayOfInt, d_out, 4 * words) || ezhip_sync()) goto done;
+        rc = pl.E;
+    } else if (opCode == op_unpack) {
+        int tokenSize = bitSizeOfPackedToken, shift = 0; unsigned minv = 0;
+        if (packedHeader) { unsigned *h = (unsigned *)packedHeader; tokenSize = h[0] & 0x3F; shift = (h[0] >> 6) & 0x3F; n = h[1]; minv = h[2]; }
+        if (tokenSize < 1 || tokenSize > 32) { fprintf(stderr, "<%s> token size %d not supported on the MI355X path\n", who, tokenSize); goto done; }
+        size_t nin = n ? (n - 1) * (size_t)stride + 1 : 0, words = ((size_t)off_set + n * (size_t)tokenSize + 31) / 32;
+        void *d_dst = ws(4, (size_t)elem_bytes * (nin ? nin : 1) + 16);
+        unsigned *d_a = (unsigned *)ws(0, 4 * (n ? n : 1)), *d_in = (unsigned *)ws(1, 4 * (words + 4));
+        if (!d_dst || !d_a || !d_in || ezhip_h2d(d_in, packedArrayOfInt, 4 * words)) goto done;
+        if (stride != 1 && ezhip_h2d(d_dst, unpacked, (size_t)elem_bytes * nin)) goto done;        /* keep the gaps */
+        if (packhip_ci_unpack(d_a, d_in, n, tokenSize, off_set, 1, packedHeader != NULL, minv, shift, 0)) goto done;
+        if (packhip_narrow(d_dst, d_a, n, stride, elem_bytes)) goto done;
+        if (ezhip_d2h(unpacked, d_dst, (size_t)elem_bytes * nin) || ezhip_sync()) goto done;
+        rc = bitSizeOfPackedToken;
+    } else fprintf(stderr, "<%s> opCode (%d) is not defined\n", who, opCode);
+done:
+    ezhip_sync();
+    return rc;
+}
+int compact_short(void *unpackedArrayOfShort, void *packedHeader, void *packedArrayOfInt, int elementCount,
+                  int bitSizeOfPackedToken, int off_set, int stride, int opCode)
+{
+    return compact_narrow("compact_short", 2, 5, 6, unpackedArrayOfShort, packedHeader, packedArrayOfInt, elementCount, bitSizeOfPackedToken, off_set, stride, opCode);
+}
+int compact_char(void *unpackedArrayOfBytes, void *packedHeader, void *packedArrayOfInt, int elementCount,
+                 int bitSizeOfPackedToken, int off_set, int stride, int opCode)
+{
+    return compact_narrow("compact_char", 1, 9, 10, unpackedArrayOfBytes, packedHeader, packedArrayOfInt, elementCount, bitSizeOfPackedToken, off_set, stride, opCode);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -124,13 +124,9 @@ extern "C" int packhip_stats(unsigned *d_stats, const void *d_a, size_t n, int s
 /* compact_float: header (compact.tmplc:210-290) on one lane, then the token stream               */
 /* ------------------------------------------------------------------------------------------ */
 /* one thread block per field: blockIdx.x selects {params, header, stats} through the strides (all 0 for a single field) */
-__global__ __launch_bounds__(256) void k_cf_header(packhip_cf_params *pp, unsigned *hdr, unsigned *stats, int npartials, unsigned n, int bs, int style, int has_missing,
-                                                   size_t hdr_stride_words, size_t stats_stride_words)
+/* the header words and quantisation parameters from the extrema (one lane): compact.tmplc:206-290 */
+__device__ __forceinline__ void cf_header_write(packhip_cf_params *pp, unsigned *hdr, double minF, double maxF, unsigned n, int bs, int style, int has_missing)
 {
-    pp += blockIdx.x; hdr += blockIdx.x * hdr_stride_words; stats += blockIdx.x * stats_stride_words;
-    if (npartials > 0) stats_reduce_partials(stats, npartials);     /* fused final reduction of k_stats (one launch less) */
-    if (threadIdx.x != 0) return;
-    double minF = (double)key2f(stats[0]), maxF = (double)key2f(stats[1]);
     unsigned missingToken = (bs != 32) ? ~(0xFFFFFFFFu << bs) : ~0u;
     int too_large = (maxF > 1.0e+38) || (minF < -1.0e+38);
     unsigned long long range = (unsigned long long)__double_as_longlong((maxF - minF) * 2);
@@ -157,6 +153,48 @@ __global__ __launch_bounds__(256) void k_cf_header(packhip_cf_params *pp, unsign
     pp->mulFactor = ldexp(1.0, bs) / ldexp(1.0, tempExpo);
     pp->missingToken = missingToken;
     pp->too_large = too_large;
+}
+/* one thread block per field: blockIdx.x selects {params, header, stats} through the strides (all 0 for a single field) */
+__global__ __launch_bounds__(256) void k_cf_header(packhip_cf_params *pp, unsigned *hdr, unsigned *stats, int npartials, unsigned n, int bs, int style, int has_missing,
+                                                   size_t hdr_stride_words, size_t stats_stride_words)
+{
+    pp += blockIdx.x; hdr += blockIdx.x * hdr_stride_words; stats += blockIdx.x * stats_stride_words;
+    if (npartials > 0) stats_reduce_partials(stats, npartials);     /* fused final reduction of k_stats (one launch less) */
+    if (threadIdx.x != 0) return;
+    cf_header_write(pp, hdr, (double)key2f(stats[0]), (double)key2f(stats[1]), n, bs, style, has_missing);
+}
+
+/* ---- compact_double (compact.c:28-32: the same template on REAL*8 arrays) -------------------------------------------- */
+/* min / max of a double array: per-block pairs, then one block; the missing-value tag is a FLOAT in the reference too
+ * (compact.tmplc:106: `float missingValueTag = *((FLOAT_TYPE *)missingTag)`) */
+__global__ __launch_bounds__(256) void k_stats_f64(double *partials, const double *a, size_t n, int stride, int has_missing, float tag)
+{
+    double lo = INFINITY, hi = -INFINITY;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double v = a[i * stride];
+        if (has_missing && v == (double)tag) continue;
+        lo = fmin(lo, v); hi = fmax(hi, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_down(lo, off, 64)); hi = fmax(hi, __shfl_down(hi, off, 64)); }
+    __shared__ double sh[2][4];
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = lo; sh[1][threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = fmin(fmin(sh[0][0], sh[0][1]), fmin(sh[0][2], sh[0][3]));
+        partials[2 * blockIdx.x + 1] = fmax(fmax(sh[1][0], sh[1][1]), fmax(sh[1][2], sh[1][3]));
+    }
+}
+__global__ __launch_bounds__(256) void k_cf_header_f64(packhip_cf_params *pp, unsigned *hdr, const double *partials, int nb, unsigned n, int bs, int style, int has_missing)
+{
+    double lo = INFINITY, hi = -INFINITY;
+    for (int b = threadIdx.x; b < nb; b += 256) { lo = fmin(lo, partials[2 * b]); hi = fmax(hi, partials[2 * b + 1]); }
+    for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_down(lo, off, 64)); hi = fmax(hi, __shfl_down(hi, off, 64)); }
+    __shared__ double sh[2][4];
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = lo; sh[1][threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    lo = fmin(fmin(sh[0][0], sh[0][1]), fmin(sh[0][2], sh[0][3])); hi = fmax(fmax(sh[1][0], sh[1][1]), fmax(sh[1][2], sh[1][3]));
+    cf_header_write(pp, hdr, lo, hi, n, bs, style, has_missing);
 }
 
 __device__ __forceinline__ unsigned cf_token(const float *a, size_t i, int stride, const packhip_cf_params &p, int has_missing, float tag)
@@ -270,6 +308,78 @@ __global__ __launch_bounds__(256) void k_cf_unpack(float *a, const unsigned *in,
     else v = (float)((tok * mulFactor) * 1.0000000000001 + minF);
     a[t * stride] = v;
 }
+__global__ __launch_bounds__(256) void k_cf_pack_f64(unsigned *out, const double *a, size_t n, int E, int offset, int stride,
+                                                     const packhip_cf_params *pp, int has_missing, float tag, size_t w0, size_t nwords)
+{
+    size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nwords) return;
+    const packhip_cf_params p = *pp;
+    emit_word(out, w0 + k, n, E, offset, [&](size_t t) {
+        const double x = a[t * stride];
+        if (has_missing == 1 && x == (double)tag) return p.missingToken;
+        return (unsigned)(long long)((x - p.minF) * p.mulFactor);
+    });
+}
+__global__ __launch_bounds__(256) void k_cf_unpack_f64(double *a, const unsigned *in, size_t n, int tokenSize, int offset, int stride,
+                                                       double minF, double mulFactor, unsigned missingToken, int has_missing, float tag)
+{
+    size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    int sig = tokenSize > 32 ? 32 : tokenSize;
+    unsigned tok = read_token(in, t, sig, offset);
+    double v;
+    if (has_missing == 1 && tok == missingToken) v = (double)tag;
+    else if (tok == 0) v = minF;
+    else v = (tok * mulFactor) * 1.0000000000001 + minF;
+    a[t * stride] = v;
+}
+/* compact_double, pack side: extrema -> header + parameters -> stream.  d_partials: 2 * 1024 doubles of scratch */
+extern "C" int packhip_cf_pack_f64(unsigned *d_out, unsigned *d_hdr, packhip_cf_params *d_pp, double *d_partials, const double *d_a, size_t n,
+                                   int bs, int E, int offset, int stride, int style, int has_missing, float tag)
+{
+    if (n == 0) return 0;
+    int nb = (int)((n + 4095) / 4096); if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_stats_f64, dim3(nb), dim3(256), 0, STREAM, d_partials, d_a, n, stride, has_missing, tag);
+    hipLaunchKernelGGL(k_cf_header_f64, dim3(1), dim3(256), 0, STREAM, d_pp, d_hdr, d_partials, nb, (unsigned)n, bs, style, has_missing);
+    size_t w0 = (size_t)offset / 32, w1 = ((size_t)offset + n * (size_t)E + 31) / 32;
+    hipLaunchKernelGGL(k_cf_pack_f64, dim3((unsigned)((w1 - w0 + 255) / 256)), dim3(256), 0, STREAM, d_out, d_a, n, E, offset, stride, d_pp, has_missing, tag, w0, w1 - w0);
+    return chk("k_cf_pack_f64");
+}
+extern "C" int packhip_cf_unpack_f64(double *d_a, const unsigned *d_in, size_t n, int tokenSize, int offset, int stride,
+                                     double minF, double mulFactor, unsigned missingToken, int has_missing, float tag)
+{
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_cf_unpack_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM, d_a, d_in, n, tokenSize, offset, stride, minF, mulFactor, missingToken, has_missing, tag);
+    return chk("k_cf_unpack_f64");
+}
+/* compact_short / compact_char (compact_integer.c:592, :830): the unsigned short / byte elements i * stride <-> a dense uint32 array */
+template <class T> __global__ __launch_bounds__(256) void k_widen(unsigned *dst, const T *src, size_t n, int stride)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (unsigned)src[i * stride];
+}
+template <class T> __global__ __launch_bounds__(256) void k_narrow(T *dst, const unsigned *src, size_t n, int stride)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i * stride] = (T)src[i];
+}
+extern "C" int packhip_widen(unsigned *d_dst, const void *d_src, size_t n, int stride, int elem_bytes)
+{
+    if (!n) return 0;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (elem_bytes == 2) hipLaunchKernelGGL(k_widen<unsigned short>, dim3(nb), dim3(256), 0, STREAM, d_dst, (const unsigned short *)d_src, n, stride);
+    else hipLaunchKernelGGL(k_widen<unsigned char>, dim3(nb), dim3(256), 0, STREAM, d_dst, (const unsigned char *)d_src, n, stride);
+    return chk("k_widen");
+}
+extern "C" int packhip_narrow(void *d_dst, const unsigned *d_src, size_t n, int stride, int elem_bytes)
+{
+    if (!n) return 0;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (elem_bytes == 2) hipLaunchKernelGGL(k_narrow<unsigned short>, dim3(nb), dim3(256), 0, STREAM, (unsigned short *)d_dst, d_src, n, stride);
+    else hipLaunchKernelGGL(k_narrow<unsigned char>, dim3(nb), dim3(256), 0, STREAM, (unsigned char *)d_dst, d_src, n, stride);
+    return chk("k_narrow");
+}
+
 extern "C" int packhip_cf_unpack(float *d_a, const unsigned *d_in, size_t n, int tokenSize, int offset, int stride,
                                  double minF, double mulFactor, unsigned missingToken, int has_missing, float tag)
 {

@@ -27,6 +27,14 @@ int packhip_cf_pack(unsigned *d_out, const float *d_a, size_t n, int E, int offs
                     const packhip_cf_params *d_pp, int has_missing, float tag);
 int packhip_cf_unpack(float *d_a, const unsigned *d_in, size_t n, int tokenSize, int offset, int stride,
                       double minF, double mulFactor, unsigned missingToken, int has_missing, float tag);
+/* compact_double (REAL*8 arrays); d_partials: 2048 doubles of scratch */
+int packhip_cf_pack_f64(unsigned *d_out, unsigned *d_hdr, packhip_cf_params *d_pp, double *d_partials, const double *d_a, size_t n,
+                        int bs, int E, int offset, int stride, int style, int has_missing, float tag);
+int packhip_cf_unpack_f64(double *d_a, const unsigned *d_in, size_t n, int tokenSize, int offset, int stride,
+                          double minF, double mulFactor, unsigned missingToken, int has_missing, float tag);
+/* compact_short / compact_char: elements i * stride of a 2- / 1-byte array <-> a dense uint32 array */
+int packhip_widen(unsigned *d_dst, const void *d_src, size_t n, int stride, int elem_bytes);
+int packhip_narrow(void *d_dst, const unsigned *d_src, size_t n, int stride, int elem_bytes);
 int packhip_ci_pack(unsigned *d_out, const void *d_a, size_t n, int E, int offset, int stride,
                     int with_header, int is_signed, unsigned minv, int shift, unsigned positiveMask);
 int packhip_ci_unpack(void *d_a, const unsigned *d_in, size_t n, int E, int offset, int stride, int with_header, unsigned minv, int shift, unsigned negMask);

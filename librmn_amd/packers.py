@@ -17,6 +17,10 @@ def _lib():
         L.compact_float.restype = vp
         L.compact_float.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.compact_integer.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci]
+        L.compact_double.restype = vp
+        L.compact_double.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.compact_short.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci]
+        L.compact_char.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci]
         L.c_float_packer.argtypes = [vp, ci, vp, vp, ci]
         L.c_float_unpacker.argtypes = [vp, vp, vp, ci, vp]
         L.armn_compress.argtypes = [vp, ci, ci, ci, ci, ci]
@@ -165,3 +169,41 @@ def ezsint_pack16_compress_batch_dev(d_records, record_stride_words, d_zin, nfie
     zl = np.zeros(nfields, np.int32)
     rc = L.ezhip_ezsint_pack16_compress_batch_dev(_dptr(d_records), record_stride_words, _dptr(d_zin), nfields, ni_out, nj_out, nbits, zl.ctypes.data)
     return rc, zl
+
+
+def compact_double_pack(a, nbits_arg, offset=0, stride=1, has_missing=0, tag=0.0, prefill=0):
+    """compact_double FLOAT_PACK on a float64 array: returns the uint32 image [4 header words | stream] (header style 2)"""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    n = (a.size + stride - 1) // stride
+    eff = (nbits_arg >> 6) if nbits_arg > 64 else nbits_arg
+    tagv = np.array([tag], np.float64)
+    buf = np.full(4 + stream_words(n, eff, offset) + 1, prefill, np.uint32)
+    r = _lib().compact_double(a.ctypes.data, buf.ctypes.data, buf[4:].ctypes.data, n, nbits_arg, offset, stride, FLOAT_PACK, has_missing, tagv.ctypes.data)
+    return None if not r else buf
+
+
+def compact_double_unpack(buf, n, nbits_arg, offset=0, stride=1, has_missing=0, tag=0.0):
+    out = np.zeros(n * stride, np.float64)
+    tagv = np.array([tag], np.float64)
+    r = _lib().compact_double(out.ctypes.data, buf.ctypes.data, buf[4:].ctypes.data, n, nbits_arg, offset, stride, FLOAT_UNPACK, has_missing, tagv.ctypes.data)
+    return None if not r else out
+
+
+def compact_narrow_pack(a, nbits, header=False, offset=0, stride=1, prefill=0):
+    """compact_short (uint16 input, opCode 5) / compact_char (uint8 input, opCode 9)"""
+    a = np.ascontiguousarray(a)
+    assert a.dtype in (np.uint16, np.uint8)
+    n = (a.size + stride - 1) // stride
+    nb = 32 if nbits == -1 else nbits
+    out = np.full(stream_words(n, nb, offset) + 1, prefill, np.uint32)
+    hdr = np.zeros(4, np.uint32)
+    fn = _lib().compact_short if a.dtype == np.uint16 else _lib().compact_char
+    rc = fn(a.ctypes.data, hdr.ctypes.data if header else None, out.ctypes.data, n, nbits, offset, stride, 5 if a.dtype == np.uint16 else 9)
+    return rc, hdr, out
+
+
+def compact_narrow_unpack(out, n, nbits, dtype, hdr=None, offset=0, stride=1, fill=0):
+    a = np.full(n * stride, fill, dtype)
+    fn = _lib().compact_short if dtype == np.uint16 else _lib().compact_char
+    rc = fn(a.ctypes.data, hdr.ctypes.data if hdr is not None else None, out.ctypes.data, n, nbits, offset, stride, 6 if dtype == np.uint16 else 10)
+    return rc, a

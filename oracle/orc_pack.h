@@ -8,6 +8,12 @@ extern "C" {
 /* compact_float, src/packers/compact.tmplc:37-431 (opCode 1 = FLOAT_PACK, 2 = FLOAT_UNPACK) */
 void *orc_compact_float(void *unpacked, void *packedHeader, void *packed, int elementCount,
                         int packedTokenBitSize, int offset, int stride, int opCode, int hasMissing, const void *missingTag);
+/* compact_double, src/packers/compact.c:28-32 (the same template on double arrays) */
+void *orc_compact_double(void *unpacked, void *packedHeader, void *packed, int elementCount,
+                         int packedTokenBitSize, int offset, int stride, int opCode, int hasMissing, const void *missingTag);
+/* compact_short / compact_char, src/packers/compact_integer.c:592, :830 (opCode 5/6, 9/10) */
+int orc_compact_short(void *unpacked, void *packedHeader, void *packed, int elementCount, int bitSize, int off_set, int stride, int opCode);
+int orc_compact_char(void *unpacked, void *packedHeader, void *packed, int elementCount, int bitSize, int off_set, int stride, int opCode);
 /* compact_integer, src/packers/compact_integer.c:325-570 */
 int orc_compact_integer(void *unpacked, void *packedHeader, void *packed, int elementCount,
                         int bitSizeOfPackedToken, int off_set, int stride, int opCode);

@@ -1015,3 +1015,77 @@ def test_abort_and_rc_on_the_per_point_path_through_dev_entry_points():
     setopts(3, 0)
     assert ez.ezsint_dev(d_out, d_in) == 0
     torch.cuda.synchronize()
+
+
+def test_pole_wait_timeout_is_reported_not_silent():
+    """k_sepx's bounded wait for the in-launch pole values (EZHIP_TEST_POLE_TIMEOUT makes the launch behave as if it had
+    given up): the polar rows become NaN -- never stale values -- and the call / the next entry point returns -1"""
+    ni, nj, no, mo = 360, 181, 500, 251
+    gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(no, mo, "L", 72, 72, 0, 0)
+    assert ez.ezdefset(gdout, gdin) == 1
+    setopts(3, 1)
+    zin = ec.synth_field(ni, nj, seed=5)
+    rc, good = ez.ezsint(zin, no * mo)
+    assert rc == 0 and np.all(np.isfinite(good))
+    os.environ["EZHIP_TEST_POLE_TIMEOUT"] = "1"
+    try:
+        rc, z = ez.ezsint(zin, no * mo)
+        assert rc == -1                                        # the host-pointer call synchronises: it reports its own failure
+        z2 = z.reshape(mo, no)
+        assert np.all(np.isnan(z2[0])) and np.all(np.isnan(z2[-1]))     # pole rows: NaN, not whatever the slot held
+        assert np.array_equal(z2[5:-5], good.reshape(mo, no)[5:-5])      # the main rows do not depend on the pole values
+        ez.use_stream(0)
+        d_in = torch.from_numpy(zin).cuda(); d_out = torch.empty(no * mo, dtype=torch.float32, device="cuda")
+        assert ez.ezsint_dev(d_out, d_in) == 0                 # asynchronous: the launch itself is fine ...
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("EZHIP_TEST_POLE_TIMEOUT", None)
+    assert ez.ezsint_dev(d_out, d_in) == -1                    # ... the next entry point reports it (sticky), once
+    assert ez.ezsint_dev(d_out, d_in) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint32), good.view(np.uint32))
+
+
+def test_two_threads_host_pointer_ezsint_on_one_grid_pair():
+    """two host threads call the host-pointer c_ezsint on the SAME grid pair at the same time, each on its own stream and field
+    (staging buffers are per thread), while a third thread defines 200 more grids (the grid table never moves)"""
+    import threading
+    ni, nj, no, mo = 360, 181, 500, 251
+    gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(no, mo, "L", 72, 72, 0, 0)
+    assert ez.ezdefset(gdout, gdin) == 1
+    setopts(3, 1)
+    fields = [ec.synth_field(ni, nj, seed=70 + k) for k in range(2)]
+    want = []
+    for k in range(2):
+        rc, z = ez.ezsint(fields[k], no * mo)
+        assert rc == 0
+        want.append(z)
+    errs = []
+
+    def worker(k):
+        try:
+            st = torch.cuda.Stream()
+            ez.use_stream(st.cuda_stream)
+            assert ez.ezdefset(gdout, gdin) == 1               # the current pair is per thread
+            for it in range(25):
+                rc, z = ez.ezsint(fields[k], no * mo)
+                if rc != 0 or not np.array_equal(z.view(np.uint32), want[k].view(np.uint32)):
+                    errs.append((k, it, rc)); return
+        except Exception as e:   # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    def definer():
+        try:
+            for g in range(200):
+                if ez.ezqkdef(10 + g, 8, "L", 100, 100, 0, 0) < 0:
+                    errs.append(("define", g)); return
+        except Exception as e:   # noqa: BLE001
+            errs.append(("define", repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(2)] + [threading.Thread(target=definer)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    ez.use_stream(0)
+    assert not errs, errs

@@ -435,3 +435,57 @@ def test_fused_cfg5_pipeline_full_size():
         assert zs == zl[f], (f, zs, int(zl[f]))
         m = 4 + (zs - 1) // 4
         assert torch.equal(one[:m], rec[f][:m]), f
+
+
+# ---------------------------------------------------------------------------------------------
+# compact_double, compact_short, compact_char (the sibling entry points c_fstecr / c_fstluk call)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nbits_arg", [4, 12, 16, 24, 31, 32, 16 + 64 * 16])
+@pytest.mark.parametrize("n,stride,offset", [(1, 1, 0), (33, 2, 5), (1000, 1, 0), (7200 * 17 + 5, 1, 0)])
+def test_compact_double_bit_exact(nbits_arg, n, stride, offset):
+    a = pc.float_field(n * stride, seed=nbits_arg + n).astype(np.float64) * (1.0 + 1e-9 * np.arange(n * stride))    # real double content
+    eff = (nbits_arg >> 6) if nbits_arg > 64 else nbits_arg
+    want = np.full(4 + (offset + n * eff + 31) // 32 + 1, 0xDEADBEEF, np.uint32)
+    tagv = np.array([0.0], np.float64)
+    assert top.O().orc_compact_double(a.ctypes.data, want.ctypes.data, want[4:].ctypes.data, n, nbits_arg, offset, stride, 1, 0, tagv.ctypes.data)
+    got = pk.compact_double_pack(a, nbits_arg, offset=offset, stride=stride, prefill=0xDEADBEEF)
+    assert got is not None and np.array_equal(got, want), np.nonzero(got != want)[0][:5]
+    back_w = np.zeros(n * stride, np.float64)
+    top.O().orc_compact_double(back_w.ctypes.data, want.ctypes.data, want[4:].ctypes.data, n, nbits_arg, offset, stride, 2, 0, tagv.ctypes.data)
+    back = pk.compact_double_unpack(got, n, nbits_arg, offset=offset, stride=stride)
+    assert np.array_equal(back.view(np.uint64), back_w.view(np.uint64))
+
+
+def test_compact_double_missing_values():
+    a = pc.float_field(5000, seed=1).astype(np.float64); a[[3, 50, 4999]] = -999.0
+    tagv = np.array([-999.0], np.float64)
+    want = np.zeros(4 + (5000 * 12 + 31) // 32 + 1, np.uint32)
+    assert top.O().orc_compact_double(a.ctypes.data, want.ctypes.data, want[4:].ctypes.data, 5000, 12, 0, 1, 1, 1, tagv.ctypes.data)
+    got = pk.compact_double_pack(a, 12, has_missing=1, tag=-999.0)
+    assert np.array_equal(got[:got.size - 1], want[:got.size - 1])
+    back = pk.compact_double_unpack(got, 5000, 12, has_missing=1, tag=-999.0)
+    assert back[3] == -999.0 and back[4999] == -999.0
+
+
+@pytest.mark.parametrize("dtype,bits", [(np.uint16, [1, 7, 12, 16, -1]), (np.uint8, [1, 5, 8, -1])])
+@pytest.mark.parametrize("header,stride,offset", [(False, 1, 0), (True, 1, 0), (False, 3, 37), (True, 2, 0)])
+def test_compact_short_and_char_bit_exact(dtype, bits, header, stride, offset):
+    n = 3001
+    rng = np.random.default_rng(17 + stride + offset)
+    O = top.O()
+    for nbits in bits:
+        width = (12 if dtype == np.uint16 else 6) if nbits == -1 else min(nbits, 8 * np.dtype(dtype).itemsize)
+        a = rng.integers(0, 2 ** width, n * stride, dtype=np.uint64).astype(dtype)
+        nb = 32 if nbits == -1 else nbits
+        w_out = np.full((offset + n * nb + 31) // 32 + 1, 0x0F0F0F0F, np.uint32); w_hdr = np.zeros(4, np.uint32)
+        fn = O.orc_compact_short if dtype == np.uint16 else O.orc_compact_char
+        ops = (5, 6) if dtype == np.uint16 else (9, 10)
+        rc_w = fn(a.ctypes.data, w_hdr.ctypes.data if header else None, w_out.ctypes.data, n, nbits, offset, stride, ops[0])
+        rc, hdr, out = pk.compact_narrow_pack(a, nbits, header=header, offset=offset, stride=stride, prefill=0x0F0F0F0F)
+        assert rc == rc_w and np.array_equal(hdr, w_hdr) and np.array_equal(out, w_out), (dtype, nbits)
+        back_w = np.full(n * stride, 7, dtype)
+        fn(back_w.ctypes.data, w_hdr.ctypes.data if header else None, w_out.ctypes.data, n, rc_w, offset, stride, ops[1])
+        rc2, back = pk.compact_narrow_unpack(out, n, rc, dtype, hdr=hdr if header else None, offset=offset, stride=stride, fill=7)
+        assert np.array_equal(back, back_w), (dtype, nbits)
+        if not header:
+            assert np.array_equal(back[::stride], a[::stride])

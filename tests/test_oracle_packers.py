@@ -18,6 +18,10 @@ def O():
     L.orc_compact_float.restype = ctypes.c_void_p
     L.orc_compact_float.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
     L.orc_compact_integer.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5
+    L.orc_compact_double.restype = ctypes.c_void_p
+    L.orc_compact_double.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
+    L.orc_compact_short.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5
+    L.orc_compact_char.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5
     L.orc_float_packer.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     L.orc_float_unpacker.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.orc_armn_compress.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
