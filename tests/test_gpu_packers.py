@@ -489,3 +489,27 @@ def test_compact_short_and_char_bit_exact(dtype, bits, header, stride, offset):
         assert np.array_equal(back, back_w), (dtype, nbits)
         if not header:
             assert np.array_equal(back[::stride], a[::stride])
+
+
+def test_known_answers_on_the_gpu():
+    """the hand-derived known-answer vectors of tests/test_known_answers.py (one stream per packer branch, derived from the reference's
+    source text, not from any code of this repository) through the HIP path"""
+    import test_known_answers as ka
+
+    def cf(a, nbits, style1=False, has_missing=0, tag=0.0):
+        return pk.compact_float_pack(a, nbits, style1=style1, has_missing=has_missing, tag=tag)
+
+    def ci(a, nbits, op, header):
+        return pk.compact_integer_pack(a, nbits, op, header=header)
+
+    for name, v in ka.PACK_VECTORS.items():
+        ka.check_pack_vector(name, v, cf, ci, pk.float_packer)
+    for val in (0x1234, 0, 0xFFFF):
+        words, zlng = ka.armn_constant_16x16(val)
+        buf = np.zeros(16 * 16 // 2 + 8, np.uint32); buf[:128] = pc.tokens_to_words(np.full(256, val, np.uint16))
+        assert pk.armn_compress(buf, 16, 16, 16) == zlng
+        assert [int(x) for x in buf[:len(words)]] == words
+    tok, words, zlng = ka.armn_one_step_16x16()
+    buf = np.zeros(16 * 16 // 2 + 8, np.uint32); buf[:128] = pc.tokens_to_words(tok)
+    assert pk.armn_compress(buf, 16, 16, 16) == zlng
+    assert [int(x) for x in buf[:len(words)]] == words
