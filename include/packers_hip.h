@@ -47,6 +47,16 @@ void    c_float_packer_params(int32_t *header_size, int32_t *stream_size, int32_
  * op_code 2 = UNCOMPRESS (:181-200, in place: (1 + ni*nj/2) words of tokens come back), returns ni*nj*2.
  * Streams of the deactivated SAMPLE predictor (c_fstunzip_sample) are refused (-1). */
 int  armn_compress(unsigned char *fld, int ni, int nj, int nk, int nbits, int op_code);
+/* src/compresseur/armn_compress_32.h ; armn_compress_32.c:59-275, :285-437 (datyp 133: sign RLE + 8-bit exponent parallelogram + mantissa
+ * parallelogram of znbits - 9 bits).  zstream: host memory of ni*nj*znbits/8 bytes (+ 64).  c_armn_compress32 returns the byte count or -1
+ * (not compressible / ni, nj < 16); c_armn_uncompress32 returns ni*nj.  Fortran twins armn_compress32_ / armn_uncompress32_. */
+int c_armn_compress32(unsigned char *zstream, float *fld, int ni, int nj, int nk, int znbits);
+int c_armn_uncompress32(float *fld, unsigned char *zstream, int ni, int nj, int nk, int znbits);
+int armn_compress32_(unsigned char *zstream, float *fld, int *ni, int *nj, int *nk, int *nbits);
+int armn_uncompress32_(float *fld, unsigned char *zstream, int *ni, int *nj, int *nk, int *nbits);
+/* additive: the field on the device (the stream of c_armn_uncompress32_dev stays in HOST memory: its chain of tile headers is walked there) */
+int c_armn_compress32_dev(void *d_zstream, const float *d_fld, int ni, int nj, int nk, int znbits);
+int c_armn_uncompress32_dev(float *d_fld, const unsigned char *zstream_host, int ni, int nj, int nk, int znbits);
 void c_armn_compress_setlevel(int level);       /* src/compresseur/c_zfstlib.c:1325 ; BEST = 1, FAST = 0 */
 int  c_armn_compress_getlevel(void);
 void c_armn_compress_setswap(int swapState);

@@ -1,0 +1,284 @@
+/*
+ * armn32_host.c -- C host front-end of the IEEE-32 compressor (datyp 133): c_armn_compress32 / c_armn_uncompress32 of librmn
+ * (src/compresseur/armn_compress_32.c:59-275, :285-437; called by c_fstecr / c_fstluk, fstd98.c:1309, :2436) over the HIP kernels of
+ * armn32_kernels.hip.  There is NO CPU fallback: without a HIP device every entry point fails loudly.
+ *
+ * What runs where: the three planes (sign, exponent, mantissa), the two parallelogram encoders, and on the way back the token extraction,
+ * the inverse predictor (2-D prefix sums) and the re-assembly of the floats are device kernels.  Two strictly sequential steps over small
+ * data stay on the host: the run-length coder of the sign plane (1 bit per point, a state machine: pack1bitRLE :827-901) and, when
+ * decoding, the walk along the chain of tile headers (a tile's position is the sum of all earlier tiles' lengths, each read from the stream).
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ezhip_shim.h"
+#include "packhip_shim.h"
+#include "../../include/packers_hip.h"
+
+static int need_dev32(const char *who)
+{
+    if (ezhip_runtime_ok()) return 0;
+    fprintf(stderr, "<%s> no usable HIP device: the MI355X packer path has no CPU fallback\n", who);
+    return -1;
+}
+/* per-thread grow-only device workspaces */
+static __thread struct { void *p; size_t cap; } t_w32[8];
+static void *w32(int slot, size_t bytes)
+{
+    if (t_w32[slot].cap < bytes) {
+        if (t_w32[slot].p) { ezhip_sync(); ezhip_free(t_w32[slot].p); }
+        t_w32[slot].p = ezhip_malloc(bytes + 256);
+        t_w32[slot].cap = t_w32[slot].p ? bytes : 0;
+    }
+    return t_w32[slot].p;
+}
+
+/* ---- MSB-first bit stream on host words: the `stuff` / `extract` rules (include/bitPacking.h:59-139) ---- */
+typedef struct { uint32_t *z; uint64_t pos; } bitw32;              /* over a zeroed buffer */
+static void bw32_put(bitw32 *w, uint32_t tok, int bits)
+{
+    for (int b = bits - 1; b >= 0; b--, w->pos++) if ((tok >> b) & 1u) w->z[w->pos >> 5] |= 0x80000000u >> (w->pos & 31);
+}
+static uint32_t br32_get(const uint32_t *z, uint64_t *pos, int bits)
+{
+    uint32_t v = 0;
+    for (int b = 0; b < bits; b++, (*pos)++) v = v << 1 | ((z[*pos >> 5] >> (31 - (*pos & 31))) & 1u);
+    return v;
+}
+/* a stream of P data bits followed by the 32 terminator bits occupies ceil(P / 32) flushed words: zlng = 1 + 4 * that (:559-561) */
+static uint32_t zlng_of_bits(uint64_t P) { return 1u + 4u * (uint32_t)((P + 31) >> 5); }
+
+/* sign plane -> run-length stream (pack1bitRLE): runs of 8 .. 62 equal signs are one {1, sign, count} token, a run longer than 256 repeats
+ * its 62-token once and then 0xFF tokens of 255 points, anything shorter is 7 raw bits behind a 0.  s(i) = bit i & 31 of mask word i >> 5. */
+static uint32_t rle_encode(uint32_t *z, const uint32_t *mask, int npts)
+{
+#define SGN(i) ((mask[(i) >> 5] >> ((i) & 31)) & 1u)
+    bitw32 w = {z, 0};
+    int last = 0, idx = 1;
+    while (idx <= npts) {
+        while (idx < npts && SGN(idx) == SGN(last)) idx++;
+        const int count = idx - last;
+        int i = 0, repeat = 0;
+        do {
+            int c = count < 8 ? count : ((count - i) >= 63 ? 62 : count - i);
+            if (c < 8) {
+                bw32_put(&w, 0, 1);
+                const int lim = last + 7 > npts ? npts - last : 7;
+                for (int j = 0; j < lim; j++) bw32_put(&w, SGN(last + j), 1);
+                last += 7;
+            } else if (c == 62 && (count - i) > 256 && repeat) {
+                c = 255;
+                bw32_put(&w, 0xFF, 8);
+                last += c;
+            } else {
+                bw32_put(&w, 1, 1); bw32_put(&w, SGN(last), 1); bw32_put(&w, (uint32_t)c, 6);
+                last += c;
+                if (c == 62) repeat = 1;
+            }
+            idx = last + 1;
+            i += c;
+        } while (count >= 8 && i < count);
+    }
+#undef SGN
+    return zlng_of_bits(w.pos);
+}
+/* run-length stream -> sign mask (unpack1bitRLE :904-955) */
+static void rle_decode(uint32_t *mask, const uint32_t *z, int npts)
+{
+    uint64_t pos = 0;
+    uint32_t last_val = 1;                   /* (unsigned char)0xFFFFFFFF of the reference is never used before a count token sets it */
+    int i = 0;
+#define SETS(k, v) do { if ((k) < npts && (v)) mask[(k) >> 5] |= 1u << ((k) & 31); } while (0)
+    while (i < npts) {
+        if (br32_get(z, &pos, 1) == 0) {
+            const int lim = i + 7 > npts ? npts - i : 7;
+            for (int j = 0; j < lim; j++) { const uint32_t b = br32_get(z, &pos, 1); SETS(i + j, b); }
+            i += lim;
+        } else {
+            const uint32_t val = br32_get(z, &pos, 1); const int count = (int)br32_get(z, &pos, 6);
+            if (count == 63) { for (int j = 0; j < 255; j++) SETS(i + j, last_val & 1u); i += 255; }
+            else { for (int j = 0; j < count; j++) SETS(i + j, val); i += count; last_val = val; }
+        }
+    }
+#undef SETS
+}
+
+static int float_width(uint32_t v) { union { float f; int32_t i; } r; r.f = (float)v; return v ? (r.i >> 23) - 126 : 0; }
+
+/* c_armn_compress32 on device data.  d_z: device buffer of at least ni*nj*znbits/8 + 64 bytes; returns the stream's byte count or -1 */
+int c_armn_compress32_dev(void *d_z, const float *d_fld, int ni, int nj, int nk, int znbits)
+{
+    (void)nk;
+    if (ni < 16 || nj < 16) { fprintf(stderr, "<c_armn_compress32> The dimensions of NI and NJ have to be > 16\n"); return -1; }
+    if (need_dev32("c_armn_compress32")) return -1;
+    const int nbits = znbits - 9;
+    if (nbits < 1 || nbits > 23) { fprintf(stderr, "<c_armn_compress32> nbits %d outside 10 .. 32\n", znbits); return -1; }
+    const size_t n = (size_t)ni * nj;
+    const size_t plane_words = n + n / 4 + 64;                  /* capacity of one plane's scratch stream */
+    unsigned char *d_expo = (unsigned char *)w32(0, n + 16);
+    unsigned *d_mant = (unsigned *)w32(1, 4 * n + 16), *d_smask = (unsigned *)w32(2, 4 * (n / 32 + 2) + 16);
+    unsigned *d_ze = (unsigned *)w32(3, 4 * plane_words), *d_zm = (unsigned *)w32(4, 4 * plane_words);
+    char *d_work = (char *)w32(5, 2 * packhip_pg_work_bytes(ni, nj) + 256);
+    if (!d_expo || !d_mant || !d_smask || !d_ze || !d_zm || !d_work) return -1;
+    unsigned st[4];
+    if (packhip_a32_split(d_expo, d_mant, d_smask, (unsigned *)d_work, d_fld, n, nbits, st)) return -1;
+    const int meme_signe = (st[0] >> 31) == (st[1] >> 31);
+    const unsigned exp_base = st[2], exp_span = st[3] - st[2];
+    const int need_e = float_width(exp_span);                    /* :143-145 */
+    unsigned char *z8 = (unsigned char *)d_z;
+    size_t off = 8;                                              /* bytes written so far */
+    uint32_t lng_signe = 0, code_signe, code_expo = 0;
+    /* sign stream (:148-180) */
+    if (meme_signe) code_signe = (st[0] >> 31) ? 0x10 : 0x00;
+    else {
+        const size_t mw = n / 32 + 2;
+        uint32_t *mask = (uint32_t *)calloc(mw, 4), *zs = (uint32_t *)calloc(n / 16 + 64, 4);      /* the RLE needs at most 8 bits per 7 points */
+        if (!mask || !zs || ezhip_d2h(mask, d_smask, 4 * (n / 32 + 1)) || ezhip_sync()) { free(mask); free(zs); return -1; }
+        lng_signe = rle_encode(zs, mask, (int)n);
+        code_signe = 0x20;
+        if (lng_signe % 4) lng_signe += 4 - lng_signe % 4;
+        int bad = ezhip_h2d(z8 + off, &lng_signe, 4) || ezhip_h2d(z8 + off + 4, zs, lng_signe) || ezhip_sync();
+        free(mask); free(zs);
+        if (bad) return -1;
+        off += 4 + lng_signe;
+    }
+    /* the two planes are encoded back to back; their lengths come back with one synchronisation each */
+    if (need_e && packhip_pg_encode(d_ze, plane_words, d_expo, 1, ni, nj, need_e, 0, d_work)) return -1;
+    unsigned long long bits_e = 0; int failed = 0;
+    if (need_e) {
+        if (packhip_pg_result(d_work, ni, nj, need_e, &bits_e, &failed)) return -1;
+        uint32_t lng_expo = zlng_of_bits(bits_e);
+        if (lng_expo > n) { fprintf(stderr, "<c_armn_compress32> Exponent range too large, original field left uncompressed\n"); return -1; }
+        if (lng_expo % 4) lng_expo += 4 - lng_expo % 4;
+        code_expo = 0x08;
+        if (ezhip_h2d(z8 + off, &lng_expo, 4) || ezhip_d2d(z8 + off + 4, d_ze, lng_expo) || ezhip_sync()) return -1;
+        off += 4 + lng_expo;
+    }
+    const size_t pos_lng_mant = off;
+    off += 4;
+    const long long remaining = (long long)(((long long)ni * nj * znbits) / 32) - (long long)(off / 4);
+    if (packhip_pg_encode(d_zm, plane_words, d_mant, 4, ni, nj, nbits, remaining, d_work)) return -1;
+    unsigned long long bits_m = 0;
+    if (packhip_pg_result(d_work, ni, nj, nbits, &bits_m, &failed)) return -1;
+    if (failed) { fprintf(stderr, "<c_armn_compress32> IEEE compressed field is larger than original, keeping original\n"); return -1; }
+    uint32_t lng_mant = zlng_of_bits(bits_m);
+    if (lng_mant % 4) lng_mant += 4 - lng_mant % 4;
+    if ((size_t)off + lng_mant > (size_t)n * (size_t)znbits / 8 + 64) return -1;
+    const uint32_t head[2] = {5u | 1u << 4 | 3u << 7 | ((uint32_t)nbits & 31u) << 10 | 1u << 15 | 2u << 18,          /* _fstzip: PARALLELOGRAM32, degree 1, step 3, nbits, levels 1, version 2 */
+                              (exp_base & 0xFF) << 16 | ((uint32_t)need_e & 0xFF) << 8 | code_signe | code_expo};
+    if (ezhip_h2d(z8, head, 8) || ezhip_h2d(z8 + pos_lng_mant, &lng_signe, 4)          /* the mantissa length slot receives lng_signe (sic, :237) */
+        || ezhip_d2d(z8 + off, d_zm, lng_mant) || ezhip_sync()) return -1;
+    return (int)(off + lng_mant);
+}
+
+int c_armn_compress32(unsigned char *zstream, float *fld, int ni, int nj, int nk, int znbits)
+{
+    if (ni < 16 || nj < 16) { fprintf(stderr, "<c_armn_compress32> The dimensions of NI and NJ have to be > 16\n"); return -1; }
+    if (need_dev32("c_armn_compress32")) return -1;
+    const size_t n = (size_t)ni * nj, cap = n * (size_t)(znbits > 0 ? znbits : 32) / 8 + 256;
+    float *d_f = (float *)w32(6, 4 * n);
+    unsigned char *d_z = (unsigned char *)w32(7, cap);
+    if (!d_f || !d_z || ezhip_h2d(d_f, fld, 4 * n)) return -1;
+    int zlng = c_armn_compress32_dev(d_z, d_f, ni, nj, nk, znbits);
+    if (zlng > 0 && (ezhip_d2h(zstream, d_z, (size_t)zlng) || ezhip_sync())) zlng = -1;
+    ezhip_sync();
+    return zlng;
+}
+
+/* bit position of every tile header of a parallelogram stream (host words): 3-bit width-field size, row 1, column 1, then the chain */
+static uint64_t *walk_tiles(const uint32_t *z, int ni, int nj, int nbits, size_t *ntiles_out)
+{
+    uint64_t pos = 0;
+    const int container = (int)br32_get(z, &pos, 3);
+    pos += (uint64_t)(ni + nj - 1) * (uint64_t)nbits;
+    const int ntx = (ni - 1 + 2) / 3, nty = (nj - 1 + 2) / 3;
+    uint64_t *tp = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)ntx * nty + 1));
+    if (!tp) return NULL;
+    size_t t = 0;
+    for (int ty = 0; ty < nty; ty++) {
+        const int tn = nj - (1 + 3 * ty) < 3 ? nj - (1 + 3 * ty) : 3;
+        for (int tx = 0; tx < ntx; tx++, t++) {
+            const int tm = ni - (1 + 3 * tx) < 3 ? ni - (1 + 3 * tx) : 3;
+            tp[t] = pos;
+            uint64_t p2 = pos;
+            const int need = (int)br32_get(z, &p2, container);
+            pos += (uint64_t)container + (need ? (uint64_t)(tm * tn) * (uint64_t)(need + 1) : 0);
+        }
+    }
+    tp[t] = pos;
+    *ntiles_out = t;
+    return tp;
+}
+
+/* one plane back: host stream words -> device plane of ints (slot: which workspaces) */
+static int decode_plane(int *d_plane, const uint32_t *z, int ni, int nj, int nbits, int wide, int slot)
+{
+    size_t ntiles = 0;
+    uint64_t *tp = walk_tiles(z, ni, nj, nbits, &ntiles);
+    if (!tp) return -1;
+    const size_t zwords = (size_t)((tp[ntiles] + 63) >> 5) + 2;
+    unsigned *d_zs = (unsigned *)w32(slot, 4 * zwords);
+    unsigned long long *d_tp = (unsigned long long *)w32(slot + 1, 8 * (ntiles + 1));
+    int *d_bs = (int *)w32(5, 4 * (size_t)ni * ((size_t)(nj + 31) / 32 + 1));
+    int rc = -1;
+    if (d_zs && d_tp && d_bs && !ezhip_h2d(d_zs, z, 4 * zwords) && !ezhip_h2d(d_tp, tp, 8 * (ntiles + 1)))
+        rc = packhip_pg_decode(d_plane, d_bs, d_zs, d_tp, ni, nj, nbits, wide);
+    if (ezhip_sync()) rc = -1;
+    free(tp);
+    return rc;
+}
+
+/* c_armn_uncompress32 with the result on the device; zstream: HOST memory (the chain of tile headers is walked on the host) */
+int c_armn_uncompress32_dev(float *d_fld, const unsigned char *zstream, int ni, int nj, int nk, int znbits)
+{
+    (void)nk; (void)znbits;
+    if (need_dev32("c_armn_uncompress32")) return -1;
+    const size_t n = (size_t)ni * nj;
+    const uint32_t *cur = (const uint32_t *)zstream;
+    const uint32_t w0 = cur[0], info = cur[1];
+    cur += 2;
+    if ((w0 & 15u) != 5u) { fprintf(stderr, "<c_armn_uncompress32> not a PARALLELOGRAM32 stream\n"); return -1; }
+    const int nbits = (int)((w0 >> 10) & 31);
+    const uint32_t exp_min = info >> 16, need_e = (info >> 8) & 0xFF, codes = info & 0xFF;
+    const int code_signe = (int)(codes & 0x30), code_expo = (int)(codes & 0xC), code_mant = (int)(codes & 0x3);
+    if (code_mant != 0) { fprintf(stderr, "<c_armn_uncompress32> plain mantissa streams are not produced by c_armn_compress32\n"); return -1; }
+    unsigned *d_smask = (unsigned *)w32(2, 4 * (n / 32 + 2) + 16);
+    int *d_expo = (int *)w32(0, 4 * n + 16), *d_mant = (int *)w32(1, 4 * n + 16);
+    if (!d_smask || !d_expo || !d_mant) return -1;
+    if (code_signe == 0x20 || code_signe == 0x30) {
+        const uint32_t lng = *cur++;
+        uint32_t *mask = (uint32_t *)calloc(n / 32 + 2 + 16, 4);
+        if (!mask) return -1;
+        rle_decode(mask, cur, (int)n);
+        int bad = ezhip_h2d(d_smask, mask, 4 * (n / 32 + 1)) || ezhip_sync();
+        free(mask);
+        if (bad) return -1;
+        cur += lng >> 2;
+    }
+    if (code_expo == 0x08 || code_expo == 0x0C) {
+        const uint32_t lng = *cur++;
+        if (decode_plane(d_expo, cur, ni, nj, (int)need_e, 0, 3)) return -1;
+        cur += lng >> 2;
+    }
+    cur++;                                                       /* the mantissa length slot */
+    if (decode_plane(d_mant, cur, ni, nj, nbits, 1, 3)) return -1;
+    if (packhip_a32_combine(d_fld, d_expo, d_mant, d_smask, n, nbits, exp_min, code_signe, code_expo != 0)) return -1;
+    return (int)n;
+}
+
+int c_armn_uncompress32(float *fld, unsigned char *zstream, int ni, int nj, int nk, int znbits)
+{
+    if (need_dev32("c_armn_uncompress32")) return -1;
+    const size_t n = (size_t)ni * nj;
+    float *d_f = (float *)w32(6, 4 * n);
+    if (!d_f) return -1;
+    int rc = c_armn_uncompress32_dev(d_f, zstream, ni, nj, nk, znbits);
+    if (rc > 0 && (ezhip_d2h(fld, d_f, 4 * n) || ezhip_sync())) rc = -1;
+    ezhip_sync();
+    return rc;
+}
+/* Fortran twins (armn_compress_32.c:53-56, :280-283) */
+int armn_compress32_(unsigned char *zstream, float *fld, int *ni, int *nj, int *nk, int *nbits) { return c_armn_compress32(zstream, fld, *ni, *nj, *nk, *nbits); }
+int armn_uncompress32_(float *fld, unsigned char *zstream, int *ni, int *nj, int *nk, int *nbits) { return c_armn_uncompress32(fld, zstream, *ni, *nj, *nk, *nbits); }

@@ -1723,6 +1723,7 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
                 if (rb >= 1) { p.x_rb = rb; p.x_nseg = (p.x_nvb + rb - 1) / rb; }
             }
             if (getenv("EZHIP_SINGLE_RB")) { int rb = atoi(getenv("EZHIP_SINGLE_RB")); if (rb >= 1) { p.x_rb = rb; p.x_nseg = (p.x_nvb + rb - 1) / rb; } }
+            if (getenv("EZHIP_SPECIAL_PCT")) { int pct = atoi(getenv("EZHIP_SPECIAL_PCT")); if (pct >= 0 && pct <= 100) p.special_last = 2 + p.x_nseg * pct / 100; }     /* development: special rows at pct % of the work order */
         }
         if (p.need_poles && !d_poles_pre) {
             /* k_sepx sums the pole rows itself (producer blocks at the head of the launch): 43 us per lone cfg2 field

@@ -748,7 +748,7 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
     /* special rows sit in the MIDDLE of the field's work order: their gathers are latency-bound (tens of us per block),
      * so they must overlap main blocks (last in the order they became an exposed tail: +6 us per field), and by then
      * the pole producers have long finished */
-    const int sp0 = p.special_last ? p.x_nseg : p.x_nseg >> 1;      /* a lone field: last (nothing to overlap, and they must not hold slots while the pole producers run) */
+    const int sp0 = p.special_last ? (p.special_last > 1 ? min(p.special_last - 2, p.x_nseg) : p.x_nseg) : p.x_nseg >> 1;      /* a lone field: last (nothing to overlap, and they must not hold slots while the pole producers run) */
     if (by >= sp0 && by < sp0 + p.n_special) {
         if (P) {
             p.polevals = p.pole_vals + 2 * bz;

@@ -57,6 +57,13 @@ int packhip_swap_halves(unsigned *d_dst, const unsigned *d_src, size_t nwords);
 size_t packhip_armn_dec_work_bytes(int ni, int nj, size_t z_words);
 int packhip_armn_decode(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
                         int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status);
+/* ---- IEEE-32 compressor (armn32_kernels.hip): planes of a float field and the parallelogram coder on a plane ---- */
+int packhip_a32_split(unsigned char *d_expo, unsigned *d_mant, unsigned *d_smask, unsigned *d_stats, const float *d_f, size_t n, int nbits, unsigned *h_stats4);
+size_t packhip_pg_work_bytes(int ni, int nj);
+int packhip_pg_encode(unsigned *d_z, size_t z_words, const void *d_u, int elem_bytes, int ni, int nj, int nbits, long long remaining_space, void *d_work);
+int packhip_pg_result(void *d_work, int ni, int nj, int nbits, unsigned long long *bits, int *failed);
+int packhip_pg_decode(int *d_D, int *d_bs, const unsigned *d_z, const unsigned long long *d_tpos, int ni, int nj, int nbits, int wide);
+int packhip_a32_combine(float *d_f, const int *d_expo, const int *d_mant, const unsigned *d_smask, size_t n, int nbits, unsigned exp_min, int code_signe, int have_expo);
 #ifdef __cplusplus
 }
 #endif

@@ -207,3 +207,21 @@ def compact_narrow_unpack(out, n, nbits, dtype, hdr=None, offset=0, stride=1, fi
     fn = _lib().compact_short if dtype == np.uint16 else _lib().compact_char
     rc = fn(a.ctypes.data, hdr.ctypes.data if hdr is not None else None, out.ctypes.data, n, nbits, offset, stride, 6 if dtype == np.uint16 else 10)
     return rc, a
+
+
+def armn_compress32(fld, ni, nj, znbits):
+    """c_armn_compress32 on a float32 field (host): returns (zlng, uint32 stream words) ; zlng = -1 when not compressible"""
+    f = np.ascontiguousarray(fld, dtype=np.float32)
+    L = _lib()
+    L.c_armn_compress32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    z = np.zeros(ni * nj * max(znbits, 8) // 32 + 64, np.uint32)
+    zlng = L.c_armn_compress32(z.ctypes.data, f.ctypes.data, ni, nj, 1, znbits)
+    return zlng, z
+
+
+def armn_uncompress32(z, ni, nj, znbits):
+    L = _lib()
+    L.c_armn_uncompress32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    out = np.zeros(ni * nj, np.float32)
+    rc = L.c_armn_uncompress32(out.ctypes.data, z.ctypes.data, ni, nj, 1, znbits)
+    return rc, out

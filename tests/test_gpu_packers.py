@@ -513,3 +513,51 @@ def test_known_answers_on_the_gpu():
     buf = np.zeros(16 * 16 // 2 + 8, np.uint32); buf[:128] = pc.tokens_to_words(tok)
     assert pk.armn_compress(buf, 16, 16, 16) == zlng
     assert [int(x) for x in buf[:len(words)]] == words
+
+
+# ---------------------------------------------------------------------------------------------
+# c_armn_compress32 / c_armn_uncompress32 (datyp 133): the IEEE-32 compressor
+# ---------------------------------------------------------------------------------------------
+import test_oracle_armn32 as ta32   # noqa: E402
+
+A32_SHAPES = [(16, 16), (17, 19), (64, 48), (100, 31), (301, 200), (1000, 777), (3073, 40)]
+
+
+@pytest.mark.parametrize("ni,nj", A32_SHAPES)
+@pytest.mark.parametrize("kind", ta32.KINDS)
+@pytest.mark.parametrize("znbits", [32, 24, 16])
+def test_armn_compress32_bit_exact(ni, nj, kind, znbits):
+    """the HIP encoder against the oracle's restatement of c_armn_compress32: same byte count, same bytes; then the HIP decoder (and the
+    oracle's) bring back the field with its mantissas cut to znbits - 9 bits"""
+    f = ta32.field32(ni, nj, kind, seed=ni + nj)
+    zw = np.zeros(ni * nj * max(znbits, 8) // 32 + 1024, np.uint32)
+    want = ta32.O().orc_armn_compress32(zw.ctypes.data, f.ctypes.data, ni, nj, 1, znbits)
+    got, zg = pk.armn_compress32(f, ni, nj, znbits)
+    assert got == want, (got, want)
+    if want < 0:
+        return
+    assert np.array_equal(zg[:want // 4], zw[:want // 4]), np.nonzero(zg[:want // 4] != zw[:want // 4])[0][:5]
+    rc, back = pk.armn_uncompress32(zg, ni, nj, znbits)
+    assert rc == ni * nj
+    assert np.array_equal(back.view(np.uint32), ta32.truncated(f, znbits).view(np.uint32)), int((back != ta32.truncated(f, znbits)).sum())
+    back_o = np.zeros(ni * nj, np.float32)
+    ta32.O().orc_armn_uncompress32(back_o.ctypes.data, zg.ctypes.data, ni, nj, 1, znbits)
+    assert np.array_equal(back_o.view(np.uint32), back.view(np.uint32))
+
+
+def test_armn_compress32_refusals_and_full_size():
+    f = ta32.random_bits_field(64, 48, seed=9)
+    assert pk.armn_compress32(f, 64, 48, 32)[0] == -1                 # incompressible: as the oracle says
+    assert pk.armn_compress32(ta32.field32(15, 40, "positive", 1), 15, 40, 32)[0] == -1
+    # a full-size cfg2 output-like field (7200 x 3601), positive and mixed signs: HIP == oracle, round trip
+    import ezcases as ec
+    ni, nj = 7200, 3601
+    for kind in ("positive", "mixed"):
+        f = ta32.field32(ni, nj, kind, seed=5)
+        zw = np.zeros(ni * nj + 1024, np.uint32)
+        want = ta32.O().orc_armn_compress32(zw.ctypes.data, f.ctypes.data, ni, nj, 1, 32)
+        got, zg = pk.armn_compress32(f, ni, nj, 32)
+        assert got == want and want > 0
+        assert np.array_equal(zg[:want // 4], zw[:want // 4])
+        rc, back = pk.armn_uncompress32(zg, ni, nj, 32)
+        assert rc == ni * nj and np.array_equal(back.view(np.uint32), f.view(np.uint32))
