@@ -102,6 +102,15 @@ int32_t ezhip_pack16_compress_batch_dev(void *d_records, int64_t record_stride_w
  * Returns 0, -1 on error, -2 when the grid set / shape is outside the fused path (use the two calls above instead). */
 int32_t ezhip_ezsint_pack16_compress_batch_dev(void *d_records, int64_t record_stride_words, const float *d_zin, int32_t nfields,
                                                int32_t ni_out, int32_t nj_out, int32_t nbits, int32_t *zlng_out);
+/* ---- FST record framing around the packers ---------------------------------------------------------------------
+ * The DATA PART of an FST record exactly as c_fstecr lays it out from buffer->data[keys_len] on (src/fstd98/fstd98.c:935-1000 sizes,
+ * :1140-1370 the datyp switch): for datyp > 128 the length word, the packer header(s), the armn_compress stream; compression that does
+ * not pay falls back to the plain type (*datyp_out).  32-bit elements; datyp 0, 1, 129, 2, 130, 4, 5 (32 bits), 6, 134, 133.
+ * Returns the number of 32-bit words of the data part (what c_xdfput would be given) or -1.  The read side (:2270-2440) expands the
+ * stream in place in `data` like the reference does in its record buffer. */
+int32_t ezhip_fst_pack_data(uint32_t *data, int64_t cap_words, void *field, int32_t ni, int32_t nj, int32_t nk, int32_t datyp, int32_t nbits,
+                            int32_t *datyp_out, int32_t *nbits_out);
+int32_t ezhip_fst_unpack_data(void *field, uint32_t *data, int32_t ni, int32_t nj, int32_t nk, int32_t datyp, int32_t nbits);
 /* frees the calling thread's grow-only device workspaces (staged operands of the host-pointer entry points,
  * the compressed stream, the armn_compress scan storage); they are re-created on the next call */
 void  ezhip_pack_release(void);

@@ -225,3 +225,24 @@ def armn_uncompress32(z, ni, nj, znbits):
     out = np.zeros(ni * nj, np.float32)
     rc = L.c_armn_uncompress32(out.ctypes.data, z.ctypes.data, ni, nj, 1, znbits)
     return rc, out
+
+
+def fst_pack_data(field, ni, nj, nk, datyp, nbits):
+    """the data part of an FST record (c_fstecr's packing switch): returns (words, datyp_out, nbits_out, uint32 buffer)"""
+    L = _lib()
+    L.ezhip_fst_pack_data.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_int32] * 5 + [ctypes.c_void_p] * 2
+    f = np.ascontiguousarray(field)
+    n = ni * nj * nk
+    cap = n * max(nbits, 16) // 32 + n // 8 + 256
+    buf = np.zeros(cap, np.uint32)
+    d = ctypes.c_int32(-1); b = ctypes.c_int32(-1)
+    w = L.ezhip_fst_pack_data(buf.ctypes.data, cap, f.ctypes.data, ni, nj, nk, datyp, nbits, ctypes.addressof(d), ctypes.addressof(b))
+    return w, d.value, b.value, buf
+
+
+def fst_unpack_data(buf, ni, nj, nk, datyp, nbits, dtype=np.float32):
+    L = _lib()
+    L.ezhip_fst_unpack_data.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 5
+    out = np.zeros(ni * nj * nk, dtype)
+    rc = L.ezhip_fst_unpack_data(out.ctypes.data, buf.ctypes.data, ni, nj, nk, datyp, nbits)
+    return rc, out

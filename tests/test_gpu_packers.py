@@ -561,3 +561,62 @@ def test_armn_compress32_refusals_and_full_size():
         assert np.array_equal(zg[:want // 4], zw[:want // 4])
         rc, back = pk.armn_uncompress32(zg, ni, nj, 32)
         assert rc == ni * nj and np.array_equal(back.view(np.uint32), f.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------
+# FST record framing: the data part of a record as c_fstecr builds it
+# ---------------------------------------------------------------------------------------------
+import fst_twin   # noqa: E402
+
+FST_CASES = [(1, 12), (1, 16), (1, 24), (129, 12), (129, 16), (6, 12), (6, 16), (6, 20), (6, 28), (134, 12), (134, 16), (133, 32), (133, 24), (5, 32), (0, 32)]
+
+
+@pytest.mark.parametrize("datyp,nbits", FST_CASES)
+@pytest.mark.parametrize("kind", ["smooth", "rough"])
+def test_fst_record_data_part_float(datyp, nbits, kind):
+    """ezhip_fst_pack_data against the test twin of c_fstecr's switch built from the oracle's packers: same final datyp, same word count, same
+    words (the stream's last, undefined byte aside); ezhip_fst_unpack_data then returns what the oracle's unpackers return"""
+    ni, nj, nk = 120, 75, 1
+    n = ni * nj
+    f = pc.float_field(n, seed=3) if kind == "smooth" else (ec_hash(n) * np.float32(1000.0)).astype(np.float32)
+    w, d_out, b_out, got = pk.fst_pack_data(f, ni, nj, nk, datyp, nbits)
+    ww, dw, want = fst_twin.pack(f, ni, nj, nk, datyp, nbits)
+    assert (w, d_out) == (ww, dw), (w, ww, d_out, dw)
+    # the words the reference DEFINES: the byte after an armn stream is undefined, and behind a refused compression the tail of the
+    # record keeps what the first attempt left there
+    m = {0: n * b_out // 32, 5: n, 1: (120 + n * b_out) // 32, 6: 3 + n // 2}.get(d_out, w - 2)
+    assert np.array_equal(got[:m], want[:m]), (datyp, nbits, np.nonzero(got[:m] != want[:m])[0][:5])
+    rc, back = pk.fst_unpack_data(got.copy(), ni, nj, nk, d_out, b_out)
+    assert rc == 0
+    back_w = fst_twin.unpack(want, ni, nj, nk, d_out, b_out)
+    assert np.array_equal(back.view(np.uint32), back_w.view(np.uint32)), int((back != back_w).sum())
+    if d_out in (0, 5) or (d_out == 133 and nbits == 32):
+        assert np.array_equal(back.view(np.uint32), f.view(np.uint32))
+    elif not (d_out == 129 and nbits < 16):      # (the reference reads a 129 record with fewer than 16 bits as contiguous tokens although they sit in 16-bit slots)
+        scale = float(np.abs(f).max())
+        mant = b_out - 9 if d_out == 133 else min(b_out, 23)
+        assert np.abs(back - f).max() <= scale * 2.0 ** (-(mant - 1)) * 1.01, float(np.abs(back - f).max())
+
+
+def ec_hash(n):
+    import ezcases as ec
+    return ec.hash_uniform(12, n)
+
+
+@pytest.mark.parametrize("datyp,nbits", [(2, 12), (2, 16), (2, 31), (130, 12), (130, 16), (4, 12), (4, 24)])
+def test_fst_record_data_part_integer(datyp, nbits):
+    ni, nj, nk = 100, 60, 1
+    n = ni * nj
+    rng = np.random.default_rng(nbits)
+    if datyp == 4:
+        f = rng.integers(-(1 << (nbits - 1)) + 1, (1 << (nbits - 1)) - 1, n).astype(np.int32)
+    else:
+        i = np.arange(n) % ni; j = np.arange(n) // ni
+        f = ((i * 7 + j * 3) % (1 << min(nbits, 15))).astype(np.int32)          # smooth enough for armn_compress
+    w, d_out, b_out, got = pk.fst_pack_data(f, ni, nj, nk, datyp, nbits)
+    ww, dw, want = fst_twin.pack(f, ni, nj, nk, datyp, nbits)
+    assert (w, d_out) == (ww, dw)
+    m = w - 2 if d_out > 128 else (n * nbits + 31) // 32
+    assert np.array_equal(got[:m], want[:m]), np.nonzero(got[:m] != want[:m])[0][:5]
+    rc, back = pk.fst_unpack_data(got.copy(), ni, nj, nk, d_out, b_out, dtype=np.int32)
+    assert rc == 0 and np.array_equal(back, f)
