@@ -634,7 +634,7 @@ __device__ __forceinline__ void sepx_ypass(const float *myrec, const double *tco
  * ds_read_b128 (the LDS cycles of the 32 ds_read_b64 of the float form) and 4 dword stores of 128 contiguous bytes per
  * row.  Same fma chains, same float rounding, then compact_float's quantisation (compact.tmplc:285-300). */
 typedef double d2_t __attribute__((ext_vector_type(2)));
-template <int DEG, int XR>
+template <int DEG, int XR, bool QNT>
 __device__ __forceinline__ void sepx_ypass_q(const float *myrec, const double *tcol2, unsigned *zw, const QuantP &qp)
 {
 #pragma unroll
@@ -675,7 +675,7 @@ __device__ __forceinline__ void sepx_ypass_q(const float *myrec, const double *t
                 else val = fma(w3, t[g][3][e], fma(w2, t[g][2][e], fma(w1, t[g][1][e], w0 * t[g][0][e])));
                 tk[e] = quant16((float)val, qp);
             }
-            __builtin_nontemporal_store(tk[0] << 16 | tk[1], &orow[32 * g]);
+            if (QNT) __builtin_nontemporal_store(tk[0] << 16 | tk[1], &orow[32 * g]); else orow[32 * g] = tk[0] << 16 | tk[1];
         }
     }
 }
@@ -875,7 +875,8 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
         if (!(dbg & 16)) {
             const float *myrec = rec + (i & 1) * SEPX_REC_DW + (2 * wv + rsub) * 16;
             if (slow) sepx_ypass<DEG, XR, true, OUT>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, (dbg & 1) != 0, vmin, vmax, qp);
-            else if (OUT == 3) sepx_ypass_q<DEG, XR>(myrec, T + 2 * l32, (unsigned *)zout + (size_t)bx * (SEP_BLOCK / 2) + l32, qp);
+            else if (OUT == 3) { if (dbg & 256) sepx_ypass_q<DEG, XR, true>(myrec, T + 2 * l32, (unsigned *)zout + (size_t)bx * (SEP_BLOCK / 2) + l32, qp);
+                                 else sepx_ypass_q<DEG, XR, false>(myrec, T + 2 * l32, (unsigned *)zout + (size_t)bx * (SEP_BLOCK / 2) + l32, qp); }
             else sepx_ypass<DEG, XR, false, OUT>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, false, vmin, vmax, qp);
         }
         st = nst;
