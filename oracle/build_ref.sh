@@ -15,6 +15,10 @@
 #     (oracle/orc_igaxg.c, -DORC_FORTRAN_ABI).  This is the one non-reference piece of the .so.
 #   * The packers / compressor (src/packers, src/compresseur) #include <App.h> from the same
 #     absent submodule: unbuildable here, NOT part of this build ("parity unpinned" for them).
+#   * src/interpv (vertical interpolation): Interp1D_Constants, Interp1D_FindPos, Interp1D_NearestNeighbour,
+#     Extrap1D_Fixed and Extrap1D_LapseRate compile unmodified into oracle/_ref/libinterpvref.so.  Interp1D_Linear,
+#     Interp1D_CubicLagrange, Interp1D_CubicWithDerivs, Extrap1D_Abort, Extrap1D_Surface, Extrap1D_SurfaceWind
+#     `use app` (same absent submodule): unbuildable, not part of the build.
 #   * FST file-I/O symbols (c_fstinf, fstluk_, fnom_ ...) referenced by grid-from-file code are
 #     left UNDEFINED; the library is loaded with lazy binding and those paths are never called.
 set -euo pipefail
@@ -46,4 +50,13 @@ done
 gcc $CFLAGS -DORC_FORTRAN_ABI -c "$HERE/orc_igaxg.c" -o "$B/orc_igaxg_fabi.o"
 "$FL" -shared -Wl,-z,lazy -Wl,-Bsymbolic -o "$OUT/libezref.so" "$B"/*.o -lm
 echo "build_ref: wrote $OUT/libezref.so"
+BV=$HERE/_build/refv
+mkdir -p "$BV"
+V=$R/src/interpv
+for f in Interp1D_Constants Interp1D_FindPos Interp1D_NearestNeighbour Extrap1D_Fixed Extrap1D_LapseRate; do
+  o=$BV/$f.o
+  [ "$o" -nt "$V/$f.F90" ] || ( cd "$BV" && "$FL" $FFLAGS -I "$V" -c "$V/$f.F90" -o "$o" 2>/dev/null )
+done
+"$FL" -shared -o "$OUT/libinterpvref.so" "$BV"/*.o -lm
+echo "build_ref: wrote $OUT/libinterpvref.so"
 nm -D --undefined-only "$OUT/libezref.so" | grep -v -E "GLIBC|_Fortran|__cxa|__gmon|_ITM|__deregister|__register" | awk '{print "  undefined (never called):", $2}'
