@@ -9,6 +9,6 @@ There is no CPU fallback: importing works anywhere, but every compute call needs
 library and a HIP device and raises/returns an error otherwise.
 """
 from .lib import load_library, library_path, build_library   # noqa: F401
-from . import ezscint, packers                                 # noqa: F401
+from . import ezscint, packers, interpv                        # noqa: F401
 
-__all__ = ["load_library", "library_path", "build_library", "ezscint", "packers"]
+__all__ = ["load_library", "library_path", "build_library", "ezscint", "packers", "interpv"]

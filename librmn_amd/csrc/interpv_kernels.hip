@@ -1,0 +1,255 @@
+/*
+ * interpv_kernels.hip -- gfx950 kernel of the 1-D (vertical) interpolation package, SURVEY.md 8f row 4.
+ *
+ * Replaces the column loops of src/interpv:
+ *   Interp1D_FindPos_Body.inc:80-144           bracket search (REAL index / uncertainty halving)
+ *   Interp1D_NearestNeighbour_Body.inc:68-97   Interp1D_Linear_Body.inc:83-112
+ *   Interp1D_CubicLagrange_Body.inc:112-157    Interp1D_CubicWithDerivs_Body.inc:151-200
+ *   Extrap1D_Fixed_Body.inc:80-99              Extrap1D_LapseRate_Body.inc:92-116        Extrap1D_Abort_Body.inc:70-92
+ *
+ * One kernel, k_interpv: a block owns COLS adjacent columns (the fast index of every array, so each level row is one
+ * contiguous COLS * sizeof(REAL) segment) and all, or a slice of, the destination levels.  The block's source levels
+ * are staged once in LDS ([level][column]: bank = column, conflict-free), because the search reads them
+ * 2 * log2(srcNumLevels) times per destination value; state values are read where the bracket points (twice to
+ * eight times per value, neighbouring columns share rows, served by L2).  Every thread walks its column's destination
+ * levels four at a time so that four independent searches overlap their LDS latencies.  Search, interpolation and
+ * extrapolation are stages of the same pass: a caller that wants all three pays the level / state traffic once and
+ * never materialises posnDestInSrc.
+ *
+ * Arithmetic: the type and operation order of the reference text, no contraction (-ffp-contract=off in the Makefile):
+ * REAL (float) or REAL*8 for NearestNeighbour / Linear / LapseRate, REAL*8 always for the two cubics.
+ * HBM-bound: bytes per column = (ns * narrays_in + nd * (1 + narrays_out)) * sizeof(REAL) (+ 4 * nd when the brackets
+ * are written or read).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ezhip_shim.h"
+#include "interpv_shim.h"
+
+#define IV_THREADS 256
+#define IV_TU 4                         /* destination levels in flight per thread */
+#define IV_LDS_MAX (80 * 1024)          /* staged levels per block: two blocks per CU */
+
+template <typename R>
+struct iv_args {
+    int algo, extrap, find, write_posn;
+    int n, ns, nd, sij, dij;
+    const R *vls, *ss, *sds;
+    int *posn;
+    const R *vld;
+    R *sd, *sdd;
+    int xdown, xup;
+    R gdown, gup;
+    unsigned long long *abort_key;
+    int t_per_block;
+};
+
+/* COLS = 0: levels are read from memory (srcNumLevels too large for LDS), 64 columns per wave */
+template <typename R, int COLS>
+__global__ __launch_bounds__(IV_THREADS) void k_interpv(iv_args<R> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char iv_smem[];
+    R *lev = (R *)iv_smem;
+    constexpr int C = COLS ? COLS : IV_THREADS;
+    constexpr int NTG = IV_THREADS / C;                       /* groups of threads sharing the block's columns */
+    const int lc = threadIdx.x % C, tg = threadIdx.x / C;
+    const long long i = (long long)blockIdx.x * C + lc;
+    const bool live = i < a.n;
+    const size_t sij = (size_t)a.sij, dij = (size_t)a.dij;
+    const int ns = a.ns;
+    if (COLS) {
+        for (int k = tg; k < ns; k += NTG) lev[(size_t)k * C + lc] = live ? a.vls[i + (size_t)k * sij] : (R)0;
+        __syncthreads();
+    }
+    if (!live) return;
+    const R *vcol = a.vls + i;
+#define LEV(k) (COLS ? lev[(size_t)((k) - 1) * C + lc] : vcol[(size_t)((k) - 1) * sij])
+#define SSRC(k) a.ss[i + (size_t)((k) - 1) * sij]
+#define DSRC(k) a.sds[i + (size_t)((k) - 1) * sij]
+    /* direction of the levels: column 1 speaks for all (Interp1D_FindPos_Body.inc:88, Interp1D_Linear_Body.inc:73) */
+    const bool asc = a.vls[sij] > a.vls[0];
+    const int smallest = asc ? 1 : ns, largest = asc ? ns : 1;
+    const int loposn = asc ? 1 : ns - 1, hiposn = asc ? ns - 1 : 1;
+    const int t_begin = blockIdx.y * a.t_per_block, t_end = min(a.nd, t_begin + a.t_per_block);
+
+    for (int tb = t_begin + tg * IV_TU; tb < t_end; tb += NTG * IV_TU) {
+        R v[IV_TU];
+        int p[IV_TU];
+#pragma unroll
+        for (int u = 0; u < IV_TU; u++) {
+            const int t = min(tb + u, t_end - 1);
+            v[u] = a.vld[i + (size_t)t * dij];
+        }
+        if (a.find) {
+            float idx[IV_TU];
+#pragma unroll
+            for (int u = 0; u < IV_TU; u++) idx[u] = 0.5f * (float)(ns + 1);
+            float unc = 0.5f * (float)(ns - 1);
+            while (unc > 0.95f) {
+                unc = 0.5f * unc;
+                const float up = asc ? unc : -unc;
+#pragma unroll
+                for (int u = 0; u < IV_TU; u++) {
+                    const int ii = (int)idx[u];
+                    const R l0 = LEV(ii), l1 = LEV(ii + 1);
+                    if (v[u] >= l0) idx[u] = idx[u] + up;
+                    if (v[u] <= l1) idx[u] = idx[u] - up;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < IV_TU; u++) p[u] = (int)idx[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < IV_TU; u++) {
+                const int t = min(tb + u, t_end - 1);
+                p[u] = min(max(a.posn[i + (size_t)t * dij], 1), ns - 1);     /* a bracket outside 1..ns-1 would read outside the arrays */
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < IV_TU; u++) {
+            const int t = tb + u;
+            if (t >= t_end) break;
+            const size_t o = i + (size_t)t * dij;
+            const R x = v[u];
+            const int q = p[u];
+            if (a.find && a.write_posn) a.posn[o] = q;
+            R out = 0, outd = 0;
+            bool have = false, have_d = false;
+            switch (a.algo) {
+            case IV_NEAREST: {
+                const R lb = LEV(q), la = LEV(q + 1);
+                out = (fabs(x - lb) < fabs(x - la)) ? SSRC(q) : SSRC(q + 1);
+                have = true;
+                break;
+            }
+            case IV_LINEAR: {
+                const R lev1 = LEV(q), lev2 = LEV(q + 1), s1 = SSRC(q), s2 = SSRC(q + 1);
+                const R slope = (s2 - s1) / (lev2 - lev1);
+                out = slope * (x - lev1) + s1;
+                have = true;
+                break;
+            }
+            case IV_CUBIC_LAGRANGE: {
+                const int f = max(min(q - 1, ns - 3), 1);
+                const double x1 = LEV(f), x2 = LEV(f + 1), x3 = LEV(f + 2), x4 = LEV(f + 3);
+                const double z1 = SSRC(f), z2 = SSRC(f + 1), z3 = SSRC(f + 2), z4 = SSRC(f + 3);
+                const double cx1 = 1.0 / (x2 - x1), cx2 = 1.0 / (x3 - x1), cx3 = 1.0 / (x3 - x2);
+                const double cx4 = 1.0 / (x4 - x1), cx5 = 1.0 / (x4 - x2), cx6 = 1.0 / (x4 - x3);
+                const double a1 = z1;
+                const double a2 = cx1 * (z2 - z1);
+                const double a3 = cx2 * (cx3 * (z3 - z2) - cx1 * (z2 - z1));
+                const double a4 = cx4 * (cx5 * (cx6 * (z4 - z3) - cx3 * (z3 - z2)) - cx2 * (cx3 * (z3 - z2) - cx1 * (z2 - z1)));
+                const double xt = x;
+                out = (R)(a1 + (xt - x1) * (a2 + (xt - x2) * (a3 + a4 * (xt - x3))));
+                have = true;
+                break;
+            }
+            case IV_CUBIC_DERIVS: {
+                const double lb = LEV(q), la = LEV(q + 1);
+                const double lc_ = 0.5 * (lb + la);
+                const double sb0 = SSRC(q), sa0 = SSRC(q + 1), sb1 = DSRC(q), sa1 = DSRC(q + 1);
+                const double dlin2 = la - lb;
+                const double o2 = 1 / dlin2;
+                const double dltar = (double)x - lc_;
+                const double dd = 0.125 * dlin2 * dlin2 - 0.5 * dltar * dltar;
+                const double sc0 = 0.5 * (sa0 + sb0);
+                const double sc1 = (sa0 - sb0) * o2;
+                const double sc2 = (sa1 - sb1) * o2;
+                const double sc3 = ((sa1 - sc1) - (sc1 - sb1)) * o2 * o2;
+                const double st2 = sc2 + 2. * dltar * sc3;
+                const double st1 = sc1 + dltar * st2;
+                const double st0 = sc0 + dltar * sc1;
+                out = (R)(st0 - dd * st2);
+                outd = (R)(st1 - 2. * dd * sc3);
+                have = have_d = true;
+                break;
+            }
+            default: break;
+            }
+            if (a.algo >= IV_LINEAR) {                          /* the clamp that closes the three polynomial routines */
+                if (!a.xdown && x < LEV(smallest)) { out = SSRC(smallest); if (have_d) outd = DSRC(smallest); }
+                else if (!a.xup && x > LEV(largest)) { out = SSRC(largest); if (have_d) outd = DSRC(largest); }
+            }
+            if (a.extrap) {
+                int side = -1;                                    /* 0 below the lowest level, 1 above the highest */
+                if (a.xdown && q == loposn) { if (x < LEV(smallest)) side = 0; }
+                else if (a.xup && q == hiposn) { if (x > LEV(largest)) side = 1; }
+                if (side >= 0) {
+                    const int e = side ? largest : smallest;
+                    if (a.extrap == IVX_FIXED) { out = side ? a.gup : a.gdown; have = true; }
+                    else if (a.extrap == IVX_LAPSERATE) {
+                        const R d = x - LEV(e);
+                        const R pr = (side ? a.gup : a.gdown) * d;
+                        out = SSRC(e) + pr;
+                        have = true;
+                    } else {
+                        atomicMin(a.abort_key, (((unsigned long long)t * (unsigned long long)a.n + (unsigned long long)i) << 1) | (unsigned)side);
+                    }
+                }
+            }
+            if (have) a.sd[o] = out;
+            if (have_d) a.sdd[o] = outd;
+        }
+    }
+#undef LEV
+#undef SSRC
+#undef DSRC
+}
+
+template <typename R, int COLS>
+static int launch_cols(const iv_args<R> &a0, hipStream_t st)
+{
+    iv_args<R> a = a0;
+    constexpr int C = COLS ? COLS : IV_THREADS;
+    const unsigned bx = (unsigned)(((long long)a.n + C - 1) / C);
+    /* few columns: slice the destination levels over blockIdx.y until the chip is covered */
+    int slices = 1;
+    const int chunk = (IV_THREADS / C) * IV_TU;
+    while (slices < 64 && (long long)bx * slices < 2048 && (a.nd + slices - 1) / slices > chunk) slices *= 2;
+    a.t_per_block = (((a.nd + slices - 1) / slices) + chunk - 1) / chunk * chunk;
+    const unsigned by = (unsigned)((a.nd + a.t_per_block - 1) / a.t_per_block);
+    const size_t lds = COLS ? (size_t)COLS * a.ns * sizeof(R) : 0;
+    if (lds > 64 * 1024) {
+        static bool raised[2][4];
+        bool &r = raised[sizeof(R) == 8][COLS == 256 ? 0 : COLS == 128 ? 1 : COLS == 64 ? 2 : 3];
+        if (!r) { if (hipFuncSetAttribute((const void *)k_interpv<R, COLS>, hipFuncAttributeMaxDynamicSharedMemorySize, IV_LDS_MAX) != hipSuccess) return -1; r = true; }
+    }
+    hipLaunchKernelGGL((k_interpv<R, COLS>), dim3(bx, by), dim3(IV_THREADS), lds, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <typename R>
+static int launch_typed(const ivhip_args *h)
+{
+    iv_args<R> a;
+    a.algo = h->algo; a.extrap = h->extrap; a.find = h->find; a.write_posn = h->write_posn;
+    a.n = h->n; a.ns = h->ns; a.nd = h->nd; a.sij = h->sij; a.dij = h->dij;
+    a.vls = (const R *)h->vls; a.ss = (const R *)h->ss; a.sds = (const R *)h->sds;
+    a.posn = h->posn; a.vld = (const R *)h->vld; a.sd = (R *)h->sd; a.sdd = (R *)h->sdd;
+    a.xdown = h->xdown; a.xup = h->xup; a.gdown = (R)h->gdown; a.gup = (R)h->gup;
+    a.abort_key = h->abort_key; a.t_per_block = 0;
+    hipStream_t st = (hipStream_t)ezhip_get_stream();
+    const size_t per_col = (size_t)a.ns * sizeof(R);
+    const char *force = getenv("INTERPV_HIP_COLS");               /* development: 256 / 128 / 64 / 0 */
+    int cols = per_col * 256 <= IV_LDS_MAX ? 256 : per_col * 128 <= IV_LDS_MAX ? 128 : per_col * 64 <= IV_LDS_MAX ? 64 : 0;
+    if (force) { const int fc = atoi(force); if (fc == 0 || (fc <= cols && (fc == 64 || fc == 128 || fc == 256))) cols = fc; }
+    switch (cols) {
+    case 256: return launch_cols<R, 256>(a, st);
+    case 128: return launch_cols<R, 128>(a, st);
+    case 64:  return launch_cols<R, 64>(a, st);
+    default:  return launch_cols<R, 0>(a, st);
+    }
+}
+
+extern "C" int ivhip_launch(const ivhip_args *h)
+{
+    if (h->n <= 0 || h->nd <= 0) return 0;
+    return h->prec8 ? launch_typed<double>(h) : launch_typed<float>(h);
+}
+
+extern "C" int ivhip_copy2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows, int to_device)
+{
+    if (!width_bytes || !rows) return 0;
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost,
+                            (hipStream_t)ezhip_get_stream()) == hipSuccess ? 0 : -1;
+}

@@ -24,6 +24,9 @@ def declared_symbols():
     for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
         text = open(os.path.join(ROOT, "include", h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"^INTERPV_F_DECL\((\w+)\)", text, flags=re.M):        # the four forms of every src/interpv routine
+            syms += [m.group(1) + sfx for sfx in ("_", "8_", "_x_", "_x8_")]
+        text = re.sub(r"^[ \t]*#[ \t]*define(?:.*\\\n)*.*$", "", text, flags=re.M)    # macro bodies declare nothing
         for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text):
             name = m.group(1)
             if name in ("defined", "sizeof") or name.isupper():
@@ -205,3 +208,18 @@ def test_threaded_host_locate_equals_serial():
     for a, b in ((0, 300_000), (300_000, 600_000), (600_000, n)):
         rc, xs, ys = ez.gdxyfll(g, lat[a:b], lon[a:b])
         assert rc == 0 and np.array_equal(xs.view(np.uint32), x[a:b].view(np.uint32)) and np.array_equal(ys.view(np.uint32), y[a:b].view(np.uint32))
+
+
+def test_vertical_interpolation_fails_loudly_without_gpu():
+    """device entry points return -1; the reference's Fortran subroutines (no status argument) abort the program"""
+    import subprocess, sys, torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from librmn_amd import interpv as V
+    z = np.zeros((4, 8), np.float32)
+    assert V.findpos_dev(8, z, np.zeros((4, 8), np.int32), z) == -1
+    assert V.column_dev(V.LINEAR, V.X_NONE, 8, z, z, z, None, z, z, z) == -1
+    code = ("import numpy as np; from librmn_amd import interpv as V; z = np.ones((4, 8), np.float32);"
+            "V.findpos(8, z, z); print('survived')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode != 0 and "survived" not in r.stdout and "no CPU fallback" in r.stderr
