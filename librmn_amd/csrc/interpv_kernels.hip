@@ -28,7 +28,8 @@
 
 #define IV_THREADS 256
 #define IV_TU 4                         /* destination levels in flight per thread */
-#define IV_LDS_MAX (80 * 1024)          /* staged levels per block: two blocks per CU */
+#define IV_LDS_MAX (80 * 1024)          /* staged levels per block, at most: two blocks per CU */
+#define IV_LDS_SOFT (40 * 1024)         /* preferred: four blocks (16 waves) per CU */
 
 template <typename R>
 struct iv_args {
@@ -211,7 +212,7 @@ static int launch_cols(const iv_args<R> &a0, hipStream_t st)
     const size_t lds = COLS ? (size_t)COLS * a.ns * sizeof(R) : 0;
     if (lds > 64 * 1024) {
         static bool raised[2][4];
-        bool &r = raised[sizeof(R) == 8][COLS == 256 ? 0 : COLS == 128 ? 1 : COLS == 64 ? 2 : 3];
+        bool &r = raised[sizeof(R) == 8][COLS == 64 ? 0 : COLS == 32 ? 1 : COLS == 16 ? 2 : 3];
         if (!r) { if (hipFuncSetAttribute((const void *)k_interpv<R, COLS>, hipFuncAttributeMaxDynamicSharedMemorySize, IV_LDS_MAX) != hipSuccess) return -1; r = true; }
     }
     hipLaunchKernelGGL((k_interpv<R, COLS>), dim3(bx, by), dim3(IV_THREADS), lds, st, a);
@@ -230,14 +231,17 @@ static int launch_typed(const ivhip_args *h)
     a.abort_key = h->abort_key; a.t_per_block = 0;
     hipStream_t st = (hipStream_t)ezhip_get_stream();
     const size_t per_col = (size_t)a.ns * sizeof(R);
-    const char *force = getenv("INTERPV_HIP_COLS");               /* development: 256 / 128 / 64 / 0 */
-    int cols = per_col * 256 <= IV_LDS_MAX ? 256 : per_col * 128 <= IV_LDS_MAX ? 128 : per_col * 64 <= IV_LDS_MAX ? 64 : 0;
-    if (force) { const int fc = atoi(force); if (fc == 0 || (fc <= cols && (fc == 64 || fc == 128 || fc == 256))) cols = fc; }
+    /* occupancy decides (measured, 80 -> 60 levels, REAL: 256 columns per block 3.9 ms, 128: 2.3 ms, 64: 1.8 ms for the search):
+     * the fewest columns whose level tile still leaves four blocks per CU, down to 16 columns (one 64-byte segment per row) */
+    const char *force = getenv("INTERPV_HIP_COLS");               /* development: 64 / 32 / 16 / 0 */
+    int cols = per_col * 64 <= IV_LDS_SOFT ? 64 : per_col * 32 <= IV_LDS_SOFT ? 32 : per_col * 16 <= IV_LDS_SOFT ? 16 :
+               per_col * 16 <= IV_LDS_MAX ? 16 : 0;
+    if (force) { const int fc = atoi(force); if (fc == 0 || (fc <= cols && (fc == 64 || fc == 32 || fc == 16))) cols = fc; }
     switch (cols) {
-    case 256: return launch_cols<R, 256>(a, st);
-    case 128: return launch_cols<R, 128>(a, st);
-    case 64:  return launch_cols<R, 64>(a, st);
-    default:  return launch_cols<R, 0>(a, st);
+    case 64: return launch_cols<R, 64>(a, st);
+    case 32: return launch_cols<R, 32>(a, st);
+    case 16: return launch_cols<R, 16>(a, st);
+    default: return launch_cols<R, 0>(a, st);
     }
 }
 

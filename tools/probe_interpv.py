@@ -8,11 +8,17 @@ from librmn_amd import interpv as V
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 7200 * 3601 // 4
 ns = int(sys.argv[2]) if len(sys.argv) > 2 else 80
 nd = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+coherent = "--random" not in sys.argv       # default: hybrid-like levels varying smoothly along the columns, common destination levels
 for dt, es in ((torch.float32, 4), (torch.float64, 8)):
-    inc = torch.rand((ns, n), device="cuda", dtype=dt) + 0.2
-    vls = torch.cumsum(inc, 0); del inc
+    if coherent:
+        ps = 1.0 + 0.05 * torch.sin(torch.arange(n, device="cuda", dtype=dt) * 1e-3)
+        vls = torch.linspace(1, ns, ns, device="cuda", dtype=dt)[:, None] * ps[None, :]
+        vld = (torch.linspace(1.5, ns - 0.5, nd, device="cuda", dtype=dt)[:, None] + torch.zeros((1, n), device="cuda", dtype=dt)).contiguous()
+    else:
+        inc = torch.rand((ns, n), device="cuda", dtype=dt) + 0.2
+        vls = torch.cumsum(inc, 0); del inc
+        vld = vls[0] + torch.rand((nd, n), device="cuda", dtype=dt) * (vls[-1] - vls[0])
     ss = torch.sin(vls * 0.1); sds = torch.cos(vls * 0.1) * 0.1
-    vld = vls[0] + torch.rand((nd, n), device="cuda", dtype=dt) * (vls[-1] - vls[0])
     sd = torch.empty((nd, n), device="cuda", dtype=dt); sdd = torch.empty_like(sd)
     posn = torch.empty((nd, n), device="cuda", dtype=torch.int32)
 
