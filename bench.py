@@ -155,6 +155,17 @@ def extras(ez, torch, stream, d_out, d_in):
         for _ in range(3):
             cez(zout_h.ctypes.data, zin_h.ctypes.data)
         ex["host_pointer_abi_ms_per_field"] = (time.perf_counter() - t0) / 3 * 1e3
+        # the same call between arrays the caller page-locked once (ezhip_register_host_buffer): source rows up / result rows down overlap
+        import ctypes as _ct
+        _L = ez._lib()
+        _L.ezhip_register_host_buffer.argtypes = [_ct.c_void_p, _ct.c_size_t]; _L.ezhip_unregister_host_buffer.argtypes = [_ct.c_void_p]
+        if _L.ezhip_register_host_buffer(zin_h.ctypes.data, zin_h.nbytes) == 0 and _L.ezhip_register_host_buffer(zout_h.ctypes.data, zout_h.nbytes) == 0:
+            cez(zout_h.ctypes.data, zin_h.ctypes.data)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                cez(zout_h.ctypes.data, zin_h.ctypes.data)
+            ex["host_pointer_abi_registered_ms_per_field"] = (time.perf_counter() - t0) / 3 * 1e3
+            _L.ezhip_unregister_host_buffer(zin_h.ctypes.data); _L.ezhip_unregister_host_buffer(zout_h.ctypes.data)
         ni, nj, no, mo = 2560, 1280, 4000, 2000
         ax, ay = ec.ze_axes(ni, nj)
         g_in = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay); g_out = ez.ezqkdef(no, mo, "L", 9, 9, 0, 0)

@@ -12,6 +12,7 @@
  */
 #ifndef EZSCINT_HIP_H
 #define EZSCINT_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -77,6 +78,11 @@ int32_t gdrls_(int32_t *gdin);
 /* All pointers are DEVICE pointers on the current HIP device; work is enqueued on the stream set by
  * ezhip_use_stream (default: the null stream) and NOT synchronised. */
 void    ezhip_use_stream(void *hip_stream);
+/* Optional, for callers of the host-array entry points who reuse their arrays: page-lock an array once (hipHostRegister).  c_ezsint between
+ * two registered arrays uploads the source in row ranges while the finished rows of the result download (PCIe carries both directions at
+ * once); between ordinary arrays the two copies run one after the other.  Unregister before freeing the memory.  0 / -1. */
+int32_t ezhip_register_host_buffer(void *p, size_t nbytes);
+int32_t ezhip_unregister_host_buffer(void *p);
 int32_t c_ezsint_dev(float *d_zout, const float *d_zin);
 int32_t c_ezuvint_dev(float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin);
 int32_t c_ezwdint_dev(float *d_spdout, float *d_dirout, const float *d_uuin, const float *d_vvin);

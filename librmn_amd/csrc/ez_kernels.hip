@@ -105,6 +105,8 @@ extern "C" void *ezhip_host_alloc(size_t n)
     return p;
 }
 extern "C" void ezhip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" int ezhip_host_pin(void *p, size_t n) { return set_err(hipHostRegister(p, n, hipHostRegisterDefault), "hipHostRegister"); }
+extern "C" int ezhip_host_unpin(void *p) { return set_err(hipHostUnregister(p), "hipHostUnregister"); }
 
 #define LAUNCH_CHECK(what) set_err(hipGetLastError(), what)
 
@@ -729,11 +731,12 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
     }
     int bx, by, bz;
     {
-        const unsigned nx = p.x_nbx, nxy = nx * (unsigned)(p.x_nseg + p.n_special);
+        const unsigned nx = p.x_nbx, nxy = nx * (unsigned)(p.by_cnt > 0 ? p.by_cnt : p.x_nseg + p.n_special);
         const unsigned total = nxy * (unsigned)(p.batch_fields > 1 ? p.batch_fields : 1);
         const unsigned M = L - P, full = total & ~7u;
         const unsigned w = M < full ? (M & 7u) * (full >> 3) + (M >> 3) : M;
         bz = w / nxy; const unsigned r = w - bz * nxy; by = r / nx; bx = r - by * nx;
+        if (p.by_cnt > 0) by += p.by_lo;
     }
     const int c = bx * SEP_BLOCK + threadIdx.x;
     const int cc = min(c, p.ni_dst - 1);
@@ -927,7 +930,7 @@ static int launch_sepx(const ezhip_sep_plan *plan, float *d_zout, const float *d
     if (pl.pole_timeout && pl.err_word) __atomic_store_n(pl.err_word, 1, __ATOMIC_RELEASE);
     const size_t nf = plan->batch_fields > 1 ? plan->batch_fields : 1;
     pl.x_nbx = (plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK;
-    const size_t nblocks = (size_t)pl.pole_blocks + (size_t)pl.x_nbx * (size_t)(plan->x_nseg + plan->n_special) * nf;
+    const size_t nblocks = (size_t)pl.pole_blocks + (size_t)pl.x_nbx * (size_t)(plan->by_cnt > 0 ? plan->by_cnt : plan->x_nseg + plan->n_special) * nf;
     if (nblocks >= ((size_t)1 << 31)) { snprintf(g_err, sizeof(g_err), "k_sepx: batch too large for one launch"); return -1; }
     dim3 grid((unsigned)nblocks), block(SEP_BLOCK);
     size_t lds = ezhip_sepx_lds_bytes(plan->x_tr, plan->x_rows_per_step, plan->x_prows, plan->wstride);
@@ -936,7 +939,7 @@ static int launch_sepx(const ezhip_sep_plan *plan, float *d_zout, const float *d
     if (lds > 64 * 1024) {        /* tall windows on wide strips: raise the per-kernel dynamic LDS limit */
         hipError_t e = hipSuccess;
         SEPX_DISPATCH(plan->degree, plan_out(plan),
-                      e = hipFuncSetAttribute((const void *)k_sepx<D, X, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                      e = hipFuncSetAttribute((const void *)k_sepx<D, X, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      /* not the CU's 160 KB: the kernel's static LDS counts against it */
         if (e != hipSuccess) return set_err(e, "k_sepx LDS size");
     }
     if (plan_out(plan) == 3 && (plan->ni_dst & 1)) { snprintf(g_err, sizeof(g_err), "k_sepx: token output needs an even ni_dst"); return -1; }

@@ -28,6 +28,8 @@ void   ezhip_set_stream(void *hip_stream);           /* thread-local; NULL = def
 void  *ezhip_get_stream(void);
 void  *ezhip_host_alloc(size_t nbytes);              /* pinned host staging */
 void   ezhip_host_free(void *p);
+int    ezhip_host_pin(void *p, size_t nbytes);       /* hipHostRegister / hipHostUnregister of a caller's array */
+int    ezhip_host_unpin(void *p);
 int    ezhip_device_error(void);                     /* sticky device-side error word (pinned host memory): returns and clears it */
 
 /* ---- interpolation plans --------------------------------------------------------------- */
@@ -115,6 +117,8 @@ typedef struct {
      * values come precomputed in `polevals`), published in pole_vals[2 f + {0 north, 1 south}] with pole_flags[] = epoch */
     int pole_blocks; unsigned pole_epoch;
     int special_last;                 /* 1: special rows at the end of the field's work order (single-field launch) */
+    int by_lo, by_cnt;                /* by_cnt > 0 (with special_last = 1, one field): the launch covers rows by_lo .. by_lo + by_cnt - 1 of the
+                                         work order [segments | special rows] only (host-pointer ABI: row ranges as the source arrives) */
     int pole_timeout; int *err_word;  /* set by the launcher / the kernel: the bounded wait for the pole values gave up (polar rows := NaN, *err_word := 1) */
     float *pole_vals; unsigned *pole_flags;
     int x_nbx; size_t x_lds_bytes;    /* set by the launcher: column strips, dynamic LDS bytes */

@@ -294,6 +294,7 @@ SEPX_SHAPES = [
     ("L_up_offset", (400, 201, "L", (90, 90, 0, 0)),               (1030, 520, "L", (30, 30, 1200, 5000))),   # target window 12S..168N?? clipped by the L definition
     ("Zregional",   (300, 200, "Z", (100, 100, 0, 0), "L", lambda ni, nj: _zl_axes(ni, nj, 200.0, 300.0, 10.0, 70.0, 5)),
                     (600, 330, "L", (20, 20, 9500, 19000))),                                                   # regional Z source: DEHORS columns and rows
+    ("L_same_res",  (500, 300, "L", (10, 10, 6000, 20000)),        (700, 420, "L", (10, 10, 5500, 19500))),   # equal resolution: 16 target rows span a 20-row source window -> ring + patch > 64 KB of LDS; regional (DEHORS fill)
     ("Zglobal_tgt", (360, 180, "G", (0, 0, 0, 0)),
                     (500, 300, "Z", (100, 100, 0, 0), "L", lambda ni, nj: _zl_axes(ni, nj, 0.0, 359.0, -88.0, 88.0, 6))),   # irregular target axes
 ]
@@ -1089,3 +1090,46 @@ def test_two_threads_host_pointer_ezsint_on_one_grid_pair():
         t.join()
     ez.use_stream(0)
     assert not errs, errs
+
+
+@pytest.mark.parametrize("case", ["global_polar", "global_nopolar", "regional_fill", "linear", "nearest"])
+def test_host_pointer_row_ranges_equal_whole_copies(case, monkeypatch):
+    """c_ezsint between arrays registered with ezhip_register_host_buffer runs k_sepx in row ranges (source rows up, finished rows down,
+    special rows and pole sums in the last range); so does EZHIP_HOST_CHUNKS between ordinary arrays.  Same bits as one launch."""
+    import ctypes
+    L = ez._lib()
+    L.ezhip_register_host_buffer.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    L.ezhip_unregister_host_buffer.argtypes = [ctypes.c_void_p]
+    L.c_ezsint.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    if case == "regional_fill":
+        ni, nj, no, mo = 500, 300, 700, 420
+        gdin = ez.ezqkdef(ni, nj, "L", 10, 10, 6000, 20000)          # 0.1 degree box; the target reaches beyond it
+        gdout = ez.ezqkdef(no, mo, "L", 10, 10, 5500, 19500)
+    else:
+        ni, nj, no, mo = 720, 360, 1100, 551
+        gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(no, mo, "L", 33, 33, 0, 0)
+    assert ez.ezdefset(gdout, gdin) == 1
+    setopts({"linear": 1, "nearest": 0}.get(case, 3), 0 if case == "global_nopolar" else 1)
+    zin = ec.synth_field(ni, nj, seed=11)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    monkeypatch.setenv("EZHIP_HOST_NO_CHUNKS", "1")
+    want = np.zeros(no * mo, np.float32)
+    rc0 = L.c_ezsint(p(want), p(zin))
+    assert rc0 in (0, 2)
+    monkeypatch.delenv("EZHIP_HOST_NO_CHUNKS")
+    for chunks in ("2", "3", "7", "100"):
+        monkeypatch.setenv("EZHIP_HOST_CHUNKS", chunks)
+        got = np.full(no * mo, np.nan, np.float32)
+        assert L.c_ezsint(p(got), p(zin)) == rc0
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), chunks
+    monkeypatch.delenv("EZHIP_HOST_CHUNKS")
+    got = np.full(no * mo, np.nan, np.float32)
+    assert L.ezhip_register_host_buffer(p(zin), zin.nbytes) == 0 and L.ezhip_register_host_buffer(p(got), got.nbytes) == 0
+    try:
+        for _ in range(3):
+            got[:] = np.nan
+            assert L.c_ezsint(p(got), p(zin)) == rc0
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    finally:
+        assert L.ezhip_unregister_host_buffer(p(zin)) == 0 and L.ezhip_unregister_host_buffer(p(got)) == 0
+    assert L.ezhip_unregister_host_buffer(p(got)) == -1                # not registered any more
