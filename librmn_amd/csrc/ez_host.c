@@ -61,6 +61,7 @@ typedef struct ezh_set {
     float *d_scratch;       /* float[8]: fill value + keys, pole values */
     float *d_poles_batch; int poles_cap;   /* pole values of a c_ezsint_batch_dev batch (2 per field) */
     float *d_prow;          /* 2 * ni_src synthetic polar wind rows (vector mode), u then v: [u_n, u_s, v_n, v_s] */
+    void *d_windM;          /* c_ezuvint through a rotated frame: the wind chain of this grid pair as a 2 x 2 matrix per target point (built on first use) */
     /* Yin-Yang 'U' source (c_ezyy_calcxy, ezyy_calcxy.c): per subgrid the list of target points it serves */
     int yy_ready, yy_count[2];
     float *d_yy_x[2], *d_yy_y[2], *d_yy_lat[2], *d_yy_lon[2], *d_yy_tmp[4];
@@ -615,7 +616,7 @@ static void free_set(ezh_set *s)
 {
     for (int d = 0; d < 3; d++) for (int v = 0; v < 2; v++) free_sepplan(&s->sep[d][v]);
     free(s->x1d); free(s->y1d);
-    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch);
+    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM);
     for (int k = 0; k < 2; k++) { ezhip_free(s->d_yy_x[k]); ezhip_free(s->d_yy_y[k]); ezhip_free(s->d_yy_lat[k]); ezhip_free(s->d_yy_lon[k]); ezhip_free(s->d_yy_idx[k]); }
     for (int k = 0; k < 4; k++) ezhip_free(s->d_yy_tmp[k]);
     free(s);
@@ -2445,6 +2446,21 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
             const float *tf = (const float *)(go->d_windtrig + 2 * ((size_t)go->ni + go->nj));
             wp.lon_trigf = tf; wp.lat_trigf = tf + 2 * (size_t)go->ni;
         }
+    }
+    /* components out through a rotated frame (E / Z-on-E source or target): the chain is a rotation per point that depends on the grid
+     * pair only -- built once per set from the chain itself (ezhip_wind_matrix), then two multiply-adds per component and call
+     * (k_wind_rotate: 112 us per cfg3 pair, k_wind_apply: see profiles) */
+    if (!wd_only && (wp.src_rotated || wp.dst_rotated) && !getenv("EZHIP_WIND_NO_MATRIX")) {
+        pthread_mutex_lock(&g_plan_mtx);
+        int mrc = 0;
+        if (!s->d_windM) {
+            s->d_windM = ezhip_malloc(16 * (size_t)go->ni * go->nj);
+            if (!s->d_windM || ezhip_wind_matrix(&wp, s->d_windM, go->d_lat, go->d_lon, go->ni, go->nj)) { ezhip_free(s->d_windM); s->d_windM = NULL; mrc = -1; }
+        }
+        pthread_mutex_unlock(&g_plan_mtx);
+        if (mrc) return dev_fail("the wind rotation matrix");
+        if (ezhip_wind_apply(s->d_windM, d_uuout, d_vvout, (size_t)go->ni * go->nj)) return -1;
+        return (r1 == 2 || r2 == 2) ? 2 : 0;
     }
     if (ezhip_wind_rotate(&wp, d_uuout, d_vvout, go->d_lat, go->d_lon, go->ni, go->nj)) return -1;
     return (r1 == 2 || r2 == 2) ? 2 : 0;

@@ -1930,6 +1930,54 @@ extern "C" int ezhip_scatter(float *d_dst, const float *d_src, const int *d_idx,
     return LAUNCH_CHECK("k_scatter");
 }
 
+/* The whole wind chain of a grid pair (grid-frame components -> true components -> speed / direction -> target components) is, point by
+ * point, a plane rotation that depends on the two grids only: ezhip_wind_matrix runs the chain once on the unit vectors (1,0) and (0,1)
+ * and keeps the four coefficients per point; k_wind_apply then replaces ~10 REAL*8 / REAL transcendentals per point and call by two
+ * multiply-adds per component.  The result differs from the chain on (u,v) by the chain's own rounding (~4e-7 |V|; tolerance 1e-5 |V|). */
+__global__ __launch_bounds__(256) void k_wind_matrix_pack(float4 *__restrict__ M, const float *__restrict__ a, const float *__restrict__ c,
+                                                          const float *__restrict__ b, const float *__restrict__ d, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) M[k] = make_float4(a[k], b[k], c[k], d[k]);           /* uo = a u + b v, vo = c u + d v */
+}
+__global__ __launch_bounds__(256) void k_fill2(float *__restrict__ a, float va, float *__restrict__ b, float vb, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) { a[k] = va; b[k] = vb; }
+}
+__global__ __launch_bounds__(256) void k_wind_apply(const float4 *__restrict__ M, float *__restrict__ uu, float *__restrict__ vv, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const float4 m = M[k];
+    const float u = uu[k], v = vv[k];
+    uu[k] = m.x * u + m.y * v;
+    vv[k] = m.z * u + m.w * v;
+}
+extern "C" int ezhip_wind_matrix(const ezhip_wind_plan *plan, void *d_M, const float *d_lat, const float *d_lon, int ni_dst, int nj_dst)
+{
+    const size_t npts = (size_t)ni_dst * nj_dst;
+    if (!npts) return 0;
+    float *t = nullptr;
+    if (set_err(hipMalloc((void **)&t, sizeof(float) * 4 * npts), "wind matrix scratch")) return -1;
+    const dim3 grid((unsigned)((npts + 255) / 256)), block(256);
+    hipLaunchKernelGGL(k_fill2, grid, block, 0, g_stream, t, 1.0f, t + npts, 0.0f, npts);                      /* (1,0) -> (a, c) */
+    hipLaunchKernelGGL(k_fill2, grid, block, 0, g_stream, t + 2 * npts, 0.0f, t + 3 * npts, 1.0f, npts);       /* (0,1) -> (b, d) */
+    hipLaunchKernelGGL(k_wind_rotate, grid, block, 0, g_stream, *plan, t, t + npts, d_lat, d_lon, ni_dst, nj_dst);
+    hipLaunchKernelGGL(k_wind_rotate, grid, block, 0, g_stream, *plan, t + 2 * npts, t + 3 * npts, d_lat, d_lon, ni_dst, nj_dst);
+    hipLaunchKernelGGL(k_wind_matrix_pack, grid, block, 0, g_stream, (float4 *)d_M, t, t + npts, t + 2 * npts, t + 3 * npts, npts);
+    int rc = LAUNCH_CHECK("k_wind_matrix");
+    if (hipStreamSynchronize(g_stream) != hipSuccess) rc = -1;
+    (void)hipFree(t);
+    return rc;
+}
+extern "C" int ezhip_wind_apply(const void *d_M, float *d_uu, float *d_vv, size_t npts)
+{
+    if (!npts) return 0;
+    hipLaunchKernelGGL(k_wind_apply, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, g_stream, (const float4 *)d_M, d_uu, d_vv, npts);
+    return LAUNCH_CHECK("k_wind_apply");
+}
+
 extern "C" int ezhip_wind_rotate(const ezhip_wind_plan *plan, float *d_uu, float *d_vv,
                                  const float *d_lat, const float *d_lon, int ni_dst, int nj_dst)
 {

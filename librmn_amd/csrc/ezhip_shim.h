@@ -225,6 +225,9 @@ int ezhip_polar_wind(float *d_out4, const float *d_uu, const float *d_vv, const 
                      float xg4_n, float xg4_s, int weighted, const float *d_ax);
 
 /* in place on (uu, vv): source-grid components -> target ('L'-like) grid components */
+/* the chain of a grid pair as a 2 x 2 matrix per point (16 bytes each): built once, applied per call */
+int ezhip_wind_matrix(const ezhip_wind_plan *plan, void *d_M, const float *d_lat, const float *d_lon, int ni_dst, int nj_dst);
+int ezhip_wind_apply(const void *d_M, float *d_uu, float *d_vv, size_t npts);
 int ezhip_wind_rotate(const ezhip_wind_plan *plan, float *d_uu, float *d_vv,
                       const float *d_lat, const float *d_lon, int ni_dst, int nj_dst);
 
