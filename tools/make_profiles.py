@@ -1,0 +1,96 @@
+"""Turns what tools/prof_round.sh left in gpurun_out/<tag>/ into the round's tracked artefacts under profiles/:
+
+    python tools/make_profiles.py <tag> <prefix>          e.g.  r02g r02
+
+    <prefix>_bench.json, <prefix>_bench_under_rocprof.json, <prefix>_bench_kernel_stats.csv      copied
+    <prefix>_timed_launches.csv          the 60 timed 32-field k_sepx<3, 16, 0> launches of the profiled run
+    <prefix>_kernel_stats_by_grid.csv    the kernel trace split by (kernel, grid)
+    <prefix>_pmc_FETCH_SIZE_per_dispatch.csv / _WRITE_SIZE_   copied
+    <prefix>_pmc_traffic.json            HBM traffic per field of k_sepx and of the fused cfg5 pipeline (FETCH_SIZE x 2 on gfx950, WRITE_SIZE exact, KiB)
+"""
+import collections, csv, json, os, shutil, statistics as st, sys
+
+tag, prefix = sys.argv[1], sys.argv[2]
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+for a, b in (("bench.json", "bench.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"), ("kernel_stats.csv", "bench_kernel_stats.csv"),
+             ("pmc_FETCH_SIZE.csv", "pmc_FETCH_SIZE_per_dispatch.csv"), ("pmc_WRITE_SIZE.csv", "pmc_WRITE_SIZE_per_dispatch.csv")):
+    shutil.copyfile(os.path.join(src, a), os.path.join(dst, f"{prefix}_{b}"))
+
+bench = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).readline())
+F = bench["roofline"]["fields_per_launch"]
+alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+rows = list(csv.DictReader(open(os.path.join(src, "dispatches.csv"))))
+by_grid = collections.Counter(r["grid_x"] for r in rows if "k_sepx<3, 16, 0>" in r["kernel"])
+big_grid = max(by_grid, key=lambda g: int(g))
+big = sorted((r for r in rows if "k_sepx<3, 16, 0>" in r["kernel"] and r["grid_x"] == big_grid), key=lambda r: int(r["start_ns"]))
+W, K = bench["warmup"], bench["steps"]
+timed = big[W:W + K]
+mean_us = st.mean(float(r["duration_us"]) for r in timed)
+with open(os.path.join(dst, f"{prefix}_timed_launches.csv"), "w") as f:
+    f.write(f"# the {K} TIMED k_sepx<3, 16, 0> launches ({F} fields each, grid {big_grid}) of the profiled bench run (rocprofv3 --kernel-trace; "
+            f"launches {W + 1}..{W + K} of that kernel: {W} warm-up steps precede them); mean {mean_us:.2f} us -> "
+            f"{alg / mean_us / 1e3:.1f} GB/s = {alg / mean_us / 1e3 / 8000:.4f} of 8 TB/s (bench line of the same run: {bench['roofline']['frac']:.4f})\n")
+    f.write("dispatch_id,kernel,grid_x,start_ns,end_ns,duration_us\n")
+    for r in timed:
+        f.write(f"{r['dispatch_id']},\"{r['kernel']}\",{r['grid_x']},{r['start_ns']},{r['end_ns']},{r['duration_us']}\n")
+
+agg = collections.defaultdict(list)
+for r in rows:
+    agg[(r["kernel"], r["grid_x"])].append(float(r["duration_us"]))
+with open(os.path.join(dst, f"{prefix}_kernel_stats_by_grid.csv"), "w") as f:
+    f.write("kernel,grid_x,calls,total_us,avg_us,min_us,max_us\n")
+    for (k, g), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        f.write(f"\"{k}\",{g},{len(v)},{sum(v):.1f},{st.mean(v):.2f},{min(v):.2f},{max(v):.2f}\n")
+
+
+def pmc(name):
+    out = collections.defaultdict(list)
+    for r in csv.DictReader(open(os.path.join(src, f"pmc_{name}.csv"))):
+        out[(r["kernel"], r["grid"])].append(float(r["value"]))
+    return out
+
+
+fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
+
+
+def per_field(kernel_part, grid=None, nfields=F):
+    def pick(tab):
+        cands = [(k, v) for k, v in tab.items() if kernel_part in k[0] and (grid is None or k[1] == grid)]
+        if not cands:
+            return None, None
+        k, v = max(cands, key=lambda kv: int(kv[0][1]))
+        return k, st.median(v)
+    kf, rd = pick(fetch); kw, wr = pick(write)
+    if rd is None or wr is None:
+        return None
+    return {"grid": kf[1], "read_MB": round(rd * 2 * 1024 / nfields / 1e6, 2), "write_MB": round(wr * 1024 / nfields / 1e6, 2)}
+
+
+main = per_field("k_sepx<3, 16, 0>")
+A = per_field("k_sepx<3, 16, 2>"); B = per_field("k_sepx<3, 16, 3>"); E = per_field("k_armn_enc1")
+zl = bench["pack"]["zlng_bytes"]
+out = {
+    "workload": "python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 under rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, tools/prof_round.sh); "
+                f"per-dispatch values in {prefix}_pmc_FETCH_SIZE_per_dispatch.csv / {prefix}_pmc_WRITE_SIZE_per_dispatch.csv (KiB); medians over the dispatches of a (kernel, grid)",
+    "FETCH_SIZE_correction": "x2 (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
+    "fields_per_launch": F,
+    "kernel": f"k_sepx<3, 16, 0> (grid {main['grid']} = {F} fields)",
+    "read_MB_per_field": main["read_MB"], "write_MB_per_field": main["write_MB"],
+    "algorithmic_MB_per_field": round(alg / F / 1e6, 2),
+    "traffic_MB_per_field": round(main["read_MB"] + main["write_MB"], 2),
+    "traffic_over_algorithmic": round((main["read_MB"] + main["write_MB"]) / (alg / F / 1e6), 3),
+}
+if A and B and E:
+    tot = sum(x["read_MB"] + x["write_MB"] for x in (A, B, E))
+    calg = (alg / F - 4 * bench["config"]["points_per_field"] + zl) / 1e6          # source field in, compressed record out
+    out["cfg5_fused_pipeline_MB_per_field"] = {"A k_sepx<3,16,2> (min/max only)": A, "B k_sepx<3,16,3> (tokens)": B, "E k_armn_enc1 (one launch per batch)": E}
+    out["cfg5_fused_pipeline_total_MB_per_field"] = round(tot, 1)
+    out["cfg5_algorithmic_MB_per_field"] = round(calg, 2)
+    out["cfg5_traffic_over_algorithmic"] = round(tot / calg, 2)
+    out["cfg5_notes"] = ("floor of this three-kernel structure: 2 x 38.7 (source read twice) + 51.9 + 51.9 (tokens out and in) + 25.4 (stream) = 206.6 MB = 3.22 x; "
+                         "measured above it: halo rows of the source and of the token rows")
+json.dump(out, open(os.path.join(dst, f"{prefix}_pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
+print(f"timed launches: mean {mean_us:.2f} us, frac {alg / mean_us / 1e3 / 8000:.4f}; bench line {bench['roofline']['avg_launch_us']:.2f} us / {bench['roofline']['frac']:.4f}")
