@@ -179,6 +179,18 @@ def extras(ez, torch, stream, d_out, d_in):
         ex["cfg3_uvint"] = {"workload": "c_ezuvint_dev bicubic, Z-on-E 2560x1280 -> L 4000x2000, polar_correction=yes",
                             "us_per_pair": us, "Mpoint_pairs_per_s": no * mo / us,
                             "algorithmic_GBps": (2 * 4 * ni * nj + 2 * 4 * no * mo) / us / 1e3}
+        del d_u, d_v, o_u, o_v
+        # the step after the horizontal one: vertical interpolation of device-resident profiles, search + linear + lapse-rate in one pass
+        from librmn_amd import interpv as V
+        ncol, ns, nd = 7200 * 3601 // 16, 80, 60
+        ps = 1.0 + 0.05 * torch.sin(torch.arange(ncol, device="cuda", dtype=torch.float32) * 1e-3)
+        vls = torch.linspace(1, ns, ns, device="cuda")[:, None] * ps[None, :]
+        vld = (torch.linspace(1.5, ns - 0.5, nd, device="cuda")[:, None] + torch.zeros((1, ncol), device="cuda")).contiguous()
+        ss = torch.sin(vls * 0.1); sd = torch.empty((nd, ncol), device="cuda")
+        us = ev_time(lambda: V.column_dev(V.LINEAR, V.X_LAPSERATE, ncol, vls, ss, ss, None, vld, sd, sd, True, True, 0.1, 0.1), 20)
+        ex["interpv_column"] = {"workload": f"Interp1D_FindPos + Interp1D_Linear + Extrap1D_LapseRate fused, REAL, {ncol} columns, {ns} -> {nd} levels (levels varying smoothly along the columns)",
+                                "us": us, "Mvalues_per_s": ncol * nd / us, "algorithmic_GBps": 4.0 * ncol * (2 * ns + 2 * nd) / us / 1e3,
+                                "frac_of_hbm_peak": 4.0 * ncol * (2 * ns + 2 * nd) / us / 1e3 / HBM_PEAK_GBPS}
     except Exception as e:   # noqa: BLE001
         ex["error"] = repr(e)
     return ex
