@@ -29,7 +29,7 @@
 #define IV_THREADS 256
 #define IV_TU 4                         /* destination levels in flight per thread */
 #define IV_LDS_MAX (80 * 1024)          /* staged levels per block, at most: two blocks per CU */
-#define IV_LDS_SOFT (40 * 1024)         /* preferred: four blocks (16 waves) per CU */
+#define IV_LDS_SOFT (24 * 1024)         /* preferred: six blocks (24 waves, the register limit) per CU -- REAL*8, 80 levels: 64 columns (40 KB) 2.75 ms, 32 columns (20 KB) 2.33 ms for the search */
 
 template <typename R>
 struct iv_args {
@@ -59,7 +59,9 @@ __global__ __launch_bounds__(IV_THREADS) void k_interpv(iv_args<R> a)
     const size_t sij = (size_t)a.sij, dij = (size_t)a.dij;
     const int ns = a.ns;
     if (COLS) {
-        for (int k = tg; k < ns; k += NTG) lev[(size_t)k * C + lc] = live ? a.vls[i + (size_t)k * sij] : (R)0;
+        /* thread group tg stages a contiguous run of rows of its column (rows tg, tg + NTG, ... measured slower: REAL*8 search 4.1 -> 2.3 ms) */
+        const int per = (ns + NTG - 1) / NTG, k0 = tg * per, k1 = min(ns, k0 + per);
+        for (int k = k0; k < k1; k++) lev[(size_t)k * C + lc] = live ? a.vls[i + (size_t)k * sij] : (R)0;
         __syncthreads();
     }
     if (!live) return;
@@ -232,7 +234,7 @@ static int launch_typed(const ivhip_args *h)
     hipStream_t st = (hipStream_t)ezhip_get_stream();
     const size_t per_col = (size_t)a.ns * sizeof(R);
     /* occupancy decides (measured, 80 -> 60 levels, REAL: 256 columns per block 3.9 ms, 128: 2.3 ms, 64: 1.8 ms for the search):
-     * the fewest columns whose level tile still leaves four blocks per CU, down to 16 columns (one 64-byte segment per row) */
+     * the most columns whose level tile still leaves six blocks per CU, down to 16 columns (one 64-byte segment per row) */
     const char *force = getenv("INTERPV_HIP_COLS");               /* development: 64 / 32 / 16 / 0 */
     int cols = per_col * 64 <= IV_LDS_SOFT ? 64 : per_col * 32 <= IV_LDS_SOFT ? 32 : per_col * 16 <= IV_LDS_SOFT ? 16 :
                per_col * 16 <= IV_LDS_MAX ? 16 : 0;

@@ -185,3 +185,27 @@ def test_too_few_levels_is_refused_like_the_reference():
     sd, sdd = iv.new_out(c)
     V.interp(V.CUBIC_LAGRANGE, 3, c["vls"], c["ss"], c["sds"], posn, c["vld"], sd, sdd)
     assert np.all(sd == 123.25)                         # an error line, nothing computed (Interp1D_CubicLagrange_Body.inc:88-91)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("ascending", [True, False])
+def test_search_corner_cases(ascending, dtype):
+    """destination levels exactly on source levels, beyond both ends, infinite and NaN; columns that are not strictly monotonic (equal
+    neighbours, a reversed pair, a NaN level, the other direction than column 1): the literal search of the reference decides, so
+    every bracket equals the oracle's"""
+    n, ns, nd = 96, 37, 50
+    c = iv.make_case(n, ns, nd, n, n, ascending, dtype, seed=17, outside=0.3, ties=0.4)
+    c["vls"][5, 10] = c["vls"][4, 10]                       # equal neighbours
+    c["vls"][[7, 8], 20] = c["vls"][[8, 7], 20]            # a reversed pair
+    c["vls"][3, 30] = np.nan
+    c["vls"][:, 40] = c["vls"][::-1, 40].copy()            # the other direction
+    c["vld"][0, :] = np.inf; c["vld"][1, :] = -np.inf; c["vld"][2, ::3] = np.nan
+    c["vld"][3, :] = c["vls"][0, :]; c["vld"][4, :] = c["vls"][-1, :]
+    with np.errstate(invalid="ignore"):
+        want = iv.orc_findpos(c)
+    d = _dev(c)
+    posn = torch.full((nd, n), -999, dtype=torch.int32, device="cuda")
+    assert V.findpos_dev(n, d["vls"], posn, d["vld"]) == 0
+    got = posn.cpu().numpy()
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, (bad[:5].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
