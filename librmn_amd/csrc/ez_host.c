@@ -1894,7 +1894,7 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
 
 /* both components of a wind pair on the per-point path in ONE pass (k_pts2); returns -2 when the set is not on that path */
 static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui, const float *d_vi,
-                        const float *pun, const float *pus, const float *pvn, const float *pvs)
+                        const float *pun, const float *pus, const float *pvn, const float *pvs, const void *d_M)
 {
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     int degree = O.degre_interp, polar = O.polar_correction == 1;
@@ -1919,6 +1919,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
         if (ezhip_fill_value(d_fill, d_ui, (size_t)gi->ni * gi->nj, O.degre_extrap, O.valeur_extrap, 1)) return -1;
     }
     pu.fill = d_fill; pu.polevals = d_poles;
+    pu.wind_M = d_M;
     pv = pu;
     pu.pole_row_n = pun; pu.pole_row_s = pus; pv.pole_row_n = pvn; pv.pole_row_s = pvs;
     if (zones == 2 && s->have_dehors) ierc = 2;
@@ -2411,15 +2412,16 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
         }
         pun = s->d_prow; pus = s->d_prow + ni; pvn = s->d_prow + 2 * ni; pvs = s->d_prow + 3 * ni;
     }
-    int r1 = run_pair_pts(s, d_uuout, d_vvout, d_uuin, d_vvin, pun, pus, pvn, pvs), r2 = r1;
-    if (r1 == -1) return -1;
-    if (r1 == -2) {                                          /* separable set: one launch per component */
-        r1 = run_field(s, d_uuout, d_uuin, 1, pun, pus);
-        if (r1 < 0) return r1;
-        r2 = run_field(s, d_vvout, d_vvin, 1, pvn, pvs);
-        if (r2 < 0) return r2;
+    /* the wind chain of the pair first: where it is a per-point matrix (below) the per-point kernel applies it as it stores */
+    {
+        int degree_ = O.degre_interp;
+        pthread_mutex_lock(&g_plan_mtx);
+        int erc_ = 0;
+        if (degree_ == DEG_NEAREST || degree_ == DEG_LINEAR || degree_ == DEG_CUBIC)
+            if (choose_mode(s, degree_, polar) == 2) erc_ = ensure_points(s);          /* the locate may still edit the target's cached longitudes */
+        pthread_mutex_unlock(&g_plan_mtx);
+        if (erc_) return -1;
     }
-    if (ezhip_side_join()) return -1;                        /* nothing may outlive the call on the side stream */
     if (ensure_coords_dev(go)) return -1;
     ezhip_wind_plan wp;
     memset(&wp, 0, sizeof(wp));
@@ -2448,8 +2450,9 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
         }
     }
     /* components out through a rotated frame (E / Z-on-E source or target): the chain is a rotation per point that depends on the grid
-     * pair only -- built once per set from the chain itself (ezhip_wind_matrix), then two multiply-adds per component and call
-     * (k_wind_rotate: 112 us per cfg3 pair, k_wind_apply: see profiles) */
+     * pair only -- built once per set from the chain itself (ezhip_wind_matrix), then two multiply-adds per component and call: inside
+     * k_pts2 as it stores (per-point sets), or k_wind_apply after the separable launches (k_wind_rotate: 112 us per cfg3 pair) */
+    const void *d_M = NULL;
     if (!wd_only && (wp.src_rotated || wp.dst_rotated) && !getenv("EZHIP_WIND_NO_MATRIX")) {
         pthread_mutex_lock(&g_plan_mtx);
         int mrc = 0;
@@ -2457,12 +2460,22 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
             s->d_windM = ezhip_malloc(16 * (size_t)go->ni * go->nj);
             if (!s->d_windM || ezhip_wind_matrix(&wp, s->d_windM, go->d_lat, go->d_lon, go->ni, go->nj)) { ezhip_free(s->d_windM); s->d_windM = NULL; mrc = -1; }
         }
+        d_M = s->d_windM;
         pthread_mutex_unlock(&g_plan_mtx);
         if (mrc) return dev_fail("the wind rotation matrix");
-        if (ezhip_wind_apply(s->d_windM, d_uuout, d_vvout, (size_t)go->ni * go->nj)) return -1;
-        return (r1 == 2 || r2 == 2) ? 2 : 0;
     }
-    if (ezhip_wind_rotate(&wp, d_uuout, d_vvout, go->d_lat, go->d_lon, go->ni, go->nj)) return -1;
+    int r1 = run_pair_pts(s, d_uuout, d_vvout, d_uuin, d_vvin, pun, pus, pvn, pvs, getenv("EZHIP_WIND_NO_FUSE") ? NULL : d_M), r2 = r1;
+    if (r1 == -1) return -1;
+    const int fused = r1 != -2 && d_M && !getenv("EZHIP_WIND_NO_FUSE");
+    if (r1 == -2) {                                          /* separable set: one launch per component */
+        r1 = run_field(s, d_uuout, d_uuin, 1, pun, pus);
+        if (r1 < 0) return r1;
+        r2 = run_field(s, d_vvout, d_vvin, 1, pvn, pvs);
+        if (r2 < 0) return r2;
+    }
+    if (ezhip_side_join()) return -1;                        /* nothing may outlive the call on the side stream */
+    if (d_M) { if (!fused && ezhip_wind_apply(d_M, d_uuout, d_vvout, (size_t)go->ni * go->nj)) return -1; }
+    else if (ezhip_wind_rotate(&wp, d_uuout, d_vvout, go->d_lat, go->d_lon, go->ni, go->nj)) return -1;
     return (r1 == 2 || r2 == 2) ? 2 : 0;
 }
 

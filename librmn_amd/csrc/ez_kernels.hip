@@ -1433,6 +1433,51 @@ __global__ __launch_bounds__(256) void k_pts(ezhip_pts_plan p, float *__restrict
     }
 }
 
+/* Both components of a wind pair on an irregular wrapped source (Z-on-E: cfg3) with SHARED weights.  ez_irgdint_3_w evaluates
+ * the cubic through four points in Newton form, whose divided differences depend on the field: ~100 REAL*8 operations per field and
+ * point.  The same polynomial in Lagrange form has weights that depend on the position only -- and the six reciprocals a column /
+ * row of the Newton tables holds (1/(x2-x1), 1/(x3-x1), 1/(x3-x2), 1/(x4-x1), 1/(x4-x2), 1/(x4-x3)) are exactly the factors of
+ * the Lagrange denominators -- so a pair costs 44 operations for the eight weights plus 35 per field.  Same polynomial, different
+ * rounding (~1e-7 relative); used for wind pairs only, whose results go through the wind rotation and are held to 1e-5 |V|.
+ * Scalars keep the Newton form of the reference (bit-exact). */
+template <bool AOS>
+__device__ __forceinline__ void lagrange_weights(const float *c, int idx, int n, double t, double t1, double t2, double t3, double t4, double w[4])
+{
+    const double c1 = coef<AOS>(c, 0, idx, n), c2 = coef<AOS>(c, 1, idx, n), c3 = coef<AOS>(c, 2, idx, n);
+    const double c4 = coef<AOS>(c, 3, idx, n), c5 = coef<AOS>(c, 4, idx, n), c6 = coef<AOS>(c, 5, idx, n);
+    const double d1 = t - t1, d2 = t - t2, d3 = t - t3, d4 = t - t4;
+    const double p12 = d1 * d2, p34 = d3 * d4;
+    w[0] = -(d2 * p34) * (c1 * c2 * c4);
+    w[1] = (d1 * p34) * (c1 * c3 * c5);
+    w[2] = -(p12 * d4) * (c2 * c3 * c6);
+    w[3] = (p12 * d3) * (c4 * c5 * c6);
+}
+template <class A>
+__device__ __forceinline__ void pair_irgdint_3_w(const ezhip_pts_plan &p, const A &Z1, const A &Z2, float px, float py, float &o1, float &o2)
+{
+    const int ni = p.ni, j1 = p.j1, j2 = p.j2, wrap = p.wrap, nnj = j2 - j1 + 1;
+    const int i = min(ni - 2 + wrap, max(1, max(2 - wrap, (int)px)));
+    const int j = min(j2 - 2, max(j1 + 1, (int)py));
+    int im1, ip1, ip2; float x1, x2, x3, x4;
+    irr_cols(p.ax, ni, wrap, i, 2, im1, ip1, ip2, x1, x2, x3, x4);
+    const float *b = p.ay - j1;
+    const double x = (double)(x2 + (x3 - x2) * (px - (float)i));
+    const double y = (double)(b[j] + (b[j + 1] - b[j]) * (py - (float)j));
+    double wx[4], wy[4];
+    lagrange_weights<true>(p.ncx8, i - 1, ni, x, (double)x1, (double)x2, (double)x3, (double)x4, wx);
+    lagrange_weights<true>(p.ncy8, j - j1, nnj, y, (double)b[j - 1], (double)b[j], (double)b[j + 1], (double)b[j + 2], wy);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        double a1, a2, a3, a4, c1, c2, c3, c4;
+        row_taps(Z1, im1, i, ip1, ip2, j - 1 + r, a1, a2, a3, a4);
+        row_taps(Z2, im1, i, ip1, ip2, j - 1 + r, c1, c2, c3, c4);
+        s1 += wy[r] * (wx[0] * a1 + wx[1] * a2 + wx[2] * a3 + wx[3] * a4);
+        s2 += wy[r] * (wx[0] * c1 + wx[1] * c2 + wx[2] * c3 + wx[3] * c4);
+    }
+    o1 = (float)s1; o2 = (float)s2;
+}
+
 /* The two components of a wind pair in one pass (c_ezuvint on the per-point path): x, y, zone test, indices and weights are
  * shared (the leaf is inlined twice and the compiler merges everything that does not depend on the field). */
 template <int KIND>
@@ -1447,8 +1492,22 @@ __global__ __launch_bounds__(256) void k_pts2(ezhip_pts_plan p, float *__restric
     const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;
     const PlainAcc Z1{zin1, p.ni, p.j1}, Z2{zin2, p.ni, p.j1};
     const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
-    if (zone == PZ_NORMAL) { zout1[o] = leaf_point<KIND>(p, Z1, px, py); zout2[o] = leaf_point<KIND>(p, Z2, px, py); }
-    else if (zone == PZ_FILL) { const float f = *p.fill; zout1[o] = f; zout2[o] = f; }
+    /* the point's wind matrix is fetched first: nothing depends on it until the store, its latency hides behind the interpolation
+     * (fetched where it is applied it cost +37 us per cfg3 pair, as much as the separate k_wind_apply pass) */
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v wm = {1.0f, 0.0f, 0.0f, 1.0f};
+    if (p.wind_M) { wm = __builtin_nontemporal_load(((const f4v *)p.wind_M) + o); asm volatile("" : "+v"(wm)); }
+    if (zone == PZ_NORMAL || zone == PZ_FILL) {
+        float a, b;
+        if (zone == PZ_FILL) a = b = *p.fill;
+        else if (KIND == PK_IRGD3_W && p.pair_shared) pair_irgdint_3_w(p, Z1, Z2, px, py, a, b);
+        else { a = leaf_point<KIND>(p, Z1, px, py); b = leaf_point<KIND>(p, Z2, px, py); }
+        if (p.wind_M) {                       /* the wind chain of the grid pair (k_wind_apply), here instead of a pass of its own */
+            const float u = a, v = b;
+            a = wm.x * u + wm.y * v; b = wm.z * u + wm.w * v;
+        }
+        zout1[o] = a; zout2[o] = b;
+    }
     const bool sp = zone == PZ_REINTERP || zone == PZ_STRIP_S || zone == PZ_STRIP_N;
     const unsigned long long m = __ballot(sp);
     if (sp) {
@@ -1517,6 +1576,19 @@ extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const
     return LAUNCH_CHECK("k_pts_special");
 }
 
+__global__ __launch_bounds__(256) void k_wind_apply_list(const float4 *__restrict__ M, float *__restrict__ uu, float *__restrict__ vv,
+                                                         const int *__restrict__ list, const unsigned *__restrict__ count, const int *__restrict__ out_idx)
+{
+    const unsigned cnt = *count;
+    for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+        const int n = list[k];
+        const size_t o = out_idx ? (size_t)out_idx[n] : (size_t)n;
+        const float4 m = M[o];
+        const float u = uu[o], v = vv[o];
+        uu[o] = m.x * u + m.y * v; vv[o] = m.z * u + m.w * v;
+    }
+}
+
 /* vector pair: plan_u / plan_v differ only in their polar wind rows (read by the special points) */
 extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_plan *plan_v, float *d_out_u, float *d_out_v,
                                  const float *d_in_u, const float *d_in_v, const float *d_x, const float *d_y, int npts)
@@ -1534,7 +1606,9 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     }
     unsigned *cnt = t_spec.count + (t_spec.epoch & 1), *cnt_next = t_spec.count + ((t_spec.epoch + 1) & 1);
     t_spec.epoch++;
-#define PTS2_CASE(K) case K: hipLaunchKernelGGL(k_pts2<K>, grid, block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, t_spec.list, cnt); break
+    ezhip_pts_plan pl_u = *plan_u;
+    pl_u.pair_shared = !getenv("EZHIP_PAIR_NEWTON");          /* development: the reference's Newton form per component */
+#define PTS2_CASE(K) case K: hipLaunchKernelGGL(k_pts2<K>, grid, block, 0, g_stream, pl_u, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, t_spec.list, cnt); break
     switch (pts_kind(plan_u)) {
     PTS2_CASE(PK_RGD0); PTS2_CASE(PK_RGD1_NW); PTS2_CASE(PK_RGD1_W); PTS2_CASE(PK_RGD3_NW); PTS2_CASE(PK_RGD3_W);
     PTS2_CASE(PK_IRGD1_NW); PTS2_CASE(PK_IRGD1_W); PTS2_CASE(PK_IRGD3_NW); PTS2_CASE(PK_IRGD3_W);
@@ -1545,6 +1619,8 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     /* the same list serves both components; both launches re-arm the same counter of the pair */
     hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan_u, d_out_u, d_in_u, d_x, d_y, t_spec.list, cnt, cnt_next);
     hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan_v, d_out_v, d_in_v, d_x, d_y, t_spec.list, cnt, cnt_next);
+    if (plan_u->wind_M)                  /* the listed points were stored un-rotated by the two launches above */
+        hipLaunchKernelGGL(k_wind_apply_list, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, (const float4 *)plan_u->wind_M, d_out_u, d_out_v, t_spec.list, cnt, plan_u->out_idx);
     return LAUNCH_CHECK("k_pts_special");
 }
 
