@@ -597,13 +597,8 @@ __device__ __forceinline__ void sepx_ypass(const float *myrec, const double *tco
                                : "=&v"(t[0][J]), "=&v"(t[1][J]), "=&v"(t[2][J]), "=&v"(t[3][J]), "=&v"(t[4][J]), "=&v"(t[5][J]), "=&v"(t[6][J]), "=&v"(t[7][J]) \
                                : "v"(A) : "memory")
             RD8(a0, 0);
-            if (nostore) {            /* development knock-out (EZHIP_DEBUG & 512): one ring read per output instead of 2 / 4 -- what the LDS reads of the y-pass cost */
-#pragma unroll
-                for (int g = 0; g < 8; g++) { t[g][1] = t[g][0]; t[g][2] = t[g][0]; t[g][3] = t[g][0]; }
-            } else {
             if (DEG >= 1) RD8(a1, 1);
             if (DEG == 3) { RD8(a2, 2); RD8(a3, 3); }
-            }
 #undef RD8
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             /* tie the values to the wait so that no consumer is scheduled above it */
@@ -885,7 +880,7 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
             if (slow) sepx_ypass<DEG, XR, true, OUT>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, (dbg & 1) != 0, vmin, vmax, qp);
             else if (OUT == 3) { if (dbg & 256) sepx_ypass_q<DEG, XR, true>(myrec, T + 2 * l32, (unsigned *)zout + (size_t)bx * (SEP_BLOCK / 2) + l32, qp);
                                  else sepx_ypass_q<DEG, XR, false>(myrec, T + 2 * l32, (unsigned *)zout + (size_t)bx * (SEP_BLOCK / 2) + l32, qp); }
-            else sepx_ypass<DEG, XR, false, OUT>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, (dbg & 512) != 0, vmin, vmax, qp);
+            else sepx_ypass<DEG, XR, false, OUT>(myrec, T + l32, zcol, fillv, dmask, l32, ncol_valid, false, vmin, vmax, qp);
         }
         st = nst;
         if ((dbg & 16) || slow || OUT == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* OUT = 2 stores nothing: only DMA(i+1) is outstanding */
