@@ -1428,55 +1428,14 @@ __global__ __launch_bounds__(256) void k_pts(ezhip_pts_plan p, float *__restrict
     }
 }
 
-/* Both components of a wind pair on an irregular wrapped source (Z-on-E: cfg3) with SHARED weights.  ez_irgdint_3_w evaluates
- * the cubic through four points in Newton form, whose divided differences depend on the field: ~100 REAL*8 operations per field and
- * point.  The same polynomial in Lagrange form has weights that depend on the position only -- and the six reciprocals a column /
- * row of the Newton tables holds (1/(x2-x1), 1/(x3-x1), 1/(x3-x2), 1/(x4-x1), 1/(x4-x2), 1/(x4-x3)) are exactly the factors of
- * the Lagrange denominators -- so a pair costs 44 operations for the eight weights plus 35 per field.  Same polynomial, different
- * rounding (~1e-7 relative); used for wind pairs only, whose results go through the wind rotation and are held to 1e-5 |V|.
- * Scalars keep the Newton form of the reference (bit-exact). */
-template <bool AOS>
-__device__ __forceinline__ void lagrange_weights(const float *c, int idx, int n, double t, double t1, double t2, double t3, double t4, double w[4])
-{
-    const double c1 = coef<AOS>(c, 0, idx, n), c2 = coef<AOS>(c, 1, idx, n), c3 = coef<AOS>(c, 2, idx, n);
-    const double c4 = coef<AOS>(c, 3, idx, n), c5 = coef<AOS>(c, 4, idx, n), c6 = coef<AOS>(c, 5, idx, n);
-    const double d1 = t - t1, d2 = t - t2, d3 = t - t3, d4 = t - t4;
-    const double p12 = d1 * d2, p34 = d3 * d4;
-    w[0] = -(d2 * p34) * (c1 * c2 * c4);
-    w[1] = (d1 * p34) * (c1 * c3 * c5);
-    w[2] = -(p12 * d4) * (c2 * c3 * c6);
-    w[3] = (p12 * d3) * (c4 * c5 * c6);
-}
-template <class A>
-__device__ __forceinline__ void pair_irgdint_3_w(const ezhip_pts_plan &p, const A &Z1, const A &Z2, float px, float py, float &o1, float &o2)
-{
-    const int ni = p.ni, j1 = p.j1, j2 = p.j2, wrap = p.wrap, nnj = j2 - j1 + 1;
-    const int i = min(ni - 2 + wrap, max(1, max(2 - wrap, (int)px)));
-    const int j = min(j2 - 2, max(j1 + 1, (int)py));
-    int im1, ip1, ip2; float x1, x2, x3, x4;
-    irr_cols(p.ax, ni, wrap, i, 2, im1, ip1, ip2, x1, x2, x3, x4);
-    const float *b = p.ay - j1;
-    const double x = (double)(x2 + (x3 - x2) * (px - (float)i));
-    const double y = (double)(b[j] + (b[j + 1] - b[j]) * (py - (float)j));
-    double wx[4], wy[4];
-    lagrange_weights<true>(p.ncx8, i - 1, ni, x, (double)x1, (double)x2, (double)x3, (double)x4, wx);
-    lagrange_weights<true>(p.ncy8, j - j1, nnj, y, (double)b[j - 1], (double)b[j], (double)b[j + 1], (double)b[j + 2], wy);
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        double a1, a2, a3, a4, c1, c2, c3, c4;
-        row_taps(Z1, im1, i, ip1, ip2, j - 1 + r, a1, a2, a3, a4);
-        row_taps(Z2, im1, i, ip1, ip2, j - 1 + r, c1, c2, c3, c4);
-        s1 += wy[r] * (wx[0] * a1 + wx[1] * a2 + wx[2] * a3 + wx[3] * a4);
-        s2 += wy[r] * (wx[0] * c1 + wx[1] * c2 + wx[2] * c3 + wx[3] * c4);
-    }
-    o1 = (float)s1; o2 = (float)s2;
-}
-
 /* The two components of a wind pair in one pass (c_ezuvint on the per-point path): x, y, zone test, indices and weights are
  * shared (the leaf is inlined twice and the compiler merges everything that does not depend on the field). */
+/* waves_per_eu(6, 8): the irregular bicubic pair otherwise takes 118 VGPRs (4 waves per SIMD) and its gathers stop overlapping its
+ * arithmetic: 80 VGPRs without spilling, -10 us per cfg3 pair.  (Lagrange weights shared by the two components -- the Newton tables'
+ * reciprocals are the Lagrange denominators -- cut the VALU work from 540 to 310 instructions per wave and were measured SLOWER at equal
+ * occupancy, 172 - 186 against 165 - 169 us: the kernel is bound by its gathers, not by its arithmetic; the reference's Newton form stays.) */
 template <int KIND>
-__global__ __launch_bounds__(256) void k_pts2(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_pts2(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
                                               const float *__restrict__ zin1, const float *__restrict__ zin2,
                                               const float *__restrict__ xs, const float *__restrict__ ys, int npts,
                                               int *__restrict__ special_list, unsigned *__restrict__ special_count)
@@ -1495,7 +1454,6 @@ __global__ __launch_bounds__(256) void k_pts2(ezhip_pts_plan p, float *__restric
     if (zone == PZ_NORMAL || zone == PZ_FILL) {
         float a, b;
         if (zone == PZ_FILL) a = b = *p.fill;
-        else if (KIND == PK_IRGD3_W && p.pair_shared) pair_irgdint_3_w(p, Z1, Z2, px, py, a, b);
         else { a = leaf_point<KIND>(p, Z1, px, py); b = leaf_point<KIND>(p, Z2, px, py); }
         if (p.wind_M) {                       /* the wind chain of the grid pair (k_wind_apply), here instead of a pass of its own */
             const float u = a, v = b;
@@ -1601,9 +1559,7 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     }
     unsigned *cnt = t_spec.count + (t_spec.epoch & 1), *cnt_next = t_spec.count + ((t_spec.epoch + 1) & 1);
     t_spec.epoch++;
-    ezhip_pts_plan pl_u = *plan_u;
-    pl_u.pair_shared = !getenv("EZHIP_PAIR_NEWTON");          /* development: the reference's Newton form per component */
-#define PTS2_CASE(K) case K: hipLaunchKernelGGL(k_pts2<K>, grid, block, 0, g_stream, pl_u, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, t_spec.list, cnt); break
+#define PTS2_CASE(K) case K: hipLaunchKernelGGL(k_pts2<K>, grid, block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, t_spec.list, cnt); break
     switch (pts_kind(plan_u)) {
     PTS2_CASE(PK_RGD0); PTS2_CASE(PK_RGD1_NW); PTS2_CASE(PK_RGD1_W); PTS2_CASE(PK_RGD3_NW); PTS2_CASE(PK_RGD3_W);
     PTS2_CASE(PK_IRGD1_NW); PTS2_CASE(PK_IRGD1_W); PTS2_CASE(PK_IRGD3_NW); PTS2_CASE(PK_IRGD3_W);

@@ -151,7 +151,6 @@ typedef struct {
     const float *ax, *ay, *ncx, *ncy; /* device; NULL for regular sources */
     const float *ncx8, *ncy8;         /* the same coefficients laid out [index][8] (6 used): two 16-byte loads per point */
     const void *wind_M;               /* k_pts2: the grid pair's wind matrices (ezhip_wind_matrix), applied to every point before it is stored; NULL: store the interpolated components */
-    int pair_shared;                  /* k_pts2 on an irregular wrapped source: Lagrange weights shared by the two components (set by ezhip_interp_pts2) */
     /* zone handling (0 = none: c_gdxysint semantics) */
     int zones;                        /* 0 none, 1 EZ_NO_EXTRAP (polar zones), 2 EZ_EXTRAP (DEHORS) */
     int degre_extrap;                 /* used when zones == 2 */
