@@ -2453,7 +2453,8 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
      * pair only -- built once per set from the chain itself (ezhip_wind_matrix), then two multiply-adds per component and call: inside
      * k_pts2 as it stores (per-point sets), or k_wind_apply after the separable launches (k_wind_rotate: 112 us per cfg3 pair) */
     const void *d_M = NULL;
-    if (!wd_only && (wp.src_rotated || wp.dst_rotated) && !getenv("EZHIP_WIND_NO_MATRIX")) {
+    if (!wd_only && (wp.src_rotated || wp.dst_rotated) && !getenv("EZHIP_WIND_NO_MATRIX") &&
+        16 * (size_t)go->ni * go->nj <= ((size_t)1 << 31)) {           /* 16 bytes per target point, kept with the set: up to 2 GiB, beyond that the chain runs per call */
         pthread_mutex_lock(&g_plan_mtx);
         int mrc = 0;
         if (!s->d_windM) {
