@@ -1133,3 +1133,35 @@ def test_host_pointer_row_ranges_equal_whole_copies(case, monkeypatch):
     finally:
         assert L.ezhip_unregister_host_buffer(p(zin)) == 0 and L.ezhip_unregister_host_buffer(p(got)) == 0
     assert L.ezhip_unregister_host_buffer(p(got)) == -1                # not registered any more
+
+
+@pytest.mark.parametrize("kind", ["rotated_source", "rotated_target"])
+def test_wind_matrix_equals_the_chain(kind, monkeypatch):
+    """c_ezuvint through a rotated frame applies the wind chain of the grid pair as a per-point matrix built from the chain itself
+    (inside k_pts2 for per-point sets, k_wind_apply after separable launches): same winds as the chain run on every call
+    (EZHIP_WIND_NO_MATRIX), to a few 1e-7 of |V|; the fused and the separate application agree bit for bit."""
+    ni, nj, no, mo = 360, 180, 500, 250
+    ax, ay = ec.ze_axes(ni, nj)
+    if kind == "rotated_source":
+        gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay); gdout = ez.ezqkdef(no, mo, "L", 72, 72, 0, 0)
+        uu, vv = ec.synth_wind(ni, nj, seed=5); nout = no * mo
+    else:
+        gdin = ez.ezqkdef(no, mo, "G", 0, 0, 0, 0); gdout = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay)
+        uu, vv = ec.synth_wind(no, mo, seed=5); nout = ni * nj
+    assert ez.ezdefset(gdout, gdin) == 1
+    for degree in (3, 1):
+        setopts(degree, 1)
+        res = {}
+        for mode in ("matrix", "nofuse", "chain"):
+            monkeypatch.delenv("EZHIP_WIND_NO_MATRIX", raising=False); monkeypatch.delenv("EZHIP_WIND_NO_FUSE", raising=False)
+            if mode == "chain":
+                monkeypatch.setenv("EZHIP_WIND_NO_MATRIX", "1")
+            if mode == "nofuse":
+                monkeypatch.setenv("EZHIP_WIND_NO_FUSE", "1")
+            rc, u, v = ez.ezuvint(uu, vv, nout)
+            assert rc >= 0
+            res[mode] = (u.copy(), v.copy())
+        scale = np.maximum(np.hypot(res["chain"][0].astype(np.float64), res["chain"][1].astype(np.float64)), 1e-3)
+        for k in (0, 1):
+            assert np.max(np.abs(res["matrix"][k].astype(np.float64) - res["chain"][k]) / scale) <= 2e-6, (kind, degree, k)
+            assert np.array_equal(res["matrix"][k].view(np.uint32), res["nofuse"][k].view(np.uint32)), (kind, degree, k)
