@@ -2,7 +2,7 @@
 Development probe for the host-pointer ABI."""
 import ctypes, time, sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
 import torch
 from librmn_amd import load_library
 L = load_library()

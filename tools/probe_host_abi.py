@@ -2,7 +2,7 @@
 ezhip_register_host_buffer for 1..16 row ranges; bitwise equality of the results."""
 import ctypes, os, sys, time
 import numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+_R = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."); sys.path.insert(0, _R); sys.path.insert(0, __import__("os").path.join(_R, "tests"))
 import torch
 from librmn_amd import ezscint as ez, load_library
 import ezcases as ec

@@ -2,7 +2,7 @@
 algorithmic bandwidth per entry point.  Development tool: python tools/probe_interpv.py [ncols ns nd]"""
 import sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
 from librmn_amd import interpv as V
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 7200 * 3601 // 4
