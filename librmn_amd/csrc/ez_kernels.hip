@@ -1496,6 +1496,40 @@ __global__ __launch_bounds__(256) void k_pts_special(ezhip_pts_plan p, float *__
     }
 }
 
+/* the special points of a wind pair: both components, then the pair's wind matrix, in one launch (two k_pts_special launches and a
+ * list pass cost 2 x 8 + 4 us per cfg3 pair, each bound by the latency of its few dependent gathers) */
+__global__ __launch_bounds__(256) void k_pts_special2(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+                                                      const float *__restrict__ zin1, const float *__restrict__ zin2,
+                                                      const float *__restrict__ prow_n2, const float *__restrict__ prow_s2,
+                                                      const float *__restrict__ xs, const float *__restrict__ ys,
+                                                      const int *__restrict__ special_list, const unsigned *__restrict__ special_count,
+                                                      unsigned *__restrict__ next_count)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
+    const unsigned cnt = *special_count;
+    for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+        const int n = special_list[k];
+        const float px = xs[n], py = ys[n];
+        const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;
+        const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
+        FieldAcc Z1, Z2;
+        Z1.z = zin1; Z1.ni = p.ni; Z1.j1 = p.j1; Z1.j2 = p.j2; Z1.pole_n = 0.f; Z1.pole_s = 0.f; Z1.prow_n = nullptr; Z1.prow_s = nullptr;
+        Z2 = Z1; Z2.z = zin2;
+        float a, b;
+        if (zone == PZ_REINTERP) { a = gdinterp_point(p, Z1, p.degre_extrap, px, py); b = gdinterp_point(p, Z2, p.degre_extrap, px, py); }
+        else {
+            Z1.prow_n = p.pole_row_n; Z1.prow_s = p.pole_row_s; Z2.prow_n = prow_n2; Z2.prow_s = prow_s2;      /* vector mode: synthetic polar wind rows */
+            a = strip_point(p, Z1, zone == PZ_STRIP_N, px, py); b = strip_point(p, Z2, zone == PZ_STRIP_N, px, py);
+        }
+        if (p.wind_M) {
+            const float4 m = ((const float4 *)p.wind_M)[o];
+            const float u = a, v = b;
+            a = m.x * u + m.y * v; b = m.z * u + m.w * v;
+        }
+        zout1[o] = a; zout2[o] = b;
+    }
+}
+
 /* per host thread: the list of special point indices of a launch and a PAIR of counters (the special kernel of
  * launch e consumes counter e & 1 and zeroes the other one for launch e + 1: no memset between launches) */
 static thread_local struct { int *list; unsigned *count; size_t cap; unsigned epoch; } t_spec;
@@ -1529,19 +1563,6 @@ extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const
     return LAUNCH_CHECK("k_pts_special");
 }
 
-__global__ __launch_bounds__(256) void k_wind_apply_list(const float4 *__restrict__ M, float *__restrict__ uu, float *__restrict__ vv,
-                                                         const int *__restrict__ list, const unsigned *__restrict__ count, const int *__restrict__ out_idx)
-{
-    const unsigned cnt = *count;
-    for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
-        const int n = list[k];
-        const size_t o = out_idx ? (size_t)out_idx[n] : (size_t)n;
-        const float4 m = M[o];
-        const float u = uu[o], v = vv[o];
-        uu[o] = m.x * u + m.y * v; vv[o] = m.z * u + m.w * v;
-    }
-}
-
 /* vector pair: plan_u / plan_v differ only in their polar wind rows (read by the special points) */
 extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_plan *plan_v, float *d_out_u, float *d_out_v,
                                  const float *d_in_u, const float *d_in_v, const float *d_x, const float *d_y, int npts)
@@ -1567,12 +1588,15 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
 #undef PTS2_CASE
     if (LAUNCH_CHECK("k_pts2")) return -1;
     if (ezhip_side_join()) return -1;
-    /* the same list serves both components; both launches re-arm the same counter of the pair */
-    hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan_u, d_out_u, d_in_u, d_x, d_y, t_spec.list, cnt, cnt_next);
-    hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan_v, d_out_v, d_in_v, d_x, d_y, t_spec.list, cnt, cnt_next);
-    if (plan_u->wind_M)                  /* the listed points were stored un-rotated by the two launches above */
-        hipLaunchKernelGGL(k_wind_apply_list, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, (const float4 *)plan_u->wind_M, d_out_u, d_out_v, t_spec.list, cnt, plan_u->out_idx);
-    return LAUNCH_CHECK("k_pts_special");
+    if (!plan_u->vector_mode) {          /* two scalar fields sharing a point list: their pole values differ, one launch each */
+        hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan_u, d_out_u, d_in_u, d_x, d_y, t_spec.list, cnt, cnt_next);
+        hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan_v, d_out_v, d_in_v, d_x, d_y, t_spec.list, cnt, cnt_next);
+        return LAUNCH_CHECK("k_pts_special");
+    }
+    /* the listed points: both components and the wind matrix in one launch (vector mode: the plans differ in their polar wind rows only) */
+    hipLaunchKernelGGL(k_pts_special2, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v,
+                       plan_v->pole_row_n, plan_v->pole_row_s, d_x, d_y, t_spec.list, cnt, cnt_next);
+    return LAUNCH_CHECK("k_pts_special2");
 }
 
 /* ===================================================================================== */
