@@ -1,0 +1,33 @@
+"""Random shapes / field kinds / precisions of c_armn_compress32 + c_armn_uncompress32 against the oracle, bit for bit.
+python tools/fuzz_armn32.py [ncases] [seed]"""
+import os, sys
+_R = os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "tests"))
+import numpy as np
+import test_oracle_armn32 as ta32
+from librmn_amd import packers as pk
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for k in range(ncases):
+    ni = int(rng.integers(16, 1400)); nj = int(rng.integers(16, 500))
+    kind = ta32.KINDS[int(rng.integers(len(ta32.KINDS)))]
+    znbits = int(rng.choice([32, 28, 24, 20, 16, 12]))
+    f = ta32.field32(ni, nj, kind, seed=int(rng.integers(1 << 30)))
+    if rng.random() < 0.2:
+        f[rng.integers(0, f.size, 5)] = 0.0                      # exact zeros (exponent 0) in the planes
+    zw = np.zeros(ni * nj * max(znbits, 8) // 32 + 1024, np.uint32)
+    want = ta32.O().orc_armn_compress32(zw.ctypes.data, f.ctypes.data, ni, nj, 1, znbits)
+    got, zg = pk.armn_compress32(f, ni, nj, znbits)
+    ok = got == want
+    if ok and want > 0:
+        ok = np.array_equal(zg[:want // 4], zw[:want // 4])
+        if ok:
+            rc, back = pk.armn_uncompress32(zg, ni, nj, znbits)
+            back_o = np.zeros(ni * nj, np.float32)
+            ta32.O().orc_armn_uncompress32(back_o.ctypes.data, zg.ctypes.data, ni, nj, 1, znbits)
+            ok = rc == ni * nj and np.array_equal(back.view(np.uint32), back_o.view(np.uint32))
+    if not ok:
+        bad += 1
+        print("MISMATCH", dict(ni=ni, nj=nj, kind=kind, znbits=znbits, got=got, want=want), flush=True)
+print(f"armn32: {ncases} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
