@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 
 #include "ezhip_shim.h"
 #include "packhip_shim.h"
@@ -37,15 +38,24 @@ static void *w32(int slot, size_t bytes)
 
 /* ---- MSB-first bit stream on host words: the `stuff` / `extract` rules (include/bitPacking.h:59-139) ---- */
 typedef struct { uint32_t *z; uint64_t pos; } bitw32;              /* over a zeroed buffer */
-static void bw32_put(bitw32 *w, uint32_t tok, int bits)
+static inline void bw32_put(bitw32 *w, uint32_t tok, int bits)              /* bits <= 32, tok < 2^bits, buffer zeroed: at most two words touched */
 {
-    for (int b = bits - 1; b >= 0; b--, w->pos++) if ((tok >> b) & 1u) w->z[w->pos >> 5] |= 0x80000000u >> (w->pos & 31);
+    const uint64_t p = w->pos;
+    const int sh = 64 - bits - (int)(p & 31);
+    const uint64_t v = (uint64_t)tok << sh;
+    w->z[p >> 5] |= (uint32_t)(v >> 32);
+    if ((uint32_t)v) w->z[(p >> 5) + 1] |= (uint32_t)v;
+    w->pos = p + (uint64_t)bits;
 }
-static uint32_t br32_get(const uint32_t *z, uint64_t *pos, int bits)
+static inline uint32_t br32_get(const uint32_t *z, uint64_t *pos, int bits)  /* bits <= 32; the second word is read only when the field reaches it */
 {
-    uint32_t v = 0;
-    for (int b = 0; b < bits; b++, (*pos)++) v = v << 1 | ((z[*pos >> 5] >> (31 - (*pos & 31))) & 1u);
-    return v;
+    if (!bits) return 0;
+    const uint64_t p = *pos;
+    const int o = (int)(p & 31);
+    uint64_t v = (uint64_t)z[p >> 5] << 32;
+    if (o + bits > 32) v |= z[(p >> 5) + 1];
+    *pos = p + (uint64_t)bits;
+    return (uint32_t)(v >> (64 - bits - o)) & (bits == 32 ? 0xFFFFFFFFu : (1u << bits) - 1u);
 }
 /* a stream of P data bits followed by the 32 terminator bits occupies ceil(P / 32) flushed words: zlng = 1 + 4 * that (:559-561) */
 static uint32_t zlng_of_bits(uint64_t P) { return 1u + 4u * (uint32_t)((P + 31) >> 5); }
@@ -58,15 +68,24 @@ static uint32_t rle_encode(uint32_t *z, const uint32_t *mask, int npts)
     bitw32 w = {z, 0};
     int last = 0, idx = 1;
     while (idx <= npts) {
-        while (idx < npts && SGN(idx) == SGN(last)) idx++;
+        {   /* the end of the run of equal signs that starts at `last`, 32 points per step */
+            const uint32_t flip = SGN(last) ? 0xFFFFFFFFu : 0u;
+            while (idx < npts) {
+                uint32_t dif = (mask[idx >> 5] ^ flip) & (0xFFFFFFFFu << (idx & 31));       /* points idx .. of this word that differ from the run's sign */
+                if (dif) { const int nxt = (idx & ~31) + __builtin_ctz(dif); idx = nxt < npts ? nxt : npts; break; }
+                idx = (idx & ~31) + 32;
+                if (idx > npts) idx = npts;
+            }
+        }
         const int count = idx - last;
         int i = 0, repeat = 0;
         do {
             int c = count < 8 ? count : ((count - i) >= 63 ? 62 : count - i);
             if (c < 8) {
-                bw32_put(&w, 0, 1);
                 const int lim = last + 7 > npts ? npts - last : 7;
-                for (int j = 0; j < lim; j++) bw32_put(&w, SGN(last + j), 1);
+                uint32_t raw = 0;
+                for (int j = 0; j < lim; j++) raw = raw << 1 | SGN(last + j);
+                bw32_put(&w, raw, 1 + lim);                      /* the 0 flag, then the signs, first point first */
                 last += 7;
             } else if (c == 62 && (count - i) > 256 && repeat) {
                 c = 255;
@@ -94,12 +113,16 @@ static void rle_decode(uint32_t *mask, const uint32_t *z, int npts)
     while (i < npts) {
         if (br32_get(z, &pos, 1) == 0) {
             const int lim = i + 7 > npts ? npts - i : 7;
-            for (int j = 0; j < lim; j++) { const uint32_t b = br32_get(z, &pos, 1); SETS(i + j, b); }
+            const uint32_t raw = br32_get(z, &pos, lim);
+            for (int j = 0; j < lim; j++) SETS(i + j, (raw >> (lim - 1 - j)) & 1u);
             i += lim;
         } else {
-            const uint32_t val = br32_get(z, &pos, 1); const int count = (int)br32_get(z, &pos, 6);
-            if (count == 63) { for (int j = 0; j < 255; j++) SETS(i + j, last_val & 1u); i += 255; }
-            else { for (int j = 0; j < count; j++) SETS(i + j, val); i += count; last_val = val; }
+            const uint32_t tok = br32_get(z, &pos, 7), val = tok >> 6; const int count = (int)(tok & 63u);
+            const int run = count == 63 ? 255 : count;
+            const uint32_t bit = count == 63 ? (last_val & 1u) : val;
+            if (bit) for (int j = 0; j < run; j++) SETS(i + j, 1u);
+            i += run;
+            if (count != 63) last_val = val;
         }
     }
 #undef SETS
@@ -212,12 +235,9 @@ static uint64_t *walk_tiles(const uint32_t *z, int ni, int nj, int nbits, size_t
     return tp;
 }
 
-/* one plane back: host stream words -> device plane of ints (slot: which workspaces) */
-static int decode_plane(int *d_plane, const uint32_t *z, int ni, int nj, int nbits, int wide, int slot)
+/* one plane back: host stream words + the tile positions walked on the host -> device plane of ints (slot: which workspaces) */
+static int decode_plane(int *d_plane, const uint32_t *z, const uint64_t *tp, size_t ntiles, int ni, int nj, int nbits, int wide, int slot)
 {
-    size_t ntiles = 0;
-    uint64_t *tp = walk_tiles(z, ni, nj, nbits, &ntiles);
-    if (!tp) return -1;
     const size_t zwords = (size_t)((tp[ntiles] + 63) >> 5) + 2;
     unsigned *d_zs = (unsigned *)w32(slot, 4 * zwords);
     unsigned long long *d_tp = (unsigned long long *)w32(slot + 1, 8 * (ntiles + 1));
@@ -226,9 +246,14 @@ static int decode_plane(int *d_plane, const uint32_t *z, int ni, int nj, int nbi
     if (d_zs && d_tp && d_bs && !ezhip_h2d(d_zs, z, 4 * zwords) && !ezhip_h2d(d_tp, tp, 8 * (ntiles + 1)))
         rc = packhip_pg_decode(d_plane, d_bs, d_zs, d_tp, ni, nj, nbits, wide);
     if (ezhip_sync()) rc = -1;
-    free(tp);
     return rc;
 }
+
+/* the three sequential host walks of a stream (sign run lengths, exponent tile chain, mantissa tile chain) are independent: one thread each */
+typedef struct { const uint32_t *z; int ni, nj, nbits; uint64_t *tp; size_t ntiles; } walk_job;
+static void *walk_thread(void *a) { walk_job *j = (walk_job *)a; j->tp = walk_tiles(j->z, j->ni, j->nj, j->nbits, &j->ntiles); return NULL; }
+typedef struct { const uint32_t *z; uint32_t *mask; int npts; } rle_job;
+static void *rle_thread(void *a) { rle_job *j = (rle_job *)a; rle_decode(j->mask, j->z, j->npts); return NULL; }
 
 /* c_armn_uncompress32 with the result on the device; zstream: HOST memory (the chain of tile headers is walked on the host) */
 int c_armn_uncompress32_dev(float *d_fld, const unsigned char *zstream, int ni, int nj, int nk, int znbits)
@@ -247,25 +272,36 @@ int c_armn_uncompress32_dev(float *d_fld, const unsigned char *zstream, int ni, 
     unsigned *d_smask = (unsigned *)w32(2, 4 * (n / 32 + 2) + 16);
     int *d_expo = (int *)w32(0, 4 * n + 16), *d_mant = (int *)w32(1, 4 * n + 16);
     if (!d_smask || !d_expo || !d_mant) return -1;
-    if (code_signe == 0x20 || code_signe == 0x30) {
-        const uint32_t lng = *cur++;
-        uint32_t *mask = (uint32_t *)calloc(n / 32 + 2 + 16, 4);
-        if (!mask) return -1;
-        rle_decode(mask, cur, (int)n);
-        int bad = ezhip_h2d(d_smask, mask, 4 * (n / 32 + 1)) || ezhip_sync();
-        free(mask);
-        if (bad) return -1;
-        cur += lng >> 2;
-    }
-    if (code_expo == 0x08 || code_expo == 0x0C) {
-        const uint32_t lng = *cur++;
-        if (decode_plane(d_expo, cur, ni, nj, (int)need_e, 0, 3)) return -1;
-        cur += lng >> 2;
-    }
+    /* the three sub-streams: [lng, sign run lengths] [lng, exponent plane] [slot, mantissa plane] */
+    const int have_s = code_signe == 0x20 || code_signe == 0x30, have_e = code_expo == 0x08 || code_expo == 0x0C;
+    const uint32_t *z_s = NULL, *z_e = NULL, *z_m;
+    if (have_s) { const uint32_t lng = *cur++; z_s = cur; cur += lng >> 2; }
+    if (have_e) { const uint32_t lng = *cur++; z_e = cur; cur += lng >> 2; }
     cur++;                                                       /* the mantissa length slot */
-    if (decode_plane(d_mant, cur, ni, nj, nbits, 1, 3)) return -1;
-    if (packhip_a32_combine(d_fld, d_expo, d_mant, d_smask, n, nbits, exp_min, code_signe, code_expo != 0)) return -1;
-    return (int)n;
+    z_m = cur;
+    rle_job rj = { z_s, NULL, (int)n };
+    walk_job we = { z_e, ni, nj, (int)need_e, NULL, 0 }, wm = { z_m, ni, nj, nbits, NULL, 0 };
+    pthread_t th_s, th_e;
+    int run_s = 0, run_e = 0, rc = -1;
+    if (have_s) {
+        rj.mask = (uint32_t *)calloc(n / 32 + 2 + 16, 4);
+        if (!rj.mask) return -1;
+        run_s = pthread_create(&th_s, NULL, rle_thread, &rj) == 0;
+        if (!run_s) rle_thread(&rj);
+    }
+    if (have_e) { run_e = pthread_create(&th_e, NULL, walk_thread, &we) == 0; if (!run_e) walk_thread(&we); }
+    walk_thread(&wm);                                            /* this thread walks the longest chain */
+    if (run_e) pthread_join(th_e, NULL);
+    if (run_s) pthread_join(th_s, NULL);
+    if ((have_e && !we.tp) || !wm.tp) goto out;
+    if (have_s && (ezhip_h2d(d_smask, rj.mask, 4 * (n / 32 + 1)) || ezhip_sync())) goto out;
+    if (have_e && decode_plane(d_expo, z_e, we.tp, we.ntiles, ni, nj, (int)need_e, 0, 3)) goto out;
+    if (decode_plane(d_mant, z_m, wm.tp, wm.ntiles, ni, nj, nbits, 1, 3)) goto out;
+    if (packhip_a32_combine(d_fld, d_expo, d_mant, d_smask, n, nbits, exp_min, code_signe, code_expo != 0)) goto out;
+    rc = (int)n;
+out:
+    free(rj.mask); free(we.tp); free(wm.tp);
+    return rc;
 }
 
 int c_armn_uncompress32(float *fld, unsigned char *zstream, int ni, int nj, int nk, int znbits)
