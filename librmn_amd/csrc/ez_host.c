@@ -71,6 +71,7 @@ typedef struct ezh_set {
 typedef struct {
     int used, refcount;
     char grtyp, grref;
+    char shown;             /* the type the caller gave when it differs from the one computed with: '#' (a regional tile through c_ezgdef_fmem is a 'Z' grid, ez_defaxes.c:44-55) */
     int ni, nj, ig[4], igref[4];
     float xg[4], xgref[4];
     int i1, i2, j1, j2, extension;
@@ -513,11 +514,11 @@ static int type_supported(char t, char ref, int ig1, int ig2)
     return 0;
 }
 
-static int find_grid(int ni, int nj, char t, char ref, const int *ig, const float *ax, const float *ay)
+static int find_grid(int ni, int nj, char t, char ref, const int *ig, const float *ax, const float *ay, char shown)
 {
     for (int k = 0; k < nG; k++) {
         ezh_grid *g = &G[k];
-        if (!g->used || g->ni != ni || g->nj != nj || g->grtyp != t) continue;
+        if (!g->used || g->ni != ni || g->nj != nj || g->grtyp != t || g->shown != shown) continue;
         if (memcmp(g->ig, ig, sizeof(int) * 4)) continue;
         if (t == 'Z') {
             if (g->grref != ref) continue;
@@ -534,20 +535,30 @@ static int find_grid(int ni, int nj, char t, char ref, const int *ig, const floa
 
 int32_t c_ezgdef_fmem(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t ig1, int32_t ig2, int32_t ig3, int32_t ig4, float *ax, float *ay)
 {
-    char t = grtyp[0], ref = grref ? grref[0] : ' ';
+    char t = grtyp[0], ref = grref ? grref[0] : ' ', shown = 0;
+    if (t == '#') {
+        /* a tile defined from memory carries its own ni / nj axes: every routine of the reference groups it with 'Z' (ez_defaxes.c:44-55,
+         * ez_calcxy.c:78-80, ez_defzones.c:62-63 ...) except the polar pieces (pole position, weighted polar wind, strip kernels), which
+         * a regional grid never reaches.  Regional tiles only; grids read from a file are out of scope */
+        if ((ref != 'L' && ref != 'E') || !ax || !ay || ni < 2 || !(358.0 > (ax[ni - 1] - ax[0]))) {
+            fprintf(stderr, "<c_ezgdef_fmem> '#' grids: regional tiles on an 'L' or 'E' reference only (a global '#' grid takes other polar kernels than 'Z' in the reference)\n");
+            return -1;
+        }
+        t = 'Z'; shown = '#';
+    }
     if (!type_supported(t, ref, ig1, ig2)) {
         fprintf(stderr, "<c_ezgdef_fmem> grid type '%c' (ref '%c') is outside the MI355X hot-path scope\n", t, ref);
         return -1;
     }
     int ig[4] = {ig1, ig2, ig3, ig4};
     pthread_mutex_lock(&g_mtx);
-    int gd = find_grid(ni, nj, t, ref, ig, ax, ay);
+    int gd = find_grid(ni, nj, t, ref, ig, ax, ay, shown);
     if (gd >= 0) { G[gd].refcount++; pthread_mutex_unlock(&g_mtx); return gd; }
     gd = grid_slot();
     if (gd < 0) { pthread_mutex_unlock(&g_mtx); return -1; }
     ezh_grid *g = &G[gd];
     memset(g, 0, sizeof(*g));
-    g->used = 1; g->refcount = 1; g->grtyp = t; g->grref = (t == 'Z' || t == 'Y') ? ref : 0;
+    g->used = 1; g->refcount = 1; g->grtyp = t; g->shown = shown; g->grref = (t == 'Z' || t == 'Y') ? ref : 0;
     g->ni = ni; g->nj = nj; memcpy(g->ig, ig, sizeof(ig));
     switch (t) {                                            /* c_ezdefxg, ez_defxg.c:28-170 */
     case 'A': case 'G':                                     /* ez_defxg.c:39-62 */
@@ -678,7 +689,7 @@ int32_t c_ezgprm(int32_t gd, char *grtyp, int32_t *ni, int32_t *nj, int32_t *ig1
 {
     if (!grid_ok(gd)) return -1;
     ezh_grid *g = &G[gd];
-    grtyp[0] = g->grtyp; *ni = g->ni; *nj = g->nj; *ig1 = g->ig[0]; *ig2 = g->ig[1]; *ig3 = g->ig[2]; *ig4 = g->ig[3];
+    grtyp[0] = g->shown ? g->shown : g->grtyp; *ni = g->ni; *nj = g->nj; *ig1 = g->ig[0]; *ig2 = g->ig[1]; *ig3 = g->ig[2]; *ig4 = g->ig[3];
     return 0;
 }
 int32_t c_ezgxprm(int32_t gd, int32_t *ni, int32_t *nj, char *grtyp, int32_t *ig1, int32_t *ig2, int32_t *ig3, int32_t *ig4,
@@ -686,7 +697,7 @@ int32_t c_ezgxprm(int32_t gd, int32_t *ni, int32_t *nj, char *grtyp, int32_t *ig
 {
     if (!grid_ok(gd)) return -1;
     ezh_grid *g = &G[gd];
-    grtyp[0] = g->grtyp; grtyp[1] = 0; *ni = g->ni; *nj = g->nj;
+    grtyp[0] = g->shown ? g->shown : g->grtyp; grtyp[1] = 0; *ni = g->ni; *nj = g->nj;
     *ig1 = g->ig[0]; *ig2 = g->ig[1]; *ig3 = g->ig[2]; *ig4 = g->ig[3];
     if (g->grtyp == 'Z' || g->grtyp == 'G') {
         grref[0] = g->grref; grref[1] = 0;

@@ -1165,3 +1165,23 @@ def test_wind_matrix_equals_the_chain(kind, monkeypatch):
         for k in (0, 1):
             assert np.max(np.abs(res["matrix"][k].astype(np.float64) - res["chain"][k]) / scale) <= 2e-6, (kind, degree, k)
             assert np.array_equal(res["matrix"][k].view(np.uint32), res["nofuse"][k].view(np.uint32)), (kind, degree, k)
+
+
+def test_regional_hash_tile_equals_the_z_grid():
+    """c_ezgdef_fmem('#', ...) on a regional tile: the same bits as the 'Z' grid with the same axes, scalars and winds (the reference
+    agrees with itself on this: tests/test_oracle_vs_ref.py)"""
+    ni, nj, no, mo = 51, 41, 50, 40
+    ax, ay = ec.zereg_axes(ni, nj)
+    gz = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay); gh = ez.ezgdef_fmem(ni, nj, "#", "E", *ec.E_IG, ax, ay)
+    gdout = ez.ezqkdef(no, mo, "L", 100, 100, 9000, 24000)
+    zin = ec.synth_field(ni, nj, seed=4); uu, vv = ec.synth_wind(ni, nj, seed=4)
+    for degree in (0, 1, 3):
+        setopts(degree, 1)
+        out = []
+        for g in (gz, gh):
+            assert ez.ezdefset(gdout, g) == 1
+            rc, z = ez.ezsint(zin, no * mo); rcv, u, v = ez.ezuvint(uu, vv, no * mo)
+            out.append((rc, rcv, z, u, v))
+        assert out[0][:2] == out[1][:2]
+        for k in (2, 3, 4):
+            assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), (degree, k)

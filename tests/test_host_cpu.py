@@ -223,3 +223,21 @@ def test_vertical_interpolation_fails_loudly_without_gpu():
             "V.findpos(8, z, z); print('survived')")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
     assert r.returncode != 0 and "survived" not in r.stdout and "no CPU fallback" in r.stderr
+
+
+def test_hash_tiles_through_fmem_are_tracked_as_their_own_grids():
+    """a regional '#' tile is computed as a 'Z' grid but keeps its own handle and reports '#' (c_ezgprm); global tiles and tiles
+    without axes are refused"""
+    import ctypes, ezcases as ec
+    ni, nj = 51, 41
+    ax, ay = ec.zereg_axes(ni, nj)
+    gz = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay)
+    gh = ez.ezgdef_fmem(ni, nj, "#", "E", *ec.E_IG, ax, ay)
+    assert gz >= 0 and gh >= 0 and gz != gh
+    assert ez.ezgdef_fmem(ni, nj, "#", "E", *ec.E_IG, ax, ay) == gh
+    L = librmn_amd.load_library()
+    t = ctypes.create_string_buffer(4); v = [ctypes.c_int32() for _ in range(6)]
+    assert L.c_ezgprm(gh, t, *[ctypes.byref(x) for x in v]) == 0 and t.value[:1] == b"#"
+    assert L.c_ezgprm(gz, t, *[ctypes.byref(x) for x in v]) == 0 and t.value[:1] == b"Z"
+    gax = (np.arange(ni) * (360.0 / (ni - 1))).astype(np.float32)
+    assert ez.ezgdef_fmem(ni, nj, "#", "E", *ec.E_IG, gax, ay) == -1            # a global tile: other polar kernels than 'Z' in the reference

@@ -432,3 +432,33 @@ def test_regular_E_grids(name):
             rc_o = O.orc_ezsint(gs, ctypes.byref(opts), fptr(zo), fptr(zin))
             assert rc_o == rc_r and np.array_equal(zo.view(np.uint32), zr.view(np.uint32)), (name, degree, polar, int((zo != zr).sum()))
     ref_setopts(L, 3, 1)
+
+
+def test_regional_hash_tiles_are_z_grids_in_the_reference():
+    """a '#' tile defined through c_ezgdef_fmem carries its own ni / nj axes and takes the 'Z' branch everywhere a regional grid goes
+    (ez_defaxes.c:44-55, ez_calcxy.c:78-80, ez_defzones.c:62-63): the reference's own results for '#' and 'Z' are the same bits.
+    This is what lets the library treat such a tile as a 'Z' grid."""
+    L = ref()
+    ni, nj, no, mo = 51, 41, 50, 40
+    ax, ay = ec.zereg_axes(ni, nj)
+    gz = L.c_ezgdef_fmem(ni, nj, b"Z", b"E", *ec.E_IG, fptr(ax), fptr(ay))
+    gh = L.c_ezgdef_fmem(ni, nj, b"#", b"E", *ec.E_IG, fptr(ax), fptr(ay))
+    gdout = L.c_ezqkdef(no, mo, b"L", 100, 100, 9000, 24000, 0)
+    assert gz >= 0 and gh >= 0 and gz != gh
+    zin = ec.synth_field(ni, nj, seed=4); uu, vv = ec.synth_wind(ni, nj, seed=4)
+    for degree in (0, 1, 3):
+        for extrap in (4, 6, 1):
+            ref_setopts(L, degree, 1, extrap, 2.5)
+            res = []
+            for g in (gz, gh):
+                assert L.c_ezdefset(gdout, g) == 1
+                z = np.full(no * mo, -9.0, np.float32); u = z.copy(); v = z.copy()
+                rc = L.c_ezsint(fptr(z), fptr(zin)); rcv = L.c_ezuvint(fptr(u), fptr(v), fptr(uu), fptr(vv))
+                res.append((rc, rcv, z, u, v))
+            assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+            for k in (2, 3, 4):
+                assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), (degree, extrap, k)
+    lat = [np.zeros(ni * nj, np.float32) for _ in range(2)]; lon = [np.zeros(ni * nj, np.float32) for _ in range(2)]
+    for k, g in enumerate((gz, gh)):
+        assert L.c_gdll(g, fptr(lat[k]), fptr(lon[k])) >= 0
+    assert np.array_equal(lat[0], lat[1]) and np.array_equal(lon[0], lon[1])
