@@ -35,7 +35,8 @@ int32_t c_ezgxprm(int32_t gdid, int32_t *ni, int32_t *nj, char *grtyp, int32_t *
                   char *grref, int32_t *ig1ref, int32_t *ig2ref, int32_t *ig3ref, int32_t *ig4ref);                                  /* ezscint.h:57 */
 int32_t c_gdgaxes(int32_t gdid, float *ax, float *ay);                                                                               /* ezscint.h:96 */
 int32_t c_gdll(int32_t gdid, float *lat, float *lon);                                                                                /* ezscint.h:62 */
-int32_t c_gdxyfll(int32_t gdid, float *x, float *y, float *lat, float *lon, int32_t n);                                              /* ezscint.h:138 ; gdxyfll.c:141 */
+int32_t c_gdxyfll(int32_t gdid, float *x, float *y, float *lat, float *lon, int32_t n);                                              /* ezscint.h:138 ; gdxyfll.c:29-104 (c_gdxyfll_new), :162 */
+int32_t c_gdxyfll_orig(int32_t gdid, float *x, float *y, float *lat, float *lon, int32_t n);                                         /* ez_funcdef.h:178 ; gdxyfll.c:107-159: without the row inversion of y-inverted 'G' grids */
 
 /* ---- options (thread-local, string keyed; src/interp/ezsetopt.c:59-215) ------------------ */
 int32_t c_ezsetopt(char *option, char *value);                                                                                       /* ezscint.h:78 ; 0 ok / -1 */
@@ -87,7 +88,7 @@ int32_t c_ezsint_dev(float *d_zout, const float *d_zin);
 int32_t c_ezuvint_dev(float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin);
 int32_t c_ezwdint_dev(float *d_spdout, float *d_dirout, const float *d_uuin, const float *d_vvin);
 int32_t c_gdxysint_dev(float *d_zout, const float *d_zin, int32_t gdin, const float *d_x, const float *d_y, int32_t npts);
-int32_t c_gdxyfll_dev(int32_t gdid, float *d_x, float *d_y, const float *d_lat, const float *d_lon, int32_t n);
+int32_t c_gdxyfll_dev(int32_t gdid, float *d_x, float *d_y, const float *d_lat, const float *d_lon, int32_t n);   /* c_gdxyfll_orig on device data (no row inversion on y-inverted 'G' grids; not for hemispheric 'G' grids) */
 /* nfields independent fields on the current grid set; field f at d_zin + f*ni_in*nj_in, d_zout + f*ni_out*nj_out */
 int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields);
 /* the same launch additionally leaves, per field, {min key, max key, 0} triples (order-preserving uint32 keys of the floats)

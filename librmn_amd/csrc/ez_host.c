@@ -223,9 +223,12 @@ static void recip6(float *c, int ld, float a, float b, float cc, float d)
     c[3 * ld] = 1.f / (d - a); c[4 * ld] = 1.f / (d - b); c[5 * ld] = 1.f / (d - cc);
 }
 
+/* rows of the latitude table: a hemispheric Gaussian grid keeps the 2 nj latitudes of the globe (ez_defaxes.c:93-99), its field is expanded
+ * into rows j1 .. j2 of that table */
+static int ay_rows(const ezh_grid *g) { return (g->grtyp == 'G' && g->ig[0] != 0) ? 2 * g->nj : g->nj; }
 static int h_nwtncof(ezh_grid *g)
 {
-    int ni = g->ni, nj = g->nj, ext = g->extension;
+    int ni = g->ni, nj = ay_rows(g), ext = g->extension;
     const float *ax = g->ax, *ay = g->ay;
     for (int i = 0; i + 1 < ni; i++) if (ax[i + 1] <= ax[i]) { fprintf(stderr, "ez_nwtncof: x axis must be strictly increasing\n"); exit(13); }
     for (int j = 0; j + 1 < nj; j++) if (ay[j + 1] <= ay[j]) { fprintf(stderr, "ez_nwtncof: y axis must be strictly increasing\n"); exit(13); }
@@ -417,6 +420,7 @@ static void h_vxyfll(float *x, float *y, const float *dlat, const float *dlon, i
     }
 }
 
+static __thread int t_locate_j2;       /* 1 inside c_gdxyfll_orig: the search length of gdxyfll.c (see the 'G' / 'Z' branch) */
 static int h_locate(const ezh_grid *g, float *x, float *y, const float *lat, float *lon, int n)
 {
     int ni = g->ni, nj = g->nj;
@@ -465,12 +469,19 @@ static int h_locate(const ezh_grid *g, float *x, float *y, const float *lat, flo
         } else {
             h_rotate(x, y, lon, lat, n, g->xgref, 1);
         }
-        for (int i = 0; i < n; i++) {
-            int ix = h_cherche(x[i], g->ax, ni), iy = h_cherche(y[i], g->ay, nj);
-            if (ix >= ni) ix = ni - 1;
-            if (iy >= nj) iy = nj - 1;
-            x[i] = (float)ix + (x[i] - g->ax[ix - 1]) / (g->ax[ix] - g->ax[ix - 1]);
-            y[i] = (float)iy + (y[i] - g->ay[iy - 1]) / (g->ay[iy] - g->ay[iy - 1]);
+        {
+            /* entries of ay the search runs over: gr.nj for the x, y of a set (ez_calcxy.c:49), gr.j2 for c_gdxyfll (gdxyfll.c:143); they
+             * differ on a hemispheric 'G' grid.  A northern hemisphere then has that count subtracted (ez_calcxy.c:90-96, gdxyfll.c:149-153):
+             * its points were sought among the SOUTHERN latitudes of the table and lie beyond the end of that half, extrapolated */
+            const int njs = t_locate_j2 ? g->j2 : nj;
+            for (int i = 0; i < n; i++) {
+                int ix = h_cherche(x[i], g->ax, ni), iy = h_cherche(y[i], g->ay, njs);
+                if (ix >= ni) ix = ni - 1;
+                if (iy >= njs) iy = njs - 1;
+                x[i] = (float)ix + (x[i] - g->ax[ix - 1]) / (g->ax[ix] - g->ax[ix - 1]);
+                y[i] = (float)iy + (y[i] - g->ay[iy - 1]) / (g->ay[iy] - g->ay[iy - 1]);
+            }
+            if (g->grtyp == 'G' && g->ig[0] == 1) for (int i = 0; i < n; i++) y[i] = y[i] - (float)njs;
         }
         return 0;
     }
@@ -502,13 +513,14 @@ static int h_locate_mt(const ezh_grid *g, float *x, float *y, const float *lat, 
 /* ------------------------------------------------------------------------------------------ */
 /* grid table                                                                                   */
 /* ------------------------------------------------------------------------------------------ */
+int32_t c_gdxyfll_orig(int32_t gd, float *x, float *y, float *lat, float *lon, int32_t n);
 static int grid_ok(int gd) { return gd >= 0 && gd < __atomic_load_n(&nG, __ATOMIC_ACQUIRE) && __atomic_load_n(&G[gd].used, __ATOMIC_ACQUIRE); }
 
 static int type_supported(char t, char ref, int ig1, int ig2)
 {
     if (t == 'L' || t == 'E' || t == 'N' || t == 'S') return 1;
     if (t == 'A' || t == 'B') return ig1 >= 0 && ig1 <= 2 && ig2 >= 0 && ig2 <= 1;   /* hemispheric / y-inverted: scalars only */
-    if (t == 'G') return ig1 == 0 && ig2 >= 0 && ig2 <= 1;
+    if (t == 'G') return ig1 >= 0 && ig1 <= 2 && ig2 >= 0 && ig2 <= 1;   /* hemispheres: scalars; the northern one reproduces the reference's locate (ez_calcxy.c:90-96) literally */
     if (t == 'Z') return ref == 'L' || ref == 'E';
     if (t == 'Y') return ref == 'L';                                      /* as a target; c_ezdefset refuses it as a source */
     return 0;
@@ -594,8 +606,8 @@ int32_t c_ezgdef_fmem(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t 
         g->ax = (float *)malloc(sizeof(float) * ni);
         float dlon = (float)(360. / (float)ni);
         for (int i = 0; i < ni; i++) g->ax[i] = (float)i * dlon;
-        g->ay = (float *)malloc(sizeof(float) * nj);
-        h_gauss_lat(g->ay, nj);
+        g->ay = (float *)malloc(sizeof(float) * (ig1 ? 2 * nj : nj));
+        h_gauss_lat(g->ay, ig1 ? 2 * nj : nj);
     }
     h_xpncof(g);
     if (t == 'Z' || t == 'G') h_nwtncof(g);
@@ -868,7 +880,7 @@ static void ensure_coords(ezh_grid *g)
         for (int j = 0; j < nj; j++) g->lat1d[j] = lat00 + (float)j * dlat;
         for (int i = 0; i < ni; i++) g->lon1d[i] = fmodf(0.0f + (float)i * dlon, 360.0f);
     } else {   /* G, Z */
-        for (int j = 0; j < nj; j++) g->lat1d[j] = g->ay[j];
+        for (int j = 0; j < nj; j++) g->lat1d[j] = g->ay[(g->grtyp == 'G' && g->ig[0] == 1) ? j + nj : j];      /* ez_calclatlon.c:167-176 */
         for (int i = 0; i < ni; i++) g->lon1d[i] = g->ax[i];
         if (g->grref == 'L') {
             for (int j = 0; j < nj; j++) {
@@ -914,15 +926,28 @@ int32_t c_gdll(int32_t gd, float *lat, float *lon)
 
 /* c_gdxyfll / c_gdxyfll_orig, gdxyfll.c:90-139: regular sources work on a copy of lon, G/Z sources
  * modify the caller's lon in place. */
-int32_t c_gdxyfll(int32_t gd, float *x, float *y, float *lat, float *lon, int32_t n)
+/* c_gdxyfll_orig (gdxyfll.c:107-159): what the library itself locates with (pole positions, c_gdllsval, c_gdllvval, c_gdxyzfll, Yin-Yang) */
+int32_t c_gdxyfll_orig(int32_t gd, float *x, float *y, float *lat, float *lon, int32_t n)
 {
     if (!grid_ok(gd)) return -1;
     ezh_grid *g = &G[gd];
+    if (g->grtyp == 'G' && g->ig[0] != 0) { t_locate_j2 = 1; int rc = h_locate(g, x, y, lat, lon, n); t_locate_j2 = 0; return rc; }
     if (g->grtyp == 'G' || g->grtyp == 'Z') return h_locate_mt(g, x, y, lat, lon, n);
     float *tmp = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
     memcpy(tmp, lon, sizeof(float) * (size_t)n);
     int rc = h_locate_mt(g, x, y, lat, tmp, n);
     free(tmp);
+    return rc;
+}
+/* the public c_gdxyfll (gdxyfll.c:29-104 for every grid but 'U'): the same, and on a y-inverted Gaussian grid the row coordinate counted
+ * from the other end, y := nj_in + 1 - y with nj_in = j2 (:88-94) -- the stored order of such a grid's rows */
+int32_t c_gdxyfll(int32_t gd, float *x, float *y, float *lat, float *lon, int32_t n)
+{
+    int rc = c_gdxyfll_orig(gd, x, y, lat, lon, n);
+    if (rc >= 0 && G[gd].grtyp == 'G' && G[gd].ig[1] == 1) {
+        const int nj_in = G[gd].j2;
+        for (int k = 0; k < n; k++) y[k] = (float)(((double)nj_in + 1.0) - (double)y[k]);
+    }
     return rc;
 }
 
@@ -960,16 +985,17 @@ static int ensure_grid_dev(ezh_grid *g)
 {
     if (g->ax && !g->d_ax) {
         g->d_ax = (float *)upload(g->ax, sizeof(float) * g->ni);
-        g->d_ay = (float *)upload(g->ay, sizeof(float) * g->nj);
+        const int nr = ay_rows(g);
+        g->d_ay = (float *)upload(g->ay, sizeof(float) * nr);
         g->d_ncx = (float *)upload(g->ncx, sizeof(float) * 6 * g->ni);
-        g->d_ncy = (float *)upload(g->ncy, sizeof(float) * 6 * g->nj);
+        g->d_ncy = (float *)upload(g->ncy, sizeof(float) * 6 * nr);
         {
-            float *t8 = (float *)calloc((size_t)8 * (g->ni > g->nj ? g->ni : g->nj), sizeof(float));
+            float *t8 = (float *)calloc((size_t)8 * (g->ni > nr ? g->ni : nr), sizeof(float));
             for (int i = 0; i < g->ni; i++) for (int k = 0; k < 6; k++) t8[8 * i + k] = g->ncx[k * g->ni + i];
             g->d_ncx8 = (float *)upload(t8, sizeof(float) * 8 * g->ni);
             ezhip_sync();
-            for (int j = 0; j < g->nj; j++) for (int k = 0; k < 6; k++) t8[8 * j + k] = g->ncy[k * g->nj + j];
-            g->d_ncy8 = (float *)upload(t8, sizeof(float) * 8 * g->nj);
+            for (int j = 0; j < nr; j++) for (int k = 0; k < 6; k++) t8[8 * j + k] = g->ncy[k * nr + j];
+            g->d_ncy8 = (float *)upload(t8, sizeof(float) * 8 * nr);
             ezhip_sync();
             free(t8);
         }
@@ -1004,7 +1030,7 @@ static int src_is_separable(const ezh_grid *g)
     return !(g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E') || g->grtyp == 'N' || g->grtyp == 'S');
 }
 static int src_irregular(const ezh_grid *g) { return g->grtyp == 'G' || g->grtyp == 'Z'; }
-static int src_hemi(const ezh_grid *g) { return (g->grtyp == 'A' || g->grtyp == 'B') && g->ig[0] != 0; }
+static int src_hemi(const ezh_grid *g) { return (g->grtyp == 'A' || g->grtyp == 'B' || g->grtyp == 'G') && g->ig[0] != 0; }
 static int grid_yinv(const ezh_grid *g) { return (g->grtyp == 'A' || g->grtyp == 'B' || g->grtyp == 'G') && g->ig[1] == 1; }      /* axe_y_inverse, ez_defxg.c:68-72 */
 
 static int set_extrap(const ezh_grid *gi)
@@ -1020,8 +1046,8 @@ static void pole_y(const ezh_grid *gi, float *yn, float *ys)
 {   /* ez_defzone_polenord.c:46-53, ez_defzone_polesud.c:46-54 */
     if (gi->grtyp == 'Z' && gi->grref == 'E') { *yn = (float)(gi->nj + 0.5); *ys = 0.5f; return; }
     float x, lat, lon;
-    lat = 90.0f; lon = 0.0f; c_gdxyfll((int)(gi - G), &x, yn, &lat, &lon, 1);
-    lat = -90.0f; lon = 0.0f; c_gdxyfll((int)(gi - G), &x, ys, &lat, &lon, 1);
+    lat = 90.0f; lon = 0.0f; c_gdxyfll_orig((int)(gi - G), &x, yn, &lat, &lon, 1);
+    lat = -90.0f; lon = 0.0f; c_gdxyfll_orig((int)(gi - G), &x, ys, &lat, &lon, 1);
 }
 
 static void analyse_set(ezh_set *s)
@@ -1557,7 +1583,7 @@ static int ensure_points(ezh_set *s)
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     size_t n = (size_t)go->ni * go->nj;
     int rotated = gi->grtyp == 'E' || (gi->grtyp == 'Z' && gi->grref == 'E');
-    int host_locate = rotated && !getenv("EZHIP_DEVICE_LOCATE");
+    int host_locate = (rotated && !getenv("EZHIP_DEVICE_LOCATE")) || (gi->grtyp == 'G' && gi->ig[0] != 0);      /* hemispheric 'G': the reference's search quirk lives in the host code only */
     float *hx = NULL, *hy = NULL;
     if (ensure_grid_dev(gi)) return -1;
     float *dx = (float *)ezhip_malloc(sizeof(float) * n), *dy = (float *)ezhip_malloc(sizeof(float) * n);
@@ -1616,7 +1642,8 @@ static void fill_pts_plan(const ezh_set *s, const ezh_grid *gi, ezhip_pts_plan *
         const float *ay = gi->ay;
         if (ay[j2 - 1] == 90.0) { pp->ay4_n[0] = ay[j2 - 4]; pp->ay4_n[1] = ay[j2 - 3]; pp->ay4_n[2] = ay[j2 - 2]; pp->ay4_n[3] = ay[j2 - 1]; }
         else { pp->ay4_n[0] = ay[j2 - 3]; pp->ay4_n[1] = ay[j2 - 2]; pp->ay4_n[2] = ay[j2 - 1]; pp->ay4_n[3] = 90.0f; }
-        if (ay[j1 - 1] == -90.0) { pp->ay4_s[0] = ay[0]; pp->ay4_s[1] = ay[1]; pp->ay4_s[2] = ay[2]; pp->ay4_s[3] = ay[3]; }
+        /* northern hemispheric 'G' (j1 = 1 - nj): the reference reads ay[j1 - 1] in FRONT of the table (ez_corrval_ausud.c); entry 0 here */
+        if (ay[j1 - 1 < 0 ? 0 : j1 - 1] == -90.0) { pp->ay4_s[0] = ay[0]; pp->ay4_s[1] = ay[1]; pp->ay4_s[2] = ay[2]; pp->ay4_s[3] = ay[3]; }
         else { pp->ay4_s[0] = -90.0f; pp->ay4_s[1] = ay[0]; pp->ay4_s[2] = ay[1]; pp->ay4_s[3] = ay[2]; }
     }
 }
@@ -2207,7 +2234,7 @@ int32_t c_gdllsval(int32_t gdid, float *zout, float *zin, float *lat, float *lon
 {
     if (!grid_ok(gdid) || n < 0) return -1;
     float *x = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1)), *y = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
-    int rc = c_gdxyfll(gdid, x, y, lat, lon, n);
+    int rc = c_gdxyfll_orig(gdid, x, y, lat, lon, n);
     if (rc >= 0) rc = c_gdxysval(gdid, zout, zin, x, y, n);
     free(x); free(y);
     return rc < 0 ? rc : 0;
@@ -2225,7 +2252,7 @@ int32_t c_gdllvval(int32_t gdid, float *uuout, float *vvout, float *uuin, float 
 {
     if (!grid_ok(gdid) || n < 0) return -1;
     float *x = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1)), *y = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
-    int rc = c_gdxyfll(gdid, x, y, lat, lon, n);
+    int rc = c_gdxyfll_orig(gdid, x, y, lat, lon, n);
     if (rc >= 0) rc = c_gdxyvval(gdid, uuout, vvout, uuin, vvin, x, y, n);
     free(x); free(y);
     return rc < 0 ? rc : 0;
@@ -2555,7 +2582,7 @@ int32_t c_gdxyzfll(int32_t gdid, float *x, float *y, float *lat, float *lon, int
     if (!grid_ok(gdid)) return -1;
     ezh_grid *g = &G[gdid];
     switch (g->grtyp) {
-    case 'A': case 'B': case 'E': case 'G': case 'L': case 'N': case 'S': c_gdxyfll(gdid, x, y, lat, lon, n); break;
+    case 'A': case 'B': case 'E': case 'G': case 'L': case 'N': case 'S': c_gdxyfll_orig(gdid, x, y, lat, lon, n); break;
     case 'Y': fprintf(stderr, "<gdxyzfll>: This operation is not supported for 'Y' grids\n"); break;
     case 'Z':
         if (g->grref == 'L') {

@@ -224,7 +224,7 @@ orc_grid *orc_grid_define(int ni, int nj, char grtyp, char grref,
         if (ig1 < 0 || ig1 > 2 || ig2 < 0 || ig2 > 1) { fprintf(stderr, "orc_grid_define: bad ig1 / ig2\n"); free(g); return NULL; }
         break;
     case 'G':
-        if (ig1 != 0 || ig2 < 0 || ig2 > 1) { fprintf(stderr, "orc_grid_define: hemispheric 'G' grids out of scope\n"); free(g); return NULL; }
+        if (ig1 < 0 || ig1 > 2 || ig2 < 0 || ig2 > 1) { fprintf(stderr, "orc_grid_define: bad ig1 / ig2\n"); free(g); return NULL; }
         break;
     case 'L': case 'E': case 'Z': case 'N': case 'S': break;
     case 'Y': if (grref != 'L') { fprintf(stderr, "orc_grid_define: 'Y' grids on '%c' out of scope\n", grref); free(g); return NULL; } break;   /* target only */
@@ -267,8 +267,9 @@ orc_grid *orc_grid_define(int ni, int nj, char grtyp, char grref,
         g->ax = (float *)malloc(sizeof(float) * ni);
         float dlon = (float)(360. / (float)ni);
         for (int i = 0; i < ni; i++) g->ax[i] = (float)i * dlon;
-        g->ay = (float *)malloc(sizeof(float) * nj);
-        orc_gauss_lat(g->ay, nj);
+        const int nlat = ig1 == 0 ? nj : 2 * nj;              /* ez_defaxes.c:86-99: a hemisphere keeps the latitudes of the whole globe */
+        g->ay = (float *)malloc(sizeof(float) * nlat);
+        orc_gauss_lat(g->ay, nlat);
     }
     xpncof(g);
     if (grtyp == 'Z' || grtyp == 'G') {
@@ -374,6 +375,8 @@ int orc_calclatlon(orc_grid *g)
     case 'Z': case 'G':                                         /* :169-226 */
         for (int j = 0; j < nj; j++)
             for (int i = 0; i < ni; i++) { g->lat[j * ni + i] = g->ay[j]; g->lon[j * ni + i] = g->ax[i]; }
+        if (g->grtyp == 'G' && g->ig[0] == 1)                  /* ez_calclatlon.c:167-176 */
+            for (int j = 0; j < nj; j++) for (int i = 0; i < ni; i++) g->lat[j * ni + i] = g->ay[j + nj];
         if (g->grref == 'L') {
             for (int k = 0; k < npts; k++) { g->lat[k] += 1.0; g->lon[k] += 1.0; }
             for (int k = 0; k < npts; k++) {                    /* c_llfgr(lat, lon, x=lon, y=lat, ...) */
@@ -425,9 +428,12 @@ static void llll2gd(float *x, float *y, const float *dlat, float *dlon, int npts
 }
 
 /* ez_ll2igd, src/interp/ez_ll2igd.inc:22-86 (coordflag = RELATIF) */
-static void ll2igd(float *px, float *py, const float *xlat, float *xlon, int npts, const orc_grid *g)
+/* nj: the number of entries of ay the search runs over -- gr.nj in ez_calcxy.c:49, gr.j2 in gdxyfll.c:143 (they differ for a hemispheric
+ * 'G' grid, whose table holds the 2 nj latitudes of the globe); a northern hemisphere then has nj subtracted (ez_calcxy.c:90-96,
+ * gdxyfll.c:149-153): its points are sought among the SOUTHERN latitudes and land beyond the end of that half, extrapolated */
+static void ll2igd(float *px, float *py, const float *xlat, float *xlon, int npts, const orc_grid *g, int nj)
 {
-    int ni = g->ni, nj = g->j2;   /* gdxyfll.c:118 nj_in = gr.j2 (== nj for global grids) */
+    int ni = g->ni;
     if (g->grref == 'L') {
         float xlat0, xlon0, dlat, dlon;
         orc_cigaxg('L', &xlat0, &xlon0, &dlat, &dlon, g->igref[0], g->igref[1], g->igref[2], g->igref[3]);
@@ -447,6 +453,7 @@ static void ll2igd(float *px, float *py, const float *xlat, float *xlon, int npt
         px[i] = (float)indx + (px[i] - g->ax[indx - 1]) / (g->ax[indx] - g->ax[indx - 1]);
         py[i] = (float)indy + (py[i] - g->ay[indy - 1]) / (g->ay[indy] - g->ay[indy - 1]);
     }
+    if (g->grtyp == 'G' && g->ig[0] == 1) for (int i = 0; i < npts; i++) py[i] = py[i] - (float)nj;
 }
 
 /* ez_ll2rgd, src/interp/ez_ll2rgd.inc:22-166 (A, B, L, E branches; mutates xlon) */
@@ -536,7 +543,7 @@ int orc_gdxyfll(const orc_grid *g, float *x, float *y, const float *lat, float *
         return rc;
     }
     case 'Z': case 'G':
-        ll2igd(x, y, lat, lon, n, g);
+        ll2igd(x, y, lat, lon, n, g, g->j2);
         return 0;
     }
     return -1;
@@ -884,6 +891,15 @@ int orc_gdinterp(const orc_grid *g, int degree, float *zout, const float *zin,
     return -1;
 }
 
+/* the public c_gdxyfll (gdxyfll.c:29-104, every grid but 'U'): c_gdxyfll_orig, and on a y-inverted Gaussian grid y := nj_in + 1 - y (:88-94) */
+int orc_gdxyfll_public(const orc_grid *g, float *x, float *y, const float *lat, float *lon, int n)
+{
+    int rc = orc_gdxyfll(g, x, y, lat, lon, n);
+    if (rc >= 0 && g->grtyp == 'G' && g->ig[1] == 1)
+        for (int k = 0; k < n; k++) y[k] = (float)(((double)g->j2 + 1.0) - (double)y[k]);
+    return rc;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Gridset, locate cache, zones
  * ---------------------------------------------------------------------------------------- */
@@ -913,7 +929,7 @@ int orc_calcxy(orc_gridset *gs)   /* src/interp/ez_calcxy.c:28-137 */
     int rc;
     switch (gi->grtyp) {   /* note: operates on the target grid's cached lon IN PLACE */
     case 'A': case 'B': case 'E': case 'L': case 'N': case 'S': rc = ll2rgd(gs->x, gs->y, go->lat, go->lon, npts, gi); break;
-    case 'Z': case 'G': ll2igd(gs->x, gs->y, go->lat, go->lon, npts, gi); rc = 0; break;
+    case 'Z': case 'G': ll2igd(gs->x, gs->y, go->lat, go->lon, npts, gi, gi->nj); rc = 0; break;
     default: rc = -1;
     }
     gs->have_xy = 1;
@@ -1140,7 +1156,7 @@ int orc_ezsint(orc_gridset *gs, const orc_opts *o, float *zout, const float *zin
         orc_permut(pz, gi->ni, gi->nj);
         zin = pz;
     }
-    if ((gi->grtyp == 'A' || gi->grtyp == 'B') && gi->ig[0] != 0) {      /* ezsint.c:108-113 -> ez_xpnsrcgd */
+    if ((gi->grtyp == 'A' || gi->grtyp == 'B' || gi->grtyp == 'G') && gi->ig[0] != 0) {      /* ezsint.c:108-113 -> ez_xpnsrcgd */
         xz = (float *)malloc(sizeof(float) * 2 * (size_t)gi->ni * gi->nj);
         orc_xpnsrcgd(gi, xz, zin, o->vecteur == 2 ? 0 : 1);
         zin = xz;

@@ -67,6 +67,7 @@ void orc_nwtncof(float *cx, float *cy, const float *ax, const float *ay, int ni,
 int orc_calclatlon(orc_grid *g);
 /* c_gdxyfll_orig (src/interp/gdxyfll.c:90-139): lon[] may be modified in place */
 int orc_gdxyfll(const orc_grid *g, float *x, float *y, const float *lat, float *lon, int n);
+int orc_gdxyfll_public(const orc_grid *g, float *x, float *y, const float *lat, float *lon, int n);      /* c_gdxyfll; orc_gdxyfll is c_gdxyfll_orig */
 /* c_gdinterp (src/interp/gdinterp.c:96-313) with an explicit degree */
 int orc_gdinterp(const orc_grid *gdin, int degree, float *zout, const float *zin,
                  const float *x, const float *y, int npts);

@@ -1185,3 +1185,31 @@ def test_regional_hash_tile_equals_the_z_grid():
         assert out[0][:2] == out[1][:2]
         for k in (2, 3, 4):
             assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), (degree, k)
+
+
+import test_oracle_vs_ref as tovr     # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(tovr.HEMI_G))
+def test_hemispheric_gaussian_sources_vs_oracle(name):
+    """hemispheric 'G' sources (the table of 2 nj latitudes, the field mirrored into rows j1 .. j2, the reference's two search lengths and
+    its northern shift): the per-point kernel against the oracle, which equals the reference build on these cases bit for bit"""
+    case = tovr.HEMI_G[name]
+    ni, nj = case["src"][:2]; no, mo = case["dst"][:2]
+    gdin = ez.ezqkdef(ni, nj, "G", *case["src"][3]); gdout = ez.ezqkdef(no, mo, "L", *case["dst"][3])
+    assert gdin >= 0 and ez.ezdefset(gdout, gdin) == 1
+    O = ol.oracle()
+    gi = ol.grid_define(ni, nj, "G", case["src"][3]); go = ol.grid_define(no, mo, "L", case["dst"][3])
+    gs = O.orc_defset(go, gi)
+    zin = ec.synth_field(ni, nj, seed=21)
+    for degree in (0, 1, 3):
+        for polar in case["polar"]:
+            setopts(degree, polar)
+            rc, z = ez.ezsint(zin, no * mo)
+            want = np.zeros(no * mo, np.float32)
+            opts = ol.default_opts(degre_interp=degree, polar_correction=polar)
+            rc_o = O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(want), ol.fptr(zin))
+            assert rc == rc_o
+            assert np.array_equal(z.view(np.uint32), want.view(np.uint32)), (name, degree, polar, int(np.count_nonzero(z != want)))
+    uu, vv = ec.synth_wind(ni, nj, seed=2)
+    assert ez.ezuvint(uu, vv, no * mo)[0] == -1            # winds from a hemisphere: undefined in the reference (DESIGN section 7), refused

@@ -84,7 +84,8 @@ def test_grid_table_semantics():
     assert a == b and a >= 0                       # identical definitions dedupe (ez_identifygrid.c)
     assert ez.ezqkdef(30, 15, "N", 455, 505, 2100, 1000) >= 0  # polar-stereographic: supported
     assert ez.ezqkdef(30, 15, "!", 1, 1, 1, 1) == -1       # Lambert: out of scope, rejected loudly
-    assert ez.ezqkdef(30, 15, "G", 1, 0, 0, 0) == -1       # hemispheric: out of scope
+    assert ez.ezqkdef(30, 15, "G", 1, 0, 0, 0) >= 0        # hemispheric Gaussian: supported (scalars)
+    assert ez.ezqkdef(30, 15, "G", 3, 0, 0, 0) == -1       # ig1 is 0, 1 or 2
     assert ez.ezdefset(a, 9999) == -1
 
 
@@ -241,3 +242,28 @@ def test_hash_tiles_through_fmem_are_tracked_as_their_own_grids():
     assert L.c_ezgprm(gz, t, *[ctypes.byref(x) for x in v]) == 0 and t.value[:1] == b"Z"
     gax = (np.arange(ni) * (360.0 / (ni - 1))).astype(np.float32)
     assert ez.ezgdef_fmem(ni, nj, "#", "E", *ec.E_IG, gax, ay) == -1            # a global tile: other polar kernels than 'Z' in the reference
+
+
+@pytest.mark.parametrize("ig", [(2, 0, 0, 0), (1, 0, 0, 0), (2, 1, 0, 0), (0, 1, 0, 0)])
+def test_hemispheric_and_inverted_gaussian_grids_locate_like_the_reference(ig):
+    """c_gdll, c_gdxyfll and c_gdxyfll_orig of hemispheric / y-inverted 'G' grids against the reference build: the table of 2 nj
+    latitudes, the two search lengths (gr.nj for a set, gr.j2 for c_gdxyfll), the northern shift, the public routine's row inversion"""
+    import reflib
+    if not reflib.have_ref():
+        pytest.skip("oracle/_ref/libezref.so not built")
+    R = reflib.ref(); L = librmn_amd.load_library()
+    import ctypes
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    ni, nj = 64, 16
+    gr = R.c_ezqkdef(ni, nj, b"G", *ig, 0); gp = ez.ezqkdef(ni, nj, "G", *ig)
+    assert gr >= 0 and gp >= 0
+    la_r = np.zeros(ni * nj, np.float32); lo_r = np.zeros(ni * nj, np.float32); la_p = la_r.copy(); lo_p = la_r.copy()
+    assert R.c_gdll(gr, fp(la_r), fp(lo_r)) >= 0 and L.c_gdll(gp, fp(la_p), fp(lo_p)) >= 0
+    assert np.array_equal(la_r, la_p) and np.array_equal(lo_r, lo_p)
+    rng = np.random.default_rng(3)
+    lat = rng.uniform(-90, 90, 500).astype(np.float32); lon = rng.uniform(0, 360, 500).astype(np.float32)
+    for name in ("c_gdxyfll", "c_gdxyfll_orig"):
+        xr = np.zeros(500, np.float32); yr = xr.copy(); xp = xr.copy(); yp = xr.copy()
+        getattr(R, name)(gr, fp(xr), fp(yr), fp(lat), fp(lon.copy()), 500)
+        getattr(L, name)(gp, fp(xp), fp(yp), fp(lat), fp(lon.copy()), 500)
+        assert np.array_equal(xr, xp) and np.array_equal(yr, yp), (ig, name)

@@ -462,3 +462,52 @@ def test_regional_hash_tiles_are_z_grids_in_the_reference():
     for k, g in enumerate((gz, gh)):
         assert L.c_gdll(g, fptr(lat[k]), fptr(lon[k])) >= 0
     assert np.array_equal(lat[0], lat[1]) and np.array_equal(lon[0], lon[1])
+
+
+HEMI_G = {
+    # southern hemisphere: well defined in the reference (the bracket search runs over the southern half of the 2 nj latitudes)
+    "Gsud_to_Lsouth": dict(src=(64, 16, "G", (2, 0, 0, 0), " ", None), dst=(40, 18, "L", (400, 800, 1000, 0)), polar=(1, 0)),
+    "Gsud_to_Lglobal": dict(src=(64, 16, "G", (2, 0, 0, 0), " ", None), dst=(40, 21, "L", (800, 900, 500, 0)), polar=(1, 0)),
+    "GsudInv_to_L": dict(src=(64, 16, "G", (2, 1, 0, 0), " ", None), dst=(40, 18, "L", (400, 800, 1000, 0)), polar=(1, 0)),
+    # northern hemisphere: the reference looks the northern latitudes up among the SOUTHERN ones and subtracts nj (ez_calcxy.c:90-96) --
+    # reproduced literally; polar correction only where no target point falls into the southern strip (ez_corrval_ausud reads ay[j1 - 1])
+    "Gnord_to_Lnorth": dict(src=(64, 16, "G", (1, 0, 0, 0), " ", None), dst=(40, 18, "L", (400, 800, 10000, 0)), polar=(0,)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(HEMI_G))
+@pytest.mark.parametrize("degree", [0, 1, 3])
+def test_hemispheric_gaussian_sources(name, degree):
+    L = ref(); O = ol.oracle()
+    case = HEMI_G[name]
+    ni, nj = case["src"][:2]; no, mo = case["dst"][:2]
+    zin = ec.synth_field(ni, nj, seed=21)
+    for polar in case["polar"]:
+        gdin = ref_define(L, case["src"]); gdout = ref_define(L, case["dst"] + (" ", None))
+        ref_setopts(L, degree, polar)
+        assert L.c_ezdefset(gdout, gdin) == 1
+        zr = np.full(no * mo, -999.0, np.float32)
+        rc_r = L.c_ezsint(fptr(zr), fptr(zin))
+        gi = orc_define(case["src"]); go = orc_define(case["dst"] + (" ", None))
+        gs = O.orc_defset(go, gi)
+        zo = np.full(no * mo, -999.0, np.float32)
+        opts = ol.default_opts(degre_interp=degree, polar_correction=polar)
+        rc_o = O.orc_ezsint(gs, ctypes.byref(opts), fptr(zo), fptr(zin))
+        assert rc_o == rc_r
+        # the located x, y of the set: c_gdxyfll uses the other search length (gdxyfll.c:143), so compare through the set's own cache
+        x = np.zeros(no * mo, np.float32); y = np.zeros(no * mo, np.float32)
+        lat = np.zeros(no * mo, np.float32); lon = np.zeros(no * mo, np.float32)
+        L.c_gdll(gdout, fptr(lat), fptr(lon))
+        L.c_gdxyfll_orig(gdin, fptr(x), fptr(y), fptr(lat), fptr(lon.copy()), no * mo)
+        xo = np.zeros(no * mo, np.float32); yo = np.zeros(no * mo, np.float32)
+        O.orc_gdxyfll(gi, fptr(xo), fptr(yo), fptr(lat), fptr(lon.copy()), no * mo)
+        assert np.array_equal(x, xo) and np.array_equal(y, yo), name
+        L.c_gdxyfll(gdin, fptr(x), fptr(y), fptr(lat), fptr(lon.copy()), no * mo)          # the public one: row coordinate from the other end on y-inverted grids
+        O.orc_gdxyfll_public(gi, fptr(xo), fptr(yo), fptr(lat), fptr(lon.copy()), no * mo)
+        assert np.array_equal(x, xo) and np.array_equal(y, yo), name
+        assert np.array_equal(zo.view(np.uint32), zr.view(np.uint32)), f"{name} deg={degree} polar={polar}: {np.count_nonzero(zo != zr)} differ"
+    # gdll of the hemispheric grid itself
+    la = np.zeros(ni * nj, np.float32); lo = np.zeros(ni * nj, np.float32)
+    L.c_gdll(gdin, fptr(la), fptr(lo))
+    O.orc_calclatlon(gi)
+    assert np.array_equal(la, ol.np_from(gi.contents.lat, ni * nj)) and np.array_equal(lo, ol.np_from(gi.contents.lon, ni * nj))
