@@ -61,6 +61,7 @@ typedef struct ezh_set {
     float *d_scratch;       /* float[8]: fill value + keys, pole values */
     float *d_poles_batch; int poles_cap;   /* pole values of a c_ezsint_batch_dev batch (2 per field) */
     float *d_prow;          /* 2 * ni_src synthetic polar wind rows (vector mode), u then v: [u_n, u_s, v_n, v_s] */
+    float *d_avg;           /* interp_degree = average: the target cells' bounds [x_low | x_high | y_low | y_high] (ez_avg.inc:55-78) */
     void *d_windM;          /* c_ezuvint through a rotated frame: the wind chain of this grid pair as a 2 x 2 matrix per target point (built on first use) */
     /* Yin-Yang 'U' source (c_ezyy_calcxy, ezyy_calcxy.c): per subgrid the list of target points it serves */
     int yy_ready, yy_count[2];
@@ -639,7 +640,7 @@ static void free_set(ezh_set *s)
 {
     for (int d = 0; d < 3; d++) for (int v = 0; v < 2; v++) free_sepplan(&s->sep[d][v]);
     free(s->x1d); free(s->y1d);
-    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM);
+    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_avg);
     for (int k = 0; k < 2; k++) { ezhip_free(s->d_yy_x[k]); ezhip_free(s->d_yy_y[k]); ezhip_free(s->d_yy_lat[k]); ezhip_free(s->d_yy_lon[k]); ezhip_free(s->d_yy_idx[k]); }
     for (int k = 0; k < 4; k++) ezhip_free(s->d_yy_tmp[k]);
     free(s);
@@ -1386,6 +1387,7 @@ static void build_sepx_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, int degree, 
 
 static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
 {
+    if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return -1;
     int di = degree == DEG_CUBIC ? 2 : degree;
     ezh_sepplan *sp = &s->sep[di][vector_mode];
     /* plans depend on polar_correction: bit 1 of built records the setting they were built for */
@@ -1821,13 +1823,89 @@ static int run_field(ezh_set *s, float *d_zout, const float *d_zin, int vector_m
     return run_field_p(s, d_zout, d_zin, vector_mode, prow_n, prow_s, NULL);
 }
 
+/* interp_degree = "average" (degre_interp 4; gdinterp.c:181-187 -> ez_avg.inc): area-weighted means of the source cells under every target
+ * cell, then the parts of the polar correction that are defined for it: the points outside a regional source (fill value or re-interpolation
+ * with extrap_degree) and the pole values.  The strip routines have no case for this degree (ez_corrval_aunord.c:52-110) and scatter an
+ * uninitialised array over their zones: a set that has strip points which are not pole points is refused (set polar_correction = no). */
+static int run_average(ezh_set *s, float *d_zout, const float *d_zin)
+{
+    ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
+    const int polar = O.polar_correction == 1;
+    if (src_hemi(gi) || grid_yinv(gi) || grid_yinv(go)) { fprintf(stderr, "<ezsint> interp_degree = average: hemispheric / y-inverted grids are outside the MI355X hot-path scope\n"); return -1; }
+    if (!s->sep_capable || !s->x1d || go->ni < 2 || go->nj < 2) {
+        fprintf(stderr, "<ezsint> interp_degree = average needs a target whose rows / columns map to rows / columns of the source (ez_avg reads the first row and column of x, y only)\n");
+        return -1;
+    }
+    const int nid = go->ni, njd = go->nj, nis = gi->ni, njs = gi->nj;
+    if (polar && !s->extrap)
+        for (int j = 0; j < njd; j++) {
+            const float py = s->y1d[j];
+            const int strip = (int)py > (gi->j2 - 2) || (int)py < (gi->j1 + 1);
+            const int pole = fabs((double)(py - s->ypole_n)) < 1.0e-3 || fabs((double)(py - s->ypole_s)) < 1.0e-3;
+            if (strip && !pole) {
+                fprintf(stderr, "<ezsint> interp_degree = average with polar_correction = yes: target row %d lies in a polar strip, where the reference writes an uninitialised array (ez_corrval_aunord.c:52-114); set polar_correction to no\n", j + 1);
+                return -1;
+            }
+        }
+    pthread_mutex_lock(&g_plan_mtx);
+    int brc = 0;
+    if (!s->d_avg) {
+        float *b = (float *)malloc(sizeof(float) * 2 * ((size_t)nid + njd)), *x = (float *)malloc(sizeof(float) * nid);
+        float *xl = b, *xh = b + nid, *yl = b + 2 * nid, *yh = b + 2 * nid + njd;
+        const float *y = s->y1d;
+        memcpy(x, s->x1d, sizeof(float) * nid);
+        if (x[0] > (float)(nis - 1)) x[0] = 1.0f;                                   /* ez_avg.inc:57 */
+        xl[0] = x[0] - 0.5f * (x[1] - x[0]);
+        for (int i = 1; i < nid; i++) xl[i] = x[i] - 0.5f * (x[i] - x[i - 1]);
+        yl[0] = fmaxf(1.0f, y[0] - 0.5f * (y[1] - y[0]));
+        for (int j = 1; j < njd; j++) yl[j] = y[j] - 0.5f * (y[j] - y[j - 1]);
+        xh[nid - 1] = x[nid - 1] + 0.5f * (x[nid - 1] - x[nid - 2]);
+        for (int i = 0; i < nid - 1; i++) xh[i] = x[i] + 0.5f * (x[i + 1] - x[i]);
+        yh[njd - 1] = fminf(1.0f * (float)njs, y[njd - 1] + 0.5f * (y[njd - 1] - y[njd - 2]));
+        for (int j = 0; j < njd - 1; j++) yh[j] = y[j] + 0.5f * (y[j + 1] - y[j]);
+        s->d_avg = (float *)upload(b, sizeof(float) * 2 * ((size_t)nid + njd));
+        if (!s->d_avg || ezhip_sync()) brc = -1;
+        free(b); free(x);
+    }
+    pthread_mutex_unlock(&g_plan_mtx);
+    if (brc) return -1;
+    if (ezhip_average(d_zout, d_zin, s->d_avg, nid, njd, nis, njs, gi->extension, s->y1d[njd - 1])) return dev_fail("the averaging kernel");
+    if (!polar) return 0;
+    /* what is left of ez_corrval: outside points / pole values through the per-point kernel, whose normal points keep the averages */
+    int ierc = 0;
+    if (ensure_scratch(s)) return -1;
+    float *d_fill = t_scratch8, *d_poles = t_scratch8 + 4;
+    const int zones = s->extrap ? 2 : 1;
+    if (s->extrap) {
+        if (!s->have_dehors) return 0;
+        ierc = 2;
+        if (O.degre_extrap == XT_ABORT) {
+            fprintf(stderr, "<ez_corrval> There are points on the destination grid that lie outside the source grid\n");
+            fprintf(stderr, "<ez_corrval> aborting at your request!\n\n\n");
+            return -1;
+        }
+        if (O.degre_extrap >= XT_MAXIMUM && ezhip_fill_value(d_fill, d_zin, (size_t)nis * njs, O.degre_extrap, O.valeur_extrap, 0)) return -1;
+    }
+    ezhip_pts_plan pp;
+    pthread_mutex_lock(&g_plan_mtx);
+    int erc = ensure_points(s);
+    if (!erc) fill_pts_plan(s, gi, &pp, DEG_LINEAR, zones, 0);
+    pthread_mutex_unlock(&g_plan_mtx);
+    if (erc) return -1;
+    pp.only_special = 1; pp.fill = d_fill; pp.polevals = d_poles;
+    if (zones == 1 && ezhip_polevals(d_poles, d_zin, nis, njs, pp.pole_weighted, gi->d_ax)) return -1;
+    if (ezhip_interp_pts(&pp, d_zout, d_zin, s->d_x, s->d_y, nid * njd)) return dev_fail("the per-point kernel (outside / pole points of an averaged field)");
+    return ierc;
+}
+
 /* d_poles_pre: device float[2] pole values of this field already computed (batch entry point), or NULL */
 static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector_mode, const float *prow_n, const float *prow_s, const float *d_poles_pre)
 {
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     int degree = O.degre_interp, polar = O.polar_correction == 1;
+    if (degree == 4 && !vector_mode) { if (hio_full((float *)d_zin)) return -1; return run_average(s, d_zout, d_zin); }
     if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) {
-        fprintf(stderr, "<ezsint> interp_degree %d (average modes) is outside the MI355X hot-path scope\n", degree);
+        fprintf(stderr, "<ezsint> interp_degree %d (%s) is outside the MI355X hot-path scope\n", degree, degree == 4 ? "average, for winds" : degree == 5 ? "sph_average" : "?");
         return -1;
     }
     int ierc = 0;
@@ -2118,6 +2196,7 @@ int32_t ezhip_prepare_set(void)
     if (G[s->gdout].grtyp == 'U') return 0;
     if (G[s->gdin].grtyp == 'U') return yy_plan(s);
     int degree = O.degre_interp, polar = O.polar_correction == 1;
+    if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return 0;       /* the averaging degrees build nothing ahead of the call */
     if (choose_mode(s, degree, polar) == 1) return build_sep_plan(s, degree, 0, polar);
     pthread_mutex_lock(&g_plan_mtx);
     int erc = ensure_points(s);                     /* locates and classifies the DEHORS zone (first-call work, like ez_defzones) */

@@ -1425,7 +1425,7 @@ __global__ __launch_bounds__(256) void k_pts(ezhip_pts_plan p, float *__restrict
     const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;        /* Yin-Yang point lists write straight to their target positions */
     const PlainAcc ZP{zin, p.ni, p.j1};
     const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
-    if (zone == PZ_NORMAL) zout[o] = leaf_point<KIND>(p, ZP, px, py);
+    if (zone == PZ_NORMAL) { if (!p.only_special) zout[o] = leaf_point<KIND>(p, ZP, px, py); }
     else if (zone == PZ_FILL) zout[o] = *p.fill;
     else if (zone == PZ_POLE_S) zout[o] = p.polevals[1];
     else if (zone == PZ_POLE_N) zout[o] = p.polevals[0];
@@ -1997,6 +1997,65 @@ extern "C" int ezhip_scatter(float *d_dst, const float *d_src, const int *d_idx,
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, d_dst, d_src, d_idx, n);
     return LAUNCH_CHECK("k_scatter");
+}
+
+/* interp_degree = "average" (ez_avg.inc:81-211): one thread per target cell; the cell's bounds in source index space come from the host
+ * (the reference derives them from the first target row / column only); the source cells under it are added in row-major order with the
+ * covered fraction as weight, all in REAL, multiply and add apart.  The three row regimes (first / middle / last target row) differ in how
+ * the first and last source rows are cut.  Columns are addressed modulo the source's wrap (ztmp, :19-52); rows and, on a regional source,
+ * columns beyond the field -- where the reference indexes outside its array -- are clamped. */
+__device__ __forceinline__ float avg_src(const float *__restrict__ zin, int ni, int nj, int ext, int ii, int jj)
+{
+    jj = min(max(jj, 1), nj);
+    if (ext == 1) { int k = ii; while (k < 1) k += ni - 1; while (k > ni - 1) k -= ni - 1; ii = k; }
+    else if (ext == 2) { int k = ii; while (k < 1) k += ni; while (k > ni) k -= ni; ii = k; }
+    else ii = min(max(ii, 1), ni);
+    return zin[(size_t)(jj - 1) * ni + (ii - 1)];
+}
+__global__ __launch_bounds__(256) void k_average(float *__restrict__ zout, const float *__restrict__ zin, const float *__restrict__ bounds,
+                                                 int nid, int njd, int nis, int njs, int ext, float ylast)
+{
+    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= (size_t)nid * njd) return;
+    const int j = (int)(n / nid), i = (int)(n - (size_t)j * nid);
+    const float xl = bounds[i], xh = bounds[nid + i], yl = bounds[2 * nid + j], yh = bounds[2 * nid + njd + j];
+    const int row = j == 0 ? 0 : (j == njd - 1 ? 2 : 1);
+    int jstart, jend = (int)lroundf(yh), istart = (int)xl, iend = (int)lroundf(xh);
+    if (row == 2) jstart = (int)ylast;
+    else {
+        jstart = (int)yl;
+        if (row == 1) { if ((0.5f + (float)jstart) < yl) jstart = jstart + 1; }
+        else { if ((float)jstart > yl) jstart = jstart - 1; }
+    }
+    if ((0.5f + (float)istart) < xl) istart = istart + 1;
+    if (row == 0 && (float)iend < xh) iend = iend + 1;
+    float z = 0.0f, total = 0.0f;
+    for (int jj = jstart; jj <= jend; jj++) {
+        float ymin = (float)jj - 0.5f, ymax = (float)jj + 0.5f, yfrac = 1.0f;
+        if (row == 0) { if (jj == 1) ymin = 1.0f; yfrac = ymax - ymin; }
+        if (row == 2) { if (jj == njs) ymax = (float)njs; yfrac = ymax - ymin; }
+        if (ymin < yl) yfrac = ymax - yl;
+        if (ymax > yh) yfrac = yh - ymin;
+        for (int ii = istart; ii <= iend; ii++) {
+            const float xmin = (float)ii - 0.5f, xmax = (float)ii + 0.5f;
+            float xfrac = 1.0f;
+            if (xmin < xl) xfrac = xmax - xl;
+            if (xmax > xh) xfrac = xh - xmin;
+            const float area = xfrac * yfrac;
+            total = total + area;
+            const float prod = avg_src(zin, nis, njs, ext, ii, jj) * area;
+            z = z + prod;
+        }
+    }
+    if (total != 0.0f) z = z / total;
+    zout[n] = z;
+}
+extern "C" int ezhip_average(float *d_zout, const float *d_zin, const float *d_bounds, int nid, int njd, int nis, int njs, int ext, float ylast)
+{
+    const size_t n = (size_t)nid * njd;
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_average, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, d_zout, d_zin, d_bounds, nid, njd, nis, njs, ext, ylast);
+    return LAUNCH_CHECK("k_average");
 }
 
 /* The whole wind chain of a grid pair (grid-frame components -> true components -> speed / direction -> target components) is, point by

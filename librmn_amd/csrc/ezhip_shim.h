@@ -153,6 +153,7 @@ typedef struct {
     const void *wind_M;               /* k_pts2: the grid pair's wind matrices (ezhip_wind_matrix), applied to every point before it is stored; NULL: store the interpolated components */
     /* zone handling (0 = none: c_gdxysint semantics) */
     int zones;                        /* 0 none, 1 EZ_NO_EXTRAP (polar zones), 2 EZ_EXTRAP (DEHORS) */
+    int only_special;                 /* 1: the normal points keep what the output already holds (interp_degree = average ran before): only fill / pole / listed points are written */
     int degre_extrap;                 /* used when zones == 2 */
     float ypole_n, ypole_s;
     float ay4_n[4], ay4_s[4];         /* strip latitudes (irregular cubic) */
@@ -229,6 +230,8 @@ int ezhip_polar_wind(float *d_out4, const float *d_uu, const float *d_vv, const 
 /* the chain of a grid pair as a 2 x 2 matrix per point (16 bytes each): built once, applied per call */
 int ezhip_wind_matrix(const ezhip_wind_plan *plan, void *d_M, const float *d_lat, const float *d_lon, int ni_dst, int nj_dst);
 int ezhip_wind_apply(const void *d_M, float *d_uu, float *d_vv, size_t npts);
+/* interp_degree = average (ez_avg.inc): bounds = [x_low ni_dst | x_high ni_dst | y_low nj_dst | y_high nj_dst] on the device */
+int ezhip_average(float *d_zout, const float *d_zin, const float *d_bounds, int ni_dst, int nj_dst, int ni_src, int nj_src, int extension, float ylast);
 int ezhip_wind_rotate(const ezhip_wind_plan *plan, float *d_uu, float *d_vv,
                       const float *d_lat, const float *d_lon, int ni_dst, int nj_dst);
 

@@ -857,6 +857,84 @@ void orc_irgdint_3_wnnc(float *zo, const float *px, const float *py, int npts, c
 #undef AY
 
 /* ------------------------------------------------------------------------------------------
+ * interp_degree = "average" (degre_interp 4, gdinterp.c:181-187 / :283-289 -> ez_avg, src/interp/ez_avg.inc:1-190): every target
+ * cell -- bounded half way to its neighbours in the located coordinates of the FIRST target row / column (x = xx(:,1), y = yy(1,:),
+ * :55-56) -- averages the source cells it covers, weighted by the covered fraction; REAL arithmetic, cells added in row-major order.
+ * The source is addressed through ztmp, the field with its columns repeated over [-ni, 2 ni] according to the grid's wrap (:19-52);
+ * outside that (a target that leaves a regional source) the reference indexes beyond the array: clamped here.
+ * ---------------------------------------------------------------------------------------- */
+static float avg_src(const float *zin, int ni, int nj, int ext, int ii, int jj)
+{
+    if (jj < 1) jj = 1;
+    if (jj > nj) jj = nj;
+    if (ext == 1) { int k = ii; while (k < 1) k += ni - 1; while (k > ni - 1) k -= ni - 1; ii = k; }
+    else if (ext == 2) { int k = ii; while (k < 1) k += ni; while (k > ni) k -= ni; ii = k; }
+    else { if (ii < 1) ii = 1; if (ii > ni) ii = ni; }
+    return zin[(size_t)(jj - 1) * ni + (ii - 1)];
+}
+/* the bounds of the target cells (:55-78): x_low / x_high [ni_dst], y_low / y_high [nj_dst] */
+void orc_avg_bounds(float *x_low, float *x_high, float *y_low, float *y_high, const float *xx, const float *yy, int nid, int njd, int nis, int njs)
+{
+    float *x = (float *)malloc(sizeof(float) * nid), *y = (float *)malloc(sizeof(float) * njd);
+    for (int i = 0; i < nid; i++) x[i] = xx[i];
+    for (int j = 0; j < njd; j++) y[j] = yy[(size_t)j * nid];
+    if (x[0] > (float)(nis - 1)) x[0] = 1.0f;
+    x_low[0] = x[0] - 0.5f * (x[1] - x[0]);
+    for (int i = 1; i < nid; i++) x_low[i] = x[i] - 0.5f * (x[i] - x[i - 1]);
+    y_low[0] = fmaxf(1.0f, y[0] - 0.5f * (y[1] - y[0]));
+    for (int j = 1; j < njd; j++) y_low[j] = y[j] - 0.5f * (y[j] - y[j - 1]);
+    x_high[nid - 1] = x[nid - 1] + 0.5f * (x[nid - 1] - x[nid - 2]);
+    for (int i = 0; i < nid - 1; i++) x_high[i] = x[i] + 0.5f * (x[i + 1] - x[i]);
+    y_high[njd - 1] = fminf(1.0f * (float)njs, y[njd - 1] + 0.5f * (y[njd - 1] - y[njd - 2]));
+    for (int j = 0; j < njd - 1; j++) y_high[j] = y[j] + 0.5f * (y[j + 1] - y[j]);
+    free(x); free(y);
+}
+/* one target cell; row: 0 first row (:121-166), 1 middle rows (:81-117), 2 last row (:171-211).  ylast = y(nj_dst) (the last row's jstart) */
+float orc_avg_cell(const float *zin, int nis, int njs, int ext, int row, float xl, float xh, float yl, float yh, float ylast)
+{
+    int jstart, jend = (int)lroundf(yh), istart = (int)xl, iend = (int)lroundf(xh);
+    if (row == 2) jstart = (int)ylast;
+    else {
+        jstart = (int)yl;
+        if (row == 1) { if ((0.5f + (float)jstart) < yl) jstart = jstart + 1; }
+        else { if ((float)jstart > yl) jstart = jstart - 1; }
+    }
+    if ((0.5f + (float)istart) < xl) istart = istart + 1;
+    if (row == 0 && (float)iend < xh) iend = iend + 1;
+    float z = 0.0f, total = 0.0f;
+    for (int jj = jstart; jj <= jend; jj++) {
+        float ymin = (float)jj - 0.5f, ymax = (float)jj + 0.5f, yfrac = 1.0f;
+        if (row == 0) { if (jj == 1) ymin = 1.0f; yfrac = ymax - ymin; }
+        if (row == 2) { if (jj == njs) ymax = (float)njs; yfrac = ymax - ymin; }
+        if (ymin < yl) yfrac = ymax - yl;
+        if (ymax > yh) yfrac = yh - ymin;
+        for (int ii = istart; ii <= iend; ii++) {
+            float xmin = (float)ii - 0.5f, xmax = (float)ii + 0.5f, xfrac = 1.0f;
+            if (xmin < xl) xfrac = xmax - xl;
+            if (xmax > xh) xfrac = xh - xmin;
+            float area = xfrac * yfrac;
+            total = total + area;
+            float prod = avg_src(zin, nis, njs, ext, ii, jj) * area;
+            z = z + prod;
+        }
+    }
+    if (total != 0.0f) z = z / total;
+    return z;
+}
+void orc_ez_avg(float *zout, const float *xx, const float *yy, int nid, int njd, const float *zin, int nis, int njs, int ext)
+{
+    float *xl = (float *)malloc(sizeof(float) * nid), *xh = (float *)malloc(sizeof(float) * nid);
+    float *yl = (float *)malloc(sizeof(float) * njd), *yh = (float *)malloc(sizeof(float) * njd);
+    orc_avg_bounds(xl, xh, yl, yh, xx, yy, nid, njd, nis, njs);
+    const float ylast = yy[(size_t)(njd - 1) * nid];
+    for (int j = 0; j < njd; j++) {
+        const int row = j == 0 ? 0 : (j == njd - 1 ? 2 : 1);
+        for (int i = 0; i < nid; i++) zout[(size_t)j * nid + i] = orc_avg_cell(zin, nis, njs, ext, row, xl[i], xh[i], yl[j], yh[j], ylast);
+    }
+    free(xl); free(xh); free(yl); free(yh);
+}
+
+/* ------------------------------------------------------------------------------------------
  * c_gdinterp dispatch, src/interp/gdinterp.c:133-309
  * ---------------------------------------------------------------------------------------- */
 int orc_gdinterp(const orc_grid *g, int degree, float *zout, const float *zin,
@@ -1111,8 +1189,21 @@ static int corrval(orc_gridset *gs, const orc_opts *o, float *zout, const float 
         }
     }
     if (o->vecteur == 1) return ierc;
-    corrval_aunord(gs, o->degre_interp, zout, zin);
-    corrval_ausud(gs, o->degre_interp, zout, zin);
+    if (o->degre_interp == 4) {
+        /* interp_degree = average: ez_corrval_aunord / _ausud have no case for it (ez_corrval_aunord.c:52-110) and scatter an
+         * uninitialised array over their zones (:112-114).  Defined only where the pole values overwrite every such point */
+        for (int k = 0; k < 2; k++) {
+            const orc_zone *st = &gs->zones[k == 0 ? ORC_Z_AU_NORD : ORC_Z_AU_SUD], *po = &gs->zones[k == 0 ? ORC_Z_POLE_NORD : ORC_Z_POLE_SUD];
+            for (int i = 0; i < st->npts; i++) {
+                int found = 0;
+                for (int q = 0; q < po->npts && !found; q++) found = po->idx[q] == st->idx[i];
+                if (!found) return -3;
+            }
+        }
+    } else {
+        corrval_aunord(gs, o->degre_interp, zout, zin);
+        corrval_ausud(gs, o->degre_interp, zout, zin);
+    }
     orc_zone *pn = &gs->zones[ORC_Z_POLE_NORD], *ps = &gs->zones[ORC_Z_POLE_SUD];
     if (pn->npts > 0 || ps->npts > 0) {
         float vpolnor = calcpoleval(&zin[(size_t)(nj - 1) * g->ni], g->ni, g->ax, g->grtyp, g->grref);
@@ -1163,7 +1254,8 @@ int orc_ezsint(orc_gridset *gs, const orc_opts *o, float *zout, const float *zin
     }
     orc_calclatlon(go);
     orc_calcxy(gs);
-    orc_gdinterp(gi, o->degre_interp, zout, zin, gs->x, gs->y, go->ni * go->nj);
+    if (o->degre_interp == 4) orc_ez_avg(zout, gs->x, gs->y, go->ni, go->nj, zin, gi->ni, gi->nj, gi->extension);      /* gdinterp.c:181-187 */
+    else orc_gdinterp(gi, o->degre_interp, zout, zin, gs->x, gs->y, go->ni * go->nj);
     int ierc = 0;
     if (o->polar_correction == 1) {
         orc_defzones(gs);

@@ -67,6 +67,7 @@ void orc_nwtncof(float *cx, float *cy, const float *ax, const float *ay, int ni,
 int orc_calclatlon(orc_grid *g);
 /* c_gdxyfll_orig (src/interp/gdxyfll.c:90-139): lon[] may be modified in place */
 int orc_gdxyfll(const orc_grid *g, float *x, float *y, const float *lat, float *lon, int n);
+void orc_ez_avg(float *zout, const float *xx, const float *yy, int nid, int njd, const float *zin, int nis, int njs, int ext);      /* ez_avg.inc */
 int orc_gdxyfll_public(const orc_grid *g, float *x, float *y, const float *lat, float *lon, int n);      /* c_gdxyfll; orc_gdxyfll is c_gdxyfll_orig */
 /* c_gdinterp (src/interp/gdinterp.c:96-313) with an explicit degree */
 int orc_gdinterp(const orc_grid *gdin, int degree, float *zout, const float *zin,

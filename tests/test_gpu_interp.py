@@ -1213,3 +1213,59 @@ def test_hemispheric_gaussian_sources_vs_oracle(name):
             assert np.array_equal(z.view(np.uint32), want.view(np.uint32)), (name, degree, polar, int(np.count_nonzero(z != want)))
     uu, vv = ec.synth_wind(ni, nj, seed=2)
     assert ez.ezuvint(uu, vv, no * mo)[0] == -1            # winds from a hemisphere: undefined in the reference, refused
+
+
+AVG_GPU_CASES = dict(tovr.AVG_CASES)
+AVG_GPU_CASES["Lregional_outside_polar"] = ((120, 90, "L", (50, 50, 6000, 20000), " ", None), (40, 30, "L", (200, 250, 5500, 19500), " ", None), 1)   # the target leaves the source: fill / re-interpolated points
+
+
+@pytest.mark.parametrize("name", sorted(AVG_GPU_CASES))
+def test_average_degree_vs_oracle(name):
+    """interp_degree = average (ez_avg.inc): k_average + the defined parts of the polar correction against the oracle (= the reference
+    build on the inside cases, tests/test_oracle_vs_ref.py), bit for bit; extrapolation by value and by nearest for the outside points"""
+    src, dst, polar = AVG_GPU_CASES[name]
+    ni, nj = src[:2]; no, mo = dst[:2]
+    gdin = ez.ezqkdef(ni, nj, src[2], *src[3]); gdout = ez.ezqkdef(no, mo, dst[2], *dst[3])
+    assert ez.ezdefset(gdout, gdin) == 1
+    O = ol.oracle()
+    gi = ol.grid_define(ni, nj, src[2], src[3]); go = ol.grid_define(no, mo, dst[2], dst[3])
+    gs = O.orc_defset(go, gi)
+    zin = ec.synth_field(ni, nj, seed=13)
+    if src[2] == "B":
+        z2 = zin.reshape(nj, ni); z2[:, -1] = z2[:, 0]; zin = np.ascontiguousarray(z2.reshape(-1))
+    for extrap, xcode in (("maximum", 4), ("nearest", 0), ("value", 6)):
+        assert ez.ezsetopt("interp_degree", "average") == 0
+        assert ez.ezsetopt("polar_correction", "yes" if polar else "no") == 0
+        assert ez.ezsetopt("extrap_degree", extrap) == 0
+        if extrap == "value":
+            assert ez.ezsetval("extrap_value", -5.5) == 0
+        rc, z = ez.ezsint(zin, no * mo)
+        want = np.zeros(no * mo, np.float32)
+        opts = ol.default_opts(degre_interp=4, polar_correction=polar, degre_extrap=xcode, valeur_extrap=-5.5)
+        rc_o = O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(want), ol.fptr(zin))
+        assert rc == rc_o, (rc, rc_o)
+        assert np.array_equal(z.view(np.uint32), want.view(np.uint32)), (name, extrap, int(np.count_nonzero(z != want)))
+
+
+def test_average_degree_refusals():
+    gdin = ez.ezqkdef(128, 64, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(40, 61, "L", 300, 900, 0, 0)     # rows every 3 degrees: 87 N / S lie in the polar strips
+    assert ez.ezdefset(gdout, gdin) == 1
+    assert ez.ezsetopt("interp_degree", "average") == 0 and ez.ezsetopt("polar_correction", "yes") == 0
+    zin = ec.synth_field(128, 64, seed=1)
+    assert ez.ezsint(zin, 40 * 61)[0] == -1             # strip rows that are not pole rows: undefined in the reference, refused
+    assert ez.ezsetopt("polar_correction", "no") == 0
+    assert ez.ezsint(zin, 40 * 61)[0] == 0
+    uu, vv = ec.synth_wind(128, 64, seed=1)
+    assert ez.ezuvint(uu, vv, 40 * 61)[0] == -1         # winds: not with this degree
+    assert ez.ezsetopt("interp_degree", "sph_average") == 0
+    assert ez.ezsint(zin, 40 * 61)[0] == -1
+    # pole rows alone are fine: the pole values overwrite them (ez_corrval.c:125-140)
+    gd2 = ez.ezqkdef(40, 21, "L", 900, 900, 0, 0)
+    assert ez.ezdefset(gd2, gdin) == 1
+    assert ez.ezsetopt("interp_degree", "average") == 0 and ez.ezsetopt("polar_correction", "yes") == 0
+    rc, z = ez.ezsint(zin, 40 * 21)
+    O = ol.oracle(); gs = O.orc_defset(ol.grid_define(40, 21, "L", (900, 900, 0, 0)), ol.grid_define(128, 64, "G"))
+    want = np.zeros(40 * 21, np.float32)
+    opts = ol.default_opts(degre_interp=4, polar_correction=1)
+    assert O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(want), ol.fptr(zin)) == rc == 0
+    assert np.array_equal(z.view(np.uint32), want.view(np.uint32))

@@ -11,7 +11,7 @@ import ezcases as ec
 
 pytestmark = [pytest.mark.ref, pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libezref.so not built")]
 
-DEG = {0: b"nearest", 1: b"linear", 3: b"cubic"}
+DEG = {0: b"nearest", 1: b"linear", 3: b"cubic", 4: b"average"}
 EXTRAP = {0: b"nearest", 1: b"linear", 3: b"cubic", 4: b"maximum", 5: b"minimum", 6: b"value"}
 
 
@@ -511,3 +511,59 @@ def test_hemispheric_gaussian_sources(name, degree):
     L.c_gdll(gdin, fptr(la), fptr(lo))
     O.orc_calclatlon(gi)
     assert np.array_equal(la, ol.np_from(gi.contents.lat, ni * nj)) and np.array_equal(lo, ol.np_from(gi.contents.lon, ni * nj))
+
+
+@pytest.mark.parametrize("ext", [0, 1, 2])
+@pytest.mark.parametrize("ratio", [0.6, 1.0, 2.7, 5.3])
+def test_ez_avg_leaf(ext, ratio):
+    """interp_degree = average: the oracle's restatement of ez_avg against the reference's own routine (ez_avg.inc), bit for bit:
+    target cells smaller, equal and several times larger than source cells; regional (ext 0: target inside the source) and wrapped sources
+    (ext 1 / 2: the first and last target columns reach across the seam)"""
+    L = ref(); O = ol.oracle()
+    nis, njs = 97, 53
+    zin = ec.synth_field(nis, njs, seed=31)
+    nid = max(4, int((nis - 8) / ratio)); njd = max(4, int((njs - 6) / ratio))
+    x1 = (4.0 + ratio * np.arange(nid) + 0.13).astype(np.float32) if ext == 0 else (1.0 + ratio * np.arange(nid) * (nis / (nid * ratio)) + 0.37).astype(np.float32)
+    y1 = (3.0 + ratio * np.arange(njd) + 0.29).astype(np.float32)
+    xx = np.ascontiguousarray(np.broadcast_to(x1[None, :], (njd, nid))).astype(np.float32)
+    yy = np.ascontiguousarray(np.broadcast_to(y1[:, None], (njd, nid))).astype(np.float32)
+    zr = np.full(nid * njd, -9.0, np.float32); zo = zr.copy()
+    i32 = lambda v: ctypes.byref(ctypes.c_int32(v))
+    L.ez_avg_(fptr(zr), fptr(xx), fptr(yy), i32(nid), i32(njd), fptr(zin), i32(nis), i32(njs), i32(ext))
+    O.orc_ez_avg.restype = None
+    O.orc_ez_avg(fptr(zo), fptr(xx), fptr(yy), nid, njd, fptr(zin), nis, njs, ext)
+    assert np.array_equal(zo.view(np.uint32), zr.view(np.uint32)), (ext, ratio, int(np.count_nonzero(zo != zr)), np.argwhere(zo != zr)[:5].tolist())
+
+
+AVG_CASES = {
+    # (source spec, target spec, polar): targets whose cells stay inside the source, or wrapped global sources
+    "G_to_L_coarse_nopolar": ((128, 64, "G", (0, 0, 0, 0), " ", None), (40, 19, "L", (900, 900, 450, 0), " ", None), 0),
+    "A_to_L_coarse_nopolar": ((144, 72, "A", (0, 0, 0, 0), " ", None), (30, 15, "L", (1100, 1200, 800, 0), " ", None), 0),
+    "Lregional_inside_polar": ((120, 90, "L", (50, 50, 6000, 20000), " ", None), (20, 14, "L", (150, 200, 6800, 20800), " ", None), 1),
+    "G_to_L_poles_polar": ((128, 64, "G", (0, 0, 0, 0), " ", None), (40, 21, "L", (900, 900, 0, 0), " ", None), 1),      # the only strip rows are the pole rows: pole values overwrite them
+    "B_to_L_midlat_polar": ((145, 73, "B", (0, 0, 0, 0), " ", None), (30, 9, "L", (1000, 1200, 5000, 0), " ", None), 1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(AVG_CASES))
+def test_ezsint_average(name):
+    """interp_degree = average through c_ezsint: the oracle against the reference build, bit for bit"""
+    L = ref(); O = ol.oracle()
+    src, dst, polar = AVG_CASES[name]
+    gdin = ref_define(L, src); gdout = ref_define(L, dst)
+    ref_setopts(L, 4, polar)
+    assert L.c_ezdefset(gdout, gdin) == 1
+    ni, nj = src[:2]; no, mo = dst[:2]
+    zin = ec.synth_field(ni, nj, seed=13)
+    if src[2] == "B":
+        z2 = zin.reshape(nj, ni); z2[:, -1] = z2[:, 0]; zin = np.ascontiguousarray(z2.reshape(-1))
+    zr = np.full(no * mo, -999.0, np.float32)
+    rc_r = L.c_ezsint(fptr(zr), fptr(zin))
+    ref_setopts(L, 3, 1)
+    gi = orc_define(src); go = orc_define(dst)
+    gs = O.orc_defset(go, gi)
+    zo = np.full(no * mo, -999.0, np.float32)
+    opts = ol.default_opts(degre_interp=4, polar_correction=polar)
+    rc_o = O.orc_ezsint(gs, ctypes.byref(opts), fptr(zo), fptr(zin))
+    assert rc_o == rc_r
+    assert np.array_equal(zo.view(np.uint32), zr.view(np.uint32)), f"{name}: {np.count_nonzero(zo != zr)} differ"
