@@ -61,7 +61,7 @@ typedef struct ezh_set {
     float *d_scratch;       /* float[8]: fill value + keys, pole values */
     float *d_poles_batch; int poles_cap;   /* pole values of a c_ezsint_batch_dev batch (2 per field) */
     float *d_prow;          /* 2 * ni_src synthetic polar wind rows (vector mode), u then v: [u_n, u_s, v_n, v_s] */
-    float *d_avg;           /* interp_degree = average: the target cells' bounds [x_low | x_high | y_low | y_high] (ez_avg.inc:55-78) */
+    float *d_avg[2];        /* interp_degree = average / sph_average: [x | row widening | y_low | y_high] of the target cells (ez_avg.inc:55-78, ez_avg_sph.inc:63-98) */
     void *d_windM;          /* c_ezuvint through a rotated frame: the wind chain of this grid pair as a 2 x 2 matrix per target point (built on first use) */
     /* Yin-Yang 'U' source (c_ezyy_calcxy, ezyy_calcxy.c): per subgrid the list of target points it serves */
     int yy_ready, yy_count[2];
@@ -640,7 +640,7 @@ static void free_set(ezh_set *s)
 {
     for (int d = 0; d < 3; d++) for (int v = 0; v < 2; v++) free_sepplan(&s->sep[d][v]);
     free(s->x1d); free(s->y1d);
-    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_avg);
+    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
     for (int k = 0; k < 2; k++) { ezhip_free(s->d_yy_x[k]); ezhip_free(s->d_yy_y[k]); ezhip_free(s->d_yy_lat[k]); ezhip_free(s->d_yy_lon[k]); ezhip_free(s->d_yy_idx[k]); }
     for (int k = 0; k < 4; k++) ezhip_free(s->d_yy_tmp[k]);
     free(s);
@@ -1827,7 +1827,8 @@ static int run_field(ezh_set *s, float *d_zout, const float *d_zin, int vector_m
  * cell, then the parts of the polar correction that are defined for it: the points outside a regional source (fill value or re-interpolation
  * with extrap_degree) and the pole values.  The strip routines have no case for this degree (ez_corrval_aunord.c:52-110) and scatter an
  * uninitialised array over their zones: a set that has strip points which are not pole points is refused (set polar_correction = no). */
-static int run_average(ezh_set *s, float *d_zout, const float *d_zin)
+static int gdllfxy_one(const ezh_grid *g, float *lat, float *lon, const float *x, const float *y, int n);
+static int run_average(ezh_set *s, float *d_zout, const float *d_zin, int sph)
 {
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     const int polar = O.polar_correction == 1;
@@ -1837,6 +1838,13 @@ static int run_average(ezh_set *s, float *d_zout, const float *d_zin)
         return -1;
     }
     const int nid = go->ni, njd = go->nj, nis = gi->ni, njs = gi->nj;
+    if (sph) {
+        ensure_coords(go);
+        for (int j = 0; j < njd; j++) if (go->separable && fabsf(go->lat1d[j]) > 89.0f) {
+            fprintf(stderr, "<ezsint> interp_degree = sph_average: target row %d lies at a pole, where the cells are widened by 1 / cos(latitude) without bound (ez_avg_sph.inc:63-93 then indexes far outside the source)\n", j + 1);
+            return -1;
+        }
+    }
     if (polar && !s->extrap)
         for (int j = 0; j < njd; j++) {
             const float py = s->y1d[j];
@@ -1849,27 +1857,34 @@ static int run_average(ezh_set *s, float *d_zout, const float *d_zin)
         }
     pthread_mutex_lock(&g_plan_mtx);
     int brc = 0;
-    if (!s->d_avg) {
-        float *b = (float *)malloc(sizeof(float) * 2 * ((size_t)nid + njd)), *x = (float *)malloc(sizeof(float) * nid);
-        float *xl = b, *xh = b + nid, *yl = b + 2 * nid, *yh = b + 2 * nid + njd;
+    if (!s->d_avg[sph]) {
+        float *b = (float *)malloc(sizeof(float) * ((size_t)nid + 3 * (size_t)njd));
+        float *x = b, *amp = b + nid, *yl = b + nid + njd, *yh = b + nid + 2 * njd;
         const float *y = s->y1d;
         memcpy(x, s->x1d, sizeof(float) * nid);
         if (x[0] > (float)(nis - 1)) x[0] = 1.0f;                                   /* ez_avg.inc:57 */
-        xl[0] = x[0] - 0.5f * (x[1] - x[0]);
-        for (int i = 1; i < nid; i++) xl[i] = x[i] - 0.5f * (x[i] - x[i - 1]);
         yl[0] = fmaxf(1.0f, y[0] - 0.5f * (y[1] - y[0]));
         for (int j = 1; j < njd; j++) yl[j] = y[j] - 0.5f * (y[j] - y[j - 1]);
-        xh[nid - 1] = x[nid - 1] + 0.5f * (x[nid - 1] - x[nid - 2]);
-        for (int i = 0; i < nid - 1; i++) xh[i] = x[i] + 0.5f * (x[i + 1] - x[i]);
         yh[njd - 1] = fminf(1.0f * (float)njs, y[njd - 1] + 0.5f * (y[njd - 1] - y[njd - 2]));
         for (int j = 0; j < njd - 1; j++) yh[j] = y[j] + 0.5f * (y[j + 1] - y[j]);
-        s->d_avg = (float *)upload(b, sizeof(float) * 2 * ((size_t)nid + njd));
-        if (!s->d_avg || ezhip_sync()) brc = -1;
-        free(b); free(x);
+        for (int j = 0; j < njd; j++) amp[j] = 1.0f;
+        if (sph) {
+            /* gdinterp.c:189-198: the latitude of every target row at its first column (c_gdllfxy_orig), then 1 / cos of it in REAL with
+             * the host's libm (ez_avg_sph.inc:63-65) -- the one transcendental of the method, kept off the device so that the cell bounds
+             * are the reference's bits */
+            const float degre_a_radian = 0.017453295199f;
+            for (int j = 0; j < njd && !brc; j++) {
+                float la = 0.0f, lo = 0.0f, xo = 1.0f, yo = 1.0f * (float)(j + 1);
+                if (gdllfxy_one(go, &la, &lo, &xo, &yo, 1) < 0) brc = -1;
+                amp[j] = 1.0f / cosf(la * degre_a_radian);
+            }
+        }
+        if (!brc) { s->d_avg[sph] = (float *)upload(b, sizeof(float) * ((size_t)nid + 3 * (size_t)njd)); if (!s->d_avg[sph] || ezhip_sync()) brc = -1; }
+        free(b);
     }
     pthread_mutex_unlock(&g_plan_mtx);
     if (brc) return -1;
-    if (ezhip_average(d_zout, d_zin, s->d_avg, nid, njd, nis, njs, gi->extension, s->y1d[njd - 1])) return dev_fail("the averaging kernel");
+    if (ezhip_average(d_zout, d_zin, s->d_avg[sph], nid, njd, nis, njs, gi->extension, s->y1d[njd - 1])) return dev_fail("the averaging kernel");
     if (!polar) return 0;
     /* what is left of ez_corrval: outside points / pole values through the per-point kernel, whose normal points keep the averages */
     int ierc = 0;
@@ -1903,9 +1918,9 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
 {
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     int degree = O.degre_interp, polar = O.polar_correction == 1;
-    if (degree == 4 && !vector_mode) { if (hio_full((float *)d_zin)) return -1; return run_average(s, d_zout, d_zin); }
+    if ((degree == 4 || degree == 5) && !vector_mode) { if (hio_full((float *)d_zin)) return -1; return run_average(s, d_zout, d_zin, degree == 5); }
     if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) {
-        fprintf(stderr, "<ezsint> interp_degree %d (%s) is outside the MI355X hot-path scope\n", degree, degree == 4 ? "average, for winds" : degree == 5 ? "sph_average" : "?");
+        fprintf(stderr, "<ezsint> interp_degree %d (%s) is outside the MI355X hot-path scope\n", degree, degree == 4 || degree == 5 ? "an averaging degree, for winds" : "?");
         return -1;
     }
     int ierc = 0;

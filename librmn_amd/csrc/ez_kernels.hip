@@ -2018,7 +2018,11 @@ __global__ __launch_bounds__(256) void k_average(float *__restrict__ zout, const
     const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= (size_t)nid * njd) return;
     const int j = (int)(n / nid), i = (int)(n - (size_t)j * nid);
-    const float xl = bounds[i], xh = bounds[nid + i], yl = bounds[2 * nid + j], yh = bounds[2 * nid + njd + j];
+    /* bounds = [x nid | widening njd | y_low njd | y_high njd]: the cell reaches half way to its neighbours in x, times the row's widening
+     * (1 for "average"; 1 / cos(latitude), evaluated on the host, for "sph_average": ez_avg_sph.inc:63-93) */
+    const float *xs = bounds, amp = bounds[nid + j], yl = bounds[nid + njd + j], yh = bounds[nid + 2 * njd + j];
+    const float xl = i == 0 ? xs[0] - 0.5f * (xs[1] - xs[0]) * amp : xs[i] - 0.5f * (xs[i] - xs[i - 1]) * amp;
+    const float xh = i == nid - 1 ? xs[nid - 1] + 0.5f * (xs[nid - 1] - xs[nid - 2]) * amp : xs[i] + 0.5f * (xs[i + 1] - xs[i]) * amp;
     const int row = j == 0 ? 0 : (j == njd - 1 ? 2 : 1);
     int jstart, jend = (int)lroundf(yh), istart = (int)xl, iend = (int)lroundf(xh);
     if (row == 2) jstart = (int)ylast;

@@ -921,6 +921,27 @@ float orc_avg_cell(const float *zin, int nis, int njs, int ext, int row, float x
     if (total != 0.0f) z = z / total;
     return z;
 }
+/* interp_degree = "sph_average" (ez_avg_sph.inc): ez_avg with the x bounds of every target row widened by 1 / cos(latitude of the row) */
+void orc_ez_avg_sph(float *zout, const float *xx, const float *yy, const float *lats_dst, int nid, int njd, const float *zin, int nis, int njs, int ext)
+{
+    float *xl = (float *)malloc(sizeof(float) * nid), *xh = (float *)malloc(sizeof(float) * nid);
+    float *yl = (float *)malloc(sizeof(float) * njd), *yh = (float *)malloc(sizeof(float) * njd), *x = (float *)malloc(sizeof(float) * nid);
+    orc_avg_bounds(xl, xh, yl, yh, xx, yy, nid, njd, nis, njs);               /* y bounds as ez_avg (:83-86, :95-98) */
+    for (int i = 0; i < nid; i++) x[i] = xx[i];
+    if (x[0] > (float)(nis - 1)) x[0] = 1.0f;
+    const float ylast = yy[(size_t)(njd - 1) * nid];
+    const float degre_a_radian = 0.017453295199f;
+    for (int j = 0; j < njd; j++) {
+        const float amplif = 1.0f / cosf(lats_dst[j] * degre_a_radian);      /* :63-65 */
+        const int row = j == 0 ? 0 : (j == njd - 1 ? 2 : 1);
+        for (int i = 0; i < nid; i++) {
+            const float lo = i == 0 ? x[0] - 0.5f * (x[1] - x[0]) * amplif : x[i] - 0.5f * (x[i] - x[i - 1]) * amplif;                 /* :71-76 */
+            const float hi = i == nid - 1 ? x[nid - 1] + 0.5f * (x[nid - 1] - x[nid - 2]) * amplif : x[i] + 0.5f * (x[i + 1] - x[i]) * amplif;   /* :88-93 */
+            zout[(size_t)j * nid + i] = orc_avg_cell(zin, nis, njs, ext, row, lo, hi, yl[j], yh[j], ylast);
+        }
+    }
+    free(xl); free(xh); free(yl); free(yh); free(x);
+}
 void orc_ez_avg(float *zout, const float *xx, const float *yy, int nid, int njd, const float *zin, int nis, int njs, int ext)
 {
     float *xl = (float *)malloc(sizeof(float) * nid), *xh = (float *)malloc(sizeof(float) * nid);

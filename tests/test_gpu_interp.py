@@ -1258,7 +1258,7 @@ def test_average_degree_refusals():
     uu, vv = ec.synth_wind(128, 64, seed=1)
     assert ez.ezuvint(uu, vv, 40 * 61)[0] == -1         # winds: not with this degree
     assert ez.ezsetopt("interp_degree", "sph_average") == 0
-    assert ez.ezsint(zin, 40 * 61)[0] == -1
+    assert ez.ezsint(zin, 40 * 61)[0] == -1             # target rows at the poles: unbounded widening, refused
     # pole rows alone are fine: the pole values overwrite them (ez_corrval.c:125-140)
     gd2 = ez.ezqkdef(40, 21, "L", 900, 900, 0, 0)
     assert ez.ezdefset(gd2, gdin) == 1
@@ -1269,3 +1269,64 @@ def test_average_degree_refusals():
     opts = ol.default_opts(degre_interp=4, polar_correction=1)
     assert O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(want), ol.fptr(zin)) == rc == 0
     assert np.array_equal(z.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("src", ["G", "A", "Lregional"])
+def test_sph_average_degree_vs_oracle_leaf(src):
+    """interp_degree = sph_average (ez_avg_sph.inc): the product through c_ezsint against the oracle's restatement of the routine (equal to
+    the reference's own, tests/test_oracle_vs_ref.py) fed with the set's located x, y and the latitudes c_gdllfxy gives for the target rows"""
+    if src == "G":
+        ni, nj, gdin = 128, 64, ez.ezqkdef(128, 64, "G", 0, 0, 0, 0); ext = 2
+        no, mo, gdout = 36, 15, ez.ezqkdef(36, 15, "L", 1000, 1000, 2000, 0)              # 70 S .. 70 N
+    elif src == "A":
+        ni, nj, gdin = 144, 72, ez.ezqkdef(144, 72, "A", 0, 0, 0, 0); ext = 2
+        no, mo, gdout = 30, 14, ez.ezqkdef(30, 14, "L", 1000, 1200, 2500, 0)
+    else:
+        ni, nj, gdin = 120, 90, ez.ezqkdef(120, 90, "L", 50, 50, 6000, 20000); ext = 0
+        no, mo, gdout = 14, 10, ez.ezqkdef(14, 10, "L", 150, 200, 7200, 21200)
+    assert ez.ezdefset(gdout, gdin) == 1
+    zin = ec.synth_field(ni, nj, seed=17)
+    assert ez.ezsetopt("interp_degree", "sph_average") == 0 and ez.ezsetopt("polar_correction", "no") == 0
+    rc, z = ez.ezsint(zin, no * mo)
+    assert rc == 0
+    d_x = torch.empty(no * mo, device="cuda"); d_y = torch.empty(no * mo, device="cuda")
+    assert ez.set_xy_dev(d_x, d_y) == 0
+    xx = d_x.cpu().numpy(); yy = d_y.cpu().numpy()
+    L = ez._lib()
+    L.c_gdllfxy.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    lats = np.zeros(mo, np.float32); lons = np.zeros(mo, np.float32)
+    xo = np.ones(mo, np.float32); yo = np.arange(1, mo + 1, dtype=np.float32)
+    assert L.c_gdllfxy(gdout, lats.ctypes.data, lons.ctypes.data, xo.ctypes.data, yo.ctypes.data, mo) == 0
+    want = np.zeros(no * mo, np.float32)
+    O = ol.oracle(); O.orc_ez_avg_sph.restype = None
+    O.orc_ez_avg_sph(ol.fptr(want), ol.fptr(xx), ol.fptr(yy), ol.fptr(lats), no, mo, ol.fptr(zin), ni, nj, ext)
+    assert np.array_equal(z.view(np.uint32), want.view(np.uint32)), (src, int(np.count_nonzero(z != want)))
+
+
+@pytest.mark.parametrize("degree", ["average", "sph_average"])
+def test_averaging_degrees_against_the_reference_build(degree):
+    """c_ezsint with the averaging degrees: the product on the GPU against the reference's own sources (oracle/_ref/libezref.so, which
+    travels with the snapshot), bit for bit, global and regional sources, polar correction off and on where it is defined"""
+    import reflib
+    if not reflib.have_ref():
+        pytest.skip("oracle/_ref/libezref.so not built")
+    R = reflib.ref()
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    cases = [((128, 64, "G", (0, 0, 0, 0)), (36, 15, "L", (1000, 1000, 2000, 0)), 0),
+             ((144, 72, "A", (0, 0, 0, 0)), (30, 14, "L", (1000, 1200, 2500, 0)), 0),
+             ((120, 90, "L", (50, 50, 6000, 20000)), (14, 10, "L", (150, 200, 7200, 21200)), 1)]
+    for src, dst, polar in cases:
+        ni, nj = src[:2]; no, mo = dst[:2]
+        zin = ec.synth_field(ni, nj, seed=23)
+        gr_in = R.c_ezqkdef(ni, nj, src[2].encode(), *src[3], 0); gr_out = R.c_ezqkdef(no, mo, dst[2].encode(), *dst[3], 0)
+        R.c_ezsetopt(b"interp_degree", degree.encode()); R.c_ezsetopt(b"polar_correction", b"yes" if polar else b"no")
+        assert R.c_ezdefset(gr_out, gr_in) == 1
+        zr = np.zeros(no * mo, np.float32)
+        rc_r = R.c_ezsint(fp(zr), fp(zin))
+        R.c_ezsetopt(b"interp_degree", b"cubic"); R.c_ezsetopt(b"polar_correction", b"yes")
+        gdin = ez.ezqkdef(ni, nj, src[2], *src[3]); gdout = ez.ezqkdef(no, mo, dst[2], *dst[3])
+        assert ez.ezdefset(gdout, gdin) == 1
+        assert ez.ezsetopt("interp_degree", degree) == 0 and ez.ezsetopt("polar_correction", "yes" if polar else "no") == 0
+        rc, z = ez.ezsint(zin, no * mo)
+        assert rc == rc_r
+        assert np.array_equal(z.view(np.uint32), zr.view(np.uint32)), (degree, src[2], int(np.count_nonzero(z != zr)))

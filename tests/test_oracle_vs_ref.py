@@ -567,3 +567,25 @@ def test_ezsint_average(name):
     rc_o = O.orc_ezsint(gs, ctypes.byref(opts), fptr(zo), fptr(zin))
     assert rc_o == rc_r
     assert np.array_equal(zo.view(np.uint32), zr.view(np.uint32)), f"{name}: {np.count_nonzero(zo != zr)} differ"
+
+
+@pytest.mark.parametrize("ext", [0, 2])
+@pytest.mark.parametrize("ratio", [1.0, 2.7])
+def test_ez_avg_sph_leaf(ext, ratio):
+    """interp_degree = sph_average: ez_avg with the x bounds of a target row widened by 1 / cos(latitude); the oracle against the
+    reference's own routine, rows between 60 S and 75 N (at a pole the widening is unbounded and the reference indexes far outside)"""
+    L = ref(); O = ol.oracle()
+    nis, njs = 97, 53
+    zin = ec.synth_field(nis, njs, seed=32)
+    nid = max(4, int((nis - 40) / ratio)); njd = max(4, int((njs - 6) / ratio))
+    x1 = (20.0 + ratio * np.arange(nid) + 0.13).astype(np.float32) if ext == 0 else (1.0 + ratio * np.arange(nid) * (nis / (nid * ratio)) + 0.37).astype(np.float32)
+    y1 = (3.0 + ratio * np.arange(njd) + 0.29).astype(np.float32)
+    lats = np.linspace(-60.0, 75.0, njd).astype(np.float32)
+    xx = np.ascontiguousarray(np.broadcast_to(x1[None, :], (njd, nid))).astype(np.float32)
+    yy = np.ascontiguousarray(np.broadcast_to(y1[:, None], (njd, nid))).astype(np.float32)
+    zr = np.full(nid * njd, -9.0, np.float32); zo = zr.copy()
+    i32 = lambda v: ctypes.byref(ctypes.c_int32(v))
+    L.ez_avg_sph_(fptr(zr), fptr(xx), fptr(yy), fptr(lats), i32(nid), i32(njd), fptr(zin), i32(nis), i32(njs), i32(ext))
+    O.orc_ez_avg_sph.restype = None
+    O.orc_ez_avg_sph(fptr(zo), fptr(xx), fptr(yy), fptr(lats), nid, njd, fptr(zin), nis, njs, ext)
+    assert np.array_equal(zo.view(np.uint32), zr.view(np.uint32)), (ext, ratio, int(np.count_nonzero(zo != zr)))
