@@ -42,18 +42,23 @@ __global__ __launch_bounds__(256) void k_stats(unsigned *stats, const unsigned *
         else if (KIND == 1) k = raw; else k = raw ^ 0x80000000u;                                                   \
         if (!skip) { kmin = min(kmin, k); kmax = max(kmax, k); kor |= raw; } } while (0)
     size_t i0 = 0;
-    /* 16 B per lane, four loads in flight; normally ONE pass per block (grid = n / 4096: the many-short-blocks shape
-     * of k_cf_pack16 streams at 6.9 TB/s where a 2048-block grid-stride loop reached 3.9) */
+    /* 16 B per lane, four loads in flight, a block sweeps 16 KB in ascending order; normally ONE pass per block (grid = n / 4096: many short
+     * blocks stream at 5.5 TB/s from HBM where a 2048-block grid-stride loop reached 3.9).  Plain loads in array order on purpose: the
+     * pass that follows (k_cf_pack16) reads the same field again and finds it in the Infinity Cache -- with `nt` loads here this pass
+     * alone is 1.4 us shorter and the pair 4.4 us longer; with the four loads a quarter of the array apart the pair is 3.9 us longer
+     * (tools/ubench_pack.hip) */
     if (stride == 1 && ((uintptr_t)a & 15) == 0) {
         const uint4 *a4 = (const uint4 *)a;
-        size_t n4 = n / 4, step = (size_t)gridDim.x * 256;
-        size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-        for (; i + 3 * step < n4; i += 4 * step) {
-            uint4 u = a4[i], v = a4[i + step], x = a4[i + 2 * step], y = a4[i + 3 * step];
-            STAT1(u.x); STAT1(u.y); STAT1(u.z); STAT1(u.w); STAT1(v.x); STAT1(v.y); STAT1(v.z); STAT1(v.w);
-            STAT1(x.x); STAT1(x.y); STAT1(x.z); STAT1(x.w); STAT1(y.x); STAT1(y.y); STAT1(y.z); STAT1(y.w);
+        const size_t n4 = n / 4;
+        for (size_t base = (size_t)blockIdx.x * 1024; base < n4; base += (size_t)gridDim.x * 1024) {
+            if (base + 1024 <= n4) {
+                const uint4 *q = a4 + base + threadIdx.x;
+                uint4 u = q[0], v = q[256], x = q[512], y = q[768];
+                STAT1(u.x); STAT1(u.y); STAT1(u.z); STAT1(u.w); STAT1(v.x); STAT1(v.y); STAT1(v.z); STAT1(v.w);
+                STAT1(x.x); STAT1(x.y); STAT1(x.z); STAT1(x.w); STAT1(y.x); STAT1(y.y); STAT1(y.z); STAT1(y.w);
+            } else
+                for (size_t i = base + threadIdx.x; i < n4; i += 256) { uint4 u = a4[i]; STAT1(u.x); STAT1(u.y); STAT1(u.z); STAT1(u.w); }
         }
-        for (; i < n4; i += step) { uint4 u = a4[i]; STAT1(u.x); STAT1(u.y); STAT1(u.z); STAT1(u.w); }
         i0 = n4 * 4;
     }
     for (size_t i = i0 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) STAT1(a[i * stride]);
@@ -82,7 +87,14 @@ __device__ __forceinline__ void stats_reduce_partials(unsigned *stats, int nb)
 {
     unsigned kmin = 0xffffffffu, kmax = 0u, kor = 0u;
     const unsigned *p = stats + PACKHIP_STATS_PARTIALS;
-    for (int b = threadIdx.x; b < nb; b += 256) { kmin = min(kmin, p[3 * b]); kmax = max(kmax, p[3 * b + 1]); kor |= p[3 * b + 2]; }
+    int b = threadIdx.x;
+    for (; b + 768 < nb; b += 1024) {           /* four triples in flight per lane: the loop is a chain of memory round trips otherwise */
+        const unsigned *q = p + 3 * b;
+        unsigned a0 = q[0], a1 = q[1], a2 = q[2], b0 = q[768], b1 = q[769], b2 = q[770];
+        unsigned c0 = q[1536], c1 = q[1537], c2 = q[1538], d0 = q[2304], d1 = q[2305], d2 = q[2306];
+        kmin = min(min(kmin, a0), min(min(b0, c0), d0)); kmax = max(max(kmax, a1), max(max(b1, c1), d1)); kor |= a2 | b2 | c2 | d2;
+    }
+    for (; b < nb; b += 256) { kmin = min(kmin, p[3 * b]); kmax = max(kmax, p[3 * b + 1]); kor |= p[3 * b + 2]; }
     for (int off = 32; off > 0; off >>= 1) {
         kmin = min(kmin, (unsigned)__shfl_down((int)kmin, off, 64));
         kmax = max(kmax, (unsigned)__shfl_down((int)kmax, off, 64));
@@ -239,19 +251,30 @@ __global__ __launch_bounds__(256) void k_cf_pack(unsigned *out, const float *a, 
     emit_word(out, w0 + k, n, E, offset, [&](size_t t) { return cf_token(a, t, stride, p, has_missing, tag); });
 }
 
-/* fast path: 16-bit slots, offset 0, stride 1: 8 floats -> 4 words per thread (16 B in / 8 B out per token pair) */
-__global__ __launch_bounds__(256) void k_cf_pack16(uint4 *out, const float4 *a, size_t n8, const packhip_cf_params *pp)
+/* fast path: 16-bit slots, offset 0, stride 1.  A block turns 4096 floats into 2048 words: 4 x (16 B in, 8 B out) per lane, every wave
+ * instruction contiguous, all four loads in flight.  Both streams are `nt`: the field is read for the last time (its first read, by
+ * k_stats, left it in the Infinity Cache: plain loads there) and the tokens are not read again by this kernel, so neither should displace
+ * the part of the field that has yet to be read a second time.  tools/ubench_pack.hip on one cfg2 field, 8 fields in rotation:
+ * k_stats + header + this pass 43.5 us, against 51.5 us with plain accesses in any shape (47.0 with nt stores only, 53.6 with nt loads only). */
+typedef float cf_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned cf_v2u __attribute__((ext_vector_type(2)));
+typedef unsigned cf_v4u __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_cf_pack16(cf_v2u *out, const cf_v4f *a, size_t n4, const packhip_cf_params *pp)
 {
-    size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (k >= n8) return;
     const double minF = pp->minF, mul = pp->mulFactor;
-    float4 x = a[2 * k], y = a[2 * k + 1];
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
 #define TK(v) ((unsigned)(long long)(((double)(v) - minF) * mul) & 0xFFFFu)
-    uint4 o;
-    o.x = TK(x.x) << 16 | TK(x.y); o.y = TK(x.z) << 16 | TK(x.w);
-    o.z = TK(y.x) << 16 | TK(y.y); o.w = TK(y.z) << 16 | TK(y.w);
+#define TK4(x_, o_) do { (o_).x = TK((x_).x) << 16 | TK((x_).y); (o_).y = TK((x_).z) << 16 | TK((x_).w); } while (0)
+    if ((size_t)(blockIdx.x + 1) * 1024 <= n4) {
+        cf_v4f x[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = __builtin_nontemporal_load(&a[i + 256 * k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { cf_v2u o; TK4(x[k], o); __builtin_nontemporal_store(o, &out[i + 256 * k]); }
+    } else                                      /* the last, partial block */
+        for (size_t j = i; j < n4; j += 256) { cf_v4f x = a[j]; cf_v2u o; TK4(x, o); out[j] = o; }
+#undef TK4
 #undef TK
-    out[k] = o;
 }
 
 extern "C" int packhip_cf_header(packhip_cf_params *d_pp, unsigned *d_hdr, unsigned *d_stats, int npartials, unsigned n, int bs, int style, int has_missing)
@@ -273,9 +296,9 @@ extern "C" int packhip_cf_pack(unsigned *d_out, const float *d_a, size_t n, int 
     if (n == 0) return 0;
     size_t w0 = (size_t)offset / 32, w1 = ((size_t)offset + n * (size_t)E + 31) / 32;
     if (E == 16 && offset == 0 && stride == 1 && !has_missing && ((uintptr_t)d_a % 16 == 0) && ((uintptr_t)d_out % 16 == 0)) {
-        size_t n8 = n / 8;
-        if (n8) hipLaunchKernelGGL(k_cf_pack16, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, STREAM, (uint4 *)d_out, (const float4 *)d_a, n8, d_pp);
-        size_t done_words = n8 * 4;
+        size_t n4 = n / 4;              /* groups of four points = two stream words; the rest (< 4 points) goes through the generic kernel */
+        if (n4) hipLaunchKernelGGL(k_cf_pack16, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, STREAM, (cf_v2u *)d_out, (const cf_v4f *)d_a, n4, d_pp);
+        size_t done_words = n4 * 2;
         if (done_words < w1)    /* tail words through the generic kernel */
             hipLaunchKernelGGL(k_cf_pack, dim3((unsigned)((w1 - done_words + 255) / 256)), dim3(256), 0, STREAM, d_out, d_a, n, E, offset, stride, d_pp, 0, tag, done_words, w1 - done_words);
         return chk("k_cf_pack16");
@@ -380,10 +403,38 @@ extern "C" int packhip_narrow(void *d_dst, const unsigned *d_src, size_t n, int 
     return chk("k_narrow");
 }
 
+/* fast path of FLOAT_UNPACK: 16-bit slots, offset 0, stride 1, no missing values: a block turns 2048 words into 4096 floats, 4 x (8 B in, 16 B out)
+ * per lane, both streams `nt` (each byte is touched once) */
+__global__ __launch_bounds__(256) void k_cf_unpack16(cf_v4f *a, const cf_v2u *in, size_t n4, double minF, double mulFactor)
+{
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    const float fmin = (float)minF;
+#define UV(t) ((t) == 0 ? fmin : (float)(((t) * mulFactor) * 1.0000000000001 + minF))
+#define UV4(w_, v_) do { unsigned t0 = (w_).x >> 16, t1 = (w_).x & 0xFFFFu, t2 = (w_).y >> 16, t3 = (w_).y & 0xFFFFu; \
+                         (v_).x = UV(t0); (v_).y = UV(t1); (v_).z = UV(t2); (v_).w = UV(t3); } while (0)
+    if ((size_t)(blockIdx.x + 1) * 1024 <= n4) {
+        cf_v2u w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = __builtin_nontemporal_load(&in[i + 256 * k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { cf_v4f v; UV4(w[k], v); __builtin_nontemporal_store(v, &a[i + 256 * k]); }
+    } else
+        for (size_t j = i; j < n4; j += 256) { cf_v2u w = in[j]; cf_v4f v; UV4(w, v); a[j] = v; }
+#undef UV4
+#undef UV
+}
 extern "C" int packhip_cf_unpack(float *d_a, const unsigned *d_in, size_t n, int tokenSize, int offset, int stride,
                                  double minF, double mulFactor, unsigned missingToken, int has_missing, float tag)
 {
     if (!n) return 0;
+    if (tokenSize == 16 && offset == 0 && stride == 1 && has_missing != 1 && ((uintptr_t)d_a % 16 == 0) && ((uintptr_t)d_in % 8 == 0) && n >= 4) {
+        size_t n4 = n / 4, done = n4 * 4;
+        hipLaunchKernelGGL(k_cf_unpack16, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, STREAM, (cf_v4f *)d_a, (const cf_v2u *)d_in, n4, minF, mulFactor);
+        if (done < n)       /* the rest: token `done` starts at word done / 2 */
+            hipLaunchKernelGGL(k_cf_unpack, dim3((unsigned)((n - done + 255) / 256)), dim3(256), 0, STREAM, d_a + done, d_in + done / 2, n - done, tokenSize, 0, 1,
+                               minF, mulFactor, missingToken, has_missing, tag);
+        return chk("k_cf_unpack16");
+    }
     hipLaunchKernelGGL(k_cf_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM, d_a, d_in, n, tokenSize, offset, stride, minF, mulFactor, missingToken, has_missing, tag);
     return chk("k_cf_unpack");
 }
