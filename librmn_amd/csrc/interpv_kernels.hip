@@ -28,6 +28,7 @@
 
 #define IV_THREADS 256
 #define IV_TU 4                         /* destination levels in flight per thread */
+#define IV_SB 16                        /* level rows in flight per lane while staging */
 #define IV_LDS_MAX (80 * 1024)          /* staged levels per block, at most: two blocks per CU */
 #define IV_LDS_SOFT (20 * 1024)         /* preferred: eight blocks (32 waves) per CU -- REAL*8, 80 levels: 64 columns (40 KB) 2.75 ms, 32 columns (20 KB) 2.33 ms for the search */
 
@@ -48,9 +49,12 @@ struct iv_args {
 /* COLS = 0: levels are read from memory (srcNumLevels too large for LDS), 64 columns per wave */
 /* waves_per_eu(8, 8): 64 VGPRs (a few spilled dwords) for eight waves per SIMD -- the kernel lives on occupancy: REAL search 1.95 -> 1.65 ms,
  * fused linear 2.70 -> 2.36 ms, cubic with derivatives 3.57 -> 2.90 ms against the 76 VGPRs / six waves the compiler picks by itself */
-template <typename R, int COLS>
+/* ALGO: the interpolation algorithm as a compile-time constant (the other algorithms' code and registers are gone: the body is VALU-bound,
+ * 1828 VALU instructions per wave with everything in one body), or -1: read from the arguments (the levels-in-memory form) */
+template <typename R, int COLS, int ALGO>
 __global__ __launch_bounds__(IV_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_interpv(iv_args<R> a)
 {
+    const int algo = ALGO >= 0 ? ALGO : a.algo;
     extern __shared__ __attribute__((aligned(16))) unsigned char iv_smem[];
     R *lev = (R *)iv_smem;
     constexpr int C = COLS ? COLS : IV_THREADS;
@@ -63,12 +67,21 @@ __global__ __launch_bounds__(IV_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     if (COLS) {
         /* thread group tg stages a contiguous run of rows of its column (rows tg, tg + NTG, ... measured slower: REAL*8 search 4.1 -> 2.3 ms) */
         const int per = (ns + NTG - 1) / NTG, k0 = tg * per, k1 = min(ns, k0 + per);
-        for (int k = k0; k < k1; k++) lev[(size_t)k * C + lc] = live ? a.vls[i + (size_t)k * sij] : (R)0;
+        /* IV_SB rows in flight per lane: written as `lev[..] = vls[..]` per row the loop waits for every load before it issues the next
+         * (one memory round trip per row: 20 per block at 80 levels) -- REAL fused linear 2.45 -> ... ms */
+        const R *vsrc = a.vls + (live ? i : (long long)a.n - 1);           /* dead lanes of the last block read the last column */
+        for (int k = k0; k < k1; k += IV_SB) {
+            R x[IV_SB];
+#pragma unroll
+            for (int j = 0; j < IV_SB; j++) x[j] = vsrc[(size_t)min(k + j, k1 - 1) * sij];
+#pragma unroll
+            for (int j = 0; j < IV_SB; j++) if (k + j < k1) lev[(size_t)(k + j) * C + lc] = x[j];
+        }
         __syncthreads();
     }
     if (!live) return;
     const R *vcol = a.vls + i;
-#define LEV(k) (COLS ? lev[(size_t)((k) - 1) * C + lc] : vcol[(size_t)((k) - 1) * sij])
+#define LEV(k) (COLS ? lev[((k) - 1) * C + lc] : vcol[(size_t)((k) - 1) * sij])
 #define SSRC(k) a.ss[i + (size_t)((k) - 1) * sij]
 #define DSRC(k) a.sds[i + (size_t)((k) - 1) * sij]
     /* direction of the levels: column 1 speaks for all (Interp1D_FindPos_Body.inc:88, Interp1D_Linear_Body.inc:73) */
@@ -76,6 +89,8 @@ __global__ __launch_bounds__(IV_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const int smallest = asc ? 1 : ns, largest = asc ? ns : 1;
     const int loposn = asc ? 1 : ns - 1, hiposn = asc ? ns - 1 : 1;
     const int t_begin = blockIdx.y * a.t_per_block, t_end = min(a.nd, t_begin + a.t_per_block);
+    const R lev_small = LEV(smallest), lev_large = LEV(largest);     /* the column's extreme levels: the clamp and the extrapolators compare against them */
+    const R *levc = lev + lc - C;                                      /* LEV(k) = levc[k * C] */
 
     for (int tb = t_begin + tg * IV_TU; tb < t_end; tb += NTG * IV_TU) {
         R v[IV_TU];
@@ -96,7 +111,8 @@ __global__ __launch_bounds__(IV_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 #pragma unroll
                 for (int u = 0; u < IV_TU; u++) {
                     const int ii = (int)idx[u];
-                    const R l0 = LEV(ii), l1 = LEV(ii + 1);
+                    R l0, l1;
+                    if (COLS) { const R *q = levc + ii * C; l0 = q[0]; l1 = q[C]; } else { l0 = LEV(ii); l1 = LEV(ii + 1); }
                     if (v[u] >= l0) idx[u] = idx[u] + up;
                     if (v[u] <= l1) idx[u] = idx[u] - up;
                 }
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(IV_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             if (a.find && a.write_posn) a.posn[o] = q;
             R out = 0, outd = 0;
             bool have = false, have_d = false;
-            switch (a.algo) {
+            switch (algo) {
             case IV_NEAREST: {
                 const R lb = LEV(q), la = LEV(q + 1);
                 out = (fabs(x - lb) < fabs(x - la)) ? SSRC(q) : SSRC(q + 1);
@@ -171,19 +187,19 @@ __global__ __launch_bounds__(IV_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             }
             default: break;
             }
-            if (a.algo >= IV_LINEAR) {                          /* the clamp that closes the three polynomial routines */
-                if (!a.xdown && x < LEV(smallest)) { out = SSRC(smallest); if (have_d) outd = DSRC(smallest); }
-                else if (!a.xup && x > LEV(largest)) { out = SSRC(largest); if (have_d) outd = DSRC(largest); }
+            if (algo >= IV_LINEAR) {                          /* the clamp that closes the three polynomial routines */
+                if (!a.xdown && x < lev_small) { out = SSRC(smallest); if (have_d) outd = DSRC(smallest); }
+                else if (!a.xup && x > lev_large) { out = SSRC(largest); if (have_d) outd = DSRC(largest); }
             }
             if (a.extrap) {
                 int side = -1;                                    /* 0 below the lowest level, 1 above the highest */
-                if (a.xdown && q == loposn) { if (x < LEV(smallest)) side = 0; }
-                else if (a.xup && q == hiposn) { if (x > LEV(largest)) side = 1; }
+                if (a.xdown && q == loposn) { if (x < lev_small) side = 0; }
+                else if (a.xup && q == hiposn) { if (x > lev_large) side = 1; }
                 if (side >= 0) {
                     const int e = side ? largest : smallest;
                     if (a.extrap == IVX_FIXED) { out = side ? a.gup : a.gdown; have = true; }
                     else if (a.extrap == IVX_LAPSERATE) {
-                        const R d = x - LEV(e);
+                        const R d = x - (side ? lev_large : lev_small);
                         const R pr = (side ? a.gup : a.gdown) * d;
                         out = SSRC(e) + pr;
                         have = true;
@@ -201,8 +217,8 @@ __global__ __launch_bounds__(IV_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 #undef DSRC
 }
 
-template <typename R, int COLS>
-static int launch_cols(const iv_args<R> &a0, hipStream_t st)
+template <typename R, int COLS, int ALGO>
+static int launch_cols_algo(const iv_args<R> &a0, hipStream_t st)
 {
     iv_args<R> a = a0;
     constexpr int C = COLS ? COLS : IV_THREADS;
@@ -215,12 +231,24 @@ static int launch_cols(const iv_args<R> &a0, hipStream_t st)
     const unsigned by = (unsigned)((a.nd + a.t_per_block - 1) / a.t_per_block);
     const size_t lds = COLS ? (size_t)COLS * a.ns * sizeof(R) : 0;
     if (lds > 64 * 1024) {
-        static bool raised[2][4];
-        bool &r = raised[sizeof(R) == 8][COLS == 64 ? 0 : COLS == 32 ? 1 : COLS == 16 ? 2 : 3];
-        if (!r) { if (hipFuncSetAttribute((const void *)k_interpv<R, COLS>, hipFuncAttributeMaxDynamicSharedMemorySize, IV_LDS_MAX) != hipSuccess) return -1; r = true; }
+        static bool raised;                                         /* one per instantiation */
+        if (!raised) { if (hipFuncSetAttribute((const void *)k_interpv<R, COLS, ALGO>, hipFuncAttributeMaxDynamicSharedMemorySize, IV_LDS_MAX) != hipSuccess) return -1; raised = true; }
     }
-    hipLaunchKernelGGL((k_interpv<R, COLS>), dim3(bx, by), dim3(IV_THREADS), lds, st, a);
+    hipLaunchKernelGGL((k_interpv<R, COLS, ALGO>), dim3(bx, by), dim3(IV_THREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+template <typename R, int COLS>
+static int launch_cols(const iv_args<R> &a, hipStream_t st)
+{
+    if constexpr (COLS == 0) return launch_cols_algo<R, COLS, -1>(a, st);
+    else switch (a.algo) {
+    case IV_NONE: return launch_cols_algo<R, COLS, IV_NONE>(a, st);
+    case IV_NEAREST: return launch_cols_algo<R, COLS, IV_NEAREST>(a, st);
+    case IV_LINEAR: return launch_cols_algo<R, COLS, IV_LINEAR>(a, st);
+    case IV_CUBIC_LAGRANGE: return launch_cols_algo<R, COLS, IV_CUBIC_LAGRANGE>(a, st);
+    case IV_CUBIC_DERIVS: return launch_cols_algo<R, COLS, IV_CUBIC_DERIVS>(a, st);
+    default: return -1;
+    }
 }
 
 template <typename R>

@@ -20,7 +20,8 @@ for r in rows:
     k = (r["Kernel_Name"][:50], r["Grid_Size"], r["Counter_Name"])
     agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
 for k, v in sorted(agg.items()):
-    if "k_armn" in k[0] or "k_sepx" in k[0]:
+    import os
+    if any(f in k[0] for f in os.environ.get("KFILTER", "k_armn,k_sepx").split(",")):
         print(f"{k[0]:52s} grid={k[1]:>10s} {k[2]:28s} dispatches={v[0]:4d} mean={v[1]/v[0]:16.1f}")
 PY
   rm -rf $R/gpurun_out/$TAG/pmc$k
