@@ -44,6 +44,8 @@ struct iv_args {
     R gdown, gup;
     unsigned long long *abort_key;
     int t_per_block;
+    unsigned nbx;                   /* column blocks; the grid's x size is nbx rounded up to a multiple of 8 when xcd_map is set */
+    int xcd_map;                    /* 0, or the number of consecutive column blocks given to one XCD at a time */
 };
 
 /* COLS = 0: levels are read from memory (srcNumLevels too large for LDS), 64 columns per wave */
@@ -60,7 +62,11 @@ __global__ __launch_bounds__(IV_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     constexpr int C = COLS ? COLS : IV_THREADS;
     constexpr int NTG = IV_THREADS / C;                       /* groups of threads sharing the block's columns */
     const int lc = threadIdx.x % C, tg = threadIdx.x / C;
-    const long long i = (long long)blockIdx.x * C + lc;
+    /* consecutive column blocks on ONE XCD (workgroups go round the 8 XCDs in turn): the 256-byte row segments of neighbouring blocks share
+     * 128-byte lines (rows are aligned to the element only), and the two blocks' fetches of such a line then meet in the same L2 */
+    unsigned bx = blockIdx.x;
+    if (a.xcd_map) { const unsigned sq = blockIdx.x >> 3, G = (unsigned)a.xcd_map; bx = ((sq / G) * 8u + (blockIdx.x & 7u)) * G + sq % G; if (bx >= a.nbx) return; }
+    const long long i = (long long)bx * C + lc;
     const bool live = i < a.n;
     const size_t sij = (size_t)a.sij, dij = (size_t)a.dij;
     const int ns = a.ns;
@@ -230,11 +236,17 @@ static int launch_cols_algo(const iv_args<R> &a0, hipStream_t st)
     a.t_per_block = (((a.nd + slices - 1) / slices) + chunk - 1) / chunk * chunk;
     const unsigned by = (unsigned)((a.nd + a.t_per_block - 1) / a.t_per_block);
     const size_t lds = COLS ? (size_t)COLS * a.ns * sizeof(R) : 0;
+    static const bool no_xcd = getenv("INTERPV_HIP_NO_XCD_MAP") != nullptr;     /* development */
+    static const char *xg = getenv("INTERPV_HIP_XCD_GROUP");                     /* development: consecutive blocks per XCD (0: an eighth of the grid) */
+    unsigned G = xg ? (unsigned)atoi(xg) : 16u;          /* 4 / 16 / 64 / 512 / an eighth: 1.67 / 1.60 / 1.59 / 1.58 / 1.59 ms (REAL fused linear), unmapped 1.71 */
+    if (G == 0) G = (bx + 7u) / 8u;
+    a.nbx = bx; a.xcd_map = (bx >= 64 && !no_xcd) ? (int)G : 0;
+    const unsigned gx = a.xcd_map ? (bx + 8u * G - 1u) / (8u * G) * (8u * G) : bx;
     if (lds > 64 * 1024) {
         static bool raised;                                         /* one per instantiation */
         if (!raised) { if (hipFuncSetAttribute((const void *)k_interpv<R, COLS, ALGO>, hipFuncAttributeMaxDynamicSharedMemorySize, IV_LDS_MAX) != hipSuccess) return -1; raised = true; }
     }
-    hipLaunchKernelGGL((k_interpv<R, COLS, ALGO>), dim3(bx, by), dim3(IV_THREADS), lds, st, a);
+    hipLaunchKernelGGL((k_interpv<R, COLS, ALGO>), dim3(gx, by), dim3(IV_THREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <typename R, int COLS>
@@ -260,7 +272,7 @@ static int launch_typed(const ivhip_args *h)
     a.vls = (const R *)h->vls; a.ss = (const R *)h->ss; a.sds = (const R *)h->sds;
     a.posn = h->posn; a.vld = (const R *)h->vld; a.sd = (R *)h->sd; a.sdd = (R *)h->sdd;
     a.xdown = h->xdown; a.xup = h->xup; a.gdown = (R)h->gdown; a.gup = (R)h->gup;
-    a.abort_key = h->abort_key; a.t_per_block = 0;
+    a.abort_key = h->abort_key; a.t_per_block = 0; a.nbx = 0; a.xcd_map = 0;
     hipStream_t st = (hipStream_t)ezhip_get_stream();
     const size_t per_col = (size_t)a.ns * sizeof(R);
     /* occupancy decides (measured, 80 -> 60 levels, REAL: 256 columns per block 3.9 ms, 128: 2.3 ms, 64: 1.8 ms for the search):
