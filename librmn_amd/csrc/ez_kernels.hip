@@ -169,9 +169,17 @@ __device__ float block_poleval(const float *zrow, int ni, int weighted, const fl
     for (int base = 0; base < n; base += chunk) {
         const int m = min(chunk, n - base);
         __syncthreads();
-        for (int k = threadIdx.x; k < m; k += blockDim.x) {
-            int i = base + k;
-            lds[k] = weighted ? zrow[i] * (ax[i + 1] - ax[i]) : zrow[i];
+        /* eight elements in flight per lane (as a plain copy loop the compiler waits for each load before it issues the next: one memory
+         * round trip per blockDim elements, 14 - 17 of them for a 4400-point row, in front of the sequential sum every special row waits for) */
+        for (int k0 = threadIdx.x; k0 < m; k0 += 8 * blockDim.x) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = base + min(k0 + u * (int)blockDim.x, m - 1);
+                x[u] = weighted ? zrow[i] * (ax[i + 1] - ax[i]) : zrow[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int k = k0 + u * (int)blockDim.x; if (k < m) lds[k] = x[u]; }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
