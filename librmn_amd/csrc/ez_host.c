@@ -2025,7 +2025,7 @@ static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector
 
 /* both components of a wind pair on the per-point path in ONE pass (k_pts2); returns -2 when the set is not on that path */
 static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui, const float *d_vi,
-                        const float *pun, const float *pus, const float *pvn, const float *pvs, const void *d_M)
+                        const float *pun, const float *pus, const float *pvn, const float *pvs, const void *d_M, int dst_rot)
 {
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     int degree = O.degre_interp, polar = O.polar_correction == 1;
@@ -2050,7 +2050,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
         if (ezhip_fill_value(d_fill, d_ui, (size_t)gi->ni * gi->nj, O.degre_extrap, O.valeur_extrap, 1)) return -1;
     }
     pu.fill = d_fill; pu.polevals = d_poles;
-    pu.wind_M = d_M;
+    pu.wind_M = d_M; pu.wind_dst_rot = dst_rot;
     pv = pu;
     pu.pole_row_n = pun; pu.pole_row_s = pus; pv.pole_row_n = pvn; pv.pole_row_s = pvs;
     if (zones == 2 && s->have_dehors) ierc = 2;
@@ -2503,8 +2503,11 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
         return -1;
     }
     int ni = gi->ni, nj = gi->nj, polar = O.polar_correction == 1;
+    /* one grid on both sides: the two c_ezsint calls of c_ezuvint_orig (ezuvint.c:68-71) copy their fields (ezsint.c: identical grids, return 1) and
+     * never define the set's zones, so ez_corrvec finds none; the wind chain still runs on the copies (ierc stays 0) */
+    const int same = s->gdin == s->gdout;
     const float *pun = NULL, *pus = NULL, *pvn = NULL, *pvs = NULL;
-    if (polar && !s->extrap) {
+    if (polar && !s->extrap && !same) {
         /* synthetic polar wind rows (ez_calcnpolarwind.c): one small kernel, no host round trip.  The row longitudes
          * and the polar-stereographic xg4 depend on the grid only: computed once on the host. */
         if (!s->d_prow) s->d_prow = (float *)ezhip_malloc(sizeof(float) * 4 * (size_t)ni);
@@ -2597,9 +2600,13 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
         pthread_mutex_unlock(&g_plan_mtx);
         if (mrc) return dev_fail("the wind rotation matrix");
     }
-    int r1 = run_pair_pts(s, d_uuout, d_vvout, d_uuin, d_vvin, pun, pus, pvn, pvs, getenv("EZHIP_WIND_NO_FUSE") ? NULL : d_M), r2 = r1;
+    int r1 = 0, r2 = 0;
+    if (same) {
+        const size_t nb = sizeof(float) * (size_t)ni * nj;
+        if ((d_uuout != d_uuin && ezhip_d2d(d_uuout, d_uuin, nb)) || (d_vvout != d_vvin && ezhip_d2d(d_vvout, d_vvin, nb))) return -1;
+    } else r1 = r2 = run_pair_pts(s, d_uuout, d_vvout, d_uuin, d_vvin, pun, pus, pvn, pvs, getenv("EZHIP_WIND_NO_FUSE") ? NULL : d_M, wp.dst_rotated);
     if (r1 == -1) return -1;
-    const int fused = r1 != -2 && d_M && !getenv("EZHIP_WIND_NO_FUSE");
+    const int fused = !same && r1 != -2 && d_M && !getenv("EZHIP_WIND_NO_FUSE");
     if (r1 == -2) {                                          /* separable set: one launch per component */
         r1 = run_field(s, d_uuout, d_uuin, 1, pun, pus);
         if (r1 < 0) return r1;
@@ -2607,7 +2614,7 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
         if (r2 < 0) return r2;
     }
     if (ezhip_side_join()) return -1;                        /* nothing may outlive the call on the side stream */
-    if (d_M) { if (!fused && ezhip_wind_apply(d_M, d_uuout, d_vvout, (size_t)go->ni * go->nj)) return -1; }
+    if (d_M) { if (!fused && ezhip_wind_apply(d_M, d_uuout, d_vvout, (size_t)go->ni * go->nj, wp.dst_rotated)) return -1; }
     else if (ezhip_wind_rotate(&wp, d_uuout, d_vvout, go->d_lat, go->d_lon, go->ni, go->nj)) return -1;
     return (r1 == 2 || r2 == 2) ? 2 : 0;
 }

@@ -1046,6 +1046,21 @@ extern "C" int ezhip_polar_wind(float *d_out4, const float *d_uu, const float *d
     return LAUNCH_CHECK("k_polar_wind");
 }
 
+/* the wind chain of a grid pair as its 2 x 2 matrix (ezhip_wind_matrix).  The chain itself passes through speed and direction, and its REAL
+ * sqrt(u*u + v*v) (ez_llwfgdw.inc:91-165) overflows for |V| > 1.8e19 -- raw cubic extrapolation far outside a polar-stereographic source gets there:
+ * the speed is then inf, and what follows it is NaN in both components when the target frame is rotated (ez_uvacart.inc: inf - inf in one of the first
+ * two cartesian components for every sign pattern, then mxm) and inf with the sign of the component otherwise (ez_gdwfllw.inc: cos(psi) * inf).
+ * The matrix has no square in it; this reproduces the chain's overflow (found by tools/fuzz_vs_ref2.py against the reference build). */
+__device__ __forceinline__ void d_wind_matrix_apply(float mx, float my, float mz, float mw, float u, float v, int dst_rot, float &a, float &b)
+{
+    a = mx * u + my * v; b = mz * u + mw * v;
+    const float s2 = dst_rot ? u * u + v * v : a * a + b * b;
+    if (!(s2 <= 3.402823466e+38f)) {
+        const float inf = __builtin_inff(), nan = __builtin_nanf("");
+        if (dst_rot) { a = nan; b = nan; }
+        else { a = (a == 0.0f || a != a) ? nan : copysignf(inf, a); b = (b == 0.0f || b != b) ? nan : copysignf(inf, b); }
+    }
+}
 /* ===================================================================================== */
 /* k_pts : generic per-point interpolation (restates the reference leaf kernels)            */
 /* ===================================================================================== */
@@ -1478,7 +1493,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         else { a = leaf_point<KIND>(p, Z1, px, py); b = leaf_point<KIND>(p, Z2, px, py); }
         if (p.wind_M) {                       /* the wind chain of the grid pair (k_wind_apply), here instead of a pass of its own */
             const float u = a, v = b;
-            a = wm.x * u + wm.y * v; b = wm.z * u + wm.w * v;
+            d_wind_matrix_apply(wm.x, wm.y, wm.z, wm.w, u, v, p.wind_dst_rot, a, b);
         }
         zout1[o] = a; zout2[o] = b;
     }
@@ -1545,7 +1560,7 @@ __global__ __launch_bounds__(256) void k_pts_special2(ezhip_pts_plan p, float *_
         if (p.wind_M) {
             const float4 m = ((const float4 *)p.wind_M)[o];
             const float u = a, v = b;
-            a = m.x * u + m.y * v; b = m.z * u + m.w * v;
+            d_wind_matrix_apply(m.x, m.y, m.z, m.w, u, v, p.wind_dst_rot, a, b);
         }
         zout1[o] = a; zout2[o] = b;
     }
@@ -2085,14 +2100,15 @@ __global__ __launch_bounds__(256) void k_fill2(float *__restrict__ a, float va, 
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (k < n) { a[k] = va; b[k] = vb; }
 }
-__global__ __launch_bounds__(256) void k_wind_apply(const float4 *__restrict__ M, float *__restrict__ uu, float *__restrict__ vv, size_t n)
+__global__ __launch_bounds__(256) void k_wind_apply(const float4 *__restrict__ M, float *__restrict__ uu, float *__restrict__ vv, size_t n, int dst_rot)
 {
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     const float4 m = M[k];
     const float u = uu[k], v = vv[k];
-    uu[k] = m.x * u + m.y * v;
-    vv[k] = m.z * u + m.w * v;
+    float a, b;
+    d_wind_matrix_apply(m.x, m.y, m.z, m.w, u, v, dst_rot, a, b);
+    uu[k] = a; vv[k] = b;
 }
 extern "C" int ezhip_wind_matrix(const ezhip_wind_plan *plan, void *d_M, const float *d_lat, const float *d_lon, int ni_dst, int nj_dst)
 {
@@ -2111,10 +2127,10 @@ extern "C" int ezhip_wind_matrix(const ezhip_wind_plan *plan, void *d_M, const f
     (void)hipFree(t);
     return rc;
 }
-extern "C" int ezhip_wind_apply(const void *d_M, float *d_uu, float *d_vv, size_t npts)
+extern "C" int ezhip_wind_apply(const void *d_M, float *d_uu, float *d_vv, size_t npts, int dst_rotated)
 {
     if (!npts) return 0;
-    hipLaunchKernelGGL(k_wind_apply, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, g_stream, (const float4 *)d_M, d_uu, d_vv, npts);
+    hipLaunchKernelGGL(k_wind_apply, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, g_stream, (const float4 *)d_M, d_uu, d_vv, npts, dst_rotated);
     return LAUNCH_CHECK("k_wind_apply");
 }
 

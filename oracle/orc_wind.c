@@ -429,7 +429,7 @@ int orc_ezuvint(orc_gridset *gs, const orc_opts *o, float *uuout, float *vvout,
     int ierc1 = orc_ezsint(gs, &ov, uuout, uuin);
     int ierc2 = orc_ezsint(gs, &ov, vvout, vvin);
     if (ierc1 == 2 || ierc2 == 2) ierc = 2;
-    if (o->polar_correction == 1) {                              /* ez_corrvec.c:24-48 */
+    if (o->polar_correction == 1 && gi != go) {                  /* ez_corrvec.c:24-48; one grid on both sides: c_ezsint returned before ez_defzones (ezsint.c), the set has no zones */
         orc_defzones(gs);
         if (gs->zones[ORC_Z_AU_NORD].npts > 0) corrvec_strip(gs, o->degre_interp, uuout, vvout, uuin, vvin, 1);
         if (gs->zones[ORC_Z_AU_SUD].npts > 0) corrvec_strip(gs, o->degre_interp, uuout, vvout, uuin, vvin, 0);
@@ -457,7 +457,7 @@ int orc_ezwdint(orc_gridset *gs, const orc_opts *o, float *uuout, float *vvout,
     int ierc1 = orc_ezsint(gs, &ov, uuout, uuin);
     int ierc2 = orc_ezsint(gs, &ov, vvout, vvin);
     if (ierc1 == 2 || ierc2 == 2) ierc = 2;
-    if (o->polar_correction == 1) {                              /* ez_corrvec.c:24-48 */
+    if (o->polar_correction == 1 && gi != go) {                  /* ez_corrvec.c:24-48; one grid on both sides: c_ezsint returned before ez_defzones (ezsint.c), the set has no zones */
         orc_defzones(gs);
         if (gs->zones[ORC_Z_AU_NORD].npts > 0) corrvec_strip(gs, o->degre_interp, uuout, vvout, uuin, vvin, 1);
         if (gs->zones[ORC_Z_AU_SUD].npts > 0) corrvec_strip(gs, o->degre_interp, uuout, vvout, uuin, vvin, 0);

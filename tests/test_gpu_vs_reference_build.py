@@ -1,6 +1,7 @@
 """The product on the GPU against the reference's OWN sources (oracle/_ref/libezref.so, built where they lie and shipped with the snapshot)
 on random grid pairs -- no oracle in between.  tools/fuzz_vs_ref.py: c_ezsint nearest / bilinear bit for bit, bicubic within 1e-5, c_ezuvint
-within 1e-5 |V|, global / hemispheric / regional sources, every extrapolation mode; tools/fuzz_average.py: the averaging degrees bit for bit."""
+within 1e-5 |V|, global / hemispheric / regional sources, every extrapolation mode; tools/fuzz_average.py: the averaging degrees bit for bit; tools/fuzz_vs_ref2.py: irregular (Z-on-L), rotated (Z-on-E, global and regional) and
+polar-stereographic grids on either side, Gaussian and Z targets -- it found the two cases tested by name below."""
 import os, subprocess, sys
 import pytest
 import reflib
@@ -10,8 +11,70 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
 
 @pytest.mark.skipif(not reflib.have_ref(), reason="oracle/_ref/libezref.so not built")
-@pytest.mark.parametrize("tool,ncases,seed", [("fuzz_vs_ref.py", 400, 1), ("fuzz_vs_ref.py", 400, 2), ("fuzz_average.py", 200, 1)])
+@pytest.mark.parametrize("tool,ncases,seed", [("fuzz_vs_ref.py", 400, 1), ("fuzz_vs_ref.py", 400, 2), ("fuzz_average.py", 200, 1),
+                                              ("fuzz_vs_ref2.py", 600, 1), ("fuzz_vs_ref2.py", 600, 7)])
 def test_random_grid_pairs_against_the_reference_build(tool, ncases, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(ncases), str(seed)], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+def _ref_and_product(src, dst, degree, polar, extrap="maximum"):
+    """(reference u, v, rc), (product u, v, rc) of c_ezuvint for grids given as (ni, nj, grtyp, ig, grref, ax, ay)"""
+    import ctypes
+    import numpy as np
+    import ezcases as ec
+    from librmn_amd import ezscint as ez
+    R = reflib.ref()
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    def define(ref_side, g):
+        ni, nj, t, ig, rf, ax, ay = g
+        if ax is None:
+            return R.c_ezqkdef(ni, nj, t.encode(), *ig, 0) if ref_side else ez.ezqkdef(ni, nj, t, *ig)
+        return R.c_ezgdef_fmem(ni, nj, t.encode(), rf.encode(), *ig, fp(ax), fp(ay)) if ref_side else ez.ezgdef_fmem(ni, nj, t, rf, *ig, ax, ay)
+    ni, nj = src[:2]; n = dst[0] * dst[1]
+    uu, vv = ec.synth_wind(ni, nj, seed=6)
+    gi, go = define(True, src), define(True, dst)
+    for name, val in (("interp_degree", degree), ("polar_correction", "yes" if polar else "no"), ("extrap_degree", extrap)):
+        R.c_ezsetopt(name.encode(), val.encode()); ez.ezsetopt(name, val)
+    assert R.c_ezdefset(go, gi) == 1
+    ur = np.zeros(n, np.float32); vr = ur.copy()
+    rcr = R.c_ezuvint(fp(ur), fp(vr), fp(uu), fp(vv))
+    a, b = define(False, src), define(False, dst)
+    assert ez.ezdefset(b, a) == 1
+    rc, u, v = ez.ezuvint(uu, vv, n)
+    for name, val in (("interp_degree", "cubic"), ("polar_correction", "yes"), ("extrap_degree", "maximum")):
+        R.c_ezsetopt(name.encode(), val.encode()); ez.ezsetopt(name, val)
+    return (ur, vr, rcr), (u, v, rc), (uu, vv)
+
+
+@pytest.mark.skipif(not reflib.have_ref(), reason="oracle/_ref/libezref.so not built")
+@pytest.mark.parametrize("degree", ["nearest", "linear", "cubic"])
+@pytest.mark.parametrize("polar", [0, 1])
+def test_winds_with_one_grid_on_both_sides(degree, polar):
+    """gdin == gdout (ezuvint.c:68-86): the fields are copied, not interpolated, and only the wind chain touches them"""
+    import numpy as np
+    g = (244, 122, "G", (0, 0, 0, 0), " ", None, None)
+    (ur, vr, rcr), (u, v, rc), (uu, vv) = _ref_and_product(g, g, degree, polar)
+    assert rc == rcr == 0
+    sc = np.maximum(np.hypot(ur, vr), 1e-3)
+    assert np.all(np.abs(u - ur) <= 1e-5 * sc) and np.all(np.abs(v - vr) <= 1e-5 * sc)
+
+
+@pytest.mark.skipif(not reflib.have_ref(), reason="oracle/_ref/libezref.so not built")
+def test_wind_chain_overflow_of_the_speed():
+    """raw cubic extrapolation far outside a polar-stereographic source reaches |V| > 1.8e19, where the REAL sqrt(u*u + v*v) of the reference's
+    speed / direction chain is inf and what follows NaN (rotated target): the per-point matrix of the product must say the same, point for point"""
+    import numpy as np
+    no, mo = 121, 60
+    ax = np.ascontiguousarray((np.arange(no) * 360.0 / (no - 1)).astype(np.float32)); ay = np.ascontiguousarray((-90.0 + (np.arange(mo) + 0.5) * 180.0 / mo).astype(np.float32))
+    src = (49, 47, "N", (345, 392, 26357, 1632), " ", None, None); dst = (no, mo, "Z", (380, 332, 31125, 35041), "E", ax, ay)
+    (ur, vr, rcr), (u, v, rc), _ = _ref_and_product(src, dst, "cubic", 0, "cubic")
+    assert rc == rcr
+    bad_r = ~(np.isfinite(ur) & np.isfinite(vr))
+    assert bad_r.sum() > 0, "the case no longer reaches the overflow"
+    assert np.array_equal(bad_r, ~(np.isfinite(u) & np.isfinite(v)))
+    assert np.array_equal(np.isnan(ur), np.isnan(u)) and np.array_equal(np.isnan(vr), np.isnan(v))
+    m = ~bad_r
+    sc = np.maximum(np.hypot(ur[m].astype(np.float64), vr[m].astype(np.float64)), 1e-3)
+    assert np.all(np.abs(u[m] - ur[m]) <= 2e-5 * sc) and np.all(np.abs(v[m] - vr[m]) <= 2e-5 * sc)      # extrapolated magnitudes up to 1e18: rounding of the chain, not of the interpolation

@@ -589,3 +589,26 @@ def test_ez_avg_sph_leaf(ext, ratio):
     O.orc_ez_avg_sph.restype = None
     O.orc_ez_avg_sph(fptr(zo), fptr(xx), fptr(yy), fptr(lats), nid, njd, fptr(zin), nis, njs, ext)
     assert np.array_equal(zo.view(np.uint32), zr.view(np.uint32)), (ext, ratio, int(np.count_nonzero(zo != zr)))
+
+
+@pytest.mark.parametrize("src", [(40, 20, "L", (900, 900, 450, 0), " ", None), (48, 24, "A", (0, 0, 0, 0), " ", None), (65, 32, "Z", ec.E_IG, "E", ec.ze_axes)])
+@pytest.mark.parametrize("degree", [1, 3])
+def test_ezuvint_one_grid_on_both_sides(src, degree):
+    """gdin == gdout: the two c_ezsint calls of c_ezuvint_orig copy the fields (ezsint.c, return 1), no zones are ever defined for the set, and the wind
+    chain still runs on the copies (ezuvint.c:68-86; found by tools/fuzz_vs_ref2.py: the product used to interpolate here)"""
+    L = ref(); O = ol.oracle()
+    gd = ref_define(L, src)
+    ref_setopts(L, degree, 1)
+    assert L.c_ezdefset(gd, gd) == 1
+    ni, nj = src[:2]
+    uu, vv = ec.synth_wind(ni, nj, seed=23)
+    ur = np.zeros(ni * nj, np.float32); vr = ur.copy()
+    rc_r = L.c_ezuvint(fptr(ur), fptr(vr), fptr(uu), fptr(vv))
+    g = orc_define(src); gs = O.orc_defset(g, g)
+    uo = np.zeros(ni * nj, np.float32); vo = uo.copy()
+    opts = ol.default_opts(degre_interp=degree, polar_correction=1)
+    rc_o = O.orc_ezuvint(gs, ctypes.byref(opts), fptr(uo), fptr(vo), fptr(uu), fptr(vv))
+    assert rc_o == rc_r == 0
+    assert np.array_equal(uo.view(np.uint32), ur.view(np.uint32)) and np.array_equal(vo.view(np.uint32), vr.view(np.uint32))
+    assert np.abs(ur - uu).max() < 1e-4 and np.abs(vr - vv).max() < 1e-4          # the chain's own rounding only
+    ref_setopts(L, 3, 1)

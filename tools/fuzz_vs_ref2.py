@@ -1,0 +1,171 @@
+"""Second fuzzer against the reference build (oracle/_ref/libezref.so), no oracle in between: irregular, rotated and polar-stereographic grids on either
+side -- sources Z-on-E (global and regional), Z-on-L (global and regional), N, S and the regular ones; targets L, Z-on-L, Z-on-E, G, N.  Random descriptors
+(integer ig from cxgaig of random parameters), degrees, polar correction, extrapolation modes.  c_ezsint: nearest / bilinear bit for bit, bicubic within 1e-5;
+c_ezuvint within 1e-5 |V|.      python tools/fuzz_vs_ref2.py [ncases] [seed]"""
+import ctypes, os, sys
+_R = os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "tests"))
+import numpy as np
+import reflib, ezcases as ec, oraclelib as ol
+DRY = bool(os.environ.get('FUZZ_REF_ONLY'))       # reference side only (no GPU): checks that the generator stays inside what the reference survives
+if not DRY:
+    from librmn_amd import ezscint as ez
+R = reflib.ref()
+fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+DEG = {0: "nearest", 1: "linear", 3: "cubic"}
+f32 = lambda a: np.ascontiguousarray(np.asarray(a, np.float64).astype(np.float32))
+
+
+def stretched(a0, a1, n):
+    """n strictly increasing values from a0 to a1, spacing modulated by +-15 %"""
+    w = 1.0 + 0.15 * np.sin(np.arange(n - 1) * float(rng.uniform(0.1, 0.9)) + float(rng.uniform(0, 6)))
+    x = np.concatenate([[0.0], np.cumsum(w)]); x = a0 + (a1 - a0) * x / x[-1]
+    return f32(x)
+
+
+def rot_ig():
+    lat1 = float(rng.uniform(-60, 60)); lon1 = float(rng.uniform(0, 360))
+    lat2 = float(np.clip(-0.4 * lat1 + rng.uniform(-20, 20), -80, 80)); lon2 = (lon1 + float(rng.uniform(60, 120))) % 360.0
+    return ol.cxgaig("E", lat1, lon1, lat2, lon2)
+
+
+def make_grid(kind):
+    """-> (ni, nj, grtyp, ig, grref, ax, ay) ; ax/ay None for ezqkdef grids"""
+    if kind == "ZEglob":            # GEM-like global rotated grid: last column repeats the first
+        nj = int(rng.integers(16, 70)); ni = 2 * nj + 1
+        ax = f32(np.arange(ni) * 360.0 / (ni - 1)); ay = f32(-90.0 + (np.arange(nj) + 0.5) * 180.0 / nj)
+        return ni, nj, "Z", rot_ig(), "E", ax, ay
+    if kind == "ZEreg":             # LAM in the rotated frame
+        ni = int(rng.integers(20, 120)); nj = int(rng.integers(16, 90))
+        x0 = float(rng.uniform(120, 170)); y0 = float(rng.uniform(-35, -5))
+        return ni, nj, "Z", rot_ig(), "E", stretched(x0, x0 + float(rng.uniform(25, 70)), ni), stretched(y0, y0 + float(rng.uniform(20, 60)), nj)
+    if kind == "ZLglob":            # irregular global lat-lon axes on the reference grid cxgaig('L', 0, 0, 1, 1)
+        ni = int(rng.integers(24, 140)); nj = int(rng.integers(13, 70))
+        ax = stretched(0.0, 360.0 * (ni - 1) / ni, ni); ay = stretched(-90.0, 90.0, nj) if rng.random() < 0.5 else stretched(-88.0, 88.5, nj)
+        return ni, nj, "Z", (100, 100, 9000, 0), "L", ax, ay
+    if kind == "ZLreg":
+        ni = int(rng.integers(20, 120)); nj = int(rng.integers(16, 90))
+        x0 = float(rng.uniform(10, 250)); y0 = float(rng.uniform(-70, 20))
+        return ni, nj, "Z", (100, 100, 9000, 0), "L", stretched(x0, x0 + float(rng.uniform(20, 90)), ni), stretched(y0, y0 + float(rng.uniform(15, 60)), nj)
+    if kind in ("N", "S"):
+        ni = int(rng.integers(30, 130)); nj = int(rng.integers(30, 130))
+        d60 = float(rng.uniform(60e3, 250e3)); dgrw = float(rng.uniform(0, 360))
+        pi = float(rng.uniform(0.2, 0.8)) * ni + 0.5; pj = float(rng.uniform(0.2, 0.8)) * nj + 0.5
+        return ni, nj, kind, ol.cxgaig(kind, pi, pj, d60, dgrw), " ", None, None
+    if kind == "G":
+        nj = int(rng.integers(12, 70)) * 2
+        return 2 * nj, nj, "G", (0, 0, 0, 0), " ", None, None
+    if kind == "A":
+        nj = int(rng.integers(12, 70)) * 2
+        return int(rng.integers(30, 200)), nj, "A", (0, 0, 0, 0), " ", None, None
+    if kind == "Lglob":
+        nj = int(rng.integers(12, 70)) * 2; ni = int(rng.integers(30, 200))
+        return ni, nj, "L", (int(round(18000 / nj)), int(round(36000 / ni)), int(round(9000 / nj)), 0), " ", None, None
+    if kind == "Lreg":
+        ni = int(rng.integers(20, 140)); nj = int(rng.integers(16, 100))
+        return ni, nj, "L", (int(rng.integers(20, 90)), int(rng.integers(20, 90)), int(rng.integers(2000, 11000)), int(rng.integers(0, 30000))), " ", None, None
+    raise ValueError(kind)
+
+
+def define(lib_is_ref, g):
+    ni, nj, t, ig, ref, ax, ay = g
+    if ax is None:
+        return R.c_ezqkdef(ni, nj, t.encode(), *ig, 0) if lib_is_ref else ez.ezqkdef(ni, nj, t, *ig)
+    return R.c_ezgdef_fmem(ni, nj, t.encode(), ref.encode(), *ig, fp(ax), fp(ay)) if lib_is_ref else ez.ezgdef_fmem(ni, nj, t, ref, *ig, ax, ay)
+
+
+SRC = ["ZEglob", "ZEreg", "ZLglob", "ZLreg", "N", "S", "G", "A", "Lglob", "Lreg"]
+DST = ["Lglob", "Lreg", "ZLreg", "ZLglob", "ZEreg", "ZEglob", "G", "N", "S"]
+bad = ran = near = overflow = 0
+for k in range(ncases):
+    sk = str(rng.choice(SRC)); dk = str(rng.choice(DST))
+    if os.environ.get('FUZZ_VERBOSE'): print(k, sk, dk, flush=True)
+    gs = make_grid(sk); gd = make_grid(dk)
+    ni, nj = gs[0], gs[1]; no, mo = gd[0], gd[1]
+    polar = int(rng.integers(0, 2)); degree = int(rng.choice([0, 1, 3])); extrap = str(rng.choice(["maximum", "minimum", "value", "nearest", "linear", "cubic"]))
+    if extrap == "cubic" and degree != 3: extrap = "value"
+    zin = ec.synth_field(ni, nj, seed=int(rng.integers(1 << 30)))
+    uu, vv = ec.synth_wind(ni, nj, seed=int(rng.integers(1 << 30)))
+    if sk == "ZEglob":
+        for a in (zin, uu, vv):
+            z2 = a.reshape(nj, ni); z2[:, -1] = z2[:, 0]
+    gr_in = define(True, gs); gr_out = define(True, gd)
+    if gr_in < 0 or gr_out < 0: continue
+    for name, val in (("interp_degree", DEG[degree]), ("polar_correction", "yes" if polar else "no"), ("extrap_degree", extrap)):
+        R.c_ezsetopt(name.encode(), val.encode())
+    R.c_ezsetval(b"extrap_value", ctypes.c_float(-3.5))
+    if R.c_ezdefset(gr_out, gr_in) != 1: continue
+    zr = np.zeros(no * mo, np.float32); ur = zr.copy(); vr = zr.copy()
+    rc_r = R.c_ezsint(fp(zr), fp(zin))
+    rcv_r = R.c_ezuvint(fp(ur), fp(vr), fp(uu), fp(vv))
+    if DRY:
+        ran += 1
+        if not (np.all(np.isfinite(zr)) and np.all(np.isfinite(ur)) and np.all(np.isfinite(vr))): print('reference: non-finite output', sk, dk, degree, polar, extrap, flush=True)
+        continue
+    gdin = define(False, gs); gdout = define(False, gd)
+    desc = dict(src=(sk,) + gs[:5], dst=(dk,) + gd[:5], degree=degree, polar=polar, extrap=extrap)
+    if gdin < 0 or gdout < 0: print("product refuses", desc, flush=True); bad += 1; continue
+    ez.ezdefset(gdout, gdin)
+    ez.ezsetopt("interp_degree", DEG[degree]); ez.ezsetopt("polar_correction", "yes" if polar else "no"); ez.ezsetopt("extrap_degree", extrap); ez.ezsetval("extrap_value", -3.5)
+    rc, z = ez.ezsint(zin, no * mo)
+    ran += 1
+    why = ""
+    # far outside a polar-stereographic source the reference's cubic extrapolation overflows: the same +-inf / NaN must come out at the same points
+    def same_nonfinite(a, b):
+        fa, fb = np.isfinite(a), np.isfinite(b)
+        canon = lambda x: np.where(np.isnan(x), np.float32(0), x)          # every NaN is the same NaN; infinities keep their sign
+        return np.array_equal(fa, fb) and np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(canon(a[~fa]), canon(b[~fb]))
+    if rc != rc_r: why = f"rc {rc} vs {rc_r}"
+    elif not same_nonfinite(z, zr): why = "non-finite scalar values differ"
+    elif degree == 3:
+        m = np.isfinite(zr)
+        e = np.abs(z[m] - zr[m]) / np.maximum(np.abs(zr[m]), 1e-30)
+        if e.size and not np.all(e <= 1e-5): why = f"scalar max rel err {e.max():.3e} at {int(np.flatnonzero(m)[e.argmax()])}"
+    elif not np.array_equal(z.view(np.uint32), zr.view(np.uint32)):
+        d = np.flatnonzero(z.view(np.uint32) != zr.view(np.uint32)); why = f"scalar bits differ at {d.size} points, first {int(d[0])}: {z[d[0]]!r} vs {zr[d[0]]!r}"
+    if not why:
+        rcv, u, v = ez.ezuvint(uu, vv, no * mo)
+        m = np.isfinite(ur) & np.isfinite(vr)
+        mp = np.isfinite(u) & np.isfinite(v)
+        sc = np.maximum(np.hypot(ur[m & mp].astype(np.float64), vr[m & mp].astype(np.float64)), 1e-3)
+        e = np.maximum(np.abs(u[m & mp] - ur[m & mp]), np.abs(v[m & mp] - vr[m & mp])) / sc
+        idx = np.flatnonzero(m & mp)
+        # conditioning: where a frame's pole is close, the wind direction turns by the point's longitude in that frame, and one ulp of a REAL sine / cosine
+        # (6e-8) moves that longitude by 6e-8 / cos(latitude): the reference's own answer moves by as much from one libm to the next.  Latitudes involved:
+        # the true one of the target point and its latitude in the rotated frames of the source and of the target.
+        lat_t = np.zeros(no * mo, np.float32); lon_t = lat_t.copy(); R.c_gdll(gr_out, fp(lat_t), fp(lon_t))
+        worst = np.abs(lat_t.astype(np.float64))
+        if gd[4] == "E": worst = np.maximum(worst, np.abs(np.repeat(gd[6].astype(np.float64), no)))
+        if gs[4] == "E":
+            xs = np.zeros(no * mo, np.float32); ys = xs.copy(); R.c_gdxyfll(gr_in, fp(xs), fp(ys), fp(lat_t), fp(lon_t), no * mo)
+            worst = np.maximum(worst, np.abs(np.interp(ys.astype(np.float64), np.arange(1, nj + 1), gs[6].astype(np.float64), left=90.0, right=90.0)))
+        allowed = 1e-5 + 8 * 6e-8 / np.maximum(np.cos(np.radians(np.minimum(worst[idx], 89.9999))), 1e-7)
+        if rcv != rcv_r: why = f"wind rc {rcv} vs {rcv_r}"
+        elif not np.array_equal(m, mp) and np.all(mp | ~m):
+            # the reference's speed / direction chain overflows REAL where |V|^2 > 3.4e38 (raw cubic extrapolation far outside a source): inf / NaN there.  The
+            # product's per-point matrix has no square in it and returns the finite rotated vector; with EZHIP_WIND_NO_MATRIX=1 it runs the chain as written.
+            os.environ["EZHIP_WIND_NO_MATRIX"] = "1"
+            rcv2, u2, v2 = ez.ezuvint(uu, vv, no * mo)
+            del os.environ["EZHIP_WIND_NO_MATRIX"]
+            m2 = np.isfinite(u2) & np.isfinite(v2)
+            if np.array_equal(m2, m): overflow += 1
+            else: why = f"winds: chain as written: finite in one, not in the other at {int((m != m2).sum())} points"
+        elif not np.array_equal(m, mp): why = f"winds: finite in one, not in the other at {int((m != mp).sum())} points, first {int(np.flatnonzero(m != mp)[0])}: ({u[np.flatnonzero(m != mp)[0]]!r}, {v[np.flatnonzero(m != mp)[0]]!r}) vs ({ur[np.flatnonzero(m != mp)[0]]!r}, {vr[np.flatnonzero(m != mp)[0]]!r})"
+        elif not (same_nonfinite(u, ur) and same_nonfinite(v, vr)):
+            q = np.flatnonzero(~m)
+            q = q[[not (same_nonfinite(u[i:i + 1], ur[i:i + 1]) and same_nonfinite(v[i:i + 1], vr[i:i + 1])) for i in q]]
+            zu = np.zeros(no * mo, np.float32); zv = zu.copy(); R.c_ezsint(fp(zu), fp(uu)); R.c_ezsint(fp(zv), fp(vv))
+            why = f"winds: non-finite values of different kinds at {q.size} points, first {int(q[0])}: ({u[q[0]]!r}, {v[q[0]]!r}) vs ({ur[q[0]]!r}, {vr[q[0]]!r}), interpolated components there ({zu[q[0]]!r}, {zv[q[0]]!r})"
+        elif e.size and not np.all(e <= allowed):
+            w = int(np.argmax(e / allowed)); why = f"wind err {e[w]:.3e} |V| (allowed {allowed[w]:.2e}, |lat| {worst[idx[w]]:.3f}) at {int(idx[w])}: ({u[idx[w]]!r}, {v[idx[w]]!r}) vs ({ur[idx[w]]!r}, {vr[idx[w]]!r})"
+        elif e.size and not np.all(e <= 1e-5): near += 1
+    if why:
+        bad += 1
+        print("MISMATCH", why, desc, flush=True)
+for name, val in (("interp_degree", "cubic"), ("polar_correction", "yes"), ("extrap_degree", "maximum")):
+    R.c_ezsetopt(name.encode(), val.encode())
+print(f"product vs reference build (irregular / rotated / polar-stereographic grids): {ran} of {ncases} cases ran, {bad} mismatches "
+      f"({near} cases with wind errors between 1e-5 |V| and the conditioning bound 1e-5 + 4.8e-7 / cos(lat) next to a pole of one of the frames; "
+      f"{overflow} cases where the reference's speed / direction chain overflows REAL and the literal chain of the product, EZHIP_WIND_NO_MATRIX=1, does the same)")
+sys.exit(1 if bad else 0)
