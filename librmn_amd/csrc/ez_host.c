@@ -1827,7 +1827,7 @@ static int run_field(ezh_set *s, float *d_zout, const float *d_zin, int vector_m
  * cell, then the parts of the polar correction that are defined for it: the points outside a regional source (fill value or re-interpolation
  * with extrap_degree) and the pole values.  The strip routines have no case for this degree (ez_corrval_aunord.c:52-110) and scatter an
  * uninitialised array over their zones: a set that has strip points which are not pole points is refused (set polar_correction = no). */
-static int gdllfxy_one(const ezh_grid *g, float *lat, float *lon, const float *x, const float *y, int n);
+static int gdllfxy_one(const ezh_grid *g, float *lat, float *lon, const float *x, const float *y, int n, int newform);
 static int run_average(ezh_set *s, float *d_zout, const float *d_zin, int sph)
 {
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
@@ -1875,7 +1875,7 @@ static int run_average(ezh_set *s, float *d_zout, const float *d_zin, int sph)
             const float degre_a_radian = 0.017453295199f;
             for (int j = 0; j < njd && !brc; j++) {
                 float la = 0.0f, lo = 0.0f, xo = 1.0f, yo = 1.0f * (float)(j + 1);
-                if (gdllfxy_one(go, &la, &lo, &xo, &yo, 1) < 0) brc = -1;
+                if (gdllfxy_one(go, &la, &lo, &xo, &yo, 1, 0) < 0) brc = -1;
                 amp[j] = 1.0f / cosf(la * degre_a_radian);
             }
         }
@@ -2722,7 +2722,9 @@ static void h_vllfxy(float *dlat, float *dlon, const float *x, const float *y, i
     }
 }
 /* c_gdllfxy_new (gdllfxy.c:92-260), host only: grid coordinates -> lat, lon */
-static int gdllfxy_one(const ezh_grid *g, float *lat, float *lon, const float *x, const float *y, int n)
+/* newform: c_gdllfxy_new (gdllfxy.c:103-250, what the public c_gdllfxy calls): rows of a 'G' / 'Z' / '#' grid whose ig2 is 1 count from the north
+ * (:190-195); 0: c_gdllfxy_orig (:252-), the form the library calls internally */
+static int gdllfxy_one(const ezh_grid *g, float *lat, float *lon, const float *x, const float *y, int n, int newform)
 {
     switch (g->grtyp) {
     case 'A': case 'B': case 'L':
@@ -2749,13 +2751,14 @@ static int gdllfxy_one(const ezh_grid *g, float *lat, float *lon, const float *x
     case 'Z': case 'G': {
         float *tx = (float *)malloc(sizeof(float) * (size_t)(n + 1)), *ty = (float *)malloc(sizeof(float) * (size_t)(n + 1));
         for (int i = 0; i < n; i++) {
-            int indx = (int)x[i] - 1, indy = (int)y[i] - 1;
+            const float yy = (newform && g->ig[1] == 1) ? (float)((double)g->nj + 1.0 - (double)y[i]) : y[i];
+            int indx = (int)x[i] - 1, indy = (int)yy - 1;
             indx = indx < 0 ? 0 : indx; indy = indy < 0 ? 0 : indy;
             indx = indx > g->ni - 2 ? g->ni - 2 : indx; indy = indy > g->j2 - 2 ? g->j2 - 2 : indy;
             float delxx = g->ax[indx + 1] - g->ax[indx];
             tx[i] = (float)((double)g->ax[indx] + (((double)x[i] - 1.0 - indx) * (double)delxx));
             float delyy = g->ay[indy + 1] - g->ay[indy];
-            ty[i] = (float)((double)g->ay[indy] + (((double)y[i] - 1.0 - indy) * (double)delyy));
+            ty[i] = (float)((double)g->ay[indy] + (((double)yy - 1.0 - indy) * (double)delyy));
         }
         if (g->grref == 'E') h_rotate(lon, lat, tx, ty, n, g->xgref, 0);
         else for (int i = 0; i < n; i++) {
@@ -2774,7 +2777,7 @@ int32_t c_gdllfxy(int32_t gdid, float *lat, float *lon, float *x, float *y, int3
     if (!grid_ok(gdid)) return -1;
     ezh_grid *g = &G[gdid];
     if (g->nsub > 0) { fprintf(stderr, "<gdllfxy> 'U' grids are outside the MI355X hot-path scope here\n"); return -1; }
-    return gdllfxy_one(g, lat, lon, x, y, n);
+    return gdllfxy_one(g, lat, lon, x, y, n, 1);
 }
 /* c_gdxywdval (gdxywdval.c:38-110) / c_gdllwdval (gdllwdval.c:36-100): interpolated winds at points as speed / direction */
 int32_t c_gdxywdval(int32_t gdin, float *uuout, float *vvout, float *uuin, float *vvin, float *x, float *y, int32_t n)

@@ -267,3 +267,10 @@ def test_hemispheric_and_inverted_gaussian_grids_locate_like_the_reference(ig):
         getattr(R, name)(gr, fp(xr), fp(yr), fp(lat), fp(lon.copy()), 500)
         getattr(L, name)(gp, fp(xp), fp(yp), fp(lat), fp(lon.copy()), 500)
         assert np.array_equal(xr, xp) and np.array_equal(yr, yp), (ig, name)
+    # the way back: the public c_gdllfxy is c_gdllfxy_new (gdllfxy.c:103-250), which counts the rows of a grid with ig2 == 1 from the north
+    # (:190-195); found by tools/fuzz_vs_ref3.py, the product used the internal form (c_gdllfxy_orig) for both
+    x = rng.uniform(0.6, ni + 0.4, 500).astype(np.float32); y = rng.uniform(0.6, nj + 0.4, 500).astype(np.float32)
+    x[:50] = np.round(x[:50]).clip(1, ni); y[:50] = np.round(y[:50]).clip(1, nj)
+    la_r = np.zeros(500, np.float32); lo_r = la_r.copy(); la_p = la_r.copy(); lo_p = la_r.copy()
+    R.c_gdllfxy(gr, fp(la_r), fp(lo_r), fp(x), fp(y), 500); L.c_gdllfxy(gp, fp(la_p), fp(lo_p), fp(x), fp(y), 500)
+    assert np.array_equal(la_r, la_p) and np.array_equal(lo_r, lo_p), ig
