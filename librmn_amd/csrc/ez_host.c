@@ -3036,11 +3036,15 @@ static int yy_plan_locked(ezh_set *s)
     {   /* the mask: a point outside the Yin core grid (zone DEHORS of the nearest-neighbour interpolation with extrapolation
          * value 1 that ezyymint.c:44-66 runs) is served by Yang */
         const ezh_grid *mg = &G[gu->maskgrid[0]];
+        /* that interpolation is a c_ezsint_orig, and c_ezsint_orig extrapolates (ez_corrval) only with polar_correction = yes (ezsint.c): with the
+         * option off when the set is first used the mask stays 0 everywhere -- every point is served by Yin, far outside it -- and the set keeps
+         * that mask (yyflags, ezyy_calcxy.c:40-42).  Reproduced: a drop-in may not know better than the reference here. */
+        const int extrapolates = O.polar_correction == 1;
         memcpy(tl, lon, sizeof(float) * (size_t)n);
         if (h_locate_mt(mg, x, y, lat, tl, n)) goto done;
         for (int k = 0; k < n; k++) {
             int ix = (int)((double)x[k] + 0.5), iy = (int)((double)y[k] + 0.5);
-            yang[k] = (ix < 1 || iy < 1 || ix > mg->ni || iy > mg->nj);
+            yang[k] = extrapolates && (ix < 1 || iy < 1 || ix > mg->ni || iy > mg->nj);
         }
     }
     for (int sub = 0; sub < 2; sub++) {

@@ -3,7 +3,8 @@ on random grid pairs -- no oracle in between.  tools/fuzz_vs_ref.py: c_ezsint ne
 within 1e-5 |V|, global / hemispheric / regional sources, every extrapolation mode; tools/fuzz_average.py: the averaging degrees bit for bit; tools/fuzz_vs_ref2.py: irregular (Z-on-L), rotated (Z-on-E, global and regional) and
 polar-stereographic grids on either side, Gaussian and Z targets -- it found the two cases tested by name below; tools/fuzz_vs_ref3.py: c_gdll,
 c_gdxyfll, c_gdllfxy, c_gdxysint, c_gdllsval, c_gdllvval, c_gdwdfuv, c_gduvfwd on random grids of every kind (it found the public c_gdllfxy's row
-inversion, tests/test_host_cpu.py)."""
+inversion, tests/test_host_cpu.py); tools/fuzz_vs_ref4.py: the mask entry points, c_ezwdint and Yin-Yang grids as source and as target (the
+reference's Yin-Yang answers from a process per case: in a long session it corrupts its own heap there)."""
 import os, subprocess, sys
 import pytest
 import reflib
@@ -14,7 +15,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
 @pytest.mark.skipif(not reflib.have_ref(), reason="oracle/_ref/libezref.so not built")
 @pytest.mark.parametrize("tool,ncases,seed", [("fuzz_vs_ref.py", 400, 1), ("fuzz_vs_ref.py", 400, 2), ("fuzz_average.py", 200, 1),
-                                              ("fuzz_vs_ref2.py", 600, 1), ("fuzz_vs_ref2.py", 600, 7), ("fuzz_vs_ref3.py", 300, 1), ("fuzz_vs_ref3.py", 300, 5)])
+                                              ("fuzz_vs_ref2.py", 600, 1), ("fuzz_vs_ref2.py", 600, 7), ("fuzz_vs_ref3.py", 300, 1), ("fuzz_vs_ref3.py", 300, 5), ("fuzz_vs_ref4.py", 250, 1)])
 def test_random_grid_pairs_against_the_reference_build(tool, ncases, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(ncases), str(seed)], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

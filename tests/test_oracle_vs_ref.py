@@ -612,3 +612,32 @@ def test_ezuvint_one_grid_on_both_sides(src, degree):
     assert np.array_equal(uo.view(np.uint32), ur.view(np.uint32)) and np.array_equal(vo.view(np.uint32), vr.view(np.uint32))
     assert np.abs(ur - uu).max() < 1e-4 and np.abs(vr - vv).max() < 1e-4          # the chain's own rounding only
     ref_setopts(L, 3, 1)
+
+
+def test_yinyang_source_first_used_without_polar_correction():
+    """c_ezyymint builds the Yin / Yang mask with a c_ezsint_orig (nearest, extrapolation value 1: ezyymint.c:44-66), and c_ezsint_orig extrapolates only
+    with polar_correction = yes: a set first used with the option off keeps a mask that is 0 everywhere -- every point from Yin, far outside it
+    (found by tools/fuzz_vs_ref4.py).  The oracle does what the reference does."""
+    L = ref(); O = ol.oracle()
+    ni, nj = 61, 25                                             # a grid of its own: the reference caches the mask with the set
+    ax = (36.0 + 4.8 * np.arange(ni, dtype=np.float64)).astype(np.float32); ay = (-57.6 + 4.8 * np.arange(nj, dtype=np.float64)).astype(np.float32)
+    gy = L.c_ezgdef_fmem(ni, nj, b"Z", b"E", *ec.YIN_IG, fptr(ax), fptr(ay)); ga = L.c_ezgdef_fmem(ni, nj, b"Z", b"E", *ec.YAN_IG, fptr(ax), fptr(ay))
+    gu = L.c_ezgdef_supergrid(ni, 2 * nj, b"U", b"F", 1, 2, iptr(np.array([gy, ga], np.int32)))
+    no, mo, gt, ig = 53, 29, "L", (600, 650, 300, 0)
+    go = L.c_ezqkdef(no, mo, gt.encode(), *ig, 0)
+    assert gu >= 0 and go >= 0 and L.c_ezdefset(go, gu) == 1
+    sg = O.orc_supergrid_define(ol.grid_define(ni, nj, "Z", ec.YIN_IG, "E", ax, ay), ol.grid_define(ni, nj, "Z", ec.YAN_IG, "E", ax, ay))
+    ogo = ol.grid_define(no, mo, gt, ig)
+    z = np.concatenate([ec.synth_field(ni, nj, seed=31), ec.synth_field(ni, nj, seed=32)])
+    ref_setopts(L, 1, 0)
+    want = np.zeros(no * mo, np.float32); got = want.copy()
+    assert L.c_ezsint(fptr(want), fptr(z)) == 0
+    opts = ol.default_opts(degre_interp=1, polar_correction=0)
+    assert O.orc_ezyysint(sg, ogo, ctypes.byref(opts), fptr(got), fptr(z)) == 0
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # and that is not what the same pair gives when its mask is built with the option on (a second supergrid object: the oracle plans per object)
+    sg2 = O.orc_supergrid_define(ol.grid_define(ni, nj, "Z", ec.YIN_IG, "E", ax, ay), ol.grid_define(ni, nj, "Z", ec.YAN_IG, "E", ax, ay))
+    on = np.zeros(no * mo, np.float32); opts1 = ol.default_opts(degre_interp=1, polar_correction=1)
+    assert O.orc_ezyysint(sg2, ogo, ctypes.byref(opts1), fptr(on), fptr(z)) == 0
+    assert np.count_nonzero(on != want) > no * mo // 5
+    ref_setopts(L, 3, 1)

@@ -8,6 +8,7 @@ _R = os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."); sys.path.in
 import numpy as np
 import reflib, ezcases as ec, oraclelib as ol
 DRY = bool(os.environ.get('FUZZ_REF_ONLY'))
+STRICT = not os.environ.get('FUZZ_LOOSE_ROTATED')      # coordinates through a rotated frame bit for bit too (the product computes them with the host libm)
 if not DRY:
     from librmn_amd import ezscint as ez
 R = reflib.ref()
@@ -110,7 +111,7 @@ for k in range(ncases):
     lat_r = np.zeros(n, np.float32); lon_r = lat_r.copy(); R.c_gdll(gr, fp(lat_r), fp(lon_r))
     if not DRY:
         rc, lat_p, lon_p = ez.gdll(gp, n)
-        if rotated:
+        if rotated and not STRICT:
             dl = np.abs(lat_p - lat_r); do = np.abs(((lon_p - lon_r + 180.0) % 360.0) - 180.0) * np.cos(np.radians(lat_r.astype(np.float64)))
             if dl.max() > 2e-5 or do.max() > 4e-5: report("gdll", desc, f"max |dlat| {dl.max():.2e} deg, max |dlon| cos(lat) {do.max():.2e} deg")
             elif not (bits_equal(lat_p, lat_r) and bits_equal(lon_p, lon_r)): notes["gdll through a rotation: last-bit differences"] = notes.get("gdll through a rotation: last-bit differences", 0) + 1
@@ -126,7 +127,7 @@ for k in range(ncases):
     if not DRY:
         rc, xp, yp = ez.gdxyfll(gp, plat, plon)
         fin = np.isfinite(xr) & np.isfinite(yr)
-        if rotated or g[2] in ("N", "S"):
+        if (rotated and not STRICT):
             tol = 2e-4 if rotated else 0.0
             # near a pole of the rotated frame x is ill-conditioned (longitude): compare x scaled by cos of the rotated latitude, approximated from y
             ok = np.array_equal(fin, np.isfinite(xp) & np.isfinite(yp))
@@ -147,7 +148,7 @@ for k in range(ncases):
     la_r = np.zeros(m, np.float32); lo_r = la_r.copy(); R.c_gdllfxy(gr, fp(la_r), fp(lo_r), fp(px), fp(py), m)
     if not DRY:
         rc, la_p, lo_p = ez.gdllfxy(gp, px, py)
-        if rotated:
+        if rotated and not STRICT:
             dl = np.abs(la_p - la_r); do = np.abs(((lo_p - lo_r + 180.0) % 360.0) - 180.0) * np.cos(np.radians(la_r.astype(np.float64)))
             if dl.max() > 2e-5 or do.max() > 4e-5: report("gdllfxy", desc, f"max |dlat| {dl.max():.2e}, max |dlon| cos(lat) {do.max():.2e}")
         elif not (bits_equal(la_p, la_r) and bits_equal(lo_p, lo_r)):
