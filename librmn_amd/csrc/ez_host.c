@@ -1914,7 +1914,21 @@ static int run_average(ezh_set *s, float *d_zout, const float *d_zin, int sph)
 }
 
 /* d_poles_pre: device float[2] pole values of this field already computed (batch entry point), or NULL */
+/* ez_corrval.c:146-148: a Z- or #-on-E source and a 'B' target end the SCALAR polar correction with ez_corrbgd (the target's pole rows -> their mean);
+ * in vector mode ez_corrval returns before it (:117-118), so the components of a wind never see it */
+static int corrbgd_applies(const ezh_grid *gi, const ezh_grid *go)
+{
+    return O.polar_correction == 1 && (gi->grtyp == 'Z' || gi->grtyp == '#') && gi->grref == 'E' && go->grtyp == 'B';
+}
+static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector_mode, const float *prow_n, const float *prow_s, const float *d_poles_pre);
 static int run_field_p(ezh_set *s, float *d_zout, const float *d_zin, int vector_mode, const float *prow_n, const float *prow_s, const float *d_poles_pre)
+{
+    int rc = run_field_q(s, d_zout, d_zin, vector_mode, prow_n, prow_s, d_poles_pre);
+    const ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
+    if (rc >= 0 && !vector_mode && corrbgd_applies(gi, go) && ezhip_corrbgd(d_zout, go->ni, go->nj, go->ig[0])) return -1;
+    return rc;
+}
+static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector_mode, const float *prow_n, const float *prow_s, const float *d_poles_pre)
 {
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     int degree = O.degre_interp, polar = O.polar_correction == 1;
@@ -2604,7 +2618,8 @@ static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, c
     if (same) {
         const size_t nb = sizeof(float) * (size_t)ni * nj;
         if ((d_uuout != d_uuin && ezhip_d2d(d_uuout, d_uuin, nb)) || (d_vvout != d_vvin && ezhip_d2d(d_vvout, d_vvin, nb))) return -1;
-    } else r1 = r2 = run_pair_pts(s, d_uuout, d_vvout, d_uuin, d_vvin, pun, pus, pvn, pvs, getenv("EZHIP_WIND_NO_FUSE") ? NULL : d_M, wp.dst_rotated);
+    }
+    if (!same) r1 = r2 = run_pair_pts(s, d_uuout, d_vvout, d_uuin, d_vvin, pun, pus, pvn, pvs, getenv("EZHIP_WIND_NO_FUSE") ? NULL : d_M, wp.dst_rotated);
     if (r1 == -1) return -1;
     const int fused = !same && r1 != -2 && d_M && !getenv("EZHIP_WIND_NO_FUSE");
     if (r1 == -2) {                                          /* separable set: one launch per component */

@@ -1039,6 +1039,24 @@ __global__ __launch_bounds__(256) void k_polar_wind(float *out, const float *uu,
         pu[i] = spd; pv[i] = wd;
     }
 }
+/* ez_corrbgd.inc:20-55 (called at the end of ez_corrval for a Z- or #-on-E source and a 'B' target, ez_corrval.c:146-148): the rows of the
+ * target at the poles become their mean -- a sequential REAL sum over the row divided by ni * 1.0 (block_poleval, unweighted).
+ * blockIdx.x: 0 = row 1, 1 = row nj; rows: bit 0 = do row 1, bit 1 = do row nj */
+__global__ __launch_bounds__(256) void k_corrbgd(float *zout, int ni, int nj, int rows)
+{
+    __shared__ __attribute__((aligned(16))) float lds[POLE_CHUNK + 4];
+    if (!((rows >> blockIdx.x) & 1)) return;
+    float *row = zout + (blockIdx.x ? (size_t)(nj - 1) * ni : 0);
+    const float m = block_poleval(row, ni, 0, nullptr, lds, POLE_CHUNK);
+    for (int i = threadIdx.x; i < ni; i += 256) row[i] = m;
+}
+extern "C" int ezhip_corrbgd(float *d_zout, int ni, int nj, int hem)
+{
+    const int rows = ((hem == 0 || hem == 2) ? 1 : 0) | ((hem == 0 || hem == 1) ? 2 : 0);
+    if (!rows) return 0;
+    hipLaunchKernelGGL(k_corrbgd, dim3(2), dim3(256), 0, g_stream, d_zout, ni, nj, rows);
+    return LAUNCH_CHECK("k_corrbgd");
+}
 extern "C" int ezhip_polar_wind(float *d_out4, const float *d_uu, const float *d_vv, const float *d_plon2, int ni, int nj,
                                 float xg4_n, float xg4_s, int weighted, const float *d_ax)
 {

@@ -230,6 +230,7 @@ int ezhip_polar_wind(float *d_out4, const float *d_uu, const float *d_vv, const 
 /* in place on (uu, vv): source-grid components -> target ('L'-like) grid components */
 /* the chain of a grid pair as a 2 x 2 matrix per point (16 bytes each): built once, applied per call */
 int ezhip_wind_matrix(const ezhip_wind_plan *plan, void *d_M, const float *d_lat, const float *d_lon, int ni_dst, int nj_dst);
+int ezhip_corrbgd(float *d_zout, int ni, int nj, int hem);
 int ezhip_wind_apply(const void *d_M, float *d_uu, float *d_vv, size_t npts, int dst_rotated);
 /* interp_degree = average / sph_average (ez_avg.inc, ez_avg_sph.inc): bounds = [x ni_dst | row widening nj_dst | y_low nj_dst | y_high nj_dst] on the device */
 int ezhip_average(float *d_zout, const float *d_zin, const float *d_bounds, int ni_dst, int nj_dst, int ni_src, int nj_src, int extension, float ylast);

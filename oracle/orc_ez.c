@@ -1232,7 +1232,20 @@ static int corrval(orc_gridset *gs, const orc_opts *o, float *zout, const float 
         float vpolsud = calcpoleval(zin, g->ni, g->ax, g->grtyp, g->grref);
         for (int i = 0; i < ps->npts; i++) zout[ps->idx[i]] = vpolsud;
     }
-    /* ez_corrbgd (Z-on-E source -> 'B' target) :146-148 : 'B' targets are not in the configs */
+    /* ez_corrval.c:146-148 -> ez_corrbgd.inc:20-55: Z- or #-on-E source, 'B' target: the rows at the poles (row 1 unless the target is the northern
+     * hemisphere, row nj unless it is the southern one: hem = the target's ig1) are replaced by their mean, a sequential REAL sum divided by ni * 1.0 */
+    if ((g->grtyp == 'Z' || g->grtyp == '#') && g->grref == 'E' && gs->gdout->grtyp == 'B') {
+        const orc_grid *t = gs->gdout;
+        const int hem = t->ig[0];
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 0 ? !(hem == 0 || hem == 2) : !(hem == 0 || hem == 1)) continue;
+            float *row = zout + (pass == 0 ? 0 : (size_t)(t->nj - 1) * t->ni);
+            float somme = 0.0f;
+            for (int i = 0; i < t->ni; i++) somme = somme + row[i];
+            const float moyenne = somme / ((float)t->ni * 1.0f);
+            for (int i = 0; i < t->ni; i++) row[i] = moyenne;
+        }
+    }
     return ierc;
 }
 

@@ -15,9 +15,11 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
 @pytest.mark.skipif(not reflib.have_ref(), reason="oracle/_ref/libezref.so not built")
 @pytest.mark.parametrize("tool,ncases,seed", [("fuzz_vs_ref.py", 400, 1), ("fuzz_vs_ref.py", 400, 2), ("fuzz_average.py", 200, 1),
-                                              ("fuzz_vs_ref2.py", 600, 1), ("fuzz_vs_ref2.py", 600, 7), ("fuzz_vs_ref3.py", 300, 1), ("fuzz_vs_ref3.py", 300, 5), ("fuzz_vs_ref4.py", 250, 1)])
+                                              ("fuzz_vs_ref2.py", 600, 1), ("fuzz_vs_ref2.py", 600, 7), ("fuzz_vs_ref3.py", 300, 1), ("fuzz_vs_ref3.py", 300, 5), ("fuzz_vs_ref4.py", 250, 1), ("fuzz_vs_ref2.py hemi", 600, 3)])
 def test_random_grid_pairs_against_the_reference_build(tool, ncases, seed):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(ncases), str(seed)], capture_output=True, text=True, cwd=ROOT)
+    env = dict(os.environ)
+    if tool.endswith(" hemi"): tool = tool.split()[0]; env["FUZZ_HEMI"] = "1"          # + hemispheric / y-inverted A B G on either side
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(ncases), str(seed)], capture_output=True, text=True, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
 
@@ -81,3 +83,33 @@ def test_wind_chain_overflow_of_the_speed():
     m = ~bad_r
     sc = np.maximum(np.hypot(ur[m].astype(np.float64), vr[m].astype(np.float64)), 1e-3)
     assert np.all(np.abs(u[m] - ur[m]) <= 2e-5 * sc) and np.all(np.abs(v[m] - vr[m]) <= 2e-5 * sc)      # extrapolated magnitudes up to 1e18: rounding of the chain, not of the interpolation
+
+
+@pytest.mark.skipif(not reflib.have_ref(), reason="oracle/_ref/libezref.so not built")
+@pytest.mark.parametrize("ig", [(0, 0, 0, 0), (0, 1, 0, 0), (1, 0, 0, 0), (2, 1, 0, 0)])
+@pytest.mark.parametrize("degree", ["nearest", "linear", "cubic"])
+def test_rotated_source_to_B_target_pole_rows(ig, degree):
+    """ez_corrbgd (ez_corrval.c:146-148): the pole rows of a 'B' target behind a Z-on-E source are their sequential REAL mean -- k_corrbgd"""
+    import ctypes
+    import numpy as np
+    import ezcases as ec
+    from librmn_amd import ezscint as ez
+    R = reflib.ref()
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    ni, nj = 65, 32; ax, ay = ec.ze_axes(ni, nj)
+    no, mo = 113, (57 if ig[0] == 0 else 29)
+    src = (ni, nj, "Z", ec.E_IG, "E", ax, ay); dst = (no, mo, "B", ig, " ", None, None)
+    (ur, vr, rcr), (u, v, rc), _ = _ref_and_product(src, dst, degree, 1)
+    assert rc == rcr
+    sc = np.maximum(np.hypot(ur, vr), 1e-3)
+    assert np.all(np.abs(u - ur) <= 1e-5 * sc) and np.all(np.abs(v - vr) <= 1e-5 * sc)
+    zin = ec.synth_field(ni, nj, seed=5); z2 = zin.reshape(nj, ni); z2[:, -1] = z2[:, 0]
+    gi = R.c_ezgdef_fmem(ni, nj, b"Z", b"E", *ec.E_IG, fp(ax), fp(ay)); go = R.c_ezqkdef(no, mo, b"B", *ig, 0)
+    a = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay); b = ez.ezqkdef(no, mo, "B", *ig)
+    R.c_ezsetopt(b"interp_degree", degree.encode()); ez.ezsetopt("interp_degree", degree)
+    assert R.c_ezdefset(go, gi) == 1 and ez.ezdefset(b, a) == 1
+    zr = np.zeros(no * mo, np.float32); rcr = R.c_ezsint(fp(zr), fp(zin)); rc, z = ez.ezsint(zin, no * mo)
+    R.c_ezsetopt(b"interp_degree", b"cubic"); ez.ezsetopt("interp_degree", "cubic")
+    assert rc == rcr
+    if degree == "cubic": assert np.all(np.abs(z - zr) <= 1e-5 * np.abs(zr))
+    else: assert np.array_equal(z.view(np.uint32), zr.view(np.uint32))

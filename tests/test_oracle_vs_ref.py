@@ -641,3 +641,31 @@ def test_yinyang_source_first_used_without_polar_correction():
     assert O.orc_ezyysint(sg2, ogo, ctypes.byref(opts1), fptr(on), fptr(z)) == 0
     assert np.count_nonzero(on != want) > no * mo // 5
     ref_setopts(L, 3, 1)
+
+
+@pytest.mark.parametrize("dst", [(49, 25, "B", (0, 0, 0, 0), " ", None), (49, 25, "B", (0, 1, 0, 0), " ", None), (49, 13, "B", (1, 0, 0, 0), " ", None), (49, 13, "B", (2, 0, 0, 0), " ", None),
+                                 (49, 13, "B", (1, 1, 0, 0), " ", None), (49, 13, "B", (2, 1, 0, 0), " ", None)])
+@pytest.mark.parametrize("src", [(65, 32, "Z", ec.E_IG, "E", ec.ze_axes), (51, 41, "Z", ec.E_IG, "E", ec.zereg_axes)])
+def test_rotated_source_to_B_target_ends_with_corrbgd(src, dst):
+    """ez_corrval.c:146-148 -> ez_corrbgd.inc: behind a Z-on-E source the pole rows of a 'B' target become their (sequential REAL) mean, per hemisphere
+    flag -- scalars only: in vector mode ez_corrval returns before it (:117-118) -- found by tools/fuzz_vs_ref2.py (FUZZ_HEMI=1); neither the oracle nor the product had it"""
+    L = ref(); O = ol.oracle()
+    gdin = ref_define(L, src); gdout = ref_define(L, dst)
+    assert L.c_ezdefset(gdout, gdin) == 1
+    gi = orc_define(src); go = orc_define(dst); gs = O.orc_defset(go, gi)
+    ni, nj = src[:2]; no, mo = dst[:2]
+    zin = ec.synth_field(ni, nj, seed=5); uu, vv = ec.synth_wind(ni, nj, seed=6)
+    for a in (zin, uu, vv):
+        a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+    for degree in (0, 1, 3):
+        for polar in (1, 0):
+            ref_setopts(L, degree, polar)
+            opts = ol.default_opts(degre_interp=degree, polar_correction=polar)
+            zr = np.zeros(no * mo, np.float32); zo = zr.copy(); ur = zr.copy(); vr = zr.copy(); uo = zr.copy(); vo = zr.copy()
+            assert L.c_ezsint(fptr(zr), fptr(zin)) == O.orc_ezsint(gs, ctypes.byref(opts), fptr(zo), fptr(zin))
+            assert L.c_ezuvint(fptr(ur), fptr(vr), fptr(uu), fptr(vv)) == O.orc_ezuvint(gs, ctypes.byref(opts), fptr(uo), fptr(vo), fptr(uu), fptr(vv))
+            for a, b in ((zr, zo), (ur, uo), (vr, vo)):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (degree, polar)
+            if polar and dst[3][0] == 0:
+                assert np.all(zr[:no] == zr[0]) and np.all(zr[-no:] == zr[-1])
+    ref_setopts(L, 3, 1)
