@@ -219,6 +219,7 @@ def main():
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):      # BENCH_FORCE_DIST: exercise the RCCL path with one rank
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()      # the communicator is built by the first collective (hundreds of ms of idle GPU): here, not between the warm-up and the timed steps
 
     from librmn_amd import ezscint as ez
     from librmn_amd import sharding as sh
@@ -258,7 +259,9 @@ def main():
     prewarm = max(0, 40 - args.warmup)
     for _ in range(prewarm + args.warmup):
         step()
-    torch.cuda.synchronize()
+    # barrier + synchronize in front of the timed steps.  The barrier goes in BEHIND the queued warm-up launches: draining the device first and
+    # then running the collective left the GPU idle for the length of a barrier, and the timed steps started on dropped clocks (+9 % per step
+    # measured with one rank under torchrun against the same box without a process group)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
