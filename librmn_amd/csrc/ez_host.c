@@ -1743,6 +1743,7 @@ int32_t ezhip_unregister_host_buffer(void *p)
     pthread_mutex_unlock(&g_pin_mtx);
     return rc;
 }
+int ezh_host_is_pinned(const void *p, size_t n);
 static int host_pinned(const void *p, size_t nbytes)
 {
     int yes = 0;
@@ -1752,6 +1753,7 @@ static int host_pinned(const void *p, size_t nbytes)
     pthread_mutex_unlock(&g_pin_mtx);
     return yes;
 }
+int ezh_host_is_pinned(const void *p, size_t n) { return host_pinned(p, n); }
 
 /* Host-pointer ABI (c_ezsint on host arrays): the caller's arrays of the field in flight.  state 0: none; 1: the source is still on the
  * host only (whoever needs all of it on the device first calls hio_full); 2: source uploaded, result still to be fetched by the caller;
@@ -1983,9 +1985,11 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
         p.pole_row_n = prow_n; p.pole_row_s = prow_s;
         p.polevals = d_poles_pre ? d_poles_pre : d_poles;
         if (getenv("EZHIP_NO_SEPX")) p.x_nseg = 0;       /* tests: force the fallback tile kernel k_sep */
-        /* row ranges pay only when the copies are asynchronous, i.e. between page-locked arrays (EZHIP_HOST_CHUNKS forces them: tests) */
+        /* row ranges pay only when the copies are asynchronous, i.e. between page-locked arrays (EZHIP_HOST_CHUNKS: their number), and are
+         * never used on ordinary memory: many short device writes into one pageable array make the runtime lock / unlock overlapping page ranges
+         * in quick succession, and the gpu test suite died there once in ten runs ("Write access to a read-only page") */
         const int chunked = t_hio.state == 1 && p.x_nseg > 1 && s->sep[di][vector_mode].h_nvb > 0 && !getenv("EZHIP_HOST_NO_CHUNKS") &&
-                            (t_hio.pinned || getenv("EZHIP_HOST_CHUNKS"));
+                            t_hio.pinned;
         if (!chunked && hio_full((float *)d_zin)) return -1;
         if (p.x_nseg > 0) {
             /* a lone field: the special rows go last in the work order (mid-order they hold slots while the pole

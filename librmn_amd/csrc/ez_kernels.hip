@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include "ezhip_shim.h"
 
 /* Everything that restates reference arithmetic must not be contracted into FMAs; the separable
@@ -59,7 +60,115 @@ extern "C" void *ezhip_malloc(size_t nbytes)
 }
 extern "C" void ezhip_free(void *d) { if (d) (void)hipFree(d); }
 extern "C" int ezhip_h2d(void *d, const void *h, size_t n) { return set_err(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, g_stream), "h2d"); }
-extern "C" int ezhip_d2h(void *h, const void *d, size_t n) { return set_err(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream), "d2h"); }
+/* ---- results into the caller's ORDINARY (pageable) memory --------------------------------------------------------------------------
+ * The device never writes the caller's ordinary memory: a copy of more than EZH_DIRECT_MAX bytes lands in two page-locked buffers of the calling thread
+ * in turn (EZH_BOUNCE bytes each, truly asynchronous), and a small pool of host threads moves each chunk on into the caller's array while the next
+ * chunk is in flight.  Why: copies into pageable memory make the runtime lock the caller's pages for the length of each copy, and with heaps that
+ * allocate and free as a test session (or a long-running service) does, the copy engine's write now and then dies with "Memory access fault by GPU ...
+ * Write access to a read-only page", the address inside the destination array -- 1 to 4 of 12 runs of the gpu test suite, any destination: a dense
+ * 2.4 MB array, the rows of a pitched one, rows cut into ranges; writing each page from the CPU first did not stop it, page-locking the array for the
+ * length of the call made it more frequent.  Arrays the caller registered (ezhip_register_host_buffer: locked once, for long) are written directly. */
+#include <pthread.h>
+#define EZH_DIRECT_MAX ((size_t)256 << 10)
+#define EZH_BOUNCE_MAX ((size_t)32 << 20)
+#define EZH_COPY_THREADS_MAX 16
+static size_t EZH_BOUNCE = (size_t)16 << 20;      /* development: EZHIP_BOUNCE_MB, EZHIP_COPY_THREADS */
+static int EZH_COPY_THREADS = 8;
+extern "C" int ezh_host_is_pinned(const void *p, size_t n);
+extern "C" void ezhip_touch_writable(void *h, size_t n)
+{
+    if (!h || !n) return;
+    volatile char *q = (volatile char *)h;
+    for (size_t off = 0; off < n; off += 4096) q[off] = q[off];
+    q[n - 1] = q[n - 1];
+}
+namespace {
+struct copy_pool {
+    pthread_mutex_t use = PTHREAD_MUTEX_INITIALIZER;        /* one big copy at a time */
+    pthread_mutex_t m = PTHREAD_MUTEX_INITIALIZER;
+    pthread_cond_t go = PTHREAD_COND_INITIALIZER, done = PTHREAD_COND_INITIALIZER;
+    pthread_t th[EZH_COPY_THREADS_MAX];
+    char *dst = nullptr; const char *src = nullptr; size_t n = 0;
+    unsigned gen = 0; int pending = 0; bool started = false;
+};
+copy_pool g_pool;
+void slice(int k, size_t n, size_t &o, size_t &l) { const size_t per = (n / EZH_COPY_THREADS + 63) & ~(size_t)63; o = per * k; l = o >= n ? 0 : (n - o < per || k == EZH_COPY_THREADS - 1 ? n - o : per); }
+void *pool_worker(void *arg)
+{
+    const int k = (int)(intptr_t)arg;
+    unsigned seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&g_pool.m);
+        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.go, &g_pool.m);
+        seen = g_pool.gen;
+        char *d = g_pool.dst; const char *s_ = g_pool.src; const size_t n = g_pool.n;
+        pthread_mutex_unlock(&g_pool.m);
+        size_t o, l; slice(k, n, o, l);
+        if (l) memcpy(d + o, s_ + o, l);
+        pthread_mutex_lock(&g_pool.m);
+        if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.done);
+        pthread_mutex_unlock(&g_pool.m);
+    }
+    return nullptr;
+}
+void pool_memcpy(void *dst, const void *src, size_t n)
+{
+    if (n < ((size_t)1 << 20)) { memcpy(dst, src, n); return; }
+    pthread_mutex_lock(&g_pool.use);
+    if (!g_pool.started) {
+        g_pool.started = true;
+        for (int k = 1; k < EZH_COPY_THREADS; k++)
+            if (pthread_create(&g_pool.th[k - 1], nullptr, pool_worker, (void *)(intptr_t)k) != 0) { g_pool.started = false; break; }
+        if (g_pool.started) for (int k = 1; k < EZH_COPY_THREADS; k++) pthread_detach(g_pool.th[k - 1]);
+    }
+    if (!g_pool.started) { memcpy(dst, src, n); pthread_mutex_unlock(&g_pool.use); return; }
+    pthread_mutex_lock(&g_pool.m);
+    g_pool.dst = (char *)dst; g_pool.src = (const char *)src; g_pool.n = n; g_pool.pending = EZH_COPY_THREADS - 1; g_pool.gen++;
+    pthread_cond_broadcast(&g_pool.go);
+    pthread_mutex_unlock(&g_pool.m);
+    size_t o, l; slice(0, n, o, l);
+    if (l) memcpy((char *)dst + o, (const char *)src + o, l);
+    pthread_mutex_lock(&g_pool.m);
+    while (g_pool.pending) pthread_cond_wait(&g_pool.done, &g_pool.m);
+    pthread_mutex_unlock(&g_pool.m);
+    pthread_mutex_unlock(&g_pool.use);
+}
+thread_local struct { char *buf[2]; hipEvent_t ev[2]; bool ok; } t_bnc = {{nullptr, nullptr}, {nullptr, nullptr}, false};
+bool bounce_ready()
+{
+    if (t_bnc.ok) return true;
+    static bool tuned = false;
+    if (!tuned) { tuned = true; const char *e = getenv("EZHIP_BOUNCE_MB"); if (e && atoi(e) >= 1 && atoi(e) <= 32) EZH_BOUNCE = (size_t)atoi(e) << 20;
+        e = getenv("EZHIP_COPY_THREADS"); if (e && atoi(e) >= 1 && atoi(e) <= EZH_COPY_THREADS_MAX) EZH_COPY_THREADS = atoi(e); }
+    for (int k = 0; k < 2; k++) {
+        if (hipHostMalloc((void **)&t_bnc.buf[k], EZH_BOUNCE, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipEventCreateWithFlags(&t_bnc.ev[k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+    }
+    return t_bnc.ok = true;
+}
+}
+extern "C" int ezhip_d2h(void *h, const void *d, size_t n)
+{
+    if (n <= EZH_DIRECT_MAX || ezh_host_is_pinned(h, n) || !bounce_ready())
+        return set_err(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream), "d2h");
+    size_t prev_off = 0, prev_len = 0;
+    int c = 0;
+    for (size_t off = 0; off < n; off += EZH_BOUNCE, c++) {
+        const int b = c & 1;
+        const size_t len = n - off < EZH_BOUNCE ? n - off : EZH_BOUNCE;
+        if (set_err(hipMemcpyAsync(t_bnc.buf[b], (const char *)d + off, len, hipMemcpyDeviceToHost, g_stream), "d2h") ||
+            set_err(hipEventRecord(t_bnc.ev[b], g_stream), "d2h event")) return -1;
+        if (c >= 1) {
+            if (set_err(hipEventSynchronize(t_bnc.ev[b ^ 1]), "d2h wait")) return -1;
+            pool_memcpy((char *)h + prev_off, t_bnc.buf[b ^ 1], prev_len);
+        }
+        prev_off = off; prev_len = len;
+    }
+    if (set_err(hipEventSynchronize(t_bnc.ev[(c - 1) & 1]), "d2h wait")) return -1;
+    pool_memcpy((char *)h + prev_off, t_bnc.buf[(c - 1) & 1], prev_len);
+    return 0;
+}
+extern "C" int ezhip_d2h_pinned(void *h, const void *d, size_t n) { return set_err(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream), "d2h"); }   /* h: page-locked memory of the library */
 extern "C" int ezhip_d2d(void *dst, const void *src, size_t n) { return set_err(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, g_stream), "d2d"); }
 extern "C" int ezhip_memset(void *d, int v, size_t n) { return set_err(hipMemsetAsync(d, v, n, g_stream), "memset"); }
 extern "C" int ezhip_sync(void) { return set_err(hipStreamSynchronize(g_stream), "sync"); }
@@ -105,7 +214,7 @@ extern "C" void *ezhip_host_alloc(size_t n)
     return p;
 }
 extern "C" void ezhip_host_free(void *p) { if (p) (void)hipHostFree(p); }
-extern "C" int ezhip_host_pin(void *p, size_t n) { return set_err(hipHostRegister(p, n, hipHostRegisterDefault), "hipHostRegister"); }
+extern "C" int ezhip_host_pin(void *p, size_t n) { ezhip_touch_writable(p, n); return set_err(hipHostRegister(p, n, hipHostRegisterDefault), "hipHostRegister"); }
 extern "C" int ezhip_host_unpin(void *p) { return set_err(hipHostUnregister(p), "hipHostUnregister"); }
 
 #define LAUNCH_CHECK(what) set_err(hipGetLastError(), what)

@@ -152,16 +152,56 @@ static void die_no_device(const char *who)
     abort();
 }
 
-/* columns 1..n of a host (ijDim, levels) array <-> a dense (n, levels) device array */
+/* columns 1..n of a host (ijDim, levels) array <-> a dense (n, levels) device array.  Dense host arrays (ijDim == n) are copied as they are.  Arrays
+ * with gaps between their rows go through a page-locked buffer of the library (rows gathered / scattered by the CPU): a pitched copy is one copy per
+ * row, and rows read or written one by one in the caller's ordinary memory make the runtime lock and unlock overlapping page ranges of one array in
+ * quick succession -- the gpu test suite died there once in eight runs ("Memory access fault ... Write access to a read-only page", the address
+ * inside a result array); page-locking the caller's array for the length of the call made it worse (four runs in twelve). */
+static __thread struct { void *p; size_t cap; } t_bounce[SL_COUNT];
+static void *bounce(int k, size_t nbytes)
+{
+    if (t_bounce[k].cap < nbytes) {
+        if (t_bounce[k].p) { ezhip_sync(); ezhip_host_free(t_bounce[k].p); }
+        t_bounce[k].p = ezhip_host_alloc(nbytes);
+        t_bounce[k].cap = t_bounce[k].p ? nbytes : 0;
+    }
+    return t_bounce[k].p;
+}
 static int up(int k, const void *h, size_t es, int n, int ijdim, int rows)
 {
-    void *d = slot(k, es * (size_t)n * (size_t)rows);
+    const size_t row = es * (size_t)n, total = row * (size_t)rows;
+    void *d = slot(k, total);
     if (!d) return -1;
-    return ivhip_copy2d(d, es * (size_t)n, h, es * (size_t)ijdim, es * (size_t)n, (size_t)rows, 1);
+    if (ijdim == n || rows == 1) return ezhip_h2d(d, h, total);
+    char *b = (char *)bounce(k, total);
+    if (!b) return -1;
+    for (int r = 0; r < rows; r++) memcpy(b + (size_t)r * row, (const char *)h + (size_t)r * es * (size_t)ijdim, row);
+    return ezhip_h2d(d, b, total);
 }
+/* results: queued here, scattered into the caller's arrays by finish() once the device is done */
+static __thread struct { void *h; int k, n, ijdim, rows; size_t es; } t_pending[2];
+static __thread int t_npending;
 static int down(void *h, int k, size_t es, int n, int ijdim, int rows)
 {
-    return ivhip_copy2d(h, es * (size_t)ijdim, t_slot[k].p, es * (size_t)n, es * (size_t)n, (size_t)rows, 0);
+    const size_t row = es * (size_t)n, total = row * (size_t)rows;
+    if (ijdim == n || rows == 1) return ezhip_d2h(h, t_slot[k].p, total);
+    char *b = (char *)bounce(k, total);
+    if (!b || t_npending >= 2) return -1;
+    if (ezhip_d2h_pinned(b, t_slot[k].p, total)) return -1;
+    t_pending[t_npending].h = h; t_pending[t_npending].k = k; t_pending[t_npending].n = n; t_pending[t_npending].ijdim = ijdim;
+    t_pending[t_npending].rows = rows; t_pending[t_npending].es = es; t_npending++;
+    return 0;
+}
+static int finish(void)
+{
+    const int rc = ezhip_sync();
+    for (int q = 0; q < t_npending && !rc; q++) {
+        const size_t row = t_pending[q].es * (size_t)t_pending[q].n;
+        const char *b = (const char *)t_bounce[t_pending[q].k].p;
+        for (int r = 0; r < t_pending[q].rows; r++) memcpy((char *)t_pending[q].h + (size_t)r * t_pending[q].es * (size_t)t_pending[q].ijdim, b + (size_t)r * row, row);
+    }
+    t_npending = 0;
+    return rc;
 }
 
 static void findpos_host(int prec8, int n, int ns, int nd, int sij, int dij, const void *vls, int32_t *posn, const void *vld)
@@ -172,9 +212,10 @@ static void findpos_host(int prec8, int n, int ns, int nd, int sij, int dij, con
     const size_t es = prec8 ? 8 : 4;
     if (up(SL_VLS, vls, es, n, sij, ns) || up(SL_VLD, vld, es, n, dij, nd) || !slot(SL_POSN, 4 * (size_t)n * nd)) goto fail;
     if (interpv_hip_findpos_dev(prec8, n, ns, nd, n, n, t_slot[SL_VLS].p, (int32_t *)t_slot[SL_POSN].p, t_slot[SL_VLD].p)) goto fail;
-    if (down(posn, SL_POSN, 4, n, dij, nd) || ezhip_sync()) goto fail;
+    if (down(posn, SL_POSN, 4, n, dij, nd) || finish()) goto fail;
     return;
 fail:
+    t_npending = 0;
     fprintf(stderr, "<%s> device error: %s\n", who, ezhip_last_error());
     abort();
 }
@@ -204,9 +245,10 @@ static void apply_host(int prec8, int algo, int extrap, int n, int ns, int nd, i
     if (rc) goto fail;
     if (extrap != IVX_ABORT && down(sd, SL_SD, es, n, dij, nd)) goto fail;
     if (need_sds && down(sdd, SL_SDD, es, n, dij, nd)) goto fail;
-    if (ezhip_sync()) goto fail;
+    if (finish()) goto fail;
     return;
 fail:
+    t_npending = 0;
     fprintf(stderr, "<%s> device error: %s\n", who, ezhip_last_error());
     abort();
 }

@@ -298,6 +298,7 @@ extern "C" int ivhip_launch(const ivhip_args *h)
 extern "C" int ivhip_copy2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows, int to_device)
 {
     if (!width_bytes || !rows) return 0;
+    if (!to_device) for (size_t r = 0; r < rows; r++) ezhip_touch_writable((char *)dst + r * dpitch, width_bytes);      /* see ezhip_d2h */
     return hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost,
                             (hipStream_t)ezhip_get_stream()) == hipSuccess ? 0 : -1;
 }
