@@ -207,13 +207,11 @@ for k in range(ncases):
     spec = yy_grid(True); uni, unj = spec[0], spec[1]
     other = make_grid(str(rng.choice(["Lglob", "Lreg", "G", "N", "ZLglob", "ZLreg"])))
     setopts(degree, polar, extrap)
-    gu_r = define_u(True, spec); go_r = define(True, other)
-    if gu_r < 0 or go_r < 0: continue
     desc = dict(mode=mode, yy=(uni, unj), other=other[:5], degree=degree, polar=polar, extrap=extrap)
     if mode == "yy_src":
-        n_in = 2 * uni * unj; n_out = other[0] * other[1]; gi_r, gd_r = gu_r, go_r
+        n_in = 2 * uni * unj; n_out = other[0] * other[1]
     else:
-        n_in = other[0] * other[1]; n_out = 2 * uni * unj; gi_r, gd_r = go_r, gu_r
+        n_in = other[0] * other[1]; n_out = 2 * uni * unj
     if mode == "yy_src":
         zin = np.concatenate([ec.synth_field(uni, unj, seed=int(rng.integers(1 << 30))) for _ in range(2)])
         w = [ec.synth_wind(uni, unj, seed=int(rng.integers(1 << 30))) for _ in range(2)]; uu = np.concatenate([w[0][0], w[1][0]]); vv = np.concatenate([w[0][1], w[1][1]])
@@ -232,29 +230,17 @@ for k in range(ncases):
         pr = subprocess.run([sys.executable, os.path.join(_R, "tools", "ref_standalone.py"), os.path.join(td, "case.npz"), os.path.join(td, "out.npz")], capture_output=True, text=True)
         if pr.returncode != 0:
             crashed += 1; continue                      # the reference did not survive the case even alone
-        o = np.load(os.path.join(td, "out.npz")); zr_, ur, vr, rc_r, rcv_r = o["zr"], o["ur"], o["vr"], int(o["rc"]), int(o["rcv"])
+        o = np.load(os.path.join(td, "out.npz")); zr_, ur, vr, rc_r, rcv_r, worst = o["zr"], o["ur"], o["vr"], int(o["rc"]), int(o["rcv"]), o["worst"]
     if DRY or os.environ.get('FUZZ_YY_REF_ONLY'): ran += 1; continue
     gu_p = define_u(False, spec); go_p = define(False, other)
     if gu_p < 0 or go_p < 0: report("define", desc, "product refuses"); continue
     ez.ezdefset(gu_p if mode == "yy_dst" else go_p, go_p if mode == "yy_dst" else gu_p)
     rc, zp = ez.ezsint(zin, n_out); rcv, up, vp = ez.ezuvint(uu, vv, n_out) if winds else (0, ur.copy(), vr.copy()); ran += 1
     def yy_compare(zr_, ur, vr, rc_r, rcv_r, quiet):
-        """-> number of findings; quiet: count only"""
-        global bad, near
-        b0, n0 = bad, near
         if rc != rc_r or rcv != rcv_r: report("yy rc", desc, f"{(rc, rcv)} vs {(rc_r, rcv_r)}")
         else:
             cmp_field("yy scalar", desc, zp, zr_, degree != 3)
-            lat_t = np.zeros(n_out, np.float32); lon_t = lat_t.copy(); R.c_gdll(gd_r, fp(lat_t), fp(lon_t))
-            worst = np.abs(lat_t.astype(np.float64))
-            for igf in (ec.YIN_IG, ec.YAN_IG):          # the rotated latitudes of the target points in the two Yin-Yang frames
-                gtmp = R.c_ezgdef_fmem(spec[0], spec[1], b"Z", b"E", *igf, fp(spec[2]), fp(spec[3]))
-                xs = np.zeros(n_out, np.float32); ys = xs.copy(); R.c_gdxyfll(gtmp, fp(xs), fp(ys), fp(lat_t), fp(lon_t.copy()), n_out)
-                dy = float(spec[3][1] - spec[3][0]); worst = np.maximum(worst, np.minimum(np.abs(spec[3][0] + (ys.astype(np.float64) - 1.0) * dy), 90.0))
             cmp_wind("yy winds", desc, up, vp, ur, vr, worst)
-        found = bad - b0
-        if quiet: bad, near = b0, n0
-        return found
     yy_compare(zr_, ur, vr, rc_r, rcv_r, False)
 setopts(3, 1, "maximum")
 print(f"masks, c_ezwdint and Yin-Yang grids vs the reference build: {ran} of {ncases} cases ran, {bad} mismatches ({near} cases with wind errors between 1e-5 |V| and the conditioning bound; "

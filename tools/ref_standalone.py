@@ -23,4 +23,10 @@ assert R.c_ezdefset(gd, gi) == 1
 zin, uu, vv = (np.ascontiguousarray(d[k]) for k in ("zin", "uu", "vv"))
 zr = np.zeros(n_out, np.float32); ur = zr.copy(); vr = zr.copy()
 rc = R.c_ezsint(fp(zr), fp(zin)); rcv = R.c_ezuvint(fp(ur), fp(vr), fp(uu), fp(vv)) if mode == "yy_src" else 0
-np.savez(sys.argv[2], zr=zr, ur=ur, vr=vr, rc=rc, rcv=rcv)
+# the latitudes that condition the wind direction at the target points: the true one and the ones in the two Yin-Yang frames
+lat_t = np.zeros(n_out, np.float32); lon_t = lat_t.copy(); R.c_gdll(gd, fp(lat_t), fp(lon_t))
+worst = np.abs(lat_t.astype(np.float64))
+for g in (a, b):
+    xs = np.zeros(n_out, np.float32); ys = xs.copy(); R.c_gdxyfll(g, fp(xs), fp(ys), fp(lat_t), fp(lon_t.copy()), n_out)
+    dy = float(uay[1] - uay[0]); worst = np.maximum(worst, np.minimum(np.abs(float(uay[0]) + (ys.astype(np.float64) - 1.0) * dy), 90.0))
+np.savez(sys.argv[2], zr=zr, ur=ur, vr=vr, rc=rc, rcv=rcv, worst=worst)
