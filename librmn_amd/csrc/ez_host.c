@@ -2806,7 +2806,7 @@ int32_t c_gdxywdval(int32_t gdin, float *uuout, float *vvout, float *uuin, float
     size_t nb = sizeof(float) * (size_t)(n > 0 ? n : 1);
     float *tlat = (float *)malloc(nb), *tlon = (float *)malloc(nb), *tu = (float *)malloc(nb), *tv = (float *)malloc(nb);
     int rc = c_gdxyvval(gdin, tu, tv, uuin, vvin, x, y, n);
-    if (rc >= 0) rc = c_gdllfxy(gdin, tlat, tlon, x, y, n);
+    if (rc >= 0) rc = gdllfxy_one(&G[gdin], tlat, tlon, x, y, n, 0);       /* c_gdllfxy_orig (gdxywdval.c:94): rows as they are counted in the array */
     if (rc >= 0) rc = c_gdwdfuv(gdin, uuout, vvout, tu, tv, tlat, tlon, n);
     free(tlat); free(tlon); free(tu); free(tv);
     return rc < 0 ? -1 : 0;

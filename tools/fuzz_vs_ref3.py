@@ -202,6 +202,24 @@ for k in range(ncases):
             fin = np.isfinite(e)
             if rcv != rcv_r: report("gdllvval", dict(desc, degree=degree), f"rc {rcv} vs {rcv_r}")
             elif np.any(e[fin] > np.broadcast_to(bound, e.shape)[fin] + (2e-4 if rotated else 0.0)): report("gdllvval", dict(desc, degree=degree), f"max err {np.nanmax(e):.2e} |V|")
+            # winds at given x, y (c_gdxyvval: the two components as they are on the grid) and as speed / direction (c_gdxywdval, c_gdllwdval)
+            L_ = ez._lib()
+            vx = px.copy(); vy = py.copy()
+            a_r = np.zeros(m, np.float32); b_r = a_r.copy(); R.c_gdxyvval(gr, fp(a_r), fp(b_r), fp(uu), fp(vv), fp(vx), fp(vy), m)
+            a_p = np.zeros(m, np.float32); b_p = a_p.copy(); L_.c_gdxyvval(gp, fp(a_p), fp(b_p), fp(uu), fp(vv), fp(vx), fp(vy), m)
+            if degree != 3:
+                if not (bits_equal(a_p, a_r) and bits_equal(b_p, b_r)): report("gdxyvval", dict(desc, degree=degree), f"{int(((a_p != a_r) | (b_p != b_r)).sum())} points differ")
+            elif np.any(np.abs(a_p - a_r) > 1e-5 * np.maximum(np.abs(a_r), 1e-3)) or np.any(np.abs(b_p - b_r) > 1e-5 * np.maximum(np.abs(b_r), 1e-3)): report("gdxyvval", dict(desc, degree=degree), "beyond 1e-5")
+            for nm, args_r, args_p in (("gdxywdval", (vx, vy), (vx, vy)), ("gdllwdval", (plat, plon.copy()), (plat, plon.copy()))):
+                s_r = np.zeros(m, np.float32); d_r = s_r.copy(); getattr(R, "c_" + nm)(gr, fp(s_r), fp(d_r), fp(uu), fp(vv), fp(args_r[0]), fp(args_r[1]), m)
+                s_p = np.zeros(m, np.float32); d_p = s_p.copy(); getattr(L_, "c_" + nm)(gp, fp(s_p), fp(d_p), fp(uu), fp(vv), fp(args_p[0]), fp(args_p[1]), m)
+                fin = np.isfinite(s_r) & np.isfinite(d_r)
+                dd = np.abs(((d_p[fin] - d_r[fin] + 180.0) % 360.0) - 180.0)
+                tol_d = 1e-3 + (np.degrees(8 * 6e-8 / cosl[fin]) if rotated else 0.0) + (2e-2 if rotated and nm == "gdllwdval" else 0.0)
+                big = s_r[fin] > 1e-2
+                if not np.array_equal(fin, np.isfinite(s_p) & np.isfinite(d_p)): report(nm, dict(desc, degree=degree), "finite in one, not in the other")
+                elif np.any(np.abs(s_p[fin] - s_r[fin]) > (2e-4 if rotated and nm == "gdllwdval" else 1e-5) * np.maximum(s_r[fin], 1e-3)) or np.any(dd[big] > np.broadcast_to(tol_d, dd.shape)[big]):
+                    report(nm, dict(desc, degree=degree), f"max speed err {np.abs(s_p[fin] - s_r[fin]).max():.2e}, max direction err {dd[big].max() if big.any() else 0:.2e} deg")
             rc, sp_p, wd_p = ez.gdwdfuv(gp, wu, wv, plat, plon)
             dd = np.abs(((wd_p - wd_r + 180.0) % 360.0) - 180.0)
             if np.any(np.abs(sp_p - sp_r) > 1e-5 * np.maximum(sp_r, 1e-3)) or np.any(dd[sp_r > 0] > 1e-3 + (np.degrees(8 * 6e-8 / cosl[sp_r > 0]) if rotated else 0.0)):
