@@ -1707,12 +1707,13 @@ static int pole_ring(int nfields, ezhip_sep_plan *p)
  * (prow_n / prow_s device pointers, may be NULL when polar correction is off) */
 /* per host thread: the expansion of a hemispheric source field (ez_xpnsrcgd) */
 static __thread struct { float *p; size_t cap; } t_xpn;
+static __thread int t_symmetrie = 1;                     /* groptions.symmetrie: 1 SYM, 0 ANTISYM (the v component of c_gdxyvval: ez_xpngdag2.inc:37-41 mirrors it with its sign changed) */
 static const float *hemi_expand(const ezh_grid *gi, const float *d_zin)
 {
     size_t n = (size_t)gi->ni * (size_t)(gi->j2 - gi->j1 + 1);
     if (t_xpn.cap < n) { if (t_xpn.p) { ezhip_sync(); ezhip_free(t_xpn.p); } t_xpn.p = (float *)ezhip_malloc(sizeof(float) * n); t_xpn.cap = t_xpn.p ? n : 0; }
     if (!t_xpn.p) return NULL;
-    if (ezhip_hemi_expand(t_xpn.p, d_zin, gi->ni, gi->nj, gi->j1, gi->j2, src_hemi(gi) ? gi->ig[0] : 0, gi->grtyp == 'B', 1, grid_yinv(gi))) return NULL;
+    if (ezhip_hemi_expand(t_xpn.p, d_zin, gi->ni, gi->nj, gi->j1, gi->j2, src_hemi(gi) ? gi->ig[0] : 0, gi->grtyp == 'B', t_symmetrie, grid_yinv(gi))) return NULL;
     return t_xpn.p;
 }
 /* Arrays the caller has page-locked for the library (ezhip_register_host_buffer): copies to / from them are asynchronous, which is what
@@ -2354,9 +2355,12 @@ int32_t c_gdllsval(int32_t gdid, float *zout, float *zin, float *lat, float *lon
 /* vector values at x,y: two scalar interpolations, no rotation (gdxyvval.c:89-102) */
 int32_t c_gdxyvval(int32_t gdin, float *uuout, float *vvout, float *uuin, float *vvin, float *x, float *y, int32_t n)
 {
+    /* gdxyvval.c:103-113: u with symmetrie = SYM, v with ANTISYM -- the mirror image of a hemispheric source carries v with its sign changed */
     int rc = c_gdxysint(uuout, uuin, gdin, x, y, n);
     if (rc < 0) return rc;
+    t_symmetrie = 0;
     rc = c_gdxysint(vvout, vvin, gdin, x, y, n);
+    t_symmetrie = 1;
     return rc < 0 ? rc : 0;
 }
 /* gdllvval.c:34-57: locate, then c_gdxyvval */

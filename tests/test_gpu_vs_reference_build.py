@@ -119,3 +119,34 @@ def test_rotated_source_to_B_target_pole_rows(ig, degree):
     assert rc == rcr
     if degree == "cubic": assert np.all(np.abs(z - zr) <= 1e-5 * np.abs(zr))
     else: assert np.array_equal(z.view(np.uint32), zr.view(np.uint32))
+
+
+@pytest.mark.skipif(not reflib.have_ref(), reason="oracle/_ref/libezref.so not built")
+@pytest.mark.parametrize("grid", [(64, 16, "G", (1, 0, 0, 0)), (64, 16, "G", (2, 1, 0, 0)), (50, 12, "A", (2, 0, 0, 0)), (51, 13, "B", (1, 1, 0, 0))])
+def test_winds_at_points_of_a_hemispheric_source_mirror_v_with_its_sign_changed(grid):
+    """c_gdxyvval / c_gdllvval (gdxyvval.c:103-113): u is interpolated with symmetrie = SYM, v with ANTISYM -- in the mirrored hemisphere of a
+    hemispheric source v changes sign (ez_xpngdag2.inc:37-41).  Found by tools/fuzz_vs_ref3.py: the product mirrored both alike."""
+    import ctypes
+    import numpy as np
+    import ezcases as ec
+    from librmn_amd import ezscint as ez
+    R = reflib.ref(); L = ez._lib()
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    ni, nj, t, ig = grid
+    uu, vv = ec.synth_wind(ni, nj, seed=9)
+    if t == "B":
+        for a in (uu, vv):
+            a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+    gr = R.c_ezqkdef(ni, nj, t.encode(), *ig, 0); gp = ez.ezqkdef(ni, nj, t, *ig)
+    rng = np.random.default_rng(4)
+    lat = rng.uniform(-89, 89, 600).astype(np.float32); lon = rng.uniform(0, 360, 600).astype(np.float32)
+    for degree in ("nearest", "linear", "cubic"):
+        R.c_ezsetopt(b"interp_degree", degree.encode()); ez.ezsetopt("interp_degree", degree)
+        ur = np.zeros(600, np.float32); vr = ur.copy(); R.c_gdllvval(gr, fp(ur), fp(vr), fp(uu), fp(vv), fp(lat), fp(lon.copy()), 600)
+        rc, u, v = ez.gdllvval(gp, uu, vv, lat, lon)
+        assert rc == 0
+        if degree == "cubic":
+            assert np.all(np.abs(u - ur) <= 1e-5 * np.maximum(np.abs(ur), 1e-3)) and np.all(np.abs(v - vr) <= 1e-5 * np.maximum(np.abs(vr), 1e-3))
+        else:
+            assert np.array_equal(u, ur) and np.array_equal(v, vr), degree
+    R.c_ezsetopt(b"interp_degree", b"cubic"); ez.ezsetopt("interp_degree", "cubic")

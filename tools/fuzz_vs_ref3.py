@@ -186,6 +186,19 @@ for k in range(ncases):
             if np.nanmax(e) > 2e-4: report("gdllsval", dict(desc, degree=degree), f"max rel err {np.nanmax(e):.2e} (through a rotated locate)")
         else: cmp_scalar("gdllsval", zlp, zl, degree != 3)
     # --- winds at lat / lon: c_gdllvval, c_gdwdfuv, c_gduvfwd
+    if hemi_or_inv and not DRY:
+        # hemispheric / y-inverted sources: c_gdxyvval and c_gdllvval are two scalar interpolations each (gdxyvval.c:89, gdllvval.c:44-47), no wind chain
+        L_ = ez._lib()
+        a_r = np.zeros(m, np.float32); b_r = a_r.copy(); R.c_gdxyvval(gr, fp(a_r), fp(b_r), fp(uu), fp(vv), fp(px.copy()), fp(py.copy()), m)
+        a_p = np.zeros(m, np.float32); b_p = a_p.copy(); rcp = L_.c_gdxyvval(gp, fp(a_p), fp(b_p), fp(uu), fp(vv), fp(px.copy()), fp(py.copy()), m)
+        if rcp < 0: report("gdxyvval (hemispheric / inverted)", dict(desc, degree=degree), "refused")
+        elif degree != 3 and not (bits_equal(a_p, a_r) and bits_equal(b_p, b_r)): report("gdxyvval (hemispheric / inverted)", dict(desc, degree=degree), f"{int(((a_p != a_r) | (b_p != b_r)).sum())} points differ")
+        elif degree == 3 and (np.any(np.abs(a_p - a_r) > 1e-5 * np.maximum(np.abs(a_r), 1e-3)) or np.any(np.abs(b_p - b_r) > 1e-5 * np.maximum(np.abs(b_r), 1e-3))): report("gdxyvval (hemispheric / inverted)", dict(desc, degree=degree), "beyond 1e-5")
+        a_r = np.zeros(m, np.float32); b_r = a_r.copy(); R.c_gdllvval(gr, fp(a_r), fp(b_r), fp(uu), fp(vv), fp(plat), fp(plon.copy()), m)
+        rcp, a_p, b_p = ez.gdllvval(gp, uu, vv, plat, plon)
+        if rcp < 0: report("gdllvval (hemispheric / inverted)", dict(desc, degree=degree), "refused")
+        elif degree != 3 and not (bits_equal(a_p, a_r) and bits_equal(b_p, b_r)): report("gdllvval (hemispheric / inverted)", dict(desc, degree=degree), f"{int(((a_p != a_r) | (b_p != b_r)).sum())} points differ")
+        elif degree == 3 and (np.any(np.abs(a_p - a_r) > 1e-5 * np.maximum(np.abs(a_r), 1e-3)) or np.any(np.abs(b_p - b_r) > 1e-5 * np.maximum(np.abs(b_r), 1e-3))): report("gdllvval (hemispheric / inverted)", dict(desc, degree=degree), "beyond 1e-5")
     if not hemi_or_inv and kind != "E":
         ur = np.zeros(m, np.float32); vr = ur.copy(); lo3 = plon.copy(); rcv_r = R.c_gdllvval(gr, fp(ur), fp(vr), fp(uu), fp(vv), fp(plat), fp(lo3), m)
         wu = f32(rng.normal(0, 15, m)); wv = f32(rng.normal(0, 15, m)); wu[:5] = 0.0; wv[5:8] = 0.0; wu[8] = wv[8] = 0.0
