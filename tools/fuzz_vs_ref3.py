@@ -107,6 +107,22 @@ for k in range(ncases):
     if not DRY and gp < 0: report("define", desc, "product refuses the grid"); continue
     ran += 1
     n = ni * nj
+    # --- the parameter getters: c_ezgprm, c_ezgxprm, c_gdgaxes
+    if not DRY:
+        L0 = ez._lib()
+        def prm(lib, gid):
+            gt = ctypes.create_string_buffer(8); v = [ctypes.c_int32() for _ in range(6)]
+            rc = lib.c_ezgprm(gid, gt, *[ctypes.byref(q) for q in v])
+            gt2 = ctypes.create_string_buffer(8); gref = ctypes.create_string_buffer(8); w = [ctypes.c_int32() for _ in range(10)]
+            rc2 = lib.c_ezgxprm(gid, ctypes.byref(w[0]), ctypes.byref(w[1]), gt2, ctypes.byref(w[2]), ctypes.byref(w[3]), ctypes.byref(w[4]), ctypes.byref(w[5]), gref,
+                                ctypes.byref(w[6]), ctypes.byref(w[7]), ctypes.byref(w[8]), ctypes.byref(w[9]))
+            return (rc, gt.value[:1], tuple(q.value for q in v)), (rc2, gt2.value[:1], gref.value[:1] if g[5] is not None else b"", tuple(q.value for q in (w if g[5] is not None else w[:6])))
+        pr, pp_ = prm(R, gr), prm(L0, gp)
+        if pr != pp_: report("ezgprm / ezgxprm", desc, f"{pp_} vs {pr}")
+        if g[5] is not None:
+            ax_r = np.zeros(ni, np.float32); ay_r = np.zeros(nj, np.float32); ax_p = ax_r.copy(); ay_p = ay_r.copy()
+            R.c_gdgaxes(gr, fp(ax_r), fp(ay_r)); L0.c_gdgaxes(gp, fp(ax_p), fp(ay_p))
+            if not (bits_equal(ax_r, ax_p) and bits_equal(ay_r, ay_p)): report("gdgaxes", desc, "axes differ")
     # --- c_gdll
     lat_r = np.zeros(n, np.float32); lon_r = lat_r.copy(); R.c_gdll(gr, fp(lat_r), fp(lon_r))
     if not DRY:
