@@ -274,3 +274,41 @@ def test_hemispheric_and_inverted_gaussian_grids_locate_like_the_reference(ig):
     la_r = np.zeros(500, np.float32); lo_r = la_r.copy(); la_p = la_r.copy(); lo_p = la_r.copy()
     R.c_gdllfxy(gr, fp(la_r), fp(lo_r), fp(x), fp(y), 500); L.c_gdllfxy(gp, fp(la_p), fp(lo_p), fp(x), fp(y), 500)
     assert np.array_equal(la_r, la_p) and np.array_equal(lo_r, lo_p), ig
+
+
+def test_options_set_and_read_back_like_the_reference():
+    """c_ezsetopt / c_ezgetopt / c_ezsetval / c_ezgetval / c_ezsetival / c_ezgetival against the reference build: every option name (English, French,
+    upper case, unknown) with every value (synonyms, unknown, empty): the same return codes and the same strings read back (ezsetopt.c:59-215)"""
+    import ctypes
+    import reflib
+    if not reflib.have_ref():
+        pytest.skip("oracle/_ref/libezref.so not built")
+    R = reflib.ref(); L = librmn_amd.load_library()
+    opts = ["interp_degree", "degre_interp", "extrap_degree", "degre_extrap", "polar_correction", "correction_polaire", "verbose", "cloud_interp_alg",
+            "use_1subgrid", "use_1sousgrille", "INTERP_DEGREE", "Extrap_Degree", "bogus_option", "missing_interp_alg", "extrap_value", "subgridid"]
+    vals = ["nearest", "voisin", "linear", "lineair", "lineaire", "cubic", "cubique", "CUBIC", "average", "sph_average", "neutral", "neutre", "maximum",
+            "minimum", "value", "valeur", "abort", "yes", "oui", "no", "non", "yesyesyes", "ouiouioui", "distance", "bogus", ""]
+    getn = ["interp_degree", "extrap_degree", "polar_correction", "verbose", "cloud_interp_alg", "use_1subgrid", "degre_interp", "INTERP_DEGREE", "bogus_option"]
+
+    def get(lib, name):
+        b = ctypes.create_string_buffer(64)
+        return lib.c_ezgetopt(name.encode(), b), b.value
+    try:
+        for o in opts:
+            for v in vals:
+                assert R.c_ezsetopt(o.encode(), v.encode()) == L.c_ezsetopt(o.encode(), v.encode()), (o, v)
+                for n in getn:
+                    assert get(R, n) == get(L, n), (o, v, n)
+        for name, x in (("extrap_value", -3.5), ("extrap_value", 1e30), ("bogus", 1.0), ("EXTRAP_VALUE", 2.0)):
+            a = ctypes.c_float(); b = ctypes.c_float()
+            assert R.c_ezsetval(name.encode(), ctypes.c_float(x)) == L.c_ezsetval(name.encode(), ctypes.c_float(x))
+            assert (R.c_ezgetval(name.encode(), ctypes.byref(a)), a.value) == (L.c_ezgetval(name.encode(), ctypes.byref(b)), b.value), name
+        for name, x in (("subgridid", 3), ("bogus", 1), ("SUBGRIDID", 7)):
+            a = ctypes.c_int(); b = ctypes.c_int()
+            assert R.c_ezsetival(name.encode(), x) == L.c_ezsetival(name.encode(), x)
+            assert (R.c_ezgetival(name.encode(), ctypes.byref(a)), a.value) == (L.c_ezgetival(name.encode(), ctypes.byref(b)), b.value), name
+    finally:
+        for lib in (R, L):
+            for o, v in (("interp_degree", "cubic"), ("extrap_degree", "maximum"), ("polar_correction", "yes"), ("verbose", "no"), ("cloud_interp_alg", "distance"), ("use_1subgrid", "no")):
+                lib.c_ezsetopt(o.encode(), v.encode())
+            lib.c_ezsetval(b"extrap_value", ctypes.c_float(0.0))
