@@ -73,7 +73,7 @@ extern "C" int ezhip_h2d(void *d, const void *h, size_t n) { return set_err(hipM
 #define EZH_BOUNCE_MAX ((size_t)32 << 20)
 #define EZH_COPY_THREADS_MAX 16
 static size_t EZH_BOUNCE = (size_t)16 << 20;      /* development: EZHIP_BOUNCE_MB, EZHIP_COPY_THREADS */
-static int EZH_COPY_THREADS = 8;
+static int EZH_COPY_THREADS = 4;
 extern "C" int ezh_host_is_pinned(const void *p, size_t n);
 extern "C" void ezhip_touch_writable(void *h, size_t n)
 {
@@ -92,6 +92,29 @@ struct copy_pool {
     unsigned gen = 0; int pending = 0; bool started = false;
 };
 copy_pool g_pool;
+/* the copy out of the page-locked buffer with non-temporal stores: the destination is written once and not read here, and an ordinary store first
+ * fetches every line it is about to overwrite (EZHIP_COPY_PLAIN=1: memcpy) */
+#include <immintrin.h>
+__attribute__((target("avx2"))) void nt_copy_avx2(char *d, const char *s_, size_t n)
+{
+    size_t head = (32 - ((uintptr_t)d & 31)) & 31;
+    if (head > n) head = n;
+    if (head) { memcpy(d, s_, head); d += head; s_ += head; n -= head; }
+    size_t k = 0;
+    for (; k + 128 <= n; k += 128) {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)(s_ + k)), b = _mm256_loadu_si256((const __m256i *)(s_ + k + 32));
+        const __m256i c = _mm256_loadu_si256((const __m256i *)(s_ + k + 64)), e = _mm256_loadu_si256((const __m256i *)(s_ + k + 96));
+        _mm256_stream_si256((__m256i *)(d + k), a); _mm256_stream_si256((__m256i *)(d + k + 32), b);
+        _mm256_stream_si256((__m256i *)(d + k + 64), c); _mm256_stream_si256((__m256i *)(d + k + 96), e);
+    }
+    _mm_sfence();
+    if (k < n) memcpy(d + k, s_ + k, n - k);
+}
+void copy_out(char *d, const char *s_, size_t n)
+{
+    static const int mode = (getenv("EZHIP_COPY_PLAIN") || !__builtin_cpu_supports("avx2")) ? 0 : 1;
+    if (mode && n >= 4096) nt_copy_avx2(d, s_, n); else memcpy(d, s_, n);
+}
 void slice(int k, size_t n, size_t &o, size_t &l) { const size_t per = (n / EZH_COPY_THREADS + 63) & ~(size_t)63; o = per * k; l = o >= n ? 0 : (n - o < per || k == EZH_COPY_THREADS - 1 ? n - o : per); }
 void *pool_worker(void *arg)
 {
@@ -104,7 +127,7 @@ void *pool_worker(void *arg)
         char *d = g_pool.dst; const char *s_ = g_pool.src; const size_t n = g_pool.n;
         pthread_mutex_unlock(&g_pool.m);
         size_t o, l; slice(k, n, o, l);
-        if (l) memcpy(d + o, s_ + o, l);
+        if (l) copy_out(d + o, s_ + o, l);
         pthread_mutex_lock(&g_pool.m);
         if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.done);
         pthread_mutex_unlock(&g_pool.m);
@@ -127,7 +150,7 @@ void pool_memcpy(void *dst, const void *src, size_t n)
     pthread_cond_broadcast(&g_pool.go);
     pthread_mutex_unlock(&g_pool.m);
     size_t o, l; slice(0, n, o, l);
-    if (l) memcpy((char *)dst + o, (const char *)src + o, l);
+    if (l) copy_out((char *)dst + o, (const char *)src + o, l);
     pthread_mutex_lock(&g_pool.m);
     while (g_pool.pending) pthread_cond_wait(&g_pool.done, &g_pool.m);
     pthread_mutex_unlock(&g_pool.m);
