@@ -2498,7 +2498,36 @@ static void h_polar_wind(const ezh_grid *g, float *pu, float *pv, const float *u
 }
 
 /* wd_only: c_ezwdint_orig (ezwdint.c:62-113) = the same path stopped after c_gdwdfuv */
+static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin, int wd_only);
+/* extrap_degree = abort with target points outside the source: each of the two c_ezsint calls inside c_ezuvint_orig prints the abort message and
+ * returns -1 from ez_corrval BEFORE anything is corrected (ez_corrval.c:54-60), c_ezuvint_orig looks for the value 2 only (ezuvint.c:68-74) and
+ * carries on: ez_corrvec finds no strip zones (a set with outside points has none: ez_defzones.c:46-113), the wind chain runs, 0 is returned.
+ * I.e. the answer of the same call with the polar correction off -- found by tools/fuzz_vs_ref2.py. */
 static int32_t uvint_impl(float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin, int wd_only)
+{
+    ezh_set *s0 = current_set(wd_only ? "c_ezwdint" : "c_ezuvint");
+    if (s0 && O.polar_correction == 1 && O.degre_extrap == XT_ABORT && s0->extrap && s0->gdin != s0->gdout &&
+        G[s0->gdin].grtyp != 'U' && G[s0->gdout].grtyp != 'U' && !need_device("c_ezuvint")) {
+        if (!s0->sep_capable) {
+            pthread_mutex_lock(&g_plan_mtx);
+            int e = ensure_points(s0);
+            pthread_mutex_unlock(&g_plan_mtx);
+            if (e) return -1;
+        }
+        if (s0->have_dehors) {
+            for (int k = 0; k < 2; k++) {
+                fprintf(stderr, "<ez_corrval> There are points on the destination grid that lie outside the source grid\n");
+                fprintf(stderr, "<ez_corrval> aborting at your request!\n\n\n");
+            }
+            O.polar_correction = 0;
+            int32_t rc = uvint_body(d_uuout, d_vvout, d_uuin, d_vvin, wd_only);
+            O.polar_correction = 1;
+            return rc < 0 ? rc : 0;
+        }
+    }
+    return uvint_body(d_uuout, d_vvout, d_uuin, d_vvin, wd_only);
+}
+static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin, int wd_only)
 {
     ezh_set *s = current_set(wd_only ? "c_ezwdint" : "c_ezuvint");
     if (!s) return -1;

@@ -989,7 +989,7 @@ def test_batch_of_32_full_size_fields_equals_single_calls_and_reference():
 
 def test_abort_and_rc_on_the_per_point_path_through_dev_entry_points():
     """a regional rotated (Z-on-E) source: the per-point path.  rc = 2 whenever target points lie outside the source
-    (ez_corrval.c:54-55) and extrap_degree=abort returns -1 (ez_corrval.c:56-60) -- also through the *_dev entry points,
+    (ez_corrval.c:54-55) and extrap_degree=abort returns -1 from the scalar calls (ez_corrval.c:56-60) -- also through the *_dev entry points,
     which do not go through ezhip_prepare_set."""
     case = CASES["ZEreg_to_L"]
     gdin = hip_define(case["src"]); gdout = hip_define(ec.dst_spec(case))
@@ -1007,7 +1007,15 @@ def test_abort_and_rc_on_the_per_point_path_through_dev_entry_points():
     try:
         assert ez.ezsint_dev(d_out, d_in) == -1
         assert ez.ezsint_batch_dev(d_out, d_in, 1) == -1
-        assert ez.ezuvint_dev(d_out, d_o2, d_u, d_v) == -1
+        # the winds: the reference's c_ezuvint ignores the -1 of its two c_ezsint calls (ezuvint.c:68-74 looks for 2 only) and returns 0 with the
+        # winds of the same call without the polar correction -- reproduced (tools/fuzz_vs_ref2.py compares it with the reference build)
+        assert ez.ezuvint_dev(d_out, d_o2, d_u, d_v) == 0
+        setopts(3, 0, "abort")
+        d_p = torch.empty_like(d_out); d_q = torch.empty_like(d_out)
+        assert ez.ezuvint_dev(d_p, d_q, d_u, d_v) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(d_p, d_out) and torch.equal(d_q, d_o2)
+        setopts(3, 1, "abort")
         rc, _ = ez.ezsint(zin, no * mo)
         assert rc == -1
     finally:
