@@ -130,6 +130,18 @@ for k in range(ncases):
     ez.ezsetopt("interp_degree", DEG[degree]); ez.ezsetopt("polar_correction", "yes" if polar else "no"); ez.ezsetopt("extrap_degree", extrap); ez.ezsetval("extrap_value", -3.5)
     rc, z = ez.ezsint(zin, no * mo)
     ran += 1
+    if os.environ.get("FUZZ_BATCH") and rc >= 0:          # c_ezsint_batch_dev on three fields against three single calls, bit for bit
+        import torch
+        fields = np.stack([zin, (zin * np.float32(1.01)).astype(np.float32), (zin + np.float32(1.0)).astype(np.float32)])
+        d_in = torch.from_numpy(fields).cuda(); d_out = torch.full((3, no * mo), float("nan"), dtype=torch.float32, device="cuda")
+        ez.use_stream(torch.cuda.current_stream().cuda_stream)
+        rcb = ez.ezsint_batch_dev(d_out, d_in, 3); torch.cuda.synchronize()
+        ez.use_stream(0)
+        ob = d_out.cpu().numpy()
+        for f in range(3):
+            rc1, z1 = ez.ezsint(fields[f], no * mo)
+            if rcb != rc1 or not np.array_equal(ob[f].view(np.uint32), z1.view(np.uint32)):
+                bad += 1; print("MISMATCH batch vs single calls, field", f, "rc", rcb, rc1, int((ob[f].view(np.uint32) != z1.view(np.uint32)).sum()), "points", dict(src=(sk,) + gs[:5], dst=(dk,) + gd[:5], degree=degree, polar=polar, extrap=extrap), flush=True); break
     why = ""
     # far outside a polar-stereographic source the reference's cubic extrapolation overflows: the same +-inf / NaN must come out at the same points
     def same_nonfinite(a, b):
