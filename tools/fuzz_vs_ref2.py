@@ -70,6 +70,9 @@ def make_grid(kind):
         if kind == "Ahem": nj //= 2
         if kind == "Bhem": nj = nj // 2 + 1
         return ni, nj, t, ig, " ", None, None
+    if kind == "E":                 # regular rotated grid (as a source only without the polar correction: the reference dereferences a NULL ay there)
+        nj = int(rng.integers(12, 50)); ni = 2 * nj + 1
+        return ni, nj, "E", rot_ig(), " ", None, None
     if kind == "Ycloud":            # a cloud of points ('Y' on L, ax = longitudes, ay = latitudes), incl. the poles and the seam
         ni = int(rng.integers(5, 60)); nj = int(rng.integers(3, 40)); n = ni * nj
         lon = rng.uniform(0, 360, n); lat = np.degrees(np.arcsin(rng.uniform(-1, 1, n)))
@@ -95,6 +98,7 @@ SRC = ["ZEglob", "ZEreg", "ZLglob", "ZLreg", "N", "S", "G", "A", "Lglob", "Lreg"
 DST = ["Lglob", "Lreg", "ZLreg", "ZLglob", "ZEreg", "ZEglob", "G", "N", "S", "Ycloud"]
 if os.environ.get("FUZZ_HEMI"):          # hemispheric / y-inverted A B G on either side (winds from such SOURCES are outside the product's scope: scalars only there)
     SRC += ["Ghem", "Ginv", "Ahem", "B", "Binv", "Ainv", "Bhem"] * 2; DST += ["Ginv", "Binv", "Ainv", "B", "Ghem", "Ahem", "Bhem"] * 2
+if os.environ.get("FUZZ_E"): SRC += ["E"] * 4; DST += ["E"] * 2
 NOWIND_SRC = ("Ghem", "Ginv", "Ahem", "Binv", "Ainv", "Bhem")
 bad = ran = near = overflow = 0
 for k in range(ncases):
@@ -104,12 +108,13 @@ for k in range(ncases):
     ni, nj = gs[0], gs[1]; no, mo = gd[0], gd[1]
     polar = int(rng.integers(0, 2)); degree = int(rng.choice([0, 1, 3])); extrap = str(rng.choice(["maximum", "minimum", "value", "nearest", "linear", "cubic", "abort"], p=[0.16, 0.15, 0.15, 0.15, 0.15, 0.12, 0.12]))
     if extrap == "cubic" and degree != 3: extrap = "value"
+    if sk == "E": polar = 0
     zin = ec.synth_field(ni, nj, seed=int(rng.integers(1 << 30)))
     uu, vv = ec.synth_wind(ni, nj, seed=int(rng.integers(1 << 30)))
-    if sk in ("ZEglob", "B", "Binv", "Bhem"):
+    if sk in ("ZEglob", "B", "Binv", "Bhem", "E"):
         for a in (zin, uu, vv):
             z2 = a.reshape(nj, ni); z2[:, -1] = z2[:, 0]
-    winds_on = sk not in NOWIND_SRC
+    winds_on = sk not in NOWIND_SRC and dk != "E"          # winds to a regular 'E' target: the reference reads uninitialised memory (refused by the product)
     gr_in = define(True, gs); gr_out = define(True, gd)
     if gr_in < 0 or gr_out < 0: continue
     for name, val in (("interp_degree", DEG[degree]), ("polar_correction", "yes" if polar else "no"), ("extrap_degree", extrap)):
@@ -173,6 +178,9 @@ for k in range(ncases):
         if gs[4] == "E":
             xs = np.zeros(no * mo, np.float32); ys = xs.copy(); R.c_gdxyfll(gr_in, fp(xs), fp(ys), fp(lat_t), fp(lon_t), no * mo)
             worst = np.maximum(worst, np.abs(np.interp(ys.astype(np.float64), np.arange(1, nj + 1), gs[6].astype(np.float64), left=90.0, right=90.0)))
+        if gs[2] == "E":                                            # a regular rotated source: its own latitude at the target points
+            xs = np.zeros(no * mo, np.float32); ys = xs.copy(); R.c_gdxyfll(gr_in, fp(xs), fp(ys), fp(lat_t), fp(lon_t.copy()), no * mo)
+            worst = np.maximum(worst, np.minimum(np.abs(-90.0 + (ys.astype(np.float64) - 0.5) * 180.0 / nj), 90.0))
         allowed = 1e-5 + 8 * 6e-8 / np.maximum(np.cos(np.radians(np.minimum(worst[idx], 89.9999))), 1e-7)
         if rcv != rcv_r: why = f"wind rc {rcv} vs {rcv_r}"
         elif rcv_r < 0: pass
