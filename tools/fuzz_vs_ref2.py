@@ -70,6 +70,9 @@ def make_grid(kind):
         if kind == "Ahem": nj //= 2
         if kind == "Bhem": nj = nj // 2 + 1
         return ni, nj, t, ig, " ", None, None
+    if kind in ("tileE", "tileL"):  # a regional '#' tile defined from memory: the 'Z' grid of the same axes under another name
+        g = make_grid("ZEreg" if kind == "tileE" else "ZLreg")
+        return g[0], g[1], "#", g[3], g[4], g[5], g[6]
     if kind == "E":                 # regular rotated grid (as a source only without the polar correction: the reference dereferences a NULL ay there)
         nj = int(rng.integers(12, 50)); ni = 2 * nj + 1
         return ni, nj, "E", rot_ig(), " ", None, None
@@ -98,7 +101,7 @@ SRC = ["ZEglob", "ZEreg", "ZLglob", "ZLreg", "N", "S", "G", "A", "Lglob", "Lreg"
 DST = ["Lglob", "Lreg", "ZLreg", "ZLglob", "ZEreg", "ZEglob", "G", "N", "S", "Ycloud"]
 if os.environ.get("FUZZ_HEMI"):          # hemispheric / y-inverted A B G on either side (winds from such SOURCES are outside the product's scope: scalars only there)
     SRC += ["Ghem", "Ginv", "Ahem", "B", "Binv", "Ainv", "Bhem"] * 2; DST += ["Ginv", "Binv", "Ainv", "B", "Ghem", "Ahem", "Bhem"] * 2
-if os.environ.get("FUZZ_E"): SRC += ["E"] * 4; DST += ["E"] * 2
+if os.environ.get("FUZZ_E"): SRC += ["E"] * 4 + ["tileE", "tileL"] * 2; DST += ["E"] * 2 + ["tileE", "tileL"]
 NOWIND_SRC = ("Ghem", "Ginv", "Ahem", "Binv", "Ainv", "Bhem")
 bad = ran = near = overflow = 0
 for k in range(ncases):
