@@ -96,12 +96,18 @@ int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields);
  * min/max pass fused into the interpolation.  -2: the plan has no single-launch path (use c_ezsint_batch_dev). */
 int32_t ezhip_ezsint_batch_minmax_dev(float *d_zout, const float *d_zin, int32_t nfields, uint32_t *d_partials,
                                       int64_t stride_words, int32_t *partials_per_field);
+/* the same extrema WITHOUT interpolating: bounds of every source window, exact evaluation of the few windows that can hold the extremum
+ * (librmn_amd/csrc/ez_kernels.hip, k_bb_*).  One triple per field; d_flags[f] (device) = 1: no valid triple for field f (too many windows
+ * qualify), use ezhip_ezsint_batch_minmax_only_dev for it.  -2: not applicable to the current grid set */
+int32_t ezhip_ezsint_batch_minmax_bb_dev(const float *d_zin, int32_t nfields, uint32_t *d_partials, int64_t stride_words, int32_t *partials_per_field, int32_t *d_flags);
 /* the two interpolation passes of the fused cfg5 pipeline (packers_hip.h: ezhip_ezsint_pack16_compress_batch_dev): A stores
  * nothing and leaves only the min/max partials; B stores compact_float's 16-bit tokens (two per word, first in the high half)
  * quantised with the {double minF, double mulFactor} found at d_params + f * param_stride_bytes.  -2: not on the k_sepx path */
 int32_t ezhip_ezsint_batch_minmax_only_dev(const float *d_zin, int32_t nfields, uint32_t *d_partials, int64_t stride_words, int32_t *partials_per_field);
 int32_t ezhip_ezsint_batch_tokens_dev(uint32_t *d_tokens, int64_t token_stride_words, const float *d_zin, int32_t nfields,
                                       const void *d_params, int64_t param_stride_bytes);
+/* dimensions of the current grid set (the pair of c_ezdefset): -1 when none is defined */
+int32_t ezhip_current_set_dims(int32_t *ni_in, int32_t *nj_in, int32_t *ni_out, int32_t *nj_out);
 /* forces plan construction for the current set / options (what the reference does lazily in its first call) */
 int32_t ezhip_prepare_set(void);
 /* which kernel family the current set uses: 1 = separable (k_sepx, or its fallback k_sep), 2 = per-point (k_pts) */

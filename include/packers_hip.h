@@ -31,7 +31,9 @@ int compact_integer(void *unpackedArrayOfInt, void *packedHeader, void *packedAr
 void *compact_double(void *unpackedArrayOfFloat, void *packedHeader, void *packedArrayOfInt, const int elementCount,
                      const int packedTokenBitSize, const int offset, const int stride, const int opCode,
                      const int hasMissing, const void *const missingTag);
-/* src/packers/compact_integer.c:592 (opCode 5 = pack, 6 = unpack unsigned short) and :830 (opCode 9 = pack, 10 = unpack unsigned char) */
+/* src/packers/compact_integer.c:592 (opCode 5 = pack, 6 = unpack unsigned short) and :830 (opCode 9 = pack, 10 = unpack unsigned char).
+ * Any other opCode -- including the signed 7 / 8 and 11 / 12 named by a branch of fstd98.c that is not compiled (fstd98.c:22) -- prints
+ * "opCode (%d) is not defined" and returns 0, as in the reference (:797-816, :1034-1053). */
 int compact_short(void *unpackedArrayOfShort, void *packedHeader, void *packedArrayOfInt, int elementCount,
                   int bitSizeOfPackedToken, int off_set, int stride, int opCode);
 int compact_char(void *unpackedArrayOfBytes, void *packedHeader, void *packedArrayOfInt, int elementCount,

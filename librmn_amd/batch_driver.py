@@ -11,6 +11,12 @@ from typing import Callable, Dict, List, Sequence
 from . import sharding as sh
 
 
+def record_stride_words(npts_out: int) -> int:
+    """words of one cfg5 record buffer: 4 compact_float header words + the 16-bit tokens (or the armn_compress stream that
+    replaces them) + slack.  The one definition the drivers and their verifiers share."""
+    return 4 + (npts_out + 1) // 2 + 64
+
+
 class HipBackend:
     """the MI355X path: fields are torch CUDA tensors, calls go through the C ABI on the current stream"""
 
@@ -47,10 +53,19 @@ class HipBackend:
         t = self.torch
         assert self.ez.ezdefset(h["gdout"], h["gdin"]) == 1
         d_in = t.stack(list(fields)).contiguous()
-        rs = 4 + h["nout"] // 2 + 16
+        rs = record_stride_words(h["nout"])
         rec = t.zeros((len(fields), rs), dtype=t.int32, device=self.device)
         rc, zl = self.pk.ezsint_pack16_compress_batch_dev(rec, rs, d_in, len(fields), h["ni_out"], h["nj_out"], nbits)
-        assert rc == 0, rc
+        if rc == -2:
+            # the fused call does not apply to this grid pair / shape (odd ni, nbits < 5, a set off the single-launch path, ...):
+            # the unfused entry points produce the same records (include/packers_hip.h)
+            d_out = t.empty((len(fields), h["nout"]), dtype=t.float32, device=self.device)
+            rc = self.ez.ezsint_batch_dev(d_out, d_in, len(fields))
+            if rc < 0:
+                raise RuntimeError(f"c_ezsint_batch_dev failed ({rc}) for grid set {h['gdin']} -> {h['gdout']}")
+            rc, zl = self.pk.pack16_compress_batch_dev(rec, rs, d_out, h["nout"], len(fields), h["ni_out"], h["nj_out"], nbits, prepacked=0)
+        if rc < 0:
+            raise RuntimeError(f"interp + pack16 + armn_compress failed ({rc}) for grid set {h['gdin']} -> {h['gdout']}, nbits {nbits}")
         return [rec[k] for k in range(len(fields))], [int(z) for z in zl]
 
     def checksum(self, x, nbytes: int = -1) -> int:

@@ -20,7 +20,7 @@
 
 static int need_dev32(const char *who)
 {
-    if (ezhip_runtime_ok()) return 0;
+    if (ezhip_runtime_ok()) return ezhip_bound_device_ok(who);
     fprintf(stderr, "<%s> no usable HIP device: the MI355X packer path has no CPU fallback\n", who);
     return -1;
 }
@@ -211,7 +211,7 @@ int c_armn_compress32(unsigned char *zstream, float *fld, int ni, int nj, int nk
 }
 
 /* bit position of every tile header of a parallelogram stream (host words): 3-bit width-field size, row 1, column 1, then the chain */
-static uint64_t *walk_tiles(const uint32_t *z, int ni, int nj, int nbits, size_t *ntiles_out)
+static uint64_t *walk_tiles(const uint32_t *z, int ni, int nj, int nbits, size_t *ntiles_out, uint64_t max_bits)
 {
     uint64_t pos = 0;
     const int container = (int)br32_get(z, &pos, 3);
@@ -225,12 +225,14 @@ static uint64_t *walk_tiles(const uint32_t *z, int ni, int nj, int nbits, size_t
         for (int tx = 0; tx < ntx; tx++, t++) {
             const int tm = ni - (1 + 3 * tx) < 3 ? ni - (1 + 3 * tx) : 3;
             tp[t] = pos;
+            if (pos + 8 > max_bits) { free(tp); return NULL; }          /* a truncated or corrupt record: the chain left the stream */
             uint64_t p2 = pos;
             const int need = (int)br32_get(z, &p2, container);
             pos += (uint64_t)container + (need ? (uint64_t)(tm * tn) * (uint64_t)(need + 1) : 0);
         }
     }
     tp[t] = pos;
+    if (pos > max_bits) { free(tp); return NULL; }
     *ntiles_out = t;
     return tp;
 }
@@ -250,8 +252,8 @@ static int decode_plane(int *d_plane, const uint32_t *z, const uint64_t *tp, siz
 }
 
 /* the three sequential host walks of a stream (sign run lengths, exponent tile chain, mantissa tile chain) are independent: one thread each */
-typedef struct { const uint32_t *z; int ni, nj, nbits; uint64_t *tp; size_t ntiles; } walk_job;
-static void *walk_thread(void *a) { walk_job *j = (walk_job *)a; j->tp = walk_tiles(j->z, j->ni, j->nj, j->nbits, &j->ntiles); return NULL; }
+typedef struct { const uint32_t *z; int ni, nj, nbits; uint64_t *tp; size_t ntiles; uint64_t max_bits; } walk_job;
+static void *walk_thread(void *a) { walk_job *j = (walk_job *)a; j->tp = walk_tiles(j->z, j->ni, j->nj, j->nbits, &j->ntiles, j->max_bits); return NULL; }
 typedef struct { const uint32_t *z; uint32_t *mask; int npts; } rle_job;
 static void *rle_thread(void *a) { rle_job *j = (rle_job *)a; rle_decode(j->mask, j->z, j->npts); return NULL; }
 
@@ -269,18 +271,24 @@ int c_armn_uncompress32_dev(float *d_fld, const unsigned char *zstream, int ni, 
     const uint32_t exp_min = info >> 16, need_e = (info >> 8) & 0xFF, codes = info & 0xFF;
     const int code_signe = (int)(codes & 0x30), code_expo = (int)(codes & 0xC), code_mant = (int)(codes & 0x3);
     if (code_mant != 0) { fprintf(stderr, "<c_armn_uncompress32> plain mantissa streams are not produced by c_armn_compress32\n"); return -1; }
+    /* header fields a record of c_armn_compress32 can hold (armn_compress_32.c:143-145, :96-99): anything else is a corrupt record */
+    if (need_e > 8 || nbits < 1 || nbits > 23) { fprintf(stderr, "<c_armn_uncompress32> broken stream (exponent width %u, mantissa width %d)\n", need_e, nbits); return -1; }
+    /* no stream of c_armn_compress32 is longer than the field it replaces (:240-247): every length read from the record is held to that */
+    const uint64_t max_words = (uint64_t)n + 64;
     unsigned *d_smask = (unsigned *)w32(2, 4 * (n / 32 + 2) + 16);
     int *d_expo = (int *)w32(0, 4 * n + 16), *d_mant = (int *)w32(1, 4 * n + 16);
     if (!d_smask || !d_expo || !d_mant) return -1;
     /* the three sub-streams: [lng, sign run lengths] [lng, exponent plane] [slot, mantissa plane] */
     const int have_s = code_signe == 0x20 || code_signe == 0x30, have_e = code_expo == 0x08 || code_expo == 0x0C;
     const uint32_t *z_s = NULL, *z_e = NULL, *z_m;
-    if (have_s) { const uint32_t lng = *cur++; z_s = cur; cur += lng >> 2; }
-    if (have_e) { const uint32_t lng = *cur++; z_e = cur; cur += lng >> 2; }
+    if (have_s) { const uint32_t lng = *cur++; if ((uint64_t)(lng >> 2) > max_words) goto broken; z_s = cur; cur += lng >> 2; }
+    if (have_e) { const uint32_t lng = *cur++; if ((uint64_t)(cur - (const uint32_t *)zstream) + (lng >> 2) > max_words) goto broken; z_e = cur; cur += lng >> 2; }
     cur++;                                                       /* the mantissa length slot */
     z_m = cur;
     rle_job rj = { z_s, NULL, (int)n };
-    walk_job we = { z_e, ni, nj, (int)need_e, NULL, 0 }, wm = { z_m, ni, nj, nbits, NULL, 0 };
+    const uint64_t used_words = (uint64_t)(cur - (const uint32_t *)zstream);
+    walk_job we = { z_e, ni, nj, (int)need_e, NULL, 0, have_e ? 32ull * (uint64_t)(z_m - 1 - z_e) : 0 };
+    walk_job wm = { z_m, ni, nj, nbits, NULL, 0, 32ull * (max_words > used_words ? max_words - used_words : 0) };
     pthread_t th_s, th_e;
     int run_s = 0, run_e = 0, rc = -1;
     if (have_s) {
@@ -293,7 +301,7 @@ int c_armn_uncompress32_dev(float *d_fld, const unsigned char *zstream, int ni, 
     walk_thread(&wm);                                            /* this thread walks the longest chain */
     if (run_e) pthread_join(th_e, NULL);
     if (run_s) pthread_join(th_s, NULL);
-    if ((have_e && !we.tp) || !wm.tp) goto out;
+    if ((have_e && !we.tp) || !wm.tp) { fprintf(stderr, "<c_armn_uncompress32> broken stream (a tile chain leaves the record)\n"); goto out; }
     if (have_s && (ezhip_h2d(d_smask, rj.mask, 4 * (n / 32 + 1)) || ezhip_sync())) goto out;
     if (have_e && decode_plane(d_expo, z_e, we.tp, we.ntiles, ni, nj, (int)need_e, 0, 3)) goto out;
     if (decode_plane(d_mant, z_m, wm.tp, wm.ntiles, ni, nj, nbits, 1, 3)) goto out;
@@ -302,6 +310,9 @@ int c_armn_uncompress32_dev(float *d_fld, const unsigned char *zstream, int ni, 
 out:
     free(rj.mask); free(we.tp); free(wm.tp);
     return rc;
+broken:
+    fprintf(stderr, "<c_armn_uncompress32> broken stream (a sub-stream length exceeds the field)\n");
+    return -1;
 }
 
 int c_armn_uncompress32(float *fld, unsigned char *zstream, int ni, int nj, int nk, int znbits)

@@ -41,7 +41,7 @@ typedef struct {            /* src/interp/ez_def.h:225-243, defaults src/interp/
 typedef struct {            /* one compiled separable plan: device tables + the descriptor */
     int built;
     ezhip_sep_plan p;
-    void *dev[24];          /* owned device allocations */
+    void *dev[32];          /* owned device allocations */
     /* host copy of the k_sepx row geometry (host-pointer ABI, sepx_host_chunks): per valid row-block its 16-row target block and the end of
      * its source window; per target row the special flag */
     int h_nvb, *h_vb_by, *h_vb_send;
@@ -631,7 +631,7 @@ int32_t c_ezqkdef(int32_t ni, int32_t nj, char *grtyp, int32_t ig1, int32_t ig2,
 
 static void free_sepplan(ezh_sepplan *sp)
 {
-    for (int k = 0; k < 24; k++) { ezhip_free(sp->dev[k]); sp->dev[k] = NULL; }
+    for (int k = 0; k < 32; k++) { ezhip_free(sp->dev[k]); sp->dev[k] = NULL; }
     free(sp->h_vb_by); free(sp->h_vb_send); free(sp->h_rflag);
     sp->h_vb_by = sp->h_vb_send = NULL; sp->h_rflag = NULL; sp->h_nvb = 0;
     sp->built = 0;
@@ -978,7 +978,7 @@ static int dev_fail(const char *what)
 }
 static int need_device(const char *who)
 {
-    if (ezhip_runtime_ok()) return 0;
+    if (ezhip_runtime_ok()) return ezhip_bound_device_ok(who);
     fprintf(stderr, "<%s> no usable HIP device: the MI355X interpolation path has no CPU fallback\n", who);
     return -1;
 }
@@ -1385,6 +1385,90 @@ static void build_sepx_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, int degree, 
     free(first); free(cont); free(xr); free(vb); free(wa); free(wn);
 }
 
+/* Tables of the exact-extrema pass (ezhip_sep_plan.bb_*, k_bb_* in ez_kernels.hip): which source windows hold target points, and which.
+ * A value of the separable kernels is sum_j wy_j (sum_k wx_k z_jk) over ntap x ntap source points -- the WINDOW named by its first source column
+ * (modulo ni: the longitude seam) and first source row.  Not built (bb_ok = 0) for vector plans, DEHORS columns / fill rows, taps that are not
+ * consecutive, or windows that leave the source rows. */
+static void build_bb_tables(ezh_sepplan *sp, ezhip_sep_plan *p, const ezh_grid *gi, int degree, int ntap, int nic, int njr, const int *cidx, const double *cw,
+                            const unsigned char *cflag, const int *rbase, const double *rw, const unsigned char *rflag,
+                            const ezhip_special_row *special, int nspecial, int vector_mode)
+{
+    p->bb_ok = 0; p->bb_ntap = ntap;
+    if (vector_mode || getenv("EZHIP_NO_BB")) return;
+    const int nis = gi->ni, njs = gi->nj;
+    if (nis < ntap + 3 || njs < ntap) return;
+    for (int c = 0; c < nic; c++) {
+        if (cflag[c]) return;
+        if (cidx[c] < 0 || cidx[c] >= nis) return;
+        for (int k = 1; k < ntap; k++) if (cidx[k * nic + c] != (cidx[c] + k) % nis) return;
+    }
+    for (int k = 0; k < nspecial; k++) if (special[k].kind == 3) return;
+    int nmain = 0;
+    for (int r = 0; r < njr; r++) {
+        if (rflag[r]) continue;
+        if (rbase[r] < 0 || rbase[r] + ntap > njs) return;
+        nmain++;
+    }
+    /* K = max sum |wx| * max sum |wy|; sdev bounds |sum wx * sum wy - 1| (cubic: the weights are the reference's Newton form evaluated on
+     * unit vectors; their sum is 1 up to REAL*8 rounding) */
+    double kx = 1.0, ky = 1.0, dx = 0.0, dy = 0.0;
+    float *colk = (float *)malloc(sizeof(float) * (size_t)nis), *rowk = (float *)malloc(sizeof(float) * (size_t)njs);
+    if (!colk || !rowk) { free(colk); free(rowk); return; }
+    for (int i = 0; i < nis; i++) colk[i] = 1.0f;
+    for (int j = 0; j < njs; j++) rowk[j] = 1.0f;
+    for (int c = 0; c < nic; c++) {
+        double sa = 0.0, sm = 0.0;
+        if (degree == DEG_CUBIC) for (int k = 0; k < 4; k++) { sa += fabs(cw[k * nic + c]); sm += cw[k * nic + c]; }
+        else if (degree == DEG_LINEAR) { sa = fabs(1.0 - cw[c]) + fabs(cw[c]); sm = 1.0; }
+        else { sa = 1.0; sm = 1.0; }
+        if (!(sa <= 1.0e6)) { free(colk); free(rowk); return; }                           /* NaN / absurd weights: no bound */
+        if (sa > kx) kx = sa;
+        { float k = nextafterf((float)sa, INFINITY); if (k > colk[cidx[c]]) colk[cidx[c]] = k; }
+        if (fabs(sm - 1.0) > dx) dx = fabs(sm - 1.0);
+    }
+    for (int r = 0; r < njr; r++) {
+        if (rflag[r]) continue;
+        double sa = 0.0, sm = 0.0;
+        if (degree == DEG_CUBIC) for (int k = 0; k < 4; k++) { sa += fabs(rw[k * njr + r]); sm += rw[k * njr + r]; }
+        else if (degree == DEG_LINEAR) { sa = fabs(1.0 - rw[r]) + fabs(rw[r]); sm = 1.0; }
+        else { sa = 1.0; sm = 1.0; }
+        if (!(sa <= 1.0e6)) { free(colk); free(rowk); return; }
+        if (sa > ky) ky = sa;
+        { float k = nextafterf((float)sa, INFINITY); if (k > rowk[rbase[r]]) rowk[rbase[r]] = k; }
+        if (fabs(sm - 1.0) > dy) dy = fabs(sm - 1.0);
+    }
+    const double K = kx * ky;
+    p->bb_a = 0.5 * (K - 1.0) * (1.0 + 1.0e-12) + 1.0e-12;
+    p->bb_s = (dx + dy + dx * dy) * kx * ky + K * 64.0 * 2.220446049250313e-16 + 1.0e-13;
+    unsigned char *colhas = (unsigned char *)calloc((size_t)nis, 1), *rowhas = (unsigned char *)calloc((size_t)njs, 1);
+    int *colstart = (int *)calloc((size_t)nis + 1, sizeof(int)), *rowstart = (int *)calloc((size_t)njs + 1, sizeof(int));
+    int *collist = (int *)malloc(sizeof(int) * (size_t)(nic > 0 ? nic : 1)), *rowlist = (int *)malloc(sizeof(int) * (size_t)(nmain > 0 ? nmain : 1));
+    if (colhas && rowhas && colstart && rowstart && collist && rowlist) {
+        for (int c = 0; c < nic; c++) { colhas[cidx[c]] = 1; colstart[cidx[c] + 1]++; }
+        for (int i = 0; i < nis; i++) colstart[i + 1] += colstart[i];
+        int *fill = (int *)calloc((size_t)(nis > njs ? nis : njs), sizeof(int));
+        if (fill) {
+            for (int c = 0; c < nic; c++) collist[colstart[cidx[c]] + fill[cidx[c]]++] = c;
+            memset(fill, 0, sizeof(int) * (size_t)(nis > njs ? nis : njs));
+            for (int r = 0; r < njr; r++) if (!rflag[r]) { rowhas[rbase[r]] = 1; rowstart[rbase[r] + 1]++; }
+            for (int j = 0; j < njs; j++) rowstart[j + 1] += rowstart[j];
+            for (int r = 0; r < njr; r++) if (!rflag[r]) rowlist[rowstart[rbase[r]] + fill[rbase[r]]++] = r;
+            free(fill);
+            p->bb_colhas = (const unsigned char *)(sp->dev[24] = upload(colhas, (size_t)nis));
+            p->bb_rowhas = (const unsigned char *)(sp->dev[25] = upload(rowhas, (size_t)njs));
+            p->bb_colstart = (const int *)(sp->dev[26] = upload(colstart, sizeof(int) * ((size_t)nis + 1)));
+            p->bb_collist = (const int *)(sp->dev[27] = upload(collist, sizeof(int) * (size_t)(nic > 0 ? nic : 1)));
+            p->bb_rowstart = (const int *)(sp->dev[28] = upload(rowstart, sizeof(int) * ((size_t)njs + 1)));
+            p->bb_rowlist = (const int *)(sp->dev[29] = upload(rowlist, sizeof(int) * (size_t)(nmain > 0 ? nmain : 1)));
+            p->bb_colk = (const float *)(sp->dev[30] = upload(colk, sizeof(float) * (size_t)nis));
+            p->bb_rowk = (const float *)(sp->dev[31] = upload(rowk, sizeof(float) * (size_t)njs));
+            p->bb_ok = sp->dev[24] && sp->dev[25] && sp->dev[26] && sp->dev[27] && sp->dev[28] && sp->dev[29] && sp->dev[30] && sp->dev[31];
+            ezhip_sync();
+        }
+    }
+    free(colhas); free(rowhas); free(colstart); free(rowstart); free(collist); free(rowlist); free(colk); free(rowk);
+}
+
 static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
 {
     if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return -1;
@@ -1522,6 +1606,7 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
     build_sepx_geometry(sp, p, degree, ntap, nbx, nic, njr, blk_base, rbase, rw, rflag);
     p->pole_weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
     p->vector_mode = vector_mode;
+    build_bb_tables(sp, p, gi, degree, ntap, nic, njr, cidx, cw, cflag, rbase, rw, rflag, special, nspecial, vector_mode);
     ezhip_sync();
     int ok = 1;
     for (int k = 0; k < 15; k++) ok &= (sp->dev[k] != NULL);
@@ -2212,6 +2297,58 @@ int32_t ezhip_ezsint_batch_minmax_only_dev(const float *d_zin, int32_t nfields, 
     batch_out bo = {2, NULL, 0, 0};
     return batch_impl_o(NULL, d_zin, nfields, d_partials, (size_t)stride_words, partials_per_field, &bo);
 }
+/* cfg5 pipeline, pass A without interpolating (k_bb_*, ez_kernels.hip): the exact {min key, max key, 0} of the values c_ezsint would produce for
+ * each of nfields source fields, left in d_partials[f * stride_words + 0..2] (*partials_per_field = 1).  d_flags[f] (device) := 1 for a field in
+ * which too many source windows can hold the extremum: its triple is NOT valid and the caller runs ezhip_ezsint_batch_minmax_only_dev for it.
+ * Asynchronous.  -2: the plan of the current grid set has no bound tables (not on the k_sepx path, vector plan, extrapolation, ...). */
+static __thread struct { void *p; size_t cap; } t_bbws;
+int32_t ezhip_ezsint_batch_minmax_bb_dev(const float *d_zin, int32_t nfields, uint32_t *d_partials, int64_t stride_words, int32_t *partials_per_field, int32_t *d_flags)
+{
+    if (!d_partials || stride_words < 3 || !d_flags || nfields < 1) return -1;
+    ezh_set *s = current_set("ezhip_ezsint_batch_minmax_bb_dev");
+    if (!s) return -1;
+    if (need_device("ezhip_ezsint_batch_minmax_bb_dev") || device_error("ezhip_ezsint_batch_minmax_bb_dev")) return -1;
+    if (G[s->gdin].grtyp == 'U' || G[s->gdout].grtyp == 'U' || s->gdin == s->gdout) return -2;
+    if ((O.polar_correction == 1 && s->extrap) || grid_yinv(&G[s->gdin])) return -2;
+    if (!(O.degre_interp == DEG_NEAREST || O.degre_interp == DEG_LINEAR || O.degre_interp == DEG_CUBIC)) return -2;
+    if (choose_mode(s, O.degre_interp, O.polar_correction == 1) != 1 || getenv("EZHIP_NO_BATCH_LAUNCH") || getenv("EZHIP_NO_SEPX")) return -2;
+    const int degree = O.degre_interp, polar = O.polar_correction == 1;
+    if (ensure_scratch(s)) return -1;
+    pthread_mutex_lock(&g_plan_mtx);
+    int brc = build_sep_plan(s, degree, 0, polar);
+    ezhip_sep_plan p = s->sep[degree == DEG_CUBIC ? 2 : degree][0].p;
+    pthread_mutex_unlock(&g_plan_mtx);
+    if (brc) return -1;
+    if (p.x_nseg <= 0 || !p.bb_ok) return -2;
+    ezh_grid *gi = &G[s->gdin];
+    const size_t nin = (size_t)gi->ni * gi->nj;
+    p.fill = t_scratch8;
+    if (p.pole_weighted) { if (ensure_grid_dev(gi)) return -1; p.ax = gi->d_ax; }
+    const size_t wb = ezhip_bb_work_bytes(&p, nfields);
+    if (t_bbws.cap < wb) {
+        if (t_bbws.p) { ezhip_sync(); ezhip_free(t_bbws.p); }
+        t_bbws.p = ezhip_malloc(wb + wb / 4); t_bbws.cap = t_bbws.p ? wb + wb / 4 : 0;
+        if (!t_bbws.p) return -1;
+    }
+    const float *d_poles = NULL;
+    int side = 0;
+    if (p.need_poles && p.n_special > 0) {
+        /* the pole values (a sequential REAL sum per pole row: ~25 us on one lane) are only read by the special rows at the end: side stream */
+        if (ensure_batch_poles(s, nfields)) return -1;
+        if (ezhip_side_begin()) return -1;
+        side = 1;
+        int bad = ezhip_polevals_batch(s->d_poles_batch, d_zin, nin, nfields, gi->ni, gi->nj, p.pole_weighted, p.ax);
+        if (ezhip_side_end() || bad) { ezhip_side_join(); return -1; }
+        d_poles = s->d_poles_batch;
+    }
+    int rc = ezhip_minmax_bb(&p, d_zin, nin, nfields, d_partials, (size_t)stride_words, d_flags, d_poles, t_bbws.p);
+    if (side && ezhip_side_join()) return -1;
+    if (rc) return rc == -2 ? -2 : -1;
+    if (ezhip_minmax_bb_special(&p, d_zin, nin, nfields, d_partials, (size_t)stride_words, d_flags, d_poles, t_bbws.p)) return -1;
+    if (partials_per_field) *partials_per_field = 1;
+    return 0;
+}
+
 /* cfg5 pipeline, pass B: interpolate again and leave compact_float's 16-bit tokens of every value (two per word, first in the
  * high half: the layout armn_compress consumes), quantised with the {minF, mulFactor} at d_params + f * param_stride_bytes */
 int32_t ezhip_ezsint_batch_tokens_dev(uint32_t *d_tokens, int64_t token_stride_words, const float *d_zin, int32_t nfields,
@@ -2220,6 +2357,17 @@ int32_t ezhip_ezsint_batch_tokens_dev(uint32_t *d_tokens, int64_t token_stride_w
     if (!d_tokens || !d_params) return -1;
     batch_out bo = {3, d_params, (size_t)param_stride_bytes, (size_t)token_stride_words};
     return batch_impl_o((float *)d_tokens, d_zin, nfields, NULL, 0, NULL, &bo);
+}
+
+/* dimensions of the current grid set (c_ezdefset): what the batch launches read and write per field.  -1 without a set */
+int32_t ezhip_current_set_dims(int32_t *ni_in, int32_t *nj_in, int32_t *ni_out, int32_t *nj_out)
+{
+    if (cur_gdin < 0 || cur_gdout < 0 || !grid_ok(cur_gdin) || !grid_ok(cur_gdout)) return -1;
+    if (ni_in) *ni_in = G[cur_gdin].ni;
+    if (nj_in) *nj_in = G[cur_gdin].nj;
+    if (ni_out) *ni_out = G[cur_gdout].ni;
+    if (nj_out) *nj_out = G[cur_gdout].nj;
+    return 0;
 }
 
 int32_t ezhip_prepare_set(void)

@@ -52,6 +52,28 @@ extern "C" int ezhip_runtime_ok(void)
     return n > 0;
 }
 extern "C" const char *ezhip_last_error(void) { return g_err; }
+/* One process per GPU: grids' device mirrors, plans, located points and the per-thread workspaces are plain device pointers of the device that
+ * was current when the library first touched the GPU.  A thread that comes in with ANOTHER current device would hand those pointers to kernels
+ * of its own device; every compute entry point checks (need_device) and refuses loudly instead.  EZHIP_TEST_BOUND_DEVICE: tests only. */
+#include <atomic>
+static std::atomic<int> g_bound_dev{-1};
+extern "C" int ezhip_bound_device_ok(const char *who)
+{
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    int bound = g_bound_dev.load(std::memory_order_acquire);
+    if (bound < 0) {
+        const char *e = getenv("EZHIP_TEST_BOUND_DEVICE");
+        int want = e ? atoi(e) : d, expected = -1;
+        bound = g_bound_dev.compare_exchange_strong(expected, want, std::memory_order_acq_rel) ? want : expected;
+    }
+    if (bound == d) return 0;
+    fprintf(stderr, "<%s> the library's grids, plans and workspaces of this process live on HIP device %d, but the calling thread's current device is %d: "
+                    "one process per GPU (select the device before the first call and keep it)\n", who, bound, d);
+    return -1;
+}
+extern "C" int ezhip_bound_device(void) { return g_bound_dev.load(std::memory_order_acquire); }
+
 extern "C" void *ezhip_malloc(size_t nbytes)
 {
     void *p = nullptr;
@@ -1114,6 +1136,402 @@ extern "C" int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const
     default: snprintf(g_err, sizeof(g_err), "ezhip_interp_sep: bad degree %d", plan->degree); return -1;
     }
     return LAUNCH_CHECK("k_sep");
+}
+
+
+/* ===================================================================================== */
+/* exact extrema of the interpolated field WITHOUT interpolating it (cfg5 pipeline, pass A) */
+/* ===================================================================================== */
+/* compact_float needs the minimum and the maximum of the interpolated field before the first token can be formed
+ * (compact.tmplc:173-204); round 2 got them from a whole k_sepx pass that stored nothing (23 us per cfg2 field, bound by the
+ * REAL*8 arithmetic of 25.9 M points).  But a value of the separable kernels is sum_j wy_j (sum_k wx_k z_jk) over ONE window of
+ * ntap x ntap source points with sum w = 1: it cannot leave [wmin - a R, wmax + a R] of its window (R = wmax - wmin,
+ * a = (max sum |wx| * max sum |wy| - 1) / 2 = 0.28 for the cubic weights; + a rounding allowance, ezhip_sep_plan.bb_s).  So
+ *   k_bb_bounds  streams the SOURCE field once (9.7 M points instead of 25.9 M, min / max only): per window the interval, per tile of
+ *                252 x 32 windows its extremes, and the best GUARANTEED value L = max over windows that hold a target point of
+ *                their lower end (some value of the field is >= L), likewise U for the minimum;
+ *   k_bb_reduce  L, U of the field; how many tiles can still hold the extremum;
+ *   k_bb_eval    a window whose upper end is below L cannot hold the maximum (monotone float rounding keeps the order): only the
+ *                windows that reach L (or U) -- a few around the field's extremes -- have their target points evaluated, with
+ *                exactly the arithmetic of k_sep / k_sepx (same tables, same fma chains): the extrema are the ones the
+ *                interpolating pass finds, bit for bit (tests/test_gpu_packers.py);
+ *   k_bb_special the polar rows (special rows of the plan) are evaluated whole.
+ * Windows with a non-finite value are always evaluated.  A field where more than max_cand tiles qualify (no extremum stands out:
+ * a field of noise) is flagged instead and the caller runs the interpolating pass for it. */
+#define BB_TW 252          /* window columns of a strip: the 64 lanes of a wave hold 256 consecutive source columns */
+#define BB_TH 32           /* window rows of a tile (one wave sweeps them) */
+#define BB_TILE_F 8            /* floats per tile record */
+#define BB_LIST_CAP (1 << 18)   /* candidate windows per field; more: the field is handed back (flags) */
+struct bb_args {
+    ezhip_sep_plan p;
+    const float *zin; size_t in_stride; int nfields;
+    int ntx, nty;                    /* tiles per field */
+    float sf;                        /* bb_s rounded up to REAL with room for the REAL arithmetic of the bounds themselves */
+    float *tile;                     /* [nfields][nty * ntx][4]: max upper end, min lower end, max lower end (-> L), min upper end (-> U) over the tile's occupied windows */
+    unsigned *tile_bad;              /* [nfields][nty * ntx]: the tile holds a non-finite value: every window of it is evaluated, none contributes to L / U */
+    float *LU;                       /* [nfields][2] */
+    unsigned *count, *list;          /* [nfields], [nfields][BB_LIST_CAP]: windows to evaluate, i0 | j0 << 16 */
+    unsigned *keys; size_t key_stride;   /* [f * key_stride + 0..2] = {min key, max key, 0} */
+    int *flags; int max_cand, force_all, list_cap, exact_ok;
+    const float *poles;
+};
+
+/* One wave sweeps the windows [tx BB_TW, +BB_TW) x [ty BB_TH, +BB_TH) of field zf: visit(valid, i0, j0, ub, lb) in wave-uniform control flow for every
+ * window row that holds a target row; valid = the window holds a target column.  COARSE = false: four calls, the lane's four windows; COARSE = true: ONE
+ * call for the lane's four windows together (the extremes of its 7 x NT values bound each of them: looser, a quarter of the arithmetic -- the first
+ * pass only needs the tile's extremes and L / U, and a window that qualifies by its own bounds sits in a tile that qualifies by these).
+ * The minima / maxima run on order-preserving INTEGER keys of the REAL bit patterns (k = u ^ ((u >> 31) & 0x7fffffff), signed compare): v_min_i32
+ * needs no canonicalisation of its inputs (fminf costs three instructions on raw loads), and a NaN or an infinity becomes the largest or smallest
+ * key instead of being skipped: *kmin / *kmax (the lane's extreme keys) tell the caller whether the tile holds a non-finite value.
+ * Sliding extremes: horizontally the six pair extremes of the lane's seven values serve its four windows, vertically the pair (row r - 1, row r)
+ * serves the windows that end at r and at r + 2. */
+__device__ __forceinline__ int bb_key(float v) { const int u = __float_as_int(v); return u ^ ((u >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float bb_unkey(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+#define BB_KEY_POS_INF 0x7f800000            /* keys >= this: +inf / NaN; keys <= ~this: -inf / -NaN */
+template <int NT, bool VEC, bool COARSE, class F>
+__device__ __forceinline__ void bb_sweep(const bb_args &a, const float *zf, int tx, int ty, int *kmin_out, int *kmax_out, F &&visit)
+{
+    const int lane = threadIdx.x & 63;
+    const int ni = a.p.ni_src, nj = a.p.nj_src;
+    const int nwr = nj - NT + 1;
+    const int j0a = ty * BB_TH, j0b = min(j0a + BB_TH, nwr);
+    int kmn = 0x7fffffff, kmx = (int)0x80000000;
+    *kmin_out = kmn; *kmax_out = kmx;
+    if (j0a >= j0b) return;
+    int col[4]; bool own[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int w = 4 * lane + q, cu = tx * BB_TW + w;
+        col[q] = cu % ni;
+        own[q] = w < BB_TW && cu < ni && a.p.bb_colhas[col[q]] != 0;
+    }
+    const bool own_any = own[0] || own[1] || own[2] || own[3];
+    const float cs = a.sf;
+    float ck[4];                                              /* max sum |wx| of the window's target columns */
+#pragma unroll
+    for (int q = 0; q < 4; q++) ck[q] = a.p.bb_colk[col[q]];
+    if (COARSE) ck[0] = fmaxf(fmaxf(ck[0], ck[1]), fmaxf(ck[2], ck[3]));
+    auto load_row = [&](int j) -> float4 {
+        const float *zr = zf + (size_t)j * ni;
+        float4 v;
+        if (VEC) v = *(const float4 *)(zr + col[0]);           /* ni % 4 == 0: the four columns never straddle the seam */
+        else { v.x = zr[col[0]]; v.y = zr[col[1]]; v.z = zr[col[2]]; v.w = zr[col[3]]; }
+        return v;
+    };
+    const int jend = j0b + NT - 1;                            /* source rows [j0a, jend) */
+    constexpr int G = 4;                                      /* rows per group: loads of the next group are in flight while this one is reduced */
+    constexpr int NW = COARSE ? 1 : 4;
+    int hpn[NW], hpx[NW], p1n[NW], p1x[NW], p2n[NW], p2x[NW];      /* row r - 1; pair (r - 2, r - 1); pair (r - 3, r - 2) */
+#pragma unroll
+    for (int q = 0; q < NW; q++) hpn[q] = hpx[q] = p1n[q] = p1x[q] = p2n[q] = p2x[q] = 0;
+    float4 nxt[G];
+#pragma unroll
+    for (int u = 0; u < G; u++) nxt[u] = load_row(min(j0a + u, nj - 1));
+    for (int j = j0a; j < jend; j += G) {
+        float4 cur[G];
+#pragma unroll
+        for (int u = 0; u < G; u++) cur[u] = nxt[u];
+#pragma unroll
+        for (int u = 0; u < G; u++) nxt[u] = load_row(min(j + G + u, nj - 1));
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const int jj = j + u;
+            if (jj >= jend) break;                            /* wave-uniform */
+            const int e0 = bb_key(cur[u].x), e1 = bb_key(cur[u].y), e2 = bb_key(cur[u].z), e3 = bb_key(cur[u].w);
+            int hn[NW], hx[NW];
+            const int n01 = min(e0, e1), n23 = min(e2, e3), x01 = max(e0, e1), x23 = max(e2, e3);
+            kmn = min(kmn, min(n01, n23)); kmx = max(kmx, max(x01, x23));
+            if (NT == 1) {
+                if (COARSE) { hn[0] = min(n01, n23); hx[0] = max(x01, x23); }
+                else { hn[0] = hx[0] = e0; hn[1 % NW] = hx[1 % NW] = e1; hn[2 % NW] = hx[2 % NW] = e2; hn[3 % NW] = hx[3 % NW] = e3; }
+            } else {
+                const int e4 = __shfl_down(e0, 1, 64);
+                if (NT == 2) {
+                    if (COARSE) { hn[0] = min(min(n01, n23), e4); hx[0] = max(max(x01, x23), e4); }
+                    else { hn[0] = n01; hn[1 % NW] = min(e1, e2); hn[2 % NW] = n23; hn[3 % NW] = min(e3, e4); hx[0] = x01; hx[1 % NW] = max(e1, e2); hx[2 % NW] = x23; hx[3 % NW] = max(e3, e4); }
+                } else {
+                    const int e5 = __shfl_down(e1, 1, 64), e6 = __shfl_down(e2, 1, 64);
+                    if (COARSE) { hn[0] = min(min(n01, n23), min(min(e4, e5), e6)); hx[0] = max(max(x01, x23), max(max(e4, e5), e6)); }
+                    else {
+                        const int n12 = min(e1, e2), n34 = min(e3, e4), n45 = min(e4, e5), n56 = min(e5, e6);
+                        const int x12 = max(e1, e2), x34 = max(e3, e4), x45 = max(e4, e5), x56 = max(e5, e6);
+                        hn[0] = min(n01, n23); hn[1 % NW] = min(n12, n34); hn[2 % NW] = min(n23, n45); hn[3 % NW] = min(n34, n56);
+                        hx[0] = max(x01, x23); hx[1 % NW] = max(x12, x34); hx[2 % NW] = max(x23, x45); hx[3 % NW] = max(x34, x56);
+                    }
+                }
+            }
+            int wn[NW], wx[NW];
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                if (NT == 1) { wn[q] = hn[q]; wx[q] = hx[q]; }
+                else {
+                    const int pn = min(hpn[q], hn[q]), px = max(hpx[q], hx[q]);      /* pair (r - 1, r) */
+                    if (NT == 2) { wn[q] = pn; wx[q] = px; }
+                    else { wn[q] = min(p2n[q], pn); wx[q] = max(p2x[q], px); p2n[q] = p1n[q]; p2x[q] = p1x[q]; p1n[q] = pn; p1x[q] = px; }
+                    hpn[q] = hn[q]; hpx[q] = hx[q];
+                }
+            }
+            const int j0 = jj - NT + 1;
+            if (j0 < j0a) continue;                           /* fewer than NT rows so far (wave-uniform) */
+            if (!a.p.bb_rowhas[j0]) continue;                 /* no target row starts here (wave-uniform) */
+            const float rk = a.p.bb_rowk[j0];                 /* max sum |wy| of the window's target rows (wave-uniform) */
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                const float ca = fmaf(fmaf(ck[q], rk, -1.0f), 0.500005f, 1.0e-6f);      /* (K - 1) / 2, rounded up with room for the REAL roundings below */
+                const float fx = bb_unkey(wx[q]), fn = bb_unkey(wn[q]);
+                const float zabs = __uint_as_float(max(__float_as_uint(fx) & 0x7fffffffu, __float_as_uint(fn) & 0x7fffffffu));
+                /* a window of ONE value c interpolates to c exactly (sum w = 1 to REAL*8 rounding, the result is rounded to REAL): upper = lower end */
+                const float slack = (a.exact_ok && fx == fn) ? 0.f : fmaf(ca, fx - fn, cs * zabs);
+                visit(COARSE ? own_any : own[q], col[q], j0, fx + slack, fn - slack);
+            }
+        }
+    }
+    *kmin_out = kmn; *kmax_out = kmx;
+}
+
+template <int NT, bool VEC>
+__global__ __launch_bounds__(256) void k_bb_bounds(bb_args a)
+{
+    const int f = blockIdx.z, tx = blockIdx.x, ty = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));      /* wave-uniform: scalar loop control */
+    if (ty >= a.nty) return;
+    const float *zf = a.zin + (size_t)f * a.in_stride;
+    float tub = -INFINITY, tlb = INFINITY, L = -INFINITY, U = INFINITY, cmx = -INFINITY, cmn = INFINITY;
+    int kmn, kmx;
+    bb_sweep<NT, VEC, true>(a, zf, tx, ty, &kmn, &kmx, [&](bool valid, int, int, float ub, float lb) {
+        const bool open = valid && ub != lb;                  /* a window whose values are still to be evaluated; else (ub == lb) its value is known: cmx / cmn */
+        tub = fmaxf(tub, open ? ub : -INFINITY); tlb = fminf(tlb, open ? lb : INFINITY);       /* selects, not branches */
+        L = fmaxf(L, valid ? lb : -INFINITY); U = fminf(U, valid ? ub : INFINITY);
+        cmx = fmaxf(cmx, (valid && !open) ? ub : -INFINITY); cmn = fminf(cmn, (valid && !open) ? lb : INFINITY);
+    });
+    for (int off = 32; off > 0; off >>= 1) {
+        tub = fmaxf(tub, __shfl_down(tub, off, 64)); tlb = fminf(tlb, __shfl_down(tlb, off, 64));
+        L = fmaxf(L, __shfl_down(L, off, 64)); U = fminf(U, __shfl_down(U, off, 64));
+        cmx = fmaxf(cmx, __shfl_down(cmx, off, 64)); cmn = fminf(cmn, __shfl_down(cmn, off, 64));
+    }
+    const bool bad = __ballot(kmx >= BB_KEY_POS_INF || kmn <= ~BB_KEY_POS_INF) != 0;
+    if ((threadIdx.x & 63) == 0) {
+        const size_t t = (size_t)f * a.ntx * a.nty + (size_t)ty * a.ntx + tx;
+        /* a tile with a non-finite value: every window of it is evaluated, and nothing of it enters L / U (the interpolating pass's fminf / fmaxf skip
+         * NaN results: a bound from a window next to one says nothing about what that pass finds) */
+        float *tl = a.tile + BB_TILE_F * t;
+        tl[0] = tub; tl[1] = tlb; tl[2] = bad ? -INFINITY : L; tl[3] = bad ? INFINITY : U; tl[4] = bad ? -INFINITY : cmx; tl[5] = bad ? INFINITY : cmn;
+        a.tile_bad[t] = bad ? 1u : 0u;
+    }
+}
+
+__device__ __forceinline__ bool bb_tile_qualifies(const bb_args &a, size_t t, float L, float U)
+{
+    return a.force_all || a.tile_bad[t] || !(a.tile[BB_TILE_F * t] < L) || !(a.tile[BB_TILE_F * t + 1] > U);
+}
+
+__global__ __launch_bounds__(256) void k_bb_reduce(bb_args a)
+{
+    const int f = blockIdx.x, nt = a.ntx * a.nty;
+    const size_t t0 = (size_t)f * nt;
+    __shared__ float shL[4], shU[4];
+    __shared__ int shc[4];
+    __shared__ float shC[4], shD[4];
+    float L = -INFINITY, U = INFINITY, C = -INFINITY, D = INFINITY;
+    for (int t = threadIdx.x; t < nt; t += 256) {
+        const float *tl = a.tile + BB_TILE_F * (t0 + t);
+        L = fmaxf(L, tl[2]); U = fminf(U, tl[3]); C = fmaxf(C, tl[4]); D = fminf(D, tl[5]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        L = fmaxf(L, __shfl_down(L, off, 64)); U = fminf(U, __shfl_down(U, off, 64));
+        C = fmaxf(C, __shfl_down(C, off, 64)); D = fminf(D, __shfl_down(D, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { shL[threadIdx.x >> 6] = L; shU[threadIdx.x >> 6] = U; shC[threadIdx.x >> 6] = C; shD[threadIdx.x >> 6] = D; }
+    __syncthreads();
+    L = fmaxf(fmaxf(shL[0], shL[1]), fmaxf(shL[2], shL[3])); U = fminf(fminf(shU[0], shU[1]), fminf(shU[2], shU[3]));
+    C = fmaxf(fmaxf(shC[0], shC[1]), fmaxf(shC[2], shC[3])); D = fminf(fminf(shD[0], shD[1]), fminf(shD[2], shD[3]));
+    int cnt = 0;
+    for (int t = threadIdx.x; t < nt; t += 256) cnt += bb_tile_qualifies(a, t0 + t, L, U) ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0) shc[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt = shc[0] + shc[1] + shc[2] + shc[3];
+        a.LU[2 * f] = L; a.LU[2 * f + 1] = U;
+        a.flags[f] = (cnt > a.max_cand && !a.force_all) ? 1 : 0;
+        a.count[f] = 0u;
+        unsigned *k = a.keys + (size_t)f * a.key_stride;
+        k[0] = D <= C ? f2key(D) : 0xFFFFFFFFu; k[1] = D <= C ? f2key(C) : 0u; k[2] = 0u;      /* the values already known: windows of one value */
+    }
+}
+
+__device__ __forceinline__ void bb_publish(const bb_args &a, int f, float vmin, float vmax)
+{
+    for (int off = 32; off > 0; off >>= 1) { vmin = fminf(vmin, __shfl_down(vmin, off, 64)); vmax = fmaxf(vmax, __shfl_down(vmax, off, 64)); }
+    if ((threadIdx.x & 63) == 0 && vmin <= vmax) {           /* something was evaluated (NaN results never enter: fminf / fmaxf, like the interpolating pass) */
+        unsigned *k = a.keys + (size_t)f * a.key_stride;
+        atomicMin(&k[0], f2key(vmin)); atomicMax(&k[1], f2key(vmax));
+    }
+}
+
+/* the tiles that can hold an extremum are swept again: their windows that reach L (or U) are collected in LDS (one wave per tile: a running count in a
+ * scalar register, ranks by ballot, no atomics) and appended to the field's list with ONE returning atomic per tile (one per window row and lane window
+ * -- 128 per tile on one word per field -- ran at the ~88 atomics per us of a single address: 19 us per cfg2 field) */
+template <int NT, bool VEC>
+__global__ __launch_bounds__(64) void k_bb_select(bb_args a)
+{
+    __shared__ unsigned buf[BB_TW * BB_TH];
+    const int f = blockIdx.y;
+    if (a.flags[f]) return;
+    const int nt = a.ntx * a.nty, t = blockIdx.x;
+    const float L = a.LU[2 * f], U = a.LU[2 * f + 1];
+    if (!bb_tile_qualifies(a, (size_t)f * nt + t, L, U)) return;
+    const float *zf = a.zin + (size_t)f * a.in_stride;
+    const int ty = t / a.ntx, tx = t - ty * a.ntx;
+    const bool all = a.force_all != 0 || a.tile_bad[(size_t)f * nt + t] != 0;
+    const int lane = threadIdx.x & 63;
+    unsigned nloc = 0;                                        /* wave-uniform */
+    float vmin = INFINITY, vmax = -INFINITY;
+    int kmn, kmx;
+    bb_sweep<NT, VEC, false>(a, zf, tx, ty, &kmn, &kmx, [&](bool valid, int i0, int j0, float ub, float lb) {
+        const bool known = !all && ub == lb;                   /* a window of one value: nothing to evaluate */
+        if (valid && known) { vmin = fminf(vmin, lb); vmax = fmaxf(vmax, ub); }
+        const bool cand = valid && !known && (all || !(ub < L) || !(lb > U));
+        const unsigned long long m = __ballot(cand);
+        if (cand) buf[nloc + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (unsigned)i0 | (unsigned)j0 << 16;
+        nloc += (unsigned)__builtin_popcountll(m);
+    });
+    bb_publish(a, f, vmin, vmax);
+    if (!nloc) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&a.count[f], nloc);
+    base = (unsigned)__shfl((int)base, 0, 64);
+    __syncthreads();
+    unsigned *list = a.list + (size_t)f * BB_LIST_CAP;
+    for (unsigned k = lane; k < nloc; k += 64) if (base + k < BB_LIST_CAP) list[base + k] = buf[k];
+}
+
+/* the value k_sep / k_sepx store at target column c, main row r: the same tables, the same operation order */
+template <int DEG>
+__device__ __forceinline__ float bb_exact(const ezhip_sep_plan &p, const float *zf, int c, int r)
+{
+    const ColTaps t = load_col(p.cidx, p.cw, p.ni_dst, c);
+    const int nis = p.ni_src, njd = p.nj_dst;
+    const float *z0 = zf + (size_t)p.rbase[r] * nis;
+    double val;
+    if (DEG == 0) val = xpass<0>(z0, t);
+    else if (DEG == 1) { const double t0 = xpass<1>(z0, t), t1 = xpass<1>(z0 + nis, t); val = t0 + (t1 - t0) * p.rw[r]; }
+    else {
+        const double t0 = xpass<3>(z0, t), t1 = xpass<3>(z0 + nis, t), t2 = xpass<3>(z0 + 2 * (size_t)nis, t), t3 = xpass<3>(z0 + 3 * (size_t)nis, t);
+        val = fma(p.rw[3 * njd + r], t3, fma(p.rw[2 * njd + r], t2, fma(p.rw[njd + r], t1, p.rw[r] * t0)));
+    }
+    return (float)val;
+}
+
+/* the listed windows: every target point whose stencil is the window, evaluated exactly */
+template <int DEG>
+__global__ __launch_bounds__(256) void k_bb_eval(bb_args a)
+{
+    const int f = blockIdx.y;
+    if (a.flags[f]) return;
+    const unsigned n = a.count[f];
+    if (n > (unsigned)a.list_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) a.flags[f] = 1; return; }      /* too many windows can hold the extremum: the field is handed back (every block of the field sees the same count and leaves) */
+    const float *zf = a.zin + (size_t)f * a.in_stride;
+    const unsigned *list = a.list + (size_t)f * BB_LIST_CAP;
+    float vmin = INFINITY, vmax = -INFINITY;
+    for (unsigned w = blockIdx.x * 256u + threadIdx.x; w < n; w += gridDim.x * 256u) {
+        const unsigned e = list[w];
+        const int i0 = (int)(e & 0xFFFFu), j0 = (int)(e >> 16);
+        const int c0 = a.p.bb_colstart[i0], c1 = a.p.bb_colstart[i0 + 1], r0 = a.p.bb_rowstart[j0], r1 = a.p.bb_rowstart[j0 + 1];
+        for (int ri = r0; ri < r1; ri++) {
+            const int r = a.p.bb_rowlist[ri];
+            for (int ci = c0; ci < c1; ci++) {
+                const float v = bb_exact<DEG>(a.p, zf, a.p.bb_collist[ci], r);
+                vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+            }
+        }
+    }
+    bb_publish(a, f, vmin, vmax);
+}
+
+template <int DEG>
+__global__ __launch_bounds__(SEP_BLOCK) void k_bb_special(bb_args a)
+{
+    const int f = blockIdx.z;
+    if (a.flags[f]) return;
+    ezhip_sep_plan &p = a.p;
+    p.polevals = a.poles ? a.poles + 2 * f : nullptr;
+    const float *zf = a.zin + (size_t)f * a.in_stride;
+    const int c = blockIdx.x * SEP_BLOCK + threadIdx.x, cc = min(c, p.ni_dst - 1);
+    const float v = sep_special<DEG, 2>(p, nullptr, zf, blockIdx.y, c, cc, c < p.ni_dst, 0.0f);
+    bb_publish(a, f, v, v);
+}
+
+static void bb_geometry(const ezhip_sep_plan *plan, int *ntx, int *nty)
+{
+    *ntx = (plan->ni_src + BB_TW - 1) / BB_TW;
+    const int nwr = plan->nj_src - plan->bb_ntap + 1;
+    *nty = (nwr + BB_TH - 1) / BB_TH;
+}
+extern "C" size_t ezhip_bb_work_bytes(const ezhip_sep_plan *plan, int nfields)
+{
+    int ntx, nty; bb_geometry(plan, &ntx, &nty);
+    const size_t nt = (size_t)ntx * nty * (size_t)nfields;
+    return 4 * BB_TILE_F * nt + 4 * nt + 8 * (size_t)nfields + 4 * (size_t)nfields + 4 * (size_t)BB_LIST_CAP * (size_t)nfields + 256;
+}
+static void bb_fill(bb_args *a, const ezhip_sep_plan *plan, const float *d_zin, size_t in_stride, int nfields, unsigned *d_partials, size_t stride_words,
+                    int *d_flags, const float *d_poles, void *d_work)
+{
+    memset(a, 0, sizeof(*a));
+    a->p = *plan; a->p.pole_timeout = 0; a->p.vector_mode = 0;
+    a->zin = d_zin; a->in_stride = in_stride; a->nfields = nfields;
+    bb_geometry(plan, &a->ntx, &a->nty);
+    /* the bounds are formed in REAL: the factors are rounded up with room for the (at most four) REAL roundings of slack, upper and lower end */
+    a->sf = (float)(plan->bb_s + 4.0e-7);
+    const size_t nt = (size_t)a->ntx * a->nty * (size_t)nfields;
+    char *w = (char *)d_work;
+    a->tile = (float *)w; w += 4 * BB_TILE_F * nt;
+    a->tile_bad = (unsigned *)w; w += 4 * nt;
+    a->LU = (float *)w; w += 8 * (size_t)nfields;
+    a->count = (unsigned *)w; w += 4 * (size_t)nfields;
+    a->list = (unsigned *)w;
+    a->keys = d_partials; a->key_stride = stride_words; a->flags = d_flags; a->poles = d_poles;
+    /* when is a field handed back (flags)?  When more than an eighth of its windows (at most BB_LIST_CAP) can hold an extremum: evaluating them point by
+     * point then costs more than the interpolating pass.  (The tile count alone says little: the second sweep of a tile costs what the first did.) */
+    a->max_cand = a->ntx * a->nty;
+    const long long nwin = (long long)plan->ni_src * (plan->nj_src - plan->bb_ntap + 1);
+    long long cap = nwin / 8;
+    if (cap < 8192) cap = 8192;
+    if (cap > BB_LIST_CAP) cap = BB_LIST_CAP;
+    a->force_all = getenv("EZHIP_BB_FORCE_ALL") ? 1 : 0;      /* tests: every window is evaluated */
+    a->list_cap = a->force_all ? BB_LIST_CAP : (int)cap;
+    a->exact_ok = plan->bb_s < 1.0e-9 ? 1 : 0;               /* sum w = 1 to REAL*8 rounding: a window of one value c gives c */
+}
+extern "C" int ezhip_minmax_bb(const ezhip_sep_plan *plan, const float *d_zin, size_t in_stride, int nfields, unsigned *d_partials, size_t stride_words,
+                               int *d_flags, const float *d_poles, void *d_work)
+{
+    if (!plan->bb_ok || nfields < 1 || plan->ni_src > 65535 || plan->nj_src > 65535) return -2;
+    bb_args a;
+    bb_fill(&a, plan, d_zin, in_stride, nfields, d_partials, stride_words, d_flags, d_poles, d_work);
+    const bool vec = plan->ni_src % 4 == 0 && in_stride % 4 == 0 && ((uintptr_t)d_zin & 15) == 0;
+    const dim3 g1((unsigned)a.ntx, (unsigned)((a.nty + 3) / 4), (unsigned)nfields), g2((unsigned)(a.ntx * a.nty), (unsigned)nfields), g3(64, (unsigned)nfields);
+#define BB_LAUNCH(NT, DEG) do { \
+        if (vec) { hipLaunchKernelGGL((k_bb_bounds<NT, true>), g1, dim3(256), 0, g_stream, a); hipLaunchKernelGGL(k_bb_reduce, dim3((unsigned)nfields), dim3(256), 0, g_stream, a); \
+                   hipLaunchKernelGGL((k_bb_select<NT, true>), g2, dim3(64), 0, g_stream, a); } \
+        else { hipLaunchKernelGGL((k_bb_bounds<NT, false>), g1, dim3(256), 0, g_stream, a); hipLaunchKernelGGL(k_bb_reduce, dim3((unsigned)nfields), dim3(256), 0, g_stream, a); \
+               hipLaunchKernelGGL((k_bb_select<NT, false>), g2, dim3(64), 0, g_stream, a); } \
+        hipLaunchKernelGGL(k_bb_eval<DEG>, g3, dim3(256), 0, g_stream, a); } while (0)
+    if (plan->bb_ntap == 4) BB_LAUNCH(4, 3); else if (plan->bb_ntap == 2) BB_LAUNCH(2, 1); else BB_LAUNCH(1, 0);
+#undef BB_LAUNCH
+    return LAUNCH_CHECK("k_bb");
+}
+/* the special (polar) rows of the plan, after ezhip_minmax_bb on the same arguments */
+extern "C" int ezhip_minmax_bb_special(const ezhip_sep_plan *plan, const float *d_zin, size_t in_stride, int nfields, unsigned *d_partials, size_t stride_words,
+                                       int *d_flags, const float *d_poles, void *d_work)
+{
+    if (!plan->bb_ok) return -2;
+    if (plan->n_special <= 0) return 0;
+    bb_args a;
+    bb_fill(&a, plan, d_zin, in_stride, nfields, d_partials, stride_words, d_flags, d_poles, d_work);
+    const dim3 g((unsigned)((plan->ni_dst + SEP_BLOCK - 1) / SEP_BLOCK), (unsigned)plan->n_special, (unsigned)nfields);
+    if (plan->degree == 0) hipLaunchKernelGGL(k_bb_special<0>, g, dim3(SEP_BLOCK), 0, g_stream, a);
+    else if (plan->degree == 1) hipLaunchKernelGGL(k_bb_special<1>, g, dim3(SEP_BLOCK), 0, g_stream, a);
+    else hipLaunchKernelGGL(k_bb_special<3>, g, dim3(SEP_BLOCK), 0, g_stream, a);
+    return LAUNCH_CHECK("k_bb_special");
 }
 
 /* ===================================================================================== */

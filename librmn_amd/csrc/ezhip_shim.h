@@ -16,6 +16,8 @@ extern "C" {
 
 /* ---- runtime plumbing ---------------------------------------------------------------- */
 int    ezhip_runtime_ok(void);                       /* 1 if a HIP device is usable, else 0 */
+int    ezhip_bound_device_ok(const char *who);       /* 0 when the calling thread's current device is the one the library is bound to (binds on first use); -1 + message otherwise */
+int    ezhip_bound_device(void);                     /* the bound device, -1 before the first use */
 const char *ezhip_last_error(void);
 void  *ezhip_malloc(size_t nbytes);                  /* NULL on failure */
 void   ezhip_free(void *d);
@@ -135,9 +137,29 @@ typedef struct {
     size_t batch_in_stride, batch_out_stride;   /* floats between consecutive fields */
     const ezhip_xstep *x_first, *x_cont;   /* [x_nvb] staging step of a row-block when it starts a segment / continues one */
     const ezhip_xrow *x_rows;         /* [x_nvb * x_rows_per_step] row records */
+    /* ---- exact extrema of the interpolated field WITHOUT interpolating it (k_bb_*, the cfg5 pipeline's pass A): every value is
+     * sum(w z) over its stencil = one WINDOW of bb_ntap x bb_ntap source points, so it lies within [wmin - bb_a range - bb_s zabs,
+     * wmax + bb_a range + bb_s zabs] of that window (range = wmax - wmin, zabs = max |z|; bb_a = (max sum |wx| * max sum |wy| - 1) / 2 and
+     * bb_s bounds |sum w - 1| and the rounding of the REAL*8 evaluation).  Only windows whose bound reaches the best GUARANTEED value can
+     * hold the extremum; their target points (CSR lists by the window's first source column / row) are evaluated exactly. */
+    int bb_ok, bb_ntap;
+    double bb_a, bb_s;
+    const unsigned char *bb_colhas, *bb_rowhas;      /* [ni_src], [nj_src]: some target column / main row has its first tap there */
+    const int *bb_colstart, *bb_collist;             /* [ni_src + 1], [ni_dst] */
+    const int *bb_rowstart, *bb_rowlist;             /* [nj_src + 1], [main rows] */
+    const float *bb_colk, *bb_rowk;                  /* [ni_src], [nj_src]: max sum |wx| of the target columns / sum |wy| of the rows of the window (rounded up); a window's a = (colk rowk - 1) / 2: the
+                                                        rows that EXTRApolate towards a pole without the polar correction carry weights far beyond the interior's 1.25 */
 } ezhip_sep_plan;
 
 int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin);
+/* exact {min, max} of the values ezhip_interp_sep would store for nfields fields (plan->bb_ok), asynchronous: d_partials[f * stride_words + 0..2] :=
+ * {min key, max key, 0} (the triple layout k_cf_header reduces); d_flags[f] := 1 when too many windows qualify (the caller then runs the
+ * interpolating pass for that field); d_poles: [2 nfields] pole values from ezhip_polevals_batch (plans with need_poles).  d_work: ezhip_bb_work_bytes */
+size_t ezhip_bb_work_bytes(const ezhip_sep_plan *plan, int nfields);
+int ezhip_minmax_bb_special(const ezhip_sep_plan *plan, const float *d_zin, size_t in_stride, int nfields, unsigned *d_partials, size_t stride_words,
+                            int *d_flags, const float *d_poles, void *d_work);
+int ezhip_minmax_bb(const ezhip_sep_plan *plan, const float *d_zin, size_t in_stride, int nfields, unsigned *d_partials, size_t stride_words,
+                    int *d_flags, const float *d_poles, void *d_work);
 /* co-resident k_sepx thread blocks on the current device for a given dynamic LDS size (0: unknown) */
 int ezhip_sepx_capacity(int degree, int rows_per_step, size_t lds_bytes);
 size_t ezhip_sepx_lds_bytes(int x_tr, int rows_per_step, int x_prows, int wstride);

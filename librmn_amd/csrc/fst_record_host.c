@@ -40,6 +40,8 @@ int32_t ezhip_fst_pack_data(uint32_t *data, int64_t cap_words, void *field, int3
 {
     const int64_t n = (int64_t)ni * nj * nk;
     if (n <= 0 || nbits < 1 || nbits > 64) return -1;
+    /* fstd98.c:934: no extra compression beyond 16 bits (IEEE 133 aside): the turbo flag is dropped BEFORE the sizes and the switch */
+    if (nbits > 16 && datyp != 133) datyp &= 0x7F;
     /* fstd98.c:936-951: float_packer beyond its range becomes IEEE or the classic packer */
     if (datyp == 6 && nbits > 24) { datyp = 5; nbits = 32; }
     if (datyp == 6 && nbits > 16) datyp = 1;

@@ -17,7 +17,7 @@
 
 static int iv_need_device(const char *who)
 {
-    if (ezhip_runtime_ok()) return 0;
+    if (ezhip_runtime_ok()) return ezhip_bound_device_ok(who);
     fprintf(stderr, "<%s> no usable HIP device: the MI355X vertical interpolation has no CPU fallback\n", who);
     return -1;
 }

@@ -15,7 +15,7 @@
 
 static int need_device(const char *who)
 {
-    if (ezhip_runtime_ok()) return 0;
+    if (ezhip_runtime_ok()) return ezhip_bound_device_ok(who);
     fprintf(stderr, "<%s> no usable HIP device: the MI355X packer path has no CPU fallback\n", who);
     return -1;
 }
@@ -324,9 +324,13 @@ done:
 }
 
 /* compact_short (compact_integer.c:592-826, opCode 5 pack / 6 unpack) and compact_char (:830-1060, opCode 9 / 10): compact_integer's
- * unsigned forms on arrays of unsigned short / unsigned char (c_fstecr / c_fstluk use them for datyp 2 / 4 fields held in 16- / 8-bit
- * arrays, fstd98.c:1214-1290, :2312-2322).  The elements are widened to a dense uint32 array on the device and go through the
- * compact_integer kernels; unpacked values are truncated to the element width like the reference's store does. */
+ * unsigned forms on arrays of unsigned short / unsigned char (c_fstecr / c_fstluk use them for datyp 2 fields held in 16- / 8-bit
+ * arrays, fstd98.c:1214-1231, :2312-2322).  The elements are widened to a dense uint32 array on the device and go through the
+ * compact_integer kernels; unpacked values are truncated to the element width like the reference's store does.
+ * The SIGNED opcodes 7 / 8 and 11 / 12 that the `#else` branch of fstd98.c:1283-1294 names do not exist in compact_integer.c (:797-816,
+ * :1034-1053 take 5 / 6 and 9 / 10 only); the reference is compiled with use_old_signed_pack_unpack_code (fstd98.c:22) and packs datyp 4
+ * fields of short / byte elements by sign-extending them and calling compact_integer(opCode 3) (:1267-1279).  Here as there those opcodes
+ * print "opCode (%d) is not defined" and return 0; the datyp 4 framing (fst_record_host.c) follows the branch that is compiled. */
 static int compact_narrow(const char *who, int elem_bytes, int op_pack, int op_unpack, void *unpacked, void *packedHeader, void *packedArrayOfInt,
                           int elementCount, int bitSizeOfPackedToken, int off_set, int stride, int opCode)
 {
@@ -727,6 +731,8 @@ int32_t ezhip_pack16_compress_batch_dev(void *d_records, int64_t record_stride_w
 /* ------------------------------------------------------------------------------------------ */
 /* the whole cfg5 pipeline on a batch, fused (round 2)                                            */
 /* ------------------------------------------------------------------------------------------ */
+int32_t ezhip_current_set_dims(int32_t *ni_in, int32_t *nj_in, int32_t *ni_out, int32_t *nj_out);
+int32_t ezhip_ezsint_batch_minmax_bb_dev(const float *d_zin, int32_t nfields, uint32_t *d_partials, int64_t stride_words, int32_t *partials_per_field, int32_t *d_flags);
 int32_t ezhip_ezsint_batch_minmax_only_dev(const float *d_zin, int32_t nfields, uint32_t *d_partials, int64_t stride_words, int32_t *partials_per_field);
 int32_t ezhip_ezsint_batch_tokens_dev(uint32_t *d_tokens, int64_t token_stride_words, const float *d_zin, int32_t nfields,
                                       const void *d_params, int64_t param_stride_bytes);
@@ -740,37 +746,99 @@ int32_t ezhip_ezsint_batch_tokens_dev(uint32_t *d_tokens, int64_t token_stride_w
  *   F  fields that are not compressible get the plain 16-bit pack (conditional copy, one launch)
  * One synchronisation at the end (zlng_out).  Returns the c_ezsint code (0), -1 on error, or -2 when the grid set is not on the
  * single-launch k_sepx path / the shape is outside the one-pass encoder (use the unfused entry points then). */
-int32_t ezhip_ezsint_pack16_compress_batch_dev(void *d_records, int64_t record_stride_words, const float *d_zin, int32_t nfields,
-                                               int32_t ni_out, int32_t nj_out, int32_t nbits, int32_t *zlng_out)
+static int32_t cfg5_batch(void *d_records, int64_t record_stride_words, const float *d_zin, int32_t nfields,
+                          int32_t ni_out, int32_t nj_out, int32_t nbits, int32_t *zlng_out, int use_bb)
 {
-    if (need_device("ezhip_ezsint_pack16_compress_batch_dev")) return -1;
-    if (nfields < 1 || nbits < 5 || nbits > 16 || ni_out < 16 || nj_out < 16 || (ni_out & 1)) return -2;
-    if (g_level == -1) g_level = 1;
-    if (g_level == 0 || g_swap != 1) return -2;
+    int32_t ni_in = 0, nj_in = 0, ni_set = 0, nj_set = 0;
+    if (ezhip_current_set_dims(&ni_in, &nj_in, &ni_set, &nj_set)) return -1;
     const size_t n = (size_t)ni_out * nj_out;
-    const size_t wb = packhip_armn_enc1_work_bytes(ni_out, nj_out, nbits, nfields);
-    if (!wb) return -2;
+    /* sub-batches (EZHIP_CFG5_SUB, development): the encoder of sub-batch k on the side stream beside passes A and B of sub-batch k + 1.
+     * Measured SLOWER on MI355X (90.7 us per field for the whole batch of 32; 92.6 / 101.0 / 112.2 for sub-batches of 16 / 8 / 4: co-running
+     * stretches k_sepx 2.5 x and the encoder 1.4 x -- both are bound by VALU issue, there is nothing to overlap): the default is one batch */
+    int sub = nfields;
+    { const char *e = getenv("EZHIP_CFG5_SUB"); const int v = e ? atoi(e) : 0; if (v >= 4 && v < nfields) sub = v; }
+    const int nsub = (nfields + sub - 1) / sub;
+    const size_t wb1 = packhip_armn_enc1_work_bytes(ni_out, nj_out, nbits, sub);
+    if (!wb1) return -2;
+    const size_t wb = (wb1 + 64 + 255) & ~(size_t)255;
     const size_t tok_stride = (n + 1) / 2 + 4;                                  /* words per field */
     const size_t stride = PACKHIP_STATS_PARTIALS + 3 * (size_t)8192;
     unsigned *d_stats_all = (unsigned *)ws(3, (4 * stride + sizeof(packhip_cf_params)) * (size_t)nfields + 64);
     unsigned *d_tok = (unsigned *)ws(1, 4 * tok_stride * (size_t)nfields);
-    char *d_work = (char *)ws(2, wb + 64);
-    int *d_zlng = (int *)ws(0, sizeof(int) * (size_t)nfields + 64);
+    char *d_work = (char *)ws(2, wb * (size_t)nsub);
+    int *d_zlng = (int *)ws(0, 2 * sizeof(int) * (size_t)nfields + 64);           /* zlng[nfields] | flags[nfields] */
     if (!d_stats_all || !d_tok || !d_work || !d_zlng) return -1;
+    int *d_flags = d_zlng + nfields;
     packhip_cf_params *d_pp = (packhip_cf_params *)(d_stats_all + stride * (size_t)nfields);
-    int32_t npf = 0;
-    int32_t rc = ezhip_ezsint_batch_minmax_only_dev(d_zin, nfields, d_stats_all + PACKHIP_STATS_PARTIALS, (int64_t)stride, &npf);
-    if (rc < 0) return rc;                                                        /* -2: not on the single-launch path */
-    if (packhip_cf_header_batch(d_pp, (unsigned *)d_records, (size_t)record_stride_words, d_stats_all, stride,
-                                npf, (unsigned)n, nbits, 2, 0, nfields)) return -1;
-    int32_t rc2 = ezhip_ezsint_batch_tokens_dev(d_tok, (int64_t)tok_stride, d_zin, nfields, d_pp, (int64_t)sizeof(packhip_cf_params));
-    if (rc2 < 0) return -1;
+    const size_t nin = (size_t)ni_in * nj_in;
     const size_t z_cap = (size_t)record_stride_words - 4 < n / 2 + 16 ? (size_t)record_stride_words - 4 : n / 2 + 16;
     if (ezhip_memset(d_zlng, 0xFD, sizeof(int) * (size_t)nfields)) return -1;       /* "unfinished" until the encoder says otherwise */
-    if (packhip_armn_encode1((unsigned *)d_records + 4, (size_t)record_stride_words, z_cap, d_tok, tok_stride,
-                             ni_out, nj_out, nbits, nfields, 1, 4, d_work, d_zlng)) return -1;
-    if (packhip_cond_copy((unsigned *)d_records + 4, (size_t)record_stride_words, d_tok, tok_stride, (n + 1) / 2, d_zlng, nfields, 1)) return -1;
-    if (ezhip_d2h(zlng_out, d_zlng, sizeof(int) * (size_t)nfields) || ezhip_sync()) return -1;
-    if (redo_wide_fields((unsigned *)d_records, (size_t)record_stride_words, d_tok, tok_stride, 0, nfields, ni_out, nj_out, nbits, zlng_out)) return -1;
+    if (ezhip_memset(d_flags, 0, sizeof(int) * (size_t)nfields)) return -1;
+    int32_t rc = 0;
+    int bb_used = 0;
+    for (int k = 0; k < nsub; k++) {
+        const int f0 = k * sub, nf = nfields - f0 < sub ? nfields - f0 : sub;
+        unsigned *rec0 = (unsigned *)d_records + (size_t)f0 * (size_t)record_stride_words;
+        unsigned *stats0 = d_stats_all + stride * (size_t)f0;
+        unsigned *tok0 = d_tok + tok_stride * (size_t)f0;
+        int32_t npf = 0, r = -2;
+        /* pass A: the field's extrema.  First choice: from bounds of the SOURCE windows + exact evaluation of the few that matter (no interpolation) */
+        if (use_bb) { r = ezhip_ezsint_batch_minmax_bb_dev(d_zin + nin * (size_t)f0, nf, stats0 + PACKHIP_STATS_PARTIALS, (int64_t)stride, &npf, d_flags + f0); if (r == 0) bb_used = 1; }
+        if (r == -2) r = ezhip_ezsint_batch_minmax_only_dev(d_zin + nin * (size_t)f0, nf, stats0 + PACKHIP_STATS_PARTIALS, (int64_t)stride, &npf);
+        if (r < 0) { if (k) { ezhip_side_join(); ezhip_sync(); } return k ? -1 : r; }          /* -2: not on the single-launch path (nothing launched yet) */
+        if (r > rc) rc = r;
+        if (packhip_cf_header_batch(d_pp + f0, rec0, (size_t)record_stride_words, stats0, stride, npf, (unsigned)n, nbits, 2, 0, nf)) goto fail;
+        if (ezhip_ezsint_batch_tokens_dev(tok0, (int64_t)tok_stride, d_zin + nin * (size_t)f0, nf, d_pp + f0, (int64_t)sizeof(packhip_cf_params)) < 0) goto fail;
+        const int side = nsub > 1;
+        if (side && ezhip_side_begin()) goto fail;
+        int bad = packhip_armn_encode1(rec0 + 4, (size_t)record_stride_words, z_cap, tok0, tok_stride, ni_out, nj_out, nbits, nf, 1, 4, d_work + wb * (size_t)k, d_zlng + f0) != 0;
+        bad = bad || packhip_cond_copy(rec0 + 4, (size_t)record_stride_words, tok0, tok_stride, (n + 1) / 2, d_zlng + f0, nf, 1);
+        if (side && ezhip_side_end()) goto fail;
+        if (bad) goto fail;
+    }
+    if (ezhip_side_join()) goto fail;
+    {
+        int32_t *h = (int32_t *)malloc(2 * sizeof(int32_t) * (size_t)nfields);
+        if (!h) goto fail;
+        if (ezhip_d2h(h, d_zlng, 2 * sizeof(int) * (size_t)nfields) || ezhip_sync()) { free(h); return -1; }
+        memcpy(zlng_out, h, sizeof(int32_t) * (size_t)nfields);
+        if (redo_wide_fields((unsigned *)d_records, (size_t)record_stride_words, d_tok, tok_stride, 0, nfields, ni_out, nj_out, nbits, zlng_out)) { free(h); return -1; }
+        /* fields the bound pass gave up on (flags: too many source windows could hold the extremum): the interpolating pass A for those */
+        for (int f = 0; f < nfields && bb_used; f++) {
+            if (!h[nfields + f]) continue;
+            int f1 = f + 1;
+            while (f1 < nfields && h[nfields + f1]) f1++;
+            int32_t r = cfg5_batch((unsigned *)d_records + (size_t)f * (size_t)record_stride_words, record_stride_words, d_zin + nin * (size_t)f, f1 - f,
+                                   ni_out, nj_out, nbits, zlng_out + f, 0);
+            if (r < 0) { free(h); return -1; }
+            f = f1 - 1;
+        }
+        free(h);
+    }
     return rc;
+fail:
+    ezhip_side_join(); ezhip_sync();
+    return -1;
+}
+
+int32_t ezhip_ezsint_pack16_compress_batch_dev(void *d_records, int64_t record_stride_words, const float *d_zin, int32_t nfields,
+                                               int32_t ni_out, int32_t nj_out, int32_t nbits, int32_t *zlng_out)
+{
+    if (need_device("ezhip_ezsint_pack16_compress_batch_dev")) return -1;
+    /* the two k_sepx passes write by the CURRENT grid set's target dimensions: the caller's must be those */
+    int32_t ni_in = 0, nj_in = 0, ni_set = 0, nj_set = 0;
+    if (ezhip_current_set_dims(&ni_in, &nj_in, &ni_set, &nj_set)) { fprintf(stderr, "<ezhip_ezsint_pack16_compress_batch_dev> no grid set defined (c_ezdefset)\n"); return -1; }
+    if (ni_out != ni_set || nj_out != nj_set) {
+        fprintf(stderr, "<ezhip_ezsint_pack16_compress_batch_dev> ni_out x nj_out = %d x %d, but the current grid set writes %d x %d\n", ni_out, nj_out, ni_set, nj_set);
+        return -1;
+    }
+    if (nfields < 1 || nbits < 5 || nbits > 16 || ni_out < 16 || nj_out < 16 || (ni_out & 1)) return -2;
+    if (g_level == -1) g_level = 1;
+    if (g_level == 0 || g_swap != 1) return -2;
+    const size_t n = (size_t)ni_out * nj_out;
+    if (record_stride_words < 4 || (size_t)record_stride_words < 4 + (n + 1) / 2) {
+        fprintf(stderr, "<ezhip_ezsint_pack16_compress_batch_dev> record_stride_words = %lld, a record needs at least %zu words\n", (long long)record_stride_words, 4 + (n + 1) / 2);
+        return -1;
+    }
+    return cfg5_batch(d_records, record_stride_words, d_zin, nfields, ni_out, nj_out, nbits, zlng_out, getenv("EZHIP_CFG5_NO_BB") ? 0 : 1);
 }

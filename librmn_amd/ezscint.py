@@ -315,3 +315,37 @@ def ezgetival(option):
     v = ctypes.c_int32(0)
     rc = _lib().c_ezgetival(option.encode(), ctypes.byref(v))
     return rc, v.value
+
+
+def _key2f(k):
+    """the ordered-key encoding of the min/max reductions (ez_kernels.hip f2key) back to float32"""
+    k = np.uint32(k)
+    u = np.uint32(k & np.uint32(0x7FFFFFFF)) if (k & np.uint32(0x80000000)) else np.uint32(~k)
+    return np.array([u], np.uint32).view(np.float32)[0]
+
+
+def ezsint_batch_extrema_dev(zin, nfields, method="bounds"):
+    """{min, max} of what c_ezsint_batch_dev would store for each of nfields device-resident source fields (current grid set), WITHOUT
+    storing anything -- compact_float's first pass of the cfg5 pipeline.  method "interp": ezhip_ezsint_batch_minmax_only_dev (a k_sepx pass
+    that stores nothing); "bounds": ezhip_ezsint_batch_minmax_bb_dev (bounds of the source windows + exact evaluation of the few that can
+    hold an extremum).  Returns (rc, mins[nfields] float32, maxs[nfields] float32, flags[nfields] int32)."""
+    import torch
+    L = _lib()
+    i32, vp, i64 = ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64
+    L.ezhip_ezsint_batch_minmax_only_dev.argtypes = [vp, i32, vp, i64, vp]
+    L.ezhip_ezsint_batch_minmax_bb_dev.argtypes = [vp, i32, vp, i64, vp, vp]
+    stride = 3 * 8192
+    part = torch.zeros((nfields, stride), dtype=torch.int32, device=zin.device)
+    flags = torch.zeros(nfields, dtype=torch.int32, device=zin.device)
+    npf = ctypes.c_int32(0)
+    if method == "bounds":
+        rc = L.ezhip_ezsint_batch_minmax_bb_dev(_dptr(zin), nfields, part.data_ptr(), stride, ctypes.byref(npf), flags.data_ptr())
+    else:
+        rc = L.ezhip_ezsint_batch_minmax_only_dev(_dptr(zin), nfields, part.data_ptr(), stride, ctypes.byref(npf))
+    torch.cuda.synchronize()
+    if rc < 0:
+        return rc, None, None, None
+    p = part.cpu().numpy().view(np.uint32)[:, :3 * npf.value].reshape(nfields, npf.value, 3)
+    mins = np.array([_key2f(p[f, :, 0].min()) for f in range(nfields)], np.float32)
+    maxs = np.array([_key2f(p[f, :, 1].max()) for f in range(nfields)], np.float32)
+    return rc, mins, maxs, flags.cpu().numpy()

@@ -25,6 +25,8 @@ def pack(field, ni, nj, nk, datyp, nbits):
     refused compression is excluded)"""
     O = top.O(); O32 = ta32.O()
     n = ni * nj * nk
+    if nbits > 16 and datyp != 133:          # fstd98.c:934
+        datyp &= 0x7F
     if datyp == 6 and nbits > 24:
         datyp, nbits = 5, 32
     if datyp == 6 and nbits > 16:

@@ -33,7 +33,14 @@ def main():
     be = bd.HipBackend()
     src = (4400, 2200, "G", 0, 0, 0, 0) if args.size == "full" else (360, 181, "G", 0, 0, 0, 0)
     dst = (7200, 3601, "L", 5, 5, 0, 0) if args.size == "full" else (520, 261, "L", 69, 69, 0, 0)
-    make = lambda f: be.to_device(ec.synth_field(src[0], src[1], seed=1000 + f))     # noqa: E731
+    # the source records of this rank, resident in HBM BEFORE anything is timed (a record is a device-side variation of one synthetic base field:
+    # building every field with numpy inside the timed region measured the host, 4.8 fields/s at full size)
+    from librmn_amd import sharding as sh
+    base = be.to_device(ec.synth_field(src[0], src[1], seed=1000))
+    mine = sh.fields_of_rank(args.fields, rank, world) if args.case != "targets" else []
+    fields = {f: (base * (1.0 + 1e-4 * (f % 97)) + 0.01 * f) for f in mine}
+    be.sync()
+    make = fields.__getitem__
     out = {"case": args.case, "world": world, "fields": args.fields, "size": args.size}
     if args.case in ("cfg4", "cfg5"):
         h = be.define_set(src, dst)
@@ -50,7 +57,7 @@ def main():
                 if args.case == "cfg4":
                     ok = ok and be.checksum(z) == res["checksums"][f]
                 else:
-                    rec = torch.zeros(4 + h["nout"] // 2 + 64, dtype=torch.int32, device="cuda")
+                    rec = torch.zeros(bd.record_stride_words(h["nout"]), dtype=torch.int32, device="cuda")
                     zl = pk.pack16_compress_dev(rec, z, dst[0], dst[1], 16)
                     torch.cuda.synchronize()
                     nb = 16 + ((zl - 1) // 4) * 4 if zl > 0 else 16 + 2 * h["nout"]
