@@ -1171,6 +1171,7 @@ struct bb_args {
     unsigned *tile_bad;              /* [nfields][nty * ntx]: the tile holds a non-finite value: every window of it is evaluated, none contributes to L / U */
     float *LU;                       /* [nfields][2] */
     unsigned *count, *list;          /* [nfields], [nfields][BB_LIST_CAP]: windows to evaluate, i0 | j0 << 16 */
+    unsigned *ntl, *tlist;           /* [nfields], [nfields][nty * ntx]: the tiles that qualify (k_bb_reduce), swept by k_bb_select */
     unsigned *keys; size_t key_stride;   /* [f * key_stride + 0..2] = {min key, max key, 0} */
     int *flags; int max_cand, force_all, list_cap, exact_ok;
     const float *poles;
@@ -1344,15 +1345,18 @@ __global__ __launch_bounds__(256) void k_bb_reduce(bb_args a)
     __syncthreads();
     L = fmaxf(fmaxf(shL[0], shL[1]), fmaxf(shL[2], shL[3])); U = fminf(fminf(shU[0], shU[1]), fminf(shU[2], shU[3]));
     C = fmaxf(fmaxf(shC[0], shC[1]), fmaxf(shC[2], shC[3])); D = fminf(fminf(shD[0], shD[1]), fminf(shD[2], shD[3]));
-    int cnt = 0;
-    for (int t = threadIdx.x; t < nt; t += 256) cnt += bb_tile_qualifies(a, t0 + t, L, U) ? 1 : 0;
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-    if ((threadIdx.x & 63) == 0) shc[threadIdx.x >> 6] = cnt;
+    /* the tiles that can still hold an extremum -> the field's tile list (39 744 blocks that look at one tile each and leave cost 3 us per field) */
+    __shared__ unsigned s_n;
+    if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
+    for (int t = threadIdx.x; t < nt; t += 256)
+        if (bb_tile_qualifies(a, t0 + t, L, U)) a.tlist[t0 + atomicAdd(&s_n, 1u)] = (unsigned)t;
+    __syncthreads();
+    (void)shc;
     if (threadIdx.x == 0) {
-        cnt = shc[0] + shc[1] + shc[2] + shc[3];
         a.LU[2 * f] = L; a.LU[2 * f + 1] = U;
-        a.flags[f] = (cnt > a.max_cand && !a.force_all) ? 1 : 0;
+        a.flags[f] = 0;
+        a.ntl[f] = s_n;
         a.count[f] = 0u;
         unsigned *k = a.keys + (size_t)f * a.key_stride;
         k[0] = D <= C ? f2key(D) : 0xFFFFFFFFu; k[1] = D <= C ? f2key(C) : 0u; k[2] = 0u;      /* the values already known: windows of one value */
@@ -1377,13 +1381,16 @@ __global__ __launch_bounds__(64) void k_bb_select(bb_args a)
     __shared__ unsigned buf[BB_TW * BB_TH];
     const int f = blockIdx.y;
     if (a.flags[f]) return;
-    const int nt = a.ntx * a.nty, t = blockIdx.x;
+    const int nt = a.ntx * a.nty;
     const float L = a.LU[2 * f], U = a.LU[2 * f + 1];
-    if (!bb_tile_qualifies(a, (size_t)f * nt + t, L, U)) return;
     const float *zf = a.zin + (size_t)f * a.in_stride;
+    const int lane = threadIdx.x & 63;
+    const unsigned ntl = a.ntl[f];
+  for (unsigned kt = blockIdx.x; kt < ntl; kt += gridDim.x) {
+    const int t = (int)a.tlist[(size_t)f * nt + kt];
     const int ty = t / a.ntx, tx = t - ty * a.ntx;
     const bool all = a.force_all != 0 || a.tile_bad[(size_t)f * nt + t] != 0;
-    const int lane = threadIdx.x & 63;
+    __syncthreads();                                          /* the previous tile's copy-out is done with buf */
     unsigned nloc = 0;                                        /* wave-uniform */
     float vmin = INFINITY, vmax = -INFINITY;
     int kmn, kmx;
@@ -1396,13 +1403,14 @@ __global__ __launch_bounds__(64) void k_bb_select(bb_args a)
         nloc += (unsigned)__builtin_popcountll(m);
     });
     bb_publish(a, f, vmin, vmax);
-    if (!nloc) return;
+    if (!nloc) continue;
     unsigned base = 0;
     if (lane == 0) base = atomicAdd(&a.count[f], nloc);
     base = (unsigned)__shfl((int)base, 0, 64);
     __syncthreads();
     unsigned *list = a.list + (size_t)f * BB_LIST_CAP;
     for (unsigned k = lane; k < nloc; k += 64) if (base + k < BB_LIST_CAP) list[base + k] = buf[k];
+  }
 }
 
 /* the value k_sep / k_sepx store at target column c, main row r: the same tables, the same operation order */
@@ -1471,7 +1479,7 @@ extern "C" size_t ezhip_bb_work_bytes(const ezhip_sep_plan *plan, int nfields)
 {
     int ntx, nty; bb_geometry(plan, &ntx, &nty);
     const size_t nt = (size_t)ntx * nty * (size_t)nfields;
-    return 4 * BB_TILE_F * nt + 4 * nt + 8 * (size_t)nfields + 4 * (size_t)nfields + 4 * (size_t)BB_LIST_CAP * (size_t)nfields + 256;
+    return 4 * BB_TILE_F * nt + 4 * nt + 4 * nt + 8 * (size_t)nfields + 8 * (size_t)nfields + 4 * (size_t)BB_LIST_CAP * (size_t)nfields + 256;
 }
 static void bb_fill(bb_args *a, const ezhip_sep_plan *plan, const float *d_zin, size_t in_stride, int nfields, unsigned *d_partials, size_t stride_words,
                     int *d_flags, const float *d_poles, void *d_work)
@@ -1486,8 +1494,10 @@ static void bb_fill(bb_args *a, const ezhip_sep_plan *plan, const float *d_zin, 
     char *w = (char *)d_work;
     a->tile = (float *)w; w += 4 * BB_TILE_F * nt;
     a->tile_bad = (unsigned *)w; w += 4 * nt;
+    a->tlist = (unsigned *)w; w += 4 * nt;
     a->LU = (float *)w; w += 8 * (size_t)nfields;
     a->count = (unsigned *)w; w += 4 * (size_t)nfields;
+    a->ntl = (unsigned *)w; w += 4 * (size_t)nfields;
     a->list = (unsigned *)w;
     a->keys = d_partials; a->key_stride = stride_words; a->flags = d_flags; a->poles = d_poles;
     /* when is a field handed back (flags)?  When more than an eighth of its windows (at most BB_LIST_CAP) can hold an extremum: evaluating them point by
@@ -1508,7 +1518,7 @@ extern "C" int ezhip_minmax_bb(const ezhip_sep_plan *plan, const float *d_zin, s
     bb_args a;
     bb_fill(&a, plan, d_zin, in_stride, nfields, d_partials, stride_words, d_flags, d_poles, d_work);
     const bool vec = plan->ni_src % 4 == 0 && in_stride % 4 == 0 && ((uintptr_t)d_zin & 15) == 0;
-    const dim3 g1((unsigned)a.ntx, (unsigned)((a.nty + 3) / 4), (unsigned)nfields), g2((unsigned)(a.ntx * a.nty), (unsigned)nfields), g3(64, (unsigned)nfields);
+    const dim3 g1((unsigned)a.ntx, (unsigned)((a.nty + 3) / 4), (unsigned)nfields), g2((unsigned)(a.ntx * a.nty < 48 ? a.ntx * a.nty : 48), (unsigned)nfields), g3(64, (unsigned)nfields);
 #define BB_LAUNCH(NT, DEG) do { \
         if (vec) { hipLaunchKernelGGL((k_bb_bounds<NT, true>), g1, dim3(256), 0, g_stream, a); hipLaunchKernelGGL(k_bb_reduce, dim3((unsigned)nfields), dim3(256), 0, g_stream, a); \
                    hipLaunchKernelGGL((k_bb_select<NT, true>), g2, dim3(64), 0, g_stream, a); } \
