@@ -2158,6 +2158,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
     pv = pu;
     pu.pole_row_n = pun; pu.pole_row_s = pus; pv.pole_row_n = pvn; pv.pole_row_s = pvs;
     if (zones == 2 && s->have_dehors) ierc = 2;
+    pu.tile_ni = go->ni; pu.tile_nj = go->nj;                  /* the points are the whole target grid in row order: 2-D tile order */
     if (ezhip_interp_pts2(&pu, &pv, d_uo, d_vo, d_ui, d_vi, s->d_x, s->d_y, go->ni * go->nj)) return -1;
     return ierc;
 }

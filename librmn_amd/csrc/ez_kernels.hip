@@ -1160,6 +1160,7 @@ extern "C" int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const
  * a field of noise) is flagged instead and the caller runs the interpolating pass for it. */
 #define BB_TW 252          /* window columns of a strip: the 64 lanes of a wave hold 256 consecutive source columns */
 #define BB_TH 32           /* window rows of a tile (one wave sweeps them) */
+#define BB_SUB 8           /* window rows per block of the second sweep */
 #define BB_TILE_F 8            /* floats per tile record */
 #define BB_LIST_CAP (1 << 18)   /* candidate windows per field; more: the field is handed back (flags) */
 struct bb_args {
@@ -1190,12 +1191,12 @@ __device__ __forceinline__ int bb_key(float v) { const int u = __float_as_int(v)
 __device__ __forceinline__ float bb_unkey(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
 #define BB_KEY_POS_INF 0x7f800000            /* keys >= this: +inf / NaN; keys <= ~this: -inf / -NaN */
 template <int NT, bool VEC, bool COARSE, class F>
-__device__ __forceinline__ void bb_sweep(const bb_args &a, const float *zf, int tx, int ty, int *kmin_out, int *kmax_out, F &&visit)
+__device__ __forceinline__ void bb_sweep(const bb_args &a, const float *zf, int tx, int j0a, int j0b_, int *kmin_out, int *kmax_out, F &&visit)
 {
     const int lane = threadIdx.x & 63;
     const int ni = a.p.ni_src, nj = a.p.nj_src;
     const int nwr = nj - NT + 1;
-    const int j0a = ty * BB_TH, j0b = min(j0a + BB_TH, nwr);
+    const int j0b = min(j0b_, nwr);                           /* window rows [j0a, j0b) */
     int kmn = 0x7fffffff, kmx = (int)0x80000000;
     *kmin_out = kmn; *kmax_out = kmx;
     if (j0a >= j0b) return;
@@ -1298,7 +1299,7 @@ __global__ __launch_bounds__(256) void k_bb_bounds(bb_args a)
     const float *zf = a.zin + (size_t)f * a.in_stride;
     float tub = -INFINITY, tlb = INFINITY, L = -INFINITY, U = INFINITY, cmx = -INFINITY, cmn = INFINITY;
     int kmn, kmx;
-    bb_sweep<NT, VEC, true>(a, zf, tx, ty, &kmn, &kmx, [&](bool valid, int, int, float ub, float lb) {
+    bb_sweep<NT, VEC, true>(a, zf, tx, ty * BB_TH, ty * BB_TH + BB_TH, &kmn, &kmx, [&](bool valid, int, int, float ub, float lb) {
         const bool open = valid && ub != lb;                  /* a window whose values are still to be evaluated; else (ub == lb) its value is known: cmx / cmn */
         tub = fmaxf(tub, open ? ub : -INFINITY); tlb = fminf(tlb, open ? lb : INFINITY);       /* selects, not branches */
         L = fmaxf(L, valid ? lb : -INFINITY); U = fminf(U, valid ? ub : INFINITY);
@@ -1378,7 +1379,7 @@ __device__ __forceinline__ void bb_publish(const bb_args &a, int f, float vmin, 
 template <int NT, bool VEC>
 __global__ __launch_bounds__(64) void k_bb_select(bb_args a)
 {
-    __shared__ unsigned buf[BB_TW * BB_TH];
+    __shared__ unsigned buf[BB_TW * BB_SUB];
     const int f = blockIdx.y;
     if (a.flags[f]) return;
     const int nt = a.ntx * a.nty;
@@ -1386,15 +1387,16 @@ __global__ __launch_bounds__(64) void k_bb_select(bb_args a)
     const float *zf = a.zin + (size_t)f * a.in_stride;
     const int lane = threadIdx.x & 63;
     const unsigned ntl = a.ntl[f];
-  for (unsigned kt = blockIdx.x; kt < ntl; kt += gridDim.x) {
-    const int t = (int)a.tlist[(size_t)f * nt + kt];
+  /* a tile goes to BB_TH / BB_SUB blocks, BB_SUB window rows each: one wave sweeping the 32 rows of a tile alone was the whole pass's duration */
+  for (unsigned kt = blockIdx.x; kt < ntl * (BB_TH / BB_SUB); kt += gridDim.x) {
+    const int t = (int)a.tlist[(size_t)f * nt + kt / (BB_TH / BB_SUB)], sub = (int)(kt % (BB_TH / BB_SUB));
     const int ty = t / a.ntx, tx = t - ty * a.ntx;
     const bool all = a.force_all != 0 || a.tile_bad[(size_t)f * nt + t] != 0;
     __syncthreads();                                          /* the previous tile's copy-out is done with buf */
     unsigned nloc = 0;                                        /* wave-uniform */
     float vmin = INFINITY, vmax = -INFINITY;
     int kmn, kmx;
-    bb_sweep<NT, VEC, false>(a, zf, tx, ty, &kmn, &kmx, [&](bool valid, int i0, int j0, float ub, float lb) {
+    bb_sweep<NT, VEC, false>(a, zf, tx, ty * BB_TH + sub * BB_SUB, ty * BB_TH + sub * BB_SUB + BB_SUB, &kmn, &kmx, [&](bool valid, int i0, int j0, float ub, float lb) {
         const bool known = !all && ub == lb;                   /* a window of one value: nothing to evaluate */
         if (valid && known) { vmin = fminf(vmin, lb); vmax = fmaxf(vmax, ub); }
         const bool cand = valid && !known && (all || !(ub < L) || !(lb > U));
@@ -1518,7 +1520,7 @@ extern "C" int ezhip_minmax_bb(const ezhip_sep_plan *plan, const float *d_zin, s
     bb_args a;
     bb_fill(&a, plan, d_zin, in_stride, nfields, d_partials, stride_words, d_flags, d_poles, d_work);
     const bool vec = plan->ni_src % 4 == 0 && in_stride % 4 == 0 && ((uintptr_t)d_zin & 15) == 0;
-    const dim3 g1((unsigned)a.ntx, (unsigned)((a.nty + 3) / 4), (unsigned)nfields), g2((unsigned)(a.ntx * a.nty < 48 ? a.ntx * a.nty : 48), (unsigned)nfields), g3(64, (unsigned)nfields);
+    const dim3 g1((unsigned)a.ntx, (unsigned)((a.nty + 3) / 4), (unsigned)nfields), g2((unsigned)(a.ntx * a.nty * (BB_TH / BB_SUB) < 128 ? a.ntx * a.nty * (BB_TH / BB_SUB) : 128), (unsigned)nfields), g3(64, (unsigned)nfields);
 #define BB_LAUNCH(NT, DEG) do { \
         if (vec) { hipLaunchKernelGGL((k_bb_bounds<NT, true>), g1, dim3(256), 0, g_stream, a); hipLaunchKernelGGL(k_bb_reduce, dim3((unsigned)nfields), dim3(256), 0, g_stream, a); \
                    hipLaunchKernelGGL((k_bb_select<NT, true>), g2, dim3(64), 0, g_stream, a); } \
@@ -1887,6 +1889,87 @@ template <class A, bool AOS = false> __device__ __forceinline__ float p_irgdint_
     double b14 = d_fa4(d1, d2, d3, d4, d5, d6, bb[0], bb[1], bb[2], bb[3]);
     return (float)d_fa(bb[0], b12, b13, b14, y, (double)y1, (double)y2, (double)y3);
 }
+/* Both components of a wind at one point, ez_irgdint_3_w.inc:20-235 regrouped: the Newton form is LINEAR in the four values of a row,
+ *   fa = z1 + t1 (a2 + t2 (a3 + t3 a4)) = z1 + A (z2 - z1) + B (z3 - z2) + G (z4 - z3),   t_k = x - x_k,
+ *   A = t1 c1 (1 - t2 c2 (1 - t3 c4)),  B = t1 t2 c3 (c2 - t3 c4 (c5 + c2)),  G = t1 t2 t3 c4 c5 c6
+ * with the reference's own REAL coefficient tables c1..c6 (ez_nwtncof) -- the same polynomial in the same differences, another association of
+ * the REAL*8 operations (results differ from the literal form by a few ulp of REAL*8, 1e-16 of the values; winds are compared at 1e-5 |V|).  A, B, G
+ * depend on the point only: 4 rows x 2 fields share them, as do the three of the y direction: 190 instead of 375 VALU instructions per point pair
+ * in k_pts2, which is bound by them (six waves per SIMD, each 18 % active: the issue slots of the SIMD are taken).  Scalars (k_pts) keep the literal form. */
+struct NewtonW { double a, b, g; };
+__device__ __forceinline__ NewtonW newton_w(double c1, double c2, double c3, double c4, double c5, double c6, double t1, double t2, double t3)
+{
+    NewtonW w;
+    const double t12 = t1 * t2, t3c4 = t3 * c4;
+    w.a = t1 * c1 * (1.0 - t2 * c2 * (1.0 - t3c4));
+    w.b = t12 * c3 * (c2 - t3c4 * (c5 + c2));
+    w.g = t12 * t3c4 * c5 * c6;
+    return w;
+}
+__device__ __forceinline__ double newton_apply(const NewtonW &w, double z1, double z2, double z3, double z4)
+{
+    return fma(w.g, z4 - z3, fma(w.b, z3 - z2, fma(w.a, z2 - z1, z1)));
+}
+template <class A, bool AOS>
+__device__ __forceinline__ void p_irgdint_3_w_pair(const A &Z1, const A &Z2, float px, float py, const float *ax, const float *ay,
+                                                   const float *cx, const float *cy, int ni, int j1, int j2, int wrap, float &r1, float &r2)
+{
+    const int nnj = j2 - j1 + 1;
+    int i = min(ni - 2 + wrap, max(1, max(2 - wrap, (int)px)));
+    int j = min(j2 - 2, max(j1 + 1, (int)py));
+    int im1, ip1, ip2; float x1, x2, x3, x4;
+    irr_cols(ax, ni, wrap, i, 2, im1, ip1, ip2, x1, x2, x3, x4);
+    const float *b = ay - j1;
+    const double x = (double)(x2 + (x3 - x2) * (px - (float)i));
+    const double y = (double)(b[j] + (b[j + 1] - b[j]) * (py - (float)j));
+    const float y1 = b[j - 1], y2 = b[j], y3 = b[j + 1];
+    const NewtonW wx = newton_w(coef<AOS>(cx, 0, i - 1, ni), coef<AOS>(cx, 1, i - 1, ni), coef<AOS>(cx, 2, i - 1, ni), coef<AOS>(cx, 3, i - 1, ni),
+                                coef<AOS>(cx, 4, i - 1, ni), coef<AOS>(cx, 5, i - 1, ni), x - (double)x1, x - (double)x2, x - (double)x3);
+    const NewtonW wy = newton_w(coef<AOS>(cy, 0, j - j1, nnj), coef<AOS>(cy, 1, j - j1, nnj), coef<AOS>(cy, 2, j - j1, nnj), coef<AOS>(cy, 3, j - j1, nnj),
+                                coef<AOS>(cy, 4, j - j1, nnj), coef<AOS>(cy, 5, j - j1, nnj), y - (double)y1, y - (double)y2, y - (double)y3);
+    /* y direction as weights of the four row values (b0 + A (b1 - b0) + B (b2 - b1) + G (b3 - b2) regrouped once more): the rows stream through two
+     * accumulators instead of waiting in eight registers */
+    const double wr[4] = {1.0 - wy.a, wy.a - wy.b, wy.b - wy.g, wy.g};
+    double su = 0.0, sv = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        double z1, z2, z3, z4;
+        row_taps(Z1, im1, i, ip1, ip2, j - 1 + r, z1, z2, z3, z4);
+        su = fma(wr[r], newton_apply(wx, z1, z2, z3, z4), su);
+        row_taps(Z2, im1, i, ip1, ip2, j - 1 + r, z1, z2, z3, z4);
+        sv = fma(wr[r], newton_apply(wx, z1, z2, z3, z4), sv);
+    }
+    r1 = (float)su; r2 = (float)sv;
+}
+/* The same away from the longitude seam (i - 1 .. i + 2 consecutive: all but two or three source columns), with EVERY load of the point issued before the
+ * first is used: the axis entries, the two coefficient records and the eight stencil rows of the pair depend on (i, j) only.  Written in program order
+ * (x, y from the axes -> coefficients -> rows) the compiler kept four dependent memory round trips per point behind the divergent seam branches;
+ * k_pts2 is bound by that chain (a wave lived 5 us for 375 instructions), not by its gathers' bandwidth or its arithmetic. */
+__device__ __forceinline__ void p_irgdint_3_w_pair_inner(const float *z1f, const float *z2f, float px, float py, const float *ax, const float *ay,
+                                                         const float *cx8, const float *cy8, int ni, int j1, int i, int j, float &r1, float &r2)
+{
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    const f4u axv = *(const f4u *)(ax + (i - 2));                            /* ax(i-1 .. i+2) */
+    const f4u ayv = *(const f4u *)(ay + (j - 1 - j1));                       /* ay(j-1 .. j+2); j <= j2 - 2 */
+    const f4u cxa = *(const f4u *)(cx8 + (size_t)(i - 1) * 8); const f2u cxb = *(const f2u *)(cx8 + (size_t)(i - 1) * 8 + 4);
+    const f4u cya = *(const f4u *)(cy8 + (size_t)(j - j1) * 8); const f2u cyb = *(const f2u *)(cy8 + (size_t)(j - j1) * 8 + 4);
+    const size_t o0 = (size_t)(j - 1 - j1) * (size_t)ni + (size_t)(i - 2);
+    f4u u[4], v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { u[r] = *(const f4u *)(z1f + o0 + (size_t)r * ni); v[r] = *(const f4u *)(z2f + o0 + (size_t)r * ni); }
+    const double x = (double)(axv.y + (axv.z - axv.y) * (px - (float)i));
+    const double y = (double)(ayv.y + (ayv.z - ayv.y) * (py - (float)j));
+    const NewtonW wx = newton_w((double)cxa.x, (double)cxa.y, (double)cxa.z, (double)cxa.w, (double)cxb.x, (double)cxb.y, x - (double)axv.x, x - (double)axv.y, x - (double)axv.z);
+    const NewtonW wy = newton_w((double)cya.x, (double)cya.y, (double)cya.z, (double)cya.w, (double)cyb.x, (double)cyb.y, y - (double)ayv.x, y - (double)ayv.y, y - (double)ayv.z);
+    const double wr[4] = {1.0 - wy.a, wy.a - wy.b, wy.b - wy.g, wy.g};
+    double su = 0.0, sv = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        su = fma(wr[r], newton_apply(wx, (double)u[r].x, (double)u[r].y, (double)u[r].z, (double)u[r].w), su);
+        sv = fma(wr[r], newton_apply(wx, (double)v[r].x, (double)v[r].y, (double)v[r].z, (double)v[r].w), sv);
+    }
+    r1 = (float)su; r2 = (float)sv;
+}
 /* ez_irgdint_3_wnnc.inc:20-246 (ay: 4-entry strip latitudes indexed from j1) */
 template <class A> __device__ __forceinline__ float p_irgdint_3_wnnc(const A &Z, float px, float py, const float *ax, const float *ay4,
                                                      int ni, int j1, int j2, int wrap)
@@ -2015,6 +2098,16 @@ __device__ __forceinline__ int pts_zone(int zones, int ni, int nj, int j1, int j
  * the version that also called the out-of-line strip / re-interpolation code kept the plan in scratch and reached its
  * tables through 100 flat loads).  Points of the polar strips and re-interpolated extrapolation points are left to
  * k_pts_special. */
+/* XCD-aware order of the point blocks: thread blocks are dealt round-robin to the 8 XCDs, each with its own L2; XCD k takes the k-th CONTIGUOUS eighth
+ * of the target points, so that its gathers stay inside an eighth of the source (+ what the rotation spreads) instead of all of it: with the linear
+ * order every L2 held the whole cfg3 source pair (measured: 370 MB fetched per 8 M point pairs for 26 MB of sources + 192 MB of x, y, matrices;
+ * L2 hit rate of the gathers 64 %) */
+__device__ __forceinline__ unsigned pts_block(unsigned b, unsigned nb)
+{
+    const unsigned full = nb & ~7u;
+    return b < full ? (b & 7u) * (full >> 3) + (b >> 3) : b;
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void k_pts(ezhip_pts_plan p, float *__restrict__ zout, const float *__restrict__ zin,
                                              const float *__restrict__ xs, const float *__restrict__ ys, int npts,
@@ -2048,13 +2141,23 @@ __global__ __launch_bounds__(256) void k_pts(ezhip_pts_plan p, float *__restrict
  * arithmetic: 80 VGPRs without spilling, -10 us per cfg3 pair.  (Lagrange weights shared by the two components -- the Newton tables'
  * reciprocals are the Lagrange denominators -- cut the VALU work from 540 to 310 instructions per wave and were measured SLOWER at equal
  * occupancy, 172 - 186 against 165 - 169 us: the kernel is bound by its gathers, not by its arithmetic; the reference's Newton form stays.) */
-template <int KIND>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_pts2(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+template <int KIND, bool LITERAL>
+__device__ __forceinline__ void pts2_body(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
                                               const float *__restrict__ zin1, const float *__restrict__ zin2,
                                               const float *__restrict__ xs, const float *__restrict__ ys, int npts,
                                               int *__restrict__ special_list, unsigned *__restrict__ special_count)
 {
-    int n = blockIdx.x * 256 + threadIdx.x;
+    int n;
+    if (p.tile_ni > 0) {
+        /* 2-D order: block = 32 x 8 target points, wave = 8 x 8.  The TCP (vector L1) looks up about one cache line per cycle; 64 consecutive points of a
+         * target row touch ~10 lines per stencil-row load when the source is rotated, an 8 x 8 patch 2 - 3.  The four waves of a block sit side by side:
+         * their 32-byte row pieces of x, y and the outputs make whole 128-byte lines */
+        const unsigned tpr = ((unsigned)p.tile_ni + 31u) >> 5, b = p.xcd_order ? pts_block(blockIdx.x, gridDim.x) : blockIdx.x;
+        const unsigned by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
+        const unsigned cx_ = bx * 32u + (t >> 6) * 8u + (t & 7u), cy_ = by * 8u + ((t >> 3) & 7u);
+        if (cx_ >= (unsigned)p.tile_ni || cy_ >= (unsigned)p.tile_nj) return;
+        n = (int)(cy_ * (unsigned)p.tile_ni + cx_);
+    } else n = (int)(p.xcd_order ? pts_block(blockIdx.x, gridDim.x) : blockIdx.x) * 256 + threadIdx.x;
     if (n >= npts) return;
     const float px = xs[n], py = ys[n];
     const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;
@@ -2064,10 +2167,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
      * (fetched where it is applied it cost +37 us per cfg3 pair, as much as the separate k_wind_apply pass) */
     typedef float f4v __attribute__((ext_vector_type(4)));
     f4v wm = {1.0f, 0.0f, 0.0f, 1.0f};
-    if (p.wind_M) { wm = __builtin_nontemporal_load(((const f4v *)p.wind_M) + o); asm volatile("" : "+v"(wm)); }
+    /* (the empty asm pins the load here -- and makes the compiler wait for it here: one memory round trip before the interpolation starts.  The
+     * all-loads-first form below issues it with the point's other loads instead) */
+    constexpr bool FRONT = KIND == PK_IRGD3_W && !LITERAL;
+    if (p.wind_M && !FRONT) { wm = __builtin_nontemporal_load(((const f4v *)p.wind_M) + o); asm volatile("" : "+v"(wm)); }
     if (zone == PZ_NORMAL || zone == PZ_FILL) {
         float a, b;
         if (zone == PZ_FILL) a = b = *p.fill;
+        else if (KIND == PK_IRGD3_W && !LITERAL) {
+            const int i = min(p.ni - 2 + p.wrap, max(1, max(2 - p.wrap, (int)px))), j = min(p.j2 - 2, max(p.j1 + 1, (int)py));
+            const bool seam = i <= 1 || i >= p.ni - 1;                         /* (wrap 0: i stays in 2 .. ni - 2) */
+            /* in flight with the loads of the interpolation; unconditional (a conditional load is merged with the identity at the join: a use, hence a
+             * wait, right behind it): without a matrix a readable dummy address */
+            wm = __builtin_nontemporal_load(p.wind_M ? ((const f4v *)p.wind_M) + o : (const f4v *)p.ncx8);
+            if (__ballot(seam) == 0ull) p_irgdint_3_w_pair_inner(zin1, zin2, px, py, p.ax, p.ay, p.ncx8, p.ncy8, p.ni, p.j1, i, j, a, b);
+            else p_irgdint_3_w_pair<PlainAcc, true>(Z1, Z2, px, py, p.ax, p.ay, p.ncx8, p.ncy8, p.ni, p.j1, p.j2, p.wrap, a, b);
+        }
         else { a = leaf_point<KIND>(p, Z1, px, py); b = leaf_point<KIND>(p, Z2, px, py); }
         if (p.wind_M) {                       /* the wind chain of the grid pair (k_wind_apply), here instead of a pass of its own */
             const float u = a, v = b;
@@ -2084,6 +2199,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         base = (unsigned)__shfl((int)base, leader, 64);
         special_list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = n;
     }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_pts2(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+                                              const float *__restrict__ zin1, const float *__restrict__ zin2,
+                                              const float *__restrict__ xs, const float *__restrict__ ys, int npts,
+                                              int *__restrict__ special_list, unsigned *__restrict__ special_count)
+{
+    pts2_body<KIND, true>(p, zout1, zout2, zin1, zin2, xs, ys, npts, special_list, special_count);
+}
+/* winds from an irregular source with wrap (cfg3): the regrouped Newton form with every load of a point in flight at once: more registers per
+ * lane (no occupancy floor), half the dependent memory round trips */
+__global__ __launch_bounds__(256) void k_pts2_irgd3w(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+                                              const float *__restrict__ zin1, const float *__restrict__ zin2,
+                                              const float *__restrict__ xs, const float *__restrict__ ys, int npts,
+                                              int *__restrict__ special_list, unsigned *__restrict__ special_count)
+{
+    pts2_body<PK_IRGD3_W, false>(p, zout1, zout2, zin1, zin2, xs, ys, npts, special_list, special_count);
 }
 
 /* Special points only (a fraction of a percent of a global target): polar strips on the virtual 4-row strip,
@@ -2182,7 +2315,7 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
                                  const float *d_in_u, const float *d_in_v, const float *d_x, const float *d_y, int npts)
 {
     if (npts <= 0) return 0;
-    const dim3 grid((npts + 255) / 256), block(256);
+    const dim3 block(256);
     if (t_spec.cap < (size_t)npts) {
         (void)hipStreamSynchronize(g_stream);
         if (t_spec.list) (void)hipFree(t_spec.list);
@@ -2194,7 +2327,13 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     }
     unsigned *cnt = t_spec.count + (t_spec.epoch & 1), *cnt_next = t_spec.count + ((t_spec.epoch + 1) & 1);
     t_spec.epoch++;
-#define PTS2_CASE(K) case K: hipLaunchKernelGGL(k_pts2<K>, grid, block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, t_spec.list, cnt); break
+    ezhip_pts_plan pu2 = *plan_u;
+    pu2.newton_literal = getenv("EZHIP_WIND_NEWTON_LITERAL") ? 1 : 0;      /* development: the reference's literal Newton form for winds too */
+    pu2.xcd_order = getenv("EZHIP_PTS_XCD") ? 1 : 0;                        /* development: XCD k takes the k-th eighth of the blocks (fewer fabric reads, measured slower) */
+    if (getenv("EZHIP_PTS_NOTILE") || (long long)pu2.tile_ni * pu2.tile_nj != (long long)npts || pu2.out_idx) pu2.tile_ni = pu2.tile_nj = 0;
+    const dim3 grid(pu2.tile_ni > 0 ? (unsigned)(((pu2.tile_ni + 31) / 32) * ((pu2.tile_nj + 7) / 8)) : (unsigned)((npts + 255) / 256));
+#define PTS2_CASE(K) case K: if (K == PK_IRGD3_W && !pu2.newton_literal) hipLaunchKernelGGL(k_pts2_irgd3w, grid, block, 0, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, t_spec.list, cnt); \
+        else hipLaunchKernelGGL(k_pts2<K>, grid, block, 0, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, t_spec.list, cnt); break
     switch (pts_kind(plan_u)) {
     PTS2_CASE(PK_RGD0); PTS2_CASE(PK_RGD1_NW); PTS2_CASE(PK_RGD1_W); PTS2_CASE(PK_RGD3_NW); PTS2_CASE(PK_RGD3_W);
     PTS2_CASE(PK_IRGD1_NW); PTS2_CASE(PK_IRGD1_W); PTS2_CASE(PK_IRGD3_NW); PTS2_CASE(PK_IRGD3_W);

@@ -188,6 +188,9 @@ typedef struct {
     const float *fill;                /* device scalar */
     const float *polevals;            /* device float[2] = {north, south}; computed by ezhip_polevals */
     const int *out_idx;               /* NULL, or target position of point n (Yin-Yang lists: no temporary + scatter pass) */
+    int newton_literal, xcd_order;    /* development switches of k_pts2 (set by its launcher from the environment) */
+    int tile_ni, tile_nj;             /* > 0: the points are a whole ni x nj target grid in row order: k_pts2 walks it in 32 x 8 tiles (a wave = 8 x 8 points: its stencils
+                                         share a few cache lines; 64 points of one target row cross a dozen source rows of a rotated source) */
 } ezhip_pts_plan;
 
 int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin,
