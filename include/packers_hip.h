@@ -105,14 +105,36 @@ int32_t ezhip_pack16_compress_batch_dev(void *d_records, int64_t record_stride_w
 int32_t ezhip_ezsint_pack16_compress_batch_dev(void *d_records, int64_t record_stride_words, const float *d_zin, int32_t nfields,
                                                int32_t ni_out, int32_t nj_out, int32_t nbits, int32_t *zlng_out);
 /* ---- FST record framing around the packers ---------------------------------------------------------------------
- * The DATA PART of an FST record exactly as c_fstecr lays it out from buffer->data[keys_len] on (src/fstd98/fstd98.c:935-1000 sizes,
- * :1140-1370 the datyp switch): for datyp > 128 the length word, the packer header(s), the armn_compress stream; compression that does
- * not pay falls back to the plain type (*datyp_out).  32-bit elements; datyp 0, 1, 129, 2, 130, 4, 5 (32 bits), 6, 134, 133.
- * Returns the number of 32-bit words of the data part (what c_xdfput would be given) or -1.  The read side (:2270-2440) expands the
- * stream in place in `data` like the reference does in its record buffer. */
+ * The DATA PART of an FST record exactly as c_fstecr lays it out from buffer->data[keys_len] on (src/fstd98/fstd98.c:808-826 flags, :935-1000
+ * sizes, :1133-1370 the datyp switch): for datyp > 128 the length word, the packer header(s), the armn_compress stream; compression that does
+ * not pay falls back to the plain type (*datyp_out); turbo types beyond 16 bits lose the flag (:934).  Returns the number of 32-bit words of the
+ * data part (what c_xdfput would be given) or -1.  The read side (:2169-2183, :2270-2466) expands the stream in place in `data` like the reference
+ * does in its record buffer.
+ * _ex: elem_bytes = size of the caller's array elements (what xdf_byte / xdf_short / xdf_double tell the reference): 4 REAL / INTEGER, 8 REAL*8
+ * (datyp 1, 129 through compact_double; datyp 5 with 64 bits), 2 and 1 for integer types (datyp 2, 130, 4 through compact_short / compact_char,
+ * the signed type through the sign-extension of the compiled branch, fstd98.c:22).  datyp may carry the missing-value flag (+64): the magic
+ * values of the array are replaced by a packable stand-in above the maximum (EncodeMissingValue, fst_missing.c:1472) and restored after
+ * unpacking (DecodeMissingValue :1579) when the mode is on (MISSING_VALUE_FLAGS in the environment, or ezhip_fst_force_missing_value_usage).
+ * The plain entry points are the 4-byte forms. */
 int32_t ezhip_fst_pack_data(uint32_t *data, int64_t cap_words, void *field, int32_t ni, int32_t nj, int32_t nk, int32_t datyp, int32_t nbits,
                             int32_t *datyp_out, int32_t *nbits_out);
 int32_t ezhip_fst_unpack_data(void *field, uint32_t *data, int32_t ni, int32_t nj, int32_t nk, int32_t datyp, int32_t nbits);
+int32_t ezhip_fst_pack_data_ex(uint32_t *data, int64_t cap_words, void *field, int32_t ni, int32_t nj, int32_t nk, int32_t datyp, int32_t nbits,
+                               int32_t elem_bytes, int32_t *datyp_out, int32_t *nbits_out);
+int32_t ezhip_fst_unpack_data_ex(void *field, uint32_t *data, int32_t ni, int32_t nj, int32_t nk, int32_t datyp, int32_t nbits, int32_t elem_bytes);
+/* A record the cfg5 pipeline left in HBM -> the data part of the FST record c_fstecr(datyp 129) writes for it, without leaving the device: the length word in
+ * front of [4 header words][stream] (in place when d_data + 1 == d_record), or -- zlng < 0: compression did not pay -- the datyp 1 form re-packed from
+ * the record's 16-bit-slot tokens (fstd98.c:1164-1190).  Asynchronous; returns the words of the data part, *datyp_out = 129 or 1; -1 on error */
+int32_t ezhip_fst_frame_record_dev(uint32_t *d_data, int64_t cap_words, const uint32_t *d_record, int32_t zlng, int32_t ni, int32_t nj, int32_t nk,
+                                   int32_t nbits, int32_t *datyp_out);
+/* src/fstd98/fst_missing.c: missing_value_used :245, ForceMissingValueUsage :309, set_missing_value_flags :100 (NULL = keep), EncodeMissingValue :1472,
+ * DecodeMissingValue :1579 */
+int32_t ezhip_fst_missing_value_used(void);
+int32_t ezhip_fst_force_missing_value_usage(int32_t enable);
+void    ezhip_fst_set_missing_value_flags(const float *f, const int32_t *i, const uint32_t *ui, const double *d, const int16_t *s, const uint16_t *us,
+                                          const int8_t *b, const uint8_t *ub);
+int32_t ezhip_fst_encode_missing_value(void *dst, const void *src, int32_t n, int32_t datatype, int32_t nbits, int32_t is_byte, int32_t is_short, int32_t is_double);
+void    ezhip_fst_decode_missing_value(void *field, int32_t n, int32_t datatype, int32_t is_byte, int32_t is_short, int32_t is_double);
 /* frees the calling thread's grow-only device workspaces (staged operands of the host-pointer entry points,
  * the compressed stream, the armn_compress scan storage); they are re-created on the next call */
 void  ezhip_pack_release(void);

@@ -746,6 +746,44 @@ int32_t ezhip_ezsint_batch_tokens_dev(uint32_t *d_tokens, int64_t token_stride_w
  *   F  fields that are not compressible get the plain 16-bit pack (conditional copy, one launch)
  * One synchronisation at the end (zlng_out).  Returns the c_ezsint code (0), -1 on error, or -2 when the grid set is not on the
  * single-launch k_sepx path / the shape is outside the one-pass encoder (use the unfused entry points then). */
+/* ------------------------------------------------------------------------------------------ */
+/* FST framing of a record the cfg5 pipeline left in HBM (fstd98.c:1164-1190)   */
+/* ------------------------------------------------------------------------------------------ */
+/* d_record = [4 compact_float header words (16-bit slots, style 2)][armn_compress stream of zlng bytes | the 16-bit-slot tokens when zlng < 0]: what
+ * ezhip_ezsint_pack16_compress_batch_dev / ezhip_pack16_compress_dev leave per field.  d_data (device, cap_words) receives the DATA PART of the FST
+ * record c_fstecr(datyp 129, nbits) writes for that field:
+ *   zlng > 0   [nw][4 header words][stream], zero padded to nw = 2 ceil((16 + zlng) 8 / 64) words; *datyp_out = 129.  d_data + 1 == d_record frames in
+ *              place: one word in front of the record is all it takes;
+ *   zlng < 0   compression did not pay: the reference packs again as datyp 1 -- header style 1 (3 words + 24 bits) and the nbits-wide tokens from bit
+ *              120 on; the tokens are the same numbers, re-packed on the device; *datyp_out = 1.
+ * Asynchronous on the current stream; returns the number of words of the data part, -1 on error. */
+int32_t ezhip_fst_frame_record_dev(uint32_t *d_data, int64_t cap_words, const uint32_t *d_record, int32_t zlng, int32_t ni, int32_t nj, int32_t nk,
+                                   int32_t nbits, int32_t *datyp_out)
+{
+    if (need_device("ezhip_fst_frame_record_dev")) return -1;
+    const int64_t n = (int64_t)ni * nj * nk;
+    if (n <= 0 || nbits < 1 || nbits > 16 || !d_data || !d_record) return -1;
+    if (zlng > 0) {
+        const int64_t nbytes = 16 + (int64_t)zlng, nw = 2 * ((nbytes * 8 + 63) / 64);
+        if (nw > cap_words) { fprintf(stderr, "<ezhip_fst_frame_record_dev> the data part needs %lld words\n", (long long)nw); return -1; }
+        int64_t ncopy = 4 + ((int64_t)zlng + 3) / 4;
+        if (ncopy > nw - 1) ncopy = nw - 1;
+        if (packhip_fst_frame129(d_data, d_record, (unsigned)nw, (unsigned)ncopy)) return -1;
+        if (datyp_out) *datyp_out = 129;
+        return (int32_t)nw;
+    }
+    if (d_data + 1 == d_record || d_data == d_record) { fprintf(stderr, "<ezhip_fst_frame_record_dev> the datyp 1 form cannot be built in place\n"); return -1; }
+    const int64_t nw = 2 * ((n * (nbits > 16 ? nbits : 16) + 128 + 32 + 63) / 64);      /* the record keeps the length computed for datyp 129 (fstd98.c:971-973: nw is not recomputed) */
+    if (nw > cap_words) { fprintf(stderr, "<ezhip_fst_frame_record_dev> the data part needs %lld words\n", (long long)nw); return -1; }
+    unsigned *d_tok32 = (unsigned *)ws(5, 4 * (size_t)n + 64);
+    if (!d_tok32) return -1;
+    if (ezhip_memset(d_data, 0, 4 * (size_t)nw)) return -1;
+    if (packhip_fst_plain_from_slots(d_data, d_tok32, d_record, (size_t)n)) return -1;
+    if (packhip_ci_pack(d_data + 3, d_tok32, (size_t)n, nbits, 24, 1, 0, 0, 0, 0, 0)) return -1;
+    if (datyp_out) *datyp_out = 1;
+    return (int32_t)nw;
+}
+
 static int32_t cfg5_batch(void *d_records, int64_t record_stride_words, const float *d_zin, int32_t nfields,
                           int32_t ni_out, int32_t nj_out, int32_t nbits, int32_t *zlng_out, int use_bb)
 {

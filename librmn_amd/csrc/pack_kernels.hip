@@ -1531,6 +1531,44 @@ extern "C" int packhip_cond_copy(unsigned *d_dst, size_t dst_stride, const unsig
     hipLaunchKernelGGL(k_cond_copy, dim3(1024, nfields), dim3(256), 0, STREAM, d_dst, dst_stride, d_src, src_stride, nwords, d_zlng, mode);
     return chk("k_cond_copy");
 }
+/* ---- FST framing of a device-resident cfg5 record (fst_record_host.c: ezhip_fst_frame_record_dev) ------------------------------------ */
+/* datyp 129 (fstd98.c:1164-1190): data[0] = nw, data[1..4] = the four compact_float header words, data[5..] = the armn_compress stream, zero up to nw.
+ * In place (data + 1 == record) only word 0 and the padding are written. */
+__global__ __launch_bounds__(256) void k_fst_frame129(unsigned *data, const unsigned *rec, unsigned nw, unsigned ncopy)
+{
+    const unsigned k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nw) return;
+    if (k == 0) data[0] = nw;
+    else if (k <= ncopy) { if (data + 1 != rec) data[k] = rec[k - 1]; }
+    else data[k] = 0u;
+}
+/* the 16-bit-slot tokens of a record (two per word, the first in the high half) as one token per 32-bit word */
+__global__ __launch_bounds__(256) void k_fst_tok16_widen(unsigned *tok32, const unsigned *slots, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const unsigned w = slots[k >> 1];
+    tok32[k] = (k & 1) ? (w & 0xFFFFu) : (w >> 16);
+}
+/* datyp 1 header (style 1, compact.tmplc:303-318) from the style-2 words of the record: the type code changes, word 3 keeps its upper 24 bits (the stream
+ * starts in its last byte) */
+__global__ void k_fst_hdr_style1(unsigned *data, const unsigned *rec)
+{
+    data[0] = (rec[0] & 0x000FFFFFu) | (((rec[0] >> 20) == 0xFEFu ? 0x7EFu : 0x7FFu) << 20);
+    data[1] = rec[1]; data[2] = rec[2]; data[3] = rec[3] & 0xFFFFFF00u;
+}
+extern "C" int packhip_fst_frame129(unsigned *d_data, const unsigned *d_rec, unsigned nw, unsigned ncopy)
+{
+    hipLaunchKernelGGL(k_fst_frame129, dim3((nw + 255) / 256), dim3(256), 0, STREAM, d_data, d_rec, nw, ncopy);
+    return chk("k_fst_frame129");
+}
+extern "C" int packhip_fst_plain_from_slots(unsigned *d_data, unsigned *d_tok32, const unsigned *d_rec, size_t n)
+{
+    hipLaunchKernelGGL(k_fst_tok16_widen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM, d_tok32, d_rec + 4, n);
+    hipLaunchKernelGGL(k_fst_hdr_style1, dim3(1), dim3(1), 0, STREAM, d_data, d_rec);
+    return chk("k_fst_plain_from_slots");
+}
+
 /* exchange the 16-bit halves of every word (c_armn_compress_setswap(0) on the multi-kernel path) */
 __global__ __launch_bounds__(256) void k_swap_halves(unsigned *dst, const unsigned *src, size_t n)
 {

@@ -53,6 +53,10 @@ int packhip_armn_encode1(unsigned *d_z, size_t z_stride_words, size_t z_cap_word
                          int ni, int nj, int nbits, int nfields, int swapped, int container, void *d_work, int *d_zlng);
 int packhip_cond_copy(unsigned *d_dst, size_t dst_stride, const unsigned *d_src, size_t src_stride, size_t nwords, const int *d_zlng, int nfields, int mode);
 int packhip_swap_halves(unsigned *d_dst, const unsigned *d_src, size_t nwords);
+/* FST framing of a device-resident cfg5 record: the datyp-129 data part (length word + record + zero padding); the datyp-1 fallback's header and
+ * one-token-per-word array (packhip_ci_pack then packs them behind the header) */
+int packhip_fst_frame129(unsigned *d_data, const unsigned *d_rec, unsigned nw, unsigned ncopy);
+int packhip_fst_plain_from_slots(unsigned *d_data, unsigned *d_tok32, const unsigned *d_rec, size_t n);
 /* armn_compress UNCOMPRESS (unpack_kernels.hip): nfields streams of z_words capacity each -> (1 + ni*nj/2) token words each */
 size_t packhip_armn_dec_work_bytes(int ni, int nj, size_t z_words);
 int packhip_armn_decode(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,

@@ -228,21 +228,38 @@ def armn_uncompress32(z, ni, nj, znbits):
 
 
 def fst_pack_data(field, ni, nj, nk, datyp, nbits):
-    """the data part of an FST record (c_fstecr's packing switch): returns (words, datyp_out, nbits_out, uint32 buffer)"""
+    """the data part of an FST record (c_fstecr's packing switch): returns (words, datyp_out, nbits_out, uint32 buffer).  The element size is the
+    array's (float32 / int32 / uint32: 4, float64: 8, int16 / uint16: 2, int8 / uint8: 1); datyp may carry the missing-value flag (+64)"""
     L = _lib()
-    L.ezhip_fst_pack_data.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_int32] * 5 + [ctypes.c_void_p] * 2
+    L.ezhip_fst_pack_data_ex.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_int32] * 6 + [ctypes.c_void_p] * 2
     f = np.ascontiguousarray(field)
     n = ni * nj * nk
-    cap = n * max(nbits, 16) // 32 + n // 8 + 256
+    cap = n * max(nbits, 16) // 32 + n // 8 + 256 + (2 * n if f.itemsize == 8 else 0)
     buf = np.zeros(cap, np.uint32)
     d = ctypes.c_int32(-1); b = ctypes.c_int32(-1)
-    w = L.ezhip_fst_pack_data(buf.ctypes.data, cap, f.ctypes.data, ni, nj, nk, datyp, nbits, ctypes.addressof(d), ctypes.addressof(b))
+    w = L.ezhip_fst_pack_data_ex(buf.ctypes.data, cap, f.ctypes.data, ni, nj, nk, datyp, nbits, f.itemsize, ctypes.addressof(d), ctypes.addressof(b))
     return w, d.value, b.value, buf
 
 
 def fst_unpack_data(buf, ni, nj, nk, datyp, nbits, dtype=np.float32):
     L = _lib()
-    L.ezhip_fst_unpack_data.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 5
+    L.ezhip_fst_unpack_data_ex.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 6
     out = np.zeros(ni * nj * nk, dtype)
-    rc = L.ezhip_fst_unpack_data(out.ctypes.data, buf.ctypes.data, ni, nj, nk, datyp, nbits)
+    rc = L.ezhip_fst_unpack_data_ex(out.ctypes.data, buf.ctypes.data, ni, nj, nk, datyp, nbits, out.itemsize)
     return rc, out
+
+
+def fst_force_missing_value_usage(enable):
+    return _lib().ezhip_fst_force_missing_value_usage(1 if enable else 0)
+
+
+def fst_frame_record_dev(d_data, cap_words, d_record, zlng, ni, nj, nk, nbits):
+    """a cfg5 record in HBM -> the data part of the datyp-129 (or, zlng < 0, datyp-1) FST record, on the device; returns (words, datyp_out).
+    d_data / d_record: torch int32 CUDA tensors or raw device pointers"""
+    L = _lib()
+    L.ezhip_fst_frame_record_dev.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_int32] * 5 + [ctypes.c_void_p]
+    d = ctypes.c_int32(-1)
+    pd = d_data if isinstance(d_data, int) else d_data.data_ptr()
+    pr = d_record if isinstance(d_record, int) else d_record.data_ptr()
+    w = L.ezhip_fst_frame_record_dev(pd, cap_words, pr, int(zlng), ni, nj, nk, nbits, ctypes.addressof(d))
+    return w, d.value

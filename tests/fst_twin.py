@@ -6,6 +6,61 @@ import test_oracle_packers as top
 import test_oracle_armn32 as ta32
 
 
+# ---- missing values: numpy restatement of src/fstd98/fst_missing.c (fld_*_anal :465-732, fst_*_encode_missing :884-1260, fst_*_decode_missing :736-880) ----
+MAGIC = {np.dtype(np.float32): np.float32(-1.0e38), np.dtype(np.float64): np.float64(-1.0e38), np.dtype(np.int32): np.int32(-2**31),
+         np.dtype(np.int16): np.int16(-2**15), np.dtype(np.int8): np.int8(-2**7), np.dtype(np.uint32): np.uint32(2**32 - 1),
+         np.dtype(np.uint16): np.uint16(2**16 - 1), np.dtype(np.uint8): np.uint8(2**8 - 1)}
+SHARE = np.array([2.0, 1.1, 0.55, 0.28, 0.14, 0.07, 0.035, 0.017, 0.01], np.float32)
+
+
+def mv_scan(a):
+    """(max, min, count) as fld_*_anal finds them: the magic values excluded, unless the field is nothing else"""
+    m = MAGIC[a.dtype]
+    good = a[a != m]
+    count = int(a.size - good.size)
+    if good.size == 0:
+        return m, m, count
+    return good.max(), good.min(), count
+
+
+def mv_encode(a, nbits):
+    """EncodeMissingValue: (array with stand-ins, count); count 0 = nothing to do"""
+    hi, lo, count = mv_scan(a)
+    if count == 0:
+        return a, 0
+    m = MAGIC[a.dtype]
+    if a.dtype == np.float32:
+        s = np.float32(np.float64(hi) + np.float64(hi - lo) * 0.01) if nbits > 8 else np.float32(hi + (hi - lo) * SHARE[nbits])
+        if s == hi:
+            s = np.float32(1.0) if hi == 0 else np.float32(np.float64(hi) * 2.0)
+    elif a.dtype == np.float64:
+        s = hi + (hi - lo) * 0.01 if nbits > 8 else hi + (hi - lo) * np.float64(SHARE[nbits])
+        if s == hi:
+            s = 1.0 if hi == 0 else hi * 2.0
+    elif a.dtype == np.int32:
+        pat = (0xFFFFFFFF >> (32 - nbits) if nbits < 32 else 0xFFFFFFFF) >> 1
+        s = np.int32(int(hi) + 1 if pat > int(hi) else pat)
+    elif a.dtype in (np.int16, np.int8):
+        s = a.dtype.type(int(hi) + 1 if -1 > int(hi) else -1)          # the all-ones signed pattern stays -1 under right shifts (sic)
+    else:
+        full = 8 * a.itemsize
+        pat = (2**full - 1) >> (full - nbits) if nbits < full else 2**full - 1
+        s = a.dtype.type(int(hi) + 1 if pat > int(hi) else pat)
+    out = a.copy()
+    out[a == m] = s
+    return out, count
+
+
+def mv_decode(a):
+    """DecodeMissingValue: the maximum becomes the magic value again, from element 1 on (sic)"""
+    hi, lo, _ = mv_scan(a)
+    out = a.copy()
+    sel = out == hi
+    sel[0] = False
+    out[sel] = MAGIC[a.dtype]
+    return out
+
+
 def plain_words(datyp, n, nbits):
     hs = ss = 0
     if datyp in (6, 134):
@@ -25,6 +80,17 @@ def pack(field, ni, nj, nk, datyp, nbits):
     refused compression is excluded)"""
     O = top.O(); O32 = ta32.O()
     n = ni * nj * nk
+    field = np.ascontiguousarray(field)
+    eb = field.itemsize
+    is_missing = datyp & 64
+    datyp &= ~64
+    in_datyp = datyp
+    if in_datyp == 1 and nbits in (31, 32):
+        datyp, nbits = 5, 32
+    if is_missing:
+        field, cnt = mv_encode(field, nbits)
+        if cnt == 0:
+            is_missing = 0
     if nbits > 16 and datyp != 133:          # fstd98.c:934
         datyp &= 0x7F
     if datyp == 6 and nbits > 24:
@@ -32,13 +98,22 @@ def pack(field, ni, nj, nk, datyp, nbits):
     if datyp == 6 and nbits > 16:
         datyp = 1
     words, hs = plain_words(datyp, n, nbits)
-    data = np.zeros(words + n + 64, np.uint32)
+    data = np.zeros(words + 2 * n + 64, np.uint32)
     tag = np.array([99999.0], np.float64)
-    out = datyp
+    out = datyp | is_missing
     f = np.ascontiguousarray(field)
 
     def cf(hdr_off, st_off, arg, offset):
-        assert O.orc_compact_float(f.ctypes.data, data[hdr_off:].ctypes.data, data[st_off:].ctypes.data, n, arg, offset, 1, 1, 0, tag.ctypes.data)
+        fn = O.orc_compact_double if eb == 8 else O.orc_compact_float
+        assert fn(f.ctypes.data, data[hdr_off:].ctypes.data, data[st_off:].ctypes.data, n, arg, offset, 1, 1, 0, tag.ctypes.data)
+
+    def ci(st_off, bits, op):
+        if eb == 2:
+            assert O.orc_compact_short(f.ctypes.data, None, data[st_off:].ctypes.data, n, bits, 0, 1, 5)
+        elif eb == 1:
+            assert O.orc_compact_char(f.ctypes.data, None, data[st_off:].ctypes.data, n, bits, 0, 1, 9)
+        else:
+            assert O.orc_compact_integer(f.ctypes.data, None, data[st_off:].ctypes.data, n, bits, 0, 1, op)
 
     if datyp == 0:
         data[:(n * nbits + 31) // 32] = f.view(np.uint32)[:(n * nbits + 31) // 32]
@@ -52,24 +127,44 @@ def pack(field, ni, nj, nk, datyp, nbits):
                 words = 2 * (((16 + zl) * 8 + 63) // 64); data[0] = words
         else:
             cf(0, 3, nbits, 24)
-    elif datyp in (2, 130, 4):
-        op = 3 if datyp == 4 else 1
+    elif datyp in (2, 130):
+        if eb == 2:
+            nbits = min(16, nbits)
+        if eb == 1:
+            nbits = min(8, nbits)
         if datyp == 130:
-            tok = (f.view(np.int32) & ((1 << nbits) - 1)).astype(np.uint16)
+            if eb == 2:
+                tok = f.view(np.uint16).copy()
+            elif eb == 1:
+                tok = f.view(np.int8).astype(np.int16).view(np.uint16)
+            else:
+                tok = (f.view(np.int32) & ((1 << nbits) - 1)).astype(np.uint16)
             z = np.zeros(n + 64, np.uint32)
             zl = O.orc_armn_encode(z.ctypes.data, tok.ctypes.data, ni, nj, nbits)
             if zl >= 1 + 2 * n:
                 zl = -1
             if zl < 0:
                 out = 2
-                assert O.orc_compact_integer(f.ctypes.data, None, data[1:].ctypes.data, n, nbits, 0, 1, 1)
+                ci(1, nbits, 1)
             else:
                 data[1:1 + (zl + 3) // 4] = z[:(zl + 3) // 4]
                 words = 2 * (((4 + zl) * 8 + 63) // 64); data[0] = words
         else:
-            assert O.orc_compact_integer(f.ctypes.data, None, data.ctypes.data, n, nbits, 0, 1, op)
+            ci(0, nbits, 1)
+    elif datyp == 4:
+        out = is_missing | 4
+        wide = np.ascontiguousarray(f.astype(np.int32))       # the compiled branch sign-extends short / byte elements (fstd98.c:22, :1267-1279)
+        assert O.orc_compact_integer(wide.ctypes.data, None, data.ctypes.data, n, nbits, 0, 1, 3)
     elif datyp == 5:
-        data[:n] = f.view(np.uint32)
+        if nbits == 32:
+            data[:n] = f.view(np.uint32)
+        elif nbits == 64:
+            w = f.view(np.uint32).reshape(n, 2)
+            data[:2 * n] = w[:, ::-1].reshape(-1)
+            words = 2 * n
+        else:
+            tok = np.ascontiguousarray(f.view(np.uint32) >> np.uint32(32 - nbits))
+            assert O.orc_compact_integer(tok.ctypes.data, None, data.ctypes.data, n, nbits, 0, 1, 1)
     elif datyp == 133:
         zl = O32.orc_armn_compress32(data[1:].ctypes.data, f.ctypes.data, ni, nj, nk, nbits)
         if zl < 0:
@@ -98,23 +193,48 @@ def unpack(data, ni, nj, nk, datyp, nbits, dtype=np.float32):
     n = ni * nj * nk
     d = data.copy()
     out = np.zeros(n, dtype)
+    eb = out.itemsize
+    has_missing = datyp & 64
+    datyp &= ~64
     tag = np.array([99999.0], np.float64)
     hs = 3
+    cfu = O.orc_compact_double if eb == 8 else O.orc_compact_float
     if datyp == 0:
         out.view(np.uint32)[:(n * nbits + 31) // 32] = d[:(n * nbits + 31) // 32]
     elif datyp == 1:
-        assert O.orc_compact_float(out.ctypes.data, d.ctypes.data, d[3:].ctypes.data, n, nbits, 24, 1, 2, 0, tag.ctypes.data)
+        assert cfu(out.ctypes.data, d.ctypes.data, d[3:].ctypes.data, n, nbits, 24, 1, 2, 0, tag.ctypes.data)
     elif datyp == 129:
         O.orc_armn_compress(d[5:].ctypes.data, ni, nj, nk, nbits, 2)
-        assert O.orc_compact_float(out.ctypes.data, d[1:].ctypes.data, d[5:].ctypes.data, n, nbits + 64 * max(16, nbits), 0, 1, 2, 0, tag.ctypes.data)
-    elif datyp in (2, 4):
-        O.orc_compact_integer(out.ctypes.data, None, d.ctypes.data, n, nbits, 0, 1, 2 if datyp == 2 else 4)
+        assert cfu(out.ctypes.data, d[1:].ctypes.data, d[5:].ctypes.data, n, nbits + 64 * max(16, nbits), 0, 1, 2, 0, tag.ctypes.data)
+    elif datyp == 2:
+        if eb == 2:
+            O.orc_compact_short(out.ctypes.data, None, d.ctypes.data, n, nbits, 0, 1, 6)
+        elif eb == 1:
+            O.orc_compact_char(out.ctypes.data, None, d.ctypes.data, n, 8, 0, 1, 10)
+        else:
+            O.orc_compact_integer(out.ctypes.data, None, d.ctypes.data, n, nbits, 0, 1, 2)
+    elif datyp == 4:
+        wide = np.zeros(n, np.int32)
+        O.orc_compact_integer(wide.ctypes.data, None, d.ctypes.data, n, nbits, 0, 1, 4)
+        out[:] = wide.astype(out.dtype)
     elif datyp == 130:
         tok = np.zeros(n, np.uint16)
         assert O.orc_armn_decode(tok.ctypes.data, d[1:].ctypes.data, ni, nj) == 0
-        out[:] = (tok.astype(np.int16) & np.int16(-1 if nbits >= 16 else (1 << nbits) - 1)).astype(np.int32)
+        if eb == 2:
+            out.view(np.uint16)[:] = tok
+        elif eb == 1:
+            out.view(np.int8)[:] = tok.view(np.int16).astype(np.int8)
+        else:
+            out[:] = (tok.astype(np.int16) & np.int16(-1 if nbits >= 16 else (1 << nbits) - 1)).astype(np.int32)
     elif datyp == 5:
-        out.view(np.uint32)[:] = d[:n]
+        if nbits == 32:
+            out.view(np.uint32)[:] = d[:n]
+        elif nbits == 64:
+            out.view(np.uint32)[:] = d[:2 * n].reshape(n, 2)[:, ::-1].reshape(-1)
+        else:
+            tok = np.zeros(n, np.uint32)
+            O.orc_compact_integer(tok.ctypes.data, None, d.ctypes.data, n, nbits, 0, 1, 2)
+            out.view(np.uint32)[:] = tok << np.uint32(32 - nbits)
     elif datyp == 133:
         O32.orc_armn_uncompress32(out.ctypes.data, d[1:].ctypes.data, ni, nj, nk, nbits)
     elif datyp == 6:
@@ -126,4 +246,6 @@ def unpack(data, ni, nj, nk, datyp, nbits, dtype=np.float32):
         O.orc_float_unpacker(out.ctypes.data, d[1:].ctypes.data, d[1 + hs:].ctypes.data, n, ctypes.byref(nb))
     else:
         raise ValueError(datyp)
+    if has_missing:
+        out = mv_decode(out)
     return out

@@ -621,3 +621,130 @@ def test_fst_record_data_part_integer(datyp, nbits):
     assert np.array_equal(got[:m], want[:m]), np.nonzero(got[:m] != want[:m])[0][:5]
     rc, back = pk.fst_unpack_data(got.copy(), ni, nj, nk, d_out, b_out, dtype=np.int32)
     assert rc == 0 and np.array_equal(back, f)
+
+
+# ---- element sizes other than 4 bytes and the missing-value flag (fstd98.c:808-826, :1133-1145, :1198-1231, :1263-1285; fst_missing.c) ----
+def _fst_field(dtype, n, ni, seed):
+    i = np.arange(n) % ni; j = np.arange(n) // ni
+    if np.dtype(dtype).kind == "f":
+        return (pc.float_field(n, seed=seed).astype(np.float64) * (1.0 + 1e-9 * np.arange(n))).astype(dtype)
+    bits = {1: 6, 2: 11, 4: 13}[np.dtype(dtype).itemsize]
+    base = ((i * 5 + j * 3) % (1 << bits)).astype(np.int64)
+    if np.dtype(dtype).kind == "i":
+        base = base - (1 << (bits - 1))
+    return base.astype(dtype)
+
+
+FST_EX_CASES = [(1, 16, np.float64), (1, 24, np.float64), (129, 16, np.float64), (129, 12, np.float64), (5, 64, np.float64), (5, 16, np.float32), (5, 24, np.float32),
+                (2, 12, np.uint16), (2, 7, np.uint8), (130, 12, np.uint16), (130, 7, np.uint8), (130, 16, np.uint16), (4, 12, np.int16), (4, 7, np.int8), (4, 16, np.int32)]
+
+
+@pytest.mark.parametrize("datyp,nbits,dtype", FST_EX_CASES)
+@pytest.mark.parametrize("missing", [0, 64])
+def test_fst_record_element_sizes_and_missing_values(datyp, nbits, dtype, missing):
+    """ezhip_fst_pack_data_ex / ezhip_fst_unpack_data_ex on REAL*8, 16-bit and 8-bit arrays, with and without the missing-value flag, against the
+    twin of c_fstecr / c_fstluk built from the oracle's packers and a numpy restatement of fst_missing.c"""
+    ni, nj, nk = 96, 50, 1
+    n = ni * nj
+    f = _fst_field(dtype, n, ni, seed=nbits)
+    if missing:
+        f = f.copy()
+        f[[5, 77, n // 2, n - 1]] = fst_twin.MAGIC[np.dtype(dtype)]
+    assert pk.fst_force_missing_value_usage(bool(missing)) == (1 if missing else 0)
+    try:
+        w, d_out, b_out, got = pk.fst_pack_data(f, ni, nj, nk, datyp | missing, nbits)
+        ww, dw, want = fst_twin.pack(f, ni, nj, nk, datyp | missing, nbits)
+        assert w > 0 and (w, d_out) == (ww, dw), (w, ww, d_out, dw)
+        base = d_out & ~64
+        m = {0: n * b_out // 32, 1: (120 + n * b_out) // 32, 2: (n * b_out) // 32, 4: (n * b_out) // 32}.get(base, w - 2)
+        if base == 5:
+            m = n * b_out // 32
+        assert np.array_equal(got[:m], want[:m]), (datyp, nbits, np.nonzero(got[:m] != want[:m])[0][:5])
+        rc, back = pk.fst_unpack_data(got.copy(), ni, nj, nk, d_out, b_out, dtype=dtype)
+        assert rc == 0
+        back_w = fst_twin.unpack(want, ni, nj, nk, d_out, b_out, dtype=dtype)
+        assert np.array_equal(back.view(np.uint8), back_w.view(np.uint8)), int((back != back_w).sum())
+        # where the reference itself reads back what it wrote (not: signed 16- / 8-bit stand-ins, which stay -1, fst_missing.c:1037-1050; byte arrays with fewer
+        # than 8 bits, fstd98.c:2321; datyp 129 below 16 bits, read as contiguous tokens)
+        sane = not (np.dtype(dtype) in (np.dtype(np.int8), np.dtype(np.int16)) or (dtype == np.uint8 and nbits < 8) or ((d_out & ~64) == 129 and nbits < 16))
+        if missing and (d_out & 64) and sane:
+            mv = fst_twin.MAGIC[np.dtype(dtype)]
+            assert (back[[5, 77, n // 2, n - 1]] == mv).all()          # the magic values come back where they were
+            keep = np.ones(n, bool); keep[[5, 77, n // 2, n - 1]] = False
+            if np.dtype(dtype).kind != "f" and not (dtype == np.uint8 and datyp == 2 and nbits < 8):
+                assert np.array_equal(back[keep], f[keep])
+        elif np.dtype(dtype).kind != "f" and not missing and not (dtype == np.uint8 and datyp == 2 and nbits < 8):
+            # (a byte array written with fewer than 8 bits does not read back in the reference either: c_fstluk unpacks 8-bit tokens whatever the record
+            # says, fstd98.c:2321 against :1222)
+            assert np.array_equal(back, f)
+    finally:
+        pk.fst_force_missing_value_usage(False)
+
+
+def test_fst_missing_value_encoders_against_the_restatement():
+    """ezhip_fst_encode_missing_value / decode on every element type: stand-in values and counts as fst_missing.c computes them (numpy twin)"""
+    import ctypes
+    from librmn_amd.lib import load_library
+    L = load_library()
+    L.ezhip_fst_encode_missing_value.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 6
+    L.ezhip_fst_decode_missing_value.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 5
+    L.ezhip_fst_decode_missing_value.restype = None
+    pk.fst_force_missing_value_usage(True)
+    try:
+        for dtype, kind in [(np.float32, 1), (np.float64, 1), (np.int32, 4), (np.int16, 4), (np.int8, 4), (np.uint32, 2), (np.uint16, 2), (np.uint8, 2)]:
+            for nbits in (6, 8, 12, 16):
+                for variant in ("some", "first", "constant", "none"):
+                    n = 500
+                    a = _fst_field(dtype, n, 25, seed=nbits + 1)
+                    mv = fst_twin.MAGIC[np.dtype(dtype)]
+                    if variant == "constant":
+                        a[:] = a[3]
+                    if variant in ("some", "constant"):
+                        a[[7, 100, 499]] = mv
+                    if variant == "first":
+                        a[[0, 1, 250]] = mv
+                    eb = a.itemsize
+                    dst = np.zeros_like(a)
+                    cnt = L.ezhip_fst_encode_missing_value(dst.ctypes.data, a.ctypes.data, n, kind, nbits, int(eb == 1), int(eb == 2), int(eb == 8))
+                    want, wc = fst_twin.mv_encode(a, nbits)
+                    assert cnt == wc, (dtype, nbits, variant, cnt, wc)
+                    if cnt:
+                        assert np.array_equal(dst.view(np.uint8), want.view(np.uint8)), (dtype, nbits, variant)
+                        back = dst.copy()
+                        L.ezhip_fst_decode_missing_value(back.ctypes.data, n, kind, int(eb == 1), int(eb == 2), int(eb == 8))
+                        assert np.array_equal(back.view(np.uint8), fst_twin.mv_decode(want).view(np.uint8)), (dtype, nbits, variant)
+    finally:
+        pk.fst_force_missing_value_usage(False)
+
+
+@pytest.mark.parametrize("kind", ["smooth", "rough"])
+@pytest.mark.parametrize("nbits", [16, 12])
+@pytest.mark.parametrize("in_place", [False, True])
+def test_fst_frame_of_a_device_resident_record(kind, nbits, in_place):
+    """ezhip_fst_frame_record_dev: the record compact_float(16-bit slots) + armn_compress left in HBM becomes the data part c_fstecr(datyp 129) writes --
+    length word + header + stream, or the re-packed datyp 1 form when compression did not pay -- without the field or the tokens visiting the host;
+    against ezhip_fst_pack_data on the same field (which the twin of c_fstecr pins)"""
+    ni, nj, nk = 120, 75, 1
+    n = ni * nj
+    f = pc.float_field(n, seed=5) if kind == "smooth" else (ec_hash(n) * np.float32(1000.0)).astype(np.float32)
+    d_f = torch.from_numpy(f).cuda()
+    front = 1
+    buf = torch.zeros(front + 4 + n // 2 + 64, dtype=torch.int32, device="cuda")
+    rec = buf[front:]
+    zl = pk.pack16_compress_dev(rec, d_f, ni, nj, nbits)
+    torch.cuda.synchronize()
+    assert zl > 0 or kind == "rough", zl                     # (12-bit noise in 16-bit slots still compresses; 16-bit noise does not)
+    w_h, d_h, b_h, want = pk.fst_pack_data(f, ni, nj, nk, 129, nbits)
+    if in_place and zl < 0:
+        w, d_out = pk.fst_frame_record_dev(buf, buf.numel(), rec, zl, ni, nj, nk, nbits)
+        assert w == -1                                         # the datyp 1 form cannot be built over its own tokens
+        return
+    out = buf if in_place else torch.full((n + 256,), 0x55555555, dtype=torch.int32, device="cuda")
+    w, d_out = pk.fst_frame_record_dev(out, out.numel(), rec, zl, ni, nj, nk, nbits)
+    torch.cuda.synchronize()
+    assert (w, d_out) == (w_h, d_h), (w, w_h, d_out, d_h)
+    got = out.cpu().numpy().view(np.uint32)
+    m = w - 2 if d_out == 129 else (120 + n * nbits) // 32
+    assert np.array_equal(got[:m], want[:m]), np.nonzero(got[:m] != want[:m])[0][:5]
+    if d_out == 129:
+        assert not got[5 + (zl + 3) // 4:w].any()              # zero padding up to the length word's count
