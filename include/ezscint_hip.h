@@ -106,6 +106,9 @@ int32_t ezhip_ezsint_batch_minmax_bb_dev(const float *d_zin, int32_t nfields, ui
 int32_t ezhip_ezsint_batch_minmax_only_dev(const float *d_zin, int32_t nfields, uint32_t *d_partials, int64_t stride_words, int32_t *partials_per_field);
 int32_t ezhip_ezsint_batch_tokens_dev(uint32_t *d_tokens, int64_t token_stride_words, const float *d_zin, int32_t nfields,
                                       const void *d_params, int64_t param_stride_bytes);
+/* frees what the CALLING host thread owns in the library: device workspaces, page-locked staging buffers, its side stream.  Called automatically when a
+ * thread that used the library ends; grids, sets and plans are process-wide and stay */
+void ezhip_thread_release(void);
 /* dimensions of the current grid set (the pair of c_ezdefset): -1 when none is defined */
 int32_t ezhip_current_set_dims(int32_t *ni_in, int32_t *nj_in, int32_t *ni_out, int32_t *nj_out);
 /* forces plan construction for the current set / options (what the reference does lazily in its first call) */

@@ -36,6 +36,8 @@ static void *w32(int slot, size_t bytes)
     return t_w32[slot].p;
 }
 
+void ezh_armn32_thread_release(void) { for (int k = 0; k < 8; k++) { ezhip_free(t_w32[k].p); t_w32[k].p = NULL; t_w32[k].cap = 0; } }
+
 /* ---- MSB-first bit stream on host words: the `stuff` / `extract` rules (include/bitPacking.h:59-139) ---- */
 typedef struct { uint32_t *z; uint64_t pos; } bitw32;              /* over a zeroed buffer */
 static inline void bw32_put(bitw32 *w, uint32_t tok, int bits)              /* bits <= 32, tok < 2^bits, buffer zeroed: at most two words touched */

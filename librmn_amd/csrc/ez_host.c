@@ -1765,26 +1765,24 @@ static pthread_mutex_t g_plan_mtx = PTHREAD_MUTEX_INITIALIZER;
 
 /* in-kernel pole values of k_sepx: per host thread a ring of 4 {values, flags} buffers (consecutive launches of one
  * thread are stream-ordered; the ring only guards a thread that switches streams between calls) and a launch epoch */
-static __thread struct { float *vals; unsigned *flags; int cap; unsigned epoch; } t_pole;
+static __thread struct { unsigned long long *gran; int cap; unsigned epoch; } t_pole;
 static int pole_ring(int nfields, ezhip_sep_plan *p)
 {
     int nb = ((2 * nfields + 7) / 8) * 8;
     if (t_pole.cap < nb) {
         ezhip_sync();
-        ezhip_free(t_pole.vals);
-        size_t bytes = (size_t)4 * nb * (sizeof(float) + sizeof(unsigned));
-        t_pole.vals = (float *)ezhip_malloc(bytes);
-        if (!t_pole.vals) { t_pole.cap = 0; return -1; }
-        if (ezhip_memset(t_pole.vals, 0, bytes) || ezhip_sync()) return -1;
-        t_pole.flags = (unsigned *)(t_pole.vals + (size_t)4 * nb);
+        ezhip_free(t_pole.gran);
+        size_t bytes = (size_t)4 * nb * sizeof(unsigned long long);
+        t_pole.gran = (unsigned long long *)ezhip_malloc(bytes);
+        if (!t_pole.gran) { t_pole.cap = 0; return -1; }
+        if (ezhip_memset(t_pole.gran, 0, bytes) || ezhip_sync()) return -1;
         t_pole.cap = nb; t_pole.epoch = 0;
     }
     t_pole.epoch++;
     if (t_pole.epoch == 0) t_pole.epoch = 1;
     int slot = (int)(t_pole.epoch & 3);
     p->pole_blocks = nb; p->pole_epoch = t_pole.epoch;
-    p->pole_vals = t_pole.vals + (size_t)slot * t_pole.cap;
-    p->pole_flags = t_pole.flags + (size_t)slot * t_pole.cap;
+    p->pole_gran = t_pole.gran + (size_t)slot * t_pole.cap;
     return 0;
 }
 
@@ -2424,6 +2422,15 @@ static float *stage(int slot, size_t n)
         t_stage[slot].cap = t_stage[slot].p ? n : 0;
     }
     return t_stage[slot].p;
+}
+/* everything the calling thread owns on the device: workspaces, staging buffers, pole granules (ezhip_thread_release / thread exit) */
+void ezh_ez_thread_release(void)
+{
+    for (int k = 0; k < 4; k++) { ezhip_free(t_stage[k].p); t_stage[k].p = NULL; t_stage[k].cap = 0; }
+    ezhip_free(t_scratch8); t_scratch8 = NULL;
+    ezhip_free(t_pole.gran); t_pole.gran = NULL; t_pole.cap = 0;
+    ezhip_free(t_xpn.p); t_xpn.p = NULL; t_xpn.cap = 0;
+    ezhip_free(t_bbws.p); t_bbws.p = NULL; t_bbws.cap = 0;
 }
 
 int32_t c_ezsint(float *zout, float *zin)               /* ezsint.c:38-135 */

@@ -57,6 +57,7 @@ extern "C" const char *ezhip_last_error(void) { return g_err; }
  * of its own device; every compute entry point checks (need_device) and refuses loudly instead.  EZHIP_TEST_BOUND_DEVICE: tests only. */
 #include <atomic>
 static std::atomic<int> g_bound_dev{-1};
+static void arm_thread_guard(void);
 extern "C" int ezhip_bound_device_ok(const char *who)
 {
     int d = -1;
@@ -67,12 +68,40 @@ extern "C" int ezhip_bound_device_ok(const char *who)
         int want = e ? atoi(e) : d, expected = -1;
         bound = g_bound_dev.compare_exchange_strong(expected, want, std::memory_order_acq_rel) ? want : expected;
     }
-    if (bound == d) return 0;
+    if (bound == d) { arm_thread_guard(); return 0; }
     fprintf(stderr, "<%s> the library's grids, plans and workspaces of this process live on HIP device %d, but the calling thread's current device is %d: "
                     "one process per GPU (select the device before the first call and keep it)\n", who, bound, d);
     return -1;
 }
 extern "C" int ezhip_bound_device(void) { return g_bound_dev.load(std::memory_order_acquire); }
+
+/* Per-thread state (workspaces, page-locked bounce buffers, the side stream, lists) is released when the host thread that owns it ends, and on request
+ * (ezhip_thread_release): a service that runs calls on short-lived threads does not accumulate 2 x 16 MB of page-locked memory and its device workspaces
+ * per thread that ever called.  Not at process exit: the HIP runtime may already be gone by then. */
+extern "C" void ezh_ez_thread_release(void);
+extern "C" void ezhip_pack_release(void);
+extern "C" void ezh_armn32_thread_release(void);
+extern "C" void ezh_interpv_thread_release(void);
+extern "C" void ezh_interpv_thread_release2(void);
+static void kernels_thread_release(void);
+static std::atomic<bool> g_process_exiting{false};
+extern "C" void ezhip_thread_release(void)
+{
+    if (g_bound_dev.load(std::memory_order_acquire) < 0) return;                /* the library never touched the device */
+    (void)hipDeviceSynchronize();
+    ezh_ez_thread_release(); ezhip_pack_release(); ezh_armn32_thread_release(); ezh_interpv_thread_release(); ezh_interpv_thread_release2();
+    kernels_thread_release();
+}
+namespace {
+struct thread_guard { bool armed = false; ~thread_guard() { if (armed && !g_process_exiting.load()) ezhip_thread_release(); } };
+thread_local thread_guard t_guard;
+}
+static void arm_thread_guard(void)
+{
+    static std::atomic<bool> once{false};
+    if (!once.exchange(true)) atexit([]() { g_process_exiting.store(true); });
+    t_guard.armed = true;
+}
 
 extern "C" void *ezhip_malloc(size_t nbytes)
 {
@@ -614,8 +643,8 @@ __device__ float sep_special(const ezhip_sep_plan &p, float *__restrict__ zout, 
             for (int k = 0; k < 4; k++) { need_n |= (sr.tap[k] == EZ_ROW_POLE_N); need_s |= (sr.tap[k] == EZ_ROW_POLE_S); }
         float pole_n = 0.f, pole_s = 0.f;
         if (!p.vector_mode) {       /* pole values: precomputed once per field by k_polevals (a sequential REAL sum: ~10 us) */
-            if (need_n) pole_n = p.pole_timeout ? __builtin_nanf("") : __hip_atomic_load(&p.polevals[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (need_s) pole_s = p.pole_timeout ? __builtin_nanf("") : __hip_atomic_load(&p.polevals[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (need_n) pole_n = p.pole_timeout ? __builtin_nanf("") : (p.pole_inline ? p.pole_now[0] : p.polevals[0]);
+            if (need_s) pole_s = p.pole_timeout ? __builtin_nanf("") : (p.pole_inline ? p.pole_now[1] : p.polevals[1]);
         }
         if (sr.kind == 1) outv = pole_n;
         else if (sr.kind == 2) outv = pole_s;
@@ -886,8 +915,7 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
         const int chunk = (int)((p.x_lds_bytes / sizeof(float) - 4) & ~(size_t)3);
         const float v = block_poleval(row, p.ni_src, p.pole_weighted, p.ax, (float *)smem_x, chunk);
         if (threadIdx.x == 0) {
-            p.pole_vals[L] = v;
-            __hip_atomic_store(&p.pole_flags[L], p.pole_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&p.pole_gran[L], (unsigned long long)p.pole_epoch << 32 | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
@@ -929,15 +957,18 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
     const int sp0 = p.special_last ? (p.special_last > 1 ? min(p.special_last - 2, p.x_nseg) : p.x_nseg) : p.x_nseg >> 1;      /* a lone field: last (nothing to overlap, and they must not hold slots while the pole producers run) */
     if (by >= sp0 && by < sp0 + p.n_special) {
         if (P) {
-            p.polevals = p.pole_vals + 2 * bz;
+            p.pole_inline = 0;
             if (p.need_poles) {
                 /* RELAXED agent-scope loads (sc1: served by the coherence point, never by a stale L1/L2 line), not
                  * acquire: on the 8-XCD part an agent-scope acquire is `buffer_inv sc1`, which drops the XCD's
                  * non-local L2 lines -- 232 special-row blocks per field doing that cost +6 us per field.  The flag
                  * load, the branch on it and the (equally cache-bypassing) value loads in sep_special issue in order. */
+                p.pole_inline = 1;
                 for (int k = 0; k < 2; k++) {
                     int spins = 0;
-                    while (__hip_atomic_load(&p.pole_flags[2 * bz + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.pole_epoch) {
+                    unsigned long long g;
+                    /* value and epoch arrive in ONE 64-bit word: no ordering between two loads to rely on */
+                    while ((unsigned)((g = __hip_atomic_load(&p.pole_gran[2 * bz + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != p.pole_epoch) {
                         __builtin_amdgcn_s_sleep(32);
                         if (++spins > (1 << 22)) {       /* seconds: never in a healthy launch.  Do not hang the device, and do not go on with
                                                             whatever the slot holds: the polar rows become NaN and the host learns of it */
@@ -946,8 +977,8 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
                             break;
                         }
                     }
+                    p.pole_now[k] = __uint_as_float((unsigned)g);
                 }
-                __atomic_signal_fence(__ATOMIC_SEQ_CST);
             }
         } else if (p.polevals) p.polevals += 2 * bz;
         const float sv = sep_special<DEG, OUT>(p, zout, zin, by - sp0, c, cc, c < p.ni_dst, fillv, qp);
@@ -2280,6 +2311,19 @@ __global__ __launch_bounds__(256) void k_pts_special2(ezhip_pts_plan p, float *_
 /* per host thread: the list of special point indices of a launch and a PAIR of counters (the special kernel of
  * launch e consumes counter e & 1 and zeroes the other one for launch e + 1: no memset between launches) */
 static thread_local struct { int *list; unsigned *count; size_t cap; unsigned epoch; } t_spec;
+static void kernels_thread_release(void)
+{
+    if (t_spec.list) { (void)hipFree(t_spec.list); t_spec.list = nullptr; t_spec.count = nullptr; t_spec.cap = 0; }
+    for (int k = 0; k < 2; k++) {
+        if (t_bnc.buf[k]) { (void)hipHostFree(t_bnc.buf[k]); t_bnc.buf[k] = nullptr; }
+        if (t_bnc.ev[k]) { (void)hipEventDestroy(t_bnc.ev[k]); t_bnc.ev[k] = nullptr; }
+    }
+    t_bnc.ok = false;
+    if (t_side) { (void)hipStreamDestroy(t_side); t_side = nullptr; }
+    if (t_ev_fork) { (void)hipEventDestroy(t_ev_fork); t_ev_fork = nullptr; }
+    if (t_ev_join) { (void)hipEventDestroy(t_ev_join); t_ev_join = nullptr; }
+    t_side_pending = false;
+}
 
 extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin,
                                 const float *d_x, const float *d_y, int npts)

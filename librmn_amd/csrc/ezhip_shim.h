@@ -118,13 +118,15 @@ typedef struct {
     int x_tr, x_prows, x_rows_per_step;   /* ring rows, patch rows, target rows per step (8 or 16) */
     int batch_fields;                 /* > 1: one launch covers this many fields, strides below, polevals[2 f] */
     /* in-kernel pole values (k_sepx): pole_blocks = 2 * fields rounded up to a multiple of 8 producer blocks (0: pole
-     * values come precomputed in `polevals`), published in pole_vals[2 f + {0 north, 1 south}] with pole_flags[] = epoch */
+     * values come precomputed in `polevals`), published in pole_gran[2 f + {0 north, 1 south}] */
     int pole_blocks; unsigned pole_epoch;
     int special_last;                 /* 1: special rows at the end of the field's work order (single-field launch) */
     int by_lo, by_cnt;                /* by_cnt > 0 (with special_last = 1, one field): the launch covers rows by_lo .. by_lo + by_cnt - 1 of the
                                          work order [segments | special rows] only (host-pointer ABI: row ranges as the source arrives) */
     int pole_timeout; int *err_word;  /* set by the launcher / the kernel: the bounded wait for the pole values gave up (polar rows := NaN, *err_word := 1) */
-    float *pole_vals; unsigned *pole_flags;
+    unsigned long long *pole_gran;    /* [pole_blocks] {launch epoch << 32 | REAL bits of the pole value}: ONE 64-bit word per value, written and polled with relaxed agent-scope
+                                         atomics: flag and value cannot be seen apart, whatever the memory model allows for two separate words */
+    float pole_now[2]; int pole_inline;   /* set inside the kernel: the two values a special-row block took from its granules */
     int x_nbx; size_t x_lds_bytes;    /* set by the launcher: column strips, dynamic LDS bytes */
     /* fused compact_float min/max (k_sepx<.., STATS>): every thread block writes {min key, max key, 0} of the values it
      * stored to stat_partials[field * stat_stride + 3 * (work item in field)]; NULL: not requested */

@@ -146,6 +146,13 @@ static void *slot(int k, size_t nbytes)
     return t_slot[k].p;
 }
 
+/* the calling thread's device slots and page-locked buffers (ezhip_thread_release / thread exit) */
+void ezh_interpv_thread_release(void)
+{
+    for (int k = 0; k < SL_COUNT; k++) { ezhip_free(t_slot[k].p); t_slot[k].p = NULL; t_slot[k].cap = 0; }
+}
+static void bounce_release(void);
+
 static void die_no_device(const char *who)
 {
     fprintf(stderr, "<%s> cannot continue without the HIP device (a Fortran subroutine has no status to return)\n", who);
@@ -167,6 +174,8 @@ static void *bounce(int k, size_t nbytes)
     }
     return t_bounce[k].p;
 }
+static void bounce_release(void) { for (int k = 0; k < SL_COUNT; k++) { ezhip_host_free(t_bounce[k].p); t_bounce[k].p = NULL; t_bounce[k].cap = 0; } }
+void ezh_interpv_thread_release2(void) { bounce_release(); }
 static int up(int k, const void *h, size_t es, int n, int ijdim, int rows)
 {
     const size_t row = es * (size_t)n, total = row * (size_t)rows;

@@ -42,6 +42,7 @@ void ezhip_pack_release(void)
 {
     ezhip_sync();
     for (int k = 0; k < 6; k++) { ezhip_free(t_ws[k].p); t_ws[k].p = NULL; t_ws[k].cap = 0; }
+    ezhip_free(t_scratch); t_scratch = NULL;
 }
 
 static void *scratch(void)

@@ -1340,3 +1340,32 @@ def test_averaging_degrees_against_the_reference_build(degree):
         rc, z = ez.ezsint(zin, no * mo)
         assert rc == rc_r
         assert np.array_equal(z.view(np.uint32), zr.view(np.uint32)), (degree, src[2], int(np.count_nonzero(z != zr)))
+
+
+def test_a_thread_that_ends_gives_its_workspaces_back():
+    """per-thread device workspaces, page-locked bounce buffers and the side stream are released when the host thread ends:
+    ten short-lived threads that each run c_ezsint on host arrays leave the device's free memory where it was"""
+    import threading
+    ni, nj, no, mo = 720, 360, 1440, 721
+    gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(no, mo, "L", 25, 25, 0, 0)
+    zin = ec.synth_field(ni, nj, seed=5)
+    errs = []
+
+    def work():
+        try:
+            assert ez.ezdefset(gdout, gdin) == 1
+            rc, z = ez.ezsint(zin, no * mo)
+            assert rc == 0 and np.isfinite(z).all()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    t = threading.Thread(target=work); t.start(); t.join()          # plans and tables (process-wide) exist after this one
+    assert not errs, errs
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(10):
+        t = threading.Thread(target=work); t.start(); t.join()
+    assert not errs, errs
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), (free0, free1)               # without the release: >= 10 x (4.2 MB staging + workspaces)
