@@ -131,6 +131,20 @@ def check_outputs(ez, torch, d_out, d_in, check_f):
     return res
 
 
+def profile_traffic(key):
+    """(value, file) of a per-unit HBM / fabric traffic figure measured by the PMC passes of tools/prof_round.sh and kept under profiles/ (FETCH_SIZE x 2 on
+    gfx950 + WRITE_SIZE: MI355X_MICROARCH.md) -- PMC counters need their own rocprofv3 runs, this run does not collect them"""
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                v = json.load(fh).get(key)
+            if v is not None:
+                return float(v), "profiles/" + name
+        except Exception:   # noqa: BLE001
+            pass
+    return None
+
+
 def extras(ez, torch, stream, d_out, d_in):
     """secondary measurements next to the headline (never part of `value`): one field per launch, the host-pointer
     ABI, and BASELINE configs[2] (c_ezuvint, Z-on-E 2560x1280 -> L 4000x2000).  Best effort: {} on any failure."""
@@ -176,9 +190,16 @@ def extras(ez, torch, stream, d_out, d_in):
         d_u = torch.from_numpy(uu).cuda(); d_v = torch.from_numpy(vv).cuda()
         o_u = torch.empty(no * mo, dtype=torch.float32, device="cuda"); o_v = torch.empty_like(o_u)
         us = ev_time(lambda: ez.ezuvint_dev(o_u, o_v, d_u, d_v), 20)
+        algo3 = 2 * 4 * ni * nj + 2 * 4 * no * mo                      # both source components in, both target components out
+        t3 = profile_traffic("cfg3_traffic_MB_per_pair")
         ex["cfg3_uvint"] = {"workload": "c_ezuvint_dev bicubic, Z-on-E 2560x1280 -> L 4000x2000, polar_correction=yes",
                             "us_per_pair": us, "Mpoint_pairs_per_s": no * mo / us,
-                            "algorithmic_GBps": (2 * 4 * ni * nj + 2 * 4 * no * mo) / us / 1e3}
+                            "algorithmic_GBps": algo3 / us / 1e3,
+                            "roofline": {"bound": "hbm", "achieved": algo3 / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": algo3 / us / 1e3 / HBM_PEAK_GBPS,
+                                         "traffic": t3[0] * 1e6 if t3 else None, "traffic_source": t3[1] if t3 else None,
+                                         "kernel": "k_pts2_irgd3w (+ k_pts_special2, k_polar_wind beside it)", "algorithmic_bytes_per_launch": algo3,
+                                         "note": "x, y of the rotated source (64 MB) and the per-point wind matrix (128 MB) are read next to the 26 MB of sources: "
+                                                 "the kernel is bound by the vector L1's 64 B/clk (TA busy 68 %), not by HBM"}}
         del d_u, d_v, o_u, o_v
         # the step after the horizontal one: vertical interpolation of device-resident profiles, search + linear + lapse-rate in one pass
         from librmn_amd import interpv as V
@@ -191,6 +212,29 @@ def extras(ez, torch, stream, d_out, d_in):
         ex["interpv_column"] = {"workload": f"Interp1D_FindPos + Interp1D_Linear + Extrap1D_LapseRate fused, REAL, {ncol} columns, {ns} -> {nd} levels (levels varying smoothly along the columns)",
                                 "us": us, "Mvalues_per_s": ncol * nd / us, "algorithmic_GBps": 4.0 * ncol * (2 * ns + 2 * nd) / us / 1e3,
                                 "frac_of_hbm_peak": 4.0 * ncol * (2 * ns + 2 * nd) / us / 1e3 / HBM_PEAK_GBPS}
+        del vls, vld, ss, sd
+        # the read side: armn_compress UNCOMPRESS of cfg5 records in HBM -- one stream alone, and 16 decoded concurrently
+        from librmn_amd import packers as pk
+        n = NPTS_OUT
+        Fd = 16
+        stride = 4 + n // 2 + 64
+        recs = torch.zeros(Fd * stride, dtype=torch.int32, device="cuda")
+        rc_, zl_ = pk.pack16_compress_batch_dev(recs, stride, d_out[:Fd].contiguous(), n, Fd, NI_D, NJ_D, 16)
+        toks = torch.zeros((Fd, 1 + n // 2), dtype=torch.int32, device="cuda")
+        cap = int(max(zl_) + 3) // 4 + 1
+        def dec(nb):
+            for _ in range(2):
+                torch.cuda.synchronize(); t0_ = time.perf_counter()
+                pk.armn_uncompress_batch_dev(toks, 1 + n // 2, recs[4:], stride, cap, NI_D, NJ_D, 16, nb)
+                torch.cuda.synchronize(); dt_ = time.perf_counter() - t0_
+            return dt_ * 1e3
+        one_ms, batch_ms = dec(1), dec(Fd)
+        zmean = float(np.mean([z for z in zl_ if z > 0]))
+        ex["armn_uncompress"] = {"workload": "armn_compress UNCOMPRESS of 7200 x 3601 16-bit records in HBM (ratio %.2f)" % (zmean / (2.0 * n)),
+                                 "single_stream_ms": one_ms, "batch_of_16_ms_per_field": batch_ms / Fd,
+                                 "single_stream_GBps": (zmean + 2.0 * n) / (one_ms * 1e-3) / 1e9, "single_stream_frac_of_hbm_peak": (zmean + 2.0 * n) / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                 "batch_GBps": (zmean + 2.0 * n) * Fd / (batch_ms * 1e-3) / 1e9, "batch_frac_of_hbm_peak": (zmean + 2.0 * n) * Fd / (batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        del recs, toks
     except Exception as e:   # noqa: BLE001
         ex["error"] = repr(e)
     return ex
@@ -350,14 +394,9 @@ def main():
     achieved = F * ALGO_BYTES / (kern_us * 1e-6) / 1e9
     # HBM/fabric traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (FETCH_SIZE x2 on gfx950,
     # WRITE_SIZE exact: MI355X_MICROARCH.md); the per-field figure measured by tools/pmc_traffic.sh is kept in profiles/
-    traffic = None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as fh:
-                traffic = json.load(fh)["traffic_MB_per_field"] * 1e6 * F
-            break
-        except Exception:   # noqa: BLE001
-            pass
+    tr = profile_traffic("traffic_MB_per_field")
+    traffic = tr[0] * 1e6 * F if tr else None
+    tr5 = profile_traffic("cfg5_fused_pipeline_total_MB_per_field")
     if rank == 0:
         total_pts = float(NPTS_OUT) * F * args.steps * world
         out = {
@@ -379,7 +418,7 @@ def main():
                                    f"{F} device-resident fields per step per GPU (sharded by record, no collective)",
                        "fields_per_step_per_gpu": F, "points_per_field": NPTS_OUT, "prewarm_steps": prewarm},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": (tr[1] + " (PMC passes of the same command, not this run)") if tr else None,
                          "kernel": "k_sepx<3, 16>", "avg_launch_us": kern_us, "fields_per_launch": F,
                          "us_per_field": kern_us / F, "algorithmic_bytes_per_launch": F * ALGO_BYTES},
             "pack": {"compact_float_16bit_GBps": 4.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9, "us_per_field": pack_us,
@@ -396,6 +435,8 @@ def main():
                      # read the source once + write zlng
                      "cfg5_algorithmic_GBps": (4.0 * NI_S * NJ_S + zl_mean) / (pipe_us * 1e-6) / 1e9,
                      "cfg5_frac_of_hbm_peak": (4.0 * NI_S * NJ_S + zl_mean) / (pipe_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                     "cfg5_traffic_MB_per_field": tr5[0] if tr5 else None, "cfg5_traffic_source": tr5[1] if tr5 else None,
+                     "cfg5_stages": "extrema from bounds of the source windows (k_bb_*: no interpolation) + header + k_sepx tokens + one-pass armn encoder",
                      "zlng_bytes": int(zl[0]),
                      "compression_ratio": float(zl[0]) / (2.0 * NPTS_OUT), "unit": "GB/s of float input"},
         }
@@ -404,7 +445,9 @@ def main():
             out["extras"]["first_call_setup_ms"] = first_call_ms     # once per grid pair; steady-state numbers exclude it
             sf = out["extras"].get("single_field_launch_us")
             if sf:      # north_star words its 60 % target on "a field": the lone-field launch next to the batch launch
-                out["roofline_single_field"] = {"bound": "hbm", "achieved": ALGO_BYTES / (sf * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                out["roofline_single_field"] = {"bound": "hbm", "note": "one field per launch: the fill and drain of one launch's staging / compute / store pipeline (~4 us) is paid per field; "
+                                                        "a batch launch pays it once per batch (the headline).  The floor of the one-launch-per-field form (DESIGN 9)",
+                                                "achieved": ALGO_BYTES / (sf * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                                 "frac": ALGO_BYTES / (sf * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                                                 "kernel": "k_sepx<3, 16> (one field per launch, launches back to back)", "avg_launch_us": sf,
                                                 "algorithmic_bytes_per_launch": ALGO_BYTES}

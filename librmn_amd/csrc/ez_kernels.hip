@@ -1190,7 +1190,7 @@ extern "C" int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const
  * Windows with a non-finite value are always evaluated.  A field where more than max_cand tiles qualify (no extremum stands out:
  * a field of noise) is flagged instead and the caller runs the interpolating pass for it. */
 #define BB_TW 252          /* window columns of a strip: the 64 lanes of a wave hold 256 consecutive source columns */
-#define BB_TH 32           /* window rows of a tile (one wave sweeps them) */
+#define BB_TH 64           /* window rows of a tile (one wave sweeps them; 32: 9 % of the rows are read twice as halo, FETCH_SIZE 56 MB per 38.7 MB field) */
 #define BB_SUB 8           /* window rows per block of the second sweep */
 #define BB_TILE_F 8            /* floats per tile record */
 #define BB_LIST_CAP (1 << 18)   /* candidate windows per field; more: the field is handed back (flags) */
@@ -1259,13 +1259,13 @@ __device__ __forceinline__ void bb_sweep(const bb_args &a, const float *zf, int 
     for (int q = 0; q < NW; q++) hpn[q] = hpx[q] = p1n[q] = p1x[q] = p2n[q] = p2x[q] = 0;
     float4 nxt[G];
 #pragma unroll
-    for (int u = 0; u < G; u++) nxt[u] = load_row(min(j0a + u, nj - 1));
+    for (int u = 0; u < G; u++) nxt[u] = load_row(min(j0a + u, jend - 1));
     for (int j = j0a; j < jend; j += G) {
         float4 cur[G];
 #pragma unroll
         for (int u = 0; u < G; u++) cur[u] = nxt[u];
 #pragma unroll
-        for (int u = 0; u < G; u++) nxt[u] = load_row(min(j + G + u, nj - 1));
+        for (int u = 0; u < G; u++) nxt[u] = load_row(min(j + G + u, jend - 1));        /* (past the tile's last row: a row that is in flight anyway) */
 #pragma unroll
         for (int u = 0; u < G; u++) {
             const int jj = j + u;
