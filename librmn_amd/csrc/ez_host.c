@@ -88,6 +88,7 @@ typedef struct {
     ezh_set *sets;                          /* sets having this grid as gdout */
     int *mask;                              /* c_gdsetmask */
     int nsub, sub[2], maskgrid[2];          /* 'U' (Yin-Yang): the two Z-on-E subgrids and their core ("mask") grids */
+    float lamb[14];                         /* '!' (Lambert conformal): the xglst of igaxg95 (qgblukig, igaxg95.F:121-150) from the gribtable entry of ig1 */
 } ezh_grid;
 
 /* The grid table never moves: one lazily backed virtual reservation of the reference's capacity (1024 chunks of 128 grids,
@@ -421,6 +422,132 @@ static void h_vxyfll(float *x, float *y, const float *dlat, const float *dlon, i
     }
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Lambert conformal '!' grids                                                 */
+/* ------------------------------------------------------------------------------------------ */
+/* The four descriptors of a '!' grid name an entry of the GRIB grid dictionary `gribtable` (igaxg95.F:63-110 -> qqqgbld :201-268, qgblukig :113-180):
+ * a text file looked for in ./, $CMCCONST/ and $ARMNLIB/data/, read once; lines that start with '#' are comments, every other line is a list-directed
+ * record  gribcode centercode subcentercode projcode grtyp lat(1,1) lon(1,1) dx[km] dy[km] yaxislon latin1 latin2 ni nj lat(ni,nj) lon(ni,nj) gds-text.
+ * The FIRST line whose gribcode equals ig1 is the grid (ig2 is compared with the centre code but the entry is used either way, :164-171). */
+#define LAMB_MAXGRIDS 1024
+static struct { int n, state; int code[LAMB_MAXGRIDS]; char gty[LAMB_MAXGRIDS]; float xg[LAMB_MAXGRIDS][14]; } GBT;       /* state: 0 not read, 1 read, -1 no file */
+static pthread_mutex_t g_gbt_mtx = PTHREAD_MUTEX_INITIALIZER;
+static int gbt_tokens(char *line, char **tok, int maxtok)
+{   /* list-directed input: blanks and commas separate, character values may be quoted */
+    int n = 0;
+    char *p = line;
+    while (*p && n < maxtok) {
+        while (*p == ' ' || *p == ',' || *p == '\t' || *p == '\r' || *p == '\n') p++;
+        if (!*p) break;
+        if (*p == '\'' || *p == '"') { const char q = *p++; tok[n++] = p; while (*p && *p != q) p++; if (*p) *p++ = 0; }
+        else { tok[n++] = p; while (*p && *p != ' ' && *p != ',' && *p != '\t' && *p != '\r' && *p != '\n') p++; if (*p) *p++ = 0; }
+    }
+    return n;
+}
+static int gbt_load(void)
+{
+    pthread_mutex_lock(&g_gbt_mtx);
+    if (GBT.state == 0) {
+        char path[1024];
+        FILE *f = fopen("gribtable", "r");
+        if (!f && getenv("CMCCONST")) { snprintf(path, sizeof(path), "%s/gribtable", getenv("CMCCONST")); f = fopen(path, "r"); }
+        if (!f && getenv("ARMNLIB")) { snprintf(path, sizeof(path), "%s/data/gribtable", getenv("ARMNLIB")); f = fopen(path, "r"); }
+        GBT.state = f ? 1 : -1;
+        char line[1024];
+        while (f && fgets(line, sizeof(line), f) && GBT.n < LAMB_MAXGRIDS) {
+            if (line[0] == '#') continue;
+            char *t[20];
+            if (gbt_tokens(line, t, 20) < 16) continue;
+            float *x = GBT.xg[GBT.n];
+            GBT.code[GBT.n] = atoi(t[0]); GBT.gty[GBT.n] = t[4][0];
+            x[0] = strtof(t[5], NULL); x[1] = strtof(t[6], NULL); x[2] = strtof(t[7], NULL); x[3] = strtof(t[8], NULL);      /* lat(1,1) lon(1,1) dx dy */
+            x[4] = strtof(t[9], NULL); x[5] = strtof(t[10], NULL); x[6] = strtof(t[11], NULL);                              /* yaxislon latin1 latin2 */
+            x[7] = (float)atoi(t[12]) * 1.0f; x[8] = (float)atoi(t[13]) * 1.0f;                                             /* ni nj */
+            x[9] = strtof(t[14], NULL); x[10] = strtof(t[15], NULL);                                                         /* lat(ni,nj) lon(ni,nj) */
+            x[11] = (float)atoi(t[1]) * 1.0f; x[12] = (float)atoi(t[2]) * 1.0f; x[13] = (float)atoi(t[3]) * 1.0f;           /* centre, sub-centre, projection */
+            GBT.n++;
+        }
+        if (f) fclose(f);
+    }
+    const int st = GBT.state;
+    pthread_mutex_unlock(&g_gbt_mtx);
+    return st;
+}
+/* the xglst of grid ig1; 0, or -1 (no table / no such code / not a Lambert entry) with the reference's message */
+static int lamb_lookup(float *xg14, int ig1)
+{
+    if (gbt_load() < 0) { fprintf(stderr, " <qqqgbld> no \"gribtable\" file found (./gribtable, $CMCCONST/gribtable, $ARMNLIB/data/gribtable)\n"); return -1; }
+    for (int k = 0; k < GBT.n; k++)
+        if (GBT.code[k] == ig1) {
+            if (GBT.gty[k] != 'H') { fprintf(stderr, " <igaxg95> GRIB code %d is not a Lambert conformal ('H') entry\n", ig1); return -1; }
+            memcpy(xg14, GBT.xg[k], sizeof(float) * 14);
+            return 0;
+        }
+    fprintf(stderr, " <qgblukig> GRIB code %d not found...\n", ig1);
+    return -1;
+}
+/* ez_lambxyfll99.inc:20-68 / ez_lambllfxy99.inc:20-58: the projection in REAL, operation by operation */
+typedef struct { float rn, rf, rhozero; } lamb_cone;
+static lamb_cone h_lamb_cone(float latin1, float latin2, float yaxislat)
+{
+    const float pisur4 = atanf(1.0f), pi = 4.0f * pisur4, d2r = pi / 180.0f, r = 6370997.0f;
+    const float rphi1 = d2r * latin1, rphi2 = d2r * latin2;
+    lamb_cone c;
+    if (rphi1 == rphi2) c.rn = sinf(rphi1);
+    else { c.rn = logf(cosf(rphi1) / cosf(rphi2)); c.rn = c.rn / logf((tanf(pisur4 + 0.5f * rphi2)) / tanf(pisur4 + 0.5f * rphi1)); }
+    const float rtan = tanf(pisur4 + rphi1 * 0.5f);
+    const float f = (cosf(rphi1) * powf(rtan, c.rn)) / c.rn;
+    c.rf = r * f;
+    c.rhozero = r * f / powf(tanf(pisur4 + yaxislat * d2r * .5f), c.rn);
+    return c;
+}
+static void h_lambxyfll99(float *x, float *y, const float *lat, const float *lon, int n, float latin1, float latin2, float yaxislat, float yaxislon)
+{
+    const float pisur4 = atanf(1.0f), pi = 4.0f * pisur4, d2r = pi / 180.0f;
+    const lamb_cone c = h_lamb_cone(latin1, latin2, yaxislat);
+    for (int i = 0; i < n; i++) {
+        float tmplat = lat[i];
+        if (tmplat > 90.0f) tmplat = 89.95f;
+        const float rho = c.rf / powf(tanf(pisur4 + tmplat * 0.5f * d2r), c.rn);
+        float dlon = lon[i] - yaxislon;
+        if (dlon < -180.0f) dlon = dlon + 360.f; else if (dlon > 180.f) dlon = dlon - 360.f;
+        const float theta = c.rn * (d2r * dlon);
+        x[i] = rho * sinf(theta);
+        y[i] = c.rhozero - rho * cosf(theta);
+    }
+}
+static void h_lambllfxy99(float *lat, float *lon, const float *x, const float *y, int n, float latin1, float latin2, float yaxislat, float yaxislon)
+{
+    const float pisur4 = atanf(1.0f), pi = 4.0f * pisur4, d2r = pi / 180.0f;
+    const lamb_cone c = h_lamb_cone(latin1, latin2, yaxislat);
+    for (int i = 0; i < n; i++) {
+        const float dy = c.rhozero - y[i];
+        const float rho = copysignf(1.0f, c.rn) * sqrtf(x[i] * x[i] + (dy * dy));
+        const float theta = atanf(x[i] / (c.rhozero - y[i]));
+        lat[i] = (2.0f * atanf(powf(c.rf / rho, 1.0f / c.rn)) - 0.5f * pi) / d2r;
+        lon[i] = theta / (d2r * c.rn) + yaxislon;
+    }
+}
+/* ez_lambfll.inc:20-70 (lat, lon -> grid coordinates) and ez_llflamb.inc:20-62 (grid coordinates -> lat, lon) of a '!' grid */
+static void h_lambfll(const ezh_grid *g, float *x, float *y, const float *lat, const float *lon, int n)
+{
+    const float *xg = g->lamb;
+    const float xlat11 = xg[0], xlon11 = xg[1], yaxislat = 0.5f * (xg[0] + xg[9]), yaxislon = xg[4], dx = xg[2] * 1000.0f, dy = xg[3] * 1000.0f;
+    float x11, y11;
+    h_lambxyfll99(&x11, &y11, &xlat11, &xlon11, 1, xg[5], xg[6], yaxislat, yaxislon);
+    h_lambxyfll99(x, y, lat, lon, n, xg[5], xg[6], yaxislat, yaxislon);
+    for (int i = 0; i < n; i++) { x[i] = 1.0f + (x[i] - x11) / dx; y[i] = 1.0f + (y[i] - y11) / dy; }
+}
+static void h_llflamb(const ezh_grid *g, float *lat, float *lon, float *x, float *y, int n)          /* (x, y are overwritten with projection coordinates, as in the reference) */
+{
+    const float *xg = g->lamb;
+    const float xlat11 = xg[0], xlon11 = xg[1], yaxislat = 0.5f * (xg[0] + xg[9]), yaxislon = xg[4], dx = xg[2] * 1000.0f, dy = xg[3] * 1000.0f;
+    float x11, y11;
+    h_lambxyfll99(&x11, &y11, &xlat11, &xlon11, 1, xg[5], xg[6], yaxislat, yaxislon);
+    for (int i = 0; i < n; i++) { x[i] = x11 + dx * (x[i] - 1.0f); y[i] = y11 + dy * (y[i] - 1.0f); }
+    h_lambllfxy99(lat, lon, x, y, n, xg[5], xg[6], yaxislat, yaxislon);
+}
+
 static __thread int t_locate_j2;       /* 1 inside c_gdxyfll_orig: the search length of gdxyfll.c (see the 'G' / 'Z' branch) */
 static int h_locate(const ezh_grid *g, float *x, float *y, const float *lat, float *lon, int n)
 {
@@ -453,6 +580,9 @@ static int h_locate(const ezh_grid *g, float *x, float *y, const float *lat, flo
         return 0;
     case 'N': case 'S':                                     /* ez_ll2rgd.inc:43-55 */
         h_vxyfll(x, y, lat, lon, n, g->xg[2], g->xg[3], g->xg[0], g->xg[1], g->grtyp == 'N' ? 1 : 2);
+        return 0;
+    case '!':                                               /* ez_ll2rgd.inc:156-159 */
+        h_lambfll(g, x, y, lat, lon, n);
         return 0;
     case 'E': {
         float *la = (float *)malloc(sizeof(float) * (size_t)n), *lo = (float *)malloc(sizeof(float) * (size_t)n);
@@ -519,7 +649,7 @@ static int grid_ok(int gd) { return gd >= 0 && gd < __atomic_load_n(&nG, __ATOMI
 
 static int type_supported(char t, char ref, int ig1, int ig2)
 {
-    if (t == 'L' || t == 'E' || t == 'N' || t == 'S') return 1;
+    if (t == 'L' || t == 'E' || t == 'N' || t == 'S' || t == '!') return 1;     /* '!': scalars and coordinates (its gribtable entry is looked up when the grid is defined) */
     if (t == 'A' || t == 'B') return ig1 >= 0 && ig1 <= 2 && ig2 >= 0 && ig2 <= 1;   /* hemispheric / y-inverted: scalars only */
     if (t == 'G') return ig1 >= 0 && ig1 <= 2 && ig2 >= 0 && ig2 <= 1;   /* hemispheres: scalars; the northern one reproduces the reference's locate (ez_calcxy.c:90-96) literally */
     if (t == 'Z') return ref == 'L' || ref == 'E';
@@ -589,6 +719,9 @@ int32_t c_ezgdef_fmem(int32_t ni, int32_t nj, char *grtyp, char *grref, int32_t 
     case 'L': case 'E':
     case 'N': case 'S':                                     /* ez_defxg.c:150-160: xg = (pi, pj, d60, dgrw) */
         h_cigaxg(t, &g->xg[0], &g->xg[1], &g->xg[2], &g->xg[3], ig1, ig2, ig3, ig4);
+        break;
+    case '!':                                               /* ez_defxg.c:130-132 keeps nothing; the dictionary entry is read here so that a grid without one fails at its definition */
+        if (lamb_lookup(g->lamb, ig1)) { g->used = 0; pthread_mutex_unlock(&g_mtx); return -1; }
         break;
     }
     if (t == 'Z') {                                         /* c_ezdefaxes, ez_defaxes.c:43-54 */
@@ -855,13 +988,27 @@ static void ensure_coords(ezh_grid *g)
 {
     if (g->coords_ready) return;
     int ni = g->ni, nj = g->nj;
-    g->separable = !(g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E') || g->grtyp == 'N' || g->grtyp == 'S' || g->grtyp == 'Y');
+    g->separable = !(g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E') || g->grtyp == 'N' || g->grtyp == 'S' || g->grtyp == 'Y' || g->grtyp == '!');
     g->lat1d = (float *)calloc((size_t)nj, sizeof(float));
     g->lon1d = (float *)calloc((size_t)ni, sizeof(float));
     if (g->grtyp == 'Y') {                                  /* ez_calclatlon.c:127-143 */
         size_t n = (size_t)ni * nj;
         g->lat2d = (float *)malloc(sizeof(float) * n); g->lon2d = (float *)malloc(sizeof(float) * n);
         memcpy(g->lon2d, g->ax, sizeof(float) * n); memcpy(g->lat2d, g->ay, sizeof(float) * n);
+        g->coords_ready = 1;
+        return;
+    }
+    if (g->grtyp == '!') {                                  /* ez_calclatlon.c:229-250 */
+        size_t n = (size_t)ni * nj;
+        g->lat2d = (float *)malloc(sizeof(float) * n); g->lon2d = (float *)malloc(sizeof(float) * n);
+        float *x = (float *)malloc(sizeof(float) * n), *y = (float *)malloc(sizeof(float) * n);
+        for (int j = 0; j < nj; j++) for (int i = 0; i < ni; i++) { x[(size_t)j * ni + i] = (float)(i + 1.0); y[(size_t)j * ni + i] = (float)(j + 1.0); }
+        h_llflamb(g, g->lat2d, g->lon2d, x, y, (int)n);
+        for (size_t k = 0; k < n; k++) if (g->lon2d[k] < 0.0f) g->lon2d[k] = g->lon2d[k] + 360.0f;
+        free(x); free(y);
+        /* igaxg95 hands back ig3 = 256 * sub-centre + projection code and ig4 = 0 THROUGH its arguments, and ez_llflamb passes the grid's own
+         * descriptors (:245-247): from its first coordinates on, the grid's ig3 / ig4 are these (c_ezgprm shows them) */
+        g->ig[2] = 256 * (int)lroundf(g->lamb[12]) + (int)lroundf(g->lamb[13]); g->ig[3] = 0;
         g->coords_ready = 1;
         return;
     }
@@ -1028,7 +1175,7 @@ static int ensure_coords_dev(ezh_grid *g)
 /* ------------------------------------------------------------------------------------------ */
 static int src_is_separable(const ezh_grid *g)
 {   /* x depends on lon only and y on lat only: everything but the rotated frames */
-    return !(g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E') || g->grtyp == 'N' || g->grtyp == 'S');
+    return !(g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E') || g->grtyp == 'N' || g->grtyp == 'S' || g->grtyp == '!');
 }
 static int src_irregular(const ezh_grid *g) { return g->grtyp == 'G' || g->grtyp == 'Z'; }
 static int src_hemi(const ezh_grid *g) { return (g->grtyp == 'A' || g->grtyp == 'B' || g->grtyp == 'G') && g->ig[0] != 0; }
@@ -1036,7 +1183,7 @@ static int grid_yinv(const ezh_grid *g) { return (g->grtyp == 'A' || g->grtyp ==
 
 static int set_extrap(const ezh_grid *gi)
 {
-    if (gi->grtyp == 'N' || gi->grtyp == 'S') return 1;       /* ez_defzones.c:46-50 */
+    if (gi->grtyp == 'N' || gi->grtyp == 'S' || gi->grtyp == '!') return 1;       /* ez_defzones.c:46-50 */
     if (gi->grtyp == 'L') return gi->extension == 0;
     if (gi->grtyp == 'Z' && (gi->grref == 'E' || gi->grref == 'L'))
         return 358.0 > (gi->ax[gi->ni - 1] - gi->ax[0]);
@@ -1670,7 +1817,7 @@ static int ensure_points(ezh_set *s)
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     size_t n = (size_t)go->ni * go->nj;
     int rotated = gi->grtyp == 'E' || (gi->grtyp == 'Z' && gi->grref == 'E');
-    int host_locate = (rotated && !getenv("EZHIP_DEVICE_LOCATE")) || (gi->grtyp == 'G' && gi->ig[0] != 0);      /* hemispheric 'G': the reference's search quirk lives in the host code only */
+    int host_locate = (rotated && !getenv("EZHIP_DEVICE_LOCATE")) || (gi->grtyp == 'G' && gi->ig[0] != 0) || gi->grtyp == '!';      /* '!': the REAL libm chain of ez_lambxyfll99 lives in the host code */      /* hemispheric 'G': the reference's search quirk lives in the host code only */
     float *hx = NULL, *hy = NULL;
     if (ensure_grid_dev(gi)) return -1;
     float *dx = (float *)ezhip_malloc(sizeof(float) * n), *dy = (float *)ezhip_malloc(sizeof(float) * n);
@@ -2709,6 +2856,10 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
         fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp);
         return -1;
     }
+    if (gi->grtyp == '!' || go->grtyp == '!') {             /* ez_lamb_llwfgdw / ez_lamb_gdwfllw: scalars and coordinates only so far */
+        fprintf(stderr, "<c_ezuvint> winds on Lambert '!' grids are outside the MI355X hot-path scope (scalars and coordinates are supported)\n");
+        return -1;
+    }
     int ni = gi->ni, nj = gi->nj, polar = O.polar_correction == 1;
     /* one grid on both sides: the two c_ezsint calls of c_ezuvint_orig (ezuvint.c:68-71) copy their fields (ezsint.c: identical grids, return 1) and
      * never define the set's zones, so ez_corrvec finds none; the wind chain still runs on the copies (ierc stays 0) */
@@ -2891,7 +3042,7 @@ int32_t c_gdxyzfll(int32_t gdid, float *x, float *y, float *lat, float *lon, int
     if (!grid_ok(gdid)) return -1;
     ezh_grid *g = &G[gdid];
     switch (g->grtyp) {
-    case 'A': case 'B': case 'E': case 'G': case 'L': case 'N': case 'S': c_gdxyfll_orig(gdid, x, y, lat, lon, n); break;
+    case 'A': case 'B': case 'E': case 'G': case 'L': case 'N': case 'S': case '!': c_gdxyfll_orig(gdid, x, y, lat, lon, n); break;
     case 'Y': fprintf(stderr, "<gdxyzfll>: This operation is not supported for 'Y' grids\n"); break;
     case 'Z':
         if (g->grref == 'L') {
@@ -2955,6 +3106,13 @@ static int gdllfxy_one(const ezh_grid *g, float *lat, float *lon, const float *x
         h_vllfxy(lat, lon, x, y, n, g->xg[2], g->xg[3], g->xg[0], g->xg[1], g->grtyp == 'N' ? 1 : 2);
         for (int i = 0; i < n; i++) lon[i] = (float)fmod((double)lon[i] + 360.0, 360.0);
         return 0;
+    case '!': {                                            /* gdllfxy.c:172-174 (the caller's x, y stay as they are here: the reference overwrites them with projection metres) */
+        float *tx = (float *)malloc(sizeof(float) * (size_t)(n + 1)), *ty = (float *)malloc(sizeof(float) * (size_t)(n + 1));
+        memcpy(tx, x, sizeof(float) * (size_t)n); memcpy(ty, y, sizeof(float) * (size_t)n);
+        h_llflamb(g, lat, lon, tx, ty, n);
+        free(tx); free(ty);
+        return 0;
+    }
     case 'Y': fprintf(stderr, "<gdllfxy>: This operation is not supported for 'Y' grids\n"); return 0;
     case 'Z': case 'G': {
         float *tx = (float *)malloc(sizeof(float) * (size_t)(n + 1)), *ty = (float *)malloc(sizeof(float) * (size_t)(n + 1));
@@ -3019,7 +3177,7 @@ static int wind_conv_dev(int32_t gdid, float *d_a, float *d_b, const float *d_la
     if (!grid_ok(gdid)) return -1;
     if (need_device(to_wd ? "c_gdwdfuv" : "c_gduvfwd")) return -1;
     ezh_grid *g = &G[gdid];
-    if (g->nsub > 0 || g->grtyp == 'Y') { fprintf(stderr, "<%s> '%c' grids are outside the MI355X hot-path scope here\n", to_wd ? "c_gdwdfuv" : "c_gduvfwd", g->grtyp); return -1; }
+    if (g->nsub > 0 || g->grtyp == 'Y' || g->grtyp == '!') { fprintf(stderr, "<%s> '%c' grids are outside the MI355X hot-path scope here\n", to_wd ? "c_gdwdfuv" : "c_gduvfwd", g->grtyp); return -1; }
     int rotated = g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E');
     ezhip_wind_plan wp;
     memset(&wp, 0, sizeof(wp));
@@ -3343,7 +3501,7 @@ static int32_t yy_uvint(ezh_set *s, float *d_uuout, float *d_vvout, const float 
         fprintf(stderr, "<c_ezuvint> this Yin-Yang case (target = one of the subgrids) is outside the MI355X hot-path scope\n");
         return -1;
     }
-    if (go->grtyp == 'E') { fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp); return -1; }
+    if (go->grtyp == 'E' || go->grtyp == '!') { fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp); return -1; }
     int degree = O.degre_interp;
     if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return -1;
     if (yy_plan(s) || ensure_coords_dev(go)) return -1;
