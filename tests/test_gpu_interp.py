@@ -1369,3 +1369,25 @@ def test_a_thread_that_ends_gives_its_workspaces_back():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (8 << 20), (free0, free1)               # without the release: >= 10 x (4.2 MB staging + workspaces)
+
+
+def test_a_thread_on_another_device_is_refused_loudly():
+    """the library binds to the device that was current at its first compute call; a call with another current device returns -1 and says which two devices
+    (one process per GPU: plans, tables and workspaces are plain pointers of one device).  Simulated on the one-GPU box by binding a fresh process to device 5."""
+    import subprocess, sys, textwrap
+    ROOT_DIR = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    code = textwrap.dedent("""
+        import sys, os
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np
+        from librmn_amd import ezscint as ez
+        import ezcases as ec
+        gi = ez.ezqkdef(64, 32, "G", 0, 0, 0, 0); go = ez.ezqkdef(90, 45, "L", 400, 400, 0, 0)
+        assert ez.ezdefset(go, gi) == 1
+        rc, z = ez.ezsint(ec.synth_field(64, 32, seed=1), 90 * 45)
+        print("rc", rc)
+    """ % (ROOT_DIR, ROOT_DIR))
+    env = dict(os.environ); env["EZHIP_TEST_BOUND_DEVICE"] = "5"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert "rc -1" in r.stdout, (r.stdout, r.stderr[-1500:])
+    assert "live on HIP device 5" in r.stderr and "current device is 0" in r.stderr, r.stderr[-1500:]
