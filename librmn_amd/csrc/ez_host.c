@@ -2272,6 +2272,8 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
     return ierc;
 }
 
+/* the polar wind rows of the pair being interpolated, handed from uvint_impl to the per-point pair launch (per host thread) */
+static __thread struct { float *out; const float *plon2, *ax; float xg4_n, xg4_s; int weighted, active; } t_pwjob;
 /* both components of a wind pair on the per-point path in ONE pass (k_pts2); returns -2 when the set is not on that path */
 static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui, const float *d_vi,
                         const float *pun, const float *pus, const float *pvn, const float *pvs, const void *d_M, int dst_rot)
@@ -2304,6 +2306,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
     pu.pole_row_n = pun; pu.pole_row_s = pus; pv.pole_row_n = pvn; pv.pole_row_s = pvs;
     if (zones == 2 && s->have_dehors) ierc = 2;
     pu.tile_ni = go->ni; pu.tile_nj = go->nj;                  /* the points are the whole target grid in row order: 2-D tile order */
+    if (t_pwjob.active) { pu.pw_out = t_pwjob.out; pu.pw_plon2 = t_pwjob.plon2; pu.pw_xg4_n = t_pwjob.xg4_n; pu.pw_xg4_s = t_pwjob.xg4_s; pu.pw_weighted = t_pwjob.weighted; pu.pw_ax = t_pwjob.ax; t_pwjob.active = 0; }
     if (ezhip_interp_pts2(&pu, &pv, d_uo, d_vo, d_ui, d_vi, s->d_x, s->d_y, go->ni * go->nj)) return -1;
     return ierc;
 }
@@ -2899,9 +2902,20 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
         } else {
             /* on the side stream: only the special points (k_pts_special, or the special rows of the separable kernel) read
              * these rows, the main kernels of both components overlap the 44 us of sequential pole sums */
-            if (ezhip_side_begin()) return -1;
-            int prc = ezhip_polar_wind(s->d_prow, d_uuin, d_vvin, gi->d_plon2, ni, nj, gi->xg4_pole[0], gi->xg4_pole[1], weighted, gi->d_ax);
-            if (ezhip_side_end() || prc) return -1;
+            int per_point = 0;
+            if (!same && (O.degre_interp == DEG_NEAREST || O.degre_interp == DEG_LINEAR || O.degre_interp == DEG_CUBIC) && !getenv("EZHIP_NO_PTS2")) {
+                pthread_mutex_lock(&g_plan_mtx);
+                per_point = choose_mode(s, O.degre_interp, polar) == 2;
+                pthread_mutex_unlock(&g_plan_mtx);
+            }
+            if (per_point) {       /* the per-point pair kernel takes the job along (two producer blocks of its own launch, or its own side-stream launch) */
+                t_pwjob.out = s->d_prow; t_pwjob.plon2 = gi->d_plon2; t_pwjob.xg4_n = gi->xg4_pole[0]; t_pwjob.xg4_s = gi->xg4_pole[1];
+                t_pwjob.weighted = weighted; t_pwjob.ax = gi->d_ax; t_pwjob.active = 1;
+            } else {
+                if (ezhip_side_begin()) return -1;
+                int prc = ezhip_polar_wind(s->d_prow, d_uuin, d_vvin, gi->d_plon2, ni, nj, gi->xg4_pole[0], gi->xg4_pole[1], weighted, gi->d_ax);
+                if (ezhip_side_end() || prc) return -1;
+            }
         }
         pun = s->d_prow; pus = s->d_prow + ni; pvn = s->d_prow + 2 * ni; pvs = s->d_prow + 3 * ni;
     }
@@ -2964,6 +2978,14 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
         if ((d_uuout != d_uuin && ezhip_d2d(d_uuout, d_uuin, nb)) || (d_vvout != d_vvin && ezhip_d2d(d_vvout, d_vvin, nb))) return -1;
     }
     if (!same) r1 = r2 = run_pair_pts(s, d_uuout, d_vvout, d_uuin, d_vvin, pun, pus, pvn, pvs, getenv("EZHIP_WIND_NO_FUSE") ? NULL : d_M, wp.dst_rotated);
+    if (t_pwjob.active) {                                     /* the pair kernel did not take the polar wind rows along (set not on its path after all) */
+        t_pwjob.active = 0;
+        if (r1 != -1) {
+            if (ezhip_side_begin()) return -1;
+            int prc = ezhip_polar_wind(t_pwjob.out, d_uuin, d_vvin, t_pwjob.plon2, ni, nj, t_pwjob.xg4_n, t_pwjob.xg4_s, t_pwjob.weighted, t_pwjob.ax);
+            if (ezhip_side_end() || prc) return -1;
+        }
+    }
     if (r1 == -1) return -1;
     const int fused = !same && r1 != -2 && d_M && !getenv("EZHIP_WIND_NO_FUSE");
     if (r1 == -2) {                                          /* separable set: one launch per component */

@@ -1604,11 +1604,11 @@ __device__ __forceinline__ void d_gdwfllw1(float &z1, float &z2, float xlon, cha
     float u = cosf(psi * DGTORD) * z1, v = sinf(psi * DGTORD) * z1;
     z1 = u; z2 = v;
 }
-__global__ __launch_bounds__(256) void k_polar_wind(float *out, const float *uu, const float *vv, const float *plon2 /* [north row | south row] */,
-                                                    int ni, int nj, float xg4_n, float xg4_s, int weighted, const float *ax)
+template <int CHUNK>
+__device__ __forceinline__ void polar_wind_body(const int north, float *out, const float *uu, const float *vv, const float *plon2 /* [north row | south row] */,
+                                                int ni, int nj, float xg4_n, float xg4_s, int weighted, const float *ax)
 {
-    __shared__ __attribute__((aligned(16))) float lds[POLE_CHUNK + 4];
-    const int north = blockIdx.x == 0;
+    __shared__ __attribute__((aligned(16))) float lds[CHUNK + 4];
     const char hs = north ? 'N' : 'S';
     const float xg4 = north ? xg4_n : xg4_s;
     const float *urow = uu + (north ? (size_t)(nj - 1) * ni : 0), *vrow = vv + (north ? (size_t)(nj - 1) * ni : 0);
@@ -1622,8 +1622,8 @@ __global__ __launch_bounds__(256) void k_polar_wind(float *out, const float *uu,
     }
     __threadfence_block();
     __syncthreads();
-    float s0 = block_poleval(pu, ni, weighted, ax, lds, POLE_CHUNK);
-    float w0 = block_poleval(pv, ni, weighted, ax, lds, POLE_CHUNK);
+    float s0 = block_poleval(pu, ni, weighted, ax, lds, CHUNK);
+    float w0 = block_poleval(pv, ni, weighted, ax, lds, CHUNK);
     d_llwfgdw1(s0, w0, 0.0f, hs, xg4);
     __syncthreads();
     for (int i = threadIdx.x; i < ni; i += 256) {
@@ -1631,6 +1631,11 @@ __global__ __launch_bounds__(256) void k_polar_wind(float *out, const float *uu,
         d_gdwfllw1(spd, wd, plon[i], 'A', 0.f);
         pu[i] = spd; pv[i] = wd;
     }
+}
+__global__ __launch_bounds__(256) void k_polar_wind(float *out, const float *uu, const float *vv, const float *plon2, int ni, int nj, float xg4_n, float xg4_s,
+                                                    int weighted, const float *ax)
+{
+    polar_wind_body<POLE_CHUNK>(blockIdx.x == 0, out, uu, vv, plon2, ni, nj, xg4_n, xg4_s, weighted, ax);
 }
 /* ez_corrbgd.inc:20-55 (called at the end of ez_corrval for a Z- or #-on-E source and a 'B' target, ez_corrval.c:146-148): the rows of the
  * target at the poles become their mean -- a sequential REAL sum over the row divided by ni * 1.0 (block_poleval, unweighted).
@@ -2176,19 +2181,19 @@ template <int KIND, bool LITERAL>
 __device__ __forceinline__ void pts2_body(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
                                               const float *__restrict__ zin1, const float *__restrict__ zin2,
                                               const float *__restrict__ xs, const float *__restrict__ ys, int npts,
-                                              int *__restrict__ special_list, unsigned *__restrict__ special_count)
+                                              int *__restrict__ special_list, unsigned *__restrict__ special_count, unsigned boff)
 {
     int n;
     if (p.tile_ni > 0) {
         /* 2-D order: block = 32 x 8 target points, wave = 8 x 8.  The TCP (vector L1) looks up about one cache line per cycle; 64 consecutive points of a
          * target row touch ~10 lines per stencil-row load when the source is rotated, an 8 x 8 patch 2 - 3.  The four waves of a block sit side by side:
          * their 32-byte row pieces of x, y and the outputs make whole 128-byte lines */
-        const unsigned tpr = ((unsigned)p.tile_ni + 31u) >> 5, b = p.xcd_order ? pts_block(blockIdx.x, gridDim.x) : blockIdx.x;
+        const unsigned tpr = ((unsigned)p.tile_ni + 31u) >> 5, b = p.xcd_order ? pts_block(blockIdx.x - boff, gridDim.x - boff) : blockIdx.x - boff;
         const unsigned by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
         const unsigned cx_ = bx * 32u + (t >> 6) * 8u + (t & 7u), cy_ = by * 8u + ((t >> 3) & 7u);
         if (cx_ >= (unsigned)p.tile_ni || cy_ >= (unsigned)p.tile_nj) return;
         n = (int)(cy_ * (unsigned)p.tile_ni + cx_);
-    } else n = (int)(p.xcd_order ? pts_block(blockIdx.x, gridDim.x) : blockIdx.x) * 256 + threadIdx.x;
+    } else n = (int)(p.xcd_order ? pts_block(blockIdx.x - boff, gridDim.x - boff) : blockIdx.x - boff) * 256 + threadIdx.x;
     if (n >= npts) return;
     const float px = xs[n], py = ys[n];
     const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;
@@ -2238,7 +2243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                               const float *__restrict__ xs, const float *__restrict__ ys, int npts,
                                               int *__restrict__ special_list, unsigned *__restrict__ special_count)
 {
-    pts2_body<KIND, true>(p, zout1, zout2, zin1, zin2, xs, ys, npts, special_list, special_count);
+    pts2_body<KIND, true>(p, zout1, zout2, zin1, zin2, xs, ys, npts, special_list, special_count, 0u);
 }
 /* winds from an irregular source with wrap (cfg3): the regrouped Newton form with every load of a point in flight at once: more registers per
  * lane (no occupancy floor), half the dependent memory round trips */
@@ -2247,7 +2252,15 @@ __global__ __launch_bounds__(256) void k_pts2_irgd3w(ezhip_pts_plan p, float *__
                                               const float *__restrict__ xs, const float *__restrict__ ys, int npts,
                                               int *__restrict__ special_list, unsigned *__restrict__ special_count)
 {
-    pts2_body<PK_IRGD3_W, false>(p, zout1, zout2, zin1, zin2, xs, ys, npts, special_list, special_count);
+    /* the pair's synthetic polar wind rows: two producer blocks at the head of this launch (they were a 2-block kernel on a side stream, forked from and
+     * joined into this stream with events: ~7 us of launch gaps per wind pair around a 107 us kernel).  Only the special points read the rows, and those
+     * are the next kernel's */
+    unsigned boff = 0;
+    if (p.pw_out) {
+        if (blockIdx.x < 2) { polar_wind_body<2048>(blockIdx.x == 0, p.pw_out, zin1, zin2, p.pw_plon2, p.ni, p.nj, p.pw_xg4_n, p.pw_xg4_s, p.pw_weighted, p.pw_ax); return; }
+        boff = 2;
+    }
+    pts2_body<PK_IRGD3_W, false>(p, zout1, zout2, zin1, zin2, xs, ys, npts, special_list, special_count, boff);
 }
 
 /* Special points only (a fraction of a percent of a global target): polar strips on the virtual 4-row strip,
@@ -2375,7 +2388,16 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     pu2.newton_literal = getenv("EZHIP_WIND_NEWTON_LITERAL") ? 1 : 0;      /* development: the reference's literal Newton form for winds too */
     pu2.xcd_order = getenv("EZHIP_PTS_XCD") ? 1 : 0;                        /* development: XCD k takes the k-th eighth of the blocks (fewer fabric reads, measured slower) */
     if (getenv("EZHIP_PTS_NOTILE") || (long long)pu2.tile_ni * pu2.tile_nj != (long long)npts || pu2.out_idx) pu2.tile_ni = pu2.tile_nj = 0;
-    const dim3 grid(pu2.tile_ni > 0 ? (unsigned)(((pu2.tile_ni + 31) / 32) * ((pu2.tile_nj + 7) / 8)) : (unsigned)((npts + 255) / 256));
+    const bool fast3w = pts_kind(plan_u) == PK_IRGD3_W && !pu2.newton_literal;
+    if (pu2.pw_out && (!fast3w || getenv("EZHIP_POLAR_WIND_SIDE"))) {
+        /* kernels without the producer blocks: the rows come from k_polar_wind on the side stream, joined below before the special points */
+        if (ezhip_side_begin()) return -1;
+        hipLaunchKernelGGL(k_polar_wind, dim3(2), dim3(256), 0, g_stream, pu2.pw_out, d_in_u, d_in_v, pu2.pw_plon2, pu2.ni, pu2.nj, pu2.pw_xg4_n, pu2.pw_xg4_s, pu2.pw_weighted, pu2.pw_ax);
+        const int bad = LAUNCH_CHECK("k_polar_wind");
+        if (ezhip_side_end() || bad) return -1;
+        pu2.pw_out = nullptr;
+    }
+    const dim3 grid((pu2.tile_ni > 0 ? (unsigned)(((pu2.tile_ni + 31) / 32) * ((pu2.tile_nj + 7) / 8)) : (unsigned)((npts + 255) / 256)) + (pu2.pw_out ? 2u : 0u));
 #define PTS2_CASE(K) case K: if (K == PK_IRGD3_W && !pu2.newton_literal) hipLaunchKernelGGL(k_pts2_irgd3w, grid, block, 0, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, t_spec.list, cnt); \
         else hipLaunchKernelGGL(k_pts2<K>, grid, block, 0, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, t_spec.list, cnt); break
     switch (pts_kind(plan_u)) {
