@@ -41,7 +41,7 @@ typedef struct {            /* src/interp/ez_def.h:225-243, defaults src/interp/
 typedef struct {            /* one compiled separable plan: device tables + the descriptor */
     int built;
     ezhip_sep_plan p;
-    void *dev[32];          /* owned device allocations */
+    void *dev[40];          /* owned device allocations */
     /* host copy of the k_sepx row geometry (host-pointer ABI, sepx_host_chunks): per valid row-block its 16-row target block and the end of
      * its source window; per target row the special flag */
     int h_nvb, *h_vb_by, *h_vb_send;
@@ -764,7 +764,7 @@ int32_t c_ezqkdef(int32_t ni, int32_t nj, char *grtyp, int32_t ig1, int32_t ig2,
 
 static void free_sepplan(ezh_sepplan *sp)
 {
-    for (int k = 0; k < 32; k++) { ezhip_free(sp->dev[k]); sp->dev[k] = NULL; }
+    for (int k = 0; k < 40; k++) { ezhip_free(sp->dev[k]); sp->dev[k] = NULL; }
     free(sp->h_vb_by); free(sp->h_vb_send); free(sp->h_rflag);
     sp->h_vb_by = sp->h_vb_send = NULL; sp->h_rflag = NULL; sp->h_nvb = 0;
     sp->built = 0;
@@ -1616,6 +1616,91 @@ static void build_bb_tables(ezh_sepplan *sp, ezhip_sep_plan *p, const ezh_grid *
     free(colhas); free(rowhas); free(colstart); free(rowstart); free(collist); free(rowlist); free(colk); free(rowk);
 }
 
+
+/* geometry of k_sepx_enc (interpolate + armn_compress in one launch): strips of 256 target columns every 255, row groups of 16 target rows every
+ * 15 (a context column / row + 85 x 5 tiles of 3 x 3); leaves p->e_ok == 0 when a strip's taps are not consecutive patch columns, a row group's
+ * source window is taller than the patch, or the plan has fill columns / rows (then the two-kernel pipeline runs) */
+static void build_enc_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, const ezh_grid *gi, int ntap, int nic, int njr, const int *cidx,
+                               const unsigned char *cflag, const int *rbase, const double *rw, const unsigned char *rflag,
+                               const ezhip_special_row *special, int nspecial)
+{
+    p->e_ok = 0;
+    if (p->x_nseg <= 0 || nic < 256 || njr < 16 || getenv("EZHIP_NO_SEPX_ENC")) return;
+    if ((size_t)njr * (size_t)nic >= ((size_t)1 << 31)) return;
+    for (int c = 0; c < nic; c++) if (cflag[c]) return;
+    for (int k = 0; k < nspecial; k++) if (special[k].kind == 3) return;
+    const int CS = 255, RS = 15;
+    const int ntx = (nic - 1 + 2) / 3, nty = (njr - 1 + 2) / 3;
+    const int nstrips = (ntx + 84) / 85, nrg = (nty + 4) / 5;
+    int *bbase = (int *)malloc(sizeof(int) * nstrips), *bw = (int *)malloc(sizeof(int) * nstrips);
+    ezhip_xstep *step = (ezhip_xstep *)calloc(nrg, sizeof(ezhip_xstep));
+    ezhip_xrow *xr = (ezhip_xrow *)calloc((size_t)nrg * 16, sizeof(ezhip_xrow));
+    int *esp = (int *)malloc(sizeof(int) * (size_t)nrg * 16), *row2sp = (int *)malloc(sizeof(int) * njr);
+    if (!bbase || !bw || !step || !xr || !esp || !row2sp) goto done;
+    int wmax = 1, ok = 1;
+    for (int s = 0; s < nstrips && ok; s++) {
+        const int c0 = s * CS, c1 = imin(c0 + 256, nic);
+        const int base = cidx[c0];
+        int maxoff = 0;
+        for (int c = c0; c < c1 && ok; c++) {
+            const int off0 = (cidx[c] - base + gi->ni) % gi->ni;
+            for (int k = 0; k < ntap; k++) {
+                const int off = (cidx[k * nic + c] - base + gi->ni) % gi->ni;
+                if (off != off0 + k) { ok = 0; break; }
+                if (off > maxoff) maxoff = off;
+            }
+        }
+        if (maxoff + 1 > EZHIP_SEP_WMAX || maxoff + 1 > gi->ni) ok = 0;
+        bbase[s] = base; bw[s] = maxoff + 1;
+        if (bw[s] > wmax) wmax = bw[s];
+    }
+    if (!ok) goto done;
+    for (int r = 0; r < njr; r++) row2sp[r] = -1;
+    for (int k = 0; k < nspecial; k++) if (special[k].row >= 0 && special[k].row < njr) row2sp[special[k].row] = k;
+    int tr = 4, prows = 1;
+    for (int i = 0; i < nrg; i++) {           /* first pass: the ring must hold the tallest window */
+        int lo = 1 << 30, hi = -1;
+        for (int k = 0; k < 16; k++) { const int r = i * RS + k; if (r >= njr || rflag[r]) continue; if (rbase[r] < lo) lo = rbase[r]; if (rbase[r] + ntap > hi) hi = rbase[r] + ntap; }
+        if (hi < 0) { step[i].s0 = 0; step[i].n = 0; continue; }
+        if (hi - lo > EZHIP_SEP_RMAX) { ok = 0; break; }
+        step[i].s0 = lo; step[i].n = hi - lo; step[i].by = i;
+        if (hi - lo > tr) tr = hi - lo;
+        if (hi - lo > prows) prows = hi - lo;
+    }
+    if (!ok) goto done;
+    for (int i = 0; i < nrg; i++) {
+        step[i].slot0 = step[i].s0 % tr;
+        int lastmain = -1;
+        for (int k = 0; k < 16; k++) { const int r = i * RS + k; if (r < njr && !rflag[r]) { lastmain = r; break; } }
+        for (int k = 0; k < 16; k++) {
+            const int r = i * RS + k;
+            esp[i * 16 + k] = (r < njr && rflag[r]) ? row2sp[r] : -1;
+            if (r < njr && rflag[r] && row2sp[r] < 0) ok = 0;                       /* a flagged row without a special record: not expected */
+            if (r < njr && !rflag[r]) lastmain = r;
+            ezhip_xrow *q = &xr[(size_t)i * 16 + k];
+            if (lastmain < 0) continue;                                              /* a row group without a main row: no y-pass */
+            for (int w = 0; w < 4; w++) {
+                q->w[w] = rw[w * njr + lastmain];
+                q->t_off[w] = ((rbase[lastmain] + w) % tr) * (int)(EZHIP_SEP_COLS * sizeof(double));
+            }
+        }
+    }
+    if (!ok) goto done;
+    p->e_nstrips = nstrips; p->e_nrg = nrg; p->e_tr = tr; p->e_prows = prows; p->e_wstride = 64 * ((wmax + 63) / 64);
+    p->e_blk_base = (const int *)(sp->dev[32] = upload(bbase, sizeof(int) * nstrips));
+    p->e_blk_w = (const int *)(sp->dev[33] = upload(bw, sizeof(int) * nstrips));
+    p->e_step = (const ezhip_xstep *)(sp->dev[34] = upload(step, sizeof(ezhip_xstep) * nrg));
+    p->e_rows = (const ezhip_xrow *)(sp->dev[35] = upload(xr, sizeof(ezhip_xrow) * (size_t)nrg * 16));
+    p->e_special = (const int *)(sp->dev[36] = upload(esp, sizeof(int) * (size_t)nrg * 16));
+    p->e_ok = sp->dev[32] && sp->dev[33] && sp->dev[34] && sp->dev[35] && sp->dev[36];
+    if (p->e_ok && ezhip_sepenc_lds_bytes(p) > 150 * 1024) p->e_ok = 0;
+    if (getenv("EZHIP_VERBOSE"))
+        fprintf(stderr, "k_sepx_enc plan: %d strips x %d row groups, ring %d rows, patch %d rows x %d, LDS %zu B, ok %d\n", nstrips, nrg, tr, prows, p->e_wstride, ezhip_sepenc_lds_bytes(p), p->e_ok);
+    ezhip_sync();
+done:
+    free(bbase); free(bw); free(step); free(xr); free(esp); free(row2sp);
+}
+
 static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
 {
     if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return -1;
@@ -1754,6 +1839,7 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
     p->pole_weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
     p->vector_mode = vector_mode;
     build_bb_tables(sp, p, gi, degree, ntap, nic, njr, cidx, cw, cflag, rbase, rw, rflag, special, nspecial, vector_mode);
+    if (!vector_mode) build_enc_geometry(sp, p, gi, ntap, nic, njr, cidx, cflag, rbase, rw, rflag, special, nspecial);
     ezhip_sync();
     int ok = 1;
     for (int k = 0; k < 15; k++) ok &= (sp->dev[k] != NULL);
@@ -2506,6 +2592,58 @@ int32_t ezhip_ezsint_batch_tokens_dev(uint32_t *d_tokens, int64_t token_stride_w
     if (!d_tokens || !d_params) return -1;
     batch_out bo = {3, d_params, (size_t)param_stride_bytes, (size_t)token_stride_words};
     return batch_impl_o((float *)d_tokens, d_zin, nfields, NULL, 0, NULL, &bo);
+}
+
+/* cfg5 pipeline, passes B + E in ONE launch (k_sepx_enc, ez_kernels.hip): interpolate nfields source fields, quantise with the {minF, mulFactor} at
+ * d_params + f * param_stride_bytes (compact.tmplc:285-300) and armn_compress (c_zfstlib.c:646-789, container 4) straight into d_z + f * z_stride_words;
+ * the tokens never reach HBM.  d_work: ezhip_sepenc_layout_of(ni_out, nj_out, nfields).total bytes of device scratch; the stream's prefix words are left
+ * to packhip_sepenc_prefix (same scratch).  d_zlng[f] := byte count, -1 / -2 (not compressible / needs the 5-bit width field: the caller redoes the field
+ * with the two-kernel path) or untouched when the launch gave up.  poles_ready: the pole values of exactly these fields are in the set's batch array
+ * (ezhip_ezsint_batch_minmax_bb_dev ran on them).  Asynchronous.  -2: the plan of the current grid set has no fused geometry */
+int32_t ezhip_ezsint_batch_encode_dev(uint32_t *d_z, int64_t z_stride_words, int64_t z_cap_words, const float *d_zin, int32_t nfields,
+                                      const void *d_params, int64_t param_stride_bytes, int32_t nbits, void *d_work, int32_t *d_zlng, int32_t poles_ready)
+{
+    if (!d_z || !d_zin || !d_params || !d_work || !d_zlng || nfields < 1 || nbits < 5 || nbits > 16) return -1;
+    ezh_set *s = current_set("ezhip_ezsint_batch_encode_dev");
+    if (!s) return -1;
+    if (need_device("ezhip_ezsint_batch_encode_dev") || device_error("ezhip_ezsint_batch_encode_dev")) return -1;
+    if (G[s->gdin].grtyp == 'U' || G[s->gdout].grtyp == 'U' || s->gdin == s->gdout) return -2;
+    if ((O.polar_correction == 1 && s->extrap) || grid_yinv(&G[s->gdin])) return -2;
+    if (!(O.degre_interp == DEG_NEAREST || O.degre_interp == DEG_LINEAR || O.degre_interp == DEG_CUBIC)) return -2;
+    if (choose_mode(s, O.degre_interp, O.polar_correction == 1) != 1 || getenv("EZHIP_NO_BATCH_LAUNCH") || getenv("EZHIP_NO_SEPX")) return -2;
+    const int degree = O.degre_interp, polar = O.polar_correction == 1;
+    if (ensure_scratch(s)) return -1;
+    pthread_mutex_lock(&g_plan_mtx);
+    int brc = build_sep_plan(s, degree, 0, polar);
+    ezhip_sep_plan p = s->sep[degree == DEG_CUBIC ? 2 : degree][0].p;
+    pthread_mutex_unlock(&g_plan_mtx);
+    if (brc) return -1;
+    if (!p.e_ok) return -2;
+    ezh_grid *gi = &G[s->gdin];
+    const size_t nin = (size_t)gi->ni * gi->nj;
+    p.fill = t_scratch8;
+    if (p.pole_weighted) { if (ensure_grid_dev(gi)) return -1; p.ax = gi->d_ax; }
+    const float *d_poles = NULL;
+    if (p.need_poles && p.n_special > 0) {
+        if (ensure_batch_poles(s, nfields)) return -1;
+        if (!poles_ready && ezhip_polevals_batch(s->d_poles_batch, d_zin, nin, nfields, gi->ni, gi->nj, p.pole_weighted, p.ax)) return -1;
+        d_poles = s->d_poles_batch;
+    }
+    const ezhip_sepenc_layout L = ezhip_sepenc_layout_of(p.ni_dst, p.nj_dst, nfields);
+    if (L.nstrips != p.e_nstrips) return -1;
+    if (ezhip_memset(d_work, 0, L.zero_bytes)) return -1;
+    ezhip_sepenc_args a;
+    memset(&a, 0, sizeof(a));
+    a.z = d_z; a.z_stride = (size_t)z_stride_words; a.z_cap = (size_t)z_cap_words;
+    a.zin = d_zin; a.in_stride = nin; a.nfields = nfields; a.poles = d_poles;
+    a.quant_params = d_params; a.quant_stride = (size_t)param_stride_bytes;
+    a.nbits = nbits; a.container = 4; a.ntx = L.ntx; a.nty = L.nty; a.nchunks = L.nchunks;
+    a.status = (unsigned long long *)((char *)d_work + L.off_status); a.tail = (unsigned long long *)((char *)d_work + L.off_tail);
+    a.ctl = (unsigned *)((char *)d_work + L.off_ctl); a.head = (unsigned *)((char *)d_work + L.off_head);
+    a.ptok = (unsigned short *)((char *)d_work + L.off_ptok); a.ptok_stride = L.ptok_stride;
+    a.zlng = d_zlng;
+    a.debug = getenv("EZHIP_ENC_DEBUG") ? atoi(getenv("EZHIP_ENC_DEBUG")) : 0;
+    return ezhip_interp_sep_enc(&p, &a) ? -1 : 0;
 }
 
 /* dimensions of the current grid set (c_ezdefset): what the batch launches read and write per field.  -1 without a set */

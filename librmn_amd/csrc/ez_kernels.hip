@@ -27,6 +27,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include "ezhip_shim.h"
+#include "armn_dev.h"
 
 /* Everything that restates reference arithmetic must not be contracted into FMAs; the separable
  * kernel uses explicit fma() where fusion is intended. */
@@ -1167,6 +1168,446 @@ extern "C" int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const
     default: snprintf(g_err, sizeof(g_err), "ezhip_interp_sep: bad degree %d", plan->degree); return -1;
     }
     return LAUNCH_CHECK("k_sep");
+}
+
+
+/* ===================================================================================== */
+/* k_sepx_enc : interpolate, quantise and armn_compress in ONE launch (cfg5 passes B + E)  */
+/* ===================================================================================== */
+/* Round 2's pipeline wrote compact_float's 16-bit tokens of every interpolated value to HBM (k_sepx<.., tokens>, 52 MB per cfg5 field) for
+ * the encoder (k_armn_enc1, pack_kernels.hip) to read back: 104 of the pipeline's 234 MB per field, and a staging wait that was 44 % of an
+ * encoder block's life.  Here the tokens never leave the CU:
+ *   - a thread block owns 256 target columns x 16 target rows: a context column and a context row (the Lorenzo predictor of a tile looks one
+ *     token up and one to the left, c_zfstlib.c:691-696) + 85 x 5 tiles of 3 x 3 = five CHUNKS of the stream (a chunk = the 85 tiles of one tile
+ *     row of a strip; the stream runs tile row by tile row, c_zfstlib.c:722-768).  Strips advance by 255 columns, row groups by 15 rows: one
+ *     column in 256 and one row in 16 are interpolated twice;
+ *   - staging, x-pass and y-pass are k_sepx's (same tables, same fma chains, same REAL rounding, compact.tmplc:285-300 quantisation): the
+ *     tokens land in an LDS patch of 16 x 256 halfwords; the rows that are not main rows (polar strips, pole rows) are evaluated by
+ *     sep_special in place; no ring reuse between thread blocks (a row group brings all its ~13 source rows: 1.4 x the x-pass work of k_sepx);
+ *   - tiles, widths, block scan, stream image in LDS, hand-off of the shared boundary words: k_armn_enc1's, per chunk.  A chunk's position comes
+ *     from the same decoupled look-back over {aggregate | inclusive prefix} granules, one wave per chunk; the chunks of a row group depend on
+ *     aggregates of the OTHER strips of the same row group (the stream interleaves them), which are published before anybody waits, by thread
+ *     blocks launched next to this one: launch order = (row group, field, strip), so the lowest unfinished (row group, field) set is always
+ *     resident or next in line on every XCD; all waits are bounded (abort flag -> the host redoes the batch with the two-kernel path);
+ *   - row 0 and column 0 (the stream's prefix, c_zfstlib.c:712-721) go to a side array of ni + nj - 1 tokens per field; a small kernel
+ *     (k_sepenc_prefix, pack_kernels.hip) assembles the prefix words and the word the prefix shares with chunk 0 afterwards.
+ * Fields that turn out not to be compressible (zlng -1), to need the 5-bit width field (-2) or whose launch gave up are redone by the host
+ * through the two-kernel path, which has the tokens.  Bit-identical records (tests/test_gpu_packers.py). */
+#define SE_TPR 85                 /* tiles per chunk: 255 new columns of a strip */
+#define SE_TROWS 5                /* tile rows (chunks) per thread block: 15 new rows */
+#define SE_TOKW 132               /* words per row of the LDS token patch: 256 tokens + 4 words (the two rows a wave stores at once land in different banks) */
+#define SE_TPT 2                  /* tiles per thread: 425 tiles per thread block */
+#define SE_IMG_WORDS ((SE_TPR * SE_TROWS * 167 + 31) / 32 + 3 * SE_TROWS + 8)   /* worst case: 5 + 9 x 18 bits per tile */
+
+extern "C" size_t ezhip_sepenc_lds_bytes(const ezhip_sep_plan *p)
+{
+    size_t front = sizeof(double) * (size_t)p->e_tr * SEP_BLOCK + sizeof(float) * (16 * 16 + (size_t)p->e_prows * p->e_wstride);
+    if (front < 4 * (size_t)SE_IMG_WORDS) front = 4 * (size_t)SE_IMG_WORDS;      /* the stream image takes the place of ring, records and patch */
+    front = (front + 15) & ~(size_t)15;
+    return front + 4 * 16 * (size_t)SE_TOKW;
+}
+
+/* y-pass of one wave into the LDS token patch: lane l32 owns the column pairs (2 l32, 2 l32 + 1) + 64 g of target rows {2 wv + rsub, 8 + 2 wv + rsub}
+ * (sepx_ypass_q's lane geometry: 16 ds_read_b128 per row pair); tokens in natural order (column c = halfword c of the row) */
+template <int DEG>
+__device__ __forceinline__ void sepx_ypass_lds(const float *myrec, const double *tcol2, unsigned *trow, const QuantP &qp)
+{
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const float4 *r4 = (const float4 *)(myrec + h * 8 * 16);
+        const float4 ra = r4[0], rb = r4[1], rc = r4[2];
+        const double w0 = __hiloint2double(__float_as_int(ra.y), __float_as_int(ra.x));
+        const double w1 = __hiloint2double(__float_as_int(ra.w), __float_as_int(ra.z));
+        const double w2 = __hiloint2double(__float_as_int(rb.y), __float_as_int(rb.x));
+        const double w3 = __hiloint2double(__float_as_int(rb.w), __float_as_int(rb.z));
+        const char *tb = (const char *)tcol2;
+        const unsigned a0 = lds_addr_of(tb + __float_as_int(rc.x)), a1 = lds_addr_of(tb + __float_as_int(rc.y));
+        const unsigned a2 = lds_addr_of(tb + __float_as_int(rc.z)), a3 = lds_addr_of(tb + __float_as_int(rc.w));
+        d2_t t[4][4];
+#define RD4(A, J) asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:512\n\tds_read_b128 %2, %4 offset:1024\n\tds_read_b128 %3, %4 offset:1536" \
+                               : "=&v"(t[0][J]), "=&v"(t[1][J]), "=&v"(t[2][J]), "=&v"(t[3][J]) : "v"(A) : "memory")
+        RD4(a0, 0);
+        if (DEG >= 1) RD4(a1, 1);
+        if (DEG == 3) { RD4(a2, 2); RD4(a3, 3); }
+#undef RD4
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            if (DEG == 3) asm volatile("" : "+v"(t[g][0]), "+v"(t[g][1]), "+v"(t[g][2]), "+v"(t[g][3]));
+            else if (DEG == 1) asm volatile("" : "+v"(t[g][0]), "+v"(t[g][1]));
+            else asm volatile("" : "+v"(t[g][0]));
+        }
+        unsigned *orow = trow + h * 8 * SE_TOKW;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            unsigned tk[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                double val;
+                if (DEG == 0) val = t[g][0][e];
+                else if (DEG == 1) val = t[g][0][e] + (t[g][1][e] - t[g][0][e]) * w0;
+                else val = fma(w3, t[g][3][e], fma(w2, t[g][2][e], fma(w1, t[g][1][e], w0 * t[g][0][e])));
+                tk[e] = quant16((float)val, qp);
+            }
+            orow[32 * g] = tk[0] | tk[1] << 16;
+        }
+    }
+}
+
+template <int DEG>
+__global__ __launch_bounds__(SEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 6)))
+void k_sepx_enc(ezhip_sep_plan p, ezhip_sepenc_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem_x[];
+    __shared__ unsigned s_wsum[SE_TPT][SEP_BLOCK / 64], s_rb[SE_TROWS + 1], s_ib[SE_TROWS + 1], s_gt, s_abort, s_gtall[SE_TROWS];
+    __shared__ unsigned long long s_start[SE_TROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    /* launch order: (row group, field, strip) -- the strips of a (row group, field) set are neighbours in the launch */
+    const unsigned ns = (unsigned)p.e_nstrips, set = blockIdx.x / ns;
+    const int s = (int)(blockIdx.x - set * ns), rg = (int)(set / (unsigned)a.nfields), f = (int)(set - (unsigned)rg * (unsigned)a.nfields);
+    const int nis = p.ni_src, nid = p.ni_dst, njd = p.nj_dst, trows = p.e_tr, wstr = p.e_wstride;
+    const int c = s * (3 * SE_TPR) + tid, cc = min(c, nid - 1);
+    const float *zin = a.zin + (size_t)f * a.in_stride;
+    QuantP qp; qp.tok16 = nullptr; qp.colbase = 0;
+    { const double *pp = (const double *)((const char *)a.quant_params + (size_t)f * a.quant_stride); qp.minF = pp[0]; qp.mul = pp[1]; }
+    double *T = smem_x;
+    float *rec = (float *)(smem_x + (size_t)trows * SEP_BLOCK);
+    float *patch = rec + 16 * 16;
+    unsigned *tokw = (unsigned *)((char *)smem_x + p.x_lds_bytes);          /* set by the launcher: the bytes in front of the token patch */
+    if (tid == 0) { s_gt = 0; s_abort = 0; }
+    /* ---- interpolation: one step of k_sepx whose source rows are all new -------------------------------------------------- */
+    const auto *sq = CONSTP(int, p.e_step) + 4 * rg;
+    const int st_s0 = sq[0], st_n = sq[1], st_slot0 = sq[2];
+    if (st_n > 0 && !(a.debug & 64)) {
+        const int base = p.e_blk_base[s], W = p.e_blk_w[s];
+        unsigned coloff[SEP_QCH];
+#pragma unroll
+        for (int q = 0; q < SEP_QCH; q++) {
+            int col = base + min(lane + 64 * q, W - 1);
+            if (col >= nis) col -= nis;
+            coloff[q] = (unsigned)col * 4u;
+        }
+        const int x4lanes = (W + 3) >> 2;
+        const bool x4ok = base + 4 * x4lanes <= nis && x4lanes <= 64 && 4 * x4lanes <= wstr;
+        const unsigned x4off = (unsigned)(base + 4 * min(lane, x4lanes - 1)) * 4u;
+        for (int row = wv; row < st_n; row += SEP_BLOCK / 64) {
+            const float *zr = zin + (size_t)(st_s0 + row) * nis;
+            float *prow = patch + row * wstr;
+            if (x4ok) { if (lane < x4lanes) lds_dma_dwordx4(zr, x4off, lds_addr_of(prow)); }
+            else {
+#pragma unroll
+                for (int q = 0; q < SEP_QCH; q++)
+                    if (64 * q < W) lds_dma_dword(zr, coloff[q], lds_addr_of(prow + 64 * q));
+            }
+        }
+        lds_dma_dword((const float *)(p.e_rows + (size_t)rg * 16), (unsigned)(threadIdx.x * 4), lds_addr_of(rec + wv * 64));      /* 16 records of 16 dwords */
+        int off0 = p.cidx[cc] - base;
+        if (off0 < 0) off0 += nis;
+        const float *pcol = patch + off0;
+        const double cw[4] = {p.cw[cc], p.cw[nid + cc], p.cw[2 * nid + cc], p.cw[3 * nid + cc]};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        {
+            int slot = st_slot0, sr = 0;
+            auto next_slot = [&](int sl) { sl++; return sl >= trows ? sl - trows : sl; };
+            for (; sr + 4 <= st_n; sr += 4) {
+                const float *r0 = pcol + sr * wstr;
+                const double t0 = xrow<DEG>(r0, cw), t1 = xrow<DEG>(r0 + wstr, cw), t2 = xrow<DEG>(r0 + 2 * wstr, cw), t3 = xrow<DEG>(r0 + 3 * wstr, cw);
+                const int s1 = next_slot(slot), s2 = next_slot(s1), s3 = next_slot(s2);
+                T[slot * SEP_BLOCK + threadIdx.x] = t0; T[s1 * SEP_BLOCK + threadIdx.x] = t1;
+                T[s2 * SEP_BLOCK + threadIdx.x] = t2; T[s3 * SEP_BLOCK + threadIdx.x] = t3;
+                slot = next_slot(s3);
+            }
+            for (; sr < st_n; sr += 2) {
+                const float *r0 = pcol + sr * wstr, *r1 = r0 + (sr + 1 < st_n ? wstr : 0);
+                const double t0 = xrow<DEG>(r0, cw), t1 = xrow<DEG>(r1, cw);
+                const int s1 = next_slot(slot);
+                T[slot * SEP_BLOCK + threadIdx.x] = t0;
+                if (sr + 1 < st_n) T[s1 * SEP_BLOCK + threadIdx.x] = t1;
+                slot = next_slot(s1);
+            }
+        }
+        __syncthreads();
+        const int l32 = lane & 31, rsub = lane >> 5;
+        sepx_ypass_lds<DEG>(rec + (2 * wv + rsub) * 16, T + 2 * l32, tokw + (2 * wv + rsub) * SE_TOKW + l32, qp);
+    }
+    __syncthreads();
+    unsigned short *p16 = (unsigned short *)tokw;
+    constexpr unsigned RP = 2 * SE_TOKW;                      /* halfwords per patch row */
+    /* ---- the rows that are not main rows (polar strips, pole rows): one value per thread and row, in place ---------------- */
+    {
+        p.polevals = a.poles ? a.poles + 2 * f : nullptr; p.pole_inline = 0; p.pole_timeout = 0;
+        const auto *es = CONSTP(int, p.e_special) + 16 * rg;
+        bool any = false;
+        for (int k = 0; k < 16; k++) {
+            const int si = es[k];                              /* block-uniform */
+            if (si < 0) continue;
+            const float v = sep_special<DEG, 2>(p, nullptr, zin, si, c, cc, false, 0.0f, qp);
+            p16[k * RP + tid] = (unsigned short)quant16(v, qp);
+            any = true;
+        }
+        if (any) __syncthreads();
+    }
+    /* ---- the stream's prefix tokens: row 0 (first row group), column 0 (first strip) ------------------------------------- */
+    {
+        unsigned short *pt = a.ptok + (size_t)f * a.ptok_stride;
+        if (rg == 0 && c < nid && (tid > 0 || s == 0)) pt[c] = p16[tid];
+        if (s == 0 && tid >= 1 && tid < 16) { const int r = 3 * SE_TROWS * rg + tid; if (r < njd) pt[nid + r - 1] = p16[tid * RP]; }
+    }
+    if (a.debug & 32) { if (p16[tid] == 0x1234 && p16[15 * RP + tid] == 0x4321) a.zlng[f] = 7; return; }      /* development: interpolation only */
+    /* ---- per tile: differences (kept in registers), width, bit count (k_armn_enc1's tile phase on the LDS patch) ---------- */
+    const int nbits = a.nbits, container = a.container;
+    const int nt_x = min(SE_TPR, a.ntx - SE_TPR * s), nrow_t = min(SE_TROWS, a.nty - SE_TROWS * rg), ntl = nt_x * nrow_t;
+    unsigned long long dpk[SE_TPT][3];
+    unsigned bits[SE_TPT], meta[SE_TPT];                    /* meta: need | tm << 8 | tn << 12 | trow << 16 */
+    bool gt = false;
+#pragma unroll
+    for (int q = 0; q < SE_TPT; q++) {
+        const int tl = tid + SEP_BLOCK * q;
+        bits[q] = 0; meta[q] = 0;
+        dpk[q][0] = dpk[q][1] = dpk[q][2] = 0ull;
+        if (tl < ntl) {
+            const int trow = tl / nt_x, tcx = tl - trow * nt_x;
+            const int tm = min(3, nid - (1 + 3 * (SE_TPR * s + tcx))), tn = min(3, njd - (1 + 3 * (SE_TROWS * rg + trow)));
+            int h[4][3];
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                const unsigned short *prow = p16 + (unsigned)(3 * trow + n) * RP + 3 * tcx;
+                const int u0 = prow[0], u1 = prow[1], u2 = prow[2], u3 = prow[3];
+                h[n][0] = u1 - u0; h[n][1] = u2 - u1; h[n][2] = u3 - u2;
+            }
+            int d[3][3];
+#pragma unroll
+            for (int n = 0; n < 3; n++)
+#pragma unroll
+                for (int m = 0; m < 3; m++) d[n][m] = h[n + 1][m] - h[n][m];        /* u11 - (u01 + u10 - u00), c_zfstlib.c:691-696 */
+            if (tm < 3 || tn < 3) {
+#pragma unroll
+                for (int n = 0; n < 3; n++)
+#pragma unroll
+                    for (int m = 0; m < 3; m++) if (n >= tn || m >= tm) d[n][m] = 0;
+            }
+            int hi = max(max(d[0][0], d[0][1]), d[0][2]), lo = min(min(d[0][0], d[0][1]), d[0][2]);
+#pragma unroll
+            for (int n = 1; n < 3; n++) { hi = max(max(hi, d[n][0]), max(d[n][1], d[n][2])); lo = min(min(lo, d[n][0]), min(d[n][1], d[n][2])); }
+            const int mx = max(hi, -lo);
+#pragma unroll
+            for (int n = 0; n < 3; n++) {
+                const unsigned a0 = (unsigned)d[n][0] & 0x3FFFFu, a1 = (unsigned)d[n][1] & 0x3FFFFu, a2 = (unsigned)d[n][2] & 0x3FFFFu;
+                dpk[q][n] = (unsigned long long)(a0 | a1 << 21) | (unsigned long long)(a1 >> 11 | a2 << 10) << 32;
+            }
+            if (mx > 65535) gt = true;
+            unsigned need = (unsigned)bitlen((unsigned)mx);
+            if (need == 16) need = 15;
+            bits[q] = tile_bits(1, need, tm * tn, container, nbits);
+            meta[q] = need | (unsigned)tm << 8 | (unsigned)tn << 12 | (unsigned)trow << 16;
+        }
+    }
+    if (gt) s_gt = 1;
+    /* ---- block scan over the tiles in (tile row, tile) order: ONE wave scan, the two layers in the halves of a word (<= 10 944 per wave) ---- */
+    unsigned incl[SE_TPT];
+    {
+        static_assert(SE_TPT == 2, "the packed scan holds two layers");
+        unsigned v = bits[0] | bits[1] << 16;
+        for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(v, off, 64); if (lane >= off) v += o; }
+        incl[0] = v & 0xFFFFu; incl[1] = v >> 16;
+        if (lane == 63) { s_wsum[0][wv] = incl[0]; s_wsum[1][wv] = incl[1]; }
+    }
+    __syncthreads();                                        /* also: every thread is done with the token patch and s_gt is final */
+    unsigned excl[SE_TPT], agg_all = 0;
+#pragma unroll
+    for (int q = 0; q < SE_TPT; q++) {
+        unsigned before = agg_all;
+        for (int w = 0; w < SEP_BLOCK / 64; w++) { if (w < wv) before += s_wsum[q][w]; agg_all += s_wsum[q][w]; }
+        excl[q] = before + incl[q] - bits[q];
+    }
+#pragma unroll
+    for (int q = 0; q < SE_TPT; q++) {                      /* the first tile of every chunk: the chunk's base in the block's scan */
+        const int tl = tid + SEP_BLOCK * q;
+        if (tl < ntl) { const int trow = (int)(meta[q] >> 16); if (tl == trow * nt_x) s_rb[trow] = excl[q]; }
+    }
+    if (tid == 0) s_rb[nrow_t] = agg_all;
+    __syncthreads();
+    const int ty0 = SE_TROWS * rg;
+    unsigned long long *status = a.status + (size_t)f * a.nchunks, *tail = a.tail + (size_t)f * a.nchunks;
+    if (tid < nrow_t) {
+        const int cr = (ty0 + tid) * (int)ns + s;
+        st_granule(&status[cr], (cr == 0 ? ST_PFX : ST_AGG) | (s_gt ? ST_GT : 0ull) | (unsigned long long)(s_rb[tid + 1] - s_rb[tid]));      /* chunk 0: its aggregate IS its inclusive prefix */
+    }
+    /* image word offsets of the chunks: every chunk starts on a word, two spare words behind it */
+    unsigned rbase[SE_TROWS + 1], ib[SE_TROWS + 1];
+    ib[0] = 0;
+#pragma unroll
+    for (int r = 0; r <= SE_TROWS; r++) rbase[r] = s_rb[min(r, nrow_t)];
+#pragma unroll
+    for (int r = 0; r < SE_TROWS; r++) ib[r + 1] = ib[r] + ((rbase[r + 1] - rbase[r] + 31) >> 5) + 2;
+    unsigned *img = (unsigned *)smem_x;
+    for (unsigned w = tid; w < ib[SE_TROWS] + 4; w += SEP_BLOCK) img[w] = 0;
+    if (tid <= SE_TROWS) { unsigned v = ib[0]; for (int r = 1; r <= SE_TROWS; r++) if (tid == r) v = ib[r]; s_ib[tid] = v; }      /* for the loops over a runtime chunk index below */
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SE_TPT; q++) {
+        if (tid + SEP_BLOCK * q >= ntl || (a.debug & 1)) continue;
+        const unsigned need = meta[q] & 0xFF; const int tm = (int)(meta[q] >> 8) & 0xF, tn = (int)(meta[q] >> 12) & 0xF, trow = (int)(meta[q] >> 16);
+        unsigned rb_ = rbase[0], ib_ = ib[0];
+#pragma unroll
+        for (int r = 1; r < SE_TROWS; r++) if (trow == r) { rb_ = rbase[r]; ib_ = ib[r]; }
+        const unsigned pos = excl[q] - rb_;
+        unsigned wi = ib_ + (pos >> 5); int fill = (int)(pos & 31);
+        unsigned long long acc = 0; bool first = true;
+        const int width = need == 0 ? 0 : (need == 15 ? 17 : (int)need + 1);
+        const unsigned mask = (1u << width) - 1;
+        const int rowlen = tm * width;
+        auto flush = [&]() {
+            const unsigned word = (unsigned)(acc >> 32);
+            if (first) { atomicOr(&img[wi], word); first = false; } else img[wi] = word;
+            wi++; acc <<= 32; fill -= 32;
+        };
+#pragma unroll
+        for (int n = 0; n < 3; n++) {
+            if (n >= tn || (n > 0 && need == 0)) break;
+            unsigned long long v = 0;
+#pragma unroll
+            for (int m = 0; m < 3; m++) if (m < tm) v = (v << width) | (unsigned long long)((unsigned)(dpk[q][n] >> (21 * m)) & mask);
+            int L = rowlen;
+            if (n == 0) { v |= (unsigned long long)need << rowlen; L += container; }
+            const int room = 64 - fill;
+            if (L <= room) { acc |= L == 64 ? v : v << (room - L); fill += L; }
+            else { acc |= v >> (L - room); fill = 64; flush(); flush(); acc = v << (64 - (L - room)); fill = L - room; continue; }
+            if (fill >= 32) flush();
+            if (fill >= 32) flush();
+        }
+        if (fill > 0) atomicOr(&img[wi], (unsigned)(acc >> 32));
+    }
+    __syncthreads();                                        /* the images are complete */
+    /* ---- per chunk, one wave: publish the tail, look back for the chunk's position, settle the word shared with the earlier chunks ---- */
+    const unsigned long long body_start = 32ull + 3ull + (unsigned long long)(nid + njd - 1) * (unsigned long long)nbits;
+    for (int r = wv; r < nrow_t; r += SEP_BLOCK / 64) {
+        const int cr = (ty0 + r) * (int)ns + s;
+        const unsigned agg = s_rb[r + 1] - s_rb[r];
+        const unsigned *im = img + s_ib[r];
+        auto wait_tail = [&](int idx, unsigned long long t) -> unsigned {
+            int spins = 0;
+            while ((t >> 62) == 0) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 19) || ((spins & 63) == 0 && __hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(&a.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 1; break;
+                }
+                t = ld_granule(&tail[idx]);
+            }
+            return (unsigned)t;
+        };
+        unsigned long long tprev = (lane == 0 && cr > 0) ? ld_granule(&tail[cr - 1]) : 0ull;
+        if (lane == 0) {
+            unsigned tl32;
+            if (agg >= 32) { const unsigned e = agg & 31, w = agg >> 5; tl32 = e ? (im[w - 1] << e) | (im[w] >> (32 - e)) : im[w - 1]; }
+            else {                                               /* a chunk shorter than a word (the few tiles of a last strip): chained.  Chunk 0 has 85 tiles */
+                const unsigned tp = cr > 0 ? wait_tail(cr - 1, tprev) : 0u;
+                tl32 = agg ? (tp << agg) | (im[0] >> (32 - agg)) : tp;
+                tprev = ST_PFX | tp;
+            }
+            st_granule(&tail[cr], ST_PFX | (unsigned long long)tl32);
+        }
+        unsigned long long excl_chunks = 0, gt_before = 0;
+        bool gave_up = false;
+        if (cr > 0 && !(a.debug & 8)) {
+            int basei = cr - 1, spins = 0;
+            for (;;) {
+                const int idx = basei - lane;
+                const unsigned long long stv = idx >= 0 ? ld_granule(&status[idx]) : ST_PFX;
+                const unsigned long long pm = __ballot((stv >> 62) == 2), okm = __ballot((stv >> 62) != 0);
+                const int firstp = pm ? __builtin_ctzll(pm) : 63;
+                const unsigned long long needm = firstp == 63 ? ~0ull : ((2ull << firstp) - 1);
+                if ((okm & needm) != needm) {
+                    /* not there yet: ONE lane polls the ONE nearest granule that is missing, with a pause, then the window is read again */
+                    const int bad_idx = basei - __builtin_ctzll(~okm & needm);
+                    if (lane == 0) {
+                        while ((ld_granule(&status[bad_idx]) >> 62) == 0) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > (1 << 19) || ((spins & 63) == 0 && __hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { gave_up = true; break; }
+                        }
+                    }
+                    gave_up = __shfl((int)gave_up, 0, 64) != 0;
+                    if (gave_up) break;
+                    continue;
+                }
+                unsigned long long v = 0; bool gg = false;
+                if (!pm || lane <= firstp) { v = ST_VAL(stv); gg = (stv & ST_GT) != 0; }
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                excl_chunks += v;
+                gt_before |= __ballot(gg);
+                if (pm) break;
+                basei -= 64;
+            }
+            if (lane == 0 && !gave_up) st_granule(&status[cr], ST_PFX | ((gt_before || s_gt) ? ST_GT : 0ull) | (excl_chunks + agg));
+        }
+        if (lane == 0) {
+            const unsigned long long S = body_start + excl_chunks;
+            s_start[r] = S;
+            s_gtall[r] = (gt_before || s_gt) ? 1u : 0u;
+            if (gave_up) { s_abort = 1; __hip_atomic_store(&a.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            else {
+                const unsigned sh = (unsigned)(S & 31);
+                if (sh && (((sh + agg) >> 5) >= 1 || cr == a.nchunks - 1) && !(a.debug & 8)) {         /* the shared word is completed here (else a later chunk stores it) */
+                    if (cr == 0) a.head[f] = im[0];                                   /* the prefix's bits come from the side array: k_sepenc_prefix stores the word */
+                    else {
+                        const unsigned tp = wait_tail(cr - 1, tprev);
+                        const unsigned v0 = (im[0] >> sh) | ((tp & ((1u << sh) - 1u)) << (32 - sh));
+                        if ((S >> 5) < a.z_cap) a.z[(size_t)f * a.z_stride + (S >> 5)] = v0;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (s_abort) return;
+    /* ---- copy out: every chunk's image shifted to its absolute bit position ------------------------------------------------ */
+    unsigned *z = a.z + (size_t)f * a.z_stride;
+    for (int r = 0; r < nrow_t; r++) {
+        const int cr = (ty0 + r) * (int)ns + s;
+        const unsigned agg = s_rb[r + 1] - s_rb[r];
+        const unsigned *im = img + s_ib[r];
+        const unsigned long long S = s_start[r];
+        const unsigned sh = (unsigned)(S & 31);
+        const unsigned long long gw0 = S >> 5;
+        const unsigned nwout = (sh + agg + 31) >> 5;
+        const bool last_chunk = cr == a.nchunks - 1;
+        const bool tail_open = ((sh + agg) & 31) != 0 && !last_chunk;
+        const unsigned nstore = nwout - (tail_open ? 1u : 0u);
+        if (!(a.debug & 2))
+        for (unsigned k = (sh ? 1u : 0u) + tid; k < nstore; k += SEP_BLOCK) {
+            const unsigned lo = im[k];
+            const unsigned v = sh == 0 ? lo : ((k ? im[k - 1] : 0u) << (32 - sh)) | (lo >> sh);
+            if (gw0 + k < a.z_cap) z[gw0 + k] = v;
+        }
+        if (tid == 0 && last_chunk) {
+            if (gw0 + nwout < a.z_cap) z[gw0 + nwout] = 0u;
+            const unsigned long long bits_total = S + agg - 32;       /* c_zfstlib.c:160-179 */
+            const long long zl = 1 + 4 * (1 + (long long)((bits_total + 31) / 32));
+            const long long lng_origin = 1 + 2 * (long long)nid * njd;
+            a.zlng[f] = (s_gtall[r] && container == 4 && nbits >= 15) ? -2 : (zl >= lng_origin ? -1 : (int)zl);
+        }
+    }
+}
+
+extern "C" int ezhip_interp_sep_enc(const ezhip_sep_plan *plan, const ezhip_sepenc_args *args)
+{
+    if (!plan->e_ok) { snprintf(g_err, sizeof(g_err), "k_sepx_enc: the plan has no fused geometry"); return -1; }
+    ezhip_sep_plan pl = *plan;
+    const size_t lds = ezhip_sepenc_lds_bytes(plan);
+    pl.x_lds_bytes = lds - 4 * 16 * (size_t)SE_TOKW;
+    const size_t nblocks = (size_t)pl.e_nstrips * (size_t)pl.e_nrg * (size_t)args->nfields;
+    if (nblocks >= ((size_t)1 << 31)) { snprintf(g_err, sizeof(g_err), "k_sepx_enc: batch too large for one launch"); return -1; }
+    hipError_t e = hipSuccess;
+    const void *fn = pl.degree == 0 ? (const void *)k_sepx_enc<0> : pl.degree == 1 ? (const void *)k_sepx_enc<1> : (const void *)k_sepx_enc<3>;
+    if (lds > 64 * 1024) { e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return set_err(e, "k_sepx_enc LDS size"); }
+    dim3 grid((unsigned)nblocks), block(SEP_BLOCK);
+    switch (pl.degree) {
+    case 0: hipLaunchKernelGGL(k_sepx_enc<0>, grid, block, lds, g_stream, pl, *args); break;
+    case 1: hipLaunchKernelGGL(k_sepx_enc<1>, grid, block, lds, g_stream, pl, *args); break;
+    default: hipLaunchKernelGGL(k_sepx_enc<3>, grid, block, lds, g_stream, pl, *args); break;
+    }
+    return LAUNCH_CHECK("k_sepx_enc");
 }
 
 

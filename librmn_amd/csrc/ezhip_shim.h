@@ -151,7 +151,45 @@ typedef struct {
     const int *bb_rowstart, *bb_rowlist;             /* [nj_src + 1], [main rows] */
     const float *bb_colk, *bb_rowk;                  /* [ni_src], [nj_src]: max sum |wx| of the target columns / sum |wy| of the rows of the window (rounded up); a window's a = (colk rowk - 1) / 2: the
                                                         rows that EXTRApolate towards a pole without the polar correction carry weights far beyond the interior's 1.25 */
+    /* ---- interpolate AND encode in one launch (k_sepx_enc, the cfg5 pipeline's passes B + E): a thread block owns 256 target columns (one context
+     * column + 85 tiles of 3) x 16 target rows (one context row + 5 tile rows) = five chunks of the armn_compress stream; strips advance by 255
+     * columns, row groups by 15 rows.  e_ok: the geometry exists (every strip staged from consecutive taps, no fill columns / rows) */
+    int e_ok, e_nstrips, e_nrg, e_tr, e_prows, e_wstride;
+    const int *e_blk_base, *e_blk_w;  /* [e_nstrips] staged source columns of a strip */
+    const ezhip_xstep *e_step;        /* [e_nrg] the source rows of a row group (all new: no ring reuse between thread blocks) */
+    const ezhip_xrow *e_rows;         /* [e_nrg][16] row records (o_off unused) */
+    const int *e_special;             /* [e_nrg][16] index into special[] of a row that is not a main row, -1: main row (or past the last row) */
 } ezhip_sep_plan;
+
+/* what k_sepx_enc needs beside the plan: the streams, the look-back storage (zeroed), compact_float's parameters per field */
+typedef struct {
+    unsigned *z; size_t z_stride, z_cap;             /* stream of field f at z + f * z_stride, capacity z_cap words */
+    const float *zin; size_t in_stride; int nfields;
+    const float *poles;                              /* [2 nfields] pole values (plans with need_poles) */
+    const void *quant_params; size_t quant_stride;   /* packhip_cf_params of field f: {minF, mulFactor} first */
+    int nbits, container, ntx, nty, nchunks;         /* tiles per tile row, tile rows, chunks per field (nty * e_nstrips) */
+    unsigned long long *status, *tail;               /* [nfields][nchunks] */
+    unsigned *ctl;                                   /* [0] abort flag */
+    unsigned short *ptok; size_t ptok_stride;        /* [nfields][ni + nj - 1] tokens of the stream prefix: row 0, then column 0 from row 1 on */
+    unsigned *head;                                  /* [nfields] first image word of chunk 0: the bits of the stream word it shares with the prefix */
+    int *zlng;                                       /* [nfields] */
+    int debug;
+} ezhip_sepenc_args;
+/* layout of the launch's device scratch (zeroed up to off_head by the caller): granules, abort flag, chunk 0's first words, prefix tokens */
+typedef struct { size_t off_status, off_tail, off_ctl, off_head, off_ptok, ptok_stride, zero_bytes, total; int ntx, nty, nstrips, nchunks; } ezhip_sepenc_layout;
+static inline ezhip_sepenc_layout ezhip_sepenc_layout_of(int ni, int nj, int nfields)
+{
+    ezhip_sepenc_layout L;
+    L.ntx = (ni - 1 + 2) / 3; L.nty = (nj - 1 + 2) / 3; L.nstrips = (L.ntx + 84) / 85; L.nchunks = L.nty * L.nstrips;
+    L.off_status = 0; L.off_tail = 8 * (size_t)L.nchunks * (size_t)nfields; L.off_ctl = 2 * L.off_tail;
+    L.off_head = L.off_ctl + 64; L.zero_bytes = L.off_head;
+    L.off_ptok = (L.off_head + 4 * (size_t)nfields + 63) & ~(size_t)63;
+    L.ptok_stride = ((size_t)ni + (size_t)nj - 1 + 7) & ~(size_t)7;
+    L.total = L.off_ptok + 2 * L.ptok_stride * (size_t)nfields + 64;
+    return L;
+}
+size_t ezhip_sepenc_lds_bytes(const ezhip_sep_plan *plan);
+int ezhip_interp_sep_enc(const ezhip_sep_plan *plan, const ezhip_sepenc_args *args);
 
 int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin);
 /* exact {min, max} of the values ezhip_interp_sep would store for nfields fields (plan->bb_ok), asynchronous: d_partials[f * stride_words + 0..2] :=

@@ -785,8 +785,13 @@ int32_t ezhip_fst_frame_record_dev(uint32_t *d_data, int64_t cap_words, const ui
     return (int32_t)nw;
 }
 
+int32_t ezhip_ezsint_batch_encode_dev(uint32_t *d_z, int64_t z_stride_words, int64_t z_cap_words, const float *d_zin, int32_t nfields,
+                                      const void *d_params, int64_t param_stride_bytes, int32_t nbits, void *d_work, int32_t *d_zlng, int32_t poles_ready);
+/* use_bb: pass A from bounds of the source windows (else the interpolating pass); use_fused: passes B + E in one launch (k_sepx_enc: the tokens never
+ * reach HBM), else tokens to HBM and the one-pass encoder.  Both fall back by themselves when the grid set's plan does not qualify; fields a first
+ * choice hands back (bound pass: no extremum stands out; fused launch: not compressible / wide differences / gave up) are redone without it. */
 static int32_t cfg5_batch(void *d_records, int64_t record_stride_words, const float *d_zin, int32_t nfields,
-                          int32_t ni_out, int32_t nj_out, int32_t nbits, int32_t *zlng_out, int use_bb)
+                          int32_t ni_out, int32_t nj_out, int32_t nbits, int32_t *zlng_out, int use_bb, int use_fused)
 {
     int32_t ni_in = 0, nj_in = 0, ni_set = 0, nj_set = 0;
     if (ezhip_current_set_dims(&ni_in, &nj_in, &ni_set, &nj_set)) return -1;
@@ -803,11 +808,17 @@ static int32_t cfg5_batch(void *d_records, int64_t record_stride_words, const fl
     const size_t tok_stride = (n + 1) / 2 + 4;                                  /* words per field */
     const size_t stride = PACKHIP_STATS_PARTIALS + 3 * (size_t)8192;
     unsigned *d_stats_all = (unsigned *)ws(3, (4 * stride + sizeof(packhip_cf_params)) * (size_t)nfields + 64);
-    unsigned *d_tok = (unsigned *)ws(1, 4 * tok_stride * (size_t)nfields);
-    char *d_work = (char *)ws(2, wb * (size_t)nsub);
+    /* MEASURED (MI355X, 32 cfg5 fields, profiles/r03_experiments.txt): the one-launch form moves half the bytes (tokens never reach HBM) and takes TWICE the
+     * time of the two kernels (135 against 68 us per field: 49 KB of LDS per thread block = 3 waves per SIMD for an encoder that wants 6, a row group brings
+     * all its source rows itself, the look-back of five chunks sits on the critical path of every thread block).  Kept as a switch: EZHIP_CFG5_FUSED=1 */
+    if (nsub > 1 || !getenv("EZHIP_CFG5_FUSED")) use_fused = 0;
+    const ezhip_sepenc_layout L = ezhip_sepenc_layout_of(ni_out, nj_out, nfields);
+    unsigned *d_tok = use_fused ? NULL : (unsigned *)ws(1, 4 * tok_stride * (size_t)nfields);      /* the fused launch needs no token array (1.66 GB for 32 cfg5 fields) */
+    char *d_work = (char *)ws(2, use_fused && L.total > wb * (size_t)nsub ? L.total : wb * (size_t)nsub);
     int *d_zlng = (int *)ws(0, 2 * sizeof(int) * (size_t)nfields + 64);           /* zlng[nfields] | flags[nfields] */
-    if (!d_stats_all || !d_tok || !d_work || !d_zlng) return -1;
+    if (!d_stats_all || (!d_tok && !use_fused) || !d_work || !d_zlng) return -1;
     int *d_flags = d_zlng + nfields;
+    int fused_used = 0;
     packhip_cf_params *d_pp = (packhip_cf_params *)(d_stats_all + stride * (size_t)nfields);
     const size_t nin = (size_t)ni_in * nj_in;
     const size_t z_cap = (size_t)record_stride_words - 4 < n / 2 + 16 ? (size_t)record_stride_words - 4 : n / 2 + 16;
@@ -819,7 +830,7 @@ static int32_t cfg5_batch(void *d_records, int64_t record_stride_words, const fl
         const int f0 = k * sub, nf = nfields - f0 < sub ? nfields - f0 : sub;
         unsigned *rec0 = (unsigned *)d_records + (size_t)f0 * (size_t)record_stride_words;
         unsigned *stats0 = d_stats_all + stride * (size_t)f0;
-        unsigned *tok0 = d_tok + tok_stride * (size_t)f0;
+        unsigned *tok0 = d_tok ? d_tok + tok_stride * (size_t)f0 : NULL;
         int32_t npf = 0, r = -2;
         /* pass A: the field's extrema.  First choice: from bounds of the SOURCE windows + exact evaluation of the few that matter (no interpolation) */
         if (use_bb) { r = ezhip_ezsint_batch_minmax_bb_dev(d_zin + nin * (size_t)f0, nf, stats0 + PACKHIP_STATS_PARTIALS, (int64_t)stride, &npf, d_flags + f0); if (r == 0) bb_used = 1; }
@@ -827,6 +838,22 @@ static int32_t cfg5_batch(void *d_records, int64_t record_stride_words, const fl
         if (r < 0) { if (k) { ezhip_side_join(); ezhip_sync(); } return k ? -1 : r; }          /* -2: not on the single-launch path (nothing launched yet) */
         if (r > rc) rc = r;
         if (packhip_cf_header_batch(d_pp + f0, rec0, (size_t)record_stride_words, stats0, stride, npf, (unsigned)n, nbits, 2, 0, nf)) goto fail;
+        if (use_fused) {
+            /* passes B + E in one launch; -2: the plan has no fused geometry -> the two kernels below (nothing launched) */
+            int32_t fr = ezhip_ezsint_batch_encode_dev(rec0 + 4, record_stride_words, (int64_t)z_cap, d_zin + nin * (size_t)f0, nf, d_pp + f0,
+                                                       (int64_t)sizeof(packhip_cf_params), nbits, d_work, d_zlng + f0, bb_used);
+            if (fr == 0) {
+                if (packhip_sepenc_prefix(rec0 + 4, (size_t)record_stride_words, z_cap, (const unsigned short *)(d_work + L.off_ptok), L.ptok_stride,
+                                          (const unsigned *)(d_work + L.off_head), d_zlng + f0, ni_out, nj_out, nbits, 4, nf)) goto fail;
+                fused_used = 1;
+                continue;
+            }
+            if (fr != -2) goto fail;
+            use_fused = 0;
+            d_tok = (unsigned *)ws(1, 4 * tok_stride * (size_t)nfields);
+            if (!d_tok) goto fail;
+            tok0 = d_tok + tok_stride * (size_t)f0;
+        }
         if (ezhip_ezsint_batch_tokens_dev(tok0, (int64_t)tok_stride, d_zin + nin * (size_t)f0, nf, d_pp + f0, (int64_t)sizeof(packhip_cf_params)) < 0) goto fail;
         const int side = nsub > 1;
         if (side && ezhip_side_begin()) goto fail;
@@ -841,6 +868,23 @@ static int32_t cfg5_batch(void *d_records, int64_t record_stride_words, const fl
         if (!h) goto fail;
         if (ezhip_d2h(h, d_zlng, 2 * sizeof(int) * (size_t)nfields) || ezhip_sync()) { free(h); return -1; }
         memcpy(zlng_out, h, sizeof(int32_t) * (size_t)nfields);
+        if (fused_used && getenv("EZHIP_CFG5_ONLY_FUSED")) { free(h); return rc; }      /* development: knock-out timings, results unchecked */
+        if (fused_used) {
+            /* the fused launch has no token array to fall back on: a field it could not finish (not compressible, differences beyond 16 bits, launch
+             * gave up: zlng still "unfinished") goes through the two-kernel path, extrema pass included (runs of such fields in one call) */
+            for (int f = 0; f < nfields; f++) {
+                if (h[f] > 0 && !h[nfields + f]) continue;
+                int f1 = f + 1;
+                while (f1 < nfields && !(h[f1] > 0 && !h[nfields + f1])) f1++;
+                if (getenv("EZHIP_VERBOSE")) fprintf(stderr, "cfg5: fields %d..%d redone with the two-kernel path (zlng %d, bound-pass flag %d)\n", f, f1 - 1, h[f], h[nfields + f]);
+                int32_t r = cfg5_batch((unsigned *)d_records + (size_t)f * (size_t)record_stride_words, record_stride_words, d_zin + nin * (size_t)f, f1 - f,
+                                       ni_out, nj_out, nbits, zlng_out + f, use_bb && !h[nfields + f], 0);
+                if (r < 0) { free(h); return -1; }
+                f = f1 - 1;
+            }
+            free(h);
+            return rc;
+        }
         if (redo_wide_fields((unsigned *)d_records, (size_t)record_stride_words, d_tok, tok_stride, 0, nfields, ni_out, nj_out, nbits, zlng_out)) { free(h); return -1; }
         /* fields the bound pass gave up on (flags: too many source windows could hold the extremum): the interpolating pass A for those */
         for (int f = 0; f < nfields && bb_used; f++) {
@@ -848,7 +892,7 @@ static int32_t cfg5_batch(void *d_records, int64_t record_stride_words, const fl
             int f1 = f + 1;
             while (f1 < nfields && h[nfields + f1]) f1++;
             int32_t r = cfg5_batch((unsigned *)d_records + (size_t)f * (size_t)record_stride_words, record_stride_words, d_zin + nin * (size_t)f, f1 - f,
-                                   ni_out, nj_out, nbits, zlng_out + f, 0);
+                                   ni_out, nj_out, nbits, zlng_out + f, 0, use_fused);
             if (r < 0) { free(h); return -1; }
             f = f1 - 1;
         }
@@ -879,5 +923,5 @@ int32_t ezhip_ezsint_pack16_compress_batch_dev(void *d_records, int64_t record_s
         fprintf(stderr, "<ezhip_ezsint_pack16_compress_batch_dev> record_stride_words = %lld, a record needs at least %zu words\n", (long long)record_stride_words, 4 + (n + 1) / 2);
         return -1;
     }
-    return cfg5_batch(d_records, record_stride_words, d_zin, nfields, ni_out, nj_out, nbits, zlng_out, getenv("EZHIP_CFG5_NO_BB") ? 0 : 1);
+    return cfg5_batch(d_records, record_stride_words, d_zin, nfields, ni_out, nj_out, nbits, zlng_out, getenv("EZHIP_CFG5_NO_BB") ? 0 : 1, 1);
 }

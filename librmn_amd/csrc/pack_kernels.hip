@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "packhip_shim.h"
+#include "armn_dev.h"
 
 #pragma clang fp contract(off)
 
@@ -552,8 +553,6 @@ extern "C" int packhip_fp_unpack(float *d_dest, const int *d_stream, int npts, i
  * gets the same ushort array by swapping halves on little-endian hosts, c_zfstlib.c:119-126) */
 __device__ __forceinline__ int tokat(const unsigned *w, size_t k) { unsigned x = w[k >> 1]; return (int)((k & 1) ? (x & 0xFFFFu) : (x >> 16)); }
 
-__device__ __forceinline__ int bitlen(unsigned v) { return v ? 32 - __clz((int)v) : 0; }
-
 /* OR `nbits` bits of `tok` into a zeroed MSB-first stream at absolute bit position `pos` */
 __device__ __forceinline__ void put_bits(unsigned *z, unsigned long long pos, unsigned tok, int nbits)
 {
@@ -617,14 +616,6 @@ __global__ __launch_bounds__(256) void k_armn_tiles(unsigned char *nb, unsigned 
     }
     if (need == 16) need = 15;
     nb[t] = (unsigned char)need;
-}
-
-__device__ __forceinline__ unsigned tile_bits(int PARA, unsigned need, int cnt, int container, int nbits)
-{
-    if (PARA) return (unsigned)container + (need == 0 ? 0u : (unsigned)cnt * (need == 15 ? 17u : need + 1u));
-    if (need == 0) return 4u + (unsigned)nbits;
-    if (need == 15) return 4u + 16u * (unsigned)cnt;
-    return 4u + (unsigned)nbits + need * (unsigned)cnt;
 }
 
 #define SCAN_TPB 256
@@ -1053,12 +1044,6 @@ struct enc1_args {
     int debug;                                          /* development knock-outs (EZHIP_ENC_DEBUG): 1 no emission, 2 no copy-out, 4 no staging, 8 no look-back wait */
     int *zlng;                                          /* [nfields] result: byte count, -1 not compressible, -2 re-run with container 5 */
 };
-#define ST_AGG (1ull << 62)
-#define ST_PFX (2ull << 62)
-#define ST_GT  (1ull << 61)          /* a |difference| > 65535 in this chunk (AGG) / in this or an earlier chunk (PFX) */
-#define ST_VAL(x) ((x) & 0x1FFFFFFFFFFFFFFFull)
-__device__ __forceinline__ unsigned long long ld_granule(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_granule(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 /* word w (>= 1) of the stream prefix: 3-bit container, row 1, column 1 (c_zfstlib.c:712-721); bits at or beyond body_start are zero */
 template <bool SWAPPED>
@@ -1513,6 +1498,48 @@ extern "C" int packhip_armn_encode1(unsigned *d_z, size_t z_stride_words, size_t
     if (swapped) hipLaunchKernelGGL(k_armn_enc1<true>, dim3((unsigned)nblocks), dim3(ENC_TPB), lds, st, a);
     else hipLaunchKernelGGL(k_armn_enc1<false>, dim3((unsigned)nblocks), dim3(ENC_TPB), lds, st, a);
     return chk("k_armn_enc1") ? -1 : 0;
+}
+
+/* the prefix words of the streams k_sepx_enc (ez_kernels.hip: interpolation and encoder in one launch) left without them: word 0 (the _fstzip header),
+ * the 3-bit container, row 0 and column 0 verbatim (c_zfstlib.c:712-721) from the side array of ni + nj - 1 tokens per field, and the word the prefix
+ * shares with the first chunk (`head` = that chunk's first image word) */
+__global__ __launch_bounds__(256) void k_sepenc_prefix(unsigned *z, size_t z_stride, size_t z_cap, const unsigned short *ptok, size_t ptok_stride,
+                                                       const unsigned *head, const int *zlng, int ni, int nj, int nbits, int container)
+{
+    const int f = blockIdx.y;
+    if (zlng[f] <= 0) return;                                 /* the host redoes such a field with the two-kernel path */
+    unsigned *zf = z + (size_t)f * z_stride;
+    const unsigned short *pt = ptok + (size_t)f * ptok_stride;
+    const unsigned long long body_start = 32ull + 3ull + (unsigned long long)(ni + nj - 1) * (unsigned long long)nbits;
+    const unsigned long long wend = body_start >> 5;
+    const unsigned sh = (unsigned)(body_start & 31);
+    const long long ntok = (long long)ni + nj - 1;
+    for (unsigned long long w = (unsigned long long)blockIdx.x * 256 + threadIdx.x; w <= wend; w += (unsigned long long)gridDim.x * 256) {
+        if (w >= z_cap) continue;
+        if (w == 0) { zf[0] = 4u | 1u << 4 | 3u << 7 | ((unsigned)nbits & 31u) << 10 | 1u << 15; continue; }
+        if (w == wend && !sh) continue;                       /* the body starts on a word: chunk 0 stored it */
+        const long long P0 = (long long)(w - 1) * 32;        /* first prefix bit of the word (prefix bit 0 = stream bit 32) */
+        unsigned word = 0;
+        if (P0 < 3) word |= (unsigned)container << 29;
+        long long q = P0 <= 3 ? 0 : (P0 - 3) / nbits;
+        for (; q < ntok; q++) {
+            const long long tb = 3 + q * nbits;
+            if (tb >= P0 + 32) break;
+            const unsigned long long v = (unsigned long long)pt[q] & ((1ull << nbits) - 1);
+            const long long s_ = (P0 + 32) - (tb + nbits);
+            word |= s_ >= 0 ? (unsigned)(v << s_) : (unsigned)(v >> (-s_));
+        }
+        if (w == wend) word |= head[f] >> sh;
+        zf[w] = word;
+    }
+}
+extern "C" int packhip_sepenc_prefix(unsigned *d_z, size_t z_stride_words, size_t z_cap_words, const unsigned short *d_ptok, size_t ptok_stride,
+                                     const unsigned *d_head, const int *d_zlng, int ni, int nj, int nbits, int container, int nfields)
+{
+    const unsigned long long wend = (32ull + 3ull + (unsigned long long)(ni + nj - 1) * (unsigned long long)nbits) >> 5;
+    hipLaunchKernelGGL(k_sepenc_prefix, dim3((unsigned)((wend + 256) / 256), (unsigned)nfields), dim3(256), 0, STREAM,
+                       d_z, z_stride_words, z_cap_words, d_ptok, ptok_stride, d_head, d_zlng, ni, nj, nbits, container);
+    return chk("k_sepenc_prefix");
 }
 
 /* conditional copies behind an asynchronous encode, all fields in one launch (blockIdx.y = field):

@@ -57,6 +57,9 @@ int packhip_swap_halves(unsigned *d_dst, const unsigned *d_src, size_t nwords);
  * one-token-per-word array (packhip_ci_pack then packs them behind the header) */
 int packhip_fst_frame129(unsigned *d_data, const unsigned *d_rec, unsigned nw, unsigned ncopy);
 int packhip_fst_plain_from_slots(unsigned *d_data, unsigned *d_tok32, const unsigned *d_rec, size_t n);
+/* prefix words of the streams the fused interpolate + encode launch (k_sepx_enc, ez_kernels.hip) produced */
+int packhip_sepenc_prefix(unsigned *d_z, size_t z_stride_words, size_t z_cap_words, const unsigned short *d_ptok, size_t ptok_stride,
+                          const unsigned *d_head, const int *d_zlng, int ni, int nj, int nbits, int container, int nfields);
 /* armn_compress UNCOMPRESS (unpack_kernels.hip): nfields streams of z_words capacity each -> (1 + ni*nj/2) token words each */
 size_t packhip_armn_dec_work_bytes(int ni, int nj, size_t z_words);
 int packhip_armn_decode(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,

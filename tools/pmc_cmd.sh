@@ -1,29 +1,22 @@
-# rocprofv3 --pmc pass(es) over a python tool: bash tools/pmc_cmd.sh <tag> "<counters pass 1>" ["<counters pass 2>" ...] -- <script> [args]
-TAG=$1; shift
-PASSES=()
-while [ "$1" != "--" ]; do PASSES+=("$1"); shift; done
-shift
+# HBM traffic of the kernels matching PATTERN in a python tool: separate --pmc passes for FETCH_SIZE (x2 on gfx950, MI355X_MICROARCH.md) and WRITE_SIZE;
+# bash tools/pmc_cmd.sh <tag> <pattern> <script> [args] -> per (kernel, grid): dispatches, median KiB per dispatch
+TAG=$1; PAT=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/$TAG
-k=0
-for P in "${PASSES[@]}"; do
-  k=$((k+1))
-  rm -rf $R/gpurun_out/$TAG/pmc$k
-  timeout 600 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/pmc$k -o p -- python3 $R/$@ > $R/gpurun_out/$TAG/pmc$k.log 2>&1
-  C=$(find $R/gpurun_out/$TAG/pmc$k -name "*counter_collection.csv" | head -1)
-  python3 - "$C" >> $R/gpurun_out/$TAG/pmc_summary.txt <<'PY'
-import csv, sys, collections
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG
+mkdir -p $O
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $O/pmc_$c
+  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python3 $R/$@ > $O/pmc_$c.log 2>&1
+  C=$(find $O/pmc_$c -name "*counter_collection.csv" | head -1)
+  python3 - "$C" "$PAT" "$c" <<'PY' | tee $O/$c.txt
+import csv, sys, re, collections, statistics
 rows = list(csv.DictReader(open(sys.argv[1])))
-agg = collections.defaultdict(lambda: [0, 0.0])
+pat = re.compile(sys.argv[2]); agg = collections.defaultdict(list)
 for r in rows:
-    k = (r["Kernel_Name"][:50], r["Grid_Size"], r["Counter_Name"])
-    agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
+    if pat.search(r["Kernel_Name"]): agg[(r["Kernel_Name"].split("(")[0][:50], r["Grid_Size"])].append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):
-    import os
-    if any(f in k[0] for f in os.environ.get("KFILTER", "k_armn,k_sepx").split(",")):
-        print(f"{k[0]:52s} grid={k[1]:>10s} {k[2]:28s} dispatches={v[0]:4d} mean={v[1]/v[0]:16.1f}")
+    mult = 2.0 if sys.argv[3] == "FETCH_SIZE" else 1.0
+    print(f"{sys.argv[3]:10s} {k[0]:52s} grid={k[1]:>10s} n={len(v):4d} median {statistics.median(v) * mult * 1024 / 1e6:10.2f} MB per dispatch (corrected)")
 PY
-  rm -rf $R/gpurun_out/$TAG/pmc$k
+  rm -rf $O/pmc_$c
 done
-cat $R/gpurun_out/$TAG/pmc_summary.txt
