@@ -2087,23 +2087,70 @@ static int hio_full(float *d_zin)
  * the side stream while the next range uploads and computes -- PCIe carries both directions at once, so the call costs about the larger
  * copy (D2H, 104 MB at cfg2) instead of the sum.  The last range carries the special (polar / outside) rows and the pole sums, which may
  * need any source row. */
+/* ordinary (pageable) arrays: an upload from them blocks the calling thread for its whole duration, and the download goes through the page-locked
+ * bounce buffers on the calling thread too -- so a second thread brings the source rows up, range by range, while the caller fetches the finished
+ * rows: the call costs about the download (1.9 ms at cfg2) instead of upload + download (2.6) */
+typedef struct { const float *src; float *d_dst; size_t row_floats; const int *need; int nchunk; int rows_up, fail, cancel; pthread_mutex_t m; pthread_cond_t cv; } hio_uploader;
+static void *hio_uploader_main(void *arg)
+{
+    hio_uploader *u = (hio_uploader *)arg;
+    int done = 0;
+    for (int k = 0; k < u->nchunk; k++) {
+        pthread_mutex_lock(&u->m); const int cancel = u->cancel; pthread_mutex_unlock(&u->m);
+        if (cancel) break;
+        int bad = 0;
+        if (u->need[k] > done) {
+            bad = ezhip_h2d_blocking_own_stream(u->d_dst + (size_t)done * u->row_floats, u->src + (size_t)done * u->row_floats, sizeof(float) * (size_t)(u->need[k] - done) * u->row_floats);
+            done = u->need[k];
+        }
+        pthread_mutex_lock(&u->m);
+        if (bad) u->fail = 1; else u->rows_up = done;
+        pthread_cond_broadcast(&u->cv);
+        pthread_mutex_unlock(&u->m);
+        if (bad) break;
+    }
+    ezhip_own_stream_release();
+    return NULL;
+}
 static int sepx_host_chunks(const ezh_sepplan *sp, ezhip_sep_plan p, float *d_zout, float *d_zin)
 {
     const int nchunk_env = getenv("EZHIP_HOST_CHUNKS") ? atoi(getenv("EZHIP_HOST_CHUNKS")) : 6;
     const int nseg = p.x_nseg, nid = p.ni_dst, njd = p.nj_dst, nis = p.ni_src, njs = p.nj_src, rows_per_vb = p.x_rows_per_step;
     int nchunk = nchunk_env < 1 ? 1 : (nchunk_env > nseg ? nseg : nchunk_env);
     unsigned char *copied = (unsigned char *)calloc((size_t)njd, 1);
-    if (!copied) return -1;
+    int *need_of = (int *)malloc(sizeof(int) * (size_t)nchunk);
+    if (!copied || !need_of) { free(copied); free(need_of); return -1; }
     int src_done = 0, rc = -1;
     const int pole_blocks = p.pole_blocks;
+    for (int k = 0; k < nchunk; k++) {       /* source rows the first k + 1 ranges need on the device */
+        const int s_lo = (int)((long long)nseg * k / nchunk), s_hi = (int)((long long)nseg * (k + 1) / nchunk);
+        const int v_lo = s_lo * p.x_rb, v_hi = imin(s_hi * p.x_rb, sp->h_nvb);
+        int need = k ? need_of[k - 1] : 0;
+        for (int i = v_lo; i < v_hi; i++) if (sp->h_vb_send[i] > need) need = sp->h_vb_send[i];
+        if (k == nchunk - 1 || need > njs) need = njs;
+        need_of[k] = need;
+    }
+    hio_uploader up;
+    pthread_t up_th;
+    int up_on = 0;
+    if (!t_hio.pinned) {
+        memset(&up, 0, sizeof(up));
+        up.src = t_hio.zin; up.d_dst = d_zin; up.row_floats = (size_t)nis; up.need = need_of; up.nchunk = nchunk;
+        pthread_mutex_init(&up.m, NULL); pthread_cond_init(&up.cv, NULL);
+        if (pthread_create(&up_th, NULL, hio_uploader_main, &up) != 0) { pthread_mutex_destroy(&up.m); pthread_cond_destroy(&up.cv); goto out; }
+        up_on = 1;
+    }
     for (int k = 0; k < nchunk; k++) {
         const int s_lo = (int)((long long)nseg * k / nchunk), s_hi = (int)((long long)nseg * (k + 1) / nchunk), last = k == nchunk - 1;
         const int v_lo = s_lo * p.x_rb, v_hi = imin(s_hi * p.x_rb, sp->h_nvb);
-        int need = 0;
-        for (int i = v_lo; i < v_hi; i++) if (sp->h_vb_send[i] > need) need = sp->h_vb_send[i];
-        if (last) need = njs;
-        if (need > njs) need = njs;
-        if (need > src_done) {
+        const int need = need_of[k];
+        if (up_on) {
+            pthread_mutex_lock(&up.m);
+            while (up.rows_up < need && !up.fail) pthread_cond_wait(&up.cv, &up.m);
+            const int failed = up.fail;
+            pthread_mutex_unlock(&up.m);
+            if (failed) goto out;
+        } else if (need > src_done) {
             if (ezhip_h2d(d_zin + (size_t)src_done * nis, t_hio.zin + (size_t)src_done * nis, sizeof(float) * (size_t)(need - src_done) * nis)) goto out;
             src_done = need;
         }
@@ -2132,7 +2179,13 @@ static int sepx_host_chunks(const ezh_sepplan *sp, ezhip_sep_plan p, float *d_zo
     t_hio.state = 3;
     rc = 0;
 out:
-    free(copied);
+    if (up_on) {
+        pthread_mutex_lock(&up.m); up.cancel = 1; pthread_mutex_unlock(&up.m);
+        pthread_join(up_th, NULL);
+        if (up.fail) rc = -1;
+        pthread_mutex_destroy(&up.m); pthread_cond_destroy(&up.cv);
+    }
+    free(copied); free(need_of);
     return rc;
 }
 
@@ -2306,7 +2359,7 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
          * never used on ordinary memory: many short device writes into one pageable array make the runtime lock / unlock overlapping page ranges
          * in quick succession, and the gpu test suite died there once in ten runs ("Write access to a read-only page") */
         const int chunked = t_hio.state == 1 && p.x_nseg > 1 && s->sep[di][vector_mode].h_nvb > 0 && !getenv("EZHIP_HOST_NO_CHUNKS") &&
-                            t_hio.pinned;
+                            (t_hio.pinned || getenv("EZHIP_HOST_UPLOADER"));
         if (!chunked && hio_full((float *)d_zin)) return -1;
         if (p.x_nseg > 0) {
             /* a lone field: the special rows go last in the work order (mid-order they hold slots while the pole

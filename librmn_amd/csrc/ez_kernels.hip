@@ -208,7 +208,9 @@ void pool_memcpy(void *dst, const void *src, size_t n)
     pthread_mutex_unlock(&g_pool.m);
     pthread_mutex_unlock(&g_pool.use);
 }
-thread_local struct { char *buf[2]; hipEvent_t ev[2]; bool ok; } t_bnc = {{nullptr, nullptr}, {nullptr, nullptr}, false};
+/* pend: the LAST chunk of the previous copy, still in its buffer: it is moved to the caller's array while the next copy's first chunk is on its way (a call
+ * that fetches a result in several row ranges keeps ONE pipeline going instead of draining it per range), at the latest by ezhip_sync */
+thread_local struct { char *buf[2]; hipEvent_t ev[2]; bool ok; int next; struct { char *h; size_t len; int b; bool on; } pend; } t_bnc = {{nullptr, nullptr}, {nullptr, nullptr}, false, 0, {nullptr, 0, 0, false}};
 bool bounce_ready()
 {
     if (t_bnc.ok) return true;
@@ -222,31 +224,53 @@ bool bounce_ready()
     return t_bnc.ok = true;
 }
 }
+static int bounce_finish()
+{
+    if (!t_bnc.pend.on) return 0;
+    t_bnc.pend.on = false;
+    if (set_err(hipEventSynchronize(t_bnc.ev[t_bnc.pend.b]), "d2h wait")) return -1;
+    pool_memcpy(t_bnc.pend.h, t_bnc.buf[t_bnc.pend.b], t_bnc.pend.len);
+    return 0;
+}
 extern "C" int ezhip_d2h(void *h, const void *d, size_t n)
 {
     if (n <= EZH_DIRECT_MAX || ezh_host_is_pinned(h, n) || !bounce_ready())
         return set_err(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream), "d2h");
-    size_t prev_off = 0, prev_len = 0;
-    int c = 0;
-    for (size_t off = 0; off < n; off += EZH_BOUNCE, c++) {
-        const int b = c & 1;
+    for (size_t off = 0; off < n; off += EZH_BOUNCE) {
+        const int b = t_bnc.next;
+        t_bnc.next ^= 1;
         const size_t len = n - off < EZH_BOUNCE ? n - off : EZH_BOUNCE;
+        if (t_bnc.pend.on && t_bnc.pend.b == b && bounce_finish()) return -1;        /* (cannot happen with two alternating buffers; kept for safety) */
         if (set_err(hipMemcpyAsync(t_bnc.buf[b], (const char *)d + off, len, hipMemcpyDeviceToHost, g_stream), "d2h") ||
             set_err(hipEventRecord(t_bnc.ev[b], g_stream), "d2h event")) return -1;
-        if (c >= 1) {
-            if (set_err(hipEventSynchronize(t_bnc.ev[b ^ 1]), "d2h wait")) return -1;
-            pool_memcpy((char *)h + prev_off, t_bnc.buf[b ^ 1], prev_len);
-        }
-        prev_off = off; prev_len = len;
+        if (bounce_finish()) return -1;                      /* the chunk before this one, of this copy or of the previous call, while this one is on its way */
+        t_bnc.pend.h = (char *)h + off; t_bnc.pend.len = len; t_bnc.pend.b = b; t_bnc.pend.on = true;
     }
-    if (set_err(hipEventSynchronize(t_bnc.ev[(c - 1) & 1]), "d2h wait")) return -1;
-    pool_memcpy((char *)h + prev_off, t_bnc.buf[(c - 1) & 1], prev_len);
-    return 0;
+    return 0;                                                /* the last chunk stays pending: ezhip_sync (every entry point ends with it) or the next copy moves it */
 }
+/* a blocking upload on a stream of the CALLING thread's own, for the host-pointer ABI's uploader thread (a hipMemcpy on the null stream would order itself
+ * against every blocking stream of the process): binds the thread to the library's device, creates the stream on first use; ezhip_own_stream_release
+ * before the thread ends */
+static thread_local hipStream_t t_up = nullptr;
+extern "C" int ezhip_h2d_blocking_own_stream(void *d, const void *h, size_t n)
+{
+    if (!t_up) {
+        const int dev = g_bound_dev.load(std::memory_order_acquire);
+        if (dev >= 0 && hipSetDevice(dev) != hipSuccess) return set_err(hipGetLastError(), "uploader thread: hipSetDevice");
+        if (hipStreamCreateWithFlags(&t_up, hipStreamNonBlocking) != hipSuccess) { t_up = nullptr; return set_err(hipGetLastError(), "uploader thread: stream"); }
+    }
+    if (set_err(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, t_up), "h2d (uploader thread)")) return -1;
+    return set_err(hipStreamSynchronize(t_up), "h2d (uploader thread)");
+}
+extern "C" void ezhip_own_stream_release(void) { if (t_up) { (void)hipStreamDestroy(t_up); t_up = nullptr; } }
 extern "C" int ezhip_d2h_pinned(void *h, const void *d, size_t n) { return set_err(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream), "d2h"); }   /* h: page-locked memory of the library */
 extern "C" int ezhip_d2d(void *dst, const void *src, size_t n) { return set_err(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, g_stream), "d2d"); }
 extern "C" int ezhip_memset(void *d, int v, size_t n) { return set_err(hipMemsetAsync(d, v, n, g_stream), "memset"); }
-extern "C" int ezhip_sync(void) { return set_err(hipStreamSynchronize(g_stream), "sync"); }
+extern "C" int ezhip_sync(void)
+{
+    const int bad = bounce_finish();                        /* a result chunk still in a bounce buffer reaches the caller's array here at the latest */
+    return set_err(hipStreamSynchronize(g_stream), "sync") || bad ? -1 : 0;
+}
 extern "C" void ezhip_set_stream(void *s) { g_stream = (hipStream_t)s; }
 extern "C" void *ezhip_get_stream(void) { return (void *)g_stream; }
 

@@ -24,6 +24,8 @@ void   ezhip_free(void *d);
 int    ezhip_h2d(void *d, const void *h, size_t nbytes);     /* async on the current stream */
 int    ezhip_d2h(void *h, const void *d, size_t nbytes);     /* async on the current stream */
 int    ezhip_d2d(void *dst, const void *src, size_t nbytes);
+int    ezhip_h2d_blocking_own_stream(void *d, const void *h, size_t nbytes);   /* blocking, on a stream of the calling thread's own (uploader thread of the host-pointer ABI) */
+void   ezhip_own_stream_release(void);
 int    ezhip_d2h_pinned(void *h, const void *d, size_t nbytes);   /* into page-locked memory of the library: plain asynchronous copy */
 void   ezhip_touch_writable(void *h, size_t nbytes);     /* the CPU writes every page of a host range onto itself before the device writes it */
 int    ezhip_memset(void *d, int v, size_t nbytes);
