@@ -805,7 +805,7 @@ static int32_t cfg5_batch(void *d_records, int64_t record_stride_words, const fl
     const size_t wb1 = packhip_armn_enc1_work_bytes(ni_out, nj_out, nbits, sub);
     if (!wb1) return -2;
     const size_t wb = (wb1 + 64 + 255) & ~(size_t)255;
-    const size_t tok_stride = (n + 1) / 2 + 4;                                  /* words per field */
+    const size_t tok_stride = ((n + 1) / 2 + 4 + 3) & ~(size_t)3;               /* words per field, a multiple of 4: the one-pass encoder stages every field's tokens in aligned 16-byte pieces */
     const size_t stride = PACKHIP_STATS_PARTIALS + 3 * (size_t)8192;
     unsigned *d_stats_all = (unsigned *)ws(3, (4 * stride + sizeof(packhip_cf_params)) * (size_t)nfields + 64);
     /* MEASURED (MI355X, 32 cfg5 fields, profiles/r03_experiments.txt): the one-launch form moves half the bytes (tokens never reach HBM) and takes TWICE the

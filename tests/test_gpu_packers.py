@@ -1,6 +1,7 @@
 """GPU parity tests of the packers: HIP path (through the C ABI) vs the CPU oracle, BIT-EXACT
 (every packed word, header words, return values)."""
 import ctypes
+import os
 import numpy as np
 import pytest
 
@@ -406,6 +407,61 @@ def test_fused_cfg5_pipeline_equals_unfused(degree, F):
         got = rec_a[0].cpu().numpy().view(np.uint32)
         assert np.array_equal(got[:4 + (zw - 1) // 4], want[:4 + (zw - 1) // 4])
     assert ez.ezsetopt("interp_degree", "cubic") == 0
+
+
+SEPENC_SHAPES = [
+    # target ni x nj of an L grid inside a G 360 x 181 source: strips of 255 columns (85 tiles), row groups of 15 rows (5 tile rows)
+    (520, 261, "three strips, the last with 3 tiles; (nj - 1) % 3 == 2"),
+    (512, 256, "(ni - 1) % 3 == 1: the last tile column holds one column; (nj - 1) % 3 == 0"),
+    (766, 122, "ni - 1 = 3 x 255: exactly three full strips; the last tile row holds one row"),
+    (768, 47, "one tile past three strips: a fourth strip of one clipped tile; the last row group holds one tile row"),
+    (256, 16, "the smallest shape the one-launch form takes: one strip, one row group"),
+    (1022, 333, "five strips, 23 row groups, both edges ragged"),
+]
+
+
+@pytest.mark.parametrize("no,mo,what", SEPENC_SHAPES, ids=[f"{a}x{b}" for a, b, _ in SEPENC_SHAPES])
+@pytest.mark.parametrize("degree", ["cubic", "linear"])
+def test_cfg5_one_launch_form_equals_the_two_kernels(no, mo, what, degree):
+    """EZHIP_CFG5_FUSED=1: interpolation, quantisation and armn_compress in ONE launch (k_sepx_enc: the tokens never reach HBM) against the
+    default two kernels (k_sepx<.., tokens> + k_armn_enc1) -- records and byte counts bit for bit, over shapes that put the strip / row-group /
+    tile edges everywhere; one field of noise (not compressible: the one-launch form hands it back to the two-kernel path), one constant"""
+    from librmn_amd import ezscint as ez
+    import ezcases as ec
+    nbits, F = 16, 4
+    ni, nj = max(64, int(no * 0.7) // 2 * 2), max(24, int(mo * 0.7) // 2 * 2)             # a finer target, as in cfg5 (a strip of 256 target columns fits the staged window)
+    gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0)
+    gdout = ez.ezqkdef(no, mo, "L", max(1, 17000 // mo), max(1, 35900 // no), 0, 0)         # the whole globe, whatever the size
+    assert ez.ezdefset(gdout, gdin) == 1
+    assert ez.ezsetopt("interp_degree", degree) == 0 and ez.ezsetopt("polar_correction", "yes") == 0
+    ez.use_stream(torch.cuda.current_stream().cuda_stream)
+    srcs = [ec.synth_field(ni, nj, seed=300 + f) for f in range(F)]
+    srcs[1] = (ec.hash_uniform(7, ni * nj) * np.float32(1000.0)).astype(np.float32)
+    srcs[2] = np.full(ni * nj, 3.25, np.float32)
+    d_in = torch.stack([torch.from_numpy(a) for a in srcs]).cuda().contiguous()
+    n = no * mo
+    rs = 4 + n // 2 + 16
+    out = {}
+    try:
+        for fused in ("0", "1"):
+            os.environ.pop("EZHIP_CFG5_FUSED", None)
+            if fused == "1": os.environ["EZHIP_CFG5_FUSED"] = "1"
+            rec = torch.full((F, rs), 0x22222222, dtype=torch.int32, device="cuda")
+            rc, zl = pk.ezsint_pack16_compress_batch_dev(rec, rs, d_in, F, no, mo, nbits)
+            if rc == -2:
+                pytest.skip("grid pair not on the single-launch k_sepx path")
+            assert rc == 0, (fused, rc)
+            out[fused] = (list(zl), rec.cpu().numpy().view(np.uint8).reshape(F, -1))
+    finally:
+        os.environ.pop("EZHIP_CFG5_FUSED", None)
+        ez.ezsetopt("interp_degree", "cubic")
+    assert out["0"][0] == out["1"][0], (what, out["0"][0], out["1"][0])
+    for f in range(F):
+        zl = out["0"][0][f]
+        m = 16 + (int(zl) - 1 if zl > 0 else 2 * n)
+        a, b = out["0"][1][f, :m], out["1"][1][f, :m]
+        assert np.array_equal(a, b), (what, f, int(zl), np.nonzero(a != b)[0][:5])
+    assert out["0"][0][0] > 0                                                                  # the smooth field did compress
 
 
 def test_fused_cfg5_pipeline_full_size():
