@@ -1810,7 +1810,9 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
         int wmax = 1, nmax = 1;
         for (int bx = 0; bx < nbx; bx++) if (blk_w[bx] > wmax) wmax = blk_w[bx];
         for (int by = 0; by < nby; by++) if (brow_n[by] > nmax) nmax = brow_n[by];
-        wmax = 64 * ((wmax + 63) / 64);      /* k_sepx stages rows with LDS-DMA in whole 64-float chunks */
+        /* k_sepx stages rows with LDS-DMA: 16 bytes per lane (rows of 4-float pieces) or, for a window that wraps at the seam, 64 dwords per instruction with the
+         * lanes past the row's end masked.  EZHIP_SEPX_WSTRIDE64: the round-2 layout (rows padded to whole 64-float chunks) */
+        wmax = getenv("EZHIP_SEPX_WSTRIDE64") ? 64 * ((wmax + 63) / 64) : 4 * ((wmax + 3) / 4);
         p->wstride = wmax; p->patch_elems = wmax * nmax;
         p->nblk_y = nby;
     }

@@ -1067,7 +1067,7 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
             } else {
 #pragma unroll
                 for (int q = 0; q < SEP_QCH; q++)
-                    if (64 * q < W) lds_dma_dword(zr, coloff[q], lds_addr_of(prow + 64 * q));
+                    if (64 * q < W && lane + 64 * q < wstr) lds_dma_dword(zr, coloff[q], lds_addr_of(prow + 64 * q));
             }
         }
         /* the XR row records of step i: 16 XR dwords, one 64-dword chunk per wave */
@@ -1321,7 +1321,7 @@ void k_sepx_enc(ezhip_sep_plan p, ezhip_sepenc_args a)
             else {
 #pragma unroll
                 for (int q = 0; q < SEP_QCH; q++)
-                    if (64 * q < W) lds_dma_dword(zr, coloff[q], lds_addr_of(prow + 64 * q));
+                    if (64 * q < W && lane + 64 * q < wstr) lds_dma_dword(zr, coloff[q], lds_addr_of(prow + 64 * q));
             }
         }
         lds_dma_dword((const float *)(p.e_rows + (size_t)rg * 16), (unsigned)(threadIdx.x * 4), lds_addr_of(rec + wv * 64));      /* 16 records of 16 dwords */
