@@ -1083,7 +1083,7 @@ __device__ __forceinline__ EncChunk enc1_chunk(const enc1_args &a, unsigned g)
 #define ENC_WK 1                        /* look-back: granules per lane and window */
 #define ENC_NLD 7                       /* 16-byte pieces a lane stages up front: rows of up to 448 pieces (chunks of up to 1024 tiles) */
 template <bool SWAPPED>
-__global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_armn_enc1(enc1_args a)
+__device__ __forceinline__ void armn_enc1_body(const enc1_args &a)
 {
     extern __shared__ unsigned lds[];                      /* token patch, then (aliased) the chunk's stream image */
     __shared__ unsigned s_wsum[ENC_TPT][ENC_TPB / 64], s_gt, s_abort, s_gt_all;
@@ -1412,6 +1412,10 @@ __global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8)))
     }
 #undef STAMP
 }
+/* seven waves per SIMD (65 VGPRs, nothing spilled).  Eight (64 VGPRs, four of them spilled to scratch, the 19.3 KB of LDS of a cfg5 chunk allow it) was measured
+ * slower: 1475 against 1439 us per 32 cfg5 fields (profiles/r03_experiments.txt) */
+template <bool SWAPPED>
+__global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_armn_enc1(enc1_args a) { armn_enc1_body<SWAPPED>(a); }
 
 static unsigned long long *g_enc1_prof = nullptr;
 /* development: phase clock sums of the last profiled launch (EZHIP_ENC_DEBUG & 16) -> out[8] */
