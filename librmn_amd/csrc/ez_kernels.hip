@@ -246,7 +246,10 @@ extern "C" int ezhip_d2h(void *h, const void *d, size_t n)
         if (bounce_finish()) return -1;                      /* the chunk before this one, of this copy or of the previous call, while this one is on its way */
         t_bnc.pend.h = (char *)h + off; t_bnc.pend.len = len; t_bnc.pend.b = b; t_bnc.pend.on = true;
     }
-    return 0;                                                /* the last chunk stays pending: ezhip_sync (every entry point ends with it) or the next copy moves it */
+    /* the last chunk: moved out now, or -- row ranges fetched one after the other (EZHIP_HOST_UPLOADER) -- left pending for the next copy's first chunk to
+     * overlap with; ezhip_sync drains it at the latest */
+    static const bool keep = getenv("EZHIP_HOST_UPLOADER") != nullptr;
+    return keep ? 0 : bounce_finish();
 }
 /* a blocking upload on a stream of the CALLING thread's own, for the host-pointer ABI's uploader thread (a hipMemcpy on the null stream would order itself
  * against every blocking stream of the process): binds the thread to the library's device, creates the stream on first use; ezhip_own_stream_release
