@@ -62,6 +62,7 @@ typedef struct ezh_set {
     float *d_poles_batch; int poles_cap;   /* pole values of a c_ezsint_batch_dev batch (2 per field) */
     float *d_prow;          /* 2 * ni_src synthetic polar wind rows (vector mode), u then v: [u_n, u_s, v_n, v_s] */
     float *d_avg[2];        /* interp_degree = average / sph_average: [x | row widening | y_low | y_high] of the target cells (ez_avg.inc:55-78, ez_avg_sph.inc:63-98) */
+    float *d_lamb_cs[2];    /* c_ezuvint from / towards a Lambert '!' grid: {cos, sin} of its rotation angle at the target points' longitudes (source leg, target leg) */
     void *d_windM;          /* c_ezuvint through a rotated frame: the wind chain of this grid pair as a 2 x 2 matrix per target point (built on first use) */
     /* Yin-Yang 'U' source (c_ezyy_calcxy, ezyy_calcxy.c): per subgrid the list of target points it serves */
     int yy_ready, yy_count[2];
@@ -548,6 +549,40 @@ static void h_llflamb(const ezh_grid *g, float *lat, float *lon, float *x, float
     h_lambllfxy99(lat, lon, x, y, n, xg[5], xg[6], yaxislat, yaxislon);
 }
 
+static void *upload(const void *h, size_t nbytes);
+/* winds on a '!' grid (ez_lamb_llwfgdw.inc:41-56, ez_lamb_gdwfllw.inc:41-56): the grid is turned against true north by the angle of the meridian through
+ * the point -- the direction from (45 N, lon) to (50 N, lon) in grid coordinates; to_wd: alpha = pi / 2 - atan2(dely, delx) (grid -> true components), else
+ * atan2(dely, delx) - pi / 2 (true -> grid).  cs[2 i] = cos(alpha_i), cs[2 i + 1] = sin(alpha_i), all REAL as in the reference */
+static int h_lamb_wind_cs(const ezh_grid *g, const float *lon, int n, int to_wd, float *cs)
+{
+    const float pie = 3.1415926535898f;
+    float *w = (float *)calloc(5 * (size_t)(n > 0 ? n : 1), sizeof(float));
+    if (!w) return -1;
+    float *la = w, *x1 = w + n, *y1 = w + 2 * (size_t)n, *x2 = w + 3 * (size_t)n, *y2 = w + 4 * (size_t)n;
+    for (int i = 0; i < n; i++) la[i] = 45.0f;
+    h_lambfll(g, x1, y1, la, lon, n);
+    for (int i = 0; i < n; i++) la[i] = 50.0f;
+    h_lambfll(g, x2, y2, la, lon, n);
+    for (int i = 0; i < n; i++) {
+        const float delx = x2[i] - x1[i], dely = y2[i] - y1[i];
+        const float alpha = to_wd ? pie * 0.50f - atan2f(dely, delx) : atan2f(dely, delx) - 0.5f * pie;
+        cs[2 * i] = cosf(alpha); cs[2 * i + 1] = sinf(alpha);
+    }
+    free(w);
+    return 0;
+}
+/* the same as a device array (NULL on failure) */
+static float *lamb_wind_cs_dev(const ezh_grid *g, const float *lon, int n, int to_wd)
+{
+    float *cs = (float *)malloc(sizeof(float) * 2 * (size_t)(n > 0 ? n : 1));
+    if (!cs) return NULL;
+    if (h_lamb_wind_cs(g, lon, n, to_wd, cs)) { free(cs); return NULL; }
+    float *d = (float *)upload(cs, sizeof(float) * 2 * (size_t)(n > 0 ? n : 1));
+    ezhip_sync();
+    free(cs);
+    return d;
+}
+
 static __thread int t_locate_j2;       /* 1 inside c_gdxyfll_orig: the search length of gdxyfll.c (see the 'G' / 'Z' branch) */
 static int h_locate(const ezh_grid *g, float *x, float *y, const float *lat, float *lon, int n)
 {
@@ -773,7 +808,7 @@ static void free_set(ezh_set *s)
 {
     for (int d = 0; d < 3; d++) for (int v = 0; v < 2; v++) free_sepplan(&s->sep[d][v]);
     free(s->x1d); free(s->y1d);
-    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
+    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_lamb_cs[0]); ezhip_free(s->d_lamb_cs[1]); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
     for (int k = 0; k < 2; k++) { ezhip_free(s->d_yy_x[k]); ezhip_free(s->d_yy_y[k]); ezhip_free(s->d_yy_lat[k]); ezhip_free(s->d_yy_lon[k]); ezhip_free(s->d_yy_idx[k]); }
     for (int k = 0; k < 4; k++) ezhip_free(s->d_yy_tmp[k]);
     free(s);
@@ -3052,10 +3087,6 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
         fprintf(stderr, "<c_ezuvint> '%c' target grids are outside the MI355X hot-path scope for winds\n", go->grtyp);
         return -1;
     }
-    if (gi->grtyp == '!' || go->grtyp == '!') {             /* ez_lamb_llwfgdw / ez_lamb_gdwfllw: scalars and coordinates only so far */
-        fprintf(stderr, "<c_ezuvint> winds on Lambert '!' grids are outside the MI355X hot-path scope (scalars and coordinates are supported)\n");
-        return -1;
-    }
     int ni = gi->ni, nj = gi->nj, polar = O.polar_correction == 1;
     /* one grid on both sides: the two c_ezsint calls of c_ezuvint_orig (ezuvint.c:68-71) copy their fields (ezsint.c: identical grids, return 1) and
      * never define the set's zones, so ez_corrvec finds none; the wind chain still runs on the copies (ierc stays 0) */
@@ -3134,6 +3165,20 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
     if (go->grtyp == 'Z' && go->grref == 'E') { float ri_[9]; wp.dst_rotated = 1; h_crot(wp.r_dst, ri_, go->xgref[1], go->xgref[0], go->xgref[3], go->xgref[2]); }
     if (wp.src_rotated) { const float *xg = gi->grtyp == 'E' ? gi->xg : gi->xgref; h_crot(wp.r, wp.ri, xg[1], xg[0], xg[3], xg[2]); }
     else if (gi->grtyp == 'Z' && gi->grref != 'L') return -1;
+    if (gi->grtyp == '!' || go->grtyp == '!') {
+        /* Lambert legs (gdwdfuv.c default branch -> ez_llwfgdw '!' -> ez_lamb_llwfgdw; gduvfwd.c -> ez_gdwfllw '!' -> ez_lamb_gdwfllw): a rotation per point whose
+         * angle depends on the point's longitude only; {cos, sin} from the host's REAL chain, once per set */
+        const float *lon_h = go->separable ? go->lon1d : go->lon2d;
+        const int nl = go->separable ? go->ni : go->ni * go->nj;
+        pthread_mutex_lock(&g_plan_mtx);
+        if (gi->grtyp == '!' && !s->d_lamb_cs[0]) s->d_lamb_cs[0] = lamb_wind_cs_dev(gi, lon_h, nl, 1);
+        if (go->grtyp == '!' && !s->d_lamb_cs[1]) s->d_lamb_cs[1] = lamb_wind_cs_dev(go, lon_h, nl, 0);
+        const int bad = (gi->grtyp == '!' && !s->d_lamb_cs[0]) || (go->grtyp == '!' && !s->d_lamb_cs[1]);
+        pthread_mutex_unlock(&g_plan_mtx);
+        if (bad) return -1;
+        if (gi->grtyp == '!') wp.src_lamb_cs = s->d_lamb_cs[0];
+        if (go->grtyp == '!') wp.dst_lamb_cs = s->d_lamb_cs[1];
+    }
     if (wp.src_rotated && wp.separable) {
         if (!go->d_windtrig) {
             size_t nt = 2 * ((size_t)go->ni + go->nj);               /* doubles, then the same count of floats */
@@ -3392,7 +3437,7 @@ static int wind_conv_dev(int32_t gdid, float *d_a, float *d_b, const float *d_la
     if (!grid_ok(gdid)) return -1;
     if (need_device(to_wd ? "c_gdwdfuv" : "c_gduvfwd")) return -1;
     ezh_grid *g = &G[gdid];
-    if (g->nsub > 0 || g->grtyp == 'Y' || g->grtyp == '!') { fprintf(stderr, "<%s> '%c' grids are outside the MI355X hot-path scope here\n", to_wd ? "c_gdwdfuv" : "c_gduvfwd", g->grtyp); return -1; }
+    if (g->nsub > 0 || g->grtyp == 'Y') { fprintf(stderr, "<%s> '%c' grids are outside the MI355X hot-path scope here\n", to_wd ? "c_gdwdfuv" : "c_gduvfwd", g->grtyp); return -1; }
     int rotated = g->grtyp == 'E' || (g->grtyp == 'Z' && g->grref == 'E');
     ezhip_wind_plan wp;
     memset(&wp, 0, sizeof(wp));
@@ -3407,7 +3452,19 @@ static int wind_conv_dev(int32_t gdid, float *d_a, float *d_b, const float *d_la
         if (g->grtyp == 'N' || g->grtyp == 'S') { wp.dst_ps = g->grtyp == 'N' ? 1 : 2; wp.dst_xg4 = g->xg[3]; }
     }
     if (npts <= 0) return 0;
-    return ezhip_wind_rotate(&wp, d_a, d_b, d_lat, d_lon, npts, 1) ? -1 : 0;
+    float *d_cs = NULL;
+    if (g->grtyp == '!') {                                  /* the rotation angles of the caller's longitudes: host (REAL libm chain of ez_lambxyfll99), then back */
+        float *lon_h = (float *)malloc(sizeof(float) * (size_t)npts);
+        if (!lon_h) return -1;
+        if (ezhip_d2h(lon_h, d_lon, sizeof(float) * (size_t)npts) || ezhip_sync()) { free(lon_h); return -1; }
+        d_cs = lamb_wind_cs_dev(g, lon_h, npts, to_wd);
+        free(lon_h);
+        if (!d_cs) return -1;
+        if (to_wd) wp.src_lamb_cs = d_cs; else wp.dst_lamb_cs = d_cs;
+    }
+    int rc = ezhip_wind_rotate(&wp, d_a, d_b, d_lat, d_lon, npts, 1) ? -1 : 0;
+    if (d_cs) { ezhip_sync(); ezhip_free(d_cs); }
+    return rc;
 }
 int32_t c_gdwdfuv_dev(int32_t gdid, float *d_spd, float *d_wd, const float *d_uu, const float *d_vv, const float *d_lat, const float *d_lon, int32_t npts)
 {

@@ -3119,11 +3119,13 @@ __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *_
     if (p.separable) { lat = lats[n / ni_dst]; lon = lons[n % ni_dst]; }
     else { lat = lats[n]; lon = lons[n]; }
     float u = uu[n], v = vv[n];
+    const size_t li = p.separable ? n % (size_t)ni_dst : n;         /* index of the point's longitude */
     if (p.wd_in) {                                          /* speed / direction given: c_gduvfwd only */
         const float spd_ = u, dir_ = v;
         float psi_ = p.dst_ps == 1 ? lon + p.dst_xg4 - dir_ : p.dst_ps == 2 ? 180.0f - lon + p.dst_xg4 - dir_ : 270.0f - dir_;
         float uo = cosf(psi_ * DGTORD) * spd_, vo = sinf(psi_ * DGTORD) * spd_;
         if (p.dst_rotated) d_to_rotated_target(p.r_dst, lon, lat, uo, vo);
+        if (p.dst_lamb_cs) { const float c_ = p.dst_lamb_cs[2 * li], s_ = p.dst_lamb_cs[2 * li + 1], a_ = uo, b_ = vo; uo = a_ * c_ - b_ * s_; vo = a_ * s_ + b_ * c_; }      /* ez_lamb_gdwfllw.inc:52-56 */
         uu[n] = uo; vv[n] = vo;
         return;
     }
@@ -3162,6 +3164,10 @@ __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *_
         double sg = ((double)q[2] * ee) - (cc * ff);
         v = (float)(sg >= 0.0 ? fabs(dd) : -fabs(dd));
     }
+    if (p.src_lamb_cs) {                                    /* ez_lamb_llwfgdw.inc:51-56: grid components -> true east / north components, then as 'L' (:58-75) */
+        const float c_ = p.src_lamb_cs[2 * li], s_ = p.src_lamb_cs[2 * li + 1], a_ = u, b_ = v;
+        u = a_ * c_ - b_ * s_; v = a_ * s_ + b_ * c_;
+    }
     /* components -> speed, direction: ez_llwfgdw.inc:91-114 ('N'), :117-140 ('S'), :143-165 ('L'/A/B/G) */
     float spd = sqrtf(u * u + v * v), dir;
     if (spd == 0.0f) dir = 0.0f;
@@ -3175,6 +3181,7 @@ __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *_
     float psi = p.dst_ps == 1 ? lon + p.dst_xg4 - dir : p.dst_ps == 2 ? 180.0f - lon + p.dst_xg4 - dir : 270.0f - dir;
     float uo = cosf(psi * DGTORD) * spd, vo = sinf(psi * DGTORD) * spd;
     if (p.dst_rotated) d_to_rotated_target(p.r_dst, lon, lat, uo, vo);      /* Z-on-E target: c_ezgfwfllw */
+    if (p.dst_lamb_cs) { const float c_ = p.dst_lamb_cs[2 * li], s_ = p.dst_lamb_cs[2 * li + 1], a_ = uo, b_ = vo; uo = a_ * c_ - b_ * s_; vo = a_ * s_ + b_ * c_; }          /* '!' target: ez_lamb_gdwfllw.inc:52-56 */
     uu[n] = uo; vv[n] = vo;
 }
 

@@ -286,6 +286,9 @@ typedef struct {
     int dst_rotated; float r_dst[9];  /* Z-on-E TARGET: c_ezgfwfllw (ez_gfwfllw.c:38-79) with its rotation matrix r */
     const double *lon_trig, *lat_trig;   /* separable + rotated source: {cos, sin} per target column / row (ezhip_wind_trig_tables), or NULL */
     const float *lon_trigf, *lat_trigf;  /* the REAL {cos, sin} pairs of the same angles (rotation into the source frame) */
+    /* Lambert '!' source / target (ez_lamb_llwfgdw.inc, ez_lamb_gdwfllw.inc): {cos, sin} of the grid's rotation angle at the point's longitude, from the host
+     * (the angle comes from two projections of the reference's REAL libm chain); one pair per target column when `separable`, else per point */
+    const float *src_lamb_cs, *dst_lamb_cs;
 } ezhip_wind_plan;
 int ezhip_wind_trig_tables(double *d_lon_trig, double *d_lat_trig, float *d_lon_trigf, float *d_lat_trigf,
                            const float *d_lat, const float *d_lon, int ni, int nj);

@@ -132,3 +132,122 @@ def test_lambert_scalar_interpolation_is_the_pointwise_one(degree):
         assert outside.any() and (out2[outside] == np.float32(-99.0)).all()
     finally:
         ez.ezsetopt("interp_degree", "cubic"); ez.ezsetopt("extrap_degree", "maximum")
+
+
+# ---------------------------------------------------------------------------------------------
+# winds on '!' grids: ez_lamb_llwfgdw.inc (c_gdwdfuv), ez_lamb_gdwfllw.inc (c_gduvfwd), c_ezuvint
+# ---------------------------------------------------------------------------------------------
+def _np_lamb_alpha(code, lon, to_wd):
+    """the grid's rotation angle at a longitude, REAL: the direction (45 N, lon) -> (50 N, lon) in grid coordinates from the reference's own projection routine"""
+    f32 = np.float32
+    lat11, lon11, dx, dy, yaxislon, latin1, latin2, yaxislat, ni, nj = _params(code)
+    x11, y11 = _ref_xyfll(np.array([lat11]), np.array([lon11]), latin1, latin2, yaxislat, yaxislon)
+    xy = []
+    for la in (45.0, 50.0):
+        xr, yr = _ref_xyfll(np.full(lon.size, la, f32), lon, latin1, latin2, yaxislat, yaxislon)
+        xy.append(((f32(1.0) + (xr - x11[0]) / dx).astype(f32), (f32(1.0) + (yr - y11[0]) / dy).astype(f32)))
+    delx = (xy[1][0] - xy[0][0]).astype(f32); dely = (xy[1][1] - xy[0][1]).astype(f32)
+    pie = f32(3.1415926535898)
+    at = np.arctan2(dely, delx).astype(f32)
+    return (pie * f32(0.5) - at).astype(f32) if to_wd else (at - f32(0.5) * pie).astype(f32)
+
+
+def _np_llwfgdw(code, u, v, lon):
+    """ez_lamb_llwfgdw.inc:41-80 in REAL"""
+    f32 = np.float32
+    a = _np_lamb_alpha(code, lon, True)
+    c, s = np.cos(a).astype(f32), np.sin(a).astype(f32)
+    z1 = (u * c - v * s).astype(f32); z2 = (u * s + v * c).astype(f32)
+    spd = np.sqrt((z1 * z1 + z2 * z2).astype(f32)).astype(f32)
+    with np.errstate(invalid="ignore"):
+        d = (f32(270.0) - f32(57.295779513082) * np.arctan2(z2, z1).astype(f32)).astype(f32)
+    d = np.where(z1 == 0, np.where(z2 >= 0, f32(180.0), f32(0.0)), d)
+    d = np.where(spd == 0, f32(0.0), d).astype(f32)
+    d = np.fmod(np.fmod(d, f32(360.0)) + f32(360.0), f32(360.0)).astype(f32)
+    return spd, d
+
+
+def _np_gdwfllw(code, spd, wd, lon):
+    """ez_lamb_gdwfllw.inc:41-57 in REAL"""
+    f32 = np.float32
+    a = _np_lamb_alpha(code, lon, False)
+    psi = (f32(270.0) - wd).astype(f32)
+    uuu = (np.cos((psi * f32(1.7453292519943e-2)).astype(f32)).astype(f32) * spd).astype(f32)
+    vvv = (np.sin((psi * f32(1.7453292519943e-2)).astype(f32)).astype(f32) * spd).astype(f32)
+    c, s = np.cos(a).astype(f32), np.sin(a).astype(f32)
+    return (uuu * c - vvv * s).astype(f32), (uuu * s + vvv * c).astype(f32)
+
+
+def _ang_diff(a, b):
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64)) % 360.0
+    return np.minimum(d, 360.0 - d)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not reflib.have_ref(), reason="oracle/_ref/libezref.so not built")
+@pytest.mark.parametrize("code", [211, 901, 902])
+def test_lambert_wind_conversions(code):
+    """c_gdwdfuv / c_gduvfwd on a '!' grid against ez_lamb_llwfgdw / ez_lamb_gdwfllw restated on the reference's own projection routine; winds to 1e-5 |V|
+    (the REAL sines and cosines of numpy, glibc and the device differ in the last place), directions to 1e-3 degrees"""
+    t = TABLE[code]
+    gd = ez.ezqkdef(t[7], t[8], "!", code, 0, 0, 0)
+    assert gd >= 0
+    rng = np.random.default_rng(code + 1)
+    n = 20000
+    lat = rng.uniform(-80, 80, n).astype(np.float32); lon = rng.uniform(0, 360, n).astype(np.float32)
+    u = rng.normal(0, 12, n).astype(np.float32); v = rng.normal(0, 12, n).astype(np.float32)
+    u[:50] = 0.0; v[25:75] = 0.0                                   # the uu == 0 and calm branches
+    rc, spd, wd = ez.gdwdfuv(gd, u, v, lat, lon)
+    assert rc >= 0
+    wspd, wwd = _np_llwfgdw(code, u, v, lon)
+    vmax = float(np.abs(wspd).max())
+    assert np.abs(spd - wspd).max() <= 1e-5 * vmax, np.abs(spd - wspd).max()
+    moving = wspd > 1e-3 * vmax
+    assert _ang_diff(wd[moving], wwd[moving]).max() < 1e-3, _ang_diff(wd[moving], wwd[moving]).max()
+    assert (spd[25:50] == 0).all() and (wd[25:50] == 0).all()     # calm: speed 0, direction 0 (:62-63)
+    # and back (the angles of the two directions are opposite: the round trip closes)
+    rc, u2, v2 = ez.gduvfwd(gd, spd, wd, lat, lon)
+    assert rc >= 0
+    wu, wv = _np_gdwfllw(code, spd, wd, lon)
+    assert np.abs(u2 - wu).max() <= 1e-5 * vmax and np.abs(v2 - wv).max() <= 1e-5 * vmax, (np.abs(u2 - wu).max(), np.abs(v2 - wv).max())
+    assert np.abs(u2 - u).max() <= 2e-4 * vmax and np.abs(v2 - v).max() <= 2e-4 * vmax
+    # a wind along the grid's y axis at the cone's central meridian blows from the south: direction 180
+    la0 = np.array([40.0], np.float32); lo0 = np.array([np.float32(t[4]) % np.float32(360.0)], np.float32)
+    rc, s0, d0 = ez.gdwdfuv(gd, np.zeros(1, np.float32), np.full(1, 5.0, np.float32), la0, lo0)
+    assert abs(float(s0[0]) - 5.0) < 1e-5 and _ang_diff(d0, np.array([180.0]))[0] < 1e-2, (s0, d0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("degree", ["cubic", "linear"])
+def test_lambert_uvint_is_interpolation_then_the_two_wind_legs(degree):
+    """c_ezuvint from / towards a '!' grid (ezuvint.c:51-94): both components interpolated as scalars, c_gdwdfuv on the source grid and c_gduvfwd on the target
+    grid at the target's points.  The legs are pinned by the test above, the scalars by test_lambert_scalar_interpolation_is_the_pointwise_one"""
+    import ezcases as ec
+    assert ez.ezsetopt("interp_degree", degree) == 0
+    try:
+        gl = ez.ezqkdef(120, 90, "!", 901, 0, 0, 0)
+        gt = ez.ezqkdef(100, 60, "L", 20, 20, 12400, 25600)           # 0.2 degrees from 34 N, 256 E: inside the cone grid (outside it a VECTOR component is filled with 0, ez_corrval.c)
+        gg = ez.ezqkdef(360, 181, "G", 0, 0, 0, 0)
+        for gsrc, gdst, ns, nd in ((gl, gt, 120 * 90, 100 * 60), (gg, gl, 360 * 181, 120 * 90)):
+            nis, njs = (120, 90) if gsrc == gl else (360, 181)
+            u = ec.synth_field(nis, njs, seed=21) - np.float32(250.0); v = ec.synth_field(nis, njs, seed=22) - np.float32(250.0)
+            assert ez.ezdefset(gdst, gsrc) == 1
+            rc, uo, vo = ez.ezuvint(u, v, nd)
+            assert rc >= 0, rc
+            rc, us = ez.ezsint(u, nd); rc, vs = ez.ezsint(v, nd)
+            rc, tlat, tlon = ez.gdll(gdst, nd)
+            if gsrc == gl:
+                rc, x, y = ez.gdxyfll(gl, tlat, tlon)
+                assert x.min() >= 2 and x.max() <= 119 and y.min() >= 2 and y.max() <= 89, (x.min(), x.max(), y.min(), y.max())
+            rc, spd, wd = ez.gdwdfuv(gsrc, us, vs, tlat, tlon)
+            assert rc >= 0
+            rc, wu, wv = ez.gduvfwd(gdst, spd, wd, tlat, tlon)
+            assert rc >= 0
+            vmax = float(np.abs(spd).max())
+            assert np.abs(uo - wu).max() <= 1e-5 * vmax and np.abs(vo - wv).max() <= 1e-5 * vmax, (np.abs(uo - wu).max(), np.abs(vo - wv).max(), vmax)
+            # the rotation is not the identity on this pair (the test would pass trivially otherwise)
+            assert np.abs(uo - us).max() > 1e-2 * vmax
+            rc, so, do = ez.ezwdint(u, v, nd)
+            assert rc >= 0 and np.abs(so - spd).max() <= 1e-5 * vmax
+    finally:
+        ez.ezsetopt("interp_degree", "cubic")
