@@ -20,12 +20,17 @@ def test_random_grid_pairs_against_the_reference_build(tool, ncases, seed):
     env = dict(os.environ)
     if tool.endswith(" hemi"): tool = tool.split()[0]; env["FUZZ_HEMI"] = "1"          # + hemispheric / y-inverted A B G on either side
     # The reference build corrupts its own heap now and then in a long session ("double free or corruption", "malloc(): corrupted top size", with no
-    # product call on the stack -- tools/fuzz_vs_ref4.py): a run that a SIGNAL ended before any mismatch was printed proves nothing either
-    # way and is repeated with another seed; three such deaths in a row fail the test.
+    # product call on the stack -- tools/fuzz_vs_ref4.py): a run that a SIGNAL ended before any mismatch was printed proves nothing about
+    # parity.  Whose crash it was is settled by running the SAME seed again with the reference's entry points replaced by no-ops (FUZZ_PRODUCT_ONLY,
+    # tests/reflib.py): the product then makes exactly the same calls alone.  If that run dies too, the product crashed: the test fails at once.  If it
+    # survives, the death was the reference's: the comparison is repeated with another seed; three such deaths in a row fail the test.
     for attempt in range(3):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(ncases), str(seed + 1000 * attempt)], capture_output=True, text=True, cwd=ROOT, env=env)
+        cmd = [sys.executable, os.path.join(ROOT, "tools", tool), str(ncases), str(seed + 1000 * attempt)]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env)
         if r.returncode >= 0 or "MISMATCH" in r.stdout:
             break
+        alone = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=dict(env, FUZZ_PRODUCT_ONLY="1"))
+        assert alone.returncode >= 0, "the PRODUCT alone dies on this sequence of calls (signal %d):\n" % -alone.returncode + alone.stderr[-2000:]
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
 
