@@ -252,7 +252,7 @@ for k in range(ncases):
             rc, sp_p, wd_p = ez.gdwdfuv(gp, wu, wv, plat, plon)
             dd = np.abs(((wd_p - wd_r + 180.0) % 360.0) - 180.0)
             if np.any(np.abs(sp_p - sp_r) > 1e-5 * np.maximum(sp_r, 1e-3)) or np.any(dd[sp_r > 0] > 1e-3 + (np.degrees(8 * 6e-8 / cosl[sp_r > 0]) if rotated else 0.0)):
-                w = int(np.argmax(dd * (sp_r > 0))); report("gdwdfuv", desc, f"max |dspd| {np.abs(sp_p - sp_r).max():.2e}, max |ddir| {dd[sp_r > 0].max():.2e} deg at lat {plat[w]!r}: {wd_p[w]!r} vs {wd_r[w]!r}")
+                w = int(np.argmax(dd * (sp_r > 0))); report("gdwdfuv", desc, f"max |dspd| {np.abs(sp_p - sp_r).max():.2e}, max |ddir| {(dd[sp_r > 0].max() if (sp_r > 0).any() else 0.0):.2e} deg at lat {plat[w]!r}: {wd_p[w]!r} vs {wd_r[w]!r}")
             rc, u2_p, v2_p = ez.gduvfwd(gp, sp_r, wd_r, plat, plon)
             sc = np.maximum(sp_r.astype(np.float64), 1e-3)
             e = np.maximum(np.abs(u2_p - u2_r), np.abs(v2_p - v2_r)) / sc
