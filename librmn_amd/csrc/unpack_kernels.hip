@@ -11,10 +11,14 @@
  *                     bits long, so the chain enters a window at one of its first `ext` bit positions; for EVERY such
  *                     entry one lane walks the window (as if a tile header started there, interior point count)
  *                     and records where the walk leaves the window and how many tiles it saw: tab[window][entry].
- *   k_armn_dec_hop    one workgroup per FIELD, one lane: follows the true chain window by window with one LDS
- *                     lookup per window (tables and stream are staged through LDS in batches).  Windows in
- *                     which the point count changes (the last tile of a row of tiles, the last row) are walked
- *                     tile by tile instead.  Writes each window's true entry and first tile index.
+ *   k_armn_dec_hop    one workgroup per FIELD: follows the true chain with one LDS lookup per window -- or per EIGHT windows
+ *                     (k_armn_dec_compose builds the composed table) -- on one wave; tables and stream are staged in LDS
+ *                     in batches of ~100 windows by LDS-DMA (every row of a batch in flight at once).  A window in which a
+ *                     row of tiles ends (its last tile holds fewer points, everything behind it shifts) is resolved by the
+ *                     WHOLE workgroup when it holds many tiles: successor and tile count of every bit position, pointer
+ *                     doubling, the walk to the row's last tile read off its binary digits (round 3); windows with few
+ *                     tiles and the last row of tiles are walked tile by tile.  Writes each window's true entry and first
+ *                     tile index.
  *   k_armn_dec_emit   all CUs, one lane per window: walks its window from the true entry -> bit position of every tile.
  *
  * then
@@ -41,7 +45,22 @@ extern "C" void *ezhip_get_stream(void);
 #define DEXT      416                   /* table entries per window: >= the longest tile (MINIMUM: 4 + 25 x 16 bits) */
 #define DTAIL     16                    /* stream words staged past a window (>= DEXT + 32 bits) */
 #define HOP_TPB   1024
-#define HOP_LDS   (96 * 1024)
+#define HOP_NP    (DW + DEXT)           /* bit positions a walk inside one window can reach (the last tile may end DEXT bits past it) */
+static_assert(HOP_TPB == DW, "the doubling rounds of k_armn_dec_hop give every thread one bit position of a window");
+#define HOP_DBL_WORDS (2 * HOP_NP)      /* [2][HOP_NP] words: {successor | tiles << 16} */
+#define HOP_DENSE 20                    /* tiles in a row-end window from which the workgroup resolves it (measured: below, wave 0 walking it tile by tile is faster) */
+#define HOP_LDS   (156 * 1024)          /* of the CU's 160 KB: 112 windows per staged batch at PARALLELOGRAM's 157 entries per window (96 KB: 69) */
+
+/* LDS-DMA of 16 bytes per lane (gfx950): lane l brings base + voff(l) to lds_byte_addr + 16 l, no VGPRs in between -- every row of a batch is in flight at
+ * once (through registers a thread holds 16 loads: two rounds of memory latency per batch of 69 windows were most of the kernel's time).  Through inline
+ * asm: completion is ordered by the s_waitcnt vmcnt(0) + barrier that follow (ez_kernels.hip, k_sepx, says why the builtin is avoided) */
+__device__ __forceinline__ void dec_dma16(const unsigned *base_uniform, unsigned voff_bytes, unsigned lds_byte_addr)
+{
+    const char *addr = (const char *)base_uniform + voff_bytes;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(addr), "s"(__builtin_amdgcn_readfirstlane((int)lds_byte_addr)) : "memory");
+}
+__device__ __forceinline__ unsigned dec_lds_addr(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; }
 
 struct DecGeom {
     int method, istep, origin, nbits, C;    /* C: width of a tile header */
@@ -171,7 +190,7 @@ __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all,
                                                           int nwin, int *status, int dbg)
 {
     extern __shared__ unsigned lds[];
-    __shared__ unsigned s_pos, s_done, s_t;
+    __shared__ unsigned s_pos, s_done, s_t, s_mid, s_state, s_rw, s_re, s_rcnt, s_dense;
     const int f = blockIdx.x, tid = threadIdx.x;
     const unsigned *z = z_all + (size_t)f * z_stride;
     DecGeom g;
@@ -183,9 +202,10 @@ __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all,
     const int ext = (int)uni((unsigned)g.ext), C = (int)uni((unsigned)g.C), n_int = g.n_int;
     const unsigned ntiles = uni((unsigned)g.ntiles);
     const int ext4 = (ext + 3) & ~3, cpr = ext4 >> 2;                  /* LDS row stride (words), 16-byte chunks per row */
-    const int nb = (HOP_LDS / 4 - DTAIL) / (2 * ext4 + DWW + 4);       /* windows per staged batch */
+    const int nb = (HOP_LDS / 4 - DTAIL - HOP_DBL_WORDS) / (2 * ext4 + DWW + 4);       /* windows per staged batch */
     unsigned *tabs = lds, *tabs8 = lds + (size_t)nb * ext4, *strm = tabs8 + (size_t)nb * ext4, *wl = strm + (size_t)nb * DWW + DTAIL, *wl8 = wl + 2 * nb;
-    if (tid == 0) { s_pos = g.body; s_t = 0; s_done = 0; }
+    unsigned *dbl = wl8 + 2 * nb;                                     /* [2][HOP_NP]: successor and tile count of every bit position of ONE window, double-buffered */
+    if (tid == 0) { s_pos = g.body; s_t = 0; s_done = 0; s_mid = 0; s_dense = 0; }
     __syncthreads();
     for (;;) {
         const unsigned pos0 = s_pos;
@@ -194,6 +214,7 @@ __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all,
         const int nbw = min(nb, nwin - b0);
         /* staging: a lone workgroup is latency-bound (bytes in flight / latency), so every thread issues up to 16
          * independent 16-byte loads before the first store: lane = 16-byte chunk of a row, 8 rows per pass, 8 passes */
+        if (dbg & 2) {                                            /* development: the round-1 staging through registers (two tables x 64 rows per round trip) */
         for (int row0 = 0; row0 < nbw; row0 += 8 * 8) {
             uint4 r[8], r8[8];
             const int ch = tid & 127, rl = tid >> 7;
@@ -207,6 +228,19 @@ __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all,
             for (int k = 0; k < 8; k++) {
                 const int row = row0 + 8 * k + rl;
                 if (ch < cpr && row < nbw) { *(uint4 *)(tabs + (size_t)row * ext4 + 4 * ch) = r[k]; *(uint4 *)(tabs8 + (size_t)row * ext4 + 4 * ch) = r8[k]; }
+            }
+        }
+        } else {
+            /* wave v brings rows v, v + 16, ... of both tables: a row is cpr 16-byte pieces, one per lane (two instructions for MINIMUM's 101 pieces) */
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+            for (int row = wv; row < nbw; row += HOP_TPB / 64) {
+                const unsigned *g1 = tab + (size_t)(b0 + row) * DEXT, *g8 = tab8 + (size_t)(b0 + row) * DEXT;
+                for (int c0 = 0; c0 < cpr; c0 += 64) {
+                    if (c0 + ln < cpr) {
+                        dec_dma16(g1, (unsigned)(c0 + ln) * 16u, dec_lds_addr(tabs + (size_t)row * ext4 + 4 * c0));
+                        dec_dma16(g8, (unsigned)(c0 + ln) * 16u, dec_lds_addr(tabs8 + (size_t)row * ext4 + 4 * c0));
+                    }
+                }
             }
         }
         {   /* stream words of the batch (+ tail): clamped unconditional loads, zero past the end of the stream */
@@ -224,50 +258,151 @@ __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all,
             }
         }
         for (int k = tid; k < 2 * nbw; k += HOP_TPB) { wl[k] = 0xFFFFFFFFu; wl8[k] = 0xFFFFFFFFu; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          /* the DMA'd rows of this wave have landed; the barrier makes that true for all */
         __syncthreads();
         if (dbg & 1) { if (tid == 0) { s_pos = (unsigned)(b0 + nbw) * DW; } __syncthreads(); continue; }
+      for (;;) {                                                  /* segments of the batch: wave 0 walks; a window that holds a row end is resolved by the whole workgroup */
         if (tid < 64) {
-            unsigned pos = uni(pos0), t = uni(s_t), run;
+            unsigned pos = uni(s_pos), t = uni(s_t), run;
             int n;
+            bool mid = uni(s_mid) != 0;                               /* pos lies INSIDE a window whose entry is already recorded (the workgroup left it there) */
+            bool dense = uni(s_dense) != 0;                           /* the last row-end window held many tiles: such windows go to the workgroup (few: one wave is faster) */
+            unsigned state = 0;
             dec_run32(g, t, n, run);
             n = (int)uni((unsigned)n); run = uni(run);
-            const unsigned wend = (unsigned)(b0 + nbw);
+            const unsigned nbw_u = (unsigned)nbw, ext_u = (unsigned)ext, ext4_u = (unsigned)ext4, base_pos = (unsigned)b0 * DW;
+            auto step_tile = [&](unsigned &pp, int nn) {            /* one tile header at pp: its length with nn points */
+                const unsigned q = pp - base_pos;
+                const unsigned long long v = (unsigned long long)uni(strm[q >> 5]) << 32 | uni(strm[(q >> 5) + 1]);
+                const unsigned hdr = (unsigned)(v >> (64 - C - (int)(q & 31))) & ((1u << C) - 1u);
+                pp += (unsigned)dec_step(g, hdr, nn);
+            };
             while (t < ntiles) {
-                const unsigned w = pos / DW;
-                if (w >= wend) break;
-                const unsigned e = pos - w * DW, wr = w - (unsigned)b0;
-                wl[2 * wr] = e; wl[2 * wr + 1] = t;
-                if (e < (unsigned)ext && n == n_int) {
-                    if (wr + 8 <= (unsigned)nbw) {                       /* eight windows at once when no point-count change lies within */
-                        const unsigned v8 = uni(tabs8[wr * (unsigned)ext4 + e]), cnt8 = v8 >> 16;
-                        if (cnt8 != 0xFFFFu && cnt8 <= run) {
-                            wl8[2 * wr] = e; wl8[2 * wr + 1] = t;
-                            pos = (w + 8) * DW + (v8 & 0xFFFFu); t += cnt8; run -= cnt8;
-                            if (run == 0 && t < ntiles) { dec_run32(g, t, n, run); n = (int)uni((unsigned)n); run = uni(run); }
-                            continue;
+                unsigned wr = pos / DW - (unsigned)b0;
+                if (wr >= nbw_u) break;
+                unsigned e = pos & (DW - 1);
+                if (!mid) { wl[2 * wr] = e; wl[2 * wr + 1] = t; }
+                if (n == n_int && !mid && e < ext_u) {
+                    /* the table path as two tight loops (the one loop with every case in it compiled into a state machine of ~100 scalar instructions per
+                     * step: 0.4 us per step for the one wave of the CU) */
+                    bool settled = false;                             /* (wr, e, t) is a window entry not recorded yet: back to the top */
+                    unsigned cnt = 0;
+                    while (wr + 8 <= nbw_u) {                         /* eight windows at once while no point-count change lies within */
+                        const unsigned v8 = uni(tabs8[wr * ext4_u + e]), cnt8 = v8 >> 16;
+                        if (cnt8 > run) break;                        /* (0xFFFF = no composed entry: larger than any run) */
+                        wl8[2 * wr] = e; wl8[2 * wr + 1] = t;
+                        t += cnt8; run -= cnt8; wr += 8; e = v8 & 0xFFFFu;
+                        if (run == 0 || e >= ext_u || wr >= nbw_u) { settled = true; break; }
+                        wl[2 * wr] = e; wl[2 * wr + 1] = t;
+                    }
+                    if (!settled) {
+                        for (;;) {                                    /* window by window up to the one that holds the row's end */
+                            const unsigned v = uni(tabs[wr * ext4_u + e]);
+                            cnt = v >> 16;
+                            if (cnt > run) break;
+                            t += cnt; run -= cnt; wr += 1; e = v & 0xFFFFu;
+                            if (run == 0 || e >= ext_u || wr >= nbw_u) { settled = true; break; }
+                            wl[2 * wr] = e; wl[2 * wr + 1] = t;
                         }
                     }
-                    const unsigned v = uni(tabs[wr * (unsigned)ext4 + e]), cnt = v >> 16;
-                    if (cnt <= run) {
-                        pos = (w + 1) * DW + (v & 0xFFFFu); t += cnt; run -= cnt;
+                    pos = base_pos + wr * DW + e;
+                    if (settled) {
                         if (run == 0 && t < ntiles) { dec_run32(g, t, n, run); n = (int)uni((unsigned)n); run = uni(run); }
                         continue;
                     }
+                    dense = cnt >= HOP_DENSE;                         /* the row ends inside window wr (its entry is recorded) */
+                    if (dense && !(dbg & 4)) { s_rw = wr; s_re = e; s_rcnt = cnt; state = 1; break; }
+                } else if (n == n_int && dense && !(dbg & 4)) {       /* no table entry for this position (behind a row's last tile, or beyond the table): the workgroup */
+                    s_rw = wr; s_re = e; s_rcnt = (DW - e) / (unsigned)C + 1u; state = 1; break;
+                } else if (n != n_int && run <= 2 && dense && !(dbg & 4)) {        /* the odd tile(s) at a row's end: stepped over here, the rest of the window is the workgroup's */
+                    const unsigned w_abs = pos / DW;
+                    while (run > 0 && t < ntiles) { step_tile(pos, n); t++; run--; }
+                    if (t < ntiles) { dec_run32(g, t, n, run); n = (int)uni((unsigned)n); run = uni(run); }
+                    mid = pos / DW == w_abs;
+                    continue;
                 }
-                const unsigned end = (w + 1) * DW;                       /* the point count changes in this window: tile by tile */
+                /* tile by tile to the window's end: row-end windows that hold few tiles, the last row of tiles (every tile of it is short) */
+                const unsigned end = base_pos + (wr + 1) * DW;
                 while (pos < end && t < ntiles) {
-                    const unsigned q = pos - (unsigned)b0 * DW;
-                    const unsigned long long v = (unsigned long long)uni(strm[q >> 5]) << 32 | uni(strm[(q >> 5) + 1]);
-                    const unsigned hdr = (unsigned)(v >> (64 - C - (int)(q & 31))) & ((1u << C) - 1u);
-                    pos += (unsigned)dec_step(g, hdr, n);
-                    t++;
-                    if (--run == 0 && t < ntiles) { dec_run32(g, t, n, run); n = (int)uni((unsigned)n); run = uni(run); }
+                    while (pos < end && run > 0) { step_tile(pos, n); t++; run--; }
+                    if (run == 0 && t < ntiles) { dec_run32(g, t, n, run); n = (int)uni((unsigned)n); run = uni(run); }
                 }
+                mid = false;
             }
-            if (tid == 0) { s_pos = pos; s_t = t; if (t >= ntiles) s_done = 1; }
+            if (tid == 0) { s_pos = pos; s_t = t; s_state = state; s_mid = 0; s_dense = dense ? 1u : 0u; if (t >= ntiles) s_done = 1; }
         }
         __syncthreads();
+        if (s_state == 0) break;
+        /* ---- a window with a row end, all threads: successor and tile count of EVERY bit position of the window under the interior point count, then
+         * pointer doubling (nine rounds: a window holds at most 256 tiles): after it nxt[p] = where the walk from p leaves the window, cnt[p] = its
+         * tiles; on the way lane 0 follows the binary digits of `run` from the entry to the row's last tile (one wave walking a window tile by tile
+         * cost ~600 clk per tile: 38 tiles per row-end window at a compression ratio of 0.2, 1200 such windows per cfg5 record) ---- */
+        {
+            const unsigned wr = s_rw, e = s_re, t0 = s_t;
+            int n0; unsigned run0;
+            dec_run32(g, t0, n0, run0);                                /* n0 == n_int here */
+            /* {successor | tiles << 16} per bit position, two buffers; positions past the window's end are their own successor with no tile (both buffers) */
+            unsigned *sc[2] = {(unsigned *)dbl, (unsigned *)dbl + HOP_NP};
+            for (int p = tid; p < HOP_NP; p += HOP_TPB) {
+                unsigned v_ = (unsigned)p;
+                if (p < DW) {
+                    const unsigned q = wr * DW + (unsigned)p;
+                    const unsigned long long v = (unsigned long long)strm[q >> 5] << 32 | strm[(q >> 5) + 1];
+                    const unsigned hdr = (unsigned)(v >> (64 - C - (int)(q & 31))) & ((1u << C) - 1u);
+                    v_ = (unsigned)(p + dec_step(g, hdr, n_int)) | 1u << 16;
+                } else sc[1][p] = v_;
+                sc[0][p] = v_;
+            }
+            /* rounds: the walk from e holds s_rcnt tiles (its table entry; without one at most (DW - e) / C + 1); the walk behind the row's last tile is
+             * checked for having left the window below */
+            int rounds = 1;
+            while (rounds < 9 && (1u << rounds) <= s_rcnt) rounds++;
+            __syncthreads();
+            unsigned pc = e;
+            int cur = 0;
+            for (int j = 0; j < rounds; j++) {
+                {
+                    const unsigned w_ = sc[cur][tid], w2 = sc[cur][w_ & 0xFFFFu];          /* HOP_TPB == DW: one position per thread */
+                    sc[cur ^ 1][tid] = (w2 & 0xFFFFu) | ((w_ >> 16) + (w2 >> 16)) << 16;
+                }
+                if (tid == 0 && ((run0 >> j) & 1u)) pc = sc[cur][pc] & 0xFFFFu;
+                __syncthreads();
+                cur ^= 1;
+            }
+            const unsigned *nxcn = sc[cur];
+            if (tid == 0) {
+                const unsigned wbase = ((unsigned)b0 + wr) * DW;
+                unsigned pos, t, mid = 0;
+                const unsigned cexit = nxcn[e] >> 16, xexit = nxcn[e] & 0xFFFFu;
+                if (xexit >= DW && cexit <= run0) { pos = wbase + xexit; t = t0 + cexit; }        /* no row end in the window after all (an entry beyond the table) */
+                else {
+                    t = t0 + run0;                                     /* the row's last tile sits at pc */
+                    unsigned p2 = pc;
+                    int n1 = n_int; unsigned run1 = 0;
+                    if (t < ntiles) {
+                        dec_run32(g, t, n1, run1);
+                        for (unsigned k = 0; k < run1 && p2 < DW && t < ntiles && n1 != n_int; k++) {        /* (one tile; two in no geometry) */
+                            const unsigned q = wr * DW + p2;
+                            const unsigned long long v = (unsigned long long)strm[q >> 5] << 32 | strm[(q >> 5) + 1];
+                            const unsigned hdr = (unsigned)(v >> (64 - C - (int)(q & 31))) & ((1u << C) - 1u);
+                            p2 += (unsigned)dec_step(g, hdr, n1); t++;
+                        }
+                    }
+                    pos = wbase + p2;
+                    if (p2 < DW && t < ntiles) {
+                        int n2; unsigned run2;
+                        dec_run32(g, t, n2, run2);
+                        if (n2 == n_int && (nxcn[p2] & 0xFFFFu) >= DW && (nxcn[p2] >> 16) <= run2) { pos = wbase + (nxcn[p2] & 0xFFFFu); t += nxcn[p2] >> 16; }      /* the next row's tiles up to the window's end */
+                        else mid = 1;                                   /* (rows shorter than a window, the last row): wave 0 goes on from inside the window */
+                    }
+                }
+                s_pos = pos; s_t = t; s_mid = mid; if (t >= ntiles) s_done = 1;
+            }
+            __syncthreads();
+        }
+      }
         for (int k = tid; k < 2 * nbw; k += HOP_TPB) { went[2 * (size_t)b0 + k] = wl[k]; went8[2 * (size_t)b0 + k] = wl8[k]; }
+        __syncthreads();                                          /* the next batch re-arms wl / wl8 right away (its staging no longer waits in between) */
     }
     if (tid == 0) status[f] = s_done ? 0 : -2;
 }

@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+timeout 900 python3 -m pytest tests/test_gpu_packers.py -x -q -m gpu -k "uncompress or decode or unzip or read_side or fst" 2>&1 | tail -3
+timeout 600 python3 tools/fuzz_armn.py 1500 8107 2>&1 | tail -n 1
+python3 tools/probe_decode1.py 1e-5 2>&1 | tail -2
+EZHIP_DEC_DEBUG=4 python3 tools/probe_decode1.py 1e-5 2>&1 | tail -1
+python3 tools/probe_decode1.py 1e-3 2>&1 | tail -2
+EZHIP_DEC_DEBUG=4 python3 tools/probe_decode1.py 1e-3 2>&1 | tail -1
