@@ -310,7 +310,7 @@ __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all,
                         if (run == 0 && t < ntiles) { dec_run32(g, t, n, run); n = (int)uni((unsigned)n); run = uni(run); }
                         continue;
                     }
-                    dense = cnt >= HOP_DENSE;                         /* the row ends inside window wr (its entry is recorded) */
+                    dense = cnt >= ((dbg >> 8) ? (unsigned)(dbg >> 8) : (unsigned)HOP_DENSE);      /* the row ends inside window wr (its entry is recorded); development: threshold in EZHIP_DEC_DEBUG's bits 8.. */
                     if (dense && !(dbg & 4)) { s_rw = wr; s_re = e; s_rcnt = cnt; state = 1; break; }
                 } else if (n == n_int && dense && !(dbg & 4)) {       /* no table entry for this position (behind a row's last tile, or beyond the table): the workgroup */
                     s_rw = wr; s_re = e; s_rcnt = (DW - e) / (unsigned)C + 1u; state = 1; break;
