@@ -1082,8 +1082,10 @@ __device__ __forceinline__ EncChunk enc1_chunk(const enc1_args &a, unsigned g)
 
 #define ENC_WK 1                        /* look-back: granules per lane and window */
 #define ENC_NLD 7                       /* 16-byte pieces a lane stages up front: rows of up to 448 pieces (chunks of up to 1024 tiles) */
+/* seven waves per SIMD (65 VGPRs, nothing spilled).  Eight (64 VGPRs, four of them spilled to scratch; the 19.3 KB of LDS of a cfg5 chunk allow it) was measured
+ * slower (profiles/r03_experiments.txt); so was this body behind a __forceinline__ function taking the arguments by reference (71 VGPRs, 10 spilled: + 14 %) */
 template <bool SWAPPED>
-__device__ __forceinline__ void armn_enc1_body(const enc1_args &a)
+__global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_armn_enc1(enc1_args a)
 {
     extern __shared__ unsigned lds[];                      /* token patch, then (aliased) the chunk's stream image */
     __shared__ unsigned s_wsum[ENC_TPT][ENC_TPB / 64], s_gt, s_abort, s_gt_all;
@@ -1412,10 +1414,6 @@ __device__ __forceinline__ void armn_enc1_body(const enc1_args &a)
     }
 #undef STAMP
 }
-/* seven waves per SIMD (65 VGPRs, nothing spilled).  Eight (64 VGPRs, four of them spilled to scratch, the 19.3 KB of LDS of a cfg5 chunk allow it) was measured
- * slower: 1475 against 1439 us per 32 cfg5 fields (profiles/r03_experiments.txt) */
-template <bool SWAPPED>
-__global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_armn_enc1(enc1_args a) { armn_enc1_body<SWAPPED>(a); }
 
 static unsigned long long *g_enc1_prof = nullptr;
 /* development: phase clock sums of the last profiled launch (EZHIP_ENC_DEBUG & 16) -> out[8] */
