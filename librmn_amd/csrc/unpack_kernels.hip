@@ -7,12 +7,13 @@
  * position is known only once every earlier header has been read (~100 clk per tile for one lane: 0.25 s for the
  * 2.9 M tiles of a cfg2 field, the speed of the CPU decoder).  The chain is resolved in three kernels:
  *
- *   k_armn_dec_spec   speculation, all CUs: the stream is cut into windows of DW = 2048 bits.  A tile is at most `ext`
+ *   k_armn_dec_spec   speculation, all CUs: the stream is cut into windows of DW = 1024 bits.  A tile is at most `ext`
  *                     bits long, so the chain enters a window at one of its first `ext` bit positions; for EVERY such
- *                     entry one lane walks the window (as if a tile header started there, interior point count)
- *                     and records where the walk leaves the window and how many tiles it saw: tab[window][entry].
+ *                     entry the walk through the window (as if a tile header started there, interior point count) is
+ *                     recorded: where it leaves the window and how many tiles it saw: tab[window][entry].  One wave per
+ *                     window: the successor of every bit position once, then the entries chase through LDS (round 3).
  *   k_armn_dec_hop    one workgroup per FIELD: follows the true chain with one LDS lookup per window -- or per EIGHT windows
- *                     (k_armn_dec_compose builds the composed table) -- on one wave; tables and stream are staged in LDS
+ *                     (k_armn_dec_compose_lds builds the composed table by doubling in LDS) -- on one wave; tables and stream are staged in LDS
  *                     in batches of ~100 windows by LDS-DMA (every row of a batch in flight at once).  A window in which a
  *                     row of tiles ends (its last tile holds fewer points, everything behind it shifts) is resolved by the
  *                     WHOLE workgroup when it holds many tiles: successor and tile count of every bit position, pointer
@@ -123,25 +124,39 @@ __device__ __forceinline__ void dec_run(const DecGeom &g, long long t, int &n, l
     else run = (long long)(g.nty - 1 - y) * g.ntx - x;
 }
 
-/* tab[window][entry] = (bits past the window's end where the walk from `entry` lands) | tiles seen << 16 */
-__global__ __launch_bounds__(256) void k_armn_dec_spec(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
-                                                       unsigned *tab_all, size_t tab_stride, int nwin)
+/* tab[window][entry] = (bits past the window's end where the walk from `entry` lands) | tiles seen << 16.
+ * One WAVE per window, four windows per thread block, no block-wide barrier (round 3: a thread block per window was bound by the dispatch of 6.3 M tiny
+ * thread blocks per 32 cfg5 streams, and walked every entry with a header decode per tile): the successor of EVERY bit position once (16 per lane), then
+ * the entries chase through LDS -- one 16-bit read per tile; the ext walks of a window merge after a few tiles (157 x 15 - 38 decodes per window before, 1024 now) */
+#define SPEC_WPB 4
+__global__ __launch_bounds__(64 * SPEC_WPB) void k_armn_dec_spec(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
+                                                                unsigned *tab_all, size_t tab_stride, int nwin)
 {
-    __shared__ unsigned s[DWW + DTAIL];
-    const int f = blockIdx.y, win = blockIdx.x, tid = threadIdx.x;
+    __shared__ unsigned s_all[SPEC_WPB][DWW + DTAIL];
+    __shared__ unsigned short nx_all[SPEC_WPB][DW];
+    const int f = blockIdx.y, wv = threadIdx.x >> 6, lane = threadIdx.x & 63, win = blockIdx.x * SPEC_WPB + wv;
+    if (win >= nwin) return;                                      /* (a whole wave leaves: nothing below synchronises across waves) */
     const unsigned *z = z_all + (size_t)f * z_stride;
     DecGeom g;
     if (!dec_geom(g, z, ni, nj)) return;
     const size_t nwords = z_words - 1;
+    unsigned *s = s_all[wv];
+    unsigned short *nx = nx_all[wv];
     unsigned mine = 0;
-    if (tid < DWW + DTAIL) { mine = gword(z + 1, (size_t)win * DWW + tid, nwords); s[tid] = mine; }
-    const int nonzero = __syncthreads_or(mine != 0);
+    if (lane < DWW + DTAIL) { mine = gword(z + 1, (size_t)win * DWW + lane, nwords); s[lane] = mine; }
+    const bool nonzero = __ballot(mine != 0) != 0;
     unsigned *tab = tab_all + (size_t)f * tab_stride + (size_t)win * DEXT;
     const unsigned step0 = (unsigned)dec_step(g, 0, g.n_int);
-    for (int e = tid; e < g.ext; e += 256) {
+    if (!nonzero) {                                               /* zero words (past the end of the stream): every header reads 0 */
+        for (int e = lane; e < g.ext; e += 64) { const unsigned cnt = (DW - (unsigned)e + step0 - 1) / step0; tab[e] = ((unsigned)e + cnt * step0 - DW) | cnt << 16; }
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int p = lane; p < DW; p += 64) nx[p] = (unsigned short)(p + dec_step(g, getbits(s, (unsigned)p, g.C), g.n_int));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = lane; e < g.ext; e += 64) {
         unsigned p = (unsigned)e, cnt = 0;
-        if (!nonzero) { cnt = (DW - p + step0 - 1) / step0; p += cnt * step0; }     /* zero words (past the end of the stream): every header reads 0 */
-        while (p < DW) { p += (unsigned)dec_step(g, getbits(s, p, g.C), g.n_int); cnt++; }
+        while (p < DW) { p = nx[p]; cnt++; }
         tab[e] = (p - DW) | cnt << 16;
     }
 }
@@ -165,6 +180,72 @@ __global__ __launch_bounds__(256) void k_armn_dec_compose(const unsigned *z_all,
             if (e >= (unsigned)g.ext || cnt >= 0xFFFFu) ok = false;
         }
         tab8[e0] = ok ? (e | cnt << 16) : 0xFFFF0000u;
+    }
+}
+
+/* the same table by DOUBLING in LDS (round 3): a thread block takes G consecutive windows, stages the G + 7 rows they need once and composes
+ * 1 -> 2 -> 4 -> 8 windows: three LDS lookups per entry instead of eight dependent global loads (10.8 ms per 32 cfg5 streams at ratio 0.5: latency-bound).
+ * An element that cannot be chained (exit beyond the table, count at the sentinel, window past the last one) is the sentinel 0xFFFF0000; counts only grow, so
+ * checking the sums after 2, 4 and 8 windows marks exactly the entries the step-by-step form marked */
+#define CMP_INV 0xFFFF0000u
+#define CMP_TPB 1024                    /* two thread blocks of 64 KB per CU: 32 waves, ~6 independent loads per thread while a group is staged */
+__device__ __forceinline__ unsigned dec_compose2(unsigned a, const unsigned *next_row)
+{
+    if (a == CMP_INV) return CMP_INV;
+    const unsigned v = next_row[a & 0xFFFFu];
+    if (v == CMP_INV) return CMP_INV;
+    const unsigned cnt = (a >> 16) + (v >> 16);
+    return cnt >= 0xFFFFu ? CMP_INV : ((v & 0xFFFFu) | cnt << 16);
+}
+__global__ __launch_bounds__(CMP_TPB) void k_armn_dec_compose_lds(const unsigned *z_all, size_t z_stride, int ni, int nj,
+                                                              const unsigned *tab_all, unsigned *tab8_all, size_t tab_stride, int nwin, int G, int lds_words)
+{
+    extern __shared__ unsigned cl[];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    DecGeom g;
+    if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj)) return;
+    const int ext = g.ext, ext4 = (ext + 3) & ~3;
+    const unsigned *tab = tab_all + (size_t)f * tab_stride;
+    unsigned *tab8 = tab8_all + (size_t)f * tab_stride;
+    /* the launch sizes the LDS for PARALLELOGRAM's 157 entries per window; a MINIMUM stream (404) takes its G windows in smaller groups */
+    const int Gc = min(G, (lds_words / ext4 - 17) / 3);
+    const int Wend = min(blockIdx.x * G + G, nwin);
+    for (int W = blockIdx.x * G; W < Wend; W += Gc) {
+        const int Gn = min(Gc, Wend - W);
+        unsigned *t1 = cl, *t2 = t1 + (size_t)(Gn + 7) * ext4, *t4 = t2 + (size_t)(Gn + 6) * ext4;
+        __syncthreads();                                              /* the previous group is done with the buffers */
+        const float rcp4 = 1.0f / (float)ext4;                        /* k / ext4 for k < 2^16: (int)((k + 0.5) / ext4) is exact */
+        auto row_of = [&](int k) { return (int)(((float)k + 0.5f) * rcp4); };
+        {   /* staging: every thread's loads issued before its first store (clamped addresses: unconditional loads stay in flight together) */
+            constexpr int U = 6;
+            const int total = (Gn + 7) * ext4, wlast = nwin - 1;
+            for (int k0 = tid; k0 < total; k0 += CMP_TPB * U) {
+                unsigned v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int k = min(k0 + u * CMP_TPB, total - 1), r = row_of(k), e = k - r * ext4;
+                    v[u] = tab[(size_t)min(W + r, wlast) * DEXT + min(e, ext - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int k = k0 + u * CMP_TPB;
+                    if (k < total) {
+                        const int r = row_of(k), e = k - r * ext4;
+                        const bool ok = W + r < nwin && e < ext && (v[u] & 0xFFFFu) < (unsigned)ext && (v[u] >> 16) < 0xFFFFu;
+                        t1[k] = ok ? v[u] : CMP_INV;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < (Gn + 6) * ext4; k += CMP_TPB) { const int r = row_of(k); t2[k] = dec_compose2(t1[k], t1 + (size_t)(r + 1) * ext4); }
+        __syncthreads();
+        for (int k = tid; k < (Gn + 4) * ext4; k += CMP_TPB) { const int r = row_of(k); t4[k] = dec_compose2(t2[k], t2 + (size_t)(r + 2) * ext4); }
+        __syncthreads();
+        for (int k = tid; k < Gn * ext4; k += CMP_TPB) {
+            const int r = row_of(k), e = k - r * ext4, w = W + r;
+            if (e < ext) tab8[(size_t)w * DEXT + e] = (w + 8 <= nwin) ? dec_compose2(t4[k], t4 + (size_t)(r + 4) * ext4) : CMP_INV;
+        }
     }
 }
 
@@ -621,8 +702,13 @@ extern "C" int packhip_armn_decode(unsigned *d_out, size_t out_stride_words, con
         if (hipMemsetAsync((char *)went + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
         if (hipMemsetAsync((char *)went8 + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
     }
-    hipLaunchKernelGGL(k_armn_dec_spec, dim3(nwin, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, tab, ws4, nwin);
-    hipLaunchKernelGGL(k_armn_dec_compose, dim3(nwin, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, tab8, ws4, nwin);
+    hipLaunchKernelGGL(k_armn_dec_spec, dim3((nwin + SPEC_WPB - 1) / SPEC_WPB, nfields), dim3(64 * SPEC_WPB), 0, st, d_z, z_stride_words, z_words, ni, nj, tab, ws4, nwin);
+    if (getenv("EZHIP_DEC_COMPOSE_GLOBAL"))        /* development: eight dependent global loads per entry (rounds 1 - 2) */
+        hipLaunchKernelGGL(k_armn_dec_compose, dim3(nwin, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, tab8, ws4, nwin);
+    else {
+        const int G = 28, lds_words = (3 * G + 17) * 160;          /* 64 640 B: G windows of 160-entry rows (t1: G + 7 rows, t2: G + 6, t4: G + 4) */
+        hipLaunchKernelGGL(k_armn_dec_compose_lds, dim3((nwin + G - 1) / G, nfields), dim3(CMP_TPB), (size_t)4 * lds_words, st, d_z, z_stride_words, ni, nj, tab, tab8, ws4, nwin, G, lds_words);
+    }
     hipLaunchKernelGGL(k_armn_dec_hop, dim3(nfields), dim3(HOP_TPB), HOP_LDS, st, d_z, z_stride_words, z_words, ni, nj, tab, tab8, ws4, went, went8, ws4, nwin, d_status, getenv("EZHIP_DEC_DEBUG") ? atoi(getenv("EZHIP_DEC_DEBUG")) : 0);
     hipLaunchKernelGGL(k_armn_dec_expand8, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, ws4, went, went8, ws4, nwin);
     hipLaunchKernelGGL(k_armn_dec_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, went, ws4, tilepos, ws4, nwin);

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for noise in 1e-5 1e-4 1e-3; do
-for th in 0 6 10 14 30; do
-  echo "noise $noise dense threshold $th: $(EZHIP_DEC_DEBUG=$((th * 256)) python3 tools/probe_decode1.py $noise 2>&1 | tail -2 | tr '\n' ' ')"
-done; done
+timeout 1500 python3 -m pytest tests/test_gpu_packers.py -x -q -m gpu 2>&1 | tail -3
+timeout 900 python3 tools/fuzz_armn.py 4000 10107 2>&1 | tail -n 1
+python3 tools/probe_decode1.py 1e-5 2>&1 | tail -1
+python3 tools/probe_decode1.py 5e-4 2>&1 | tail -1
