@@ -21,6 +21,10 @@
 #include "../../include/packers_hip.h"
 
 #define W64TOWD(n) ((n) << 1)
+int32_t ezhip_pack16_compress_host(uint32_t *record, int64_t (*out_words_of)(int32_t zlng), const float *field, int32_t ni, int32_t nj, int32_t nbits);
+int32_t ezhip_uncompress_unpack16_host(float *field, const uint32_t *record, int64_t record_words, int32_t ni, int32_t nj, int32_t nbits);
+/* words of a datyp-129 data part behind its length word: 16 header bytes + zlng stream bytes, padded to 64 bits (fstd98.c:1178-1180), minus the length word */
+static int64_t fst129_words_after_length(int32_t zlng) { return ((((int64_t)16 + zlng) * 8 + 63) / 64) * 2 - 1; }
 static int imax(int a, int b) { return a > b ? a : b; }
 static int imin(int a, int b) { return a < b ? a : b; }
 
@@ -250,7 +254,19 @@ int32_t ezhip_fst_pack_data_ex(uint32_t *data, int64_t cap_words, void *field_in
         break;
     }
     case 1: case 129:                                                               /* :1161-1190 */
-        if (datyp > 128 && nbits <= 16) {
+        if (datyp > 128 && nbits <= 16 && !is_double && nk == 1 && ni > 1 && nj > 1 && !getenv("EZHIP_FST_FOUR_TRIPS")) {
+            /* REAL field, one level: the field goes up once and the data part comes down once (compact_float + armn_compress on host arrays moved it
+             * over PCIe four times); the words behind the stream are what the in-place compressor leaves there (token words), as before */
+            const int zl = ezhip_pack16_compress_host(&data[1], fst129_words_after_length, (const float *)field, ni, nj, nbits);
+            if (zl < 0) {
+                out_datyp = 1;                                                      /* (sic: the missing-value flag is lost with the turbo flag, :1173) */
+                if (!packfunc(field, &data[0], &data[3], (int)n, nbits, 24, 1, 1, 0, &tempfloat)) goto done;
+            } else {
+                const int64_t nbytes = 16 + zl;
+                words = W64TOWD((nbytes * 8 + 63) / 64);
+                data[0] = (uint32_t)words;
+            }
+        } else if (datyp > 128 && nbits <= 16) {
             if (!packfunc(field, &data[1], &data[5], (int)n, nbits + 64 * imax(16, nbits), 0, 1, 1, 0, &tempfloat)) goto done;
             const int zl = armn_compress((unsigned char *)&data[5], ni, nj, nk, nbits, 1);
             if (zl < 0) {
@@ -394,6 +410,10 @@ int32_t ezhip_fst_unpack_data_ex(void *field, uint32_t *data, int32_t ni, int32_
     case 0: memcpy(field, data, (size_t)((n * nbits + 31) / 32) * 4); break;
     case 1: rc = packfunc(field, data, data + 3, (int)n, nbits, 24, 1, 2, 0, &tempfloat) ? 0 : -1; break;
     case 129:
+        if (!is_double && nk == 1 && nbits <= 16 && ni > 1 && nj > 1 && !getenv("EZHIP_FST_FOUR_TRIPS")) {      /* the record up, the field down (the data part is left as it is) */
+            rc = ezhip_uncompress_unpack16_host((float *)field, data + 1, (int64_t)data[0], ni, nj, nbits);
+            break;
+        }
         if (armn_compress((unsigned char *)(data + 5), ni, nj, nk, nbits, 2) < 0) return -1;
         rc = packfunc(field, data + 1, data + 5, (int)n, nbits + 64 * imax(16, nbits), 0, 1, 2, 0, &tempfloat) ? 0 : -1;
         break;

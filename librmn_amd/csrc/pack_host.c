@@ -27,7 +27,7 @@ static __thread void *t_scratch = NULL;
 /* per-thread grow-only device workspaces (slot 0/1: staged operands of the host-pointer entry points and the
  * compressed stream, slot 2: armn_compress scan storage): hipMalloc + hipFree per call cost more than the kernels
  * (a 52 MB hipMalloc/hipFree pair is ~0.4 ms and hipFree synchronises the device) */
-static __thread struct { void *p; size_t cap; } t_ws[6];
+static __thread struct { void *p; size_t cap; } t_ws[8];
 static void *ws(int slot, size_t bytes)
 {
     if (t_ws[slot].cap < bytes) {
@@ -41,7 +41,7 @@ static void *ws(int slot, size_t bytes)
 void ezhip_pack_release(void)
 {
     ezhip_sync();
-    for (int k = 0; k < 6; k++) { ezhip_free(t_ws[k].p); t_ws[k].p = NULL; t_ws[k].cap = 0; }
+    for (int k = 0; k < 8; k++) { ezhip_free(t_ws[k].p); t_ws[k].p = NULL; t_ws[k].cap = 0; }
     ezhip_free(t_scratch); t_scratch = NULL;
 }
 
@@ -630,6 +630,42 @@ int ezhip_uncompress_unpack16_dev(float *d_field, const void *d_record, int ni, 
         tok = d_tok;
     }
     if (!compact_float_dev(d_field, (void *)rec, (void *)tok, (int)n, nbits + 64 * (nbits > 16 ? nbits : 16), 0, 1, 2, 0, &tag, 2)) return -1;
+    return 0;
+}
+
+/* The same two steps between HOST arrays with ONE trip each way (what c_fstecr / c_fstluk do for datyp 129, nbits <= 16: fstd98.c:1170-1172, :2285-2290):
+ * through compact_float + armn_compress on host arrays a field crossed PCIe four times (up, tokens down, tokens up, stream down).
+ * ezhip_pack16_compress_host: the field goes up, `out_words` words [4 header words][stream][what the token array held behind it, as the in-place
+ * compressor leaves it] come down; returns zlng, or < 0 when compression does not pay (nothing written: the caller packs the plain form).
+ * ezhip_uncompress_unpack16_host: the record goes up, the field comes down. */
+int32_t ezhip_pack16_compress_host(uint32_t *record, int64_t (*out_words_of)(int32_t zlng), const float *field, int32_t ni, int32_t nj, int32_t nbits)
+{
+    if (need_device("ezhip_pack16_compress_host")) return -1;
+    const size_t n = (size_t)ni * nj;
+    if (!record || !field || !out_words_of || n == 0 || nbits < 1 || nbits > 16) return -1;
+    float *d_f = (float *)ws(6, 4 * n + 64);
+    unsigned *d_rec = (unsigned *)ws(7, 4 * (4 + n / 2 + 64));
+    if (!d_f || !d_rec) return -1;
+    if (ezhip_h2d(d_f, field, 4 * n)) return -1;
+    const int zl = ezhip_pack16_compress_dev(d_rec, d_f, ni, nj, nbits);
+    if (zl <= 0) return zl < 0 ? zl : -1;
+    int64_t nw = out_words_of(zl);
+    if (nw > (int64_t)(4 + (n + 1) / 2)) nw = (int64_t)(4 + (n + 1) / 2);
+    if (ezhip_d2h(record, d_rec, 4 * (size_t)nw) || ezhip_sync()) return -1;
+    return zl;
+}
+int32_t ezhip_uncompress_unpack16_host(float *field, const uint32_t *record, int64_t record_words, int32_t ni, int32_t nj, int32_t nbits)
+{
+    if (need_device("ezhip_uncompress_unpack16_host")) return -1;
+    const size_t n = (size_t)ni * nj, cap = 4 + n / 2 + 64;
+    if (!record || !field || n == 0 || nbits < 1 || nbits > 16 || record_words < 5) return -1;
+    if ((size_t)record_words > cap) record_words = (int64_t)cap;
+    float *d_f = (float *)ws(6, 4 * n + 64);
+    unsigned *d_rec = (unsigned *)ws(7, 4 * cap);
+    if (!d_f || !d_rec) return -1;
+    if (ezhip_h2d(d_rec, record, 4 * (size_t)record_words)) return -1;
+    if (ezhip_uncompress_unpack16_dev(d_f, d_rec, ni, nj, nbits, 1) < 0) { ezhip_sync(); return -1; }
+    if (ezhip_d2h(field, d_f, 4 * n) || ezhip_sync()) return -1;
     return 0;
 }
 
