@@ -62,6 +62,7 @@ typedef struct ezh_set {
     float *d_poles_batch; int poles_cap;   /* pole values of a c_ezsint_batch_dev batch (2 per field) */
     float *d_prow;          /* 2 * ni_src synthetic polar wind rows (vector mode), u then v: [u_n, u_s, v_n, v_s] */
     float *d_avg[2];        /* interp_degree = average / sph_average: [x | row widening | y_low | y_high] of the target cells (ez_avg.inc:55-78, ez_avg_sph.inc:63-98) */
+    int *d_cspec_list; float *d_cspec_xy; int cspec_count, cspec_key;      /* the special points (polar strips, re-interpolated extrapolation) of the wind-pair launch, kept after its first call: index, x, y; key = the zone options they were listed under (0: none yet) */
     float *d_lamb_cs[2];    /* c_ezuvint from / towards a Lambert '!' grid: {cos, sin} of its rotation angle at the target points' longitudes (source leg, target leg) */
     void *d_windM;          /* c_ezuvint through a rotated frame: the wind chain of this grid pair as a 2 x 2 matrix per target point (built on first use) */
     /* Yin-Yang 'U' source (c_ezyy_calcxy, ezyy_calcxy.c): per subgrid the list of target points it serves */
@@ -808,7 +809,7 @@ static void free_set(ezh_set *s)
 {
     for (int d = 0; d < 3; d++) for (int v = 0; v < 2; v++) free_sepplan(&s->sep[d][v]);
     free(s->x1d); free(s->y1d);
-    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_lamb_cs[0]); ezhip_free(s->d_lamb_cs[1]); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
+    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_lamb_cs[0]); ezhip_free(s->d_lamb_cs[1]); ezhip_free(s->d_cspec_list); ezhip_free(s->d_cspec_xy); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
     for (int k = 0; k < 2; k++) { ezhip_free(s->d_yy_x[k]); ezhip_free(s->d_yy_y[k]); ezhip_free(s->d_yy_lat[k]); ezhip_free(s->d_yy_lon[k]); ezhip_free(s->d_yy_idx[k]); }
     for (int k = 0; k < 4; k++) ezhip_free(s->d_yy_tmp[k]);
     free(s);
@@ -2483,7 +2484,31 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
     if (zones == 2 && s->have_dehors) ierc = 2;
     pu.tile_ni = go->ni; pu.tile_nj = go->nj;                  /* the points are the whole target grid in row order: 2-D tile order */
     if (t_pwjob.active) { pu.pw_out = t_pwjob.out; pu.pw_plon2 = t_pwjob.plon2; pu.pw_xg4_n = t_pwjob.xg4_n; pu.pw_xg4_s = t_pwjob.xg4_s; pu.pw_weighted = t_pwjob.weighted; pu.pw_ax = t_pwjob.ax; t_pwjob.active = 0; }
+    /* the special points of the set under these zone options: listed by the first launch, kept with the set, handed to the later ones */
+    const int key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4 | degree << 12;
+    const int use_cache = !getenv("EZHIP_NO_SPEC_CACHE");
+    if (use_cache) {
+        pthread_mutex_lock(&g_plan_mtx);
+        if (s->cspec_key == key) {
+            pu.cspec_valid = 1; pu.cspec_count = s->cspec_count; pu.cspec_list = s->d_cspec_list;
+            pu.cspec_x = s->d_cspec_xy; pu.cspec_y = s->d_cspec_xy ? s->d_cspec_xy + s->cspec_count : NULL;
+        }
+        pthread_mutex_unlock(&g_plan_mtx);
+    }
     if (ezhip_interp_pts2(&pu, &pv, d_uo, d_vo, d_ui, d_vi, s->d_x, s->d_y, go->ni * go->nj)) return -1;
+    if (use_cache && !pu.cspec_valid && s->cspec_key == 0) {              /* (the first option set seen on the set is the one that is kept: the arrays are never replaced while launches may read them) */
+        const int cnt = ezhip_pts2_special_snapshot(NULL, NULL, NULL, 0, s->d_x, s->d_y);        /* synchronises: once per set and option set */
+        if (cnt >= 0) {
+            int *dl = cnt ? (int *)ezhip_malloc(sizeof(int) * (size_t)cnt) : NULL;
+            float *dxy = cnt ? (float *)ezhip_malloc(sizeof(float) * 2 * (size_t)cnt) : NULL;
+            if (cnt == 0 || (dl && dxy && ezhip_pts2_special_snapshot(dl, dxy, dxy + cnt, cnt, s->d_x, s->d_y) == cnt)) {
+                pthread_mutex_lock(&g_plan_mtx);
+                if (s->cspec_key == 0) { s->d_cspec_list = dl; s->d_cspec_xy = dxy; s->cspec_count = cnt; s->cspec_key = key; dl = NULL; dxy = NULL; }
+                pthread_mutex_unlock(&g_plan_mtx);
+            }
+            ezhip_free(dl); ezhip_free(dxy);                        /* (another thread was first, or the copy failed) */
+        }
+    }
     return ierc;
 }
 

@@ -2694,7 +2694,7 @@ __device__ __forceinline__ void pts2_body(ezhip_pts_plan p, float *__restrict__ 
         }
         zout1[o] = a; zout2[o] = b;
     }
-    const bool sp = zone == PZ_REINTERP || zone == PZ_STRIP_S || zone == PZ_STRIP_N;
+    const bool sp = (zone == PZ_REINTERP || zone == PZ_STRIP_S || zone == PZ_STRIP_N) && special_list != nullptr;      /* (nullptr: the host already knows this set's special points) */
     const unsigned long long m = __ballot(sp);
     if (sp) {
         const int lane = (int)__lane_id(), leader = __ffsll((long long)m) - 1;
@@ -2789,6 +2789,41 @@ __global__ __launch_bounds__(256) void k_pts_special2(ezhip_pts_plan p, float *_
     }
 }
 
+/* the same with the points known to the host (ezhip_pts_plan.cspec_*): index, x and y of point k side by side, their number by value */
+__global__ __launch_bounds__(256) void k_pts_special2c(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+                                                       const float *__restrict__ zin1, const float *__restrict__ zin2,
+                                                       const float *__restrict__ prow_n2, const float *__restrict__ prow_s2)
+{
+    const unsigned cnt = (unsigned)p.cspec_count;
+    for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+        const int n = p.cspec_list[k];
+        const float px = p.cspec_x[k], py = p.cspec_y[k];
+        const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;
+        float4 m = make_float4(1.f, 0.f, 0.f, 1.f);
+        if (p.wind_M) m = ((const float4 *)p.wind_M)[o];       /* on its way while the stencils are gathered */
+        const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
+        FieldAcc Z1, Z2;
+        Z1.z = zin1; Z1.ni = p.ni; Z1.j1 = p.j1; Z1.j2 = p.j2; Z1.pole_n = 0.f; Z1.pole_s = 0.f; Z1.prow_n = nullptr; Z1.prow_s = nullptr;
+        Z2 = Z1; Z2.z = zin2;
+        float a, b;
+        if (zone == PZ_REINTERP) { a = gdinterp_point(p, Z1, p.degre_extrap, px, py); b = gdinterp_point(p, Z2, p.degre_extrap, px, py); }
+        else {
+            Z1.prow_n = p.pole_row_n; Z1.prow_s = p.pole_row_s; Z2.prow_n = prow_n2; Z2.prow_s = prow_s2;
+            a = strip_point(p, Z1, zone == PZ_STRIP_N, px, py); b = strip_point(p, Z2, zone == PZ_STRIP_N, px, py);
+        }
+        if (p.wind_M) { const float u = a, v = b; d_wind_matrix_apply(m.x, m.y, m.z, m.w, u, v, p.wind_dst_rot, a, b); }
+        zout1[o] = a; zout2[o] = b;
+    }
+}
+__global__ __launch_bounds__(256) void k_spec_gather(int *__restrict__ list_out, float *__restrict__ x_out, float *__restrict__ y_out,
+                                                     const int *__restrict__ list_in, const float *__restrict__ xs, const float *__restrict__ ys, unsigned cnt)
+{
+    const unsigned k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cnt) return;
+    const int n = list_in[k];
+    list_out[k] = n; x_out[k] = xs[n]; y_out[k] = ys[n];
+}
+
 /* per host thread: the list of special point indices of a launch and a PAIR of counters (the special kernel of
  * launch e consumes counter e & 1 and zeroes the other one for launch e + 1: no memset between launches) */
 static thread_local struct { int *list; unsigned *count; size_t cap; unsigned epoch; } t_spec;
@@ -2850,8 +2885,10 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
         if (hipMemsetAsync(t_spec.count, 0, 64, g_stream) != hipSuccess) return -1;
         t_spec.cap = (size_t)npts; t_spec.epoch = 0;
     }
+    const bool cached = plan_u->cspec_valid && plan_u->vector_mode;      /* the set's special points are known: nothing is listed, no counter is used */
     unsigned *cnt = t_spec.count + (t_spec.epoch & 1), *cnt_next = t_spec.count + ((t_spec.epoch + 1) & 1);
-    t_spec.epoch++;
+    if (!cached) t_spec.epoch++;
+    int *list_arg = cached ? nullptr : t_spec.list;
     ezhip_pts_plan pu2 = *plan_u;
     pu2.newton_literal = getenv("EZHIP_WIND_NEWTON_LITERAL") ? 1 : 0;      /* development: the reference's literal Newton form for winds too */
     pu2.xcd_order = getenv("EZHIP_PTS_XCD") ? 1 : 0;                        /* development: XCD k takes the k-th eighth of the blocks (fewer fabric reads, measured slower) */
@@ -2866,8 +2903,8 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
         pu2.pw_out = nullptr;
     }
     const dim3 grid((pu2.tile_ni > 0 ? (unsigned)(((pu2.tile_ni + 31) / 32) * ((pu2.tile_nj + 7) / 8)) : (unsigned)((npts + 255) / 256)) + (pu2.pw_out ? 2u : 0u));
-#define PTS2_CASE(K) case K: if (K == PK_IRGD3_W && !pu2.newton_literal) hipLaunchKernelGGL(k_pts2_irgd3w, grid, block, 0, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, t_spec.list, cnt); \
-        else hipLaunchKernelGGL(k_pts2<K>, grid, block, 0, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, t_spec.list, cnt); break
+#define PTS2_CASE(K) case K: if (K == PK_IRGD3_W && !pu2.newton_literal) hipLaunchKernelGGL(k_pts2_irgd3w, grid, block, 0, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, list_arg, cnt); \
+        else hipLaunchKernelGGL(k_pts2<K>, grid, block, 0, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, list_arg, cnt); break
     switch (pts_kind(plan_u)) {
     PTS2_CASE(PK_RGD0); PTS2_CASE(PK_RGD1_NW); PTS2_CASE(PK_RGD1_W); PTS2_CASE(PK_RGD3_NW); PTS2_CASE(PK_RGD3_W);
     PTS2_CASE(PK_IRGD1_NW); PTS2_CASE(PK_IRGD1_W); PTS2_CASE(PK_IRGD3_NW); PTS2_CASE(PK_IRGD3_W);
@@ -2875,6 +2912,14 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
 #undef PTS2_CASE
     if (LAUNCH_CHECK("k_pts2")) return -1;
     if (ezhip_side_join()) return -1;
+    if (cached) {
+        if (plan_u->cspec_count > 0) {
+            const unsigned nbk = (unsigned)((plan_u->cspec_count + 255) / 256);
+            hipLaunchKernelGGL(k_pts_special2c, dim3(nbk < 256 ? nbk : 256), block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v, plan_v->pole_row_n, plan_v->pole_row_s);
+            return LAUNCH_CHECK("k_pts_special2c");
+        }
+        return 0;
+    }
     if (!plan_u->vector_mode) {          /* two scalar fields sharing a point list: their pole values differ, one launch each */
         hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan_u, d_out_u, d_in_u, d_x, d_y, t_spec.list, cnt, cnt_next);
         hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan_v, d_out_v, d_in_v, d_x, d_y, t_spec.list, cnt, cnt_next);
@@ -2884,6 +2929,22 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     hipLaunchKernelGGL(k_pts_special2, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v,
                        plan_v->pole_row_n, plan_v->pole_row_s, d_x, d_y, t_spec.list, cnt, cnt_next);
     return LAUNCH_CHECK("k_pts_special2");
+}
+
+extern "C" int ezhip_pts2_special_snapshot(int *d_list_out, float *d_x_out, float *d_y_out, int cap, const float *d_xs, const float *d_ys)
+{
+    if (!t_spec.count || t_spec.epoch == 0) return -1;
+    unsigned h = 0;
+    /* the counter the last launch consumed keeps its value until the launch after the next one zeroes it */
+    if (set_err(hipMemcpyAsync(&h, t_spec.count + ((t_spec.epoch - 1) & 1), sizeof(h), hipMemcpyDeviceToHost, g_stream), "special count") ||
+        set_err(hipStreamSynchronize(g_stream), "special count")) return -1;
+    if (h > (unsigned)0x7fffffff || (size_t)h > t_spec.cap) return -1;
+    if (d_list_out && h > 0) {
+        if ((unsigned)cap < h) return -1;
+        hipLaunchKernelGGL(k_spec_gather, dim3((h + 255) / 256), dim3(256), 0, g_stream, d_list_out, d_x_out, d_y_out, t_spec.list, d_xs, d_ys, h);
+        if (LAUNCH_CHECK("k_spec_gather") || set_err(hipStreamSynchronize(g_stream), "special points")) return -1;
+    }
+    return (int)h;
 }
 
 /* ===================================================================================== */

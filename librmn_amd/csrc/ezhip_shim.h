@@ -194,6 +194,9 @@ size_t ezhip_sepenc_lds_bytes(const ezhip_sep_plan *plan);
 int ezhip_interp_sep_enc(const ezhip_sep_plan *plan, const ezhip_sepenc_args *args);
 
 int ezhip_interp_sep(const ezhip_sep_plan *plan, float *d_zout, const float *d_zin);
+/* after an ezhip_interp_pts2 launch of the calling thread that listed its special points: their number (synchronises the stream); with arrays of that many
+ * elements also the points themselves (index, x, y), copied on the device.  -1 on error */
+int ezhip_pts2_special_snapshot(int *d_list_out, float *d_x_out, float *d_y_out, int cap, const float *d_xs, const float *d_ys);
 /* exact {min, max} of the values ezhip_interp_sep would store for nfields fields (plan->bb_ok), asynchronous: d_partials[f * stride_words + 0..2] :=
  * {min key, max key, 0} (the triple layout k_cf_header reduces); d_flags[f] := 1 when too many windows qualify (the caller then runs the
  * interpolating pass for that field); d_poles: [2 nfields] pole values from ezhip_polevals_batch (plans with need_poles).  d_work: ezhip_bb_work_bytes */
@@ -234,6 +237,10 @@ typedef struct {
     /* the synthetic polar wind rows of the pair (k_polar_wind's job) riding in the k_pts2 launch as two producer blocks: only the special points, handled by
      * the NEXT kernel, read them.  pw_out != NULL: out4 = [u north | u south | v north | v south] rows of ni floats */
     float *pw_out; const float *pw_plon2; float pw_xg4_n, pw_xg4_s; int pw_weighted; const float *pw_ax;
+    /* the special points of a grid set depend on its located x, y and the zone options only: once a launch has listed them the host keeps them with the set
+     * (ezhip_pts2_special_snapshot) and later launches take them from here -- k_pts2 lists nothing, the special kernel reads n, x, y side by side instead of
+     * count -> list -> x, y (three dependent round trips) */
+    int cspec_valid, cspec_count; const int *cspec_list; const float *cspec_x, *cspec_y;
     int tile_ni, tile_nj;             /* > 0: the points are a whole ni x nj target grid in row order: k_pts2 walks it in 32 x 8 tiles (a wave = 8 x 8 points: its stencils
                                          share a few cache lines; 64 points of one target row cross a dozen source rows of a rotated source) */
 } ezhip_pts_plan;
