@@ -548,7 +548,20 @@ int32_t ezhip_armn_uncompress_batch_dev(void *d_words, int64_t out_stride_words,
     char *d_work = (char *)ws(2, per * (size_t)nfields + 4 * (size_t)nfields + 256);
     if (!d_work) return -1;
     int *d_status = (int *)(d_work + per * (size_t)nfields);
-    if (packhip_armn_decode((unsigned *)d_words, (size_t)out_stride_words, (const unsigned *)d_z, (size_t)z_stride_words, (size_t)z_words,
+    if (nfields >= 8 && out_stride_words > 0 && z_stride_words > 0 && !getenv("EZHIP_DEC_ONE_STREAM")) {
+        /* a batch in two halves: the chain kernels of the first half (one CU per stream, ~half of a batch's time) run beside the speculation and composition
+         * kernels of the second half, which fill the device: first half up to its composed table; second half whole, on the side stream, from there on;
+         * the first half's chain kernel and what follows on the caller's stream meanwhile */
+        const int h = nfields / 2;
+        unsigned *o = (unsigned *)d_words; const unsigned *z = (const unsigned *)d_z;
+        if (packhip_armn_decode_phase(o, (size_t)out_stride_words, z, (size_t)z_stride_words, (size_t)z_words, ni, nj, h, g_swap == 1, d_work, per, d_status, 1)) return -1;
+        if (ezhip_side_begin()) return -1;
+        int bad = packhip_armn_decode_phase(o + (size_t)h * (size_t)out_stride_words, (size_t)out_stride_words, z + (size_t)h * (size_t)z_stride_words, (size_t)z_stride_words,
+                                            (size_t)z_words, ni, nj, nfields - h, g_swap == 1, d_work + per * (size_t)h, per, d_status + h, 0);
+        if (ezhip_side_end()) bad = 1;
+        if (!bad) bad = packhip_armn_decode_phase(o, (size_t)out_stride_words, z, (size_t)z_stride_words, (size_t)z_words, ni, nj, h, g_swap == 1, d_work, per, d_status, 2);
+        if (ezhip_side_join() || bad) { ezhip_sync(); return -1; }
+    } else if (packhip_armn_decode((unsigned *)d_words, (size_t)out_stride_words, (const unsigned *)d_z, (size_t)z_stride_words, (size_t)z_words,
                             ni, nj, nfields, g_swap == 1, d_work, per, d_status)) return -1;
     int st[64], rc = ni * nj * 2;
     for (int f0 = 0; f0 < nfields; f0 += 64) {

@@ -62,6 +62,8 @@ int packhip_sepenc_prefix(unsigned *d_z, size_t z_stride_words, size_t z_cap_wor
                           const unsigned *d_head, const int *d_zlng, int ni, int nj, int nbits, int container, int nfields);
 /* armn_compress UNCOMPRESS (unpack_kernels.hip): nfields streams of z_words capacity each -> (1 + ni*nj/2) token words each */
 size_t packhip_armn_dec_work_bytes(int ni, int nj, size_t z_words);
+int packhip_armn_decode_phase(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
+                              int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status, int phase);      /* 0 all, 1 up to the composed table, 2 the chain kernel and what follows */
 int packhip_armn_decode(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
                         int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status);
 /* ---- IEEE-32 compressor (armn32_kernels.hip): planes of a float field and the parallelogram coder on a plane ---- */

@@ -674,8 +674,18 @@ extern "C" size_t packhip_armn_dec_work_bytes(int ni, int nj, size_t z_words)
 
 /* d_out: (1 + ni*nj/2) words per field, zero-filled first (the odd trailing half-word).  d_status: one int per field
  * (0 ok, -1 unknown header, -2 broken chain).  Everything is asynchronous on the current stream. */
+extern "C" int packhip_armn_decode_phase(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
+                                         int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status, int phase);
 extern "C" int packhip_armn_decode(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
                                    int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status)
+{
+    return packhip_armn_decode_phase(d_out, out_stride_words, d_z, z_stride_words, z_words, ni, nj, nfields, swap, d_work, work_stride_bytes, d_status, 0);
+}
+/* phase 0: everything; 1: the kernels that run on all CUs in front of the chain kernel (speculation, composed table); 2: the chain kernel and what follows.
+ * A caller with a batch runs phase 1 of one half, then ALL of the other half on a second stream, then phase 2 of the first half: the chain kernels (one CU
+ * per stream) of the first half run beside the all-CU kernels of the second */
+extern "C" int packhip_armn_decode_phase(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
+                                         int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status, int phase)
 {
     static int attr_done = 0;
     if (!attr_done) {
@@ -697,6 +707,7 @@ extern "C" int packhip_armn_decode(unsigned *d_out, size_t out_stride_words, con
     unsigned *went = (unsigned *)wk;                        wk += al256(8 * (size_t)nwin);
     unsigned *went8 = (unsigned *)wk;
     const size_t ws4 = work_stride_bytes / 4, ws2 = work_stride_bytes / 2;
+    if (phase != 2) {
     for (int f = 0; f < nfields; f++) {
         if (hipMemsetAsync(d_out + (size_t)f * out_stride_words, 0, 4 * (1 + n / 2), st) != hipSuccess) return -1;
         if (hipMemsetAsync((char *)went + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
@@ -709,6 +720,8 @@ extern "C" int packhip_armn_decode(unsigned *d_out, size_t out_stride_words, con
         const int G = 28, lds_words = (3 * G + 17) * 160;          /* 64 640 B: G windows of 160-entry rows (t1: G + 7 rows, t2: G + 6, t4: G + 4) */
         hipLaunchKernelGGL(k_armn_dec_compose_lds, dim3((nwin + G - 1) / G, nfields), dim3(CMP_TPB), (size_t)4 * lds_words, st, d_z, z_stride_words, ni, nj, tab, tab8, ws4, nwin, G, lds_words);
     }
+    }
+    if (phase == 1) { hipError_t e1 = hipGetLastError(); if (e1 != hipSuccess) { fprintf(stderr, "<armn_compress> UNCOMPRESS launch failed: %s\n", hipGetErrorString(e1)); return -1; } return 0; }
     hipLaunchKernelGGL(k_armn_dec_hop, dim3(nfields), dim3(HOP_TPB), HOP_LDS, st, d_z, z_stride_words, z_words, ni, nj, tab, tab8, ws4, went, went8, ws4, nwin, d_status, getenv("EZHIP_DEC_DEBUG") ? atoi(getenv("EZHIP_DEC_DEBUG")) : 0);
     hipLaunchKernelGGL(k_armn_dec_expand8, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, ws4, went, went8, ws4, nwin);
     hipLaunchKernelGGL(k_armn_dec_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, went, ws4, tilepos, ws4, nwin);
