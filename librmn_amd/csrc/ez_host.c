@@ -2403,10 +2403,10 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
             /* a lone field: the special rows go last in the work order (mid-order they hold slots while the pole
              * producers of the same launch run) */
             p.special_last = 1;
-            if (p.need_poles && !getenv("EZHIP_SINGLE_RB")) {     /* measured at cfg2, polar on: 44.3 us with 9 row-blocks per thread block, 39.7 with 6 */
-                int rb = (2 * p.x_rb + 1) / 3;
-                if (rb >= 1) { p.x_rb = rb; p.x_nseg = (p.x_nvb + rb - 1) / rb; }
-            }
+            /* the plan's row-blocks per thread block make the main blocks of ONE field just fill the device (strips x segments <= co-resident thread
+             * blocks): kept for a lone field.  (With three thread blocks per CU two thirds of it were faster: 44.3 -> 39.7 us at cfg2; with four -- 39.7 KB
+             * of LDS -- one full round wins: 29.3 - 30.7 us against 30.7 - 32.8 with five row-blocks and 32.2 - 32.4 with six or eight, tools/sweep_lone.py
+             * interleaved on one device.  EZHIP_SINGLE_RB overrides) */
             if (getenv("EZHIP_SINGLE_RB")) { int rb = atoi(getenv("EZHIP_SINGLE_RB")); if (rb >= 1) { p.x_rb = rb; p.x_nseg = (p.x_nvb + rb - 1) / rb; } }
             if (getenv("EZHIP_SPECIAL_PCT")) { int pct = atoi(getenv("EZHIP_SPECIAL_PCT")); if (pct >= 0 && pct <= 100) p.special_last = 2 + p.x_nseg * pct / 100; }     /* development: special rows at pct % of the work order */
         }
