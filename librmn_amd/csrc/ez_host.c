@@ -2594,6 +2594,7 @@ static int32_t batch_impl_o(float *d_zout, const float *d_zin, int32_t nfields, 
                 }
             }
             p.batch_fields = nfields; p.batch_in_stride = nin; p.batch_out_stride = nout;
+            if (getenv("EZHIP_DEBUG")) p.debug_flags = atoi(getenv("EZHIP_DEBUG"));      /* development: the kernel's knock-outs / variants at call time too (the plan keeps what the environment held when it was built) */
             if (getenv("EZHIP_BATCH_RB")) { int rb = atoi(getenv("EZHIP_BATCH_RB")); if (rb >= 1) { p.x_rb = rb; p.x_nseg = (p.x_nvb + rb - 1) / rb; } }      /* development: row-blocks per thread block of a batch launch */
             if (getenv("EZHIP_BATCH_SPECIAL_PCT")) { int pct = atoi(getenv("EZHIP_BATCH_SPECIAL_PCT")); if (pct >= 0 && pct <= 100) p.special_last = 2 + p.x_nseg * pct / 100; }      /* development: the special rows at pct % of a field's work order (default: the middle) */
             if (bo) {
