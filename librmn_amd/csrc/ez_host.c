@@ -2600,7 +2600,13 @@ static int32_t batch_impl_o(float *d_zout, const float *d_zin, int32_t nfields, 
             if (bo) {
                 if (bo->mode == 3 && (p.ni_dst & 1)) return -2;               /* a token word holds two columns of one row */
                 p.out_mode = bo->mode; p.quant_params = bo->qparams; p.quant_stride = bo->qstride;
-                if (bo->mode == 3) p.batch_out_stride = bo->out_stride_words;
+                if (bo->mode == 3) {
+                    p.batch_out_stride = bo->out_stride_words;
+                    /* the token pass stores half the bytes of the float pass: the source rows a thread block stages again where the one above it stopped weigh
+                     * more, and longer walks down a strip pay (tools/sweep_cfg5.py, interleaved: 79.2 us per field of the cfg5 pipeline with the plan's 7
+                     * row-blocks per thread block, 78.2 with 10, 77.9 with 14, 77.6 with 19, 77.9 with 28; the float pass is flat from 7 to 14) */
+                    if (!getenv("EZHIP_BATCH_RB")) { int rb = (8 * p.x_rb + 2) / 3; if (rb > p.x_nvb) rb = p.x_nvb; if (rb >= 1) { p.x_rb = rb; p.x_nseg = (p.x_nvb + rb - 1) / rb; } }
+                }
             }
             if (stat_partials) {
                 int nbx = (p.ni_dst + EZHIP_SEP_COLS - 1) / EZHIP_SEP_COLS, npf = nbx * (p.x_nseg + p.n_special);
