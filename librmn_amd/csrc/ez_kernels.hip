@@ -2653,12 +2653,19 @@ __device__ __forceinline__ void pts2_body(ezhip_pts_plan p, float *__restrict__ 
 {
     int n;
     if (p.tile_ni > 0) {
-        /* 2-D order: block = 32 x 8 target points, wave = 8 x 8.  The TCP (vector L1) looks up about one cache line per cycle; 64 consecutive points of a
+        /* 2-D order: a wave = a patch of target points (16 x 4 since the end of round 3; 8 x 8 before).  The TCP (vector L1) looks up about one cache line per cycle; 64 consecutive points of a
          * target row touch ~10 lines per stencil-row load when the source is rotated, an 8 x 8 patch 2 - 3.  The four waves of a block sit side by side:
          * their 32-byte row pieces of x, y and the outputs make whole 128-byte lines */
-        const unsigned tpr = ((unsigned)p.tile_ni + 31u) >> 5, b = p.xcd_order ? pts_block(blockIdx.x - boff, gridDim.x - boff) : blockIdx.x - boff;
+        /* p.tile_shape: 1 (default) = a wave 16 x 4, a block 64 x 4; 0 = a wave 8 x 8, a block 32 x 8; 2 = a wave 4 x 16, a block 16 x 16; 3 .. 5 below */
+        const unsigned bw = p.tile_shape == 1 ? 64u : p.tile_shape == 2 ? 16u : p.tile_shape == 3 ? 128u : p.tile_shape == 5 ? 16u : 32u;
+        const unsigned tpr = ((unsigned)p.tile_ni + bw - 1u) / bw, b = p.xcd_order ? pts_block(blockIdx.x - boff, gridDim.x - boff) : blockIdx.x - boff;
         const unsigned by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
-        const unsigned cx_ = bx * 32u + (t >> 6) * 8u + (t & 7u), cy_ = by * 8u + ((t >> 3) & 7u);
+        unsigned cx_ = bx * 32u + (t >> 6) * 8u + (t & 7u), cy_ = by * 8u + ((t >> 3) & 7u);
+        if (p.tile_shape == 1) { cx_ = bx * 64u + (t >> 6) * 16u + (t & 15u); cy_ = by * 4u + ((t >> 4) & 3u); }
+        else if (p.tile_shape == 2) { cx_ = bx * 16u + (t >> 6) * 4u + (t & 3u); cy_ = by * 16u + ((t >> 2) & 15u); }
+        else if (p.tile_shape == 3) { cx_ = bx * 128u + (t >> 6) * 32u + (t & 31u); cy_ = by * 2u + ((t >> 5) & 1u); }                       /* a wave 32 x 2, a block 128 x 2 */
+        else if (p.tile_shape == 4) { cx_ = bx * 32u + ((t >> 6) & 1u) * 16u + (t & 15u); cy_ = by * 8u + (t >> 7) * 4u + ((t >> 4) & 3u); }    /* a wave 16 x 4, a block 32 x 8 (2 x 2 waves) */
+        else if (p.tile_shape == 5) { cx_ = bx * 16u + (t & 15u); cy_ = by * 16u + (t >> 6) * 4u + ((t >> 4) & 3u); }                            /* a wave 16 x 4, a block 16 x 16 (waves stacked) */
         if (cx_ >= (unsigned)p.tile_ni || cy_ >= (unsigned)p.tile_nj) return;
         n = (int)(cy_ * (unsigned)p.tile_ni + cx_);
     } else n = (int)(p.xcd_order ? pts_block(blockIdx.x - boff, gridDim.x - boff) : blockIdx.x - boff) * 256 + threadIdx.x;
@@ -2902,7 +2909,12 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
         if (ezhip_side_end() || bad) return -1;
         pu2.pw_out = nullptr;
     }
-    const dim3 grid((pu2.tile_ni > 0 ? (unsigned)(((pu2.tile_ni + 31) / 32) * ((pu2.tile_nj + 7) / 8)) : (unsigned)((npts + 255) / 256)) + (pu2.pw_out ? 2u : 0u));
+    /* a wave = 16 x 4 target points, a block = 64 x 4 (tools/sweep_cfg3.py, interleaved, cfg3: 108.7 us per pair; a wave 8 x 8 in a block 32 x 8 -- the first tile order --
+     * 111.1; 16 x 4 in a block 32 x 8: 109.1; in a block 16 x 16: 114.0; a wave 32 x 2: 117.6; 4 x 16: 136.2).  EZHIP_PTS_TILE: 0 = 8 x 8, 2 .. 5 the others */
+    pu2.tile_shape = getenv("EZHIP_PTS_TILE") ? atoi(getenv("EZHIP_PTS_TILE")) : 1;
+    const int tbw = pu2.tile_shape == 1 ? 64 : pu2.tile_shape == 2 ? 16 : pu2.tile_shape == 3 ? 128 : pu2.tile_shape == 5 ? 16 : 32;
+    const int tbh = pu2.tile_shape == 1 ? 4 : pu2.tile_shape == 2 ? 16 : pu2.tile_shape == 3 ? 2 : pu2.tile_shape == 5 ? 16 : 8;
+    const dim3 grid((pu2.tile_ni > 0 ? (unsigned)(((pu2.tile_ni + tbw - 1) / tbw) * ((pu2.tile_nj + tbh - 1) / tbh)) : (unsigned)((npts + 255) / 256)) + (pu2.pw_out ? 2u : 0u));
 #define PTS2_CASE(K) case K: if (K == PK_IRGD3_W && !pu2.newton_literal) hipLaunchKernelGGL(k_pts2_irgd3w, grid, block, 0, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, list_arg, cnt); \
         else hipLaunchKernelGGL(k_pts2<K>, grid, block, 0, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, list_arg, cnt); break
     switch (pts_kind(plan_u)) {

@@ -233,7 +233,7 @@ typedef struct {
     const float *fill;                /* device scalar */
     const float *polevals;            /* device float[2] = {north, south}; computed by ezhip_polevals */
     const int *out_idx;               /* NULL, or target position of point n (Yin-Yang lists: no temporary + scatter pass) */
-    int newton_literal, xcd_order;    /* development switches of k_pts2 (set by its launcher from the environment) */
+    int newton_literal, xcd_order, tile_shape;    /* development switches of k_pts2 (set by its launcher from the environment) */
     /* the synthetic polar wind rows of the pair (k_polar_wind's job) riding in the k_pts2 launch as two producer blocks: only the special points, handled by
      * the NEXT kernel, read them.  pw_out != NULL: out4 = [u north | u south | v north | v south] rows of ni floats */
     float *pw_out; const float *pw_plon2; float pw_xg4_n, pw_xg4_s; int pw_weighted; const float *pw_ax;
