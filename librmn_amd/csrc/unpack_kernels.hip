@@ -7,7 +7,7 @@
  * position is known only once every earlier header has been read (~100 clk per tile for one lane: 0.25 s for the
  * 2.9 M tiles of a cfg2 field, the speed of the CPU decoder).  The chain is resolved in three kernels:
  *
- *   k_armn_dec_spec   speculation, all CUs: the stream is cut into windows of DW = 1024 bits.  A tile is at most `ext`
+ *   k_armn_dec_spec   speculation, all CUs: the stream is cut into windows of DW = 2048 bits.  A tile is at most `ext`
  *                     bits long, so the chain enters a window at one of its first `ext` bit positions; for EVERY such
  *                     entry the walk through the window (as if a tile header started there, interior point count) is
  *                     recorded: where it leaves the window and how many tiles it saw: tab[window][entry].  One wave per
@@ -41,13 +41,12 @@
 extern "C" void *ezhip_get_stream(void);
 #define STREAM ((hipStream_t)ezhip_get_stream())
 
-#define DW        1024                  /* bits per window (measured: 512 -> 40 ms, 1024 -> 24 ms, 2048 -> 27 ms, 4096 worse, before the 8-window table) */
+#define DW        2048                  /* bits per window (round 1, before the 8-window table and with row-end windows walked tile by tile: 512 -> 40 ms, 1024 -> 24 ms, 2048 -> 27 ms; round 3, see profiles/r03_experiments.txt) */
 #define DWW       (DW / 32)
 #define DEXT      416                   /* table entries per window: >= the longest tile (MINIMUM: 4 + 25 x 16 bits) */
 #define DTAIL     16                    /* stream words staged past a window (>= DEXT + 32 bits) */
 #define HOP_TPB   1024
 #define HOP_NP    (DW + DEXT)           /* bit positions a walk inside one window can reach (the last tile may end DEXT bits past it) */
-static_assert(HOP_TPB == DW, "the doubling rounds of k_armn_dec_hop give every thread one bit position of a window");
 #define HOP_DBL_WORDS (2 * HOP_NP)      /* [2][HOP_NP] words: {successor | tiles << 16} */
 #define HOP_DENSE 20                    /* tiles in a row-end window from which the workgroup resolves it (measured: below, wave 0 walking it tile by tile is faster) */
 #define HOP_LDS   (156 * 1024)          /* of the CU's 160 KB: 112 windows per staged batch at PARALLELOGRAM's 157 entries per window (96 KB: 69) */
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(64 * SPEC_WPB) void k_armn_dec_spec(const unsigned 
     unsigned *s = s_all[wv];
     unsigned short *nx = nx_all[wv];
     unsigned mine = 0;
-    if (lane < DWW + DTAIL) { mine = gword(z + 1, (size_t)win * DWW + lane, nwords); s[lane] = mine; }
+    for (int k = lane; k < DWW + DTAIL; k += 64) { const unsigned v = gword(z + 1, (size_t)win * DWW + k, nwords); s[k] = v; mine |= v; }
     const bool nonzero = __ballot(mine != 0) != 0;
     unsigned *tab = tab_all + (size_t)f * tab_stride + (size_t)win * DEXT;
     const unsigned step0 = (unsigned)dec_step(g, 0, g.n_int);
@@ -415,7 +414,7 @@ __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all,
         __syncthreads();
         if (s_state == 0) break;
         /* ---- a window with a row end, all threads: successor and tile count of EVERY bit position of the window under the interior point count, then
-         * pointer doubling (nine rounds: a window holds at most 256 tiles): after it nxt[p] = where the walk from p leaves the window, cnt[p] = its
+         * pointer doubling (up to ten rounds: a window holds at most 512 tiles): after it nxt[p] = where the walk from p leaves the window, cnt[p] = its
          * tiles; on the way lane 0 follows the binary digits of `run` from the entry to the row's last tile (one wave walking a window tile by tile
          * cost ~600 clk per tile: 38 tiles per row-end window at a compression ratio of 0.2, 1200 such windows per cfg5 record) ---- */
         {
@@ -437,14 +436,14 @@ __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all,
             /* rounds: the walk from e holds s_rcnt tiles (its table entry; without one at most (DW - e) / C + 1); the walk behind the row's last tile is
              * checked for having left the window below */
             int rounds = 1;
-            while (rounds < 9 && (1u << rounds) <= s_rcnt) rounds++;
+            while (rounds < 10 && (1u << rounds) <= s_rcnt) rounds++;                  /* (a window holds at most DW / 4 = 512 tiles) */
             __syncthreads();
             unsigned pc = e;
             int cur = 0;
             for (int j = 0; j < rounds; j++) {
-                {
-                    const unsigned w_ = sc[cur][tid], w2 = sc[cur][w_ & 0xFFFFu];          /* HOP_TPB == DW: one position per thread */
-                    sc[cur ^ 1][tid] = (w2 & 0xFFFFu) | ((w_ >> 16) + (w2 >> 16)) << 16;
+                for (int p = tid; p < DW; p += HOP_TPB) {                                /* (DW / HOP_TPB positions per thread) */
+                    const unsigned w_ = sc[cur][p], w2 = sc[cur][w_ & 0xFFFFu];
+                    sc[cur ^ 1][p] = (w2 & 0xFFFFu) | ((w_ >> 16) + (w2 >> 16)) << 16;
                 }
                 if (tid == 0 && ((run0 >> j) & 1u)) pc = sc[cur][pc] & 0xFFFFu;
                 __syncthreads();
