@@ -10,6 +10,7 @@
  */
 #ifndef PACKERS_HIP_H
 #define PACKERS_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -59,6 +60,11 @@ int armn_uncompress32_(float *fld, unsigned char *zstream, int *ni, int *nj, int
 /* additive: the field on the device (the stream of c_armn_uncompress32_dev stays in HOST memory: its chain of tile headers is walked there) */
 int c_armn_compress32_dev(void *d_zstream, const float *d_fld, int ni, int nj, int nk, int znbits);
 int c_armn_uncompress32_dev(float *d_fld, const unsigned char *zstream_host, int ni, int nj, int nk, int znbits);
+/* additive: the same with the stream's byte length given (an upper bound that the caller's buffer holds, e.g. the data part of an FST record, fstd98.c:2436):
+ * c_armn_uncompress32 has no length argument and has to find the record's end by walking its tile headers on the host; with the length the planes are
+ * uploaded at once and both chains are followed on the device (only the sign plane's run-length decoder stays on the host) */
+int c_armn_uncompress32_lng(float *fld, const unsigned char *zstream, size_t zbytes, int ni, int nj, int nk, int znbits);
+int c_armn_uncompress32_lng_dev(float *d_fld, const unsigned char *zstream_host, size_t zbytes, int ni, int nj, int nk, int znbits);
 void c_armn_compress_setlevel(int level);       /* src/compresseur/c_zfstlib.c:1325 ; BEST = 1, FAST = 0 */
 int  c_armn_compress_getlevel(void);
 void c_armn_compress_setswap(int swapState);

@@ -227,7 +227,7 @@ static uint64_t *walk_tiles(const uint32_t *z, int ni, int nj, int nbits, size_t
         for (int tx = 0; tx < ntx; tx++, t++) {
             const int tm = ni - (1 + 3 * tx) < 3 ? ni - (1 + 3 * tx) : 3;
             tp[t] = pos;
-            if (pos + 8 > max_bits) { free(tp); return NULL; }          /* a truncated or corrupt record: the chain left the stream */
+            if (pos + (uint64_t)container > max_bits) { free(tp); return NULL; }      /* a truncated or corrupt record: the chain left the stream */
             uint64_t p2 = pos;
             const int need = (int)br32_get(z, &p2, container);
             pos += (uint64_t)container + (need ? (uint64_t)(tm * tn) * (uint64_t)(need + 1) : 0);
@@ -259,8 +259,14 @@ static void *walk_thread(void *a) { walk_job *j = (walk_job *)a; j->tp = walk_ti
 typedef struct { const uint32_t *z; uint32_t *mask; int npts; } rle_job;
 static void *rle_thread(void *a) { rle_job *j = (rle_job *)a; rle_decode(j->mask, j->z, j->npts); return NULL; }
 
-/* c_armn_uncompress32 with the result on the device; zstream: HOST memory (the chain of tile headers is walked on the host) */
+/* c_armn_uncompress32 with the result on the device; zstream: HOST memory (the chain of tile headers is walked on the host).  word_limit: words the
+ * caller's buffer is known to hold (0: unknown -- no stream of c_armn_compress32 is longer than the field it replaces) */
+static int uncompress32_host_walk(float *d_fld, const unsigned char *zstream, size_t word_limit, int ni, int nj, int nk, int znbits);
 int c_armn_uncompress32_dev(float *d_fld, const unsigned char *zstream, int ni, int nj, int nk, int znbits)
+{
+    return uncompress32_host_walk(d_fld, zstream, 0, ni, nj, nk, znbits);
+}
+static int uncompress32_host_walk(float *d_fld, const unsigned char *zstream, size_t word_limit, int ni, int nj, int nk, int znbits)
 {
     (void)nk; (void)znbits;
     if (need_dev32("c_armn_uncompress32")) return -1;
@@ -276,7 +282,7 @@ int c_armn_uncompress32_dev(float *d_fld, const unsigned char *zstream, int ni, 
     /* header fields a record of c_armn_compress32 can hold (armn_compress_32.c:143-145, :96-99): anything else is a corrupt record */
     if (need_e > 8 || nbits < 1 || nbits > 23) { fprintf(stderr, "<c_armn_uncompress32> broken stream (exponent width %u, mantissa width %d)\n", need_e, nbits); return -1; }
     /* no stream of c_armn_compress32 is longer than the field it replaces (:240-247): every length read from the record is held to that */
-    const uint64_t max_words = (uint64_t)n + 64;
+    const uint64_t max_words = (word_limit && word_limit < n + 64) ? (uint64_t)word_limit : (uint64_t)n + 64;
     unsigned *d_smask = (unsigned *)w32(2, 4 * (n / 32 + 2) + 16);
     int *d_expo = (int *)w32(0, 4 * n + 16), *d_mant = (int *)w32(1, 4 * n + 16);
     if (!d_smask || !d_expo || !d_mant) return -1;
@@ -315,6 +321,97 @@ out:
 broken:
     fprintf(stderr, "<c_armn_uncompress32> broken stream (a sub-stream length exceeds the field)\n");
     return -1;
+}
+
+/* ---- the same with the stream's LENGTH known (the data part of an FST record, fstd98.c:2436: its word count is data[0]).  c_armn_uncompress32 itself has
+ * no length argument and the mantissa length slot of a record holds the sign stream's length (:237, reproduced), so the plain entry point above can only FIND
+ * the end of the record by walking it -- on the host, where the caller's buffer is.  With the length in hand the walk is held to it, and (EZHIP_A32_DEVICE_WALK=1)
+ * the planes can go up once and both chains of tile headers be followed on the device (packhip_armn_tile_walk: the speculation tables / composed tables /
+ * chain kernel of armn_compress UNCOMPRESS with the plane's tile rule; only the run-length decoder of the sign plane stays on the host, in its own thread).
+ * That form is NOT the default: measured on 7200 x 3601 fields (tools/probe_a32.py, profiles/r03_experiments.txt) it takes 43 - 55 ms against 22 - 25 with
+ * the host walks -- a mantissa plane is a stream of 300 - 550 Mbit, two to three times a cfg5 record, the chain kernel is one CU following it at ~0.25 us
+ * per dependent step, and a host core walks the same chain in ~10 ms while the other planes are walked on other threads. ---- */
+static __thread uint32_t t_plane_hdr[2], t_plane_status[2];
+static int decode_plane_walked_on_device(int *d_plane, const uint32_t *z, size_t words, int ni, int nj, int nbits, int wide, int which)
+{
+    const size_t zw = words + 1;                                  /* [header word in armn_compress's layout][the plane's stream] */
+    unsigned *d_zs = (unsigned *)w32(3, 4 * (zw + 64));
+    void *d_work = w32(4, packhip_armn_dec_work_bytes(ni, nj, zw));
+    int *d_bs = (int *)w32(5, 4 * (size_t)ni * ((size_t)(nj + 31) / 32 + 1));
+    int *d_status = (int *)w32(7, 256);
+    if (!d_zs || !d_work || !d_bs || !d_status) return -1;
+    t_plane_hdr[which] = packhip_armn_plane_header(nbits);
+    if (ezhip_h2d(d_zs, &t_plane_hdr[which], 4) || ezhip_h2d(d_zs + 1, z, 4 * words) || ezhip_memset(d_zs + zw, 0, 4 * 64)) return -1;
+    if (packhip_armn_tile_walk(d_zs, zw, ni, nj, d_work, d_status + which)) return -1;
+    if (packhip_pg_decode2(d_plane, d_bs, d_zs + 1, NULL, (const unsigned *)d_work, ni, nj, nbits, wide)) return -1;
+    if (ezhip_d2h(&t_plane_status[which], d_status + which, 4) || ezhip_sync()) return -1;
+    return t_plane_status[which] == 0 ? 0 : -1;
+}
+
+int c_armn_uncompress32_lng_dev(float *d_fld, const unsigned char *zstream, size_t zbytes, int ni, int nj, int nk, int znbits)
+{
+    (void)nk; (void)znbits;
+    if (need_dev32("c_armn_uncompress32")) return -1;
+    const size_t n = (size_t)ni * nj, zwords = zbytes / 4;
+    if (ni < 16 || nj < 16 || zwords < 4) return -1;
+    const char *dw = getenv("EZHIP_A32_DEVICE_WALK");
+    if (!dw || !atoi(dw) || (uint64_t)zwords * 32 + 16384 >= (1ull << 32))         /* (the device walk holds bit positions in 32 bits) */
+        return uncompress32_host_walk(d_fld, zstream, zwords, ni, nj, nk, znbits);
+    const uint32_t *z0 = (const uint32_t *)zstream, *cur = z0 + 2, *zend = z0 + zwords;
+    const uint32_t w0 = z0[0], info = z0[1];
+    if ((w0 & 15u) != 5u) { fprintf(stderr, "<c_armn_uncompress32> not a PARALLELOGRAM32 stream\n"); return -1; }
+    const int nbits = (int)((w0 >> 10) & 31);
+    const uint32_t exp_min = info >> 16, need_e = (info >> 8) & 0xFF, codes = info & 0xFF;
+    const int code_signe = (int)(codes & 0x30), code_expo = (int)(codes & 0xC), code_mant = (int)(codes & 0x3);
+    if (code_mant != 0) { fprintf(stderr, "<c_armn_uncompress32> plain mantissa streams are not produced by c_armn_compress32\n"); return -1; }
+    if (need_e > 8 || nbits < 1 || nbits > 23) { fprintf(stderr, "<c_armn_uncompress32> broken stream (exponent width %u, mantissa width %d)\n", need_e, nbits); return -1; }
+    unsigned *d_smask = (unsigned *)w32(2, 4 * (n / 32 + 2) + 16);
+    int *d_expo = (int *)w32(0, 4 * n + 16), *d_mant = (int *)w32(1, 4 * n + 16);
+    if (!d_smask || !d_expo || !d_mant) return -1;
+    const int have_s = code_signe == 0x20 || code_signe == 0x30, have_e = code_expo == 0x08 || code_expo == 0x0C;
+    const uint32_t *z_s = NULL, *z_e = NULL, *z_m;
+    size_t words_e = 0;
+    if (have_s) { if (cur >= zend) goto broken; const uint32_t lng = *cur++; if ((size_t)(lng >> 2) > (size_t)(zend - cur)) goto broken; z_s = cur; cur += lng >> 2; }
+    if (have_e) { if (cur >= zend) goto broken; const uint32_t lng = *cur++; if ((size_t)(lng >> 2) > (size_t)(zend - cur)) goto broken; z_e = cur; words_e = lng >> 2; cur += lng >> 2; }
+    if (cur + 1 >= zend) goto broken;
+    cur++;                                                       /* the mantissa length slot */
+    z_m = cur;
+    rle_job rj = { z_s, NULL, (int)n };
+    pthread_t th_s;
+    int run_s = 0, rc = -1;
+    if (have_s) {
+        rj.mask = (uint32_t *)calloc(n / 32 + 2 + 16, 4);
+        if (!rj.mask) return -1;
+        run_s = pthread_create(&th_s, NULL, rle_thread, &rj) == 0;
+        if (!run_s) rle_thread(&rj);
+    }
+    int bad = 0;
+    if (have_e && decode_plane_walked_on_device(d_expo, z_e, words_e, ni, nj, (int)need_e, 0, 0)) bad = 1;
+    if (!bad && decode_plane_walked_on_device(d_mant, z_m, (size_t)(zend - z_m), ni, nj, nbits, 1, 1)) bad = 1;
+    if (run_s) pthread_join(th_s, NULL);
+    if (bad) { fprintf(stderr, "<c_armn_uncompress32> broken stream (a tile chain leaves the record)\n"); goto out; }
+    if (have_s && (ezhip_h2d(d_smask, rj.mask, 4 * (n / 32 + 1)) || ezhip_sync())) goto out;
+    if (packhip_a32_combine(d_fld, d_expo, d_mant, d_smask, n, nbits, exp_min, code_signe, code_expo != 0)) goto out;
+    if (ezhip_sync()) goto out;
+    rc = (int)n;
+out:
+    free(rj.mask);
+    return rc;
+broken:
+    fprintf(stderr, "<c_armn_uncompress32> broken stream (a sub-stream length exceeds the record)\n");
+    return -1;
+}
+
+int c_armn_uncompress32_lng(float *fld, const unsigned char *zstream, size_t zbytes, int ni, int nj, int nk, int znbits)
+{
+    if (need_dev32("c_armn_uncompress32")) return -1;
+    const size_t n = (size_t)ni * nj;
+    float *d_f = (float *)w32(6, 4 * n);
+    if (!d_f) return -1;
+    int rc = c_armn_uncompress32_lng_dev(d_f, zstream, zbytes, ni, nj, nk, znbits);
+    if (rc > 0 && (ezhip_d2h(fld, d_f, 4 * n) || ezhip_sync())) rc = -1;
+    ezhip_sync();
+    return rc;
 }
 
 int c_armn_uncompress32(float *fld, unsigned char *zstream, int ni, int nj, int nk, int znbits)

@@ -267,12 +267,12 @@ __device__ __forceinline__ unsigned pg_get(const unsigned *z, unsigned long long
     return (unsigned)((v << sh) >> (64 - w));
 }
 /* D = the 2-D differences whose inclusive prefix sum is the plane: tile interiors = the coded differences */
-__global__ __launch_bounds__(256) void k_pg_dec_tiles(int *D, const unsigned *z, const unsigned long long *tpos, int ni, int nj, int ntx, unsigned ntiles, int container)
+__global__ __launch_bounds__(256) void k_pg_dec_tiles(int *D, const unsigned *z, const unsigned long long *tpos, const unsigned *tpos32, int ni, int nj, int ntx, unsigned ntiles, int container)
 {
     const unsigned t = blockIdx.x * 256 + threadIdx.x;
     if (t >= ntiles) return;
     const PgTile P = pg_tile(t, ni, nj, ntx);
-    unsigned long long pos = tpos[t];
+    unsigned long long pos = tpos32 ? (unsigned long long)tpos32[t] : tpos[t];     /* (the device walk of unpack_kernels.hip leaves 32-bit positions) */
     const int need = (int)pg_get(z, pos, container);
     pos += container;
     for (int n = 0; n < P.tn; n++) for (int m = 0; m < P.tm; m++) {
@@ -334,12 +334,18 @@ __global__ __launch_bounds__(256) void k_pg_colscan(int *D, const int *bs, int n
     int run = bs[(size_t)b * ni + i];
     for (int j = b * PG_BAND; j < min((b + 1) * PG_BAND, nj); j++) { run += D[(size_t)j * ni + i]; D[(size_t)j * ni + i] = (int)((unsigned)run & mask); }
 }
-/* d_z: the plane's stream (device), d_tpos: bit position of every tile header (host walk), d_D: ni*nj ints out (the plane), d_bs: ceil(nj/32)*ni ints */
+/* d_z: the plane's stream (device), d_tpos / d_tpos32: bit position of every tile header (the host walk's 64-bit ones, or the device walk's 32-bit ones: the
+ * other pointer is NULL), d_D: ni*nj ints out (the plane), d_bs: ceil(nj/32)*ni ints */
+extern "C" int packhip_pg_decode2(int *d_D, int *d_bs, const unsigned *d_z, const unsigned long long *d_tpos, const unsigned *d_tpos32, int ni, int nj, int nbits, int wide);
 extern "C" int packhip_pg_decode(int *d_D, int *d_bs, const unsigned *d_z, const unsigned long long *d_tpos, int ni, int nj, int nbits, int wide)
+{
+    return packhip_pg_decode2(d_D, d_bs, d_z, d_tpos, NULL, ni, nj, nbits, wide);
+}
+extern "C" int packhip_pg_decode2(int *d_D, int *d_bs, const unsigned *d_z, const unsigned long long *d_tpos, const unsigned *d_tpos32, int ni, int nj, int nbits, int wide)
 {
     int ntx; const unsigned ntiles = (unsigned)pg_ntiles(ni, nj, &ntx);
     hipStream_t st = STREAM;
-    hipLaunchKernelGGL(k_pg_dec_tiles, dim3((ntiles + 255) / 256), dim3(256), 0, st, d_D, d_z, d_tpos, ni, nj, ntx, ntiles, wide ? 5 : 4);
+    hipLaunchKernelGGL(k_pg_dec_tiles, dim3((ntiles + 255) / 256), dim3(256), 0, st, d_D, d_z, d_tpos, d_tpos32, ni, nj, ntx, ntiles, wide ? 5 : 4);
     hipLaunchKernelGGL(k_pg_dec_prefix, dim3((ni + nj + 255) / 256), dim3(256), 0, st, d_D, d_z, ni, nj, nbits);
     hipLaunchKernelGGL(k_pg_rowscan, dim3(nj), dim3(256), 0, st, d_D, ni);
     const int nbands = (nj + PG_BAND - 1) / PG_BAND;

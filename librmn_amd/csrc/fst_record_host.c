@@ -455,7 +455,10 @@ int32_t ezhip_fst_unpack_data_ex(void *field, uint32_t *data, int32_t ni, int32_
             for (int64_t i = 0; i < n; i++) d[i] <<= (32 - nbits);                    /* LSHIFT(IFLD, 32 - NBITS) */
         } else return -1;
         break;
-    case 133: rc = c_armn_uncompress32((float *)field, (unsigned char *)(data + 1), ni, nj, nk, nbits) < 0 ? -1 : 0; break;
+    case 133:                                                                       /* :2436; data[0] = the data part's words (:1318): the stream's length, so its tile chains are followed on the device */
+        if (data[0] < 5) return -1;
+        rc = c_armn_uncompress32_lng((float *)field, (const unsigned char *)(data + 1), 4 * ((size_t)data[0] - 1), ni, nj, nk, nbits) < 0 ? -1 : 0;
+        break;
     case 6: { int32_t nb; rc = c_float_unpacker((float *)field, (int32_t *)data, (int32_t *)(data + hs), (int32_t)n, &nb); break; }
     case 134: {
         int32_t nb;

@@ -72,6 +72,10 @@ size_t packhip_pg_work_bytes(int ni, int nj);
 int packhip_pg_encode(unsigned *d_z, size_t z_words, const void *d_u, int elem_bytes, int ni, int nj, int nbits, long long remaining_space, void *d_work);
 int packhip_pg_result(void *d_work, int ni, int nj, int nbits, unsigned long long *bits, int *failed);
 int packhip_pg_decode(int *d_D, int *d_bs, const unsigned *d_z, const unsigned long long *d_tpos, int ni, int nj, int nbits, int wide);
+int packhip_pg_decode2(int *d_D, int *d_bs, const unsigned *d_z, const unsigned long long *d_tpos, const unsigned *d_tpos32, int ni, int nj, int nbits, int wide);
+/* the tile-header chain of one plane of c_armn_compress32 walked on the device (unpack_kernels.hip) */
+unsigned packhip_armn_plane_header(int nbits);
+int packhip_armn_tile_walk(const unsigned *d_z, size_t z_words, int ni, int nj, void *d_work, int *d_status);
 int packhip_a32_combine(float *d_f, const int *d_expo, const int *d_mant, const unsigned *d_smask, size_t n, int nbits, unsigned exp_min, int code_signe, int have_expo);
 #ifdef __cplusplus
 }

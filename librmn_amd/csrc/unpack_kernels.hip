@@ -64,15 +64,17 @@ __device__ __forceinline__ unsigned dec_lds_addr(const void *p) { return (unsign
 
 struct DecGeom {
     int method, istep, origin, nbits, C;    /* C: width of a tile header */
+    int plain;                               /* a plane of c_armn_compress32: a tile's tokens are hdr + 1 bits wide, no 17-bit escape (armn_compress_32.c:753-824) */
     int ntx, nty, mlast, hlast;
     int n_int, ext;                          /* points of an interior tile; bits of the longest tile */
     long long ntiles;
     unsigned body;                           /* bit position of the first tile header (bit 0 = MSB of z[1]) */
 };
 
-__device__ __forceinline__ bool dec_geom(DecGeom &g, const unsigned *z, int ni, int nj)
+__device__ __forceinline__ bool dec_geom(DecGeom &g, const unsigned *z, int ni, int nj, int plain = 0)
 {
     const unsigned h = z[0];
+    g.plain = plain;
     g.method = h & 15; g.istep = (h >> 7) & 7; g.nbits = (h >> 10) & 31;
     /* the encoder names PARALLELOGRAM with step 3 and MINIMUM with step 5, nothing else (:132, :157) */
     if (g.method == 4 && g.istep == 3) {
@@ -92,7 +94,7 @@ __device__ __forceinline__ bool dec_geom(DecGeom &g, const unsigned *z, int ni, 
 /* bits of tile `hdr` with n points: the distance to the next header */
 __device__ __forceinline__ int dec_step(const DecGeom &g, unsigned hdr, int n)
 {
-    if (g.method == 4) return g.C + (hdr == 0 ? 0 : n * ((hdr == 15 || hdr == 16) ? 17 : (int)hdr + 1));     /* :826-858 */
+    if (g.method == 4) return g.C + (hdr == 0 ? 0 : n * ((!g.plain && (hdr == 15 || hdr == 16)) ? 17 : (int)hdr + 1));     /* :826-858 */
     return hdr == 0 ? 4 + g.nbits : (hdr >= 15 ? 4 + n * 16 : 4 + g.nbits + n * (int)hdr);                    /* :610-638 */
 }
 
@@ -129,7 +131,7 @@ __device__ __forceinline__ void dec_run(const DecGeom &g, long long t, int &n, l
  * the entries chase through LDS -- one 16-bit read per tile; the ext walks of a window merge after a few tiles (157 x 15 - 38 decodes per window before, 1024 now) */
 #define SPEC_WPB 4
 __global__ __launch_bounds__(64 * SPEC_WPB) void k_armn_dec_spec(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
-                                                                unsigned *tab_all, size_t tab_stride, int nwin)
+                                                                unsigned *tab_all, size_t tab_stride, int nwin, int plain)
 {
     __shared__ unsigned s_all[SPEC_WPB][DWW + DTAIL];
     __shared__ unsigned short nx_all[SPEC_WPB][DW];
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(64 * SPEC_WPB) void k_armn_dec_spec(const unsigned 
     if (win >= nwin) return;                                      /* (a whole wave leaves: nothing below synchronises across waves) */
     const unsigned *z = z_all + (size_t)f * z_stride;
     DecGeom g;
-    if (!dec_geom(g, z, ni, nj)) return;
+    if (!dec_geom(g, z, ni, nj, plain)) return;
     const size_t nwords = z_words - 1;
     unsigned *s = s_all[wv];
     unsigned short *nx = nx_all[wv];
@@ -267,14 +269,14 @@ __device__ __forceinline__ void dec_run32(const DecGeom &g, unsigned t, int &n, 
 __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
                                                           const unsigned *tab_all, const unsigned *tab8_all, size_t tab_stride,
                                                           unsigned *went_all, unsigned *went8_all, size_t went_stride,
-                                                          int nwin, int *status, int dbg)
+                                                          int nwin, int *status, int dbg, int plain)
 {
     extern __shared__ unsigned lds[];
     __shared__ unsigned s_pos, s_done, s_t, s_mid, s_state, s_rw, s_re, s_rcnt, s_dense;
     const int f = blockIdx.x, tid = threadIdx.x;
     const unsigned *z = z_all + (size_t)f * z_stride;
     DecGeom g;
-    if (!dec_geom(g, z, ni, nj)) { if (tid == 0) status[f] = -1; return; }
+    if (!dec_geom(g, z, ni, nj, plain)) { if (tid == 0) status[f] = -1; return; }
     const unsigned *z1 = z + 1;
     const size_t nwords = z_words - 1;
     const unsigned *tab = tab_all + (size_t)f * tab_stride, *tab8 = tab8_all + (size_t)f * tab_stride;
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all,
         for (int k = tid; k < 2 * nbw; k += HOP_TPB) { went[2 * (size_t)b0 + k] = wl[k]; went8[2 * (size_t)b0 + k] = wl8[k]; }
         __syncthreads();                                          /* the next batch re-arms wl / wl8 right away (its staging no longer waits in between) */
     }
-    if (tid == 0) status[f] = s_done ? 0 : -2;
+    if (tid == 0) status[f] = s_done ? ((plain && (unsigned long long)s_pos > 32ull * nwords) ? -2 : 0) : -2;      /* (a plane: its last tile ends inside the stream) */
 }
 
 /* the seven windows an eight-window hop jumped over: their entries follow from the one-window table */
@@ -509,14 +511,14 @@ __global__ __launch_bounds__(256) void k_armn_dec_expand8(const unsigned *z_all,
 }
 
 __global__ __launch_bounds__(256) void k_armn_dec_emit(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
-                                                       const unsigned *went_all, size_t went_stride, unsigned *tilepos_all, size_t tp_stride, int nwin)
+                                                       const unsigned *went_all, size_t went_stride, unsigned *tilepos_all, size_t tp_stride, int nwin, int plain)
 {
     const int f = blockIdx.y;
     const int w = blockIdx.x * 256 + threadIdx.x;
     if (w >= nwin) return;
     const unsigned *z = z_all + (size_t)f * z_stride;
     DecGeom g;
-    if (!dec_geom(g, z, ni, nj)) return;
+    if (!dec_geom(g, z, ni, nj, plain)) return;
     const unsigned e = went_all[(size_t)f * went_stride + 2 * (size_t)w];
     if (e == 0xFFFFFFFFu) return;
     long long t = went_all[(size_t)f * went_stride + 2 * (size_t)w + 1];
@@ -682,9 +684,27 @@ extern "C" int packhip_armn_decode(unsigned *d_out, size_t out_stride_words, con
 }
 /* phase 0: everything; 1: the kernels that run on all CUs in front of the chain kernel (speculation, composed table); 2: the chain kernel and what follows.
  * A caller with a batch runs phase 1 of one half, then ALL of the other half on a second stream, then phase 2 of the first half: the chain kernels (one CU
- * per stream) of the first half run beside the all-CU kernels of the second */
+ * per stream) of the first half run beside the all-CU kernels of the second.
+ * walk_only: stop behind k_armn_dec_emit (the bit position of every tile header, 32-bit, at the start of the work area); plain: the tile rule of a plane of
+ * c_armn_compress32 */
+static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
+                      int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status, int phase, int plain, int walk_only);
 extern "C" int packhip_armn_decode_phase(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
                                          int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status, int phase)
+{
+    return dec_launch(d_out, out_stride_words, d_z, z_stride_words, z_words, ni, nj, nfields, swap, d_work, work_stride_bytes, d_status, phase, 0, 0);
+}
+/* The chain of tile headers of ONE parallelogram plane of c_armn_compress32 (armn_compress_32.c:568-639, :753-824: the decoders read it tile after tile) on
+ * the device.  d_z[0]: a header word in armn_compress's layout (method 4, step 3, the plane's nbits: packhip_armn_plane_header), d_z[1..]: the plane's
+ * stream, z_words in all, followed by >= DTAIL + 2 readable words.  The positions (bits from the plane's first word, 32-bit) of the (ni+1)/3 x (nj+1)/3 tiles
+ * land at the START of d_work (packhip_armn_dec_work_bytes(ni, nj, z_words) bytes); *d_status: 0, -1 (header), -2 (the chain leaves the stream). */
+extern "C" unsigned packhip_armn_plane_header(int nbits) { return 4u | 1u << 4 | 3u << 7 | ((unsigned)nbits & 31u) << 10; }
+extern "C" int packhip_armn_tile_walk(const unsigned *d_z, size_t z_words, int ni, int nj, void *d_work, int *d_status)
+{
+    return dec_launch(NULL, 0, d_z, 0, z_words, ni, nj, 1, 0, d_work, 0, d_status, 0, 1, 1);
+}
+static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
+                      int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status, int phase, int plain, int walk_only)
 {
     static int attr_done = 0;
     if (!attr_done) {
@@ -708,11 +728,11 @@ extern "C" int packhip_armn_decode_phase(unsigned *d_out, size_t out_stride_word
     const size_t ws4 = work_stride_bytes / 4, ws2 = work_stride_bytes / 2;
     if (phase != 2) {
     for (int f = 0; f < nfields; f++) {
-        if (hipMemsetAsync(d_out + (size_t)f * out_stride_words, 0, 4 * (1 + n / 2), st) != hipSuccess) return -1;
+        if (d_out && hipMemsetAsync(d_out + (size_t)f * out_stride_words, 0, 4 * (1 + n / 2), st) != hipSuccess) return -1;
         if (hipMemsetAsync((char *)went + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
         if (hipMemsetAsync((char *)went8 + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
     }
-    hipLaunchKernelGGL(k_armn_dec_spec, dim3((nwin + SPEC_WPB - 1) / SPEC_WPB, nfields), dim3(64 * SPEC_WPB), 0, st, d_z, z_stride_words, z_words, ni, nj, tab, ws4, nwin);
+    hipLaunchKernelGGL(k_armn_dec_spec, dim3((nwin + SPEC_WPB - 1) / SPEC_WPB, nfields), dim3(64 * SPEC_WPB), 0, st, d_z, z_stride_words, z_words, ni, nj, tab, ws4, nwin, plain);
     if (getenv("EZHIP_DEC_COMPOSE_GLOBAL"))        /* development: eight dependent global loads per entry (rounds 1 - 2) */
         hipLaunchKernelGGL(k_armn_dec_compose, dim3(nwin, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, tab8, ws4, nwin);
     else {
@@ -721,9 +741,10 @@ extern "C" int packhip_armn_decode_phase(unsigned *d_out, size_t out_stride_word
     }
     }
     if (phase == 1) { hipError_t e1 = hipGetLastError(); if (e1 != hipSuccess) { fprintf(stderr, "<armn_compress> UNCOMPRESS launch failed: %s\n", hipGetErrorString(e1)); return -1; } return 0; }
-    hipLaunchKernelGGL(k_armn_dec_hop, dim3(nfields), dim3(HOP_TPB), HOP_LDS, st, d_z, z_stride_words, z_words, ni, nj, tab, tab8, ws4, went, went8, ws4, nwin, d_status, getenv("EZHIP_DEC_DEBUG") ? atoi(getenv("EZHIP_DEC_DEBUG")) : 0);
+    hipLaunchKernelGGL(k_armn_dec_hop, dim3(nfields), dim3(HOP_TPB), HOP_LDS, st, d_z, z_stride_words, z_words, ni, nj, tab, tab8, ws4, went, went8, ws4, nwin, d_status, getenv("EZHIP_DEC_DEBUG") ? atoi(getenv("EZHIP_DEC_DEBUG")) : 0, plain);
     hipLaunchKernelGGL(k_armn_dec_expand8, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, ws4, went, went8, ws4, nwin);
-    hipLaunchKernelGGL(k_armn_dec_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, went, ws4, tilepos, ws4, nwin);
+    hipLaunchKernelGGL(k_armn_dec_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, went, ws4, tilepos, ws4, nwin, plain);
+    if (walk_only) { hipError_t e2 = hipGetLastError(); if (e2 != hipSuccess) { fprintf(stderr, "<armn_compress> tile walk launch failed: %s\n", hipGetErrorString(e2)); return -1; } return 0; }
     const long long grid_tiles = max_tiles > (long long)(ni + nj) ? max_tiles : (long long)(ni + nj);
     hipLaunchKernelGGL(k_armn_dec_tiles, dim3((unsigned)((grid_tiles + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj,
                        tilepos, ws4, d16, ws2, (unsigned short *)d_out, out_stride_words * 2, swap, max_tiles);

@@ -227,6 +227,15 @@ def armn_uncompress32(z, ni, nj, znbits):
     return rc, out
 
 
+def armn_uncompress32_lng(z, zbytes, ni, nj, znbits):
+    """c_armn_uncompress32_lng: the stream's byte length is given (an upper bound inside the buffer), the tile chains are followed on the device"""
+    L = _lib()
+    L.c_armn_uncompress32_lng.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    out = np.zeros(ni * nj, np.float32)
+    rc = L.c_armn_uncompress32_lng(out.ctypes.data, z.ctypes.data, int(zbytes), ni, nj, 1, znbits)
+    return rc, out
+
+
 def fst_pack_data(field, ni, nj, nk, datyp, nbits):
     """the data part of an FST record (c_fstecr's packing switch): returns (words, datyp_out, nbits_out, uint32 buffer).  The element size is the
     array's (float32 / int32 / uint32: 4, float64: 8, int16 / uint16: 2, int8 / uint8: 1); datyp may carry the missing-value flag (+64)"""

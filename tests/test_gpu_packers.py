@@ -599,6 +599,16 @@ def test_armn_compress32_bit_exact(ni, nj, kind, znbits):
     back_o = np.zeros(ni * nj, np.float32)
     ta32.O().orc_armn_uncompress32(back_o.ctypes.data, zg.ctypes.data, ni, nj, 1, znbits)
     assert np.array_equal(back_o.view(np.uint32), back.view(np.uint32))
+    # the stream's length given (the FST record's case): both tile chains are followed on the device -- the exact length, and an upper bound with zero words behind
+    for device_walk in ("0", "1"):
+        os.environ["EZHIP_A32_DEVICE_WALK"] = device_walk         # 1: the chains followed by the kernels of armn_compress UNCOMPRESS (opt-in: slower than the host walks at full size)
+        try:
+            for zbytes in (4 * ((want + 3) // 4), 4 * ((want + 3) // 4) + 4 * 37):
+                rc2, back2 = pk.armn_uncompress32_lng(zg, zbytes, ni, nj, znbits)
+                assert rc2 == ni * nj
+                assert np.array_equal(back2.view(np.uint32), back.view(np.uint32)), (device_walk, zbytes, int((back2.view(np.uint32) != back.view(np.uint32)).sum()))
+        finally:
+            del os.environ["EZHIP_A32_DEVICE_WALK"]
 
 
 def test_armn_compress32_refusals_and_full_size():
@@ -617,6 +627,15 @@ def test_armn_compress32_refusals_and_full_size():
         assert np.array_equal(zg[:want // 4], zw[:want // 4])
         rc, back = pk.armn_uncompress32(zg, ni, nj, 32)
         assert rc == ni * nj and np.array_equal(back.view(np.uint32), f.view(np.uint32))
+        for device_walk in ("0", "1"):
+            os.environ["EZHIP_A32_DEVICE_WALK"] = device_walk
+            try:
+                rc, back = pk.armn_uncompress32_lng(zg, 4 * ((want + 3) // 4), ni, nj, 32)
+                assert rc == ni * nj and np.array_equal(back.view(np.uint32), f.view(np.uint32)), device_walk
+                rc, _ = pk.armn_uncompress32_lng(zg, 4 * (want // 8), ni, nj, 32)      # half the record: the chain leaves the stream, refused
+                assert rc == -1, device_walk
+            finally:
+                del os.environ["EZHIP_A32_DEVICE_WALK"]
 
 
 # ---------------------------------------------------------------------------------------------
