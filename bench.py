@@ -198,7 +198,7 @@ def extras(ez, torch, stream, d_out, d_in):
                             "roofline": {"bound": "hbm", "achieved": algo3 / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": algo3 / us / 1e3 / HBM_PEAK_GBPS,
                                          "traffic": t3[0] * 1e6 if t3 else None, "traffic_source": t3[1] if t3 else None,
                                          "kernel": "k_pts2_irgd3w (+ k_pts_special2, k_polar_wind beside it)", "algorithmic_bytes_per_launch": algo3,
-                                         "note": "x, y of the rotated source (64 MB) and the per-point wind matrix (128 MB) are read next to the 26 MB of sources: "
+                                         "note": "x, y of the rotated source (64 MB) and the per-point wind rotation (a, b: 64 MB; 128 as four coefficients until the end of round 3) are read next to the 26 MB of sources: "
                                                  "the kernel is bound by the vector L1's 64 B/clk (TA busy 68 %), not by HBM"}}
         del d_u, d_v, o_u, o_v
         # the step after the horizontal one: vertical interpolation of device-resident profiles, search + linear + lapse-rate in one pass

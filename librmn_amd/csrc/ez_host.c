@@ -65,6 +65,8 @@ typedef struct ezh_set {
     int *d_cspec_list; float *d_cspec_xy; int cspec_count, cspec_key;      /* the special points (polar strips, re-interpolated extrapolation) of the wind-pair launch, kept after its first call: index, x, y; key = the zone options they were listed under (0: none yet) */
     float *d_lamb_cs[2];    /* c_ezuvint from / towards a Lambert '!' grid: {cos, sin} of its rotation angle at the target points' longitudes (source leg, target leg) */
     void *d_windM;          /* c_ezuvint through a rotated frame: the wind chain of this grid pair as a 2 x 2 matrix per target point (built on first use) */
+    int windM_half;         /* every point's matrix is a pure rotation to rounding (ezhip_wind_matrix's max_dev <= 4e-6): the (a, b) form behind the float4 form is used */
+    float windM_dev;
     /* Yin-Yang 'U' source (c_ezyy_calcxy, ezyy_calcxy.c): per subgrid the list of target points it serves */
     int yy_ready, yy_count[2];
     float *d_yy_x[2], *d_yy_y[2], *d_yy_lat[2], *d_yy_lon[2], *d_yy_tmp[4];
@@ -2453,7 +2455,7 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
 static __thread struct { float *out; const float *plon2, *ax; float xg4_n, xg4_s; int weighted, active; } t_pwjob;
 /* both components of a wind pair on the per-point path in ONE pass (k_pts2); returns -2 when the set is not on that path */
 static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui, const float *d_vi,
-                        const float *pun, const float *pus, const float *pvn, const float *pvs, const void *d_M, int dst_rot)
+                        const float *pun, const float *pus, const float *pvn, const float *pvs, const void *d_M, int m_half, int dst_rot)
 {
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     int degree = O.degre_interp, polar = O.polar_correction == 1;
@@ -2478,7 +2480,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
         if (ezhip_fill_value(d_fill, d_ui, (size_t)gi->ni * gi->nj, O.degre_extrap, O.valeur_extrap, 1)) return -1;
     }
     pu.fill = d_fill; pu.polevals = d_poles;
-    pu.wind_M = d_M; pu.wind_dst_rot = dst_rot;
+    pu.wind_M = d_M; pu.wind_M_half = m_half; pu.wind_dst_rot = dst_rot;
     pv = pu;
     pu.pole_row_n = pun; pu.pole_row_s = pus; pv.pole_row_n = pvn; pv.pole_row_s = pvs;
     if (zones == 2 && s->have_dehors) ierc = 2;
@@ -3232,15 +3234,22 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
      * pair only -- built once per set from the chain itself (ezhip_wind_matrix), then two multiply-adds per component and call: inside
      * k_pts2 as it stores (per-point sets), or k_wind_apply after the separable launches (k_wind_rotate: 112 us per cfg3 pair) */
     const void *d_M = NULL;
+    int m_half = 0;
     if (!wd_only && (wp.src_rotated || wp.dst_rotated) && !getenv("EZHIP_WIND_NO_MATRIX") &&
-        16 * (size_t)go->ni * go->nj <= ((size_t)1 << 31)) {           /* 16 bytes per target point, kept with the set: up to 2 GiB, beyond that the chain runs per call */
+        24 * (size_t)go->ni * go->nj <= ((size_t)3 << 30)) {           /* 16 + 8 bytes per target point, kept with the set: up to 3 GiB, beyond that the chain runs per call */
         pthread_mutex_lock(&g_plan_mtx);
         int mrc = 0;
         if (!s->d_windM) {
-            s->d_windM = ezhip_malloc(16 * (size_t)go->ni * go->nj);
-            if (!s->d_windM || ezhip_wind_matrix(&wp, s->d_windM, go->d_lat, go->d_lon, go->ni, go->nj)) { ezhip_free(s->d_windM); s->d_windM = NULL; mrc = -1; }
+            s->d_windM = ezhip_malloc(24 * (size_t)go->ni * go->nj + 16);
+            if (!s->d_windM || ezhip_wind_matrix(&wp, s->d_windM, go->d_lat, go->d_lon, go->ni, go->nj, &s->windM_dev)) { ezhip_free(s->d_windM); s->d_windM = NULL; mrc = -1; }
+            /* the chain is a rotation by construction (speed kept, direction turned); its REAL roundings leave a - d and b + c at a few 1e-7.  Where that holds
+             * at every point the (a, b) form is read: half the matrix bytes per call.  Anything else (a non-finite coefficient, a frame that is no rotation)
+             * keeps the four coefficients */
+            s->windM_half = !mrc && s->windM_dev <= 4.0e-6f;
+            if (getenv("EZHIP_WIND_MATRIX_REPORT")) fprintf(stderr, "<ezhip> wind matrix of set (%d, %d): max distance from a rotation %.3g -> %s\n", s->gdin, s->gdout, (double)s->windM_dev, s->windM_half ? "(a, b) form" : "four coefficients");
         }
-        d_M = s->d_windM;
+        m_half = s->windM_half && !getenv("EZHIP_WIND_FULL_MATRIX");
+        d_M = m_half ? (const void *)((const char *)s->d_windM + 16 * (size_t)go->ni * go->nj) : s->d_windM;
         pthread_mutex_unlock(&g_plan_mtx);
         if (mrc) return dev_fail("the wind rotation matrix");
     }
@@ -3249,7 +3258,7 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
         const size_t nb = sizeof(float) * (size_t)ni * nj;
         if ((d_uuout != d_uuin && ezhip_d2d(d_uuout, d_uuin, nb)) || (d_vvout != d_vvin && ezhip_d2d(d_vvout, d_vvin, nb))) return -1;
     }
-    if (!same) r1 = r2 = run_pair_pts(s, d_uuout, d_vvout, d_uuin, d_vvin, pun, pus, pvn, pvs, getenv("EZHIP_WIND_NO_FUSE") ? NULL : d_M, wp.dst_rotated);
+    if (!same) r1 = r2 = run_pair_pts(s, d_uuout, d_vvout, d_uuin, d_vvin, pun, pus, pvn, pvs, getenv("EZHIP_WIND_NO_FUSE") ? NULL : d_M, m_half, wp.dst_rotated);
     if (t_pwjob.active) {                                     /* the pair kernel did not take the polar wind rows along (set not on its path after all) */
         t_pwjob.active = 0;
         if (r1 != -1) {
@@ -3267,7 +3276,7 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
         if (r2 < 0) return r2;
     }
     if (ezhip_side_join()) return -1;                        /* nothing may outlive the call on the side stream */
-    if (d_M) { if (!fused && ezhip_wind_apply(d_M, d_uuout, d_vvout, (size_t)go->ni * go->nj, wp.dst_rotated)) return -1; }
+    if (d_M) { if (!fused && ezhip_wind_apply(d_M, m_half, d_uuout, d_vvout, (size_t)go->ni * go->nj, wp.dst_rotated)) return -1; }
     else if (ezhip_wind_rotate(&wp, d_uuout, d_vvout, go->d_lat, go->d_lon, go->ni, go->nj)) return -1;
     return (r1 == 2 || r2 == 2) ? 2 : 0;
 }

@@ -2145,6 +2145,22 @@ __device__ __forceinline__ void d_wind_matrix_apply(float mx, float my, float mz
         else { a = (a == 0.0f || a != a) ? nan : copysignf(inf, a); b = (b == 0.0f || b != b) ? nan : copysignf(inf, b); }
     }
 }
+/* the matrix of point o.  half: the set's chain is a pure rotation to rounding at every point (checked when the matrix is built) and the matrix is kept as
+ * (a, b) with c = -b, d = a: 8 instead of 16 bytes per target point and call (cfg3: 64 of its 436 MB per pair).  The same two unconditional 8-byte loads
+ * in both forms (a conditional one costs a wait at the join, one more address costs registers the pair kernel does not have): the half form's second load
+ * brings the NEXT point's pair -- same or next line, ignored; the buffer ends with 16 spare bytes */
+typedef float wm_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wind_m_load(const void *M, int half, size_t o, wm_f2 &lo, wm_f2 &hi)
+{
+    const wm_f2 *mp = (const wm_f2 *)((const char *)M + (o << (half ? 3 : 4)));
+    lo = __builtin_nontemporal_load(mp);
+    hi = __builtin_nontemporal_load(mp + 1);
+}
+__device__ __forceinline__ void wind_m_apply(wm_f2 lo, wm_f2 hi, int half, float u, float v, int dst_rot, float &a, float &b)
+{
+    if (half) d_wind_matrix_apply(lo.x, lo.y, -lo.y, lo.x, u, v, dst_rot, a, b);       /* (a wave-uniform branch: as selects the two forms cost the pair kernel two spilled registers) */
+    else d_wind_matrix_apply(lo.x, lo.y, hi.x, hi.y, u, v, dst_rot, a, b);
+}
 /* ===================================================================================== */
 /* k_pts : generic per-point interpolation (restates the reference leaf kernels)            */
 /* ===================================================================================== */
@@ -2676,12 +2692,11 @@ __device__ __forceinline__ void pts2_body(ezhip_pts_plan p, float *__restrict__ 
     const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
     /* the point's wind matrix is fetched first: nothing depends on it until the store, its latency hides behind the interpolation
      * (fetched where it is applied it cost +37 us per cfg3 pair, as much as the separate k_wind_apply pass) */
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    f4v wm = {1.0f, 0.0f, 0.0f, 1.0f};
+    wm_f2 wlo = {1.0f, 0.0f}, whi = {0.0f, 1.0f};
     /* (the empty asm pins the load here -- and makes the compiler wait for it here: one memory round trip before the interpolation starts.  The
      * all-loads-first form below issues it with the point's other loads instead) */
     constexpr bool FRONT = KIND == PK_IRGD3_W && !LITERAL;
-    if (p.wind_M && !FRONT) { wm = __builtin_nontemporal_load(((const f4v *)p.wind_M) + o); asm volatile("" : "+v"(wm)); }
+    if (p.wind_M && !FRONT) { wind_m_load(p.wind_M, p.wind_M_half, o, wlo, whi); asm volatile("" : "+v"(wlo), "+v"(whi)); }
     if (zone == PZ_NORMAL || zone == PZ_FILL) {
         float a, b;
         if (zone == PZ_FILL) a = b = *p.fill;
@@ -2690,14 +2705,14 @@ __device__ __forceinline__ void pts2_body(ezhip_pts_plan p, float *__restrict__ 
             const bool seam = i <= 1 || i >= p.ni - 1;                         /* (wrap 0: i stays in 2 .. ni - 2) */
             /* in flight with the loads of the interpolation; unconditional (a conditional load is merged with the identity at the join: a use, hence a
              * wait, right behind it): without a matrix a readable dummy address */
-            wm = __builtin_nontemporal_load(p.wind_M ? ((const f4v *)p.wind_M) + o : (const f4v *)p.ncx8);
+            wind_m_load(p.wind_M ? p.wind_M : (const void *)p.ncx8, p.wind_M_half, p.wind_M ? o : (size_t)0, wlo, whi);
             if (__ballot(seam) == 0ull) p_irgdint_3_w_pair_inner(zin1, zin2, px, py, p.ax, p.ay, p.ncx8, p.ncy8, p.ni, p.j1, i, j, a, b);
             else p_irgdint_3_w_pair<PlainAcc, true>(Z1, Z2, px, py, p.ax, p.ay, p.ncx8, p.ncy8, p.ni, p.j1, p.j2, p.wrap, a, b);
         }
         else { a = leaf_point<KIND>(p, Z1, px, py); b = leaf_point<KIND>(p, Z2, px, py); }
         if (p.wind_M) {                       /* the wind chain of the grid pair (k_wind_apply), here instead of a pass of its own */
             const float u = a, v = b;
-            d_wind_matrix_apply(wm.x, wm.y, wm.z, wm.w, u, v, p.wind_dst_rot, a, b);
+            wind_m_apply(wlo, whi, p.wind_M_half, u, v, p.wind_dst_rot, a, b);
         }
         zout1[o] = a; zout2[o] = b;
     }
@@ -2788,9 +2803,10 @@ __global__ __launch_bounds__(256) void k_pts_special2(ezhip_pts_plan p, float *_
             a = strip_point(p, Z1, zone == PZ_STRIP_N, px, py); b = strip_point(p, Z2, zone == PZ_STRIP_N, px, py);
         }
         if (p.wind_M) {
-            const float4 m = ((const float4 *)p.wind_M)[o];
+            wm_f2 lo, hi;
+            wind_m_load(p.wind_M, p.wind_M_half, o, lo, hi);
             const float u = a, v = b;
-            d_wind_matrix_apply(m.x, m.y, m.z, m.w, u, v, p.wind_dst_rot, a, b);
+            wind_m_apply(lo, hi, p.wind_M_half, u, v, p.wind_dst_rot, a, b);
         }
         zout1[o] = a; zout2[o] = b;
     }
@@ -2806,8 +2822,8 @@ __global__ __launch_bounds__(256) void k_pts_special2c(ezhip_pts_plan p, float *
         const int n = p.cspec_list[k];
         const float px = p.cspec_x[k], py = p.cspec_y[k];
         const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;
-        float4 m = make_float4(1.f, 0.f, 0.f, 1.f);
-        if (p.wind_M) m = ((const float4 *)p.wind_M)[o];       /* on its way while the stencils are gathered */
+        wm_f2 mlo = {1.f, 0.f}, mhi = {0.f, 1.f};
+        if (p.wind_M) wind_m_load(p.wind_M, p.wind_M_half, o, mlo, mhi);       /* on its way while the stencils are gathered */
         const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
         FieldAcc Z1, Z2;
         Z1.z = zin1; Z1.ni = p.ni; Z1.j1 = p.j1; Z1.j2 = p.j2; Z1.pole_n = 0.f; Z1.pole_s = 0.f; Z1.prow_n = nullptr; Z1.prow_s = nullptr;
@@ -2818,7 +2834,7 @@ __global__ __launch_bounds__(256) void k_pts_special2c(ezhip_pts_plan p, float *
             Z1.prow_n = p.pole_row_n; Z1.prow_s = p.pole_row_s; Z2.prow_n = prow_n2; Z2.prow_s = prow_s2;
             a = strip_point(p, Z1, zone == PZ_STRIP_N, px, py); b = strip_point(p, Z2, zone == PZ_STRIP_N, px, py);
         }
-        if (p.wind_M) { const float u = a, v = b; d_wind_matrix_apply(m.x, m.y, m.z, m.w, u, v, p.wind_dst_rot, a, b); }
+        if (p.wind_M) { const float u = a, v = b; wind_m_apply(mlo, mhi, p.wind_M_half, u, v, p.wind_dst_rot, a, b); }
         zout1[o] = a; zout2[o] = b;
     }
 }
@@ -3420,48 +3436,66 @@ extern "C" int ezhip_average(float *d_zout, const float *d_zin, const float *d_b
  * point, a plane rotation that depends on the two grids only: ezhip_wind_matrix runs the chain once on the unit vectors (1,0) and (0,1)
  * and keeps the four coefficients per point; k_wind_apply then replaces ~10 REAL*8 / REAL transcendentals per point and call by two
  * multiply-adds per component.  The result differs from the chain on (u,v) by the chain's own rounding (~4e-7 |V|; tolerance 1e-5 |V|). */
-__global__ __launch_bounds__(256) void k_wind_matrix_pack(float4 *__restrict__ M, const float *__restrict__ a, const float *__restrict__ c,
-                                                          const float *__restrict__ b, const float *__restrict__ d, size_t n)
+/* M: the four coefficients per point; M2 (behind it): the rotation (a + d) / 2, (b - c) / 2 the four stand for when the chain is one; *dev: the largest
+ * distance of a point's matrix from that form (max |a - d|, |b + c|; infinite when a coefficient is not finite), as the bits of a non-negative float */
+__global__ __launch_bounds__(256) void k_wind_matrix_pack(float4 *__restrict__ M, float2 *__restrict__ M2, unsigned *__restrict__ dev, const float *__restrict__ a,
+                                                          const float *__restrict__ c, const float *__restrict__ b, const float *__restrict__ d, size_t n)
 {
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (k < n) M[k] = make_float4(a[k], b[k], c[k], d[k]);           /* uo = a u + b v, vo = c u + d v */
+    float dv = 0.0f;
+    if (k < n) {
+        const float ak = a[k], bk = b[k], ck = c[k], dk = d[k];
+        M[k] = make_float4(ak, bk, ck, dk);                          /* uo = a u + b v, vo = c u + d v */
+        M2[k] = make_float2(0.5f * (ak + dk), 0.5f * (bk - ck));
+        dv = fmaxf(fabsf(ak - dk), fabsf(bk + ck));
+        if (!(dv <= 3.0e38f)) dv = __builtin_inff();
+    }
+    for (int off = 32; off; off >>= 1) dv = fmaxf(dv, __shfl_xor(dv, off));
+    if ((threadIdx.x & 63) == 0 && dv > 0.0f) atomicMax(dev, __float_as_uint(dv));
 }
 __global__ __launch_bounds__(256) void k_fill2(float *__restrict__ a, float va, float *__restrict__ b, float vb, size_t n)
 {
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (k < n) { a[k] = va; b[k] = vb; }
 }
-__global__ __launch_bounds__(256) void k_wind_apply(const float4 *__restrict__ M, float *__restrict__ uu, float *__restrict__ vv, size_t n, int dst_rot)
+__global__ __launch_bounds__(256) void k_wind_apply(const void *__restrict__ M, int half, float *__restrict__ uu, float *__restrict__ vv, size_t n, int dst_rot)
 {
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
-    const float4 m = M[k];
+    wm_f2 lo, hi;
+    wind_m_load(M, half, k, lo, hi);
     const float u = uu[k], v = vv[k];
     float a, b;
-    d_wind_matrix_apply(m.x, m.y, m.z, m.w, u, v, dst_rot, a, b);
+    wind_m_apply(lo, hi, half, u, v, dst_rot, a, b);
     uu[k] = a; vv[k] = b;
 }
-extern "C" int ezhip_wind_matrix(const ezhip_wind_plan *plan, void *d_M, const float *d_lat, const float *d_lon, int ni_dst, int nj_dst)
+/* d_M: 24 bytes per point (the float4 form, then the float2 form); *max_dev: how far the matrices are from pure rotations (see k_wind_matrix_pack) */
+extern "C" int ezhip_wind_matrix(const ezhip_wind_plan *plan, void *d_M, const float *d_lat, const float *d_lon, int ni_dst, int nj_dst, float *max_dev)
 {
     const size_t npts = (size_t)ni_dst * nj_dst;
+    *max_dev = 0.0f;
     if (!npts) return 0;
     float *t = nullptr;
-    if (set_err(hipMalloc((void **)&t, sizeof(float) * 4 * npts), "wind matrix scratch")) return -1;
+    if (set_err(hipMalloc((void **)&t, sizeof(float) * 4 * npts + 16), "wind matrix scratch")) return -1;
+    unsigned *d_dev = (unsigned *)(t + 4 * npts);
+    if (hipMemsetAsync(d_dev, 0, 4, g_stream) != hipSuccess) { (void)hipFree(t); return -1; }
     const dim3 grid((unsigned)((npts + 255) / 256)), block(256);
     hipLaunchKernelGGL(k_fill2, grid, block, 0, g_stream, t, 1.0f, t + npts, 0.0f, npts);                      /* (1,0) -> (a, c) */
     hipLaunchKernelGGL(k_fill2, grid, block, 0, g_stream, t + 2 * npts, 0.0f, t + 3 * npts, 1.0f, npts);       /* (0,1) -> (b, d) */
     hipLaunchKernelGGL(k_wind_rotate, grid, block, 0, g_stream, *plan, t, t + npts, d_lat, d_lon, ni_dst, nj_dst);
     hipLaunchKernelGGL(k_wind_rotate, grid, block, 0, g_stream, *plan, t + 2 * npts, t + 3 * npts, d_lat, d_lon, ni_dst, nj_dst);
-    hipLaunchKernelGGL(k_wind_matrix_pack, grid, block, 0, g_stream, (float4 *)d_M, t, t + npts, t + 2 * npts, t + 3 * npts, npts);
+    hipLaunchKernelGGL(k_wind_matrix_pack, grid, block, 0, g_stream, (float4 *)d_M, (float2 *)((float4 *)d_M + npts), d_dev, t, t + npts, t + 2 * npts, t + 3 * npts, npts);
     int rc = LAUNCH_CHECK("k_wind_matrix");
-    if (hipStreamSynchronize(g_stream) != hipSuccess) rc = -1;
+    unsigned dev_bits = 0x7F800000u;
+    if (hipMemcpyAsync(&dev_bits, d_dev, 4, hipMemcpyDeviceToHost, g_stream) != hipSuccess || hipStreamSynchronize(g_stream) != hipSuccess) rc = -1;
+    memcpy(max_dev, &dev_bits, 4);
     (void)hipFree(t);
     return rc;
 }
-extern "C" int ezhip_wind_apply(const void *d_M, float *d_uu, float *d_vv, size_t npts, int dst_rotated)
+extern "C" int ezhip_wind_apply(const void *d_M, int half, float *d_uu, float *d_vv, size_t npts, int dst_rotated)
 {
     if (!npts) return 0;
-    hipLaunchKernelGGL(k_wind_apply, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, g_stream, (const float4 *)d_M, d_uu, d_vv, npts, dst_rotated);
+    hipLaunchKernelGGL(k_wind_apply, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, g_stream, d_M, half, d_uu, d_vv, npts, dst_rotated);
     return LAUNCH_CHECK("k_wind_apply");
 }
 

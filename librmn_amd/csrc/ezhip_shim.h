@@ -220,6 +220,7 @@ typedef struct {
     const float *ax, *ay, *ncx, *ncy; /* device; NULL for regular sources */
     const float *ncx8, *ncy8;         /* the same coefficients laid out [index][8] (6 used): two 16-byte loads per point */
     int wind_dst_rot;                 /* with wind_M: the TARGET frame is a rotated one (decides what a REAL overflow of the chain's speed turns into) */
+    int wind_M_half;                  /* wind_M holds (a, b) per point: a pure rotation, c = -b, d = a */
     const void *wind_M;               /* k_pts2: the grid pair's wind matrices (ezhip_wind_matrix), applied to every point before it is stored; NULL: store the interpolated components */
     /* zone handling (0 = none: c_gdxysint semantics) */
     int zones;                        /* 0 none, 1 EZ_NO_EXTRAP (polar zones), 2 EZ_EXTRAP (DEHORS) */
@@ -311,9 +312,9 @@ int ezhip_polar_wind(float *d_out4, const float *d_uu, const float *d_vv, const 
 
 /* in place on (uu, vv): source-grid components -> target ('L'-like) grid components */
 /* the chain of a grid pair as a 2 x 2 matrix per point (16 bytes each): built once, applied per call */
-int ezhip_wind_matrix(const ezhip_wind_plan *plan, void *d_M, const float *d_lat, const float *d_lon, int ni_dst, int nj_dst);
+int ezhip_wind_matrix(const ezhip_wind_plan *plan, void *d_M, const float *d_lat, const float *d_lon, int ni_dst, int nj_dst, float *max_dev);   /* d_M: 24 bytes per point */
 int ezhip_corrbgd(float *d_zout, int ni, int nj, int hem);
-int ezhip_wind_apply(const void *d_M, float *d_uu, float *d_vv, size_t npts, int dst_rotated);
+int ezhip_wind_apply(const void *d_M, int half, float *d_uu, float *d_vv, size_t npts, int dst_rotated);
 /* interp_degree = average / sph_average (ez_avg.inc, ez_avg_sph.inc): bounds = [x ni_dst | row widening nj_dst | y_low nj_dst | y_high nj_dst] on the device */
 int ezhip_average(float *d_zout, const float *d_zin, const float *d_bounds, int ni_dst, int nj_dst, int ni_src, int nj_src, int extension, float ylast);
 int ezhip_wind_rotate(const ezhip_wind_plan *plan, float *d_uu, float *d_vv,

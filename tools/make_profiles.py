@@ -106,7 +106,7 @@ if P3:
     out["cfg3_traffic_MB_per_pair"] = round(tot3, 1)
     out["cfg3_algorithmic_MB_per_pair"] = 90.21
     out["cfg3_traffic_over_algorithmic"] = round(tot3 / 90.21, 2)
-    out["cfg3_notes"] = "x, y of the located points (64 MB) and the per-point wind matrices (128 MB) are inputs of every call next to the 26 MB of sources and 64 MB of results"
+    out["cfg3_notes"] = "x, y of the located points (64 MB) and the per-point wind rotations (a, b: 64 MB) are inputs of every call next to the 26 MB of sources and 64 MB of results"
 json.dump(out, open(os.path.join(dst, f"{prefix}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 print(f"timed launches: mean {mean_us:.2f} us, frac {alg / mean_us / 1e3 / 8000:.4f}; bench line {bench['roofline']['avg_launch_us']:.2f} us / {bench['roofline']['frac']:.4f}")
