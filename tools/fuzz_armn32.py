@@ -26,6 +26,9 @@ for k in range(ncases):
             back_o = np.zeros(ni * nj, np.float32)
             ta32.O().orc_armn_uncompress32(back_o.ctypes.data, zg.ctypes.data, ni, nj, 1, znbits)
             ok = rc == ni * nj and np.array_equal(back.view(np.uint32), back_o.view(np.uint32))
+            if ok:                                               # the length-aware entry (host walk held to the length; EZHIP_A32_DEVICE_WALK=1: the device walk)
+                rc2, back2 = pk.armn_uncompress32_lng(zg, 4 * ((want + 3) // 4) + 4 * int(rng.integers(0, 3)), ni, nj, znbits)
+                ok = rc2 == ni * nj and np.array_equal(back2.view(np.uint32), back_o.view(np.uint32))
     if not ok:
         bad += 1
         print("MISMATCH", dict(ni=ni, nj=nj, kind=kind, znbits=znbits, got=got, want=want), flush=True)
