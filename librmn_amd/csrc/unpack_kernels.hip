@@ -269,9 +269,10 @@ __device__ __forceinline__ void dec_run32(const DecGeom &g, unsigned t, int &n, 
 __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
                                                           const unsigned *tab_all, const unsigned *tab8_all, size_t tab_stride,
                                                           unsigned *went_all, unsigned *went8_all, size_t went_stride,
-                                                          int nwin, int *status, int dbg, int plain)
+                                                          int nwin, int *status, int dbg, int plain, const unsigned *skip, size_t skip_stride)
 {
     extern __shared__ unsigned lds[];
+    if (skip && skip[(size_t)blockIdx.x * skip_stride]) return;          /* the parallel form (k_dsc_*) has the field's tile positions already */
     __shared__ unsigned s_pos, s_done, s_t, s_mid, s_state, s_rw, s_re, s_rcnt, s_dense;
     const int f = blockIdx.x, tid = threadIdx.x;
     const unsigned *z = z_all + (size_t)f * z_stride;
@@ -491,9 +492,10 @@ __global__ __launch_bounds__(HOP_TPB) void k_armn_dec_hop(const unsigned *z_all,
 
 /* the seven windows an eight-window hop jumped over: their entries follow from the one-window table */
 __global__ __launch_bounds__(256) void k_armn_dec_expand8(const unsigned *z_all, size_t z_stride, int ni, int nj, const unsigned *tab_all, size_t tab_stride,
-                                                          unsigned *went_all, const unsigned *went8_all, size_t went_stride, int nwin)
+                                                          unsigned *went_all, const unsigned *went8_all, size_t went_stride, int nwin, const unsigned *skip, size_t skip_stride)
 {
     const int f = blockIdx.y;
+    if (skip && skip[(size_t)f * skip_stride]) return;
     const int w = blockIdx.x * 256 + threadIdx.x;
     if (w >= nwin) return;
     DecGeom g;
@@ -511,9 +513,10 @@ __global__ __launch_bounds__(256) void k_armn_dec_expand8(const unsigned *z_all,
 }
 
 __global__ __launch_bounds__(256) void k_armn_dec_emit(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
-                                                       const unsigned *went_all, size_t went_stride, unsigned *tilepos_all, size_t tp_stride, int nwin, int plain)
+                                                       const unsigned *went_all, size_t went_stride, unsigned *tilepos_all, size_t tp_stride, int nwin, int plain, const unsigned *skip, size_t skip_stride)
 {
     const int f = blockIdx.y;
+    if (skip && skip[(size_t)f * skip_stride]) return;
     const int w = blockIdx.x * 256 + threadIdx.x;
     if (w >= nwin) return;
     const unsigned *z = z_all + (size_t)f * z_stride;
@@ -539,6 +542,310 @@ __global__ __launch_bounds__(256) void k_armn_dec_emit(const unsigned *z_all, si
 /* ------------------------------------------------------------------------------------------ */
 /* token k of the output goes to half-word k^1 when the stream is swapped (high half first)      */
 __device__ __forceinline__ size_t out_slot(size_t k, int swap) { return swap ? (k ^ 1) : k; }
+
+
+/* ============================================================================================================================================
+ * The chain between row ends resolved in parallel (round 3, opt-in: EZHIP_DEC_SCAN=1; DESIGN 9 item 4, tools/probe_merge.py).
+ * The walks of eight composed windows leave ONE exit for (nearly) all entries: the entry of an eight-window block follows from the block before it alone.  So
+ * the CANONICAL chain -- the one from the first tile that never meets a row end -- is written down for all blocks at once (k_dsc_m8, k_dsc_blocks, k_dsc_scan,
+ * k_armn_dec_expand8, k_dsc_emit: the position of every canonical tile).  The real chain leaves it at the odd tile that ends a row of tiles and rejoins it
+ * within a few windows, its tile index shifted.  k_dsc_dtab computes, for EVERY canonical tile c, the change of that shift if the row ended at c; the shifts of
+ * the 1200 rows are then a recurrence of 1200 table lookups (k_dsc_rows); k_dsc_stretch re-walks the stretches between an odd tile and the rejoining point,
+ * k_dsc_final shifts the rest, k_dsc_lastrow walks the last row of tiles (another height) tile by tile.  Anything unexpected (short rows, a block that does not
+ * merge for long, a stretch that does not rejoin before the next row end) leaves st[DSC_OK] at 0 and the serial chain kernel runs as before.
+ * ============================================================================================================================================ */
+enum { DSC_OK = 0, DSC_WB, DSC_EB, DSC_TB, DSC_K, DSC_NCANON, DSC_FAIL, DSC_RINT, DSC_WORDS = 16 };
+#define DSC_D_INVALID 0x7FFF
+#define DSC_MARGIN 65536                 /* canonical tiles kept beyond the field's own tile count */
+
+__device__ __forceinline__ bool dsc_eligible(const DecGeom &g, int nwin, int min_ntx) { return g.method == 4 && g.ntx >= min_ntx && g.nty >= 3 && nwin >= 64; }
+
+/* one wave per field: the first (partial) window tile by tile, the block origin */
+__global__ __launch_bounds__(64) void k_dsc_init(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, unsigned *st_all, size_t st_stride,
+                                                 unsigned *wentc_all, size_t went_stride, int nwin, int plain, int min_ntx)
+{
+    const int f = blockIdx.x;
+    if (threadIdx.x) return;
+    unsigned *st = st_all + (size_t)f * st_stride;
+    for (int k = 0; k < DSC_WORDS; k++) st[k] = 0;
+    const unsigned *z = z_all + (size_t)f * z_stride;
+    DecGeom g;
+    if (!dec_geom(g, z, ni, nj, plain) || !dsc_eligible(g, nwin, min_ntx)) { st[DSC_FAIL] = 1; return; }
+    const size_t nwords = z_words - 1;
+    unsigned *wentc = wentc_all + (size_t)f * went_stride;
+    unsigned pos = g.body, t = 0;
+    const unsigned w0 = pos / DW, end = (w0 + 1) * DW;
+    if ((int)w0 + 17 >= nwin) { st[DSC_FAIL] = 2; return; }
+    wentc[2 * w0] = pos - w0 * DW; wentc[2 * w0 + 1] = 0;
+    while (pos < end) { pos += (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.n_int); t++; }
+    if (t + 1 >= (unsigned)g.ntx) { st[DSC_FAIL] = 12; return; }          /* a row of tiles ends inside the first window */
+    st[DSC_WB] = w0 + 1; st[DSC_EB] = pos - end; st[DSC_TB] = t; st[DSC_K] = ((unsigned)nwin - (w0 + 1)) / 8u;
+    st[DSC_RINT] = (unsigned)((g.hlast != g.istep) ? g.nty - 1 : g.nty);
+}
+
+/* m8[w] = the exit all entries of tab8[w] share, 0xFFFF when they do not (or one cannot be composed); one wave per window */
+__global__ __launch_bounds__(256) void k_dsc_m8(const unsigned *z_all, size_t z_stride, int ni, int nj, const unsigned *st_all, size_t st_stride,
+                                                const unsigned *tab8_all, size_t tab_stride, unsigned short *m8_all, size_t m8_stride, int nwin, int plain)
+{
+    const int f = blockIdx.y, w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= nwin || st_all[(size_t)f * st_stride + DSC_FAIL]) return;
+    DecGeom g;
+    if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, plain)) return;
+    const unsigned *row = tab8_all + (size_t)f * tab_stride + (size_t)w * DEXT;
+    const unsigned x0 = row[0];
+    bool same = x0 != CMP_INV;
+    for (int e = lane; e < g.ext; e += 64) { const unsigned v = row[e]; if (v == CMP_INV || (v & 0xFFFFu) != (x0 & 0xFFFFu)) same = false; }
+    const bool all = __ballot(!same) == 0ull;
+    if (lane == 0) m8_all[(size_t)f * m8_stride + w] = all ? (unsigned short)(x0 & 0xFFFFu) : (unsigned short)0xFFFFu;
+}
+
+/* block k = windows wB + 8k ..: its canonical entry (from the nearest merged block behind it) and tile count */
+__global__ __launch_bounds__(256) void k_dsc_blocks(unsigned *st_all, size_t st_stride, const unsigned *tab8_all, size_t tab_stride,
+                                                    const unsigned short *m8_all, size_t m8_stride, unsigned *eblk_all, unsigned *cblk_all, size_t blk_stride, int ext)
+{
+    const int f = blockIdx.y;
+    unsigned *st = st_all + (size_t)f * st_stride;
+    if (st[DSC_FAIL]) return;
+    const unsigned K = st[DSC_K], wB = st[DSC_WB], k = blockIdx.x * 256 + threadIdx.x;
+    if (k > K) return;
+    const unsigned *tab8 = tab8_all + (size_t)f * tab_stride;
+    const unsigned short *m8 = m8_all + (size_t)f * m8_stride;
+    unsigned j = k;
+    while (j > 0 && m8[wB + 8 * (j - 1)] == 0xFFFFu && k - j < 256) j--;
+    if (j > 0 && m8[wB + 8 * (j - 1)] == 0xFFFFu) { st[DSC_FAIL] = 3; return; }       /* a long run of blocks that do not merge */
+    unsigned e = j > 0 ? (unsigned)m8[wB + 8 * (j - 1)] : st[DSC_EB];
+    for (unsigned i = j; i < k; i++) {
+        const unsigned v = e < (unsigned)ext ? tab8[(size_t)(wB + 8 * i) * DEXT + e] : CMP_INV;
+        if (v == CMP_INV) { st[DSC_FAIL] = 4; return; }
+        e = v & 0xFFFFu;
+    }
+    unsigned cnt = 0;
+    if (k < K) {
+        const unsigned v = e < (unsigned)ext ? tab8[(size_t)(wB + 8 * k) * DEXT + e] : CMP_INV;
+        if (v == CMP_INV) { st[DSC_FAIL] = 5; return; }
+        cnt = v >> 16;
+    } else if (e >= (unsigned)ext) { st[DSC_FAIL] = 6; return; }
+    eblk_all[(size_t)f * blk_stride + k] = e; cblk_all[(size_t)f * blk_stride + k] = cnt;
+}
+
+/* exclusive prefix sum of the blocks' tile counts -> the eight-window entries of the canonical chain; the windows behind the last block one by one */
+__global__ __launch_bounds__(1024) void k_dsc_scan(unsigned *st_all, size_t st_stride, const unsigned *tab_all, size_t tab_stride, const unsigned *eblk_all,
+                                                   const unsigned *cblk_all, size_t blk_stride, unsigned *wentc_all, unsigned *wentc8_all, size_t went_stride, int nwin, int ext)
+{
+    __shared__ unsigned part[1024];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    unsigned *st = st_all + (size_t)f * st_stride;
+    if (st[DSC_FAIL]) return;
+    const unsigned K = st[DSC_K], wB = st[DSC_WB];
+    const unsigned *eblk = eblk_all + (size_t)f * blk_stride, *cblk = cblk_all + (size_t)f * blk_stride;
+    unsigned *wentc = wentc_all + (size_t)f * went_stride, *wentc8 = wentc8_all + (size_t)f * went_stride;
+    const unsigned per = (K + 1 + 1023) / 1024, k0 = tid * per, k1 = min(k0 + per, K + 1);
+    unsigned s = 0;
+    for (unsigned k = k0; k < k1; k++) s += cblk[k];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) { const unsigned add = tid >= off ? part[tid - off] : 0u; __syncthreads(); part[tid] += add; __syncthreads(); }
+    unsigned run = st[DSC_TB] + part[tid] - s;
+    unsigned tK = 0;
+    for (unsigned k = k0; k < k1; k++) {
+        if (k < K) { wentc8[2 * (size_t)(wB + 8 * k)] = eblk[k]; wentc8[2 * (size_t)(wB + 8 * k) + 1] = run; }
+        else tK = run;
+        run += cblk[k];
+    }
+    if (k0 <= K && K < k1) {                                   /* the thread that holds block K: the tail */
+        unsigned w = wB + 8 * K, e = eblk[K], t = tK;
+        const unsigned *tab = tab_all + (size_t)f * tab_stride;
+        while ((int)w < nwin) {
+            wentc[2 * (size_t)w] = e; wentc[2 * (size_t)w + 1] = t;
+            if (e >= (unsigned)ext) { st[DSC_FAIL] = 7; break; }
+            const unsigned v = tab[(size_t)w * DEXT + e];
+            t += v >> 16; e = v & 0xFFFFu; w++;
+        }
+        st[DSC_NCANON] = t;
+    }
+}
+
+/* position of every canonical tile (interior point count everywhere) */
+__global__ __launch_bounds__(256) void k_dsc_emit(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, const unsigned *st_all, size_t st_stride,
+                                                  const unsigned *wentc_all, size_t went_stride, unsigned *tpc_all, size_t tpc_stride, unsigned capc, int nwin, int plain)
+{
+    const int f = blockIdx.y, w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nwin || st_all[(size_t)f * st_stride + DSC_FAIL]) return;
+    const unsigned *z = z_all + (size_t)f * z_stride;
+    DecGeom g;
+    if (!dec_geom(g, z, ni, nj, plain)) return;
+    const unsigned e = wentc_all[(size_t)f * went_stride + 2 * (size_t)w];
+    if (e == 0xFFFFFFFFu) return;
+    unsigned t = wentc_all[(size_t)f * went_stride + 2 * (size_t)w + 1];
+    unsigned *tpc = tpc_all + (size_t)f * tpc_stride;
+    const size_t nwords = z_words - 1;
+    unsigned pos = (unsigned)w * DW + e;
+    const unsigned end = (unsigned)(w + 1) * DW;
+    while (pos < end) {
+        if (t < capc) tpc[t] = pos;
+        pos += (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.n_int);
+        t++;
+    }
+}
+
+/* dtab[c]: if the odd tile that ends a row sat at canonical tile c, the tile-index shift behind it minus the shift in front of it */
+__global__ __launch_bounds__(256) void k_dsc_dtab(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, const unsigned *st_all, size_t st_stride,
+                                                  const unsigned *tab_all, size_t tab_stride, const unsigned *wentc_all, size_t went_stride,
+                                                  const unsigned *tpc_all, size_t tpc_stride, short *dtab_all, size_t dtab_stride, unsigned capc, int nwin, int plain)
+{
+    const int f = blockIdx.y;
+    const unsigned *st = st_all + (size_t)f * st_stride;
+    if (st[DSC_FAIL]) return;
+    const unsigned c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= min(st[DSC_NCANON], capc)) return;
+    const unsigned *z = z_all + (size_t)f * z_stride;
+    DecGeom g;
+    if (!dec_geom(g, z, ni, nj, plain)) return;
+    short *dtab = dtab_all + (size_t)f * dtab_stride;
+    if (g.mlast == g.istep) { dtab[c] = 0; return; }
+    const size_t nwords = z_words - 1;
+    const unsigned *tab = tab_all + (size_t)f * tab_stride, *wentc = wentc_all + (size_t)f * went_stride;
+    const unsigned pos = tpc_all[(size_t)f * tpc_stride + c];
+    unsigned w = pos / DW;
+    unsigned p = pos + (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.mlast * g.istep);
+    unsigned j = 0;
+    const unsigned end = (w + 1) * DW;
+    while (p < end) { p += (unsigned)dec_step(g, getbits_g(z + 1, nwords, p, g.C), g.n_int); j++; }
+    unsigned e = p - end;
+    w++;
+    int d = DSC_D_INVALID;
+    for (int h = 0; h < 128 && (int)w < nwin; h++) {
+        if (wentc[2 * (size_t)w] == e) {
+            const long long dd = (long long)(1u + j) - ((long long)wentc[2 * (size_t)w + 1] - (long long)c);
+            if (dd > -16000 && dd < 16000 && 1u + j + 2u < (unsigned)g.ntx) d = (int)dd;
+            break;
+        }
+        if (e >= (unsigned)g.ext) break;
+        const unsigned v = tab[(size_t)w * DEXT + e];
+        j += v >> 16; e = v & 0xFFFFu; w++;
+    }
+    dtab[c] = (short)d;
+}
+
+/* the recurrence over the rows of tiles: rowc[r] = canonical index of the odd tile that ends row r.  One wave; the lanes fetch the neighbourhood of the next
+ * row's index while the current value is on its way */
+__global__ __launch_bounds__(64) void k_dsc_rows(const unsigned *z_all, size_t z_stride, int ni, int nj, unsigned *st_all, size_t st_stride,
+                                                 const short *dtab_all, size_t dtab_stride, unsigned *rowc_all, size_t row_stride, unsigned capc, int plain)
+{
+    const int f = blockIdx.x, lane = threadIdx.x;
+    unsigned *st = st_all + (size_t)f * st_stride;
+    if (st[DSC_FAIL]) return;
+    DecGeom g;
+    if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, plain)) return;
+    const short *dtab = dtab_all + (size_t)f * dtab_stride;
+    unsigned *rowc = rowc_all + (size_t)f * row_stride;
+    const unsigned rint = st[DSC_RINT], lim = min(st[DSC_NCANON], capc), ntx = (unsigned)g.ntx;
+    unsigned c = ntx - 1;
+    int fail = 0, dprev = 0;
+    /* lane l holds dtab[base + l]: the neighbourhood of the row's index, fetched one row ahead -- around the place the PREVIOUS row's shift change would put
+     * the next index (consecutive changes differ by a few tiles), while the current row's value is still on its way */
+    auto fetch = [&](long long b) -> int { const long long i = b + lane; return (i >= 0 && i < (long long)lim) ? (int)dtab[i] : DSC_D_INVALID; };
+    long long base = (long long)c - 32;
+    int mine = fetch(base);
+    for (unsigned r = 0; r < rint; r++) {
+        if (c >= lim) { fail = 8; break; }
+        if (lane == 0) rowc[r] = c;
+        if (r + 1 >= rint) break;
+        const long long nbase = (long long)c + ntx - dprev - 32;
+        const int ahead = fetch(nbase);                          /* issued before the current value is needed */
+        const long long off = (long long)c - base;
+        const int d = (off >= 0 && off < 64) ? __shfl(mine, (int)off, 64) : (int)dtab[c];
+        if (d == DSC_D_INVALID) { fail = 9; break; }
+        c = c + ntx - (unsigned)d;
+        dprev = d; base = nbase; mine = ahead;
+    }
+    if (lane == 0 && fail) st[DSC_FAIL] = (unsigned)fail;
+}
+
+/* the stretch between the odd tile that ends row r and the tile where the real chain is canonical again: tile by tile; rowmerge[r + 1] = that tile's index */
+__global__ __launch_bounds__(64) void k_dsc_stretch(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, unsigned *st_all, size_t st_stride,
+                                                    const unsigned *tpc_all, size_t tpc_stride, const unsigned *rowc_all, unsigned *rowmerge_all, size_t row_stride,
+                                                    unsigned *tilepos_all, size_t tp_stride, unsigned capc, int plain)
+{
+    const int f = blockIdx.y;
+    unsigned *st = st_all + (size_t)f * st_stride;
+    if (st[DSC_FAIL]) return;
+    const unsigned r = blockIdx.x * 64 + threadIdx.x, rint = st[DSC_RINT];
+    if (r >= rint) return;
+    unsigned *rowmerge = rowmerge_all + (size_t)f * row_stride;
+    if (r == 0) rowmerge[0] = 0;
+    if (r + 1 >= rint) return;
+    const unsigned *z = z_all + (size_t)f * z_stride;
+    DecGeom g;
+    if (!dec_geom(g, z, ni, nj, plain)) return;
+    const size_t nwords = z_words - 1;
+    const unsigned *tpc = tpc_all + (size_t)f * tpc_stride;
+    unsigned *tilepos = tilepos_all + (size_t)f * tp_stride;
+    const unsigned ntx = (unsigned)g.ntx, lim = min(st[DSC_NCANON], capc);
+    unsigned c = rowc_all[(size_t)f * row_stride + r];
+    const unsigned cn = rowc_all[(size_t)f * row_stride + r + 1];
+    unsigned t = (r + 1) * ntx;                               /* first tile of row r + 1 */
+    const unsigned pos = tpc[c];
+    unsigned p = pos + (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.mlast * g.istep);
+    c++;
+    unsigned pc = c < lim ? tpc[c] : 0xFFFFFFFFu;
+    const unsigned tend = t + ntx - 1;                        /* the next odd tile: the chains must have met before */
+    bool ok = false;
+    while (t < tend) {
+        if (p == pc) { ok = true; break; }
+        if (p < pc) { tilepos[t] = p; p += (unsigned)dec_step(g, getbits_g(z + 1, nwords, p, g.C), g.n_int); t++; }
+        else { c++; pc = c < lim ? tpc[c] : 0xFFFFFFFFu; }
+    }
+    if (!ok || t - c != (r + 2) * ntx - 1 - cn) { st[DSC_FAIL] = 10; return; }       /* (the shift behind the stretch is the one the recurrence used) */
+    rowmerge[r + 1] = t;
+}
+
+/* every tile outside the stretches: its canonical twin, shifted */
+__global__ __launch_bounds__(256) void k_dsc_final(const unsigned *z_all, size_t z_stride, int ni, int nj, const unsigned *st_all, size_t st_stride,
+                                                   const unsigned *tpc_all, size_t tpc_stride, const unsigned *rowc_all, const unsigned *rowmerge_all, size_t row_stride,
+                                                   unsigned *tilepos_all, size_t tp_stride, int plain)
+{
+    const int f = blockIdx.y;
+    const unsigned *st = st_all + (size_t)f * st_stride;
+    if (st[DSC_FAIL]) return;
+    DecGeom g;
+    if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, plain)) return;
+    const unsigned ntx = (unsigned)g.ntx, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= st[DSC_RINT] * ntx) return;
+    const unsigned r = t / ntx;
+    if (t < rowmerge_all[(size_t)f * row_stride + r]) return;
+    const unsigned shift = (r + 1) * ntx - 1 - rowc_all[(size_t)f * row_stride + r];           /* true index minus canonical index in row r (mod 2^32) */
+    tilepos_all[(size_t)f * tp_stride + t] = tpc_all[(size_t)f * tpc_stride + (t - shift)];       /* (t - shift < the canonical tiles kept: the stretch kernel met that index) */
+}
+
+/* the last row of tiles when its height differs: tile by tile behind the odd tile of the row before it; then the verdict */
+__global__ __launch_bounds__(64) void k_dsc_lastrow(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, unsigned *st_all, size_t st_stride,
+                                                    const unsigned *tpc_all, size_t tpc_stride, const unsigned *rowc_all, size_t row_stride,
+                                                    unsigned *tilepos_all, size_t tp_stride, int *status, int plain)
+{
+    const int f = blockIdx.x;
+    if (threadIdx.x) return;
+    unsigned *st = st_all + (size_t)f * st_stride;
+    if (st[DSC_FAIL]) return;
+    const unsigned *z = z_all + (size_t)f * z_stride;
+    DecGeom g;
+    if (!dec_geom(g, z, ni, nj, plain)) return;
+    const size_t nwords = z_words - 1;
+    if (g.hlast != g.istep) {
+        const unsigned rint = st[DSC_RINT], ntx = (unsigned)g.ntx;
+        unsigned *tilepos = tilepos_all + (size_t)f * tp_stride;
+        const unsigned pos = tpc_all[(size_t)f * tpc_stride + rowc_all[(size_t)f * row_stride + rint - 1]];
+        unsigned p = pos + (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.mlast * g.istep);
+        unsigned t = rint * ntx;
+        for (unsigned x = 0; x < ntx; x++, t++) {
+            tilepos[t] = p;
+            p += (unsigned)dec_step(g, getbits_g(z + 1, nwords, p, g.C), (x == ntx - 1 ? g.mlast : g.istep) * g.hlast);
+        }
+        if ((unsigned long long)p > 32ull * nwords + 64) { st[DSC_FAIL] = 11; return; }
+    }
+    st[DSC_OK] = 1;
+    status[f] = 0;
+}
 
 __global__ __launch_bounds__(256) void k_armn_dec_tiles(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
                                                         const unsigned *tilepos_all, size_t tp_stride,
@@ -670,7 +977,10 @@ static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" size_t packhip_armn_dec_work_bytes(int ni, int nj, size_t z_words)
 {
     const size_t n = (size_t)ni * nj, nwin = dec_nwin(z_words);
-    return al256(4 * dec_max_tiles(ni, nj)) + al256(2 * (n + 8)) + al256(2 * (size_t)DEC_BANDS * ni) + 2 * al256(4 * nwin * DEXT) + 2 * al256(8 * nwin) + 256;
+    const size_t capc = dec_max_tiles(ni, nj) + DSC_MARGIN, nty = (size_t)(nj + 2) / 3 + 2;
+    return al256(4 * dec_max_tiles(ni, nj)) + al256(2 * (n + 8)) + al256(2 * (size_t)DEC_BANDS * ni) + 2 * al256(4 * nwin * DEXT) + 2 * al256(8 * nwin) + 256
+           /* the parallel form: canonical tile positions, shift changes, merged exits, block entries / counts, canonical window entries, rows, state */
+           + al256(4 * capc) + al256(2 * capc) + al256(2 * nwin) + 2 * al256(4 * (nwin / 8 + 2)) + 2 * al256(8 * nwin) + 2 * al256(4 * nty) + 256;
 }
 
 /* d_out: (1 + ni*nj/2) words per field, zero-filled first (the odd trailing half-word).  d_status: one int per field
@@ -724,7 +1034,22 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
     unsigned *tab = (unsigned *)wk;                         wk += al256(4 * (size_t)nwin * DEXT);
     unsigned *tab8 = (unsigned *)wk;                        wk += al256(4 * (size_t)nwin * DEXT);
     unsigned *went = (unsigned *)wk;                        wk += al256(8 * (size_t)nwin);
-    unsigned *went8 = (unsigned *)wk;
+    unsigned *went8 = (unsigned *)wk;                       wk += al256(8 * (size_t)nwin) + 256;
+    const size_t capc = (size_t)max_tiles + DSC_MARGIN, ntyc = (size_t)(nj + 2) / 3 + 2, nblk = (size_t)nwin / 8 + 2;
+    unsigned *tpc = (unsigned *)wk;                         wk += al256(4 * capc);
+    short *dtab = (short *)wk;                              wk += al256(2 * capc);
+    unsigned short *m8 = (unsigned short *)wk;              wk += al256(2 * (size_t)nwin);
+    unsigned *eblk = (unsigned *)wk;                        wk += al256(4 * nblk);
+    unsigned *cblk = (unsigned *)wk;                        wk += al256(4 * nblk);
+    unsigned *wentc = (unsigned *)wk;                       wk += al256(8 * (size_t)nwin);
+    unsigned *wentc8 = (unsigned *)wk;                      wk += al256(8 * (size_t)nwin);
+    unsigned *rowc = (unsigned *)wk;                        wk += al256(4 * ntyc);
+    unsigned *rowmerge = (unsigned *)wk;                    wk += al256(4 * ntyc);
+    unsigned *dst = (unsigned *)wk;
+    const char *scan_env = getenv("EZHIP_DEC_SCAN");
+    const int scan = scan_env ? atoi(scan_env) : 1;          /* the chain between row ends in parallel (k_dsc_*, the default since the end of round 3); the serial chain
+                                                              * kernel runs only for the fields that form gives up on (small fields, streams whose windows do not merge);
+                                                              * EZHIP_DEC_SCAN=0: the serial kernel for everything, 2: print every field's state words */
     const size_t ws4 = work_stride_bytes / 4, ws2 = work_stride_bytes / 2;
     if (phase != 2) {
     for (int f = 0; f < nfields; f++) {
@@ -741,9 +1066,38 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
     }
     }
     if (phase == 1) { hipError_t e1 = hipGetLastError(); if (e1 != hipSuccess) { fprintf(stderr, "<armn_compress> UNCOMPRESS launch failed: %s\n", hipGetErrorString(e1)); return -1; } return 0; }
-    hipLaunchKernelGGL(k_armn_dec_hop, dim3(nfields), dim3(HOP_TPB), HOP_LDS, st, d_z, z_stride_words, z_words, ni, nj, tab, tab8, ws4, went, went8, ws4, nwin, d_status, getenv("EZHIP_DEC_DEBUG") ? atoi(getenv("EZHIP_DEC_DEBUG")) : 0, plain);
-    hipLaunchKernelGGL(k_armn_dec_expand8, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, ws4, went, went8, ws4, nwin);
-    hipLaunchKernelGGL(k_armn_dec_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, went, ws4, tilepos, ws4, nwin, plain);
+    const unsigned *skip = NULL;
+    if (scan) {
+        const int ext_max = 5 + 9 * 32;                      /* (the kernels read the geometry from the stream; here ext only bounds a table row: the larger of the two) */
+        for (int f = 0; f < nfields; f++) {
+            if (hipMemsetAsync((char *)wentc + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
+            if (hipMemsetAsync((char *)wentc8 + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
+        }
+        const size_t ws2b = work_stride_bytes / 2;
+        hipLaunchKernelGGL(k_dsc_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, wentc, ws4, nwin, plain, getenv("EZHIP_DEC_SCAN_MIN_NTX") ? atoi(getenv("EZHIP_DEC_SCAN_MIN_NTX")) : 1024);
+        hipLaunchKernelGGL(k_dsc_m8, dim3((nwin + 3) / 4, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, tab8, ws4, m8, ws2b, nwin, plain);
+        hipLaunchKernelGGL(k_dsc_blocks, dim3((unsigned)((nblk + 255) / 256), nfields), dim3(256), 0, st, dst, ws4, tab8, ws4, m8, ws2b, eblk, cblk, ws4, ext_max);
+        hipLaunchKernelGGL(k_dsc_scan, dim3(nfields), dim3(1024), 0, st, dst, ws4, tab, ws4, eblk, cblk, ws4, wentc, wentc8, ws4, nwin, ext_max);
+        hipLaunchKernelGGL(k_armn_dec_expand8, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, ws4, wentc, wentc8, ws4, nwin, (const unsigned *)NULL, (size_t)0);
+        hipLaunchKernelGGL(k_dsc_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, wentc, ws4, tpc, ws4, (unsigned)capc, nwin, plain);
+        hipLaunchKernelGGL(k_dsc_dtab, dim3((unsigned)((capc + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, tab, ws4, wentc, ws4, tpc, ws4, dtab, ws2b, (unsigned)capc, nwin, plain);
+        hipLaunchKernelGGL(k_dsc_rows, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, dtab, ws2b, rowc, ws4, (unsigned)capc, plain);
+        hipLaunchKernelGGL(k_dsc_stretch, dim3((unsigned)((ntyc + 63) / 64), nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, tpc, ws4, rowc, rowmerge, ws4, tilepos, ws4, (unsigned)capc, plain);
+        hipLaunchKernelGGL(k_dsc_final, dim3((unsigned)((max_tiles + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, tpc, ws4, rowc, rowmerge, ws4, tilepos, ws4, plain);
+        hipLaunchKernelGGL(k_dsc_lastrow, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, tpc, ws4, rowc, ws4, tilepos, ws4, d_status, plain);
+        skip = dst;                                          /* dst[DSC_OK] of a field: 1 when its tile positions are complete */
+        if (scan == 2) {                                     /* development: the state words of every field */
+            unsigned h[DSC_WORDS];
+            for (int f = 0; f < nfields; f++) {
+                if (hipMemcpyAsync(h, dst + (size_t)f * ws4, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+                fprintf(stderr, "<armn_compress> scan form, field %d: ok %u fail %u  first block window %u entry %u tiles %u  blocks %u  canonical tiles %u  interior rows %u\n",
+                        f, h[DSC_OK], h[DSC_FAIL], h[DSC_WB], h[DSC_EB], h[DSC_TB], h[DSC_K], h[DSC_NCANON], h[DSC_RINT]);
+            }
+        }
+    }
+    hipLaunchKernelGGL(k_armn_dec_hop, dim3(nfields), dim3(HOP_TPB), HOP_LDS, st, d_z, z_stride_words, z_words, ni, nj, tab, tab8, ws4, went, went8, ws4, nwin, d_status, getenv("EZHIP_DEC_DEBUG") ? atoi(getenv("EZHIP_DEC_DEBUG")) : 0, plain, skip, ws4);
+    hipLaunchKernelGGL(k_armn_dec_expand8, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, ws4, went, went8, ws4, nwin, skip, ws4);
+    hipLaunchKernelGGL(k_armn_dec_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, went, ws4, tilepos, ws4, nwin, plain, skip, ws4);
     if (walk_only) { hipError_t e2 = hipGetLastError(); if (e2 != hipSuccess) { fprintf(stderr, "<armn_compress> tile walk launch failed: %s\n", hipGetErrorString(e2)); return -1; } return 0; }
     const long long grid_tiles = max_tiles > (long long)(ni + nj) ? max_tiles : (long long)(ni + nj);
     hipLaunchKernelGGL(k_armn_dec_tiles, dim3((unsigned)((grid_tiles + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj,

@@ -237,6 +237,33 @@ def test_armn_uncompress_matches_oracle_decoder(ni, nj, kind, nbits, level):
     assert np.all(got[1 + ni * nj // 2:] == 0xFFFFFFFF)            # nothing written past the (1 + n/2) words
 
 
+SCAN_SHAPES = [(3100, 200), (3076, 64), (3074, 47), (3073, 46), (1501, 300), (600, 601), (257, 1000)]      # rows of >= 1024 tiles take the parallel form by default
+
+
+@pytest.mark.parametrize("ni,nj", SCAN_SHAPES)
+@pytest.mark.parametrize("kind", ["smooth", "noisy", "constant", "bigdiff"])
+@pytest.mark.parametrize("mode", ["default", "chain_kernel", "scan_from_64_tiles_per_row"])
+def test_armn_uncompress_parallel_form_and_chain_kernel(ni, nj, kind, mode, monkeypatch):
+    """the chain between row ends resolved in parallel (k_dsc_*: the default for rows of >= 1024 tiles), the serial chain kernel (EZHIP_DEC_SCAN=0) and the
+    parallel form pushed onto short rows (where it gives up on some streams and hands them to the chain kernel): the oracle's tokens every time; shapes with
+    and without a last row of another height, with and without an odd last tile per row"""
+    if mode == "chain_kernel":
+        monkeypatch.setenv("EZHIP_DEC_SCAN", "0")
+    if mode == "scan_from_64_tiles_per_row":
+        monkeypatch.setenv("EZHIP_DEC_SCAN_MIN_NTX", "64")
+    nbits = 16
+    tok = pc.token_field(ni, nj, nbits, kind, seed=ni + 3 * nj)
+    z, zlng = _oracle_stream(tok, ni, nj, nbits, 1)
+    zwords = (zlng - 1) // 4 + 1
+    d_z = torch.from_numpy(z[:zwords].view(np.int32).copy()).cuda()
+    d_out = torch.full((1 + ni * nj // 2 + 4,), -1, dtype=torch.int32, device="cuda")
+    assert pk.armn_uncompress_dev(d_out, d_z, zwords, ni, nj, nbits) == ni * nj * 2
+    got = d_out.cpu().numpy().view(np.uint32)
+    words = pc.tokens_to_words(tok)
+    assert np.array_equal(got[:words.size], words), np.nonzero(got[:words.size] != words)[0][:5]
+    assert np.all(got[1 + ni * nj // 2:] == 0xFFFFFFFF)
+
+
 @pytest.mark.parametrize("swap", [1, 0])
 def test_armn_uncompress_host_in_place_round_trip(swap):
     ni, nj, nbits = 301, 200, 16

@@ -21,3 +21,13 @@ for rep in range(5):
     r = pk.armn_uncompress_batch_dev(toks, 1 + n // 2, recs[4:], stride, cap, no, mo, 16, 1)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"decode: {dt * 1e3:.2f} ms (rc {r})")
+ref = toks.clone()
+for mode in ("0", "2"):
+    os.environ["EZHIP_DEC_SCAN"] = mode
+    toks.zero_()
+    for rep in range(1 if mode == "2" else 5):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r = pk.armn_uncompress_batch_dev(toks, 1 + n // 2, recs[4:], stride, cap, no, mo, 16, 1)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"EZHIP_DEC_SCAN={mode}: {dt * 1e3:.2f} ms (rc {r}); tokens equal to the default form's: {bool(torch.equal(toks, ref))}")
+os.environ.pop("EZHIP_DEC_SCAN")
