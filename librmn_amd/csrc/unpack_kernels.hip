@@ -727,45 +727,91 @@ __global__ __launch_bounds__(256) void k_dsc_dtab(const unsigned *z_all, size_t 
     dtab[c] = (short)d;
 }
 
-/* the recurrence over the rows of tiles: rowc[r] = canonical index of the odd tile that ends row r.  One wave; the lanes fetch the neighbourhood of the next
- * row's index while the current value is on its way */
-__global__ __launch_bounds__(64) void k_dsc_rows(const unsigned *z_all, size_t z_stride, int ni, int nj, unsigned *st_all, size_t st_stride,
-                                                 const short *dtab_all, size_t dtab_stride, unsigned *rowc_all, size_t row_stride, unsigned capc, int plain)
+/* the recurrence over the rows of tiles: rowc[r] = canonical index of the odd tile that ends row r; c(r + 1) = c(r) + ntx - dtab[c(r)].  A dependent global
+ * load per row costs ~0.4 us (1200 rows: 0.5 ms, measured; prefetching the neighbourhoods of the next rows through LDS did not beat it: the loads of a chunk
+ * cost what they save).  Instead the table is composed with itself three times, for ALL indices in parallel (k_dsc_jump: J1[c] = the shift change over two
+ * rows from c, J2 over four, J3 over eight; one gather pass each), the serial walk takes eight rows per step (k_dsc_rows: 150 dependent loads) and the
+ * rows in between follow from the one-row table, every group of eight on its own lane (k_dsc_rowfill) */
+#define DSC_J_INVALID 0x7FFFFFFF
+template <class TIN>
+__global__ __launch_bounds__(256) void k_dsc_jump(const unsigned *z_all, size_t z_stride, int ni, int nj, const unsigned *st_all, size_t st_stride,
+                                                  const TIN *in_all, size_t in_stride, int *out_all, size_t out_stride, unsigned rows, unsigned capc, int plain)
 {
-    const int f = blockIdx.x, lane = threadIdx.x;
+    const int f = blockIdx.y;
+    const unsigned *st = st_all + (size_t)f * st_stride;
+    if (st[DSC_FAIL]) return;
+    const unsigned lim = min(st[DSC_NCANON], capc), c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= lim) return;
+    DecGeom g;
+    if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, plain)) return;
+    const TIN *in = in_all + (size_t)f * in_stride;
+    const int inval = sizeof(TIN) == 2 ? DSC_D_INVALID : DSC_J_INVALID;
+    int out = DSC_J_INVALID;
+    const int a = (int)in[c];
+    if (a != inval) {
+        const long long c2 = (long long)c + (long long)rows * g.ntx - a;
+        if (c2 >= 0 && c2 < (long long)lim) { const int b = (int)in[c2]; if (b != inval) out = a + b; }
+    }
+    out_all[(size_t)f * out_stride + c] = out;
+}
+__global__ __launch_bounds__(64) void k_dsc_rows(const unsigned *z_all, size_t z_stride, int ni, int nj, unsigned *st_all, size_t st_stride,
+                                                 const short *dtab_all, size_t dtab_stride, const int *j3_all, size_t j_stride,
+                                                 unsigned *rowc_all, unsigned *head_all, size_t row_stride, unsigned capc, int plain)
+{
+    const int f = blockIdx.x;
+    if (threadIdx.x) return;
     unsigned *st = st_all + (size_t)f * st_stride;
     if (st[DSC_FAIL]) return;
     DecGeom g;
     if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, plain)) return;
     const short *dtab = dtab_all + (size_t)f * dtab_stride;
-    unsigned *rowc = rowc_all + (size_t)f * row_stride;
+    const int *j3 = j3_all + (size_t)f * j_stride;
+    unsigned *rowc = rowc_all + (size_t)f * row_stride, *head = head_all + (size_t)f * row_stride;
     const unsigned rint = st[DSC_RINT], lim = min(st[DSC_NCANON], capc), ntx = (unsigned)g.ntx;
-    unsigned c = ntx - 1;
-    int fail = 0, dprev = 0;
-    /* lane l holds dtab[base + l]: the neighbourhood of the row's index, fetched one row ahead -- around the place the PREVIOUS row's shift change would put
-     * the next index (consecutive changes differ by a few tiles), while the current row's value is still on its way */
-    auto fetch = [&](long long b) -> int { const long long i = b + lane; return (i >= 0 && i < (long long)lim) ? (int)dtab[i] : DSC_D_INVALID; };
-    long long base = (long long)c - 32;
-    int mine = fetch(base);
-    for (unsigned r = 0; r < rint; r++) {
-        if (c >= lim) { fail = 8; break; }
-        if (lane == 0) rowc[r] = c;
+    unsigned c = ntx - 1, r = 0;
+    while (r < rint) {
+        if (c >= lim) { st[DSC_FAIL] = 8; return; }
+        rowc[r] = c; head[r] = 0;
         if (r + 1 >= rint) break;
-        const long long nbase = (long long)c + ntx - dprev - 32;
-        const int ahead = fetch(nbase);                          /* issued before the current value is needed */
-        const long long off = (long long)c - base;
-        const int d = (off >= 0 && off < 64) ? __shfl(mine, (int)off, 64) : (int)dtab[c];
-        if (d == DSC_D_INVALID) { fail = 9; break; }
-        c = c + ntx - (unsigned)d;
-        dprev = d; base = nbase; mine = ahead;
+        const int j = r + 8 < rint ? j3[c] : DSC_J_INVALID;
+        if (j != DSC_J_INVALID) { head[r] = 1; c = c + 8 * ntx - (unsigned)j; r += 8; }       /* rows r + 1 .. r + 7: k_dsc_rowfill */
+        else {
+            const int d = dtab[c];
+            if (d == DSC_D_INVALID) { st[DSC_FAIL] = 9; return; }
+            c = c + ntx - (unsigned)d; r++;
+        }
     }
-    if (lane == 0 && fail) st[DSC_FAIL] = (unsigned)fail;
+}
+__global__ __launch_bounds__(64) void k_dsc_rowfill(const unsigned *z_all, size_t z_stride, int ni, int nj, unsigned *st_all, size_t st_stride,
+                                                    const short *dtab_all, size_t dtab_stride, unsigned *rowc_all, const unsigned *head_all, size_t row_stride, unsigned capc, int plain)
+{
+    const int f = blockIdx.y;
+    unsigned *st = st_all + (size_t)f * st_stride;
+    if (st[DSC_FAIL]) return;
+    const unsigned r = blockIdx.x * 64 + threadIdx.x;                     /* (one lane per row; the rows at which the walk took an eight-row step have work) */
+    if (r + 8 >= st[DSC_RINT]) return;
+    DecGeom g;
+    if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, plain)) return;
+    if (!head_all[(size_t)f * row_stride + r]) return;
+    const short *dtab = dtab_all + (size_t)f * dtab_stride;
+    unsigned *rowc = rowc_all + (size_t)f * row_stride;
+    unsigned c = rowc[r];
+    const unsigned lim = min(st[DSC_NCANON], capc);
+    for (int i = 1; i < 8; i++) {                                         /* (J3[c] valid: every step on the way is) */
+        if (c >= lim) { st[DSC_FAIL] = 14; return; }
+        c = c + (unsigned)g.ntx - (unsigned)(int)dtab[c]; rowc[r + i] = c;
+    }
 }
 
-/* the stretch between the odd tile that ends row r and the tile where the real chain is canonical again: tile by tile; rowmerge[r + 1] = that tile's index */
+/* the stretch between the odd tile that ends row r and the window in which the real chain is canonical again.  One lane per row: tile by tile to the end of
+ * the odd tile's window, then window by window through the speculation table until the entry is the canonical one -- the windows on the way are listed (window,
+ * entry, first tile) and k_dsc_stretch2 writes their tiles, one lane per listed window.  rowmerge[r + 1] = the first tile that is canonical again */
+#define DSC_LIST 128
 __global__ __launch_bounds__(64) void k_dsc_stretch(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, unsigned *st_all, size_t st_stride,
+                                                    const unsigned *tab_all, size_t tab_stride, const unsigned *wentc_all, size_t went_stride,
                                                     const unsigned *tpc_all, size_t tpc_stride, const unsigned *rowc_all, unsigned *rowmerge_all, size_t row_stride,
-                                                    unsigned *tilepos_all, size_t tp_stride, unsigned capc, int plain)
+                                                    unsigned *slist_all, unsigned *nlist_all, size_t list_stride,
+                                                    unsigned *tilepos_all, size_t tp_stride, int nwin, int plain)
 {
     const int f = blockIdx.y;
     unsigned *st = st_all + (size_t)f * st_stride;
@@ -773,31 +819,59 @@ __global__ __launch_bounds__(64) void k_dsc_stretch(const unsigned *z_all, size_
     const unsigned r = blockIdx.x * 64 + threadIdx.x, rint = st[DSC_RINT];
     if (r >= rint) return;
     unsigned *rowmerge = rowmerge_all + (size_t)f * row_stride;
+    unsigned *nlist = nlist_all + (size_t)f * row_stride;
+    nlist[r] = 0;
     if (r == 0) rowmerge[0] = 0;
     if (r + 1 >= rint) return;
     const unsigned *z = z_all + (size_t)f * z_stride;
     DecGeom g;
     if (!dec_geom(g, z, ni, nj, plain)) return;
     const size_t nwords = z_words - 1;
-    const unsigned *tpc = tpc_all + (size_t)f * tpc_stride;
+    const unsigned *tpc = tpc_all + (size_t)f * tpc_stride, *tab = tab_all + (size_t)f * tab_stride, *wentc = wentc_all + (size_t)f * went_stride;
     unsigned *tilepos = tilepos_all + (size_t)f * tp_stride;
-    const unsigned ntx = (unsigned)g.ntx, lim = min(st[DSC_NCANON], capc);
-    unsigned c = rowc_all[(size_t)f * row_stride + r];
-    const unsigned cn = rowc_all[(size_t)f * row_stride + r + 1];
+    unsigned *slist = slist_all + (size_t)f * list_stride + (size_t)r * DSC_LIST * 3;
+    const unsigned ntx = (unsigned)g.ntx;
+    const unsigned c = rowc_all[(size_t)f * row_stride + r], cn = rowc_all[(size_t)f * row_stride + r + 1];
     unsigned t = (r + 1) * ntx;                               /* first tile of row r + 1 */
+    const unsigned tend = t + ntx - 1;                        /* the next odd tile: the chains must have met before */
     const unsigned pos = tpc[c];
     unsigned p = pos + (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.mlast * g.istep);
-    c++;
-    unsigned pc = c < lim ? tpc[c] : 0xFFFFFFFFu;
-    const unsigned tend = t + ntx - 1;                        /* the next odd tile: the chains must have met before */
+    unsigned w = pos / DW;
+    const unsigned end = (w + 1) * DW;
+    while (p < end && t < tend) { tilepos[t] = p; p += (unsigned)dec_step(g, getbits_g(z + 1, nwords, p, g.C), g.n_int); t++; }
+    if (p < end) { st[DSC_FAIL] = 10; return; }
+    unsigned e = p - end, n = 0;
+    w++;
     bool ok = false;
-    while (t < tend) {
-        if (p == pc) { ok = true; break; }
-        if (p < pc) { tilepos[t] = p; p += (unsigned)dec_step(g, getbits_g(z + 1, nwords, p, g.C), g.n_int); t++; }
-        else { c++; pc = c < lim ? tpc[c] : 0xFFFFFFFFu; }
+    for (int h = 0; h <= DSC_LIST && (int)w < nwin && t < tend; h++) {
+        if (wentc[2 * (size_t)w] == e) { ok = t - wentc[2 * (size_t)w + 1] == (r + 2) * ntx - 1 - cn; break; }      /* (the shift behind the stretch is the one the recurrence used) */
+        if (n >= DSC_LIST || e >= (unsigned)g.ext) break;
+        slist[3 * n] = w; slist[3 * n + 1] = e; slist[3 * n + 2] = t; n++;
+        const unsigned v = tab[(size_t)w * DEXT + e];
+        t += v >> 16; e = v & 0xFFFFu; w++;
     }
-    if (!ok || t - c != (r + 2) * ntx - 1 - cn) { st[DSC_FAIL] = 10; return; }       /* (the shift behind the stretch is the one the recurrence used) */
+    if (!ok || t >= tend) { st[DSC_FAIL] = 13; return; }
+    nlist[r] = n;
     rowmerge[r + 1] = t;
+}
+__global__ __launch_bounds__(256) void k_dsc_stretch2(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, const unsigned *st_all, size_t st_stride,
+                                                      const unsigned *slist_all, const unsigned *nlist_all, size_t list_stride, size_t row_stride,
+                                                      unsigned *tilepos_all, size_t tp_stride, int plain)
+{
+    const int f = blockIdx.y;
+    const unsigned *st = st_all + (size_t)f * st_stride;
+    if (st[DSC_FAIL]) return;
+    const unsigned idx = blockIdx.x * 256 + threadIdx.x, r = idx / DSC_LIST, i = idx % DSC_LIST;
+    if (r >= st[DSC_RINT] || i >= nlist_all[(size_t)f * row_stride + r]) return;
+    const unsigned *z = z_all + (size_t)f * z_stride;
+    DecGeom g;
+    if (!dec_geom(g, z, ni, nj, plain)) return;
+    const size_t nwords = z_words - 1;
+    const unsigned *sl = slist_all + (size_t)f * list_stride + ((size_t)r * DSC_LIST + i) * 3;
+    unsigned *tilepos = tilepos_all + (size_t)f * tp_stride;
+    unsigned pos = sl[0] * DW + sl[1], t = sl[2];
+    const unsigned end = (sl[0] + 1) * DW;
+    while (pos < end) { tilepos[t++] = pos; pos += (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.n_int); }
 }
 
 /* every tile outside the stretches: its canonical twin, shifted */
@@ -980,7 +1054,7 @@ extern "C" size_t packhip_armn_dec_work_bytes(int ni, int nj, size_t z_words)
     const size_t capc = dec_max_tiles(ni, nj) + DSC_MARGIN, nty = (size_t)(nj + 2) / 3 + 2;
     return al256(4 * dec_max_tiles(ni, nj)) + al256(2 * (n + 8)) + al256(2 * (size_t)DEC_BANDS * ni) + 2 * al256(4 * nwin * DEXT) + 2 * al256(8 * nwin) + 256
            /* the parallel form: canonical tile positions, shift changes, merged exits, block entries / counts, canonical window entries, rows, state */
-           + al256(4 * capc) + al256(2 * capc) + al256(2 * nwin) + 2 * al256(4 * (nwin / 8 + 2)) + 2 * al256(8 * nwin) + 2 * al256(4 * nty) + 256;
+           + al256(4 * capc) + al256(2 * capc) + al256(2 * nwin) + 2 * al256(4 * (nwin / 8 + 2)) + 2 * al256(8 * nwin) + 4 * al256(4 * nty) + al256(12 * 128 * nty) + 2 * al256(4 * capc) + 256;
 }
 
 /* d_out: (1 + ni*nj/2) words per field, zero-filled first (the odd trailing half-word).  d_status: one int per field
@@ -1045,6 +1119,11 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
     unsigned *wentc8 = (unsigned *)wk;                      wk += al256(8 * (size_t)nwin);
     unsigned *rowc = (unsigned *)wk;                        wk += al256(4 * ntyc);
     unsigned *rowmerge = (unsigned *)wk;                    wk += al256(4 * ntyc);
+    unsigned *nlist = (unsigned *)wk;                       wk += al256(4 * ntyc);
+    unsigned *slist = (unsigned *)wk;                       wk += al256(12 * DSC_LIST * ntyc);
+    unsigned *rowhead = (unsigned *)wk;                     wk += al256(4 * ntyc);
+    int *jA = (int *)wk;                                    wk += al256(4 * capc);
+    int *jB = (int *)wk;                                    wk += al256(4 * capc);
     unsigned *dst = (unsigned *)wk;
     const char *scan_env = getenv("EZHIP_DEC_SCAN");
     const int scan = scan_env ? atoi(scan_env) : 1;          /* the chain between row ends in parallel (k_dsc_*, the default since the end of round 3); the serial chain
@@ -1072,6 +1151,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
         for (int f = 0; f < nfields; f++) {
             if (hipMemsetAsync((char *)wentc + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
             if (hipMemsetAsync((char *)wentc8 + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
+            if (hipMemsetAsync((char *)rowhead + (size_t)f * work_stride_bytes, 0, 4 * ntyc, st) != hipSuccess) return -1;      /* (the row walk marks the rows it steps from) */
         }
         const size_t ws2b = work_stride_bytes / 2;
         hipLaunchKernelGGL(k_dsc_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, wentc, ws4, nwin, plain, getenv("EZHIP_DEC_SCAN_MIN_NTX") ? atoi(getenv("EZHIP_DEC_SCAN_MIN_NTX")) : 1024);
@@ -1081,8 +1161,16 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
         hipLaunchKernelGGL(k_armn_dec_expand8, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, ws4, wentc, wentc8, ws4, nwin, (const unsigned *)NULL, (size_t)0);
         hipLaunchKernelGGL(k_dsc_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, wentc, ws4, tpc, ws4, (unsigned)capc, nwin, plain);
         hipLaunchKernelGGL(k_dsc_dtab, dim3((unsigned)((capc + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, tab, ws4, wentc, ws4, tpc, ws4, dtab, ws2b, (unsigned)capc, nwin, plain);
-        hipLaunchKernelGGL(k_dsc_rows, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, dtab, ws2b, rowc, ws4, (unsigned)capc, plain);
-        hipLaunchKernelGGL(k_dsc_stretch, dim3((unsigned)((ntyc + 63) / 64), nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, tpc, ws4, rowc, rowmerge, ws4, tilepos, ws4, (unsigned)capc, plain);
+        {
+            const dim3 gj((unsigned)((capc + 255) / 256), nfields);
+            hipLaunchKernelGGL(k_dsc_jump<short>, gj, dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, dtab, ws2b, jA, ws4, 1u, (unsigned)capc, plain);
+            hipLaunchKernelGGL(k_dsc_jump<int>, gj, dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, jA, ws4, jB, ws4, 2u, (unsigned)capc, plain);
+            hipLaunchKernelGGL(k_dsc_jump<int>, gj, dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, jB, ws4, jA, ws4, 4u, (unsigned)capc, plain);
+        }
+        hipLaunchKernelGGL(k_dsc_rows, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, dtab, ws2b, jA, ws4, rowc, rowhead, ws4, (unsigned)capc, plain);
+        hipLaunchKernelGGL(k_dsc_rowfill, dim3((unsigned)((ntyc + 63) / 64), nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, dtab, ws2b, rowc, rowhead, ws4, (unsigned)capc, plain);
+        hipLaunchKernelGGL(k_dsc_stretch, dim3((unsigned)((ntyc + 63) / 64), nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, tab, ws4, wentc, ws4, tpc, ws4, rowc, rowmerge, ws4, slist, nlist, ws4, tilepos, ws4, nwin, plain);
+        hipLaunchKernelGGL(k_dsc_stretch2, dim3((unsigned)((ntyc * DSC_LIST + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, slist, nlist, ws4, ws4, tilepos, ws4, plain);
         hipLaunchKernelGGL(k_dsc_final, dim3((unsigned)((max_tiles + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, tpc, ws4, rowc, rowmerge, ws4, tilepos, ws4, plain);
         hipLaunchKernelGGL(k_dsc_lastrow, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, tpc, ws4, rowc, ws4, tilepos, ws4, d_status, plain);
         skip = dst;                                          /* dst[DSC_OK] of a field: 1 when its tile positions are complete */
