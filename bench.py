@@ -232,7 +232,7 @@ def extras(ez, torch, stream, d_out, d_in):
         zmean = float(np.mean([z for z in zl_ if z > 0]))
         ex["armn_uncompress"] = {"workload": "armn_compress UNCOMPRESS of 7200 x 3601 16-bit records in HBM (ratio %.2f)" % (zmean / (2.0 * n)),
                                  "single_stream_ms": one_ms, "batch_of_16_ms_per_field": batch16_ms / 16, "batch_of_32_ms_per_field": batch_ms / Fd,
-                                 "note": "one chain of tile headers per stream (one CU each): a batch decodes its streams side by side, the per-field time falls with the batch (DESIGN 9 item 4)",
+                                 "note": "the chain of tile headers between row ends is resolved in parallel since the end of round 3 (canonical chain from merged eight-window blocks, the row ends as a recurrence on the tile-index shift: DESIGN 9 item 4); the serial chain kernel (one CU per stream) only for streams that form gives up on",
                                  "single_stream_GBps": (zmean + 2.0 * n) / (one_ms * 1e-3) / 1e9, "single_stream_frac_of_hbm_peak": (zmean + 2.0 * n) / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                  "batch_GBps": (zmean + 2.0 * n) * Fd / (batch_ms * 1e-3) / 1e9, "batch_frac_of_hbm_peak": (zmean + 2.0 * n) * Fd / (batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         del recs, toks
