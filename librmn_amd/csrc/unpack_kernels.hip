@@ -22,6 +22,12 @@
  *                     tile index.
  *   k_armn_dec_emit   all CUs, one lane per window: walks its window from the true entry -> bit position of every tile.
  *
+ * Since the end of round 3 the serial kernel is the FALLBACK.  Streams with long rows of tiles (>= 1024 tiles: the fields of the cfg5 path) take
+ *   k_dsc_*           the chain between row ends resolved in parallel: eight composed windows leave one exit whatever the entry (measured: tools/probe_merge.py),
+ *                     so the chain that never meets a row end is known for all eight-window blocks at once; the odd tile that ends a row shifts the tile index
+ *                     for a few windows, and the shifts of the ~1200 rows are a recurrence on a table computed for every tile in parallel (see the block in
+ *                     front of k_dsc_init).  A stream that form gives up on (a flag per field, set on the device) goes through k_armn_dec_hop as before.
+ *
  * then
  *   k_armn_dec_tiles  one thread per tile: reads its tokens.  MINIMUM: value = minimum + token, final.
  *                     PARALLELOGRAM: the sign-extended Lorenzo difference mod 2^16.
