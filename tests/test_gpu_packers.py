@@ -264,6 +264,40 @@ def test_armn_uncompress_parallel_form_and_chain_kernel(ni, nj, kind, mode, monk
     assert np.all(got[1 + ni * nj // 2:] == 0xFFFFFFFF)
 
 
+@pytest.mark.parametrize("damage", ["half_the_stream", "bit_flips", "zeroed_piece"])
+def test_armn_uncompress_damaged_streams_both_forms_agree(damage, monkeypatch):
+    """a truncated or corrupted record: the parallel form either follows the same (wrong) chain as the serial kernel or gives the field up to it -- the same
+    return code and, where a result exists, the same words; nothing hangs, nothing is read or written outside the buffers"""
+    ni, nj, nbits = 3100, 200, 16
+    tok = pc.token_field(ni, nj, nbits, "smooth", seed=77)
+    z, zlng = _oracle_stream(tok, ni, nj, nbits, 1)
+    zwords = (zlng - 1) // 4 + 1
+    zd = z[:zwords].copy()
+    rng = np.random.default_rng(5)
+    if damage == "half_the_stream":
+        zd = zd[:zwords // 2].copy()
+    elif damage == "bit_flips":
+        for k in rng.integers(zwords // 8, zwords, 40):
+            zd[k] ^= np.uint32(1 << int(rng.integers(0, 32)))
+    else:
+        zd[zwords // 3: zwords // 3 + 300] = 0
+    res = {}
+    for mode in ("default", "chain_kernel"):
+        if mode == "chain_kernel":
+            monkeypatch.setenv("EZHIP_DEC_SCAN", "0")
+        else:
+            monkeypatch.delenv("EZHIP_DEC_SCAN", raising=False)
+        d_z = torch.from_numpy(zd.view(np.int32).copy()).cuda()
+        d_out = torch.full((1 + ni * nj // 2 + 4,), -1, dtype=torch.int32, device="cuda")
+        rc = pk.armn_uncompress_dev(d_out, d_z, zd.size, ni, nj, nbits)
+        torch.cuda.synchronize()
+        res[mode] = (rc, d_out.cpu().numpy().copy())
+    assert res["default"][0] == res["chain_kernel"][0], (res["default"][0], res["chain_kernel"][0])
+    if res["default"][0] > 0:
+        assert np.array_equal(res["default"][1], res["chain_kernel"][1])
+    assert np.all(res["default"][1][1 + ni * nj // 2:] == -1)
+
+
 @pytest.mark.parametrize("swap", [1, 0])
 def test_armn_uncompress_host_in_place_round_trip(swap):
     ni, nj, nbits = 301, 200, 16
