@@ -564,7 +564,7 @@ enum { DSC_OK = 0, DSC_WB, DSC_EB, DSC_TB, DSC_K, DSC_NCANON, DSC_FAIL, DSC_RINT
 #define DSC_D_INVALID 0x7FFF
 #define DSC_MARGIN 65536                 /* canonical tiles kept beyond the field's own tile count */
 
-__device__ __forceinline__ bool dsc_eligible(const DecGeom &g, int nwin, int min_ntx) { return g.method == 4 && g.ntx >= min_ntx && g.nty >= 3 && nwin >= 64; }
+__device__ __forceinline__ bool dsc_eligible(const DecGeom &g, int nwin, int min_ntx) { return g.ntx >= min_ntx && g.nty >= 3 && nwin >= 64; }       /* (both methods: the geometry and dec_step carry the difference) */
 
 /* one wave per field: the first (partial) window tile by tile, the block origin */
 __global__ __launch_bounds__(64) void k_dsc_init(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, unsigned *st_all, size_t st_stride,
@@ -1153,7 +1153,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
     if (phase == 1) { hipError_t e1 = hipGetLastError(); if (e1 != hipSuccess) { fprintf(stderr, "<armn_compress> UNCOMPRESS launch failed: %s\n", hipGetErrorString(e1)); return -1; } return 0; }
     const unsigned *skip = NULL;
     if (scan) {
-        const int ext_max = 5 + 9 * 32;                      /* (the kernels read the geometry from the stream; here ext only bounds a table row: the larger of the two) */
+        const int ext_max = DEXT;                            /* (the kernels read the geometry from the stream; here ext only bounds a table row) */
         for (int f = 0; f < nfields; f++) {
             if (hipMemsetAsync((char *)wentc + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
             if (hipMemsetAsync((char *)wentc8 + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;

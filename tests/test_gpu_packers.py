@@ -237,13 +237,14 @@ def test_armn_uncompress_matches_oracle_decoder(ni, nj, kind, nbits, level):
     assert np.all(got[1 + ni * nj // 2:] == 0xFFFFFFFF)            # nothing written past the (1 + n/2) words
 
 
-SCAN_SHAPES = [(3100, 200), (3076, 64), (3074, 47), (3073, 46), (1501, 300), (600, 601), (257, 1000)]      # rows of >= 1024 tiles take the parallel form by default
+SCAN_SHAPES = [(3100, 200), (3076, 64), (3074, 47), (3073, 46), (5200, 40), (1501, 300), (600, 601), (257, 1000)]      # rows of >= 1024 tiles take the parallel form by default
 
 
 @pytest.mark.parametrize("ni,nj", SCAN_SHAPES)
 @pytest.mark.parametrize("kind", ["smooth", "noisy", "constant", "bigdiff"])
 @pytest.mark.parametrize("mode", ["default", "chain_kernel", "scan_from_64_tiles_per_row"])
-def test_armn_uncompress_parallel_form_and_chain_kernel(ni, nj, kind, mode, monkeypatch):
+@pytest.mark.parametrize("level", [1, 0])
+def test_armn_uncompress_parallel_form_and_chain_kernel(ni, nj, kind, mode, level, monkeypatch):
     """the chain between row ends resolved in parallel (k_dsc_*: the default for rows of >= 1024 tiles), the serial chain kernel (EZHIP_DEC_SCAN=0) and the
     parallel form pushed onto short rows (where it gives up on some streams and hands them to the chain kernel): the oracle's tokens every time; shapes with
     and without a last row of another height, with and without an odd last tile per row"""
@@ -253,7 +254,7 @@ def test_armn_uncompress_parallel_form_and_chain_kernel(ni, nj, kind, mode, monk
         monkeypatch.setenv("EZHIP_DEC_SCAN_MIN_NTX", "64")
     nbits = 16
     tok = pc.token_field(ni, nj, nbits, kind, seed=ni + 3 * nj)
-    z, zlng = _oracle_stream(tok, ni, nj, nbits, 1)
+    z, zlng = _oracle_stream(tok, ni, nj, nbits, level)              # level 1: PARALLELOGRAM (tiles of 3 x 3), 0: MINIMUM (5 x 5)
     zwords = (zlng - 1) // 4 + 1
     d_z = torch.from_numpy(z[:zwords].view(np.int32).copy()).cuda()
     d_out = torch.full((1 + ni * nj // 2 + 4,), -1, dtype=torch.int32, device="cuda")
