@@ -236,6 +236,19 @@ def extras(ez, torch, stream, d_out, d_in):
                                  "single_stream_GBps": (zmean + 2.0 * n) / (one_ms * 1e-3) / 1e9, "single_stream_frac_of_hbm_peak": (zmean + 2.0 * n) / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                  "batch_GBps": (zmean + 2.0 * n) * Fd / (batch_ms * 1e-3) / 1e9, "batch_frac_of_hbm_peak": (zmean + 2.0 * n) * Fd / (batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         del recs, toks
+        # the IEEE-32 compressor's read side (datyp 133): c_armn_uncompress32 through the API, host stream in, host field out (its tile chains are walked on
+        # the host: the device walk is built and measured slower)
+        import ezcases as _ec
+        f32 = _ec.synth_field(NI_D, NJ_D, seed=5)
+        zl32, z32 = pk.armn_compress32(f32, NI_D, NJ_D, 32)
+        if zl32 > 0:
+            best = 1e9
+            for _ in range(3):
+                t0_ = time.perf_counter(); rc32, back32 = pk.armn_uncompress32(z32, NI_D, NJ_D, 32); best = min(best, time.perf_counter() - t0_)
+            ex["armn_uncompress32"] = {"workload": "c_armn_uncompress32 of a 7200 x 3601 REAL field (32 bits kept, ratio %.2f), host arrays" % (zl32 / (4.0 * n)),
+                                       "ms_per_field": best * 1e3, "bit_identical": bool(rc32 == n and np.array_equal(back32.view(np.uint32), f32.view(np.uint32))),
+                                       "GBps": (zl32 + 4.0 * n) / best / 1e9, "frac_of_hbm_peak": (zl32 + 4.0 * n) / best / 1e9 / HBM_PEAK_GBPS,
+                                       "note": "host stream up, field down over PCIe; three host threads walk the sign runs and the two tile chains meanwhile"}
     except Exception as e:   # noqa: BLE001
         ex["error"] = repr(e)
     return ex
