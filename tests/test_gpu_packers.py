@@ -237,7 +237,7 @@ def test_armn_uncompress_matches_oracle_decoder(ni, nj, kind, nbits, level):
     assert np.all(got[1 + ni * nj // 2:] == 0xFFFFFFFF)            # nothing written past the (1 + n/2) words
 
 
-SCAN_SHAPES = [(3100, 200), (3076, 64), (3074, 47), (3073, 46), (5200, 40), (1501, 300), (600, 601), (257, 1000)]      # rows of >= 1024 tiles take the parallel form by default
+SCAN_SHAPES = [(3100, 200), (3076, 64), (3076, 65), (3077, 64), (3074, 47), (3073, 46), (5200, 40), (1501, 300), (600, 601), (257, 1000)]      # odd last tile per row or not x last row of another height or not      # rows of >= 1024 tiles take the parallel form by default
 
 
 @pytest.mark.parametrize("ni,nj", SCAN_SHAPES)
