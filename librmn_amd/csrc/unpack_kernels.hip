@@ -22,7 +22,7 @@
  *                     tile index.
  *   k_armn_dec_emit   all CUs, one lane per window: walks its window from the true entry -> bit position of every tile.
  *
- * Since the end of round 3 the serial kernel is the FALLBACK.  Streams with long rows of tiles (>= 1024 tiles: the fields of the cfg5 path) take
+ * Since the end of round 3 the serial kernel is the FALLBACK.  Streams with long rows of tiles (>= 768 tiles: the fields of the cfg2 / cfg5 path) take
  *   k_dsc_*           the chain between row ends resolved in parallel: eight composed windows leave one exit whatever the entry (measured: tools/probe_merge.py),
  *                     so the chain that never meets a row end is known for all eight-window blocks at once; the odd tile that ends a row shifts the tile index
  *                     for a few windows, and the shifts of the ~1200 rows are a recurrence on a table computed for every tile in parallel (see the block in
@@ -1160,7 +1160,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
             if (hipMemsetAsync((char *)rowhead + (size_t)f * work_stride_bytes, 0, 4 * ntyc, st) != hipSuccess) return -1;      /* (the row walk marks the rows it steps from) */
         }
         const size_t ws2b = work_stride_bytes / 2;
-        hipLaunchKernelGGL(k_dsc_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, wentc, ws4, nwin, plain, getenv("EZHIP_DEC_SCAN_MIN_NTX") ? atoi(getenv("EZHIP_DEC_SCAN_MIN_NTX")) : 1024);
+        hipLaunchKernelGGL(k_dsc_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, wentc, ws4, nwin, plain, getenv("EZHIP_DEC_SCAN_MIN_NTX") ? atoi(getenv("EZHIP_DEC_SCAN_MIN_NTX")) : 768);       /* (rows of 853 tiles: 0.65 against 0.65 - 1.1 ms; of 480: the form gives up and costs 0.2 ms more than it saves) */
         hipLaunchKernelGGL(k_dsc_m8, dim3((nwin + 3) / 4, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, tab8, ws4, m8, ws2b, nwin, plain);
         hipLaunchKernelGGL(k_dsc_blocks, dim3((unsigned)((nblk + 255) / 256), nfields), dim3(256), 0, st, dst, ws4, tab8, ws4, m8, ws2b, eblk, cblk, ws4, ext_max);
         hipLaunchKernelGGL(k_dsc_scan, dim3(nfields), dim3(1024), 0, st, dst, ws4, tab, ws4, eblk, cblk, ws4, wentc, wentc8, ws4, nwin, ext_max);

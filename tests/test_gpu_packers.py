@@ -245,7 +245,7 @@ SCAN_SHAPES = [(3100, 200), (3076, 64), (3076, 65), (3077, 64), (3074, 47), (307
 @pytest.mark.parametrize("mode", ["default", "chain_kernel", "scan_from_64_tiles_per_row"])
 @pytest.mark.parametrize("level", [1, 0])
 def test_armn_uncompress_parallel_form_and_chain_kernel(ni, nj, kind, mode, level, monkeypatch):
-    """the chain between row ends resolved in parallel (k_dsc_*: the default for rows of >= 1024 tiles), the serial chain kernel (EZHIP_DEC_SCAN=0) and the
+    """the chain between row ends resolved in parallel (k_dsc_*: the default for rows of >= 768 tiles), the serial chain kernel (EZHIP_DEC_SCAN=0) and the
     parallel form pushed onto short rows (where it gives up on some streams and hands them to the chain kernel): the oracle's tokens every time; shapes with
     and without a last row of another height, with and without an odd last tile per row"""
     if mode == "chain_kernel":

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import ezcases as ec
 from librmn_amd import packers as pk
-no, mo = 7200, 3601
+no, mo = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (7200, 3601)
 n = no * mo
 noise = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-5
 stride = 4 + n // 2 + 64
