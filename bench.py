@@ -254,24 +254,175 @@ def extras(ez, torch, stream, d_out, d_in):
     return ex
 
 
+def free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def launch_ranks(n, argv, stub):
+    """`python bench.py --gpus N` without a launcher's WORLD_SIZE in the environment: start N FRESH rank processes (this file again, one per
+    LOCAL_RANK, rendezvous on 127.0.0.1) BEFORE anything in this process touches a GPU, wait for them, return the worst exit code.  The
+    parent never initialises HIP (torch.cuda.device_count() only counts devices) and never exec()s: children are ordinary subprocesses."""
+    import subprocess
+    if not stub:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} asked for, {have} GPU(s) visible on this node: refusing to report an N-GPU line from fewer devices\n")
+            return 2
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_LAUNCHED_BY="bench.py")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    worst = 0
+    pending = list(procs)
+    while pending:
+        for pr in list(pending):
+            rc = pr.poll()
+            if rc is None:
+                continue
+            pending.remove(pr)
+            if rc != 0:
+                worst = worst or rc
+                for other in pending:          # a dead rank leaves the others in a collective: end exactly the processes started here
+                    other.terminate()
+        time.sleep(0.05)
+    return worst
+
+
+def timed_region(step, steps, dist, sync, stream=None, torch=None):
+    """the contract's timed region: barrier + synchronize, EXACTLY `steps` steps, synchronize + barrier; returns (wall seconds of this
+    rank, HIP-event ms on the launch stream or None).  The barrier in front goes in BEHIND whatever the caller queued as warm-up: draining
+    the device first and then running the collective left the GPU idle for the length of a barrier and the timed steps started on dropped
+    clocks (+9 % per step, measured with one rank under torchrun against the same box without a process group)."""
+    if dist:
+        dist.barrier()
+    sync()
+    ev0 = ev1 = None
+    if torch is not None and stream is not None:
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    if ev0:
+        ev0.record(stream)
+    for _ in range(steps):
+        step()
+    if ev1:
+        ev1.record(stream)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        dist.barrier()
+    sync()
+    return elapsed, (ev0.elapsed_time(ev1) if ev0 else None)
+
+
+def ranks_seen(dist, device):
+    """how many ranks the collective layer really connected: an all_reduce(SUM) of ones (RCCL on the GPU box)"""
+    if not dist:
+        return 1
+    import torch
+    one = torch.ones(1, dtype=torch.int32, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(one.item())
+
+
+def stub_rank(args, world, rank):
+    """TEST ONLY (--stub-step, tests/test_bench_launcher.py): the launcher, the rendezvous, the barriers, the max-over-ranks time and the
+    rank count of the real bench, over gloo on the CPU with a sleep as the step.  No GPU, no library: the line says "stub": true and
+    carries no throughput -- nothing in it can be mistaken for a measurement."""
+    import torch.distributed as dist
+    from librmn_amd import sharding as sh
+    d = None
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        d = dist
+    F = args.fields_per_step
+    mine = sh.fields_of_rank(F * world, rank, world)
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    elapsed, _ = timed_region(lambda: time.sleep(0.002 * (1 + rank)), args.steps, d, lambda: None)
+    elapsed = sh.max_over_ranks(elapsed)
+    n = ranks_seen(d, "cpu")
+    owned = sh.sum_over_ranks(float(len(mine)))
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (no GPU work)", "stub": True, "value": None, "n_gpus": n, "world_size_env": world,
+                          "gpus_flag": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+                          "fields_owned_by_all_ranks": int(owned), "fields_per_step_per_gpu": F, "feed": args.feed,
+                          "launched_by": os.environ.get("BENCH_LAUNCHED_BY", "external launcher")}), flush=True)
+    if d:
+        d.destroy_process_group()
+
+
+def host_fed(ez, torch, stream, d_in, d_out, F, steps, dist, sh):
+    """SURVEY 8e "bench both": the same batch step with its F source fields starting in (page-locked) HOST memory -- every step uploads
+    F x 38.72 MB inside the timed region; upload of step k+1 (copy stream) overlaps the interpolation of step k (two device buffers).
+    Results stay in HBM as in the headline.  Returns the object for the JSON line."""
+    nin = NI_S * NJ_S
+    h_in = torch.empty((F, nin), dtype=torch.float32, pin_memory=True)
+    h_in.copy_(d_in)
+    bufs = [d_in, torch.empty_like(d_in)]
+    copy_stream = torch.cuda.Stream()
+    up = [torch.cuda.Event() for _ in range(2)]; done = [torch.cuda.Event() for _ in range(2)]
+    k = [0]
+
+    def step():
+        b = k[0] & 1; k[0] += 1
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(done[b])              # the launch that last read this buffer
+            bufs[b].copy_(h_in, non_blocking=True)
+            up[b].record(copy_stream)
+        stream.wait_event(up[b])
+        rc = ez.ezsint_batch_dev(d_out, bufs[b], F)
+        assert rc == 0, rc
+        done[b].record(stream)
+    for _ in range(2):
+        step()
+    elapsed, _ = timed_region(step, steps, dist, torch.cuda.synchronize)
+    elapsed = sh.max_over_ranks(elapsed, device="cuda")
+    world = dist.get_world_size() if dist else 1
+    up_bytes = 4.0 * nin * F
+    return {"workload": f"the headline step with its {F} source fields uploaded from page-locked host memory inside the timed region (double-buffered, copy stream); outputs stay in HBM",
+            "steps": steps, "ms_per_step": elapsed * 1e3 / steps, "value": float(NPTS_OUT) * F * steps * world / elapsed / 1e6, "unit": "Mpoints/s",
+            "upload_GBps_per_gpu": up_bytes * steps / elapsed / 1e9, "upload_bytes_per_step_per_gpu": up_bytes}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node.  Under an external launcher (WORLD_SIZE set) it must agree with it; "
+                                                           "alone with N > 1, bench.py starts the N rank processes itself")
     # defaults: a step is ~1 ms.  After an idle period the launch durations run 0.92, 0.95, 1.08, 1.18, 1.13, 1.06 ... ms
     # and settle at 0.92-0.94 ms only after ~40 launches (power management; profiles/r01_launch_series.txt): warm up
     # past that, then time 60 steps
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--fields-per-step", type=int, default=32)
+    ap.add_argument("--feed", choices=["device", "host"], default="device",
+                    help="device (default, the contract's `value`): sources resident in HBM when the timed region starts.  host: every step uploads its "
+                         "sources from page-locked host memory inside the timed region (SURVEY 8e); the line then says config.feed = host")
+    ap.add_argument("--host-fed-steps", type=int, default=4, help="steps of the host-fed secondary measurement reported next to a device-fed headline (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)      # tests only: see stub_rank
     args = ap.parse_args()
 
-    import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus is not None and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.stub_step))
+    world = int(env_world or "1")
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}: refusing to print a line whose n_gpus is ambiguous")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.stub_step:
+        return stub_rank(args, world, rank)
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X hot path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):      # BENCH_FORCE_DIST: exercise the RCCL path with one rank
@@ -317,26 +468,21 @@ def main():
     prewarm = max(0, 40 - args.warmup)
     for _ in range(prewarm + args.warmup):
         step()
-    # barrier + synchronize in front of the timed steps.  The barrier goes in BEHIND the queued warm-up launches: draining the device first and
-    # then running the collective left the GPU idle for the length of a barrier, and the timed steps started on dropped clocks (+9 % per step
-    # measured with one rank under torchrun against the same box without a process group)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev_ms = ev0.elapsed_time(ev1)
-    elapsed = sh.max_over_ranks(elapsed, device="cuda")        # the batch takes as long as its slowest rank
+    hf = None
+    if args.feed == "host":
+        # the headline region itself is host-fed: `value` then includes the uploads and config.feed says so
+        hf = host_fed(ez, torch, stream, d_in, d_out, F, args.steps, dist, sh)
+        elapsed, ev_ms = hf["ms_per_step"] * args.steps / 1e3, None
+        for _ in range(10):
+            step()
+        _, ev_ms = timed_region(step, args.steps, dist, torch.cuda.synchronize, stream, torch)      # the kernel's own duration for `roofline`
+    else:
+        elapsed, ev_ms = timed_region(step, args.steps, dist, torch.cuda.synchronize, stream, torch)
+        elapsed = sh.max_over_ranks(elapsed, device="cuda")        # the batch takes as long as its slowest rank
+    n_seen = ranks_seen(dist, "cuda")
     checked = check_outputs(ez, torch, d_out, d_in, CHECK_F) if rank == 0 else None
+    if args.feed == "device" and args.host_fed_steps > 0:
+        hf = host_fed(ez, torch, stream, d_in, d_out, F, args.host_fed_steps, dist, sh)      # every rank: it carries barriers
 
     # ---- second timed region: the packers on the interpolated fields (device-resident) ------------------
     from librmn_amd import packers as pk
@@ -417,7 +563,7 @@ def main():
             "metric": "interp Mpoints/s + pack GB/s, 4400x2200->7200x3601 bicubic, 1/2/4/8 GPU",
             "value": total_pts / elapsed / 1e6,
             "unit": "Mpoints/s",
-            "n_gpus": world,
+            "n_gpus": n_seen,                      # what an all_reduce(SUM) of ones over the process group returned, not the flag
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
@@ -430,7 +576,9 @@ def main():
             "check": checked,
             "config": {"workload": "cfg2/cfg4: c_ezsint bicubic G 4400x2200 -> L 7200x3601, polar_correction=yes, "
                                    f"{F} device-resident fields per step per GPU (sharded by record, no collective)",
-                       "fields_per_step_per_gpu": F, "points_per_field": NPTS_OUT, "prewarm_steps": prewarm},
+                       "fields_per_step_per_gpu": F, "points_per_field": NPTS_OUT, "prewarm_steps": prewarm, "feed": args.feed,
+                       "world_size": world, "launched_by": os.environ.get("BENCH_LAUNCHED_BY", "external launcher" if env_world else "single process"),
+                       "develop_build": ez.develop_build(), "env_overrides": sorted(k for k in os.environ if k.startswith(("EZHIP_", "INTERPV_HIP_")))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": (tr[1] + " (PMC passes of the same command, not this run)") if tr else None,
                          "kernel": "k_sepx<3, 16>", "avg_launch_us": kern_us, "fields_per_launch": F,
@@ -465,15 +613,21 @@ def main():
                                                 "frac": ALGO_BYTES / (sf * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                                                 "kernel": "k_sepx<3, 16> (one field per launch, launches back to back)", "avg_launch_us": sf,
                                                 "algorithmic_bytes_per_launch": ALGO_BYTES}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
-            try:
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
-            except Exception as e:   # noqa: BLE001
-                out["cpu_baseline_all_cores"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        if hf is not None:
+            out["host_fed"] = hf
     if dist:
-        dist.destroy_process_group()
+        dist.destroy_process_group()      # before rank 0's CPU legs: the other ranks leave, nobody waits in a collective
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            # the reference's CPU path on this box's host cores, in the same run, at every N (a SCALE line carries it too).  Bounded
+            # sample; at N > 1 the all-cores leg is skipped (the other ranks' processes are ending on the same cores)
+            out["cpu_baseline"] = cpu_baseline()
+            if world == 1:
+                try:
+                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
+                except Exception as e:   # noqa: BLE001
+                    out["cpu_baseline_all_cores"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

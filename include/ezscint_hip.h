@@ -79,6 +79,9 @@ int32_t gdrls_(int32_t *gdin);
 /* All pointers are DEVICE pointers on the current HIP device; work is enqueued on the stream set by
  * ezhip_use_stream (default: the null stream) and NOT synchronised. */
 void    ezhip_use_stream(void *hip_stream);
+/* 0 for the shipped library; 1 when it was built with -DEZHIP_DEVELOP (`make develop`: the kernels' development knock-outs, which an
+ * environment variable can switch on, exist only in that build). */
+int32_t ezhip_develop_build(void);
 /* Optional, for callers of the host-array entry points who reuse their arrays: page-lock an array once (hipHostRegister).  c_ezsint between
  * two registered arrays uploads the source in row ranges while the finished rows of the result download (PCIe carries both directions at
  * once); between ordinary arrays the two copies run one after the other.  Unregister before freeing the memory.  0 / -1. */

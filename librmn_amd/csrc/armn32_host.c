@@ -106,19 +106,23 @@ static uint32_t rle_encode(uint32_t *z, const uint32_t *mask, int npts)
     return zlng_of_bits(w.pos);
 }
 /* run-length stream -> sign mask (unpack1bitRLE :904-955) */
-static void rle_decode(uint32_t *mask, const uint32_t *z, int npts)
+/* max_bits: the bits of the sub-stream (its length word, read from the record): a damaged stream stops there instead of running off the caller's buffer.  0 / -1 */
+static int rle_decode(uint32_t *mask, const uint32_t *z, int npts, uint64_t max_bits)
 {
     uint64_t pos = 0;
     uint32_t last_val = 1;                   /* (unsigned char)0xFFFFFFFF of the reference is never used before a count token sets it */
     int i = 0;
 #define SETS(k, v) do { if ((k) < npts && (v)) mask[(k) >> 5] |= 1u << ((k) & 31); } while (0)
     while (i < npts) {
+        if (pos + 1 > max_bits) return -1;
         if (br32_get(z, &pos, 1) == 0) {
             const int lim = i + 7 > npts ? npts - i : 7;
+            if (pos + (uint64_t)lim > max_bits) return -1;
             const uint32_t raw = br32_get(z, &pos, lim);
             for (int j = 0; j < lim; j++) SETS(i + j, (raw >> (lim - 1 - j)) & 1u);
             i += lim;
         } else {
+            if (pos + 7 > max_bits) return -1;
             const uint32_t tok = br32_get(z, &pos, 7), val = tok >> 6; const int count = (int)(tok & 63u);
             const int run = count == 63 ? 255 : count;
             const uint32_t bit = count == 63 ? (last_val & 1u) : val;
@@ -128,6 +132,7 @@ static void rle_decode(uint32_t *mask, const uint32_t *z, int npts)
         }
     }
 #undef SETS
+    return 0;
 }
 
 static int float_width(uint32_t v) { union { float f; int32_t i; } r; r.f = (float)v; return v ? (r.i >> 23) - 126 : 0; }
@@ -256,8 +261,8 @@ static int decode_plane(int *d_plane, const uint32_t *z, const uint64_t *tp, siz
 /* the three sequential host walks of a stream (sign run lengths, exponent tile chain, mantissa tile chain) are independent: one thread each */
 typedef struct { const uint32_t *z; int ni, nj, nbits; uint64_t *tp; size_t ntiles; uint64_t max_bits; } walk_job;
 static void *walk_thread(void *a) { walk_job *j = (walk_job *)a; j->tp = walk_tiles(j->z, j->ni, j->nj, j->nbits, &j->ntiles, j->max_bits); return NULL; }
-typedef struct { const uint32_t *z; uint32_t *mask; int npts; } rle_job;
-static void *rle_thread(void *a) { rle_job *j = (rle_job *)a; rle_decode(j->mask, j->z, j->npts); return NULL; }
+typedef struct { const uint32_t *z; uint32_t *mask; int npts; uint64_t max_bits; int rc; } rle_job;
+static void *rle_thread(void *a) { rle_job *j = (rle_job *)a; j->rc = rle_decode(j->mask, j->z, j->npts, j->max_bits); return NULL; }
 
 /* c_armn_uncompress32 with the result on the device; zstream: HOST memory (the chain of tile headers is walked on the host).  word_limit: words the
  * caller's buffer is known to hold (0: unknown -- no stream of c_armn_compress32 is longer than the field it replaces) */
@@ -289,11 +294,12 @@ static int uncompress32_host_walk(float *d_fld, const unsigned char *zstream, si
     /* the three sub-streams: [lng, sign run lengths] [lng, exponent plane] [slot, mantissa plane] */
     const int have_s = code_signe == 0x20 || code_signe == 0x30, have_e = code_expo == 0x08 || code_expo == 0x0C;
     const uint32_t *z_s = NULL, *z_e = NULL, *z_m;
-    if (have_s) { const uint32_t lng = *cur++; if ((uint64_t)(lng >> 2) > max_words) goto broken; z_s = cur; cur += lng >> 2; }
+    uint64_t bits_s = 0;
+    if (have_s) { const uint32_t lng = *cur++; if ((uint64_t)(lng >> 2) > max_words) goto broken; z_s = cur; bits_s = 32ull * (lng >> 2); cur += lng >> 2; }
     if (have_e) { const uint32_t lng = *cur++; if ((uint64_t)(cur - (const uint32_t *)zstream) + (lng >> 2) > max_words) goto broken; z_e = cur; cur += lng >> 2; }
     cur++;                                                       /* the mantissa length slot */
     z_m = cur;
-    rle_job rj = { z_s, NULL, (int)n };
+    rle_job rj = { z_s, NULL, (int)n, bits_s, 0 };
     const uint64_t used_words = (uint64_t)(cur - (const uint32_t *)zstream);
     walk_job we = { z_e, ni, nj, (int)need_e, NULL, 0, have_e ? 32ull * (uint64_t)(z_m - 1 - z_e) : 0 };
     walk_job wm = { z_m, ni, nj, nbits, NULL, 0, 32ull * (max_words > used_words ? max_words - used_words : 0) };
@@ -309,6 +315,7 @@ static int uncompress32_host_walk(float *d_fld, const unsigned char *zstream, si
     walk_thread(&wm);                                            /* this thread walks the longest chain */
     if (run_e) pthread_join(th_e, NULL);
     if (run_s) pthread_join(th_s, NULL);
+    if (have_s && rj.rc) { fprintf(stderr, "<c_armn_uncompress32> broken stream (the sign runs leave their sub-stream)\n"); goto out; }
     if ((have_e && !we.tp) || !wm.tp) { fprintf(stderr, "<c_armn_uncompress32> broken stream (a tile chain leaves the record)\n"); goto out; }
     if (have_s && (ezhip_h2d(d_smask, rj.mask, 4 * (n / 32 + 1)) || ezhip_sync())) goto out;
     if (have_e && decode_plane(d_expo, z_e, we.tp, we.ntiles, ni, nj, (int)need_e, 0, 3)) goto out;
@@ -371,12 +378,13 @@ int c_armn_uncompress32_lng_dev(float *d_fld, const unsigned char *zstream, size
     const int have_s = code_signe == 0x20 || code_signe == 0x30, have_e = code_expo == 0x08 || code_expo == 0x0C;
     const uint32_t *z_s = NULL, *z_e = NULL, *z_m;
     size_t words_e = 0;
-    if (have_s) { if (cur >= zend) goto broken; const uint32_t lng = *cur++; if ((size_t)(lng >> 2) > (size_t)(zend - cur)) goto broken; z_s = cur; cur += lng >> 2; }
+    uint64_t bits_s = 0;
+    if (have_s) { if (cur >= zend) goto broken; const uint32_t lng = *cur++; if ((size_t)(lng >> 2) > (size_t)(zend - cur)) goto broken; z_s = cur; bits_s = 32ull * (lng >> 2); cur += lng >> 2; }
     if (have_e) { if (cur >= zend) goto broken; const uint32_t lng = *cur++; if ((size_t)(lng >> 2) > (size_t)(zend - cur)) goto broken; z_e = cur; words_e = lng >> 2; cur += lng >> 2; }
     if (cur + 1 >= zend) goto broken;
     cur++;                                                       /* the mantissa length slot */
     z_m = cur;
-    rle_job rj = { z_s, NULL, (int)n };
+    rle_job rj = { z_s, NULL, (int)n, bits_s, 0 };
     pthread_t th_s;
     int run_s = 0, rc = -1;
     if (have_s) {
@@ -389,6 +397,7 @@ int c_armn_uncompress32_lng_dev(float *d_fld, const unsigned char *zstream, size
     if (have_e && decode_plane_walked_on_device(d_expo, z_e, words_e, ni, nj, (int)need_e, 0, 0)) bad = 1;
     if (!bad && decode_plane_walked_on_device(d_mant, z_m, (size_t)(zend - z_m), ni, nj, nbits, 1, 1)) bad = 1;
     if (run_s) pthread_join(th_s, NULL);
+    if (have_s && rj.rc) bad = 1;
     if (bad) { fprintf(stderr, "<c_armn_uncompress32> broken stream (a tile chain leaves the record)\n"); goto out; }
     if (have_s && (ezhip_h2d(d_smask, rj.mask, 4 * (n / 32 + 1)) || ezhip_sync())) goto out;
     if (packhip_a32_combine(d_fld, d_expo, d_mant, d_smask, n, nbits, exp_min, code_signe, code_expo != 0)) goto out;

@@ -1495,7 +1495,7 @@ static void build_sepx_geometry(ezh_sepplan *sp, ezhip_sep_plan *p, int degree, 
                                 const int *blk_base, const int *rbase, const double *rw, const unsigned char *rflag)
 {
     p->x_nseg = 0;
-    p->debug_flags = getenv("EZHIP_DEBUG") ? atoi(getenv("EZHIP_DEBUG")) : 0;
+    p->debug_flags = EZH_DEVINT("EZHIP_DEBUG");
     for (int bx = 0; bx < nbx; bx++) if (blk_base[bx] < 0) return;
     if ((size_t)njr * (size_t)nic >= ((size_t)1 << 31)) return;
     const int xr_rows = EZHIP_SEP_ROWS;          /* target rows per step (row-block of k_sepx) */
@@ -2515,6 +2515,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
 }
 
 void ezhip_use_stream(void *hip_stream) { ezhip_set_stream(hip_stream); }
+int32_t ezhip_develop_build(void) { return EZH_DEVELOP_BUILD; }      /* 1: built with -DEZHIP_DEVELOP (kernel knock-outs compiled in; never the shipped library) */
 int32_t ezhip_available(void) { return ezhip_runtime_ok(); }
 
 static int yy_plan(ezh_set *s);
@@ -2596,7 +2597,7 @@ static int32_t batch_impl_o(float *d_zout, const float *d_zin, int32_t nfields, 
                 }
             }
             p.batch_fields = nfields; p.batch_in_stride = nin; p.batch_out_stride = nout;
-            if (getenv("EZHIP_DEBUG")) p.debug_flags = atoi(getenv("EZHIP_DEBUG"));      /* development: the kernel's knock-outs / variants at call time too (the plan keeps what the environment held when it was built) */
+            if (EZH_DEVENV("EZHIP_DEBUG")) p.debug_flags = EZH_DEVINT("EZHIP_DEBUG");      /* development: the kernel's knock-outs / variants at call time too (the plan keeps what the environment held when it was built) */
             if (getenv("EZHIP_BATCH_RB")) { int rb = atoi(getenv("EZHIP_BATCH_RB")); if (rb >= 1) { p.x_rb = rb; p.x_nseg = (p.x_nvb + rb - 1) / rb; } }      /* development: row-blocks per thread block of a batch launch */
             if (getenv("EZHIP_BATCH_SPECIAL_PCT")) { int pct = atoi(getenv("EZHIP_BATCH_SPECIAL_PCT")); if (pct >= 0 && pct <= 100) p.special_last = 2 + p.x_nseg * pct / 100; }      /* development: the special rows at pct % of a field's work order (default: the middle) */
             if (bo) {
@@ -2768,7 +2769,7 @@ int32_t ezhip_ezsint_batch_encode_dev(uint32_t *d_z, int64_t z_stride_words, int
     a.ctl = (unsigned *)((char *)d_work + L.off_ctl); a.head = (unsigned *)((char *)d_work + L.off_head);
     a.ptok = (unsigned short *)((char *)d_work + L.off_ptok); a.ptok_stride = L.ptok_stride;
     a.zlng = d_zlng;
-    a.debug = getenv("EZHIP_ENC_DEBUG") ? atoi(getenv("EZHIP_ENC_DEBUG")) : 0;
+    a.debug = EZH_DEVINT("EZHIP_ENC_DEBUG");
     return ezhip_interp_sep_enc(&p, &a) ? -1 : 0;
 }
 

@@ -39,9 +39,16 @@
 static thread_local hipStream_t g_stream = nullptr;
 static thread_local char g_err[256] = "";
 
+/* every failed runtime call / launch of the library counts here: callers whose return value doubles as "not compressible" (armn_compress's -1) tell
+ * an error from that answer by the count moving */
+#include <atomic>
+static std::atomic<unsigned> g_error_count{0};
+extern "C" void ezhip_note_error(void) { g_error_count.fetch_add(1, std::memory_order_relaxed); }
+extern "C" unsigned ezhip_error_count(void) { return g_error_count.load(std::memory_order_relaxed); }
 static int set_err(hipError_t e, const char *what)
 {
     if (e == hipSuccess) return 0;
+    ezhip_note_error();
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
     return -1;
 }
@@ -78,7 +85,11 @@ extern "C" int ezhip_bound_device(void) { return g_bound_dev.load(std::memory_or
 
 /* Per-thread state (workspaces, page-locked bounce buffers, the side stream, lists) is released when the host thread that owns it ends, and on request
  * (ezhip_thread_release): a service that runs calls on short-lived threads does not accumulate 2 x 16 MB of page-locked memory and its device workspaces
- * per thread that ever called.  Not at process exit: the HIP runtime may already be gone by then. */
+ * per thread that ever called.  Never from the MAIN thread and never in another process than the one that armed the guard: exit() runs the main
+ * thread's thread_local destructors BEFORE the atexit handlers (so a flag set at exit is still clear there) with the HIP runtime on its way out, and a
+ * fork()ed child inherits an armed guard over a runtime it cannot use.  The main thread's state goes with the process. */
+#include <unistd.h>
+#include <sys/syscall.h>
 extern "C" void ezh_ez_thread_release(void);
 extern "C" void ezhip_pack_release(void);
 extern "C" void ezh_armn32_thread_release(void);
@@ -94,14 +105,21 @@ extern "C" void ezhip_thread_release(void)
     kernels_thread_release();
 }
 namespace {
-struct thread_guard { bool armed = false; ~thread_guard() { if (armed && !g_process_exiting.load()) ezhip_thread_release(); } };
+struct thread_guard {
+    bool armed = false; pid_t pid = 0;
+    ~thread_guard() {
+        const pid_t me = getpid();
+        if (!armed || g_process_exiting.load() || pid != me || (pid_t)syscall(SYS_gettid) == me) return;      /* main thread (tid == pid), or a forked child */
+        ezhip_thread_release();
+    }
+};
 thread_local thread_guard t_guard;
 }
 static void arm_thread_guard(void)
 {
     static std::atomic<bool> once{false};
     if (!once.exchange(true)) atexit([]() { g_process_exiting.store(true); });
-    t_guard.armed = true;
+    t_guard.armed = true; t_guard.pid = getpid();
 }
 
 extern "C" void *ezhip_malloc(size_t nbytes)
@@ -1022,7 +1040,7 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
     constexpr int SEPX_REC_DW = XR * 16;                                        /* dwords of one step's row records */
     float *rec = (float *)(smem_x + (size_t)trows * SEP_BLOCK);                /* 2 x XR row records of 64 B */
     float *patch = rec + 2 * SEPX_REC_DW;
-    const int dbg = p.debug_flags;          /* development knock-outs (EZHIP_DEBUG): 1 no stores, 4 no DMA, 8 no x-pass, 16 no y-pass */
+    const int dbg = EZH_DBG(p.debug_flags);          /* development knock-outs (EZHIP_DEBUG): 1 no stores, 4 no DMA, 8 no x-pass, 16 no y-pass */
     unsigned coloff[SEP_QCH];
 #pragma unroll
     for (int q = 0; q < SEP_QCH; q++) {          /* source column of patch column lane + 64 q (seam unrolled; tail lanes clamp) */
@@ -1129,7 +1147,7 @@ void k_sepx(ezhip_sep_plan p, float *__restrict__ zout, const float *__restrict_
 extern "C" size_t ezhip_sepx_lds_bytes(int x_tr, int rows_per_step, int x_prows, int wstride)
 {
     size_t b = sizeof(double) * (size_t)x_tr * SEP_BLOCK + sizeof(float) * (2 * 16 * (size_t)rows_per_step + (size_t)x_prows * wstride);
-    if (getenv("EZHIP_SEPX_PAD")) b += (size_t)atoi(getenv("EZHIP_SEPX_PAD"));      /* development: occupancy experiments */
+    b += (size_t)EZH_DEVINT("EZHIP_SEPX_PAD");      /* development: occupancy experiments */
     return b;
 }
 
@@ -1305,7 +1323,7 @@ void k_sepx_enc(ezhip_sep_plan p, ezhip_sepenc_args a)
     /* ---- interpolation: one step of k_sepx whose source rows are all new -------------------------------------------------- */
     const auto *sq = CONSTP(int, p.e_step) + 4 * rg;
     const int st_s0 = sq[0], st_n = sq[1], st_slot0 = sq[2];
-    if (st_n > 0 && !(a.debug & 64)) {
+    if (st_n > 0 && !(EZH_DBG(a.debug) & 64)) {
         const int base = p.e_blk_base[s], W = p.e_blk_w[s];
         unsigned coloff[SEP_QCH];
 #pragma unroll
@@ -1381,7 +1399,7 @@ void k_sepx_enc(ezhip_sep_plan p, ezhip_sepenc_args a)
         if (rg == 0 && c < nid && (tid > 0 || s == 0)) pt[c] = p16[tid];
         if (s == 0 && tid >= 1 && tid < 16) { const int r = 3 * SE_TROWS * rg + tid; if (r < njd) pt[nid + r - 1] = p16[tid * RP]; }
     }
-    if (a.debug & 32) { if (p16[tid] == 0x1234 && p16[15 * RP + tid] == 0x4321) a.zlng[f] = 7; return; }      /* development: interpolation only */
+    if (EZH_DBG(a.debug) & 32) { if (p16[tid] == 0x1234 && p16[15 * RP + tid] == 0x4321) a.zlng[f] = 7; return; }      /* development: interpolation only */
     /* ---- per tile: differences (kept in registers), width, bit count (k_armn_enc1's tile phase on the LDS patch) ---------- */
     const int nbits = a.nbits, container = a.container;
     const int nt_x = min(SE_TPR, a.ntx - SE_TPR * s), nrow_t = min(SE_TROWS, a.nty - SE_TROWS * rg), ntl = nt_x * nrow_t;
@@ -1474,7 +1492,7 @@ void k_sepx_enc(ezhip_sep_plan p, ezhip_sepenc_args a)
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < SE_TPT; q++) {
-        if (tid + SEP_BLOCK * q >= ntl || (a.debug & 1)) continue;
+        if (tid + SEP_BLOCK * q >= ntl || (EZH_DBG(a.debug) & 1)) continue;
         const unsigned need = meta[q] & 0xFF; const int tm = (int)(meta[q] >> 8) & 0xF, tn = (int)(meta[q] >> 12) & 0xF, trow = (int)(meta[q] >> 16);
         unsigned rb_ = rbase[0], ib_ = ib[0];
 #pragma unroll
@@ -1537,7 +1555,7 @@ void k_sepx_enc(ezhip_sep_plan p, ezhip_sepenc_args a)
         }
         unsigned long long excl_chunks = 0, gt_before = 0;
         bool gave_up = false;
-        if (cr > 0 && !(a.debug & 8)) {
+        if (cr > 0 && !(EZH_DBG(a.debug) & 8)) {
             int basei = cr - 1, spins = 0;
             for (;;) {
                 const int idx = basei - lane;
@@ -1575,7 +1593,7 @@ void k_sepx_enc(ezhip_sep_plan p, ezhip_sepenc_args a)
             if (gave_up) { s_abort = 1; __hip_atomic_store(&a.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             else {
                 const unsigned sh = (unsigned)(S & 31);
-                if (sh && (((sh + agg) >> 5) >= 1 || cr == a.nchunks - 1) && !(a.debug & 8)) {         /* the shared word is completed here (else a later chunk stores it) */
+                if (sh && (((sh + agg) >> 5) >= 1 || cr == a.nchunks - 1) && !(EZH_DBG(a.debug) & 8)) {         /* the shared word is completed here (else a later chunk stores it) */
                     if (cr == 0) a.head[f] = im[0];                                   /* the prefix's bits come from the side array: k_sepenc_prefix stores the word */
                     else {
                         const unsigned tp = wait_tail(cr - 1, tprev);
@@ -1601,7 +1619,7 @@ void k_sepx_enc(ezhip_sep_plan p, ezhip_sepenc_args a)
         const bool last_chunk = cr == a.nchunks - 1;
         const bool tail_open = ((sh + agg) & 31) != 0 && !last_chunk;
         const unsigned nstore = nwout - (tail_open ? 1u : 0u);
-        if (!(a.debug & 2))
+        if (!(EZH_DBG(a.debug) & 2))
         for (unsigned k = (sh ? 1u : 0u) + tid; k < nstore; k += SEP_BLOCK) {
             const unsigned lo = im[k];
             const unsigned v = sh == 0 ? lo : ((k ? im[k - 1] : 0u) << (32 - sh)) | (lo >> sh);

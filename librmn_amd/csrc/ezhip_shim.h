@@ -8,6 +8,7 @@
 #ifndef EZHIP_SHIM_H
 #define EZHIP_SHIM_H
 #include <stddef.h>
+#include "ezhip_develop.h"
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -19,6 +20,8 @@ int    ezhip_runtime_ok(void);                       /* 1 if a HIP device is usa
 int    ezhip_bound_device_ok(const char *who);       /* 0 when the calling thread's current device is the one the library is bound to (binds on first use); -1 + message otherwise */
 int    ezhip_bound_device(void);                     /* the bound device, -1 before the first use */
 const char *ezhip_last_error(void);
+void ezhip_note_error(void);
+unsigned ezhip_error_count(void);      /* failed runtime calls / launches so far (process-wide) */
 void  *ezhip_malloc(size_t nbytes);                  /* NULL on failure */
 void   ezhip_free(void *d);
 int    ezhip_h2d(void *d, const void *h, size_t nbytes);     /* async on the current stream */

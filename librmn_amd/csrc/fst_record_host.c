@@ -258,6 +258,7 @@ int32_t ezhip_fst_pack_data_ex(uint32_t *data, int64_t cap_words, void *field_in
             /* REAL field, one level: the field goes up once and the data part comes down once (compact_float + armn_compress on host arrays moved it
              * over PCIe four times); the words behind the stream are what the in-place compressor leaves there (token words), as before */
             const int zl = ezhip_pack16_compress_host(&data[1], fst129_words_after_length, (const float *)field, ni, nj, nbits);
+            if (zl == -2) goto done;                                                /* an error underneath, not armn_compress's "does not pay": the record's type is not changed over it */
             if (zl < 0) {
                 out_datyp = 1;                                                      /* (sic: the missing-value flag is lost with the turbo flag, :1173) */
                 if (!packfunc(field, &data[0], &data[3], (int)n, nbits, 24, 1, 1, 0, &tempfloat)) goto done;
@@ -411,7 +412,11 @@ int32_t ezhip_fst_unpack_data_ex(void *field, uint32_t *data, int32_t ni, int32_
     case 1: rc = packfunc(field, data, data + 3, (int)n, nbits, 24, 1, 2, 0, &tempfloat) ? 0 : -1; break;
     case 129:
         if (!is_double && nk == 1 && nbits <= 16 && ni > 1 && nj > 1 && !getenv("EZHIP_FST_FOUR_TRIPS")) {      /* the record up, the field down (the data part is left as it is) */
-            rc = ezhip_uncompress_unpack16_host((float *)field, data + 1, (int64_t)data[0], ni, nj, nbits);
+            /* data[0] = the words of the data part, itself included (:1186): data + 1 holds data[0] - 1 of them.  The value comes from the file: it is
+             * held to the documented size of the buffer (the plain word count) before anything is read */
+            const int64_t cap129 = plain_words(129, n, nbits, &hs, &ss);
+            if ((int64_t)data[0] < 6 || (int64_t)data[0] > cap129) { fprintf(stderr, "<ezhip_fst_unpack_data> datyp 129: the record's length word (%u) is outside 6 .. %lld\n", data[0], (long long)cap129); return -1; }
+            rc = ezhip_uncompress_unpack16_host((float *)field, data + 1, (int64_t)data[0] - 1, ni, nj, nbits);
             break;
         }
         if (armn_compress((unsigned char *)(data + 5), ni, nj, nk, nbits, 2) < 0) return -1;
@@ -456,7 +461,8 @@ int32_t ezhip_fst_unpack_data_ex(void *field, uint32_t *data, int32_t ni, int32_
         } else return -1;
         break;
     case 133:                                                                       /* :2436; data[0] = the data part's words (:1318): the stream's length, so its tile chains are followed on the device */
-        if (data[0] < 5) return -1;
+        if ((int64_t)data[0] < 5 || (int64_t)data[0] > plain_words(133, n, nbits, &hs, &ss)) {      /* from the file: held to the buffer's documented size */
+            fprintf(stderr, "<ezhip_fst_unpack_data> datyp 133: the record's length word (%u) does not fit the data part\n", data[0]); return -1; }
         rc = c_armn_uncompress32_lng((float *)field, (const unsigned char *)(data + 1), 4 * ((size_t)data[0] - 1), ni, nj, nk, nbits) < 0 ? -1 : 0;
         break;
     case 6: { int32_t nb; rc = c_float_unpacker((float *)field, (int32_t *)data, (int32_t *)(data + hs), (int32_t)n, &nb); break; }

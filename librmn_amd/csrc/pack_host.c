@@ -613,6 +613,7 @@ done:
     return zlng;
 }
 
+static int pack16_compress_dev_ex(void *d_record, const float *d_field, int ni, int nj, int nbits, int32_t *failed);
 /* fused cfg5 step on device data (fstd98.c:1170-1172): compact_float(16-bit slots, style 2) + armn_compress */
 int ezhip_pack16_compress_dev(void *d_record, const float *d_field, int ni, int nj, int nbits)
 {
@@ -626,6 +627,15 @@ int ezhip_pack16_compress_dev(void *d_record, const float *d_field, int ni, int 
     if (zlng > 0 && ezhip_d2d(rec + 4, d_z, (size_t)zlng)) zlng = -1;
     ezhip_sync();
     return zlng;
+}
+
+/* the same, telling "not compressible" (-1, *failed = 0) from an error (-1, *failed = 1: a runtime call or launch failed underneath) */
+static int pack16_compress_dev_ex(void *d_record, const float *d_field, int ni, int nj, int nbits, int32_t *failed)
+{
+    const unsigned before = ezhip_error_count();
+    const int zl = ezhip_pack16_compress_dev(d_record, d_field, ni, nj, nbits);
+    *failed = zl < 0 && ezhip_error_count() != before;
+    return zl;
 }
 
 /* read side of ezhip_pack16_compress_dev (fstd98.c:2285-2290): a record of 4 header words + armn stream (compressed != 0) or
@@ -649,22 +659,25 @@ int ezhip_uncompress_unpack16_dev(float *d_field, const void *d_record, int ni, 
 /* The same two steps between HOST arrays with ONE trip each way (what c_fstecr / c_fstluk do for datyp 129, nbits <= 16: fstd98.c:1170-1172, :2285-2290):
  * through compact_float + armn_compress on host arrays a field crossed PCIe four times (up, tokens down, tokens up, stream down).
  * ezhip_pack16_compress_host: the field goes up, `out_words` words [4 header words][stream][what the token array held behind it, as the in-place
- * compressor leaves it] come down; returns zlng, or < 0 when compression does not pay (nothing written: the caller packs the plain form).
+ * compressor leaves it] come down; returns zlng; -1 when compression does not pay (armn_compress's own answer; nothing written: the caller packs the
+ * plain form); -2 on an ERROR (no device, workspace, copy or kernel failure): the caller must fail, not change the record's type.
  * ezhip_uncompress_unpack16_host: the record goes up, the field comes down. */
 int32_t ezhip_pack16_compress_host(uint32_t *record, int64_t (*out_words_of)(int32_t zlng), const float *field, int32_t ni, int32_t nj, int32_t nbits)
 {
-    if (need_device("ezhip_pack16_compress_host")) return -1;
+    if (need_device("ezhip_pack16_compress_host")) return -2;
     const size_t n = (size_t)ni * nj;
-    if (!record || !field || !out_words_of || n == 0 || nbits < 1 || nbits > 16) return -1;
+    if (!record || !field || !out_words_of || n == 0 || nbits < 1 || nbits > 16) return -2;
     float *d_f = (float *)ws(6, 4 * n + 64);
     unsigned *d_rec = (unsigned *)ws(7, 4 * (4 + n / 2 + 64));
-    if (!d_f || !d_rec) return -1;
-    if (ezhip_h2d(d_f, field, 4 * n)) return -1;
-    const int zl = ezhip_pack16_compress_dev(d_rec, d_f, ni, nj, nbits);
-    if (zl <= 0) return zl < 0 ? zl : -1;
+    if (!d_f || !d_rec) return -2;
+    if (ezhip_h2d(d_f, field, 4 * n)) return -2;
+    int32_t failed = 0;
+    const int zl = pack16_compress_dev_ex(d_rec, d_f, ni, nj, nbits, &failed);
+    if (failed) return -2;
+    if (zl <= 0) return -1;                                         /* not compressible */
     int64_t nw = out_words_of(zl);
     if (nw > (int64_t)(4 + (n + 1) / 2)) nw = (int64_t)(4 + (n + 1) / 2);
-    if (ezhip_d2h(record, d_rec, 4 * (size_t)nw) || ezhip_sync()) return -1;
+    if (ezhip_d2h(record, d_rec, 4 * (size_t)nw) || ezhip_sync()) return -2;
     return zl;
 }
 int32_t ezhip_uncompress_unpack16_host(float *field, const uint32_t *record, int64_t record_words, int32_t ni, int32_t nj, int32_t nbits)
@@ -803,7 +816,10 @@ int32_t ezhip_ezsint_batch_tokens_dev(uint32_t *d_tokens, int64_t token_stride_w
  * ezhip_ezsint_pack16_compress_batch_dev / ezhip_pack16_compress_dev leave per field.  d_data (device, cap_words) receives the DATA PART of the FST
  * record c_fstecr(datyp 129, nbits) writes for that field:
  *   zlng > 0   [nw][4 header words][stream], zero padded to nw = 2 ceil((16 + zlng) 8 / 64) words; *datyp_out = 129.  d_data + 1 == d_record frames in
- *              place: one word in front of the record is all it takes;
+ *              place: one word in front of the record is all it takes; any OTHER overlap of the two ranges is refused (the shift by one word would race).
+ *              The up to two padding words behind the stream are ZERO here; c_fstecr (and the host path ezhip_fst_pack_data) leave there what the
+ *              in-place compressor left of its token array -- bytes no reader looks at (c_fstluk hands armn_compress the stream, whose header holds its
+ *              own extent), so a device-framed data part equals the reference's on its first 5 + ceil(zlng / 4) words, not necessarily on the padding;
  *   zlng < 0   compression did not pay: the reference packs again as datyp 1 -- header style 1 (3 words + 24 bits) and the nbits-wide tokens from bit
  *              120 on; the tokens are the same numbers, re-packed on the device; *datyp_out = 1.
  * Asynchronous on the current stream; returns the number of words of the data part, -1 on error. */
@@ -818,6 +834,10 @@ int32_t ezhip_fst_frame_record_dev(uint32_t *d_data, int64_t cap_words, const ui
         if (nw > cap_words) { fprintf(stderr, "<ezhip_fst_frame_record_dev> the data part needs %lld words\n", (long long)nw); return -1; }
         int64_t ncopy = 4 + ((int64_t)zlng + 3) / 4;
         if (ncopy > nw - 1) ncopy = nw - 1;
+        if (d_data + 1 != d_record) {                              /* not the in-place form: the ranges must be disjoint */
+            const uintptr_t a0 = (uintptr_t)d_data, a1 = a0 + 4 * (uintptr_t)nw, b0 = (uintptr_t)d_record, b1 = b0 + 4 * (uintptr_t)ncopy;
+            if (a0 < b1 && b0 < a1) { fprintf(stderr, "<ezhip_fst_frame_record_dev> d_data and d_record overlap (only d_data + 1 == d_record frames in place)\n"); return -1; }
+        }
         if (packhip_fst_frame129(d_data, d_record, (unsigned)nw, (unsigned)ncopy)) return -1;
         if (datyp_out) *datyp_out = 129;
         return (int32_t)nw;
@@ -917,7 +937,7 @@ static int32_t cfg5_batch(void *d_records, int64_t record_stride_words, const fl
         if (!h) goto fail;
         if (ezhip_d2h(h, d_zlng, 2 * sizeof(int) * (size_t)nfields) || ezhip_sync()) { free(h); return -1; }
         memcpy(zlng_out, h, sizeof(int32_t) * (size_t)nfields);
-        if (fused_used && getenv("EZHIP_CFG5_ONLY_FUSED")) { free(h); return rc; }      /* development: knock-out timings, results unchecked */
+        if (fused_used && EZH_DEVENV("EZHIP_CFG5_ONLY_FUSED")) { free(h); return rc; }      /* development: knock-out timings, results unchecked */
         if (fused_used) {
             /* the fused launch has no token array to fall back on: a field it could not finish (not compressible, differences beyond 16 bits, launch
              * gave up: zlng still "unfinished") goes through the two-kernel path, extrema pass included (runs of such fields in one call) */

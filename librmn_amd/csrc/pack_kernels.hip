@@ -20,10 +20,11 @@
 
 extern "C" void *ezhip_get_stream(void);
 #define STREAM ((hipStream_t)ezhip_get_stream())
+extern "C" void ezhip_note_error(void);
 static int chk(const char *what)
 {
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return -1; }
+    if (e != hipSuccess) { ezhip_note_error(); fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return -1; }
     return 0;
 }
 
@@ -1165,7 +1166,7 @@ __global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8)))
     }
     __syncthreads();
     STAMP();
-    if (a.debug & 32) { if (tid == 0 && (c == a.nchunks - 1 || lds[0] == 0x12345u)) a.zlng[f] = 1000; return; }      /* development: staging only */
+    if (EZH_DBG(a.debug) & 32) { if (tid == 0 && (c == a.nchunks - 1 || lds[0] == 0x12345u)) a.zlng[f] = 1000; return; }      /* development: staging only */
     /* ---- per tile: differences (kept in registers), width, bit count ------------------------------------------- */
     const unsigned short *p16 = (const unsigned short *)lds;
     unsigned long long dpk[ENC_TPT][3];                     /* the 3 differences of a tile row, 18 bits each at bits 0 / 21 / 42 (36 plain registers cost two waves per SIMD) */
@@ -1252,7 +1253,7 @@ __global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8)))
      * free, were slower: the same-word and same-bank conflicts of adjacent tiles cost more than the branches.) */
 #pragma unroll
     for (int q = 0; q < ENC_TPT; q++) {
-        if (tid + ENC_TPB * q >= ntl || (a.debug & 1)) continue;
+        if (tid + ENC_TPB * q >= ntl || (EZH_DBG(a.debug) & 1)) continue;
         const unsigned need = meta[q] & 0xFF; const int tm = (int)(meta[q] >> 8) & 0xF, tn = (int)(meta[q] >> 12) & 0xF;
         unsigned wi = excl[q] >> 5; int fill = (int)(excl[q] & 31);
         unsigned long long acc = 0; bool first = true;
@@ -1319,7 +1320,7 @@ __global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8)))
         }
         unsigned long long excl_chunks = 0, gt_before = 0;
         bool gave_up = false;
-        if (c > 0 && !(a.debug & 8)) {
+        if (c > 0 && !(EZH_DBG(a.debug) & 8)) {
             /* windows of 256 predecessors (4 per lane, nearest first) */
             int basei = c - 1, spins = 0;
             for (;;) {
@@ -1394,7 +1395,7 @@ __global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8)))
     const bool last_chunk = c == a.nchunks - 1;
     const bool tail_open = ((sh + agg) & 31) != 0 && !last_chunk;      /* the last word is completed (and stored) by a later chunk */
     const unsigned nstore = nwout - (tail_open ? 1u : 0u);   /* words [0, nstore) are completed by this chunk */
-    if (!(a.debug & 2))
+    if (!(EZH_DBG(a.debug) & 2))
         for (unsigned k = (sh ? 1u : 0u) + tid; k < nstore; k += ENC_TPB) {        /* word 0 with bits of earlier chunks: stored above */
             const unsigned lo = img[k];
             const unsigned v = sh == 0 ? lo : ((k ? img[k - 1] : 0u) << (32 - sh)) | (lo >> sh);
@@ -1483,7 +1484,7 @@ extern "C" int packhip_armn_encode1(unsigned *d_z, size_t z_stride_words, size_t
     if (lds > 64 * 1024) return 1;
     a.z = d_z; a.z_stride = z_stride_words; a.z_cap = z_cap_words; a.tok = d_tok; a.tok_stride = tok_stride_words;
     a.container = container; a.nfields = nfields; a.zlng = d_zlng;
-    a.debug = getenv("EZHIP_ENC_DEBUG") ? atoi(getenv("EZHIP_ENC_DEBUG")) : 0;
+    a.debug = EZH_DEVINT("EZHIP_ENC_DEBUG");
     a.tok_words = ((size_t)ni * nj + 1) / 2;
     if (((uintptr_t)d_tok % 16 != 0) || (tok_stride_words % 4 != 0 && nfields > 1)) return 1;      /* the LDS-DMA staging moves aligned 16-byte pieces */
     a.vec = 1;
@@ -1491,8 +1492,8 @@ extern "C" int packhip_armn_encode1(unsigned *d_z, size_t z_stride_words, size_t
     a.status = (unsigned long long *)w; w += 8 * (size_t)a.nchunks * nfields;
     a.tail = (unsigned long long *)w; w += 8 * (size_t)a.nchunks * nfields;
     a.ctl = (unsigned *)w; w += 16;
-    a.prof = (a.debug & 16) ? (unsigned long long *)w : nullptr; w += 64;
-    g_enc1_prof = (a.debug & 16) ? (unsigned long long *)(w - 64) : nullptr;
+    a.prof = (EZH_DBG(a.debug) & 16) ? (unsigned long long *)w : nullptr; w += 64;
+    g_enc1_prof = (EZH_DBG(a.debug) & 16) ? (unsigned long long *)(w - 64) : nullptr;
     hipStream_t st = STREAM;
     if (hipMemsetAsync(d_work, 0, (size_t)(w - (char *)d_work), st) != hipSuccess) return -1;
     const size_t nblocks = (size_t)(a.npre + a.nchunks) * (size_t)nfields;

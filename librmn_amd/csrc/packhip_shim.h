@@ -2,6 +2,7 @@
 #ifndef PACKHIP_SHIM_H
 #define PACKHIP_SHIM_H
 #include <stddef.h>
+#include "ezhip_develop.h"
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {

@@ -178,6 +178,11 @@ def use_stream(stream_handle):
     _lib().ezhip_use_stream(ctypes.c_void_p(stream_handle or 0))
 
 
+def develop_build():
+    """True when the loaded library carries the development knock-outs (make develop); the shipped one never does"""
+    return bool(_lib().ezhip_develop_build())
+
+
 def ezsint_dev(zout, zin):
     return _lib().c_ezsint_dev(_dptr(zout), _dptr(zin))
 

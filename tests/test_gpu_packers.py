@@ -885,3 +885,44 @@ def test_fst_frame_of_a_device_resident_record(kind, nbits, in_place):
     assert np.array_equal(got[:m], want[:m]), np.nonzero(got[:m] != want[:m])[0][:5]
     if d_out == 129:
         assert not got[5 + (zl + 3) // 4:w].any()              # zero padding up to the length word's count
+
+
+def test_fst_frame_rejects_overlapping_ranges():
+    """only d_data + 1 == d_record frames in place: d_data == d_record (or any other overlap) would shift words while other threads still read them"""
+    ni, nj, nk, nbits = 120, 75, 1, 16
+    n = ni * nj
+    d_f = torch.from_numpy(pc.float_field(n, seed=5)).cuda()
+    buf = torch.zeros(8 + 4 + n // 2 + 64, dtype=torch.int32, device="cuda")
+    rec = buf[2:]
+    zl = pk.pack16_compress_dev(rec, d_f, ni, nj, nbits)
+    assert zl > 0
+    for data in (buf[2:], buf[0:], buf[3:]):                    # same start, two words in front, one word behind
+        w, _ = pk.fst_frame_record_dev(data, data.numel(), rec, zl, ni, nj, nk, nbits)
+        assert w == -1
+    w, d_out = pk.fst_frame_record_dev(buf[1:], buf.numel() - 1, rec, zl, ni, nj, nk, nbits)      # the in-place form still works
+    assert w > 0 and d_out == 129
+
+
+@pytest.mark.parametrize("datyp,nbits", [(129, 16), (133, 32)])
+def test_fst_unpack_damaged_length_word_is_refused(datyp, nbits):
+    """data[0] comes from the file: a length word beyond the documented size of the data part (or too small to hold a record) is refused before anything
+    is copied; a damaged sign sub-stream of a datyp 133 record stops at its own length instead of running through the buffer"""
+    ni, nj, nk = 120, 75, 1
+    f = pc.float_field(ni * nj, seed=7)
+    if datyp == 133:
+        f = (f - np.float32(f.mean())).astype(np.float32)        # both signs: the record carries a sign sub-stream
+    w, d_out, b_out, got = pk.fst_pack_data(f, ni, nj, nk, datyp, nbits)
+    assert d_out == datyp
+    rc, back = pk.fst_unpack_data(got.copy(), ni, nj, nk, d_out, b_out)
+    assert rc == 0
+    for bad in (0, 3, got.size + 1000, 0x7FFFFFF0, 0xFFFFFFFF):
+        dmg = got.copy(); dmg[0] = np.uint32(bad)
+        rc, _ = pk.fst_unpack_data(dmg, ni, nj, nk, d_out, b_out)
+        assert rc == -1, bad
+    if datyp == 133:
+        dmg = got.copy()
+        lng_s = int(dmg[3]) >> 2                                  # [lng][w0][info][lng_s][sign runs ...]
+        assert 0 < lng_s < w
+        dmg[4:4 + lng_s] = 0                                      # all-zero sign stream = raw 7-bit groups only: needs 8/7 n bits, more than the sub-stream holds
+        rc, _ = pk.fst_unpack_data(dmg, ni, nj, nk, d_out, b_out)
+        assert rc == -1
