@@ -62,6 +62,8 @@ typedef struct ezh_set {
     float *d_poles_batch; int poles_cap;   /* pole values of a c_ezsint_batch_dev batch (2 per field) */
     float *d_prow;          /* 2 * ni_src synthetic polar wind rows (vector mode), u then v: [u_n, u_s, v_n, v_s] */
     float *d_avg[2];        /* interp_degree = average / sph_average: [x | row widening | y_low | y_high] of the target cells (ez_avg.inc:55-78, ez_avg_sph.inc:63-98) */
+    void *d_uvt_tiles; int uvt_shape, uvt_cap, uvt_stats[4];
+    void *d_uvt_streams; const void *uvt_streams_M;      /* the tile-ordered {x, y, a, b} copy and the matrix array it was packed from (another matrix: the plain arrays are read) */      /* k_uvt's tile table over the set's x, y (built with the special-point cache, under the same key) */
     int *d_cspec_list; float *d_cspec_xy; int cspec_count, cspec_key;      /* the special points (polar strips, re-interpolated extrapolation) of the wind-pair launch, kept after its first call: index, x, y; key = the zone options they were listed under (0: none yet) */
     float *d_lamb_cs[2];    /* c_ezuvint from / towards a Lambert '!' grid: {cos, sin} of its rotation angle at the target points' longitudes (source leg, target leg) */
     void *d_windM;          /* c_ezuvint through a rotated frame: the wind chain of this grid pair as a 2 x 2 matrix per target point (built on first use) */
@@ -83,6 +85,7 @@ typedef struct {
     float *ax, *ay, *ncx, *ncy;            /* host */
     float *d_ax, *d_ay, *d_ncx, *d_ncy;    /* device mirrors */
     float *d_ncx8, *d_ncy8;                /* Newton coefficients laid out [index][8] for the per-point kernel */
+    float *d_xrec12, *d_yrec12;            /* k_uvt: {ax(i-1 .. i+2), c1 .. c6, 0, 0} per column i (index i - 1), the same per row */
     /* this grid as a TARGET: its lat/lon.  Separable grids keep 1-D arrays. */
     int coords_ready, separable;
     float *lat1d, *lon1d, *lat2d, *lon2d;
@@ -811,7 +814,7 @@ static void free_set(ezh_set *s)
 {
     for (int d = 0; d < 3; d++) for (int v = 0; v < 2; v++) free_sepplan(&s->sep[d][v]);
     free(s->x1d); free(s->y1d);
-    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_lamb_cs[0]); ezhip_free(s->d_lamb_cs[1]); ezhip_free(s->d_cspec_list); ezhip_free(s->d_cspec_xy); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
+    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_lamb_cs[0]); ezhip_free(s->d_lamb_cs[1]); ezhip_free(s->d_cspec_list); ezhip_free(s->d_cspec_xy); ezhip_free(s->d_uvt_tiles); ezhip_free(s->d_uvt_streams); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
     for (int k = 0; k < 2; k++) { ezhip_free(s->d_yy_x[k]); ezhip_free(s->d_yy_y[k]); ezhip_free(s->d_yy_lat[k]); ezhip_free(s->d_yy_lon[k]); ezhip_free(s->d_yy_idx[k]); }
     for (int k = 0; k < 4; k++) ezhip_free(s->d_yy_tmp[k]);
     free(s);
@@ -832,7 +835,7 @@ int32_t c_gdrls(int32_t gd)          /* gdrls.c:34-77: refcount, free at zero */
         }
         free(g->ax); free(g->ay); free(g->ncx); free(g->ncy);
         free(g->lat1d); free(g->lon1d); free(g->lat2d); free(g->lon2d); free(g->mask);
-        ezhip_free(g->d_ax); ezhip_free(g->d_ay); ezhip_free(g->d_ncx); ezhip_free(g->d_ncy); ezhip_free(g->d_ncx8); ezhip_free(g->d_ncy8);
+        ezhip_free(g->d_ax); ezhip_free(g->d_ay); ezhip_free(g->d_ncx); ezhip_free(g->d_ncy); ezhip_free(g->d_ncx8); ezhip_free(g->d_ncy8); ezhip_free(g->d_xrec12); ezhip_free(g->d_yrec12);
         ezhip_free(g->d_lat); ezhip_free(g->d_lon); ezhip_free(g->d_plon2); g->d_plon2 = NULL; ezhip_free(g->d_windtrig); g->d_windtrig = NULL;
         memset(g, 0, sizeof(*g));
         if (cur_gdin == gd) cur_gdin = -1;
@@ -1185,8 +1188,22 @@ static int ensure_grid_dev(ezh_grid *g)
             ezhip_sync();
             free(t8);
         }
+        {   /* the 48-byte records k_uvt stages per tile: axis entries i-1 .. i+2 next to the six coefficients of stencil i (interior indices only: the
+             * tiles that touch the seam or the first / last rows' clamps never read the others) */
+            const int m = g->ni > nr ? g->ni : nr;
+            float *t12 = (float *)calloc((size_t)12 * m, sizeof(float));
+            if (!t12) return -1;
+            for (int i = 1; i + 2 < g->ni; i++) { for (int k = 0; k < 4; k++) t12[12 * i + k] = g->ax[i - 1 + k]; for (int k = 0; k < 6; k++) t12[12 * i + 4 + k] = g->ncx[k * g->ni + i]; }
+            g->d_xrec12 = (float *)upload(t12, sizeof(float) * 12 * g->ni);
+            ezhip_sync();
+            memset(t12, 0, sizeof(float) * 12 * (size_t)m);
+            for (int j = 1; j + 2 < nr; j++) { for (int k = 0; k < 4; k++) t12[12 * j + k] = g->ay[j - 1 + k]; for (int k = 0; k < 6; k++) t12[12 * j + 4 + k] = g->ncy[k * nr + j]; }
+            g->d_yrec12 = (float *)upload(t12, sizeof(float) * 12 * nr);
+            ezhip_sync();
+            free(t12);
+        }
         ezhip_sync();
-        if (!g->d_ax || !g->d_ay || !g->d_ncx || !g->d_ncy || !g->d_ncx8 || !g->d_ncy8) return -1;
+        if (!g->d_ax || !g->d_ay || !g->d_ncx || !g->d_ncy || !g->d_ncx8 || !g->d_ncy8 || !g->d_xrec12 || !g->d_yrec12) return -1;
     }
     return 0;
 }
@@ -1993,7 +2010,7 @@ static void fill_pts_plan(const ezh_set *s, const ezh_grid *gi, ezhip_pts_plan *
     pp->degree = degree; pp->irregular = src_irregular(gi);
     pp->ni = gi->ni; pp->nj = gi->nj; pp->i1 = gi->i1; pp->i2 = gi->i2; pp->j1 = gi->j1; pp->j2 = gi->j2; pp->wrap = gi->extension;
     pp->ax = gi->d_ax; pp->ay = gi->d_ay; pp->ncx = gi->d_ncx; pp->ncy = gi->d_ncy;
-    pp->ncx8 = gi->d_ncx8; pp->ncy8 = gi->d_ncy8;
+    pp->ncx8 = gi->d_ncx8; pp->ncy8 = gi->d_ncy8; pp->xrec12 = gi->d_xrec12; pp->yrec12 = gi->d_yrec12;
     pp->zones = zones; pp->degre_extrap = O.degre_extrap; pp->vector_mode = vector_mode;
     pp->pole_weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
     if (s) { pp->ypole_n = s->ypole_n; pp->ypole_s = s->ypole_s; }
@@ -2494,6 +2511,8 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
         if (s->cspec_key == key) {
             pu.cspec_valid = 1; pu.cspec_count = s->cspec_count; pu.cspec_list = s->d_cspec_list;
             pu.cspec_x = s->d_cspec_xy; pu.cspec_y = s->d_cspec_xy ? s->d_cspec_xy + s->cspec_count : NULL;
+            if (s->d_uvt_tiles && !getenv("EZHIP_NO_UVT")) { pu.uvt_tiles = s->d_uvt_tiles; pu.uvt_shape = s->uvt_shape; pu.uvt_cap = s->uvt_cap;
+                if (s->d_uvt_streams && s->uvt_streams_M == d_M && (!d_M || m_half) && !getenv("EZHIP_UVT_NO_STREAMS")) pu.uvt_streams = s->d_uvt_streams; }      /* EZHIP_NO_UVT: the gathering kernel (same results) */
         }
         pthread_mutex_unlock(&g_plan_mtx);
     }
@@ -2505,8 +2524,36 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
             float *dxy = cnt ? (float *)ezhip_malloc(sizeof(float) * 2 * (size_t)cnt) : NULL;
             if (cnt == 0 || (dl && dxy && ezhip_pts2_special_snapshot(dl, dxy, dxy + cnt, cnt, s->d_x, s->d_y) == cnt)) {
                 pthread_mutex_lock(&g_plan_mtx);
-                if (s->cspec_key == 0) { s->d_cspec_list = dl; s->d_cspec_xy = dxy; s->cspec_count = cnt; s->cspec_key = key; dl = NULL; dxy = NULL; }
+                int first = 0;
+                if (s->cspec_key == 0) { s->d_cspec_list = dl; s->d_cspec_xy = dxy; s->cspec_count = cnt; s->cspec_key = key; dl = NULL; dxy = NULL; first = 1; }
                 pthread_mutex_unlock(&g_plan_mtx);
+                /* with the special points known, the irregular bicubic pair can run from LDS-staged stencil windows: the tile table over the set's x, y, once */
+                if (first && degree == DEG_CUBIC && pu.irregular && pu.wrap != 0 && pu.tile_ni > 0 && pu.xrec12) {
+                    const int th = getenv("EZHIP_UVT_SHAPE") ? atoi(getenv("EZHIP_UVT_SHAPE")) : 3232;      /* 100 TW + TH: 3232, 3216, 6416, 6408 (same results) */
+                    int cap = getenv("EZHIP_UVT_CAP") ? atoi(getenv("EZHIP_UVT_CAP")) : 2560;      /* 8 bytes a cell + 9 KB of records: five blocks per CU */
+                    if (cap < 256) cap = 256;
+                    if (cap > 4096) cap = 4096;
+                    pu.uvt_cap = cap;
+                    const int nt = ezhip_uvt_ntiles(&pu, th);
+                    void *dt = nt > 0 ? ezhip_malloc(16 * (size_t)nt) : NULL;
+                    int st[4] = {0, 0, 0, 0};
+                    if (dt && ezhip_uvt_build(&pu, s->d_x, s->d_y, dt, th, st) == 0 && st[0] >= 4 * st[1]) {      /* (a set whose tiles mostly do not qualify keeps the gathering kernel) */
+                        pthread_mutex_lock(&g_plan_mtx);
+                        s->uvt_shape = th; s->uvt_cap = cap; memcpy(s->uvt_stats, st, sizeof(st)); s->d_uvt_tiles = dt; dt = NULL;
+                        pthread_mutex_unlock(&g_plan_mtx);
+                        if (!d_M || m_half) {      /* x, y and the pair's (a, b) once more in tile order (16 bytes per target point) */
+                            void *ds = ezhip_malloc(ezhip_uvt_stream_bytes(&pu, th));
+                            if (ds && ezhip_uvt_pack_streams(&pu, s->d_x, s->d_y, ds, th) == 0) {
+                                pthread_mutex_lock(&g_plan_mtx);
+                                s->d_uvt_streams = ds; s->uvt_streams_M = d_M; ds = NULL;
+                                pthread_mutex_unlock(&g_plan_mtx);
+                            }
+                            ezhip_free(ds);
+                        }
+                        if (getenv("EZHIP_VERBOSE")) fprintf(stderr, "<ezhip> k_uvt tile table of set (%d, %d): %d tiles staged, %d gathered, %d empty, largest window %d cells\n", s->gdin, s->gdout, st[0], st[1], st[2], st[3]);
+                    }
+                    ezhip_free(dt);
+                }
             }
             ezhip_free(dl); ezhip_free(dxy);                        /* (another thread was first, or the copy failed) */
         }

@@ -2092,9 +2092,8 @@ __device__ __forceinline__ void d_gdwfllw1(float &z1, float &z2, float xlon, cha
 }
 template <int CHUNK>
 __device__ __forceinline__ void polar_wind_body(const int north, float *out, const float *uu, const float *vv, const float *plon2 /* [north row | south row] */,
-                                                int ni, int nj, float xg4_n, float xg4_s, int weighted, const float *ax)
+                                                int ni, int nj, float xg4_n, float xg4_s, int weighted, const float *ax, float *lds /* CHUNK + 4 floats, 16-byte aligned */)
 {
-    __shared__ __attribute__((aligned(16))) float lds[CHUNK + 4];
     const char hs = north ? 'N' : 'S';
     const float xg4 = north ? xg4_n : xg4_s;
     const float *urow = uu + (north ? (size_t)(nj - 1) * ni : 0), *vrow = vv + (north ? (size_t)(nj - 1) * ni : 0);
@@ -2121,7 +2120,8 @@ __device__ __forceinline__ void polar_wind_body(const int north, float *out, con
 __global__ __launch_bounds__(256) void k_polar_wind(float *out, const float *uu, const float *vv, const float *plon2, int ni, int nj, float xg4_n, float xg4_s,
                                                     int weighted, const float *ax)
 {
-    polar_wind_body<POLE_CHUNK>(blockIdx.x == 0, out, uu, vv, plon2, ni, nj, xg4_n, xg4_s, weighted, ax);
+    __shared__ __attribute__((aligned(16))) float lds[POLE_CHUNK + 4];
+    polar_wind_body<POLE_CHUNK>(blockIdx.x == 0, out, uu, vv, plon2, ni, nj, xg4_n, xg4_s, weighted, ax, lds);
 }
 /* ez_corrbgd.inc:20-55 (called at the end of ez_corrval for a Z- or #-on-E source and a 'B' target, ez_corrval.c:146-148): the rows of the
  * target at the poles become their mean -- a sequential REAL sum over the row divided by ni * 1.0 (block_poleval, unweighted).
@@ -2680,6 +2680,11 @@ __global__ __launch_bounds__(256) void k_pts(ezhip_pts_plan p, float *__restrict
  * reciprocals are the Lagrange denominators -- cut the VALU work from 540 to 310 instructions per wave and were measured SLOWER at equal
  * occupancy, 172 - 186 against 165 - 169 us: the kernel is bound by its gathers, not by its arithmetic; the reference's Newton form stays.) */
 template <int KIND, bool LITERAL>
+__device__ __forceinline__ void pts2_point(const ezhip_pts_plan &p, float *__restrict__ zout1, float *__restrict__ zout2,
+                                           const float *__restrict__ zin1, const float *__restrict__ zin2,
+                                           const float *__restrict__ xs, const float *__restrict__ ys, int n,
+                                           int *__restrict__ special_list, unsigned *__restrict__ special_count);
+template <int KIND, bool LITERAL>
 __device__ __forceinline__ void pts2_body(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
                                               const float *__restrict__ zin1, const float *__restrict__ zin2,
                                               const float *__restrict__ xs, const float *__restrict__ ys, int npts,
@@ -2704,6 +2709,15 @@ __device__ __forceinline__ void pts2_body(ezhip_pts_plan p, float *__restrict__ 
         n = (int)(cy_ * (unsigned)p.tile_ni + cx_);
     } else n = (int)(p.xcd_order ? pts_block(blockIdx.x - boff, gridDim.x - boff) : blockIdx.x - boff) * 256 + threadIdx.x;
     if (n >= npts) return;
+    pts2_point<KIND, LITERAL>(p, zout1, zout2, zin1, zin2, xs, ys, n, special_list, special_count);
+}
+/* one point pair of k_pts2 / k_pts2_irgd3w (and of the tiles k_uvt hands back) */
+template <int KIND, bool LITERAL>
+__device__ __forceinline__ void pts2_point(const ezhip_pts_plan &p, float *__restrict__ zout1, float *__restrict__ zout2,
+                                           const float *__restrict__ zin1, const float *__restrict__ zin2,
+                                           const float *__restrict__ xs, const float *__restrict__ ys, int n,
+                                           int *__restrict__ special_list, unsigned *__restrict__ special_count)
+{
     const float px = xs[n], py = ys[n];
     const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;
     const PlainAcc Z1{zin1, p.ni, p.j1}, Z2{zin2, p.ni, p.j1};
@@ -2765,12 +2779,213 @@ __global__ __launch_bounds__(256) void k_pts2_irgd3w(ezhip_pts_plan p, float *__
      * are the next kernel's */
     unsigned boff = 0;
     if (p.pw_out) {
-        if (blockIdx.x < 2) { polar_wind_body<2048>(blockIdx.x == 0, p.pw_out, zin1, zin2, p.pw_plon2, p.ni, p.nj, p.pw_xg4_n, p.pw_xg4_s, p.pw_weighted, p.pw_ax); return; }
+        if (blockIdx.x < 2) {
+            __shared__ __attribute__((aligned(16))) float pw_lds[2048 + 4];
+            polar_wind_body<2048>(blockIdx.x == 0, p.pw_out, zin1, zin2, p.pw_plon2, p.ni, p.nj, p.pw_xg4_n, p.pw_xg4_s, p.pw_weighted, p.pw_ax, pw_lds); return;
+        }
         boff = 2;
     }
     pts2_body<PK_IRGD3_W, false>(p, zout1, zout2, zin1, zin2, xs, ys, npts, special_list, special_count, boff);
 }
 
+/* ---- k_uvt: the wind pair from an irregular (rotated) source with its stencil tiles STAGED IN LDS -------------------------------------------
+ * k_pts2_irgd3w gathers 17 times per point pair through the vector L1 (8 stencil rows, 6 coefficient pieces, x, y, the wind matrix): 404 cache
+ * accesses of 64 bytes per wave, the L1's 64 B / clk is the kernel's bound (profiles/r03_experiments.txt).  Here a thread block takes a 32 x UVT_TH
+ * tile of the target; the source window its normal points' stencils touch (known per tile from the set's located x, y: k_uvt_bbox, once per grid set)
+ * comes in with coalesced loads -- both components side by side as float2 cells -- together with the columns' and rows' axis / Newton-coefficient records
+ * (48 bytes each: ax(i-1 .. i+2), c1 .. c6); every point then reads its 16 cells and its two records from LDS.  Through the vector L1 go only the
+ * streams (x, y, matrix in; u, v out: whole 128-byte row pieces) and the staging.  Tiles that do not qualify (the longitude seam; windows beyond UVT_CAP
+ * cells next to the rotated poles) take the gathering path point by point; polar-strip and re-interpolated points stay with k_pts_special2c.
+ * The arithmetic is p_irgdint_3_w_pair_inner's, operation for operation: results are bit-identical to k_pts2_irgd3w's. */
+#define UVT_CAP_DEFAULT 2560                           /* staged cells per tile */
+#define UVT_REC_MAX 192                                /* records (x + y) per tile */
+__device__ __forceinline__ int uvt_wave_min(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64)); return v; }
+__device__ __forceinline__ int uvt_wave_max(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64)); return v; }
+/* tile (TW x TH target points, a thread block of 256: thread t takes column t % TW, rows t / TW + k * 256 / TW) */
+template <int TW, int TH> struct uvt_geom {
+    static constexpr int PPT = TW * TH / 256, RSTEP = 256 / TW;
+    static_assert(TW * TH % 256 == 0 && (TW == 32 || TW == 64), "k_uvt tile shape");
+};
+/* per tile {i0, j0, W, H}: source columns i0 .. i0 + W - 1 (1-based) and rows j0 .. j0 + H - 1 under the stencils of the tile's NORMAL points;
+ * W = 0: hand the tile to the gathering path; W < 0: nothing in the tile is this kernel's (only special points) */
+template <int TW, int TH>
+__global__ __launch_bounds__(256) void k_uvt_bbox(ezhip_pts_plan p, const float *__restrict__ xs, const float *__restrict__ ys, int4 *__restrict__ tiles, int cap, int recmax)
+{
+    typedef uvt_geom<TW, TH> G;
+    __shared__ int red[4][6];
+    const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW, b = blockIdx.x, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
+    const unsigned cx = bx * TW + (t % TW);
+    int imin = 0x7fffffff, imax = -1, jmin = 0x7fffffff, jmax = -1, seam = 0, mine = 0;
+#pragma unroll
+    for (int k = 0; k < G::PPT; k++) {
+        const unsigned cy = by * TH + t / TW + (unsigned)(G::RSTEP * k);
+        if (cx >= (unsigned)p.tile_ni || cy >= (unsigned)p.tile_nj) continue;
+        const size_t n = (size_t)cy * p.tile_ni + cx;
+        const float px = xs[n], py = ys[n];
+        const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
+        if (zone == PZ_FILL) mine = 1;
+        if (zone != PZ_NORMAL) continue;
+        mine = 1;
+        const int i = min(p.ni - 2 + p.wrap, max(1, max(2 - p.wrap, (int)px))), j = min(p.j2 - 2, max(p.j1 + 1, (int)py));
+        seam |= (i <= 1 || i >= p.ni - 1) ? 1 : 0;
+        imin = min(imin, i); imax = max(imax, i); jmin = min(jmin, j); jmax = max(jmax, j);
+    }
+    imin = uvt_wave_min(imin); jmin = uvt_wave_min(jmin); imax = uvt_wave_max(imax); jmax = uvt_wave_max(jmax); seam = uvt_wave_max(seam); mine = uvt_wave_max(mine);
+    if ((t & 63u) == 0) { int *r = red[t >> 6]; r[0] = imin; r[1] = imax; r[2] = jmin; r[3] = jmax; r[4] = seam; r[5] = mine; }
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < 4; w++) { imin = min(imin, red[w][0]); imax = max(imax, red[w][1]); jmin = min(jmin, red[w][2]); jmax = max(jmax, red[w][3]); seam |= red[w][4]; mine |= red[w][5]; }
+        int4 o;
+        if (!mine) o = make_int4(0, 0, -1, 0);
+        else if (imax < 0) o = make_int4(0, 0, 0, 0);                                     /* fill points only: the gathering path writes them */
+        else {
+            const int W = imax - imin + 4, H = jmax - jmin + 4;
+            const bool ok = !seam && W * H <= cap && (W - 3) + (H - 3) <= recmax;
+            o = ok ? make_int4(imin - 1, jmin - 1, W, H) : make_int4(0, 0, 0, 0);
+        }
+        tiles[b] = o;
+    }
+}
+/* The streams of a tile -- x, y and the wind matrix's (a, b) of its points -- are the grid SET's own data, so their layout is ours: kept a second time in tile
+ * order, one float4 {x, y, a, b} per point, [tile][k][thread].  A block then reads 16 contiguous KB (4 loads of 16 bytes per thread) where the row-major
+ * arrays give it 128-byte pieces 16 KB apart in three arrays (12 loads per thread): those pieces, not the bytes, bounded the streaming side of k_uvt
+ * (2.5 - 3.5 TB/s with everything else knocked out: profiles/r04_experiments.txt).  16 bytes per target point of extra HBM per grid set. */
+template <int TW, int TH>
+__global__ __launch_bounds__(256) void k_uvt_pack(ezhip_pts_plan p, const float *__restrict__ xs, const float *__restrict__ ys, float4 *__restrict__ streams)
+{
+    typedef uvt_geom<TW, TH> G;
+    const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW, b = blockIdx.x, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
+    const unsigned cx = bx * TW + (t % TW);
+#pragma unroll
+    for (int k = 0; k < G::PPT; k++) {
+        const unsigned cy = by * TH + t / TW + (unsigned)(G::RSTEP * k);
+        float4 o = make_float4(0.f, 0.f, 1.f, 0.f);
+        if (cx < (unsigned)p.tile_ni && cy < (unsigned)p.tile_nj) {
+            const size_t n = (size_t)cy * p.tile_ni + cx;
+            o.x = xs[n]; o.y = ys[n];
+            if (p.wind_M) { const wm_f2 m = *(const wm_f2 *)((const char *)p.wind_M + (n << 3)); o.z = m.x; o.w = m.y; }
+        }
+        streams[((size_t)b * G::PPT + k) * 256 + t] = o;
+    }
+}
+/* (The set's special points -- polar strips, re-interpolated extrapolation: a fraction of a percent of the points, a chain of dependent gathers, 12 us of
+ * latency per cfg3 pair as a kernel of their own behind this one -- were tried (a) on a side stream beside this kernel: fork / join events, 98.8 against
+ * 87.7 us per pair; (b) as blocks at the head of this launch waiting for the polar-wind producers: the out-of-line strip / re-interpolation code they call
+ * takes 146 VGPRs and a call stack, capped at 128 it spills into scratch and the WHOLE launch slows to 227 us.  They stay a kernel of their own.) */
+template <int TW, int TH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_uvt(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+                                             const float *__restrict__ zin1, const float *__restrict__ zin2,
+                                             const float *__restrict__ xs, const float *__restrict__ ys, const int4 *__restrict__ tiles)
+{
+    typedef uvt_geom<TW, TH> G;
+    constexpr int PPT = G::PPT;
+    extern __shared__ __attribute__((aligned(16))) float uvt_lds[];
+    const int dbg = EZH_DBG(p.uvt_debug);      /* development knock-outs (EZHIP_UVT_DEBUG, develop build only): 1 skip handed-back tiles, 2 no staging loads, 4 no arithmetic, 16 no matrix */
+    unsigned boff = 0;
+    if (p.pw_out) {           /* the pair's synthetic polar wind rows: two producer blocks at the head of the launch, as in k_pts2_irgd3w */
+        if (blockIdx.x < 2) { polar_wind_body<2048>(blockIdx.x == 0, p.pw_out, zin1, zin2, p.pw_plon2, p.ni, p.nj, p.pw_xg4_n, p.pw_xg4_s, p.pw_weighted, p.pw_ax, uvt_lds); return; }      /* (the launch's dynamic LDS holds 2052 floats and more) */
+        boff = 2;
+    }
+    const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW, b = blockIdx.x - boff, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
+    const unsigned cx = bx * TW + (t % TW), cy0 = by * TH + t / TW;
+    const bool okx = cx < (unsigned)p.tile_ni;
+    /* the points' own streams first -- before the tile's table entry is even looked at (their addresses depend on the block index only): in flight
+     * while the entry arrives and the window is staged.  (Point index 0 for the lanes beyond the target's edge: a readable address.) */
+    float px[PPT], py[PPT]; wm_f2 wlo[PPT];
+    const unsigned n0 = okx && cy0 < (unsigned)p.tile_nj ? cy0 * (unsigned)p.tile_ni + cx : 0u, nstep = (unsigned)G::RSTEP * (unsigned)p.tile_ni;
+    if (p.uvt_streams) {              /* the set's tile-ordered copy: {x, y, a, b} of a point in one 16-byte load, a block's share contiguous */
+        typedef float f4a __attribute__((ext_vector_type(4)));
+        const f4a *S = (const f4a *)p.uvt_streams + (size_t)b * (PPT * 256) + t;
+#pragma unroll
+        for (int k = 0; k < PPT; k++) { const f4a q = __builtin_nontemporal_load(S + k * 256); px[k] = q.x; py[k] = q.y; wlo[k] = wm_f2{q.z, q.w}; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const bool ok = okx && cy0 + (unsigned)(G::RSTEP * k) < (unsigned)p.tile_nj;
+            const unsigned n = ok ? n0 + (unsigned)k * nstep : 0u;
+            px[k] = xs[n]; py[k] = ys[n];
+            wlo[k] = wm_f2{1.0f, 0.0f};
+            if (p.wind_M && !(dbg & 16)) wlo[k] = __builtin_nontemporal_load((const wm_f2 *)((const char *)p.wind_M + ((size_t)n << (p.wind_M_half ? 3 : 4))));
+        }
+    }
+    const int4 tb = tiles[b];
+    if (tb.z < 0) return;
+    if (tb.z == 0) {
+        if (dbg & 1) return;
+#pragma unroll 1
+        for (int k = 0; k < PPT; k++) {
+            const unsigned cy = cy0 + (unsigned)(G::RSTEP * k);
+            if (okx && cy < (unsigned)p.tile_nj) pts2_point<PK_IRGD3_W, false>(p, zout1, zout2, zin1, zin2, xs, ys, (int)(cy * (unsigned)p.tile_ni + cx), nullptr, nullptr);
+        }
+        return;
+    }
+    const int i0 = tb.x, j0 = tb.y, W = tb.z, H = tb.w, ncell = W * H;
+    typedef float c2 __attribute__((ext_vector_type(2)));
+    c2 *cells = (c2 *)uvt_lds;
+    float4 *xr = (float4 *)(uvt_lds + 2 * ((ncell + 1) & ~1));
+    const int nxr = (W - 3) * 3, nyr = (H - 3) * 3;
+    float4 *yr = xr + nxr;
+    {
+        const unsigned magic = 0xFFFFFFFFu / (unsigned)W + 1u;
+        const float *s1 = zin1 + (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1), *s2 = zin2 + (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1);
+        if (!(dbg & 2)) {
+#pragma unroll 4
+            for (int idx = (int)t; idx < ncell; idx += 256) {
+                const unsigned r = __umulhi((unsigned)idx, magic), c = (unsigned)idx - r * (unsigned)W;
+                const size_t off = (size_t)r * (size_t)p.ni + c;
+                cells[idx] = c2{s1[off], s2[off]};
+            }
+        }
+        const float4 *gx = (const float4 *)p.xrec12 + (size_t)i0 * 3, *gy = (const float4 *)p.yrec12 + (size_t)(j0 + 1 - p.j1) * 3;
+        for (int idx = (int)t; idx < nxr; idx += 256) xr[idx] = gx[idx];
+        for (int idx = (int)t; idx < nyr; idx += 256) yr[idx] = gy[idx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        if (!(okx && cy0 + (unsigned)(G::RSTEP * k) < (unsigned)p.tile_nj)) continue;
+        const size_t n = (size_t)n0 + (size_t)k * nstep;
+        const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px[k], py[k]);
+        float a, bb;
+        if (zone == PZ_FILL) a = bb = *p.fill;
+        else if (zone == PZ_NORMAL) {
+            const int i = min(p.ni - 2 + p.wrap, max(1, max(2 - p.wrap, (int)px[k]))), j = min(p.j2 - 2, max(p.j1 + 1, (int)py[k]));
+            if (dbg & 4) { a = px[k] + (float)i; bb = py[k] + (float)j; }
+            else {
+                const float4 *xq = xr + (i - 1 - i0) * 3, *yq = yr + (j - 1 - j0) * 3;
+                const float4 axv = xq[0], cxa = xq[1]; const c2 cxb = *(const c2 *)(xq + 2);
+                const float4 ayv = yq[0], cya = yq[1]; const c2 cyb = *(const c2 *)(yq + 2);
+                const c2 *cp = cells + (j - 1 - j0) * W + (i - 1 - i0);
+                c2 q[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { q[r][0] = cp[r * W]; q[r][1] = cp[r * W + 1]; q[r][2] = cp[r * W + 2]; q[r][3] = cp[r * W + 3]; }
+                const double x = (double)(axv.y + (axv.z - axv.y) * (px[k] - (float)i));
+                const double y = (double)(ayv.y + (ayv.z - ayv.y) * (py[k] - (float)j));
+                const NewtonW wx = newton_w((double)cxa.x, (double)cxa.y, (double)cxa.z, (double)cxa.w, (double)cxb.x, (double)cxb.y, x - (double)axv.x, x - (double)axv.y, x - (double)axv.z);
+                const NewtonW wy = newton_w((double)cya.x, (double)cya.y, (double)cya.z, (double)cya.w, (double)cyb.x, (double)cyb.y, y - (double)ayv.x, y - (double)ayv.y, y - (double)ayv.z);
+                const double wr[4] = {1.0 - wy.a, wy.a - wy.b, wy.b - wy.g, wy.g};
+                double su = 0.0, sv = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    su = fma(wr[r], newton_apply(wx, (double)q[r][0].x, (double)q[r][1].x, (double)q[r][2].x, (double)q[r][3].x), su);
+                    sv = fma(wr[r], newton_apply(wx, (double)q[r][0].y, (double)q[r][1].y, (double)q[r][2].y, (double)q[r][3].y), sv);
+                }
+                a = (float)su; bb = (float)sv;
+            }
+        } else continue;
+        if (p.wind_M) {
+            wm_f2 whi = wm_f2{0.0f, 1.0f};
+            if (!p.wind_M_half) whi = __builtin_nontemporal_load((const wm_f2 *)((const char *)p.wind_M + (n << 4)) + 1);      /* (sets whose chain is not a pure rotation: rare) */
+            const float u = a, v = bb;
+            wind_m_apply(wlo[k], whi, p.wind_M_half, u, v, p.wind_dst_rot, a, bb);
+        }
+        if (!(dbg & 32) || a == 12345.678f) { zout1[n] = a; zout2[n] = bb; }      /* (32: development, no stores) */
+    }
+}
+
+/* (k_uvt as a pipeline -- persistent blocks with two staging buffers, the next tile's window and streams in flight while a tile is computed -- was built twice
+ * and measured slower both times: with LDS-DMA staging (the window as separate u / v planes: twice the LDS read instructions) 111 us per cfg3 pair against 90;
+ * with the next window held in registers (135 - 155 VGPRs, three waves per SIMD) 96 - 104 us for the kernel against 76.  profiles/r04_experiments.txt.) */
 /* Special points only (a fraction of a percent of a global target): polar strips on the virtual 4-row strip,
  * extrapolation points re-interpolated with degre_extrap. */
 __global__ __launch_bounds__(256) void k_pts_special(ezhip_pts_plan p, float *__restrict__ zout, const float *__restrict__ zin,
@@ -2831,12 +3046,12 @@ __global__ __launch_bounds__(256) void k_pts_special2(ezhip_pts_plan p, float *_
 }
 
 /* the same with the points known to the host (ezhip_pts_plan.cspec_*): index, x and y of point k side by side, their number by value */
-__global__ __launch_bounds__(256) void k_pts_special2c(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
-                                                       const float *__restrict__ zin1, const float *__restrict__ zin2,
-                                                       const float *__restrict__ prow_n2, const float *__restrict__ prow_s2)
+__device__ __forceinline__ void special2c_body(const ezhip_pts_plan &p, float *__restrict__ zout1, float *__restrict__ zout2,
+                                               const float *__restrict__ zin1, const float *__restrict__ zin2,
+                                               const float *__restrict__ prow_n2, const float *__restrict__ prow_s2, unsigned blk, unsigned nblk)
 {
     const unsigned cnt = (unsigned)p.cspec_count;
-    for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+    for (unsigned k = blk * 256 + threadIdx.x; k < cnt; k += nblk * 256) {
         const int n = p.cspec_list[k];
         const float px = p.cspec_x[k], py = p.cspec_y[k];
         const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;
@@ -2855,6 +3070,12 @@ __global__ __launch_bounds__(256) void k_pts_special2c(ezhip_pts_plan p, float *
         if (p.wind_M) { const float u = a, v = b; wind_m_apply(mlo, mhi, p.wind_M_half, u, v, p.wind_dst_rot, a, b); }
         zout1[o] = a; zout2[o] = b;
     }
+}
+__global__ __launch_bounds__(256) void k_pts_special2c(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+                                                       const float *__restrict__ zin1, const float *__restrict__ zin2,
+                                                       const float *__restrict__ prow_n2, const float *__restrict__ prow_s2)
+{
+    special2c_body(p, zout1, zout2, zin1, zin2, prow_n2, prow_s2, blockIdx.x, gridDim.x);
 }
 __global__ __launch_bounds__(256) void k_spec_gather(int *__restrict__ list_out, float *__restrict__ x_out, float *__restrict__ y_out,
                                                      const int *__restrict__ list_in, const float *__restrict__ xs, const float *__restrict__ ys, unsigned cnt)
@@ -2949,6 +3170,25 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     const int tbw = pu2.tile_shape == 1 ? 64 : pu2.tile_shape == 2 ? 16 : pu2.tile_shape == 3 ? 128 : pu2.tile_shape == 5 ? 16 : 32;
     const int tbh = pu2.tile_shape == 1 ? 4 : pu2.tile_shape == 2 ? 16 : pu2.tile_shape == 3 ? 2 : pu2.tile_shape == 5 ? 16 : 8;
     const dim3 grid((pu2.tile_ni > 0 ? (unsigned)(((pu2.tile_ni + tbw - 1) / tbw) * ((pu2.tile_nj + tbh - 1) / tbh)) : (unsigned)((npts + 255) / 256)) + (pu2.pw_out ? 2u : 0u));
+    if (cached && fast3w && pu2.uvt_tiles && pu2.tile_ni > 0 && pu2.xrec12 && pu2.yrec12 && !pu2.out_idx) {
+        /* the grid set's tile table is known: stencil windows staged in LDS (k_uvt); the set's special points behind it */
+        pu2.uvt_debug = EZH_DEVINT("EZHIP_UVT_DEBUG");
+        const unsigned nt = (unsigned)ezhip_uvt_ntiles(&pu2, pu2.uvt_shape);
+        const int4 *tl = (const int4 *)pu2.uvt_tiles;
+        const dim3 g(nt + (pu2.pw_out ? 2u : 0u));
+        const size_t lds = (size_t)8 * (size_t)pu2.uvt_cap + 48 * UVT_REC_MAX;
+#define UVT_LAUNCH(TW, TH) hipLaunchKernelGGL((k_uvt<TW, TH>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl)
+        switch (pu2.uvt_shape) { case 3216: UVT_LAUNCH(32, 16); break; case 6408: UVT_LAUNCH(64, 8); break; case 6416: UVT_LAUNCH(64, 16); break; default: UVT_LAUNCH(32, 32); break; }
+#undef UVT_LAUNCH
+        if (LAUNCH_CHECK("k_uvt")) return -1;
+        if (ezhip_side_join()) return -1;
+        if (plan_u->cspec_count > 0 && !(pu2.uvt_debug & 8)) {
+            const unsigned nbk = (unsigned)((plan_u->cspec_count + 255) / 256);
+            hipLaunchKernelGGL(k_pts_special2c, dim3(nbk < 256 ? nbk : 256), block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v, plan_v->pole_row_n, plan_v->pole_row_s);
+            return LAUNCH_CHECK("k_pts_special2c");
+        }
+        return 0;
+    }
 #define PTS2_CASE(K) case K: if (K == PK_IRGD3_W && !pu2.newton_literal) hipLaunchKernelGGL(k_pts2_irgd3w, grid, block, 0, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, list_arg, cnt); \
         else hipLaunchKernelGGL(k_pts2<K>, grid, block, 0, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, npts, list_arg, cnt); break
     switch (pts_kind(plan_u)) {
@@ -2975,6 +3215,59 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     hipLaunchKernelGGL(k_pts_special2, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v,
                        plan_v->pole_row_n, plan_v->pole_row_s, d_x, d_y, t_spec.list, cnt, cnt_next);
     return LAUNCH_CHECK("k_pts_special2");
+}
+
+/* shape = 100 TW + TH: 3232 (default), 3216, 6416, 6408 */
+static void uvt_dims(int shape, int *tw, int *th) { *tw = shape / 100; *th = shape % 100; if (!((*tw == 32 && (*th == 32 || *th == 16)) || (*tw == 64 && (*th == 16 || *th == 8)))) { *tw = 32; *th = 32; } }
+extern "C" int ezhip_uvt_ntiles(const ezhip_pts_plan *plan, int shape)
+{
+    int tw, th;
+    uvt_dims(shape, &tw, &th);
+    if (plan->tile_ni <= 0 || plan->tile_nj <= 0) return 0;
+    return ((plan->tile_ni + tw - 1) / tw) * ((plan->tile_nj + th - 1) / th);
+}
+extern "C" int ezhip_uvt_build(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_tiles, int shape, int *stats)
+{
+    const int nt = ezhip_uvt_ntiles(plan, shape);
+    if (nt <= 0 || !d_tiles) return -1;
+    const int cap = plan->uvt_cap > 0 ? plan->uvt_cap : UVT_CAP_DEFAULT;
+    int tw, th;
+    uvt_dims(shape, &tw, &th);
+    const int recmax = UVT_REC_MAX;
+#define UVT_BB(TW, TH) hipLaunchKernelGGL((k_uvt_bbox<TW, TH>), dim3(nt), dim3(256), 0, g_stream, *plan, d_x, d_y, (int4 *)d_tiles, cap, recmax)
+    if (tw == 32 && th == 16) UVT_BB(32, 16); else if (tw == 64 && th == 8) UVT_BB(64, 8); else if (tw == 64 && th == 16) UVT_BB(64, 16); else UVT_BB(32, 32);
+#undef UVT_BB
+    if (LAUNCH_CHECK("k_uvt_bbox")) return -1;
+    if (set_err(hipStreamSynchronize(g_stream), "k_uvt_bbox")) return -1;
+    if (stats) {
+        int4 *h = (int4 *)malloc(sizeof(int4) * (size_t)nt);
+        if (!h) return -1;
+        if (set_err(hipMemcpy(h, d_tiles, sizeof(int4) * (size_t)nt, hipMemcpyDeviceToHost), "k_uvt_bbox tiles")) { free(h); return -1; }
+        stats[0] = stats[1] = stats[2] = stats[3] = 0;
+        for (int k = 0; k < nt; k++) { if (h[k].z > 0) { stats[0]++; if (h[k].z * h[k].w > stats[3]) stats[3] = h[k].z * h[k].w; } else if (h[k].z == 0) stats[1]++; else stats[2]++; }
+        free(h);
+    }
+    return 0;
+}
+
+/* the tile-ordered stream copy of a wind-pair plan (k_uvt_pack): d_streams holds 16 bytes x 256 x PPT x ntiles.  plan->wind_M: NULL or the (a, b) form */
+extern "C" size_t ezhip_uvt_stream_bytes(const ezhip_pts_plan *plan, int shape)
+{
+    int tw, th;
+    uvt_dims(shape, &tw, &th);
+    return (size_t)16 * (size_t)tw * (size_t)th * (size_t)ezhip_uvt_ntiles(plan, shape);
+}
+extern "C" int ezhip_uvt_pack_streams(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_streams, int shape)
+{
+    const int nt = ezhip_uvt_ntiles(plan, shape);
+    if (nt <= 0 || !d_streams || (plan->wind_M && !plan->wind_M_half)) return -1;
+    int tw, th;
+    uvt_dims(shape, &tw, &th);
+#define UVT_PK(TW, TH) hipLaunchKernelGGL((k_uvt_pack<TW, TH>), dim3(nt), dim3(256), 0, g_stream, *plan, d_x, d_y, (float4 *)d_streams)
+    if (tw == 32 && th == 16) UVT_PK(32, 16); else if (tw == 64 && th == 8) UVT_PK(64, 8); else if (tw == 64 && th == 16) UVT_PK(64, 16); else UVT_PK(32, 32);
+#undef UVT_PK
+    if (LAUNCH_CHECK("k_uvt_pack")) return -1;
+    return set_err(hipStreamSynchronize(g_stream), "k_uvt_pack");
 }
 
 extern "C" int ezhip_pts2_special_snapshot(int *d_list_out, float *d_x_out, float *d_y_out, int cap, const float *d_xs, const float *d_ys)

@@ -222,6 +222,12 @@ typedef struct {
     int ni, nj, i1, i2, j1, j2, wrap; /* source geometry, 1-based bounds as in the reference */
     const float *ax, *ay, *ncx, *ncy; /* device; NULL for regular sources */
     const float *ncx8, *ncy8;         /* the same coefficients laid out [index][8] (6 used): two 16-byte loads per point */
+    const float *xrec12, *yrec12;     /* k_uvt: per source column i (row j) one 48-byte record {ax(i-1 .. i+2), c1 .. c6, 0, 0}, staged in LDS per tile; index i - 1 (j - j1) */
+    const void *uvt_tiles;            /* k_uvt: the grid set's tile table (int4 {i0, j0, W, H} per 32 x uvt_th tile of the target: ezhip_uvt_build), NULL: k_pts2 */
+    int uvt_shape;                    /* 100 TW + TH of the table's tiles: 3232 (default), 3216, 6416, 6408 */
+    int uvt_cap;                      /* staged cells a tile may need (the table was built under it) */
+    const void *uvt_streams;          /* NULL, or the set's x, y and (a, b) once more in tile order: float4 per point (ezhip_uvt_pack_streams) */
+    int uvt_debug;                    /* development knock-outs (develop build only) */
     int wind_dst_rot;                 /* with wind_M: the TARGET frame is a rotated one (decides what a REAL overflow of the chain's speed turns into) */
     int wind_M_half;                  /* wind_M holds (a, b) per point: a pure rotation, c = -b, d = a */
     const void *wind_M;               /* k_pts2: the grid pair's wind matrices (ezhip_wind_matrix), applied to every point before it is stored; NULL: store the interpolated components */
@@ -255,6 +261,12 @@ int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const float *d_z
 /* masks (ez_mask.c): mode 0 = c_ezsint_mask, 1 = c_ezget_mask_zones; x, y = located coordinates of every target point */
 int ezhip_mask(int *d_mask_out, const float *d_x, const float *d_y, const int *d_mask_in, int ni_in, int nj_in, int ni_out, int nj_out, int mode, int cloud_linear);
 int ezhip_mask_fill_min(float *d_fld, const int *d_mask, size_t n, unsigned *d_keys2);
+/* k_uvt's tile table of a wind-pair plan over the located x, y of its grid set (tile_ni x tile_nj target in row order): d_tiles receives
+ * ezhip_uvt_ntiles(plan, shape) int4 entries (shape = 100 TW + TH).  stats (host, may be NULL): [0] tiles staged, [1] handed to the gathering path, [2] empty, [3] largest window (cells).  Synchronises. */
+int ezhip_uvt_ntiles(const ezhip_pts_plan *plan, int shape);
+int ezhip_uvt_build(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_tiles, int shape, int *stats);
+size_t ezhip_uvt_stream_bytes(const ezhip_pts_plan *plan, int shape);
+int ezhip_uvt_pack_streams(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_streams, int shape);
 int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_plan *plan_v, float *d_out_u, float *d_out_v,
                       const float *d_in_u, const float *d_in_v, const float *d_x, const float *d_y, int npts);
 /* ez_xpngdag2 / ez_xpngdb2: hemispheric field (ni x nj) -> rows j1..j2 of its global expansion, mirrored rows times +-1 */

@@ -936,6 +936,14 @@ def test_cfg3_full_size_against_reference_run():
             assert ez.ezsint_dev(o_z, d_u) == 0
             assert ez.ezuvint_dev(o_u, o_v, d_u, d_v) == 0
             torch.cuda.synchronize()
+            if (degree, polar) == (3, 1):
+                # the first call of a grid set lists its special points with the gathering kernel; from the second call on the pair runs from LDS-staged
+                # stencil windows (k_uvt): the same numbers bit for bit, and it is THAT call's output the checks below look at
+                first_u, first_v = o_u.clone(), o_v.clone()
+                o_u.zero_(); o_v.zero_()
+                assert ez.ezuvint_dev(o_u, o_v, d_u, d_v) == 0
+                torch.cuda.synchronize()
+                assert torch.equal(o_u, first_u) and torch.equal(o_v, first_v)
             z2 = o_z.view(mo, no)
             for got, want in ((z2[rows].cpu().numpy(), G3[key + "/z/rows"]), (z2[:, cols].cpu().numpy(), G3[key + "/z/cols"])):
                 assert relerr(got, want).max() <= RTOL, (key, float(relerr(got, want).max()))
@@ -1391,3 +1399,41 @@ def test_a_thread_on_another_device_is_refused_loudly():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert "rc -1" in r.stdout, (r.stdout, r.stderr[-1500:])
     assert "live on HIP device 5" in r.stderr and "current device is 0" in r.stderr, r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("th", [3232, 3216, 6416, 6408, -3232])
+@pytest.mark.parametrize("shape", [(320, 160, 500, 250), (257, 130, 333, 167), (640, 320, 1000, 500), (1280, 640, 2000, 1000)])
+@pytest.mark.parametrize("eig", ["cfg3", "tilted"])
+def test_uvt_staged_tiles_equal_gathering_kernel(shape, eig, th):
+    """k_uvt (wind pair from LDS-staged stencil windows, second call of a grid set on) against k_pts2_irgd3w (first call; EZHIP_NO_UVT=1): bit-identical
+    outputs on rotated global sources whose target tiles include the longitude seam, both rotated poles (windows too large to stage) and ragged edges"""
+    ni, nj, no, mo = shape
+    ax, ay = ec.ze_axes(ni, nj)
+    ig = ec.E_IG if eig == "cfg3" else ol.cxgaig("E", 62.0, 20.0, -15.0, 110.0)
+    os.environ["EZHIP_UVT_SHAPE"] = str(abs(th))
+    if th < 0:
+        os.environ["EZHIP_UVT_NO_STREAMS"] = "1"      # the row-major x, y and matrix arrays instead of the set's tile-ordered copy
+    try:
+        gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ig, ax, ay); gdout = ez.ezqkdef(no, mo, "L", *ol.cxgaig("L", -90.0, 0.0, 180.0 / (mo - 1), 360.0 / no))
+        assert ez.ezdefset(gdout, gdin) == 1
+        setopts(3, 1)
+        uu, vv = ec.synth_wind(ni, nj, seed=11)
+        for a in (uu, vv):
+            a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+        ez.use_stream(torch.cuda.current_stream().cuda_stream)
+        d_u = torch.from_numpy(uu).cuda(); d_v = torch.from_numpy(vv).cuda()
+        outs = []
+        for call in range(3):
+            o_u = torch.full((no * mo,), float("nan"), dtype=torch.float32, device="cuda"); o_v = torch.full_like(o_u, float("nan"))
+            if call == 2:
+                os.environ["EZHIP_NO_UVT"] = "1"
+            assert ez.ezuvint_dev(o_u, o_v, d_u, d_v) == 0
+            torch.cuda.synchronize()
+            outs.append((o_u, o_v))
+        for k in (1, 2):
+            assert torch.equal(outs[0][0].view(torch.int32), outs[k][0].view(torch.int32)), (k, int((outs[0][0] != outs[k][0]).sum()))
+            assert torch.equal(outs[0][1].view(torch.int32), outs[k][1].view(torch.int32)), k
+        assert not torch.isnan(outs[1][0]).any()
+    finally:
+        os.environ.pop("EZHIP_UVT_SHAPE", None); os.environ.pop("EZHIP_NO_UVT", None); os.environ.pop("EZHIP_UVT_NO_STREAMS", None)
+        ez.gdrls(gdin); ez.gdrls(gdout)
