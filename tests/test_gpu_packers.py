@@ -631,6 +631,22 @@ def test_known_answers_on_the_gpu():
     buf = np.zeros(16 * 16 // 2 + 8, np.uint32); buf[:128] = pc.tokens_to_words(tok)
     assert pk.armn_compress(buf, 16, 16, 16) == zlng
     assert [int(x) for x in buf[:len(words)]] == words
+    # the 5-bit width field (a difference beyond 16 bits) and a MINIMUM stream with its three tile forms (raw escape, constant, minimum + offsets)
+    for (tok, words, zlng), (ni, nj) in ((ka.armn_wide_difference_16x16(), (16, 16)), (ka.armn_minimum_15x5(), (15, 5))):
+        buf = np.zeros(ni * nj // 2 + 8, np.uint32); buf[:(ni * nj + 1) // 2] = pc.tokens_to_words(tok)
+        assert pk.armn_compress(buf, ni, nj, 16) == zlng
+        assert [int(x) for x in buf[:len(words)]] == words, [hex(int(x)) for x in buf[:len(words)]]
+        assert pk.armn_uncompress(buf, ni, nj, 16) == ni * nj * 2                      # and back, through the decoder
+        assert np.array_equal(buf[:(ni * nj + 1) // 2], pc.tokens_to_words(tok))
+    # c_armn_compress32: the exponent plane (packTokensParallelogram_8) and the mantissa plane (packTokensParallelogram32) of a hand-derived record
+    for with_mantissa in (False, True):
+        f, pieces, zlng = ka.armn32_step_16x16(with_mantissa)
+        zl, z = pk.armn_compress32(f, 16, 16, 32)
+        assert zl == zlng
+        for w0, words in pieces:
+            assert [int(x) for x in z[w0:w0 + len(words)]] == words, (w0, [hex(int(x)) for x in z[w0:w0 + len(words)]])
+        rc, back = pk.armn_uncompress32(z, 16, 16, 32)
+        assert rc == 256 and np.array_equal(back.view(np.uint32), f.view(np.uint32))
 
 
 # ---------------------------------------------------------------------------------------------

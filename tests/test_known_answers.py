@@ -113,6 +113,12 @@ PACK_VECTORS = {
     # scaledExpOfRange = -2 -> 0xFFE; min = 0: scaledExpOfMinFloat = (0 - 1023 + 1024 - 48) & 0x111 = 0xFFFFFFD1 & 0x111 = 0x111 (sic, :240-242),
     # h[1] = 0xFFE << 16 | (0x111 << 4 | 0) = 0x0FFE1110; h[2] = 0; mulFactor 4: tokens 0, int(7.5) = 7, F
     "cf_bump": dict(a=[0.0, 1.875, -999.0], nbits=4, tag=-999.0, hdr=[0xFEF00003, 0x0FFE1110, 0x00000000, 0x00000400], stream=[0x07F00000]),
+    # 32-bit tokens, offset 0 (the direct-copy branch, compact.tmplc:302-312): range 4 = 2^2 -> tempExpo 2; scaledExpOfRange = 2 - 32 = -30 -> + 4096 = 0xFE2;
+    #   h[1] = 0xFE2 << 16 | 0x3D0 << 4 = 0x0FE23D00; h[3] = 32 << 8; mulFactor = 2^32 / 2^2 = 2^30: tokens (x - 1) * 2^30, one per word, no shifting
+    "cf_32bits": dict(a=[1.0, 2.0, 3.0, 4.0], nbits=32, hdr=[0xFFF00004, 0x0FE23D00, 0x80000000, 0x00002000], stream=[0x00000000, 0x40000000, 0x80000000, 0xC0000000]),
+    # more than 16 bits per token (20): scaledExpOfRange = 2 - 20 = -18 -> 0xFEE; h[3] = 20 << 8; mulFactor = 2^20 / 4 = 2^18: tokens 0, 0x40000, 0x80000, 0xC0000
+    #   in 20 bits each, MSB first: 00000 40000 80000 C0000 -> 0x00000400 0x0080000C 0x0000....
+    "cf_20bits": dict(a=[1.0, 2.0, 3.0, 4.0], nbits=20, hdr=[0xFFF00004, 0x0FEE3D00, 0x80000000, 0x00001400], stream=[0x00000400, 0x0080000C, 0x00000000]),
     # compact_integer (compact_integer.c:325-570), unsigned, no header, 4 bits: tokens 1, 2, 3
     "ci_plain": dict(a=[1, 2, 3], nbits=4, op=1, stream=[0x12300000], rc=4),
     # with header (constructHeader :186-231), nbits = -1: min 1, max 3, bitRequired = bitlen(2) = 2, shift 0:
@@ -148,6 +154,79 @@ def armn_one_step_16x16():
     words = [4 | 1 << 4 | 3 << 7 | 16 << 10 | 1 << 15] + _bits([(4, 3)] + row1 + col1 + tiles)
     nbits = 3 + 31 * 16 + 4 + 9 * 4 + 24 * 4
     return u.reshape(-1), words, 1 + 4 * (1 + (nbits + 31) // 32)
+
+
+ARMN_HEADER_PG = 4 | 1 << 4 | 3 << 7 | 16 << 10 | 1 << 15        # PARALLELOGRAM, degree 1, step 3, nbits 16, levels 1 (zfstlib.h:49, c_zfstlib.c:222-236)
+ARMN_HEADER_MIN = 3 | 0 << 4 | 5 << 7 | 16 << 10 | 1 << 15       # MINIMUM, degree 0, step 5 (c_zfstlib.c:132: c_fstzip(..., MINIMUM, 0, 5, nbits, 0))
+
+
+def armn_wide_difference_16x16():
+    """the 5-bit width field (c_zfstlib.c:701-711, :736-737, :758-766).  u(2,1) = u(1,2) = 65535, everything else 0 (1-based (i, j), i fastest):
+       d(2,2) = 0 - (u(2,1) + u(1,2) - u(1,1)) = -131070: |d| > 65535 with nbits >= 15 -> the container of the width fields is 5 bits;
+       d(3,2) = 0 - (u(3,1) + u(2,2) - u(2,1)) = +65535, d(2,3) = 0 - (u(2,2) + u(1,3) - u(1,2)) = +65535, d(3,3) = 0 - (0 + 0 - 0) = 0, the rest 0.
+       First tile (i, j = 2..4): local_max = 131070 > 65535 -> nbits_needed = (int)(1 + log(131070.5) / log(2)) = (int)17.99999 = 17 (not 16: no 17-bit escape),
+       its 9 differences in 17 + 1 = 18 bits, tile rows outer: -131070 & 0x3FFFF = 0x20002, 0xFFFF, 0 | 0xFFFF, 0, 0 | 0, 0, 0.  The other 24 tiles: 5-bit zeros."""
+    u = np.zeros((16, 16), np.uint16); u[0, 1] = 65535; u[1, 0] = 65535            # [j - 1, i - 1]
+    row1 = [(int(v), 16) for v in u[0, :]]; col1 = [(int(v), 16) for v in u[1:, 0]]
+    tile1 = [(17, 5)] + [(t, 18) for t in (0x20002, 0xFFFF, 0, 0xFFFF, 0, 0, 0, 0, 0)]
+    fields = [(5, 3)] + row1 + col1 + tile1 + [(0, 5)] * 24
+    nbits = sum(w for _, w in fields)                        # 3 + 31 * 16 + 5 + 9 * 18 + 24 * 5 = 786
+    assert nbits == 786
+    return u.reshape(-1), [ARMN_HEADER_PG] + _bits(fields), 1 + 4 * (1 + (nbits + 31) // 32)
+
+
+def armn_minimum_15x5():
+    """MINIMUM (packTokensMinimum, c_zfstlib.c:469-588; taken because nj < 16, :132): tiles of 5 x 5 from (1, 1), a 4-bit width per tile.
+       ni = 15, nj = 5: three tiles side by side.
+       tile 1 (i = 1..5): values 0 everywhere but one 40000: max - min = 40000 >= 256 -> 8 + fastlog[40000 >> 8 = 156] = 8 + (int)(1 + log2(156.5) = 8.29) = 16 -> 15
+               (the escape): width 15, then the 25 values RAW in 16 bits each, no minimum;
+       tile 2 (i = 6..10): constant 0x1234: width 0, then the minimum in nbits = 16 bits;
+       tile 3 (i = 11..15): 100 everywhere but one 103: max - min = 3 -> fastlog[3] = (int)(1 + log2(3.5) = 2.81) = 2: width 2, the minimum (16 bits), 25 x 2 bits."""
+    u = np.zeros((5, 15), np.uint16)
+    u[:, 0:5] = 0; u[2, 3] = 40000
+    u[:, 5:10] = 0x1234
+    u[:, 10:15] = 100; u[4, 14] = 103
+    t1 = [(15, 4)] + [(int(u[n, m]), 16) for n in range(5) for m in range(0, 5)]
+    t2 = [(0, 4), (0x1234, 16)]
+    t3 = [(2, 4), (100, 16)] + [(int(u[n, m]) - 100, 2) for n in range(5) for m in range(10, 15)]
+    fields = t1 + t2 + t3
+    nbits = sum(w for _, w in fields)                        # 404 + 20 + 70 = 494
+    assert nbits == 494
+    return u.reshape(-1), [ARMN_HEADER_MIN] + _bits(fields), 1 + 4 * (1 + (nbits + 31) // 32)
+
+
+def armn32_step_16x16(with_mantissa):
+    """c_armn_compress32 (armn_compress_32.c:59-275) of a 16 x 16 REAL field, znbits = 32 (23 mantissa bits kept): 1.0 on the first row and column,
+       2.0 elsewhere (and 3.0 at (2, 2) when with_mantissa).  All positive -> no sign stream (code 0x00); exponents 127 / 128: exp_base 127, range 1 ->
+       nbits_needed = ((float)1 exponent field 127) - 126 = 1, code 0x08.
+       word 0: PARALLELOGRAM32 (5) | degree 1 << 4 | step 3 << 7 | nbits 23 << 10 | levels 1 << 15 | version 2 << 18 = 0x0008DD95 (:96-101, zfstlib.h:49)
+       word 1: exp_base << 16 | nbits_needed << 8 | codes = 0x007F0108 (:252-256)
+       word 2: the exponent plane's byte count rounded up to 4 (:196-199); then the plane (packTokensParallelogram_8, :642-750): width container 4 in istep = 3
+               bits, row 1 (16 x 1 bit, zeros), column 1 (15 x 1 bit, zeros); d(2,2) = 1 - (0 + 0 - 0) = 1, d(3,2) = 1 - (0 + 1 - 0) = 0, d(2,3) = 0, the rest 0:
+               first tile width fastlog[1] = (int)(1 + log2(1.5)) = 1 in 4 bits, its 9 differences in 2 bits (1, then zeros); 24 tiles of 4-bit zeros: 152 bits ->
+               5 words flushed -> 1 + 4 * 5 = 21 -> 24 bytes (the sixth word is never written: undefined)
+       then the slot in front of the mantissa plane, which receives lng_signe = 0 (sic, :244), and the plane (packTokensParallelogram32, :456-565): container 5 in
+               3 bits, row 1 and column 1 (31 x 23 bits), 25 tiles with 5-bit widths.  Mantissas all zero: 841 bits -> 27 words, first 0xA0000000.
+               with 3.0 at (2, 2): mantissa 0x400000 there: d(2,2) = +X, d(3,2) = -X, d(2,3) = -X, d(3,3) = +X (X = 2^22): width = exponent field of (float)X - 126 =
+               149 - 126 = 23, differences in 24 bits: X, -X & 0xFFFFFF = 0xC00000, 0 | 0xC00000, X, 0 | 0, 0, 0 -> 1057 bits -> 34 words.
+       returns (field, [(first word index, words)...], zlng)"""
+    f = np.full((16, 16), 2.0, np.float32); f[0, :] = 1.0; f[:, 0] = 1.0
+    if with_mantissa:
+        f[1, 1] = 3.0
+    expo = _bits([(4, 3)] + [(0, 1)] * 31 + [(1, 4), (1, 2)] + [(0, 2)] * 8 + [(0, 4)] * 24)
+    assert len(expo) == 5
+    X = 1 << 22
+    m11 = X if with_mantissa else 0
+    mrow1 = [(0, 23)] * 16; mcol1 = [(0, 23)] * 15
+    tile1 = ([(23, 5)] + [(t, 24) for t in (X, 0xC00000, 0, 0xC00000, X, 0, 0, 0, 0)]) if with_mantissa else [(0, 5)]
+    mfields = [(5, 3)] + mrow1 + mcol1 + tile1 + [(0, 5)] * 24
+    mbits = sum(w for _, w in mfields)
+    assert mbits == (1057 if with_mantissa else 841) and m11 in (0, X)
+    mant = _bits(mfields)
+    nm = (mbits + 31) // 32                                  # words flushed by the terminator
+    lng_m = 1 + 4 * nm; lng_m += (4 - lng_m % 4) % 4
+    pieces = [(0, [0x0008DD95, 0x007F0108, 24]), (3, expo), (9, [0]), (10, mant[:nm])]
+    return f.reshape(-1), pieces, 40 + lng_m
 
 
 def check_pack_vector(name, v, cf_pack, ci_pack, fp_pack):
@@ -206,3 +285,21 @@ def test_armn_known_answers_oracle():
     z = np.zeros(16 * 16 + 64, np.uint32)
     assert O.orc_armn_encode(z.ctypes.data, tok.ctypes.data, 16, 16, 16) == zlng
     assert [int(x) for x in z[:len(words)]] == words
+    tok, words, zlng = armn_wide_difference_16x16()
+    z = np.zeros(16 * 16 + 64, np.uint32)
+    assert O.orc_armn_encode(z.ctypes.data, tok.ctypes.data, 16, 16, 16) == zlng == 105
+    assert [int(x) for x in z[:len(words)]] == words
+    tok, words, zlng = armn_minimum_15x5()
+    z = np.zeros(15 * 5 + 64, np.uint32)
+    assert O.orc_armn_encode(z.ctypes.data, tok.ctypes.data, 15, 5, 16) == zlng == 69
+    assert [int(x) for x in z[:len(words)]] == words
+
+
+@pytest.mark.parametrize("with_mantissa", [False, True])
+def test_armn32_known_answers_oracle(with_mantissa):
+    import test_oracle_armn32 as ta32
+    f, pieces, zlng = armn32_step_16x16(with_mantissa)
+    z = np.zeros(16 * 16 * 2 + 64, np.uint32)
+    assert ta32.O().orc_armn_compress32(z.ctypes.data, f.ctypes.data, 16, 16, 1, 32) == zlng == (180 if with_mantissa else 152)
+    for w0, words in pieces:
+        assert [int(x) for x in z[w0:w0 + len(words)]] == words, (w0, [hex(int(x)) for x in z[w0:w0 + len(words)]], [hex(x) for x in words])
