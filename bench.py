@@ -156,17 +156,23 @@ def extras(ez, torch, stream, d_out, d_in):
     import ezcases as ec
     ex = {}
     try:
-        def ev_time(fn, reps):
-            for _ in range(3):
+        def ev_time(fn, reps, bursts=5):
+            """median over `bursts` bursts of `reps` back-to-back calls (HIP events on the launch stream); ten untimed calls first.  One burst now and then
+            runs 15 - 20 % long on a fresh box (clocks): the median of five does not move with it"""
+            for _ in range(10):
                 fn()
             torch.cuda.synchronize()
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(reps):
-                fn()
-            e1.record(stream); torch.cuda.synchronize()
-            return e0.elapsed_time(e1) * 1e3 / reps
+            ts = []
+            for _ in range(bursts):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(reps):
+                    fn()
+                e1.record(stream); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3 / reps)
+            return sorted(ts)[len(ts) // 2]
         ex["single_field_launch_us"] = ev_time(lambda: ez.ezsint_dev(d_out[0], d_in[0]), 40)
+        ex["single_field_launch_note"] = "median of 5 bursts of 40 back-to-back c_ezsint_dev calls, HIP events"
         zin_h = np.ascontiguousarray(d_in[0].cpu().numpy()); zout_h = np.zeros(NPTS_OUT, np.float32)     # pageable, touched
         cez = ez._lib().c_ezsint
         cez(zout_h.ctypes.data, zin_h.ctypes.data)
@@ -202,9 +208,10 @@ def extras(ez, torch, stream, d_out, d_in):
                             "algorithmic_GBps": algo3 / us / 1e3,
                             "roofline": {"bound": "hbm", "achieved": algo3 / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": algo3 / us / 1e3 / HBM_PEAK_GBPS,
                                          "traffic": t3[0] * 1e6 if t3 else None, "traffic_source": t3[1] if t3 else None,
-                                         "kernel": "k_pts2_irgd3w (+ k_pts_special2, k_polar_wind beside it)", "algorithmic_bytes_per_launch": algo3,
-                                         "note": "x, y of the rotated source (64 MB) and the per-point wind rotation (a, b: 64 MB; 128 as four coefficients until the end of round 3) are read next to the 26 MB of sources: "
-                                                 "the kernel is bound by the vector L1's 64 B/clk (TA busy 68 %), not by HBM"}}
+                                         "kernel": "k_uvt<32, 32> (stencil windows staged in LDS; the first call of a grid set: k_pts2_irgd3w) + k_pts_special2c behind it", "algorithmic_bytes_per_launch": algo3,
+                                         "note": "x, y of the rotated source and the per-point wind rotation (a, b) -- 16 bytes per target point, read from the set's tile-ordered copy -- and the 64 MB of results "
+                                                 "stream next to the staged source windows; the kernel's phases (streams 42 us, staging 9, REAL*8 arithmetic 20, handed-back tiles 5) do not overlap: "
+                                                 "profiles/r04_experiments.txt"}}
         del d_u, d_v, o_u, o_v
         # the step after the horizontal one: vertical interpolation of device-resident profiles, search + linear + lapse-rate in one pass
         from librmn_amd import interpv as V
@@ -604,6 +611,20 @@ def main():
                      "cfg5_frac_of_hbm_peak": (4.0 * NI_S * NJ_S + zl_mean) / (pipe_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                      "cfg5_traffic_MB_per_field": tr5[0] if tr5 else None, "cfg5_traffic_source": tr5[1] if tr5 else None,
                      "cfg5_stages": "extrema from bounds of the source windows (k_bb_*: no interpolation) + header + k_sepx tokens + one-pass armn encoder",
+                     # what bounds them.  compact_float: two passes (extrema, tokens) = 4 + 4 + 2 bytes of traffic per value for 6 algorithmic; measured against HBM.
+                     "roofline_compact_float": {"bound": "hbm", "achieved": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                                "traffic": 10.0 * NPTS_OUT, "traffic_source": "profiles/r03_pmc_traffic.json (two reads + one write of the field: 10 B per value)",
+                                                "traffic_GBps": 10.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9,
+                                                "kernel": "k_stats + k_cf_header + k_cf_pack16", "algorithmic_bytes_per_launch": 6.0 * NPTS_OUT,
+                                                "note": "the traffic moves at ~93 % of the 6.29 TB/s a copy reaches; a one-launch form (two variants) ends at the same time: profiles/r04_experiments.txt"},
+                     # the cfg5 pipeline is bound by instruction ISSUE, not by bytes: its two big kernels retire ~2.0e7 VALU wave-instructions per field
+                     # (k_sepx<3,16,3>: 1659 per wave x 3604 waves; k_armn_enc1: 979 x 14 424: SQ_INSTS_VALU, profiles/r03_experiments.txt) at 4.7 clk each per SIMD
+                     "roofline_cfg5": {"bound": "issue", "achieved": 2.01e7 / (pipe_us * 1e-6) / 1e9, "peak": 1024 * 2.4 / 4.7, "unit": "G VALU wave-instructions/s",
+                                       "frac": 2.01e7 / (pipe_us * 1e-6) / 1e9 / (1024 * 2.4 / 4.7),
+                                       "hbm_frac_of_algorithmic_bytes": (4.0 * NI_S * NJ_S + zl_mean) / (pipe_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                       "kernel": "k_bb_* (extrema from bounds) + k_sepx<3, 16, 3> (tokens) + k_armn_enc1 (one-pass encoder)",
+                                       "note": "peak = 1024 SIMDs x 2.4 GHz / 4.7 clk per wave64 VALU instruction (tools/irate.hip); of the encoder's 41 us per field 13.5 are its memory side, "
+                                               "of the token pass's 26.5 us 2.5 are its stores (kernel-level knock-outs, profiles/r04_experiments.txt)"},
                      "zlng_bytes": int(zl[0]),
                      "compression_ratio": float(zl[0]) / (2.0 * NPTS_OUT), "unit": "GB/s of float input"},
         }
