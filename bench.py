@@ -139,7 +139,7 @@ def check_outputs(ez, torch, d_out, d_in, check_f):
 def profile_traffic(key):
     """(value, file) of a per-unit HBM / fabric traffic figure measured by the PMC passes of tools/prof_round.sh and kept under profiles/ (FETCH_SIZE x 2 on
     gfx950 + WRITE_SIZE: MI355X_MICROARCH.md) -- PMC counters need their own rocprofv3 runs, this run does not collect them"""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 v = json.load(fh).get(key)

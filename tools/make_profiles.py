@@ -75,8 +75,8 @@ BB = [per_field(k) for k in ("k_bb_bounds", "k_bb_select", "k_bb_eval", "k_bb_sp
 if all(BB):
     A = {"grid": "+".join(x["grid"] for x in BB), "read_MB": round(sum(x["read_MB"] for x in BB), 2), "write_MB": round(sum(x["write_MB"] for x in BB), 2),
          "parts": dict(zip(("k_bb_bounds", "k_bb_select", "k_bb_eval", "k_bb_special"), BB))}
-P3 = per_field("k_pts2_irgd3w", nfields=1) or per_field("k_pts2", nfields=1)
-S3 = per_field("k_pts_special2", nfields=1); W3 = per_field("k_polar_wind", nfields=1)
+P3 = per_field("k_uvt", nfields=1) or per_field("k_pts2_irgd3w", nfields=1) or per_field("k_pts2", nfields=1)      # round 4: k_uvt from the second call of a grid set on
+S3 = per_field("k_pts_special2c", nfields=1) or per_field("k_pts_special2", nfields=1); W3 = per_field("k_polar_wind", nfields=1)
 zl = bench["pack"]["zlng_bytes"]
 out = {
     "workload": "python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 under rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, tools/prof_round.sh); "
@@ -100,13 +100,14 @@ if A and B and E:
     out["cfg5_notes"] = ("floor of this structure: 2 x 38.7 (source read twice: bounds, tokens) + 51.9 + 51.9 (tokens out and in) + 25.4 (stream) = 206.6 MB = 3.22 x; "
                          "measured above it: halo rows of the source and of the token rows")
 if P3:
-    parts = {"k_pts2": P3, "k_pts_special2": S3, "k_polar_wind": W3}
+    parts = {"k_uvt (k_pts2 before round 4)": P3, "k_pts_special2c": S3, "k_polar_wind": W3}
     tot3 = sum(x["read_MB"] + x["write_MB"] for x in parts.values() if x)
     out["cfg3_kernels_MB_per_pair"] = parts
     out["cfg3_traffic_MB_per_pair"] = round(tot3, 1)
     out["cfg3_algorithmic_MB_per_pair"] = 90.21
     out["cfg3_traffic_over_algorithmic"] = round(tot3 / 90.21, 2)
-    out["cfg3_notes"] = "x, y of the located points (64 MB) and the per-point wind rotations (a, b: 64 MB) are inputs of every call next to the 26 MB of sources and 64 MB of results"
+    out["cfg3_notes"] = ("x, y of the located points and the per-point wind rotations (a, b) -- 128 MB, read from the set's tile-ordered copy -- are inputs of every call next to "
+                         "the staged source windows (~0.94 cells of 8 bytes per point) and 64 MB of results")
 json.dump(out, open(os.path.join(dst, f"{prefix}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 print(f"timed launches: mean {mean_us:.2f} us, frac {alg / mean_us / 1e3 / 8000:.4f}; bench line {bench['roofline']['avg_launch_us']:.2f} us / {bench['roofline']['frac']:.4f}")
