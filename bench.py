@@ -244,12 +244,12 @@ def extras(ez, torch, stream, d_out, d_in):
         zmean = float(np.mean([z for z in zl_ if z > 0]))
         ex["armn_uncompress"] = {"workload": "armn_compress UNCOMPRESS of 7200 x 3601 16-bit records in HBM (ratio %.2f)" % (zmean / (2.0 * n)),
                                  "single_stream_ms": one_ms, "batch_of_16_ms_per_field": batch16_ms / 16, "batch_of_32_ms_per_field": batch_ms / Fd,
-                                 "note": "the chain of tile headers between row ends is resolved in parallel since the end of round 3 (canonical chain from merged eight-window blocks, the row ends as a recurrence on the tile-index shift: DESIGN 9 item 4); the serial chain kernel (one CU per stream) only for streams that form gives up on",
+                                 "note": "the chain of tile headers between row ends is resolved in parallel since the end of round 3 (canonical chain from merged eight-window blocks, the row ends as a recurrence on the tile-index shift: DESIGN_LOG.md 9 item 4); the serial chain kernel (one CU per stream) only for streams that form gives up on",
                                  "single_stream_GBps": (zmean + 2.0 * n) / (one_ms * 1e-3) / 1e9, "single_stream_frac_of_hbm_peak": (zmean + 2.0 * n) / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                  "batch_GBps": (zmean + 2.0 * n) * Fd / (batch_ms * 1e-3) / 1e9, "batch_frac_of_hbm_peak": (zmean + 2.0 * n) * Fd / (batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         del recs, toks
         # the IEEE-32 compressor's read side (datyp 133): c_armn_uncompress32 through the API, host stream in, host field out (its tile chains are walked on
-        # the host: the device walk is built and measured slower)
+        # the host: the device walk is built and measured slower, DESIGN_LOG.md 9 item 4)
         import ezcases as _ec
         f32 = _ec.synth_field(NI_D, NJ_D, seed=5)
         zl32, z32 = pk.armn_compress32(f32, NI_D, NJ_D, 32)
@@ -634,7 +634,7 @@ def main():
             sf = out["extras"].get("single_field_launch_us")
             if sf:      # north_star words its 60 % target on "a field": the lone-field launch next to the batch launch
                 out["roofline_single_field"] = {"bound": "hbm", "note": "one field per launch: the fill and drain of one launch's staging / compute / store pipeline (~4 us) is paid per field; "
-                                                        "a batch launch pays it once per batch (the headline).  The floor of the one-launch-per-field form (DESIGN 9)",
+                                                        "a batch launch pays it once per batch (the headline).  The floor of the one-launch-per-field form (DESIGN_LOG.md 9)",
                                                 "achieved": ALGO_BYTES / (sf * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                                 "frac": ALGO_BYTES / (sf * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                                                 "kernel": "k_sepx<3, 16> (one field per launch, launches back to back)", "avg_launch_us": sf,

@@ -18,7 +18,7 @@
  *   k_wind_rotate   c_gdwdfuv + c_gduvfwd fused (ez_llwfgdw.inc, ez_gdwfllw.inc, ez_llwfgfw.c).
  *   k_polevals / k_minmax / k_fill   small reductions (ez_calcpoleval.inc, ez_aminmax.inc).
  *
- * No MFMA: there is no dense contraction on this path; the bound is HBM (DESIGN.md section 5).
+ * No MFMA: there is no dense contraction on this path; the bound is HBM (DESIGN.md section 4).
  * Wavefront = 64 lanes throughout.
  */
 #include <hip/hip_runtime.h>

@@ -551,7 +551,7 @@ __device__ __forceinline__ size_t out_slot(size_t k, int swap) { return swap ? (
 
 
 /* ============================================================================================================================================
- * The chain between row ends resolved in parallel (round 3, opt-in: EZHIP_DEC_SCAN=1; DESIGN 9 item 4, tools/probe_merge.py).
+ * The chain between row ends resolved in parallel (round 3, opt-in: EZHIP_DEC_SCAN=1; DESIGN_LOG.md 9 item 4, tools/probe_merge.py).
  * The walks of eight composed windows leave ONE exit for (nearly) all entries: the entry of an eight-window block follows from the block before it alone.  So
  * the CANONICAL chain -- the one from the first tile that never meets a row end -- is written down for all blocks at once (k_dsc_m8, k_dsc_blocks, k_dsc_scan,
  * k_armn_dec_expand8, k_dsc_emit: the position of every canonical tile).  The real chain leaves it at the odd tile that ends a row of tiles and rejoins it

@@ -1245,7 +1245,7 @@ def test_hemispheric_gaussian_sources_vs_oracle(name):
             assert rc == rc_o
             assert np.array_equal(z.view(np.uint32), want.view(np.uint32)), (name, degree, polar, int(np.count_nonzero(z != want)))
     uu, vv = ec.synth_wind(ni, nj, seed=2)
-    assert ez.ezuvint(uu, vv, no * mo)[0] == -1            # winds from a hemisphere: undefined in the reference (DESIGN section 7), refused
+    assert ez.ezuvint(uu, vv, no * mo)[0] == -1            # winds from a hemisphere: undefined in the reference (DESIGN.md section 8), refused
 
 
 AVG_GPU_CASES = dict(tovr.AVG_CASES)

@@ -20,7 +20,7 @@ def test_random_grid_pairs_against_the_reference_build(tool, ncases, seed):
     env = dict(os.environ)
     if tool.endswith(" hemi"): tool = tool.split()[0]; env["FUZZ_HEMI"] = "1"          # + hemispheric / y-inverted A B G on either side
     # The reference build corrupts its own heap now and then in a long session ("double free or corruption", "malloc(): corrupted top size", with no
-    # product call on the stack -- tools/fuzz_vs_ref4.py): a run that a SIGNAL ended before any mismatch was printed proves nothing about
+    # product call on the stack -- tools/fuzz_vs_ref4.py, DESIGN_LOG.md 2): a run that a SIGNAL ended before any mismatch was printed proves nothing about
     # parity.  Whose crash it was is settled by running the SAME seed again with the reference's entry points replaced by no-ops (FUZZ_PRODUCT_ONLY,
     # tests/reflib.py): the product then makes exactly the same calls alone.  If that run dies too, the product crashed: the test fails at once.  If it
     # survives, the death was the reference's: the comparison is repeated with another seed; three such deaths in a row fail the test.

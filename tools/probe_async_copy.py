@@ -1,5 +1,5 @@
 """Does hipMemcpyAsync on PAGEABLE host memory return before the copy is done, and do an H2D and a D2H on two streams overlap?
-Development probe for the host-pointer ABI."""
+Development probe for the host-pointer ABI (DESIGN_LOG.md section 5)."""
 import ctypes, time, sys
 import numpy as np
 sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))

@@ -1,4 +1,4 @@
-"""How fast do the speculative walks of a window merge?  (CPU, oracle stream; the measurement behind DESIGN 9 item 4's plan.)
+"""How fast do the speculative walks of a window merge?  (CPU, oracle stream; the measurement behind DESIGN_LOG.md 9 item 4's plan.)
 For windows of DW bits of a PARALLELOGRAM stream: the walk from every entry offset e < ext under the interior point count; per window the number of
 distinct exits, and the same for the composition of 8 windows.  python tools/probe_merge.py [noise] [ni nj]"""
 import sys, os
