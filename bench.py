@@ -247,6 +247,26 @@ def extras(ez, torch, stream, d_out, d_in):
                                  "note": "the chain of tile headers between row ends is resolved in parallel since the end of round 3 (canonical chain from merged eight-window blocks, the row ends as a recurrence on the tile-index shift: DESIGN_LOG.md 9 item 4); the serial chain kernel (one CU per stream) only for streams that form gives up on",
                                  "single_stream_GBps": (zmean + 2.0 * n) / (one_ms * 1e-3) / 1e9, "single_stream_frac_of_hbm_peak": (zmean + 2.0 * n) / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                  "batch_GBps": (zmean + 2.0 * n) * Fd / (batch_ms * 1e-3) / 1e9, "batch_frac_of_hbm_peak": (zmean + 2.0 * n) * Fd / (batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        # the same field as a MINIMUM stream (c_armn_compress_setlevel(FAST)): since round 4 its chain of tile headers is resolved by composition of the windows' maps
+        # (k_dmin_*: rows of whole 5 x 5 tiles) instead of the serial chain kernel
+        try:
+            pk.armn_setlevel(0)
+            d_zm = torch.zeros(n // 2 + 64, dtype=torch.int32, device="cuda")
+            zlm = pk.armn_compress_dev(d_zm, toks[0], NI_D, NJ_D, 16)
+            pk.armn_setlevel(1)
+            if zlm > 0:
+                zwm = (zlm - 1) // 4 + 1
+                tk = torch.zeros(1 + n // 2, dtype=torch.int32, device="cuda")
+                best = 1e9
+                for _ in range(4):
+                    torch.cuda.synchronize(); t0_ = time.perf_counter()
+                    rcm = pk.armn_uncompress_dev(tk, d_zm, zwm, NI_D, NJ_D, 16)
+                    torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0_)
+                ex["armn_uncompress_minimum"] = {"workload": "armn_compress UNCOMPRESS of a 7200 x 3601 MINIMUM stream (level FAST, ratio %.2f) in HBM" % (zlm / (2.0 * n)),
+                                                 "single_stream_ms": best * 1e3, "tokens_equal": bool(rcm == 2 * n and torch.equal(tk[:n // 2], toks[0][:n // 2])),
+                                                 "note": "the serial chain kernel took 16 ms (rounds 1 - 3)"}
+        finally:
+            pk.armn_setlevel(1)
         del recs, toks
         # the IEEE-32 compressor's read side (datyp 133): c_armn_uncompress32 through the API, host stream in, host field out (its tile chains are walked on
         # the host: the device walk is built and measured slower, DESIGN_LOG.md 9 item 4)

@@ -42,6 +42,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "packhip_shim.h"
 
 extern "C" void *ezhip_get_stream(void);
@@ -927,6 +928,156 @@ __global__ __launch_bounds__(64) void k_dsc_lastrow(const unsigned *z_all, size_
     status[f] = 0;
 }
 
+/* ============================================================================================================================================
+ * MINIMUM streams (packTokensMinimum, c_zfstlib.c:469-588): the chain of tile headers by COMPOSITION (round 4).
+ * A MINIMUM tile is 4 + nbits (+ 25 x nb) bits: walks from different entries of a window do not merge (all tile lengths are multiples of 5 bits away from each
+ * other: five residue classes that never meet), so the parallel form above (k_dsc_*: one exit per eight-window block) gives up on these streams and they went
+ * through the serial chain kernel: 16 ms per 7200 x 3601 stream.  But when every tile of a row holds the same number of points (ni a multiple of 5) the chain up
+ * to the last row of tiles is a PURE function of the bit position, and functions compose: the speculation table of a window IS its map entry -> (exit, tiles);
+ * the maps of 8, 64, 512 ... windows follow level by level (k_dmin_up: one thread per (block, entry), eight lookups), the true entry of every block from the top
+ * down (k_dmin_down: one thread per block, eight lookups), down to the windows: went[w] = (entry, first tile) for ALL windows after ~6 + 6 short launches
+ * instead of 10^5 dependent steps on one CU.  The last row of tiles (another height: another tile length) is walked tile by tile from LDS by one workgroup
+ * (k_dmin_lastrow); k_armn_dec_emit then writes the position of every tile as before.
+ * Fields the form does not apply to (PARALLELOGRAM streams, a ragged last column of tiles, streams of a few windows) keep their old routes; dm[DM_NOTMINE] says
+ * which. ============================================================================================================================================ */
+enum { DM_NOTMINE = 0, DM_TOPLEV, DM_WORDS = 8 };
+#define DM_MAXLEV 9
+struct DmPlan { int nlev; unsigned nblk[DM_MAXLEV + 1]; unsigned long long off[DM_MAXLEV + 1]; unsigned long long eoff[DM_MAXLEV + 1]; };      /* level l: blocks of 8^l windows; level 0 = windows */
+__device__ __forceinline__ bool dmin_eligible(const DecGeom &g, int nwin, int plain) { return !plain && g.method == 3 && g.mlast == g.istep && g.nty >= 2 && nwin >= 64; }
+__global__ void k_dmin_init(const unsigned *z_all, size_t z_stride, int ni, int nj, unsigned *dm_all, size_t dm_stride, const unsigned *dst_all, size_t dst_stride, int nwin, int plain)
+{
+    const int f = blockIdx.x;
+    if (threadIdx.x) return;
+    unsigned *dm = dm_all + (size_t)f * dm_stride;
+    DecGeom g;
+    const bool ok = dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, plain) && dmin_eligible(g, nwin, plain) && !(dst_all && dst_all[(size_t)f * dst_stride + DSC_OK]);
+    dm[DM_NOTMINE] = ok ? 0u : 1u;
+}
+/* level l + 1 from level l: T[l + 1][b][e] = the walk from entry e through blocks 8 b .. 8 b + 7 of level l: (exit, tiles).  Level 0 is the speculation table
+ * (exit | tiles << 16 in one word), the levels above hold uint2 */
+__global__ __launch_bounds__(256) void k_dmin_up(const unsigned *z_all, size_t z_stride, int ni, int nj, const unsigned *dm_all, size_t dm_stride,
+                                                 const unsigned *tab_all, size_t tab_stride, uint2 *lev_all, size_t lev_stride, DmPlan pl, int l, int ext /* row stride of the tables */)
+{
+    const int f = blockIdx.y;
+    if (dm_all[(size_t)f * dm_stride + DM_NOTMINE]) return;
+    const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned b = (unsigned)(idx / (unsigned)ext), e0 = (unsigned)(idx % (unsigned)ext);
+    if (b >= pl.nblk[l + 1]) return;
+    DecGeom g;
+    if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, 0) || e0 >= (unsigned)g.ext) return;      /* (entries beyond the longest tile do not occur) */
+    uint2 *lev = lev_all + (size_t)f * lev_stride;
+    unsigned e = e0, cnt = 0;
+    if (l == 0) {
+        const unsigned *tab = tab_all + (size_t)f * tab_stride;
+        for (unsigned c = 8 * b; c < 8 * b + 8 && c < pl.nblk[0]; c++) { const unsigned v = tab[(size_t)c * DEXT + e]; cnt += v >> 16; e = v & 0xFFFFu; }
+    } else {
+        const uint2 *in = lev + pl.off[l];
+        for (unsigned c = 8 * b; c < 8 * b + 8 && c < pl.nblk[l]; c++) { const uint2 v = in[(size_t)c * (unsigned)ext + e]; cnt += v.y; e = v.x; }
+    }
+    lev[pl.off[l + 1] + (size_t)b * (unsigned)ext + e0] = make_uint2(e, cnt);
+}
+/* the entries of the top level's (<= 8) blocks, one lane */
+__global__ void k_dmin_top(const unsigned *z_all, size_t z_stride, int ni, int nj, const unsigned *dm_all, size_t dm_stride, uint2 *lev_all, size_t lev_stride, DmPlan pl, int ext)
+{
+    const int f = blockIdx.x;
+    if (threadIdx.x || dm_all[(size_t)f * dm_stride + DM_NOTMINE]) return;
+    DecGeom g;
+    if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, 0)) return;
+    uint2 *lev = lev_all + (size_t)f * lev_stride;
+    const int L = pl.nlev;
+    unsigned e = g.body, t = 0;                                      /* MINIMUM: the first header is the first bit of z[1] */
+    for (unsigned b = 0; b < pl.nblk[L]; b++) {
+        lev[pl.eoff[L] + b] = make_uint2(e, t);
+        const uint2 v = lev[pl.off[L] + (size_t)b * (unsigned)ext + e];
+        e = v.x; t += v.y;
+    }
+}
+/* entries of level l from those of level l + 1; at level 0 they are the windows' (went) */
+__global__ __launch_bounds__(256) void k_dmin_down(const unsigned *dm_all, size_t dm_stride, const unsigned *tab_all, size_t tab_stride, uint2 *lev_all, size_t lev_stride,
+                                                   unsigned *went_all, size_t went_stride, DmPlan pl, int l, int ext)
+{
+    const int f = blockIdx.y;
+    if (dm_all[(size_t)f * dm_stride + DM_NOTMINE]) return;
+    const unsigned b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= pl.nblk[l + 1]) return;
+    uint2 *lev = lev_all + (size_t)f * lev_stride;
+    const uint2 en = lev[pl.eoff[l + 1] + b];
+    unsigned e = en.x, t = en.y;
+    if (l == 0) {
+        const unsigned *tab = tab_all + (size_t)f * tab_stride;
+        unsigned *went = went_all + (size_t)f * went_stride;
+        for (unsigned c = 8 * b; c < 8 * b + 8 && c < pl.nblk[0]; c++) {
+            went[2 * (size_t)c] = e; went[2 * (size_t)c + 1] = t;
+            const unsigned v = tab[(size_t)c * DEXT + e]; t += v >> 16; e = v & 0xFFFFu;
+        }
+    } else {
+        const uint2 *in = lev + pl.off[l];
+        for (unsigned c = 8 * b; c < 8 * b + 8 && c < pl.nblk[l]; c++) {
+            lev[pl.eoff[l] + c] = make_uint2(e, t);
+            const uint2 v = in[(size_t)c * (unsigned)ext + e]; t += v.y; e = v.x;
+        }
+    }
+}
+/* the last row of tiles (hlast != istep: another point count, another tile length) and the end of the chain.  One workgroup per field: finds the window in which
+ * the regular chain reaches tile T = (nty - 1) ntx, walks to it, then walks the ntx tiles of the last row from LDS (chunks of DM_LR_WORDS words); every window
+ * behind that one is taken out of went (the regular chain means nothing there).  status: -2 when the chain leaves the stream. */
+#define DM_LR_WORDS 12288
+__global__ __launch_bounds__(256) void k_dmin_lastrow(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, const unsigned *dm_all, size_t dm_stride,
+                                                      unsigned *went_all, size_t went_stride, unsigned *tilepos_all, size_t tp_stride, int nwin, int *status, unsigned *dst_all, size_t dst_stride)
+{
+    __shared__ unsigned lr[DM_LR_WORDS + 2];
+    __shared__ unsigned s_pos, s_t, s_wstar, s_bad;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    if (dm_all[(size_t)f * dm_stride + DM_NOTMINE]) return;
+    const unsigned *z = z_all + (size_t)f * z_stride;
+    DecGeom g;
+    if (!dec_geom(g, z, ni, nj, 0)) return;
+    const size_t nwords = z_words - 1;
+    unsigned *went = went_all + (size_t)f * went_stride, *tilepos = tilepos_all + (size_t)f * tp_stride;
+    const unsigned ntiles = (unsigned)g.ntiles;
+    const unsigned Treg = g.hlast != g.istep ? (unsigned)(g.nty - 1) * (unsigned)g.ntx : ntiles;       /* tiles of the regular chain */
+    if (tid == 0) {
+        /* the last window whose first tile is <= Treg (first tiles are non-decreasing) */
+        int lo = 0, hi = nwin - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (went[2 * (size_t)mid + 1] <= Treg) lo = mid; else hi = mid - 1; }
+        unsigned pos = (unsigned)lo * DW + went[2 * (size_t)lo], t = went[2 * (size_t)lo + 1];
+        unsigned bad = 0;
+        while (t < Treg) {                                            /* <= the tiles of one window */
+            if ((size_t)(pos >> 5) >= nwords) { bad = 1; break; }
+            pos += (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.n_int); t++;
+        }
+        s_wstar = (unsigned)lo; s_pos = pos; s_t = t; s_bad = bad;
+    }
+    __syncthreads();
+    for (int w = (int)s_wstar + 1 + tid; w < nwin; w += 256) went[2 * (size_t)w] = 0xFFFFFFFFu;
+    if (g.hlast != g.istep && !s_bad) {
+        const int nlast = g.istep * g.hlast;
+        while (s_t < ntiles && !s_bad) {
+            const unsigned base_w = s_pos >> 5;                       /* chunk of the stream in LDS */
+            __syncthreads();
+            for (int k = tid; k < DM_LR_WORDS + 2; k += 256) lr[k] = gword(z + 1, (size_t)base_w + k, nwords);
+            __syncthreads();
+            if (tid == 0) {
+                unsigned pos = s_pos, t = s_t;
+                const unsigned lim = (base_w + DM_LR_WORDS) * 32u - (unsigned)g.ext - 32u;      /* a whole tile (and its header's two words) inside the chunk */
+                while (t < ntiles && pos < lim) {
+                    tilepos[t] = pos;
+                    pos += (unsigned)dec_step(g, getbits(lr, pos - base_w * 32u, g.C), nlast); t++;
+                }
+                if (pos == s_pos) s_bad = 1;                          /* (cannot happen: ext + 32 bits < the chunk) */
+                s_pos = pos; s_t = t;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        /* the chain must end inside the stream: the terminator (two 16-bit zero tokens) follows the last tile */
+        const bool broken = s_bad || (size_t)(s_pos >> 5) > nwords;
+        if (status) status[f] = broken ? -2 : 0;
+        if (!broken && dst_all) dst_all[(size_t)f * dst_stride + DSC_OK] = 1u;      /* the serial chain kernel and its followers skip this field */
+    }
+}
+
 __global__ __launch_bounds__(256) void k_armn_dec_tiles(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
                                                         const unsigned *tilepos_all, size_t tp_stride,
                                                         unsigned short *d16_all, size_t d_stride,           /* PARALLELOGRAM differences */
@@ -1054,13 +1205,29 @@ __global__ __launch_bounds__(256) void k_armn_dec_cols(const unsigned *z_all, si
 static size_t dec_max_tiles(int ni, int nj) { return ((size_t)(ni + 2) / 3 + 1) * ((size_t)(nj + 2) / 3 + 1); }   /* tile step >= 3 */
 static size_t dec_nwin(size_t z_words) { return (z_words * 32 + DW - 1) / DW + 1; }
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+/* levels of the composition: nblk[0] = windows, nblk[l + 1] = ceil(nblk[l] / 8) down to <= 8 blocks; tables (uint2 [nblk][DEXT]) from level 1, entry arrays beside them */
+static void dmin_plan(DmPlan *pl, size_t nwin)
+{
+    memset(pl, 0, sizeof(*pl));
+    pl->nblk[0] = (unsigned)nwin;
+    int l = 0;
+    while (pl->nblk[l] > 8 && l < DM_MAXLEV) { pl->nblk[l + 1] = (pl->nblk[l] + 7) / 8; l++; }
+    pl->nlev = l;
+    unsigned long long o = 0;
+    for (int k = 1; k <= l; k++) { pl->off[k] = o; o += (unsigned long long)pl->nblk[k] * DEXT; }
+    for (int k = 1; k <= l; k++) { pl->eoff[k] = o; o += ((unsigned long long)pl->nblk[k] + 31) & ~31ull; }
+    pl->off[0] = o;                                             /* (total, in uint2) */
+}
+static size_t dmin_bytes(size_t nwin) { DmPlan pl; dmin_plan(&pl, nwin); return al256(8 * (size_t)pl.off[0]) + 256; }
 extern "C" size_t packhip_armn_dec_work_bytes(int ni, int nj, size_t z_words)
 {
     const size_t n = (size_t)ni * nj, nwin = dec_nwin(z_words);
     const size_t capc = dec_max_tiles(ni, nj) + DSC_MARGIN, nty = (size_t)(nj + 2) / 3 + 2;
     return al256(4 * dec_max_tiles(ni, nj)) + al256(2 * (n + 8)) + al256(2 * (size_t)DEC_BANDS * ni) + 2 * al256(4 * nwin * DEXT) + 2 * al256(8 * nwin) + 256
            /* the parallel form: canonical tile positions, shift changes, merged exits, block entries / counts, canonical window entries, rows, state */
-           + al256(4 * capc) + al256(2 * capc) + al256(2 * nwin) + 2 * al256(4 * (nwin / 8 + 2)) + 2 * al256(8 * nwin) + 4 * al256(4 * nty) + al256(12 * 128 * nty) + 2 * al256(4 * capc) + 256;
+           + al256(4 * capc) + al256(2 * capc) + al256(2 * nwin) + 2 * al256(4 * (nwin / 8 + 2)) + 2 * al256(8 * nwin) + 4 * al256(4 * nty) + al256(12 * 128 * nty) + 2 * al256(4 * capc) + 256
+           /* MINIMUM streams by composition: the tables of 8, 64, ... windows and the blocks' entries (k_dmin_*) */
+           + dmin_bytes(nwin);
 }
 
 /* d_out: (1 + ni*nj/2) words per field, zero-filled first (the odd trailing half-word).  d_status: one int per field
@@ -1130,7 +1297,9 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
     unsigned *rowhead = (unsigned *)wk;                     wk += al256(4 * ntyc);
     int *jA = (int *)wk;                                    wk += al256(4 * capc);
     int *jB = (int *)wk;                                    wk += al256(4 * capc);
-    unsigned *dst = (unsigned *)wk;
+    unsigned *dst = (unsigned *)wk;                         wk += 128;
+    unsigned *dmst = (unsigned *)wk;                        wk += 128;
+    uint2 *dmlev = (uint2 *)wk;
     const char *scan_env = getenv("EZHIP_DEC_SCAN");
     const int scan = scan_env ? atoi(scan_env) : 1;          /* the chain between row ends in parallel (k_dsc_*, the default since the end of round 3); the serial chain
                                                               * kernel runs only for the fields that form gives up on (small fields, streams whose windows do not merge);
@@ -1179,6 +1348,22 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
         hipLaunchKernelGGL(k_dsc_stretch2, dim3((unsigned)((ntyc * DSC_LIST + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, slist, nlist, ws4, ws4, tilepos, ws4, plain);
         hipLaunchKernelGGL(k_dsc_final, dim3((unsigned)((max_tiles + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, tpc, ws4, rowc, rowmerge, ws4, tilepos, ws4, plain);
         hipLaunchKernelGGL(k_dsc_lastrow, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, tpc, ws4, rowc, ws4, tilepos, ws4, d_status, plain);
+        if (!plain && !getenv("EZHIP_DEC_NO_DMIN")) {
+            /* MINIMUM streams whose tiles all hold the same number of points up to the last row: the chain by composition of the windows' maps (k_dmin_*) */
+            DmPlan pl;
+            dmin_plan(&pl, (size_t)nwin);
+            const size_t ws8 = work_stride_bytes / 8;
+            hipLaunchKernelGGL(k_dmin_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dmst, ws4, dst, ws4, nwin, plain);
+            for (int l = 0; l < pl.nlev; l++)
+                hipLaunchKernelGGL(k_dmin_up, dim3((unsigned)(((unsigned long long)pl.nblk[l + 1] * DEXT + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dmst, ws4, tab, ws4, dmlev, ws8, pl, l, DEXT);
+            if (pl.nlev >= 1) {
+                hipLaunchKernelGGL(k_dmin_top, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dmst, ws4, dmlev, ws8, pl, DEXT);
+                for (int l = pl.nlev - 1; l >= 0; l--)
+                    hipLaunchKernelGGL(k_dmin_down, dim3((pl.nblk[l + 1] + 255) / 256, nfields), dim3(256), 0, st, dmst, ws4, tab, ws4, dmlev, ws8, went, ws4, pl, l, DEXT);
+                hipLaunchKernelGGL(k_dmin_lastrow, dim3(nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dmst, ws4, went, ws4, tilepos, ws4, nwin, d_status, dst, ws4);
+                hipLaunchKernelGGL(k_armn_dec_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, went, ws4, tilepos, ws4, nwin, plain, dmst, ws4);
+            }
+        }
         skip = dst;                                          /* dst[DSC_OK] of a field: 1 when its tile positions are complete */
         if (scan == 2) {                                     /* development: the state words of every field */
             unsigned h[DSC_WORDS];

@@ -942,3 +942,66 @@ def test_fst_unpack_damaged_length_word_is_refused(datyp, nbits):
         dmg[4:4 + lng_s] = 0                                      # all-zero sign stream = raw 7-bit groups only: needs 8/7 n bits, more than the sub-stream holds
         rc, _ = pk.fst_unpack_data(dmg, ni, nj, nk, d_out, b_out)
         assert rc == -1
+
+
+DMIN_SHAPES = [(600, 601), (3100, 203), (1000, 777), (5200, 44), (50, 4000), (1280, 640), (355, 1002)]      # ni a multiple of 5: every tile of a row holds 25 points; nj with and without a last row of another height
+
+
+@pytest.mark.parametrize("ni,nj", DMIN_SHAPES)
+@pytest.mark.parametrize("kind", ["smooth", "noisy", "constant", "bigdiff"])
+@pytest.mark.parametrize("nbits", [16, 9, 5])
+def test_armn_uncompress_minimum_streams_by_composition(ni, nj, kind, nbits, monkeypatch):
+    """MINIMUM streams (level FAST) whose rows hold whole tiles: the chain of tile headers by composition of the windows' maps (k_dmin_*, the default) against
+    the serial chain kernel (EZHIP_DEC_NO_DMIN=1) and the oracle's tokens; widths 16 / 9 / 5 bits (tiles of 20 to 404 bits)"""
+    tok = pc.token_field(ni, nj, nbits, kind, seed=ni + 5 * nj + nbits)
+    z, zlng = _oracle_stream(tok, ni, nj, nbits, 0)
+    assert int(z[0] & 15) == 3                                          # MINIMUM
+    zwords = (zlng - 1) // 4 + 1
+    d_z = torch.from_numpy(z[:zwords].view(np.int32).copy()).cuda()
+    words = pc.tokens_to_words(tok)
+    outs = []
+    for no_dmin in (False, True):
+        if no_dmin:
+            monkeypatch.setenv("EZHIP_DEC_NO_DMIN", "1")
+        d_out = torch.full((1 + ni * nj // 2 + 4,), -1, dtype=torch.int32, device="cuda")
+        assert pk.armn_uncompress_dev(d_out, d_z, zwords, ni, nj, nbits) == ni * nj * 2
+        got = d_out.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got[:words.size], words), (no_dmin, np.nonzero(got[:words.size] != words)[0][:5])
+        assert np.all(got[1 + ni * nj // 2:] == 0xFFFFFFFF)
+        outs.append(got)
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_armn_uncompress_minimum_batch_and_damaged(monkeypatch):
+    """a batch of MINIMUM streams through the composed form, one of them cut short: the damaged one is reported (-1), the others decode"""
+    ni, nj, nbits, F = 1000, 303, 16, 5
+    toks = [pc.token_field(ni, nj, nbits, "smooth" if f % 2 else "noisy", seed=50 + f) for f in range(F)]
+    streams = [_oracle_stream(t, ni, nj, nbits, 0) for t in toks]
+    zw = max((zl - 1) // 4 + 1 for _, zl in streams)
+    stride = zw + 64
+    buf = np.zeros((F, stride), np.uint32)
+    for f, (z, zl) in enumerate(streams):
+        buf[f, :(zl - 1) // 4 + 1] = z[:(zl - 1) // 4 + 1]
+    d_z = torch.from_numpy(buf.view(np.int32)).cuda()
+    ostride = 1 + ni * nj // 2
+    d_out = torch.zeros((F, ostride), dtype=torch.int32, device="cuda")
+    assert pk.armn_uncompress_batch_dev(d_out, ostride, d_z, stride, zw, ni, nj, nbits, F) == ni * nj * 2
+    got = d_out.cpu().numpy().view(np.uint32)
+    for f in range(F):
+        w = pc.tokens_to_words(toks[f])
+        assert np.array_equal(got[f, :w.size], w), f
+    # field 2 loses the second half of its stream (zeros): the chain ends long before the last tile's data is there -- values differ, nothing crashes,
+    # both forms agree on what they return
+    dmg = buf.copy(); zl2 = streams[2][1]; dmg[2, ((zl2 - 1) // 4 + 1) // 2:] = 0
+    res = []
+    for no_dmin in (False, True):
+        if no_dmin:
+            monkeypatch.setenv("EZHIP_DEC_NO_DMIN", "1")
+        d_o = torch.zeros((F, ostride), dtype=torch.int32, device="cuda")
+        rc = pk.armn_uncompress_batch_dev(d_o, ostride, torch.from_numpy(dmg.view(np.int32)).cuda(), stride, zw, ni, nj, nbits, F)
+        g = d_o.cpu().numpy().view(np.uint32)
+        for f in (0, 1, 3, 4):
+            w = pc.tokens_to_words(toks[f])
+            assert np.array_equal(g[f, :w.size], w), (no_dmin, f)
+        res.append(rc)
+    assert res[0] == res[1]
