@@ -3050,25 +3050,29 @@ __device__ __forceinline__ void special2c_body(const ezhip_pts_plan &p, float *_
                                                const float *__restrict__ zin1, const float *__restrict__ zin2,
                                                const float *__restrict__ prow_n2, const float *__restrict__ prow_s2, unsigned blk, unsigned nblk)
 {
-    const unsigned cnt = (unsigned)p.cspec_count;
-    for (unsigned k = blk * 256 + threadIdx.x; k < cnt; k += nblk * 256) {
+    /* a LANE PAIR per point: lane 2 k takes the first component, lane 2 k + 1 the second (the few special points of a set are a chain of dependent gathers --
+     * ~12 us of latency per call with both components one after the other on one lane), then they swap results for the wind matrix */
+    const unsigned cnt2 = 2u * (unsigned)p.cspec_count;
+    for (unsigned k2 = blk * 256 + threadIdx.x; k2 < cnt2; k2 += nblk * 256) {
+        const unsigned k = k2 >> 1, comp = k2 & 1u;
         const int n = p.cspec_list[k];
         const float px = p.cspec_x[k], py = p.cspec_y[k];
         const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;
         wm_f2 mlo = {1.f, 0.f}, mhi = {0.f, 1.f};
         if (p.wind_M) wind_m_load(p.wind_M, p.wind_M_half, o, mlo, mhi);       /* on its way while the stencils are gathered */
         const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
-        FieldAcc Z1, Z2;
-        Z1.z = zin1; Z1.ni = p.ni; Z1.j1 = p.j1; Z1.j2 = p.j2; Z1.pole_n = 0.f; Z1.pole_s = 0.f; Z1.prow_n = nullptr; Z1.prow_s = nullptr;
-        Z2 = Z1; Z2.z = zin2;
-        float a, b;
-        if (zone == PZ_REINTERP) { a = gdinterp_point(p, Z1, p.degre_extrap, px, py); b = gdinterp_point(p, Z2, p.degre_extrap, px, py); }
+        FieldAcc Z;
+        Z.z = comp ? zin2 : zin1; Z.ni = p.ni; Z.j1 = p.j1; Z.j2 = p.j2; Z.pole_n = 0.f; Z.pole_s = 0.f; Z.prow_n = nullptr; Z.prow_s = nullptr;
+        float mine;
+        if (zone == PZ_REINTERP) mine = gdinterp_point(p, Z, p.degre_extrap, px, py);
         else {
-            Z1.prow_n = p.pole_row_n; Z1.prow_s = p.pole_row_s; Z2.prow_n = prow_n2; Z2.prow_s = prow_s2;
-            a = strip_point(p, Z1, zone == PZ_STRIP_N, px, py); b = strip_point(p, Z2, zone == PZ_STRIP_N, px, py);
+            Z.prow_n = comp ? prow_n2 : p.pole_row_n; Z.prow_s = comp ? prow_s2 : p.pole_row_s;
+            mine = strip_point(p, Z, zone == PZ_STRIP_N, px, py);
         }
+        const float other = __shfl_xor(mine, 1, 64);                           /* (both lanes of a pair are in the loop together: cnt2 is even, the stride too) */
+        float a = comp ? other : mine, b = comp ? mine : other;
         if (p.wind_M) { const float u = a, v = b; wind_m_apply(mlo, mhi, p.wind_M_half, u, v, p.wind_dst_rot, a, b); }
-        zout1[o] = a; zout2[o] = b;
+        if (comp) zout2[o] = b; else zout1[o] = a;
     }
 }
 __global__ __launch_bounds__(256) void k_pts_special2c(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
@@ -3183,7 +3187,7 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
         if (LAUNCH_CHECK("k_uvt")) return -1;
         if (ezhip_side_join()) return -1;
         if (plan_u->cspec_count > 0 && !(pu2.uvt_debug & 8)) {
-            const unsigned nbk = (unsigned)((plan_u->cspec_count + 255) / 256);
+            const unsigned nbk = (unsigned)((2 * plan_u->cspec_count + 255) / 256);      /* a lane pair per point */
             hipLaunchKernelGGL(k_pts_special2c, dim3(nbk < 256 ? nbk : 256), block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v, plan_v->pole_row_n, plan_v->pole_row_s);
             return LAUNCH_CHECK("k_pts_special2c");
         }
@@ -3200,7 +3204,7 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     if (ezhip_side_join()) return -1;
     if (cached) {
         if (plan_u->cspec_count > 0) {
-            const unsigned nbk = (unsigned)((plan_u->cspec_count + 255) / 256);
+            const unsigned nbk = (unsigned)((2 * plan_u->cspec_count + 255) / 256);      /* a lane pair per point */
             hipLaunchKernelGGL(k_pts_special2c, dim3(nbk < 256 ? nbk : 256), block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v, plan_v->pole_row_n, plan_v->pole_row_s);
             return LAUNCH_CHECK("k_pts_special2c");
         }
