@@ -84,3 +84,20 @@ def test_gpus_2_on_a_one_gpu_box_is_refused():
         pytest.skip("this box has two GPUs")
     p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert p.returncode != 0 and "GPU(s) visible" in p.stderr
+
+
+@pytest.mark.gpu
+def test_rank_body_with_a_real_process_group_of_one():
+    """the N-rank code path of bench.py on the GPU box's one device: RCCL process group (BENCH_FORCE_DIST), barriers around the timed steps, the rank
+    count from an all_reduce, host-fed object, checked outputs -- what the driver's `torch.distributed.run ... bench.py --gpus N` exercises per rank"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = _clean_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_FORCE_DIST="1")
+    p = _run(["--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--host-fed-steps", "2"], env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = _line(p)
+    assert out["n_gpus"] == 1 and out["config"]["launched_by"] == "external launcher" and out["config"]["feed"] == "device"
+    assert out["checked"] is True and out["config"]["develop_build"] is False
+    assert out["roofline"]["bound"] == "hbm" and 0.3 < out["roofline"]["frac"] < 1.0
+    assert out["host_fed"]["steps"] == 2 and out["host_fed"]["value"] < out["value"]
+    assert out["pack"]["roofline_cfg5"]["bound"] == "issue"
