@@ -167,6 +167,10 @@ for k in range(ncases):
         d = np.flatnonzero(z.view(np.uint32) != zr.view(np.uint32)); why = f"scalar bits differ at {d.size} points, first {int(d[0])}: {z[d[0]]!r} vs {zr[d[0]]!r}"
     if not why and winds_on:
         rcv, u, v = ez.ezuvint(uu, vv, no * mo)
+        # round 4: the second call of a grid set may take another kernel (k_uvt: stencil windows staged in LDS, the set's special points from its cache): same bits
+        rcv_b, u_b, v_b = ez.ezuvint(uu, vv, no * mo)
+        if rcv_b != rcv or not np.array_equal(u_b.view(np.uint32), u.view(np.uint32)) or not np.array_equal(v_b.view(np.uint32), v.view(np.uint32)):
+            why = f"winds: the second call of the set differs from the first (rc {rcv} / {rcv_b}, {int((u_b.view(np.uint32) != u.view(np.uint32)).sum())} u and {int((v_b.view(np.uint32) != v.view(np.uint32)).sum())} v values)"
         m = np.isfinite(ur) & np.isfinite(vr)
         mp = np.isfinite(u) & np.isfinite(v)
         sc = np.maximum(np.hypot(ur[m & mp].astype(np.float64), vr[m & mp].astype(np.float64)), 1e-3)
