@@ -85,7 +85,7 @@ typedef struct {
     float *ax, *ay, *ncx, *ncy;            /* host */
     float *d_ax, *d_ay, *d_ncx, *d_ncy;    /* device mirrors */
     float *d_ncx8, *d_ncy8;                /* Newton coefficients laid out [index][8] for the per-point kernel */
-    float *d_xrec12, *d_yrec12;            /* k_uvt: {ax(i-1 .. i+2), c1 .. c6, 0, 0} per column i (index i - 1), the same per row */
+    double *d_xrec10, *d_yrec10;           /* k_uvt: REAL*8 {ax(i-1), ax(i), ax(i+1), c1 .. c6, c5 + c2} per column i (index i - 1), the same per row */
     /* this grid as a TARGET: its lat/lon.  Separable grids keep 1-D arrays. */
     int coords_ready, separable;
     float *lat1d, *lon1d, *lat2d, *lon2d;
@@ -835,7 +835,7 @@ int32_t c_gdrls(int32_t gd)          /* gdrls.c:34-77: refcount, free at zero */
         }
         free(g->ax); free(g->ay); free(g->ncx); free(g->ncy);
         free(g->lat1d); free(g->lon1d); free(g->lat2d); free(g->lon2d); free(g->mask);
-        ezhip_free(g->d_ax); ezhip_free(g->d_ay); ezhip_free(g->d_ncx); ezhip_free(g->d_ncy); ezhip_free(g->d_ncx8); ezhip_free(g->d_ncy8); ezhip_free(g->d_xrec12); ezhip_free(g->d_yrec12);
+        ezhip_free(g->d_ax); ezhip_free(g->d_ay); ezhip_free(g->d_ncx); ezhip_free(g->d_ncy); ezhip_free(g->d_ncx8); ezhip_free(g->d_ncy8); ezhip_free(g->d_xrec10); ezhip_free(g->d_yrec10);
         ezhip_free(g->d_lat); ezhip_free(g->d_lon); ezhip_free(g->d_plon2); g->d_plon2 = NULL; ezhip_free(g->d_windtrig); g->d_windtrig = NULL;
         memset(g, 0, sizeof(*g));
         if (cur_gdin == gd) cur_gdin = -1;
@@ -1191,19 +1191,27 @@ static int ensure_grid_dev(ezh_grid *g)
         {   /* the 48-byte records k_uvt stages per tile: axis entries i-1 .. i+2 next to the six coefficients of stencil i (interior indices only: the
              * tiles that touch the seam or the first / last rows' clamps never read the others) */
             const int m = g->ni > nr ? g->ni : nr;
-            float *t12 = (float *)calloc((size_t)12 * m, sizeof(float));
-            if (!t12) return -1;
-            for (int i = 1; i + 2 < g->ni; i++) { for (int k = 0; k < 4; k++) t12[12 * i + k] = g->ax[i - 1 + k]; for (int k = 0; k < 6; k++) t12[12 * i + 4 + k] = g->ncx[k * g->ni + i]; }
-            g->d_xrec12 = (float *)upload(t12, sizeof(float) * 12 * g->ni);
+            double *t10 = (double *)calloc((size_t)10 * m, sizeof(double));
+            if (!t10) return -1;
+            for (int i = 1; i + 2 < g->ni; i++) {
+                for (int k = 0; k < 3; k++) t10[10 * i + k] = (double)g->ax[i - 1 + k];
+                for (int k = 0; k < 6; k++) t10[10 * i + 3 + k] = (double)g->ncx[k * g->ni + i];
+                t10[10 * i + 9] = (double)g->ncx[4 * g->ni + i] + (double)g->ncx[1 * g->ni + i];              /* c5 + c2, as the kernels form it */
+            }
+            g->d_xrec10 = (double *)upload(t10, sizeof(double) * 10 * g->ni);
             ezhip_sync();
-            memset(t12, 0, sizeof(float) * 12 * (size_t)m);
-            for (int j = 1; j + 2 < nr; j++) { for (int k = 0; k < 4; k++) t12[12 * j + k] = g->ay[j - 1 + k]; for (int k = 0; k < 6; k++) t12[12 * j + 4 + k] = g->ncy[k * nr + j]; }
-            g->d_yrec12 = (float *)upload(t12, sizeof(float) * 12 * nr);
+            memset(t10, 0, sizeof(double) * 10 * (size_t)m);
+            for (int j = 1; j + 2 < nr; j++) {
+                for (int k = 0; k < 3; k++) t10[10 * j + k] = (double)g->ay[j - 1 + k];
+                for (int k = 0; k < 6; k++) t10[10 * j + 3 + k] = (double)g->ncy[k * nr + j];
+                t10[10 * j + 9] = (double)g->ncy[4 * nr + j] + (double)g->ncy[1 * nr + j];
+            }
+            g->d_yrec10 = (double *)upload(t10, sizeof(double) * 10 * nr);
             ezhip_sync();
-            free(t12);
+            free(t10);
         }
         ezhip_sync();
-        if (!g->d_ax || !g->d_ay || !g->d_ncx || !g->d_ncy || !g->d_ncx8 || !g->d_ncy8 || !g->d_xrec12 || !g->d_yrec12) return -1;
+        if (!g->d_ax || !g->d_ay || !g->d_ncx || !g->d_ncy || !g->d_ncx8 || !g->d_ncy8 || !g->d_xrec10 || !g->d_yrec10) return -1;
     }
     return 0;
 }
@@ -2010,7 +2018,7 @@ static void fill_pts_plan(const ezh_set *s, const ezh_grid *gi, ezhip_pts_plan *
     pp->degree = degree; pp->irregular = src_irregular(gi);
     pp->ni = gi->ni; pp->nj = gi->nj; pp->i1 = gi->i1; pp->i2 = gi->i2; pp->j1 = gi->j1; pp->j2 = gi->j2; pp->wrap = gi->extension;
     pp->ax = gi->d_ax; pp->ay = gi->d_ay; pp->ncx = gi->d_ncx; pp->ncy = gi->d_ncy;
-    pp->ncx8 = gi->d_ncx8; pp->ncy8 = gi->d_ncy8; pp->xrec12 = gi->d_xrec12; pp->yrec12 = gi->d_yrec12;
+    pp->ncx8 = gi->d_ncx8; pp->ncy8 = gi->d_ncy8; pp->xrec10 = gi->d_xrec10; pp->yrec10 = gi->d_yrec10;
     pp->zones = zones; pp->degre_extrap = O.degre_extrap; pp->vector_mode = vector_mode;
     pp->pole_weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
     if (s) { pp->ypole_n = s->ypole_n; pp->ypole_s = s->ypole_s; }
@@ -2528,7 +2536,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
                 if (s->cspec_key == 0) { s->d_cspec_list = dl; s->d_cspec_xy = dxy; s->cspec_count = cnt; s->cspec_key = key; dl = NULL; dxy = NULL; first = 1; }
                 pthread_mutex_unlock(&g_plan_mtx);
                 /* with the special points known, the irregular bicubic pair can run from LDS-staged stencil windows: the tile table over the set's x, y, once */
-                if (first && degree == DEG_CUBIC && pu.irregular && pu.wrap != 0 && pu.tile_ni > 0 && pu.xrec12) {
+                if (first && degree == DEG_CUBIC && pu.irregular && pu.wrap != 0 && pu.tile_ni > 0 && pu.xrec10) {
                     const int th = getenv("EZHIP_UVT_SHAPE") ? atoi(getenv("EZHIP_UVT_SHAPE")) : 3232;      /* 100 TW + TH: 3232, 3216, 6416, 6408 (same results) */
                     int cap = getenv("EZHIP_UVT_CAP") ? atoi(getenv("EZHIP_UVT_CAP")) : 2560;      /* 8 bytes a cell + 9 KB of records: five blocks per CU */
                     if (cap < 256) cap = 256;

@@ -2434,19 +2434,28 @@ template <class A, bool AOS = false> __device__ __forceinline__ float p_irgdint_
  * the REAL*8 operations (results differ from the literal form by a few ulp of REAL*8, 1e-16 of the values; winds are compared at 1e-5 |V|).  A, B, G
  * depend on the point only: 4 rows x 2 fields share them, as do the three of the y direction: 190 instead of 375 VALU instructions per point pair
  * in k_pts2, which is bound by them (six waves per SIMD, each 18 % active: the issue slots of the SIMD are taken).  Scalars (k_pts) keep the literal form. */
-struct NewtonW { double a, b, g; };
-__device__ __forceinline__ NewtonW newton_w(double c1, double c2, double c3, double c4, double c5, double c6, double t1, double t2, double t3)
+/* (round 4) ... and once more as WEIGHTS of the four values: z1 + A (z2 - z1) + B (z3 - z2) + G (z4 - z3) = (1 - A) z1 + (A - B) z2 + (B - G) z3 + G z4: one
+ * multiplication and three fused multiply-adds per row and field instead of three subtractions and three fma (the pair kernels are bound by their REAL*8-rate
+ * VALU work: SQ_ACTIVE_INST_VALU 88 % of the SIMD, profiles/r04_experiments.txt).  The same polynomial, another association once more; every kernel of the
+ * pair path (k_pts2_irgd3w, its seam variant, k_uvt) uses this one form, so a grid set's first call and its later calls return the same bits. */
+struct NewtonW { double a, b, g, w0, w1, w2; };
+__device__ __forceinline__ NewtonW newton_w52(double c1, double c2, double c3, double c4, double c5, double c6, double c52 /* c5 + c2 */, double t1, double t2, double t3)
 {
     NewtonW w;
     const double t12 = t1 * t2, t3c4 = t3 * c4;
     w.a = t1 * c1 * (1.0 - t2 * c2 * (1.0 - t3c4));
-    w.b = t12 * c3 * (c2 - t3c4 * (c5 + c2));
+    w.b = t12 * c3 * (c2 - t3c4 * c52);
     w.g = t12 * t3c4 * c5 * c6;
+    w.w0 = 1.0 - w.a; w.w1 = w.a - w.b; w.w2 = w.b - w.g;
     return w;
+}
+__device__ __forceinline__ NewtonW newton_w(double c1, double c2, double c3, double c4, double c5, double c6, double t1, double t2, double t3)
+{
+    return newton_w52(c1, c2, c3, c4, c5, c6, c5 + c2, t1, t2, t3);
 }
 __device__ __forceinline__ double newton_apply(const NewtonW &w, double z1, double z2, double z3, double z4)
 {
-    return fma(w.g, z4 - z3, fma(w.b, z3 - z2, fma(w.a, z2 - z1, z1)));
+    return fma(w.g, z4, fma(w.w2, z3, fma(w.w1, z2, w.w0 * z1)));
 }
 template <class A, bool AOS>
 __device__ __forceinline__ void p_irgdint_3_w_pair(const A &Z1, const A &Z2, float px, float py, const float *ax, const float *ay,
@@ -2467,7 +2476,7 @@ __device__ __forceinline__ void p_irgdint_3_w_pair(const A &Z1, const A &Z2, flo
                                 coef<AOS>(cy, 4, j - j1, nnj), coef<AOS>(cy, 5, j - j1, nnj), y - (double)y1, y - (double)y2, y - (double)y3);
     /* y direction as weights of the four row values (b0 + A (b1 - b0) + B (b2 - b1) + G (b3 - b2) regrouped once more): the rows stream through two
      * accumulators instead of waiting in eight registers */
-    const double wr[4] = {1.0 - wy.a, wy.a - wy.b, wy.b - wy.g, wy.g};
+    const double wr[4] = {wy.w0, wy.w1, wy.w2, wy.g};
     double su = 0.0, sv = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -2499,7 +2508,7 @@ __device__ __forceinline__ void p_irgdint_3_w_pair_inner(const float *z1f, const
     const double y = (double)(ayv.y + (ayv.z - ayv.y) * (py - (float)j));
     const NewtonW wx = newton_w((double)cxa.x, (double)cxa.y, (double)cxa.z, (double)cxa.w, (double)cxb.x, (double)cxb.y, x - (double)axv.x, x - (double)axv.y, x - (double)axv.z);
     const NewtonW wy = newton_w((double)cya.x, (double)cya.y, (double)cya.z, (double)cya.w, (double)cyb.x, (double)cyb.y, y - (double)ayv.x, y - (double)ayv.y, y - (double)ayv.z);
-    const double wr[4] = {1.0 - wy.a, wy.a - wy.b, wy.b - wy.g, wy.g};
+    const double wr[4] = {wy.w0, wy.w1, wy.w2, wy.g};
     double su = 0.0, sv = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -2798,7 +2807,7 @@ __global__ __launch_bounds__(256) void k_pts2_irgd3w(ezhip_pts_plan p, float *__
  * cells next to the rotated poles) take the gathering path point by point; polar-strip and re-interpolated points stay with k_pts_special2c.
  * The arithmetic is p_irgdint_3_w_pair_inner's, operation for operation: results are bit-identical to k_pts2_irgd3w's. */
 #define UVT_CAP_DEFAULT 2560                           /* staged cells per tile */
-#define UVT_REC_MAX 192                                /* records (x + y) per tile */
+#define UVT_REC_MAX 128                                /* records (x + y) per tile, 80 bytes each */
 __device__ __forceinline__ int uvt_wave_min(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64)); return v; }
 __device__ __forceinline__ int uvt_wave_max(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64)); return v; }
 /* tile (TW x TH target points, a thread block of 256: thread t takes column t % TW, rows t / TW + k * 256 / TW) */
@@ -2872,8 +2881,11 @@ __global__ __launch_bounds__(256) void k_uvt_pack(ezhip_pts_plan p, const float 
  * latency per cfg3 pair as a kernel of their own behind this one -- were tried (a) on a side stream beside this kernel: fork / join events, 98.8 against
  * 87.7 us per pair; (b) as blocks at the head of this launch waiting for the polar-wind producers: the out-of-line strip / re-interpolation code they call
  * takes 146 VGPRs and a call stack, capped at 128 it spills into scratch and the WHOLE launch slows to 227 us.  They stay a kernel of their own.) */
+#ifndef UVT_WAVES
+#define UVT_WAVES 5
+#endif
 template <int TW, int TH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_uvt(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVT_WAVES, 8))) void k_uvt(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
                                              const float *__restrict__ zin1, const float *__restrict__ zin2,
                                              const float *__restrict__ xs, const float *__restrict__ ys, const int4 *__restrict__ tiles)
 {
@@ -2921,10 +2933,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     }
     const int i0 = tb.x, j0 = tb.y, W = tb.z, H = tb.w, ncell = W * H;
     typedef float c2 __attribute__((ext_vector_type(2)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
     c2 *cells = (c2 *)uvt_lds;
-    float4 *xr = (float4 *)(uvt_lds + 2 * ((ncell + 1) & ~1));
-    const int nxr = (W - 3) * 3, nyr = (H - 3) * 3;
-    float4 *yr = xr + nxr;
+    d2 *xr = (d2 *)(uvt_lds + 2 * ((ncell + 1) & ~1));                 /* 5 x 16 bytes per record */
+    const int nxr = (W - 3) * 5, nyr = (H - 3) * 5;
+    d2 *yr = xr + nxr;
     {
         const unsigned magic = 0xFFFFFFFFu / (unsigned)W + 1u;
         const float *s1 = zin1 + (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1), *s2 = zin2 + (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1);
@@ -2936,7 +2949,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 cells[idx] = c2{s1[off], s2[off]};
             }
         }
-        const float4 *gx = (const float4 *)p.xrec12 + (size_t)i0 * 3, *gy = (const float4 *)p.yrec12 + (size_t)(j0 + 1 - p.j1) * 3;
+        const d2 *gx = (const d2 *)p.xrec10 + (size_t)i0 * 5, *gy = (const d2 *)p.yrec10 + (size_t)(j0 + 1 - p.j1) * 5;
         for (int idx = (int)t; idx < nxr; idx += 256) xr[idx] = gx[idx];
         for (int idx = (int)t; idx < nyr; idx += 256) yr[idx] = gy[idx];
     }
@@ -2952,18 +2965,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             const int i = min(p.ni - 2 + p.wrap, max(1, max(2 - p.wrap, (int)px[k]))), j = min(p.j2 - 2, max(p.j1 + 1, (int)py[k]));
             if (dbg & 4) { a = px[k] + (float)i; bb = py[k] + (float)j; }
             else {
-                const float4 *xq = xr + (i - 1 - i0) * 3, *yq = yr + (j - 1 - j0) * 3;
-                const float4 axv = xq[0], cxa = xq[1]; const c2 cxb = *(const c2 *)(xq + 2);
-                const float4 ayv = yq[0], cya = yq[1]; const c2 cyb = *(const c2 *)(yq + 2);
+                /* records {x1, x2 | x3, c1 | c2, c3 | c4, c5 | c6, c5 + c2} in REAL*8: the table's REAL entries converted once per grid, not per point */
+                const d2 *xq = xr + (i - 1 - i0) * 5, *yq = yr + (j - 1 - j0) * 5;
+                const d2 xa = xq[0], xb = xq[1], xc = xq[2], xd = xq[3], xe = xq[4];
+                const d2 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3], ye = yq[4];
                 const c2 *cp = cells + (j - 1 - j0) * W + (i - 1 - i0);
                 c2 q[4][4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) { q[r][0] = cp[r * W]; q[r][1] = cp[r * W + 1]; q[r][2] = cp[r * W + 2]; q[r][3] = cp[r * W + 3]; }
-                const double x = (double)(axv.y + (axv.z - axv.y) * (px[k] - (float)i));
-                const double y = (double)(ayv.y + (ayv.z - ayv.y) * (py[k] - (float)j));
-                const NewtonW wx = newton_w((double)cxa.x, (double)cxa.y, (double)cxa.z, (double)cxa.w, (double)cxb.x, (double)cxb.y, x - (double)axv.x, x - (double)axv.y, x - (double)axv.z);
-                const NewtonW wy = newton_w((double)cya.x, (double)cya.y, (double)cya.z, (double)cya.w, (double)cyb.x, (double)cyb.y, y - (double)ayv.x, y - (double)ayv.y, y - (double)ayv.z);
-                const double wr[4] = {1.0 - wy.a, wy.a - wy.b, wy.b - wy.g, wy.g};
+                const float fx2 = (float)xa.y, fx3 = (float)xb.x, fy2 = (float)ya.y, fy3 = (float)yb.x;      /* (exact: they were REAL) */
+                const double x = (double)(fx2 + (fx3 - fx2) * (px[k] - (float)i));
+                const double y = (double)(fy2 + (fy3 - fy2) * (py[k] - (float)j));
+                const NewtonW wx = newton_w52(xb.y, xc.x, xc.y, xd.x, xd.y, xe.x, xe.y, x - xa.x, x - xa.y, x - xb.x);
+                const NewtonW wy = newton_w52(yb.y, yc.x, yc.y, yd.x, yd.y, ye.x, ye.y, y - ya.x, y - ya.y, y - yb.x);
+                const double wr[4] = {wy.w0, wy.w1, wy.w2, wy.g};
                 double su = 0.0, sv = 0.0;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -3174,13 +3189,13 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     const int tbw = pu2.tile_shape == 1 ? 64 : pu2.tile_shape == 2 ? 16 : pu2.tile_shape == 3 ? 128 : pu2.tile_shape == 5 ? 16 : 32;
     const int tbh = pu2.tile_shape == 1 ? 4 : pu2.tile_shape == 2 ? 16 : pu2.tile_shape == 3 ? 2 : pu2.tile_shape == 5 ? 16 : 8;
     const dim3 grid((pu2.tile_ni > 0 ? (unsigned)(((pu2.tile_ni + tbw - 1) / tbw) * ((pu2.tile_nj + tbh - 1) / tbh)) : (unsigned)((npts + 255) / 256)) + (pu2.pw_out ? 2u : 0u));
-    if (cached && fast3w && pu2.uvt_tiles && pu2.tile_ni > 0 && pu2.xrec12 && pu2.yrec12 && !pu2.out_idx) {
+    if (cached && fast3w && pu2.uvt_tiles && pu2.tile_ni > 0 && pu2.xrec10 && pu2.yrec10 && !pu2.out_idx) {
         /* the grid set's tile table is known: stencil windows staged in LDS (k_uvt); the set's special points behind it */
         pu2.uvt_debug = EZH_DEVINT("EZHIP_UVT_DEBUG");
         const unsigned nt = (unsigned)ezhip_uvt_ntiles(&pu2, pu2.uvt_shape);
         const int4 *tl = (const int4 *)pu2.uvt_tiles;
         const dim3 g(nt + (pu2.pw_out ? 2u : 0u));
-        const size_t lds = (size_t)8 * (size_t)pu2.uvt_cap + 48 * UVT_REC_MAX;
+        const size_t lds = (size_t)8 * (size_t)pu2.uvt_cap + 80 * UVT_REC_MAX;
 #define UVT_LAUNCH(TW, TH) hipLaunchKernelGGL((k_uvt<TW, TH>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl)
         switch (pu2.uvt_shape) { case 3216: UVT_LAUNCH(32, 16); break; case 6408: UVT_LAUNCH(64, 8); break; case 6416: UVT_LAUNCH(64, 16); break; default: UVT_LAUNCH(32, 32); break; }
 #undef UVT_LAUNCH

@@ -222,7 +222,8 @@ typedef struct {
     int ni, nj, i1, i2, j1, j2, wrap; /* source geometry, 1-based bounds as in the reference */
     const float *ax, *ay, *ncx, *ncy; /* device; NULL for regular sources */
     const float *ncx8, *ncy8;         /* the same coefficients laid out [index][8] (6 used): two 16-byte loads per point */
-    const float *xrec12, *yrec12;     /* k_uvt: per source column i (row j) one 48-byte record {ax(i-1 .. i+2), c1 .. c6, 0, 0}, staged in LDS per tile; index i - 1 (j - j1) */
+    const double *xrec10, *yrec10;    /* k_uvt: per source column i (row j) one 80-byte record of REAL*8 {ax(i-1), ax(i), ax(i+1), c1 .. c6, c5 + c2} (the REAL table entries converted once,
+                                         not per point), staged in LDS per tile; index i - 1 (j - j1) */
     const void *uvt_tiles;            /* k_uvt: the grid set's tile table (int4 {i0, j0, W, H} per 32 x uvt_th tile of the target: ezhip_uvt_build), NULL: k_pts2 */
     int uvt_shape;                    /* 100 TW + TH of the table's tiles: 3232 (default), 3216, 6416, 6408 */
     int uvt_cap;                      /* staged cells a tile may need (the table was built under it) */
