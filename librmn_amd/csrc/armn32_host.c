@@ -361,8 +361,13 @@ int c_armn_uncompress32_lng_dev(float *d_fld, const unsigned char *zstream, size
     if (need_dev32("c_armn_uncompress32")) return -1;
     const size_t n = (size_t)ni * nj, zwords = zbytes / 4;
     if (ni < 16 || nj < 16 || zwords < 4) return -1;
+    /* the chains of tile headers on the device when every tile of a row holds nine points (ni - 1 a multiple of 3): the chain is then a pure function of the bit
+     * position and resolves by composition of the windows' maps (unpack_kernels.hip, k_dmin_*) in a fraction of a millisecond per plane.  With a ragged last tile
+     * per row the device can only follow the chain step by step on one CU (43 - 55 ms per 7200 x 3601 field against 21 - 24 with the host threads): host walk.
+     * EZHIP_A32_DEVICE_WALK=0 / 1 forces either */
     const char *dw = getenv("EZHIP_A32_DEVICE_WALK");
-    if (!dw || !atoi(dw) || (uint64_t)zwords * 32 + 16384 >= (1ull << 32))         /* (the device walk holds bit positions in 32 bits) */
+    const int device_walk = dw ? atoi(dw) != 0 : ((ni - 1) % 3 == 0 && (size_t)ni * nj >= 65536);
+    if (!device_walk || (uint64_t)zwords * 32 + 16384 >= (1ull << 32))         /* (the device walk holds bit positions in 32 bits) */
         return uncompress32_host_walk(d_fld, zstream, zwords, ni, nj, nk, znbits);
     const uint32_t *z0 = (const uint32_t *)zstream, *cur = z0 + 2, *zend = z0 + zwords;
     const uint32_t w0 = z0[0], info = z0[1];

@@ -929,34 +929,39 @@ __global__ __launch_bounds__(64) void k_dsc_lastrow(const unsigned *z_all, size_
 }
 
 /* ============================================================================================================================================
- * MINIMUM streams (packTokensMinimum, c_zfstlib.c:469-588): the chain of tile headers by COMPOSITION (round 4).
- * A MINIMUM tile is 4 + nbits (+ 25 x nb) bits: walks from different entries of a window do not merge (all tile lengths are multiples of 5 bits away from each
- * other: five residue classes that never meet), so the parallel form above (k_dsc_*: one exit per eight-window block) gives up on these streams and they went
- * through the serial chain kernel: 16 ms per 7200 x 3601 stream.  But when every tile of a row holds the same number of points (ni a multiple of 5) the chain up
- * to the last row of tiles is a PURE function of the bit position, and functions compose: the speculation table of a window IS its map entry -> (exit, tiles);
- * the maps of 8, 64, 512 ... windows follow level by level (k_dmin_up: one thread per (block, entry), eight lookups), the true entry of every block from the top
- * down (k_dmin_down: one thread per block, eight lookups), down to the windows: went[w] = (entry, first tile) for ALL windows after ~6 + 6 short launches
- * instead of 10^5 dependent steps on one CU.  The last row of tiles (another height: another tile length) is walked tile by tile from LDS by one workgroup
- * (k_dmin_lastrow); k_armn_dec_emit then writes the position of every tile as before.
- * Fields the form does not apply to (PARALLELOGRAM streams, a ragged last column of tiles, streams of a few windows) keep their old routes; dm[DM_NOTMINE] says
- * which. ============================================================================================================================================ */
-enum { DM_NOTMINE = 0, DM_TOPLEV, DM_WORDS = 8 };
+ * Streams whose rows hold WHOLE tiles: the chain of tile headers by COMPOSITION (round 4).
+ * When every tile of a row holds the same number of points -- MINIMUM (packTokensMinimum, c_zfstlib.c:469-588) with ni a multiple of 5, PARALLELOGRAM (:646-789)
+ * and the planes of c_armn_compress32 (armn_compress_32.c:456-565, :642-750) with ni - 1 a multiple of 3 -- the chain up to the last row of tiles is a PURE
+ * function of the bit position, and functions compose: the speculation table of a window IS its map entry -> (exit, tiles); the maps of 8, 64, 512 ... windows
+ * follow level by level (k_dmin_up: one thread per (block, entry), eight lookups), the true entry of every block from the top down (k_dmin_top seeds the blocks
+ * next to the start, k_dmin_down: one thread per block, eight lookups), down to the windows: went[w] = (entry, first tile) for ALL windows after ~6 + 6 short
+ * launches instead of 10^5 dependent steps on one CU.  The last row of tiles (another height: another tile length) is walked tile by tile from LDS by one
+ * workgroup (k_dmin_lastrow); k_armn_dec_emit then writes the position of every tile as before.
+ * Who needs it: MINIMUM streams (a tile is 4 + nbits (+ 25 x nb) bits: walks from different entries never merge -- five residue classes mod 5 -- so the parallel
+ * form above, one exit per eight-window block, gives up on them: 16 ms per 7200 x 3601 stream through the serial chain kernel, 1.1 ms here); the mantissa planes
+ * of c_armn_compress32 (tiles of ~185 bits: no merged exit within eight windows either); PARALLELOGRAM streams with short rows or noisy data the parallel form
+ * gives up on.  The form applies to what k_dsc_* left unresolved (dst[DSC_OK] == 0); ragged rows (a narrower last tile per row shifts everything behind it)
+ * and streams of a few windows keep the serial chain kernel; dm[DM_NOTMINE] says which.
+ * ============================================================================================================================================ */
+enum { DM_NOTMINE = 0, DM_W0, DM_WORDS = 8 };
 #define DM_MAXLEV 9
 struct DmPlan { int nlev; unsigned nblk[DM_MAXLEV + 1]; unsigned long long off[DM_MAXLEV + 1]; unsigned long long eoff[DM_MAXLEV + 1]; };      /* level l: blocks of 8^l windows; level 0 = windows */
-__device__ __forceinline__ bool dmin_eligible(const DecGeom &g, int nwin, int plain) { return !plain && g.method == 3 && g.mlast == g.istep && g.nty >= 2 && nwin >= 64; }
+/* both methods and the planes of c_armn_compress32: what counts is that every tile of a row holds the same number of points */
+__device__ __forceinline__ bool dmin_eligible(const DecGeom &g, int nwin) { return g.mlast == g.istep && g.nty >= 2 && g.ntx >= 2 && nwin >= 64; }
 __global__ void k_dmin_init(const unsigned *z_all, size_t z_stride, int ni, int nj, unsigned *dm_all, size_t dm_stride, const unsigned *dst_all, size_t dst_stride, int nwin, int plain)
 {
     const int f = blockIdx.x;
     if (threadIdx.x) return;
     unsigned *dm = dm_all + (size_t)f * dm_stride;
     DecGeom g;
-    const bool ok = dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, plain) && dmin_eligible(g, nwin, plain) && !(dst_all && dst_all[(size_t)f * dst_stride + DSC_OK]);
-    dm[DM_NOTMINE] = ok ? 0u : 1u;
+    const bool ok = dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, plain) && dmin_eligible(g, nwin) && (int)(g.body / DW) + 17 < nwin &&
+                    !(dst_all && dst_all[(size_t)f * dst_stride + DSC_OK]);
+    dm[DM_NOTMINE] = ok ? 0u : 1u; dm[DM_W0] = 0;
 }
 /* level l + 1 from level l: T[l + 1][b][e] = the walk from entry e through blocks 8 b .. 8 b + 7 of level l: (exit, tiles).  Level 0 is the speculation table
  * (exit | tiles << 16 in one word), the levels above hold uint2 */
 __global__ __launch_bounds__(256) void k_dmin_up(const unsigned *z_all, size_t z_stride, int ni, int nj, const unsigned *dm_all, size_t dm_stride,
-                                                 const unsigned *tab_all, size_t tab_stride, uint2 *lev_all, size_t lev_stride, DmPlan pl, int l, int ext /* row stride of the tables */)
+                                                 const unsigned *tab_all, size_t tab_stride, uint2 *lev_all, size_t lev_stride, DmPlan pl, int l, int ext /* row stride of the tables */, int plain)
 {
     const int f = blockIdx.y;
     if (dm_all[(size_t)f * dm_stride + DM_NOTMINE]) return;
@@ -964,7 +969,7 @@ __global__ __launch_bounds__(256) void k_dmin_up(const unsigned *z_all, size_t z
     const unsigned b = (unsigned)(idx / (unsigned)ext), e0 = (unsigned)(idx % (unsigned)ext);
     if (b >= pl.nblk[l + 1]) return;
     DecGeom g;
-    if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, 0) || e0 >= (unsigned)g.ext) return;      /* (entries beyond the longest tile do not occur) */
+    if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, plain) || e0 >= (unsigned)g.ext) return;      /* (entries beyond the longest tile do not occur) */
     uint2 *lev = lev_all + (size_t)f * lev_stride;
     unsigned e = e0, cnt = 0;
     if (l == 0) {
@@ -976,19 +981,43 @@ __global__ __launch_bounds__(256) void k_dmin_up(const unsigned *z_all, size_t z
     }
     lev[pl.off[l + 1] + (size_t)b * (unsigned)ext + e0] = make_uint2(e, cnt);
 }
-/* the entries of the top level's (<= 8) blocks, one lane */
-__global__ void k_dmin_top(const unsigned *z_all, size_t z_stride, int ni, int nj, const unsigned *dm_all, size_t dm_stride, uint2 *lev_all, size_t lev_stride, DmPlan pl, int ext)
+/* the seeds, one lane: the window in which the first tile starts is walked tile by tile (the chain does not enter it at one of its first `ext` bits: the
+ * prefix of a PARALLELOGRAM stream ends anywhere); from the next window on, the entries of the windows up to the next multiple of 8, then of the level-1 blocks up
+ * to the next multiple of 8 ... and of every block of the top level.  Everything to the right of a seed follows from its parent in k_dmin_down; blocks to the left
+ * of the start stay invalid */
+__global__ void k_dmin_top(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, unsigned *dm_all, size_t dm_stride, const unsigned *tab_all, size_t tab_stride,
+                           uint2 *lev_all, size_t lev_stride, unsigned *went_all, size_t went_stride, DmPlan pl, int ext, int plain)
 {
     const int f = blockIdx.x;
-    if (threadIdx.x || dm_all[(size_t)f * dm_stride + DM_NOTMINE]) return;
+    unsigned *dm = dm_all + (size_t)f * dm_stride;
+    if (threadIdx.x || dm[DM_NOTMINE]) return;
+    const unsigned *z = z_all + (size_t)f * z_stride;
     DecGeom g;
-    if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, 0)) return;
+    if (!dec_geom(g, z, ni, nj, plain)) return;
+    const size_t nwords = z_words - 1;
+    const unsigned *tab = tab_all + (size_t)f * tab_stride;
     uint2 *lev = lev_all + (size_t)f * lev_stride;
+    unsigned *went = went_all + (size_t)f * went_stride;
+    unsigned pos = g.body, t = 0;
+    const unsigned w0 = pos / DW, end0 = (w0 + 1) * DW;
+    went[2 * (size_t)w0] = pos - w0 * DW; went[2 * (size_t)w0 + 1] = 0;
+    dm[DM_W0] = w0;
+    while (pos < end0) { pos += (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.n_int); t++; }      /* (a row of >= 2 tiles and >= 64 windows: the first run does not end here... */
+    if ((long long)t >= (long long)g.ntx * (g.nty - 1)) { dm[DM_NOTMINE] = 1; return; }                           /* ... unless the field is tiny: leave it to the serial kernel) */
+    unsigned e = pos - end0, idx = w0 + 1;
     const int L = pl.nlev;
-    unsigned e = g.body, t = 0;                                      /* MINIMUM: the first header is the first bit of z[1] */
-    for (unsigned b = 0; b < pl.nblk[L]; b++) {
-        lev[pl.eoff[L] + b] = make_uint2(e, t);
-        const uint2 v = lev[pl.off[L] + (size_t)b * (unsigned)ext + e];
+    for (int l = 0; l < L; l++) {
+        while ((idx & 7u) && idx < pl.nblk[l]) {
+            if (l == 0) { went[2 * (size_t)idx] = e; went[2 * (size_t)idx + 1] = t; const unsigned v = tab[(size_t)idx * DEXT + e]; t += v >> 16; e = v & 0xFFFFu; }
+            else { lev[pl.eoff[l] + idx] = make_uint2(e, t); const uint2 v = lev[pl.off[l] + (size_t)idx * (unsigned)ext + e]; t += v.y; e = v.x; }
+            idx++;
+        }
+        if (idx >= pl.nblk[l]) return;                               /* the stream's windows ended at this level */
+        idx >>= 3;
+    }
+    for (; idx < pl.nblk[L]; idx++) {
+        lev[pl.eoff[L] + idx] = make_uint2(e, t);
+        const uint2 v = lev[pl.off[L] + (size_t)idx * (unsigned)ext + e];
         e = v.x; t += v.y;
     }
 }
@@ -1002,6 +1031,7 @@ __global__ __launch_bounds__(256) void k_dmin_down(const unsigned *dm_all, size_
     if (b >= pl.nblk[l + 1]) return;
     uint2 *lev = lev_all + (size_t)f * lev_stride;
     const uint2 en = lev[pl.eoff[l + 1] + b];
+    if (en.x == 0xFFFFFFFFu) return;                                 /* left of the start, or seeded child by child */
     unsigned e = en.x, t = en.y;
     if (l == 0) {
         const unsigned *tab = tab_all + (size_t)f * tab_stride;
@@ -1023,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_dmin_down(const unsigned *dm_all, size_
  * behind that one is taken out of went (the regular chain means nothing there).  status: -2 when the chain leaves the stream. */
 #define DM_LR_WORDS 12288
 __global__ __launch_bounds__(256) void k_dmin_lastrow(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, const unsigned *dm_all, size_t dm_stride,
-                                                      unsigned *went_all, size_t went_stride, unsigned *tilepos_all, size_t tp_stride, int nwin, int *status, unsigned *dst_all, size_t dst_stride)
+                                                      unsigned *went_all, size_t went_stride, unsigned *tilepos_all, size_t tp_stride, int nwin, int *status, unsigned *dst_all, size_t dst_stride, int plain)
 {
     __shared__ unsigned lr[DM_LR_WORDS + 2];
     __shared__ unsigned s_pos, s_t, s_wstar, s_bad;
@@ -1031,14 +1061,14 @@ __global__ __launch_bounds__(256) void k_dmin_lastrow(const unsigned *z_all, siz
     if (dm_all[(size_t)f * dm_stride + DM_NOTMINE]) return;
     const unsigned *z = z_all + (size_t)f * z_stride;
     DecGeom g;
-    if (!dec_geom(g, z, ni, nj, 0)) return;
+    if (!dec_geom(g, z, ni, nj, plain)) return;
     const size_t nwords = z_words - 1;
     unsigned *went = went_all + (size_t)f * went_stride, *tilepos = tilepos_all + (size_t)f * tp_stride;
     const unsigned ntiles = (unsigned)g.ntiles;
     const unsigned Treg = g.hlast != g.istep ? (unsigned)(g.nty - 1) * (unsigned)g.ntx : ntiles;       /* tiles of the regular chain */
     if (tid == 0) {
         /* the last window whose first tile is <= Treg (first tiles are non-decreasing) */
-        int lo = 0, hi = nwin - 1;
+        int lo = (int)dm_all[(size_t)f * dm_stride + DM_W0], hi = nwin - 1;      /* (the windows in front of the first tile hold no entry) */
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (went[2 * (size_t)mid + 1] <= Treg) lo = mid; else hi = mid - 1; }
         unsigned pos = (unsigned)lo * DW + went[2 * (size_t)lo], t = went[2 * (size_t)lo + 1];
         unsigned bad = 0;
@@ -1348,19 +1378,22 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
         hipLaunchKernelGGL(k_dsc_stretch2, dim3((unsigned)((ntyc * DSC_LIST + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, slist, nlist, ws4, ws4, tilepos, ws4, plain);
         hipLaunchKernelGGL(k_dsc_final, dim3((unsigned)((max_tiles + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, tpc, ws4, rowc, rowmerge, ws4, tilepos, ws4, plain);
         hipLaunchKernelGGL(k_dsc_lastrow, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, tpc, ws4, rowc, ws4, tilepos, ws4, d_status, plain);
-        if (!plain && !getenv("EZHIP_DEC_NO_DMIN")) {
-            /* MINIMUM streams whose tiles all hold the same number of points up to the last row: the chain by composition of the windows' maps (k_dmin_*) */
+        if (!getenv("EZHIP_DEC_NO_DMIN")) {
+            /* streams whose tiles all hold the same number of points up to the last row (MINIMUM with ni a multiple of 5, PARALLELOGRAM and the planes of
+             * c_armn_compress32 with ni - 1 a multiple of 3) that the form above did not resolve: the chain by composition of the windows' maps (k_dmin_*) */
             DmPlan pl;
             dmin_plan(&pl, (size_t)nwin);
             const size_t ws8 = work_stride_bytes / 8;
             hipLaunchKernelGGL(k_dmin_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dmst, ws4, dst, ws4, nwin, plain);
             for (int l = 0; l < pl.nlev; l++)
-                hipLaunchKernelGGL(k_dmin_up, dim3((unsigned)(((unsigned long long)pl.nblk[l + 1] * DEXT + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dmst, ws4, tab, ws4, dmlev, ws8, pl, l, DEXT);
+                hipLaunchKernelGGL(k_dmin_up, dim3((unsigned)(((unsigned long long)pl.nblk[l + 1] * DEXT + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dmst, ws4, tab, ws4, dmlev, ws8, pl, l, DEXT, plain);
             if (pl.nlev >= 1) {
-                hipLaunchKernelGGL(k_dmin_top, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dmst, ws4, dmlev, ws8, pl, DEXT);
+                for (int f = 0; f < nfields; f++)          /* the blocks' entries start out invalid (small: one uint2 per block of every level) */
+                    if (hipMemsetAsync((char *)(dmlev + pl.eoff[1]) + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)(pl.off[0] - pl.eoff[1]), st) != hipSuccess) return -1;
+                hipLaunchKernelGGL(k_dmin_top, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dmst, ws4, tab, ws4, dmlev, ws8, went, ws4, pl, DEXT, plain);
                 for (int l = pl.nlev - 1; l >= 0; l--)
                     hipLaunchKernelGGL(k_dmin_down, dim3((pl.nblk[l + 1] + 255) / 256, nfields), dim3(256), 0, st, dmst, ws4, tab, ws4, dmlev, ws8, went, ws4, pl, l, DEXT);
-                hipLaunchKernelGGL(k_dmin_lastrow, dim3(nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dmst, ws4, went, ws4, tilepos, ws4, nwin, d_status, dst, ws4);
+                hipLaunchKernelGGL(k_dmin_lastrow, dim3(nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dmst, ws4, went, ws4, tilepos, ws4, nwin, d_status, dst, ws4, plain);
                 hipLaunchKernelGGL(k_armn_dec_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, went, ws4, tilepos, ws4, nwin, plain, dmst, ws4);
             }
         }

@@ -1005,3 +1005,27 @@ def test_armn_uncompress_minimum_batch_and_damaged(monkeypatch):
             assert np.array_equal(g[f, :w.size], w), (no_dmin, f)
         res.append(rc)
     assert res[0] == res[1]
+
+
+@pytest.mark.parametrize("ni,nj", [(1600, 801), (2560, 1280)])
+def test_armn_uncompress32_whole_rows_take_the_device_walk(ni, nj):
+    """ni - 1 a multiple of 3: every row of tiles of the exponent / mantissa planes is whole, the chains resolve by composition on the device (the default
+    route of the length-aware entry for such shapes); same bits as the host walks and as the field"""
+    for kind in ("positive", "mixed"):
+        f = ta32.field32(ni, nj, kind, seed=ni + nj)
+        zl, z = pk.armn_compress32(f, ni, nj, 32)
+        assert zl > 0
+        res = {}
+        for route in ("default", "0", "1"):
+            if route != "default":
+                os.environ["EZHIP_A32_DEVICE_WALK"] = route
+            try:
+                rc, back = pk.armn_uncompress32_lng(z, 4 * ((zl + 3) // 4), ni, nj, 32)
+            finally:
+                os.environ.pop("EZHIP_A32_DEVICE_WALK", None)
+            assert rc == ni * nj, (kind, route)
+            res[route] = back
+        for route in res:
+            assert np.array_equal(res[route].view(np.uint32), f.view(np.uint32)), (kind, route)
+        rc, _ = pk.armn_uncompress32_lng(z, 4 * (zl // 8), ni, nj, 32)          # half the record: refused on the default (device) route too
+        assert rc == -1
