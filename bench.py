@@ -309,6 +309,17 @@ def launch_ranks(n, argv, stub):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_LAUNCHED_BY="bench.py")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    import signal
+
+    def stop_children(signum=None, frame=None):     # end exactly the processes started here (never by pattern)
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        if signum is not None:
+            raise SystemExit(128 + signum)
+    for sg in (signal.SIGTERM, signal.SIGINT):      # the driver's own timeout must not leave ranks behind on the GPUs
+        signal.signal(sg, stop_children)
+    deadline = time.time() + float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "1800"))
     worst = 0
     pending = list(procs)
     while pending:
@@ -319,8 +330,12 @@ def launch_ranks(n, argv, stub):
             pending.remove(pr)
             if rc != 0:
                 worst = worst or rc
-                for other in pending:          # a dead rank leaves the others in a collective: end exactly the processes started here
+                for other in pending:          # a dead rank leaves the others in a collective
                     other.terminate()
+        if time.time() > deadline:
+            sys.stderr.write("bench.py: the ranks did not finish within BENCH_LAUNCH_TIMEOUT_S; stopping them\n")
+            stop_children()
+            return 124
         time.sleep(0.05)
     return worst
 
