@@ -1359,7 +1359,10 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
             if (hipMemsetAsync((char *)rowhead + (size_t)f * work_stride_bytes, 0, 4 * ntyc, st) != hipSuccess) return -1;      /* (the row walk marks the rows it steps from) */
         }
         const size_t ws2b = work_stride_bytes / 2;
-        hipLaunchKernelGGL(k_dsc_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, wentc, ws4, nwin, plain, getenv("EZHIP_DEC_SCAN_MIN_NTX") ? atoi(getenv("EZHIP_DEC_SCAN_MIN_NTX")) : 768);       /* (rows of 853 tiles: 0.65 against 0.65 - 1.1 ms; of 480: the form gives up and costs 0.2 ms more than it saves) */
+        hipLaunchKernelGGL(k_dsc_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, wentc, ws4, nwin, plain,
+                           /* a plane of c_armn_compress32 with whole rows of tiles goes straight to the composed form below (the parallel form's kernels then see FAIL and
+                            * leave at once): its mantissa tiles (~185 bits) do not merge within eight windows, the attempt cost ~1 ms per plane */
+                           (plain && (ni - 1) % 3 == 0 && !getenv("EZHIP_DEC_NO_DMIN")) ? 0x7fffffff : getenv("EZHIP_DEC_SCAN_MIN_NTX") ? atoi(getenv("EZHIP_DEC_SCAN_MIN_NTX")) : 768);       /* (rows of 853 tiles: 0.65 against 0.65 - 1.1 ms; of 480: the form gives up and costs 0.2 ms more than it saves) */
         hipLaunchKernelGGL(k_dsc_m8, dim3((nwin + 3) / 4, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, tab8, ws4, m8, ws2b, nwin, plain);
         hipLaunchKernelGGL(k_dsc_blocks, dim3((unsigned)((nblk + 255) / 256), nfields), dim3(256), 0, st, dst, ws4, tab8, ws4, m8, ws2b, eblk, cblk, ws4, ext_max);
         hipLaunchKernelGGL(k_dsc_scan, dim3(nfields), dim3(1024), 0, st, dst, ws4, tab, ws4, eblk, cblk, ws4, wentc, wentc8, ws4, nwin, ext_max);
