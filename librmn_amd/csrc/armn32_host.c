@@ -25,7 +25,7 @@ static int need_dev32(const char *who)
     return -1;
 }
 /* per-thread grow-only device workspaces */
-static __thread struct { void *p; size_t cap; } t_w32[8];
+static __thread struct { void *p; size_t cap; } t_w32[10];
 static void *w32(int slot, size_t bytes)
 {
     if (t_w32[slot].cap < bytes) {
@@ -36,7 +36,7 @@ static void *w32(int slot, size_t bytes)
     return t_w32[slot].p;
 }
 
-void ezh_armn32_thread_release(void) { for (int k = 0; k < 8; k++) { ezhip_free(t_w32[k].p); t_w32[k].p = NULL; t_w32[k].cap = 0; } }
+void ezh_armn32_thread_release(void) { for (int k = 0; k < 10; k++) { ezhip_free(t_w32[k].p); t_w32[k].p = NULL; t_w32[k].cap = 0; } }
 
 /* ---- MSB-first bit stream on host words: the `stuff` / `extract` rules (include/bitPacking.h:59-139) ---- */
 typedef struct { uint32_t *z; uint64_t pos; } bitw32;              /* over a zeroed buffer */
@@ -264,6 +264,18 @@ static void *walk_thread(void *a) { walk_job *j = (walk_job *)a; j->tp = walk_ti
 typedef struct { const uint32_t *z; uint32_t *mask; int npts; uint64_t max_bits; int rc; } rle_job;
 static void *rle_thread(void *a) { rle_job *j = (rle_job *)a; j->rc = rle_decode(j->mask, j->z, j->npts, j->max_bits); return NULL; }
 
+/* the sign run lengths on the device (packhip_a32_rle_decode): the sub-stream goes up (at most n / 7 bytes), three short kernels write the mask.  The launches
+ * are queued at once -- they run while the host walks the tile chains -- and *bad is read back behind them.  EZHIP_A32_RLE_HOST=1: the host thread (rle_decode) */
+static int sign_mask_on_device(unsigned *d_smask, const uint32_t *z_s, uint64_t bits_s, size_t n, int *bad)
+{
+    const size_t nbytes = (size_t)(bits_s / 8);
+    unsigned *d_zs = (unsigned *)w32(8, nbytes + 64);
+    void *d_wk = w32(9, packhip_a32_rle_work_bytes(nbytes));
+    if (!d_zs || !d_wk) return -1;
+    if (ezhip_h2d(d_zs, z_s, nbytes)) return -1;
+    return packhip_a32_rle_decode(d_smask, d_zs, nbytes, n, d_wk, bad);
+}
+
 /* c_armn_uncompress32 with the result on the device; zstream: HOST memory (the chain of tile headers is walked on the host).  word_limit: words the
  * caller's buffer is known to hold (0: unknown -- no stream of c_armn_compress32 is longer than the field it replaces) */
 static int uncompress32_host_walk(float *d_fld, const unsigned char *zstream, size_t word_limit, int ni, int nj, int nk, int znbits);
@@ -305,7 +317,8 @@ static int uncompress32_host_walk(float *d_fld, const unsigned char *zstream, si
     walk_job wm = { z_m, ni, nj, nbits, NULL, 0, 32ull * (max_words > used_words ? max_words - used_words : 0) };
     pthread_t th_s, th_e;
     int run_s = 0, run_e = 0, rc = -1;
-    if (have_s) {
+    const int rle_host = getenv("EZHIP_A32_RLE_HOST") != NULL;
+    if (have_s && rle_host) {
         rj.mask = (uint32_t *)calloc(n / 32 + 2 + 16, 4);
         if (!rj.mask) return -1;
         run_s = pthread_create(&th_s, NULL, rle_thread, &rj) == 0;
@@ -315,9 +328,10 @@ static int uncompress32_host_walk(float *d_fld, const unsigned char *zstream, si
     walk_thread(&wm);                                            /* this thread walks the longest chain */
     if (run_e) pthread_join(th_e, NULL);
     if (run_s) pthread_join(th_s, NULL);
+    if (have_s && !rle_host) { int bad = 0; if (sign_mask_on_device(d_smask, z_s, bits_s, n, &bad)) goto out; rj.rc = bad ? -1 : 0; }
     if (have_s && rj.rc) { fprintf(stderr, "<c_armn_uncompress32> broken stream (the sign runs leave their sub-stream)\n"); goto out; }
     if ((have_e && !we.tp) || !wm.tp) { fprintf(stderr, "<c_armn_uncompress32> broken stream (a tile chain leaves the record)\n"); goto out; }
-    if (have_s && (ezhip_h2d(d_smask, rj.mask, 4 * (n / 32 + 1)) || ezhip_sync())) goto out;
+    if (have_s && rle_host && (ezhip_h2d(d_smask, rj.mask, 4 * (n / 32 + 1)) || ezhip_sync())) goto out;
     if (have_e && decode_plane(d_expo, z_e, we.tp, we.ntiles, ni, nj, (int)need_e, 0, 3)) goto out;
     if (decode_plane(d_mant, z_m, wm.tp, wm.ntiles, ni, nj, nbits, 1, 3)) goto out;
     if (packhip_a32_combine(d_fld, d_expo, d_mant, d_smask, n, nbits, exp_min, code_signe, code_expo != 0)) goto out;
@@ -392,19 +406,21 @@ int c_armn_uncompress32_lng_dev(float *d_fld, const unsigned char *zstream, size
     rle_job rj = { z_s, NULL, (int)n, bits_s, 0 };
     pthread_t th_s;
     int run_s = 0, rc = -1;
-    if (have_s) {
+    const int rle_host = getenv("EZHIP_A32_RLE_HOST") != NULL;
+    if (have_s && rle_host) {
         rj.mask = (uint32_t *)calloc(n / 32 + 2 + 16, 4);
         if (!rj.mask) return -1;
         run_s = pthread_create(&th_s, NULL, rle_thread, &rj) == 0;
         if (!run_s) rle_thread(&rj);
     }
     int bad = 0;
+    if (have_s && !rle_host) { int sb = 0; if (sign_mask_on_device(d_smask, z_s, bits_s, n, &sb)) bad = 1; rj.rc = sb ? -1 : 0; }
     if (have_e && decode_plane_walked_on_device(d_expo, z_e, words_e, ni, nj, (int)need_e, 0, 0)) bad = 1;
     if (!bad && decode_plane_walked_on_device(d_mant, z_m, (size_t)(zend - z_m), ni, nj, nbits, 1, 1)) bad = 1;
     if (run_s) pthread_join(th_s, NULL);
     if (have_s && rj.rc) bad = 1;
     if (bad) { fprintf(stderr, "<c_armn_uncompress32> broken stream (a tile chain leaves the record)\n"); goto out; }
-    if (have_s && (ezhip_h2d(d_smask, rj.mask, 4 * (n / 32 + 1)) || ezhip_sync())) goto out;
+    if (have_s && rle_host && (ezhip_h2d(d_smask, rj.mask, 4 * (n / 32 + 1)) || ezhip_sync())) goto out;
     if (packhip_a32_combine(d_fld, d_expo, d_mant, d_smask, n, nbits, exp_min, code_signe, code_expo != 0)) goto out;
     if (ezhip_sync()) goto out;
     rc = (int)n;

@@ -354,6 +354,130 @@ extern "C" int packhip_pg_decode2(int *d_D, int *d_bs, const unsigned *d_z, cons
     hipLaunchKernelGGL(k_pg_colscan, dim3((ni + 255) / 256, nbands), dim3(256), 0, st, d_D, d_bs, ni, nj, wide ? 0xFFFFFFFFu : 0xFFu);
     return chk32("pg_decode");
 }
+/* ---- the sign run lengths (unpack1bitRLE, armn_compress_32.c:904-955) on the device ----------------------------------------------------------------------
+ * The stream is a sequence of tokens of EIGHT bits each (only the very last one may be shorter): flag 0 + seven raw sign bits, or flag 1 + value bit + a 6-bit
+ * count (63: a run of 255 with the value of the last token that carried one).  So token k is byte k of the MSB-first stream; where its points start is a prefix sum
+ * of the run lengths, and "the value of the last token that carried one" is a prefix operation too: both ride one scan over {length, last defined value}
+ * (k_rle_blocks: 4096 tokens per block; k_rle_scan: the blocks' aggregates on one block; k_rle_emit: every thread re-reads its 16 tokens and ORs their bits into the
+ * zeroed mask).  The host did this on one thread: ~8 ms for the 26 M points of a 7200 x 3601 field with mixed signs. */
+#define RLE_TPT 16
+__device__ __forceinline__ unsigned rle_byte(const unsigned *z, size_t k, size_t nbytes) { return k < nbytes ? (z[k >> 2] >> (24 - 8 * (unsigned)(k & 3))) & 0xFFu : 0u; }
+__device__ __forceinline__ uint2 rle_tok(unsigned b)           /* {points covered, 2 | value when the token defines the running value} */
+{
+    if (!(b & 0x80u)) return make_uint2(7u, 0u);
+    const unsigned cnt = b & 63u;
+    return cnt == 63u ? make_uint2(255u, 0u) : make_uint2(cnt, 2u | ((b >> 6) & 1u));
+}
+__device__ __forceinline__ uint2 rle_comb(uint2 a, uint2 b) { return make_uint2(a.x + b.x, b.y ? b.y : a.y); }
+/* aggregate of this thread's tokens, inclusive scan over the block in sh[] (returns the thread's EXCLUSIVE prefix within the block; sh[255] = block aggregate) */
+__device__ __forceinline__ uint2 rle_block_scan(uint2 mine, uint2 *sh)
+{
+    const unsigned t = threadIdx.x;
+    sh[t] = mine;
+    __syncthreads();
+    for (unsigned o = 1; o < 256; o <<= 1) {
+        uint2 v = sh[t];
+        if (t >= o) v = rle_comb(sh[t - o], v);
+        __syncthreads();
+        sh[t] = v;
+        __syncthreads();
+    }
+    return t ? sh[t - 1] : make_uint2(0u, 0u);
+}
+__global__ __launch_bounds__(256) void k_rle_blocks(uint2 *bagg, const unsigned *z, size_t nbytes)
+{
+    __shared__ uint2 sh[256];
+    const size_t k0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * RLE_TPT;
+    uint2 a = make_uint2(0u, 0u);
+#pragma unroll
+    for (int q = 0; q < RLE_TPT; q++) if (k0 + q < nbytes) a = rle_comb(a, rle_tok(rle_byte(z, k0 + q, nbytes)));
+    rle_block_scan(a, sh);
+    if (threadIdx.x == 255) bagg[blockIdx.x] = sh[255];
+}
+/* exclusive prefix of the blocks' aggregates (one block); *bad = 1 when the stream's tokens cover fewer than npts points */
+__global__ __launch_bounds__(1024) void k_rle_scan(uint2 *bpre, const uint2 *bagg, unsigned nblk, unsigned npts, int *bad)
+{
+    __shared__ uint2 sh[1024];
+    __shared__ uint2 carry;
+    if (threadIdx.x == 0) carry = make_uint2(0u, 0u);
+    __syncthreads();
+    for (unsigned base = 0; base < nblk; base += 1024) {
+        const unsigned k = base + threadIdx.x;
+        uint2 v = k < nblk ? bagg[k] : make_uint2(0u, 0u);
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (unsigned o = 1; o < 1024; o <<= 1) {
+            uint2 w = sh[threadIdx.x];
+            if (threadIdx.x >= o) w = rle_comb(sh[threadIdx.x - o], w);
+            __syncthreads();
+            sh[threadIdx.x] = w;
+            __syncthreads();
+        }
+        const uint2 c = carry;
+        if (k < nblk) bpre[k] = rle_comb(c, threadIdx.x ? sh[threadIdx.x - 1] : make_uint2(0u, 0u));
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = rle_comb(c, sh[1023]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *bad = carry.x < npts ? 1 : 0;
+}
+__device__ __forceinline__ void rle_or(unsigned *mask, unsigned i, unsigned pattern, unsigned nbits_)   /* `nbits_` <= 32 bits of `pattern` (LSB = point i) into the mask */
+{
+    if (!pattern) return;
+    const unsigned sh = i & 31u;
+    atomicOr(&mask[i >> 5], pattern << sh);
+    if (sh && sh + nbits_ > 32u) atomicOr(&mask[(i >> 5) + 1], pattern >> (32u - sh));
+}
+__global__ __launch_bounds__(256) void k_rle_emit(unsigned *mask, const uint2 *bpre, const unsigned *z, size_t nbytes, unsigned npts)
+{
+    __shared__ uint2 sh[256];
+    const size_t k0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * RLE_TPT;
+    unsigned bytes[RLE_TPT];
+    uint2 a = make_uint2(0u, 0u);
+#pragma unroll
+    for (int q = 0; q < RLE_TPT; q++) { bytes[q] = rle_byte(z, k0 + q, nbytes); if (k0 + q < nbytes) a = rle_comb(a, rle_tok(bytes[q])); }
+    const uint2 pre = rle_comb(bpre[blockIdx.x], rle_block_scan(a, sh));
+    unsigned i = pre.x, last = pre.y ? (pre.y & 1u) : 1u;          /* (the reference's running value starts as 1) */
+#pragma unroll
+    for (int q = 0; q < RLE_TPT; q++) {
+        if (k0 + q >= nbytes || i >= npts) break;
+        const unsigned b = bytes[q];
+        if (!(b & 0x80u)) {
+            const unsigned lim = min(7u, npts - i);
+            unsigned pat = 0;                                       /* raw bit j (MSB first behind the flag) is point i + j */
+            for (unsigned j = 0; j < lim; j++) pat |= ((b >> (6u - j)) & 1u) << j;
+            rle_or(mask, i, pat, lim);
+            i += 7u;
+        } else {
+            const unsigned cnt = b & 63u, run = cnt == 63u ? 255u : cnt, bit = cnt == 63u ? last : (b >> 6) & 1u;
+            if (cnt != 63u) last = (b >> 6) & 1u;
+            if (bit) {
+                unsigned p = i;
+                const unsigned end = min(i + run, npts);
+                while (p < end) { const unsigned m = min(32u - (p & 31u), end - p); rle_or(mask, p, m == 32u ? 0xFFFFFFFFu : (1u << m) - 1u, m); p += m; }
+            }
+            i += run;
+        }
+    }
+}
+/* d_mask: npts / 32 + 2 words, zeroed here; d_z: the sub-stream's words on the device, nbytes of them meaningful; d_work: 16 bytes per 4096 tokens + 16;
+ * *h_bad (host): 1 when the tokens cover fewer than npts points (a damaged stream).  Synchronises once (the flag). */
+extern "C" size_t packhip_a32_rle_work_bytes(size_t nbytes) { return 16 * ((nbytes + 256 * RLE_TPT - 1) / (256 * RLE_TPT) + 1) + 64; }
+extern "C" int packhip_a32_rle_decode(unsigned *d_mask, const unsigned *d_z, size_t nbytes, size_t npts, void *d_work, int *h_bad)
+{
+    const unsigned nblk = (unsigned)((nbytes + 256 * RLE_TPT - 1) / (256 * RLE_TPT));
+    if (nblk == 0 || npts == 0 || npts >= (1ull << 31)) return -1;
+    uint2 *bagg = (uint2 *)d_work, *bpre = bagg + nblk;
+    int *d_bad = (int *)(bpre + nblk);
+    if (hipMemsetAsync(d_mask, 0, 4 * (npts / 32 + 2), STREAM) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_rle_blocks, dim3(nblk), dim3(256), 0, STREAM, bagg, d_z, nbytes);
+    hipLaunchKernelGGL(k_rle_scan, dim3(1), dim3(1024), 0, STREAM, bpre, bagg, nblk, (unsigned)npts, d_bad);
+    hipLaunchKernelGGL(k_rle_emit, dim3(nblk), dim3(256), 0, STREAM, d_mask, bpre, d_z, nbytes, (unsigned)npts);
+    if (chk32("k_rle")) return -1;
+    if (hipMemcpyAsync(h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, STREAM) != hipSuccess || hipStreamSynchronize(STREAM) != hipSuccess) return -1;
+    return 0;
+}
+
 extern "C" int packhip_a32_combine(float *d_f, const int *d_expo, const int *d_mant, const unsigned *d_smask, size_t n, int nbits, unsigned exp_min, int code_signe, int have_expo)
 {
     hipLaunchKernelGGL(k_a32_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM, (unsigned *)d_f, d_expo, d_mant, d_smask, n, nbits, exp_min, code_signe, have_expo);

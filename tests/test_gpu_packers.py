@@ -1029,3 +1029,28 @@ def test_armn_uncompress32_whole_rows_take_the_device_walk(ni, nj):
             assert np.array_equal(res[route].view(np.uint32), f.view(np.uint32)), (kind, route)
         rc, _ = pk.armn_uncompress32_lng(z, 4 * (zl // 8), ni, nj, 32)          # half the record: refused on the default (device) route too
         assert rc == -1
+
+
+@pytest.mark.parametrize("ni,nj", [(64, 48), (301, 200), (1000, 777), (2560, 1280)])
+@pytest.mark.parametrize("kind", ["mixed", "stripes"])
+def test_armn_uncompress32_sign_runs_on_the_device(ni, nj, kind):
+    """the sign run lengths (unpack1bitRLE: raw groups of seven, counted runs, the 255-repeat token) decoded by the device kernels (the default) against the
+    host thread (EZHIP_A32_RLE_HOST=1) and the field; whole and ragged rows of tiles (device and host walks of the planes)"""
+    f = ta32.field32(ni, nj, kind, seed=3 * ni + nj)
+    zl, z = pk.armn_compress32(f, ni, nj, 32)
+    if zl < 0:
+        pytest.skip("not compressible at this size")
+    outs = []
+    for host in (False, True):
+        if host:
+            os.environ["EZHIP_A32_RLE_HOST"] = "1"
+        try:
+            rc, back = pk.armn_uncompress32(z, ni, nj, 32)
+            rc2, back2 = pk.armn_uncompress32_lng(z, 4 * ((zl + 3) // 4), ni, nj, 32)
+        finally:
+            os.environ.pop("EZHIP_A32_RLE_HOST", None)
+        assert rc == ni * nj and rc2 == ni * nj
+        assert np.array_equal(back.view(np.uint32), f.view(np.uint32)), (host, int((back.view(np.uint32) != f.view(np.uint32)).sum()))
+        assert np.array_equal(back2.view(np.uint32), f.view(np.uint32)), host
+        outs.append(back)
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
