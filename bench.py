@@ -275,14 +275,30 @@ def extras(ez, torch, stream, d_out, d_in):
             f32 = _ec.synth_field(ni32, NJ_D, seed=5); n32 = ni32 * NJ_D
             zl32, z32 = pk.armn_compress32(f32, ni32, NJ_D, 32)
             if zl32 <= 0: continue
-            best = 1e9
+            best = bestl = 1e9
             for _ in range(3):
                 t0_ = time.perf_counter(); rc32, back32 = pk.armn_uncompress32(z32, ni32, NJ_D, 32); best = min(best, time.perf_counter() - t0_)
+                t0_ = time.perf_counter(); rcl, backl = pk.armn_uncompress32_lng(z32, 4 * ((zl32 + 3) // 4), ni32, NJ_D, 32); bestl = min(bestl, time.perf_counter() - t0_)
             ex[key] = {"workload": "c_armn_uncompress32 of a %d x %d REAL field (32 bits kept, ratio %.2f), host arrays" % (ni32, NJ_D, zl32 / (4.0 * n32)),
                        "ms_per_field": best * 1e3, "bit_identical": bool(rc32 == n32 and np.array_equal(back32.view(np.uint32), f32.view(np.uint32))),
                        "GBps": (zl32 + 4.0 * n32) / best / 1e9, "frac_of_hbm_peak": (zl32 + 4.0 * n32) / best / 1e9 / HBM_PEAK_GBPS,
-                       "note": "host stream up, field down over PCIe; sign runs on the device; tile chains " +
-                               ("on the device (rows end on whole tiles)" if (ni32 - 1) % 3 == 0 else "on two host threads meanwhile (ragged rows: a sequential chain)")}
+                       "length_given_ms": bestl * 1e3, "length_given_bit_identical": bool(rcl == n32 and np.array_equal(backl.view(np.uint32), f32.view(np.uint32))),
+                       "note": "ms_per_field: c_armn_uncompress32 as the reference declares it (no length: the record's end is found by walking the chains on two host "
+                               "threads); length_given_ms: c_armn_uncompress32_lng (the FST record's word count): sign runs and tile chains on the device -- " +
+                               ("rows end on whole tiles: composition of the windows' maps" if (ni32 - 1) % 3 == 0 else
+                                "ragged rows: composition + row recurrence; a plane that form leaves open (long runs of empty exponent tiles) is walked on the host") +
+                               "; host arrays: stream up, field down over PCIe in both"}
+            # record and field both in HBM (c_armn_compress32_dev -> c_armn_uncompress32_zdev)
+            d_f32 = torch.from_numpy(f32).cuda(); d_z32 = torch.zeros(n32 + 64, dtype=torch.int32, device="cuda"); d_b32 = torch.empty(n32, dtype=torch.float32, device="cuda")
+            if pk.armn_compress32_dev(d_z32, d_f32, ni32, NJ_D, 32) == zl32:
+                bestd = 1e9
+                for _ in range(4):
+                    torch.cuda.synchronize(); t0_ = time.perf_counter()
+                    rcd = pk.armn_uncompress32_zdev(d_b32, d_z32, 4 * ((zl32 + 3) // 4), ni32, NJ_D, 32)
+                    torch.cuda.synchronize(); bestd = min(bestd, time.perf_counter() - t0_)
+                ex[key]["record_and_field_in_hbm_ms"] = bestd * 1e3
+                ex[key]["record_and_field_in_hbm_bit_identical"] = bool(rcd == n32 and torch.equal(d_b32.view(torch.int32), d_f32.view(torch.int32)))
+            del d_f32, d_z32, d_b32
     except Exception as e:   # noqa: BLE001
         ex["error"] = repr(e)
     return ex

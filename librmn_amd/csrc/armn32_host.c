@@ -217,26 +217,44 @@ int c_armn_compress32(unsigned char *zstream, float *fld, int ni, int nj, int nk
     return zlng;
 }
 
-/* bit position of every tile header of a parallelogram stream (host words): 3-bit width-field size, row 1, column 1, then the chain */
+/* bit position of every tile header of a parallelogram stream (host words): 3-bit width-field size, row 1, column 1, then the chain.
+ * Runs of zero bits are taken at once: a header inside one says "no tokens" whatever the tile's point count, so every tile in it is `container` bits long (the
+ * exponent plane of a smooth field is mostly such runs: 10 ms of dependent steps become ~1 ms of stores) */
 static uint64_t *walk_tiles(const uint32_t *z, int ni, int nj, int nbits, size_t *ntiles_out, uint64_t max_bits)
 {
     uint64_t pos = 0;
     const int container = (int)br32_get(z, &pos, 3);
     pos += (uint64_t)(ni + nj - 1) * (uint64_t)nbits;
     const int ntx = (ni - 1 + 2) / 3, nty = (nj - 1 + 2) / 3;
-    uint64_t *tp = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)ntx * nty + 1));
+    const size_t ntiles = (size_t)ntx * nty;
+    uint64_t *tp = (uint64_t *)malloc(sizeof(uint64_t) * (ntiles + 1));
     if (!tp) return NULL;
+    const uint64_t max_word = max_bits >> 5;                      /* whole words the stream is known to hold */
     size_t t = 0;
-    for (int ty = 0; ty < nty; ty++) {
-        const int tn = nj - (1 + 3 * ty) < 3 ? nj - (1 + 3 * ty) : 3;
-        for (int tx = 0; tx < ntx; tx++, t++) {
-            const int tm = ni - (1 + 3 * tx) < 3 ? ni - (1 + 3 * tx) : 3;
-            tp[t] = pos;
-            if (pos + (uint64_t)container > max_bits) { free(tp); return NULL; }      /* a truncated or corrupt record: the chain left the stream */
-            uint64_t p2 = pos;
-            const int need = (int)br32_get(z, &p2, container);
-            pos += (uint64_t)container + (need ? (uint64_t)(tm * tn) * (uint64_t)(need + 1) : 0);
+    int tx = 0, ty = 0;
+    while (t < ntiles) {
+        if (pos + (uint64_t)container > max_bits) { free(tp); return NULL; }      /* a truncated or corrupt record: the chain left the stream */
+        const uint64_t wi = pos >> 5;
+        /* (no word is looked at that the remaining tiles, were they all empty, would not cover: the record's end is not always known) */
+        const uint64_t cover = ((pos + (uint64_t)(ntiles - t) * (uint64_t)container) >> 5) + 1, lim = cover < max_word ? cover : max_word;
+        if (container > 0 && wi + 1 < lim && (z[wi] & (0xFFFFFFFFu >> (pos & 31))) == 0 && z[wi + 1] == 0) {
+            uint64_t wj = wi + 2;
+            while (wj < lim && z[wj] == 0) wj++;
+            const uint64_t zend = 32 * wj + (wj < lim ? (uint64_t)__builtin_clz(z[wj]) : 0);      /* zero bits from pos to here */
+            size_t k = (size_t)((zend - pos) / (uint64_t)container);
+            if (k > ntiles - t) k = ntiles - t;
+            for (size_t i = 0; i < k; i++) tp[t + i] = pos + (uint64_t)i * (uint64_t)container;
+            t += k; pos += (uint64_t)k * (uint64_t)container;
+            const size_t x = (size_t)tx + k;
+            ty += (int)(x / (size_t)ntx); tx = (int)(x % (size_t)ntx);
+            continue;
         }
+        const int tn = nj - (1 + 3 * ty) < 3 ? nj - (1 + 3 * ty) : 3, tm = ni - (1 + 3 * tx) < 3 ? ni - (1 + 3 * tx) : 3;
+        tp[t++] = pos;
+        uint64_t p2 = pos;
+        const int need = (int)br32_get(z, &p2, container);
+        pos += (uint64_t)container + (need ? (uint64_t)(tm * tn) * (uint64_t)(need + 1) : 0);
+        if (++tx == ntx) { tx = 0; ty++; }
     }
     tp[t] = pos;
     if (pos > max_bits) { free(tp); return NULL; }
@@ -266,13 +284,13 @@ static void *rle_thread(void *a) { rle_job *j = (rle_job *)a; j->rc = rle_decode
 
 /* the sign run lengths on the device (packhip_a32_rle_decode): the sub-stream goes up (at most n / 7 bytes), three short kernels write the mask.  The launches
  * are queued at once -- they run while the host walks the tile chains -- and *bad is read back behind them.  EZHIP_A32_RLE_HOST=1: the host thread (rle_decode) */
-static int sign_mask_on_device(unsigned *d_smask, const uint32_t *z_s, uint64_t bits_s, size_t n, int *bad)
+static int sign_mask_on_device(unsigned *d_smask, const uint32_t *z_s, int z_on_device, uint64_t bits_s, size_t n, int *bad)
 {
     const size_t nbytes = (size_t)(bits_s / 8);
     unsigned *d_zs = (unsigned *)w32(8, nbytes + 64);
     void *d_wk = w32(9, packhip_a32_rle_work_bytes(nbytes));
     if (!d_zs || !d_wk) return -1;
-    if (ezhip_h2d(d_zs, z_s, nbytes)) return -1;
+    if (z_on_device ? ezhip_d2d(d_zs, z_s, nbytes) : ezhip_h2d(d_zs, z_s, nbytes)) return -1;
     return packhip_a32_rle_decode(d_smask, d_zs, nbytes, n, d_wk, bad);
 }
 
@@ -328,7 +346,7 @@ static int uncompress32_host_walk(float *d_fld, const unsigned char *zstream, si
     walk_thread(&wm);                                            /* this thread walks the longest chain */
     if (run_e) pthread_join(th_e, NULL);
     if (run_s) pthread_join(th_s, NULL);
-    if (have_s && !rle_host) { int bad = 0; if (sign_mask_on_device(d_smask, z_s, bits_s, n, &bad)) goto out; rj.rc = bad ? -1 : 0; }
+    if (have_s && !rle_host) { int bad = 0; if (sign_mask_on_device(d_smask, z_s, 0, bits_s, n, &bad)) goto out; rj.rc = bad ? -1 : 0; }
     if (have_s && rj.rc) { fprintf(stderr, "<c_armn_uncompress32> broken stream (the sign runs leave their sub-stream)\n"); goto out; }
     if ((have_e && !we.tp) || !wm.tp) { fprintf(stderr, "<c_armn_uncompress32> broken stream (a tile chain leaves the record)\n"); goto out; }
     if (have_s && rle_host && (ezhip_h2d(d_smask, rj.mask, 4 * (n / 32 + 1)) || ezhip_sync())) goto out;
@@ -353,7 +371,7 @@ broken:
  * the host walks -- a mantissa plane is a stream of 300 - 550 Mbit, two to three times a cfg5 record, the chain kernel is one CU following it at ~0.25 us
  * per dependent step, and a host core walks the same chain in ~10 ms while the other planes are walked on other threads. ---- */
 static __thread uint32_t t_plane_hdr[2], t_plane_status[2];
-static int decode_plane_walked_on_device(int *d_plane, const uint32_t *z, size_t words, int ni, int nj, int nbits, int wide, int which)
+static int decode_plane_walked_on_device(int *d_plane, const uint32_t *z, int z_on_device, size_t words, int ni, int nj, int nbits, int wide, int which)
 {
     const size_t zw = words + 1;                                  /* [header word in armn_compress's layout][the plane's stream] */
     unsigned *d_zs = (unsigned *)w32(3, 4 * (zw + 64));
@@ -362,29 +380,101 @@ static int decode_plane_walked_on_device(int *d_plane, const uint32_t *z, size_t
     int *d_status = (int *)w32(7, 256);
     if (!d_zs || !d_work || !d_bs || !d_status) return -1;
     t_plane_hdr[which] = packhip_armn_plane_header(nbits);
-    if (ezhip_h2d(d_zs, &t_plane_hdr[which], 4) || ezhip_h2d(d_zs + 1, z, 4 * words) || ezhip_memset(d_zs + zw, 0, 4 * 64)) return -1;
-    if (packhip_armn_tile_walk(d_zs, zw, ni, nj, d_work, d_status + which)) return -1;
-    if (packhip_pg_decode2(d_plane, d_bs, d_zs + 1, NULL, (const unsigned *)d_work, ni, nj, nbits, wide)) return -1;
-    if (ezhip_d2h(&t_plane_status[which], d_status + which, 4) || ezhip_sync()) return -1;
-    return t_plane_status[which] == 0 ? 0 : -1;
+    if (ezhip_h2d(d_zs, &t_plane_hdr[which], 4) || (z_on_device ? ezhip_d2d(d_zs + 1, z, 4 * words) : ezhip_h2d(d_zs + 1, z, 4 * words)) || ezhip_memset(d_zs + zw, 0, 4 * 64)) return -1;
+    if (packhip_armn_tile_walk_parallel(d_zs, zw, ni, nj, d_work, d_status + which)) return -1;
+    if (ezhip_d2h(&t_plane_status[which], d_status + which, 4) || ezhip_sync()) return -1;      /* (the verdict first: positions of an unresolved chain are not positions) */
+    if (t_plane_status[which] != 0) return t_plane_status[which] == 1 ? 1 : -1;      /* 1: the parallel forms did not resolve the chain (the caller walks it on the host) */
+    if (packhip_pg_decode2(d_plane, d_bs, d_zs + 1, NULL, (const unsigned *)d_work, ni, nj, nbits, wide) || ezhip_sync()) return -1;
+    return 0;
+}
+
+static int device_walk_wanted(int ni, int nj, size_t zwords)
+{
+    const char *dw = getenv("EZHIP_A32_DEVICE_WALK");
+    /* whole rows of tiles: composition (k_dmin_*); ragged rows: composition + the row recurrence (k_drg_*), which wants rows of a few hundred tiles */
+    const int device_walk = dw ? atoi(dw) != 0 : ((size_t)ni * nj >= 65536 && ((ni - 1) % 3 == 0 || ni >= 768));
+    return device_walk && (uint64_t)zwords * 32 + 16384 < (1ull << 32);         /* (the device walk holds bit positions in 32 bits) */
+}
+/* one word of the record: from the host's copy, or -- the record in HBM -- read back (four dependent words per record: w0, info and the two length words) */
+static int rec_word(const uint32_t *z0, int z_on_device, size_t idx, uint32_t *out)
+{
+    if (!z_on_device) { *out = z0[idx]; return 0; }
+    return (ezhip_d2h(out, z0 + idx, 4) || ezhip_sync()) ? -1 : 0;
+}
+static int uncompress32_device_walk(float *d_fld, const uint32_t *z0, int z_on_device, size_t zwords, int ni, int nj);
+
+/* a plane in HBM: chain and tiles on the device; when the parallel forms leave the chain unresolved -- typically the exponent plane of a smooth field, whose long
+ * runs of empty tiles keep walks of different phase apart for good -- THIS plane's chain is walked on the host (zero runs at once) and only its positions go up */
+static int plane_on_device(int *d_plane, const uint32_t *z, int z_on_device, size_t words, int ni, int nj, int nbits, int wide, int which)
+{
+    const int r = decode_plane_walked_on_device(d_plane, z, z_on_device, words, ni, nj, nbits, wide, which);
+    if (r != 1) return r;
+    const uint32_t *zh = z;
+    uint32_t *tmp = NULL;
+    if (z_on_device) {
+        tmp = (uint32_t *)malloc(4 * (words + 4));
+        if (!tmp) return -1;
+        if (ezhip_d2h(tmp, z, 4 * words) || ezhip_sync()) { free(tmp); return -1; }
+        tmp[words] = tmp[words + 1] = 0;
+        zh = tmp;
+    }
+    size_t ntiles = 0;
+    uint64_t *tp = walk_tiles(zh, ni, nj, nbits, &ntiles, 32ull * words);
+    int rc = -1;
+    if (tp) {
+        unsigned *d_zs = (unsigned *)w32(3, 4 * (words + 1 + 64));                    /* (still [header word][the plane] from the attempt above) */
+        unsigned long long *d_tp = (unsigned long long *)w32(4, 8 * (ntiles + 1));
+        int *d_bs = (int *)w32(5, 4 * (size_t)ni * ((size_t)(nj + 31) / 32 + 1));
+        if (d_zs && d_tp && d_bs && !ezhip_h2d(d_tp, tp, 8 * (ntiles + 1))) rc = packhip_pg_decode(d_plane, d_bs, d_zs + 1, d_tp, ni, nj, nbits, wide);
+        if (ezhip_sync()) rc = -1;
+    }
+    free(tp); free(tmp);
+    return rc;
 }
 
 int c_armn_uncompress32_lng_dev(float *d_fld, const unsigned char *zstream, size_t zbytes, int ni, int nj, int nk, int znbits)
 {
-    (void)nk; (void)znbits;
     if (need_dev32("c_armn_uncompress32")) return -1;
-    const size_t n = (size_t)ni * nj, zwords = zbytes / 4;
+    const size_t zwords = zbytes / 4;
     if (ni < 16 || nj < 16 || zwords < 4) return -1;
     /* the chains of tile headers on the device when every tile of a row holds nine points (ni - 1 a multiple of 3): the chain is then a pure function of the bit
      * position and resolves by composition of the windows' maps (unpack_kernels.hip, k_dmin_*) in a fraction of a millisecond per plane.  With a ragged last tile
      * per row the device can only follow the chain step by step on one CU (43 - 55 ms per 7200 x 3601 field against 21 - 24 with the host threads): host walk.
      * EZHIP_A32_DEVICE_WALK=0 / 1 forces either */
-    const char *dw = getenv("EZHIP_A32_DEVICE_WALK");
-    const int device_walk = dw ? atoi(dw) != 0 : ((ni - 1) % 3 == 0 && (size_t)ni * nj >= 65536);
-    if (!device_walk || (uint64_t)zwords * 32 + 16384 >= (1ull << 32))         /* (the device walk holds bit positions in 32 bits) */
-        return uncompress32_host_walk(d_fld, zstream, zwords, ni, nj, nk, znbits);
-    const uint32_t *z0 = (const uint32_t *)zstream, *cur = z0 + 2, *zend = z0 + zwords;
-    const uint32_t w0 = z0[0], info = z0[1];
+    if (device_walk_wanted(ni, nj, zwords)) {
+        const int rc = uncompress32_device_walk(d_fld, (const uint32_t *)zstream, 0, zwords, ni, nj);
+        if (rc != 1) return rc;                                  /* 1: a chain the device forms did not resolve (rows that rejoin late, tiny planes) */
+    }
+    return uncompress32_host_walk(d_fld, zstream, zwords, ni, nj, nk, znbits);
+}
+
+/* the record AND the field in HBM (a record the device compressor wrote, or one read into device memory): whole-tile rows decode without the host seeing more
+ * than four words of the record; a ragged last tile per row sends the record down to the host's walk (the chain is sequential there: see above) */
+int c_armn_uncompress32_zdev(float *d_fld, const void *d_zstream, size_t zbytes, int ni, int nj, int nk, int znbits)
+{
+    if (need_dev32("c_armn_uncompress32")) return -1;
+    const size_t zwords = zbytes / 4;
+    if (ni < 16 || nj < 16 || zwords < 4 || !d_zstream || !d_fld) return -1;
+    if (device_walk_wanted(ni, nj, zwords)) {
+        const int rc1 = uncompress32_device_walk(d_fld, (const uint32_t *)d_zstream, 1, zwords, ni, nj);
+        if (rc1 != 1) return rc1;
+    }
+    unsigned char *h = (unsigned char *)malloc(4 * zwords + 64);
+    if (!h) return -1;
+    int rc = -1;
+    if (!ezhip_d2h(h, d_zstream, 4 * zwords) && !ezhip_sync()) rc = uncompress32_host_walk(d_fld, h, zwords, ni, nj, nk, znbits);
+    if (ezhip_sync()) rc = -1;                                    /* (the host copy is read by queued uploads until here) */
+    free(h);
+    return rc;
+}
+
+static int uncompress32_device_walk(float *d_fld, const uint32_t *z0, int z_on_device, size_t zwords, int ni, int nj)
+{
+    const size_t n = (size_t)ni * nj;
+    const uint32_t *cur = z0 + 2, *zend = z0 + zwords;
+    uint32_t w0, info;
+    if (z_on_device) { uint32_t h2[2]; if (ezhip_d2h(h2, z0, 8) || ezhip_sync()) return -1; w0 = h2[0]; info = h2[1]; }
+    else { w0 = z0[0]; info = z0[1]; }
     if ((w0 & 15u) != 5u) { fprintf(stderr, "<c_armn_uncompress32> not a PARALLELOGRAM32 stream\n"); return -1; }
     const int nbits = (int)((w0 >> 10) & 31);
     const uint32_t exp_min = info >> 16, need_e = (info >> 8) & 0xFF, codes = info & 0xFF;
@@ -398,27 +488,28 @@ int c_armn_uncompress32_lng_dev(float *d_fld, const unsigned char *zstream, size
     const uint32_t *z_s = NULL, *z_e = NULL, *z_m;
     size_t words_e = 0;
     uint64_t bits_s = 0;
-    if (have_s) { if (cur >= zend) goto broken; const uint32_t lng = *cur++; if ((size_t)(lng >> 2) > (size_t)(zend - cur)) goto broken; z_s = cur; bits_s = 32ull * (lng >> 2); cur += lng >> 2; }
-    if (have_e) { if (cur >= zend) goto broken; const uint32_t lng = *cur++; if ((size_t)(lng >> 2) > (size_t)(zend - cur)) goto broken; z_e = cur; words_e = lng >> 2; cur += lng >> 2; }
+    if (have_s) { uint32_t lng; if (cur >= zend || rec_word(z0, z_on_device, (size_t)(cur - z0), &lng)) goto broken; cur++; if ((size_t)(lng >> 2) > (size_t)(zend - cur)) goto broken; z_s = cur; bits_s = 32ull * (lng >> 2); cur += lng >> 2; }
+    if (have_e) { uint32_t lng; if (cur >= zend || rec_word(z0, z_on_device, (size_t)(cur - z0), &lng)) goto broken; cur++; if ((size_t)(lng >> 2) > (size_t)(zend - cur)) goto broken; z_e = cur; words_e = lng >> 2; cur += lng >> 2; }
     if (cur + 1 >= zend) goto broken;
     cur++;                                                       /* the mantissa length slot */
     z_m = cur;
     rle_job rj = { z_s, NULL, (int)n, bits_s, 0 };
     pthread_t th_s;
     int run_s = 0, rc = -1;
-    const int rle_host = getenv("EZHIP_A32_RLE_HOST") != NULL;
+    const int rle_host = getenv("EZHIP_A32_RLE_HOST") != NULL && !z_on_device;
     if (have_s && rle_host) {
         rj.mask = (uint32_t *)calloc(n / 32 + 2 + 16, 4);
         if (!rj.mask) return -1;
         run_s = pthread_create(&th_s, NULL, rle_thread, &rj) == 0;
         if (!run_s) rle_thread(&rj);
     }
-    int bad = 0;
-    if (have_s && !rle_host) { int sb = 0; if (sign_mask_on_device(d_smask, z_s, bits_s, n, &sb)) bad = 1; rj.rc = sb ? -1 : 0; }
-    if (have_e && decode_plane_walked_on_device(d_expo, z_e, words_e, ni, nj, (int)need_e, 0, 0)) bad = 1;
-    if (!bad && decode_plane_walked_on_device(d_mant, z_m, (size_t)(zend - z_m), ni, nj, nbits, 1, 1)) bad = 1;
+    int bad = 0, unresolved = 0;
+    if (have_s && !rle_host) { int sb = 0; if (sign_mask_on_device(d_smask, z_s, z_on_device, bits_s, n, &sb)) bad = 1; rj.rc = sb ? -1 : 0; }
+    if (have_e) { const int r = plane_on_device(d_expo, z_e, z_on_device, words_e, ni, nj, (int)need_e, 0, 0); if (r == 1) unresolved = 1; else if (r) bad = 1; }
+    if (!bad && !unresolved) { const int r = plane_on_device(d_mant, z_m, z_on_device, (size_t)(zend - z_m), ni, nj, nbits, 1, 1); if (r == 1) unresolved = 1; else if (r) bad = 1; }
     if (run_s) pthread_join(th_s, NULL);
     if (have_s && rj.rc) bad = 1;
+    if (!bad && unresolved) { rc = 1; goto out; }
     if (bad) { fprintf(stderr, "<c_armn_uncompress32> broken stream (a tile chain leaves the record)\n"); goto out; }
     if (have_s && rle_host && (ezhip_h2d(d_smask, rj.mask, 4 * (n / 32 + 1)) || ezhip_sync())) goto out;
     if (packhip_a32_combine(d_fld, d_expo, d_mant, d_smask, n, nbits, exp_min, code_signe, code_expo != 0)) goto out;

@@ -77,6 +77,7 @@ int packhip_pg_decode2(int *d_D, int *d_bs, const unsigned *d_z, const unsigned 
 /* the tile-header chain of one plane of c_armn_compress32 walked on the device (unpack_kernels.hip) */
 unsigned packhip_armn_plane_header(int nbits);
 int packhip_armn_tile_walk(const unsigned *d_z, size_t z_words, int ni, int nj, void *d_work, int *d_status);
+int packhip_armn_tile_walk_parallel(const unsigned *d_z, size_t z_words, int ni, int nj, void *d_work, int *d_status);      /* no serial chain kernel behind the parallel forms: *d_status = 1 when they did not resolve the chain */
 /* sign run lengths -> sign mask on the device (unpack1bitRLE); d_z: the sub-stream on the device */
 size_t packhip_a32_rle_work_bytes(size_t nbytes);
 int packhip_a32_rle_decode(unsigned *d_mask, const unsigned *d_z, size_t nbytes, size_t npts, void *d_work, int *h_bad);

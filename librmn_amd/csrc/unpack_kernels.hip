@@ -563,13 +563,17 @@ __device__ __forceinline__ size_t out_slot(size_t k, int swap) { return swap ? (
  * ============================================================================================================================================ */
 enum { DSC_OK = 0, DSC_WB, DSC_EB, DSC_TB, DSC_K, DSC_NCANON, DSC_FAIL, DSC_RINT, DSC_WORDS = 16 };
 #define DSC_D_INVALID 0x7FFF
-#define DSC_MARGIN 65536                 /* canonical tiles kept beyond the field's own tile count */
+/* canonical tiles kept beyond the field's own tile count: the canonical chain reads the bits of a row's narrow last tile as interior tiles and runs ahead of the
+ * real tile index by some tens of tiles per row (mantissa plane of a 7200 x 3601 field: 67 596 at the last row) */
+static inline size_t dsc_margin(size_t max_tiles) { return max_tiles / 4 > 65536 ? max_tiles / 4 : 65536; }
+#define DSC_LIST 512                     /* windows a stretch may take to rejoin the canonical chain (mantissa planes of c_armn_compress32: 16 on average, 130 seen) */
 
 __device__ __forceinline__ bool dsc_eligible(const DecGeom &g, int nwin, int min_ntx) { return g.ntx >= min_ntx && g.nty >= 3 && nwin >= 64; }       /* (both methods: the geometry and dec_step carry the difference) */
 
 /* one wave per field: the first (partial) window tile by tile, the block origin */
 __global__ __launch_bounds__(64) void k_dsc_init(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, unsigned *st_all, size_t st_stride,
-                                                 unsigned *wentc_all, size_t went_stride, int nwin, int plain, int min_ntx)
+                                                 unsigned *wentc_all, size_t went_stride, int nwin, int plain, int min_ntx,
+                                                 const unsigned *done_all = nullptr, size_t done_stride = 0)     /* second use (the composed ragged form): the first form's state */
 {
     const int f = blockIdx.x;
     if (threadIdx.x) return;
@@ -578,6 +582,7 @@ __global__ __launch_bounds__(64) void k_dsc_init(const unsigned *z_all, size_t z
     const unsigned *z = z_all + (size_t)f * z_stride;
     DecGeom g;
     if (!dec_geom(g, z, ni, nj, plain) || !dsc_eligible(g, nwin, min_ntx)) { st[DSC_FAIL] = 1; return; }
+    if (done_all && (done_all[(size_t)f * done_stride + DSC_OK] || g.mlast == g.istep || g.method != 4)) { st[DSC_FAIL] = 100; return; }      /* resolved already; whole rows of tiles (k_dmin_* has those); MINIMUM (its walks never rejoin: five residue classes) */
     const size_t nwords = z_words - 1;
     unsigned *wentc = wentc_all + (size_t)f * went_stride;
     unsigned pos = g.body, t = 0;
@@ -721,7 +726,7 @@ __global__ __launch_bounds__(256) void k_dsc_dtab(const unsigned *z_all, size_t 
     unsigned e = p - end;
     w++;
     int d = DSC_D_INVALID;
-    for (int h = 0; h < 128 && (int)w < nwin; h++) {
+    for (int h = 0; h < DSC_LIST && (int)w < nwin; h++) {
         if (wentc[2 * (size_t)w] == e) {
             const long long dd = (long long)(1u + j) - ((long long)wentc[2 * (size_t)w + 1] - (long long)c);
             if (dd > -16000 && dd < 16000 && 1u + j + 2u < (unsigned)g.ntx) d = (int)dd;
@@ -784,7 +789,7 @@ __global__ __launch_bounds__(64) void k_dsc_rows(const unsigned *z_all, size_t z
         if (j != DSC_J_INVALID) { head[r] = 1; c = c + 8 * ntx - (unsigned)j; r += 8; }       /* rows r + 1 .. r + 7: k_dsc_rowfill */
         else {
             const int d = dtab[c];
-            if (d == DSC_D_INVALID) { st[DSC_FAIL] = 9; return; }
+            if (d == DSC_D_INVALID) { st[DSC_FAIL] = 9; st[8] = r; st[9] = c; return; }      /* (st[8], st[9]: where, for EZHIP_DEC_SCAN=2) */
             c = c + ntx - (unsigned)d; r++;
         }
     }
@@ -813,7 +818,6 @@ __global__ __launch_bounds__(64) void k_dsc_rowfill(const unsigned *z_all, size_
 /* the stretch between the odd tile that ends row r and the window in which the real chain is canonical again.  One lane per row: tile by tile to the end of
  * the odd tile's window, then window by window through the speculation table until the entry is the canonical one -- the windows on the way are listed (window,
  * entry, first tile) and k_dsc_stretch2 writes their tiles, one lane per listed window.  rowmerge[r + 1] = the first tile that is canonical again */
-#define DSC_LIST 128
 __global__ __launch_bounds__(64) void k_dsc_stretch(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, unsigned *st_all, size_t st_stride,
                                                     const unsigned *tab_all, size_t tab_stride, const unsigned *wentc_all, size_t went_stride,
                                                     const unsigned *tpc_all, size_t tpc_stride, const unsigned *rowc_all, unsigned *rowmerge_all, size_t row_stride,
@@ -943,20 +947,23 @@ __global__ __launch_bounds__(64) void k_dsc_lastrow(const unsigned *z_all, size_
  * gives up on.  The form applies to what k_dsc_* left unresolved (dst[DSC_OK] == 0); ragged rows (a narrower last tile per row shifts everything behind it)
  * and streams of a few windows keep the serial chain kernel; dm[DM_NOTMINE] says which.
  * ============================================================================================================================================ */
-enum { DM_NOTMINE = 0, DM_W0, DM_WORDS = 8 };
+enum { DM_NOTMINE = 0, DM_W0, DM_RAGGED, DM_WORDS = 8 };      /* DM_RAGGED: the canonical chain of the composed ragged form (k_drg_*) is wanted */
 #define DM_MAXLEV 9
 struct DmPlan { int nlev; unsigned nblk[DM_MAXLEV + 1]; unsigned long long off[DM_MAXLEV + 1]; unsigned long long eoff[DM_MAXLEV + 1]; };      /* level l: blocks of 8^l windows; level 0 = windows */
 /* both methods and the planes of c_armn_compress32: what counts is that every tile of a row holds the same number of points */
 __device__ __forceinline__ bool dmin_eligible(const DecGeom &g, int nwin) { return g.mlast == g.istep && g.nty >= 2 && g.ntx >= 2 && nwin >= 64; }
-__global__ void k_dmin_init(const unsigned *z_all, size_t z_stride, int ni, int nj, unsigned *dm_all, size_t dm_stride, const unsigned *dst_all, size_t dst_stride, int nwin, int plain)
+__global__ void k_dmin_init(const unsigned *z_all, size_t z_stride, int ni, int nj, unsigned *dm_all, size_t dm_stride, const unsigned *dst_all, size_t dst_stride, int nwin, int plain,
+                            int ragged_min_ntx)
 {
     const int f = blockIdx.x;
     if (threadIdx.x) return;
     unsigned *dm = dm_all + (size_t)f * dm_stride;
     DecGeom g;
-    const bool ok = dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, plain) && dmin_eligible(g, nwin) && (int)(g.body / DW) + 17 < nwin &&
-                    !(dst_all && dst_all[(size_t)f * dst_stride + DSC_OK]);
-    dm[DM_NOTMINE] = ok ? 0u : 1u; dm[DM_W0] = 0;
+    const bool geom = dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, plain), todo = !(dst_all && dst_all[(size_t)f * dst_stride + DSC_OK]);
+    const bool ok = geom && dmin_eligible(g, nwin) && (int)(g.body / DW) + 17 < nwin && todo;
+    /* ragged rows of a PARALLELOGRAM stream or plane that the merged-exit form did not resolve: the same composition gives the CANONICAL chain (k_drg_*) */
+    const bool rag = geom && todo && g.method == 4 && g.mlast != g.istep && dsc_eligible(g, nwin, ragged_min_ntx) && (int)(g.body / DW) + 17 < nwin;
+    dm[DM_NOTMINE] = ok ? 0u : 1u; dm[DM_W0] = 0; dm[DM_RAGGED] = rag ? 1u : 0u;
 }
 /* level l + 1 from level l: T[l + 1][b][e] = the walk from entry e through blocks 8 b .. 8 b + 7 of level l: (exit, tiles).  Level 0 is the speculation table
  * (exit | tiles << 16 in one word), the levels above hold uint2 */
@@ -964,7 +971,7 @@ __global__ __launch_bounds__(256) void k_dmin_up(const unsigned *z_all, size_t z
                                                  const unsigned *tab_all, size_t tab_stride, uint2 *lev_all, size_t lev_stride, DmPlan pl, int l, int ext /* row stride of the tables */, int plain)
 {
     const int f = blockIdx.y;
-    if (dm_all[(size_t)f * dm_stride + DM_NOTMINE]) return;
+    if (dm_all[(size_t)f * dm_stride + DM_NOTMINE] && !dm_all[(size_t)f * dm_stride + DM_RAGGED]) return;
     const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     const unsigned b = (unsigned)(idx / (unsigned)ext), e0 = (unsigned)(idx % (unsigned)ext);
     if (b >= pl.nblk[l + 1]) return;
@@ -986,11 +993,11 @@ __global__ __launch_bounds__(256) void k_dmin_up(const unsigned *z_all, size_t z
  * to the next multiple of 8 ... and of every block of the top level.  Everything to the right of a seed follows from its parent in k_dmin_down; blocks to the left
  * of the start stay invalid */
 __global__ void k_dmin_top(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, unsigned *dm_all, size_t dm_stride, const unsigned *tab_all, size_t tab_stride,
-                           uint2 *lev_all, size_t lev_stride, unsigned *went_all, size_t went_stride, DmPlan pl, int ext, int plain)
+                           uint2 *lev_all, size_t lev_stride, unsigned *went_all, size_t went_stride, DmPlan pl, int ext, int plain, int ragged = 0 /* 1: the canonical chain of the ragged form, went_all = its array */)
 {
     const int f = blockIdx.x;
     unsigned *dm = dm_all + (size_t)f * dm_stride;
-    if (threadIdx.x || dm[DM_NOTMINE]) return;
+    if (threadIdx.x || (ragged ? !dm[DM_RAGGED] : dm[DM_NOTMINE])) return;
     const unsigned *z = z_all + (size_t)f * z_stride;
     DecGeom g;
     if (!dec_geom(g, z, ni, nj, plain)) return;
@@ -1003,7 +1010,7 @@ __global__ void k_dmin_top(const unsigned *z_all, size_t z_stride, size_t z_word
     went[2 * (size_t)w0] = pos - w0 * DW; went[2 * (size_t)w0 + 1] = 0;
     dm[DM_W0] = w0;
     while (pos < end0) { pos += (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.n_int); t++; }      /* (a row of >= 2 tiles and >= 64 windows: the first run does not end here... */
-    if ((long long)t >= (long long)g.ntx * (g.nty - 1)) { dm[DM_NOTMINE] = 1; return; }                           /* ... unless the field is tiny: leave it to the serial kernel) */
+    if (ragged ? (long long)t + 1 >= (long long)g.ntx : (long long)t >= (long long)g.ntx * (g.nty - 1)) { dm[ragged ? DM_RAGGED : DM_NOTMINE] = ragged ? 0u : 1u; return; }      /* ... unless the field is tiny: leave it to the serial kernel) */
     unsigned e = pos - end0, idx = w0 + 1;
     const int L = pl.nlev;
     for (int l = 0; l < L; l++) {
@@ -1023,10 +1030,10 @@ __global__ void k_dmin_top(const unsigned *z_all, size_t z_stride, size_t z_word
 }
 /* entries of level l from those of level l + 1; at level 0 they are the windows' (went) */
 __global__ __launch_bounds__(256) void k_dmin_down(const unsigned *dm_all, size_t dm_stride, const unsigned *tab_all, size_t tab_stride, uint2 *lev_all, size_t lev_stride,
-                                                   unsigned *went_all, size_t went_stride, DmPlan pl, int l, int ext)
+                                                   unsigned *went_all, size_t went_stride, DmPlan pl, int l, int ext, int ragged = 0)
 {
     const int f = blockIdx.y;
-    if (dm_all[(size_t)f * dm_stride + DM_NOTMINE]) return;
+    if (ragged ? !dm_all[(size_t)f * dm_stride + DM_RAGGED] : dm_all[(size_t)f * dm_stride + DM_NOTMINE]) return;
     const unsigned b = blockIdx.x * 256 + threadIdx.x;
     if (b >= pl.nblk[l + 1]) return;
     uint2 *lev = lev_all + (size_t)f * lev_stride;
@@ -1106,6 +1113,41 @@ __global__ __launch_bounds__(256) void k_dmin_lastrow(const unsigned *z_all, siz
         if (status) status[f] = broken ? -2 : 0;
         if (!broken && dst_all) dst_all[(size_t)f * dst_stride + DSC_OK] = 1u;      /* the serial chain kernel and its followers skip this field */
     }
+}
+
+/* ============================================================================================================================================
+ * RAGGED rows by composition (round 4, k_drg_*): PARALLELOGRAM streams and planes of c_armn_compress32 whose rows end on a narrower tile ((ni - 1) % 3 != 0) and
+ * that the merged-exit form gave up on (mantissa planes: tiles of ~185 bits do not merge within eight windows; short rows; noisy data).  That form consists of two
+ * halves: the CANONICAL chain (the walk from the first tile that never meets a row end), which it gets from merged exits of eight-window blocks, and the row
+ * recurrence on top of it (k_dsc_emit .. k_dsc_lastrow: the shift of the tile index per row end, the stretches between a row end and the rejoining point).  Only
+ * the first half needs merging -- and the composition of the windows' maps (k_dmin_up / top / down with the interior tile rule) yields the canonical entries of
+ * ALL windows without it.  So: canonical entries by composition into wentc, the count of canonical tiles (k_drg_ncanon), then the second half unchanged, on a
+ * state of its own; k_drg_done hands a resolved field to the kernels behind (dst[DSC_OK]).  A stretch rejoins the canonical chain after 16 windows on average in a
+ * mantissa plane (130 seen: DSC_LIST).
+ * ============================================================================================================================================ */
+__global__ void k_drg_ncanon(unsigned *st_all, size_t st_stride, const unsigned *dm_all, size_t dm_stride, const unsigned *tab_all, size_t tab_stride,
+                             const unsigned *wentc_all, size_t went_stride, int nwin, int ext)
+{
+    const int f = blockIdx.x;
+    if (threadIdx.x) return;
+    unsigned *st = st_all + (size_t)f * st_stride;
+    if (st[DSC_FAIL]) return;
+    if (!dm_all[(size_t)f * dm_stride + DM_RAGGED]) { st[DSC_FAIL] = 101; return; }
+    const unsigned *wentc = wentc_all + (size_t)f * went_stride;
+    const unsigned e = wentc[2 * (size_t)(nwin - 1)], t = wentc[2 * (size_t)(nwin - 1) + 1];
+    if (e >= (unsigned)ext) { st[DSC_FAIL] = 102; return; }
+    st[DSC_NCANON] = t + (tab_all[(size_t)f * tab_stride + (size_t)(nwin - 1) * DEXT + e] >> 16);
+}
+__global__ void k_drg_done(unsigned *dst_all, const unsigned *st2_all, size_t st_stride)
+{
+    const int f = blockIdx.x;
+    if (threadIdx.x == 0 && st2_all[(size_t)f * st_stride + DSC_OK]) dst_all[(size_t)f * st_stride + DSC_OK] = 1u;
+}
+/* the tile walk of a plane without the serial chain kernel behind it (the caller has a faster fallback: the host's walk): 0 stays 0, -2 stays, anything else 1 */
+__global__ void k_drg_verdict(const unsigned *dst_all, size_t st_stride, int *status)
+{
+    const int f = blockIdx.x;
+    if (threadIdx.x == 0 && !dst_all[(size_t)f * st_stride + DSC_OK] && status[f] != -2) status[f] = 1;
 }
 
 __global__ __launch_bounds__(256) void k_armn_dec_tiles(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj,
@@ -1252,10 +1294,10 @@ static size_t dmin_bytes(size_t nwin) { DmPlan pl; dmin_plan(&pl, nwin); return 
 extern "C" size_t packhip_armn_dec_work_bytes(int ni, int nj, size_t z_words)
 {
     const size_t n = (size_t)ni * nj, nwin = dec_nwin(z_words);
-    const size_t capc = dec_max_tiles(ni, nj) + DSC_MARGIN, nty = (size_t)(nj + 2) / 3 + 2;
+    const size_t capc = dec_max_tiles(ni, nj) + dsc_margin(dec_max_tiles(ni, nj)), nty = (size_t)(nj + 2) / 3 + 2;
     return al256(4 * dec_max_tiles(ni, nj)) + al256(2 * (n + 8)) + al256(2 * (size_t)DEC_BANDS * ni) + 2 * al256(4 * nwin * DEXT) + 2 * al256(8 * nwin) + 256
            /* the parallel form: canonical tile positions, shift changes, merged exits, block entries / counts, canonical window entries, rows, state */
-           + al256(4 * capc) + al256(2 * capc) + al256(2 * nwin) + 2 * al256(4 * (nwin / 8 + 2)) + 2 * al256(8 * nwin) + 4 * al256(4 * nty) + al256(12 * 128 * nty) + 2 * al256(4 * capc) + 256
+           + al256(4 * capc) + al256(2 * capc) + al256(2 * nwin) + 2 * al256(4 * (nwin / 8 + 2)) + 2 * al256(8 * nwin) + 4 * al256(4 * nty) + al256(12 * DSC_LIST * nty) + 2 * al256(4 * capc) + 256
            /* MINIMUM streams by composition: the tables of 8, 64, ... windows and the blocks' entries (k_dmin_*) */
            + dmin_bytes(nwin);
 }
@@ -1275,7 +1317,7 @@ extern "C" int packhip_armn_decode(unsigned *d_out, size_t out_stride_words, con
  * walk_only: stop behind k_armn_dec_emit (the bit position of every tile header, 32-bit, at the start of the work area); plain: the tile rule of a plane of
  * c_armn_compress32 */
 static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
-                      int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status, int phase, int plain, int walk_only);
+                      int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status, int phase, int plain, int walk_only, int no_serial = 0);
 extern "C" int packhip_armn_decode_phase(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
                                          int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status, int phase)
 {
@@ -1290,8 +1332,13 @@ extern "C" int packhip_armn_tile_walk(const unsigned *d_z, size_t z_words, int n
 {
     return dec_launch(NULL, 0, d_z, 0, z_words, ni, nj, 1, 0, d_work, 0, d_status, 0, 1, 1);
 }
+/* the same without the serial chain kernel behind the parallel forms: *d_status = 1 when none of them resolved the chain (the caller walks it on the host) */
+extern "C" int packhip_armn_tile_walk_parallel(const unsigned *d_z, size_t z_words, int ni, int nj, void *d_work, int *d_status)
+{
+    return dec_launch(NULL, 0, d_z, 0, z_words, ni, nj, 1, 0, d_work, 0, d_status, 0, 1, 1, 1);
+}
 static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
-                      int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status, int phase, int plain, int walk_only)
+                      int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status, int phase, int plain, int walk_only, int no_serial)
 {
     static int attr_done = 0;
     if (!attr_done) {
@@ -1312,7 +1359,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
     unsigned *tab8 = (unsigned *)wk;                        wk += al256(4 * (size_t)nwin * DEXT);
     unsigned *went = (unsigned *)wk;                        wk += al256(8 * (size_t)nwin);
     unsigned *went8 = (unsigned *)wk;                       wk += al256(8 * (size_t)nwin) + 256;
-    const size_t capc = (size_t)max_tiles + DSC_MARGIN, ntyc = (size_t)(nj + 2) / 3 + 2, nblk = (size_t)nwin / 8 + 2;
+    const size_t capc = (size_t)max_tiles + dsc_margin((size_t)max_tiles), ntyc = (size_t)(nj + 2) / 3 + 2, nblk = (size_t)nwin / 8 + 2;
     unsigned *tpc = (unsigned *)wk;                         wk += al256(4 * capc);
     short *dtab = (short *)wk;                              wk += al256(2 * capc);
     unsigned short *m8 = (unsigned short *)wk;              wk += al256(2 * (size_t)nwin);
@@ -1328,7 +1375,8 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
     int *jA = (int *)wk;                                    wk += al256(4 * capc);
     int *jB = (int *)wk;                                    wk += al256(4 * capc);
     unsigned *dst = (unsigned *)wk;                         wk += 128;
-    unsigned *dmst = (unsigned *)wk;                        wk += 128;
+    unsigned *dmst = (unsigned *)wk;                        wk += 64;
+    unsigned *dst2 = (unsigned *)wk;                        wk += 64;       /* (DSC_WORDS = 16 words; dmst: DM_WORDS = 8) */
     uint2 *dmlev = (uint2 *)wk;
     const char *scan_env = getenv("EZHIP_DEC_SCAN");
     const int scan = scan_env ? atoi(scan_env) : 1;          /* the chain between row ends in parallel (k_dsc_*, the default since the end of round 3); the serial chain
@@ -1351,6 +1399,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
     }
     if (phase == 1) { hipError_t e1 = hipGetLastError(); if (e1 != hipSuccess) { fprintf(stderr, "<armn_compress> UNCOMPRESS launch failed: %s\n", hipGetErrorString(e1)); return -1; } return 0; }
     const unsigned *skip = NULL;
+    if (no_serial && hipMemsetAsync(d_status, 0, 4 * (size_t)nfields, st) != hipSuccess) return -1;
     if (scan) {
         const int ext_max = DEXT;                            /* (the kernels read the geometry from the stream; here ext only bounds a table row) */
         for (int f = 0; f < nfields; f++) {
@@ -1360,9 +1409,9 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
         }
         const size_t ws2b = work_stride_bytes / 2;
         hipLaunchKernelGGL(k_dsc_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, wentc, ws4, nwin, plain,
-                           /* a plane of c_armn_compress32 with whole rows of tiles goes straight to the composed form below (the parallel form's kernels then see FAIL and
+                           /* a plane of c_armn_compress32 goes straight to the composed forms below (the parallel form's kernels then see FAIL and
                             * leave at once): its mantissa tiles (~185 bits) do not merge within eight windows, the attempt cost ~1 ms per plane */
-                           (plain && (ni - 1) % 3 == 0 && !getenv("EZHIP_DEC_NO_DMIN")) ? 0x7fffffff : getenv("EZHIP_DEC_SCAN_MIN_NTX") ? atoi(getenv("EZHIP_DEC_SCAN_MIN_NTX")) : 768);       /* (rows of 853 tiles: 0.65 against 0.65 - 1.1 ms; of 480: the form gives up and costs 0.2 ms more than it saves) */
+                           (plain && !getenv("EZHIP_DEC_NO_DMIN")) ? 0x7fffffff : getenv("EZHIP_DEC_SCAN_MIN_NTX") ? atoi(getenv("EZHIP_DEC_SCAN_MIN_NTX")) : 768);       /* (rows of 853 tiles: 0.65 against 0.65 - 1.1 ms; of 480: the form gives up and costs 0.2 ms more than it saves) */
         hipLaunchKernelGGL(k_dsc_m8, dim3((nwin + 3) / 4, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, tab8, ws4, m8, ws2b, nwin, plain);
         hipLaunchKernelGGL(k_dsc_blocks, dim3((unsigned)((nblk + 255) / 256), nfields), dim3(256), 0, st, dst, ws4, tab8, ws4, m8, ws2b, eblk, cblk, ws4, ext_max);
         hipLaunchKernelGGL(k_dsc_scan, dim3(nfields), dim3(1024), 0, st, dst, ws4, tab, ws4, eblk, cblk, ws4, wentc, wentc8, ws4, nwin, ext_max);
@@ -1387,7 +1436,10 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
             DmPlan pl;
             dmin_plan(&pl, (size_t)nwin);
             const size_t ws8 = work_stride_bytes / 8;
-            hipLaunchKernelGGL(k_dmin_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dmst, ws4, dst, ws4, nwin, plain);
+            const int rag_min_ntx = getenv("EZHIP_DEC_NO_RAGGED") ? 0x7fffffff : getenv("EZHIP_DEC_RAGGED_MIN_NTX") ? atoi(getenv("EZHIP_DEC_RAGGED_MIN_NTX")) : plain ? 256 : 768;
+            /* (rows the stretches fit in: a mantissa plane rejoins after ~150 tiles on average, 1000 seen; for armn_compress streams the threshold of the first form: the
+             * composed form is its second chance on long rows whose eight-window blocks do not merge.  tools: EZHIP_DEC_SCAN=2 prints both verdicts) */
+            hipLaunchKernelGGL(k_dmin_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dmst, ws4, dst, ws4, nwin, plain, rag_min_ntx);
             for (int l = 0; l < pl.nlev; l++)
                 hipLaunchKernelGGL(k_dmin_up, dim3((unsigned)(((unsigned long long)pl.nblk[l + 1] * DEXT + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dmst, ws4, tab, ws4, dmlev, ws8, pl, l, DEXT, plain);
             if (pl.nlev >= 1) {
@@ -1398,6 +1450,32 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
                     hipLaunchKernelGGL(k_dmin_down, dim3((pl.nblk[l + 1] + 255) / 256, nfields), dim3(256), 0, st, dmst, ws4, tab, ws4, dmlev, ws8, went, ws4, pl, l, DEXT);
                 hipLaunchKernelGGL(k_dmin_lastrow, dim3(nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dmst, ws4, went, ws4, tilepos, ws4, nwin, d_status, dst, ws4, plain);
                 hipLaunchKernelGGL(k_armn_dec_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, went, ws4, tilepos, ws4, nwin, plain, dmst, ws4);
+                if (rag_min_ntx != 0x7fffffff && ((ni - 1) % 3 != 0)) {
+                    /* ragged rows the first form left unresolved: the canonical chain by composition (into wentc), then the row recurrence of the first form on
+                     * a state of its own (k_drg_* above) */
+                    for (int f = 0; f < nfields; f++)
+                        if (hipMemsetAsync((char *)wentc + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
+                    hipLaunchKernelGGL(k_dsc_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, wentc, ws4, nwin, plain, rag_min_ntx, (const unsigned *)dst, ws4);
+                    hipLaunchKernelGGL(k_dmin_top, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dmst, ws4, tab, ws4, dmlev, ws8, wentc, ws4, pl, DEXT, plain, 1);
+                    for (int l = pl.nlev - 1; l >= 0; l--)
+                        hipLaunchKernelGGL(k_dmin_down, dim3((pl.nblk[l + 1] + 255) / 256, nfields), dim3(256), 0, st, dmst, ws4, tab, ws4, dmlev, ws8, wentc, ws4, pl, l, DEXT, 1);
+                    hipLaunchKernelGGL(k_drg_ncanon, dim3(nfields), dim3(64), 0, st, dst2, ws4, dmst, ws4, tab, ws4, wentc, ws4, nwin, ext_max);
+                    hipLaunchKernelGGL(k_dsc_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, wentc, ws4, tpc, ws4, (unsigned)capc, nwin, plain);
+                    hipLaunchKernelGGL(k_dsc_dtab, dim3((unsigned)((capc + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, tab, ws4, wentc, ws4, tpc, ws4, dtab, ws2b, (unsigned)capc, nwin, plain);
+                    const dim3 gj((unsigned)((capc + 255) / 256), nfields);
+                    hipLaunchKernelGGL(k_dsc_jump<short>, gj, dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, dtab, ws2b, jA, ws4, 1u, (unsigned)capc, plain);
+                    hipLaunchKernelGGL(k_dsc_jump<int>, gj, dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, jA, ws4, jB, ws4, 2u, (unsigned)capc, plain);
+                    hipLaunchKernelGGL(k_dsc_jump<int>, gj, dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, jB, ws4, jA, ws4, 4u, (unsigned)capc, plain);
+                    for (int f = 0; f < nfields; f++)
+                        if (hipMemsetAsync((char *)rowhead + (size_t)f * work_stride_bytes, 0, 4 * ntyc, st) != hipSuccess) return -1;
+                    hipLaunchKernelGGL(k_dsc_rows, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, dtab, ws2b, jA, ws4, rowc, rowhead, ws4, (unsigned)capc, plain);
+                    hipLaunchKernelGGL(k_dsc_rowfill, dim3((unsigned)((ntyc + 63) / 64), nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, dtab, ws2b, rowc, rowhead, ws4, (unsigned)capc, plain);
+                    hipLaunchKernelGGL(k_dsc_stretch, dim3((unsigned)((ntyc + 63) / 64), nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, tab, ws4, wentc, ws4, tpc, ws4, rowc, rowmerge, ws4, slist, nlist, ws4, tilepos, ws4, nwin, plain);
+                    hipLaunchKernelGGL(k_dsc_stretch2, dim3((unsigned)((ntyc * DSC_LIST + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, slist, nlist, ws4, ws4, tilepos, ws4, plain);
+                    hipLaunchKernelGGL(k_dsc_final, dim3((unsigned)((max_tiles + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, tpc, ws4, rowc, rowmerge, ws4, tilepos, ws4, plain);
+                    hipLaunchKernelGGL(k_dsc_lastrow, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, tpc, ws4, rowc, ws4, tilepos, ws4, d_status, plain);
+                    hipLaunchKernelGGL(k_drg_done, dim3(nfields), dim3(64), 0, st, dst, dst2, ws4);
+                }
             }
         }
         skip = dst;                                          /* dst[DSC_OK] of a field: 1 when its tile positions are complete */
@@ -1407,8 +1485,16 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
                 if (hipMemcpyAsync(h, dst + (size_t)f * ws4, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
                 fprintf(stderr, "<armn_compress> scan form, field %d: ok %u fail %u  first block window %u entry %u tiles %u  blocks %u  canonical tiles %u  interior rows %u\n",
                         f, h[DSC_OK], h[DSC_FAIL], h[DSC_WB], h[DSC_EB], h[DSC_TB], h[DSC_K], h[DSC_NCANON], h[DSC_RINT]);
+                if (hipMemcpyAsync(h, dst2 + (size_t)f * ws4, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+                fprintf(stderr, "<armn_compress> composed ragged form, field %d: ok %u fail %u  canonical tiles %u  interior rows %u  (row %u, canonical tile %u)\n", f, h[DSC_OK], h[DSC_FAIL], h[DSC_NCANON], h[DSC_RINT], h[8], h[9]);
             }
         }
+    }
+    if (no_serial) {
+        if (!scan) return -1;
+        hipLaunchKernelGGL(k_drg_verdict, dim3(nfields), dim3(64), 0, st, dst, ws4, d_status);
+        hipError_t e3 = hipGetLastError(); if (e3 != hipSuccess) { fprintf(stderr, "<armn_compress> tile walk launch failed: %s\n", hipGetErrorString(e3)); return -1; }
+        return 0;
     }
     hipLaunchKernelGGL(k_armn_dec_hop, dim3(nfields), dim3(HOP_TPB), HOP_LDS, st, d_z, z_stride_words, z_words, ni, nj, tab, tab8, ws4, went, went8, ws4, nwin, d_status, getenv("EZHIP_DEC_DEBUG") ? atoi(getenv("EZHIP_DEC_DEBUG")) : 0, plain, skip, ws4);
     hipLaunchKernelGGL(k_armn_dec_expand8, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, ws4, went, went8, ws4, nwin, skip, ws4);

@@ -236,6 +236,20 @@ def armn_uncompress32_lng(z, zbytes, ni, nj, znbits):
     return rc, out
 
 
+def armn_compress32_dev(d_z, d_fld, ni, nj, znbits):
+    """c_armn_compress32_dev: torch CUDA float32 field -> record in the torch CUDA int32 buffer d_z (ni*nj + 64 words); returns the byte count or -1"""
+    L = _lib()
+    L.c_armn_compress32_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    return L.c_armn_compress32_dev(d_z.data_ptr(), d_fld.data_ptr(), ni, nj, 1, znbits)
+
+
+def armn_uncompress32_zdev(d_fld, d_z, zbytes, ni, nj, znbits):
+    """c_armn_uncompress32_zdev: record and field both torch CUDA tensors; returns ni*nj or -1"""
+    L = _lib()
+    L.c_armn_uncompress32_zdev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    return L.c_armn_uncompress32_zdev(d_fld.data_ptr(), d_z.data_ptr(), int(zbytes), ni, nj, 1, znbits)
+
+
 def fst_pack_data(field, ni, nj, nk, datyp, nbits):
     """the data part of an FST record (c_fstecr's packing switch): returns (words, datyp_out, nbits_out, uint32 buffer).  The element size is the
     array's (float32 / int32 / uint32: 4, float64: 8, int16 / uint16: 2, int8 / uint8: 1); datyp may carry the missing-value flag (+64)"""

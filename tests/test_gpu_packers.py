@@ -1054,3 +1054,98 @@ def test_armn_uncompress32_sign_runs_on_the_device(ni, nj, kind):
         assert np.array_equal(back2.view(np.uint32), f.view(np.uint32)), host
         outs.append(back)
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("ni,nj", [(301, 220), (300, 220), (1600, 801), (2560, 1280)])
+@pytest.mark.parametrize("kind", ["positive", "mixed"])
+def test_armn_uncompress32_record_and_field_on_the_device(ni, nj, kind):
+    """c_armn_uncompress32_zdev: the record stays where c_armn_compress32_dev wrote it (HBM), the field comes back in HBM.  Whole-tile rows resolve on the
+    device, ragged rows send the record down for the host's walk: both give the field's bits, and the device-written record equals the host entry's"""
+    import torch
+    f = ta32.field32(ni, nj, kind, seed=5 * ni + nj)
+    zl, z = pk.armn_compress32(f, ni, nj, 32)
+    d_f = torch.from_numpy(f).cuda()
+    d_z = torch.zeros(ni * nj + 64, dtype=torch.int32, device="cuda")
+    zl_dev = pk.armn_compress32_dev(d_z, d_f, ni, nj, 32)
+    assert zl_dev == zl
+    if zl < 0:
+        pytest.skip("not compressible at this size")
+    nw = (zl + 3) // 4
+    assert np.array_equal(d_z[:nw].cpu().numpy().view(np.uint32), z[:nw])
+    d_back = torch.full((ni * nj,), -7.0, dtype=torch.float32, device="cuda")
+    before = d_z.clone()
+    assert pk.armn_uncompress32_zdev(d_back, d_z, 4 * nw, ni, nj, 32) == ni * nj
+    assert np.array_equal(d_back.cpu().numpy().view(np.uint32), f.view(np.uint32))
+    assert torch.equal(before, d_z)                                   # the caller's record is read only
+    assert pk.armn_uncompress32_zdev(d_back, d_z, 4 * (nw // 2), ni, nj, 32) == -1        # half a record
+    d_bad = d_z.clone(); d_bad[0] = 0x7                               # not a PARALLELOGRAM32 record
+    assert pk.armn_uncompress32_zdev(d_back, d_bad, 4 * nw, ni, nj, 32) == -1
+
+
+RAGGED_SHAPES = [(902, 400), (1502, 300), (1001, 298), (3077, 130), (3002, 700)]      # (ni - 1) % 3 != 0: a narrower last tile per row; with and without a last row of another height
+
+
+@pytest.mark.parametrize("ni,nj", RAGGED_SHAPES)
+@pytest.mark.parametrize("kind", ["smooth", "noisy", "bigdiff"])
+@pytest.mark.parametrize("mode", ["composed_only", "default", "ragged_off"])
+def test_armn_uncompress_ragged_rows_by_composition(ni, nj, kind, mode, monkeypatch, capfd):
+    """PARALLELOGRAM streams with ragged rows of tiles through the composed ragged form (k_drg_*: the canonical chain from the composition of the windows' maps, then
+    the row recurrence): pushed onto every stream (the merged-exit form switched off through its row-length threshold), the default order of the forms, and
+    the form switched off (merged-exit form or serial chain kernel): the oracle's tokens every time.  EZHIP_DEC_SCAN=2 prints each form's verdict: in the
+    first mode the composed form has to be the one that resolved the chain"""
+    if mode == "composed_only":
+        monkeypatch.setenv("EZHIP_DEC_SCAN_MIN_NTX", "1000000"); monkeypatch.setenv("EZHIP_DEC_SCAN", "2"); monkeypatch.setenv("EZHIP_DEC_RAGGED_MIN_NTX", "96")
+    if mode == "ragged_off":
+        monkeypatch.setenv("EZHIP_DEC_NO_RAGGED", "1")
+    nbits = 16
+    tok = pc.token_field(ni, nj, nbits, kind, seed=2 * ni + nj)
+    z, zlng = _oracle_stream(tok, ni, nj, nbits, 1)
+    zwords = (zlng - 1) // 4 + 1
+    d_z = torch.from_numpy(z[:zwords].view(np.int32).copy()).cuda()
+    d_out = torch.full((1 + ni * nj // 2 + 4,), -1, dtype=torch.int32, device="cuda")
+    assert pk.armn_uncompress_dev(d_out, d_z, zwords, ni, nj, nbits) == ni * nj * 2
+    got = d_out.cpu().numpy().view(np.uint32)
+    words = pc.tokens_to_words(tok)
+    assert np.array_equal(got[:words.size], words), np.nonzero(got[:words.size] != words)[0][:5]
+    assert np.all(got[1 + ni * nj // 2:] == 0xFFFFFFFF)
+    if mode == "composed_only":
+        err = capfd.readouterr().err
+        assert "composed ragged form, field 0:" in err, err[-600:]
+        # rows of tiles shorter than a stretch, long runs of empty tiles, escape tiles: the form may give up (the serial chain kernel then runs); these it resolves
+        if (ni, nj, kind) in ((3077, 130, "smooth"), (3077, 130, "noisy"), (1502, 300, "smooth"), (3002, 700, "smooth")):
+            assert "composed ragged form, field 0: ok 1" in err, err[-600:]
+
+
+@pytest.mark.parametrize("ni,nj", [(1001, 600), (2000, 1000), (2561, 1281), (3002, 700)])
+@pytest.mark.parametrize("kind", ["positive", "mixed"])
+def test_armn_uncompress32_ragged_rows_on_the_device(ni, nj, kind, capfd):
+    """the exponent and mantissa planes of a field whose rows of tiles end on a narrower tile: chains by composition + row recurrence on the device (the default
+    for rows of >= 256 tiles), forced on, and the host's walk: the field's bits every time; record in host memory and in HBM.  With EZHIP_DEC_SCAN=2 the
+    device's verdict is printed: the composed ragged form resolves both planes"""
+    import torch
+    f = ta32.field32(ni, nj, kind, seed=ni + 2 * nj)
+    zl, z = pk.armn_compress32(f, ni, nj, 32)
+    assert zl > 0
+    nw = (zl + 3) // 4
+    for route in ("default", "0", "1"):
+        if route != "default":
+            os.environ["EZHIP_A32_DEVICE_WALK"] = route
+        try:
+            rc, back = pk.armn_uncompress32_lng(z, 4 * nw, ni, nj, 32)
+        finally:
+            os.environ.pop("EZHIP_A32_DEVICE_WALK", None)
+        assert rc == ni * nj, (kind, route)
+        assert np.array_equal(back.view(np.uint32), f.view(np.uint32)), (kind, route)
+    d_z = torch.from_numpy(z[:nw + 64].view(np.int32).copy()).cuda()
+    d_back = torch.zeros(ni * nj, dtype=torch.float32, device="cuda")
+    capfd.readouterr()
+    os.environ["EZHIP_A32_DEVICE_WALK"] = "1"; os.environ["EZHIP_DEC_SCAN"] = "2"
+    try:
+        assert pk.armn_uncompress32_zdev(d_back, d_z, 4 * nw, ni, nj, 32) == ni * nj
+    finally:
+        os.environ.pop("EZHIP_A32_DEVICE_WALK", None); os.environ.pop("EZHIP_DEC_SCAN", None)
+    assert np.array_equal(d_back.cpu().numpy().view(np.uint32), f.view(np.uint32))
+    err = capfd.readouterr().err
+    assert "composed ragged form, field 0:" in err, err[-800:]      # (each plane's verdict; a plane it leaves open is walked on the host)
+    rc, _ = pk.armn_uncompress32_lng(z, 4 * (nw // 2), ni, nj, 32)          # half the record
+    assert rc == -1
