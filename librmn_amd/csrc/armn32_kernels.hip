@@ -291,24 +291,41 @@ __global__ __launch_bounds__(256) void k_pg_dec_prefix(int *D, const unsigned *z
     else if (t < ni) D[t] = tok(t) - tok(t - 1);
     else { const int j = t - ni + 1; D[(size_t)j * ni] = tok(t) - (j == 1 ? tok(0) : tok(t - 1)); }
 }
-/* inclusive prefix sum along i, one block per row */
+/* inclusive prefix sum along i, one block per row: 1024 elements per step as four coalesced sub-chunks of 256 (wave scans by shuffles, the sixteen wave totals
+ * through LDS, one barrier per step).  (The first version gave every thread a contiguous 29-element piece -- two passes of strided accesses: 561 us per
+ * 7200 x 3601 plane against ~50 here.) */
 __global__ __launch_bounds__(256) void k_pg_rowscan(int *D, int ni)
 {
-    __shared__ int part[256];
+    __shared__ int wsum[2][16];
     int *row = D + (size_t)blockIdx.x * ni;
-    const int per = (ni + 255) / 256, i0 = threadIdx.x * per, i1 = min(i0 + per, ni);
-    int s = 0;
-    for (int i = i0; i < i1; i++) s += row[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int carry = 0;
+    for (int base = 0, it = 0; base < ni; base += 1024, it++) {
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int i = base + k * 256 + t; v[k] = i < ni ? row[i] : 0; }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int u = __shfl_up(v[k], o, 64); if (lane >= o) v[k] += u; }
+        }
+        int *ws = wsum[it & 1];
+        if (lane == 63) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) ws[k * 4 + wv] = v[k];
+        }
         __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
+        int run = carry;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int off = run;
+#pragma unroll
+            for (int w = 0; w < 4; w++) { const int s = ws[k * 4 + w]; if (w < wv) off += s; run += s; }
+            const int i = base + k * 256 + t;
+            if (i < ni) row[i] = v[k] + off;
+        }
+        carry = run;
     }
-    int run = part[threadIdx.x] - s;
-    for (int i = i0; i < i1; i++) { run += row[i]; row[i] = run; }
 }
 /* column sums in bands of PG_BAND rows: band totals, their exclusive scan per column, then the running sums */
 #define PG_BAND 32

@@ -1390,7 +1390,8 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
         if (hipMemsetAsync((char *)went8 + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
     }
     hipLaunchKernelGGL(k_armn_dec_spec, dim3((nwin + SPEC_WPB - 1) / SPEC_WPB, nfields), dim3(64 * SPEC_WPB), 0, st, d_z, z_stride_words, z_words, ni, nj, tab, ws4, nwin, plain);
-    if (getenv("EZHIP_DEC_COMPOSE_GLOBAL"))        /* development: eight dependent global loads per entry (rounds 1 - 2) */
+    if (plain && no_serial) { }                     /* (the eight-window tables serve the merged-exit form and the serial chain kernel: neither runs for a plane walked this way) */
+    else if (getenv("EZHIP_DEC_COMPOSE_GLOBAL"))        /* development: eight dependent global loads per entry (rounds 1 - 2) */
         hipLaunchKernelGGL(k_armn_dec_compose, dim3(nwin, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, tab8, ws4, nwin);
     else {
         const int G = 28, lds_words = (3 * G + 17) * 160;          /* 64 640 B: G windows of 160-entry rows (t1: G + 7 rows, t2: G + 6, t4: G + 4) */
@@ -1412,6 +1413,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
                            /* a plane of c_armn_compress32 goes straight to the composed forms below (the parallel form's kernels then see FAIL and
                             * leave at once): its mantissa tiles (~185 bits) do not merge within eight windows, the attempt cost ~1 ms per plane */
                            (plain && !getenv("EZHIP_DEC_NO_DMIN")) ? 0x7fffffff : getenv("EZHIP_DEC_SCAN_MIN_NTX") ? atoi(getenv("EZHIP_DEC_SCAN_MIN_NTX")) : 768);       /* (rows of 853 tiles: 0.65 against 0.65 - 1.1 ms; of 480: the form gives up and costs 0.2 ms more than it saves) */
+        if (!(plain && !getenv("EZHIP_DEC_NO_DMIN"))) {        /* (a plane: k_dsc_init has just said FAIL, the composed forms below take it) */
         hipLaunchKernelGGL(k_dsc_m8, dim3((nwin + 3) / 4, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, tab8, ws4, m8, ws2b, nwin, plain);
         hipLaunchKernelGGL(k_dsc_blocks, dim3((unsigned)((nblk + 255) / 256), nfields), dim3(256), 0, st, dst, ws4, tab8, ws4, m8, ws2b, eblk, cblk, ws4, ext_max);
         hipLaunchKernelGGL(k_dsc_scan, dim3(nfields), dim3(1024), 0, st, dst, ws4, tab, ws4, eblk, cblk, ws4, wentc, wentc8, ws4, nwin, ext_max);
@@ -1430,6 +1432,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
         hipLaunchKernelGGL(k_dsc_stretch2, dim3((unsigned)((ntyc * DSC_LIST + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, slist, nlist, ws4, ws4, tilepos, ws4, plain);
         hipLaunchKernelGGL(k_dsc_final, dim3((unsigned)((max_tiles + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, tpc, ws4, rowc, rowmerge, ws4, tilepos, ws4, plain);
         hipLaunchKernelGGL(k_dsc_lastrow, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, tpc, ws4, rowc, ws4, tilepos, ws4, d_status, plain);
+        }
         if (!getenv("EZHIP_DEC_NO_DMIN")) {
             /* streams whose tiles all hold the same number of points up to the last row (MINIMUM with ni a multiple of 5, PARALLELOGRAM and the planes of
              * c_armn_compress32 with ni - 1 a multiple of 3) that the form above did not resolve: the chain by composition of the windows' maps (k_dmin_*) */
