@@ -1400,6 +1400,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
     }
     if (phase == 1) { hipError_t e1 = hipGetLastError(); if (e1 != hipSuccess) { fprintf(stderr, "<armn_compress> UNCOMPRESS launch failed: %s\n", hipGetErrorString(e1)); return -1; } return 0; }
     const unsigned *skip = NULL;
+    int all_ok_known = 0;                                    /* every field's chain resolved by a parallel form (known when the verdicts were read back) */
     if (no_serial && hipMemsetAsync(d_status, 0, 4 * (size_t)nfields, st) != hipSuccess) return -1;
     if (scan) {
         const int ext_max = DEXT;                            /* (the kernels read the geometry from the stream; here ext only bounds a table row) */
@@ -1433,7 +1434,28 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
         hipLaunchKernelGGL(k_dsc_final, dim3((unsigned)((max_tiles + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, tpc, ws4, rowc, rowmerge, ws4, tilepos, ws4, plain);
         hipLaunchKernelGGL(k_dsc_lastrow, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, tpc, ws4, rowc, ws4, tilepos, ws4, d_status, plain);
         }
-        if (!getenv("EZHIP_DEC_NO_DMIN")) {
+        /* What is still to do?  The two composed forms below are second chances: ~35 launches that leave at once when the first form resolved every field --
+         * ~125 us of dispatches behind a 1 ms decode.  For a plane the geometry says which of them applies; for armn_compress streams the fields' verdicts and
+         * methods are read back (one small copy, one wait: ~20 us) and the forms nobody needs are not launched.  EZHIP_DEC_ASYNC=1: no read-back, everything queued */
+        int want_whole = 1, want_ragged = 1, all_ok = 0;
+        if (plain) { want_whole = (ni - 1) % 3 == 0; want_ragged = !want_whole; }
+        else if (!getenv("EZHIP_DEC_ASYNC") && nfields <= 256) {
+            unsigned hv[2 * 256];
+            hipError_t ec = nfields == 1 ? hipMemcpyAsync(hv, dst, 4, hipMemcpyDeviceToHost, st)
+                                         : hipMemcpy2DAsync(hv, 4, dst, work_stride_bytes, 4, (size_t)nfields, hipMemcpyDeviceToHost, st);
+            if (ec == hipSuccess) ec = nfields == 1 ? hipMemcpyAsync(hv + 256, d_z, 4, hipMemcpyDeviceToHost, st)
+                                                    : hipMemcpy2DAsync(hv + 256, 4, d_z, 4 * z_stride_words, 4, (size_t)nfields, hipMemcpyDeviceToHost, st);
+            if (ec != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { fprintf(stderr, "<armn_compress> UNCOMPRESS: reading the verdicts back failed\n"); return -1; }
+            want_whole = want_ragged = 0; all_ok = 1;
+            for (int f = 0; f < nfields; f++) {
+                if (hv[f]) continue;                              /* dst[DSC_OK] */
+                all_ok = 0;
+                const unsigned method = hv[256 + f] & 15u;
+                if (method == 4) { if ((ni - 1) % 3 == 0) want_whole = 1; else want_ragged = 1; }
+                else if (method == 3 && ni % 5 == 0) want_whole = 1;
+            }
+        }
+        if (!getenv("EZHIP_DEC_NO_DMIN") && (want_whole || want_ragged)) {
             /* streams whose tiles all hold the same number of points up to the last row (MINIMUM with ni a multiple of 5, PARALLELOGRAM and the planes of
              * c_armn_compress32 with ni - 1 a multiple of 3) that the form above did not resolve: the chain by composition of the windows' maps (k_dmin_*) */
             DmPlan pl;
@@ -1448,12 +1470,14 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
             if (pl.nlev >= 1) {
                 for (int f = 0; f < nfields; f++)          /* the blocks' entries start out invalid (small: one uint2 per block of every level) */
                     if (hipMemsetAsync((char *)(dmlev + pl.eoff[1]) + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)(pl.off[0] - pl.eoff[1]), st) != hipSuccess) return -1;
+                if (want_whole) {
                 hipLaunchKernelGGL(k_dmin_top, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dmst, ws4, tab, ws4, dmlev, ws8, went, ws4, pl, DEXT, plain);
                 for (int l = pl.nlev - 1; l >= 0; l--)
                     hipLaunchKernelGGL(k_dmin_down, dim3((pl.nblk[l + 1] + 255) / 256, nfields), dim3(256), 0, st, dmst, ws4, tab, ws4, dmlev, ws8, went, ws4, pl, l, DEXT);
                 hipLaunchKernelGGL(k_dmin_lastrow, dim3(nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dmst, ws4, went, ws4, tilepos, ws4, nwin, d_status, dst, ws4, plain);
                 hipLaunchKernelGGL(k_armn_dec_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, went, ws4, tilepos, ws4, nwin, plain, dmst, ws4);
-                if (rag_min_ntx != 0x7fffffff && ((ni - 1) % 3 != 0)) {
+                }
+                if (want_ragged && rag_min_ntx != 0x7fffffff && ((ni - 1) % 3 != 0)) {
                     /* ragged rows the first form left unresolved: the canonical chain by composition (into wentc), then the row recurrence of the first form on
                      * a state of its own (k_drg_* above) */
                     for (int f = 0; f < nfields; f++)
@@ -1482,6 +1506,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
             }
         }
         skip = dst;                                          /* dst[DSC_OK] of a field: 1 when its tile positions are complete */
+        all_ok_known = all_ok;
         if (scan == 2) {                                     /* development: the state words of every field */
             unsigned h[DSC_WORDS];
             for (int f = 0; f < nfields; f++) {
@@ -1499,9 +1524,11 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
         hipError_t e3 = hipGetLastError(); if (e3 != hipSuccess) { fprintf(stderr, "<armn_compress> tile walk launch failed: %s\n", hipGetErrorString(e3)); return -1; }
         return 0;
     }
+    if (!all_ok_known) {
     hipLaunchKernelGGL(k_armn_dec_hop, dim3(nfields), dim3(HOP_TPB), HOP_LDS, st, d_z, z_stride_words, z_words, ni, nj, tab, tab8, ws4, went, went8, ws4, nwin, d_status, getenv("EZHIP_DEC_DEBUG") ? atoi(getenv("EZHIP_DEC_DEBUG")) : 0, plain, skip, ws4);
     hipLaunchKernelGGL(k_armn_dec_expand8, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, ws4, went, went8, ws4, nwin, skip, ws4);
     hipLaunchKernelGGL(k_armn_dec_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, went, ws4, tilepos, ws4, nwin, plain, skip, ws4);
+    }
     if (walk_only) { hipError_t e2 = hipGetLastError(); if (e2 != hipSuccess) { fprintf(stderr, "<armn_compress> tile walk launch failed: %s\n", hipGetErrorString(e2)); return -1; } return 0; }
     const long long grid_tiles = max_tiles > (long long)(ni + nj) ? max_tiles : (long long)(ni + nj);
     hipLaunchKernelGGL(k_armn_dec_tiles, dim3((unsigned)((grid_tiles + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj,
