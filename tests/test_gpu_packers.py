@@ -1149,3 +1149,34 @@ def test_armn_uncompress32_ragged_rows_on_the_device(ni, nj, kind, capfd):
     assert "composed ragged form, field 0:" in err, err[-800:]      # (each plane's verdict; a plane it leaves open is walked on the host)
     rc, _ = pk.armn_uncompress32_lng(z, 4 * (nw // 2), ni, nj, 32)          # half the record
     assert rc == -1
+
+
+@pytest.mark.parametrize("ni,nj", [(2000, 1000), (1600, 801)])
+def test_armn_uncompress32_damaged_records_device_and_host_routes_agree(ni, nj):
+    """bit flips and a zeroed piece inside the planes of a record (ragged rows: composition + row recurrence; whole rows: composition): the device route and the
+    host's walk read the same damaged stream the same way -- same return code, same bits when one comes back -- and nothing faults"""
+    f = ta32.field32(ni, nj, "mixed", seed=77)
+    zl, z = pk.armn_compress32(f, ni, nj, 32)
+    assert zl > 0
+    nw = (zl + 3) // 4
+    rng = np.random.default_rng(5)
+    for damage in ("bit_flips", "zeroed_piece", "late_flip"):
+        d = z.copy()
+        if damage == "bit_flips":
+            for w in rng.integers(nw // 8, nw - 8, 6):
+                d[w] ^= np.uint32(1 << int(rng.integers(0, 32)))
+        elif damage == "zeroed_piece":
+            a = int(nw * 0.6); d[a:a + 300] = 0
+        else:
+            d[nw - 40] ^= np.uint32(0x00010000)
+        res = []
+        for route in ("0", "1"):
+            os.environ["EZHIP_A32_DEVICE_WALK"] = route
+            try:
+                rc, back = pk.armn_uncompress32_lng(d, 4 * nw, ni, nj, 32)
+            finally:
+                os.environ.pop("EZHIP_A32_DEVICE_WALK", None)
+            res.append((rc, back))
+        assert res[0][0] == res[1][0], (damage, res[0][0], res[1][0])
+        if res[0][0] > 0:
+            assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32)), damage
