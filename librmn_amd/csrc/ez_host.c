@@ -2471,7 +2471,11 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
         nj_rows = gi->j2 - gi->j1 + 1;
         d_poles_pre = NULL; pp.polevals = d_poles;          /* pole values of the EXPANDED field */
     }
-    if (zones == 1 && !vector_mode && !d_poles_pre && ezhip_polevals(d_poles, d_zin, gi->ni, nj_rows, pp.pole_weighted, gi->d_ax)) return -1;
+    /* the field's pole values: two producer blocks of the k_pts launch (EZHIP_PTS_POLEVALS_FIRST=1: the separate launch in front, as before) */
+    if (zones == 1 && !vector_mode && !d_poles_pre) {
+        if (getenv("EZHIP_PTS_POLEVALS_FIRST")) { if (ezhip_polevals(d_poles, d_zin, gi->ni, nj_rows, pp.pole_weighted, gi->d_ax)) return -1; }
+        else { pp.pv_out = d_poles; pp.pv_nj = nj_rows; }
+    }
     if (ezhip_interp_pts(&pp, d_zout, d_zin, s->d_x, s->d_y, go->ni * go->nj)) return dev_fail("the per-point interpolation kernel");
     return ierc;
 }

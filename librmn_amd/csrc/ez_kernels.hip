@@ -2660,18 +2660,31 @@ __global__ __launch_bounds__(256) void k_pts(ezhip_pts_plan p, float *__restrict
                                              const float *__restrict__ xs, const float *__restrict__ ys, int npts,
                                              int *__restrict__ special_list, unsigned *__restrict__ special_count)
 {
-    int n = blockIdx.x * 256 + threadIdx.x;
+    unsigned boff = 0;
+    if (p.pv_out) {            /* the field's pole values: two producer blocks at the head of this launch; whoever reads them is in the next one */
+        if (blockIdx.x < 2) {
+            __shared__ __attribute__((aligned(16))) float pv_lds[2048 + 4];
+            const float *row = blockIdx.x == 0 ? zin + (size_t)(p.pv_nj - 1) * p.ni : zin;
+            const float v = block_poleval(row, p.ni, p.pole_weighted, p.ax, pv_lds, 2048);
+            if (threadIdx.x == 0) p.pv_out[blockIdx.x] = v;
+            return;
+        }
+        boff = 2;
+    }
+    int n = (blockIdx.x - boff) * 256 + threadIdx.x;
     if (n >= npts) return;
     const float px = xs[n], py = ys[n];
     const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;        /* Yin-Yang point lists write straight to their target positions */
     const PlainAcc ZP{zin, p.ni, p.j1};
     const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
+    const bool pole_later = p.pv_out != nullptr && (zone == PZ_POLE_S || zone == PZ_POLE_N);
     if (zone == PZ_NORMAL) { if (!p.only_special) zout[o] = leaf_point<KIND>(p, ZP, px, py); }
     else if (zone == PZ_FILL) zout[o] = *p.fill;
+    else if (pole_later) { }
     else if (zone == PZ_POLE_S) zout[o] = p.polevals[1];
     else if (zone == PZ_POLE_N) zout[o] = p.polevals[0];
     /* strip / re-interpolated points: appended to the launch's list, one atomic per wave that has any */
-    const bool sp = zone == PZ_REINTERP || zone == PZ_STRIP_S || zone == PZ_STRIP_N;
+    const bool sp = zone == PZ_REINTERP || zone == PZ_STRIP_S || zone == PZ_STRIP_N || pole_later;
     const unsigned long long m = __ballot(sp);
     if (sp) {
         const int lane = (int)__lane_id(), leader = __ffsll((long long)m) - 1;
@@ -3019,6 +3032,7 @@ __global__ __launch_bounds__(256) void k_pts_special(ezhip_pts_plan p, float *__
         Z.z = zin; Z.ni = p.ni; Z.j1 = p.j1; Z.j2 = p.j2;
         Z.pole_n = 0.f; Z.pole_s = 0.f; Z.prow_n = nullptr; Z.prow_s = nullptr;
         if (zone == PZ_REINTERP) { zout[o] = gdinterp_point(p, Z, p.degre_extrap, px, py); continue; }
+        if (zone == PZ_POLE_S || zone == PZ_POLE_N) { zout[o] = p.polevals[zone == PZ_POLE_S ? 1 : 0]; continue; }      /* (listed when the pole values came from the launch in front: pv_out) */
         if (p.vector_mode) { Z.prow_n = p.pole_row_n; Z.prow_s = p.pole_row_s; }
         else { Z.pole_n = p.polevals[0]; Z.pole_s = p.polevals[1]; }
         zout[o] = strip_point(p, Z, zone == PZ_STRIP_N, px, py);
@@ -3126,7 +3140,7 @@ extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const
                                 const float *d_x, const float *d_y, int npts)
 {
     if (npts <= 0) return 0;
-    const dim3 grid((npts + 255) / 256), block(256);
+    const dim3 grid((npts + 255) / 256 + (plan->pv_out ? 2 : 0)), block(256);
     if (t_spec.cap < (size_t)npts) {
         (void)hipStreamSynchronize(g_stream);
         if (t_spec.list) (void)hipFree(t_spec.list);

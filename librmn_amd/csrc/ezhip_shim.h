@@ -248,6 +248,10 @@ typedef struct {
     /* the synthetic polar wind rows of the pair (k_polar_wind's job) riding in the k_pts2 launch as two producer blocks: only the special points, handled by
      * the NEXT kernel, read them.  pw_out != NULL: out4 = [u north | u south | v north | v south] rows of ni floats */
     float *pw_out; const float *pw_plon2; float pw_xg4_n, pw_xg4_s; int pw_weighted; const float *pw_ax;
+    /* scalar per-point path: pv_out != NULL: the two pole values of the field are summed by two producer blocks at the head of the k_pts launch (they were a
+     * launch of their own in front of it: 16 us of a 99 us c_ezsint from a rotated 2560 x 1280 source); the points that read them -- the pole points and the
+     * polar strips -- are the NEXT kernel's.  pv_nj: rows of the field the sums run over */
+    float *pv_out; int pv_nj;
     /* the special points of a grid set depend on its located x, y and the zone options only: once a launch has listed them the host keeps them with the set
      * (ezhip_pts2_special_snapshot) and later launches take them from here -- k_pts2 lists nothing, the special kernel reads n, x, y side by side instead of
      * count -> list -> x, y (three dependent round trips) */
