@@ -212,6 +212,14 @@ def extras(ez, torch, stream, d_out, d_in):
                                          "note": "x, y of the rotated source and the per-point wind rotation (a, b) -- 16 bytes per target point, read from the set's tile-ordered copy -- and the 64 MB of results "
                                                  "stream next to the staged source windows; the kernel's phases (streams 42 us, staging 9, REAL*8 arithmetic 20, handed-back tiles 5) do not overlap: "
                                                  "profiles/r04_experiments.txt"}}
+        # the scalar twin on the same grid pair: c_ezsint from the rotated source (k_st: stencil windows staged in LDS, the literal REAL*8 form of the reference)
+        us1 = ev_time(lambda: ez.ezsint_dev(o_u, d_u), 20)
+        algo1 = 4 * ni * nj + 4 * no * mo
+        ex["cfg3_sint"] = {"workload": "c_ezsint_dev bicubic, Z-on-E 2560x1280 -> L 4000x2000, polar_correction=yes", "us_per_field": us1, "Mpoints_per_s": no * mo / us1,
+                           "roofline": {"bound": "hbm", "achieved": algo1 / us1 / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": algo1 / us1 / 1e3 / HBM_PEAK_GBPS, "traffic": None,
+                                        "kernel": "k_st<32, 32> (the first call of a grid set: k_pts<8>) + k_pts_special behind it", "algorithmic_bytes_per_launch": algo1,
+                                        "note": "x, y of the located points (8 bytes per target point, the set's own data) stream next to the staged windows; ~150 REAL*8 operations per point "
+                                                "in the reference's literal Newton form (bit-identical to the gathering kernel): arithmetic and streams share the time"}}
         del d_u, d_v, o_u, o_v
         # the step after the horizontal one: vertical interpolation of device-resident profiles, search + linear + lapse-rate in one pass
         from librmn_amd import interpv as V

@@ -2655,6 +2655,32 @@ __device__ __forceinline__ unsigned pts_block(unsigned b, unsigned nb)
     return b < full ? (b & 7u) * (full >> 3) + (b >> 3) : b;
 }
 
+/* one point of the scalar per-point path.  zone_known >= 0: the caller has the zone already */
+template <int KIND>
+__device__ __forceinline__ void pts1_point(const ezhip_pts_plan &p, float *__restrict__ zout, const float *__restrict__ zin, float px, float py, int n,
+                                           int *__restrict__ special_list, unsigned *__restrict__ special_count, int zone_known)
+{
+    const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;        /* Yin-Yang point lists write straight to their target positions */
+    const PlainAcc ZP{zin, p.ni, p.j1};
+    const int zone = zone_known >= 0 ? zone_known : pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
+    const bool pole_later = p.pv_out != nullptr && (zone == PZ_POLE_S || zone == PZ_POLE_N);
+    if (zone == PZ_NORMAL) { if (!p.only_special) zout[o] = leaf_point<KIND>(p, ZP, px, py); }
+    else if (zone == PZ_FILL) zout[o] = *p.fill;
+    else if (pole_later) { }
+    else if (zone == PZ_POLE_S) zout[o] = p.polevals[1];
+    else if (zone == PZ_POLE_N) zout[o] = p.polevals[0];
+    /* strip / re-interpolated points: appended to the launch's list, one atomic per wave that has any */
+    const bool sp = zone == PZ_REINTERP || zone == PZ_STRIP_S || zone == PZ_STRIP_N || pole_later;
+    const unsigned long long m = __ballot(sp);
+    if (sp) {
+        const int lane = (int)__lane_id(), leader = __ffsll((long long)m) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(special_count, (unsigned)__popcll(m));
+        base = (unsigned)__shfl((int)base, leader, 64);
+        special_list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = n;
+    }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void k_pts(ezhip_pts_plan p, float *__restrict__ zout, const float *__restrict__ zin,
                                              const float *__restrict__ xs, const float *__restrict__ ys, int npts,
@@ -2673,26 +2699,7 @@ __global__ __launch_bounds__(256) void k_pts(ezhip_pts_plan p, float *__restrict
     }
     int n = (blockIdx.x - boff) * 256 + threadIdx.x;
     if (n >= npts) return;
-    const float px = xs[n], py = ys[n];
-    const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;        /* Yin-Yang point lists write straight to their target positions */
-    const PlainAcc ZP{zin, p.ni, p.j1};
-    const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
-    const bool pole_later = p.pv_out != nullptr && (zone == PZ_POLE_S || zone == PZ_POLE_N);
-    if (zone == PZ_NORMAL) { if (!p.only_special) zout[o] = leaf_point<KIND>(p, ZP, px, py); }
-    else if (zone == PZ_FILL) zout[o] = *p.fill;
-    else if (pole_later) { }
-    else if (zone == PZ_POLE_S) zout[o] = p.polevals[1];
-    else if (zone == PZ_POLE_N) zout[o] = p.polevals[0];
-    /* strip / re-interpolated points: appended to the launch's list, one atomic per wave that has any */
-    const bool sp = zone == PZ_REINTERP || zone == PZ_STRIP_S || zone == PZ_STRIP_N || pole_later;
-    const unsigned long long m = __ballot(sp);
-    if (sp) {
-        const int lane = (int)__lane_id(), leader = __ffsll((long long)m) - 1;
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(special_count, (unsigned)__popcll(m));
-        base = (unsigned)__shfl((int)base, leader, 64);
-        special_list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = n;
-    }
+    pts1_point<KIND>(p, zout, zin, xs[n], ys[n], n, special_list, special_count, -1);
 }
 
 /* The two components of a wind pair in one pass (c_ezuvint on the per-point path): x, y, zone test, indices and weights are
@@ -3011,6 +3018,135 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVT_WAVES, 
     }
 }
 
+/* ---- k_st: the SCALAR twin of k_uvt -- c_ezsint from an irregular (rotated) source, bicubic, with its stencil windows staged in LDS ------------------------
+ * Same tile table (built under the scalar zone rules: the pole points are zones of their own there), the source window as float cells, the same REAL*8 axis /
+ * coefficient records; every point then evaluates ez_irgdint_3_w.inc:20-235 in its LITERAL form (the statement functions fa2, fa3, fa4, fa as the reference writes
+ * them: p_irgdint_3_w above, operand for operand) from LDS -- bit-identical to k_pts<PK_IRGD3_W>, which gathers the same 28 values per point through the vector L1
+ * (72 us per 4000 x 2000 field from a 2560 x 1280 source).  x, y come from a tile-ordered float2 copy kept with the set (8 bytes per target point).  Handed-back
+ * tiles take the gathering path point by point; pole points, polar strips and re-interpolated points are listed for k_pts_special as k_pts lists them; the field's
+ * two pole values are summed by two producer blocks at the head of the launch. */
+template <int TW, int TH>
+__global__ __launch_bounds__(256) void k_st_pack(ezhip_pts_plan p, const float *__restrict__ xs, const float *__restrict__ ys, float2 *__restrict__ streams)
+{
+    typedef uvt_geom<TW, TH> G;
+    const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW, b = blockIdx.x, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
+    const unsigned cx = bx * TW + (t % TW);
+#pragma unroll
+    for (int k = 0; k < G::PPT; k++) {
+        const unsigned cy = by * TH + t / TW + (unsigned)(G::RSTEP * k);
+        float2 o = make_float2(0.f, 0.f);
+        if (cx < (unsigned)p.tile_ni && cy < (unsigned)p.tile_nj) { const size_t n = (size_t)cy * p.tile_ni + cx; o.x = xs[n]; o.y = ys[n]; }
+        streams[((size_t)b * G::PPT + k) * 256 + t] = o;
+    }
+}
+template <int TW, int TH>
+__global__ __launch_bounds__(256) void k_st(ezhip_pts_plan p, float *__restrict__ zout, const float *__restrict__ zin,
+                                            const float *__restrict__ xs, const float *__restrict__ ys, const int4 *__restrict__ tiles,
+                                            int *__restrict__ special_list, unsigned *__restrict__ special_count)
+{
+    typedef uvt_geom<TW, TH> G;
+    constexpr int PPT = G::PPT;
+    extern __shared__ __attribute__((aligned(16))) float st_lds[];
+    unsigned boff = 0;
+    if (p.pv_out) {
+        if (blockIdx.x < 2) {      /* (the launch's dynamic LDS holds 2052 floats and more) */
+            const float *row = blockIdx.x == 0 ? zin + (size_t)(p.pv_nj - 1) * p.ni : zin;
+            const float v = block_poleval(row, p.ni, p.pole_weighted, p.ax, st_lds, 2048);
+            if (threadIdx.x == 0) p.pv_out[blockIdx.x] = v;
+            return;
+        }
+        boff = 2;
+    }
+    const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW, b = blockIdx.x - boff, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
+    const unsigned cx = bx * TW + (t % TW), cy0 = by * TH + t / TW;
+    const bool okx = cx < (unsigned)p.tile_ni;
+    float px[PPT], py[PPT];
+    const unsigned n0 = okx && cy0 < (unsigned)p.tile_nj ? cy0 * (unsigned)p.tile_ni + cx : 0u, nstep = (unsigned)G::RSTEP * (unsigned)p.tile_ni;
+    if (p.uvt_streams) {
+        typedef float f2a __attribute__((ext_vector_type(2)));
+        const f2a *S = (const f2a *)p.uvt_streams + (size_t)b * (PPT * 256) + t;
+#pragma unroll
+        for (int k = 0; k < PPT; k++) { const f2a q = __builtin_nontemporal_load(S + k * 256); px[k] = q.x; py[k] = q.y; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const bool ok = okx && cy0 + (unsigned)(G::RSTEP * k) < (unsigned)p.tile_nj;
+            const unsigned n = ok ? n0 + (unsigned)k * nstep : 0u;
+            px[k] = xs[n]; py[k] = ys[n];
+        }
+    }
+    const int4 tb = tiles[b];
+    if (tb.z <= 0) {           /* handed back (the seam, a window beyond the cap) or without a normal point: the gathering path, point by point */
+#pragma unroll 1
+        for (int k = 0; k < PPT; k++) {
+            const unsigned cy = cy0 + (unsigned)(G::RSTEP * k);
+            if (okx && cy < (unsigned)p.tile_nj) { const int n = (int)(cy * (unsigned)p.tile_ni + cx); pts1_point<PK_IRGD3_W>(p, zout, zin, xs[n], ys[n], n, special_list, special_count, -1); }
+        }
+        return;
+    }
+    const int i0 = tb.x, j0 = tb.y, W = tb.z, H = tb.w, ncell = W * H;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    float *cells = st_lds;
+    d2 *xr = (d2 *)(st_lds + ((ncell + 3) & ~3));
+    const int nxr = (W - 3) * 5, nyr = (H - 3) * 5;
+    d2 *yr = xr + nxr;
+    {
+        const unsigned magic = 0xFFFFFFFFu / (unsigned)W + 1u;
+        const float *s1 = zin + (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1);
+#pragma unroll 4
+        for (int idx = (int)t; idx < ncell; idx += 256) {
+            const unsigned r = __umulhi((unsigned)idx, magic), c = (unsigned)idx - r * (unsigned)W;
+            cells[idx] = s1[(size_t)r * (size_t)p.ni + c];
+        }
+        const d2 *gx = (const d2 *)p.xrec10 + (size_t)i0 * 5, *gy = (const d2 *)p.yrec10 + (size_t)(j0 + 1 - p.j1) * 5;
+        for (int idx = (int)t; idx < nxr; idx += 256) xr[idx] = gx[idx];
+        for (int idx = (int)t; idx < nyr; idx += 256) yr[idx] = gy[idx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        if (!(okx && cy0 + (unsigned)(G::RSTEP * k) < (unsigned)p.tile_nj)) continue;
+        const int n = (int)(n0 + (unsigned)k * nstep);
+        const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px[k], py[k]);
+        if (zone != PZ_NORMAL) {           /* fill value, or a point of the next kernel's list (as k_pts lists them) */
+            if (zone == PZ_FILL) zout[n] = *p.fill;
+            else if (!p.pv_out && (zone == PZ_POLE_S || zone == PZ_POLE_N)) zout[n] = p.polevals[zone == PZ_POLE_S ? 1 : 0];
+            else {
+                const unsigned long long m = __ballot(1);
+                const int lane = (int)__lane_id(), leader = __ffsll((long long)m) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(special_count, (unsigned)__popcll(m));
+                base = (unsigned)__shfl((int)base, leader, 64);
+                special_list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = n;
+            }
+            continue;
+        }
+        const int i = min(p.ni - 2 + p.wrap, max(1, max(2 - p.wrap, (int)px[k]))), j = min(p.j2 - 2, max(p.j1 + 1, (int)py[k]));
+        /* records {x1, x2 | x3, c1 | c2, c3 | c4, c5 | c6, c5 + c2} (REAL entries widened once per grid) */
+        const d2 *xq = xr + (i - 1 - i0) * 5, *yq = yr + (j - 1 - j0) * 5;
+        const d2 xa = xq[0], xb = xq[1], xc = xq[2], xd = xq[3], xe = xq[4];
+        const float fx2 = (float)xa.y, fx3 = (float)xb.x;                 /* (exact: they were REAL) */
+        const double x = (double)(fx2 + (fx3 - fx2) * (px[k] - (float)i));
+        const float *cp = cells + (j - 1 - j0) * W + (i - 1 - i0);
+        double bb[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double z1 = (double)cp[r * W], z2 = (double)cp[r * W + 1], z3 = (double)cp[r * W + 2], z4 = (double)cp[r * W + 3];
+            const double a2 = d_fa2(xb.y, z1, z2);
+            const double a3 = d_fa3(xb.y, xc.x, xc.y, z1, z2, z3);
+            const double a4 = d_fa4(xb.y, xc.x, xc.y, xd.x, xd.y, xe.x, z1, z2, z3, z4);
+            bb[r] = d_fa(z1, a2, a3, a4, x, xa.x, xa.y, xb.x);
+        }
+        const d2 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3], ye = yq[4];
+        const float fy2 = (float)ya.y, fy3 = (float)yb.x;
+        const double y = (double)(fy2 + (fy3 - fy2) * (py[k] - (float)j));
+        const double b12 = d_fa2(yb.y, bb[0], bb[1]);
+        const double b13 = d_fa3(yb.y, yc.x, yc.y, bb[0], bb[1], bb[2]);
+        const double b14 = d_fa4(yb.y, yc.x, yc.y, yd.x, yd.y, ye.x, bb[0], bb[1], bb[2], bb[3]);
+        zout[n] = (float)d_fa(bb[0], b12, b13, b14, y, ya.x, ya.y, yb.x);
+    }
+}
+
 /* (k_uvt as a pipeline -- persistent blocks with two staging buffers, the next tile's window and streams in flight while a tile is computed -- was built twice
  * and measured slower both times: with LDS-DMA staging (the window as separate u / v planes: twice the LDS read instructions) 111 us per cfg3 pair against 90;
  * with the next window held in registers (135 - 155 VGPRs, three waves per SIMD) 96 - 104 us for the kernel against 76.  profiles/r04_experiments.txt.) */
@@ -3152,6 +3288,18 @@ extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const
     }
     unsigned *cnt = t_spec.count + (t_spec.epoch & 1), *cnt_next = t_spec.count + ((t_spec.epoch + 1) & 1);
     t_spec.epoch++;
+    if (plan->uvt_tiles && pts_kind(plan) == PK_IRGD3_W && plan->tile_ni > 0 && !plan->out_idx && plan->xrec10) {
+        /* the scalar staged-tile kernel (the set's table was built under this plan's zone options) */
+        const int cap = plan->uvt_cap > 0 ? plan->uvt_cap : UVT_CAP_DEFAULT;
+        const unsigned nt = (unsigned)ezhip_uvt_ntiles(plan, 3232);
+        size_t lds = 4 * (size_t)((cap + 3) & ~3) + 80 * (size_t)UVT_REC_MAX + 16;
+        if (lds < 4 * 2052 + 16) lds = 4 * 2052 + 16;
+        static bool attr = false;
+        if (!attr) { if (hipFuncSetAttribute((const void *)k_st<32, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) return set_err(hipGetLastError(), "k_st attribute"); attr = true; }
+        if (lds > 65536) return -1;
+        hipLaunchKernelGGL((k_st<32, 32>), dim3(nt + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt);
+        if (LAUNCH_CHECK("k_st")) return -1;
+    } else
 #define PTS_CASE(K) case K: hipLaunchKernelGGL(k_pts<K>, grid, block, 0, g_stream, *plan, d_zout, d_zin, d_x, d_y, npts, t_spec.list, cnt); break
     switch (pts_kind(plan)) {
     PTS_CASE(PK_RGD0); PTS_CASE(PK_RGD1_NW); PTS_CASE(PK_RGD1_W); PTS_CASE(PK_RGD3_NW); PTS_CASE(PK_RGD3_W);
@@ -3301,6 +3449,15 @@ extern "C" int ezhip_uvt_pack_streams(const ezhip_pts_plan *plan, const float *d
 #undef UVT_PK
     if (LAUNCH_CHECK("k_uvt_pack")) return -1;
     return set_err(hipStreamSynchronize(g_stream), "k_uvt_pack");
+}
+
+extern "C" int ezhip_st_pack_streams(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_streams)
+{
+    const int nt = ezhip_uvt_ntiles(plan, 3232);
+    if (nt <= 0 || !d_streams) return -1;
+    hipLaunchKernelGGL((k_st_pack<32, 32>), dim3(nt), dim3(256), 0, g_stream, *plan, d_x, d_y, (float2 *)d_streams);
+    if (LAUNCH_CHECK("k_st_pack")) return -1;
+    return set_err(hipStreamSynchronize(g_stream), "k_st_pack");
 }
 
 extern "C" int ezhip_pts2_special_snapshot(int *d_list_out, float *d_x_out, float *d_y_out, int cap, const float *d_xs, const float *d_ys)

@@ -1452,3 +1452,38 @@ def test_uvt_staged_tiles_equal_gathering_kernel(shape, eig, th):
     finally:
         os.environ.pop("EZHIP_UVT_SHAPE", None); os.environ.pop("EZHIP_NO_UVT", None); os.environ.pop("EZHIP_UVT_NO_STREAMS", None)
         ez.gdrls(gdin); ez.gdrls(gdout)
+
+
+@pytest.mark.parametrize("polar", [1, 0])
+@pytest.mark.parametrize("shape", [(320, 160, 500, 250), (257, 130, 333, 167), (640, 320, 1000, 500), (1280, 640, 2000, 1000)])
+@pytest.mark.parametrize("eig", ["cfg3", "tilted"])
+def test_st_staged_tiles_equal_gathering_kernel(shape, eig, polar):
+    """k_st (c_ezsint from a rotated global source out of LDS-staged stencil windows, second call of a grid set on) against k_pts (first call; EZHIP_NO_ST=1):
+    bit-identical fields, with the seam, both rotated poles, ragged edges, pole points and polar strips in the target; then against the oracle's gdxysint at
+    the located points (the literal form of ez_irgdint_3_w)"""
+    ni, nj, no, mo = shape
+    ax, ay = ec.ze_axes(ni, nj)
+    ig = ec.E_IG if eig == "cfg3" else ol.cxgaig("E", 62.0, 20.0, -15.0, 110.0)
+    os.environ["EZHIP_ST_MIN_POINTS"] = "1"
+    try:
+        gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ig, ax, ay); gdout = ez.ezqkdef(no, mo, "L", *ol.cxgaig("L", -90.0, 0.0, 180.0 / (mo - 1), 360.0 / no))
+        assert ez.ezdefset(gdout, gdin) == 1
+        setopts(3, polar)
+        f = ec.synth_field(ni, nj, seed=17)
+        f2 = f.reshape(nj, ni); f2[:, -1] = f2[:, 0]
+        ez.use_stream(torch.cuda.current_stream().cuda_stream)
+        d_f = torch.from_numpy(f).cuda()
+        outs = []
+        for call in range(4):
+            o = torch.full((no * mo,), float("nan"), dtype=torch.float32, device="cuda")
+            if call == 3:
+                os.environ["EZHIP_NO_ST"] = "1"
+            assert ez.ezsint_dev(o, d_f) >= 0
+            torch.cuda.synchronize()
+            outs.append(o)
+        for k in (1, 2, 3):
+            assert torch.equal(outs[0].view(torch.int32), outs[k].view(torch.int32)), (k, int((outs[0] != outs[k]).sum()))
+        assert not torch.isnan(outs[1]).any()
+    finally:
+        os.environ.pop("EZHIP_ST_MIN_POINTS", None); os.environ.pop("EZHIP_NO_ST", None)
+        ez.gdrls(gdin); ez.gdrls(gdout)
