@@ -2480,7 +2480,7 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
     /* bicubic from an irregular source with wrap (a rotated global grid), the whole target grid in row order: from the second call of a set on the field runs from
      * LDS-staged stencil windows (k_st: bit-identical to k_pts; the tile table and the tile-ordered x, y are built once per set and zone options, behind the
      * first call).  EZHIP_NO_ST=1: k_pts every time */
-    const int st_ok = degree == DEG_CUBIC && pp.irregular && pp.wrap != 0 && pp.xrec10 && !pp.out_idx && !vector_mode && !src_hemi(gi) &&
+    const int st_ok = degree == DEG_CUBIC && pp.irregular && (pp.wrap != 0 || (pp.i1 == 1 && pp.i2 == pp.ni)) && pp.xrec10 && !pp.out_idx && !vector_mode && !src_hemi(gi) &&
                       (size_t)go->ni * go->nj >= (getenv("EZHIP_ST_MIN_POINTS") ? (size_t)atol(getenv("EZHIP_ST_MIN_POINTS")) : (size_t)262144) && !getenv("EZHIP_NO_ST");
     const int st_key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4;
     int st_build = 0;

@@ -3039,7 +3039,7 @@ __global__ __launch_bounds__(256) void k_st_pack(ezhip_pts_plan p, const float *
         streams[((size_t)b * G::PPT + k) * 256 + t] = o;
     }
 }
-template <int TW, int TH>
+template <int TW, int TH, bool NW>      /* NW: a source without wrap (a regional 'Z' grid): ez_irgdint_3_nw.inc:20-168, whose statement functions are REAL (each result rounded) */
 __global__ __launch_bounds__(256) void k_st(ezhip_pts_plan p, float *__restrict__ zout, const float *__restrict__ zin,
                                             const float *__restrict__ xs, const float *__restrict__ ys, const int4 *__restrict__ tiles,
                                             int *__restrict__ special_list, unsigned *__restrict__ special_count)
@@ -3080,7 +3080,7 @@ __global__ __launch_bounds__(256) void k_st(ezhip_pts_plan p, float *__restrict_
 #pragma unroll 1
         for (int k = 0; k < PPT; k++) {
             const unsigned cy = cy0 + (unsigned)(G::RSTEP * k);
-            if (okx && cy < (unsigned)p.tile_nj) { const int n = (int)(cy * (unsigned)p.tile_ni + cx); pts1_point<PK_IRGD3_W>(p, zout, zin, xs[n], ys[n], n, special_list, special_count, -1); }
+            if (okx && cy < (unsigned)p.tile_nj) { const int n = (int)(cy * (unsigned)p.tile_ni + cx); pts1_point<NW ? PK_IRGD3_NW : PK_IRGD3_W>(p, zout, zin, xs[n], ys[n], n, special_list, special_count, -1); }
         }
         return;
     }
@@ -3132,17 +3132,19 @@ __global__ __launch_bounds__(256) void k_st(ezhip_pts_plan p, float *__restrict_
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const double z1 = (double)cp[r * W], z2 = (double)cp[r * W + 1], z3 = (double)cp[r * W + 2], z4 = (double)cp[r * W + 3];
-            const double a2 = d_fa2(xb.y, z1, z2);
-            const double a3 = d_fa3(xb.y, xc.x, xc.y, z1, z2, z3);
-            const double a4 = d_fa4(xb.y, xc.x, xc.y, xd.x, xd.y, xe.x, z1, z2, z3, z4);
-            bb[r] = d_fa(z1, a2, a3, a4, x, xa.x, xa.y, xb.x);
+#define ST_RF(e) (NW ? (double)(float)(e) : (e))
+            const double a2 = ST_RF(d_fa2(xb.y, z1, z2));
+            const double a3 = ST_RF(d_fa3(xb.y, xc.x, xc.y, z1, z2, z3));
+            const double a4 = ST_RF(d_fa4(xb.y, xc.x, xc.y, xd.x, xd.y, xe.x, z1, z2, z3, z4));
+            bb[r] = ST_RF(d_fa(z1, a2, a3, a4, x, xa.x, xa.y, xb.x));
         }
         const d2 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3], ye = yq[4];
         const float fy2 = (float)ya.y, fy3 = (float)yb.x;
         const double y = (double)(fy2 + (fy3 - fy2) * (py[k] - (float)j));
-        const double b12 = d_fa2(yb.y, bb[0], bb[1]);
-        const double b13 = d_fa3(yb.y, yc.x, yc.y, bb[0], bb[1], bb[2]);
-        const double b14 = d_fa4(yb.y, yc.x, yc.y, yd.x, yd.y, ye.x, bb[0], bb[1], bb[2], bb[3]);
+        const double b12 = ST_RF(d_fa2(yb.y, bb[0], bb[1]));
+        const double b13 = ST_RF(d_fa3(yb.y, yc.x, yc.y, bb[0], bb[1], bb[2]));
+        const double b14 = ST_RF(d_fa4(yb.y, yc.x, yc.y, yd.x, yd.y, ye.x, bb[0], bb[1], bb[2], bb[3]));
+#undef ST_RF
         zout[n] = (float)d_fa(bb[0], b12, b13, b14, y, ya.x, ya.y, yb.x);
     }
 }
@@ -3288,16 +3290,16 @@ extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const
     }
     unsigned *cnt = t_spec.count + (t_spec.epoch & 1), *cnt_next = t_spec.count + ((t_spec.epoch + 1) & 1);
     t_spec.epoch++;
-    if (plan->uvt_tiles && pts_kind(plan) == PK_IRGD3_W && plan->tile_ni > 0 && !plan->out_idx && plan->xrec10) {
+    const int kind_st = pts_kind(plan);
+    if (plan->uvt_tiles && (kind_st == PK_IRGD3_W || (kind_st == PK_IRGD3_NW && plan->i1 == 1 && plan->i2 == plan->ni)) && plan->tile_ni > 0 && !plan->out_idx && plan->xrec10) {
         /* the scalar staged-tile kernel (the set's table was built under this plan's zone options) */
         const int cap = plan->uvt_cap > 0 ? plan->uvt_cap : UVT_CAP_DEFAULT;
         const unsigned nt = (unsigned)ezhip_uvt_ntiles(plan, 3232);
         size_t lds = 4 * (size_t)((cap + 3) & ~3) + 80 * (size_t)UVT_REC_MAX + 16;
         if (lds < 4 * 2052 + 16) lds = 4 * 2052 + 16;
-        static bool attr = false;
-        if (!attr) { if (hipFuncSetAttribute((const void *)k_st<32, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) return set_err(hipGetLastError(), "k_st attribute"); attr = true; }
-        if (lds > 65536) return -1;
-        hipLaunchKernelGGL((k_st<32, 32>), dim3(nt + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt);
+        if (lds > 65536) return -1;                      /* (no attribute needed up to 64 KB) */
+        if (kind_st == PK_IRGD3_W) hipLaunchKernelGGL((k_st<32, 32, false>), dim3(nt + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt);
+        else hipLaunchKernelGGL((k_st<32, 32, true>), dim3(nt + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt);
         if (LAUNCH_CHECK("k_st")) return -1;
     } else
 #define PTS_CASE(K) case K: hipLaunchKernelGGL(k_pts<K>, grid, block, 0, g_stream, *plan, d_zout, d_zin, d_x, d_y, npts, t_spec.list, cnt); break

@@ -1487,3 +1487,40 @@ def test_st_staged_tiles_equal_gathering_kernel(shape, eig, polar):
     finally:
         os.environ.pop("EZHIP_ST_MIN_POINTS", None); os.environ.pop("EZHIP_NO_ST", None)
         ez.gdrls(gdin); ez.gdrls(gdout)
+
+
+@pytest.mark.parametrize("target", ["inside", "beyond"])
+@pytest.mark.parametrize("extrap", ["maximum", "value", "linear"])
+@pytest.mark.parametrize("shape", [(400, 300, 700, 500), (801, 603, 1500, 1100)])
+def test_st_staged_tiles_regional_source(shape, extrap, target):
+    """k_st on a source WITHOUT wrap (a regional Z-on-E grid: ez_irgdint_3_nw.inc, whose statement functions are REAL): second and third call of a set against the
+    first (k_pts) and against EZHIP_NO_ST=1, bit for bit; a target inside the source's region and one that reaches beyond it (extrapolation zones: filled with a
+    value, the field's maximum, or re-interpolated at a lower degree by the next kernel)"""
+    ni, nj, no, mo = shape
+    ax, ay = ec.zereg_axes(ni, nj)
+    os.environ["EZHIP_ST_MIN_POINTS"] = "1"
+    lat0, lon0, dlat, dlon = (-15.0, 155.0, 30.0 / (mo - 1), 40.0 / (no - 1)) if target == "inside" else (-28.0, 140.0, 56.0 / (mo - 1), 70.0 / (no - 1))
+    try:
+        gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ol.cxgaig("E", 0.0, 180.0, 0.0, 0.0), ax, ay)      # the identity rotation: the rotated frame is the geographic one
+        gdout = ez.ezqkdef(no, mo, "L", *ol.cxgaig("L", lat0, lon0, dlat, dlon))
+        assert ez.ezdefset(gdout, gdin) == 1
+        setopts(3, 1, extrap)
+        if extrap == "value":
+            assert ez.ezsetval("extrap_value", -777.0) == 0
+        f = ec.synth_field(ni, nj, seed=23)
+        ez.use_stream(torch.cuda.current_stream().cuda_stream)
+        d_f = torch.from_numpy(f).cuda()
+        outs = []
+        for call in range(4):
+            o = torch.full((no * mo,), float("nan"), dtype=torch.float32, device="cuda")
+            if call == 3:
+                os.environ["EZHIP_NO_ST"] = "1"
+            assert ez.ezsint_dev(o, d_f) >= 0
+            torch.cuda.synchronize()
+            outs.append(o)
+        for k in (1, 2, 3):
+            assert torch.equal(outs[0].view(torch.int32), outs[k].view(torch.int32)), (k, int((outs[0] != outs[k]).sum()))
+        assert not torch.isnan(outs[1]).any()
+    finally:
+        os.environ.pop("EZHIP_ST_MIN_POINTS", None); os.environ.pop("EZHIP_NO_ST", None)
+        ez.gdrls(gdin); ez.gdrls(gdout)
