@@ -2641,6 +2641,38 @@ static int ensure_batch_poles(ezh_set *s, int nfields)
  * output at stat_partials[f * stat_stride + 3 k], k < *partials_per_field (compact_float's min/max pass fused into the
  * interpolation); only the single-launch k_sepx path can do that: returns -2 when it does not apply */
 typedef struct { int mode; const void *qparams; size_t qstride, out_stride_words; } batch_out;      /* ezhip_sep_plan.out_mode and friends */
+/* c_ezsint_batch_dev on the per-point path with the set's staged-tile table in place: one k_st launch + one k_pts_special launch for all fields.  -2: not this case
+ * (no table yet or built under other zone options, extrapolation zones -- their fill value is a field's own --, a source that is expanded or flipped first, the
+ * background correction of 'B' grids behind the interpolation) */
+static int run_batch_st(ezh_set *s, float *d_zout, const float *d_zin, int nfields, size_t nin, size_t nout, const float *d_poles_all)
+{
+    ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
+    const int degree = O.degre_interp, polar = O.polar_correction == 1;
+    if (degree != DEG_CUBIC || grid_yinv(gi) || src_hemi(gi) || corrbgd_applies(gi, go) || (polar && s->extrap)) return -2;
+    if (polar && !d_poles_all) return -2;
+    pthread_mutex_lock(&g_plan_mtx);
+    const int mode = choose_mode(s, degree, polar);
+    const int zones = !polar ? 0 : 1;
+    const int st_key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4;
+    const int have = mode != 1 && s->st_key == st_key && s->d_st_tiles != NULL;
+    pthread_mutex_unlock(&g_plan_mtx);
+    if (!have) return -2;
+    if (hio_full((float *)d_zin) || ensure_scratch(s)) return -1;
+    ezhip_pts_plan pp;
+    pthread_mutex_lock(&g_plan_mtx);
+    int erc = ensure_points(s);
+    if (!erc) fill_pts_plan(s, gi, &pp, degree, zones, 0);
+    pthread_mutex_unlock(&g_plan_mtx);
+    if (erc) return -1;
+    if (!pp.irregular || !pp.xrec10 || pp.out_idx) return -2;
+    pp.fill = t_scratch8; pp.polevals = d_poles_all ? d_poles_all : t_scratch8 + 4;
+    pp.tile_ni = go->ni; pp.tile_nj = go->nj;
+    pp.uvt_tiles = s->d_st_tiles; pp.uvt_shape = 3232; pp.uvt_cap = s->st_cap; pp.uvt_streams = s->d_st_streams;
+    const int rc = ezhip_interp_pts_batch(&pp, d_zout, d_zin, s->d_x, s->d_y, go->ni * go->nj, nfields, nin, nout);
+    if (rc == -2) return -2;
+    return rc ? dev_fail("the per-point interpolation kernel (batch)") : 0;
+}
+
 static int32_t batch_impl_o(float *d_zout, const float *d_zin, int32_t nfields, unsigned *stat_partials, size_t stat_stride, int32_t *partials_per_field, const batch_out *bo);
 static int32_t batch_impl(float *d_zout, const float *d_zin, int32_t nfields, unsigned *stat_partials, size_t stat_stride, int32_t *partials_per_field)
 {
@@ -2723,6 +2755,12 @@ static int32_t batch_impl_o(float *d_zout, const float *d_zin, int32_t nfields, 
         if (weighted && ensure_grid_dev(gi)) return -1;
         if (s->d_poles_batch && ezhip_polevals_batch(s->d_poles_batch, d_zin, nin, nfields, gi->ni, gi->nj, weighted, gi->d_ax) == 0)
             d_poles_all = s->d_poles_batch;
+    }
+    /* a rotated / regional source whose set has its staged-tile table (k_st, from the second call on): the whole batch in one launch -- x, y, the zones and the
+     * list of special points once per batch instead of once per field */
+    if (s->gdin != s->gdout && nfields > 1 && !getenv("EZHIP_NO_ST_BATCH")) {
+        const int brc = run_batch_st(s, d_zout, d_zin, nfields, nin, nout, d_poles_all);
+        if (brc != -2) return brc;
     }
     for (int f = 0; f < nfields; f++) {
         int r = (s->gdin == s->gdout) ? (ezhip_d2d(d_zout + f * nout, d_zin + f * nin, sizeof(float) * nin), 1)

@@ -2658,7 +2658,7 @@ __device__ __forceinline__ unsigned pts_block(unsigned b, unsigned nb)
 /* one point of the scalar per-point path.  zone_known >= 0: the caller has the zone already */
 template <int KIND>
 __device__ __forceinline__ void pts1_point(const ezhip_pts_plan &p, float *__restrict__ zout, const float *__restrict__ zin, float px, float py, int n,
-                                           int *__restrict__ special_list, unsigned *__restrict__ special_count, int zone_known)
+                                           int *__restrict__ special_list, unsigned *__restrict__ special_count, int zone_known, const float *__restrict__ polevals)
 {
     const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;        /* Yin-Yang point lists write straight to their target positions */
     const PlainAcc ZP{zin, p.ni, p.j1};
@@ -2667,10 +2667,10 @@ __device__ __forceinline__ void pts1_point(const ezhip_pts_plan &p, float *__res
     if (zone == PZ_NORMAL) { if (!p.only_special) zout[o] = leaf_point<KIND>(p, ZP, px, py); }
     else if (zone == PZ_FILL) zout[o] = *p.fill;
     else if (pole_later) { }
-    else if (zone == PZ_POLE_S) zout[o] = p.polevals[1];
-    else if (zone == PZ_POLE_N) zout[o] = p.polevals[0];
-    /* strip / re-interpolated points: appended to the launch's list, one atomic per wave that has any */
-    const bool sp = zone == PZ_REINTERP || zone == PZ_STRIP_S || zone == PZ_STRIP_N || pole_later;
+    else if (zone == PZ_POLE_S) zout[o] = polevals[1];
+    else if (zone == PZ_POLE_N) zout[o] = polevals[0];
+    /* strip / re-interpolated points: appended to the launch's list, one atomic per wave that has any (special_list == nullptr: a later field of a batch, listed already) */
+    const bool sp = (zone == PZ_REINTERP || zone == PZ_STRIP_S || zone == PZ_STRIP_N || pole_later) && special_list != nullptr;
     const unsigned long long m = __ballot(sp);
     if (sp) {
         const int lane = (int)__lane_id(), leader = __ffsll((long long)m) - 1;
@@ -2699,7 +2699,7 @@ __global__ __launch_bounds__(256) void k_pts(ezhip_pts_plan p, float *__restrict
     }
     int n = (blockIdx.x - boff) * 256 + threadIdx.x;
     if (n >= npts) return;
-    pts1_point<KIND>(p, zout, zin, xs[n], ys[n], n, special_list, special_count, -1);
+    pts1_point<KIND>(p, zout, zin, xs[n], ys[n], n, special_list, special_count, -1, p.polevals);
 }
 
 /* The two components of a wind pair in one pass (c_ezuvint on the per-point path): x, y, zone test, indices and weights are
@@ -3039,11 +3039,15 @@ __global__ __launch_bounds__(256) void k_st_pack(ezhip_pts_plan p, const float *
         streams[((size_t)b * G::PPT + k) * 256 + t] = o;
     }
 }
-template <int TW, int TH, bool NW>      /* NW: a source without wrap (a regional 'Z' grid): ez_irgdint_3_nw.inc:20-168, whose statement functions are REAL (each result rounded) */
-__global__ __launch_bounds__(256) void k_st(ezhip_pts_plan p, float *__restrict__ zout, const float *__restrict__ zin,
+template <int TW, int TH, bool NW, bool BATCH>      /* BATCH: nfields > 1 with the next field's window prefetched (its own instantiation: ten more registers); NW: a source without wrap (a regional 'Z' grid): ez_irgdint_3_nw.inc:20-168, whose statement functions are REAL (each result rounded) */
+__global__ __launch_bounds__(256) void k_st(ezhip_pts_plan p, float *__restrict__ zout0, const float *__restrict__ zin0,
                                             const float *__restrict__ xs, const float *__restrict__ ys, const int4 *__restrict__ tiles,
-                                            int *__restrict__ special_list, unsigned *__restrict__ special_count)
+                                            int *__restrict__ special_list, unsigned *__restrict__ special_count,
+                                            int nfields, size_t in_stride, size_t out_stride)      /* nfields > 1 (c_ezsint_batch_dev): the fields one after the other per tile -- x, y, zones and the
+                                                                                                     * list of special points once per batch; pole values of field f in p.polevals[2 f .. 2 f + 1] */
 {
+    float *__restrict__ zout = zout0;
+    const float *__restrict__ zin = zin0;
     typedef uvt_geom<TW, TH> G;
     constexpr int PPT = G::PPT;
     extern __shared__ __attribute__((aligned(16))) float st_lds[];
@@ -3078,9 +3082,15 @@ __global__ __launch_bounds__(256) void k_st(ezhip_pts_plan p, float *__restrict_
     const int4 tb = tiles[b];
     if (tb.z <= 0) {           /* handed back (the seam, a window beyond the cap) or without a normal point: the gathering path, point by point */
 #pragma unroll 1
-        for (int k = 0; k < PPT; k++) {
-            const unsigned cy = cy0 + (unsigned)(G::RSTEP * k);
-            if (okx && cy < (unsigned)p.tile_nj) { const int n = (int)(cy * (unsigned)p.tile_ni + cx); pts1_point<NW ? PK_IRGD3_NW : PK_IRGD3_W>(p, zout, zin, xs[n], ys[n], n, special_list, special_count, -1); }
+        for (int f = 0; f < (BATCH ? nfields : 1); f++) {
+#pragma unroll 1
+            for (int k = 0; k < PPT; k++) {
+                const unsigned cy = cy0 + (unsigned)(G::RSTEP * k);
+                if (okx && cy < (unsigned)p.tile_nj) {
+                    const int n = (int)(cy * (unsigned)p.tile_ni + cx);
+                    pts1_point<NW ? PK_IRGD3_NW : PK_IRGD3_W>(p, zout0 + (size_t)f * out_stride, zin0 + (size_t)f * in_stride, xs[n], ys[n], n, f == 0 ? special_list : nullptr, special_count, -1, p.polevals + 2 * f);
+                }
+            }
         }
         return;
     }
@@ -3091,16 +3101,41 @@ __global__ __launch_bounds__(256) void k_st(ezhip_pts_plan p, float *__restrict_
     const int nxr = (W - 3) * 5, nyr = (H - 3) * 5;
     d2 *yr = xr + nxr;
     {
-        const unsigned magic = 0xFFFFFFFFu / (unsigned)W + 1u;
-        const float *s1 = zin + (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1);
+        const d2 *gx = (const d2 *)p.xrec10 + (size_t)i0 * 5, *gy = (const d2 *)p.yrec10 + (size_t)(j0 + 1 - p.j1) * 5;
+        for (int idx = (int)t; idx < nxr; idx += 256) xr[idx] = gx[idx];
+        for (int idx = (int)t; idx < nyr; idx += 256) yr[idx] = gy[idx];
+    }
+    /* a batch: the window of field f + 1 is on its way into registers while field f is evaluated (ten cells per thread cover the default 2560 of a tile; a set
+     * built under a larger cap stages in place) */
+    constexpr int PF = BATCH ? 10 : 1;
+    const bool prefetch = BATCH && nfields > 1 && ncell <= PF * 256;
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)W + 1u;
+    const size_t win0 = (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1);
+    float nxt[PF];
+    const int nf = BATCH ? nfields : 1;                               /* (the one-field instantiation has no loop: 72 VGPRs, seven waves per SIMD) */
+#pragma unroll 1
+    for (int f = 0; f < nf; f++) {
+    zin = zin0 + (size_t)f * in_stride; zout = zout0 + (size_t)f * out_stride;
+    const float *pv = p.polevals + 2 * f;
+    /* (the per-point state -- zone, indices, records, x, y -- is loop-invariant and the compiler keeps it in registers across the fields: 125 VGPRs, four waves per
+     * SIMD, 50.5 us per field of a 16-field cfg3 batch; formed again for every field (113 VGPRs, the same four waves): 55.8) */
+    if (f == 0 || !prefetch) {
+        if (f) __syncthreads();                                       /* (the cells of the field before are read no more) */
+        const float *s1 = zin + win0;
 #pragma unroll 4
         for (int idx = (int)t; idx < ncell; idx += 256) {
             const unsigned r = __umulhi((unsigned)idx, magic), c = (unsigned)idx - r * (unsigned)W;
             cells[idx] = s1[(size_t)r * (size_t)p.ni + c];
         }
-        const d2 *gx = (const d2 *)p.xrec10 + (size_t)i0 * 5, *gy = (const d2 *)p.yrec10 + (size_t)(j0 + 1 - p.j1) * 5;
-        for (int idx = (int)t; idx < nxr; idx += 256) xr[idx] = gx[idx];
-        for (int idx = (int)t; idx < nyr; idx += 256) yr[idx] = gy[idx];
+    } else {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PF; u++) if ((int)(t + 256u * (unsigned)u) < ncell) cells[t + 256u * (unsigned)u] = nxt[u];
+    }
+    if (prefetch && f + 1 < nfields) {
+        const float *s2 = zin + in_stride + win0;
+#pragma unroll
+        for (int u = 0; u < PF; u++) { const unsigned idx = t + 256u * (unsigned)u, r = __umulhi(idx, magic); nxt[u] = s2[(int)idx < ncell ? r * (unsigned)p.ni + (idx - r * (unsigned)W) : 0u]; }
     }
     __syncthreads();
 #pragma unroll
@@ -3110,8 +3145,8 @@ __global__ __launch_bounds__(256) void k_st(ezhip_pts_plan p, float *__restrict_
         const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px[k], py[k]);
         if (zone != PZ_NORMAL) {           /* fill value, or a point of the next kernel's list (as k_pts lists them) */
             if (zone == PZ_FILL) zout[n] = *p.fill;
-            else if (!p.pv_out && (zone == PZ_POLE_S || zone == PZ_POLE_N)) zout[n] = p.polevals[zone == PZ_POLE_S ? 1 : 0];
-            else {
+            else if (!p.pv_out && (zone == PZ_POLE_S || zone == PZ_POLE_N)) zout[n] = pv[zone == PZ_POLE_S ? 1 : 0];
+            else if (f == 0) {
                 const unsigned long long m = __ballot(1);
                 const int lane = (int)__lane_id(), leader = __ffsll((long long)m) - 1;
                 unsigned base = 0;
@@ -3147,6 +3182,7 @@ __global__ __launch_bounds__(256) void k_st(ezhip_pts_plan p, float *__restrict_
 #undef ST_RF
         zout[n] = (float)d_fa(bb[0], b12, b13, b14, y, ya.x, ya.y, yb.x);
     }
+    }
 }
 
 /* (k_uvt as a pipeline -- persistent blocks with two staging buffers, the next tile's window and streams in flight while a tile is computed -- was built twice
@@ -3157,22 +3193,25 @@ __global__ __launch_bounds__(256) void k_st(ezhip_pts_plan p, float *__restrict_
 __global__ __launch_bounds__(256) void k_pts_special(ezhip_pts_plan p, float *__restrict__ zout, const float *__restrict__ zin,
                                                      const float *__restrict__ xs, const float *__restrict__ ys,
                                                      const int *__restrict__ special_list, const unsigned *__restrict__ special_count,
-                                                     unsigned *__restrict__ next_count)
+                                                     unsigned *__restrict__ next_count, int nfields = 1, size_t in_stride = 0, size_t out_stride = 0)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;          /* the other counter of the pair: the next launch's */
     const unsigned cnt = *special_count;
-    for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+    const unsigned total = cnt * (unsigned)nfields;                    /* (a batch: every listed point once per field, pole values of field f in polevals[2 f ..]) */
+    for (unsigned kk = blockIdx.x * 256 + threadIdx.x; kk < total; kk += gridDim.x * 256) {
+        const unsigned f = kk / cnt, k = kk - f * cnt;
         const int n = special_list[k];
         const float px = xs[n], py = ys[n];
-        const size_t o = p.out_idx ? (size_t)p.out_idx[n] : (size_t)n;
+        const size_t o = (p.out_idx ? (size_t)p.out_idx[n] : (size_t)n) + (size_t)f * out_stride;
+        const float *pv = p.polevals + 2 * f;
         const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
         FieldAcc Z;
-        Z.z = zin; Z.ni = p.ni; Z.j1 = p.j1; Z.j2 = p.j2;
+        Z.z = zin + (size_t)f * in_stride; Z.ni = p.ni; Z.j1 = p.j1; Z.j2 = p.j2;
         Z.pole_n = 0.f; Z.pole_s = 0.f; Z.prow_n = nullptr; Z.prow_s = nullptr;
         if (zone == PZ_REINTERP) { zout[o] = gdinterp_point(p, Z, p.degre_extrap, px, py); continue; }
-        if (zone == PZ_POLE_S || zone == PZ_POLE_N) { zout[o] = p.polevals[zone == PZ_POLE_S ? 1 : 0]; continue; }      /* (listed when the pole values came from the launch in front: pv_out) */
+        if (zone == PZ_POLE_S || zone == PZ_POLE_N) { zout[o] = pv[zone == PZ_POLE_S ? 1 : 0]; continue; }      /* (listed when the pole values came from the launch in front: pv_out) */
         if (p.vector_mode) { Z.prow_n = p.pole_row_n; Z.prow_s = p.pole_row_s; }
-        else { Z.pole_n = p.polevals[0]; Z.pole_s = p.polevals[1]; }
+        else { Z.pole_n = pv[0]; Z.pole_s = pv[1]; }
         zout[o] = strip_point(p, Z, zone == PZ_STRIP_N, px, py);
     }
 }
@@ -3274,8 +3313,22 @@ static void kernels_thread_release(void)
     t_side_pending = false;
 }
 
+static int interp_pts_impl(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin, const float *d_x, const float *d_y, int npts, int nfields, size_t in_stride, size_t out_stride);
 extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin,
                                 const float *d_x, const float *d_y, int npts)
+{
+    return interp_pts_impl(plan, d_zout, d_zin, d_x, d_y, npts, 1, 0, 0);
+}
+/* nfields fields of one grid set through the staged-tile kernel in ONE launch (plan->uvt_tiles set, plan->polevals: 2 values per field, no pv_out): -2 when the
+ * plan is not on that path */
+extern "C" int ezhip_interp_pts_batch(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin, const float *d_x, const float *d_y, int npts,
+                                      int nfields, size_t in_stride, size_t out_stride)
+{
+    const int kind = pts_kind(plan);
+    if (!plan->uvt_tiles || plan->pv_out || !(kind == PK_IRGD3_W || (kind == PK_IRGD3_NW && plan->i1 == 1 && plan->i2 == plan->ni)) || plan->tile_ni <= 0 || plan->out_idx || !plan->xrec10 || nfields < 1) return -2;
+    return interp_pts_impl(plan, d_zout, d_zin, d_x, d_y, npts, nfields, in_stride, out_stride);
+}
+static int interp_pts_impl(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin, const float *d_x, const float *d_y, int npts, int nfields, size_t in_stride, size_t out_stride)
 {
     if (npts <= 0) return 0;
     const dim3 grid((npts + 255) / 256 + (plan->pv_out ? 2 : 0)), block(256);
@@ -3298,8 +3351,10 @@ extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const
         size_t lds = 4 * (size_t)((cap + 3) & ~3) + 80 * (size_t)UVT_REC_MAX + 16;
         if (lds < 4 * 2052 + 16) lds = 4 * 2052 + 16;
         if (lds > 65536) return -1;                      /* (no attribute needed up to 64 KB) */
-        if (kind_st == PK_IRGD3_W) hipLaunchKernelGGL((k_st<32, 32, false>), dim3(nt + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt);
-        else hipLaunchKernelGGL((k_st<32, 32, true>), dim3(nt + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt);
+#define ST_LAUNCH(NW, B) hipLaunchKernelGGL((k_st<32, 32, NW, B>), dim3(nt + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt, nfields, in_stride, out_stride)
+        if (kind_st == PK_IRGD3_W) { if (nfields > 1) ST_LAUNCH(false, true); else ST_LAUNCH(false, false); }
+        else { if (nfields > 1) ST_LAUNCH(true, true); else ST_LAUNCH(true, false); }
+#undef ST_LAUNCH
         if (LAUNCH_CHECK("k_st")) return -1;
     } else
 #define PTS_CASE(K) case K: hipLaunchKernelGGL(k_pts<K>, grid, block, 0, g_stream, *plan, d_zout, d_zin, d_x, d_y, npts, t_spec.list, cnt); break
@@ -3311,7 +3366,7 @@ extern "C" int ezhip_interp_pts(const ezhip_pts_plan *plan, float *d_zout, const
     if (LAUNCH_CHECK("k_pts")) return -1;
     if (ezhip_side_join()) return -1;       /* the special points read the polar wind rows a side stream may still be producing */
     /* always launched (it also re-arms the counter pair); a grid-stride loop over the few listed points */
-    hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan, d_zout, d_zin, d_x, d_y, t_spec.list, cnt, cnt_next);
+    hipLaunchKernelGGL(k_pts_special, dim3(npts < 65536 ? 16 : 256), block, 0, g_stream, *plan, d_zout, d_zin, d_x, d_y, t_spec.list, cnt, cnt_next, nfields, in_stride, out_stride);
     return LAUNCH_CHECK("k_pts_special");
 }
 

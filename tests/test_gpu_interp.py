@@ -1524,3 +1524,45 @@ def test_st_staged_tiles_regional_source(shape, extrap, target):
     finally:
         os.environ.pop("EZHIP_ST_MIN_POINTS", None); os.environ.pop("EZHIP_NO_ST", None)
         ez.gdrls(gdin); ez.gdrls(gdout)
+
+
+@pytest.mark.parametrize("polar", [1, 0])
+@pytest.mark.parametrize("kind", ["global_rotated", "regional"])
+def test_st_batch_equals_single_calls(kind, polar):
+    """c_ezsint_batch_dev on a set with its staged-tile table: ONE k_st launch for the batch (x, y, zones, special points once) against the fields one call at a
+    time, bit for bit; a rotated global source (pole points, polar strips, the seam) and a regional one"""
+    os.environ["EZHIP_ST_MIN_POINTS"] = "1"
+    try:
+        if kind == "global_rotated":
+            ni, nj, no, mo = 640, 320, 1000, 500
+            ax, ay = ec.ze_axes(ni, nj)
+            gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay); gdout = ez.ezqkdef(no, mo, "L", *ol.cxgaig("L", -90.0, 0.0, 180.0 / (mo - 1), 360.0 / no))
+        else:
+            ni, nj, no, mo = 400, 300, 700, 500
+            ax, ay = ec.zereg_axes(ni, nj)
+            gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ol.cxgaig("E", 0.0, 180.0, 0.0, 0.0), ax, ay)
+            gdout = ez.ezqkdef(no, mo, "L", *ol.cxgaig("L", -15.0, 155.0, 30.0 / (mo - 1), 40.0 / (no - 1)))
+        assert ez.ezdefset(gdout, gdin) == 1
+        setopts(3, polar)
+        F = 5
+        fields = np.stack([ec.synth_field(ni, nj, seed=30 + f) for f in range(F)])
+        if kind == "global_rotated":
+            fields.reshape(F, nj, ni)[:, :, -1] = fields.reshape(F, nj, ni)[:, :, 0]
+        ez.use_stream(torch.cuda.current_stream().cuda_stream)
+        d_in = torch.from_numpy(fields).cuda().contiguous()
+        singles = []
+        for f in range(F):
+            o = torch.full((no * mo,), float("nan"), dtype=torch.float32, device="cuda")
+            assert ez.ezsint_dev(o, d_in[f]) >= 0
+            singles.append(o)
+        for mode in ("batch", "no_st_batch"):
+            if mode == "no_st_batch":
+                os.environ["EZHIP_NO_ST_BATCH"] = "1"
+            d_out = torch.full((F, no * mo), float("nan"), dtype=torch.float32, device="cuda")
+            assert ez.ezsint_batch_dev(d_out, d_in, F) >= 0
+            torch.cuda.synchronize()
+            for f in range(F):
+                assert torch.equal(d_out[f].view(torch.int32), singles[f].view(torch.int32)), (mode, f, int((d_out[f] != singles[f]).sum()))
+    finally:
+        os.environ.pop("EZHIP_ST_MIN_POINTS", None); os.environ.pop("EZHIP_NO_ST_BATCH", None)
+        ez.gdrls(gdin); ez.gdrls(gdout)
