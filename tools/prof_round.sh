@@ -17,7 +17,7 @@ T=$(find $O/trace -name "*kernel_trace.csv" | head -1)
 python3 - "$T" "$O" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_sepx", "k_armn", "k_cf_", "k_cond", "k_stats", "k_bb_", "k_pts", "k_uvt", "k_polar", "k_interpv", "k_pg_", "k_a32_", "k_dsc", "k_armn_dec"))]
+keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_sepx", "k_armn", "k_cf_", "k_cond", "k_stats", "k_bb_", "k_pts", "k_uvt", "k_st<", "k_polar", "k_interpv", "k_pg_", "k_a32_", "k_dsc", "k_dmin", "k_drg", "k_rle", "k_armn_dec"))]
 with open(sys.argv[2] + "/dispatches.csv", "w") as f:
     f.write("dispatch_id,kernel,grid_x,workgroup_x,start_ns,end_ns,duration_us\n")
     for r in keep:
@@ -35,7 +35,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 with open(sys.argv[2], "w") as f:
     f.write("dispatch_id,kernel,grid,counter,value\n")
     for r in rows:
-        if any(k in r["Kernel_Name"] for k in ("k_sepx", "k_armn", "k_cf_", "k_cond", "k_stats", "k_bb_", "k_pts", "k_uvt", "k_polar")):
+        if any(k in r["Kernel_Name"] for k in ("k_sepx", "k_armn", "k_cf_", "k_cond", "k_stats", "k_bb_", "k_pts", "k_uvt", "k_st<", "k_polar")):
             f.write("%s,\"%s\",%s,%s,%s\n" % (r["Dispatch_Id"], r["Kernel_Name"].split("(")[0][:60], r["Grid_Size"], r["Counter_Name"], r["Counter_Value"]))
 PY
   rm -rf $O/pmc_$c
