@@ -2574,8 +2574,8 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
                 if (s->cspec_key == 0) { s->d_cspec_list = dl; s->d_cspec_xy = dxy; s->cspec_count = cnt; s->cspec_key = key; dl = NULL; dxy = NULL; first = 1; }
                 pthread_mutex_unlock(&g_plan_mtx);
                 /* with the special points known, the irregular bicubic pair can run from LDS-staged stencil windows: the tile table over the set's x, y, once */
-                if (first && degree == DEG_CUBIC && pu.irregular && pu.wrap != 0 && pu.tile_ni > 0 && pu.xrec10) {
-                    const int th = getenv("EZHIP_UVT_SHAPE") ? atoi(getenv("EZHIP_UVT_SHAPE")) : 3232;      /* 100 TW + TH: 3232, 3216, 6416, 6408 (same results) */
+                if (first && degree == DEG_CUBIC && pu.irregular && (pu.wrap != 0 || (pu.i1 == 1 && pu.i2 == pu.ni)) && pu.tile_ni > 0 && pu.xrec10) {
+                    const int th = pu.wrap == 0 ? 3232 : getenv("EZHIP_UVT_SHAPE") ? atoi(getenv("EZHIP_UVT_SHAPE")) : 3232;      /* 100 TW + TH: 3232, 3216, 6416, 6408 (same results) */
                     int cap = getenv("EZHIP_UVT_CAP") ? atoi(getenv("EZHIP_UVT_CAP")) : 2560;      /* 8 bytes a cell + 9 KB of records: five blocks per CU */
                     if (cap < 256) cap = 256;
                     if (cap > 4096) cap = 4096;

@@ -2904,7 +2904,8 @@ __global__ __launch_bounds__(256) void k_uvt_pack(ezhip_pts_plan p, const float 
 #ifndef UVT_WAVES
 #define UVT_WAVES 5
 #endif
-template <int TW, int TH>
+template <int TW, int TH, bool NW = false>      /* NW: a source without wrap (a regional 'Z' grid): both components in the LITERAL form of ez_irgdint_3_nw.inc (REAL statement
+                                                 * functions), as k_pts2<PK_IRGD3_NW> evaluates them on the set's first call */
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVT_WAVES, 8))) void k_uvt(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
                                              const float *__restrict__ zin1, const float *__restrict__ zin2,
                                              const float *__restrict__ xs, const float *__restrict__ ys, const int4 *__restrict__ tiles)
@@ -2947,7 +2948,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVT_WAVES, 
 #pragma unroll 1
         for (int k = 0; k < PPT; k++) {
             const unsigned cy = cy0 + (unsigned)(G::RSTEP * k);
-            if (okx && cy < (unsigned)p.tile_nj) pts2_point<PK_IRGD3_W, false>(p, zout1, zout2, zin1, zin2, xs, ys, (int)(cy * (unsigned)p.tile_ni + cx), nullptr, nullptr);
+            if (okx && cy < (unsigned)p.tile_nj) pts2_point<NW ? PK_IRGD3_NW : PK_IRGD3_W, NW>(p, zout1, zout2, zin1, zin2, xs, ys, (int)(cy * (unsigned)p.tile_ni + cx), nullptr, nullptr);
         }
         return;
     }
@@ -2996,6 +2997,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVT_WAVES, 
                 const float fx2 = (float)xa.y, fx3 = (float)xb.x, fy2 = (float)ya.y, fy3 = (float)yb.x;      /* (exact: they were REAL) */
                 const double x = (double)(fx2 + (fx3 - fx2) * (px[k] - (float)i));
                 const double y = (double)(fy2 + (fy3 - fy2) * (py[k] - (float)j));
+                if (NW) {
+#define UV_RF(e) ((double)(float)(e))
+                    float res[2];
+#pragma unroll
+                    for (int comp = 0; comp < 2; comp++) {
+                        double br[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const double z1 = (double)(comp ? q[r][0].y : q[r][0].x), z2 = (double)(comp ? q[r][1].y : q[r][1].x), z3 = (double)(comp ? q[r][2].y : q[r][2].x), z4 = (double)(comp ? q[r][3].y : q[r][3].x);
+                            const double a2 = UV_RF(d_fa2(xb.y, z1, z2));
+                            const double a3 = UV_RF(d_fa3(xb.y, xc.x, xc.y, z1, z2, z3));
+                            const double a4 = UV_RF(d_fa4(xb.y, xc.x, xc.y, xd.x, xd.y, xe.x, z1, z2, z3, z4));
+                            br[r] = UV_RF(d_fa(z1, a2, a3, a4, x, xa.x, xa.y, xb.x));
+                        }
+                        const double b12 = UV_RF(d_fa2(yb.y, br[0], br[1]));
+                        const double b13 = UV_RF(d_fa3(yb.y, yc.x, yc.y, br[0], br[1], br[2]));
+                        const double b14 = UV_RF(d_fa4(yb.y, yc.x, yc.y, yd.x, yd.y, ye.x, br[0], br[1], br[2], br[3]));
+                        res[comp] = (float)d_fa(br[0], b12, b13, b14, y, ya.x, ya.y, yb.x);
+                    }
+#undef UV_RF
+                    a = res[0]; bb = res[1];
+                } else {
                 const NewtonW wx = newton_w52(xb.y, xc.x, xc.y, xd.x, xd.y, xe.x, xe.y, x - xa.x, x - xa.y, x - xb.x);
                 const NewtonW wy = newton_w52(yb.y, yc.x, yc.y, yd.x, yd.y, ye.x, ye.y, y - ya.x, y - ya.y, y - yb.x);
                 const double wr[4] = {wy.w0, wy.w1, wy.w2, wy.g};
@@ -3006,6 +3029,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVT_WAVES, 
                     sv = fma(wr[r], newton_apply(wx, (double)q[r][0].y, (double)q[r][1].y, (double)q[r][2].y, (double)q[r][3].y), sv);
                 }
                 a = (float)su; bb = (float)sv;
+                }
             }
         } else continue;
         if (p.wind_M) {
@@ -3394,6 +3418,7 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     pu2.xcd_order = getenv("EZHIP_PTS_XCD") ? 1 : 0;                        /* development: XCD k takes the k-th eighth of the blocks (fewer fabric reads, measured slower) */
     if (getenv("EZHIP_PTS_NOTILE") || (long long)pu2.tile_ni * pu2.tile_nj != (long long)npts || pu2.out_idx) pu2.tile_ni = pu2.tile_nj = 0;
     const bool fast3w = pts_kind(plan_u) == PK_IRGD3_W && !pu2.newton_literal;
+    const bool stage3nw = pts_kind(plan_u) == PK_IRGD3_NW && plan_u->i1 == 1 && plan_u->i2 == plan_u->ni;      /* a regional source: k_uvt's literal twin */
     if (pu2.pw_out && (!fast3w || getenv("EZHIP_POLAR_WIND_SIDE"))) {
         /* kernels without the producer blocks: the rows come from k_polar_wind on the side stream, joined below before the special points */
         if (ezhip_side_begin()) return -1;
@@ -3408,7 +3433,7 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     const int tbw = pu2.tile_shape == 1 ? 64 : pu2.tile_shape == 2 ? 16 : pu2.tile_shape == 3 ? 128 : pu2.tile_shape == 5 ? 16 : 32;
     const int tbh = pu2.tile_shape == 1 ? 4 : pu2.tile_shape == 2 ? 16 : pu2.tile_shape == 3 ? 2 : pu2.tile_shape == 5 ? 16 : 8;
     const dim3 grid((pu2.tile_ni > 0 ? (unsigned)(((pu2.tile_ni + tbw - 1) / tbw) * ((pu2.tile_nj + tbh - 1) / tbh)) : (unsigned)((npts + 255) / 256)) + (pu2.pw_out ? 2u : 0u));
-    if (cached && fast3w && pu2.uvt_tiles && pu2.tile_ni > 0 && pu2.xrec10 && pu2.yrec10 && !pu2.out_idx) {
+    if (cached && (fast3w || stage3nw) && pu2.uvt_tiles && pu2.tile_ni > 0 && pu2.xrec10 && pu2.yrec10 && !pu2.out_idx) {
         /* the grid set's tile table is known: stencil windows staged in LDS (k_uvt); the set's special points behind it */
         pu2.uvt_debug = EZH_DEVINT("EZHIP_UVT_DEBUG");
         const unsigned nt = (unsigned)ezhip_uvt_ntiles(&pu2, pu2.uvt_shape);
@@ -3416,6 +3441,8 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
         const dim3 g(nt + (pu2.pw_out ? 2u : 0u));
         const size_t lds = (size_t)8 * (size_t)pu2.uvt_cap + 80 * UVT_REC_MAX;
 #define UVT_LAUNCH(TW, TH) hipLaunchKernelGGL((k_uvt<TW, TH>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl)
+        if (stage3nw) hipLaunchKernelGGL((k_uvt<32, 32, true>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl);      /* (tables of regional sets are built with 32 x 32 tiles) */
+        else
         switch (pu2.uvt_shape) { case 3216: UVT_LAUNCH(32, 16); break; case 6408: UVT_LAUNCH(64, 8); break; case 6416: UVT_LAUNCH(64, 16); break; default: UVT_LAUNCH(32, 32); break; }
 #undef UVT_LAUNCH
         if (LAUNCH_CHECK("k_uvt")) return -1;

@@ -1566,3 +1566,39 @@ def test_st_batch_equals_single_calls(kind, polar):
     finally:
         os.environ.pop("EZHIP_ST_MIN_POINTS", None); os.environ.pop("EZHIP_NO_ST_BATCH", None)
         ez.gdrls(gdin); ez.gdrls(gdout)
+
+
+@pytest.mark.parametrize("target", ["inside", "beyond"])
+@pytest.mark.parametrize("extrap", ["maximum", "value"])
+@pytest.mark.parametrize("shape", [(400, 300, 700, 500), (801, 603, 1500, 1100)])
+def test_uvt_staged_tiles_regional_source(shape, extrap, target):
+    """k_uvt's literal twin on a source WITHOUT wrap (a regional rotated grid: both components in the REAL statement functions of ez_irgdint_3_nw.inc): second and
+    third call of a set against the first (k_pts2) and against EZHIP_NO_UVT=1, bit for bit; a rotated frame, so the wind rotation is applied per point"""
+    ni, nj, no, mo = shape
+    ax, ay = ec.zereg_axes(ni, nj)
+    lat0, lon0, dlat, dlon = (28.0, 255.0, 24.0 / (mo - 1), 36.0 / (no - 1)) if target == "inside" else (15.0, 235.0, 50.0 / (mo - 1), 75.0 / (no - 1))
+    try:
+        gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ol.cxgaig("E", 40.0, 270.0, 50.0, 95.0), ax, ay)      # a tilted frame whose equator runs through the middle of North America
+        gdout = ez.ezqkdef(no, mo, "L", *ol.cxgaig("L", lat0, lon0, dlat, dlon))
+        assert ez.ezdefset(gdout, gdin) == 1
+        setopts(3, 1, extrap)
+        if extrap == "value":
+            assert ez.ezsetval("extrap_value", -55.0) == 0
+        uu, vv = ec.synth_wind(ni, nj, seed=19)
+        ez.use_stream(torch.cuda.current_stream().cuda_stream)
+        d_u = torch.from_numpy(uu).cuda(); d_v = torch.from_numpy(vv).cuda()
+        outs = []
+        for call in range(4):
+            o_u = torch.full((no * mo,), float("nan"), dtype=torch.float32, device="cuda"); o_v = torch.full_like(o_u, float("nan"))
+            if call == 3:
+                os.environ["EZHIP_NO_UVT"] = "1"
+            assert ez.ezuvint_dev(o_u, o_v, d_u, d_v) >= 0
+            torch.cuda.synchronize()
+            outs.append((o_u, o_v))
+        for k in (1, 2, 3):
+            assert torch.equal(outs[0][0].view(torch.int32), outs[k][0].view(torch.int32)), (k, int((outs[0][0] != outs[k][0]).sum()))
+            assert torch.equal(outs[0][1].view(torch.int32), outs[k][1].view(torch.int32)), k
+        assert not torch.isnan(outs[1][0]).any()
+    finally:
+        os.environ.pop("EZHIP_NO_UVT", None)
+        ez.gdrls(gdin); ez.gdrls(gdout)
