@@ -2480,9 +2480,9 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
     /* bicubic from an irregular source with wrap (a rotated global grid), the whole target grid in row order: from the second call of a set on the field runs from
      * LDS-staged stencil windows (k_st: bit-identical to k_pts; the tile table and the tile-ordered x, y are built once per set and zone options, behind the
      * first call).  EZHIP_NO_ST=1: k_pts every time */
-    const int st_ok = degree == DEG_CUBIC && pp.irregular && (pp.wrap != 0 || (pp.i1 == 1 && pp.i2 == pp.ni)) && pp.xrec10 && !pp.out_idx && !vector_mode && !src_hemi(gi) &&
+    const int st_ok = ((degree == DEG_CUBIC && (pp.wrap != 0 || (pp.i1 == 1 && pp.i2 == pp.ni)) && pp.xrec10) || degree == DEG_LINEAR) && pp.irregular && !pp.out_idx && !vector_mode && !src_hemi(gi) &&
                       (size_t)go->ni * go->nj >= (getenv("EZHIP_ST_MIN_POINTS") ? (size_t)atol(getenv("EZHIP_ST_MIN_POINTS")) : (size_t)262144) && !getenv("EZHIP_NO_ST");
-    const int st_key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4;
+    const int st_key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4 | degree << 12;      /* (one table per set: the first degree and zone options that ask) */
     int st_build = 0;
     if (st_ok) {
         pp.tile_ni = go->ni; pp.tile_nj = go->nj;
@@ -2501,7 +2501,7 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
         const int nt = ezhip_uvt_ntiles(&pt, 3232);
         void *dt = nt > 0 ? ezhip_malloc(16 * (size_t)nt) : NULL, *ds = nt > 0 ? ezhip_malloc((size_t)8 * 1024 * (size_t)nt) : NULL;
         int st[4] = {0, 0, 0, 0}, good = 0;
-        if (dt && ds && ezhip_uvt_build(&pt, s->d_x, s->d_y, dt, 3232, st) == 0 && st[0] >= 4 * st[1] && ezhip_st_pack_streams(&pt, s->d_x, s->d_y, ds) == 0) good = 1;
+        if (dt && ds && (degree == DEG_CUBIC ? ezhip_uvt_build(&pt, s->d_x, s->d_y, dt, 3232, st) : ezhip_st1_build(&pt, s->d_x, s->d_y, dt, st)) == 0 && st[0] >= 4 * st[1] && ezhip_st_pack_streams(&pt, s->d_x, s->d_y, ds) == 0) good = 1;
         pthread_mutex_lock(&g_plan_mtx);
         if (s->st_key == 0) {
             if (good) { s->d_st_tiles = dt; s->d_st_streams = ds; s->st_cap = cap; memcpy(s->st_stats, st, sizeof(st)); s->st_key = st_key; dt = ds = NULL; }
@@ -2648,12 +2648,12 @@ static int run_batch_st(ezh_set *s, float *d_zout, const float *d_zin, int nfiel
 {
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     const int degree = O.degre_interp, polar = O.polar_correction == 1;
-    if (degree != DEG_CUBIC || grid_yinv(gi) || src_hemi(gi) || corrbgd_applies(gi, go) || (polar && s->extrap)) return -2;
+    if ((degree != DEG_CUBIC && degree != DEG_LINEAR) || grid_yinv(gi) || src_hemi(gi) || corrbgd_applies(gi, go) || (polar && s->extrap)) return -2;
     if (polar && !d_poles_all) return -2;
     pthread_mutex_lock(&g_plan_mtx);
     const int mode = choose_mode(s, degree, polar);
     const int zones = !polar ? 0 : 1;
-    const int st_key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4;
+    const int st_key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4 | degree << 12;
     const int have = mode != 1 && s->st_key == st_key && s->d_st_tiles != NULL;
     pthread_mutex_unlock(&g_plan_mtx);
     if (!have) return -2;
@@ -2664,7 +2664,7 @@ static int run_batch_st(ezh_set *s, float *d_zout, const float *d_zin, int nfiel
     if (!erc) fill_pts_plan(s, gi, &pp, degree, zones, 0);
     pthread_mutex_unlock(&g_plan_mtx);
     if (erc) return -1;
-    if (!pp.irregular || !pp.xrec10 || pp.out_idx) return -2;
+    if (!pp.irregular || (degree == DEG_CUBIC && !pp.xrec10) || pp.out_idx) return -2;
     pp.fill = t_scratch8; pp.polevals = d_poles_all ? d_poles_all : t_scratch8 + 4;
     pp.tile_ni = go->ni; pp.tile_nj = go->nj;
     pp.uvt_tiles = s->d_st_tiles; pp.uvt_shape = 3232; pp.uvt_cap = s->st_cap; pp.uvt_streams = s->d_st_streams;

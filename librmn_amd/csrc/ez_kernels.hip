@@ -3209,6 +3209,188 @@ __global__ __launch_bounds__(256) void k_st(ezhip_pts_plan p, float *__restrict_
     }
 }
 
+/* ---- k_st1: the bilinear member of the family (ez_irgdint_1_w.inc / ez_irgdint_1_nw.inc from an irregular source) ---------------------------------------------
+ * The gathering kernel k_pts<PK_IRGD1_*> takes 54.7 us per 4000 x 2000 field from a rotated 2560 x 1280 source -- as long as the staged bicubic: four gathers of the
+ * field and four of the axes per point, no arithmetic to speak of.  Here the tile's window (columns i .. i + 1, rows j .. j + 1 of its normal points) and the axis
+ * entries under it are staged as floats; the arithmetic is p_irgdint_1_w's, operand for operand (NW: the clamps of p_irgdint_1_nw).  Tiles on the seam (the wrapped
+ * last column has its own x2) are handed back. */
+#define ST1_AXMAX 1024                                 /* axis entries (columns + rows) a tile may stage */
+template <bool NW> __device__ __forceinline__ void st1_ij(const ezhip_pts_plan &p, float px, float py, int &i, int &j)
+{
+    if (NW) { i = min(p.ni - 1, max(1, (int)px)); j = min(p.nj - 1, max(1, (int)py)); }
+    else { i = min(p.ni - 2 + p.wrap, max(1, (int)px)); j = min(p.j2 - 1, max(p.j1 + 1, (int)py)); }
+}
+template <bool NW>
+__global__ __launch_bounds__(256) void k_st1_bbox(ezhip_pts_plan p, const float *__restrict__ xs, const float *__restrict__ ys, int4 *__restrict__ tiles, int cap)
+{
+    typedef uvt_geom<32, 32> G;
+    __shared__ int red[4][6];
+    const unsigned tpr = ((unsigned)p.tile_ni + 31u) / 32u, b = blockIdx.x, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
+    const unsigned cx = bx * 32 + (t % 32);
+    int imin = 0x7fffffff, imax = -1, jmin = 0x7fffffff, jmax = -1, seam = 0, mine = 0;
+#pragma unroll
+    for (int k = 0; k < G::PPT; k++) {
+        const unsigned cy = by * 32 + t / 32 + (unsigned)(G::RSTEP * k);
+        if (cx >= (unsigned)p.tile_ni || cy >= (unsigned)p.tile_nj) continue;
+        const size_t n = (size_t)cy * p.tile_ni + cx;
+        const float px = xs[n], py = ys[n];
+        const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
+        if (zone == PZ_FILL) mine = 1;
+        if (zone != PZ_NORMAL) continue;
+        mine = 1;
+        int i, j;
+        st1_ij<NW>(p, px, py, i, j);
+        if (!NW && ((p.wrap > 0 && i == p.ni - 2 + p.wrap) || j < 0 || i + 1 > p.ni)) seam = 1;
+        imin = min(imin, i); imax = max(imax, i); jmin = min(jmin, j); jmax = max(jmax, j);
+    }
+    imin = uvt_wave_min(imin); jmin = uvt_wave_min(jmin); imax = uvt_wave_max(imax); jmax = uvt_wave_max(jmax); seam = uvt_wave_max(seam); mine = uvt_wave_max(mine);
+    if ((t & 63u) == 0) { int *r = red[t >> 6]; r[0] = imin; r[1] = imax; r[2] = jmin; r[3] = jmax; r[4] = seam; r[5] = mine; }
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < 4; w++) { imin = min(imin, red[w][0]); imax = max(imax, red[w][1]); jmin = min(jmin, red[w][2]); jmax = max(jmax, red[w][3]); seam |= red[w][4]; mine |= red[w][5]; }
+        int4 o;
+        if (!mine) o = make_int4(0, 0, -1, 0);
+        else if (imax < 0) o = make_int4(0, 0, 0, 0);
+        else {
+            const int W = imax - imin + 2, H = jmax - jmin + 2;
+            o = (!seam && W * H <= cap && W + H <= ST1_AXMAX) ? make_int4(imin, jmin, W, H) : make_int4(0, 0, 0, 0);
+        }
+        tiles[b] = o;
+    }
+}
+/* thread t of a 32 x 32 tile takes FOUR CONSECUTIVE COLUMNS of one row (columns 4 (t % 8) .., row t / 8): its x, y arrive as two 16-byte loads from the set's tile-ordered
+ * copy ([tile][half][thread] float4 {x, y, x, y}: a wave's load is one contiguous KB) and its results leave as one 16-byte store.  (Measured against k_st's map -- a
+ * column of four rows per thread, 8-byte loads, 4-byte stores: 47.9 against 47.4 us per cfg3 field: the kernel is not bound by the width of its accesses but by a
+ * thread block's chain of dependent round trips -- streams and table entry, window, barrier, two REAL*8 divisions per point, store -- at seven blocks per CU.) */
+__global__ __launch_bounds__(256) void k_st1_pack(ezhip_pts_plan p, const float *__restrict__ xs, const float *__restrict__ ys, float4 *__restrict__ streams)
+{
+    const unsigned tpr = ((unsigned)p.tile_ni + 31u) / 32u, b = blockIdx.x, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
+    const unsigned cx0 = bx * 32 + (t % 8) * 4, cy = by * 32 + t / 8;
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        v[2 * u] = 0.f; v[2 * u + 1] = 0.f;
+        if (cx0 + u < (unsigned)p.tile_ni && cy < (unsigned)p.tile_nj) { const size_t n = (size_t)cy * p.tile_ni + cx0 + u; v[2 * u] = xs[n]; v[2 * u + 1] = ys[n]; }
+    }
+    streams[((size_t)b * 2 + 0) * 256 + t] = make_float4(v[0], v[1], v[2], v[3]);
+    streams[((size_t)b * 2 + 1) * 256 + t] = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <bool NW>
+__global__ __launch_bounds__(256) void k_st1(ezhip_pts_plan p, float *__restrict__ zout0, const float *__restrict__ zin0,
+                                             const float *__restrict__ xs, const float *__restrict__ ys, const int4 *__restrict__ tiles,
+                                             int *__restrict__ special_list, unsigned *__restrict__ special_count, int nfields, size_t in_stride, size_t out_stride)
+{
+    typedef uvt_geom<32, 32> G;
+    constexpr int PPT = G::PPT;
+    constexpr int KIND = NW ? PK_IRGD1_NW : PK_IRGD1_W;
+    extern __shared__ __attribute__((aligned(16))) float st_lds[];
+    unsigned boff = 0;
+    if (p.pv_out) {
+        if (blockIdx.x < 2) {
+            const float *row = blockIdx.x == 0 ? zin0 + (size_t)(p.pv_nj - 1) * p.ni : zin0;
+            const float v = block_poleval(row, p.ni, p.pole_weighted, p.ax, st_lds, 2048);
+            if (threadIdx.x == 0) p.pv_out[blockIdx.x] = v;
+            return;
+        }
+        boff = 2;
+    }
+    const unsigned tpr = ((unsigned)p.tile_ni + 31u) / 32u, b = blockIdx.x - boff, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
+    const unsigned cx0 = bx * 32 + (t % 8) * 4, cy = by * 32 + t / 8;      /* four consecutive columns of one row */
+    const bool oky = cy < (unsigned)p.tile_nj;
+    float px[PPT], py[PPT];
+    const unsigned n0 = oky && cx0 < (unsigned)p.tile_ni ? cy * (unsigned)p.tile_ni + cx0 : 0u;
+    if (p.uvt_streams) {
+        typedef float f4a __attribute__((ext_vector_type(4)));
+        const f4a *S = (const f4a *)p.uvt_streams + (size_t)b * 512 + t;
+        const f4a q0 = __builtin_nontemporal_load(S), q1 = __builtin_nontemporal_load(S + 256);
+        px[0] = q0.x; py[0] = q0.y; px[1] = q0.z; py[1] = q0.w; px[2] = q1.x; py[2] = q1.y; px[3] = q1.z; py[3] = q1.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const bool ok = oky && cx0 + (unsigned)k < (unsigned)p.tile_ni;
+            const unsigned n = ok ? n0 + (unsigned)k : 0u;
+            px[k] = xs[n]; py[k] = ys[n];
+        }
+    }
+    const int4 tb = tiles[b];
+    if (tb.z <= 0) {
+#pragma unroll 1
+        for (int f = 0; f < nfields; f++) {
+#pragma unroll 1
+            for (int k = 0; k < PPT; k++) {
+                if (oky && cx0 + (unsigned)k < (unsigned)p.tile_ni) {
+                    const int n = (int)(n0 + (unsigned)k);
+                    pts1_point<KIND>(p, zout0 + (size_t)f * out_stride, zin0 + (size_t)f * in_stride, xs[n], ys[n], n, f == 0 ? special_list : nullptr, special_count, -1, p.polevals + 2 * f);
+                }
+            }
+        }
+        return;
+    }
+    const int i0 = tb.x, j0 = tb.y, W = tb.z, H = tb.w, ncell = W * H;
+    float *cells = st_lds, *axf = st_lds + ((ncell + 3) & ~3), *ayf = axf + W;
+    for (int k = (int)t; k < W; k += 256) axf[k] = p.ax[i0 - 1 + k];
+    for (int k = (int)t; k < H; k += 256) ayf[k] = p.ay[j0 - p.j1 + k];
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)W + 1u;
+    const size_t win0 = (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1);
+#pragma unroll 1
+    for (int f = 0; f < nfields; f++) {
+        const float *zin = zin0 + (size_t)f * in_stride;
+        float *zout = zout0 + (size_t)f * out_stride;
+        const float *pv = p.polevals + 2 * f;
+        if (f) __syncthreads();
+        {
+            const float *s1 = zin + win0;
+#pragma unroll 4
+            for (int idx = (int)t; idx < ncell; idx += 256) {
+                const unsigned r = __umulhi((unsigned)idx, magic), c = (unsigned)idx - r * (unsigned)W;
+                cells[idx] = s1[(size_t)r * (size_t)p.ni + c];
+            }
+        }
+        __syncthreads();
+        float res[PPT];
+        unsigned written = 0;                                         /* bit k: this kernel has the value of column k */
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            res[k] = 0.f;
+            if (!(oky && cx0 + (unsigned)k < (unsigned)p.tile_ni)) continue;
+            const int n = (int)(n0 + (unsigned)k);
+            const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px[k], py[k]);
+            if (zone != PZ_NORMAL) {
+                if (zone == PZ_FILL) { res[k] = *p.fill; written |= 1u << k; }
+                else if (!p.pv_out && (zone == PZ_POLE_S || zone == PZ_POLE_N)) { res[k] = pv[zone == PZ_POLE_S ? 1 : 0]; written |= 1u << k; }
+                else if (f == 0) {
+                    const unsigned long long m = __ballot(1);
+                    const int lane = (int)__lane_id(), leader = __ffsll((long long)m) - 1;
+                    unsigned base = 0;
+                    if (lane == leader) base = atomicAdd(special_count, (unsigned)__popcll(m));
+                    base = (unsigned)__shfl((int)base, leader, 64);
+                    special_list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = n;
+                }
+                continue;
+            }
+            int i, j;
+            st1_ij<NW>(p, px[k], py[k], i, j);
+            const double x1 = (double)axf[i - i0], x2 = (double)axf[i + 1 - i0];
+            const float ayj = ayf[j - j0], ayj1 = ayf[j + 1 - j0];
+            const double x = x1 + (x2 - x1) * (double)(px[k] - (float)i);
+            const double y = (double)(ayj + (ayj1 - ayj) * (py[k] - (float)j));
+            const double dx = (x - x1) / (x2 - x1);
+            const double dy = (y - (double)ayj) / (double)(ayj1 - ayj);
+            const float *cp = cells + (j - j0) * W + (i - i0);
+            const double y1 = d_zlin((double)cp[0], (double)cp[1], dx);
+            const double y2 = d_zlin((double)cp[W], (double)cp[W + 1], dx);
+            res[k] = (float)d_zlin(y1, y2, dy); written |= 1u << k;
+        }
+        if (written == 15u && ((p.tile_ni & 3) == 0)) {               /* the row pieces of a tile start at multiples of 32 columns: 16-byte aligned when ni is a multiple of 4 */
+            typedef float f4a __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(f4a{res[0], res[1], res[2], res[3]}, (f4a *)(zout + n0));
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPT; k++) if (written >> k & 1u) zout[n0 + (unsigned)k] = res[k];
+        }
+    }
+}
+
 /* (k_uvt as a pipeline -- persistent blocks with two staging buffers, the next tile's window and streams in flight while a tile is computed -- was built twice
  * and measured slower both times: with LDS-DMA staging (the window as separate u / v planes: twice the LDS read instructions) 111 us per cfg3 pair against 90;
  * with the next window held in registers (135 - 155 VGPRs, three waves per SIMD) 96 - 104 us for the kernel against 76.  profiles/r04_experiments.txt.) */
@@ -3349,7 +3531,8 @@ extern "C" int ezhip_interp_pts_batch(const ezhip_pts_plan *plan, float *d_zout,
                                       int nfields, size_t in_stride, size_t out_stride)
 {
     const int kind = pts_kind(plan);
-    if (!plan->uvt_tiles || plan->pv_out || !(kind == PK_IRGD3_W || (kind == PK_IRGD3_NW && plan->i1 == 1 && plan->i2 == plan->ni)) || plan->tile_ni <= 0 || plan->out_idx || !plan->xrec10 || nfields < 1) return -2;
+    const bool cubic = (kind == PK_IRGD3_W || (kind == PK_IRGD3_NW && plan->i1 == 1 && plan->i2 == plan->ni)) && plan->xrec10, linear = kind == PK_IRGD1_W || kind == PK_IRGD1_NW;
+    if (!plan->uvt_tiles || plan->pv_out || !(cubic || linear) || plan->tile_ni <= 0 || plan->out_idx || nfields < 1) return -2;
     return interp_pts_impl(plan, d_zout, d_zin, d_x, d_y, npts, nfields, in_stride, out_stride);
 }
 static int interp_pts_impl(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin, const float *d_x, const float *d_y, int npts, int nfields, size_t in_stride, size_t out_stride)
@@ -3368,6 +3551,17 @@ static int interp_pts_impl(const ezhip_pts_plan *plan, float *d_zout, const floa
     unsigned *cnt = t_spec.count + (t_spec.epoch & 1), *cnt_next = t_spec.count + ((t_spec.epoch + 1) & 1);
     t_spec.epoch++;
     const int kind_st = pts_kind(plan);
+    if (plan->uvt_tiles && (kind_st == PK_IRGD1_W || kind_st == PK_IRGD1_NW) && plan->tile_ni > 0 && !plan->out_idx) {
+        /* the bilinear staged-tile kernel (the set's table was built for this degree and these zone options) */
+        const int cap = plan->uvt_cap > 0 ? plan->uvt_cap : UVT_CAP_DEFAULT;
+        const unsigned nt = (unsigned)ezhip_uvt_ntiles(plan, 3232);
+        size_t lds = 4 * (size_t)((cap + 3) & ~3) + 4 * (size_t)ST1_AXMAX + 16;
+        if (lds < 4 * 2052 + 16) lds = 4 * 2052 + 16;
+        if (lds > 65536) return -1;
+        if (kind_st == PK_IRGD1_W) hipLaunchKernelGGL(k_st1<false>, dim3(nt + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt, nfields, in_stride, out_stride);
+        else hipLaunchKernelGGL(k_st1<true>, dim3(nt + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt, nfields, in_stride, out_stride);
+        if (LAUNCH_CHECK("k_st1")) return -1;
+    } else
     if (plan->uvt_tiles && (kind_st == PK_IRGD3_W || (kind_st == PK_IRGD3_NW && plan->i1 == 1 && plan->i2 == plan->ni)) && plan->tile_ni > 0 && !plan->out_idx && plan->xrec10) {
         /* the scalar staged-tile kernel (the set's table was built under this plan's zone options) */
         const int cap = plan->uvt_cap > 0 ? plan->uvt_cap : UVT_CAP_DEFAULT;
@@ -3535,10 +3729,31 @@ extern "C" int ezhip_uvt_pack_streams(const ezhip_pts_plan *plan, const float *d
     return set_err(hipStreamSynchronize(g_stream), "k_uvt_pack");
 }
 
+/* the tile table of the bilinear kernel (k_st1_bbox): as ezhip_uvt_build, 32 x 32 tiles */
+extern "C" int ezhip_st1_build(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_tiles, int *stats)
+{
+    const int nt = ezhip_uvt_ntiles(plan, 3232), kind = pts_kind(plan);
+    if (nt <= 0 || !d_tiles || !(kind == PK_IRGD1_W || kind == PK_IRGD1_NW)) return -1;
+    const int cap = plan->uvt_cap > 0 ? plan->uvt_cap : UVT_CAP_DEFAULT;
+    if (kind == PK_IRGD1_W) hipLaunchKernelGGL(k_st1_bbox<false>, dim3(nt), dim3(256), 0, g_stream, *plan, d_x, d_y, (int4 *)d_tiles, cap);
+    else hipLaunchKernelGGL(k_st1_bbox<true>, dim3(nt), dim3(256), 0, g_stream, *plan, d_x, d_y, (int4 *)d_tiles, cap);
+    if (LAUNCH_CHECK("k_st1_bbox") || set_err(hipStreamSynchronize(g_stream), "k_st1_bbox")) return -1;
+    if (stats) {
+        int4 *h = (int4 *)malloc(sizeof(int4) * (size_t)nt);
+        if (!h) return -1;
+        if (set_err(hipMemcpy(h, d_tiles, sizeof(int4) * (size_t)nt, hipMemcpyDeviceToHost), "k_st1_bbox tiles")) { free(h); return -1; }
+        stats[0] = stats[1] = stats[2] = stats[3] = 0;
+        for (int k = 0; k < nt; k++) { if (h[k].z > 0) { stats[0]++; if (h[k].z * h[k].w > stats[3]) stats[3] = h[k].z * h[k].w; } else if (h[k].z == 0) stats[1]++; else stats[2]++; }
+        free(h);
+    }
+    return 0;
+}
 extern "C" int ezhip_st_pack_streams(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_streams)
 {
-    const int nt = ezhip_uvt_ntiles(plan, 3232);
+    const int nt = ezhip_uvt_ntiles(plan, 3232), kind = pts_kind(plan);
     if (nt <= 0 || !d_streams) return -1;
+    if (kind == PK_IRGD1_W || kind == PK_IRGD1_NW) hipLaunchKernelGGL(k_st1_pack, dim3(nt), dim3(256), 0, g_stream, *plan, d_x, d_y, (float4 *)d_streams);      /* (the bilinear kernel's thread-to-point map) */
+    else
     hipLaunchKernelGGL((k_st_pack<32, 32>), dim3(nt), dim3(256), 0, g_stream, *plan, d_x, d_y, (float2 *)d_streams);
     if (LAUNCH_CHECK("k_st_pack")) return -1;
     return set_err(hipStreamSynchronize(g_stream), "k_st_pack");

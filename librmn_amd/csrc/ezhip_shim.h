@@ -273,6 +273,7 @@ int ezhip_uvt_build(const ezhip_pts_plan *plan, const float *d_x, const float *d
 size_t ezhip_uvt_stream_bytes(const ezhip_pts_plan *plan, int shape);
 int ezhip_uvt_pack_streams(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_streams, int shape);
 int ezhip_interp_pts_batch(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin, const float *d_x, const float *d_y, int npts, int nfields, size_t in_stride, size_t out_stride);      /* k_st over a batch: -2 when the plan is not on that path */
+int ezhip_st1_build(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_tiles, int *stats);      /* k_st1: the bilinear kernel's tile table (32 x 32 tiles) */
 int ezhip_st_pack_streams(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_streams);      /* k_st: {x, y} of every point in tile order (32 x 32 tiles), 8 bytes x 1024 x ntiles */
 int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_plan *plan_v, float *d_out_u, float *d_out_v,
                       const float *d_in_u, const float *d_in_v, const float *d_x, const float *d_y, int npts);

@@ -1454,10 +1454,11 @@ def test_uvt_staged_tiles_equal_gathering_kernel(shape, eig, th):
         ez.gdrls(gdin); ez.gdrls(gdout)
 
 
+@pytest.mark.parametrize("degree", [3, 1])
 @pytest.mark.parametrize("polar", [1, 0])
 @pytest.mark.parametrize("shape", [(320, 160, 500, 250), (257, 130, 333, 167), (640, 320, 1000, 500), (1280, 640, 2000, 1000)])
 @pytest.mark.parametrize("eig", ["cfg3", "tilted"])
-def test_st_staged_tiles_equal_gathering_kernel(shape, eig, polar):
+def test_st_staged_tiles_equal_gathering_kernel(shape, eig, polar, degree):
     """k_st (c_ezsint from a rotated global source out of LDS-staged stencil windows, second call of a grid set on) against k_pts (first call; EZHIP_NO_ST=1):
     bit-identical fields, with the seam, both rotated poles, ragged edges, pole points and polar strips in the target; then against the oracle's gdxysint at
     the located points (the literal form of ez_irgdint_3_w)"""
@@ -1468,7 +1469,7 @@ def test_st_staged_tiles_equal_gathering_kernel(shape, eig, polar):
     try:
         gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ig, ax, ay); gdout = ez.ezqkdef(no, mo, "L", *ol.cxgaig("L", -90.0, 0.0, 180.0 / (mo - 1), 360.0 / no))
         assert ez.ezdefset(gdout, gdin) == 1
-        setopts(3, polar)
+        setopts(degree, polar)                                    # 3: k_st, 1: k_st1 (the bilinear member)
         f = ec.synth_field(ni, nj, seed=17)
         f2 = f.reshape(nj, ni); f2[:, -1] = f2[:, 0]
         ez.use_stream(torch.cuda.current_stream().cuda_stream)
@@ -1489,10 +1490,11 @@ def test_st_staged_tiles_equal_gathering_kernel(shape, eig, polar):
         ez.gdrls(gdin); ez.gdrls(gdout)
 
 
+@pytest.mark.parametrize("degree", [3, 1])
 @pytest.mark.parametrize("target", ["inside", "beyond"])
 @pytest.mark.parametrize("extrap", ["maximum", "value", "linear"])
 @pytest.mark.parametrize("shape", [(400, 300, 700, 500), (801, 603, 1500, 1100)])
-def test_st_staged_tiles_regional_source(shape, extrap, target):
+def test_st_staged_tiles_regional_source(shape, extrap, target, degree):
     """k_st on a source WITHOUT wrap (a regional Z-on-E grid: ez_irgdint_3_nw.inc, whose statement functions are REAL): second and third call of a set against the
     first (k_pts) and against EZHIP_NO_ST=1, bit for bit; a target inside the source's region and one that reaches beyond it (extrapolation zones: filled with a
     value, the field's maximum, or re-interpolated at a lower degree by the next kernel)"""
@@ -1504,7 +1506,7 @@ def test_st_staged_tiles_regional_source(shape, extrap, target):
         gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ol.cxgaig("E", 0.0, 180.0, 0.0, 0.0), ax, ay)      # the identity rotation: the rotated frame is the geographic one
         gdout = ez.ezqkdef(no, mo, "L", *ol.cxgaig("L", lat0, lon0, dlat, dlon))
         assert ez.ezdefset(gdout, gdin) == 1
-        setopts(3, 1, extrap)
+        setopts(degree, 1, extrap)
         if extrap == "value":
             assert ez.ezsetval("extrap_value", -777.0) == 0
         f = ec.synth_field(ni, nj, seed=23)
@@ -1526,9 +1528,10 @@ def test_st_staged_tiles_regional_source(shape, extrap, target):
         ez.gdrls(gdin); ez.gdrls(gdout)
 
 
+@pytest.mark.parametrize("degree", [3, 1])
 @pytest.mark.parametrize("polar", [1, 0])
 @pytest.mark.parametrize("kind", ["global_rotated", "regional"])
-def test_st_batch_equals_single_calls(kind, polar):
+def test_st_batch_equals_single_calls(kind, polar, degree):
     """c_ezsint_batch_dev on a set with its staged-tile table: ONE k_st launch for the batch (x, y, zones, special points once) against the fields one call at a
     time, bit for bit; a rotated global source (pole points, polar strips, the seam) and a regional one"""
     os.environ["EZHIP_ST_MIN_POINTS"] = "1"
@@ -1543,7 +1546,7 @@ def test_st_batch_equals_single_calls(kind, polar):
             gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ol.cxgaig("E", 0.0, 180.0, 0.0, 0.0), ax, ay)
             gdout = ez.ezqkdef(no, mo, "L", *ol.cxgaig("L", -15.0, 155.0, 30.0 / (mo - 1), 40.0 / (no - 1)))
         assert ez.ezdefset(gdout, gdin) == 1
-        setopts(3, polar)
+        setopts(degree, polar)
         F = 5
         fields = np.stack([ec.synth_field(ni, nj, seed=30 + f) for f in range(F)])
         if kind == "global_rotated":
