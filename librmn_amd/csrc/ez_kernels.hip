@@ -3063,8 +3063,14 @@ __global__ __launch_bounds__(256) void k_st_pack(ezhip_pts_plan p, const float *
         streams[((size_t)b * G::PPT + k) * 256 + t] = o;
     }
 }
+#ifndef ST_WAVES
+#define ST_WAVES 7
+#endif
+#ifndef STB_WAVES
+#define STB_WAVES 4
+#endif
 template <int TW, int TH, bool NW, bool BATCH>      /* BATCH: nfields > 1 with the next field's window prefetched (its own instantiation: ten more registers); NW: a source without wrap (a regional 'Z' grid): ez_irgdint_3_nw.inc:20-168, whose statement functions are REAL (each result rounded) */
-__global__ __launch_bounds__(256) void k_st(ezhip_pts_plan p, float *__restrict__ zout0, const float *__restrict__ zin0,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? STB_WAVES : ST_WAVES, 8))) void k_st(ezhip_pts_plan p, float *__restrict__ zout0, const float *__restrict__ zin0,
                                             const float *__restrict__ xs, const float *__restrict__ ys, const int4 *__restrict__ tiles,
                                             int *__restrict__ special_list, unsigned *__restrict__ special_count,
                                             int nfields, size_t in_stride, size_t out_stride)      /* nfields > 1 (c_ezsint_batch_dev): the fields one after the other per tile -- x, y, zones and the
@@ -3214,6 +3220,9 @@ __global__ __launch_bounds__(256) void k_st(ezhip_pts_plan p, float *__restrict_
  * field and four of the axes per point, no arithmetic to speak of.  Here the tile's window (columns i .. i + 1, rows j .. j + 1 of its normal points) and the axis
  * entries under it are staged as floats; the arithmetic is p_irgdint_1_w's, operand for operand (NW: the clamps of p_irgdint_1_nw).  Tiles on the seam (the wrapped
  * last column has its own x2) are handed back. */
+#ifndef ST1_WAVES
+#define ST1_WAVES 7
+#endif
 #define ST1_AXMAX 1024                                 /* axis entries (columns + rows) a tile may stage */
 template <bool NW> __device__ __forceinline__ void st1_ij(const ezhip_pts_plan &p, float px, float py, int &i, int &j)
 {
@@ -3275,8 +3284,8 @@ __global__ __launch_bounds__(256) void k_st1_pack(ezhip_pts_plan p, const float 
     streams[((size_t)b * 2 + 0) * 256 + t] = make_float4(v[0], v[1], v[2], v[3]);
     streams[((size_t)b * 2 + 1) * 256 + t] = make_float4(v[4], v[5], v[6], v[7]);
 }
-template <bool NW>
-__global__ __launch_bounds__(256) void k_st1(ezhip_pts_plan p, float *__restrict__ zout0, const float *__restrict__ zin0,
+template <bool NW, bool BATCH>      /* BATCH: the loop over the fields of a batch (its per-point state lives across the loop: 109 VGPRs; one field: no loop) */
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? 4 : ST1_WAVES, 8))) void k_st1(ezhip_pts_plan p, float *__restrict__ zout0, const float *__restrict__ zin0,
                                              const float *__restrict__ xs, const float *__restrict__ ys, const int4 *__restrict__ tiles,
                                              int *__restrict__ special_list, unsigned *__restrict__ special_count, int nfields, size_t in_stride, size_t out_stride)
 {
@@ -3284,6 +3293,7 @@ __global__ __launch_bounds__(256) void k_st1(ezhip_pts_plan p, float *__restrict
     constexpr int PPT = G::PPT;
     constexpr int KIND = NW ? PK_IRGD1_NW : PK_IRGD1_W;
     extern __shared__ __attribute__((aligned(16))) float st_lds[];
+    const int nf = BATCH ? nfields : 1;
     unsigned boff = 0;
     if (p.pv_out) {
         if (blockIdx.x < 2) {
@@ -3315,7 +3325,7 @@ __global__ __launch_bounds__(256) void k_st1(ezhip_pts_plan p, float *__restrict
     const int4 tb = tiles[b];
     if (tb.z <= 0) {
 #pragma unroll 1
-        for (int f = 0; f < nfields; f++) {
+        for (int f = 0; f < nf; f++) {
 #pragma unroll 1
             for (int k = 0; k < PPT; k++) {
                 if (oky && cx0 + (unsigned)k < (unsigned)p.tile_ni) {
@@ -3333,7 +3343,7 @@ __global__ __launch_bounds__(256) void k_st1(ezhip_pts_plan p, float *__restrict
     const unsigned magic = 0xFFFFFFFFu / (unsigned)W + 1u;
     const size_t win0 = (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1);
 #pragma unroll 1
-    for (int f = 0; f < nfields; f++) {
+    for (int f = 0; f < nf; f++) {
         const float *zin = zin0 + (size_t)f * in_stride;
         float *zout = zout0 + (size_t)f * out_stride;
         const float *pv = p.polevals + 2 * f;
@@ -3558,8 +3568,10 @@ static int interp_pts_impl(const ezhip_pts_plan *plan, float *d_zout, const floa
         size_t lds = 4 * (size_t)((cap + 3) & ~3) + 4 * (size_t)ST1_AXMAX + 16;
         if (lds < 4 * 2052 + 16) lds = 4 * 2052 + 16;
         if (lds > 65536) return -1;
-        if (kind_st == PK_IRGD1_W) hipLaunchKernelGGL(k_st1<false>, dim3(nt + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt, nfields, in_stride, out_stride);
-        else hipLaunchKernelGGL(k_st1<true>, dim3(nt + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt, nfields, in_stride, out_stride);
+#define ST1_LAUNCH(NW, B) hipLaunchKernelGGL((k_st1<NW, B>), dim3(nt + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt, nfields, in_stride, out_stride)
+        if (kind_st == PK_IRGD1_W) { if (nfields > 1) ST1_LAUNCH(false, true); else ST1_LAUNCH(false, false); }
+        else { if (nfields > 1) ST1_LAUNCH(true, true); else ST1_LAUNCH(true, false); }
+#undef ST1_LAUNCH
         if (LAUNCH_CHECK("k_st1")) return -1;
     } else
     if (plan->uvt_tiles && (kind_st == PK_IRGD3_W || (kind_st == PK_IRGD3_NW && plan->i1 == 1 && plan->i2 == plan->ni)) && plan->tile_ni > 0 && !plan->out_idx && plan->xrec10) {
