@@ -647,6 +647,15 @@ def test_known_answers_on_the_gpu():
             assert [int(x) for x in z[w0:w0 + len(words)]] == words, (w0, [hex(int(x)) for x in z[w0:w0 + len(words)]])
         rc, back = pk.armn_uncompress32(z, 16, 16, 32)
         assert rc == 256 and np.array_equal(back.view(np.uint32), f.view(np.uint32))
+    # its sign sub-stream (pack1bitRLE): counted runs, the cut into 62s, the 255-repeat byte; decoded by the host walk and by the device kernels (k_rle_*)
+    for ni, nj in ((16, 16), (32, 32)):
+        f, pieces, zlng = ka.armn32_signed(ni, nj)
+        zl, z = pk.armn_compress32(f, ni, nj, 32)
+        assert zl == zlng
+        for w0, words in pieces:
+            assert [int(x) for x in z[w0:w0 + len(words)]] == words, (w0, [hex(int(x)) for x in z[w0:w0 + len(words)]])
+        for rc, back in (pk.armn_uncompress32(z, ni, nj, 32), pk.armn_uncompress32_lng(z, 4 * ((zl + 3) // 4), ni, nj, 32)):
+            assert rc == ni * nj and np.array_equal(back.view(np.uint32), f.view(np.uint32))
 
 
 # ---------------------------------------------------------------------------------------------

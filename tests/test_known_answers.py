@@ -229,6 +229,37 @@ def armn32_step_16x16(with_mantissa):
     return f.reshape(-1), pieces, 40 + lng_m
 
 
+def armn32_signed(ni, nj):
+    """the sign sub-stream of c_armn_compress32 (pack1bitRLE, armn_compress_32.c:827-905; code DIFF_SIGNE_PACKED 0x20, :171-176): the field of armn32_step_16x16
+       (1.0 on the first row and column, 2.0 elsewhere) with its first 20 values negated.  Signs: a run of 20 ones, then ni * nj - 20 zeros.  Tokens are 8 bits:
+       COUNT(1) | value | 6-bit count for runs of 8 .. 62 (:888-893); a longer run is cut into 62s (:862) -- and from the second piece on, while more than 256
+       points remain, the byte 0xFF stands for 255 more points of the last value (:865-869); 32 zero bits end the stream (:902-903).
+         16 x 16: 11|010100 (20 ones) = D4; 236 zeros = 62 + 62 + 62 + 50 (never more than 256 left): BE BE BE, 10|110010 = B2; + 32 zero bits = 72 bits: two words
+                  flushed, lng = 1 + 4 * 2 = 9 -> 12 bytes (:183-185)
+         32 x 32: D4; 1004 zeros = 62 (BE), then 942, 687, 432 left: FF FF FF (255 each), then 177 = 62 + 62 + 53: BE BE, 10|110101 = B5; + 32 zero bits = 96 bits.  `stuff` writes a word when the NEXT token
+                  does not fit (bitPacking.h:126-139): the third, exactly full word is never flushed: two words, lng = 9 -> 12 bytes as well
+       Layout (:160-245): [w0][w1: codes 0x20 | 0x08][lng_signe][sign words][lng_exposant][exponent plane][slot := lng_signe (sic, :244)][mantissa plane].  The planes
+       are armn32_step_16x16's with ni + nj - 1 prefix entries and ((ni + 1) / 3) x ((nj + 1) / 3) tiles; mantissas all zero."""
+    f = np.full((nj, ni), 2.0, np.float32); f[0, :] = 1.0; f[:, 0] = 1.0
+    f = f.reshape(-1); f[:20] *= -1.0
+    ntiles = ((ni - 1 + 2) // 3) * ((nj - 1 + 2) // 3)
+    if (ni, nj) == (16, 16):
+        sign = [0xD4BEBEBE, 0xB2000000]; lng_s = 12
+    else:
+        assert (ni, nj) == (32, 32)
+        sign = [0xD4BEFFFF, 0xFFBEBEB5]; lng_s = 12
+    efields = [(4, 3)] + [(0, 1)] * (ni + nj - 1) + [(1, 4), (1, 2)] + [(0, 2)] * 8 + [(0, 4)] * (ntiles - 1)
+    ebits = sum(w for _, w in efields); ne = (ebits + 31) // 32
+    lng_e = 1 + 4 * ne; lng_e += (4 - lng_e % 4) % 4
+    mfields = [(5, 3)] + [(0, 23)] * (ni + nj - 1) + [(0, 5)] * ntiles
+    mbits = sum(w for _, w in mfields); nm = (mbits + 31) // 32
+    lng_m = 1 + 4 * nm; lng_m += (4 - lng_m % 4) % 4
+    w_e = 3 + lng_s // 4                                     # the exponent plane's length word
+    w_m = w_e + 1 + lng_e // 4                               # the slot in front of the mantissa plane
+    pieces = [(0, [0x0008DD95, 0x007F0128, lng_s]), (3, sign), (w_e, [lng_e]), (w_e + 1, _bits(efields)[:ne]), (w_m, [lng_s]), (w_m + 1, _bits(mfields)[:nm])]
+    return f, pieces, 4 * (w_m + 1) + lng_m
+
+
 def check_pack_vector(name, v, cf_pack, ci_pack, fp_pack):
     """runs one vector through the three packer callables (oracle or HIP path) and compares with the hand-computed words"""
     if name.startswith("cf_"):
@@ -303,3 +334,16 @@ def test_armn32_known_answers_oracle(with_mantissa):
     assert ta32.O().orc_armn_compress32(z.ctypes.data, f.ctypes.data, 16, 16, 1, 32) == zlng == (180 if with_mantissa else 152)
     for w0, words in pieces:
         assert [int(x) for x in z[w0:w0 + len(words)]] == words, (w0, [hex(int(x)) for x in z[w0:w0 + len(words)]], [hex(x) for x in words])
+
+
+@pytest.mark.parametrize("ni,nj,want", [(16, 16, 168), (32, 32, 372)])
+def test_armn32_sign_runs_known_answers_oracle(ni, nj, want):
+    import test_oracle_armn32 as ta32
+    f, pieces, zlng = armn32_signed(ni, nj)
+    z = np.zeros(ni * nj * 2 + 64, np.uint32)
+    assert ta32.O().orc_armn_compress32(z.ctypes.data, f.ctypes.data, ni, nj, 1, 32) == zlng == want
+    for w0, words in pieces:
+        assert [int(x) for x in z[w0:w0 + len(words)]] == words, (w0, [hex(int(x)) for x in z[w0:w0 + len(words)]], [hex(x) for x in words])
+    back = np.zeros(ni * nj, np.float32)
+    assert ta32.O().orc_armn_uncompress32(back.ctypes.data, z.ctypes.data, ni, nj, 1, 32) == ni * nj
+    assert np.array_equal(back.view(np.uint32), f.view(np.uint32))
