@@ -647,6 +647,14 @@ def test_known_answers_on_the_gpu():
             assert [int(x) for x in z[w0:w0 + len(words)]] == words, (w0, [hex(int(x)) for x in z[w0:w0 + len(words)]])
         rc, back = pk.armn_uncompress32(z, 16, 16, 32)
         assert rc == 256 and np.array_equal(back.view(np.uint32), f.view(np.uint32))
+    # compact_integer with a bit offset and a stride: the words around the tokens keep their bits
+    a, before, after = ka.ci_offset_stride()
+    out = np.array([before, 0x55555555], np.uint32)
+    assert pk._lib().compact_integer(a.ctypes.data, None, out.ctypes.data, 3, 4, 8, 2, 1) == 4
+    assert int(out[0]) == after and int(out[1]) == 0x55555555
+    back = np.full(5, 7, np.uint32)
+    assert pk._lib().compact_integer(back.ctypes.data, None, out.ctypes.data, 3, 4, 8, 2, 2) == 4
+    assert [int(x) for x in back] == [1, 7, 2, 7, 3]
     # its sign sub-stream (pack1bitRLE): counted runs, the cut into 62s, the 255-repeat byte; decoded by the host walk and by the device kernels (k_rle_*)
     for ni, nj in ((16, 16), (32, 32)):
         f, pieces, zlng = ka.armn32_signed(ni, nj)

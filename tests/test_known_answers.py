@@ -347,3 +347,20 @@ def test_armn32_sign_runs_known_answers_oracle(ni, nj, want):
     back = np.zeros(ni * nj, np.float32)
     assert ta32.O().orc_armn_uncompress32(back.ctypes.data, z.ctypes.data, ni, nj, 1, 32) == ni * nj
     assert np.array_equal(back.view(np.uint32), f.view(np.uint32))
+
+
+def ci_offset_stride():
+    """compact_integer with a bit offset and a stride (compact_integer.c:136-170, :104-125): a = [1, 99, 2, 99, 3], stride 2 -> the tokens 1, 2, 3 in 4 bits behind the
+       first 8 bits of a word that holds 0xAB000FFF: lastWordShifted = 0xAB, then 0xAB123 with 12 bits of space left; the squeeze at the end (:165-169) keeps the
+       word's last 12 bits: 0xAB123FFF.  Returns 4 (the token size).  Unpacking from bit 8 with stride 2 writes elements 0, 2, 4 and leaves 1, 3 alone."""
+    return np.array([1, 99, 2, 99, 3], np.uint32), 0xAB000FFF, 0xAB123FFF
+
+
+def test_ci_offset_stride_known_answer_oracle():
+    a, before, after = ci_offset_stride()
+    out = np.array([before, 0x55555555], np.uint32)
+    assert top.O().orc_compact_integer(a.ctypes.data, None, out.ctypes.data, 3, 4, 8, 2, 1) == 4
+    assert int(out[0]) == after and int(out[1]) == 0x55555555
+    back = np.full(5, 7, np.uint32)
+    assert top.O().orc_compact_integer(back.ctypes.data, None, out.ctypes.data, 3, 4, 8, 2, 2) == 4
+    assert [int(x) for x in back] == [1, 7, 2, 7, 3]
