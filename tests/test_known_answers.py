@@ -133,6 +133,10 @@ PACK_VECTORS = {
     # 2.0 -> 0x800000, 3.0 -> 0xC00000; range 0x800000: smallest shift with range >> s <= 255 is 16 (0x80), Round = 0x8000;
     # tokens (m - Min + Round) >> 16 = 0, 0x40, 0x80; h[0] = 0xEFF << 20 | (8 - 1) << 16 | 128 << 8 | 16
     "fp_round": dict(a=[1.0, 2.0, 3.0], nbits=8, hdr=[0xEFF78010, 0x00400000, 3], stream=[0x00000040, 0x00800000]),
+    # both signs, 16 bits: [-1, 2]: MaxExp 128 (2.0); Maximum = 0x800000; Minimum: 1.0's mantissa 0x800000 >> (128 - 127) = 0x400000, negated (:160-168);
+    # range 0xC00000: >> 8 = 0xC000 <= 0xFFFF (>> 7 = 0x18000 is not): Shift2 8, Round 0x80; tokens (-0x400000 + 0x400000 + 0x80) >> 8 = 0 and
+    # (0x800000 + 0x400000 + 0x80) >> 8 = 0xC000, two per word; h[0] = 0xEFF << 20 | 15 << 16 | 128 << 8 | 8; h[1] = Minimum = -0x400000
+    "fp_signed": dict(a=[-1.0, 2.0], nbits=16, hdr=[0xEFFF8008, 0xFFC00000, 2], stream=[0x0000C000]),
 }
 
 
