@@ -647,6 +647,18 @@ def test_known_answers_on_the_gpu():
             assert [int(x) for x in z[w0:w0 + len(words)]] == words, (w0, [hex(int(x)) for x in z[w0:w0 + len(words)]])
         rc, back = pk.armn_uncompress32(z, 16, 16, 32)
         assert rc == 256 and np.array_equal(back.view(np.uint32), f.view(np.uint32))
+    # the data part of an FST record (c_fstecr's packing switch) composed by hand from the vectors above
+    for datyp, nbits, f, ni, nj, pieces, nw in ka.fst_data_part_vectors():
+        w, d_out, b_out, buf = pk.fst_pack_data(f, ni, nj, 1, datyp, nbits)
+        assert d_out == datyp and b_out == nbits and w > 0, (datyp, d_out, b_out, w)
+        if nw is not None:
+            assert w == nw
+        for w0, want in pieces:
+            assert [int(x) for x in buf[w0:w0 + len(want)]] == want, (datyp, w0, [hex(int(x)) for x in buf[w0:w0 + len(want)]])
+        rc, back = pk.fst_unpack_data(buf, ni, nj, 1, d_out, b_out, dtype=f.dtype)
+        assert rc == 0 or rc == ni * nj, rc
+        if datyp != 6:
+            assert np.array_equal(back.view(np.uint32), f.view(np.uint32)), datyp
     # compact_integer with a bit offset and a stride: the words around the tokens keep their bits
     a, before, after = ka.ci_offset_stride()
     out = np.array([before, 0x55555555], np.uint32)

@@ -368,3 +368,33 @@ def test_ci_offset_stride_known_answer_oracle():
     back = np.full(5, 7, np.uint32)
     assert top.O().orc_compact_integer(back.ctypes.data, None, out.ctypes.data, 3, 4, 8, 2, 2) == 4
     assert [int(x) for x in back] == [1, 7, 2, 7, 3]
+
+
+def fst_data_part_vectors():
+    """the data part of an FST record as c_fstecr lays it out (fstd98.c:1160-1352), composed by hand from the vectors above:
+         datyp 2, 4 bits, [1, 2, 3] (unsigned)      compact_integer(field, NULL, &data[0], n, nbits, 0, 1, 1) (:1236): the plain stream 0x123.....
+         datyp 4, 4 bits, [-1, 0, 1] (signed)       compact_integer(..., 3) (:1288): tokens (x + 8) & 15 = 7 8 9
+         datyp 6, 8 bits, [1., 2., 3.]              c_float_packer(field, nbits, &data[0], &data[header_size], n) with header_size 3 (:1347, float_packer.c:305):
+                                                    the three header words, then the 16-bit tokens
+         datyp 133, 32 bits, armn32_step_16x16      data[0] = the record's length in words: nbytes = 16 + zlng = 168 -> (168 * 8 + 63) / 64 = 21 pairs = 42 words
+                                                    (:1317-1321), the record of c_armn_compress32 from data[1] on
+       -> list of (datyp, nbits, field, ni, nj, [(first word, words) ...], words of the data part or None)"""
+    f133, pieces, zlng = armn32_step_16x16(False)
+    nw = 2 * ((8 * (16 + zlng) + 63) // 64)
+    return [
+        (2, 4, np.array([1, 2, 3], np.uint32), 3, 1, [(0, [0x12300000])], None),
+        (4, 4, np.array([-1, 0, 1], np.int32), 3, 1, [(0, [0x78900000])], None),
+        (6, 8, np.array([1.0, 2.0, 3.0], np.float32), 3, 1, [(0, [0xEFF78010, 0x00400000, 3, 0x00000040, 0x00800000])], None),
+        (133, 32, f133, 16, 16, [(0, [nw])] + [(1 + w0, words) for w0, words in pieces], nw),
+    ]
+
+
+def test_fst_data_part_known_answers_twin():
+    import fst_twin
+    for datyp, nbits, f, ni, nj, pieces, nw in fst_data_part_vectors():
+        words, d_out, data = fst_twin.pack(f, ni, nj, 1, datyp, nbits)
+        assert d_out == datyp, (datyp, d_out)
+        if nw is not None:
+            assert words == nw == 42
+        for w0, want in pieces:
+            assert [int(x) & 0xFFFFFFFF for x in data[w0:w0 + len(want)]] == want, (datyp, w0, [hex(int(x)) for x in data[w0:w0 + len(want)]])
