@@ -63,7 +63,7 @@ typedef struct ezh_set {
     float *d_prow;          /* 2 * ni_src synthetic polar wind rows (vector mode), u then v: [u_n, u_s, v_n, v_s] */
     float *d_avg[2];        /* interp_degree = average / sph_average: [x | row widening | y_low | y_high] of the target cells (ez_avg.inc:55-78, ez_avg_sph.inc:63-98) */
     void *d_uvt_tiles; int uvt_shape, uvt_cap, uvt_stats[4];
-    void *d_st_tiles, *d_st_streams; int st_key, st_cap, st_stats[4];      /* k_st (the scalar twin): its tile table (scalar zone rules) and the tile-ordered {x, y} copy; st_key: the zone options they were built under, -1: tried, not worth it */
+    void *d_st_tiles[2], *d_st_streams[2]; int st_key[2], st_cap[2], st_stats[2][4];      /* k_st1 / k_st (slot 0: bilinear, 1: bicubic): the tile table (scalar zone rules) and the tile-ordered {x, y} copy; st_key: the zone options they were built under, -1: tried, not worth it */
     void *d_uvt_streams; const void *uvt_streams_M;      /* the tile-ordered {x, y, a, b} copy and the matrix array it was packed from (another matrix: the plain arrays are read) */      /* k_uvt's tile table over the set's x, y (built with the special-point cache, under the same key) */
     int *d_cspec_list; float *d_cspec_xy; int cspec_count, cspec_key;      /* the special points (polar strips, re-interpolated extrapolation) of the wind-pair launch, kept after its first call: index, x, y; key = the zone options they were listed under (0: none yet) */
     float *d_lamb_cs[2];    /* c_ezuvint from / towards a Lambert '!' grid: {cos, sin} of its rotation angle at the target points' longitudes (source leg, target leg) */
@@ -815,7 +815,7 @@ static void free_set(ezh_set *s)
 {
     for (int d = 0; d < 3; d++) for (int v = 0; v < 2; v++) free_sepplan(&s->sep[d][v]);
     free(s->x1d); free(s->y1d);
-    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_lamb_cs[0]); ezhip_free(s->d_lamb_cs[1]); ezhip_free(s->d_cspec_list); ezhip_free(s->d_cspec_xy); ezhip_free(s->d_uvt_tiles); ezhip_free(s->d_uvt_streams); ezhip_free(s->d_st_tiles); ezhip_free(s->d_st_streams); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
+    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_lamb_cs[0]); ezhip_free(s->d_lamb_cs[1]); ezhip_free(s->d_cspec_list); ezhip_free(s->d_cspec_xy); ezhip_free(s->d_uvt_tiles); ezhip_free(s->d_uvt_streams); ezhip_free(s->d_st_tiles[0]); ezhip_free(s->d_st_streams[0]); ezhip_free(s->d_st_tiles[1]); ezhip_free(s->d_st_streams[1]); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
     for (int k = 0; k < 2; k++) { ezhip_free(s->d_yy_x[k]); ezhip_free(s->d_yy_y[k]); ezhip_free(s->d_yy_lat[k]); ezhip_free(s->d_yy_lon[k]); ezhip_free(s->d_yy_idx[k]); }
     for (int k = 0; k < 4; k++) ezhip_free(s->d_yy_tmp[k]);
     free(s);
@@ -2482,13 +2482,13 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
      * first call).  EZHIP_NO_ST=1: k_pts every time */
     const int st_ok = ((degree == DEG_CUBIC && (pp.wrap != 0 || (pp.i1 == 1 && pp.i2 == pp.ni)) && pp.xrec10) || degree == DEG_LINEAR) && pp.irregular && !pp.out_idx && !vector_mode && !src_hemi(gi) &&
                       (size_t)go->ni * go->nj >= (getenv("EZHIP_ST_MIN_POINTS") ? (size_t)atol(getenv("EZHIP_ST_MIN_POINTS")) : (size_t)262144) && !getenv("EZHIP_NO_ST");
-    const int st_key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4 | degree << 12;      /* (one table per set: the first degree and zone options that ask) */
+    const int st_key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4 | degree << 12, sl = degree == DEG_CUBIC;      /* (one table per set and degree: the first zone options that ask) */
     int st_build = 0;
     if (st_ok) {
         pp.tile_ni = go->ni; pp.tile_nj = go->nj;
         pthread_mutex_lock(&g_plan_mtx);
-        if (s->st_key == st_key && s->d_st_tiles) { pp.uvt_tiles = s->d_st_tiles; pp.uvt_shape = 3232; pp.uvt_cap = s->st_cap; pp.uvt_streams = s->d_st_streams; }
-        else if (s->st_key == 0) st_build = 1;
+        if (s->st_key[sl] == st_key && s->d_st_tiles[sl]) { pp.uvt_tiles = s->d_st_tiles[sl]; pp.uvt_shape = 3232; pp.uvt_cap = s->st_cap[sl]; pp.uvt_streams = s->d_st_streams[sl]; }
+        else if (s->st_key[sl] == 0) st_build = 1;
         pthread_mutex_unlock(&g_plan_mtx);
     }
     if (ezhip_interp_pts(&pp, d_zout, d_zin, s->d_x, s->d_y, go->ni * go->nj)) return dev_fail("the per-point interpolation kernel");
@@ -2503,9 +2503,9 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
         int st[4] = {0, 0, 0, 0}, good = 0;
         if (dt && ds && (degree == DEG_CUBIC ? ezhip_uvt_build(&pt, s->d_x, s->d_y, dt, 3232, st) : ezhip_st1_build(&pt, s->d_x, s->d_y, dt, st)) == 0 && st[0] >= 4 * st[1] && ezhip_st_pack_streams(&pt, s->d_x, s->d_y, ds) == 0) good = 1;
         pthread_mutex_lock(&g_plan_mtx);
-        if (s->st_key == 0) {
-            if (good) { s->d_st_tiles = dt; s->d_st_streams = ds; s->st_cap = cap; memcpy(s->st_stats, st, sizeof(st)); s->st_key = st_key; dt = ds = NULL; }
-            else s->st_key = -1;
+        if (s->st_key[sl] == 0) {
+            if (good) { s->d_st_tiles[sl] = dt; s->d_st_streams[sl] = ds; s->st_cap[sl] = cap; memcpy(s->st_stats[sl], st, sizeof(st)); s->st_key[sl] = st_key; dt = ds = NULL; }
+            else s->st_key[sl] = -1;
         }
         pthread_mutex_unlock(&g_plan_mtx);
         if (good && getenv("EZHIP_VERBOSE")) fprintf(stderr, "<ezhip> k_st tile table of set (%d, %d): %d tiles staged, %d gathered, %d without a normal point, largest window %d cells\n", s->gdin, s->gdout, st[0], st[1], st[2], st[3]);
@@ -2653,8 +2653,8 @@ static int run_batch_st(ezh_set *s, float *d_zout, const float *d_zin, int nfiel
     pthread_mutex_lock(&g_plan_mtx);
     const int mode = choose_mode(s, degree, polar);
     const int zones = !polar ? 0 : 1;
-    const int st_key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4 | degree << 12;
-    const int have = mode != 1 && s->st_key == st_key && s->d_st_tiles != NULL;
+    const int st_key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4 | degree << 12, sl = degree == DEG_CUBIC;
+    const int have = mode != 1 && s->st_key[sl] == st_key && s->d_st_tiles[sl] != NULL;
     pthread_mutex_unlock(&g_plan_mtx);
     if (!have) return -2;
     if (hio_full((float *)d_zin) || ensure_scratch(s)) return -1;
@@ -2667,7 +2667,7 @@ static int run_batch_st(ezh_set *s, float *d_zout, const float *d_zin, int nfiel
     if (!pp.irregular || (degree == DEG_CUBIC && !pp.xrec10) || pp.out_idx) return -2;
     pp.fill = t_scratch8; pp.polevals = d_poles_all ? d_poles_all : t_scratch8 + 4;
     pp.tile_ni = go->ni; pp.tile_nj = go->nj;
-    pp.uvt_tiles = s->d_st_tiles; pp.uvt_shape = 3232; pp.uvt_cap = s->st_cap; pp.uvt_streams = s->d_st_streams;
+    pp.uvt_tiles = s->d_st_tiles[sl]; pp.uvt_shape = 3232; pp.uvt_cap = s->st_cap[sl]; pp.uvt_streams = s->d_st_streams[sl];
     const int rc = ezhip_interp_pts_batch(&pp, d_zout, d_zin, s->d_x, s->d_y, go->ni * go->nj, nfields, nin, nout);
     if (rc == -2) return -2;
     return rc ? dev_fail("the per-point interpolation kernel (batch)") : 0;

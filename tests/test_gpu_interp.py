@@ -1605,3 +1605,31 @@ def test_uvt_staged_tiles_regional_source(shape, extrap, target):
     finally:
         os.environ.pop("EZHIP_NO_UVT", None)
         ez.gdrls(gdin); ez.gdrls(gdout)
+
+
+def test_st_one_set_keeps_a_table_per_degree():
+    """bicubic and bilinear calls alternate on one grid set: each degree builds its own staged-tile table behind its first call and uses it from its second call on;
+    results equal the gathering kernels' (EZHIP_NO_ST=1) bit for bit whatever the order"""
+    ni, nj, no, mo = 640, 320, 1000, 500
+    ax, ay = ec.ze_axes(ni, nj)
+    os.environ["EZHIP_ST_MIN_POINTS"] = "1"
+    try:
+        gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay); gdout = ez.ezqkdef(no, mo, "L", *ol.cxgaig("L", -90.0, 0.0, 180.0 / (mo - 1), 360.0 / no))
+        assert ez.ezdefset(gdout, gdin) == 1
+        f = ec.synth_field(ni, nj, seed=41); f.reshape(nj, ni)[:, -1] = f.reshape(nj, ni)[:, 0]
+        ez.use_stream(torch.cuda.current_stream().cuda_stream)
+        d_f = torch.from_numpy(f).cuda()
+        want = {}
+        os.environ["EZHIP_NO_ST"] = "1"
+        for deg in (3, 1, 0):
+            setopts(deg, 1)
+            o = torch.empty(no * mo, dtype=torch.float32, device="cuda"); assert ez.ezsint_dev(o, d_f) >= 0; want[deg] = o
+        os.environ.pop("EZHIP_NO_ST")
+        for deg in (3, 1, 3, 0, 1, 1, 3, 3, 0, 1):
+            setopts(deg, 1)
+            o = torch.full((no * mo,), float("nan"), dtype=torch.float32, device="cuda")
+            assert ez.ezsint_dev(o, d_f) >= 0
+            assert torch.equal(o.view(torch.int32), want[deg].view(torch.int32)), deg
+    finally:
+        os.environ.pop("EZHIP_ST_MIN_POINTS", None); os.environ.pop("EZHIP_NO_ST", None)
+        ez.gdrls(gdin); ez.gdrls(gdout)
