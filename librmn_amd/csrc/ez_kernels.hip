@@ -3269,8 +3269,8 @@ __global__ __launch_bounds__(256) void k_st1_bbox(ezhip_pts_plan p, const float 
 }
 /* thread t of a 32 x 32 tile takes FOUR CONSECUTIVE COLUMNS of one row (columns 4 (t % 8) .., row t / 8): its x, y arrive as two 16-byte loads from the set's tile-ordered
  * copy ([tile][half][thread] float4 {x, y, x, y}: a wave's load is one contiguous KB) and its results leave as one 16-byte store.  (Measured against k_st's map -- a
- * column of four rows per thread, 8-byte loads, 4-byte stores: 47.9 against 47.4 us per cfg3 field: the kernel is not bound by the width of its accesses but by a
- * thread block's chain of dependent round trips -- streams and table entry, window, barrier, two REAL*8 divisions per point, store -- at seven blocks per CU.) */
+ * column of four rows per thread, 8-byte loads, 4-byte stores: 47.9 against 47.4 us per cfg3 field: the kernel is not bound by the width of its accesses: SQ counters say 116 VALU
+ * instructions per point -- two REAL*8 divisions, the zone test in REAL*8, clamps, conversions -- and the SIMDs ~68 % busy; the rest is a block's dependent round trips.) */
 __global__ __launch_bounds__(256) void k_st1_pack(ezhip_pts_plan p, const float *__restrict__ xs, const float *__restrict__ ys, float4 *__restrict__ streams)
 {
     const unsigned tpr = ((unsigned)p.tile_ni + 31u) / 32u, b = blockIdx.x, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
