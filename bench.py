@@ -321,15 +321,42 @@ def free_port():
     return p
 
 
+def visible_gpus_without_runtime():
+    """GPUs this process would see, counted WITHOUT the HIP runtime (torch.cuda.device_count() falls back to hipGetDeviceCount -- which initialises the
+    runtime -- when amdsmi discovery fails; forking ranks from a GPU-initialised parent is the fragile pattern on this pool): KFD topology nodes with
+    SIMDs, cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when they hold a plain index list.  None: unknown (no sysfs)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(base):
+            try:
+                props = open(os.path.join(base, d, "properties")).read()
+            except OSError:
+                continue
+            for line in props.splitlines():
+                f = line.split()
+                if len(f) == 2 and f[0] == "simd_count" and int(f[1]) > 0:
+                    n += 1
+    except OSError:
+        return None
+    if n == 0:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and all(t.strip().isdigit() for t in v.split(",") if t.strip()):
+            n = min(n, len([t for t in v.split(",") if t.strip()]))
+    return n
+
+
 def launch_ranks(n, argv, stub):
     """`python bench.py --gpus N` without a launcher's WORLD_SIZE in the environment: start N FRESH rank processes (this file again, one per
     LOCAL_RANK, rendezvous on 127.0.0.1) BEFORE anything in this process touches a GPU, wait for them, return the worst exit code.  The
-    parent never initialises HIP (torch.cuda.device_count() only counts devices) and never exec()s: children are ordinary subprocesses."""
+    parent never initialises HIP -- it does not even import torch: the devices are counted from the KFD topology in sysfs, and where that cannot be read
+    the ranks' own refusal (LOCAL_RANK >= device count -> exit 2) is the check -- and never exec()s: children are ordinary subprocesses."""
     import subprocess
     if not stub:
-        import torch
-        have = torch.cuda.device_count()
-        if have < n:
+        have = visible_gpus_without_runtime()
+        if have is not None and have < n:
             sys.stderr.write(f"bench.py: --gpus {n} asked for, {have} GPU(s) visible on this node: refusing to report an N-GPU line from fewer devices\n")
             return 2
     port = free_port()
@@ -496,7 +523,7 @@ def main():
 
     import torch
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the MI355X hot path has no CPU fallback")
+        raise SystemExit("bench.py needs a GPU (0 GPU(s) visible): the MI355X hot path has no CPU fallback")
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)

@@ -75,9 +75,25 @@ int32_t gdxyfll_(int32_t *gdid, float *x, float *y, float *lat, float *lon, int3
 int32_t gdll_(int32_t *gdid, float *lat, float *lon);
 int32_t gdrls_(int32_t *gdin);
 
+/* ---- the set-up routines the grid table is filled by, under the reference's own (internal) signatures: host only ---------------- */
+/* Newton divided-difference tables of an irregular axis pair, cx(ni, 6), cy(j1:j2, 6): ez_nwtncof.inc:20-178 (f_ezscint.F90), called from ez_calcntncof.c:44 */
+void ez_nwtncof_(float *cx, float *cy, const float *ax, const float *ay, const int32_t *ni, const int32_t *nj, const int32_t *i1, const int32_t *i2,
+                 const int32_t *j1, const int32_t *j2, const int32_t *extension);
+/* row / column bounds of a source and its longitude extension (0, 1, 2) from the grid's descriptors: ez_xpncof.c:48-226, ez_funcdef.h:67 */
+void ez_xpncof(int32_t *i1, int32_t *i2, int32_t *j1, int32_t *j2, int32_t *extension, int32_t ni, int32_t nj, char grtyp, char grref,
+               int32_t ig1, int32_t ig2, int32_t ig3, int32_t ig4, int32_t sym, float *ax, float *ay);
+
 /* ---- additive: device-resident entry points ----------------------------------------------- */
 /* All pointers are DEVICE pointers on the current HIP device; work is enqueued on the stream set by
  * ezhip_use_stream (default: the null stream) and NOT synchronised. */
+/* FIRST CALL of a grid set on a per-point route (rotated / irregular sources: c_ezsint_dev, c_ezuvint_dev, c_ezsint_batch_dev): besides the kernels it allocates
+ * and builds the set's caches -- located x, y (8 bytes per target point), the wind matrix (8), and for the staged-tile kernels a tile table plus a tile-ordered
+ * copy of those streams (8 bytes per target point and degree for scalars, 16 for wind pairs) -- and SYNCHRONISES the stream two or three times while doing so
+ * (hipMalloc, hipStreamSynchronize, one blocking copy).  Do not issue a set's first call inside a stream capture; call ezhip_prepare_set() (or any first call)
+ * beforehand.  Later calls of the set only enqueue.  The caches live until c_gdrls of either grid.  Their total is bounded by a byte budget (default 4 GiB,
+ * EZHIP_CACHE_MB at first use, or the call below); a set that does not fit keeps the gathering kernels: same results, slower. */
+void ezhip_set_cache_budget_mb(int32_t mb);                 /* 0: no staged-tile caches at all */
+long long ezhip_cache_bytes(void);                           /* bytes the staged-tile caches of all sets hold now */
 void    ezhip_use_stream(void *hip_stream);
 /* 0 for the shipped library; 1 when it was built with -DEZHIP_DEVELOP (`make develop`: the kernels' development knock-outs, which an
  * environment variable can switch on, exist only in that build). */

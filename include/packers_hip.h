@@ -62,12 +62,14 @@ int c_armn_compress32_dev(void *d_zstream, const float *d_fld, int ni, int nj, i
 int c_armn_uncompress32_dev(float *d_fld, const unsigned char *zstream_host, int ni, int nj, int nk, int znbits);
 /* additive: the same with the stream's byte length given (an upper bound that the caller's buffer holds, e.g. the data part of an FST record, fstd98.c:2436):
  * c_armn_uncompress32 has no length argument and has to find the record's end by walking its tile headers on the host; with the length the planes are
- * uploaded at once and -- when a row of tiles ends on a whole tile, (ni - 1) % 3 == 0 -- both chains and the sign runs are resolved on the device; with a
- * ragged last tile per row the chains are walked on the host as in c_armn_uncompress32 */
+ * uploaded at once and the sign runs and both planes' chains of tile headers are resolved on the device when the field has >= 65536 points and either every
+ * row ends on a whole tile ((ni - 1) % 3 == 0: composition of the windows' maps) or ni >= 768 (ragged rows: composition + the row recurrence).  A plane the
+ * device forms leave open (long runs of empty tiles, rows that rejoin late), smaller fields and records beyond 2^32 bits are walked on host threads, plane by
+ * plane, as in c_armn_uncompress32 */
 int c_armn_uncompress32_lng(float *fld, const unsigned char *zstream, size_t zbytes, int ni, int nj, int nk, int znbits);
 int c_armn_uncompress32_lng_dev(float *d_fld, const unsigned char *zstream_host, size_t zbytes, int ni, int nj, int nk, int znbits);
-/* additive: record AND field in device memory (the counterpart of c_armn_compress32_dev, whose stream stays in HBM).  Whole-tile rows: the host reads four
- * words of the record, everything else is device work; ragged rows: the record is copied down for the host's walk.  Returns ni*nj or -1. */
+/* additive: record AND field in device memory (the counterpart of c_armn_compress32_dev, whose stream stays in HBM).  Under the routing above the host reads
+ * four words of the record and everything else is device work; a plane the device forms leave open is copied down for the host's walk.  Returns ni*nj or -1. */
 int c_armn_uncompress32_zdev(float *d_fld, const void *d_zstream, size_t zbytes, int ni, int nj, int nk, int znbits);
 void c_armn_compress_setlevel(int level);       /* src/compresseur/c_zfstlib.c:1325 ; BEST = 1, FAST = 0 */
 int  c_armn_compress_getlevel(void);

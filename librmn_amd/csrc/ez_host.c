@@ -61,9 +61,12 @@ typedef struct ezh_set {
     float *d_scratch;       /* float[8]: fill value + keys, pole values */
     float *d_poles_batch; int poles_cap;   /* pole values of a c_ezsint_batch_dev batch (2 per field) */
     float *d_prow;          /* 2 * ni_src synthetic polar wind rows (vector mode), u then v: [u_n, u_s, v_n, v_s] */
+    unsigned pw_epoch;      /* launches that took the rows' job along as producer TEAMS (k_uvp): their arrival counters behind the rows count up by the team size per launch */
     float *d_avg[2];        /* interp_degree = average / sph_average: [x | row widening | y_low | y_high] of the target cells (ez_avg.inc:55-78, ez_avg_sph.inc:63-98) */
     void *d_uvt_tiles; int uvt_shape, uvt_cap, uvt_stats[4];
+    int *d_uvt_hb; int uvt_nhb;            /* the table's handed-back tiles (k_uvp leaves them to the launch behind it); uvt_nhb < 0: not listed (k_uvt then) */
     void *d_st_tiles[2], *d_st_streams[2]; int st_key[2], st_cap[2], st_stats[2][4];      /* k_st1 / k_st (slot 0: bilinear, 1: bicubic): the tile table (scalar zone rules) and the tile-ordered {x, y} copy; st_key: the zone options they were built under, -1: tried, not worth it */
+    size_t cache_bytes;                    /* HBM this set's staged-tile caches hold (tile tables + tile-ordered stream copies): counted against g_cache_budget */
     void *d_uvt_streams; const void *uvt_streams_M;      /* the tile-ordered {x, y, a, b} copy and the matrix array it was packed from (another matrix: the plain arrays are read) */      /* k_uvt's tile table over the set's x, y (built with the special-point cache, under the same key) */
     int *d_cspec_list; float *d_cspec_xy; int cspec_count, cspec_key;      /* the special points (polar strips, re-interpolated extrapolation) of the wind-pair launch, kept after its first call: index, x, y; key = the zone options they were listed under (0: none yet) */
     float *d_lamb_cs[2];    /* c_ezuvint from / towards a Lambert '!' grid: {cos, sin} of its rotation angle at the target points' longitudes (source leg, target leg) */
@@ -87,6 +90,7 @@ typedef struct {
     float *d_ax, *d_ay, *d_ncx, *d_ncy;    /* device mirrors */
     float *d_ncx8, *d_ncy8;                /* Newton coefficients laid out [index][8] for the per-point kernel */
     double *d_xrec10, *d_yrec10;           /* k_uvt: REAL*8 {ax(i-1), ax(i), ax(i+1), c1 .. c6, c5 + c2} per column i (index i - 1), the same per row */
+    float *d_xrec8, *d_yrec8;              /* the wind pair kernels: REAL {ax(i-1 .. i+2), the four Lagrange denominators' reciprocals} per column i (index i - 1), the same per row */
     /* this grid as a TARGET: its lat/lon.  Separable grids keep 1-D arrays. */
     int coords_ready, separable;
     float *lat1d, *lon1d, *lat2d, *lon2d;
@@ -236,27 +240,39 @@ static void recip6(float *c, int ld, float a, float b, float cc, float d)
 /* rows of the latitude table: a hemispheric Gaussian grid keeps the 2 nj latitudes of the globe (ez_defaxes.c:93-99), its field is expanded
  * into rows j1 .. j2 of that table */
 static int ay_rows(const ezh_grid *g) { return (g->grtyp == 'G' && g->ig[0] != 0) ? 2 * g->nj : g->nj; }
+/* the tables themselves: cx[6][ni], cy[6][nr] (nr rows of the latitude table: ay(j1:j2) of the reference) */
+static void nwtncof_tables(float *cx, float *cy, const float *ax, const float *ay, int ni, int nr, int ext)
+{
+    for (int i = 0; i + 1 < ni; i++) if (ax[i + 1] <= ax[i]) { fprintf(stderr, "ez_nwtncof: x axis must be strictly increasing\n"); exit(13); }
+    for (int j = 0; j + 1 < nr; j++) if (ay[j + 1] <= ay[j]) { fprintf(stderr, "ez_nwtncof: y axis must be strictly increasing\n"); exit(13); }
+    for (int k = 0; k < 6 * ni; k++) cx[k] = 1.0f;
+    for (int k = 0; k < 6 * nr; k++) cy[k] = 1.0f;
+    for (int i = 1; i + 2 < ni; i++) recip6(&cx[i], ni, ax[i - 1], ax[i], ax[i + 1], ax[i + 2]);
+    for (int j = 1; j + 2 < nr; j++) recip6(&cy[j], nr, ay[j - 1], ay[j], ay[j + 1], ay[j + 2]);
+    if (ext == 1) {
+        recip6(&cx[0], ni, ax[0] - (ax[ni - 1] - ax[ni - 2]), ax[0], ax[1], ax[2]);
+        recip6(&cx[ni - 2], ni, ax[ni - 3], ax[ni - 2], ax[ni - 1], ax[ni - 1] + (ax[1] - ax[0]));
+    } else if (ext == 2) {
+        recip6(&cx[0], ni, ax[0] - (360.0f - ax[ni - 1]), ax[0], ax[1], ax[2]);
+        recip6(&cx[ni - 2], ni, ax[ni - 3], ax[ni - 2], ax[ni - 1], ax[0] + 360.0f);
+        recip6(&cx[ni - 1], ni, ax[ni - 2], ax[ni - 1], ax[0] + 360.0f, ax[1] + 360.0f);
+    }
+}
 static int h_nwtncof(ezh_grid *g)
 {
-    int ni = g->ni, nj = ay_rows(g), ext = g->extension;
-    const float *ax = g->ax, *ay = g->ay;
-    for (int i = 0; i + 1 < ni; i++) if (ax[i + 1] <= ax[i]) { fprintf(stderr, "ez_nwtncof: x axis must be strictly increasing\n"); exit(13); }
-    for (int j = 0; j + 1 < nj; j++) if (ay[j + 1] <= ay[j]) { fprintf(stderr, "ez_nwtncof: y axis must be strictly increasing\n"); exit(13); }
+    const int ni = g->ni, nr = ay_rows(g);
     g->ncx = (float *)malloc(sizeof(float) * 6 * ni);
-    g->ncy = (float *)malloc(sizeof(float) * 6 * nj);
-    for (int k = 0; k < 6 * ni; k++) g->ncx[k] = 1.0f;
-    for (int k = 0; k < 6 * nj; k++) g->ncy[k] = 1.0f;
-    for (int i = 1; i + 2 < ni; i++) recip6(&g->ncx[i], ni, ax[i - 1], ax[i], ax[i + 1], ax[i + 2]);
-    for (int j = 1; j + 2 < nj; j++) recip6(&g->ncy[j], nj, ay[j - 1], ay[j], ay[j + 1], ay[j + 2]);
-    if (ext == 1) {
-        recip6(&g->ncx[0], ni, ax[0] - (ax[ni - 1] - ax[ni - 2]), ax[0], ax[1], ax[2]);
-        recip6(&g->ncx[ni - 2], ni, ax[ni - 3], ax[ni - 2], ax[ni - 1], ax[ni - 1] + (ax[1] - ax[0]));
-    } else if (ext == 2) {
-        recip6(&g->ncx[0], ni, ax[0] - (360.0f - ax[ni - 1]), ax[0], ax[1], ax[2]);
-        recip6(&g->ncx[ni - 2], ni, ax[ni - 3], ax[ni - 2], ax[ni - 1], ax[0] + 360.0f);
-        recip6(&g->ncx[ni - 1], ni, ax[ni - 2], ax[ni - 1], ax[0] + 360.0f, ax[1] + 360.0f);
-    }
+    g->ncy = (float *)malloc(sizeof(float) * 6 * nr);
+    nwtncof_tables(g->ncx, g->ncy, g->ax, g->ay, ni, nr, g->extension);
     return 0;
+}
+/* the reference's own entry point (f_ezscint.F90 / ez_nwtncof.inc:20: subroutine ez_nwtncof(cx, cy, ax, ay, ni, nj, i1, i2, j1, j2, extension), called from
+ * ez_calcntncof.c:44 through f77name): the same routine the grid table above is filled by.  Host only. */
+void ez_nwtncof_(float *cx, float *cy, const float *ax, const float *ay, const int32_t *ni, const int32_t *nj, const int32_t *i1, const int32_t *i2,
+                 const int32_t *j1, const int32_t *j2, const int32_t *extension)
+{
+    (void)nj; (void)i1; (void)i2;
+    nwtncof_tables(cx, cy, ax, ay, *ni, *j2 - *j1 + 1, *extension);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -296,6 +312,19 @@ static void h_xpncof(ezh_grid *g)
         if ((double)(ax[ni - 1] - ax[0]) > (360.0 - 0.01 * (double)dlon)) g->extension = 1;
         else if ((double)((ax[ni - 1] + dlon) - ax[0]) > (360.0 - 0.01 * (double)dlon)) g->extension = 2;
     }
+}
+
+/* the reference's own entry point (ez_xpncof.c:48, declared in ez_funcdef.h:67): bounds of the source rows / columns and the longitude extension of a grid
+ * given by its descriptors.  sym is unused there as here ('!' grids: no extension).  Host only. */
+void ez_xpncof(int32_t *i1, int32_t *i2, int32_t *j1, int32_t *j2, int32_t *extension, int32_t ni, int32_t nj, char grtyp, char grref,
+               int32_t ig1, int32_t ig2, int32_t ig3, int32_t ig4, int32_t sym, float *ax, float *ay)
+{
+    ezh_grid g;
+    (void)sym;
+    memset(&g, 0, sizeof(g));
+    g.ni = ni; g.nj = nj; g.grtyp = grtyp; g.grref = grref; g.ig[0] = ig1; g.ig[1] = ig2; g.ig[2] = ig3; g.ig[3] = ig4; g.ax = ax; g.ay = ay;
+    h_xpncof(&g);
+    *i1 = g.i1; *i2 = g.i2; *j1 = g.j1; *j2 = g.j2; *extension = g.extension;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -811,11 +840,42 @@ static void free_sepplan(ezh_sepplan *sp)
     sp->h_vb_by = sp->h_vb_send = NULL; sp->h_rflag = NULL; sp->h_nvb = 0;
     sp->built = 0;
 }
+static pthread_mutex_t g_plan_mtx = PTHREAD_MUTEX_INITIALIZER;
+/* The staged-tile kernels (k_st, k_st1, k_uvt / k_uvp) keep, per grid set, a tile table and a tile-ordered copy of the set's streams: 8 bytes per target point and
+ * degree for scalars, 16 for wind pairs (a 7200 x 3601 target: 207 MB + 415 MB), held until c_gdrls.  All sets together stay under a byte budget; a set whose
+ * caches would not fit keeps the gathering kernels (same results, slower).  Default 4 GiB; EZHIP_CACHE_MB or ezhip_set_cache_budget_mb() change it (0: no caches). */
+static size_t g_cache_bytes = 0;
+static long long g_cache_budget = -1;
+static size_t cache_budget(void)
+{
+    if (g_cache_budget < 0) { const char *e = getenv("EZHIP_CACHE_MB"); g_cache_budget = (e ? atoll(e) : 4096LL) << 20; if (g_cache_budget < 0) g_cache_budget = 0; }
+    return (size_t)g_cache_budget;
+}
+/* under g_plan_mtx: reserve `bytes` for set s (0 when the budget is spent) / give them back */
+static int cache_reserve(ezh_set *s, size_t bytes)
+{
+    if (g_cache_bytes + bytes > cache_budget()) return 0;
+    g_cache_bytes += bytes; s->cache_bytes += bytes;
+    return 1;
+}
+static void cache_unreserve(ezh_set *s, size_t bytes)
+{
+    if (bytes > s->cache_bytes) bytes = s->cache_bytes;
+    s->cache_bytes -= bytes; g_cache_bytes -= bytes <= g_cache_bytes ? bytes : g_cache_bytes;
+}
+void ezhip_set_cache_budget_mb(int32_t mb)
+{
+    pthread_mutex_lock(&g_plan_mtx);
+    g_cache_budget = mb > 0 ? (long long)mb << 20 : 0;
+    pthread_mutex_unlock(&g_plan_mtx);
+}
+long long ezhip_cache_bytes(void) { pthread_mutex_lock(&g_plan_mtx); const long long b = (long long)g_cache_bytes; pthread_mutex_unlock(&g_plan_mtx); return b; }
+
 static void free_set(ezh_set *s)
 {
     for (int d = 0; d < 3; d++) for (int v = 0; v < 2; v++) free_sepplan(&s->sep[d][v]);
     free(s->x1d); free(s->y1d);
-    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_lamb_cs[0]); ezhip_free(s->d_lamb_cs[1]); ezhip_free(s->d_cspec_list); ezhip_free(s->d_cspec_xy); ezhip_free(s->d_uvt_tiles); ezhip_free(s->d_uvt_streams); ezhip_free(s->d_st_tiles[0]); ezhip_free(s->d_st_streams[0]); ezhip_free(s->d_st_tiles[1]); ezhip_free(s->d_st_streams[1]); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
+    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_lamb_cs[0]); ezhip_free(s->d_lamb_cs[1]); ezhip_free(s->d_cspec_list); ezhip_free(s->d_cspec_xy); pthread_mutex_lock(&g_plan_mtx); cache_unreserve(s, s->cache_bytes); pthread_mutex_unlock(&g_plan_mtx); ezhip_free(s->d_uvt_tiles); ezhip_free(s->d_uvt_hb); ezhip_free(s->d_uvt_streams); ezhip_free(s->d_st_tiles[0]); ezhip_free(s->d_st_streams[0]); ezhip_free(s->d_st_tiles[1]); ezhip_free(s->d_st_streams[1]); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
     for (int k = 0; k < 2; k++) { ezhip_free(s->d_yy_x[k]); ezhip_free(s->d_yy_y[k]); ezhip_free(s->d_yy_lat[k]); ezhip_free(s->d_yy_lon[k]); ezhip_free(s->d_yy_idx[k]); }
     for (int k = 0; k < 4; k++) ezhip_free(s->d_yy_tmp[k]);
     free(s);
@@ -836,7 +896,7 @@ int32_t c_gdrls(int32_t gd)          /* gdrls.c:34-77: refcount, free at zero */
         }
         free(g->ax); free(g->ay); free(g->ncx); free(g->ncy);
         free(g->lat1d); free(g->lon1d); free(g->lat2d); free(g->lon2d); free(g->mask);
-        ezhip_free(g->d_ax); ezhip_free(g->d_ay); ezhip_free(g->d_ncx); ezhip_free(g->d_ncy); ezhip_free(g->d_ncx8); ezhip_free(g->d_ncy8); ezhip_free(g->d_xrec10); ezhip_free(g->d_yrec10);
+        ezhip_free(g->d_ax); ezhip_free(g->d_ay); ezhip_free(g->d_ncx); ezhip_free(g->d_ncy); ezhip_free(g->d_ncx8); ezhip_free(g->d_ncy8); ezhip_free(g->d_xrec10); ezhip_free(g->d_yrec10); ezhip_free(g->d_xrec8); ezhip_free(g->d_yrec8);
         ezhip_free(g->d_lat); ezhip_free(g->d_lon); ezhip_free(g->d_plon2); g->d_plon2 = NULL; ezhip_free(g->d_windtrig); g->d_windtrig = NULL;
         memset(g, 0, sizeof(*g));
         if (cur_gdin == gd) cur_gdin = -1;
@@ -1211,8 +1271,32 @@ static int ensure_grid_dev(ezh_grid *g)
             ezhip_sync();
             free(t10);
         }
+        {   /* the 32-byte records of the wind pair kernels (interior stencils only, as above): the axis entries of stencil i and 1 / prod_{m != k} (x_k - x_m),
+             * formed in REAL*8 from the REAL axis and rounded once */
+            const int m = g->ni > nr ? g->ni : nr;
+            float *t8 = (float *)calloc((size_t)8 * m, sizeof(float));
+            if (!t8) return -1;
+            for (int pass = 0; pass < 2; pass++) {
+                const float *a = pass ? g->ay : g->ax;
+                const int n = pass ? nr : g->ni;
+                memset(t8, 0, sizeof(float) * 8 * (size_t)m);
+                for (int i = 1; i + 2 < n; i++) {
+                    double x[4];
+                    for (int k = 0; k < 4; k++) { x[k] = (double)a[i - 1 + k]; t8[8 * i + k] = a[i - 1 + k]; }
+                    for (int k = 0; k < 4; k++) {
+                        double den = 1.0;
+                        for (int q = 0; q < 4; q++) if (q != k) den *= x[k] - x[q];
+                        t8[8 * i + 4 + k] = (float)(1.0 / den);
+                    }
+                }
+                float *d = (float *)upload(t8, sizeof(float) * 8 * n);
+                ezhip_sync();
+                if (pass) g->d_yrec8 = d; else g->d_xrec8 = d;
+            }
+            free(t8);
+        }
         ezhip_sync();
-        if (!g->d_ax || !g->d_ay || !g->d_ncx || !g->d_ncy || !g->d_ncx8 || !g->d_ncy8 || !g->d_xrec10 || !g->d_yrec10) return -1;
+        if (!g->d_ax || !g->d_ay || !g->d_ncx || !g->d_ncy || !g->d_ncx8 || !g->d_ncy8 || !g->d_xrec10 || !g->d_yrec10 || !g->d_xrec8 || !g->d_yrec8) return -1;
     }
     return 0;
 }
@@ -2019,7 +2103,7 @@ static void fill_pts_plan(const ezh_set *s, const ezh_grid *gi, ezhip_pts_plan *
     pp->degree = degree; pp->irregular = src_irregular(gi);
     pp->ni = gi->ni; pp->nj = gi->nj; pp->i1 = gi->i1; pp->i2 = gi->i2; pp->j1 = gi->j1; pp->j2 = gi->j2; pp->wrap = gi->extension;
     pp->ax = gi->d_ax; pp->ay = gi->d_ay; pp->ncx = gi->d_ncx; pp->ncy = gi->d_ncy;
-    pp->ncx8 = gi->d_ncx8; pp->ncy8 = gi->d_ncy8; pp->xrec10 = gi->d_xrec10; pp->yrec10 = gi->d_yrec10;
+    pp->ncx8 = gi->d_ncx8; pp->ncy8 = gi->d_ncy8; pp->xrec10 = gi->d_xrec10; pp->yrec10 = gi->d_yrec10; pp->xrec8 = gi->d_xrec8; pp->yrec8 = gi->d_yrec8;
     pp->zones = zones; pp->degre_extrap = O.degre_extrap; pp->vector_mode = vector_mode;
     pp->pole_weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
     if (s) { pp->ypole_n = s->ypole_n; pp->ypole_s = s->ypole_s; }
@@ -2060,7 +2144,6 @@ static int ensure_scratch(ezh_set *s)
     return t_scratch8 ? 0 : -1;
 }
 /* lazily built per-set state (plans, located points, device mirrors) is built under this lock */
-static pthread_mutex_t g_plan_mtx = PTHREAD_MUTEX_INITIALIZER;
 
 /* in-kernel pole values of k_sepx: per host thread a ring of 4 {values, flags} buffers (consecutive launches of one
  * thread are stream-ordered; the ring only guards a thread that switches streams between calls) and a launch epoch */
@@ -2499,7 +2582,11 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
         ezhip_pts_plan pt = pp;
         pt.pv_out = NULL; pt.uvt_cap = cap;
         const int nt = ezhip_uvt_ntiles(&pt, 3232);
-        void *dt = nt > 0 ? ezhip_malloc(16 * (size_t)nt) : NULL, *ds = nt > 0 ? ezhip_malloc((size_t)8 * 1024 * (size_t)nt) : NULL;
+        const size_t st_bytes = nt > 0 ? 16 * (size_t)nt + (size_t)8 * 1024 * (size_t)nt : 0;
+        pthread_mutex_lock(&g_plan_mtx);
+        const int fits = nt > 0 && cache_reserve(s, st_bytes);
+        pthread_mutex_unlock(&g_plan_mtx);
+        void *dt = fits ? ezhip_malloc(16 * (size_t)nt) : NULL, *ds = fits ? ezhip_malloc((size_t)8 * 1024 * (size_t)nt) : NULL;
         int st[4] = {0, 0, 0, 0}, good = 0;
         if (dt && ds && (degree == DEG_CUBIC ? ezhip_uvt_build(&pt, s->d_x, s->d_y, dt, 3232, st) : ezhip_st1_build(&pt, s->d_x, s->d_y, dt, st)) == 0 && st[0] >= 4 * st[1] && ezhip_st_pack_streams(&pt, s->d_x, s->d_y, ds) == 0) good = 1;
         pthread_mutex_lock(&g_plan_mtx);
@@ -2507,6 +2594,7 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
             if (good) { s->d_st_tiles[sl] = dt; s->d_st_streams[sl] = ds; s->st_cap[sl] = cap; memcpy(s->st_stats[sl], st, sizeof(st)); s->st_key[sl] = st_key; dt = ds = NULL; }
             else s->st_key[sl] = -1;
         }
+        if ((dt || ds || !good) && fits) cache_unreserve(s, st_bytes);      /* not kept: the reservation goes back */
         pthread_mutex_unlock(&g_plan_mtx);
         if (good && getenv("EZHIP_VERBOSE")) fprintf(stderr, "<ezhip> k_st tile table of set (%d, %d): %d tiles staged, %d gathered, %d without a normal point, largest window %d cells\n", s->gdin, s->gdout, st[0], st[1], st[2], st[3]);
         ezhip_free(dt); ezhip_free(ds);
@@ -2515,7 +2603,7 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
 }
 
 /* the polar wind rows of the pair being interpolated, handed from uvint_impl to the per-point pair launch (per host thread) */
-static __thread struct { float *out; const float *plon2, *ax; float xg4_n, xg4_s; int weighted, active; } t_pwjob;
+static __thread struct { float *out; const float *plon2, *ax; float xg4_n, xg4_s; int weighted, active; unsigned *sync; unsigned *epoch; } t_pwjob;
 /* both components of a wind pair on the per-point path in ONE pass (k_pts2); returns -2 when the set is not on that path */
 static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui, const float *d_vi,
                         const float *pun, const float *pus, const float *pvn, const float *pvs, const void *d_M, int m_half, int dst_rot)
@@ -2548,7 +2636,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
     pu.pole_row_n = pun; pu.pole_row_s = pus; pv.pole_row_n = pvn; pv.pole_row_s = pvs;
     if (zones == 2 && s->have_dehors) ierc = 2;
     pu.tile_ni = go->ni; pu.tile_nj = go->nj;                  /* the points are the whole target grid in row order: 2-D tile order */
-    if (t_pwjob.active) { pu.pw_out = t_pwjob.out; pu.pw_plon2 = t_pwjob.plon2; pu.pw_xg4_n = t_pwjob.xg4_n; pu.pw_xg4_s = t_pwjob.xg4_s; pu.pw_weighted = t_pwjob.weighted; pu.pw_ax = t_pwjob.ax; t_pwjob.active = 0; }
+    if (t_pwjob.active) { pu.pw_out = t_pwjob.out; pu.pw_plon2 = t_pwjob.plon2; pu.pw_xg4_n = t_pwjob.xg4_n; pu.pw_xg4_s = t_pwjob.xg4_s; pu.pw_weighted = t_pwjob.weighted; pu.pw_ax = t_pwjob.ax; pu.pw_sync = t_pwjob.sync; pu.pw_epoch_io = t_pwjob.epoch; t_pwjob.active = 0; }
     /* the special points of the set under these zone options: listed by the first launch, kept with the set, handed to the later ones */
     const int key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4 | degree << 12;
     const int use_cache = !getenv("EZHIP_NO_SPEC_CACHE");
@@ -2557,7 +2645,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
         if (s->cspec_key == key) {
             pu.cspec_valid = 1; pu.cspec_count = s->cspec_count; pu.cspec_list = s->d_cspec_list;
             pu.cspec_x = s->d_cspec_xy; pu.cspec_y = s->d_cspec_xy ? s->d_cspec_xy + s->cspec_count : NULL;
-            if (s->d_uvt_tiles && !getenv("EZHIP_NO_UVT")) { pu.uvt_tiles = s->d_uvt_tiles; pu.uvt_shape = s->uvt_shape; pu.uvt_cap = s->uvt_cap;
+            if (s->d_uvt_tiles && !getenv("EZHIP_NO_UVT")) { pu.uvt_tiles = s->d_uvt_tiles; pu.uvt_shape = s->uvt_shape; pu.uvt_cap = s->uvt_cap; pu.uvt_hb_list = s->d_uvt_hb; pu.uvt_hb_count = s->uvt_nhb;
                 if (s->d_uvt_streams && s->uvt_streams_M == d_M && (!d_M || m_half) && !getenv("EZHIP_UVT_NO_STREAMS")) pu.uvt_streams = s->d_uvt_streams; }      /* EZHIP_NO_UVT: the gathering kernel (same results) */
         }
         pthread_mutex_unlock(&g_plan_mtx);
@@ -2581,23 +2669,33 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
                     if (cap > 4096) cap = 4096;
                     pu.uvt_cap = cap;
                     const int nt = ezhip_uvt_ntiles(&pu, th);
-                    void *dt = nt > 0 ? ezhip_malloc(16 * (size_t)nt) : NULL;
-                    int st[4] = {0, 0, 0, 0};
+                    const size_t tb_bytes = nt > 0 ? 16 * (size_t)nt : 0, sb_bytes = nt > 0 ? ezhip_uvt_stream_bytes(&pu, th) : 0;
+                    pthread_mutex_lock(&g_plan_mtx);
+                    const int fits_t = nt > 0 && cache_reserve(s, tb_bytes);
+                    pthread_mutex_unlock(&g_plan_mtx);
+                    void *dt = fits_t ? ezhip_malloc(tb_bytes) : NULL;
+                    int st[4] = {0, 0, 0, 0}, kept_t = 0;
                     if (dt && ezhip_uvt_build(&pu, s->d_x, s->d_y, dt, th, st) == 0 && st[0] >= 4 * st[1]) {      /* (a set whose tiles mostly do not qualify keeps the gathering kernel) */
                         pthread_mutex_lock(&g_plan_mtx);
-                        s->uvt_shape = th; s->uvt_cap = cap; memcpy(s->uvt_stats, st, sizeof(st)); s->d_uvt_tiles = dt; dt = NULL;
+                        s->uvt_shape = th; s->uvt_cap = cap; memcpy(s->uvt_stats, st, sizeof(st)); s->d_uvt_tiles = dt; kept_t = 1;
+                        { int *dl = NULL; s->uvt_nhb = ezhip_uvt_handed_back(dt, nt, &dl); s->d_uvt_hb = dl; }
+                        dt = NULL;
+                        const int fits_s = (!d_M || m_half) && cache_reserve(s, sb_bytes);
                         pthread_mutex_unlock(&g_plan_mtx);
-                        if (!d_M || m_half) {      /* x, y and the pair's (a, b) once more in tile order (16 bytes per target point) */
-                            void *ds = ezhip_malloc(ezhip_uvt_stream_bytes(&pu, th));
+                        if (fits_s) {      /* x, y and the pair's (a, b) once more in tile order (16 bytes per target point) */
+                            void *ds = ezhip_malloc(sb_bytes);
+                            int kept_s = 0;
                             if (ds && ezhip_uvt_pack_streams(&pu, s->d_x, s->d_y, ds, th) == 0) {
                                 pthread_mutex_lock(&g_plan_mtx);
-                                s->d_uvt_streams = ds; s->uvt_streams_M = d_M; ds = NULL;
+                                s->d_uvt_streams = ds; s->uvt_streams_M = d_M; ds = NULL; kept_s = 1;
                                 pthread_mutex_unlock(&g_plan_mtx);
                             }
                             ezhip_free(ds);
+                            if (!kept_s) { pthread_mutex_lock(&g_plan_mtx); cache_unreserve(s, sb_bytes); pthread_mutex_unlock(&g_plan_mtx); }
                         }
                         if (getenv("EZHIP_VERBOSE")) fprintf(stderr, "<ezhip> k_uvt tile table of set (%d, %d): %d tiles staged, %d gathered, %d empty, largest window %d cells\n", s->gdin, s->gdout, st[0], st[1], st[2], st[3]);
                     }
+                    if (fits_t && !kept_t) { pthread_mutex_lock(&g_plan_mtx); cache_unreserve(s, tb_bytes); pthread_mutex_unlock(&g_plan_mtx); }
                     ezhip_free(dt);
                 }
             }
@@ -3263,7 +3361,11 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
     if (polar && !s->extrap && !same) {
         /* synthetic polar wind rows (ez_calcnpolarwind.c): one small kernel, no host round trip.  The row longitudes
          * and the polar-stereographic xg4 depend on the grid only: computed once on the host. */
-        if (!s->d_prow) s->d_prow = (float *)ezhip_malloc(sizeof(float) * 4 * (size_t)ni);
+        if (!s->d_prow) {      /* (+ 16 words behind the rows: the arrival counters of the producer teams of the pipelined pair kernel, zero once) */
+            s->d_prow = (float *)ezhip_malloc(sizeof(float) * (4 * (size_t)ni + 16));
+            if (s->d_prow && ezhip_memset(s->d_prow + 4 * (size_t)ni, 0, 64)) { ezhip_free(s->d_prow); s->d_prow = NULL; }
+            s->pw_epoch = 0;
+        }
         if (!s->d_prow) return -1;
         if (!gi->d_plon2) {
             float *pl = (float *)malloc(sizeof(float) * 3 * (size_t)ni);
@@ -3303,6 +3405,7 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
             if (per_point) {       /* the per-point pair kernel takes the job along (two producer blocks of its own launch, or its own side-stream launch) */
                 t_pwjob.out = s->d_prow; t_pwjob.plon2 = gi->d_plon2; t_pwjob.xg4_n = gi->xg4_pole[0]; t_pwjob.xg4_s = gi->xg4_pole[1];
                 t_pwjob.weighted = weighted; t_pwjob.ax = gi->d_ax; t_pwjob.active = 1;
+                t_pwjob.sync = (unsigned *)(s->d_prow + 4 * (size_t)ni); t_pwjob.epoch = &s->pw_epoch;
             } else {
                 if (ezhip_side_begin()) return -1;
                 int prc = ezhip_polar_wind(s->d_prow, d_uuin, d_vvin, gi->d_plon2, ni, nj, gi->xg4_pole[0], gi->xg4_pole[1], weighted, gi->d_ax);

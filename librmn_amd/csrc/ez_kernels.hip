@@ -438,6 +438,57 @@ __device__ float block_poleval(const float *zrow, int ni, int weighted, const fl
     return s;
 }
 
+/* two rows at once (the pole values of the two components of a wind): the same sequential REAL sums, row a by lane 0 of wave 0 and row b by lane 0 of wave 1 at the
+ * same time (each row has its half of the staging buffer: lds holds 2 * chunk + 4 floats) -- the two dependent-add chains of ~ni terms were most of the
+ * polar-wind producer blocks' 45 - 65 us, and those blocks bound the pair kernel once it runs faster than that */
+template <bool COHERENT = false>      /* COHERENT: the rows were written by other thread blocks of this launch with agent-scope atomic stores: read them the same way */
+__device__ void block_poleval2(const float *rowa, const float *rowb, int ni, int weighted, const float *ax, float *lds, const int chunk, float &ra, float &rb, const int nthr /* threads taking part (the first nthr of the block) */)
+{
+    const int n = weighted ? ni - 1 : ni;
+    float s = 0.0f;
+    for (int base = 0; base < n; base += chunk) {
+        const int m = min(chunk, n - base);
+        __syncthreads();
+        for (int k0 = threadIdx.x; k0 < m; k0 += 4 * nthr) {
+            float x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = base + min(k0 + u * nthr, m - 1);
+                const float w = weighted ? ax[i + 1] - ax[i] : 1.0f;
+                const float va = COHERENT ? __hip_atomic_load(&rowa[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rowa[i];
+                const float vb = COHERENT ? __hip_atomic_load(&rowb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rowb[i];
+                x[u] = weighted ? va * w : va; y[u] = weighted ? vb * w : vb;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int k = k0 + u * nthr; if (k < m) { lds[k] = x[u]; lds[chunk + k] = y[u]; } }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 || threadIdx.x == 64) {
+            const float *mine = lds + (threadIdx.x ? chunk : 0);
+            const float4 *l4 = (const float4 *)mine;
+            const int m4 = m >> 2;
+            int q = 0;
+            for (; q + 16 <= m4; q += 16) {
+                float4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) v[u] = l4[q + u];
+#pragma unroll
+                for (int u = 0; u < 16; u++) { s = s + v[u].x; s = s + v[u].y; s = s + v[u].z; s = s + v[u].w; }
+            }
+            for (int k = 4 * q; k < m; k++) s = s + mine[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 || threadIdx.x == 64) {
+        if (weighted) { float span = ax[ni - 1] - ax[0]; if (span != 0.0f) s = s / span; }
+        else s = s / (1.0f * (float)ni);
+        lds[2 * chunk + (threadIdx.x ? 1 : 0)] = s;
+    }
+    __syncthreads();
+    ra = lds[2 * chunk]; rb = lds[2 * chunk + 1];
+    __syncthreads();
+}
+
 /* order-preserving float <-> uint32 keys (min / max by integer compare) */
 __device__ __forceinline__ unsigned f2key(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
@@ -2107,8 +2158,63 @@ __device__ __forceinline__ void polar_wind_body(const int north, float *out, con
     }
     __threadfence_block();
     __syncthreads();
-    float s0 = block_poleval(pu, ni, weighted, ax, lds, CHUNK);
-    float w0 = block_poleval(pv, ni, weighted, ax, lds, CHUNK);
+    float s0, w0;
+    block_poleval2(pu, pv, ni, weighted, ax, lds, CHUNK / 2, s0, w0, 256);      /* (the body's loops are written for 256 threads; k_uvp calls it from the first 256 of 512) */
+    d_llwfgdw1(s0, w0, 0.0f, hs, xg4);
+    __syncthreads();
+    for (int i = threadIdx.x; i < ni; i += 256) {
+        float spd = s0, wd = (i == 0 || north) ? w0 + plon[i] : w0 - plon[i];
+        d_gdwfllw1(spd, wd, plon[i], 'A', 0.f);
+        pu[i] = spd; pv[i] = wd;
+    }
+}
+/* The same by a TEAM of PW_TEAM thread blocks per pole (k_uvp): the two producer blocks above run 37 us alone and 60 - 70 us next to the worker blocks of their
+ * CU (ten columns of REAL trigonometry per thread, then the sums) -- longer than the pipelined pair kernel itself.  The first loop (per column: speed / direction,
+ * polar-stereographic components) is spread over the team, every block an equal share of the columns; the blocks of a team sit on ONE XCD (blockIdx = pole + 8 k:
+ * one L2), announce their share with a release fence + one atomic add on the team's counter, and leave; the leader (k = 0) waits for the counter, sums the two rows (sequential REAL sums, as the reference) and writes the rows.  A leader that does not see its team in
+ * time redoes the first loop itself: never wrong, only slower. */
+#define PW_TEAM 8
+template <int CHUNK>
+__device__ __forceinline__ void polar_wind_team(const int north, const int rank, float *out, const float *uu, const float *vv, const float *plon2,
+                                                int ni, int nj, float xg4_n, float xg4_s, int weighted, const float *ax, unsigned *counter, unsigned *counter_next, float *lds)
+{
+    __builtin_amdgcn_s_setprio(3);                       /* these few waves are on the launch's critical path */
+    const char hs = north ? 'N' : 'S';
+    const float xg4 = north ? xg4_n : xg4_s;
+    const float *urow = uu + (north ? (size_t)(nj - 1) * ni : 0), *vrow = vv + (north ? (size_t)(nj - 1) * ni : 0);
+    const float *plon = plon2 + (north ? 0 : ni);
+    float *pu = out + (north ? 0 : ni), *pv = out + 2 * (size_t)ni + (north ? 0 : ni);
+    const int share = (ni + PW_TEAM - 1) / PW_TEAM;
+    /* (the shares travel between the team's blocks as agent-scope relaxed atomic stores / loads of single words: an agent-scope FENCE writes back the XCD's whole
+     * L2, which the worker blocks keep full of dirty output lines -- with fences the team took 100 us) */
+    auto first_loop = [&](int lo, int hi) {
+        for (int i = lo + (int)threadIdx.x; i < hi; i += 256) {
+            float a = urow[i], b = vrow[i];
+            d_llwfgdw1(a, b, plon[i], 'A', 0.f);
+            d_gdwfllw1(a, b, plon[i], hs, xg4);
+            __hip_atomic_store(&pu[i], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&pv[i], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    /* a PAIR of counters per pole: the launch of epoch e counts in slot e & 1 and zeroes the other one for the next launch (a launch is complete before the
+     * next one of the stream starts: no host-side bookkeeping beyond the parity, nothing to get out of step when a launch is skipped or gives up) */
+    if (rank == 0 && threadIdx.x == 0) __hip_atomic_store(counter_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    first_loop(rank * share, min(ni, (rank + 1) * share));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* my stores have been acknowledged ... */
+    __syncthreads();                                       /* ... and so have the block's */
+    if (rank != 0) { if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    __shared__ int s_team_ok;
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int spins = 0; spins < (1 << 17); spins++) {
+            if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(PW_TEAM - 1)) { ok = 1; break; }      /* the team's other blocks */
+            __builtin_amdgcn_s_sleep(4);
+        }
+        s_team_ok = ok;
+    }
+    __syncthreads();
+    if (!s_team_ok) { first_loop(share, ni); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+    float s0, w0;
+    block_poleval2<true>(pu, pv, ni, weighted, ax, lds, CHUNK / 2, s0, w0, 256);
     d_llwfgdw1(s0, w0, 0.0f, hs, xg4);
     __syncthreads();
     for (int i = threadIdx.x; i < ni; i += 256) {
@@ -2189,11 +2295,14 @@ struct FieldAcc {
     const float *z; int ni, j1, j2;
     float pole_n, pole_s;
     const float *prow_n, *prow_s;       /* vector mode: per-column pole rows */
+    /* ONE unconditional load per access, the row chosen by selects: behind the two row tests the 16 gathers of a strip point were 16 dependent round trips (the
+     * special points' kernels -- a fraction of a percent of the points -- ran 9.5 us behind every cfg3 call: latency, nothing else) */
     __device__ __forceinline__ float operator()(int i, int j) const
     {
-        if (j > j2) return prow_n ? prow_n[i - 1] : pole_n;
-        if (j < j1) return prow_s ? prow_s[i - 1] : pole_s;
-        return z[(size_t)(j - j1) * ni + (i - 1)];
+        const bool hi = j > j2, lo = j < j1;
+        const float *row = hi ? prow_n : (lo ? prow_s : z + (size_t)(j - j1) * ni);
+        const float v = (row ? row : z)[i - 1];
+        return (hi && !prow_n) ? pole_n : ((lo && !prow_s) ? pole_s : v);
     }
 };
 
@@ -2453,9 +2562,46 @@ __device__ __forceinline__ NewtonW newton_w(double c1, double c2, double c3, dou
 {
     return newton_w52(c1, c2, c3, c4, c5, c6, c5 + c2, t1, t2, t3);
 }
-__device__ __forceinline__ double newton_apply(const NewtonW &w, double z1, double z2, double z3, double z4)
+/* (round 5) The 2 x 20 multiply-adds of a wind pair in REAL: the eight weights come out of the REAL*8 Newton form above and are rounded to REAL once; the
+ * sixteen cells of a component are then combined row by row, rows by the y weights, with fused REAL multiply-adds -- as PAIRS (u, v) where the cells lie
+ * that way (k_uvt's LDS image: v_pk_fma_f32, 20 packed instructions per point pair instead of 32 conversions + 40 REAL*8-rate operations; the pair kernels are
+ * bound by exactly those, SQ_ACTIVE_INST_VALU 88 % in round 4).  Against the all-REAL*8 evaluation the result moves by <= 2.8e-7 |V| (measured on cfg3's
+ * golden rows, 3e-8 typical), the bar for winds is 1e-5 |V|.  Every kernel of the pair path uses THIS function in THIS order, so a set's first call (gathering)
+ * and its later calls (staged windows) return the same bits; a packed and a scalar fused multiply-add round identically. */
+typedef float pk2 __attribute__((ext_vector_type(2)));
+struct PairW { float x0, x1, x2, x3, y0, y1, y2, y3; };
+__device__ __forceinline__ PairW pair_weights(const NewtonW &wx, const NewtonW &wy)
 {
-    return fma(w.g, z4, fma(w.w2, z3, fma(w.w1, z2, w.w0 * z1)));
+    return PairW{(float)wx.w0, (float)wx.w1, (float)wx.w2, (float)wx.g, (float)wy.w0, (float)wy.w1, (float)wy.w2, (float)wy.g};
+}
+__device__ __forceinline__ pk2 pk_bc(float w) { return pk2{w, w}; }
+__device__ __forceinline__ pk2 pair_row(const PairW &w, pk2 z1, pk2 z2, pk2 z3, pk2 z4)
+{
+    return __builtin_elementwise_fma(z4, pk_bc(w.x3), __builtin_elementwise_fma(z3, pk_bc(w.x2), __builtin_elementwise_fma(z2, pk_bc(w.x1), z1 * pk_bc(w.x0))));
+}
+__device__ __forceinline__ pk2 pair_cols(const PairW &w, pk2 r0, pk2 r1, pk2 r2, pk2 r3)
+{
+    return __builtin_elementwise_fma(r3, pk_bc(w.y3), __builtin_elementwise_fma(r2, pk_bc(w.y2), __builtin_elementwise_fma(r1, pk_bc(w.y1), r0 * pk_bc(w.y0))));
+}
+/* ... and away from the longitude seam the eight weights themselves in REAL, in Lagrange's form from the set-up's 32-byte records {x1 .. x4, d1 .. d4}
+ * (ezhip_pts_plan.xrec8 / yrec8: d_k = 1 / prod_{m != k} (x_k - x_m) from REAL*8): w_k = d_k prod_{m != k} (x - x_m) -- the interpolating cubic of the four
+ * values, the polynomial the reference's Newton form evaluates; 14 REAL operations per direction instead of 21 REAL*8 ones + 4 conversions, records of 32
+ * instead of 80 bytes in LDS.  With the REAL sums above: <= 3.9e-7 |V| from the all-REAL*8 evaluation on cfg3's golden rows (bar: 1e-5 |V|). */
+typedef float f4a16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lagrange_w(float x, f4a16 xs, f4a16 d, float &w0, float &w1, float &w2, float &w3)
+{
+    const float t1 = x - xs.x, t2 = x - xs.y, t3 = x - xs.z, t4 = x - xs.w;
+    const float p12 = t1 * t2, p34 = t3 * t4;
+    w0 = (t2 * p34) * d.x; w1 = (t1 * p34) * d.y; w2 = (p12 * t4) * d.z; w3 = (p12 * t3) * d.w;
+}
+__device__ __forceinline__ PairW pair_weights_lagrange(float px, float py, int i, int j, f4a16 xs, f4a16 xd, f4a16 ys, f4a16 yd)
+{
+    const float x = xs.y + (xs.z - xs.y) * (px - (float)i);          /* REAL, as ez_irgdint_3_w.inc:158 - 159 */
+    const float y = ys.y + (ys.z - ys.y) * (py - (float)j);
+    PairW w;
+    lagrange_w(x, xs, xd, w.x0, w.x1, w.x2, w.x3);
+    lagrange_w(y, ys, yd, w.y0, w.y1, w.y2, w.y3);
+    return w;
 }
 template <class A, bool AOS>
 __device__ __forceinline__ void p_irgdint_3_w_pair(const A &Z1, const A &Z2, float px, float py, const float *ax, const float *ay,
@@ -2474,48 +2620,37 @@ __device__ __forceinline__ void p_irgdint_3_w_pair(const A &Z1, const A &Z2, flo
                                 coef<AOS>(cx, 4, i - 1, ni), coef<AOS>(cx, 5, i - 1, ni), x - (double)x1, x - (double)x2, x - (double)x3);
     const NewtonW wy = newton_w(coef<AOS>(cy, 0, j - j1, nnj), coef<AOS>(cy, 1, j - j1, nnj), coef<AOS>(cy, 2, j - j1, nnj), coef<AOS>(cy, 3, j - j1, nnj),
                                 coef<AOS>(cy, 4, j - j1, nnj), coef<AOS>(cy, 5, j - j1, nnj), y - (double)y1, y - (double)y2, y - (double)y3);
-    /* y direction as weights of the four row values (b0 + A (b1 - b0) + B (b2 - b1) + G (b3 - b2) regrouped once more): the rows stream through two
-     * accumulators instead of waiting in eight registers */
-    const double wr[4] = {wy.w0, wy.w1, wy.w2, wy.g};
-    double su = 0.0, sv = 0.0;
+    const PairW w = pair_weights(wx, wy);
+    pk2 rw[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        double z1, z2, z3, z4;
-        row_taps(Z1, im1, i, ip1, ip2, j - 1 + r, z1, z2, z3, z4);
-        su = fma(wr[r], newton_apply(wx, z1, z2, z3, z4), su);
-        row_taps(Z2, im1, i, ip1, ip2, j - 1 + r, z1, z2, z3, z4);
-        sv = fma(wr[r], newton_apply(wx, z1, z2, z3, z4), sv);
+        double a1, a2, a3, a4, b1, b2, b3, b4;              /* (row_taps hands REAL values back as REAL*8: exact both ways) */
+        row_taps(Z1, im1, i, ip1, ip2, j - 1 + r, a1, a2, a3, a4);
+        row_taps(Z2, im1, i, ip1, ip2, j - 1 + r, b1, b2, b3, b4);
+        rw[r] = pair_row(w, pk2{(float)a1, (float)b1}, pk2{(float)a2, (float)b2}, pk2{(float)a3, (float)b3}, pk2{(float)a4, (float)b4});
     }
-    r1 = (float)su; r2 = (float)sv;
+    const pk2 s = pair_cols(w, rw[0], rw[1], rw[2], rw[3]);
+    r1 = s.x; r2 = s.y;
 }
 /* The same away from the longitude seam (i - 1 .. i + 2 consecutive: all but two or three source columns), with EVERY load of the point issued before the
  * first is used: the axis entries, the two coefficient records and the eight stencil rows of the pair depend on (i, j) only.  Written in program order
  * (x, y from the axes -> coefficients -> rows) the compiler kept four dependent memory round trips per point behind the divergent seam branches;
  * k_pts2 is bound by that chain (a wave lived 5 us for 375 instructions), not by its gathers' bandwidth or its arithmetic. */
-__device__ __forceinline__ void p_irgdint_3_w_pair_inner(const float *z1f, const float *z2f, float px, float py, const float *ax, const float *ay,
-                                                         const float *cx8, const float *cy8, int ni, int j1, int i, int j, float &r1, float &r2)
+__device__ __forceinline__ void p_irgdint_3_w_pair_inner(const float *z1f, const float *z2f, float px, float py, const float *xrec8, const float *yrec8,
+                                                         int ni, int j1, int i, int j, float &r1, float &r2)
 {
-    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-    const f4u axv = *(const f4u *)(ax + (i - 2));                            /* ax(i-1 .. i+2) */
-    const f4u ayv = *(const f4u *)(ay + (j - 1 - j1));                       /* ay(j-1 .. j+2); j <= j2 - 2 */
-    const f4u cxa = *(const f4u *)(cx8 + (size_t)(i - 1) * 8); const f2u cxb = *(const f2u *)(cx8 + (size_t)(i - 1) * 8 + 4);
-    const f4u cya = *(const f4u *)(cy8 + (size_t)(j - j1) * 8); const f2u cyb = *(const f2u *)(cy8 + (size_t)(j - j1) * 8 + 4);
+    const f4a16 xs = *(const f4a16 *)(xrec8 + (size_t)(i - 1) * 8), xd = *(const f4a16 *)(xrec8 + (size_t)(i - 1) * 8 + 4);
+    const f4a16 ys = *(const f4a16 *)(yrec8 + (size_t)(j - j1) * 8), yd = *(const f4a16 *)(yrec8 + (size_t)(j - j1) * 8 + 4);
     const size_t o0 = (size_t)(j - 1 - j1) * (size_t)ni + (size_t)(i - 2);
     f4u u[4], v[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) { u[r] = *(const f4u *)(z1f + o0 + (size_t)r * ni); v[r] = *(const f4u *)(z2f + o0 + (size_t)r * ni); }
-    const double x = (double)(axv.y + (axv.z - axv.y) * (px - (float)i));
-    const double y = (double)(ayv.y + (ayv.z - ayv.y) * (py - (float)j));
-    const NewtonW wx = newton_w((double)cxa.x, (double)cxa.y, (double)cxa.z, (double)cxa.w, (double)cxb.x, (double)cxb.y, x - (double)axv.x, x - (double)axv.y, x - (double)axv.z);
-    const NewtonW wy = newton_w((double)cya.x, (double)cya.y, (double)cya.z, (double)cya.w, (double)cyb.x, (double)cyb.y, y - (double)ayv.x, y - (double)ayv.y, y - (double)ayv.z);
-    const double wr[4] = {wy.w0, wy.w1, wy.w2, wy.g};
-    double su = 0.0, sv = 0.0;
+    const PairW w = pair_weights_lagrange(px, py, i, j, xs, xd, ys, yd);
+    pk2 rw[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        su = fma(wr[r], newton_apply(wx, (double)u[r].x, (double)u[r].y, (double)u[r].z, (double)u[r].w), su);
-        sv = fma(wr[r], newton_apply(wx, (double)v[r].x, (double)v[r].y, (double)v[r].z, (double)v[r].w), sv);
-    }
-    r1 = (float)su; r2 = (float)sv;
+    for (int r = 0; r < 4; r++) rw[r] = pair_row(w, pk2{u[r].x, v[r].x}, pk2{u[r].y, v[r].y}, pk2{u[r].z, v[r].z}, pk2{u[r].w, v[r].w});
+    const pk2 s = pair_cols(w, rw[0], rw[1], rw[2], rw[3]);
+    r1 = s.x; r2 = s.y;
 }
 /* ez_irgdint_3_wnnc.inc:20-246 (ay: 4-entry strip latitudes indexed from j1) */
 template <class A> __device__ __forceinline__ float p_irgdint_3_wnnc(const A &Z, float px, float py, const float *ax, const float *ay4,
@@ -2767,7 +2902,9 @@ __device__ __forceinline__ void pts2_point(const ezhip_pts_plan &p, float *__res
             /* in flight with the loads of the interpolation; unconditional (a conditional load is merged with the identity at the join: a use, hence a
              * wait, right behind it): without a matrix a readable dummy address */
             wind_m_load(p.wind_M ? p.wind_M : (const void *)p.ncx8, p.wind_M_half, p.wind_M ? o : (size_t)0, wlo, whi);
-            if (__ballot(seam) == 0ull) p_irgdint_3_w_pair_inner(zin1, zin2, px, py, p.ax, p.ay, p.ncx8, p.ncy8, p.ni, p.j1, i, j, a, b);
+            /* (per LANE: the two forms round differently -- the seam's weights come from the Newton tables -- and which waves a point shares differs between
+             * the kernels of the pair path; a point's form must not depend on its neighbours) */
+            if (!seam) p_irgdint_3_w_pair_inner(zin1, zin2, px, py, p.xrec8, p.yrec8, p.ni, p.j1, i, j, a, b);
             else p_irgdint_3_w_pair<PlainAcc, true>(Z1, Z2, px, py, p.ax, p.ay, p.ncx8, p.ncy8, p.ni, p.j1, p.j2, p.wrap, a, b);
         }
         else { a = leaf_point<KIND>(p, Z1, px, py); b = leaf_point<KIND>(p, Z2, px, py); }
@@ -2828,6 +2965,8 @@ __global__ __launch_bounds__(256) void k_pts2_irgd3w(ezhip_pts_plan p, float *__
  * The arithmetic is p_irgdint_3_w_pair_inner's, operation for operation: results are bit-identical to k_pts2_irgd3w's. */
 #define UVT_CAP_DEFAULT 2560                           /* staged cells per tile */
 #define UVT_REC_MAX 128                                /* records (x + y) per tile, 80 bytes each */
+#define UVT_ALL_NORMAL 0x40000000                      /* tile table, .w: every point of the tile is a main-zone point */
+#define UVT_H_MASK 0xFFFF
 __device__ __forceinline__ int uvt_wave_min(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64)); return v; }
 __device__ __forceinline__ int uvt_wave_max(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64)); return v; }
 /* tile (TW x TH target points, a thread block of 256: thread t takes column t % TW, rows t / TW + k * 256 / TW) */
@@ -2841,10 +2980,10 @@ template <int TW, int TH>
 __global__ __launch_bounds__(256) void k_uvt_bbox(ezhip_pts_plan p, const float *__restrict__ xs, const float *__restrict__ ys, int4 *__restrict__ tiles, int cap, int recmax)
 {
     typedef uvt_geom<TW, TH> G;
-    __shared__ int red[4][6];
+    __shared__ int red[4][7];
     const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW, b = blockIdx.x, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
     const unsigned cx = bx * TW + (t % TW);
-    int imin = 0x7fffffff, imax = -1, jmin = 0x7fffffff, jmax = -1, seam = 0, mine = 0;
+    int imin = 0x7fffffff, imax = -1, jmin = 0x7fffffff, jmax = -1, seam = 0, mine = 0, other = 0;
 #pragma unroll
     for (int k = 0; k < G::PPT; k++) {
         const unsigned cy = by * TH + t / TW + (unsigned)(G::RSTEP * k);
@@ -2853,24 +2992,25 @@ __global__ __launch_bounds__(256) void k_uvt_bbox(ezhip_pts_plan p, const float 
         const float px = xs[n], py = ys[n];
         const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
         if (zone == PZ_FILL) mine = 1;
+        if (zone != PZ_NORMAL) other = 1;
         if (zone != PZ_NORMAL) continue;
         mine = 1;
         const int i = min(p.ni - 2 + p.wrap, max(1, max(2 - p.wrap, (int)px))), j = min(p.j2 - 2, max(p.j1 + 1, (int)py));
         seam |= (i <= 1 || i >= p.ni - 1) ? 1 : 0;
         imin = min(imin, i); imax = max(imax, i); jmin = min(jmin, j); jmax = max(jmax, j);
     }
-    imin = uvt_wave_min(imin); jmin = uvt_wave_min(jmin); imax = uvt_wave_max(imax); jmax = uvt_wave_max(jmax); seam = uvt_wave_max(seam); mine = uvt_wave_max(mine);
-    if ((t & 63u) == 0) { int *r = red[t >> 6]; r[0] = imin; r[1] = imax; r[2] = jmin; r[3] = jmax; r[4] = seam; r[5] = mine; }
+    imin = uvt_wave_min(imin); jmin = uvt_wave_min(jmin); imax = uvt_wave_max(imax); jmax = uvt_wave_max(jmax); seam = uvt_wave_max(seam); mine = uvt_wave_max(mine); other = uvt_wave_max(other);
+    if ((t & 63u) == 0) { int *r = red[t >> 6]; r[0] = imin; r[1] = imax; r[2] = jmin; r[3] = jmax; r[4] = seam; r[5] = mine; r[6] = other; }
     __syncthreads();
     if (t == 0) {
-        for (int w = 1; w < 4; w++) { imin = min(imin, red[w][0]); imax = max(imax, red[w][1]); jmin = min(jmin, red[w][2]); jmax = max(jmax, red[w][3]); seam |= red[w][4]; mine |= red[w][5]; }
+        for (int w = 1; w < 4; w++) { imin = min(imin, red[w][0]); imax = max(imax, red[w][1]); jmin = min(jmin, red[w][2]); jmax = max(jmax, red[w][3]); seam |= red[w][4]; mine |= red[w][5]; other |= red[w][6]; }
         int4 o;
         if (!mine) o = make_int4(0, 0, -1, 0);
         else if (imax < 0) o = make_int4(0, 0, 0, 0);                                     /* fill points only: the gathering path writes them */
         else {
             const int W = imax - imin + 4, H = jmax - jmin + 4;
             const bool ok = !seam && W * H <= cap && (W - 3) + (H - 3) <= recmax;
-            o = ok ? make_int4(imin - 1, jmin - 1, W, H) : make_int4(0, 0, 0, 0);
+            o = ok ? make_int4(imin - 1, jmin - 1, W, H | (other ? 0 : UVT_ALL_NORMAL)) : make_int4(0, 0, 0, 0);
         }
         tiles[b] = o;
     }
@@ -2904,9 +3044,13 @@ __global__ __launch_bounds__(256) void k_uvt_pack(ezhip_pts_plan p, const float 
 #ifndef UVT_WAVES
 #define UVT_WAVES 5
 #endif
+#ifndef UVT_WAVES_W
+#define UVT_WAVES_W 6                                   /* the REAL form of the wrap-around variant needs fewer registers, its records a third of the LDS */
+#endif
+
 template <int TW, int TH, bool NW = false>      /* NW: a source without wrap (a regional 'Z' grid): both components in the LITERAL form of ez_irgdint_3_nw.inc (REAL statement
                                                  * functions), as k_pts2<PK_IRGD3_NW> evaluates them on the set's first call */
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVT_WAVES, 8))) void k_uvt(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW ? UVT_WAVES : UVT_WAVES_W, 8))) void k_uvt(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
                                              const float *__restrict__ zin1, const float *__restrict__ zin2,
                                              const float *__restrict__ xs, const float *__restrict__ ys, const int4 *__restrict__ tiles)
 {
@@ -2919,7 +3063,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVT_WAVES, 
         if (blockIdx.x < 2) { polar_wind_body<2048>(blockIdx.x == 0, p.pw_out, zin1, zin2, p.pw_plon2, p.ni, p.nj, p.pw_xg4_n, p.pw_xg4_s, p.pw_weighted, p.pw_ax, uvt_lds); return; }      /* (the launch's dynamic LDS holds 2052 floats and more) */
         boff = 2;
     }
-    const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW, b = blockIdx.x - boff, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
+    /* (xcd_order: XCD k takes the k-th contiguous eighth of the tiles -- neighbouring tiles' windows overlap and share cache lines: one L2 then fetches them once) */
+    const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW, b = p.xcd_order ? pts_block(blockIdx.x - boff, gridDim.x - boff) : blockIdx.x - boff, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
     const unsigned cx = bx * TW + (t % TW), cy0 = by * TH + t / TW;
     const bool okx = cx < (unsigned)p.tile_ni;
     /* the points' own streams first -- before the tile's table entry is even looked at (their addresses depend on the block index only): in flight
@@ -2952,12 +3097,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVT_WAVES, 
         }
         return;
     }
-    const int i0 = tb.x, j0 = tb.y, W = tb.z, H = tb.w, ncell = W * H;
+    const int i0 = tb.x, j0 = tb.y, W = tb.z, H = tb.w & UVT_H_MASK, ncell = W * H;
+    const bool all_normal = (tb.w & UVT_ALL_NORMAL) != 0;          /* every point of the tile lies in the main zone (k_uvt_bbox): no zone test per point */
     typedef float c2 __attribute__((ext_vector_type(2)));
     typedef double d2 __attribute__((ext_vector_type(2)));
     c2 *cells = (c2 *)uvt_lds;
-    d2 *xr = (d2 *)(uvt_lds + 2 * ((ncell + 1) & ~1));                 /* 5 x 16 bytes per record */
-    const int nxr = (W - 3) * 5, nyr = (H - 3) * 5;
+    /* NW: 5 x 16 bytes per record (REAL*8, the literal form's operands); else 2 x 16 bytes (REAL: axis entries, Lagrange denominators) */
+    d2 *xr = (d2 *)(uvt_lds + 2 * ((ncell + 1) & ~1));
+    const int nxr = (W - 3) * (NW ? 5 : 2), nyr = (H - 3) * (NW ? 5 : 2);
     d2 *yr = xr + nxr;
     {
         const unsigned magic = 0xFFFFFFFFu / (unsigned)W + 1u;
@@ -2970,7 +3117,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVT_WAVES, 
                 cells[idx] = c2{s1[off], s2[off]};
             }
         }
-        const d2 *gx = (const d2 *)p.xrec10 + (size_t)i0 * 5, *gy = (const d2 *)p.yrec10 + (size_t)(j0 + 1 - p.j1) * 5;
+        const d2 *gx = NW ? (const d2 *)p.xrec10 + (size_t)i0 * 5 : (const d2 *)p.xrec8 + (size_t)i0 * 2;
+        const d2 *gy = NW ? (const d2 *)p.yrec10 + (size_t)(j0 + 1 - p.j1) * 5 : (const d2 *)p.yrec8 + (size_t)(j0 + 1 - p.j1) * 2;
         for (int idx = (int)t; idx < nxr; idx += 256) xr[idx] = gx[idx];
         for (int idx = (int)t; idx < nyr; idx += 256) yr[idx] = gy[idx];
     }
@@ -2979,25 +3127,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVT_WAVES, 
     for (int k = 0; k < PPT; k++) {
         if (!(okx && cy0 + (unsigned)(G::RSTEP * k) < (unsigned)p.tile_nj)) continue;
         const size_t n = (size_t)n0 + (size_t)k * nstep;
-        const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px[k], py[k]);
+        const int zone = all_normal ? (int)PZ_NORMAL : pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px[k], py[k]);
         float a, bb;
         if (zone == PZ_FILL) a = bb = *p.fill;
         else if (zone == PZ_NORMAL) {
             const int i = min(p.ni - 2 + p.wrap, max(1, max(2 - p.wrap, (int)px[k]))), j = min(p.j2 - 2, max(p.j1 + 1, (int)py[k]));
             if (dbg & 4) { a = px[k] + (float)i; bb = py[k] + (float)j; }
             else {
-                /* records {x1, x2 | x3, c1 | c2, c3 | c4, c5 | c6, c5 + c2} in REAL*8: the table's REAL entries converted once per grid, not per point */
-                const d2 *xq = xr + (i - 1 - i0) * 5, *yq = yr + (j - 1 - j0) * 5;
-                const d2 xa = xq[0], xb = xq[1], xc = xq[2], xd = xq[3], xe = xq[4];
-                const d2 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3], ye = yq[4];
                 const c2 *cp = cells + (j - 1 - j0) * W + (i - 1 - i0);
                 c2 q[4][4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) { q[r][0] = cp[r * W]; q[r][1] = cp[r * W + 1]; q[r][2] = cp[r * W + 2]; q[r][3] = cp[r * W + 3]; }
+                if (NW) {
+                /* records {x1, x2 | x3, c1 | c2, c3 | c4, c5 | c6, c5 + c2} in REAL*8: the table's REAL entries converted once per grid, not per point */
+                const d2 *xq = xr + (i - 1 - i0) * 5, *yq = yr + (j - 1 - j0) * 5;
+                const d2 xa = xq[0], xb = xq[1], xc = xq[2], xd = xq[3], xe = xq[4];
+                const d2 ya = yq[0], yb = yq[1], yc = yq[2], yd = yq[3], ye = yq[4];
                 const float fx2 = (float)xa.y, fx3 = (float)xb.x, fy2 = (float)ya.y, fy3 = (float)yb.x;      /* (exact: they were REAL) */
                 const double x = (double)(fx2 + (fx3 - fx2) * (px[k] - (float)i));
                 const double y = (double)(fy2 + (fy3 - fy2) * (py[k] - (float)j));
-                if (NW) {
 #define UV_RF(e) ((double)(float)(e))
                     float res[2];
 #pragma unroll
@@ -3019,16 +3167,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVT_WAVES, 
 #undef UV_RF
                     a = res[0]; bb = res[1];
                 } else {
-                const NewtonW wx = newton_w52(xb.y, xc.x, xc.y, xd.x, xd.y, xe.x, xe.y, x - xa.x, x - xa.y, x - xb.x);
-                const NewtonW wy = newton_w52(yb.y, yc.x, yc.y, yd.x, yd.y, ye.x, ye.y, y - ya.x, y - ya.y, y - yb.x);
-                const double wr[4] = {wy.w0, wy.w1, wy.w2, wy.g};
-                double su = 0.0, sv = 0.0;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    su = fma(wr[r], newton_apply(wx, (double)q[r][0].x, (double)q[r][1].x, (double)q[r][2].x, (double)q[r][3].x), su);
-                    sv = fma(wr[r], newton_apply(wx, (double)q[r][0].y, (double)q[r][1].y, (double)q[r][2].y, (double)q[r][3].y), sv);
-                }
-                a = (float)su; bb = (float)sv;
+                    /* p_irgdint_3_w_pair_inner's arithmetic, operation for operation, on the staged window and records */
+                    const f4a16 *xq = (const f4a16 *)xr + (i - 1 - i0) * 2, *yq = (const f4a16 *)yr + (j - 1 - j0) * 2;
+                    const PairW w = pair_weights_lagrange(px[k], py[k], i, j, xq[0], xq[1], yq[0], yq[1]);
+                    const pk2 s = pair_cols(w, pair_row(w, q[0][0], q[0][1], q[0][2], q[0][3]), pair_row(w, q[1][0], q[1][1], q[1][2], q[1][3]),
+                                            pair_row(w, q[2][0], q[2][1], q[2][2], q[2][3]), pair_row(w, q[3][0], q[3][1], q[3][2], q[3][3]));
+                    a = s.x; bb = s.y;
                 }
             }
         } else continue;
@@ -3040,6 +3184,192 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVT_WAVES, 
         }
         if (!(dbg & 32) || a == 12345.678f) { zout1[n] = a; zout2[n] = bb; }      /* (32: development, no stores) */
     }
+}
+
+/* ---- k_uvp (round 5): k_uvt as a PIPELINE -- persistent thread blocks, two LDS images, the next tile's window on its way while a tile is evaluated ---------
+ * k_uvt's blocks run their phases one after another (tile entry -> window -> barrier -> arithmetic -> stores: three dependent memory round trips per 1024 points)
+ * and only the CU's other blocks cover them: 70 us per cfg3 pair with 150 VALU instructions per point, 76 - 80 with 200 (the arithmetic was never the bound).  Here
+ *   - a block walks a list of tiles: XCD k (blockIdx % 8) takes the k-th contiguous eighth of the tile table, its blocks stride through it;
+ *   - the window of tile n + 1 is brought into the OTHER LDS image by LDS-DMA (global_load_lds_dword: no VGPRs, nothing to wait for) as (u, v) CELLS -- the lanes
+ *     of a DMA instruction take their dword from the u plane (even lanes) or the v plane (odd lanes), so the image is interleaved although the sources are two
+ *     arrays (round 4's pipeline staged planes: 32 ds_read2_b32 per point instead of 8 ds_read2_b64, and lost) -- with the tile's column / row records
+ *     (global_load_lds_dwordx4, 16 bytes per lane) behind them; issued right after the barrier that frees that image, i.e. a whole tile's arithmetic ahead;
+ *   - the points' own streams {x, y, a, b} of tile n + 1 are loaded into registers at the same moment, the table entry of tile n + 2 by scalar loads;
+ *   - per tile ONE barrier: "my DMAs have landed" (s_waitcnt vmcnt: in order, so the tile's 8 stores per thread stay in flight: vmcnt(8) on tiles whose
+ *     waves all store 8 times) + s_barrier.
+ * Arithmetic: uvt_eval_w below = p_irgdint_3_w_pair_inner's, operation for operation.  Tiles the table hands back take the gathering path inside the loop. */
+#define UVP_SERVICE (8 * PW_TEAM)                       /* the first blocks do not walk tiles: blocks 0 + 8 k and 1 + 8 k (XCD 0 and 1) are the two polar-wind producer teams */
+__device__ __forceinline__ void lds_dma_dword_p(const void *lane_addr, unsigned lds_byte_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                 :: "v"(lane_addr), "s"(__builtin_amdgcn_readfirstlane((int)lds_byte_addr)) : "memory");
+}
+__device__ __forceinline__ void lds_dma_dwordx4_p(const void *lane_addr, unsigned lds_byte_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(lane_addr), "s"(__builtin_amdgcn_readfirstlane((int)lds_byte_addr)) : "memory");
+}
+/* window and records of tile entry tb into the LDS image at byte address img: cells [W * H] x 8 bytes, then (W - 3) + (H - 3) records of 32 bytes */
+template <int NTHREADS>
+__device__ __forceinline__ void uvp_stage(const ezhip_pts_plan &p, const float *__restrict__ zin1, const float *__restrict__ zin2, int4 tb, unsigned img, unsigned t)
+{
+    const int i0 = tb.x, j0 = tb.y, W = tb.z, H = tb.w & UVT_H_MASK, ncell = W * H;
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)W + 1u, wv = t >> 6, lane = t & 63u;
+    const float *s1 = zin1 + (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1), *s2 = zin2 + (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1);
+    const float *sl = (lane & 1u) ? s2 : s1;                        /* odd lanes: the v plane */
+    const unsigned nd = 2u * (unsigned)ncell;
+    for (unsigned d0 = wv * 64u; d0 < nd; d0 += (unsigned)NTHREADS) {             /* a DMA instruction = 32 cells */
+        const unsigned cell = (d0 + lane) >> 1;
+        if (d0 + lane < nd) {
+            const unsigned r = __umulhi(cell, magic), c = cell - r * (unsigned)W;
+            lds_dma_dword_p(sl + ((size_t)r * (size_t)p.ni + c), img + d0 * 4u);
+        }
+    }
+    const unsigned rec0 = img + 8u * (unsigned)((ncell + 1) & ~1), nx = 2u * (unsigned)(W - 3), nr = nx + 2u * (unsigned)(H - 3);      /* 16-byte units */
+    if (wv * 64u < nr) {
+        if (t < nr) {
+            const float *g = t < nx ? p.xrec8 + (size_t)i0 * 8 + (size_t)t * 4 : p.yrec8 + (size_t)(j0 + 1 - p.j1) * 8 + (size_t)(t - nx) * 4;
+            lds_dma_dwordx4_p(g, rec0 + wv * 1024u);
+        }
+    }
+}
+/* one main-zone point of a staged tile: p_irgdint_3_w_pair_inner's arithmetic on the LDS image */
+__device__ __forceinline__ pk2 uvt_eval_w(const ezhip_pts_plan &p, const float *img, int4 tb, float px, float py)
+{
+    typedef float c2 __attribute__((ext_vector_type(2)));
+    const int i0 = tb.x, j0 = tb.y, W = tb.z, H = tb.w & UVT_H_MASK, ncell = W * H;
+    const c2 *cells = (const c2 *)img;
+    const f4a16 *xr = (const f4a16 *)(img + 2 * ((ncell + 1) & ~1)), *yr = xr + 2 * (W - 3);
+    const int i = min(p.ni - 2 + p.wrap, max(1, max(2 - p.wrap, (int)px))), j = min(p.j2 - 2, max(p.j1 + 1, (int)py));
+    const c2 *cp = cells + (j - 1 - j0) * W + (i - 1 - i0);
+    c2 q[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { q[r][0] = cp[r * W]; q[r][1] = cp[r * W + 1]; q[r][2] = cp[r * W + 2]; q[r][3] = cp[r * W + 3]; }
+    const f4a16 *xq = xr + (i - 1 - i0) * 2, *yq = yr + (j - 1 - j0) * 2;
+    const PairW w = pair_weights_lagrange(px, py, i, j, xq[0], xq[1], yq[0], yq[1]);
+    return pair_cols(w, pair_row(w, q[0][0], q[0][1], q[0][2], q[0][3]), pair_row(w, q[1][0], q[1][1], q[1][2], q[1][3]),
+                     pair_row(w, q[2][0], q[2][1], q[2][2], q[2][3]), pair_row(w, q[3][0], q[3][1], q[3][2], q[3][3]));
+}
+/* the points of tile b (entry tb, streams sq[]: {x, y, a, b} per point) from the LDS image img; drain_all := the tile's waves did NOT all issue exactly 2 PPT stores.
+ * A block of 1024 / PPT threads: thread t takes column t % 32 and the rows t / 32 + (32 / PPT) k of the tile */
+typedef float uvp_f4 __attribute__((ext_vector_type(4)));
+template <int PPT>
+__device__ __forceinline__ void uvp_tile(const ezhip_pts_plan &p, float *__restrict__ zout1, float *__restrict__ zout2, const float *__restrict__ zin1, const float *__restrict__ zin2,
+                                         const float *__restrict__ xs, const float *__restrict__ ys, int4 tb, unsigned b, unsigned tpr, unsigned t,
+                                         const float *img, const uvp_f4 (&sq)[PPT], int dbg, bool &drain_all)
+{
+    constexpr int TW = 32, TH = 32, RSTEP = 32 / PPT;
+    const unsigned by = b / tpr, bx = b - by * tpr, nstep = (unsigned)RSTEP * (unsigned)p.tile_ni;
+    const unsigned cx = bx * TW + (t & 31u), cy0 = by * TH + (t >> 5);
+    const bool okx = cx < (unsigned)p.tile_ni;
+    const bool inside = bx * TW + TW <= (unsigned)p.tile_ni && by * TH + TH <= (unsigned)p.tile_nj;
+    drain_all = true;
+    if (tb.z > 0) {                                      /* (W = 0: a handed-back tile, a block of k_uvp_rest behind this kernel gathers it) */
+        const bool all_normal = (tb.w & UVT_ALL_NORMAL) != 0;
+        const unsigned n0 = okx && cy0 < (unsigned)p.tile_nj ? cy0 * (unsigned)p.tile_ni + cx : 0u;
+        drain_all = !(all_normal && inside) || (p.wind_M && !p.wind_M_half) || (dbg & 32);      /* (the short wait needs exactly 2 PPT vector memory instructions per wave behind the DMAs) */
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            if (!(okx && cy0 + (unsigned)(RSTEP * k) < (unsigned)p.tile_nj)) continue;
+            const size_t n = (size_t)n0 + (size_t)k * nstep;
+            const float px = sq[k].x, py = sq[k].y;
+            const int zone = all_normal ? (int)PZ_NORMAL : pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
+            float a, bb;
+            if (zone == PZ_FILL) a = bb = *p.fill;
+            else if (zone == PZ_NORMAL) {
+                if (dbg & 4) { a = px; bb = py; }
+                else { const pk2 s = uvt_eval_w(p, img, tb, px, py); a = s.x; bb = s.y; }
+            } else continue;
+            if (p.wind_M) {
+                wm_f2 whi = wm_f2{0.0f, 1.0f};
+                if (!p.wind_M_half) whi = __builtin_nontemporal_load((const wm_f2 *)((const char *)p.wind_M + (n << 4)) + 1);
+                const float u = a, v = bb;
+                wind_m_apply(wm_f2{sq[k].z, sq[k].w}, whi, p.wind_M_half, u, v, p.wind_dst_rot, a, bb);
+            }
+            if (!(dbg & 32) || a == 12345.678f) { zout1[n] = a; zout2[n] = bb; }
+        }
+    }
+}
+/* PPT points per thread, 1024 / PPT threads per block: 2 (512 threads: eight waves share a tile's two LDS images -- the images, 49 KB per block, allow three blocks
+ * per CU whatever the block size, and twelve waves per CU hide too little of the LDS / VALU latency of the evaluation: 75 us per cfg3 pair against k_uvt's 60) */
+#ifndef UVP_PPT
+#define UVP_PPT 2
+#endif
+#ifndef UVP_WAVES2
+#define UVP_WAVES2 5
+#endif
+#ifndef UVP_WAVES4
+#define UVP_WAVES4 4
+#endif
+template <int PPT>
+__global__ __launch_bounds__(1024 / PPT) __attribute__((amdgpu_waves_per_eu(PPT == 2 ? UVP_WAVES2 : UVP_WAVES4, 8))) void k_uvp(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+                                             const float *__restrict__ zin1, const float *__restrict__ zin2,
+                                             const float *__restrict__ xs, const float *__restrict__ ys, const int4 *__restrict__ tiles, unsigned ntiles, unsigned img_bytes)
+{
+    constexpr int TW = 32, NT = 1024 / PPT;
+    typedef float f4a __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float uvt_lds[];
+    const int dbg = EZH_DBG(p.uvt_debug);
+    if (blockIdx.x < UVP_SERVICE) {
+        if (p.pw_out && (blockIdx.x & 7u) < 2u && !(dbg & 64) && threadIdx.x < 256) {
+            const int north = (blockIdx.x & 7u) == 0u;
+            if (p.pw_sync) polar_wind_team<2048>(north, (int)(blockIdx.x >> 3), p.pw_out, zin1, zin2, p.pw_plon2, p.ni, p.nj, p.pw_xg4_n, p.pw_xg4_s, p.pw_weighted, p.pw_ax,
+                                                 p.pw_sync + (north ? 0 : 4) + (p.pw_epoch & 1u), p.pw_sync + (north ? 0 : 4) + ((p.pw_epoch + 1u) & 1u), uvt_lds);
+            else if (blockIdx.x < 2) polar_wind_body<2048>(north, p.pw_out, zin1, zin2, p.pw_plon2, p.ni, p.nj, p.pw_xg4_n, p.pw_xg4_s, p.pw_weighted, p.pw_ax, uvt_lds);
+        }
+        return;
+    }
+    const unsigned xcd = blockIdx.x & 7u, rk = (blockIdx.x >> 3) - (unsigned)PW_TEAM, R = (gridDim.x >> 3) - (unsigned)PW_TEAM, t = threadIdx.x;
+    const unsigned lo = (unsigned)(((unsigned long long)ntiles * xcd) >> 3), hi = (unsigned)(((unsigned long long)ntiles * (xcd + 1u)) >> 3);
+    unsigned b = lo + rk;
+    if (b >= hi) return;
+    const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW;
+    const unsigned img0 = lds_addr_of(uvt_lds);
+    /* the tile-ordered copy is laid out for k_uvt's 256 threads x 4 points, [tile][k4][t256]: row r (0 .. 31) of a tile is k4 = r / 8, t256 = 32 (r % 8) + column */
+    const unsigned r0 = t >> 5;
+    const f4a *S = (const f4a *)p.uvt_streams + ((r0 >> 3) * 256u + (r0 & 7u) * 32u + (t & 31u));
+    constexpr unsigned KSTEP = (32 / PPT) / 8 * 256;                  /* f4a elements between a thread's consecutive points */
+    /* prologue: the streams of the first TWO tiles, the first tile's window, the entries of the first three tiles.  Streams run two tiles ahead of the evaluation
+     * (registers: 2 x PPT x 4 dwords), the window one tile ahead (the second LDS image): per CU ~70 KB have to be in flight to keep HBM busy at this kernel's
+     * rate, one tile ahead left 23 KB per block */
+    const unsigned last = lo + rk + ((hi - 1u - (lo + rk)) / R) * R;      /* this block's last tile */
+    int4 tb = tiles[b];
+    f4a s0[PPT], s1[PPT], s2[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; k++) s0[k] = __builtin_nontemporal_load(S + (size_t)b * 1024 + k * KSTEP);
+#pragma unroll
+    for (int k = 0; k < PPT; k++) s1[k] = __builtin_nontemporal_load(S + (size_t)min(b + R, last) * 1024 + k * KSTEP);
+    if (tb.z > 0 && !(dbg & 2)) uvp_stage<NT>(p, zin1, zin2, tb, img0, t);
+    int4 tbn = b + R < hi ? tiles[b + R] : make_int4(0, 0, -1, 0);
+    int4 tbnn = b + 2u * R < hi ? tiles[b + 2u * R] : make_int4(0, 0, -1, 0);
+    /* (the compiler's waits for the prologue's loads belong HERE: left to the first use they would sit inside the loop, where they wait for every step's loads) */
+#pragma unroll
+    for (int k = 0; k < PPT; k++) asm volatile("" : "+v"(s0[k]), "+v"(s1[k]));
+    unsigned cur = 0;
+    bool drain_all = true;
+    /* one tile: SQ = this tile's streams (in registers since two steps ago), LQ = the set the tile after next is loaded into (this step's SQ of the step before);
+     * a macro expanded three times with the register sets rotated: copies between the sets would make a step wait for the loads it has just issued.
+     * Vector memory instructions of a step, in issue order: the DMAs of the next tile's window, PPT stream loads, 2 PPT stores: the next step's wait lets the last
+     * 3 PPT of them stay in flight (the loads are issued even when no tile is left to load: the count must not depend on it) */
+#define UVP_STEP(SQ, LQ) { \
+        if (drain_all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else if (PPT == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
+        __syncthreads(); \
+        /* (SQ HAS arrived -- it is older than the DMAs the wait above covered -- but the compiler cannot see the DMAs: its own waits for SQ, placed where SQ is \
+         * first used, would count this step's loads in.  Make it place them here) */ \
+        _Pragma("unroll") for (int k = 0; k < PPT; k++) asm volatile("" : "+v"(SQ[k])); \
+        const unsigned bn = b + R; \
+        if (bn < hi && tbn.z > 0 && !(dbg & 2)) uvp_stage<NT>(p, zin1, zin2, tbn, img0 + (cur ^ 1u) * img_bytes, t); \
+        _Pragma("unroll") for (int k = 0; k < PPT; k++) LQ[k] = __builtin_nontemporal_load(S + (size_t)min(bn + R, last) * 1024 + k * KSTEP); \
+        const int4 tbn3 = bn + 2u * R < hi ? tiles[bn + 2u * R] : make_int4(0, 0, -1, 0); \
+        uvp_tile<PPT>(p, zout1, zout2, zin1, zin2, xs, ys, tb, b, tpr, t, uvt_lds + (size_t)cur * (img_bytes >> 2), SQ, dbg, drain_all); \
+        if (bn >= hi) break; \
+        b = bn; tb = tbn; tbn = tbnn; tbnn = tbn3; cur ^= 1u; }
+    for (;;) {
+        UVP_STEP(s0, s2)
+        UVP_STEP(s1, s0)
+        UVP_STEP(s2, s1)
+    }
+#undef UVP_STEP
 }
 
 /* ---- k_st: the SCALAR twin of k_uvt -- c_ezsint from an irregular (rotated) source, bicubic, with its stencil windows staged in LDS ------------------------
@@ -3124,7 +3454,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? STB
         }
         return;
     }
-    const int i0 = tb.x, j0 = tb.y, W = tb.z, H = tb.w, ncell = W * H;
+    const int i0 = tb.x, j0 = tb.y, W = tb.z, H = tb.w & UVT_H_MASK, ncell = W * H;
     typedef double d2 __attribute__((ext_vector_type(2)));
     float *cells = st_lds;
     d2 *xr = (d2 *)(st_lds + ((ncell + 3) & ~3));
@@ -3391,7 +3721,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? 4 :
             const double y2 = d_zlin((double)cp[W], (double)cp[W + 1], dx);
             res[k] = (float)d_zlin(y1, y2, dy); written |= 1u << k;
         }
-        if (written == 15u && ((p.tile_ni & 3) == 0)) {               /* the row pieces of a tile start at multiples of 32 columns: 16-byte aligned when ni is a multiple of 4 */
+        if (written == 15u && ((p.tile_ni & 3) == 0) && (((size_t)zout & 15) == 0)) {      /* the row pieces of a tile start at multiples of 32 columns: 16-byte aligned when ni is a multiple of 4 and the caller's array is */
             typedef float f4a __attribute__((ext_vector_type(4)));
             __builtin_nontemporal_store(f4a{res[0], res[1], res[2], res[3]}, (f4a *)(zout + n0));
         } else {
@@ -3502,6 +3832,19 @@ __global__ __launch_bounds__(256) void k_pts_special2c(ezhip_pts_plan p, float *
                                                        const float *__restrict__ prow_n2, const float *__restrict__ prow_s2)
 {
     special2c_body(p, zout1, zout2, zin1, zin2, prow_n2, prow_s2, blockIdx.x, gridDim.x);
+}
+/* behind k_uvp: the set's special points (blocks [0, nspec_blocks)) and the tiles its table hands back to the gathering path (four blocks per listed tile) in ONE launch -- inside the pipelined kernel the gathering code cost it a third of its registers and its tiles stalled a whole block */
+__global__ __launch_bounds__(256) void k_uvp_rest(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+                                                  const float *__restrict__ zin1, const float *__restrict__ zin2,
+                                                  const float *__restrict__ prow_n2, const float *__restrict__ prow_s2,
+                                                  const float *__restrict__ xs, const float *__restrict__ ys, unsigned nspec_blocks)
+{
+    if (blockIdx.x < nspec_blocks) { special2c_body(p, zout1, zout2, zin1, zin2, prow_n2, prow_s2, blockIdx.x, nspec_blocks); return; }
+    /* four blocks per tile, a point per thread (a gathered point is a chain of dependent round trips: four of them one after the other made these blocks the
+     * launch's long pole) */
+    const unsigned q = blockIdx.x - nspec_blocks, b = (unsigned)p.uvt_hb_list[q >> 2], tpr = ((unsigned)p.tile_ni + 31u) / 32u, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
+    const unsigned cx = bx * 32u + (t & 31u), cy = by * 32u + (q & 3u) * 8u + (t >> 5);
+    if (cx < (unsigned)p.tile_ni && cy < (unsigned)p.tile_nj) pts2_point<PK_IRGD3_W, false>(p, zout1, zout2, zin1, zin2, xs, ys, (int)(cy * (unsigned)p.tile_ni + cx), nullptr, nullptr);
 }
 __global__ __launch_bounds__(256) void k_spec_gather(int *__restrict__ list_out, float *__restrict__ x_out, float *__restrict__ y_out,
                                                      const int *__restrict__ list_in, const float *__restrict__ xs, const float *__restrict__ ys, unsigned cnt)
@@ -3645,14 +3988,65 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
         const unsigned nt = (unsigned)ezhip_uvt_ntiles(&pu2, pu2.uvt_shape);
         const int4 *tl = (const int4 *)pu2.uvt_tiles;
         const dim3 g(nt + (pu2.pw_out ? 2u : 0u));
-        const size_t lds = (size_t)8 * (size_t)pu2.uvt_cap + 80 * UVT_REC_MAX;
+        size_t lds = (size_t)8 * (size_t)pu2.uvt_cap + (stage3nw ? 80 : 32) * UVT_REC_MAX;
+        if (lds < 4 * 2052 + 16) lds = 4 * 2052 + 16;                          /* (the polar-wind producer blocks' row buffer) */
+        pu2.xcd_order = getenv("EZHIP_UVT_XCD") ? atoi(getenv("EZHIP_UVT_XCD")) : 0;
 #define UVT_LAUNCH(TW, TH) hipLaunchKernelGGL((k_uvt<TW, TH>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl)
+        bool uvp = false;
+        if (!stage3nw && pu2.uvt_shape == 3232 && pu2.uvt_streams && (pu2.uvt_hb_count == 0 || pu2.uvt_hb_list) && !getenv("EZHIP_NO_UVP")) {
+            /* the pipelined form (k_uvp): as many persistent blocks as the device holds at once, in whole rounds of the 8 XCDs */
+            static int per_cu = -1, ncu = 0;
+            const unsigned img = 8u * (unsigned)pu2.uvt_cap + 32u * UVT_REC_MAX;
+            size_t lds2 = 2 * (size_t)img;
+            if (lds2 < 4 * 2052 + 16) lds2 = 4 * 2052 + 16;
+            if (per_cu < 0) {
+                int dev = 0, nb = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_uvp<UVP_PPT>, 1024 / UVP_PPT, lds2) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+                per_cu = nb;
+            }
+            const int ppt = EZH_DEVINT("EZHIP_UVP_PPT") == 4 ? 4 : EZH_DEVINT("EZHIP_UVP_PPT") == 2 ? 2 : UVP_PPT;
+            if (ppt != UVP_PPT) {      /* development: the other block shape */
+                int nb = 0;
+                if ((ppt == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_uvp<4>, 256, lds2) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_uvp<2>, 512, lds2)) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+                per_cu = -1;
+                if (nb > 0 && ncu >= 8 && lds2 <= 65536) {
+                    int bpc2 = EZH_DEVINT("EZHIP_UVP_BPC") > 0 ? EZH_DEVINT("EZHIP_UVP_BPC") : nb;
+                    unsigned R = (unsigned)bpc2 * (unsigned)(ncu / 8);
+                    if (R > (nt + 7u) / 8u) R = (nt + 7u) / 8u;
+                    if (pu2.pw_out && pu2.pw_sync && pu2.pw_epoch_io) pu2.pw_epoch = ++*pu2.pw_epoch_io; else pu2.pw_sync = nullptr;
+                    if (ppt == 4) hipLaunchKernelGGL(k_uvp<4>, dim3(8u * (R + (unsigned)PW_TEAM)), dim3(256), lds2, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl, nt, img);
+                    else hipLaunchKernelGGL(k_uvp<2>, dim3(8u * (R + (unsigned)PW_TEAM)), dim3(512), lds2, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl, nt, img);
+                    uvp = true;
+                    goto uvt_launched;
+                }
+            }
+            int bpc = EZH_DEVINT("EZHIP_UVP_BPC") > 0 ? EZH_DEVINT("EZHIP_UVP_BPC") : per_cu;
+            if (bpc > 0 && ncu >= 8 && lds2 <= 65536) {
+                unsigned R = (unsigned)bpc * (unsigned)(ncu / 8);
+                if (R > (nt + 7u) / 8u) R = (nt + 7u) / 8u;
+                if (pu2.pw_out && pu2.pw_sync && pu2.pw_epoch_io) pu2.pw_epoch = ++*pu2.pw_epoch_io; else pu2.pw_sync = nullptr;
+                hipLaunchKernelGGL(k_uvp<UVP_PPT>, dim3(8u * (R + (unsigned)PW_TEAM)), dim3(1024 / UVP_PPT), lds2, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl, nt, img);
+                uvp = true;
+                goto uvt_launched;
+            }
+        }
         if (stage3nw) hipLaunchKernelGGL((k_uvt<32, 32, true>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl);      /* (tables of regional sets are built with 32 x 32 tiles) */
         else
         switch (pu2.uvt_shape) { case 3216: UVT_LAUNCH(32, 16); break; case 6408: UVT_LAUNCH(64, 8); break; case 6416: UVT_LAUNCH(64, 16); break; default: UVT_LAUNCH(32, 32); break; }
 #undef UVT_LAUNCH
+uvt_launched:
         if (LAUNCH_CHECK("k_uvt")) return -1;
         if (ezhip_side_join()) return -1;
+        if (uvp) {
+            const unsigned nsp = (plan_u->cspec_count > 0 && !(pu2.uvt_debug & 8)) ? (unsigned)((2 * plan_u->cspec_count + 255) / 256) : 0u, nbk = nsp < 256u ? nsp : 256u;
+            const unsigned nhb = (pu2.uvt_debug & 1) ? 0u : (unsigned)pu2.uvt_hb_count;
+            if (nbk + nhb == 0) return 0;
+            ezhip_pts_plan pr = *plan_u;
+            pr.uvt_hb_list = pu2.uvt_hb_list; pr.uvt_hb_count = pu2.uvt_hb_count; pr.tile_ni = pu2.tile_ni; pr.tile_nj = pu2.tile_nj; pr.newton_literal = 0;
+            hipLaunchKernelGGL(k_uvp_rest, dim3(nbk + 4u * nhb), block, 0, g_stream, pr, d_out_u, d_out_v, d_in_u, d_in_v, plan_v->pole_row_n, plan_v->pole_row_s, d_x, d_y, nbk);
+            return LAUNCH_CHECK("k_uvp_rest");
+        }
         if (plan_u->cspec_count > 0 && !(pu2.uvt_debug & 8)) {
             const unsigned nbk = (unsigned)((2 * plan_u->cspec_count + 255) / 256);      /* a lane pair per point */
             hipLaunchKernelGGL(k_pts_special2c, dim3(nbk < 256 ? nbk : 256), block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v, plan_v->pole_row_n, plan_v->pole_row_s);
@@ -3715,10 +4109,30 @@ extern "C" int ezhip_uvt_build(const ezhip_pts_plan *plan, const float *d_x, con
         if (!h) return -1;
         if (set_err(hipMemcpy(h, d_tiles, sizeof(int4) * (size_t)nt, hipMemcpyDeviceToHost), "k_uvt_bbox tiles")) { free(h); return -1; }
         stats[0] = stats[1] = stats[2] = stats[3] = 0;
-        for (int k = 0; k < nt; k++) { if (h[k].z > 0) { stats[0]++; if (h[k].z * h[k].w > stats[3]) stats[3] = h[k].z * h[k].w; } else if (h[k].z == 0) stats[1]++; else stats[2]++; }
+        for (int k = 0; k < nt; k++) { if (h[k].z > 0) { stats[0]++; if (h[k].z * (h[k].w & UVT_H_MASK) > stats[3]) stats[3] = h[k].z * (h[k].w & UVT_H_MASK); } else if (h[k].z == 0) stats[1]++; else stats[2]++; }
         free(h);
     }
     return 0;
+}
+
+extern "C" int ezhip_uvt_handed_back(const void *d_tiles, int ntiles, int **d_list_out)
+{
+    *d_list_out = nullptr;
+    if (ntiles <= 0 || !d_tiles) return -1;
+    int4 *h = (int4 *)malloc(sizeof(int4) * (size_t)ntiles);
+    int *list = (int *)malloc(sizeof(int) * (size_t)ntiles);
+    int n = 0, rc = -1;
+    if (h && list && !set_err(hipStreamSynchronize(g_stream), "handed-back tiles") && !set_err(hipMemcpy(h, d_tiles, sizeof(int4) * (size_t)ntiles, hipMemcpyDeviceToHost), "handed-back tiles")) {
+        for (int k = 0; k < ntiles; k++) if (h[k].z == 0) list[n++] = k;
+        rc = n;
+        if (n > 0) {
+            int *d = nullptr;
+            if (hipMalloc((void **)&d, sizeof(int) * (size_t)n) != hipSuccess || set_err(hipMemcpy(d, list, sizeof(int) * (size_t)n, hipMemcpyHostToDevice), "handed-back tiles")) { if (d) (void)hipFree(d); (void)hipGetLastError(); rc = -1; }
+            else *d_list_out = d;
+        }
+    }
+    free(h); free(list);
+    return rc;
 }
 
 /* the tile-ordered stream copy of a wind-pair plan (k_uvt_pack): d_streams holds 16 bytes x 256 x PPT x ntiles.  plan->wind_M: NULL or the (a, b) form */

@@ -1,7 +1,7 @@
 /* Development switches.  The shipped library (make) is built WITHOUT -DEZHIP_DEVELOP: every knock-out that changes what a kernel
  * computes or stores (EZHIP_DEBUG, EZHIP_ENC_DEBUG, EZHIP_CFG5_ONLY_FUSED, EZHIP_SEPX_PAD ...) is then compiled out -- the kernels
  * see the constant 0 and the host never reads those environment variables.  `make develop` builds devlibs/librmn_ez_hip_dev.so with
- * them in, for the measurement scripts under tools/ (EZHIP_LIB=devlibs/librmn_ez_hip_dev.so).  ezhip_develop_build() tells which one
+ * them in, for the measurement scripts under tools/ (EZHIP_LIBRARY=devlibs/librmn_ez_hip_dev.so).  ezhip_develop_build() tells which one
  * a process loaded; bench.py records it in its JSON line.
  *
  * Environment variables that only choose between routes producing the SAME results (EZHIP_NO_SEPX, EZHIP_FORCE_PTS, ... -- the tests

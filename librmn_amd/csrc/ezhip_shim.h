@@ -224,9 +224,13 @@ typedef struct {
     const float *ncx8, *ncy8;         /* the same coefficients laid out [index][8] (6 used): two 16-byte loads per point */
     const double *xrec10, *yrec10;    /* k_uvt: per source column i (row j) one 80-byte record of REAL*8 {ax(i-1), ax(i), ax(i+1), c1 .. c6, c5 + c2} (the REAL table entries converted once,
                                          not per point), staged in LDS per tile; index i - 1 (j - j1) */
+    const float *xrec8, *yrec8;       /* the wind pair kernels (k_pts2_irgd3w, k_uvt): per source column i (row j) one 32-byte record of REAL {ax(i-1 .. i+2), d1 .. d4},
+                                         d_k = 1 / prod_{m != k} (x_k - x_m) formed in REAL*8 and rounded once: the Lagrange weights of the stencil; index i - 1 (j - j1) */
     const void *uvt_tiles;            /* k_uvt: the grid set's tile table (int4 {i0, j0, W, H} per 32 x uvt_th tile of the target: ezhip_uvt_build), NULL: k_pts2 */
     int uvt_shape;                    /* 100 TW + TH of the table's tiles: 3232 (default), 3216, 6416, 6408 */
     int uvt_cap;                      /* staged cells a tile may need (the table was built under it) */
+    const int *uvt_hb_list; int uvt_hb_count;      /* k_uvp: the tiles the table hands back to the gathering path (W = 0), listed once per set (ezhip_uvt_handed_back): they run as
+                                                      blocks of the special points' launch behind the pipelined kernel, which skips them */
     const void *uvt_streams;          /* NULL, or the set's x, y and (a, b) once more in tile order: float4 per point (ezhip_uvt_pack_streams) */
     int uvt_debug;                    /* development knock-outs (develop build only) */
     int wind_dst_rot;                 /* with wind_M: the TARGET frame is a rotated one (decides what a REAL overflow of the chain's speed turns into) */
@@ -248,6 +252,9 @@ typedef struct {
     /* the synthetic polar wind rows of the pair (k_polar_wind's job) riding in the k_pts2 launch as two producer blocks: only the special points, handled by
      * the NEXT kernel, read them.  pw_out != NULL: out4 = [u north | u south | v north | v south] rows of ni floats */
     float *pw_out; const float *pw_plon2; float pw_xg4_n, pw_xg4_s; int pw_weighted; const float *pw_ax;
+    /* k_uvp: the rows come from two TEAMS of producer blocks; pw_sync: 16 device words (zero when allocated): per pole a PAIR of arrival counters, the launch of
+     * epoch e counts in slot e & 1 and zeroes the other; *pw_epoch_io (host): launches so far, incremented by the launcher; pw_epoch: its value for this launch */
+    unsigned *pw_sync; unsigned *pw_epoch_io; unsigned pw_epoch;
     /* scalar per-point path: pv_out != NULL: the two pole values of the field are summed by two producer blocks at the head of the k_pts launch (they were a
      * launch of their own in front of it: 16 us of a 99 us c_ezsint from a rotated 2560 x 1280 source); the points that read them -- the pole points and the
      * polar strips -- are the NEXT kernel's.  pv_nj: rows of the field the sums run over */
@@ -270,6 +277,8 @@ int ezhip_mask_fill_min(float *d_fld, const int *d_mask, size_t n, unsigned *d_k
  * ezhip_uvt_ntiles(plan, shape) int4 entries (shape = 100 TW + TH).  stats (host, may be NULL): [0] tiles staged, [1] handed to the gathering path, [2] empty, [3] largest window (cells).  Synchronises. */
 int ezhip_uvt_ntiles(const ezhip_pts_plan *plan, int shape);
 int ezhip_uvt_build(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_tiles, int shape, int *stats);
+/* the indices of the table's handed-back tiles (W = 0) as a device array (caller frees with ezhip_free; NULL when there are none); returns their number, -1 on error.  Synchronises. */
+int ezhip_uvt_handed_back(const void *d_tiles, int ntiles, int **d_list_out);
 size_t ezhip_uvt_stream_bytes(const ezhip_pts_plan *plan, int shape);
 int ezhip_uvt_pack_streams(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_streams, int shape);
 int ezhip_interp_pts_batch(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin, const float *d_x, const float *d_y, int npts, int nfields, size_t in_stride, size_t out_stride);      /* k_st over a batch: -2 when the plan is not on that path */

@@ -553,6 +553,54 @@ def test_fused_cfg5_pipeline_full_size():
         assert zs == zl[f], (f, zs, int(zl[f]))
         m = 4 + (zs - 1) // 4
         assert torch.equal(one[:m], rec[f][:m]), f
+    # ... and one field DIRECTLY against the oracle chain (compact_float + armn_compress of the float field c_ezsint_dev leaves), not only through the
+    # unfused HIP chain: header words, byte count and every full word of the stream
+    assert ez.ezsint_dev(z, d_in[0]) == 0
+    torch.cuda.synchronize()
+    want = top.pack_float(z.cpu().numpy(), 16 + 64 * 16)
+    zw = top.O().orc_armn_compress(want[4:].ctypes.data, no, mo, 1, 16, 1)
+    assert zw == zl[0] and zw > 0, (zw, int(zl[0]))
+    got = rec[0].cpu().numpy().view(np.uint32)
+    nfull = 4 + (zw - 1) // 4
+    assert np.array_equal(got[:nfull], want[:nfull]), np.nonzero(got[:nfull] != want[:nfull])[0][:5]
+
+
+def test_cfg5_record_against_reference_interpolated_floats():
+    """cfg5 END TO END against the reference side: tests/golden/cfg5_record_golden.npz holds zlng, the header and sampled 16-bit tokens of the record the
+    oracle's packers make of the field the REFERENCE's c_ezsint interpolated (tests/golden/make_cfg5_record.py).  The HIP pipeline's bicubic values are
+    within 1 ulp of the reference's, not identical (the 1e-5 bar), so its record may differ where a value crosses a quantisation step: the header must be
+    identical (the field's extrema are), at most 0.1 % of the sampled tokens may differ and then by one step, and the byte count within 1e-3."""
+    from librmn_amd import ezscint as ez
+    import ezcases as ec
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg5_record_golden.npz"))
+    ni, nj, no, mo = 4400, 2200, 7200, 3601
+    gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(no, mo, "L", 5, 5, 0, 0)
+    assert ez.ezdefset(gdout, gdin) == 1
+    ez.ezsetopt("interp_degree", "cubic"); ez.ezsetopt("polar_correction", "yes")
+    ez.use_stream(torch.cuda.current_stream().cuda_stream)
+    d_in = torch.from_numpy(ec.synth_field(ni, nj, seed=2)).cuda().reshape(1, -1).contiguous()
+    n = no * mo
+    rs = 4 + n // 2 + 16
+    rec = torch.zeros((1, rs), dtype=torch.int32, device="cuda")
+    rc, zl = pk.ezsint_pack16_compress_batch_dev(rec, rs, d_in, 1, no, mo, 16)
+    assert rc == 0 and zl[0] > 0, (rc, list(zl))
+    zlng, want_zlng = int(zl[0]), int(G["zlng"])
+    assert abs(zlng - want_zlng) <= 1e-3 * want_zlng, (zlng, want_zlng)
+    got_hdr = rec[0, :4].cpu().numpy().view(np.uint32)
+    assert np.array_equal(got_hdr, G["header"]), ([hex(int(x)) for x in got_hdr], [hex(int(x)) for x in G["header"]])
+    # the record's tokens back (the HIP decoder; bit-exact against the oracle's in the decoder tests)
+    zwords = (zlng - 1) // 4 + 1
+    d_tok = torch.full((1 + n // 2 + 4,), -1, dtype=torch.int32, device="cuda")
+    assert pk.armn_uncompress_dev(d_tok, rec[0, 4:4 + zwords].contiguous(), zwords, no, mo, 16) == n * 2
+    w = d_tok[:n // 2].cpu().numpy().view(np.uint32)
+    tok = np.empty(n, np.uint16); tok[0::2] = (w >> 16).astype(np.uint16); tok[1::2] = (w & 0xFFFF).astype(np.uint16)
+    tok = tok.reshape(mo, no)
+    ndiff = 0; nsamp = 0; worst = 0
+    for got, want in ((tok[G["rows"]], G["tok_rows"]), (tok[:, G["cols"]], G["tok_cols"])):
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        ndiff += int((d != 0).sum()); nsamp += d.size; worst = max(worst, int(d.max()))
+    print(f"cfg5 end to end: zlng {zlng} (reference-side {want_zlng}, {abs(zlng - want_zlng) / want_zlng:.2e}), {ndiff} of {nsamp} sampled tokens differ (max {worst} step)")
+    assert ndiff <= 1e-3 * nsamp and worst <= 1, (ndiff, nsamp, worst)
 
 
 # ---------------------------------------------------------------------------------------------

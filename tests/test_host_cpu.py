@@ -8,6 +8,7 @@ import pytest
 import librmn_amd
 from librmn_amd import ezscint as ez
 import ezcases as ec
+from conftest import both_legs
 
 ROOT = os.path.join(os.path.dirname(__file__), "..")
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "ez_golden.npz"))
@@ -35,14 +36,16 @@ def declared_symbols():
     return sorted(set(syms))
 
 
-def test_library_exports_every_declared_symbol():
+@both_legs
+def test_library_exports_every_declared_symbol(leg):
     L = librmn_amd.load_library()
     missing = [s for s in declared_symbols() if not hasattr(L, s)]
     assert not missing, missing
     assert len(declared_symbols()) >= 30
 
 
-def test_gaussian_latitudes_match_reference_golden():
+@both_legs
+def test_gaussian_latitudes_match_reference_golden(leg):
     for nj in (8, 32, 200, 2200):
         gd = ez.ezqkdef(2 * nj, nj, "G", 0, 0, 0, 0)
         rc, ax, ay = ez.gdgaxes(gd, 2 * nj, nj)
@@ -58,8 +61,9 @@ def _define(spec):
     return ez.ezqkdef(ni, nj, grtyp, ig[0], ig[1], ig[2], ig[3])
 
 
+@both_legs
 @pytest.mark.parametrize("name", sorted(ec.scalar_cases()))
-def test_gdll_and_host_locate_match_reference_golden(name):
+def test_gdll_and_host_locate_match_reference_golden(name, leg):
     case = ec.scalar_cases()[name]
     gdin = _define(case["src"]); gdout = _define(ec.dst_spec(case))
     no, mo = case["dst"][:2]
@@ -78,7 +82,8 @@ def test_gdll_and_host_locate_match_reference_golden(name):
     assert np.array_equal(y.view(np.uint32), GOLD[f"{name}/y"].view(np.uint32))
 
 
-def test_grid_table_semantics():
+@both_legs
+def test_grid_table_semantics(leg):
     a = ez.ezqkdef(30, 15, "L", 100, 100, 0, 0)
     b = ez.ezqkdef(30, 15, "L", 100, 100, 0, 0)
     assert a == b and a >= 0                       # identical definitions dedupe (ez_identifygrid.c)
@@ -89,7 +94,8 @@ def test_grid_table_semantics():
     assert ez.ezdefset(a, 9999) == -1
 
 
-def test_options_round_trip():
+@both_legs
+def test_options_round_trip(leg):
     assert ez.ezsetopt("INTERP_DEGREE", "LINEAR") == 0 and ez.ezgetopt("interp_degree") == "linear"
     assert ez.ezsetopt("degre_interp", "cubique") == 0 and ez.ezgetopt("interp_degree") == "cubic"
     assert ez.ezgetopt("degre_interp") == "cubique"
@@ -111,7 +117,8 @@ def test_compute_fails_loudly_without_gpu():
     assert rc == -1                                 # no CPU fallback
 
 
-def test_subgrid_queries_and_fll():
+@both_legs
+def test_subgrid_queries_and_fll(leg):
     """c_ezget_nsubgrids / c_ezget_subgridids (ezget_nsubgrids.c, ezget_subgridids.c), c_ezgdef_fll == 'Y' on 'L' (ezgdef_fll.c)"""
     ax, ay = ec.yy_axes(ec.YY_NI, ec.YY_NJ)
     gy = ez.ezgdef_fmem(ec.YY_NI, ec.YY_NJ, "Z", "E", *ec.YIN_IG, ax, ay); ga = ez.ezgdef_fmem(ec.YY_NI, ec.YY_NJ, "Z", "E", *ec.YAN_IG, ax, ay)
@@ -126,7 +133,8 @@ def test_subgrid_queries_and_fll():
     assert g1 >= 0 and g1 == ez.ezgdef_fmem(37, 11, "Y", "L", 100, 100, 9000, 0, lon, lat)      # cxgaig('L', 0, 0, 1, 1)
 
 
-def test_gdxyzfll_vs_reference():
+@both_legs
+def test_gdxyzfll_vs_reference(leg):
     """c_gdxyzfll (host only): regular types == c_gdxyfll, 'Z' grids in reference-grid coordinates -- against the reference build"""
     import reflib as rl
     if not rl.have_ref():
@@ -147,7 +155,8 @@ def test_gdxyzfll_vs_reference():
         assert rc == 0 and np.array_equal(x.view(np.uint32), xr.view(np.uint32)) and np.array_equal(y.view(np.uint32), yr.view(np.uint32))
 
 
-def test_gdllfxy_vs_reference():
+@both_legs
+def test_gdllfxy_vs_reference(leg):
     """c_gdllfxy (host only), every supported grid type, against the reference build: bit-exact"""
     import reflib as rl
     if not rl.have_ref():
@@ -177,7 +186,8 @@ def test_gdllfxy_vs_reference():
         assert np.array_equal(lon.view(np.uint32), lonr.view(np.uint32)), (name, int((lon != lonr).sum()))
 
 
-def test_fortran_twins_by_reference_and_hidden_lengths():
+@both_legs
+def test_fortran_twins_by_reference_and_hidden_lengths(leg):
     """the Fortran-ABI twins (f77name(x) = x_): scalars by reference, blank-padded strings with hidden trailing lengths"""
     import ctypes
     L = ez._lib()
@@ -226,7 +236,8 @@ def test_vertical_interpolation_fails_loudly_without_gpu():
     assert r.returncode != 0 and "survived" not in r.stdout and "no CPU fallback" in r.stderr
 
 
-def test_hash_tiles_through_fmem_are_tracked_as_their_own_grids():
+@both_legs
+def test_hash_tiles_through_fmem_are_tracked_as_their_own_grids(leg):
     """a regional '#' tile is computed as a 'Z' grid but keeps its own handle and reports '#' (c_ezgprm); global tiles and tiles
     without axes are refused"""
     import ctypes, ezcases as ec
@@ -244,8 +255,9 @@ def test_hash_tiles_through_fmem_are_tracked_as_their_own_grids():
     assert ez.ezgdef_fmem(ni, nj, "#", "E", *ec.E_IG, gax, ay) == -1            # a global tile: other polar kernels than 'Z' in the reference
 
 
+@both_legs
 @pytest.mark.parametrize("ig", [(2, 0, 0, 0), (1, 0, 0, 0), (2, 1, 0, 0), (0, 1, 0, 0)])
-def test_hemispheric_and_inverted_gaussian_grids_locate_like_the_reference(ig):
+def test_hemispheric_and_inverted_gaussian_grids_locate_like_the_reference(ig, leg):
     """c_gdll, c_gdxyfll and c_gdxyfll_orig of hemispheric / y-inverted 'G' grids against the reference build: the table of 2 nj
     latitudes, the two search lengths (gr.nj for a set, gr.j2 for c_gdxyfll), the northern shift, the public routine's row inversion"""
     import reflib
@@ -276,7 +288,8 @@ def test_hemispheric_and_inverted_gaussian_grids_locate_like_the_reference(ig):
     assert np.array_equal(la_r, la_p) and np.array_equal(lo_r, lo_p), ig
 
 
-def test_options_set_and_read_back_like_the_reference():
+@both_legs
+def test_options_set_and_read_back_like_the_reference(leg):
     """c_ezsetopt / c_ezgetopt / c_ezsetval / c_ezgetval / c_ezsetival / c_ezgetival against the reference build: every option name (English, French,
     upper case, unknown) with every value (synonyms, unknown, empty): the same return codes and the same strings read back (ezsetopt.c:59-215)"""
     import ctypes

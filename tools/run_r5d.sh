@@ -1,0 +1,7 @@
+set -x
+mkdir -p gpurun_out/r5d
+python -m pytest tests/test_gpu_interp.py -x -q -m gpu -k "uvt or cfg3 or wind or uvint or pts2" 2>&1 | tail -15 > gpurun_out/r5d/tests.txt
+python tools/sweep_cfg3.py "" "EZHIP_NO_UVP=1" "EZHIP_UVP_BPC=2" > gpurun_out/r5d/sweep_new.txt 2>&1
+EZHIP_LIBRARY=$PWD/devlibs/librmn_ez_hip_dev.so python tools/sweep_cfg3.py "" "EZHIP_UVT_DEBUG=64" "EZHIP_UVT_DEBUG=65" "EZHIP_UVT_DEBUG=66" "EZHIP_UVT_DEBUG=68" "EZHIP_UVT_DEBUG=71" "EZHIP_UVT_DEBUG=79" "EZHIP_UVT_DEBUG=111" "EZHIP_UVT_DEBUG=64,EZHIP_UVP_BPC=2" "EZHIP_UVT_DEBUG=64,EZHIP_UVP_BPC=1" > gpurun_out/r5d/sweep_dbg.txt 2>&1
+bash tools/prof_cmd.sh r5d/prof tools/probe_cfg3.py > /dev/null 2>&1
+cat gpurun_out/r5d/tests.txt gpurun_out/r5d/sweep_*.txt; head -6 gpurun_out/r5d/prof/summary.txt
