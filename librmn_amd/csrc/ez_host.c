@@ -61,10 +61,8 @@ typedef struct ezh_set {
     float *d_scratch;       /* float[8]: fill value + keys, pole values */
     float *d_poles_batch; int poles_cap;   /* pole values of a c_ezsint_batch_dev batch (2 per field) */
     float *d_prow;          /* 2 * ni_src synthetic polar wind rows (vector mode), u then v: [u_n, u_s, v_n, v_s] */
-    unsigned pw_epoch;      /* launches that took the rows' job along as producer TEAMS (k_uvp): their arrival counters behind the rows count up by the team size per launch */
     float *d_avg[2];        /* interp_degree = average / sph_average: [x | row widening | y_low | y_high] of the target cells (ez_avg.inc:55-78, ez_avg_sph.inc:63-98) */
     void *d_uvt_tiles; int uvt_shape, uvt_cap, uvt_stats[4];
-    int *d_uvt_hb; int uvt_nhb;            /* the table's handed-back tiles (k_uvp leaves them to the launch behind it); uvt_nhb < 0: not listed (k_uvt then) */
     void *d_st_tiles[2], *d_st_streams[2]; int st_key[2], st_cap[2], st_stats[2][4];      /* k_st1 / k_st (slot 0: bilinear, 1: bicubic): the tile table (scalar zone rules) and the tile-ordered {x, y} copy; st_key: the zone options they were built under, -1: tried, not worth it */
     size_t cache_bytes;                    /* HBM this set's staged-tile caches hold (tile tables + tile-ordered stream copies): counted against g_cache_budget */
     void *d_uvt_streams; const void *uvt_streams_M;      /* the tile-ordered {x, y, a, b} copy and the matrix array it was packed from (another matrix: the plain arrays are read) */      /* k_uvt's tile table over the set's x, y (built with the special-point cache, under the same key) */
@@ -841,7 +839,7 @@ static void free_sepplan(ezh_sepplan *sp)
     sp->built = 0;
 }
 static pthread_mutex_t g_plan_mtx = PTHREAD_MUTEX_INITIALIZER;
-/* The staged-tile kernels (k_st, k_st1, k_uvt / k_uvp) keep, per grid set, a tile table and a tile-ordered copy of the set's streams: 8 bytes per target point and
+/* The staged-tile kernels (k_st, k_st1, k_uvt) keep, per grid set, a tile table and a tile-ordered copy of the set's streams: 8 bytes per target point and
  * degree for scalars, 16 for wind pairs (a 7200 x 3601 target: 207 MB + 415 MB), held until c_gdrls.  All sets together stay under a byte budget; a set whose
  * caches would not fit keeps the gathering kernels (same results, slower).  Default 4 GiB; EZHIP_CACHE_MB or ezhip_set_cache_budget_mb() change it (0: no caches). */
 static size_t g_cache_bytes = 0;
@@ -875,7 +873,7 @@ static void free_set(ezh_set *s)
 {
     for (int d = 0; d < 3; d++) for (int v = 0; v < 2; v++) free_sepplan(&s->sep[d][v]);
     free(s->x1d); free(s->y1d);
-    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_lamb_cs[0]); ezhip_free(s->d_lamb_cs[1]); ezhip_free(s->d_cspec_list); ezhip_free(s->d_cspec_xy); pthread_mutex_lock(&g_plan_mtx); cache_unreserve(s, s->cache_bytes); pthread_mutex_unlock(&g_plan_mtx); ezhip_free(s->d_uvt_tiles); ezhip_free(s->d_uvt_hb); ezhip_free(s->d_uvt_streams); ezhip_free(s->d_st_tiles[0]); ezhip_free(s->d_st_streams[0]); ezhip_free(s->d_st_tiles[1]); ezhip_free(s->d_st_streams[1]); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
+    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_lamb_cs[0]); ezhip_free(s->d_lamb_cs[1]); ezhip_free(s->d_cspec_list); ezhip_free(s->d_cspec_xy); pthread_mutex_lock(&g_plan_mtx); cache_unreserve(s, s->cache_bytes); pthread_mutex_unlock(&g_plan_mtx); ezhip_free(s->d_uvt_tiles); ezhip_free(s->d_uvt_streams); ezhip_free(s->d_st_tiles[0]); ezhip_free(s->d_st_streams[0]); ezhip_free(s->d_st_tiles[1]); ezhip_free(s->d_st_streams[1]); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
     for (int k = 0; k < 2; k++) { ezhip_free(s->d_yy_x[k]); ezhip_free(s->d_yy_y[k]); ezhip_free(s->d_yy_lat[k]); ezhip_free(s->d_yy_lon[k]); ezhip_free(s->d_yy_idx[k]); }
     for (int k = 0; k < 4; k++) ezhip_free(s->d_yy_tmp[k]);
     free(s);
@@ -2603,7 +2601,7 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
 }
 
 /* the polar wind rows of the pair being interpolated, handed from uvint_impl to the per-point pair launch (per host thread) */
-static __thread struct { float *out; const float *plon2, *ax; float xg4_n, xg4_s; int weighted, active; unsigned *sync; unsigned *epoch; } t_pwjob;
+static __thread struct { float *out; const float *plon2, *ax; float xg4_n, xg4_s; int weighted, active; } t_pwjob;
 /* both components of a wind pair on the per-point path in ONE pass (k_pts2); returns -2 when the set is not on that path */
 static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui, const float *d_vi,
                         const float *pun, const float *pus, const float *pvn, const float *pvs, const void *d_M, int m_half, int dst_rot)
@@ -2636,7 +2634,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
     pu.pole_row_n = pun; pu.pole_row_s = pus; pv.pole_row_n = pvn; pv.pole_row_s = pvs;
     if (zones == 2 && s->have_dehors) ierc = 2;
     pu.tile_ni = go->ni; pu.tile_nj = go->nj;                  /* the points are the whole target grid in row order: 2-D tile order */
-    if (t_pwjob.active) { pu.pw_out = t_pwjob.out; pu.pw_plon2 = t_pwjob.plon2; pu.pw_xg4_n = t_pwjob.xg4_n; pu.pw_xg4_s = t_pwjob.xg4_s; pu.pw_weighted = t_pwjob.weighted; pu.pw_ax = t_pwjob.ax; pu.pw_sync = t_pwjob.sync; pu.pw_epoch_io = t_pwjob.epoch; t_pwjob.active = 0; }
+    if (t_pwjob.active) { pu.pw_out = t_pwjob.out; pu.pw_plon2 = t_pwjob.plon2; pu.pw_xg4_n = t_pwjob.xg4_n; pu.pw_xg4_s = t_pwjob.xg4_s; pu.pw_weighted = t_pwjob.weighted; pu.pw_ax = t_pwjob.ax; t_pwjob.active = 0; }
     /* the special points of the set under these zone options: listed by the first launch, kept with the set, handed to the later ones */
     const int key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4 | degree << 12;
     const int use_cache = !getenv("EZHIP_NO_SPEC_CACHE");
@@ -2645,7 +2643,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
         if (s->cspec_key == key) {
             pu.cspec_valid = 1; pu.cspec_count = s->cspec_count; pu.cspec_list = s->d_cspec_list;
             pu.cspec_x = s->d_cspec_xy; pu.cspec_y = s->d_cspec_xy ? s->d_cspec_xy + s->cspec_count : NULL;
-            if (s->d_uvt_tiles && !getenv("EZHIP_NO_UVT")) { pu.uvt_tiles = s->d_uvt_tiles; pu.uvt_shape = s->uvt_shape; pu.uvt_cap = s->uvt_cap; pu.uvt_hb_list = s->d_uvt_hb; pu.uvt_hb_count = s->uvt_nhb;
+            if (s->d_uvt_tiles && !getenv("EZHIP_NO_UVT")) { pu.uvt_tiles = s->d_uvt_tiles; pu.uvt_shape = s->uvt_shape; pu.uvt_cap = s->uvt_cap;
                 if (s->d_uvt_streams && s->uvt_streams_M == d_M && (!d_M || m_half) && !getenv("EZHIP_UVT_NO_STREAMS")) pu.uvt_streams = s->d_uvt_streams; }      /* EZHIP_NO_UVT: the gathering kernel (same results) */
         }
         pthread_mutex_unlock(&g_plan_mtx);
@@ -2677,9 +2675,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
                     int st[4] = {0, 0, 0, 0}, kept_t = 0;
                     if (dt && ezhip_uvt_build(&pu, s->d_x, s->d_y, dt, th, st) == 0 && st[0] >= 4 * st[1]) {      /* (a set whose tiles mostly do not qualify keeps the gathering kernel) */
                         pthread_mutex_lock(&g_plan_mtx);
-                        s->uvt_shape = th; s->uvt_cap = cap; memcpy(s->uvt_stats, st, sizeof(st)); s->d_uvt_tiles = dt; kept_t = 1;
-                        { int *dl = NULL; s->uvt_nhb = ezhip_uvt_handed_back(dt, nt, &dl); s->d_uvt_hb = dl; }
-                        dt = NULL;
+                        s->uvt_shape = th; s->uvt_cap = cap; memcpy(s->uvt_stats, st, sizeof(st)); s->d_uvt_tiles = dt; dt = NULL; kept_t = 1;
                         const int fits_s = (!d_M || m_half) && cache_reserve(s, sb_bytes);
                         pthread_mutex_unlock(&g_plan_mtx);
                         if (fits_s) {      /* x, y and the pair's (a, b) once more in tile order (16 bytes per target point) */
@@ -3361,11 +3357,7 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
     if (polar && !s->extrap && !same) {
         /* synthetic polar wind rows (ez_calcnpolarwind.c): one small kernel, no host round trip.  The row longitudes
          * and the polar-stereographic xg4 depend on the grid only: computed once on the host. */
-        if (!s->d_prow) {      /* (+ 16 words behind the rows: the arrival counters of the producer teams of the pipelined pair kernel, zero once) */
-            s->d_prow = (float *)ezhip_malloc(sizeof(float) * (4 * (size_t)ni + 16));
-            if (s->d_prow && ezhip_memset(s->d_prow + 4 * (size_t)ni, 0, 64)) { ezhip_free(s->d_prow); s->d_prow = NULL; }
-            s->pw_epoch = 0;
-        }
+        if (!s->d_prow) s->d_prow = (float *)ezhip_malloc(sizeof(float) * 4 * (size_t)ni);
         if (!s->d_prow) return -1;
         if (!gi->d_plon2) {
             float *pl = (float *)malloc(sizeof(float) * 3 * (size_t)ni);
@@ -3405,7 +3397,6 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
             if (per_point) {       /* the per-point pair kernel takes the job along (two producer blocks of its own launch, or its own side-stream launch) */
                 t_pwjob.out = s->d_prow; t_pwjob.plon2 = gi->d_plon2; t_pwjob.xg4_n = gi->xg4_pole[0]; t_pwjob.xg4_s = gi->xg4_pole[1];
                 t_pwjob.weighted = weighted; t_pwjob.ax = gi->d_ax; t_pwjob.active = 1;
-                t_pwjob.sync = (unsigned *)(s->d_prow + 4 * (size_t)ni); t_pwjob.epoch = &s->pw_epoch;
             } else {
                 if (ezhip_side_begin()) return -1;
                 int prc = ezhip_polar_wind(s->d_prow, d_uuin, d_vvin, gi->d_plon2, ni, nj, gi->xg4_pole[0], gi->xg4_pole[1], weighted, gi->d_ax);

@@ -439,9 +439,7 @@ __device__ float block_poleval(const float *zrow, int ni, int weighted, const fl
 }
 
 /* two rows at once (the pole values of the two components of a wind): the same sequential REAL sums, row a by lane 0 of wave 0 and row b by lane 0 of wave 1 at the
- * same time (each row has its half of the staging buffer: lds holds 2 * chunk + 4 floats) -- the two dependent-add chains of ~ni terms were most of the
- * polar-wind producer blocks' 45 - 65 us, and those blocks bound the pair kernel once it runs faster than that */
-template <bool COHERENT = false>      /* COHERENT: the rows were written by other thread blocks of this launch with agent-scope atomic stores: read them the same way */
+ * same time (each row has its half of the staging buffer: lds holds 2 * chunk + 4 floats): the two dependent-add chains of ~ni terms run side by side */
 __device__ void block_poleval2(const float *rowa, const float *rowb, int ni, int weighted, const float *ax, float *lds, const int chunk, float &ra, float &rb, const int nthr /* threads taking part (the first nthr of the block) */)
 {
     const int n = weighted ? ni - 1 : ni;
@@ -455,9 +453,7 @@ __device__ void block_poleval2(const float *rowa, const float *rowb, int ni, int
             for (int u = 0; u < 4; u++) {
                 const int i = base + min(k0 + u * nthr, m - 1);
                 const float w = weighted ? ax[i + 1] - ax[i] : 1.0f;
-                const float va = COHERENT ? __hip_atomic_load(&rowa[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rowa[i];
-                const float vb = COHERENT ? __hip_atomic_load(&rowb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rowb[i];
-                x[u] = weighted ? va * w : va; y[u] = weighted ? vb * w : vb;
+                x[u] = weighted ? rowa[i] * w : rowa[i]; y[u] = weighted ? rowb[i] * w : rowb[i];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) { const int k = k0 + u * nthr; if (k < m) { lds[k] = x[u]; lds[chunk + k] = y[u]; } }
@@ -2159,62 +2155,7 @@ __device__ __forceinline__ void polar_wind_body(const int north, float *out, con
     __threadfence_block();
     __syncthreads();
     float s0, w0;
-    block_poleval2(pu, pv, ni, weighted, ax, lds, CHUNK / 2, s0, w0, 256);      /* (the body's loops are written for 256 threads; k_uvp calls it from the first 256 of 512) */
-    d_llwfgdw1(s0, w0, 0.0f, hs, xg4);
-    __syncthreads();
-    for (int i = threadIdx.x; i < ni; i += 256) {
-        float spd = s0, wd = (i == 0 || north) ? w0 + plon[i] : w0 - plon[i];
-        d_gdwfllw1(spd, wd, plon[i], 'A', 0.f);
-        pu[i] = spd; pv[i] = wd;
-    }
-}
-/* The same by a TEAM of PW_TEAM thread blocks per pole (k_uvp): the two producer blocks above run 37 us alone and 60 - 70 us next to the worker blocks of their
- * CU (ten columns of REAL trigonometry per thread, then the sums) -- longer than the pipelined pair kernel itself.  The first loop (per column: speed / direction,
- * polar-stereographic components) is spread over the team, every block an equal share of the columns; the blocks of a team sit on ONE XCD (blockIdx = pole + 8 k:
- * one L2), announce their share with a release fence + one atomic add on the team's counter, and leave; the leader (k = 0) waits for the counter, sums the two rows (sequential REAL sums, as the reference) and writes the rows.  A leader that does not see its team in
- * time redoes the first loop itself: never wrong, only slower. */
-#define PW_TEAM 8
-template <int CHUNK>
-__device__ __forceinline__ void polar_wind_team(const int north, const int rank, float *out, const float *uu, const float *vv, const float *plon2,
-                                                int ni, int nj, float xg4_n, float xg4_s, int weighted, const float *ax, unsigned *counter, unsigned *counter_next, float *lds)
-{
-    __builtin_amdgcn_s_setprio(3);                       /* these few waves are on the launch's critical path */
-    const char hs = north ? 'N' : 'S';
-    const float xg4 = north ? xg4_n : xg4_s;
-    const float *urow = uu + (north ? (size_t)(nj - 1) * ni : 0), *vrow = vv + (north ? (size_t)(nj - 1) * ni : 0);
-    const float *plon = plon2 + (north ? 0 : ni);
-    float *pu = out + (north ? 0 : ni), *pv = out + 2 * (size_t)ni + (north ? 0 : ni);
-    const int share = (ni + PW_TEAM - 1) / PW_TEAM;
-    /* (the shares travel between the team's blocks as agent-scope relaxed atomic stores / loads of single words: an agent-scope FENCE writes back the XCD's whole
-     * L2, which the worker blocks keep full of dirty output lines -- with fences the team took 100 us) */
-    auto first_loop = [&](int lo, int hi) {
-        for (int i = lo + (int)threadIdx.x; i < hi; i += 256) {
-            float a = urow[i], b = vrow[i];
-            d_llwfgdw1(a, b, plon[i], 'A', 0.f);
-            d_gdwfllw1(a, b, plon[i], hs, xg4);
-            __hip_atomic_store(&pu[i], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&pv[i], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    /* a PAIR of counters per pole: the launch of epoch e counts in slot e & 1 and zeroes the other one for the next launch (a launch is complete before the
-     * next one of the stream starts: no host-side bookkeeping beyond the parity, nothing to get out of step when a launch is skipped or gives up) */
-    if (rank == 0 && threadIdx.x == 0) __hip_atomic_store(counter_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    first_loop(rank * share, min(ni, (rank + 1) * share));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* my stores have been acknowledged ... */
-    __syncthreads();                                       /* ... and so have the block's */
-    if (rank != 0) { if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-    __shared__ int s_team_ok;
-    if (threadIdx.x == 0) {
-        int ok = 0;
-        for (int spins = 0; spins < (1 << 17); spins++) {
-            if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(PW_TEAM - 1)) { ok = 1; break; }      /* the team's other blocks */
-            __builtin_amdgcn_s_sleep(4);
-        }
-        s_team_ok = ok;
-    }
-    __syncthreads();
-    if (!s_team_ok) { first_loop(share, ni); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
-    float s0, w0;
-    block_poleval2<true>(pu, pv, ni, weighted, ax, lds, CHUNK / 2, s0, w0, 256);
+    block_poleval2(pu, pv, ni, weighted, ax, lds, CHUNK / 2, s0, w0, 256);
     d_llwfgdw1(s0, w0, 0.0f, hs, xg4);
     __syncthreads();
     for (int i = threadIdx.x; i < ni; i += 256) {
@@ -3186,192 +3127,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW ? UVT_WA
     }
 }
 
-/* ---- k_uvp (round 5): k_uvt as a PIPELINE -- persistent thread blocks, two LDS images, the next tile's window on its way while a tile is evaluated ---------
- * k_uvt's blocks run their phases one after another (tile entry -> window -> barrier -> arithmetic -> stores: three dependent memory round trips per 1024 points)
- * and only the CU's other blocks cover them: 70 us per cfg3 pair with 150 VALU instructions per point, 76 - 80 with 200 (the arithmetic was never the bound).  Here
- *   - a block walks a list of tiles: XCD k (blockIdx % 8) takes the k-th contiguous eighth of the tile table, its blocks stride through it;
- *   - the window of tile n + 1 is brought into the OTHER LDS image by LDS-DMA (global_load_lds_dword: no VGPRs, nothing to wait for) as (u, v) CELLS -- the lanes
- *     of a DMA instruction take their dword from the u plane (even lanes) or the v plane (odd lanes), so the image is interleaved although the sources are two
- *     arrays (round 4's pipeline staged planes: 32 ds_read2_b32 per point instead of 8 ds_read2_b64, and lost) -- with the tile's column / row records
- *     (global_load_lds_dwordx4, 16 bytes per lane) behind them; issued right after the barrier that frees that image, i.e. a whole tile's arithmetic ahead;
- *   - the points' own streams {x, y, a, b} of tile n + 1 are loaded into registers at the same moment, the table entry of tile n + 2 by scalar loads;
- *   - per tile ONE barrier: "my DMAs have landed" (s_waitcnt vmcnt: in order, so the tile's 8 stores per thread stay in flight: vmcnt(8) on tiles whose
- *     waves all store 8 times) + s_barrier.
- * Arithmetic: uvt_eval_w below = p_irgdint_3_w_pair_inner's, operation for operation.  Tiles the table hands back take the gathering path inside the loop. */
-#define UVP_SERVICE (8 * PW_TEAM)                       /* the first blocks do not walk tiles: blocks 0 + 8 k and 1 + 8 k (XCD 0 and 1) are the two polar-wind producer teams */
-__device__ __forceinline__ void lds_dma_dword_p(const void *lane_addr, unsigned lds_byte_addr)
-{
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
-                 :: "v"(lane_addr), "s"(__builtin_amdgcn_readfirstlane((int)lds_byte_addr)) : "memory");
-}
-__device__ __forceinline__ void lds_dma_dwordx4_p(const void *lane_addr, unsigned lds_byte_addr)
-{
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(lane_addr), "s"(__builtin_amdgcn_readfirstlane((int)lds_byte_addr)) : "memory");
-}
-/* window and records of tile entry tb into the LDS image at byte address img: cells [W * H] x 8 bytes, then (W - 3) + (H - 3) records of 32 bytes */
-template <int NTHREADS>
-__device__ __forceinline__ void uvp_stage(const ezhip_pts_plan &p, const float *__restrict__ zin1, const float *__restrict__ zin2, int4 tb, unsigned img, unsigned t)
-{
-    const int i0 = tb.x, j0 = tb.y, W = tb.z, H = tb.w & UVT_H_MASK, ncell = W * H;
-    const unsigned magic = 0xFFFFFFFFu / (unsigned)W + 1u, wv = t >> 6, lane = t & 63u;
-    const float *s1 = zin1 + (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1), *s2 = zin2 + (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1);
-    const float *sl = (lane & 1u) ? s2 : s1;                        /* odd lanes: the v plane */
-    const unsigned nd = 2u * (unsigned)ncell;
-    for (unsigned d0 = wv * 64u; d0 < nd; d0 += (unsigned)NTHREADS) {             /* a DMA instruction = 32 cells */
-        const unsigned cell = (d0 + lane) >> 1;
-        if (d0 + lane < nd) {
-            const unsigned r = __umulhi(cell, magic), c = cell - r * (unsigned)W;
-            lds_dma_dword_p(sl + ((size_t)r * (size_t)p.ni + c), img + d0 * 4u);
-        }
-    }
-    const unsigned rec0 = img + 8u * (unsigned)((ncell + 1) & ~1), nx = 2u * (unsigned)(W - 3), nr = nx + 2u * (unsigned)(H - 3);      /* 16-byte units */
-    if (wv * 64u < nr) {
-        if (t < nr) {
-            const float *g = t < nx ? p.xrec8 + (size_t)i0 * 8 + (size_t)t * 4 : p.yrec8 + (size_t)(j0 + 1 - p.j1) * 8 + (size_t)(t - nx) * 4;
-            lds_dma_dwordx4_p(g, rec0 + wv * 1024u);
-        }
-    }
-}
-/* one main-zone point of a staged tile: p_irgdint_3_w_pair_inner's arithmetic on the LDS image */
-__device__ __forceinline__ pk2 uvt_eval_w(const ezhip_pts_plan &p, const float *img, int4 tb, float px, float py)
-{
-    typedef float c2 __attribute__((ext_vector_type(2)));
-    const int i0 = tb.x, j0 = tb.y, W = tb.z, H = tb.w & UVT_H_MASK, ncell = W * H;
-    const c2 *cells = (const c2 *)img;
-    const f4a16 *xr = (const f4a16 *)(img + 2 * ((ncell + 1) & ~1)), *yr = xr + 2 * (W - 3);
-    const int i = min(p.ni - 2 + p.wrap, max(1, max(2 - p.wrap, (int)px))), j = min(p.j2 - 2, max(p.j1 + 1, (int)py));
-    const c2 *cp = cells + (j - 1 - j0) * W + (i - 1 - i0);
-    c2 q[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { q[r][0] = cp[r * W]; q[r][1] = cp[r * W + 1]; q[r][2] = cp[r * W + 2]; q[r][3] = cp[r * W + 3]; }
-    const f4a16 *xq = xr + (i - 1 - i0) * 2, *yq = yr + (j - 1 - j0) * 2;
-    const PairW w = pair_weights_lagrange(px, py, i, j, xq[0], xq[1], yq[0], yq[1]);
-    return pair_cols(w, pair_row(w, q[0][0], q[0][1], q[0][2], q[0][3]), pair_row(w, q[1][0], q[1][1], q[1][2], q[1][3]),
-                     pair_row(w, q[2][0], q[2][1], q[2][2], q[2][3]), pair_row(w, q[3][0], q[3][1], q[3][2], q[3][3]));
-}
-/* the points of tile b (entry tb, streams sq[]: {x, y, a, b} per point) from the LDS image img; drain_all := the tile's waves did NOT all issue exactly 2 PPT stores.
- * A block of 1024 / PPT threads: thread t takes column t % 32 and the rows t / 32 + (32 / PPT) k of the tile */
-typedef float uvp_f4 __attribute__((ext_vector_type(4)));
-template <int PPT>
-__device__ __forceinline__ void uvp_tile(const ezhip_pts_plan &p, float *__restrict__ zout1, float *__restrict__ zout2, const float *__restrict__ zin1, const float *__restrict__ zin2,
-                                         const float *__restrict__ xs, const float *__restrict__ ys, int4 tb, unsigned b, unsigned tpr, unsigned t,
-                                         const float *img, const uvp_f4 (&sq)[PPT], int dbg, bool &drain_all)
-{
-    constexpr int TW = 32, TH = 32, RSTEP = 32 / PPT;
-    const unsigned by = b / tpr, bx = b - by * tpr, nstep = (unsigned)RSTEP * (unsigned)p.tile_ni;
-    const unsigned cx = bx * TW + (t & 31u), cy0 = by * TH + (t >> 5);
-    const bool okx = cx < (unsigned)p.tile_ni;
-    const bool inside = bx * TW + TW <= (unsigned)p.tile_ni && by * TH + TH <= (unsigned)p.tile_nj;
-    drain_all = true;
-    if (tb.z > 0) {                                      /* (W = 0: a handed-back tile, a block of k_uvp_rest behind this kernel gathers it) */
-        const bool all_normal = (tb.w & UVT_ALL_NORMAL) != 0;
-        const unsigned n0 = okx && cy0 < (unsigned)p.tile_nj ? cy0 * (unsigned)p.tile_ni + cx : 0u;
-        drain_all = !(all_normal && inside) || (p.wind_M && !p.wind_M_half) || (dbg & 32);      /* (the short wait needs exactly 2 PPT vector memory instructions per wave behind the DMAs) */
-#pragma unroll
-        for (int k = 0; k < PPT; k++) {
-            if (!(okx && cy0 + (unsigned)(RSTEP * k) < (unsigned)p.tile_nj)) continue;
-            const size_t n = (size_t)n0 + (size_t)k * nstep;
-            const float px = sq[k].x, py = sq[k].y;
-            const int zone = all_normal ? (int)PZ_NORMAL : pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
-            float a, bb;
-            if (zone == PZ_FILL) a = bb = *p.fill;
-            else if (zone == PZ_NORMAL) {
-                if (dbg & 4) { a = px; bb = py; }
-                else { const pk2 s = uvt_eval_w(p, img, tb, px, py); a = s.x; bb = s.y; }
-            } else continue;
-            if (p.wind_M) {
-                wm_f2 whi = wm_f2{0.0f, 1.0f};
-                if (!p.wind_M_half) whi = __builtin_nontemporal_load((const wm_f2 *)((const char *)p.wind_M + (n << 4)) + 1);
-                const float u = a, v = bb;
-                wind_m_apply(wm_f2{sq[k].z, sq[k].w}, whi, p.wind_M_half, u, v, p.wind_dst_rot, a, bb);
-            }
-            if (!(dbg & 32) || a == 12345.678f) { zout1[n] = a; zout2[n] = bb; }
-        }
-    }
-}
-/* PPT points per thread, 1024 / PPT threads per block: 2 (512 threads: eight waves share a tile's two LDS images -- the images, 49 KB per block, allow three blocks
- * per CU whatever the block size, and twelve waves per CU hide too little of the LDS / VALU latency of the evaluation: 75 us per cfg3 pair against k_uvt's 60) */
-#ifndef UVP_PPT
-#define UVP_PPT 2
-#endif
-#ifndef UVP_WAVES2
-#define UVP_WAVES2 5
-#endif
-#ifndef UVP_WAVES4
-#define UVP_WAVES4 4
-#endif
-template <int PPT>
-__global__ __launch_bounds__(1024 / PPT) __attribute__((amdgpu_waves_per_eu(PPT == 2 ? UVP_WAVES2 : UVP_WAVES4, 8))) void k_uvp(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
-                                             const float *__restrict__ zin1, const float *__restrict__ zin2,
-                                             const float *__restrict__ xs, const float *__restrict__ ys, const int4 *__restrict__ tiles, unsigned ntiles, unsigned img_bytes)
-{
-    constexpr int TW = 32, NT = 1024 / PPT;
-    typedef float f4a __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) float uvt_lds[];
-    const int dbg = EZH_DBG(p.uvt_debug);
-    if (blockIdx.x < UVP_SERVICE) {
-        if (p.pw_out && (blockIdx.x & 7u) < 2u && !(dbg & 64) && threadIdx.x < 256) {
-            const int north = (blockIdx.x & 7u) == 0u;
-            if (p.pw_sync) polar_wind_team<2048>(north, (int)(blockIdx.x >> 3), p.pw_out, zin1, zin2, p.pw_plon2, p.ni, p.nj, p.pw_xg4_n, p.pw_xg4_s, p.pw_weighted, p.pw_ax,
-                                                 p.pw_sync + (north ? 0 : 4) + (p.pw_epoch & 1u), p.pw_sync + (north ? 0 : 4) + ((p.pw_epoch + 1u) & 1u), uvt_lds);
-            else if (blockIdx.x < 2) polar_wind_body<2048>(north, p.pw_out, zin1, zin2, p.pw_plon2, p.ni, p.nj, p.pw_xg4_n, p.pw_xg4_s, p.pw_weighted, p.pw_ax, uvt_lds);
-        }
-        return;
-    }
-    const unsigned xcd = blockIdx.x & 7u, rk = (blockIdx.x >> 3) - (unsigned)PW_TEAM, R = (gridDim.x >> 3) - (unsigned)PW_TEAM, t = threadIdx.x;
-    const unsigned lo = (unsigned)(((unsigned long long)ntiles * xcd) >> 3), hi = (unsigned)(((unsigned long long)ntiles * (xcd + 1u)) >> 3);
-    unsigned b = lo + rk;
-    if (b >= hi) return;
-    const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW;
-    const unsigned img0 = lds_addr_of(uvt_lds);
-    /* the tile-ordered copy is laid out for k_uvt's 256 threads x 4 points, [tile][k4][t256]: row r (0 .. 31) of a tile is k4 = r / 8, t256 = 32 (r % 8) + column */
-    const unsigned r0 = t >> 5;
-    const f4a *S = (const f4a *)p.uvt_streams + ((r0 >> 3) * 256u + (r0 & 7u) * 32u + (t & 31u));
-    constexpr unsigned KSTEP = (32 / PPT) / 8 * 256;                  /* f4a elements between a thread's consecutive points */
-    /* prologue: the streams of the first TWO tiles, the first tile's window, the entries of the first three tiles.  Streams run two tiles ahead of the evaluation
-     * (registers: 2 x PPT x 4 dwords), the window one tile ahead (the second LDS image): per CU ~70 KB have to be in flight to keep HBM busy at this kernel's
-     * rate, one tile ahead left 23 KB per block */
-    const unsigned last = lo + rk + ((hi - 1u - (lo + rk)) / R) * R;      /* this block's last tile */
-    int4 tb = tiles[b];
-    f4a s0[PPT], s1[PPT], s2[PPT];
-#pragma unroll
-    for (int k = 0; k < PPT; k++) s0[k] = __builtin_nontemporal_load(S + (size_t)b * 1024 + k * KSTEP);
-#pragma unroll
-    for (int k = 0; k < PPT; k++) s1[k] = __builtin_nontemporal_load(S + (size_t)min(b + R, last) * 1024 + k * KSTEP);
-    if (tb.z > 0 && !(dbg & 2)) uvp_stage<NT>(p, zin1, zin2, tb, img0, t);
-    int4 tbn = b + R < hi ? tiles[b + R] : make_int4(0, 0, -1, 0);
-    int4 tbnn = b + 2u * R < hi ? tiles[b + 2u * R] : make_int4(0, 0, -1, 0);
-    /* (the compiler's waits for the prologue's loads belong HERE: left to the first use they would sit inside the loop, where they wait for every step's loads) */
-#pragma unroll
-    for (int k = 0; k < PPT; k++) asm volatile("" : "+v"(s0[k]), "+v"(s1[k]));
-    unsigned cur = 0;
-    bool drain_all = true;
-    /* one tile: SQ = this tile's streams (in registers since two steps ago), LQ = the set the tile after next is loaded into (this step's SQ of the step before);
-     * a macro expanded three times with the register sets rotated: copies between the sets would make a step wait for the loads it has just issued.
-     * Vector memory instructions of a step, in issue order: the DMAs of the next tile's window, PPT stream loads, 2 PPT stores: the next step's wait lets the last
-     * 3 PPT of them stay in flight (the loads are issued even when no tile is left to load: the count must not depend on it) */
-#define UVP_STEP(SQ, LQ) { \
-        if (drain_all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else if (PPT == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
-        __syncthreads(); \
-        /* (SQ HAS arrived -- it is older than the DMAs the wait above covered -- but the compiler cannot see the DMAs: its own waits for SQ, placed where SQ is \
-         * first used, would count this step's loads in.  Make it place them here) */ \
-        _Pragma("unroll") for (int k = 0; k < PPT; k++) asm volatile("" : "+v"(SQ[k])); \
-        const unsigned bn = b + R; \
-        if (bn < hi && tbn.z > 0 && !(dbg & 2)) uvp_stage<NT>(p, zin1, zin2, tbn, img0 + (cur ^ 1u) * img_bytes, t); \
-        _Pragma("unroll") for (int k = 0; k < PPT; k++) LQ[k] = __builtin_nontemporal_load(S + (size_t)min(bn + R, last) * 1024 + k * KSTEP); \
-        const int4 tbn3 = bn + 2u * R < hi ? tiles[bn + 2u * R] : make_int4(0, 0, -1, 0); \
-        uvp_tile<PPT>(p, zout1, zout2, zin1, zin2, xs, ys, tb, b, tpr, t, uvt_lds + (size_t)cur * (img_bytes >> 2), SQ, dbg, drain_all); \
-        if (bn >= hi) break; \
-        b = bn; tb = tbn; tbn = tbnn; tbnn = tbn3; cur ^= 1u; }
-    for (;;) {
-        UVP_STEP(s0, s2)
-        UVP_STEP(s1, s0)
-        UVP_STEP(s2, s1)
-    }
-#undef UVP_STEP
-}
-
 /* ---- k_st: the SCALAR twin of k_uvt -- c_ezsint from an irregular (rotated) source, bicubic, with its stencil windows staged in LDS ------------------------
  * Same tile table (built under the scalar zone rules: the pole points are zones of their own there), the source window as float cells, the same REAL*8 axis /
  * coefficient records; every point then evaluates ez_irgdint_3_w.inc:20-235 in its LITERAL form (the statement functions fa2, fa3, fa4, fa as the reference writes
@@ -3833,19 +3588,6 @@ __global__ __launch_bounds__(256) void k_pts_special2c(ezhip_pts_plan p, float *
 {
     special2c_body(p, zout1, zout2, zin1, zin2, prow_n2, prow_s2, blockIdx.x, gridDim.x);
 }
-/* behind k_uvp: the set's special points (blocks [0, nspec_blocks)) and the tiles its table hands back to the gathering path (four blocks per listed tile) in ONE launch -- inside the pipelined kernel the gathering code cost it a third of its registers and its tiles stalled a whole block */
-__global__ __launch_bounds__(256) void k_uvp_rest(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
-                                                  const float *__restrict__ zin1, const float *__restrict__ zin2,
-                                                  const float *__restrict__ prow_n2, const float *__restrict__ prow_s2,
-                                                  const float *__restrict__ xs, const float *__restrict__ ys, unsigned nspec_blocks)
-{
-    if (blockIdx.x < nspec_blocks) { special2c_body(p, zout1, zout2, zin1, zin2, prow_n2, prow_s2, blockIdx.x, nspec_blocks); return; }
-    /* four blocks per tile, a point per thread (a gathered point is a chain of dependent round trips: four of them one after the other made these blocks the
-     * launch's long pole) */
-    const unsigned q = blockIdx.x - nspec_blocks, b = (unsigned)p.uvt_hb_list[q >> 2], tpr = ((unsigned)p.tile_ni + 31u) / 32u, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
-    const unsigned cx = bx * 32u + (t & 31u), cy = by * 32u + (q & 3u) * 8u + (t >> 5);
-    if (cx < (unsigned)p.tile_ni && cy < (unsigned)p.tile_nj) pts2_point<PK_IRGD3_W, false>(p, zout1, zout2, zin1, zin2, xs, ys, (int)(cy * (unsigned)p.tile_ni + cx), nullptr, nullptr);
-}
 __global__ __launch_bounds__(256) void k_spec_gather(int *__restrict__ list_out, float *__restrict__ x_out, float *__restrict__ y_out,
                                                      const int *__restrict__ list_in, const float *__restrict__ xs, const float *__restrict__ ys, unsigned cnt)
 {
@@ -3992,61 +3734,12 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
         if (lds < 4 * 2052 + 16) lds = 4 * 2052 + 16;                          /* (the polar-wind producer blocks' row buffer) */
         pu2.xcd_order = getenv("EZHIP_UVT_XCD") ? atoi(getenv("EZHIP_UVT_XCD")) : 0;
 #define UVT_LAUNCH(TW, TH) hipLaunchKernelGGL((k_uvt<TW, TH>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl)
-        bool uvp = false;
-        if (!stage3nw && pu2.uvt_shape == 3232 && pu2.uvt_streams && (pu2.uvt_hb_count == 0 || pu2.uvt_hb_list) && !getenv("EZHIP_NO_UVP")) {
-            /* the pipelined form (k_uvp): as many persistent blocks as the device holds at once, in whole rounds of the 8 XCDs */
-            static int per_cu = -1, ncu = 0;
-            const unsigned img = 8u * (unsigned)pu2.uvt_cap + 32u * UVT_REC_MAX;
-            size_t lds2 = 2 * (size_t)img;
-            if (lds2 < 4 * 2052 + 16) lds2 = 4 * 2052 + 16;
-            if (per_cu < 0) {
-                int dev = 0, nb = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_uvp<UVP_PPT>, 1024 / UVP_PPT, lds2) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
-                per_cu = nb;
-            }
-            const int ppt = EZH_DEVINT("EZHIP_UVP_PPT") == 4 ? 4 : EZH_DEVINT("EZHIP_UVP_PPT") == 2 ? 2 : UVP_PPT;
-            if (ppt != UVP_PPT) {      /* development: the other block shape */
-                int nb = 0;
-                if ((ppt == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_uvp<4>, 256, lds2) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_uvp<2>, 512, lds2)) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
-                per_cu = -1;
-                if (nb > 0 && ncu >= 8 && lds2 <= 65536) {
-                    int bpc2 = EZH_DEVINT("EZHIP_UVP_BPC") > 0 ? EZH_DEVINT("EZHIP_UVP_BPC") : nb;
-                    unsigned R = (unsigned)bpc2 * (unsigned)(ncu / 8);
-                    if (R > (nt + 7u) / 8u) R = (nt + 7u) / 8u;
-                    if (pu2.pw_out && pu2.pw_sync && pu2.pw_epoch_io) pu2.pw_epoch = ++*pu2.pw_epoch_io; else pu2.pw_sync = nullptr;
-                    if (ppt == 4) hipLaunchKernelGGL(k_uvp<4>, dim3(8u * (R + (unsigned)PW_TEAM)), dim3(256), lds2, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl, nt, img);
-                    else hipLaunchKernelGGL(k_uvp<2>, dim3(8u * (R + (unsigned)PW_TEAM)), dim3(512), lds2, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl, nt, img);
-                    uvp = true;
-                    goto uvt_launched;
-                }
-            }
-            int bpc = EZH_DEVINT("EZHIP_UVP_BPC") > 0 ? EZH_DEVINT("EZHIP_UVP_BPC") : per_cu;
-            if (bpc > 0 && ncu >= 8 && lds2 <= 65536) {
-                unsigned R = (unsigned)bpc * (unsigned)(ncu / 8);
-                if (R > (nt + 7u) / 8u) R = (nt + 7u) / 8u;
-                if (pu2.pw_out && pu2.pw_sync && pu2.pw_epoch_io) pu2.pw_epoch = ++*pu2.pw_epoch_io; else pu2.pw_sync = nullptr;
-                hipLaunchKernelGGL(k_uvp<UVP_PPT>, dim3(8u * (R + (unsigned)PW_TEAM)), dim3(1024 / UVP_PPT), lds2, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl, nt, img);
-                uvp = true;
-                goto uvt_launched;
-            }
-        }
         if (stage3nw) hipLaunchKernelGGL((k_uvt<32, 32, true>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl);      /* (tables of regional sets are built with 32 x 32 tiles) */
         else
         switch (pu2.uvt_shape) { case 3216: UVT_LAUNCH(32, 16); break; case 6408: UVT_LAUNCH(64, 8); break; case 6416: UVT_LAUNCH(64, 16); break; default: UVT_LAUNCH(32, 32); break; }
 #undef UVT_LAUNCH
-uvt_launched:
         if (LAUNCH_CHECK("k_uvt")) return -1;
         if (ezhip_side_join()) return -1;
-        if (uvp) {
-            const unsigned nsp = (plan_u->cspec_count > 0 && !(pu2.uvt_debug & 8)) ? (unsigned)((2 * plan_u->cspec_count + 255) / 256) : 0u, nbk = nsp < 256u ? nsp : 256u;
-            const unsigned nhb = (pu2.uvt_debug & 1) ? 0u : (unsigned)pu2.uvt_hb_count;
-            if (nbk + nhb == 0) return 0;
-            ezhip_pts_plan pr = *plan_u;
-            pr.uvt_hb_list = pu2.uvt_hb_list; pr.uvt_hb_count = pu2.uvt_hb_count; pr.tile_ni = pu2.tile_ni; pr.tile_nj = pu2.tile_nj; pr.newton_literal = 0;
-            hipLaunchKernelGGL(k_uvp_rest, dim3(nbk + 4u * nhb), block, 0, g_stream, pr, d_out_u, d_out_v, d_in_u, d_in_v, plan_v->pole_row_n, plan_v->pole_row_s, d_x, d_y, nbk);
-            return LAUNCH_CHECK("k_uvp_rest");
-        }
         if (plan_u->cspec_count > 0 && !(pu2.uvt_debug & 8)) {
             const unsigned nbk = (unsigned)((2 * plan_u->cspec_count + 255) / 256);      /* a lane pair per point */
             hipLaunchKernelGGL(k_pts_special2c, dim3(nbk < 256 ? nbk : 256), block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v, plan_v->pole_row_n, plan_v->pole_row_s);
@@ -4113,26 +3806,6 @@ extern "C" int ezhip_uvt_build(const ezhip_pts_plan *plan, const float *d_x, con
         free(h);
     }
     return 0;
-}
-
-extern "C" int ezhip_uvt_handed_back(const void *d_tiles, int ntiles, int **d_list_out)
-{
-    *d_list_out = nullptr;
-    if (ntiles <= 0 || !d_tiles) return -1;
-    int4 *h = (int4 *)malloc(sizeof(int4) * (size_t)ntiles);
-    int *list = (int *)malloc(sizeof(int) * (size_t)ntiles);
-    int n = 0, rc = -1;
-    if (h && list && !set_err(hipStreamSynchronize(g_stream), "handed-back tiles") && !set_err(hipMemcpy(h, d_tiles, sizeof(int4) * (size_t)ntiles, hipMemcpyDeviceToHost), "handed-back tiles")) {
-        for (int k = 0; k < ntiles; k++) if (h[k].z == 0) list[n++] = k;
-        rc = n;
-        if (n > 0) {
-            int *d = nullptr;
-            if (hipMalloc((void **)&d, sizeof(int) * (size_t)n) != hipSuccess || set_err(hipMemcpy(d, list, sizeof(int) * (size_t)n, hipMemcpyHostToDevice), "handed-back tiles")) { if (d) (void)hipFree(d); (void)hipGetLastError(); rc = -1; }
-            else *d_list_out = d;
-        }
-    }
-    free(h); free(list);
-    return rc;
 }
 
 /* the tile-ordered stream copy of a wind-pair plan (k_uvt_pack): d_streams holds 16 bytes x 256 x PPT x ntiles.  plan->wind_M: NULL or the (a, b) form */

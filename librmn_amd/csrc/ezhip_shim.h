@@ -229,8 +229,6 @@ typedef struct {
     const void *uvt_tiles;            /* k_uvt: the grid set's tile table (int4 {i0, j0, W, H} per 32 x uvt_th tile of the target: ezhip_uvt_build), NULL: k_pts2 */
     int uvt_shape;                    /* 100 TW + TH of the table's tiles: 3232 (default), 3216, 6416, 6408 */
     int uvt_cap;                      /* staged cells a tile may need (the table was built under it) */
-    const int *uvt_hb_list; int uvt_hb_count;      /* k_uvp: the tiles the table hands back to the gathering path (W = 0), listed once per set (ezhip_uvt_handed_back): they run as
-                                                      blocks of the special points' launch behind the pipelined kernel, which skips them */
     const void *uvt_streams;          /* NULL, or the set's x, y and (a, b) once more in tile order: float4 per point (ezhip_uvt_pack_streams) */
     int uvt_debug;                    /* development knock-outs (develop build only) */
     int wind_dst_rot;                 /* with wind_M: the TARGET frame is a rotated one (decides what a REAL overflow of the chain's speed turns into) */
@@ -252,9 +250,6 @@ typedef struct {
     /* the synthetic polar wind rows of the pair (k_polar_wind's job) riding in the k_pts2 launch as two producer blocks: only the special points, handled by
      * the NEXT kernel, read them.  pw_out != NULL: out4 = [u north | u south | v north | v south] rows of ni floats */
     float *pw_out; const float *pw_plon2; float pw_xg4_n, pw_xg4_s; int pw_weighted; const float *pw_ax;
-    /* k_uvp: the rows come from two TEAMS of producer blocks; pw_sync: 16 device words (zero when allocated): per pole a PAIR of arrival counters, the launch of
-     * epoch e counts in slot e & 1 and zeroes the other; *pw_epoch_io (host): launches so far, incremented by the launcher; pw_epoch: its value for this launch */
-    unsigned *pw_sync; unsigned *pw_epoch_io; unsigned pw_epoch;
     /* scalar per-point path: pv_out != NULL: the two pole values of the field are summed by two producer blocks at the head of the k_pts launch (they were a
      * launch of their own in front of it: 16 us of a 99 us c_ezsint from a rotated 2560 x 1280 source); the points that read them -- the pole points and the
      * polar strips -- are the NEXT kernel's.  pv_nj: rows of the field the sums run over */
@@ -277,8 +272,6 @@ int ezhip_mask_fill_min(float *d_fld, const int *d_mask, size_t n, unsigned *d_k
  * ezhip_uvt_ntiles(plan, shape) int4 entries (shape = 100 TW + TH).  stats (host, may be NULL): [0] tiles staged, [1] handed to the gathering path, [2] empty, [3] largest window (cells).  Synchronises. */
 int ezhip_uvt_ntiles(const ezhip_pts_plan *plan, int shape);
 int ezhip_uvt_build(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_tiles, int shape, int *stats);
-/* the indices of the table's handed-back tiles (W = 0) as a device array (caller frees with ezhip_free; NULL when there are none); returns their number, -1 on error.  Synchronises. */
-int ezhip_uvt_handed_back(const void *d_tiles, int ntiles, int **d_list_out);
 size_t ezhip_uvt_stream_bytes(const ezhip_pts_plan *plan, int shape);
 int ezhip_uvt_pack_streams(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_streams, int shape);
 int ezhip_interp_pts_batch(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin, const float *d_x, const float *d_y, int npts, int nfields, size_t in_stride, size_t out_stride);      /* k_st over a batch: -2 when the plan is not on that path */
