@@ -87,8 +87,8 @@ void ez_xpncof(int32_t *i1, int32_t *i2, int32_t *j1, int32_t *j2, int32_t *exte
 /* All pointers are DEVICE pointers on the current HIP device; work is enqueued on the stream set by
  * ezhip_use_stream (default: the null stream) and NOT synchronised. */
 /* FIRST CALL of a grid set on a per-point route (rotated / irregular sources: c_ezsint_dev, c_ezuvint_dev, c_ezsint_batch_dev): besides the kernels it allocates
- * and builds the set's caches -- located x, y (8 bytes per target point), the wind matrix (8), and for the staged-tile kernels a tile table plus a tile-ordered
- * copy of those streams (8 bytes per target point and degree for scalars, 16 for wind pairs) -- and SYNCHRONISES the stream two or three times while doing so
+ * and builds the set's caches -- located x, y (8 bytes per target point), the wind matrix (20), and for the staged-tile kernels a tile table plus a tile-ordered
+ * copy of those streams (8 bytes per target point and degree for scalars, 12 for wind pairs) -- and SYNCHRONISES the stream two or three times while doing so
  * (hipMalloc, hipStreamSynchronize, one blocking copy).  Do not issue a set's first call inside a stream capture; call ezhip_prepare_set() (or any first call)
  * beforehand.  Later calls of the set only enqueue.  The caches live until c_gdrls of either grid.  Their total is bounded by a byte budget (default 4 GiB,
  * EZHIP_CACHE_MB at first use, or the call below); a set that does not fit keeps the gathering kernels: same results, slower. */

@@ -69,7 +69,7 @@ typedef struct ezh_set {
     int *d_cspec_list; float *d_cspec_xy; int cspec_count, cspec_key;      /* the special points (polar strips, re-interpolated extrapolation) of the wind-pair launch, kept after its first call: index, x, y; key = the zone options they were listed under (0: none yet) */
     float *d_lamb_cs[2];    /* c_ezuvint from / towards a Lambert '!' grid: {cos, sin} of its rotation angle at the target points' longitudes (source leg, target leg) */
     void *d_windM;          /* c_ezuvint through a rotated frame: the wind chain of this grid pair as a 2 x 2 matrix per target point (built on first use) */
-    int windM_half;         /* every point's matrix is a pure rotation to rounding (ezhip_wind_matrix's max_dev <= 4e-6): the (a, b) form behind the float4 form is used */
+    int windM_half;         /* every point's matrix is a pure rotation to rounding (ezhip_wind_matrix's max_dev <= 4e-6): the packed rotation (one word per point) behind the float4 form is used */
     float windM_dev;
     /* Yin-Yang 'U' source (c_ezyy_calcxy, ezyy_calcxy.c): per subgrid the list of target points it serves */
     int yy_ready, yy_count[2];
@@ -840,7 +840,7 @@ static void free_sepplan(ezh_sepplan *sp)
 }
 static pthread_mutex_t g_plan_mtx = PTHREAD_MUTEX_INITIALIZER;
 /* The staged-tile kernels (k_st, k_st1, k_uvt) keep, per grid set, a tile table and a tile-ordered copy of the set's streams: 8 bytes per target point and
- * degree for scalars, 16 for wind pairs (a 7200 x 3601 target: 207 MB + 415 MB), held until c_gdrls.  All sets together stay under a byte budget; a set whose
+ * degree for scalars, 12 for wind pairs (a 7200 x 3601 target: 207 MB + 311 MB), held until c_gdrls.  All sets together stay under a byte budget; a set whose
  * caches would not fit keeps the gathering kernels (same results, slower).  Default 4 GiB; EZHIP_CACHE_MB or ezhip_set_cache_budget_mb() change it (0: no caches). */
 static size_t g_cache_bytes = 0;
 static long long g_cache_budget = -1;
@@ -2678,7 +2678,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
                         s->uvt_shape = th; s->uvt_cap = cap; memcpy(s->uvt_stats, st, sizeof(st)); s->d_uvt_tiles = dt; dt = NULL; kept_t = 1;
                         const int fits_s = (!d_M || m_half) && cache_reserve(s, sb_bytes);
                         pthread_mutex_unlock(&g_plan_mtx);
-                        if (fits_s) {      /* x, y and the pair's (a, b) once more in tile order (16 bytes per target point) */
+                        if (fits_s) {      /* x, y and the pair's packed rotation once more in tile order (12 bytes per target point) */
                             void *ds = ezhip_malloc(sb_bytes);
                             int kept_s = 0;
                             if (ds && ezhip_uvt_pack_streams(&pu, s->d_x, s->d_y, ds, th) == 0) {
@@ -3462,17 +3462,17 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
     const void *d_M = NULL;
     int m_half = 0;
     if (!wd_only && (wp.src_rotated || wp.dst_rotated) && !getenv("EZHIP_WIND_NO_MATRIX") &&
-        24 * (size_t)go->ni * go->nj <= ((size_t)3 << 30)) {           /* 16 + 8 bytes per target point, kept with the set: up to 3 GiB, beyond that the chain runs per call */
+        20 * (size_t)go->ni * go->nj <= ((size_t)3 << 30)) {           /* 16 + 4 bytes per target point, kept with the set: up to 3 GiB, beyond that the chain runs per call */
         pthread_mutex_lock(&g_plan_mtx);
         int mrc = 0;
         if (!s->d_windM) {
-            s->d_windM = ezhip_malloc(24 * (size_t)go->ni * go->nj + 16);
+            s->d_windM = ezhip_malloc(20 * (size_t)go->ni * go->nj + 16);
             if (!s->d_windM || ezhip_wind_matrix(&wp, s->d_windM, go->d_lat, go->d_lon, go->ni, go->nj, &s->windM_dev)) { ezhip_free(s->d_windM); s->d_windM = NULL; mrc = -1; }
             /* the chain is a rotation by construction (speed kept, direction turned); its REAL roundings leave a - d and b + c at a few 1e-7.  Where that holds
-             * at every point the (a, b) form is read: half the matrix bytes per call.  Anything else (a non-finite coefficient, a frame that is no rotation)
+             * at every point the rotation is read as ONE packed word per point (rot_pack in the kernels): a quarter of the matrix bytes per call.  Anything else (a non-finite coefficient, a frame that is no rotation)
              * keeps the four coefficients */
             s->windM_half = !mrc && s->windM_dev <= 4.0e-6f;
-            if (getenv("EZHIP_WIND_MATRIX_REPORT")) fprintf(stderr, "<ezhip> wind matrix of set (%d, %d): max distance from a rotation %.3g -> %s\n", s->gdin, s->gdout, (double)s->windM_dev, s->windM_half ? "(a, b) form" : "four coefficients");
+            if (getenv("EZHIP_WIND_MATRIX_REPORT")) fprintf(stderr, "<ezhip> wind matrix of set (%d, %d): max distance from a rotation %.3g -> %s\n", s->gdin, s->gdout, (double)s->windM_dev, s->windM_half ? "packed rotation" : "four coefficients");
         }
         m_half = s->windM_half && !getenv("EZHIP_WIND_FULL_MATRIX");
         d_M = m_half ? (const void *)((const char *)s->d_windM + 16 * (size_t)go->ni * go->nj) : s->d_windM;

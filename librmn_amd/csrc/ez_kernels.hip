@@ -2210,16 +2210,38 @@ __device__ __forceinline__ void d_wind_matrix_apply(float mx, float my, float mz
         else { a = (a == 0.0f || a != a) ? nan : copysignf(inf, a); b = (b == 0.0f || b != b) ? nan : copysignf(inf, b); }
     }
 }
-/* the matrix of point o.  half: the set's chain is a pure rotation to rounding at every point (checked when the matrix is built) and the matrix is kept as
- * (a, b) with c = -b, d = a: 8 instead of 16 bytes per target point and call (cfg3: 64 of its 436 MB per pair).  The same two unconditional 8-byte loads
- * in both forms (a conditional one costs a wait at the join, one more address costs registers the pair kernel does not have): the half form's second load
- * brings the NEXT point's pair -- same or next line, ignored; the buffer ends with 16 spare bytes */
+/* the matrix of point o.  half: the set's chain is a pure rotation to rounding at every point (checked when the matrix is built) and the matrix is kept as ONE word
+ * per point (round 5; a pair (a, b) before: 8 bytes per point and call, 64 of the 192 MB cfg3's pair kernel streams): the SMALLER of a, b as a REAL whose two lowest
+ * mantissa bits say which one it is (bit 0: 1 = a) and the sign of the other (bit 1); the other is +- sqrt(1 - s^2).  |s| <= 0.708, so both come back to ~1.5e-7
+ * absolute (the packing rounds s to 22 mantissa bits; the square root of 1 - s^2 is no worse than s) -- the chain's own roundings leave a^2 + b^2 - 1 at a few
+ * 1e-7 too.  EVERY consumer of the half form decodes this word (first call, staged tiles, special points, k_wind_apply): one set of values per grid set.
+ * The same two unconditional loads in both forms (a conditional one costs a wait at the join): the half form's second load brings the next point's word, ignored;
+ * the buffer ends with 16 spare bytes */
 typedef float wm_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned rot_pack(float a, float b)
+{
+    const bool a_small = fabsf(a) < fabsf(b);
+    const float sm = a_small ? a : b, other = a_small ? b : a;
+    return ((__float_as_uint(sm) + 2u) & ~3u) | (a_small ? 1u : 0u) | (other < 0.0f ? 2u : 0u);
+}
+__device__ __forceinline__ wm_f2 rot_unpack(unsigned q)
+{
+    const float sm = __uint_as_float(q & ~3u);
+    float other = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - sm * sm));      /* (v_sqrt_f32 itself, 1 ulp: one instruction, the same in every kernel; the IEEE sequence costs ten) */
+    other = (q & 2u) ? -other : other;
+    return (q & 1u) ? wm_f2{sm, other} : wm_f2{other, sm};
+}
 __device__ __forceinline__ void wind_m_load(const void *M, int half, size_t o, wm_f2 &lo, wm_f2 &hi)
 {
-    const wm_f2 *mp = (const wm_f2 *)((const char *)M + (o << (half ? 3 : 4)));
-    lo = __builtin_nontemporal_load(mp);
-    hi = __builtin_nontemporal_load(mp + 1);
+    if (half) {
+        const unsigned *mq = (const unsigned *)M + o;
+        const unsigned q = __builtin_nontemporal_load(mq), q2 = __builtin_nontemporal_load(mq + 1);
+        lo = rot_unpack(q); hi = wm_f2{__uint_as_float(q2), 0.0f};
+    } else {
+        const wm_f2 *mp = (const wm_f2 *)((const char *)M + (o << 4));
+        lo = __builtin_nontemporal_load(mp);
+        hi = __builtin_nontemporal_load(mp + 1);
+    }
 }
 __device__ __forceinline__ void wind_m_apply(wm_f2 lo, wm_f2 hi, int half, float u, float v, int dst_rot, float &a, float &b)
 {
@@ -2503,18 +2525,12 @@ __device__ __forceinline__ NewtonW newton_w(double c1, double c2, double c3, dou
 {
     return newton_w52(c1, c2, c3, c4, c5, c6, c5 + c2, t1, t2, t3);
 }
-/* (round 5) The 2 x 20 multiply-adds of a wind pair in REAL: the eight weights come out of the REAL*8 Newton form above and are rounded to REAL once; the
- * sixteen cells of a component are then combined row by row, rows by the y weights, with fused REAL multiply-adds -- as PAIRS (u, v) where the cells lie
- * that way (k_uvt's LDS image: v_pk_fma_f32, 20 packed instructions per point pair instead of 32 conversions + 40 REAL*8-rate operations; the pair kernels are
- * bound by exactly those, SQ_ACTIVE_INST_VALU 88 % in round 4).  Against the all-REAL*8 evaluation the result moves by <= 2.8e-7 |V| (measured on cfg3's
- * golden rows, 3e-8 typical), the bar for winds is 1e-5 |V|.  Every kernel of the pair path uses THIS function in THIS order, so a set's first call (gathering)
- * and its later calls (staged windows) return the same bits; a packed and a scalar fused multiply-add round identically. */
+/* (round 5) The 2 x 20 multiply-adds of a wind pair in REAL: the sixteen cells of a component are combined row by row, rows by the y weights, with fused REAL
+ * multiply-adds -- as PAIRS (u, v) where the cells lie that way (k_uvt's LDS image: v_pk_fma_f32, 20 packed instructions per point pair instead of 32 conversions
+ * + 40 REAL*8-rate operations).  Every kernel of the pair path evaluates a point with pair_eval below, so a set's first call (gathering) and its later calls
+ * (staged windows) return the same bits; a packed and a scalar fused multiply-add round identically. */
 typedef float pk2 __attribute__((ext_vector_type(2)));
 struct PairW { float x0, x1, x2, x3, y0, y1, y2, y3; };
-__device__ __forceinline__ PairW pair_weights(const NewtonW &wx, const NewtonW &wy)
-{
-    return PairW{(float)wx.w0, (float)wx.w1, (float)wx.w2, (float)wx.g, (float)wy.w0, (float)wy.w1, (float)wy.w2, (float)wy.g};
-}
 __device__ __forceinline__ pk2 pk_bc(float w) { return pk2{w, w}; }
 __device__ __forceinline__ pk2 pair_row(const PairW &w, pk2 z1, pk2 z2, pk2 z3, pk2 z4)
 {
@@ -2524,7 +2540,7 @@ __device__ __forceinline__ pk2 pair_cols(const PairW &w, pk2 r0, pk2 r1, pk2 r2,
 {
     return __builtin_elementwise_fma(r3, pk_bc(w.y3), __builtin_elementwise_fma(r2, pk_bc(w.y2), __builtin_elementwise_fma(r1, pk_bc(w.y1), r0 * pk_bc(w.y0))));
 }
-/* ... and away from the longitude seam the eight weights themselves in REAL, in Lagrange's form from the set-up's 32-byte records {x1 .. x4, d1 .. d4}
+/* The eight weights in REAL too (away from the longitude seam), in Lagrange's form from the set-up's 32-byte records {x1 .. x4, d1 .. d4}
  * (ezhip_pts_plan.xrec8 / yrec8: d_k = 1 / prod_{m != k} (x_k - x_m) from REAL*8): w_k = d_k prod_{m != k} (x - x_m) -- the interpolating cubic of the four
  * values, the polynomial the reference's Newton form evaluates; 14 REAL operations per direction instead of 21 REAL*8 ones + 4 conversions, records of 32
  * instead of 80 bytes in LDS.  With the REAL sums above: <= 3.9e-7 |V| from the all-REAL*8 evaluation on cfg3's golden rows (bar: 1e-5 |V|). */
@@ -2544,6 +2560,52 @@ __device__ __forceinline__ PairW pair_weights_lagrange(float px, float py, int i
     lagrange_w(y, ys, yd, w.y0, w.y1, w.y2, w.y3);
     return w;
 }
+/* The REAL sums are as good as the stencil is LARGE: their error is ~4e-7 of M = the largest |cell| under the stencil (both components), whatever comes out.
+ * Where the wind is nearly calm next to stronger winds (a coarse source, a calm point between two jets) that is more than 1e-5 of |V| -- the reference build found
+ * such a point (tools/fuzz_vs_ref2.py 600 7: 3.8e-5 |V| at |V| = 0.037 under cells of +- 15).  And the reference's own polynomial is not the exact interpolating
+ * cubic there: its Newton coefficients are REAL-rounded reciprocals, which moves it by ~1e-7 M (exact Lagrange weights in REAL*8 were still 4e-5 |V| off at that
+ * point).  So: a point whose larger component is below M / 8 (M taken over the two central rows of the stencil) is evaluated once more the reference's way -- its Newton form with its REAL coefficient tables, REAL*8
+ * throughout (the pair path's arithmetic of rounds 3 - 4) --, everywhere else the REAL result stands (<= 8 x ~7e-7 = 6e-6 |V|).  The test reads the REAL result: deterministic, the same in every kernel of the pair path.  Calm points are isolated: a few waves in
+ * a thousand take the second path. */
+/* everything by address (its REAL*8 temporaries must not be alive next to the common path's registers: k_uvt runs it as a second pass over the flagged points of a
+ * thread, after the last store).  cu / cv: the first cell of the stencil (row j - 1, column i - 1) of either component, cstep floats between columns, cstride
+ * between rows; xrec / yrec: the point's 32-byte records (the axis entries); cx8 / cy8: the reference's REAL Newton coefficients of column i / row j ([index][8]).
+ * The arithmetic is the pair path's of rounds 3 - 4: ez_irgdint_3_w.inc's Newton form with ITS coefficient tables, regrouped as weights, REAL*8 throughout. */
+template <class P>
+__device__ __forceinline__ pk2 pair_eval_real8(P cu, P cv, int cstep, int cstride, P xrec, P yrec, const float *cx8, const float *cy8, float px, float py, int i, int j)
+{
+    const float x1 = xrec[0], x2 = xrec[1], x3 = xrec[2], y1 = yrec[0], y2 = yrec[1], y3 = yrec[2];
+    const double x = (double)(x2 + (x3 - x2) * (px - (float)i)), y = (double)(y2 + (y3 - y2) * (py - (float)j));
+    const NewtonW wx = newton_w((double)cx8[0], (double)cx8[1], (double)cx8[2], (double)cx8[3], (double)cx8[4], (double)cx8[5], x - (double)x1, x - (double)x2, x - (double)x3);
+    const NewtonW wy = newton_w((double)cy8[0], (double)cy8[1], (double)cy8[2], (double)cy8[3], (double)cy8[4], (double)cy8[5], y - (double)y1, y - (double)y2, y - (double)y3);
+    const double wr[4] = {wy.w0, wy.w1, wy.w2, wy.g};
+    double su = 0.0, sv = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const P ru_ = cu + r * cstride, rv_ = cv + r * cstride;
+        su = fma(wr[r], fma(wx.g, (double)ru_[3 * cstep], fma(wx.w2, (double)ru_[2 * cstep], fma(wx.w1, (double)ru_[cstep], wx.w0 * (double)ru_[0]))), su);
+        sv = fma(wr[r], fma(wx.g, (double)rv_[3 * cstep], fma(wx.w2, (double)rv_[2 * cstep], fma(wx.w1, (double)rv_[cstep], wx.w0 * (double)rv_[0]))), sv);
+    }
+    return pk2{(float)su, (float)sv};
+}
+/* REAL result and "is it trustworthy" (see above): the caller sends the point to pair_eval_real8 when not */
+__device__ __forceinline__ pk2 pair_eval(float px, float py, int i, int j, f4a16 xs, f4a16 xd, f4a16 ys, f4a16 yd, const pk2 (&q)[4][4], bool &again)
+{
+    const PairW w = pair_weights_lagrange(px, py, i, j, xs, xd, ys, yd);
+    pk2 rw[4];
+    float m = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {      /* (a row's cells die with the row: M row by row, not from sixteen live cells at the end) */
+        rw[r] = pair_row(w, q[r][0], q[r][1], q[r][2], q[r][3]);
+        if (r == 1 || r == 2) {        /* M over the two CENTRAL rows (the outer rows' weights are below 0.075: they would have to be an order of magnitude larger to matter) */
+            m = fmaxf(fmaxf(m, fabsf(q[r][0].x)), fabsf(q[r][0].y)); m = fmaxf(fmaxf(m, fabsf(q[r][1].x)), fabsf(q[r][1].y));
+            m = fmaxf(fmaxf(m, fabsf(q[r][2].x)), fabsf(q[r][2].y)); m = fmaxf(fmaxf(m, fabsf(q[r][3].x)), fabsf(q[r][3].y));
+        }
+    }
+    const pk2 s = pair_cols(w, rw[0], rw[1], rw[2], rw[3]);
+    again = !(fmaxf(fabsf(s.x), fabsf(s.y)) * 8.0f >= m);      /* (also when something is not finite) */
+    return s;
+}
 template <class A, bool AOS>
 __device__ __forceinline__ void p_irgdint_3_w_pair(const A &Z1, const A &Z2, float px, float py, const float *ax, const float *ay,
                                                    const float *cx, const float *cy, int ni, int j1, int j2, int wrap, float &r1, float &r2)
@@ -2561,24 +2623,26 @@ __device__ __forceinline__ void p_irgdint_3_w_pair(const A &Z1, const A &Z2, flo
                                 coef<AOS>(cx, 4, i - 1, ni), coef<AOS>(cx, 5, i - 1, ni), x - (double)x1, x - (double)x2, x - (double)x3);
     const NewtonW wy = newton_w(coef<AOS>(cy, 0, j - j1, nnj), coef<AOS>(cy, 1, j - j1, nnj), coef<AOS>(cy, 2, j - j1, nnj), coef<AOS>(cy, 3, j - j1, nnj),
                                 coef<AOS>(cy, 4, j - j1, nnj), coef<AOS>(cy, 5, j - j1, nnj), y - (double)y1, y - (double)y2, y - (double)y3);
-    const PairW w = pair_weights(wx, wy);
-    pk2 rw[4];
+    /* (the two or three columns at the longitude seam: REAL*8 throughout, as before round 5 -- the weights as the four values' coefficients, the rows through two
+     * accumulators) */
+    const double wr[4] = {wy.w0, wy.w1, wy.w2, wy.g};
+    double su = 0.0, sv = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        double a1, a2, a3, a4, b1, b2, b3, b4;              /* (row_taps hands REAL values back as REAL*8: exact both ways) */
-        row_taps(Z1, im1, i, ip1, ip2, j - 1 + r, a1, a2, a3, a4);
-        row_taps(Z2, im1, i, ip1, ip2, j - 1 + r, b1, b2, b3, b4);
-        rw[r] = pair_row(w, pk2{(float)a1, (float)b1}, pk2{(float)a2, (float)b2}, pk2{(float)a3, (float)b3}, pk2{(float)a4, (float)b4});
+        double z1, z2, z3, z4;
+        row_taps(Z1, im1, i, ip1, ip2, j - 1 + r, z1, z2, z3, z4);
+        su = fma(wr[r], fma(wx.g, z4, fma(wx.w2, z3, fma(wx.w1, z2, wx.w0 * z1))), su);
+        row_taps(Z2, im1, i, ip1, ip2, j - 1 + r, z1, z2, z3, z4);
+        sv = fma(wr[r], fma(wx.g, z4, fma(wx.w2, z3, fma(wx.w1, z2, wx.w0 * z1))), sv);
     }
-    const pk2 s = pair_cols(w, rw[0], rw[1], rw[2], rw[3]);
-    r1 = s.x; r2 = s.y;
+    r1 = (float)su; r2 = (float)sv;
 }
 /* The same away from the longitude seam (i - 1 .. i + 2 consecutive: all but two or three source columns), with EVERY load of the point issued before the
  * first is used: the axis entries, the two coefficient records and the eight stencil rows of the pair depend on (i, j) only.  Written in program order
  * (x, y from the axes -> coefficients -> rows) the compiler kept four dependent memory round trips per point behind the divergent seam branches;
  * k_pts2 is bound by that chain (a wave lived 5 us for 375 instructions), not by its gathers' bandwidth or its arithmetic. */
 __device__ __forceinline__ void p_irgdint_3_w_pair_inner(const float *z1f, const float *z2f, float px, float py, const float *xrec8, const float *yrec8,
-                                                         int ni, int j1, int i, int j, float &r1, float &r2)
+                                                         const float *cx8, const float *cy8, int ni, int j1, int i, int j, float &r1, float &r2)
 {
     const f4a16 xs = *(const f4a16 *)(xrec8 + (size_t)(i - 1) * 8), xd = *(const f4a16 *)(xrec8 + (size_t)(i - 1) * 8 + 4);
     const f4a16 ys = *(const f4a16 *)(yrec8 + (size_t)(j - j1) * 8), yd = *(const f4a16 *)(yrec8 + (size_t)(j - j1) * 8 + 4);
@@ -2586,11 +2650,12 @@ __device__ __forceinline__ void p_irgdint_3_w_pair_inner(const float *z1f, const
     f4u u[4], v[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) { u[r] = *(const f4u *)(z1f + o0 + (size_t)r * ni); v[r] = *(const f4u *)(z2f + o0 + (size_t)r * ni); }
-    const PairW w = pair_weights_lagrange(px, py, i, j, xs, xd, ys, yd);
-    pk2 rw[4];
+    pk2 q[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) rw[r] = pair_row(w, pk2{u[r].x, v[r].x}, pk2{u[r].y, v[r].y}, pk2{u[r].z, v[r].z}, pk2{u[r].w, v[r].w});
-    const pk2 s = pair_cols(w, rw[0], rw[1], rw[2], rw[3]);
+    for (int r = 0; r < 4; r++) { q[r][0] = pk2{u[r].x, v[r].x}; q[r][1] = pk2{u[r].y, v[r].y}; q[r][2] = pk2{u[r].z, v[r].z}; q[r][3] = pk2{u[r].w, v[r].w}; }
+    bool again;
+    pk2 s = pair_eval(px, py, i, j, xs, xd, ys, yd, q, again);
+    if (again) s = pair_eval_real8<const float *>(z1f + o0, z2f + o0, 1, ni, xrec8 + (size_t)(i - 1) * 8, yrec8 + (size_t)(j - j1) * 8, cx8 + (size_t)(i - 1) * 8, cy8 + (size_t)(j - j1) * 8, px, py, i, j);
     r1 = s.x; r2 = s.y;
 }
 /* ez_irgdint_3_wnnc.inc:20-246 (ay: 4-entry strip latitudes indexed from j1) */
@@ -2845,7 +2910,7 @@ __device__ __forceinline__ void pts2_point(const ezhip_pts_plan &p, float *__res
             wind_m_load(p.wind_M ? p.wind_M : (const void *)p.ncx8, p.wind_M_half, p.wind_M ? o : (size_t)0, wlo, whi);
             /* (per LANE: the two forms round differently -- the seam's weights come from the Newton tables -- and which waves a point shares differs between
              * the kernels of the pair path; a point's form must not depend on its neighbours) */
-            if (!seam) p_irgdint_3_w_pair_inner(zin1, zin2, px, py, p.xrec8, p.yrec8, p.ni, p.j1, i, j, a, b);
+            if (!seam) p_irgdint_3_w_pair_inner(zin1, zin2, px, py, p.xrec8, p.yrec8, p.ncx8, p.ncy8, p.ni, p.j1, i, j, a, b);
             else p_irgdint_3_w_pair<PlainAcc, true>(Z1, Z2, px, py, p.ax, p.ay, p.ncx8, p.ncy8, p.ni, p.j1, p.j2, p.wrap, a, b);
         }
         else { a = leaf_point<KIND>(p, Z1, px, py); b = leaf_point<KIND>(p, Z2, px, py); }
@@ -2957,11 +3022,12 @@ __global__ __launch_bounds__(256) void k_uvt_bbox(ezhip_pts_plan p, const float 
     }
 }
 /* The streams of a tile -- x, y and the wind matrix's (a, b) of its points -- are the grid SET's own data, so their layout is ours: kept a second time in tile
- * order, one float4 {x, y, a, b} per point, [tile][k][thread].  A block then reads 16 contiguous KB (4 loads of 16 bytes per thread) where the row-major
+ * order, one 12-byte record {x, y, packed rotation} per point (16 bytes with (a, b) as two REALs until round 5), [tile][k][thread].  A block then reads 12 contiguous KB (4 loads of 12 bytes per thread) where the row-major
  * arrays give it 128-byte pieces 16 KB apart in three arrays (12 loads per thread): those pieces, not the bytes, bounded the streaming side of k_uvt
- * (2.5 - 3.5 TB/s with everything else knocked out: profiles/r04_experiments.txt).  16 bytes per target point of extra HBM per grid set. */
+ * (2.5 - 3.5 TB/s with everything else knocked out: profiles/r04_experiments.txt).  12 bytes per target point of extra HBM per grid set. */
+struct __attribute__((aligned(4))) uvt_rec { float x, y; unsigned q; };      /* 12 bytes per point: x, y, the packed rotation (rot_pack; the identity without a matrix) */
 template <int TW, int TH>
-__global__ __launch_bounds__(256) void k_uvt_pack(ezhip_pts_plan p, const float *__restrict__ xs, const float *__restrict__ ys, float4 *__restrict__ streams)
+__global__ __launch_bounds__(256) void k_uvt_pack(ezhip_pts_plan p, const float *__restrict__ xs, const float *__restrict__ ys, uvt_rec *__restrict__ streams)
 {
     typedef uvt_geom<TW, TH> G;
     const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW, b = blockIdx.x, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
@@ -2969,11 +3035,11 @@ __global__ __launch_bounds__(256) void k_uvt_pack(ezhip_pts_plan p, const float 
 #pragma unroll
     for (int k = 0; k < G::PPT; k++) {
         const unsigned cy = by * TH + t / TW + (unsigned)(G::RSTEP * k);
-        float4 o = make_float4(0.f, 0.f, 1.f, 0.f);
+        uvt_rec o{0.f, 0.f, rot_pack(1.0f, 0.0f)};
         if (cx < (unsigned)p.tile_ni && cy < (unsigned)p.tile_nj) {
             const size_t n = (size_t)cy * p.tile_ni + cx;
             o.x = xs[n]; o.y = ys[n];
-            if (p.wind_M) { const wm_f2 m = *(const wm_f2 *)((const char *)p.wind_M + (n << 3)); o.z = m.x; o.w = m.y; }
+            if (p.wind_M) o.q = ((const unsigned *)p.wind_M)[n];
         }
         streams[((size_t)b * G::PPT + k) * 256 + t] = o;
     }
@@ -3012,11 +3078,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW ? UVT_WA
      * while the entry arrives and the window is staged.  (Point index 0 for the lanes beyond the target's edge: a readable address.) */
     float px[PPT], py[PPT]; wm_f2 wlo[PPT];
     const unsigned n0 = okx && cy0 < (unsigned)p.tile_nj ? cy0 * (unsigned)p.tile_ni + cx : 0u, nstep = (unsigned)G::RSTEP * (unsigned)p.tile_ni;
-    if (p.uvt_streams) {              /* the set's tile-ordered copy: {x, y, a, b} of a point in one 16-byte load, a block's share contiguous */
-        typedef float f4a __attribute__((ext_vector_type(4)));
-        const f4a *S = (const f4a *)p.uvt_streams + (size_t)b * (PPT * 256) + t;
+    if (p.uvt_streams) {              /* the set's tile-ordered copy: {x, y, rotation} of a point in one 12-byte load, a block's share contiguous */
+        const uvt_rec *S = (const uvt_rec *)p.uvt_streams + (size_t)b * (PPT * 256) + t;
+        /* (the rotation word rides in wlo[k].x and is unpacked where it is applied, behind the barrier: unpacked here the loads would be waited for before the window is asked for) */
 #pragma unroll
-        for (int k = 0; k < PPT; k++) { const f4a q = __builtin_nontemporal_load(S + k * 256); px[k] = q.x; py[k] = q.y; wlo[k] = wm_f2{q.z, q.w}; }
+        for (int k = 0; k < PPT; k++) { const uvt_rec *r = S + k * 256; px[k] = __builtin_nontemporal_load(&r->x); py[k] = __builtin_nontemporal_load(&r->y); wlo[k] = wm_f2{__uint_as_float(__builtin_nontemporal_load(&r->q)), 0.0f}; }
     } else {
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
@@ -3024,7 +3090,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW ? UVT_WA
             const unsigned n = ok ? n0 + (unsigned)k * nstep : 0u;
             px[k] = xs[n]; py[k] = ys[n];
             wlo[k] = wm_f2{1.0f, 0.0f};
-            if (p.wind_M && !(dbg & 16)) wlo[k] = __builtin_nontemporal_load((const wm_f2 *)((const char *)p.wind_M + ((size_t)n << (p.wind_M_half ? 3 : 4))));
+            if (p.wind_M && !(dbg & 16)) wlo[k] = p.wind_M_half ? rot_unpack(__builtin_nontemporal_load((const unsigned *)p.wind_M + n)) : __builtin_nontemporal_load((const wm_f2 *)((const char *)p.wind_M + ((size_t)n << 4)));
         }
     }
     const int4 tb = tiles[b];
@@ -3064,6 +3130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW ? UVT_WA
         for (int idx = (int)t; idx < nyr; idx += 256) yr[idx] = gy[idx];
     }
     __syncthreads();
+    unsigned redo = 0;
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
         if (!(okx && cy0 + (unsigned)(G::RSTEP * k) < (unsigned)p.tile_nj)) continue;
@@ -3110,9 +3177,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW ? UVT_WA
                 } else {
                     /* p_irgdint_3_w_pair_inner's arithmetic, operation for operation, on the staged window and records */
                     const f4a16 *xq = (const f4a16 *)xr + (i - 1 - i0) * 2, *yq = (const f4a16 *)yr + (j - 1 - j0) * 2;
-                    const PairW w = pair_weights_lagrange(px[k], py[k], i, j, xq[0], xq[1], yq[0], yq[1]);
-                    const pk2 s = pair_cols(w, pair_row(w, q[0][0], q[0][1], q[0][2], q[0][3]), pair_row(w, q[1][0], q[1][1], q[1][2], q[1][3]),
-                                            pair_row(w, q[2][0], q[2][1], q[2][2], q[2][3]), pair_row(w, q[3][0], q[3][1], q[3][2], q[3][3]));
+                    bool again;
+                    const pk2 s = pair_eval(px[k], py[k], i, j, xq[0], xq[1], yq[0], yq[1], q, again);
+                    if (again) redo |= 1u << k;                 /* (nearly calm under a strong stencil: once more in REAL*8, below) */
                     a = s.x; bb = s.y;
                 }
             }
@@ -3121,9 +3188,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW ? UVT_WA
             wm_f2 whi = wm_f2{0.0f, 1.0f};
             if (!p.wind_M_half) whi = __builtin_nontemporal_load((const wm_f2 *)((const char *)p.wind_M + (n << 4)) + 1);      /* (sets whose chain is not a pure rotation: rare) */
             const float u = a, v = bb;
-            wind_m_apply(wlo[k], whi, p.wind_M_half, u, v, p.wind_dst_rot, a, bb);
+            wind_m_apply(p.uvt_streams ? rot_unpack(__float_as_uint(wlo[k].x)) : wlo[k], whi, p.wind_M_half, u, v, p.wind_dst_rot, a, bb);
         }
         if (!(dbg & 32) || a == 12345.678f) { zout1[n] = a; zout2[n] = bb; }      /* (32: development, no stores) */
+    }
+    /* second pass: the thread's flagged points once more in REAL*8 (a few waves in a thousand have any), stored over the REAL result */
+    if (!NW && __ballot(redo != 0u) != 0ull) {
+        typedef __attribute__((address_space(3))) const float *ldsf;
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            if (!((redo >> k) & 1u)) continue;
+            const size_t n = (size_t)n0 + (size_t)k * nstep;
+            const float fx = px[k], fy = py[k];
+            const int i = min(p.ni - 2 + p.wrap, max(1, max(2 - p.wrap, (int)fx))), j = min(p.j2 - 2, max(p.j1 + 1, (int)fy));
+            const ldsf cu = (ldsf)(uvt_lds + 2 * ((j - 1 - j0) * W + (i - 1 - i0)));
+            const ldsf xq = (ldsf)((const float *)xr + (i - 1 - i0) * 8), yq = (ldsf)((const float *)yr + (j - 1 - j0) * 8);
+            const pk2 s = pair_eval_real8<ldsf>(cu, cu + 1, 2, 2 * W, xq, yq, p.ncx8 + (size_t)(i - 1) * 8, p.ncy8 + (size_t)(j - p.j1) * 8, fx, fy, i, j);
+            float a = s.x, bb = s.y;
+            if (p.wind_M) {
+                wm_f2 whi = wm_f2{0.0f, 1.0f};
+                if (!p.wind_M_half) whi = __builtin_nontemporal_load((const wm_f2 *)((const char *)p.wind_M + (n << 4)) + 1);
+                const float u = a, v = bb;
+                wind_m_apply(p.uvt_streams ? rot_unpack(__float_as_uint(wlo[k].x)) : wlo[k], whi, p.wind_M_half, u, v, p.wind_dst_rot, a, bb);
+            }
+            zout1[n] = a; zout2[n] = bb;
+        }
     }
 }
 
@@ -3808,12 +3897,12 @@ extern "C" int ezhip_uvt_build(const ezhip_pts_plan *plan, const float *d_x, con
     return 0;
 }
 
-/* the tile-ordered stream copy of a wind-pair plan (k_uvt_pack): d_streams holds 16 bytes x 256 x PPT x ntiles.  plan->wind_M: NULL or the (a, b) form */
+/* the tile-ordered stream copy of a wind-pair plan (k_uvt_pack): d_streams holds 12 bytes x 256 x PPT x ntiles (+ 16).  plan->wind_M: NULL or the packed-rotation form */
 extern "C" size_t ezhip_uvt_stream_bytes(const ezhip_pts_plan *plan, int shape)
 {
     int tw, th;
     uvt_dims(shape, &tw, &th);
-    return (size_t)16 * (size_t)tw * (size_t)th * (size_t)ezhip_uvt_ntiles(plan, shape);
+    return (size_t)12 * (size_t)tw * (size_t)th * (size_t)ezhip_uvt_ntiles(plan, shape) + 16;
 }
 extern "C" int ezhip_uvt_pack_streams(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_streams, int shape)
 {
@@ -3821,7 +3910,7 @@ extern "C" int ezhip_uvt_pack_streams(const ezhip_pts_plan *plan, const float *d
     if (nt <= 0 || !d_streams || (plan->wind_M && !plan->wind_M_half)) return -1;
     int tw, th;
     uvt_dims(shape, &tw, &th);
-#define UVT_PK(TW, TH) hipLaunchKernelGGL((k_uvt_pack<TW, TH>), dim3(nt), dim3(256), 0, g_stream, *plan, d_x, d_y, (float4 *)d_streams)
+#define UVT_PK(TW, TH) hipLaunchKernelGGL((k_uvt_pack<TW, TH>), dim3(nt), dim3(256), 0, g_stream, *plan, d_x, d_y, (uvt_rec *)d_streams)
     if (tw == 32 && th == 16) UVT_PK(32, 16); else if (tw == 64 && th == 8) UVT_PK(64, 8); else if (tw == 64 && th == 16) UVT_PK(64, 16); else UVT_PK(32, 32);
 #undef UVT_PK
     if (LAUNCH_CHECK("k_uvt_pack")) return -1;
@@ -4335,9 +4424,9 @@ extern "C" int ezhip_average(float *d_zout, const float *d_zin, const float *d_b
  * point, a plane rotation that depends on the two grids only: ezhip_wind_matrix runs the chain once on the unit vectors (1,0) and (0,1)
  * and keeps the four coefficients per point; k_wind_apply then replaces ~10 REAL*8 / REAL transcendentals per point and call by two
  * multiply-adds per component.  The result differs from the chain on (u,v) by the chain's own rounding (~4e-7 |V|; tolerance 1e-5 |V|). */
-/* M: the four coefficients per point; M2 (behind it): the rotation (a + d) / 2, (b - c) / 2 the four stand for when the chain is one; *dev: the largest
+/* M: the four coefficients per point; M2 (behind it): the rotation (a + d) / 2, (b - c) / 2 the four stand for when the chain is one, as one word per point (rot_pack); *dev: the largest
  * distance of a point's matrix from that form (max |a - d|, |b + c|; infinite when a coefficient is not finite), as the bits of a non-negative float */
-__global__ __launch_bounds__(256) void k_wind_matrix_pack(float4 *__restrict__ M, float2 *__restrict__ M2, unsigned *__restrict__ dev, const float *__restrict__ a,
+__global__ __launch_bounds__(256) void k_wind_matrix_pack(float4 *__restrict__ M, unsigned *__restrict__ M2, unsigned *__restrict__ dev, const float *__restrict__ a,
                                                           const float *__restrict__ c, const float *__restrict__ b, const float *__restrict__ d, size_t n)
 {
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -4345,7 +4434,7 @@ __global__ __launch_bounds__(256) void k_wind_matrix_pack(float4 *__restrict__ M
     if (k < n) {
         const float ak = a[k], bk = b[k], ck = c[k], dk = d[k];
         M[k] = make_float4(ak, bk, ck, dk);                          /* uo = a u + b v, vo = c u + d v */
-        M2[k] = make_float2(0.5f * (ak + dk), 0.5f * (bk - ck));
+        M2[k] = rot_pack(0.5f * (ak + dk), 0.5f * (bk - ck));
         dv = fmaxf(fabsf(ak - dk), fabsf(bk + ck));
         if (!(dv <= 3.0e38f)) dv = __builtin_inff();
     }
@@ -4368,7 +4457,7 @@ __global__ __launch_bounds__(256) void k_wind_apply(const void *__restrict__ M, 
     wind_m_apply(lo, hi, half, u, v, dst_rot, a, b);
     uu[k] = a; vv[k] = b;
 }
-/* d_M: 24 bytes per point (the float4 form, then the float2 form); *max_dev: how far the matrices are from pure rotations (see k_wind_matrix_pack) */
+/* d_M: 20 bytes per point (the float4 form, then the packed rotations); *max_dev: how far the matrices are from pure rotations (see k_wind_matrix_pack) */
 extern "C" int ezhip_wind_matrix(const ezhip_wind_plan *plan, void *d_M, const float *d_lat, const float *d_lon, int ni_dst, int nj_dst, float *max_dev)
 {
     const size_t npts = (size_t)ni_dst * nj_dst;
@@ -4383,7 +4472,7 @@ extern "C" int ezhip_wind_matrix(const ezhip_wind_plan *plan, void *d_M, const f
     hipLaunchKernelGGL(k_fill2, grid, block, 0, g_stream, t + 2 * npts, 0.0f, t + 3 * npts, 1.0f, npts);       /* (0,1) -> (b, d) */
     hipLaunchKernelGGL(k_wind_rotate, grid, block, 0, g_stream, *plan, t, t + npts, d_lat, d_lon, ni_dst, nj_dst);
     hipLaunchKernelGGL(k_wind_rotate, grid, block, 0, g_stream, *plan, t + 2 * npts, t + 3 * npts, d_lat, d_lon, ni_dst, nj_dst);
-    hipLaunchKernelGGL(k_wind_matrix_pack, grid, block, 0, g_stream, (float4 *)d_M, (float2 *)((float4 *)d_M + npts), d_dev, t, t + npts, t + 2 * npts, t + 3 * npts, npts);
+    hipLaunchKernelGGL(k_wind_matrix_pack, grid, block, 0, g_stream, (float4 *)d_M, (unsigned *)((float4 *)d_M + npts), d_dev, t, t + npts, t + 2 * npts, t + 3 * npts, npts);
     int rc = LAUNCH_CHECK("k_wind_matrix");
     unsigned dev_bits = 0x7F800000u;
     if (hipMemcpyAsync(&dev_bits, d_dev, 4, hipMemcpyDeviceToHost, g_stream) != hipSuccess || hipStreamSynchronize(g_stream) != hipSuccess) rc = -1;

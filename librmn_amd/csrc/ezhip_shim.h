@@ -229,10 +229,10 @@ typedef struct {
     const void *uvt_tiles;            /* k_uvt: the grid set's tile table (int4 {i0, j0, W, H} per 32 x uvt_th tile of the target: ezhip_uvt_build), NULL: k_pts2 */
     int uvt_shape;                    /* 100 TW + TH of the table's tiles: 3232 (default), 3216, 6416, 6408 */
     int uvt_cap;                      /* staged cells a tile may need (the table was built under it) */
-    const void *uvt_streams;          /* NULL, or the set's x, y and (a, b) once more in tile order: float4 per point (ezhip_uvt_pack_streams) */
+    const void *uvt_streams;          /* NULL, or the set's x, y and packed rotation once more in tile order: 12 bytes per point (ezhip_uvt_pack_streams) */
     int uvt_debug;                    /* development knock-outs (develop build only) */
     int wind_dst_rot;                 /* with wind_M: the TARGET frame is a rotated one (decides what a REAL overflow of the chain's speed turns into) */
-    int wind_M_half;                  /* wind_M holds (a, b) per point: a pure rotation, c = -b, d = a */
+    int wind_M_half;                  /* wind_M holds ONE word per point: a pure rotation (a, b), c = -b, d = a, packed by rot_pack (ez_kernels.hip) */
     const void *wind_M;               /* k_pts2: the grid pair's wind matrices (ezhip_wind_matrix), applied to every point before it is stored; NULL: store the interpolated components */
     /* zone handling (0 = none: c_gdxysint semantics) */
     int zones;                        /* 0 none, 1 EZ_NO_EXTRAP (polar zones), 2 EZ_EXTRAP (DEHORS) */
