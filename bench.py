@@ -136,18 +136,43 @@ def check_outputs(ez, torch, d_out, d_in, check_f):
     return res
 
 
-def profile_traffic(key):
-    """(value, file) of a per-unit HBM / fabric traffic figure measured by the PMC passes of tools/prof_round.sh and kept under profiles/ (FETCH_SIZE x 2 on
-    gfx950 + WRITE_SIZE: MI355X_MICROARCH.md) -- PMC counters need their own rocprofv3 runs, this run does not collect them"""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+def profile_value(key):
+    """(value, file) of a figure the round's profiling passes left under profiles/ (newest round first): HBM / fabric traffic per unit from the PMC passes of
+    tools/prof_round.sh (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE: MI355X_MICROARCH.md), instruction counts from the SQ passes (tools/pmc_sq.sh).  Counters need their
+    own rocprofv3 runs: this run does not collect them, and every figure taken from here is labelled with its file in the line."""
+    import glob, re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")), key=lambda f: int(re.search(r"r(\d\d)_", f).group(1)), reverse=True)
+    for f in files:
         try:
-            with open(os.path.join(ROOT, "profiles", name)) as fh:
+            with open(f) as fh:
                 v = json.load(fh).get(key)
             if v is not None:
-                return float(v), "profiles/" + name
+                return float(v), "profiles/" + os.path.basename(f)
         except Exception:   # noqa: BLE001
             pass
     return None
+
+
+profile_traffic = profile_value
+
+
+def roofline_cfg5(pipe_us, zl_mean):
+    """the cfg5 pipeline is bound by instruction ISSUE, not by bytes.  Its VALU wave-instructions per field come from the newest SQ-counter profile under profiles/
+    (labelled; never a literal in this file); without one `achieved` and `frac` are omitted."""
+    v = profile_value("cfg5_valu_wave_instructions_per_field")
+    peak = 1024 * 2.4 / 2.0                      # the guide: a wave64 VALU instruction takes 2 cycles on a SIMD-32 once two or more waves feed it
+    r = {"bound": "issue", "peak": peak, "unit": "G VALU wave-instructions/s",
+         "peak_one_wave_per_simd": 1024 * 2.4 / 4.7,
+         "peak_note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md constants table: SIMD-32, two or more waves); one wave's stream alone "
+                      "sustains 4 cycles (guide) / 4.7 (tools/irate.hip on this path's instruction mix) = peak_one_wave_per_simd, the figure rounds 3 - 4 measured against",
+         "hbm_frac_of_algorithmic_bytes": (4.0 * NI_S * NJ_S + zl_mean) / (pipe_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+         "kernel": "k_bb_* (extrema from bounds) + k_sepx<3, 16, 3> (tokens) + k_armn_enc1 (one-pass encoder)"}
+    if v:
+        r.update({"achieved": v[0] / (pipe_us * 1e-6) / 1e9, "frac": v[0] / (pipe_us * 1e-6) / 1e9 / peak, "frac_of_one_wave_rate": v[0] / (pipe_us * 1e-6) / 1e9 / (1024 * 2.4 / 4.7),
+                  "valu_wave_instructions_per_field": v[0], "valu_source": v[1] + " (SQ_INSTS_VALU of the pipeline's kernels, not this run)"})
+    else:
+        r["note"] = "no SQ-counter profile of this code under profiles/: achieved / frac omitted"
+    return r
 
 
 def extras(ez, torch, stream, d_out, d_in):
@@ -200,6 +225,14 @@ def extras(ez, torch, stream, d_out, d_in):
             a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
         d_u = torch.from_numpy(uu).cuda(); d_v = torch.from_numpy(vv).cuda()
         o_u = torch.empty(no * mo, dtype=torch.float32, device="cuda"); o_v = torch.empty_like(o_u)
+        # the set's FIRST call: locate of the 8 M target points in the rotated source (host threads: bit-exact with the reference's libm, uploaded once), Newton
+        # tables, the wind matrix of the grid pair, the special points' list, the tile table and the tile-ordered stream copy
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        assert ez.ezuvint_dev(o_u, o_v, d_u, d_v) >= 0
+        torch.cuda.synchronize(); ex["cfg3_first_call_ms"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        assert ez.ezuvint_dev(o_u, o_v, d_u, d_v) >= 0
+        torch.cuda.synchronize(); ex["cfg3_second_call_ms"] = (time.perf_counter() - t0) * 1e3      # (builds the staged-tile caches behind it)
         us = ev_time(lambda: ez.ezuvint_dev(o_u, o_v, d_u, d_v), 20)
         algo3 = 2 * 4 * ni * nj + 2 * 4 * no * mo                      # both source components in, both target components out
         t3 = profile_traffic("cfg3_traffic_MB_per_pair")
@@ -209,17 +242,26 @@ def extras(ez, torch, stream, d_out, d_in):
                             "roofline": {"bound": "hbm", "achieved": algo3 / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": algo3 / us / 1e3 / HBM_PEAK_GBPS,
                                          "traffic": t3[0] * 1e6 if t3 else None, "traffic_source": t3[1] if t3 else None,
                                          "kernel": "k_uvt<32, 32> (stencil windows staged in LDS; the first call of a grid set: k_pts2_irgd3w) + k_pts_special2c behind it", "algorithmic_bytes_per_launch": algo3,
-                                         "note": "x, y of the rotated source and the per-point wind rotation (a, b) -- 16 bytes per target point, read from the set's tile-ordered copy -- and the 64 MB of results "
-                                                 "stream next to the staged source windows; the kernel's phases (streams 42 us, staging 9, REAL*8 arithmetic 20, handed-back tiles 5) do not overlap: "
-                                                 "profiles/r04_experiments.txt"}}
+                                         "note": "x, y of the rotated source and the per-point wind rotation (one packed word) -- 12 bytes per target point, read from the set's tile-ordered copy -- and the "
+                                                 "64 MB of results stream next to the staged source windows; REAL (packed fp32) evaluation with a REAL*8 second pass where the wind is small under a strong "
+                                                 "stencil; no unit saturated (VALU 40 %, LDS 47 % of the kernel: SQ counters, profiles/r05_experiments.txt): the vector L1 returns in order, a block's round "
+                                                 "trips bound it; the pipelined form (persistent blocks, LDS-DMA double buffering) was built and measured slower"}}
         # the scalar twin on the same grid pair: c_ezsint from the rotated source (k_st: stencil windows staged in LDS, the literal REAL*8 form of the reference)
         us1 = ev_time(lambda: ez.ezsint_dev(o_u, d_u), 20)
         algo1 = 4 * ni * nj + 4 * no * mo
+        t1 = profile_value("cfg3_sint_traffic_MB_per_field"); v1 = profile_value("cfg3_sint_valu_wave_instructions_per_field")
+        valu_peak = 1024 * 2.4 / 2.0                # G wave64 VALU instructions / s: 2 cycles each on a SIMD-32 with two or more waves (MI355X_MICROARCH.md, constants table)
         ex["cfg3_sint"] = {"workload": "c_ezsint_dev bicubic, Z-on-E 2560x1280 -> L 4000x2000, polar_correction=yes", "us_per_field": us1, "Mpoints_per_s": no * mo / us1,
-                           "roofline": {"bound": "hbm", "achieved": algo1 / us1 / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": algo1 / us1 / 1e3 / HBM_PEAK_GBPS, "traffic": None,
+                           "roofline": {"bound": "valu", "achieved": (v1[0] / us1 / 1e3) if v1 else None, "peak": valu_peak, "unit": "G VALU wave-instructions/s",
+                                        "frac": (v1[0] / us1 / 1e3 / valu_peak) if v1 else None,
+                                        "valu_wave_instructions_per_field": v1[0] if v1 else None, "valu_source": v1[1] if v1 else None,
+                                        "peak_one_wave_per_simd": 1024 * 2.4 / 4.7, "peak_note": "peak: the guide's 2 cycles per wave64 VALU instruction (SIMD-32, two or more waves); one wave's stream alone sustains 4 (guide) / 4.7 (tools/irate.hip, REAL*8 mix)",
+                                        "hbm_achieved_GBps": algo1 / us1 / 1e3, "hbm_frac_of_algorithmic_bytes": algo1 / us1 / 1e3 / HBM_PEAK_GBPS,
+                                        "traffic": t1[0] * 1e6 if t1 else None, "traffic_source": t1[1] if t1 else None,
                                         "kernel": "k_st<32, 32> (the first call of a grid set: k_pts<8>) + k_pts_special behind it", "algorithmic_bytes_per_launch": algo1,
-                                        "note": "x, y of the located points (8 bytes per target point, the set's own data) stream next to the staged windows; ~150 REAL*8 operations per point "
-                                                "in the reference's literal Newton form (bit-identical to the gathering kernel): arithmetic and streams share the time"}}
+                                        "note": "195 VALU instructions per point in the reference's literal REAL*8 statement-function form (bit-identical to the gathering kernel; hash-equal to the "
+                                                "reference over 8 M points without polar correction): SQ_ACTIVE_INST_VALU ~70 % of the SIMDs' time at the 4-cycle single-stream rate, the rest is the "
+                                                "blocks' dependent round trips; x, y (8 bytes per target point) stream next to the staged windows"}}
         del d_u, d_v, o_u, o_v
         # the step after the horizontal one: vertical interpolation of device-resident profiles, search + linear + lapse-rate in one pass
         from librmn_amd import interpv as V
@@ -704,18 +746,14 @@ def main():
                      "cfg5_stages": "extrema from bounds of the source windows (k_bb_*: no interpolation) + header + k_sepx tokens + one-pass armn encoder",
                      # what bounds them.  compact_float: two passes (extrema, tokens) = 4 + 4 + 2 bytes of traffic per value for 6 algorithmic; measured against HBM.
                      "roofline_compact_float": {"bound": "hbm", "achieved": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                                                "traffic": 10.0 * NPTS_OUT, "traffic_source": "profiles/r03_pmc_traffic.json (two reads + one write of the field: 10 B per value)",
-                                                "traffic_GBps": 10.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9,
+                                                "traffic": (profile_value("compact_float_traffic_bytes_per_value") or (10.0, None))[0] * NPTS_OUT,
+                                                "traffic_source": ((profile_value("compact_float_traffic_bytes_per_value") or (0, "profiles/r03_pmc_traffic.json"))[1] + " (two reads + one write of the field: 10 B per value; not this run)"),
+                                                "traffic_GBps": (profile_value("compact_float_traffic_bytes_per_value") or (10.0, None))[0] * NPTS_OUT / (pack_us * 1e-6) / 1e9,
                                                 "kernel": "k_stats + k_cf_header + k_cf_pack16", "algorithmic_bytes_per_launch": 6.0 * NPTS_OUT,
                                                 "note": "the traffic moves at ~93 % of the 6.29 TB/s a copy reaches; a one-launch form (two variants) ends at the same time: profiles/r04_experiments.txt"},
                      # the cfg5 pipeline is bound by instruction ISSUE, not by bytes: its two big kernels retire ~2.0e7 VALU wave-instructions per field
                      # (k_sepx<3,16,3>: 1659 per wave x 3604 waves; k_armn_enc1: 979 x 14 424: SQ_INSTS_VALU, profiles/r03_experiments.txt) at 4.7 clk each per SIMD
-                     "roofline_cfg5": {"bound": "issue", "achieved": 2.01e7 / (pipe_us * 1e-6) / 1e9, "peak": 1024 * 2.4 / 4.7, "unit": "G VALU wave-instructions/s",
-                                       "frac": 2.01e7 / (pipe_us * 1e-6) / 1e9 / (1024 * 2.4 / 4.7),
-                                       "hbm_frac_of_algorithmic_bytes": (4.0 * NI_S * NJ_S + zl_mean) / (pipe_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                                       "kernel": "k_bb_* (extrema from bounds) + k_sepx<3, 16, 3> (tokens) + k_armn_enc1 (one-pass encoder)",
-                                       "note": "peak = 1024 SIMDs x 2.4 GHz / 4.7 clk per wave64 VALU instruction (tools/irate.hip); of the encoder's 41 us per field 13.5 are its memory side, "
-                                               "of the token pass's 26.5 us 2.5 are its stores (kernel-level knock-outs, profiles/r04_experiments.txt)"},
+                     "roofline_cfg5": roofline_cfg5(pipe_us, zl_mean),
                      "zlng_bytes": int(zl[0]),
                      "compression_ratio": float(zl[0]) / (2.0 * NPTS_OUT), "unit": "GB/s of float input"},
         }
@@ -727,7 +765,9 @@ def main():
                 out["roofline_single_field"] = {"bound": "hbm", "note": "one field per launch: the fill and drain of one launch's staging / compute / store pipeline (~4 us) is paid per field; "
                                                         "a batch launch pays it once per batch (the headline).  The floor of the one-launch-per-field form (DESIGN_LOG.md 9)",
                                                 "achieved": ALGO_BYTES / (sf * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                                "frac": ALGO_BYTES / (sf * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                                                "frac": ALGO_BYTES / (sf * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                                "traffic": (profile_value("single_field_traffic_MB")[0] * 1e6) if profile_value("single_field_traffic_MB") else None,
+                                                "traffic_source": profile_value("single_field_traffic_MB")[1] if profile_value("single_field_traffic_MB") else None,
                                                 "kernel": "k_sepx<3, 16> (one field per launch, launches back to back)", "avg_launch_us": sf,
                                                 "algorithmic_bytes_per_launch": ALGO_BYTES}
         if hf is not None:

@@ -106,8 +106,44 @@ if P3:
     out["cfg3_traffic_MB_per_pair"] = round(tot3, 1)
     out["cfg3_algorithmic_MB_per_pair"] = 90.21
     out["cfg3_traffic_over_algorithmic"] = round(tot3 / 90.21, 2)
-    out["cfg3_notes"] = ("x, y of the located points and the per-point wind rotations (a, b) -- 128 MB, read from the set's tile-ordered copy -- are inputs of every call next to "
+    out["cfg3_notes"] = ("x, y of the located points and the per-point wind rotation (one packed word) -- 96 MB, read from the set's tile-ordered copy -- are inputs of every call next to "
                          "the staged source windows (~0.94 cells of 8 bytes per point) and 64 MB of results")
+# round 5: the figures bench.py's other roofline objects read (every one labelled with this file in the line)
+lone = [(k, st.median(v)) for k, v in fetch.items() if "k_sepx<3, 16, 0>" in k[0]]
+if lone:
+    kmin = min(lone, key=lambda kv: int(kv[0][1]))[0]
+    if kmin in write:
+        out["single_field_traffic_MB"] = round((st.median(fetch[kmin]) * 2 + st.median(write[kmin])) * 1024 / 1e6, 2)
+        out["single_field_grid"] = kmin[1]
+S1 = per_field("k_st<32, 32", nfields=1); S1s = per_field("k_pts_special(", nfields=1) or per_field("k_pts_special", nfields=1)
+if S1:
+    out["cfg3_sint_kernels_MB_per_field"] = {"k_st": S1, "k_pts_special": S1s}
+    out["cfg3_sint_traffic_MB_per_field"] = round(sum(x["read_MB"] + x["write_MB"] for x in (S1, S1s) if x), 1)
+CF = [per_field(k, nfields=1) for k in ("k_stats", "k_cf_header", "k_cf_pack16")]
+if all(CF):
+    out["compact_float_traffic_bytes_per_value"] = round(sum(x["read_MB"] + x["write_MB"] for x in CF) * 1e6 / bench["config"]["points_per_field"], 2)
+try:
+    valu = pmc("SQ_INSTS_VALU")
+
+    def instr(kernel_part, nfields):
+        c = [(k, v) for k, v in valu.items() if kernel_part in k[0]]
+        if not c:
+            return None
+        k, v = max(c, key=lambda kv: int(kv[0][1]))
+        return st.median(v) / nfields
+    parts5 = {k: instr(k, F) for k in ("k_bb_bounds", "k_bb_select", "k_bb_eval", "k_bb_special", "k_sepx<3, 16, 3>", "k_armn_enc1")}
+    if all(v is not None for v in parts5.values()):
+        out["cfg5_valu_wave_instructions_per_field_by_kernel"] = {k: round(v) for k, v in parts5.items()}
+        out["cfg5_valu_wave_instructions_per_field"] = round(sum(parts5.values()))
+    i_st = instr("k_st<32, 32", 1)
+    if i_st is not None:
+        out["cfg3_sint_valu_wave_instructions_per_field"] = round(i_st + (instr("k_pts_special", 1) or 0))
+    i_uvt = instr("k_uvt", 1)
+    if i_uvt is not None:
+        out["cfg3_uvint_valu_wave_instructions_per_pair"] = round(i_uvt)
+    shutil.copyfile(os.path.join(src, "pmc_SQ_INSTS_VALU.csv"), os.path.join(dst, f"{prefix}_pmc_SQ_INSTS_VALU_per_dispatch.csv"))
+except FileNotFoundError:
+    pass
 json.dump(out, open(os.path.join(dst, f"{prefix}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 print(f"timed launches: mean {mean_us:.2f} us, frac {alg / mean_us / 1e3 / 8000:.4f}; bench line {bench['roofline']['avg_launch_us']:.2f} us / {bench['roofline']['frac']:.4f}")

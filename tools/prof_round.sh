@@ -4,6 +4,7 @@
 #   kernel_stats.csv              rocprofv3 --kernel-trace --stats of the same command
 #   dispatches.csv                every k_sepx / k_armn / k_cf dispatch of the profiled run: id, kernel, grid, start, end, duration
 #   pmc_FETCH_SIZE.csv, pmc_WRITE_SIZE.csv   separate --pmc passes (MI355X_MICROARCH.md: FETCH_SIZE x2 on gfx950, WRITE_SIZE exact), per dispatch
+#   pmc_SQ_INSTS_VALU.csv         a third pass: VALU wave-instructions per dispatch (the issue-bound rooflines of bench.py read them from profiles/)
 TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -25,7 +26,7 @@ with open(sys.argv[2] + "/dispatches.csv", "w") as f:
                 r["Start_Timestamp"], r["End_Timestamp"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
 PY
 rm -rf $O/trace
-for c in FETCH_SIZE WRITE_SIZE; do
+for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
   rm -rf $O/pmc_$c
   timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python3 $R/bench.py --no-cpu-baseline --steps 6 --warmup 2 > $O/pmc_$c.log 2>&1
   C=$(find $O/pmc_$c -name "*counter_collection.csv" | head -1)
