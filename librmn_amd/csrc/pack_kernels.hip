@@ -1132,25 +1132,22 @@ __global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8)))
     {
         const int rv = rw >> 2, nitems = ck.prow_n * rv;
         uint4 *lds4 = (uint4 *)lds;
-        auto rot = [](uint4 &x) {
-            x.x = __builtin_amdgcn_alignbit(x.x, x.x, 16); x.y = __builtin_amdgcn_alignbit(x.y, x.y, 16);
-            x.z = __builtin_amdgcn_alignbit(x.z, x.z, 16); x.w = __builtin_amdgcn_alignbit(x.w, x.w, 16);
-        };
         const int wv_u = __builtin_amdgcn_readfirstlane(wave);
         const size_t wb_u = (size_t)((((unsigned)(3 * ty0 + wv_u) * (unsigned)ni + (unsigned)col_lo) >> 1) & ~3u);      /* first staged word of patch row `wave` */
         const size_t wb_last = (size_t)((((unsigned)(3 * ty0 + ck.prow_n - 1) * (unsigned)ni + (unsigned)col_lo) >> 1) & ~3u);   /* the chunk's last row: the one nearest the array's end */
         if (nrow_t == 1 && rv <= 64 * ENC_NLD && wb_last + 4u * (unsigned)rv <= a.tok_words) {        /* block-uniform */
-            /* the common shape (one tile row per chunk): wave w stages patch row w; the row base is wave-uniform, a lane's pieces are
-             * 1 KB apart.  (Deriving row and column of every 16-byte piece from a flat index cost 780 instructions per wave.) */
+            /* the common shape (one tile row per chunk): wave w stages patch row w; the row base is wave-uniform, a lane's pieces are 1 KB apart.  By LDS-DMA
+             * (round 5): no registers, no ds_write -- the seven ds_write_b128 per wave were 316 LDS-array cycles per wave (44 each), a quarter of what the LDS
+             * array did in this kernel.  The words arrive as they lie in memory; which half of a word holds the earlier token (SWAPPED) is the readers' business */
             if (wv_u < ck.prow_n) {
                 const uint4 *src = (const uint4 *)(tok + wb_u) + lane;
-                uint4 *dst = lds4 + wv_u * rv + lane;
-                uint4 val[ENC_NLD];
+                const unsigned dst0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)(lds4 + wv_u * rv);
 #pragma unroll
-                for (int u = 0; u < ENC_NLD; u++) if (lane + 64 * u < rv) val[u] = src[64 * u];
-#pragma unroll
-                for (int u = 0; u < ENC_NLD; u++) if (lane + 64 * u < rv) { if (SWAPPED) rot(val[u]); dst[64 * u] = val[u]; }
+                for (int u = 0; u < ENC_NLD; u++)
+                    if (lane + 64 * u < rv)
+                        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src + 64 * u), "s"(__builtin_amdgcn_readfirstlane((int)(dst0 + 1024u * (unsigned)u))) : "memory");
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             /* chunks of several tile rows (narrow fields) and the last rows of the token array: piece by piece, bounds checked */
             for (int idx = tid; idx < nitems; idx += ENC_TPB) {
@@ -1159,7 +1156,6 @@ __global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8)))
                 uint4 x = make_uint4(0u, 0u, 0u, 0u);
                 if (gw + 3 < a.tok_words) x = *(const uint4 *)(tok + gw);
                 else { if (gw < a.tok_words) x.x = tok[gw]; if (gw + 1 < a.tok_words) x.y = tok[gw + 1]; if (gw + 2 < a.tok_words) x.z = tok[gw + 2]; }
-                if (SWAPPED) rot(x);
                 lds4[idx] = x;
             }
         }
@@ -1168,7 +1164,6 @@ __global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8)))
     STAMP();
     if (EZH_DBG(a.debug) & 32) { if (tid == 0 && (c == a.nchunks - 1 || lds[0] == 0x12345u)) a.zlng[f] = 1000; return; }      /* development: staging only */
     /* ---- per tile: differences (kept in registers), width, bit count ------------------------------------------- */
-    const unsigned short *p16 = (const unsigned short *)lds;
     unsigned long long dpk[ENC_TPT][3];                     /* the 3 differences of a tile row, 18 bits each at bits 0 / 21 / 42 (36 plain registers cost two waves per SIMD) */
     unsigned bits[ENC_TPT], meta[ENC_TPT];                  /* meta: need | tm << 8 | tn << 12 */
     bool gt = false;
@@ -1190,8 +1185,17 @@ __global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8)))
             int h[4][3];
 #pragma unroll
             for (int n = 0; n < 4; n++) {
-                const unsigned short *prow = p16 + 3 * tcx + (nrow_t > 1 ? (unsigned)(3 * trow + n) * (unsigned)rw * 2u + (((unsigned)(3 * (ty0 + trow) + n) * (unsigned)ni + (unsigned)col_lo) & 7u) : rowoff[n]);
-                const int u0 = prow[0], u1 = prow[1], u2 = prow[2], u3 = prow[3];
+                /* the row's four tokens as THREE aligned dwords and two funnel shifts (round 5).  As four ds_read_u16 they were 19 LDS-array cycles each (lanes 6 bytes
+                 * apart, sub-dword accesses): 908 of the kernel's 1319 LDS cycles per wave, and the LDS array was 75 % busy -- the encoder's real bound
+                 * (SQ_LDS_IDX_ACTIVE, profiles/r05_experiments.txt); a dword read is 2 cycles.  (The third dword may lie one word past the row: inside the allocation.) */
+                const unsigned hidx = 3u * (unsigned)tcx + (nrow_t > 1 ? (unsigned)(3 * trow + n) * (unsigned)rw * 2u + (((unsigned)(3 * (ty0 + trow) + n) * (unsigned)ni + (unsigned)col_lo) & 7u) : rowoff[n]);
+                const unsigned *pw = lds + (hidx >> 1);
+                const unsigned d0 = pw[0], d1 = pw[1], d2 = pw[2];
+                /* u0 | u1 << 16 and u2 | u3 << 16 by byte permutes of (d1 : d0) and (d2 : d1): the selector knows the row's parity and which half of a word holds the
+                 * earlier token (c_zfstlib.c:119-126: the high half when SWAPPED) */
+                const unsigned sel = (hidx & 1u) ? (SWAPPED ? 0x07060100u : 0x05040302u) : (SWAPPED ? 0x01000302u : 0x03020100u);
+                const unsigned ta = __builtin_amdgcn_perm(d1, d0, sel), tb = __builtin_amdgcn_perm(d2, d1, sel);
+                const int u0 = (int)(ta & 0xFFFFu), u1 = (int)(ta >> 16), u2 = (int)(tb & 0xFFFFu), u3 = (int)(tb >> 16);
                 h[n][0] = u1 - u0; h[n][1] = u2 - u1; h[n][2] = u3 - u2;
             }
             int d[3][3];
@@ -1462,7 +1466,7 @@ static size_t enc1_lds_bytes(const enc1_args *a)
     size_t tiles = (size_t)(a->nseg > 1 ? a->seg_tiles : a->ntx * a->rows_per_chunk);
     size_t img = (tiles * 167 + 31) / 32 + 8;
     size_t patch = enc1_patch_words(a);
-    return 4 * (patch > img ? patch : img);
+    return 4 * (patch > img ? patch : img) + 16;      /* (+ 16: the tile phase reads a row's tokens as three aligned dwords, the third may lie behind the last row) */
 }
 /* control / granule storage of one launch over nfields fields (device scratch, zeroed by the launcher) */
 extern "C" size_t packhip_armn_enc1_work_bytes(int ni, int nj, int nbits, int nfields)
