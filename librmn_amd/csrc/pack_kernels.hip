@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8)))
     STAMP();
     if (EZH_DBG(a.debug) & 32) { if (tid == 0 && (c == a.nchunks - 1 || lds[0] == 0x12345u)) a.zlng[f] = 1000; return; }      /* development: staging only */
     /* ---- per tile: differences (kept in registers), width, bit count ------------------------------------------- */
-    unsigned long long dpk[ENC_TPT][3];                     /* the 3 differences of a tile row, 18 bits each at bits 0 / 21 / 42 (36 plain registers cost two waves per SIMD) */
+    unsigned long long dpk[ENC_TPT][3];                     /* the tokens of a tile row packed at the tile's width, first token on top (36 plain registers for the differences cost two waves per SIMD) */
     unsigned bits[ENC_TPT], meta[ENC_TPT];                  /* meta: need | tm << 8 | tn << 12 */
     bool gt = false;
     /* halfword offset of patch row n of the chunk's FIRST tile row (block-uniform): row base + token offset inside the row's first 4 staged words */
@@ -1213,14 +1213,21 @@ __global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8)))
 #pragma unroll
             for (int n = 1; n < 3; n++) { hi = max(max(hi, d[n][0]), max(d[n][1], d[n][2])); lo = min(min(lo, d[n][0]), min(d[n][1], d[n][2])); }
             const int mx = max(hi, -lo);
-#pragma unroll
-            for (int n = 0; n < 3; n++) {
-                const unsigned a0 = (unsigned)d[n][0] & 0x3FFFFu, a1 = (unsigned)d[n][1] & 0x3FFFFu, a2 = (unsigned)d[n][2] & 0x3FFFFu;
-                dpk[q][n] = (unsigned long long)(a0 | a1 << 21) | (unsigned long long)(a1 >> 11 | a2 << 10) << 32;
-            }
             if (mx > 65535) gt = true;
             unsigned need = (unsigned)bitlen((unsigned)mx);
             if (need == 16) need = 15;
+            {   /* the tile's rows as the emission wants them: a row's tokens side by side at the tile's own width, first token on top (round 5; 18-bit fields that the
+                 * emission unpacked and packed again before: 24 of its 93 VALU instructions per tile were that) */
+                const int width = need == 0 ? 0 : (need == 15 ? 17 : (int)need + 1);
+                const unsigned mask = (1u << width) - 1u;
+#pragma unroll
+                for (int n = 0; n < 3; n++) {
+                    const unsigned a0 = (unsigned)d[n][0] & mask, a1 = (unsigned)d[n][1] & mask, a2 = (unsigned)d[n][2] & mask;
+                    /* (three tokens, then the missing ones of a clipped tile shifted out again: no branch on tm) */
+                    const unsigned long long v = ((unsigned long long)a0 << (2 * width)) | ((unsigned long long)a1 << width) | (unsigned long long)a2;
+                    dpk[q][n] = v >> ((3 - tm) * width);
+                }
+            }
             bits[q] = tile_bits(1, need, tm * tn, container, nbits);
             meta[q] = need | (unsigned)tm << 8 | (unsigned)tn << 12;
         }
@@ -1264,7 +1271,6 @@ __global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8)))
         /* the (up to) three tokens of a tile row are ONE value of at most 3 x 18 = 54 bits (the first row carries the tile's width field
          * in front: <= 59); it goes through a 96-bit window (acc + the row): at most two words are completed per row */
         const int width = need == 0 ? 0 : (need == 15 ? 17 : (int)need + 1);
-        const unsigned mask = (1u << width) - 1;
         const int rowlen = tm * width;
         auto flush = [&]() {
             const unsigned word = (unsigned)(acc >> 32);
@@ -1274,9 +1280,7 @@ __global__ __launch_bounds__(ENC_TPB) __attribute__((amdgpu_waves_per_eu(7, 8)))
 #pragma unroll
         for (int n = 0; n < 3; n++) {
             if (n >= tn || (n > 0 && need == 0)) break;
-            unsigned long long v = 0;
-#pragma unroll
-            for (int m = 0; m < 3; m++) if (m < tm) v = (v << width) | (unsigned long long)((unsigned)(dpk[q][n] >> (21 * m)) & mask);
+            unsigned long long v = dpk[q][n];
             int L = rowlen;
             if (n == 0) { v |= (unsigned long long)need << rowlen; L += container; }
             /* fill < 32 pending bits in acc's top; append L <= 59 bits: first the part that fits the 64-bit accumulator */
