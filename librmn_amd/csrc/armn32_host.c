@@ -297,8 +297,95 @@ static int sign_mask_on_device(unsigned *d_smask, const uint32_t *z_s, int z_on_
 /* c_armn_uncompress32 with the result on the device; zstream: HOST memory (the chain of tile headers is walked on the host).  word_limit: words the
  * caller's buffer is known to hold (0: unknown -- no stream of c_armn_compress32 is longer than the field it replaces) */
 static int uncompress32_host_walk(float *d_fld, const unsigned char *zstream, size_t word_limit, int ni, int nj, int nk, int znbits);
+static int uncompress32_device_walk(float *d_fld, const uint32_t *z0, int z_on_device, size_t zwords, int ni, int nj);
+static int device_walk_wanted(int ni, int nj, size_t zwords);
+static __thread int t_quiet32;                /* a first attempt on a GUESSED length must not report a broken stream */
+/* words of [p, p + 4 want) that this process may READ, from p on: the readable mappings of /proc/self/maps that follow one another without a gap (mincore would
+ * also count PROT_NONE reservations -- glibc's arenas end in one).  c_armn_uncompress32 has no length argument; reading what is readable cannot fault, and
+ * nothing read behind the record's true end is ever used (the chains stop after the field's tiles).  ~0.1 ms per call */
+static size_t readable_words(const void *p, size_t want_words)
+{
+    FILE *f = fopen("/proc/self/maps", "r");
+    if (!f) return 0;
+    const uintptr_t a = (uintptr_t)p, want_end = a + 4 * want_words;
+    uintptr_t end = 0;                            /* end of the readable run that holds p (0: p not found yet) */
+    char line[512];
+    while (fgets(line, sizeof(line), f)) {
+        unsigned long lo, hi; char perms[8];
+        if (sscanf(line, "%lx-%lx %7s", &lo, &hi, perms) != 3) continue;
+        if (!end) { if (a >= lo && a < hi) { if (perms[0] != 'r') break; end = hi; } }
+        else if (lo == end && perms[0] == 'r') end = hi;
+        else break;                               /* (the file is sorted by address) */
+        if (end >= want_end) break;
+    }
+    fclose(f);
+    if (end <= a) return 0;
+    const size_t w = (size_t)(((end < want_end ? end : want_end) - a) / 4);
+    return w < want_words ? w : want_words;
+}
+/* words in front of the mantissa plane (header, sign runs, exponent plane, the length slot) and the mantissa width of a record in host memory; 0: not a record */
+static size_t record_prefix_words(const uint32_t *z, size_t bound, int *nbits_out)
+{
+    if (bound < 4 || (z[0] & 15u) != 5u) return 0;
+    const uint32_t codes = z[1] & 0xFF;
+    size_t cur = 2;
+    if ((codes & 0x30) == 0x20 || (codes & 0x30) == 0x30) { if (cur >= bound) return 0; cur += 1 + (size_t)(z[cur] >> 2); }
+    if ((codes & 0xC) == 0x08 || (codes & 0xC) == 0x0C) { if (cur >= bound) return 0; cur += 1 + (size_t)(z[cur] >> 2); }
+    *nbits_out = (int)((z[0] >> 10) & 31);
+    return cur + 1 < bound ? cur + 1 : 0;
+}
+/* bits the first `maxtiles` tiles of a parallelogram plane take (host words, at most max_bits of them readable); 0: the walk left the readable part */
+static uint64_t plane_head_bits(const uint32_t *z, int ni, int nj, int nbits, size_t maxtiles, uint64_t max_bits, size_t *tiles_out)
+{
+    uint64_t pos = 0;
+    if (max_bits < 64) return 0;
+    const int container = (int)br32_get(z, &pos, 3);
+    pos += (uint64_t)(ni + nj - 1) * (uint64_t)nbits;
+    const int ntx = (ni - 1 + 2) / 3, nty = (nj - 1 + 2) / 3;
+    size_t ntiles = (size_t)ntx * nty, t = 0;
+    if (ntiles > maxtiles) ntiles = maxtiles;
+    int tx = 0, ty = 0;
+    while (t < ntiles) {
+        if (pos + (uint64_t)container + 64 > max_bits) return 0;
+        const int tn = nj - (1 + 3 * ty) < 3 ? nj - (1 + 3 * ty) : 3, tm = ni - (1 + 3 * tx) < 3 ? ni - (1 + 3 * tx) : 3;
+        uint64_t p2 = pos;
+        const int need = (int)br32_get(z, &p2, container);
+        pos += (uint64_t)container + (need ? (uint64_t)(tm * tn) * (uint64_t)(need + 1) : 0);
+        t++;
+        if (++tx == ntx) { tx = 0; ty++; }
+    }
+    *tiles_out = t;
+    return pos;
+}
 int c_armn_uncompress32_dev(float *d_fld, const unsigned char *zstream, int ni, int nj, int nk, int znbits)
 {
+    /* (round 5) the record's end is not an argument and cannot be read from the record (its mantissa length slot holds the sign stream's length, armn_compress_32.c:237).
+     * Rounds 3 - 4 found it by walking both tile chains on host threads (10 - 12 ms of a 7200 x 3601 field's 18).  Now: whatever of the largest possible record
+     * (no record is longer than its field) is READABLE behind the pointer may be read; a first attempt uploads the sub-streams whose lengths the record states and
+     * a mantissa plane of ESTIMATED length (its first tiles walked on the host, extrapolated, + 12 %) and resolves the chains on the device (the forms of c_armn_uncompress32_lng); a chain that leaves that piece
+     * sends the rest up for a second attempt; planes the device forms leave open and small fields take the host walk as before */
+    if (!getenv("EZHIP_A32_HOST_END") && need_dev32("c_armn_uncompress32") == 0 && ni >= 16 && nj >= 16) {
+        const size_t n = (size_t)ni * nj, bound = readable_words(zstream, n + 64);
+        int nbits = 0;
+        const size_t pre = bound >= 4 ? record_prefix_words((const uint32_t *)zstream, bound, &nbits) : 0;
+        if (pre && nbits >= 1 && nbits <= 23 && device_walk_wanted(ni, nj, bound)) {
+            /* the mantissa plane's length from its first 98 304 tiles (~0.3 ms on the host: a field's tiles are much alike), + 12 % */
+            size_t seen = 0;
+            const size_t ntiles = (size_t)((ni - 1 + 2) / 3) * (size_t)((nj - 1 + 2) / 3);
+            const uint64_t hb = plane_head_bits((const uint32_t *)zstream + pre, ni, nj, nbits, 98304, 32ull * (bound - pre), &seen);
+            size_t guess = bound;
+            if (hb && seen) {
+                const double est = (double)hb / (double)seen * (double)ntiles * 1.12 / 32.0;
+                if (est < (double)(bound - pre)) guess = pre + (size_t)est + 16384;
+            }
+            if (guess > bound) guess = bound;
+            t_quiet32 = guess < bound;
+            int rc = uncompress32_device_walk(d_fld, (const uint32_t *)zstream, 0, guess, ni, nj);
+            t_quiet32 = 0;
+            if (rc == -1 && guess < bound) rc = uncompress32_device_walk(d_fld, (const uint32_t *)zstream, 0, bound, ni, nj);
+            if (rc != 1) return rc;
+        }
+    }
     return uncompress32_host_walk(d_fld, zstream, 0, ni, nj, nk, znbits);
 }
 static int uncompress32_host_walk(float *d_fld, const unsigned char *zstream, size_t word_limit, int ni, int nj, int nk, int znbits)
@@ -401,8 +488,6 @@ static int rec_word(const uint32_t *z0, int z_on_device, size_t idx, uint32_t *o
     if (!z_on_device) { *out = z0[idx]; return 0; }
     return (ezhip_d2h(out, z0 + idx, 4) || ezhip_sync()) ? -1 : 0;
 }
-static int uncompress32_device_walk(float *d_fld, const uint32_t *z0, int z_on_device, size_t zwords, int ni, int nj);
-
 /* a plane in HBM: chain and tiles on the device; when the parallel forms leave the chain unresolved -- typically the exponent plane of a smooth field, whose long
  * runs of empty tiles keep walks of different phase apart for good -- THIS plane's chain is walked on the host (zero runs at once) and only its positions go up */
 static int plane_on_device(int *d_plane, const uint32_t *z, int z_on_device, size_t words, int ni, int nj, int nbits, int wide, int which)
@@ -510,7 +595,7 @@ static int uncompress32_device_walk(float *d_fld, const uint32_t *z0, int z_on_d
     if (run_s) pthread_join(th_s, NULL);
     if (have_s && rj.rc) bad = 1;
     if (!bad && unresolved) { rc = 1; goto out; }
-    if (bad) { fprintf(stderr, "<c_armn_uncompress32> broken stream (a tile chain leaves the record)\n"); goto out; }
+    if (bad) { if (!t_quiet32) fprintf(stderr, "<c_armn_uncompress32> broken stream (a tile chain leaves the record)\n"); goto out; }
     if (have_s && rle_host && (ezhip_h2d(d_smask, rj.mask, 4 * (n / 32 + 1)) || ezhip_sync())) goto out;
     if (packhip_a32_combine(d_fld, d_expo, d_mant, d_smask, n, nbits, exp_min, code_signe, code_expo != 0)) goto out;
     if (ezhip_sync()) goto out;
@@ -519,7 +604,7 @@ out:
     free(rj.mask);
     return rc;
 broken:
-    fprintf(stderr, "<c_armn_uncompress32> broken stream (a sub-stream length exceeds the record)\n");
+    if (!t_quiet32) fprintf(stderr, "<c_armn_uncompress32> broken stream (a sub-stream length exceeds the record)\n");
     return -1;
 }
 

@@ -1,8 +1,3 @@
-python -m pytest tests/test_gpu_packers.py tests/test_known_answers.py -x -q -m gpu 2>&1 | tail -2
-python tools/fuzz_armn.py 60 5 2>&1 | tail -1
-python tools/fuzz_armn_wide.py 100 3 2>&1 | tail -1
-export EZHIP_LIBRARY=$PWD/devlibs/librmn_ez_hip_dev.so
-bash tools/pmc_enc_phases.sh 2>&1 | tail -6
-python tools/probe_enc_batch.py 0 32 3 2>/dev/null
-unset EZHIP_LIBRARY
-bash tools/prof_cmd.sh r5enc3 tools/probe_enc_batch.py 0 > /dev/null 2>&1; head -3 gpurun_out/r5enc3/summary.txt
+python -m pytest tests/test_gpu_packers.py -x -q -m gpu -k "armn32 or a32 or uncompress32 or compress32" 2>&1 | tail -2
+python tools/probe_a32.py 2>&1 | grep -v amdgpu.ids | grep "zlng\|host walk \|default"
+python tools/fuzz_armn32.py 80 13 2>&1 | tail -1
