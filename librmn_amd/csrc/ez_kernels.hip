@@ -3602,7 +3602,10 @@ __global__ __launch_bounds__(256) void k_pts_special(ezhip_pts_plan p, float *__
         if (zone == PZ_POLE_S || zone == PZ_POLE_N) { zout[o] = pv[zone == PZ_POLE_S ? 1 : 0]; continue; }      /* (listed when the pole values came from the launch in front: pv_out) */
         if (p.vector_mode) { Z.prow_n = p.pole_row_n; Z.prow_s = p.pole_row_s; }
         else { Z.pole_n = pv[0]; Z.pole_s = pv[1]; }
-        zout[o] = strip_point(p, Z, zone == PZ_STRIP_N, px, py);
+        if (p.degree == 3 && p.irregular) {      /* (inline, as in special2c_body) */
+            const int north = zone == PZ_STRIP_N, j1s = north ? p.j2 - 2 : p.j1 - 1;
+            zout[o] = p_irgdint_3_wnnc(Z, px, py, p.ax, north ? p.ay4_n : p.ay4_s, p.ni, j1s, j1s + 3, p.wrap);
+        } else zout[o] = strip_point(p, Z, zone == PZ_STRIP_N, px, py);
     }
 }
 
@@ -3663,7 +3666,12 @@ __device__ __forceinline__ void special2c_body(const ezhip_pts_plan &p, float *_
         if (zone == PZ_REINTERP) mine = gdinterp_point(p, Z, p.degre_extrap, px, py);
         else {
             Z.prow_n = comp ? prow_n2 : p.pole_row_n; Z.prow_s = comp ? prow_s2 : p.pole_row_s;
-            mine = strip_point(p, Z, zone == PZ_STRIP_N, px, py);
+            /* (the bicubic strip of an irregular source -- cfg3's case -- inline: through the out-of-line strip_point this launch of ONE thread block spent most of
+             * its 10 us fetching instructions and passing arguments through scratch) */
+            if (p.degree == 3 && p.irregular) {
+                const int north = zone == PZ_STRIP_N, j1s = north ? p.j2 - 2 : p.j1 - 1;
+                mine = p_irgdint_3_wnnc(Z, px, py, p.ax, north ? p.ay4_n : p.ay4_s, p.ni, j1s, j1s + 3, p.wrap);
+            } else mine = strip_point(p, Z, zone == PZ_STRIP_N, px, py);
         }
         const float other = __shfl_xor(mine, 1, 64);                           /* (both lanes of a pair are in the loop together: cnt2 is even, the stride too) */
         float a = comp ? other : mine, b = comp ? mine : other;

@@ -1,3 +1,3 @@
-python -m pytest tests/test_gpu_packers.py -x -q -m gpu -k "armn32 or a32 or uncompress32 or compress32" 2>&1 | tail -2
-python tools/probe_a32.py 2>&1 | grep -v amdgpu.ids | grep "zlng\|host walk \|default"
-python tools/fuzz_armn32.py 80 13 2>&1 | tail -1
+python -m pytest tests/test_gpu_interp.py -x -q -m gpu 2>&1 | tail -2
+bash tools/prof_cmd.sh r5sp tools/probe_cfg3.py > /dev/null 2>&1; grep "special\|k_uvt<" gpurun_out/r5sp/summary.txt
+bash tools/prof_cmd.sh r5sp2 tools/probe_cfg3_scalar.py > /dev/null 2>&1; grep "special\|k_st<" gpurun_out/r5sp2/summary.txt
