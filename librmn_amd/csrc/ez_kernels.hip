@@ -3578,13 +3578,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? 4 :
 /* (k_uvt as a pipeline -- persistent blocks with two staging buffers, the next tile's window and streams in flight while a tile is computed -- was built twice
  * and measured slower both times: with LDS-DMA staging (the window as separate u / v planes: twice the LDS read instructions) 111 us per cfg3 pair against 90;
  * with the next window held in registers (135 - 155 VGPRs, three waves per SIMD) 96 - 104 us for the kernel against 76.  profiles/r04_experiments.txt.) */
+/* The out-of-line strip / re-interpolation code takes the plan BY REFERENCE: a kernel that hands its by-value argument on copies all 400 bytes of it into every
+ * thread's scratch first (24 scratch_store_dwordx4 per thread: k_pts_special's 256 blocks wrote 25 MB per launch, half its 10 us).  The plan already lies in
+ * memory: the kernel-argument segment, first argument at offset 0 */
+#define PLAN_IN_KERNARG() (*(const ezhip_pts_plan *)__builtin_amdgcn_kernarg_segment_ptr())
 /* Special points only (a fraction of a percent of a global target): polar strips on the virtual 4-row strip,
  * extrapolation points re-interpolated with degre_extrap. */
-__global__ __launch_bounds__(256) void k_pts_special(ezhip_pts_plan p, float *__restrict__ zout, const float *__restrict__ zin,
+__global__ __launch_bounds__(256) void k_pts_special(ezhip_pts_plan p_arg, float *__restrict__ zout, const float *__restrict__ zin,
                                                      const float *__restrict__ xs, const float *__restrict__ ys,
                                                      const int *__restrict__ special_list, const unsigned *__restrict__ special_count,
                                                      unsigned *__restrict__ next_count, int nfields = 1, size_t in_stride = 0, size_t out_stride = 0)
 {
+    const ezhip_pts_plan &p = PLAN_IN_KERNARG();
     if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;          /* the other counter of the pair: the next launch's */
     const unsigned cnt = *special_count;
     const unsigned total = cnt * (unsigned)nfields;                    /* (a batch: every listed point once per field, pole values of field f in polevals[2 f ..]) */
@@ -3611,13 +3616,14 @@ __global__ __launch_bounds__(256) void k_pts_special(ezhip_pts_plan p, float *__
 
 /* the special points of a wind pair: both components, then the pair's wind matrix, in one launch (two k_pts_special launches and a
  * list pass cost 2 x 8 + 4 us per cfg3 pair, each bound by the latency of its few dependent gathers) */
-__global__ __launch_bounds__(256) void k_pts_special2(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+__global__ __launch_bounds__(256) void k_pts_special2(ezhip_pts_plan p_arg, float *__restrict__ zout1, float *__restrict__ zout2,
                                                       const float *__restrict__ zin1, const float *__restrict__ zin2,
                                                       const float *__restrict__ prow_n2, const float *__restrict__ prow_s2,
                                                       const float *__restrict__ xs, const float *__restrict__ ys,
                                                       const int *__restrict__ special_list, const unsigned *__restrict__ special_count,
                                                       unsigned *__restrict__ next_count)
 {
+    const ezhip_pts_plan &p = PLAN_IN_KERNARG();
     if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
     const unsigned cnt = *special_count;
     for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
@@ -3679,11 +3685,11 @@ __device__ __forceinline__ void special2c_body(const ezhip_pts_plan &p, float *_
         if (comp) zout2[o] = b; else zout1[o] = a;
     }
 }
-__global__ __launch_bounds__(256) void k_pts_special2c(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+__global__ __launch_bounds__(256) void k_pts_special2c(ezhip_pts_plan p_arg, float *__restrict__ zout1, float *__restrict__ zout2,
                                                        const float *__restrict__ zin1, const float *__restrict__ zin2,
                                                        const float *__restrict__ prow_n2, const float *__restrict__ prow_s2)
 {
-    special2c_body(p, zout1, zout2, zin1, zin2, prow_n2, prow_s2, blockIdx.x, gridDim.x);
+    special2c_body(PLAN_IN_KERNARG(), zout1, zout2, zin1, zin2, prow_n2, prow_s2, blockIdx.x, gridDim.x);
 }
 __global__ __launch_bounds__(256) void k_spec_gather(int *__restrict__ list_out, float *__restrict__ x_out, float *__restrict__ y_out,
                                                      const int *__restrict__ list_in, const float *__restrict__ xs, const float *__restrict__ ys, unsigned cnt)
