@@ -374,12 +374,17 @@ static void h_mxm3(const float *a, const float *b, float *c, int n)
 static void h_rotate(float *lon_o, float *lat_o, const float *lon, const float *lat, int n, const float *xg4, int forward)
 {
     float r[9], ri[9];
-    float *cart = (float *)malloc(sizeof(float) * 3 * (size_t)n), *rot = (float *)malloc(sizeof(float) * 3 * (size_t)n);
     h_crot(r, ri, xg4[1], xg4[0], xg4[3], xg4[2]);
-    h_lac(cart, lon, lat, n);
-    h_mxm3(forward ? r : ri, cart, rot, n);
-    h_cal(lon_o, lat_o, rot, n);
-    free(cart); free(rot);
+    /* in pieces of 2048 points through two stack buffers: as whole-array temporaries (2 x 12 bytes per point from malloc, fresh pages every call) the first touch of
+     * those pages -- serialised in the kernel whatever the number of threads -- was most of the 60 ms the set's first call spent locating cfg3's 8 M points */
+    enum { PIECE = 2048 };
+    float cart[3 * PIECE], rot[3 * PIECE];
+    for (int o = 0; o < n; o += PIECE) {
+        const int c = n - o < PIECE ? n - o : PIECE;
+        h_lac(cart, lon + o, lat + o, c);
+        h_mxm3(forward ? r : ri, cart, rot, c);
+        h_cal(lon_o + o, lat_o + o, rot, c);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -690,20 +695,35 @@ static int h_locate(const ezh_grid *g, float *x, float *y, const float *lat, flo
 
 /* h_locate over many points: slices on host threads (the point loops are independent; first-call work such as the
  * Yin-Yang point lists locates 3 x 25.9 M points) */
-typedef struct { const ezh_grid *g; float *x, *y; const float *lat; float *lon; int n, rc; } locate_job;
-static void *locate_worker(void *p) { locate_job *j = (locate_job *)p; j->rc = h_locate(j->g, j->x, j->y, j->lat, j->lon, j->n); return NULL; }
-static int h_locate_mt(const ezh_grid *g, float *x, float *y, const float *lat, float *lon, int n)
+typedef struct { const ezh_grid *g; float *x, *y; const float *lat; float *lon; int n, rc; const float *lat1d, *lon1d; int ni_t; size_t first; } locate_job;
+static void *locate_worker(void *p)
+{
+    locate_job *j = (locate_job *)p;
+    if (j->lat1d) {      /* a separable target: the slice's latitudes and longitudes are written here, by the thread that reads them (first touch of fresh pages in parallel) */
+        float *la = (float *)j->lat;
+        for (int k = 0; k < j->n; k++) { const size_t q = j->first + (size_t)k; la[k] = j->lat1d[q / (size_t)j->ni_t]; j->lon[k] = j->lon1d[q % (size_t)j->ni_t]; }
+    }
+    j->rc = h_locate(j->g, j->x, j->y, j->lat, j->lon, j->n);
+    return NULL;
+}
+static int h_locate_mt2(const ezh_grid *g, float *x, float *y, const float *lat, float *lon, int n, const float *lat1d, const float *lon1d, int ni_t);
+static int h_locate_mt(const ezh_grid *g, float *x, float *y, const float *lat, float *lon, int n) { return h_locate_mt2(g, x, y, lat, lon, n, NULL, NULL, 0); }
+/* lat1d / lon1d != NULL: lat[] and lon[] are OUTPUT too -- the points are the rows of a separable ni_t-wide target, filled slice by slice by the workers */
+static int h_locate_mt2(const ezh_grid *g, float *x, float *y, const float *lat, float *lon, int n, const float *lat1d, const float *lon1d, int ni_t)
 {
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-    int nt = (int)(ncpu > 32 ? 32 : ncpu);
-    if (n < 400000 || nt < 2) return h_locate(g, x, y, lat, lon, n);
-    pthread_t th[32]; locate_job job[32];
+    /* up to 128 threads, at least 32 768 points each (round 5: 32 threads took 61 ms for cfg3's 8 M points on a 256-thread host -- the set's first call) */
+    int nt = (int)(ncpu > 128 ? 128 : ncpu);
+    if (getenv("EZHIP_LOCATE_THREADS")) { const int v = atoi(getenv("EZHIP_LOCATE_THREADS")); if (v >= 1 && v <= 128) nt = v; }
+    if (nt > n / 32768) nt = n / 32768;
+    if (n < 400000 || nt < 2) { locate_job one = {g, x, y, lat, lon, n, 0, lat1d, lon1d, ni_t, 0}; locate_worker(&one); return one.rc; }
+    pthread_t th[128]; locate_job job[128];
     int per = (n + nt - 1) / nt, used = 0, rc = 0;
     for (int t = 0; t < nt; t++) {
         int o = t * per, c = n - o < per ? n - o : per;
         if (c <= 0) break;
-        job[t] = (locate_job){g, x + o, y + o, lat + o, lon + o, c, 0};
-        if (pthread_create(&th[t], NULL, locate_worker, &job[t])) { job[t].rc = h_locate(g, x + o, y + o, lat + o, lon + o, c); th[t] = 0; }
+        job[t] = (locate_job){g, x + o, y + o, lat + o, lon + o, c, 0, lat1d, lon1d, ni_t, (size_t)o};
+        if (pthread_create(&th[t], NULL, locate_worker, &job[t])) { locate_worker(&job[t]); th[t] = 0; }
         used = t + 1;
     }
     for (int t = 0; t < used; t++) { if (th[t]) pthread_join(th[t], NULL); if (job[t].rc) rc = job[t].rc; }
@@ -2063,10 +2083,8 @@ static int ensure_points(ezh_set *s)
         float *lat = (float *)malloc(sizeof(float) * n), *lon = (float *)malloc(sizeof(float) * n);
         if (!hx || !hy || !lat || !lon) rc = -1;
         else {
-            if (go->separable) {
-                for (int j = 0; j < go->nj; j++) for (int i = 0; i < go->ni; i++) { lat[(size_t)j * go->ni + i] = go->lat1d[j]; lon[(size_t)j * go->ni + i] = go->lon1d[i]; }
-            } else { memcpy(lat, go->lat2d, sizeof(float) * n); memcpy(lon, go->lon2d, sizeof(float) * n); }
-            rc = h_locate_mt(gi, hx, hy, lat, lon, (int)n);
+            if (go->separable) rc = h_locate_mt2(gi, hx, hy, lat, lon, (int)n, go->lat1d, go->lon1d, go->ni);
+            else { memcpy(lat, go->lat2d, sizeof(float) * n); memcpy(lon, go->lon2d, sizeof(float) * n); rc = h_locate_mt(gi, hx, hy, lat, lon, (int)n); }
             if (!rc) rc = ezhip_h2d(dx, hx, sizeof(float) * n) || ezhip_h2d(dy, hy, sizeof(float) * n) || ezhip_sync();
         }
         free(lat); free(lon);
