@@ -25,7 +25,7 @@ static int need_dev32(const char *who)
     return -1;
 }
 /* per-thread grow-only device workspaces */
-static __thread struct { void *p; size_t cap; } t_w32[10];
+static __thread struct { void *p; size_t cap; } t_w32[14];
 static void *w32(int slot, size_t bytes)
 {
     if (t_w32[slot].cap < bytes) {
@@ -36,7 +36,7 @@ static void *w32(int slot, size_t bytes)
     return t_w32[slot].p;
 }
 
-void ezh_armn32_thread_release(void) { for (int k = 0; k < 10; k++) { ezhip_free(t_w32[k].p); t_w32[k].p = NULL; t_w32[k].cap = 0; } }
+void ezh_armn32_thread_release(void) { for (int k = 0; k < 14; k++) { ezhip_free(t_w32[k].p); t_w32[k].p = NULL; t_w32[k].cap = 0; } }
 
 /* ---- MSB-first bit stream on host words: the `stuff` / `extract` rules (include/bitPacking.h:59-139) ---- */
 typedef struct { uint32_t *z; uint64_t pos; } bitw32;              /* over a zeroed buffer */
@@ -137,6 +137,7 @@ static int rle_decode(uint32_t *mask, const uint32_t *z, int npts, uint64_t max_
 
 static int float_width(uint32_t v) { union { float f; int32_t i; } r; r.f = (float)v; return v ? (r.i >> 23) - 126 : 0; }
 
+static void *rle_grow(int slot, size_t bytes) { return w32(10 + slot, bytes); }      /* the run arrays of the device run-length coder: slots 10 .. 13 */
 /* c_armn_compress32 on device data.  d_z: device buffer of at least ni*nj*znbits/8 + 64 bytes; returns the stream's byte count or -1 */
 int c_armn_compress32_dev(void *d_z, const float *d_fld, int ni, int nj, int nk, int znbits)
 {
@@ -162,7 +163,19 @@ int c_armn_compress32_dev(void *d_z, const float *d_fld, int ni, int nj, int nk,
     uint32_t lng_signe = 0, code_signe, code_expo = 0;
     /* sign stream (:148-180) */
     if (meme_signe) code_signe = (st[0] >> 31) ? 0x10 : 0x00;
-    else {
+    else if (!getenv("EZHIP_A32_RLE_ENC_HOST")) {
+        /* the run-length coder on the device (round 5: a prefix scan of seven-state maps, armn32_kernels.hip k_re_*): the mask stays in HBM, 8 bytes come down */
+        const size_t zs_bytes = 4 * (n / 28 + 8);
+        unsigned *d_zs = (unsigned *)w32(8, zs_bytes);
+        void *d_wk = w32(9, packhip_a32_rle_enc_work_bytes(n));
+        unsigned long long bits_s = 0;
+        if (!d_zs || !d_wk || ezhip_memset(d_zs, 0, zs_bytes) || packhip_a32_rle_encode(d_zs, d_smask, n, d_wk, rle_grow, &bits_s)) return -1;
+        lng_signe = zlng_of_bits(bits_s);
+        code_signe = 0x20;
+        if (lng_signe % 4) lng_signe += 4 - lng_signe % 4;
+        if ((size_t)lng_signe > zs_bytes || ezhip_h2d(z8 + off, &lng_signe, 4) || ezhip_d2d(z8 + off + 4, d_zs, lng_signe) || ezhip_sync()) return -1;
+        off += 4 + lng_signe;
+    } else {
         const size_t mw = n / 32 + 2;
         uint32_t *mask = (uint32_t *)calloc(mw, 4), *zs = (uint32_t *)calloc(n / 16 + 64, 4);      /* the RLE needs at most 8 bits per 7 points */
         if (!mask || !zs || ezhip_d2h(mask, d_smask, 4 * (n / 32 + 1)) || ezhip_sync()) { free(mask); free(zs); return -1; }

@@ -11,7 +11,7 @@
  *   decode: the chain of tile headers is walked on the host (a tile's position is known only once every earlier width field
  *           has been read; armn32_host.c), then k_pg_dec_tiles / k_pg_dec_prefix rebuild the differences and a 2-D prefix sum
  *           (row scans, banded column scans) undoes the predictor, exactly like the 16-bit decoder does.
- * The sign plane's run-length coder (pack1bitRLE :827-901) is a sequential state machine over 1 bit per point: host code.
+ * The sign plane's run-length coder (pack1bitRLE :827-901) is a state machine over 1 bit per point with seven states: a prefix scan of state maps (k_re_*, below).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -492,6 +492,319 @@ extern "C" int packhip_a32_rle_decode(unsigned *d_mask, const unsigned *d_z, siz
     hipLaunchKernelGGL(k_rle_emit, dim3(nblk), dim3(256), 0, STREAM, d_mask, bpre, d_z, nbytes, (unsigned)npts);
     if (chk32("k_rle")) return -1;
     if (hipMemcpyAsync(h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, STREAM) != hipSuccess || hipStreamSynchronize(STREAM) != hipSuccess) return -1;
+    return 0;
+}
+
+/* ---- the sign run lengths the other way: pack1bitRLE (armn_compress_32.c:827-901) on the device (round 5) -------------------------------------------------------
+ * The coder is a state machine over positions, but its state is small.  At a position f it looks at the run of equal signs that STARTS at f (length L up to the
+ * next sign change): L < 8 -> one RAW token (flag 0 + the next seven signs, whatever runs they belong to), next position f + 7; otherwise count tokens that end
+ * exactly at the run's end E -- {1, sign, 62}, then 0xFF (255 points) while more than 256 remain, then {1, sign, 62} while 63 or more remain, then {1, sign, rem} --
+ * except that a last remainder of 1 .. 7 points goes out as a RAW token at E - rem, which reaches 7 - rem points into the following runs.  So the only thing a run
+ * needs to know from everything in front of it is HOW MANY OF ITS FIRST POINTS a RAW token has already taken: d in 0 .. 6 (a run shorter than d is swallowed and
+ * hands d - length on).  Every run is a map {0..6} -> {0..6}; the entry state of every run is a prefix "sum" of those maps under composition (21 bits per map), and
+ * with it the run's tokens -- all 8 bits wide, only the field's very last one may be a shorter RAW -- follow in closed form: a second prefix sum gives their byte
+ * positions.  Kernels: change bits per mask word -> run starts (scan 1) -> maps -> entry states (scan 2, composition) -> token counts -> byte offsets (scan 3) ->
+ * one thread per stream word writes its four tokens.  The host did this walk on a downloaded mask: 1 - 3.4 ms per 7200 x 3601 field of both signs. */
+#define RE_ITEMS 8
+__device__ __forceinline__ unsigned re_block_excl_scan(unsigned v, unsigned *sh, unsigned &total)      /* 256 threads; returns the exclusive prefix of v */
+{
+    const unsigned t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (unsigned o = 1; o < 256; o <<= 1) {
+        unsigned w = sh[t];
+        if (t >= o) w += sh[t - o];
+        __syncthreads();
+        sh[t] = w;
+        __syncthreads();
+    }
+    total = sh[255];
+    const unsigned r = t ? sh[t - 1] : 0u;
+    __syncthreads();
+    return r;
+}
+/* exclusive scan of nblk block sums on one block (in place: agg[k] := sum of agg[0 .. k - 1]); total[0] := the sum of all */
+__global__ __launch_bounds__(1024) void k_re_scan_sums(unsigned *agg, unsigned nblk, unsigned *total)
+{
+    __shared__ unsigned sh[1024];
+    __shared__ unsigned carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (unsigned base = 0; base < nblk; base += 1024) {
+        const unsigned k = base + threadIdx.x;
+        const unsigned v = k < nblk ? agg[k] : 0u;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (unsigned o = 1; o < 1024; o <<= 1) {
+            unsigned w = sh[threadIdx.x];
+            if (threadIdx.x >= o) w += sh[threadIdx.x - o];
+            __syncthreads();
+            sh[threadIdx.x] = w;
+            __syncthreads();
+        }
+        const unsigned c = carry;
+        if (k < nblk) agg[k] = c + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = carry;
+}
+/* bit i of the result: point 32 w + i starts a new run (its sign differs from the point in front of it); point 0 never does */
+__device__ __forceinline__ unsigned re_change_bits(const unsigned *mask, size_t w, size_t nwords, unsigned npts)
+{
+    if (w >= nwords) return 0u;
+    const unsigned m = mask[w], prev = w ? mask[w - 1] >> 31 : (m & 1u);
+    unsigned cb = m ^ ((m << 1) | prev);
+    const size_t base = 32 * w;
+    if (base + 32 > npts) cb &= (npts > base) ? (0xFFFFFFFFu >> (32u - (unsigned)(npts - base))) : 0u;
+    return cb;
+}
+__global__ __launch_bounds__(256) void k_re_count(unsigned *bagg, const unsigned *mask, size_t nwords, unsigned npts)
+{
+    __shared__ unsigned sh[256];
+    const size_t w0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * RE_ITEMS;
+    unsigned c = 0;
+#pragma unroll
+    for (int q = 0; q < RE_ITEMS; q++) c += __popc(re_change_bits(mask, w0 + q, nwords, npts));
+    unsigned tot;
+    re_block_excl_scan(c, sh, tot);
+    if (threadIdx.x == 0) bagg[blockIdx.x] = tot;
+}
+/* starts[k] = first point of run k (starts[0] = 0, starts[nruns] = npts) */
+__global__ __launch_bounds__(256) void k_re_starts(unsigned *starts, const unsigned *bpre, const unsigned *mask, size_t nwords, unsigned npts, const unsigned *nchanges)
+{
+    __shared__ unsigned sh[256];
+    const size_t w0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * RE_ITEMS;
+    unsigned cb[RE_ITEMS], c = 0;
+#pragma unroll
+    for (int q = 0; q < RE_ITEMS; q++) { cb[q] = re_change_bits(mask, w0 + q, nwords, npts); c += __popc(cb[q]); }
+    unsigned tot;
+    unsigned k = 1u + bpre[blockIdx.x] + re_block_excl_scan(c, sh, tot);
+#pragma unroll
+    for (int q = 0; q < RE_ITEMS; q++) {
+        unsigned b = cb[q];
+        while (b) { const unsigned i = __ffs(b) - 1u; b &= b - 1u; starts[k++] = (unsigned)(32 * (w0 + q)) + i; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { starts[0] = 0u; starts[nchanges[0] + 1u] = npts; }
+}
+/* what a run of `len` points does when its first d points are already taken: returns the state it hands on; ntok: tokens it emits */
+__device__ __forceinline__ unsigned re_run(unsigned len, unsigned d, unsigned &ntok)
+{
+    if (d >= len) { ntok = 0; return d - len; }
+    const unsigned L = len - d;
+    if (L < 8u) { ntok = 1; return 7u - L; }
+    if (L <= 62u) { ntok = 1; return 0u; }
+    const unsigned rem0 = L - 62u, n255 = rem0 > 256u ? (rem0 - 256u + 254u) / 255u : 0u;
+    unsigned rem = rem0 - 255u * n255, n62 = 0;
+    if (rem >= 63u) { n62 = (rem - 63u) / 62u + 1u; rem -= 62u * n62; }
+    ntok = 1u + n255 + n62 + (rem ? 1u : 0u);
+    return (rem >= 1u && rem <= 7u) ? 7u - rem : 0u;
+}
+__device__ __forceinline__ unsigned re_map_of(unsigned len)      /* seven 3-bit states: entry d -> exit */
+{
+    unsigned m = 0, nt;
+#pragma unroll
+    for (unsigned d = 0; d < 7u; d++) m |= re_run(len, d, nt) << (3u * d);
+    return m;
+}
+#define RE_ID_MAP 0x1AC688u                               /* d -> d: 0 | 1 << 3 | 2 << 6 | ... | 6 << 18 */
+__device__ __forceinline__ unsigned re_compose(unsigned first, unsigned then)      /* d -> then[first[d]] */
+{
+    unsigned m = 0;
+#pragma unroll
+    for (unsigned d = 0; d < 7u; d++) m |= ((then >> (3u * ((first >> (3u * d)) & 7u))) & 7u) << (3u * d);
+    return m;
+}
+__device__ __forceinline__ unsigned re_block_excl_scan_maps(unsigned v, unsigned *sh, unsigned &total)
+{
+    const unsigned t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (unsigned o = 1; o < 256; o <<= 1) {
+        unsigned w = sh[t];
+        if (t >= o) w = re_compose(sh[t - o], w);
+        __syncthreads();
+        sh[t] = w;
+        __syncthreads();
+    }
+    total = sh[255];
+    const unsigned r = t ? sh[t - 1] : RE_ID_MAP;
+    __syncthreads();
+    return r;
+}
+#define RE_RUNS 4                                          /* runs per thread */
+__global__ __launch_bounds__(256) void k_re_maps(unsigned *bmap, const unsigned *starts, unsigned nruns)
+{
+    __shared__ unsigned sh[256];
+    const unsigned k0 = (blockIdx.x * 256u + threadIdx.x) * RE_RUNS;
+    unsigned m = RE_ID_MAP;
+#pragma unroll
+    for (unsigned q = 0; q < RE_RUNS; q++) if (k0 + q < nruns) m = re_compose(m, re_map_of(starts[k0 + q + 1] - starts[k0 + q]));
+    unsigned tot;
+    re_block_excl_scan_maps(m, sh, tot);
+    if (threadIdx.x == 0) bmap[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(1024) void k_re_scan_maps(unsigned *bmap, unsigned nblk)      /* in place: bmap[k] := composition of the blocks in front of k */
+{
+    __shared__ unsigned sh[1024];
+    __shared__ unsigned carry;
+    if (threadIdx.x == 0) carry = RE_ID_MAP;
+    __syncthreads();
+    for (unsigned base = 0; base < nblk; base += 1024) {
+        const unsigned k = base + threadIdx.x;
+        const unsigned v = k < nblk ? bmap[k] : RE_ID_MAP;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (unsigned o = 1; o < 1024; o <<= 1) {
+            unsigned w = sh[threadIdx.x];
+            if (threadIdx.x >= o) w = re_compose(sh[threadIdx.x - o], w);
+            __syncthreads();
+            sh[threadIdx.x] = w;
+            __syncthreads();
+        }
+        const unsigned c = carry;
+        if (k < nblk) bmap[k] = re_compose(c, threadIdx.x ? sh[threadIdx.x - 1] : RE_ID_MAP);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = re_compose(c, sh[1023]);
+        __syncthreads();
+    }
+}
+/* entry state of every run (packed with its token count: state << 28 | ntok) and the blocks' token sums */
+__global__ __launch_bounds__(256) void k_re_states(unsigned *runinfo, unsigned *bsum, const unsigned *bmap, const unsigned *starts, unsigned nruns)
+{
+    __shared__ unsigned sh[256];
+    const unsigned k0 = (blockIdx.x * 256u + threadIdx.x) * RE_RUNS;
+    unsigned len[RE_RUNS], m = RE_ID_MAP;
+#pragma unroll
+    for (unsigned q = 0; q < RE_RUNS; q++) { len[q] = k0 + q < nruns ? starts[k0 + q + 1] - starts[k0 + q] : 0u; if (k0 + q < nruns) m = re_compose(m, re_map_of(len[q])); }
+    unsigned tot;
+    const unsigned pre = re_compose(bmap[blockIdx.x], re_block_excl_scan_maps(m, sh, tot));
+    unsigned d = pre & 7u, nsum = 0;                       /* the coder starts in state 0 */
+#pragma unroll
+    for (unsigned q = 0; q < RE_RUNS; q++) {
+        if (k0 + q >= nruns) break;
+        unsigned nt;
+        const unsigned dn = re_run(len[q], d, nt);
+        runinfo[k0 + q] = d << 28 | nt;
+        nsum += nt; d = dn;
+    }
+    unsigned tt;
+    re_block_excl_scan(nsum, sh, tt);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tt;
+}
+/* first token (byte) index of every run */
+__global__ __launch_bounds__(256) void k_re_offsets(unsigned *tokoff, const unsigned *bpre, const unsigned *runinfo, unsigned nruns)
+{
+    __shared__ unsigned sh[256];
+    const unsigned k0 = (blockIdx.x * 256u + threadIdx.x) * RE_RUNS;
+    unsigned nt[RE_RUNS], nsum = 0;
+#pragma unroll
+    for (unsigned q = 0; q < RE_RUNS; q++) { nt[q] = k0 + q < nruns ? runinfo[k0 + q] & 0x0FFFFFFFu : 0u; nsum += nt[q]; }
+    unsigned tt;
+    unsigned o = bpre[blockIdx.x] + re_block_excl_scan(nsum, sh, tt);
+#pragma unroll
+    for (unsigned q = 0; q < RE_RUNS; q++) { if (k0 + q < nruns) tokoff[k0 + q] = o; o += nt[q]; }
+}
+__device__ __forceinline__ unsigned re_sign(const unsigned *mask, unsigned i) { return (mask[i >> 5] >> (i & 31u)) & 1u; }
+__device__ __forceinline__ unsigned re_raw(const unsigned *mask, unsigned f, unsigned npts)      /* 0 flag + the seven signs from f on, first point on top; points beyond the field: 0 */
+{
+    unsigned b = 0;
+    for (unsigned j = 0; j < 7u; j++) b = b << 1 | (f + j < npts ? re_sign(mask, f + j) : 0u);
+    return b;
+}
+/* token j of a run that starts at `start` with `len` points, entered in state d */
+__device__ __forceinline__ unsigned re_token(const unsigned *mask, unsigned start, unsigned len, unsigned d, unsigned j, unsigned npts)
+{
+    const unsigned f = start + d, L = len - d, s = re_sign(mask, f);
+    if (L < 8u) return re_raw(mask, f, npts);
+    if (L <= 62u) return 0x80u | s << 6 | L;
+    const unsigned rem0 = L - 62u, n255 = rem0 > 256u ? (rem0 - 256u + 254u) / 255u : 0u;
+    unsigned rem = rem0 - 255u * n255, n62 = 0;
+    if (rem >= 63u) { n62 = (rem - 63u) / 62u + 1u; rem -= 62u * n62; }
+    if (j == 0u) return 0x80u | s << 6 | 62u;
+    if (j <= n255) return 0xFFu;
+    if (j <= n255 + n62) return 0x80u | s << 6 | 62u;
+    return rem >= 8u ? (0x80u | s << 6 | rem) : re_raw(mask, start + len - rem, npts);
+}
+/* one thread per stream word: tokens 4 w .. 4 w + 3; res[0] = tokens, res[1] = stream bits (the last token may be a RAW of fewer than seven points) */
+__global__ __launch_bounds__(256) void k_re_emit(unsigned *z, unsigned *res, const unsigned *tokoff, const unsigned *runinfo, const unsigned *starts,
+                                                 const unsigned *mask, unsigned nruns, const unsigned *ntok_total, unsigned npts)
+{
+    const unsigned T = ntok_total[0];
+    const unsigned w = blockIdx.x * 256u + threadIdx.x;
+    if (w == 0u) {
+        /* the last token: the last run that emits one */
+        unsigned bits = 8u * T;
+        unsigned lo = 0, hi = nruns;                       /* last run k with tokoff[k] < T and ntok > 0: search the largest k with tokoff[k] <= T - 1 */
+        if (T) {
+            while (lo + 1 < hi) { const unsigned mid = (lo + hi) >> 1; if (tokoff[mid] <= T - 1u) lo = mid; else hi = mid; }
+            const unsigned info = runinfo[lo], d = info >> 28, st = starts[lo], len = starts[lo + 1] - st, j = T - 1u - tokoff[lo];
+            const unsigned L = len - d;
+            unsigned rawpos = 0xFFFFFFFFu;                 /* where the last token reads its seven signs, if it is a RAW */
+            if (L < 8u) rawpos = st + d;
+            else if (L > 62u) {
+                const unsigned rem0 = L - 62u, n255 = rem0 > 256u ? (rem0 - 256u + 254u) / 255u : 0u;
+                unsigned rem = rem0 - 255u * n255, n62 = 0;
+                if (rem >= 63u) { n62 = (rem - 63u) / 62u + 1u; rem -= 62u * n62; }
+                if (j > n255 + n62 && rem >= 1u && rem <= 7u) rawpos = st + len - rem;
+            }
+            if (rawpos != 0xFFFFFFFFu && rawpos + 7u > npts) bits = 8u * (T - 1u) + 1u + (npts - rawpos);
+        }
+        res[0] = T; res[1] = bits;
+    }
+    if (4u * w >= T) return;
+    unsigned t = 4u * w;
+    unsigned lo = 0, hi = nruns;
+    while (lo + 1 < hi) { const unsigned mid = (lo + hi) >> 1; if (tokoff[mid] <= t) lo = mid; else hi = mid; }
+    unsigned k = lo;
+    while ((runinfo[k] & 0x0FFFFFFFu) == 0u || tokoff[k] + (runinfo[k] & 0x0FFFFFFFu) <= t) k++;      /* (runs without tokens share their neighbour's offset) */
+    unsigned word = 0;
+    for (unsigned q = 0; q < 4u; q++, t++) {
+        unsigned byte = 0;
+        if (t < T) {
+            while ((runinfo[k] & 0x0FFFFFFFu) == 0u || tokoff[k] + (runinfo[k] & 0x0FFFFFFFu) <= t) k++;
+            const unsigned st = starts[k];
+            byte = re_token(mask, st, starts[k + 1] - st, runinfo[k] >> 28, t - tokoff[k], npts);
+        }
+        word |= byte << (24u - 8u * q);
+    }
+    z[w] = word;
+}
+/* d_z: the stream (ceil(tokens / 4) words are written: at most npts / 7 / 4 + 2); d_mask: npts / 32 + 1 words (bits beyond npts in the last word may hold anything);
+ * d_work: packhip_a32_rle_enc_work_bytes(npts); h_bits (host): the stream's bit count.  Synchronises twice (the number of runs, the result). */
+extern "C" size_t packhip_a32_rle_enc_work_bytes(size_t npts)
+{
+    const size_t nwords = npts / 32 + 1, nb1 = (nwords + 256 * RE_ITEMS - 1) / (256 * RE_ITEMS);
+    return 4 * (nb1 + 16) + 64;                            /* the run arrays are sized once the number of runs is known: packhip_a32_rle_encode takes them separately */
+}
+extern "C" int packhip_a32_rle_encode(unsigned *d_z, const unsigned *d_mask, size_t npts, void *d_work, void *(*grow)(int slot, size_t bytes), unsigned long long *h_bits)
+{
+    if (npts == 0 || npts >= (1ull << 28)) return -1;      /* (token counts ride in 28 bits) */
+    const size_t nwords = (npts + 31) / 32;
+    const unsigned nb1 = (unsigned)((nwords + 256 * RE_ITEMS - 1) / (256 * RE_ITEMS));
+    unsigned *bagg = (unsigned *)d_work, *tot = bagg + nb1 + 1;          /* tot[0] changes, tot[1] tokens, tot[2..3] result */
+    hipStream_t st = STREAM;
+    hipLaunchKernelGGL(k_re_count, dim3(nb1), dim3(256), 0, st, bagg, d_mask, nwords, (unsigned)npts);
+    hipLaunchKernelGGL(k_re_scan_sums, dim3(1), dim3(1024), 0, st, bagg, nb1, tot);
+    unsigned nch = 0;
+    if (chk32("k_re_count") || hipMemcpyAsync(&nch, tot, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+    const unsigned nruns = nch + 1u, nb2 = (nruns + 256 * RE_RUNS - 1) / (256 * RE_RUNS);
+    unsigned *starts = (unsigned *)grow(0, 4 * ((size_t)nruns + 2)), *runinfo = (unsigned *)grow(1, 4 * ((size_t)nruns + 1)), *tokoff = (unsigned *)grow(2, 4 * ((size_t)nruns + 1)),
+             *bmap = (unsigned *)grow(3, 8 * ((size_t)nb2 + 1));
+    if (!starts || !runinfo || !tokoff || !bmap) return -1;
+    unsigned *bsum = bmap + nb2 + 1;
+    hipLaunchKernelGGL(k_re_starts, dim3(nb1), dim3(256), 0, st, starts, bagg, d_mask, nwords, (unsigned)npts, tot);
+    hipLaunchKernelGGL(k_re_maps, dim3(nb2), dim3(256), 0, st, bmap, starts, nruns);
+    hipLaunchKernelGGL(k_re_scan_maps, dim3(1), dim3(1024), 0, st, bmap, nb2);
+    hipLaunchKernelGGL(k_re_states, dim3(nb2), dim3(256), 0, st, runinfo, bsum, bmap, starts, nruns);
+    hipLaunchKernelGGL(k_re_scan_sums, dim3(1), dim3(1024), 0, st, bsum, nb2, tot + 1);
+    hipLaunchKernelGGL(k_re_offsets, dim3(nb2), dim3(256), 0, st, tokoff, bsum, runinfo, nruns);
+    const unsigned maxw = (unsigned)(npts / 7 / 4 + 2);
+    hipLaunchKernelGGL(k_re_emit, dim3((maxw + 255) / 256), dim3(256), 0, st, d_z, tot + 2, tokoff, runinfo, starts, d_mask, nruns, tot + 1, (unsigned)npts);
+    unsigned res[2] = {0, 0};
+    if (chk32("k_re_emit") || hipMemcpyAsync(res, tot + 2, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+    *h_bits = res[1];
     return 0;
 }
 

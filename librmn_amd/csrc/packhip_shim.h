@@ -81,6 +81,10 @@ int packhip_armn_tile_walk_parallel(const unsigned *d_z, size_t z_words, int ni,
 /* sign run lengths -> sign mask on the device (unpack1bitRLE); d_z: the sub-stream on the device */
 size_t packhip_a32_rle_work_bytes(size_t nbytes);
 int packhip_a32_rle_decode(unsigned *d_mask, const unsigned *d_z, size_t nbytes, size_t npts, void *d_work, int *h_bad);
+/* pack1bitRLE on the device: d_z receives the token stream (at most npts / 28 + 2 words), *h_bits its bit count; grow(slot, bytes): the caller's grow-only device
+ * workspaces (four slots: the run arrays are sized by the number of runs) */
+size_t packhip_a32_rle_enc_work_bytes(size_t npts);
+int packhip_a32_rle_encode(unsigned *d_z, const unsigned *d_mask, size_t npts, void *d_work, void *(*grow)(int slot, size_t bytes), unsigned long long *h_bits);
 int packhip_a32_combine(float *d_f, const int *d_expo, const int *d_mant, const unsigned *d_smask, size_t n, int nbits, unsigned exp_min, int code_signe, int have_expo);
 #ifdef __cplusplus
 }

@@ -766,6 +766,62 @@ def test_armn_compress32_bit_exact(ni, nj, kind, znbits):
             del os.environ["EZHIP_A32_DEVICE_WALK"]
 
 
+def _signs_from_runs(n, runs):
+    """+-1 per point: consecutive runs of the given lengths with alternating signs, the last one stretched / cut to n points"""
+    s = np.ones(n, np.float32); pos = 0; sg = 1.0
+    for r in runs:
+        if pos >= n:
+            break
+        s[pos:pos + r] = sg; pos += r; sg = -sg
+    s[pos:] = sg
+    return s
+
+
+RLE_PATTERNS = {
+    # every branch of pack1bitRLE (armn_compress_32.c:827-901): raw tokens, count tokens 8 .. 62, the 62 + remainder split, remainders of 1 .. 7 points that leave as a
+    # raw token reaching into the following runs, the 0xFF repeat (more than 256 points left after a 62), runs swallowed by a raw token, the field's end inside a raw token
+    "short": [1, 2, 3, 4, 5, 6, 7] * 40,
+    "around8": [7, 8, 9, 7, 8, 15, 14, 16, 6, 8] * 30,
+    "around62": [61, 62, 63, 64, 65, 69, 70, 71, 62, 1, 62, 7, 63] * 12,
+    "tails": [62 + k for k in range(0, 20)] + [124 + k for k in range(0, 20)] + [3, 1, 2] * 5 + [62 + 62 + k for k in range(1, 9)],
+    "repeat255": [62 + 256, 62 + 257, 62 + 257 + 255, 62 + 256 + 255 * 3 + 5, 62 + 258 + 255 * 2, 1, 62 + 1000, 2, 3, 62 + 511, 62 + 512, 62 + 513],
+    "swallow": [70, 1, 1, 1, 1, 1, 1, 1, 1, 9, 67, 2, 2, 2, 30, 66, 6, 8, 65, 3, 3, 9] * 15,
+    "alternating": [1] * 3000,
+    "one_change": [5000],
+    "end_raw": [100] * 5 + [3],
+}
+
+
+@pytest.mark.parametrize("pattern", sorted(RLE_PATTERNS))
+@pytest.mark.parametrize("ni,nj", [(64, 48), (301, 200), (1000, 777)])
+def test_armn_compress32_sign_run_coder_on_the_device(pattern, ni, nj):
+    """c_armn_compress32 of fields whose SIGNS follow crafted run lengths (the magnitudes are a smooth positive field): the device run-length coder (a prefix scan
+    of seven-state maps) against the oracle's sequential restatement of pack1bitRLE, byte for byte; the host coder (EZHIP_A32_RLE_ENC_HOST=1) gives the same bytes"""
+    n = ni * nj
+    runs = list(RLE_PATTERNS[pattern])
+    reps = 1
+    while sum(runs) * reps < n and pattern not in ("one_change",):
+        reps += 1
+    sg = _signs_from_runs(n, runs * reps)
+    if pattern == "end_raw":                                   # the last points: a short run that ends the field inside a raw token
+        sg[-3:] = -sg[-4]
+    f = (ta32.field32(ni, nj, "positive", seed=ni + nj) * sg).astype(np.float32)
+    zw = np.zeros(n + 1024, np.uint32)
+    want = ta32.O().orc_armn_compress32(zw.ctypes.data, f.ctypes.data, ni, nj, 1, 32)
+    got, zg = pk.armn_compress32(f, ni, nj, 32)
+    assert got == want, (pattern, got, want)
+    if want > 0:
+        assert np.array_equal(zg[:want // 4], zw[:want // 4]), (pattern, np.nonzero(zg[:want // 4] != zw[:want // 4])[0][:5])
+        os.environ["EZHIP_A32_RLE_ENC_HOST"] = "1"
+        try:
+            got_h, zh = pk.armn_compress32(f, ni, nj, 32)
+        finally:
+            del os.environ["EZHIP_A32_RLE_ENC_HOST"]
+        assert got_h == want and np.array_equal(zh[:want // 4], zw[:want // 4])
+        rc, back = pk.armn_uncompress32(zg, ni, nj, 32)
+        assert rc == n and np.array_equal(back.view(np.uint32), f.view(np.uint32))
+
+
 def test_armn_compress32_refusals_and_full_size():
     f = ta32.random_bits_field(64, 48, seed=9)
     assert pk.armn_compress32(f, 64, 48, 32)[0] == -1                 # incompressible: as the oracle says

@@ -1,4 +1,2 @@
-python tools/probe_cfg3_first.py 2>&1 | tail -1
-EZHIP_LOCATE_THREADS=32 python tools/probe_cfg3_first.py 2>&1 | tail -1
-EZHIP_LOCATE_THREADS=64 python tools/probe_cfg3_first.py 2>&1 | tail -1
-python -m pytest tests/test_gpu_interp.py -x -q -m gpu -k "cfg3" 2>&1 | tail -2
+for k in positive mixed stripes; do python tools/probe_a32_enc.py 7200 3601 $k 2>&1 | grep -v amdgpu.ids | tail -2; done
+EZHIP_A32_RLE_ENC_HOST=1 python tools/probe_a32_enc.py 7200 3601 mixed 2>&1 | grep -v amdgpu.ids | tail -2
