@@ -3144,8 +3144,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW ? UVT_WA
             else {
                 const c2 *cp = cells + (j - 1 - j0) * W + (i - 1 - i0);
                 c2 q[4][4];
+                if (!NW && !p.uvt_read2) {
+                    /* sixteen ds_read_b64 (2 LDS-array cycles each) instead of the eight ds_read2_b64 the compiler pairs them into (8 cycles each: half the bytes per
+                     * cycle, MI355X_MICROARCH.md LDS table) -- the LDS array is this kernel's busiest unit (47 %).  Issued by hand: the compiler does not see them, the
+                     * wait below names all sixteen results */
+                    const unsigned a0 = lds_addr_of(cp), a1 = a0 + 8u * (unsigned)W, a2 = a1 + 8u * (unsigned)W, a3 = a2 + 8u * (unsigned)W;
+#define UVT_RD4(r, A) asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24" \
+                                   : "=&v"(q[r][0]), "=&v"(q[r][1]), "=&v"(q[r][2]), "=&v"(q[r][3]) : "v"(A))
+                    UVT_RD4(0, a0); UVT_RD4(1, a1); UVT_RD4(2, a2); UVT_RD4(3, a3);
+#undef UVT_RD4
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[0][3]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[1][2]), "+v"(q[1][3]),
+                                                          "+v"(q[2][0]), "+v"(q[2][1]), "+v"(q[2][2]), "+v"(q[2][3]), "+v"(q[3][0]), "+v"(q[3][1]), "+v"(q[3][2]), "+v"(q[3][3]));
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; r++) { q[r][0] = cp[r * W]; q[r][1] = cp[r * W + 1]; q[r][2] = cp[r * W + 2]; q[r][3] = cp[r * W + 3]; }
+                }
                 if (NW) {
                 /* records {x1, x2 | x3, c1 | c2, c3 | c4, c5 | c6, c5 + c2} in REAL*8: the table's REAL entries converted once per grid, not per point */
                 const d2 *xq = xr + (i - 1 - i0) * 5, *yq = yr + (j - 1 - j0) * 5;
@@ -3836,6 +3849,7 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
         size_t lds = (size_t)8 * (size_t)pu2.uvt_cap + (stage3nw ? 80 : 32) * UVT_REC_MAX;
         if (lds < 4 * 2052 + 16) lds = 4 * 2052 + 16;                          /* (the polar-wind producer blocks' row buffer) */
         pu2.xcd_order = getenv("EZHIP_UVT_XCD") ? atoi(getenv("EZHIP_UVT_XCD")) : 0;
+        pu2.uvt_read2 = getenv("EZHIP_UVT_READ2") ? 1 : 0;                      /* development: the compiler's paired LDS reads (same results) */
 #define UVT_LAUNCH(TW, TH) hipLaunchKernelGGL((k_uvt<TW, TH>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl)
         if (stage3nw) hipLaunchKernelGGL((k_uvt<32, 32, true>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl);      /* (tables of regional sets are built with 32 x 32 tiles) */
         else

@@ -1,2 +1,1 @@
-for k in positive mixed stripes; do python tools/probe_a32_enc.py 7200 3601 $k 2>&1 | grep -v amdgpu.ids | tail -2; done
-EZHIP_A32_RLE_ENC_HOST=1 python tools/probe_a32_enc.py 7200 3601 mixed 2>&1 | grep -v amdgpu.ids | tail -2
+python tools/sweep_cfg3.py "" "EZHIP_UVT_READ2=1" 2>&1 | grep -v amdgpu.ids
