@@ -111,7 +111,7 @@ if P3:
 # round 5: the figures bench.py's other roofline objects read (every one labelled with this file in the line)
 lone = [(k, st.median(v)) for k, v in fetch.items() if "k_sepx<3, 16, 0>" in k[0]]
 if lone:
-    kmin = min(lone, key=lambda kv: int(kv[0][1]))[0]
+    kmin = min(lone, key=lambda kv: abs(int(kv[0][1]) - int(big_grid) / F))[0]      # the one-field launch of the headline's grid pair (the batch's grid / F, + its own pole blocks)
     if kmin in write:
         out["single_field_traffic_MB"] = round((st.median(fetch[kmin]) * 2 + st.median(write[kmin])) * 1024 / 1e6, 2)
         out["single_field_grid"] = kmin[1]
