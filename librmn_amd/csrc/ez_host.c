@@ -2059,23 +2059,29 @@ static void fill_locate_plan(const ezh_grid *gi, ezhip_locate_plan *lp)
 }
 
 /* x,y of every target point of a set on the per-point path (the gridset cache of ez_calcxy.c:28-137), device resident.
- * Rotated sources ('E', Z-on-'E': ez_gfxyfll.c:38-57 -- REAL trig through libm) are located ONCE per set by the exact
- * host code (h_locate_mt, bit-exact against the reference: tests/test_host_cpu.py) and uploaded: the device's
- * sinf/cosf/asinf/atan2f differ from glibc in the last ulp, which moved x,y by ~1e-6 of a cell and flipped
- * nearest-neighbour picks.  EZHIP_DEVICE_LOCATE=1 keeps the device locate (k_locate kinds 2/3) for experiments.
+ * Rotated sources ('E', Z-on-'E': ez_gfxyfll.c:38-57 -- REAL trig through libm) are located on the device as well: k_locate
+ * kinds 2 / 3 evaluate sinf / cosf / asinf / atan2f as GNU libc 2.35 does, operation by operation (libm_exact.h, equal to the C
+ * library over every REAL argument: tools/check_libm_exact.c), so x, y have c_gdxyfll's bits
+ * (test_rotated_source_locate_is_bit_exact).  EZHIP_HOST_LOCATE=1 keeps the host threads (h_locate_mt) that did this until
+ * round 5 -- for a C library other than the one libm_exact.h restates.
  * The same first-call pass classifies the DEHORS zone (ez_defzone_dehors.c:63-74): have_dehors decides rc = 2 and
  * extrap_degree = abort on every entry point. */
+static double wall_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec; }
 static int ensure_points(ezh_set *s)
 {
     if (s->d_x) return 0;
+    const int trace = getenv("EZHIP_TRACE_FIRST") != NULL;      /* first-call work by part, on stderr */
+    double t0 = trace ? wall_ms() : 0.0, t1;
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     size_t n = (size_t)go->ni * go->nj;
     int rotated = gi->grtyp == 'E' || (gi->grtyp == 'Z' && gi->grref == 'E');
-    int host_locate = (rotated && !getenv("EZHIP_DEVICE_LOCATE")) || (gi->grtyp == 'G' && gi->ig[0] != 0) || gi->grtyp == '!';      /* '!': the REAL libm chain of ez_lambxyfll99 lives in the host code */      /* hemispheric 'G': the reference's search quirk lives in the host code only */
+    int host_locate = (rotated && getenv("EZHIP_HOST_LOCATE")) || (gi->grtyp == 'G' && gi->ig[0] != 0) || gi->grtyp == '!';      /* '!': the REAL libm chain of ez_lambxyfll99 lives in the host code */      /* hemispheric 'G': the reference's search quirk lives in the host code only */
     float *hx = NULL, *hy = NULL;
     if (ensure_grid_dev(gi)) return -1;
+    if (trace) { ezhip_sync(); t1 = wall_ms(); fprintf(stderr, "ensure_points: source tables on the device %.2f ms\n", t1 - t0); t0 = t1; }
     float *dx = (float *)ezhip_malloc(sizeof(float) * n), *dy = (float *)ezhip_malloc(sizeof(float) * n);
     if (!dx || !dy) { ezhip_free(dx); ezhip_free(dy); return -1; }
+    if (trace) { t1 = wall_ms(); fprintf(stderr, "ensure_points: 2 x %zu bytes allocated %.2f ms\n", sizeof(float) * n, t1 - t0); t0 = t1; }
     int rc = 0;
     if (host_locate) {
         ensure_coords(go);
@@ -2091,23 +2097,29 @@ static int ensure_points(ezh_set *s)
     } else {
         if (ensure_coords_dev(go)) rc = -1;
         else {
+            if (trace) { ezhip_sync(); t1 = wall_ms(); fprintf(stderr, "ensure_points: target coordinates on the device %.2f ms\n", t1 - t0); t0 = t1; }
             ezhip_locate_plan lp;
             fill_locate_plan(gi, &lp);
             rc = ezhip_locate(&lp, dx, dy, go->d_lat, go->d_lon, go->ni, go->nj, go->separable);
         }
     }
+    if (trace) { ezhip_sync(); t1 = wall_ms(); fprintf(stderr, "ensure_points: located (%s) %.2f ms\n", host_locate ? "host" : "device", t1 - t0); t0 = t1; }
     if (!rc && s->extrap && !s->sep_capable) {
-        if (!hx) {
-            hx = (float *)malloc(sizeof(float) * n); hy = (float *)malloc(sizeof(float) * n);
-            if (!hx || !hy || ezhip_d2h(hx, dx, sizeof(float) * n) || ezhip_d2h(hy, dy, sizeof(float) * n) || ezhip_sync()) rc = -1;
-        }
         s->have_dehors = 0;
-        for (size_t k = 0; k < n && !rc; k++) {
-            int ix = (int)((double)hx[k] + 0.5), iy = (int)((double)hy[k] + 0.5);
-            if (ix < 1 || iy < 1 || ix > gi->ni || iy > gi->nj) { s->have_dehors = 1; break; }
+        if (hx) {
+            for (size_t k = 0; k < n; k++) {
+                int ix = (int)((double)hx[k] + 0.5), iy = (int)((double)hy[k] + 0.5);
+                if (ix < 1 || iy < 1 || ix > gi->ni || iy > gi->nj) { s->have_dehors = 1; break; }
+            }
+        } else {                                            /* the points never leave the device: one flag comes back */
+            int *d_flag = (int *)ezhip_malloc(sizeof(int)), flag = 0;
+            if (!d_flag || ezhip_any_dehors(dx, dy, n, gi->ni, gi->nj, d_flag) || ezhip_d2h(&flag, d_flag, sizeof(int)) || ezhip_sync()) rc = -1;
+            ezhip_free(d_flag);
+            s->have_dehors = flag;
         }
     }
     free(hx); free(hy);
+    if (trace) { t1 = wall_ms(); fprintf(stderr, "ensure_points: outside-the-source test %.2f ms\n", t1 - t0); }
     if (rc) { ezhip_free(dx); ezhip_free(dy); return -1; }
     s->d_y = dy; s->d_x = dx;
     return 0;

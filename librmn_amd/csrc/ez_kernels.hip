@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include "ezhip_shim.h"
 #include "armn_dev.h"
+#include "libm_exact.h"
 
 /* Everything that restates reference arithmetic must not be contracted into FMAs; the separable
  * kernel uses explicit fma() where fusion is intended. */
@@ -4084,6 +4085,22 @@ __device__ __forceinline__ void d_rotate(const float *r, float lon, float lat, f
     const float dar = (float)(3.14159274101257324 / 180.0);     /* acos(-1.)/180. evaluated in REAL */
     d_rotate_cs(r, cosf(dar * lat), sinf(dar * lat), cosf(dar * lon), sinf(dar * lon), lon_o, lat_o);
 }
+/* the same with the C library's own REAL functions (libm_exact.h: GNU libc 2.35's sinf / cosf / asinf / atan2f operation by operation): the locate of a
+ * rotated source then has the bits ez_gfxyfll has on the host (ez_gfxyfll.c:38-57, ez_lac.inc:31-47, ez_cal.inc:22-47) */
+__device__ __noinline__ void d_rotate_exact(const float *r, float lon, float lat, float &lon_o, float &lat_o)
+{
+    const float dar = (float)(3.14159274101257324 / 180.0);
+    const float cosdar = glx_cosf(dar * lat);
+    const float c0 = cosdar * glx_cosf(dar * lon), c1 = cosdar * glx_sinf(dar * lon), c2 = glx_sinf(dar * lat);
+    float q[3];
+    for (int i = 0; i < 3; i++) { float s = 0.0f; s = s + r[i] * c0; s = s + r[3 + i] * c1; s = s + r[6 + i] * c2; q[i] = s; }
+    const float rad = (float)(180.0 / 3.14159274101257324);
+    lat_o = glx_asinf(fmaxf(-1.00f, fminf(1.0f, q[2]))) * rad;
+    float lo = glx_atan2f(q[1], q[0]) * rad;
+    lo = fmodf(lo, 360.0f);
+    if (lo < 0.0f) lo = lo + 360.0f;
+    lon_o = lo;
+}
 __device__ __forceinline__ void d_rotate_cs(const float *r, float coslat, float sinlat, float coslon, float sinlon, float &lon_o, float &lat_o)
 {
     float cosdar = coslat;
@@ -4128,7 +4145,7 @@ __global__ __launch_bounds__(256) void k_locate(ezhip_locate_plan p, float *__re
         px = (float)(r * cos(rlon) + (double)pi);
         py = (float)(r * sin(rlon) + (double)pj);
     } else if (p.kind == 0 || p.kind == 3) {
-        if (p.kind == 3) { float lo, la; d_rotate(p.r, lon, lat, lo, la); lon = lo; lat = la; }
+        if (p.kind == 3) { float lo, la; d_rotate_exact(p.r, lon, lat, lo, la); lon = lo; lat = la; }
         if (p.lon_fix == 1) {                               /* ez_ll2rgd.inc:137-145 */
             if (lon < p.lon0) lon = lon + 360.0f;
             if (lon > (p.lon0 + (float)p.ni * p.dlon)) lon = lon - 360.0f;
@@ -4146,7 +4163,7 @@ __global__ __launch_bounds__(256) void k_locate(ezhip_locate_plan p, float *__re
             py = (lat - p.lat0) / p.dlat + 1.0f;
             px = px - 1.0f; py = py - 1.0f;
         } else {                                            /* ez_ll2igd.inc:69-72 */
-            d_rotate(p.r, lon, lat, px, py);
+            d_rotate_exact(p.r, lon, lat, px, py);
         }
         int indx = d_cherche(px, p.ax, p.ni);               /* ez_ll2igd.inc:74-85 */
         int indy = d_cherche(py, p.ay, p.nj);
@@ -4156,6 +4173,42 @@ __global__ __launch_bounds__(256) void k_locate(ezhip_locate_plan p, float *__re
         py = (float)indy + (py - p.ay[indy - 1]) / (p.ay[indy] - p.ay[indy - 1]);
     }
     xo[n] = px; yo[n] = py;
+}
+
+/* libm_exact.h on the device, function by function (fn 0 sinf, 1 cosf, 2 asinf, 3 atanf, 4 atan2f(a, b)): what tests/test_gpu_interp.py and
+ * tools/check_libm_exact_gpu.py compare with the host's C library */
+__global__ __launch_bounds__(256) void k_libm_exact_probe(int fn, const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const float x = a[k];
+    out[k] = fn == 0 ? glx_sinf(x) : fn == 1 ? glx_cosf(x) : fn == 2 ? glx_asinf(x) : fn == 3 ? glx_atanf(x) : glx_atan2f(x, b[k]);
+}
+extern "C" int ezhip_libm_exact_probe(int fn, const float *d_a, const float *d_b, float *d_out, size_t n)
+{
+    if (!n) return 0;
+    if (fn < 0 || fn > 4 || (fn == 4 && !d_b)) return -1;
+    hipLaunchKernelGGL(k_libm_exact_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, fn, d_a, d_b, d_out, n);
+    return LAUNCH_CHECK("k_libm_exact_probe");
+}
+
+/* does any located point fall outside the source (the DEHORS zone's test, ez_defzone_dehors.c:63-74: nint of x, y against 1 .. ni, 1 .. nj)? *flag |= 1 */
+__global__ __launch_bounds__(256) void k_any_dehors(const float *__restrict__ x, const float *__restrict__ y, size_t n, int ni, int nj, int *flag)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int out = 0;
+    if (k < n) {
+        const int ix = (int)((double)x[k] + 0.5), iy = (int)((double)y[k] + 0.5);
+        out = ix < 1 || iy < 1 || ix > ni || iy > nj;
+    }
+    if (__ballot(out) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+extern "C" int ezhip_any_dehors(const float *d_x, const float *d_y, size_t n, int ni, int nj, int *d_flag)
+{
+    if (hipMemsetAsync(d_flag, 0, sizeof(int), g_stream) != hipSuccess) return -1;
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_any_dehors, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, d_x, d_y, n, ni, nj, d_flag);
+    return LAUNCH_CHECK("k_any_dehors");
 }
 
 extern "C" int ezhip_locate(const ezhip_locate_plan *plan, float *d_x, float *d_y,

@@ -307,6 +307,11 @@ typedef struct {
 int ezhip_locate(const ezhip_locate_plan *plan, float *d_x, float *d_y,
                  const float *d_lat, const float *d_lon, int ni_dst, int nj_dst, int separable);
 
+/* libm_exact.h evaluated on the device (fn 0 sinf, 1 cosf, 2 asinf, 3 atanf, 4 atan2f(a, b)); tests compare with the host's C library */
+int ezhip_libm_exact_probe(int fn, const float *d_a, const float *d_b, float *d_out, size_t n);
+/* *d_flag = 1 if any located point lies outside 1 .. ni, 1 .. nj after rounding (the DEHORS zone's test), else 0 */
+int ezhip_any_dehors(const float *d_x, const float *d_y, size_t n, int ni, int nj, int *d_flag);
+
 /* ---- winds ------------------------------------------------------------------------------- */
 typedef struct {
     int src_rotated;                  /* 1: source is E / Z-on-E: rotate through ri */

@@ -221,6 +221,13 @@ def set_xy_dev(x, y):
     return L.ezhip_set_xy_dev(_dptr(x), _dptr(y))
 
 
+def libm_exact_probe(fn, a, b, out):
+    """libm_exact.h on the device: fn 0 sinf, 1 cosf, 2 asinf, 3 atanf, 4 atan2f(a, b) over device arrays"""
+    L = _lib()
+    L.ezhip_libm_exact_probe.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    return L.ezhip_libm_exact_probe(fn, _dptr(a), _dptr(b) if b is not None else None, _dptr(out), a.numel())
+
+
 def gdsetmask(gdid, mask):
     m = np.ascontiguousarray(mask, dtype=np.int32)
     return _lib().c_gdsetmask(gdid, m.ctypes.data)

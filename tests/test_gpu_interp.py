@@ -889,9 +889,69 @@ def test_cfg1_exact_size_against_reference_run():
                 assert h == tuple(int(v) for v in G1[key + "/hash"]), key
 
 
+def _libm_arguments(seed, n):
+    """REAL arguments for the C library comparison: every exponent with random mantissas, the rotated frame's ranges densely, and the special values"""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    dar = np.float32(np.pi / 180.0)
+    b = (rng.uniform(-400.0, 760.0, n).astype(np.float32) * dar).astype(np.float32)          # dar * lon, dar * lat as ez_lac forms them
+    c = rng.uniform(-1.0, 1.0, n).astype(np.float32)                                         # components of unit vectors (ez_cal)
+    d = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 0.975, 0.4375, 0.6875, 1.1875, 2.4375, 120.0, -120.0, 0.785398, 0.7853982, 1e-30, -1e-30, 1e-40, 3e38,
+                  np.inf, -np.inf, np.nan, 2.0 ** -12, 2.0 ** -27, 2.0 ** -29, 2.0 ** 25, 1.5707964, 3.1415927, 6.2831855], dtype=np.float32)
+    near = np.concatenate([(d.view(np.int32) + np.int32(k)).view(np.float32) for k in (-2, -1, 1, 2)])
+    return np.ascontiguousarray(np.concatenate([a, b, c, d, near]))
+
+
+def test_libm_exact_on_the_device_equals_the_c_library():
+    """librmn_amd/csrc/libm_exact.h (GNU libc 2.35's REAL sinf / cosf / asinf / atanf / atan2f, operation by operation) evaluated ON THE DEVICE against the
+    C library of this machine, bit for bit, over ~3 M arguments per function (tools/check_libm_exact.c covers all 2^32 on the host, tools/check_libm_exact_gpu.py
+    all 2^32 on the device): what makes the device locate of a rotated source bit-exact (ez_lac.inc:31-47, ez_cal.inc:22-47)"""
+    O = ol.oracle()
+    O.orc_libm_apply.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    a = _libm_arguments(5, 1 << 20); b = np.ascontiguousarray(_libm_arguments(6, 1 << 20)[::-1])
+    d_a = torch.from_numpy(a).cuda(); d_b = torch.from_numpy(b).cuda(); d_o = torch.empty_like(d_a)
+    want = np.empty_like(a)
+    for fn, name in enumerate(("sinf", "cosf", "asinf", "atanf", "atan2f")):
+        with np.errstate(all="ignore"):
+            O.orc_libm_apply(fn, a.ctypes.data, b.ctypes.data, want.ctypes.data, a.size)
+        assert ez.libm_exact_probe(fn, d_a, d_b, d_o) == 0
+        torch.cuda.synchronize()
+        got = d_o.cpu().numpy()
+        differ = (got.view(np.uint32) != want.view(np.uint32)) & ~(np.isnan(got) & np.isnan(want))
+        assert not differ.any(), (name, int(differ.sum()), a[differ][:4], b[differ][:4], got[differ][:4], want[differ][:4])
+
+
+def test_rotated_source_locate_on_the_device_equals_the_host_locate(monkeypatch):
+    """a set's x, y located by k_locate (rotated kinds 2 / 3 with libm_exact.h) against the same set located by the host code that calls the C library
+    (EZHIP_HOST_LOCATE=1): every point, every bit; separable, cloud and rotated (2-D coordinates) targets, 1.1 M points in the largest"""
+    big = dict(CASES["ZE_to_L"]); big["dst"] = (1500, 750, "L", (24, 24, 0, 0))
+    onto_ze = dict(src=ECASES["E_to_L"]["src"], dst=(120, 60, "Z", ec.E_IG), dst_ref="E", dst_axes=ec.ze_axes)
+    ze_onto_ze = dict(src=CASES["ZE_to_L"]["src"], dst=(120, 60, "Z", ec.YAN_IG), dst_ref="E", dst_axes=ec.ze_axes)          # (another rotation than the source's)
+    for name, case in (("ZE_to_L", CASES["ZE_to_L"]), ("ZEreg_to_L", CASES["ZEreg_to_L"]), ("ZE_to_Y", CASES["ZE_to_Y"]), ("E_to_L", ECASES["E_to_L"]),
+                       ("ZE_to_L_big", big), ("E_to_ZE", onto_ze), ("ZE_to_ZE", ze_onto_ze)):
+        n = case["dst"][0] * case["dst"][1]
+        got = []
+        for host in (False, True):
+            if host:
+                monkeypatch.setenv("EZHIP_HOST_LOCATE", "1")
+            else:
+                monkeypatch.delenv("EZHIP_HOST_LOCATE", raising=False)
+            gdin = hip_define(case["src"]); gdout = hip_define(ec.dst_spec(case))          # (fresh grids: a set keeps the x, y it located first)
+            assert ez.ezdefset(gdout, gdin) == 1
+            d_x = torch.empty(n, dtype=torch.float32, device="cuda"); d_y = torch.empty_like(d_x)
+            assert ez.set_xy_dev(d_x, d_y) == 0
+            torch.cuda.synchronize()
+            got.append((d_x.cpu().numpy(), d_y.cpu().numpy()))
+            ez.gdrls(gdout); ez.gdrls(gdin)
+        monkeypatch.delenv("EZHIP_HOST_LOCATE", raising=False)
+        assert np.array_equal(got[0][0].view(np.uint32), got[1][0].view(np.uint32)), name
+        assert np.array_equal(got[0][1].view(np.uint32), got[1][1].view(np.uint32)), name
+
+
 def test_rotated_source_locate_is_bit_exact():
     """the x,y a set with a rotated source ('E', Z-on-'E': ez_gfxyfll.c:38-57) interpolates with -- read back through
-    ezhip_set_xy_dev -- equal the reference's c_gdxyfll bit for bit (exact host locate, uploaded once per set)"""
+    ezhip_set_xy_dev -- equal the reference's c_gdxyfll bit for bit: located ON THE DEVICE (k_locate with the C library's REAL functions restated in
+    libm_exact.h) since round 5, by host threads before"""
     for name in ("ZE_to_L", "ZEreg_to_L", "ZE_to_Y"):
         case = CASES[name]
         gdin = hip_define(case["src"]); gdout = hip_define(ec.dst_spec(case))

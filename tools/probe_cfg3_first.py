@@ -1,4 +1,4 @@
-"""cfg3's first-call cost by part: c_ezdefset, the set's located x, y (ezhip_prepare_set: host threads for a rotated source, EZHIP_DEVICE_LOCATE=1: the device), the first
+"""cfg3's first-call cost by part: c_ezdefset, the set's located x, y (ezhip_prepare_set: the device since round 5, EZHIP_HOST_LOCATE=1: host threads), the first
 and the second c_ezuvint_dev (wind matrix, special points' list, tile table, tile-ordered copy).  ms, wall clock."""
 import os, sys, time
 _R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -25,3 +25,23 @@ torch.cuda.synchronize(); t4 = time.perf_counter()
 assert ez.ezuvint_dev(o_u, o_v, d_u, d_v) >= 0
 torch.cuda.synchronize(); t5 = time.perf_counter()
 print(f"define grids + set {1e3 * (t1 - t0):.2f} | prepare_set (locate x, y of {no * mo} points) {1e3 * (t2 - t1):.2f} | first c_ezuvint_dev {1e3 * (t4 - t3):.2f} | second {1e3 * (t5 - t4):.2f} ms; host threads available: {os.cpu_count()}")
+# a second, different set in the same process: its first-call cost without the process's one-time work (code object load, first allocations)
+ta = time.perf_counter()
+g_in2 = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay); g_out2 = ez.ezqkdef(no - 8, mo - 4, "L", 9, 9, 0, 0)
+assert ez.ezdefset(g_out2, g_in2) == 1
+tb = time.perf_counter()
+assert ez.prepare_set() >= 0
+torch.cuda.synchronize(); tc = time.perf_counter()
+o_u2 = torch.empty((no - 8) * (mo - 4), device="cuda"); o_v2 = torch.empty_like(o_u2)
+torch.cuda.synchronize(); td = time.perf_counter()
+assert ez.ezuvint_dev(o_u2, o_v2, d_u, d_v) >= 0
+torch.cuda.synchronize(); te = time.perf_counter()
+print(f"second set in the same process: define {1e3 * (tb - ta):.2f} | prepare_set {1e3 * (tc - tb):.2f} | first c_ezuvint_dev {1e3 * (te - td):.2f} ms")
+ax3, ay3 = ec.ze_axes(2400, 1200)
+ta = time.perf_counter()
+g_in3 = ez.ezgdef_fmem(2400, 1200, "Z", "E", *ec.E_IG, ax3, ay3)
+assert ez.ezdefset(g_out, g_in3) == 1
+tb = time.perf_counter()
+assert ez.prepare_set() >= 0
+torch.cuda.synchronize(); tc = time.perf_counter()
+print(f"third set (another source grid): define {1e3 * (tb - ta):.2f} | prepare_set {1e3 * (tc - tb):.2f} ms")
