@@ -335,6 +335,24 @@ def extras(ez, torch, stream, d_out, d_in):
                 ex["armn_uncompress_minimum"] = {"workload": "armn_compress UNCOMPRESS of a 7200 x 3601 MINIMUM stream (level FAST, ratio %.2f) in HBM" % (zlm / (2.0 * n)),
                                                  "single_stream_ms": best * 1e3, "tokens_equal": bool(rcm == 2 * n and torch.equal(tk[:n // 2], toks[0][:n // 2])),
                                                  "note": "the serial chain kernel took 16 ms (rounds 1 - 3)"}
+            # ... and with rows that end on a narrower tile (the same tokens read as a 7201 x 3600 field): the composed ragged form, rows whose stretch outlasts them
+            # walked explicitly by the row recurrence (round 5); the serial chain kernel before
+            pk.armn_setlevel(0)
+            nir, njr = NI_D + 1, NJ_D - 1
+            nr = nir * njr
+            zlr = pk.armn_compress_dev(d_zm, toks[0], nir, njr, 16)
+            pk.armn_setlevel(1)
+            if zlr > 0:
+                zwr = (zlr - 1) // 4 + 1
+                tk = torch.zeros(1 + nr // 2, dtype=torch.int32, device="cuda")
+                best = 1e9
+                for _ in range(4):
+                    torch.cuda.synchronize(); t0_ = time.perf_counter()
+                    rcr = pk.armn_uncompress_dev(tk, d_zm, zwr, nir, njr, 16)
+                    torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0_)
+                ex["armn_uncompress_minimum_ragged"] = {"workload": "armn_compress UNCOMPRESS of a 7201 x 3600 MINIMUM stream (level FAST, ratio %.2f) in HBM" % (zlr / (2.0 * nr)),
+                                                        "single_stream_ms": best * 1e3, "tokens_equal": bool(rcr == 2 * nr and torch.equal(tk[:nr // 2], toks[0][:nr // 2])),
+                                                        "note": "the serial chain kernel took 17 ms (rounds 1 - 4)"}
         finally:
             pk.armn_setlevel(1)
         del recs, toks

@@ -563,6 +563,7 @@ __device__ __forceinline__ size_t out_slot(size_t k, int swap) { return swap ? (
  * ============================================================================================================================================ */
 enum { DSC_OK = 0, DSC_WB, DSC_EB, DSC_TB, DSC_K, DSC_NCANON, DSC_FAIL, DSC_RINT, DSC_WORDS = 16 };
 #define DSC_D_INVALID 0x7FFF
+#define DM_MAXLEV 9                     /* levels of composed window maps (k_dmin_up): blocks of 8^l windows */
 /* canonical tiles kept beyond the field's own tile count: the canonical chain reads the bits of a row's narrow last tile as interior tiles and runs ahead of the
  * real tile index by some tens of tiles per row (mantissa plane of a 7200 x 3601 field: 67 596 at the last row) */
 static inline size_t dsc_margin(size_t max_tiles) { return max_tiles / 4 > 65536 ? max_tiles / 4 : 65536; }
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(64) void k_dsc_init(const unsigned *z_all, size_t z
     const unsigned *z = z_all + (size_t)f * z_stride;
     DecGeom g;
     if (!dec_geom(g, z, ni, nj, plain) || !dsc_eligible(g, nwin, min_ntx)) { st[DSC_FAIL] = 1; return; }
-    if (done_all && (done_all[(size_t)f * done_stride + DSC_OK] || g.mlast == g.istep || g.method != 4)) { st[DSC_FAIL] = 100; return; }      /* resolved already; whole rows of tiles (k_dmin_* has those); MINIMUM (its walks never rejoin: five residue classes) */
+    if (done_all && (done_all[(size_t)f * done_stride + DSC_OK] || g.mlast == g.istep)) { st[DSC_FAIL] = 100; return; }      /* resolved already; whole rows of tiles (k_dmin_* has those) */
     const size_t nwords = z_words - 1;
     unsigned *wentc = wentc_all + (size_t)f * went_stride;
     unsigned pos = g.body, t = 0;
@@ -766,33 +767,92 @@ __global__ __launch_bounds__(256) void k_dsc_jump(const unsigned *z_all, size_t 
     }
     out_all[(size_t)f * out_stride + c] = out;
 }
+/* A row whose stretch does NOT rejoin the canonical chain before the row's own odd tile (MINIMUM streams of 16-bit tokens: every tile length is a multiple of 5
+ * but the raw tile's 404 bits, a misread header of 15 throws the canonical chain into another residue class and it takes several of them to come back: 1 - 6 % of
+ * the rows of a 7201-point-wide field) is walked EXPLICITLY by the row recurrence: from the bit position behind the odd tile of the row before, `need` interior tiles
+ * ahead through the composed maps of 8^l windows (k_dmin_up's tables: the largest aligned block whose tile count still fits, ~20 dependent lookups instead of the
+ * ~150 windows of a row), then tile by tile inside the window where the row's odd tile starts.  pn = that tile's bit position; cn = its canonical index when the
+ * chain is the canonical one again by that window (the recurrence goes back to its tables), 0xFFFFFFFF when not (the next row is walked the same way). */
+__device__ bool dsc_walk_row(const DecGeom &g, const unsigned *z1, size_t nwords, const unsigned *tab, const unsigned *wentc, const uint2 *lev,
+                             const unsigned *lev_nblk, const unsigned long long *lev_off, int nlev, int nwin, unsigned p, unsigned need, unsigned &pn, unsigned &cn)
+{
+    unsigned w = p / DW, tacc = 0;
+    const unsigned end = (w + 1) * DW;
+    while (p < end && tacc < need) { p += (unsigned)dec_step(g, getbits_g(z1, nwords, p, g.C), g.n_int); tacc++; }
+    if (p < end) return false;                                       /* (a row inside one window: not a geometry this form takes) */
+    unsigned e = p - end;
+    w++;
+    for (;;) {
+        if ((int)w >= nwin || e >= (unsigned)g.ext) return false;
+        /* candidates of every level aligned at w, all loaded at once (their addresses depend on (w, e) only); the largest that fits is taken */
+        unsigned ex[DM_MAXLEV + 1], cnt[DM_MAXLEV + 1];
+        bool ok[DM_MAXLEV + 1];
+        { const unsigned v = tab[(size_t)w * DEXT + e]; ex[0] = v & 0xFFFFu; cnt[0] = v >> 16; ok[0] = true; }
+#pragma unroll
+        for (int l = 1; l <= DM_MAXLEV; l++) {
+            const unsigned b = w >> (3 * l);
+            ok[l] = l <= nlev && !(w & ((1u << (3 * l)) - 1u)) && b < lev_nblk[l] && ((unsigned long long)(b + 1) << (3 * l)) <= (unsigned long long)nwin;
+            ex[l] = 0; cnt[l] = 0;
+            if (ok[l]) { const uint2 v = lev[lev_off[l] + (size_t)b * DEXT + e]; ex[l] = v.x; cnt[l] = v.y; }
+        }
+        int take = -1;
+        unsigned tex = 0, tcnt = 0;
+#pragma unroll
+        for (int l = 0; l <= DM_MAXLEV; l++)
+            if (ok[l] && tacc + cnt[l] <= need) { take = l; tex = ex[l]; tcnt = cnt[l]; }
+        if (take < 0) break;                                         /* the odd tile starts in window w */
+        tacc += tcnt; e = tex; w += 1u << (3 * take);
+    }
+    unsigned q = w * DW + e;
+    for (unsigned k = tacc; k < need; k++) q += (unsigned)dec_step(g, getbits_g(z1, nwords, q, g.C), g.n_int);
+    pn = q;
+    cn = wentc[2 * (size_t)w] == e ? wentc[2 * (size_t)w + 1] + (need - tacc) : 0xFFFFFFFFu;
+    return true;
+}
+struct DscLev { const uint2 *lev; size_t lev_stride; int nlev; unsigned nblk[DM_MAXLEV + 1]; unsigned long long off[DM_MAXLEV + 1]; };      /* lev == nullptr: no composed maps (the merged-exit form) */
 __global__ __launch_bounds__(64) void k_dsc_rows(const unsigned *z_all, size_t z_stride, int ni, int nj, unsigned *st_all, size_t st_stride,
                                                  const short *dtab_all, size_t dtab_stride, const int *j3_all, size_t j_stride,
-                                                 unsigned *rowc_all, unsigned *head_all, size_t row_stride, unsigned capc, int plain)
+                                                 unsigned *rowc_all, unsigned *head_all, size_t row_stride, unsigned capc, int plain,
+                                                 size_t z_words = 0, const unsigned *tab_all = nullptr, const unsigned *wentc_all = nullptr, const unsigned *tpc_all = nullptr,
+                                                 size_t w_stride = 0 /* of the three, in words */, unsigned *rowpn_all = nullptr, DscLev lv = DscLev(), int nwin = 0)
 {
     const int f = blockIdx.x;
     if (threadIdx.x) return;
     unsigned *st = st_all + (size_t)f * st_stride;
     if (st[DSC_FAIL]) return;
+    const unsigned *z = z_all + (size_t)f * z_stride;
     DecGeom g;
-    if (!dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, plain)) return;
+    if (!dec_geom(g, z, ni, nj, plain)) return;
     const short *dtab = dtab_all + (size_t)f * dtab_stride;
     const int *j3 = j3_all + (size_t)f * j_stride;
     unsigned *rowc = rowc_all + (size_t)f * row_stride, *head = head_all + (size_t)f * row_stride;
+    unsigned *rowpn = rowpn_all ? rowpn_all + (size_t)f * row_stride : nullptr;
     const unsigned rint = st[DSC_RINT], lim = min(st[DSC_NCANON], capc), ntx = (unsigned)g.ntx;
-    unsigned c = ntx - 1, r = 0;
+    const size_t nwords = z_words ? z_words - 1 : 0;
+    unsigned c = ntx - 1, r = 0, pn = 0xFFFFFFFFu, nslow = 0;        /* the odd tile of row r: canonical tile c, or (c == 0xFFFFFFFF) the tile at bit pn */
     while (r < rint) {
-        if (c >= lim) { st[DSC_FAIL] = 8; return; }
+        if (c != 0xFFFFFFFFu && c >= lim) { st[DSC_FAIL] = 8; return; }
         rowc[r] = c; head[r] = 0;
+        if (rowpn) rowpn[r] = pn;
         if (r + 1 >= rint) break;
-        const int j = r + 8 < rint ? j3[c] : DSC_J_INVALID;
-        if (j != DSC_J_INVALID) { head[r] = 1; c = c + 8 * ntx - (unsigned)j; r += 8; }       /* rows r + 1 .. r + 7: k_dsc_rowfill */
-        else {
+        if (c != 0xFFFFFFFFu) {
+            const int j = r + 8 < rint ? j3[c] : DSC_J_INVALID;
+            if (j != DSC_J_INVALID) { head[r] = 1; c = c + 8 * ntx - (unsigned)j; r += 8; continue; }       /* rows r + 1 .. r + 7: k_dsc_rowfill */
             const int d = dtab[c];
-            if (d == DSC_D_INVALID) { st[DSC_FAIL] = 9; st[8] = r; st[9] = c; return; }      /* (st[8], st[9]: where, for EZHIP_DEC_SCAN=2) */
-            c = c + ntx - (unsigned)d; r++;
+            if (d != DSC_D_INVALID) { c = c + ntx - (unsigned)d; r++; continue; }
+            if (!rowpn || !lv.lev) { st[DSC_FAIL] = 9; st[8] = r; st[9] = c; return; }      /* (st[8], st[9]: where, for EZHIP_DEC_SCAN=2) */
+            pn = tpc_all[(size_t)f * w_stride + c];
         }
+        /* the explicit walk of row r + 1 from behind the odd tile at pn */
+        const unsigned start = pn + (unsigned)dec_step(g, getbits_g(z + 1, nwords, pn, g.C), g.mlast * g.istep);
+        unsigned cn;
+        if (!dsc_walk_row(g, z + 1, nwords, tab_all + (size_t)f * w_stride, wentc_all + (size_t)f * w_stride, lv.lev + (size_t)f * lv.lev_stride, lv.nblk, lv.off, lv.nlev, nwin,
+                          start, ntx - 1, pn, cn)) { st[DSC_FAIL] = 15; st[8] = r; return; }
+        c = cn;
+        if (c != 0xFFFFFFFFu) pn = 0xFFFFFFFFu;
+        r++; nslow++;
     }
+    st[10] = nslow;                                                  /* rows walked explicitly (EZHIP_DEC_SCAN=2 prints it) */
 }
 __global__ __launch_bounds__(64) void k_dsc_rowfill(const unsigned *z_all, size_t z_stride, int ni, int nj, unsigned *st_all, size_t st_stride,
                                                     const short *dtab_all, size_t dtab_stride, unsigned *rowc_all, const unsigned *head_all, size_t row_stride, unsigned capc, int plain)
@@ -822,7 +882,7 @@ __global__ __launch_bounds__(64) void k_dsc_stretch(const unsigned *z_all, size_
                                                     const unsigned *tab_all, size_t tab_stride, const unsigned *wentc_all, size_t went_stride,
                                                     const unsigned *tpc_all, size_t tpc_stride, const unsigned *rowc_all, unsigned *rowmerge_all, size_t row_stride,
                                                     unsigned *slist_all, unsigned *nlist_all, size_t list_stride,
-                                                    unsigned *tilepos_all, size_t tp_stride, int nwin, int plain)
+                                                    unsigned *tilepos_all, size_t tp_stride, int nwin, int plain, const unsigned *rowpn_all = nullptr)
 {
     const int f = blockIdx.y;
     unsigned *st = st_all + (size_t)f * st_stride;
@@ -844,8 +904,8 @@ __global__ __launch_bounds__(64) void k_dsc_stretch(const unsigned *z_all, size_
     const unsigned ntx = (unsigned)g.ntx;
     const unsigned c = rowc_all[(size_t)f * row_stride + r], cn = rowc_all[(size_t)f * row_stride + r + 1];
     unsigned t = (r + 1) * ntx;                               /* first tile of row r + 1 */
-    const unsigned tend = t + ntx - 1;                        /* the next odd tile: the chains must have met before */
-    const unsigned pos = tpc[c];
+    const unsigned tend = t + ntx - 1;                        /* the next odd tile: the chains have met before it, or the recurrence walked this row explicitly (cn == 0xFFFFFFFF) */
+    const unsigned pos = c != 0xFFFFFFFFu ? tpc[c] : rowpn_all[(size_t)f * row_stride + r];
     unsigned p = pos + (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.mlast * g.istep);
     unsigned w = pos / DW;
     const unsigned end = (w + 1) * DW;
@@ -854,14 +914,21 @@ __global__ __launch_bounds__(64) void k_dsc_stretch(const unsigned *z_all, size_
     unsigned e = p - end, n = 0;
     w++;
     bool ok = false;
-    for (int h = 0; h <= DSC_LIST && (int)w < nwin && t < tend; h++) {
-        if (wentc[2 * (size_t)w] == e) { ok = t - wentc[2 * (size_t)w + 1] == (r + 2) * ntx - 1 - cn; break; }      /* (the shift behind the stretch is the one the recurrence used) */
+    for (int h = 0; h <= DSC_LIST && (int)w < nwin && t <= tend; h++) {
+        if (wentc[2 * (size_t)w] == e) { ok = cn != 0xFFFFFFFFu && t - wentc[2 * (size_t)w + 1] == (r + 2) * ntx - 1 - cn; break; }      /* (the shift behind the stretch is the one the recurrence used) */
         if (n >= DSC_LIST || e >= (unsigned)g.ext) break;
         slist[3 * n] = w; slist[3 * n + 1] = e; slist[3 * n + 2] = t; n++;
         const unsigned v = tab[(size_t)w * DEXT + e];
         t += v >> 16; e = v & 0xFFFFu; w++;
     }
-    if (!ok || t >= tend) { st[DSC_FAIL] = 13; return; }
+    if (cn == 0xFFFFFFFFu) {
+        /* a row the recurrence walked explicitly: never canonical up to its odd tile -- every tile of it comes from the listed windows (k_dsc_stretch2 stops at tend) */
+        if (ok || t <= tend) { st[DSC_FAIL] = 16; return; }          /* (met the canonical chain after all, or the list ran out before the row did) */
+        nlist[r] = n;
+        rowmerge[r + 1] = tend + 1;
+        return;
+    }
+    if (!ok || t > tend) { st[DSC_FAIL] = 13; return; }
     nlist[r] = n;
     rowmerge[r + 1] = t;
 }
@@ -881,8 +948,8 @@ __global__ __launch_bounds__(256) void k_dsc_stretch2(const unsigned *z_all, siz
     const unsigned *sl = slist_all + (size_t)f * list_stride + ((size_t)r * DSC_LIST + i) * 3;
     unsigned *tilepos = tilepos_all + (size_t)f * tp_stride;
     unsigned pos = sl[0] * DW + sl[1], t = sl[2];
-    const unsigned end = (sl[0] + 1) * DW;
-    while (pos < end) { tilepos[t++] = pos; pos += (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.n_int); }
+    const unsigned end = (sl[0] + 1) * DW, tend = (r + 2) * (unsigned)g.ntx - 1;          /* (the odd tile of row r + 1: the last tile a stretch behind row r may hold) */
+    while (pos < end && t <= tend) { tilepos[t++] = pos; pos += (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.n_int); }
 }
 
 /* every tile outside the stretches: its canonical twin, shifted */
@@ -906,7 +973,7 @@ __global__ __launch_bounds__(256) void k_dsc_final(const unsigned *z_all, size_t
 /* the last row of tiles when its height differs: tile by tile behind the odd tile of the row before it; then the verdict */
 __global__ __launch_bounds__(64) void k_dsc_lastrow(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, unsigned *st_all, size_t st_stride,
                                                     const unsigned *tpc_all, size_t tpc_stride, const unsigned *rowc_all, size_t row_stride,
-                                                    unsigned *tilepos_all, size_t tp_stride, int *status, int plain)
+                                                    unsigned *tilepos_all, size_t tp_stride, int *status, int plain, const unsigned *rowpn_all = nullptr)
 {
     const int f = blockIdx.x;
     if (threadIdx.x) return;
@@ -919,7 +986,8 @@ __global__ __launch_bounds__(64) void k_dsc_lastrow(const unsigned *z_all, size_
     if (g.hlast != g.istep) {
         const unsigned rint = st[DSC_RINT], ntx = (unsigned)g.ntx;
         unsigned *tilepos = tilepos_all + (size_t)f * tp_stride;
-        const unsigned pos = tpc_all[(size_t)f * tpc_stride + rowc_all[(size_t)f * row_stride + rint - 1]];
+        const unsigned cl = rowc_all[(size_t)f * row_stride + rint - 1];
+        const unsigned pos = cl != 0xFFFFFFFFu ? tpc_all[(size_t)f * tpc_stride + cl] : rowpn_all[(size_t)f * row_stride + rint - 1];
         unsigned p = pos + (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.mlast * g.istep);
         unsigned t = rint * ntx;
         for (unsigned x = 0; x < ntx; x++, t++) {
@@ -945,10 +1013,9 @@ __global__ __launch_bounds__(64) void k_dsc_lastrow(const unsigned *z_all, size_
  * form above, one exit per eight-window block, gives up on them: 16 ms per 7200 x 3601 stream through the serial chain kernel, 1.1 ms here); the mantissa planes
  * of c_armn_compress32 (tiles of ~185 bits: no merged exit within eight windows either); PARALLELOGRAM streams with short rows or noisy data the parallel form
  * gives up on.  The form applies to what k_dsc_* left unresolved (dst[DSC_OK] == 0); ragged rows (a narrower last tile per row shifts everything behind it)
- * and streams of a few windows keep the serial chain kernel; dm[DM_NOTMINE] says which.
+ * go to the composed ragged form (k_drg_*), streams of a few windows keep the serial chain kernel; dm[DM_NOTMINE] says which.
  * ============================================================================================================================================ */
 enum { DM_NOTMINE = 0, DM_W0, DM_RAGGED, DM_WORDS = 8 };      /* DM_RAGGED: the canonical chain of the composed ragged form (k_drg_*) is wanted */
-#define DM_MAXLEV 9
 struct DmPlan { int nlev; unsigned nblk[DM_MAXLEV + 1]; unsigned long long off[DM_MAXLEV + 1]; unsigned long long eoff[DM_MAXLEV + 1]; };      /* level l: blocks of 8^l windows; level 0 = windows */
 /* both methods and the planes of c_armn_compress32: what counts is that every tile of a row holds the same number of points */
 __device__ __forceinline__ bool dmin_eligible(const DecGeom &g, int nwin) { return g.mlast == g.istep && g.nty >= 2 && g.ntx >= 2 && nwin >= 64; }
@@ -962,7 +1029,7 @@ __global__ void k_dmin_init(const unsigned *z_all, size_t z_stride, int ni, int 
     const bool geom = dec_geom(g, z_all + (size_t)f * z_stride, ni, nj, plain), todo = !(dst_all && dst_all[(size_t)f * dst_stride + DSC_OK]);
     const bool ok = geom && dmin_eligible(g, nwin) && (int)(g.body / DW) + 17 < nwin && todo;
     /* ragged rows of a PARALLELOGRAM stream or plane that the merged-exit form did not resolve: the same composition gives the CANONICAL chain (k_drg_*) */
-    const bool rag = geom && todo && g.method == 4 && g.mlast != g.istep && dsc_eligible(g, nwin, ragged_min_ntx) && (int)(g.body / DW) + 17 < nwin;
+    const bool rag = geom && todo && g.mlast != g.istep && dsc_eligible(g, nwin, ragged_min_ntx) && (int)(g.body / DW) + 17 < nwin;
     dm[DM_NOTMINE] = ok ? 0u : 1u; dm[DM_W0] = 0; dm[DM_RAGGED] = rag ? 1u : 0u;
 }
 /* level l + 1 from level l: T[l + 1][b][e] = the walk from entry e through blocks 8 b .. 8 b + 7 of level l: (exit, tiles).  Level 0 is the speculation table
@@ -1116,7 +1183,8 @@ __global__ __launch_bounds__(256) void k_dmin_lastrow(const unsigned *z_all, siz
 }
 
 /* ============================================================================================================================================
- * RAGGED rows by composition (round 4, k_drg_*): PARALLELOGRAM streams and planes of c_armn_compress32 whose rows end on a narrower tile ((ni - 1) % 3 != 0) and
+ * RAGGED rows by composition (round 4, k_drg_*): PARALLELOGRAM streams and planes of c_armn_compress32 whose rows end on a narrower tile ((ni - 1) % 3 != 0), since
+ * round 5 MINIMUM streams as well (ni % 5 != 0; rows whose stretch outlasts them are walked explicitly: dsc_walk_row above k_dsc_rows),
  * that the merged-exit form gave up on (mantissa planes: tiles of ~185 bits do not merge within eight windows; short rows; noisy data).  That form consists of two
  * halves: the CANONICAL chain (the walk from the first tile that never meets a row end), which it gets from merged exits of eight-window blocks, and the row
  * recurrence on top of it (k_dsc_emit .. k_dsc_lastrow: the shift of the tile index per row end, the stretches between a row end and the rejoining point).  Only
@@ -1297,7 +1365,7 @@ extern "C" size_t packhip_armn_dec_work_bytes(int ni, int nj, size_t z_words)
     const size_t capc = dec_max_tiles(ni, nj) + dsc_margin(dec_max_tiles(ni, nj)), nty = (size_t)(nj + 2) / 3 + 2;
     return al256(4 * dec_max_tiles(ni, nj)) + al256(2 * (n + 8)) + al256(2 * (size_t)DEC_BANDS * ni) + 2 * al256(4 * nwin * DEXT) + 2 * al256(8 * nwin) + 256
            /* the parallel form: canonical tile positions, shift changes, merged exits, block entries / counts, canonical window entries, rows, state */
-           + al256(4 * capc) + al256(2 * capc) + al256(2 * nwin) + 2 * al256(4 * (nwin / 8 + 2)) + 2 * al256(8 * nwin) + 4 * al256(4 * nty) + al256(12 * DSC_LIST * nty) + 2 * al256(4 * capc) + 256
+           + al256(4 * capc) + al256(2 * capc) + al256(2 * nwin) + 2 * al256(4 * (nwin / 8 + 2)) + 2 * al256(8 * nwin) + 5 * al256(4 * nty) + al256(12 * DSC_LIST * nty) + 2 * al256(4 * capc) + 256
            /* MINIMUM streams by composition: the tables of 8, 64, ... windows and the blocks' entries (k_dmin_*) */
            + dmin_bytes(nwin);
 }
@@ -1372,6 +1440,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
     unsigned *nlist = (unsigned *)wk;                       wk += al256(4 * ntyc);
     unsigned *slist = (unsigned *)wk;                       wk += al256(12 * DSC_LIST * ntyc);
     unsigned *rowhead = (unsigned *)wk;                     wk += al256(4 * ntyc);
+    unsigned *rowpn = (unsigned *)wk;                       wk += al256(4 * ntyc);      /* bit position of a row's odd tile where it is not a canonical tile (k_dsc_rows' explicit walk) */
     int *jA = (int *)wk;                                    wk += al256(4 * capc);
     int *jB = (int *)wk;                                    wk += al256(4 * capc);
     unsigned *dst = (unsigned *)wk;                         wk += 128;
@@ -1452,7 +1521,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
                 all_ok = 0;
                 const unsigned method = hv[256 + f] & 15u;
                 if (method == 4) { if ((ni - 1) % 3 == 0) want_whole = 1; else want_ragged = 1; }
-                else if (method == 3 && ni % 5 == 0) want_whole = 1;
+                else if (method == 3) { if (ni % 5 == 0) want_whole = 1; else want_ragged = 1; }
             }
         }
         if (!getenv("EZHIP_DEC_NO_DMIN") && (want_whole || want_ragged)) {
@@ -1477,7 +1546,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
                 hipLaunchKernelGGL(k_dmin_lastrow, dim3(nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dmst, ws4, went, ws4, tilepos, ws4, nwin, d_status, dst, ws4, plain);
                 hipLaunchKernelGGL(k_armn_dec_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, went, ws4, tilepos, ws4, nwin, plain, dmst, ws4);
                 }
-                if (want_ragged && rag_min_ntx != 0x7fffffff && ((ni - 1) % 3 != 0)) {
+                if (want_ragged && rag_min_ntx != 0x7fffffff) {
                     /* ragged rows the first form left unresolved: the canonical chain by composition (into wentc), then the row recurrence of the first form on
                      * a state of its own (k_drg_* above) */
                     for (int f = 0; f < nfields; f++)
@@ -1495,12 +1564,17 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
                     hipLaunchKernelGGL(k_dsc_jump<int>, gj, dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, jB, ws4, jA, ws4, 4u, (unsigned)capc, plain);
                     for (int f = 0; f < nfields; f++)
                         if (hipMemsetAsync((char *)rowhead + (size_t)f * work_stride_bytes, 0, 4 * ntyc, st) != hipSuccess) return -1;
-                    hipLaunchKernelGGL(k_dsc_rows, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, dtab, ws2b, jA, ws4, rowc, rowhead, ws4, (unsigned)capc, plain);
+                    DscLev lv;
+                    lv.lev = dmlev; lv.lev_stride = ws8; lv.nlev = pl.nlev;
+                    for (int l = 0; l <= DM_MAXLEV; l++) { lv.nblk[l] = pl.nblk[l]; lv.off[l] = pl.off[l]; }
+                    if (getenv("EZHIP_DEC_NO_SLOW_ROWS")) lv.lev = NULL;      /* development: a row whose stretch does not rejoin in time fails the form, as before round 5 */
+                    hipLaunchKernelGGL(k_dsc_rows, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, dtab, ws2b, jA, ws4, rowc, rowhead, ws4, (unsigned)capc, plain,
+                                       z_words, (const unsigned *)tab, (const unsigned *)wentc, (const unsigned *)tpc, ws4, rowpn, lv, nwin);
                     hipLaunchKernelGGL(k_dsc_rowfill, dim3((unsigned)((ntyc + 63) / 64), nfields), dim3(64), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, dtab, ws2b, rowc, rowhead, ws4, (unsigned)capc, plain);
-                    hipLaunchKernelGGL(k_dsc_stretch, dim3((unsigned)((ntyc + 63) / 64), nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, tab, ws4, wentc, ws4, tpc, ws4, rowc, rowmerge, ws4, slist, nlist, ws4, tilepos, ws4, nwin, plain);
+                    hipLaunchKernelGGL(k_dsc_stretch, dim3((unsigned)((ntyc + 63) / 64), nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, tab, ws4, wentc, ws4, tpc, ws4, rowc, rowmerge, ws4, slist, nlist, ws4, tilepos, ws4, nwin, plain, (const unsigned *)rowpn);
                     hipLaunchKernelGGL(k_dsc_stretch2, dim3((unsigned)((ntyc * DSC_LIST + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, slist, nlist, ws4, ws4, tilepos, ws4, plain);
                     hipLaunchKernelGGL(k_dsc_final, dim3((unsigned)((max_tiles + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, tpc, ws4, rowc, rowmerge, ws4, tilepos, ws4, plain);
-                    hipLaunchKernelGGL(k_dsc_lastrow, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, tpc, ws4, rowc, ws4, tilepos, ws4, d_status, plain);
+                    hipLaunchKernelGGL(k_dsc_lastrow, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, tpc, ws4, rowc, ws4, tilepos, ws4, d_status, plain, (const unsigned *)rowpn);
                     hipLaunchKernelGGL(k_drg_done, dim3(nfields), dim3(64), 0, st, dst, dst2, ws4);
                 }
             }
@@ -1514,7 +1588,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
                 fprintf(stderr, "<armn_compress> scan form, field %d: ok %u fail %u  first block window %u entry %u tiles %u  blocks %u  canonical tiles %u  interior rows %u\n",
                         f, h[DSC_OK], h[DSC_FAIL], h[DSC_WB], h[DSC_EB], h[DSC_TB], h[DSC_K], h[DSC_NCANON], h[DSC_RINT]);
                 if (hipMemcpyAsync(h, dst2 + (size_t)f * ws4, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
-                fprintf(stderr, "<armn_compress> composed ragged form, field %d: ok %u fail %u  canonical tiles %u  interior rows %u  (row %u, canonical tile %u)\n", f, h[DSC_OK], h[DSC_FAIL], h[DSC_NCANON], h[DSC_RINT], h[8], h[9]);
+                fprintf(stderr, "<armn_compress> composed ragged form, field %d: ok %u fail %u  canonical tiles %u  interior rows %u  (row %u, canonical tile %u)  rows walked explicitly %u\n", f, h[DSC_OK], h[DSC_FAIL], h[DSC_NCANON], h[DSC_RINT], h[8], h[9], h[10]);
             }
         }
     }

@@ -1105,6 +1105,42 @@ def test_armn_uncompress_minimum_streams_by_composition(ni, nj, kind, nbits, mon
     assert np.array_equal(outs[0], outs[1])
 
 
+RAGGED_MIN_SHAPES = [(4001, 203, None), (3903, 77, None), (7201, 61, None), (5204, 96, None),           # rows of >= 768 tiles: the form's own threshold
+                     (403, 300, 16), (1001, 160, 16), (603, 200, 16), (1604, 111, 16)]                    # narrow rows forced through it: most stretches outlast their row
+
+
+@pytest.mark.parametrize("ni,nj,min_ntx", RAGGED_MIN_SHAPES)
+@pytest.mark.parametrize("kind", ["smooth", "noisy"])
+@pytest.mark.parametrize("nbits", [16, 11, 9])
+def test_armn_uncompress_ragged_minimum_streams(ni, nj, min_ntx, kind, nbits, monkeypatch, capfd):
+    """MINIMUM streams whose rows end on a narrower tile (ni not a multiple of 5; c_zfstlib.c:592-643): the canonical chain by composition, the row recurrence on
+    top of it and -- where a stretch does not rejoin the canonical chain before its row ends (16- and 11-bit tokens: tile lengths are multiples of 5 but the raw
+    tile's) -- rows walked explicitly through the composed maps (k_dsc_rows / dsc_walk_row); against the serial chain kernel and the oracle's tokens"""
+    tok = pc.token_field(ni, nj, nbits, kind, seed=3 * ni + nj + nbits)
+    z, zlng = _oracle_stream(tok, ni, nj, nbits, 0)
+    assert int(z[0] & 15) == 3                                          # MINIMUM
+    zwords = (zlng - 1) // 4 + 1
+    d_z = torch.from_numpy(z[:zwords].view(np.int32).copy()).cuda()
+    words = pc.tokens_to_words(tok)
+    if min_ntx is not None:
+        monkeypatch.setenv("EZHIP_DEC_RAGGED_MIN_NTX", str(min_ntx))
+    outs = []
+    for scan in ("2", "0"):
+        monkeypatch.setenv("EZHIP_DEC_SCAN", scan)
+        d_out = torch.full((1 + ni * nj // 2 + 4,), -1, dtype=torch.int32, device="cuda")
+        capfd.readouterr()
+        assert pk.armn_uncompress_dev(d_out, d_z, zwords, ni, nj, nbits) == ni * nj * 2
+        torch.cuda.synchronize()
+        if scan == "2" and zwords * 32 >= 64 * 2048 + 17 * 2048:        # (streams of fewer than 64 windows stay with the serial kernel)
+            err = capfd.readouterr().err
+            assert "scan form, field 0: ok 1" in err or "composed ragged form, field 0: ok 1" in err, err[-600:]      # a parallel form resolved the chain, not the serial kernel
+        got = d_out.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got[:words.size], words), (scan, np.nonzero(got[:words.size] != words)[0][:5])
+        assert np.all(got[1 + ni * nj // 2:] == 0xFFFFFFFF)
+        outs.append(got)
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_armn_uncompress_minimum_batch_and_damaged(monkeypatch):
     """a batch of MINIMUM streams through the composed form, one of them cut short: the damaged one is reported (-1), the others decode"""
     ni, nj, nbits, F = 1000, 303, 16, 5

@@ -3,7 +3,7 @@ sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np, torch
 import ezcases as ec, test_oracle_packers as top
 from librmn_amd import packers as pk
-ni, nj = 7200, 3601
+ni, nj = (int(sys.argv[2]) if len(sys.argv) > 2 else 7200), (int(sys.argv[3]) if len(sys.argv) > 3 else 3601)
 f = ec.synth_field(ni, nj, seed=40, noise=float(sys.argv[1]) if len(sys.argv) > 1 else 1e-5).astype(np.float64)
 tok = np.round((f - f.min()) / (f.max() - f.min()) * 65535.0).astype(np.uint16)
 O = top.O(); O.orc_armn_compress_setlevel(0)
