@@ -1867,8 +1867,13 @@ done:
     free(bbase); free(bw); free(step); free(xr); free(esp); free(row2sp);
 }
 
+static double wall_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec; }
+/* EZHIP_TRACE_FIRST=1: a set's first-call work by part, on stderr */
+#define TRACE_PART(label) do { if (trace) { const double t1_ = wall_ms(); fprintf(stderr, "%s: %s %.2f ms\n", __func__, label, t1_ - t0_); t0_ = t1_; } } while (0)
 static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
 {
+    const int trace = getenv("EZHIP_TRACE_FIRST") != NULL;
+    double t0_ = trace ? wall_ms() : 0.0;
     if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return -1;
     int di = degree == DEG_CUBIC ? 2 : degree;
     ezh_sepplan *sp = &s->sep[di][vector_mode];
@@ -1968,6 +1973,7 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
         }
         for (int k = 0; k < EZHIP_SEP_ROWS; k++) rinfo[by * EZHIP_SEP_ROWS + k].pad0 = ok;
     }
+    TRACE_PART("host tables (columns, rows, blocks)");
     ezhip_sep_plan *p = &sp->p;
     memset(p, 0, sizeof(*p));
     p->degree = degree; p->ni_src = gi->ni; p->nj_src = gi->nj; p->ni_dst = nic; p->nj_dst = njr;
@@ -2003,12 +2009,17 @@ static int build_sep_plan(ezh_set *s, int degree, int vector_mode, int polar)
         if (special[k].kind == 1 || special[k].kind == 2) p->need_poles = 1;
         if (special[k].kind == 0) for (int q = 0; q < 4; q++) if (special[k].tap[q] < 0) p->need_poles = 1;
     }
+    TRACE_PART("15 uploads");
     build_sepx_geometry(sp, p, degree, ntap, nbx, nic, njr, blk_base, rbase, rw, rflag);
+    TRACE_PART("k_sepx geometry");
     p->pole_weighted = (gi->grtyp == 'Z' && gi->grref == 'E');
     p->vector_mode = vector_mode;
     build_bb_tables(sp, p, gi, degree, ntap, nic, njr, cidx, cw, cflag, rbase, rw, rflag, special, nspecial, vector_mode);
+    TRACE_PART("bounds tables");
     if (!vector_mode) build_enc_geometry(sp, p, gi, ntap, nic, njr, cidx, cflag, rbase, rw, rflag, special, nspecial);
+    TRACE_PART("encoder geometry");
     ezhip_sync();
+    TRACE_PART("sync");
     int ok = 1;
     for (int k = 0; k < 15; k++) ok &= (sp->dev[k] != NULL);
     free(coff); free(blk_base); free(blk_w); free(brow_s0); free(brow_n);
@@ -2066,7 +2077,6 @@ static void fill_locate_plan(const ezh_grid *gi, ezhip_locate_plan *lp)
  * round 5 -- for a C library other than the one libm_exact.h restates.
  * The same first-call pass classifies the DEHORS zone (ez_defzone_dehors.c:63-74): have_dehors decides rc = 2 and
  * extrap_degree = abort on every entry point. */
-static double wall_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec; }
 static int ensure_points(ezh_set *s)
 {
     if (s->d_x) return 0;
@@ -3048,7 +3058,11 @@ int32_t ezhip_prepare_set(void)
     if (G[s->gdin].grtyp == 'U') return yy_plan(s);
     int degree = O.degre_interp, polar = O.polar_correction == 1;
     if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return 0;       /* the averaging degrees build nothing ahead of the call */
-    if (choose_mode(s, degree, polar) == 1) return build_sep_plan(s, degree, 0, polar);
+    const int trace = getenv("EZHIP_TRACE_FIRST") != NULL;
+    double t0_ = trace ? wall_ms() : 0.0;
+    const int mode = choose_mode(s, degree, polar);
+    TRACE_PART("choose_mode");
+    if (mode == 1) return build_sep_plan(s, degree, 0, polar);
     pthread_mutex_lock(&g_plan_mtx);
     int erc = ensure_points(s);                     /* locates and classifies the DEHORS zone (first-call work, like ez_defzones) */
     pthread_mutex_unlock(&g_plan_mtx);

@@ -1405,6 +1405,38 @@ extern "C" int packhip_armn_tile_walk_parallel(const unsigned *d_z, size_t z_wor
 {
     return dec_launch(NULL, 0, d_z, 0, z_words, ni, nj, 1, 0, d_work, 0, d_status, 0, 1, 1, 1);
 }
+/* one region per field set to a byte value, all fields in ONE launch (a batch of 32 streams issued ~400 hipMemsetAsync calls per decode: ~10 us of host time each, more
+ * than the fills themselves) */
+__global__ __launch_bounds__(256) void k_dec_fill(unsigned *base, size_t stride_words, size_t nwords, unsigned v)
+{
+    unsigned *p = base + (size_t)blockIdx.y * stride_words;
+    const size_t head = (4u - (unsigned)(((size_t)p >> 2) & 3u)) & 3u;            /* words in front of the first 16-byte boundary */
+    const size_t h = head < nwords ? head : nwords, nq = (nwords - h) / 4, tail = h + 4 * nq;
+    uint4 *q = (uint4 *)(p + h);
+    const uint4 vv = make_uint4(v, v, v, v);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nq; i += (size_t)gridDim.x * 256) q[i] = vv;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < h) p[threadIdx.x] = v;
+        if (tail + threadIdx.x < nwords) p[tail + threadIdx.x] = v;              /* (at most 3 words) */
+    }
+}
+static int dec_fill(hipStream_t st, void *base, size_t stride_bytes, int nfields, size_t nbytes, int byte)
+{
+    if (!nbytes || nfields <= 0) return 0;
+    if (nfields == 1 || (nbytes & 3) || (stride_bytes & 3) || ((size_t)base & 3))         /* (one field: the runtime's fill is one call as well) */
+    {
+        for (int f = 0; f < nfields; f++)
+            if (hipMemsetAsync((char *)base + (size_t)f * stride_bytes, byte, nbytes, st) != hipSuccess) return -1;
+        return 0;
+    }
+    const unsigned v = 0x01010101u * (unsigned)(byte & 0xFF);
+    const size_t nq = nbytes / 16;
+    unsigned bx = (unsigned)((nq + 256 * 8 - 1) / (256 * 8));
+    if (bx < 1) bx = 1;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(k_dec_fill, dim3(bx, (unsigned)nfields), dim3(256), 0, st, (unsigned *)base, stride_bytes / 4, nbytes / 4, v);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *d_z, size_t z_stride_words, size_t z_words,
                       int ni, int nj, int nfields, int swap, void *d_work, size_t work_stride_bytes, int *d_status, int phase, int plain, int walk_only, int no_serial)
 {
@@ -1453,11 +1485,8 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
                                                               * EZHIP_DEC_SCAN=0: the serial kernel for everything, 2: print every field's state words */
     const size_t ws4 = work_stride_bytes / 4, ws2 = work_stride_bytes / 2;
     if (phase != 2) {
-    for (int f = 0; f < nfields; f++) {
-        if (d_out && hipMemsetAsync(d_out + (size_t)f * out_stride_words, 0, 4 * (1 + n / 2), st) != hipSuccess) return -1;
-        if (hipMemsetAsync((char *)went + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
-        if (hipMemsetAsync((char *)went8 + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
-    }
+    if (d_out && dec_fill(st, d_out, 4 * out_stride_words, nfields, 4 * (1 + n / 2), 0)) return -1;
+    if (dec_fill(st, went, work_stride_bytes, nfields, 8 * (size_t)nwin, 0xFF) || dec_fill(st, went8, work_stride_bytes, nfields, 8 * (size_t)nwin, 0xFF)) return -1;
     hipLaunchKernelGGL(k_armn_dec_spec, dim3((nwin + SPEC_WPB - 1) / SPEC_WPB, nfields), dim3(64 * SPEC_WPB), 0, st, d_z, z_stride_words, z_words, ni, nj, tab, ws4, nwin, plain);
     if (plain && no_serial) { }                     /* (the eight-window tables serve the merged-exit form and the serial chain kernel: neither runs for a plane walked this way) */
     else if (getenv("EZHIP_DEC_COMPOSE_GLOBAL"))        /* development: eight dependent global loads per entry (rounds 1 - 2) */
@@ -1473,11 +1502,8 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
     if (no_serial && hipMemsetAsync(d_status, 0, 4 * (size_t)nfields, st) != hipSuccess) return -1;
     if (scan) {
         const int ext_max = DEXT;                            /* (the kernels read the geometry from the stream; here ext only bounds a table row) */
-        for (int f = 0; f < nfields; f++) {
-            if (hipMemsetAsync((char *)wentc + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
-            if (hipMemsetAsync((char *)wentc8 + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
-            if (hipMemsetAsync((char *)rowhead + (size_t)f * work_stride_bytes, 0, 4 * ntyc, st) != hipSuccess) return -1;      /* (the row walk marks the rows it steps from) */
-        }
+        if (dec_fill(st, wentc, work_stride_bytes, nfields, 8 * (size_t)nwin, 0xFF) || dec_fill(st, wentc8, work_stride_bytes, nfields, 8 * (size_t)nwin, 0xFF)
+            || dec_fill(st, rowhead, work_stride_bytes, nfields, 4 * ntyc, 0)) return -1;      /* (the row walk marks the rows it steps from) */
         const size_t ws2b = work_stride_bytes / 2;
         hipLaunchKernelGGL(k_dsc_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, wentc, ws4, nwin, plain,
                            /* a plane of c_armn_compress32 goes straight to the composed forms below (the parallel form's kernels then see FAIL and
@@ -1537,8 +1563,8 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
             for (int l = 0; l < pl.nlev; l++)
                 hipLaunchKernelGGL(k_dmin_up, dim3((unsigned)(((unsigned long long)pl.nblk[l + 1] * DEXT + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dmst, ws4, tab, ws4, dmlev, ws8, pl, l, DEXT, plain);
             if (pl.nlev >= 1) {
-                for (int f = 0; f < nfields; f++)          /* the blocks' entries start out invalid (small: one uint2 per block of every level) */
-                    if (hipMemsetAsync((char *)(dmlev + pl.eoff[1]) + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)(pl.off[0] - pl.eoff[1]), st) != hipSuccess) return -1;
+                /* the blocks' entries start out invalid (small: one uint2 per block of every level) */
+                if (dec_fill(st, dmlev + pl.eoff[1], work_stride_bytes, nfields, 8 * (size_t)(pl.off[0] - pl.eoff[1]), 0xFF)) return -1;
                 if (want_whole) {
                 hipLaunchKernelGGL(k_dmin_top, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dmst, ws4, tab, ws4, dmlev, ws8, went, ws4, pl, DEXT, plain);
                 for (int l = pl.nlev - 1; l >= 0; l--)
@@ -1549,8 +1575,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
                 if (want_ragged && rag_min_ntx != 0x7fffffff) {
                     /* ragged rows the first form left unresolved: the canonical chain by composition (into wentc), then the row recurrence of the first form on
                      * a state of its own (k_drg_* above) */
-                    for (int f = 0; f < nfields; f++)
-                        if (hipMemsetAsync((char *)wentc + (size_t)f * work_stride_bytes, 0xFF, 8 * (size_t)nwin, st) != hipSuccess) return -1;
+                    if (dec_fill(st, wentc, work_stride_bytes, nfields, 8 * (size_t)nwin, 0xFF)) return -1;
                     hipLaunchKernelGGL(k_dsc_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, wentc, ws4, nwin, plain, rag_min_ntx, (const unsigned *)dst, ws4);
                     hipLaunchKernelGGL(k_dmin_top, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dmst, ws4, tab, ws4, dmlev, ws8, wentc, ws4, pl, DEXT, plain, 1);
                     for (int l = pl.nlev - 1; l >= 0; l--)
@@ -1562,8 +1587,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
                     hipLaunchKernelGGL(k_dsc_jump<short>, gj, dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, dtab, ws2b, jA, ws4, 1u, (unsigned)capc, plain);
                     hipLaunchKernelGGL(k_dsc_jump<int>, gj, dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, jA, ws4, jB, ws4, 2u, (unsigned)capc, plain);
                     hipLaunchKernelGGL(k_dsc_jump<int>, gj, dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, jB, ws4, jA, ws4, 4u, (unsigned)capc, plain);
-                    for (int f = 0; f < nfields; f++)
-                        if (hipMemsetAsync((char *)rowhead + (size_t)f * work_stride_bytes, 0, 4 * ntyc, st) != hipSuccess) return -1;
+                    if (dec_fill(st, rowhead, work_stride_bytes, nfields, 4 * ntyc, 0)) return -1;
                     DscLev lv;
                     lv.lev = dmlev; lv.lev_stride = ws8; lv.nlev = pl.nlev;
                     for (int l = 0; l <= DM_MAXLEV; l++) { lv.nblk[l] = pl.nblk[l]; lv.off[l] = pl.off[l]; }
