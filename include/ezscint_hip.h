@@ -94,6 +94,10 @@ void ez_xpncof(int32_t *i1, int32_t *i2, int32_t *j1, int32_t *j2, int32_t *exte
  * EZHIP_CACHE_MB at first use, or the call below); a set that does not fit keeps the gathering kernels: same results, slower. */
 void ezhip_set_cache_budget_mb(int32_t mb);                 /* 0: no staged-tile caches at all */
 long long ezhip_cache_bytes(void);                           /* bytes the staged-tile caches of all sets hold now */
+/* Rotated sources ('E', Z-on-'E') are located on the device with the C library's REAL sinf / cosf / asinf / atan2f restated operation by operation
+ * (librmn_amd/csrc/libm_exact.h: GNU libc 2.35, x86-64 FMA variants -- what the reference's ez_gfxyfll.c:38-57 reaches through the Fortran intrinsics on such a host).
+ * 1: this process's C library is that one (sampled once); 0: it is not, and such sets are located by host threads through the library itself, as with EZHIP_HOST_LOCATE=1 */
+int32_t ezhip_libm_exact_matches_host(void);
 void    ezhip_use_stream(void *hip_stream);
 /* 0 for the shipped library; 1 when it was built with -DEZHIP_DEVELOP (`make develop`: the kernels' development knock-outs, which an
  * environment variable can switch on, exist only in that build). */

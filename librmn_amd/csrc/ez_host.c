@@ -18,6 +18,7 @@
 #include <math.h>
 #include <pthread.h>
 #include <unistd.h>
+#include "libm_exact.h"
 #include <sys/mman.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -179,14 +180,19 @@ static void h_cxgaig(char t, int *i1, int *i2, int *i3, int *i4, float x1, float
 /* Gaussian latitudes: ez_glat.inc:26-67 -> DGAUSS (dgauss.F:90-131) -> ORDLEG (ordleg.F:50-86)   */
 /* all REAL arithmetic with the float libm, as the reference                                    */
 /* ------------------------------------------------------------------------------------------ */
-static float legendre_norm(float coa, int ir)
+/* ORDLEG's leading coefficient: a product over n = 1 .. ir that depends on ir alone (the reference recomputes it in every call: the same REAL operations, the same value) */
+static float legendre_c1(int ir)
 {
-    float theta = acosf(coa), c1 = sqrtf(2.f), fn = 0.f, fn2 = 0.f;
+    float c1 = sqrtf(2.f);
     for (int n = 1; n <= ir; n++) {
-        fn = (float)n; fn2 = 2.f * fn;
-        float q = fn2 * fn2;
+        const float fn2 = 2.f * (float)n, q = fn2 * fn2;
         c1 = c1 * sqrtf(1.0f - 1.0f / q);
     }
+    return c1;
+}
+static float legendre_norm(float coa, int ir, float c1)
+{
+    const float theta = acosf(coa), fn = ir >= 1 ? (float)ir : 0.f, fn2 = ir >= 1 ? 2.f * fn : 0.f;
     float ang = fn * theta, s1 = 0.0f, c4 = 1.0f, a = -1.0f, b = 0.0f;
     for (int kk = 1; kk <= ir + 1; kk += 2) {
         int k = kk - 1;
@@ -199,9 +205,30 @@ static float legendre_norm(float coa, int ir)
     return s1 * c1;
 }
 
+/* the Newton iterations of the roots are independent of each other (dgauss.F:107-125): slices of them on host threads, every root by the reference's own operations */
+typedef struct { float *rt; int nj, i0, i1; float normn, normnm, c1n, c1nm; } glat_job;
+static void *glat_worker(void *arg)
+{
+    glat_job *j = (glat_job *)arg;
+    const float tol = 1.0e-6f;
+    float *rt = j->rt;
+    const int nj = j->nj;
+    for (int i = j->i0; i < j->i1; i++) {
+        float delta;
+        do {
+            float pn = j->normn * legendre_norm(rt[i], nj, j->c1n);
+            float pnm = j->normnm * legendre_norm(rt[i], nj - 1, j->c1nm);
+            float rdpdx = (rt[i] * rt[i] - 1.0f) / ((float)nj * (rt[i] * pn - pnm));
+            delta = -pn * rdpdx;
+            rt[i] = rt[i] + delta;
+        } while (fabsf(delta) > tol);
+        rt[nj + 1 - i] = -rt[i];
+    }
+    return NULL;
+}
 static void h_gauss_lat(float *lat, int nj)
 {
-    const float pie = 3.1415926535898f, rdtodg = 57.295779513082f, tol = 1.0e-6f;
+    const float pie = 3.1415926535898f, rdtodg = 57.295779513082f;
     float *rt = (float *)calloc((size_t)nj + 2, sizeof(float));
     float normn = sqrtf(2.0f / (2.0f * (float)nj + 1.0f)), normnm = sqrtf(2.0f / (2.0f * (float)nj - 1.0f));
     int half = nj / 2;
@@ -209,16 +236,19 @@ static void h_gauss_lat(float *lat, int nj)
         float t = (float)(4 * i - 1) * pie / (float)(4 * nj + 2);
         rt[i] = cosf(t + 1.0f / (8.0f * (float)(nj * nj) * tanf(t)));
     }
-    for (int i = 1; i <= half; i++) {
-        float delta;
-        do {
-            float pn = normn * legendre_norm(rt[i], nj);
-            float pnm = normnm * legendre_norm(rt[i], nj - 1);
-            float rdpdx = (rt[i] * rt[i] - 1.0f) / ((float)nj * (rt[i] * pn - pnm));
-            delta = -pn * rdpdx;
-            rt[i] = rt[i] + delta;
-        } while (fabsf(delta) > tol);
-        rt[nj + 1 - i] = -rt[i];
+    {
+        long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        int nt = half >= 256 ? (int)(ncpu > 16 ? 16 : ncpu < 1 ? 1 : ncpu) : 1;
+        if (getenv("EZHIP_GLAT_THREADS")) nt = atoi(getenv("EZHIP_GLAT_THREADS"));
+        if (nt < 1) nt = 1;
+        if (nt > 16) nt = 16;
+        glat_job job[16]; pthread_t th[16];
+        const float c1n = legendre_c1(nj), c1nm = legendre_c1(nj - 1);
+        for (int t = 0; t < nt; t++) {
+            job[t] = (glat_job){rt, nj, 1 + (int)((long long)half * t / nt), 1 + (int)((long long)half * (t + 1) / nt), normn, normnm, c1n, c1nm};
+            if (t == nt - 1 || pthread_create(&th[t], NULL, glat_worker, &job[t])) { glat_worker(&job[t]); th[t] = 0; }
+        }
+        for (int t = 0; t < nt - 1; t++) if (th[t]) pthread_join(th[t], NULL);
     }
     if (nj % 2) rt[half + 1] = 0.0f;
     /* ez_glat: reverse to south->north, then degrees */
@@ -2077,6 +2107,33 @@ static void fill_locate_plan(const ezh_grid *gi, ezhip_locate_plan *lp)
  * round 5 -- for a C library other than the one libm_exact.h restates.
  * The same first-call pass classifies the DEHORS zone (ez_defzone_dehors.c:63-74): have_dehors decides rc = 2 and
  * extrap_degree = abort on every entry point. */
+/* Is the C library behind this process the one libm_exact.h restates?  Checked once, on the host compilation of the header: 4 x 16 384 arguments in the ranges the
+ * rotated-frame locate uses plus arbitrary bit patterns (another implementation of sinf differs on a large share of arguments; tools/check_libm_exact.c is the
+ * exhaustive form).  0: rotated sources are located by host threads through that library instead (what EZHIP_HOST_LOCATE=1 asks for) */
+static int libm_exact_matches_host(void)
+{
+    static int state = -1;
+    if (state >= 0) return state;
+    unsigned long long r = 0x9E3779B97F4A7C15ULL;
+    int ok = 1;
+    for (int k = 0; k < 4096 && ok; k++) {
+        r ^= r << 13; r ^= r >> 7; r ^= r << 17;
+        const float any = glx_float((uint32_t)r), ang = (float)((double)(r >> 40) * (14.0 / 16777216.0) - 7.0), unit = (float)((double)((r >> 16) & 0xFFFFFF) * (2.0 / 16777216.0) - 1.0);
+        const float other = (float)((double)(r & 0xFFFF) * (2.0 / 65536.0) - 1.0);
+        const float a[4] = {any, ang, unit, other};
+        for (int q = 0; q < 4 && ok; q++) {
+            const float x = a[q], y = a[(q + 1) & 3];
+            const float g0 = glx_sinf(x), h0 = sinf(x), g1 = glx_cosf(x), h1 = cosf(x), g2 = glx_asinf(x), h2 = asinf(x), g3 = glx_atan2f(x, y), h3 = atan2f(x, y);
+            ok = (glx_bits(g0) == glx_bits(h0) || (g0 != g0 && h0 != h0)) && (glx_bits(g1) == glx_bits(h1) || (g1 != g1 && h1 != h1))
+              && (glx_bits(g2) == glx_bits(h2) || (g2 != g2 && h2 != h2)) && (glx_bits(g3) == glx_bits(h3) || (g3 != g3 && h3 != h3));
+        }
+    }
+    if (!ok) fprintf(stderr, "<ezscint> the C library's sinf / cosf / asinf / atan2f are not the ones libm_exact.h restates (GNU libc 2.35, x86-64 FMA variants): "
+                             "rotated sources are located on host threads through the library itself\n");
+    state = ok;
+    return ok;
+}
+int32_t ezhip_libm_exact_matches_host(void) { return libm_exact_matches_host(); }
 static int ensure_points(ezh_set *s)
 {
     if (s->d_x) return 0;
@@ -2085,7 +2142,7 @@ static int ensure_points(ezh_set *s)
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     size_t n = (size_t)go->ni * go->nj;
     int rotated = gi->grtyp == 'E' || (gi->grtyp == 'Z' && gi->grref == 'E');
-    int host_locate = (rotated && getenv("EZHIP_HOST_LOCATE")) || (gi->grtyp == 'G' && gi->ig[0] != 0) || gi->grtyp == '!';      /* '!': the REAL libm chain of ez_lambxyfll99 lives in the host code */      /* hemispheric 'G': the reference's search quirk lives in the host code only */
+    int host_locate = (rotated && (getenv("EZHIP_HOST_LOCATE") || !libm_exact_matches_host())) || (gi->grtyp == 'G' && gi->ig[0] != 0) || gi->grtyp == '!';      /* '!': the REAL libm chain of ez_lambxyfll99 lives in the host code */      /* hemispheric 'G': the reference's search quirk lives in the host code only */
     float *hx = NULL, *hy = NULL;
     if (ensure_grid_dev(gi)) return -1;
     if (trace) { ezhip_sync(); t1 = wall_ms(); fprintf(stderr, "ensure_points: source tables on the device %.2f ms\n", t1 - t0); t0 = t1; }

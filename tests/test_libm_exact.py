@@ -16,3 +16,14 @@ def test_libm_exact_header_equals_the_c_library(leg, tmp_path):
     out = subprocess.run([exe, "8", "8", "251"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "sinf 0, cosf 0, asinf 0, atanf 0" in out.stdout and "atan2f 0 of" in out.stdout, out.stdout
+
+
+@both_legs
+def test_library_recognises_this_c_library(leg):
+    """the library's own sampled check (made once, before the first rotated source is located on the device) agrees with the exhaustive one above on this image"""
+    import ctypes, time
+    from librmn_amd import lib
+    L = lib.load_library()
+    t0 = time.perf_counter()
+    assert L.ezhip_libm_exact_matches_host() == 1
+    assert time.perf_counter() - t0 < 0.5
