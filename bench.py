@@ -363,12 +363,16 @@ def extras(ez, torch, stream, d_out, d_in):
             f32 = _ec.synth_field(ni32, NJ_D, seed=5); n32 = ni32 * NJ_D
             zl32, z32 = pk.armn_compress32(f32, ni32, NJ_D, 32)
             if zl32 <= 0: continue
-            best = bestl = 1e9
+            best = bestl = bestf = 1e9
+            out_a = np.zeros(n32, np.float32); out_b = np.zeros(n32, np.float32)          # the caller's field buffers, kept across calls (touched: no first-touch page faults in the clock)
+            out_a.fill(1.0); out_b.fill(1.0)
             for _ in range(3):
-                t0_ = time.perf_counter(); rc32, back32 = pk.armn_uncompress32(z32, ni32, NJ_D, 32); best = min(best, time.perf_counter() - t0_)
-                t0_ = time.perf_counter(); rcl, backl = pk.armn_uncompress32_lng(z32, 4 * ((zl32 + 3) // 4), ni32, NJ_D, 32); bestl = min(bestl, time.perf_counter() - t0_)
+                t0_ = time.perf_counter(); rc32, back32 = pk.armn_uncompress32(z32, ni32, NJ_D, 32, out=out_a); best = min(best, time.perf_counter() - t0_)
+                t0_ = time.perf_counter(); rcl, backl = pk.armn_uncompress32_lng(z32, 4 * ((zl32 + 3) // 4), ni32, NJ_D, 32, out=out_b); bestl = min(bestl, time.perf_counter() - t0_)
+                t0_ = time.perf_counter(); rcf, backf = pk.armn_uncompress32(z32, ni32, NJ_D, 32); bestf = min(bestf, time.perf_counter() - t0_)      # into a fresh array each call
+                del backf
             ex[key] = {"workload": "c_armn_uncompress32 of a %d x %d REAL field (32 bits kept, ratio %.2f), host arrays" % (ni32, NJ_D, zl32 / (4.0 * n32)),
-                       "ms_per_field": best * 1e3, "bit_identical": bool(rc32 == n32 and np.array_equal(back32.view(np.uint32), f32.view(np.uint32))),
+                       "ms_per_field": best * 1e3, "ms_per_field_into_a_fresh_array": bestf * 1e3, "bit_identical": bool(rc32 == n32 and np.array_equal(back32.view(np.uint32), f32.view(np.uint32))),
                        "GBps": (zl32 + 4.0 * n32) / best / 1e9, "frac_of_hbm_peak": (zl32 + 4.0 * n32) / best / 1e9 / HBM_PEAK_GBPS,
                        "length_given_ms": bestl * 1e3, "length_given_bit_identical": bool(rcl == n32 and np.array_equal(backl.view(np.uint32), f32.view(np.uint32))),
                        "note": "ms_per_field: c_armn_uncompress32 as the reference declares it (no length: the record's end is found by walking the chains on two host "

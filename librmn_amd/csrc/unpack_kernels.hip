@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * SPEC_WPB) void k_armn_dec_spec(const unsigned 
                                                                 unsigned *tab_all, size_t tab_stride, int nwin, int plain)
 {
     __shared__ unsigned s_all[SPEC_WPB][DWW + DTAIL];
-    __shared__ unsigned short nx_all[SPEC_WPB][DW];
+    __shared__ __attribute__((aligned(16))) unsigned short nx_all[SPEC_WPB][DW];
     const int f = blockIdx.y, wv = threadIdx.x >> 6, lane = threadIdx.x & 63, win = blockIdx.x * SPEC_WPB + wv;
     if (win >= nwin) return;                                      /* (a whole wave leaves: nothing below synchronises across waves) */
     const unsigned *z = z_all + (size_t)f * z_stride;
@@ -160,7 +160,21 @@ __global__ __launch_bounds__(64 * SPEC_WPB) void k_armn_dec_spec(const unsigned 
         return;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int p = lane; p < DW; p += 64) nx[p] = (unsigned short)(p + dec_step(g, getbits(s, (unsigned)p, g.C), g.n_int));
+    /* the successor of every bit position: a lane takes the positions 2 lane, 2 lane + 1 of every group of 128 -- one 64-bit read of the stream serves both
+     * headers (C <= 5 bits each), the two 16-bit successors go out as one word, lane after lane.  (Round 5; a position per lane and iteration read the stream
+     * twice as often and wrote half-words.  The kernel's time did not move -- 2.40 ms per 16 cfg5 streams before and after: it is the chase below, ~36 dependent
+     * LDS reads per lane at scattered addresses with the LDS array 63 % busy, that bounds it: profiles/r05_experiments.txt) */
+    {
+        unsigned *nx32 = (unsigned *)nx;
+#pragma unroll 4
+        for (int k = 0; k < DW / 128; k++) {
+            const unsigned p0 = 128u * (unsigned)k + 2u * (unsigned)lane, wi = p0 >> 5, sh = p0 & 31u;
+            const unsigned long long v = ((unsigned long long)s[wi] << 32 | s[wi + 1]) << sh;
+            const unsigned t = (unsigned)(v >> 32);                                   /* the 32 bits from position p0 on */
+            const unsigned h0 = t >> (32 - g.C), h1 = (t << 1) >> (32 - g.C);
+            nx32[64 * k + lane] = ((p0 + (unsigned)dec_step(g, h0, g.n_int)) & 0xFFFFu) | (p0 + 1u + (unsigned)dec_step(g, h1, g.n_int)) << 16;
+        }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int e = lane; e < g.ext; e += 64) {
         unsigned p = (unsigned)e, cnt = 0;

@@ -219,19 +219,25 @@ def armn_compress32(fld, ni, nj, znbits):
     return zlng, z
 
 
-def armn_uncompress32(z, ni, nj, znbits):
+def armn_uncompress32(z, ni, nj, znbits, out=None):
+    """c_armn_uncompress32 (the reference's signature: no length); out: a float32 array of ni * nj to decode into (a caller that keeps its field buffer, as the
+    reference's callers do, pays no page faults of a fresh one)"""
     L = _lib()
     L.c_armn_uncompress32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-    out = np.zeros(ni * nj, np.float32)
+    if out is None:
+        out = np.zeros(ni * nj, np.float32)
+    assert out.dtype == np.float32 and out.size >= ni * nj and out.flags["C_CONTIGUOUS"]
     rc = L.c_armn_uncompress32(out.ctypes.data, z.ctypes.data, ni, nj, 1, znbits)
     return rc, out
 
 
-def armn_uncompress32_lng(z, zbytes, ni, nj, znbits):
+def armn_uncompress32_lng(z, zbytes, ni, nj, znbits, out=None):
     """c_armn_uncompress32_lng: the stream's byte length is given (an upper bound inside the buffer), the tile chains are followed on the device"""
     L = _lib()
     L.c_armn_uncompress32_lng.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-    out = np.zeros(ni * nj, np.float32)
+    if out is None:
+        out = np.zeros(ni * nj, np.float32)
+    assert out.dtype == np.float32 and out.size >= ni * nj and out.flags["C_CONTIGUOUS"]
     rc = L.c_armn_uncompress32_lng(out.ctypes.data, z.ctypes.data, int(zbytes), ni, nj, 1, znbits)
     return rc, out
 
