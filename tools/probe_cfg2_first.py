@@ -24,3 +24,11 @@ torch.cuda.synchronize(); t4 = time.perf_counter()
 assert ez.ezsint_dev(d_out, d_in) >= 0
 torch.cuda.synchronize(); t5 = time.perf_counter()
 print(f"define G {1e3 * (ta - t0):.2f} | define L {1e3 * (tb - ta):.2f} | c_ezdefset {1e3 * (t1 - tb):.2f} | prepare_set {1e3 * (t2 - t1):.2f} | first c_ezsint_dev {1e3 * (t4 - t3):.2f} | second {1e3 * (t5 - t4):.2f} ms")
+# a second separable set in the same process (another target): without the process's one-time work
+ta = time.perf_counter()
+g_out2 = ez.ezqkdef(no - 16, mo - 7, "L", 5, 5, 0, 0)
+assert ez.ezdefset(g_out2, g_in) == 1
+tb = time.perf_counter()
+assert ez.prepare_set() >= 0
+torch.cuda.synchronize(); tc = time.perf_counter()
+print(f"second set in the same process: define + set {1e3 * (tb - ta):.2f} | prepare_set {1e3 * (tc - tb):.2f} ms")
