@@ -266,6 +266,22 @@ def extras(ez, torch, stream, d_out, d_in):
                                                  "64 MB of results stream next to the staged source windows; REAL (packed fp32) evaluation with a REAL*8 second pass where the wind is small under a strong "
                                                  "stencil; no unit saturated (VALU 40 %, LDS 47 % of the kernel: SQ counters, profiles/r05_experiments.txt): the vector L1 returns in order, a block's round "
                                                  "trips bound it; the pipelined form (persistent blocks, LDS-DMA double buffering) was built and measured slower"}}
+        # several pairs of the same grid set at once (wind levels): c_ezuvint_batch_dev reads x, y and the rotation of a point once per batch (12 of a pair's 34 bytes
+        # per point) -- one launch of k_uvt's batch form, the special points' kernel once with a pair index; results equal to single calls bit for bit
+        KB = 8
+        d_ub = torch.stack([d_u * (1.0 + 0.01 * f) for f in range(KB)]).contiguous(); d_vb = torch.stack([d_v * (1.0 - 0.01 * f) for f in range(KB)]).contiguous()
+        o_ub = torch.empty((KB, no * mo), dtype=torch.float32, device="cuda"); o_vb = torch.empty_like(o_ub)
+        usb = ev_time(lambda: ez.ezuvint_batch_dev(o_ub, o_vb, d_ub, d_vb, KB), 10) / KB
+        r_u = torch.empty_like(o_u); r_v = torch.empty_like(o_v)
+        same_b = True
+        for f in (0, KB - 1):
+            assert ez.ezuvint_dev(r_u, r_v, d_ub[f], d_vb[f]) >= 0
+            torch.cuda.synchronize()
+            same_b = same_b and bool(torch.equal(r_u, o_ub[f]) and torch.equal(r_v, o_vb[f]))
+        ex["cfg3_uvint_batch"] = {"workload": "c_ezuvint_batch_dev, %d pairs per call, bicubic, Z-on-E 2560x1280 -> L 4000x2000, polar_correction=yes" % KB,
+                                  "us_per_pair": usb, "Mpoint_pairs_per_s": no * mo / usb, "algorithmic_GBps": algo3 / usb / 1e3, "frac_of_hbm_peak": algo3 / usb / 1e3 / HBM_PEAK_GBPS,
+                                  "equal_to_single_calls_bitwise": same_b, "single_call_us_per_pair": us}
+        del d_ub, d_vb, o_ub, o_vb, r_u, r_v
         # the scalar twin on the same grid pair: c_ezsint from the rotated source (k_st: stencil windows staged in LDS, the literal REAL*8 form of the reference)
         us1 = ev_time(lambda: ez.ezsint_dev(o_u, d_u), 20)
         algo1 = 4 * ni * nj + 4 * no * mo

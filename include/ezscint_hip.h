@@ -114,6 +114,11 @@ int32_t c_gdxysint_dev(float *d_zout, const float *d_zin, int32_t gdin, const fl
 int32_t c_gdxyfll_dev(int32_t gdid, float *d_x, float *d_y, const float *d_lat, const float *d_lon, int32_t n);   /* c_gdxyfll_orig on device data (no row inversion on y-inverted 'G' grids; not for hemispheric 'G' grids) */
 /* nfields independent fields on the current grid set; field f at d_zin + f*ni_in*nj_in, d_zout + f*ni_out*nj_out */
 int32_t c_ezsint_batch_dev(float *d_zout, const float *d_zin, int32_t nfields);
+/* npairs wind pairs of the current grid set (ezuvint.c:51-94 per pair), device resident and contiguous: pair f's components at d_uuin / d_vvin + f * ni_in * nj_in,
+ * its results at d_uuout / d_vvout + f * ni_out * nj_out -- the results of npairs c_ezuvint_dev calls, bit for bit.  Bicubic from a rotated source with wrap
+ * (BASELINE cfg3), from the set's second pair on: ONE staged-tile launch for all pairs (x, y and the rotation of a point read once per batch); anything else:
+ * pair by pair.  Returns like c_ezuvint_dev. */
+int32_t c_ezuvint_batch_dev(float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin, int32_t npairs);
 /* the same launch additionally leaves, per field, {min key, max key, 0} triples (order-preserving uint32 keys of the floats)
  * of every thread block's output at d_partials[f * stride_words + 3 k], k < *partials_per_field -- compact_float's
  * min/max pass fused into the interpolation.  -2: the plan has no single-launch path (use c_ezsint_batch_dev). */

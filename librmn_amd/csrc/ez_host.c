@@ -62,6 +62,7 @@ typedef struct ezh_set {
     float *d_scratch;       /* float[8]: fill value + keys, pole values */
     float *d_poles_batch; int poles_cap;   /* pole values of a c_ezsint_batch_dev batch (2 per field) */
     float *d_prow;          /* 2 * ni_src synthetic polar wind rows (vector mode), u then v: [u_n, u_s, v_n, v_s] */
+    int prow_pairs;         /* pairs d_prow holds rows for (1; more after a c_ezuvint_batch_dev) */
     float *d_avg[2];        /* interp_degree = average / sph_average: [x | row widening | y_low | y_high] of the target cells (ez_avg.inc:55-78, ez_avg_sph.inc:63-98) */
     void *d_uvt_tiles; int uvt_shape, uvt_cap, uvt_stats[4];
     void *d_st_tiles[2], *d_st_streams[2]; int st_key[2], st_cap[2], st_stats[2][4];      /* k_st1 / k_st (slot 0: bilinear, 1: bicubic): the tile table (scalar zone rules) and the tile-ordered {x, y} copy; st_key: the zone options they were built under, -1: tried, not worth it */
@@ -2697,6 +2698,9 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
     return ierc;
 }
 
+/* c_ezuvint_batch_dev in flight on this host thread: n pairs (0: none), pair f's components at d_in + f * in_stride, its results at d_out + f * out_stride;
+ * refused := 1 when the launch layer has no batch form for the plan after all (nothing was launched: the caller goes pair by pair) */
+static __thread struct { int n, refused; size_t in_stride, out_stride; } t_pairs;
 /* the polar wind rows of the pair being interpolated, handed from uvint_impl to the per-point pair launch (per host thread) */
 static __thread struct { float *out; const float *plon2, *ax; float xg4_n, xg4_s; int weighted, active; } t_pwjob;
 /* both components of a wind pair on the per-point path in ONE pass (k_pts2); returns -2 when the set is not on that path */
@@ -2745,7 +2749,15 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
         }
         pthread_mutex_unlock(&g_plan_mtx);
     }
-    if (ezhip_interp_pts2(&pu, &pv, d_uo, d_vo, d_ui, d_vi, s->d_x, s->d_y, go->ni * go->nj)) return -1;
+    if (t_pairs.n > 1) {
+        if (!pu.cspec_valid || !pu.uvt_streams) { t_pairs.refused = 1; return -1; }
+        pu.npairs = t_pairs.n; pu.pair_in_stride = t_pairs.in_stride; pu.pair_out_stride = t_pairs.out_stride; pu.pair_rows_stride = 4 * gi->ni;
+    }
+    {
+        const int prc = ezhip_interp_pts2(&pu, &pv, d_uo, d_vo, d_ui, d_vi, s->d_x, s->d_y, go->ni * go->nj);
+        if (prc == -2 && t_pairs.n > 1) { t_pairs.refused = 1; return -1; }
+        if (prc) return -1;
+    }
     if (use_cache && !pu.cspec_valid && s->cspec_key == 0) {              /* (the first option set seen on the set is the one that is kept: the arrays are never replaced while launches may read them) */
         const int cnt = ezhip_pts2_special_snapshot(NULL, NULL, NULL, 0, s->d_x, s->d_y);        /* synchronises: once per set and option set */
         if (cnt >= 0) {
@@ -3458,7 +3470,14 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
     if (polar && !s->extrap && !same) {
         /* synthetic polar wind rows (ez_calcnpolarwind.c): one small kernel, no host round trip.  The row longitudes
          * and the polar-stereographic xg4 depend on the grid only: computed once on the host. */
-        if (!s->d_prow) s->d_prow = (float *)ezhip_malloc(sizeof(float) * 4 * (size_t)ni);
+        {
+            const int np = t_pairs.n > 1 ? t_pairs.n : 1;
+            if (!s->d_prow || s->prow_pairs < np) {             /* (ezhip_free waits for the device: no launch still reads the rows that go) */
+                ezhip_free(s->d_prow);
+                s->d_prow = (float *)ezhip_malloc(sizeof(float) * 4 * (size_t)ni * (size_t)np);
+                s->prow_pairs = s->d_prow ? np : 0;
+            }
+        }
         if (!s->d_prow) return -1;
         if (!gi->d_plon2) {
             float *pl = (float *)malloc(sizeof(float) * 3 * (size_t)ni);
@@ -3610,6 +3629,57 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
 
 int32_t c_ezuvint_dev(float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin) { return uvint_impl(d_uuout, d_vvout, d_uuin, d_vvin, 0); }
 int32_t c_ezwdint_dev(float *d_spdout, float *d_dirout, const float *d_uuin, const float *d_vvin) { return uvint_impl(d_spdout, d_dirout, d_uuin, d_vvin, 1); }
+
+/* npairs wind pairs of the current grid set, device resident: pair f's components at d_uuin / d_vvin + f * ni_in * nj_in, its results at d_uuout / d_vvout +
+ * f * ni_out * nj_out.  The results are those of npairs c_ezuvint_dev calls, bit for bit (ezuvint.c:51-94 per pair).  Where the set runs its pairs from LDS-staged
+ * stencil windows (bicubic from a rotated source with wrap, from the set's second call on: k_uvt) ONE launch takes all pairs: x, y and the rotation of a target
+ * point -- 12 of the 34 bytes a pair moves per point -- are read once per batch, the tile table and the axis records too; any other set, option or state: pair
+ * by pair.  Returns 0 / 2 like c_ezuvint_dev (2: points outside the source), -1 on error. */
+static int pair_batch_ready(ezh_set *s)
+{
+    if (G[s->gdin].grtyp == 'U' || G[s->gdout].grtyp == 'U' || s->gdin == s->gdout) return 0;
+    const int degree = O.degre_interp, polar = O.polar_correction == 1;
+    if (degree != DEG_CUBIC) return 0;
+    if (getenv("EZHIP_POLAR_WIND_HOST") || getenv("EZHIP_NO_PTS2") || getenv("EZHIP_NO_UVT") || getenv("EZHIP_WIND_NO_FUSE") || getenv("EZHIP_WIND_NO_MATRIX") ||
+        getenv("EZHIP_WIND_FULL_MATRIX") || getenv("EZHIP_UVT_NO_STREAMS") || getenv("EZHIP_NO_SPEC_CACHE") || getenv("EZHIP_NO_PAIR_BATCH")) return 0;
+    if (polar && s->extrap && s->have_dehors) return 0;          /* (a fill value per pair: pair by pair) */
+    const int zones = !polar ? 0 : (s->extrap ? 2 : 1);
+    const int key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4 | degree << 12;
+    pthread_mutex_lock(&g_plan_mtx);
+    const int ok = choose_mode(s, degree, polar) == 2 && s->cspec_key == key && s->d_uvt_tiles && s->d_uvt_streams && s->uvt_shape == 3232 && s->d_windM && s->windM_half &&
+                   s->uvt_streams_M == (const void *)((const char *)s->d_windM + 16 * (size_t)G[s->gdout].ni * G[s->gdout].nj);
+    pthread_mutex_unlock(&g_plan_mtx);
+    return ok;
+}
+int32_t c_ezuvint_batch_dev(float *d_uuout, float *d_vvout, const float *d_uuin, const float *d_vvin, int32_t npairs)
+{
+    if (npairs < 1 || !d_uuout || !d_vvout || !d_uuin || !d_vvin) return -1;
+    ezh_set *s = current_set("c_ezuvint_batch_dev");
+    if (!s) return -1;
+    if (need_device("c_ezuvint_batch_dev")) return -1;
+    const size_t nin = (size_t)G[s->gdin].ni * G[s->gdin].nj, nout = (size_t)G[s->gdout].ni * G[s->gdout].nj;
+    int first = 0, rc = 0;
+    /* the set's first pair builds its caches (special points, tile table, tile-ordered streams); the batch form needs them */
+    if (npairs >= 2 && !pair_batch_ready(s)) {
+        const int r = c_ezuvint_dev(d_uuout, d_vvout, d_uuin, d_vvin);
+        if (r < 0) return r;
+        if (r == 2) rc = 2;
+        first = 1;
+    }
+    if (npairs - first >= 2 && pair_batch_ready(s)) {
+        t_pairs.n = npairs - first; t_pairs.refused = 0; t_pairs.in_stride = nin; t_pairs.out_stride = nout;
+        const int r = uvint_impl(d_uuout + first * nout, d_vvout + first * nout, d_uuin + first * nin, d_vvin + first * nin, 0);
+        const int refused = t_pairs.refused;
+        t_pairs.n = 0; t_pairs.refused = 0;
+        if (!refused) return r < 0 ? r : (r == 2 || rc == 2) ? 2 : 0;
+    }
+    for (int f = first; f < npairs; f++) {
+        const int r = c_ezuvint_dev(d_uuout + f * nout, d_vvout + f * nout, d_uuin + f * nin, d_vvin + f * nin);
+        if (r < 0) return r;
+        if (r == 2) rc = 2;
+    }
+    return rc;
+}
 
 static int32_t uvint_host(float *uuout, float *vvout, float *uuin, float *vvin, int wd_only)
 {

@@ -3052,13 +3052,18 @@ __global__ __launch_bounds__(256) void k_uvt_pack(ezhip_pts_plan p, const float 
 #ifndef UVT_WAVES
 #define UVT_WAVES 5
 #endif
+#ifndef UVT_WAVES_B
+#define UVT_WAVES_B 5                                   /* the batch form (c_ezuvint_batch_dev): the pair loop needs 96 registers (at 80 it spills 160 bytes: 69 - 90 us per pair
+                                                         * against 50 - 60; 4 waves: the same as 5; the next pair's window prefetched into 20 registers at 4 waves: 56 - 79) */
+#endif
 #ifndef UVT_WAVES_W
 #define UVT_WAVES_W 6                                   /* the REAL form of the wrap-around variant needs fewer registers, its records a third of the LDS */
 #endif
 
-template <int TW, int TH, bool NW = false>      /* NW: a source without wrap (a regional 'Z' grid): both components in the LITERAL form of ez_irgdint_3_nw.inc (REAL statement
+template <int TW, int TH, bool NW = false, bool BATCH = false>      /* BATCH: p.npairs wind pairs one after the other per tile (c_ezuvint_batch_dev): the points' x, y and rotation, the
+                                                 * tile's table entry and its axis records once for all of them; NW: a source without wrap (a regional 'Z' grid): both components in the LITERAL form of ez_irgdint_3_nw.inc (REAL statement
                                                  * functions), as k_pts2<PK_IRGD3_NW> evaluates them on the set's first call */
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW ? UVT_WAVES : UVT_WAVES_W, 8))) void k_uvt(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? UVT_WAVES_B : NW ? UVT_WAVES : UVT_WAVES_W, 8))) void k_uvt(ezhip_pts_plan p, float *__restrict__ zout1, float *__restrict__ zout2,
                                              const float *__restrict__ zin1, const float *__restrict__ zin2,
                                              const float *__restrict__ xs, const float *__restrict__ ys, const int4 *__restrict__ tiles)
 {
@@ -3067,9 +3072,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW ? UVT_WA
     extern __shared__ __attribute__((aligned(16))) float uvt_lds[];
     const int dbg = EZH_DBG(p.uvt_debug);      /* development knock-outs (EZHIP_UVT_DEBUG, develop build only): 1 skip handed-back tiles, 2 no staging loads, 4 no arithmetic, 16 no matrix */
     unsigned boff = 0;
-    if (p.pw_out) {           /* the pair's synthetic polar wind rows: two producer blocks at the head of the launch, as in k_pts2_irgd3w */
-        if (blockIdx.x < 2) { polar_wind_body<2048>(blockIdx.x == 0, p.pw_out, zin1, zin2, p.pw_plon2, p.ni, p.nj, p.pw_xg4_n, p.pw_xg4_s, p.pw_weighted, p.pw_ax, uvt_lds); return; }      /* (the launch's dynamic LDS holds 2052 floats and more) */
-        boff = 2;
+    const int npairs = BATCH ? p.npairs : 1;
+    if (p.pw_out) {           /* the pair's synthetic polar wind rows: two producer blocks at the head of the launch, as in k_pts2_irgd3w (a batch: two per pair) */
+        if (blockIdx.x < 2u * (unsigned)npairs) {
+            const size_t f = BATCH ? blockIdx.x >> 1 : 0;
+            polar_wind_body<2048>((blockIdx.x & 1u) == 0, p.pw_out + f * (size_t)p.pair_rows_stride, zin1 + f * p.pair_in_stride, zin2 + f * p.pair_in_stride, p.pw_plon2, p.ni, p.nj, p.pw_xg4_n, p.pw_xg4_s, p.pw_weighted, p.pw_ax, uvt_lds);
+            return;      /* (the launch's dynamic LDS holds 2052 floats and more) */
+        }
+        boff = 2u * (unsigned)npairs;
     }
     /* (xcd_order: XCD k takes the k-th contiguous eighth of the tiles -- neighbouring tiles' windows overlap and share cache lines: one L2 then fetches them once) */
     const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW, b = p.xcd_order ? pts_block(blockIdx.x - boff, gridDim.x - boff) : blockIdx.x - boff, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
@@ -3099,9 +3109,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW ? UVT_WA
     if (tb.z == 0) {
         if (dbg & 1) return;
 #pragma unroll 1
-        for (int k = 0; k < PPT; k++) {
-            const unsigned cy = cy0 + (unsigned)(G::RSTEP * k);
-            if (okx && cy < (unsigned)p.tile_nj) pts2_point<NW ? PK_IRGD3_NW : PK_IRGD3_W, NW>(p, zout1, zout2, zin1, zin2, xs, ys, (int)(cy * (unsigned)p.tile_ni + cx), nullptr, nullptr);
+        for (int f = 0; f < npairs; f++) {
+            const size_t oi = BATCH ? (size_t)f * p.pair_in_stride : 0, oo = BATCH ? (size_t)f * p.pair_out_stride : 0;
+#pragma unroll 1
+            for (int k = 0; k < PPT; k++) {
+                const unsigned cy = cy0 + (unsigned)(G::RSTEP * k);
+                if (okx && cy < (unsigned)p.tile_nj) pts2_point<NW ? PK_IRGD3_NW : PK_IRGD3_W, NW>(p, zout1 + oo, zout2 + oo, zin1 + oi, zin2 + oi, xs, ys, (int)(cy * (unsigned)p.tile_ni + cx), nullptr, nullptr);
+            }
         }
         return;
     }
@@ -3114,6 +3128,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW ? UVT_WA
     d2 *xr = (d2 *)(uvt_lds + 2 * ((ncell + 1) & ~1));
     const int nxr = (W - 3) * (NW ? 5 : 2), nyr = (H - 3) * (NW ? 5 : 2);
     d2 *yr = xr + nxr;
+    float *const zout1_0 = zout1, *const zout2_0 = zout2;
+    const float *const zin1_0 = zin1, *const zin2_0 = zin2;
+#pragma unroll 1
+    for (int f = 0; f < npairs; f++) {                          /* (one pass unless BATCH) */
+    if (BATCH) {
+        zout1 = zout1_0 + (size_t)f * p.pair_out_stride; zout2 = zout2_0 + (size_t)f * p.pair_out_stride;
+        zin1 = zin1_0 + (size_t)f * p.pair_in_stride; zin2 = zin2_0 + (size_t)f * p.pair_in_stride;
+        if (f) __syncthreads();                                 /* the pair before has been evaluated: its window may go */
+        /* what depends on x, y alone (weights, cell addresses) is formed again for every pair: hoisted out of this loop for the thread's four points it does not
+         * fit the registers (308 bytes of spills at 96 VGPRs); the kernel is not bound by its arithmetic */
+#pragma unroll
+        for (int k = 0; k < PPT; k++) asm volatile("" : "+v"(px[k]), "+v"(py[k]));
+    }
     {
         const unsigned magic = 0xFFFFFFFFu / (unsigned)W + 1u;
         const float *s1 = zin1 + (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1), *s2 = zin2 + (size_t)(j0 - p.j1) * (size_t)p.ni + (size_t)(i0 - 1);
@@ -3125,10 +3152,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW ? UVT_WA
                 cells[idx] = c2{s1[off], s2[off]};
             }
         }
-        const d2 *gx = NW ? (const d2 *)p.xrec10 + (size_t)i0 * 5 : (const d2 *)p.xrec8 + (size_t)i0 * 2;
-        const d2 *gy = NW ? (const d2 *)p.yrec10 + (size_t)(j0 + 1 - p.j1) * 5 : (const d2 *)p.yrec8 + (size_t)(j0 + 1 - p.j1) * 2;
-        for (int idx = (int)t; idx < nxr; idx += 256) xr[idx] = gx[idx];
-        for (int idx = (int)t; idx < nyr; idx += 256) yr[idx] = gy[idx];
+        if (!BATCH || f == 0) {
+            const d2 *gx = NW ? (const d2 *)p.xrec10 + (size_t)i0 * 5 : (const d2 *)p.xrec8 + (size_t)i0 * 2;
+            const d2 *gy = NW ? (const d2 *)p.yrec10 + (size_t)(j0 + 1 - p.j1) * 5 : (const d2 *)p.yrec8 + (size_t)(j0 + 1 - p.j1) * 2;
+            for (int idx = (int)t; idx < nxr; idx += 256) xr[idx] = gx[idx];
+            for (int idx = (int)t; idx < nyr; idx += 256) yr[idx] = gy[idx];
+        }
     }
     __syncthreads();
     unsigned redo = 0;
@@ -3228,6 +3257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW ? UVT_WA
             zout1[n] = a; zout2[n] = bb;
         }
     }
+    }                                                           /* (pairs) */
 }
 
 /* ---- k_st: the SCALAR twin of k_uvt -- c_ezsint from an irregular (rotated) source, bicubic, with its stencil windows staged in LDS ------------------------
@@ -3667,7 +3697,7 @@ __global__ __launch_bounds__(256) void k_pts_special2(ezhip_pts_plan p_arg, floa
 /* the same with the points known to the host (ezhip_pts_plan.cspec_*): index, x and y of point k side by side, their number by value */
 __device__ __forceinline__ void special2c_body(const ezhip_pts_plan &p, float *__restrict__ zout1, float *__restrict__ zout2,
                                                const float *__restrict__ zin1, const float *__restrict__ zin2,
-                                               const float *__restrict__ prow_n2, const float *__restrict__ prow_s2, unsigned blk, unsigned nblk)
+                                               const float *__restrict__ prow_n2, const float *__restrict__ prow_s2, unsigned blk, unsigned nblk, size_t roff = 0 /* a batch: the pair's polar wind rows */)
 {
     /* a LANE PAIR per point: lane 2 k takes the first component, lane 2 k + 1 the second (the few special points of a set are a chain of dependent gathers --
      * ~12 us of latency per call with both components one after the other on one lane), then they swap results for the wind matrix */
@@ -3686,6 +3716,7 @@ __device__ __forceinline__ void special2c_body(const ezhip_pts_plan &p, float *_
         if (zone == PZ_REINTERP) mine = gdinterp_point(p, Z, p.degre_extrap, px, py);
         else {
             Z.prow_n = comp ? prow_n2 : p.pole_row_n; Z.prow_s = comp ? prow_s2 : p.pole_row_s;
+            if (roff) { if (Z.prow_n) Z.prow_n += roff; if (Z.prow_s) Z.prow_s += roff; }
             /* (the bicubic strip of an irregular source -- cfg3's case -- inline: through the out-of-line strip_point this launch of ONE thread block spent most of
              * its 10 us fetching instructions and passing arguments through scratch) */
             if (p.degree == 3 && p.irregular) {
@@ -3703,7 +3734,10 @@ __global__ __launch_bounds__(256) void k_pts_special2c(ezhip_pts_plan p_arg, flo
                                                        const float *__restrict__ zin1, const float *__restrict__ zin2,
                                                        const float *__restrict__ prow_n2, const float *__restrict__ prow_s2)
 {
-    special2c_body(PLAN_IN_KERNARG(), zout1, zout2, zin1, zin2, prow_n2, prow_s2, blockIdx.x, gridDim.x);
+    const ezhip_pts_plan &p = PLAN_IN_KERNARG();
+    const size_t f = blockIdx.y;                                                  /* the pair of a batch (c_ezuvint_batch_dev); 0 otherwise */
+    special2c_body(p, zout1 + f * p.pair_out_stride, zout2 + f * p.pair_out_stride, zin1 + f * p.pair_in_stride, zin2 + f * p.pair_in_stride, prow_n2, prow_s2, blockIdx.x, gridDim.x,
+                   f * (size_t)p.pair_rows_stride);
 }
 __global__ __launch_bounds__(256) void k_spec_gather(int *__restrict__ list_out, float *__restrict__ x_out, float *__restrict__ y_out,
                                                      const int *__restrict__ list_in, const float *__restrict__ xs, const float *__restrict__ ys, unsigned cnt)
@@ -3827,6 +3861,9 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     if (getenv("EZHIP_PTS_NOTILE") || (long long)pu2.tile_ni * pu2.tile_nj != (long long)npts || pu2.out_idx) pu2.tile_ni = pu2.tile_nj = 0;
     const bool fast3w = pts_kind(plan_u) == PK_IRGD3_W && !pu2.newton_literal;
     const bool stage3nw = pts_kind(plan_u) == PK_IRGD3_NW && plan_u->i1 == 1 && plan_u->i2 == plan_u->ni;      /* a regional source: k_uvt's literal twin */
+    const int npairs = pu2.npairs > 1 ? pu2.npairs : 1;
+    if (npairs > 1 && !(cached && fast3w && pu2.uvt_tiles && pu2.uvt_streams && pu2.tile_ni > 0 && pu2.xrec10 && pu2.yrec10 && !pu2.out_idx && pu2.uvt_shape == 3232
+                        && (!pu2.pw_out || !getenv("EZHIP_POLAR_WIND_SIDE")))) return -2;      /* c_ezuvint_batch_dev: only the staged-tile kernel has a batch form (the caller goes pair by pair) */
     if (pu2.pw_out && (!fast3w || getenv("EZHIP_POLAR_WIND_SIDE"))) {
         /* kernels without the producer blocks: the rows come from k_polar_wind on the side stream, joined below before the special points */
         if (ezhip_side_begin()) return -1;
@@ -3846,13 +3883,14 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
         pu2.uvt_debug = EZH_DEVINT("EZHIP_UVT_DEBUG");
         const unsigned nt = (unsigned)ezhip_uvt_ntiles(&pu2, pu2.uvt_shape);
         const int4 *tl = (const int4 *)pu2.uvt_tiles;
-        const dim3 g(nt + (pu2.pw_out ? 2u : 0u));
+        const dim3 g(nt + (pu2.pw_out ? 2u * (unsigned)npairs : 0u));
         size_t lds = (size_t)8 * (size_t)pu2.uvt_cap + (stage3nw ? 80 : 32) * UVT_REC_MAX;
         if (lds < 4 * 2052 + 16) lds = 4 * 2052 + 16;                          /* (the polar-wind producer blocks' row buffer) */
         pu2.xcd_order = getenv("EZHIP_UVT_XCD") ? atoi(getenv("EZHIP_UVT_XCD")) : 0;
         pu2.uvt_read2 = getenv("EZHIP_UVT_READ2") ? 1 : 0;                      /* development: the compiler's paired LDS reads (same results) */
 #define UVT_LAUNCH(TW, TH) hipLaunchKernelGGL((k_uvt<TW, TH>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl)
-        if (stage3nw) hipLaunchKernelGGL((k_uvt<32, 32, true>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl);      /* (tables of regional sets are built with 32 x 32 tiles) */
+        if (npairs > 1) hipLaunchKernelGGL((k_uvt<32, 32, false, true>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl);      /* all pairs of the batch */
+        else if (stage3nw) hipLaunchKernelGGL((k_uvt<32, 32, true>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl);      /* (tables of regional sets are built with 32 x 32 tiles) */
         else
         switch (pu2.uvt_shape) { case 3216: UVT_LAUNCH(32, 16); break; case 6408: UVT_LAUNCH(64, 8); break; case 6416: UVT_LAUNCH(64, 16); break; default: UVT_LAUNCH(32, 32); break; }
 #undef UVT_LAUNCH
@@ -3860,7 +3898,7 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
         if (ezhip_side_join()) return -1;
         if (plan_u->cspec_count > 0 && !(pu2.uvt_debug & 8)) {
             const unsigned nbk = (unsigned)((2 * plan_u->cspec_count + 255) / 256);      /* a lane pair per point */
-            hipLaunchKernelGGL(k_pts_special2c, dim3(nbk < 256 ? nbk : 256), block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v, plan_v->pole_row_n, plan_v->pole_row_s);
+            hipLaunchKernelGGL(k_pts_special2c, dim3(nbk < 256 ? nbk : 256, (unsigned)npairs), block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v, plan_v->pole_row_n, plan_v->pole_row_s);
             return LAUNCH_CHECK("k_pts_special2c");
         }
         return 0;

@@ -232,6 +232,11 @@ typedef struct {
     const void *uvt_streams;          /* NULL, or the set's x, y and packed rotation once more in tile order: 12 bytes per point (ezhip_uvt_pack_streams) */
     int uvt_debug;                    /* development knock-outs (develop build only) */
     int uvt_read2;                    /* development: k_uvt reads its cells with the compiler's ds_read2_b64 pairs instead of single ds_read_b64 (same results) */
+    /* c_ezuvint_batch_dev: npairs > 1 wind pairs of one grid set in ONE staged-tile launch -- pair f's components at d_in + f * pair_in_stride, its results at
+     * d_out + f * pair_out_stride (floats), its four polar wind rows at pw_out / pole_row_* + f * pair_rows_stride; x, y and the rotation of a point are read once
+     * for all pairs */
+    int npairs, pair_rows_stride;
+    size_t pair_in_stride, pair_out_stride;
     int wind_dst_rot;                 /* with wind_M: the TARGET frame is a rotated one (decides what a REAL overflow of the chain's speed turns into) */
     int wind_M_half;                  /* wind_M holds ONE word per point: a pure rotation (a, b), c = -b, d = a, packed by rot_pack (ez_kernels.hip) */
     const void *wind_M;               /* k_pts2: the grid pair's wind matrices (ezhip_wind_matrix), applied to every point before it is stored; NULL: store the interpolated components */

@@ -48,6 +48,7 @@ def _lib():
         L.c_gdxysint_dev.argtypes = [vp, vp, i32, vp, vp, i32]
         L.c_gdxyfll_dev.argtypes = [i32, vp, vp, vp, vp, i32]
         L.c_ezsint_batch_dev.argtypes = [vp, vp, i32]
+        L.c_ezuvint_batch_dev.argtypes = [vp, vp, vp, vp, i32]
         _configured = True
     return L
 
@@ -219,6 +220,11 @@ def set_xy_dev(x, y):
     L = _lib()
     L.ezhip_set_xy_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     return L.ezhip_set_xy_dev(_dptr(x), _dptr(y))
+
+
+def ezuvint_batch_dev(uuout, vvout, uuin, vvin, npairs):
+    """c_ezuvint_batch_dev: npairs wind pairs, contiguous torch CUDA tensors [npairs, n]"""
+    return _lib().c_ezuvint_batch_dev(_dptr(uuout), _dptr(vvout), _dptr(uuin), _dptr(vvin), npairs)
 
 
 def libm_exact_probe(fn, a, b, out):

@@ -979,6 +979,47 @@ def _hash_t(t):
     return _bit_hash(t)
 
 
+@pytest.mark.parametrize("polar", [1, 0])
+@pytest.mark.parametrize("npairs", [2, 5])
+def test_ezuvint_batch_equals_single_calls(npairs, polar, monkeypatch):
+    """c_ezuvint_batch_dev (additive): npairs wind pairs of one grid set in ONE staged-tile launch (k_uvt's batch form: x, y and the rotation of a point read once for all
+    pairs, two polar-wind producer blocks per pair, the special points' kernel once with a pair index) against npairs c_ezuvint_dev calls: every bit of every pair,
+    with and without polar correction; also when the batch is the set's FIRST call (the first pair then goes alone and builds the caches) and with the batch form
+    switched off (EZHIP_NO_PAIR_BATCH=1: pair by pair).  ezuvint.c:51-94"""
+    ni, nj, no, mo = 320, 160, 1000, 500
+    ax, ay = ec.ze_axes(ni, nj)
+    winds = [ec.synth_wind(ni, nj, seed=70 + f) for f in range(npairs)]
+    for uu, vv in winds:
+        for a in (uu, vv):
+            a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+    d_u = torch.from_numpy(np.stack([w[0] for w in winds])).cuda().contiguous(); d_v = torch.from_numpy(np.stack([w[1] for w in winds])).cuda().contiguous()
+    setopts(3, polar)
+    ez.use_stream(torch.cuda.current_stream().cuda_stream)
+    outs = {}
+    for mode in ("single", "batch_first", "batch", "batch_off"):
+        gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay); gdout = ez.ezqkdef(no, mo, "L", 36, 36, 0, 0)
+        assert ez.ezdefset(gdout, gdin) == 1
+        o_u = torch.full((npairs, no * mo), -7.0, dtype=torch.float32, device="cuda"); o_v = torch.full_like(o_u, -9.0)
+        if mode == "single":
+            for rep in range(2):                    # (the second round runs from the staged windows)
+                for f in range(npairs):
+                    assert ez.ezuvint_dev(o_u[f], o_v[f], d_u[f], d_v[f]) == 0
+        else:
+            if mode == "batch_off":
+                monkeypatch.setenv("EZHIP_NO_PAIR_BATCH", "1")
+            if mode != "batch_first":
+                assert ez.ezuvint_dev(o_u[0], o_v[0], d_u[0], d_v[0]) == 0      # the set's caches exist: the batch form takes all pairs
+                o_u.fill_(-7.0); o_v.fill_(-9.0)
+            assert ez.ezuvint_batch_dev(o_u, o_v, d_u, d_v, npairs) == 0
+            monkeypatch.delenv("EZHIP_NO_PAIR_BATCH", raising=False)
+        torch.cuda.synchronize()
+        outs[mode] = (o_u.clone(), o_v.clone())
+        ez.gdrls(gdout); ez.gdrls(gdin)
+    for mode in ("batch_first", "batch", "batch_off"):
+        assert torch.equal(outs[mode][0], outs["single"][0]) and torch.equal(outs[mode][1], outs["single"][1]), mode
+    assert float(outs["single"][0].abs().max()) > 1.0 and not bool((outs["single"][0] == -7.0).any())
+
+
 def test_cfg3_full_size_against_reference_run():
     """BASELINE cfg3 at full size (Z-on-E 2560x1280 rotated global grid -> L 4000x2000), device resident, against the
     reference's own c_gdxyfll / c_ezsint / c_ezuvint run (tests/golden/make_cfg3_full.py): located x,y bit-exact over all

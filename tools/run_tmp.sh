@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-EZHIP_TRACE_FIRST=1 python tools/probe_cfg2_first.py 2>&1 | tail -18
-python tools/probe_cfg3_first.py 2>&1 | tail -3
-python -m pytest tests/test_gpu_interp.py -x -q -m gpu -k "wind or uvint or cfg3" 2>&1 | tail -2
+for l in pf10w4 pf0w4; do echo $l; EZHIP_LIBRARY=$GRAFT_REPO_ROOT/devlibs/$l.so python tools/probe_cfg3_batch.py 2 4 8 16 2>&1 | grep -v amdgpu; done
+echo product; python tools/probe_cfg3_batch.py 2 4 8 16 2>&1 | grep -v amdgpu
