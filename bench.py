@@ -280,7 +280,9 @@ def extras(ez, torch, stream, d_out, d_in):
             same_b = same_b and bool(torch.equal(r_u, o_ub[f]) and torch.equal(r_v, o_vb[f]))
         ex["cfg3_uvint_batch"] = {"workload": "c_ezuvint_batch_dev, %d pairs per call, bicubic, Z-on-E 2560x1280 -> L 4000x2000, polar_correction=yes" % KB,
                                   "us_per_pair": usb, "Mpoint_pairs_per_s": no * mo / usb, "algorithmic_GBps": algo3 / usb / 1e3, "frac_of_hbm_peak": algo3 / usb / 1e3 / HBM_PEAK_GBPS,
-                                  "equal_to_single_calls_bitwise": same_b, "single_call_us_per_pair": us}
+                                  "equal_to_single_calls_bitwise": same_b, "single_call_us_per_pair": us,
+                                  "traffic": (profile_value("cfg3_batch_traffic_MB_per_pair") or (None, None))[0], "traffic_unit": "MB per pair", "traffic_source": (profile_value("cfg3_batch_traffic_MB_per_pair") or (None, None))[1],
+                                  "kernel": "k_uvt<32, 32, false, true> (the pairs of the batch one after the other per tile) + k_pts_special2c once with a pair index"}
         del d_ub, d_vb, o_ub, o_vb, r_u, r_v
         # the scalar twin on the same grid pair: c_ezsint from the rotated source (k_st: stencil windows staged in LDS, the literal REAL*8 form of the reference)
         us1 = ev_time(lambda: ez.ezsint_dev(o_u, d_u), 20)

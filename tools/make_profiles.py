@@ -75,7 +75,10 @@ BB = [per_field(k) for k in ("k_bb_bounds", "k_bb_select", "k_bb_eval", "k_bb_sp
 if all(BB):
     A = {"grid": "+".join(x["grid"] for x in BB), "read_MB": round(sum(x["read_MB"] for x in BB), 2), "write_MB": round(sum(x["write_MB"] for x in BB), 2),
          "parts": dict(zip(("k_bb_bounds", "k_bb_select", "k_bb_eval", "k_bb_special"), BB))}
-P3 = per_field("k_uvt", nfields=1) or per_field("k_pts2_irgd3w", nfields=1) or per_field("k_pts2", nfields=1)      # round 4: k_uvt from the second call of a grid set on
+P3 = per_field("k_uvt<32, 32, false, false>", nfields=1) or per_field("k_uvt<32, 32>", nfields=1) or per_field("k_pts2_irgd3w", nfields=1) or per_field("k_pts2", nfields=1)      # round 4: k_uvt from the second call of a grid set on
+KB3 = bench.get("extras", {}).get("cfg3_uvint_batch", {}).get("workload", "")
+KB3 = int(KB3.split(",")[1].split()[0]) if "pairs per call" in KB3 else 0                                             # c_ezuvint_batch_dev's pairs per call in this bench
+P3B = per_field("k_uvt<32, 32, false, true>", nfields=KB3) if KB3 else None
 S3 = per_field("k_pts_special2c", nfields=1) or per_field("k_pts_special2", nfields=1); W3 = per_field("k_polar_wind", nfields=1)
 zl = bench["pack"]["zlng_bytes"]
 out = {
@@ -106,6 +109,9 @@ if P3:
     out["cfg3_traffic_MB_per_pair"] = round(tot3, 1)
     out["cfg3_algorithmic_MB_per_pair"] = 90.21
     out["cfg3_traffic_over_algorithmic"] = round(tot3 / 90.21, 2)
+    if P3B:
+        out["cfg3_batch_kernel_MB_per_pair"] = {"k_uvt<32, 32, false, true> (%d pairs per launch)" % KB3: P3B}
+        out["cfg3_batch_traffic_MB_per_pair"] = round(P3B["read_MB"] + P3B["write_MB"] + (S3["read_MB"] + S3["write_MB"] if S3 else 0.0), 1)
     out["cfg3_notes"] = ("x, y of the located points and the per-point wind rotation (one packed word) -- 96 MB, read from the set's tile-ordered copy -- are inputs of every call next to "
                          "the staged source windows (~0.94 cells of 8 bytes per point) and 64 MB of results")
 # round 5: the figures bench.py's other roofline objects read (every one labelled with this file in the line)
@@ -138,7 +144,7 @@ try:
     i_st = instr("k_st<32, 32", 1)
     if i_st is not None:
         out["cfg3_sint_valu_wave_instructions_per_field"] = round(i_st + (instr("k_pts_special", 1) or 0))
-    i_uvt = instr("k_uvt", 1)
+    i_uvt = instr("k_uvt<32, 32, false, false>", 1) or instr("k_uvt<32, 32>", 1)
     if i_uvt is not None:
         out["cfg3_uvint_valu_wave_instructions_per_pair"] = round(i_uvt)
     shutil.copyfile(os.path.join(src, "pmc_SQ_INSTS_VALU.csv"), os.path.join(dst, f"{prefix}_pmc_SQ_INSTS_VALU_per_dispatch.csv"))
