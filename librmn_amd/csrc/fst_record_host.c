@@ -289,7 +289,7 @@ int32_t ezhip_fst_pack_data_ex(uint32_t *data, int64_t cap_words, void *field_in
             if (is_short) memcpy(p16, field, (size_t)n * 2);                        /* :1201 */
             else if (is_byte) { const int8_t *p8 = (const int8_t *)field; for (int64_t i = 0; i < n; i++) p16[i] = p8[i]; }      /* memcpy_8_16 */
             else {
-                const int32_t mask = nbits >= 32 ? -1 : ~(-1 << nbits);
+                const int32_t mask = nbits >= 32 ? -1 : (int32_t)~(~0u << nbits);
                 const int32_t *p32 = (const int32_t *)field;
                 for (int64_t i = 0; i < n; i++) p16[i] = (int16_t)(p32[i] & mask);  /* memcpy_32_16 */
             }
@@ -436,7 +436,7 @@ int32_t ezhip_fst_unpack_data_ex(void *field, uint32_t *data, int32_t ni, int32_
         if (is_short) memcpy(field, p16, (size_t)n * 2);                             /* :2310 (nbytes = 2 n) */
         else if (is_byte) { int8_t *p8 = (int8_t *)field; for (int64_t i = 0; i < n; i++) p8[i] = (int8_t)p16[i]; }      /* memcpy_16_8 */
         else {
-            const int16_t mask = (int16_t)(nbits >= 16 ? -1 : ~(-1 << nbits));
+            const int16_t mask = (int16_t)(nbits >= 16 ? -1 : (int)~(~0u << nbits));
             int32_t *p32 = (int32_t *)field;
             for (int64_t i = 0; i < n; i++) p32[i] = p16[i] & mask;                  /* memcpy_16_32 */
         }

@@ -425,7 +425,7 @@ int32_t c_float_packer(float *source, int32_t nbits, int32_t *header, int32_t *s
         int Minimum = aligned_mantissa(fmin_i, MaxExp);
         if (((fmin_i >> 23) & 0xFF) < 1) Minimum = 0;
         Maximum = Maximum - Minimum;
-        int Shift2 = 0, Round = 1, Mask = ~(-1 << nbits);
+        int Shift2 = 0, Round = 1, Mask = (int)~(~0u << nbits);
         while (Maximum > Mask) { Maximum = Maximum >> 1; Round = Round << 1; Shift2++; }
         Round = Round >> 1;
         header[1] = Minimum;

@@ -692,25 +692,39 @@ __global__ __launch_bounds__(1024) void k_dsc_scan(unsigned *st_all, size_t st_s
     }
 }
 
-/* position of every canonical tile (interior point count everywhere) */
-__global__ __launch_bounds__(256) void k_dsc_emit(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, const unsigned *st_all, size_t st_stride,
-                                                  const unsigned *wentc_all, size_t went_stride, unsigned *tpc_all, size_t tpc_stride, unsigned capc, int nwin, int plain)
+/* position of every canonical tile (interior point count everywhere).  A lane per window as before, but the 64 windows of a wave are STAGED IN LDS first (round 5:
+ * coalesced reads, every word of the stream once; 81-word rows so that the lanes' reads fall on different banks) and walked from there -- the walk's ~ten dependent
+ * reads per window were global ones, 132 us per 7200 x 3601 stream (a wave per window walking in scalar registers: 236 us, the CU's one scalar unit serialises them) */
+#define EMIT_STRIDE (DWW + DTAIL + 1)
+__global__ __launch_bounds__(64) void k_dsc_emit(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, const unsigned *st_all, size_t st_stride,
+                                                 const unsigned *wentc_all, size_t went_stride, unsigned *tpc_all, size_t tpc_stride, unsigned capc, int nwin, int plain)
 {
-    const int f = blockIdx.y, w = blockIdx.x * 256 + threadIdx.x;
-    if (w >= nwin || st_all[(size_t)f * st_stride + DSC_FAIL]) return;
+    __shared__ unsigned sw[64 * EMIT_STRIDE];
+    const int f = blockIdx.y, wbase = blockIdx.x * 64, lane = (int)threadIdx.x, w = wbase + lane;
+    if (st_all[(size_t)f * st_stride + DSC_FAIL]) return;
     const unsigned *z = z_all + (size_t)f * z_stride;
     DecGeom g;
     if (!dec_geom(g, z, ni, nj, plain)) return;
-    const unsigned e = wentc_all[(size_t)f * went_stride + 2 * (size_t)w];
-    if (e == 0xFFFFFFFFu) return;
-    unsigned t = wentc_all[(size_t)f * went_stride + 2 * (size_t)w + 1];
-    unsigned *tpc = tpc_all + (size_t)f * tpc_stride;
     const size_t nwords = z_words - 1;
-    unsigned pos = (unsigned)w * DW + e;
-    const unsigned end = (unsigned)(w + 1) * DW;
-    while (pos < end) {
-        if (t < capc) tpc[t] = pos;
-        pos += (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.n_int);
+    /* (the window's entry and first tile index are asked for before the staging: in flight with it) */
+    const unsigned e = w < nwin ? wentc_all[(size_t)f * went_stride + 2 * (size_t)w] : 0xFFFFFFFFu;
+    unsigned t = w < nwin ? wentc_all[(size_t)f * went_stride + 2 * (size_t)w + 1] : 0u;
+#pragma unroll 16
+    for (int k = 0; k < 64; k++) sw[k * EMIT_STRIDE + lane] = gword(z + 1, (size_t)(wbase + k) * DWW + (size_t)lane, nwords);
+#pragma unroll
+    for (int q = 0; q < 64 * DTAIL / 64; q++) {
+        const int k = q * (64 / DTAIL) + (lane / DTAIL), i = lane % DTAIL;
+        sw[k * EMIT_STRIDE + DWW + i] = gword(z + 1, (size_t)(wbase + k + 1) * DWW + (size_t)i, nwords);
+    }
+    __syncthreads();
+    if (e == 0xFFFFFFFFu) return;
+    unsigned *tpc = tpc_all + (size_t)f * tpc_stride;
+    const unsigned *my = sw + lane * EMIT_STRIDE;
+    const unsigned base = (unsigned)w * DW;
+    unsigned pos = e;
+    while (pos < DW) {
+        if (t < capc) tpc[t] = base + pos;
+        pos += (unsigned)dec_step(g, getbits(my, pos, g.C), g.n_int);
         t++;
     }
 }
@@ -1528,7 +1542,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
         hipLaunchKernelGGL(k_dsc_blocks, dim3((unsigned)((nblk + 255) / 256), nfields), dim3(256), 0, st, dst, ws4, tab8, ws4, m8, ws2b, eblk, cblk, ws4, ext_max);
         hipLaunchKernelGGL(k_dsc_scan, dim3(nfields), dim3(1024), 0, st, dst, ws4, tab, ws4, eblk, cblk, ws4, wentc, wentc8, ws4, nwin, ext_max);
         hipLaunchKernelGGL(k_armn_dec_expand8, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, ws4, wentc, wentc8, ws4, nwin, (const unsigned *)NULL, (size_t)0);
-        hipLaunchKernelGGL(k_dsc_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, wentc, ws4, tpc, ws4, (unsigned)capc, nwin, plain);
+        hipLaunchKernelGGL(k_dsc_emit, dim3((nwin + 63) / 64, nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, wentc, ws4, tpc, ws4, (unsigned)capc, nwin, plain);
         hipLaunchKernelGGL(k_dsc_dtab, dim3((unsigned)((capc + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, tab, ws4, wentc, ws4, tpc, ws4, dtab, ws2b, (unsigned)capc, nwin, plain);
         {
             const dim3 gj((unsigned)((capc + 255) / 256), nfields);
@@ -1595,7 +1609,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
                     for (int l = pl.nlev - 1; l >= 0; l--)
                         hipLaunchKernelGGL(k_dmin_down, dim3((pl.nblk[l + 1] + 255) / 256, nfields), dim3(256), 0, st, dmst, ws4, tab, ws4, dmlev, ws8, wentc, ws4, pl, l, DEXT, 1);
                     hipLaunchKernelGGL(k_drg_ncanon, dim3(nfields), dim3(64), 0, st, dst2, ws4, dmst, ws4, tab, ws4, wentc, ws4, nwin, ext_max);
-                    hipLaunchKernelGGL(k_dsc_emit, dim3((nwin + 255) / 256, nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, wentc, ws4, tpc, ws4, (unsigned)capc, nwin, plain);
+                    hipLaunchKernelGGL(k_dsc_emit, dim3((nwin + 63) / 64, nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, wentc, ws4, tpc, ws4, (unsigned)capc, nwin, plain);
                     hipLaunchKernelGGL(k_dsc_dtab, dim3((unsigned)((capc + 255) / 256), nfields), dim3(256), 0, st, d_z, z_stride_words, z_words, ni, nj, dst2, ws4, tab, ws4, wentc, ws4, tpc, ws4, dtab, ws2b, (unsigned)capc, nwin, plain);
                     const dim3 gj((unsigned)((capc + 255) / 256), nfields);
                     hipLaunchKernelGGL(k_dsc_jump<short>, gj, dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst2, ws4, dtab, ws2b, jA, ws4, 1u, (unsigned)capc, plain);

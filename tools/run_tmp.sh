@@ -1,3 +1,8 @@
 cd $GRAFT_REPO_ROOT
-bash tools/prof_round.sh r05f > gpurun_out/prof_round.log 2>&1
-tail -3 gpurun_out/prof_round.log
+python -m pytest tests/test_gpu_packers.py -x -q -m gpu -k "uncompress or armn" 2>&1 | tail -2
+python tools/probe_decode_batch.py 1 2>&1 | tail -1
+python tools/probe_decode_batch.py 32 2>&1 | tail -1
+python tools/fuzz_armn_wide.py 21 40 2>&1 | tail -1
+python tools/fuzz_armn32.py 40 22 2>&1 | tail -1
+bash tools/prof_cmd.sh r5dec4 tools/probe_decode_batch.py 1 > /dev/null 2>&1
+grep "k_dsc_emit\|k_dsc_dtab" gpurun_out/r5dec4/summary.txt | cut -c1-150
