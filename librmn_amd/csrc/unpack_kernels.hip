@@ -113,7 +113,28 @@ __device__ __forceinline__ unsigned getbits(P s, unsigned p, int nb)
     const unsigned long long v = (unsigned long long)s[p >> 5] << 32 | s[(p >> 5) + 1];
     return (unsigned)(v >> (64 - nb - (int)(p & 31))) & (nb == 32 ? 0xFFFFFFFFu : (1u << nb) - 1u);
 }
+/* the 64 - (p & 31) stream bits from position p on, left-aligned (the rest zero) */
+template <class P>
+__device__ __forceinline__ unsigned long long bits64(P s, unsigned p) { return ((unsigned long long)s[p >> 5] << 32 | s[(p >> 5) + 1]) << (p & 31u); }
+/* PARALLELOGRAM streams and planes: an empty tile is its header alone (C zero bits), so a run of zero bits is a run of empty tiles whatever their point counts.
+ * How many whole empty tiles start at p, given v = bits64(s, p), of those that start before `lim`: 0 when the header at p is not empty.  (A constant region -- a
+ * mask, dry precipitation -- is thousands of them: taken one by one, 512 per window, they were the long pole of every lane-per-window walk) */
+__device__ __forceinline__ unsigned dec_empty_run(const DecGeom &g, unsigned long long v, unsigned p, unsigned lim)
+{
+    if (g.method != 4) return 0u;
+    const unsigned avail = 64u - (p & 31u), z = v ? (unsigned)__clzll((long long)v) : 64u;
+    const unsigned k = (z < avail ? z : avail) / (unsigned)g.C, kmax = (lim - p + (unsigned)g.C - 1u) / (unsigned)g.C;
+    return k < kmax ? k : kmax;
+}
 __device__ __forceinline__ unsigned gword(const unsigned *z1, size_t w, size_t nwords) { return w < nwords ? z1[w] : 0u; }
+/* the same without a branch around the load (index clamped, result masked): a run of such loads is issued back to back -- behind `w < nwords ? load : 0` the compiler
+ * puts every load in a block of its own and waits for it before the next (80 staged words per lane: 80 round trips, the whole 96 us of k_dsc_emit) */
+__device__ __forceinline__ unsigned gword_nb(const unsigned *z1, size_t w, size_t nwords)
+{
+    const bool in = w < nwords;
+    const unsigned v = __builtin_nontemporal_load(z1 + (in ? w : (size_t)0));
+    return in ? v : 0u;
+}
 __device__ __forceinline__ unsigned getbits_g(const unsigned *z1, size_t nwords, unsigned p, int nb)
 {
     if (nb == 0) return 0;
@@ -710,11 +731,11 @@ __global__ __launch_bounds__(64) void k_dsc_emit(const unsigned *z_all, size_t z
     const unsigned e = w < nwin ? wentc_all[(size_t)f * went_stride + 2 * (size_t)w] : 0xFFFFFFFFu;
     unsigned t = w < nwin ? wentc_all[(size_t)f * went_stride + 2 * (size_t)w + 1] : 0u;
 #pragma unroll 16
-    for (int k = 0; k < 64; k++) sw[k * EMIT_STRIDE + lane] = gword(z + 1, (size_t)(wbase + k) * DWW + (size_t)lane, nwords);
+    for (int k = 0; k < 64; k++) sw[k * EMIT_STRIDE + lane] = gword_nb(z + 1, (size_t)(wbase + k) * DWW + (size_t)lane, nwords);
 #pragma unroll
     for (int q = 0; q < 64 * DTAIL / 64; q++) {
         const int k = q * (64 / DTAIL) + (lane / DTAIL), i = lane % DTAIL;
-        sw[k * EMIT_STRIDE + DWW + i] = gword(z + 1, (size_t)(wbase + k + 1) * DWW + (size_t)i, nwords);
+        sw[k * EMIT_STRIDE + DWW + i] = gword_nb(z + 1, (size_t)(wbase + k + 1) * DWW + (size_t)i, nwords);
     }
     __syncthreads();
     if (e == 0xFFFFFFFFu) return;
@@ -723,41 +744,95 @@ __global__ __launch_bounds__(64) void k_dsc_emit(const unsigned *z_all, size_t z
     const unsigned base = (unsigned)w * DW;
     unsigned pos = e;
     while (pos < DW) {
+        const unsigned long long v = bits64(my, pos);
+        const unsigned k = dec_empty_run(g, v, pos, DW);
+        if (k) {                                                     /* k empty tiles in a row: their positions without another look at the stream */
+            for (unsigned q = 0; q < k; q++) if (t + q < capc) tpc[t + q] = base + pos + q * (unsigned)g.C;
+            t += k; pos += k * (unsigned)g.C;
+            continue;
+        }
         if (t < capc) tpc[t] = base + pos;
-        pos += (unsigned)dec_step(g, getbits(my, pos, g.C), g.n_int);
+        pos += (unsigned)dec_step(g, (unsigned)(v >> (64 - g.C)), g.n_int);
         t++;
     }
 }
 
-/* dtab[c]: if the odd tile that ends a row sat at canonical tile c, the tile-index shift behind it minus the shift in front of it */
+/* dtab[c]: if the odd tile that ends a row sat at canonical tile c, the tile-index shift behind it minus the shift in front of it.
+ * A lane per canonical tile; the stream under the wave's 64 consecutive tiles -- from the first one's word to the end of the last one's window, at most
+ * 64 x 416 bits + a window + the tail: DTAB_SPAN words -- is staged in LDS first (round 5): the header of the tile and the walk to the end of its window read it
+ * there instead of through ~10 dependent global reads per lane (the waves of this kernel spent 84 % of their cycles waiting: SQ counters, r05_experiments.txt) */
+#define DTAB_SPAN 1024
 __global__ __launch_bounds__(256) void k_dsc_dtab(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, const unsigned *st_all, size_t st_stride,
                                                   const unsigned *tab_all, size_t tab_stride, const unsigned *wentc_all, size_t went_stride,
                                                   const unsigned *tpc_all, size_t tpc_stride, short *dtab_all, size_t dtab_stride, unsigned capc, int nwin, int plain)
 {
+    __shared__ unsigned sp_all[4][DTAB_SPAN];
     const int f = blockIdx.y;
     const unsigned *st = st_all + (size_t)f * st_stride;
     if (st[DSC_FAIL]) return;
+    const unsigned lim = min(st[DSC_NCANON], capc), lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const unsigned c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= min(st[DSC_NCANON], capc)) return;
+    if (blockIdx.x * 256 + wv * 64 >= lim) return;                   /* (the whole wave) */
     const unsigned *z = z_all + (size_t)f * z_stride;
     DecGeom g;
     if (!dec_geom(g, z, ni, nj, plain)) return;
     short *dtab = dtab_all + (size_t)f * dtab_stride;
-    if (g.mlast == g.istep) { dtab[c] = 0; return; }
+    const bool act = c < lim;
+    if (g.mlast == g.istep) { if (act) dtab[c] = 0; return; }
     const size_t nwords = z_words - 1;
     const unsigned *tab = tab_all + (size_t)f * tab_stride, *wentc = wentc_all + (size_t)f * went_stride;
-    const unsigned pos = tpc_all[(size_t)f * tpc_stride + c];
+    const unsigned pos = tpc_all[(size_t)f * tpc_stride + (act ? c : lim - 1)];      /* (canonical positions grow with the index: lane 0 holds the wave's first, lane 63 its last) */
+    const unsigned pfirst = (unsigned)__builtin_amdgcn_readfirstlane((int)pos), plast = (unsigned)__builtin_amdgcn_readlane((int)pos, 63);
+    const unsigned ws = pfirst >> 5, nsp = (plast / DW + 1) * DWW + DTAIL - ws;
+    const bool staged = nsp <= DTAB_SPAN;                            /* (always, by the bound above; a stream that breaks it reads through the global path) */
+    unsigned *sp = sp_all[wv];
+    if (staged) {
+#pragma unroll 8
+        for (unsigned i = lane; i < nsp; i += 64) sp[i] = gword_nb(z + 1, (size_t)ws + i, nwords);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (!act) return;
+    const unsigned o = ws << 5;
+#define DTAB_HDR(P) (staged ? getbits(sp, (P) - o, g.C) : getbits_g(z + 1, nwords, (P), g.C))
     unsigned w = pos / DW;
-    unsigned p = pos + (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.mlast * g.istep);
+    unsigned p = pos + (unsigned)dec_step(g, DTAB_HDR(pos), g.mlast * g.istep);
     unsigned j = 0;
     const unsigned end = (w + 1) * DW;
-    while (p < end) { p += (unsigned)dec_step(g, getbits_g(z + 1, nwords, p, g.C), g.n_int); j++; }
+    while (p < end) {
+        if (staged) {
+            const unsigned long long v = bits64(sp, p - o);
+            const unsigned k = dec_empty_run(g, v, p, end);
+            if (k) { p += k * (unsigned)g.C; j += k; continue; }
+            p += (unsigned)dec_step(g, (unsigned)(v >> (64 - g.C)), g.n_int); j++;
+        } else { p += (unsigned)dec_step(g, DTAB_HDR(p), g.n_int); j++; }
+    }
+#undef DTAB_HDR
     unsigned e = p - end;
     w++;
     int d = DSC_D_INVALID;
-    for (int h = 0; h < DSC_LIST && (int)w < nwin; h++) {
-        if (wentc[2 * (size_t)w] == e) {
-            const long long dd = (long long)(1u + j) - ((long long)wentc[2 * (size_t)w + 1] - (long long)c);
+    /* the canonical entries of the next windows do not depend on the walk (only its offset e does): the first four asked for at once, the table lookups between
+     * them are the dependent chain */
+    const uint2 *wc2 = (const uint2 *)wentc;
+    uint2 pre[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) pre[k] = (int)(w + k) < nwin ? wc2[(size_t)w + k] : make_uint2(0xFFFFFFFFu, 0u);
+    bool done = false;
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        if (done || (int)w >= nwin) { done = true; continue; }
+        if (pre[h].x == e) {
+            const long long dd = (long long)(1u + j) - ((long long)pre[h].y - (long long)c);
+            if (dd > -16000 && dd < 16000 && 1u + j + 2u < (unsigned)g.ntx) d = (int)dd;
+            done = true; continue;
+        }
+        if (e >= (unsigned)g.ext) { done = true; continue; }
+        const unsigned v = tab[(size_t)w * DEXT + e];
+        j += v >> 16; e = v & 0xFFFFu; w++;
+    }
+    for (int h = 4; !done && h < DSC_LIST && (int)w < nwin; h++) {
+        const uint2 q = wc2[(size_t)w];
+        if (q.x == e) {
+            const long long dd = (long long)(1u + j) - ((long long)q.y - (long long)c);
             if (dd > -16000 && dd < 16000 && 1u + j + 2u < (unsigned)g.ntx) d = (int)dd;
             break;
         }
