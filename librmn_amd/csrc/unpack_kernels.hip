@@ -126,13 +126,12 @@ __device__ __forceinline__ unsigned dec_empty_run(const DecGeom &g, unsigned lon
     const unsigned k = (z < avail ? z : avail) / (unsigned)g.C, kmax = (lim - p + (unsigned)g.C - 1u) / (unsigned)g.C;
     return k < kmax ? k : kmax;
 }
-__device__ __forceinline__ unsigned gword(const unsigned *z1, size_t w, size_t nwords) { return w < nwords ? z1[w] : 0u; }
-/* the same without a branch around the load (index clamped, result masked): a run of such loads is issued back to back -- behind `w < nwords ? load : 0` the compiler
- * puts every load in a block of its own and waits for it before the next (80 staged words per lane: 80 round trips, the whole 96 us of k_dsc_emit) */
-__device__ __forceinline__ unsigned gword_nb(const unsigned *z1, size_t w, size_t nwords)
+/* word w of the stream, 0 behind its end.  No branch around the load (index clamped, result masked): behind `w < nwords ? z1[w] : 0` the compiler put every load in a
+ * block of its own and waited for it before the next one -- the two words of a getbits_g one after the other, 80 staged words per lane as 80 round trips */
+__device__ __forceinline__ unsigned gword(const unsigned *z1, size_t w, size_t nwords)
 {
     const bool in = w < nwords;
-    const unsigned v = __builtin_nontemporal_load(z1 + (in ? w : (size_t)0));
+    const unsigned v = *(in ? z1 + w : z1 - 1);          /* (z1 = the stream + 1 in every caller: the header word is always there) */
     return in ? v : 0u;
 }
 __device__ __forceinline__ unsigned getbits_g(const unsigned *z1, size_t nwords, unsigned p, int nb)
@@ -731,11 +730,11 @@ __global__ __launch_bounds__(64) void k_dsc_emit(const unsigned *z_all, size_t z
     const unsigned e = w < nwin ? wentc_all[(size_t)f * went_stride + 2 * (size_t)w] : 0xFFFFFFFFu;
     unsigned t = w < nwin ? wentc_all[(size_t)f * went_stride + 2 * (size_t)w + 1] : 0u;
 #pragma unroll 16
-    for (int k = 0; k < 64; k++) sw[k * EMIT_STRIDE + lane] = gword_nb(z + 1, (size_t)(wbase + k) * DWW + (size_t)lane, nwords);
+    for (int k = 0; k < 64; k++) sw[k * EMIT_STRIDE + lane] = gword(z + 1, (size_t)(wbase + k) * DWW + (size_t)lane, nwords);
 #pragma unroll
     for (int q = 0; q < 64 * DTAIL / 64; q++) {
         const int k = q * (64 / DTAIL) + (lane / DTAIL), i = lane % DTAIL;
-        sw[k * EMIT_STRIDE + DWW + i] = gword_nb(z + 1, (size_t)(wbase + k + 1) * DWW + (size_t)i, nwords);
+        sw[k * EMIT_STRIDE + DWW + i] = gword(z + 1, (size_t)(wbase + k + 1) * DWW + (size_t)i, nwords);
     }
     __syncthreads();
     if (e == 0xFFFFFFFFu) return;
@@ -788,7 +787,7 @@ __global__ __launch_bounds__(256) void k_dsc_dtab(const unsigned *z_all, size_t 
     unsigned *sp = sp_all[wv];
     if (staged) {
 #pragma unroll 8
-        for (unsigned i = lane; i < nsp; i += 64) sp[i] = gword_nb(z + 1, (size_t)ws + i, nwords);
+        for (unsigned i = lane; i < nsp; i += 64) sp[i] = gword(z + 1, (size_t)ws + i, nwords);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (!act) return;
