@@ -3060,6 +3060,9 @@ __global__ __launch_bounds__(256) void k_uvt_pack(ezhip_pts_plan p, const float 
 #define UVT_WAVES_W 6                                   /* the REAL form of the wrap-around variant needs fewer registers, its records a third of the LDS */
 #endif
 
+template <bool STRIP3 = false>
+__device__ __forceinline__ void special2c_body(const ezhip_pts_plan &p, float *__restrict__ zout1, float *__restrict__ zout2, const float *__restrict__ zin1, const float *__restrict__ zin2,
+                                               const float *__restrict__ prow_n2, const float *__restrict__ prow_s2, unsigned blk, unsigned nblk, size_t roff = 0, int part = 0);
 template <int TW, int TH, bool NW = false, bool BATCH = false>      /* BATCH: p.npairs wind pairs one after the other per tile (c_ezuvint_batch_dev): the points' x, y and rotation, the
                                                  * tile's table entry and its axis records once for all of them; NW: a source without wrap (a regional 'Z' grid): both components in the LITERAL form of ez_irgdint_3_nw.inc (REAL statement
                                                  * functions), as k_pts2<PK_IRGD3_NW> evaluates them on the set's first call */
@@ -3077,6 +3080,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? UVT
         if (blockIdx.x < 2u * (unsigned)npairs) {
             const size_t f = BATCH ? blockIdx.x >> 1 : 0;
             polar_wind_body<2048>((blockIdx.x & 1u) == 0, p.pw_out + f * (size_t)p.pair_rows_stride, zin1 + f * p.pair_in_stride, zin2 + f * p.pair_in_stride, p.pw_plon2, p.ni, p.nj, p.pw_xg4_n, p.pw_xg4_s, p.pw_weighted, p.pw_ax, uvt_lds);
+            if (!NW && p.cspec_inline) {
+                /* the set's special points (a few polar-strip and re-interpolated points: a chain of dependent gathers, 5 us as a launch of their own behind this kernel)
+                 * right here: the northern producer has the northern rows it needs, the southern one the southern; nobody else writes these points */
+                __threadfence_block();
+                __syncthreads();
+                special2c_body<true>(p, zout1 + f * p.pair_out_stride, zout2 + f * p.pair_out_stride, zin1 + f * p.pair_in_stride, zin2 + f * p.pair_in_stride,
+                                     p.pw_out + 2 * (size_t)p.ni, p.pw_out + 3 * (size_t)p.ni, 0u, 1u, f * (size_t)p.pair_rows_stride, (blockIdx.x & 1u) ? 2 : 1);
+            }
             return;      /* (the launch's dynamic LDS holds 2052 floats and more) */
         }
         boff = 2u * (unsigned)npairs;
@@ -3694,10 +3705,14 @@ __global__ __launch_bounds__(256) void k_pts_special2(ezhip_pts_plan p_arg, floa
     }
 }
 
-/* the same with the points known to the host (ezhip_pts_plan.cspec_*): index, x and y of point k side by side, their number by value */
+/* the same with the points known to the host (ezhip_pts_plan.cspec_*): index, x and y of point k side by side, their number by value.
+ * STRIP3: polar-strip points of a bicubic irregular source only (no re-interpolated points in the set: zones == 1) -- nothing but the inline strip, no out-of-line
+ * callee: what k_uvt's producer blocks can carry within that kernel's registers */
+template <bool STRIP3>
 __device__ __forceinline__ void special2c_body(const ezhip_pts_plan &p, float *__restrict__ zout1, float *__restrict__ zout2,
                                                const float *__restrict__ zin1, const float *__restrict__ zin2,
-                                               const float *__restrict__ prow_n2, const float *__restrict__ prow_s2, unsigned blk, unsigned nblk, size_t roff = 0 /* a batch: the pair's polar wind rows */)
+                                               const float *__restrict__ prow_n2, const float *__restrict__ prow_s2, unsigned blk, unsigned nblk, size_t roff /* a batch: the pair's polar wind rows */,
+                                               int part /* 0: every point; 1: everything but the southern strip, 2: the southern strip only (the two polar-wind producer blocks of k_uvt: each has its own rows) */)
 {
     /* a LANE PAIR per point: lane 2 k takes the first component, lane 2 k + 1 the second (the few special points of a set are a chain of dependent gathers --
      * ~12 us of latency per call with both components one after the other on one lane), then they swap results for the wind matrix */
@@ -3710,16 +3725,17 @@ __device__ __forceinline__ void special2c_body(const ezhip_pts_plan &p, float *_
         wm_f2 mlo = {1.f, 0.f}, mhi = {0.f, 1.f};
         if (p.wind_M) wind_m_load(p.wind_M, p.wind_M_half, o, mlo, mhi);       /* on its way while the stencils are gathered */
         const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, px, py);
+        if (part && (part == 2) != (zone == PZ_STRIP_S)) continue;      /* (both lanes of a pair alike) */
         FieldAcc Z;
         Z.z = comp ? zin2 : zin1; Z.ni = p.ni; Z.j1 = p.j1; Z.j2 = p.j2; Z.pole_n = 0.f; Z.pole_s = 0.f; Z.prow_n = nullptr; Z.prow_s = nullptr;
         float mine;
-        if (zone == PZ_REINTERP) mine = gdinterp_point(p, Z, p.degre_extrap, px, py);
+        if (!STRIP3 && zone == PZ_REINTERP) mine = gdinterp_point(p, Z, p.degre_extrap, px, py);
         else {
             Z.prow_n = comp ? prow_n2 : p.pole_row_n; Z.prow_s = comp ? prow_s2 : p.pole_row_s;
             if (roff) { if (Z.prow_n) Z.prow_n += roff; if (Z.prow_s) Z.prow_s += roff; }
             /* (the bicubic strip of an irregular source -- cfg3's case -- inline: through the out-of-line strip_point this launch of ONE thread block spent most of
              * its 10 us fetching instructions and passing arguments through scratch) */
-            if (p.degree == 3 && p.irregular) {
+            if (STRIP3 || (p.degree == 3 && p.irregular)) {
                 const int north = zone == PZ_STRIP_N, j1s = north ? p.j2 - 2 : p.j1 - 1;
                 mine = p_irgdint_3_wnnc(Z, px, py, p.ax, north ? p.ay4_n : p.ay4_s, p.ni, j1s, j1s + 3, p.wrap);
             } else mine = strip_point(p, Z, zone == PZ_STRIP_N, px, py);
@@ -3736,7 +3752,7 @@ __global__ __launch_bounds__(256) void k_pts_special2c(ezhip_pts_plan p_arg, flo
 {
     const ezhip_pts_plan &p = PLAN_IN_KERNARG();
     const size_t f = blockIdx.y;                                                  /* the pair of a batch (c_ezuvint_batch_dev); 0 otherwise */
-    special2c_body(p, zout1 + f * p.pair_out_stride, zout2 + f * p.pair_out_stride, zin1 + f * p.pair_in_stride, zin2 + f * p.pair_in_stride, prow_n2, prow_s2, blockIdx.x, gridDim.x,
+    special2c_body<false>(p, zout1 + f * p.pair_out_stride, zout2 + f * p.pair_out_stride, zin1 + f * p.pair_in_stride, zin2 + f * p.pair_in_stride, prow_n2, prow_s2, blockIdx.x, gridDim.x,
                    f * (size_t)p.pair_rows_stride);
 }
 __global__ __launch_bounds__(256) void k_spec_gather(int *__restrict__ list_out, float *__restrict__ x_out, float *__restrict__ y_out,
@@ -3887,6 +3903,8 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
         size_t lds = (size_t)8 * (size_t)pu2.uvt_cap + (stage3nw ? 80 : 32) * UVT_REC_MAX;
         if (lds < 4 * 2052 + 16) lds = 4 * 2052 + 16;                          /* (the polar-wind producer blocks' row buffer) */
         pu2.xcd_order = getenv("EZHIP_UVT_XCD") ? atoi(getenv("EZHIP_UVT_XCD")) : 0;
+        /* few special points and polar-wind producer blocks in the launch: the producers take them along (EZHIP_UVT_SPECIAL_LAUNCH=1: the launch of their own, as before) */
+        pu2.cspec_inline = pu2.pw_out && !stage3nw && fast3w && pu2.zones == 1 && plan_u->cspec_count > 0 && plan_u->cspec_count <= 512 && pu2.pole_row_n == pu2.pw_out && !(pu2.uvt_debug & 8) && !getenv("EZHIP_UVT_SPECIAL_LAUNCH");
         pu2.uvt_read2 = getenv("EZHIP_UVT_READ2") ? 1 : 0;                      /* development: the compiler's paired LDS reads (same results) */
 #define UVT_LAUNCH(TW, TH) hipLaunchKernelGGL((k_uvt<TW, TH>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl)
         if (npairs > 1) hipLaunchKernelGGL((k_uvt<32, 32, false, true>), g, block, lds, g_stream, pu2, d_out_u, d_out_v, d_in_u, d_in_v, d_x, d_y, tl);      /* all pairs of the batch */
@@ -3896,7 +3914,7 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
 #undef UVT_LAUNCH
         if (LAUNCH_CHECK("k_uvt")) return -1;
         if (ezhip_side_join()) return -1;
-        if (plan_u->cspec_count > 0 && !(pu2.uvt_debug & 8)) {
+        if (plan_u->cspec_count > 0 && !(pu2.uvt_debug & 8) && !pu2.cspec_inline) {
             const unsigned nbk = (unsigned)((2 * plan_u->cspec_count + 255) / 256);      /* a lane pair per point */
             hipLaunchKernelGGL(k_pts_special2c, dim3(nbk < 256 ? nbk : 256, (unsigned)npairs), block, 0, g_stream, *plan_u, d_out_u, d_out_v, d_in_u, d_in_v, plan_v->pole_row_n, plan_v->pole_row_s);
             return LAUNCH_CHECK("k_pts_special2c");

@@ -236,6 +236,7 @@ typedef struct {
      * d_out + f * pair_out_stride (floats), its four polar wind rows at pw_out / pole_row_* + f * pair_rows_stride; x, y and the rotation of a point are read once
      * for all pairs */
     int npairs, pair_rows_stride;
+    int cspec_inline;                 /* k_uvt: the polar-wind producer blocks take the set's (few) special points along when their rows are done -- no launch behind the kernel */
     size_t pair_in_stride, pair_out_stride;
     int wind_dst_rot;                 /* with wind_M: the TARGET frame is a rotated one (decides what a REAL overflow of the chain's speed turns into) */
     int wind_M_half;                  /* wind_M holds ONE word per point: a pure rotation (a, b), c = -b, d = a, packed by rot_pack (ez_kernels.hip) */
