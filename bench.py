@@ -261,7 +261,7 @@ def extras(ez, torch, stream, d_out, d_in):
                             "algorithmic_GBps": algo3 / us / 1e3,
                             "roofline": {"bound": "hbm", "achieved": algo3 / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": algo3 / us / 1e3 / HBM_PEAK_GBPS,
                                          "traffic": t3[0] * 1e6 if t3 else None, "traffic_source": t3[1] if t3 else None,
-                                         "kernel": "k_uvt<32, 32> (stencil windows staged in LDS; the first call of a grid set: k_pts2_irgd3w) + k_pts_special2c behind it", "algorithmic_bytes_per_launch": algo3,
+                                         "kernel": "k_uvt<32, 32> (stencil windows staged in LDS; the set's few special points ride in its polar-wind producer blocks; the first call of a grid set: k_pts2_irgd3w)", "algorithmic_bytes_per_launch": algo3,
                                          "note": "x, y of the rotated source and the per-point wind rotation (one packed word) -- 12 bytes per target point, read from the set's tile-ordered copy -- and the "
                                                  "64 MB of results stream next to the staged source windows; REAL (packed fp32) evaluation with a REAL*8 second pass where the wind is small under a strong "
                                                  "stencil; no unit saturated (VALU 40 %, LDS 47 % of the kernel: SQ counters, profiles/r05_experiments.txt): the vector L1 returns in order, a block's round "
@@ -282,7 +282,7 @@ def extras(ez, torch, stream, d_out, d_in):
                                   "us_per_pair": usb, "Mpoint_pairs_per_s": no * mo / usb, "algorithmic_GBps": algo3 / usb / 1e3, "frac_of_hbm_peak": algo3 / usb / 1e3 / HBM_PEAK_GBPS,
                                   "equal_to_single_calls_bitwise": same_b, "single_call_us_per_pair": us,
                                   "traffic": (profile_value("cfg3_batch_traffic_MB_per_pair") or (None, None))[0], "traffic_unit": "MB per pair", "traffic_source": (profile_value("cfg3_batch_traffic_MB_per_pair") or (None, None))[1],
-                                  "kernel": "k_uvt<32, 32, false, true> (the pairs of the batch one after the other per tile) + k_pts_special2c once with a pair index"}
+                                  "kernel": "k_uvt<32, 32, false, true> (the pairs of the batch one after the other per tile; two producer blocks per pair, which also take the pair's special points)"}
         del d_ub, d_vb, o_ub, o_vb, r_u, r_v
         # the scalar twin on the same grid pair: c_ezsint from the rotated source (k_st: stencil windows staged in LDS, the literal REAL*8 form of the reference)
         us1 = ev_time(lambda: ez.ezsint_dev(o_u, d_u), 20)
