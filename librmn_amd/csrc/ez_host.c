@@ -68,6 +68,7 @@ typedef struct ezh_set {
     void *d_st_tiles[2], *d_st_streams[2]; int st_key[2], st_cap[2], st_stats[2][4];      /* k_st1 / k_st (slot 0: bilinear, 1: bicubic): the tile table (scalar zone rules) and the tile-ordered {x, y} copy; st_key: the zone options they were built under, -1: tried, not worth it */
     size_t cache_bytes;                    /* HBM this set's staged-tile caches hold (tile tables + tile-ordered stream copies): counted against g_cache_budget */
     void *d_uvt_streams; const void *uvt_streams_M;      /* the tile-ordered {x, y, a, b} copy and the matrix array it was packed from (another matrix: the plain arrays are read) */      /* k_uvt's tile table over the set's x, y (built with the special-point cache, under the same key) */
+    int *d_sspec_list; float *d_sspec_xy; int sspec_count, sspec_key;      /* the same for the bicubic SCALAR staged-tile launch (k_st): pole points and polar strips under the zone options of st_key[1]; 0: none kept */
     int *d_cspec_list; float *d_cspec_xy; int cspec_count, cspec_key;      /* the special points (polar strips, re-interpolated extrapolation) of the wind-pair launch, kept after its first call: index, x, y; key = the zone options they were listed under (0: none yet) */
     float *d_lamb_cs[2];    /* c_ezuvint from / towards a Lambert '!' grid: {cos, sin} of its rotation angle at the target points' longitudes (source leg, target leg) */
     void *d_windM;          /* c_ezuvint through a rotated frame: the wind chain of this grid pair as a 2 x 2 matrix per target point (built on first use) */
@@ -924,7 +925,7 @@ static void free_set(ezh_set *s)
 {
     for (int d = 0; d < 3; d++) for (int v = 0; v < 2; v++) free_sepplan(&s->sep[d][v]);
     free(s->x1d); free(s->y1d);
-    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_lamb_cs[0]); ezhip_free(s->d_lamb_cs[1]); ezhip_free(s->d_cspec_list); ezhip_free(s->d_cspec_xy); pthread_mutex_lock(&g_plan_mtx); cache_unreserve(s, s->cache_bytes); pthread_mutex_unlock(&g_plan_mtx); ezhip_free(s->d_uvt_tiles); ezhip_free(s->d_uvt_streams); ezhip_free(s->d_st_tiles[0]); ezhip_free(s->d_st_streams[0]); ezhip_free(s->d_st_tiles[1]); ezhip_free(s->d_st_streams[1]); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
+    ezhip_free(s->d_x); ezhip_free(s->d_y); ezhip_free(s->d_scratch); ezhip_free(s->d_prow); ezhip_free(s->d_poles_batch); ezhip_free(s->d_windM); ezhip_free(s->d_lamb_cs[0]); ezhip_free(s->d_lamb_cs[1]); ezhip_free(s->d_cspec_list); ezhip_free(s->d_cspec_xy); ezhip_free(s->d_sspec_list); ezhip_free(s->d_sspec_xy); pthread_mutex_lock(&g_plan_mtx); cache_unreserve(s, s->cache_bytes); pthread_mutex_unlock(&g_plan_mtx); ezhip_free(s->d_uvt_tiles); ezhip_free(s->d_uvt_streams); ezhip_free(s->d_st_tiles[0]); ezhip_free(s->d_st_streams[0]); ezhip_free(s->d_st_tiles[1]); ezhip_free(s->d_st_streams[1]); ezhip_free(s->d_avg[0]); ezhip_free(s->d_avg[1]);
     for (int k = 0; k < 2; k++) { ezhip_free(s->d_yy_x[k]); ezhip_free(s->d_yy_y[k]); ezhip_free(s->d_yy_lat[k]); ezhip_free(s->d_yy_lon[k]); ezhip_free(s->d_yy_idx[k]); }
     for (int k = 0; k < 4; k++) ezhip_free(s->d_yy_tmp[k]);
     free(s);
@@ -2666,7 +2667,12 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
     if (st_ok) {
         pp.tile_ni = go->ni; pp.tile_nj = go->nj;
         pthread_mutex_lock(&g_plan_mtx);
-        if (s->st_key[sl] == st_key && s->d_st_tiles[sl]) { pp.uvt_tiles = s->d_st_tiles[sl]; pp.uvt_shape = 3232; pp.uvt_cap = s->st_cap[sl]; pp.uvt_streams = s->d_st_streams[sl]; }
+        if (s->st_key[sl] == st_key && s->d_st_tiles[sl]) {
+            pp.uvt_tiles = s->d_st_tiles[sl]; pp.uvt_shape = 3232; pp.uvt_cap = s->st_cap[sl]; pp.uvt_streams = s->d_st_streams[sl];
+            if (sl == 1 && s->sspec_key == st_key && s->sspec_count > 0) {      /* the set's special points under these options: the kernel's producer blocks take them along */
+                pp.cspec_valid = 1; pp.cspec_count = s->sspec_count; pp.cspec_list = s->d_sspec_list; pp.cspec_x = s->d_sspec_xy; pp.cspec_y = s->d_sspec_xy + s->sspec_count;
+            }
+        }
         else if (s->st_key[sl] == 0) st_build = 1;
         pthread_mutex_unlock(&g_plan_mtx);
     }
@@ -2692,6 +2698,20 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
         }
         if ((dt || ds || !good) && fits) cache_unreserve(s, st_bytes);      /* not kept: the reservation goes back */
         pthread_mutex_unlock(&g_plan_mtx);
+        /* ... and the special points this call's gathering kernel has just listed (pole points, polar strips; a set with re-interpolated points keeps the launch of its own) */
+        if (good && sl == 1 && zones == 1 && pp.pv_out && !getenv("EZHIP_NO_SPEC_CACHE")) {      /* (pv_out: this call listed its pole points too -- their values came out of its own launch) */
+            const int cnt = ezhip_pts2_special_snapshot(NULL, NULL, NULL, 0, s->d_x, s->d_y);
+            if (cnt > 0 && cnt <= 4096) {
+                int *dl = (int *)ezhip_malloc(sizeof(int) * (size_t)cnt);
+                float *dxy = (float *)ezhip_malloc(sizeof(float) * 2 * (size_t)cnt);
+                if (dl && dxy && ezhip_pts2_special_snapshot(dl, dxy, dxy + cnt, cnt, s->d_x, s->d_y) == cnt) {
+                    pthread_mutex_lock(&g_plan_mtx);
+                    if (s->sspec_key == 0 && s->st_key[sl] == st_key) { s->d_sspec_list = dl; s->d_sspec_xy = dxy; s->sspec_count = cnt; s->sspec_key = st_key; dl = NULL; dxy = NULL; }
+                    pthread_mutex_unlock(&g_plan_mtx);
+                }
+                ezhip_free(dl); ezhip_free(dxy);
+            }
+        }
         if (good && getenv("EZHIP_VERBOSE")) fprintf(stderr, "<ezhip> k_st tile table of set (%d, %d): %d tiles staged, %d gathered, %d without a normal point, largest window %d cells\n", s->gdin, s->gdout, st[0], st[1], st[2], st[3]);
         ezhip_free(dt); ezhip_free(ds);
     }

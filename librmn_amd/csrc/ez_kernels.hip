@@ -3316,6 +3316,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? STB
             const float *row = blockIdx.x == 0 ? zin + (size_t)(p.pv_nj - 1) * p.ni : zin;
             const float v = block_poleval(row, p.ni, p.pole_weighted, p.ax, st_lds, 2048);
             if (threadIdx.x == 0) p.pv_out[blockIdx.x] = v;
+            if (!NW && !BATCH && p.cspec_inline) {
+                /* the set's special points (pole points and polar strips; no re-interpolated ones: zones == 1), known to the host: the northern producer takes the
+                 * northern ones with the pole value it has just summed, the southern one the southern -- no launch behind the kernel (ez_corrval.c:62-126) */
+                const bool north = blockIdx.x == 0;
+                for (int k = (int)threadIdx.x; k < p.cspec_count; k += 256) {
+                    const int n = p.cspec_list[k];
+                    const float fx = p.cspec_x[k], fy = p.cspec_y[k];
+                    const int zone = pts_zone(p.zones, p.ni, p.nj, p.j1, p.j2, p.ypole_n, p.ypole_s, p.vector_mode, p.degre_extrap, fx, fy);
+                    if (north ? (zone == PZ_POLE_N) : (zone == PZ_POLE_S)) { zout[n] = v; continue; }
+                    if (!(north ? (zone == PZ_STRIP_N) : (zone == PZ_STRIP_S))) continue;
+                    FieldAcc Z;
+                    Z.z = zin; Z.ni = p.ni; Z.j1 = p.j1; Z.j2 = p.j2; Z.pole_n = v; Z.pole_s = v; Z.prow_n = nullptr; Z.prow_s = nullptr;      /* (a strip reaches its own pole only) */
+                    const int j1s = north ? p.j2 - 2 : p.j1 - 1;
+                    zout[n] = p_irgdint_3_wnnc(Z, fx, fy, p.ax, north ? p.ay4_n : p.ay4_s, p.ni, j1s, j1s + 3, p.wrap);
+                }
+            }
             return;
         }
         boff = 2;
@@ -3405,7 +3421,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? STB
         if (zone != PZ_NORMAL) {           /* fill value, or a point of the next kernel's list (as k_pts lists them) */
             if (zone == PZ_FILL) zout[n] = *p.fill;
             else if (!p.pv_out && (zone == PZ_POLE_S || zone == PZ_POLE_N)) zout[n] = pv[zone == PZ_POLE_S ? 1 : 0];
-            else if (f == 0) {
+            else if (f == 0 && special_list) {      /* (nullptr: the set's special points are known and ride in the producer blocks) */
                 const unsigned long long m = __ballot(1);
                 const int lane = (int)__lane_id(), leader = __ffsll((long long)m) - 1;
                 unsigned base = 0;
@@ -3833,6 +3849,15 @@ static int interp_pts_impl(const ezhip_pts_plan *plan, float *d_zout, const floa
         size_t lds = 4 * (size_t)((cap + 3) & ~3) + 80 * (size_t)UVT_REC_MAX + 16;
         if (lds < 4 * 2052 + 16) lds = 4 * 2052 + 16;
         if (lds > 65536) return -1;                      /* (no attribute needed up to 64 KB) */
+        /* the set's special points known to the host, few, none re-interpolated, and producer blocks in the launch: they take the points along (k_st), nothing is listed,
+         * no launch behind the kernel (EZHIP_ST_SPECIAL_LAUNCH=1: as before) */
+        if (kind_st == PK_IRGD3_W && nfields == 1 && plan->pv_out && plan->cspec_valid && plan->cspec_count > 0 && plan->cspec_count <= 4096 && plan->zones == 1 && !plan->vector_mode && !getenv("EZHIP_ST_SPECIAL_LAUNCH")) {
+            ezhip_pts_plan pi = *plan;
+            pi.cspec_inline = 1;
+            t_spec.epoch--;                                          /* (no list, no counter used by this launch) */
+            hipLaunchKernelGGL((k_st<32, 32, false, false>), dim3(nt + 2u), block, lds, g_stream, pi, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, (int *)nullptr, cnt, 1, in_stride, out_stride);
+            return LAUNCH_CHECK("k_st");
+        }
 #define ST_LAUNCH(NW, B) hipLaunchKernelGGL((k_st<32, 32, NW, B>), dim3(nt + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt, nfields, in_stride, out_stride)
         if (kind_st == PK_IRGD3_W) { if (nfields > 1) ST_LAUNCH(false, true); else ST_LAUNCH(false, false); }
         else { if (nfields > 1) ST_LAUNCH(true, true); else ST_LAUNCH(true, false); }

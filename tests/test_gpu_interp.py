@@ -1539,19 +1539,21 @@ def test_uvt_staged_tiles_equal_gathering_kernel(shape, eig, th):
         ez.use_stream(torch.cuda.current_stream().cuda_stream)
         d_u = torch.from_numpy(uu).cuda(); d_v = torch.from_numpy(vv).cuda()
         outs = []
-        for call in range(3):
+        for call in range(4):                                     # 0: k_pts2_irgd3w; 1: k_uvt (the special points inside its producer blocks, round 5); 2: their launch of their own; 3: the gathering kernel
             o_u = torch.full((no * mo,), float("nan"), dtype=torch.float32, device="cuda"); o_v = torch.full_like(o_u, float("nan"))
             if call == 2:
+                os.environ["EZHIP_UVT_SPECIAL_LAUNCH"] = "1"
+            if call == 3:
                 os.environ["EZHIP_NO_UVT"] = "1"
             assert ez.ezuvint_dev(o_u, o_v, d_u, d_v) == 0
             torch.cuda.synchronize()
             outs.append((o_u, o_v))
-        for k in (1, 2):
+        for k in (1, 2, 3):
             assert torch.equal(outs[0][0].view(torch.int32), outs[k][0].view(torch.int32)), (k, int((outs[0][0] != outs[k][0]).sum()))
             assert torch.equal(outs[0][1].view(torch.int32), outs[k][1].view(torch.int32)), k
-        assert not torch.isnan(outs[1][0]).any()
+        assert not torch.isnan(outs[1][0]).any() and not torch.isnan(outs[1][1]).any()
     finally:
-        os.environ.pop("EZHIP_UVT_SHAPE", None); os.environ.pop("EZHIP_NO_UVT", None); os.environ.pop("EZHIP_UVT_NO_STREAMS", None)
+        os.environ.pop("EZHIP_UVT_SHAPE", None); os.environ.pop("EZHIP_NO_UVT", None); os.environ.pop("EZHIP_UVT_NO_STREAMS", None); os.environ.pop("EZHIP_UVT_SPECIAL_LAUNCH", None)
         ez.gdrls(gdin); ez.gdrls(gdout)
 
 
@@ -1576,18 +1578,20 @@ def test_st_staged_tiles_equal_gathering_kernel(shape, eig, polar, degree):
         ez.use_stream(torch.cuda.current_stream().cuda_stream)
         d_f = torch.from_numpy(f).cuda()
         outs = []
-        for call in range(4):
+        for call in range(5):                                     # 0: k_pts; 1, 2: k_st (the special points inside its producer blocks, round 5); 3: their launch of their own; 4: k_pts again
             o = torch.full((no * mo,), float("nan"), dtype=torch.float32, device="cuda")
             if call == 3:
+                os.environ["EZHIP_ST_SPECIAL_LAUNCH"] = "1"
+            if call == 4:
                 os.environ["EZHIP_NO_ST"] = "1"
             assert ez.ezsint_dev(o, d_f) >= 0
             torch.cuda.synchronize()
             outs.append(o)
-        for k in (1, 2, 3):
+        for k in (1, 2, 3, 4):
             assert torch.equal(outs[0].view(torch.int32), outs[k].view(torch.int32)), (k, int((outs[0] != outs[k]).sum()))
         assert not torch.isnan(outs[1]).any()
     finally:
-        os.environ.pop("EZHIP_ST_MIN_POINTS", None); os.environ.pop("EZHIP_NO_ST", None)
+        os.environ.pop("EZHIP_ST_MIN_POINTS", None); os.environ.pop("EZHIP_NO_ST", None); os.environ.pop("EZHIP_ST_SPECIAL_LAUNCH", None)
         ez.gdrls(gdin); ez.gdrls(gdout)
 
 
