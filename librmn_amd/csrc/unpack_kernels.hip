@@ -875,12 +875,30 @@ __global__ __launch_bounds__(256) void k_dsc_jump(const unsigned *z_all, size_t 
  * ahead through the composed maps of 8^l windows (k_dmin_up's tables: the largest aligned block whose tile count still fits, ~20 dependent lookups instead of the
  * ~150 windows of a row), then tile by tile inside the window where the row's odd tile starts.  pn = that tile's bit position; cn = its canonical index when the
  * chain is the canonical one again by that window (the recurrence goes back to its tables), 0xFFFFFFFF when not (the next row is walked the same way). */
+/* (the whole wave runs this, every lane alike: the window under the walk is staged in LDS by all lanes -- one coalesced read instead of a dependent global read per tile
+ * step -- and read back by all of them; sw_w = the window sw holds, -1 none) */
+__device__ __forceinline__ void dsc_stage_window(unsigned *sw, int &sw_w, const unsigned *z1, size_t nwords, unsigned w)
+{
+    if (sw_w == (int)w) return;
+    const unsigned lane = threadIdx.x & 63u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();          /* (reads of the window before are done) */
+    sw[lane] = gword(z1, (size_t)w * DWW + lane, nwords);
+    if (lane < DTAIL) sw[DWW + lane] = gword(z1, (size_t)(w + 1) * DWW + lane, nwords);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    sw_w = (int)w;
+}
+__device__ __forceinline__ unsigned dsc_hdr(const DecGeom &g, const unsigned *sw, int sw_w, const unsigned *z1, size_t nwords, unsigned p)
+{
+    return (int)(p / DW) == sw_w ? getbits(sw, p - (unsigned)sw_w * DW, g.C) : getbits_g(z1, nwords, p, g.C);
+}
 __device__ bool dsc_walk_row(const DecGeom &g, const unsigned *z1, size_t nwords, const unsigned *tab, const unsigned *wentc, const uint2 *lev,
-                             const unsigned *lev_nblk, const unsigned long long *lev_off, int nlev, int nwin, unsigned p, unsigned need, unsigned &pn, unsigned &cn)
+                             const unsigned *lev_nblk, const unsigned long long *lev_off, int nlev, int nwin, unsigned p, unsigned need, unsigned &pn, unsigned &cn,
+                             unsigned *sw, int &sw_w)
 {
     unsigned w = p / DW, tacc = 0;
     const unsigned end = (w + 1) * DW;
-    while (p < end && tacc < need) { p += (unsigned)dec_step(g, getbits_g(z1, nwords, p, g.C), g.n_int); tacc++; }
+    dsc_stage_window(sw, sw_w, z1, nwords, w);
+    while (p < end && tacc < need) { p += (unsigned)dec_step(g, getbits(sw, p - w * DW, g.C), g.n_int); tacc++; }
     if (p < end) return false;                                       /* (a row inside one window: not a geometry this form takes) */
     unsigned e = p - end;
     w++;
@@ -905,9 +923,10 @@ __device__ bool dsc_walk_row(const DecGeom &g, const unsigned *z1, size_t nwords
         if (take < 0) break;                                         /* the odd tile starts in window w */
         tacc += tcnt; e = tex; w += 1u << (3 * take);
     }
-    unsigned q = w * DW + e;
-    for (unsigned k = tacc; k < need; k++) q += (unsigned)dec_step(g, getbits_g(z1, nwords, q, g.C), g.n_int);
-    pn = q;
+    dsc_stage_window(sw, sw_w, z1, nwords, w);
+    unsigned q = e;                                                   /* (relative to the window) */
+    for (unsigned k = tacc; k < need; k++) q += (unsigned)dec_step(g, getbits(sw, q, g.C), g.n_int);
+    pn = w * DW + q;
     cn = wentc[2 * (size_t)w] == e ? wentc[2 * (size_t)w + 1] + (need - tacc) : 0xFFFFFFFFu;
     return true;
 }
@@ -918,8 +937,10 @@ __global__ __launch_bounds__(64) void k_dsc_rows(const unsigned *z_all, size_t z
                                                  size_t z_words = 0, const unsigned *tab_all = nullptr, const unsigned *wentc_all = nullptr, const unsigned *tpc_all = nullptr,
                                                  size_t w_stride = 0 /* of the three, in words */, unsigned *rowpn_all = nullptr, DscLev lv = DscLev(), int nwin = 0)
 {
+    __shared__ unsigned sw[DWW + DTAIL];                              /* the stream window under an explicit walk (dsc_walk_row) */
+    int sw_w = -1;
     const int f = blockIdx.x;
-    if (threadIdx.x) return;
+    const bool l0 = threadIdx.x == 0;                                /* every lane runs the recurrence (the same loads, the same values); lane 0 stores */
     unsigned *st = st_all + (size_t)f * st_stride;
     if (st[DSC_FAIL]) return;
     const unsigned *z = z_all + (size_t)f * z_stride;
@@ -933,28 +954,27 @@ __global__ __launch_bounds__(64) void k_dsc_rows(const unsigned *z_all, size_t z
     const size_t nwords = z_words ? z_words - 1 : 0;
     unsigned c = ntx - 1, r = 0, pn = 0xFFFFFFFFu, nslow = 0;        /* the odd tile of row r: canonical tile c, or (c == 0xFFFFFFFF) the tile at bit pn */
     while (r < rint) {
-        if (c != 0xFFFFFFFFu && c >= lim) { st[DSC_FAIL] = 8; return; }
-        rowc[r] = c; head[r] = 0;
-        if (rowpn) rowpn[r] = pn;
+        if (c != 0xFFFFFFFFu && c >= lim) { if (l0) st[DSC_FAIL] = 8; return; }
+        if (l0) { rowc[r] = c; head[r] = 0; if (rowpn) rowpn[r] = pn; }
         if (r + 1 >= rint) break;
         if (c != 0xFFFFFFFFu) {
             const int j = r + 8 < rint ? j3[c] : DSC_J_INVALID;
-            if (j != DSC_J_INVALID) { head[r] = 1; c = c + 8 * ntx - (unsigned)j; r += 8; continue; }       /* rows r + 1 .. r + 7: k_dsc_rowfill */
+            if (j != DSC_J_INVALID) { if (l0) head[r] = 1; c = c + 8 * ntx - (unsigned)j; r += 8; continue; }       /* rows r + 1 .. r + 7: k_dsc_rowfill */
             const int d = dtab[c];
             if (d != DSC_D_INVALID) { c = c + ntx - (unsigned)d; r++; continue; }
-            if (!rowpn || !lv.lev) { st[DSC_FAIL] = 9; st[8] = r; st[9] = c; return; }      /* (st[8], st[9]: where, for EZHIP_DEC_SCAN=2) */
+            if (!rowpn || !lv.lev) { if (l0) { st[DSC_FAIL] = 9; st[8] = r; st[9] = c; } return; }      /* (st[8], st[9]: where, for EZHIP_DEC_SCAN=2) */
             pn = tpc_all[(size_t)f * w_stride + c];
         }
         /* the explicit walk of row r + 1 from behind the odd tile at pn */
-        const unsigned start = pn + (unsigned)dec_step(g, getbits_g(z + 1, nwords, pn, g.C), g.mlast * g.istep);
+        const unsigned start = pn + (unsigned)dec_step(g, dsc_hdr(g, sw, sw_w, z + 1, nwords, pn), g.mlast * g.istep);
         unsigned cn;
         if (!dsc_walk_row(g, z + 1, nwords, tab_all + (size_t)f * w_stride, wentc_all + (size_t)f * w_stride, lv.lev + (size_t)f * lv.lev_stride, lv.nblk, lv.off, lv.nlev, nwin,
-                          start, ntx - 1, pn, cn)) { st[DSC_FAIL] = 15; st[8] = r; return; }
+                          start, ntx - 1, pn, cn, sw, sw_w)) { if (l0) { st[DSC_FAIL] = 15; st[8] = r; } return; }
         c = cn;
         if (c != 0xFFFFFFFFu) pn = 0xFFFFFFFFu;
         r++; nslow++;
     }
-    st[10] = nslow;                                                  /* rows walked explicitly (EZHIP_DEC_SCAN=2 prints it) */
+    if (l0) st[10] = nslow;                                                  /* rows walked explicitly (EZHIP_DEC_SCAN=2 prints it) */
 }
 __global__ __launch_bounds__(64) void k_dsc_rowfill(const unsigned *z_all, size_t z_stride, int ni, int nj, unsigned *st_all, size_t st_stride,
                                                     const short *dtab_all, size_t dtab_stride, unsigned *rowc_all, const unsigned *head_all, size_t row_stride, unsigned capc, int plain)
