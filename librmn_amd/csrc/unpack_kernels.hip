@@ -898,7 +898,12 @@ __device__ bool dsc_walk_row(const DecGeom &g, const unsigned *z1, size_t nwords
     unsigned w = p / DW, tacc = 0;
     const unsigned end = (w + 1) * DW;
     dsc_stage_window(sw, sw_w, z1, nwords, w);
-    while (p < end && tacc < need) { p += (unsigned)dec_step(g, getbits(sw, p - w * DW, g.C), g.n_int); tacc++; }
+    while (p < end && tacc < need) {
+        const unsigned long long v = bits64(sw, p - w * DW);
+        unsigned k = dec_empty_run(g, v, p, end);                    /* (a run of empty tiles at once) */
+        if (k) { k = k < need - tacc ? k : need - tacc; p += k * (unsigned)g.C; tacc += k; continue; }
+        p += (unsigned)dec_step(g, (unsigned)(v >> (64 - g.C)), g.n_int); tacc++;
+    }
     if (p < end) return false;                                       /* (a row inside one window: not a geometry this form takes) */
     unsigned e = p - end;
     w++;
@@ -925,7 +930,12 @@ __device__ bool dsc_walk_row(const DecGeom &g, const unsigned *z1, size_t nwords
     }
     dsc_stage_window(sw, sw_w, z1, nwords, w);
     unsigned q = e;                                                   /* (relative to the window) */
-    for (unsigned k = tacc; k < need; k++) q += (unsigned)dec_step(g, getbits(sw, q, g.C), g.n_int);
+    for (unsigned k = tacc; k < need; ) {
+        const unsigned long long v = bits64(sw, q);
+        unsigned kk = dec_empty_run(g, v, q, DW);
+        if (kk) { kk = kk < need - k ? kk : need - k; q += kk * (unsigned)g.C; k += kk; continue; }
+        q += (unsigned)dec_step(g, (unsigned)(v >> (64 - g.C)), g.n_int); k++;
+    }
     pn = w * DW + q;
     cn = wentc[2 * (size_t)w] == e ? wentc[2 * (size_t)w + 1] + (need - tacc) : 0xFFFFFFFFu;
     return true;
@@ -952,20 +962,32 @@ __global__ __launch_bounds__(64) void k_dsc_rows(const unsigned *z_all, size_t z
     unsigned *rowpn = rowpn_all ? rowpn_all + (size_t)f * row_stride : nullptr;
     const unsigned rint = st[DSC_RINT], lim = min(st[DSC_NCANON], capc), ntx = (unsigned)g.ntx;
     const size_t nwords = z_words ? z_words - 1 : 0;
-    unsigned c = ntx - 1, r = 0, pn = 0xFFFFFFFFu, nslow = 0;        /* the odd tile of row r: canonical tile c, or (c == 0xFFFFFFFF) the tile at bit pn */
-    while (r < rint) {
-        if (c != 0xFFFFFFFFu && c >= lim) { if (l0) st[DSC_FAIL] = 8; return; }
-        if (l0) { rowc[r] = c; head[r] = 0; if (rowpn) rowpn[r] = pn; }
-        if (r + 1 >= rint) break;
-        if (c != 0xFFFFFFFFu) {
-            const int j = r + 8 < rint ? j3[c] : DSC_J_INVALID;
-            if (j != DSC_J_INVALID) { if (l0) head[r] = 1; c = c + 8 * ntx - (unsigned)j; r += 8; continue; }       /* rows r + 1 .. r + 7: k_dsc_rowfill */
-            const int d = dtab[c];
-            if (d != DSC_D_INVALID) { c = c + ntx - (unsigned)d; r++; continue; }
-            if (!rowpn || !lv.lev) { if (l0) { st[DSC_FAIL] = 9; st[8] = r; st[9] = c; } return; }      /* (st[8], st[9]: where, for EZHIP_DEC_SCAN=2) */
-            pn = tpc_all[(size_t)f * w_stride + c];
+    unsigned c = ntx - 1, r = 0, pn = 0xFFFFFFFFu, nslow = 0, njump = 0, nstep = 0;        /* the odd tile of row r: canonical tile c, or (c == 0xFFFFFFFF) the tile at bit pn */
+    /* Lane 0 alone walks the tables (a dependent load per step: with all 64 lanes in it a step took 0.7 us instead of 0.47); when a row has to be walked explicitly the
+     * whole wave joins in -- it stages the stream windows of that walk -- and lane 0 goes on alone behind it.  what: 0 go on, 1 done, 2 an explicit walk is wanted, 3 failed */
+    for (;;) {
+        int what = 0;
+        if (l0) {
+            while (r < rint) {
+                if (c != 0xFFFFFFFFu && c >= lim) { st[DSC_FAIL] = 8; what = 3; break; }
+                rowc[r] = c; head[r] = 0;
+                if (rowpn) rowpn[r] = pn;
+                if (r + 1 >= rint) { what = 1; break; }
+                if (c == 0xFFFFFFFFu) { what = 2; break; }
+                const int j = r + 8 < rint ? j3[c] : DSC_J_INVALID;
+                if (j != DSC_J_INVALID) { head[r] = 1; c = c + 8 * ntx - (unsigned)j; r += 8; njump++; continue; }       /* rows r + 1 .. r + 7: k_dsc_rowfill */
+                const int d = dtab[c];
+                if (d != DSC_D_INVALID) { c = c + ntx - (unsigned)d; r++; nstep++; continue; }
+                if (!rowpn || !lv.lev) { st[DSC_FAIL] = 9; st[8] = r; st[9] = c; what = 3; break; }      /* (st[8], st[9]: where, for EZHIP_DEC_SCAN=2) */
+                pn = tpc_all[(size_t)f * w_stride + c];
+                what = 2; break;
+            }
+            if (what == 0) what = 1;                                 /* (r reached rint) */
         }
-        /* the explicit walk of row r + 1 from behind the odd tile at pn */
+        what = __builtin_amdgcn_readfirstlane(what);
+        if (what != 2) break;
+        pn = (unsigned)__builtin_amdgcn_readfirstlane((int)pn); r = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+        /* the explicit walk of row r + 1 from behind the odd tile at pn, the whole wave */
         const unsigned start = pn + (unsigned)dec_step(g, dsc_hdr(g, sw, sw_w, z + 1, nwords, pn), g.mlast * g.istep);
         unsigned cn;
         if (!dsc_walk_row(g, z + 1, nwords, tab_all + (size_t)f * w_stride, wentc_all + (size_t)f * w_stride, lv.lev + (size_t)f * lv.lev_stride, lv.nblk, lv.off, lv.nlev, nwin,
@@ -974,7 +996,7 @@ __global__ __launch_bounds__(64) void k_dsc_rows(const unsigned *z_all, size_t z
         if (c != 0xFFFFFFFFu) pn = 0xFFFFFFFFu;
         r++; nslow++;
     }
-    if (l0) st[10] = nslow;                                                  /* rows walked explicitly (EZHIP_DEC_SCAN=2 prints it) */
+    if (l0) { st[10] = nslow; st[11] = njump; st[12] = nstep; }      /* (EZHIP_DEC_SCAN=2: rows walked explicitly, eight-row jumps, single-row steps) */
 }
 __global__ __launch_bounds__(64) void k_dsc_rowfill(const unsigned *z_all, size_t z_stride, int ni, int nj, unsigned *st_all, size_t st_stride,
                                                     const short *dtab_all, size_t dtab_stride, unsigned *rowc_all, const unsigned *head_all, size_t row_stride, unsigned capc, int plain)
@@ -1734,7 +1756,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
                 fprintf(stderr, "<armn_compress> scan form, field %d: ok %u fail %u  first block window %u entry %u tiles %u  blocks %u  canonical tiles %u  interior rows %u\n",
                         f, h[DSC_OK], h[DSC_FAIL], h[DSC_WB], h[DSC_EB], h[DSC_TB], h[DSC_K], h[DSC_NCANON], h[DSC_RINT]);
                 if (hipMemcpyAsync(h, dst2 + (size_t)f * ws4, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
-                fprintf(stderr, "<armn_compress> composed ragged form, field %d: ok %u fail %u  canonical tiles %u  interior rows %u  (row %u, canonical tile %u)  rows walked explicitly %u\n", f, h[DSC_OK], h[DSC_FAIL], h[DSC_NCANON], h[DSC_RINT], h[8], h[9], h[10]);
+                fprintf(stderr, "<armn_compress> composed ragged form, field %d: ok %u fail %u  canonical tiles %u  interior rows %u  (row %u, canonical tile %u)  rows walked explicitly %u, eight-row jumps %u, single steps %u\n", f, h[DSC_OK], h[DSC_FAIL], h[DSC_NCANON], h[DSC_RINT], h[8], h[9], h[10], h[11], h[12]);
             }
         }
     }
