@@ -1053,7 +1053,18 @@ __global__ __launch_bounds__(64) void k_dsc_stretch(const unsigned *z_all, size_
     unsigned p = pos + (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.mlast * g.istep);
     unsigned w = pos / DW;
     const unsigned end = (w + 1) * DW;
-    while (p < end && t < tend) { tilepos[t] = p; p += (unsigned)dec_step(g, getbits_g(z + 1, nwords, p, g.C), g.n_int); t++; }
+    while (p < end && t < tend) {
+        const unsigned long long v = (unsigned long long)gword(z + 1, p >> 5, nwords) << 32 | gword(z + 1, (p >> 5) + 1, nwords);
+        const unsigned long long vs = v << (p & 31u);
+        unsigned k = dec_empty_run(g, vs, p, end);                   /* (a run of empty tiles: their positions without another read) */
+        if (k) {
+            k = k < tend - t ? k : tend - t;
+            for (unsigned q = 0; q < k; q++) tilepos[t + q] = p + q * (unsigned)g.C;
+            t += k; p += k * (unsigned)g.C;
+            continue;
+        }
+        tilepos[t] = p; p += (unsigned)dec_step(g, (unsigned)(vs >> (64 - g.C)), g.n_int); t++;
+    }
     if (p < end) { st[DSC_FAIL] = 10; return; }
     unsigned e = p - end, n = 0;
     w++;
@@ -1093,7 +1104,17 @@ __global__ __launch_bounds__(256) void k_dsc_stretch2(const unsigned *z_all, siz
     unsigned *tilepos = tilepos_all + (size_t)f * tp_stride;
     unsigned pos = sl[0] * DW + sl[1], t = sl[2];
     const unsigned end = (sl[0] + 1) * DW, tend = (r + 2) * (unsigned)g.ntx - 1;          /* (the odd tile of row r + 1: the last tile a stretch behind row r may hold) */
-    while (pos < end && t <= tend) { tilepos[t++] = pos; pos += (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.n_int); }
+    while (pos < end && t <= tend) {
+        const unsigned long long v = ((unsigned long long)gword(z + 1, pos >> 5, nwords) << 32 | gword(z + 1, (pos >> 5) + 1, nwords)) << (pos & 31u);
+        unsigned k = dec_empty_run(g, v, pos, end);
+        if (k) {
+            k = k < tend + 1u - t ? k : tend + 1u - t;
+            for (unsigned q = 0; q < k; q++) tilepos[t + q] = pos + q * (unsigned)g.C;
+            t += k; pos += k * (unsigned)g.C;
+            continue;
+        }
+        tilepos[t++] = pos; pos += (unsigned)dec_step(g, (unsigned)(v >> (64 - g.C)), g.n_int);
+    }
 }
 
 /* every tile outside the stretches: its canonical twin, shifted */
