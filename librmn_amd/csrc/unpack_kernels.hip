@@ -1135,13 +1135,17 @@ __global__ __launch_bounds__(256) void k_dsc_final(const unsigned *z_all, size_t
     tilepos_all[(size_t)f * tp_stride + t] = tpc_all[(size_t)f * tpc_stride + (t - shift)];       /* (t - shift < the canonical tiles kept: the stretch kernel met that index) */
 }
 
-/* the last row of tiles when its height differs: tile by tile behind the odd tile of the row before it; then the verdict */
+/* the last row of tiles when its height differs: tile by tile behind the odd tile of the row before it; then the verdict.  The whole wave: the window under the walk
+ * sits in LDS (one coalesced read per window instead of a dependent global read per tile: 1441 tiles of a 7201-point row took 0.41 ms), the next window's words are
+ * on their way into registers while this one is walked; every lane walks alike, lane 0 stores */
 __global__ __launch_bounds__(64) void k_dsc_lastrow(const unsigned *z_all, size_t z_stride, size_t z_words, int ni, int nj, unsigned *st_all, size_t st_stride,
                                                     const unsigned *tpc_all, size_t tpc_stride, const unsigned *rowc_all, size_t row_stride,
                                                     unsigned *tilepos_all, size_t tp_stride, int *status, int plain, const unsigned *rowpn_all = nullptr)
 {
+    __shared__ unsigned sw[DWW + DTAIL];
     const int f = blockIdx.x;
-    if (threadIdx.x) return;
+    const unsigned lane = threadIdx.x;
+    const bool l0 = lane == 0;
     unsigned *st = st_all + (size_t)f * st_stride;
     if (st[DSC_FAIL]) return;
     const unsigned *z = z_all + (size_t)f * z_stride;
@@ -1154,15 +1158,30 @@ __global__ __launch_bounds__(64) void k_dsc_lastrow(const unsigned *z_all, size_
         const unsigned cl = rowc_all[(size_t)f * row_stride + rint - 1];
         const unsigned pos = cl != 0xFFFFFFFFu ? tpc_all[(size_t)f * tpc_stride + cl] : rowpn_all[(size_t)f * row_stride + rint - 1];
         unsigned p = pos + (unsigned)dec_step(g, getbits_g(z + 1, nwords, pos, g.C), g.mlast * g.istep);
-        unsigned t = rint * ntx;
-        for (unsigned x = 0; x < ntx; x++, t++) {
-            tilepos[t] = p;
-            p += (unsigned)dec_step(g, getbits_g(z + 1, nwords, p, g.C), (x == ntx - 1 ? g.mlast : g.istep) * g.hlast);
+        unsigned t = rint * ntx, x = 0;
+        unsigned w = p / DW;
+        unsigned n0 = gword(z + 1, (size_t)w * DWW + lane, nwords), n1 = lane < DTAIL ? gword(z + 1, (size_t)(w + 1) * DWW + lane, nwords) : 0u;
+        while (x < ntx) {
+            /* window w into LDS (its words are in n0 / n1), window w + 1 asked for */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            sw[lane] = n0;
+            if (lane < DTAIL) sw[DWW + lane] = n1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            n0 = gword(z + 1, (size_t)(w + 1) * DWW + lane, nwords); n1 = lane < DTAIL ? gword(z + 1, (size_t)(w + 2) * DWW + lane, nwords) : 0u;
+            const unsigned base = w * DW, end = base + DW;
+            while (x < ntx && p < end) {
+                if (l0) tilepos[t] = p;
+                p += (unsigned)dec_step(g, getbits(sw, p - base, g.C), (x == ntx - 1 ? g.mlast : g.istep) * g.hlast);
+                x++; t++;
+            }
+            if (x < ntx && p >= end + DW) {                       /* (cannot happen: a tile is shorter than a window) */
+                w = p / DW;
+                n0 = gword(z + 1, (size_t)w * DWW + lane, nwords); n1 = lane < DTAIL ? gword(z + 1, (size_t)(w + 1) * DWW + lane, nwords) : 0u;
+            } else w++;
         }
-        if ((unsigned long long)p > 32ull * nwords + 64) { st[DSC_FAIL] = 11; return; }
+        if ((unsigned long long)p > 32ull * nwords + 64) { if (l0) st[DSC_FAIL] = 11; return; }
     }
-    st[DSC_OK] = 1;
-    status[f] = 0;
+    if (l0) { st[DSC_OK] = 1; status[f] = 0; }
 }
 
 /* ============================================================================================================================================
@@ -1649,17 +1668,30 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
                                                               * kernel runs only for the fields that form gives up on (small fields, streams whose windows do not merge);
                                                               * EZHIP_DEC_SCAN=0: the serial kernel for everything, 2: print every field's state words */
     const size_t ws4 = work_stride_bytes / 4, ws2 = work_stride_bytes / 2;
+    /* MINIMUM streams only?  Their walks do not merge within eight windows, so the merged-exit form (k_dsc_m8 .. k_dsc_scan) and the eight-window tables it and the
+     * serial chain kernel read (k_armn_dec_compose_lds) only cost time: 0.45 ms of a 1.2 ms decode.  The headers are read first (one small copy, one wait); such a batch
+     * goes straight to the composed forms, and only if those leave a field open are the tables made for the serial kernel.  EZHIP_DEC_MIN_FIRST_FORM=1: as before */
+    int all_min = 0;
+    if (phase == 0 && !plain && !walk_only && scan && nfields <= 256 && !getenv("EZHIP_DEC_ASYNC") && !getenv("EZHIP_DEC_NO_DMIN") && !getenv("EZHIP_DEC_MIN_FIRST_FORM")) {
+        unsigned hm[256];
+        hipError_t ec = nfields == 1 ? hipMemcpyAsync(hm, d_z, 4, hipMemcpyDeviceToHost, st)
+                                     : hipMemcpy2DAsync(hm, 4, d_z, 4 * z_stride_words, 4, (size_t)nfields, hipMemcpyDeviceToHost, st);
+        if (ec != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { fprintf(stderr, "<armn_compress> UNCOMPRESS: reading the stream headers failed\n"); return -1; }
+        all_min = 1;
+        for (int f = 0; f < nfields; f++) if ((hm[f] & 15u) != 3u) all_min = 0;
+    }
+    auto launch_compose = [&]() {
+        const int G = 28, lds_words = (3 * G + 17) * 160;          /* 64 640 B: G windows of 160-entry rows (t1: G + 7 rows, t2: G + 6, t4: G + 4) */
+        hipLaunchKernelGGL(k_armn_dec_compose_lds, dim3((nwin + G - 1) / G, nfields), dim3(CMP_TPB), (size_t)4 * lds_words, st, d_z, z_stride_words, ni, nj, tab, tab8, ws4, nwin, G, lds_words);
+    };
     if (phase != 2) {
     if (d_out && dec_fill(st, d_out, 4 * out_stride_words, nfields, 4 * (1 + n / 2), 0)) return -1;
     if (dec_fill(st, went, work_stride_bytes, nfields, 8 * (size_t)nwin, 0xFF) || dec_fill(st, went8, work_stride_bytes, nfields, 8 * (size_t)nwin, 0xFF)) return -1;
     hipLaunchKernelGGL(k_armn_dec_spec, dim3((nwin + SPEC_WPB - 1) / SPEC_WPB, nfields), dim3(64 * SPEC_WPB), 0, st, d_z, z_stride_words, z_words, ni, nj, tab, ws4, nwin, plain);
-    if (plain && no_serial) { }                     /* (the eight-window tables serve the merged-exit form and the serial chain kernel: neither runs for a plane walked this way) */
+    if ((plain && no_serial) || all_min) { }        /* (the eight-window tables serve the merged-exit form and the serial chain kernel: neither runs for a plane walked this way; MINIMUM: see above) */
     else if (getenv("EZHIP_DEC_COMPOSE_GLOBAL"))        /* development: eight dependent global loads per entry (rounds 1 - 2) */
         hipLaunchKernelGGL(k_armn_dec_compose, dim3(nwin, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, tab, tab8, ws4, nwin);
-    else {
-        const int G = 28, lds_words = (3 * G + 17) * 160;          /* 64 640 B: G windows of 160-entry rows (t1: G + 7 rows, t2: G + 6, t4: G + 4) */
-        hipLaunchKernelGGL(k_armn_dec_compose_lds, dim3((nwin + G - 1) / G, nfields), dim3(CMP_TPB), (size_t)4 * lds_words, st, d_z, z_stride_words, ni, nj, tab, tab8, ws4, nwin, G, lds_words);
-    }
+    else launch_compose();
     }
     if (phase == 1) { hipError_t e1 = hipGetLastError(); if (e1 != hipSuccess) { fprintf(stderr, "<armn_compress> UNCOMPRESS launch failed: %s\n", hipGetErrorString(e1)); return -1; } return 0; }
     const unsigned *skip = NULL;
@@ -1670,11 +1702,13 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
         if (dec_fill(st, wentc, work_stride_bytes, nfields, 8 * (size_t)nwin, 0xFF) || dec_fill(st, wentc8, work_stride_bytes, nfields, 8 * (size_t)nwin, 0xFF)
             || dec_fill(st, rowhead, work_stride_bytes, nfields, 4 * ntyc, 0)) return -1;      /* (the row walk marks the rows it steps from) */
         const size_t ws2b = work_stride_bytes / 2;
+        if (all_min) { if (dec_fill(st, dst, work_stride_bytes, nfields, 4 * DSC_WORDS, 0)) return -1; }      /* (no merged-exit form: nothing resolved yet) */
+        else
         hipLaunchKernelGGL(k_dsc_init, dim3(nfields), dim3(64), 0, st, d_z, z_stride_words, z_words, ni, nj, dst, ws4, wentc, ws4, nwin, plain,
                            /* a plane of c_armn_compress32 goes straight to the composed forms below (the parallel form's kernels then see FAIL and
                             * leave at once): its mantissa tiles (~185 bits) do not merge within eight windows, the attempt cost ~1 ms per plane */
                            (plain && !getenv("EZHIP_DEC_NO_DMIN")) ? 0x7fffffff : getenv("EZHIP_DEC_SCAN_MIN_NTX") ? atoi(getenv("EZHIP_DEC_SCAN_MIN_NTX")) : 768);       /* (rows of 853 tiles: 0.65 against 0.65 - 1.1 ms; of 480: the form gives up and costs 0.2 ms more than it saves) */
-        if (!(plain && !getenv("EZHIP_DEC_NO_DMIN"))) {        /* (a plane: k_dsc_init has just said FAIL, the composed forms below take it) */
+        if (!(plain && !getenv("EZHIP_DEC_NO_DMIN")) && !all_min) {        /* (a plane: k_dsc_init has just said FAIL, the composed forms below take it) */
         hipLaunchKernelGGL(k_dsc_m8, dim3((nwin + 3) / 4, nfields), dim3(256), 0, st, d_z, z_stride_words, ni, nj, dst, ws4, tab8, ws4, m8, ws2b, nwin, plain);
         hipLaunchKernelGGL(k_dsc_blocks, dim3((unsigned)((nblk + 255) / 256), nfields), dim3(256), 0, st, dst, ws4, tab8, ws4, m8, ws2b, eblk, cblk, ws4, ext_max);
         hipLaunchKernelGGL(k_dsc_scan, dim3(nfields), dim3(1024), 0, st, dst, ws4, tab, ws4, eblk, cblk, ws4, wentc, wentc8, ws4, nwin, ext_max);
@@ -1699,6 +1733,7 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
          * methods are read back (one small copy, one wait: ~20 us) and the forms nobody needs are not launched.  EZHIP_DEC_ASYNC=1: no read-back, everything queued */
         int want_whole = 1, want_ragged = 1, all_ok = 0;
         if (plain) { want_whole = (ni - 1) % 3 == 0; want_ragged = !want_whole; }
+        else if (all_min) { want_whole = ni % 5 == 0; want_ragged = !want_whole; }
         else if (!getenv("EZHIP_DEC_ASYNC") && nfields <= 256) {
             unsigned hv[2 * 256];
             hipError_t ec = nfields == 1 ? hipMemcpyAsync(hv, dst, 4, hipMemcpyDeviceToHost, st)
@@ -1770,6 +1805,15 @@ static int dec_launch(unsigned *d_out, size_t out_stride_words, const unsigned *
         }
         skip = dst;                                          /* dst[DSC_OK] of a field: 1 when its tile positions are complete */
         all_ok_known = all_ok;
+        if (all_min) {                                       /* did the composed form resolve every field?  (one small copy, one wait) else: the tables of the serial kernel, now */
+            unsigned hv[256];
+            hipError_t ec = nfields == 1 ? hipMemcpyAsync(hv, dst, 4, hipMemcpyDeviceToHost, st)
+                                         : hipMemcpy2DAsync(hv, 4, dst, work_stride_bytes, 4, (size_t)nfields, hipMemcpyDeviceToHost, st);
+            if (ec != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { fprintf(stderr, "<armn_compress> UNCOMPRESS: reading the verdicts back failed\n"); return -1; }
+            all_ok_known = 1;
+            for (int f = 0; f < nfields; f++) if (!hv[f]) all_ok_known = 0;
+            if (!all_ok_known) launch_compose();
+        }
         if (scan == 2) {                                     /* development: the state words of every field */
             unsigned h[DSC_WORDS];
             for (int f = 0; f < nfields; f++) {

@@ -1,5 +1,5 @@
 import sys, os, time
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+_R = os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."); sys.path.insert(0, os.path.join(_R, "tests")); sys.path.insert(0, _R)
 import numpy as np, torch
 import ezcases as ec, test_oracle_packers as top
 from librmn_amd import packers as pk
