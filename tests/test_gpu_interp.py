@@ -979,6 +979,31 @@ def _hash_t(t):
     return _bit_hash(t)
 
 
+def test_cfg3_full_size_pair_batch_equals_single_calls():
+    """BASELINE cfg3's grid pair at full size (Z-on-E 2560x1280 -> L 4000x2000): three wind pairs through c_ezuvint_batch_dev in one launch against three c_ezuvint_dev
+    calls, every bit of 8 M points per component (the single calls themselves are held to the reference run by test_cfg3_full_size_against_reference_run)"""
+    ni, nj, no, mo, K = 2560, 1280, 4000, 2000, 3
+    ax, ay = ec.ze_axes(ni, nj)
+    gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay); gdout = ez.ezqkdef(no, mo, "L", 9, 9, 0, 0)
+    assert ez.ezdefset(gdout, gdin) == 1
+    setopts(3, 1)
+    ez.use_stream(torch.cuda.current_stream().cuda_stream)
+    uu, vv = ec.synth_wind(ni, nj, seed=3)
+    for a in (uu, vv):
+        a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+    bu = torch.from_numpy(uu).cuda(); bv = torch.from_numpy(vv).cuda()
+    d_u = torch.stack([bu * (1.0 + 0.125 * f) for f in range(K)]).contiguous(); d_v = torch.stack([bv * (1.0 - 0.25 * f) for f in range(K)]).contiguous()
+    r_u = torch.empty((K, no * mo), dtype=torch.float32, device="cuda"); r_v = torch.empty_like(r_u)
+    for rep in range(2):                                          # (the second round: k_uvt)
+        for f in range(K):
+            assert ez.ezuvint_dev(r_u[f], r_v[f], d_u[f], d_v[f]) == 0
+    o_u = torch.full_like(r_u, float("nan")); o_v = torch.full_like(r_v, float("nan"))
+    assert ez.ezuvint_batch_dev(o_u, o_v, d_u, d_v, K) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o_u.view(torch.int32), r_u.view(torch.int32)) and torch.equal(o_v.view(torch.int32), r_v.view(torch.int32))
+    ez.gdrls(gdout); ez.gdrls(gdin)
+
+
 @pytest.mark.parametrize("polar", [1, 0])
 @pytest.mark.parametrize("npairs", [2, 5])
 def test_ezuvint_batch_equals_single_calls(npairs, polar, monkeypatch):
