@@ -3052,6 +3052,9 @@ __global__ __launch_bounds__(256) void k_uvt_pack(ezhip_pts_plan p, const float 
 #ifndef UVT_WAVES
 #define UVT_WAVES 5
 #endif
+#ifndef UVT_HB_UNROLL
+#define UVT_HB_UNROLL 4                                 /* points of a handed-back tile (the gathering path) in flight per thread */
+#endif
 #ifndef UVT_WAVES_B
 #define UVT_WAVES_B 5                                   /* the batch form (c_ezuvint_batch_dev): the pair loop needs 96 registers (at 80 it spills 160 bytes: 69 - 90 us per pair
                                                          * against 50 - 60; 4 waves: the same as 5; the next pair's window prefetched into 20 registers at 4 waves: 56 - 79) */
@@ -3122,7 +3125,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? UVT
 #pragma unroll 1
         for (int f = 0; f < npairs; f++) {
             const size_t oi = BATCH ? (size_t)f * p.pair_in_stride : 0, oo = BATCH ? (size_t)f * p.pair_out_stride : 0;
-#pragma unroll 1
+#pragma unroll UVT_HB_UNROLL
             for (int k = 0; k < PPT; k++) {
                 const unsigned cy = cy0 + (unsigned)(G::RSTEP * k);
                 if (okx && cy < (unsigned)p.tile_nj) pts2_point<NW ? PK_IRGD3_NW : PK_IRGD3_W, NW>(p, zout1 + oo, zout2 + oo, zin1 + oi, zin2 + oi, xs, ys, (int)(cy * (unsigned)p.tile_ni + cx), nullptr, nullptr);
@@ -3292,6 +3295,9 @@ __global__ __launch_bounds__(256) void k_st_pack(ezhip_pts_plan p, const float *
         streams[((size_t)b * G::PPT + k) * 256 + t] = o;
     }
 }
+#ifndef ST_HB_UNROLL
+#define ST_HB_UNROLL 1                                  /* points of a handed-back tile in flight per thread (k_st) */
+#endif
 #ifndef ST_WAVES
 #define ST_WAVES 7
 #endif
@@ -3358,7 +3364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? STB
     if (tb.z <= 0) {           /* handed back (the seam, a window beyond the cap) or without a normal point: the gathering path, point by point */
 #pragma unroll 1
         for (int f = 0; f < (BATCH ? nfields : 1); f++) {
-#pragma unroll 1
+#pragma unroll ST_HB_UNROLL
             for (int k = 0; k < PPT; k++) {
                 const unsigned cy = cy0 + (unsigned)(G::RSTEP * k);
                 if (okx && cy < (unsigned)p.tile_nj) {
