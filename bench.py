@@ -54,9 +54,8 @@ def cpu_baseline(sample_fields=4):
             for _ in range(sample_fields):
                 L.c_ezsint(fptr(zout), fptr(zin))
             dt = (time.perf_counter() - t0) / sample_fields
-            return {"value": NPTS_OUT / dt / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "reference",
-                    "sample": f"{sample_fields} fields cfg2 steady-state c_ezsint ({dt:.3f} s/field), "
-                              f"first call incl. locate {first:.2f} s, oracle/_ref/libezref.so"}
+            return {"value": NPTS_OUT / dt / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "reference", "s_per_field": dt, "first_call_s": first,
+                    "sample": f"{sample_fields} fields cfg2 steady-state c_ezsint, oracle/_ref/libezref.so"}
     except Exception as e:   # noqa: BLE001
         sys.stderr.write(f"cpu_baseline: reference build unusable ({e}); timing the oracle port\n")
     import oraclelib as ol
@@ -69,8 +68,8 @@ def cpu_baseline(sample_fields=4):
     for _ in range(sample_fields):
         O.orc_ezsint(gs, ctypes.byref(opts), ol.fptr(zout), ol.fptr(zin))
     dt = (time.perf_counter() - t0) / sample_fields
-    return {"value": NPTS_OUT / dt / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "port",
-            "sample": f"{sample_fields} fields cfg2 steady-state orc_ezsint ({dt:.3f} s/field)"}
+    return {"value": NPTS_OUT / dt / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "port", "s_per_field": dt,
+            "sample": f"{sample_fields} fields cfg2 steady-state orc_ezsint"}
 
 
 def cpu_baseline_all_cores(per_thread_fields=3):
@@ -99,7 +98,72 @@ def cpu_baseline_all_cores(per_thread_fields=3):
     dt = time.perf_counter() - t0
     nf = nthreads * per_thread_fields
     return {"value": NPTS_OUT * nf / dt / 1e6, "unit": "Mpoints/s", "cores": nthreads, "nproc": os.cpu_count(), "kind": "port",
-            "sample": f"{nf} fields cfg2 steady-state orc_ezsint on {nthreads} threads ({dt:.2f} s)"}
+            "sample": f"{nf} fields cfg2 orc_ezsint, {dt:.1f} s"}
+
+
+def pack_cpu_baseline(field, ref_interp_s):
+    """the pack half of the metric on the CPU, 1 thread, ONE 7200 x 3601 field (the timed batch's checked output, copied to the host): the oracle's
+    compact_float (compact.tmplc:143-334; 16-bit tokens in 16-bit slots) and armn_compress (c_zfstlib.c:67-203) -- the packers' sources include the
+    un-vendored App.h, so the CPU side is the oracle port, not a reference build -- and cfg5's chain (fstd98.c:1170-1172) = the reference's c_ezsint
+    (`ref_interp_s`, from cpu_baseline) + those two."""
+    import oraclelib as ol
+    O = ol.oracle()
+    n = field.size
+    buf = np.zeros(4 + n // 2 + 64, np.uint32)
+    tag = np.array([9.9e30], np.float32)
+    O.orc_compact_float.restype = ctypes.c_void_p
+    args = (ctypes.c_void_p(field.ctypes.data), ctypes.c_void_p(buf.ctypes.data), ctypes.c_void_p(buf[4:].ctypes.data), n, 16 + 64 * 16, 0, 1, 1, 0, ctypes.c_void_p(tag.ctypes.data))
+    O.orc_compact_float(*args)                          # untimed: page faults of the record
+    t0 = time.perf_counter(); O.orc_compact_float(*args); cf = time.perf_counter() - t0
+    t0 = time.perf_counter(); zl = O.orc_armn_compress(ctypes.c_void_p(buf[4:].ctypes.data), NI_D, NJ_D, 1, 16, 1); ac = time.perf_counter() - t0
+    r = {"kind": "port", "cores": 1, "sample": "1 field 7200x3601 (orc_compact_float 16-bit + orc_armn_compress)",
+         "compact_float_s_per_field": cf, "compact_float_GBps": 4.0 * n / cf / 1e9,
+         "armn_compress_s_per_field": ac, "armn_compress_GBps": 2.0 * n / ac / 1e9, "zlng_bytes": int(zl), "unit": "GB/s of input"}
+    if ref_interp_s:
+        r["cfg5_chain_s_per_field"] = ref_interp_s + cf + ac
+        r["cfg5_chain_fields_per_s"] = 1.0 / (ref_interp_s + cf + ac)
+    return r
+
+
+def start_cfg3_reference_child():
+    """the reference's c_ezuvint on cfg3 (tests/ref_child.py: oracle/_ref, 1 thread, a stack of its own for the Fortran automatic arrays) in a FRESH process,
+    started before this process imports torch or touches a GPU; collected before the warm-up starts (nothing of it runs beside a timed region)."""
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "_ref", "libezref.so")
+    if not os.path.exists(so):
+        return None
+    try:
+        return subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ref_child.py"), "cfg3_uvint", "--reps", "2"],
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT)
+    except OSError:
+        return None
+
+
+def collect_cfg3_reference_child(proc):
+    if proc is None:
+        return None
+    try:
+        out, _ = proc.communicate(timeout=180)
+        r = json.loads(out.strip().splitlines()[-1])
+        return {"value": r["points"] / r["s_per_pair"] / 1e6, "unit": "Mpoint-pairs/s", "cores": 1, "kind": "reference", "s_per_pair": r["s_per_pair"],
+                "first_call_s": r["first_s"], "sample": "%d pairs cfg3 steady-state c_ezuvint, fresh child process, oracle/_ref/libezref.so" % r["reps"]}
+    except Exception as e:   # noqa: BLE001
+        try:
+            proc.kill()
+        except Exception:   # noqa: BLE001
+            pass
+        return {"error": repr(e)[:120]}
+
+
+def slim(o, sig=5):
+    """floats to `sig` significant digits (the line has to fit the driver's 8 KB tail; every figure keeps more digits than its run-to-run spread)"""
+    if isinstance(o, float):
+        return float("%.*g" % (sig, o)) if o == o and abs(o) != float("inf") else None
+    if isinstance(o, dict):
+        return {k: slim(v, sig) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [slim(v, sig) for v in o]
+    return o
 
 
 def check_outputs(ez, torch, d_out, d_in, check_f):
@@ -129,10 +193,10 @@ def check_outputs(ez, torch, d_out, d_in, check_f):
             torch.cuda.synchronize()
             same = same and bool(torch.equal(one, d_out[f]))
         res = {"ok": bool(worst <= 1e-5 and sum_rel <= 1e-8 and same), "field": check_f,
-               "max_rel_err_vs_reference_run": worst, "max_pure_rel_err_where_abs_ge_1e-3_of_max": worst_rel, "max_abs_err_elsewhere": worst_abs, "sum_rel_diff": sum_rel, "batch_equals_single_calls_bitwise": same,
-               "against": "tests/golden/cfg2_full_golden.npz (reference c_ezsint, sampled rows/cols + sum) and c_ezsint_dev"}
+               "max_rel_err_vs_reference_run": worst, "max_pure_rel_err": worst_rel, "max_abs_err_near_zero": worst_abs, "sum_rel_diff": sum_rel, "batch_equals_single_calls_bitwise": same,
+               "against": "tests/golden/cfg2_full_golden.npz + c_ezsint_dev"}
     except Exception as e:   # noqa: BLE001
-        res["error"] = repr(e)
+        res["error"] = repr(e)[:200]
     return res
 
 
@@ -158,20 +222,15 @@ profile_traffic = profile_value
 
 def roofline_cfg5(pipe_us, zl_mean):
     """the cfg5 pipeline is bound by instruction ISSUE, not by bytes.  Its VALU wave-instructions per field come from the newest SQ-counter profile under profiles/
-    (labelled; never a literal in this file); without one `achieved` and `frac` are omitted."""
+    (labelled; never a literal in this file); without one `achieved` and `frac` are omitted.  peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction
+    (MI355X_MICROARCH.md: SIMD-32, two or more waves); peak_one_wave = the same at the 4.7 cycles one wave's stream alone sustains (tools/irate.hip).  DESIGN.md 5."""
     v = profile_value("cfg5_valu_wave_instructions_per_field")
-    peak = 1024 * 2.4 / 2.0                      # the guide: a wave64 VALU instruction takes 2 cycles on a SIMD-32 once two or more waves feed it
-    r = {"bound": "issue", "peak": peak, "unit": "G VALU wave-instructions/s",
-         "peak_one_wave_per_simd": 1024 * 2.4 / 4.7,
-         "peak_note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md constants table: SIMD-32, two or more waves); one wave's stream alone "
-                      "sustains 4 cycles (guide) / 4.7 (tools/irate.hip on this path's instruction mix) = peak_one_wave_per_simd, the figure rounds 3 - 4 measured against",
-         "hbm_frac_of_algorithmic_bytes": (4.0 * NI_S * NJ_S + zl_mean) / (pipe_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-         "kernel": "k_bb_* (extrema from bounds) + k_sepx<3, 16, 3> (tokens) + k_armn_enc1 (one-pass encoder)"}
+    peak = 1024 * 2.4 / 2.0
+    r = {"bound": "issue", "peak": peak, "unit": "G VALU wave-instr/s", "peak_one_wave": 1024 * 2.4 / 4.7,
+         "kernel": "k_bb_* + k_sepx<3,16,3> + k_armn_enc1"}
     if v:
-        r.update({"achieved": v[0] / (pipe_us * 1e-6) / 1e9, "frac": v[0] / (pipe_us * 1e-6) / 1e9 / peak, "frac_of_one_wave_rate": v[0] / (pipe_us * 1e-6) / 1e9 / (1024 * 2.4 / 4.7),
-                  "valu_wave_instructions_per_field": v[0], "valu_source": v[1] + " (SQ_INSTS_VALU of the pipeline's kernels, not this run)"})
-    else:
-        r["note"] = "no SQ-counter profile of this code under profiles/: achieved / frac omitted"
+        r.update({"achieved": v[0] / (pipe_us * 1e-6) / 1e9, "frac": v[0] / (pipe_us * 1e-6) / 1e9 / peak,
+                  "valu_wave_instr_per_field": v[0], "valu_source": v[1]})
     return r
 
 
@@ -196,8 +255,7 @@ def extras(ez, torch, stream, d_out, d_in):
                 e1.record(stream); torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) * 1e3 / reps)
             return sorted(ts)[len(ts) // 2]
-        ex["single_field_launch_us"] = ev_time(lambda: ez.ezsint_dev(d_out[0], d_in[0]), 40)
-        ex["single_field_launch_note"] = "median of 5 bursts of 40 back-to-back c_ezsint_dev calls, HIP events"
+        ex["single_field_launch_us"] = ev_time(lambda: ez.ezsint_dev(d_out[0], d_in[0]), 40)      # median of 5 bursts of 40 back-to-back c_ezsint_dev calls, HIP events
         # the same calls with the CALLER alternating two streams (ezhip_use_stream between calls; separate output arrays): consecutive launches of one stream cannot
         # overlap, those of two streams do -- the fill of one launch runs beside the drain of the other.  Nothing in the library changes: the drop-in call, one field each
         try:
@@ -214,8 +272,7 @@ def extras(ez, torch, stream, d_out, d_in):
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 burst(80)
                 torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 80 * 1e6)
-            ex["single_field_two_streams_us"] = sorted(ts)[2]
-            ex["single_field_two_streams_note"] = "median of 5 bursts of 80 c_ezsint_dev calls alternating over two caller streams, wall clock incl. the launch calls"
+            ex["single_field_two_streams_us"] = sorted(ts)[2]       # median of 5 bursts of 80 calls alternating over two caller streams, wall clock incl. the launch calls
         finally:
             ez.use_stream(stream.cuda_stream)
         zin_h = np.ascontiguousarray(d_in[0].cpu().numpy()); zout_h = np.zeros(NPTS_OUT, np.float32)     # pageable, touched
@@ -236,6 +293,7 @@ def extras(ez, torch, stream, d_out, d_in):
                 cez(zout_h.ctypes.data, zin_h.ctypes.data)
             ex["host_pointer_abi_registered_ms_per_field"] = (time.perf_counter() - t0) / 3 * 1e3
             _L.ezhip_unregister_host_buffer(zin_h.ctypes.data); _L.ezhip_unregister_host_buffer(zout_h.ctypes.data)
+        # ---- BASELINE configs[2]: c_ezuvint, Z-on-E 2560x1280 (rotated global) -> L 4000x2000, bicubic, polar_correction=yes
         ni, nj, no, mo = 2560, 1280, 4000, 2000
         ax, ay = ec.ze_axes(ni, nj)
         g_in = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay); g_out = ez.ezqkdef(no, mo, "L", 9, 9, 0, 0)
@@ -245,27 +303,22 @@ def extras(ez, torch, stream, d_out, d_in):
             a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
         d_u = torch.from_numpy(uu).cuda(); d_v = torch.from_numpy(vv).cuda()
         o_u = torch.empty(no * mo, dtype=torch.float32, device="cuda"); o_v = torch.empty_like(o_u)
-        # the set's FIRST call: locate of the 8 M target points in the rotated source (host threads: bit-exact with the reference's libm, uploaded once), Newton
+        # the set's FIRST call: locate of the 8 M target points in the rotated source (k_locate, bit-equal to the C library's REAL trig), Newton
         # tables, the wind matrix of the grid pair, the special points' list, the tile table and the tile-ordered stream copy
         torch.cuda.synchronize(); t0 = time.perf_counter()
         assert ez.ezuvint_dev(o_u, o_v, d_u, d_v) >= 0
-        torch.cuda.synchronize(); ex["cfg3_first_call_ms"] = (time.perf_counter() - t0) * 1e3
+        torch.cuda.synchronize(); first3 = (time.perf_counter() - t0) * 1e3
         t0 = time.perf_counter()
         assert ez.ezuvint_dev(o_u, o_v, d_u, d_v) >= 0
-        torch.cuda.synchronize(); ex["cfg3_second_call_ms"] = (time.perf_counter() - t0) * 1e3      # (builds the staged-tile caches behind it)
+        torch.cuda.synchronize(); second3 = (time.perf_counter() - t0) * 1e3      # (builds the staged-tile caches behind it)
         us = ev_time(lambda: ez.ezuvint_dev(o_u, o_v, d_u, d_v), 20)
         algo3 = 2 * 4 * ni * nj + 2 * 4 * no * mo                      # both source components in, both target components out
         t3 = profile_traffic("cfg3_traffic_MB_per_pair")
-        ex["cfg3_uvint"] = {"workload": "c_ezuvint_dev bicubic, Z-on-E 2560x1280 -> L 4000x2000, polar_correction=yes",
-                            "us_per_pair": us, "Mpoint_pairs_per_s": no * mo / us,
-                            "algorithmic_GBps": algo3 / us / 1e3,
+        ex["cfg3_uvint"] = {"workload": "c_ezuvint_dev bicubic Z-on-E 2560x1280 -> L 4000x2000", "dtype": "f32 + f64 second pass",
+                            "us_per_pair": us, "Mpoint_pairs_per_s": no * mo / us, "first_call_ms": first3, "second_call_ms": second3,
                             "roofline": {"bound": "hbm", "achieved": algo3 / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": algo3 / us / 1e3 / HBM_PEAK_GBPS,
                                          "traffic": t3[0] * 1e6 if t3 else None, "traffic_source": t3[1] if t3 else None,
-                                         "kernel": "k_uvt<32, 32> (stencil windows staged in LDS; the set's few special points ride in its polar-wind producer blocks; the first call of a grid set: k_pts2_irgd3w)", "algorithmic_bytes_per_launch": algo3,
-                                         "note": "x, y of the rotated source and the per-point wind rotation (one packed word) -- 12 bytes per target point, read from the set's tile-ordered copy -- and the "
-                                                 "64 MB of results stream next to the staged source windows; REAL (packed fp32) evaluation with a REAL*8 second pass where the wind is small under a strong "
-                                                 "stencil; no unit saturated (VALU 40 %, LDS 47 % of the kernel: SQ counters, profiles/r05_experiments.txt): the vector L1 returns in order, a block's round "
-                                                 "trips bound it; the pipelined form (persistent blocks, LDS-DMA double buffering) was built and measured slower"}}
+                                         "kernel": "k_uvt<32,32>", "algorithmic_bytes_per_launch": algo3}}
         # several pairs of the same grid set at once (wind levels): c_ezuvint_batch_dev reads x, y and the rotation of a point once per batch (12 of a pair's 34 bytes
         # per point) -- one launch of k_uvt's batch form, the special points' kernel once with a pair index; results equal to single calls bit for bit
         KB = 8
@@ -278,28 +331,22 @@ def extras(ez, torch, stream, d_out, d_in):
             assert ez.ezuvint_dev(r_u, r_v, d_ub[f], d_vb[f]) >= 0
             torch.cuda.synchronize()
             same_b = same_b and bool(torch.equal(r_u, o_ub[f]) and torch.equal(r_v, o_vb[f]))
-        ex["cfg3_uvint_batch"] = {"workload": "c_ezuvint_batch_dev, %d pairs per call, bicubic, Z-on-E 2560x1280 -> L 4000x2000, polar_correction=yes" % KB,
-                                  "us_per_pair": usb, "Mpoint_pairs_per_s": no * mo / usb, "algorithmic_GBps": algo3 / usb / 1e3, "frac_of_hbm_peak": algo3 / usb / 1e3 / HBM_PEAK_GBPS,
-                                  "equal_to_single_calls_bitwise": same_b, "single_call_us_per_pair": us,
-                                  "traffic": (profile_value("cfg3_batch_traffic_MB_per_pair") or (None, None))[0], "traffic_unit": "MB per pair", "traffic_source": (profile_value("cfg3_batch_traffic_MB_per_pair") or (None, None))[1],
-                                  "kernel": "k_uvt<32, 32, false, true> (the pairs of the batch one after the other per tile; two producer blocks per pair, which also take the pair's special points)"}
+        tb = profile_value("cfg3_batch_traffic_MB_per_pair")
+        ex["cfg3_uvint_batch"] = {"workload": "c_ezuvint_batch_dev, %d pairs per call, same grids" % KB, "dtype": "f32 + f64 second pass",
+                                  "us_per_pair": usb, "Mpoint_pairs_per_s": no * mo / usb, "frac_of_hbm_peak": algo3 / usb / 1e3 / HBM_PEAK_GBPS,
+                                  "equal_to_single_calls_bitwise": same_b, "traffic_MB_per_pair": tb[0] if tb else None, "traffic_source": tb[1] if tb else None,
+                                  "kernel": "k_uvt<32,32,false,true>"}
         del d_ub, d_vb, o_ub, o_vb, r_u, r_v
         # the scalar twin on the same grid pair: c_ezsint from the rotated source (k_st: stencil windows staged in LDS, the literal REAL*8 form of the reference)
         us1 = ev_time(lambda: ez.ezsint_dev(o_u, d_u), 20)
         algo1 = 4 * ni * nj + 4 * no * mo
         t1 = profile_value("cfg3_sint_traffic_MB_per_field"); v1 = profile_value("cfg3_sint_valu_wave_instructions_per_field")
         valu_peak = 1024 * 2.4 / 2.0                # G wave64 VALU instructions / s: 2 cycles each on a SIMD-32 with two or more waves (MI355X_MICROARCH.md, constants table)
-        ex["cfg3_sint"] = {"workload": "c_ezsint_dev bicubic, Z-on-E 2560x1280 -> L 4000x2000, polar_correction=yes", "us_per_field": us1, "Mpoints_per_s": no * mo / us1,
-                           "roofline": {"bound": "valu", "achieved": (v1[0] / us1 / 1e3) if v1 else None, "peak": valu_peak, "unit": "G VALU wave-instructions/s",
-                                        "frac": (v1[0] / us1 / 1e3 / valu_peak) if v1 else None,
-                                        "valu_wave_instructions_per_field": v1[0] if v1 else None, "valu_source": v1[1] if v1 else None,
-                                        "peak_one_wave_per_simd": 1024 * 2.4 / 4.7, "peak_note": "peak: the guide's 2 cycles per wave64 VALU instruction (SIMD-32, two or more waves); one wave's stream alone sustains 4 (guide) / 4.7 (tools/irate.hip, REAL*8 mix)",
-                                        "hbm_achieved_GBps": algo1 / us1 / 1e3, "hbm_frac_of_algorithmic_bytes": algo1 / us1 / 1e3 / HBM_PEAK_GBPS,
-                                        "traffic": t1[0] * 1e6 if t1 else None, "traffic_source": t1[1] if t1 else None,
-                                        "kernel": "k_st<32, 32> (the first call of a grid set: k_pts<8>) + k_pts_special behind it", "algorithmic_bytes_per_launch": algo1,
-                                        "note": "195 VALU instructions per point in the reference's literal REAL*8 statement-function form (bit-identical to the gathering kernel; hash-equal to the "
-                                                "reference over 8 M points without polar correction): SQ_ACTIVE_INST_VALU ~70 % of the SIMDs' time at the 4-cycle single-stream rate, the rest is the "
-                                                "blocks' dependent round trips; x, y (8 bytes per target point) stream next to the staged windows"}}
+        ex["cfg3_sint"] = {"workload": "c_ezsint_dev bicubic, same grids", "dtype": "f64", "us_per_field": us1, "Mpoints_per_s": no * mo / us1,
+                           "roofline": {"bound": "valu", "achieved": (v1[0] / us1 / 1e3) if v1 else None, "peak": valu_peak, "unit": "G VALU wave-instr/s",
+                                        "frac": (v1[0] / us1 / 1e3 / valu_peak) if v1 else None, "valu_source": v1[1] if v1 else None,
+                                        "hbm_frac_of_algorithmic_bytes": algo1 / us1 / 1e3 / HBM_PEAK_GBPS,
+                                        "traffic": t1[0] * 1e6 if t1 else None, "kernel": "k_st<32,32>"}}
         del d_u, d_v, o_u, o_v
         # the step after the horizontal one: vertical interpolation of device-resident profiles, search + linear + lapse-rate in one pass
         from librmn_amd import interpv as V
@@ -309,9 +356,8 @@ def extras(ez, torch, stream, d_out, d_in):
         vld = (torch.linspace(1.5, ns - 0.5, nd, device="cuda")[:, None] + torch.zeros((1, ncol), device="cuda")).contiguous()
         ss = torch.sin(vls * 0.1); sd = torch.empty((nd, ncol), device="cuda")
         us = ev_time(lambda: V.column_dev(V.LINEAR, V.X_LAPSERATE, ncol, vls, ss, ss, None, vld, sd, sd, True, True, 0.1, 0.1), 20)
-        ex["interpv_column"] = {"workload": f"Interp1D_FindPos + Interp1D_Linear + Extrap1D_LapseRate fused, REAL, {ncol} columns, {ns} -> {nd} levels (levels varying smoothly along the columns)",
-                                "us": us, "Mvalues_per_s": ncol * nd / us, "algorithmic_GBps": 4.0 * ncol * (2 * ns + 2 * nd) / us / 1e3,
-                                "frac_of_hbm_peak": 4.0 * ncol * (2 * ns + 2 * nd) / us / 1e3 / HBM_PEAK_GBPS}
+        ex["interpv_column"] = {"workload": f"FindPos + Linear + LapseRate fused, {ncol} columns, {ns} -> {nd} levels", "dtype": "f32",
+                                "us": us, "frac_of_hbm_peak": 4.0 * ncol * (2 * ns + 2 * nd) / us / 1e3 / HBM_PEAK_GBPS}
         del vls, vld, ss, sd
         # the read side: armn_compress UNCOMPRESS of cfg5 records in HBM -- one stream alone, and 16 / 32 decoded concurrently
         from librmn_amd import packers as pk
@@ -330,90 +376,65 @@ def extras(ez, torch, stream, d_out, d_in):
             return dt_ * 1e3
         one_ms, batch16_ms, batch_ms = dec(1), dec(16), dec(Fd)
         zmean = float(np.mean([z for z in zl_ if z > 0]))
-        ex["armn_uncompress"] = {"workload": "armn_compress UNCOMPRESS of 7200 x 3601 16-bit records in HBM (ratio %.2f)" % (zmean / (2.0 * n)),
+        ex["armn_uncompress"] = {"workload": "UNCOMPRESS of 7200x3601 16-bit records in HBM, ratio %.2f" % (zmean / (2.0 * n)), "dtype": "u16",
                                  "single_stream_ms": one_ms, "batch_of_16_ms_per_field": batch16_ms / 16, "batch_of_32_ms_per_field": batch_ms / Fd,
-                                 "note": "the chain of tile headers between row ends is resolved in parallel since the end of round 3 (canonical chain from merged eight-window blocks, the row ends as a recurrence on the tile-index shift: DESIGN_LOG.md 9 item 4); the serial chain kernel (one CU per stream) only for streams that form gives up on",
-                                 "single_stream_GBps": (zmean + 2.0 * n) / (one_ms * 1e-3) / 1e9, "single_stream_frac_of_hbm_peak": (zmean + 2.0 * n) / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                 "batch_GBps": (zmean + 2.0 * n) * Fd / (batch_ms * 1e-3) / 1e9, "batch_frac_of_hbm_peak": (zmean + 2.0 * n) * Fd / (batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-        # the same field as a MINIMUM stream (c_armn_compress_setlevel(FAST)): since round 4 its chain of tile headers is resolved by composition of the windows' maps
-        # (k_dmin_*: rows of whole 5 x 5 tiles) instead of the serial chain kernel
+                                 "single_stream_frac_of_hbm_peak": (zmean + 2.0 * n) / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                 "batch_frac_of_hbm_peak": (zmean + 2.0 * n) * Fd / (batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        # the same field as a MINIMUM stream (c_armn_compress_setlevel(FAST)): its chain of tile headers is resolved by composition of the windows' maps
+        # (k_dmin_*: rows of whole 5 x 5 tiles); ... and with rows that end on a narrower tile (the same tokens read as a 7201 x 3600 field): the composed ragged form
         try:
             pk.armn_setlevel(0)
             d_zm = torch.zeros(n // 2 + 64, dtype=torch.int32, device="cuda")
-            zlm = pk.armn_compress_dev(d_zm, toks[0], NI_D, NJ_D, 16)
-            pk.armn_setlevel(1)
-            if zlm > 0:
-                zwm = (zlm - 1) // 4 + 1
-                tk = torch.zeros(1 + n // 2, dtype=torch.int32, device="cuda")
-                best = 1e9
-                for _ in range(4):
-                    torch.cuda.synchronize(); t0_ = time.perf_counter()
-                    rcm = pk.armn_uncompress_dev(tk, d_zm, zwm, NI_D, NJ_D, 16)
-                    torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0_)
-                ex["armn_uncompress_minimum"] = {"workload": "armn_compress UNCOMPRESS of a 7200 x 3601 MINIMUM stream (level FAST, ratio %.2f) in HBM" % (zlm / (2.0 * n)),
-                                                 "single_stream_ms": best * 1e3, "tokens_equal": bool(rcm == 2 * n and torch.equal(tk[:n // 2], toks[0][:n // 2])),
-                                                 "note": "the serial chain kernel took 16 ms (rounds 1 - 3)"}
-            # ... and with rows that end on a narrower tile (the same tokens read as a 7201 x 3600 field): the composed ragged form, rows whose stretch outlasts them
-            # walked explicitly by the row recurrence (round 5); the serial chain kernel before
-            pk.armn_setlevel(0)
-            nir, njr = NI_D + 1, NJ_D - 1
-            nr = nir * njr
-            zlr = pk.armn_compress_dev(d_zm, toks[0], nir, njr, 16)
-            pk.armn_setlevel(1)
-            if zlr > 0:
-                zwr = (zlr - 1) // 4 + 1
-                tk = torch.zeros(1 + nr // 2, dtype=torch.int32, device="cuda")
-                best = 1e9
-                for _ in range(4):
-                    torch.cuda.synchronize(); t0_ = time.perf_counter()
-                    rcr = pk.armn_uncompress_dev(tk, d_zm, zwr, nir, njr, 16)
-                    torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0_)
-                ex["armn_uncompress_minimum_ragged"] = {"workload": "armn_compress UNCOMPRESS of a 7201 x 3600 MINIMUM stream (level FAST, ratio %.2f) in HBM" % (zlr / (2.0 * nr)),
-                                                        "single_stream_ms": best * 1e3, "tokens_equal": bool(rcr == 2 * nr and torch.equal(tk[:nr // 2], toks[0][:nr // 2])),
-                                                        "note": "the serial chain kernel took 17 ms (rounds 1 - 4)"}
+            for key, nim, njm in (("minimum_ms", NI_D, NJ_D), ("minimum_ragged_ms", NI_D + 1, NJ_D - 1)):
+                pk.armn_setlevel(0)
+                nm_ = nim * njm
+                zlm = pk.armn_compress_dev(d_zm, toks[0], nim, njm, 16)
+                pk.armn_setlevel(1)
+                if zlm > 0:
+                    zwm = (zlm - 1) // 4 + 1
+                    tk = torch.zeros(1 + nm_ // 2, dtype=torch.int32, device="cuda")
+                    best = 1e9
+                    for _ in range(4):
+                        torch.cuda.synchronize(); t0_ = time.perf_counter()
+                        rcm = pk.armn_uncompress_dev(tk, d_zm, zwm, nim, njm, 16)
+                        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0_)
+                    ex["armn_uncompress"][key] = best * 1e3
+                    ex["armn_uncompress"][key.replace("_ms", "_tokens_equal")] = bool(rcm == 2 * nm_ and torch.equal(tk[:nm_ // 2], toks[0][:nm_ // 2]))
         finally:
             pk.armn_setlevel(1)
         del recs, toks
-        # the IEEE-32 compressor's read side (datyp 133): c_armn_uncompress32 through the API, host stream in, host field out.  The sign runs are decoded on the
-        # device (k_rle_*); the two planes' tile chains too when a row ends on a whole tile ((ni - 1) % 3 == 0: k_dmin_*), on two host threads otherwise
+        # the IEEE-32 compressor's read side (datyp 133): c_armn_uncompress32 through its three entries (the reference's signature without a length, _lng with the
+        # record's length, _zdev record and field in HBM); 7200 columns = ragged rows, 7201 = rows of whole tiles
         import ezcases as _ec
         for key, ni32 in (("armn_uncompress32", NI_D), ("armn_uncompress32_whole_tile_rows", NI_D + 1)):
             f32 = _ec.synth_field(ni32, NJ_D, seed=5); n32 = ni32 * NJ_D
             zl32, z32 = pk.armn_compress32(f32, ni32, NJ_D, 32)
             if zl32 <= 0: continue
-            best = bestl = bestf = 1e9
+            best = bestl = 1e9
             out_a = np.zeros(n32, np.float32); out_b = np.zeros(n32, np.float32)          # the caller's field buffers, kept across calls (touched: no first-touch page faults in the clock)
             out_a.fill(1.0); out_b.fill(1.0)
             for _ in range(3):
                 t0_ = time.perf_counter(); rc32, back32 = pk.armn_uncompress32(z32, ni32, NJ_D, 32, out=out_a); best = min(best, time.perf_counter() - t0_)
                 t0_ = time.perf_counter(); rcl, backl = pk.armn_uncompress32_lng(z32, 4 * ((zl32 + 3) // 4), ni32, NJ_D, 32, out=out_b); bestl = min(bestl, time.perf_counter() - t0_)
-                t0_ = time.perf_counter(); rcf, backf = pk.armn_uncompress32(z32, ni32, NJ_D, 32); bestf = min(bestf, time.perf_counter() - t0_)      # into a fresh array each call
-                del backf
-            ex[key] = {"workload": "c_armn_uncompress32 of a %d x %d REAL field (32 bits kept, ratio %.2f), host arrays" % (ni32, NJ_D, zl32 / (4.0 * n32)),
-                       "ms_per_field": best * 1e3, "ms_per_field_into_a_fresh_array": bestf * 1e3, "bit_identical": bool(rc32 == n32 and np.array_equal(back32.view(np.uint32), f32.view(np.uint32))),
-                       "GBps": (zl32 + 4.0 * n32) / best / 1e9, "frac_of_hbm_peak": (zl32 + 4.0 * n32) / best / 1e9 / HBM_PEAK_GBPS,
-                       "length_given_ms": bestl * 1e3, "length_given_bit_identical": bool(rcl == n32 and np.array_equal(backl.view(np.uint32), f32.view(np.uint32))),
-                       "note": "ms_per_field: c_armn_uncompress32 as the reference declares it (no length: the record's end is found by walking the chains on two host "
-                               "threads); length_given_ms: c_armn_uncompress32_lng (the FST record's word count): sign runs and tile chains on the device -- " +
-                               ("rows end on whole tiles: composition of the windows' maps" if (ni32 - 1) % 3 == 0 else
-                                "ragged rows: composition + row recurrence; a plane that form leaves open (long runs of empty exponent tiles) is walked on the host") +
-                               "; host arrays: stream up, field down over PCIe in both"}
+            ex[key] = {"columns": ni32, "dtype": "u32 planes of f32", "ratio": zl32 / (4.0 * n32), "host_arrays_no_length_ms": best * 1e3, "host_arrays_length_given_ms": bestl * 1e3,
+                       "bit_identical": bool(rc32 == n32 and np.array_equal(back32.view(np.uint32), f32.view(np.uint32)) and rcl == n32 and np.array_equal(backl.view(np.uint32), f32.view(np.uint32)))}
             # record and field both in HBM (c_armn_compress32_dev -> c_armn_uncompress32_zdev)
             d_f32 = torch.from_numpy(f32).cuda(); d_z32 = torch.zeros(n32 + 64, dtype=torch.int32, device="cuda"); d_b32 = torch.empty(n32, dtype=torch.float32, device="cuda")
-            torch.cuda.synchronize(); t0_ = time.perf_counter()
+            pk.armn_compress32_dev(d_z32, d_f32, ni32, NJ_D, 32); torch.cuda.synchronize()
+            t0_ = time.perf_counter()
             zl32_dev = pk.armn_compress32_dev(d_z32, d_f32, ni32, NJ_D, 32)
-            torch.cuda.synchronize(); ex[key]["compress32_field_and_record_in_hbm_ms"] = (time.perf_counter() - t0_) * 1e3
+            torch.cuda.synchronize(); ex[key]["compress32_in_hbm_ms"] = (time.perf_counter() - t0_) * 1e3
             if zl32_dev == zl32:
                 bestd = 1e9
                 for _ in range(4):
                     torch.cuda.synchronize(); t0_ = time.perf_counter()
                     rcd = pk.armn_uncompress32_zdev(d_b32, d_z32, 4 * ((zl32 + 3) // 4), ni32, NJ_D, 32)
                     torch.cuda.synchronize(); bestd = min(bestd, time.perf_counter() - t0_)
-                ex[key]["record_and_field_in_hbm_ms"] = bestd * 1e3
-                ex[key]["record_and_field_in_hbm_bit_identical"] = bool(rcd == n32 and torch.equal(d_b32.view(torch.int32), d_f32.view(torch.int32)))
+                ex[key]["in_hbm_ms"] = bestd * 1e3
+                ex[key]["in_hbm_bit_identical"] = bool(rcd == n32 and torch.equal(d_b32.view(torch.int32), d_f32.view(torch.int32)))
             del d_f32, d_z32, d_b32
     except Exception as e:   # noqa: BLE001
-        ex["error"] = repr(e)
+        ex["error"] = repr(e)[:300]
     return ex
 
 
@@ -589,7 +610,7 @@ def host_fed(ez, torch, stream, d_in, d_out, F, steps, dist, sh):
     elapsed = sh.max_over_ranks(elapsed, device="cuda")
     world = dist.get_world_size() if dist else 1
     up_bytes = 4.0 * nin * F
-    return {"workload": f"the headline step with its {F} source fields uploaded from page-locked host memory inside the timed region (double-buffered, copy stream); outputs stay in HBM",
+    return {"workload": f"the headline step, its {F} sources uploaded from page-locked host memory inside the timed region",
             "steps": steps, "ms_per_step": elapsed * 1e3 / steps, "value": float(NPTS_OUT) * F * steps * world / elapsed / 1e6, "unit": "Mpoints/s",
             "upload_GBps_per_gpu": up_bytes * steps / elapsed / 1e9, "upload_bytes_per_step_per_gpu": up_bytes}
 
@@ -623,6 +644,8 @@ def main():
     if args.stub_step:
         return stub_rank(args, world, rank)
 
+    # the reference's c_ezuvint on cfg3 as a child of its own, started BEFORE anything here touches a GPU (extras.cfg3_uvint.cpu_baseline)
+    cfg3_child = start_cfg3_reference_child() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (0 GPU(s) visible): the MI355X hot path has no CPU fallback")
@@ -673,6 +696,7 @@ def main():
         rc = ez.ezsint_batch_dev(d_out, d_in, F)
         assert rc == 0, rc
 
+    cfg3_cpu = collect_cfg3_reference_child(cfg3_child)      # it has been running beside the imports and the set-up; nothing of it is left when the warm-up starts
     # the launch durations settle only after ~40 launches from idle (see the defaults above): when the caller asks for
     # a shorter warm-up, the difference runs first as untimed initialisation (reported as config.prewarm_steps)
     prewarm = max(0, 40 - args.warmup)
@@ -767,8 +791,12 @@ def main():
     tr = profile_traffic("traffic_MB_per_field")
     traffic = tr[0] * 1e6 * F if tr else None
     tr5 = profile_traffic("cfg5_fused_pipeline_total_MB_per_field")
+    out = None
     if rank == 0:
         total_pts = float(NPTS_OUT) * F * args.steps * world
+        cf_tr = profile_value("compact_float_traffic_bytes_per_value")
+        fused_cost = fused_us - ev_ms * 1e3 / (args.steps * F)
+        # key order: contract fields, roofline, cpu_baseline, pack, check, then the secondary objects -- prose lives in DESIGN.md section 5, not in the line
         out = {
             "metric": "interp Mpoints/s + pack GB/s, 4400x2200->7200x3601 bicubic, 1/2/4/8 GPU",
             "value": total_pts / elapsed / 1e6,
@@ -782,66 +810,54 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "checked": bool(checked and checked.get("ok")),
-            "check": checked,
             "config": {"workload": "cfg2/cfg4: c_ezsint bicubic G 4400x2200 -> L 7200x3601, polar_correction=yes, "
                                    f"{F} device-resident fields per step per GPU (sharded by record, no collective)",
                        "fields_per_step_per_gpu": F, "points_per_field": NPTS_OUT, "prewarm_steps": prewarm, "feed": args.feed,
                        "world_size": world, "launched_by": os.environ.get("BENCH_LAUNCHED_BY", "external launcher" if env_world else "single process"),
                        "develop_build": ez.develop_build(), "env_overrides": sorted(k for k in os.environ if k.startswith(("EZHIP_", "INTERPV_HIP_")))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": (tr[1] + " (PMC passes of the same command, not this run)") if tr else None,
-                         "kernel": "k_sepx<3, 16>", "avg_launch_us": kern_us, "fields_per_launch": F,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tr[1] if tr else None,
+                         "kernel": "k_sepx<3,16>", "avg_launch_us": kern_us, "fields_per_launch": F,
                          "us_per_field": kern_us / F, "algorithmic_bytes_per_launch": F * ALGO_BYTES},
-            "pack": {"compact_float_16bit_GBps": 4.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9, "us_per_field": pack_us,
-                     "algorithmic_GBps_6B_per_elem": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9,
-                     "frac_of_hbm_peak": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                     "fused_interp_pack16_us_per_field": fused_us,
-                     "fused_pack16_cost_us_per_field": fused_us - ev_ms * 1e3 / (args.steps * F),
-                     "fused_compact_float_16bit_GBps": 4.0 * NPTS_OUT / (max(fused_us - ev_ms * 1e3 / (args.steps * F), 1e-3) * 1e-6) / 1e9,
+            "cpu_baseline": None,
+            "pack": {"unit": "GB/s of float input", "dtype": "f32 -> u16 tokens (f64 quantisation)",
+                     "compact_float": {"us_per_field": pack_us, "GBps": 4.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9,
+                                       "fused_into_interp_cost_us_per_field": fused_cost,
+                                       "roofline": {"bound": "hbm", "achieved": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                                    "frac": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                                    "traffic": cf_tr[0] * NPTS_OUT if cf_tr else None, "traffic_source": cf_tr[1] if cf_tr else None,
+                                                    "kernel": "k_stats + k_cf_header + k_cf_pack16", "algorithmic_bytes_per_launch": 6.0 * NPTS_OUT}},
                      "pack16_plus_armn_compress_us_per_field": comp_us,
-                     "cfg5_pipeline_us_per_field": pipe_us,       # fused: interp x2 (min/max, tokens) + one-pass armn_compress, batch of F, one sync (host wall clock)
-                     "cfg5_pipeline_fields_per_s": 1e6 / pipe_us,
-                     "cfg5_pipeline_unfused_us_per_field": pipe_unfused_us,     # interp + pack16 + armn_compress as separate steps
-                     "cfg5_pipeline_records_equal_unfused": pipe_checked,
-                     # read the source once + write zlng
-                     "cfg5_algorithmic_GBps": (4.0 * NI_S * NJ_S + zl_mean) / (pipe_us * 1e-6) / 1e9,
-                     "cfg5_frac_of_hbm_peak": (4.0 * NI_S * NJ_S + zl_mean) / (pipe_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                     "cfg5_traffic_MB_per_field": tr5[0] if tr5 else None, "cfg5_traffic_source": tr5[1] if tr5 else None,
-                     "cfg5_stages": "extrema from bounds of the source windows (k_bb_*: no interpolation) + header + k_sepx tokens + one-pass armn encoder",
-                     # what bounds them.  compact_float: two passes (extrema, tokens) = 4 + 4 + 2 bytes of traffic per value for 6 algorithmic; measured against HBM.
-                     "roofline_compact_float": {"bound": "hbm", "achieved": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 6.0 * NPTS_OUT / (pack_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                                                "traffic": (profile_value("compact_float_traffic_bytes_per_value") or (10.0, None))[0] * NPTS_OUT,
-                                                "traffic_source": ((profile_value("compact_float_traffic_bytes_per_value") or (0, "profiles/r03_pmc_traffic.json"))[1] + " (two reads + one write of the field: 10 B per value; not this run)"),
-                                                "traffic_GBps": (profile_value("compact_float_traffic_bytes_per_value") or (10.0, None))[0] * NPTS_OUT / (pack_us * 1e-6) / 1e9,
-                                                "kernel": "k_stats + k_cf_header + k_cf_pack16", "algorithmic_bytes_per_launch": 6.0 * NPTS_OUT,
-                                                "note": "the traffic moves at ~93 % of the 6.29 TB/s a copy reaches; a one-launch form (two variants) ends at the same time: profiles/r04_experiments.txt"},
-                     # the cfg5 pipeline is bound by instruction ISSUE, not by bytes: its two big kernels retire ~2.0e7 VALU wave-instructions per field
-                     # (k_sepx<3,16,3>: 1659 per wave x 3604 waves; k_armn_enc1: 979 x 14 424: SQ_INSTS_VALU, profiles/r03_experiments.txt) at 4.7 clk each per SIMD
-                     "roofline_cfg5": roofline_cfg5(pipe_us, zl_mean),
-                     "zlng_bytes": int(zl[0]),
-                     "compression_ratio": float(zl[0]) / (2.0 * NPTS_OUT), "unit": "GB/s of float input"},
+                     "cfg5": {"pipeline_us_per_field": pipe_us,       # fused: extrema from bounds + interpolation straight to tokens + one-pass armn_compress, batch of F, one sync (host wall clock)
+                              "fields_per_s": 1e6 / pipe_us, "GBps": 4.0 * NPTS_OUT / (pipe_us * 1e-6) / 1e9,
+                              "unfused_us_per_field": pipe_unfused_us,     # interp + pack16 + armn_compress as separate steps
+                              "records_equal_unfused": pipe_checked, "zlng_bytes": int(zl[0]), "compression_ratio": float(zl[0]) / (2.0 * NPTS_OUT),
+                              # read the source once + write zlng
+                              "hbm_frac_of_algorithmic_bytes": (4.0 * NI_S * NJ_S + zl_mean) / (pipe_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                              "traffic_MB_per_field": tr5[0] if tr5 else None, "traffic_source": tr5[1] if tr5 else None,
+                              "roofline": roofline_cfg5(pipe_us, zl_mean)},
+                     "cpu_baseline": None},
+            "checked": bool(checked and checked.get("ok")),
+            "check": checked,
         }
         if world == 1:
-            out["extras"] = extras(ez, torch, stream, d_out, d_in)
-            out["extras"]["first_call_setup_ms"] = first_call_ms     # once per grid pair; steady-state numbers exclude it
-            out["extras"]["first_call_setup_note"] = "c_ezqkdef x 2 (%.1f ms: the Gaussian latitudes of the source) + c_ezdefset + ezhip_prepare_set (plan tables, uploads; includes the library's code object load); the HIP runtime's own lazy initialisation (~150 ms, counted here until round 5) is triggered before the clock starts" % gauss_ms
-            sf = out["extras"].get("single_field_launch_us")
-            if sf:      # north_star words its 60 % target on "a field": the lone-field launch next to the batch launch
-                out["roofline_single_field"] = {"bound": "hbm", "note": "one field per launch: the fill and drain of one launch's staging / compute / store pipeline (~4 us) is paid per field; "
-                                                        "a batch launch pays it once per batch (the headline).  The floor of the one-launch-per-field form (DESIGN_LOG.md 9)",
-                                                "achieved": ALGO_BYTES / (sf * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            ex = extras(ez, torch, stream, d_out, d_in)
+            ex["first_call_setup_ms"] = first_call_ms     # c_ezqkdef x 2 + c_ezdefset + ezhip_prepare_set, once per grid pair; steady-state numbers exclude it
+            ex["gauss_latitudes_ms"] = gauss_ms
+            if "cfg3_uvint" in ex:
+                ex["cfg3_uvint"]["cpu_baseline"] = cfg3_cpu
+            sf = ex.get("single_field_launch_us")
+            if sf:      # north_star words its 60 % target on "a field": the lone-field launch next to the batch launch (a property of the batch launch: DESIGN.md 10.4)
+                t1f = profile_value("single_field_traffic_MB")
+                s2u = ex.get("single_field_two_streams_us")
+                out["roofline_single_field"] = {"bound": "hbm", "achieved": ALGO_BYTES / (sf * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                                 "frac": ALGO_BYTES / (sf * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                                                "traffic": (profile_value("single_field_traffic_MB")[0] * 1e6) if profile_value("single_field_traffic_MB") else None,
-                                                "traffic_source": profile_value("single_field_traffic_MB")[1] if profile_value("single_field_traffic_MB") else None,
-                                                "two_streams": ({"us_per_field": out["extras"]["single_field_two_streams_us"],
-                                                                 "frac": ALGO_BYTES / (out["extras"]["single_field_two_streams_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                                                                 "note": "the same one-field calls with the caller alternating two streams (ezhip_use_stream): the launches' fill and drain overlap"}
-                                                                if out["extras"].get("single_field_two_streams_us") else None),
-                                                "kernel": "k_sepx<3, 16> (one field per launch, launches back to back)", "avg_launch_us": sf,
-                                                "algorithmic_bytes_per_launch": ALGO_BYTES}
+                                                "traffic": t1f[0] * 1e6 if t1f else None, "avg_launch_us": sf,
+                                                "two_streams_us_per_field": s2u, "two_streams_frac": (ALGO_BYTES / (s2u * 1e-6) / 1e9 / HBM_PEAK_GBPS) if s2u else None}
+            out["extras"] = ex
         if hf is not None:
             out["host_fed"] = hf
+        check_field_host = d_out[CHECK_F].cpu().numpy() if not args.no_cpu_baseline else None
     if dist:
         dist.destroy_process_group()      # before rank 0's CPU legs: the other ranks leave, nobody waits in a collective
     if rank == 0:
@@ -849,12 +865,19 @@ def main():
             # the reference's CPU path on this box's host cores, in the same run, at every N (a SCALE line carries it too).  Bounded
             # sample; at N > 1 the all-cores leg is skipped (the other ranks' processes are ending on the same cores)
             out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["pack"]["cpu_baseline"] = pack_cpu_baseline(check_field_host, out["cpu_baseline"].get("s_per_field"))
+            except Exception as e:   # noqa: BLE001
+                out["pack"]["cpu_baseline"] = {"error": repr(e)[:200]}
             if world == 1:
                 try:
                     out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
                 except Exception as e:   # noqa: BLE001
-                    out["cpu_baseline_all_cores"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+                    out["cpu_baseline_all_cores"] = {"error": repr(e)[:200]}
+        line = json.dumps(slim(out), separators=(",", ":"))
+        if len(line) > 7600:
+            sys.stderr.write("bench.py: the line is %d bytes; the driver keeps an 8 KB tail\n" % len(line))
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

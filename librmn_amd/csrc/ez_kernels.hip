@@ -2565,7 +2565,7 @@ __device__ __forceinline__ PairW pair_weights_lagrange(float px, float py, int i
  * Where the wind is nearly calm next to stronger winds (a coarse source, a calm point between two jets) that is more than 1e-5 of |V| -- the reference build found
  * such a point (tools/fuzz_vs_ref2.py 600 7: 3.8e-5 |V| at |V| = 0.037 under cells of +- 15).  And the reference's own polynomial is not the exact interpolating
  * cubic there: its Newton coefficients are REAL-rounded reciprocals, which moves it by ~1e-7 M (exact Lagrange weights in REAL*8 were still 4e-5 |V| off at that
- * point).  So: a point whose larger component is below M / 8 (M taken over the two central rows of the stencil) is evaluated once more the reference's way -- its Newton form with its REAL coefficient tables, REAL*8
+ * point).  So: a point whose larger component is below M / 8 (M = the largest |cell| of the stencil's two central rows or |w_y| x the largest |cell| of an outer row, whichever is larger) is evaluated once more the reference's way -- its Newton form with its REAL coefficient tables, REAL*8
  * throughout (the pair path's arithmetic of rounds 3 - 4) --, everywhere else the REAL result stands (<= 8 x ~7e-7 = 6e-6 |V|).  The test reads the REAL result: deterministic, the same in every kernel of the pair path.  Calm points are isolated: a few waves in
  * a thousand take the second path. */
 /* everything by address (its REAL*8 temporaries must not be alive next to the common path's registers: k_uvt runs it as a second pass over the flagged points of a
@@ -2598,10 +2598,14 @@ __device__ __forceinline__ pk2 pair_eval(float px, float py, int i, int j, f4a16
 #pragma unroll
     for (int r = 0; r < 4; r++) {      /* (a row's cells die with the row: M row by row, not from sixteen live cells at the end) */
         rw[r] = pair_row(w, q[r][0], q[r][1], q[r][2], q[r][3]);
-        if (r == 1 || r == 2) {        /* M over the two CENTRAL rows (the outer rows' weights are below 0.075: they would have to be an order of magnitude larger to matter) */
-            m = fmaxf(fmaxf(m, fabsf(q[r][0].x)), fabsf(q[r][0].y)); m = fmaxf(fmaxf(m, fabsf(q[r][1].x)), fabsf(q[r][1].y));
-            m = fmaxf(fmaxf(m, fabsf(q[r][2].x)), fabsf(q[r][2].y)); m = fmaxf(fmaxf(m, fabsf(q[r][3].x)), fabsf(q[r][3].y));
-        }
+        /* M: the central rows' largest |cell| as it is (their y weights are of order one), an OUTER row's scaled by |its y weight| (<= 0.075 on a uniform axis, whatever
+         * the axis gives otherwise): what a row can put into the sum -- and into its rounding error -- is |w_y| x its largest cell (round 6: until then the outer rows were
+         * not looked at, and large cells of alternating sign there could cancel unseen next to calm central rows) */
+        float mr = fmaxf(fmaxf(fabsf(q[r][0].x), fabsf(q[r][0].y)), fmaxf(fabsf(q[r][1].x), fabsf(q[r][1].y)));
+        mr = fmaxf(mr, fmaxf(fmaxf(fabsf(q[r][2].x), fabsf(q[r][2].y)), fmaxf(fabsf(q[r][3].x), fabsf(q[r][3].y))));
+        if (r == 0) mr *= fabsf(w.y0);
+        if (r == 3) mr *= fabsf(w.y3);
+        m = fmaxf(m, mr);
     }
     const pk2 s = pair_cols(w, rw[0], rw[1], rw[2], rw[3]);
     again = !(fmaxf(fabsf(s.x), fabsf(s.y)) * 8.0f >= m);      /* (also when something is not finite) */

@@ -1,0 +1,105 @@
+"""TEST / BASELINE INFRASTRUCTURE: the reference build (oracle/_ref/libezref.so) in a process of its own.
+
+Why a process of its own: (1) the reference's Fortran leaf routines keep ~24 bytes per target point in automatic arrays --
+cfg3's 8 M points need ~200 MB of stack, so the calls run on a thread whose stack this file sizes itself (no `ulimit -s` needed); (2) a caller that
+already holds GPU mappings must not fork -- the GPU suite asks its fork-server (tests/conftest.py, created before the first GPU call) to start this file,
+bench.py starts it before it imports torch.  It never touches a GPU and reads nothing but the repository copy (oracle/_ref travels with the snapshot).
+
+    python tests/ref_child.py cfg3_uvint [--reps N] [--out FILE.npy]
+        the reference's c_ezuvint (src/interp/ezuvint.c:51-94) on BASELINE configs[2]: Z-on-E 2560x1280 -> L 4000x2000, bicubic, polar correction,
+        inputs = tests/golden/make_cfg3_full.py's.  Prints one JSON line {first_s, s_per_pair, reps, rc}; --out: the two result fields as a
+        float32 [2, 8 M] array (u, v).
+    python tests/ref_child.py uvint_case CASE.npz OUT.npz
+        c_ezuvint on a case file: src_* / dst_* = (ni, nj, grtyp, grref, ig[4], ax, ay), degree, polar, uu, vv  ->  ur, vr, rc
+"""
+import ctypes, json, os, sys, threading, time
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, _HERE)
+import numpy as np          # noqa: E402
+import reflib               # noqa: E402
+import ezcases as ec        # noqa: E402
+
+fp = reflib.fptr
+DEG = {0: b"nearest", 1: b"linear", 3: b"cubic"}
+
+
+def cfg3_inputs():
+    ni, nj = 2560, 1280
+    uu, vv = ec.synth_wind(ni, nj, seed=3)
+    for a in (uu, vv):
+        a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+    return uu, vv
+
+
+def cfg3_uvint(argv):
+    reps = int(argv[argv.index("--reps") + 1]) if "--reps" in argv else 3
+    out = argv[argv.index("--out") + 1] if "--out" in argv else None
+    L = reflib.ref()
+    ni, nj, no, mo = 2560, 1280, 4000, 2000
+    ax, ay = ec.ze_axes(ni, nj)
+    gdin = L.c_ezgdef_fmem(ni, nj, b"Z", b"E", *ec.E_IG, fp(ax), fp(ay))
+    gdout = L.c_ezqkdef(no, mo, b"L", 9, 9, 0, 0, 0)
+    assert gdin >= 0 and gdout >= 0 and L.c_ezdefset(gdout, gdin) == 1
+    L.c_ezsetopt(b"interp_degree", b"cubic"); L.c_ezsetopt(b"polar_correction", b"yes")
+    uu, vv = cfg3_inputs()
+    uv = np.zeros((2, no * mo), np.float32)
+    t0 = time.perf_counter()
+    rc = L.c_ezuvint(fp(uv[0]), fp(uv[1]), fp(uu), fp(vv))                # first call of the set: lat / lon, locate through the rotation, zones
+    first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rc = min(rc, L.c_ezuvint(fp(uv[0]), fp(uv[1]), fp(uu), fp(vv)))
+    dt = (time.perf_counter() - t0) / max(reps, 1)
+    if out:
+        np.save(out, uv)
+    print(json.dumps({"first_s": first, "s_per_pair": dt, "reps": reps, "rc": int(rc), "points": no * mo}), flush=True)
+
+
+def _define(L, ni, nj, grtyp, grref, ig, ax, ay):
+    ig = [int(v) for v in ig]
+    if ax is None or np.size(ax) == 0:
+        return L.c_ezqkdef(int(ni), int(nj), str(grtyp).encode(), *ig, 0)
+    ax = np.ascontiguousarray(ax, np.float32); ay = np.ascontiguousarray(ay, np.float32)
+    _define.keep.append((ax, ay))
+    return L.c_ezgdef_fmem(int(ni), int(nj), str(grtyp).encode(), str(grref).encode(), *ig, fp(ax), fp(ay))
+_define.keep = []
+
+
+def uvint_case(argv):
+    d = np.load(argv[0], allow_pickle=False)
+    L = reflib.ref()
+    gi = _define(L, d["src_ni"], d["src_nj"], d["src_grtyp"], d["src_grref"], d["src_ig"], d["src_ax"], d["src_ay"])
+    go = _define(L, d["dst_ni"], d["dst_nj"], d["dst_grtyp"], d["dst_grref"], d["dst_ig"], d["dst_ax"], d["dst_ay"])
+    assert gi >= 0 and go >= 0 and L.c_ezdefset(go, gi) == 1
+    L.c_ezsetopt(b"interp_degree", DEG[int(d["degree"])]); L.c_ezsetopt(b"polar_correction", b"yes" if int(d["polar"]) else b"no")
+    n = int(d["dst_ni"]) * int(d["dst_nj"])
+    uu = np.ascontiguousarray(d["uu"], np.float32); vv = np.ascontiguousarray(d["vv"], np.float32)
+    ur = np.zeros(n, np.float32); vr = np.zeros(n, np.float32)
+    rc = L.c_ezuvint(fp(ur), fp(vr), fp(uu), fp(vv))
+    np.savez(argv[1], ur=ur, vr=vr, rc=np.int32(rc))
+    print(json.dumps({"rc": int(rc), "points": n}), flush=True)
+
+
+MODES = {"cfg3_uvint": cfg3_uvint, "uvint_case": uvint_case}
+
+
+def main():
+    if len(sys.argv) < 2 or sys.argv[1] not in MODES:
+        sys.stderr.write(__doc__); return 2
+    if not reflib.have_ref():
+        sys.stderr.write("ref_child: oracle/_ref/libezref.so is not built\n"); return 3
+    res = {}
+
+    def run():
+        try:
+            MODES[sys.argv[1]](sys.argv[2:]); res["rc"] = 0
+        except BaseException as e:      # noqa: BLE001
+            sys.stderr.write("ref_child: %r\n" % (e,)); res["rc"] = 1
+    threading.stack_size(2 << 30)       # the Fortran automatic arrays: 24 B per target point and more, on the calling thread's stack
+    t = threading.Thread(target=run); t.start(); t.join()
+    return res.get("rc", 1)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

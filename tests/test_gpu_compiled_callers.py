@@ -3,6 +3,7 @@ include/*.h, linked with -lrmn_ez_hip) and tests/callers/ez_f.f90 (AMD flang: hi
 rpnmacros.h:21,32-49, ezqkdef.c:39-55, Interp1D_Linear.F90:22-99).  Each runs as a child process with no Python in it; its outputs must equal
 the ctypes results of this process bit for bit."""
 import os, subprocess
+from conftest import run_child
 import numpy as np
 import pytest
 
@@ -39,7 +40,7 @@ def _run(exe, fin, fout):
     path = os.path.join(CALLERS, exe)
     if not os.path.exists(path):
         pytest.skip(f"{path} not built (__graft_entry__.build() makes it)")
-    r = subprocess.run([path, fin, fout], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    r = run_child([path, fin, fout], cwd=ROOT, timeout=600)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2000:])
     return r.stdout
 

@@ -5,6 +5,7 @@ Tolerances (BASELINE.json north_star): float interpolation within 1e-5 relative.
 kernel restates the reference arithmetic operation by operation (nearest, linear, and every degree
 on the per-point kernel) the comparison is bit-exact."""
 import ctypes, os
+from conftest import run_child
 import numpy as np
 import pytest
 
@@ -1537,7 +1538,7 @@ def test_a_thread_on_another_device_is_refused_loudly():
         print("rc", rc)
     """ % (ROOT_DIR, ROOT_DIR))
     env = dict(os.environ); env["EZHIP_TEST_BOUND_DEVICE"] = "5"
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    r = run_child([sys.executable, "-c", code], env=env, timeout=300)
     assert "rc -1" in r.stdout, (r.stdout, r.stderr[-1500:])
     assert "live on HIP device 5" in r.stderr and "current device is 0" in r.stderr, r.stderr[-1500:]
 

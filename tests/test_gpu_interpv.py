@@ -3,6 +3,7 @@ Fortran-callable symbols on host arrays and the device-pointer entry points -- a
 (REAL and REAL*8, levels ascending and descending, every LDS tiling of the kernel), plus the reference test program's
 own data / criteria and the hand-derived known answers."""
 import os
+from conftest import run_child
 import subprocess
 import sys
 import numpy as np
@@ -174,7 +175,7 @@ def test_abort_returns_2_and_the_fortran_symbol_exits_2():
     code = ("import sys; sys.path.insert(0, 'tests'); import numpy as np, interpvcases as iv; from librmn_amd import interpv as V;"
             "c, *_ = iv.reference_test_case(True); p = V.findpos(2, c['vls'], c['vld']); sd, sdd = iv.new_out(c);"
             "V.extrap(V.X_ABORT, 2, c['vls'], c['ss'], c['sds'], p, c['vld'], sd, sdd, True, True); print('survived')")
-    r = subprocess.run([sys.executable, "-c", code], cwd=os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."), capture_output=True, text=True)
+    r = run_child([sys.executable, "-c", code], cwd=os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     assert r.returncode == 2 and "survived" not in r.stdout and "Extrap1D_Abort: Attempting extrapolation to level" in r.stderr
     assert "below the lowest level" in r.stderr                                                              # vt = 4 (0.5) comes before vt = 5 (3.1)
 

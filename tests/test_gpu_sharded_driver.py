@@ -6,6 +6,7 @@ one GPU; the same code path as N ranks -- init_process_group("nccl"), barriers, 
     full-size run.
 SURVEY.md section 8e.  The 8-GPU scaling curve is the driver's job; this pins the code path it runs."""
 import json, os, socket, subprocess, sys
+from conftest import run_child
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -22,7 +23,7 @@ def _child(argv, extra_env, timeout=900):
     env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
                 "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     env.update(extra_env)
-    r = subprocess.run([sys.executable] + argv, capture_output=True, text=True, cwd=ROOT, env=env, timeout=timeout)
+    r = run_child([sys.executable] + argv, cwd=ROOT, env=env, timeout=timeout)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert lines, (r.stdout[-1500:], r.stderr[-1500:])
@@ -51,4 +52,4 @@ def test_bench_under_a_process_group_checks_its_outputs():
     out = _child([os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline"], {"BENCH_FORCE_DIST": "1"})
     assert out["n_gpus"] == 1 and out["steps"] == 3
     assert out["checked"] is True, out.get("check")
-    assert out["roofline"]["frac"] > 0.3 and out["pack"]["cfg5_pipeline_records_equal_unfused"] is True
+    assert out["roofline"]["frac"] > 0.3 and out["pack"]["cfg5"]["records_equal_unfused"] is True

@@ -6,6 +6,7 @@ c_gdxyfll, c_gdllfxy, c_gdxysint, c_gdllsval, c_gdllvval, c_gdwdfuv, c_gduvfwd o
 inversion, tests/test_host_cpu.py); tools/fuzz_vs_ref4.py: the mask entry points, c_ezwdint and Yin-Yang grids as source and as target (the
 reference's Yin-Yang answers from a process per case: in a long session it corrupts its own heap there)."""
 import os, subprocess, sys
+from conftest import run_child
 import pytest
 import reflib
 
@@ -26,10 +27,10 @@ def test_random_grid_pairs_against_the_reference_build(tool, ncases, seed):
     # survives, the death was the reference's: the comparison is repeated with another seed; three such deaths in a row fail the test.
     for attempt in range(3):
         cmd = [sys.executable, os.path.join(ROOT, "tools", tool), str(ncases), str(seed + 1000 * attempt)]
-        r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env)
+        r = run_child(cmd, cwd=ROOT, env=env)
         if r.returncode >= 0 or "MISMATCH" in r.stdout:
             break
-        alone = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=dict(env, FUZZ_PRODUCT_ONLY="1"))
+        alone = run_child(cmd, cwd=ROOT, env=dict(env, FUZZ_PRODUCT_ONLY="1"))
         assert alone.returncode >= 0, "the PRODUCT alone dies on this sequence of calls (signal %d):\n" % -alone.returncode + alone.stderr[-2000:]
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout

@@ -8,7 +8,7 @@ import pytest
 import librmn_amd
 from librmn_amd import ezscint as ez
 import ezcases as ec
-from conftest import both_legs
+from conftest import run_child, both_legs
 
 ROOT = os.path.join(os.path.dirname(__file__), "..")
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "ez_golden.npz"))
@@ -232,7 +232,7 @@ def test_vertical_interpolation_fails_loudly_without_gpu():
     assert V.column_dev(V.LINEAR, V.X_NONE, 8, z, z, z, None, z, z, z) == -1
     code = ("import numpy as np; from librmn_amd import interpv as V; z = np.ones((4, 8), np.float32);"
             "V.findpos(8, z, z); print('survived')")
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    r = run_child([sys.executable, "-c", code], cwd=ROOT)
     assert r.returncode != 0 and "survived" not in r.stdout and "no CPU fallback" in r.stderr
 
 
