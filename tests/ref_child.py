@@ -9,6 +9,8 @@ bench.py starts it before it imports torch.  It never touches a GPU and reads no
         the reference's c_ezuvint (src/interp/ezuvint.c:51-94) on BASELINE configs[2]: Z-on-E 2560x1280 -> L 4000x2000, bicubic, polar correction,
         inputs = tests/golden/make_cfg3_full.py's.  Prints one JSON line {first_s, s_per_pair, reps, rc}; --out: the two result fields as a
         float32 [2, 8 M] array (u, v).
+    python tests/ref_child.py cfg2_sint | cfg3_sint [--out FILE.npy]
+        the reference's c_ezsint, bicubic with polar correction, on BASELINE configs[1] / on cfg3's grid pair: the whole result field
     python tests/ref_child.py uvint_case CASE.npz OUT.npz
         c_ezuvint on a case file: src_* / dst_* = (ni, nj, grtyp, grref, ig[4], ax, ay), degree, polar, uu, vv  ->  ur, vr, rc
 """
@@ -81,7 +83,30 @@ def uvint_case(argv):
     print(json.dumps({"rc": int(rc), "points": n}), flush=True)
 
 
-MODES = {"cfg3_uvint": cfg3_uvint, "uvint_case": uvint_case}
+def cfg_sint(argv, which):
+    """c_ezsint (src/interp/ezsint.c) bicubic with polar correction on BASELINE configs[1] (G 4400x2200 -> L 7200x3601, tests/ezcases.synth_field seed 2) or on cfg3's grid
+    pair (the u field of cfg3_inputs): --out FILE.npy = the whole result field"""
+    out = argv[argv.index("--out") + 1] if "--out" in argv else None
+    L = reflib.ref()
+    if which == 2:
+        ni, nj, no, mo = 4400, 2200, 7200, 3601
+        gdin = L.c_ezqkdef(ni, nj, b"G", 0, 0, 0, 0, 0); gdout = L.c_ezqkdef(no, mo, b"L", 5, 5, 0, 0, 0)
+        zin = ec.synth_field(ni, nj, seed=2)
+    else:
+        ni, nj, no, mo = 2560, 1280, 4000, 2000
+        ax, ay = ec.ze_axes(ni, nj)
+        gdin = L.c_ezgdef_fmem(ni, nj, b"Z", b"E", *ec.E_IG, fp(ax), fp(ay)); gdout = L.c_ezqkdef(no, mo, b"L", 9, 9, 0, 0, 0)
+        zin = cfg3_inputs()[0]
+    assert gdin >= 0 and gdout >= 0 and L.c_ezdefset(gdout, gdin) == 1
+    L.c_ezsetopt(b"interp_degree", b"cubic"); L.c_ezsetopt(b"polar_correction", b"yes")
+    z = np.zeros(no * mo, np.float32)
+    t0 = time.perf_counter(); rc = L.c_ezsint(fp(z), fp(zin)); first = time.perf_counter() - t0
+    if out:
+        np.save(out, z)
+    print(json.dumps({"first_s": first, "rc": int(rc), "points": no * mo}), flush=True)
+
+
+MODES = {"cfg3_uvint": cfg3_uvint, "uvint_case": uvint_case, "cfg2_sint": lambda a: cfg_sint(a, 2), "cfg3_sint": lambda a: cfg_sint(a, 3)}
 
 
 def main():

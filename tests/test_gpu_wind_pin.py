@@ -166,3 +166,37 @@ def test_adversarial_winds_against_the_reference_run(kind, shape, tmp_path):
         relv, relm, calm = _compare("%s %s call %d" % (kind, shape, call), pu, pv, R["ur"], R["vr"], meff)
     assert calm > 0, "the case does not exercise the second pass"
     print("%s %dx%d -> %dx%d: max err %.3g |V|, max (e - %.1e |V|) / M_eff %.3g; %d of %d points under the M_eff / %g rule" % (kind, ni, nj, no, mo, relv, C_V, relm, calm, no * mo, RULE))
+
+
+@pytest.mark.parametrize("which", ["cfg2", "cfg3"])
+def test_every_scalar_value_against_the_reference_run(which, tmp_path):
+    """c_ezsint bicubic with polar correction at BASELINE configs[1] (k_sepx) and on cfg3's grid pair (k_st): ALL output values against the reference's own run in a
+    fresh child -- the sampled rows / columns of tests/test_gpu_interp.py cover 0.5 % of them.  1e-5 relative where |want| >= 1e-3 max|want|, 1e-8 max|want| absolute below."""
+    out = str(tmp_path / "ref.npy")
+    r = run_child([sys.executable, os.path.join(HERE, "ref_child.py"), which + "_sint", "--out", out], cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = np.load(out).astype(np.float64)
+    if which == "cfg2":
+        ni, nj, no, mo = 4400, 2200, 7200, 3601
+        gdin = ez.ezqkdef(ni, nj, "G", 0, 0, 0, 0); gdout = ez.ezqkdef(no, mo, "L", 5, 5, 0, 0)
+        zin = ec.synth_field(ni, nj, seed=2)
+    else:
+        ni, nj, no, mo = 2560, 1280, 4000, 2000
+        ax, ay = ec.ze_axes(ni, nj)
+        gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay); gdout = ez.ezqkdef(no, mo, "L", 9, 9, 0, 0)
+        zin = ec.synth_wind(ni, nj, seed=3)[0]; z2 = zin.reshape(nj, ni); z2[:, -1] = z2[:, 0]
+    assert ez.ezdefset(gdout, gdin) == 1
+    _setopts()
+    ez.use_stream(torch.cuda.current_stream().cuda_stream)
+    d_in = torch.from_numpy(zin).cuda()
+    for call in range(2):          # cfg3: the first call of a set gathers, the second runs from staged windows
+        d_out = torch.zeros(no * mo, dtype=torch.float32, device="cuda")
+        assert ez.ezsint_dev(d_out, d_in) == 0
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().astype(np.float64)
+        d = np.abs(got - want); aw = np.abs(want); big = aw >= aw.max() * 1e-3
+        rel = float((d[big] / aw[big]).max()); ab = float(d[~big].max()) if (~big).any() else 0.0
+        nbits = int(np.count_nonzero(got != want))
+        print("%s c_ezsint call %d: %d of %d values differ from the reference's; max rel %.3g, max abs near zero %.3g" % (which, call, nbits, want.size, rel, ab))
+        assert rel <= TOL_V and ab <= 1e-8 * aw.max(), (which, call, rel, ab)
+    ez.gdrls(gdout); ez.gdrls(gdin)
