@@ -54,6 +54,12 @@ int  armn_compress(unsigned char *fld, int ni, int nj, int nk, int nbits, int op
  * parallelogram of znbits - 9 bits).  zstream: host memory of ni*nj*znbits/8 bytes (+ 64).  c_armn_compress32 returns the byte count or -1
  * (not compressible / ni, nj < 16); c_armn_uncompress32 returns ni*nj.  Fortran twins armn_compress32_ / armn_uncompress32_. */
 int c_armn_compress32(unsigned char *zstream, float *fld, int ni, int nj, int nk, int znbits);
+/* NOTE on c_armn_uncompress32 (the reference's own signature: NO stream length).  To upload the record in one piece the library has to bound it: it reads
+ * /proc/self/maps (Linux procfs; one parse per call) for the readable extent behind `zstream`, estimates the mantissa plane's length from its first tiles
+ * (+ 12 %) and uploads that much -- i.e. it READS caller memory beyond the record's end, up to the end of the mapping at most, never beyond it -- and tries
+ * once more with everything readable if a chain leaves the estimate; without procfs the chains are walked on host threads first.  Results are the reference's
+ * either way.  A caller that knows the record's byte length (every FST reader does: fstd98.c:2436) should call c_armn_uncompress32_lng below: no procfs, no
+ * over-read, no second attempt -- it is the documented default for new call sites, this entry exists for source compatibility. */
 int c_armn_uncompress32(float *fld, unsigned char *zstream, int ni, int nj, int nk, int znbits);
 int armn_compress32_(unsigned char *zstream, float *fld, int *ni, int *nj, int *nk, int *nbits);
 int armn_uncompress32_(float *fld, unsigned char *zstream, int *ni, int *nj, int *nk, int *nbits);

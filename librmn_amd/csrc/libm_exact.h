@@ -10,7 +10,18 @@
  *
  * Nothing here is taken on trust: tools/check_libm_exact.c compares each function with the C library's over EVERY REAL argument (2^32 of them;
  * atan2f over its quotient's 2^32 and a few 10^9 random pairs) on the host, tests/test_gpu_interp.py compares the device's x, y with c_gdxyfll's.
- * Compiled with -ffp-contract=off on both sides (the Makefile's flags): the only fused operations are the ones spelled fma(). */
+ * Compiled with -ffp-contract=off on both sides (the Makefile's flags): the only fused operations are the ones spelled fma().
+ *
+ * PROVENANCE AND LICENCE.  This header is not reference (librmn) code.  It is a restatement of algorithms published in the GNU C Library 2.35
+ * (sysdeps/ieee754/flt-32/: s_sinf.c, s_cosf.c, sincosf.h, s_sincosf_data.c -- Copyright (C) 2018-2022 Free Software Foundation, Inc., contributed by
+ * Arm Ltd.; e_asinf.c, s_atanf.c, e_atan2f.c -- derived from FreeBSD msun, Copyright (C) 1993 Sun Microsystems, Inc., "Permission to use, copy, modify,
+ * and distribute this software is freely granted, provided that this notice is preserved").  The polynomial coefficients, reduction constants and the
+ * 2/pi table are those sources' published values (the tables were cross-checked against the .rodata of this image's libm.so.6); the control flow was
+ * rewritten for this file.  glibc is distributed under the GNU Lesser General Public License, version 2.1 or later: anyone redistributing a binary of
+ * librmn_ez_hip.so should treat this header as LGPL-2.1-or-later material (its source is this file; relinking against a modified version is possible by
+ * rebuilding librmn_amd/csrc).  It welds the product's rotated-frame results to glibc 2.35's REAL functions: a process whose C library computes them
+ * otherwise is recognised at run time (ez_host.c: 16 384 sampled arguments per function at the first rotated set) and falls back to host locates through
+ * its own library; the WIND chain (round 6: d_rotate*, k_wind_rotate) uses this header unconditionally -- the reference platform's answers. */
 #ifndef LIBM_EXACT_H
 #define LIBM_EXACT_H
 #include <stdint.h>
