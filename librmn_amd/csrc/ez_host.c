@@ -2669,6 +2669,7 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
         pthread_mutex_lock(&g_plan_mtx);
         if (s->st_key[sl] == st_key && s->d_st_tiles[sl]) {
             pp.uvt_tiles = s->d_st_tiles[sl]; pp.uvt_shape = 3232; pp.uvt_cap = s->st_cap[sl]; pp.uvt_streams = s->d_st_streams[sl];
+            pp.uvt_nhb = (sl == 1 && !getenv("EZHIP_UVT_TABLE_ORDER")) ? s->st_stats[sl][1] + s->st_stats[sl][2] : 0;      /* (bicubic: k_st; the bilinear k_st1 keeps table order) */
             if (sl == 1 && s->sspec_key == st_key && s->sspec_count > 0) {      /* the set's special points under these options: the kernel's producer blocks take them along */
                 pp.cspec_valid = 1; pp.cspec_count = s->sspec_count; pp.cspec_list = s->d_sspec_list; pp.cspec_x = s->d_sspec_xy; pp.cspec_y = s->d_sspec_xy + s->sspec_count;
             }
@@ -2684,13 +2685,13 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
         ezhip_pts_plan pt = pp;
         pt.pv_out = NULL; pt.uvt_cap = cap;
         const int nt = ezhip_uvt_ntiles(&pt, 3232);
-        const size_t st_bytes = nt > 0 ? 16 * (size_t)nt + (size_t)8 * 1024 * (size_t)nt : 0;
+        const size_t st_bytes = nt > 0 ? 20 * (size_t)nt + (size_t)8 * 1024 * (size_t)nt : 0;      /* (16 per table entry + the gathering path's tile list) */
         pthread_mutex_lock(&g_plan_mtx);
         const int fits = nt > 0 && cache_reserve(s, st_bytes);
         pthread_mutex_unlock(&g_plan_mtx);
-        void *dt = fits ? ezhip_malloc(16 * (size_t)nt) : NULL, *ds = fits ? ezhip_malloc((size_t)8 * 1024 * (size_t)nt) : NULL;
+        void *dt = fits ? ezhip_malloc(20 * (size_t)nt) : NULL, *ds = fits ? ezhip_malloc((size_t)8 * 1024 * (size_t)nt) : NULL;
         int st[4] = {0, 0, 0, 0}, good = 0;
-        if (dt && ds && (degree == DEG_CUBIC ? ezhip_uvt_build(&pt, s->d_x, s->d_y, dt, 3232, st) : ezhip_st1_build(&pt, s->d_x, s->d_y, dt, st)) == 0 && st[0] >= 4 * st[1] && ezhip_st_pack_streams(&pt, s->d_x, s->d_y, ds) == 0) good = 1;
+        if (dt && ds && (degree == DEG_CUBIC ? ezhip_uvt_build(&pt, s->d_x, s->d_y, dt, 3232, st, 2) : ezhip_st1_build(&pt, s->d_x, s->d_y, dt, st)) == 0 && st[0] >= 4 * st[1] && ezhip_st_pack_streams(&pt, s->d_x, s->d_y, ds) == 0) good = 1;
         pthread_mutex_lock(&g_plan_mtx);
         if (s->st_key[sl] == 0) {
             if (good) { s->d_st_tiles[sl] = dt; s->d_st_streams[sl] = ds; s->st_cap[sl] = cap; memcpy(s->st_stats[sl], st, sizeof(st)); s->st_key[sl] = st_key; dt = ds = NULL; }
@@ -2764,7 +2765,7 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
         if (s->cspec_key == key) {
             pu.cspec_valid = 1; pu.cspec_count = s->cspec_count; pu.cspec_list = s->d_cspec_list;
             pu.cspec_x = s->d_cspec_xy; pu.cspec_y = s->d_cspec_xy ? s->d_cspec_xy + s->cspec_count : NULL;
-            if (s->d_uvt_tiles && !getenv("EZHIP_NO_UVT")) { pu.uvt_tiles = s->d_uvt_tiles; pu.uvt_shape = s->uvt_shape; pu.uvt_cap = s->uvt_cap;
+            if (s->d_uvt_tiles && !getenv("EZHIP_NO_UVT")) { pu.uvt_tiles = s->d_uvt_tiles; pu.uvt_shape = s->uvt_shape; pu.uvt_cap = s->uvt_cap; pu.uvt_nhb = getenv("EZHIP_UVT_TABLE_ORDER") ? 0 : s->uvt_stats[1];
                 if (s->d_uvt_streams && s->uvt_streams_M == d_M && (!d_M || m_half) && !getenv("EZHIP_UVT_NO_STREAMS")) pu.uvt_streams = s->d_uvt_streams; }      /* EZHIP_NO_UVT: the gathering kernel (same results) */
         }
         pthread_mutex_unlock(&g_plan_mtx);
@@ -2796,13 +2797,13 @@ static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui,
                     if (cap > 4096) cap = 4096;
                     pu.uvt_cap = cap;
                     const int nt = ezhip_uvt_ntiles(&pu, th);
-                    const size_t tb_bytes = nt > 0 ? 16 * (size_t)nt : 0, sb_bytes = nt > 0 ? ezhip_uvt_stream_bytes(&pu, th) : 0;
+                    const size_t tb_bytes = nt > 0 ? 20 * (size_t)nt : 0, sb_bytes = nt > 0 ? ezhip_uvt_stream_bytes(&pu, th) : 0;      /* (16 per entry + the handed-back tiles' list) */
                     pthread_mutex_lock(&g_plan_mtx);
                     const int fits_t = nt > 0 && cache_reserve(s, tb_bytes);
                     pthread_mutex_unlock(&g_plan_mtx);
                     void *dt = fits_t ? ezhip_malloc(tb_bytes) : NULL;
                     int st[4] = {0, 0, 0, 0}, kept_t = 0;
-                    if (dt && ezhip_uvt_build(&pu, s->d_x, s->d_y, dt, th, st) == 0 && st[0] >= 4 * st[1]) {      /* (a set whose tiles mostly do not qualify keeps the gathering kernel) */
+                    if (dt && ezhip_uvt_build(&pu, s->d_x, s->d_y, dt, th, st, 1) == 0 && st[0] >= 4 * st[1]) {      /* (a set whose tiles mostly do not qualify keeps the gathering kernel) */
                         pthread_mutex_lock(&g_plan_mtx);
                         s->uvt_shape = th; s->uvt_cap = cap; memcpy(s->uvt_stats, st, sizeof(st)); s->d_uvt_tiles = dt; dt = NULL; kept_t = 1;
                         const int fits_s = (!d_M || m_half) && cache_reserve(s, sb_bytes);
@@ -2891,6 +2892,7 @@ static int run_batch_st(ezh_set *s, float *d_zout, const float *d_zin, int nfiel
     pp.fill = t_scratch8; pp.polevals = d_poles_all ? d_poles_all : t_scratch8 + 4;
     pp.tile_ni = go->ni; pp.tile_nj = go->nj;
     pp.uvt_tiles = s->d_st_tiles[sl]; pp.uvt_shape = 3232; pp.uvt_cap = s->st_cap[sl]; pp.uvt_streams = s->d_st_streams[sl];
+            pp.uvt_nhb = (sl == 1 && !getenv("EZHIP_UVT_TABLE_ORDER")) ? s->st_stats[sl][1] + s->st_stats[sl][2] : 0;      /* (bicubic: k_st; the bilinear k_st1 keeps table order) */
     const int rc = ezhip_interp_pts_batch(&pp, d_zout, d_zin, s->d_x, s->d_y, go->ni * go->nj, nfields, nin, nout);
     if (rc == -2) return -2;
     return rc ? dev_fail("the per-point interpolation kernel (batch)") : 0;

@@ -3112,7 +3112,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? UVT
         boff = 2u * (unsigned)npairs;
     }
     /* (xcd_order: XCD k takes the k-th contiguous eighth of the tiles -- neighbouring tiles' windows overlap and share cache lines: one L2 then fetches them once) */
-    const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW, b = p.xcd_order ? pts_block(blockIdx.x - boff, gridDim.x - boff) : blockIdx.x - boff, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
+    /* (round 6) the tiles handed back to the gathering path run ~7 times as long as a staged one: the launch's first uvt_nhb blocks take them (listed behind the table), the
+     * blocks in table order skip them */
+    const unsigned nhb = (unsigned)p.uvt_nhb, bt = blockIdx.x - boff;
+    const bool hb_block = bt < nhb;
+    unsigned b = hb_block ? 0u : (p.xcd_order ? pts_block(bt - nhb, gridDim.x - boff - nhb) : bt - nhb);
+    if (hb_block) b = ((const unsigned *)(tiles + (gridDim.x - boff - nhb)))[bt];
+    const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
     const unsigned cx = bx * TW + (t % TW), cy0 = by * TH + t / TW;
     const bool okx = cx < (unsigned)p.tile_ni;
     /* the points' own streams first -- before the tile's table entry is even looked at (their addresses depend on the block index only): in flight
@@ -3137,7 +3143,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? UVT
     const int4 tb = tiles[b];
     if (tb.z < 0) return;
     if (tb.z == 0) {
-        if (dbg & 1) return;
+        if ((dbg & 1) || (nhb != 0u && !hb_block)) return;
 #pragma unroll 1
         for (int f = 0; f < npairs; f++) {
             const size_t oi = BATCH ? (size_t)f * p.pair_in_stride : 0, oo = BATCH ? (size_t)f * p.pair_out_stride : 0;
@@ -3358,7 +3364,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? STB
         }
         boff = 2;
     }
-    const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW, b = blockIdx.x - boff, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
+    /* (round 6, as k_uvt) the tiles of the gathering path first: the launch's first uvt_nhb blocks take them from the list behind the table, the blocks in table order skip them */
+    const unsigned nhb = (unsigned)p.uvt_nhb, bt = blockIdx.x - boff;
+    const bool hb_block = bt < nhb;
+    const unsigned b = hb_block ? ((const unsigned *)(tiles + (gridDim.x - boff - nhb)))[bt] : bt - nhb;
+    const unsigned tpr = ((unsigned)p.tile_ni + TW - 1u) / TW, by = b / tpr, bx = b - by * tpr, t = threadIdx.x;
     const unsigned cx = bx * TW + (t % TW), cy0 = by * TH + t / TW;
     const bool okx = cx < (unsigned)p.tile_ni;
     float px[PPT], py[PPT];
@@ -3378,6 +3388,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BATCH ? STB
     }
     const int4 tb = tiles[b];
     if (tb.z <= 0) {           /* handed back (the seam, a window beyond the cap) or without a normal point: the gathering path, point by point */
+        if (nhb != 0u && !hb_block) return;
 #pragma unroll 1
         for (int f = 0; f < (BATCH ? nfields : 1); f++) {
 #pragma unroll ST_HB_UNROLL
@@ -3877,10 +3888,10 @@ static int interp_pts_impl(const ezhip_pts_plan *plan, float *d_zout, const floa
             ezhip_pts_plan pi = *plan;
             pi.cspec_inline = 1;
             t_spec.epoch--;                                          /* (no list, no counter used by this launch) */
-            hipLaunchKernelGGL((k_st<32, 32, false, false>), dim3(nt + 2u), block, lds, g_stream, pi, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, (int *)nullptr, cnt, 1, in_stride, out_stride);
+            hipLaunchKernelGGL((k_st<32, 32, false, false>), dim3(nt + (unsigned)pi.uvt_nhb + 2u), block, lds, g_stream, pi, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, (int *)nullptr, cnt, 1, in_stride, out_stride);
             return LAUNCH_CHECK("k_st");
         }
-#define ST_LAUNCH(NW, B) hipLaunchKernelGGL((k_st<32, 32, NW, B>), dim3(nt + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt, nfields, in_stride, out_stride)
+#define ST_LAUNCH(NW, B) hipLaunchKernelGGL((k_st<32, 32, NW, B>), dim3(nt + (unsigned)plan->uvt_nhb + (plan->pv_out ? 2u : 0u)), block, lds, g_stream, *plan, d_zout, d_zin, d_x, d_y, (const int4 *)plan->uvt_tiles, t_spec.list, cnt, nfields, in_stride, out_stride)
         if (kind_st == PK_IRGD3_W) { if (nfields > 1) ST_LAUNCH(false, true); else ST_LAUNCH(false, false); }
         else { if (nfields > 1) ST_LAUNCH(true, true); else ST_LAUNCH(true, false); }
 #undef ST_LAUNCH
@@ -3946,7 +3957,7 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
         pu2.uvt_debug = EZH_DEVINT("EZHIP_UVT_DEBUG");
         const unsigned nt = (unsigned)ezhip_uvt_ntiles(&pu2, pu2.uvt_shape);
         const int4 *tl = (const int4 *)pu2.uvt_tiles;
-        const dim3 g(nt + (pu2.pw_out ? 2u * (unsigned)npairs : 0u));
+        const dim3 g(nt + (unsigned)pu2.uvt_nhb + (pu2.pw_out ? 2u * (unsigned)npairs : 0u));
         size_t lds = (size_t)8 * (size_t)pu2.uvt_cap + (stage3nw ? 80 : 32) * UVT_REC_MAX;
         if (lds < 4 * 2052 + 16) lds = 4 * 2052 + 16;                          /* (the polar-wind producer blocks' row buffer) */
         pu2.xcd_order = getenv("EZHIP_UVT_XCD") ? atoi(getenv("EZHIP_UVT_XCD")) : 0;
@@ -4005,7 +4016,7 @@ extern "C" int ezhip_uvt_ntiles(const ezhip_pts_plan *plan, int shape)
     if (plan->tile_ni <= 0 || plan->tile_nj <= 0) return 0;
     return ((plan->tile_ni + tw - 1) / tw) * ((plan->tile_nj + th - 1) / th);
 }
-extern "C" int ezhip_uvt_build(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_tiles, int shape, int *stats)
+extern "C" int ezhip_uvt_build(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_tiles, int shape, int *stats, int want_list)
 {
     const int nt = ezhip_uvt_ntiles(plan, shape);
     if (nt <= 0 || !d_tiles) return -1;
@@ -4024,6 +4035,15 @@ extern "C" int ezhip_uvt_build(const ezhip_pts_plan *plan, const float *d_x, con
         if (set_err(hipMemcpy(h, d_tiles, sizeof(int4) * (size_t)nt, hipMemcpyDeviceToHost), "k_uvt_bbox tiles")) { free(h); return -1; }
         stats[0] = stats[1] = stats[2] = stats[3] = 0;
         for (int k = 0; k < nt; k++) { if (h[k].z > 0) { stats[0]++; if (h[k].z * (h[k].w & UVT_H_MASK) > stats[3]) stats[3] = h[k].z * (h[k].w & UVT_H_MASK); } else if (h[k].z == 0) stats[1]++; else stats[2]++; }
+        if (want_list && stats[1] + (want_list == 2 ? stats[2] : 0) > 0) {         /* the handed-back tiles' indices behind the table: the launch's first blocks take them (they run several times as long as a staged tile); 2: k_st, whose gathering path also takes the tiles without a normal point */
+            unsigned *l = (unsigned *)malloc(sizeof(unsigned) * (size_t)(stats[1] + stats[2]));
+            if (!l) { free(h); return -1; }
+            int m = 0;
+            for (int k = 0; k < nt; k++) if (h[k].z == 0 || (want_list == 2 && h[k].z < 0)) l[m++] = (unsigned)k;
+            const int bad = set_err(hipMemcpy((char *)d_tiles + sizeof(int4) * (size_t)nt, l, sizeof(unsigned) * (size_t)m, hipMemcpyHostToDevice), "k_uvt_bbox list");
+            free(l);
+            if (bad) { free(h); return -1; }
+        }
         free(h);
     }
     return 0;

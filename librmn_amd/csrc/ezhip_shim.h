@@ -229,6 +229,8 @@ typedef struct {
     const void *uvt_tiles;            /* k_uvt: the grid set's tile table (int4 {i0, j0, W, H} per 32 x uvt_th tile of the target: ezhip_uvt_build), NULL: k_pts2 */
     int uvt_shape;                    /* 100 TW + TH of the table's tiles: 3232 (default), 3216, 6416, 6408 */
     int uvt_cap;                      /* staged cells a tile may need (the table was built under it) */
+    int uvt_nhb;                      /* k_uvt (round 6): tiles handed back to the gathering path (seam, windows beyond the cap), listed BEHIND the table's int4 entries
+                                         (unsigned[uvt_nhb] at tiles + ntiles): the launch's first uvt_nhb blocks take them, the blocks in table order skip them.  0: table order only */
     const void *uvt_streams;          /* NULL, or the set's x, y and packed rotation once more in tile order: 12 bytes per point (ezhip_uvt_pack_streams) */
     int uvt_debug;                    /* development knock-outs (develop build only) */
     int uvt_read2;                    /* development: k_uvt reads its cells with the compiler's ds_read2_b64 pairs instead of single ds_read_b64 (same results) */
@@ -278,7 +280,8 @@ int ezhip_mask_fill_min(float *d_fld, const int *d_mask, size_t n, unsigned *d_k
 /* k_uvt's tile table of a wind-pair plan over the located x, y of its grid set (tile_ni x tile_nj target in row order): d_tiles receives
  * ezhip_uvt_ntiles(plan, shape) int4 entries (shape = 100 TW + TH).  stats (host, may be NULL): [0] tiles staged, [1] handed to the gathering path, [2] empty, [3] largest window (cells).  Synchronises. */
 int ezhip_uvt_ntiles(const ezhip_pts_plan *plan, int shape);
-int ezhip_uvt_build(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_tiles, int shape, int *stats);
+/* want_list: d_tiles holds 20 bytes per tile; the indices of the handed-back tiles (stats[1] of them) are written behind the table's entries */
+int ezhip_uvt_build(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_tiles, int shape, int *stats, int want_list);
 size_t ezhip_uvt_stream_bytes(const ezhip_pts_plan *plan, int shape);
 int ezhip_uvt_pack_streams(const ezhip_pts_plan *plan, const float *d_x, const float *d_y, void *d_streams, int shape);
 int ezhip_interp_pts_batch(const ezhip_pts_plan *plan, float *d_zout, const float *d_zin, const float *d_x, const float *d_y, int npts, int nfields, size_t in_stride, size_t out_stride);      /* k_st over a batch: -2 when the plan is not on that path */

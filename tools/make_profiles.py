@@ -80,7 +80,7 @@ KB3 = bench.get("extras", {}).get("cfg3_uvint_batch", {}).get("workload", "")
 KB3 = int(KB3.split(",")[1].split()[0]) if "pairs per call" in KB3 else 0                                             # c_ezuvint_batch_dev's pairs per call in this bench
 P3B = per_field("k_uvt<32, 32, false, true>", nfields=KB3) if KB3 else None
 S3 = per_field("k_pts_special2c", nfields=1) or per_field("k_pts_special2", nfields=1); W3 = per_field("k_polar_wind", nfields=1)
-zl = bench["pack"]["zlng_bytes"]
+zl = bench["pack"]["cfg5"]["zlng_bytes"] if "cfg5" in bench["pack"] else bench["pack"]["zlng_bytes"]      # (round 6: the pack object is nested)
 out = {
     "workload": "python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 under rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, tools/prof_round.sh); "
                 f"per-dispatch values in {prefix}_pmc_FETCH_SIZE_per_dispatch.csv / {prefix}_pmc_WRITE_SIZE_per_dispatch.csv (KiB); medians over the dispatches of a (kernel, grid)",
