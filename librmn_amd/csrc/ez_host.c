@@ -3059,10 +3059,20 @@ int32_t ezhip_ezsint_batch_minmax_bb_dev(const float *d_zin, int32_t nfields, ui
         if (ezhip_side_end() || bad) { ezhip_side_join(); return -1; }
         d_poles = s->d_poles_batch;
     }
-    int rc = ezhip_minmax_bb(&p, d_zin, nin, nfields, d_partials, (size_t)stride_words, d_flags, d_poles, t_bbws.p);
-    if (side && ezhip_side_join()) return -1;
-    if (rc) return rc == -2 ? -2 : -1;
-    if (ezhip_minmax_bb_special(&p, d_zin, nin, nfields, d_partials, (size_t)stride_words, d_flags, d_poles, t_bbws.p)) return -1;
+    /* (round 6) the special rows need the bounds pass's reduction (it initialises the fields' keys and flags) and the pole values, nothing of the second sweep: they run on
+     * the side stream -- behind the pole sums, which are already there -- beside k_bb_select / k_bb_eval (39 of the pass's 420 us per batch of 32) */
+    int rc = ezhip_minmax_bb_stage(&p, d_zin, nin, nfields, d_partials, (size_t)stride_words, d_flags, d_poles, t_bbws.p, getenv("EZHIP_BB_ONE_STREAM") ? 0 : 1);
+    if (rc) { if (side) ezhip_side_join(); return rc == -2 ? -2 : -1; }
+    if (getenv("EZHIP_BB_ONE_STREAM")) {
+        if (side && ezhip_side_join()) return -1;
+        if (ezhip_minmax_bb_special(&p, d_zin, nin, nfields, d_partials, (size_t)stride_words, d_flags, d_poles, t_bbws.p)) return -1;
+    } else {
+        if (ezhip_side_begin()) return -1;              /* (the side stream now waits for the reduction as well; it is in order behind its own pole sums) */
+        int bad = ezhip_minmax_bb_special(&p, d_zin, nin, nfields, d_partials, (size_t)stride_words, d_flags, d_poles, t_bbws.p);
+        if (ezhip_side_end() || bad) { ezhip_side_join(); return -1; }
+        rc = ezhip_minmax_bb_stage(&p, d_zin, nin, nfields, d_partials, (size_t)stride_words, d_flags, d_poles, t_bbws.p, 2);
+        if (ezhip_side_join() || rc) return -1;
+    }
     if (partials_per_field) *partials_per_field = 1;
     return 0;
 }

@@ -2078,8 +2078,10 @@ static void bb_fill(bb_args *a, const ezhip_sep_plan *plan, const float *d_zin, 
     a->list_cap = a->force_all ? BB_LIST_CAP : (int)cap;
     a->exact_ok = plan->bb_s < 1.0e-9 ? 1 : 0;               /* sum w = 1 to REAL*8 rounding: a window of one value c gives c */
 }
-extern "C" int ezhip_minmax_bb(const ezhip_sep_plan *plan, const float *d_zin, size_t in_stride, int nfields, unsigned *d_partials, size_t stride_words,
-                               int *d_flags, const float *d_poles, void *d_work)
+/* stage 0: everything; 1: the bounds sweep and the reduction (which also initialises the fields' keys and flags); 2: the second sweep of the listed tiles and the evaluation
+ * of their windows -- the special rows (ezhip_minmax_bb_special) need stage 1 only and can run beside stage 2 on another stream */
+extern "C" int ezhip_minmax_bb_stage(const ezhip_sep_plan *plan, const float *d_zin, size_t in_stride, int nfields, unsigned *d_partials, size_t stride_words,
+                                     int *d_flags, const float *d_poles, void *d_work, int stage)
 {
     if (!plan->bb_ok || nfields < 1 || plan->ni_src > 65535 || plan->nj_src > 65535) return -2;
     bb_args a;
@@ -2087,16 +2089,22 @@ extern "C" int ezhip_minmax_bb(const ezhip_sep_plan *plan, const float *d_zin, s
     const bool vec = plan->ni_src % 4 == 0 && in_stride % 4 == 0 && ((uintptr_t)d_zin & 15) == 0;
     const dim3 g1((unsigned)a.ntx, (unsigned)((a.nty + 3) / 4), (unsigned)nfields), g2((unsigned)(a.ntx * a.nty * (BB_TH / BB_SUB) < 128 ? a.ntx * a.nty * (BB_TH / BB_SUB) : 128), (unsigned)nfields), g3(64, (unsigned)nfields);
 #define BB_LAUNCH(NT, DEG) do { \
-        if (vec) { hipLaunchKernelGGL((k_bb_bounds<NT, true>), g1, dim3(256), 0, g_stream, a); hipLaunchKernelGGL(k_bb_reduce, dim3((unsigned)nfields), dim3(256), 0, g_stream, a); \
-                   hipLaunchKernelGGL((k_bb_select<NT, true>), g2, dim3(64), 0, g_stream, a); } \
-        else { hipLaunchKernelGGL((k_bb_bounds<NT, false>), g1, dim3(256), 0, g_stream, a); hipLaunchKernelGGL(k_bb_reduce, dim3((unsigned)nfields), dim3(256), 0, g_stream, a); \
-               hipLaunchKernelGGL((k_bb_select<NT, false>), g2, dim3(64), 0, g_stream, a); } \
-        hipLaunchKernelGGL(k_bb_eval<DEG>, g3, dim3(256), 0, g_stream, a); } while (0)
+        if (stage != 2) { \
+            if (vec) hipLaunchKernelGGL((k_bb_bounds<NT, true>), g1, dim3(256), 0, g_stream, a); else hipLaunchKernelGGL((k_bb_bounds<NT, false>), g1, dim3(256), 0, g_stream, a); \
+            hipLaunchKernelGGL(k_bb_reduce, dim3((unsigned)nfields), dim3(256), 0, g_stream, a); } \
+        if (stage != 1) { \
+            if (vec) hipLaunchKernelGGL((k_bb_select<NT, true>), g2, dim3(64), 0, g_stream, a); else hipLaunchKernelGGL((k_bb_select<NT, false>), g2, dim3(64), 0, g_stream, a); \
+            hipLaunchKernelGGL(k_bb_eval<DEG>, g3, dim3(256), 0, g_stream, a); } } while (0)
     if (plan->bb_ntap == 4) BB_LAUNCH(4, 3); else if (plan->bb_ntap == 2) BB_LAUNCH(2, 1); else BB_LAUNCH(1, 0);
 #undef BB_LAUNCH
     return LAUNCH_CHECK("k_bb");
 }
-/* the special (polar) rows of the plan, after ezhip_minmax_bb on the same arguments */
+extern "C" int ezhip_minmax_bb(const ezhip_sep_plan *plan, const float *d_zin, size_t in_stride, int nfields, unsigned *d_partials, size_t stride_words,
+                               int *d_flags, const float *d_poles, void *d_work)
+{
+    return ezhip_minmax_bb_stage(plan, d_zin, in_stride, nfields, d_partials, stride_words, d_flags, d_poles, d_work, 0);
+}
+/* the special (polar) rows of the plan, after (stage 1 of) ezhip_minmax_bb on the same arguments */
 extern "C" int ezhip_minmax_bb_special(const ezhip_sep_plan *plan, const float *d_zin, size_t in_stride, int nfields, unsigned *d_partials, size_t stride_words,
                                        int *d_flags, const float *d_poles, void *d_work)
 {

@@ -208,6 +208,8 @@ int ezhip_minmax_bb_special(const ezhip_sep_plan *plan, const float *d_zin, size
                             int *d_flags, const float *d_poles, void *d_work);
 int ezhip_minmax_bb(const ezhip_sep_plan *plan, const float *d_zin, size_t in_stride, int nfields, unsigned *d_partials, size_t stride_words,
                     int *d_flags, const float *d_poles, void *d_work);
+int ezhip_minmax_bb_stage(const ezhip_sep_plan *plan, const float *d_zin, size_t in_stride, int nfields, unsigned *d_partials, size_t stride_words,
+                    int *d_flags, const float *d_poles, void *d_work, int stage);
 /* co-resident k_sepx thread blocks on the current device for a given dynamic LDS size (0: unknown) */
 int ezhip_sepx_capacity(int degree, int rows_per_step, size_t lds_bytes);
 size_t ezhip_sepx_lds_bytes(int x_tr, int rows_per_step, int x_prows, int wstride);
