@@ -189,6 +189,11 @@ for k in range(ncases):
             xs = np.zeros(no * mo, np.float32); ys = xs.copy(); R.c_gdxyfll(gr_in, fp(xs), fp(ys), fp(lat_t), fp(lon_t.copy()), no * mo)
             worst = np.maximum(worst, np.minimum(np.abs(-90.0 + (ys.astype(np.float64) - 0.5) * 180.0 / nj), 90.0))
         allowed = 1e-5 + 8 * 6e-8 / np.maximum(np.cos(np.radians(np.minimum(worst[idx], 89.9999))), 1e-7)
+        # round 6: the wind chain's REAL trig is the C library's own (libm_exact.h) and the allowance above is no longer needed for what it was written for -- over 16 x 300
+        # cases the only ones beyond 1e-5 |V| have a Z-on-E TARGET, where the reference's c_gduvfwd passes UNINITIALISED arrays to ez_gfxyfll as its inputs and overwrites the
+        # true lat / lon with the result (gduvfwd.c:66-69: the arguments of the 'Z' / 'E' branch are swapped against the 'E' branch at :47-49): its answer there depends on what the
+        # heap block held before.  Everywhere else the bar is 1e-5 |V|, no allowance.
+        if not (gd[2] == "Z" and gd[4] == "E"): allowed = np.full_like(allowed, 1e-5)
         if rcv != rcv_r: why = f"wind rc {rcv} vs {rcv_r}"
         elif rcv_r < 0: pass
         elif not np.array_equal(m, mp) and np.all(mp | ~m):
@@ -208,13 +213,15 @@ for k in range(ncases):
             why = f"winds: non-finite values of different kinds at {q.size} points, first {int(q[0])}: ({u[q[0]]!r}, {v[q[0]]!r}) vs ({ur[q[0]]!r}, {vr[q[0]]!r}), interpolated components there ({zu[q[0]]!r}, {zv[q[0]]!r})"
         elif e.size and not np.all(e <= allowed):
             w = int(np.argmax(e / allowed)); why = f"wind err {e[w]:.3e} |V| (allowed {allowed[w]:.2e}, |lat| {worst[idx[w]]:.3f}) at {int(idx[w])}: ({u[idx[w]]!r}, {v[idx[w]]!r}) vs ({ur[idx[w]]!r}, {vr[idx[w]]!r})"
-        elif e.size and not np.all(e <= 1e-5): near += 1
+        elif e.size and not np.all(e <= 1e-5):
+            near += 1
+            w = int(np.argmax(e)); print(f"NEAR wind err {e[w]:.3e} |V| (allowed {allowed[w]:.2e}, |lat| {worst[idx[w]]:.4f}; {int(np.count_nonzero(e > 1e-5))} points above 1e-5) at {int(idx[w])}: ({u[idx[w]]!r}, {v[idx[w]]!r}) vs ({ur[idx[w]]!r}, {vr[idx[w]]!r})", desc, flush=True)
     if why:
         bad += 1
         print("MISMATCH", why, desc, flush=True)
 for name, val in (("interp_degree", "cubic"), ("polar_correction", "yes"), ("extrap_degree", "maximum")):
     R.c_ezsetopt(name.encode(), val.encode())
 print(f"product vs reference build (irregular / rotated / polar-stereographic grids): {ran} of {ncases} cases ran, {bad} mismatches "
-      f"({near} cases with wind errors between 1e-5 |V| and the conditioning bound 1e-5 + 4.8e-7 / cos(lat) next to a pole of one of the frames; "
+      f"({near} cases with wind errors between 1e-5 |V| and the conditioning bound 1e-5 + 4.8e-7 / cos(lat) next to a pole of one of the frames -- allowed for Z-on-E TARGETS only, where the reference reads uninitialised memory; "
       f"{overflow} cases where the reference's speed / direction chain overflows REAL and the literal chain of the product, EZHIP_WIND_NO_MATRIX=1, does the same)")
 sys.exit(1 if bad else 0)
