@@ -171,7 +171,7 @@ def test_adversarial_winds_against_the_reference_run(kind, shape, tmp_path):
 @pytest.mark.parametrize("which", ["cfg2", "cfg3"])
 def test_every_scalar_value_against_the_reference_run(which, tmp_path):
     """c_ezsint bicubic with polar correction at BASELINE configs[1] (k_sepx) and on cfg3's grid pair (k_st): ALL output values against the reference's own run in a
-    fresh child -- the sampled rows / columns of tests/test_gpu_interp.py cover 0.5 % of them.  1e-5 relative where |want| >= 1e-3 max|want|, 1e-8 max|want| absolute below."""
+    fresh child -- the sampled rows / columns of tests/test_gpu_interp.py cover 0.5 % of them.  Pure relative error <= 1e-5 at every point (measured: 0 values differ at all)."""
     out = str(tmp_path / "ref.npy")
     r = run_child([sys.executable, os.path.join(HERE, "ref_child.py"), which + "_sint", "--out", out], cwd=ROOT, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -194,9 +194,9 @@ def test_every_scalar_value_against_the_reference_run(which, tmp_path):
         assert ez.ezsint_dev(d_out, d_in) == 0
         torch.cuda.synchronize()
         got = d_out.cpu().numpy().astype(np.float64)
-        d = np.abs(got - want); aw = np.abs(want); big = aw >= aw.max() * 1e-3
-        rel = float((d[big] / aw[big]).max()); ab = float(d[~big].max()) if (~big).any() else 0.0
+        d = np.abs(got - want); aw = np.abs(want)
+        rel = float((d / np.maximum(aw, 1e-30)).max())
         nbits = int(np.count_nonzero(got != want))
-        print("%s c_ezsint call %d: %d of %d values differ from the reference's; max rel %.3g, max abs near zero %.3g" % (which, call, nbits, want.size, rel, ab))
-        assert rel <= TOL_V and ab <= 1e-8 * aw.max(), (which, call, rel, ab)
+        print("%s c_ezsint call %d: %d of %d values differ from the reference's; max relative error %.3g" % (which, call, nbits, want.size, rel))
+        assert rel <= TOL_V, (which, call, rel)
     ez.gdrls(gdout); ez.gdrls(gdin)
