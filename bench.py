@@ -125,6 +125,9 @@ def pack_cpu_baseline(field, ref_interp_s):
     return r
 
 
+CFG3_REF_FILE = None
+
+
 def start_cfg3_reference_child():
     """the reference's c_ezuvint on cfg3 (tests/ref_child.py: oracle/_ref, 1 thread, a stack of its own for the Fortran automatic arrays) in a FRESH process,
     started before this process imports torch or touches a GPU; collected before the warm-up starts (nothing of it runs beside a timed region)."""
@@ -133,7 +136,10 @@ def start_cfg3_reference_child():
     if not os.path.exists(so):
         return None
     try:
-        return subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ref_child.py"), "cfg3_uvint", "--reps", "2"],
+        import tempfile
+        global CFG3_REF_FILE
+        CFG3_REF_FILE = os.path.join(tempfile.mkdtemp(prefix="ezbench_"), "cfg3_ref.npy")      # the reference's (u, v): extras compares the exact-winds mode with it bit for bit
+        return subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ref_child.py"), "cfg3_uvint", "--reps", "2", "--out", CFG3_REF_FILE],
                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT)
     except OSError:
         return None
@@ -319,6 +325,31 @@ def extras(ez, torch, stream, d_out, d_in):
                             "roofline": {"bound": "hbm", "achieved": algo3 / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": algo3 / us / 1e3 / HBM_PEAK_GBPS,
                                          "traffic": t3[0] * 1e6 if t3 else None, "traffic_source": t3[1] if t3 else None,
                                          "kernel": "k_uvt<32,32>", "algorithmic_bytes_per_launch": algo3}}
+        # the exact-winds mode (ezhip_set_wind_exact: the reference's chain as written on every call, scalar kernels in front): time, and every one of its 16 M values
+        # against the reference child's own result, bit for bit
+        try:
+            ez.set_wind_exact(1)
+            assert ez.ezuvint_dev(o_u, o_v, d_u, d_v) >= 0
+            usx = ev_time(lambda: ez.ezuvint_dev(o_u, o_v, d_u, d_v), 5, bursts=3)
+            ex["cfg3_uvint_exact"] = {"workload": "the same with ezhip_set_wind_exact(1)", "dtype": "f64", "us_per_pair": usx}
+            if CFG3_REF_FILE and os.path.exists(CFG3_REF_FILE):
+                ref = np.load(CFG3_REF_FILE)
+                nd = int(np.count_nonzero(o_u.cpu().numpy().view(np.uint32) != ref[0].view(np.uint32)) + np.count_nonzero(o_v.cpu().numpy().view(np.uint32) != ref[1].view(np.uint32)))
+                ex["cfg3_uvint_exact"]["values_differing_from_reference_bits"] = nd
+                ex["cfg3_uvint_exact"]["values_compared"] = int(2 * no * mo)
+                del ref
+        finally:
+            ez.set_wind_exact(0)
+        assert ez.ezuvint_dev(o_u, o_v, d_u, d_v) >= 0
+        if CFG3_REF_FILE and os.path.exists(CFG3_REF_FILE):      # ... and the default (fast) mode's distance from the same field
+            ref = np.load(CFG3_REF_FILE)
+            gu = o_u.cpu().numpy().astype(np.float64); gv = o_v.cpu().numpy().astype(np.float64)
+            ex["cfg3_uvint"]["max_err_vs_reference_in_V"] = float((np.maximum(np.abs(gu - ref[0]), np.abs(gv - ref[1])) / np.maximum(np.hypot(ref[0].astype(np.float64), ref[1].astype(np.float64)), 1e-3)).max())
+            del ref, gu, gv
+            try:
+                os.remove(CFG3_REF_FILE); os.rmdir(os.path.dirname(CFG3_REF_FILE))
+            except OSError:
+                pass
         # several pairs of the same grid set at once (wind levels): c_ezuvint_batch_dev reads x, y and the rotation of a point once per batch (12 of a pair's 34 bytes
         # per point) -- one launch of k_uvt's batch form, the special points' kernel once with a pair index; results equal to single calls bit for bit
         KB = 8

@@ -93,6 +93,14 @@ void ez_xpncof(int32_t *i1, int32_t *i2, int32_t *j1, int32_t *j2, int32_t *exte
  * beforehand.  Later calls of the set only enqueue.  The caches live until c_gdrls of either grid.  Their total is bounded by a byte budget (default 4 GiB,
  * EZHIP_CACHE_MB at first use, or the call below); a set that does not fit keeps the gathering kernels: same results, slower. */
 void ezhip_set_cache_budget_mb(int32_t mb);                 /* 0: no staged-tile caches at all */
+/* additive (round 6): EXACT WINDS for c_ezuvint / c_ezwdint and their _dev forms.  Default (0): the wind chain of a grid pair (c_gdwdfuv + c_gduvfwd, gdwdfuv.c:29-100,
+ * gduvfwd.c:29-96) is applied as a per-point 2 x 2 matrix made once per set from the chain itself, bicubic pairs from rotated sources are evaluated in REAL with a REAL*8 second
+ * pass: within 2e-6 |V| of the reference (the size of the chain's own noise: its wind direction passes through REAL degrees).  1: every call runs the reference's chain as written
+ * (speed / direction through REAL degrees, the C library's REAL trig restated in libm_exact.h, REAL*8 where the reference has it) on components interpolated by the scalar kernels:
+ * at BASELINE configs[2] all 16 M values of nearest, bilinear and bicubic winds equal the reference build's BIT FOR BIT -- at ~5 x the time
+ * (tests/test_gpu_wind_pin.py).  Process-wide. */
+void ezhip_set_wind_exact(int32_t on);
+int32_t ezhip_get_wind_exact(void);
 long long ezhip_cache_bytes(void);                           /* bytes the staged-tile caches of all sets hold now */
 /* Rotated sources ('E', Z-on-'E') are located on the device with the C library's REAL sinf / cosf / asinf / atan2f restated operation by operation
  * (librmn_amd/csrc/libm_exact.h: GNU libc 2.35, x86-64 FMA variants -- what the reference's ez_gfxyfll.c:38-57 reaches through the Fortran intrinsics on such a host).

@@ -2725,13 +2725,23 @@ static __thread struct { int n, refused; size_t in_stride, out_stride; } t_pairs
 /* the polar wind rows of the pair being interpolated, handed from uvint_impl to the per-point pair launch (per host thread) */
 static __thread struct { float *out; const float *plon2, *ax; float xg4_n, xg4_s; int weighted, active; } t_pwjob;
 /* both components of a wind pair on the per-point path in ONE pass (k_pts2); returns -2 when the set is not on that path */
+/* additive (round 6): EXACT WINDS.  By default c_ezuvint applies the wind chain of a grid pair as a per-point 2 x 2 matrix made once per set from the chain itself, and
+ * evaluates bicubic pairs from rotated sources in REAL with a REAL*8 second pass: within 2e-6 |V| of the reference (the chain's own noise: its direction passes through REAL
+ * degrees) at 58 - 70 us per cfg3 pair.  With ezhip_set_wind_exact(1) every call runs the reference's chain as written (k_wind_rotate: speed / direction through REAL degrees, the C
+ * library's REAL trig from libm_exact.h, REAL*8 where the reference has it) on components interpolated by the scalar kernels, pole rows included: at cfg3 the 16 M values of
+ * nearest, bilinear and bicubic winds equal the reference build's BIT FOR BIT -- at ~290 us per pair.  Process-wide; 0 switches back. */
+static int g_wind_exact = 0;
+void ezhip_set_wind_exact(int32_t on) { g_wind_exact = on ? 1 : 0; }
+int32_t ezhip_get_wind_exact(void) { return g_wind_exact; }
+#define WIND_EXACT() (g_wind_exact != 0)
+
 static int run_pair_pts(ezh_set *s, float *d_uo, float *d_vo, const float *d_ui, const float *d_vi,
                         const float *pun, const float *pus, const float *pvn, const float *pvs, const void *d_M, int m_half, int dst_rot)
 {
     ezh_grid *gi = &G[s->gdin], *go = &G[s->gdout];
     int degree = O.degre_interp, polar = O.polar_correction == 1;
     if (degree != DEG_NEAREST && degree != DEG_LINEAR && degree != DEG_CUBIC) return -2;
-    if (getenv("EZHIP_NO_PTS2") || src_hemi(gi) || grid_yinv(gi)) return -2;
+    if (getenv("EZHIP_NO_PTS2") || WIND_EXACT() || src_hemi(gi) || grid_yinv(gi)) return -2;
     pthread_mutex_lock(&g_plan_mtx);
     int mode = choose_mode(s, degree, polar);
     pthread_mutex_unlock(&g_plan_mtx);
@@ -3541,7 +3551,7 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
             /* on the side stream: only the special points (k_pts_special, or the special rows of the separable kernel) read
              * these rows, the main kernels of both components overlap the 44 us of sequential pole sums */
             int per_point = 0;
-            if (!same && (O.degre_interp == DEG_NEAREST || O.degre_interp == DEG_LINEAR || O.degre_interp == DEG_CUBIC) && !getenv("EZHIP_NO_PTS2")) {
+            if (!same && (O.degre_interp == DEG_NEAREST || O.degre_interp == DEG_LINEAR || O.degre_interp == DEG_CUBIC) && !getenv("EZHIP_NO_PTS2") && !WIND_EXACT()) {
                 pthread_mutex_lock(&g_plan_mtx);
                 per_point = choose_mode(s, O.degre_interp, polar) == 2;
                 pthread_mutex_unlock(&g_plan_mtx);
@@ -3551,7 +3561,7 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
                 t_pwjob.weighted = weighted; t_pwjob.ax = gi->d_ax; t_pwjob.active = 1;
             } else {
                 if (ezhip_side_begin()) return -1;
-                int prc = ezhip_polar_wind(s->d_prow, d_uuin, d_vvin, gi->d_plon2, ni, nj, gi->xg4_pole[0], gi->xg4_pole[1], weighted, gi->d_ax);
+                int prc = ezhip_polar_wind(s->d_prow, d_uuin, d_vvin, gi->d_plon2, ni, nj, gi->xg4_pole[0], gi->xg4_pole[1], weighted, gi->d_ax, WIND_EXACT());
                 if (ezhip_side_end() || prc) return -1;
             }
         }
@@ -3613,7 +3623,7 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
      * k_pts2 as it stores (per-point sets), or k_wind_apply after the separable launches (k_wind_rotate: 112 us per cfg3 pair) */
     const void *d_M = NULL;
     int m_half = 0;
-    if (!wd_only && (wp.src_rotated || wp.dst_rotated) && !getenv("EZHIP_WIND_NO_MATRIX") &&
+    if (!wd_only && (wp.src_rotated || wp.dst_rotated) && !getenv("EZHIP_WIND_NO_MATRIX") && !WIND_EXACT() &&
         20 * (size_t)go->ni * go->nj <= ((size_t)3 << 30)) {           /* 16 + 4 bytes per target point, kept with the set: up to 3 GiB, beyond that the chain runs per call */
         pthread_mutex_lock(&g_plan_mtx);
         int mrc = 0;
@@ -3641,7 +3651,7 @@ static int32_t uvint_body(float *d_uuout, float *d_vvout, const float *d_uuin, c
         t_pwjob.active = 0;
         if (r1 != -1) {
             if (ezhip_side_begin()) return -1;
-            int prc = ezhip_polar_wind(t_pwjob.out, d_uuin, d_vvin, t_pwjob.plon2, ni, nj, t_pwjob.xg4_n, t_pwjob.xg4_s, t_pwjob.weighted, t_pwjob.ax);
+            int prc = ezhip_polar_wind(t_pwjob.out, d_uuin, d_vvin, t_pwjob.plon2, ni, nj, t_pwjob.xg4_n, t_pwjob.xg4_s, t_pwjob.weighted, t_pwjob.ax, 0);
             if (ezhip_side_end() || prc) return -1;
         }
     }
@@ -3672,7 +3682,7 @@ static int pair_batch_ready(ezh_set *s)
     if (G[s->gdin].grtyp == 'U' || G[s->gdout].grtyp == 'U' || s->gdin == s->gdout) return 0;
     const int degree = O.degre_interp, polar = O.polar_correction == 1;
     if (degree != DEG_CUBIC) return 0;
-    if (getenv("EZHIP_POLAR_WIND_HOST") || getenv("EZHIP_NO_PTS2") || getenv("EZHIP_NO_UVT") || getenv("EZHIP_WIND_NO_FUSE") || getenv("EZHIP_WIND_NO_MATRIX") ||
+    if (WIND_EXACT() || getenv("EZHIP_POLAR_WIND_HOST") || getenv("EZHIP_NO_PTS2") || getenv("EZHIP_NO_UVT") || getenv("EZHIP_WIND_NO_FUSE") || getenv("EZHIP_WIND_NO_MATRIX") ||
         getenv("EZHIP_WIND_FULL_MATRIX") || getenv("EZHIP_UVT_NO_STREAMS") || getenv("EZHIP_NO_SPEC_CACHE") || getenv("EZHIP_NO_PAIR_BATCH")) return 0;
     if (polar && s->extrap && s->have_dehors) return 0;          /* (a fill value per pair: pair by pair) */
     const int zones = !polar ? 0 : (s->extrap ? 2 : 1);

@@ -2130,30 +2130,31 @@ extern "C" int ezhip_minmax_bb_special(const ezhip_sep_plan *plan, const float *
  * matrix is made from) are libm_exact.h's (GNU libc's, operation by operation: the reference reaches them through the Fortran intrinsics) since round 6: the device
  * library's own differ by <= 2 ulp, which the rotated frame's atan2f(q1, q0) next to a rotated pole (|q| ~ 1e-3) turns into 3e-5 |V| of wind direction -- found by
  * comparing ALL of cfg3's 16 M values with the reference run (tests/test_gpu_wind_pin.py); the sampled rows / columns of the earlier test had missed the 122 points. */
-/* (the pole rows keep the device library's REAL functions: nothing amplifies their <= 2 ulp here -- EZHIP_POLAR_WIND_HOST=1, the C library's own, moves no cfg3 value by
- * more than 2e-7 |V| -- and libm_exact.h's versions in the two producer blocks of k_uvt made them the launch's long pole: 69 -> 73 us per cfg3 pair, profiles/r06_experiments.txt) */
-#define PW_ATAN2 atan2f
-#define PW_COS cosf
-#define PW_SIN sinf
+/* (the pole rows of the pair kernels keep the device library's REAL functions: nothing amplifies their <= 2 ulp here -- EZHIP_POLAR_WIND_HOST=1, the C library's own, moves no cfg3
+ * value by more than 2e-7 |V| -- and libm_exact.h's versions in the two producer blocks of k_uvt made them the launch's long pole: 69 -> 73 us per cfg3 pair, profiles/r06_experiments.txt.
+ * EXACT = true: the standalone k_polar_wind of the exact-winds mode, ezhip_set_wind_exact) */
+template <bool EXACT>
 __device__ __forceinline__ void d_llwfgdw1(float &z1, float &z2, float xlon, char t, float xg4)
 {
     const float RDTODG = 57.295779513082f;
     float uu = z1, vv = z2, spd = sqrtf(uu * uu + vv * vv), dir;
+    const float at = (spd == 0.0f || uu == 0.0f) ? 0.0f : (EXACT ? glx_atan2f(vv, uu) : atan2f(vv, uu));
     if (spd == 0.0f) dir = 0.0f;
-    else if (t == 'N') dir = (uu == 0.0f) ? ((vv >= 0.0f) ? xlon + xg4 - 90.0f : xlon + xg4 + 90.0f) : xlon + xg4 - RDTODG * PW_ATAN2(vv, uu);
-    else if (t == 'S') dir = (uu == 0.0f) ? ((vv >= 0.0f) ? 90.0f - xlon + xg4 : 270.0f - xlon + xg4) : 180.0f - xlon + xg4 - RDTODG * PW_ATAN2(vv, uu);
-    else dir = (uu == 0.0f) ? ((vv >= 0.0f) ? 180.0f : 0.0f) : 270.0f - RDTODG * PW_ATAN2(vv, uu);
+    else if (t == 'N') dir = (uu == 0.0f) ? ((vv >= 0.0f) ? xlon + xg4 - 90.0f : xlon + xg4 + 90.0f) : xlon + xg4 - RDTODG * at;
+    else if (t == 'S') dir = (uu == 0.0f) ? ((vv >= 0.0f) ? 90.0f - xlon + xg4 : 270.0f - xlon + xg4) : 180.0f - xlon + xg4 - RDTODG * at;
+    else dir = (uu == 0.0f) ? ((vv >= 0.0f) ? 180.0f : 0.0f) : 270.0f - RDTODG * at;
     dir = fmodf(fmodf(dir, 360.0f) + 360.0f, 360.0f);
     z1 = spd; z2 = dir;
 }
+template <bool EXACT>
 __device__ __forceinline__ void d_gdwfllw1(float &z1, float &z2, float xlon, char t, float xg4)
 {
     const float DGTORD = 1.7453292519943e-2f;
     float psi = t == 'N' ? xlon + xg4 - z2 : t == 'S' ? 180.0f - xlon + xg4 - z2 : 270.0f - z2;
-    float u = PW_COS(psi * DGTORD) * z1, v = PW_SIN(psi * DGTORD) * z1;
+    float u = (EXACT ? glx_cosf(psi * DGTORD) : cosf(psi * DGTORD)) * z1, v = (EXACT ? glx_sinf(psi * DGTORD) : sinf(psi * DGTORD)) * z1;
     z1 = u; z2 = v;
 }
-template <int CHUNK>
+template <int CHUNK, bool EXACT = false>
 __device__ __forceinline__ void polar_wind_body(const int north, float *out, const float *uu, const float *vv, const float *plon2 /* [north row | south row] */,
                                                 int ni, int nj, float xg4_n, float xg4_s, int weighted, const float *ax, float *lds /* CHUNK + 4 floats, 16-byte aligned */)
 {
@@ -2164,27 +2165,28 @@ __device__ __forceinline__ void polar_wind_body(const int north, float *out, con
     float *pu = out + (north ? 0 : ni), *pv = out + 2 * (size_t)ni + (north ? 0 : ni);
     for (int i = threadIdx.x; i < ni; i += 256) {          /* speed / direction on the lat-lon frame, then polar-stereographic components */
         float a = urow[i], b = vrow[i];
-        d_llwfgdw1(a, b, plon[i], 'A', 0.f);
-        d_gdwfllw1(a, b, plon[i], hs, xg4);
+        d_llwfgdw1<EXACT>(a, b, plon[i], 'A', 0.f);
+        d_gdwfllw1<EXACT>(a, b, plon[i], hs, xg4);
         pu[i] = a; pv[i] = b;
     }
     __threadfence_block();
     __syncthreads();
     float s0, w0;
     block_poleval2(pu, pv, ni, weighted, ax, lds, CHUNK / 2, s0, w0, 256);
-    d_llwfgdw1(s0, w0, 0.0f, hs, xg4);
+    d_llwfgdw1<EXACT>(s0, w0, 0.0f, hs, xg4);
     __syncthreads();
     for (int i = threadIdx.x; i < ni; i += 256) {
         float spd = s0, wd = (i == 0 || north) ? w0 + plon[i] : w0 - plon[i];
-        d_gdwfllw1(spd, wd, plon[i], 'A', 0.f);
+        d_gdwfllw1<EXACT>(spd, wd, plon[i], 'A', 0.f);
         pu[i] = spd; pv[i] = wd;
     }
 }
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k_polar_wind(float *out, const float *uu, const float *vv, const float *plon2, int ni, int nj, float xg4_n, float xg4_s,
                                                     int weighted, const float *ax)
 {
     __shared__ __attribute__((aligned(16))) float lds[POLE_CHUNK + 4];
-    polar_wind_body<POLE_CHUNK>(blockIdx.x == 0, out, uu, vv, plon2, ni, nj, xg4_n, xg4_s, weighted, ax, lds);
+    polar_wind_body<POLE_CHUNK, EXACT>(blockIdx.x == 0, out, uu, vv, plon2, ni, nj, xg4_n, xg4_s, weighted, ax, lds);
 }
 /* ez_corrbgd.inc:20-55 (called at the end of ez_corrval for a Z- or #-on-E source and a 'B' target, ez_corrval.c:146-148): the rows of the
  * target at the poles become their mean -- a sequential REAL sum over the row divided by ni * 1.0 (block_poleval, unweighted).
@@ -2205,9 +2207,10 @@ extern "C" int ezhip_corrbgd(float *d_zout, int ni, int nj, int hem)
     return LAUNCH_CHECK("k_corrbgd");
 }
 extern "C" int ezhip_polar_wind(float *d_out4, const float *d_uu, const float *d_vv, const float *d_plon2, int ni, int nj,
-                                float xg4_n, float xg4_s, int weighted, const float *d_ax)
+                                float xg4_n, float xg4_s, int weighted, const float *d_ax, int exact)
 {
-    hipLaunchKernelGGL(k_polar_wind, dim3(2), dim3(256), 0, g_stream, d_out4, d_uu, d_vv, d_plon2, ni, nj, xg4_n, xg4_s, weighted, d_ax);
+    if (exact) hipLaunchKernelGGL(k_polar_wind<true>, dim3(2), dim3(256), 0, g_stream, d_out4, d_uu, d_vv, d_plon2, ni, nj, xg4_n, xg4_s, weighted, d_ax);
+    else hipLaunchKernelGGL(k_polar_wind<false>, dim3(2), dim3(256), 0, g_stream, d_out4, d_uu, d_vv, d_plon2, ni, nj, xg4_n, xg4_s, weighted, d_ax);
     return LAUNCH_CHECK("k_polar_wind");
 }
 
@@ -3949,7 +3952,7 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     if (pu2.pw_out && (!fast3w || getenv("EZHIP_POLAR_WIND_SIDE"))) {
         /* kernels without the producer blocks: the rows come from k_polar_wind on the side stream, joined below before the special points */
         if (ezhip_side_begin()) return -1;
-        hipLaunchKernelGGL(k_polar_wind, dim3(2), dim3(256), 0, g_stream, pu2.pw_out, d_in_u, d_in_v, pu2.pw_plon2, pu2.ni, pu2.nj, pu2.pw_xg4_n, pu2.pw_xg4_s, pu2.pw_weighted, pu2.pw_ax);
+        hipLaunchKernelGGL(k_polar_wind<false>, dim3(2), dim3(256), 0, g_stream, pu2.pw_out, d_in_u, d_in_v, pu2.pw_plon2, pu2.ni, pu2.nj, pu2.pw_xg4_n, pu2.pw_xg4_s, pu2.pw_weighted, pu2.pw_ax);
         const int bad = LAUNCH_CHECK("k_polar_wind");
         if (ezhip_side_end() || bad) return -1;
         pu2.pw_out = nullptr;

@@ -350,7 +350,7 @@ int ezhip_side_begin(void);
 int ezhip_side_end(void);
 int ezhip_side_join(void);
 int ezhip_polar_wind(float *d_out4, const float *d_uu, const float *d_vv, const float *d_plon2, int ni, int nj,
-                     float xg4_n, float xg4_s, int weighted, const float *d_ax);
+                     float xg4_n, float xg4_s, int weighted, const float *d_ax, int exact);
 
 /* in place on (uu, vv): source-grid components -> target ('L'-like) grid components */
 /* the chain of a grid pair as a 2 x 2 matrix per point (16 bytes each): built once, applied per call */

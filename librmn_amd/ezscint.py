@@ -216,6 +216,13 @@ def set_mode():
     return _lib().ezhip_set_mode()
 
 
+def set_wind_exact(on):
+    """ezhip_set_wind_exact: 1 = c_ezuvint runs the reference's wind chain as written on every call (bit-exact nearest / bilinear winds), 0 = the per-point matrix (default)"""
+    L = _lib()
+    L.ezhip_set_wind_exact.argtypes = [ctypes.c_int32]; L.ezhip_set_wind_exact.restype = None
+    L.ezhip_set_wind_exact(int(on))
+
+
 def set_xy_dev(x, y):
     L = _lib()
     L.ezhip_set_xy_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -5,7 +5,7 @@ cfg3's 8 M points need ~200 MB of stack, so the calls run on a thread whose stac
 already holds GPU mappings must not fork -- the GPU suite asks its fork-server (tests/conftest.py, created before the first GPU call) to start this file,
 bench.py starts it before it imports torch.  It never touches a GPU and reads nothing but the repository copy (oracle/_ref travels with the snapshot).
 
-    python tests/ref_child.py cfg3_uvint [--reps N] [--out FILE.npy]
+    python tests/ref_child.py cfg3_uvint [--reps N] [--out FILE.npy] [--degree 0|1|3] [--polar 0|1]
         the reference's c_ezuvint (src/interp/ezuvint.c:51-94) on BASELINE configs[2]: Z-on-E 2560x1280 -> L 4000x2000, bicubic, polar correction,
         inputs = tests/golden/make_cfg3_full.py's.  Prints one JSON line {first_s, s_per_pair, reps, rc}; --out: the two result fields as a
         float32 [2, 8 M] array (u, v).
@@ -43,7 +43,9 @@ def cfg3_uvint(argv):
     gdin = L.c_ezgdef_fmem(ni, nj, b"Z", b"E", *ec.E_IG, fp(ax), fp(ay))
     gdout = L.c_ezqkdef(no, mo, b"L", 9, 9, 0, 0, 0)
     assert gdin >= 0 and gdout >= 0 and L.c_ezdefset(gdout, gdin) == 1
-    L.c_ezsetopt(b"interp_degree", b"cubic"); L.c_ezsetopt(b"polar_correction", b"yes")
+    degree = int(argv[argv.index("--degree") + 1]) if "--degree" in argv else 3
+    polar = int(argv[argv.index("--polar") + 1]) if "--polar" in argv else 1
+    L.c_ezsetopt(b"interp_degree", DEG[degree]); L.c_ezsetopt(b"polar_correction", b"yes" if polar else b"no")
     uu, vv = cfg3_inputs()
     uv = np.zeros((2, no * mo), np.float32)
     t0 = time.perf_counter()

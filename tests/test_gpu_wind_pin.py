@@ -73,11 +73,11 @@ def _compare(tag, u, v, ur, vr, meff):
     return float(relv.max()), float(relm.max()), calm
 
 
-def _product(ni, nj, no, mo, ig_src, ax, ay, dst_ig, uu, vv):
+def _product(ni, nj, no, mo, ig_src, ax, ay, dst_ig, uu, vv, degree="cubic", polar="yes"):
     """both calls of a set (first: gathering kernel + special-point listing; second: staged windows), x, y of the set"""
     gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ig_src, ax, ay); gdout = ez.ezqkdef(no, mo, "L", *dst_ig)
     assert ez.ezdefset(gdout, gdin) == 1
-    _setopts()
+    assert ez.ezsetopt("interp_degree", degree) == 0 and ez.ezsetopt("polar_correction", polar) == 0
     ez.use_stream(torch.cuda.current_stream().cuda_stream)
     d_u = torch.from_numpy(uu).cuda(); d_v = torch.from_numpy(vv).cuda()
     outs = []
@@ -91,7 +91,56 @@ def _product(ni, nj, no, mo, ig_src, ax, ay, dst_ig, uu, vv):
     torch.cuda.synchronize()
     x, y = d_x.cpu().numpy(), d_y.cpu().numpy()
     ez.gdrls(gdout); ez.gdrls(gdin)
+    _setopts()
     return outs, x, y
+
+
+@pytest.mark.parametrize("degree,polar", [(1, 1), (0, 1), (3, 0)])
+def test_cfg3_every_wind_value_other_options(degree, polar, tmp_path):
+    """the same whole-field comparison for bilinear and nearest-neighbour winds (other kernels in front of the same wind chain) and without the polar correction"""
+    ni, nj, no, mo = 2560, 1280, 4000, 2000
+    out = str(tmp_path / "cfg3_ref.npy")
+    r = run_child([sys.executable, os.path.join(HERE, "ref_child.py"), "cfg3_uvint", "--reps", "0", "--out", out, "--degree", str(degree), "--polar", str(polar)], cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = np.load(out)
+    ax, ay = ec.ze_axes(ni, nj)
+    uu, vv = ec.synth_wind(ni, nj, seed=3)
+    for a in (uu, vv):
+        a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+    outs, x, y = _product(ni, nj, no, mo, ec.E_IG, ax, ay, (9, 9, 0, 0), uu, vv, {0: "nearest", 1: "linear", 3: "cubic"}[degree], "yes" if polar else "no")
+    for call, (pu, pv) in enumerate(outs):
+        e = np.maximum(np.abs(pu.astype(np.float64) - ref[0]), np.abs(pv.astype(np.float64) - ref[1]))
+        V = np.maximum(np.hypot(ref[0].astype(np.float64), ref[1].astype(np.float64)), 1e-3)
+        rel = e / V
+        k = int(np.argmax(rel))
+        print("cfg3 winds degree %d polar %d call %d: max err %.3g |V| over %d values (%d values differ at all)" % (degree, polar, call, rel[k], 2 * no * mo, int(np.count_nonzero(pu != ref[0]) + np.count_nonzero(pv != ref[1]))))
+        assert rel[k] <= TOL_V, (degree, polar, call, float(rel[k]), k, float(ref[0][k]), float(ref[1][k]), float(pu[k]), float(pv[k]))
+
+
+@pytest.mark.parametrize("degree", [0, 1, 3])
+def test_cfg3_exact_winds_equal_the_reference_bit_for_bit(degree, tmp_path):
+    """ezhip_set_wind_exact(1): the reference's wind chain as written on every call (k_wind_rotate with the C library's REAL trig) on components from the scalar kernels.
+    Nearest, bilinear AND bicubic winds at cfg3: all 16 M values equal the reference build's bit for bit (with the pole rows from the device library's trig nine bicubic
+    values differed in the last place: the exact mode's k_polar_wind uses libm_exact.h too)."""
+    ni, nj, no, mo = 2560, 1280, 4000, 2000
+    out = str(tmp_path / "cfg3_ref.npy")
+    r = run_child([sys.executable, os.path.join(HERE, "ref_child.py"), "cfg3_uvint", "--reps", "0", "--out", out, "--degree", str(degree)], cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = np.load(out)
+    ax, ay = ec.ze_axes(ni, nj)
+    uu, vv = ec.synth_wind(ni, nj, seed=3)
+    for a in (uu, vv):
+        a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+    ez.set_wind_exact(1)
+    try:
+        outs, x, y = _product(ni, nj, no, mo, ec.E_IG, ax, ay, (9, 9, 0, 0), uu, vv, {0: "nearest", 1: "linear", 3: "cubic"}[degree], "yes")
+    finally:
+        ez.set_wind_exact(0)
+    for call, (pu, pv) in enumerate(outs):
+        ndiff = int(np.count_nonzero(pu.view(np.uint32) != ref[0].view(np.uint32)) + np.count_nonzero(pv.view(np.uint32) != ref[1].view(np.uint32)))
+        e = np.maximum(np.abs(pu.astype(np.float64) - ref[0]), np.abs(pv.astype(np.float64) - ref[1])) / np.maximum(np.hypot(ref[0].astype(np.float64), ref[1].astype(np.float64)), 1e-3)
+        print("cfg3 exact winds degree %d call %d: %d of %d values differ from the reference's bits (max %.3g |V|)" % (degree, call, ndiff, 2 * no * mo, e.max()))
+        assert ndiff == 0, ndiff
 
 
 def test_cfg3_every_wind_value_against_the_reference_run(tmp_path):

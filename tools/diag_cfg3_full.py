@@ -16,7 +16,7 @@ for var in (sys.argv[2:] or [""]):
         k, val = kv.split("="); os.environ[k] = val
     g_in = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay); g_out = ez.ezqkdef(no, mo, "L", 9, 9, 0, 0)
     assert ez.ezdefset(g_out, g_in) == 1
-    ez.ezsetopt("interp_degree", "cubic"); ez.ezsetopt("polar_correction", "yes")
+    ez.ezsetopt("interp_degree", os.environ.get("DIAG_DEGREE", "cubic")); ez.ezsetopt("polar_correction", "yes")
     d_u = torch.from_numpy(uu).cuda(); d_v = torch.from_numpy(vv).cuda()
     o_u = torch.zeros(no * mo, device="cuda"); o_v = torch.zeros_like(o_u)
     for call in range(2):
@@ -25,7 +25,7 @@ for var in (sys.argv[2:] or [""]):
         u = o_u.cpu().numpy().astype(np.float64); v = o_v.cpu().numpy().astype(np.float64)
         e = np.maximum(np.abs(u - ur), np.abs(v - vr)) / V
         bad = np.nonzero(e > 5e-6)[0]
-        print(f"[{var or 'defaults'}] call {call}: max {e.max():.3g} |V|; {bad.size} points above 5e-6; 99.99 pct {np.quantile(e, 0.9999):.3g}", flush=True)
+        print(f"[{var or 'defaults'}] call {call}: max {e.max():.3g} |V|; {bad.size} points above 5e-6; 99.99 pct {np.quantile(e, 0.9999):.3g}; values that differ at all: {int(np.count_nonzero(u != ur) + np.count_nonzero(v != vr))}", flush=True)
         if call == 1 and bad.size:
             d_x = torch.empty(no * mo, device="cuda"); d_y = torch.empty_like(d_x); ez.set_xy_dev(d_x, d_y); torch.cuda.synchronize()
             x = d_x.cpu().numpy(); y = d_y.cpu().numpy()
