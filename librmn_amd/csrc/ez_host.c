@@ -2136,6 +2136,37 @@ static int libm_exact_matches_host(void)
     return ok;
 }
 int32_t ezhip_libm_exact_matches_host(void) { return libm_exact_matches_host(); }
+/* The in-place edits the reference's locate makes to the longitudes it is handed -- for the x, y of a grid set those are the TARGET grid's cached longitudes
+ * (ez_calcxy.c:41-57: Grille[gdout].lon itself), which c_ezuvint's wind chain reads afterwards (and c_gdll returns): ez_ll2rgd.inc:137-145 for an 'L'
+ * source, ez_llll2gd.inc:40-45 behind every regular and Z-on-L source.  h_locate makes them as it goes; this is the same without the locate, for targets whose 2-D longitudes
+ * were located on the device or on copies (round 6: with them the exact-winds mode equals the reference bit for bit on regional 'L' sources too).  Returns 1 when something changed. */
+static int h_lon_edits(const ezh_grid *g, float *lon, size_t n)
+{
+    float lat0, lon0, dlat, dlon, lonref = 0.0f;
+    int changed = 0;
+    switch (g->grtyp) {
+    case 'A': case 'B':
+        break;                                              /* (lon < 0 -> + 360: the rule of ez_llll2gd below) */
+    case 'L':
+        h_cigaxg('L', &lat0, &lon0, &dlat, &dlon, g->ig[0], g->ig[1], g->ig[2], g->ig[3]);
+        for (size_t i = 0; i < n; i++) {
+            const float v = lon[i];
+            if (lon[i] < lon0) lon[i] = lon[i] + 360.0f;
+            if (lon[i] > (lon0 + (float)g->ni * dlon)) lon[i] = lon[i] - 360.0f;
+            if (lon[i] != v) changed = 1;
+        }
+        break;
+    case 'G': case 'Z':
+        if (g->grref != 'L') return 0;                      /* a rotated frame: the locate works on the rotated copies */
+        lonref = (g->ax[0] < 0.0f) ? -180.0f : 0.0f;
+        break;
+    default:
+        return 0;                                           /* E, N, S, !: nothing is edited */
+    }
+    if (lonref == -180.0f) { for (size_t i = 0; i < n; i++) if (lon[i] > 180.0f) { lon[i] = lon[i] - 360.0f; changed = 1; } }
+    else { for (size_t i = 0; i < n; i++) if (lon[i] < 0.0f) { lon[i] = lon[i] + 360.0f; changed = 1; } }
+    return changed;
+}
 static int ensure_points(ezh_set *s)
 {
     if (s->d_x) return 0;
@@ -2190,6 +2221,8 @@ static int ensure_points(ezh_set *s)
     free(hx); free(hy);
     if (trace) { t1 = wall_ms(); fprintf(stderr, "ensure_points: outside-the-source test %.2f ms\n", t1 - t0); }
     if (rc) { ezhip_free(dx); ezhip_free(dy); return -1; }
+    /* a target with 2-D coordinates: the reference's locate has edited its cached longitudes as it went (a separable target's 1-D ones: analyse_set) */
+    if (!go->separable && go->lon2d && h_lon_edits(gi, go->lon2d, n)) go->d_coords_valid = 0;
     s->d_y = dy; s->d_x = dx;
     return 0;
 }
