@@ -123,8 +123,16 @@ def main():
             MODES[sys.argv[1]](sys.argv[2:]); res["rc"] = 0
         except BaseException as e:      # noqa: BLE001
             sys.stderr.write("ref_child: %r\n" % (e,)); res["rc"] = 1
-    threading.stack_size(2 << 30)       # the Fortran automatic arrays: 24 B per target point and more, on the calling thread's stack
-    t = threading.Thread(target=run); t.start(); t.join()
+    # the Fortran automatic arrays: 24 B per target point and more, on the calling thread's stack (cfg2's 26 M points: ~0.7 GB).  The reservation is virtual; where a
+    # 2 GB thread stack is refused, smaller ones are tried
+    for size in (2 << 30, 1 << 30, 768 << 20, 512 << 20):
+        try:
+            threading.stack_size(size)
+            t = threading.Thread(target=run); t.start()
+        except (ValueError, RuntimeError):
+            continue
+        t.join()
+        break
     return res.get("rc", 1)
 
 
