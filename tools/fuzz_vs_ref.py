@@ -12,6 +12,7 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 DEG = {0: "nearest", 1: "linear", 3: "cubic"}
 bad = ran = 0
+cub_cases = cub_same = wind_cases = wind_same = 0
 for k in range(ncases):
     st = str(rng.choice(["G", "A", "B", "L", "Lreg", "Ghem", "Ahem"]))
     nj = int(rng.integers(12, 80)) * 2; ni = 2 * nj if st in ("G", "Ghem") else int(rng.integers(30, 220))
@@ -53,8 +54,12 @@ for k in range(ncases):
     if ok:
         if degree == 3: ok = bool(np.all(np.abs(z - zr) <= 1e-5 * np.maximum(np.abs(zr), 1e-30)))
         else: ok = np.array_equal(z.view(np.uint32), zr.view(np.uint32))
+    if ok and degree == 3: cub_cases += 1; cub_same += int(np.array_equal(z.view(np.uint32), zr.view(np.uint32)))
     if ok and winds:
+        if os.environ.get("FUZZ_WIND_EXACT"): ez.set_wind_exact(1)
         rcv, u, v = ez.ezuvint(uu, vv, no * mo)
+        ez.set_wind_exact(0)
+        wind_cases += 1; wind_same += int(rcv == rcv_r and np.array_equal(u.view(np.uint32), ur.view(np.uint32)) and np.array_equal(v.view(np.uint32), vr.view(np.uint32)))
         sc = np.maximum(np.hypot(ur.astype(np.float64), vr.astype(np.float64)), 1e-3)
         ok = rcv == rcv_r and bool(np.all(np.abs(u - ur) <= 1e-5 * sc) and np.all(np.abs(v - vr) <= 1e-5 * sc))
     if not ok:
@@ -63,4 +68,5 @@ for k in range(ncases):
 for name, val in (("interp_degree", "cubic"), ("polar_correction", "yes"), ("extrap_degree", "maximum")):
     R.c_ezsetopt(name.encode(), val.encode())
 print(f"product vs reference build: {ran} of {ncases} cases ran, {bad} mismatches")
+print(f"  bit for bit: bicubic scalars {cub_same} of {cub_cases} cases; winds{' (exact mode)' if os.environ.get('FUZZ_WIND_EXACT') else ''} {wind_same} of {wind_cases} cases")
 sys.exit(1 if bad else 0)
