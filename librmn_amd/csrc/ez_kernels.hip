@@ -2133,6 +2133,13 @@ extern "C" int ezhip_minmax_bb_special(const ezhip_sep_plan *plan, const float *
 /* (the pole rows of the pair kernels keep the device library's REAL functions: nothing amplifies their <= 2 ulp here -- EZHIP_POLAR_WIND_HOST=1, the C library's own, moves no cfg3
  * value by more than 2e-7 |V| -- and libm_exact.h's versions in the two producer blocks of k_uvt made them the launch's long pole: 69 -> 73 us per cfg3 pair, profiles/r06_experiments.txt.
  * EXACT = true: the standalone k_polar_wind of the exact-winds mode, ezhip_set_wind_exact) */
+/* fmodf(x, 360.0f), AMOD(x, 360.) of ez_llwfgdw.inc: x - 360 trunc(x / 360), always exact.  The wind directions that reach it lie in [0, 720) but for polar-stereographic
+ * frames with large dgrw: there one subtraction (exact: x and 360 are within a factor of two of each other) replaces the library's remainder loop */
+__device__ __forceinline__ float d_fmod360(float x)
+{
+    if (x >= 0.0f && x < 720.0f) return x >= 360.0f ? x - 360.0f : x;
+    return fmodf(x, 360.0f);
+}
 template <bool EXACT>
 __device__ __forceinline__ void d_llwfgdw1(float &z1, float &z2, float xlon, char t, float xg4)
 {
@@ -2143,7 +2150,7 @@ __device__ __forceinline__ void d_llwfgdw1(float &z1, float &z2, float xlon, cha
     else if (t == 'N') dir = (uu == 0.0f) ? ((vv >= 0.0f) ? xlon + xg4 - 90.0f : xlon + xg4 + 90.0f) : xlon + xg4 - RDTODG * at;
     else if (t == 'S') dir = (uu == 0.0f) ? ((vv >= 0.0f) ? 90.0f - xlon + xg4 : 270.0f - xlon + xg4) : 180.0f - xlon + xg4 - RDTODG * at;
     else dir = (uu == 0.0f) ? ((vv >= 0.0f) ? 180.0f : 0.0f) : 270.0f - RDTODG * at;
-    dir = fmodf(fmodf(dir, 360.0f) + 360.0f, 360.0f);
+    dir = d_fmod360(d_fmod360(dir) + 360.0f);
     z1 = spd; z2 = dir;
 }
 template <bool EXACT>
@@ -4467,7 +4474,7 @@ __global__ __launch_bounds__(256) void k_wind_rotate(ezhip_wind_plan p, float *_
     else if (p.src_ps == 2) dir = (u == 0.0f) ? ((v >= 0.0f) ? 90.0f - lon + p.src_xg4 : 270.0f - lon + p.src_xg4) : 180.0f - lon + p.src_xg4 - RDTODG * glx_atan2f(v, u);
     else if (u == 0.0f) dir = (v >= 0.0f) ? 180.0f : 0.0f;
     else dir = 270.0f - RDTODG * glx_atan2f(v, u);
-    dir = fmodf(fmodf(dir, 360.0f) + 360.0f, 360.0f);
+    dir = d_fmod360(d_fmod360(dir) + 360.0f);
     if (p.wd_only) { uu[n] = spd; vv[n] = dir; return; }      /* c_ezwdint: speed / direction are the result */
     /* speed, direction -> target components: ez_gdwfllw.inc:93-105 ('N'), :108-121 ('S'), :123-134 ('L'/A/B/G) */
     float psi = p.dst_ps == 1 ? lon + p.dst_xg4 - dir : p.dst_ps == 2 ? 180.0f - lon + p.dst_xg4 - dir : 270.0f - dir;
