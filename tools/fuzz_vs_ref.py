@@ -54,7 +54,12 @@ for k in range(ncases):
     if ok:
         if degree == 3: ok = bool(np.all(np.abs(z - zr) <= 1e-5 * np.maximum(np.abs(zr), 1e-30)))
         else: ok = np.array_equal(z.view(np.uint32), zr.view(np.uint32))
-    if ok and degree == 3: cub_cases += 1; cub_same += int(np.array_equal(z.view(np.uint32), zr.view(np.uint32)))
+    if ok and degree == 3:
+        cub_cases += 1; same_z = np.array_equal(z.view(np.uint32), zr.view(np.uint32)); cub_same += int(same_z)
+        if not same_z and os.environ.get("FUZZ_VERBOSE"):
+            d = np.flatnonzero(z.view(np.uint32) != zr.view(np.uint32)); rows = np.unique(d // no)
+            print(f"CUBIC not bit-identical: {d.size} of {no * mo} points, rows {rows[:12].tolist()}{'...' if rows.size > 12 else ''} of {mo}, max rel {float(np.max(np.abs(z[d] - zr[d]) / np.maximum(np.abs(zr[d]), 1e-30))):.2e}",
+                  dict(src=(ni, nj, t, ig), dst=(no, mo, dig), polar=polar, extrap=extrap), flush=True)
     if ok and winds:
         if os.environ.get("FUZZ_WIND_EXACT"): ez.set_wind_exact(1)
         rcv, u, v = ez.ezuvint(uu, vv, no * mo)
