@@ -2693,9 +2693,9 @@ static int run_field_q(ezh_set *s, float *d_zout, const float *d_zin, int vector
     /* bicubic from an irregular source with wrap (a rotated global grid), the whole target grid in row order: from the second call of a set on the field runs from
      * LDS-staged stencil windows (k_st: bit-identical to k_pts; the tile table and the tile-ordered x, y are built once per set and zone options, behind the
      * first call).  EZHIP_NO_ST=1: k_pts every time */
-    const int st_ok = ((degree == DEG_CUBIC && (pp.wrap != 0 || (pp.i1 == 1 && pp.i2 == pp.ni)) && pp.xrec10) || degree == DEG_LINEAR) && pp.irregular && !pp.out_idx && !vector_mode && !src_hemi(gi) &&
+    const int st_ok = ((degree == DEG_CUBIC && (pp.wrap != 0 || (pp.i1 == 1 && pp.i2 == pp.ni)) && pp.xrec10) || degree == DEG_LINEAR) && pp.irregular && !pp.out_idx && (!vector_mode || !getenv("EZHIP_ST_NO_VECTOR")) && !src_hemi(gi) &&
                       (size_t)go->ni * go->nj >= (getenv("EZHIP_ST_MIN_POINTS") ? (size_t)atol(getenv("EZHIP_ST_MIN_POINTS")) : (size_t)262144) && !getenv("EZHIP_NO_ST");
-    const int st_key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4 | degree << 12, sl = degree == DEG_CUBIC;      /* (one table per set and degree: the first zone options that ask) */
+    const int st_key = 1 | zones << 1 | (O.degre_extrap & 0xFF) << 4 | degree << 12 | (vector_mode ? 1 << 20 : 0), sl = degree == DEG_CUBIC;      /* (one table per set and degree: the first zone options that ask; vector mode, round 6: the component passes of the exact-winds mode -- their zone rules differ) */
     int st_build = 0;
     if (st_ok) {
         pp.tile_ni = go->ni; pp.tile_nj = go->nj;
