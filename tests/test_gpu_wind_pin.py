@@ -249,3 +249,49 @@ def test_every_scalar_value_against_the_reference_run(which, tmp_path):
         print("%s c_ezsint call %d: %d of %d values differ from the reference's; max relative error %.3g" % (which, call, nbits, want.size, rel))
         assert rel <= TOL_V, (which, call, rel)
     ez.gdrls(gdout); ez.gdrls(gdin)
+
+
+def test_exact_winds_through_the_batch_entry_and_back_to_the_default():
+    """c_ezuvint_batch_dev under ezhip_set_wind_exact(1) goes pair by pair through the exact route (same bits as single exact calls); switching the mode off brings the
+    default route's bits back (the set's caches of either mode do not leak into the other)"""
+    ni, nj, no, mo = 640, 320, 1000, 500
+    ax, ay = ec.ze_axes(ni, nj)
+    gdin = ez.ezgdef_fmem(ni, nj, "Z", "E", *ec.E_IG, ax, ay); gdout = ez.ezqkdef(no, mo, "L", *ol.cxgaig("L", -90.0, 0.0, 180.0 / (mo - 1), 360.0 / no))
+    assert ez.ezdefset(gdout, gdin) == 1
+    _setopts()
+    ez.use_stream(torch.cuda.current_stream().cuda_stream)
+    K = 3
+    winds = [ec.synth_wind(ni, nj, seed=50 + k) for k in range(K)]
+    for u_, v_ in winds:
+        for a in (u_, v_):
+            a2 = a.reshape(nj, ni); a2[:, -1] = a2[:, 0]
+    d_u = torch.from_numpy(np.stack([w[0] for w in winds])).cuda().contiguous(); d_v = torch.from_numpy(np.stack([w[1] for w in winds])).cuda().contiguous()
+    def single(k):
+        o_u = torch.zeros(no * mo, device="cuda"); o_v = torch.zeros_like(o_u)
+        assert ez.ezuvint_dev(o_u, o_v, d_u[k], d_v[k]) == 0
+        torch.cuda.synchronize()
+        return o_u, o_v
+    def batch():
+        o_u = torch.zeros((K, no * mo), device="cuda"); o_v = torch.zeros_like(o_u)
+        assert ez.ezuvint_batch_dev(o_u, o_v, d_u, d_v, K) == 0
+        torch.cuda.synchronize()
+        return o_u, o_v
+    fast0 = [single(k) for k in range(K)]; fast0 = [single(k) for k in range(K)]           # (second calls: the staged-tile route)
+    fast_b = batch()
+    ez.set_wind_exact(1)
+    try:
+        exact = [single(k) for k in range(K)]
+        exact_b = batch()
+    finally:
+        ez.set_wind_exact(0)
+    fast1 = [single(k) for k in range(K)]
+    fast_b1 = batch()
+    for k in range(K):
+        assert torch.equal(exact_b[0][k], exact[k][0]) and torch.equal(exact_b[1][k], exact[k][1]), k
+        assert torch.equal(fast_b[0][k], fast0[k][0]) and torch.equal(fast_b[1][k], fast0[k][1]), k
+        assert torch.equal(fast1[k][0], fast0[k][0]) and torch.equal(fast1[k][1], fast0[k][1]), k
+        assert torch.equal(fast_b1[0][k], fast0[k][0]) and torch.equal(fast_b1[1][k], fast0[k][1]), k
+        assert not torch.equal(exact[k][0], fast0[k][0])                                     # the two modes do differ (in the last places)
+        e = float(((exact[k][0] - fast0[k][0]).abs().max() / exact[k][0].abs().max()).item())
+        assert e <= 1e-5, e
+    ez.gdrls(gdout); ez.gdrls(gdin)
