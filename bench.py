@@ -299,6 +299,17 @@ def extras(ez, torch, stream, d_out, d_in):
                 cez(zout_h.ctypes.data, zin_h.ctypes.data)
             ex["host_pointer_abi_registered_ms_per_field"] = (time.perf_counter() - t0) / 3 * 1e3
             _L.ezhip_unregister_host_buffer(zin_h.ctypes.data); _L.ezhip_unregister_host_buffer(zout_h.ctypes.data)
+        # winds between the headline's own (unrotated) grids: no per-point matrix there, the reference's chain runs per call (k_wind_rotate with the C library's REAL trig) and
+        # the result equals the reference's bit for bit in the default mode (tools/fuzz_vs_ref.py: 423 of 423 random pairs)
+        try:
+            uu2, vv2 = ec.synth_wind(NI_S, NJ_S, seed=4)
+            d_u2 = torch.from_numpy(uu2).cuda(); d_v2 = torch.from_numpy(vv2).cuda()
+            assert ez.ezuvint_dev(d_out[0], d_out[1], d_u2, d_v2) >= 0
+            us2 = ev_time(lambda: ez.ezuvint_dev(d_out[0], d_out[1], d_u2, d_v2), 5, bursts=3)
+            ex["cfg2_uvint"] = {"workload": "c_ezuvint_dev bicubic G 4400x2200 -> L 7200x3601", "dtype": "f64", "us_per_pair": us2, "Mpoint_pairs_per_s": NPTS_OUT / us2}
+            del d_u2, d_v2
+        except Exception as e:   # noqa: BLE001
+            ex["cfg2_uvint"] = {"error": repr(e)[:120]}
         # ---- BASELINE configs[2]: c_ezuvint, Z-on-E 2560x1280 (rotated global) -> L 4000x2000, bicubic, polar_correction=yes
         ni, nj, no, mo = 2560, 1280, 4000, 2000
         ax, ay = ec.ze_axes(ni, nj)
