@@ -2161,7 +2161,7 @@ __device__ __forceinline__ void d_gdwfllw1(float &z1, float &z2, float xlon, cha
     float u = (EXACT ? glx_cosf(psi * DGTORD) : cosf(psi * DGTORD)) * z1, v = (EXACT ? glx_sinf(psi * DGTORD) : sinf(psi * DGTORD)) * z1;
     z1 = u; z2 = v;
 }
-template <int CHUNK, bool EXACT = false>
+template <int CHUNK, bool EXACT = false, int NT = 256>      /* NT: threads of the block that runs it (the standalone launch: 1024 -- its exact trig is the long part) */
 __device__ __forceinline__ void polar_wind_body(const int north, float *out, const float *uu, const float *vv, const float *plon2 /* [north row | south row] */,
                                                 int ni, int nj, float xg4_n, float xg4_s, int weighted, const float *ax, float *lds /* CHUNK + 4 floats, 16-byte aligned */)
 {
@@ -2170,7 +2170,7 @@ __device__ __forceinline__ void polar_wind_body(const int north, float *out, con
     const float *urow = uu + (north ? (size_t)(nj - 1) * ni : 0), *vrow = vv + (north ? (size_t)(nj - 1) * ni : 0);
     const float *plon = plon2 + (north ? 0 : ni);
     float *pu = out + (north ? 0 : ni), *pv = out + 2 * (size_t)ni + (north ? 0 : ni);
-    for (int i = threadIdx.x; i < ni; i += 256) {          /* speed / direction on the lat-lon frame, then polar-stereographic components */
+    for (int i = threadIdx.x; i < ni; i += NT) {          /* speed / direction on the lat-lon frame, then polar-stereographic components */
         float a = urow[i], b = vrow[i];
         d_llwfgdw1<EXACT>(a, b, plon[i], 'A', 0.f);
         d_gdwfllw1<EXACT>(a, b, plon[i], hs, xg4);
@@ -2179,21 +2179,21 @@ __device__ __forceinline__ void polar_wind_body(const int north, float *out, con
     __threadfence_block();
     __syncthreads();
     float s0, w0;
-    block_poleval2(pu, pv, ni, weighted, ax, lds, CHUNK / 2, s0, w0, 256);
+    block_poleval2(pu, pv, ni, weighted, ax, lds, CHUNK / 2, s0, w0, NT);
     d_llwfgdw1<EXACT>(s0, w0, 0.0f, hs, xg4);
     __syncthreads();
-    for (int i = threadIdx.x; i < ni; i += 256) {
+    for (int i = threadIdx.x; i < ni; i += NT) {
         float spd = s0, wd = (i == 0 || north) ? w0 + plon[i] : w0 - plon[i];
         d_gdwfllw1<EXACT>(spd, wd, plon[i], 'A', 0.f);
         pu[i] = spd; pv[i] = wd;
     }
 }
 template <bool EXACT>
-__global__ __launch_bounds__(256) void k_polar_wind(float *out, const float *uu, const float *vv, const float *plon2, int ni, int nj, float xg4_n, float xg4_s,
-                                                    int weighted, const float *ax)
+__global__ __launch_bounds__(1024) void k_polar_wind(float *out, const float *uu, const float *vv, const float *plon2, int ni, int nj, float xg4_n, float xg4_s,
+                                                     int weighted, const float *ax)
 {
     __shared__ __attribute__((aligned(16))) float lds[POLE_CHUNK + 4];
-    polar_wind_body<POLE_CHUNK, EXACT>(blockIdx.x == 0, out, uu, vv, plon2, ni, nj, xg4_n, xg4_s, weighted, ax, lds);
+    polar_wind_body<POLE_CHUNK, EXACT, 1024>(blockIdx.x == 0, out, uu, vv, plon2, ni, nj, xg4_n, xg4_s, weighted, ax, lds);
 }
 /* ez_corrbgd.inc:20-55 (called at the end of ez_corrval for a Z- or #-on-E source and a 'B' target, ez_corrval.c:146-148): the rows of the
  * target at the poles become their mean -- a sequential REAL sum over the row divided by ni * 1.0 (block_poleval, unweighted).
@@ -2216,8 +2216,8 @@ extern "C" int ezhip_corrbgd(float *d_zout, int ni, int nj, int hem)
 extern "C" int ezhip_polar_wind(float *d_out4, const float *d_uu, const float *d_vv, const float *d_plon2, int ni, int nj,
                                 float xg4_n, float xg4_s, int weighted, const float *d_ax, int exact)
 {
-    if (exact) hipLaunchKernelGGL(k_polar_wind<true>, dim3(2), dim3(256), 0, g_stream, d_out4, d_uu, d_vv, d_plon2, ni, nj, xg4_n, xg4_s, weighted, d_ax);
-    else hipLaunchKernelGGL(k_polar_wind<false>, dim3(2), dim3(256), 0, g_stream, d_out4, d_uu, d_vv, d_plon2, ni, nj, xg4_n, xg4_s, weighted, d_ax);
+    if (exact) hipLaunchKernelGGL(k_polar_wind<true>, dim3(2), dim3(1024), 0, g_stream, d_out4, d_uu, d_vv, d_plon2, ni, nj, xg4_n, xg4_s, weighted, d_ax);
+    else hipLaunchKernelGGL(k_polar_wind<false>, dim3(2), dim3(1024), 0, g_stream, d_out4, d_uu, d_vv, d_plon2, ni, nj, xg4_n, xg4_s, weighted, d_ax);
     return LAUNCH_CHECK("k_polar_wind");
 }
 
@@ -3959,7 +3959,7 @@ extern "C" int ezhip_interp_pts2(const ezhip_pts_plan *plan_u, const ezhip_pts_p
     if (pu2.pw_out && (!fast3w || getenv("EZHIP_POLAR_WIND_SIDE"))) {
         /* kernels without the producer blocks: the rows come from k_polar_wind on the side stream, joined below before the special points */
         if (ezhip_side_begin()) return -1;
-        hipLaunchKernelGGL(k_polar_wind<false>, dim3(2), dim3(256), 0, g_stream, pu2.pw_out, d_in_u, d_in_v, pu2.pw_plon2, pu2.ni, pu2.nj, pu2.pw_xg4_n, pu2.pw_xg4_s, pu2.pw_weighted, pu2.pw_ax);
+        hipLaunchKernelGGL(k_polar_wind<false>, dim3(2), dim3(1024), 0, g_stream, pu2.pw_out, d_in_u, d_in_v, pu2.pw_plon2, pu2.ni, pu2.nj, pu2.pw_xg4_n, pu2.pw_xg4_s, pu2.pw_weighted, pu2.pw_ax);
         const int bad = LAUNCH_CHECK("k_polar_wind");
         if (ezhip_side_end() || bad) return -1;
         pu2.pw_out = nullptr;
